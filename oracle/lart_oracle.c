@@ -1,0 +1,1452 @@
+/* TEST INFRASTRUCTURE ONLY -- see lart_oracle.h.  Plain C restatement of the LaRT (v2.00) photon-packet
+ * hot path for Cartesian media.  Every routine cites the reference file:line it follows
+ * (paths relative to /root/reference/src).  Arithmetic is IEEE double, no FMA contraction
+ * (-ffp-contract=off), evaluation order as in the reference. */
+#define _GNU_SOURCE
+#include "lart_oracle.h"
+#include "voigt_tables.h"
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ---- constants: define.f90:43-78 ---- */
+#define PI      3.141592653589793238462643383279502884197
+#define TWOPI   6.283185307179586476925286766559005768394
+#define FOURPI  12.56637061435917295385057353311801153679
+#define HALFPI  (PI/2.0)
+#define RAD2DEG (180.0/PI)
+#define DEG2RAD (PI/180.0)
+#define HUGEST  DBL_MAX
+#define SPEEDC  2.99792458e5
+#define UM2KM   1.0e-9
+#define UM2M    1.0e-6
+#define H_PLANCK 6.62607004e-34
+#define TAU_HUGE 745.2                      /* raytrace_car.f90:106,184,432,497 */
+#define MAX_OBS 16
+
+static char g_err[512];
+const char *orc_last_error(void) { return g_err; }
+
+/* =====================================================================================
+ * RNG
+ * ===================================================================================== */
+/* MT19937-64 (Matsumoto & Nishimura 2004), as random_mt.f90:486-498 (init_mt) and :579-630 (rand_mt) */
+#define MT_N 312
+#define MT_M 156
+typedef struct { uint64_t mt[MT_N]; int mti; } mt_t;
+static void mt_init(mt_t *s, int64_t seed) {
+    s->mt[0] = (uint64_t)seed;
+    for (int i = 1; i < MT_N; i++)
+        s->mt[i] = 6364136223846793005ULL * (s->mt[i-1] ^ (s->mt[i-1] >> 62)) + (uint64_t)i;
+    s->mti = MT_N;
+}
+static uint64_t mt_next(mt_t *s) {
+    static const uint64_t mag01[2] = {0ULL, 0xB5026F5AA96619E9ULL};
+    const uint64_t UM = 0xFFFFFFFF80000000ULL, LM = 0x7FFFFFFFULL;
+    if (s->mti >= MT_N) {
+        int i; uint64_t x;
+        for (i = 0; i < MT_N - MT_M; i++) {
+            x = (s->mt[i] & UM) | (s->mt[i+1] & LM);
+            s->mt[i] = s->mt[i+MT_M] ^ (x >> 1) ^ mag01[x & 1ULL];
+        }
+        for (; i < MT_N - 1; i++) {
+            x = (s->mt[i] & UM) | (s->mt[i+1] & LM);
+            s->mt[i] = s->mt[i+(MT_M-MT_N)] ^ (x >> 1) ^ mag01[x & 1ULL];
+        }
+        x = (s->mt[MT_N-1] & UM) | (s->mt[0] & LM);
+        s->mt[MT_N-1] = s->mt[MT_M-1] ^ (x >> 1) ^ mag01[x & 1ULL];
+        s->mti = 0;
+    }
+    uint64_t x = s->mt[s->mti++];
+    x ^= (x >> 29) & 0x5555555555555555ULL;
+    x ^= (x << 17) & 0x71D67FFFEDA60000ULL;
+    x ^= (x << 37) & 0xFFF7EEE000000000ULL;
+    x ^= (x >> 43);
+    return x;
+}
+
+/* Philox4x32-10 (Salmon et al. 2011, "Parallel random numbers: as easy as 1, 2, 3") */
+void orc_philox4x32_10(const uint32_t c_in[4], const uint32_t k_in[2], uint32_t out[4]) {
+    uint32_t c0 = c_in[0], c1 = c_in[1], c2 = c_in[2], c3 = c_in[3], k0 = k_in[0], k1 = k_in[1];
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+typedef struct {
+    int kind;                 /* 0 MT stream, 1 philox per photon */
+    mt_t *mt;                 /* kind 0 */
+    int gaus_stored; double gset;   /* rand_gauss1 cache (random_mt.f90:968-987), kind 0 only */
+    uint64_t seed, id, n;     /* kind 1: key, stream id, draw index */
+    double spare;             /* second half of the current philox block */
+} rng_t;
+
+/* uniform deviate on the OPEN interval (0,1): (x>>12 + 0.5)/2^52   (random_mt.f90:627-629) */
+static inline double u64_to_open01(uint64_t x) { return ((double)(x >> 12) + 0.5) * (1.0 / 4503599627370496.0); }
+
+static double rnd(rng_t *g) {
+    if (g->kind == 0) return u64_to_open01(mt_next(g->mt));
+    uint64_t n = g->n++;
+    if (n & 1ULL) return g->spare;
+    uint64_t blk = n >> 1;
+    uint32_t c[4] = {(uint32_t)blk, (uint32_t)(blk >> 32), (uint32_t)g->id, (uint32_t)(g->id >> 32)};
+    uint32_t k[2] = {(uint32_t)g->seed, (uint32_t)(g->seed >> 32)}, o[4];
+    orc_philox4x32_10(c, k, o);
+    g->spare = u64_to_open01((uint64_t)o[2] | ((uint64_t)o[3] << 32));
+    return u64_to_open01((uint64_t)o[0] | ((uint64_t)o[1] << 32));
+}
+static void rng_philox(rng_t *g, uint64_t seed, uint64_t id, uint64_t n0) {
+    memset(g, 0, sizeof *g); g->kind = 1; g->seed = seed; g->id = id; g->n = n0 & ~1ULL;
+    if (n0 & 1ULL) { (void)rnd(g); }          /* re-derive the spare half when resuming on an odd draw */
+}
+
+/* Marsaglia polar pair (random_mt.f90:964-988).  Returns the deviate the reference returns first
+ * (v2*rsq); *second = v1*rsq is the one the reference caches. */
+static double gauss_pair(rng_t *g, double *second) {
+    double v1, v2, rsq;
+    do {
+        v1 = 2.0 * rnd(g) - 1.0;
+        v2 = 2.0 * rnd(g) - 1.0;
+        rsq = v1 * v1 + v2 * v2;
+    } while (!(rsq > 0.0 && rsq < 1.0));
+    rsq = sqrt(-2.0 * log(rsq) / rsq);
+    *second = v1 * rsq;
+    return v2 * rsq;
+}
+/* rand_gauss: MT mode keeps the reference's hidden cache; the counter-based mode has none
+ *  and discards the second deviate. */
+static double rand_gauss(rng_t *g) {
+    double s;
+    if (g->kind == 0) {
+        if (g->gaus_stored) { g->gaus_stored = 0; return g->gset; }
+        double r = gauss_pair(g, &s); g->gset = s; g->gaus_stored = 1; return r;
+    }
+    return gauss_pair(g, &s);
+}
+
+/* =====================================================================================
+ * Voigt H(x,a): voigt_mod.f90:541-733 (voigt_seon2).  u(k) = k-1 so (vv - u(k1)) = vv - (k1-1).
+ * ===================================================================================== */
+double orc_voigt(double vin, double a) {
+    double v = (vin < 0.0) ? -vin : vin, vv, y1, y2, y3;
+    int k1, k2, k3;
+    if (v < 1.0) {
+        vv = v * 20.0; k1 = (int)vv + 1; k2 = k1 + 1;
+        y1 = VOIGT_H0[k1-1] + a * (VOIGT_H1[k1-1] + a * VOIGT_H2[k1-1]);
+        y2 = VOIGT_H0[k2-1] + a * (VOIGT_H1[k2-1] + a * VOIGT_H2[k2-1]);
+        return y1 + (y2 - y1) * (vv - (double)(k1 - 1));
+    } else if (v < 5.0) {
+        vv = v * 20.0; k1 = (int)vv; k2 = k1 + 1; k3 = k1 + 2;
+        y1 = VOIGT_H0[k1-1] + a * (VOIGT_H1[k1-1] + a * (VOIGT_H2[k1-1] + a * VOIGT_H3[k1-1]));
+        y2 = VOIGT_H0[k2-1] + a * (VOIGT_H1[k2-1] + a * (VOIGT_H2[k2-1] + a * VOIGT_H3[k2-1]));
+        y3 = VOIGT_H0[k3-1] + a * (VOIGT_H1[k3-1] + a * (VOIGT_H2[k3-1] + a * VOIGT_H3[k3-1]));
+        double u1 = (double)(k1 - 1), u2 = (double)(k2 - 1), u3 = (double)(k3 - 1);
+        return 0.5 * y1 * (vv - u2) * (vv - u3) - y2 * (vv - u1) * (vv - u3) + 0.5 * y3 * (vv - u1) * (vv - u2);
+    } else if (v < 10.0) {
+        vv = v * 20.0; k1 = (int)vv + 1; k2 = k1 + 1;
+        double a2 = a * a;
+        y1 = a * (VOIGT_H1[k1-1] + a2 * VOIGT_H3[k1-1]);
+        y2 = a * (VOIGT_H1[k2-1] + a2 * VOIGT_H3[k2-1]);
+        return y1 + (y2 - y1) * (vv - (double)(k1 - 1));
+    }
+    double v2 = 1.0 / (v * v);
+    return 0.56418958354775628695 * a * v2 * (1.0 + ((1.5 - a * a) + 3.75 * v2) * v2);
+}
+void orc_voigt_v(int n, const double *x, const double *a, double *h) { for (int i = 0; i < n; i++) h[i] = orc_voigt(x[i], a[i]); }
+
+/* =====================================================================================
+ * Samplers
+ * ===================================================================================== */
+/* rand_resonance_vz_seon: random_mt.f90:2562-2696 */
+static double rand_resonance_vz(rng_t *g, double x0in, double a) {
+    const double xc = 1.0 + sqrt(2.0), two_over_PI = 2.0 / PI;
+    double x0 = fabs(x0in), vz, beta = 0, Cb = 0, pb, t1 = 0, t2, delt = 0;
+    if (x0 <= 1.0) {
+        for (;;) {
+            vz = x0 + a * tan(PI * (rnd(g) - 0.5));
+            if (rnd(g) <= exp(-(vz * vz))) break;
+        }
+        return (x0in < 0.0) ? -vz : vz;
+    }
+    double x0sq = x0 * x0, api = a * PI, beta0 = exp(-x0sq / 2.0), h0_two = beta0 / a, h0 = h0_two / 2.0;
+    if (x0 < xc) {
+        double dbeta = sqrt(two_over_PI * a * (1.0 - beta0) * beta0 * x0), beta1 = beta0 + dbeta, one_b1 = 1.0 - beta1;
+        double pb1 = sqrt(-2.0 * log(beta1)), h1 = two_over_PI * beta1 * pb1 / (x0sq - pb1 * pb1);
+        double S0 = beta0 * h0, S1 = dbeta * h0, S2 = one_b1 * h1, Stot = S0 + S1 + S2;
+        for (;;) {
+            double rS = rnd(g);
+            if (rS < S0 / Stot)              { beta = beta0 * sqrt(rnd(g)); Cb = beta / a; }
+            else if (rS < 1.0 - S2 / Stot)   { beta = beta0 + dbeta * rnd(g); Cb = h0; }
+            else                             { beta = beta1 + one_b1 * rnd(g); Cb = h1; }
+            pb = sqrt(-2.0 * log(beta));
+            t2 = atan((pb - x0) / a); t1 = atan((-pb - x0) / a); delt = t2 - t1;
+            if (rnd(g) * Cb < (beta / api) * delt) break;
+        }
+    } else {
+        double h2 = 0.3861 / (x0sq - 1.373);
+        if (h0_two < h2) {
+            for (;;) {
+                beta = rnd(g); Cb = h2;
+                pb = sqrt(-2.0 * log(beta));
+                t2 = atan((pb - x0) / a); t1 = atan((-pb - x0) / a); delt = t2 - t1;
+                if (rnd(g) * Cb < (beta / api) * delt) break;
+            }
+        } else if (h0 < h2) {
+            double S0 = beta0 * h0, one_b0 = 1.0 - beta0, S1 = one_b0 * h2, Stot = S0 + S1;
+            for (;;) {
+                if (rnd(g) < S0 / Stot) { beta = beta0 * sqrt(rnd(g)); Cb = beta / a; }
+                else                    { beta = beta0 + one_b0 * rnd(g); Cb = h2; }
+                pb = sqrt(-2.0 * log(beta));
+                t2 = atan((pb - x0) / a); t1 = atan((-pb - x0) / a); delt = t2 - t1;
+                if (rnd(g) * Cb < (beta / api) * delt) break;
+            }
+        } else {
+            double dbeta = sqrt(two_over_PI * a * (1.0 - beta0) * beta0 * x0), beta1 = beta0 + dbeta, one_b1 = 1.0 - beta1;
+            double pb1 = sqrt(-2.0 * log(beta1)), h1 = two_over_PI * beta1 * pb1 / (x0sq - pb1 * pb1);
+            double hmax = (h1 > h2) ? h1 : h2;
+            double S0 = beta0 * h0, S1 = dbeta * h0, S2 = one_b1 * hmax, Stot = S0 + S1 + S2;
+            for (;;) {
+                double rS = rnd(g);
+                if (rS < S0 / Stot)              { beta = beta0 * sqrt(rnd(g)); Cb = beta / a; }
+                else if (rS < 1.0 - S2 / Stot)   { beta = beta0 + dbeta * rnd(g); Cb = h0; }
+                else                             { beta = beta1 + one_b1 * rnd(g); Cb = hmax; }
+                pb = sqrt(-2.0 * log(beta));
+                t2 = atan((pb - x0) / a); t1 = atan((-pb - x0) / a); delt = t2 - t1;
+                if (rnd(g) * Cb < (beta / api) * delt) break;
+            }
+        }
+    }
+    vz = x0 + a * tan(delt * rnd(g) + t1);
+    return (x0in < 0.0) ? -vz : vz;
+}
+/* rand_resonance: random_mt.f90:2974-2993 */
+static double rand_resonance(rng_t *g, double E1) {
+    if (E1 > 0.0) {
+        double p2 = sqrt((4.0 - E1) / (3.0 * E1));
+        double Q = (4.0 * rnd(g) - 2.0) / (E1 * (p2 * p2 * p2));
+        double W = pow(Q + sqrt(Q * Q + 1.0), 1.0 / 3.0);
+        return p2 * (W - 1.0 / W);
+    } else if (E1 < 0.0) {
+        double p2 = sqrt(fabs((4.0 - E1) / (3.0 * E1)));
+        double Q = (4.0 * rnd(g) - 2.0) / (E1 * (p2 * p2 * p2));
+        return 2.0 * p2 * cos((acos(Q) + FOURPI) / 3.0);
+    }
+    return 2.0 * rnd(g) - 1.0;
+}
+/* rand_henyey_greenstein: random_mt.f90:3022-3042 */
+static double rand_hg(rng_t *g, double gg) {
+    double x = rnd(g);
+    if (gg == 0.0) return 2.0 * x - 1.0;
+    double g2 = gg * gg, twog = 2.0 * gg, t = (1.0 - g2) / (1.0 - gg + twog * x);
+    return ((1.0 + g2) - t * t) / twog;
+}
+/* rand_voigt: random_mt.f90:3062-3083  (a*tan(pi*xi - pi/2) + gauss/sqrt2; Cauchy drawn first) */
+static double rand_voigt(rng_t *g, double a) {
+    double c = tan(PI * rnd(g) - HALFPI);
+    return a * c + rand_gauss(g) * (1.0 / sqrt(2.0));
+}
+
+/* =====================================================================================
+ * Simulation state
+ * ===================================================================================== */
+typedef struct {
+    double x, y, z, rm[9];            /* rmatrix row-major rm[3*r+c] = rmatrix(r+1,c+1) */
+    double *scatt, *direc, *I, *Q, *U, *V;
+    double *scatt_2D, *direc_2D, *I_2D, *Q_2D, *U_2D, *V_2D;
+} obs_t;
+
+typedef struct {
+    double id; double nscatt_gas, nscatt_dust;
+    double x, y, z, kx, ky, kz, mx, my, mz, nx, ny, nz;
+    int icell, jcell, kcell;
+    double xfreq, xfreq_ref, wgt;
+    int inside;
+    double I, Q, U, V, E1, E2, E3;
+} photon_t;
+
+struct orc_sim {
+    /* --- par% (define.f90:209-544) --- */
+    double no_photons; int iseed;
+    double temperature, taumax, tauhomo, N_gasmax, N_gashomo, Vexp;
+    int velocity_type;               /* 0 none, 1 hubble, 2 constant_radial, 3 parallel_velocity */
+    double Vx, Vy, Vz;
+    int comoving_source, recoil, core_skip, core_skip_global, xyz_symmetry, xy_periodic;
+    int nx, ny, nz; double xmax, ymax, zmax, rmax, rmin;
+    double xs_point, ys_point, zs_point, source_rmax; int source_geometry;   /* 0 point, 1 uniform_sphere */
+    double xfreq0, par_xfreq_min, par_xfreq_max; int nxfreq;
+    int spectral_type;               /* 0 monochromatic, 1 voigt */
+    int use_stokes, use_reduced_wgt, save_Jin, save_Jabs, save_Jmu, nmu;
+    double mu_min, dmu;
+    double hgg, albedo, cext_dust, DGR, distance2cm;
+    int save_peeloff, save_peeloff_2D, save_peeloff_3D, nobs, nxim, nyim;
+    double distance, alpha[MAX_OBS], beta[MAX_OBS], gamma[MAX_OBS], obsx[MAX_OBS], obsy[MAX_OBS], obsz[MAX_OBS], dxim, dyim;
+    char scatt_mat_file[512];
+    int geometry;                    /* 0 sphere, 1 rectangle */
+    double atau3;
+    /* --- line (line_mod.f90:1241-1270) --- */
+    double cross0, vtherm1, damping, wavelength0, g_recoil0, E1, E2, E3;
+    /* --- grid (define.f90:117-206) --- */
+    int i0, j0, k0;
+    double xmin, ymin, zmin, dx, dy, dz, xrange, yrange, zrange;
+    double *xface, *yface, *zface;
+    double *rhokap, *voigt_a, *Dfreq, *vfx, *vfy, *vfz, *rhokapD;
+    double Dfreq_ref, voigt_amean, xfreq_min, xfreq_max, dxfreq, xcrit, xcrit2;
+    double *Jout, *Jin, *Jabs, *Jmu;
+    /* --- Mueller table (define.f90:616-625) --- */
+    int nPDF; double *coss, *S11, *S12, *S33, *S34, *phase_PDF; int *alias;
+    obs_t obs[MAX_OBS];
+    /* --- run results --- */
+    double nscatt_gas, nscatt_dust; int64_t nphotons_done;
+    double n_cellsteps, n_cellsteps_peel, n_events;
+    int raytrace_variant;            /* 0 car, 1 xyzsym, 2 zonly */
+    int64_t log_n; double *log_nscatt, *log_xfreq;
+};
+
+#define IDX(s,i,j,k) ((size_t)((i)-1) + (size_t)(s)->nx * ((size_t)((j)-1) + (size_t)(s)->ny * (size_t)((k)-1)))
+
+/* per-thread accumulators, merged after the run */
+typedef struct { orc_sim *s; double *Jout, *Jin, *Jabs, *Jmu; obs_t obs[MAX_OBS];
+                 double nscatt_gas, nscatt_dust, n_cellsteps, n_cellsteps_peel, n_events; } acc_t;
+
+/* =====================================================================================
+ * Parameter parsing + read_input post-processing (setup.f90:42-562)
+ * ===================================================================================== */
+static int parse_bool(const char *v) { return (v[0] == '1' || v[0] == 't' || v[0] == 'T' || !strncmp(v, ".t", 2) || !strncmp(v, ".T", 2)); }
+
+static void set_defaults(orc_sim *s) {
+    memset(s, 0, sizeof *s);
+    s->no_photons = 1e5; s->iseed = 0; s->temperature = 1e4;
+    s->taumax = -999.0; s->tauhomo = -999.0; s->N_gasmax = -999.0; s->N_gashomo = -999.0;
+    s->comoving_source = 1; s->nx = 1; s->ny = 1; s->nz = 11; s->xmax = s->ymax = s->zmax = 1.0;
+    s->rmin = -999.0; s->rmax = -999.0; s->source_rmax = -999.0;
+    s->par_xfreq_min = NAN; s->par_xfreq_max = NAN; s->nxfreq = 121; s->spectral_type = 1;
+    s->save_Jin = 1; s->save_Jabs = 1; s->nmu = 11; s->save_peeloff_3D = 1;
+    /* float32 literals widened to double (define.f90:454-456) */
+    s->hgg = (double)0.6761f; s->albedo = (double)0.3253f; s->cext_dust = (double)1.6059e-21f;
+    s->DGR = 0.0; s->distance2cm = -999.9; s->distance = NAN; s->dxim = NAN; s->dyim = NAN;
+    for (int i = 0; i < MAX_OBS; i++) s->alpha[i] = s->beta[i] = s->gamma[i] = s->obsx[i] = s->obsy[i] = s->obsz[i] = NAN;
+    s->geometry = 0;
+}
+
+static int set_param(orc_sim *s, const char *k, const char *v) {
+#define D(name) if (!strcmp(k, #name)) { s->name = atof(v); return 0; }
+#define I(name) if (!strcmp(k, #name)) { s->name = atoi(v); return 0; }
+#define B(name) if (!strcmp(k, #name)) { s->name = parse_bool(v); return 0; }
+    D(no_photons) I(iseed) D(temperature) D(taumax) D(tauhomo) D(Vexp) D(Vx) D(Vy) D(Vz)
+    B(comoving_source) B(recoil) B(core_skip) B(core_skip_global) B(xyz_symmetry) B(xy_periodic)
+    I(nx) I(ny) I(nz) D(xmax) D(ymax) D(zmax) D(rmax) D(rmin) D(xs_point) D(ys_point) D(zs_point) D(source_rmax)
+    D(xfreq0) I(nxfreq) B(use_stokes) B(use_reduced_wgt) B(save_Jin) B(save_Jabs) B(save_Jmu) I(nmu)
+    D(hgg) D(albedo) D(cext_dust) D(DGR) D(distance2cm) B(save_peeloff) B(save_peeloff_2D) B(save_peeloff_3D)
+    I(nxim) I(nyim) D(distance) D(dxim) D(dyim)
+    if (!strcmp(k, "xfreq_min")) { s->par_xfreq_min = atof(v); return 0; }
+    if (!strcmp(k, "xfreq_max")) { s->par_xfreq_max = atof(v); return 0; }
+    if (!strcmp(k, "N_HImax") || !strcmp(k, "N_gasmax") || !strcmp(k, "N_HI")) { s->N_gasmax = atof(v); return 0; }
+    if (!strcmp(k, "N_HIhomo") || !strcmp(k, "N_gashomo")) { s->N_gashomo = atof(v); return 0; }
+    if (!strcmp(k, "tau0")) { s->taumax = atof(v); return 0; }
+    if (!strcmp(k, "scatt_mat_file")) { snprintf(s->scatt_mat_file, sizeof s->scatt_mat_file, "%s", v); return 0; }
+    if (!strcmp(k, "spectral_type")) {
+        if (!strcmp(v, "voigt")) s->spectral_type = 1; else if (!strcmp(v, "monochromatic")) s->spectral_type = 0;
+        else { snprintf(g_err, sizeof g_err, "spectral_type '%s' not supported by the oracle", v); return -1; }
+        return 0; }
+    if (!strcmp(k, "source_geometry")) {
+        if (!strcmp(v, "point")) s->source_geometry = 0; else if (!strcmp(v, "uniform_sphere") || !strcmp(v, "sphere")) s->source_geometry = 1;
+        else { snprintf(g_err, sizeof g_err, "source_geometry '%s' not supported by the oracle", v); return -1; }
+        return 0; }
+    if (!strcmp(k, "velocity_type")) {
+        if (!strcmp(v, "hubble")) s->velocity_type = 1; else if (!strcmp(v, "constant_radial")) s->velocity_type = 2;
+        else if (!strcmp(v, "parallel_velocity")) s->velocity_type = 3; else if (!v[0]) s->velocity_type = 0;
+        else { snprintf(g_err, sizeof g_err, "velocity_type '%s' not supported by the oracle", v); return -1; }
+        return 0; }
+    if (!strcmp(k, "geometry")) {
+        if (!strcmp(v, "sphere") || !v[0]) s->geometry = 0; else if (!strcmp(v, "rectangle") || !strcmp(v, "box")) s->geometry = 1;
+        else { snprintf(g_err, sizeof g_err, "geometry '%s' not supported by the oracle", v); return -1; }
+        return 0; }
+    /* observer arrays: alpha(1)=..  written as alpha1=..; bare name sets element 1 */
+    { const char *names[6] = {"alpha", "beta", "gamma", "obsx", "obsy", "obsz"};
+      double *arrs[6] = {s->alpha, s->beta, s->gamma, s->obsx, s->obsy, s->obsz};
+      for (int a = 0; a < 6; a++) { size_t L = strlen(names[a]);
+        if (!strncmp(k, names[a], L)) { int idx = k[L] ? atoi(k + L) : 1;
+            if (idx >= 1 && idx <= MAX_OBS && (k[L] == 0 || (k[L] >= '0' && k[L] <= '9'))) { arrs[a][idx-1] = atof(v); return 0; } } } }
+    snprintf(g_err, sizeof g_err, "unknown parameter '%s' (unknown names fail the namelist read in the reference too)", k);
+    return -1;
+#undef D
+#undef I
+#undef B
+}
+
+/* line constants, Ly-alpha default branch: line_mod.f90:1241-1270 */
+static void setup_line(orc_sim *s) {
+    const double sigma_0 = 0.026540083434, amu = 1.67262192e-24, vtherm1_amu = 0.12895319011972164, mass_amu = 1.00797;
+    s->E1 = 1.0; s->E2 = 0.0; s->E3 = 1.0;
+    s->wavelength0 = 0.1215668237310;
+    s->damping = 6.2649e8;
+    s->cross0 = sigma_0 / sqrt(PI) * (0.27760 + 0.13881 + 0.0);
+    s->vtherm1 = vtherm1_amu / sqrt(mass_amu);
+    double wl = s->wavelength0 * UM2M;
+    s->g_recoil0 = (H_PLANCK / amu / mass_amu) / (wl * wl);
+}
+void orc_line_constants(double *cross0, double *vtherm1, double *damping, double *wavelength0, double *g_recoil0) {
+    orc_sim t; setup_line(&t);
+    *cross0 = t.cross0; *vtherm1 = t.vtherm1; *damping = t.damping; *wavelength0 = t.wavelength0; *g_recoil0 = t.g_recoil0;
+}
+/* vtherm_total: define.f90:928-933 (bturb unset) */
+static double vtherm_total(const orc_sim *s, double T) { return s->vtherm1 * sqrt(T); }
+
+/* random_alias_setup64: random_mt.f90:2016-2067 */
+static void alias_setup(int n, double *probs, int *alias) {
+    int *small = calloc(n, sizeof(int)), *large = calloc(n, sizeof(int)), ns = 0, nl = 0;
+    for (int i = 1; i <= n; i++) { alias[i-1] = 0; probs[i-1] = n * probs[i-1];
+        if (probs[i-1] < 1.0) small[ns++] = i; else large[nl++] = i; }
+    while (ns > 0 && nl > 0) {
+        int ks = small[--ns], kl = large[--nl];
+        alias[ks-1] = kl;
+        probs[kl-1] = probs[kl-1] + probs[ks-1] - 1.0;
+        if (probs[kl-1] < 1.0) small[ns++] = kl; else large[nl++] = kl;
+    }
+    free(small); free(large);
+}
+/* setup_scattering_matrix: setup.f90:581-649 */
+static int setup_mueller(orc_sim *s) {
+    FILE *f = fopen(s->scatt_mat_file, "r");
+    if (!f) { snprintf(g_err, sizeof g_err, "cannot open scatt_mat_file '%s'", s->scatt_mat_file); return -1; }
+    char line[512]; double wl, cext, alb, hgg; int n;
+    if (!fgets(line, sizeof line, f) || !fgets(line, sizeof line, f) || sscanf(line, "%lf %lf %lf %lf %d", &wl, &cext, &alb, &hgg, &n) != 5)
+        { fclose(f); snprintf(g_err, sizeof g_err, "bad Mueller header"); return -1; }
+    s->albedo = alb; s->hgg = hgg; s->cext_dust = cext; s->nPDF = n;
+    if (!fgets(line, sizeof line, f)) { fclose(f); return -1; }
+    s->coss = malloc(n * sizeof(double)); s->S11 = malloc(n * sizeof(double)); s->S12 = malloc(n * sizeof(double));
+    s->S33 = malloc(n * sizeof(double)); s->S34 = malloc(n * sizeof(double));
+    s->phase_PDF = malloc((n - 1) * sizeof(double)); s->alias = malloc((n - 1) * sizeof(int));
+    for (int i = 0; i < n; i++)
+        if (fscanf(f, "%lf %lf %lf %lf %lf", &s->coss[i], &s->S11[i], &s->S12[i], &s->S33[i], &s->S34[i]) != 5)
+            { fclose(f); snprintf(g_err, sizeof g_err, "bad Mueller row %d", i); return -1; }
+    fclose(f);
+    double norm = 0.0;                                           /* calc_Integral: mathlib.f90:218-240 */
+    for (int i = 1; i < n; i++) norm = norm + 0.5 * (s->S11[i] + s->S11[i-1]) * fabs(s->coss[i] - s->coss[i-1]);
+    for (int i = 0; i < n; i++) { s->S11[i] /= norm; s->S12[i] /= norm; s->S33[i] /= norm; s->S34[i] /= norm; }
+    double sum = 0.0;
+    for (int i = 0; i < n - 1; i++) { s->phase_PDF[i] = (s->S11[i] + s->S11[i+1]) / 2.0; sum += s->phase_PDF[i]; }
+    for (int i = 0; i < n - 1; i++) s->phase_PDF[i] /= sum;
+    alias_setup(n - 1, s->phase_PDF, s->alias);
+    return 0;
+}
+/* interp_eq: mathlib.f90:71-106 */
+static double interp_eq(int n, const double *x, const double *y, double xnew) {
+    double dx = x[1] - x[0];
+    int i = (int)((xnew - x[0]) / dx + 1);         /* Fortran real->integer assignment truncates toward zero */
+    if (i <= 0) return y[0];
+    if (i >= n) return y[n-1];
+    return y[i-1] + (y[i] - y[i-1]) * (xnew - x[i-1]) / dx;
+}
+/* rand_alias_linear64: random_mt.f90:2196-2216 */
+static double rand_alias_linear(rng_t *g, int n, const double *prob_alias, const int *alias, const double *xaxis, const double *prob) {
+    int k = (int)floor(n * rnd(g)) + 1, idx;
+    if (rnd(g) < prob_alias[k-1]) idx = k; else idx = alias[k-1];
+    double p0 = prob[idx-1], p1 = prob[idx];
+    return (sqrt(p0 * p0 + (p1 * p1 - p0 * p0) * rnd(g)) - p0) * (xaxis[idx] - xaxis[idx-1]) / (p1 - p0) + xaxis[idx-1];
+}
+
+static int read_input_post(orc_sim *s) {
+    /* setup.f90:161-165: a 1-cell axis disables xyz_symmetry */
+    if (s->nx == 1 || s->ny == 1 || s->nz == 1) s->xyz_symmetry = 0;
+    /* :188-206 peel-off switches */
+    if (!(s->save_peeloff_2D || s->save_peeloff_3D)) s->save_peeloff = 0;
+    if (s->nxim > 0 && s->nyim > 0) s->save_peeloff = 1;
+    if (s->save_peeloff && s->xyz_symmetry) s->save_peeloff = 0;
+    if (!s->save_peeloff) { s->save_peeloff_2D = 0; s->save_peeloff_3D = 0; }
+    /* :236-238 */
+    if (s->cext_dust <= 0.0) s->DGR = 0.0;
+    if (s->DGR == 0.0) s->save_Jabs = 0;
+    if (s->core_skip_global) s->core_skip = 1;
+    /* :367-381 Jmu */
+    if (s->save_Jmu) { if (s->xyz_symmetry) { s->mu_min = 0.0; s->dmu = 1.0 / s->nmu; } else { s->mu_min = -1.0; s->dmu = 2.0 / s->nmu; } }
+    /* :398-428 geometry normalisation */
+    if (s->geometry == 0) {
+        if (!s->xy_periodic) {
+            double c[4] = {s->rmax, s->xmax, s->ymax, s->zmax}, r0 = -HUGEST;
+            for (int i = 0; i < 4; i++) if (c[i] > 0.0 && c[i] > r0) r0 = c[i];
+            if (r0 > 0.0) { s->rmax = s->xmax = s->ymax = s->zmax = r0; }
+            int n = s->nx; if (s->ny > n) n = s->ny; if (s->nz > n) n = s->nz;
+            s->nx = s->ny = s->nz = n;
+        }
+    } else s->rmax = -1.0;
+    if (s->source_rmax < 0.0) s->source_rmax = s->rmax;
+    /* :473-489 distance unit ('' -> 1) */
+    if (s->distance2cm < 0.0) s->distance2cm = 1.0;
+    /* :496-500 Mueller table / Stokes without table forces DGR = 0 */
+    if (s->scatt_mat_file[0] && s->DGR > 0.0) { if (setup_mueller(s)) return -1; }
+    else if (s->use_stokes) s->DGR = 0.0;
+    if (s->DGR == 0.0) s->save_Jabs = 0;
+    return 0;
+}
+
+/* =====================================================================================
+ * grid_create, uniform-medium subset: grid_mod_car.f90:73-1238
+ * ===================================================================================== */
+static void sym_axis(int n, double vmax, double *d, double *vmin, int *i0) {      /* :85-112 */
+    if ((n / 2) * 2 == n) { *d = vmax / n; *vmin = 0.0; *i0 = 1; }
+    else { *d = vmax / (n - 0.5); *vmin = -(*d) / 2.0; *i0 = 2; }
+}
+static int grid_create(orc_sim *s) {
+    int nx = s->nx, ny = s->ny, nz = s->nz; size_t nc = (size_t)nx * ny * nz;
+    if (s->xyz_symmetry) {
+        sym_axis(nx, s->xmax, &s->dx, &s->xmin, &s->i0);
+        sym_axis(ny, s->ymax, &s->dy, &s->ymin, &s->j0);
+        sym_axis(nz, s->zmax, &s->dz, &s->zmin, &s->k0);
+    } else {                                                                     /* :166-176 */
+        s->dx = 2.0 * s->xmax / nx; s->dy = 2.0 * s->ymax / ny; s->dz = 2.0 * s->zmax / nz;
+        s->xmin = -s->xmax; s->ymin = -s->ymax; s->zmin = -s->zmax; s->i0 = s->j0 = s->k0 = 0;
+    }
+    s->xrange = s->xmax - s->xmin; s->yrange = s->ymax - s->ymin; s->zrange = s->zmax - s->zmin;
+    s->xface = malloc((nx + 1) * sizeof(double)); s->yface = malloc((ny + 1) * sizeof(double)); s->zface = malloc((nz + 1) * sizeof(double));
+    for (int i = 1; i <= nx + 1; i++) s->xface[i-1] = (i - 1) * s->dx + s->xmin;   /* :184-187 */
+    for (int i = 1; i <= ny + 1; i++) s->yface[i-1] = (i - 1) * s->dy + s->ymin;
+    for (int i = 1; i <= nz + 1; i++) s->zface[i-1] = (i - 1) * s->dz + s->zmin;
+    s->vfx = calloc(nc, sizeof(double)); s->vfy = calloc(nc, sizeof(double)); s->vfz = calloc(nc, sizeof(double));
+    s->Dfreq = malloc(nc * sizeof(double)); s->voigt_a = malloc(nc * sizeof(double)); s->rhokap = malloc(nc * sizeof(double));
+    s->rhokapD = calloc(nc, sizeof(double));
+    double *xx = malloc(nx * sizeof(double)), *yy = malloc(ny * sizeof(double)), *zz = malloc(nz * sizeof(double));
+    for (int i = 0; i < nx; i++) xx[i] = (s->xface[i] + s->xface[i+1]) / 2.0;      /* :224-232 */
+    for (int i = 0; i < ny; i++) yy[i] = (s->yface[i] + s->yface[i+1]) / 2.0;
+    for (int i = 0; i < nz; i++) zz[i] = (s->zface[i] + s->zface[i+1]) / 2.0;
+    s->Dfreq_ref = vtherm_total(s, s->temperature) / (s->wavelength0 * UM2KM);      /* :238 */
+    /* (1) temperature -> Dfreq, voigt_a :273-284 */
+    double vth = vtherm_total(s, s->temperature);
+    for (size_t c = 0; c < nc; c++) { s->Dfreq[c] = vth / (s->wavelength0 * UM2KM); s->voigt_a[c] = (s->damping / FOURPI) / s->Dfreq[c]; }
+    /* (2) density: :352-365 synthetic medium, distance2cm reset to 1 */
+    s->distance2cm = 1.0;
+    for (size_t c = 0; c < nc; c++) { s->rhokap[c] = 1.0; if (s->DGR > 0.0) s->rhokapD[c] = s->cext_dust * s->DGR; }
+    if (s->rmax > 0.0) {                                                            /* :367-395 sphere carved by cell centre */
+        for (int k = 1; k <= nz; k++) for (int j = 1; j <= ny; j++) for (int i = 1; i <= nx; i++) {
+            double rr = sqrt(xx[i-1] * xx[i-1] + yy[j-1] * yy[j-1] + zz[k-1] * zz[k-1]);
+            if (rr < s->rmin || rr > s->rmax) { s->rhokap[IDX(s,i,j,k)] = 0.0; if (s->DGR > 0.0) s->rhokapD[IDX(s,i,j,k)] = 0.0; }
+        }
+    }
+    for (size_t c = 0; c < nc; c++) s->rhokap[c] = s->rhokap[c] / s->Dfreq[c] * s->cross0;    /* :487-493 */
+    double opac_length;                                                             /* :495-503 */
+    if (s->rmax > 0.0 && s->rmin > 0.0) opac_length = s->rmax - s->rmin;
+    else if (s->rmax > 0.0) opac_length = s->rmax;
+    else if (s->zmax == -s->zmin) opac_length = s->zrange / 2.0;
+    else opac_length = s->zrange;
+    int nxcen, nycen;                                                               /* :505-515 */
+    if (s->xyz_symmetry) { nxcen = 1; nycen = 1; } else { nxcen = (nx + 1) / 2; nycen = (ny + 1) / 2; }
+#define NADD(i,j,k,nadd) do { nadd = 1.0; if (s->xyz_symmetry) { \
+        if ((i) == 1 && (nx/2)*2 != nx) nadd = nadd / 2.0; if ((j) == 1 && (ny/2)*2 != ny) nadd = nadd / 2.0; \
+        if ((k) == 1 && (nz/2)*2 != nz) nadd = nadd / 2.0; } } while (0)
+    double opacity_sum, opacity1, opac_norm, nopac, nadd;
+    if (s->taumax > 0.0) {                                                          /* :518-538 */
+        opacity_sum = 0.0;
+        for (int k = 1; k <= nz; k++) opacity_sum = opacity_sum + s->rhokap[IDX(s,nxcen,nycen,k)] * orc_voigt(0.0, s->voigt_a[IDX(s,nxcen,nycen,k)]);
+        if (s->xyz_symmetry) {
+            if ((nz / 2) * 2 == nz) opac_norm = s->taumax / (opacity_sum * s->dz);
+            else { opacity1 = s->rhokap[IDX(s,nxcen,nycen,1)] * orc_voigt(0.0, s->voigt_a[IDX(s,nxcen,nycen,1)]);
+                   opac_norm = s->taumax / ((opacity_sum - opacity1 / 2.0) * s->dz); }
+        } else if (s->zmax == -s->zmin) opac_norm = (2.0 * s->taumax) / (opacity_sum * s->dz);
+        else opac_norm = s->taumax / (opacity_sum * s->dz);
+        for (size_t c = 0; c < nc; c++) { s->rhokap[c] *= opac_norm; if (s->DGR > 0.0) s->rhokapD[c] *= opac_norm; }
+    } else if (s->tauhomo > 0.0) {                                                  /* :539-566 */
+        opacity_sum = 0.0; nopac = 0.0;
+        for (int k = 1; k <= nz; k++) for (int j = 1; j <= ny; j++) for (int i = 1; i <= nx; i++) {
+            NADD(i, j, k, nadd);
+            if (s->rhokap[IDX(s,i,j,k)] > 0.0) { opacity_sum += s->rhokap[IDX(s,i,j,k)] * orc_voigt(0.0, s->voigt_a[IDX(s,i,j,k)]) * nadd; nopac += nadd; } }
+        opac_norm = s->tauhomo / (opacity_sum / nopac * opac_length);
+        for (size_t c = 0; c < nc; c++) { s->rhokap[c] *= opac_norm; if (s->DGR > 0.0) s->rhokapD[c] *= opac_norm; }
+    } else if (s->N_gasmax > 0.0) {                                                 /* :567-586 */
+        opacity_sum = 0.0;
+        for (int k = 1; k <= nz; k++) opacity_sum += s->rhokap[IDX(s,nxcen,nycen,k)] * s->Dfreq[IDX(s,nxcen,nycen,k)];
+        if (s->xyz_symmetry) {
+            if ((nz / 2) * 2 == nz) opac_norm = s->N_gasmax / (opacity_sum * s->dz / s->cross0);
+            else { opacity1 = s->rhokap[IDX(s,nxcen,nycen,1)] * s->Dfreq[IDX(s,nxcen,nycen,1)];
+                   opac_norm = s->N_gasmax / ((opacity_sum - opacity1 / 2.0) * s->dz / s->cross0); }
+        } else if (s->zmax == -s->zmin) opac_norm = (2.0 * s->N_gasmax) / (opacity_sum * s->dz / s->cross0);
+        else opac_norm = s->N_gasmax / (opacity_sum * s->dz / s->cross0);
+        for (size_t c = 0; c < nc; c++) { s->rhokap[c] *= opac_norm; if (s->DGR > 0.0) s->rhokapD[c] *= opac_norm; }
+    } else if (s->N_gashomo > 0.0) {                                                /* :587-615 */
+        opacity_sum = 0.0; nopac = 0.0;
+        for (int k = 1; k <= nz; k++) for (int j = 1; j <= ny; j++) for (int i = 1; i <= nx; i++) {
+            NADD(i, j, k, nadd);
+            if (s->rhokap[IDX(s,i,j,k)] > 0.0) { opacity_sum += s->rhokap[IDX(s,i,j,k)] * s->Dfreq[IDX(s,i,j,k)] * nadd; nopac += nadd; } }
+        double dens = opacity_sum / nopac / s->cross0;
+        opac_norm = s->N_gashomo / (dens * opac_length);
+        for (size_t c = 0; c < nc; c++) { s->rhokap[c] *= opac_norm; if (s->DGR > 0.0) s->rhokapD[c] *= opac_norm; }
+    }
+    /* homogeneous / pole optical depths and columns :617-737 */
+    double tauhomo, taupole, N_gashomo, N_gaspole, os2 = 0.0;
+    opacity_sum = 0.0; nopac = 0.0;
+    for (int k = 1; k <= nz; k++) for (int j = 1; j <= ny; j++) for (int i = 1; i <= nx; i++) {
+        NADD(i, j, k, nadd);
+        if (s->rhokap[IDX(s,i,j,k)] > 0.0) { opacity_sum += s->rhokap[IDX(s,i,j,k)] * orc_voigt(0.0, s->voigt_a[IDX(s,i,j,k)]) * nadd;
+                                              os2 += s->rhokap[IDX(s,i,j,k)] * s->Dfreq[IDX(s,i,j,k)] * nadd; nopac += nadd; } }
+    tauhomo = opacity_sum / nopac * opac_length;
+    N_gashomo = os2 / nopac / s->cross0 * opac_length;
+    opacity_sum = 0.0; os2 = 0.0;
+    for (int k = 1; k <= nz; k++) { opacity_sum += s->rhokap[IDX(s,nxcen,nycen,k)] * orc_voigt(0.0, s->voigt_a[IDX(s,nxcen,nycen,k)]);
+                                    os2 += s->rhokap[IDX(s,nxcen,nycen,k)] * s->Dfreq[IDX(s,nxcen,nycen,k)]; }
+    if (s->xyz_symmetry) {
+        taupole = opacity_sum * s->dz; N_gaspole = os2 * s->dz / s->cross0;
+        if ((nz / 2) * 2 != nz) {
+            taupole -= s->rhokap[IDX(s,nxcen,nycen,1)] * orc_voigt(0.0, s->voigt_a[IDX(s,nxcen,nycen,1)]) * s->dz / 2.0;
+            N_gaspole -= s->rhokap[IDX(s,nxcen,nycen,1)] * s->Dfreq[IDX(s,nxcen,nycen,1)] * s->dz / 2.0 / s->cross0; }
+    } else if (s->zmax == -s->zmin) { taupole = opacity_sum * s->dz / 2.0; N_gaspole = os2 * s->dz / 2.0 / s->cross0; }
+    else { taupole = opacity_sum * s->dz; N_gaspole = os2 * s->dz / s->cross0; }
+    if (s->taumax <= 0.0) s->taumax = taupole;
+    if (s->tauhomo <= 0.0) s->tauhomo = tauhomo;
+    if (s->N_gasmax <= 0.0) s->N_gasmax = N_gaspole;
+    if (s->N_gashomo <= 0.0) s->N_gashomo = N_gashomo;
+    /* (3) velocity field :786-946 (velocities in units of the local thermal speed) */
+    if (s->velocity_type) {
+        double rpeak = (s->rmax <= 0.0) ? fmax(s->xmax, fmax(s->ymax, s->zmax)) : s->rmax;
+        for (int k = 1; k <= nz; k++) for (int j = 1; j <= ny; j++) for (int i = 1; i <= nx; i++) {
+            size_t c = IDX(s,i,j,k); if (!(s->rhokap[c] > 0.0)) continue;
+            double vt = vtherm_total(s, s->temperature);
+            if (s->velocity_type == 1) {                                            /* hubble :786-803 */
+                s->vfx[c] = (s->Vexp / vt) * xx[i-1] / rpeak; s->vfy[c] = (s->Vexp / vt) * yy[j-1] / rpeak; s->vfz[c] = (s->Vexp / vt) * zz[k-1] / rpeak;
+            } else if (s->velocity_type == 2) {                                     /* constant_radial :839-865 */
+                double rr = sqrt(xx[i-1] * xx[i-1] + yy[j-1] * yy[j-1] + zz[k-1] * zz[k-1]);
+                if (rr > s->dz / 10.0) { s->vfx[c] = s->Vexp / vt * xx[i-1] / rr; s->vfy[c] = s->Vexp / vt * yy[j-1] / rr; s->vfz[c] = s->Vexp / vt * zz[k-1] / rr; }
+            } else { s->vfx[c] = s->Vx / vt; s->vfy[c] = s->Vy / vt; s->vfz[c] = s->Vz / vt; }   /* parallel :804-816 */
+        }
+    }
+    free(xx); free(yy); free(zz);
+    /* :1150-1154 */
+    s->voigt_amean = (s->damping / FOURPI) / s->Dfreq_ref;
+    double atau0 = s->voigt_amean * s->tauhomo;
+    /* car_setup_freq_grid :1442-1548 */
+    s->atau3 = pow(s->voigt_amean * s->tauhomo, 1.0 / 3.0);
+    if (!(isfinite(s->par_xfreq_max) && isfinite(s->par_xfreq_min))) {
+        double xscale = (s->taumax <= 5e1) ? 25.0 : (s->taumax <= 5e2) ? 14.0 : (s->taumax <= 5e3) ? 10.0 : 5.0;
+        double vt = vtherm_total(s, s->temperature);
+        if (s->Vexp == 0.0) { s->par_xfreq_max = floor(xscale * s->atau3) + 1; s->par_xfreq_min = -(floor(xscale * s->atau3 + 0.0) + 1); }
+        else if (s->Vexp > 0.0) { s->par_xfreq_max = floor(xscale * s->atau3) + 1; s->par_xfreq_min = -(floor(xscale * s->atau3 + fabs(s->Vexp) / vt + 0.0) + 1); }
+        else { s->par_xfreq_max = floor(xscale * s->atau3 + fabs(s->Vexp) / vt) + 1; s->par_xfreq_min = -(floor(xscale * s->atau3 + 0.0) + 1); }
+    }
+    s->dxfreq = (s->par_xfreq_max - s->par_xfreq_min) / s->nxfreq;
+    s->xfreq_max = s->par_xfreq_max; s->xfreq_min = s->par_xfreq_min;
+    /* tallies :1161-1183 */
+    s->Jout = calloc(s->nxfreq, sizeof(double)); s->Jin = calloc(s->nxfreq, sizeof(double)); s->Jabs = calloc(s->nxfreq, sizeof(double));
+    s->Jmu = calloc((size_t)s->nxfreq * (s->nmu > 0 ? s->nmu : 1), sizeof(double));
+    /* global core-skip parameters :1186-1219 */
+    double at = s->core_skip_global ? atau0 : atau0 / (s->xmax / s->dx);
+    if (at <= 1.0) { s->xcrit = 0.0; s->xcrit2 = 0.0; }
+    else { double xi = (at <= 60.0) ? 0.6 : 1.4, chi = (at <= 60.0) ? 1.2 : 0.6;
+           s->xcrit = 0.02 * exp(xi * pow(log(at), chi)); s->xcrit2 = s->xcrit * s->xcrit; }
+    /* dispatch as setup_procedure, setup.f90:967-990 */
+    if (s->xyz_symmetry) s->raytrace_variant = 1;
+    else if (s->xy_periodic && s->nx == 1 && s->ny == 1) s->raytrace_variant = 2;
+    else if (s->xy_periodic) { snprintf(g_err, sizeof g_err, "xy_periodic with nx,ny>1 not supported by the oracle"); return -1; }
+    else s->raytrace_variant = 0;
+    return 0;
+}
+
+/* observer_create_outside: observer_rect.f90:24-326 */
+static int observer_create(orc_sim *s) {
+    if (!s->save_peeloff) { s->nobs = 0; return 0; }
+    double cosa[MAX_OBS], sina[MAX_OBS], cosb[MAX_OBS], sinb[MAX_OBS], cosg[MAX_OBS], sing[MAX_OBS];
+    double rcx = 0.0, rcy = 0.0, rcz = 0.0;
+    double maxsz = fmax(s->xmax, fmax(s->ymax, s->zmax));
+    for (int i = 0; i < MAX_OBS; i++) {                                            /* :54-55 */
+        if (isfinite(s->beta[i]) && !isfinite(s->alpha[i])) s->alpha[i] = 0.0;
+        if (isfinite(s->alpha[i]) && !isfinite(s->beta[i])) s->beta[i] = 0.0; }
+    if (!(isfinite(s->alpha[0]) && isfinite(s->beta[0])) && !(isfinite(s->obsx[0]) && isfinite(s->obsy[0]) && isfinite(s->obsz[0]))) {
+        if (!isfinite(s->distance)) s->distance = maxsz * 100.0;                   /* :58-71 default observer */
+        s->obsx[0] = 0.0; s->obsy[0] = 0.0; s->obsz[0] = 1.0; s->alpha[0] = 0.0; s->beta[0] = 0.0; }
+    if (isfinite(s->alpha[0]) && isfinite(s->beta[0])) {                           /* :73-122 */
+        int n = 0; for (int i = 0; i < MAX_OBS; i++) if (isfinite(s->alpha[i]) && isfinite(s->beta[i])) n++;
+        s->nobs = n;
+        if (!isfinite(s->distance)) s->distance = maxsz * 100.0;
+        for (int i = 0; i < n; i++) {
+            if (!isfinite(s->gamma[i])) { if (s->beta[i] > 0.0 && s->beta[i] <= 90.0) s->gamma[i] = 90.0; else if (s->beta[i] > 90.0) s->gamma[i] = -90.0; else s->gamma[i] = 0.0; }
+            cosa[i] = cos(s->alpha[i] * DEG2RAD); sina[i] = sin(s->alpha[i] * DEG2RAD);
+            cosb[i] = cos(s->beta[i] * DEG2RAD);  sinb[i] = sin(s->beta[i] * DEG2RAD);
+            cosg[i] = cos(s->gamma[i] * DEG2RAD); sing[i] = sin(s->gamma[i] * DEG2RAD);
+            s->obs[i].x = s->distance * cosa[i] * sinb[i] + rcx; s->obs[i].y = s->distance * sina[i] * sinb[i] + rcy; s->obs[i].z = s->distance * cosb[i] + rcz;
+        }
+    } else {                                                                       /* :123-199 */
+        int n = 0; for (int i = 0; i < MAX_OBS; i++) if (isfinite(s->obsx[i]) && isfinite(s->obsy[i]) && isfinite(s->obsz[i])) n++;
+        s->nobs = n;
+        if (!isfinite(s->distance)) { s->distance = sqrt(s->obsx[0] * s->obsx[0] + s->obsy[0] * s->obsy[0] + s->obsz[0] * s->obsz[0]);
+            if (s->distance < 10.0 * maxsz) s->distance = maxsz * 100.0; }
+        for (int i = 0; i < n; i++) {
+            if (!isfinite(s->gamma[i])) { if (s->beta[i] > 0.0 && s->beta[i] <= 90.0) s->gamma[i] = 90.0; else if (s->beta[i] > 90.0) s->gamma[i] = -90.0; else s->gamma[i] = 0.0; }
+            double ds = s->distance / sqrt(s->obsx[i] * s->obsx[i] + s->obsy[i] * s->obsy[i] + s->obsz[i] * s->obsz[i]);
+            if (ds > 1.001) { s->obs[i].x = s->obsx[i] * ds + rcx; s->obs[i].y = s->obsy[i] * ds + rcy; s->obs[i].z = s->obsz[i] * ds + rcz; }
+            else { s->obs[i].x = s->obsx[i]; s->obs[i].y = s->obsy[i]; s->obs[i].z = s->obsz[i]; }
+            cosb[i] = (s->obs[i].z - rcz) / s->distance;
+            if (fabs(cosb[i] - 1.0) < DBL_EPSILON) cosb[i] = 1.0;
+            if (fabs(cosb[i] + 1.0) < DBL_EPSILON) cosb[i] = -1.0;
+            sinb[i] = sqrt(1.0 - cosb[i] * cosb[i]);
+            s->beta[i] = atan2(sinb[i], cosb[i]) * RAD2DEG;
+            cosg[i] = cos(s->gamma[i] * DEG2RAD); sing[i] = sin(s->gamma[i] * DEG2RAD);
+            if (sinb[i] == 0.0) { cosa[i] = 1.0; sina[i] = 0.0; s->alpha[i] = 0.0; }
+            else { double al = atan2(s->obs[i].y - rcy, s->obs[i].x - rcx); cosa[i] = cos(al); sina[i] = sin(al); s->alpha[i] = al * RAD2DEG; }
+        }
+    }
+    for (int i = 0; i < s->nobs; i++) {                                            /* :207-217 */
+        double *m = s->obs[i].rm;
+        m[0] =  cosa[i] * cosb[i] * cosg[i] - sina[i] * sing[i]; m[1] =  sina[i] * cosb[i] * cosg[i] + cosa[i] * sing[i]; m[2] = -sinb[i] * cosg[i];
+        m[3] = -cosa[i] * cosb[i] * sing[i] - sina[i] * cosg[i]; m[4] = -sina[i] * cosb[i] * sing[i] + cosa[i] * cosg[i]; m[5] =  sinb[i] * sing[i];
+        m[6] =  cosa[i] * sinb[i]; m[7] = sina[i] * sinb[i]; m[8] = cosb[i];
+    }
+    if (!(isfinite(s->dxim) && isfinite(s->dyim))) {                               /* :244-276 */
+        if (s->geometry == 0) { s->dxim = asin(s->rmax / s->distance) / (s->nxim / 2.0) * RAD2DEG; s->dyim = asin(s->rmax / s->distance) / (s->nyim / 2.0) * RAD2DEG; }
+        else {
+            static const double vx[8] = {1, 1, 1, -1, -1, -1, 1, -1}, vy[8] = {1, 1, -1, 1, -1, 1, -1, -1}, vz[8] = {1, -1, 1, 1, 1, -1, -1, -1};
+            double max_x = -999.0, max_y = -999.0;
+            for (int i = 0; i < s->nobs; i++) for (int iv = 0; iv < 8; iv++) {
+                double px = s->obs[i].x - vx[iv] * s->xmax, py = s->obs[i].y - vy[iv] * s->ymax, pz = s->obs[i].z - vz[iv] * s->zmax, *m = s->obs[i].rm;
+                double kx = m[0] * px + m[1] * py + m[2] * pz, ky = m[3] * px + m[4] * py + m[5] * pz, kz = m[6] * px + m[7] * py + m[8] * pz;
+                double ax = fabs(atan2(-kx, kz)), ay = fabs(atan2(-ky, kz));
+                if (max_x < ax) max_x = ax; if (max_y < ay) max_y = ay; }
+            if (s->nxim == s->nyim) { double m = fmax(max_x, max_y); s->dxim = m / (s->nxim / 2.0) * RAD2DEG; s->dyim = m / (s->nyim / 2.0) * RAD2DEG; }
+            else { if (!isfinite(s->dxim)) s->dxim = max_x / (s->nxim / 2.0) * RAD2DEG; if (!isfinite(s->dyim)) s->dyim = max_y / (s->nyim / 2.0) * RAD2DEG; }
+        }
+    }
+    size_t n2 = (size_t)s->nxim * s->nyim, n3 = n2 * s->nxfreq;                    /* :287-324 */
+    for (int i = 0; i < s->nobs; i++) { obs_t *o = &s->obs[i];
+        if (s->save_peeloff_2D) { o->scatt_2D = calloc(n2, 8); o->direc_2D = calloc(n2, 8);
+            if (s->use_stokes) { o->I_2D = calloc(n2, 8); o->Q_2D = calloc(n2, 8); o->U_2D = calloc(n2, 8); o->V_2D = calloc(n2, 8); } }
+        if (s->save_peeloff_3D) { o->scatt = calloc(n3, 8); o->direc = calloc(n3, 8);
+            if (s->use_stokes) { o->I = calloc(n3, 8); o->Q = calloc(n3, 8); o->U = calloc(n3, 8); o->V = calloc(n3, 8); } } }
+    return 0;
+}
+
+orc_sim *orc_create(const char *params) {
+    orc_sim *s = malloc(sizeof *s); set_defaults(s); setup_line(s);
+    char *buf = strdup(params), *save = NULL;
+    for (char *tok = strtok_r(buf, " \t\n,", &save); tok; tok = strtok_r(NULL, " \t\n,", &save)) {
+        char *eq = strchr(tok, '='); if (!eq) { snprintf(g_err, sizeof g_err, "bad token '%s'", tok); free(buf); free(s); return NULL; }
+        *eq = 0; const char *k = tok; if (!strncmp(k, "par%", 4)) k += 4;
+        if (set_param(s, k, eq + 1)) { free(buf); free(s); return NULL; }
+    }
+    free(buf);
+    if (read_input_post(s) || grid_create(s) || observer_create(s)) { free(s); return NULL; }
+    return s;
+}
+static void free_obs(obs_t *o) { free(o->scatt); free(o->direc); free(o->I); free(o->Q); free(o->U); free(o->V);
+    free(o->scatt_2D); free(o->direc_2D); free(o->I_2D); free(o->Q_2D); free(o->U_2D); free(o->V_2D); }
+void orc_destroy(orc_sim *s) {
+    if (!s) return;
+    free(s->xface); free(s->yface); free(s->zface); free(s->rhokap); free(s->voigt_a); free(s->Dfreq); free(s->vfx); free(s->vfy); free(s->vfz); free(s->rhokapD);
+    free(s->Jout); free(s->Jin); free(s->Jabs); free(s->Jmu); free(s->coss); free(s->S11); free(s->S12); free(s->S33); free(s->S34); free(s->phase_PDF); free(s->alias);
+    for (int i = 0; i < MAX_OBS; i++) free_obs(&s->obs[i]);
+    free(s->log_nscatt); free(s->log_xfreq); free(s);
+}
+
+/* =====================================================================================
+ * Ray marches: raytrace_car.f90
+ * ===================================================================================== */
+typedef struct { int icell, jcell, kcell, istep, jstep, kstep; double kx, ky, kz, tx, ty, tz, delx, dely, delz; } trav_t;
+
+/* setup_traversal_car: raytrace_car.f90:12-87.  Returns 1 when out_of_grid. */
+static int setup_traversal_car(const orc_sim *s, double xp, double yp, double zp, trav_t *t) {
+    if (t->kx > 0.0) {
+        if (t->icell > s->nx && s->xface[t->icell-1] <= xp) return 1;
+        t->istep = 1; t->tx = (s->xface[t->icell] - xp) / t->kx; t->delx = s->dx / t->kx;
+    } else if (t->kx < 0.0) {
+        if (s->xface[t->icell-1] == xp) { if (t->icell > 1) t->icell -= 1; else return 1; }
+        t->istep = -1; t->tx = (s->xface[t->icell-1] - xp) / t->kx; t->delx = -s->dx / t->kx;
+    } else { t->istep = 0; t->tx = HUGEST; t->delx = HUGEST; }
+    if (t->ky > 0.0) {
+        if (t->jcell > s->ny && s->yface[t->jcell-1] <= yp) return 1;
+        t->jstep = 1; t->ty = (s->yface[t->jcell] - yp) / t->ky; t->dely = s->dy / t->ky;
+    } else if (t->ky < 0.0) {
+        if (s->yface[t->jcell-1] == yp) { if (t->jcell > 1) t->jcell -= 1; else return 1; }
+        t->jstep = -1; t->ty = (s->yface[t->jcell-1] - yp) / t->ky; t->dely = -s->dy / t->ky;
+    } else { t->jstep = 0; t->ty = HUGEST; t->dely = HUGEST; }
+    if (t->kz > 0.0) {
+        if (t->kcell > s->nz && s->zface[t->kcell-1] <= zp) return 1;
+        t->kstep = 1; t->tz = (s->zface[t->kcell] - zp) / t->kz; t->delz = s->dz / t->kz;
+    } else if (t->kz < 0.0) {
+        if (s->zface[t->kcell-1] == zp) { if (t->kcell > 1) t->kcell -= 1; else return 1; }
+        t->kstep = -1; t->tz = (s->zface[t->kcell-1] - zp) / t->kz; t->delz = -s->dz / t->kz;
+    } else { t->kstep = 0; t->tz = HUGEST; t->delz = HUGEST; }
+    return 0;
+}
+/* xyz-symmetric set-up of one axis: raytrace_car.f90:1691-1721 (tau; strict: face == xp leaves) and
+ * :631-661 (edge; face <= xp leaves).  Returns 1 when the ray leaves the grid at once. */
+static int setup_axis_sym(int n, const double *face, double d, int i0, double xp, int strict_eq,
+                          int *cell, int *step, double *k, double *t, double *del) {
+    if (*k > 0.0) {
+        if (*cell > n && (strict_eq ? (face[*cell-1] == xp) : (face[*cell-1] <= xp))) return 1;
+        *step = 1; *t = (face[*cell] - xp) / *k; *del = d / *k;
+    } else if (*k < 0.0) {
+        *step = -1; *del = -d / *k;
+        if (face[*cell-1] == xp) { if (*cell > 1) *cell -= 1; else { *cell = i0; *step = 1; *k = fabs(*k); } }
+        if (*step == 1) *t = (face[*cell] - xp) / *k; else *t = (face[*cell-1] - xp) / *k;
+    } else { *step = 0; *t = HUGEST; *del = HUGEST; }
+    return 0;
+}
+static inline int minloc3(double a, double b, double c) { int m = 1; double v = a; if (b < v) { m = 2; v = b; } if (c < v) m = 3; return m; }
+static inline double udot(const orc_sim *s, size_t c, double kx, double ky, double kz) { return s->vfx[c] * kx + s->vfy[c] * ky + s->vfz[c] * kz; }
+
+static void add_to_Jmu(const orc_sim *s, acc_t *A, const photon_t *p, int ix) {        /* raytrace_car.f90:4049-4064 */
+    double mu = p->kz; if (s->xyz_symmetry) mu = fabs(mu);
+    int imu = (int)floor((mu - s->mu_min) / s->dmu) + 1;
+    if (imu < 1) imu = 1; if (imu > s->nmu) imu = s->nmu;
+    A->Jmu[(size_t)(ix - 1) + (size_t)s->nxfreq * (imu - 1)] += p->wgt;
+}
+
+/* raytrace_to_tau_car (:1425-1648), _car_xyzsym (:1650-1949), _car_zonly (:2519-2675) */
+static void raytrace_to_tau(const orc_sim *s, acc_t *A, photon_t *p, double tau_in, int variant) {
+    trav_t t; double xp = p->x, yp = p->y, zp = p->z;
+    t.kx = p->kx; t.ky = p->ky; t.kz = p->kz; t.icell = p->icell; t.jcell = p->jcell; t.kcell = p->kcell;
+    if (variant == 0) { if (setup_traversal_car(s, xp, yp, zp, &t)) { p->inside = 0; return; } }
+    else if (variant == 1) {
+        if (setup_axis_sym(s->nx, s->xface, s->dx, s->i0, xp, 1, &t.icell, &t.istep, &t.kx, &t.tx, &t.delx)) { p->inside = 0; return; }
+        if (setup_axis_sym(s->ny, s->yface, s->dy, s->j0, yp, 1, &t.jcell, &t.jstep, &t.ky, &t.ty, &t.dely)) { p->inside = 0; return; }
+        if (setup_axis_sym(s->nz, s->zface, s->dz, s->k0, zp, 1, &t.kcell, &t.kstep, &t.kz, &t.tz, &t.delz)) { p->inside = 0; return; }
+    } else {                                                                         /* zonly :2558-2582 */
+        t.istep = t.jstep = 0; t.tx = t.ty = HUGEST; t.delx = t.dely = HUGEST;
+        if (t.kz > 0.0) { if (t.kcell > s->nz && s->zface[t.kcell-1] == zp) { p->inside = 0; return; }
+            t.kstep = 1; t.tz = (s->zface[t.kcell] - zp) / t.kz; t.delz = s->dz / t.kz; }
+        else if (t.kz < 0.0) { if (s->zface[t.kcell-1] == zp) { if (t.kcell > 1) t.kcell -= 1; else { p->inside = 0; return; } }
+            t.kstep = -1; t.tz = (s->zface[t.kcell-1] - zp) / t.kz; t.delz = -s->dz / t.kz; }
+        else { t.kstep = 0; t.tz = HUGEST; t.delz = HUGEST; }
+    }
+    double tau = 0.0, d = 0.0, del = 0.0, rhokap, rhokapH;
+    int iold = t.icell, jold = t.jcell, kold = t.kcell;
+    double u1 = udot(s, IDX(s,iold,jold,kold), t.kx, t.ky, t.kz), u2;
+    while (p->inside) {
+        size_t c = IDX(s,t.icell,t.jcell,t.kcell);
+        rhokapH = s->rhokap[c] * orc_voigt(p->xfreq, s->voigt_a[c]);
+        rhokap = (s->DGR > 0.0) ? rhokapH + s->rhokapD[c] : rhokapH;
+        A->n_cellsteps += 1.0;
+        int idx = (variant == 2) ? 3 : minloc3(t.tx, t.ty, t.tz);
+        double *tt = (idx == 1) ? &t.tx : (idx == 2) ? &t.ty : &t.tz;
+        del = *tt - d; tau = tau + del * rhokap; d = *tt;
+        if (tau >= tau_in) {
+            if (rhokap > 0.0) { double d_over = (tau - tau_in) / rhokap; d = d - d_over; del = del - d_over; }
+            if (variant != 1) { xp = xp + d * t.kx; yp = yp + d * t.ky; zp = zp + d * t.kz; }
+            break;
+        }
+        if (idx == 1) { t.icell += t.istep;
+            if (variant == 1 && t.icell < 1) { t.icell = s->i0; t.istep = 1; t.kx = -t.kx; }
+            else if (t.icell < 1 || t.icell > s->nx) { p->inside = 0; break; }
+            t.tx += t.delx; }
+        else if (idx == 2) { t.jcell += t.jstep;
+            if (variant == 1 && t.jcell < 1) { t.jcell = s->j0; t.jstep = 1; t.ky = -t.ky; }
+            else if (t.jcell < 1 || t.jcell > s->ny) { p->inside = 0; break; }
+            t.ty += t.dely; }
+        else { t.kcell += t.kstep;
+            if (variant == 1 && t.kcell < 1) { t.kcell = s->k0; t.kstep = 1; t.kz = -t.kz; }
+            else if (t.kcell < 1 || t.kcell > s->nz) { p->inside = 0; break; }
+            t.tz += t.delz; }
+        size_t cn = IDX(s,t.icell,t.jcell,t.kcell), co = IDX(s,iold,jold,kold);
+        u2 = udot(s, cn, t.kx, t.ky, t.kz);
+        p->xfreq = (p->xfreq + u1) * s->Dfreq[co] / s->Dfreq[cn] - u2;
+        iold = t.icell; jold = t.jcell; kold = t.kcell; u1 = u2;
+    }
+    if (!p->inside) { t.icell = iold; t.jcell = jold; t.kcell = kold; }
+    if (!p->inside) {                                                                /* escape tally :1613-1623 */
+        size_t c = IDX(s,t.icell,t.jcell,t.kcell);
+        u1 = udot(s, c, t.kx, t.ky, t.kz);
+        p->xfreq = p->xfreq + u1;
+        p->xfreq_ref = p->xfreq * (s->Dfreq[c] / s->Dfreq_ref);
+        int ix = (int)floor((p->xfreq_ref - s->xfreq_min) / s->dxfreq) + 1;
+        if (ix >= 1 && ix <= s->nxfreq) { A->Jout[ix-1] += p->wgt; if (s->save_Jmu) add_to_Jmu(s, A, p, ix); }
+    }
+    if (variant == 1) {                                                              /* :1935-1946 */
+        p->x = p->x + d * p->kx; p->y = p->y + d * p->ky; p->z = p->z + d * p->kz;
+        if (p->x < s->xmin) p->x = -p->x; if (p->y < s->ymin) p->y = -p->y; if (p->z < s->zmin) p->z = -p->z;
+        p->kx = t.kx; p->ky = t.ky; p->kz = t.kz;
+        p->icell = t.icell; p->jcell = t.jcell; p->kcell = t.kcell;
+    } else if (variant == 0) { p->x = xp; p->y = yp; p->z = zp; p->icell = t.icell; p->jcell = t.jcell; p->kcell = t.kcell; }
+    else { p->x = xp; p->y = yp; p->z = zp; p->kcell = t.kcell; }                     /* zonly :2669-2673 */
+}
+
+/* raytrace_to_edge_car (:410-508), _car_xyzsym (:584-781), _car_zonly (:1138-1234); dist >= 0 selects
+ * raytrace_to_dist_car (:89-195) on the plain grid */
+static double raytrace_to_edge(const orc_sim *s, const photon_t *p, int variant, double dist, double *nsteps) {
+    trav_t t; double xp = p->x, yp = p->y, zp = p->z, tau = 0.0, d = 0.0;
+    t.kx = p->kx; t.ky = p->ky; t.kz = p->kz; t.icell = p->icell; t.jcell = p->jcell; t.kcell = p->kcell;
+    if (variant == 0) { if (setup_traversal_car(s, xp, yp, zp, &t)) return tau; }
+    else if (variant == 1) {
+        if (setup_axis_sym(s->nx, s->xface, s->dx, s->i0, xp, 0, &t.icell, &t.istep, &t.kx, &t.tx, &t.delx)) return tau;
+        if (setup_axis_sym(s->ny, s->yface, s->dy, s->j0, yp, 0, &t.jcell, &t.jstep, &t.ky, &t.ty, &t.dely)) return tau;
+        if (setup_axis_sym(s->nz, s->zface, s->dz, s->k0, zp, 0, &t.kcell, &t.kstep, &t.kz, &t.tz, &t.delz)) return tau;
+    } else {
+        t.istep = t.jstep = 0; t.tx = t.ty = HUGEST; t.delx = t.dely = HUGEST;
+        if (t.kz > 0.0) { if (t.kcell > s->nz && s->zface[t.kcell-1] <= zp) return tau;
+            t.kstep = 1; t.tz = (s->zface[t.kcell] - zp) / t.kz; t.delz = s->dz / t.kz; }
+        else if (t.kz < 0.0) { if (s->zface[t.kcell-1] == zp) { if (t.kcell > 1) t.kcell -= 1; else return tau; }
+            t.kstep = -1; t.tz = (s->zface[t.kcell-1] - zp) / t.kz; t.delz = -s->dz / t.kz; }
+        else { t.kstep = 0; t.tz = HUGEST; t.delz = HUGEST; }
+    }
+    int iold = t.icell, jold = t.jcell, kold = t.kcell;
+    double u1 = udot(s, IDX(s,iold,jold,kold), t.kx, t.ky, t.kz), u2, xfreq = p->xfreq, rhokap;
+    for (;;) {
+        size_t c = IDX(s,t.icell,t.jcell,t.kcell);
+        rhokap = s->rhokap[c] * orc_voigt(xfreq, s->voigt_a[c]);
+        if (s->DGR > 0.0) rhokap = rhokap + s->rhokapD[c];
+        if (nsteps) *nsteps += 1.0;
+        int idx = (variant == 2) ? 3 : minloc3(t.tx, t.ty, t.tz);
+        double *tt = (idx == 1) ? &t.tx : (idx == 2) ? &t.ty : &t.tz;
+        if (dist >= 0.0) { if (*tt >= dist) { tau = tau + (dist - d) * rhokap; break; } }
+        tau = tau + (*tt - d) * rhokap; d = *tt;
+        if (idx == 1) { t.icell += t.istep;
+            if (variant == 1 && t.icell < 1) { t.icell = s->i0; t.istep = 1; t.kx = -t.kx; }
+            else if (t.icell < 1 || t.icell > s->nx) break;
+            t.tx += t.delx; }
+        else if (idx == 2) { t.jcell += t.jstep;
+            if (variant == 1 && t.jcell < 1) { t.jcell = s->j0; t.jstep = 1; t.ky = -t.ky; }
+            else if (t.jcell < 1 || t.jcell > s->ny) break;
+            t.ty += t.dely; }
+        else { t.kcell += t.kstep;
+            if (variant == 1 && t.kcell < 1) { t.kcell = s->k0; t.kstep = 1; t.kz = -t.kz; }
+            else if (t.kcell < 1 || t.kcell > s->nz) break;
+            t.tz += t.delz; }
+        if (tau >= TAU_HUGE) break;
+        size_t cn = IDX(s,t.icell,t.jcell,t.kcell), co = IDX(s,iold,jold,kold);
+        u2 = udot(s, cn, t.kx, t.ky, t.kz);
+        xfreq = (xfreq + u1) * s->Dfreq[co] / s->Dfreq[cn] - u2;
+        iold = t.icell; jold = t.jcell; kold = t.kcell; u1 = u2;
+    }
+    return tau;
+}
+
+/* car_xcrit_local: grid_mod_car.f90:1598-1629 */
+static void car_xcrit_local(const orc_sim *s, int i, int j, int k, double x, double y, double z, double *xc, double *xc2) {
+    if (s->core_skip_global) { *xc = s->xcrit; *xc2 = s->xcrit2; return; }
+    *xc = 0.0; *xc2 = 0.0;
+    if (i < 1 || j < 1 || k < 1) return;
+    double dlx = fmin(x - s->xface[i-1], s->xface[i] - x), dly = fmin(y - s->yface[j-1], s->yface[j] - y), dlz = fmin(z - s->zface[k-1], s->zface[k] - z);
+    double dl = fmin(dlx, fmin(dly, dlz));
+    if (dl <= 0.0) return;
+    double atau = s->voigt_a[IDX(s,i,j,k)] * s->rhokap[IDX(s,i,j,k)] * dl;
+    if (atau > 1.0) { *xc = pow(atau, 1.0 / 3.0) / 5.0; *xc2 = (*xc) * (*xc); }
+}
+double orc_xcrit_local(const orc_sim *s, int i, int j, int k, double x, double y, double z) { double a, b; car_xcrit_local(s, i, j, k, x, y, z, &a, &b); return a; }
+
+/* =====================================================================================
+ * Peel-off to far observers: peelingoff_rect.f90
+ * ===================================================================================== */
+static inline void obs_dir(const obs_t *o, const photon_t *p, photon_t *pobs, double *r2, int nxim, int nyim, double dxim, double dyim, int *ix, int *iy) {
+    *pobs = *p;
+    pobs->kx = o->x - p->x; pobs->ky = o->y - p->y; pobs->kz = o->z - p->z;
+    *r2 = pobs->kx * pobs->kx + pobs->ky * pobs->ky + pobs->kz * pobs->kz;
+    double r = sqrt(*r2);
+    pobs->kx = pobs->kx / r; pobs->ky = pobs->ky / r; pobs->kz = pobs->kz / r;
+    const double *m = o->rm;
+    double kx = m[0] * pobs->kx + m[1] * pobs->ky + m[2] * pobs->kz, ky = m[3] * pobs->kx + m[4] * pobs->ky + m[5] * pobs->kz, kz = m[6] * pobs->kx + m[7] * pobs->ky + m[8] * pobs->kz;
+    *ix = (int)floor(atan2(-kx, kz) * RAD2DEG / dxim + nxim / 2.0) + 1;
+    *iy = (int)floor(atan2(-ky, kz) * RAD2DEG / dyim + nyim / 2.0) + 1;
+}
+#define PIX2(s,ix,iy)      ((size_t)((ix)-1) + (size_t)(s)->nxim * (size_t)((iy)-1))
+#define PIX3(s,ixf,ix,iy)  ((size_t)((ixf)-1) + (size_t)(s)->nxfreq * PIX2(s,ix,iy))
+
+/* peeling_direct_outside: peelingoff_rect.f90:24-129 */
+static void peeling_direct(const orc_sim *s, acc_t *A, const photon_t *p) {
+    for (int i = 0; i < s->nobs; i++) {
+        photon_t po; double r2; int ix, iy;
+        obs_dir(&s->obs[i], p, &po, &r2, s->nxim, s->nyim, s->dxim, s->dyim, &ix, &iy);
+        size_t c = IDX(s,p->icell,p->jcell,p->kcell);
+        double xfreq_ref, u1, u2;
+        if (!s->comoving_source) { u1 = udot(s, c, p->kx, p->ky, p->kz); xfreq_ref = p->xfreq + u1; u2 = udot(s, c, po.kx, po.ky, po.kz); po.xfreq = xfreq_ref - u2; }
+        else { u1 = udot(s, c, po.kx, po.ky, po.kz); xfreq_ref = p->xfreq + u1; }
+        xfreq_ref = xfreq_ref * (s->Dfreq[c] / s->Dfreq_ref);
+        int ixf = (int)floor((xfreq_ref - s->xfreq_min) / s->dxfreq) + 1;
+        if (ix >= 1 && ix <= s->nxim && iy >= 1 && iy <= s->nyim) {
+            double tau = raytrace_to_edge(s, &po, s->raytrace_variant, -1.0, &A->n_cellsteps_peel);
+            double wgt0 = 1.0 / (FOURPI * r2) * p->wgt, wgt = exp(-tau) * wgt0;
+            obs_t *o = &A->obs[i];
+            if (s->save_peeloff_2D) { o->direc_2D[PIX2(s,ix,iy)] += wgt; if (s->use_stokes) o->I_2D[PIX2(s,ix,iy)] += wgt; }
+            if (s->save_peeloff_3D && ixf >= 1 && ixf <= s->nxfreq) { o->direc[PIX3(s,ixf,ix,iy)] += wgt; if (s->use_stokes) o->I[PIX3(s,ixf,ix,iy)] += wgt; }
+        }
+    }
+}
+/* peeling_resonance_nostokes_outside: :576-690 */
+static void peeling_resonance_nostokes(const orc_sim *s, acc_t *A, const photon_t *p, double xfreq_atom, const double va[3]) {
+    for (int i = 0; i < s->nobs; i++) {
+        photon_t po; double r2; int ix, iy;
+        obs_dir(&s->obs[i], p, &po, &r2, s->nxim, s->nyim, s->dxim, s->dyim, &ix, &iy);
+        if (!(ix >= 1 && ix <= s->nxim && iy >= 1 && iy <= s->nyim)) continue;
+        double cost = p->kx * po.kx + p->ky * po.ky + p->kz * po.kz, cost2 = cost * cost, sint = sqrt(1.0 - cost2);
+        double rho1 = sqrt(1.0 - p->kz * p->kz) * sint, cosp, sinp, xfreq;
+        if (rho1 == 0.0) { cosp = 1.0; sinp = 0.0; }
+        else { double rho = 1.0 / rho1; cosp = rho * (cost * p->kz - po.kz); sinp = rho * (p->kx * po.ky - po.kx * p->ky); }
+        xfreq = xfreq_atom + (va[0] * cosp + va[1] * sinp) * sint + va[2] * cost;
+        size_t c = IDX(s,p->icell,p->jcell,p->kcell);
+        if (s->recoil) { double g_recoil = s->g_recoil0 / s->Dfreq[c]; xfreq = xfreq - g_recoil * (1.0 - cost); }
+        double u1 = udot(s, c, po.kx, po.ky, po.kz), xfreq_ref = xfreq + u1;
+        xfreq_ref = xfreq_ref * (s->Dfreq[c] / s->Dfreq_ref);
+        int ixf = (int)floor((xfreq_ref - s->xfreq_min) / s->dxfreq) + 1;
+        po.xfreq = xfreq;
+        double tau = raytrace_to_edge(s, &po, s->raytrace_variant, -1.0, &A->n_cellsteps_peel);
+        double peel = 0.75 * p->E1 * (cost2 + 1.0) + p->E2;
+        double wgt = peel / (FOURPI * r2) * exp(-tau) * p->wgt;
+        obs_t *o = &A->obs[i];
+        if (s->save_peeloff_2D) o->scatt_2D[PIX2(s,ix,iy)] += wgt;
+        if (s->save_peeloff_3D && ixf >= 1 && ixf <= s->nxfreq) o->scatt[PIX3(s,ixf,ix,iy)] += wgt;
+    }
+}
+static inline void stokes_deposit(const orc_sim *s, obs_t *o, int ix, int iy, int ixf, double wgt, double Id, double Qd, double Ud, double Vd) {
+    if (s->save_peeloff_2D) { size_t q = PIX2(s,ix,iy);
+        o->scatt_2D[q] += wgt * Id; o->I_2D[q] += wgt * Id; o->Q_2D[q] += wgt * Qd; o->U_2D[q] += wgt * Ud; o->V_2D[q] += wgt * Vd; }
+    if (s->save_peeloff_3D && ixf >= 1 && ixf <= s->nxfreq) { size_t q = PIX3(s,ixf,ix,iy);
+        o->scatt[q] += wgt * Id; o->I[q] += wgt * Id; o->Q[q] += wgt * Qd; o->U[q] += wgt * Ud; o->V[q] += wgt * Vd; }
+}
+/* common geometry of the two Stokes peels (:356-385 / :204-224): azimuth about the (m,n,k) triad and n_obs */
+static inline void stokes_peel_geom(const photon_t *p, photon_t *po, double *cost, double *sint, double *cosp, double *sinp, double *cos2p, double *sin2p) {
+    *cost = p->kx * po->kx + p->ky * po->ky + p->kz * po->kz; *sint = sqrt(1.0 - (*cost) * (*cost));
+    if (*sint == 0.0) { *cosp = 1.0; *sinp = 0.0; *cos2p = 1.0; *sin2p = 0.0; }
+    else { *cosp = (po->kx * p->mx + po->ky * p->my + po->kz * p->mz) / *sint; *sinp = (po->kx * p->nx + po->ky * p->ny + po->kz * p->nz) / *sint;
+           *cos2p = 2.0 * (*cosp) * (*cosp) - 1.0; *sin2p = 2.0 * (*cosp) * (*sinp); }
+    po->nx = -(*sinp) * p->mx + (*cosp) * p->nx; po->ny = -(*sinp) * p->my + (*cosp) * p->ny; po->nz = -(*sinp) * p->mz + (*cosp) * p->nz;
+}
+/* peeling_resonance_stokes_outside: :303-482 */
+static void peeling_resonance_stokes(const orc_sim *s, acc_t *A, const photon_t *p, double xfreq_atom, const double va[3]) {
+    for (int i = 0; i < s->nobs; i++) {
+        photon_t po; double r2; int ix, iy;
+        obs_dir(&s->obs[i], p, &po, &r2, s->nxim, s->nyim, s->dxim, s->dyim, &ix, &iy);
+        if (!(ix >= 1 && ix <= s->nxim && iy >= 1 && iy <= s->nyim)) continue;
+        double cost, sint, cosp, sinp, cos2p, sin2p;
+        stokes_peel_geom(p, &po, &cost, &sint, &cosp, &sinp, &cos2p, &sin2p);
+        double cost2 = cost * cost, S22 = 0.75 * p->E1 * (cost2 + 1.0), S11 = S22 + p->E2, S12 = 0.75 * p->E1 * (cost2 - 1.0), S33 = 1.5 * p->E1 * cost, S44 = 1.5 * p->E3 * cost;
+        double xfreq = xfreq_atom + (va[0] * cosp + va[1] * sinp) * sint + va[2] * cost;
+        size_t c = IDX(s,p->icell,p->jcell,p->kcell);
+        if (s->recoil) { double g_recoil = s->g_recoil0 / s->Dfreq[c]; xfreq = xfreq - g_recoil * (1.0 - cost); }
+        double u1 = udot(s, c, po.kx, po.ky, po.kz), xfreq_ref = (xfreq + u1) * (s->Dfreq[c] / s->Dfreq_ref);
+        int ixf = (int)floor((xfreq_ref - s->xfreq_min) / s->dxfreq) + 1;
+        double Q0 = cos2p * p->Q + sin2p * p->U, U0 = -sin2p * p->Q + cos2p * p->U;
+        double Iobs = (S11 + S12 * Q0) / FOURPI, Qobs = (S12 + S22 * Q0) / FOURPI, Uobs = (S33 * U0) / FOURPI, Vobs = (S44 * p->V) / FOURPI;
+        const double *m = s->obs[i].rm;
+        double cosg = -(m[0] * po.nx + m[1] * po.ny + m[2] * po.nz), sing = m[3] * po.nx + m[4] * po.ny + m[5] * po.nz;
+        double cos2g = 2.0 * cosg * cosg - 1.0, sin2g = 2.0 * cosg * sing;
+        double Idet = Iobs, Qdet = cos2g * Qobs + sin2g * Uobs, Udet = -sin2g * Qobs + cos2g * Uobs, Vdet = Vobs;
+        po.xfreq = xfreq;
+        double tau = raytrace_to_edge(s, &po, s->raytrace_variant, -1.0, &A->n_cellsteps_peel);
+        double wgt = 1.0 / r2 * exp(-tau) * p->wgt;
+        stokes_deposit(s, &A->obs[i], ix, iy, ixf, wgt, Idet, Qdet, Udet, Vdet);
+    }
+}
+/* peeling_dust_nostokes_outside: :484-574 */
+static void peeling_dust_nostokes(const orc_sim *s, acc_t *A, const photon_t *p) {
+    for (int i = 0; i < s->nobs; i++) {
+        photon_t po; double r2; int ix, iy;
+        obs_dir(&s->obs[i], p, &po, &r2, s->nxim, s->nyim, s->dxim, s->dyim, &ix, &iy);
+        if (!(ix >= 1 && ix <= s->nxim && iy >= 1 && iy <= s->nyim)) continue;
+        size_t c = IDX(s,p->icell,p->jcell,p->kcell);
+        double u1 = udot(s, c, po.kx, po.ky, po.kz), xfreq_ref = (p->xfreq + u1) * (s->Dfreq[c] / s->Dfreq_ref);
+        int ixf = (int)floor((xfreq_ref - s->xfreq_min) / s->dxfreq) + 1;
+        double tau = raytrace_to_edge(s, &po, s->raytrace_variant, -1.0, &A->n_cellsteps_peel);
+        double cosa = p->kx * po.kx + p->ky * po.ky + p->kz * po.kz;
+        double peel = (1.0 - s->hgg * s->hgg) / pow((1.0 + s->hgg * s->hgg) - 2.0 * s->hgg * cosa, 1.5) / FOURPI;
+        double wgt = peel / r2 * exp(-tau) * p->wgt;
+        obs_t *o = &A->obs[i];
+        if (s->save_peeloff_2D) o->scatt_2D[PIX2(s,ix,iy)] += wgt;
+        if (s->save_peeloff_3D && ixf >= 1 && ixf <= s->nxfreq) o->scatt[PIX3(s,ixf,ix,iy)] += wgt;
+    }
+}
+/* peeling_dust_stokes_outside: :131-299 */
+static void peeling_dust_stokes(const orc_sim *s, acc_t *A, const photon_t *p) {
+    for (int i = 0; i < s->nobs; i++) {
+        photon_t po; double r2; int ix, iy;
+        obs_dir(&s->obs[i], p, &po, &r2, s->nxim, s->nyim, s->dxim, s->dyim, &ix, &iy);
+        size_t c = IDX(s,p->icell,p->jcell,p->kcell);
+        double u1 = udot(s, c, po.kx, po.ky, po.kz), xfreq_ref = (p->xfreq + u1) * (s->Dfreq[c] / s->Dfreq_ref);
+        int ixf = (int)floor((xfreq_ref - s->xfreq_min) / s->dxfreq) + 1;
+        if (!(ix >= 1 && ix <= s->nxim && iy >= 1 && iy <= s->nyim)) continue;
+        double cost, sint, cosp, sinp, cos2p, sin2p;
+        stokes_peel_geom(p, &po, &cost, &sint, &cosp, &sinp, &cos2p, &sin2p);
+        double S11 = interp_eq(s->nPDF, s->coss, s->S11, cost), S12 = interp_eq(s->nPDF, s->coss, s->S12, cost);
+        double S33 = interp_eq(s->nPDF, s->coss, s->S33, cost), S34 = interp_eq(s->nPDF, s->coss, s->S34, cost);
+        double Q0 = cos2p * p->Q + sin2p * p->U, U0 = -sin2p * p->Q + cos2p * p->U;
+        double Iobs = (S11 * p->I + S12 * Q0) / TWOPI, Qobs = (S12 * p->I + S11 * Q0) / TWOPI;
+        double Uobs = (S33 * U0 + S34 * p->V) / TWOPI, Vobs = (-S34 * U0 + S33 * p->V) / TWOPI;
+        const double *m = s->obs[i].rm;
+        double cosg = -(m[0] * po.nx + m[1] * po.ny + m[2] * po.nz), sing = m[3] * po.nx + m[4] * po.ny + m[5] * po.nz;
+        double cos2g = 2.0 * cosg * cosg - 1.0, sin2g = 2.0 * cosg * sing;
+        double Idet = Iobs, Qdet = cos2g * Qobs + sin2g * Uobs, Udet = -sin2g * Qobs + cos2g * Uobs, Vdet = Vobs;
+        double tau = raytrace_to_edge(s, &po, s->raytrace_variant, -1.0, &A->n_cellsteps_peel);
+        double wgt = 1.0 / r2 * exp(-tau) * p->wgt;
+        stokes_deposit(s, &A->obs[i], ix, iy, ixf, wgt, Idet, Qdet, Udet, Vdet);
+    }
+}
+
+/* =====================================================================================
+ * Scattering: scattering_car.f90
+ * ===================================================================================== */
+/* do_resonance1: line_mod.f90:108-139 */
+static void do_resonance1(const orc_sim *s, rng_t *g, photon_t *p, double *uz, double *xfreq_atom, double *cost, double *sint,
+                          double *S11, double *S22, double *S12, double *S33, double *S44) {
+    *uz = rand_resonance_vz(g, p->xfreq, s->voigt_a[IDX(s,p->icell,p->jcell,p->kcell)]);
+    *xfreq_atom = p->xfreq - *uz;
+    p->E1 = s->E1; p->E2 = s->E2; p->E3 = s->E3;
+    *cost = rand_resonance(g, p->E1);
+    double cost2 = (*cost) * (*cost);
+    *sint = sqrt(1.0 - cost2);
+    if (S44) { *S22 = 0.75 * p->E1 * (cost2 + 1.0); *S11 = *S22 + p->E2; *S12 = 0.75 * p->E1 * (cost2 - 1.0); *S33 = 1.5 * p->E1 * (*cost); *S44 = 1.5 * p->E3 * (*cost); }
+}
+/* direction update about the old k: scattering_car.f90:795-809 (also :568-582) */
+static inline void rotate_k(photon_t *p, double cost, double sint, double cosp, double sinp) {
+    if (fabs(p->kz) >= 0.99999999999) { p->kx = sint * cosp; p->ky = sint * sinp; p->kz = cost; }
+    else { double kx1 = p->kx, ky1 = p->ky, kz1 = p->kz, kr = sqrt(kx1 * kx1 + ky1 * ky1);
+        p->kx = cost * kx1 + sint * (kz1 * kx1 * cosp - ky1 * sinp) / kr;
+        p->ky = cost * ky1 + sint * (kz1 * ky1 * cosp + kx1 * sinp) / kr;
+        p->kz = cost * kz1 - sint * cosp * kr; }
+}
+/* triad rotation, fixed order ("Do not change the calculation order"): :470-484 and :315-328 */
+static inline void rotate_triad(photon_t *p, double cost, double sint, double cosp, double sinp) {
+    double px = cosp * p->mx + sinp * p->nx, py = cosp * p->my + sinp * p->ny, pz = cosp * p->mz + sinp * p->nz;
+    p->nx = cosp * p->nx - sinp * p->mx; p->ny = cosp * p->ny - sinp * p->my; p->nz = cosp * p->nz - sinp * p->mz;
+    p->mx = cost * px - sint * p->kx; p->my = cost * py - sint * p->ky; p->mz = cost * pz - sint * p->kz;
+    p->kx = sint * px + cost * p->kx; p->ky = sint * py + cost * p->ky; p->kz = sint * pz + cost * p->kz;
+}
+/* perpendicular atom velocity: core-skip branch :733-737, plain :749-752 */
+static inline void perp_velocity_rayleigh(const orc_sim *s, rng_t *g, const photon_t *p, double *ux, double *uy) {
+    double xc = 0.0, xc2 = 0.0, phi2, uxy;
+    if (s->core_skip) car_xcrit_local(s, p->icell, p->jcell, p->kcell, p->x, p->y, p->z, &xc, &xc2);
+    if (s->core_skip && fabs(p->xfreq) < xc) { phi2 = TWOPI * rnd(g); uxy = sqrt(xc2 - log(rnd(g))); }
+    else                                     { phi2 = TWOPI * rnd(g); uxy = sqrt(-log(rnd(g))); }
+    *ux = uxy * cos(phi2); *uy = uxy * sin(phi2);
+}
+/* scatter_resonance_nostokes: :660-827 */
+static void scatter_resonance_nostokes(const orc_sim *s, acc_t *A, rng_t *g, photon_t *p) {
+    double uz, xfreq_atom, cost, sint, ux, uy;
+    p->nscatt_gas = p->nscatt_gas + p->wgt;
+    do_resonance1(s, g, p, &uz, &xfreq_atom, &cost, &sint, 0, 0, 0, 0, 0);
+    double phi = TWOPI * rnd(g), cosp = cos(phi), sinp = sin(phi);
+    perp_velocity_rayleigh(s, g, p, &ux, &uy);
+    p->xfreq = xfreq_atom + uz * cost + (ux * cosp + uy * sinp) * sint;
+    if (s->recoil) { double g_recoil = s->g_recoil0 / s->Dfreq[IDX(s,p->icell,p->jcell,p->kcell)]; p->xfreq = p->xfreq - g_recoil * (1.0 - cost); }
+    if (s->save_peeloff) { double va[3] = {ux, uy, uz}; peeling_resonance_nostokes(s, A, p, xfreq_atom, va); }
+    rotate_k(p, cost, sint, cosp, sinp);
+}
+/* azimuth by rejection on 1 + S12/S11 (Q cos2phi + U sin2phi): :364-371 and :281-288 */
+static inline double phi_rejection(rng_t *g, const photon_t *p, double S12overS11) {
+    for (;;) {
+        double phi = TWOPI * rnd(g), phi1 = 2.0 * phi;
+        double Prand = (1.0 + fabs(S12overS11) * sqrt(p->Q * p->Q + p->U * p->U)) * rnd(g);
+        double Pcomp = 1.0 + S12overS11 * (p->Q * cos(phi1) + p->U * sin(phi1));
+        if (Prand <= Pcomp) return phi;
+    }
+}
+/* scatter_resonance_stokes: :331-486 */
+static void scatter_resonance_stokes(const orc_sim *s, acc_t *A, rng_t *g, photon_t *p) {
+    double uz, xfreq_atom, cost, sint, S11, S22, S12, S33, S44, ux, uy;
+    p->nscatt_gas = p->nscatt_gas + p->wgt;
+    do_resonance1(s, g, p, &uz, &xfreq_atom, &cost, &sint, &S11, &S22, &S12, &S33, &S44);
+    double phi = phi_rejection(g, p, S12 / S11), cosp = cos(phi), sinp = sin(phi);
+    double xc = 0.0, xc2 = 0.0;
+    if (s->core_skip) car_xcrit_local(s, p->icell, p->jcell, p->kcell, p->x, p->y, p->z, &xc, &xc2);
+    if (s->core_skip && fabs(p->xfreq) < xc) { double phi2 = TWOPI * rnd(g), uxy = sqrt(xc2 - log(rnd(g))); ux = uxy * cos(phi2); uy = uxy * sin(phi2); }
+    else {                                                                            /* :413-414 two gaussians / sqrt2 */
+        if (g->kind == 0) { ux = rand_gauss(g) * (1.0 / sqrt(2.0)); uy = rand_gauss(g) * (1.0 / sqrt(2.0)); }
+        else { double g2, g1 = gauss_pair(g, &g2); ux = g1 * (1.0 / sqrt(2.0)); uy = g2 * (1.0 / sqrt(2.0)); }
+    }
+    p->xfreq = xfreq_atom + uz * cost + (ux * cosp + uy * sinp) * sint;
+    if (s->recoil) { double g_recoil = s->g_recoil0 / s->Dfreq[IDX(s,p->icell,p->jcell,p->kcell)]; p->xfreq = p->xfreq - g_recoil * (1.0 - cost); }
+    if (s->save_peeloff) { double va[3] = {ux, uy, uz}; peeling_resonance_stokes(s, A, p, xfreq_atom, va); }
+    double cos2p = 2.0 * cosp * cosp - 1.0, sin2p = 2.0 * sinp * cosp;
+    double Q0 = cos2p * p->Q + sin2p * p->U, U0 = -sin2p * p->Q + cos2p * p->U;
+    double I1 = S11 + S12 * Q0, Q1 = S12 + S22 * Q0, U1 = S33 * U0, V1 = S44 * p->V;
+    p->I = 1.0; p->Q = Q1 / I1; p->U = U1 / I1; p->V = V1 / I1;
+    rotate_triad(p, cost, sint, cosp, sinp);
+}
+/* absorption / reduced weight shared by both dust routines: :504-555 and :217-264. Returns 1 if absorbed */
+static int dust_absorb(const orc_sim *s, acc_t *A, rng_t *g, photon_t *p) {
+    p->nscatt_dust = p->nscatt_dust + p->wgt;
+    size_t c = IDX(s,p->icell,p->jcell,p->kcell);
+    if (!s->use_reduced_wgt) {
+        if (rnd(g) > s->albedo) {
+            if (s->save_Jabs) { double uu1 = udot(s, c, p->kx, p->ky, p->kz), xr = (p->xfreq + uu1) * (s->Dfreq[c] / s->Dfreq_ref);
+                int ix = (int)floor((xr - s->xfreq_min) / s->dxfreq) + 1; if (ix >= 1 && ix <= s->nxfreq) A->Jabs[ix-1] += p->wgt; }
+            p->inside = 0; return 1; }
+    } else {
+        if (s->save_Jabs) { double uu1 = udot(s, c, p->kx, p->ky, p->kz), xr = (p->xfreq + uu1) * (s->Dfreq[c] / s->Dfreq_ref);
+            int ix = (int)floor((xr - s->xfreq_min) / s->dxfreq) + 1; if (ix >= 1 && ix <= s->nxfreq) A->Jabs[ix-1] += p->wgt * (1.0 - s->albedo); }
+        p->wgt = p->wgt * s->albedo;
+    }
+    return 0;
+}
+/* scatter_dust_nostokes: :488-584 */
+static void scatter_dust_nostokes(const orc_sim *s, acc_t *A, rng_t *g, photon_t *p) {
+    if (dust_absorb(s, A, g, p)) return;
+    if (s->save_peeloff) peeling_dust_nostokes(s, A, p);
+    double cost = rand_hg(g, s->hgg), sint = sqrt(1.0 - cost * cost);
+    double phi = TWOPI * rnd(g), cosp = cos(phi), sinp = sin(phi);
+    rotate_k(p, cost, sint, cosp, sinp);
+}
+/* scatter_dust_stokes: :201-329 */
+static void scatter_dust_stokes(const orc_sim *s, acc_t *A, rng_t *g, photon_t *p) {
+    if (dust_absorb(s, A, g, p)) return;
+    if (s->save_peeloff) peeling_dust_stokes(s, A, p);
+    double cost = rand_alias_linear(g, s->nPDF - 1, s->phase_PDF, s->alias, s->coss, s->S11), sint = sqrt(1.0 - cost * cost);
+    double S11 = interp_eq(s->nPDF, s->coss, s->S11, cost), S12 = interp_eq(s->nPDF, s->coss, s->S12, cost);
+    double S33 = interp_eq(s->nPDF, s->coss, s->S33, cost), S34 = interp_eq(s->nPDF, s->coss, s->S34, cost);
+    double phi = phi_rejection(g, p, S12 / S11), cosp = cos(phi), sinp = sin(phi);
+    double cos2p = 2.0 * cosp * cosp - 1.0, sin2p = 2.0 * sinp * cosp;
+    double Q0 = cos2p * p->Q + sin2p * p->U, U0 = -sin2p * p->Q + cos2p * p->U;
+    double I1 = S11 + S12 * Q0, Q1 = S12 + S11 * Q0, U1 = S33 * U0 + S34 * p->V, V1 = -S34 * U0 + S33 * p->V;
+    p->I = 1.0; p->Q = Q1 / I1; p->U = U1 / I1; p->V = V1 / I1;
+    rotate_triad(p, cost, sint, cosp, sinp);
+}
+/* scattering: scattering_car.f90:14-120 (Cartesian branch :106-118) */
+static void scattering(const orc_sim *s, acc_t *A, rng_t *g, photon_t *p) {
+    A->n_events += 1.0;
+    if (s->DGR > 0.0) {
+        size_t c = IDX(s,p->icell,p->jcell,p->kcell);
+        double p_dust = s->rhokapD[c] / (s->rhokap[c] * orc_voigt(p->xfreq, s->voigt_a[c]) + s->rhokapD[c]);
+        if (rnd(g) <= p_dust) { if (s->use_stokes && s->nPDF > 0) scatter_dust_stokes(s, A, g, p); else scatter_dust_nostokes(s, A, g, p); return; }
+    }
+    if (s->use_stokes) scatter_resonance_stokes(s, A, g, p); else scatter_resonance_nostokes(s, A, g, p);
+}
+
+/* =====================================================================================
+ * Photon birth and the photon loop
+ * ===================================================================================== */
+/* setup_isotropic_injection: generate_photon.f90:342-408 */
+static void setup_isotropic_injection(const orc_sim *s, rng_t *g, photon_t *p) {
+    p->wgt = 1.0;
+    if (s->xyz_symmetry) { if (p->x < s->xmin) p->x = -p->x; if (p->y < s->ymin) p->y = -p->y; if (p->z < s->zmin) p->z = -p->z; }
+    double cost = 2.0 * rnd(g) - 1.0, sint = sqrt(1.0 - cost * cost), phi = TWOPI * rnd(g), cosp = cos(phi), sinp = sin(phi);
+    p->kx = sint * cosp; p->ky = sint * sinp; p->kz = cost;
+    p->icell = (int)floor((p->x - s->xmin) / s->dx) + 1; p->jcell = (int)floor((p->y - s->ymin) / s->dy) + 1; p->kcell = (int)floor((p->z - s->zmin) / s->dz) + 1;
+    if (p->kx < 0.0 && p->icell == s->nx + 1) p->icell = s->nx;
+    if (p->ky < 0.0 && p->jcell == s->ny + 1) p->jcell = s->ny;
+    if (p->kz < 0.0 && p->kcell == s->nz + 1) p->kcell = s->nz;
+    if (p->kx > 0.0 && p->icell < 1) p->icell = 1;
+    if (p->ky > 0.0 && p->jcell < 1) p->jcell = 1;
+    if (p->kz > 0.0 && p->kcell < 1) p->kcell = 1;
+    if (s->use_stokes) { p->mx = cost * cosp; p->my = cost * sinp; p->mz = -sint; p->nx = -sinp; p->ny = cosp; p->nz = 0.0; p->I = 1.0; p->Q = 0.0; p->U = 0.0; p->V = 0.0; }
+}
+/* generate_photon: generate_photon.f90:3-339 (point / uniform_sphere sources, voigt / monochromatic spectra) */
+static void generate_photon(const orc_sim *s, acc_t *A, rng_t *g, photon_t *p) {
+    if (s->source_geometry == 1) {                                                   /* :34-42 */
+        double rp = pow(rnd(g), 1.0 / 3.0) * s->source_rmax, cost = 2.0 * rnd(g) - 1.0, sint = sqrt(1.0 - cost * cost), phi = TWOPI * rnd(g);
+        p->x = rp * sint * cos(phi); p->y = rp * sint * sin(phi); p->z = rp * cost;
+    } else { p->x = s->xs_point; p->y = s->ys_point; p->z = s->zs_point; }             /* :126-131 */
+    setup_isotropic_injection(s, g, p);
+    p->nscatt_gas = 0.0; p->nscatt_dust = 0.0; p->inside = 1; p->xfreq = s->xfreq0;
+    p->E1 = 0.0; p->E2 = 1.0; p->E3 = 2.0 / 3.0;                                       /* photon_type defaults, define.f90:108-110 */
+    size_t c = IDX(s,p->icell,p->jcell,p->kcell);
+    if (s->spectral_type == 1) p->xfreq = p->xfreq + rand_voigt(g, s->voigt_a[c]);     /* :252-253 */
+    double u1;
+    if (!s->comoving_source) { u1 = udot(s, c, p->kx, p->ky, p->kz); p->xfreq = p->xfreq - u1; }   /* :303-306 */
+    if (s->save_Jin) {                                                               /* :309-322 */
+        u1 = udot(s, c, p->kx, p->ky, p->kz);
+        double xlab = (p->xfreq + u1) * (s->Dfreq[c] / s->Dfreq_ref);
+        int ix = (int)floor((xlab - s->xfreq_min) / s->dxfreq) + 1;
+        if (ix >= 1 && ix <= s->nxfreq) A->Jin[ix-1] += p->wgt;
+    }
+    if (s->save_peeloff) peeling_direct(s, A, p);                                      /* :334-336 */
+}
+/* add_escaped_fraction_to_Jout: run_simulation_mod.f90:208-247 */
+static void add_escaped_fraction_to_Jout(const orc_sim *s, acc_t *A, const photon_t *p, double tau0) {
+    double wgt_esc = p->wgt * exp(-tau0);
+    size_t c = IDX(s,p->icell,p->jcell,p->kcell);
+    double u1 = udot(s, c, p->kx, p->ky, p->kz), xr = (p->xfreq + u1) * (s->Dfreq[c] / s->Dfreq_ref);
+    int ix = (int)floor((xr - s->xfreq_min) / s->dxfreq) + 1;
+    if (ix >= 1 && ix <= s->nxfreq) { A->Jout[ix-1] += wgt_esc;
+        if (s->save_Jmu) { double mu = p->kz; if (s->xyz_symmetry) mu = fabs(mu);
+            int imu = (int)floor((mu - s->mu_min) / s->dmu) + 1; if (imu < 1) imu = 1; if (imu > s->nmu) imu = s->nmu;
+            A->Jmu[(size_t)(ix - 1) + (size_t)s->nxfreq * (imu - 1)] += wgt_esc; } }
+}
+/* one photon: run_equal_number body, run_simulation_mod.f90:155-192 */
+static void run_photon(const orc_sim *s, acc_t *A, rng_t *g, photon_t *p) {
+    generate_photon(s, A, g, p);
+    int first = 1; double tau, tau0, wgt1;
+    while (p->inside) {
+        if (first) {
+            tau0 = raytrace_to_edge(s, p, s->raytrace_variant, -1.0, &A->n_cellsteps);
+            add_escaped_fraction_to_Jout(s, A, p, tau0);
+            wgt1 = 1.0 - exp(-tau0);
+            p->wgt = p->wgt * wgt1;
+            if (tau0 > 0.0) tau = -log(1.0 - rnd(g) * wgt1); else tau = HUGEST;
+            first = 0;
+        } else tau = -log(rnd(g));
+        raytrace_to_tau(s, A, p, tau, s->raytrace_variant);
+        if (p->inside) scattering(s, A, g, p);
+    }
+    A->nscatt_gas += p->nscatt_gas; A->nscatt_dust += p->nscatt_dust;
+}
+
+static void acc_alloc(acc_t *A, orc_sim *s) {
+    memset(A, 0, sizeof *A); A->s = s;
+    A->Jout = calloc(s->nxfreq, 8); A->Jin = calloc(s->nxfreq, 8); A->Jabs = calloc(s->nxfreq, 8); A->Jmu = calloc((size_t)s->nxfreq * (s->nmu > 0 ? s->nmu : 1), 8);
+    size_t n2 = (size_t)s->nxim * s->nyim, n3 = n2 * s->nxfreq;
+    for (int i = 0; i < s->nobs; i++) { obs_t *o = &A->obs[i], *q = &s->obs[i];
+        if (q->scatt_2D) { o->scatt_2D = calloc(n2, 8); o->direc_2D = calloc(n2, 8); }
+        if (q->I_2D) { o->I_2D = calloc(n2, 8); o->Q_2D = calloc(n2, 8); o->U_2D = calloc(n2, 8); o->V_2D = calloc(n2, 8); }
+        if (q->scatt) { o->scatt = calloc(n3, 8); o->direc = calloc(n3, 8); }
+        if (q->I) { o->I = calloc(n3, 8); o->Q = calloc(n3, 8); o->U = calloc(n3, 8); o->V = calloc(n3, 8); } }
+}
+static void addv(double *dst, const double *src, size_t n) { if (dst && src) for (size_t i = 0; i < n; i++) dst[i] += src[i]; }
+static void acc_merge_free(acc_t *A, orc_sim *s) {
+    addv(s->Jout, A->Jout, s->nxfreq); addv(s->Jin, A->Jin, s->nxfreq); addv(s->Jabs, A->Jabs, s->nxfreq); addv(s->Jmu, A->Jmu, (size_t)s->nxfreq * (s->nmu > 0 ? s->nmu : 1));
+    size_t n2 = (size_t)s->nxim * s->nyim, n3 = n2 * s->nxfreq;
+    for (int i = 0; i < s->nobs; i++) { obs_t *o = &A->obs[i], *q = &s->obs[i];
+        addv(q->scatt_2D, o->scatt_2D, n2); addv(q->direc_2D, o->direc_2D, n2); addv(q->I_2D, o->I_2D, n2); addv(q->Q_2D, o->Q_2D, n2); addv(q->U_2D, o->U_2D, n2); addv(q->V_2D, o->V_2D, n2);
+        addv(q->scatt, o->scatt, n3); addv(q->direc, o->direc, n3); addv(q->I, o->I, n3); addv(q->Q, o->Q, n3); addv(q->U, o->U, n3); addv(q->V, o->V, n3);
+        free_obs(o); }
+    s->nscatt_gas += A->nscatt_gas; s->nscatt_dust += A->nscatt_dust;
+    s->n_cellsteps += A->n_cellsteps; s->n_cellsteps_peel += A->n_cellsteps_peel; s->n_events += A->n_events;
+    free(A->Jout); free(A->Jin); free(A->Jabs); free(A->Jmu);
+}
+
+int orc_run(orc_sim *s, int64_t first_id, int64_t stride, int64_t count, int rng_kind, uint64_t seed, int nthreads) {
+    if (nthreads < 1) nthreads = 1;
+    free(s->log_nscatt); free(s->log_xfreq);
+    s->log_n = count; s->log_nscatt = calloc(count > 0 ? count : 1, 8); s->log_xfreq = calloc(count > 0 ? count : 1, 8);
+    acc_t *accs = malloc(nthreads * sizeof(acc_t));
+    for (int t = 0; t < nthreads; t++) acc_alloc(&accs[t], s);
+#ifdef _OPENMP
+#pragma omp parallel num_threads(nthreads)
+#endif
+    {
+        int tid = 0;
+#ifdef _OPENMP
+        tid = omp_get_thread_num();
+#endif
+        acc_t *A = &accs[tid]; rng_t g; mt_t mt; photon_t p;
+        if (rng_kind == 0) {   /* static interleave over workers, seed + 9999*worker: run_simulation_mod.f90:150-151, random_mt.f90:940-953 */
+            memset(&g, 0, sizeof g); g.kind = 0; g.mt = &mt; mt_init(&mt, (int64_t)(int32_t)((int32_t)seed + 9999 * tid));
+            for (int64_t k = tid; k < count; k += nthreads) { memset(&p, 0, sizeof p); p.id = (double)(first_id + k * stride);
+                run_photon(s, A, &g, &p); s->log_nscatt[k] = p.nscatt_gas + p.nscatt_dust; s->log_xfreq[k] = p.xfreq_ref; }
+        } else {
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1)
+#endif
+            for (int64_t k = 0; k < count; k++) { memset(&p, 0, sizeof p); uint64_t id = (uint64_t)(first_id + k * stride); p.id = (double)id;
+                rng_philox(&g, seed, id, 0); run_photon(s, A, &g, &p); s->log_nscatt[k] = p.nscatt_gas + p.nscatt_dust; s->log_xfreq[k] = p.xfreq_ref; }
+        }
+    }
+    for (int t = 0; t < nthreads; t++) acc_merge_free(&accs[t], s);
+    free(accs);
+    s->nphotons_done += count;
+    return 0;
+}
+int64_t orc_get_photon_log(const orc_sim *s, double *nscatt, double *xfreq_out, int64_t n) {
+    int64_t m = s->log_n < n ? s->log_n : n;
+    for (int64_t i = 0; i < m; i++) { if (nscatt) nscatt[i] = s->log_nscatt[i]; if (xfreq_out) xfreq_out[i] = s->log_xfreq[i]; }
+    return s->log_n;
+}
+
+void orc_zero_tallies(orc_sim *s) {
+    memset(s->Jout, 0, s->nxfreq * 8); memset(s->Jin, 0, s->nxfreq * 8); memset(s->Jabs, 0, s->nxfreq * 8); memset(s->Jmu, 0, (size_t)s->nxfreq * (s->nmu > 0 ? s->nmu : 1) * 8);
+    size_t n2 = (size_t)s->nxim * s->nyim, n3 = n2 * s->nxfreq;
+    for (int i = 0; i < s->nobs; i++) { obs_t *o = &s->obs[i];
+        double *a2[6] = {o->scatt_2D, o->direc_2D, o->I_2D, o->Q_2D, o->U_2D, o->V_2D}, *a3[6] = {o->scatt, o->direc, o->I, o->Q, o->U, o->V};
+        for (int k = 0; k < 6; k++) { if (a2[k]) memset(a2[k], 0, n2 * 8); if (a3[k]) memset(a3[k], 0, n3 * 8); } }
+    s->nscatt_gas = s->nscatt_dust = 0.0; s->nphotons_done = 0; s->n_cellsteps = s->n_cellsteps_peel = s->n_events = 0.0;
+}
+
+/* output_normalize_outside, Jout only: output_sum_rect.f90:185-202 */
+int orc_normalized_Jout(const orc_sim *s, double *out, int n) {
+    double nph = (double)s->nphotons_done, scale;
+    if (s->rmax > 0.0) scale = nph * s->dxfreq * TWOPI * (FOURPI * s->rmax * s->rmax * s->distance2cm * s->distance2cm);
+    else scale = nph * s->dxfreq * TWOPI * 2.0;
+    for (int i = 0; i < n && i < s->nxfreq; i++) out[i] = s->Jout[i] / scale;
+    return s->nxfreq;
+}
+
+double orc_get_scalar(const orc_sim *s, const char *k) {
+#define G(name) if (!strcmp(k, #name)) return (double)s->name;
+    G(nscatt_gas) G(nscatt_dust) G(nphotons_done) G(n_cellsteps) G(n_cellsteps_peel) G(n_events)
+    G(dx) G(dy) G(dz) G(xmin) G(ymin) G(zmin) G(i0) G(j0) G(k0) G(nx) G(ny) G(nz) G(Dfreq_ref) G(xfreq_min) G(xfreq_max) G(dxfreq) G(nxfreq)
+    G(taumax) G(tauhomo) G(N_gasmax) G(N_gashomo) G(voigt_amean) G(atau3) G(nobs) G(dxim) G(dyim) G(distance) G(nxim) G(nyim)
+    G(rmax) G(xmax) G(ymax) G(zmax) G(DGR) G(albedo) G(hgg) G(cext_dust) G(cross0) G(g_recoil0) G(xcrit) G(raytrace_variant) G(save_peeloff)
+    G(use_stokes) G(nPDF) G(save_Jabs) G(nmu) G(mu_min) G(dmu) G(distance2cm) G(source_rmax) G(comoving_source) G(recoil) G(core_skip) G(core_skip_global)
+    G(xyz_symmetry) G(xy_periodic) G(save_Jin) G(save_Jmu) G(use_reduced_wgt) G(xs_point) G(ys_point) G(zs_point) G(xfreq0) G(spectral_type) G(source_geometry)
+    G(save_peeloff_2D) G(save_peeloff_3D) G(E1) G(E2) G(E3)
+#undef G
+    return NAN;
+}
+static int64_t copy_out(const double *src, int64_t cnt, double *out, int64_t n) { if (!src) return -1; for (int64_t i = 0; i < cnt && i < n; i++) out[i] = src[i]; return cnt; }
+int64_t orc_get_array(const orc_sim *s, const char *k, double *out, int64_t n) {
+    int64_t nc = (int64_t)s->nx * s->ny * s->nz;
+    if (!strcmp(k, "Jout")) return copy_out(s->Jout, s->nxfreq, out, n);
+    if (!strcmp(k, "Jin")) return copy_out(s->Jin, s->nxfreq, out, n);
+    if (!strcmp(k, "Jabs")) return copy_out(s->Jabs, s->nxfreq, out, n);
+    if (!strcmp(k, "Jmu")) return copy_out(s->Jmu, (int64_t)s->nxfreq * s->nmu, out, n);
+    if (!strcmp(k, "rhokap")) return copy_out(s->rhokap, nc, out, n);
+    if (!strcmp(k, "voigt_a")) return copy_out(s->voigt_a, nc, out, n);
+    if (!strcmp(k, "Dfreq")) return copy_out(s->Dfreq, nc, out, n);
+    if (!strcmp(k, "vfx")) return copy_out(s->vfx, nc, out, n);
+    if (!strcmp(k, "vfy")) return copy_out(s->vfy, nc, out, n);
+    if (!strcmp(k, "vfz")) return copy_out(s->vfz, nc, out, n);
+    if (!strcmp(k, "rhokapD")) return copy_out(s->rhokapD, nc, out, n);
+    if (!strcmp(k, "xface")) return copy_out(s->xface, s->nx + 1, out, n);
+    if (!strcmp(k, "yface")) return copy_out(s->yface, s->ny + 1, out, n);
+    if (!strcmp(k, "zface")) return copy_out(s->zface, s->nz + 1, out, n);
+    if (!strcmp(k, "coss")) return copy_out(s->coss, s->nPDF, out, n);
+    if (!strcmp(k, "S11")) return copy_out(s->S11, s->nPDF, out, n);
+    if (!strcmp(k, "S12")) return copy_out(s->S12, s->nPDF, out, n);
+    if (!strcmp(k, "S33")) return copy_out(s->S33, s->nPDF, out, n);
+    if (!strcmp(k, "S34")) return copy_out(s->S34, s->nPDF, out, n);
+    if (!strcmp(k, "phase_PDF")) return copy_out(s->phase_PDF, s->nPDF - 1, out, n);
+    if (!strcmp(k, "alias")) { if (!s->alias) return -1; for (int i = 0; i < s->nPDF - 1 && i < n; i++) out[i] = s->alias[i]; return s->nPDF - 1; }
+    if (!strcmp(k, "obs_xyz")) { for (int i = 0; i < s->nobs && 3 * i + 2 < n; i++) { out[3*i] = s->obs[i].x; out[3*i+1] = s->obs[i].y; out[3*i+2] = s->obs[i].z; } return 3 * s->nobs; }
+    if (!strcmp(k, "rmatrix")) { for (int i = 0; i < s->nobs; i++) for (int q = 0; q < 9 && 9 * i + q < n; q++) out[9*i+q] = s->obs[i].rm[q]; return 9 * s->nobs; }
+    const char *col = strchr(k, ':');
+    if (col) { int io = atoi(col + 1); if (io < 0 || io >= s->nobs) return -1; const obs_t *o = &s->obs[io];
+        int64_t n2 = (int64_t)s->nxim * s->nyim, n3 = n2 * s->nxfreq; size_t L = col - k;
+#define M(name, ptr, cnt) if (L == strlen(name) && !strncmp(k, name, L)) return copy_out(ptr, cnt, out, n);
+        M("scatt", o->scatt, n3) M("direc", o->direc, n3) M("I", o->I, n3) M("Q", o->Q, n3) M("U", o->U, n3) M("V", o->V, n3)
+        M("scatt_2D", o->scatt_2D, n2) M("direc_2D", o->direc_2D, n2) M("I_2D", o->I_2D, n2) M("Q_2D", o->Q_2D, n2) M("U_2D", o->U_2D, n2) M("V_2D", o->V_2D, n2)
+#undef M
+    }
+    return -1;
+}
+
+/* =====================================================================================
+ * Function-level entry points
+ * ===================================================================================== */
+static mt_t g_mt; static rng_t g_rng_mt;
+static rng_t *pick_rng(rng_t *tmp, int kind, uint64_t seed, uint64_t stream) {
+    if (kind == 0) { if (seed != UINT64_MAX) { memset(&g_rng_mt, 0, sizeof g_rng_mt); g_rng_mt.mt = &g_mt; mt_init(&g_mt, (int64_t)(int32_t)seed); } return &g_rng_mt; }
+    rng_philox(tmp, seed, stream, 0); return tmp;
+}
+void orc_rand_number_v(int kind, uint64_t seed, uint64_t id, int n, double *u) { rng_t t, *g = pick_rng(&t, kind, seed, id); for (int i = 0; i < n; i++) u[i] = rnd(g); }
+void orc_rand_resonance_vz_v(int kind, uint64_t seed, uint64_t id, int n, double x, double a, double *vz) { rng_t t, *g = pick_rng(&t, kind, seed, id); for (int i = 0; i < n; i++) vz[i] = rand_resonance_vz(g, x, a); }
+void orc_rand_resonance_v(int kind, uint64_t seed, uint64_t id, int n, double E1, double *c) { rng_t t, *g = pick_rng(&t, kind, seed, id); for (int i = 0; i < n; i++) c[i] = rand_resonance(g, E1); }
+void orc_rand_hg_v(int kind, uint64_t seed, uint64_t id, int n, double gg, double *c) { rng_t t, *g = pick_rng(&t, kind, seed, id); for (int i = 0; i < n; i++) c[i] = rand_hg(g, gg); }
+void orc_rand_voigt_v(int kind, uint64_t seed, uint64_t id, int n, double a, double *c) { rng_t t, *g = pick_rng(&t, kind, seed, id); for (int i = 0; i < n; i++) c[i] = rand_voigt(g, a); }
+void orc_rand_gauss_v(int kind, uint64_t seed, uint64_t id, int n, double *c) { rng_t t, *g = pick_rng(&t, kind, seed, id); for (int i = 0; i < n; i++) c[i] = rand_gauss(g); }
+
+static void unpack(const double r[8], const int ic[4], photon_t *p) {
+    memset(p, 0, sizeof *p); p->x = r[0]; p->y = r[1]; p->z = r[2]; p->kx = r[3]; p->ky = r[4]; p->kz = r[5]; p->xfreq = r[6]; p->wgt = r[7];
+    p->icell = ic[0]; p->jcell = ic[1]; p->kcell = ic[2]; p->inside = ic[3];
+}
+void orc_raytrace_to_tau(orc_sim *s, int variant, double r[8], int ic[4], double tau_in) {
+    photon_t p; unpack(r, ic, &p); acc_t A; acc_alloc(&A, s);
+    raytrace_to_tau(s, &A, &p, tau_in, variant);
+    acc_merge_free(&A, s);
+    r[0] = p.x; r[1] = p.y; r[2] = p.z; r[3] = p.kx; r[4] = p.ky; r[5] = p.kz; r[6] = p.xfreq; r[7] = p.wgt;
+    ic[0] = p.icell; ic[1] = p.jcell; ic[2] = p.kcell; ic[3] = p.inside;
+}
+void orc_raytrace_to_edge(const orc_sim *s, int variant, const double r[8], const int ic[4], double *tau) { photon_t p; unpack(r, ic, &p); *tau = raytrace_to_edge(s, &p, variant, -1.0, 0); }
+void orc_raytrace_to_dist(const orc_sim *s, const double r[8], const int ic[4], double dist, double *tau) { photon_t p; unpack(r, ic, &p); *tau = raytrace_to_edge(s, &p, 0, dist, 0); }
+
+int64_t orc_scatter_event(orc_sim *s, double st[18], int ic[4], uint64_t seed, uint64_t id, uint64_t n0) {
+    photon_t p; unpack(st, ic, &p);
+    p.mx = st[8]; p.my = st[9]; p.mz = st[10]; p.nx = st[11]; p.ny = st[12]; p.nz = st[13]; p.I = st[14]; p.Q = st[15]; p.U = st[16]; p.V = st[17];
+    rng_t g; rng_philox(&g, seed, id, n0); acc_t A; acc_alloc(&A, s);
+    scattering(s, &A, &g, &p);
+    acc_merge_free(&A, s);
+    st[0] = p.x; st[1] = p.y; st[2] = p.z; st[3] = p.kx; st[4] = p.ky; st[5] = p.kz; st[6] = p.xfreq; st[7] = p.wgt;
+    st[8] = p.mx; st[9] = p.my; st[10] = p.mz; st[11] = p.nx; st[12] = p.ny; st[13] = p.nz; st[14] = p.I; st[15] = p.Q; st[16] = p.U; st[17] = p.V;
+    ic[0] = p.icell; ic[1] = p.jcell; ic[2] = p.kcell; ic[3] = p.inside;
+    return (int64_t)(g.n - n0);
+}
+
+int64_t orc_set_array(orc_sim *s, const char *k, const double *in, int64_t n) {
+    int64_t nc = (int64_t)s->nx * s->ny * s->nz; double *dst = NULL;
+    if (!strcmp(k, "rhokap")) dst = s->rhokap; else if (!strcmp(k, "voigt_a")) dst = s->voigt_a; else if (!strcmp(k, "Dfreq")) dst = s->Dfreq;
+    else if (!strcmp(k, "vfx")) dst = s->vfx; else if (!strcmp(k, "vfy")) dst = s->vfy; else if (!strcmp(k, "vfz")) dst = s->vfz; else if (!strcmp(k, "rhokapD")) dst = s->rhokapD;
+    if (!dst || n != nc) return -1;
+    memcpy(dst, in, nc * 8); return nc;
+}
+
+/* vec2pix (RING): healpix.f90:29-112 -- restated when the HEALPix observer lands. */
+int orc_vec2pix(int nside, double vx, double vy, double vz) { (void)nside; (void)vx; (void)vy; (void)vz; return -1; }

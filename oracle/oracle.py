@@ -1,0 +1,246 @@
+"""TEST INFRASTRUCTURE: ctypes bindings of oracle/liblart_oracle.so (the CPU restatement) and, when it has
+been built in the container that mounts /root/reference, of oracle/_ref/libref.so (the reference's own
+MPI-free modules).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_d, _i, _u64, _i64, _vp = C.c_double, C.c_int, C.c_uint64, C.c_int64, C.c_void_p
+
+
+def build(ref=True):
+    tgt = ["liblart_oracle.so"]
+    if ref and os.path.exists("/root/reference/src/define.f90"):
+        tgt.append("_ref/libref.so")
+    subprocess.check_call(["make", "-s", "-C", HERE] + tgt)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_vp)
+
+
+class Oracle:
+    _lib = None
+
+    @classmethod
+    def lib(cls):
+        if cls._lib is None:
+            p = os.path.join(HERE, "liblart_oracle.so")
+            if not os.path.exists(p):
+                build(ref=False)
+            L = C.CDLL(p)
+            L.orc_create.restype = _vp; L.orc_create.argtypes = [C.c_char_p]
+            L.orc_destroy.argtypes = [_vp]
+            L.orc_last_error.restype = C.c_char_p
+            L.orc_run.argtypes = [_vp, _i64, _i64, _i64, _i, _u64, _i]; L.orc_run.restype = _i
+            L.orc_get_scalar.restype = _d; L.orc_get_scalar.argtypes = [_vp, C.c_char_p]
+            L.orc_get_array.restype = _i64; L.orc_get_array.argtypes = [_vp, C.c_char_p, _vp, _i64]
+            L.orc_zero_tallies.argtypes = [_vp]
+            L.orc_set_array.restype = _i64; L.orc_set_array.argtypes = [_vp, C.c_char_p, _vp, _i64]
+            L.orc_normalized_Jout.argtypes = [_vp, _vp, _i]
+            L.orc_get_photon_log.restype = _i64; L.orc_get_photon_log.argtypes = [_vp, _vp, _vp, _i64]
+            L.orc_voigt.restype = _d; L.orc_voigt.argtypes = [_d, _d]
+            L.orc_voigt_v.argtypes = [_i, _vp, _vp, _vp]
+            L.orc_line_constants.argtypes = [_vp] * 5
+            L.orc_rand_number_v.argtypes = [_i, _u64, _u64, _i, _vp]
+            L.orc_rand_resonance_vz_v.argtypes = [_i, _u64, _u64, _i, _d, _d, _vp]
+            L.orc_rand_resonance_v.argtypes = [_i, _u64, _u64, _i, _d, _vp]
+            L.orc_rand_hg_v.argtypes = [_i, _u64, _u64, _i, _d, _vp]
+            L.orc_rand_voigt_v.argtypes = [_i, _u64, _u64, _i, _d, _vp]
+            L.orc_rand_gauss_v.argtypes = [_i, _u64, _u64, _i, _vp]
+            L.orc_philox4x32_10.argtypes = [_vp, _vp, _vp]
+            L.orc_raytrace_to_tau.argtypes = [_vp, _i, _vp, _vp, _d]
+            L.orc_raytrace_to_edge.argtypes = [_vp, _i, _vp, _vp, _vp]
+            L.orc_raytrace_to_dist.argtypes = [_vp, _vp, _vp, _d, _vp]
+            L.orc_xcrit_local.restype = _d; L.orc_xcrit_local.argtypes = [_vp, _i, _i, _i, _d, _d, _d]
+            L.orc_scatter_event.restype = _i64; L.orc_scatter_event.argtypes = [_vp, _vp, _vp, _u64, _u64, _u64]
+            cls._lib = L
+        return cls._lib
+
+    def __init__(self, params=None, **kw):
+        L = self.lib()
+        if params is None:
+            params = ""
+        if isinstance(params, dict):
+            kw = {**params, **kw}; params = ""
+        toks = [params] if params else []
+        for k, v in kw.items():
+            if isinstance(v, bool):
+                v = int(v)
+            toks.append("%s=%s" % (k, repr(float(v)) if isinstance(v, float) else v))
+        self.params = " ".join(toks)
+        self.h = L.orc_create(self.params.encode())
+        if not self.h:
+            raise RuntimeError("orc_create failed: " + L.orc_last_error().decode())
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib().orc_destroy(self.h); self.h = None
+
+    def scalar(self, name):
+        return self.lib().orc_get_scalar(self.h, name.encode())
+
+    def array(self, name, shape=None):
+        L = self.lib()
+        n = L.orc_get_array(self.h, name.encode(), None, 0)
+        if n < 0:
+            raise KeyError(name)
+        a = np.zeros(n)
+        L.orc_get_array(self.h, name.encode(), _ptr(a), n)
+        return a.reshape(shape, order="F") if shape else a
+
+    def set_array(self, name, a):
+        a = np.ascontiguousarray(np.asarray(a, dtype=np.float64).ravel(order='F'))
+        if self.lib().orc_set_array(self.h, name.encode(), _ptr(a), a.size) < 0:
+            raise KeyError(name)
+
+    def grid3(self, name):
+        n = [int(self.scalar(k)) for k in ("nx", "ny", "nz")]
+        return self.array(name, tuple(n))
+
+    def run(self, count, first_id=1, stride=1, rng_kind=1, seed=1234, nthreads=None):
+        if nthreads is None:
+            nthreads = os.cpu_count() or 1
+        return self.lib().orc_run(self.h, first_id, stride, int(count), rng_kind, seed, nthreads)
+
+    def zero(self):
+        self.lib().orc_zero_tallies(self.h)
+
+    def normalized_Jout(self):
+        n = int(self.scalar("nxfreq")); a = np.zeros(n)
+        self.lib().orc_normalized_Jout(self.h, _ptr(a), n); return a
+
+    def photon_log(self):
+        L = self.lib(); n = L.orc_get_photon_log(self.h, None, None, 0)
+        a, b = np.zeros(n), np.zeros(n); L.orc_get_photon_log(self.h, _ptr(a), _ptr(b), n); return a, b
+
+    def xfreq_axis(self):
+        n = int(self.scalar("nxfreq"))
+        return (np.arange(n) + 0.5) * self.scalar("dxfreq") + self.scalar("xfreq_min")
+
+    def raytrace_to_tau(self, variant, r, ic, tau):
+        r = np.array(r, dtype=np.float64); ic = np.array(ic, dtype=np.int32)
+        self.lib().orc_raytrace_to_tau(self.h, variant, _ptr(r), _ptr(ic), tau); return r, ic
+
+    def raytrace_to_edge(self, variant, r, ic):
+        r = np.array(r, dtype=np.float64); ic = np.array(ic, dtype=np.int32); t = _d()
+        self.lib().orc_raytrace_to_edge(self.h, variant, _ptr(r), _ptr(ic), C.byref(t)); return t.value
+
+    def raytrace_to_dist(self, r, ic, dist):
+        r = np.array(r, dtype=np.float64); ic = np.array(ic, dtype=np.int32); t = _d()
+        self.lib().orc_raytrace_to_dist(self.h, _ptr(r), _ptr(ic), dist, C.byref(t)); return t.value
+
+    def scatter_event(self, st, ic, seed, pid, n0=0):
+        st = np.array(st, dtype=np.float64); ic = np.array(ic, dtype=np.int32)
+        nd = self.lib().orc_scatter_event(self.h, _ptr(st), _ptr(ic), seed, pid, n0); return st, ic, nd
+
+
+def voigt(x, a):
+    x = np.ascontiguousarray(np.broadcast_to(x, np.broadcast(x, a).shape), dtype=np.float64).ravel()
+    a = np.ascontiguousarray(np.broadcast_to(a, x.shape), dtype=np.float64).ravel()
+    h = np.zeros_like(x); Oracle.lib().orc_voigt_v(len(x), _ptr(x), _ptr(a), _ptr(h)); return h
+
+
+def line_constants():
+    v = [_d() for _ in range(5)]
+    Oracle.lib().orc_line_constants(*[C.byref(t) for t in v]); return [t.value for t in v]
+
+
+def philox(ctr, key):
+    c = np.array(ctr, dtype=np.uint32); k = np.array(key, dtype=np.uint32); o = np.zeros(4, dtype=np.uint32)
+    Oracle.lib().orc_philox4x32_10(_ptr(c), _ptr(k), _ptr(o)); return o
+
+
+def _sampler(fn, kind, seed, stream, n, *args):
+    out = np.zeros(n); getattr(Oracle.lib(), fn)(kind, seed, stream, n, *args, _ptr(out)); return out
+
+
+MT_CONTINUE = 2 ** 64 - 1     # seed value meaning "continue the global MT stream"
+rand_number = lambda kind, seed, stream, n: _sampler("orc_rand_number_v", kind, seed, stream, n)
+rand_resonance_vz = lambda kind, seed, stream, n, x, a: _sampler("orc_rand_resonance_vz_v", kind, seed, stream, n, x, a)
+rand_resonance = lambda kind, seed, stream, n, E1: _sampler("orc_rand_resonance_v", kind, seed, stream, n, E1)
+rand_hg = lambda kind, seed, stream, n, g: _sampler("orc_rand_hg_v", kind, seed, stream, n, g)
+rand_voigt = lambda kind, seed, stream, n, a: _sampler("orc_rand_voigt_v", kind, seed, stream, n, a)
+rand_gauss = lambda kind, seed, stream, n: _sampler("orc_rand_gauss_v", kind, seed, stream, n)
+
+
+class Ref:
+    """oracle/_ref/libref.so -- only exists in the container that mounts /root/reference."""
+    _lib = None
+
+    @classmethod
+    def available(cls):
+        return os.path.exists(os.path.join(HERE, "_ref", "libref.so"))
+
+    @classmethod
+    def lib(cls):
+        if cls._lib is None:
+            L = C.CDLL(os.path.join(HERE, "_ref", "libref.so"))
+            L.ref_voigt.restype = _d; L.ref_voigt.argtypes = [_d, _d]
+            L.ref_voigt_v.argtypes = [_i, _vp, _vp, _vp]
+            L.ref_seed.argtypes = [_i]
+            L.ref_rand_number_v.argtypes = [_i, _vp]
+            L.ref_rand_resonance_vz_v.argtypes = [_i, _d, _d, _vp]
+            L.ref_rand_resonance_v.argtypes = [_i, _d, _vp]
+            L.ref_rand_hg_v.argtypes = [_i, _d, _vp]
+            L.ref_rand_voigt_v.argtypes = [_i, _d, _vp]
+            L.ref_rand_gauss_v.argtypes = [_i, _vp]
+            L.ref_alias_setup.argtypes = [_i, _vp, _vp]
+            L.ref_rand_alias_linear_v.argtypes = [_i, _i, _vp, _vp, _vp, _vp, _vp]
+            L.ref_interp_eq.argtypes = [_i, _vp, _vp, _d, _vp]
+            L.ref_vec2pix.argtypes = [_i, _d, _d, _d, _vp]
+            L.ref_do_resonance1_v.argtypes = [_i, _d, _i, _i, _i, _vp, _vp, _vp, _vp]
+            L.ref_set_par.argtypes = [_d, _i, _i, _i]
+            L.ref_set_grid.argtypes = [_i, _i, _i] + [_d] * 6 + [_i] * 3 + [_d] * 3 + [_i] + [_vp] * 7
+            L.ref_raytrace_to_tau.argtypes = [_i, _vp, _vp, _d]
+            L.ref_raytrace_to_edge.argtypes = [_i, _vp, _vp, _vp]
+            L.ref_raytrace_to_dist.argtypes = [_vp, _vp, _d, _vp]
+            L.ref_get_Jout.argtypes = [_vp]
+            L.ref_get_faces.argtypes = [_vp, _vp, _vp]
+            v = [_d() for _ in range(5)]
+            L.ref_init_line(*[C.byref(t) for t in v])
+            cls.line = [t.value for t in v]
+            cls._lib = L
+        return cls._lib
+
+    @classmethod
+    def voigt(cls, x, a):
+        x = np.ascontiguousarray(x, dtype=np.float64).ravel(); a = np.ascontiguousarray(np.broadcast_to(a, x.shape), dtype=np.float64)
+        h = np.zeros_like(x); cls.lib().ref_voigt_v(len(x), _ptr(x), _ptr(a), _ptr(h)); return h
+
+    @classmethod
+    def seed(cls, s):
+        cls.lib().ref_seed(s)
+
+    @classmethod
+    def draw(cls, fn, n, *args):
+        out = np.zeros(n); getattr(cls.lib(), fn)(n, *args, _ptr(out)); return out
+
+    @classmethod
+    def set_grid_from(cls, o):
+        """load the oracle-built medium into the reference's grid_type"""
+        L = cls.lib()
+        g = lambda k: o.scalar(k)
+        L.ref_set_par(g("DGR"), int(g("save_Jmu")), int(g("nmu")), int(g("xyz_symmetry")))
+        arrs = [np.ascontiguousarray(o.array(k)) for k in ("rhokap", "voigt_a", "Dfreq", "vfx", "vfy", "vfz", "rhokapD")]
+        L.ref_set_grid(int(g("nx")), int(g("ny")), int(g("nz")), g("xmin"), g("ymin"), g("zmin"), g("dx"), g("dy"), g("dz"),
+                       int(g("i0")), int(g("j0")), int(g("k0")), g("Dfreq_ref"), g("xfreq_min"), g("dxfreq"), int(g("nxfreq")),
+                       *[_ptr(a) for a in arrs])
+        cls._keep = arrs
+
+    @classmethod
+    def raytrace_to_tau(cls, variant, r, ic, tau):
+        r = np.array(r, dtype=np.float64); ic = np.array(ic, dtype=np.int32)
+        cls.lib().ref_raytrace_to_tau(variant, _ptr(r), _ptr(ic), tau); return r, ic
+
+    @classmethod
+    def raytrace_to_edge(cls, variant, r, ic):
+        r = np.array(r, dtype=np.float64); ic = np.array(ic, dtype=np.int32); t = _d()
+        cls.lib().ref_raytrace_to_edge(variant, _ptr(r), _ptr(ic), C.byref(t)); return t.value
+
+    @classmethod
+    def raytrace_to_dist(cls, r, ic, dist):
+        r = np.array(r, dtype=np.float64); ic = np.array(ic, dtype=np.int32); t = _d()
+        cls.lib().ref_raytrace_to_dist(_ptr(r), _ptr(ic), dist, C.byref(t)); return t.value

@@ -1,0 +1,329 @@
+!------------------------------------------------------------------------------
+! TEST INFRASTRUCTURE ONLY (never linked into, imported by or shipped with the
+! product path).
+!
+! bind(C) entry points over the reference's OWN compiled modules, built by
+! oracle/Makefile from the sources where they lie under /root/reference/src
+! (define, random_mt [without -DMPI], voigt_mod, mathlib, healpix, line_mod,
+! h2_mod, raytrace_car).  Nothing here restates reference arithmetic: each
+! wrapper only marshals C arguments into the reference's derived types and
+! calls the reference routine.  Used by tools/gen_golden.py to produce the
+! vectors under tests/golden/ and by tests that run in the container where
+! /root/reference is mounted.
+!
+! The rest of LaRT (grid_mod_car, scattering_car, generate_photon, peelingoff_*,
+! run_simulation_mod, ...) needs `use mpi` and cannot be built here without
+! stand-ins, so those routines are pinned through oracle/lart_oracle.c +
+! the known answers in the shipped logs (DESIGN.md, "Oracle").
+!------------------------------------------------------------------------------
+module ref_driver
+  use iso_c_binding
+  use define
+  use random
+  use voigt_mod
+  use mathlib
+  use line_mod
+  use raytrace
+  implicit none
+  type(grid_type), save, target :: g
+contains
+
+  !--- line constants: line_mod.f90:551-1272 (setup_resonance_line), Ly-alpha default
+  subroutine ref_init_line(cross0, vtherm1, damping, wavelength0, g_recoil0) bind(C, name='ref_init_line')
+    real(c_double), intent(out) :: cross0, vtherm1, damping, wavelength0, g_recoil0
+    par%line_id = 'ly_alpha'
+    par%fine_structure = .false.
+    call setup_resonance_line()
+    calc_voigt   => calc_voigt1
+    do_resonance => do_resonance1
+    cross0      = line%cross0
+    vtherm1     = line%vtherm1
+    damping     = line%damping
+    wavelength0 = line%wavelength0
+    g_recoil0   = line%g_recoil0
+  end subroutine ref_init_line
+
+  function ref_voigt(x, a) bind(C, name='ref_voigt') result(h)
+    real(c_double), value :: x, a
+    real(c_double) :: h
+    h = voigt(x, a)
+  end function ref_voigt
+
+  subroutine ref_voigt_v(n, x, a, h) bind(C, name='ref_voigt_v')
+    integer(c_int), value :: n
+    real(c_double), intent(in)  :: x(n), a(n)
+    real(c_double), intent(out) :: h(n)
+    integer :: i
+    do i = 1, n
+       h(i) = voigt(x(i), a(i))
+    enddo
+  end subroutine ref_voigt_v
+
+  !--- RNG: random_mt.f90 init_random_mt_seed (:889-956) / rand_mt (:579-630)
+  subroutine ref_seed(iseed) bind(C, name='ref_seed')
+    integer(c_int), value :: iseed
+    integer :: is
+    is = iseed
+    call init_random_seed(is)
+  end subroutine ref_seed
+
+  subroutine ref_rand_number_v(n, u) bind(C, name='ref_rand_number_v')
+    integer(c_int), value :: n
+    real(c_double), intent(out) :: u(n)
+    integer :: i
+    do i = 1, n
+       u(i) = rand_number()
+    enddo
+  end subroutine ref_rand_number_v
+
+  !--- samplers, n draws each from the current MT state
+  subroutine ref_rand_resonance_vz_v(n, x, a, vz) bind(C, name='ref_rand_resonance_vz_v')
+    integer(c_int), value :: n
+    real(c_double), value :: x, a
+    real(c_double), intent(out) :: vz(n)
+    integer :: i
+    do i = 1, n
+       vz(i) = rand_resonance_vz(x, a)
+    enddo
+  end subroutine ref_rand_resonance_vz_v
+
+  subroutine ref_rand_resonance_v(n, E1, c) bind(C, name='ref_rand_resonance_v')
+    integer(c_int), value :: n
+    real(c_double), value :: E1
+    real(c_double), intent(out) :: c(n)
+    integer :: i
+    do i = 1, n
+       c(i) = rand_resonance(E1)
+    enddo
+  end subroutine ref_rand_resonance_v
+
+  subroutine ref_rand_hg_v(n, gg, c) bind(C, name='ref_rand_hg_v')
+    integer(c_int), value :: n
+    real(c_double), value :: gg
+    real(c_double), intent(out) :: c(n)
+    integer :: i
+    do i = 1, n
+       c(i) = rand_henyey_greenstein(gg)
+    enddo
+  end subroutine ref_rand_hg_v
+
+  subroutine ref_rand_voigt_v(n, a, c) bind(C, name='ref_rand_voigt_v')
+    integer(c_int), value :: n
+    real(c_double), value :: a
+    real(c_double), intent(out) :: c(n)
+    integer :: i
+    do i = 1, n
+       c(i) = rand_voigt(a)
+    enddo
+  end subroutine ref_rand_voigt_v
+
+  subroutine ref_rand_gauss_v(n, c) bind(C, name='ref_rand_gauss_v')
+    integer(c_int), value :: n
+    real(c_double), intent(out) :: c(n)
+    integer :: i
+    do i = 1, n
+       c(i) = rand_gauss()
+    enddo
+  end subroutine ref_rand_gauss_v
+
+  !--- alias tables (random_mt.f90:2016-2238)
+  subroutine ref_alias_setup(n, probs, alias) bind(C, name='ref_alias_setup')
+    integer(c_int), value :: n
+    real(c_double), intent(inout) :: probs(n)
+    integer(c_int), intent(out)   :: alias(n)
+    integer :: al(n)
+    call random_alias_setup(probs, al)
+    alias(:) = al(:)
+  end subroutine ref_alias_setup
+
+  subroutine ref_rand_alias_linear_v(m, n, prob_alias, alias, xaxis, prob, xout) bind(C, name='ref_rand_alias_linear_v')
+    integer(c_int), value :: m, n
+    real(c_double), intent(in) :: prob_alias(n), xaxis(n+1), prob(n+1)
+    integer(c_int), intent(in) :: alias(n)
+    real(c_double), intent(out) :: xout(m)
+    integer :: i, al(n)
+    al(:) = alias(:)
+    do i = 1, m
+       xout(i) = rand_alias_linear(prob_alias, al, xaxis, prob)
+    enddo
+  end subroutine ref_rand_alias_linear_v
+
+  !--- mathlib.f90:71-106
+  subroutine ref_interp_eq(n, x, y, xnew, ynew) bind(C, name='ref_interp_eq')
+    integer(c_int), value :: n
+    real(c_double), intent(in) :: x(n), y(n)
+    real(c_double), value :: xnew
+    real(c_double), intent(out) :: ynew
+    call interp_eq(x, y, xnew, ynew)
+  end subroutine ref_interp_eq
+
+  !--- healpix.f90:29-112
+  subroutine ref_vec2pix(nside, vx, vy, vz, ipix) bind(C, name='ref_vec2pix')
+    use healpix, only: vec2pix
+    integer(c_int), value :: nside
+    real(c_double), value :: vx, vy, vz
+    integer(c_int), intent(out) :: ipix
+    integer :: ip
+    call vec2pix(nside, vx, vy, vz, ip)
+    ipix = ip
+  end subroutine ref_vec2pix
+
+  !--- do_resonance1: line_mod.f90:108-139 (uses grid%voigt_a at the photon cell)
+  subroutine ref_do_resonance1_v(n, xfreq, ic, jc, kc, uz, xatom, cost, sint) bind(C, name='ref_do_resonance1_v')
+    integer(c_int), value :: n, ic, jc, kc
+    real(c_double), value :: xfreq
+    real(c_double), intent(out) :: uz(n), xatom(n), cost(n), sint(n)
+    type(photon_type) :: ph
+    integer :: i
+    do i = 1, n
+       ph%xfreq = xfreq
+       ph%icell = ic; ph%jcell = jc; ph%kcell = kc
+       call do_resonance1(ph, g, uz(i), xatom(i), cost(i), sint(i))
+    enddo
+  end subroutine ref_do_resonance1_v
+
+  !--- switches of par% that the compiled raytrace routines read
+  subroutine ref_set_par(DGR, save_Jmu, nmu, xyz_symmetry) bind(C, name='ref_set_par')
+    real(c_double), value :: DGR
+    integer(c_int), value :: save_Jmu, nmu, xyz_symmetry
+    par%DGR = DGR
+    par%save_Jmu = (save_Jmu /= 0)
+    par%nmu = nmu
+    par%xyz_symmetry = (xyz_symmetry /= 0)
+    if (par%xyz_symmetry) then
+       par%mu_min = 0.0_wp;  par%dmu = 1.0_wp/par%nmu
+    else
+       par%mu_min = -1.0_wp; par%dmu = 2.0_wp/par%nmu
+    endif
+  end subroutine ref_set_par
+
+  !--- fill the reference grid_type from caller arrays (column-major nx,ny,nz)
+  subroutine ref_set_grid(nx, ny, nz, xmin, ymin, zmin, dx, dy, dz, i0, j0, k0, Dfreq_ref, &
+                          xfreq_min, dxfreq, nxfreq, rhokap, voigt_a, Dfreq, vfx, vfy, vfz, rhokapD) &
+                          bind(C, name='ref_set_grid')
+    integer(c_int), value :: nx, ny, nz, i0, j0, k0, nxfreq
+    real(c_double), value :: xmin, ymin, zmin, dx, dy, dz, Dfreq_ref, xfreq_min, dxfreq
+    real(c_double), intent(in) :: rhokap(nx,ny,nz), voigt_a(nx,ny,nz), Dfreq(nx,ny,nz)
+    real(c_double), intent(in) :: vfx(nx,ny,nz), vfy(nx,ny,nz), vfz(nx,ny,nz), rhokapD(nx,ny,nz)
+    integer :: i
+    call ref_free_grid()
+    g%nx = nx; g%ny = ny; g%nz = nz
+    g%i0 = i0; g%j0 = j0; g%k0 = k0
+    g%dx = dx; g%dy = dy; g%dz = dz
+    g%xmin = xmin; g%ymin = ymin; g%zmin = zmin
+    g%xmax = xmin + nx*dx; g%ymax = ymin + ny*dy; g%zmax = zmin + nz*dz
+    g%xrange = g%xmax - g%xmin; g%yrange = g%ymax - g%ymin; g%zrange = g%zmax - g%zmin
+    g%Dfreq_ref = Dfreq_ref
+    g%xfreq_min = xfreq_min; g%dxfreq = dxfreq; g%nxfreq = nxfreq
+    g%xfreq_max = xfreq_min + nxfreq*dxfreq
+    allocate(g%xface(nx+1), g%yface(ny+1), g%zface(nz+1))
+    !-- same expression as grid_mod_car.f90:184-187
+    g%xface(:) = [ ((i-1)*g%dx + g%xmin, i=1,nx+1) ]
+    g%yface(:) = [ ((i-1)*g%dy + g%ymin, i=1,ny+1) ]
+    g%zface(:) = [ ((i-1)*g%dz + g%zmin, i=1,nz+1) ]
+    allocate(g%rhokap(nx,ny,nz), g%voigt_a(nx,ny,nz), g%Dfreq(nx,ny,nz))
+    allocate(g%vfx(nx,ny,nz), g%vfy(nx,ny,nz), g%vfz(nx,ny,nz), g%rhokapD(nx,ny,nz))
+    g%rhokap = rhokap; g%voigt_a = voigt_a; g%Dfreq = Dfreq
+    g%vfx = vfx; g%vfy = vfy; g%vfz = vfz; g%rhokapD = rhokapD
+    allocate(g%Jout(nxfreq)); g%Jout = 0.0_wp
+    allocate(g%Jmu(nxfreq, max(par%nmu,1))); g%Jmu = 0.0_wp
+  end subroutine ref_set_grid
+
+  subroutine ref_free_grid() bind(C, name='ref_free_grid')
+    if (associated(g%xface))   deallocate(g%xface)
+    if (associated(g%yface))   deallocate(g%yface)
+    if (associated(g%zface))   deallocate(g%zface)
+    if (associated(g%rhokap))  deallocate(g%rhokap)
+    if (associated(g%voigt_a)) deallocate(g%voigt_a)
+    if (associated(g%Dfreq))   deallocate(g%Dfreq)
+    if (associated(g%vfx))     deallocate(g%vfx)
+    if (associated(g%vfy))     deallocate(g%vfy)
+    if (associated(g%vfz))     deallocate(g%vfz)
+    if (associated(g%rhokapD)) deallocate(g%rhokapD)
+    if (associated(g%Jout))    deallocate(g%Jout)
+    if (associated(g%Jmu))     deallocate(g%Jmu)
+  end subroutine ref_free_grid
+
+  subroutine ref_get_faces(xf, yf, zf) bind(C, name='ref_get_faces')
+    real(c_double), intent(out) :: xf(g%nx+1), yf(g%ny+1), zf(g%nz+1)
+    xf = g%xface; yf = g%yface; zf = g%zface
+  end subroutine ref_get_faces
+
+  subroutine ref_get_Jout(J) bind(C, name='ref_get_Jout')
+    real(c_double), intent(out) :: J(g%nxfreq)
+    J = g%Jout
+  end subroutine ref_get_Jout
+
+  subroutine ref_zero_Jout() bind(C, name='ref_zero_Jout')
+    g%Jout = 0.0_wp
+    g%Jmu  = 0.0_wp
+  end subroutine ref_zero_Jout
+
+  !--- photon state marshalling: r = [x,y,z,kx,ky,kz,xfreq,wgt], ic = [icell,jcell,kcell,inside]
+  subroutine unpack(r, ic, ph)
+    real(c_double), intent(in) :: r(8)
+    integer(c_int), intent(in) :: ic(4)
+    type(photon_type), intent(out) :: ph
+    ph%x = r(1); ph%y = r(2); ph%z = r(3)
+    ph%kx = r(4); ph%ky = r(5); ph%kz = r(6)
+    ph%xfreq = r(7); ph%wgt = r(8)
+    ph%icell = ic(1); ph%jcell = ic(2); ph%kcell = ic(3)
+    ph%inside = (ic(4) /= 0)
+    ph%iband = 1
+    ph%vfy_shear = 0.0_wp
+  end subroutine unpack
+
+  subroutine pack(ph, r, ic)
+    type(photon_type), intent(in) :: ph
+    real(c_double), intent(out) :: r(8)
+    integer(c_int), intent(out) :: ic(4)
+    r(1) = ph%x; r(2) = ph%y; r(3) = ph%z
+    r(4) = ph%kx; r(5) = ph%ky; r(6) = ph%kz
+    r(7) = ph%xfreq; r(8) = ph%wgt
+    ic(1) = ph%icell; ic(2) = ph%jcell; ic(3) = ph%kcell
+    ic(4) = merge(1, 0, ph%inside)
+  end subroutine pack
+
+  !--- variant: 0 = raytrace_to_tau_car (:1425), 1 = _car_xyzsym (:1650), 2 = _car_zonly (:2519)
+  subroutine ref_raytrace_to_tau(variant, r, ic, tau_in) bind(C, name='ref_raytrace_to_tau')
+    integer(c_int), value :: variant
+    real(c_double), intent(inout) :: r(8)
+    integer(c_int), intent(inout) :: ic(4)
+    real(c_double), value :: tau_in
+    type(photon_type) :: ph
+    call unpack(r, ic, ph)
+    select case (variant)
+    case (0); call raytrace_to_tau_car(ph, g, tau_in)
+    case (1); call raytrace_to_tau_car_xyzsym(ph, g, tau_in)
+    case (2); call raytrace_to_tau_car_zonly(ph, g, tau_in)
+    end select
+    call pack(ph, r, ic)
+  end subroutine ref_raytrace_to_tau
+
+  !--- variant: 0 = raytrace_to_edge_car (:410), 1 = _car_xyzsym (:584), 2 = _car_zonly (:1138)
+  subroutine ref_raytrace_to_edge(variant, r, ic, tau) bind(C, name='ref_raytrace_to_edge')
+    integer(c_int), value :: variant
+    real(c_double), intent(in) :: r(8)
+    integer(c_int), intent(in) :: ic(4)
+    real(c_double), intent(out) :: tau
+    type(photon_type) :: ph
+    call unpack(r, ic, ph)
+    select case (variant)
+    case (0); call raytrace_to_edge_car(ph, g, tau)
+    case (1); call raytrace_to_edge_car_xyzsym(ph, g, tau)
+    case (2); call raytrace_to_edge_car_zonly(ph, g, tau)
+    end select
+  end subroutine ref_raytrace_to_edge
+
+  !--- raytrace_to_dist_car (:89-195)
+  subroutine ref_raytrace_to_dist(r, ic, dist, tau) bind(C, name='ref_raytrace_to_dist')
+    real(c_double), intent(in) :: r(8)
+    integer(c_int), intent(in) :: ic(4)
+    real(c_double), value :: dist
+    real(c_double), intent(out) :: tau
+    type(photon_type) :: ph
+    call unpack(r, ic, ph)
+    call raytrace_to_dist_car(ph, g, dist, tau)
+  end subroutine ref_raytrace_to_dist
+
+end module ref_driver
