@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""bench.py -- scattering events/s of the MI355X photon-packet path on BASELINE.json's headline workload.
+
+Workload (config.workload): examples/sphere/t1tau6.in physics = static uniform sphere, tau0 = 1e6, T = 10 K,
+101^3 cells in the +++ octant (xyz_symmetry), point source, Voigt emission, 201 frequency bins, 1e7 photons
+per GPU ("weak" scaling: each rank owns the photon ids rank+1, rank+1+N, ... of an N x 1e7 photon job, no
+data-path collective; one RCCL sum of the fused tally buffer after the timed region).
+
+A "step" = one transport-kernel launch in which every resident photon lane advances by at most
+--events-per-step scattering events (lanes refill from the photon counter when their packet escapes).
+The timed region holds exactly K steps between barrier + device synchronisation; inputs are resident in HBM.
+value = scattering events executed by all ranks / max-over-ranks wall time.
+
+roofline.achieved = algorithmic bytes of the transport kernel per launch (48 B per cell visited by a flight:
+6 f64 medium gathers; + 16 B per tally atomic) / its average launch duration from HIP
+events on the launch stream.  The kernel is fp64-ALU/latency bound, not HBM bound: the fraction
+is expected to be tiny and is reported as such.
+cpu_baseline = the CPU oracle (a port, oracle/lart_oracle.c) on a bounded sample of the same workload on the
+host cores of this box (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOAD = dict(temperature=10.0, taumax=1.0e6, DGR=0.0, Vexp=0.0, xyz_symmetry=True, comoving_source=False, recoil=False,
+                spectral_type="voigt", nx=101, ny=101, nz=101, nxfreq=201, rmax=1.0, no_photons=1.0e7, iseed=20261003)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--events-per-step", type=int, default=4096)
+    ap.add_argument("--lanes", type=int, default=0, help="resident photon lanes per GPU (0 = library default)")
+    ap.add_argument("--block", type=int, default=0)
+    ap.add_argument("--cpu-photons", type=int, default=0, help="oracle sample size (0 = auto, ~20 s)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        torch.cuda.set_device(local)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(local)
+
+    import __graft_entry__ as ge
+    if not os.path.exists(os.path.join(ROOT, "lart_amd", "csrc", "liblart_gpu.so")):
+        ge.build()
+    from lart_amd import host
+
+    sim = host.Simulation(dict(WORKLOAD), device=local)
+    if a.lanes or a.block:
+        sim.ctx.set_pool(a.lanes, a.block)
+    nph = int(WORKLOAD["no_photons"])
+    # rank r of an (N x 1e7)-photon job: ids r+1, r+1+N, ...   (run_simulation_mod.f90:150-151)
+    sim.ctx.begin(nph, first_id=rank + 1, stride=world, seed=WORKLOAD["iseed"])
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        sim.ctx.step(1, a.events_per_step)
+    sim.ctx.sync()
+    t_a = sim.ctx.tallies()
+    ms_a, nl_a = sim.ctx.kernel_time()
+    barrier()
+    t0 = time.perf_counter()
+    sim.ctx.step(a.steps, a.events_per_step)
+    sim.ctx.sync()
+    barrier()
+    dt = time.perf_counter() - t0
+    t_b = sim.ctx.tallies()
+    ms_b, nl_b = sim.ctx.kernel_time()
+
+    ev = t_b["n_events"] - t_a["n_events"]
+    cells = t_b["n_cellsteps"] - t_a["n_cellsteps"]
+    done = t_b["nphotons_done"] - t_a["nphotons_done"]
+    tot = torch.tensor([ev, cells, float(done), dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        mx = tot.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dt = float(mx[3])
+    ev_all, cells_all, done_all = float(tot[0]), float(tot[1]), float(tot[2])
+
+    # the path's only exchange step: one RCCL sum of the fused tally buffer (output_reduce)
+    t_r0 = time.perf_counter()
+    sim.output_reduce(dist if world > 1 else None)
+    torch.cuda.synchronize()
+    reduce_ms = (time.perf_counter() - t_r0) * 1e3
+    _, ntally = sim.ctx.tally_buffer()
+
+    if rank == 0:
+        launches = max(nl_b - nl_a, 1)
+        k_ms = (ms_b - ms_a) / launches
+        # algorithmic bytes per launch on THIS rank: 48 B per visited cell + 16 B per tally atomic
+        # (Jout escape + forced-first-scatter fraction: 2 per finished photon; scalar counters are per wave)
+        bytes_launch = (48.0 * cells + 16.0 * 2.0 * done) / launches
+        achieved = bytes_launch / (k_ms * 1e-3) / 1e9
+        out = {
+            "metric": "scattering events/sec (whole node), tau0=1e6 sphere",
+            "value": ev_all / dt, "unit": "events/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "examples/sphere/t1tau6.in: static uniform sphere tau0=1e6, T=10K, 101^3 xyz_symmetry octant, "
+                                   "point source, Voigt line, nxfreq=201, 1e7 photons per GPU (BASELINE.json configs[1])",
+                       "events_per_step_per_lane": a.events_per_step, "lanes_per_gpu": sim.ctx.pool_info()[0], "block": sim.ctx.pool_info()[1],
+                       "cells_per_event": cells_all / max(ev_all, 1.0), "photons_finished_in_timed_region": done_all,
+                       "tally_reduce_ms": reduce_ms, "tally_doubles": ntally, "parallelism": "photon-dp%d" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                         "kernel": "transport_kernel<1,false,false,false>", "avg_launch_ms": k_ms,
+                         "algorithmic_bytes_per_launch": bytes_launch,
+                         "note": "fp64 ALU/latency-bound path; see DESIGN.md 'Roofline' for the VALU accounting"},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.cpu_photons)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(nphot):
+    """the CPU oracle (kind 'port') on the first photons of the same workload, all host cores"""
+    from oracle import oracle as O
+    O.build(ref=False)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    kw = {k: v for k, v in WORKLOAD.items() if k not in ("iseed", "no_photons")}
+    o = O.Oracle(**kw)
+    if nphot <= 0:
+        # ~0.5 core-seconds per photon at tau0 = 1e6: aim at ~20 s of wall time
+        nphot = max(cores * 2, int(20.0 * cores / 0.55))
+        nphot = (nphot // cores) * cores
+    t0 = time.perf_counter()
+    o.run(nphot, first_id=1, stride=1, rng_kind=1, seed=WORKLOAD["iseed"], nthreads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": o.scalar("n_events") / dt, "unit": "events/s", "cores": cores, "kind": "port",
+            "sample": "first %d photons (ids 1..%d) of the same workload run to completion by oracle/lart_oracle.c with %d OpenMP threads, %.1f s"
+                      % (nphot, nphot, cores, dt),
+            "mean_scatterings": o.scalar("nscatt_gas") / nphot}
+
+
+if __name__ == "__main__":
+    main()

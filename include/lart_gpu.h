@@ -1,0 +1,124 @@
+/* lart_gpu.h -- C-ABI of the MI355X-native LaRT photon-packet path (liblart_gpu.so).
+ *
+ * Drop-in boundary: the reference crosses into its hot path through the Fortran procedure pointer
+ *     procedure(run_sim), pointer :: run_simulation      (define.f90:832-838, called at main.f90:42)
+ * after grid_create / observer_create have filled the read-only tables, and leaves it through
+ *     output_reduce(grid)                                 (define.f90:897-904, main.f90:46).
+ * The entry points below are what a maintainer binds with ISO_C_BINDING in place of those two calls
+ * (INTEGRATION.md shows the Fortran interface block).  Plain pointers and sizes only; arrays are
+ * borrowed for the duration of the call and copied to the device inside; Fortran column-major order
+ * and 1-based cell indices are kept as the reference stores them.
+ *
+ * Every function returns 0 on success, non-zero on error (lart_gpu_last_error() has the text);
+ * the host prints it and stops, like the reference's "message + MPI_ABORT" convention (setup.f90:132-139).
+ * There is no CPU fallback: without a visible gfx950 device lart_gpu_create() fails.
+ */
+#ifndef LART_GPU_H
+#define LART_GPU_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LART_MAX_OBSERVERS 16
+
+/* Run-time switches and scalars the kernels read.  Field names are the reference's par%/grid%/line%
+ * names (define.f90:209-544, :117-206, :639-680). */
+typedef struct lart_params {
+    /* geometry / boundary variant: selects raytrace_to_{tau,edge}_car | _car_xyzsym | _car_zonly
+     * exactly as setup_procedure does (setup.f90:961-990) */
+    int32_t xyz_symmetry, xy_periodic;
+    /* source: generate_photon.f90:33-132, :243-306 */
+    int32_t source_geometry;       /* 0 'point', 1 'uniform_sphere' */
+    int32_t spectral_type;         /* 0 'monochromatic', 1 'voigt' */
+    int32_t comoving_source;
+    /* scattering physics: scattering_car.f90 */
+    int32_t recoil, core_skip, core_skip_global, use_stokes, use_reduced_wgt;
+    /* tallies */
+    int32_t save_Jin, save_Jabs, save_Jmu, nmu;
+    int32_t save_peeloff, save_peeloff_2D, save_peeloff_3D;
+    int32_t nxfreq;
+    double  xs_point, ys_point, zs_point, source_rmax, xfreq0;
+    double  xfreq_min, dxfreq, Dfreq_ref;          /* grid%xfreq_min, grid%dxfreq, grid%Dfreq_ref */
+    double  DGR, hgg, albedo;
+    double  mu_min, dmu;
+    double  g_recoil0, E1, E2, E3;                 /* line%g_recoil0, line%E1..E3 (line_mod.f90:1255-1270) */
+    double  xcrit, xcrit2;                         /* grid%xcrit, grid%xcrit2 (core_skip_global) */
+} lart_params;
+
+/* Host views of the tallies the path adds into (reference: grid%Jout/Jin/Jabs/Jmu, par%nscatt_*,
+ * observer(:)%scatt/direc/I/Q/U/V and *_2D).  NULL members are skipped. Peel arrays are
+ * [nobs][nyim][nxim][nxfreq] in C order = Fortran (nxfreq,nxim,nyim) per observer. */
+typedef struct lart_tallies {
+    double *Jout, *Jin, *Jabs, *Jmu;                         /* nxfreq, nxfreq, nxfreq, nxfreq*nmu */
+    double *scatt, *direc, *I, *Q, *U, *V;                   /* nobs*nxfreq*nxim*nyim each */
+    double *scatt_2D, *direc_2D, *I_2D, *Q_2D, *U_2D, *V_2D; /* nobs*nxim*nyim each */
+    double nscatt_gas, nscatt_dust;                          /* weight sums over finished photons (par%nscatt_*) */
+    double n_events;                                         /* scattering events executed */
+    double n_cellsteps, n_cellsteps_peel;                    /* cells visited by flight / peel rays (roofline accounting) */
+    int64_t nphotons_done, nphotons_active;
+} lart_tallies;
+
+typedef struct lart_gpu lart_gpu;   /* one context = one GPU */
+
+int  lart_gpu_device_count(void);
+/* replaces the set-up half of setup_procedure + the table hand-over; device = HIP ordinal */
+int  lart_gpu_create(lart_gpu **ctx, const lart_params *par, int device);
+int  lart_gpu_destroy(lart_gpu *ctx);
+const char *lart_gpu_last_error(void);
+
+/* medium: grid_type tables built by grid_create (grid_mod_car.f90:184-203, :273-538).
+ * rhokapD may be NULL when DGR == 0. */
+int  lart_gpu_set_grid_car(lart_gpu *ctx, int32_t nx, int32_t ny, int32_t nz,
+                           double xmin, double ymin, double zmin, double dx, double dy, double dz,
+                           int32_t i0, int32_t j0, int32_t k0,
+                           const double *xface, const double *yface, const double *zface,
+                           const double *rhokap, const double *voigt_a, const double *Dfreq,
+                           const double *vfx, const double *vfy, const double *vfz, const double *rhokapD);
+/* Mueller table as setup_scattering_matrix leaves it (setup.f90:581-649): normalised S11..S34 on the
+ * equispaced coss grid (nPDF points), phase_PDF/alias with nPDF-1 entries (alias 1-based). */
+int  lart_gpu_set_mueller(lart_gpu *ctx, int32_t nPDF, const double *coss, const double *S11, const double *S12,
+                          const double *S33, const double *S34, const double *phase_PDF, const int32_t *alias);
+/* far observers as observer_create_outside leaves them (observer_rect.f90:207-285): xyz[3*nobs],
+ * rmatrix[9*nobs] with rmatrix(r,c) at [9*i + 3*(r-1) + (c-1)] */
+int  lart_gpu_set_observers(lart_gpu *ctx, int32_t nobs, const double *xyz, const double *rmatrix,
+                            double dxim, double dyim, int32_t nxim, int32_t nyim);
+
+/* replaces `call run_simulation(grid)` (main.f90:42): photons first_id, first_id+stride, ... (count of
+ * them; the reference's static decomposition `do ip = rank+1, nphotons, nproc`, run_simulation_mod.f90:150).
+ * The random stream of a photon depends only on (seed, id). Runs to completion. */
+int  lart_gpu_run(lart_gpu *ctx, int64_t first_id, int64_t stride, int64_t count, uint64_t seed);
+
+/* the same in bounded slices (bench / progress printing, cf. par%nprint): begin, then step until done.
+ * One step = one kernel launch in which every resident photon lane advances by at most
+ * max_events scattering events (lanes refill from the photon counter when a packet escapes). */
+int  lart_gpu_begin(lart_gpu *ctx, int64_t first_id, int64_t stride, int64_t count, uint64_t seed);
+int  lart_gpu_step(lart_gpu *ctx, int32_t nsteps, int32_t max_events);
+int  lart_gpu_sync(lart_gpu *ctx, int64_t *nphotons_done, int64_t *nphotons_active);
+/* average device time of the transport kernel launches since begin (HIP events on the launch stream) */
+int  lart_gpu_kernel_time(lart_gpu *ctx, double *total_ms, int64_t *nlaunches);
+/* optional per-photon record (reference: allph%nscatt_gas / xfreq2, run_simulation_mod.f90:249-358):
+ * device keeps nscatt and exit xfreq_ref for photon k = 0..count-1 of the current begin() */
+int  lart_gpu_enable_photon_log(lart_gpu *ctx, int32_t on);
+int  lart_gpu_get_photon_log(lart_gpu *ctx, double *nscatt, double *xfreq_ref, int64_t n);
+/* pool geometry knobs (0 = default): resident photon lanes and threads per workgroup */
+int  lart_gpu_set_pool(lart_gpu *ctx, int64_t nlanes, int32_t block);
+int  lart_gpu_pool_info(lart_gpu *ctx, int64_t *nlanes, int32_t *block);   /* valid after lart_gpu_begin */
+
+/* replaces `call output_reduce(grid)` (main.f90:46): with one process per GPU the fused device tally
+ * buffer is summed across ranks by the caller's RCCL collective (torch.distributed / ncclReduce) on the
+ * pointer returned here, then copied out by lart_gpu_get_tallies. */
+int  lart_gpu_tally_buffer(lart_gpu *ctx, void **device_ptr, int64_t *n_doubles);
+int  lart_gpu_zero_tallies(lart_gpu *ctx);
+int  lart_gpu_get_tallies(lart_gpu *ctx, lart_tallies *out);
+
+/* device-function probes used by the parity tests (each runs a tiny kernel, one lane per element) */
+int  lart_gpu_test_voigt(lart_gpu *ctx, int32_t n, const double *x, const double *a, double *h);
+int  lart_gpu_test_rand(lart_gpu *ctx, int32_t what, uint64_t seed, uint64_t id, int32_t n, double p1, double p2, double *out);
+int  lart_gpu_test_raytrace(lart_gpu *ctx, int32_t mode, int32_t n, double *r8, int32_t *ic4, const double *tau_or_dist, double *tau_out);
+int  lart_gpu_test_scatter(lart_gpu *ctx, int32_t n, double *st18, int32_t *ic4, uint64_t seed, const uint64_t *ids, int64_t *ndraws);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,220 @@
+"""ctypes binding of the C-ABI in include/lart_gpu.h (liblart_gpu.so, built in-tree by lart_amd/csrc/Makefile).
+
+Plumbing only: the product is the shared library.  Loading fails loudly when the library is missing --
+there is no CPU path behind this module.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "liblart_gpu.so")
+
+_d, _i32, _i64, _u64, _vp = C.c_double, C.c_int32, C.c_int64, C.c_uint64, C.c_void_p
+
+
+class LartParams(C.Structure):
+    """struct lart_params (include/lart_gpu.h) -- field names are the reference's par%/grid%/line% names."""
+    _fields_ = [(n, _i32) for n in (
+        "xyz_symmetry", "xy_periodic", "source_geometry", "spectral_type", "comoving_source",
+        "recoil", "core_skip", "core_skip_global", "use_stokes", "use_reduced_wgt",
+        "save_Jin", "save_Jabs", "save_Jmu", "nmu", "save_peeloff", "save_peeloff_2D", "save_peeloff_3D", "nxfreq")] + \
+        [(n, _d) for n in (
+            "xs_point", "ys_point", "zs_point", "source_rmax", "xfreq0", "xfreq_min", "dxfreq", "Dfreq_ref",
+            "DGR", "hgg", "albedo", "mu_min", "dmu", "g_recoil0", "E1", "E2", "E3", "xcrit", "xcrit2")]
+
+
+class LartTallies(C.Structure):
+    _fields_ = [(n, _vp) for n in ("Jout", "Jin", "Jabs", "Jmu", "scatt", "direc", "I", "Q", "U", "V",
+                                   "scatt_2D", "direc_2D", "I_2D", "Q_2D", "U_2D", "V_2D")] + \
+        [(n, _d) for n in ("nscatt_gas", "nscatt_dust", "n_events", "n_cellsteps", "n_cellsteps_peel")] + \
+        [("nphotons_done", _i64), ("nphotons_active", _i64)]
+
+
+SYMBOLS = ["lart_gpu_device_count", "lart_gpu_create", "lart_gpu_destroy", "lart_gpu_last_error",
+           "lart_gpu_set_grid_car", "lart_gpu_set_mueller", "lart_gpu_set_observers", "lart_gpu_run",
+           "lart_gpu_begin", "lart_gpu_step", "lart_gpu_sync", "lart_gpu_kernel_time",
+           "lart_gpu_enable_photon_log", "lart_gpu_get_photon_log", "lart_gpu_set_pool", "lart_gpu_pool_info",
+           "lart_gpu_tally_buffer", "lart_gpu_zero_tallies", "lart_gpu_get_tallies",
+           "lart_gpu_test_voigt", "lart_gpu_test_rand", "lart_gpu_test_raytrace", "lart_gpu_test_scatter"]
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("liblart_gpu.so is not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "or `make -C lart_amd/csrc`; there is no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.lart_gpu_last_error.restype = C.c_char_p
+        L.lart_gpu_create.argtypes = [C.POINTER(_vp), C.POINTER(LartParams), C.c_int]
+        L.lart_gpu_destroy.argtypes = [_vp]
+        L.lart_gpu_set_grid_car.argtypes = [_vp, _i32, _i32, _i32] + [_d] * 6 + [_i32] * 3 + [_vp] * 10
+        L.lart_gpu_set_mueller.argtypes = [_vp, _i32] + [_vp] * 7
+        L.lart_gpu_set_observers.argtypes = [_vp, _i32, _vp, _vp, _d, _d, _i32, _i32]
+        L.lart_gpu_run.argtypes = [_vp, _i64, _i64, _i64, _u64]
+        L.lart_gpu_begin.argtypes = [_vp, _i64, _i64, _i64, _u64]
+        L.lart_gpu_step.argtypes = [_vp, _i32, _i32]
+        L.lart_gpu_sync.argtypes = [_vp, C.POINTER(_i64), C.POINTER(_i64)]
+        L.lart_gpu_kernel_time.argtypes = [_vp, C.POINTER(_d), C.POINTER(_i64)]
+        L.lart_gpu_enable_photon_log.argtypes = [_vp, _i32]
+        L.lart_gpu_get_photon_log.argtypes = [_vp, _vp, _vp, _i64]
+        L.lart_gpu_set_pool.argtypes = [_vp, _i64, _i32]
+        L.lart_gpu_pool_info.argtypes = [_vp, C.POINTER(_i64), C.POINTER(_i32)]
+        L.lart_gpu_tally_buffer.argtypes = [_vp, C.POINTER(_vp), C.POINTER(_i64)]
+        L.lart_gpu_zero_tallies.argtypes = [_vp]
+        L.lart_gpu_get_tallies.argtypes = [_vp, C.POINTER(LartTallies)]
+        L.lart_gpu_test_voigt.argtypes = [_vp, _i32, _vp, _vp, _vp]
+        L.lart_gpu_test_rand.argtypes = [_vp, _i32, _u64, _u64, _i32, _d, _d, _vp]
+        L.lart_gpu_test_raytrace.argtypes = [_vp, _i32, _i32, _vp, _vp, _vp, _vp]
+        L.lart_gpu_test_scatter.argtypes = [_vp, _i32, _vp, _vp, _u64, _vp, _vp]
+        _lib = L
+    return _lib
+
+
+class LartError(RuntimeError):
+    pass
+
+
+def _chk(rc):
+    if rc != 0:
+        raise LartError(lib().lart_gpu_last_error().decode())
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(_vp)
+
+
+def _f64(a):
+    return None if a is None else np.ascontiguousarray(np.asarray(a, dtype=np.float64).ravel(order="F"))
+
+
+class Context:
+    """One GPU.  Thin, argument-for-argument wrapper of the lart_gpu_* entry points."""
+
+    def __init__(self, params: LartParams, device=0):
+        self.h = _vp()
+        self.par = params
+        _chk(lib().lart_gpu_create(C.byref(self.h), C.byref(params), device))
+        self.nobs = self.nxim = self.nyim = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().lart_gpu_destroy(self.h); self.h = None
+
+    __del__ = close
+
+    def set_grid_car(self, nx, ny, nz, xmin, ymin, zmin, dx, dy, dz, i0, j0, k0, xface, yface, zface,
+                     rhokap, voigt_a, Dfreq, vfx, vfy, vfz, rhokapD=None):
+        arrs = [_f64(a) for a in (xface, yface, zface, rhokap, voigt_a, Dfreq, vfx, vfy, vfz, rhokapD)]
+        nc = nx * ny * nz
+        for a, n in zip(arrs, (nx + 1, ny + 1, nz + 1) + (nc,) * 7):
+            if a is not None and a.size != n:
+                raise ValueError("table size %d != %d" % (a.size, n))
+        _chk(lib().lart_gpu_set_grid_car(self.h, nx, ny, nz, xmin, ymin, zmin, dx, dy, dz, i0, j0, k0, *[_p(a) for a in arrs]))
+
+    def set_mueller(self, coss, S11, S12, S33, S34, phase_PDF, alias):
+        n = len(coss)
+        a = [_f64(x) for x in (coss, S11, S12, S33, S34, phase_PDF)]
+        al = np.ascontiguousarray(alias, dtype=np.int32)
+        if a[5].size != n - 1 or al.size != n - 1:
+            raise ValueError("phase_PDF / alias must have nPDF-1 entries")
+        _chk(lib().lart_gpu_set_mueller(self.h, n, *[_p(x) for x in a], _p(al)))
+
+    def set_observers(self, xyz, rmatrix, dxim, dyim, nxim, nyim):
+        xyz = _f64(np.asarray(xyz).reshape(-1)); rm = _f64(np.asarray(rmatrix).reshape(-1))
+        nobs = xyz.size // 3
+        if rm.size != 9 * nobs:
+            raise ValueError("rmatrix must have 9*nobs entries")
+        _chk(lib().lart_gpu_set_observers(self.h, nobs, _p(xyz), _p(rm), dxim, dyim, nxim, nyim))
+        self.nobs, self.nxim, self.nyim = nobs, nxim, nyim
+
+    def set_pool(self, nlanes=0, block=0):
+        _chk(lib().lart_gpu_set_pool(self.h, nlanes, block))
+
+    def pool_info(self):
+        n, b = _i64(), _i32()
+        _chk(lib().lart_gpu_pool_info(self.h, C.byref(n), C.byref(b)))
+        return n.value, b.value
+
+    def enable_photon_log(self, on=True):
+        _chk(lib().lart_gpu_enable_photon_log(self.h, int(on)))
+
+    def run(self, count, first_id=1, stride=1, seed=1234):
+        _chk(lib().lart_gpu_run(self.h, first_id, stride, int(count), seed))
+
+    def begin(self, count, first_id=1, stride=1, seed=1234):
+        _chk(lib().lart_gpu_begin(self.h, first_id, stride, int(count), seed))
+
+    def step(self, nsteps=1, max_events=1024):
+        _chk(lib().lart_gpu_step(self.h, nsteps, max_events))
+
+    def sync(self):
+        d, a = _i64(), _i64()
+        _chk(lib().lart_gpu_sync(self.h, C.byref(d), C.byref(a)))
+        return d.value, a.value
+
+    def kernel_time(self):
+        ms, n = _d(), _i64()
+        _chk(lib().lart_gpu_kernel_time(self.h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def photon_log(self, count):
+        a, b = np.zeros(count), np.zeros(count)
+        _chk(lib().lart_gpu_get_photon_log(self.h, _p(a), _p(b), count))
+        return a, b
+
+    def tally_buffer(self):
+        p, n = _vp(), _i64()
+        _chk(lib().lart_gpu_tally_buffer(self.h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def zero_tallies(self):
+        _chk(lib().lart_gpu_zero_tallies(self.h))
+
+    def tallies(self):
+        """dict of numpy arrays (Fortran shapes) + scalars"""
+        p = self.par
+        nxf, nmu = p.nxfreq, (p.nmu if p.save_Jmu else 0)
+        t = LartTallies()
+        out = {"Jout": np.zeros(nxf), "Jin": np.zeros(nxf), "Jabs": np.zeros(nxf)}
+        if nmu:
+            out["Jmu"] = np.zeros((nxf, nmu), order="F")
+        if p.save_peeloff and self.nobs:
+            names3 = ["scatt", "direc"] + (["I", "Q", "U", "V"] if p.use_stokes else [])
+            if p.save_peeloff_3D:
+                for n in names3:
+                    out[n] = np.zeros((nxf, self.nxim, self.nyim, self.nobs), order="F")
+            if p.save_peeloff_2D:
+                for n in names3:
+                    out[n + "_2D"] = np.zeros((self.nxim, self.nyim, self.nobs), order="F")
+        for k, a in out.items():
+            setattr(t, k, a.ctypes.data)
+        _chk(lib().lart_gpu_get_tallies(self.h, C.byref(t)))
+        for k in ("nscatt_gas", "nscatt_dust", "n_events", "n_cellsteps", "n_cellsteps_peel", "nphotons_done", "nphotons_active"):
+            out[k] = getattr(t, k)
+        return out
+
+    # ---- device-function probes -------------------------------------------------------------
+    def test_voigt(self, x, a):
+        x = _f64(x); a = _f64(np.broadcast_to(a, x.shape)); h = np.zeros_like(x)
+        _chk(lib().lart_gpu_test_voigt(self.h, x.size, _p(x), _p(a), _p(h))); return h
+
+    def test_rand(self, what, seed, pid, n, p1=0.0, p2=0.0):
+        out = np.zeros(n)
+        _chk(lib().lart_gpu_test_rand(self.h, what, seed, pid, n, p1, p2, _p(out))); return out
+
+    def test_raytrace(self, kind, variant, r8, ic4, tq=None):
+        r = np.ascontiguousarray(r8, dtype=np.float64).copy(); ic = np.ascontiguousarray(ic4, dtype=np.int32).copy()
+        n = r.shape[0]; tau = np.zeros(n)
+        q = None if tq is None else np.ascontiguousarray(tq, dtype=np.float64)
+        _chk(lib().lart_gpu_test_raytrace(self.h, 10 * kind + variant, n, _p(r), _p(ic), _p(q), _p(tau)))
+        return r, ic, tau
+
+    def test_scatter(self, st18, ic4, seed, ids):
+        st = np.ascontiguousarray(st18, dtype=np.float64).copy(); ic = np.ascontiguousarray(ic4, dtype=np.int32).copy()
+        ids = np.ascontiguousarray(ids, dtype=np.uint64); nd = np.zeros(st.shape[0], dtype=np.int64)
+        _chk(lib().lart_gpu_test_scatter(self.h, st.shape[0], _p(st), _p(ic), seed, _p(ids), _p(nd)))
+        return st, ic, nd

@@ -1,0 +1,780 @@
+// lart_device.hpp -- CDNA4 (gfx950) device functions of the LaRT photon-packet path.
+//
+// One photon packet per lane, all arithmetic IEEE f64 (reference: wp = real64, define.f90:25-26).
+// Per-lane counter-based RNG (Philox4x32-10 keyed (seed, photon id), counter = draw index) replaces
+// the reference's per-rank MT19937-64 stream (random_mt.f90:579-630) so a packet's history does not
+// depend on which lane / GPU runs it.  Read-only medium = one 64-byte record per cell (one cache
+// line sector per gather); Voigt tables and cell faces live in LDS.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/lart_gpu.h"
+
+#define LART_PI      3.141592653589793238462643383279502884197
+#define LART_TWOPI   6.283185307179586476925286766559005768394
+#define LART_FOURPI  12.56637061435917295385057353311801153679
+#define LART_HALFPI  (LART_PI / 2.0)
+#define LART_RAD2DEG (180.0 / LART_PI)
+#define LART_HUGEST  1.7976931348623157e308
+#define LART_TAU_HUGE 745.2                 // raytrace_car.f90:432 -- exp(-tau_huge) underflows
+
+// ---------------------------------------------------------------------------------------------
+// medium: one record per cell, Fortran (i,j,k) order, 64-byte aligned
+// ---------------------------------------------------------------------------------------------
+struct __attribute__((aligned(64))) Cell {
+    double rhokap, voigt_a, Dfreq, vfx, vfy, vfz, rhokapD, pad;
+};
+
+struct DGrid {
+    int nx, ny, nz, i0, j0, k0;
+    double xmin, ymin, zmin, dx, dy, dz;
+    const Cell *cell;
+    const double *faces;          // xface(nx+1) | yface(ny+1) | zface(nz+1), global copy (staged to LDS)
+};
+
+struct DObs { double x, y, z, rm[9]; };
+
+struct DMueller { int nPDF; const double *coss, *S11, *S12, *S33, *S34, *phase_PDF; const int *alias; };
+
+// fused tally buffer (one RCCL reduce): pointers into it
+struct DTally {
+    double *scal;                 // [0] nscatt_gas [1] nscatt_dust [2] n_events [3] n_cellsteps [4] n_cellsteps_peel [5] nphotons_done
+    double *Jout, *Jin, *Jabs, *Jmu;
+    double *c3[6];                // scatt, direc, I, Q, U, V       (nobs * nxfreq*nxim*nyim)
+    double *c2[6];                // *_2D                            (nobs * nxim*nyim)
+};
+
+// resident photon pool (SoA, coalesced load/store at launch boundaries)
+enum { F_X = 0, F_Y, F_Z, F_KX, F_KY, F_KZ, F_XFREQ, F_WGT, F_NSG, F_NSD,
+       F_MX, F_MY, F_MZ, F_NX, F_NY, F_NZ, F_Q, F_U, F_V, F_COUNT };
+enum { FLAG_ALIVE = 1, FLAG_FIRST = 2 };
+struct DPool {
+    int64_t n;                    // lanes
+    double *f;                    // F_COUNT planes of n doubles
+    unsigned long long *rng_n;    // draw counter
+    long long *k;                 // photon ordinal (id = first_id + k*stride)
+    int *ic, *jc, *kc, *flags;
+};
+
+struct DCtl { unsigned long long next_k; unsigned long long n_active; };
+
+struct KArgs {
+    lart_params par;
+    DGrid g;
+    DTally t;
+    DPool pool;
+    DMueller mu;
+    const DObs *obs; int nobs, nxim, nyim; double dxim, dyim;
+    DCtl *ctl;
+    long long first_id, stride, count;
+    unsigned long long seed;
+    int max_events;
+    double *log_nscatt, *log_xfreq;
+};
+
+// ---------------------------------------------------------------------------------------------
+// LDS image: Voigt tables (606 f64) followed by the three face arrays
+// ---------------------------------------------------------------------------------------------
+static __device__ const double c_voigt_tab[606] = {   // H0(101) | H1(202) | H2(101) | H3(202)
+#include "voigt_tables.inc"
+};
+#define VT_H0 0
+#define VT_H1 101
+#define VT_H2 303
+#define VT_H3 404
+#define VT_END 606
+
+struct Lds { const double *vt; const double *xf, *yf, *zf; };
+
+__device__ inline Lds lds_stage(double *sh, const DGrid &g) {
+    for (int i = threadIdx.x; i < VT_END; i += blockDim.x) sh[i] = c_voigt_tab[i];
+    int nf = g.nx + g.ny + g.nz + 3;
+    for (int i = threadIdx.x; i < nf; i += blockDim.x) sh[VT_END + i] = g.faces[i];
+    __syncthreads();
+    Lds l; l.vt = sh; l.xf = sh + VT_END; l.yf = l.xf + (g.nx + 1); l.zf = l.yf + (g.ny + 1);
+    return l;
+}
+
+// ---------------------------------------------------------------------------------------------
+// RNG
+// ---------------------------------------------------------------------------------------------
+struct Rng {
+    uint32_t k0, k1; uint64_t id, n; double spare;
+    __device__ inline void init(uint64_t seed, uint64_t pid, uint64_t n0) {
+        k0 = (uint32_t)seed; k1 = (uint32_t)(seed >> 32); id = pid; n = n0 & ~1ULL; spare = 0.0;
+        if (n0 & 1ULL) (void)next();
+    }
+    // open-interval uniform: (x>>12 + 0.5) / 2^52  (random_mt.f90:627-629)
+    static __device__ inline double open01(uint32_t lo, uint32_t hi) {
+        uint64_t x = ((uint64_t)hi << 32) | lo;
+        return ((double)(x >> 12) + 0.5) * (1.0 / 4503599627370496.0);
+    }
+    __device__ inline double next() {
+        uint64_t m = n++;
+        if (m & 1ULL) return spare;
+        uint64_t blk = m >> 1;
+        uint32_t c0 = (uint32_t)blk, c1 = (uint32_t)(blk >> 32), c2 = (uint32_t)id, c3 = (uint32_t)(id >> 32);
+        uint32_t a = k0, b = k1;
+#pragma unroll
+        for (int r = 0; r < 10; r++) {
+            uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+            uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+            uint32_t n0 = h1 ^ c1 ^ a, n2 = h0 ^ c3 ^ b;
+            c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+            a += 0x9E3779B9u; b += 0xBB67AE85u;
+        }
+        spare = open01(c2, c3);
+        return open01(c0, c1);
+    }
+    // Marsaglia polar pair (random_mt.f90:964-988); first = v2*rsq (what the reference returns first)
+    __device__ inline double gauss_pair(double &second) {
+        double v1, v2, rsq;
+        do { v1 = 2.0 * next() - 1.0; v2 = 2.0 * next() - 1.0; rsq = v1 * v1 + v2 * v2; } while (!(rsq > 0.0 && rsq < 1.0));
+        rsq = sqrt(-2.0 * log(rsq) / rsq);
+        second = v1 * rsq;
+        return v2 * rsq;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Voigt H(x,a): voigt_mod.f90:541-733 (four regimes on a 0.05 grid)
+// ---------------------------------------------------------------------------------------------
+__device__ inline double voigt_H(const double *vt, double vin, double a) {
+    double v = vin < 0.0 ? -vin : vin;
+    if (v < 1.0) {
+        double vv = v * 20.0; int k = (int)vv;                // k = k1-1
+        double y1 = vt[VT_H0 + k] + a * (vt[VT_H1 + k] + a * vt[VT_H2 + k]);
+        double y2 = vt[VT_H0 + k + 1] + a * (vt[VT_H1 + k + 1] + a * vt[VT_H2 + k + 1]);
+        return y1 + (y2 - y1) * (vv - (double)k);
+    } else if (v < 5.0) {
+        double vv = v * 20.0; int k = (int)vv - 1;            // k = k1-1, k1 = int(vv)
+        double y1 = vt[VT_H0 + k] + a * (vt[VT_H1 + k] + a * (vt[VT_H2 + k] + a * vt[VT_H3 + k]));
+        double y2 = vt[VT_H0 + k + 1] + a * (vt[VT_H1 + k + 1] + a * (vt[VT_H2 + k + 1] + a * vt[VT_H3 + k + 1]));
+        double y3 = vt[VT_H0 + k + 2] + a * (vt[VT_H1 + k + 2] + a * (vt[VT_H2 + k + 2] + a * vt[VT_H3 + k + 2]));
+        double u1 = (double)k, u2 = (double)(k + 1), u3 = (double)(k + 2);
+        return 0.5 * y1 * (vv - u2) * (vv - u3) - y2 * (vv - u1) * (vv - u3) + 0.5 * y3 * (vv - u1) * (vv - u2);
+    } else if (v < 10.0) {
+        double vv = v * 20.0; int k = (int)vv; double a2 = a * a;
+        double y1 = a * (vt[VT_H1 + k] + a2 * vt[VT_H3 + k]);
+        double y2 = a * (vt[VT_H1 + k + 1] + a2 * vt[VT_H3 + k + 1]);
+        return y1 + (y2 - y1) * (vv - (double)k);
+    }
+    double v2 = 1.0 / (v * v);
+    return 0.56418958354775628695 * a * v2 * (1.0 + ((1.5 - a * a) + 3.75 * v2) * v2);
+}
+
+// ---------------------------------------------------------------------------------------------
+// samplers
+// ---------------------------------------------------------------------------------------------
+// atom velocity parallel to k: random_mt.f90:2562-2696 (rand_resonance_vz_seon)
+__device__ inline double rand_resonance_vz(Rng &g, double x0in, double a) {
+    const double xc = 2.414213562373095048801688724209698, two_over_PI = 2.0 / LART_PI;
+    double x0 = fabs(x0in), vz;
+    if (x0 <= 1.0) {
+        for (;;) {
+            vz = x0 + a * tan(LART_PI * (g.next() - 0.5));
+            if (g.next() <= exp(-(vz * vz))) break;
+        }
+        return x0in < 0.0 ? -vz : vz;
+    }
+    double x0sq = x0 * x0, api = a * LART_PI, beta0 = exp(-x0sq / 2.0), h0_two = beta0 / a, h0 = h0_two / 2.0;
+    // comparison function in beta-space: up to three segments [0,beta0) ~ beta/a, [beta0,beta1) = hA, [beta1,1) = hB
+    double dbeta = 0.0, beta1 = beta0, hA = h0, hB, S0 = beta0 * h0, S1 = 0.0, S2;
+    int mode;                                    // 0: single segment (uniform beta, Cb = h2); 1: segmented
+    if (x0 < xc) {
+        dbeta = sqrt(two_over_PI * a * (1.0 - beta0) * beta0 * x0); beta1 = beta0 + dbeta;
+        double pb1 = sqrt(-2.0 * log(beta1));
+        hB = two_over_PI * beta1 * pb1 / (x0sq - pb1 * pb1);
+        S1 = dbeta * h0; S2 = (1.0 - beta1) * hB; mode = 1;
+    } else {
+        double h2 = 0.3861 / (x0sq - 1.373);
+        if (h0_two < h2) { mode = 0; hB = h2; S2 = 1.0; }
+        else if (h0 < h2) { mode = 1; hB = h2; S2 = (1.0 - beta0) * h2; }     // two segments: dbeta = 0
+        else {
+            dbeta = sqrt(two_over_PI * a * (1.0 - beta0) * beta0 * x0); beta1 = beta0 + dbeta;
+            double pb1 = sqrt(-2.0 * log(beta1));
+            double h1 = two_over_PI * beta1 * pb1 / (x0sq - pb1 * pb1);
+            hB = h1 > h2 ? h1 : h2;
+            S1 = dbeta * h0; S2 = (1.0 - beta1) * hB; mode = 1;
+        }
+    }
+    bool two_seg = (mode == 1 && dbeta == 0.0 && !(x0 < xc));
+    double Stot = S0 + S1 + S2, t1, delt;
+    for (;;) {
+        double beta, Cb;
+        if (mode == 0) { beta = g.next(); Cb = hB; }
+        else if (two_seg) {
+            if (g.next() < S0 / Stot) { beta = beta0 * sqrt(g.next()); Cb = beta / a; }
+            else                      { beta = beta0 + (1.0 - beta0) * g.next(); Cb = hB; }
+        } else {
+            double rS = g.next();
+            if (rS < S0 / Stot)             { beta = beta0 * sqrt(g.next()); Cb = beta / a; }
+            else if (rS < 1.0 - S2 / Stot)  { beta = beta0 + dbeta * g.next(); Cb = hA; }
+            else                            { beta = beta1 + (1.0 - beta1) * g.next(); Cb = hB; }
+        }
+        double pb = sqrt(-2.0 * log(beta));
+        double t2 = atan((pb - x0) / a); t1 = atan((-pb - x0) / a); delt = t2 - t1;
+        if (g.next() * Cb < (beta / api) * delt) break;
+    }
+    vz = x0 + a * tan(delt * g.next() + t1);
+    return x0in < 0.0 ? -vz : vz;
+}
+// dipole/isotropic mix scattering angle: random_mt.f90:2974-2993
+__device__ inline double rand_resonance(Rng &g, double E1) {
+    if (E1 > 0.0) {
+        double p2 = sqrt((4.0 - E1) / (3.0 * E1));
+        double Q = (4.0 * g.next() - 2.0) / (E1 * (p2 * p2 * p2));
+        double W = cbrt(Q + sqrt(Q * Q + 1.0));
+        return p2 * (W - 1.0 / W);
+    } else if (E1 < 0.0) {
+        double p2 = sqrt(fabs((4.0 - E1) / (3.0 * E1)));
+        double Q = (4.0 * g.next() - 2.0) / (E1 * (p2 * p2 * p2));
+        return 2.0 * p2 * cos((acos(Q) + LART_FOURPI) / 3.0);
+    }
+    return 2.0 * g.next() - 1.0;
+}
+// Henyey-Greenstein: random_mt.f90:3022-3042
+__device__ inline double rand_hg(Rng &g, double gg) {
+    double x = g.next();
+    if (gg == 0.0) return 2.0 * x - 1.0;
+    double g2 = gg * gg, twog = 2.0 * gg, t = (1.0 - g2) / (1.0 - gg + twog * x);
+    return ((1.0 + g2) - t * t) / twog;
+}
+// Voigt-distributed offset: random_mt.f90:3062-3083
+__device__ inline double rand_voigt(Rng &g, double a) {
+    double c = tan(LART_PI * g.next() - LART_HALFPI), s2;
+    return a * c + g.gauss_pair(s2) * 0.70710678118654752440084436210485;
+}
+// equispaced-grid linear interpolation: mathlib.f90:71-106
+__device__ inline double interp_eq(int n, const double *x, const double *y, double xnew) {
+    double dx = x[1] - x[0];
+    int i = (int)((xnew - x[0]) / dx + 1);
+    if (i <= 0) return y[0];
+    if (i >= n) return y[n - 1];
+    return y[i - 1] + (y[i] - y[i - 1]) * (xnew - x[i - 1]) / dx;
+}
+// alias-table draw with in-bin linear pdf inversion: random_mt.f90:2196-2216
+__device__ inline double rand_alias_linear(Rng &g, const DMueller &m) {
+    int n = m.nPDF - 1;
+    int k = (int)floor(n * g.next()) + 1, idx;
+    if (g.next() < m.phase_PDF[k - 1]) idx = k; else idx = m.alias[k - 1];
+    double p0 = m.S11[idx - 1], p1 = m.S11[idx];
+    return (sqrt(p0 * p0 + (p1 * p1 - p0 * p0) * g.next()) - p0) * (m.coss[idx] - m.coss[idx - 1]) / (p1 - p0) + m.coss[idx - 1];
+}
+
+// ---------------------------------------------------------------------------------------------
+// photon packet (registers)
+// ---------------------------------------------------------------------------------------------
+struct Photon {
+    double x, y, z, kx, ky, kz, xfreq, wgt, nsg, nsd;
+    double mx, my, mz, nx, ny, nz, Q, U, V;
+    int ic, jc, kc; bool inside;
+    double xfreq_ref;
+};
+
+__device__ inline size_t cidx(const DGrid &g, int i, int j, int k) {
+    return (size_t)(i - 1) + (size_t)g.nx * ((size_t)(j - 1) + (size_t)g.ny * (size_t)(k - 1));
+}
+__device__ inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// ---------------------------------------------------------------------------------------------
+// ray marches (Amanatides-Woo DDA): raytrace_car.f90
+//   VAR 0: plain grid            raytrace_to_tau_car :1425-1648, raytrace_to_edge_car :410-508
+//   VAR 1: +++ octant, mirrors   _car_xyzsym :1650-1949 / :584-781
+//   VAR 2: slab, z only          _car_zonly  :2519-2675 / :1138-1234
+// ---------------------------------------------------------------------------------------------
+struct Trav { int ic, jc, kc, is, js, ks; double kx, ky, kz, tx, ty, tz, delx, dely, delz; };
+
+// one axis of setup_traversal_car (:12-87); returns true when the ray leaves the grid at once
+__device__ inline bool axis_setup_plain(int n, const double *face, double d, double xp, int &cell, int &step, double k, double &t, double &del) {
+    if (k > 0.0) {
+        if (cell > n && face[cell - 1] <= xp) return true;
+        step = 1; t = (face[cell] - xp) / k; del = d / k;
+    } else if (k < 0.0) {
+        if (face[cell - 1] == xp) { if (cell > 1) cell -= 1; else return true; }
+        step = -1; t = (face[cell - 1] - xp) / k; del = -d / k;
+    } else { step = 0; t = LART_HUGEST; del = LART_HUGEST; }
+    return false;
+}
+// one axis of the mirror-symmetric set-up (:1691-1721 tau [strict], :631-661 edge)
+__device__ inline bool axis_setup_sym(int n, const double *face, double d, int i0, double xp, bool strict, int &cell, int &step, double &k, double &t, double &del) {
+    if (k > 0.0) {
+        if (cell > n && (strict ? (face[cell - 1] == xp) : (face[cell - 1] <= xp))) return true;
+        step = 1; t = (face[cell] - xp) / k; del = d / k;
+    } else if (k < 0.0) {
+        step = -1; del = -d / k;
+        if (face[cell - 1] == xp) { if (cell > 1) cell -= 1; else { cell = i0; step = 1; k = fabs(k); } }
+        if (step == 1) t = (face[cell] - xp) / k; else t = (face[cell - 1] - xp) / k;
+    } else { step = 0; t = LART_HUGEST; del = LART_HUGEST; }
+    return false;
+}
+// z axis of the slab variants: tau (:2558-2582, strict) / edge (:1182-1201)
+__device__ inline bool axis_setup_z(int n, const double *face, double d, double zp, bool strict, int &cell, int &step, double k, double &t, double &del) {
+    if (k > 0.0) {
+        if (cell > n && (strict ? (face[cell - 1] == zp) : (face[cell - 1] <= zp))) return true;
+        step = 1; t = (face[cell] - zp) / k; del = d / k;
+    } else if (k < 0.0) {
+        if (face[cell - 1] == zp) { if (cell > 1) cell -= 1; else return true; }
+        step = -1; t = (face[cell - 1] - zp) / k; del = -d / k;
+    } else { step = 0; t = LART_HUGEST; del = LART_HUGEST; }
+    return false;
+}
+template <int VAR>
+__device__ inline bool trav_setup(const DGrid &g, const Lds &l, double xp, double yp, double zp, bool strict, Trav &t) {
+    if (VAR == 0) {
+        if (axis_setup_plain(g.nx, l.xf, g.dx, xp, t.ic, t.is, t.kx, t.tx, t.delx)) return true;
+        if (axis_setup_plain(g.ny, l.yf, g.dy, yp, t.jc, t.js, t.ky, t.ty, t.dely)) return true;
+        if (axis_setup_plain(g.nz, l.zf, g.dz, zp, t.kc, t.ks, t.kz, t.tz, t.delz)) return true;
+    } else if (VAR == 1) {
+        if (axis_setup_sym(g.nx, l.xf, g.dx, g.i0, xp, strict, t.ic, t.is, t.kx, t.tx, t.delx)) return true;
+        if (axis_setup_sym(g.ny, l.yf, g.dy, g.j0, yp, strict, t.jc, t.js, t.ky, t.ty, t.dely)) return true;
+        if (axis_setup_sym(g.nz, l.zf, g.dz, g.k0, zp, strict, t.kc, t.ks, t.kz, t.tz, t.delz)) return true;
+    } else {
+        t.is = 0; t.js = 0; t.tx = LART_HUGEST; t.ty = LART_HUGEST; t.delx = LART_HUGEST; t.dely = LART_HUGEST;
+        if (axis_setup_z(g.nz, l.zf, g.dz, zp, strict, t.kc, t.ks, t.kz, t.tz, t.delz)) return true;
+    }
+    return false;
+}
+// advance the traversal across the nearest face (idx as Fortran minloc: first minimum).
+// returns false when the ray left the grid.
+template <int VAR>
+__device__ inline bool trav_cross(const DGrid &g, Trav &t, int idx) {
+    if (idx == 1) {
+        t.ic += t.is;
+        if (VAR == 1 && t.ic < 1) { t.ic = g.i0; t.is = 1; t.kx = -t.kx; }
+        else if (t.ic < 1 || t.ic > g.nx) return false;
+        t.tx += t.delx;
+    } else if (idx == 2) {
+        t.jc += t.js;
+        if (VAR == 1 && t.jc < 1) { t.jc = g.j0; t.js = 1; t.ky = -t.ky; }
+        else if (t.jc < 1 || t.jc > g.ny) return false;
+        t.ty += t.dely;
+    } else {
+        t.kc += t.ks;
+        if (VAR == 1 && t.kc < 1) { t.kc = g.k0; t.ks = 1; t.kz = -t.kz; }
+        else if (t.kc < 1 || t.kc > g.nz) return false;
+        t.tz += t.delz;
+    }
+    return true;
+}
+__device__ inline int minloc3(double a, double b, double c) { int m = 1; double v = a; if (b < v) { m = 2; v = b; } if (c < v) m = 3; return m; }
+
+// tau to the grid edge (dist < 0) or to a finite distance (raytrace_to_dist_car :89-195, VAR 0 only)
+template <int VAR>
+__device__ inline double raytrace_to_edge(const DGrid &g, const Lds &l, bool dust, const Photon &p, double xfreq, double kx, double ky, double kz, double dist, unsigned &nsteps) {
+    Trav t; t.kx = kx; t.ky = ky; t.kz = kz; t.ic = p.ic; t.jc = p.jc; t.kc = p.kc;
+    double tau = 0.0, d = 0.0;
+    if (trav_setup<VAR>(g, l, p.x, p.y, p.z, false, t)) return tau;
+    const Cell *c = &g.cell[cidx(g, t.ic, t.jc, t.kc)];
+    double Dold = c->Dfreq, u1 = c->vfx * t.kx + c->vfy * t.ky + c->vfz * t.kz;
+    double rk = c->rhokap, va = c->voigt_a, rD = c->rhokapD;
+    for (;;) {
+        double rhokap = rk * voigt_H(l.vt, xfreq, va);
+        if (dust) rhokap = rhokap + rD;
+        nsteps++;
+        int idx = (VAR == 2) ? 3 : minloc3(t.tx, t.ty, t.tz);
+        double tt = idx == 1 ? t.tx : (idx == 2 ? t.ty : t.tz);
+        if (dist >= 0.0 && tt >= dist) { tau = tau + (dist - d) * rhokap; break; }
+        tau = tau + (tt - d) * rhokap; d = tt;
+        if (!trav_cross<VAR>(g, t, idx)) break;
+        if (tau >= LART_TAU_HUGE) break;
+        c = &g.cell[cidx(g, t.ic, t.jc, t.kc)];
+        double Dn = c->Dfreq, u2 = c->vfx * t.kx + c->vfy * t.ky + c->vfz * t.kz;
+        xfreq = (xfreq + u1) * Dold / Dn - u2;
+        Dold = Dn; u1 = u2; rk = c->rhokap; va = c->voigt_a; rD = c->rhokapD;
+    }
+    return tau;
+}
+
+__device__ inline void tally_escape(const lart_params &par, const DTally &T, const Photon &p) {
+    int ix = (int)floor((p.xfreq_ref - par.xfreq_min) / par.dxfreq) + 1;
+    if (ix >= 1 && ix <= par.nxfreq) {
+        atomicAdd(&T.Jout[ix - 1], p.wgt);
+        if (par.save_Jmu) {                                   // add_to_Jmu: raytrace_car.f90:4049-4064
+            double mu = p.kz; if (par.xyz_symmetry) mu = fabs(mu);
+            int imu = (int)floor((mu - par.mu_min) / par.dmu) + 1;
+            imu = clampi(imu, 1, par.nmu);
+            atomicAdd(&T.Jmu[(size_t)(ix - 1) + (size_t)par.nxfreq * (imu - 1)], p.wgt);
+        }
+    }
+}
+
+// march to optical depth tau_in; moves the packet, re-expresses xfreq at every crossing, tallies escape
+template <int VAR>
+__device__ inline void raytrace_to_tau(const KArgs &A, const Lds &l, bool dust, Photon &p, double tau_in, unsigned &nsteps) {
+    const DGrid &g = A.g;
+    Trav t; t.kx = p.kx; t.ky = p.ky; t.kz = p.kz; t.ic = p.ic; t.jc = p.jc; t.kc = p.kc;
+    double xp = p.x, yp = p.y, zp = p.z;
+    if (trav_setup<VAR>(g, l, xp, yp, zp, true, t)) { p.inside = false; return; }
+    double tau = 0.0, d = 0.0;
+    const Cell *c = &g.cell[cidx(g, t.ic, t.jc, t.kc)];
+    double Dold = c->Dfreq, u1 = c->vfx * t.kx + c->vfy * t.ky + c->vfz * t.kz;
+    double rk = c->rhokap, va = c->voigt_a, rD = c->rhokapD;
+    double vx = c->vfx, vy = c->vfy, vz = c->vfz;
+    for (;;) {
+        double rhokap = rk * voigt_H(l.vt, p.xfreq, va);
+        if (dust) rhokap = rhokap + rD;
+        nsteps++;
+        int idx = (VAR == 2) ? 3 : minloc3(t.tx, t.ty, t.tz);
+        double tt = idx == 1 ? t.tx : (idx == 2 ? t.ty : t.tz);
+        double del = tt - d;
+        tau = tau + del * rhokap; d = tt;
+        if (tau >= tau_in) {
+            if (rhokap > 0.0) d = d - (tau - tau_in) / rhokap;
+            break;
+        }
+        int io = t.ic, jo = t.jc, ko = t.kc;
+        if (!trav_cross<VAR>(g, t, idx)) { p.inside = false; t.ic = io; t.jc = jo; t.kc = ko; break; }
+        c = &g.cell[cidx(g, t.ic, t.jc, t.kc)];
+        vx = c->vfx; vy = c->vfy; vz = c->vfz;
+        double Dn = c->Dfreq, u2 = vx * t.kx + vy * t.ky + vz * t.kz;
+        p.xfreq = (p.xfreq + u1) * Dold / Dn - u2;
+        Dold = Dn; u1 = u2; rk = c->rhokap; va = c->voigt_a; rD = c->rhokapD;
+    }
+    if (!p.inside) {                                          // :1613-1623 fluid frame -> lab frame, escape tally
+        // (for VAR 1 the mirrored direction components of the last flight segment are used, :1918)
+        u1 = vx * t.kx + vy * t.ky + vz * t.kz;
+        p.xfreq = p.xfreq + u1;
+        p.xfreq_ref = p.xfreq * (Dold / A.par.Dfreq_ref);
+        tally_escape(A.par, A.t, p);
+    }
+    if (VAR == 1) {                                           // :1935-1946 unfolded path, then fold back into the octant
+        p.x = p.x + d * p.kx; p.y = p.y + d * p.ky; p.z = p.z + d * p.kz;
+        if (p.x < g.xmin) p.x = -p.x;
+        if (p.y < g.ymin) p.y = -p.y;
+        if (p.z < g.zmin) p.z = -p.z;
+        p.kx = t.kx; p.ky = t.ky; p.kz = t.kz;
+        p.ic = t.ic; p.jc = t.jc; p.kc = t.kc;
+    } else {
+        if (p.inside) { p.x = xp + d * t.kx; p.y = yp + d * t.ky; p.z = zp + d * t.kz; }
+        if (VAR == 0) { p.ic = t.ic; p.jc = t.jc; }
+        p.kc = t.kc;
+    }
+}
+
+// cell-by-cell core-skip threshold (Smith+15 eq. 35): grid_mod_car.f90:1598-1629
+__device__ inline void xcrit_local(const lart_params &par, const DGrid &g, const Lds &l, const Photon &p, double &xc, double &xc2) {
+    if (par.core_skip_global) { xc = par.xcrit; xc2 = par.xcrit2; return; }
+    xc = 0.0; xc2 = 0.0;
+    if (p.ic < 1 || p.jc < 1 || p.kc < 1) return;
+    double dlx = fmin(p.x - l.xf[p.ic - 1], l.xf[p.ic] - p.x), dly = fmin(p.y - l.yf[p.jc - 1], l.yf[p.jc] - p.y), dlz = fmin(p.z - l.zf[p.kc - 1], l.zf[p.kc] - p.z);
+    double dl = fmin(dlx, fmin(dly, dlz));
+    if (dl <= 0.0) return;
+    const Cell &c = g.cell[cidx(g, p.ic, p.jc, p.kc)];
+    double atau = c.voigt_a * c.rhokap * dl;
+    if (atau > 1.0) { xc = cbrt(atau) / 5.0; xc2 = xc * xc; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// peel-off (next-event estimator) to far observers: peelingoff_rect.f90
+// ---------------------------------------------------------------------------------------------
+struct PeelDir { double kx, ky, kz, r2; int ix, iy; bool in_image; };
+__device__ inline PeelDir peel_dir(const KArgs &A, const DObs &o, const Photon &p) {
+    PeelDir q;
+    q.kx = o.x - p.x; q.ky = o.y - p.y; q.kz = o.z - p.z;
+    q.r2 = q.kx * q.kx + q.ky * q.ky + q.kz * q.kz;
+    double r = sqrt(q.r2);
+    q.kx = q.kx / r; q.ky = q.ky / r; q.kz = q.kz / r;
+    double kx = o.rm[0] * q.kx + o.rm[1] * q.ky + o.rm[2] * q.kz, ky = o.rm[3] * q.kx + o.rm[4] * q.ky + o.rm[5] * q.kz, kz = o.rm[6] * q.kx + o.rm[7] * q.ky + o.rm[8] * q.kz;
+    q.ix = (int)floor(atan2(-kx, kz) * LART_RAD2DEG / A.dxim + A.nxim / 2.0) + 1;
+    q.iy = (int)floor(atan2(-ky, kz) * LART_RAD2DEG / A.dyim + A.nyim / 2.0) + 1;
+    q.in_image = (q.ix >= 1 && q.ix <= A.nxim && q.iy >= 1 && q.iy <= A.nyim);
+    return q;
+}
+__device__ inline size_t pix2(const KArgs &A, int io, int ix, int iy) { return (size_t)io * A.nxim * A.nyim + (size_t)(ix - 1) + (size_t)A.nxim * (size_t)(iy - 1); }
+__device__ inline size_t pix3(const KArgs &A, int io, int ixf, int ix, int iy) {
+    return ((size_t)io * A.nxim * A.nyim + (size_t)(ix - 1) + (size_t)A.nxim * (size_t)(iy - 1)) * (size_t)A.par.nxfreq + (size_t)(ixf - 1);
+}
+// e^{-tau} is exactly 0 once tau >= 745.2 in f64: adding it leaves the tally unchanged, so skip the atomics
+__device__ inline void add_if(double *arr, size_t i, double v) { if (v != 0.0) atomicAdd(&arr[i], v); }
+
+// peeling_direct_outside: peelingoff_rect.f90:24-129
+template <int VAR>
+__device__ inline void peel_direct(const KArgs &A, const Lds &l, bool dust, const Photon &p, unsigned &nsteps) {
+    const Cell &c = A.g.cell[cidx(A.g, p.ic, p.jc, p.kc)];
+    for (int i = 0; i < A.nobs; i++) {
+        PeelDir q = peel_dir(A, A.obs[i], p);
+        double xfreq_ref, xf = p.xfreq;
+        if (!A.par.comoving_source) {
+            double u1 = c.vfx * p.kx + c.vfy * p.ky + c.vfz * p.kz; xfreq_ref = p.xfreq + u1;
+            double u2 = c.vfx * q.kx + c.vfy * q.ky + c.vfz * q.kz; xf = xfreq_ref - u2;
+        } else { double u1 = c.vfx * q.kx + c.vfy * q.ky + c.vfz * q.kz; xfreq_ref = p.xfreq + u1; }
+        xfreq_ref = xfreq_ref * (c.Dfreq / A.par.Dfreq_ref);
+        int ixf = (int)floor((xfreq_ref - A.par.xfreq_min) / A.par.dxfreq) + 1;
+        if (!q.in_image) continue;
+        double tau = raytrace_to_edge<VAR>(A.g, l, dust, p, xf, q.kx, q.ky, q.kz, -1.0, nsteps);
+        double wgt = exp(-tau) * (1.0 / (LART_FOURPI * q.r2) * p.wgt);
+        if (A.par.save_peeloff_2D) { add_if(A.t.c2[1], pix2(A, i, q.ix, q.iy), wgt); if (A.par.use_stokes) add_if(A.t.c2[2], pix2(A, i, q.ix, q.iy), wgt); }
+        if (A.par.save_peeloff_3D && ixf >= 1 && ixf <= A.par.nxfreq) { add_if(A.t.c3[1], pix3(A, i, ixf, q.ix, q.iy), wgt); if (A.par.use_stokes) add_if(A.t.c3[2], pix3(A, i, ixf, q.ix, q.iy), wgt); }
+    }
+}
+// peeling_resonance_nostokes_outside: :576-690
+template <int VAR>
+__device__ inline void peel_resonance_nostokes(const KArgs &A, const Lds &l, bool dust, const Photon &p, double xfreq_atom, double ux, double uy, double uz, unsigned &nsteps) {
+    const Cell &c = A.g.cell[cidx(A.g, p.ic, p.jc, p.kc)];
+    for (int i = 0; i < A.nobs; i++) {
+        PeelDir q = peel_dir(A, A.obs[i], p);
+        if (!q.in_image) continue;
+        double cost = p.kx * q.kx + p.ky * q.ky + p.kz * q.kz, cost2 = cost * cost, sint = sqrt(1.0 - cost2);
+        double rho1 = sqrt(1.0 - p.kz * p.kz) * sint, cosp = 1.0, sinp = 0.0;
+        if (rho1 != 0.0) { double rho = 1.0 / rho1; cosp = rho * (cost * p.kz - q.kz); sinp = rho * (p.kx * q.ky - q.kx * p.ky); }
+        double xfreq = xfreq_atom + (ux * cosp + uy * sinp) * sint + uz * cost;
+        if (A.par.recoil) xfreq = xfreq - (A.par.g_recoil0 / c.Dfreq) * (1.0 - cost);
+        double u1 = c.vfx * q.kx + c.vfy * q.ky + c.vfz * q.kz;
+        double xfreq_ref = (xfreq + u1) * (c.Dfreq / A.par.Dfreq_ref);
+        int ixf = (int)floor((xfreq_ref - A.par.xfreq_min) / A.par.dxfreq) + 1;
+        double tau = raytrace_to_edge<VAR>(A.g, l, dust, p, xfreq, q.kx, q.ky, q.kz, -1.0, nsteps);
+        double peel = 0.75 * A.par.E1 * (cost2 + 1.0) + A.par.E2;
+        double wgt = peel / (LART_FOURPI * q.r2) * exp(-tau) * p.wgt;
+        if (A.par.save_peeloff_2D) add_if(A.t.c2[0], pix2(A, i, q.ix, q.iy), wgt);
+        if (A.par.save_peeloff_3D && ixf >= 1 && ixf <= A.par.nxfreq) add_if(A.t.c3[0], pix3(A, i, ixf, q.ix, q.iy), wgt);
+    }
+}
+__device__ inline void stokes_deposit(const KArgs &A, int io, const PeelDir &q, int ixf, double wgt, double Id, double Qd, double Ud, double Vd) {
+    if (wgt == 0.0) return;
+    if (A.par.save_peeloff_2D) { size_t s = pix2(A, io, q.ix, q.iy);
+        atomicAdd(&A.t.c2[0][s], wgt * Id); atomicAdd(&A.t.c2[2][s], wgt * Id); atomicAdd(&A.t.c2[3][s], wgt * Qd); atomicAdd(&A.t.c2[4][s], wgt * Ud); atomicAdd(&A.t.c2[5][s], wgt * Vd); }
+    if (A.par.save_peeloff_3D && ixf >= 1 && ixf <= A.par.nxfreq) { size_t s = pix3(A, io, ixf, q.ix, q.iy);
+        atomicAdd(&A.t.c3[0][s], wgt * Id); atomicAdd(&A.t.c3[2][s], wgt * Id); atomicAdd(&A.t.c3[3][s], wgt * Qd); atomicAdd(&A.t.c3[4][s], wgt * Ud); atomicAdd(&A.t.c3[5][s], wgt * Vd); }
+}
+// azimuth about the (m,n,k) triad and the peel reference normal: :356-385 (= :204-224)
+struct StokesGeom { double cost, sint, cosp, sinp, cos2p, sin2p, nx, ny, nz; };
+__device__ inline StokesGeom stokes_geom(const Photon &p, const PeelDir &q) {
+    StokesGeom s;
+    s.cost = p.kx * q.kx + p.ky * q.ky + p.kz * q.kz; s.sint = sqrt(1.0 - s.cost * s.cost);
+    if (s.sint == 0.0) { s.cosp = 1.0; s.sinp = 0.0; s.cos2p = 1.0; s.sin2p = 0.0; }
+    else { s.cosp = (q.kx * p.mx + q.ky * p.my + q.kz * p.mz) / s.sint; s.sinp = (q.kx * p.nx + q.ky * p.ny + q.kz * p.nz) / s.sint;
+           s.cos2p = 2.0 * s.cosp * s.cosp - 1.0; s.sin2p = 2.0 * s.cosp * s.sinp; }
+    s.nx = -s.sinp * p.mx + s.cosp * p.nx; s.ny = -s.sinp * p.my + s.cosp * p.ny; s.nz = -s.sinp * p.mz + s.cosp * p.nz;
+    return s;
+}
+// peeling_resonance_stokes_outside: :303-482
+template <int VAR>
+__device__ inline void peel_resonance_stokes(const KArgs &A, const Lds &l, bool dust, const Photon &p, double xfreq_atom, double ux, double uy, double uz, unsigned &nsteps) {
+    const Cell &c = A.g.cell[cidx(A.g, p.ic, p.jc, p.kc)];
+    for (int i = 0; i < A.nobs; i++) {
+        const DObs &o = A.obs[i];
+        PeelDir q = peel_dir(A, o, p);
+        if (!q.in_image) continue;
+        StokesGeom s = stokes_geom(p, q);
+        double cost2 = s.cost * s.cost, E1 = A.par.E1, E2 = A.par.E2, E3 = A.par.E3;
+        double S22 = 0.75 * E1 * (cost2 + 1.0), S11 = S22 + E2, S12 = 0.75 * E1 * (cost2 - 1.0), S33 = 1.5 * E1 * s.cost, S44 = 1.5 * E3 * s.cost;
+        double xfreq = xfreq_atom + (ux * s.cosp + uy * s.sinp) * s.sint + uz * s.cost;
+        if (A.par.recoil) xfreq = xfreq - (A.par.g_recoil0 / c.Dfreq) * (1.0 - s.cost);
+        double u1 = c.vfx * q.kx + c.vfy * q.ky + c.vfz * q.kz;
+        double xfreq_ref = (xfreq + u1) * (c.Dfreq / A.par.Dfreq_ref);
+        int ixf = (int)floor((xfreq_ref - A.par.xfreq_min) / A.par.dxfreq) + 1;
+        double Q0 = s.cos2p * p.Q + s.sin2p * p.U, U0 = -s.sin2p * p.Q + s.cos2p * p.U;
+        double Iobs = (S11 + S12 * Q0) / LART_FOURPI, Qobs = (S12 + S22 * Q0) / LART_FOURPI, Uobs = (S33 * U0) / LART_FOURPI, Vobs = (S44 * p.V) / LART_FOURPI;
+        double cosg = -(o.rm[0] * s.nx + o.rm[1] * s.ny + o.rm[2] * s.nz), sing = o.rm[3] * s.nx + o.rm[4] * s.ny + o.rm[5] * s.nz;
+        double cos2g = 2.0 * cosg * cosg - 1.0, sin2g = 2.0 * cosg * sing;
+        double Qdet = cos2g * Qobs + sin2g * Uobs, Udet = -sin2g * Qobs + cos2g * Uobs;
+        double tau = raytrace_to_edge<VAR>(A.g, l, dust, p, xfreq, q.kx, q.ky, q.kz, -1.0, nsteps);
+        double wgt = 1.0 / q.r2 * exp(-tau) * p.wgt;
+        stokes_deposit(A, i, q, ixf, wgt, Iobs, Qdet, Udet, Vobs);
+    }
+}
+// peeling_dust_nostokes_outside: :484-574
+template <int VAR>
+__device__ inline void peel_dust_nostokes(const KArgs &A, const Lds &l, const Photon &p, unsigned &nsteps) {
+    const Cell &c = A.g.cell[cidx(A.g, p.ic, p.jc, p.kc)];
+    for (int i = 0; i < A.nobs; i++) {
+        PeelDir q = peel_dir(A, A.obs[i], p);
+        if (!q.in_image) continue;
+        double u1 = c.vfx * q.kx + c.vfy * q.ky + c.vfz * q.kz;
+        double xfreq_ref = (p.xfreq + u1) * (c.Dfreq / A.par.Dfreq_ref);
+        int ixf = (int)floor((xfreq_ref - A.par.xfreq_min) / A.par.dxfreq) + 1;
+        double tau = raytrace_to_edge<VAR>(A.g, l, true, p, p.xfreq, q.kx, q.ky, q.kz, -1.0, nsteps);
+        double cosa = p.kx * q.kx + p.ky * q.ky + p.kz * q.kz, hgg = A.par.hgg;
+        double b = (1.0 + hgg * hgg) - 2.0 * hgg * cosa;
+        double peel = (1.0 - hgg * hgg) / (b * sqrt(b)) / LART_FOURPI;
+        double wgt = peel / q.r2 * exp(-tau) * p.wgt;
+        if (A.par.save_peeloff_2D) add_if(A.t.c2[0], pix2(A, i, q.ix, q.iy), wgt);
+        if (A.par.save_peeloff_3D && ixf >= 1 && ixf <= A.par.nxfreq) add_if(A.t.c3[0], pix3(A, i, ixf, q.ix, q.iy), wgt);
+    }
+}
+// peeling_dust_stokes_outside: :131-299
+template <int VAR>
+__device__ inline void peel_dust_stokes(const KArgs &A, const Lds &l, const Photon &p, unsigned &nsteps) {
+    const Cell &c = A.g.cell[cidx(A.g, p.ic, p.jc, p.kc)];
+    for (int i = 0; i < A.nobs; i++) {
+        const DObs &o = A.obs[i];
+        PeelDir q = peel_dir(A, o, p);
+        double u1 = c.vfx * q.kx + c.vfy * q.ky + c.vfz * q.kz;
+        double xfreq_ref = (p.xfreq + u1) * (c.Dfreq / A.par.Dfreq_ref);
+        int ixf = (int)floor((xfreq_ref - A.par.xfreq_min) / A.par.dxfreq) + 1;
+        if (!q.in_image) continue;
+        StokesGeom s = stokes_geom(p, q);
+        const DMueller &m = A.mu;
+        double S11 = interp_eq(m.nPDF, m.coss, m.S11, s.cost), S12 = interp_eq(m.nPDF, m.coss, m.S12, s.cost);
+        double S33 = interp_eq(m.nPDF, m.coss, m.S33, s.cost), S34 = interp_eq(m.nPDF, m.coss, m.S34, s.cost);
+        double Q0 = s.cos2p * p.Q + s.sin2p * p.U, U0 = -s.sin2p * p.Q + s.cos2p * p.U;
+        double Iobs = (S11 * 1.0 + S12 * Q0) / LART_TWOPI, Qobs = (S12 * 1.0 + S11 * Q0) / LART_TWOPI;
+        double Uobs = (S33 * U0 + S34 * p.V) / LART_TWOPI, Vobs = (-S34 * U0 + S33 * p.V) / LART_TWOPI;
+        double cosg = -(o.rm[0] * s.nx + o.rm[1] * s.ny + o.rm[2] * s.nz), sing = o.rm[3] * s.nx + o.rm[4] * s.ny + o.rm[5] * s.nz;
+        double cos2g = 2.0 * cosg * cosg - 1.0, sin2g = 2.0 * cosg * sing;
+        double Qdet = cos2g * Qobs + sin2g * Uobs, Udet = -sin2g * Qobs + cos2g * Uobs;
+        double tau = raytrace_to_edge<VAR>(A.g, l, true, p, p.xfreq, q.kx, q.ky, q.kz, -1.0, nsteps);
+        double wgt = 1.0 / q.r2 * exp(-tau) * p.wgt;
+        stokes_deposit(A, i, q, ixf, wgt, Iobs, Qdet, Udet, Vobs);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// scattering: scattering_car.f90
+// ---------------------------------------------------------------------------------------------
+// closed-form rotation of k by (theta, phi) about the old k: :795-809
+__device__ inline void rotate_k(Photon &p, double cost, double sint, double cosp, double sinp) {
+    if (fabs(p.kz) >= 0.99999999999) { p.kx = sint * cosp; p.ky = sint * sinp; p.kz = cost; }
+    else {
+        double kx1 = p.kx, ky1 = p.ky, kz1 = p.kz, kr = sqrt(kx1 * kx1 + ky1 * ky1);
+        p.kx = cost * kx1 + sint * (kz1 * kx1 * cosp - ky1 * sinp) / kr;
+        p.ky = cost * ky1 + sint * (kz1 * ky1 * cosp + kx1 * sinp) / kr;
+        p.kz = cost * kz1 - sint * cosp * kr;
+    }
+}
+// (m,n,k) triad rotation, fixed order: :470-484
+__device__ inline void rotate_triad(Photon &p, double cost, double sint, double cosp, double sinp) {
+    double px = cosp * p.mx + sinp * p.nx, py = cosp * p.my + sinp * p.ny, pz = cosp * p.mz + sinp * p.nz;
+    p.nx = cosp * p.nx - sinp * p.mx; p.ny = cosp * p.ny - sinp * p.my; p.nz = cosp * p.nz - sinp * p.mz;
+    p.mx = cost * px - sint * p.kx; p.my = cost * py - sint * p.ky; p.mz = cost * pz - sint * p.kz;
+    p.kx = sint * px + cost * p.kx; p.ky = sint * py + cost * p.ky; p.kz = sint * pz + cost * p.kz;
+}
+// azimuth by rejection on 1 + S12/S11 (Q cos 2phi + U sin 2phi): :364-371
+__device__ inline double phi_rejection(Rng &g, const Photon &p, double r) {
+    double amp = 1.0 + fabs(r) * sqrt(p.Q * p.Q + p.U * p.U);
+    for (;;) {
+        double phi = LART_TWOPI * g.next(), s2, c2;
+        double Prand = amp * g.next();
+        sincos(2.0 * phi, &s2, &c2);
+        if (Prand <= 1.0 + r * (p.Q * c2 + p.U * s2)) return phi;
+    }
+}
+// dust absorption / reduced weight: :504-555 (= :217-264). true when the packet is destroyed
+__device__ inline bool dust_absorb(const KArgs &A, Rng &g, Photon &p, const Cell &c) {
+    p.nsd = p.nsd + p.wgt;
+    const lart_params &par = A.par;
+    double dep = 0.0; bool killed = false;
+    if (!par.use_reduced_wgt) { if (g.next() > par.albedo) { dep = p.wgt; killed = true; } }
+    else { dep = p.wgt * (1.0 - par.albedo); }
+    if (dep != 0.0 && par.save_Jabs) {
+        double uu1 = c.vfx * p.kx + c.vfy * p.ky + c.vfz * p.kz;
+        double xr = (p.xfreq + uu1) * (c.Dfreq / par.Dfreq_ref);
+        int ix = (int)floor((xr - par.xfreq_min) / par.dxfreq) + 1;
+        if (ix >= 1 && ix <= par.nxfreq) atomicAdd(&A.t.Jabs[ix - 1], dep);
+        p.xfreq_ref = xr;
+    }
+    if (killed) { p.inside = false; return true; }
+    if (par.use_reduced_wgt) p.wgt = p.wgt * par.albedo;
+    return false;
+}
+
+// one scattering event (scattering :14-120 Cartesian branch, then the selected routine)
+template <int VAR, bool STOKES, bool DUST, bool PEEL>
+__device__ inline void scatter_event(const KArgs &A, const Lds &l, Rng &g, Photon &p, unsigned &npeel) {
+    const lart_params &par = A.par;
+    const Cell &c = A.g.cell[cidx(A.g, p.ic, p.jc, p.kc)];
+    double va = c.voigt_a;
+    if (DUST) {
+        double rD = c.rhokapD;
+        double p_dust = rD / (c.rhokap * voigt_H(l.vt, p.xfreq, va) + rD);
+        if (g.next() <= p_dust) {
+            if (dust_absorb(A, g, p, c)) return;
+            if (STOKES && A.mu.nPDF > 0) {                     // scatter_dust_stokes :201-329
+                if (PEEL) peel_dust_stokes<VAR>(A, l, p, npeel);
+                double cost = rand_alias_linear(g, A.mu), sint = sqrt(1.0 - cost * cost);
+                const DMueller &m = A.mu;
+                double S11 = interp_eq(m.nPDF, m.coss, m.S11, cost), S12 = interp_eq(m.nPDF, m.coss, m.S12, cost);
+                double S33 = interp_eq(m.nPDF, m.coss, m.S33, cost), S34 = interp_eq(m.nPDF, m.coss, m.S34, cost);
+                double phi = phi_rejection(g, p, S12 / S11), sinp, cosp; sincos(phi, &sinp, &cosp);
+                double cos2p = 2.0 * cosp * cosp - 1.0, sin2p = 2.0 * sinp * cosp;
+                double Q0 = cos2p * p.Q + sin2p * p.U, U0 = -sin2p * p.Q + cos2p * p.U;
+                double I1 = S11 + S12 * Q0, Q1 = S12 + S11 * Q0, U1 = S33 * U0 + S34 * p.V, V1 = -S34 * U0 + S33 * p.V;
+                p.Q = Q1 / I1; p.U = U1 / I1; p.V = V1 / I1;
+                rotate_triad(p, cost, sint, cosp, sinp);
+            } else {                                           // scatter_dust_nostokes :488-584
+                if (PEEL) peel_dust_nostokes<VAR>(A, l, p, npeel);
+                double cost = rand_hg(g, par.hgg), sint = sqrt(1.0 - cost * cost);
+                double phi = LART_TWOPI * g.next(), sinp, cosp; sincos(phi, &sinp, &cosp);
+                rotate_k(p, cost, sint, cosp, sinp);
+            }
+            return;
+        }
+    }
+    // resonance scattering: scatter_resonance_nostokes :660-827 / _stokes :331-486
+    p.nsg = p.nsg + p.wgt;
+    // do_resonance1: line_mod.f90:108-139
+    double uz = rand_resonance_vz(g, p.xfreq, va);
+    double xfreq_atom = p.xfreq - uz;
+    double cost = rand_resonance(g, par.E1), cost2 = cost * cost, sint = sqrt(1.0 - cost2);
+    double S11 = 0, S22 = 0, S12 = 0, S33 = 0, S44 = 0, phi;
+    if (STOKES) {
+        S22 = 0.75 * par.E1 * (cost2 + 1.0); S11 = S22 + par.E2; S12 = 0.75 * par.E1 * (cost2 - 1.0); S33 = 1.5 * par.E1 * cost; S44 = 1.5 * par.E3 * cost;
+        phi = phi_rejection(g, p, S12 / S11);
+    } else phi = LART_TWOPI * g.next();
+    double sinp, cosp; sincos(phi, &sinp, &cosp);
+    // perpendicular atom velocity; truncated tail when core-skipping (:726-752, :400-430)
+    double ux, uy, xc = 0.0, xc2 = 0.0;
+    if (par.core_skip) xcrit_local(par, A.g, l, p, xc, xc2);
+    if (par.core_skip && fabs(p.xfreq) < xc) {
+        double phi2 = LART_TWOPI * g.next(), uxy = sqrt(xc2 - log(g.next())), s2, c2; sincos(phi2, &s2, &c2);
+        ux = uxy * c2; uy = uxy * s2;
+    } else if (STOKES) {
+        double g2, g1 = g.gauss_pair(g2);
+        ux = g1 * 0.70710678118654752440084436210485; uy = g2 * 0.70710678118654752440084436210485;
+    } else {
+        double phi2 = LART_TWOPI * g.next(), uxy = sqrt(-log(g.next())), s2, c2; sincos(phi2, &s2, &c2);
+        ux = uxy * c2; uy = uxy * s2;
+    }
+    p.xfreq = xfreq_atom + uz * cost + (ux * cosp + uy * sinp) * sint;
+    if (par.recoil) p.xfreq = p.xfreq - (par.g_recoil0 / c.Dfreq) * (1.0 - cost);
+    if (STOKES) {
+        if (PEEL) peel_resonance_stokes<VAR>(A, l, DUST, p, xfreq_atom, ux, uy, uz, npeel);
+        double cos2p = 2.0 * cosp * cosp - 1.0, sin2p = 2.0 * sinp * cosp;
+        double Q0 = cos2p * p.Q + sin2p * p.U, U0 = -sin2p * p.Q + cos2p * p.U;
+        double I1 = S11 + S12 * Q0, Q1 = S12 + S22 * Q0, U1 = S33 * U0, V1 = S44 * p.V;
+        p.Q = Q1 / I1; p.U = U1 / I1; p.V = V1 / I1;
+        rotate_triad(p, cost, sint, cosp, sinp);
+    } else {
+        if (PEEL) peel_resonance_nostokes<VAR>(A, l, DUST, p, xfreq_atom, ux, uy, uz, npeel);
+        rotate_k(p, cost, sint, cosp, sinp);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// photon birth: generate_photon.f90:3-339, setup_isotropic_injection :342-408
+// ---------------------------------------------------------------------------------------------
+template <int VAR, bool STOKES, bool DUST, bool PEEL>
+__device__ inline void generate_photon(const KArgs &A, const Lds &l, Rng &g, Photon &p, unsigned &npeel) {
+    const lart_params &par = A.par; const DGrid &gr = A.g;
+    if (par.source_geometry == 1) {
+        double rp = cbrt(g.next()) * par.source_rmax, cost = 2.0 * g.next() - 1.0, sint = sqrt(1.0 - cost * cost), phi = LART_TWOPI * g.next(), sp, cp;
+        sincos(phi, &sp, &cp);
+        p.x = rp * sint * cp; p.y = rp * sint * sp; p.z = rp * cost;
+    } else { p.x = par.xs_point; p.y = par.ys_point; p.z = par.zs_point; }
+    p.wgt = 1.0;
+    if (VAR == 1) { if (p.x < gr.xmin) p.x = -p.x; if (p.y < gr.ymin) p.y = -p.y; if (p.z < gr.zmin) p.z = -p.z; }
+    double cost = 2.0 * g.next() - 1.0, sint = sqrt(1.0 - cost * cost), phi = LART_TWOPI * g.next(), sinp, cosp;
+    sincos(phi, &sinp, &cosp);
+    p.kx = sint * cosp; p.ky = sint * sinp; p.kz = cost;
+    p.ic = (int)floor((p.x - gr.xmin) / gr.dx) + 1; p.jc = (int)floor((p.y - gr.ymin) / gr.dy) + 1; p.kc = (int)floor((p.z - gr.zmin) / gr.dz) + 1;
+    if (p.kx < 0.0 && p.ic == gr.nx + 1) p.ic = gr.nx;
+    if (p.ky < 0.0 && p.jc == gr.ny + 1) p.jc = gr.ny;
+    if (p.kz < 0.0 && p.kc == gr.nz + 1) p.kc = gr.nz;
+    if (p.kx > 0.0 && p.ic < 1) p.ic = 1;
+    if (p.ky > 0.0 && p.jc < 1) p.jc = 1;
+    if (p.kz > 0.0 && p.kc < 1) p.kc = 1;
+    if (STOKES) { p.mx = cost * cosp; p.my = cost * sinp; p.mz = -sint; p.nx = -sinp; p.ny = cosp; p.nz = 0.0; p.Q = 0.0; p.U = 0.0; p.V = 0.0; }
+    p.nsg = 0.0; p.nsd = 0.0; p.inside = true; p.xfreq = par.xfreq0;
+    // a source outside the medium box never reaches a table in the reference's configs; clamp the gather
+    const Cell &c = gr.cell[cidx(gr, clampi(p.ic, 1, gr.nx), clampi(p.jc, 1, gr.ny), clampi(p.kc, 1, gr.nz))];
+    if (par.spectral_type == 1) p.xfreq = p.xfreq + rand_voigt(g, c.voigt_a);
+    double u1 = c.vfx * p.kx + c.vfy * p.ky + c.vfz * p.kz;
+    if (!par.comoving_source) p.xfreq = p.xfreq - u1;
+    if (par.save_Jin) {
+        double xlab = (p.xfreq + u1) * (c.Dfreq / par.Dfreq_ref);
+        int ix = (int)floor((xlab - par.xfreq_min) / par.dxfreq) + 1;
+        if (ix >= 1 && ix <= par.nxfreq) atomicAdd(&A.t.Jin[ix - 1], p.wgt);
+    }
+    if (PEEL) peel_direct<VAR>(A, l, DUST, p, npeel);
+}

@@ -1,0 +1,466 @@
+// lart_gpu.hip -- C-ABI (include/lart_gpu.h) over the HIP transport kernels + device-function probes.
+// Host side is plain HIP runtime calls on one stream per context; no torch types, no CPU fallback.
+#include "transport_kernel.hpp"
+#include <string>
+#include <vector>
+#include <cstring>
+#include <cstdio>
+#include <cmath>
+
+extern "C" void lart_launch_transport_var0(int, int, int, dim3, dim3, size_t, hipStream_t, const KArgs &);
+extern "C" void lart_launch_transport_var1(int, int, int, dim3, dim3, size_t, hipStream_t, const KArgs &);
+extern "C" void lart_launch_transport_var2(int, int, int, dim3, dim3, size_t, hipStream_t, const KArgs &);
+
+static thread_local std::string g_err;
+static int fail(const std::string &m) { g_err = m; return 1; }
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+
+struct lart_gpu {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    lart_params par{};
+    // medium
+    DGrid g{}; Cell *d_cell = nullptr; double *d_faces = nullptr; size_t ncell = 0; bool has_dust_table = false;
+    // Mueller
+    DMueller mu{}; double *d_mu = nullptr; int *d_alias = nullptr;
+    // observers
+    DObs *d_obs = nullptr; int nobs = 0, nxim = 0, nyim = 0; double dxim = 0, dyim = 0;
+    // fused tally buffer
+    double *d_tally = nullptr; int64_t ntally = 0; DTally t{};
+    // pool
+    DPool pool{}; void *d_pool = nullptr; int64_t want_lanes = 0; int block = 256;
+    DCtl *d_ctl = nullptr;
+    // run
+    long long first_id = 0, stride = 1, count = 0; unsigned long long seed = 0; bool begun = false;
+    int log_on = 0; double *d_log = nullptr; int64_t nlog = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; double kernel_ms = 0.0; int64_t nlaunch = 0;
+};
+
+extern "C" const char *lart_gpu_last_error(void) { return g_err.c_str(); }
+
+extern "C" int lart_gpu_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+
+extern "C" int lart_gpu_create(lart_gpu **out, const lart_params *par, int device) {
+    if (!out || !par) return fail("lart_gpu_create: null argument");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail("lart_gpu_create: no HIP device visible (this library has no CPU path)");
+    if (device < 0 || device >= n) return fail("lart_gpu_create: device ordinal out of range");
+    HIPCHK(hipSetDevice(device));
+    lart_gpu *c = new lart_gpu();
+    c->device = device; c->par = *par;
+    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPCHK(hipMalloc(&c->d_ctl, sizeof(DCtl)));
+    HIPCHK(hipMemset(c->d_ctl, 0, sizeof(DCtl)));
+    *out = c;
+    return 0;
+}
+
+static void free_tally(lart_gpu *c) { if (c->d_tally) { (void)hipFree(c->d_tally); c->d_tally = nullptr; } }
+
+extern "C" int lart_gpu_destroy(lart_gpu *c) {
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto &e : c->ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    (void)hipFree(c->d_cell); (void)hipFree(c->d_faces); (void)hipFree(c->d_mu); (void)hipFree(c->d_alias); (void)hipFree(c->d_obs);
+    free_tally(c); (void)hipFree(c->d_pool); (void)hipFree(c->d_ctl); (void)hipFree(c->d_log);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return 0;
+}
+
+// lay the fused tally buffer out: scalars | Jout | Jin | Jabs | Jmu | per-observer cubes and images
+static int build_tally(lart_gpu *c) {
+    (void)hipSetDevice(c->device);
+    free_tally(c);
+    const lart_params &p = c->par;
+    int64_t nxf = p.nxfreq, nmu = p.save_Jmu ? p.nmu : 0;
+    int64_t n2 = (int64_t)c->nobs * c->nxim * c->nyim, n3 = n2 * nxf;
+    bool peel = p.save_peeloff && c->nobs > 0;
+    int64_t off = 16;
+    int64_t oJout = off; off += nxf; int64_t oJin = off; off += nxf; int64_t oJabs = off; off += nxf; int64_t oJmu = off; off += nxf * nmu;
+    int64_t o3[6], o2[6];
+    for (int k = 0; k < 6; k++) { bool on = peel && p.save_peeloff_3D && (k < 2 || p.use_stokes); o3[k] = on ? off : -1; if (on) off += n3; }
+    for (int k = 0; k < 6; k++) { bool on = peel && p.save_peeloff_2D && (k < 2 || p.use_stokes); o2[k] = on ? off : -1; if (on) off += n2; }
+    c->ntally = off;
+    HIPCHK(hipMalloc(&c->d_tally, off * sizeof(double)));
+    HIPCHK(hipMemset(c->d_tally, 0, off * sizeof(double)));
+    c->t.scal = c->d_tally; c->t.Jout = c->d_tally + oJout; c->t.Jin = c->d_tally + oJin; c->t.Jabs = c->d_tally + oJabs; c->t.Jmu = c->d_tally + oJmu;
+    for (int k = 0; k < 6; k++) { c->t.c3[k] = o3[k] >= 0 ? c->d_tally + o3[k] : nullptr; c->t.c2[k] = o2[k] >= 0 ? c->d_tally + o2[k] : nullptr; }
+    return 0;
+}
+
+extern "C" int lart_gpu_set_grid_car(lart_gpu *c, int32_t nx, int32_t ny, int32_t nz, double xmin, double ymin, double zmin,
+                                     double dx, double dy, double dz, int32_t i0, int32_t j0, int32_t k0,
+                                     const double *xface, const double *yface, const double *zface,
+                                     const double *rhokap, const double *voigt_a, const double *Dfreq,
+                                     const double *vfx, const double *vfy, const double *vfz, const double *rhokapD) {
+    if (!c) return fail("set_grid_car: null context");
+    if (nx < 1 || ny < 1 || nz < 1) return fail("set_grid_car: nx, ny, nz must be >= 1");
+    if (!xface || !yface || !zface || !rhokap || !voigt_a || !Dfreq || !vfx || !vfy || !vfz) return fail("set_grid_car: null table");
+    if (c->par.DGR > 0.0 && !rhokapD) return fail("set_grid_car: DGR > 0 needs rhokapD");
+    if (c->par.xyz_symmetry && (i0 < 1 || j0 < 1 || k0 < 1 || i0 > nx || j0 > ny || k0 > nz)) return fail("set_grid_car: xyz_symmetry needs mirror indices i0,j0,k0 inside the grid");
+    HIPCHK(hipSetDevice(c->device));
+    size_t nc = (size_t)nx * ny * nz;
+    std::vector<Cell> h(nc);
+    for (size_t i = 0; i < nc; i++) {
+        h[i].rhokap = rhokap[i]; h[i].voigt_a = voigt_a[i]; h[i].Dfreq = Dfreq[i];
+        h[i].vfx = vfx[i]; h[i].vfy = vfy[i]; h[i].vfz = vfz[i]; h[i].rhokapD = rhokapD ? rhokapD[i] : 0.0; h[i].pad = 0.0;
+        if (!(Dfreq[i] > 0.0)) return fail("set_grid_car: Dfreq must be > 0 in every cell (grid_mod_car.f90:276-277)");
+    }
+    (void)hipFree(c->d_cell); (void)hipFree(c->d_faces); c->d_cell = nullptr; c->d_faces = nullptr;
+    HIPCHK(hipMalloc(&c->d_cell, nc * sizeof(Cell)));
+    HIPCHK(hipMemcpy(c->d_cell, h.data(), nc * sizeof(Cell), hipMemcpyHostToDevice));
+    size_t nf = (size_t)nx + ny + nz + 3;
+    std::vector<double> f(nf);
+    std::memcpy(&f[0], xface, (nx + 1) * sizeof(double)); std::memcpy(&f[nx + 1], yface, (ny + 1) * sizeof(double)); std::memcpy(&f[nx + ny + 2], zface, (nz + 1) * sizeof(double));
+    HIPCHK(hipMalloc(&c->d_faces, nf * sizeof(double)));
+    HIPCHK(hipMemcpy(c->d_faces, f.data(), nf * sizeof(double), hipMemcpyHostToDevice));
+    c->g.nx = nx; c->g.ny = ny; c->g.nz = nz; c->g.i0 = i0; c->g.j0 = j0; c->g.k0 = k0;
+    c->g.xmin = xmin; c->g.ymin = ymin; c->g.zmin = zmin; c->g.dx = dx; c->g.dy = dy; c->g.dz = dz;
+    c->g.cell = c->d_cell; c->g.faces = c->d_faces; c->ncell = nc; c->has_dust_table = rhokapD != nullptr;
+    return 0;
+}
+
+extern "C" int lart_gpu_set_mueller(lart_gpu *c, int32_t nPDF, const double *coss, const double *S11, const double *S12,
+                                    const double *S33, const double *S34, const double *phase_PDF, const int32_t *alias) {
+    if (!c) return fail("set_mueller: null context");
+    if (nPDF < 2 || !coss || !S11 || !S12 || !S33 || !S34 || !phase_PDF || !alias) return fail("set_mueller: bad table");
+    for (int i = 0; i < nPDF - 1; i++) if (alias[i] < 0 || alias[i] > nPDF - 1) return fail("set_mueller: alias entries must be 0..nPDF-1 (1-based, 0 = unused)");
+    HIPCHK(hipSetDevice(c->device));
+    (void)hipFree(c->d_mu); (void)hipFree(c->d_alias);
+    size_t n = nPDF;
+    std::vector<double> h(6 * n, 0.0);
+    std::memcpy(&h[0], coss, n * 8); std::memcpy(&h[n], S11, n * 8); std::memcpy(&h[2 * n], S12, n * 8);
+    std::memcpy(&h[3 * n], S33, n * 8); std::memcpy(&h[4 * n], S34, n * 8); std::memcpy(&h[5 * n], phase_PDF, (n - 1) * 8);
+    HIPCHK(hipMalloc(&c->d_mu, 6 * n * 8)); HIPCHK(hipMemcpy(c->d_mu, h.data(), 6 * n * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&c->d_alias, n * 4)); HIPCHK(hipMemset(c->d_alias, 0, n * 4));
+    HIPCHK(hipMemcpy(c->d_alias, alias, (n - 1) * 4, hipMemcpyHostToDevice));
+    c->mu.nPDF = nPDF; c->mu.coss = c->d_mu; c->mu.S11 = c->d_mu + n; c->mu.S12 = c->d_mu + 2 * n; c->mu.S33 = c->d_mu + 3 * n; c->mu.S34 = c->d_mu + 4 * n;
+    c->mu.phase_PDF = c->d_mu + 5 * n; c->mu.alias = c->d_alias;
+    return 0;
+}
+
+extern "C" int lart_gpu_set_observers(lart_gpu *c, int32_t nobs, const double *xyz, const double *rmatrix, double dxim, double dyim, int32_t nxim, int32_t nyim) {
+    if (!c) return fail("set_observers: null context");
+    if (nobs < 0 || nobs > LART_MAX_OBSERVERS) return fail("set_observers: nobs out of range");
+    if (nobs > 0 && (!xyz || !rmatrix || nxim < 1 || nyim < 1 || !(dxim > 0.0) || !(dyim > 0.0))) return fail("set_observers: bad image geometry");
+    HIPCHK(hipSetDevice(c->device));
+    (void)hipFree(c->d_obs); c->d_obs = nullptr;
+    std::vector<DObs> h(nobs > 0 ? nobs : 1);
+    for (int i = 0; i < nobs; i++) { h[i].x = xyz[3 * i]; h[i].y = xyz[3 * i + 1]; h[i].z = xyz[3 * i + 2]; for (int q = 0; q < 9; q++) h[i].rm[q] = rmatrix[9 * i + q]; }
+    HIPCHK(hipMalloc(&c->d_obs, h.size() * sizeof(DObs)));
+    HIPCHK(hipMemcpy(c->d_obs, h.data(), h.size() * sizeof(DObs), hipMemcpyHostToDevice));
+    c->nobs = nobs; c->nxim = nxim; c->nyim = nyim; c->dxim = dxim; c->dyim = dyim;
+    free_tally(c);
+    return 0;
+}
+
+extern "C" int lart_gpu_set_pool(lart_gpu *c, int64_t nlanes, int32_t block) {
+    if (!c) return fail("set_pool: null context");
+    if (block != 0 && (block % 64 != 0 || block < 64 || block > 256)) return fail("set_pool: block must be 64, 128, 192 or 256");
+    if (c->begun) return fail("set_pool: call before lart_gpu_begin");
+    c->want_lanes = nlanes; if (block) c->block = block;
+    return 0;
+}
+
+extern "C" int lart_gpu_pool_info(lart_gpu *c, int64_t *nlanes, int32_t *block) {
+    if (!c) return fail("pool_info: null context");
+    if (nlanes) *nlanes = c->pool.n; if (block) *block = c->block;
+    return 0;
+}
+
+extern "C" int lart_gpu_enable_photon_log(lart_gpu *c, int32_t on) { if (!c) return fail("null context"); c->log_on = on; return 0; }
+
+static int ensure_pool(lart_gpu *c) {
+    int64_t n = c->want_lanes;
+    if (n <= 0) {
+        hipDeviceProp_t pr; HIPCHK(hipGetDeviceProperties(&pr, c->device));
+        n = (int64_t)pr.multiProcessorCount * 1024;            // 16 waves per CU
+    }
+    if (c->count > 0 && n > c->count) n = c->count;
+    if (n < c->block) n = c->block;
+    n = ((n + c->block - 1) / c->block) * c->block;
+    if (c->d_pool && c->pool.n == n) return 0;
+    (void)hipFree(c->d_pool); c->d_pool = nullptr;
+    size_t bytes = (size_t)n * (F_COUNT * 8 + 8 + 8 + 4 * 4);
+    HIPCHK(hipMalloc(&c->d_pool, bytes));
+    char *b = (char *)c->d_pool;
+    c->pool.n = n;
+    c->pool.f = (double *)b; b += (size_t)n * F_COUNT * 8;
+    c->pool.rng_n = (unsigned long long *)b; b += (size_t)n * 8;
+    c->pool.k = (long long *)b; b += (size_t)n * 8;
+    c->pool.ic = (int *)b; b += (size_t)n * 4; c->pool.jc = (int *)b; b += (size_t)n * 4; c->pool.kc = (int *)b; b += (size_t)n * 4; c->pool.flags = (int *)b;
+    return 0;
+}
+
+extern "C" int lart_gpu_begin(lart_gpu *c, int64_t first_id, int64_t stride, int64_t count, uint64_t seed) {
+    if (!c) return fail("begin: null context");
+    if (!c->d_cell) return fail("begin: no medium (call lart_gpu_set_grid_car first)");
+    if (count < 0 || stride < 1 || first_id < 0) return fail("begin: need count >= 0, stride >= 1, first_id >= 0");
+    if (c->par.save_peeloff && c->nobs == 0) return fail("begin: save_peeloff set but no observers (lart_gpu_set_observers)");
+    if (c->par.save_peeloff && c->par.xyz_symmetry) return fail("begin: peel-off is not allowed with xyz_symmetry (setup.f90:198-206)");
+    if (c->par.DGR > 0.0 && !c->has_dust_table) return fail("begin: DGR > 0 but the grid has no rhokapD");
+    if (c->par.xy_periodic && !(c->g.nx == 1 && c->g.ny == 1)) return fail("begin: xy_periodic is supported for nx = ny = 1 (raytrace_to_tau_car_zonly) only");
+    HIPCHK(hipSetDevice(c->device));
+    if (!c->d_tally) { if (build_tally(c)) return 1; }
+    c->first_id = first_id; c->stride = stride; c->count = count; c->seed = seed;
+    if (ensure_pool(c)) return 1;
+    HIPCHK(hipMemsetAsync(c->pool.flags, 0, (size_t)c->pool.n * 4, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_ctl, 0, sizeof(DCtl), c->stream));
+    (void)hipFree(c->d_log); c->d_log = nullptr; c->nlog = 0;
+    if (c->log_on && count > 0) { HIPCHK(hipMalloc(&c->d_log, (size_t)count * 16)); HIPCHK(hipMemsetAsync(c->d_log, 0, (size_t)count * 16, c->stream)); c->nlog = count; }
+    for (auto &e : c->ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    c->ev.clear(); c->kernel_ms = 0.0; c->nlaunch = 0;
+    c->begun = true;
+    return 0;
+}
+
+static int collect_events(lart_gpu *c) {
+    for (auto &e : c->ev) {
+        float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, e.first, e.second));
+        c->kernel_ms += ms; c->nlaunch++;
+        (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second);
+    }
+    c->ev.clear();
+    return 0;
+}
+
+extern "C" int lart_gpu_step(lart_gpu *c, int32_t nsteps, int32_t max_events) {
+    if (!c || !c->begun) return fail("step: call lart_gpu_begin first");
+    if (max_events < 1) return fail("step: max_events must be >= 1");
+    HIPCHK(hipSetDevice(c->device));
+    KArgs A{};
+    A.par = c->par; A.g = c->g; A.t = c->t; A.pool = c->pool; A.mu = c->mu; A.obs = c->d_obs; A.nobs = c->par.save_peeloff ? c->nobs : 0;
+    A.nxim = c->nxim; A.nyim = c->nyim; A.dxim = c->dxim; A.dyim = c->dyim; A.ctl = c->d_ctl;
+    A.first_id = c->first_id; A.stride = c->stride; A.count = c->count; A.seed = c->seed; A.max_events = max_events;
+    A.log_nscatt = c->d_log; A.log_xfreq = c->d_log ? c->d_log + c->nlog : nullptr;
+    int var = c->par.xyz_symmetry ? 1 : (c->par.xy_periodic ? 2 : 0);     // setup.f90:961-990
+    int stokes = c->par.use_stokes ? 1 : 0, dust = c->par.DGR > 0.0 ? 1 : 0, peel = (c->par.save_peeloff && c->nobs > 0) ? 1 : 0;
+    dim3 block(c->block), grid((unsigned)(c->pool.n / c->block));
+    size_t shmem = (size_t)(VT_END + c->g.nx + c->g.ny + c->g.nz + 3) * sizeof(double);
+    if (shmem > 160 * 1024) return fail("step: grid faces do not fit the 160 KiB LDS");
+    for (int s = 0; s < nsteps; s++) {
+        hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+        HIPCHK(hipMemsetAsync(&c->d_ctl->n_active, 0, sizeof(unsigned long long), c->stream));
+        HIPCHK(hipEventRecord(e0, c->stream));
+        if (var == 0) lart_launch_transport_var0(stokes, dust, peel, grid, block, shmem, c->stream, A);
+        else if (var == 1) lart_launch_transport_var1(stokes, dust, peel, grid, block, shmem, c->stream, A);
+        else lart_launch_transport_var2(stokes, dust, peel, grid, block, shmem, c->stream, A);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(e1, c->stream));
+        c->ev.emplace_back(e0, e1);
+    }
+    return 0;
+}
+
+extern "C" int lart_gpu_sync(lart_gpu *c, int64_t *done, int64_t *active) {
+    if (!c) return fail("sync: null context");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (collect_events(c)) return 1;
+    DCtl h{}; double nd = 0.0;
+    HIPCHK(hipMemcpy(&h, c->d_ctl, sizeof h, hipMemcpyDeviceToHost));
+    if (c->d_tally) HIPCHK(hipMemcpy(&nd, c->d_tally + 5, 8, hipMemcpyDeviceToHost));
+    if (done) *done = (int64_t)(nd + 0.5);
+    if (active) *active = (int64_t)h.n_active + ((int64_t)h.next_k < c->count ? (c->count - (int64_t)h.next_k) : 0);
+    return 0;
+}
+
+extern "C" int lart_gpu_kernel_time(lart_gpu *c, double *total_ms, int64_t *nlaunches) {
+    if (!c) return fail("kernel_time: null context");
+    if (total_ms) *total_ms = c->kernel_ms; if (nlaunches) *nlaunches = c->nlaunch;
+    return 0;
+}
+
+extern "C" int lart_gpu_run(lart_gpu *c, int64_t first_id, int64_t stride, int64_t count, uint64_t seed) {
+    if (lart_gpu_begin(c, first_id, stride, count, seed)) return 1;
+    // photons still to be processed before this call (device nphotons_done is cumulative over runs)
+    for (;;) {
+        if (lart_gpu_step(c, 1, 4096)) return 1;
+        int64_t done = 0, active = 0;
+        if (lart_gpu_sync(c, &done, &active)) return 1;
+        if (active == 0) break;
+    }
+    return 0;
+}
+
+extern "C" int lart_gpu_tally_buffer(lart_gpu *c, void **p, int64_t *n) {
+    if (!c) return fail("tally_buffer: null context");
+    if (!c->d_tally) { if (build_tally(c)) return 1; }
+    if (p) *p = c->d_tally; if (n) *n = c->ntally;
+    return 0;
+}
+extern "C" int lart_gpu_zero_tallies(lart_gpu *c) {
+    if (!c) return fail("zero_tallies: null context");
+    HIPCHK(hipSetDevice(c->device));
+    if (!c->d_tally) { if (build_tally(c)) return 1; }
+    HIPCHK(hipMemsetAsync(c->d_tally, 0, c->ntally * 8, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+extern "C" int lart_gpu_get_tallies(lart_gpu *c, lart_tallies *o) {
+    if (!c || !o) return fail("get_tallies: null argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (collect_events(c)) return 1;
+    if (!c->d_tally) { if (build_tally(c)) return 1; }
+    double s[16]; HIPCHK(hipMemcpy(s, c->d_tally, sizeof s, hipMemcpyDeviceToHost));
+    o->nscatt_gas = s[0]; o->nscatt_dust = s[1]; o->n_events = s[2]; o->n_cellsteps = s[3]; o->n_cellsteps_peel = s[4]; o->nphotons_done = (int64_t)(s[5] + 0.5);
+    DCtl h{}; HIPCHK(hipMemcpy(&h, c->d_ctl, sizeof h, hipMemcpyDeviceToHost)); o->nphotons_active = (int64_t)h.n_active;
+    int64_t nxf = c->par.nxfreq, n2 = (int64_t)c->nobs * c->nxim * c->nyim, n3 = n2 * nxf;
+#define CP(dst, src, cnt) if ((dst) && (src) && (cnt) > 0) HIPCHK(hipMemcpy((dst), (src), (size_t)(cnt) * 8, hipMemcpyDeviceToHost))
+    CP(o->Jout, c->t.Jout, nxf); CP(o->Jin, c->t.Jin, nxf); CP(o->Jabs, c->t.Jabs, nxf); CP(o->Jmu, c->t.Jmu, c->par.save_Jmu ? nxf * c->par.nmu : 0);
+    double *h3[6] = {o->scatt, o->direc, o->I, o->Q, o->U, o->V}, *h2[6] = {o->scatt_2D, o->direc_2D, o->I_2D, o->Q_2D, o->U_2D, o->V_2D};
+    for (int k = 0; k < 6; k++) { CP(h3[k], c->t.c3[k], n3); CP(h2[k], c->t.c2[k], n2); }
+#undef CP
+    return 0;
+}
+extern "C" int lart_gpu_get_photon_log(lart_gpu *c, double *nscatt, double *xfreq_ref, int64_t n) {
+    if (!c) return fail("photon_log: null context");
+    if (!c->d_log) return fail("photon_log: not enabled (lart_gpu_enable_photon_log before lart_gpu_begin)");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    int64_t m = n < c->nlog ? n : c->nlog;
+    if (nscatt) HIPCHK(hipMemcpy(nscatt, c->d_log, (size_t)m * 8, hipMemcpyDeviceToHost));
+    if (xfreq_ref) HIPCHK(hipMemcpy(xfreq_ref, c->d_log + c->nlog, (size_t)m * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// device-function probes (parity tests): one lane per element
+// ---------------------------------------------------------------------------------------------
+__global__ void k_test_voigt(DGrid g, int n, const double *x, const double *a, double *h) {
+    extern __shared__ double sh[];
+    Lds l = lds_stage(sh, g);
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) h[i] = voigt_H(l.vt, x[i], a[i]);
+}
+// what: 0 uniform, 1 rand_resonance_vz(p1=x,p2=a), 2 rand_resonance(p1=E1), 3 HG(p1=g), 4 rand_voigt(p1=a), 5 gauss (first of pair)
+__global__ void k_test_rand(int what, unsigned long long seed, unsigned long long id, int n, double p1, double p2, double *out) {
+    if (blockIdx.x * blockDim.x + threadIdx.x != 0) return;
+    Rng g; g.init(seed, id, 0);
+    for (int i = 0; i < n; i++) {
+        double v, s2;
+        switch (what) {
+        case 0: v = g.next(); break;
+        case 1: v = rand_resonance_vz(g, p1, p2); break;
+        case 2: v = rand_resonance(g, p1); break;
+        case 3: v = rand_hg(g, p1); break;
+        case 4: v = rand_voigt(g, p1); break;
+        default: v = g.gauss_pair(s2); break;
+        }
+        out[i] = v;
+    }
+}
+// mode = 10*kind + variant; kind 0 = to_tau, 1 = to_edge, 2 = to_dist (variant 0)
+template <int VAR>
+__device__ void test_ray_one(const KArgs &A, const Lds &l, int kind, double *r, int *ic, double tq, double *tau_out) {
+    Photon p{}; p.x = r[0]; p.y = r[1]; p.z = r[2]; p.kx = r[3]; p.ky = r[4]; p.kz = r[5]; p.xfreq = r[6]; p.wgt = r[7];
+    p.ic = ic[0]; p.jc = ic[1]; p.kc = ic[2]; p.inside = ic[3] != 0;
+    unsigned ns = 0; bool dust = A.par.DGR > 0.0;
+    if (kind == 0) {
+        raytrace_to_tau<VAR>(A, l, dust, p, tq, ns);
+        r[0] = p.x; r[1] = p.y; r[2] = p.z; r[3] = p.kx; r[4] = p.ky; r[5] = p.kz; r[6] = p.xfreq; r[7] = p.wgt;
+        ic[0] = p.ic; ic[1] = p.jc; ic[2] = p.kc; ic[3] = p.inside ? 1 : 0;
+    } else *tau_out = raytrace_to_edge<VAR>(A.g, l, dust, p, p.xfreq, p.kx, p.ky, p.kz, kind == 2 ? tq : -1.0, ns);
+}
+__global__ void k_test_raytrace(KArgs A, int mode, int n, double *r8, int *ic4, const double *tq, double *tau_out) {
+    extern __shared__ double sh[];
+    Lds l = lds_stage(sh, A.g);
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int kind = mode / 10, var = mode % 10;
+    if (var == 0) test_ray_one<0>(A, l, kind, r8 + 8 * i, ic4 + 4 * i, tq ? tq[i] : 0.0, tau_out + i);
+    else if (var == 1) test_ray_one<1>(A, l, kind, r8 + 8 * i, ic4 + 4 * i, tq ? tq[i] : 0.0, tau_out + i);
+    else test_ray_one<2>(A, l, kind, r8 + 8 * i, ic4 + 4 * i, tq ? tq[i] : 0.0, tau_out + i);
+}
+template <bool STOKES, bool DUST>
+__device__ void test_scatter_one(const KArgs &A, const Lds &l, double *st, int *ic, unsigned long long seed, unsigned long long id, long long *nd) {
+    Photon p{}; p.x = st[0]; p.y = st[1]; p.z = st[2]; p.kx = st[3]; p.ky = st[4]; p.kz = st[5]; p.xfreq = st[6]; p.wgt = st[7];
+    p.mx = st[8]; p.my = st[9]; p.mz = st[10]; p.nx = st[11]; p.ny = st[12]; p.nz = st[13]; p.Q = st[15]; p.U = st[16]; p.V = st[17];
+    p.ic = ic[0]; p.jc = ic[1]; p.kc = ic[2]; p.inside = true;
+    Rng g; g.init(seed, id, 0); unsigned np = 0;
+    scatter_event<0, STOKES, DUST, false>(A, l, g, p, np);
+    st[0] = p.x; st[1] = p.y; st[2] = p.z; st[3] = p.kx; st[4] = p.ky; st[5] = p.kz; st[6] = p.xfreq; st[7] = p.wgt;
+    st[8] = p.mx; st[9] = p.my; st[10] = p.mz; st[11] = p.nx; st[12] = p.ny; st[13] = p.nz; st[14] = 1.0; st[15] = p.Q; st[16] = p.U; st[17] = p.V;
+    ic[3] = p.inside ? 1 : 0; *nd = (long long)g.n;
+}
+__global__ void k_test_scatter(KArgs A, int n, double *st18, int *ic4, unsigned long long seed, const unsigned long long *ids, long long *nd) {
+    extern __shared__ double sh[];
+    Lds l = lds_stage(sh, A.g);
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    bool stokes = A.par.use_stokes, dust = A.par.DGR > 0.0;
+    if (stokes && dust) test_scatter_one<true, true>(A, l, st18 + 18 * i, ic4 + 4 * i, seed, ids[i], nd + i);
+    else if (stokes) test_scatter_one<true, false>(A, l, st18 + 18 * i, ic4 + 4 * i, seed, ids[i], nd + i);
+    else if (dust) test_scatter_one<false, true>(A, l, st18 + 18 * i, ic4 + 4 * i, seed, ids[i], nd + i);
+    else test_scatter_one<false, false>(A, l, st18 + 18 * i, ic4 + 4 * i, seed, ids[i], nd + i);
+}
+
+template <typename T> struct DevBuf {
+    T *p = nullptr; size_t n = 0;
+    int alloc(size_t cnt, const T *src) { n = cnt; if (hipMalloc(&p, cnt * sizeof(T) + 8) != hipSuccess) return 1; if (src && hipMemcpy(p, src, cnt * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return 1; return 0; }
+    int back(T *dst) { return hipMemcpy(dst, p, n * sizeof(T), hipMemcpyDeviceToHost) != hipSuccess; }
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+static KArgs probe_args(lart_gpu *c) {
+    KArgs A{}; A.par = c->par; A.g = c->g; A.t = c->t; A.mu = c->mu; A.obs = c->d_obs; A.nobs = 0; A.nxim = c->nxim; A.nyim = c->nyim; A.dxim = c->dxim; A.dyim = c->dyim; A.ctl = c->d_ctl;
+    return A;
+}
+static size_t probe_shmem(lart_gpu *c) { return (size_t)(VT_END + c->g.nx + c->g.ny + c->g.nz + 3) * sizeof(double); }
+
+extern "C" int lart_gpu_test_voigt(lart_gpu *c, int32_t n, const double *x, const double *a, double *h) {
+    if (!c || n < 0) return fail("test_voigt: bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    DevBuf<double> dx, da, dh; if (dx.alloc(n, x) || da.alloc(n, a) || dh.alloc(n, nullptr)) return fail("test_voigt: hipMalloc failed");
+    DGrid g{}; g.nx = g.ny = g.nz = 0; double zero[3] = {0, 0, 0}; DevBuf<double> df; if (df.alloc(3, zero)) return fail("test_voigt: hipMalloc failed"); g.faces = df.p;
+    hipLaunchKernelGGL(k_test_voigt, dim3((n + 255) / 256), dim3(256), (VT_END + 3) * sizeof(double), c->stream, g, n, dx.p, da.p, dh.p);
+    HIPCHK(hipGetLastError()); HIPCHK(hipStreamSynchronize(c->stream));
+    if (dh.back(h)) return fail("test_voigt: copy back failed");
+    return 0;
+}
+extern "C" int lart_gpu_test_rand(lart_gpu *c, int32_t what, uint64_t seed, uint64_t id, int32_t n, double p1, double p2, double *out) {
+    if (!c || n < 0) return fail("test_rand: bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    DevBuf<double> d; if (d.alloc(n, nullptr)) return fail("test_rand: hipMalloc failed");
+    hipLaunchKernelGGL(k_test_rand, dim3(1), dim3(64), 0, c->stream, what, (unsigned long long)seed, (unsigned long long)id, n, p1, p2, d.p);
+    HIPCHK(hipGetLastError()); HIPCHK(hipStreamSynchronize(c->stream));
+    if (d.back(out)) return fail("test_rand: copy back failed");
+    return 0;
+}
+extern "C" int lart_gpu_test_raytrace(lart_gpu *c, int32_t mode, int32_t n, double *r8, int32_t *ic4, const double *tq, double *tau_out) {
+    if (!c || n < 0 || !c->d_cell) return fail("test_raytrace: needs a context with a medium");
+    int kind = mode / 10, var = mode % 10;
+    if (kind < 0 || kind > 2 || var < 0 || var > 2 || (kind == 2 && var != 0)) return fail("test_raytrace: bad mode");
+    HIPCHK(hipSetDevice(c->device));
+    if (!c->d_tally) { if (build_tally(c)) return 1; }
+    // host-side shape check before touching the kernel: every start cell must be a valid gather target
+    for (int i = 0; i < n; i++) {
+        const int *q = ic4 + 4 * i;
+        if (q[0] < 1 || q[0] > c->g.nx + 1 || q[1] < 1 || q[1] > c->g.ny + 1 || q[2] < 1 || q[2] > c->g.nz + 1) return fail("test_raytrace: start cell outside the grid");
+        if (q[0] > c->g.nx || q[1] > c->g.ny || q[2] > c->g.nz) return fail("test_raytrace: probe start cells must be interior (1..n)");
+    }
+    DevBuf<double> dr, dt, dq; DevBuf<int> di;
+    if (dr.alloc((size_t)8 * n, r8) || di.alloc((size_t)4 * n, ic4) || dt.alloc(n, nullptr) || dq.alloc(n, tq)) return fail("test_raytrace: hipMalloc failed");
+    KArgs A = probe_args(c);
+    hipLaunchKernelGGL(k_test_raytrace, dim3((n + 63) / 64), dim3(64), probe_shmem(c), c->stream, A, mode, n, dr.p, di.p, tq ? dq.p : nullptr, dt.p);
+    HIPCHK(hipGetLastError()); HIPCHK(hipStreamSynchronize(c->stream));
+    if (dr.back(r8) || di.back(ic4) || (tau_out && dt.back(tau_out))) return fail("test_raytrace: copy back failed");
+    return 0;
+}
+extern "C" int lart_gpu_test_scatter(lart_gpu *c, int32_t n, double *st18, int32_t *ic4, uint64_t seed, const uint64_t *ids, int64_t *ndraws) {
+    if (!c || n < 0 || !c->d_cell) return fail("test_scatter: needs a context with a medium");
+    HIPCHK(hipSetDevice(c->device));
+    if (!c->d_tally) { if (build_tally(c)) return 1; }
+    for (int i = 0; i < n; i++) { const int *q = ic4 + 4 * i;
+        if (q[0] < 1 || q[0] > c->g.nx || q[1] < 1 || q[1] > c->g.ny || q[2] < 1 || q[2] > c->g.nz) return fail("test_scatter: cell outside the grid"); }
+    if (c->par.use_stokes && c->par.DGR > 0.0 && c->mu.nPDF == 0) return fail("test_scatter: Stokes dust scattering needs a Mueller table");
+    DevBuf<double> ds; DevBuf<int> di; DevBuf<unsigned long long> dd; DevBuf<long long> dn;
+    if (ds.alloc((size_t)18 * n, st18) || di.alloc((size_t)4 * n, ic4) || dd.alloc(n, (const unsigned long long *)ids) || dn.alloc(n, nullptr)) return fail("test_scatter: hipMalloc failed");
+    KArgs A = probe_args(c);
+    hipLaunchKernelGGL(k_test_scatter, dim3((n + 63) / 64), dim3(64), probe_shmem(c), c->stream, A, n, ds.p, di.p, (unsigned long long)seed, dd.p, dn.p);
+    HIPCHK(hipGetLastError()); HIPCHK(hipStreamSynchronize(c->stream));
+    if (ds.back(st18) || di.back(ic4) || dn.back((long long *)ndraws)) return fail("test_scatter: copy back failed");
+    return 0;
+}

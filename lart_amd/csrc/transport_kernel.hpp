@@ -1,0 +1,113 @@
+// transport_kernel.hpp -- the persistent-lane transport kernel.
+//
+// Reference loop being replaced: run_equal_number, run_simulation_mod.f90:150-202 (one packet at a
+// time per MPI rank).  Here every lane owns one resident packet (state in a SoA pool in HBM between
+// launches, in registers inside a launch), advances it by at most `max_events` scattering events per
+// launch and, when its packet escapes or is absorbed, draws the next photon ordinal from a device
+// counter (replaces the master/worker token protocol, run_simulation_mod.f90:31-64).
+#pragma once
+#include "lart_device.hpp"
+
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+template <int VAR, bool STOKES, bool DUST, bool PEEL>
+__global__ __launch_bounds__(256) void transport_kernel(KArgs A) {
+    extern __shared__ double sh[];
+    const Lds l = lds_stage(sh, A.g);
+    const lart_params &par = A.par;
+    const int64_t lane = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // pool.n is a multiple of blockDim.x
+    const int64_t P = A.pool.n;
+    double *F = A.pool.f;
+
+    Photon p; Rng g;
+    int flags = A.pool.flags[lane];
+    bool alive = flags & FLAG_ALIVE, first = flags & FLAG_FIRST;
+    long long k = A.pool.k[lane];
+    if (alive) {
+        p.x = F[F_X * P + lane]; p.y = F[F_Y * P + lane]; p.z = F[F_Z * P + lane];
+        p.kx = F[F_KX * P + lane]; p.ky = F[F_KY * P + lane]; p.kz = F[F_KZ * P + lane];
+        p.xfreq = F[F_XFREQ * P + lane]; p.wgt = F[F_WGT * P + lane]; p.nsg = F[F_NSG * P + lane]; p.nsd = F[F_NSD * P + lane];
+        if (STOKES) {
+            p.mx = F[F_MX * P + lane]; p.my = F[F_MY * P + lane]; p.mz = F[F_MZ * P + lane];
+            p.nx = F[F_NX * P + lane]; p.ny = F[F_NY * P + lane]; p.nz = F[F_NZ * P + lane];
+            p.Q = F[F_Q * P + lane]; p.U = F[F_U * P + lane]; p.V = F[F_V * P + lane];
+        }
+        p.ic = A.pool.ic[lane]; p.jc = A.pool.jc[lane]; p.kc = A.pool.kc[lane]; p.inside = true; p.xfreq_ref = 0.0;
+        g.init(A.seed, (uint64_t)(A.first_id + k * A.stride), A.pool.rng_n[lane]);
+    }
+
+    unsigned nsteps = 0, npeel = 0, nev = 0, ndone = 0;
+    double nsg_done = 0.0, nsd_done = 0.0;
+    int budget = A.max_events;
+
+    for (;;) {
+        if (!alive) {
+            unsigned long long kk = atomicAdd(&A.ctl->next_k, 1ULL);
+            if (kk >= (unsigned long long)A.count) break;
+            k = (long long)kk;
+            g.init(A.seed, (uint64_t)(A.first_id + k * A.stride), 0);
+            generate_photon<VAR, STOKES, DUST, PEEL>(A, l, g, p, npeel);
+            alive = true; first = true;
+        }
+        if (budget <= 0) break;
+        double tau;
+        if (first) {
+            // forced first scattering: run_simulation_mod.f90:163-177, add_escaped_fraction_to_Jout :208-247
+            double tau0 = raytrace_to_edge<VAR>(A.g, l, DUST, p, p.xfreq, p.kx, p.ky, p.kz, -1.0, nsteps);
+            double esc = exp(-tau0);
+            {
+                const Cell &c = A.g.cell[cidx(A.g, p.ic, p.jc, p.kc)];
+                double u1 = c.vfx * p.kx + c.vfy * p.ky + c.vfz * p.kz;
+                Photon e = p; e.wgt = p.wgt * esc; e.xfreq_ref = (p.xfreq + u1) * (c.Dfreq / par.Dfreq_ref);
+                if (e.wgt != 0.0) tally_escape(par, A.t, e);
+            }
+            double wgt1 = 1.0 - esc;
+            p.wgt = p.wgt * wgt1;
+            tau = (tau0 > 0.0) ? -log(1.0 - g.next() * wgt1) : LART_HUGEST;
+            first = false;
+        } else tau = -log(g.next());
+        raytrace_to_tau<VAR>(A, l, DUST, p, tau, nsteps);
+        if (p.inside) { scatter_event<VAR, STOKES, DUST, PEEL>(A, l, g, p, npeel); nev++; budget--; }
+        if (!p.inside) {
+            nsg_done += p.nsg; nsd_done += p.nsd; ndone++;
+            if (A.log_nscatt) { A.log_nscatt[k] = p.nsg + p.nsd; A.log_xfreq[k] = p.xfreq_ref; }
+            alive = false;
+        }
+    }
+
+    A.pool.flags[lane] = (alive ? FLAG_ALIVE : 0) | (first ? FLAG_FIRST : 0);
+    if (alive) {
+        A.pool.k[lane] = k; A.pool.rng_n[lane] = g.n;
+        F[F_X * P + lane] = p.x; F[F_Y * P + lane] = p.y; F[F_Z * P + lane] = p.z;
+        F[F_KX * P + lane] = p.kx; F[F_KY * P + lane] = p.ky; F[F_KZ * P + lane] = p.kz;
+        F[F_XFREQ * P + lane] = p.xfreq; F[F_WGT * P + lane] = p.wgt; F[F_NSG * P + lane] = p.nsg; F[F_NSD * P + lane] = p.nsd;
+        if (STOKES) {
+            F[F_MX * P + lane] = p.mx; F[F_MY * P + lane] = p.my; F[F_MZ * P + lane] = p.mz;
+            F[F_NX * P + lane] = p.nx; F[F_NY * P + lane] = p.ny; F[F_NZ * P + lane] = p.nz;
+            F[F_Q * P + lane] = p.Q; F[F_U * P + lane] = p.U; F[F_V * P + lane] = p.V;
+        }
+        A.pool.ic[lane] = p.ic; A.pool.jc[lane] = p.jc; A.pool.kc[lane] = p.kc;
+    }
+    // per-wave pre-reduction, one atomic per wave per scalar
+    double s0 = wave_sum(nsg_done), s1 = wave_sum(nsd_done), s2 = wave_sum((double)nev), s3 = wave_sum((double)nsteps),
+           s4 = wave_sum((double)npeel), s5 = wave_sum((double)ndone), s6 = wave_sum(alive ? 1.0 : 0.0);
+    if ((threadIdx.x & 63) == 0) {
+        if (s0 != 0.0) atomicAdd(&A.t.scal[0], s0);
+        if (s1 != 0.0) atomicAdd(&A.t.scal[1], s1);
+        if (s2 != 0.0) atomicAdd(&A.t.scal[2], s2);
+        if (s3 != 0.0) atomicAdd(&A.t.scal[3], s3);
+        if (s4 != 0.0) atomicAdd(&A.t.scal[4], s4);
+        if (s5 != 0.0) atomicAdd(&A.t.scal[5], s5);
+        if (s6 != 0.0) atomicAdd(&A.ctl->n_active, (unsigned long long)(s6 + 0.5));
+    }
+}
+
+// launcher signature shared by the per-variant translation units
+typedef void (*transport_launch_fn)(int stokes, int dust, int peel, dim3 grid, dim3 block, size_t shmem, hipStream_t st, const KArgs &A);
+
+#define LART_LAUNCH_CASE(VAR, S, D, P) \
+    if (stokes == S && dust == D && peel == P) { hipLaunchKernelGGL((transport_kernel<VAR, (bool)S, (bool)D, (bool)P>), grid, block, shmem, st, A); return; }

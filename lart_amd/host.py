@@ -1,0 +1,753 @@
+"""Python mirror of the reference's host-side interface around the photon path.
+
+Same names, argument meaning and error behaviour as the Fortran host of the reference:
+    read_input        setup.f90:4-579            namelist &parameters par%... / + post-processing
+    setup_resonance_line  line_mod.f90:551-1272  (Ly-alpha branch)
+    grid_create       grid_mod_car.f90:11-1238   (analytic uniform sphere / slab / box subset)
+    observer_create   observer_rect.f90:24-326
+    run_simulation    main.f90:42                -> lart_gpu_run through the C-ABI (lart_amd.capi)
+    output_reduce     main.f90:46                -> RCCL sum of the fused device tally buffer
+    output_normalize  output_sum_rect.f90:151-487 (Jout/Jin/Jabs/Jmu + peel cubes)
+This module is host plumbing (numpy); all transport arithmetic runs in liblart_gpu.so.  The Fortran host
+with the same sequence lives in lart_amd/fhost/*.f90.
+"""
+import math
+import os
+import re
+from dataclasses import dataclass, field
+import numpy as np
+
+from . import capi
+
+PI = 3.141592653589793238462643383279502884197
+TWOPI, FOURPI = 2 * PI, 4 * PI
+UM2KM, UM2M = 1.0e-9, 1.0e-6
+H_PLANCK = 6.62607004e-34
+SPEEDC = 2.99792458e5
+DEG2RAD, RAD2DEG = PI / 180.0, 180.0 / PI
+NAN = float("nan")
+MAX_OBSERVERS = capi_max = 16
+
+
+class LartInputError(ValueError):
+    """raised where the reference prints a message and aborts (setup.f90:132-139, :244-280)"""
+
+
+def _f32(x):
+    return float(np.float32(x))
+
+
+@dataclass
+class Params:
+    """subset of params_type (define.f90:209-544) that the Cartesian hot path reads; defaults as there.
+    hgg / albedo / cext_dust defaults are float32 literals widened to f64 (define.f90:454-456)."""
+    no_photons: float = 1e5
+    iseed: int = 0
+    temperature: float = 1e4
+    taumax: float = -999.0
+    tauhomo: float = -999.0
+    tau0: float = -999.0
+    N_HImax: float = -999.0
+    N_HIhomo: float = -999.0
+    N_HI: float = -999.0
+    Vexp: float = 0.0
+    Vx: float = 0.0
+    Vy: float = 0.0
+    Vz: float = 0.0
+    comoving_source: bool = True
+    recoil: bool = False
+    core_skip: bool = False
+    core_skip_global: bool = False
+    xyz_symmetry: bool = False
+    xy_periodic: bool = False
+    geometry: str = ""
+    velocity_type: str = ""
+    nx: int = 1
+    ny: int = 1
+    nz: int = 11
+    nr: int = -999
+    xmax: float = 1.0
+    ymax: float = 1.0
+    zmax: float = 1.0
+    rmin: float = -999.0
+    rmax: float = -999.0
+    source_rmax: float = -999.0
+    xs_point: float = 0.0
+    ys_point: float = 0.0
+    zs_point: float = 0.0
+    xfreq0: float = 0.0
+    xfreq_min: float = NAN
+    xfreq_max: float = NAN
+    nxfreq: int = 121
+    velocity_min: float = NAN
+    velocity_max: float = NAN
+    nvelocity: int = 0
+    source_geometry: str = "point"
+    spectral_type: str = "voigt"
+    distance2cm: float = -999.9
+    distance_unit: str = ""
+    out_file: str = ""
+    out_merge: bool = False
+    file_format: str = "hdf5"
+    use_master_slave: bool = True
+    num_send_at_once: int = 100
+    use_reduced_wgt: bool = False
+    use_stokes: bool = False
+    save_all: bool = False
+    save_Jin: bool = True
+    save_Jabs: bool = True
+    save_Jmu: bool = False
+    nmu: int = 11
+    save_peeloff: bool = False
+    save_peeloff_2D: bool = False
+    save_peeloff_3D: bool = True
+    save_sightline_tau: bool = False
+    save_direc0: bool = False
+    hgg: float = _f32(0.6761)
+    albedo: float = _f32(0.3253)
+    cext_dust: float = _f32(1.6059e-21)
+    DGR: float = 0.0
+    scatt_mat_file: str = ""
+    nprint: int = 10000000
+    no_print: float = 0.0
+    nobs: int = 1
+    nxim: int = 0
+    nyim: int = 0
+    distance: float = NAN
+    alpha: list = field(default_factory=lambda: [NAN] * MAX_OBSERVERS)
+    beta: list = field(default_factory=lambda: [NAN] * MAX_OBSERVERS)
+    gamma: list = field(default_factory=lambda: [NAN] * MAX_OBSERVERS)
+    obsx: list = field(default_factory=lambda: [NAN] * MAX_OBSERVERS)
+    obsy: list = field(default_factory=lambda: [NAN] * MAX_OBSERVERS)
+    obsz: list = field(default_factory=lambda: [NAN] * MAX_OBSERVERS)
+    dxim: float = NAN
+    dyim: float = NAN
+    nside: int = 0
+    # derived (not inputs)
+    nphotons: int = 100000
+    mu_min: float = -1.0
+    dmu: float = 0.0
+    atau3: float = 0.0
+    N_gasmax: float = -999.0
+    N_gashomo: float = -999.0
+
+
+# fields of params_type that exist in the reference but select physics outside this path: accepted at their
+# default, rejected ("not supported") when set to something that would change the path
+_UNSUPPORTED_DEFAULTS = {
+    "use_amr_grid": False, "use_clump_medium": False, "fine_structure": False, "include_deuterium": False,
+    "line_id": "ly_alpha", "h2_model": "none", "xy_symmetry": False, "z_symmetry": False, "bturb": -999.0,
+    "dens_file": "", "temp_file": "", "velo_file": "", "emiss_file": "", "cart_file": "", "input_field": "",
+    "star_file": "", "use_cie_condition": False, "density_rscale": -999.9, "density_zscale": -999.9,
+    "density_alpha": 0.0, "cone_opening": 0.0, "Omega": 0.0, "save_all_photons": False, "temperature0": -999.0,
+    "line_prof_file": "", "luminosity": 1.0, "save_backup": False, "save_input_grid": False,
+    "save_dust_scattered": False, "intensity_unit": -999, "out_bitpix": 0,
+}
+
+
+def _parse_value(s):
+    s = s.strip().rstrip(",")
+    if s.lower() in (".true.", "t", ".t."):
+        return True
+    if s.lower() in (".false.", "f", ".f."):
+        return False
+    if s[:1] in "'\"":
+        return s.strip("'\"")
+    t = re.sub(r"[dD]", "e", s)
+    try:
+        return int(t)
+    except ValueError:
+        return float(t)
+
+
+def read_namelist(path):
+    """&parameters par%name = value ... /  (setup.f90:27-40).  Unknown names fail like a Fortran namelist read."""
+    par = Params()
+    txt = open(path).read()
+    m = re.search(r"&parameters(.*?)^\s*/", txt, re.S | re.M | re.I)
+    if not m:
+        raise LartInputError("no &parameters namelist group in " + path)
+    for line in m.group(1).splitlines():
+        line = line.split("!")[0].strip()
+        if not line:
+            continue
+        mm = re.match(r"par%(\w+)\s*(?:\((\d+)\))?\s*=\s*(.+)$", line, re.I)
+        if not mm:
+            raise LartInputError("cannot parse namelist line: " + line)
+        name, idx, val = mm.group(1), mm.group(2), _parse_value(mm.group(3))
+        set_param(par, name, val, idx)
+    return par
+
+
+def set_param(par, name, val, idx=None):
+    if name in _UNSUPPORTED_DEFAULTS:
+        if val != _UNSUPPORTED_DEFAULTS[name]:
+            raise LartInputError("par%%%s = %r is not supported by this path (only the default %r)" % (name, val, _UNSUPPORTED_DEFAULTS[name]))
+        return
+    if not hasattr(par, name):
+        raise LartInputError("unknown namelist variable par%" + name)
+    cur = getattr(par, name)
+    if isinstance(cur, list):
+        vals = val if isinstance(val, (list, tuple)) else [val]
+        i0 = int(idx) - 1 if idx else 0
+        for k, v in enumerate(vals):
+            cur[i0 + k] = float(v)
+    elif isinstance(cur, bool):
+        setattr(par, name, bool(val))
+    elif isinstance(cur, int):
+        setattr(par, name, int(val))
+    elif isinstance(cur, float):
+        setattr(par, name, float(val))
+    else:
+        setattr(par, name, str(val))
+
+
+@dataclass
+class Line:
+    """line_type (define.f90:639-680) for Ly-alpha: line_mod.f90:1241-1270"""
+    wavelength0: float = 0.1215668237310
+    damping: float = 6.2649e8
+    cross0: float = 0.026540083434 / math.sqrt(PI) * (0.27760 + 0.13881 + 0.0)
+    vtherm1: float = 0.12895319011972164 / math.sqrt(1.00797)
+    g_recoil0: float = (H_PLANCK / 1.67262192e-24 / 1.00797) / (0.1215668237310 * UM2M) ** 2
+    E1: float = 1.0
+    E2: float = 0.0
+    E3: float = 1.0
+
+
+def vtherm_total(line, T):
+    """define.f90:928-933 with par%bturb unset"""
+    return line.vtherm1 * math.sqrt(T)
+
+
+@dataclass
+class ScattMat:
+    nPDF: int = 0
+    coss: np.ndarray = None
+    S11: np.ndarray = None
+    S12: np.ndarray = None
+    S33: np.ndarray = None
+    S34: np.ndarray = None
+    phase_PDF: np.ndarray = None
+    alias: np.ndarray = None
+
+
+def random_alias_setup(probs):
+    """random_mt.f90:2016-2067; returns (scaled probs, 1-based alias)"""
+    n = len(probs)
+    probs = np.array(probs, dtype=np.float64) * n
+    alias = np.zeros(n, dtype=np.int32)
+    small = [i + 1 for i in range(n) if probs[i] < 1.0]
+    large = [i + 1 for i in range(n) if not probs[i] < 1.0]
+    while small and large:
+        ks, kl = small.pop(), large.pop()
+        alias[ks - 1] = kl
+        probs[kl - 1] = probs[kl - 1] + probs[ks - 1] - 1.0
+        (small if probs[kl - 1] < 1.0 else large).append(kl)
+    return probs, alias
+
+
+def setup_scattering_matrix(par, path):
+    """setup.f90:581-649: header overrides albedo/hgg/cext_dust; S11..S34 normalised by the trapezoid integral of S11"""
+    with open(path) as f:
+        f.readline()
+        h = f.readline().split()
+        f.readline()
+        par.cext_dust, par.albedo, par.hgg, n = float(h[1]), float(h[2]), float(h[3]), int(h[4])
+        tab = np.array([[float(t) for t in f.readline().split()[:5]] for _ in range(n)])
+    sm = ScattMat(nPDF=n, coss=tab[:, 0].copy(), S11=tab[:, 1].copy(), S12=tab[:, 2].copy(), S33=tab[:, 3].copy(), S34=tab[:, 4].copy())
+    norm = 0.0
+    for i in range(1, n):
+        norm = norm + 0.5 * (sm.S11[i] + sm.S11[i - 1]) * abs(sm.coss[i] - sm.coss[i - 1])
+    for a in (sm.S11, sm.S12, sm.S33, sm.S34):
+        a /= norm
+    pdf = (sm.S11[:-1] + sm.S11[1:]) / 2.0
+    pdf = pdf / pdf.sum()
+    sm.phase_PDF, sm.alias = random_alias_setup(pdf)
+    return sm
+
+
+def read_input(par, line=None):
+    """post-processing part of read_input (setup.f90:42-562) for the fields this path uses. Returns (par, line, scatt_mat)."""
+    line = line or Line()
+    if par.no_photons >= 1:
+        par.nphotons = int(par.no_photons)
+    for n in ("geometry", "source_geometry", "velocity_type", "spectral_type"):
+        setattr(par, n, getattr(par, n).lower())
+    if par.geometry == "":
+        par.geometry = "sphere"
+    elif par.geometry == "box":
+        par.geometry = "rectangle"
+    if par.geometry not in ("sphere", "rectangle"):
+        raise LartInputError("par%%geometry = '%s' is not supported by this path" % par.geometry)
+    if par.source_geometry == "sphere":
+        par.source_geometry = "uniform_sphere"
+    if par.source_geometry not in ("point", "uniform_sphere"):
+        raise LartInputError("par%%source_geometry = '%s' is not supported by this path" % par.source_geometry)
+    if par.spectral_type not in ("voigt", "monochromatic"):
+        raise LartInputError("par%%spectral_type = '%s' is not supported by this path" % par.spectral_type)
+    if par.velocity_type not in ("", "hubble", "constant_radial", "parallel_velocity"):
+        raise LartInputError("par%%velocity_type = '%s' is not supported by this path" % par.velocity_type)
+    if par.temperature <= 0.0:
+        raise LartInputError("ERROR: par%temperature must be > 0 K (or set par%bturb > 0)")
+    if par.nx == 1 or par.ny == 1 or par.nz == 1:
+        par.xyz_symmetry = False                                          # setup.f90:167
+    if par.nside > 0:
+        raise LartInputError("HEALPix inside observers (par%nside > 0) are not built yet")
+    if not (par.save_peeloff_2D or par.save_peeloff_3D):                  # :188-206
+        par.save_peeloff = False
+    if par.nxim > 0 and par.nyim > 0:
+        par.save_peeloff = True
+    if par.save_peeloff and par.xyz_symmetry:
+        par.save_peeloff = False
+        print("---> peelingoff is not allowed for a geometry with the xyz_symmetry.\n---> setting par%save_peeloff = .false.")
+    if not par.save_peeloff:
+        par.save_peeloff_2D = par.save_peeloff_3D = False
+    if par.tau0 > 0.0 and par.taumax < 0.0:                               # :228-233
+        par.taumax = par.tau0
+    if par.N_HI > 0.0 and par.N_HImax < 0.0:
+        par.N_HImax = par.N_HI
+    if par.N_HImax > 0.0 and par.N_gasmax < 0.0:
+        par.N_gasmax = par.N_HImax
+    if par.N_HIhomo > 0.0 and par.N_gashomo < 0.0:
+        par.N_gashomo = par.N_HIhomo
+    if par.cext_dust <= 0.0:
+        par.DGR = 0.0
+    if par.DGR == 0.0:
+        par.save_Jabs = False
+    if par.core_skip_global:
+        par.core_skip = True
+    if par.save_Jmu:                                                      # :367-381
+        if par.nmu < 1:
+            raise LartInputError("ERROR: par%nmu must be >= 1 when par%save_Jmu = .true.")
+        if par.xyz_symmetry:
+            par.mu_min, par.dmu = 0.0, 1.0 / par.nmu
+        else:
+            par.mu_min, par.dmu = -1.0, 2.0 / par.nmu
+    if par.nr > 1:
+        par.nx = par.ny = par.nz = par.nr
+    if par.geometry == "sphere":                                          # :398-428
+        if not par.xy_periodic:
+            c = [v for v in (par.rmax, par.xmax, par.ymax, par.zmax) if v > 0.0]
+            if c:
+                par.rmax = par.xmax = par.ymax = par.zmax = max(c)
+            par.nx = par.ny = par.nz = max(par.nx, par.ny, par.nz)
+    else:
+        par.rmax = -1.0
+    if par.source_rmax < 0.0:
+        par.source_rmax = par.rmax
+    if par.distance2cm < 0.0:                                             # :473-489
+        par.distance2cm = {"kpc": 3.0856776e21, "pc": 3.0856776e18, "au": 1.4960e13, "": 1.0}.get(par.distance_unit, 3.0856776e21)
+    scatt_mat = ScattMat()
+    if par.scatt_mat_file and par.DGR > 0.0:                              # :496-500
+        scatt_mat = setup_scattering_matrix(par, par.scatt_mat_file)
+    elif par.use_stokes:
+        par.DGR = 0.0
+    if par.DGR == 0.0:
+        par.save_Jabs = False
+    return par, line, scatt_mat
+
+
+@dataclass
+class Grid:
+    """grid_type (define.f90:117-206): geometry scalars + read-only tables + frequency axis"""
+    nx: int = 0
+    ny: int = 0
+    nz: int = 0
+    i0: int = 0
+    j0: int = 0
+    k0: int = 0
+    xmin: float = 0.0
+    ymin: float = 0.0
+    zmin: float = 0.0
+    xmax: float = 0.0
+    ymax: float = 0.0
+    zmax: float = 0.0
+    dx: float = 0.0
+    dy: float = 0.0
+    dz: float = 0.0
+    rmin: float = 0.0
+    rmax: float = 0.0
+    xface: np.ndarray = None
+    yface: np.ndarray = None
+    zface: np.ndarray = None
+    rhokap: np.ndarray = None
+    voigt_a: np.ndarray = None
+    Dfreq: np.ndarray = None
+    vfx: np.ndarray = None
+    vfy: np.ndarray = None
+    vfz: np.ndarray = None
+    rhokapD: np.ndarray = None
+    Dfreq_ref: float = 0.0
+    voigt_amean: float = 0.0
+    nxfreq: int = 0
+    xfreq_min: float = 0.0
+    xfreq_max: float = 0.0
+    dxfreq: float = 0.0
+    dwave: float = 0.0
+    xfreq: np.ndarray = None
+    velocity: np.ndarray = None
+    wavelength: np.ndarray = None
+    xcrit: float = 0.0
+    xcrit2: float = 0.0
+    taupole: float = 0.0
+    tauhomo: float = 0.0
+
+
+def _sym_axis(n, vmax):
+    if (n // 2) * 2 == n:
+        return vmax / n, 0.0, 1
+    d = vmax / (n - 0.5)
+    return d, -d / 2.0, 2
+
+
+def voigt_center(a):
+    """H(0,a) from the first Harris terms on the x=0 table node: voigt_mod.f90:691-700 with v = 0"""
+    return 1.0 + a * (-1.1283791671 + a * 1.0)
+
+
+def grid_create(par, line):
+    """grid_mod_car.f90:73-1238, analytic-medium subset (no input files)."""
+    g = Grid(nx=par.nx, ny=par.ny, nz=par.nz, xmax=par.xmax, ymax=par.ymax, zmax=par.zmax, rmin=par.rmin, rmax=par.rmax)
+    nx, ny, nz = g.nx, g.ny, g.nz
+    if par.xyz_symmetry:
+        g.dx, g.xmin, g.i0 = _sym_axis(nx, g.xmax)
+        g.dy, g.ymin, g.j0 = _sym_axis(ny, g.ymax)
+        g.dz, g.zmin, g.k0 = _sym_axis(nz, g.zmax)
+    else:
+        g.dx, g.dy, g.dz = 2.0 * par.xmax / nx, 2.0 * par.ymax / ny, 2.0 * par.zmax / nz
+        g.xmin, g.ymin, g.zmin = -g.xmax, -g.ymax, -g.zmax
+    g.xface = np.arange(nx + 1) * g.dx + g.xmin
+    g.yface = np.arange(ny + 1) * g.dy + g.ymin
+    g.zface = np.arange(nz + 1) * g.dz + g.zmin
+    xx = (g.xface[:-1] + g.xface[1:]) / 2.0
+    yy = (g.yface[:-1] + g.yface[1:]) / 2.0
+    zz = (g.zface[:-1] + g.zface[1:]) / 2.0
+    shape = (nx, ny, nz)
+    vth = vtherm_total(line, par.temperature)
+    g.Dfreq_ref = vth / (line.wavelength0 * UM2KM)
+    g.Dfreq = np.full(shape, vth / (line.wavelength0 * UM2KM), order="F")
+    g.voigt_a = (line.damping / FOURPI) / g.Dfreq
+    par.distance_unit, par.distance2cm = "", 1.0                          # :352-365
+    g.rhokap = np.ones(shape, order="F")
+    g.rhokapD = np.full(shape, par.cext_dust * par.DGR, order="F") if par.DGR > 0.0 else None
+    X, Y, Z = np.meshgrid(xx, yy, zz, indexing="ij")
+    rr = np.sqrt(X ** 2 + Y ** 2 + Z ** 2)
+    if par.rmax > 0.0:                                                    # :367-395
+        out = (rr < par.rmin) | (rr > par.rmax)
+        g.rhokap[out] = 0.0
+        if g.rhokapD is not None:
+            g.rhokapD[out] = 0.0
+    g.rhokap = g.rhokap / g.Dfreq * line.cross0                           # :487-493
+    if par.rmax > 0.0 and par.rmin > 0.0:
+        opac_length = par.rmax - par.rmin
+    elif par.rmax > 0.0:
+        opac_length = par.rmax
+    elif g.zmax == -g.zmin:
+        opac_length = (g.zmax - g.zmin) / 2.0
+    else:
+        opac_length = g.zmax - g.zmin
+    nxcen, nycen = (1, 1) if par.xyz_symmetry else ((nx + 1) // 2, (ny + 1) // 2)
+    H0 = voigt_center(g.voigt_a)
+    pole_k = g.rhokap[nxcen - 1, nycen - 1, :] * H0[nxcen - 1, nycen - 1, :]
+    pole_n = g.rhokap[nxcen - 1, nycen - 1, :] * g.Dfreq[nxcen - 1, nycen - 1, :]
+    nadd = np.ones(shape)
+    if par.xyz_symmetry:
+        if nx % 2:
+            nadd[0, :, :] /= 2.0
+        if ny % 2:
+            nadd[:, 0, :] /= 2.0
+        if nz % 2:
+            nadd[:, :, 0] /= 2.0
+    gas = g.rhokap > 0.0
+
+    def pole(v):
+        s = _seqsum(v)
+        if par.xyz_symmetry:
+            return (s - v[0] / 2.0) * g.dz if nz % 2 else s * g.dz
+        return s * g.dz / 2.0 if g.zmax == -g.zmin else s * g.dz
+
+    opac_norm = None
+    if par.taumax > 0.0:                                                  # :518-538
+        opac_norm = par.taumax / pole(pole_k)
+    elif par.tauhomo > 0.0:                                               # :539-566
+        opac_norm = par.tauhomo / ((g.rhokap * H0 * nadd)[gas].sum() / nadd[gas].sum() * opac_length)
+    elif par.N_gasmax > 0.0:                                              # :567-586
+        opac_norm = par.N_gasmax / (pole(pole_n) / line.cross0)
+    elif par.N_gashomo > 0.0:                                             # :587-615
+        opac_norm = par.N_gashomo / ((g.rhokap * g.Dfreq * nadd)[gas].sum() / nadd[gas].sum() / line.cross0 * opac_length)
+    if opac_norm is not None:
+        g.rhokap *= opac_norm
+        if g.rhokapD is not None:
+            g.rhokapD *= opac_norm
+        pole_k = pole_k * opac_norm
+        pole_n = pole_n * opac_norm
+    g.tauhomo = (g.rhokap * H0 * nadd)[gas].sum() / nadd[gas].sum() * opac_length      # :617-640
+    g.taupole = pole(pole_k)
+    N_gashomo = (g.rhokap * g.Dfreq * nadd)[gas].sum() / nadd[gas].sum() / line.cross0 * opac_length
+    N_gaspole = pole(pole_n) / line.cross0
+    if par.taumax <= 0.0:
+        par.taumax = g.taupole
+    if par.tauhomo <= 0.0:
+        par.tauhomo = g.tauhomo
+    if par.N_gasmax <= 0.0:
+        par.N_gasmax = N_gaspole
+    if par.N_gashomo <= 0.0:
+        par.N_gashomo = N_gashomo
+    g.vfx = np.zeros(shape, order="F"); g.vfy = np.zeros(shape, order="F"); g.vfz = np.zeros(shape, order="F")
+    if par.velocity_type:                                                 # :786-946
+        rpeak = max(g.xmax, g.ymax, g.zmax) if par.rmax <= 0.0 else par.rmax
+        if par.velocity_type == "hubble":
+            g.vfx[gas] = ((par.Vexp / vth) * X / rpeak)[gas]; g.vfy[gas] = ((par.Vexp / vth) * Y / rpeak)[gas]; g.vfz[gas] = ((par.Vexp / vth) * Z / rpeak)[gas]
+        elif par.velocity_type == "constant_radial":
+            m = gas & (rr > g.dz / 10.0)
+            with np.errstate(invalid="ignore", divide="ignore"):
+                g.vfx[m] = (par.Vexp / vth * X / rr)[m]; g.vfy[m] = (par.Vexp / vth * Y / rr)[m]; g.vfz[m] = (par.Vexp / vth * Z / rr)[m]
+        else:
+            g.vfx[gas] = par.Vx / vth; g.vfy[gas] = par.Vy / vth; g.vfz[gas] = par.Vz / vth
+    g.voigt_amean = (line.damping / FOURPI) / g.Dfreq_ref                 # :1150-1154
+    atau0 = g.voigt_amean * par.tauhomo
+    car_setup_freq_grid(par, line, g)
+    at = atau0 if par.core_skip_global else atau0 / (g.xmax / g.dx)       # :1186-1219
+    if at > 1.0:
+        xi, chi = (0.6, 1.2) if at <= 60.0 else (1.4, 0.6)
+        g.xcrit = 0.02 * math.exp(xi * math.log(at) ** chi)
+        g.xcrit2 = g.xcrit ** 2
+    return g
+
+
+def _seqsum(v):
+    s = 0.0
+    for t in v:
+        s = s + float(t)
+    return s
+
+
+def car_setup_freq_grid(par, line, g):
+    """grid_mod_car.f90:1442-1548"""
+    par.atau3 = (g.voigt_amean * par.tauhomo) ** (1.0 / 3.0)
+    vth = vtherm_total(line, par.temperature)
+    if math.isfinite(par.velocity_min) and math.isfinite(par.velocity_max):
+        if par.nvelocity == 0 and par.nxfreq > 0:
+            par.nvelocity = par.nxfreq
+        if par.nvelocity > 0:
+            par.nxfreq = par.nvelocity
+        par.xfreq_min, par.xfreq_max = -par.velocity_max / vth, -par.velocity_min / vth
+    g.nxfreq = par.nxfreq
+    if not (math.isfinite(par.xfreq_max) and math.isfinite(par.xfreq_min)):
+        xscale = 25.0 if par.taumax <= 5e1 else 14.0 if par.taumax <= 5e2 else 10.0 if par.taumax <= 5e3 else 5.0
+        if par.Vexp == 0.0:
+            par.xfreq_max = math.floor(xscale * par.atau3) + 1
+            par.xfreq_min = -(math.floor(xscale * par.atau3 + 0.0) + 1)
+        elif par.Vexp > 0.0:
+            par.xfreq_max = math.floor(xscale * par.atau3) + 1
+            par.xfreq_min = -(math.floor(xscale * par.atau3 + abs(par.Vexp) / vth + 0.0) + 1)
+        else:
+            par.xfreq_max = math.floor(xscale * par.atau3 + abs(par.Vexp) / vth) + 1
+            par.xfreq_min = -(math.floor(xscale * par.atau3 + 0.0) + 1)
+    g.dxfreq = (par.xfreq_max - par.xfreq_min) / par.nxfreq
+    g.xfreq_max, g.xfreq_min = float(par.xfreq_max), float(par.xfreq_min)
+    g.xfreq = (np.arange(1, g.nxfreq + 1) - 0.5) * g.dxfreq + g.xfreq_min
+    g.velocity = -vth * g.xfreq
+    g.dwave = vth / SPEEDC * (line.wavelength0 * 1e4) * g.dxfreq
+    g.wavelength = (g.velocity / SPEEDC + 1.0) * (line.wavelength0 * 1e4)
+
+
+@dataclass
+class Observers:
+    nobs: int = 0
+    xyz: np.ndarray = None
+    rmatrix: np.ndarray = None      # (nobs, 3, 3) row r, column c = rmatrix(r+1, c+1)
+    dxim: float = 0.0
+    dyim: float = 0.0
+    nxim: int = 0
+    nyim: int = 0
+    steradian_pix: float = 0.0
+
+
+def observer_create(par):
+    """observer_create_outside: observer_rect.f90:24-326 (rotation centre at the origin)"""
+    if not par.save_peeloff:
+        return Observers()
+    fin = math.isfinite
+    maxsz = max(par.xmax, par.ymax, par.zmax)
+    for i in range(MAX_OBSERVERS):
+        if fin(par.beta[i]) and not fin(par.alpha[i]):
+            par.alpha[i] = 0.0
+        if fin(par.alpha[i]) and not fin(par.beta[i]):
+            par.beta[i] = 0.0
+    if not (fin(par.alpha[0]) and fin(par.beta[0])) and not (fin(par.obsx[0]) and fin(par.obsy[0]) and fin(par.obsz[0])):
+        if not fin(par.distance):
+            par.distance = maxsz * 100.0
+        par.obsx[0], par.obsy[0], par.obsz[0] = 0.0, 0.0, 1.0
+        par.alpha[0], par.beta[0] = 0.0, 0.0
+
+    def default_gamma(i):
+        if not fin(par.gamma[i]):
+            par.gamma[i] = 90.0 if 0.0 < par.beta[i] <= 90.0 else (-90.0 if par.beta[i] > 90.0 else 0.0)
+
+    xyz, trig = [], []
+    if fin(par.alpha[0]) and fin(par.beta[0]):
+        n = sum(1 for i in range(MAX_OBSERVERS) if fin(par.alpha[i]) and fin(par.beta[i]))
+        if not fin(par.distance):
+            par.distance = maxsz * 100.0
+        for i in range(n):
+            default_gamma(i)
+            ca, sa = math.cos(par.alpha[i] * DEG2RAD), math.sin(par.alpha[i] * DEG2RAD)
+            cb, sb = math.cos(par.beta[i] * DEG2RAD), math.sin(par.beta[i] * DEG2RAD)
+            cg, sg = math.cos(par.gamma[i] * DEG2RAD), math.sin(par.gamma[i] * DEG2RAD)
+            xyz.append((par.distance * ca * sb, par.distance * sa * sb, par.distance * cb))
+            trig.append((ca, sa, cb, sb, cg, sg))
+    else:
+        n = sum(1 for i in range(MAX_OBSERVERS) if fin(par.obsx[i]) and fin(par.obsy[i]) and fin(par.obsz[i]))
+        if not fin(par.distance):
+            par.distance = math.sqrt(par.obsx[0] ** 2 + par.obsy[0] ** 2 + par.obsz[0] ** 2)
+            if par.distance < 10.0 * maxsz:
+                par.distance = maxsz * 100.0
+        eps = np.finfo(np.float64).eps
+        for i in range(n):
+            default_gamma(i)
+            ds = par.distance / math.sqrt(par.obsx[i] ** 2 + par.obsy[i] ** 2 + par.obsz[i] ** 2)
+            p = (par.obsx[i] * ds, par.obsy[i] * ds, par.obsz[i] * ds) if ds > 1.001 else (par.obsx[i], par.obsy[i], par.obsz[i])
+            cb = p[2] / par.distance
+            if abs(cb - 1.0) < eps:
+                cb = 1.0
+            if abs(cb + 1.0) < eps:
+                cb = -1.0
+            sb = math.sqrt(1.0 - cb * cb)
+            par.beta[i] = math.atan2(sb, cb) * RAD2DEG
+            cg, sg = math.cos(par.gamma[i] * DEG2RAD), math.sin(par.gamma[i] * DEG2RAD)
+            if sb == 0.0:
+                ca, sa, par.alpha[i] = 1.0, 0.0, 0.0
+            else:
+                al = math.atan2(p[1], p[0]); ca, sa = math.cos(al), math.sin(al); par.alpha[i] = al * RAD2DEG
+            xyz.append(p); trig.append((ca, sa, cb, sb, cg, sg))
+    par.nobs = n
+    rm = np.zeros((n, 3, 3))
+    for i, (ca, sa, cb, sb, cg, sg) in enumerate(trig):                   # :207-217
+        rm[i] = [[ca * cb * cg - sa * sg, sa * cb * cg + ca * sg, -sb * cg],
+                 [-ca * cb * sg - sa * cg, -sa * cb * sg + ca * cg, sb * sg],
+                 [ca * sb, sa * sb, cb]]
+    if not (fin(par.dxim) and fin(par.dyim)):                             # :244-276
+        if par.geometry == "sphere":
+            par.dxim = math.asin(par.rmax / par.distance) / (par.nxim / 2.0) * RAD2DEG
+            par.dyim = math.asin(par.rmax / par.distance) / (par.nyim / 2.0) * RAD2DEG
+        else:
+            vx = [1, 1, 1, -1, -1, -1, 1, -1]; vy = [1, 1, -1, 1, -1, 1, -1, -1]; vz = [1, -1, 1, 1, 1, -1, -1, -1]
+            mx = my = -999.0
+            for i in range(n):
+                for iv in range(8):
+                    pv = np.array(xyz[i]) - np.array([vx[iv] * par.xmax, vy[iv] * par.ymax, vz[iv] * par.zmax])
+                    k = rm[i] @ pv
+                    mx = max(mx, abs(math.atan2(-k[0], k[2]))); my = max(my, abs(math.atan2(-k[1], k[2])))
+            if par.nxim == par.nyim:
+                par.dxim = max(mx, my) / (par.nxim / 2.0) * RAD2DEG; par.dyim = max(mx, my) / (par.nyim / 2.0) * RAD2DEG
+            else:
+                if not fin(par.dxim):
+                    par.dxim = mx / (par.nxim / 2.0) * RAD2DEG
+                if not fin(par.dyim):
+                    par.dyim = my / (par.nyim / 2.0) * RAD2DEG
+    return Observers(nobs=n, xyz=np.array(xyz), rmatrix=rm, dxim=par.dxim, dyim=par.dyim, nxim=par.nxim, nyim=par.nyim,
+                     steradian_pix=par.dxim * par.dyim * DEG2RAD ** 2)
+
+
+def make_lart_params(par, line, g):
+    p = capi.LartParams()
+    for n in ("xyz_symmetry", "xy_periodic", "comoving_source", "recoil", "core_skip", "core_skip_global", "use_stokes",
+              "use_reduced_wgt", "save_Jin", "save_Jabs", "save_Jmu", "nmu", "save_peeloff", "save_peeloff_2D", "save_peeloff_3D"):
+        setattr(p, n, int(getattr(par, n)))
+    p.source_geometry = {"point": 0, "uniform_sphere": 1}[par.source_geometry]
+    p.spectral_type = {"monochromatic": 0, "voigt": 1}[par.spectral_type]
+    p.nxfreq = g.nxfreq
+    for n in ("xs_point", "ys_point", "zs_point", "source_rmax", "xfreq0", "DGR", "hgg", "albedo", "mu_min", "dmu"):
+        setattr(p, n, float(getattr(par, n)))
+    p.xfreq_min, p.dxfreq, p.Dfreq_ref = g.xfreq_min, g.dxfreq, g.Dfreq_ref
+    p.g_recoil0, p.E1, p.E2, p.E3 = line.g_recoil0, line.E1, line.E2, line.E3
+    p.xcrit, p.xcrit2 = g.xcrit, g.xcrit2
+    return p
+
+
+class Simulation:
+    """main.f90:19-69 sequence: read_input -> setup -> grid_create -> observer_create -> run_simulation ->
+    output_reduce -> output_normalize, with run_simulation/output_reduce crossing the C-ABI."""
+
+    def __init__(self, par, device=0):
+        if isinstance(par, str):
+            par = read_namelist(par)
+        elif isinstance(par, dict):
+            d = par; par = Params()
+            for k, v in d.items():
+                set_param(par, k, v)
+        self.par, self.line, self.scatt_mat = read_input(par)
+        self.grid = grid_create(self.par, self.line)
+        self.obs = observer_create(self.par)
+        self.cpar = make_lart_params(self.par, self.line, self.grid)
+        self.ctx = capi.Context(self.cpar, device)
+        g = self.grid
+        self.ctx.set_grid_car(g.nx, g.ny, g.nz, g.xmin, g.ymin, g.zmin, g.dx, g.dy, g.dz, g.i0, g.j0, g.k0,
+                              g.xface, g.yface, g.zface, g.rhokap, g.voigt_a, g.Dfreq, g.vfx, g.vfy, g.vfz, g.rhokapD)
+        if self.scatt_mat.nPDF:
+            s = self.scatt_mat
+            self.ctx.set_mueller(s.coss, s.S11, s.S12, s.S33, s.S34, s.phase_PDF, s.alias)
+        if self.obs.nobs:
+            o = self.obs
+            self.ctx.set_observers(o.xyz, o.rmatrix, o.dxim, o.dyim, o.nxim, o.nyim)
+        self.nphotons_run = 0
+
+    def run_simulation(self, nphotons=None, rank=0, nproc=1, seed=None):
+        """photon ids rank+1, rank+1+nproc, ... <= nphotons (run_equal_number, run_simulation_mod.f90:150-151)"""
+        n = self.par.nphotons if nphotons is None else int(nphotons)
+        count = (n - rank - 1) // nproc + 1 if n > rank else 0
+        self.ctx.run(count, first_id=rank + 1, stride=nproc, seed=self.par.iseed if seed is None else seed)
+        self.nphotons_run = n
+        return count
+
+    def output_reduce(self, dist=None):
+        """sum of the fused tally buffer over ranks (reduce_mem, memory_mod_mpi.f90:366-394) by one RCCL collective"""
+        if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+            return
+        import torch
+        ptr, n = self.ctx.tally_buffer()
+        t = _as_cuda_tensor(ptr, n, self.ctx)
+        torch.cuda.synchronize()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
+
+    def output_normalize(self, t=None, nphotons=None):
+        """output_normalize_outside (output_sum_rect.f90:151-487): physical units for Jout/Jin/Jabs/Jmu and peel cubes"""
+        t = t or self.ctx.tallies()
+        par, g = self.par, self.grid
+        nph = float(nphotons or self.nphotons_run or t["nphotons_done"])
+        out = dict(t)
+        unit = g.dwave if par.distance2cm != 1.0 else g.dxfreq            # par%intensity_unit default, setup.f90:491-497
+        if par.xy_periodic:                                               # slab, two faces: :174-190
+            area = 2.0
+        elif par.geometry == "sphere":                                    # :191-196
+            area = FOURPI * g.rmax ** 2 * par.distance2cm ** 2
+        else:
+            area = (g.xmax * g.ymax + g.ymax * g.zmax + g.zmax * g.xmax) * 8.0 * par.distance2cm ** 2
+        scale = nph * unit * TWOPI * area
+        for k in ("Jout", "Jin", "Jabs"):
+            out[k] = t[k] / scale
+        if "Jmu" in t:
+            out["Jmu"] = t["Jmu"] * par.nmu / scale                       # :188-190, :206-208
+        if self.obs.nobs:
+            sc3 = nph * self.obs.steradian_pix * unit * par.distance2cm ** 2                    # :428-430
+            sc2 = nph * self.obs.steradian_pix * par.distance2cm ** 2
+            for k in ("scatt", "direc", "I", "Q", "U", "V"):
+                if k in t:
+                    out[k] = t[k] / sc3
+                if k + "_2D" in t:
+                    out[k + "_2D"] = t[k + "_2D"] / sc2
+        out["nscatt_tot"] = (t["nscatt_gas"] + t["nscatt_dust"]) / nph
+        return out
+
+
+def _as_cuda_tensor(ptr, n, keep):
+    """wrap the device tally buffer (owned by liblart_gpu) as a torch f64 tensor for torch.distributed"""
+    import torch
+
+    class _Wrap:
+        __cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 3, "strides": None}
+        _keep = keep
+    return torch.as_tensor(_Wrap(), device="cuda")

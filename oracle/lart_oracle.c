@@ -1343,9 +1343,11 @@ void orc_zero_tallies(orc_sim *s) {
 
 /* output_normalize_outside, Jout only: output_sum_rect.f90:185-202 */
 int orc_normalized_Jout(const orc_sim *s, double *out, int n) {
-    double nph = (double)s->nphotons_done, scale;
-    if (s->rmax > 0.0) scale = nph * s->dxfreq * TWOPI * (FOURPI * s->rmax * s->rmax * s->distance2cm * s->distance2cm);
-    else scale = nph * s->dxfreq * TWOPI * 2.0;
+    double nph = (double)s->nphotons_done, area, scale;
+    if (s->xy_periodic) area = 2.0;
+    else if (s->geometry == 0) area = FOURPI * s->rmax * s->rmax * s->distance2cm * s->distance2cm;
+    else area = (s->xmax * s->ymax + s->ymax * s->zmax + s->zmax * s->xmax) * 8.0 * s->distance2cm * s->distance2cm;
+    scale = nph * s->dxfreq * TWOPI * area;
     for (int i = 0; i < n && i < s->nxfreq; i++) out[i] = s->Jout[i] / scale;
     return s->nxfreq;
 }

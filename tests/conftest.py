@@ -1,0 +1,49 @@
+import os
+import sys
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: longer oracle statistics run")
+
+
+@pytest.fixture(scope="session")
+def oracle_mod():
+    from oracle import oracle as O
+    O.build(ref=False)
+    return O
+
+
+@pytest.fixture(scope="session")
+def golden():
+    def load(name):
+        return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+    return load
+
+
+@pytest.fixture(scope="session")
+def mueller_file(tmp_path_factory):
+    """write the Mueller fixture back in the 3-header-line text layout that par%scatt_mat_file expects (setup.f90:597-627)"""
+    z = np.load(os.path.join(GOLDEN, "mueller_Lyalpha.npz"))
+    p = tmp_path_factory.mktemp("mueller") / "mueller_Lyalpha.dat"
+    h, tab = z["header"], z["table"]
+    with open(p, "w") as f:
+        f.write("lambda(um), Cext(cm^2/H), albedo, <cos>, # of angles\n")
+        f.write("  %.5f  %.5E  %.5f  %.5f  %d\n" % (h[0], h[1], h[2], h[3], len(tab)))
+        f.write("cos(theta),     S11,               S12,             S33,             S34\n")
+        for r in tab:
+            f.write("%.4f  %.10E  %.10E  %.10E  %.10E\n" % tuple(r))
+    return str(p)
+
+
+def rms_diff(a, b):
+    """spectrum rms-diff as BASELINE.json's metric defines it: sqrt(mean((a-b)^2)) / max(b)"""
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return float(np.sqrt(np.mean((a - b) ** 2)) / np.max(b))

@@ -1,0 +1,100 @@
+"""The drop-in boundary without a GPU: the shared library loads, exports every symbol include/lart_gpu.h declares,
+the ctypes structs match the C layout, and the host-side mirror builds the same tables as the oracle."""
+import ctypes
+import os
+import re
+import subprocess
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as g
+    g.build()
+    from lart_amd import capi
+    return capi
+
+
+def test_library_exports_every_declared_symbol(built):
+    hdr = open(os.path.join(ROOT, "include", "lart_gpu.h")).read()
+    declared = sorted(set(re.findall(r"\b(lart_gpu_\w+)\s*\(", hdr)))
+    assert declared, "no declarations parsed"
+    L = ctypes.CDLL(built.LIB_PATH)
+    for s in declared:
+        assert hasattr(L, s), "missing export " + s
+    assert sorted(built.SYMBOLS) == declared
+
+
+def test_struct_layout_matches_header(built, tmp_path):
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "lart_gpu.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(lart_params), '
+                   'offsetof(lart_params, xs_point), offsetof(lart_params, xcrit2), sizeof(lart_tallies), offsetof(lart_tallies, nphotons_done));return 0;}')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    sz = [int(t) for t in subprocess.check_output([str(exe)]).split()]
+    P, T = built.LartParams, built.LartTallies
+    assert sz == [ctypes.sizeof(P), P.xs_point.offset, P.xcrit2.offset, ctypes.sizeof(T), T.nphotons_done.offset]
+
+
+def test_no_device_fails_loudly(built):
+    # this container has no GPU: the product path must refuse, not fall back
+    if built.lib().lart_gpu_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(built.LartError, match="no HIP device"):
+        built.Context(built.LartParams(), 0)
+
+
+def test_product_does_not_touch_the_oracle():
+    for dp, _, fs in os.walk(os.path.join(ROOT, "lart_amd")):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".f90", ".inc")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "liblart_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, f
+
+
+CASES = [dict(temperature=10.0, taumax=1e6, xyz_symmetry=True, nx=101, ny=101, nz=101, rmax=1.0, nxfreq=201),
+         dict(temperature=10.0, taumax=1e4, use_stokes=True, xy_periodic=True, nx=1, ny=1, nz=201, hgg=0.6592, albedo=0.3899),
+         dict(temperature=1e4, taumax=1e3, nx=30, ny=30, nz=30, rmax=1.0, nxim=16, nyim=16, use_stokes=True, Vexp=20.0, velocity_type="hubble"),
+         dict(temperature=1e4, N_HI=1e19, nx=21, ny=21, nz=21, geometry="rectangle", nxim=8, nyim=12)]
+
+
+@pytest.mark.parametrize("kw", CASES)
+def test_host_tables_match_oracle(built, oracle_mod, kw):
+    from lart_amd import host
+    par = host.Params()
+    for k, v in kw.items():
+        host.set_param(par, k, v)
+    par, line, _ = host.read_input(par)
+    g = host.grid_create(par, line)
+    ob = host.observer_create(par)
+    o = oracle_mod.Oracle(**kw)
+    for k in ("rhokap", "voigt_a", "Dfreq", "vfx", "vfy", "vfz"):
+        assert np.allclose(getattr(g, k), o.grid3(k), rtol=1e-13, atol=0), k
+    for k in ("dx", "dy", "dz", "xmin", "ymin", "zmin", "i0", "j0", "k0", "Dfreq_ref", "xfreq_min", "dxfreq", "nxfreq"):
+        assert getattr(g, k) == o.scalar(k), k
+    assert np.isclose(g.xcrit, o.scalar("xcrit"), rtol=1e-12)
+    if ob.nobs:
+        assert np.allclose(ob.xyz.ravel(), o.array("obs_xyz"), rtol=1e-14)
+        assert np.allclose(ob.rmatrix.ravel(), o.array("rmatrix"), atol=1e-15)
+        assert np.isclose(ob.dxim, o.scalar("dxim"), rtol=1e-13) and np.isclose(ob.dyim, o.scalar("dyim"), rtol=1e-13)
+
+
+def test_namelist_surface(built, tmp_path):
+    from lart_amd import host
+    f = tmp_path / "t1tau6.in"
+    f.write_text("&parameters\n par%no_photons  = 1e6\n par%temperature = 1.0e1\n par%taumax      = 1.0e6\n par%DGR = 0.0\n"
+                 " par%xyz_symmetry    = .true.\n par%comoving_source = .false.\n par%spectral_type   = 'voigt'\n"
+                 " par%nx = 101\n par%ny = 101\n par%nz = 101\n par%nxfreq = 201\n par%rmax   = 1.0\n par%nprint = 100000\n/\n")
+    par = host.read_namelist(str(f))
+    assert par.xyz_symmetry and not par.comoving_source and par.nx == 101 and par.taumax == 1e6 and par.no_photons == 1e6
+    bad = tmp_path / "bad.in"
+    bad.write_text("&parameters\n par%not_a_field = 1\n/\n")
+    with pytest.raises(host.LartInputError):
+        host.read_namelist(str(bad))
+    amr = tmp_path / "amr.in"
+    amr.write_text("&parameters\n par%use_amr_grid = .true.\n/\n")
+    with pytest.raises(host.LartInputError, match="not supported"):
+        host.read_namelist(str(amr))

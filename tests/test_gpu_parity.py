@@ -1,0 +1,233 @@
+"""Parity of the HIP path (through the C-ABI) against the CPU oracle on a real MI355X.
+
+Device functions are checked element-wise on the same inputs and the same counter-based random streams;
+whole-path runs are checked per photon where histories are short (identical streams -> identical histories up to
+libm last-bit differences) and statistically (BASELINE.json's spectrum rms-diff) at the configs' sizes."""
+import numpy as np
+import pytest
+from conftest import rms_diff
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def capi():
+    import __graft_entry__ as g
+    g.build()
+    from lart_amd import capi
+    assert capi.lib().lart_gpu_device_count() > 0, "no GPU visible: the HIP path cannot run (there is no fallback)"
+    return capi
+
+
+def make(kw, device=0):
+    from lart_amd import host
+    return host.Simulation(dict(kw), device)
+
+
+def oracle_of(oracle_mod, kw):
+    return oracle_mod.Oracle(**{k: v for k, v in kw.items() if k != "iseed"})
+
+
+def test_voigt_device(capi, oracle_mod):
+    sim = make(dict(temperature=1e4, taumax=10.0, nx=5, ny=5, nz=5, rmax=1.0))
+    x = np.concatenate([np.linspace(-12, 12, 20001), np.random.default_rng(1).uniform(-60, 60, 5000), [0, 1, 5, 10, -1, -5, -10]])
+    for a in (1.492e-2, 4.7186e-4):
+        h = sim.ctx.test_voigt(x, a)
+        ho = oracle_mod.voigt(x, a)
+        assert np.max(np.abs(h - ho) / ho) < 1e-13           # same tables, same regimes; only FMA contraction differs
+
+
+def test_rng_stream_device(capi, oracle_mod):
+    sim = make(dict(temperature=1e4, taumax=10.0, nx=5, ny=5, nz=5, rmax=1.0))
+    for seed, pid in ((1234, 1), (2**40 + 17, 2**33 + 5), (0, 0)):
+        assert np.array_equal(sim.ctx.test_rand(0, seed, pid, 1001), oracle_mod.rand_number(1, seed, pid, 1001))   # bit-exact
+
+
+@pytest.mark.parametrize("x,a", [(0.0, 1.492e-2), (0.7, 1.492e-2), (1.7, 1.492e-2), (2.3, 4.7186e-4), (2.5, 4.7186e-4), (3.0, 1.492e-2),
+                                 (8.0, 1.492e-2), (30.0, 1.492e-2), (-2.0, 1.492e-2), (2.45, 1e-3), (2.6, 5e-2)])
+def test_vz_sampler_device(capi, oracle_mod, x, a):
+    sim = make(dict(temperature=1e4, taumax=10.0, nx=5, ny=5, nz=5, rmax=1.0))
+    # same stream, same rejection decisions: streams stay aligned unless a last-bit libm difference flips a comparison
+    n = 400
+    g = sim.ctx.test_rand(1, 99, 5, n, x, a)
+    o = oracle_mod.rand_resonance_vz(1, 99, 5, n, x, a)
+    first_bad = np.argmax(~np.isclose(g, o, rtol=1e-9, atol=1e-12)) if not np.allclose(g, o, rtol=1e-9, atol=1e-12) else n
+    assert first_bad >= n // 2, (x, a, first_bad)
+    # and as distributions (long run): mean / variance agree
+    g2 = sim.ctx.test_rand(1, 7, 11, 20000, x, a); o2 = oracle_mod.rand_resonance_vz(1, 8, 12, 20000, x, a)
+    assert abs(g2.mean() - o2.mean()) < 5 * np.hypot(g2.std(), o2.std()) / np.sqrt(20000)
+
+
+def test_other_samplers_device(capi, oracle_mod):
+    sim = make(dict(temperature=1e4, taumax=10.0, nx=5, ny=5, nz=5, rmax=1.0))
+    c = sim.ctx
+    assert np.allclose(c.test_rand(2, 5, 6, 2000, 1.0), oracle_mod.rand_resonance(1, 5, 6, 2000, 1.0), rtol=0, atol=1e-14)
+    assert np.allclose(c.test_rand(2, 5, 6, 2000, -0.3), oracle_mod.rand_resonance(1, 5, 6, 2000, -0.3), rtol=0, atol=1e-13)
+    assert np.allclose(c.test_rand(3, 5, 6, 2000, 0.6761), oracle_mod.rand_hg(1, 5, 6, 2000, 0.6761), rtol=0, atol=1e-14)
+    assert np.allclose(c.test_rand(5, 5, 6, 2000), oracle_mod.rand_gauss(1, 5, 6, 2000), rtol=1e-13, atol=1e-14)
+    g, o = c.test_rand(4, 5, 6, 2000, 1.492e-2), oracle_mod.rand_voigt(1, 5, 6, 2000, 1.492e-2)
+    assert np.allclose(g, o, rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["car", "xyzsym_odd", "xyzsym_even", "zonly"])
+def test_ray_marches_device_vs_reference_vectors(capi, golden, name):
+    """the committed vectors come from the reference's own compiled raytrace_car.f90"""
+    from lart_amd import host
+    z = golden("raytrace_%s.npz" % name)
+    kw = dict(tok.split("=") for tok in str(z["params"]).split())
+    par = host.Params()
+    for k, v in kw.items():
+        host.set_param(par, k, host._parse_value(v) if k != "geometry" else v)
+    sim = host.Simulation(par)
+    g = sim.grid
+    sim.ctx.set_grid_car(g.nx, g.ny, g.nz, g.xmin, g.ymin, g.zmin, g.dx, g.dy, g.dz, g.i0, g.j0, g.k0, g.xface, g.yface, g.zface,
+                         z["rhokap"], z["voigt_a"], z["Dfreq"], z["vfx"], z["vfy"], z["vfz"], z["rhokapD"] if sim.par.DGR > 0 else None)
+    v = int(z["variant"])
+    sim.ctx.zero_tallies()
+    r, ic, _ = sim.ctx.test_raytrace(0, v, z["r_in"], z["ic_in"], z["tau_in"])
+    assert np.array_equal(ic, z["ic_out"])
+    assert np.allclose(r, z["r_out"], rtol=1e-10, atol=1e-12)
+    _, _, te = sim.ctx.test_raytrace(1, v, z["r_in"], z["ic_in"])
+    assert np.allclose(te, z["tau_edge"], rtol=1e-10, atol=1e-300)
+    if v == 0:
+        _, _, td = sim.ctx.test_raytrace(2, v, z["r_in"], z["ic_in"], z["dist"])
+        assert np.allclose(td, z["tau_dist"], rtol=1e-10, atol=1e-300)
+    assert np.allclose(sim.ctx.tallies()["Jout"], z["Jout"], rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("kw", [dict(temperature=1e4, taumax=1e3, nx=11, ny=11, nz=11, rmax=1.0),
+                                dict(temperature=1e4, taumax=1e3, nx=11, ny=11, nz=11, rmax=1.0, use_stokes=True, recoil=True),
+                                dict(temperature=10.0, taumax=1e5, nx=11, ny=11, nz=11, rmax=1.0, core_skip=True),
+                                dict(temperature=1e4, taumax=1e2, nx=11, ny=11, nz=11, rmax=1.0, DGR=1.0, cext_dust=1e-19, use_reduced_wgt=True)])
+def test_scatter_event_device(capi, oracle_mod, kw):
+    sim = make(kw); o = oracle_of(oracle_mod, kw)
+    rng = np.random.default_rng(3)
+    n = 512
+    st = np.zeros((n, 18)); ic = np.zeros((n, 4), dtype=np.int32)
+    g = sim.grid
+    for i in range(n):
+        c = [int(rng.integers(3, 9)) for _ in range(3)]
+        pos = [g.xmin + (c[0] - 1 + rng.uniform()) * g.dx, g.ymin + (c[1] - 1 + rng.uniform()) * g.dy, g.zmin + (c[2] - 1 + rng.uniform()) * g.dz]
+        mu, ph = rng.uniform(-1, 1), rng.uniform(0, 2 * np.pi); s = np.sqrt(1 - mu * mu)
+        k = np.array([s * np.cos(ph), s * np.sin(ph), mu])
+        m = np.array([mu * np.cos(ph), mu * np.sin(ph), -s]); nn = np.array([-np.sin(ph), np.cos(ph), 0.0])
+        q, u = rng.uniform(-0.3, 0.3, 2)
+        st[i] = pos + list(k) + [rng.normal(0, 2.0) if i % 3 else rng.normal(0, 0.3), 1.0] + list(m) + list(nn) + [1.0, q, u, 0.05]
+        ic[i] = c + [1]
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    sg, icg, ndg = sim.ctx.test_scatter(st, ic, 4242, ids)
+    nbad = 0
+    for i in range(n):
+        so, ico, ndo = o.scatter_event(st[i], ic[i], 4242, int(ids[i]))
+        ok = ndo == ndg[i] and np.allclose(sg[i], so, rtol=1e-9, atol=1e-11) and ico[3] == icg[i][3]
+        nbad += not ok
+    assert nbad <= n // 100, nbad     # a last-bit libm difference may flip a rejection: <1% of events
+
+
+@pytest.mark.parametrize("kw,n", [
+    (dict(temperature=1e4, taumax=1e1, xyz_symmetry=True, nx=21, ny=21, nz=21, rmax=1.0, nxfreq=81, iseed=5), 20000),
+    (dict(temperature=1e4, taumax=1e1, nx=21, ny=21, nz=21, rmax=1.0, nxfreq=81, iseed=6, source_geometry="uniform_sphere", save_Jmu=True, nmu=5), 20000),
+    (dict(temperature=1e1, taumax=1e1, xy_periodic=True, nx=1, ny=1, nz=51, nxfreq=81, iseed=7, use_stokes=True), 20000),
+])
+def test_short_histories_photon_by_photon(capi, oracle_mod, kw, n):
+    sim = make(kw); sim.ctx.enable_photon_log(True)
+    sim.run_simulation(n)
+    t = sim.ctx.tallies()
+    o = oracle_of(oracle_mod, kw); o.run(n, seed=kw["iseed"])
+    ng, xg = sim.ctx.photon_log(n); no, xo = o.photon_log()
+    same = (ng == no) & np.isclose(xg, xo, rtol=1e-7, atol=1e-9)
+    assert same.mean() > 0.97, same.mean()
+    assert t["nphotons_done"] == n
+    assert np.isclose(t["Jin"].sum(), n)
+    assert rms_diff(t["Jout"], o.array("Jout")) < 0.01
+    if kw.get("save_Jmu"):
+        assert rms_diff(t["Jmu"].ravel(order="F"), o.array("Jmu")) < 0.02
+
+
+def test_scheduling_independence(capi):
+    """a packet's history depends only on (seed, id): different pool sizes / slice lengths give the same tallies"""
+    kw = dict(temperature=1e4, taumax=3e2, xyz_symmetry=True, nx=31, ny=31, nz=31, rmax=1.0, nxfreq=101, iseed=9)
+    a = make(kw); a.ctx.set_pool(1024, 64); a.ctx.enable_photon_log(True)
+    a.ctx.begin(6000, seed=9)
+    while True:
+        a.ctx.step(1, 37)
+        if a.ctx.sync()[1] == 0:
+            break
+    b = make(kw); b.ctx.enable_photon_log(True); b.run_simulation(6000)
+    na, _ = a.ctx.photon_log(6000); nb, _ = b.ctx.photon_log(6000)
+    assert np.array_equal(na, nb)
+    ta, tb = a.ctx.tallies(), b.ctx.tallies()
+    assert np.allclose(ta["Jout"], tb["Jout"], rtol=0, atol=1e-9)
+    # rank decomposition (id = rank+1, rank+1+nproc, ...) sums to the single-rank answer
+    c = make(kw); c.ctx.enable_photon_log(True)
+    c.run_simulation(6000, rank=0, nproc=2); j0 = c.ctx.tallies()["Jout"].copy()
+    d = make(kw); d.run_simulation(6000, rank=1, nproc=2); j1 = d.ctx.tallies()["Jout"]
+    assert np.allclose(j0 + j1, tb["Jout"], rtol=0, atol=1e-9)
+
+
+def test_sphere_tau3_statistics_and_known_answer(capi, oracle_mod):
+    """C2's physics at tau0 = 1e3 (cheap): <N_scatt> vs the shipped log (1789.8) and spectrum vs the oracle"""
+    kw = dict(temperature=10.0, taumax=1e3, xyz_symmetry=True, nx=101, ny=101, nz=101, rmax=1.0, nxfreq=201, iseed=21)
+    n = 200000
+    sim = make(kw); sim.ctx.enable_photon_log(True); sim.run_simulation(n)
+    t = sim.output_normalize()
+    ns, _ = sim.ctx.photon_log(n)
+    mean, err = ns.mean(), ns.std() / np.sqrt(n)
+    # 101^3 octant vs the log's 201^3 full grid: the survey measured 1804.9 on this grid, the log says 1789.8 (<1%)
+    assert abs(mean - 1797.0) < 0.012 * 1797.0 + 4 * err, (mean, err)
+    o = oracle_of(oracle_mod, kw); o.run(40000, seed=22)
+    no, _ = o.photon_log()
+    assert abs(mean - no.mean()) < 4 * np.hypot(err, no.std() / np.sqrt(len(no)))
+    jo = o.normalized_Jout()
+    # Poisson-expected rms of the 40k-photon oracle spectrum dominates: ~ sqrt(nbins_eff/N)
+    assert rms_diff(t["Jout"], jo) < 0.03
+
+
+def test_peel_stokes_vs_oracle(capi, oracle_mod):
+    """C3's path (plain grid, Stokes resonance scattering, one far observer) at a cheap optical depth"""
+    kw = dict(temperature=1e4, taumax=50.0, nx=41, ny=41, nz=41, rmax=1.0, nxfreq=61, nxim=16, nyim=16, use_stokes=True,
+              save_peeloff_2D=True, iseed=31, alpha=25.0, beta=60.0)
+    n = 100000
+    sim = make(kw); sim.run_simulation(n); t = sim.ctx.tallies()
+    o = oracle_of(oracle_mod, kw); o.run(n, seed=32)
+    sh3 = (kw["nxfreq"], 16, 16)
+    for name in ("scatt", "direc", "I"):
+        g3 = t[name][..., 0]; o3 = o.array(name + ":0").reshape(sh3, order="F")
+        sg, so = g3.sum(axis=(1, 2)), o3.sum(axis=(1, 2))          # peel-integrated spectrum
+        assert rms_diff(sg, so) < 0.02, name
+        ig, io = g3.sum(axis=0), o3.sum(axis=0)                    # image
+        assert abs(ig.sum() - io.sum()) < 0.01 * io.sum(), name
+    for name in ("Q", "U"):
+        g3 = t[name][..., 0]; o3 = o.array(name + ":0").reshape(sh3, order="F")
+        scale = np.abs(o.array("I:0")).reshape(sh3, order="F").sum(axis=0).max()
+        assert np.abs(g3.sum(axis=0) - o3.sum(axis=0)).max() < 0.05 * scale, name
+    assert np.allclose(t["scatt_2D"][..., 0].sum(), t["scatt"][..., 0].sum(), rtol=0.02)   # out-of-band bins only
+
+
+def test_dust_mueller_vs_oracle(capi, oracle_mod, mueller_file):
+    kw = dict(temperature=1e4, taumax=1e3, nx=31, ny=31, nz=31, rmax=1.0, nxfreq=81, nxim=8, nyim=8, use_stokes=True, DGR=1.0,
+              scatt_mat_file=mueller_file, cext_dust=1.6e-21, iseed=41)
+    n = 60000
+    sim = make(kw); sim.run_simulation(n); t = sim.ctx.tallies()
+    assert sim.scatt_mat.nPDF == 161
+    o = oracle_of(oracle_mod, kw); o.run(n, seed=42)
+    assert abs(t["nscatt_dust"] / n - o.scalar("nscatt_dust") / n) < 0.05 * max(o.scalar("nscatt_dust") / n, 1e-3) + 0.01
+    assert abs(t["nscatt_gas"] / n - o.scalar("nscatt_gas") / n) < 0.03 * o.scalar("nscatt_gas") / n
+    assert rms_diff(t["Jout"], o.array("Jout")) < 0.03
+    assert abs(t["Jabs"].sum() - o.array("Jabs").sum()) < 0.05 * o.array("Jabs").sum() + 50
+    # energy bookkeeping: escaped + absorbed = emitted
+    assert abs(t["Jout"].sum() + t["Jabs"].sum() - n) < 0.01 * n
+
+
+def test_edge_cases(capi):
+    # zero photons, one photon, optically thin medium (forced first scattering weight ~ tau0), source off-centre
+    sim = make(dict(temperature=1e4, taumax=1e-3, nx=11, ny=11, nz=11, rmax=1.0, nxfreq=41, xs_point=0.3, ys_point=-0.2, zs_point=0.1, iseed=3))
+    sim.run_simulation(0); assert sim.ctx.tallies()["nphotons_done"] == 0
+    sim.run_simulation(1); assert sim.ctx.tallies()["nphotons_done"] == 1
+    sim.ctx.zero_tallies(); sim.run_simulation(5000)
+    t = sim.ctx.tallies()
+    assert abs(t["Jout"].sum() - 5000) < 1e-6 * 5000 + 5       # conservation (a few packets may leave the spectral window)
+    assert 0 < t["nscatt_gas"] / 5000 < 2e-3                   # weight sums, not counts
+    from lart_amd import capi as C
+    with pytest.raises(C.LartError):
+        sim.ctx.step(1, 0)
