@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "liblart_gpu.so")
+LIB_PATH = os.environ.get("LART_GPU_LIB") or os.path.join(_HERE, "csrc", "liblart_gpu.so")   # override: tuning builds only
 
 _d, _i32, _i64, _u64, _vp = C.c_double, C.c_int32, C.c_int64, C.c_uint64, C.c_void_p
 

@@ -14,8 +14,12 @@ __device__ inline double wave_sum(double v) {
     return v;
 }
 
+#ifndef LART_MIN_WAVES
+#define LART_MIN_WAVES 2          // waves per SIMD the register allocator must leave room for
+#endif
+
 template <int VAR, bool STOKES, bool DUST, bool PEEL>
-__global__ __launch_bounds__(256) void transport_kernel(KArgs A) {
+__global__ __launch_bounds__(256, LART_MIN_WAVES) void transport_kernel(KArgs A) {
     extern __shared__ double sh[];
     const Lds l = lds_stage(sh, A.g);
     const lart_params &par = A.par;

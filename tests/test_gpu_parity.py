@@ -135,10 +135,11 @@ def test_short_histories_photon_by_photon(capi, oracle_mod, kw, n):
     t = sim.ctx.tallies()
     o = oracle_of(oracle_mod, kw); o.run(n, seed=kw["iseed"])
     ng, xg = sim.ctx.photon_log(n); no, xo = o.photon_log()
-    same = (ng == no) & np.isclose(xg, xo, rtol=1e-7, atol=1e-9)
+    # nscatt is a WEIGHT sum (forced first scattering: wgt = 1 - exp(-tau0)), so equal up to the libm exp() last bit
+    same = np.isclose(ng, no, rtol=1e-12, atol=0) & np.isclose(xg, xo, rtol=1e-7, atol=1e-9)
     assert same.mean() > 0.97, same.mean()
     assert t["nphotons_done"] == n
-    assert np.isclose(t["Jin"].sum(), n)
+    assert np.abs(t["Jin"] - o.array("Jin")).sum() <= 4          # same births, same bins (a bin edge may flip on the last bit)
     assert rms_diff(t["Jout"], o.array("Jout")) < 0.01
     if kw.get("save_Jmu"):
         assert rms_diff(t["Jmu"].ravel(order="F"), o.array("Jmu")) < 0.02
@@ -189,7 +190,7 @@ def test_peel_stokes_vs_oracle(capi, oracle_mod):
               save_peeloff_2D=True, iseed=31, alpha=25.0, beta=60.0)
     n = 100000
     sim = make(kw); sim.run_simulation(n); t = sim.ctx.tallies()
-    o = oracle_of(oracle_mod, kw); o.run(n, seed=32)
+    o = oracle_of(oracle_mod, kw); o.run(n, seed=31)      # same streams: histories agree photon by photon
     sh3 = (kw["nxfreq"], 16, 16)
     for name in ("scatt", "direc", "I"):
         g3 = t[name][..., 0]; o3 = o.array(name + ":0").reshape(sh3, order="F")
@@ -210,7 +211,7 @@ def test_dust_mueller_vs_oracle(capi, oracle_mod, mueller_file):
     n = 60000
     sim = make(kw); sim.run_simulation(n); t = sim.ctx.tallies()
     assert sim.scatt_mat.nPDF == 161
-    o = oracle_of(oracle_mod, kw); o.run(n, seed=42)
+    o = oracle_of(oracle_mod, kw); o.run(n, seed=41)
     assert abs(t["nscatt_dust"] / n - o.scalar("nscatt_dust") / n) < 0.05 * max(o.scalar("nscatt_dust") / n, 1e-3) + 0.01
     assert abs(t["nscatt_gas"] / n - o.scalar("nscatt_gas") / n) < 0.03 * o.scalar("nscatt_gas") / n
     assert rms_diff(t["Jout"], o.array("Jout")) < 0.03
@@ -221,7 +222,7 @@ def test_dust_mueller_vs_oracle(capi, oracle_mod, mueller_file):
 
 def test_edge_cases(capi):
     # zero photons, one photon, optically thin medium (forced first scattering weight ~ tau0), source off-centre
-    sim = make(dict(temperature=1e4, taumax=1e-3, nx=11, ny=11, nz=11, rmax=1.0, nxfreq=41, xs_point=0.3, ys_point=-0.2, zs_point=0.1, iseed=3))
+    sim = make(dict(temperature=1e4, taumax=1e-3, nx=11, ny=11, nz=11, rmax=1.0, nxfreq=41, xfreq_min=-12.0, xfreq_max=12.0, xs_point=0.3, ys_point=-0.2, zs_point=0.1, iseed=3))
     sim.run_simulation(0); assert sim.ctx.tallies()["nphotons_done"] == 0
     sim.run_simulation(1); assert sim.ctx.tallies()["nphotons_done"] == 1
     sim.ctx.zero_tallies(); sim.run_simulation(5000)

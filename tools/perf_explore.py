@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""throughput of the transport kernel vs photon age / pool geometry on the headline workload (GPU box)."""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from lart_amd import host
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--steps", type=int, default=20)
+ap.add_argument("--events", type=int, default=8192)
+ap.add_argument("--lanes", type=int, default=0)
+ap.add_argument("--block", type=int, default=0)
+ap.add_argument("--tau", type=float, default=1e6)
+ap.add_argument("--photons", type=float, default=1e7)
+ap.add_argument("--every", type=int, default=1)
+a = ap.parse_args()
+w = dict(bench.WORKLOAD); w["taumax"] = a.tau; w["no_photons"] = a.photons
+sim = host.Simulation(w)
+if a.lanes or a.block:
+    sim.ctx.set_pool(a.lanes, a.block)
+sim.ctx.begin(int(a.photons), seed=w["iseed"])
+prev = sim.ctx.tallies(); tprev = time.perf_counter(); t00 = tprev
+for s in range(a.steps):
+    sim.ctx.step(1, a.events)
+    done, active = sim.ctx.sync()
+    if (s + 1) % a.every == 0 or active == 0:
+        t = sim.ctx.tallies(); now = time.perf_counter()
+        ev = t["n_events"] - prev["n_events"]; cs = t["n_cellsteps"] - prev["n_cellsteps"]
+        print(json.dumps(dict(step=s + 1, t=round(now - t00, 3), events_per_s=ev / (now - tprev), cells_per_event=cs / max(ev, 1), done=done, active=active,
+                              mean_nscatt_done=(t["nscatt_gas"] / max(t["nphotons_done"], 1)), lanes=sim.ctx.pool_info()[0])), flush=True)
+        prev, tprev = t, now
+    if active == 0:
+        break
+ms, n = sim.ctx.kernel_time()
+print(json.dumps(dict(total_kernel_ms=ms, launches=n, total_events=prev["n_events"], overall_events_per_s=prev["n_events"] / (time.perf_counter() - t00))))
