@@ -1,0 +1,116 @@
+!------------------------------------------------------------------------------
+! lart_gpu_c -- ISO_C_BINDING view of include/lart_gpu.h (liblart_gpu.so).
+!
+! This is the whole Fortran<->HIP boundary: one derived type per C struct and one
+! interface per entry point.  A maintainer of the reference adds this module and
+! replaces `call run_simulation(grid)` / `call output_reduce(grid)` in main.f90:42,46
+! by lart_gpu_run / lart_gpu_get_tallies (see INTEGRATION.md).
+!------------------------------------------------------------------------------
+module lart_gpu_c
+  use, intrinsic :: iso_c_binding
+  implicit none
+  public
+
+  !--- struct lart_params (field names = par% / grid% / line% names of the reference)
+  type, bind(C) :: lart_params
+     integer(c_int32_t) :: xyz_symmetry, xy_periodic
+     integer(c_int32_t) :: source_geometry, spectral_type, comoving_source
+     integer(c_int32_t) :: recoil, core_skip, core_skip_global, use_stokes, use_reduced_wgt
+     integer(c_int32_t) :: save_Jin, save_Jabs, save_Jmu, nmu
+     integer(c_int32_t) :: save_peeloff, save_peeloff_2D, save_peeloff_3D
+     integer(c_int32_t) :: nxfreq
+     real(c_double) :: xs_point, ys_point, zs_point, source_rmax, xfreq0
+     real(c_double) :: xfreq_min, dxfreq, Dfreq_ref
+     real(c_double) :: DGR, hgg, albedo
+     real(c_double) :: mu_min, dmu
+     real(c_double) :: g_recoil0, E1, E2, E3
+     real(c_double) :: xcrit, xcrit2
+  end type lart_params
+
+  !--- struct lart_tallies: host pointers (c_null_ptr = skip) + scalars
+  type, bind(C) :: lart_tallies
+     type(c_ptr) :: Jout, Jin, Jabs, Jmu
+     type(c_ptr) :: scatt, direc, I, Q, U, V
+     type(c_ptr) :: scatt_2D, direc_2D, I_2D, Q_2D, U_2D, V_2D
+     real(c_double) :: nscatt_gas, nscatt_dust, n_events, n_cellsteps, n_cellsteps_peel
+     integer(c_int64_t) :: nphotons_done, nphotons_active
+  end type lart_tallies
+
+  interface
+     function lart_gpu_device_count() bind(C, name='lart_gpu_device_count') result(n)
+       import; integer(c_int) :: n
+     end function
+     function lart_gpu_create(ctx, par, device) bind(C, name='lart_gpu_create') result(rc)
+       import; type(c_ptr), intent(out) :: ctx; type(lart_params), intent(in) :: par
+       integer(c_int), value :: device; integer(c_int) :: rc
+     end function
+     function lart_gpu_destroy(ctx) bind(C, name='lart_gpu_destroy') result(rc)
+       import; type(c_ptr), value :: ctx; integer(c_int) :: rc
+     end function
+     function lart_gpu_last_error() bind(C, name='lart_gpu_last_error') result(p)
+       import; type(c_ptr) :: p
+     end function
+     function lart_gpu_set_grid_car(ctx, nx, ny, nz, xmin, ymin, zmin, dx, dy, dz, i0, j0, k0, xface, yface, zface, &
+                                    rhokap, voigt_a, Dfreq, vfx, vfy, vfz, rhokapD) bind(C, name='lart_gpu_set_grid_car') result(rc)
+       import; type(c_ptr), value :: ctx
+       integer(c_int32_t), value :: nx, ny, nz, i0, j0, k0
+       real(c_double), value :: xmin, ymin, zmin, dx, dy, dz
+       real(c_double), intent(in) :: xface(*), yface(*), zface(*), rhokap(*), voigt_a(*), Dfreq(*), vfx(*), vfy(*), vfz(*)
+       type(c_ptr), value :: rhokapD          ! c_loc(array) or c_null_ptr when DGR = 0
+       integer(c_int) :: rc
+     end function
+     function lart_gpu_set_mueller(ctx, nPDF, coss, S11, S12, S33, S34, phase_PDF, alias) bind(C, name='lart_gpu_set_mueller') result(rc)
+       import; type(c_ptr), value :: ctx; integer(c_int32_t), value :: nPDF
+       real(c_double), intent(in) :: coss(*), S11(*), S12(*), S33(*), S34(*), phase_PDF(*)
+       integer(c_int32_t), intent(in) :: alias(*); integer(c_int) :: rc
+     end function
+     function lart_gpu_set_observers(ctx, nobs, xyz, rmatrix, dxim, dyim, nxim, nyim) bind(C, name='lart_gpu_set_observers') result(rc)
+       import; type(c_ptr), value :: ctx; integer(c_int32_t), value :: nobs, nxim, nyim
+       real(c_double), intent(in) :: xyz(*), rmatrix(*); real(c_double), value :: dxim, dyim; integer(c_int) :: rc
+     end function
+     function lart_gpu_run(ctx, first_id, stride, count, seed) bind(C, name='lart_gpu_run') result(rc)
+       import; type(c_ptr), value :: ctx; integer(c_int64_t), value :: first_id, stride, count, seed; integer(c_int) :: rc
+     end function
+     function lart_gpu_begin(ctx, first_id, stride, count, seed) bind(C, name='lart_gpu_begin') result(rc)
+       import; type(c_ptr), value :: ctx; integer(c_int64_t), value :: first_id, stride, count, seed; integer(c_int) :: rc
+     end function
+     function lart_gpu_step(ctx, nsteps, max_events) bind(C, name='lart_gpu_step') result(rc)
+       import; type(c_ptr), value :: ctx; integer(c_int32_t), value :: nsteps, max_events; integer(c_int) :: rc
+     end function
+     function lart_gpu_sync(ctx, nphotons_done, nphotons_active) bind(C, name='lart_gpu_sync') result(rc)
+       import; type(c_ptr), value :: ctx; integer(c_int64_t), intent(out) :: nphotons_done, nphotons_active; integer(c_int) :: rc
+     end function
+     function lart_gpu_zero_tallies(ctx) bind(C, name='lart_gpu_zero_tallies') result(rc)
+       import; type(c_ptr), value :: ctx; integer(c_int) :: rc
+     end function
+     function lart_gpu_get_tallies(ctx, t) bind(C, name='lart_gpu_get_tallies') result(rc)
+       import; type(c_ptr), value :: ctx; type(lart_tallies), intent(inout) :: t; integer(c_int) :: rc
+     end function
+  end interface
+
+contains
+
+  !--- error convention of the reference: print the message and stop (setup.f90:132-139)
+  subroutine lart_check(rc, where)
+    integer(c_int), intent(in) :: rc
+    character(len=*), intent(in) :: where
+    character(kind=c_char), pointer :: msg(:)
+    type(c_ptr) :: p
+    integer :: n
+    if (rc == 0) return
+    p = lart_gpu_last_error()
+    write(*,'(3a)', advance='no') 'ERROR in ', where, ': '
+    if (c_associated(p)) then
+       call c_f_pointer(p, msg, [512])
+       n = 1
+       do while (n <= 512)
+          if (msg(n) == c_null_char) exit
+          write(*,'(a)', advance='no') msg(n)
+          n = n + 1
+       enddo
+    endif
+    write(*,*)
+    stop 1
+  end subroutine lart_check
+
+end module lart_gpu_c

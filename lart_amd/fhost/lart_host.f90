@@ -1,0 +1,871 @@
+!------------------------------------------------------------------------------
+! Fortran host of the MI355X photon path: the reference's main.f90 sequence
+!   read_input -> setup -> grid_create -> observer_create -> run_simulation -> output_reduce
+!   -> output_normalize -> write_output
+! with the same namelist surface (&parameters par%... /), the uniform-medium subset of
+! grid_create, and run_simulation/output_reduce crossing the C-ABI (module lart_gpu_c).
+! Citations: files under /root/reference/src.
+!------------------------------------------------------------------------------
+module lart_define
+  use, intrinsic :: iso_fortran_env, only: real64, int32, int64
+  use, intrinsic :: ieee_arithmetic
+  implicit none
+  public
+  integer, parameter :: wp = real64
+  real(wp), parameter :: pi = 3.141592653589793238462643383279502884197_wp
+  real(wp), parameter :: twopi = 6.283185307179586476925286766559005768394_wp
+  real(wp), parameter :: fourpi = 12.56637061435917295385057353311801153679_wp
+  real(wp), parameter :: rad2deg = 180.0_wp/pi, deg2rad = pi/180.0_wp
+  real(wp), parameter :: um2m = 1.0e-6_wp, um2km = 1.0e-9_wp
+  real(wp), parameter :: speedc = 2.99792458e5_wp, h_planck = 6.62607004e-34_wp
+  real(wp), parameter :: nan64 = transfer(-2251799813685248_int64, 1._real64)
+  integer,  parameter :: MAX_OBSERVERS = 16
+
+  !--- params_type: the fields of define.f90:209-544 that this path reads, same names and defaults
+  !--- (hgg, albedo, cext_dust defaults are single-precision literals widened to f64, define.f90:454-456).
+  !--- Fields that select physics outside the path are kept so example inputs parse; read_input rejects
+  !--- non-default values with "not supported".
+  type params_type
+     integer(int64) :: nphotons = 100000_int64
+     integer        :: nprint   = 10000000
+     real(wp) :: no_photons = 1e5
+     real(wp) :: no_print   = 0
+     integer  :: iseed      = 0
+     real(wp) :: temperature = 1d4
+     real(wp) :: taumax = -999.0, tauhomo = -999.0, tau0 = -999.0
+     real(wp) :: N_HImax = -999.0, N_HIhomo = -999.0, N_HI = -999.0, N_gasmax = -999.0, N_gashomo = -999.0
+     real(wp) :: atau3 = 0.0_wp
+     real(wp) :: Vexp = 0.0_wp, Vx = 0.0_wp, Vy = 0.0_wp, Vz = 0.0_wp
+     logical  :: comoving_source = .true., recoil = .false., core_skip = .false., core_skip_global = .false.
+     logical  :: xyz_symmetry = .false., xy_symmetry = .false., xy_periodic = .false., z_symmetry = .false.
+     character(len=128) :: geometry = '', velocity_type = ''
+     integer  :: nx = 1, ny = 1, nz = 11, nr = -999
+     real(wp) :: xmax = 1.0_wp, ymax = 1.0_wp, zmax = 1.0_wp
+     real(wp) :: rmin = -999.0, rmax = -999.0, source_rmax = -999.0_wp
+     real(wp) :: xs_point = 0.0_wp, ys_point = 0.0_wp, zs_point = 0.0_wp
+     real(wp) :: xfreq0 = 0.0_wp, xfreq_min = nan64, xfreq_max = nan64
+     integer  :: nxfreq = 121
+     real(wp) :: velocity_min = nan64, velocity_max = nan64
+     integer  :: nvelocity = 0
+     real(wp) :: distance2cm = -999.9_wp
+     character(len=128) :: distance_unit = '', source_geometry = 'point', spectral_type = 'voigt'
+     character(len=128) :: base_name = '', out_file = ''
+     logical  :: out_merge = .false.
+     character(len=8) :: file_format = 'hdf5'
+     integer(int64) :: num_send_at_once = 100
+     logical  :: use_master_slave = .true., use_reduced_wgt = .false., use_stokes = .false.
+     logical  :: save_all = .false., save_Jin = .true., save_Jabs = .true., save_Jmu = .false.
+     integer  :: nmu = 11
+     real(wp) :: mu_min = -1.0_wp, dmu = 0.0_wp
+     logical  :: save_peeloff = .false., save_peeloff_2D = .false., save_peeloff_3D = .true.
+     logical  :: save_sightline_tau = .false., save_direc0 = .false., save_all_photons = .false.
+     integer  :: intensity_unit = -999
+     real(wp) :: hgg = 0.6761, albedo = 0.3253, cext_dust = 1.6059e-21, DGR = 0.0
+     character(len=128) :: scatt_mat_file = ''
+     real(wp) :: nscatt_gas = 0.0_wp, nscatt_dust = 0.0_wp, nscatt_tot = 0.0_wp, exetime = 0.0_wp
+     integer  :: nobs = 1, nxim = 0, nyim = 0
+     real(wp) :: distance = nan64
+     real(wp) :: alpha(MAX_OBSERVERS) = nan64, beta(MAX_OBSERVERS) = nan64, gamma(MAX_OBSERVERS) = nan64
+     real(wp) :: obsx(MAX_OBSERVERS) = nan64, obsy(MAX_OBSERVERS) = nan64, obsz(MAX_OBSERVERS) = nan64
+     real(wp) :: dxim = nan64, dyim = nan64
+     integer  :: nside = 0
+     !--- outside this path (accepted at default only)
+     logical  :: use_amr_grid = .false., use_clump_medium = .false., fine_structure = .false., include_deuterium = .false.
+     character(len=20)  :: line_id = 'ly_alpha'
+     character(len=8)   :: h2_model = 'none'
+     character(len=128) :: dens_file = '', temp_file = '', velo_file = '', emiss_file = '', cart_file = '', input_field = '', star_file = ''
+     character(len=256) :: amr_file = '', clump_input_file = ''
+     real(wp) :: bturb = -999.0
+     !--- GPU host additions (not in the reference): number of GPUs driven by this process, slice length
+     integer  :: ngpu = 1
+     integer  :: gpu_events_per_step = 4096
+  end type params_type
+
+  type line_type          ! define.f90:639-680, Ly-alpha values of line_mod.f90:1241-1270
+     real(wp) :: wavelength0 = 0.1215668237310_wp
+     real(wp) :: damping     = 6.2649e8_wp
+     real(wp) :: cross0, vtherm1, g_recoil0
+     real(wp) :: E1 = 1.0_wp, E2 = 0.0_wp, E3 = 1.0_wp
+  end type line_type
+
+  type grid_type          ! define.f90:117-206 (tables are contiguous, Fortran order = what the C-ABI takes)
+     integer  :: nx, ny, nz, nxfreq, i0 = 0, j0 = 0, k0 = 0
+     real(wp) :: rmin, rmax, xmin, xmax, ymin, ymax, zmin, zmax, xrange, yrange, zrange, dx, dy, dz
+     real(wp) :: xfreq_min, xfreq_max, dxfreq, dwave, Dfreq_ref, voigt_amean, xcrit = 0.0_wp, xcrit2 = 0.0_wp
+     real(wp), allocatable :: xfreq(:), velocity(:), wavelength(:), xface(:), yface(:), zface(:)
+     real(wp), allocatable :: vfx(:,:,:), vfy(:,:,:), vfz(:,:,:), Dfreq(:,:,:), voigt_a(:,:,:), rhokap(:,:,:)
+     real(wp), allocatable :: rhokapD(:,:,:)
+     real(wp), allocatable :: Jin(:), Jout(:), Jabs(:), Jmu(:,:)
+  end type grid_type
+
+  type observer_type      ! define.f90:547-600
+     real(wp) :: x, y, z, rmatrix(3,3), dxim, dyim, steradian_pix
+     integer  :: nxim, nyim
+  end type observer_type
+
+  type scattering_matrix_type   ! define.f90:616-625
+     integer :: nPDF = 0
+     real(wp), allocatable :: coss(:), S11(:), S12(:), S33(:), S34(:), phase_PDF(:)
+     integer(int32), allocatable :: alias(:)
+  end type scattering_matrix_type
+
+  type(params_type) :: par
+  type(line_type)   :: line
+  type(scattering_matrix_type) :: scatt_mat
+  type(observer_type), allocatable :: observer(:)
+  !--- peel-off tallies of all observers: (nxfreq,nxim,nyim,nobs) and (nxim,nyim,nobs)
+  real(wp), allocatable, target :: obs_scatt(:,:,:,:), obs_direc(:,:,:,:), obs_I(:,:,:,:), obs_Q(:,:,:,:), obs_U(:,:,:,:), obs_V(:,:,:,:)
+  real(wp), allocatable, target :: obs_scatt_2D(:,:,:), obs_direc_2D(:,:,:), obs_I_2D(:,:,:), obs_Q_2D(:,:,:), obs_U_2D(:,:,:), obs_V_2D(:,:,:)
+
+contains
+  elemental function is_finite(x) result(r)
+    real(wp), intent(in) :: x
+    logical :: r
+    r = ieee_is_finite(x)
+  end function is_finite
+
+  elemental function vtherm_total(T) result(vt)       ! define.f90:928-933 (par%bturb unset)
+    real(wp), intent(in) :: T
+    real(wp) :: vt
+    vt = line%vtherm1 * sqrt(T)
+  end function vtherm_total
+
+  function strlowcase(s) result(t)
+    character(len=*), intent(in) :: s
+    character(len=len(s)) :: t
+    integer :: i, c
+    t = s
+    do i = 1, len(s)
+       c = iachar(s(i:i))
+       if (c >= 65 .and. c <= 90) t(i:i) = achar(c + 32)
+    enddo
+  end function strlowcase
+end module lart_define
+
+!==============================================================================
+module lart_host
+  use lart_define
+  implicit none
+contains
+
+  !--- setup_resonance_line, Ly-alpha branch: line_mod.f90:1241-1270
+  subroutine setup_resonance_line()
+    real(wp), parameter :: sigma_0 = 0.026540083434_wp, amu = 1.67262192e-24_wp, vtherm1_amu = 0.12895319011972164_wp
+    real(wp) :: mass_amu
+    line%wavelength0 = 0.1215668237310_wp
+    line%damping     = 6.2649e8_wp
+    line%cross0      = sigma_0/sqrt(pi)*(0.27760_wp + 0.13881_wp + 0.0_wp)
+    mass_amu         = 1.00797_wp
+    line%vtherm1     = vtherm1_amu/sqrt(mass_amu)
+    line%g_recoil0   = (h_planck/amu/mass_amu)/(line%wavelength0*um2m)**2
+    line%E1 = 1.0_wp; line%E2 = 0.0_wp; line%E3 = 1.0_wp
+  end subroutine setup_resonance_line
+
+  subroutine not_supported(what)
+    character(len=*), intent(in) :: what
+    write(*,'(3a)') 'ERROR: ', what, ' is not supported by the MI355X photon path (Cartesian uniform media only).'
+    stop 1
+  end subroutine not_supported
+
+  !--- read_input: setup.f90:4-579 (namelist + the post-processing this path needs)
+  subroutine read_input(model_infile)
+    character(len=*), intent(in) :: model_infile
+    integer :: unit, ios
+    real(wp) :: r0
+    character(len=256) :: msg
+    namelist /parameters/ par
+
+    call open_sanitized(model_infile, unit)
+    read(unit, parameters, iostat=ios, iomsg=msg)
+    close(unit)
+    if (ios /= 0) then          ! unknown names fail the namelist read, as in the reference
+       write(*,'(2a)') 'ERROR reading &parameters: ', trim(msg); stop 1
+    endif
+
+    if (par%no_photons >= 1) par%nphotons = int(par%no_photons, int64)
+    if (par%no_print   > 1) par%nprint = int(par%no_print)
+    if (par%nprint >= par%nphotons) par%nprint = int(par%nphotons/10)
+    if (par%no_photons <= 10) par%nprint = 1
+
+    par%geometry        = strlowcase(par%geometry)
+    par%source_geometry = strlowcase(par%source_geometry)
+    par%velocity_type   = strlowcase(par%velocity_type)
+    par%distance_unit   = strlowcase(par%distance_unit)
+    par%spectral_type   = strlowcase(par%spectral_type)
+
+    if (par%use_amr_grid)      call not_supported('par%use_amr_grid = .true.')
+    if (par%use_clump_medium)  call not_supported('par%use_clump_medium = .true.')
+    if (par%fine_structure)    call not_supported('par%fine_structure = .true.')
+    if (par%include_deuterium) call not_supported('par%include_deuterium = .true.')
+    if (trim(par%line_id) /= 'ly_alpha') call not_supported('par%line_id /= ly_alpha')
+    if (trim(strlowcase(par%h2_model)) /= 'none') call not_supported('par%h2_model')
+    if (par%xy_symmetry .or. par%z_symmetry) call not_supported('par%xy_symmetry / par%z_symmetry')
+    if (par%bturb > 0.0_wp) call not_supported('par%bturb')
+    if (len_trim(par%dens_file) + len_trim(par%temp_file) + len_trim(par%velo_file) + len_trim(par%emiss_file) + &
+        len_trim(par%cart_file) + len_trim(par%input_field) + len_trim(par%star_file) > 0) call not_supported('an input field file')
+    if (par%nside > 0) call not_supported('par%nside > 0 (HEALPix inside observer)')
+    if (par%save_all_photons) call not_supported('par%save_all_photons')
+
+    select case(trim(par%geometry))
+    case ('');    par%geometry = 'sphere'
+    case ('box'); par%geometry = 'rectangle'
+    end select
+    if (trim(par%geometry) /= 'sphere' .and. trim(par%geometry) /= 'rectangle') call not_supported('par%geometry = '//trim(par%geometry))
+    if (trim(par%source_geometry) == 'sphere') par%source_geometry = 'uniform_sphere'
+    if (trim(par%source_geometry) /= 'point' .and. trim(par%source_geometry) /= 'uniform_sphere') &
+       call not_supported('par%source_geometry = '//trim(par%source_geometry))
+    if (trim(par%spectral_type) /= 'voigt' .and. trim(par%spectral_type) /= 'monochromatic') &
+       call not_supported('par%spectral_type = '//trim(par%spectral_type))
+    select case(trim(par%velocity_type))
+    case ('', 'hubble', 'constant_radial', 'parallel_velocity')
+    case default; call not_supported('par%velocity_type = '//trim(par%velocity_type))
+    end select
+
+    call setup_resonance_line()
+    par%nscatt_dust = 0.0_wp; par%nscatt_gas = 0.0_wp; par%nscatt_tot = 0.0_wp
+
+    if (par%temperature <= 0.0_wp) then
+       write(*,'(a)') 'ERROR: par%temperature must be > 0 K (or set par%bturb > 0)'; stop 1
+    endif
+    if (par%nx == 1 .or. par%ny == 1 .or. par%nz == 1) par%xyz_symmetry = .false.            ! setup.f90:167
+
+    if (.not.(par%save_peeloff_2D .or. par%save_peeloff_3D)) par%save_peeloff = .false.      ! :188-206
+    if (par%nxim > 0 .and. par%nyim > 0)                     par%save_peeloff = .true.
+    if (par%save_peeloff .and. par%xyz_symmetry) then
+       par%save_peeloff = .false.
+       write(*,'(a)') '---> peelingoff is not allowed for a geometry with the xyz_symmetry.'
+       write(*,'(a)') '---> setting par%save_peeloff = .false.'
+    endif
+    if (.not. par%save_peeloff) then
+       par%save_peeloff_2D = .false.; par%save_peeloff_3D = .false.
+    endif
+
+    if (par%tau0 > 0.0_wp .and. par%taumax  < 0.0_wp) par%taumax  = par%tau0                   ! :228-233
+    if (par%N_HI > 0.0_wp .and. par%N_HImax < 0.0_wp) par%N_HImax = par%N_HI
+    if (par%N_HImax  > 0.0_wp .and. par%N_gasmax  < 0.0_wp) par%N_gasmax  = par%N_HImax
+    if (par%N_HIhomo > 0.0_wp .and. par%N_gashomo < 0.0_wp) par%N_gashomo = par%N_HIhomo
+    if (par%cext_dust <= 0.0_wp) par%DGR       = 0.0_wp
+    if (par%DGR == 0.0_wp)       par%save_Jabs = .false.
+    if (par%core_skip_global)    par%core_skip = .true.
+
+    if (par%save_Jmu) then                                                                      ! :367-381
+       if (par%nmu < 1) then
+          write(*,'(a)') 'ERROR: par%nmu must be >= 1 when par%save_Jmu = .true.'; stop 1
+       endif
+       if (par%xyz_symmetry) then
+          par%mu_min = 0.0_wp;  par%dmu = 1.0_wp/par%nmu
+       else
+          par%mu_min = -1.0_wp; par%dmu = 2.0_wp/par%nmu
+       endif
+    endif
+    if (par%nr > 1) then
+       par%nx = par%nr; par%ny = par%nr; par%nz = par%nr
+    endif
+    select case(trim(par%geometry))                                                             ! :398-428
+    case ('sphere')
+       if (.not. par%xy_periodic) then
+          r0 = maxval([par%rmax, par%xmax, par%ymax, par%zmax], mask=[par%rmax, par%xmax, par%ymax, par%zmax] > 0.0_wp)
+          if (r0 > 0.0_wp) then
+             par%rmax = r0; par%xmax = r0; par%ymax = r0; par%zmax = r0
+          endif
+          par%nx = maxval([par%nx, par%ny, par%nz]); par%ny = par%nx; par%nz = par%nx
+       endif
+    case ('rectangle')
+       par%rmax = -1.0_wp
+    end select
+    if (par%source_rmax < 0.0_wp) par%source_rmax = par%rmax
+    if (par%distance2cm < 0.0_wp) then                                                          ! :473-489
+       select case(trim(par%distance_unit))
+       case ('kpc'); par%distance2cm = 3.0856776e18_wp*1e3_wp
+       case ('pc');  par%distance2cm = 3.0856776e18_wp
+       case ('au');  par%distance2cm = 1.4960e13_wp
+       case ('');    par%distance2cm = 1.0_wp
+       case default; par%distance2cm = 3.0856776e18_wp*1e3_wp
+       end select
+    else
+       par%distance_unit = 'user'
+    endif
+    if (par%intensity_unit < 0) then
+       if (par%distance2cm /= 1.0_wp) then
+          par%intensity_unit = 1
+       else
+          par%intensity_unit = 0
+       endif
+    endif
+    if (len_trim(par%scatt_mat_file) > 0 .and. par%DGR > 0.0_wp) then                          ! :496-500
+       call setup_scattering_matrix(trim(par%scatt_mat_file))
+    else
+       if (par%use_stokes) par%DGR = 0.0_wp
+    endif
+    if (par%DGR == 0.0_wp) par%save_Jabs = .false.
+
+    if (len_trim(par%out_file) == 0) then
+       par%base_name = base_of(model_infile)
+    else
+       par%base_name = base_of(par%out_file)
+    endif
+    par%out_file = trim(par%base_name)//'.fits'
+
+    write(*,'(a)')        ''
+    write(*,'(3a)')       '+++++ ',trim(model_infile),' +++++'
+    write(*,'(2a)')       'Line ID                   : ', trim(par%line_id)
+    write(*,'(a,2f7.4)')  'Dust Parameters(a, g)     : ', par%albedo, par%hgg
+    write(*,'(a,es12.3)') 'Dust-to-Gas Ratio         : ', par%DGR
+    if (par%DGR > 0.0) write(*,'(a,es12.3)') 'Dust Extinction per H     : ', par%cext_dust
+    write(*,'(a,es12.3)') 'Total number of photons   : ', par%no_photons
+  contains
+    !--- the shipped example inputs assign real literals to integer fields (par%nprint = 1e5), which ifort and
+    !--- gfortran accept and flang rejects: copy the file to a scratch unit with those literals made integer.
+    subroutine open_sanitized(fname, uout)
+      character(len=*), intent(in) :: fname
+      integer, intent(out) :: uout
+      character(len=*), parameter :: intfields(14) = [character(len=10) :: 'nprint', 'nx', 'ny', 'nz', 'nr', 'nxfreq', 'nxim', &
+           'nyim', 'nmu', 'nside', 'iseed', 'nobs', 'nvelocity', 'ngpu']
+      character(len=512) :: ln, name, val
+      integer :: uin, io, ip, ie, k
+      real(wp) :: rv
+      open(newunit=uin, file=trim(fname), status='old', iostat=io)
+      if (io /= 0) then
+         write(*,'(2a)') 'ERROR: cannot open input file ', trim(fname); stop 1
+      endif
+      open(newunit=uout, status='scratch', form='formatted')
+      do
+         read(uin, '(a)', iostat=io) ln
+         if (io /= 0) exit
+         ip = index(ln, 'par%'); ie = index(ln, '=')
+         if (ip > 0 .and. ie > ip .and. (index(ln, '!') == 0 .or. index(ln, '!') > ie)) then
+            name = adjustl(ln(ip+4:ie-1)); val = adjustl(ln(ie+1:))
+            if (index(val, '!') > 0) val = val(1:index(val, '!')-1)
+            do k = 1, size(intfields)
+               if (trim(strlowcase(name)) == trim(intfields(k)) .and. scan(trim(val), '.eEdD') > 0) then
+                  read(val, *, iostat=io) rv
+                  if (io == 0) write(ln, '(a,a,a,i0)') ' par%', trim(name), ' = ', nint(rv)
+               endif
+            enddo
+         endif
+         write(uout, '(a)') trim(ln)
+      enddo
+      close(uin)
+      rewind(uout)
+    end subroutine open_sanitized
+    function base_of(f) result(b)
+      character(len=*), intent(in) :: f
+      character(len=128) :: b
+      integer :: i1, i2
+      i1 = index(f, '/', back=.true.) + 1
+      b = f(i1:)
+      i2 = index(b, '.')
+      if (i2 > 1) b = b(1:i2-1)
+    end function base_of
+  end subroutine read_input
+
+  !--- random_alias_setup64: random_mt.f90:2016-2067
+  subroutine random_alias_setup(probs, alias)
+    real(wp), intent(inout) :: probs(:)
+    integer(int32), intent(out) :: alias(:)
+    integer, allocatable :: small(:), large(:)
+    integer :: n, i, ns, nl, ks, kl
+    n = size(probs)
+    allocate(small(n), large(n)); small = 0; large = 0; alias = 0
+    ns = 0; nl = 0
+    do i = 1, n
+       probs(i) = n * probs(i)
+       if (probs(i) < 1.0_wp) then
+          ns = ns + 1; small(ns) = i
+       else
+          nl = nl + 1; large(nl) = i
+       endif
+    enddo
+    do while (ns > 0 .and. nl > 0)
+       ks = small(ns); kl = large(nl); ns = ns - 1; nl = nl - 1
+       alias(ks) = kl
+       probs(kl) = probs(kl) + probs(ks) - 1.0_wp
+       if (probs(kl) < 1.0_wp) then
+          ns = ns + 1; small(ns) = kl
+       else
+          nl = nl + 1; large(nl) = kl
+       endif
+    enddo
+  end subroutine random_alias_setup
+
+  !--- setup_scattering_matrix: setup.f90:581-649
+  subroutine setup_scattering_matrix(fname)
+    character(len=*), intent(in) :: fname
+    character(len=128) :: string_tmp
+    real(wp) :: wavelength, cext, albedo, hgg, S11_norm
+    integer :: i, unit, n, ios
+    open(newunit=unit, file=fname, status='old', iostat=ios)
+    if (ios /= 0) then
+       write(*,'(2a)') 'ERROR: cannot open par%scatt_mat_file ', fname; stop 1
+    endif
+    read(unit,*) string_tmp
+    read(unit,*) wavelength, cext, albedo, hgg, n
+    par%albedo = albedo; par%hgg = hgg; par%cext_dust = cext
+    read(unit,*) string_tmp
+    scatt_mat%nPDF = n
+    allocate(scatt_mat%coss(n), scatt_mat%S11(n), scatt_mat%S12(n), scatt_mat%S33(n), scatt_mat%S34(n))
+    allocate(scatt_mat%phase_PDF(n-1), scatt_mat%alias(n-1))
+    do i = 1, n
+       read(unit,*) scatt_mat%coss(i), scatt_mat%S11(i), scatt_mat%S12(i), scatt_mat%S33(i), scatt_mat%S34(i)
+    enddo
+    close(unit)
+    S11_norm = 0.0_wp                                  ! calc_Integral, mathlib.f90:218-240
+    do i = 2, n
+       S11_norm = S11_norm + 0.5_wp*(scatt_mat%S11(i) + scatt_mat%S11(i-1))*abs(scatt_mat%coss(i) - scatt_mat%coss(i-1))
+    enddo
+    scatt_mat%S11 = scatt_mat%S11/S11_norm; scatt_mat%S12 = scatt_mat%S12/S11_norm
+    scatt_mat%S33 = scatt_mat%S33/S11_norm; scatt_mat%S34 = scatt_mat%S34/S11_norm
+    do i = 1, n-1
+       scatt_mat%phase_PDF(i) = (scatt_mat%S11(i) + scatt_mat%S11(i+1))/2.0_wp
+    enddo
+    scatt_mat%phase_PDF = scatt_mat%phase_PDF / sum(scatt_mat%phase_PDF)
+    call random_alias_setup(scatt_mat%phase_PDF, scatt_mat%alias)
+  end subroutine setup_scattering_matrix
+
+  !--- H(0,a) on the x = 0 node of the Voigt table (voigt_mod.f90:691-700 with v = 0)
+  elemental function voigt0(a) result(h)
+    real(wp), intent(in) :: a
+    real(wp) :: h
+    h = 1.0_wp + a*(-1.1283791671_wp + a*1.0_wp)
+  end function voigt0
+
+  !--- grid_create: grid_mod_car.f90:73-1238, analytic-medium subset
+  subroutine grid_create(grid)
+    type(grid_type), intent(inout) :: grid
+    integer  :: i, j, k, nx, ny, nz, nxcen, nycen
+    real(wp) :: rr, vtherm, opac_length, opacity_sum, opacity1, opac_norm, nopac, nadd, os2
+    real(wp) :: tauhomo, taupole, N_gashomo, N_gaspole, atau0, atau0_cell, xi, chi, rpeak
+    real(wp), allocatable :: xx(:), yy(:), zz(:)
+
+    grid%nx = par%nx; grid%ny = par%ny; grid%nz = par%nz
+    grid%xmax = par%xmax; grid%ymax = par%ymax; grid%zmax = par%zmax; grid%rmin = par%rmin; grid%rmax = par%rmax
+    nx = grid%nx; ny = grid%ny; nz = grid%nz
+    if (par%xyz_symmetry) then                                                                  ! :85-112
+       call sym_axis(nx, grid%xmax, grid%dx, grid%xmin, grid%i0)
+       call sym_axis(ny, grid%ymax, grid%dy, grid%ymin, grid%j0)
+       call sym_axis(nz, grid%zmax, grid%dz, grid%zmin, grid%k0)
+    else                                                                                        ! :166-176
+       grid%dx = 2.0_wp*par%xmax/par%nx; grid%dy = 2.0_wp*par%ymax/par%ny; grid%dz = 2.0_wp*par%zmax/par%nz
+       grid%xmin = -grid%xmax; grid%ymin = -grid%ymax; grid%zmin = -grid%zmax
+       grid%i0 = 0; grid%j0 = 0; grid%k0 = 0
+    endif
+    grid%xrange = grid%xmax - grid%xmin; grid%yrange = grid%ymax - grid%ymin; grid%zrange = grid%zmax - grid%zmin
+    allocate(grid%xface(nx+1), grid%yface(ny+1), grid%zface(nz+1))
+    grid%xface(:) = [ ((i-1)*grid%dx + grid%xmin, i=1,nx+1) ]
+    grid%yface(:) = [ ((j-1)*grid%dy + grid%ymin, j=1,ny+1) ]
+    grid%zface(:) = [ ((k-1)*grid%dz + grid%zmin, k=1,nz+1) ]
+    allocate(grid%vfx(nx,ny,nz), grid%vfy(nx,ny,nz), grid%vfz(nx,ny,nz), grid%Dfreq(nx,ny,nz), grid%voigt_a(nx,ny,nz), grid%rhokap(nx,ny,nz))
+    if (par%DGR > 0.0_wp) allocate(grid%rhokapD(nx,ny,nz))
+    grid%vfx = 0.0_wp; grid%vfy = 0.0_wp; grid%vfz = 0.0_wp
+    allocate(xx(nx), yy(ny), zz(nz))
+    do i = 1, nx; xx(i) = (grid%xface(i) + grid%xface(i+1))/2.0_wp; enddo
+    do j = 1, ny; yy(j) = (grid%yface(j) + grid%yface(j+1))/2.0_wp; enddo
+    do k = 1, nz; zz(k) = (grid%zface(k) + grid%zface(k+1))/2.0_wp; enddo
+
+    grid%Dfreq_ref = vtherm_total(par%temperature)/(line%wavelength0*um2km)                      ! :238
+    vtherm = vtherm_total(par%temperature)                                                      ! :273-284
+    grid%Dfreq   = vtherm/(line%wavelength0*um2km)
+    grid%voigt_a = (line%damping/fourpi)/grid%Dfreq
+    par%distance_unit = ''; par%distance2cm = 1.0_wp                                            ! :352-365
+    grid%rhokap = 1.0_wp
+    if (par%DGR > 0.0_wp) grid%rhokapD = par%cext_dust * par%DGR
+    if (par%rmax > 0.0_wp) then                                                                 ! :367-395
+       do k = 1, nz; do j = 1, ny; do i = 1, nx
+          rr = sqrt(xx(i)**2 + yy(j)**2 + zz(k)**2)
+          if (rr < par%rmin .or. rr > par%rmax) then
+             grid%rhokap(i,j,k) = 0.0_wp
+             if (par%DGR > 0.0_wp) grid%rhokapD(i,j,k) = 0.0_wp
+          endif
+       enddo; enddo; enddo
+    endif
+    grid%rhokap = grid%rhokap/grid%Dfreq*line%cross0                                            ! :487-493
+    if (par%rmax > 0.0_wp .and. par%rmin > 0.0_wp) then                                         ! :495-503
+       opac_length = par%rmax - par%rmin
+    else if (par%rmax > 0.0_wp) then
+       opac_length = par%rmax
+    else if (grid%zmax == -grid%zmin) then
+       opac_length = grid%zrange/2.0_wp
+    else
+       opac_length = grid%zrange
+    endif
+    if (par%xyz_symmetry) then
+       nxcen = 1; nycen = 1
+    else
+       nxcen = (nx+1)/2; nycen = (ny+1)/2
+    endif
+
+    if (par%taumax > 0.0_wp) then                                                               ! :518-538
+       opacity_sum = 0.0_wp
+       do k = 1, nz
+          opacity_sum = opacity_sum + grid%rhokap(nxcen,nycen,k)*voigt0(grid%voigt_a(nxcen,nycen,k))
+       enddo
+       if (par%xyz_symmetry) then
+          if ((nz/2)*2 == nz) then
+             opac_norm = par%taumax/(opacity_sum*grid%dz)
+          else
+             opacity1  = grid%rhokap(nxcen,nycen,1)*voigt0(grid%voigt_a(nxcen,nycen,1))
+             opac_norm = par%taumax/((opacity_sum - opacity1/2.0_wp)*grid%dz)
+          endif
+       else if (grid%zmax == -grid%zmin) then
+          opac_norm = (2.0_wp*par%taumax)/(opacity_sum*grid%dz)
+       else
+          opac_norm = par%taumax/(opacity_sum*grid%dz)
+       endif
+       call scale_opacity(opac_norm)
+    else if (par%tauhomo > 0.0_wp) then                                                         ! :539-566
+       call homo_sums(opacity_sum, os2, nopac)
+       call scale_opacity(par%tauhomo/(opacity_sum/nopac*opac_length))
+    else if (par%N_gasmax > 0.0_wp) then                                                        ! :567-586
+       opacity_sum = 0.0_wp
+       do k = 1, nz
+          opacity_sum = opacity_sum + grid%rhokap(nxcen,nycen,k)*grid%Dfreq(nxcen,nycen,k)
+       enddo
+       if (par%xyz_symmetry) then
+          if ((nz/2)*2 == nz) then
+             opac_norm = par%N_gasmax/(opacity_sum*grid%dz/line%cross0)
+          else
+             opacity1  = grid%rhokap(nxcen,nycen,1)*grid%Dfreq(nxcen,nycen,1)
+             opac_norm = par%N_gasmax/((opacity_sum - opacity1/2.0_wp)*grid%dz/line%cross0)
+          endif
+       else if (grid%zmax == -grid%zmin) then
+          opac_norm = (2.0_wp*par%N_gasmax)/(opacity_sum*grid%dz/line%cross0)
+       else
+          opac_norm = par%N_gasmax/(opacity_sum*grid%dz/line%cross0)
+       endif
+       call scale_opacity(opac_norm)
+    else if (par%N_gashomo > 0.0_wp) then                                                       ! :587-615
+       call homo_sums(opacity_sum, os2, nopac)
+       call scale_opacity(par%N_gashomo/((os2/nopac/line%cross0)*opac_length))
+    endif
+
+    call homo_sums(opacity_sum, os2, nopac)                                                     ! :617-737
+    tauhomo   = opacity_sum/nopac*opac_length
+    N_gashomo = os2/nopac/line%cross0*opac_length
+    opacity_sum = 0.0_wp; os2 = 0.0_wp
+    do k = 1, nz
+       opacity_sum = opacity_sum + grid%rhokap(nxcen,nycen,k)*voigt0(grid%voigt_a(nxcen,nycen,k))
+       os2         = os2 + grid%rhokap(nxcen,nycen,k)*grid%Dfreq(nxcen,nycen,k)
+    enddo
+    if (par%xyz_symmetry) then
+       taupole = opacity_sum*grid%dz; N_gaspole = os2*grid%dz/line%cross0
+       if ((nz/2)*2 /= nz) then
+          taupole   = taupole - grid%rhokap(nxcen,nycen,1)*voigt0(grid%voigt_a(nxcen,nycen,1))*grid%dz/2.0_wp
+          N_gaspole = N_gaspole - grid%rhokap(nxcen,nycen,1)*grid%Dfreq(nxcen,nycen,1)*grid%dz/2.0_wp/line%cross0
+       endif
+    else if (grid%zmax == -grid%zmin) then
+       taupole = opacity_sum*grid%dz/2.0_wp; N_gaspole = os2*grid%dz/2.0_wp/line%cross0
+    else
+       taupole = opacity_sum*grid%dz; N_gaspole = os2*grid%dz/line%cross0
+    endif
+    if (par%taumax    <= 0.0_wp) par%taumax    = taupole
+    if (par%tauhomo   <= 0.0_wp) par%tauhomo   = tauhomo
+    if (par%N_gasmax  <= 0.0_wp) par%N_gasmax  = N_gaspole
+    if (par%N_gashomo <= 0.0_wp) par%N_gashomo = N_gashomo
+
+    if (len_trim(par%velocity_type) > 0) then                                                   ! :786-946
+       if (par%rmax <= 0.0_wp) then
+          rpeak = maxval([grid%xmax, grid%ymax, grid%zmax])
+       else
+          rpeak = par%rmax
+       endif
+       do k = 1, nz; do j = 1, ny; do i = 1, nx
+          if (grid%rhokap(i,j,k) > 0.0_wp) then
+             select case(trim(par%velocity_type))
+             case ('hubble')
+                grid%vfx(i,j,k) = (par%Vexp/vtherm)*xx(i)/rpeak
+                grid%vfy(i,j,k) = (par%Vexp/vtherm)*yy(j)/rpeak
+                grid%vfz(i,j,k) = (par%Vexp/vtherm)*zz(k)/rpeak
+             case ('constant_radial')
+                rr = sqrt(xx(i)**2 + yy(j)**2 + zz(k)**2)
+                if (rr > grid%dz/10.0_wp) then
+                   grid%vfx(i,j,k) = par%Vexp/vtherm*xx(i)/rr
+                   grid%vfy(i,j,k) = par%Vexp/vtherm*yy(j)/rr
+                   grid%vfz(i,j,k) = par%Vexp/vtherm*zz(k)/rr
+                endif
+             case ('parallel_velocity')
+                grid%vfx(i,j,k) = par%Vx/vtherm; grid%vfy(i,j,k) = par%Vy/vtherm; grid%vfz(i,j,k) = par%Vz/vtherm
+             end select
+          endif
+       enddo; enddo; enddo
+    endif
+
+    grid%voigt_amean = (line%damping/fourpi)/grid%Dfreq_ref                                     ! :1150-1154
+    atau0 = grid%voigt_amean*par%tauhomo
+    call car_setup_freq_grid(grid)
+    allocate(grid%Jout(grid%nxfreq), grid%Jin(grid%nxfreq), grid%Jabs(grid%nxfreq), grid%Jmu(grid%nxfreq, max(par%nmu,1)))
+    grid%Jout = 0.0_wp; grid%Jin = 0.0_wp; grid%Jabs = 0.0_wp; grid%Jmu = 0.0_wp
+    if (par%core_skip_global) then                                                              ! :1186-1219
+       atau0_cell = atau0
+    else
+       atau0_cell = atau0/(grid%xmax/grid%dx)
+    endif
+    if (atau0_cell > 1.0_wp) then
+       if (atau0_cell <= 60.0_wp) then
+          xi = 0.6_wp; chi = 1.2_wp
+       else
+          xi = 1.4_wp; chi = 0.6_wp
+       endif
+       grid%xcrit = 0.02_wp*exp(xi*(log(atau0_cell))**chi); grid%xcrit2 = grid%xcrit**2
+    endif
+
+    write(6,'(a,es16.3)') 'voigt_a          : ', grid%voigt_amean                                ! :1228-1237
+    write(6,'(a,es16.3)') 'temperature (K)  : ', par%temperature
+    write(6,'(a,es16.3)') 'N(H  I)_pole     : ', N_gaspole
+    write(6,'(a,es16.3)') 'N(H  I)_homo     : ', N_gashomo
+    write(6,'(a,es16.3)') 'tau_pole  (H  I) : ', taupole
+    write(6,'(a,es16.3)') 'tau_homo  (H  I) : ', tauhomo
+  contains
+    subroutine sym_axis(n, vmax, d, vmin, i0)
+      integer, intent(in) :: n
+      real(wp), intent(in) :: vmax
+      real(wp), intent(out) :: d, vmin
+      integer, intent(out) :: i0
+      if ((n/2)*2 == n) then
+         d = vmax/n; vmin = 0.0_wp; i0 = 1
+      else
+         d = vmax/(n - 0.5_wp); vmin = -d/2.0_wp; i0 = 2
+      endif
+    end subroutine sym_axis
+    subroutine scale_opacity(f)
+      real(wp), intent(in) :: f
+      grid%rhokap = grid%rhokap*f
+      if (par%DGR > 0.0_wp) grid%rhokapD = grid%rhokapD*f
+    end subroutine scale_opacity
+    subroutine homo_sums(s_tau, s_n, cnt)
+      real(wp), intent(out) :: s_tau, s_n, cnt
+      integer :: ii, jj, kk
+      s_tau = 0.0_wp; s_n = 0.0_wp; cnt = 0.0_wp
+      do kk = 1, nz; do jj = 1, ny; do ii = 1, nx
+         nadd = 1.0_wp
+         if (par%xyz_symmetry) then
+            if (ii == 1 .and. (nx/2)*2 /= nx) nadd = nadd/2.0_wp
+            if (jj == 1 .and. (ny/2)*2 /= ny) nadd = nadd/2.0_wp
+            if (kk == 1 .and. (nz/2)*2 /= nz) nadd = nadd/2.0_wp
+         endif
+         if (grid%rhokap(ii,jj,kk) > 0.0_wp) then
+            s_tau = s_tau + grid%rhokap(ii,jj,kk)*voigt0(grid%voigt_a(ii,jj,kk))*nadd
+            s_n   = s_n   + grid%rhokap(ii,jj,kk)*grid%Dfreq(ii,jj,kk)*nadd
+            cnt   = cnt + nadd
+         endif
+      enddo; enddo; enddo
+    end subroutine homo_sums
+  end subroutine grid_create
+
+  !--- car_setup_freq_grid: grid_mod_car.f90:1442-1548
+  subroutine car_setup_freq_grid(grid)
+    type(grid_type), intent(inout) :: grid
+    real(wp) :: vtherm, xscale, atau3
+    integer :: i
+    atau3 = (grid%voigt_amean*par%tauhomo)**(1.0_wp/3.0_wp)
+    par%atau3 = atau3
+    vtherm = vtherm_total(par%temperature)
+    if (is_finite(par%velocity_min) .and. is_finite(par%velocity_max)) then
+       if (par%nvelocity == 0 .and. par%nxfreq > 0) par%nvelocity = par%nxfreq
+       if (par%nvelocity > 0) par%nxfreq = par%nvelocity
+       par%xfreq_min = -par%velocity_max/vtherm
+       par%xfreq_max = -par%velocity_min/vtherm
+    endif
+    grid%nxfreq = par%nxfreq
+    if (.not.(is_finite(par%xfreq_max) .and. is_finite(par%xfreq_min))) then
+       if (par%taumax <= 5e1_wp) then
+          xscale = 25.0_wp
+       else if (par%taumax <= 5e2_wp) then
+          xscale = 14.0_wp
+       else if (par%taumax <= 5e3_wp) then
+          xscale = 10.0_wp
+       else
+          xscale = 5.0_wp
+       endif
+       if (par%Vexp == 0.0_wp) then
+          par%xfreq_max = floor(xscale*atau3) + 1
+          par%xfreq_min = -(floor(xscale*atau3 + 0.0_wp) + 1)
+       else if (par%Vexp > 0.0_wp) then
+          par%xfreq_max = floor(xscale*atau3) + 1
+          par%xfreq_min = -(floor(xscale*atau3 + abs(par%Vexp)/vtherm + 0.0_wp) + 1)
+       else
+          par%xfreq_max = floor(xscale*atau3 + abs(par%Vexp)/vtherm) + 1
+          par%xfreq_min = -(floor(xscale*atau3 + 0.0_wp) + 1)
+       endif
+    endif
+    allocate(grid%xfreq(grid%nxfreq), grid%velocity(grid%nxfreq), grid%wavelength(grid%nxfreq))
+    grid%dxfreq    = (par%xfreq_max - par%xfreq_min)/par%nxfreq
+    grid%xfreq_max = par%xfreq_max; grid%xfreq_min = par%xfreq_min
+    grid%xfreq(:)      = [ ((i-0.5_wp)*grid%dxfreq + grid%xfreq_min, i=1, grid%nxfreq) ]
+    grid%velocity(:)   = -vtherm_total(par%temperature)*grid%xfreq(:)
+    grid%dwave         =  vtherm_total(par%temperature)/speedc*(line%wavelength0*1e4_wp)*grid%dxfreq
+    grid%wavelength(:) = (grid%velocity(:)/speedc + 1.0_wp)*(line%wavelength0*1e4_wp)
+  end subroutine car_setup_freq_grid
+
+  !--- observer_create_outside: observer_rect.f90:24-326 (rotation centre at the origin)
+  subroutine observer_create()
+    real(wp), allocatable :: cosa(:), sina(:), cosb(:), sinb(:), cosg(:), sing(:)
+    real(wp) :: dist_scale, maxsz, px, py, pz, kx, ky, kz, ang_x, ang_y, max_ang_x, max_ang_y
+    real(wp), parameter :: vertex_x(8) = [1.0, 1.0, 1.0, -1.0, -1.0, -1.0,  1.0, -1.0]
+    real(wp), parameter :: vertex_y(8) = [1.0, 1.0, -1.0, 1.0, -1.0,  1.0, -1.0, -1.0]
+    real(wp), parameter :: vertex_z(8) = [1.0, -1.0, 1.0, 1.0,  1.0, -1.0, -1.0, -1.0]
+    integer :: i, iv, n
+    if (.not. par%save_peeloff) then
+       par%nobs = 0; return
+    endif
+    maxsz = maxval([par%xmax, par%ymax, par%zmax])
+    where (is_finite(par%beta)  .and. .not. is_finite(par%alpha)) par%alpha = 0.0_wp
+    where (is_finite(par%alpha) .and. .not. is_finite(par%beta))  par%beta  = 0.0_wp
+    if (.not. (is_finite(par%alpha(1)) .and. is_finite(par%beta(1))) .and. &
+        .not. (is_finite(par%obsx(1)) .and. is_finite(par%obsy(1)) .and. is_finite(par%obsz(1)))) then
+       if (.not. is_finite(par%distance)) par%distance = maxsz*100.0_wp
+       par%obsx(1) = 0.0_wp; par%obsy(1) = 0.0_wp; par%obsz(1) = 1.0_wp
+       par%alpha(1) = 0.0_wp; par%beta(1) = 0.0_wp
+    endif
+    if (is_finite(par%alpha(1)) .and. is_finite(par%beta(1))) then
+       n = count(is_finite(par%alpha) .and. is_finite(par%beta))
+       par%nobs = n
+       allocate(cosa(n), sina(n), cosb(n), sinb(n), cosg(n), sing(n), observer(n))
+       if (.not. is_finite(par%distance)) par%distance = maxsz*100.0_wp
+       do i = 1, n
+          call default_gamma(i)
+          cosa(i) = cos(par%alpha(i)*deg2rad); sina(i) = sin(par%alpha(i)*deg2rad)
+          cosb(i) = cos(par%beta(i) *deg2rad); sinb(i) = sin(par%beta(i) *deg2rad)
+          cosg(i) = cos(par%gamma(i)*deg2rad); sing(i) = sin(par%gamma(i)*deg2rad)
+          observer(i)%x = par%distance*cosa(i)*sinb(i)
+          observer(i)%y = par%distance*sina(i)*sinb(i)
+          observer(i)%z = par%distance*cosb(i)
+       enddo
+    else
+       n = count(is_finite(par%obsx) .and. is_finite(par%obsy) .and. is_finite(par%obsz))
+       par%nobs = n
+       allocate(cosa(n), sina(n), cosb(n), sinb(n), cosg(n), sing(n), observer(n))
+       if (.not. is_finite(par%distance)) then
+          par%distance = sqrt(par%obsx(1)**2 + par%obsy(1)**2 + par%obsz(1)**2)
+          if (par%distance < 10.0_wp*maxsz) par%distance = maxsz*100.0_wp
+       endif
+       do i = 1, n
+          call default_gamma(i)
+          dist_scale = par%distance/sqrt(par%obsx(i)**2 + par%obsy(i)**2 + par%obsz(i)**2)
+          if (dist_scale > 1.001_wp) then
+             observer(i)%x = par%obsx(i)*dist_scale; observer(i)%y = par%obsy(i)*dist_scale; observer(i)%z = par%obsz(i)*dist_scale
+          else
+             observer(i)%x = par%obsx(i); observer(i)%y = par%obsy(i); observer(i)%z = par%obsz(i)
+          endif
+          cosb(i) = observer(i)%z/par%distance
+          if (abs(cosb(i) - 1.0_wp) < epsilon(0.0_wp)) cosb(i) =  1.0_wp
+          if (abs(cosb(i) + 1.0_wp) < epsilon(0.0_wp)) cosb(i) = -1.0_wp
+          sinb(i) = sqrt(1.0_wp - cosb(i)**2)
+          par%beta(i) = atan2(sinb(i), cosb(i))*rad2deg
+          cosg(i) = cos(par%gamma(i)*deg2rad); sing(i) = sin(par%gamma(i)*deg2rad)
+          if (sinb(i) == 0.0_wp) then
+             cosa(i) = 1.0_wp; sina(i) = 0.0_wp; par%alpha(i) = 0.0_wp
+          else
+             par%alpha(i) = atan2(observer(i)%y, observer(i)%x)
+             cosa(i) = cos(par%alpha(i)); sina(i) = sin(par%alpha(i)); par%alpha(i) = par%alpha(i)*rad2deg
+          endif
+       enddo
+    endif
+    do i = 1, par%nobs                                                                          ! :207-217
+       observer(i)%rmatrix(1,1) =  cosa(i)*cosb(i)*cosg(i) - sina(i)*sing(i)
+       observer(i)%rmatrix(1,2) =  sina(i)*cosb(i)*cosg(i) + cosa(i)*sing(i)
+       observer(i)%rmatrix(1,3) = -sinb(i)*cosg(i)
+       observer(i)%rmatrix(2,1) = -cosa(i)*cosb(i)*sing(i) - sina(i)*cosg(i)
+       observer(i)%rmatrix(2,2) = -sina(i)*cosb(i)*sing(i) + cosa(i)*cosg(i)
+       observer(i)%rmatrix(2,3) =  sinb(i)*sing(i)
+       observer(i)%rmatrix(3,1) =  cosa(i)*sinb(i)
+       observer(i)%rmatrix(3,2) =  sina(i)*sinb(i)
+       observer(i)%rmatrix(3,3) =  cosb(i)
+    enddo
+    if (.not. (is_finite(par%dxim) .and. is_finite(par%dyim))) then                             ! :244-276
+       if (trim(par%geometry) == 'sphere') then
+          par%dxim = asin(par%rmax/par%distance)/(par%nxim/2.0_wp)*rad2deg
+          par%dyim = asin(par%rmax/par%distance)/(par%nyim/2.0_wp)*rad2deg
+       else
+          max_ang_x = -999.0; max_ang_y = -999.0
+          do i = 1, par%nobs
+             do iv = 1, 8
+                px = observer(i)%x - vertex_x(iv)*par%xmax; py = observer(i)%y - vertex_y(iv)*par%ymax; pz = observer(i)%z - vertex_z(iv)*par%zmax
+                kx = observer(i)%rmatrix(1,1)*px + observer(i)%rmatrix(1,2)*py + observer(i)%rmatrix(1,3)*pz
+                ky = observer(i)%rmatrix(2,1)*px + observer(i)%rmatrix(2,2)*py + observer(i)%rmatrix(2,3)*pz
+                kz = observer(i)%rmatrix(3,1)*px + observer(i)%rmatrix(3,2)*py + observer(i)%rmatrix(3,3)*pz
+                ang_x = abs(atan2(-kx, kz)); ang_y = abs(atan2(-ky, kz))
+                if (max_ang_x < ang_x) max_ang_x = ang_x
+                if (max_ang_y < ang_y) max_ang_y = ang_y
+             enddo
+          enddo
+          if (par%nxim == par%nyim) then
+             par%dxim = maxval([max_ang_x, max_ang_y])/(par%nxim/2.0_wp)*rad2deg
+             par%dyim = maxval([max_ang_x, max_ang_y])/(par%nyim/2.0_wp)*rad2deg
+          else
+             if (.not. is_finite(par%dxim)) par%dxim = max_ang_x/(par%nxim/2.0_wp)*rad2deg
+             if (.not. is_finite(par%dyim)) par%dyim = max_ang_y/(par%nyim/2.0_wp)*rad2deg
+          endif
+       endif
+    endif
+    do i = 1, par%nobs
+       observer(i)%dxim = par%dxim; observer(i)%dyim = par%dyim; observer(i)%nxim = par%nxim; observer(i)%nyim = par%nyim
+       observer(i)%steradian_pix = par%dxim*par%dyim*(deg2rad**2)
+    enddo
+    n = par%nobs                                                                                ! :287-324
+    if (par%save_peeloff_2D) then
+       allocate(obs_scatt_2D(par%nxim,par%nyim,n), obs_direc_2D(par%nxim,par%nyim,n)); obs_scatt_2D = 0; obs_direc_2D = 0
+       if (par%use_stokes) then
+          allocate(obs_I_2D(par%nxim,par%nyim,n), obs_Q_2D(par%nxim,par%nyim,n), obs_U_2D(par%nxim,par%nyim,n), obs_V_2D(par%nxim,par%nyim,n))
+       endif
+    endif
+    if (par%save_peeloff_3D) then
+       allocate(obs_scatt(par%nxfreq,par%nxim,par%nyim,n), obs_direc(par%nxfreq,par%nxim,par%nyim,n)); obs_scatt = 0; obs_direc = 0
+       if (par%use_stokes) then
+          allocate(obs_I(par%nxfreq,par%nxim,par%nyim,n), obs_Q(par%nxfreq,par%nxim,par%nyim,n), &
+                   obs_U(par%nxfreq,par%nxim,par%nyim,n), obs_V(par%nxfreq,par%nxim,par%nyim,n))
+       endif
+    endif
+  contains
+    subroutine default_gamma(k)
+      integer, intent(in) :: k
+      if (.not. is_finite(par%gamma(k))) then
+         if (par%beta(k) > 0.0_wp .and. par%beta(k) <= 90.0_wp) then
+            par%gamma(k) = 90.0_wp
+         else if (par%beta(k) > 90.0_wp) then
+            par%gamma(k) = -90.0_wp
+         else
+            par%gamma(k) = 0.0_wp
+         endif
+      endif
+    end subroutine default_gamma
+  end subroutine observer_create
+
+  !--- output_normalize_outside: output_sum_rect.f90:151-487 (Jout/Jin/Jabs/Jmu and the peel tallies)
+  subroutine output_normalize(grid)
+    type(grid_type), intent(inout) :: grid
+    real(wp) :: area, intensity_bin_unit, scale_factor
+    par%nscatt_dust = par%nscatt_dust/par%nphotons
+    par%nscatt_gas  = par%nscatt_gas /par%nphotons
+    par%nscatt_tot  = par%nscatt_gas + par%nscatt_dust
+    if (par%intensity_unit == 1) then
+       intensity_bin_unit = grid%dwave
+    else
+       intensity_bin_unit = grid%dxfreq
+    endif
+    if (par%xy_periodic) then
+       area = 2.0_wp
+    else if (trim(par%geometry) == 'sphere') then
+       area = fourpi*grid%rmax**2*(par%distance2cm)**2
+    else
+       area = (grid%xmax*grid%ymax + grid%ymax*grid%zmax + grid%zmax*grid%xmax)*8.0_wp*(par%distance2cm)**2
+    endif
+    grid%Jout(:) = grid%Jout(:)/(par%nphotons*intensity_bin_unit*twopi*area)
+    if (par%save_Jin) grid%Jin(:) = grid%Jin(:)/(par%nphotons*intensity_bin_unit*twopi*area)
+    if (par%save_Jmu) grid%Jmu(:,:) = grid%Jmu(:,:)*par%nmu/(par%nphotons*intensity_bin_unit*twopi*area)
+    if (par%DGR > 0.0_wp .and. par%save_Jabs) grid%Jabs(:) = grid%Jabs(:)/(par%nphotons*intensity_bin_unit*twopi*area)
+    if (par%save_peeloff_2D .and. par%nobs > 0) then
+       scale_factor = par%no_photons*observer(1)%steradian_pix*par%distance2cm**2
+       obs_scatt_2D = obs_scatt_2D/scale_factor; obs_direc_2D = obs_direc_2D/scale_factor
+       if (par%use_stokes) then
+          obs_I_2D = obs_I_2D/scale_factor; obs_Q_2D = obs_Q_2D/scale_factor; obs_U_2D = obs_U_2D/scale_factor; obs_V_2D = obs_V_2D/scale_factor
+       endif
+    endif
+    if (par%save_peeloff_3D .and. par%nobs > 0) then
+       scale_factor = par%no_photons*observer(1)%steradian_pix*intensity_bin_unit*par%distance2cm**2
+       obs_scatt = obs_scatt/scale_factor; obs_direc = obs_direc/scale_factor
+       if (par%use_stokes) then
+          obs_I = obs_I/scale_factor; obs_Q = obs_Q/scale_factor; obs_U = obs_U/scale_factor; obs_V = obs_V/scale_factor
+       endif
+    endif
+  end subroutine output_normalize
+end module lart_host

@@ -1,0 +1,257 @@
+!------------------------------------------------------------------------------
+! LaRT_amd.x <input.in> [--dry-run]
+! Same sequence as the reference's main.f90:19-69; run_simulation and output_reduce cross the
+! C-ABI (include/lart_gpu.h) into the HIP kernels.  --dry-run stops after the grid/observer set-up
+! (prints the same grid summary the reference prints) so the host logic can be checked without a GPU.
+!------------------------------------------------------------------------------
+program LaRT_amd
+  use, intrinsic :: iso_c_binding
+  use lart_define
+  use lart_host
+  use lart_gpu_c
+  use lart_fits
+  implicit none
+  type(grid_type), target :: grid
+  type(lart_params) :: cpar
+  type(lart_tallies) :: t
+  type(c_ptr) :: ctx
+  character(len=256) :: infile, arg
+  logical :: dry_run
+  integer :: i, ndev
+  integer(int64) :: done, active, t0, t1, rate
+  real(wp), allocatable, target :: xyz(:), rmat(:)
+  real(wp) :: dtime
+
+  if (command_argument_count() < 1) then
+     call get_command_argument(0, arg)
+     write(*,*) 'Usage: ', trim(arg), ' input_file [--dry-run]'
+     stop
+  endif
+  call get_command_argument(1, infile)
+  dry_run = .false.
+  do i = 2, command_argument_count()
+     call get_command_argument(i, arg)
+     if (trim(arg) == '--dry-run') dry_run = .true.
+  enddo
+  call system_clock(t0, rate)
+
+  call read_input(trim(infile))
+  call grid_create(grid)
+  call observer_create()
+  if (par%save_peeloff) write(*,'(a,i4,a,2i6,a,2es13.5)') 'observers: ', par%nobs, '  image ', par%nxim, par%nyim, '  pixel (deg) ', par%dxim, par%dyim
+  write(*,'(a,2f10.3,i6)') 'xfreq_min, xfreq_max, nxfreq : ', grid%xfreq_min, grid%xfreq_max, grid%nxfreq
+  if (dry_run) then
+     write(*,'(a)') '--dry-run: set-up only, no transport.'
+     stop
+  endif
+
+  !--- hand the read-only tables to the device (replaces the MPI shared-memory windows, memory_mod_mpi.f90:96-130)
+  ndev = lart_gpu_device_count()
+  if (ndev < 1) then
+     write(*,'(a)') 'ERROR: no MI355X/HIP device visible; this build has no CPU transport path.'; stop 1
+  endif
+  call fill_params(cpar)
+  call lart_check(lart_gpu_create(ctx, cpar, 0_c_int), 'lart_gpu_create')
+  if (par%DGR > 0.0_wp) then
+     call lart_check(lart_gpu_set_grid_car(ctx, grid%nx, grid%ny, grid%nz, grid%xmin, grid%ymin, grid%zmin, grid%dx, grid%dy, grid%dz, &
+          grid%i0, grid%j0, grid%k0, grid%xface, grid%yface, grid%zface, grid%rhokap, grid%voigt_a, grid%Dfreq, &
+          grid%vfx, grid%vfy, grid%vfz, c_loc(grid%rhokapD)), 'lart_gpu_set_grid_car')
+  else
+     call lart_check(lart_gpu_set_grid_car(ctx, grid%nx, grid%ny, grid%nz, grid%xmin, grid%ymin, grid%zmin, grid%dx, grid%dy, grid%dz, &
+          grid%i0, grid%j0, grid%k0, grid%xface, grid%yface, grid%zface, grid%rhokap, grid%voigt_a, grid%Dfreq, &
+          grid%vfx, grid%vfy, grid%vfz, c_null_ptr), 'lart_gpu_set_grid_car')
+  endif
+  if (scatt_mat%nPDF > 0) call lart_check(lart_gpu_set_mueller(ctx, scatt_mat%nPDF, scatt_mat%coss, scatt_mat%S11, scatt_mat%S12, &
+       scatt_mat%S33, scatt_mat%S34, scatt_mat%phase_PDF, scatt_mat%alias), 'lart_gpu_set_mueller')
+  if (par%nobs > 0 .and. par%save_peeloff) then
+     allocate(xyz(3*par%nobs), rmat(9*par%nobs))
+     do i = 1, par%nobs
+        xyz(3*i-2:3*i) = [observer(i)%x, observer(i)%y, observer(i)%z]
+        rmat(9*i-8:9*i) = [observer(i)%rmatrix(1,:), observer(i)%rmatrix(2,:), observer(i)%rmatrix(3,:)]
+     enddo
+     call lart_check(lart_gpu_set_observers(ctx, par%nobs, xyz, rmat, par%dxim, par%dyim, par%nxim, par%nyim), 'lart_gpu_set_observers')
+  endif
+
+  !--- run_simulation (main.f90:42): bounded slices so progress can be printed like par%nprint does
+  call time_stamp(dtime)
+  write(6,'(a,f8.3,a)') '---> Now starting simulation...  @ ', dtime/60.0_wp, ' mins'
+  call lart_check(lart_gpu_begin(ctx, 1_c_int64_t, 1_c_int64_t, par%nphotons, int(par%iseed, c_int64_t)), 'lart_gpu_begin')
+  do
+     call lart_check(lart_gpu_step(ctx, 1_c_int32_t, int(par%gpu_events_per_step, c_int32_t)), 'lart_gpu_step')
+     call lart_check(lart_gpu_sync(ctx, done, active), 'lart_gpu_sync')
+     if (active == 0) exit
+  enddo
+  call time_stamp(dtime)
+  write(6,'(es14.5,a,f8.3,a)') dble(par%nphotons), ' photons calculated: ', dtime/60.0_wp, ' mins'
+
+  !--- output_reduce (main.f90:46): one GPU per process here, so the "reduce" is the device->host copy
+  write(6,'(a)') '---> Now Gathering Results...'
+  call null_tallies(t)
+  t%Jout = c_loc(grid%Jout); t%Jin = c_loc(grid%Jin)
+  if (par%save_Jabs) t%Jabs = c_loc(grid%Jabs)
+  if (par%save_Jmu)  t%Jmu  = c_loc(grid%Jmu)
+  if (allocated(obs_scatt)) then
+     t%scatt = c_loc(obs_scatt); t%direc = c_loc(obs_direc)
+  endif
+  if (allocated(obs_I)) then
+     t%I = c_loc(obs_I); t%Q = c_loc(obs_Q); t%U = c_loc(obs_U); t%V = c_loc(obs_V)
+  endif
+  if (allocated(obs_scatt_2D)) then
+     t%scatt_2D = c_loc(obs_scatt_2D); t%direc_2D = c_loc(obs_direc_2D)
+  endif
+  if (allocated(obs_I_2D)) then
+     t%I_2D = c_loc(obs_I_2D); t%Q_2D = c_loc(obs_Q_2D); t%U_2D = c_loc(obs_U_2D); t%V_2D = c_loc(obs_V_2D)
+  endif
+  call lart_check(lart_gpu_get_tallies(ctx, t), 'lart_gpu_get_tallies')
+  par%nscatt_gas = t%nscatt_gas; par%nscatt_dust = t%nscatt_dust
+
+  call output_normalize(grid)
+  call time_stamp(dtime); par%exetime = dtime/60.0_wp
+  call write_output(trim(par%out_file), grid)
+
+  write(6,'(a,es12.4)')   'Average Number of scattering : ', par%nscatt_tot
+  write(6,'(a,2es12.4)')  'Nscatt_dust, Nscatt_gas      : ', par%nscatt_dust, par%nscatt_gas
+  write(6,'(a,es12.4)')   'Scattering events per second : ', t%n_events/max(dtime, 1e-9_wp)
+  write(6,'(a,f8.3,a)')   'Total Excution Time          : ', par%exetime, ' mins'
+  call lart_check(lart_gpu_destroy(ctx), 'lart_gpu_destroy')
+
+contains
+  subroutine time_stamp(dt)
+    real(wp), intent(out) :: dt
+    call system_clock(t1)
+    dt = real(t1 - t0, wp)/real(rate, wp)
+  end subroutine time_stamp
+
+  subroutine null_tallies(tt)
+    type(lart_tallies), intent(out) :: tt
+    tt%Jout = c_null_ptr; tt%Jin = c_null_ptr; tt%Jabs = c_null_ptr; tt%Jmu = c_null_ptr
+    tt%scatt = c_null_ptr; tt%direc = c_null_ptr; tt%I = c_null_ptr; tt%Q = c_null_ptr; tt%U = c_null_ptr; tt%V = c_null_ptr
+    tt%scatt_2D = c_null_ptr; tt%direc_2D = c_null_ptr; tt%I_2D = c_null_ptr; tt%Q_2D = c_null_ptr; tt%U_2D = c_null_ptr; tt%V_2D = c_null_ptr
+  end subroutine null_tallies
+
+  subroutine fill_params(p)
+    type(lart_params), intent(out) :: p
+    p%xyz_symmetry = merge(1, 0, par%xyz_symmetry); p%xy_periodic = merge(1, 0, par%xy_periodic)
+    p%source_geometry = merge(1, 0, trim(par%source_geometry) == 'uniform_sphere')
+    p%spectral_type = merge(1, 0, trim(par%spectral_type) == 'voigt')
+    p%comoving_source = merge(1, 0, par%comoving_source)
+    p%recoil = merge(1, 0, par%recoil); p%core_skip = merge(1, 0, par%core_skip); p%core_skip_global = merge(1, 0, par%core_skip_global)
+    p%use_stokes = merge(1, 0, par%use_stokes); p%use_reduced_wgt = merge(1, 0, par%use_reduced_wgt)
+    p%save_Jin = merge(1, 0, par%save_Jin); p%save_Jabs = merge(1, 0, par%save_Jabs); p%save_Jmu = merge(1, 0, par%save_Jmu); p%nmu = par%nmu
+    p%save_peeloff = merge(1, 0, par%save_peeloff); p%save_peeloff_2D = merge(1, 0, par%save_peeloff_2D); p%save_peeloff_3D = merge(1, 0, par%save_peeloff_3D)
+    p%nxfreq = grid%nxfreq
+    p%xs_point = par%xs_point; p%ys_point = par%ys_point; p%zs_point = par%zs_point; p%source_rmax = par%source_rmax; p%xfreq0 = par%xfreq0
+    p%xfreq_min = grid%xfreq_min; p%dxfreq = grid%dxfreq; p%Dfreq_ref = grid%Dfreq_ref
+    p%DGR = par%DGR; p%hgg = par%hgg; p%albedo = par%albedo; p%mu_min = par%mu_min; p%dmu = par%dmu
+    p%g_recoil0 = line%g_recoil0; p%E1 = line%E1; p%E2 = line%E2; p%E3 = line%E3
+    p%xcrit = grid%xcrit; p%xcrit2 = grid%xcrit2
+  end subroutine fill_params
+
+  !--- write_output_outside: `Spectrum` table + keywords (write_output_rect.f90:423-498), Jmu image (:524-539),
+  !--- peel-off HDUs Scattered/Direct/Stokes_* (:1113-1344) in <base>_obs.fits / <base>_stokes.fits
+  subroutine write_output(filename, g)
+    character(len=*), intent(in) :: filename
+    type(grid_type), intent(in) :: g
+    type(fits_file) :: f
+    character(len=16) :: names(6)
+    real(wp), allocatable :: cols(:,:)
+    integer :: ncol
+    ncol = 4; names(1:4) = [character(len=16) :: 'Xfreq', 'velocity', 'wavelength', 'Jout']
+    if (par%save_Jabs) then
+       ncol = ncol + 1; names(ncol) = 'Jabs'
+    endif
+    if (par%save_Jin) then
+       ncol = ncol + 1; names(ncol) = 'Jin'
+    endif
+    allocate(cols(g%nxfreq, ncol))
+    cols(:,1) = g%xfreq; cols(:,2) = g%velocity; cols(:,3) = g%wavelength; cols(:,4) = g%Jout
+    ncol = 4
+    if (par%save_Jabs) then
+       ncol = ncol + 1; cols(:,ncol) = g%Jabs
+    endif
+    if (par%save_Jin) then
+       ncol = ncol + 1; cols(:,ncol) = g%Jin
+    endif
+    call fits_open(f, filename)
+    call fits_begin_table(f, g%nxfreq, ncol, names(1:ncol))
+    call fits_key(f, 'ExeTime',  par%exetime,        'Excution Time (min)')
+    call fits_key(f, 'Nprocs',   1,                  'No. of Threads')
+    call fits_key(f, 'recoil',   par%recoil,         'recoil')
+    call fits_key(f, 'coreskip', par%core_skip,      'coreskip algorithm')
+    call fits_key(f, 'xyz_sym',  par%xyz_symmetry,   'xyz_symmetry')
+    call fits_key(f, 'xy_per',   par%xy_periodic,    'xy_periodic')
+    call fits_key(f, 'save_all', par%save_all,       'save all 3D output?')
+    call fits_key(f, 'save_Jin', par%save_Jin,       'save input J?')
+    call fits_key(f, 'save_Jab', par%save_Jabs,      'save absorbed J?')
+    call fits_key(f, 'nphotons', real(par%nphotons, wp), 'number of photons')
+    call fits_key(f, 'taumax',   par%taumax,         'tau_max')
+    call fits_key(f, 'tauhomo',  par%tauhomo,        'tau_homo')
+    call fits_key(f, 'Ngasmax',  par%N_gasmax,       'N(gas)_max cm^-2')
+    call fits_key(f, 'Ngashomo', par%N_gashomo,      'N(gas)_homo cm^-2')
+    call fits_key(f, 'temp',     par%temperature,    'temperature (K)')
+    call fits_key(f, 'Vexp',     par%Vexp,           'Velocity (km/s)')
+    call fits_key(f, 'DGR',      par%DGR,            'Dust-to-Gas Ratio')
+    call fits_key(f, 'atau3',    par%atau3,          '(a*tau_max)^(1/3)')
+    call fits_key(f, 'voigta',   g%voigt_amean,      'voigt_a')
+    call fits_key(f, 'Xfreq1',   g%xfreq_min,        'Xfreq_min')
+    call fits_key(f, 'Xfreq2',   g%xfreq_max,        'Xfreq_max')
+    call fits_key(f, 'Dxfreq',   g%dxfreq,           'Dxfreq')
+    call fits_key(f, 'Dwave',    g%dwave,            'Dwavelength (angstrom)')
+    call fits_key(f, 'I_unit',   par%intensity_unit, 'Intensity Unit (0:no dimension, 1:cm^-2 A^-1)')
+    call fits_key(f, 'Dfreq',    g%Dfreq_ref,        'Doppler Freq. (Hz)')
+    call fits_key(f, 'Nsc_dust', par%nscatt_dust,    'Nscatt_dust/photon')
+    call fits_key(f, 'Nsc_gas',  par%nscatt_gas,     'Nscatt_gas/photon')
+    call fits_key(f, 'Nsc_tot',  par%nscatt_tot,     'Nscatt_tot/photon')
+    call fits_key(f, 'nx',       g%nx,               'No. of x cells')
+    call fits_key(f, 'ny',       g%ny,               'No. of y cells')
+    call fits_key(f, 'nz',       g%nz,               'No. of z cells')
+    call fits_key(f, 'xmax',     par%xmax,           'xmax')
+    call fits_key(f, 'ymax',     par%ymax,           'ymax')
+    call fits_key(f, 'zmax',     par%zmax,           'zmax')
+    call fits_key(f, 'EXTNAME',  'Spectrum',         'Spectrum')
+    call fits_key(f, 'calc_P',   .false.,            'calculated Pa within media?')
+    call fits_key(f, 'calc_Pnew', .false.,           'calculated Pa within media?')
+    call fits_key(f, 'calc_J',   .false.,            'calculated J within media?')
+    call fits_end_header(f)
+    call fits_write_table_rows(f, cols)
+    if (par%save_Jmu) call put_image(f, 'Jmu', [g%nxfreq, par%nmu], g%Jmu)
+    call fits_close(f)
+    if (par%save_peeloff .and. par%nobs > 0) then
+       call fits_open(f, trim(par%base_name)//'_obs.fits')
+       if (allocated(obs_scatt)) then
+          call put_image(f, 'Scattered', shape(obs_scatt), obs_scatt)
+          call put_image(f, 'Direct', shape(obs_direc), obs_direc)
+       endif
+       if (allocated(obs_scatt_2D)) then
+          call put_image(f, 'Scattered_2D', shape(obs_scatt_2D), obs_scatt_2D)
+          call put_image(f, 'Direct_2D', shape(obs_direc_2D), obs_direc_2D)
+       endif
+       call fits_close(f)
+       if (par%use_stokes .and. allocated(obs_I)) then
+          call fits_open(f, trim(par%base_name)//'_stokes.fits')
+          call put_image(f, 'Stokes_I', shape(obs_I), obs_I)
+          call put_image(f, 'Stokes_Q', shape(obs_Q), obs_Q)
+          call put_image(f, 'Stokes_U', shape(obs_U), obs_U)
+          call put_image(f, 'Stokes_V', shape(obs_V), obs_V)
+          call fits_close(f)
+       endif
+    endif
+    write(6,'(2a)') 'output written: ', filename
+  end subroutine write_output
+
+  subroutine put_image(f, extname, naxes, a)
+    type(fits_file), intent(inout) :: f
+    character(len=*), intent(in) :: extname
+    integer, intent(in) :: naxes(:)
+    real(wp), intent(in) :: a(*)
+    call fits_begin_image(f, naxes)
+    call fits_key(f, 'EXTNAME', extname, extname)
+    call fits_key(f, 'nphotons', real(par%nphotons, wp), 'number of photons')
+    call fits_key(f, 'dxim', par%dxim, 'pixel size along x (deg)')
+    call fits_key(f, 'dyim', par%dyim, 'pixel size along y (deg)')
+    call fits_key(f, 'distance', par%distance, 'observer distance')
+    call fits_end_header(f)
+    f%nbytes = product(int(naxes, int64))
+    call fits_write_image(f, a)
+  end subroutine put_image
+end program LaRT_amd

@@ -697,7 +697,7 @@ class Simulation:
     def run_simulation(self, nphotons=None, rank=0, nproc=1, seed=None):
         """photon ids rank+1, rank+1+nproc, ... <= nphotons (run_equal_number, run_simulation_mod.f90:150-151)"""
         n = self.par.nphotons if nphotons is None else int(nphotons)
-        count = (n - rank - 1) // nproc + 1 if n > rank else 0
+        count = photons_of_rank(n, rank, nproc)
         self.ctx.run(count, first_id=rank + 1, stride=nproc, seed=self.par.iseed if seed is None else seed)
         self.nphotons_run = n
         return count
@@ -710,7 +710,7 @@ class Simulation:
         ptr, n = self.ctx.tally_buffer()
         t = _as_cuda_tensor(ptr, n, self.ctx)
         torch.cuda.synchronize()
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        reduce_tally_buffer(t, dist)
         torch.cuda.synchronize()
 
     def output_normalize(self, t=None, nphotons=None):
@@ -741,6 +741,18 @@ class Simulation:
                     out[k + "_2D"] = t[k + "_2D"] / sc2
         out["nscatt_tot"] = (t["nscatt_gas"] + t["nscatt_dust"]) / nph
         return out
+
+
+def photons_of_rank(nphotons, rank, nproc):
+    """how many of the ids 1..nphotons fall on `rank` under `do ip = rank+1, nphotons, nproc` (run_simulation_mod.f90:150-151)"""
+    return (nphotons - rank - 1) // nproc + 1 if nphotons > rank else 0
+
+
+def reduce_tally_buffer(t, dist):
+    """the path's only exchange step: element-wise SUM of the fused tally buffer over all ranks
+    (backend nccl = RCCL over xGMI on GPUs, gloo on CPU tensors in the tests)"""
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
 
 
 def _as_cuda_tensor(ptr, n, keep):

@@ -1,0 +1,115 @@
+"""The Fortran host (LaRT_amd.x): namelist surface + grid set-up without a GPU (--dry-run), end to end on the GPU."""
+import os
+import re
+import subprocess
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "lart_amd", "fhost", "LaRT_amd.x")
+
+T1TAU3 = """&parameters
+ par%no_photons  = 1e6
+ par%temperature = 1.0e1
+ par%taumax      = 1.0e3
+ par%scatt_mat_file = '../data/mueller_Lyalpha.dat'
+ par%DGR         = 0.0
+ par%Vexp        = 0.0
+ par%use_stokes   = .true.
+ par%save_Jin     = .true.
+ par%nx = 201
+ par%ny = 201
+ par%nz = 201
+ par%rmax   = 1.0
+ par%nxfreq = 201
+ par%nxim   = 129
+ par%nyim   = 129
+ par%nprint = 1e6
+/
+"""
+
+
+@pytest.fixture(scope="module")
+def exe():
+    import __graft_entry__ as g
+    g.build()
+    assert os.path.exists(EXE)
+    return EXE
+
+
+def run(exe, text, tmp_path, *args, name="case.in"):
+    f = tmp_path / name
+    f.write_text(text)
+    return subprocess.run([exe, name, *args], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+
+
+def test_dry_run_reproduces_the_shipped_log_header(exe, tmp_path):
+    # examples/sphere_peel/out.txt:8-20 prints these lines for t1tau3.in
+    r = run(exe, T1TAU3, tmp_path, "--dry-run")
+    out = r.stdout
+    assert "voigt_a          :        1.492E-02" in out
+    assert "N(H  I)_pole     :        5.449E+14" in out
+    assert "tau_pole  (H  I) :        1.000E+03" in out
+    assert "tau_homo  (H  I) :        1.000E+03" in out
+    assert re.search(r"observers:\s+1\s+image\s+129\s+129", out)
+
+
+def test_unknown_field_and_unsupported_mode_fail(exe, tmp_path):
+    r = run(exe, "&parameters\n par%no_such_thing = 1\n/\n", tmp_path, "--dry-run", name="bad.in")
+    assert r.returncode != 0 and "ERROR" in r.stdout
+    r = run(exe, "&parameters\n par%use_amr_grid = .true.\n/\n", tmp_path, "--dry-run", name="amr.in")
+    assert r.returncode != 0 and "not supported" in r.stdout
+
+
+def read_fits(path):
+    """tiny reader for the uncompressed FITS the host writes: returns {EXTNAME: (header dict, array or table dict)}"""
+    raw = open(path, "rb").read()
+    pos, hdus = 0, {}
+    while pos < len(raw):
+        hdr = {}
+        while True:
+            block = raw[pos:pos + 2880].decode("ascii"); pos += 2880
+            cards = [block[i:i + 80] for i in range(0, 2880, 80)]
+            done = False
+            for c in cards:
+                k = c[:8].strip()
+                if k == "END":
+                    done = True; break
+                if c[8:10] == "= ":
+                    hdr[k] = c[10:].split(" / ")[0].strip().strip("'").strip()
+            if done:
+                break
+        naxis = int(hdr.get("NAXIS", 0))
+        dims = [int(hdr["NAXIS%d" % (i + 1)]) for i in range(naxis)]
+        nbytes = abs(int(hdr.get("BITPIX", 8))) // 8 * int(np.prod(dims)) if naxis else 0
+        data = raw[pos:pos + nbytes]; pos += (nbytes + 2879) // 2880 * 2880
+        if hdr.get("XTENSION", "").startswith("BINTABLE"):
+            ncol = int(hdr["TFIELDS"]); arr = np.frombuffer(data, dtype=">f8").reshape(dims[1], ncol)
+            hdus[hdr["EXTNAME"]] = (hdr, {hdr["TTYPE%d" % (i + 1)]: arr[:, i] for i in range(ncol)})
+        elif naxis:
+            hdus[hdr["EXTNAME"]] = (hdr, np.frombuffer(data, dtype=">f8").reshape(dims[::-1]).T)
+    return hdus
+
+
+@pytest.mark.gpu
+def test_end_to_end_matches_python_host(exe, tmp_path):
+    text = ("&parameters\n par%no_photons = 30000\n par%iseed = 5\n par%temperature = 1e4\n par%taumax = 1e2\n par%nx = 31\n par%ny = 31\n"
+            " par%nz = 31\n par%rmax = 1.0\n par%nxfreq = 81\n par%nxim = 12\n par%nyim = 12\n par%use_stokes = .true.\n par%save_peeloff_2D = .true.\n/\n")
+    r = run(exe, text, tmp_path, name="e2e.in")
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Average Number of scattering" in r.stdout
+    spec = read_fits(str(tmp_path / "e2e.fits"))["Spectrum"]
+    assert list(spec[1].keys()) == ["Xfreq", "velocity", "wavelength", "Jout", "Jin"]
+    from lart_amd import host
+    sim = host.Simulation(dict(no_photons=30000, iseed=5, temperature=1e4, taumax=1e2, nx=31, ny=31, nz=31, rmax=1.0, nxfreq=81,
+                               nxim=12, nyim=12, use_stokes=True, save_peeloff_2D=True))
+    sim.run_simulation()
+    t = sim.output_normalize()
+    # same tables, same seed, same photon ids -> same histories; tallies equal up to atomic summation order
+    assert np.allclose(spec[1]["Jout"], t["Jout"], rtol=1e-9, atol=1e-15)
+    assert np.allclose(spec[1]["Jin"], t["Jin"], rtol=1e-9, atol=1e-15)
+    assert np.isclose(float(spec[0]["Nsc_tot"]), t["nscatt_tot"], rtol=1e-9)
+    obs = read_fits(str(tmp_path / "e2e_obs.fits"))
+    assert np.allclose(obs["Scattered"][1][..., 0], t["scatt"][..., 0], rtol=1e-6, atol=1e-12 * t["scatt"].max())
+    stk = read_fits(str(tmp_path / "e2e_stokes.fits"))
+    assert np.allclose(stk["Stokes_Q"][1][..., 0], t["Q"][..., 0], rtol=1e-6, atol=1e-9 * np.abs(t["I"]).max())
