@@ -107,6 +107,7 @@ def main():
         # (Jout escape + forced-first-scatter fraction: 2 per finished photon; scalar counters are per wave)
         bytes_launch = (48.0 * cells + 16.0 * 2.0 * done) / launches
         achieved = bytes_launch / (k_ms * 1e-3) / 1e9
+        traffic = pmc_traffic(a.events_per_step)
         out = {
             "metric": "scattering events/sec (whole node), tau0=1e6 sphere",
             "value": ev_all / dt, "unit": "events/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -117,7 +118,7 @@ def main():
                        "events_per_step_per_lane": a.events_per_step, "lanes_per_gpu": sim.ctx.pool_info()[0], "block": sim.ctx.pool_info()[1],
                        "cells_per_event": cells_all / max(ev_all, 1.0), "photons_finished_in_timed_region": done_all,
                        "tally_reduce_ms": reduce_ms, "tally_doubles": ntally, "parallelism": "photon-dp%d" % world},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                          "kernel": "transport_kernel<1,false,false,false>", "avg_launch_ms": k_ms,
                          "algorithmic_bytes_per_launch": bytes_launch,
                          "note": "fp64 ALU/latency-bound path; see DESIGN.md 'Roofline' for the VALU accounting"},
@@ -130,16 +131,44 @@ def main():
         dist.destroy_process_group()
 
 
+def pmc_traffic(events_per_step):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/*pmc*.json, separate
+    FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE doubled as the guide's gfx950 correction prescribes).  None when no pass
+    exists for this events-per-step setting."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary*.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+            if int(d.get("events_per_step", -1)) == int(events_per_step) and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+                return (2.0 * d["FETCH_SIZE"]["mean_per_launch"] + d["WRITE_SIZE"]["mean_per_launch"]) * 1024.0
+        except Exception:
+            pass
+    return None
+
+
+def host_cores():
+    """usable host cores: the cgroup CPU quota when there is one (a 1-GPU box gets a 16-core share of a 256-thread host),
+    else the affinity mask"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per) + 0.5)))
+    except Exception:
+        pass
+    return min(n, int(os.environ.get("LART_CPU_CORES", "16")))
+
+
 def cpu_baseline(nphot):
     """the CPU oracle (kind 'port') on the first photons of the same workload, all host cores"""
     from oracle import oracle as O
     O.build(ref=False)
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_cores()
     kw = {k: v for k, v in WORKLOAD.items() if k not in ("iseed", "no_photons")}
     o = O.Oracle(**kw)
     if nphot <= 0:
-        # ~0.5 core-seconds per photon at tau0 = 1e6: aim at ~20 s of wall time
-        nphot = max(cores * 2, int(20.0 * cores / 0.55))
+        # ~0.4 core-seconds per photon at tau0 = 1e6 (1.0e6 events at ~2.8e6 events/s/core): aim at ~20 s of wall time
+        nphot = max(cores * 2, int(20.0 * cores / 0.4))
         nphot = (nphot // cores) * cores
     t0 = time.perf_counter()
     o.run(nphot, first_id=1, stride=1, rng_kind=1, seed=WORKLOAD["iseed"], nthreads=cores)

@@ -309,13 +309,18 @@ struct orc_sim {
     double nscatt_gas, nscatt_dust; int64_t nphotons_done;
     double n_cellsteps, n_cellsteps_peel, n_events;
     int raytrace_variant;            /* 0 car, 1 xyzsym, 2 zonly */
+    /* --- CALCJ / CALCP / CALCPnew profile tallies (compile-time switches in the reference, Makefile:33-61) --- */
+    int calc_J, calc_P, calc_Pnew, geometry_JPa, nbins;
+    int *ind_bin; double *ncount, *J1, *P1, *P1_new;
+    /* --- HEALPix inside observers (observer_heal.f90) --- */
+    int nside, npix;
     int64_t log_n; double *log_nscatt, *log_xfreq;
 };
 
 #define IDX(s,i,j,k) ((size_t)((i)-1) + (size_t)(s)->nx * ((size_t)((j)-1) + (size_t)(s)->ny * (size_t)((k)-1)))
 
 /* per-thread accumulators, merged after the run */
-typedef struct { orc_sim *s; double *Jout, *Jin, *Jabs, *Jmu; obs_t obs[MAX_OBS];
+typedef struct { orc_sim *s; double *Jout, *Jin, *Jabs, *Jmu, *J1, *P1, *P1_new; obs_t obs[MAX_OBS];
                  double nscatt_gas, nscatt_dust, n_cellsteps, n_cellsteps_peel, n_events; } acc_t;
 
 /* =====================================================================================
@@ -335,7 +340,7 @@ static void set_defaults(orc_sim *s) {
     s->hgg = (double)0.6761f; s->albedo = (double)0.3253f; s->cext_dust = (double)1.6059e-21f;
     s->DGR = 0.0; s->distance2cm = -999.9; s->distance = NAN; s->dxim = NAN; s->dyim = NAN;
     for (int i = 0; i < MAX_OBS; i++) s->alpha[i] = s->beta[i] = s->gamma[i] = s->obsx[i] = s->obsy[i] = s->obsz[i] = NAN;
-    s->geometry = 0;
+    s->geometry = 0; s->geometry_JPa = 2147483647;
 }
 
 static int set_param(orc_sim *s, const char *k, const char *v) {
@@ -347,7 +352,7 @@ static int set_param(orc_sim *s, const char *k, const char *v) {
     I(nx) I(ny) I(nz) D(xmax) D(ymax) D(zmax) D(rmax) D(rmin) D(xs_point) D(ys_point) D(zs_point) D(source_rmax)
     D(xfreq0) I(nxfreq) B(use_stokes) B(use_reduced_wgt) B(save_Jin) B(save_Jabs) B(save_Jmu) I(nmu)
     D(hgg) D(albedo) D(cext_dust) D(DGR) D(distance2cm) B(save_peeloff) B(save_peeloff_2D) B(save_peeloff_3D)
-    I(nxim) I(nyim) D(distance) D(dxim) D(dyim)
+    I(nxim) I(nyim) D(distance) D(dxim) D(dyim) B(calc_J) B(calc_P) B(calc_Pnew) I(geometry_JPa) I(nside)
     if (!strcmp(k, "xfreq_min")) { s->par_xfreq_min = atof(v); return 0; }
     if (!strcmp(k, "xfreq_max")) { s->par_xfreq_max = atof(v); return 0; }
     if (!strcmp(k, "N_HImax") || !strcmp(k, "N_gasmax") || !strcmp(k, "N_HI")) { s->N_gasmax = atof(v); return 0; }
@@ -459,6 +464,8 @@ static double rand_alias_linear(rng_t *g, int n, const double *prob_alias, const
 static int read_input_post(orc_sim *s) {
     /* setup.f90:161-165: a 1-cell axis disables xyz_symmetry */
     if (s->nx == 1 || s->ny == 1 || s->nz == 1) s->xyz_symmetry = 0;
+    /* :169-186 observer inside the medium (HEALPix): nostokes, no symmetry, no TAN image */
+    if (s->nside > 0) { s->use_stokes = 0; s->save_peeloff = 1; s->xyz_symmetry = 0; s->nxim = 0; s->nyim = 0; }
     /* :188-206 peel-off switches */
     if (!(s->save_peeloff_2D || s->save_peeloff_3D)) s->save_peeloff = 0;
     if (s->nxim > 0 && s->nyim > 0) s->save_peeloff = 1;
@@ -481,6 +488,11 @@ static int read_input_post(orc_sim *s) {
         }
     } else s->rmax = -1.0;
     if (s->source_rmax < 0.0) s->source_rmax = s->rmax;
+    /* :438-459 geometry of the J/P profiles: 3 = per cell, 1 = spherical shells, -1 = plane-parallel layers */
+    if (s->rmax <= 0.0) s->geometry_JPa = 3;
+    if (s->geometry_JPa < -1 || s->geometry_JPa > 3) { s->geometry_JPa = 1;
+        if (s->xy_periodic) s->geometry_JPa = -1; else if (s->xyz_symmetry) s->geometry_JPa = 1; }
+    if (s->geometry_JPa == 2 || s->geometry_JPa == 0) { snprintf(g_err, sizeof g_err, "geometry_JPa = %d (cylinder) not supported by the oracle", s->geometry_JPa); return -1; }
     /* :473-489 distance unit ('' -> 1) */
     if (s->distance2cm < 0.0) s->distance2cm = 1.0;
     /* :496-500 Mueller table / Stokes without table forces DGR = 0 */
@@ -648,9 +660,78 @@ static int grid_create(orc_sim *s) {
     return 0;
 }
 
+/* create_JPa_mem: grid_mod_car.f90:1242-1434 (geometry_JPa = 1 spherical shells, -1 layers, 3 per cell).
+ * ind_bin(cell) = 1-based profile bin of a cell, 0 = none; ncount(bin) = cells per bin (x8/4/2 in the folded octant). */
+static int create_JPa_mem(orc_sim *s) {
+    if (!(s->calc_J || s->calc_P || s->calc_Pnew)) return 0;
+    int nx = s->nx, ny = s->ny, nz = s->nz; size_t nc = (size_t)nx * ny * nz;
+    s->ind_bin = calloc(nc, sizeof(int));
+    if (s->geometry_JPa == 1) {
+        int nr = nx > ny ? nx : ny; if (nz > nr) nr = nz;
+        if (!s->xyz_symmetry) { if ((nr / 2) * 2 == nr) nr = nr / 2; else nr = (nr - 1) / 2 + 1; }
+        double rmax = fmin(s->xmax, fmin(s->ymax, s->zmax)), dr, roff;
+        if ((nr / 2) * 2 == nr) { dr = rmax / nr; roff = 0.0; } else { dr = rmax / (nr - 0.5); roff = -dr / 2.0; }
+        s->nbins = nr; s->ncount = calloc(nr, sizeof(double));
+        for (int k = 1; k <= nz; k++) for (int j = 1; j <= ny; j++) for (int i = 1; i <= nx; i++) {
+            double xx = (s->xface[i-1] + s->xface[i]) / 2.0, yy = (s->yface[j-1] + s->yface[j]) / 2.0, zz = (s->zface[k-1] + s->zface[k]) / 2.0;
+            double rr = sqrt(xx * xx + yy * yy + zz * zz);
+            int ib = (int)floor((rr - roff) / dr) + 1;
+            s->ind_bin[IDX(s,i,j,k)] = (ib >= 1 && ib <= nr) ? ib : 0;        /* the reference indexes past nr here; guard */
+            if (s->rhokap[IDX(s,i,j,k)] > 0.0 && ib >= 1 && ib <= nr) {
+                int nadd = 1;
+                if (s->xyz_symmetry) { nadd = 8; if (i == 1 && (nx/2)*2 != nx) nadd /= 2; if (j == 1 && (ny/2)*2 != ny) nadd /= 2; if (k == 1 && (nz/2)*2 != nz) nadd /= 2; }
+                s->ncount[ib-1] += nadd; }
+        }
+    } else if (s->geometry_JPa == -1) {
+        s->nbins = nz; s->ncount = calloc(nz, sizeof(double));
+        for (int k = 1; k <= nz; k++) for (int j = 1; j <= ny; j++) for (int i = 1; i <= nx; i++) {
+            s->ind_bin[IDX(s,i,j,k)] = k; if (s->rhokap[IDX(s,i,j,k)] > 0.0) s->ncount[k-1] += 1.0; }
+    } else {
+        s->nbins = (int)nc; s->ncount = calloc(nc, sizeof(double));
+        for (int k = 1; k <= nz; k++) for (int j = 1; j <= ny; j++) for (int i = 1; i <= nx; i++) {
+            size_t c = IDX(s,i,j,k); s->ind_bin[c] = (int)c + 1; int nadd = 1;
+            if (s->xyz_symmetry) { nadd = 8; if (i == 1 && (nx/2)*2 != nx) nadd /= 2; if (j == 1 && (ny/2)*2 != ny) nadd /= 2; if (k == 1 && (nz/2)*2 != nz) nadd /= 2; }
+            s->ncount[c] = nadd; }
+    }
+    if (s->calc_J) s->J1 = calloc((size_t)s->nxfreq * s->nbins, sizeof(double));
+    if (s->calc_P) s->P1 = calloc(s->nbins, sizeof(double));
+    if (s->calc_Pnew) s->P1_new = calloc(s->nbins, sizeof(double));
+    return 0;
+}
+/* add_to_J (raytrace_car.f90:3979-4011) and add_to_Pnew (:4015-4045) for one path segment in cell c */
+static inline void add_to_JPnew(const orc_sim *s, acc_t *A, const photon_t *p, size_t c, double del, double dtauH) {
+    if (!(s->rhokap[c] > 0.0)) return;
+    int ib = s->ind_bin[c]; if (ib < 1) return;
+    if (s->calc_J) {
+        double xr = p->xfreq * (s->Dfreq[c] / s->Dfreq_ref);
+        int ix = (int)floor((xr - s->xfreq_min) / s->dxfreq) + 1;
+        if (ix > 0 && ix <= s->nxfreq) A->J1[(size_t)(ix - 1) + (size_t)s->nxfreq * (ib - 1)] += del * p->wgt;
+    }
+    if (s->calc_Pnew) { double n = s->rhokap[c] * s->Dfreq[c] / s->cross0; A->P1_new[ib-1] += dtauH * p->wgt / n; }
+}
+/* add_to_Pa: scattering_car.f90:830-859 */
+static inline void add_to_Pa(const orc_sim *s, acc_t *A, const photon_t *p) {
+    if (!s->calc_P) return;
+    size_t c = IDX(s,p->icell,p->jcell,p->kcell);
+    if (!(s->rhokap[c] > 0.0)) return;
+    int ib = s->ind_bin[c]; if (ib < 1) return;
+    A->P1[ib-1] += p->wgt / (s->rhokap[c] * s->Dfreq[c] / s->cross0);
+}
+
 /* observer_create_outside: observer_rect.f90:24-326 */
 static int observer_create(orc_sim *s) {
     if (!s->save_peeloff) { s->nobs = 0; return 0; }
+    if (s->nside > 0) {                                                             /* observer_create_inside: observer_heal.f90:24-80 */
+        if (s->raytrace_variant != 0) { snprintf(g_err, sizeof g_err, "HEALPix inside observers need the plain Cartesian grid"); return -1; }
+        if (!(isfinite(s->obsx[0]) && isfinite(s->obsy[0]) && isfinite(s->obsz[0]))) { s->obsx[0] = 0.0; s->obsy[0] = 0.0; s->obsz[0] = 0.0; }
+        int n = 0; for (int i = 0; i < MAX_OBS; i++) if (isfinite(s->obsx[i]) && isfinite(s->obsy[i]) && isfinite(s->obsz[i])) n++;
+        s->nobs = n; s->npix = 12 * s->nside * s->nside; s->nxim = s->npix; s->nyim = 1;
+        size_t n2 = s->npix, n3 = n2 * s->nxfreq;
+        for (int i = 0; i < n; i++) { obs_t *o = &s->obs[i]; o->x = s->obsx[i]; o->y = s->obsy[i]; o->z = s->obsz[i];
+            if (s->save_peeloff_2D) { o->scatt_2D = calloc(n2, 8); o->direc_2D = calloc(n2, 8); }
+            if (s->save_peeloff_3D) { o->scatt = calloc(n3, 8); o->direc = calloc(n3, 8); } }
+        return 0;
+    }
     double cosa[MAX_OBS], sina[MAX_OBS], cosb[MAX_OBS], sinb[MAX_OBS], cosg[MAX_OBS], sing[MAX_OBS];
     double rcx = 0.0, rcy = 0.0, rcz = 0.0;
     double maxsz = fmax(s->xmax, fmax(s->ymax, s->zmax));
@@ -729,7 +810,7 @@ orc_sim *orc_create(const char *params) {
         if (set_param(s, k, eq + 1)) { free(buf); free(s); return NULL; }
     }
     free(buf);
-    if (read_input_post(s) || grid_create(s) || observer_create(s)) { free(s); return NULL; }
+    if (read_input_post(s) || grid_create(s) || create_JPa_mem(s) || observer_create(s)) { free(s); return NULL; }
     return s;
 }
 static void free_obs(obs_t *o) { free(o->scatt); free(o->direc); free(o->I); free(o->Q); free(o->U); free(o->V);
@@ -739,6 +820,7 @@ void orc_destroy(orc_sim *s) {
     free(s->xface); free(s->yface); free(s->zface); free(s->rhokap); free(s->voigt_a); free(s->Dfreq); free(s->vfx); free(s->vfy); free(s->vfz); free(s->rhokapD);
     free(s->Jout); free(s->Jin); free(s->Jabs); free(s->Jmu); free(s->coss); free(s->S11); free(s->S12); free(s->S33); free(s->S34); free(s->phase_PDF); free(s->alias);
     for (int i = 0; i < MAX_OBS; i++) free_obs(&s->obs[i]);
+    free(s->ind_bin); free(s->ncount); free(s->J1); free(s->P1); free(s->P1_new);
     free(s->log_nscatt); free(s->log_xfreq); free(s);
 }
 
@@ -813,7 +895,7 @@ static void raytrace_to_tau(const orc_sim *s, acc_t *A, photon_t *p, double tau_
             t.kstep = -1; t.tz = (s->zface[t.kcell-1] - zp) / t.kz; t.delz = -s->dz / t.kz; }
         else { t.kstep = 0; t.tz = HUGEST; t.delz = HUGEST; }
     }
-    double tau = 0.0, d = 0.0, del = 0.0, rhokap, rhokapH;
+    double tau = 0.0, d = 0.0, del = 0.0, rhokap, rhokapH = 0.0;
     int iold = t.icell, jold = t.jcell, kold = t.kcell;
     double u1 = udot(s, IDX(s,iold,jold,kold), t.kx, t.ky, t.kz), u2;
     while (p->inside) {
@@ -842,11 +924,13 @@ static void raytrace_to_tau(const orc_sim *s, acc_t *A, photon_t *p, double tau_
             else if (t.kcell < 1 || t.kcell > s->nz) { p->inside = 0; break; }
             t.tz += t.delz; }
         size_t cn = IDX(s,t.icell,t.jcell,t.kcell), co = IDX(s,iold,jold,kold);
+        if (s->nbins) add_to_JPnew(s, A, p, co, del, del * rhokapH);                   /* :1579-1584 */
         u2 = udot(s, cn, t.kx, t.ky, t.kz);
         p->xfreq = (p->xfreq + u1) * s->Dfreq[co] / s->Dfreq[cn] - u2;
         iold = t.icell; jold = t.jcell; kold = t.kcell; u1 = u2;
     }
     if (!p->inside) { t.icell = iold; t.jcell = jold; t.kcell = kold; }
+    if (s->nbins) add_to_JPnew(s, A, p, IDX(s,t.icell,t.jcell,t.kcell), del, del * rhokapH);   /* :1604-1609 last segment */
     if (!p->inside) {                                                                /* escape tally :1613-1623 */
         size_t c = IDX(s,t.icell,t.jcell,t.kcell);
         u1 = udot(s, c, t.kx, t.ky, t.kz);
@@ -927,9 +1011,53 @@ static void car_xcrit_local(const orc_sim *s, int i, int j, int k, double x, dou
 }
 double orc_xcrit_local(const orc_sim *s, int i, int j, int k, double x, double y, double z) { double a, b; car_xcrit_local(s, i, j, k, x, y, z, &a, &b); return a; }
 
+/* vec2pix, RING scheme, 1-based pixel: healpix.f90:29-112 */
+int orc_vec2pix(int nside, double vx, double vy, double vz) {
+    const double halfpi = 1.570796326794896619231321691639751442099, twothird = 0.6666666666666666666666666666666666666666;
+    double dnorm = sqrt(vx * vx + vy * vy + vz * vz), z = vz / dnorm, phi = 0.0;
+    if (vx != 0.0 || vy != 0.0) phi = atan2(vy, vx);
+    double za = fabs(z);
+    if (phi < 0.0) phi = phi + TWOPI;
+    double tt = phi / halfpi;
+    int nl2 = 2 * nside, nl4 = 4 * nside, ncap = nl2 * (nside - 1), npix = 12 * nside * nside, ipix1;
+    if (za <= twothird) {
+        int jp = (int)(nside * (0.5 + tt - z * 0.75)), jm = (int)(nside * (0.5 + tt + z * 0.75));
+        int ir = nside + 1 + jp - jm, kshift = 0;
+        if (((ir % 2) + 2) % 2 == 0) kshift = 1;
+        int ip = (int)((jp + jm - nside + kshift + 1) / 2) + 1;
+        if (ip > nl4) ip = ip - nl4;
+        ipix1 = ncap + nl4 * (ir - 1) + ip;
+    } else {
+        double tp = tt - (int)tt, tmp = nside * sqrt(3.0 * (1.0 - za));
+        int jp = (int)(tp * tmp), jm = (int)((1.0 - tp) * tmp);
+        int ir = jp + jm + 1, ip = (int)(tt * ir) + 1;
+        if (ip > 4 * ir) ip = ip - 4 * ir;
+        if (z <= 0.0) ipix1 = npix - 2 * ir * (ir + 1) + ip; else ipix1 = 2 * ir * (ir - 1) + ip;
+    }
+    return ipix1;
+}
+
 /* =====================================================================================
  * Peel-off to far observers: peelingoff_rect.f90
  * ===================================================================================== */
+static int g_heal_nside = 0;      /* set per call site through obs_dir_s() */
+static inline void obs_dir(const obs_t *o, const photon_t *p, photon_t *pobs, double *r2, int nxim, int nyim, double dxim, double dyim, int *ix, int *iy);
+/* peel direction + pixel: TAN image (peelingoff_rect.f90:595-627) or HEALPix pixel of -k_obs (peelingoff_heal.f90:35-45) */
+static inline void obs_dir_s(const orc_sim *s, int i, const photon_t *p, photon_t *pobs, double *r2, int *ix, int *iy) {
+    if (s->nside > 0) {
+        const obs_t *o = &s->obs[i];
+        *pobs = *p;
+        pobs->kx = o->x - p->x; pobs->ky = o->y - p->y; pobs->kz = o->z - p->z;
+        *r2 = pobs->kx * pobs->kx + pobs->ky * pobs->ky + pobs->kz * pobs->kz;
+        double r = sqrt(*r2);
+        pobs->kx = pobs->kx / r; pobs->ky = pobs->ky / r; pobs->kz = pobs->kz / r;
+        *ix = orc_vec2pix(s->nside, -pobs->kx, -pobs->ky, -pobs->kz); *iy = 1;
+    } else obs_dir(&s->obs[i], p, pobs, r2, s->nxim, s->nyim, s->dxim, s->dyim, ix, iy);
+}
+/* tau along the peel ray: to the grid edge (far observers) or to the observer (inside: raytrace_to_dist, peelingoff_heal.f90:60) */
+static inline double peel_tau(const orc_sim *s, acc_t *A, const photon_t *po, double r2) {
+    return raytrace_to_edge(s, po, s->raytrace_variant, s->nside > 0 ? sqrt(r2) : -1.0, &A->n_cellsteps_peel);
+}
 static inline void obs_dir(const obs_t *o, const photon_t *p, photon_t *pobs, double *r2, int nxim, int nyim, double dxim, double dyim, int *ix, int *iy) {
     *pobs = *p;
     pobs->kx = o->x - p->x; pobs->ky = o->y - p->y; pobs->kz = o->z - p->z;
@@ -948,7 +1076,7 @@ static inline void obs_dir(const obs_t *o, const photon_t *p, photon_t *pobs, do
 static void peeling_direct(const orc_sim *s, acc_t *A, const photon_t *p) {
     for (int i = 0; i < s->nobs; i++) {
         photon_t po; double r2; int ix, iy;
-        obs_dir(&s->obs[i], p, &po, &r2, s->nxim, s->nyim, s->dxim, s->dyim, &ix, &iy);
+        obs_dir_s(s, i, p, &po, &r2, &ix, &iy);
         size_t c = IDX(s,p->icell,p->jcell,p->kcell);
         double xfreq_ref, u1, u2;
         if (!s->comoving_source) { u1 = udot(s, c, p->kx, p->ky, p->kz); xfreq_ref = p->xfreq + u1; u2 = udot(s, c, po.kx, po.ky, po.kz); po.xfreq = xfreq_ref - u2; }
@@ -956,7 +1084,7 @@ static void peeling_direct(const orc_sim *s, acc_t *A, const photon_t *p) {
         xfreq_ref = xfreq_ref * (s->Dfreq[c] / s->Dfreq_ref);
         int ixf = (int)floor((xfreq_ref - s->xfreq_min) / s->dxfreq) + 1;
         if (ix >= 1 && ix <= s->nxim && iy >= 1 && iy <= s->nyim) {
-            double tau = raytrace_to_edge(s, &po, s->raytrace_variant, -1.0, &A->n_cellsteps_peel);
+            double tau = peel_tau(s, A, &po, r2);
             double wgt0 = 1.0 / (FOURPI * r2) * p->wgt, wgt = exp(-tau) * wgt0;
             obs_t *o = &A->obs[i];
             if (s->save_peeloff_2D) { o->direc_2D[PIX2(s,ix,iy)] += wgt; if (s->use_stokes) o->I_2D[PIX2(s,ix,iy)] += wgt; }
@@ -968,7 +1096,7 @@ static void peeling_direct(const orc_sim *s, acc_t *A, const photon_t *p) {
 static void peeling_resonance_nostokes(const orc_sim *s, acc_t *A, const photon_t *p, double xfreq_atom, const double va[3]) {
     for (int i = 0; i < s->nobs; i++) {
         photon_t po; double r2; int ix, iy;
-        obs_dir(&s->obs[i], p, &po, &r2, s->nxim, s->nyim, s->dxim, s->dyim, &ix, &iy);
+        obs_dir_s(s, i, p, &po, &r2, &ix, &iy);
         if (!(ix >= 1 && ix <= s->nxim && iy >= 1 && iy <= s->nyim)) continue;
         double cost = p->kx * po.kx + p->ky * po.ky + p->kz * po.kz, cost2 = cost * cost, sint = sqrt(1.0 - cost2);
         double rho1 = sqrt(1.0 - p->kz * p->kz) * sint, cosp, sinp, xfreq;
@@ -981,7 +1109,7 @@ static void peeling_resonance_nostokes(const orc_sim *s, acc_t *A, const photon_
         xfreq_ref = xfreq_ref * (s->Dfreq[c] / s->Dfreq_ref);
         int ixf = (int)floor((xfreq_ref - s->xfreq_min) / s->dxfreq) + 1;
         po.xfreq = xfreq;
-        double tau = raytrace_to_edge(s, &po, s->raytrace_variant, -1.0, &A->n_cellsteps_peel);
+        double tau = peel_tau(s, A, &po, r2);
         double peel = 0.75 * p->E1 * (cost2 + 1.0) + p->E2;
         double wgt = peel / (FOURPI * r2) * exp(-tau) * p->wgt;
         obs_t *o = &A->obs[i];
@@ -1007,7 +1135,7 @@ static inline void stokes_peel_geom(const photon_t *p, photon_t *po, double *cos
 static void peeling_resonance_stokes(const orc_sim *s, acc_t *A, const photon_t *p, double xfreq_atom, const double va[3]) {
     for (int i = 0; i < s->nobs; i++) {
         photon_t po; double r2; int ix, iy;
-        obs_dir(&s->obs[i], p, &po, &r2, s->nxim, s->nyim, s->dxim, s->dyim, &ix, &iy);
+        obs_dir_s(s, i, p, &po, &r2, &ix, &iy);
         if (!(ix >= 1 && ix <= s->nxim && iy >= 1 && iy <= s->nyim)) continue;
         double cost, sint, cosp, sinp, cos2p, sin2p;
         stokes_peel_geom(p, &po, &cost, &sint, &cosp, &sinp, &cos2p, &sin2p);
@@ -1024,7 +1152,7 @@ static void peeling_resonance_stokes(const orc_sim *s, acc_t *A, const photon_t 
         double cos2g = 2.0 * cosg * cosg - 1.0, sin2g = 2.0 * cosg * sing;
         double Idet = Iobs, Qdet = cos2g * Qobs + sin2g * Uobs, Udet = -sin2g * Qobs + cos2g * Uobs, Vdet = Vobs;
         po.xfreq = xfreq;
-        double tau = raytrace_to_edge(s, &po, s->raytrace_variant, -1.0, &A->n_cellsteps_peel);
+        double tau = peel_tau(s, A, &po, r2);
         double wgt = 1.0 / r2 * exp(-tau) * p->wgt;
         stokes_deposit(s, &A->obs[i], ix, iy, ixf, wgt, Idet, Qdet, Udet, Vdet);
     }
@@ -1033,12 +1161,12 @@ static void peeling_resonance_stokes(const orc_sim *s, acc_t *A, const photon_t 
 static void peeling_dust_nostokes(const orc_sim *s, acc_t *A, const photon_t *p) {
     for (int i = 0; i < s->nobs; i++) {
         photon_t po; double r2; int ix, iy;
-        obs_dir(&s->obs[i], p, &po, &r2, s->nxim, s->nyim, s->dxim, s->dyim, &ix, &iy);
+        obs_dir_s(s, i, p, &po, &r2, &ix, &iy);
         if (!(ix >= 1 && ix <= s->nxim && iy >= 1 && iy <= s->nyim)) continue;
         size_t c = IDX(s,p->icell,p->jcell,p->kcell);
         double u1 = udot(s, c, po.kx, po.ky, po.kz), xfreq_ref = (p->xfreq + u1) * (s->Dfreq[c] / s->Dfreq_ref);
         int ixf = (int)floor((xfreq_ref - s->xfreq_min) / s->dxfreq) + 1;
-        double tau = raytrace_to_edge(s, &po, s->raytrace_variant, -1.0, &A->n_cellsteps_peel);
+        double tau = peel_tau(s, A, &po, r2);
         double cosa = p->kx * po.kx + p->ky * po.ky + p->kz * po.kz;
         double peel = (1.0 - s->hgg * s->hgg) / pow((1.0 + s->hgg * s->hgg) - 2.0 * s->hgg * cosa, 1.5) / FOURPI;
         double wgt = peel / r2 * exp(-tau) * p->wgt;
@@ -1051,7 +1179,7 @@ static void peeling_dust_nostokes(const orc_sim *s, acc_t *A, const photon_t *p)
 static void peeling_dust_stokes(const orc_sim *s, acc_t *A, const photon_t *p) {
     for (int i = 0; i < s->nobs; i++) {
         photon_t po; double r2; int ix, iy;
-        obs_dir(&s->obs[i], p, &po, &r2, s->nxim, s->nyim, s->dxim, s->dyim, &ix, &iy);
+        obs_dir_s(s, i, p, &po, &r2, &ix, &iy);
         size_t c = IDX(s,p->icell,p->jcell,p->kcell);
         double u1 = udot(s, c, po.kx, po.ky, po.kz), xfreq_ref = (p->xfreq + u1) * (s->Dfreq[c] / s->Dfreq_ref);
         int ixf = (int)floor((xfreq_ref - s->xfreq_min) / s->dxfreq) + 1;
@@ -1067,7 +1195,7 @@ static void peeling_dust_stokes(const orc_sim *s, acc_t *A, const photon_t *p) {
         double cosg = -(m[0] * po.nx + m[1] * po.ny + m[2] * po.nz), sing = m[3] * po.nx + m[4] * po.ny + m[5] * po.nz;
         double cos2g = 2.0 * cosg * cosg - 1.0, sin2g = 2.0 * cosg * sing;
         double Idet = Iobs, Qdet = cos2g * Qobs + sin2g * Uobs, Udet = -sin2g * Qobs + cos2g * Uobs, Vdet = Vobs;
-        double tau = raytrace_to_edge(s, &po, s->raytrace_variant, -1.0, &A->n_cellsteps_peel);
+        double tau = peel_tau(s, A, &po, r2);
         double wgt = 1.0 / r2 * exp(-tau) * p->wgt;
         stokes_deposit(s, &A->obs[i], ix, iy, ixf, wgt, Idet, Qdet, Udet, Vdet);
     }
@@ -1114,6 +1242,7 @@ static inline void perp_velocity_rayleigh(const orc_sim *s, rng_t *g, const phot
 static void scatter_resonance_nostokes(const orc_sim *s, acc_t *A, rng_t *g, photon_t *p) {
     double uz, xfreq_atom, cost, sint, ux, uy;
     p->nscatt_gas = p->nscatt_gas + p->wgt;
+    add_to_Pa(s, A, p);
     do_resonance1(s, g, p, &uz, &xfreq_atom, &cost, &sint, 0, 0, 0, 0, 0);
     double phi = TWOPI * rnd(g), cosp = cos(phi), sinp = sin(phi);
     perp_velocity_rayleigh(s, g, p, &ux, &uy);
@@ -1135,6 +1264,7 @@ static inline double phi_rejection(rng_t *g, const photon_t *p, double S12overS1
 static void scatter_resonance_stokes(const orc_sim *s, acc_t *A, rng_t *g, photon_t *p) {
     double uz, xfreq_atom, cost, sint, S11, S22, S12, S33, S44, ux, uy;
     p->nscatt_gas = p->nscatt_gas + p->wgt;
+    add_to_Pa(s, A, p);
     do_resonance1(s, g, p, &uz, &xfreq_atom, &cost, &sint, &S11, &S22, &S12, &S33, &S44);
     double phi = phi_rejection(g, p, S12 / S11), cosp = cos(phi), sinp = sin(phi);
     double xc = 0.0, xc2 = 0.0;
@@ -1274,6 +1404,7 @@ static void run_photon(const orc_sim *s, acc_t *A, rng_t *g, photon_t *p) {
 static void acc_alloc(acc_t *A, orc_sim *s) {
     memset(A, 0, sizeof *A); A->s = s;
     A->Jout = calloc(s->nxfreq, 8); A->Jin = calloc(s->nxfreq, 8); A->Jabs = calloc(s->nxfreq, 8); A->Jmu = calloc((size_t)s->nxfreq * (s->nmu > 0 ? s->nmu : 1), 8);
+    if (s->J1) A->J1 = calloc((size_t)s->nxfreq * s->nbins, 8); if (s->P1) A->P1 = calloc(s->nbins, 8); if (s->P1_new) A->P1_new = calloc(s->nbins, 8);
     size_t n2 = (size_t)s->nxim * s->nyim, n3 = n2 * s->nxfreq;
     for (int i = 0; i < s->nobs; i++) { obs_t *o = &A->obs[i], *q = &s->obs[i];
         if (q->scatt_2D) { o->scatt_2D = calloc(n2, 8); o->direc_2D = calloc(n2, 8); }
@@ -1291,7 +1422,8 @@ static void acc_merge_free(acc_t *A, orc_sim *s) {
         free_obs(o); }
     s->nscatt_gas += A->nscatt_gas; s->nscatt_dust += A->nscatt_dust;
     s->n_cellsteps += A->n_cellsteps; s->n_cellsteps_peel += A->n_cellsteps_peel; s->n_events += A->n_events;
-    free(A->Jout); free(A->Jin); free(A->Jabs); free(A->Jmu);
+    addv(s->J1, A->J1, (size_t)s->nxfreq * s->nbins); addv(s->P1, A->P1, s->nbins); addv(s->P1_new, A->P1_new, s->nbins);
+    free(A->Jout); free(A->Jin); free(A->Jabs); free(A->Jmu); free(A->J1); free(A->P1); free(A->P1_new);
 }
 
 int orc_run(orc_sim *s, int64_t first_id, int64_t stride, int64_t count, int rng_kind, uint64_t seed, int nthreads) {
@@ -1338,6 +1470,7 @@ void orc_zero_tallies(orc_sim *s) {
     for (int i = 0; i < s->nobs; i++) { obs_t *o = &s->obs[i];
         double *a2[6] = {o->scatt_2D, o->direc_2D, o->I_2D, o->Q_2D, o->U_2D, o->V_2D}, *a3[6] = {o->scatt, o->direc, o->I, o->Q, o->U, o->V};
         for (int k = 0; k < 6; k++) { if (a2[k]) memset(a2[k], 0, n2 * 8); if (a3[k]) memset(a3[k], 0, n3 * 8); } }
+    if (s->J1) memset(s->J1, 0, (size_t)s->nxfreq * s->nbins * 8); if (s->P1) memset(s->P1, 0, s->nbins * 8); if (s->P1_new) memset(s->P1_new, 0, s->nbins * 8);
     s->nscatt_gas = s->nscatt_dust = 0.0; s->nphotons_done = 0; s->n_cellsteps = s->n_cellsteps_peel = s->n_events = 0.0;
 }
 
@@ -1360,7 +1493,7 @@ double orc_get_scalar(const orc_sim *s, const char *k) {
     G(rmax) G(xmax) G(ymax) G(zmax) G(DGR) G(albedo) G(hgg) G(cext_dust) G(cross0) G(g_recoil0) G(xcrit) G(raytrace_variant) G(save_peeloff)
     G(use_stokes) G(nPDF) G(save_Jabs) G(nmu) G(mu_min) G(dmu) G(distance2cm) G(source_rmax) G(comoving_source) G(recoil) G(core_skip) G(core_skip_global)
     G(xyz_symmetry) G(xy_periodic) G(save_Jin) G(save_Jmu) G(use_reduced_wgt) G(xs_point) G(ys_point) G(zs_point) G(xfreq0) G(spectral_type) G(source_geometry)
-    G(save_peeloff_2D) G(save_peeloff_3D) G(E1) G(E2) G(E3)
+    G(save_peeloff_2D) G(save_peeloff_3D) G(E1) G(E2) G(E3) G(nbins) G(geometry_JPa) G(calc_J) G(calc_P) G(calc_Pnew) G(nside) G(npix)
 #undef G
     return NAN;
 }
@@ -1381,6 +1514,11 @@ int64_t orc_get_array(const orc_sim *s, const char *k, double *out, int64_t n) {
     if (!strcmp(k, "xface")) return copy_out(s->xface, s->nx + 1, out, n);
     if (!strcmp(k, "yface")) return copy_out(s->yface, s->ny + 1, out, n);
     if (!strcmp(k, "zface")) return copy_out(s->zface, s->nz + 1, out, n);
+    if (!strcmp(k, "J1")) return copy_out(s->J1, (int64_t)s->nxfreq * s->nbins, out, n);
+    if (!strcmp(k, "P1")) return copy_out(s->P1, s->nbins, out, n);
+    if (!strcmp(k, "P1_new")) return copy_out(s->P1_new, s->nbins, out, n);
+    if (!strcmp(k, "ncount")) return copy_out(s->ncount, s->nbins, out, n);
+    if (!strcmp(k, "ind_bin")) { if (!s->ind_bin) return -1; for (int64_t i = 0; i < nc && i < n; i++) out[i] = s->ind_bin[i]; return nc; }
     if (!strcmp(k, "coss")) return copy_out(s->coss, s->nPDF, out, n);
     if (!strcmp(k, "S11")) return copy_out(s->S11, s->nPDF, out, n);
     if (!strcmp(k, "S12")) return copy_out(s->S12, s->nPDF, out, n);
@@ -1450,5 +1588,3 @@ int64_t orc_set_array(orc_sim *s, const char *k, const double *in, int64_t n) {
     memcpy(dst, in, nc * 8); return nc;
 }
 
-/* vec2pix (RING): healpix.f90:29-112 -- restated when the HEALPix observer lands. */
-int orc_vec2pix(int nside, double vx, double vy, double vz) { (void)nside; (void)vx; (void)vy; (void)vz; return -1; }

@@ -169,15 +169,16 @@ rand_gauss = lambda kind, seed, stream, n: _sampler("orc_rand_gauss_v", kind, se
 class Ref:
     """oracle/_ref/libref.so -- only exists in the container that mounts /root/reference."""
     _lib = None
+    SO = "libref.so"
 
     @classmethod
     def available(cls):
-        return os.path.exists(os.path.join(HERE, "_ref", "libref.so"))
+        return os.path.exists(os.path.join(HERE, "_ref", cls.SO))
 
     @classmethod
     def lib(cls):
-        if cls._lib is None:
-            L = C.CDLL(os.path.join(HERE, "_ref", "libref.so"))
+        if cls.__dict__.get("_lib") is None:
+            L = C.CDLL(os.path.join(HERE, "_ref", cls.SO))
             L.ref_voigt.restype = _d; L.ref_voigt.argtypes = [_d, _d]
             L.ref_voigt_v.argtypes = [_i, _vp, _vp, _vp]
             L.ref_seed.argtypes = [_i]
@@ -202,8 +203,11 @@ class Ref:
             v = [_d() for _ in range(5)]
             L.ref_init_line(*[C.byref(t) for t in v])
             cls.line = [t.value for t in v]
+            if hasattr(L, "ref_set_JPa"):
+                L.ref_set_JPa.argtypes = [_i, _i, _vp]
+                L.ref_get_JP.argtypes = [_i, _vp, _vp]
             cls._lib = L
-        return cls._lib
+        return cls.__dict__["_lib"]
 
     @classmethod
     def voigt(cls, x, a):
@@ -244,3 +248,19 @@ class Ref:
     def raytrace_to_dist(cls, r, ic, dist):
         r = np.array(r, dtype=np.float64); ic = np.array(ic, dtype=np.int32); t = _d()
         cls.lib().ref_raytrace_to_dist(_ptr(r), _ptr(ic), dist, C.byref(t)); return t.value
+
+
+class RefCalc(Ref):
+    """the same reference subset compiled with -DCALCJ -DCALCP -DCALCPnew (oracle/_ref/libref_calc.so)"""
+    _lib = None
+    SO = "libref_calc.so"
+
+    @classmethod
+    def set_JPa(cls, geometry_JPa, nbins, ind):
+        ind = np.ascontiguousarray(np.asarray(ind, dtype=np.int32).ravel(order="F"))
+        cls.lib().ref_set_JPa(geometry_JPa, nbins, _ptr(ind)); cls._keep_ind = ind
+
+    @classmethod
+    def get_JP(cls, nxfreq, nbins):
+        J = np.zeros(nxfreq * nbins); P = np.zeros(nbins)
+        cls.lib().ref_get_JP(nbins, _ptr(J), _ptr(P)); return J.reshape((nxfreq, nbins), order="F"), P

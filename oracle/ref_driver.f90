@@ -326,4 +326,25 @@ contains
     call raytrace_to_dist_car(ph, g, dist, tau)
   end subroutine ref_raytrace_to_dist
 
+#if defined(CALCJ) && defined(CALCPnew)
+  !--- profile tallies compiled into raytrace_car.f90 by -DCALCJ -DCALCPnew (add_to_J :3979-4011, add_to_Pnew :4015-4045)
+  subroutine ref_set_JPa(geometry_JPa, nbins, ind) bind(C, name='ref_set_JPa')
+    integer(c_int), value :: geometry_JPa, nbins
+    integer(c_int), intent(in) :: ind(g%nx, g%ny, g%nz)
+    g%geometry_JPa = geometry_JPa
+    g%nr = nbins
+    if (associated(g%ind_sph)) deallocate(g%ind_sph)
+    if (associated(g%J1))      deallocate(g%J1)
+    if (associated(g%P1_new))  deallocate(g%P1_new)
+    allocate(g%ind_sph(g%nx, g%ny, g%nz)); g%ind_sph = ind
+    allocate(g%J1(g%nxfreq, nbins), g%P1_new(nbins)); g%J1 = 0.0_wp; g%P1_new = 0.0_wp
+  end subroutine ref_set_JPa
+
+  subroutine ref_get_JP(nbins, J1, P1_new) bind(C, name='ref_get_JP')
+    integer(c_int), value :: nbins
+    real(c_double), intent(out) :: J1(g%nxfreq, nbins), P1_new(nbins)
+    J1 = g%J1; P1_new = g%P1_new
+  end subroutine ref_get_JP
+#endif
+
 end module ref_driver

@@ -133,3 +133,38 @@ def test_photon_conservation(oracle_mod):
 def test_unknown_parameter_fails_like_a_namelist(oracle_mod):
     with pytest.raises(RuntimeError):
         oracle_mod.Oracle("no_such_field=1")
+
+
+@pytest.mark.parametrize("name", ["car_sph", "xyzsym_sph", "zonly_plane"])
+def test_JPnew_deposits_vs_reference(oracle_mod, golden, name):
+    """J(x) and P_alpha(new) path deposits: vectors from the reference's raytrace_car.f90 built with -DCALCJ -DCALCPnew"""
+    z = golden("jpa_%s.npz" % name)
+    o = oracle_mod.Oracle(str(z["params"]))
+    for k in ("rhokap", "voigt_a", "Dfreq", "vfx", "vfy", "vfz"):
+        o.set_array(k, z[k])
+    assert int(o.scalar("geometry_JPa")) == int(z["geometry_JPa"])
+    for r, ic, tau in zip(z["r_in"], z["ic_in"], z["tau_in"]):
+        o.raytrace_to_tau(int(z["variant"]), r, ic, float(tau))
+    nb, nxf = int(o.scalar("nbins")), int(o.scalar("nxfreq"))
+    J1 = o.array("J1").reshape((nxf, nb), order="F")
+    assert np.allclose(J1, z["J1"], rtol=1e-10, atol=1e-14)
+    assert np.allclose(o.array("P1_new"), z["P1_new"], rtol=1e-10, atol=1e-30)
+    assert (z["J1"] > 0).sum() > 20
+
+
+def test_vec2pix_vs_reference(oracle_mod, golden):
+    import ctypes
+    z = golden("vec2pix.npz")
+    L = oracle_mod.Oracle.lib(); L.orc_vec2pix.restype = ctypes.c_int; L.orc_vec2pix.argtypes = [ctypes.c_int] + [ctypes.c_double] * 3
+    for nside in (1, 2, 8, 64):
+        got = np.array([L.orc_vec2pix(nside, *map(float, v)) for v in z["v"]])
+        assert np.array_equal(got, z["nside%d" % nside])
+
+
+def test_Pa_estimators_agree(oracle_mod):
+    # the event-count (CALCP) and path-length (CALCPnew) estimators of the scattering rate converge to the same profile
+    o = oracle_mod.Oracle("temperature=1e4 taumax=1e3 nx=31 ny=31 nz=31 rmax=1 xyz_symmetry=1 calc_P=1 calc_Pnew=1 calc_J=1")
+    o.run(20000, seed=5)
+    P, Pn = o.array("P1"), o.array("P1_new")
+    assert abs(P.sum() / Pn.sum() - 1.0) < 0.01
+    assert np.allclose(P[2:12], Pn[2:12], rtol=0.05)

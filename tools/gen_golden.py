@@ -97,6 +97,45 @@ for name, (variant, params) in cases.items():
                         tau_edge=np.array(tedge), dist=np.array(dist), tau_dist=np.array(tdist), Jout=J)
     print(name, "escaped", int(np.sum(np.array(icout)[:, 3] == 0)), "Jout sum", J.sum())
 
+# J(x) / P_alpha(new) path-length deposits compiled into the reference's raytrace_car.f90 by -DCALCJ -DCALCPnew
+RC = O.RefCalc
+RC.lib()
+jcases = {"car_sph": (0, "nx=9 ny=9 nz=9 rmax=1 taumax=50 temperature=1e4"),
+          "xyzsym_sph": (1, "nx=9 ny=9 nz=9 rmax=1 taumax=50 temperature=1e4 xyz_symmetry=1"),
+          "zonly_plane": (2, "nx=1 ny=1 nz=21 xy_periodic=1 taumax=50 temperature=1e4 geometry_JPa=-1 rmax=1")}
+for name, (variant, params) in jcases.items():
+    o = O.Oracle(params + " calc_J=1 calc_Pnew=1"); perturb(o); RC.set_grid_from(o)
+    g = o.scalar
+    nx, ny, nz, nb, nxf = int(g("nx")), int(g("ny")), int(g("nz")), int(g("nbins")), int(g("nxfreq"))
+    geo = int(g("geometry_JPa"))
+    ind = np.maximum(o.array("ind_bin"), 1).astype(np.int32)          # cells outside every bin carry no gas; keep the index legal
+    RC.set_JPa(1 if geo == 1 else geo, nb, ind)
+    rin, icin, tauin = [], [], []
+    for it in range(400):
+        ic = [int(rng.integers(1, nx + 1)), int(rng.integers(1, ny + 1)), int(rng.integers(1, nz + 1))]
+        pos = [g("xmin") + (ic[0] - 1 + rng.uniform()) * g("dx"), g("ymin") + (ic[1] - 1 + rng.uniform()) * g("dy"), g("zmin") + (ic[2] - 1 + rng.uniform()) * g("dz")]
+        mu = rng.uniform(-1, 1); ph = rng.uniform(0, 2 * np.pi); st = np.sqrt(1 - mu * mu)
+        r = pos + [st * np.cos(ph), st * np.sin(ph), mu] + [rng.normal(0, 3.0), rng.uniform(0.2, 1.0)]; icc = ic + [1]
+        tau = rng.exponential(1.0) * (10 if it % 3 else 0.3)
+        RC.raytrace_to_tau(variant, r, icc, tau)
+        rin.append(r); icin.append(icc); tauin.append(tau)
+    J1, P1n = RC.get_JP(nxf, nb)
+    np.savez_compressed(os.path.join(OUT, "jpa_%s.npz" % name), params=params + " calc_J=1 calc_Pnew=1", variant=variant,
+                        rhokap=o.array("rhokap"), voigt_a=o.array("voigt_a"), Dfreq=o.array("Dfreq"), vfx=o.array("vfx"), vfy=o.array("vfy"),
+                        vfz=o.array("vfz"), r_in=np.array(rin), ic_in=np.array(icin), tau_in=np.array(tauin), J1=J1, P1_new=P1n, geometry_JPa=geo)
+    print("jpa", name, "geometry", geo, "nbins", nb, "J1 sum", J1.sum(), "P1_new sum", P1n.sum())
+
+# HEALPix pixel index (healpix.f90:29-112)
+vv = rng.normal(size=(4000, 3)); vv[::50, 2] = 0.0; vv[1::50, :2] = 0.0
+pix = {}
+ip = __import__("ctypes").c_int()
+for nside in (1, 2, 8, 64):
+    out = []
+    for v in vv:
+        R.lib().ref_vec2pix(nside, float(v[0]), float(v[1]), float(v[2]), __import__("ctypes").byref(ip)); out.append(ip.value)
+    pix["nside%d" % nside] = np.array(out, dtype=np.int32)
+np.savez_compressed(os.path.join(OUT, "vec2pix.npz"), v=vv, **pix)
+
 # alias table + in-bin sampling (random_mt.f90:2016-2238) on the Mueller phase function shape
 mu_file = "/root/reference/data/mueller_Lyalpha.dat"
 tab = np.loadtxt(mu_file, skiprows=3)

@@ -13,8 +13,11 @@ ap.add_argument("--block", type=int, default=0)
 ap.add_argument("--tau", type=float, default=1e6)
 ap.add_argument("--photons", type=float, default=1e7)
 ap.add_argument("--every", type=int, default=1)
+ap.add_argument("--config", default="sphere")
 a = ap.parse_args()
 w = dict(bench.WORKLOAD); w["taumax"] = a.tau; w["no_photons"] = a.photons
+if a.config == "peel":      # examples/sphere_peel/t1tau6.in (C3): 201^3, Stokes, 129x129x201 peel cube
+    w.update(xyz_symmetry=False, comoving_source=True, nx=201, ny=201, nz=201, use_stokes=True, save_Jin=True, nxim=129, nyim=129)
 sim = host.Simulation(w)
 if a.lanes or a.block:
     sim.ctx.set_pool(a.lanes, a.block)
@@ -26,7 +29,8 @@ for s in range(a.steps):
     if (s + 1) % a.every == 0 or active == 0:
         t = sim.ctx.tallies(); now = time.perf_counter()
         ev = t["n_events"] - prev["n_events"]; cs = t["n_cellsteps"] - prev["n_cellsteps"]
-        print(json.dumps(dict(step=s + 1, t=round(now - t00, 3), events_per_s=ev / (now - tprev), cells_per_event=cs / max(ev, 1), done=done, active=active,
+        cp = t["n_cellsteps_peel"] - prev["n_cellsteps_peel"]
+        print(json.dumps(dict(step=s + 1, t=round(now - t00, 3), events_per_s=ev / (now - tprev), cells_per_event=cs / max(ev, 1), peel_cells_per_event=cp / max(ev, 1), done=done, active=active,
                               mean_nscatt_done=(t["nscatt_gas"] / max(t["nphotons_done"], 1)), lanes=sim.ctx.pool_info()[0])), flush=True)
         prev, tprev = t, now
     if active == 0:
