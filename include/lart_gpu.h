@@ -53,6 +53,7 @@ typedef struct lart_tallies {
     double *Jout, *Jin, *Jabs, *Jmu;                         /* nxfreq, nxfreq, nxfreq, nxfreq*nmu */
     double *scatt, *direc, *I, *Q, *U, *V;                   /* nobs*nxfreq*nxim*nyim each */
     double *scatt_2D, *direc_2D, *I_2D, *Q_2D, *U_2D, *V_2D; /* nobs*nxim*nyim each */
+    double *J1, *P1, *P1_new;                                /* nxfreq*nbins, nbins, nbins (lart_gpu_set_JPa) */
     double nscatt_gas, nscatt_dust;                          /* weight sums over finished photons (par%nscatt_*) */
     double n_events;                                         /* scattering events executed */
     double n_cellsteps, n_cellsteps_peel;                    /* cells visited by flight / peel rays (roofline accounting) */
@@ -83,6 +84,15 @@ int  lart_gpu_set_mueller(lart_gpu *ctx, int32_t nPDF, const double *coss, const
  * rmatrix[9*nobs] with rmatrix(r,c) at [9*i + 3*(r-1) + (c-1)] */
 int  lart_gpu_set_observers(lart_gpu *ctx, int32_t nobs, const double *xyz, const double *rmatrix,
                             double dxim, double dyim, int32_t nxim, int32_t nyim);
+
+/* observers inside the medium, HEALPix all-sky maps (observer_create_inside, observer_heal.f90:24-80): xyz[3*nobs], nside.
+ * Tallies use the scatt/direc (+_2D) members of lart_tallies with nxim = 12*nside^2, nyim = 1.  Plain grid, no Stokes. */
+int  lart_gpu_set_observers_heal(lart_gpu *ctx, int32_t nobs, const double *xyz, int32_t nside);
+/* J(x) / P_alpha profile tallies, the reference's compile-time switches CALCJ / CALCP / CALCPnew as run-time flags
+ * (add_to_J raytrace_car.f90:3979-4011, add_to_Pnew :4015-4045, add_to_Pa scattering_car.f90:830-859).
+ * ind_bin[ncell] = 1-based profile bin of each cell as create_JPa_mem builds it (grid_mod_car.f90:1242-1434:
+ * ind_sph for geometry_JPa = 1, kcell for -1, the cell index for 3), 0 = cell belongs to no bin; cross0 = line%cross0. */
+int  lart_gpu_set_JPa(lart_gpu *ctx, int32_t calc_J, int32_t calc_P, int32_t calc_Pnew, int32_t nbins, const int32_t *ind_bin, double cross0);
 
 /* replaces `call run_simulation(grid)` (main.f90:42): photons first_id, first_id+stride, ... (count of
  * them; the reference's static decomposition `do ip = rank+1, nphotons, nproc`, run_simulation_mod.f90:150).
@@ -116,6 +126,7 @@ int  lart_gpu_get_tallies(lart_gpu *ctx, lart_tallies *out);
 int  lart_gpu_test_voigt(lart_gpu *ctx, int32_t n, const double *x, const double *a, double *h);
 int  lart_gpu_test_rand(lart_gpu *ctx, int32_t what, uint64_t seed, uint64_t id, int32_t n, double p1, double p2, double *out);
 int  lart_gpu_test_raytrace(lart_gpu *ctx, int32_t mode, int32_t n, double *r8, int32_t *ic4, const double *tau_or_dist, double *tau_out);
+int  lart_gpu_test_vec2pix(lart_gpu *ctx, int32_t nside, int32_t n, const double *v3, int32_t *ipix);
 int  lart_gpu_test_scatter(lart_gpu *ctx, int32_t n, double *st18, int32_t *ic4, uint64_t seed, const uint64_t *ids, int64_t *ndraws);
 
 #ifdef __cplusplus

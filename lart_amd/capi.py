@@ -26,17 +26,18 @@ class LartParams(C.Structure):
 
 class LartTallies(C.Structure):
     _fields_ = [(n, _vp) for n in ("Jout", "Jin", "Jabs", "Jmu", "scatt", "direc", "I", "Q", "U", "V",
-                                   "scatt_2D", "direc_2D", "I_2D", "Q_2D", "U_2D", "V_2D")] + \
+                                   "scatt_2D", "direc_2D", "I_2D", "Q_2D", "U_2D", "V_2D", "J1", "P1", "P1_new")] + \
         [(n, _d) for n in ("nscatt_gas", "nscatt_dust", "n_events", "n_cellsteps", "n_cellsteps_peel")] + \
         [("nphotons_done", _i64), ("nphotons_active", _i64)]
 
 
 SYMBOLS = ["lart_gpu_device_count", "lart_gpu_create", "lart_gpu_destroy", "lart_gpu_last_error",
-           "lart_gpu_set_grid_car", "lart_gpu_set_mueller", "lart_gpu_set_observers", "lart_gpu_run",
+           "lart_gpu_set_grid_car", "lart_gpu_set_mueller", "lart_gpu_set_observers", "lart_gpu_set_observers_heal",
+           "lart_gpu_set_JPa", "lart_gpu_run",
            "lart_gpu_begin", "lart_gpu_step", "lart_gpu_sync", "lart_gpu_kernel_time",
            "lart_gpu_enable_photon_log", "lart_gpu_get_photon_log", "lart_gpu_set_pool", "lart_gpu_pool_info",
            "lart_gpu_tally_buffer", "lart_gpu_zero_tallies", "lart_gpu_get_tallies",
-           "lart_gpu_test_voigt", "lart_gpu_test_rand", "lart_gpu_test_raytrace", "lart_gpu_test_scatter"]
+           "lart_gpu_test_voigt", "lart_gpu_test_rand", "lart_gpu_test_raytrace", "lart_gpu_test_vec2pix", "lart_gpu_test_scatter"]
 
 _lib = None
 
@@ -54,6 +55,9 @@ def lib():
         L.lart_gpu_set_grid_car.argtypes = [_vp, _i32, _i32, _i32] + [_d] * 6 + [_i32] * 3 + [_vp] * 10
         L.lart_gpu_set_mueller.argtypes = [_vp, _i32] + [_vp] * 7
         L.lart_gpu_set_observers.argtypes = [_vp, _i32, _vp, _vp, _d, _d, _i32, _i32]
+        L.lart_gpu_set_observers_heal.argtypes = [_vp, _i32, _vp, _i32]
+        L.lart_gpu_set_JPa.argtypes = [_vp, _i32, _i32, _i32, _i32, _vp, _d]
+        L.lart_gpu_test_vec2pix.argtypes = [_vp, _i32, _i32, _vp, _vp]
         L.lart_gpu_run.argtypes = [_vp, _i64, _i64, _i64, _u64]
         L.lart_gpu_begin.argtypes = [_vp, _i64, _i64, _i64, _u64]
         L.lart_gpu_step.argtypes = [_vp, _i32, _i32]
@@ -99,6 +103,7 @@ class Context:
         self.par = params
         _chk(lib().lart_gpu_create(C.byref(self.h), C.byref(params), device))
         self.nobs = self.nxim = self.nyim = 0
+        self.nbins = 0; self.jpa = (0, 0, 0)
 
     def close(self):
         if getattr(self, "h", None):
@@ -130,6 +135,16 @@ class Context:
             raise ValueError("rmatrix must have 9*nobs entries")
         _chk(lib().lart_gpu_set_observers(self.h, nobs, _p(xyz), _p(rm), dxim, dyim, nxim, nyim))
         self.nobs, self.nxim, self.nyim = nobs, nxim, nyim
+
+    def set_observers_heal(self, xyz, nside):
+        xyz = _f64(np.asarray(xyz).reshape(-1)); nobs = xyz.size // 3
+        _chk(lib().lart_gpu_set_observers_heal(self.h, nobs, _p(xyz), nside))
+        self.nobs, self.nxim, self.nyim = nobs, 12 * nside * nside, 1
+
+    def set_JPa(self, calc_J, calc_P, calc_Pnew, nbins, ind_bin, cross0):
+        ind = np.ascontiguousarray(np.asarray(ind_bin, dtype=np.int32).ravel(order="F"))
+        _chk(lib().lart_gpu_set_JPa(self.h, int(calc_J), int(calc_P), int(calc_Pnew), nbins, _p(ind), cross0))
+        self.nbins = nbins; self.jpa = (int(calc_J), int(calc_P), int(calc_Pnew))
 
     def set_pool(self, nlanes=0, block=0):
         _chk(lib().lart_gpu_set_pool(self.h, nlanes, block))
@@ -190,6 +205,13 @@ class Context:
             if p.save_peeloff_2D:
                 for n in names3:
                     out[n + "_2D"] = np.zeros((self.nxim, self.nyim, self.nobs), order="F")
+        if self.nbins:
+            if self.jpa[0]:
+                out["J1"] = np.zeros((nxf, self.nbins), order="F")
+            if self.jpa[1]:
+                out["P1"] = np.zeros(self.nbins)
+            if self.jpa[2]:
+                out["P1_new"] = np.zeros(self.nbins)
         for k, a in out.items():
             setattr(t, k, a.ctypes.data)
         _chk(lib().lart_gpu_get_tallies(self.h, C.byref(t)))
@@ -212,6 +234,10 @@ class Context:
         q = None if tq is None else np.ascontiguousarray(tq, dtype=np.float64)
         _chk(lib().lart_gpu_test_raytrace(self.h, 10 * kind + variant, n, _p(r), _p(ic), _p(q), _p(tau)))
         return r, ic, tau
+
+    def test_vec2pix(self, nside, v3):
+        v = np.ascontiguousarray(v3, dtype=np.float64); out = np.zeros(v.shape[0], dtype=np.int32)
+        _chk(lib().lart_gpu_test_vec2pix(self.h, nside, v.shape[0], _p(v), _p(out))); return out
 
     def test_scatter(self, st18, ic4, seed, ids):
         st = np.ascontiguousarray(st18, dtype=np.float64).copy(); ic = np.ascontiguousarray(ic4, dtype=np.int32).copy()

@@ -56,6 +56,9 @@ struct DPool {
     int *ic, *jc, *kc, *flags;
 };
 
+// J(x) / P_alpha profile tallies (compile-time CALCJ/CALCP/CALCPnew in the reference; run-time switches here)
+struct DJPa { int calc_J, calc_P, calc_Pnew, nbins; const int *ind_bin; double cross0; double *J1, *P1, *P1_new; };
+
 struct DCtl { unsigned long long next_k; unsigned long long n_active; };
 
 struct KArgs {
@@ -65,6 +68,8 @@ struct KArgs {
     DPool pool;
     DMueller mu;
     const DObs *obs; int nobs, nxim, nyim; double dxim, dyim;
+    int heal_nside;               // > 0: HEALPix inside observers (nxim = npix, nyim = 1)
+    DJPa jpa;
     DCtl *ctl;
     long long first_id, stride, count;
     unsigned long long seed;
@@ -399,6 +404,19 @@ __device__ inline void tally_escape(const lart_params &par, const DTally &T, con
     }
 }
 
+// add_to_J (raytrace_car.f90:3979-4011) + add_to_Pnew (:4015-4045): one path segment of length del in cell `ci`
+__device__ inline void jpa_segment(const KArgs &A, const Photon &p, size_t ci, double rhokap_cell, double Dfreq_cell, double del, double dtauH) {
+    if (!(rhokap_cell > 0.0)) return;
+    int ib = A.jpa.ind_bin[ci];
+    if (ib < 1) return;
+    if (A.jpa.calc_J) {
+        double xr = p.xfreq * (Dfreq_cell / A.par.Dfreq_ref);
+        int ix = (int)floor((xr - A.par.xfreq_min) / A.par.dxfreq) + 1;
+        if (ix > 0 && ix <= A.par.nxfreq) atomicAdd(&A.jpa.J1[(size_t)(ix - 1) + (size_t)A.par.nxfreq * (ib - 1)], del * p.wgt);
+    }
+    if (A.jpa.calc_Pnew) atomicAdd(&A.jpa.P1_new[ib - 1], dtauH * p.wgt / (rhokap_cell * Dfreq_cell / A.jpa.cross0));
+}
+
 // march to optical depth tau_in; moves the packet, re-expresses xfreq at every crossing, tallies escape
 template <int VAR>
 __device__ inline void raytrace_to_tau(const KArgs &A, const Lds &l, bool dust, Photon &p, double tau_in, unsigned &nsteps) {
@@ -411,26 +429,30 @@ __device__ inline void raytrace_to_tau(const KArgs &A, const Lds &l, bool dust, 
     double Dold = c->Dfreq, u1 = c->vfx * t.kx + c->vfy * t.ky + c->vfz * t.kz;
     double rk = c->rhokap, va = c->voigt_a, rD = c->rhokapD;
     double vx = c->vfx, vy = c->vfy, vz = c->vfz;
+    double del = 0.0, vH = 0.0;
     for (;;) {
-        double rhokap = rk * voigt_H(l.vt, p.xfreq, va);
+        vH = voigt_H(l.vt, p.xfreq, va);
+        double rhokap = rk * vH;
         if (dust) rhokap = rhokap + rD;
         nsteps++;
         int idx = (VAR == 2) ? 3 : minloc3(t.tx, t.ty, t.tz);
         double tt = idx == 1 ? t.tx : (idx == 2 ? t.ty : t.tz);
-        double del = tt - d;
+        del = tt - d;
         tau = tau + del * rhokap; d = tt;
         if (tau >= tau_in) {
-            if (rhokap > 0.0) d = d - (tau - tau_in) / rhokap;
+            if (rhokap > 0.0) { double over = (tau - tau_in) / rhokap; d = d - over; del = del - over; }
             break;
         }
         int io = t.ic, jo = t.jc, ko = t.kc;
         if (!trav_cross<VAR>(g, t, idx)) { p.inside = false; t.ic = io; t.jc = jo; t.kc = ko; break; }
+        if (A.jpa.nbins) jpa_segment(A, p, cidx(g, io, jo, ko), rk, Dold, del, del * (rk * vH));      // add_to_J / add_to_Pnew :1579-1584
         c = &g.cell[cidx(g, t.ic, t.jc, t.kc)];
         vx = c->vfx; vy = c->vfy; vz = c->vfz;
         double Dn = c->Dfreq, u2 = vx * t.kx + vy * t.ky + vz * t.kz;
         p.xfreq = (p.xfreq + u1) * Dold / Dn - u2;
         Dold = Dn; u1 = u2; rk = c->rhokap; va = c->voigt_a; rD = c->rhokapD;
     }
+    if (A.jpa.nbins) jpa_segment(A, p, cidx(g, t.ic, t.jc, t.kc), rk, Dold, del, del * (rk * vH));          // last segment :1604-1609
     if (!p.inside) {                                          // :1613-1623 fluid frame -> lab frame, escape tally
         // (for VAR 1 the mirrored direction components of the last flight segment are used, :1918)
         u1 = vx * t.kx + vy * t.ky + vz * t.kz;
@@ -465,16 +487,45 @@ __device__ inline void xcrit_local(const lart_params &par, const DGrid &g, const
     if (atau > 1.0) { xc = cbrt(atau) / 5.0; xc2 = xc * xc; }
 }
 
+// HEALPix RING pixel (1-based) of a direction: healpix.f90:29-112
+__device__ inline int vec2pix(int nside, double vx, double vy, double vz) {
+    const double halfpi = 1.570796326794896619231321691639751442099, twothird = 0.6666666666666666666666666666666666666666;
+    double dnorm = sqrt(vx * vx + vy * vy + vz * vz), z = vz / dnorm, phi = 0.0;
+    if (vx != 0.0 || vy != 0.0) phi = atan2(vy, vx);
+    double za = fabs(z);
+    if (phi < 0.0) phi = phi + LART_TWOPI;
+    double tt = phi / halfpi;
+    int nl2 = 2 * nside, nl4 = 4 * nside, ncap = nl2 * (nside - 1), npix = 12 * nside * nside;
+    if (za <= twothird) {
+        int jp = (int)(nside * (0.5 + tt - z * 0.75)), jm = (int)(nside * (0.5 + tt + z * 0.75));
+        int ir = nside + 1 + jp - jm, kshift = ((ir & 1) == 0) ? 1 : 0;
+        int ip = (int)((jp + jm - nside + kshift + 1) / 2) + 1;
+        if (ip > nl4) ip = ip - nl4;
+        return ncap + nl4 * (ir - 1) + ip;
+    }
+    double tp = tt - (double)(int)tt, tmp = nside * sqrt(3.0 * (1.0 - za));
+    int jp = (int)(tp * tmp), jm = (int)((1.0 - tp) * tmp);
+    int ir = jp + jm + 1, ip = (int)(tt * ir) + 1;
+    if (ip > 4 * ir) ip = ip - 4 * ir;
+    return (z <= 0.0) ? npix - 2 * ir * (ir + 1) + ip : 2 * ir * (ir - 1) + ip;
+}
+
 // ---------------------------------------------------------------------------------------------
-// peel-off (next-event estimator) to far observers: peelingoff_rect.f90
+// peel-off (next-event estimator): far observers peelingoff_rect.f90, inside observers peelingoff_heal.f90
 // ---------------------------------------------------------------------------------------------
-struct PeelDir { double kx, ky, kz, r2; int ix, iy; bool in_image; };
+struct PeelDir { double kx, ky, kz, r2, dist; int ix, iy; bool in_image; };   // dist < 0: march to the grid edge
 __device__ inline PeelDir peel_dir(const KArgs &A, const DObs &o, const Photon &p) {
     PeelDir q;
     q.kx = o.x - p.x; q.ky = o.y - p.y; q.kz = o.z - p.z;
     q.r2 = q.kx * q.kx + q.ky * q.ky + q.kz * q.kz;
     double r = sqrt(q.r2);
     q.kx = q.kx / r; q.ky = q.ky / r; q.kz = q.kz / r;
+    if (A.heal_nside > 0) {               // inside observer: pixel of -k_obs, tau to the observer (peelingoff_heal.f90:45,60)
+        q.ix = vec2pix(A.heal_nside, -q.kx, -q.ky, -q.kz); q.iy = 1; q.dist = r;
+        q.in_image = (q.ix >= 1 && q.ix <= A.nxim);
+        return q;
+    }
+    q.dist = -1.0;
     double kx = o.rm[0] * q.kx + o.rm[1] * q.ky + o.rm[2] * q.kz, ky = o.rm[3] * q.kx + o.rm[4] * q.ky + o.rm[5] * q.kz, kz = o.rm[6] * q.kx + o.rm[7] * q.ky + o.rm[8] * q.kz;
     q.ix = (int)floor(atan2(-kx, kz) * LART_RAD2DEG / A.dxim + A.nxim / 2.0) + 1;
     q.iy = (int)floor(atan2(-ky, kz) * LART_RAD2DEG / A.dyim + A.nyim / 2.0) + 1;
@@ -502,7 +553,7 @@ __device__ inline void peel_direct(const KArgs &A, const Lds &l, bool dust, cons
         xfreq_ref = xfreq_ref * (c.Dfreq / A.par.Dfreq_ref);
         int ixf = (int)floor((xfreq_ref - A.par.xfreq_min) / A.par.dxfreq) + 1;
         if (!q.in_image) continue;
-        double tau = raytrace_to_edge<VAR>(A.g, l, dust, p, xf, q.kx, q.ky, q.kz, -1.0, nsteps);
+        double tau = raytrace_to_edge<VAR>(A.g, l, dust, p, xf, q.kx, q.ky, q.kz, q.dist, nsteps);
         double wgt = exp(-tau) * (1.0 / (LART_FOURPI * q.r2) * p.wgt);
         if (A.par.save_peeloff_2D) { add_if(A.t.c2[1], pix2(A, i, q.ix, q.iy), wgt); if (A.par.use_stokes) add_if(A.t.c2[2], pix2(A, i, q.ix, q.iy), wgt); }
         if (A.par.save_peeloff_3D && ixf >= 1 && ixf <= A.par.nxfreq) { add_if(A.t.c3[1], pix3(A, i, ixf, q.ix, q.iy), wgt); if (A.par.use_stokes) add_if(A.t.c3[2], pix3(A, i, ixf, q.ix, q.iy), wgt); }
@@ -523,7 +574,7 @@ __device__ inline void peel_resonance_nostokes(const KArgs &A, const Lds &l, boo
         double u1 = c.vfx * q.kx + c.vfy * q.ky + c.vfz * q.kz;
         double xfreq_ref = (xfreq + u1) * (c.Dfreq / A.par.Dfreq_ref);
         int ixf = (int)floor((xfreq_ref - A.par.xfreq_min) / A.par.dxfreq) + 1;
-        double tau = raytrace_to_edge<VAR>(A.g, l, dust, p, xfreq, q.kx, q.ky, q.kz, -1.0, nsteps);
+        double tau = raytrace_to_edge<VAR>(A.g, l, dust, p, xfreq, q.kx, q.ky, q.kz, q.dist, nsteps);
         double peel = 0.75 * A.par.E1 * (cost2 + 1.0) + A.par.E2;
         double wgt = peel / (LART_FOURPI * q.r2) * exp(-tau) * p.wgt;
         if (A.par.save_peeloff_2D) add_if(A.t.c2[0], pix2(A, i, q.ix, q.iy), wgt);
@@ -569,7 +620,7 @@ __device__ inline void peel_resonance_stokes(const KArgs &A, const Lds &l, bool 
         double cosg = -(o.rm[0] * s.nx + o.rm[1] * s.ny + o.rm[2] * s.nz), sing = o.rm[3] * s.nx + o.rm[4] * s.ny + o.rm[5] * s.nz;
         double cos2g = 2.0 * cosg * cosg - 1.0, sin2g = 2.0 * cosg * sing;
         double Qdet = cos2g * Qobs + sin2g * Uobs, Udet = -sin2g * Qobs + cos2g * Uobs;
-        double tau = raytrace_to_edge<VAR>(A.g, l, dust, p, xfreq, q.kx, q.ky, q.kz, -1.0, nsteps);
+        double tau = raytrace_to_edge<VAR>(A.g, l, dust, p, xfreq, q.kx, q.ky, q.kz, q.dist, nsteps);
         double wgt = 1.0 / q.r2 * exp(-tau) * p.wgt;
         stokes_deposit(A, i, q, ixf, wgt, Iobs, Qdet, Udet, Vobs);
     }
@@ -584,7 +635,7 @@ __device__ inline void peel_dust_nostokes(const KArgs &A, const Lds &l, const Ph
         double u1 = c.vfx * q.kx + c.vfy * q.ky + c.vfz * q.kz;
         double xfreq_ref = (p.xfreq + u1) * (c.Dfreq / A.par.Dfreq_ref);
         int ixf = (int)floor((xfreq_ref - A.par.xfreq_min) / A.par.dxfreq) + 1;
-        double tau = raytrace_to_edge<VAR>(A.g, l, true, p, p.xfreq, q.kx, q.ky, q.kz, -1.0, nsteps);
+        double tau = raytrace_to_edge<VAR>(A.g, l, true, p, p.xfreq, q.kx, q.ky, q.kz, q.dist, nsteps);
         double cosa = p.kx * q.kx + p.ky * q.ky + p.kz * q.kz, hgg = A.par.hgg;
         double b = (1.0 + hgg * hgg) - 2.0 * hgg * cosa;
         double peel = (1.0 - hgg * hgg) / (b * sqrt(b)) / LART_FOURPI;
@@ -614,7 +665,7 @@ __device__ inline void peel_dust_stokes(const KArgs &A, const Lds &l, const Phot
         double cosg = -(o.rm[0] * s.nx + o.rm[1] * s.ny + o.rm[2] * s.nz), sing = o.rm[3] * s.nx + o.rm[4] * s.ny + o.rm[5] * s.nz;
         double cos2g = 2.0 * cosg * cosg - 1.0, sin2g = 2.0 * cosg * sing;
         double Qdet = cos2g * Qobs + sin2g * Uobs, Udet = -sin2g * Qobs + cos2g * Uobs;
-        double tau = raytrace_to_edge<VAR>(A.g, l, true, p, p.xfreq, q.kx, q.ky, q.kz, -1.0, nsteps);
+        double tau = raytrace_to_edge<VAR>(A.g, l, true, p, p.xfreq, q.kx, q.ky, q.kz, q.dist, nsteps);
         double wgt = 1.0 / q.r2 * exp(-tau) * p.wgt;
         stokes_deposit(A, i, q, ixf, wgt, Iobs, Qdet, Udet, Vobs);
     }
@@ -703,6 +754,10 @@ __device__ inline void scatter_event(const KArgs &A, const Lds &l, Rng &g, Photo
     }
     // resonance scattering: scatter_resonance_nostokes :660-827 / _stokes :331-486
     p.nsg = p.nsg + p.wgt;
+    if (A.jpa.calc_P && c.rhokap > 0.0) {                      // add_to_Pa: scattering_car.f90:830-859
+        int ib = A.jpa.ind_bin[cidx(A.g, p.ic, p.jc, p.kc)];
+        if (ib >= 1) atomicAdd(&A.jpa.P1[ib - 1], p.wgt / (c.rhokap * c.Dfreq / A.jpa.cross0));
+    }
     // do_resonance1: line_mod.f90:108-139
     double uz = rand_resonance_vz(g, p.xfreq, va);
     double xfreq_atom = p.xfreq - uz;

@@ -24,7 +24,9 @@ struct lart_gpu {
     // Mueller
     DMueller mu{}; double *d_mu = nullptr; int *d_alias = nullptr;
     // observers
-    DObs *d_obs = nullptr; int nobs = 0, nxim = 0, nyim = 0; double dxim = 0, dyim = 0;
+    DObs *d_obs = nullptr; int nobs = 0, nxim = 0, nyim = 0; double dxim = 0, dyim = 0; int heal_nside = 0;
+    // J/P profile tallies
+    DJPa jpa{}; int *d_ind_bin = nullptr;
     // fused tally buffer
     double *d_tally = nullptr; int64_t ntally = 0; DTally t{};
     // pool
@@ -62,7 +64,7 @@ extern "C" int lart_gpu_destroy(lart_gpu *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (auto &e : c->ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-    (void)hipFree(c->d_cell); (void)hipFree(c->d_faces); (void)hipFree(c->d_mu); (void)hipFree(c->d_alias); (void)hipFree(c->d_obs);
+    (void)hipFree(c->d_cell); (void)hipFree(c->d_faces); (void)hipFree(c->d_mu); (void)hipFree(c->d_alias); (void)hipFree(c->d_obs); (void)hipFree(c->d_ind_bin);
     free_tally(c); (void)hipFree(c->d_pool); (void)hipFree(c->d_ctl); (void)hipFree(c->d_log);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -82,11 +84,18 @@ static int build_tally(lart_gpu *c) {
     int64_t o3[6], o2[6];
     for (int k = 0; k < 6; k++) { bool on = peel && p.save_peeloff_3D && (k < 2 || p.use_stokes); o3[k] = on ? off : -1; if (on) off += n3; }
     for (int k = 0; k < 6; k++) { bool on = peel && p.save_peeloff_2D && (k < 2 || p.use_stokes); o2[k] = on ? off : -1; if (on) off += n2; }
+    int64_t oJ1 = -1, oP1 = -1, oPn = -1;
+    if (c->jpa.nbins > 0) {
+        if (c->jpa.calc_J)    { oJ1 = off; off += nxf * c->jpa.nbins; }
+        if (c->jpa.calc_P)    { oP1 = off; off += c->jpa.nbins; }
+        if (c->jpa.calc_Pnew) { oPn = off; off += c->jpa.nbins; }
+    }
     c->ntally = off;
     HIPCHK(hipMalloc(&c->d_tally, off * sizeof(double)));
     HIPCHK(hipMemset(c->d_tally, 0, off * sizeof(double)));
     c->t.scal = c->d_tally; c->t.Jout = c->d_tally + oJout; c->t.Jin = c->d_tally + oJin; c->t.Jabs = c->d_tally + oJabs; c->t.Jmu = c->d_tally + oJmu;
     for (int k = 0; k < 6; k++) { c->t.c3[k] = o3[k] >= 0 ? c->d_tally + o3[k] : nullptr; c->t.c2[k] = o2[k] >= 0 ? c->d_tally + o2[k] : nullptr; }
+    c->jpa.J1 = oJ1 >= 0 ? c->d_tally + oJ1 : nullptr; c->jpa.P1 = oP1 >= 0 ? c->d_tally + oP1 : nullptr; c->jpa.P1_new = oPn >= 0 ? c->d_tally + oPn : nullptr;
     return 0;
 }
 
@@ -151,7 +160,40 @@ extern "C" int lart_gpu_set_observers(lart_gpu *c, int32_t nobs, const double *x
     for (int i = 0; i < nobs; i++) { h[i].x = xyz[3 * i]; h[i].y = xyz[3 * i + 1]; h[i].z = xyz[3 * i + 2]; for (int q = 0; q < 9; q++) h[i].rm[q] = rmatrix[9 * i + q]; }
     HIPCHK(hipMalloc(&c->d_obs, h.size() * sizeof(DObs)));
     HIPCHK(hipMemcpy(c->d_obs, h.data(), h.size() * sizeof(DObs), hipMemcpyHostToDevice));
-    c->nobs = nobs; c->nxim = nxim; c->nyim = nyim; c->dxim = dxim; c->dyim = dyim;
+    c->nobs = nobs; c->nxim = nxim; c->nyim = nyim; c->dxim = dxim; c->dyim = dyim; c->heal_nside = 0;
+    free_tally(c);
+    return 0;
+}
+
+extern "C" int lart_gpu_set_observers_heal(lart_gpu *c, int32_t nobs, const double *xyz, int32_t nside) {
+    if (!c) return fail("set_observers_heal: null context");
+    if (nobs < 1 || nobs > LART_MAX_OBSERVERS || !xyz) return fail("set_observers_heal: nobs out of range");
+    bool pow2 = nside >= 1 && nside <= 8192 && (nside & (nside - 1)) == 0;
+    if (!pow2) return fail("set_observers_heal: nside must be a power of 2 in 1..8192 (nside2npix, healpix.f90:5-27)");
+    if (c->par.use_stokes) return fail("set_observers_heal: Stokes parameters are not defined for the HEALPix path (setup.f90:181)");
+    if (c->par.xyz_symmetry || c->par.xy_periodic) return fail("set_observers_heal: inside observers need the plain Cartesian grid");
+    HIPCHK(hipSetDevice(c->device));
+    (void)hipFree(c->d_obs); c->d_obs = nullptr;
+    std::vector<DObs> h(nobs);
+    for (int i = 0; i < nobs; i++) { h[i].x = xyz[3 * i]; h[i].y = xyz[3 * i + 1]; h[i].z = xyz[3 * i + 2]; for (int q = 0; q < 9; q++) h[i].rm[q] = 0.0; }
+    HIPCHK(hipMalloc(&c->d_obs, h.size() * sizeof(DObs)));
+    HIPCHK(hipMemcpy(c->d_obs, h.data(), h.size() * sizeof(DObs), hipMemcpyHostToDevice));
+    c->nobs = nobs; c->nxim = 12 * nside * nside; c->nyim = 1; c->dxim = 1.0; c->dyim = 1.0; c->heal_nside = nside;
+    free_tally(c);
+    return 0;
+}
+
+extern "C" int lart_gpu_set_JPa(lart_gpu *c, int32_t calc_J, int32_t calc_P, int32_t calc_Pnew, int32_t nbins, const int32_t *ind_bin, double cross0) {
+    if (!c) return fail("set_JPa: null context");
+    if (!c->d_cell) return fail("set_JPa: set the medium first (lart_gpu_set_grid_car)");
+    if (nbins < 1 || !ind_bin || !(cross0 > 0.0)) return fail("set_JPa: bad arguments");
+    for (size_t i = 0; i < c->ncell; i++) if (ind_bin[i] < 0 || ind_bin[i] > nbins) return fail("set_JPa: ind_bin entries must be 0..nbins");
+    HIPCHK(hipSetDevice(c->device));
+    (void)hipFree(c->d_ind_bin); c->d_ind_bin = nullptr;
+    HIPCHK(hipMalloc(&c->d_ind_bin, c->ncell * sizeof(int)));
+    HIPCHK(hipMemcpy(c->d_ind_bin, ind_bin, c->ncell * sizeof(int), hipMemcpyHostToDevice));
+    c->jpa.calc_J = calc_J ? 1 : 0; c->jpa.calc_P = calc_P ? 1 : 0; c->jpa.calc_Pnew = calc_Pnew ? 1 : 0;
+    c->jpa.nbins = (calc_J || calc_P || calc_Pnew) ? nbins : 0; c->jpa.ind_bin = c->d_ind_bin; c->jpa.cross0 = cross0;
     free_tally(c);
     return 0;
 }
@@ -199,6 +241,7 @@ extern "C" int lart_gpu_begin(lart_gpu *c, int64_t first_id, int64_t stride, int
     if (!c->d_cell) return fail("begin: no medium (call lart_gpu_set_grid_car first)");
     if (count < 0 || stride < 1 || first_id < 0) return fail("begin: need count >= 0, stride >= 1, first_id >= 0");
     if (c->par.save_peeloff && c->nobs == 0) return fail("begin: save_peeloff set but no observers (lart_gpu_set_observers)");
+    if (c->heal_nside > 0 && (c->par.use_stokes || c->par.xyz_symmetry || c->par.xy_periodic)) return fail("begin: HEALPix observers need the plain grid without Stokes");
     if (c->par.save_peeloff && c->par.xyz_symmetry) return fail("begin: peel-off is not allowed with xyz_symmetry (setup.f90:198-206)");
     if (c->par.DGR > 0.0 && !c->has_dust_table) return fail("begin: DGR > 0 but the grid has no rhokapD");
     if (c->par.xy_periodic && !(c->g.nx == 1 && c->g.ny == 1)) return fail("begin: xy_periodic is supported for nx = ny = 1 (raytrace_to_tau_car_zonly) only");
@@ -232,7 +275,7 @@ extern "C" int lart_gpu_step(lart_gpu *c, int32_t nsteps, int32_t max_events) {
     HIPCHK(hipSetDevice(c->device));
     KArgs A{};
     A.par = c->par; A.g = c->g; A.t = c->t; A.pool = c->pool; A.mu = c->mu; A.obs = c->d_obs; A.nobs = c->par.save_peeloff ? c->nobs : 0;
-    A.nxim = c->nxim; A.nyim = c->nyim; A.dxim = c->dxim; A.dyim = c->dyim; A.ctl = c->d_ctl;
+    A.nxim = c->nxim; A.nyim = c->nyim; A.dxim = c->dxim; A.dyim = c->dyim; A.ctl = c->d_ctl; A.heal_nside = c->heal_nside; A.jpa = c->jpa;
     A.first_id = c->first_id; A.stride = c->stride; A.count = c->count; A.seed = c->seed; A.max_events = max_events;
     A.log_nscatt = c->d_log; A.log_xfreq = c->d_log ? c->d_log + c->nlog : nullptr;
     int var = c->par.xyz_symmetry ? 1 : (c->par.xy_periodic ? 2 : 0);     // setup.f90:961-990
@@ -313,6 +356,7 @@ extern "C" int lart_gpu_get_tallies(lart_gpu *c, lart_tallies *o) {
     CP(o->Jout, c->t.Jout, nxf); CP(o->Jin, c->t.Jin, nxf); CP(o->Jabs, c->t.Jabs, nxf); CP(o->Jmu, c->t.Jmu, c->par.save_Jmu ? nxf * c->par.nmu : 0);
     double *h3[6] = {o->scatt, o->direc, o->I, o->Q, o->U, o->V}, *h2[6] = {o->scatt_2D, o->direc_2D, o->I_2D, o->Q_2D, o->U_2D, o->V_2D};
     for (int k = 0; k < 6; k++) { CP(h3[k], c->t.c3[k], n3); CP(h2[k], c->t.c2[k], n2); }
+    CP(o->J1, c->jpa.J1, nxf * c->jpa.nbins); CP(o->P1, c->jpa.P1, c->jpa.nbins); CP(o->P1_new, c->jpa.P1_new, c->jpa.nbins);
 #undef CP
     return 0;
 }
@@ -375,6 +419,10 @@ __global__ void k_test_raytrace(KArgs A, int mode, int n, double *r8, int *ic4, 
     else if (var == 1) test_ray_one<1>(A, l, kind, r8 + 8 * i, ic4 + 4 * i, tq ? tq[i] : 0.0, tau_out + i);
     else test_ray_one<2>(A, l, kind, r8 + 8 * i, ic4 + 4 * i, tq ? tq[i] : 0.0, tau_out + i);
 }
+__global__ void k_test_vec2pix(int nside, int n, const double *v, int *ipix) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) ipix[i] = vec2pix(nside, v[3 * i], v[3 * i + 1], v[3 * i + 2]);
+}
 template <bool STOKES, bool DUST>
 __device__ void test_scatter_one(const KArgs &A, const Lds &l, double *st, int *ic, unsigned long long seed, unsigned long long id, long long *nd) {
     Photon p{}; p.x = st[0]; p.y = st[1]; p.z = st[2]; p.kx = st[3]; p.ky = st[4]; p.kz = st[5]; p.xfreq = st[6]; p.wgt = st[7];
@@ -405,7 +453,7 @@ template <typename T> struct DevBuf {
     ~DevBuf() { if (p) (void)hipFree(p); }
 };
 static KArgs probe_args(lart_gpu *c) {
-    KArgs A{}; A.par = c->par; A.g = c->g; A.t = c->t; A.mu = c->mu; A.obs = c->d_obs; A.nobs = 0; A.nxim = c->nxim; A.nyim = c->nyim; A.dxim = c->dxim; A.dyim = c->dyim; A.ctl = c->d_ctl;
+    KArgs A{}; A.par = c->par; A.g = c->g; A.t = c->t; A.mu = c->mu; A.obs = c->d_obs; A.nobs = 0; A.nxim = c->nxim; A.nyim = c->nyim; A.dxim = c->dxim; A.dyim = c->dyim; A.ctl = c->d_ctl; A.heal_nside = c->heal_nside; A.jpa = c->jpa;
     return A;
 }
 static size_t probe_shmem(lart_gpu *c) { return (size_t)(VT_END + c->g.nx + c->g.ny + c->g.nz + 3) * sizeof(double); }
@@ -447,6 +495,16 @@ extern "C" int lart_gpu_test_raytrace(lart_gpu *c, int32_t mode, int32_t n, doub
     hipLaunchKernelGGL(k_test_raytrace, dim3((n + 63) / 64), dim3(64), probe_shmem(c), c->stream, A, mode, n, dr.p, di.p, tq ? dq.p : nullptr, dt.p);
     HIPCHK(hipGetLastError()); HIPCHK(hipStreamSynchronize(c->stream));
     if (dr.back(r8) || di.back(ic4) || (tau_out && dt.back(tau_out))) return fail("test_raytrace: copy back failed");
+    return 0;
+}
+extern "C" int lart_gpu_test_vec2pix(lart_gpu *c, int32_t nside, int32_t n, const double *v3, int32_t *ipix) {
+    if (!c || n < 0 || nside < 1) return fail("test_vec2pix: bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    DevBuf<double> dv; DevBuf<int> di;
+    if (dv.alloc((size_t)3 * n, v3) || di.alloc(n, nullptr)) return fail("test_vec2pix: hipMalloc failed");
+    hipLaunchKernelGGL(k_test_vec2pix, dim3((n + 255) / 256), dim3(256), 0, c->stream, nside, n, dv.p, di.p);
+    HIPCHK(hipGetLastError()); HIPCHK(hipStreamSynchronize(c->stream));
+    if (di.back(ipix)) return fail("test_vec2pix: copy back failed");
     return 0;
 }
 extern "C" int lart_gpu_test_scatter(lart_gpu *c, int32_t n, double *st18, int32_t *ic4, uint64_t seed, const uint64_t *ids, int64_t *ndraws) {

@@ -127,6 +127,7 @@ contains
     tt%Jout = c_null_ptr; tt%Jin = c_null_ptr; tt%Jabs = c_null_ptr; tt%Jmu = c_null_ptr
     tt%scatt = c_null_ptr; tt%direc = c_null_ptr; tt%I = c_null_ptr; tt%Q = c_null_ptr; tt%U = c_null_ptr; tt%V = c_null_ptr
     tt%scatt_2D = c_null_ptr; tt%direc_2D = c_null_ptr; tt%I_2D = c_null_ptr; tt%Q_2D = c_null_ptr; tt%U_2D = c_null_ptr; tt%V_2D = c_null_ptr
+    tt%J1 = c_null_ptr; tt%P1 = c_null_ptr; tt%P1_new = c_null_ptr
   end subroutine null_tallies
 
   subroutine fill_params(p)

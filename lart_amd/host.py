@@ -123,6 +123,12 @@ class Params:
     dxim: float = NAN
     dyim: float = NAN
     nside: int = 0
+    npix: int = 0
+    # the reference's compile-time tally switches (Makefile:33-61), run-time here
+    calc_J: bool = False
+    calc_P: bool = False
+    calc_Pnew: bool = False
+    geometry_JPa: int = 2147483647
     # derived (not inputs)
     nphotons: int = 100000
     mu_min: float = -1.0
@@ -292,8 +298,11 @@ def read_input(par, line=None):
         raise LartInputError("ERROR: par%temperature must be > 0 K (or set par%bturb > 0)")
     if par.nx == 1 or par.ny == 1 or par.nz == 1:
         par.xyz_symmetry = False                                          # setup.f90:167
-    if par.nside > 0:
-        raise LartInputError("HEALPix inside observers (par%nside > 0) are not built yet")
+    if par.nside > 0:                                                    # observer inside the medium: setup.f90:169-186
+        par.use_stokes = False
+        par.save_peeloff = True
+        par.xyz_symmetry = False
+        par.nxim = par.nyim = 0
     if not (par.save_peeloff_2D or par.save_peeloff_3D):                  # :188-206
         par.save_peeloff = False
     if par.nxim > 0 and par.nyim > 0:
@@ -336,6 +345,12 @@ def read_input(par, line=None):
         par.rmax = -1.0
     if par.source_rmax < 0.0:
         par.source_rmax = par.rmax
+    if par.rmax <= 0.0:                                                   # geometry of the J/P profiles: setup.f90:438-459
+        par.geometry_JPa = 3
+    if par.geometry_JPa < -1 or par.geometry_JPa > 3:
+        par.geometry_JPa = 3 if par.save_all else (-1 if par.xy_periodic else 1)
+    if par.geometry_JPa in (0, 2) and (par.calc_J or par.calc_P or par.calc_Pnew):
+        raise LartInputError("par%geometry_JPa = 2 (cylindrical profiles) is not supported by this path")
     if par.distance2cm < 0.0:                                             # :473-489
         par.distance2cm = {"kpc": 3.0856776e21, "pc": 3.0856776e18, "au": 1.4960e13, "": 1.0}.get(par.distance_unit, 3.0856776e21)
     scatt_mat = ScattMat()
@@ -516,6 +531,49 @@ def grid_create(par, line):
     return g
 
 
+@dataclass
+class JPa:
+    """create_JPa_mem (grid_mod_car.f90:1242-1434): profile bin of every cell + cells per bin"""
+    nbins: int = 0
+    ind_bin: np.ndarray = None      # (nx,ny,nz) int32, 1-based, 0 = none
+    ncount: np.ndarray = None
+
+
+def create_JPa_mem(par, g):
+    if not (par.calc_J or par.calc_P or par.calc_Pnew):
+        return JPa()
+    nx, ny, nz = g.nx, g.ny, g.nz
+    nadd = np.ones((nx, ny, nz))
+    if par.xyz_symmetry:
+        nadd[:] = 8.0
+        if nx % 2:
+            nadd[0, :, :] /= 2.0
+        if ny % 2:
+            nadd[:, 0, :] /= 2.0
+        if nz % 2:
+            nadd[:, :, 0] /= 2.0
+    gas = g.rhokap > 0.0
+    if par.geometry_JPa == 1:
+        nr = max(nx, ny, nz)
+        if not par.xyz_symmetry:
+            nr = nr // 2 if nr % 2 == 0 else (nr - 1) // 2 + 1
+        rmax = min(g.xmax, g.ymax, g.zmax)
+        dr, roff = (rmax / nr, 0.0) if nr % 2 == 0 else (rmax / (nr - 0.5), -(rmax / (nr - 0.5)) / 2.0)
+        xx = (g.xface[:-1] + g.xface[1:]) / 2.0; yy = (g.yface[:-1] + g.yface[1:]) / 2.0; zz = (g.zface[:-1] + g.zface[1:]) / 2.0
+        X, Y, Z = np.meshgrid(xx, yy, zz, indexing="ij")
+        ib = np.floor((np.sqrt(X ** 2 + Y ** 2 + Z ** 2) - roff) / dr).astype(np.int64) + 1
+        ok = (ib >= 1) & (ib <= nr)
+        ind = np.where(ok, ib, 0).astype(np.int32)
+        ncount = np.zeros(nr)
+        np.add.at(ncount, ib[ok & gas] - 1, nadd[ok & gas])
+        return JPa(nr, np.asfortranarray(ind), ncount)
+    if par.geometry_JPa == -1:
+        ind = np.broadcast_to(np.arange(1, nz + 1, dtype=np.int32)[None, None, :], (nx, ny, nz))
+        return JPa(nz, np.asfortranarray(ind), gas.sum(axis=(0, 1)).astype(float))
+    ind = (np.arange(nx * ny * nz, dtype=np.int32) + 1).reshape((nx, ny, nz), order="F")
+    return JPa(nx * ny * nz, np.asfortranarray(ind), (nadd if par.xyz_symmetry else np.ones((nx, ny, nz))).ravel(order="F"))
+
+
 def _seqsum(v):
     s = 0.0
     for t in v:
@@ -570,6 +628,13 @@ def observer_create(par):
     if not par.save_peeloff:
         return Observers()
     fin = math.isfinite
+    if par.nside > 0:                                                     # observer_create_inside: observer_heal.f90:24-80
+        if not (fin(par.obsx[0]) and fin(par.obsy[0]) and fin(par.obsz[0])):
+            par.obsx[0] = par.obsy[0] = par.obsz[0] = 0.0
+        n = sum(1 for i in range(MAX_OBSERVERS) if fin(par.obsx[i]) and fin(par.obsy[i]) and fin(par.obsz[i]))
+        par.nobs, par.npix = n, 12 * par.nside ** 2
+        return Observers(nobs=n, xyz=np.array([[par.obsx[i], par.obsy[i], par.obsz[i]] for i in range(n)]), nxim=par.npix, nyim=1,
+                         steradian_pix=4.0 * PI / par.npix)
     maxsz = max(par.xmax, par.ymax, par.zmax)
     for i in range(MAX_OBSERVERS):
         if fin(par.beta[i]) and not fin(par.alpha[i]):
@@ -691,7 +756,13 @@ class Simulation:
             self.ctx.set_mueller(s.coss, s.S11, s.S12, s.S33, s.S34, s.phase_PDF, s.alias)
         if self.obs.nobs:
             o = self.obs
-            self.ctx.set_observers(o.xyz, o.rmatrix, o.dxim, o.dyim, o.nxim, o.nyim)
+            if self.par.nside > 0:
+                self.ctx.set_observers_heal(o.xyz, self.par.nside)
+            else:
+                self.ctx.set_observers(o.xyz, o.rmatrix, o.dxim, o.dyim, o.nxim, o.nyim)
+        self.jpa = create_JPa_mem(self.par, g)
+        if self.jpa.nbins:
+            self.ctx.set_JPa(self.par.calc_J, self.par.calc_P, self.par.calc_Pnew, self.jpa.nbins, self.jpa.ind_bin, self.line.cross0)
         self.nphotons_run = 0
 
     def run_simulation(self, nphotons=None, rank=0, nproc=1, seed=None):
@@ -739,6 +810,17 @@ class Simulation:
                     out[k] = t[k] / sc3
                 if k + "_2D" in t:
                     out[k + "_2D"] = t[k + "_2D"] / sc2
+        if self.jpa.nbins:                                                # :275-360 J(x) and P_alpha profiles
+            dVol = g.dx * g.dy * g.dz * par.distance2cm ** 2
+            cnt = np.where(self.jpa.ncount > 0, self.jpa.ncount, np.inf)
+            geo_area = (g.xmax - g.xmin) * (g.ymax - g.ymin) * par.distance2cm ** 2 if par.xy_periodic else 1.0
+            f = geo_area if (par.xy_periodic and par.geometry_JPa in (3, -1)) else 1.0
+            if "J1" in t:
+                out["J1"] = t["J1"] / cnt[None, :] * (f / (FOURPI * dVol * nph * unit))
+            if "P1" in t:
+                out["P1"] = t["P1"] / cnt * (f / (dVol * nph))
+            if "P1_new" in t:
+                out["P1_new"] = t["P1_new"] / cnt * (f / (dVol * nph))
         out["nscatt_tot"] = (t["nscatt_gas"] + t["nscatt_dust"]) / nph
         return out
 
