@@ -94,6 +94,22 @@ int  lart_gpu_set_observers_heal(lart_gpu *ctx, int32_t nobs, const double *xyz,
  * ind_sph for geometry_JPa = 1, kcell for -1, the cell index for 3), 0 = cell belongs to no bin; cross0 = line%cross0. */
 int  lart_gpu_set_JPa(lart_gpu *ctx, int32_t calc_J, int32_t calc_P, int32_t calc_Pnew, int32_t nbins, const int32_t *ind_bin, double cross0);
 
+/* Octree AMR medium as grid_create_amr leaves it (grid_mod_amr.f90:34-526; tree tables of amr_grid_type,
+ * octree_mod.f90:19-138).  All indices 1-based, 0 = none:  children[8*ncells] (sub-octant fastest; bit0 = x >= cx,
+ * bit1 = y, bit2 = z), neighbor[6*ncells] (face fastest; faces +x,-x,+y,-y,+z,-z), ileaf[ncells] (leaf number of a
+ * cell, 0 for internal nodes), icell_of_leaf[nleaf]; cell centres cx,cy,cz and half-widths ch per cell; the box is
+ * the cube [lo,hi]^3.  Media tables are per LEAF (length nleaf), same meaning as lart_gpu_set_grid_car.
+ * Replaces raytrace_{to_tau,to_edge,to_dist}_amr and scattering_amr for the kernels; par.xyz_symmetry selects the
+ * mirror planes of the +++ octant (raytrace_amr.f90:176-201). */
+int  lart_gpu_set_grid_amr(lart_gpu *ctx, int32_t ncells, int32_t nleaf, double lo, double hi,
+                           const double *cx, const double *cy, const double *cz, const double *ch,
+                           const int32_t *children, const int32_t *neighbor, const int32_t *ileaf, const int32_t *icell_of_leaf,
+                           const double *rhokap, const double *voigt_a, const double *Dfreq,
+                           const double *vfx, const double *vfy, const double *vfz, const double *rhokapD);
+/* profile tallies on the octree: bins by POSITION (amr_JPa_bin, octree_mod.f90:286-311): geometry_JPa 1 = radial
+ * shells of width dbin (nbins of them), -1 = z slabs of width dbin from lo, 3 = one bin per leaf (nbins = nleaf). */
+int  lart_gpu_set_JPa_amr(lart_gpu *ctx, int32_t calc_J, int32_t calc_P, int32_t calc_Pnew, int32_t geometry_JPa, int32_t nbins, double dbin, double cross0);
+
 /* replaces `call run_simulation(grid)` (main.f90:42): photons first_id, first_id+stride, ... (count of
  * them; the reference's static decomposition `do ip = rank+1, nphotons, nproc`, run_simulation_mod.f90:150).
  * The random stream of a photon depends only on (seed, id). Runs to completion. */

@@ -33,7 +33,7 @@ class LartTallies(C.Structure):
 
 SYMBOLS = ["lart_gpu_device_count", "lart_gpu_create", "lart_gpu_destroy", "lart_gpu_last_error",
            "lart_gpu_set_grid_car", "lart_gpu_set_mueller", "lart_gpu_set_observers", "lart_gpu_set_observers_heal",
-           "lart_gpu_set_JPa", "lart_gpu_run",
+           "lart_gpu_set_JPa", "lart_gpu_set_grid_amr", "lart_gpu_set_JPa_amr", "lart_gpu_run",
            "lart_gpu_begin", "lart_gpu_step", "lart_gpu_sync", "lart_gpu_kernel_time",
            "lart_gpu_enable_photon_log", "lart_gpu_get_photon_log", "lart_gpu_set_pool", "lart_gpu_pool_info",
            "lart_gpu_tally_buffer", "lart_gpu_zero_tallies", "lart_gpu_get_tallies",
@@ -57,6 +57,8 @@ def lib():
         L.lart_gpu_set_observers.argtypes = [_vp, _i32, _vp, _vp, _d, _d, _i32, _i32]
         L.lart_gpu_set_observers_heal.argtypes = [_vp, _i32, _vp, _i32]
         L.lart_gpu_set_JPa.argtypes = [_vp, _i32, _i32, _i32, _i32, _vp, _d]
+        L.lart_gpu_set_grid_amr.argtypes = [_vp, _i32, _i32, _d, _d] + [_vp] * 15
+        L.lart_gpu_set_JPa_amr.argtypes = [_vp, _i32, _i32, _i32, _i32, _i32, _d, _d]
         L.lart_gpu_test_vec2pix.argtypes = [_vp, _i32, _i32, _vp, _vp]
         L.lart_gpu_run.argtypes = [_vp, _i64, _i64, _i64, _u64]
         L.lart_gpu_begin.argtypes = [_vp, _i64, _i64, _i64, _u64]
@@ -144,6 +146,26 @@ class Context:
     def set_JPa(self, calc_J, calc_P, calc_Pnew, nbins, ind_bin, cross0):
         ind = np.ascontiguousarray(np.asarray(ind_bin, dtype=np.int32).ravel(order="F"))
         _chk(lib().lart_gpu_set_JPa(self.h, int(calc_J), int(calc_P), int(calc_Pnew), nbins, _p(ind), cross0))
+        self.nbins = nbins; self.jpa = (int(calc_J), int(calc_P), int(calc_Pnew))
+
+    def set_grid_amr(self, lo, hi, cx, cy, cz, ch, children, neighbor, ileaf, icell_of_leaf,
+                     rhokap, voigt_a, Dfreq, vfx, vfy, vfz, rhokapD=None):
+        """octree tables as amr_grid_type holds them (children (8,ncells), neighbor (6,ncells), 1-based, 0 = none)"""
+        ncells, nleaf = int(np.asarray(ileaf).size), int(np.asarray(icell_of_leaf).size)
+        geo = [_f64(a) for a in (cx, cy, cz, ch)]
+        ch8 = np.ascontiguousarray(np.asarray(children, dtype=np.int32).ravel(order="F"))
+        nb6 = np.ascontiguousarray(np.asarray(neighbor, dtype=np.int32).ravel(order="F"))
+        il = np.ascontiguousarray(ileaf, dtype=np.int32); icl = np.ascontiguousarray(icell_of_leaf, dtype=np.int32)
+        med = [_f64(a) for a in (rhokap, voigt_a, Dfreq, vfx, vfy, vfz, rhokapD)]
+        if any(a.size != ncells for a in geo) or ch8.size != 8 * ncells or nb6.size != 6 * ncells:
+            raise ValueError("tree tables must have ncells (x8 children, x6 neighbor) entries")
+        if any(a is not None and a.size != nleaf for a in med):
+            raise ValueError("medium tables must have nleaf entries")
+        _chk(lib().lart_gpu_set_grid_amr(self.h, ncells, nleaf, lo, hi, *[_p(a) for a in geo], _p(ch8), _p(nb6), _p(il), _p(icl),
+                                         *[_p(a) for a in med]))
+
+    def set_JPa_amr(self, calc_J, calc_P, calc_Pnew, geometry_JPa, nbins, dbin, cross0):
+        _chk(lib().lart_gpu_set_JPa_amr(self.h, int(calc_J), int(calc_P), int(calc_Pnew), int(geometry_JPa), int(nbins), float(dbin), cross0))
         self.nbins = nbins; self.jpa = (int(calc_J), int(calc_P), int(calc_Pnew))
 
     def set_pool(self, nlanes=0, block=0):

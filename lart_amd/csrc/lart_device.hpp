@@ -32,6 +32,18 @@ struct DGrid {
     const double *faces;          // xface(nx+1) | yface(ny+1) | zface(nz+1), global copy (staged to LDS)
 };
 
+// octree (amr_grid_type, octree_mod.f90:19-138): flat arrays with the reference's 1-based numbering; leaf tables are the
+// Cell records of DGrid indexed by the leaf number (photon ic = leaf index, jc = kc = 1)
+struct __attribute__((aligned(32))) AmrGeom { double cx, cy, cz, ch; };
+struct DAmr {
+    int ncells, nleaf;
+    const int *children, *neighbor, *ileaf, *icell_of_leaf;    // children(8,ncells), neighbor(6,ncells)
+    const AmrGeom *geom;                                       // per cell
+    double lo, hi;                                             // cubic box [lo,hi]^3
+    int jpa_geometry; double dr_JPa, dz_JPa;                   // position-binned profile tallies (amr_JPa_bin)
+    int nr_JPa, nz_JPa;
+};
+
 struct DObs { double x, y, z, rm[9]; };
 
 struct DMueller { int nPDF; const double *coss, *S11, *S12, *S33, *S34, *phase_PDF; const int *alias; };
@@ -70,6 +82,7 @@ struct KArgs {
     const DObs *obs; int nobs, nxim, nyim; double dxim, dyim;
     int heal_nside;               // > 0: HEALPix inside observers (nxim = npix, nyim = 1)
     DJPa jpa;
+    DAmr amr;
     DCtl *ctl;
     long long first_id, stride, count;
     unsigned long long seed;
@@ -364,9 +377,110 @@ __device__ inline bool trav_cross(const DGrid &g, Trav &t, int idx) {
 }
 __device__ inline int minloc3(double a, double b, double c) { int m = 1; double v = a; if (b < v) { m = 2; v = b; } if (c < v) m = 3; return m; }
 
+
+// ---------------------------------------------------------------------------------------------
+// octree marches (VAR 3): octree_mod.f90 + raytrace_amr.f90
+// ---------------------------------------------------------------------------------------------
+__device__ inline int amr_find_leaf(const DAmr &a, double x, double y, double z) {          // octree_mod.f90:149-171
+    if (x < a.lo || x > a.hi || y < a.lo || y > a.hi || z < a.lo || z > a.hi) return 0;
+    int ic = 1;
+    for (;;) {
+        int il = a.ileaf[ic - 1];
+        if (il > 0) return il;
+        const AmrGeom &q = a.geom[ic - 1];
+        int io = (x >= q.cx ? 1 : 0) + (y >= q.cy ? 2 : 0) + (z >= q.cz ? 4 : 0);
+        ic = a.children[io + 8 * (size_t)(ic - 1)];
+        if (ic == 0) return 0;
+    }
+}
+// distance to the exit face of cell q (iface 1=+x 2=-x 3=+y 4=-y 5=+z 6=-z, first minimum): :412-451
+__device__ inline double amr_cell_exit(const AmrGeom &q, double x, double y, double z, double kx, double ky, double kz, int &iface) {
+    double tx = LART_HUGEST, ty = LART_HUGEST, tz = LART_HUGEST; int fx = 1, fy = 3, fz = 5;
+    if (kx > 0.0) tx = (q.cx + q.ch - x) / kx; else if (kx < 0.0) { tx = (q.cx - q.ch - x) / kx; fx = 2; }
+    if (ky > 0.0) ty = (q.cy + q.ch - y) / ky; else if (ky < 0.0) { ty = (q.cy - q.ch - y) / ky; fy = 4; }
+    if (kz > 0.0) tz = (q.cz + q.ch - z) / kz; else if (kz < 0.0) { tz = (q.cz - q.ch - z) / kz; fz = 6; }
+    // minloc over t(1..6) with the unused direction of each axis = hugest: ties resolve to the lower face index
+    double t = tx; iface = fx;
+    if (ty < t || (ty == t && fy < iface)) { t = ty; iface = fy; }
+    if (tz < t || (tz == t && fz < iface)) { t = tz; iface = fz; }
+    return t;
+}
+// leaf entered through face `iface` of cell ic: neighbour table + descent, normal bit from iface: :718-758
+__device__ inline int amr_next_leaf(const DAmr &a, int ic, int iface, double x, double y, double z) {
+    int ng = a.neighbor[(iface - 1) + 6 * (size_t)(ic - 1)];
+    if (ng == 0) return 0;
+    int il;
+    while ((il = a.ileaf[ng - 1]) == 0) {
+        const AmrGeom &q = a.geom[ng - 1];
+        int bx = x >= q.cx ? 1 : 0, by = y >= q.cy ? 2 : 0, bz = z >= q.cz ? 4 : 0;
+        if (iface == 1) bx = 0; else if (iface == 2) bx = 1; else if (iface == 3) by = 0; else if (iface == 4) by = 2; else if (iface == 5) bz = 0; else bz = 4;
+        int ch = a.children[(bx + by + bz) + 8 * (size_t)(ng - 1)];
+        if (ch == 0) break;
+        ng = ch;
+    }
+    return a.ileaf[ng - 1];
+}
+// mirror planes of the +++ octant (raytrace_amr.f90:176-201); returns the leaf to continue in, 0 = escape
+__device__ inline int amr_boundary(const lart_params &par, int il, int iface, double &kx, double &ky, double &kz, bool &reflected) {
+    if (par.xyz_symmetry) {
+        if (iface == 2) { kx = -kx; reflected = true; return il; }
+        if (iface == 4) { ky = -ky; reflected = true; return il; }
+        if (iface == 6) { kz = -kz; reflected = true; return il; }
+    }
+    return 0;
+}
+// amr_JPa_bin: octree_mod.f90:286-311 (3 = the leaf itself)
+__device__ inline int amr_JPa_bin(const DAmr &a, int il, double x0, double y0, double z0) {
+    if (a.jpa_geometry == 3) return il;
+    if (a.jpa_geometry == 1) { int ib = (int)floor(sqrt(x0 * x0 + y0 * y0 + z0 * z0) / a.dr_JPa) + 1; return (ib >= 1 && ib <= a.nr_JPa) ? ib : 0; }
+    int ib = (int)floor((z0 - a.lo) / a.dz_JPa) + 1;
+    return clampi(ib, 1, a.nz_JPa);
+}
+// add_to_J_amr / add_to_Pnew_amr: raytrace_amr.f90:848-912 (bin of the segment midpoint)
+__device__ inline void jpa_segment_amr(const KArgs &A, const Photon &p, int il, const Cell &c, double x0, double y0, double z0, double del, double dtauH) {
+    if (!(c.rhokap > 0.0)) return;
+    int ib = amr_JPa_bin(A.amr, il, x0, y0, z0);
+    if (ib < 1) return;
+    if (A.jpa.calc_J) {
+        double xr = p.xfreq * (c.Dfreq / A.par.Dfreq_ref);
+        int ix = (int)floor((xr - A.par.xfreq_min) / A.par.dxfreq) + 1;
+        if (ix >= 1 && ix <= A.par.nxfreq) atomicAdd(&A.jpa.J1[(size_t)(ix - 1) + (size_t)A.par.nxfreq * (ib - 1)], del * p.wgt);
+    }
+    if (A.jpa.calc_Pnew) atomicAdd(&A.jpa.P1_new[ib - 1], dtauH * p.wgt / (c.rhokap * c.Dfreq / A.jpa.cross0));
+}
+// raytrace_to_edge_amr (:265-344) / raytrace_to_dist_amr (:559-640)
+__device__ inline double raytrace_to_edge_amr(const KArgs &A, const Lds &l, bool dust, const Photon &p, double xfreq, double kx, double ky, double kz, double dist, unsigned &nsteps) {
+    const DAmr &a = A.amr;
+    double x = p.x, y = p.y, z = p.z, tau = 0.0, d = 0.0;
+    int il = p.ic;
+    if (il <= 0) { il = amr_find_leaf(a, x, y, z); if (il <= 0) return tau; }
+    const Cell *c = &A.g.cell[il - 1];
+    double u1 = c->vfx * kx + c->vfy * ky + c->vfz * kz;
+    for (;;) {
+        int ic = a.icell_of_leaf[il - 1], iface;
+        double t_exit = amr_cell_exit(a.geom[ic - 1], x, y, z, kx, ky, kz, iface);
+        double rhokap = c->rhokap * voigt_H(l.vt, xfreq, c->voigt_a);
+        if (dust) rhokap = rhokap + c->rhokapD;
+        nsteps++;
+        if (dist >= 0.0 && d + t_exit >= dist) return tau + (dist - d) * rhokap;
+        tau = tau + t_exit * rhokap;
+        if (tau >= LART_TAU_HUGE) return tau;
+        d = d + t_exit; x = x + t_exit * kx; y = y + t_exit * ky; z = z + t_exit * kz;
+        int il_new = amr_next_leaf(a, ic, iface, x, y, z); bool reflected = false;
+        if (il_new <= 0) il_new = amr_boundary(A.par, il, iface, kx, ky, kz, reflected);
+        if (il_new <= 0) return tau;
+        const Cell *cn = &A.g.cell[il_new - 1];
+        double u2 = cn->vfx * kx + cn->vfy * ky + cn->vfz * kz;
+        xfreq = reflected ? (xfreq + u1) - u2 : (xfreq + u1) * c->Dfreq / cn->Dfreq - u2;
+        u1 = u2; il = il_new; c = cn;
+    }
+}
+
 // tau to the grid edge (dist < 0) or to a finite distance (raytrace_to_dist_car :89-195, VAR 0 only)
 template <int VAR>
-__device__ inline double raytrace_to_edge(const DGrid &g, const Lds &l, bool dust, const Photon &p, double xfreq, double kx, double ky, double kz, double dist, unsigned &nsteps) {
+__device__ inline double raytrace_to_edge(const KArgs &A, const Lds &l, bool dust, const Photon &p, double xfreq, double kx, double ky, double kz, double dist, unsigned &nsteps) {
+    if (VAR == 3) return raytrace_to_edge_amr(A, l, dust, p, xfreq, kx, ky, kz, dist, nsteps);
+    const DGrid &g = A.g;
     Trav t; t.kx = kx; t.ky = ky; t.kz = kz; t.ic = p.ic; t.jc = p.jc; t.kc = p.kc;
     double tau = 0.0, d = 0.0;
     if (trav_setup<VAR>(g, l, p.x, p.y, p.z, false, t)) return tau;
@@ -417,9 +531,50 @@ __device__ inline void jpa_segment(const KArgs &A, const Photon &p, size_t ci, d
     if (A.jpa.calc_Pnew) atomicAdd(&A.jpa.P1_new[ib - 1], dtauH * p.wgt / (rhokap_cell * Dfreq_cell / A.jpa.cross0));
 }
 
+
+// raytrace_to_tau_amr: raytrace_amr.f90:77-259
+__device__ inline void raytrace_to_tau_amr(const KArgs &A, const Lds &l, bool dust, Photon &p, double tau_in, unsigned &nsteps) {
+    const DAmr &a = A.amr;
+    double x = p.x, y = p.y, z = p.z, kx = p.kx, ky = p.ky, kz = p.kz, tau = 0.0;
+    int il = p.ic;
+    if (il <= 0) { il = amr_find_leaf(a, x, y, z); if (il <= 0) { p.inside = false; return; } }
+    const Cell *c = &A.g.cell[il - 1];
+    double u1 = c->vfx * kx + c->vfy * ky + c->vfz * kz;
+    for (;;) {
+        int ic = a.icell_of_leaf[il - 1], iface;
+        double t_exit = amr_cell_exit(a.geom[ic - 1], x, y, z, kx, ky, kz, iface);
+        double rhokapH = c->rhokap * voigt_H(l.vt, p.xfreq, c->voigt_a), rhokap = rhokapH;
+        if (dust) rhokap = rhokap + c->rhokapD;
+        nsteps++;
+        if (tau + t_exit * rhokap >= tau_in) {
+            double d_step = (rhokap > 0.0) ? (tau_in - tau) / rhokap : t_exit;
+            if (A.jpa.nbins) jpa_segment_amr(A, p, il, *c, x + 0.5 * d_step * kx, y + 0.5 * d_step * ky, z + 0.5 * d_step * kz, d_step, d_step * rhokapH);
+            x = x + d_step * kx; y = y + d_step * ky; z = z + d_step * kz;
+            break;
+        }
+        tau = tau + t_exit * rhokap; x = x + t_exit * kx; y = y + t_exit * ky; z = z + t_exit * kz;
+        if (A.jpa.nbins) jpa_segment_amr(A, p, il, *c, x - 0.5 * t_exit * kx, y - 0.5 * t_exit * ky, z - 0.5 * t_exit * kz, t_exit, t_exit * rhokapH);
+        int il_new = amr_next_leaf(a, ic, iface, x, y, z); bool reflected = false;
+        if (il_new <= 0) il_new = amr_boundary(A.par, il, iface, kx, ky, kz, reflected);
+        if (il_new <= 0) { p.inside = false; break; }
+        const Cell *cn = &A.g.cell[il_new - 1];
+        double u2 = cn->vfx * kx + cn->vfy * ky + cn->vfz * kz;
+        p.xfreq = reflected ? (p.xfreq + u1) - u2 : (p.xfreq + u1) * c->Dfreq / cn->Dfreq - u2;
+        u1 = u2; il = il_new; c = cn;
+    }
+    p.x = x; p.y = y; p.z = z; p.kx = kx; p.ky = ky; p.kz = kz; p.ic = il; p.jc = 1; p.kc = 1;
+    if (!p.inside) {
+        u1 = c->vfx * kx + c->vfy * ky + c->vfz * kz;
+        p.xfreq = p.xfreq + u1;
+        p.xfreq_ref = p.xfreq * (c->Dfreq / A.par.Dfreq_ref);
+        tally_escape(A.par, A.t, p);
+    }
+}
+
 // march to optical depth tau_in; moves the packet, re-expresses xfreq at every crossing, tallies escape
 template <int VAR>
 __device__ inline void raytrace_to_tau(const KArgs &A, const Lds &l, bool dust, Photon &p, double tau_in, unsigned &nsteps) {
+    if (VAR == 3) { raytrace_to_tau_amr(A, l, dust, p, tau_in, nsteps); return; }
     const DGrid &g = A.g;
     Trav t; t.kx = p.kx; t.ky = p.ky; t.kz = p.kz; t.ic = p.ic; t.jc = p.jc; t.kc = p.kc;
     double xp = p.x, yp = p.y, zp = p.z;
@@ -475,6 +630,18 @@ __device__ inline void raytrace_to_tau(const KArgs &A, const Lds &l, bool dust, 
 }
 
 // cell-by-cell core-skip threshold (Smith+15 eq. 35): grid_mod_car.f90:1598-1629
+// amr_xcrit_local: octree_mod.f90:248-278
+__device__ inline void xcrit_local_amr(const KArgs &A, const Photon &p, double &xc, double &xc2) {
+    if (A.par.core_skip_global) { xc = A.par.xcrit; xc2 = A.par.xcrit2; return; }
+    xc = 0.0; xc2 = 0.0;
+    if (p.ic <= 0) return;
+    const AmrGeom &q = A.amr.geom[A.amr.icell_of_leaf[p.ic - 1] - 1];
+    double dl = fmin(q.ch - fabs(p.x - q.cx), fmin(q.ch - fabs(p.y - q.cy), q.ch - fabs(p.z - q.cz)));
+    if (dl <= 0.0) return;
+    const Cell &c = A.g.cell[p.ic - 1];
+    double atau = c.voigt_a * c.rhokap * dl;
+    if (atau > 1.0) { xc = cbrt(atau) / 5.0; xc2 = xc * xc; }
+}
 __device__ inline void xcrit_local(const lart_params &par, const DGrid &g, const Lds &l, const Photon &p, double &xc, double &xc2) {
     if (par.core_skip_global) { xc = par.xcrit; xc2 = par.xcrit2; return; }
     xc = 0.0; xc2 = 0.0;
@@ -553,7 +720,7 @@ __device__ inline void peel_direct(const KArgs &A, const Lds &l, bool dust, cons
         xfreq_ref = xfreq_ref * (c.Dfreq / A.par.Dfreq_ref);
         int ixf = (int)floor((xfreq_ref - A.par.xfreq_min) / A.par.dxfreq) + 1;
         if (!q.in_image) continue;
-        double tau = raytrace_to_edge<VAR>(A.g, l, dust, p, xf, q.kx, q.ky, q.kz, q.dist, nsteps);
+        double tau = raytrace_to_edge<VAR>(A, l, dust, p, xf, q.kx, q.ky, q.kz, q.dist, nsteps);
         double wgt = exp(-tau) * (1.0 / (LART_FOURPI * q.r2) * p.wgt);
         if (A.par.save_peeloff_2D) { add_if(A.t.c2[1], pix2(A, i, q.ix, q.iy), wgt); if (A.par.use_stokes) add_if(A.t.c2[2], pix2(A, i, q.ix, q.iy), wgt); }
         if (A.par.save_peeloff_3D && ixf >= 1 && ixf <= A.par.nxfreq) { add_if(A.t.c3[1], pix3(A, i, ixf, q.ix, q.iy), wgt); if (A.par.use_stokes) add_if(A.t.c3[2], pix3(A, i, ixf, q.ix, q.iy), wgt); }
@@ -574,7 +741,7 @@ __device__ inline void peel_resonance_nostokes(const KArgs &A, const Lds &l, boo
         double u1 = c.vfx * q.kx + c.vfy * q.ky + c.vfz * q.kz;
         double xfreq_ref = (xfreq + u1) * (c.Dfreq / A.par.Dfreq_ref);
         int ixf = (int)floor((xfreq_ref - A.par.xfreq_min) / A.par.dxfreq) + 1;
-        double tau = raytrace_to_edge<VAR>(A.g, l, dust, p, xfreq, q.kx, q.ky, q.kz, q.dist, nsteps);
+        double tau = raytrace_to_edge<VAR>(A, l, dust, p, xfreq, q.kx, q.ky, q.kz, q.dist, nsteps);
         double peel = 0.75 * A.par.E1 * (cost2 + 1.0) + A.par.E2;
         double wgt = peel / (LART_FOURPI * q.r2) * exp(-tau) * p.wgt;
         if (A.par.save_peeloff_2D) add_if(A.t.c2[0], pix2(A, i, q.ix, q.iy), wgt);
@@ -620,7 +787,7 @@ __device__ inline void peel_resonance_stokes(const KArgs &A, const Lds &l, bool 
         double cosg = -(o.rm[0] * s.nx + o.rm[1] * s.ny + o.rm[2] * s.nz), sing = o.rm[3] * s.nx + o.rm[4] * s.ny + o.rm[5] * s.nz;
         double cos2g = 2.0 * cosg * cosg - 1.0, sin2g = 2.0 * cosg * sing;
         double Qdet = cos2g * Qobs + sin2g * Uobs, Udet = -sin2g * Qobs + cos2g * Uobs;
-        double tau = raytrace_to_edge<VAR>(A.g, l, dust, p, xfreq, q.kx, q.ky, q.kz, q.dist, nsteps);
+        double tau = raytrace_to_edge<VAR>(A, l, dust, p, xfreq, q.kx, q.ky, q.kz, q.dist, nsteps);
         double wgt = 1.0 / q.r2 * exp(-tau) * p.wgt;
         stokes_deposit(A, i, q, ixf, wgt, Iobs, Qdet, Udet, Vobs);
     }
@@ -635,7 +802,7 @@ __device__ inline void peel_dust_nostokes(const KArgs &A, const Lds &l, const Ph
         double u1 = c.vfx * q.kx + c.vfy * q.ky + c.vfz * q.kz;
         double xfreq_ref = (p.xfreq + u1) * (c.Dfreq / A.par.Dfreq_ref);
         int ixf = (int)floor((xfreq_ref - A.par.xfreq_min) / A.par.dxfreq) + 1;
-        double tau = raytrace_to_edge<VAR>(A.g, l, true, p, p.xfreq, q.kx, q.ky, q.kz, q.dist, nsteps);
+        double tau = raytrace_to_edge<VAR>(A, l, true, p, p.xfreq, q.kx, q.ky, q.kz, q.dist, nsteps);
         double cosa = p.kx * q.kx + p.ky * q.ky + p.kz * q.kz, hgg = A.par.hgg;
         double b = (1.0 + hgg * hgg) - 2.0 * hgg * cosa;
         double peel = (1.0 - hgg * hgg) / (b * sqrt(b)) / LART_FOURPI;
@@ -665,7 +832,7 @@ __device__ inline void peel_dust_stokes(const KArgs &A, const Lds &l, const Phot
         double cosg = -(o.rm[0] * s.nx + o.rm[1] * s.ny + o.rm[2] * s.nz), sing = o.rm[3] * s.nx + o.rm[4] * s.ny + o.rm[5] * s.nz;
         double cos2g = 2.0 * cosg * cosg - 1.0, sin2g = 2.0 * cosg * sing;
         double Qdet = cos2g * Qobs + sin2g * Uobs, Udet = -sin2g * Qobs + cos2g * Uobs;
-        double tau = raytrace_to_edge<VAR>(A.g, l, true, p, p.xfreq, q.kx, q.ky, q.kz, q.dist, nsteps);
+        double tau = raytrace_to_edge<VAR>(A, l, true, p, p.xfreq, q.kx, q.ky, q.kz, q.dist, nsteps);
         double wgt = 1.0 / q.r2 * exp(-tau) * p.wgt;
         stokes_deposit(A, i, q, ixf, wgt, Iobs, Qdet, Udet, Vobs);
     }
@@ -755,7 +922,7 @@ __device__ inline void scatter_event(const KArgs &A, const Lds &l, Rng &g, Photo
     // resonance scattering: scatter_resonance_nostokes :660-827 / _stokes :331-486
     p.nsg = p.nsg + p.wgt;
     if (A.jpa.calc_P && c.rhokap > 0.0) {                      // add_to_Pa: scattering_car.f90:830-859
-        int ib = A.jpa.ind_bin[cidx(A.g, p.ic, p.jc, p.kc)];
+        int ib = (VAR == 3) ? amr_JPa_bin(A.amr, p.ic, p.x, p.y, p.z) : A.jpa.ind_bin[cidx(A.g, p.ic, p.jc, p.kc)];   // add_to_Pa_amr: scattering_amr.f90:917-942
         if (ib >= 1) atomicAdd(&A.jpa.P1[ib - 1], p.wgt / (c.rhokap * c.Dfreq / A.jpa.cross0));
     }
     // do_resonance1: line_mod.f90:108-139
@@ -770,7 +937,7 @@ __device__ inline void scatter_event(const KArgs &A, const Lds &l, Rng &g, Photo
     double sinp, cosp; sincos(phi, &sinp, &cosp);
     // perpendicular atom velocity; truncated tail when core-skipping (:726-752, :400-430)
     double ux, uy, xc = 0.0, xc2 = 0.0;
-    if (par.core_skip) xcrit_local(par, A.g, l, p, xc, xc2);
+    if (par.core_skip) { if (VAR == 3) xcrit_local_amr(A, p, xc, xc2); else xcrit_local(par, A.g, l, p, xc, xc2); }
     if (par.core_skip && fabs(p.xfreq) < xc) {
         double phi2 = LART_TWOPI * g.next(), uxy = sqrt(xc2 - log(g.next())), s2, c2; sincos(phi2, &s2, &c2);
         ux = uxy * c2; uy = uxy * s2;
@@ -812,6 +979,8 @@ __device__ inline void generate_photon(const KArgs &A, const Lds &l, Rng &g, Pho
     double cost = 2.0 * g.next() - 1.0, sint = sqrt(1.0 - cost * cost), phi = LART_TWOPI * g.next(), sinp, cosp;
     sincos(phi, &sinp, &cosp);
     p.kx = sint * cosp; p.ky = sint * sinp; p.kz = cost;
+    if (VAR == 3) { p.ic = amr_find_leaf(A.amr, p.x, p.y, p.z); p.jc = 1; p.kc = 1; if (p.ic <= 0) p.ic = 1; }   // generate_photon.f90:375-379 (source inside the box)
+    else {
     p.ic = (int)floor((p.x - gr.xmin) / gr.dx) + 1; p.jc = (int)floor((p.y - gr.ymin) / gr.dy) + 1; p.kc = (int)floor((p.z - gr.zmin) / gr.dz) + 1;
     if (p.kx < 0.0 && p.ic == gr.nx + 1) p.ic = gr.nx;
     if (p.ky < 0.0 && p.jc == gr.ny + 1) p.jc = gr.ny;
@@ -819,10 +988,11 @@ __device__ inline void generate_photon(const KArgs &A, const Lds &l, Rng &g, Pho
     if (p.kx > 0.0 && p.ic < 1) p.ic = 1;
     if (p.ky > 0.0 && p.jc < 1) p.jc = 1;
     if (p.kz > 0.0 && p.kc < 1) p.kc = 1;
+    }
     if (STOKES) { p.mx = cost * cosp; p.my = cost * sinp; p.mz = -sint; p.nx = -sinp; p.ny = cosp; p.nz = 0.0; p.Q = 0.0; p.U = 0.0; p.V = 0.0; }
     p.nsg = 0.0; p.nsd = 0.0; p.inside = true; p.xfreq = par.xfreq0;
     // a source outside the medium box never reaches a table in the reference's configs; clamp the gather
-    const Cell &c = gr.cell[cidx(gr, clampi(p.ic, 1, gr.nx), clampi(p.jc, 1, gr.ny), clampi(p.kc, 1, gr.nz))];
+    const Cell &c = (VAR == 3) ? gr.cell[p.ic - 1] : gr.cell[cidx(gr, clampi(p.ic, 1, gr.nx), clampi(p.jc, 1, gr.ny), clampi(p.kc, 1, gr.nz))];
     if (par.spectral_type == 1) p.xfreq = p.xfreq + rand_voigt(g, c.voigt_a);
     double u1 = c.vfx * p.kx + c.vfy * p.ky + c.vfz * p.kz;
     if (!par.comoving_source) p.xfreq = p.xfreq - u1;

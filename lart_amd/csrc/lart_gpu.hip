@@ -10,6 +10,7 @@
 extern "C" void lart_launch_transport_var0(int, int, int, dim3, dim3, size_t, hipStream_t, const KArgs &);
 extern "C" void lart_launch_transport_var1(int, int, int, dim3, dim3, size_t, hipStream_t, const KArgs &);
 extern "C" void lart_launch_transport_var2(int, int, int, dim3, dim3, size_t, hipStream_t, const KArgs &);
+extern "C" void lart_launch_transport_var3(int, int, int, dim3, dim3, size_t, hipStream_t, const KArgs &);
 
 static thread_local std::string g_err;
 static int fail(const std::string &m) { g_err = m; return 1; }
@@ -27,6 +28,8 @@ struct lart_gpu {
     DObs *d_obs = nullptr; int nobs = 0, nxim = 0, nyim = 0; double dxim = 0, dyim = 0; int heal_nside = 0;
     // J/P profile tallies
     DJPa jpa{}; int *d_ind_bin = nullptr;
+    // octree (VAR 3)
+    bool is_amr = false; DAmr amr{}; int *d_amr_int = nullptr; AmrGeom *d_amr_geom = nullptr;
     // fused tally buffer
     double *d_tally = nullptr; int64_t ntally = 0; DTally t{};
     // pool
@@ -64,7 +67,7 @@ extern "C" int lart_gpu_destroy(lart_gpu *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (auto &e : c->ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-    (void)hipFree(c->d_cell); (void)hipFree(c->d_faces); (void)hipFree(c->d_mu); (void)hipFree(c->d_alias); (void)hipFree(c->d_obs); (void)hipFree(c->d_ind_bin);
+    (void)hipFree(c->d_cell); (void)hipFree(c->d_faces); (void)hipFree(c->d_mu); (void)hipFree(c->d_alias); (void)hipFree(c->d_obs); (void)hipFree(c->d_ind_bin); (void)hipFree(c->d_amr_int); (void)hipFree(c->d_amr_geom);
     free_tally(c); (void)hipFree(c->d_pool); (void)hipFree(c->d_ctl); (void)hipFree(c->d_log);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -128,6 +131,7 @@ extern "C" int lart_gpu_set_grid_car(lart_gpu *c, int32_t nx, int32_t ny, int32_
     c->g.nx = nx; c->g.ny = ny; c->g.nz = nz; c->g.i0 = i0; c->g.j0 = j0; c->g.k0 = k0;
     c->g.xmin = xmin; c->g.ymin = ymin; c->g.zmin = zmin; c->g.dx = dx; c->g.dy = dy; c->g.dz = dz;
     c->g.cell = c->d_cell; c->g.faces = c->d_faces; c->ncell = nc; c->has_dust_table = rhokapD != nullptr;
+    c->is_amr = false; c->jpa.nbins = 0; free_tally(c);
     return 0;
 }
 
@@ -185,7 +189,7 @@ extern "C" int lart_gpu_set_observers_heal(lart_gpu *c, int32_t nobs, const doub
 
 extern "C" int lart_gpu_set_JPa(lart_gpu *c, int32_t calc_J, int32_t calc_P, int32_t calc_Pnew, int32_t nbins, const int32_t *ind_bin, double cross0) {
     if (!c) return fail("set_JPa: null context");
-    if (!c->d_cell) return fail("set_JPa: set the medium first (lart_gpu_set_grid_car)");
+    if (!c->d_cell || c->is_amr) return fail("set_JPa: set the Cartesian medium first (lart_gpu_set_grid_car); the octree uses lart_gpu_set_JPa_amr");
     if (nbins < 1 || !ind_bin || !(cross0 > 0.0)) return fail("set_JPa: bad arguments");
     for (size_t i = 0; i < c->ncell; i++) if (ind_bin[i] < 0 || ind_bin[i] > nbins) return fail("set_JPa: ind_bin entries must be 0..nbins");
     HIPCHK(hipSetDevice(c->device));
@@ -194,6 +198,80 @@ extern "C" int lart_gpu_set_JPa(lart_gpu *c, int32_t calc_J, int32_t calc_P, int
     HIPCHK(hipMemcpy(c->d_ind_bin, ind_bin, c->ncell * sizeof(int), hipMemcpyHostToDevice));
     c->jpa.calc_J = calc_J ? 1 : 0; c->jpa.calc_P = calc_P ? 1 : 0; c->jpa.calc_Pnew = calc_Pnew ? 1 : 0;
     c->jpa.nbins = (calc_J || calc_P || calc_Pnew) ? nbins : 0; c->jpa.ind_bin = c->d_ind_bin; c->jpa.cross0 = cross0;
+    free_tally(c);
+    return 0;
+}
+
+extern "C" int lart_gpu_set_grid_amr(lart_gpu *c, int32_t ncells, int32_t nleaf, double lo, double hi,
+                                     const double *cx, const double *cy, const double *cz, const double *ch,
+                                     const int32_t *children, const int32_t *neighbor, const int32_t *ileaf, const int32_t *icell_of_leaf,
+                                     const double *rhokap, const double *voigt_a, const double *Dfreq,
+                                     const double *vfx, const double *vfy, const double *vfz, const double *rhokapD) {
+    if (!c) return fail("set_grid_amr: null context");
+    if (ncells < 1 || nleaf < 1 || nleaf > ncells || !(hi > lo)) return fail("set_grid_amr: need 1 <= nleaf <= ncells and hi > lo");
+    if (!cx || !cy || !cz || !ch || !children || !neighbor || !ileaf || !icell_of_leaf) return fail("set_grid_amr: null tree table");
+    if (!rhokap || !voigt_a || !Dfreq || !vfx || !vfy || !vfz) return fail("set_grid_amr: null medium table");
+    if (c->par.DGR > 0.0 && !rhokapD) return fail("set_grid_amr: DGR > 0 needs rhokapD");
+    if (c->par.xy_periodic) return fail("set_grid_amr: xy_periodic is not defined for the octree path");
+    // every index the kernels follow is checked here, so a bad table cannot send a wave out of bounds
+    for (size_t i = 0; i < (size_t)8 * ncells; i++) if (children[i] < 0 || children[i] > ncells) return fail("set_grid_amr: children entries must be 0..ncells");
+    for (size_t i = 0; i < (size_t)6 * ncells; i++) if (neighbor[i] < 0 || neighbor[i] > ncells) return fail("set_grid_amr: neighbor entries must be 0..ncells");
+    for (int i = 0; i < ncells; i++) {
+        if (ileaf[i] < 0 || ileaf[i] > nleaf) return fail("set_grid_amr: ileaf entries must be 0..nleaf");
+        if (!(ch[i] > 0.0)) return fail("set_grid_amr: cell half-widths must be > 0");
+        if (ileaf[i] == 0) { bool any = false; for (int o = 0; o < 8; o++) any = any || children[8 * (size_t)i + o] > 0; if (!any) return fail("set_grid_amr: an internal cell has no children"); }
+        else if (icell_of_leaf[ileaf[i] - 1] != i + 1) return fail("set_grid_amr: ileaf / icell_of_leaf are not inverse of each other");
+        for (int o = 0; o < 8; o++) { int k = children[8 * (size_t)i + o]; if (k != 0 && k <= i + 1) return fail("set_grid_amr: children must have larger cell numbers than their parent (amr_build_tree order)"); }
+    }
+    for (int i = 0; i < nleaf; i++) {
+        if (icell_of_leaf[i] < 1 || icell_of_leaf[i] > ncells) return fail("set_grid_amr: icell_of_leaf entries must be 1..ncells");
+        if (!(Dfreq[i] > 0.0)) return fail("set_grid_amr: Dfreq must be > 0 in every leaf");
+    }
+    HIPCHK(hipSetDevice(c->device));
+    std::vector<Cell> h(nleaf);
+    for (int i = 0; i < nleaf; i++) {
+        h[i].rhokap = rhokap[i]; h[i].voigt_a = voigt_a[i]; h[i].Dfreq = Dfreq[i];
+        h[i].vfx = vfx[i]; h[i].vfy = vfy[i]; h[i].vfz = vfz[i]; h[i].rhokapD = rhokapD ? rhokapD[i] : 0.0; h[i].pad = 0.0;
+    }
+    (void)hipFree(c->d_cell); (void)hipFree(c->d_faces); (void)hipFree(c->d_amr_int); (void)hipFree(c->d_amr_geom);
+    c->d_cell = nullptr; c->d_faces = nullptr; c->d_amr_int = nullptr; c->d_amr_geom = nullptr;
+    HIPCHK(hipMalloc(&c->d_cell, (size_t)nleaf * sizeof(Cell)));
+    HIPCHK(hipMemcpy(c->d_cell, h.data(), (size_t)nleaf * sizeof(Cell), hipMemcpyHostToDevice));
+    double f[6] = {lo, hi, lo, hi, lo, hi};
+    HIPCHK(hipMalloc(&c->d_faces, sizeof f)); HIPCHK(hipMemcpy(c->d_faces, f, sizeof f, hipMemcpyHostToDevice));
+    std::vector<AmrGeom> gq(ncells);
+    for (int i = 0; i < ncells; i++) { gq[i].cx = cx[i]; gq[i].cy = cy[i]; gq[i].cz = cz[i]; gq[i].ch = ch[i]; }
+    HIPCHK(hipMalloc(&c->d_amr_geom, (size_t)ncells * sizeof(AmrGeom)));
+    HIPCHK(hipMemcpy(c->d_amr_geom, gq.data(), (size_t)ncells * sizeof(AmrGeom), hipMemcpyHostToDevice));
+    size_t ni = (size_t)15 * ncells + nleaf;
+    HIPCHK(hipMalloc(&c->d_amr_int, ni * sizeof(int)));
+    int *d = c->d_amr_int;
+    HIPCHK(hipMemcpy(d, children, (size_t)8 * ncells * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d + (size_t)8 * ncells, neighbor, (size_t)6 * ncells * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d + (size_t)14 * ncells, ileaf, (size_t)ncells * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d + (size_t)15 * ncells, icell_of_leaf, (size_t)nleaf * 4, hipMemcpyHostToDevice));
+    c->amr = DAmr{};
+    c->amr.ncells = ncells; c->amr.nleaf = nleaf; c->amr.children = d; c->amr.neighbor = d + (size_t)8 * ncells;
+    c->amr.ileaf = d + (size_t)14 * ncells; c->amr.icell_of_leaf = d + (size_t)15 * ncells; c->amr.geom = c->d_amr_geom;
+    c->amr.lo = lo; c->amr.hi = hi;
+    // leaf records are addressed as cell (il,1,1) of a 1x1x1 "grid": cidx() = il-1
+    c->g = DGrid{}; c->g.nx = 1; c->g.ny = 1; c->g.nz = 1; c->g.i0 = 1; c->g.j0 = 1; c->g.k0 = 1;
+    c->g.xmin = lo; c->g.ymin = lo; c->g.zmin = lo; c->g.dx = hi - lo; c->g.dy = hi - lo; c->g.dz = hi - lo;
+    c->g.cell = c->d_cell; c->g.faces = c->d_faces; c->ncell = nleaf; c->has_dust_table = rhokapD != nullptr;
+    c->is_amr = true; c->jpa.nbins = 0; free_tally(c);
+    return 0;
+}
+
+extern "C" int lart_gpu_set_JPa_amr(lart_gpu *c, int32_t calc_J, int32_t calc_P, int32_t calc_Pnew, int32_t geometry_JPa, int32_t nbins, double dbin, double cross0) {
+    if (!c) return fail("set_JPa_amr: null context");
+    if (!c->is_amr) return fail("set_JPa_amr: set the octree first (lart_gpu_set_grid_amr)");
+    if (!(cross0 > 0.0) || nbins < 1) return fail("set_JPa_amr: bad arguments");
+    if (geometry_JPa != 1 && geometry_JPa != -1 && geometry_JPa != 3) return fail("set_JPa_amr: geometry_JPa must be 1 (shells), -1 (z slabs) or 3 (leaves)");
+    if (geometry_JPa == 3 && nbins != c->amr.nleaf) return fail("set_JPa_amr: geometry_JPa = 3 needs nbins = nleaf");
+    if (geometry_JPa != 3 && !(dbin > 0.0)) return fail("set_JPa_amr: bin width must be > 0");
+    c->amr.jpa_geometry = geometry_JPa; c->amr.dr_JPa = dbin; c->amr.dz_JPa = dbin; c->amr.nr_JPa = nbins; c->amr.nz_JPa = nbins;
+    c->jpa.calc_J = calc_J ? 1 : 0; c->jpa.calc_P = calc_P ? 1 : 0; c->jpa.calc_Pnew = calc_Pnew ? 1 : 0;
+    c->jpa.nbins = (calc_J || calc_P || calc_Pnew) ? nbins : 0; c->jpa.ind_bin = nullptr; c->jpa.cross0 = cross0;
     free_tally(c);
     return 0;
 }
@@ -244,6 +322,7 @@ extern "C" int lart_gpu_begin(lart_gpu *c, int64_t first_id, int64_t stride, int
     if (c->heal_nside > 0 && (c->par.use_stokes || c->par.xyz_symmetry || c->par.xy_periodic)) return fail("begin: HEALPix observers need the plain grid without Stokes");
     if (c->par.save_peeloff && c->par.xyz_symmetry) return fail("begin: peel-off is not allowed with xyz_symmetry (setup.f90:198-206)");
     if (c->par.DGR > 0.0 && !c->has_dust_table) return fail("begin: DGR > 0 but the grid has no rhokapD");
+    if (c->is_amr && c->heal_nside > 0 && c->par.xyz_symmetry) return fail("begin: inside observers need the full octree");
     if (c->par.xy_periodic && !(c->g.nx == 1 && c->g.ny == 1)) return fail("begin: xy_periodic is supported for nx = ny = 1 (raytrace_to_tau_car_zonly) only");
     HIPCHK(hipSetDevice(c->device));
     if (!c->d_tally) { if (build_tally(c)) return 1; }
@@ -275,10 +354,10 @@ extern "C" int lart_gpu_step(lart_gpu *c, int32_t nsteps, int32_t max_events) {
     HIPCHK(hipSetDevice(c->device));
     KArgs A{};
     A.par = c->par; A.g = c->g; A.t = c->t; A.pool = c->pool; A.mu = c->mu; A.obs = c->d_obs; A.nobs = c->par.save_peeloff ? c->nobs : 0;
-    A.nxim = c->nxim; A.nyim = c->nyim; A.dxim = c->dxim; A.dyim = c->dyim; A.ctl = c->d_ctl; A.heal_nside = c->heal_nside; A.jpa = c->jpa;
+    A.nxim = c->nxim; A.nyim = c->nyim; A.dxim = c->dxim; A.dyim = c->dyim; A.ctl = c->d_ctl; A.heal_nside = c->heal_nside; A.jpa = c->jpa; A.amr = c->amr;
     A.first_id = c->first_id; A.stride = c->stride; A.count = c->count; A.seed = c->seed; A.max_events = max_events;
     A.log_nscatt = c->d_log; A.log_xfreq = c->d_log ? c->d_log + c->nlog : nullptr;
-    int var = c->par.xyz_symmetry ? 1 : (c->par.xy_periodic ? 2 : 0);     // setup.f90:961-990
+    int var = c->is_amr ? 3 : (c->par.xyz_symmetry ? 1 : (c->par.xy_periodic ? 2 : 0));     // setup.f90:961-990
     int stokes = c->par.use_stokes ? 1 : 0, dust = c->par.DGR > 0.0 ? 1 : 0, peel = (c->par.save_peeloff && c->nobs > 0) ? 1 : 0;
     dim3 block(c->block), grid((unsigned)(c->pool.n / c->block));
     size_t shmem = (size_t)(VT_END + c->g.nx + c->g.ny + c->g.nz + 3) * sizeof(double);
@@ -289,7 +368,8 @@ extern "C" int lart_gpu_step(lart_gpu *c, int32_t nsteps, int32_t max_events) {
         HIPCHK(hipEventRecord(e0, c->stream));
         if (var == 0) lart_launch_transport_var0(stokes, dust, peel, grid, block, shmem, c->stream, A);
         else if (var == 1) lart_launch_transport_var1(stokes, dust, peel, grid, block, shmem, c->stream, A);
-        else lart_launch_transport_var2(stokes, dust, peel, grid, block, shmem, c->stream, A);
+        else if (var == 2) lart_launch_transport_var2(stokes, dust, peel, grid, block, shmem, c->stream, A);
+        else lart_launch_transport_var3(stokes, dust, peel, grid, block, shmem, c->stream, A);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(e1, c->stream));
         c->ev.emplace_back(e0, e1);
@@ -407,7 +487,7 @@ __device__ void test_ray_one(const KArgs &A, const Lds &l, int kind, double *r, 
         raytrace_to_tau<VAR>(A, l, dust, p, tq, ns);
         r[0] = p.x; r[1] = p.y; r[2] = p.z; r[3] = p.kx; r[4] = p.ky; r[5] = p.kz; r[6] = p.xfreq; r[7] = p.wgt;
         ic[0] = p.ic; ic[1] = p.jc; ic[2] = p.kc; ic[3] = p.inside ? 1 : 0;
-    } else *tau_out = raytrace_to_edge<VAR>(A.g, l, dust, p, p.xfreq, p.kx, p.ky, p.kz, kind == 2 ? tq : -1.0, ns);
+    } else *tau_out = raytrace_to_edge<VAR>(A, l, dust, p, p.xfreq, p.kx, p.ky, p.kz, kind == 2 ? tq : -1.0, ns);
 }
 __global__ void k_test_raytrace(KArgs A, int mode, int n, double *r8, int *ic4, const double *tq, double *tau_out) {
     extern __shared__ double sh[];
@@ -417,7 +497,8 @@ __global__ void k_test_raytrace(KArgs A, int mode, int n, double *r8, int *ic4, 
     int kind = mode / 10, var = mode % 10;
     if (var == 0) test_ray_one<0>(A, l, kind, r8 + 8 * i, ic4 + 4 * i, tq ? tq[i] : 0.0, tau_out + i);
     else if (var == 1) test_ray_one<1>(A, l, kind, r8 + 8 * i, ic4 + 4 * i, tq ? tq[i] : 0.0, tau_out + i);
-    else test_ray_one<2>(A, l, kind, r8 + 8 * i, ic4 + 4 * i, tq ? tq[i] : 0.0, tau_out + i);
+    else if (var == 2) test_ray_one<2>(A, l, kind, r8 + 8 * i, ic4 + 4 * i, tq ? tq[i] : 0.0, tau_out + i);
+    else test_ray_one<3>(A, l, kind, r8 + 8 * i, ic4 + 4 * i, tq ? tq[i] : 0.0, tau_out + i);
 }
 __global__ void k_test_vec2pix(int nside, int n, const double *v, int *ipix) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -453,7 +534,7 @@ template <typename T> struct DevBuf {
     ~DevBuf() { if (p) (void)hipFree(p); }
 };
 static KArgs probe_args(lart_gpu *c) {
-    KArgs A{}; A.par = c->par; A.g = c->g; A.t = c->t; A.mu = c->mu; A.obs = c->d_obs; A.nobs = 0; A.nxim = c->nxim; A.nyim = c->nyim; A.dxim = c->dxim; A.dyim = c->dyim; A.ctl = c->d_ctl; A.heal_nside = c->heal_nside; A.jpa = c->jpa;
+    KArgs A{}; A.par = c->par; A.g = c->g; A.t = c->t; A.mu = c->mu; A.obs = c->d_obs; A.nobs = 0; A.nxim = c->nxim; A.nyim = c->nyim; A.dxim = c->dxim; A.dyim = c->dyim; A.ctl = c->d_ctl; A.heal_nside = c->heal_nside; A.jpa = c->jpa; A.amr = c->amr;
     return A;
 }
 static size_t probe_shmem(lart_gpu *c) { return (size_t)(VT_END + c->g.nx + c->g.ny + c->g.nz + 3) * sizeof(double); }
@@ -480,12 +561,14 @@ extern "C" int lart_gpu_test_rand(lart_gpu *c, int32_t what, uint64_t seed, uint
 extern "C" int lart_gpu_test_raytrace(lart_gpu *c, int32_t mode, int32_t n, double *r8, int32_t *ic4, const double *tq, double *tau_out) {
     if (!c || n < 0 || !c->d_cell) return fail("test_raytrace: needs a context with a medium");
     int kind = mode / 10, var = mode % 10;
-    if (kind < 0 || kind > 2 || var < 0 || var > 2 || (kind == 2 && var != 0)) return fail("test_raytrace: bad mode");
+    if (kind < 0 || kind > 2 || var < 0 || var > 3 || (kind == 2 && var != 0 && var != 3)) return fail("test_raytrace: bad mode");
+    if ((var == 3) != c->is_amr) return fail("test_raytrace: variant 3 needs the octree medium, variants 0-2 the Cartesian one");
     HIPCHK(hipSetDevice(c->device));
     if (!c->d_tally) { if (build_tally(c)) return 1; }
     // host-side shape check before touching the kernel: every start cell must be a valid gather target
     for (int i = 0; i < n; i++) {
         const int *q = ic4 + 4 * i;
+        if (var == 3) { if (q[0] < 1 || q[0] > c->amr.nleaf) return fail("test_raytrace: start leaf must be 1..nleaf"); continue; }
         if (q[0] < 1 || q[0] > c->g.nx + 1 || q[1] < 1 || q[1] > c->g.ny + 1 || q[2] < 1 || q[2] > c->g.nz + 1) return fail("test_raytrace: start cell outside the grid");
         if (q[0] > c->g.nx || q[1] > c->g.ny || q[2] > c->g.nz) return fail("test_raytrace: probe start cells must be interior (1..n)");
     }

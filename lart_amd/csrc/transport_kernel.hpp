@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256, LART_MIN_WAVES) void transport_kernel(KArgs A)
         double tau;
         if (first) {
             // forced first scattering: run_simulation_mod.f90:163-177, add_escaped_fraction_to_Jout :208-247
-            double tau0 = raytrace_to_edge<VAR>(A.g, l, DUST, p, p.xfreq, p.kx, p.ky, p.kz, -1.0, nsteps);
+            double tau0 = raytrace_to_edge<VAR>(A, l, DUST, p, p.xfreq, p.kx, p.ky, p.kz, -1.0, nsteps);
             double esc = exp(-tau0);
             {
                 const Cell &c = A.g.cell[cidx(A.g, p.ic, p.jc, p.kc)];

@@ -129,6 +129,10 @@ class Params:
     calc_P: bool = False
     calc_Pnew: bool = False
     geometry_JPa: int = 2147483647
+    # octree medium (grid_mod_amr.f90); only the generic text format of read_generic_amr.f90:112-185 is read here
+    use_amr_grid: bool = False
+    amr_type: str = "generic"
+    amr_file: str = ""
     # derived (not inputs)
     nphotons: int = 100000
     mu_min: float = -1.0
@@ -141,7 +145,7 @@ class Params:
 # fields of params_type that exist in the reference but select physics outside this path: accepted at their
 # default, rejected ("not supported") when set to something that would change the path
 _UNSUPPORTED_DEFAULTS = {
-    "use_amr_grid": False, "use_clump_medium": False, "fine_structure": False, "include_deuterium": False,
+    "use_clump_medium": False, "fine_structure": False, "include_deuterium": False,
     "line_id": "ly_alpha", "h2_model": "none", "xy_symmetry": False, "z_symmetry": False, "bturb": -999.0,
     "dens_file": "", "temp_file": "", "velo_file": "", "emiss_file": "", "cart_file": "", "input_field": "",
     "star_file": "", "use_cie_condition": False, "density_rscale": -999.9, "density_zscale": -999.9,
@@ -335,8 +339,15 @@ def read_input(par, line=None):
             par.mu_min, par.dmu = -1.0, 2.0 / par.nmu
     if par.nr > 1:
         par.nx = par.ny = par.nz = par.nr
+    if par.use_amr_grid:
+        if par.amr_type.lower() != "generic":
+            raise LartInputError("par%%amr_type = '%s' is not supported by this path (generic text files only)" % par.amr_type)
+        if not par.amr_file:
+            raise LartInputError("par%use_amr_grid = .true. needs par%amr_file")
+        if par.xy_periodic:
+            raise LartInputError("par%xy_periodic is not defined for the octree path")
     if par.geometry == "sphere":                                          # :398-428
-        if not par.xy_periodic:
+        if not par.xy_periodic and not par.use_amr_grid:
             c = [v for v in (par.rmax, par.xmax, par.ymax, par.zmax) if v > 0.0]
             if c:
                 par.rmax = par.xmax = par.ymax = par.zmax = max(c)
@@ -744,13 +755,23 @@ class Simulation:
             for k, v in d.items():
                 set_param(par, k, v)
         self.par, self.line, self.scatt_mat = read_input(par)
-        self.grid = grid_create(self.par, self.line)
+        self.amr = None
+        if self.par.use_amr_grid:                                         # grid_create_amr (main.f90:31-35)
+            from . import amr as amr_mod
+            self.amr, self.grid = amr_mod.grid_create_amr(self.par, self.line, self.par.amr_file)
+        else:
+            self.grid = grid_create(self.par, self.line)
         self.obs = observer_create(self.par)
         self.cpar = make_lart_params(self.par, self.line, self.grid)
         self.ctx = capi.Context(self.cpar, device)
         g = self.grid
-        self.ctx.set_grid_car(g.nx, g.ny, g.nz, g.xmin, g.ymin, g.zmin, g.dx, g.dy, g.dz, g.i0, g.j0, g.k0,
-                              g.xface, g.yface, g.zface, g.rhokap, g.voigt_a, g.Dfreq, g.vfx, g.vfy, g.vfz, g.rhokapD)
+        if self.amr is not None:
+            a = self.amr
+            self.ctx.set_grid_amr(a.xmin, a.xmax, a.cx, a.cy, a.cz, a.ch, a.children, a.neighbor, a.ileaf, a.icell_of_leaf,
+                                  a.rhokap, a.voigt_a, a.Dfreq, a.vfx, a.vfy, a.vfz, a.rhokapD)
+        else:
+            self.ctx.set_grid_car(g.nx, g.ny, g.nz, g.xmin, g.ymin, g.zmin, g.dx, g.dy, g.dz, g.i0, g.j0, g.k0,
+                                  g.xface, g.yface, g.zface, g.rhokap, g.voigt_a, g.Dfreq, g.vfx, g.vfy, g.vfz, g.rhokapD)
         if self.scatt_mat.nPDF:
             s = self.scatt_mat
             self.ctx.set_mueller(s.coss, s.S11, s.S12, s.S33, s.S34, s.phase_PDF, s.alias)
@@ -760,6 +781,14 @@ class Simulation:
                 self.ctx.set_observers_heal(o.xyz, self.par.nside)
             else:
                 self.ctx.set_observers(o.xyz, o.rmatrix, o.dxim, o.dyim, o.nxim, o.nyim)
+        if self.amr is not None:
+            amr_mod.create_JPa_amr_mem(self.par, self.amr)
+            self.jpa = JPa(nbins=self.amr.nbins)
+            if self.jpa.nbins:
+                dbin = self.amr.dr_JPa if self.par.geometry_JPa == 1 else self.amr.dz_JPa
+                self.ctx.set_JPa_amr(self.par.calc_J, self.par.calc_P, self.par.calc_Pnew, self.par.geometry_JPa, self.jpa.nbins, dbin, self.line.cross0)
+            self.nphotons_run = 0
+            return
         self.jpa = create_JPa_mem(self.par, g)
         if self.jpa.nbins:
             self.ctx.set_JPa(self.par.calc_J, self.par.calc_P, self.par.calc_Pnew, self.jpa.nbins, self.jpa.ind_bin, self.line.cross0)
@@ -810,7 +839,14 @@ class Simulation:
                     out[k] = t[k] / sc3
                 if k + "_2D" in t:
                     out[k + "_2D"] = t[k + "_2D"] / sc2
-        if self.jpa.nbins:                                                # :275-360 J(x) and P_alpha profiles
+        if self.jpa.nbins and self.amr is not None:                       # octree: volume-weighted, output_sum_heal.f90:476-590
+            vol = np.where(self.amr.vol > 0, self.amr.vol, np.inf) * par.distance2cm ** 2
+            if "J1" in t:
+                out["J1"] = t["J1"] / (FOURPI * vol[None, :] * nph * unit)
+            for k in ("P1", "P1_new"):
+                if k in t:
+                    out[k] = t[k] / (vol * nph)
+        elif self.jpa.nbins:                                              # :275-360 J(x) and P_alpha profiles
             dVol = g.dx * g.dy * g.dz * par.distance2cm ** 2
             cnt = np.where(self.jpa.ncount > 0, self.jpa.ncount, np.inf)
             geo_area = (g.xmax - g.xmin) * (g.ymax - g.ymin) * par.distance2cm ** 2 if par.xy_periodic else 1.0

@@ -274,7 +274,17 @@ typedef struct {
     double I, Q, U, V, E1, E2, E3;
 } photon_t;
 
+/* amr_grid_type (octree_mod.f90:19-138): flat octree, 1-based cell and leaf indices stored as in the reference */
+typedef struct {
+    int ncells, nleaf, levelmax;
+    int *parent, *children, *level, *ileaf, *icell_of_leaf, *neighbor;   /* children(8,ncells), neighbor(6,ncells) column-major */
+    double *cx, *cy, *cz, *ch;
+    double xmin, xmax, ymin, ymax, zmin, zmax, L_box;
+    int nr_JPa, nz_JPa; double rmax_JPa, dr_JPa, dz_JPa;
+} amr_t;
+
 struct orc_sim {
+    int use_amr_grid; char amr_file[512]; amr_t amr;
     /* --- par% (define.f90:209-544) --- */
     double no_photons; int iseed;
     double temperature, taumax, tauhomo, N_gasmax, N_gashomo, Vexp;
@@ -317,6 +327,10 @@ struct orc_sim {
     int64_t log_n; double *log_nscatt, *log_xfreq;
 };
 
+static int grid_create_amr(orc_sim *s);
+static int create_JPa_amr_mem(orc_sim *s);
+static int amr_JPa_bin(const orc_sim *s, int il, double x0, double y0, double z0);
+static void amr_xcrit_local(const orc_sim *s, int il, double x, double y, double z, double *xc, double *xc2);
 #define IDX(s,i,j,k) ((size_t)((i)-1) + (size_t)(s)->nx * ((size_t)((j)-1) + (size_t)(s)->ny * (size_t)((k)-1)))
 
 /* per-thread accumulators, merged after the run */
@@ -358,6 +372,9 @@ static int set_param(orc_sim *s, const char *k, const char *v) {
     if (!strcmp(k, "N_HImax") || !strcmp(k, "N_gasmax") || !strcmp(k, "N_HI")) { s->N_gasmax = atof(v); return 0; }
     if (!strcmp(k, "N_HIhomo") || !strcmp(k, "N_gashomo")) { s->N_gashomo = atof(v); return 0; }
     if (!strcmp(k, "tau0")) { s->taumax = atof(v); return 0; }
+    if (!strcmp(k, "use_amr_grid")) { s->use_amr_grid = parse_bool(v); return 0; }
+    if (!strcmp(k, "amr_file")) { snprintf(s->amr_file, sizeof s->amr_file, "%s", v); return 0; }
+    if (!strcmp(k, "amr_type")) return 0;
     if (!strcmp(k, "scatt_mat_file")) { snprintf(s->scatt_mat_file, sizeof s->scatt_mat_file, "%s", v); return 0; }
     if (!strcmp(k, "spectral_type")) {
         if (!strcmp(v, "voigt")) s->spectral_type = 1; else if (!strcmp(v, "monochromatic")) s->spectral_type = 0;
@@ -479,7 +496,7 @@ static int read_input_post(orc_sim *s) {
     if (s->save_Jmu) { if (s->xyz_symmetry) { s->mu_min = 0.0; s->dmu = 1.0 / s->nmu; } else { s->mu_min = -1.0; s->dmu = 2.0 / s->nmu; } }
     /* :398-428 geometry normalisation */
     if (s->geometry == 0) {
-        if (!s->xy_periodic) {
+        if (!s->use_amr_grid && !s->xy_periodic) {
             double c[4] = {s->rmax, s->xmax, s->ymax, s->zmax}, r0 = -HUGEST;
             for (int i = 0; i < 4; i++) if (c[i] > 0.0 && c[i] > r0) r0 = c[i];
             if (r0 > 0.0) { s->rmax = s->xmax = s->ymax = s->zmax = r0; }
@@ -489,7 +506,7 @@ static int read_input_post(orc_sim *s) {
     } else s->rmax = -1.0;
     if (s->source_rmax < 0.0) s->source_rmax = s->rmax;
     /* :438-459 geometry of the J/P profiles: 3 = per cell, 1 = spherical shells, -1 = plane-parallel layers */
-    if (s->rmax <= 0.0) s->geometry_JPa = 3;
+    if (s->rmax <= 0.0) s->geometry_JPa = 3;                     /* evaluated on the INPUT rmax, also for the octree (grid_create_amr sets par%rmax later) */
     if (s->geometry_JPa < -1 || s->geometry_JPa > 3) { s->geometry_JPa = 1;
         if (s->xy_periodic) s->geometry_JPa = -1; else if (s->xyz_symmetry) s->geometry_JPa = 1; }
     if (s->geometry_JPa == 2 || s->geometry_JPa == 0) { snprintf(g_err, sizeof g_err, "geometry_JPa = %d (cylinder) not supported by the oracle", s->geometry_JPa); return -1; }
@@ -714,7 +731,8 @@ static inline void add_to_Pa(const orc_sim *s, acc_t *A, const photon_t *p) {
     if (!s->calc_P) return;
     size_t c = IDX(s,p->icell,p->jcell,p->kcell);
     if (!(s->rhokap[c] > 0.0)) return;
-    int ib = s->ind_bin[c]; if (ib < 1) return;
+    int ib = s->use_amr_grid ? amr_JPa_bin(s, p->icell, p->x, p->y, p->z) : s->ind_bin[c];   /* add_to_Pa_amr: scattering_amr.f90:917-942 */
+    if (ib < 1) return;
     A->P1[ib-1] += p->wgt / (s->rhokap[c] * s->Dfreq[c] / s->cross0);
 }
 
@@ -810,7 +828,7 @@ orc_sim *orc_create(const char *params) {
         if (set_param(s, k, eq + 1)) { free(buf); free(s); return NULL; }
     }
     free(buf);
-    if (read_input_post(s) || grid_create(s) || create_JPa_mem(s) || observer_create(s)) { free(s); return NULL; }
+    if (read_input_post(s) || (s->use_amr_grid ? (grid_create_amr(s) || create_JPa_amr_mem(s)) : (grid_create(s) || create_JPa_mem(s))) || observer_create(s)) { free(s); return NULL; }
     return s;
 }
 static void free_obs(obs_t *o) { free(o->scatt); free(o->direc); free(o->I); free(o->Q); free(o->U); free(o->V);
@@ -822,6 +840,333 @@ void orc_destroy(orc_sim *s) {
     for (int i = 0; i < MAX_OBS; i++) free_obs(&s->obs[i]);
     free(s->ind_bin); free(s->ncount); free(s->J1); free(s->P1); free(s->P1_new);
     free(s->log_nscatt); free(s->log_xfreq); free(s);
+}
+
+
+/* =====================================================================================
+ * Octree AMR medium: octree_mod.f90, grid_mod_amr.f90, read_generic_amr.f90, raytrace_amr.f90
+ * ===================================================================================== */
+#define CH(a,io,ic) ((a)->children[(size_t)((io)-1) + 8 * (size_t)((ic)-1)])
+#define NB(a,f,ic)  ((a)->neighbor[(size_t)((f)-1) + 6 * (size_t)((ic)-1)])
+
+/* amr_find_leaf: octree_mod.f90:149-171 */
+static int amr_find_leaf(const amr_t *a, double x, double y, double z) {
+    if (x < a->xmin || x > a->xmax || y < a->ymin || y > a->ymax || z < a->zmin || z > a->zmax) return 0;
+    int ic = 1;
+    for (;;) {
+        if (a->ileaf[ic-1] > 0) return a->ileaf[ic-1];
+        int io = 1; if (x >= a->cx[ic-1]) io += 1; if (y >= a->cy[ic-1]) io += 2; if (z >= a->cz[ic-1]) io += 4;
+        ic = CH(a, io, ic);
+        if (ic == 0) return 0;
+    }
+}
+/* amr_find_cell_at_level: :827-849 */
+static int amr_find_cell_at_level(const amr_t *a, double x, double y, double z, int target) {
+    if (x < a->xmin || x > a->xmax || y < a->ymin || y > a->ymax || z < a->zmin || z > a->zmax) return 0;
+    int ic = 1;
+    for (;;) {
+        if (a->level[ic-1] >= target) return ic;
+        if (a->ileaf[ic-1] > 0) return ic;
+        int io = 1; if (x >= a->cx[ic-1]) io += 1; if (y >= a->cy[ic-1]) io += 2; if (z >= a->cz[ic-1]) io += 4;
+        int ch = CH(a, io, ic);
+        if (ch == 0) return ic;
+        ic = ch;
+    }
+}
+/* amr_cell_exit: :412-451 (iface 1=+x 2=-x 3=+y 4=-y 5=+z 6=-z; first minimum) */
+static void amr_cell_exit(const amr_t *a, int ic, double x, double y, double z, double kx, double ky, double kz, double *t_exit, int *iface) {
+    double cx = a->cx[ic-1], cy = a->cy[ic-1], cz = a->cz[ic-1], h = a->ch[ic-1], t[6];
+    if (kx > 0.0) { t[0] = (cx + h - x) / kx; t[1] = HUGEST; } else if (kx < 0.0) { t[0] = HUGEST; t[1] = (cx - h - x) / kx; } else { t[0] = HUGEST; t[1] = HUGEST; }
+    if (ky > 0.0) { t[2] = (cy + h - y) / ky; t[3] = HUGEST; } else if (ky < 0.0) { t[2] = HUGEST; t[3] = (cy - h - y) / ky; } else { t[2] = HUGEST; t[3] = HUGEST; }
+    if (kz > 0.0) { t[4] = (cz + h - z) / kz; t[5] = HUGEST; } else if (kz < 0.0) { t[4] = HUGEST; t[5] = (cz - h - z) / kz; } else { t[4] = HUGEST; t[5] = HUGEST; }
+    int m = 0; for (int i = 1; i < 6; i++) if (t[i] < t[m]) m = i;
+    *iface = m + 1; *t_exit = t[m];
+}
+/* amr_next_leaf: :718-758 (normal sub-octant bit from iface, transverse bits from the position) */
+static int amr_next_leaf(const amr_t *a, int ic, int iface, double x, double y, double z) {
+    int ng = NB(a, iface, ic);
+    if (ng == 0) return 0;
+    while (a->ileaf[ng-1] == 0) {
+        int io = 1;
+        switch (iface) {
+        case 1: if (y >= a->cy[ng-1]) io += 2; if (z >= a->cz[ng-1]) io += 4; break;
+        case 2: io += 1; if (y >= a->cy[ng-1]) io += 2; if (z >= a->cz[ng-1]) io += 4; break;
+        case 3: if (x >= a->cx[ng-1]) io += 1; if (z >= a->cz[ng-1]) io += 4; break;
+        case 4: if (x >= a->cx[ng-1]) io += 1; io += 2; if (z >= a->cz[ng-1]) io += 4; break;
+        case 5: if (x >= a->cx[ng-1]) io += 1; if (y >= a->cy[ng-1]) io += 2; break;
+        default: if (x >= a->cx[ng-1]) io += 1; if (y >= a->cy[ng-1]) io += 2; io += 4; break;
+        }
+        int ch = CH(a, io, ng);
+        if (ch == 0) break;
+        ng = ch;
+    }
+    return a->ileaf[ng-1];
+}
+/* amr_build_tree: :460-569 (insert leaves in file order, creating internal nodes on the way down) */
+static void amr_build_tree(amr_t *a, int nleaf, const double *xl, const double *yl, const double *zl, const int *lev, double lo, double hi) {
+    int cap = nleaf * 2 > 16 ? nleaf * 2 : 16, nc = 1;
+    a->parent = calloc(cap, 4); a->children = calloc((size_t)8 * cap, 4); a->level = calloc(cap, 4); a->ileaf = calloc(cap, 4);
+    a->cx = calloc(cap, 8); a->cy = calloc(cap, 8); a->cz = calloc(cap, 8); a->ch = calloc(cap, 8); a->icell_of_leaf = calloc(nleaf, 4);
+    a->xmin = a->ymin = a->zmin = lo; a->xmax = a->ymax = a->zmax = hi; a->L_box = hi - lo;
+    a->cx[0] = a->cy[0] = a->cz[0] = (lo + hi) * 0.5; a->ch[0] = a->L_box * 0.5;
+    a->levelmax = 0;
+    for (int il = 1; il <= nleaf; il++) {
+        int ic = 1;
+        for (int l = 0; l <= lev[il-1] - 1; l++) {
+            int io = 1; if (xl[il-1] >= a->cx[ic-1]) io += 1; if (yl[il-1] >= a->cy[ic-1]) io += 2; if (zl[il-1] >= a->cz[ic-1]) io += 4;
+            if (CH(a, io, ic) == 0) {
+                nc++;
+                if (nc > cap) { int nc2 = cap * 2;
+                    a->parent = realloc(a->parent, nc2 * 4); a->children = realloc(a->children, (size_t)8 * nc2 * 4); a->level = realloc(a->level, nc2 * 4); a->ileaf = realloc(a->ileaf, nc2 * 4);
+                    a->cx = realloc(a->cx, nc2 * 8); a->cy = realloc(a->cy, nc2 * 8); a->cz = realloc(a->cz, nc2 * 8); a->ch = realloc(a->ch, nc2 * 8);
+                    memset(a->children + (size_t)8 * cap, 0, (size_t)8 * (nc2 - cap) * 4); memset(a->ileaf + cap, 0, (nc2 - cap) * 4); cap = nc2; }
+                a->parent[nc-1] = ic; a->level[nc-1] = l + 1; a->ileaf[nc-1] = 0; a->ch[nc-1] = a->ch[ic-1] * 0.5;
+                for (int q = 1; q <= 8; q++) CH(a, q, nc) = 0;
+                int ix = (io - 1) % 2, iy = ((io - 1) / 2) % 2, iz = (io - 1) / 4;
+                a->cx[nc-1] = a->cx[ic-1] + (2 * ix - 1) * a->ch[nc-1]; a->cy[nc-1] = a->cy[ic-1] + (2 * iy - 1) * a->ch[nc-1]; a->cz[nc-1] = a->cz[ic-1] + (2 * iz - 1) * a->ch[nc-1];
+                CH(a, io, ic) = nc;
+            }
+            ic = CH(a, io, ic);
+        }
+        a->ileaf[ic-1] = il; a->icell_of_leaf[il-1] = ic;
+        if (lev[il-1] > a->levelmax) a->levelmax = lev[il-1];
+    }
+    a->ncells = nc; a->nleaf = nleaf;
+}
+static int amr_is_ancestor(const amr_t *a, int anc, int desc) { int c = desc; while (c > 0) { c = a->parent[c-1]; if (c == anc) return 1; } return 0; }
+/* amr_build_neighbors: :619-682 */
+static void amr_build_neighbors(amr_t *a) {
+    a->neighbor = calloc((size_t)6 * a->ncells, 4);
+    for (int ic = 1; ic <= a->ncells; ic++) {
+        double cx = a->cx[ic-1], cy = a->cy[ic-1], cz = a->cz[ic-1], hp = 2.0 * a->ch[ic-1]; int lv = a->level[ic-1];
+        if (cx + hp <= a->xmax) NB(a, 1, ic) = amr_find_cell_at_level(a, cx + hp, cy, cz, lv);
+        if (cx - hp >= a->xmin) NB(a, 2, ic) = amr_find_cell_at_level(a, cx - hp, cy, cz, lv);
+        if (cy + hp <= a->ymax) NB(a, 3, ic) = amr_find_cell_at_level(a, cx, cy + hp, cz, lv);
+        if (cy - hp >= a->ymin) NB(a, 4, ic) = amr_find_cell_at_level(a, cx, cy - hp, cz, lv);
+        if (cz + hp <= a->zmax) NB(a, 5, ic) = amr_find_cell_at_level(a, cx, cy, cz + hp, lv);
+        if (cz - hp >= a->zmin) NB(a, 6, ic) = amr_find_cell_at_level(a, cx, cy, cz - hp, lv);
+        for (int f = 1; f <= 6; f++) { int ng = NB(a, f, ic); if (ng > 0 && ng != ic && amr_is_ancestor(a, ng, ic)) NB(a, f, ic) = 0; }
+    }
+}
+/* generic AMR text reader: read_generic_amr.f90:112-185 ("NLEAF n" / "BOXLEN L" or legacy "n L"; rows x y z level nH T vx vy vz) */
+static int amr_read_text(const char *fn, int *nleaf, double *boxlen, double **col) {
+    FILE *f = fopen(fn, "r"); if (!f) { snprintf(g_err, sizeof g_err, "generic_amr_read: cannot open file: %s", fn); return -1; }
+    char line[1024]; int n = 0; double bl = -1.0;
+    while (fgets(line, sizeof line, f)) {
+        char *q = line; while (*q == ' ' || *q == '\t') q++;
+        if (*q == 0 || *q == '\n' || *q == '#') continue;
+        if (!strncmp(q, "BOXLEN", 6) || !strncmp(q, "boxlen", 6)) bl = atof(q + 6);
+        else if (!strncmp(q, "NLEAF", 5) || !strncmp(q, "nleaf", 5)) n = atoi(q + 5);
+        else if (sscanf(q, "%d %lf", &n, &bl) != 2) { fclose(f); snprintf(g_err, sizeof g_err, "generic_amr_read: cannot parse text header"); return -1; }
+        if (n > 0 && bl > 0.0) break;
+    }
+    if (n <= 0 || bl <= 0.0) { fclose(f); snprintf(g_err, sizeof g_err, "generic_amr_read: text header must provide NLEAF and BOXLEN"); return -1; }
+    for (int c = 0; c < 9; c++) col[c] = malloc((size_t)n * 8);
+    int m = 0;
+    while (m < n && fgets(line, sizeof line, f)) {
+        char *q = line; while (*q == ' ' || *q == '\t') q++;
+        if (*q == 0 || *q == '\n' || *q == '#') continue;
+        double v[9];
+        if (sscanf(q, "%lf %lf %lf %lf %lf %lf %lf %lf %lf", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6], &v[7], &v[8]) != 9) break;
+        for (int c = 0; c < 9; c++) col[c][m] = v[c];
+        m++;
+    }
+    fclose(f);
+    if (m != n) { snprintf(g_err, sizeof g_err, "generic_amr_read: expected %d rows, got %d", n, m); return -1; }
+    *nleaf = n; *boxlen = bl; return 0;
+}
+/* grid_create_amr: grid_mod_amr.f90:34-526 (text input, all hydrogen neutral, no dust model / emissivity) */
+static int grid_create_amr(orc_sim *s) {
+    int nleaf; double boxlen, *col[9];
+    if (amr_read_text(s->amr_file, &nleaf, &boxlen, col)) return -1;
+    int *lev = malloc(nleaf * sizeof(int)); for (int i = 0; i < nleaf; i++) lev[i] = (int)col[3][i];
+    amr_t *a = &s->amr;
+    amr_build_tree(a, nleaf, col[0], col[1], col[2], lev, -0.5 * boxlen, 0.5 * boxlen);      /* text files: centred box (:179-181) */
+    amr_build_neighbors(a);
+    if (s->geometry == 0) { s->rmax = a->L_box * 0.5; s->xmax = s->ymax = s->zmax = s->rmax; }   /* :202-216 */
+    else { s->rmax = -1.0; s->xmax = a->xmax; s->ymax = a->ymax; s->zmax = a->zmax; }
+    if (s->source_rmax < 0.0) s->source_rmax = s->rmax;
+    /* leaf tables live in the Cartesian arrays with nx = nleaf, ny = nz = 1 (photon%icell = leaf index) */
+    s->nx = nleaf; s->ny = 1; s->nz = 1; s->xmin = a->xmin; s->ymin = a->ymin; s->zmin = a->zmin; s->dx = s->dy = s->dz = a->L_box;
+    s->xface = calloc(2, 8); s->yface = calloc(2, 8); s->zface = calloc(2, 8);
+    s->vfx = calloc(nleaf, 8); s->vfy = calloc(nleaf, 8); s->vfz = calloc(nleaf, 8);
+    s->Dfreq = malloc(nleaf * 8); s->voigt_a = malloc(nleaf * 8); s->rhokap = malloc(nleaf * 8); s->rhokapD = calloc(nleaf, 8);
+    s->Dfreq_ref = vtherm_total(s, s->temperature) / (s->wavelength0 * UM2KM);              /* :219-221 */
+    s->voigt_amean = (s->damping / FOURPI) / s->Dfreq_ref;
+    for (int il = 0; il < nleaf; il++) {                                                    /* :236-318 */
+        double T = fmax(col[5][il], 10.0), vt = vtherm_total(s, T);
+        s->Dfreq[il] = vt / (s->wavelength0 * UM2KM); s->voigt_a[il] = (s->damping / FOURPI) / s->Dfreq[il];
+        s->rhokap[il] = col[4][il] * s->cross0 / s->Dfreq[il] * s->distance2cm;
+        if (s->DGR > 0.0) s->rhokapD[il] = col[4][il] * s->cext_dust * s->DGR * s->distance2cm;
+        s->vfx[il] = col[6][il] / vt; s->vfy[il] = col[7][il] / vt; s->vfz[il] = col[8][il] / vt;
+    }
+    for (int c = 0; c < 9; c++) free(col[c]); free(lev);
+    /* Step 5 (:355-446): tau_homo and the +z pole traversal from the box centre */
+    double opacity_sum = 0.0, nopac = 0.0, opac_length = boxlen / 2.0, tauhomo = 0.0, taupole, NHI_pole_raw = 0.0, tau_raw = 0.0, opac_norm = 1.0;
+    for (int il = 0; il < nleaf; il++) { opacity_sum += s->rhokap[il] * orc_voigt(0.0, s->voigt_a[il]); if (s->rhokap[il] > 0.0) nopac += 1.0; }
+    if (nopac > 0.0) tauhomo = (opacity_sum / nopac) * opac_length;
+    { double xc = a->cx[0], yc = a->cy[0], zc = a->cz[0];
+      for (int it = 0; it < 10000000 && zc < a->zmax; it++) {
+          int il = amr_find_leaf(a, xc, yc, zc);
+          if (il <= 0) break;                                    /* gaps do not occur in complete octrees */
+          double t; int f; amr_cell_exit(a, a->icell_of_leaf[il-1], xc, yc, zc, 0.0, 0.0, 1.0, &t, &f);
+          tau_raw += s->rhokap[il-1] * orc_voigt(0.0, s->voigt_a[il-1]) * t;
+          NHI_pole_raw += s->rhokap[il-1] * s->Dfreq[il-1] / s->cross0 * t;
+          zc += t; } }
+    taupole = tau_raw > 0.0 ? tau_raw : tauhomo;
+    if (s->taumax > 0.0) { if (taupole > 0.0) opac_norm = s->taumax / taupole; }
+    else if (s->N_gasmax > 0.0) { if (NHI_pole_raw > 0.0) opac_norm = s->N_gasmax / NHI_pole_raw; }
+    for (int il = 0; il < nleaf; il++) { s->rhokap[il] *= opac_norm; if (s->DGR > 0.0) s->rhokapD[il] *= opac_norm; }
+    opacity_sum = 0.0; for (int il = 0; il < nleaf; il++) opacity_sum += s->rhokap[il] * orc_voigt(0.0, s->voigt_a[il]);
+    if (nopac > 0.0) tauhomo = (opacity_sum / nopac) * opac_length;
+    taupole = s->taumax > 0.0 ? s->taumax : tauhomo;
+    s->N_gasmax = NHI_pole_raw * opac_norm; s->N_gashomo = s->N_gasmax; s->tauhomo = tauhomo; s->taumax = taupole;
+    /* Step 6 core-skip (:479-492) */
+    double atau0 = s->voigt_amean * s->tauhomo, at = atau0 / (boxlen / (2.0 * a->ch[0]));
+    if (at <= 1.0) { s->xcrit = 0.0; s->xcrit2 = 0.0; } else { double xi = (at <= 60.0) ? 0.6 : 1.4, chi = (at <= 60.0) ? 1.2 : 0.6; s->xcrit = 0.02 * exp(xi * pow(log(at), chi)); s->xcrit2 = s->xcrit * s->xcrit; }
+    /* amr_setup_freq_grid (:726-800): same rules as the Cartesian grid */
+    s->atau3 = pow(s->voigt_amean * s->tauhomo, 1.0 / 3.0);
+    if (!(isfinite(s->par_xfreq_max) && isfinite(s->par_xfreq_min))) {
+        double xscale = (s->taumax <= 5e1) ? 25.0 : (s->taumax <= 5e2) ? 14.0 : (s->taumax <= 5e3) ? 10.0 : 5.0, vt = vtherm_total(s, s->temperature);
+        if (s->Vexp == 0.0) { s->par_xfreq_max = floor(xscale * s->atau3) + 1.0; s->par_xfreq_min = -(floor(xscale * s->atau3 + 0.0) + 1.0); }
+        else if (s->Vexp > 0.0) { s->par_xfreq_max = floor(xscale * s->atau3) + 1.0; s->par_xfreq_min = -(floor(xscale * s->atau3 + fabs(s->Vexp) / vt + 0.0) + 1.0); }
+        else { s->par_xfreq_max = floor(xscale * s->atau3 + fabs(s->Vexp) / vt) + 1.0; s->par_xfreq_min = -(floor(xscale * s->atau3 + 0.0) + 1.0); }
+    }
+    s->dxfreq = (s->par_xfreq_max - s->par_xfreq_min) / s->nxfreq; s->xfreq_max = s->par_xfreq_max; s->xfreq_min = s->par_xfreq_min;
+    s->Jout = calloc(s->nxfreq, 8); s->Jin = calloc(s->nxfreq, 8); s->Jabs = calloc(s->nxfreq, 8); s->Jmu = calloc((size_t)s->nxfreq * (s->nmu > 0 ? s->nmu : 1), 8);
+    s->raytrace_variant = 3;
+    if (s->xy_periodic) { snprintf(g_err, sizeof g_err, "xy_periodic AMR boxes are not supported by the oracle"); return -1; }
+    return 0;
+}
+/* create_JPa_amr_mem: grid_mod_amr.f90:543-724 (position-binned deposits, gas volume per bin by ns^3 sub-sampling) */
+static int create_JPa_amr_mem(orc_sim *s) {
+    if (!(s->calc_J || s->calc_P || s->calc_Pnew)) return 0;
+    amr_t *a = &s->amr;
+    double rmax = s->rmax; if (rmax <= 0.0) rmax = a->L_box * 0.5;
+    int nr = 1; { int e = a->levelmax - 1; if (e < 0) e = 0; nr = 1 << e; if (nr > 512) nr = 512; if (nr < 1) nr = 1; }
+    int nz = 1; { int e = a->levelmax; if (e < 0) e = 0; nz = 1 << e; if (nz > 512) nz = 512; }
+    a->nr_JPa = nr; a->nz_JPa = nz; a->rmax_JPa = rmax; a->dr_JPa = rmax / nr; a->dz_JPa = (a->zmax - a->zmin) / nz;
+    int nadd = s->xyz_symmetry ? 8 : 1;
+    if (s->geometry_JPa == 1) s->nbins = nr; else if (s->geometry_JPa == -1) s->nbins = nz; else s->nbins = a->nleaf;
+    s->ncount = calloc(s->nbins, 8);                             /* here: gas volume per bin (vol_sph / vol_plane / vol_leaf) */
+    for (int il = 1; il <= a->nleaf; il++) {
+        int ic = a->icell_of_leaf[il-1]; double hc = a->ch[ic-1], vleaf = pow(2.0 * hc, 3) * nadd;
+        if (s->geometry_JPa == 3) { s->ncount[il-1] = vleaf; continue; }
+        if (s->rhokap[il-1] <= 0.0) continue;
+        if (s->geometry_JPa == 1) {
+            int ns = (int)lround(2.0 * hc / a->dr_JPa); if (ns < 2) ns = 2; if (ns > 8) ns = 8;
+            double wsub = vleaf / (double)(ns * ns * ns);
+            for (int ks = 1; ks <= ns; ks++) for (int js = 1; js <= ns; js++) for (int is = 1; is <= ns; is++) {
+                double xs = a->cx[ic-1] + (2.0 * is - ns - 1.0) * hc / ns, ys = a->cy[ic-1] + (2.0 * js - ns - 1.0) * hc / ns, zs = a->cz[ic-1] + (2.0 * ks - ns - 1.0) * hc / ns;
+                int ir = (int)floor(sqrt(xs * xs + ys * ys + zs * zs) / a->dr_JPa) + 1;
+                if (ir >= 1 && ir <= nr) s->ncount[ir-1] += wsub; }
+        } else {
+            double z1 = a->cz[ic-1] - hc, z2 = a->cz[ic-1] + hc, zlo = a->zmin, dz = a->dz_JPa;
+            int iz1 = (int)floor((z1 - zlo) / dz) + 1, iz2 = (int)floor((z2 - zlo) / dz) + 1; if (iz1 < 1) iz1 = 1; if (iz2 > nz) iz2 = nz;
+            for (int iz = iz1; iz <= iz2; iz++) { double ov = fmin(z2, zlo + iz * dz) - fmax(z1, zlo + (iz - 1) * dz); if (ov > 0.0) s->ncount[iz-1] += vleaf * ov / (2.0 * hc); }
+        }
+    }
+    if (s->calc_J) s->J1 = calloc((size_t)s->nxfreq * s->nbins, 8);
+    if (s->calc_P) s->P1 = calloc(s->nbins, 8);
+    if (s->calc_Pnew) s->P1_new = calloc(s->nbins, 8);
+    return 0;
+}
+/* amr_JPa_bin: octree_mod.f90:286-311 (geometry 1 and -1; 3 = the leaf itself) */
+static int amr_JPa_bin(const orc_sim *s, int il, double x0, double y0, double z0) {
+    const amr_t *a = &s->amr;
+    if (s->geometry_JPa == 3) return il;
+    if (s->geometry_JPa == 1) { int ib = (int)floor(sqrt(x0 * x0 + y0 * y0 + z0 * z0) / a->dr_JPa) + 1; return (ib >= 1 && ib <= a->nr_JPa) ? ib : 0; }
+    int ib = (int)floor((z0 - a->zmin) / a->dz_JPa) + 1; if (ib < 1) ib = 1; if (ib > a->nz_JPa) ib = a->nz_JPa; return ib;
+}
+/* add_to_J_amr / add_to_Pnew_amr: raytrace_amr.f90:848-912 (segment midpoint decides the bin) */
+static inline void add_to_JPnew_amr(const orc_sim *s, acc_t *A, const photon_t *p, int il, double x0, double y0, double z0, double del, double dtauH) {
+    if (s->rhokap[il-1] <= 0.0) return;
+    int ib = amr_JPa_bin(s, il, x0, y0, z0); if (ib < 1) return;
+    if (s->calc_J) { double xr = p->xfreq * (s->Dfreq[il-1] / s->Dfreq_ref); int ix = (int)floor((xr - s->xfreq_min) / s->dxfreq) + 1;
+        if (ix >= 1 && ix <= s->nxfreq) A->J1[(size_t)(ix - 1) + (size_t)s->nxfreq * (ib - 1)] += del * p->wgt; }
+    if (s->calc_Pnew) A->P1_new[ib-1] += dtauH * p->wgt / (s->rhokap[il-1] * s->Dfreq[il-1] / s->cross0);
+}
+/* amr_xcrit_local: octree_mod.f90:248-278 */
+static void amr_xcrit_local(const orc_sim *s, int il, double x, double y, double z, double *xc, double *xc2) {
+    if (s->core_skip_global) { *xc = s->xcrit; *xc2 = s->xcrit2; return; }
+    *xc = 0.0; *xc2 = 0.0; if (il <= 0) return;
+    const amr_t *a = &s->amr; int ic = a->icell_of_leaf[il-1]; double h = a->ch[ic-1];
+    double dl = fmin(h - fabs(x - a->cx[ic-1]), fmin(h - fabs(y - a->cy[ic-1]), h - fabs(z - a->cz[ic-1])));
+    if (dl <= 0.0) return;
+    double atau = s->voigt_a[il-1] * s->rhokap[il-1] * dl;
+    if (atau > 1.0) { *xc = pow(atau, 1.0 / 3.0) / 5.0; *xc2 = (*xc) * (*xc); }
+}
+/* boundary handling shared by the three AMR marches (raytrace_amr.f90:176-201): mirror planes of the +++ octant */
+static inline int amr_boundary(const orc_sim *s, int il, int iface, double *kx, double *ky, double *kz, int *reflected) {
+    if (s->xyz_symmetry) {
+        if (iface == 2) { *kx = -*kx; *reflected = 1; return il; }
+        if (iface == 4) { *ky = -*ky; *reflected = 1; return il; }
+        if (iface == 6) { *kz = -*kz; *reflected = 1; return il; }
+    }
+    return 0;
+}
+static void add_to_Jmu(const orc_sim *s, acc_t *A, const photon_t *p, int ix);
+/* raytrace_to_tau_amr: raytrace_amr.f90:77-259 */
+static void raytrace_to_tau_amr(const orc_sim *s, acc_t *A, photon_t *p, double tau_in) {
+    const amr_t *a = &s->amr;
+    double x = p->x, y = p->y, z = p->z, kx = p->kx, ky = p->ky, kz = p->kz, tau = 0.0;
+    int il = p->icell;
+    if (il <= 0) { il = amr_find_leaf(a, x, y, z); if (il <= 0) { p->inside = 0; return; } }
+    double u1 = s->vfx[il-1] * kx + s->vfy[il-1] * ky + s->vfz[il-1] * kz, u2;
+    while (p->inside) {
+        int ic = a->icell_of_leaf[il-1], iface; double t_exit;
+        amr_cell_exit(a, ic, x, y, z, kx, ky, kz, &t_exit, &iface);
+        double rhokapH = s->rhokap[il-1] * orc_voigt(p->xfreq, s->voigt_a[il-1]), rhokap = rhokapH;
+        if (s->DGR > 0.0) rhokap = rhokap + s->rhokapD[il-1];
+        A->n_cellsteps += 1.0;
+        if (tau + t_exit * rhokap >= tau_in) {
+            double d_step = (rhokap > 0.0) ? (tau_in - tau) / rhokap : t_exit;
+            if (s->nbins) add_to_JPnew_amr(s, A, p, il, x + 0.5 * d_step * kx, y + 0.5 * d_step * ky, z + 0.5 * d_step * kz, d_step, d_step * rhokapH);
+            x = x + d_step * kx; y = y + d_step * ky; z = z + d_step * kz; tau = tau_in;
+            break;
+        }
+        tau = tau + t_exit * rhokap; x = x + t_exit * kx; y = y + t_exit * ky; z = z + t_exit * kz;
+        if (s->nbins) add_to_JPnew_amr(s, A, p, il, x - 0.5 * t_exit * kx, y - 0.5 * t_exit * ky, z - 0.5 * t_exit * kz, t_exit, t_exit * rhokapH);
+        int il_new = amr_next_leaf(a, ic, iface, x, y, z), reflected = 0;
+        if (il_new <= 0) il_new = amr_boundary(s, il, iface, &kx, &ky, &kz, &reflected);
+        if (il_new <= 0) { p->inside = 0; break; }
+        u2 = s->vfx[il_new-1] * kx + s->vfy[il_new-1] * ky + s->vfz[il_new-1] * kz;
+        if (reflected) p->xfreq = (p->xfreq + u1) - u2; else p->xfreq = (p->xfreq + u1) * s->Dfreq[il-1] / s->Dfreq[il_new-1] - u2;
+        u1 = u2; il = il_new;
+    }
+    p->x = x; p->y = y; p->z = z; p->kx = kx; p->ky = ky; p->kz = kz; p->icell = il; p->jcell = 1; p->kcell = 1;
+    if (!p->inside) {
+        u1 = s->vfx[il-1] * kx + s->vfy[il-1] * ky + s->vfz[il-1] * kz;
+        p->xfreq = p->xfreq + u1;
+        p->xfreq_ref = p->xfreq * (s->Dfreq[il-1] / s->Dfreq_ref);
+        int ix = (int)floor((p->xfreq_ref - s->xfreq_min) / s->dxfreq) + 1;
+        if (ix >= 1 && ix <= s->nxfreq) { A->Jout[ix-1] += p->wgt; if (s->save_Jmu) add_to_Jmu(s, A, p, ix); }
+    }
+}
+/* raytrace_to_edge_amr (:265-344) and raytrace_to_dist_amr (:559-640, dist >= 0) */
+static double raytrace_to_edge_amr(const orc_sim *s, const photon_t *p, double dist, double *nsteps) {
+    const amr_t *a = &s->amr;
+    double x = p->x, y = p->y, z = p->z, kx = p->kx, ky = p->ky, kz = p->kz, tau = 0.0, d = 0.0, xfreq = p->xfreq;
+    int il = p->icell;
+    if (il <= 0) { il = amr_find_leaf(a, x, y, z); if (il <= 0) return tau; }
+    double u1 = s->vfx[il-1] * kx + s->vfy[il-1] * ky + s->vfz[il-1] * kz, u2;
+    for (;;) {
+        int ic = a->icell_of_leaf[il-1], iface; double t_exit;
+        amr_cell_exit(a, ic, x, y, z, kx, ky, kz, &t_exit, &iface);
+        double rhokap = s->rhokap[il-1] * orc_voigt(xfreq, s->voigt_a[il-1]);
+        if (s->DGR > 0.0) rhokap = rhokap + s->rhokapD[il-1];
+        if (nsteps) *nsteps += 1.0;
+        if (dist >= 0.0 && d + t_exit >= dist) { tau = tau + (dist - d) * rhokap; return tau; }
+        tau = tau + t_exit * rhokap;
+        if (tau >= TAU_HUGE) return tau;
+        d = d + t_exit; x = x + t_exit * kx; y = y + t_exit * ky; z = z + t_exit * kz;
+        int il_new = amr_next_leaf(a, ic, iface, x, y, z), reflected = 0;
+        if (il_new <= 0) il_new = amr_boundary(s, il, iface, &kx, &ky, &kz, &reflected);
+        if (il_new <= 0) return tau;
+        u2 = s->vfx[il_new-1] * kx + s->vfy[il_new-1] * ky + s->vfz[il_new-1] * kz;
+        if (reflected) xfreq = (xfreq + u1) - u2; else xfreq = (xfreq + u1) * s->Dfreq[il-1] / s->Dfreq[il_new-1] - u2;
+        u1 = u2; il = il_new;
+    }
 }
 
 /* =====================================================================================
@@ -880,6 +1225,7 @@ static void add_to_Jmu(const orc_sim *s, acc_t *A, const photon_t *p, int ix) { 
 
 /* raytrace_to_tau_car (:1425-1648), _car_xyzsym (:1650-1949), _car_zonly (:2519-2675) */
 static void raytrace_to_tau(const orc_sim *s, acc_t *A, photon_t *p, double tau_in, int variant) {
+    if (variant == 3) { raytrace_to_tau_amr(s, A, p, tau_in); return; }
     trav_t t; double xp = p->x, yp = p->y, zp = p->z;
     t.kx = p->kx; t.ky = p->ky; t.kz = p->kz; t.icell = p->icell; t.jcell = p->jcell; t.kcell = p->kcell;
     if (variant == 0) { if (setup_traversal_car(s, xp, yp, zp, &t)) { p->inside = 0; return; } }
@@ -951,6 +1297,7 @@ static void raytrace_to_tau(const orc_sim *s, acc_t *A, photon_t *p, double tau_
 /* raytrace_to_edge_car (:410-508), _car_xyzsym (:584-781), _car_zonly (:1138-1234); dist >= 0 selects
  * raytrace_to_dist_car (:89-195) on the plain grid */
 static double raytrace_to_edge(const orc_sim *s, const photon_t *p, int variant, double dist, double *nsteps) {
+    if (variant == 3) return raytrace_to_edge_amr(s, p, dist, nsteps);
     trav_t t; double xp = p->x, yp = p->y, zp = p->z, tau = 0.0, d = 0.0;
     t.kx = p->kx; t.ky = p->ky; t.kz = p->kz; t.icell = p->icell; t.jcell = p->jcell; t.kcell = p->kcell;
     if (variant == 0) { if (setup_traversal_car(s, xp, yp, zp, &t)) return tau; }
@@ -1000,6 +1347,7 @@ static double raytrace_to_edge(const orc_sim *s, const photon_t *p, int variant,
 
 /* car_xcrit_local: grid_mod_car.f90:1598-1629 */
 static void car_xcrit_local(const orc_sim *s, int i, int j, int k, double x, double y, double z, double *xc, double *xc2) {
+    if (s->use_amr_grid) { amr_xcrit_local(s, i, x, y, z, xc, xc2); return; }
     if (s->core_skip_global) { *xc = s->xcrit; *xc2 = s->xcrit2; return; }
     *xc = 0.0; *xc2 = 0.0;
     if (i < 1 || j < 1 || k < 1) return;
@@ -1338,9 +1686,10 @@ static void scattering(const orc_sim *s, acc_t *A, rng_t *g, photon_t *p) {
 /* setup_isotropic_injection: generate_photon.f90:342-408 */
 static void setup_isotropic_injection(const orc_sim *s, rng_t *g, photon_t *p) {
     p->wgt = 1.0;
-    if (s->xyz_symmetry) { if (p->x < s->xmin) p->x = -p->x; if (p->y < s->ymin) p->y = -p->y; if (p->z < s->zmin) p->z = -p->z; }
+    if (!s->use_amr_grid && s->xyz_symmetry) { if (p->x < s->xmin) p->x = -p->x; if (p->y < s->ymin) p->y = -p->y; if (p->z < s->zmin) p->z = -p->z; }
     double cost = 2.0 * rnd(g) - 1.0, sint = sqrt(1.0 - cost * cost), phi = TWOPI * rnd(g), cosp = cos(phi), sinp = sin(phi);
     p->kx = sint * cosp; p->ky = sint * sinp; p->kz = cost;
+    if (s->use_amr_grid) { p->icell = amr_find_leaf(&s->amr, p->x, p->y, p->z); p->jcell = 1; p->kcell = 1; goto triad; }   /* :375-379 */
     p->icell = (int)floor((p->x - s->xmin) / s->dx) + 1; p->jcell = (int)floor((p->y - s->ymin) / s->dy) + 1; p->kcell = (int)floor((p->z - s->zmin) / s->dz) + 1;
     if (p->kx < 0.0 && p->icell == s->nx + 1) p->icell = s->nx;
     if (p->ky < 0.0 && p->jcell == s->ny + 1) p->jcell = s->ny;
@@ -1348,6 +1697,7 @@ static void setup_isotropic_injection(const orc_sim *s, rng_t *g, photon_t *p) {
     if (p->kx > 0.0 && p->icell < 1) p->icell = 1;
     if (p->ky > 0.0 && p->jcell < 1) p->jcell = 1;
     if (p->kz > 0.0 && p->kcell < 1) p->kcell = 1;
+triad:
     if (s->use_stokes) { p->mx = cost * cosp; p->my = cost * sinp; p->mz = -sint; p->nx = -sinp; p->ny = cosp; p->nz = 0.0; p->I = 1.0; p->Q = 0.0; p->U = 0.0; p->V = 0.0; }
 }
 /* generate_photon: generate_photon.f90:3-339 (point / uniform_sphere sources, voigt / monochromatic spectra) */
@@ -1493,7 +1843,9 @@ double orc_get_scalar(const orc_sim *s, const char *k) {
     G(rmax) G(xmax) G(ymax) G(zmax) G(DGR) G(albedo) G(hgg) G(cext_dust) G(cross0) G(g_recoil0) G(xcrit) G(raytrace_variant) G(save_peeloff)
     G(use_stokes) G(nPDF) G(save_Jabs) G(nmu) G(mu_min) G(dmu) G(distance2cm) G(source_rmax) G(comoving_source) G(recoil) G(core_skip) G(core_skip_global)
     G(xyz_symmetry) G(xy_periodic) G(save_Jin) G(save_Jmu) G(use_reduced_wgt) G(xs_point) G(ys_point) G(zs_point) G(xfreq0) G(spectral_type) G(source_geometry)
-    G(save_peeloff_2D) G(save_peeloff_3D) G(E1) G(E2) G(E3) G(nbins) G(geometry_JPa) G(calc_J) G(calc_P) G(calc_Pnew) G(nside) G(npix)
+    if (!strcmp(k, "amr_ncells")) return s->amr.ncells; if (!strcmp(k, "amr_nleaf")) return s->amr.nleaf; if (!strcmp(k, "amr_levelmax")) return s->amr.levelmax;
+    if (!strcmp(k, "amr_dr_JPa")) return s->amr.dr_JPa; if (!strcmp(k, "amr_dz_JPa")) return s->amr.dz_JPa; if (!strcmp(k, "amr_boxlen")) return s->amr.L_box;
+    G(use_amr_grid) G(save_peeloff_2D) G(save_peeloff_3D) G(E1) G(E2) G(E3) G(nbins) G(geometry_JPa) G(calc_J) G(calc_P) G(calc_Pnew) G(nside) G(npix)
 #undef G
     return NAN;
 }
@@ -1514,6 +1866,14 @@ int64_t orc_get_array(const orc_sim *s, const char *k, double *out, int64_t n) {
     if (!strcmp(k, "xface")) return copy_out(s->xface, s->nx + 1, out, n);
     if (!strcmp(k, "yface")) return copy_out(s->yface, s->ny + 1, out, n);
     if (!strcmp(k, "zface")) return copy_out(s->zface, s->nz + 1, out, n);
+    if (s->use_amr_grid) { const amr_t *a = &s->amr;
+        if (!strcmp(k, "amr_cx")) return copy_out(a->cx, a->ncells, out, n); if (!strcmp(k, "amr_cy")) return copy_out(a->cy, a->ncells, out, n);
+        if (!strcmp(k, "amr_cz")) return copy_out(a->cz, a->ncells, out, n); if (!strcmp(k, "amr_ch")) return copy_out(a->ch, a->ncells, out, n);
+        const int *ia = NULL; int64_t cnt = 0;
+        if (!strcmp(k, "amr_children")) { ia = a->children; cnt = 8 * (int64_t)a->ncells; } else if (!strcmp(k, "amr_neighbor")) { ia = a->neighbor; cnt = 6 * (int64_t)a->ncells; }
+        else if (!strcmp(k, "amr_ileaf")) { ia = a->ileaf; cnt = a->ncells; } else if (!strcmp(k, "amr_icell_of_leaf")) { ia = a->icell_of_leaf; cnt = a->nleaf; }
+        else if (!strcmp(k, "amr_level")) { ia = a->level; cnt = a->ncells; } else if (!strcmp(k, "amr_parent")) { ia = a->parent; cnt = a->ncells; }
+        if (ia) { for (int64_t i = 0; i < cnt && i < n; i++) out[i] = ia[i]; return cnt; } }
     if (!strcmp(k, "J1")) return copy_out(s->J1, (int64_t)s->nxfreq * s->nbins, out, n);
     if (!strcmp(k, "P1")) return copy_out(s->P1, s->nbins, out, n);
     if (!strcmp(k, "P1_new")) return copy_out(s->P1_new, s->nbins, out, n);
@@ -1565,8 +1925,9 @@ void orc_raytrace_to_tau(orc_sim *s, int variant, double r[8], int ic[4], double
     r[0] = p.x; r[1] = p.y; r[2] = p.z; r[3] = p.kx; r[4] = p.ky; r[5] = p.kz; r[6] = p.xfreq; r[7] = p.wgt;
     ic[0] = p.icell; ic[1] = p.jcell; ic[2] = p.kcell; ic[3] = p.inside;
 }
+int orc_amr_find_leaf(const orc_sim *s, double x, double y, double z) { return s->use_amr_grid ? amr_find_leaf(&s->amr, x, y, z) : 0; }
 void orc_raytrace_to_edge(const orc_sim *s, int variant, const double r[8], const int ic[4], double *tau) { photon_t p; unpack(r, ic, &p); *tau = raytrace_to_edge(s, &p, variant, -1.0, 0); }
-void orc_raytrace_to_dist(const orc_sim *s, const double r[8], const int ic[4], double dist, double *tau) { photon_t p; unpack(r, ic, &p); *tau = raytrace_to_edge(s, &p, 0, dist, 0); }
+void orc_raytrace_to_dist(const orc_sim *s, const double r[8], const int ic[4], double dist, double *tau) { photon_t p; unpack(r, ic, &p); *tau = raytrace_to_edge(s, &p, s->use_amr_grid ? 3 : 0, dist, 0); }
 
 int64_t orc_scatter_event(orc_sim *s, double st[18], int ic[4], uint64_t seed, uint64_t id, uint64_t n0) {
     photon_t p; unpack(st, ic, &p);

@@ -67,6 +67,8 @@ void   orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t 
 /* ray marches on the sim's grid. r = [x,y,z,kx,ky,kz,xfreq,wgt], ic = [icell,jcell,kcell,inside] (1-based)
  * variant 0 = plain, 1 = xyz_symmetry, 2 = z-only */
 void   orc_raytrace_to_tau(orc_sim *, int variant, double r[8], int ic[4], double tau_in);
+/* amr_find_leaf (octree_mod.f90:149-171): 1-based leaf holding the point, 0 = outside the box */
+int orc_amr_find_leaf(const orc_sim *s, double x, double y, double z);
 void   orc_raytrace_to_edge(const orc_sim *, int variant, const double r[8], const int ic[4], double *tau);
 void   orc_raytrace_to_dist(const orc_sim *, const double r[8], const int ic[4], double dist, double *tau);
 int    orc_vec2pix(int nside, double vx, double vy, double vz);          /* healpix.f90:29-112 */

@@ -54,6 +54,7 @@ class Oracle:
             L.orc_raytrace_to_tau.argtypes = [_vp, _i, _vp, _vp, _d]
             L.orc_raytrace_to_edge.argtypes = [_vp, _i, _vp, _vp, _vp]
             L.orc_raytrace_to_dist.argtypes = [_vp, _vp, _vp, _d, _vp]
+            L.orc_amr_find_leaf.argtypes = [_vp, _d, _d, _d]
             L.orc_xcrit_local.restype = _d; L.orc_xcrit_local.argtypes = [_vp, _i, _i, _i, _d, _d, _d]
             L.orc_scatter_event.restype = _i64; L.orc_scatter_event.argtypes = [_vp, _vp, _vp, _u64, _u64, _u64]
             cls._lib = L
@@ -127,6 +128,9 @@ class Oracle:
     def raytrace_to_edge(self, variant, r, ic):
         r = np.array(r, dtype=np.float64); ic = np.array(ic, dtype=np.int32); t = _d()
         self.lib().orc_raytrace_to_edge(self.h, variant, _ptr(r), _ptr(ic), C.byref(t)); return t.value
+
+    def amr_find_leaf(self, x, y, z):
+        return int(self.lib().orc_amr_find_leaf(self.h, float(x), float(y), float(z)))
 
     def raytrace_to_dist(self, r, ic, dist):
         r = np.array(r, dtype=np.float64); ic = np.array(ic, dtype=np.int32); t = _d()

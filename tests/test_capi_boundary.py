@@ -94,7 +94,11 @@ def test_namelist_surface(built, tmp_path):
     bad.write_text("&parameters\n par%not_a_field = 1\n/\n")
     with pytest.raises(host.LartInputError):
         host.read_namelist(str(bad))
-    amr = tmp_path / "amr.in"
-    amr.write_text("&parameters\n par%use_amr_grid = .true.\n/\n")
+    clump = tmp_path / "clump.in"
+    clump.write_text("&parameters\n par%use_clump_medium = .true.\n/\n")
     with pytest.raises(host.LartInputError, match="not supported"):
-        host.read_namelist(str(amr))
+        host.read_namelist(str(clump))
+    amr = tmp_path / "amr.in"
+    amr.write_text("&parameters\n par%use_amr_grid = .true.\n par%amr_type = 'generic'\n par%amr_file = 'leaves.dat'\n/\n")
+    par = host.read_namelist(str(amr))
+    assert par.use_amr_grid and par.amr_file == "leaves.dat"

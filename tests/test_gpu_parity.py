@@ -283,3 +283,98 @@ def test_profiles_and_healpix_whole_path(capi, oracle_mod):
     assert abs(t["direc"].sum() - o.array("direc:0").sum()) <= 0.01 * o.array("direc:0").sum() + 1e-12
     out = sim.output_normalize(t)
     assert np.all(np.isfinite(out["J1"])) and out["P1"].shape == (nb,)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# octree (AMR) medium: raytrace_amr.f90 / scattering_amr.f90 on the device (variant 3)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def amr_file(tmp_path_factory):
+    from lart_amd import amr
+    d = amr.make_amr_sphere(level_min=2, level_max=5)
+    fn = str(tmp_path_factory.mktemp("amr") / "sphere_small.dat")
+    amr.write_generic_amr(fn, d)
+    return fn
+
+
+def test_ray_marches_amr_device_vs_oracle(capi, oracle_mod, amr_file):
+    kw = dict(use_amr_grid=True, amr_file=amr_file, temperature=1e4, taumax=1e2, rmax=1.0, nxfreq=61, velocity_type="hubble", Vexp=40.0)
+    sim = make(kw); o = oracle_of(oracle_mod, kw)
+    rng = np.random.default_rng(11); n = 4000
+    pos = rng.uniform(-0.95, 0.95, (n, 3)); k = rng.normal(size=(n, 3)); k /= np.linalg.norm(k, axis=1)[:, None]
+    k[:30] = np.eye(3)[rng.integers(0, 3, 30)] * rng.choice([-1.0, 1.0], 30)[:, None]            # axis-parallel rays (huge t on two axes)
+    r8 = np.column_stack([pos, k, rng.uniform(-5, 5, n), np.ones(n)])
+    ic4 = np.array([[o.amr_find_leaf(*p), 1, 1, 1] for p in pos], dtype=np.int32)
+    assert np.all(ic4[:, 0] >= 1)
+    tq = rng.exponential(30.0, n)
+    rg, icg, _ = sim.ctx.test_raytrace(0, 3, r8, ic4, tq)
+    _, _, tau_edge = sim.ctx.test_raytrace(1, 3, r8, ic4)
+    dq = rng.uniform(0.01, 1.5, n)
+    _, _, tau_dist = sim.ctx.test_raytrace(2, 3, r8, ic4, dq)
+    bad = 0
+    for i in range(n):
+        ro, ico = o.raytrace_to_tau(3, r8[i], ic4[i], tq[i])
+        assert np.array_equal(ico, icg[i]), i                                   # same leaf, same inside flag: integer work, bit-exact
+        assert np.allclose(rg[i], ro, rtol=1e-10, atol=1e-12), i
+        assert np.isclose(tau_edge[i], o.raytrace_to_edge(3, r8[i], ic4[i]), rtol=1e-10, atol=1e-13), i
+        assert np.isclose(tau_dist[i], o.raytrace_to_dist(r8[i], ic4[i], dq[i]), rtol=1e-10, atol=1e-13), i
+
+
+@pytest.mark.parametrize("extra", [dict(), dict(xyz_symmetry=True), dict(use_stokes=True, velocity_type="hubble", Vexp=20.0)])
+def test_amr_short_histories_photon_by_photon(capi, oracle_mod, amr_file, extra):
+    kw = dict(use_amr_grid=True, amr_file=amr_file, temperature=1e4, taumax=1e1, rmax=1.0, nxfreq=81, iseed=61, **extra)
+    n = 20000
+    sim = make(kw); sim.ctx.enable_photon_log(True); sim.run_simulation(n); t = sim.ctx.tallies()
+    o = oracle_of(oracle_mod, kw); o.run(n, seed=61)
+    ng, xg = sim.ctx.photon_log(n); no, xo = o.photon_log()
+    same = np.isclose(ng, no, rtol=1e-12, atol=0) & np.isclose(xg, xo, rtol=1e-7, atol=1e-9)
+    assert same.mean() > 0.97, same.mean()
+    assert t["nphotons_done"] == n
+    assert rms_diff(t["Jout"], o.array("Jout")) < 0.01
+    assert np.isclose(t["n_cellsteps"], o.scalar("n_cellsteps"), rtol=0.02)     # the same leaves are visited
+
+
+def test_amr_profiles_peel_and_known_answer(capi, oracle_mod, amr_file):
+    """octree + radial J/P profiles + a far observer, against the oracle on the same streams; then the reference's
+    logged <N_scatt> = 2.8225E+04 (examples/amr_sphere_generic/log_amr_1M.txt) at tau0 = 1e4"""
+    kw = dict(use_amr_grid=True, amr_file=amr_file, temperature=1e4, taumax=3e2, rmax=1.0, nxfreq=61, nxim=8, nyim=8, save_peeloff_2D=True,
+              calc_J=True, calc_P=True, calc_Pnew=True, iseed=71)
+    n = 30000
+    sim = make(kw); sim.run_simulation(n); t = sim.ctx.tallies()
+    o = oracle_of(oracle_mod, kw); o.run(n, seed=71)
+    assert sim.jpa.nbins == int(o.scalar("nbins")) == 16
+    for name in ("P1", "P1_new"):
+        a, b = t[name], o.array(name)
+        assert np.allclose(a, b, rtol=0.03, atol=2e-3 * b.max()), name
+    assert rms_diff(t["J1"].ravel(order="F"), o.array("J1")) < 0.01
+    sc_g, sc_o = t["scatt"][..., 0], o.array("scatt:0").reshape((61, 8, 8), order="F")
+    assert rms_diff(sc_g.sum(axis=(1, 2)), sc_o.sum(axis=(1, 2))) < 0.02
+    assert abs(t["direc"].sum() - o.array("direc:0").sum()) <= 0.01 * o.array("direc:0").sum() + 1e-12
+    out = sim.output_normalize(t)
+    assert np.all(np.isfinite(out["J1"])) and np.all(np.isfinite(out["P1"]))
+    kw2 = dict(use_amr_grid=True, amr_file=amr_file, temperature=1e4, taumax=1e4, rmax=1.0, nxfreq=121, iseed=72)
+    n2 = 20000
+    s2 = make(kw2); s2.ctx.enable_photon_log(True); s2.run_simulation(n2)
+    ns, _ = s2.ctx.photon_log(n2)
+    assert abs(ns.mean() - 2.8225e4) < 0.02 * 2.8225e4 + 4 * ns.std() / np.sqrt(n2), ns.mean()
+
+
+def test_amr_boundary_errors(capi, amr_file):
+    """the octree setter validates every index the kernels follow (a bad table must not reach the device)"""
+    sim = make(dict(use_amr_grid=True, amr_file=amr_file, temperature=1e4, taumax=10.0, rmax=1.0))
+    a = sim.amr
+    args = [a.xmin, a.xmax, a.cx, a.cy, a.cz, a.ch, a.children, a.neighbor, a.ileaf, a.icell_of_leaf, a.rhokap, a.voigt_a, a.Dfreq, a.vfx, a.vfy, a.vfz]
+    bad = a.children.copy(); bad[0, 0] = a.ncells + 5
+    with pytest.raises(RuntimeError, match="children"):
+        sim.ctx.set_grid_amr(*args[:6], bad, *args[7:])
+    bad = a.neighbor.copy(); bad[2, 3] = -1
+    with pytest.raises(RuntimeError, match="neighbor"):
+        sim.ctx.set_grid_amr(*args[:7], bad, *args[8:])
+    bad = a.icell_of_leaf.copy(); bad[[0, 1]] = bad[[1, 0]]
+    with pytest.raises(RuntimeError, match="inverse"):
+        sim.ctx.set_grid_amr(*args[:9], bad, *args[10:])
+    with pytest.raises(RuntimeError, match="octree"):
+        sim.ctx.set_JPa(True, False, False, 4, np.ones(a.nleaf, dtype=np.int32), 1e-13)
+    sim.ctx.set_grid_amr(*args)                                                     # a valid table still goes through
+    sim.run_simulation(2000)
+    assert sim.ctx.tallies()["nphotons_done"] == 2000
