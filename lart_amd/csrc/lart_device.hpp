@@ -9,6 +9,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/lart_gpu.h"
+#define LART_HD __device__ inline
+#include "lart_math.hpp"
 
 #define LART_PI      3.141592653589793238462643383279502884197
 #define LART_TWOPI   6.283185307179586476925286766559005768394
@@ -114,41 +116,117 @@ __device__ inline Lds lds_stage(double *sh, const DGrid &g) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// elementary functions on the arguments this path produces (lart_math.hpp); -DLART_OCML_MATH = device library versions
+// ---------------------------------------------------------------------------------------------
+#ifdef LART_OCML_MATH
+__device__ inline double d_log(double x) { return log(x); }
+__device__ inline double d_tan(double x) { return tan(x); }
+__device__ inline void d_sincos_2pi(double u, double *s, double *c) { sincos(LART_TWOPI * u, s, c); }
+#else
+__device__ inline double d_log(double x) { return lartm::log_pos(x); }
+__device__ inline double d_tan(double x) { return lartm::tan_halfpi(x); }
+__device__ inline void d_sincos_2pi(double u, double *s, double *c) { lartm::sincos_2pi(u, s, c); }
+#endif
+
+// ---------------------------------------------------------------------------------------------
 // RNG
 // ---------------------------------------------------------------------------------------------
+// 32x32 -> 64 bit product in one quarter-rate instruction (the compiler emits v_mul_hi_u32 + v_mul_lo_u32)
+__device__ inline void mulhilo32(uint32_t k, uint32_t v, uint32_t &hi, uint32_t &lo) {
+#ifdef LART_PHILOX_PLAIN
+    hi = __umulhi(k, v); lo = k * v;
+#else
+    uint64_t p;
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(p) : "s"(k), "v"(v) : "vcc");
+    lo = (uint32_t)p; hi = (uint32_t)(p >> 32);
+#endif
+}
+// Philox4x32-10, key = seed, counter = (block, photon id): draw n of a packet is half (n & 1) of block n >> 1, so any
+// lane can produce any draw of its packet without state.  The photon loop uses that to take the generator out of the
+// divergent code: at the top of every event round ALL lanes of the wave fill a small per-lane buffer in LDS with the
+// next LART_RNG_BUF draws (full SIMD utilisation, LART_RNG_BUF/2 independent blocks interleaved for latency hiding), and
+// the rejection loops downstream read from it.  Values not consumed are simply produced again next round (same
+// counters, same values).  A lane that runs its buffer dry continues with single blocks (`slow` path); next2() needs
+// one block evaluation for two draws whatever the parity.
+#ifndef LART_RNG_BUF
+#define LART_RNG_BUF 12
+#endif
 struct Rng {
-    uint32_t k0, k1; uint64_t id, n; double spare;
+    uint32_t k0, k1; uint64_t id, n; double spare;          // spare: second half of the last slow block, valid while n is odd
+    double *lbuf = nullptr; uint32_t stride = 0, bi = LART_RNG_BUF;   // lbuf[j * stride] = draw (n - bi + j); bi >= LART_RNG_BUF: slow path
     __device__ inline void init(uint64_t seed, uint64_t pid, uint64_t n0) {
         k0 = (uint32_t)seed; k1 = (uint32_t)(seed >> 32); id = pid; n = n0 & ~1ULL; spare = 0.0;
+        bi = LART_RNG_BUF;                                    // nothing buffered: slow path until the next prefill()
         if (n0 & 1ULL) (void)next();
     }
+    __device__ inline void attach(double *lds_lane, uint32_t lds_stride) { lbuf = lds_lane; stride = lds_stride; bi = LART_RNG_BUF; }
     // open-interval uniform: (x>>12 + 0.5) / 2^52  (random_mt.f90:627-629)
     static __device__ inline double open01(uint32_t lo, uint32_t hi) {
         uint64_t x = ((uint64_t)hi << 32) | lo;
         return ((double)(x >> 12) + 0.5) * (1.0 / 4503599627370496.0);
     }
-    __device__ inline double next() {
-        uint64_t m = n++;
-        if (m & 1ULL) return spare;
-        uint64_t blk = m >> 1;
+    __device__ inline void block(uint64_t blk, double &first, double &second) const {
         uint32_t c0 = (uint32_t)blk, c1 = (uint32_t)(blk >> 32), c2 = (uint32_t)id, c3 = (uint32_t)(id >> 32);
         uint32_t a = k0, b = k1;
+        // rolled on purpose: inlined at every slow-path call site, and the ten rounds are one dependency chain anyway
+#ifdef LART_PHILOX_PLAIN
 #pragma unroll
+#else
+#pragma unroll 1
+#endif
         for (int r = 0; r < 10; r++) {
-            uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
-            uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+            uint32_t h0, l0, h1, l1;
+            mulhilo32(0xD2511F53u, c0, h0, l0); mulhilo32(0xCD9E8D57u, c2, h1, l1);
             uint32_t n0 = h1 ^ c1 ^ a, n2 = h0 ^ c3 ^ b;
             c0 = n0; c1 = l1; c2 = n2; c3 = l0;
             a += 0x9E3779B9u; b += 0xBB67AE85u;
         }
-        spare = open01(c2, c3);
-        return open01(c0, c1);
+        first = open01(c0, c1); second = open01(c2, c3);
+    }
+    // fill the lane's LDS buffer with draws [n & ~1, (n & ~1) + LART_RNG_BUF); call with the whole wave converged
+    __device__ inline void prefill() {
+        constexpr int NB = LART_RNG_BUF / 2;
+        uint64_t b0 = n >> 1;
+        uint32_t c0[NB], c1[NB], c2[NB], c3[NB];
+#pragma unroll
+        for (int j = 0; j < NB; j++) { uint64_t blk = b0 + j; c0[j] = (uint32_t)blk; c1[j] = (uint32_t)(blk >> 32); c2[j] = (uint32_t)id; c3[j] = (uint32_t)(id >> 32); }
+        uint32_t a = k0, b = k1;
+#pragma unroll 1
+        for (int r = 0; r < 10; r++) {
+#pragma unroll
+            for (int j = 0; j < NB; j++) {
+                uint32_t h0, l0, h1, l1;
+                mulhilo32(0xD2511F53u, c0[j], h0, l0); mulhilo32(0xCD9E8D57u, c2[j], h1, l1);
+                uint32_t n0 = h1 ^ c1[j] ^ a, n2 = h0 ^ c3[j] ^ b;
+                c0[j] = n0; c1[j] = l1; c2[j] = n2; c3[j] = l0;
+            }
+            a += 0x9E3779B9u; b += 0xBB67AE85u;
+        }
+#pragma unroll
+        for (int j = 0; j < NB; j++) { lbuf[(2 * j) * stride] = open01(c0[j], c1[j]); lbuf[(2 * j + 1) * stride] = open01(c2[j], c3[j]); }
+        bi = (uint32_t)(n & 1ULL);
+    }
+    __device__ inline double next() {
+        if (bi < LART_RNG_BUF) { double v = lbuf[bi * stride]; bi++; n++; return v; }
+        uint64_t m = n++;
+        if (m & 1ULL) return spare;
+        double first; block(m >> 1, first, spare);
+        return first;
+    }
+    // two consecutive draws; off the buffer this is ONE block evaluation for either parity of n
+    __device__ inline void next2(double &u1, double &u2) {
+        if (bi + 1 < LART_RNG_BUF) { u1 = lbuf[bi * stride]; u2 = lbuf[(bi + 1) * stride]; bi += 2; n += 2; return; }
+        bool odd = n & 1ULL;                                  // one buffered draw left <=> n odd (the buffer starts on an even draw)
+        double prev = (bi < LART_RNG_BUF) ? lbuf[bi * stride] : spare, first, second;
+        block((n + 1) >> 1, first, second);
+        if (odd) { u1 = prev; u2 = first; spare = second; } else { u1 = first; u2 = second; }
+        bi = LART_RNG_BUF; n += 2;
     }
     // Marsaglia polar pair (random_mt.f90:964-988); first = v2*rsq (what the reference returns first)
     __device__ inline double gauss_pair(double &second) {
         double v1, v2, rsq;
-        do { v1 = 2.0 * next() - 1.0; v2 = 2.0 * next() - 1.0; rsq = v1 * v1 + v2 * v2; } while (!(rsq > 0.0 && rsq < 1.0));
-        rsq = sqrt(-2.0 * log(rsq) / rsq);
+        do { double u1, u2; next2(u1, u2); v1 = 2.0 * u1 - 1.0; v2 = 2.0 * u2 - 1.0; rsq = v1 * v1 + v2 * v2; } while (!(rsq > 0.0 && rsq < 1.0));
+        rsq = sqrt(-2.0 * d_log(rsq) / rsq);
         second = v1 * rsq;
         return v2 * rsq;
     }
@@ -181,27 +259,58 @@ __device__ inline double voigt_H(const double *vt, double vin, double a) {
     return 0.56418958354775628695 * a * v2 * (1.0 + ((1.5 - a * a) + 3.75 * v2) * v2);
 }
 
+// packet state of one lane (photon_type, define.f90)
+struct Photon {
+    double x, y, z, kx, ky, kz, xfreq, wgt, nsg, nsd;
+    double mx, my, mz, nx, ny, nz, Q, U, V;
+    int ic, jc, kc; bool inside;
+    double xfreq_ref;
+#ifdef LART_PROFILE
+    long long pt[12], plast;       // tuning builds only: wave clocks per code section (prof_mark)
+    unsigned pc[4];                // wave-level trip counts
+#endif
+};
+// section timers of the tuning build (make SUFFIX=_prof EXTRA=-DLART_PROFILE): the clocks since the previous mark are
+// charged to section i.  0 pool load/store, 1 refill + birth, 2 tau draw + forced first scattering, 3 raytrace_to_tau,
+// 4 scatter: before the vz sampler, 5 vz sampler |x|<=1 loop, 6 scatter: after the vz sampler, 7 bookkeeping of finished
+// packets, 8 vz |x|>1 set-up, 9 vz |x|>1 loop, 10 vz |x|>1 final tangent.  LART_PROF_TRIP counts how often the WAVE runs a
+// loop body (first active lane counts): 0 |x|<=1 tries, 1 |x|>1 tries, 2 event rounds, 3 rounds that entered |x|>1
+#ifdef LART_PROFILE
+#define LART_PROF_MARK(p, i) do { long long t_ = clock64(); (p).pt[i] += t_ - (p).plast; (p).plast = t_; } while (0)
+#define LART_PROF_TRIP(p, i) do { if ((int)__lane_id() == __ffsll((long long)__ballot(1)) - 1) (p).pc[i]++; } while (0)
+#define LART_PROF_ARG(p) , Photon &p
+#define LART_PROF_PASS(p) , p
+#else
+#define LART_PROF_MARK(p, i) do { } while (0)
+#define LART_PROF_TRIP(p, i) do { } while (0)
+#define LART_PROF_ARG(p)
+#define LART_PROF_PASS(p)
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // samplers
 // ---------------------------------------------------------------------------------------------
 // atom velocity parallel to k: random_mt.f90:2562-2696 (rand_resonance_vz_seon)
-__device__ inline double rand_resonance_vz(Rng &g, double x0in, double a) {
+__device__ inline double rand_resonance_vz(Rng &g, double x0in, double a LART_PROF_ARG(pp)) {
     const double xc = 2.414213562373095048801688724209698, two_over_PI = 2.0 / LART_PI;
     double x0 = fabs(x0in), vz;
     if (x0 <= 1.0) {
         for (;;) {
-            vz = x0 + a * tan(LART_PI * (g.next() - 0.5));
-            if (g.next() <= exp(-(vz * vz))) break;
+            LART_PROF_TRIP(pp, 0);
+            double u1, u2; g.next2(u1, u2);
+            vz = x0 + a * d_tan(LART_PI * (u1 - 0.5));
+            if (u2 <= exp(-(vz * vz))) break;
         }
         return x0in < 0.0 ? -vz : vz;
     }
+    LART_PROF_MARK(pp, 5); LART_PROF_TRIP(pp, 3);
     double x0sq = x0 * x0, api = a * LART_PI, beta0 = exp(-x0sq / 2.0), h0_two = beta0 / a, h0 = h0_two / 2.0;
     // comparison function in beta-space: up to three segments [0,beta0) ~ beta/a, [beta0,beta1) = hA, [beta1,1) = hB
     double dbeta = 0.0, beta1 = beta0, hA = h0, hB, S0 = beta0 * h0, S1 = 0.0, S2;
     int mode;                                    // 0: single segment (uniform beta, Cb = h2); 1: segmented
     if (x0 < xc) {
         dbeta = sqrt(two_over_PI * a * (1.0 - beta0) * beta0 * x0); beta1 = beta0 + dbeta;
-        double pb1 = sqrt(-2.0 * log(beta1));
+        double pb1 = sqrt(-2.0 * d_log(beta1));
         hB = two_over_PI * beta1 * pb1 / (x0sq - pb1 * pb1);
         S1 = dbeta * h0; S2 = (1.0 - beta1) * hB; mode = 1;
     } else {
@@ -210,7 +319,7 @@ __device__ inline double rand_resonance_vz(Rng &g, double x0in, double a) {
         else if (h0 < h2) { mode = 1; hB = h2; S2 = (1.0 - beta0) * h2; }     // two segments: dbeta = 0
         else {
             dbeta = sqrt(two_over_PI * a * (1.0 - beta0) * beta0 * x0); beta1 = beta0 + dbeta;
-            double pb1 = sqrt(-2.0 * log(beta1));
+            double pb1 = sqrt(-2.0 * d_log(beta1));
             double h1 = two_over_PI * beta1 * pb1 / (x0sq - pb1 * pb1);
             hB = h1 > h2 ? h1 : h2;
             S1 = dbeta * h0; S2 = (1.0 - beta1) * hB; mode = 1;
@@ -218,39 +327,42 @@ __device__ inline double rand_resonance_vz(Rng &g, double x0in, double a) {
     }
     bool two_seg = (mode == 1 && dbeta == 0.0 && !(x0 < xc));
     double Stot = S0 + S1 + S2, t1, delt;
+    LART_PROF_MARK(pp, 8);
     for (;;) {
-        double beta, Cb;
-        if (mode == 0) { beta = g.next(); Cb = hB; }
-        else if (two_seg) {
-            if (g.next() < S0 / Stot) { beta = beta0 * sqrt(g.next()); Cb = beta / a; }
-            else                      { beta = beta0 + (1.0 - beta0) * g.next(); Cb = hB; }
-        } else {
-            double rS = g.next();
-            if (rS < S0 / Stot)             { beta = beta0 * sqrt(g.next()); Cb = beta / a; }
-            else if (rS < 1.0 - S2 / Stot)  { beta = beta0 + dbeta * g.next(); Cb = hA; }
-            else                            { beta = beta1 + (1.0 - beta1) * g.next(); Cb = hB; }
-        }
-        double pb = sqrt(-2.0 * log(beta));
+        LART_PROF_TRIP(pp, 1);
+        // segment pick rS (not drawn in single-segment mode), then one draw u inside the segment: same order of draws
+        // as the reference's three branches, two call sites instead of six
+        double beta, Cb, rS = 2.0, u, acc;
+        if (mode == 0) g.next2(u, acc); else { g.next2(rS, u); acc = g.next(); }
+        if (mode == 0) { beta = u; Cb = hB; }
+        else if (rS < S0 / Stot)                      { beta = beta0 * sqrt(u); Cb = beta / a; }
+        else if (two_seg)                             { beta = beta0 + (1.0 - beta0) * u; Cb = hB; }
+        else if (rS < 1.0 - S2 / Stot)                { beta = beta0 + dbeta * u; Cb = hA; }
+        else                                          { beta = beta1 + (1.0 - beta1) * u; Cb = hB; }
+        double pb = sqrt(-2.0 * d_log(beta));
         double t2 = atan((pb - x0) / a); t1 = atan((-pb - x0) / a); delt = t2 - t1;
-        if (g.next() * Cb < (beta / api) * delt) break;
+        if (acc * Cb < (beta / api) * delt) break;
     }
-    vz = x0 + a * tan(delt * g.next() + t1);
+    LART_PROF_MARK(pp, 9);
+    vz = x0 + a * d_tan(delt * g.next() + t1);
+    LART_PROF_MARK(pp, 10);
     return x0in < 0.0 ? -vz : vz;
 }
 // dipole/isotropic mix scattering angle: random_mt.f90:2974-2993
-__device__ inline double rand_resonance(Rng &g, double E1) {
+__device__ inline double rand_resonance_u(double u, double E1) {       // the same with the uniform draw handed in
     if (E1 > 0.0) {
         double p2 = sqrt((4.0 - E1) / (3.0 * E1));
-        double Q = (4.0 * g.next() - 2.0) / (E1 * (p2 * p2 * p2));
+        double Q = (4.0 * u - 2.0) / (E1 * (p2 * p2 * p2));
         double W = cbrt(Q + sqrt(Q * Q + 1.0));
         return p2 * (W - 1.0 / W);
     } else if (E1 < 0.0) {
         double p2 = sqrt(fabs((4.0 - E1) / (3.0 * E1)));
-        double Q = (4.0 * g.next() - 2.0) / (E1 * (p2 * p2 * p2));
+        double Q = (4.0 * u - 2.0) / (E1 * (p2 * p2 * p2));
         return 2.0 * p2 * cos((acos(Q) + LART_FOURPI) / 3.0);
     }
-    return 2.0 * g.next() - 1.0;
+    return 2.0 * u - 1.0;
 }
+__device__ inline double rand_resonance(Rng &g, double E1) { return rand_resonance_u(g.next(), E1); }
 // Henyey-Greenstein: random_mt.f90:3022-3042
 __device__ inline double rand_hg(Rng &g, double gg) {
     double x = g.next();
@@ -283,12 +395,6 @@ __device__ inline double rand_alias_linear(Rng &g, const DMueller &m) {
 // ---------------------------------------------------------------------------------------------
 // photon packet (registers)
 // ---------------------------------------------------------------------------------------------
-struct Photon {
-    double x, y, z, kx, ky, kz, xfreq, wgt, nsg, nsd;
-    double mx, my, mz, nx, ny, nz, Q, U, V;
-    int ic, jc, kc; bool inside;
-    double xfreq_ref;
-};
 
 __device__ inline size_t cidx(const DGrid &g, int i, int j, int k) {
     return (size_t)(i - 1) + (size_t)g.nx * ((size_t)(j - 1) + (size_t)g.ny * (size_t)(k - 1));
@@ -858,14 +964,16 @@ __device__ inline void rotate_triad(Photon &p, double cost, double sint, double 
     p.mx = cost * px - sint * p.kx; p.my = cost * py - sint * p.ky; p.mz = cost * pz - sint * p.kz;
     p.kx = sint * px + cost * p.kx; p.ky = sint * py + cost * p.ky; p.kz = sint * pz + cost * p.kz;
 }
-// azimuth by rejection on 1 + S12/S11 (Q cos 2phi + U sin 2phi): :364-371
-__device__ inline double phi_rejection(Rng &g, const Photon &p, double r) {
+// azimuth by rejection on 1 + S12/S11 (Q cos 2phi + U sin 2phi): :364-371.  Returns sin/cos of the accepted phi = 2 pi u;
+// the double angle comes from the same pair (cos 2phi = (c-s)(c+s), sin 2phi = 2sc), one sincos per try.
+__device__ inline void phi_rejection(Rng &g, const Photon &p, double r, double &sinp, double &cosp) {
     double amp = 1.0 + fabs(r) * sqrt(p.Q * p.Q + p.U * p.U);
     for (;;) {
-        double phi = LART_TWOPI * g.next(), s2, c2;
-        double Prand = amp * g.next();
-        sincos(2.0 * phi, &s2, &c2);
-        if (Prand <= 1.0 + r * (p.Q * c2 + p.U * s2)) return phi;
+        double u, u2; g.next2(u, u2);
+        double Prand = amp * u2, s, c;
+        d_sincos_2pi(u, &s, &c);
+        double c2 = (c - s) * (c + s), s2 = 2.0 * s * c;
+        if (Prand <= 1.0 + r * (p.Q * c2 + p.U * s2)) { sinp = s; cosp = c; return; }
     }
 }
 // dust absorption / reduced weight: :504-555 (= :217-264). true when the packet is destroyed
@@ -904,7 +1012,7 @@ __device__ inline void scatter_event(const KArgs &A, const Lds &l, Rng &g, Photo
                 const DMueller &m = A.mu;
                 double S11 = interp_eq(m.nPDF, m.coss, m.S11, cost), S12 = interp_eq(m.nPDF, m.coss, m.S12, cost);
                 double S33 = interp_eq(m.nPDF, m.coss, m.S33, cost), S34 = interp_eq(m.nPDF, m.coss, m.S34, cost);
-                double phi = phi_rejection(g, p, S12 / S11), sinp, cosp; sincos(phi, &sinp, &cosp);
+                double sinp, cosp; phi_rejection(g, p, S12 / S11, sinp, cosp);
                 double cos2p = 2.0 * cosp * cosp - 1.0, sin2p = 2.0 * sinp * cosp;
                 double Q0 = cos2p * p.Q + sin2p * p.U, U0 = -sin2p * p.Q + cos2p * p.U;
                 double I1 = S11 + S12 * Q0, Q1 = S12 + S11 * Q0, U1 = S33 * U0 + S34 * p.V, V1 = -S34 * U0 + S33 * p.V;
@@ -913,7 +1021,7 @@ __device__ inline void scatter_event(const KArgs &A, const Lds &l, Rng &g, Photo
             } else {                                           // scatter_dust_nostokes :488-584
                 if (PEEL) peel_dust_nostokes<VAR>(A, l, p, npeel);
                 double cost = rand_hg(g, par.hgg), sint = sqrt(1.0 - cost * cost);
-                double phi = LART_TWOPI * g.next(), sinp, cosp; sincos(phi, &sinp, &cosp);
+                double sinp, cosp; d_sincos_2pi(g.next(), &sinp, &cosp);
                 rotate_k(p, cost, sint, cosp, sinp);
             }
             return;
@@ -926,26 +1034,31 @@ __device__ inline void scatter_event(const KArgs &A, const Lds &l, Rng &g, Photo
         if (ib >= 1) atomicAdd(&A.jpa.P1[ib - 1], p.wgt / (c.rhokap * c.Dfreq / A.jpa.cross0));
     }
     // do_resonance1: line_mod.f90:108-139
-    double uz = rand_resonance_vz(g, p.xfreq, va);
+    LART_PROF_MARK(p, 4);
+    double uz = rand_resonance_vz(g, p.xfreq, va LART_PROF_PASS(p));
+    LART_PROF_MARK(p, 5);
     double xfreq_atom = p.xfreq - uz;
-    double cost = rand_resonance(g, par.E1), cost2 = cost * cost, sint = sqrt(1.0 - cost2);
-    double S11 = 0, S22 = 0, S12 = 0, S33 = 0, S44 = 0, phi;
+    double S11 = 0, S22 = 0, S12 = 0, S33 = 0, S44 = 0, sinp, cosp, cost, cost2, sint;
     if (STOKES) {
+        cost = rand_resonance(g, par.E1); cost2 = cost * cost; sint = sqrt(1.0 - cost2);
         S22 = 0.75 * par.E1 * (cost2 + 1.0); S11 = S22 + par.E2; S12 = 0.75 * par.E1 * (cost2 - 1.0); S33 = 1.5 * par.E1 * cost; S44 = 1.5 * par.E3 * cost;
-        phi = phi_rejection(g, p, S12 / S11);
-    } else phi = LART_TWOPI * g.next();
-    double sinp, cosp; sincos(phi, &sinp, &cosp);
+        phi_rejection(g, p, S12 / S11, sinp, cosp);
+    } else {
+        double ud, up; g.next2(ud, up);                       // polar angle, then azimuth: the reference's order of draws
+        cost = rand_resonance_u(ud, par.E1); cost2 = cost * cost; sint = sqrt(1.0 - cost2);
+        d_sincos_2pi(up, &sinp, &cosp);
+    }
     // perpendicular atom velocity; truncated tail when core-skipping (:726-752, :400-430)
     double ux, uy, xc = 0.0, xc2 = 0.0;
     if (par.core_skip) { if (VAR == 3) xcrit_local_amr(A, p, xc, xc2); else xcrit_local(par, A.g, l, p, xc, xc2); }
     if (par.core_skip && fabs(p.xfreq) < xc) {
-        double phi2 = LART_TWOPI * g.next(), uxy = sqrt(xc2 - log(g.next())), s2, c2; sincos(phi2, &s2, &c2);
+        double u2, u3; g.next2(u2, u3); double uxy = sqrt(xc2 - d_log(u3)), s2, c2; d_sincos_2pi(u2, &s2, &c2);
         ux = uxy * c2; uy = uxy * s2;
     } else if (STOKES) {
         double g2, g1 = g.gauss_pair(g2);
         ux = g1 * 0.70710678118654752440084436210485; uy = g2 * 0.70710678118654752440084436210485;
     } else {
-        double phi2 = LART_TWOPI * g.next(), uxy = sqrt(-log(g.next())), s2, c2; sincos(phi2, &s2, &c2);
+        double u2, u3; g.next2(u2, u3); double uxy = sqrt(-d_log(u3)), s2, c2; d_sincos_2pi(u2, &s2, &c2);
         ux = uxy * c2; uy = uxy * s2;
     }
     p.xfreq = xfreq_atom + uz * cost + (ux * cosp + uy * sinp) * sint;
@@ -970,14 +1083,14 @@ template <int VAR, bool STOKES, bool DUST, bool PEEL>
 __device__ inline void generate_photon(const KArgs &A, const Lds &l, Rng &g, Photon &p, unsigned &npeel) {
     const lart_params &par = A.par; const DGrid &gr = A.g;
     if (par.source_geometry == 1) {
-        double rp = cbrt(g.next()) * par.source_rmax, cost = 2.0 * g.next() - 1.0, sint = sqrt(1.0 - cost * cost), phi = LART_TWOPI * g.next(), sp, cp;
-        sincos(phi, &sp, &cp);
+        double rp = cbrt(g.next()) * par.source_rmax, cost = 2.0 * g.next() - 1.0, sint = sqrt(1.0 - cost * cost), sp, cp;
+        d_sincos_2pi(g.next(), &sp, &cp);
         p.x = rp * sint * cp; p.y = rp * sint * sp; p.z = rp * cost;
     } else { p.x = par.xs_point; p.y = par.ys_point; p.z = par.zs_point; }
     p.wgt = 1.0;
     if (VAR == 1) { if (p.x < gr.xmin) p.x = -p.x; if (p.y < gr.ymin) p.y = -p.y; if (p.z < gr.zmin) p.z = -p.z; }
-    double cost = 2.0 * g.next() - 1.0, sint = sqrt(1.0 - cost * cost), phi = LART_TWOPI * g.next(), sinp, cosp;
-    sincos(phi, &sinp, &cosp);
+    double cost = 2.0 * g.next() - 1.0, sint = sqrt(1.0 - cost * cost), sinp, cosp;
+    d_sincos_2pi(g.next(), &sinp, &cosp);
     p.kx = sint * cosp; p.ky = sint * sinp; p.kz = cost;
     if (VAR == 3) { p.ic = amr_find_leaf(A.amr, p.x, p.y, p.z); p.jc = 1; p.kc = 1; if (p.ic <= 0) p.ic = 1; }   // generate_photon.f90:375-379 (source inside the box)
     else {

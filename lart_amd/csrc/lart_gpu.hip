@@ -82,7 +82,7 @@ static int build_tally(lart_gpu *c) {
     int64_t nxf = p.nxfreq, nmu = p.save_Jmu ? p.nmu : 0;
     int64_t n2 = (int64_t)c->nobs * c->nxim * c->nyim, n3 = n2 * nxf;
     bool peel = p.save_peeloff && c->nobs > 0;
-    int64_t off = 16;
+    int64_t off = 32;                                       // scalars 0..6; 8..31 are section clocks / trip counts of -DLART_PROFILE builds
     int64_t oJout = off; off += nxf; int64_t oJin = off; off += nxf; int64_t oJabs = off; off += nxf; int64_t oJmu = off; off += nxf * nmu;
     int64_t o3[6], o2[6];
     for (int k = 0; k < 6; k++) { bool on = peel && p.save_peeloff_3D && (k < 2 || p.use_stokes); o3[k] = on ? off : -1; if (on) off += n3; }
@@ -360,7 +360,7 @@ extern "C" int lart_gpu_step(lart_gpu *c, int32_t nsteps, int32_t max_events) {
     int var = c->is_amr ? 3 : (c->par.xyz_symmetry ? 1 : (c->par.xy_periodic ? 2 : 0));     // setup.f90:961-990
     int stokes = c->par.use_stokes ? 1 : 0, dust = c->par.DGR > 0.0 ? 1 : 0, peel = (c->par.save_peeloff && c->nobs > 0) ? 1 : 0;
     dim3 block(c->block), grid((unsigned)(c->pool.n / c->block));
-    size_t shmem = (size_t)(VT_END + c->g.nx + c->g.ny + c->g.nz + 3) * sizeof(double);
+    size_t shmem = (size_t)(VT_END + c->g.nx + c->g.ny + c->g.nz + 3 + LART_RNG_BUF * c->block) * sizeof(double);
     if (shmem > 160 * 1024) return fail("step: grid faces do not fit the 160 KiB LDS");
     for (int s = 0; s < nsteps; s++) {
         hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
@@ -468,7 +468,7 @@ __global__ void k_test_rand(int what, unsigned long long seed, unsigned long lon
         double v, s2;
         switch (what) {
         case 0: v = g.next(); break;
-        case 1: v = rand_resonance_vz(g, p1, p2); break;
+        case 1: { Photon pp{}; v = rand_resonance_vz(g, p1, p2 LART_PROF_PASS(pp)); } break;
         case 2: v = rand_resonance(g, p1); break;
         case 3: v = rand_hg(g, p1); break;
         case 4: v = rand_voigt(g, p1); break;

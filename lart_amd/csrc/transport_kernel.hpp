@@ -22,12 +22,18 @@ template <int VAR, bool STOKES, bool DUST, bool PEEL>
 __global__ __launch_bounds__(256, LART_MIN_WAVES) void transport_kernel(KArgs A) {
     extern __shared__ double sh[];
     const Lds l = lds_stage(sh, A.g);
+    double *rng_lds = sh + VT_END + (A.g.nx + A.g.ny + A.g.nz + 3) + threadIdx.x;      // [LART_RNG_BUF][blockDim.x] draws
     const lart_params &par = A.par;
     const int64_t lane = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // pool.n is a multiple of blockDim.x
     const int64_t P = A.pool.n;
     double *F = A.pool.f;
 
-    Photon p; Rng g;
+    Photon p; Rng g; g.attach(rng_lds, blockDim.x);
+#ifdef LART_PROFILE
+    for (int i = 0; i < 12; i++) p.pt[i] = 0;
+    for (int i = 0; i < 4; i++) p.pc[i] = 0;
+    p.plast = clock64();
+#endif
     int flags = A.pool.flags[lane];
     bool alive = flags & FLAG_ALIVE, first = flags & FLAG_FIRST;
     long long k = A.pool.k[lane];
@@ -44,6 +50,7 @@ __global__ __launch_bounds__(256, LART_MIN_WAVES) void transport_kernel(KArgs A)
         g.init(A.seed, (uint64_t)(A.first_id + k * A.stride), A.pool.rng_n[lane]);
     }
 
+    LART_PROF_MARK(p, 0);
     unsigned nsteps = 0, npeel = 0, nev = 0, ndone = 0;
     double nsg_done = 0.0, nsd_done = 0.0;
     int budget = A.max_events;
@@ -56,8 +63,11 @@ __global__ __launch_bounds__(256, LART_MIN_WAVES) void transport_kernel(KArgs A)
             g.init(A.seed, (uint64_t)(A.first_id + k * A.stride), 0);
             generate_photon<VAR, STOKES, DUST, PEEL>(A, l, g, p, npeel);
             alive = true; first = true;
+            LART_PROF_MARK(p, 1);
         }
         if (budget <= 0) break;
+        g.prefill();
+        LART_PROF_TRIP(p, 2);
         double tau;
         if (first) {
             // forced first scattering: run_simulation_mod.f90:163-177, add_escaped_fraction_to_Jout :208-247
@@ -71,16 +81,20 @@ __global__ __launch_bounds__(256, LART_MIN_WAVES) void transport_kernel(KArgs A)
             }
             double wgt1 = 1.0 - esc;
             p.wgt = p.wgt * wgt1;
-            tau = (tau0 > 0.0) ? -log(1.0 - g.next() * wgt1) : LART_HUGEST;
+            tau = (tau0 > 0.0) ? -d_log(1.0 - g.next() * wgt1) : LART_HUGEST;
             first = false;
-        } else tau = -log(g.next());
+        } else tau = -d_log(g.next());
+        LART_PROF_MARK(p, 2);
         raytrace_to_tau<VAR>(A, l, DUST, p, tau, nsteps);
+        LART_PROF_MARK(p, 3);
         if (p.inside) { scatter_event<VAR, STOKES, DUST, PEEL>(A, l, g, p, npeel); nev++; budget--; }
+        LART_PROF_MARK(p, 6);
         if (!p.inside) {
             nsg_done += p.nsg; nsd_done += p.nsd; ndone++;
             if (A.log_nscatt) { A.log_nscatt[k] = p.nsg + p.nsd; A.log_xfreq[k] = p.xfreq_ref; }
             alive = false;
         }
+        LART_PROF_MARK(p, 7);
     }
 
     A.pool.flags[lane] = (alive ? FLAG_ALIVE : 0) | (first ? FLAG_FIRST : 0);
@@ -96,6 +110,11 @@ __global__ __launch_bounds__(256, LART_MIN_WAVES) void transport_kernel(KArgs A)
         }
         A.pool.ic[lane] = p.ic; A.pool.jc[lane] = p.jc; A.pool.kc[lane] = p.kc;
     }
+#ifdef LART_PROFILE
+    LART_PROF_MARK(p, 0);
+    if ((threadIdx.x & 63) == 0) for (int i = 0; i < 12; i++) atomicAdd(&A.t.scal[8 + i], (double)p.pt[i]);
+    for (int i = 0; i < 4; i++) { double v = wave_sum((double)p.pc[i]); if ((threadIdx.x & 63) == 0) atomicAdd(&A.t.scal[20 + i], v); }
+#endif
     // per-wave pre-reduction, one atomic per wave per scalar
     double s0 = wave_sum(nsg_done), s1 = wave_sum(nsd_done), s2 = wave_sum((double)nev), s3 = wave_sum((double)nsteps),
            s4 = wave_sum((double)npeel), s5 = wave_sum((double)ndone), s6 = wave_sum(alive ? 1.0 : 0.0);
@@ -114,4 +133,6 @@ __global__ __launch_bounds__(256, LART_MIN_WAVES) void transport_kernel(KArgs A)
 typedef void (*transport_launch_fn)(int stokes, int dust, int peel, dim3 grid, dim3 block, size_t shmem, hipStream_t st, const KArgs &A);
 
 #define LART_LAUNCH_CASE(VAR, S, D, P) \
-    if (stokes == S && dust == D && peel == P) { hipLaunchKernelGGL((transport_kernel<VAR, (bool)S, (bool)D, (bool)P>), grid, block, shmem, st, A); return; }
+    if (stokes == S && dust == D && peel == P) { \
+        if (shmem > 64 * 1024) (void)hipFuncSetAttribute((const void *)transport_kernel<VAR, (bool)S, (bool)D, (bool)P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
+        hipLaunchKernelGGL((transport_kernel<VAR, (bool)S, (bool)D, (bool)P>), grid, block, shmem, st, A); return; }

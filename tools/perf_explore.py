@@ -2,6 +2,8 @@
 """throughput of the transport kernel vs photon age / pool geometry on the headline workload (GPU box)."""
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+torch.cuda.init()            # before liblart_gpu touches HIP (torch's lazy init fails afterwards)
 import bench
 from lart_amd import host
 
@@ -35,5 +37,13 @@ for s in range(a.steps):
         prev, tprev = t, now
     if active == 0:
         break
+if os.environ.get("LART_GPU_LIB", "").endswith("_prof.so"):            # section clocks of the -DLART_PROFILE tuning build
+    ptr, nt = sim.ctx.tally_buffer()
+    buf = host._as_cuda_tensor(ptr, 32, sim.ctx).cpu().numpy()
+    sc, tr = buf[8:20], buf[20:24]
+    names = ["pool", "birth", "tau+first", "raytrace_to_tau", "scatter_pre", "vz_core_loop", "scatter_post", "finish", "vz_wing_setup", "vz_wing_loop", "vz_wing_tan", "-"]
+    print(json.dumps({"section_clock_share": {k: round(float(v / sc.sum()), 4) for k, v in zip(names, sc)},
+                      "wave_trips_per_round": {"core_tries": tr[0] / tr[2], "wing_tries": tr[1] / tr[2], "wing_entered": tr[3] / tr[2]},
+                      "clocks_per_round": float(sc.sum() / tr[2])}))
 ms, n = sim.ctx.kernel_time()
 print(json.dumps(dict(total_kernel_ms=ms, launches=n, total_events=prev["n_events"], overall_events_per_s=prev["n_events"] / (time.perf_counter() - t00))))
