@@ -121,10 +121,12 @@ __device__ inline Lds lds_stage(double *sh, const DGrid &g) {
 #ifdef LART_OCML_MATH
 __device__ inline double d_log(double x) { return log(x); }
 __device__ inline double d_tan(double x) { return tan(x); }
+__device__ inline double d_exp_neg(double x) { return exp(x); }
 __device__ inline void d_sincos_2pi(double u, double *s, double *c) { sincos(LART_TWOPI * u, s, c); }
 #else
 __device__ inline double d_log(double x) { return lartm::log_pos(x); }
 __device__ inline double d_tan(double x) { return lartm::tan_halfpi(x); }
+__device__ inline double d_exp_neg(double x) { return lartm::exp_neg(x); }
 __device__ inline void d_sincos_2pi(double u, double *s, double *c) { lartm::sincos_2pi(u, s, c); }
 #endif
 
@@ -149,7 +151,10 @@ __device__ inline void mulhilo32(uint32_t k, uint32_t v, uint32_t &hi, uint32_t 
 // counters, same values).  A lane that runs its buffer dry continues with single blocks (`slow` path); next2() needs
 // one block evaluation for two draws whatever the parity.
 #ifndef LART_RNG_BUF
-#define LART_RNG_BUF 12
+#define LART_RNG_BUF 16
+#endif
+#ifndef LART_PHILOX_ROUNDS
+#define LART_PHILOX_ROUNDS 10      // Philox4x32-10 (the KAT-pinned default of Salmon et al. 2011); tuning builds only change this to measure
 #endif
 struct Rng {
     uint32_t k0, k1; uint64_t id, n; double spare;          // spare: second half of the last slow block, valid while n is odd
@@ -174,7 +179,7 @@ struct Rng {
 #else
 #pragma unroll 1
 #endif
-        for (int r = 0; r < 10; r++) {
+        for (int r = 0; r < LART_PHILOX_ROUNDS; r++) {
             uint32_t h0, l0, h1, l1;
             mulhilo32(0xD2511F53u, c0, h0, l0); mulhilo32(0xCD9E8D57u, c2, h1, l1);
             uint32_t n0 = h1 ^ c1 ^ a, n2 = h0 ^ c3 ^ b;
@@ -183,27 +188,64 @@ struct Rng {
         }
         first = open01(c0, c1); second = open01(c2, c3);
     }
-    // fill the lane's LDS buffer with draws [n & ~1, (n & ~1) + LART_RNG_BUF); call with the whole wave converged
+    // fill the lane's LDS buffer with draws [n & ~1, (n & ~1) + LART_RNG_BUF); call with the whole wave converged.
+    // Blocks are named scalars (not arrays, which end up in scratch) and advance together round by round.
+    struct Ctr { uint32_t c0, c1, c2, c3; };
+    static __device__ inline void round1(Ctr &c, uint32_t a, uint32_t b) {
+        uint32_t h0, l0, h1, l1;
+        mulhilo32(0xD2511F53u, c.c0, h0, l0); mulhilo32(0xCD9E8D57u, c.c2, h1, l1);
+        uint32_t n0 = h1 ^ c.c1 ^ a, n2 = h0 ^ c.c3 ^ b;
+        c.c0 = n0; c.c1 = l1; c.c2 = n2; c.c3 = l0;
+    }
+    __device__ inline Ctr ctr_of(uint64_t blk) const { Ctr c; c.c0 = (uint32_t)blk; c.c1 = (uint32_t)(blk >> 32); c.c2 = (uint32_t)id; c.c3 = (uint32_t)(id >> 32); return c; }
+    __device__ inline void store2(int j, const Ctr &c) { lbuf[(2 * j) * stride] = open01(c.c0, c.c1); lbuf[(2 * j + 1) * stride] = open01(c.c2, c.c3); }
     __device__ inline void prefill() {
-        constexpr int NB = LART_RNG_BUF / 2;
+        static_assert(LART_RNG_BUF >= 8 && LART_RNG_BUF <= 16 && LART_RNG_BUF % 2 == 0, "LART_RNG_BUF must be even, 8..16");
         uint64_t b0 = n >> 1;
-        uint32_t c0[NB], c1[NB], c2[NB], c3[NB];
-#pragma unroll
-        for (int j = 0; j < NB; j++) { uint64_t blk = b0 + j; c0[j] = (uint32_t)blk; c1[j] = (uint32_t)(blk >> 32); c2[j] = (uint32_t)id; c3[j] = (uint32_t)(id >> 32); }
+        Ctr q0 = ctr_of(b0), q1 = ctr_of(b0 + 1), q2 = ctr_of(b0 + 2), q3 = ctr_of(b0 + 3);
+#if LART_RNG_BUF >= 10
+        Ctr q4 = ctr_of(b0 + 4);
+#endif
+#if LART_RNG_BUF >= 12
+        Ctr q5 = ctr_of(b0 + 5);
+#endif
+#if LART_RNG_BUF >= 14
+        Ctr q6 = ctr_of(b0 + 6);
+#endif
+#if LART_RNG_BUF >= 16
+        Ctr q7 = ctr_of(b0 + 7);
+#endif
         uint32_t a = k0, b = k1;
 #pragma unroll 1
-        for (int r = 0; r < 10; r++) {
-#pragma unroll
-            for (int j = 0; j < NB; j++) {
-                uint32_t h0, l0, h1, l1;
-                mulhilo32(0xD2511F53u, c0[j], h0, l0); mulhilo32(0xCD9E8D57u, c2[j], h1, l1);
-                uint32_t n0 = h1 ^ c1[j] ^ a, n2 = h0 ^ c3[j] ^ b;
-                c0[j] = n0; c1[j] = l1; c2[j] = n2; c3[j] = l0;
-            }
+        for (int r = 0; r < LART_PHILOX_ROUNDS; r++) {
+            round1(q0, a, b); round1(q1, a, b); round1(q2, a, b); round1(q3, a, b);
+#if LART_RNG_BUF >= 10
+            round1(q4, a, b);
+#endif
+#if LART_RNG_BUF >= 12
+            round1(q5, a, b);
+#endif
+#if LART_RNG_BUF >= 14
+            round1(q6, a, b);
+#endif
+#if LART_RNG_BUF >= 16
+            round1(q7, a, b);
+#endif
             a += 0x9E3779B9u; b += 0xBB67AE85u;
         }
-#pragma unroll
-        for (int j = 0; j < NB; j++) { lbuf[(2 * j) * stride] = open01(c0[j], c1[j]); lbuf[(2 * j + 1) * stride] = open01(c2[j], c3[j]); }
+        store2(0, q0); store2(1, q1); store2(2, q2); store2(3, q3);
+#if LART_RNG_BUF >= 10
+        store2(4, q4);
+#endif
+#if LART_RNG_BUF >= 12
+        store2(5, q5);
+#endif
+#if LART_RNG_BUF >= 14
+        store2(6, q6);
+#endif
+#if LART_RNG_BUF >= 16
+        store2(7, q7);
+#endif
         bi = (uint32_t)(n & 1ULL);
     }
     __device__ inline double next() {
@@ -299,12 +341,17 @@ __device__ inline double rand_resonance_vz(Rng &g, double x0in, double a LART_PR
             LART_PROF_TRIP(pp, 0);
             double u1, u2; g.next2(u1, u2);
             vz = x0 + a * d_tan(LART_PI * (u1 - 0.5));
-            if (u2 <= exp(-(vz * vz))) break;
+#ifdef LART_EXPERIMENT_DOUBLE_TRY                              // timing experiment: the arithmetic of a try done twice, same result
+            double vzb = x0 + a * d_tan(LART_PI * (u2 - 0.5));
+            if (u2 <= d_exp_neg(-(vz * vz)) + 0.0 * d_exp_neg(-(vzb * vzb))) break;
+#else
+            if (u2 <= d_exp_neg(-(vz * vz))) break;
+#endif
         }
         return x0in < 0.0 ? -vz : vz;
     }
     LART_PROF_MARK(pp, 5); LART_PROF_TRIP(pp, 3);
-    double x0sq = x0 * x0, api = a * LART_PI, beta0 = exp(-x0sq / 2.0), h0_two = beta0 / a, h0 = h0_two / 2.0;
+    double x0sq = x0 * x0, api = a * LART_PI, beta0 = d_exp_neg(-x0sq / 2.0), h0_two = beta0 / a, h0 = h0_two / 2.0;
     // comparison function in beta-space: up to three segments [0,beta0) ~ beta/a, [beta0,beta1) = hA, [beta1,1) = hB
     double dbeta = 0.0, beta1 = beta0, hA = h0, hB, S0 = beta0 * h0, S1 = 0.0, S2;
     int mode;                                    // 0: single segment (uniform beta, Cb = h2); 1: segmented
@@ -463,23 +510,25 @@ __device__ inline bool trav_setup(const DGrid &g, const Lds &l, double xp, doubl
 // returns false when the ray left the grid.
 template <int VAR>
 __device__ inline bool trav_cross(const DGrid &g, Trav &t, int idx) {
-    if (idx == 1) {
-        t.ic += t.is;
-        if (VAR == 1 && t.ic < 1) { t.ic = g.i0; t.is = 1; t.kx = -t.kx; }
-        else if (t.ic < 1 || t.ic > g.nx) return false;
-        t.tx += t.delx;
-    } else if (idx == 2) {
-        t.jc += t.js;
-        if (VAR == 1 && t.jc < 1) { t.jc = g.j0; t.js = 1; t.ky = -t.ky; }
-        else if (t.jc < 1 || t.jc > g.ny) return false;
-        t.ty += t.dely;
-    } else {
-        t.kc += t.ks;
-        if (VAR == 1 && t.kc < 1) { t.kc = g.k0; t.ks = 1; t.kz = -t.kz; }
-        else if (t.kc < 1 || t.kc > g.nz) return false;
-        t.tz += t.delz;
+    // value selects on purpose: the obvious three-way if() is merged by the compiler into pointer selects over the fields
+    // of `t`, which moves the whole traversal state into scratch memory
+    const bool ax = idx == 1, ay = idx == 2;
+    int cell = ax ? t.ic : (ay ? t.jc : t.kc), step = ax ? t.is : (ay ? t.js : t.ks);
+    const int n = ax ? g.nx : (ay ? g.ny : g.nz), m0 = ax ? g.i0 : (ay ? g.j0 : g.k0);
+    double k = ax ? t.kx : (ay ? t.ky : t.kz), tt = ax ? t.tx : (ay ? t.ty : t.tz);
+    const double del = ax ? t.delx : (ay ? t.dely : t.delz);
+    cell += step;
+    bool ok = true;
+    if (VAR == 1 && cell < 1) { cell = m0; step = 1; k = -k; }
+    else if (cell < 1 || cell > n) ok = false;
+    if (ok) tt += del;
+    t.ic = ax ? cell : t.ic; t.jc = ay ? cell : t.jc; t.kc = (!ax && !ay) ? cell : t.kc;
+    if (VAR == 1) {
+        t.is = ax ? step : t.is; t.js = ay ? step : t.js; t.ks = (!ax && !ay) ? step : t.ks;
+        t.kx = ax ? k : t.kx; t.ky = ay ? k : t.ky; t.kz = (!ax && !ay) ? k : t.kz;
     }
-    return true;
+    t.tx = ax ? tt : t.tx; t.ty = ay ? tt : t.ty; t.tz = (!ax && !ay) ? tt : t.tz;
+    return ok;
 }
 __device__ inline int minloc3(double a, double b, double c) { int m = 1; double v = a; if (b < v) { m = 2; v = b; } if (c < v) m = 3; return m; }
 
@@ -827,7 +876,7 @@ __device__ inline void peel_direct(const KArgs &A, const Lds &l, bool dust, cons
         int ixf = (int)floor((xfreq_ref - A.par.xfreq_min) / A.par.dxfreq) + 1;
         if (!q.in_image) continue;
         double tau = raytrace_to_edge<VAR>(A, l, dust, p, xf, q.kx, q.ky, q.kz, q.dist, nsteps);
-        double wgt = exp(-tau) * (1.0 / (LART_FOURPI * q.r2) * p.wgt);
+        double wgt = d_exp_neg(-tau) * (1.0 / (LART_FOURPI * q.r2) * p.wgt);
         if (A.par.save_peeloff_2D) { add_if(A.t.c2[1], pix2(A, i, q.ix, q.iy), wgt); if (A.par.use_stokes) add_if(A.t.c2[2], pix2(A, i, q.ix, q.iy), wgt); }
         if (A.par.save_peeloff_3D && ixf >= 1 && ixf <= A.par.nxfreq) { add_if(A.t.c3[1], pix3(A, i, ixf, q.ix, q.iy), wgt); if (A.par.use_stokes) add_if(A.t.c3[2], pix3(A, i, ixf, q.ix, q.iy), wgt); }
     }
@@ -849,7 +898,7 @@ __device__ inline void peel_resonance_nostokes(const KArgs &A, const Lds &l, boo
         int ixf = (int)floor((xfreq_ref - A.par.xfreq_min) / A.par.dxfreq) + 1;
         double tau = raytrace_to_edge<VAR>(A, l, dust, p, xfreq, q.kx, q.ky, q.kz, q.dist, nsteps);
         double peel = 0.75 * A.par.E1 * (cost2 + 1.0) + A.par.E2;
-        double wgt = peel / (LART_FOURPI * q.r2) * exp(-tau) * p.wgt;
+        double wgt = peel / (LART_FOURPI * q.r2) * d_exp_neg(-tau) * p.wgt;
         if (A.par.save_peeloff_2D) add_if(A.t.c2[0], pix2(A, i, q.ix, q.iy), wgt);
         if (A.par.save_peeloff_3D && ixf >= 1 && ixf <= A.par.nxfreq) add_if(A.t.c3[0], pix3(A, i, ixf, q.ix, q.iy), wgt);
     }
@@ -894,7 +943,7 @@ __device__ inline void peel_resonance_stokes(const KArgs &A, const Lds &l, bool 
         double cos2g = 2.0 * cosg * cosg - 1.0, sin2g = 2.0 * cosg * sing;
         double Qdet = cos2g * Qobs + sin2g * Uobs, Udet = -sin2g * Qobs + cos2g * Uobs;
         double tau = raytrace_to_edge<VAR>(A, l, dust, p, xfreq, q.kx, q.ky, q.kz, q.dist, nsteps);
-        double wgt = 1.0 / q.r2 * exp(-tau) * p.wgt;
+        double wgt = 1.0 / q.r2 * d_exp_neg(-tau) * p.wgt;
         stokes_deposit(A, i, q, ixf, wgt, Iobs, Qdet, Udet, Vobs);
     }
 }
@@ -912,7 +961,7 @@ __device__ inline void peel_dust_nostokes(const KArgs &A, const Lds &l, const Ph
         double cosa = p.kx * q.kx + p.ky * q.ky + p.kz * q.kz, hgg = A.par.hgg;
         double b = (1.0 + hgg * hgg) - 2.0 * hgg * cosa;
         double peel = (1.0 - hgg * hgg) / (b * sqrt(b)) / LART_FOURPI;
-        double wgt = peel / q.r2 * exp(-tau) * p.wgt;
+        double wgt = peel / q.r2 * d_exp_neg(-tau) * p.wgt;
         if (A.par.save_peeloff_2D) add_if(A.t.c2[0], pix2(A, i, q.ix, q.iy), wgt);
         if (A.par.save_peeloff_3D && ixf >= 1 && ixf <= A.par.nxfreq) add_if(A.t.c3[0], pix3(A, i, ixf, q.ix, q.iy), wgt);
     }
@@ -939,7 +988,7 @@ __device__ inline void peel_dust_stokes(const KArgs &A, const Lds &l, const Phot
         double cos2g = 2.0 * cosg * cosg - 1.0, sin2g = 2.0 * cosg * sing;
         double Qdet = cos2g * Qobs + sin2g * Uobs, Udet = -sin2g * Qobs + cos2g * Uobs;
         double tau = raytrace_to_edge<VAR>(A, l, true, p, p.xfreq, q.kx, q.ky, q.kz, q.dist, nsteps);
-        double wgt = 1.0 / q.r2 * exp(-tau) * p.wgt;
+        double wgt = 1.0 / q.r2 * d_exp_neg(-tau) * p.wgt;
         stokes_deposit(A, i, q, ixf, wgt, Iobs, Qdet, Udet, Vobs);
     }
 }

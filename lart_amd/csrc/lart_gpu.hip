@@ -296,7 +296,7 @@ static int ensure_pool(lart_gpu *c) {
     int64_t n = c->want_lanes;
     if (n <= 0) {
         hipDeviceProp_t pr; HIPCHK(hipGetDeviceProperties(&pr, c->device));
-        n = (int64_t)pr.multiProcessorCount * 1024;            // 16 waves per CU
+        n = (int64_t)pr.multiProcessorCount * 6144;            // 96 waves per CU: 6 full residencies at 4 waves/SIMD (lanes sweep in profiles/README.md)
     }
     if (c->count > 0 && n > c->count) n = c->count;
     if (n < c->block) n = c->block;

@@ -5,7 +5,7 @@
 // arguments: tan on (-pi/2, pi/2), sin/cos on 2*pi*u with u in (0,1), log on (0, 1].  These versions use the
 // classical Sun fdlibm kernels (minimax polynomials on [-pi/4, pi/4], log via s = f/(2+f)) with explicit fma,
 // so host (tests/test_fastmath_cpu.py, g++) and device produce the same bits.  Measured max error against
-// libm: tan <= 2.5 ulp, sin/cos <= 1 ulp (abs 2e-16 near zeros of the other), log <= 1 ulp.
+// libm: tan <= 2.6 ulp, sin/cos <= 1 ulp (abs 2e-16 near zeros of the other), log <= 1 ulp, exp_neg <= 1 ulp.
 //
 // LART_HD is empty for the host test build.
 #pragma once
@@ -19,20 +19,38 @@
 
 namespace lartm {
 
+// K(c): a coefficient held in a scalar register pair.  The compiler otherwise materialises every coefficient with two
+// v_mov_b32 in front of a two-address v_fmac_f64 (3 vector instructions per polynomial term, in loops that run a few
+// thousand times per packet); pinned to SGPRs the term is s_mov x2 on the scalar unit + one v_fma_f64.
+#if defined(__HIPCC__)
+__host__ __device__ inline double K(double v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#ifdef LART_K_HOISTABLE
+    asm("" : "+s"(v));
+#else
+    asm volatile("" : "+s"(v));
+#endif
+#endif
+    return v;
+}
+#else
+static inline double K(double v) { return v; }
+#endif
+
 // sin(x), |x| <= pi/4
 LART_HD double ksin(double x) {
     const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
                  S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
     double z = x * x, v = z * x;
-    double r = fma(z, fma(z, fma(z, fma(z, S6, S5), S4), S3), S2);
-    return fma(v, fma(z, r, S1), x);
+    double r = fma(z, fma(z, fma(z, fma(z, K(S6), K(S5)), K(S4)), K(S3)), K(S2));
+    return fma(v, fma(z, r, K(S1)), x);
 }
 // cos(x), |x| <= pi/4
 LART_HD double kcos(double x) {
     const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
                  C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
     double z = x * x, w = z * z;
-    double r = z * fma(z, fma(z, C3, C2), C1) + w * w * fma(z, fma(z, C6, C5), C4);
+    double r = fma(w * w, fma(z, fma(z, K(C6), K(C5)), K(C4)), z * fma(z, fma(z, K(C3), K(C2)), K(C1)));
     double hz = 0.5 * z, a = 1.0 - hz;
     return a + (((1.0 - a) - hz) + z * r);
 }
@@ -43,8 +61,8 @@ LART_HD double tan_halfpi(double t) {
     bool big = ax > pio4;
     double r = big ? (pio2_hi - ax) + pio2_lo : ax;       // pio2_hi - ax is exact on [pi/4, pi/2]
     double s = ksin(r), c = kcos(r);
-    double q = big ? c / s : s / c;
-    return copysign(q, t);
+    double num = big ? c : s, den = big ? s : c;           // one division for both halves of the range
+    return copysign(num / den, t);
 }
 // sin and cos of 2*pi*u, u in [0, 1]
 LART_HD void sincos_2pi(double u, double *sn, double *cs) {
@@ -71,10 +89,32 @@ LART_HD double log_pos(double x) {
     m = lo ? 2.0 * m : m; e = lo ? e - 1 : e;              // [sqrt(1/2), sqrt(2))
     double f = m - 1.0, k = (double)e;
     double s = f / (2.0 + f), z = s * s, w = z * z;
-    double t1 = w * fma(w, fma(w, Lg6, Lg4), Lg2);
-    double t2 = z * fma(w, fma(w, fma(w, Lg7, Lg5), Lg3), Lg1);
+    double t1 = w * fma(w, fma(w, K(Lg6), K(Lg4)), K(Lg2));
+    double t2 = z * fma(w, fma(w, fma(w, K(Lg7), K(Lg5)), K(Lg3)), K(Lg1));
     double R = t2 + t1, hfsq = 0.5 * f * f;
-    return fma(k, ln2_hi, -((hfsq - fma(s, hfsq + R, k * ln2_lo)) - f));
+    return fma(k, K(ln2_hi), -((hfsq - fma(s, hfsq + R, k * K(ln2_lo))) - f));
+}
+
+// exp(x) for x <= 0 (the acceptance test exp(-v^2) and the escape fractions exp(-tau)); 0 below the double range.
+// x = n ln2 + r, |r| <= ln2/2, degree-11 near-minimax polynomial (Chebyshev fit, |err| < 3.2e-18), then ldexp.
+LART_HD double exp_neg(double x) {
+    const double log2e = 1.44269504088896338700e+00, ln2_hi = 6.93147180559945286227e-01, ln2_lo = 2.31904681384629955842e-17;
+    x = fmax(x, -1100.0);                                  // keeps n in int range; exp(-1100) underflows to 0 anyway
+    double n = rint(x * K(log2e));
+    double r = fma(-n, K(ln2_hi), x);
+    r = fma(-n, K(ln2_lo), r);
+    double p = fma(r, K(2.5110037605963777712e-8), K(2.76326396390410297493e-7));
+    p = fma(r, p, K(2.7557240918578969823e-6));
+    p = fma(r, p, K(2.4801485482328492419e-5));
+    p = fma(r, p, K(1.98412698900471137067e-4));
+    p = fma(r, p, K(1.38888889523147746524e-3));
+    p = fma(r, p, K(8.33333333331960061091e-3));
+    p = fma(r, p, K(4.16666666664880954954e-2));
+    p = fma(r, p, K(1.66666666666666808057e-1));
+    p = fma(r, p, K(5.00000000000001838553e-1));
+    p = fma(r, p, 1.0);
+    p = fma(r, p, 1.0);
+    return ldexp(p, (int)n);
 }
 
 }  // namespace lartm

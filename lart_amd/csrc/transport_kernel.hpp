@@ -14,12 +14,17 @@ __device__ inline double wave_sum(double v) {
     return v;
 }
 
-#ifndef LART_MIN_WAVES
-#define LART_MIN_WAVES 2          // waves per SIMD the register allocator must leave room for
+// waves per SIMD the register allocator must leave room for.  Measured on the headline workload (profiles/README.md):
+// the plain kernel fits 128 VGPRs (4 waves) with a handful of spills and is fastest there; the Stokes triad adds ~30
+// registers, the peel-off rays ~40 more, and forcing those variants to 128 puts 200+ values in scratch.
+#ifdef LART_MIN_WAVES
+#define LART_WAVES(S, P) LART_MIN_WAVES
+#else
+#define LART_WAVES(S, P) ((P) ? 2 : ((S) ? 3 : 4))
 #endif
 
 template <int VAR, bool STOKES, bool DUST, bool PEEL>
-__global__ __launch_bounds__(256, LART_MIN_WAVES) void transport_kernel(KArgs A) {
+__global__ __launch_bounds__(256, LART_WAVES(STOKES, PEEL)) void transport_kernel(KArgs A) {
     extern __shared__ double sh[];
     const Lds l = lds_stage(sh, A.g);
     double *rng_lds = sh + VT_END + (A.g.nx + A.g.ny + A.g.nz + 3) + threadIdx.x;      // [LART_RNG_BUF][blockDim.x] draws
@@ -72,7 +77,7 @@ __global__ __launch_bounds__(256, LART_MIN_WAVES) void transport_kernel(KArgs A)
         if (first) {
             // forced first scattering: run_simulation_mod.f90:163-177, add_escaped_fraction_to_Jout :208-247
             double tau0 = raytrace_to_edge<VAR>(A, l, DUST, p, p.xfreq, p.kx, p.ky, p.kz, -1.0, nsteps);
-            double esc = exp(-tau0);
+            double esc = d_exp_neg(-tau0);
             {
                 const Cell &c = A.g.cell[cidx(A.g, p.ic, p.jc, p.kc)];
                 double u1 = c.vfx * p.kx + c.vfy * p.ky + c.vfz * p.kz;
