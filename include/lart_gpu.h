@@ -110,6 +110,34 @@ int  lart_gpu_set_grid_amr(lart_gpu *ctx, int32_t ncells, int32_t nleaf, double 
  * shells of width dbin (nbins of them), -1 = z slabs of width dbin from lo, 3 = one bin per leaf (nbins = nleaf). */
 int  lart_gpu_set_JPa_amr(lart_gpu *ctx, int32_t calc_J, int32_t calc_P, int32_t calc_Pnew, int32_t geometry_JPa, int32_t nbins, double dbin, double cross0);
 
+/* Clump medium as init_clumps leaves it (clump_mod.f90:646-891; arrays cl_x..cl_Dfreq :37-71, CSR grid :110-118):
+ * n spherical clumps in vacuum inside the sphere of radius sphere_R.  Per clump: centre x,y,z, bulk velocity vx,vy,vz in
+ * units of the clump's thermal speed, radius, line-centre opacity rhokap per unit length, dust opacity rhokapD (NULL when
+ * par.DGR = 0), voigt_a, Dfreq [Hz].  Dfreq_ref / voigt_a_ref = cl_Dfreq_ref / cl_voigt_a_ref (the units of xfreq and the
+ * uniform background record of grid_create_clump, grid_mod_clump.f90:101-113).  CSR acceleration grid: cgx^3 cells of edge
+ * cg_d from cg_min on every axis, cg_start[cgx^3+1] (1-based offsets, cg_start[0] = 1), cg_list[cg_start[cgx^3]-1] (1-based
+ * clump numbers).  Non-overlapping clumps only (has_overlap = .false.).  Replaces raytrace_to_{tau,edge}_clump[_capped],
+ * do_resonance1_clump and the clump branches of scattering / generate_photon / peeling_*_outside for the kernels. */
+int  lart_gpu_set_clumps(lart_gpu *ctx, int64_t n, const double *x, const double *y, const double *z,
+                         const double *vx, const double *vy, const double *vz, const double *radius,
+                         const double *rhokap, const double *rhokapD, const double *voigt_a, const double *Dfreq,
+                         double sphere_R, double Dfreq_ref, double voigt_a_ref,
+                         int32_t cgx, double cg_min, double cg_d, const int32_t *cg_start, const int32_t *cg_list);
+
+/* ---- host-side set-up helpers for the clump medium (CPU, no device): the per-clump loops of init_clumps ----
+ * lart_host_clumps_generate: generate_clumps, uniform path (clump_mod.f90:897-1151): n non-overlapping centres in the shell
+ *   [r_min, sphere_R] by random sequential adsorption with the reference's grid and its MT19937-64 stream seeded with
+ *   par%iseed (rank 0); sigma_v_over_vtherm = par%clump_sigma_v / cl_vtherm adds Gaussian bulk velocities (rand_gauss).
+ * lart_host_clumps_csr_dims / _build_csr: build_clump_csr (:1267-1360); call _build_csr with cg_list = NULL first to
+ *   learn the registration count.  Errors: non-zero + lart_host_last_error(). */
+const char *lart_host_last_error(void);
+int  lart_host_clumps_generate(int64_t n, double sphere_R, double r_min, double clump_radius, int32_t fully_inside,
+                               double sigma_v_over_vtherm, int64_t iseed, double *x, double *y, double *z,
+                               double *vx, double *vy, double *vz, double *acceptance);
+int  lart_host_clumps_csr_dims(int64_t n, double sphere_R, double radius_max, int32_t *cgx, double *cg_min, double *cg_d);
+int  lart_host_clumps_build_csr(int64_t n, const double *x, const double *y, const double *z, const double *radius,
+                                int32_t cgx, double cg_min, double cg_d, int32_t *cg_start, int32_t *cg_list, int64_t *nreg);
+
 /* replaces `call run_simulation(grid)` (main.f90:42): photons first_id, first_id+stride, ... (count of
  * them; the reference's static decomposition `do ip = rank+1, nphotons, nproc`, run_simulation_mod.f90:150).
  * The random stream of a photon depends only on (seed, id). Runs to completion. */

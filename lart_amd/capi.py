@@ -33,7 +33,7 @@ class LartTallies(C.Structure):
 
 SYMBOLS = ["lart_gpu_device_count", "lart_gpu_create", "lart_gpu_destroy", "lart_gpu_last_error",
            "lart_gpu_set_grid_car", "lart_gpu_set_mueller", "lart_gpu_set_observers", "lart_gpu_set_observers_heal",
-           "lart_gpu_set_JPa", "lart_gpu_set_grid_amr", "lart_gpu_set_JPa_amr", "lart_gpu_run",
+           "lart_gpu_set_JPa", "lart_gpu_set_grid_amr", "lart_gpu_set_JPa_amr", "lart_gpu_set_clumps", "lart_host_last_error", "lart_host_clumps_generate", "lart_host_clumps_csr_dims", "lart_host_clumps_build_csr", "lart_gpu_run",
            "lart_gpu_begin", "lart_gpu_step", "lart_gpu_sync", "lart_gpu_kernel_time",
            "lart_gpu_enable_photon_log", "lart_gpu_get_photon_log", "lart_gpu_set_pool", "lart_gpu_pool_info",
            "lart_gpu_tally_buffer", "lart_gpu_zero_tallies", "lart_gpu_get_tallies",
@@ -59,6 +59,11 @@ def lib():
         L.lart_gpu_set_JPa.argtypes = [_vp, _i32, _i32, _i32, _i32, _vp, _d]
         L.lart_gpu_set_grid_amr.argtypes = [_vp, _i32, _i32, _d, _d] + [_vp] * 15
         L.lart_gpu_set_JPa_amr.argtypes = [_vp, _i32, _i32, _i32, _i32, _i32, _d, _d]
+        L.lart_host_last_error.restype = C.c_char_p
+        L.lart_host_clumps_generate.argtypes = [_i64, _d, _d, _d, _i32, _d, _i64] + [_vp] * 7
+        L.lart_host_clumps_csr_dims.argtypes = [_i64, _d, _d, _vp, _vp, _vp]
+        L.lart_host_clumps_build_csr.argtypes = [_i64, _vp, _vp, _vp, _vp, _i32, _d, _d, _vp, _vp, _vp]
+        L.lart_gpu_set_clumps.argtypes = [_vp, _i64] + [_vp] * 11 + [_d, _d, _d, _i32, _d, _d, _vp, _vp]
         L.lart_gpu_test_vec2pix.argtypes = [_vp, _i32, _i32, _vp, _vp]
         L.lart_gpu_run.argtypes = [_vp, _i64, _i64, _i64, _u64]
         L.lart_gpu_begin.argtypes = [_vp, _i64, _i64, _i64, _u64]
@@ -167,6 +172,18 @@ class Context:
     def set_JPa_amr(self, calc_J, calc_P, calc_Pnew, geometry_JPa, nbins, dbin, cross0):
         _chk(lib().lart_gpu_set_JPa_amr(self.h, int(calc_J), int(calc_P), int(calc_Pnew), int(geometry_JPa), int(nbins), float(dbin), cross0))
         self.nbins = nbins; self.jpa = (int(calc_J), int(calc_P), int(calc_Pnew))
+
+    def set_clumps(self, x, y, z, vx, vy, vz, radius, rhokap, rhokapD, voigt_a, Dfreq, sphere_R, Dfreq_ref, voigt_a_ref,
+                   cgx, cg_min, cg_d, cg_start, cg_list):
+        """clump population + CSR grid as clump_mod.f90 holds them (1-based cg_start / cg_list)"""
+        a = [_f64(v) for v in (x, y, z, vx, vy, vz, radius, rhokap, rhokapD, voigt_a, Dfreq)]
+        n = a[0].size
+        if any(v is not None and v.size != n for v in a):
+            raise ValueError("clump tables must all have n entries")
+        st = np.ascontiguousarray(cg_start, dtype=np.int32); li = np.ascontiguousarray(cg_list, dtype=np.int32)
+        if st.size != cgx ** 3 + 1 or li.size < st[-1] - 1:
+            raise ValueError("cg_start must have cgx^3+1 entries and cg_list cg_start[-1]-1")
+        _chk(lib().lart_gpu_set_clumps(self.h, n, *[_p(v) for v in a], sphere_R, Dfreq_ref, voigt_a_ref, cgx, cg_min, cg_d, _p(st), _p(li)))
 
     def set_pool(self, nlanes=0, block=0):
         _chk(lib().lart_gpu_set_pool(self.h, nlanes, block))

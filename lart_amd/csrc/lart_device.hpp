@@ -46,6 +46,16 @@ struct DAmr {
     int nr_JPa, nz_JPa;
 };
 
+// clump medium (VAR 4): clump_mod.f90:27-118.  Geometry and physics in separate records: the CSR search only touches geometry.
+struct ClumpGeo  { double x, y, z, r2; };                                           // centre, radius^2
+struct ClumpPhys { double rhokap, rhokapD, voigt_a, Dfreq, vx, vy, vz, pad; };     // v in units of the clump's thermal speed
+struct DClumps {
+    long long N;
+    const ClumpGeo *geo; const ClumpPhys *phys;
+    const int *cg_start, *cg_list;                             // CSR over cgx^3 cells, 1-based entries as the reference builds them
+    int cgx; double cg_min, cg_d, cg_inv, sphere_R, Dfreq_ref;
+};
+
 struct DObs { double x, y, z, rm[9]; };
 
 struct DMueller { int nPDF; const double *coss, *S11, *S12, *S33, *S34, *phase_PDF; const int *alias; };
@@ -85,6 +95,7 @@ struct KArgs {
     int heal_nside;               // > 0: HEALPix inside observers (nxim = npix, nyim = 1)
     DJPa jpa;
     DAmr amr;
+    DClumps cl;
     DCtl *ctl;
     long long first_id, stride, count;
     unsigned long long seed;
@@ -306,6 +317,7 @@ struct Photon {
     double x, y, z, kx, ky, kz, xfreq, wgt, nsg, nsd;
     double mx, my, mz, nx, ny, nz, Q, U, V;
     int ic, jc, kc; bool inside;
+    int icl;                       // owner clump (VAR 4): 0 = vacuum (photon%icell_clump, define.f90:90)
     double xfreq_ref;
 #ifdef LART_PROFILE
     long long pt[12], plast;       // tuning builds only: wave clocks per code section (prof_mark)
@@ -631,10 +643,154 @@ __device__ inline double raytrace_to_edge_amr(const KArgs &A, const Lds &l, bool
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// clump medium (VAR 4): clump_mod.f90 + raytrace_clump.f90.  xfreq stays in REF Doppler units; -/+ ulos at entry/exit.
+// ---------------------------------------------------------------------------------------------
+__device__ inline double voigt_clump(const KArgs &A, const Lds &l, double xfreq, const ClumpPhys &c) { return voigt_H(l.vt, xfreq * (A.cl.Dfreq_ref / c.Dfreq), c.voigt_a); }   // clump_mod.f90:130-170 (line type 1)
+__device__ inline double kappa_clump(const KArgs &A, const Lds &l, bool dust, double xfreq, const ClumpPhys &c) {                                                                 // :176-182
+    double kap = c.rhokap * voigt_clump(A, l, xfreq, c);
+    if (dust) kap = kap + c.rhokapD;
+    return kap;
+}
+__device__ inline double ulos_clump(const KArgs &A, const ClumpPhys &c, double kx, double ky, double kz) { return (c.vx * kx + c.vy * ky + c.vz * kz) * (c.Dfreq / A.cl.Dfreq_ref); }   // :184-190
+__device__ inline double clump_exit_dist(const ClumpGeo &q, double xp, double yp, double zp, double kx, double ky, double kz) {       // :1511-1526
+    double rx = xp - q.x, ry = yp - q.y, rz = zp - q.z, b = rx * kx + ry * ky + rz * kz;
+    double disc = b * b - (rx * rx + ry * ry + rz * rz) + q.r2; if (disc < 0.0) disc = 0.0;
+    return fmax(0.0, -b + sqrt(disc));
+}
+__device__ inline double sphere_exit_dist(const DClumps &c, double xp, double yp, double zp, double kx, double ky, double kz) {       // :1530-1540
+    double b = xp * kx + yp * ky + zp * kz, disc = b * b - (xp * xp + yp * yp + zp * zp) + c.sphere_R * c.sphere_R; if (disc < 0.0) disc = 0.0;
+    return fmax(0.0, -b + sqrt(disc));
+}
+__device__ inline int cg_clamp(const DClumps &c, double v) { int i = (int)((v - c.cg_min) * c.cg_inv); return i < 0 ? 0 : (i > c.cgx - 1 ? c.cgx - 1 : i); }
+// find_next_clump: :1390-1507 (Amanatides-Woo over the CSR grid; nearest entry point wins, stop once the cell starts beyond it)
+__device__ inline bool find_next_clump(const DClumps &c, double xp, double yp, double zp, double kx, double ky, double kz, long long skip_icl, double t_max,
+                                       double &t_entry, double &t_exit, long long &icl_found, unsigned &nsteps) {
+    double best_te = LART_HUGEST, best_tx2 = 0.0, d = 0.0; long long best_icl = 0; const int cg = c.cgx;
+    int ci = cg_clamp(c, xp), cj = cg_clamp(c, yp), ck = cg_clamp(c, zp), si, sj, sk;
+    double tx, ty, tz, delx, dely, delz;
+    if (kx > 0.0) { si = 1; tx = ((c.cg_min + (double)(ci + 1) * c.cg_d) - xp) / kx; delx = c.cg_d / kx; }
+    else if (kx < 0.0) { si = -1; tx = ((c.cg_min + (double)ci * c.cg_d) - xp) / kx; delx = -c.cg_d / kx; } else { si = 0; tx = LART_HUGEST; delx = LART_HUGEST; }
+    if (ky > 0.0) { sj = 1; ty = ((c.cg_min + (double)(cj + 1) * c.cg_d) - yp) / ky; dely = c.cg_d / ky; }
+    else if (ky < 0.0) { sj = -1; ty = ((c.cg_min + (double)cj * c.cg_d) - yp) / ky; dely = -c.cg_d / ky; } else { sj = 0; ty = LART_HUGEST; dely = LART_HUGEST; }
+    if (kz > 0.0) { sk = 1; tz = ((c.cg_min + (double)(ck + 1) * c.cg_d) - zp) / kz; delz = c.cg_d / kz; }
+    else if (kz < 0.0) { sk = -1; tz = ((c.cg_min + (double)ck * c.cg_d) - zp) / kz; delz = -c.cg_d / kz; } else { sk = 0; tz = LART_HUGEST; delz = LART_HUGEST; }
+    for (;;) {
+        if (d > best_te || d > t_max) break;
+        nsteps++;
+        size_t q = (size_t)ci + (size_t)cj * cg + (size_t)ck * cg * cg;
+        int ip1 = c.cg_start[q + 1];
+        for (int ip = c.cg_start[q]; ip < ip1; ip++) {
+            long long icl = c.cg_list[ip - 1];
+            if (icl == skip_icl) continue;
+            const ClumpGeo g = c.geo[icl - 1];
+            double rx = xp - g.x, ry = yp - g.y, rz = zp - g.z, b = rx * kx + ry * ky + rz * kz;            // ray_sphere_isect :1363-1387
+            double disc = b * b - (rx * rx + ry * ry + rz * rz) + g.r2;
+            if (disc < 0.0) continue;
+            disc = sqrt(disc);
+            double te = -b - disc, tx2 = -b + disc;
+            if (tx2 > 0.0 && te < best_te) { best_te = te; best_tx2 = tx2; best_icl = icl; }
+        }
+        if (tx <= ty && tx <= tz) { d = tx; ci += si; if (ci < 0 || ci >= cg) break; tx += delx; }
+        else if (ty <= tz)        { d = ty; cj += sj; if (cj < 0 || cj >= cg) break; ty += dely; }
+        else                      { d = tz; ck += sk; if (ck < 0 || ck >= cg) break; tz += delz; }
+    }
+    if (best_icl > 0 && best_te <= t_max) { t_entry = best_te; t_exit = fmin(best_tx2, t_max); icl_found = best_icl; return true; }
+    return false;
+}
+// the clump holding a point (first hit of active_set_at_point, :1595-1634): birth clump, generate_photon.f90:325-332
+__device__ inline int clump_at_point(const DClumps &c, double xp, double yp, double zp) {
+    const int cg = c.cgx; int ci = cg_clamp(c, xp), cj = cg_clamp(c, yp), ck = cg_clamp(c, zp);
+    for (int k = (ck > 0 ? ck - 1 : 0); k <= (ck < cg - 1 ? ck + 1 : cg - 1); k++)
+        for (int j = (cj > 0 ? cj - 1 : 0); j <= (cj < cg - 1 ? cj + 1 : cg - 1); j++)
+            for (int i = (ci > 0 ? ci - 1 : 0); i <= (ci < cg - 1 ? ci + 1 : cg - 1); i++) {
+                size_t q = (size_t)i + (size_t)j * cg + (size_t)k * cg * cg;
+                int ip1 = c.cg_start[q + 1];
+                for (int ip = c.cg_start[q]; ip < ip1; ip++) {
+                    int icl = c.cg_list[ip - 1]; const ClumpGeo g = c.geo[icl - 1];
+                    double rx = xp - g.x, ry = yp - g.y, rz = zp - g.z;
+                    if (rx * rx + ry * ry + rz * rz <= g.r2) return icl;
+                }
+            }
+    return 0;
+}
+__device__ inline void tally_escape(const lart_params &par, const DTally &T, const Photon &p);
+// raytrace_to_tau_clump: raytrace_clump.f90:83-201
+__device__ inline void raytrace_to_tau_clump(const KArgs &A, const Lds &l, bool dust, Photon &p, double tau_in, unsigned &nsteps) {
+    const DClumps &c = A.cl;
+    const double kx = p.kx, ky = p.ky, kz = p.kz; double tau_rem = tau_in; long long last_icl = 0;
+    while (p.inside) {
+        if (p.icl > 0) {
+            const ClumpPhys ph = c.phys[p.icl - 1];
+            double t_seg = clump_exit_dist(c.geo[p.icl - 1], p.x, p.y, p.z, kx, ky, kz), kap = kappa_clump(A, l, dust, p.xfreq, ph);
+            nsteps++;
+            if (tau_rem <= kap * t_seg) {
+                double ds = tau_rem / fmax(kap, 2.2250738585072014e-308);
+                p.x = p.x + ds * kx; p.y = p.y + ds * ky; p.z = p.z + ds * kz;
+                return;
+            }
+            tau_rem = tau_rem - kap * t_seg;
+            p.x = p.x + t_seg * kx; p.y = p.y + t_seg * ky; p.z = p.z + t_seg * kz;
+            p.xfreq = p.xfreq + ulos_clump(A, ph, kx, ky, kz);
+            last_icl = p.icl; p.icl = 0;
+            if (p.x * p.x + p.y * p.y + p.z * p.z >= c.sphere_R * c.sphere_R) { p.inside = false; p.xfreq_ref = p.xfreq; tally_escape(A.par, A.t, p); return; }
+        } else {
+            double t_sp = sphere_exit_dist(c, p.x, p.y, p.z, kx, ky, kz), te, tx2; long long icl_found;
+            if (t_sp <= 0.0) { p.inside = false; p.xfreq_ref = p.xfreq; tally_escape(A.par, A.t, p); return; }
+            if (find_next_clump(c, p.x, p.y, p.z, kx, ky, kz, last_icl, t_sp, te, tx2, icl_found, nsteps)) {
+                te = fmax(0.0, te);
+                p.x = p.x + te * kx; p.y = p.y + te * ky; p.z = p.z + te * kz;
+                p.xfreq = p.xfreq - ulos_clump(A, c.phys[icl_found - 1], kx, ky, kz);
+                last_icl = 0; p.icl = (int)icl_found;
+            } else {
+                p.x = p.x + t_sp * kx; p.y = p.y + t_sp * ky; p.z = p.z + t_sp * kz;
+                p.inside = false; p.xfreq_ref = p.xfreq; tally_escape(A.par, A.t, p); return;
+            }
+        }
+    }
+}
+// raytrace_to_edge_clump_capped: :494-541.  The uncapped form (:204-267) is what the reference calls for the forced first
+// flight; its only consumers are exp(-tau0) and 1 - exp(-tau0), which are exactly 0 and 1 beyond the cap, so one routine serves both.
+__device__ inline double raytrace_to_edge_clump(const KArgs &A, const Lds &l, bool dust, const Photon &p0, double xf, double kx, double ky, double kz, unsigned &nsteps) {
+    const DClumps &c = A.cl;
+    double tau = 0.0, xp = p0.x, yp = p0.y, zp = p0.z; long long icl_cur = p0.icl, icl_found;
+    if (icl_cur > 0) {
+        const ClumpPhys ph = c.phys[icl_cur - 1];
+        double t_seg = clump_exit_dist(c.geo[icl_cur - 1], xp, yp, zp, kx, ky, kz);
+        nsteps++;
+        tau = tau + kappa_clump(A, l, dust, xf, ph) * t_seg;
+        if (tau >= LART_TAU_HUGE) return tau;
+        xp = xp + t_seg * kx; yp = yp + t_seg * ky; zp = zp + t_seg * kz;
+        xf = xf + ulos_clump(A, ph, kx, ky, kz);
+        if (xp * xp + yp * yp + zp * zp >= c.sphere_R * c.sphere_R) return tau;
+    }
+    for (;;) {
+        double t_sp = sphere_exit_dist(c, xp, yp, zp, kx, ky, kz), te, tx2;
+        if (t_sp <= 0.0) break;
+        if (!find_next_clump(c, xp, yp, zp, kx, ky, kz, icl_cur, t_sp, te, tx2, icl_found, nsteps)) break;
+        te = fmax(0.0, te);
+        xp = xp + te * kx; yp = yp + te * ky; zp = zp + te * kz;
+        const ClumpPhys ph = c.phys[icl_found - 1];
+        double u_los = ulos_clump(A, ph, kx, ky, kz);
+        xf = xf - u_los;
+        double t_seg = clump_exit_dist(c.geo[icl_found - 1], xp, yp, zp, kx, ky, kz);
+        nsteps++;
+        tau = tau + kappa_clump(A, l, dust, xf, ph) * t_seg;
+        if (tau >= LART_TAU_HUGE) return tau;
+        xp = xp + t_seg * kx; yp = yp + t_seg * ky; zp = zp + t_seg * kz;
+        xf = xf + u_los;
+        icl_cur = icl_found;
+        if (xp * xp + yp * yp + zp * zp >= c.sphere_R * c.sphere_R) break;
+    }
+    return tau;
+}
+
 // tau to the grid edge (dist < 0) or to a finite distance (raytrace_to_dist_car :89-195, VAR 0 only)
 template <int VAR>
 __device__ inline double raytrace_to_edge(const KArgs &A, const Lds &l, bool dust, const Photon &p, double xfreq, double kx, double ky, double kz, double dist, unsigned &nsteps) {
     if (VAR == 3) return raytrace_to_edge_amr(A, l, dust, p, xfreq, kx, ky, kz, dist, nsteps);
+    if (VAR == 4) return raytrace_to_edge_clump(A, l, dust, p, xfreq, kx, ky, kz, nsteps);
     const DGrid &g = A.g;
     Trav t; t.kx = kx; t.ky = ky; t.kz = kz; t.ic = p.ic; t.jc = p.jc; t.kc = p.kc;
     double tau = 0.0, d = 0.0;
@@ -730,6 +886,7 @@ __device__ inline void raytrace_to_tau_amr(const KArgs &A, const Lds &l, bool du
 template <int VAR>
 __device__ inline void raytrace_to_tau(const KArgs &A, const Lds &l, bool dust, Photon &p, double tau_in, unsigned &nsteps) {
     if (VAR == 3) { raytrace_to_tau_amr(A, l, dust, p, tau_in, nsteps); return; }
+    if (VAR == 4) { raytrace_to_tau_clump(A, l, dust, p, tau_in, nsteps); return; }
     const DGrid &g = A.g;
     Trav t; t.kx = p.kx; t.ky = p.ky; t.kz = p.kz; t.ic = p.ic; t.jc = p.jc; t.kc = p.kc;
     double xp = p.x, yp = p.y, zp = p.z;
@@ -861,6 +1018,12 @@ __device__ inline size_t pix3(const KArgs &A, int io, int ixf, int ix, int iy) {
 // e^{-tau} is exactly 0 once tau >= 745.2 in f64: adding it leaves the tally unchanged, so skip the atomics
 __device__ inline void add_if(double *arr, size_t i, double v) { if (v != 0.0) atomicAdd(&arr[i], v); }
 
+// bulk velocity along the peel direction: the owner clump's in clump mode (peelingoff_rect.f90:65-68, 186-187, 403-404, 534-535, 658-659)
+template <int VAR>
+__device__ inline double peel_u1(const KArgs &A, const Photon &p, const Cell &c, const PeelDir &q) {
+    if (VAR == 4 && p.icl > 0) return ulos_clump(A, A.cl.phys[p.icl - 1], q.kx, q.ky, q.kz);
+    return c.vfx * q.kx + c.vfy * q.ky + c.vfz * q.kz;
+}
 // peeling_direct_outside: peelingoff_rect.f90:24-129
 template <int VAR>
 __device__ inline void peel_direct(const KArgs &A, const Lds &l, bool dust, const Photon &p, unsigned &nsteps) {
@@ -868,7 +1031,8 @@ __device__ inline void peel_direct(const KArgs &A, const Lds &l, bool dust, cons
     for (int i = 0; i < A.nobs; i++) {
         PeelDir q = peel_dir(A, A.obs[i], p);
         double xfreq_ref, xf = p.xfreq;
-        if (!A.par.comoving_source) {
+        if (VAR == 4 && p.icl > 0) xfreq_ref = p.xfreq + peel_u1<VAR>(A, p, c, q);      // clump frame -> lab frame along the peel direction
+        else if (!A.par.comoving_source) {
             double u1 = c.vfx * p.kx + c.vfy * p.ky + c.vfz * p.kz; xfreq_ref = p.xfreq + u1;
             double u2 = c.vfx * q.kx + c.vfy * q.ky + c.vfz * q.kz; xf = xfreq_ref - u2;
         } else { double u1 = c.vfx * q.kx + c.vfy * q.ky + c.vfz * q.kz; xfreq_ref = p.xfreq + u1; }
@@ -893,7 +1057,7 @@ __device__ inline void peel_resonance_nostokes(const KArgs &A, const Lds &l, boo
         if (rho1 != 0.0) { double rho = 1.0 / rho1; cosp = rho * (cost * p.kz - q.kz); sinp = rho * (p.kx * q.ky - q.kx * p.ky); }
         double xfreq = xfreq_atom + (ux * cosp + uy * sinp) * sint + uz * cost;
         if (A.par.recoil) xfreq = xfreq - (A.par.g_recoil0 / c.Dfreq) * (1.0 - cost);
-        double u1 = c.vfx * q.kx + c.vfy * q.ky + c.vfz * q.kz;
+        double u1 = peel_u1<VAR>(A, p, c, q);
         double xfreq_ref = (xfreq + u1) * (c.Dfreq / A.par.Dfreq_ref);
         int ixf = (int)floor((xfreq_ref - A.par.xfreq_min) / A.par.dxfreq) + 1;
         double tau = raytrace_to_edge<VAR>(A, l, dust, p, xfreq, q.kx, q.ky, q.kz, q.dist, nsteps);
@@ -934,7 +1098,7 @@ __device__ inline void peel_resonance_stokes(const KArgs &A, const Lds &l, bool 
         double S22 = 0.75 * E1 * (cost2 + 1.0), S11 = S22 + E2, S12 = 0.75 * E1 * (cost2 - 1.0), S33 = 1.5 * E1 * s.cost, S44 = 1.5 * E3 * s.cost;
         double xfreq = xfreq_atom + (ux * s.cosp + uy * s.sinp) * s.sint + uz * s.cost;
         if (A.par.recoil) xfreq = xfreq - (A.par.g_recoil0 / c.Dfreq) * (1.0 - s.cost);
-        double u1 = c.vfx * q.kx + c.vfy * q.ky + c.vfz * q.kz;
+        double u1 = peel_u1<VAR>(A, p, c, q);
         double xfreq_ref = (xfreq + u1) * (c.Dfreq / A.par.Dfreq_ref);
         int ixf = (int)floor((xfreq_ref - A.par.xfreq_min) / A.par.dxfreq) + 1;
         double Q0 = s.cos2p * p.Q + s.sin2p * p.U, U0 = -s.sin2p * p.Q + s.cos2p * p.U;
@@ -954,7 +1118,7 @@ __device__ inline void peel_dust_nostokes(const KArgs &A, const Lds &l, const Ph
     for (int i = 0; i < A.nobs; i++) {
         PeelDir q = peel_dir(A, A.obs[i], p);
         if (!q.in_image) continue;
-        double u1 = c.vfx * q.kx + c.vfy * q.ky + c.vfz * q.kz;
+        double u1 = peel_u1<VAR>(A, p, c, q);
         double xfreq_ref = (p.xfreq + u1) * (c.Dfreq / A.par.Dfreq_ref);
         int ixf = (int)floor((xfreq_ref - A.par.xfreq_min) / A.par.dxfreq) + 1;
         double tau = raytrace_to_edge<VAR>(A, l, true, p, p.xfreq, q.kx, q.ky, q.kz, q.dist, nsteps);
@@ -973,7 +1137,7 @@ __device__ inline void peel_dust_stokes(const KArgs &A, const Lds &l, const Phot
     for (int i = 0; i < A.nobs; i++) {
         const DObs &o = A.obs[i];
         PeelDir q = peel_dir(A, o, p);
-        double u1 = c.vfx * q.kx + c.vfy * q.ky + c.vfz * q.kz;
+        double u1 = peel_u1<VAR>(A, p, c, q);
         double xfreq_ref = (p.xfreq + u1) * (c.Dfreq / A.par.Dfreq_ref);
         int ixf = (int)floor((xfreq_ref - A.par.xfreq_min) / A.par.dxfreq) + 1;
         if (!q.in_image) continue;
@@ -1050,9 +1214,13 @@ __device__ inline void scatter_event(const KArgs &A, const Lds &l, Rng &g, Photo
     const lart_params &par = A.par;
     const Cell &c = A.g.cell[cidx(A.g, p.ic, p.jc, p.kc)];
     double va = c.voigt_a;
+    // clump mode (scattering_car.f90:69-84, line_clump_mod.f90:30-59): opacities, Voigt parameter and Doppler width of the owner clump;
+    // scale = Dfreq_ref / Dfreq_clump moves x into the clump's local Doppler units for the sampler and back
+    double cl_scale = 1.0, cl_Dfreq = c.Dfreq, cl_rhokap = c.rhokap, cl_rhokapD = c.rhokapD;
+    if (VAR == 4) { const ClumpPhys ph = A.cl.phys[p.icl - 1]; va = ph.voigt_a; cl_Dfreq = ph.Dfreq; cl_rhokap = ph.rhokap; cl_rhokapD = ph.rhokapD; cl_scale = A.cl.Dfreq_ref / ph.Dfreq; }
     if (DUST) {
-        double rD = c.rhokapD;
-        double p_dust = rD / (c.rhokap * voigt_H(l.vt, p.xfreq, va) + rD);
+        double rD = cl_rhokapD;
+        double p_dust = rD / (cl_rhokap * voigt_H(l.vt, p.xfreq * cl_scale, va) + rD);
         if (g.next() <= p_dust) {
             if (dust_absorb(A, g, p, c)) return;
             if (STOKES && A.mu.nPDF > 0) {                     // scatter_dust_stokes :201-329
@@ -1084,9 +1252,12 @@ __device__ inline void scatter_event(const KArgs &A, const Lds &l, Rng &g, Photo
     }
     // do_resonance1: line_mod.f90:108-139
     LART_PROF_MARK(p, 4);
-    double uz = rand_resonance_vz(g, p.xfreq, va LART_PROF_PASS(p));
+    double uz, xfreq_atom;
+    if (VAR == 4) {
+        double xloc = p.xfreq * cl_scale, uz_loc = rand_resonance_vz(g, xloc, va LART_PROF_PASS(p)), scale_inv = 1.0 / cl_scale;
+        xfreq_atom = (xloc - uz_loc) * scale_inv; uz = uz_loc * scale_inv;
+    } else { uz = rand_resonance_vz(g, p.xfreq, va LART_PROF_PASS(p)); xfreq_atom = p.xfreq - uz; }
     LART_PROF_MARK(p, 5);
-    double xfreq_atom = p.xfreq - uz;
     double S11 = 0, S22 = 0, S12 = 0, S33 = 0, S44 = 0, sinp, cosp, cost, cost2, sint;
     if (STOKES) {
         cost = rand_resonance(g, par.E1); cost2 = cost * cost; sint = sqrt(1.0 - cost2);
@@ -1110,8 +1281,9 @@ __device__ inline void scatter_event(const KArgs &A, const Lds &l, Rng &g, Photo
         double u2, u3; g.next2(u2, u3); double uxy = sqrt(-d_log(u3)), s2, c2; d_sincos_2pi(u2, &s2, &c2);
         ux = uxy * c2; uy = uxy * s2;
     }
+    if (VAR == 4) { double vth_ratio = cl_Dfreq / A.cl.Dfreq_ref; ux = ux * vth_ratio; uy = uy * vth_ratio; }   // scattering_car.f90:384-388, 715-719
     p.xfreq = xfreq_atom + uz * cost + (ux * cosp + uy * sinp) * sint;
-    if (par.recoil) p.xfreq = p.xfreq - (par.g_recoil0 / c.Dfreq) * (1.0 - cost);
+    if (par.recoil) p.xfreq = p.xfreq - (par.g_recoil0 / cl_Dfreq) * (1.0 - cost);
     if (STOKES) {
         if (PEEL) peel_resonance_stokes<VAR>(A, l, DUST, p, xfreq_atom, ux, uy, uz, npeel);
         double cos2p = 2.0 * cosp * cosp - 1.0, sin2p = 2.0 * sinp * cosp;
@@ -1142,6 +1314,7 @@ __device__ inline void generate_photon(const KArgs &A, const Lds &l, Rng &g, Pho
     d_sincos_2pi(g.next(), &sinp, &cosp);
     p.kx = sint * cosp; p.ky = sint * sinp; p.kz = cost;
     if (VAR == 3) { p.ic = amr_find_leaf(A.amr, p.x, p.y, p.z); p.jc = 1; p.kc = 1; if (p.ic <= 0) p.ic = 1; }   // generate_photon.f90:375-379 (source inside the box)
+    else if (VAR == 4) { p.ic = 1; p.jc = 1; p.kc = 1; }                       // the background grid is uniform (grid_mod_clump.f90:101-108): one record
     else {
     p.ic = (int)floor((p.x - gr.xmin) / gr.dx) + 1; p.jc = (int)floor((p.y - gr.ymin) / gr.dy) + 1; p.kc = (int)floor((p.z - gr.zmin) / gr.dz) + 1;
     if (p.kx < 0.0 && p.ic == gr.nx + 1) p.ic = gr.nx;
@@ -1154,7 +1327,7 @@ __device__ inline void generate_photon(const KArgs &A, const Lds &l, Rng &g, Pho
     if (STOKES) { p.mx = cost * cosp; p.my = cost * sinp; p.mz = -sint; p.nx = -sinp; p.ny = cosp; p.nz = 0.0; p.Q = 0.0; p.U = 0.0; p.V = 0.0; }
     p.nsg = 0.0; p.nsd = 0.0; p.inside = true; p.xfreq = par.xfreq0;
     // a source outside the medium box never reaches a table in the reference's configs; clamp the gather
-    const Cell &c = (VAR == 3) ? gr.cell[p.ic - 1] : gr.cell[cidx(gr, clampi(p.ic, 1, gr.nx), clampi(p.jc, 1, gr.ny), clampi(p.kc, 1, gr.nz))];
+    const Cell &c = (VAR == 3 || VAR == 4) ? gr.cell[p.ic - 1] : gr.cell[cidx(gr, clampi(p.ic, 1, gr.nx), clampi(p.jc, 1, gr.ny), clampi(p.kc, 1, gr.nz))];
     if (par.spectral_type == 1) p.xfreq = p.xfreq + rand_voigt(g, c.voigt_a);
     double u1 = c.vfx * p.kx + c.vfy * p.ky + c.vfz * p.kz;
     if (!par.comoving_source) p.xfreq = p.xfreq - u1;
@@ -1162,6 +1335,11 @@ __device__ inline void generate_photon(const KArgs &A, const Lds &l, Rng &g, Pho
         double xlab = (p.xfreq + u1) * (c.Dfreq / par.Dfreq_ref);
         int ix = (int)floor((xlab - par.xfreq_min) / par.dxfreq) + 1;
         if (ix >= 1 && ix <= par.nxfreq) atomicAdd(&A.t.Jin[ix - 1], p.wgt);
+    }
+    p.icl = 0;
+    if (VAR == 4) {                                           // birth clump: generate_photon.f90:325-332
+        p.icl = clump_at_point(A.cl, p.x, p.y, p.z);
+        if (p.icl > 0) p.xfreq = p.xfreq - ulos_clump(A, A.cl.phys[p.icl - 1], p.kx, p.ky, p.kz);
     }
     if (PEEL) peel_direct<VAR>(A, l, DUST, p, npeel);
 }

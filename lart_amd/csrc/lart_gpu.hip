@@ -11,6 +11,7 @@ extern "C" void lart_launch_transport_var0(int, int, int, dim3, dim3, size_t, hi
 extern "C" void lart_launch_transport_var1(int, int, int, dim3, dim3, size_t, hipStream_t, const KArgs &);
 extern "C" void lart_launch_transport_var2(int, int, int, dim3, dim3, size_t, hipStream_t, const KArgs &);
 extern "C" void lart_launch_transport_var3(int, int, int, dim3, dim3, size_t, hipStream_t, const KArgs &);
+extern "C" void lart_launch_transport_var4(int, int, int, dim3, dim3, size_t, hipStream_t, const KArgs &);
 
 static thread_local std::string g_err;
 static int fail(const std::string &m) { g_err = m; return 1; }
@@ -30,6 +31,8 @@ struct lart_gpu {
     DJPa jpa{}; int *d_ind_bin = nullptr;
     // octree (VAR 3)
     bool is_amr = false; DAmr amr{}; int *d_amr_int = nullptr; AmrGeom *d_amr_geom = nullptr;
+    // clump medium (VAR 4)
+    bool is_clump = false; DClumps cl{}; ClumpGeo *d_cl_geo = nullptr; ClumpPhys *d_cl_phys = nullptr; int *d_cl_int = nullptr;
     // fused tally buffer
     double *d_tally = nullptr; int64_t ntally = 0; DTally t{};
     // pool
@@ -67,7 +70,7 @@ extern "C" int lart_gpu_destroy(lart_gpu *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (auto &e : c->ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-    (void)hipFree(c->d_cell); (void)hipFree(c->d_faces); (void)hipFree(c->d_mu); (void)hipFree(c->d_alias); (void)hipFree(c->d_obs); (void)hipFree(c->d_ind_bin); (void)hipFree(c->d_amr_int); (void)hipFree(c->d_amr_geom);
+    (void)hipFree(c->d_cell); (void)hipFree(c->d_faces); (void)hipFree(c->d_mu); (void)hipFree(c->d_alias); (void)hipFree(c->d_obs); (void)hipFree(c->d_ind_bin); (void)hipFree(c->d_amr_int); (void)hipFree(c->d_amr_geom); (void)hipFree(c->d_cl_geo); (void)hipFree(c->d_cl_phys); (void)hipFree(c->d_cl_int);
     free_tally(c); (void)hipFree(c->d_pool); (void)hipFree(c->d_ctl); (void)hipFree(c->d_log);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -131,7 +134,7 @@ extern "C" int lart_gpu_set_grid_car(lart_gpu *c, int32_t nx, int32_t ny, int32_
     c->g.nx = nx; c->g.ny = ny; c->g.nz = nz; c->g.i0 = i0; c->g.j0 = j0; c->g.k0 = k0;
     c->g.xmin = xmin; c->g.ymin = ymin; c->g.zmin = zmin; c->g.dx = dx; c->g.dy = dy; c->g.dz = dz;
     c->g.cell = c->d_cell; c->g.faces = c->d_faces; c->ncell = nc; c->has_dust_table = rhokapD != nullptr;
-    c->is_amr = false; c->jpa.nbins = 0; free_tally(c);
+    c->is_amr = false; c->is_clump = false; c->jpa.nbins = 0; free_tally(c);
     return 0;
 }
 
@@ -189,6 +192,7 @@ extern "C" int lart_gpu_set_observers_heal(lart_gpu *c, int32_t nobs, const doub
 
 extern "C" int lart_gpu_set_JPa(lart_gpu *c, int32_t calc_J, int32_t calc_P, int32_t calc_Pnew, int32_t nbins, const int32_t *ind_bin, double cross0) {
     if (!c) return fail("set_JPa: null context");
+    if (c->is_clump) return fail("set_JPa: profile tallies are not defined for the clump medium");
     if (!c->d_cell || c->is_amr) return fail("set_JPa: set the Cartesian medium first (lart_gpu_set_grid_car); the octree uses lart_gpu_set_JPa_amr");
     if (nbins < 1 || !ind_bin || !(cross0 > 0.0)) return fail("set_JPa: bad arguments");
     for (size_t i = 0; i < c->ncell; i++) if (ind_bin[i] < 0 || ind_bin[i] > nbins) return fail("set_JPa: ind_bin entries must be 0..nbins");
@@ -258,7 +262,7 @@ extern "C" int lart_gpu_set_grid_amr(lart_gpu *c, int32_t ncells, int32_t nleaf,
     c->g = DGrid{}; c->g.nx = 1; c->g.ny = 1; c->g.nz = 1; c->g.i0 = 1; c->g.j0 = 1; c->g.k0 = 1;
     c->g.xmin = lo; c->g.ymin = lo; c->g.zmin = lo; c->g.dx = hi - lo; c->g.dy = hi - lo; c->g.dz = hi - lo;
     c->g.cell = c->d_cell; c->g.faces = c->d_faces; c->ncell = nleaf; c->has_dust_table = rhokapD != nullptr;
-    c->is_amr = true; c->jpa.nbins = 0; free_tally(c);
+    c->is_amr = true; c->is_clump = false; c->jpa.nbins = 0; free_tally(c);
     return 0;
 }
 
@@ -273,6 +277,58 @@ extern "C" int lart_gpu_set_JPa_amr(lart_gpu *c, int32_t calc_J, int32_t calc_P,
     c->jpa.calc_J = calc_J ? 1 : 0; c->jpa.calc_P = calc_P ? 1 : 0; c->jpa.calc_Pnew = calc_Pnew ? 1 : 0;
     c->jpa.nbins = (calc_J || calc_P || calc_Pnew) ? nbins : 0; c->jpa.ind_bin = nullptr; c->jpa.cross0 = cross0;
     free_tally(c);
+    return 0;
+}
+
+extern "C" int lart_gpu_set_clumps(lart_gpu *c, int64_t n, const double *x, const double *y, const double *z,
+                                   const double *vx, const double *vy, const double *vz, const double *radius,
+                                   const double *rhokap, const double *rhokapD, const double *voigt_a, const double *Dfreq,
+                                   double sphere_R, double Dfreq_ref, double voigt_a_ref,
+                                   int32_t cgx, double cg_min, double cg_d, const int32_t *cg_start, const int32_t *cg_list) {
+    if (!c) return fail("set_clumps: null context");
+    if (n < 1 || n > 2147483647LL) return fail("set_clumps: need 1 <= n < 2^31 clumps");
+    if (!x || !y || !z || !vx || !vy || !vz || !radius || !rhokap || !voigt_a || !Dfreq || !cg_start || !cg_list) return fail("set_clumps: null table");
+    if (c->par.DGR > 0.0 && !rhokapD) return fail("set_clumps: DGR > 0 needs rhokapD");
+    if (!(sphere_R > 0.0) || !(Dfreq_ref > 0.0) || !(voigt_a_ref > 0.0) || cgx < 1 || cgx > 1024 || !(cg_d > 0.0)) return fail("set_clumps: bad scalar argument");
+    if (c->par.xyz_symmetry || c->par.xy_periodic) return fail("set_clumps: the clump medium has no symmetry / periodic variant (grid_mod_clump.f90:62-65)");
+    if (cg_min > -sphere_R || cg_min + cgx * cg_d < sphere_R) return fail("set_clumps: the CSR grid must cover the sphere");
+    // every index the kernels follow is checked here
+    size_t ncells = (size_t)cgx * cgx * cgx;
+    if (cg_start[0] != 1) return fail("set_clumps: cg_start[0] must be 1 (1-based offsets)");
+    for (size_t q = 0; q < ncells; q++) if (cg_start[q + 1] < cg_start[q]) return fail("set_clumps: cg_start must be non-decreasing");
+    int64_t nreg = (int64_t)cg_start[ncells] - 1;
+    for (int64_t i = 0; i < nreg; i++) if (cg_list[i] < 1 || cg_list[i] > n) return fail("set_clumps: cg_list entries must be 1..n");
+    for (int64_t i = 0; i < n; i++) {
+        if (!(radius[i] > 0.0) || !(Dfreq[i] > 0.0) || !(rhokap[i] >= 0.0) || !(voigt_a[i] > 0.0)) return fail("set_clumps: radius, Dfreq, voigt_a must be > 0 and rhokap >= 0 for every clump");
+        if (!std::isfinite(x[i]) || !std::isfinite(y[i]) || !std::isfinite(z[i]) || !std::isfinite(vx[i]) || !std::isfinite(vy[i]) || !std::isfinite(vz[i])) return fail("set_clumps: non-finite clump position / velocity");
+    }
+    HIPCHK(hipSetDevice(c->device));
+    std::vector<ClumpGeo> hg((size_t)n); std::vector<ClumpPhys> hp((size_t)n);
+    for (int64_t i = 0; i < n; i++) {
+        hg[i].x = x[i]; hg[i].y = y[i]; hg[i].z = z[i]; hg[i].r2 = radius[i] * radius[i];
+        hp[i].rhokap = rhokap[i]; hp[i].rhokapD = rhokapD ? rhokapD[i] : 0.0; hp[i].voigt_a = voigt_a[i]; hp[i].Dfreq = Dfreq[i];
+        hp[i].vx = vx[i]; hp[i].vy = vy[i]; hp[i].vz = vz[i]; hp[i].pad = 0.0;
+    }
+    (void)hipFree(c->d_cl_geo); (void)hipFree(c->d_cl_phys); (void)hipFree(c->d_cl_int); c->d_cl_geo = nullptr; c->d_cl_phys = nullptr; c->d_cl_int = nullptr;
+    (void)hipFree(c->d_cell); (void)hipFree(c->d_faces); c->d_cell = nullptr; c->d_faces = nullptr;
+    HIPCHK(hipMalloc(&c->d_cl_geo, (size_t)n * sizeof(ClumpGeo))); HIPCHK(hipMemcpy(c->d_cl_geo, hg.data(), (size_t)n * sizeof(ClumpGeo), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&c->d_cl_phys, (size_t)n * sizeof(ClumpPhys))); HIPCHK(hipMemcpy(c->d_cl_phys, hp.data(), (size_t)n * sizeof(ClumpPhys), hipMemcpyHostToDevice));
+    size_t ni = ncells + 1 + (size_t)(nreg > 0 ? nreg : 1);
+    HIPCHK(hipMalloc(&c->d_cl_int, ni * sizeof(int)));
+    HIPCHK(hipMemcpy(c->d_cl_int, cg_start, (ncells + 1) * sizeof(int), hipMemcpyHostToDevice));
+    if (nreg > 0) HIPCHK(hipMemcpy(c->d_cl_int + ncells + 1, cg_list, (size_t)nreg * sizeof(int), hipMemcpyHostToDevice));
+    c->cl = DClumps{};
+    c->cl.N = n; c->cl.geo = c->d_cl_geo; c->cl.phys = c->d_cl_phys; c->cl.cg_start = c->d_cl_int; c->cl.cg_list = c->d_cl_int + ncells + 1;
+    c->cl.cgx = cgx; c->cl.cg_min = cg_min; c->cl.cg_d = cg_d; c->cl.cg_inv = 1.0 / cg_d; c->cl.sphere_R = sphere_R; c->cl.Dfreq_ref = Dfreq_ref;
+    // the background medium of grid_create_clump is uniform (rhokap = 0, Dfreq = Dfreq_ref, voigt_a = voigt_a_ref, v = 0): one record
+    Cell bg{}; bg.rhokap = 0.0; bg.voigt_a = voigt_a_ref; bg.Dfreq = Dfreq_ref; bg.vfx = bg.vfy = bg.vfz = 0.0; bg.rhokapD = 0.0; bg.pad = 0.0;
+    HIPCHK(hipMalloc(&c->d_cell, sizeof(Cell))); HIPCHK(hipMemcpy(c->d_cell, &bg, sizeof(Cell), hipMemcpyHostToDevice));
+    double f[6] = {-sphere_R, sphere_R, -sphere_R, sphere_R, -sphere_R, sphere_R};
+    HIPCHK(hipMalloc(&c->d_faces, sizeof f)); HIPCHK(hipMemcpy(c->d_faces, f, sizeof f, hipMemcpyHostToDevice));
+    c->g = DGrid{}; c->g.nx = 1; c->g.ny = 1; c->g.nz = 1; c->g.i0 = 1; c->g.j0 = 1; c->g.k0 = 1;
+    c->g.xmin = -sphere_R; c->g.ymin = -sphere_R; c->g.zmin = -sphere_R; c->g.dx = 2 * sphere_R; c->g.dy = 2 * sphere_R; c->g.dz = 2 * sphere_R;
+    c->g.cell = c->d_cell; c->g.faces = c->d_faces; c->ncell = 1; c->has_dust_table = rhokapD != nullptr;
+    c->is_clump = true; c->is_amr = false; c->jpa.nbins = 0; free_tally(c);
     return 0;
 }
 
@@ -322,6 +378,7 @@ extern "C" int lart_gpu_begin(lart_gpu *c, int64_t first_id, int64_t stride, int
     if (c->heal_nside > 0 && (c->par.use_stokes || c->par.xyz_symmetry || c->par.xy_periodic)) return fail("begin: HEALPix observers need the plain grid without Stokes");
     if (c->par.save_peeloff && c->par.xyz_symmetry) return fail("begin: peel-off is not allowed with xyz_symmetry (setup.f90:198-206)");
     if (c->par.DGR > 0.0 && !c->has_dust_table) return fail("begin: DGR > 0 but the grid has no rhokapD");
+    if (c->is_clump && c->heal_nside > 0) return fail("begin: HEALPix inside observers are not supported with the clump medium (setup.f90:177)");
     if (c->is_amr && c->heal_nside > 0 && c->par.xyz_symmetry) return fail("begin: inside observers need the full octree");
     if (c->par.xy_periodic && !(c->g.nx == 1 && c->g.ny == 1)) return fail("begin: xy_periodic is supported for nx = ny = 1 (raytrace_to_tau_car_zonly) only");
     HIPCHK(hipSetDevice(c->device));
@@ -354,10 +411,10 @@ extern "C" int lart_gpu_step(lart_gpu *c, int32_t nsteps, int32_t max_events) {
     HIPCHK(hipSetDevice(c->device));
     KArgs A{};
     A.par = c->par; A.g = c->g; A.t = c->t; A.pool = c->pool; A.mu = c->mu; A.obs = c->d_obs; A.nobs = c->par.save_peeloff ? c->nobs : 0;
-    A.nxim = c->nxim; A.nyim = c->nyim; A.dxim = c->dxim; A.dyim = c->dyim; A.ctl = c->d_ctl; A.heal_nside = c->heal_nside; A.jpa = c->jpa; A.amr = c->amr;
+    A.nxim = c->nxim; A.nyim = c->nyim; A.dxim = c->dxim; A.dyim = c->dyim; A.ctl = c->d_ctl; A.heal_nside = c->heal_nside; A.jpa = c->jpa; A.amr = c->amr; A.cl = c->cl;
     A.first_id = c->first_id; A.stride = c->stride; A.count = c->count; A.seed = c->seed; A.max_events = max_events;
     A.log_nscatt = c->d_log; A.log_xfreq = c->d_log ? c->d_log + c->nlog : nullptr;
-    int var = c->is_amr ? 3 : (c->par.xyz_symmetry ? 1 : (c->par.xy_periodic ? 2 : 0));     // setup.f90:961-990
+    int var = c->is_clump ? 4 : c->is_amr ? 3 : (c->par.xyz_symmetry ? 1 : (c->par.xy_periodic ? 2 : 0));     // setup.f90:961-990
     int stokes = c->par.use_stokes ? 1 : 0, dust = c->par.DGR > 0.0 ? 1 : 0, peel = (c->par.save_peeloff && c->nobs > 0) ? 1 : 0;
     dim3 block(c->block), grid((unsigned)(c->pool.n / c->block));
     size_t shmem = (size_t)(VT_END + c->g.nx + c->g.ny + c->g.nz + 3 + LART_RNG_BUF * c->block) * sizeof(double);
@@ -369,7 +426,8 @@ extern "C" int lart_gpu_step(lart_gpu *c, int32_t nsteps, int32_t max_events) {
         if (var == 0) lart_launch_transport_var0(stokes, dust, peel, grid, block, shmem, c->stream, A);
         else if (var == 1) lart_launch_transport_var1(stokes, dust, peel, grid, block, shmem, c->stream, A);
         else if (var == 2) lart_launch_transport_var2(stokes, dust, peel, grid, block, shmem, c->stream, A);
-        else lart_launch_transport_var3(stokes, dust, peel, grid, block, shmem, c->stream, A);
+        else if (var == 3) lart_launch_transport_var3(stokes, dust, peel, grid, block, shmem, c->stream, A);
+        else lart_launch_transport_var4(stokes, dust, peel, grid, block, shmem, c->stream, A);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(e1, c->stream));
         c->ev.emplace_back(e0, e1);
@@ -482,11 +540,12 @@ template <int VAR>
 __device__ void test_ray_one(const KArgs &A, const Lds &l, int kind, double *r, int *ic, double tq, double *tau_out) {
     Photon p{}; p.x = r[0]; p.y = r[1]; p.z = r[2]; p.kx = r[3]; p.ky = r[4]; p.kz = r[5]; p.xfreq = r[6]; p.wgt = r[7];
     p.ic = ic[0]; p.jc = ic[1]; p.kc = ic[2]; p.inside = ic[3] != 0;
+    if (VAR == 4) { p.icl = ic[0]; p.ic = 1; p.jc = 1; p.kc = 1; }          // clump mode: ic[0] carries the owner clump (0 = vacuum)
     unsigned ns = 0; bool dust = A.par.DGR > 0.0;
     if (kind == 0) {
         raytrace_to_tau<VAR>(A, l, dust, p, tq, ns);
         r[0] = p.x; r[1] = p.y; r[2] = p.z; r[3] = p.kx; r[4] = p.ky; r[5] = p.kz; r[6] = p.xfreq; r[7] = p.wgt;
-        ic[0] = p.ic; ic[1] = p.jc; ic[2] = p.kc; ic[3] = p.inside ? 1 : 0;
+        ic[0] = (VAR == 4) ? p.icl : p.ic; ic[1] = p.jc; ic[2] = p.kc; ic[3] = p.inside ? 1 : 0;
     } else *tau_out = raytrace_to_edge<VAR>(A, l, dust, p, p.xfreq, p.kx, p.ky, p.kz, kind == 2 ? tq : -1.0, ns);
 }
 __global__ void k_test_raytrace(KArgs A, int mode, int n, double *r8, int *ic4, const double *tq, double *tau_out) {
@@ -498,19 +557,21 @@ __global__ void k_test_raytrace(KArgs A, int mode, int n, double *r8, int *ic4, 
     if (var == 0) test_ray_one<0>(A, l, kind, r8 + 8 * i, ic4 + 4 * i, tq ? tq[i] : 0.0, tau_out + i);
     else if (var == 1) test_ray_one<1>(A, l, kind, r8 + 8 * i, ic4 + 4 * i, tq ? tq[i] : 0.0, tau_out + i);
     else if (var == 2) test_ray_one<2>(A, l, kind, r8 + 8 * i, ic4 + 4 * i, tq ? tq[i] : 0.0, tau_out + i);
-    else test_ray_one<3>(A, l, kind, r8 + 8 * i, ic4 + 4 * i, tq ? tq[i] : 0.0, tau_out + i);
+    else if (var == 3) test_ray_one<3>(A, l, kind, r8 + 8 * i, ic4 + 4 * i, tq ? tq[i] : 0.0, tau_out + i);
+    else test_ray_one<4>(A, l, kind, r8 + 8 * i, ic4 + 4 * i, tq ? tq[i] : 0.0, tau_out + i);
 }
 __global__ void k_test_vec2pix(int nside, int n, const double *v, int *ipix) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) ipix[i] = vec2pix(nside, v[3 * i], v[3 * i + 1], v[3 * i + 2]);
 }
-template <bool STOKES, bool DUST>
+template <int VAR, bool STOKES, bool DUST>
 __device__ void test_scatter_one(const KArgs &A, const Lds &l, double *st, int *ic, unsigned long long seed, unsigned long long id, long long *nd) {
     Photon p{}; p.x = st[0]; p.y = st[1]; p.z = st[2]; p.kx = st[3]; p.ky = st[4]; p.kz = st[5]; p.xfreq = st[6]; p.wgt = st[7];
     p.mx = st[8]; p.my = st[9]; p.mz = st[10]; p.nx = st[11]; p.ny = st[12]; p.nz = st[13]; p.Q = st[15]; p.U = st[16]; p.V = st[17];
     p.ic = ic[0]; p.jc = ic[1]; p.kc = ic[2]; p.inside = true;
+    if (VAR == 4) { p.icl = ic[0]; p.ic = 1; p.jc = 1; p.kc = 1; }
     Rng g; g.init(seed, id, 0); unsigned np = 0;
-    scatter_event<0, STOKES, DUST, false>(A, l, g, p, np);
+    scatter_event<VAR, STOKES, DUST, false>(A, l, g, p, np);
     st[0] = p.x; st[1] = p.y; st[2] = p.z; st[3] = p.kx; st[4] = p.ky; st[5] = p.kz; st[6] = p.xfreq; st[7] = p.wgt;
     st[8] = p.mx; st[9] = p.my; st[10] = p.mz; st[11] = p.nx; st[12] = p.ny; st[13] = p.nz; st[14] = 1.0; st[15] = p.Q; st[16] = p.U; st[17] = p.V;
     ic[3] = p.inside ? 1 : 0; *nd = (long long)g.n;
@@ -521,10 +582,17 @@ __global__ void k_test_scatter(KArgs A, int n, double *st18, int *ic4, unsigned 
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     bool stokes = A.par.use_stokes, dust = A.par.DGR > 0.0;
-    if (stokes && dust) test_scatter_one<true, true>(A, l, st18 + 18 * i, ic4 + 4 * i, seed, ids[i], nd + i);
-    else if (stokes) test_scatter_one<true, false>(A, l, st18 + 18 * i, ic4 + 4 * i, seed, ids[i], nd + i);
-    else if (dust) test_scatter_one<false, true>(A, l, st18 + 18 * i, ic4 + 4 * i, seed, ids[i], nd + i);
-    else test_scatter_one<false, false>(A, l, st18 + 18 * i, ic4 + 4 * i, seed, ids[i], nd + i);
+    if (A.cl.N > 0) {
+        if (stokes && dust) test_scatter_one<4, true, true>(A, l, st18 + 18 * i, ic4 + 4 * i, seed, ids[i], nd + i);
+        else if (stokes) test_scatter_one<4, true, false>(A, l, st18 + 18 * i, ic4 + 4 * i, seed, ids[i], nd + i);
+        else if (dust) test_scatter_one<4, false, true>(A, l, st18 + 18 * i, ic4 + 4 * i, seed, ids[i], nd + i);
+        else test_scatter_one<4, false, false>(A, l, st18 + 18 * i, ic4 + 4 * i, seed, ids[i], nd + i);
+        return;
+    }
+    if (stokes && dust) test_scatter_one<0, true, true>(A, l, st18 + 18 * i, ic4 + 4 * i, seed, ids[i], nd + i);
+    else if (stokes) test_scatter_one<0, true, false>(A, l, st18 + 18 * i, ic4 + 4 * i, seed, ids[i], nd + i);
+    else if (dust) test_scatter_one<0, false, true>(A, l, st18 + 18 * i, ic4 + 4 * i, seed, ids[i], nd + i);
+    else test_scatter_one<0, false, false>(A, l, st18 + 18 * i, ic4 + 4 * i, seed, ids[i], nd + i);
 }
 
 template <typename T> struct DevBuf {
@@ -534,7 +602,7 @@ template <typename T> struct DevBuf {
     ~DevBuf() { if (p) (void)hipFree(p); }
 };
 static KArgs probe_args(lart_gpu *c) {
-    KArgs A{}; A.par = c->par; A.g = c->g; A.t = c->t; A.mu = c->mu; A.obs = c->d_obs; A.nobs = 0; A.nxim = c->nxim; A.nyim = c->nyim; A.dxim = c->dxim; A.dyim = c->dyim; A.ctl = c->d_ctl; A.heal_nside = c->heal_nside; A.jpa = c->jpa; A.amr = c->amr;
+    KArgs A{}; A.par = c->par; A.g = c->g; A.t = c->t; A.mu = c->mu; A.obs = c->d_obs; A.nobs = 0; A.nxim = c->nxim; A.nyim = c->nyim; A.dxim = c->dxim; A.dyim = c->dyim; A.ctl = c->d_ctl; A.heal_nside = c->heal_nside; A.jpa = c->jpa; A.amr = c->amr; A.cl = c->cl;
     return A;
 }
 static size_t probe_shmem(lart_gpu *c) { return (size_t)(VT_END + c->g.nx + c->g.ny + c->g.nz + 3) * sizeof(double); }
@@ -561,14 +629,15 @@ extern "C" int lart_gpu_test_rand(lart_gpu *c, int32_t what, uint64_t seed, uint
 extern "C" int lart_gpu_test_raytrace(lart_gpu *c, int32_t mode, int32_t n, double *r8, int32_t *ic4, const double *tq, double *tau_out) {
     if (!c || n < 0 || !c->d_cell) return fail("test_raytrace: needs a context with a medium");
     int kind = mode / 10, var = mode % 10;
-    if (kind < 0 || kind > 2 || var < 0 || var > 3 || (kind == 2 && var != 0 && var != 3)) return fail("test_raytrace: bad mode");
-    if ((var == 3) != c->is_amr) return fail("test_raytrace: variant 3 needs the octree medium, variants 0-2 the Cartesian one");
+    if (kind < 0 || kind > 2 || var < 0 || var > 4 || (kind == 2 && var != 0 && var != 3)) return fail("test_raytrace: bad mode");
+    if ((var == 3) != c->is_amr || (var == 4) != c->is_clump) return fail("test_raytrace: variant 3 needs the octree medium, 4 the clump medium, 0-2 the Cartesian one");
     HIPCHK(hipSetDevice(c->device));
     if (!c->d_tally) { if (build_tally(c)) return 1; }
     // host-side shape check before touching the kernel: every start cell must be a valid gather target
     for (int i = 0; i < n; i++) {
         const int *q = ic4 + 4 * i;
         if (var == 3) { if (q[0] < 1 || q[0] > c->amr.nleaf) return fail("test_raytrace: start leaf must be 1..nleaf"); continue; }
+        if (var == 4) { if (q[0] < 0 || q[0] > c->cl.N) return fail("test_raytrace: owner clump must be 0..n"); continue; }
         if (q[0] < 1 || q[0] > c->g.nx + 1 || q[1] < 1 || q[1] > c->g.ny + 1 || q[2] < 1 || q[2] > c->g.nz + 1) return fail("test_raytrace: start cell outside the grid");
         if (q[0] > c->g.nx || q[1] > c->g.ny || q[2] > c->g.nz) return fail("test_raytrace: probe start cells must be interior (1..n)");
     }
@@ -595,6 +664,7 @@ extern "C" int lart_gpu_test_scatter(lart_gpu *c, int32_t n, double *st18, int32
     HIPCHK(hipSetDevice(c->device));
     if (!c->d_tally) { if (build_tally(c)) return 1; }
     for (int i = 0; i < n; i++) { const int *q = ic4 + 4 * i;
+        if (c->is_clump) { if (q[0] < 1 || q[0] > c->cl.N) return fail("test_scatter: clump mode scatters inside a clump (owner 1..n)"); continue; }
         if (q[0] < 1 || q[0] > c->g.nx || q[1] < 1 || q[1] > c->g.ny || q[2] < 1 || q[2] > c->g.nz) return fail("test_scatter: cell outside the grid"); }
     if (c->par.use_stokes && c->par.DGR > 0.0 && c->mu.nPDF == 0) return fail("test_scatter: Stokes dust scattering needs a Mueller table");
     DevBuf<double> ds; DevBuf<int> di; DevBuf<unsigned long long> dd; DevBuf<long long> dn;

@@ -51,7 +51,8 @@ __global__ __launch_bounds__(256, LART_WAVES(STOKES, PEEL)) void transport_kerne
             p.nx = F[F_NX * P + lane]; p.ny = F[F_NY * P + lane]; p.nz = F[F_NZ * P + lane];
             p.Q = F[F_Q * P + lane]; p.U = F[F_U * P + lane]; p.V = F[F_V * P + lane];
         }
-        p.ic = A.pool.ic[lane]; p.jc = A.pool.jc[lane]; p.kc = A.pool.kc[lane]; p.inside = true; p.xfreq_ref = 0.0;
+        p.ic = A.pool.ic[lane]; p.jc = A.pool.jc[lane]; p.kc = A.pool.kc[lane]; p.inside = true; p.xfreq_ref = 0.0; p.icl = 0;
+        if (VAR == 4) { p.icl = p.ic; p.ic = 1; }               // clump mode keeps the owner clump in the cell-index plane
         g.init(A.seed, (uint64_t)(A.first_id + k * A.stride), A.pool.rng_n[lane]);
     }
 
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(256, LART_WAVES(STOKES, PEEL)) void transport_kerne
             F[F_NX * P + lane] = p.nx; F[F_NY * P + lane] = p.ny; F[F_NZ * P + lane] = p.nz;
             F[F_Q * P + lane] = p.Q; F[F_U * P + lane] = p.U; F[F_V * P + lane] = p.V;
         }
-        A.pool.ic[lane] = p.ic; A.pool.jc[lane] = p.jc; A.pool.kc[lane] = p.kc;
+        A.pool.ic[lane] = (VAR == 4) ? p.icl : p.ic; A.pool.jc[lane] = p.jc; A.pool.kc[lane] = p.kc;
     }
 #ifdef LART_PROFILE
     LART_PROF_MARK(p, 0);

@@ -129,6 +129,21 @@ class Params:
     calc_P: bool = False
     calc_Pnew: bool = False
     geometry_JPa: int = 2147483647
+    # clump medium (define.f90:325-352; uniform clump properties, no overlap, no radial profiles / file input)
+    use_clump_medium: bool = False
+    clump_radius: float = -1.0
+    clump_N_clumps: float = -1.0
+    clump_f_vol: float = -1.0
+    clump_f_cov: float = -1.0
+    clump_tau0: float = -1.0
+    clump_NHI: float = -1.0
+    clump_nH: float = -1.0
+    clump_temperature: float = -1.0
+    clump_sigma_v: float = 0.0
+    clump_fully_inside: bool = True
+    save_clump_info: bool = False
+    Vrot: float = 0.0
+    rinner: float = 0.0
     # octree medium (grid_mod_amr.f90); only the generic text format of read_generic_amr.f90:112-185 is read here
     use_amr_grid: bool = False
     amr_type: str = "generic"
@@ -145,7 +160,7 @@ class Params:
 # fields of params_type that exist in the reference but select physics outside this path: accepted at their
 # default, rejected ("not supported") when set to something that would change the path
 _UNSUPPORTED_DEFAULTS = {
-    "use_clump_medium": False, "fine_structure": False, "include_deuterium": False,
+    "fine_structure": False, "include_deuterium": False,
     "line_id": "ly_alpha", "h2_model": "none", "xy_symmetry": False, "z_symmetry": False, "bturb": -999.0,
     "dens_file": "", "temp_file": "", "velo_file": "", "emiss_file": "", "cart_file": "", "input_field": "",
     "star_file": "", "use_cie_condition": False, "density_rscale": -999.9, "density_zscale": -999.9,
@@ -296,12 +311,18 @@ def read_input(par, line=None):
         raise LartInputError("par%%source_geometry = '%s' is not supported by this path" % par.source_geometry)
     if par.spectral_type not in ("voigt", "monochromatic"):
         raise LartInputError("par%%spectral_type = '%s' is not supported by this path" % par.spectral_type)
-    if par.velocity_type not in ("", "hubble", "constant_radial", "parallel_velocity"):
+    if par.use_clump_medium and par.velocity_type in ("rotating_solid_body", "rotating_galaxy_halo"):
+        pass                                                              # per-clump fields of assign_clump_velocities_from_type
+    elif par.velocity_type not in ("", "hubble", "constant_radial", "parallel_velocity"):
         raise LartInputError("par%%velocity_type = '%s' is not supported by this path" % par.velocity_type)
     if par.temperature <= 0.0:
         raise LartInputError("ERROR: par%temperature must be > 0 K (or set par%bturb > 0)")
     if par.nx == 1 or par.ny == 1 or par.nz == 1:
         par.xyz_symmetry = False                                          # setup.f90:167
+    if par.nside > 0 and par.use_clump_medium:                           # setup.f90:177-181
+        raise LartInputError("ERROR: nside>0 (HEALPIX inside observer) is not supported with clump mode")
+    if par.use_clump_medium and par.use_amr_grid:
+        raise LartInputError("par%use_clump_medium and par%use_amr_grid are mutually exclusive")
     if par.nside > 0:                                                    # observer inside the medium: setup.f90:169-186
         par.use_stokes = False
         par.save_peeloff = True
@@ -755,8 +776,11 @@ class Simulation:
             for k, v in d.items():
                 set_param(par, k, v)
         self.par, self.line, self.scatt_mat = read_input(par)
-        self.amr = None
-        if self.par.use_amr_grid:                                         # grid_create_amr (main.f90:31-35)
+        self.amr = None; self.clumps = None
+        if self.par.use_clump_medium:                                     # grid_create_clump (main.f90:25-27)
+            from . import clump as clump_mod
+            self.clumps, self.grid = clump_mod.grid_create_clump(self.par, self.line)
+        elif self.par.use_amr_grid:                                       # grid_create_amr (main.f90:31-35)
             from . import amr as amr_mod
             self.amr, self.grid = amr_mod.grid_create_amr(self.par, self.line, self.par.amr_file)
         else:
@@ -765,7 +789,11 @@ class Simulation:
         self.cpar = make_lart_params(self.par, self.line, self.grid)
         self.ctx = capi.Context(self.cpar, device)
         g = self.grid
-        if self.amr is not None:
+        if self.clumps is not None:
+            c = self.clumps
+            self.ctx.set_clumps(c.x, c.y, c.z, c.vx, c.vy, c.vz, c.radius, c.rhokap, c.rhokapD, c.voigt_a, c.Dfreq,
+                                c.sphere_R, c.Dfreq_ref, c.voigt_a_ref, c.cgx, c.cg_min, c.cg_d, c.cg_start, c.cg_list)
+        elif self.amr is not None:
             a = self.amr
             self.ctx.set_grid_amr(a.xmin, a.xmax, a.cx, a.cy, a.cz, a.ch, a.children, a.neighbor, a.ileaf, a.icell_of_leaf,
                                   a.rhokap, a.voigt_a, a.Dfreq, a.vfx, a.vfy, a.vfz, a.rhokapD)
@@ -781,6 +809,11 @@ class Simulation:
                 self.ctx.set_observers_heal(o.xyz, self.par.nside)
             else:
                 self.ctx.set_observers(o.xyz, o.rmatrix, o.dxim, o.dyim, o.nxim, o.nyim)
+        if self.clumps is not None:
+            if self.par.calc_J or self.par.calc_P or self.par.calc_Pnew:
+                raise LartInputError("CALCJ/CALCP profile tallies are not defined for the clump medium")
+            self.jpa = JPa(); self.nphotons_run = 0
+            return
         if self.amr is not None:
             amr_mod.create_JPa_amr_mem(self.par, self.amr)
             self.jpa = JPa(nbins=self.amr.nbins)

@@ -269,6 +269,7 @@ typedef struct {
     double id; double nscatt_gas, nscatt_dust;
     double x, y, z, kx, ky, kz, mx, my, mz, nx, ny, nz;
     int icell, jcell, kcell;
+    int icell_clump;                  /* 0 = vacuum, > 0 = owner clump (define.f90:90) */
     double xfreq, xfreq_ref, wgt;
     int inside;
     double I, Q, U, V, E1, E2, E3;
@@ -283,8 +284,20 @@ typedef struct {
     int nr_JPa, nz_JPa; double rmax_JPa, dr_JPa, dz_JPa;
 } amr_t;
 
+/* clump population and CSR acceleration grid: clump_mod.f90:27-118 */
+typedef struct {
+    int64_t N; double sphere_R, r_min, radius_max;
+    double rhokap_ref, voigt_a_ref, Dfreq_ref, vtherm_ref, temperature_ref;
+    double *x, *y, *z, *vx, *vy, *vz, *radius, *radius2, *rhokap, *rhokapD, *voigt_a, *Dfreq, *vtherm;
+    int cgx; double cg_min, cg_d, cg_inv; int32_t *cg_start, *cg_list; int64_t nreg;
+    double fvol, fcov; int rsa_grid; double rsa_acceptance;
+} clumps_t;
+
 struct orc_sim {
     int use_amr_grid; char amr_file[512]; amr_t amr;
+    int use_clump_medium, clump_fully_inside; clumps_t cl;
+    double clump_radius, clump_N_clumps, clump_f_vol, clump_f_cov, clump_tau0, clump_NHI, clump_nH, clump_temperature, clump_sigma_v;
+    double Vrot, rinner, velocity_min, velocity_max;
     /* --- par% (define.f90:209-544) --- */
     double no_photons; int iseed;
     double temperature, taumax, tauhomo, N_gasmax, N_gashomo, Vexp;
@@ -327,6 +340,7 @@ struct orc_sim {
     int64_t log_n; double *log_nscatt, *log_xfreq;
 };
 
+static int grid_create_clump(orc_sim *s);
 static int grid_create_amr(orc_sim *s);
 static int create_JPa_amr_mem(orc_sim *s);
 static int amr_JPa_bin(const orc_sim *s, int il, double x0, double y0, double z0);
@@ -355,6 +369,8 @@ static void set_defaults(orc_sim *s) {
     s->DGR = 0.0; s->distance2cm = -999.9; s->distance = NAN; s->dxim = NAN; s->dyim = NAN;
     for (int i = 0; i < MAX_OBS; i++) s->alpha[i] = s->beta[i] = s->gamma[i] = s->obsx[i] = s->obsy[i] = s->obsz[i] = NAN;
     s->geometry = 0; s->geometry_JPa = 2147483647;
+    s->clump_radius = s->clump_N_clumps = s->clump_f_vol = s->clump_f_cov = s->clump_tau0 = s->clump_NHI = s->clump_nH = s->clump_temperature = -1.0;
+    s->clump_fully_inside = 1; s->velocity_min = NAN; s->velocity_max = NAN;
 }
 
 static int set_param(orc_sim *s, const char *k, const char *v) {
@@ -372,6 +388,8 @@ static int set_param(orc_sim *s, const char *k, const char *v) {
     if (!strcmp(k, "N_HImax") || !strcmp(k, "N_gasmax") || !strcmp(k, "N_HI")) { s->N_gasmax = atof(v); return 0; }
     if (!strcmp(k, "N_HIhomo") || !strcmp(k, "N_gashomo")) { s->N_gashomo = atof(v); return 0; }
     if (!strcmp(k, "tau0")) { s->taumax = atof(v); return 0; }
+    B(use_clump_medium) B(clump_fully_inside) D(clump_radius) D(clump_N_clumps) D(clump_f_vol) D(clump_f_cov) D(clump_tau0) D(clump_NHI) D(clump_nH)
+    D(clump_temperature) D(clump_sigma_v) D(Vrot) D(rinner) D(velocity_min) D(velocity_max)
     if (!strcmp(k, "use_amr_grid")) { s->use_amr_grid = parse_bool(v); return 0; }
     if (!strcmp(k, "amr_file")) { snprintf(s->amr_file, sizeof s->amr_file, "%s", v); return 0; }
     if (!strcmp(k, "amr_type")) return 0;
@@ -387,6 +405,7 @@ static int set_param(orc_sim *s, const char *k, const char *v) {
     if (!strcmp(k, "velocity_type")) {
         if (!strcmp(v, "hubble")) s->velocity_type = 1; else if (!strcmp(v, "constant_radial")) s->velocity_type = 2;
         else if (!strcmp(v, "parallel_velocity")) s->velocity_type = 3; else if (!v[0]) s->velocity_type = 0;
+        else if (!strcmp(v, "rotating_solid_body")) s->velocity_type = 4; else if (!strcmp(v, "rotating_galaxy_halo")) s->velocity_type = 5;   /* clump medium only */
         else { snprintf(g_err, sizeof g_err, "velocity_type '%s' not supported by the oracle", v); return -1; }
         return 0; }
     if (!strcmp(k, "geometry")) {
@@ -482,6 +501,7 @@ static int read_input_post(orc_sim *s) {
     /* setup.f90:161-165: a 1-cell axis disables xyz_symmetry */
     if (s->nx == 1 || s->ny == 1 || s->nz == 1) s->xyz_symmetry = 0;
     /* :169-186 observer inside the medium (HEALPix): nostokes, no symmetry, no TAN image */
+    if (s->nside > 0 && s->use_clump_medium) { snprintf(g_err, sizeof g_err, "ERROR: nside>0 (HEALPIX inside observer) is not supported with clump mode"); return -1; }
     if (s->nside > 0) { s->use_stokes = 0; s->save_peeloff = 1; s->xyz_symmetry = 0; s->nxim = 0; s->nyim = 0; }
     /* :188-206 peel-off switches */
     if (!(s->save_peeloff_2D || s->save_peeloff_3D)) s->save_peeloff = 0;
@@ -633,6 +653,7 @@ static int grid_create(orc_sim *s) {
     if (s->N_gasmax <= 0.0) s->N_gasmax = N_gaspole;
     if (s->N_gashomo <= 0.0) s->N_gashomo = N_gashomo;
     /* (3) velocity field :786-946 (velocities in units of the local thermal speed) */
+    if (s->velocity_type >= 4 && !s->use_clump_medium) { snprintf(g_err, sizeof g_err, "rotating velocity fields are supported for the clump medium only"); return -1; }
     if (s->velocity_type) {
         double rpeak = (s->rmax <= 0.0) ? fmax(s->xmax, fmax(s->ymax, s->zmax)) : s->rmax;
         for (int k = 1; k <= nz; k++) for (int j = 1; j <= ny; j++) for (int i = 1; i <= nx; i++) {
@@ -652,6 +673,10 @@ static int grid_create(orc_sim *s) {
     double atau0 = s->voigt_amean * s->tauhomo;
     /* car_setup_freq_grid :1442-1548 */
     s->atau3 = pow(s->voigt_amean * s->tauhomo, 1.0 / 3.0);
+    if (isfinite(s->velocity_min) && isfinite(s->velocity_max)) {                   /* :1462-1467 */
+        double vt0 = vtherm_total(s, s->temperature);
+        s->par_xfreq_min = -s->velocity_max / vt0; s->par_xfreq_max = -s->velocity_min / vt0;
+    }
     if (!(isfinite(s->par_xfreq_max) && isfinite(s->par_xfreq_min))) {
         double xscale = (s->taumax <= 5e1) ? 25.0 : (s->taumax <= 5e2) ? 14.0 : (s->taumax <= 5e3) ? 10.0 : 5.0;
         double vt = vtherm_total(s, s->temperature);
@@ -828,7 +853,7 @@ orc_sim *orc_create(const char *params) {
         if (set_param(s, k, eq + 1)) { free(buf); free(s); return NULL; }
     }
     free(buf);
-    if (read_input_post(s) || (s->use_amr_grid ? (grid_create_amr(s) || create_JPa_amr_mem(s)) : (grid_create(s) || create_JPa_mem(s))) || observer_create(s)) { free(s); return NULL; }
+    if (read_input_post(s) || (s->use_clump_medium ? grid_create_clump(s) : s->use_amr_grid ? (grid_create_amr(s) || create_JPa_amr_mem(s)) : (grid_create(s) || create_JPa_mem(s))) || observer_create(s)) { free(s); return NULL; }
     return s;
 }
 static void free_obs(obs_t *o) { free(o->scatt); free(o->direc); free(o->I); free(o->Q); free(o->U); free(o->V);
@@ -1026,6 +1051,10 @@ static int grid_create_amr(orc_sim *s) {
     if (at <= 1.0) { s->xcrit = 0.0; s->xcrit2 = 0.0; } else { double xi = (at <= 60.0) ? 0.6 : 1.4, chi = (at <= 60.0) ? 1.2 : 0.6; s->xcrit = 0.02 * exp(xi * pow(log(at), chi)); s->xcrit2 = s->xcrit * s->xcrit; }
     /* amr_setup_freq_grid (:726-800): same rules as the Cartesian grid */
     s->atau3 = pow(s->voigt_amean * s->tauhomo, 1.0 / 3.0);
+    if (isfinite(s->velocity_min) && isfinite(s->velocity_max)) {                   /* :1462-1467 */
+        double vt0 = vtherm_total(s, s->temperature);
+        s->par_xfreq_min = -s->velocity_max / vt0; s->par_xfreq_max = -s->velocity_min / vt0;
+    }
     if (!(isfinite(s->par_xfreq_max) && isfinite(s->par_xfreq_min))) {
         double xscale = (s->taumax <= 5e1) ? 25.0 : (s->taumax <= 5e2) ? 14.0 : (s->taumax <= 5e3) ? 10.0 : 5.0, vt = vtherm_total(s, s->temperature);
         if (s->Vexp == 0.0) { s->par_xfreq_max = floor(xscale * s->atau3) + 1.0; s->par_xfreq_min = -(floor(xscale * s->atau3 + 0.0) + 1.0); }
@@ -1169,6 +1198,338 @@ static double raytrace_to_edge_amr(const orc_sim *s, const photon_t *p, double d
     }
 }
 
+
+/* =====================================================================================
+ * Clump medium: clump_mod.f90, grid_mod_clump.f90, raytrace_clump.f90, line_clump_mod.f90
+ * (non-overlapping spheres of uniform interior in vacuum; uniform clump properties unless set per clump;
+ *  radial profiles, file input and overlapping clumps are outside this path: SURVEY 8f-3)
+ * photon%xfreq is in REF Doppler units (cl_Dfreq_ref) throughout; shifted by -/+ ulos_clump at clump entry/exit.
+ * ===================================================================================== */
+/* voigt_clump (line type 1): clump_mod.f90:130-170; kappa_clump :176-182; ulos_clump :184-190 */
+static inline double voigt_clump(const clumps_t *c, double xfreq, int64_t icl) { return orc_voigt(xfreq * (c->Dfreq_ref / c->Dfreq[icl-1]), c->voigt_a[icl-1]); }
+static inline double kappa_clump(const orc_sim *s, double xfreq, int64_t icl) {
+    const clumps_t *c = &s->cl; double kap = c->rhokap[icl-1] * voigt_clump(c, xfreq, icl);
+    if (s->DGR > 0.0) kap = kap + c->rhokapD[icl-1];
+    return kap;
+}
+static inline double ulos_clump(const clumps_t *c, int64_t icl, double kx, double ky, double kz) {
+    return (c->vx[icl-1] * kx + c->vy[icl-1] * ky + c->vz[icl-1] * kz) * (c->Dfreq[icl-1] / c->Dfreq_ref);
+}
+#define CGIDX(c,i,j,k) ((size_t)(i) + (size_t)(j) * (c)->cgx + (size_t)(k) * (c)->cgx * (c)->cgx)      /* 0-based cell -> 0-based slot of cg_start */
+
+/* generate_clumps, uniform path: clump_mod.f90:897-1151 (RSA with linked-list grid; MT stream of rank 0) */
+static int generate_clumps(orc_sim *s, rng_t *g) {
+    clumps_t *c = &s->cl; int64_t N = c->N;
+    int rg = (int)pow((double)N, 1.0 / 3.0) + 1; if (rg < 32) rg = 32; if (rg > 512) rg = 512;
+    double rg_cell = fmax(2.0 * c->sphere_R / rg, 2.0 * c->radius_max);
+    rg = (int)((2.0 * c->sphere_R) / rg_cell) + 1; if (rg < 2) rg = 2;
+    rg_cell = (2.0 * c->sphere_R) / rg;
+    c->rsa_grid = rg;
+    double min_sep2 = (2.0 * c->radius_max) * (2.0 * c->radius_max);
+    if (s->clump_fully_inside) {
+        if (c->radius_max >= c->sphere_R) { snprintf(g_err, sizeof g_err, "clump_fully_inside: max clump radius >= sphere_R"); return -1; }
+        if (c->r_min + 2.0 * c->radius_max > c->sphere_R) { snprintf(g_err, sizeof g_err, "clump_fully_inside: rmin + 2*cl_radius_max > rmax"); return -1; }
+    }
+    size_t ncell = (size_t)rg * rg * rg;
+    int *head = malloc(ncell * sizeof(int)), *nxt = malloc((size_t)N * sizeof(int));
+    for (size_t i = 0; i < ncell; i++) head[i] = -1;
+    for (int64_t i = 0; i < N; i++) nxt[i] = -1;
+    int64_t n_attempts = 0, icl = 0;
+    double r_max_center = s->clump_fully_inside ? c->sphere_R - s->clump_radius : c->sphere_R;
+    double r_min_center = s->clump_fully_inside ? c->r_min + s->clump_radius : c->r_min;
+    double r_max_center2 = r_max_center * r_max_center, r_min_center2 = r_min_center * r_min_center;
+    while (icl < N) {
+        n_attempts++;
+        double xc, yc, zc, d2;
+        for (;;) {                                                  /* box rejection :1044-1051 */
+            xc = (2.0 * rnd(g) - 1.0) * r_max_center; yc = (2.0 * rnd(g) - 1.0) * r_max_center; zc = (2.0 * rnd(g) - 1.0) * r_max_center;
+            d2 = xc * xc + yc * yc + zc * zc;
+            if (d2 <= r_max_center2 && d2 >= r_min_center2) break;
+        }
+        int ig = (int)((xc + c->sphere_R) / rg_cell), jg = (int)((yc + c->sphere_R) / rg_cell), kg = (int)((zc + c->sphere_R) / rg_cell);
+        if (ig < 0) ig = 0; if (ig > rg - 1) ig = rg - 1; if (jg < 0) jg = 0; if (jg > rg - 1) jg = rg - 1; if (kg < 0) kg = 0; if (kg > rg - 1) kg = rg - 1;
+        int overlap = 0;
+        for (int k2 = (kg > 0 ? kg - 1 : 0); k2 <= (kg < rg - 1 ? kg + 1 : rg - 1) && !overlap; k2++)
+            for (int j2 = (jg > 0 ? jg - 1 : 0); j2 <= (jg < rg - 1 ? jg + 1 : rg - 1) && !overlap; j2++)
+                for (int i2 = (ig > 0 ? ig - 1 : 0); i2 <= (ig < rg - 1 ? ig + 1 : rg - 1) && !overlap; i2++) {
+                    int jnb = head[(size_t)i2 + (size_t)j2 * rg + (size_t)k2 * rg * rg];
+                    while (jnb > 0) {
+                        double ddx = xc - c->x[jnb-1], ddy = yc - c->y[jnb-1], ddz = zc - c->z[jnb-1];
+                        if (ddx * ddx + ddy * ddy + ddz * ddz < min_sep2) { overlap = 1; break; }
+                        jnb = nxt[jnb-1];
+                    }
+                }
+        if (overlap) continue;
+        icl++;
+        c->x[icl-1] = xc; c->y[icl-1] = yc; c->z[icl-1] = zc;
+        if (s->clump_sigma_v > 0.0) {                                /* :1126-1131 */
+            c->vx[icl-1] = s->clump_sigma_v / c->vtherm[icl-1] * rand_gauss(g);
+            c->vy[icl-1] = s->clump_sigma_v / c->vtherm[icl-1] * rand_gauss(g);
+            c->vz[icl-1] = s->clump_sigma_v / c->vtherm[icl-1] * rand_gauss(g);
+        }
+        size_t cell = (size_t)ig + (size_t)jg * rg + (size_t)kg * rg * rg;
+        nxt[icl-1] = head[cell]; head[cell] = (int)icl;
+    }
+    c->rsa_acceptance = (double)N / (double)n_attempts;
+    free(head); free(nxt);
+    return 0;
+}
+/* assign_clump_velocities_from_type: :1153-1264 */
+static void assign_clump_velocities(orc_sim *s) {
+    clumps_t *c = &s->cl;
+    for (int64_t i = 0; i < c->N; i++) {
+        double xc = c->x[i], yc = c->y[i], zc = c->z[i], rr = sqrt(xc * xc + yc * yc + zc * zc), vx = 0, vy = 0, vz = 0;
+        switch (s->velocity_type) {
+        case 1: vx = s->Vexp * xc / c->sphere_R; vy = s->Vexp * yc / c->sphere_R; vz = s->Vexp * zc / c->sphere_R; break;
+        case 2: if (rr > 0.0) { vx = s->Vexp * xc / rr; vy = s->Vexp * yc / rr; vz = s->Vexp * zc / rr; } break;
+        case 3: vx = s->Vx; vy = s->Vy; vz = s->Vz; break;
+        case 4: vx = -s->Vrot * yc / c->sphere_R; vy = s->Vrot * xc / c->sphere_R; break;
+        case 5: { double rc = sqrt(xc * xc + yc * yc);
+                  if (rc > 0.0) { if (rc < s->rinner) { vx = -s->Vrot * yc / s->rinner; vy = s->Vrot * xc / s->rinner; } else { vx = -s->Vrot * yc / rc; vy = s->Vrot * xc / rc; } } } break;
+        default: break; }
+        c->vx[i] += vx / c->vtherm[i]; c->vy[i] += vy / c->vtherm[i]; c->vz[i] += vz / c->vtherm[i];
+    }
+}
+/* clump_cell_range :1345-1360 and build_clump_csr :1267-1342 */
+static void clump_cell_range(const clumps_t *c, int64_t i, int r[6]) {
+    double rcl = c->radius[i]; int m = c->cgx - 1;
+    r[0] = (int)((c->x[i] - c->cg_min - rcl) * c->cg_inv); if (r[0] < 0) r[0] = 0;
+    r[1] = (int)((c->x[i] - c->cg_min + rcl) * c->cg_inv); if (r[1] > m) r[1] = m;
+    r[2] = (int)((c->y[i] - c->cg_min - rcl) * c->cg_inv); if (r[2] < 0) r[2] = 0;
+    r[3] = (int)((c->y[i] - c->cg_min + rcl) * c->cg_inv); if (r[3] > m) r[3] = m;
+    r[4] = (int)((c->z[i] - c->cg_min - rcl) * c->cg_inv); if (r[4] < 0) r[4] = 0;
+    r[5] = (int)((c->z[i] - c->cg_min + rcl) * c->cg_inv); if (r[5] > m) r[5] = m;
+}
+static void build_clump_csr(clumps_t *c) {
+    int cg = (int)pow((double)c->N, 1.0 / 3.0) + 1; if (cg < 32) cg = 32; if (cg > 512) cg = 512;
+    c->cgx = cg; size_t ncells = (size_t)cg * cg * cg;
+    c->cg_min = -(c->sphere_R + c->radius_max);
+    c->cg_d = (2.0 * (c->sphere_R + c->radius_max)) / cg; c->cg_inv = 1.0 / c->cg_d;
+    free(c->cg_start); free(c->cg_list);
+    c->cg_start = malloc((ncells + 1) * sizeof(int32_t));
+    int *cnt = calloc(ncells, sizeof(int)); int r[6];
+    for (int64_t i = 0; i < c->N; i++) { clump_cell_range(c, i, r);
+        for (int k = r[4]; k <= r[5]; k++) for (int j = r[2]; j <= r[3]; j++) for (int ii = r[0]; ii <= r[1]; ii++) cnt[CGIDX(c,ii,j,k)]++; }
+    c->cg_start[0] = 1;
+    for (size_t q = 0; q < ncells; q++) c->cg_start[q+1] = c->cg_start[q] + cnt[q];
+    c->nreg = c->cg_start[ncells] - 1;
+    c->cg_list = malloc((size_t)(c->nreg > 0 ? c->nreg : 1) * sizeof(int32_t));
+    memset(cnt, 0, ncells * sizeof(int));
+    for (int64_t i = 0; i < c->N; i++) { clump_cell_range(c, i, r);
+        for (int k = r[4]; k <= r[5]; k++) for (int j = r[2]; j <= r[3]; j++) for (int ii = r[0]; ii <= r[1]; ii++) {
+            size_t q = CGIDX(c,ii,j,k); c->cg_list[c->cg_start[q] - 1 + cnt[q]] = (int32_t)(i + 1); cnt[q]++; } }
+    free(cnt);
+}
+/* init_clumps, uniform path: clump_mod.f90:646-891 */
+static int init_clumps(orc_sim *s, double R_sphere) {
+    clumps_t *c = &s->cl; memset(c, 0, sizeof *c);
+    c->sphere_R = R_sphere;
+    if (s->clump_radius <= 0.0) { snprintf(g_err, sizeof g_err, "ERROR: clump_radius must be > 0"); return -1; }
+    c->r_min = s->rmin > 0.0 ? s->rmin : 0.0;
+    if (c->r_min >= R_sphere) { snprintf(g_err, sizeof g_err, "ERROR: par%%rmin must be < par%%rmax for clump placement"); return -1; }
+    c->radius_max = s->clump_radius;
+    double temp_cl = s->clump_temperature < 0.0 ? s->temperature : s->clump_temperature, vth = vtherm_total(s, temp_cl);
+    c->Dfreq_ref = vth / (s->wavelength0 * UM2KM); c->vtherm_ref = vth; c->temperature_ref = temp_cl;
+    c->voigt_a_ref = (s->damping / FOURPI) / c->Dfreq_ref;
+    double R = R_sphere, r0 = c->r_min, rc = c->radius_max, shell2 = R * R + R * r0 + r0 * r0;
+    if (s->clump_N_clumps > 0.0) c->N = (int64_t)s->clump_N_clumps;
+    else if (s->clump_f_vol > 0.0) c->N = (int64_t)llround(s->clump_f_vol * (R * R * R - r0 * r0 * r0) / (rc * rc * rc));
+    else if (s->clump_f_cov > 0.0) c->N = (int64_t)llround((4.0 / 3.0) * s->clump_f_cov * shell2 / (rc * rc));
+    else { snprintf(g_err, sizeof g_err, "ERROR: specify clump_N_clumps, clump_f_vol, or clump_f_cov"); return -1; }
+    if (c->N <= 0) c->N = 1;
+    c->fvol = (double)c->N * rc * rc * rc / fmax(R * R * R - r0 * r0 * r0, 2.2250738585072014e-308);
+    c->fcov = 0.75 * (double)c->N * rc * rc / fmax(shell2, 2.2250738585072014e-308);
+    if (s->clump_tau0 > 0.0) c->rhokap_ref = s->clump_tau0 / (orc_voigt(0.0, c->voigt_a_ref) * s->clump_radius);
+    else if (s->clump_NHI > 0.0) c->rhokap_ref = s->clump_NHI * s->cross0 / (c->Dfreq_ref * s->clump_radius);
+    else if (s->clump_nH > 0.0) c->rhokap_ref = s->clump_nH * s->cross0 * s->distance2cm / c->Dfreq_ref;
+    else if (s->taumax > 0.0 || s->N_gasmax > 0.0) {
+        double GF = (double)c->N * rc * rc * rc / fmax(shell2, 2.2250738585072014e-308);
+        if (GF <= 0.0) { snprintf(g_err, sizeof g_err, "ERROR: cannot back-solve clump opacity"); return -1; }
+        if (s->taumax > 0.0) c->rhokap_ref = s->taumax / (GF * orc_voigt(0.0, c->voigt_a_ref));
+        else c->rhokap_ref = s->N_gasmax * s->cross0 / (GF * c->Dfreq_ref);
+    } else { snprintf(g_err, sizeof g_err, "ERROR: specify clump_tau0, clump_NHI, clump_nH, taumax, or N_HImax"); return -1; }
+    size_t n = (size_t)c->N;
+    c->x = calloc(n, 8); c->y = calloc(n, 8); c->z = calloc(n, 8); c->vx = calloc(n, 8); c->vy = calloc(n, 8); c->vz = calloc(n, 8);
+    c->radius = malloc(n * 8); c->radius2 = malloc(n * 8); c->rhokap = malloc(n * 8); c->rhokapD = calloc(n, 8);
+    c->voigt_a = malloc(n * 8); c->Dfreq = malloc(n * 8); c->vtherm = malloc(n * 8);
+    for (size_t i = 0; i < n; i++) { c->radius[i] = rc; c->radius2[i] = rc * rc; c->rhokap[i] = c->rhokap_ref; c->voigt_a[i] = c->voigt_a_ref;
+        c->Dfreq[i] = c->Dfreq_ref; c->vtherm[i] = c->vtherm_ref;
+        if (s->DGR > 0.0) c->rhokapD[i] = c->rhokap_ref * s->cext_dust * s->DGR * c->Dfreq_ref / s->cross0; }
+    mt_t *mt = malloc(sizeof *mt); mt_init(mt, (int64_t)s->iseed);      /* rank 0's stream: init_random_seed(par%iseed), setup.f90:775 */
+    rng_t g; memset(&g, 0, sizeof g); g.kind = 0; g.mt = mt;
+    int rc_ = generate_clumps(s, &g);
+    free(mt);
+    if (rc_) return -1;
+    if (s->velocity_type) assign_clump_velocities(s);
+    build_clump_csr(c);
+    return 0;
+}
+/* compute_clump_scalars: :2316-2378 */
+static void compute_clump_scalars(orc_sim *s) {
+    const clumps_t *c = &s->cl; double shell2 = c->sphere_R * c->sphere_R + c->sphere_R * c->r_min + c->r_min * c->r_min, v[4] = {0, 0, 0, 0};
+    if (shell2 <= 0.0) shell2 = c->sphere_R * c->sphere_R;
+    for (int64_t i = 0; i < c->N; i++) {
+        double voigt0 = orc_voigt(0.0, c->voigt_a[i]), r3 = c->radius[i] * c->radius[i] * c->radius[i];
+        double di2 = fmax(c->x[i] * c->x[i] + c->y[i] * c->y[i] + c->z[i] * c->z[i], c->radius[i] * c->radius[i]);
+        double wh = r3 / shell2, wm = r3 / (3.0 * di2);
+        v[0] += c->rhokap[i] * voigt0 * wh; v[1] += c->rhokap[i] * voigt0 * wm;
+        v[2] += c->rhokap[i] * c->Dfreq[i] * wh / s->cross0; v[3] += c->rhokap[i] * c->Dfreq[i] * wm / s->cross0;
+    }
+    s->tauhomo = v[0]; s->taumax = v[1]; s->N_gashomo = v[2]; s->N_gasmax = v[3];
+}
+/* grid_create_clump: grid_mod_clump.f90:33-131 */
+static int grid_create_clump(orc_sim *s) {
+    if (s->rmax <= 0.0) { snprintf(g_err, sizeof g_err, "ERROR: par%%rmax must be > 0 for clump medium"); return -1; }
+    s->xmax = s->ymax = s->zmax = s->rmax;
+    if (s->nx < 1) s->nx = 11; if (s->ny < 1) s->ny = 11; if (s->nz < 1) s->nz = 11;
+    s->xyz_symmetry = 0; s->xy_periodic = 0;
+    if (init_clumps(s, s->rmax)) return -1;
+    compute_clump_scalars(s);
+    if (grid_create(s)) return -1;
+    size_t nc = (size_t)s->nx * s->ny * s->nz;
+    for (size_t i = 0; i < nc; i++) { s->rhokap[i] = 0.0; s->Dfreq[i] = s->cl.Dfreq_ref; s->voigt_a[i] = s->cl.voigt_a_ref; s->vfx[i] = s->vfy[i] = s->vfz[i] = 0.0; }
+    s->Dfreq_ref = s->cl.Dfreq_ref; s->voigt_amean = s->cl.voigt_a_ref;
+    s->raytrace_variant = 4;
+    return 0;
+}
+/* find_next_clump: clump_mod.f90:1390-1507 (DDA over the CSR grid, nearest entry first) */
+static int find_next_clump(const clumps_t *c, double xp, double yp, double zp, double kx, double ky, double kz, int64_t skip_icl, double t_max,
+                           double *t_entry, double *t_exit, int64_t *icl_found, double *ncell) {
+    double best_te = HUGEST, best_tx2 = 0.0, d = 0.0; int64_t best_icl = 0; int cg = c->cgx;
+    int ci = (int)((xp - c->cg_min) * c->cg_inv), cj = (int)((yp - c->cg_min) * c->cg_inv), ck = (int)((zp - c->cg_min) * c->cg_inv);
+    if (ci > cg - 1) ci = cg - 1; if (ci < 0) ci = 0; if (cj > cg - 1) cj = cg - 1; if (cj < 0) cj = 0; if (ck > cg - 1) ck = cg - 1; if (ck < 0) ck = 0;
+    int si, sj, sk; double tx, ty, tz, delx, dely, delz;
+    if (kx > 0.0) { si = 1; tx = ((c->cg_min + (double)(ci + 1) * c->cg_d) - xp) / kx; delx = c->cg_d / kx; }
+    else if (kx < 0.0) { si = -1; tx = ((c->cg_min + (double)ci * c->cg_d) - xp) / kx; delx = -c->cg_d / kx; } else { si = 0; tx = HUGEST; delx = HUGEST; }
+    if (ky > 0.0) { sj = 1; ty = ((c->cg_min + (double)(cj + 1) * c->cg_d) - yp) / ky; dely = c->cg_d / ky; }
+    else if (ky < 0.0) { sj = -1; ty = ((c->cg_min + (double)cj * c->cg_d) - yp) / ky; dely = -c->cg_d / ky; } else { sj = 0; ty = HUGEST; dely = HUGEST; }
+    if (kz > 0.0) { sk = 1; tz = ((c->cg_min + (double)(ck + 1) * c->cg_d) - zp) / kz; delz = c->cg_d / kz; }
+    else if (kz < 0.0) { sk = -1; tz = ((c->cg_min + (double)ck * c->cg_d) - zp) / kz; delz = -c->cg_d / kz; } else { sk = 0; tz = HUGEST; delz = HUGEST; }
+    for (;;) {
+        if (d > best_te || d > t_max) break;
+        if (ncell) *ncell += 1.0;
+        size_t q = CGIDX(c,ci,cj,ck);
+        for (int32_t ip = c->cg_start[q]; ip <= c->cg_start[q+1] - 1; ip++) {
+            int64_t icl = c->cg_list[ip-1];
+            if (icl == skip_icl) continue;
+            double rx = xp - c->x[icl-1], ry = yp - c->y[icl-1], rz = zp - c->z[icl-1];       /* ray_sphere_isect :1363-1387 */
+            double b = rx * kx + ry * ky + rz * kz, disc = b * b - (rx * rx + ry * ry + rz * rz) + c->radius2[icl-1];
+            if (disc < 0.0) continue;
+            disc = sqrt(disc);
+            double te = -b - disc, tx2 = -b + disc;
+            if (tx2 > 0.0 && te < best_te) { best_te = te; best_tx2 = tx2; best_icl = icl; }       /* (te > 0 .or. icl /= skip) holds: skip was excluded above */
+        }
+        if (tx <= ty && tx <= tz) { d = tx; ci += si; if (ci < 0 || ci >= cg) break; tx += delx; }
+        else if (ty <= tz)        { d = ty; cj += sj; if (cj < 0 || cj >= cg) break; ty += dely; }
+        else                      { d = tz; ck += sk; if (ck < 0 || ck >= cg) break; tz += delz; }
+    }
+    if (best_icl > 0 && best_te <= t_max) { *t_entry = best_te; *t_exit = fmin(best_tx2, t_max); *icl_found = best_icl; return 1; }
+    return 0;
+}
+/* clump_exit_dist :1511-1526, sphere_exit_dist :1530-1540 */
+static inline double clump_exit_dist(const clumps_t *c, double xp, double yp, double zp, double kx, double ky, double kz, int64_t icl) {
+    double rx = xp - c->x[icl-1], ry = yp - c->y[icl-1], rz = zp - c->z[icl-1], b = rx * kx + ry * ky + rz * kz;
+    double disc = b * b - (rx * rx + ry * ry + rz * rz) + c->radius2[icl-1]; if (disc < 0.0) disc = 0.0;
+    return fmax(0.0, -b + sqrt(disc));
+}
+static inline double sphere_exit_dist(const clumps_t *c, double xp, double yp, double zp, double kx, double ky, double kz) {
+    double b = xp * kx + yp * ky + zp * kz, disc = b * b - (xp * xp + yp * yp + zp * zp) + c->sphere_R * c->sphere_R; if (disc < 0.0) disc = 0.0;
+    return fmax(0.0, -b + sqrt(disc));
+}
+/* active_set_at_point (first hit): :1595-1634 -- the birth clump, generate_photon.f90:325-332 */
+static int64_t clump_at_point(const clumps_t *c, double xp, double yp, double zp) {
+    int cg = c->cgx;
+    int ci = (int)((xp - c->cg_min) * c->cg_inv), cj = (int)((yp - c->cg_min) * c->cg_inv), ck = (int)((zp - c->cg_min) * c->cg_inv);
+    if (ci > cg - 1) ci = cg - 1; if (ci < 0) ci = 0; if (cj > cg - 1) cj = cg - 1; if (cj < 0) cj = 0; if (ck > cg - 1) ck = cg - 1; if (ck < 0) ck = 0;
+    for (int k = (ck > 0 ? ck - 1 : 0); k <= (ck < cg - 1 ? ck + 1 : cg - 1); k++)
+        for (int j = (cj > 0 ? cj - 1 : 0); j <= (cj < cg - 1 ? cj + 1 : cg - 1); j++)
+            for (int i = (ci > 0 ? ci - 1 : 0); i <= (ci < cg - 1 ? ci + 1 : cg - 1); i++) {
+                size_t q = CGIDX(c,i,j,k);
+                for (int32_t ip = c->cg_start[q]; ip <= c->cg_start[q+1] - 1; ip++) {
+                    int64_t icl = c->cg_list[ip-1];
+                    double rx = xp - c->x[icl-1], ry = yp - c->y[icl-1], rz = zp - c->z[icl-1];
+                    if (rx * rx + ry * ry + rz * rz <= c->radius2[icl-1]) return icl;
+                }
+            }
+    return 0;
+}
+static inline void update_cell_idx(const orc_sim *s, photon_t *p) {             /* raytrace_clump.f90:69-76 */
+    int i = (int)floor((p->x - s->xmin) / s->dx) + 1, j = (int)floor((p->y - s->ymin) / s->dy) + 1, k = (int)floor((p->z - s->zmin) / s->dz) + 1;
+    p->icell = i < 1 ? 1 : (i > s->nx ? s->nx : i); p->jcell = j < 1 ? 1 : (j > s->ny ? s->ny : j); p->kcell = k < 1 ? 1 : (k > s->nz ? s->nz : k);
+}
+static void add_to_Jmu(const orc_sim *s, acc_t *A, const photon_t *p, int ix);
+static inline void clump_escape(const orc_sim *s, acc_t *A, const photon_t *p) {
+    int ix = (int)floor((p->xfreq - s->xfreq_min) / s->dxfreq) + 1;
+    if (ix >= 1 && ix <= s->nxfreq) { A->Jout[ix-1] += p->wgt; if (s->save_Jmu) add_to_Jmu(s, A, p, ix); }
+}
+/* raytrace_to_tau_clump: raytrace_clump.f90:83-201 */
+static void raytrace_to_tau_clump(const orc_sim *s, acc_t *A, photon_t *p, double tau_in) {
+    const clumps_t *c = &s->cl;
+    double kx = p->kx, ky = p->ky, kz = p->kz, tau_rem = tau_in; int64_t last_icl = 0;
+    while (p->inside) {
+        if (p->icell_clump > 0) {
+            int64_t icl = p->icell_clump;
+            double t_seg = clump_exit_dist(c, p->x, p->y, p->z, kx, ky, kz, icl), kap = kappa_clump(s, p->xfreq, icl);
+            A->n_cellsteps += 1.0;
+            if (tau_rem <= kap * t_seg) {
+                double ds = tau_rem / fmax(kap, 2.2250738585072014e-308);
+                p->x = p->x + ds * kx; p->y = p->y + ds * ky; p->z = p->z + ds * kz;
+                update_cell_idx(s, p); return;
+            }
+            tau_rem = tau_rem - kap * t_seg;
+            p->x = p->x + t_seg * kx; p->y = p->y + t_seg * ky; p->z = p->z + t_seg * kz;
+            p->xfreq = p->xfreq + ulos_clump(c, icl, kx, ky, kz);
+            last_icl = icl; p->icell_clump = 0;
+            if (p->x * p->x + p->y * p->y + p->z * p->z >= c->sphere_R * c->sphere_R) { p->inside = 0; update_cell_idx(s, p); p->xfreq_ref = p->xfreq; clump_escape(s, A, p); return; }
+        } else {
+            double t_sp = sphere_exit_dist(c, p->x, p->y, p->z, kx, ky, kz), te, tx2; int64_t icl_found;
+            if (t_sp <= 0.0) { p->inside = 0; p->xfreq_ref = p->xfreq; clump_escape(s, A, p); return; }
+            if (find_next_clump(c, p->x, p->y, p->z, kx, ky, kz, last_icl, t_sp, &te, &tx2, &icl_found, &A->n_cellsteps)) {
+                te = fmax(0.0, te);
+                p->x = p->x + te * kx; p->y = p->y + te * ky; p->z = p->z + te * kz;
+                p->xfreq = p->xfreq - ulos_clump(c, icl_found, kx, ky, kz);
+                last_icl = 0; p->icell_clump = (int)icl_found; update_cell_idx(s, p);
+            } else {
+                p->x = p->x + t_sp * kx; p->y = p->y + t_sp * ky; p->z = p->z + t_sp * kz;
+                p->inside = 0; update_cell_idx(s, p); p->xfreq_ref = p->xfreq; clump_escape(s, A, p); return;
+            }
+        }
+    }
+}
+/* raytrace_to_edge_clump (:204-267, tau_max < 0) and raytrace_to_edge_clump_capped (:494-541, peel-off, tau_max = 745.2) */
+static double raytrace_to_edge_clump(const orc_sim *s, const photon_t *p0, double tau_max, double *nsteps) {
+    const clumps_t *c = &s->cl;
+    double tau = 0.0, xp = p0->x, yp = p0->y, zp = p0->z, kx = p0->kx, ky = p0->ky, kz = p0->kz, xf = p0->xfreq;
+    int64_t icl_cur = p0->icell_clump, icl_found; int capped = tau_max >= 0.0;
+    if (icl_cur > 0) {
+        double t_seg = clump_exit_dist(c, xp, yp, zp, kx, ky, kz, icl_cur), kap = kappa_clump(s, xf, icl_cur);
+        if (nsteps) *nsteps += 1.0;
+        tau = tau + kap * t_seg;
+        if (capped && tau >= tau_max) return tau;
+        xp = xp + t_seg * kx; yp = yp + t_seg * ky; zp = zp + t_seg * kz;
+        xf = xf + ulos_clump(c, icl_cur, kx, ky, kz);
+        if (xp * xp + yp * yp + zp * zp >= c->sphere_R * c->sphere_R) return tau;
+    }
+    for (;;) {
+        double t_sp = sphere_exit_dist(c, xp, yp, zp, kx, ky, kz), te, tx2;
+        if (t_sp <= 0.0) break;
+        if (!find_next_clump(c, xp, yp, zp, kx, ky, kz, icl_cur, t_sp, &te, &tx2, &icl_found, nsteps)) break;
+        te = fmax(0.0, te);
+        xp = xp + te * kx; yp = yp + te * ky; zp = zp + te * kz;
+        double u_los = ulos_clump(c, icl_found, kx, ky, kz);
+        xf = xf - u_los;
+        double t_seg = clump_exit_dist(c, xp, yp, zp, kx, ky, kz, icl_found), kap = kappa_clump(s, xf, icl_found);
+        if (nsteps) *nsteps += 1.0;
+        tau = tau + kap * t_seg;
+        if (capped && tau >= tau_max) return tau;
+        xp = xp + t_seg * kx; yp = yp + t_seg * ky; zp = zp + t_seg * kz;
+        xf = xf + u_los;
+        icl_cur = icl_found;
+        if (xp * xp + yp * yp + zp * zp >= c->sphere_R * c->sphere_R) break;
+    }
+    return tau;
+}
+
 /* =====================================================================================
  * Ray marches: raytrace_car.f90
  * ===================================================================================== */
@@ -1226,6 +1587,7 @@ static void add_to_Jmu(const orc_sim *s, acc_t *A, const photon_t *p, int ix) { 
 /* raytrace_to_tau_car (:1425-1648), _car_xyzsym (:1650-1949), _car_zonly (:2519-2675) */
 static void raytrace_to_tau(const orc_sim *s, acc_t *A, photon_t *p, double tau_in, int variant) {
     if (variant == 3) { raytrace_to_tau_amr(s, A, p, tau_in); return; }
+    if (variant == 4) { raytrace_to_tau_clump(s, A, p, tau_in); return; }
     trav_t t; double xp = p->x, yp = p->y, zp = p->z;
     t.kx = p->kx; t.ky = p->ky; t.kz = p->kz; t.icell = p->icell; t.jcell = p->jcell; t.kcell = p->kcell;
     if (variant == 0) { if (setup_traversal_car(s, xp, yp, zp, &t)) { p->inside = 0; return; } }
@@ -1298,6 +1660,7 @@ static void raytrace_to_tau(const orc_sim *s, acc_t *A, photon_t *p, double tau_
  * raytrace_to_dist_car (:89-195) on the plain grid */
 static double raytrace_to_edge(const orc_sim *s, const photon_t *p, int variant, double dist, double *nsteps) {
     if (variant == 3) return raytrace_to_edge_amr(s, p, dist, nsteps);
+    if (variant == 4) return raytrace_to_edge_clump(s, p, -1.0, nsteps);                 /* uncapped: first flight (run_simulation_mod.f90:165) */
     trav_t t; double xp = p->x, yp = p->y, zp = p->z, tau = 0.0, d = 0.0;
     t.kx = p->kx; t.ky = p->ky; t.kz = p->kz; t.icell = p->icell; t.jcell = p->jcell; t.kcell = p->kcell;
     if (variant == 0) { if (setup_traversal_car(s, xp, yp, zp, &t)) return tau; }
@@ -1404,6 +1767,7 @@ static inline void obs_dir_s(const orc_sim *s, int i, const photon_t *p, photon_
 }
 /* tau along the peel ray: to the grid edge (far observers) or to the observer (inside: raytrace_to_dist, peelingoff_heal.f90:60) */
 static inline double peel_tau(const orc_sim *s, acc_t *A, const photon_t *po, double r2) {
+    if (s->use_clump_medium) return raytrace_to_edge_clump(s, po, TAU_HUGE, &A->n_cellsteps_peel);      /* peel_raytrace_to_edge: peelingoff_rect.f90:872-906 */
     return raytrace_to_edge(s, po, s->raytrace_variant, s->nside > 0 ? sqrt(r2) : -1.0, &A->n_cellsteps_peel);
 }
 static inline void obs_dir(const obs_t *o, const photon_t *p, photon_t *pobs, double *r2, int nxim, int nyim, double dxim, double dyim, int *ix, int *iy) {
@@ -1420,6 +1784,11 @@ static inline void obs_dir(const obs_t *o, const photon_t *p, photon_t *pobs, do
 #define PIX2(s,ix,iy)      ((size_t)((ix)-1) + (size_t)(s)->nxim * (size_t)((iy)-1))
 #define PIX3(s,ixf,ix,iy)  ((size_t)((ixf)-1) + (size_t)(s)->nxfreq * PIX2(s,ix,iy))
 
+/* bulk line-of-sight velocity towards the observer: the owner clump's in clump mode (peelingoff_rect.f90:65-68,186-187,403-404,534-535,658-659) */
+static inline double peel_u1(const orc_sim *s, const photon_t *p, size_t c, const photon_t *po) {
+    if (s->use_clump_medium && p->icell_clump > 0) return ulos_clump(&s->cl, p->icell_clump, po->kx, po->ky, po->kz);
+    return udot(s, c, po->kx, po->ky, po->kz);
+}
 /* peeling_direct_outside: peelingoff_rect.f90:24-129 */
 static void peeling_direct(const orc_sim *s, acc_t *A, const photon_t *p) {
     for (int i = 0; i < s->nobs; i++) {
@@ -1427,7 +1796,8 @@ static void peeling_direct(const orc_sim *s, acc_t *A, const photon_t *p) {
         obs_dir_s(s, i, p, &po, &r2, &ix, &iy);
         size_t c = IDX(s,p->icell,p->jcell,p->kcell);
         double xfreq_ref, u1, u2;
-        if (!s->comoving_source) { u1 = udot(s, c, p->kx, p->ky, p->kz); xfreq_ref = p->xfreq + u1; u2 = udot(s, c, po.kx, po.ky, po.kz); po.xfreq = xfreq_ref - u2; }
+        if (s->use_clump_medium && p->icell_clump > 0) { u1 = peel_u1(s, p, c, &po); xfreq_ref = p->xfreq + u1; }
+        else if (!s->comoving_source) { u1 = udot(s, c, p->kx, p->ky, p->kz); xfreq_ref = p->xfreq + u1; u2 = udot(s, c, po.kx, po.ky, po.kz); po.xfreq = xfreq_ref - u2; }
         else { u1 = udot(s, c, po.kx, po.ky, po.kz); xfreq_ref = p->xfreq + u1; }
         xfreq_ref = xfreq_ref * (s->Dfreq[c] / s->Dfreq_ref);
         int ixf = (int)floor((xfreq_ref - s->xfreq_min) / s->dxfreq) + 1;
@@ -1453,7 +1823,7 @@ static void peeling_resonance_nostokes(const orc_sim *s, acc_t *A, const photon_
         xfreq = xfreq_atom + (va[0] * cosp + va[1] * sinp) * sint + va[2] * cost;
         size_t c = IDX(s,p->icell,p->jcell,p->kcell);
         if (s->recoil) { double g_recoil = s->g_recoil0 / s->Dfreq[c]; xfreq = xfreq - g_recoil * (1.0 - cost); }
-        double u1 = udot(s, c, po.kx, po.ky, po.kz), xfreq_ref = xfreq + u1;
+        double u1 = peel_u1(s, p, c, &po), xfreq_ref = xfreq + u1;
         xfreq_ref = xfreq_ref * (s->Dfreq[c] / s->Dfreq_ref);
         int ixf = (int)floor((xfreq_ref - s->xfreq_min) / s->dxfreq) + 1;
         po.xfreq = xfreq;
@@ -1491,7 +1861,7 @@ static void peeling_resonance_stokes(const orc_sim *s, acc_t *A, const photon_t 
         double xfreq = xfreq_atom + (va[0] * cosp + va[1] * sinp) * sint + va[2] * cost;
         size_t c = IDX(s,p->icell,p->jcell,p->kcell);
         if (s->recoil) { double g_recoil = s->g_recoil0 / s->Dfreq[c]; xfreq = xfreq - g_recoil * (1.0 - cost); }
-        double u1 = udot(s, c, po.kx, po.ky, po.kz), xfreq_ref = (xfreq + u1) * (s->Dfreq[c] / s->Dfreq_ref);
+        double u1 = peel_u1(s, p, c, &po), xfreq_ref = (xfreq + u1) * (s->Dfreq[c] / s->Dfreq_ref);
         int ixf = (int)floor((xfreq_ref - s->xfreq_min) / s->dxfreq) + 1;
         double Q0 = cos2p * p->Q + sin2p * p->U, U0 = -sin2p * p->Q + cos2p * p->U;
         double Iobs = (S11 + S12 * Q0) / FOURPI, Qobs = (S12 + S22 * Q0) / FOURPI, Uobs = (S33 * U0) / FOURPI, Vobs = (S44 * p->V) / FOURPI;
@@ -1512,7 +1882,7 @@ static void peeling_dust_nostokes(const orc_sim *s, acc_t *A, const photon_t *p)
         obs_dir_s(s, i, p, &po, &r2, &ix, &iy);
         if (!(ix >= 1 && ix <= s->nxim && iy >= 1 && iy <= s->nyim)) continue;
         size_t c = IDX(s,p->icell,p->jcell,p->kcell);
-        double u1 = udot(s, c, po.kx, po.ky, po.kz), xfreq_ref = (p->xfreq + u1) * (s->Dfreq[c] / s->Dfreq_ref);
+        double u1 = peel_u1(s, p, c, &po), xfreq_ref = (p->xfreq + u1) * (s->Dfreq[c] / s->Dfreq_ref);
         int ixf = (int)floor((xfreq_ref - s->xfreq_min) / s->dxfreq) + 1;
         double tau = peel_tau(s, A, &po, r2);
         double cosa = p->kx * po.kx + p->ky * po.ky + p->kz * po.kz;
@@ -1529,7 +1899,7 @@ static void peeling_dust_stokes(const orc_sim *s, acc_t *A, const photon_t *p) {
         photon_t po; double r2; int ix, iy;
         obs_dir_s(s, i, p, &po, &r2, &ix, &iy);
         size_t c = IDX(s,p->icell,p->jcell,p->kcell);
-        double u1 = udot(s, c, po.kx, po.ky, po.kz), xfreq_ref = (p->xfreq + u1) * (s->Dfreq[c] / s->Dfreq_ref);
+        double u1 = peel_u1(s, p, c, &po), xfreq_ref = (p->xfreq + u1) * (s->Dfreq[c] / s->Dfreq_ref);
         int ixf = (int)floor((xfreq_ref - s->xfreq_min) / s->dxfreq) + 1;
         if (!(ix >= 1 && ix <= s->nxim && iy >= 1 && iy <= s->nyim)) continue;
         double cost, sint, cosp, sinp, cos2p, sin2p;
@@ -1555,8 +1925,15 @@ static void peeling_dust_stokes(const orc_sim *s, acc_t *A, const photon_t *p) {
 /* do_resonance1: line_mod.f90:108-139 */
 static void do_resonance1(const orc_sim *s, rng_t *g, photon_t *p, double *uz, double *xfreq_atom, double *cost, double *sint,
                           double *S11, double *S22, double *S12, double *S33, double *S44) {
+    if (s->use_clump_medium) {                          /* do_resonance1_clump: line_clump_mod.f90:30-59 (local Doppler units and back) */
+        const clumps_t *c = &s->cl; int64_t icl = p->icell_clump;
+        double scale = c->Dfreq_ref / c->Dfreq[icl-1], scale_inv = 1.0 / scale, xfreq_loc = p->xfreq * scale;
+        double uz_loc = rand_resonance_vz(g, xfreq_loc, c->voigt_a[icl-1]);
+        *xfreq_atom = (xfreq_loc - uz_loc) * scale_inv; *uz = uz_loc * scale_inv;
+    } else {
     *uz = rand_resonance_vz(g, p->xfreq, s->voigt_a[IDX(s,p->icell,p->jcell,p->kcell)]);
     *xfreq_atom = p->xfreq - *uz;
+    }
     p->E1 = s->E1; p->E2 = s->E2; p->E3 = s->E3;
     *cost = rand_resonance(g, p->E1);
     double cost2 = (*cost) * (*cost);
@@ -1578,6 +1955,12 @@ static inline void rotate_triad(photon_t *p, double cost, double sint, double co
     p->mx = cost * px - sint * p->kx; p->my = cost * py - sint * p->ky; p->mz = cost * pz - sint * p->kz;
     p->kx = sint * px + cost * p->kx; p->ky = sint * py + cost * p->ky; p->kz = sint * pz + cost * p->kz;
 }
+/* clump thermal-width ratio (scattering_car.f90:384-388, 715-719) and recoil constant (:428-433, 769-774) of the owner clump */
+static inline double clump_vth_ratio(const orc_sim *s, const photon_t *p) { return (s->use_clump_medium && p->icell_clump > 0) ? s->cl.Dfreq[p->icell_clump-1] / s->cl.Dfreq_ref : 1.0; }
+static inline double recoil_const(const orc_sim *s, const photon_t *p) {
+    if (s->use_clump_medium && p->icell_clump > 0) return s->g_recoil0 / s->cl.Dfreq[p->icell_clump-1];
+    return s->g_recoil0 / s->Dfreq[IDX(s,p->icell,p->jcell,p->kcell)];
+}
 /* perpendicular atom velocity: core-skip branch :733-737, plain :749-752 */
 static inline void perp_velocity_rayleigh(const orc_sim *s, rng_t *g, const photon_t *p, double *ux, double *uy) {
     double xc = 0.0, xc2 = 0.0, phi2, uxy;
@@ -1585,6 +1968,7 @@ static inline void perp_velocity_rayleigh(const orc_sim *s, rng_t *g, const phot
     if (s->core_skip && fabs(p->xfreq) < xc) { phi2 = TWOPI * rnd(g); uxy = sqrt(xc2 - log(rnd(g))); }
     else                                     { phi2 = TWOPI * rnd(g); uxy = sqrt(-log(rnd(g))); }
     *ux = uxy * cos(phi2); *uy = uxy * sin(phi2);
+    double vr = clump_vth_ratio(s, p); *ux = *ux * vr; *uy = *uy * vr;
 }
 /* scatter_resonance_nostokes: :660-827 */
 static void scatter_resonance_nostokes(const orc_sim *s, acc_t *A, rng_t *g, photon_t *p) {
@@ -1595,7 +1979,7 @@ static void scatter_resonance_nostokes(const orc_sim *s, acc_t *A, rng_t *g, pho
     double phi = TWOPI * rnd(g), cosp = cos(phi), sinp = sin(phi);
     perp_velocity_rayleigh(s, g, p, &ux, &uy);
     p->xfreq = xfreq_atom + uz * cost + (ux * cosp + uy * sinp) * sint;
-    if (s->recoil) { double g_recoil = s->g_recoil0 / s->Dfreq[IDX(s,p->icell,p->jcell,p->kcell)]; p->xfreq = p->xfreq - g_recoil * (1.0 - cost); }
+    if (s->recoil) { double g_recoil = recoil_const(s, p); p->xfreq = p->xfreq - g_recoil * (1.0 - cost); }
     if (s->save_peeloff) { double va[3] = {ux, uy, uz}; peeling_resonance_nostokes(s, A, p, xfreq_atom, va); }
     rotate_k(p, cost, sint, cosp, sinp);
 }
@@ -1622,8 +2006,9 @@ static void scatter_resonance_stokes(const orc_sim *s, acc_t *A, rng_t *g, photo
         if (g->kind == 0) { ux = rand_gauss(g) * (1.0 / sqrt(2.0)); uy = rand_gauss(g) * (1.0 / sqrt(2.0)); }
         else { double g2, g1 = gauss_pair(g, &g2); ux = g1 * (1.0 / sqrt(2.0)); uy = g2 * (1.0 / sqrt(2.0)); }
     }
+    { double vr = clump_vth_ratio(s, p); ux = ux * vr; uy = uy * vr; }
     p->xfreq = xfreq_atom + uz * cost + (ux * cosp + uy * sinp) * sint;
-    if (s->recoil) { double g_recoil = s->g_recoil0 / s->Dfreq[IDX(s,p->icell,p->jcell,p->kcell)]; p->xfreq = p->xfreq - g_recoil * (1.0 - cost); }
+    if (s->recoil) { double g_recoil = recoil_const(s, p); p->xfreq = p->xfreq - g_recoil * (1.0 - cost); }
     if (s->save_peeloff) { double va[3] = {ux, uy, uz}; peeling_resonance_stokes(s, A, p, xfreq_atom, va); }
     double cos2p = 2.0 * cosp * cosp - 1.0, sin2p = 2.0 * sinp * cosp;
     double Q0 = cos2p * p->Q + sin2p * p->U, U0 = -sin2p * p->Q + cos2p * p->U;
@@ -1672,6 +2057,15 @@ static void scatter_dust_stokes(const orc_sim *s, acc_t *A, rng_t *g, photon_t *
 /* scattering: scattering_car.f90:14-120 (Cartesian branch :106-118) */
 static void scattering(const orc_sim *s, acc_t *A, rng_t *g, photon_t *p) {
     A->n_events += 1.0;
+    if (s->use_clump_medium) {                                   /* scattering_car.f90:69-84 */
+        if (s->DGR > 0.0) {
+            int64_t icl = p->icell_clump; const clumps_t *c = &s->cl;
+            double p_dust = c->rhokapD[icl-1] / (c->rhokap[icl-1] * voigt_clump(c, p->xfreq, icl) + c->rhokapD[icl-1]);
+            if (rnd(g) <= p_dust) { if (s->use_stokes && s->nPDF > 0) scatter_dust_stokes(s, A, g, p); else scatter_dust_nostokes(s, A, g, p); return; }
+        }
+        if (s->use_stokes) scatter_resonance_stokes(s, A, g, p); else scatter_resonance_nostokes(s, A, g, p);
+        return;
+    }
     if (s->DGR > 0.0) {
         size_t c = IDX(s,p->icell,p->jcell,p->kcell);
         double p_dust = s->rhokapD[c] / (s->rhokap[c] * orc_voigt(p->xfreq, s->voigt_a[c]) + s->rhokapD[c]);
@@ -1718,6 +2112,11 @@ static void generate_photon(const orc_sim *s, acc_t *A, rng_t *g, photon_t *p) {
         double xlab = (p->xfreq + u1) * (s->Dfreq[c] / s->Dfreq_ref);
         int ix = (int)floor((xlab - s->xfreq_min) / s->dxfreq) + 1;
         if (ix >= 1 && ix <= s->nxfreq) A->Jin[ix-1] += p->wgt;
+    }
+    p->icell_clump = 0;
+    if (s->use_clump_medium) {                                                       /* :325-332 */
+        int64_t icl = clump_at_point(&s->cl, p->x, p->y, p->z);
+        if (icl > 0) { p->icell_clump = (int)icl; p->xfreq = p->xfreq - ulos_clump(&s->cl, icl, p->kx, p->ky, p->kz); }
     }
     if (s->save_peeloff) peeling_direct(s, A, p);                                      /* :334-336 */
 }
@@ -1843,9 +2242,15 @@ double orc_get_scalar(const orc_sim *s, const char *k) {
     G(rmax) G(xmax) G(ymax) G(zmax) G(DGR) G(albedo) G(hgg) G(cext_dust) G(cross0) G(g_recoil0) G(xcrit) G(raytrace_variant) G(save_peeloff)
     G(use_stokes) G(nPDF) G(save_Jabs) G(nmu) G(mu_min) G(dmu) G(distance2cm) G(source_rmax) G(comoving_source) G(recoil) G(core_skip) G(core_skip_global)
     G(xyz_symmetry) G(xy_periodic) G(save_Jin) G(save_Jmu) G(use_reduced_wgt) G(xs_point) G(ys_point) G(zs_point) G(xfreq0) G(spectral_type) G(source_geometry)
+    if (s->use_clump_medium) { const clumps_t *c = &s->cl;
+        if (!strcmp(k, "cl_N")) return (double)c->N; if (!strcmp(k, "cl_nreg")) return (double)c->nreg; if (!strcmp(k, "cl_cgx")) return c->cgx;
+        if (!strcmp(k, "cl_rhokap_ref")) return c->rhokap_ref; if (!strcmp(k, "cl_voigt_a_ref")) return c->voigt_a_ref; if (!strcmp(k, "cl_Dfreq_ref")) return c->Dfreq_ref;
+        if (!strcmp(k, "cl_vtherm_ref")) return c->vtherm_ref; if (!strcmp(k, "cl_fvol")) return c->fvol; if (!strcmp(k, "cl_fcov")) return c->fcov;
+        if (!strcmp(k, "cl_rsa_grid")) return c->rsa_grid; if (!strcmp(k, "cl_rsa_acceptance")) return c->rsa_acceptance;
+        if (!strcmp(k, "cg_min")) return c->cg_min; if (!strcmp(k, "cg_d")) return c->cg_d; if (!strcmp(k, "cl_sphere_R")) return c->sphere_R; if (!strcmp(k, "cl_radius_max")) return c->radius_max; }
     if (!strcmp(k, "amr_ncells")) return s->amr.ncells; if (!strcmp(k, "amr_nleaf")) return s->amr.nleaf; if (!strcmp(k, "amr_levelmax")) return s->amr.levelmax;
     if (!strcmp(k, "amr_dr_JPa")) return s->amr.dr_JPa; if (!strcmp(k, "amr_dz_JPa")) return s->amr.dz_JPa; if (!strcmp(k, "amr_boxlen")) return s->amr.L_box;
-    G(use_amr_grid) G(save_peeloff_2D) G(save_peeloff_3D) G(E1) G(E2) G(E3) G(nbins) G(geometry_JPa) G(calc_J) G(calc_P) G(calc_Pnew) G(nside) G(npix)
+    G(use_clump_medium) G(tauhomo) G(N_gashomo) G(use_amr_grid) G(save_peeloff_2D) G(save_peeloff_3D) G(E1) G(E2) G(E3) G(nbins) G(geometry_JPa) G(calc_J) G(calc_P) G(calc_Pnew) G(nside) G(npix)
 #undef G
     return NAN;
 }
@@ -1866,6 +2271,14 @@ int64_t orc_get_array(const orc_sim *s, const char *k, double *out, int64_t n) {
     if (!strcmp(k, "xface")) return copy_out(s->xface, s->nx + 1, out, n);
     if (!strcmp(k, "yface")) return copy_out(s->yface, s->ny + 1, out, n);
     if (!strcmp(k, "zface")) return copy_out(s->zface, s->nz + 1, out, n);
+    if (s->use_clump_medium) { const clumps_t *c = &s->cl; const double *da = NULL;
+        if (!strcmp(k, "cl_x")) da = c->x; else if (!strcmp(k, "cl_y")) da = c->y; else if (!strcmp(k, "cl_z")) da = c->z;
+        else if (!strcmp(k, "cl_vx")) da = c->vx; else if (!strcmp(k, "cl_vy")) da = c->vy; else if (!strcmp(k, "cl_vz")) da = c->vz;
+        else if (!strcmp(k, "cl_radius")) da = c->radius; else if (!strcmp(k, "cl_rhokap")) da = c->rhokap; else if (!strcmp(k, "cl_rhokapD")) da = c->rhokapD;
+        else if (!strcmp(k, "cl_voigt_a")) da = c->voigt_a; else if (!strcmp(k, "cl_Dfreq")) da = c->Dfreq;
+        if (da) return copy_out(da, c->N, out, n);
+        if (!strcmp(k, "cg_start")) { int64_t cnt = (int64_t)c->cgx * c->cgx * c->cgx + 1; for (int64_t i = 0; i < cnt && i < n; i++) out[i] = c->cg_start[i]; return cnt; }
+        if (!strcmp(k, "cg_list")) { for (int64_t i = 0; i < c->nreg && i < n; i++) out[i] = c->cg_list[i]; return c->nreg; } }
     if (s->use_amr_grid) { const amr_t *a = &s->amr;
         if (!strcmp(k, "amr_cx")) return copy_out(a->cx, a->ncells, out, n); if (!strcmp(k, "amr_cy")) return copy_out(a->cy, a->ncells, out, n);
         if (!strcmp(k, "amr_cz")) return copy_out(a->cz, a->ncells, out, n); if (!strcmp(k, "amr_ch")) return copy_out(a->ch, a->ncells, out, n);
@@ -1918,19 +2331,28 @@ static void unpack(const double r[8], const int ic[4], photon_t *p) {
     memset(p, 0, sizeof *p); p->x = r[0]; p->y = r[1]; p->z = r[2]; p->kx = r[3]; p->ky = r[4]; p->kz = r[5]; p->xfreq = r[6]; p->wgt = r[7];
     p->icell = ic[0]; p->jcell = ic[1]; p->kcell = ic[2]; p->inside = ic[3];
 }
+/* clump mode: ic[0] carries photon%icell_clump (0 = vacuum) in and out */
+static void unpack_s(const orc_sim *s, const double r[8], const int ic[4], photon_t *p) {
+    unpack(r, ic, p);
+    if (s->use_clump_medium) { p->icell_clump = ic[0]; p->icell = p->jcell = p->kcell = 1; }
+}
 void orc_raytrace_to_tau(orc_sim *s, int variant, double r[8], int ic[4], double tau_in) {
-    photon_t p; unpack(r, ic, &p); acc_t A; acc_alloc(&A, s);
+    photon_t p; unpack_s(s, r, ic, &p); acc_t A; acc_alloc(&A, s);
     raytrace_to_tau(s, &A, &p, tau_in, variant);
     acc_merge_free(&A, s);
     r[0] = p.x; r[1] = p.y; r[2] = p.z; r[3] = p.kx; r[4] = p.ky; r[5] = p.kz; r[6] = p.xfreq; r[7] = p.wgt;
-    ic[0] = p.icell; ic[1] = p.jcell; ic[2] = p.kcell; ic[3] = p.inside;
+    ic[0] = s->use_clump_medium ? p.icell_clump : p.icell; ic[1] = p.jcell; ic[2] = p.kcell; ic[3] = p.inside;
 }
 int orc_amr_find_leaf(const orc_sim *s, double x, double y, double z) { return s->use_amr_grid ? amr_find_leaf(&s->amr, x, y, z) : 0; }
-void orc_raytrace_to_edge(const orc_sim *s, int variant, const double r[8], const int ic[4], double *tau) { photon_t p; unpack(r, ic, &p); *tau = raytrace_to_edge(s, &p, variant, -1.0, 0); }
+void orc_raytrace_to_edge(const orc_sim *s, int variant, const double r[8], const int ic[4], double *tau) {
+    photon_t p; unpack_s(s, r, ic, &p);
+    if (variant == 14) *tau = raytrace_to_edge_clump(s, &p, TAU_HUGE, 0);         /* the capped peel-off form */
+    else *tau = raytrace_to_edge(s, &p, variant, -1.0, 0);
+}
 void orc_raytrace_to_dist(const orc_sim *s, const double r[8], const int ic[4], double dist, double *tau) { photon_t p; unpack(r, ic, &p); *tau = raytrace_to_edge(s, &p, s->use_amr_grid ? 3 : 0, dist, 0); }
 
 int64_t orc_scatter_event(orc_sim *s, double st[18], int ic[4], uint64_t seed, uint64_t id, uint64_t n0) {
-    photon_t p; unpack(st, ic, &p);
+    photon_t p; unpack_s(s, st, ic, &p);
     p.mx = st[8]; p.my = st[9]; p.mz = st[10]; p.nx = st[11]; p.ny = st[12]; p.nz = st[13]; p.I = st[14]; p.Q = st[15]; p.U = st[16]; p.V = st[17];
     rng_t g; rng_philox(&g, seed, id, n0); acc_t A; acc_alloc(&A, s);
     scattering(s, &A, &g, &p);
@@ -1943,6 +2365,13 @@ int64_t orc_scatter_event(orc_sim *s, double st[18], int ic[4], uint64_t seed, u
 
 int64_t orc_set_array(orc_sim *s, const char *k, const double *in, int64_t n) {
     int64_t nc = (int64_t)s->nx * s->ny * s->nz; double *dst = NULL;
+    if (s->use_clump_medium && !strncmp(k, "cl_", 3)) {            /* per-clump properties (tests: clumps of different temperature / opacity) */
+        clumps_t *c = &s->cl; double *d = NULL;
+        if (!strcmp(k, "cl_rhokap")) d = c->rhokap; else if (!strcmp(k, "cl_rhokapD")) d = c->rhokapD; else if (!strcmp(k, "cl_voigt_a")) d = c->voigt_a;
+        else if (!strcmp(k, "cl_Dfreq")) d = c->Dfreq; else if (!strcmp(k, "cl_vx")) d = c->vx; else if (!strcmp(k, "cl_vy")) d = c->vy; else if (!strcmp(k, "cl_vz")) d = c->vz;
+        if (!d || n != c->N) return -1;
+        memcpy(d, in, (size_t)n * 8); return n;
+    }
     if (!strcmp(k, "rhokap")) dst = s->rhokap; else if (!strcmp(k, "voigt_a")) dst = s->voigt_a; else if (!strcmp(k, "Dfreq")) dst = s->Dfreq;
     else if (!strcmp(k, "vfx")) dst = s->vfx; else if (!strcmp(k, "vfy")) dst = s->vfy; else if (!strcmp(k, "vfz")) dst = s->vfz; else if (!strcmp(k, "rhokapD")) dst = s->rhokapD;
     if (!dst || n != nc) return -1;

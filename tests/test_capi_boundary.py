@@ -20,7 +20,7 @@ def built():
 
 def test_library_exports_every_declared_symbol(built):
     hdr = open(os.path.join(ROOT, "include", "lart_gpu.h")).read()
-    declared = sorted(set(re.findall(r"\b(lart_gpu_\w+)\s*\(", hdr)))
+    declared = sorted(set(re.findall(r"\b(lart_(?:gpu|host)_\w+)\s*\(", hdr)))
     assert declared, "no declarations parsed"
     L = ctypes.CDLL(built.LIB_PATH)
     for s in declared:
@@ -94,10 +94,14 @@ def test_namelist_surface(built, tmp_path):
     bad.write_text("&parameters\n par%not_a_field = 1\n/\n")
     with pytest.raises(host.LartInputError):
         host.read_namelist(str(bad))
-    clump = tmp_path / "clump.in"
-    clump.write_text("&parameters\n par%use_clump_medium = .true.\n/\n")
+    fs = tmp_path / "fs.in"
+    fs.write_text("&parameters\n par%fine_structure = .true.\n/\n")
     with pytest.raises(host.LartInputError, match="not supported"):
-        host.read_namelist(str(clump))
+        host.read_namelist(str(fs))
+    clump = tmp_path / "clump.in"
+    clump.write_text("&parameters\n par%use_clump_medium = .true.\n par%clump_radius = 0.01\n par%clump_f_cov = 5.0\n par%clump_tau0 = 1.0e3\n/\n")
+    par = host.read_namelist(str(clump))
+    assert par.use_clump_medium and par.clump_f_cov == 5.0 and par.clump_fully_inside
     amr = tmp_path / "amr.in"
     amr.write_text("&parameters\n par%use_amr_grid = .true.\n par%amr_type = 'generic'\n par%amr_file = 'leaves.dat'\n/\n")
     par = host.read_namelist(str(amr))

@@ -378,3 +378,122 @@ def test_amr_boundary_errors(capi, amr_file):
     sim.ctx.set_grid_amr(*args)                                                     # a valid table still goes through
     sim.run_simulation(2000)
     assert sim.ctx.tallies()["nphotons_done"] == 2000
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# clump medium: clump_mod.f90 / raytrace_clump.f90 / line_clump_mod.f90 on the device (variant 4)
+# ---------------------------------------------------------------------------------------------------------------
+CLUMP = dict(use_clump_medium=True, rmax=1.0, clump_radius=0.01, clump_f_cov=5.0, clump_tau0=1e3, temperature=1e4, nxfreq=301,
+             velocity_min=-100.0, velocity_max=100.0, nx=11, ny=11, nz=11, iseed=7)
+
+
+def perturbed_clumps(o, sim, seed):
+    """give every clump its own temperature / opacity / velocity in BOTH the oracle and the device tables"""
+    c = sim.clumps; rng = np.random.default_rng(seed); n = c.N
+    f = rng.uniform(0.6, 1.8, n)                                   # Doppler width ratio to the reference
+    c.Dfreq = c.Dfreq_ref * f; c.voigt_a = c.voigt_a_ref / f; c.rhokap = c.rhokap_ref * rng.uniform(0.2, 3.0, n)
+    c.vx, c.vy, c.vz = rng.normal(0, 2.0, n), rng.normal(0, 2.0, n), rng.normal(0, 2.0, n)
+    for k in ("Dfreq", "voigt_a", "rhokap", "vx", "vy", "vz"):
+        o.set_array("cl_" + k, getattr(c, k))
+    sim.ctx.set_clumps(c.x, c.y, c.z, c.vx, c.vy, c.vz, c.radius, c.rhokap, c.rhokapD, c.voigt_a, c.Dfreq,
+                       c.sphere_R, c.Dfreq_ref, c.voigt_a_ref, c.cgx, c.cg_min, c.cg_d, c.cg_start, c.cg_list)
+
+
+def test_clump_ray_marches_device_vs_oracle(capi, oracle_mod):
+    sim = make(CLUMP); o = oracle_of(oracle_mod, CLUMP)
+    perturbed_clumps(o, sim, 3)
+    c = sim.clumps; rng = np.random.default_rng(12); n = 3000
+    k = rng.normal(size=(n, 3)); k /= np.linalg.norm(k, axis=1)[:, None]
+    pos = rng.uniform(-0.55, 0.55, (n, 3)); icl = np.zeros(n, dtype=np.int32)
+    inside = rng.random(n) < 0.4                                   # 40 % start inside a clump, the rest in vacuum (points inside a clump by chance are re-labelled)
+    j = rng.integers(0, c.N, n)
+    pos[inside] = np.column_stack([c.x, c.y, c.z])[j[inside]] + rng.uniform(-0.005, 0.005, (inside.sum(), 3)); icl[inside] = j[inside] + 1
+    from scipy.spatial import cKDTree
+    d, nn = cKDTree(np.column_stack([c.x, c.y, c.z])).query(pos[~inside])
+    keep = np.ones(n, bool); keep[np.nonzero(~inside)[0][d <= 0.01]] = False        # vacuum starts must really be in vacuum
+    pos, k, icl = pos[keep], k[keep], icl[keep]; n = len(pos)
+    r8 = np.column_stack([pos, k, rng.uniform(-4, 4, n), np.ones(n)])
+    ic4 = np.column_stack([icl, np.ones(n, np.int32), np.ones(n, np.int32), np.ones(n, np.int32)]).astype(np.int32)
+    tq = rng.exponential(200.0, n)
+    rg, icg, _ = sim.ctx.test_raytrace(0, 4, r8, ic4, tq)
+    _, _, tau_edge = sim.ctx.test_raytrace(1, 4, r8, ic4)
+    for i in range(n):
+        ro, ico = o.raytrace_to_tau(4, r8[i], ic4[i], tq[i])
+        assert ico[0] == icg[i][0] and ico[3] == icg[i][3], i                   # same owner clump / same escape decision
+        assert np.allclose(rg[i], ro, rtol=1e-10, atol=1e-11), i
+        assert np.isclose(tau_edge[i], o.raytrace_to_edge(14, r8[i], ic4[i]), rtol=1e-10, atol=1e-12), i
+
+
+def test_clump_scatter_event_device(capi, oracle_mod):
+    kw = dict(CLUMP, recoil=True)
+    sim = make(kw); o = oracle_of(oracle_mod, kw)
+    perturbed_clumps(o, sim, 4)
+    c = sim.clumps; rng = np.random.default_rng(2); n = 2000
+    j = rng.integers(0, c.N, n)
+    st = np.zeros((n, 18)); st[:, 0:3] = np.column_stack([c.x, c.y, c.z])[j] + rng.uniform(-0.004, 0.004, (n, 3))
+    k = rng.normal(size=(n, 3)); k /= np.linalg.norm(k, axis=1)[:, None]; st[:, 3:6] = k
+    st[:, 6] = rng.uniform(-6, 6, n); st[:, 7] = 1.0; st[:, 14] = 1.0
+    ic = np.column_stack([j + 1, np.ones(n), np.ones(n), np.ones(n)]).astype(np.int32)
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    sg, icg, ndg = sim.ctx.test_scatter(st, ic, 77, ids)
+    same = 0
+    for i in range(n):
+        so, ico, ndo = o.scatter_event(st[i], ic[i], 77, int(ids[i]))
+        if ndo == ndg[i] and np.allclose(sg[i][:8], so[:8], rtol=1e-9, atol=1e-11):
+            same += 1
+    assert same >= 0.985 * n, same                                  # identical unless a last-bit difference flips a rejection
+
+
+@pytest.mark.parametrize("extra,n", [(dict(), 20000), (dict(clump_sigma_v=30.0, velocity_type="hubble", Vexp=80.0), 20000),
+                                     (dict(use_stokes=True, clump_tau0=30.0, recoil=True), 10000)])
+def test_clump_histories_photon_by_photon(capi, oracle_mod, extra, n):
+    kw = dict(CLUMP, clump_tau0=1e2, **extra)
+    sim = make(kw); sim.ctx.enable_photon_log(True); sim.run_simulation(n); t = sim.ctx.tallies()
+    o = oracle_of(oracle_mod, kw); o.run(n, seed=kw["iseed"])
+    ng, xg = sim.ctx.photon_log(n); no, xo = o.photon_log()
+    same = np.isclose(ng, no, rtol=1e-12, atol=0) & np.isclose(xg, xo, rtol=1e-7, atol=1e-9)
+    assert same.mean() > 0.95, same.mean()
+    assert t["nphotons_done"] == n
+    assert rms_diff(t["Jout"], o.array("Jout")) < 0.01
+    assert abs(ng.mean() - no.mean()) < 4 * np.hypot(ng.std(), no.std()) / np.sqrt(n) + 1e-9
+
+
+def test_clump_dust_stokes_peel_whole_path(capi, oracle_mod, mueller_file):
+    """C4: clumpy sphere + dust with the Mueller Ly-alpha table + Stokes + core-skip switch + one far observer"""
+    kw = dict(CLUMP, clump_tau0=3e2, use_stokes=True, DGR=1.0, scatt_mat_file=mueller_file, cext_dust=1.6e-21, core_skip=True,
+              nxim=16, nyim=16, save_peeloff_2D=True, alpha=20.0, beta=50.0, iseed=81)
+    n = 30000
+    sim = make(kw); sim.run_simulation(n); t = sim.ctx.tallies()
+    o = oracle_of(oracle_mod, kw); o.run(n, seed=81)
+    assert abs(t["nscatt_gas"] / o.scalar("nscatt_gas") - 1) < 0.03
+    assert abs(t["nscatt_dust"] - o.scalar("nscatt_dust")) < 0.05 * o.scalar("nscatt_dust") + 0.01 * n
+    assert rms_diff(t["Jout"], o.array("Jout")) < 0.02
+    assert abs(t["Jabs"].sum() - o.array("Jabs").sum()) < 0.05 * o.array("Jabs").sum() + 50
+    assert abs(t["Jout"].sum() + t["Jabs"].sum() - n) < 0.01 * n               # escaped + absorbed = emitted
+    sh3 = (kw["nxfreq"], 16, 16)
+    for name in ("scatt", "direc", "I"):
+        g3 = t[name][..., 0]; o3 = o.array(name + ":0").reshape(sh3, order="F")
+        assert rms_diff(g3.sum(axis=(1, 2)), o3.sum(axis=(1, 2))) < 0.03, name
+        assert abs(g3.sum() - o3.sum()) < 0.02 * o3.sum() + 1e-12, name
+
+
+def test_clump_known_answer_and_boundary(capi):
+    """log_back:52 of examples/clump_sphere: <N_scatt> = 4.3454E+03 for clump_NHI18_fcov1 (1.33e6 clumps, flat rotation curve)"""
+    kw = dict(use_clump_medium=True, rmax=1.0, clump_radius=0.001, clump_f_cov=1.0, N_HImax=1e18, temperature=1e4, clump_fully_inside=False,
+              spectral_type="monochromatic", velocity_type="rotating_galaxy_halo", Vrot=300.0, rinner=0.1, nxfreq=500,
+              velocity_min=-1000.0, velocity_max=1000.0, nx=11, ny=11, nz=11, iseed=1)
+    n = 400000
+    sim = make(kw); sim.ctx.enable_photon_log(True); sim.run_simulation(n)
+    assert sim.clumps.N == 1333333
+    ns, _ = sim.ctx.photon_log(n)
+    assert abs(ns.mean() - 4345.4) < 0.025 * 4345.4 + 4 * ns.std() / np.sqrt(n), (ns.mean(), ns.std() / np.sqrt(n))
+    c = sim.clumps
+    args = [c.x, c.y, c.z, c.vx, c.vy, c.vz, c.radius, c.rhokap, c.rhokapD, c.voigt_a, c.Dfreq, c.sphere_R, c.Dfreq_ref, c.voigt_a_ref, c.cgx, c.cg_min, c.cg_d, c.cg_start, c.cg_list]
+    bad = c.cg_list.copy(); bad[5] = c.N + 1
+    with pytest.raises(RuntimeError, match="cg_list"):
+        sim.ctx.set_clumps(*args[:18], bad)
+    bad = c.cg_start.copy(); bad[100] = bad[99] - 1 if bad[99] > 1 else bad[101] + 5
+    with pytest.raises(RuntimeError, match="cg_start"):
+        sim.ctx.set_clumps(*args[:17], bad, c.cg_list)
+    with pytest.raises(RuntimeError, match="profile tallies"):
+        sim.ctx.set_JPa(True, False, False, 1, np.ones(1, dtype=np.int32), 1e-13)
