@@ -387,6 +387,7 @@ CLUMP = dict(use_clump_medium=True, rmax=1.0, clump_radius=0.01, clump_f_cov=5.0
              velocity_min=-100.0, velocity_max=100.0, nx=11, ny=11, nz=11, iseed=7)
 
 
+# NB: the oracle gets par%iseed too -- it seeds the clump placement (the same MT19937-64 stream as the host helper)
 def perturbed_clumps(o, sim, seed):
     """give every clump its own temperature / opacity / velocity in BOTH the oracle and the device tables"""
     c = sim.clumps; rng = np.random.default_rng(seed); n = c.N
@@ -400,7 +401,7 @@ def perturbed_clumps(o, sim, seed):
 
 
 def test_clump_ray_marches_device_vs_oracle(capi, oracle_mod):
-    sim = make(CLUMP); o = oracle_of(oracle_mod, CLUMP)
+    sim = make(CLUMP); o = oracle_mod.Oracle(**CLUMP)
     perturbed_clumps(o, sim, 3)
     c = sim.clumps; rng = np.random.default_rng(12); n = 3000
     k = rng.normal(size=(n, 3)); k /= np.linalg.norm(k, axis=1)[:, None]
@@ -426,7 +427,7 @@ def test_clump_ray_marches_device_vs_oracle(capi, oracle_mod):
 
 def test_clump_scatter_event_device(capi, oracle_mod):
     kw = dict(CLUMP, recoil=True)
-    sim = make(kw); o = oracle_of(oracle_mod, kw)
+    sim = make(kw); o = oracle_mod.Oracle(**kw)
     perturbed_clumps(o, sim, 4)
     c = sim.clumps; rng = np.random.default_rng(2); n = 2000
     j = rng.integers(0, c.N, n)
@@ -447,9 +448,9 @@ def test_clump_scatter_event_device(capi, oracle_mod):
 @pytest.mark.parametrize("extra,n", [(dict(), 20000), (dict(clump_sigma_v=30.0, velocity_type="hubble", Vexp=80.0), 20000),
                                      (dict(use_stokes=True, clump_tau0=30.0, recoil=True), 10000)])
 def test_clump_histories_photon_by_photon(capi, oracle_mod, extra, n):
-    kw = dict(CLUMP, clump_tau0=1e2, **extra)
+    kw = dict(dict(CLUMP, clump_tau0=1e2), **extra)
     sim = make(kw); sim.ctx.enable_photon_log(True); sim.run_simulation(n); t = sim.ctx.tallies()
-    o = oracle_of(oracle_mod, kw); o.run(n, seed=kw["iseed"])
+    o = oracle_mod.Oracle(**kw); o.run(n, seed=kw["iseed"])
     ng, xg = sim.ctx.photon_log(n); no, xo = o.photon_log()
     same = np.isclose(ng, no, rtol=1e-12, atol=0) & np.isclose(xg, xo, rtol=1e-7, atol=1e-9)
     assert same.mean() > 0.95, same.mean()
@@ -464,7 +465,7 @@ def test_clump_dust_stokes_peel_whole_path(capi, oracle_mod, mueller_file):
               nxim=16, nyim=16, save_peeloff_2D=True, alpha=20.0, beta=50.0, iseed=81)
     n = 30000
     sim = make(kw); sim.run_simulation(n); t = sim.ctx.tallies()
-    o = oracle_of(oracle_mod, kw); o.run(n, seed=81)
+    o = oracle_mod.Oracle(**kw); o.run(n, seed=81)
     assert abs(t["nscatt_gas"] / o.scalar("nscatt_gas") - 1) < 0.03
     assert abs(t["nscatt_dust"] - o.scalar("nscatt_dust")) < 0.05 * o.scalar("nscatt_dust") + 0.01 * n
     assert rms_diff(t["Jout"], o.array("Jout")) < 0.02
