@@ -69,6 +69,40 @@ module lart_gpu_c
        import; type(c_ptr), value :: ctx; integer(c_int32_t), value :: nobs, nxim, nyim
        real(c_double), intent(in) :: xyz(*), rmatrix(*); real(c_double), value :: dxim, dyim; integer(c_int) :: rc
      end function
+     function lart_gpu_set_clumps(ctx, n, x, y, z, vx, vy, vz, radius, rhokap, rhokapD, voigt_a, Dfreq, sphere_R, Dfreq_ref, voigt_a_ref, &
+                                  cgx, cg_min, cg_d, cg_start, cg_list) bind(C, name='lart_gpu_set_clumps') result(rc)
+       import; type(c_ptr), value :: ctx; integer(c_int64_t), value :: n
+       real(c_double), intent(in) :: x(*), y(*), z(*), vx(*), vy(*), vz(*), radius(*), rhokap(*), voigt_a(*), Dfreq(*)
+       type(c_ptr), value :: rhokapD          ! c_loc(cl_rhokapD) or c_null_ptr when DGR = 0
+       real(c_double), value :: sphere_R, Dfreq_ref, voigt_a_ref, cg_min, cg_d
+       integer(c_int32_t), value :: cgx
+       integer(c_int32_t), intent(in) :: cg_start(*), cg_list(*)
+       integer(c_int) :: rc
+     end function
+     !--- host-side helpers (CPU): the per-clump loops of generate_clumps / build_clump_csr (clump_mod.f90:897-1151, 1267-1360)
+     function lart_host_last_error() bind(C, name='lart_host_last_error') result(p)
+       import; type(c_ptr) :: p
+     end function
+     function lart_host_clumps_generate(n, sphere_R, r_min, clump_radius, fully_inside, sigma_v_over_vtherm, iseed, &
+                                        x, y, z, vx, vy, vz, acceptance) bind(C, name='lart_host_clumps_generate') result(rc)
+       import; integer(c_int64_t), value :: n, iseed; real(c_double), value :: sphere_R, r_min, clump_radius, sigma_v_over_vtherm
+       integer(c_int32_t), value :: fully_inside
+       real(c_double), intent(out) :: x(*), y(*), z(*), vx(*), vy(*), vz(*), acceptance
+       integer(c_int) :: rc
+     end function
+     function lart_host_clumps_csr_dims(n, sphere_R, radius_max, cgx, cg_min, cg_d) bind(C, name='lart_host_clumps_csr_dims') result(rc)
+       import; integer(c_int64_t), value :: n; real(c_double), value :: sphere_R, radius_max
+       integer(c_int32_t), intent(out) :: cgx; real(c_double), intent(out) :: cg_min, cg_d
+       integer(c_int) :: rc
+     end function
+     function lart_host_clumps_build_csr(n, x, y, z, radius, cgx, cg_min, cg_d, cg_start, cg_list, nreg) bind(C, name='lart_host_clumps_build_csr') result(rc)
+       import; integer(c_int64_t), value :: n; real(c_double), intent(in) :: x(*), y(*), z(*), radius(*)
+       integer(c_int32_t), value :: cgx; real(c_double), value :: cg_min, cg_d
+       integer(c_int32_t), intent(out) :: cg_start(*)
+       type(c_ptr), value :: cg_list          ! c_null_ptr on the counting pass
+       integer(c_int64_t), intent(out) :: nreg
+       integer(c_int) :: rc
+     end function
      function lart_gpu_run(ctx, first_id, stride, count, seed) bind(C, name='lart_gpu_run') result(rc)
        import; type(c_ptr), value :: ctx; integer(c_int64_t), value :: first_id, stride, count, seed; integer(c_int) :: rc
      end function

@@ -70,7 +70,12 @@ module lart_define
      real(wp) :: dxim = nan64, dyim = nan64
      integer  :: nside = 0
      !--- outside this path (accepted at default only)
-     logical  :: use_amr_grid = .false., use_clump_medium = .false., fine_structure = .false., include_deuterium = .false.
+     logical  :: use_amr_grid = .false., fine_structure = .false., include_deuterium = .false.
+     !--- clump medium (define.f90:325-352): uniform clump properties, non-overlapping clumps
+     logical  :: use_clump_medium = .false., clump_fully_inside = .true., save_clump_info = .false.
+     real(wp) :: clump_radius = -1.0_wp, clump_N_clumps = -1.0_wp, clump_f_vol = -1.0_wp, clump_f_cov = -1.0_wp
+     real(wp) :: clump_tau0 = -1.0_wp, clump_NHI = -1.0_wp, clump_nH = -1.0_wp, clump_temperature = -1.0_wp, clump_sigma_v = 0.0_wp
+     real(wp) :: Vrot = 0.0_wp, rinner = 0.0_wp
      character(len=20)  :: line_id = 'ly_alpha'
      character(len=8)   :: h2_model = 'none'
      character(len=128) :: dens_file = '', temp_file = '', velo_file = '', emiss_file = '', cart_file = '', input_field = '', star_file = ''
@@ -116,6 +121,15 @@ module lart_define
   !--- peel-off tallies of all observers: (nxfreq,nxim,nyim,nobs) and (nxim,nyim,nobs)
   real(wp), allocatable, target :: obs_scatt(:,:,:,:), obs_direc(:,:,:,:), obs_I(:,:,:,:), obs_Q(:,:,:,:), obs_U(:,:,:,:), obs_V(:,:,:,:)
   real(wp), allocatable, target :: obs_scatt_2D(:,:,:), obs_direc_2D(:,:,:), obs_I_2D(:,:,:), obs_Q_2D(:,:,:), obs_U_2D(:,:,:), obs_V_2D(:,:,:)
+  !--- clump population (clump_mod.f90:27-118), filled by grid_create_clump
+  integer(int64) :: N_clumps = 0_int64
+  real(wp) :: sphere_R = 0.0_wp, r_min_clump = 0.0_wp, cl_radius_max = 0.0_wp
+  real(wp) :: cl_rhokap_ref = 0.0_wp, cl_voigt_a_ref = 0.0_wp, cl_Dfreq_ref = 0.0_wp, cl_vtherm_ref = 0.0_wp
+  real(wp), allocatable, target :: cl_x(:), cl_y(:), cl_z(:), cl_vx(:), cl_vy(:), cl_vz(:)
+  real(wp), allocatable, target :: cl_radius(:), cl_rhokap(:), cl_rhokapD(:), cl_voigt_a(:), cl_Dfreq(:), cl_vtherm(:)
+  integer(int32) :: cgx = 0
+  real(wp) :: cg_xmin = 0.0_wp, cg_dx = 0.0_wp
+  integer(int32), allocatable, target :: cg_start(:), cg_list(:)
 
 contains
   elemental function is_finite(x) result(r)
@@ -144,7 +158,9 @@ end module lart_define
 
 !==============================================================================
 module lart_host
+  use, intrinsic :: iso_c_binding
   use lart_define
+  use lart_gpu_c
   implicit none
 contains
 
@@ -194,7 +210,7 @@ contains
     par%spectral_type   = strlowcase(par%spectral_type)
 
     if (par%use_amr_grid)      call not_supported('par%use_amr_grid = .true.')
-    if (par%use_clump_medium)  call not_supported('par%use_clump_medium = .true.')
+    if (par%use_clump_medium .and. len_trim(par%clump_input_file) > 0) call not_supported('par%clump_input_file')
     if (par%fine_structure)    call not_supported('par%fine_structure = .true.')
     if (par%include_deuterium) call not_supported('par%include_deuterium = .true.')
     if (trim(par%line_id) /= 'ly_alpha') call not_supported('par%line_id /= ly_alpha')
@@ -218,6 +234,8 @@ contains
        call not_supported('par%spectral_type = '//trim(par%spectral_type))
     select case(trim(par%velocity_type))
     case ('', 'hubble', 'constant_radial', 'parallel_velocity')
+    case ('rotating_solid_body', 'rotating_galaxy_halo')       ! per-clump fields of assign_clump_velocities_from_type
+       if (.not. par%use_clump_medium) call not_supported('par%velocity_type = '//trim(par%velocity_type))
     case default; call not_supported('par%velocity_type = '//trim(par%velocity_type))
     end select
 
@@ -650,6 +668,199 @@ contains
       enddo; enddo; enddo
     end subroutine homo_sums
   end subroutine grid_create
+
+  !--- host-side error of the lart_host_* helpers: print and stop (reference convention)
+  subroutine host_check(rc, where)
+    integer(c_int), intent(in) :: rc
+    character(len=*), intent(in) :: where
+    character(kind=c_char), pointer :: msg(:)
+    type(c_ptr) :: p
+    integer :: n
+    if (rc == 0) return
+    p = lart_host_last_error()
+    write(*,'(3a)', advance='no') 'ERROR in ', where, ': '
+    if (c_associated(p)) then
+       call c_f_pointer(p, msg, [512])
+       do n = 1, 512
+          if (msg(n) == c_null_char) exit
+          write(*,'(a)', advance='no') msg(n)
+       enddo
+    endif
+    write(*,*)
+    stop 1
+  end subroutine host_check
+
+  !--- init_clumps, uniform path (clump_mod.f90:646-891); the per-clump loops (generate_clumps :897-1151,
+  !--- build_clump_csr :1267-1342) run in liblart_gpu's host helpers on the reference's MT19937-64 stream
+  subroutine init_clumps(R_sphere)
+    real(wp), intent(in) :: R_sphere
+    real(wp) :: temp_cl, vtherm, rc, shell2, GF_los, fvol_realized, fcov_realized, sig, acc
+    real(c_double) :: cmin, cd
+    integer(c_int32_t) :: cg
+    integer(c_int64_t) :: nreg
+    integer :: n
+    sphere_R = R_sphere
+    if (par%clump_radius <= 0.0_wp) then
+       write(*,*) 'ERROR: clump_radius must be > 0'; stop 1
+    endif
+    r_min_clump = max(0.0_wp, par%rmin)
+    if (r_min_clump >= R_sphere) then
+       write(*,'(a,2es12.4)') 'ERROR: par%rmin must be < par%rmax for clump placement; rmin, rmax = ', r_min_clump, R_sphere; stop 1
+    endif
+    cl_radius_max = par%clump_radius; rc = cl_radius_max
+    temp_cl = par%clump_temperature
+    if (temp_cl < 0.0_wp) temp_cl = par%temperature
+    vtherm         = vtherm_total(temp_cl)
+    cl_Dfreq_ref   = vtherm/(line%wavelength0*um2km)
+    cl_vtherm_ref  = vtherm
+    cl_voigt_a_ref = (line%damping/fourpi)/cl_Dfreq_ref
+    shell2 = R_sphere**2 + R_sphere*r_min_clump + r_min_clump**2
+    if (par%clump_N_clumps > 0.0_wp) then
+       N_clumps = int(par%clump_N_clumps, int64)
+    else if (par%clump_f_vol > 0.0_wp) then
+       N_clumps = nint(par%clump_f_vol*(R_sphere**3 - r_min_clump**3)/rc**3, int64)
+    else if (par%clump_f_cov > 0.0_wp) then
+       N_clumps = nint((4.0_wp/3.0_wp)*par%clump_f_cov*shell2/rc**2, int64)
+    else
+       write(*,*) 'ERROR: specify clump_N_clumps, clump_f_vol, or clump_f_cov'; stop 1
+    endif
+    if (N_clumps <= 0_int64) N_clumps = 1_int64
+    fvol_realized = real(N_clumps, wp)*rc**3/max(R_sphere**3 - r_min_clump**3, tiny(1.0_wp))
+    fcov_realized = 0.75_wp*real(N_clumps, wp)*rc**2/max(shell2, tiny(1.0_wp))
+    if (par%clump_tau0 > 0.0_wp) then
+       cl_rhokap_ref = par%clump_tau0/(voigt0(cl_voigt_a_ref)*par%clump_radius)
+    else if (par%clump_NHI > 0.0_wp) then
+       cl_rhokap_ref = par%clump_NHI*line%cross0/(cl_Dfreq_ref*par%clump_radius)
+    else if (par%clump_nH > 0.0_wp) then
+       if (par%distance2cm <= 0.0_wp) then
+          write(*,*) 'ERROR: clump_nH requires distance_unit'; stop 1
+       endif
+       cl_rhokap_ref = par%clump_nH*line%cross0*par%distance2cm/cl_Dfreq_ref
+    else if (par%taumax > 0.0_wp .or. par%N_gasmax > 0.0_wp) then
+       GF_los = real(N_clumps, wp)*rc**3/max(shell2, tiny(1.0_wp))
+       if (par%taumax > 0.0_wp) then
+          cl_rhokap_ref = par%taumax/(GF_los*voigt0(cl_voigt_a_ref))
+       else
+          cl_rhokap_ref = par%N_gasmax*line%cross0/(GF_los*cl_Dfreq_ref)
+       endif
+    else
+       write(*,*) 'ERROR: specify clump_tau0, clump_NHI, clump_nH, taumax, or N_HImax'; stop 1
+    endif
+    write(*,'(a,i14)')    ' Clumps: N_clumps  = ', N_clumps
+    write(*,'(a,f12.6)')  ' Clumps: f_vol     = ', fvol_realized
+    write(*,'(a,f12.5)')  ' Clumps: f_cov     = ', fcov_realized
+    write(*,'(a,2f12.5)') ' Clumps: rmin/rmax = ', r_min_clump, R_sphere
+    write(*,'(a,es12.4)') ' Clumps: cl_rhokap = ', cl_rhokap_ref
+    write(*,'(a,f12.5)')  ' Clumps: voigt_a   = ', cl_voigt_a_ref
+    write(*,'(a,es12.4)') ' Clumps: cl_Dfreq  = ', cl_Dfreq_ref
+    n = int(N_clumps)
+    allocate(cl_x(n), cl_y(n), cl_z(n), cl_vx(n), cl_vy(n), cl_vz(n), cl_radius(n), cl_rhokap(n), cl_voigt_a(n), cl_Dfreq(n), cl_vtherm(n))
+    cl_radius = rc; cl_rhokap = cl_rhokap_ref; cl_voigt_a = cl_voigt_a_ref; cl_Dfreq = cl_Dfreq_ref; cl_vtherm = cl_vtherm_ref
+    if (par%DGR > 0.0_wp) then
+       allocate(cl_rhokapD(n)); cl_rhokapD = cl_rhokap_ref*par%cext_dust*par%DGR*cl_Dfreq_ref/line%cross0
+    endif
+    sig = 0.0_wp
+    if (par%clump_sigma_v > 0.0_wp) sig = par%clump_sigma_v/cl_vtherm_ref
+    call host_check(lart_host_clumps_generate(N_clumps, sphere_R, r_min_clump, rc, merge(1_c_int32_t, 0_c_int32_t, par%clump_fully_inside), &
+         sig, int(par%iseed, c_int64_t), cl_x, cl_y, cl_z, cl_vx, cl_vy, cl_vz, acc), 'lart_host_clumps_generate')
+    write(*,'(a,f6.1,a)') ' RSA done, acceptance rate = ', acc*100.0_wp, '%'
+    if (len_trim(par%velocity_type) > 0) call assign_clump_velocities_from_type()
+    call host_check(lart_host_clumps_csr_dims(N_clumps, sphere_R, cl_radius_max, cg, cmin, cd), 'lart_host_clumps_csr_dims')
+    cgx = cg; cg_xmin = cmin; cg_dx = cd
+    allocate(cg_start(cgx**3 + 1))
+    call host_check(lart_host_clumps_build_csr(N_clumps, cl_x, cl_y, cl_z, cl_radius, cgx, cg_xmin, cg_dx, cg_start, c_null_ptr, nreg), 'lart_host_clumps_build_csr')
+    allocate(cg_list(max(1_int64, nreg)))
+    call host_check(lart_host_clumps_build_csr(N_clumps, cl_x, cl_y, cl_z, cl_radius, cgx, cg_xmin, cg_dx, cg_start, c_loc(cg_list), nreg), 'lart_host_clumps_build_csr')
+    write(*,'(a,i12,a,i5,a)') ' CSR grid: ', nreg, ' registrations in ', cgx, '^3 cells.'
+  end subroutine init_clumps
+
+  !--- assign_clump_velocities_from_type: clump_mod.f90:1153-1264 (the fields this path supports)
+  subroutine assign_clump_velocities_from_type()
+    integer(int64) :: icl
+    real(wp) :: xc, yc, zc, rr, rr_cyl, vx, vy, vz
+    do icl = 1_int64, N_clumps
+       xc = cl_x(icl); yc = cl_y(icl); zc = cl_z(icl)
+       rr = sqrt(xc**2 + yc**2 + zc**2)
+       vx = 0.0_wp; vy = 0.0_wp; vz = 0.0_wp
+       select case (trim(par%velocity_type))
+       case ('hubble')
+          vx = par%Vexp*xc/sphere_R; vy = par%Vexp*yc/sphere_R; vz = par%Vexp*zc/sphere_R
+       case ('constant_radial')
+          if (rr > 0.0_wp) then
+             vx = par%Vexp*xc/rr; vy = par%Vexp*yc/rr; vz = par%Vexp*zc/rr
+          endif
+       case ('parallel_velocity')
+          vx = par%Vx; vy = par%Vy; vz = par%Vz
+       case ('rotating_solid_body')
+          vx = -par%Vrot*yc/sphere_R; vy = par%Vrot*xc/sphere_R
+       case ('rotating_galaxy_halo')
+          rr_cyl = sqrt(xc**2 + yc**2)
+          if (rr_cyl > 0.0_wp) then
+             if (rr_cyl < par%rinner) then
+                vx = -par%Vrot*yc/par%rinner; vy = par%Vrot*xc/par%rinner
+             else
+                vx = -par%Vrot*yc/rr_cyl; vy = par%Vrot*xc/rr_cyl
+             endif
+          endif
+       end select
+       cl_vx(icl) = cl_vx(icl) + vx/cl_vtherm(icl)
+       cl_vy(icl) = cl_vy(icl) + vy/cl_vtherm(icl)
+       cl_vz(icl) = cl_vz(icl) + vz/cl_vtherm(icl)
+    enddo
+    write(*,'(2a)') ' Clumps: velocity_type   = ', trim(par%velocity_type)
+  end subroutine assign_clump_velocities_from_type
+
+  !--- compute_clump_scalars: clump_mod.f90:2316-2378
+  subroutine compute_clump_scalars()
+    integer(int64) :: i
+    real(wp) :: voigt0_i, di2, shell2, w_homo, w_max, vals(4)
+    shell2 = sphere_R**2 + sphere_R*r_min_clump + r_min_clump**2
+    if (shell2 <= 0.0_wp) shell2 = sphere_R**2
+    vals = 0.0_wp
+    do i = 1_int64, N_clumps
+       voigt0_i = voigt0(cl_voigt_a(i))
+       di2    = max(cl_x(i)**2 + cl_y(i)**2 + cl_z(i)**2, cl_radius(i)**2)
+       w_homo = cl_radius(i)**3/shell2
+       w_max  = cl_radius(i)**3/(3.0_wp*di2)
+       vals(1) = vals(1) + cl_rhokap(i)*voigt0_i*w_homo
+       vals(2) = vals(2) + cl_rhokap(i)*voigt0_i*w_max
+       vals(3) = vals(3) + cl_rhokap(i)*cl_Dfreq(i)*w_homo/line%cross0
+       vals(4) = vals(4) + cl_rhokap(i)*cl_Dfreq(i)*w_max/line%cross0
+    enddo
+    par%tauhomo = vals(1); par%taumax = vals(2); par%N_gashomo = vals(3); par%N_gasmax = vals(4)
+  end subroutine compute_clump_scalars
+
+  !--- grid_create_clump: grid_mod_clump.f90:33-131
+  subroutine grid_create_clump(grid)
+    type(grid_type), intent(inout) :: grid
+    character(len=128) :: vtype
+    if (par%rmax <= 0.0_wp) then
+       write(*,*) 'ERROR: par%rmax must be > 0 for clump medium'; stop 1
+    endif
+    par%xmax = par%rmax; par%ymax = par%rmax; par%zmax = par%rmax
+    if (par%nx < 1) par%nx = 11
+    if (par%ny < 1) par%ny = 11
+    if (par%nz < 1) par%nz = 11
+    par%xyz_symmetry = .false.; par%xy_symmetry = .false.; par%xy_periodic = .false.; par%z_symmetry = .false.
+    call init_clumps(par%rmax)
+    call compute_clump_scalars()
+    write(*,'(a,es14.5)') ' Clump derived: tauhomo   = ', par%tauhomo
+    write(*,'(a,es14.5)') ' Clump derived: taumax    = ', par%taumax
+    write(*,'(a,es14.5)') ' Clump derived: N_gashomo = ', par%N_gashomo
+    write(*,'(a,es14.5)') ' Clump derived: N_gasmax  = ', par%N_gasmax
+    vtype = par%velocity_type; par%velocity_type = ''       ! the background grid is static; velocities live on the clumps
+    call grid_create(grid)
+    par%velocity_type = vtype
+    grid%rhokap = 0.0_wp; grid%Dfreq = cl_Dfreq_ref; grid%voigt_a = cl_voigt_a_ref
+    grid%vfx = 0.0_wp; grid%vfy = 0.0_wp; grid%vfz = 0.0_wp
+    if (allocated(grid%rhokapD)) grid%rhokapD = 0.0_wp
+    grid%Dfreq_ref = cl_Dfreq_ref; grid%voigt_amean = cl_voigt_a_ref
+    write(*,'(a,f12.5)')  ' Clump grid: rmax      = ', par%rmax
+    write(*,'(a,3i5)')    ' Clump grid: nx,ny,nz  = ', grid%nx, grid%ny, grid%nz
+    write(*,'(a,es12.4)') ' Clump grid: cl_Dfreq_ref  = ', cl_Dfreq_ref
+    write(*,'(a,f12.5,a)')' Clump grid: cl_vtherm_ref = ', cl_vtherm_ref, ' km/s'
+    write(*,'(a,f12.5)')  ' Clump grid: voigt_a   = ', cl_voigt_a_ref
+  end subroutine grid_create_clump
 
   !--- car_setup_freq_grid: grid_mod_car.f90:1442-1548
   subroutine car_setup_freq_grid(grid)

@@ -36,7 +36,11 @@ program LaRT_amd
   call system_clock(t0, rate)
 
   call read_input(trim(infile))
-  call grid_create(grid)
+  if (par%use_clump_medium) then            ! main.f90:25-27
+     call grid_create_clump(grid)
+  else
+     call grid_create(grid)
+  endif
   call observer_create()
   if (par%save_peeloff) write(*,'(a,i4,a,2i6,a,2es13.5)') 'observers: ', par%nobs, '  image ', par%nxim, par%nyim, '  pixel (deg) ', par%dxim, par%dyim
   write(*,'(a,2f10.3,i6)') 'xfreq_min, xfreq_max, nxfreq : ', grid%xfreq_min, grid%xfreq_max, grid%nxfreq
@@ -52,7 +56,15 @@ program LaRT_amd
   endif
   call fill_params(cpar)
   call lart_check(lart_gpu_create(ctx, cpar, 0_c_int), 'lart_gpu_create')
-  if (par%DGR > 0.0_wp) then
+  if (par%use_clump_medium) then
+     if (par%DGR > 0.0_wp) then
+        call lart_check(lart_gpu_set_clumps(ctx, N_clumps, cl_x, cl_y, cl_z, cl_vx, cl_vy, cl_vz, cl_radius, cl_rhokap, c_loc(cl_rhokapD), &
+             cl_voigt_a, cl_Dfreq, sphere_R, cl_Dfreq_ref, cl_voigt_a_ref, cgx, cg_xmin, cg_dx, cg_start, cg_list), 'lart_gpu_set_clumps')
+     else
+        call lart_check(lart_gpu_set_clumps(ctx, N_clumps, cl_x, cl_y, cl_z, cl_vx, cl_vy, cl_vz, cl_radius, cl_rhokap, c_null_ptr, &
+             cl_voigt_a, cl_Dfreq, sphere_R, cl_Dfreq_ref, cl_voigt_a_ref, cgx, cg_xmin, cg_dx, cg_start, cg_list), 'lart_gpu_set_clumps')
+     endif
+  else if (par%DGR > 0.0_wp) then
      call lart_check(lart_gpu_set_grid_car(ctx, grid%nx, grid%ny, grid%nz, grid%xmin, grid%ymin, grid%zmin, grid%dx, grid%dy, grid%dz, &
           grid%i0, grid%j0, grid%k0, grid%xface, grid%yface, grid%zface, grid%rhokap, grid%voigt_a, grid%Dfreq, &
           grid%vfx, grid%vfy, grid%vfz, c_loc(grid%rhokapD)), 'lart_gpu_set_grid_car')

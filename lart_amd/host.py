@@ -192,15 +192,23 @@ def read_namelist(path):
     m = re.search(r"&parameters(.*?)^\s*/", txt, re.S | re.M | re.I)
     if not m:
         raise LartInputError("no &parameters namelist group in " + path)
-    for line in m.group(1).splitlines():
-        line = line.split("!")[0].strip()
-        if not line:
-            continue
-        mm = re.match(r"par%(\w+)\s*(?:\((\d+)\))?\s*=\s*(.+)$", line, re.I)
-        if not mm:
-            raise LartInputError("cannot parse namelist line: " + line)
-        name, idx, val = mm.group(1), mm.group(2), _parse_value(mm.group(3))
-        set_param(par, name, val, idx)
+    # strip comments, then split the group body at every `par%name[(i)] =`: several assignments may share a line
+    # (par%nx = 11, par%ny = 11) and a value list may follow one name (par%alpha = -90.0, -90.0)
+    body = "\n".join(ln.split("!")[0] for ln in m.group(1).splitlines())
+    parts = re.split(r"(par%\w+\s*(?:\(\s*\d+\s*\))?\s*=)", body, flags=re.I)
+    if parts[0].strip().strip(","):
+        raise LartInputError("cannot parse namelist text: " + parts[0].strip())
+    for key, val in zip(parts[1::2], parts[2::2]):
+        mm = re.match(r"par%(\w+)\s*(?:\(\s*(\d+)\s*\))?\s*=", key, re.I)
+        val = val.strip().rstrip(",").strip()
+        if not val:
+            raise LartInputError("no value for par%" + mm.group(1))
+        if val[:1] in "'\"":
+            v = _parse_value(val)
+        else:
+            items = [t for t in re.split(r"[,\s]+", val) if t]
+            v = _parse_value(items[0]) if len(items) == 1 else [_parse_value(t) for t in items]
+        set_param(par, mm.group(1), v, mm.group(2))
     return par
 
 

@@ -113,3 +113,56 @@ def test_end_to_end_matches_python_host(exe, tmp_path):
     assert np.allclose(obs["Scattered"][1][..., 0], t["scatt"][..., 0], rtol=1e-6, atol=1e-12 * t["scatt"].max())
     stk = read_fits(str(tmp_path / "e2e_stokes.fits"))
     assert np.allclose(stk["Stokes_Q"][1][..., 0], t["Q"][..., 0], rtol=1e-6, atol=1e-9 * np.abs(t["I"]).max())
+
+
+CLUMP_IN = """&parameters
+ par%use_clump_medium = .true.
+ par%rmax             = 1.0
+ par%clump_radius     = 0.01
+ par%clump_f_cov      = 5.0
+ par%clump_tau0       = 1.0e2
+ par%temperature      = 1.0e4
+ par%clump_sigma_v    = 15.0
+ par%velocity_type    = 'hubble'
+ par%Vexp             = 40.0
+ par%no_photons       = 40000
+ par%spectral_type    = 'voigt'
+ par%nxfreq           = 151
+ par%velocity_min     = -300.0
+ par%velocity_max     =  300.0
+ par%nx = 11, par%ny = 11, par%nz = 11
+ par%nxim = 16, par%nyim = 16
+ par%save_peeloff_2D  = .true.
+ par%iseed            = 7
+/
+"""
+
+
+def test_clump_dry_run_equals_python_host(exe, tmp_path):
+    """the clump population of the Fortran host (C helpers on the reference's MT19937-64 stream) = the Python host's"""
+    r = run(exe, CLUMP_IN, tmp_path, "--dry-run", name="clump.in")
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = r.stdout
+    from lart_amd import host, clump
+    par = host.read_namelist(str(tmp_path / "clump.in")); par, line, _ = host.read_input(par)
+    cl, g = clump.grid_create_clump(par, line)
+    assert re.search(r"Clumps: N_clumps\s+=\s+%d\b" % cl.N, out) and cl.N == 66667
+    assert re.search(r"CSR grid:\s+%d registrations in\s+%d\^3 cells" % (len(cl.cg_list), cl.cgx), out)
+    m = re.search(r"Clump derived: taumax\s+=\s+(\S+)", out); assert abs(float(m.group(1)) / par.taumax - 1) < 1e-5
+    m = re.search(r"Clumps: cl_rhokap =\s+(\S+)", out); assert abs(float(m.group(1)) / cl.rhokap_ref - 1) < 1e-4
+    assert "Clumps: velocity_type   = hubble" in out
+
+
+@pytest.mark.gpu
+def test_clump_end_to_end_matches_python_host(exe, tmp_path):
+    r = run(exe, CLUMP_IN, tmp_path, name="clump.in")
+    assert r.returncode == 0, r.stdout + r.stderr
+    spec = read_fits(str(tmp_path / "clump.fits"))["Spectrum"]
+    from lart_amd import host
+    sim = host.Simulation(str(tmp_path / "clump.in"))
+    sim.run_simulation()
+    t = sim.output_normalize()
+    assert np.allclose(spec[1]["Jout"], t["Jout"], rtol=1e-9, atol=1e-15)           # same clumps, same seed, same photon ids
+    assert np.isclose(float(spec[0]["Nsc_tot"]), t["nscatt_tot"], rtol=1e-9)
+    obs = read_fits(str(tmp_path / "clump_obs.fits"))
+    assert np.allclose(obs["Scattered"][1][..., 0], t["scatt"][..., 0], rtol=1e-6, atol=1e-12 * t["scatt"].max())
