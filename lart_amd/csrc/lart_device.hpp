@@ -156,26 +156,30 @@ __device__ inline void mulhilo32(uint32_t k, uint32_t v, uint32_t &hi, uint32_t 
 }
 // Philox4x32-10, key = seed, counter = (block, photon id): draw n of a packet is half (n & 1) of block n >> 1, so any
 // lane can produce any draw of its packet without state.  The photon loop uses that to take the generator out of the
-// divergent code: at the top of every event round ALL lanes of the wave fill a small per-lane buffer in LDS with the
-// next LART_RNG_BUF draws (full SIMD utilisation, LART_RNG_BUF/2 independent blocks interleaved for latency hiding), and
-// the rejection loops downstream read from it.  Values not consumed are simply produced again next round (same
-// counters, same values).  A lane that runs its buffer dry continues with single blocks (`slow` path); next2() needs
-// one block evaluation for two draws whatever the parity.
+// divergent code: at the top of every event round ALL lanes of the wave evaluate LART_RNG_TOPUP Philox blocks (full SIMD
+// utilisation, independent blocks interleaved for latency hiding) and append them to a per-lane ring of 16 draws in LDS;
+// the rejection loops downstream read the ring.  A lane that runs its ring dry continues with single blocks (`slow`
+// path); next2() needs one block evaluation for two draws whatever the parity.
 #ifndef LART_RNG_BUF
 #define LART_RNG_BUF 16
+#endif
+#ifndef LART_RNG_TOPUP
+#define LART_RNG_TOPUP 5         // blocks evaluated per event round (tools/gpu_ab*.sh sweeps)
 #endif
 #ifndef LART_PHILOX_ROUNDS
 #define LART_PHILOX_ROUNDS 10      // Philox4x32-10 (the KAT-pinned default of Salmon et al. 2011); tuning builds only change this to measure
 #endif
 struct Rng {
     uint32_t k0, k1; uint64_t id, n; double spare;          // spare: second half of the last slow block, valid while n is odd
-    double *lbuf = nullptr; uint32_t stride = 0, bi = LART_RNG_BUF;   // lbuf[j * stride] = draw (n - bi + j); bi >= LART_RNG_BUF: slow path
+    // ring of LART_RNG_BUF (= 16) draws in LDS: draw i of the packet lives in slot i & 15 of this lane's column;
+    // `have` draws are buffered ahead of n (n + have is even while have > 0); have == 0: slow path until the next prefill()
+    double *lbuf = nullptr; uint32_t stride = 0, have = 0;
     __device__ inline void init(uint64_t seed, uint64_t pid, uint64_t n0) {
         k0 = (uint32_t)seed; k1 = (uint32_t)(seed >> 32); id = pid; n = n0 & ~1ULL; spare = 0.0;
-        bi = LART_RNG_BUF;                                    // nothing buffered: slow path until the next prefill()
+        have = 0;
         if (n0 & 1ULL) (void)next();
     }
-    __device__ inline void attach(double *lds_lane, uint32_t lds_stride) { lbuf = lds_lane; stride = lds_stride; bi = LART_RNG_BUF; }
+    __device__ inline void attach(double *lds_lane, uint32_t lds_stride) { lbuf = lds_lane; stride = lds_stride; have = 0; }
     // open-interval uniform: (x>>12 + 0.5) / 2^52  (random_mt.f90:627-629)
     static __device__ inline double open01(uint32_t lo, uint32_t hi) {
         uint64_t x = ((uint64_t)hi << 32) | lo;
@@ -199,7 +203,6 @@ struct Rng {
         }
         first = open01(c0, c1); second = open01(c2, c3);
     }
-    // fill the lane's LDS buffer with draws [n & ~1, (n & ~1) + LART_RNG_BUF); call with the whole wave converged.
     // Blocks are named scalars (not arrays, which end up in scratch) and advance together round by round.
     struct Ctr { uint32_t c0, c1, c2, c3; };
     static __device__ inline void round1(Ctr &c, uint32_t a, uint32_t b) {
@@ -209,71 +212,93 @@ struct Rng {
         c.c0 = n0; c.c1 = l1; c.c2 = n2; c.c3 = l0;
     }
     __device__ inline Ctr ctr_of(uint64_t blk) const { Ctr c; c.c0 = (uint32_t)blk; c.c1 = (uint32_t)(blk >> 32); c.c2 = (uint32_t)id; c.c3 = (uint32_t)(id >> 32); return c; }
-    __device__ inline void store2(int j, const Ctr &c) { lbuf[(2 * j) * stride] = open01(c.c0, c.c1); lbuf[(2 * j + 1) * stride] = open01(c.c2, c.c3); }
+    __device__ inline void store2(uint32_t slot, bool on, const Ctr &c) {
+        if (on) { lbuf[(slot & (LART_RNG_BUF - 1)) * stride] = open01(c.c0, c.c1); lbuf[((slot + 1) & (LART_RNG_BUF - 1)) * stride] = open01(c.c2, c.c3); }
+    }
+    // Top the ring up with LART_RNG_TOPUP blocks (2 draws each) behind the draws still buffered; call with the whole wave
+    // converged.  Every lane evaluates the same number of blocks; a lane whose ring is nearly full stores only what fits
+    // (those counters are simply produced again later).  An event consumes ~8 draws on average, so 5 blocks per round keep
+    // the ring filling while a lane that needs many tries draws the reserve down before it falls back to single blocks.
     __device__ inline void prefill() {
-        static_assert(LART_RNG_BUF >= 8 && LART_RNG_BUF <= 16 && LART_RNG_BUF % 2 == 0, "LART_RNG_BUF must be even, 8..16");
-        uint64_t b0 = n >> 1;
-        Ctr q0 = ctr_of(b0), q1 = ctr_of(b0 + 1), q2 = ctr_of(b0 + 2), q3 = ctr_of(b0 + 3);
-#if LART_RNG_BUF >= 10
+        static_assert(LART_RNG_BUF == 16, "the ring indexes draws by i & 15");
+        static_assert(LART_RNG_TOPUP >= 3 && LART_RNG_TOPUP <= 8, "LART_RNG_TOPUP must be 3..8 blocks");
+        uint64_t e = have ? n + have : (n & ~1ULL);          // first draw not buffered (even); nothing buffered: restart on draw n's block
+        uint32_t used = (uint32_t)(e - (n & ~1ULL)), freeb = (LART_RNG_BUF - used) >> 1, slot = (uint32_t)e;
+        uint64_t b0 = e >> 1;
+        Ctr q0 = ctr_of(b0), q1 = ctr_of(b0 + 1), q2 = ctr_of(b0 + 2);
+#if LART_RNG_TOPUP >= 4
+        Ctr q3 = ctr_of(b0 + 3);
+#endif
+#if LART_RNG_TOPUP >= 5
         Ctr q4 = ctr_of(b0 + 4);
 #endif
-#if LART_RNG_BUF >= 12
+#if LART_RNG_TOPUP >= 6
         Ctr q5 = ctr_of(b0 + 5);
 #endif
-#if LART_RNG_BUF >= 14
+#if LART_RNG_TOPUP >= 7
         Ctr q6 = ctr_of(b0 + 6);
 #endif
-#if LART_RNG_BUF >= 16
+#if LART_RNG_TOPUP >= 8
         Ctr q7 = ctr_of(b0 + 7);
 #endif
         uint32_t a = k0, b = k1;
 #pragma unroll 1
         for (int r = 0; r < LART_PHILOX_ROUNDS; r++) {
-            round1(q0, a, b); round1(q1, a, b); round1(q2, a, b); round1(q3, a, b);
-#if LART_RNG_BUF >= 10
+            round1(q0, a, b); round1(q1, a, b); round1(q2, a, b);
+#if LART_RNG_TOPUP >= 4
+            round1(q3, a, b);
+#endif
+#if LART_RNG_TOPUP >= 5
             round1(q4, a, b);
 #endif
-#if LART_RNG_BUF >= 12
+#if LART_RNG_TOPUP >= 6
             round1(q5, a, b);
 #endif
-#if LART_RNG_BUF >= 14
+#if LART_RNG_TOPUP >= 7
             round1(q6, a, b);
 #endif
-#if LART_RNG_BUF >= 16
+#if LART_RNG_TOPUP >= 8
             round1(q7, a, b);
 #endif
             a += 0x9E3779B9u; b += 0xBB67AE85u;
         }
-        store2(0, q0); store2(1, q1); store2(2, q2); store2(3, q3);
-#if LART_RNG_BUF >= 10
-        store2(4, q4);
+        store2(slot, freeb > 0, q0); store2(slot + 2, freeb > 1, q1); store2(slot + 4, freeb > 2, q2);
+#if LART_RNG_TOPUP >= 4
+        store2(slot + 6, freeb > 3, q3);
 #endif
-#if LART_RNG_BUF >= 12
-        store2(5, q5);
+#if LART_RNG_TOPUP >= 5
+        store2(slot + 8, freeb > 4, q4);
 #endif
-#if LART_RNG_BUF >= 14
-        store2(6, q6);
+#if LART_RNG_TOPUP >= 6
+        store2(slot + 10, freeb > 5, q5);
 #endif
-#if LART_RNG_BUF >= 16
-        store2(7, q7);
+#if LART_RNG_TOPUP >= 7
+        store2(slot + 12, freeb > 6, q6);
 #endif
-        bi = (uint32_t)(n & 1ULL);
+#if LART_RNG_TOPUP >= 8
+        store2(slot + 14, freeb > 7, q7);
+#endif
+        uint32_t stored = freeb < LART_RNG_TOPUP ? freeb : LART_RNG_TOPUP;
+        have = (uint32_t)(e + 2 * stored - n);
     }
     __device__ inline double next() {
-        if (bi < LART_RNG_BUF) { double v = lbuf[bi * stride]; bi++; n++; return v; }
+        if (have) { double v = lbuf[((uint32_t)n & (LART_RNG_BUF - 1)) * stride]; n++; have--; return v; }
         uint64_t m = n++;
         if (m & 1ULL) return spare;
         double first; block(m >> 1, first, spare);
         return first;
     }
-    // two consecutive draws; off the buffer this is ONE block evaluation for either parity of n
+    // two consecutive draws; off the ring this is ONE block evaluation for either parity of n
     __device__ inline void next2(double &u1, double &u2) {
-        if (bi + 1 < LART_RNG_BUF) { u1 = lbuf[bi * stride]; u2 = lbuf[(bi + 1) * stride]; bi += 2; n += 2; return; }
-        bool odd = n & 1ULL;                                  // one buffered draw left <=> n odd (the buffer starts on an even draw)
-        double prev = (bi < LART_RNG_BUF) ? lbuf[bi * stride] : spare, first, second;
+        if (have >= 2) {
+            u1 = lbuf[((uint32_t)n & (LART_RNG_BUF - 1)) * stride]; u2 = lbuf[(((uint32_t)n + 1) & (LART_RNG_BUF - 1)) * stride];
+            n += 2; have -= 2; return;
+        }
+        bool odd = n & 1ULL;                                  // one buffered draw left <=> n odd (n + have is even)
+        double prev = have ? lbuf[((uint32_t)n & (LART_RNG_BUF - 1)) * stride] : spare, first, second;
         block((n + 1) >> 1, first, second);
         if (odd) { u1 = prev; u2 = first; spare = second; } else { u1 = first; u2 = second; }
-        bi = LART_RNG_BUF; n += 2;
+        have = 0; n += 2;
     }
     // Marsaglia polar pair (random_mt.f90:964-988); first = v2*rsq (what the reference returns first)
     __device__ inline double gauss_pair(double &second) {

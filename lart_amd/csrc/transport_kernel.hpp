@@ -73,6 +73,9 @@ __global__ __launch_bounds__(256, LART_WAVES(STOKES, PEEL)) void transport_kerne
         }
         if (budget <= 0) break;
         g.prefill();
+#ifdef LART_EXPERIMENT_PREFILL2                        // timing experiment: cost of one buffer fill
+        g.prefill();
+#endif
         LART_PROF_TRIP(p, 2);
         double tau;
         if (first) {
@@ -91,6 +94,9 @@ __global__ __launch_bounds__(256, LART_WAVES(STOKES, PEEL)) void transport_kerne
             first = false;
         } else tau = -d_log(g.next());
         LART_PROF_MARK(p, 2);
+#ifdef LART_EXPERIMENT_RAY2                            // timing experiment: cost of one flight (the copy's escapes are tallied twice: timing only)
+        { Photon p2 = p; unsigned ns2 = 0; raytrace_to_tau<VAR>(A, l, DUST, p2, tau, ns2); if (p2.x == 1e300) p.x = p2.y; }
+#endif
         raytrace_to_tau<VAR>(A, l, DUST, p, tau, nsteps);
         LART_PROF_MARK(p, 3);
         if (p.inside) { scatter_event<VAR, STOKES, DUST, PEEL>(A, l, g, p, npeel); nev++; budget--; }
