@@ -115,7 +115,8 @@ static __device__ const double c_voigt_tab[606] = {   // H0(101) | H1(202) | H2(
 #define VT_H3 404
 #define VT_END 606
 
-struct Lds { const double *vt; const double *xf, *yf, *zf; };
+struct Lds { const double *vt; const double *xf, *yf, *zf;
+             double dip_p2, dip_qs; };   // Cardano constants of the dipole phase function for par.E1 > 0 (rand_resonance): p, 1/(E1 p^3)
 
 __device__ inline Lds lds_stage(double *sh, const DGrid &g) {
     for (int i = threadIdx.x; i < VT_END; i += blockDim.x) sh[i] = c_voigt_tab[i];
@@ -123,6 +124,7 @@ __device__ inline Lds lds_stage(double *sh, const DGrid &g) {
     for (int i = threadIdx.x; i < nf; i += blockDim.x) sh[VT_END + i] = g.faces[i];
     __syncthreads();
     Lds l; l.vt = sh; l.xf = sh + VT_END; l.yf = l.xf + (g.nx + 1); l.zf = l.yf + (g.ny + 1);
+    l.dip_p2 = 0.0; l.dip_qs = 0.0;
     return l;
 }
 
@@ -410,7 +412,7 @@ __device__ inline double rand_resonance_vz(Rng &g, double x0in, double a LART_PR
         }
     }
     bool two_seg = (mode == 1 && dbeta == 0.0 && !(x0 < xc));
-    double Stot = S0 + S1 + S2, t1, delt;
+    double Stot = S0 + S1 + S2, t1, delt, pb = 0.0;
     LART_PROF_MARK(pp, 8);
     for (;;) {
         LART_PROF_TRIP(pp, 1);
@@ -423,10 +425,14 @@ __device__ inline double rand_resonance_vz(Rng &g, double x0in, double a LART_PR
         else if (two_seg)                             { beta = beta0 + (1.0 - beta0) * u; Cb = hB; }
         else if (rS < 1.0 - S2 / Stot)                { beta = beta0 + dbeta * u; Cb = hA; }
         else                                          { beta = beta1 + (1.0 - beta1) * u; Cb = hB; }
-        double pb = sqrt(-2.0 * d_log(beta));
-        double t2 = atan((pb - x0) / a); t1 = atan((-pb - x0) / a); delt = t2 - t1;
+        pb = sqrt(-2.0 * d_log(beta));
+        // window width delt = atan((pb-x0)/a) - atan((-pb-x0)/a) in one arctangent: tan(delt) = 2 pb a / (a^2 + x0^2 - pb^2),
+        // delt in (0, pi).  (The two-arctangent form of the reference cancels near -pi/2 for |x| >> a; this one does not.)
+        double den = fma(x0 - pb, x0 + pb, a * a);
+        delt = atan((2.0 * pb * a) / den); if (den < 0.0) delt = delt + LART_PI;
         if (acc * Cb < (beta / api) * delt) break;
     }
+    t1 = atan((-pb - x0) / a);                               // lower edge of the window of the accepted try only
     LART_PROF_MARK(pp, 9);
     vz = x0 + a * d_tan(delt * g.next() + t1);
     LART_PROF_MARK(pp, 10);
@@ -447,6 +453,19 @@ __device__ inline double rand_resonance_u(double u, double E1) {       // the sa
     return 2.0 * u - 1.0;
 }
 __device__ inline double rand_resonance(Rng &g, double E1) { return rand_resonance_u(g.next(), E1); }
+// the same with the constants of the E1 > 0 branch computed once per kernel (Lds::dip_p2, dip_qs); they are wave-uniform
+__device__ inline double uniform_f64(double v) {
+    uint64_t b = __double_as_longlong(v);
+    uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+    return __longlong_as_double(((uint64_t)hi << 32) | lo);
+}
+__device__ inline void lds_set_dipole(Lds &l, double E1) {
+    if (E1 > 0.0) { double p2 = sqrt((4.0 - E1) / (3.0 * E1)); l.dip_p2 = uniform_f64(p2); l.dip_qs = uniform_f64(1.0 / (E1 * (p2 * p2 * p2))); }
+}
+__device__ inline double dipole_cost(const Lds &l, double u, double E1) {
+    if (l.dip_p2 > 0.0) { double Q = (4.0 * u - 2.0) * l.dip_qs, W = cbrt(Q + sqrt(Q * Q + 1.0)); return l.dip_p2 * (W - 1.0 / W); }
+    return rand_resonance_u(u, E1);
+}
 // Henyey-Greenstein: random_mt.f90:3022-3042
 __device__ inline double rand_hg(Rng &g, double gg) {
     double x = g.next();
@@ -1189,9 +1208,9 @@ __device__ inline void peel_dust_stokes(const KArgs &A, const Lds &l, const Phot
 __device__ inline void rotate_k(Photon &p, double cost, double sint, double cosp, double sinp) {
     if (fabs(p.kz) >= 0.99999999999) { p.kx = sint * cosp; p.ky = sint * sinp; p.kz = cost; }
     else {
-        double kx1 = p.kx, ky1 = p.ky, kz1 = p.kz, kr = sqrt(kx1 * kx1 + ky1 * ky1);
-        p.kx = cost * kx1 + sint * (kz1 * kx1 * cosp - ky1 * sinp) / kr;
-        p.ky = cost * ky1 + sint * (kz1 * ky1 * cosp + kx1 * sinp) / kr;
+        double kx1 = p.kx, ky1 = p.ky, kz1 = p.kz, kr = sqrt(kx1 * kx1 + ky1 * ky1), s_kr = sint / kr;   // one division for both components
+        p.kx = cost * kx1 + (kz1 * kx1 * cosp - ky1 * sinp) * s_kr;
+        p.ky = cost * ky1 + (kz1 * ky1 * cosp + kx1 * sinp) * s_kr;
         p.kz = cost * kz1 - sint * cosp * kr;
     }
 }
@@ -1285,12 +1304,12 @@ __device__ inline void scatter_event(const KArgs &A, const Lds &l, Rng &g, Photo
     LART_PROF_MARK(p, 5);
     double S11 = 0, S22 = 0, S12 = 0, S33 = 0, S44 = 0, sinp, cosp, cost, cost2, sint;
     if (STOKES) {
-        cost = rand_resonance(g, par.E1); cost2 = cost * cost; sint = sqrt(1.0 - cost2);
+        cost = dipole_cost(l, g.next(), par.E1); cost2 = cost * cost; sint = sqrt(1.0 - cost2);
         S22 = 0.75 * par.E1 * (cost2 + 1.0); S11 = S22 + par.E2; S12 = 0.75 * par.E1 * (cost2 - 1.0); S33 = 1.5 * par.E1 * cost; S44 = 1.5 * par.E3 * cost;
         phi_rejection(g, p, S12 / S11, sinp, cosp);
     } else {
         double ud, up; g.next2(ud, up);                       // polar angle, then azimuth: the reference's order of draws
-        cost = rand_resonance_u(ud, par.E1); cost2 = cost * cost; sint = sqrt(1.0 - cost2);
+        cost = dipole_cost(l, ud, par.E1); cost2 = cost * cost; sint = sqrt(1.0 - cost2);
         d_sincos_2pi(up, &sinp, &cosp);
     }
     // perpendicular atom velocity; truncated tail when core-skipping (:726-752, :400-430)

@@ -26,7 +26,8 @@ __device__ inline double wave_sum(double v) {
 template <int VAR, bool STOKES, bool DUST, bool PEEL>
 __global__ __launch_bounds__(256, LART_WAVES(STOKES, PEEL)) void transport_kernel(KArgs A) {
     extern __shared__ double sh[];
-    const Lds l = lds_stage(sh, A.g);
+    Lds l_ = lds_stage(sh, A.g); lds_set_dipole(l_, A.par.E1);
+    const Lds l = l_;
     double *rng_lds = sh + VT_END + (A.g.nx + A.g.ny + A.g.nz + 3) + threadIdx.x;      // [LART_RNG_BUF][blockDim.x] draws
     const lart_params &par = A.par;
     const int64_t lane = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // pool.n is a multiple of blockDim.x
