@@ -372,23 +372,26 @@ struct Photon {
 // samplers
 // ---------------------------------------------------------------------------------------------
 // atom velocity parallel to k: random_mt.f90:2562-2696 (rand_resonance_vz_seon)
-__device__ inline double rand_resonance_vz(Rng &g, double x0in, double a LART_PROF_ARG(pp)) {
+// |x| <= 1: Lorentzian proposal, Gaussian rejection (random_mt.f90:2579-2586)
+__device__ inline double vz_core(Rng &g, double x0in, double a LART_PROF_ARG(pp)) {
+    double x0 = fabs(x0in), vz;
+    for (;;) {
+        LART_PROF_TRIP(pp, 0);
+        double u1, u2; g.next2(u1, u2);
+        vz = x0 + a * d_tan(LART_PI * (u1 - 0.5));
+#ifdef LART_EXPERIMENT_DOUBLE_TRY                              // timing experiment: the arithmetic of a try done twice, same result
+        double vzb = x0 + a * d_tan(LART_PI * (u2 - 0.5));
+        if (u2 <= d_exp_neg(-(vz * vz)) + 0.0 * d_exp_neg(-(vzb * vzb))) break;
+#else
+        if (u2 <= d_exp_neg(-(vz * vz))) break;
+#endif
+    }
+    return x0in < 0.0 ? -vz : vz;
+}
+// |x| > 1: piecewise-constant comparison function in beta = exp(-u^2/2) space (random_mt.f90:2588-2693)
+__device__ inline double vz_wing(Rng &g, double x0in, double a LART_PROF_ARG(pp)) {
     const double xc = 2.414213562373095048801688724209698, two_over_PI = 2.0 / LART_PI;
     double x0 = fabs(x0in), vz;
-    if (x0 <= 1.0) {
-        for (;;) {
-            LART_PROF_TRIP(pp, 0);
-            double u1, u2; g.next2(u1, u2);
-            vz = x0 + a * d_tan(LART_PI * (u1 - 0.5));
-#ifdef LART_EXPERIMENT_DOUBLE_TRY                              // timing experiment: the arithmetic of a try done twice, same result
-            double vzb = x0 + a * d_tan(LART_PI * (u2 - 0.5));
-            if (u2 <= d_exp_neg(-(vz * vz)) + 0.0 * d_exp_neg(-(vzb * vzb))) break;
-#else
-            if (u2 <= d_exp_neg(-(vz * vz))) break;
-#endif
-        }
-        return x0in < 0.0 ? -vz : vz;
-    }
     LART_PROF_MARK(pp, 5); LART_PROF_TRIP(pp, 3);
     double x0sq = x0 * x0, api = a * LART_PI, beta0 = d_exp_neg(-x0sq / 2.0), h0_two = beta0 / a, h0 = h0_two / 2.0;
     // comparison function in beta-space: up to three segments [0,beta0) ~ beta/a, [beta0,beta1) = hA, [beta1,1) = hB
@@ -437,6 +440,10 @@ __device__ inline double rand_resonance_vz(Rng &g, double x0in, double a LART_PR
     vz = x0 + a * d_tan(delt * g.next() + t1);
     LART_PROF_MARK(pp, 10);
     return x0in < 0.0 ? -vz : vz;
+}
+// atom velocity parallel to k: random_mt.f90:2562-2696 (rand_resonance_vz_seon)
+__device__ inline double rand_resonance_vz(Rng &g, double x0in, double a LART_PROF_ARG(pp)) {
+    return fabs(x0in) <= 1.0 ? vz_core(g, x0in, a LART_PROF_PASS(pp)) : vz_wing(g, x0in, a LART_PROF_PASS(pp));
 }
 // dipole/isotropic mix scattering angle: random_mt.f90:2974-2993
 __device__ inline double rand_resonance_u(double u, double E1) {       // the same with the uniform draw handed in
@@ -1252,9 +1259,14 @@ __device__ inline bool dust_absorb(const KArgs &A, Rng &g, Photon &p, const Cell
     return false;
 }
 
-// one scattering event (scattering :14-120 Cartesian branch, then the selected routine)
+// one scattering event (scattering :14-120 Cartesian branch, then the selected routine), in three pieces so that the
+// atom-velocity sampler between them can also run somewhere else (transport_kernel.hpp batches its |x| > 1 branch per block):
+//   scatter_pre  -> dust-or-gas decision; a dust event completes here; a resonance event returns true with the sampler's
+//                   arguments in ScatCtx (x in the local Doppler units of the cell / clump)
+//   scatter_post -> everything after do_resonance's `uz = rand_resonance_vz(x, a)`
+struct ScatCtx { double va, xloc, cl_scale, cl_Dfreq; };
 template <int VAR, bool STOKES, bool DUST, bool PEEL>
-__device__ inline void scatter_event(const KArgs &A, const Lds &l, Rng &g, Photon &p, unsigned &npeel) {
+__device__ inline bool scatter_pre(const KArgs &A, const Lds &l, Rng &g, Photon &p, unsigned &npeel, ScatCtx &sc) {
     const lart_params &par = A.par;
     const Cell &c = A.g.cell[cidx(A.g, p.ic, p.jc, p.kc)];
     double va = c.voigt_a;
@@ -1266,7 +1278,7 @@ __device__ inline void scatter_event(const KArgs &A, const Lds &l, Rng &g, Photo
         double rD = cl_rhokapD;
         double p_dust = rD / (cl_rhokap * voigt_H(l.vt, p.xfreq * cl_scale, va) + rD);
         if (g.next() <= p_dust) {
-            if (dust_absorb(A, g, p, c)) return;
+            if (dust_absorb(A, g, p, c)) return false;
             if (STOKES && A.mu.nPDF > 0) {                     // scatter_dust_stokes :201-329
                 if (PEEL) peel_dust_stokes<VAR>(A, l, p, npeel);
                 double cost = rand_alias_linear(g, A.mu), sint = sqrt(1.0 - cost * cost);
@@ -1285,7 +1297,7 @@ __device__ inline void scatter_event(const KArgs &A, const Lds &l, Rng &g, Photo
                 double sinp, cosp; d_sincos_2pi(g.next(), &sinp, &cosp);
                 rotate_k(p, cost, sint, cosp, sinp);
             }
-            return;
+            return false;
         }
     }
     // resonance scattering: scatter_resonance_nostokes :660-827 / _stokes :331-486
@@ -1294,14 +1306,16 @@ __device__ inline void scatter_event(const KArgs &A, const Lds &l, Rng &g, Photo
         int ib = (VAR == 3) ? amr_JPa_bin(A.amr, p.ic, p.x, p.y, p.z) : A.jpa.ind_bin[cidx(A.g, p.ic, p.jc, p.kc)];   // add_to_Pa_amr: scattering_amr.f90:917-942
         if (ib >= 1) atomicAdd(&A.jpa.P1[ib - 1], p.wgt / (c.rhokap * c.Dfreq / A.jpa.cross0));
     }
-    // do_resonance1: line_mod.f90:108-139
-    LART_PROF_MARK(p, 4);
+    sc.va = va; sc.cl_scale = cl_scale; sc.cl_Dfreq = cl_Dfreq; sc.xloc = (VAR == 4) ? p.xfreq * cl_scale : p.xfreq;
+    return true;
+}
+template <int VAR, bool STOKES, bool DUST, bool PEEL>
+__device__ inline void scatter_post(const KArgs &A, const Lds &l, Rng &g, Photon &p, unsigned &npeel, const ScatCtx &sc, double uz_loc) {
+    const lart_params &par = A.par;
+    // do_resonance1 (line_mod.f90:108-139; do_resonance1_clump: local Doppler units and back)
     double uz, xfreq_atom;
-    if (VAR == 4) {
-        double xloc = p.xfreq * cl_scale, uz_loc = rand_resonance_vz(g, xloc, va LART_PROF_PASS(p)), scale_inv = 1.0 / cl_scale;
-        xfreq_atom = (xloc - uz_loc) * scale_inv; uz = uz_loc * scale_inv;
-    } else { uz = rand_resonance_vz(g, p.xfreq, va LART_PROF_PASS(p)); xfreq_atom = p.xfreq - uz; }
-    LART_PROF_MARK(p, 5);
+    if (VAR == 4) { double scale_inv = 1.0 / sc.cl_scale; xfreq_atom = (sc.xloc - uz_loc) * scale_inv; uz = uz_loc * scale_inv; }
+    else { uz = uz_loc; xfreq_atom = p.xfreq - uz; }
     double S11 = 0, S22 = 0, S12 = 0, S33 = 0, S44 = 0, sinp, cosp, cost, cost2, sint;
     if (STOKES) {
         cost = dipole_cost(l, g.next(), par.E1); cost2 = cost * cost; sint = sqrt(1.0 - cost2);
@@ -1325,9 +1339,9 @@ __device__ inline void scatter_event(const KArgs &A, const Lds &l, Rng &g, Photo
         double u2, u3; g.next2(u2, u3); double uxy = sqrt(-d_log(u3)), s2, c2; d_sincos_2pi(u2, &s2, &c2);
         ux = uxy * c2; uy = uxy * s2;
     }
-    if (VAR == 4) { double vth_ratio = cl_Dfreq / A.cl.Dfreq_ref; ux = ux * vth_ratio; uy = uy * vth_ratio; }   // scattering_car.f90:384-388, 715-719
+    if (VAR == 4) { double vth_ratio = sc.cl_Dfreq / A.cl.Dfreq_ref; ux = ux * vth_ratio; uy = uy * vth_ratio; }   // scattering_car.f90:384-388, 715-719
     p.xfreq = xfreq_atom + uz * cost + (ux * cosp + uy * sinp) * sint;
-    if (par.recoil) p.xfreq = p.xfreq - (par.g_recoil0 / cl_Dfreq) * (1.0 - cost);
+    if (par.recoil) p.xfreq = p.xfreq - (par.g_recoil0 / sc.cl_Dfreq) * (1.0 - cost);
     if (STOKES) {
         if (PEEL) peel_resonance_stokes<VAR>(A, l, DUST, p, xfreq_atom, ux, uy, uz, npeel);
         double cos2p = 2.0 * cosp * cosp - 1.0, sin2p = 2.0 * sinp * cosp;
@@ -1339,6 +1353,15 @@ __device__ inline void scatter_event(const KArgs &A, const Lds &l, Rng &g, Photo
         if (PEEL) peel_resonance_nostokes<VAR>(A, l, DUST, p, xfreq_atom, ux, uy, uz, npeel);
         rotate_k(p, cost, sint, cosp, sinp);
     }
+}
+template <int VAR, bool STOKES, bool DUST, bool PEEL>
+__device__ inline void scatter_event(const KArgs &A, const Lds &l, Rng &g, Photon &p, unsigned &npeel) {
+    ScatCtx sc;
+    if (!scatter_pre<VAR, STOKES, DUST, PEEL>(A, l, g, p, npeel, sc)) return;
+    LART_PROF_MARK(p, 4);
+    double uz_loc = rand_resonance_vz(g, sc.xloc, sc.va LART_PROF_PASS(p));
+    LART_PROF_MARK(p, 5);
+    scatter_post<VAR, STOKES, DUST, PEEL>(A, l, g, p, npeel, sc, uz_loc);
 }
 
 // ---------------------------------------------------------------------------------------------

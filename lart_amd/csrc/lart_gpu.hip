@@ -417,6 +417,7 @@ extern "C" int lart_gpu_step(lart_gpu *c, int32_t nsteps, int32_t max_events) {
     int var = c->is_clump ? 4 : c->is_amr ? 3 : (c->par.xyz_symmetry ? 1 : (c->par.xy_periodic ? 2 : 0));     // setup.f90:961-990
     int stokes = c->par.use_stokes ? 1 : 0, dust = c->par.DGR > 0.0 ? 1 : 0, peel = (c->par.save_peeloff && c->nobs > 0) ? 1 : 0;
     dim3 block(c->block), grid((unsigned)(c->pool.n / c->block));
+    // Voigt tables + faces | ring of random draws [LART_RNG_BUF][block]
     size_t shmem = (size_t)(VT_END + c->g.nx + c->g.ny + c->g.nz + 3 + LART_RNG_BUF * c->block) * sizeof(double);
     if (shmem > 160 * 1024) return fail("step: grid faces do not fit the 160 KiB LDS");
     for (int s = 0; s < nsteps; s++) {

@@ -23,6 +23,35 @@ __device__ inline double wave_sum(double v) {
 #define LART_WAVES(S, P) ((P) ? 2 : ((S) ? 3 : 4))
 #endif
 
+
+// one flight of a packet: optical depth to the next interaction (forced on the first flight: run_simulation_mod.f90:163-177,
+// add_escaped_fraction_to_Jout :208-247), then the march
+template <int VAR, bool DUST>
+__device__ inline void fly(const KArgs &A, const Lds &l, Rng &g, Photon &p, bool &first, unsigned &nsteps) {
+    const lart_params &par = A.par;
+    double tau;
+    if (first) {
+        double tau0 = raytrace_to_edge<VAR>(A, l, DUST, p, p.xfreq, p.kx, p.ky, p.kz, -1.0, nsteps);
+        double esc = d_exp_neg(-tau0);
+        {
+            const Cell &c = A.g.cell[cidx(A.g, p.ic, p.jc, p.kc)];
+            double u1 = c.vfx * p.kx + c.vfy * p.ky + c.vfz * p.kz;
+            Photon e = p; e.wgt = p.wgt * esc; e.xfreq_ref = (p.xfreq + u1) * (c.Dfreq / par.Dfreq_ref);
+            if (e.wgt != 0.0) tally_escape(par, A.t, e);
+        }
+        double wgt1 = 1.0 - esc;
+        p.wgt = p.wgt * wgt1;
+        tau = (tau0 > 0.0) ? -d_log(1.0 - g.next() * wgt1) : LART_HUGEST;
+        first = false;
+    } else tau = -d_log(g.next());
+    LART_PROF_MARK(p, 2);
+#ifdef LART_EXPERIMENT_RAY2                            // timing experiment: cost of one flight (the copy's escapes are tallied twice: timing only)
+    { Photon p2 = p; unsigned ns2 = 0; raytrace_to_tau<VAR>(A, l, DUST, p2, tau, ns2); if (p2.x == 1e300) p.x = p2.y; }
+#endif
+    raytrace_to_tau<VAR>(A, l, DUST, p, tau, nsteps);
+    LART_PROF_MARK(p, 3);
+}
+
 template <int VAR, bool STOKES, bool DUST, bool PEEL>
 __global__ __launch_bounds__(256, LART_WAVES(STOKES, PEEL)) void transport_kernel(KArgs A) {
     extern __shared__ double sh[];
@@ -78,28 +107,7 @@ __global__ __launch_bounds__(256, LART_WAVES(STOKES, PEEL)) void transport_kerne
         g.prefill();
 #endif
         LART_PROF_TRIP(p, 2);
-        double tau;
-        if (first) {
-            // forced first scattering: run_simulation_mod.f90:163-177, add_escaped_fraction_to_Jout :208-247
-            double tau0 = raytrace_to_edge<VAR>(A, l, DUST, p, p.xfreq, p.kx, p.ky, p.kz, -1.0, nsteps);
-            double esc = d_exp_neg(-tau0);
-            {
-                const Cell &c = A.g.cell[cidx(A.g, p.ic, p.jc, p.kc)];
-                double u1 = c.vfx * p.kx + c.vfy * p.ky + c.vfz * p.kz;
-                Photon e = p; e.wgt = p.wgt * esc; e.xfreq_ref = (p.xfreq + u1) * (c.Dfreq / par.Dfreq_ref);
-                if (e.wgt != 0.0) tally_escape(par, A.t, e);
-            }
-            double wgt1 = 1.0 - esc;
-            p.wgt = p.wgt * wgt1;
-            tau = (tau0 > 0.0) ? -d_log(1.0 - g.next() * wgt1) : LART_HUGEST;
-            first = false;
-        } else tau = -d_log(g.next());
-        LART_PROF_MARK(p, 2);
-#ifdef LART_EXPERIMENT_RAY2                            // timing experiment: cost of one flight (the copy's escapes are tallied twice: timing only)
-        { Photon p2 = p; unsigned ns2 = 0; raytrace_to_tau<VAR>(A, l, DUST, p2, tau, ns2); if (p2.x == 1e300) p.x = p2.y; }
-#endif
-        raytrace_to_tau<VAR>(A, l, DUST, p, tau, nsteps);
-        LART_PROF_MARK(p, 3);
+        fly<VAR, DUST>(A, l, g, p, first, nsteps);
         if (p.inside) { scatter_event<VAR, STOKES, DUST, PEEL>(A, l, g, p, npeel); nev++; budget--; }
         LART_PROF_MARK(p, 6);
         if (!p.inside) {
