@@ -138,6 +138,19 @@ int  lart_host_clumps_csr_dims(int64_t n, double sphere_R, double radius_max, in
 int  lart_host_clumps_build_csr(int64_t n, const double *x, const double *y, const double *z, const double *radius,
                                 int32_t cgx, double cg_min, double cg_d, int32_t *cg_start, int32_t *cg_list, int64_t *nreg);
 
+/* ---- host-side set-up helpers for the octree (CPU): amr_build_tree + amr_build_neighbors (octree_mod.f90:460-569, 619-682)
+ * from a list of leaf cells (centre, refinement level) in the cube [lo,hi]^3, numbered like the reference (root = 1, cells in
+ * creation order while the leaves are inserted in input order).  lart_host_amr_count gives ncells; lart_host_amr_build fills
+ * the tables lart_gpu_set_grid_amr takes (children[8*ncells], neighbor[6*ncells], ...; cell_level and levelmax optional).
+ * Errors: non-zero + lart_host_amr_last_error(). */
+const char *lart_host_amr_last_error(void);
+int  lart_host_amr_count(int32_t nleaf, const double *x, const double *y, const double *z, const int32_t *level,
+                         double lo, double hi, int32_t *ncells);
+int  lart_host_amr_build(int32_t nleaf, const double *x, const double *y, const double *z, const int32_t *level,
+                         double lo, double hi, int32_t ncells, double *cx, double *cy, double *cz, double *ch,
+                         int32_t *children, int32_t *neighbor, int32_t *ileaf, int32_t *icell_of_leaf,
+                         int32_t *cell_level, int32_t *levelmax);
+
 /* replaces `call run_simulation(grid)` (main.f90:42): photons first_id, first_id+stride, ... (count of
  * them; the reference's static decomposition `do ip = rank+1, nphotons, nproc`, run_simulation_mod.f90:150).
  * The random stream of a photon depends only on (seed, id). Runs to completion. */

@@ -103,6 +103,34 @@ module lart_gpu_c
        integer(c_int64_t), intent(out) :: nreg
        integer(c_int) :: rc
      end function
+     function lart_gpu_set_grid_amr(ctx, ncells, nleaf, lo, hi, cx, cy, cz, ch, children, neighbor, ileaf, icell_of_leaf, &
+                                    rhokap, voigt_a, Dfreq, vfx, vfy, vfz, rhokapD) bind(C, name='lart_gpu_set_grid_amr') result(rc)
+       import; type(c_ptr), value :: ctx; integer(c_int32_t), value :: ncells, nleaf; real(c_double), value :: lo, hi
+       real(c_double), intent(in) :: cx(*), cy(*), cz(*), ch(*), rhokap(*), voigt_a(*), Dfreq(*), vfx(*), vfy(*), vfz(*)
+       integer(c_int32_t), intent(in) :: children(*), neighbor(*), ileaf(*), icell_of_leaf(*)
+       type(c_ptr), value :: rhokapD
+       integer(c_int) :: rc
+     end function
+     function lart_gpu_set_JPa_amr(ctx, calc_J, calc_P, calc_Pnew, geometry_JPa, nbins, dbin, cross0) bind(C, name='lart_gpu_set_JPa_amr') result(rc)
+       import; type(c_ptr), value :: ctx; integer(c_int32_t), value :: calc_J, calc_P, calc_Pnew, geometry_JPa, nbins
+       real(c_double), value :: dbin, cross0; integer(c_int) :: rc
+     end function
+     function lart_host_amr_last_error() bind(C, name='lart_host_amr_last_error') result(p)
+       import; type(c_ptr) :: p
+     end function
+     function lart_host_amr_count(nleaf, x, y, z, level, lo, hi, ncells) bind(C, name='lart_host_amr_count') result(rc)
+       import; integer(c_int32_t), value :: nleaf; real(c_double), intent(in) :: x(*), y(*), z(*); integer(c_int32_t), intent(in) :: level(*)
+       real(c_double), value :: lo, hi; integer(c_int32_t), intent(out) :: ncells; integer(c_int) :: rc
+     end function
+     function lart_host_amr_build(nleaf, x, y, z, level, lo, hi, ncells, cx, cy, cz, ch, children, neighbor, ileaf, icell_of_leaf, &
+                                  cell_level, levelmax) bind(C, name='lart_host_amr_build') result(rc)
+       import; integer(c_int32_t), value :: nleaf, ncells; real(c_double), intent(in) :: x(*), y(*), z(*); integer(c_int32_t), intent(in) :: level(*)
+       real(c_double), value :: lo, hi
+       real(c_double), intent(out) :: cx(*), cy(*), cz(*), ch(*)
+       integer(c_int32_t), intent(out) :: children(*), neighbor(*), ileaf(*), icell_of_leaf(*), levelmax
+       type(c_ptr), value :: cell_level
+       integer(c_int) :: rc
+     end function
      function lart_gpu_run(ctx, first_id, stride, count, seed) bind(C, name='lart_gpu_run') result(rc)
        import; type(c_ptr), value :: ctx; integer(c_int64_t), value :: first_id, stride, count, seed; integer(c_int) :: rc
      end function

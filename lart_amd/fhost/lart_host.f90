@@ -70,7 +70,11 @@ module lart_define
      real(wp) :: dxim = nan64, dyim = nan64
      integer  :: nside = 0
      !--- outside this path (accepted at default only)
-     logical  :: use_amr_grid = .false., fine_structure = .false., include_deuterium = .false.
+     logical  :: fine_structure = .false., include_deuterium = .false.
+     !--- octree medium (generic text leaf table, read_generic_amr.f90:112-185) and the run-time form of CALCJ / CALCP / CALCPnew
+     logical  :: use_amr_grid = .false., calc_J = .false., calc_P = .false., calc_Pnew = .false.
+     character(len=16) :: amr_type = 'generic'
+     integer  :: geometry_JPa = huge(1)
      !--- clump medium (define.f90:325-352): uniform clump properties, non-overlapping clumps
      logical  :: use_clump_medium = .false., clump_fully_inside = .true., save_clump_info = .false.
      real(wp) :: clump_radius = -1.0_wp, clump_N_clumps = -1.0_wp, clump_f_vol = -1.0_wp, clump_f_cov = -1.0_wp
@@ -121,6 +125,13 @@ module lart_define
   !--- peel-off tallies of all observers: (nxfreq,nxim,nyim,nobs) and (nxim,nyim,nobs)
   real(wp), allocatable, target :: obs_scatt(:,:,:,:), obs_direc(:,:,:,:), obs_I(:,:,:,:), obs_Q(:,:,:,:), obs_U(:,:,:,:), obs_V(:,:,:,:)
   real(wp), allocatable, target :: obs_scatt_2D(:,:,:), obs_direc_2D(:,:,:), obs_I_2D(:,:,:), obs_Q_2D(:,:,:), obs_U_2D(:,:,:), obs_V_2D(:,:,:)
+  !--- octree (amr_grid_type, octree_mod.f90:19-138), filled by grid_create_amr
+  integer(int32) :: amr_ncells = 0, amr_nleaf = 0, amr_levelmax = 0, amr_nbins = 0
+  real(wp) :: amr_lo = 0.0_wp, amr_hi = 0.0_wp, amr_dbin = 0.0_wp
+  real(wp), allocatable, target :: amr_cx(:), amr_cy(:), amr_cz(:), amr_ch(:)
+  integer(int32), allocatable, target :: amr_children(:,:), amr_neighbor(:,:), amr_ileaf(:), amr_icell_of_leaf(:)
+  real(wp), allocatable, target :: amr_rhokap(:), amr_rhokapD(:), amr_Dfreq(:), amr_voigt_a(:), amr_vfx(:), amr_vfy(:), amr_vfz(:)
+  real(wp), allocatable, target :: amr_vol(:), amr_J1(:,:), amr_P1(:), amr_P1_new(:)
   !--- clump population (clump_mod.f90:27-118), filled by grid_create_clump
   integer(int64) :: N_clumps = 0_int64
   real(wp) :: sphere_R = 0.0_wp, r_min_clump = 0.0_wp, cl_radius_max = 0.0_wp
@@ -209,7 +220,13 @@ contains
     par%distance_unit   = strlowcase(par%distance_unit)
     par%spectral_type   = strlowcase(par%spectral_type)
 
-    if (par%use_amr_grid)      call not_supported('par%use_amr_grid = .true.')
+    if (par%use_amr_grid .and. trim(strlowcase(par%amr_type)) /= 'generic') call not_supported('par%amr_type = '//trim(par%amr_type))
+    if (par%use_amr_grid .and. len_trim(par%amr_file) == 0) then
+       write(*,'(a)') 'ERROR: par%use_amr_grid = .true. needs par%amr_file'; stop 1
+    endif
+    if (par%use_amr_grid .and. par%use_clump_medium) call not_supported('use_amr_grid together with use_clump_medium')
+    if ((par%calc_J .or. par%calc_P .or. par%calc_Pnew) .and. .not. par%use_amr_grid) &
+       call not_supported('calc_J / calc_P / calc_Pnew on the Cartesian grid in the Fortran host (use lart_amd.host)')
     if (par%use_clump_medium .and. len_trim(par%clump_input_file) > 0) call not_supported('par%clump_input_file')
     if (par%fine_structure)    call not_supported('par%fine_structure = .true.')
     if (par%include_deuterium) call not_supported('par%include_deuterium = .true.')
@@ -281,7 +298,7 @@ contains
     endif
     select case(trim(par%geometry))                                                             ! :398-428
     case ('sphere')
-       if (.not. par%xy_periodic) then
+       if (.not. par%xy_periodic .and. .not. par%use_amr_grid) then
           r0 = maxval([par%rmax, par%xmax, par%ymax, par%zmax], mask=[par%rmax, par%xmax, par%ymax, par%zmax] > 0.0_wp)
           if (r0 > 0.0_wp) then
              par%rmax = r0; par%xmax = r0; par%ymax = r0; par%zmax = r0
@@ -292,6 +309,14 @@ contains
        par%rmax = -1.0_wp
     end select
     if (par%source_rmax < 0.0_wp) par%source_rmax = par%rmax
+    if (par%rmax <= 0.0_wp) par%geometry_JPa = 3                                                 ! :438-459
+    if (par%geometry_JPa < -1 .or. par%geometry_JPa > 3) then
+       par%geometry_JPa = 1
+       if (par%save_all) par%geometry_JPa = 3
+       if (par%geometry_JPa /= 3 .and. par%xy_periodic) par%geometry_JPa = -1
+    endif
+    if ((par%geometry_JPa == 0 .or. par%geometry_JPa == 2) .and. (par%calc_J .or. par%calc_P .or. par%calc_Pnew)) &
+       call not_supported('par%geometry_JPa = 2 (cylindrical profiles)')
     if (par%distance2cm < 0.0_wp) then                                                          ! :473-489
        select case(trim(par%distance_unit))
        case ('kpc'); par%distance2cm = 3.0856776e18_wp*1e3_wp
@@ -862,6 +887,252 @@ contains
     write(*,'(a,f12.5)')  ' Clump grid: voigt_a   = ', cl_voigt_a_ref
   end subroutine grid_create_clump
 
+  !--- grid_create_amr: grid_mod_amr.f90:34-526 for the generic text leaf table (all hydrogen neutral, no dust model file)
+  subroutine grid_create_amr(grid)
+    type(grid_type), intent(inout) :: grid
+    integer :: unit, ios, n, i, il, ic, nread
+    real(wp) :: boxlen, row(9), vt, opac_length, nopac, tauhomo, tau_raw, NHI, taupole, opac_norm, xc, zc, t, atau0_cell, xi, chi, H0
+    real(wp), allocatable, target :: lx(:), ly(:), lz(:), nH(:), Tl(:), lvx(:), lvy(:), lvz(:)
+    integer(int32), allocatable, target :: lev(:)
+    integer(c_int32_t) :: nc, lm
+    character(len=512) :: line_txt
+    character(len=512) :: q
+
+    !--- read_generic_amr.f90:112-185: "NLEAF n" / "BOXLEN L" or legacy "n L", rows x y z level nH T vx vy vz, '#' comments
+    open(newunit=unit, file=trim(par%amr_file), status='old', action='read', iostat=ios)
+    if (ios /= 0) then
+       write(*,'(2a)') 'generic_amr_read: cannot open file: ', trim(par%amr_file); stop 1
+    endif
+    n = 0; boxlen = -1.0_wp
+    do
+       read(unit,'(a)', iostat=ios) line_txt
+       if (ios /= 0) exit
+       q = adjustl(line_txt)
+       if (len_trim(q) == 0 .or. q(1:1) == '#') cycle
+       if (strlowcase(q(1:6)) == 'boxlen') then
+          read(q(7:), *) boxlen
+       else if (strlowcase(q(1:5)) == 'nleaf') then
+          read(q(6:), *) n
+       else
+          read(q, *, iostat=ios) n, boxlen
+          if (ios /= 0) then
+             write(*,'(a)') 'generic_amr_read: cannot parse text header'; stop 1
+          endif
+       endif
+       if (n > 0 .and. boxlen > 0.0_wp) exit
+    enddo
+    if (n <= 0 .or. boxlen <= 0.0_wp) then
+       write(*,'(a)') 'generic_amr_read: text header must provide NLEAF and BOXLEN'; stop 1
+    endif
+    allocate(lx(n), ly(n), lz(n), lev(n), nH(n), Tl(n), lvx(n), lvy(n), lvz(n))
+    nread = 0
+    do while (nread < n)
+       read(unit,'(a)', iostat=ios) line_txt
+       if (ios /= 0) exit
+       q = adjustl(line_txt)
+       if (len_trim(q) == 0 .or. q(1:1) == '#') cycle
+       read(q, *, iostat=ios) row
+       if (ios /= 0) exit
+       nread = nread + 1
+       lx(nread) = row(1); ly(nread) = row(2); lz(nread) = row(3); lev(nread) = int(row(4)); nH(nread) = row(5); Tl(nread) = row(6)
+       lvx(nread) = row(7); lvy(nread) = row(8); lvz(nread) = row(9)
+    enddo
+    close(unit)
+    if (nread /= n) then
+       write(*,'(a,i0,a,i0)') 'generic_amr_read: expected ', n, ' rows, got ', nread; stop 1
+    endif
+
+    !--- tree + neighbour tables (octree_mod.f90:460-569, 619-682) by the host helper; text files: box centred on the origin (:179-181)
+    amr_nleaf = n; amr_lo = -0.5_wp*boxlen; amr_hi = 0.5_wp*boxlen
+    call amr_check(lart_host_amr_count(amr_nleaf, lx, ly, lz, lev, amr_lo, amr_hi, nc), 'lart_host_amr_count')
+    amr_ncells = nc
+    allocate(amr_cx(nc), amr_cy(nc), amr_cz(nc), amr_ch(nc), amr_children(8,nc), amr_neighbor(6,nc), amr_ileaf(nc), amr_icell_of_leaf(n))
+    call amr_check(lart_host_amr_build(amr_nleaf, lx, ly, lz, lev, amr_lo, amr_hi, nc, amr_cx, amr_cy, amr_cz, amr_ch, &
+         amr_children, amr_neighbor, amr_ileaf, amr_icell_of_leaf, c_null_ptr, lm), 'lart_host_amr_build')
+    amr_levelmax = lm
+    write(*,'(a,i0)')     'AMR nleaf    : ', amr_nleaf
+    write(*,'(a,es12.4,a)') 'AMR boxlen   : ', boxlen, ' (code units)'
+
+    !--- geometry (:186-199)
+    if (trim(par%geometry) == 'sphere') then
+       par%rmax = boxlen*0.5_wp; par%xmax = par%rmax; par%ymax = par%rmax; par%zmax = par%rmax
+    else
+       par%rmax = -1.0_wp; par%xmax = amr_hi; par%ymax = amr_hi; par%zmax = amr_hi
+    endif
+    if (par%source_rmax < 0.0_wp) par%source_rmax = par%rmax
+
+    !--- leaf physics (:230-330): T floor 10 K, all H neutral
+    grid%Dfreq_ref   = vtherm_total(par%temperature)/(line%wavelength0*um2km)
+    grid%voigt_amean = (line%damping/fourpi)/grid%Dfreq_ref
+    allocate(amr_Dfreq(n), amr_voigt_a(n), amr_rhokap(n), amr_vfx(n), amr_vfy(n), amr_vfz(n))
+    if (par%DGR > 0.0_wp) allocate(amr_rhokapD(n))
+    par%distance_unit = ''; par%distance2cm = merge(par%distance2cm, 1.0_wp, par%distance2cm > 0.0_wp)
+    do il = 1, n
+       vt = line%vtherm1*sqrt(max(Tl(il), 10.0_wp))
+       amr_Dfreq(il)   = vt/(line%wavelength0*um2km)
+       amr_voigt_a(il) = (line%damping/fourpi)/amr_Dfreq(il)
+       amr_rhokap(il)  = nH(il)*line%cross0/amr_Dfreq(il)*par%distance2cm
+       if (par%DGR > 0.0_wp) amr_rhokapD(il) = nH(il)*par%cext_dust*par%DGR*par%distance2cm
+       amr_vfx(il) = lvx(il)/vt; amr_vfy(il) = lvy(il)/vt; amr_vfz(il) = lvz(il)/vt
+    enddo
+
+    !--- homogeneous and +z pole optical depths, normalisation (:352-470)
+    opac_length = boxlen/2.0_wp
+    nopac = real(count(amr_rhokap > 0.0_wp), wp)
+    tauhomo = 0.0_wp
+    do il = 1, n
+       tauhomo = tauhomo + amr_rhokap(il)*voigt0(amr_voigt_a(il))
+    enddo
+    if (nopac > 0.0_wp) then
+       tauhomo = tauhomo/nopac*opac_length
+    else
+       tauhomo = 0.0_wp
+    endif
+    xc = amr_cx(1); zc = amr_cz(1); tau_raw = 0.0_wp; NHI = 0.0_wp
+    do while (zc < amr_hi)
+       il = amr_find_leaf(xc, xc, zc)
+       if (il <= 0) exit
+       ic = amr_icell_of_leaf(il)
+       t  = (amr_cz(ic) + amr_ch(ic) - zc)/1.0_wp
+       tau_raw = tau_raw + amr_rhokap(il)*voigt0(amr_voigt_a(il))*t
+       NHI     = NHI + amr_rhokap(il)*amr_Dfreq(il)/line%cross0*t
+       zc = zc + t
+    enddo
+    taupole = tau_raw
+    if (taupole <= 0.0_wp) taupole = tauhomo
+    opac_norm = 1.0_wp
+    if (par%taumax > 0.0_wp) then
+       if (taupole > 0.0_wp) opac_norm = par%taumax/taupole
+    else if (par%N_gasmax > 0.0_wp .and. NHI > 0.0_wp) then
+       opac_norm = par%N_gasmax/NHI
+    endif
+    amr_rhokap = amr_rhokap*opac_norm
+    if (allocated(amr_rhokapD)) amr_rhokapD = amr_rhokapD*opac_norm
+    tauhomo = 0.0_wp
+    do il = 1, n
+       tauhomo = tauhomo + amr_rhokap(il)*voigt0(amr_voigt_a(il))
+    enddo
+    if (nopac > 0.0_wp) tauhomo = tauhomo/nopac*opac_length
+    if (par%taumax <= 0.0_wp) par%taumax = tauhomo
+    par%N_gasmax = NHI*opac_norm; par%N_gashomo = par%N_gasmax; par%tauhomo = tauhomo
+    write(*,'(a,es12.4)') 'AMR voigt_a      : ', grid%voigt_amean
+    write(*,'(a,es12.4)') 'AMR temperature  : ', par%temperature
+    write(*,'(a,es12.4)') 'AMR N(HI)_pole   : ', par%N_gasmax
+    write(*,'(a,es12.4)') 'AMR tau_pole      : ', par%taumax
+
+    !--- spectral axis and global core-skip threshold (amr_setup_freq_grid :726-800: the Cartesian rules)
+    grid%nx = n; grid%ny = 1; grid%nz = 1
+    grid%xmax = par%xmax; grid%ymax = par%ymax; grid%zmax = par%zmax; grid%xmin = amr_lo; grid%ymin = amr_lo; grid%zmin = amr_lo
+    grid%rmax = par%rmax; grid%rmin = par%rmin; grid%dx = boxlen; grid%dy = boxlen; grid%dz = boxlen
+    call car_setup_freq_grid(grid)
+    allocate(grid%Jout(grid%nxfreq), grid%Jin(grid%nxfreq), grid%Jabs(grid%nxfreq), grid%Jmu(grid%nxfreq, max(par%nmu,1)))
+    grid%Jout = 0.0_wp; grid%Jin = 0.0_wp; grid%Jabs = 0.0_wp; grid%Jmu = 0.0_wp
+    atau0_cell = grid%voigt_amean*par%tauhomo/(boxlen/(2.0_wp*amr_ch(1)))
+    if (atau0_cell > 1.0_wp) then
+       if (atau0_cell <= 60.0_wp) then
+          xi = 0.6_wp; chi = 1.2_wp
+       else
+          xi = 1.4_wp; chi = 0.6_wp
+       endif
+       grid%xcrit = 0.02_wp*exp(xi*(log(atau0_cell))**chi); grid%xcrit2 = grid%xcrit**2
+    endif
+    call create_JPa_amr_mem(grid)
+  end subroutine grid_create_amr
+
+  subroutine amr_check(rc, where)
+    integer(c_int), intent(in) :: rc
+    character(len=*), intent(in) :: where
+    character(kind=c_char), pointer :: msg(:)
+    type(c_ptr) :: p
+    integer :: n
+    if (rc == 0) return
+    p = lart_host_amr_last_error()
+    write(*,'(3a)', advance='no') 'ERROR in ', where, ': '
+    if (c_associated(p)) then
+       call c_f_pointer(p, msg, [512])
+       do n = 1, 512
+          if (msg(n) == c_null_char) exit
+          write(*,'(a)', advance='no') msg(n)
+       enddo
+    endif
+    write(*,*)
+    stop 1
+  end subroutine amr_check
+
+  !--- amr_find_leaf: octree_mod.f90:149-171
+  function amr_find_leaf(x, y, z) result(il)
+    real(wp), intent(in) :: x, y, z
+    integer :: il, ic, io
+    il = 0
+    if (x < amr_lo .or. x > amr_hi .or. y < amr_lo .or. y > amr_hi .or. z < amr_lo .or. z > amr_hi) return
+    ic = 1
+    do
+       if (amr_ileaf(ic) > 0) then
+          il = amr_ileaf(ic); return
+       endif
+       io = 1
+       if (x >= amr_cx(ic)) io = io + 1
+       if (y >= amr_cy(ic)) io = io + 2
+       if (z >= amr_cz(ic)) io = io + 4
+       ic = amr_children(io, ic)
+       if (ic == 0) return
+    enddo
+  end function amr_find_leaf
+
+  !--- create_JPa_amr_mem: grid_mod_amr.f90:543-724 (number of position bins and gas volume per bin by ns^3 sub-sampling)
+  subroutine create_JPa_amr_mem(grid)
+    type(grid_type), intent(in) :: grid
+    integer :: nr, nz, il, ic, ns, i, j, k, ir, iz, iz1, iz2
+    real(wp) :: rmax, hc, vleaf, nadd, dr, dz, wsub, xs, ys, zs, z1, z2, ov
+    if (.not. (par%calc_J .or. par%calc_P .or. par%calc_Pnew)) return
+    rmax = par%rmax
+    if (rmax <= 0.0_wp) rmax = (amr_hi - amr_lo)*0.5_wp
+    nr = min(512, max(1, 2**max(0, amr_levelmax - 1))); nz = min(512, max(1, 2**max(0, amr_levelmax)))
+    dr = rmax/nr; dz = (amr_hi - amr_lo)/nz
+    nadd = 1.0_wp
+    if (par%xyz_symmetry) nadd = 8.0_wp
+    select case (par%geometry_JPa)
+    case (3);     amr_nbins = amr_nleaf; amr_dbin = 0.0_wp
+    case (-1);    amr_nbins = nz;        amr_dbin = dz
+    case default; amr_nbins = nr;        amr_dbin = dr
+    end select
+    allocate(amr_vol(amr_nbins)); amr_vol = 0.0_wp
+    do il = 1, amr_nleaf
+       ic = amr_icell_of_leaf(il); hc = amr_ch(ic); vleaf = (2.0_wp*hc)**3*nadd
+       if (par%geometry_JPa == 3) then
+          amr_vol(il) = vleaf; cycle
+       endif
+       if (.not. (amr_rhokap(il) > 0.0_wp)) cycle
+       if (par%geometry_JPa == -1) then
+          z1 = amr_cz(ic) - hc; z2 = amr_cz(ic) + hc
+          iz1 = max(1, int(floor((z1 - amr_lo)/dz)) + 1); iz2 = min(nz, int(floor((z2 - amr_lo)/dz)) + 1)
+          do iz = iz1, iz2
+             ov = min(z2, amr_lo + iz*dz) - max(z1, amr_lo + (iz-1)*dz)
+             if (ov > 0.0_wp) amr_vol(iz) = amr_vol(iz) + vleaf*ov/(2.0_wp*hc)
+          enddo
+       else
+          ns = max(2, min(8, nint(2.0_wp*hc/dr))); wsub = vleaf/real(ns, wp)**3
+          do k = 1, ns; do j = 1, ns; do i = 1, ns
+             xs = amr_cx(ic) + (2.0_wp*i - ns - 1.0_wp)/ns*hc; ys = amr_cy(ic) + (2.0_wp*j - ns - 1.0_wp)/ns*hc; zs = amr_cz(ic) + (2.0_wp*k - ns - 1.0_wp)/ns*hc
+             ir = int(floor(sqrt(xs*xs + ys*ys + zs*zs)/dr)) + 1
+             if (ir >= 1 .and. ir <= nr) amr_vol(ir) = amr_vol(ir) + wsub
+          enddo; enddo; enddo
+       endif
+    enddo
+    if (par%calc_J) then
+       allocate(amr_J1(grid%nxfreq, amr_nbins)); amr_J1 = 0.0_wp
+    endif
+    if (par%calc_P) then
+       allocate(amr_P1(amr_nbins)); amr_P1 = 0.0_wp
+    endif
+    if (par%calc_Pnew) then
+       allocate(amr_P1_new(amr_nbins)); amr_P1_new = 0.0_wp
+    endif
+    if (par%calc_J)    write(6,'(a,i0)') 'AMR CALCJ enabled, geometry_JPa = ', par%geometry_JPa
+    if (par%calc_P)    write(6,'(a,i0)') 'AMR CALCP enabled, geometry_JPa = ', par%geometry_JPa
+    if (par%calc_Pnew) write(6,'(a,i0)') 'AMR CALCPnew enabled, geometry_JPa = ', par%geometry_JPa
+  end subroutine create_JPa_amr_mem
+
   !--- car_setup_freq_grid: grid_mod_car.f90:1442-1548
   subroutine car_setup_freq_grid(grid)
     type(grid_type), intent(inout) :: grid
@@ -1077,6 +1348,21 @@ contains
        if (par%use_stokes) then
           obs_I = obs_I/scale_factor; obs_Q = obs_Q/scale_factor; obs_U = obs_U/scale_factor; obs_V = obs_V/scale_factor
        endif
+    endif
+    !--- octree profiles: volume-weighted normalisation (output_sum_heal.f90:476-590)
+    if (allocated(amr_vol)) then
+       block
+         integer :: ib
+         real(wp) :: d2
+         d2 = par%distance2cm**2
+         do ib = 1, amr_nbins
+            if (amr_vol(ib) > 0.0_wp) then
+               if (allocated(amr_J1))     amr_J1(:,ib)   = amr_J1(:,ib)/(fourpi*amr_vol(ib)*d2*par%nphotons*intensity_bin_unit)
+               if (allocated(amr_P1))     amr_P1(ib)     = amr_P1(ib)/(amr_vol(ib)*d2*par%nphotons)
+               if (allocated(amr_P1_new)) amr_P1_new(ib) = amr_P1_new(ib)/(amr_vol(ib)*d2*par%nphotons)
+            endif
+         enddo
+       end block
     endif
   end subroutine output_normalize
 end module lart_host

@@ -38,6 +38,8 @@ program LaRT_amd
   call read_input(trim(infile))
   if (par%use_clump_medium) then            ! main.f90:25-27
      call grid_create_clump(grid)
+  else if (par%use_amr_grid) then           ! main.f90:28-30
+     call grid_create_amr(grid)
   else
      call grid_create(grid)
   endif
@@ -56,7 +58,17 @@ program LaRT_amd
   endif
   call fill_params(cpar)
   call lart_check(lart_gpu_create(ctx, cpar, 0_c_int), 'lart_gpu_create')
-  if (par%use_clump_medium) then
+  if (par%use_amr_grid) then
+     if (par%DGR > 0.0_wp) then
+        call lart_check(lart_gpu_set_grid_amr(ctx, amr_ncells, amr_nleaf, amr_lo, amr_hi, amr_cx, amr_cy, amr_cz, amr_ch, amr_children, amr_neighbor, &
+             amr_ileaf, amr_icell_of_leaf, amr_rhokap, amr_voigt_a, amr_Dfreq, amr_vfx, amr_vfy, amr_vfz, c_loc(amr_rhokapD)), 'lart_gpu_set_grid_amr')
+     else
+        call lart_check(lart_gpu_set_grid_amr(ctx, amr_ncells, amr_nleaf, amr_lo, amr_hi, amr_cx, amr_cy, amr_cz, amr_ch, amr_children, amr_neighbor, &
+             amr_ileaf, amr_icell_of_leaf, amr_rhokap, amr_voigt_a, amr_Dfreq, amr_vfx, amr_vfy, amr_vfz, c_null_ptr), 'lart_gpu_set_grid_amr')
+     endif
+     if (amr_nbins > 0) call lart_check(lart_gpu_set_JPa_amr(ctx, merge(1, 0, par%calc_J), merge(1, 0, par%calc_P), merge(1, 0, par%calc_Pnew), &
+          par%geometry_JPa, amr_nbins, amr_dbin, line%cross0), 'lart_gpu_set_JPa_amr')
+  else if (par%use_clump_medium) then
      if (par%DGR > 0.0_wp) then
         call lart_check(lart_gpu_set_clumps(ctx, N_clumps, cl_x, cl_y, cl_z, cl_vx, cl_vy, cl_vz, cl_radius, cl_rhokap, c_loc(cl_rhokapD), &
              cl_voigt_a, cl_Dfreq, sphere_R, cl_Dfreq_ref, cl_voigt_a_ref, cgx, cg_xmin, cg_dx, cg_start, cg_list), 'lart_gpu_set_clumps')
@@ -114,6 +126,9 @@ program LaRT_amd
   if (allocated(obs_I_2D)) then
      t%I_2D = c_loc(obs_I_2D); t%Q_2D = c_loc(obs_Q_2D); t%U_2D = c_loc(obs_U_2D); t%V_2D = c_loc(obs_V_2D)
   endif
+  if (allocated(amr_J1))     t%J1     = c_loc(amr_J1)
+  if (allocated(amr_P1))     t%P1     = c_loc(amr_P1)
+  if (allocated(amr_P1_new)) t%P1_new = c_loc(amr_P1_new)
   call lart_check(lart_gpu_get_tallies(ctx, t), 'lart_gpu_get_tallies')
   par%nscatt_gas = t%nscatt_gas; par%nscatt_dust = t%nscatt_dust
 
@@ -222,12 +237,16 @@ contains
     call fits_key(f, 'ymax',     par%ymax,           'ymax')
     call fits_key(f, 'zmax',     par%zmax,           'zmax')
     call fits_key(f, 'EXTNAME',  'Spectrum',         'Spectrum')
-    call fits_key(f, 'calc_P',   .false.,            'calculated Pa within media?')
-    call fits_key(f, 'calc_Pnew', .false.,           'calculated Pa within media?')
-    call fits_key(f, 'calc_J',   .false.,            'calculated J within media?')
+    call fits_key(f, 'calc_P',   par%calc_P,         'calculated Pa within media?')
+    call fits_key(f, 'calc_Pnew', par%calc_Pnew,     'calculated Pa within media?')
+    call fits_key(f, 'calc_J',   par%calc_J,         'calculated J within media?')
     call fits_end_header(f)
     call fits_write_table_rows(f, cols)
     if (par%save_Jmu) call put_image(f, 'Jmu', [g%nxfreq, par%nmu], g%Jmu)
+    !--- volume-normalised profiles on the octree (write_output_rect.f90:541-650, sections Jx_1D / Pa_1D / Pa_1D_new)
+    if (allocated(amr_J1))     call put_image(f, 'Jx_1D', shape(amr_J1), amr_J1)
+    if (allocated(amr_P1))     call put_image(f, 'Pa_1D', shape(amr_P1), amr_P1)
+    if (allocated(amr_P1_new)) call put_image(f, 'Pa_1D_new', shape(amr_P1_new), amr_P1_new)
     call fits_close(f)
     if (par%save_peeloff .and. par%nobs > 0) then
        call fits_open(f, trim(par%base_name)//'_obs.fits')

@@ -58,6 +58,8 @@ def test_unknown_field_and_unsupported_mode_fail(exe, tmp_path):
     r = run(exe, "&parameters\n par%no_such_thing = 1\n/\n", tmp_path, "--dry-run", name="bad.in")
     assert r.returncode != 0 and "ERROR" in r.stdout
     r = run(exe, "&parameters\n par%use_amr_grid = .true.\n/\n", tmp_path, "--dry-run", name="amr.in")
+    assert r.returncode != 0 and "needs par%amr_file" in r.stdout
+    r = run(exe, "&parameters\n par%fine_structure = .true.\n/\n", tmp_path, "--dry-run", name="fs.in")
     assert r.returncode != 0 and "not supported" in r.stdout
 
 
@@ -166,3 +168,53 @@ def test_clump_end_to_end_matches_python_host(exe, tmp_path):
     assert np.isclose(float(spec[0]["Nsc_tot"]), t["nscatt_tot"], rtol=1e-9)
     obs = read_fits(str(tmp_path / "clump_obs.fits"))
     assert np.allclose(obs["Scattered"][1][..., 0], t["scatt"][..., 0], rtol=1e-6, atol=1e-12 * t["scatt"].max())
+
+
+AMR_IN = """&parameters
+ par%use_amr_grid  = .true.
+ par%amr_type      = 'generic'
+ par%amr_file      = 'sphere_small.dat'
+ par%no_photons    = 3e4
+ par%temperature   = 1.0e4
+ par%taumax        = 1.0e2
+ par%rmax          = 1.0
+ par%nxfreq = 121
+ par%calc_J = .true., par%calc_P = .true., par%calc_Pnew = .true.
+ par%iseed = 3
+/
+"""
+
+
+def write_amr(tmp_path):
+    from lart_amd import amr
+    amr.write_generic_amr(str(tmp_path / "sphere_small.dat"), amr.make_amr_sphere(level_min=2, level_max=5))
+
+
+def test_amr_dry_run_equals_python_host(exe, tmp_path):
+    write_amr(tmp_path)
+    r = run(exe, AMR_IN, tmp_path, "--dry-run", name="amr.in")
+    assert r.returncode == 0, r.stdout + r.stderr
+    from lart_amd import host, amr
+    par = host.read_namelist(str(tmp_path / "amr.in")); par.amr_file = str(tmp_path / "sphere_small.dat")
+    par, line, _ = host.read_input(par)
+    g, sg = amr.grid_create_amr(par, line, par.amr_file)
+    assert re.search(r"AMR nleaf\s+:\s+%d\b" % g.nleaf, r.stdout)
+    m = re.search(r"AMR N\(HI\)_pole\s+:\s+(\S+)", r.stdout); assert abs(float(m.group(1)) / par.N_gasmax - 1) < 1e-4
+    m = re.search(r"xfreq_min, xfreq_max, nxfreq :\s+(\S+)\s+(\S+)\s+(\d+)", r.stdout)
+    assert abs(float(m.group(1)) - sg.xfreq_min) < 1e-3 and abs(float(m.group(2)) - sg.xfreq_max) < 1e-3 and int(m.group(3)) == 121
+
+
+@pytest.mark.gpu
+def test_amr_end_to_end_matches_python_host(exe, tmp_path):
+    write_amr(tmp_path)
+    r = run(exe, AMR_IN, tmp_path, name="amr.in")
+    assert r.returncode == 0, r.stdout + r.stderr
+    hdus = read_fits(str(tmp_path / "amr.fits"))
+    from lart_amd import host
+    par = host.read_namelist(str(tmp_path / "amr.in")); par.amr_file = str(tmp_path / "sphere_small.dat")
+    sim = host.Simulation(par)
+    sim.run_simulation()
+    t = sim.output_normalize()
+    assert np.allclose(hdus["Spectrum"][1]["Jout"], t["Jout"], rtol=1e-9, atol=1e-15)
+    assert np.allclose(hdus["Jx_1D"][1], t["J1"], rtol=1e-8, atol=1e-12 * t["J1"].max())
+    assert np.allclose(hdus["Pa_1D"][1].ravel(), t["P1"], rtol=1e-8) and np.allclose(hdus["Pa_1D_new"][1].ravel(), t["P1_new"], rtol=1e-8)
