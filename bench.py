@@ -41,12 +41,14 @@ def main():
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--cpu-photons", type=int, default=0, help="oracle sample size (0 = auto, ~20 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the tally reduction even with one rank (rehearsal of the N>1 path)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     import torch.distributed as dist
-    if world > 1:
+    use_dist = world > 1 or a.force_dist
+    if use_dist:
         torch.cuda.set_device(local)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
     else:
@@ -65,7 +67,7 @@ def main():
     sim.ctx.begin(nph, first_id=rank + 1, stride=world, seed=WORKLOAD["iseed"])
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -87,7 +89,7 @@ def main():
     cells = t_b["n_cellsteps"] - t_a["n_cellsteps"]
     done = t_b["nphotons_done"] - t_a["nphotons_done"]
     tot = torch.tensor([ev, cells, float(done), dt], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_dist:
         mx = tot.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dt = float(mx[3])
@@ -95,7 +97,7 @@ def main():
 
     # the path's only exchange step: one RCCL sum of the fused tally buffer (output_reduce)
     t_r0 = time.perf_counter()
-    sim.output_reduce(dist if world > 1 else None)
+    sim.output_reduce(dist if use_dist else None, force=a.force_dist)
     torch.cuda.synchronize()
     reduce_ms = (time.perf_counter() - t_r0) * 1e3
     _, ntally = sim.ctx.tally_buffer()
@@ -126,7 +128,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_photons)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -843,9 +843,9 @@ class Simulation:
         self.nphotons_run = n
         return count
 
-    def output_reduce(self, dist=None):
+    def output_reduce(self, dist=None, force=False):
         """sum of the fused tally buffer over ranks (reduce_mem, memory_mod_mpi.f90:366-394) by one RCCL collective"""
-        if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
             return
         import torch
         ptr, n = self.ctx.tally_buffer()
