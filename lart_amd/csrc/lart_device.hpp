@@ -81,7 +81,14 @@ struct DPool {
 };
 
 // J(x) / P_alpha profile tallies (compile-time CALCJ/CALCP/CALCPnew in the reference; run-time switches here)
-struct DJPa { int calc_J, calc_P, calc_Pnew, nbins; const int *ind_bin; double cross0; double *J1, *P1, *P1_new; };
+// profile tallies; P1 / P1_new are accumulated per block in LDS when `lds_bins` > 0 and flushed once at kernel end
+struct DJPa { int calc_J, calc_P, calc_Pnew, nbins; const int *ind_bin; double cross0; double *J1, *P1, *P1_new; int lds_bins; };
+// Copies of the contended tally sections (peel cubes and images, J1, P1, P1_new = the tail [off, off+len) of the fused buffer).
+// Workgroups are dispatched round-robin over the 8 XCDs, each with its own L2: same-address atomics from different XCDs meet
+// at the memory side and serialise there (measured: 70x slow-down of a 64-bin P_alpha profile).  Block b therefore adds into
+// copy b % nrep -- copy 0 is the fused buffer itself, copies 1.. live in `base` -- so one XCD's atomics stay in its own L2;
+// lart_gpu_get_tallies / lart_gpu_tally_buffer fold the copies back (k_fold_copies) before anything is read.
+struct DRep { double *base; long long off, len; int nrep; };
 
 struct DCtl { unsigned long long next_k; unsigned long long n_active; };
 
@@ -96,6 +103,7 @@ struct KArgs {
     DJPa jpa;
     DAmr amr;
     DClumps cl;
+    DRep rep;
     DCtl *ctl;
     long long first_id, stride, count;
     unsigned long long seed;
@@ -116,7 +124,8 @@ static __device__ const double c_voigt_tab[606] = {   // H0(101) | H1(202) | H2(
 #define VT_END 606
 
 struct Lds { const double *vt; const double *xf, *yf, *zf;
-             double dip_p2, dip_qs; };   // Cardano constants of the dipole phase function for par.E1 > 0 (rand_resonance): p, 1/(E1 p^3)
+             double dip_p2, dip_qs;      // Cardano constants of the dipole phase function for par.E1 > 0 (rand_resonance): p, 1/(E1 p^3)
+             double *jp_P, *jp_Pn; };   // per-block LDS copies of P1 / P1_new (nullptr: deposits go to global memory)   // Cardano constants of the dipole phase function for par.E1 > 0 (rand_resonance): p, 1/(E1 p^3)
 
 __device__ inline Lds lds_stage(double *sh, const DGrid &g) {
     for (int i = threadIdx.x; i < VT_END; i += blockDim.x) sh[i] = c_voigt_tab[i];
@@ -124,7 +133,7 @@ __device__ inline Lds lds_stage(double *sh, const DGrid &g) {
     for (int i = threadIdx.x; i < nf; i += blockDim.x) sh[VT_END + i] = g.faces[i];
     __syncthreads();
     Lds l; l.vt = sh; l.xf = sh + VT_END; l.yf = l.xf + (g.nx + 1); l.zf = l.yf + (g.ny + 1);
-    l.dip_p2 = 0.0; l.dip_qs = 0.0;
+    l.dip_p2 = 0.0; l.dip_qs = 0.0; l.jp_P = nullptr; l.jp_Pn = nullptr;
     return l;
 }
 
@@ -655,7 +664,7 @@ __device__ inline int amr_JPa_bin(const DAmr &a, int il, double x0, double y0, d
     return clampi(ib, 1, a.nz_JPa);
 }
 // add_to_J_amr / add_to_Pnew_amr: raytrace_amr.f90:848-912 (bin of the segment midpoint)
-__device__ inline void jpa_segment_amr(const KArgs &A, const Photon &p, int il, const Cell &c, double x0, double y0, double z0, double del, double dtauH) {
+__device__ inline void jpa_segment_amr(const KArgs &A, const Lds &l, const Photon &p, int il, const Cell &c, double x0, double y0, double z0, double del, double dtauH) {
     if (!(c.rhokap > 0.0)) return;
     int ib = amr_JPa_bin(A.amr, il, x0, y0, z0);
     if (ib < 1) return;
@@ -664,7 +673,7 @@ __device__ inline void jpa_segment_amr(const KArgs &A, const Photon &p, int il, 
         int ix = (int)floor((xr - A.par.xfreq_min) / A.par.dxfreq) + 1;
         if (ix >= 1 && ix <= A.par.nxfreq) atomicAdd(&A.jpa.J1[(size_t)(ix - 1) + (size_t)A.par.nxfreq * (ib - 1)], del * p.wgt);
     }
-    if (A.jpa.calc_Pnew) atomicAdd(&A.jpa.P1_new[ib - 1], dtauH * p.wgt / (c.rhokap * c.Dfreq / A.jpa.cross0));
+    if (A.jpa.calc_Pnew) atomicAdd(&(l.jp_Pn ? l.jp_Pn : A.jpa.P1_new)[ib - 1], dtauH * p.wgt / (c.rhokap * c.Dfreq / A.jpa.cross0));
 }
 // raytrace_to_edge_amr (:265-344) / raytrace_to_dist_amr (:559-640)
 __device__ inline double raytrace_to_edge_amr(const KArgs &A, const Lds &l, bool dust, const Photon &p, double xfreq, double kx, double ky, double kz, double dist, unsigned &nsteps) {
@@ -881,7 +890,7 @@ __device__ inline void tally_escape(const lart_params &par, const DTally &T, con
 }
 
 // add_to_J (raytrace_car.f90:3979-4011) + add_to_Pnew (:4015-4045): one path segment of length del in cell `ci`
-__device__ inline void jpa_segment(const KArgs &A, const Photon &p, size_t ci, double rhokap_cell, double Dfreq_cell, double del, double dtauH) {
+__device__ inline void jpa_segment(const KArgs &A, const Lds &l, const Photon &p, size_t ci, double rhokap_cell, double Dfreq_cell, double del, double dtauH) {
     if (!(rhokap_cell > 0.0)) return;
     int ib = A.jpa.ind_bin[ci];
     if (ib < 1) return;
@@ -890,7 +899,7 @@ __device__ inline void jpa_segment(const KArgs &A, const Photon &p, size_t ci, d
         int ix = (int)floor((xr - A.par.xfreq_min) / A.par.dxfreq) + 1;
         if (ix > 0 && ix <= A.par.nxfreq) atomicAdd(&A.jpa.J1[(size_t)(ix - 1) + (size_t)A.par.nxfreq * (ib - 1)], del * p.wgt);
     }
-    if (A.jpa.calc_Pnew) atomicAdd(&A.jpa.P1_new[ib - 1], dtauH * p.wgt / (rhokap_cell * Dfreq_cell / A.jpa.cross0));
+    if (A.jpa.calc_Pnew) atomicAdd(&(l.jp_Pn ? l.jp_Pn : A.jpa.P1_new)[ib - 1], dtauH * p.wgt / (rhokap_cell * Dfreq_cell / A.jpa.cross0));
 }
 
 
@@ -910,12 +919,12 @@ __device__ inline void raytrace_to_tau_amr(const KArgs &A, const Lds &l, bool du
         nsteps++;
         if (tau + t_exit * rhokap >= tau_in) {
             double d_step = (rhokap > 0.0) ? (tau_in - tau) / rhokap : t_exit;
-            if (A.jpa.nbins) jpa_segment_amr(A, p, il, *c, x + 0.5 * d_step * kx, y + 0.5 * d_step * ky, z + 0.5 * d_step * kz, d_step, d_step * rhokapH);
+            if (A.jpa.nbins) jpa_segment_amr(A, l, p, il, *c, x + 0.5 * d_step * kx, y + 0.5 * d_step * ky, z + 0.5 * d_step * kz, d_step, d_step * rhokapH);
             x = x + d_step * kx; y = y + d_step * ky; z = z + d_step * kz;
             break;
         }
         tau = tau + t_exit * rhokap; x = x + t_exit * kx; y = y + t_exit * ky; z = z + t_exit * kz;
-        if (A.jpa.nbins) jpa_segment_amr(A, p, il, *c, x - 0.5 * t_exit * kx, y - 0.5 * t_exit * ky, z - 0.5 * t_exit * kz, t_exit, t_exit * rhokapH);
+        if (A.jpa.nbins) jpa_segment_amr(A, l, p, il, *c, x - 0.5 * t_exit * kx, y - 0.5 * t_exit * ky, z - 0.5 * t_exit * kz, t_exit, t_exit * rhokapH);
         int il_new = amr_next_leaf(a, ic, iface, x, y, z); bool reflected = false;
         if (il_new <= 0) il_new = amr_boundary(A.par, il, iface, kx, ky, kz, reflected);
         if (il_new <= 0) { p.inside = false; break; }
@@ -963,14 +972,14 @@ __device__ inline void raytrace_to_tau(const KArgs &A, const Lds &l, bool dust, 
         }
         int io = t.ic, jo = t.jc, ko = t.kc;
         if (!trav_cross<VAR>(g, t, idx)) { p.inside = false; t.ic = io; t.jc = jo; t.kc = ko; break; }
-        if (A.jpa.nbins) jpa_segment(A, p, cidx(g, io, jo, ko), rk, Dold, del, del * (rk * vH));      // add_to_J / add_to_Pnew :1579-1584
+        if (A.jpa.nbins) jpa_segment(A, l, p, cidx(g, io, jo, ko), rk, Dold, del, del * (rk * vH));      // add_to_J / add_to_Pnew :1579-1584
         c = &g.cell[cidx(g, t.ic, t.jc, t.kc)];
         vx = c->vfx; vy = c->vfy; vz = c->vfz;
         double Dn = c->Dfreq, u2 = vx * t.kx + vy * t.ky + vz * t.kz;
         p.xfreq = (p.xfreq + u1) * Dold / Dn - u2;
         Dold = Dn; u1 = u2; rk = c->rhokap; va = c->voigt_a; rD = c->rhokapD;
     }
-    if (A.jpa.nbins) jpa_segment(A, p, cidx(g, t.ic, t.jc, t.kc), rk, Dold, del, del * (rk * vH));          // last segment :1604-1609
+    if (A.jpa.nbins) jpa_segment(A, l, p, cidx(g, t.ic, t.jc, t.kc), rk, Dold, del, del * (rk * vH));          // last segment :1604-1609
     if (!p.inside) {                                          // :1613-1623 fluid frame -> lab frame, escape tally
         // (for VAR 1 the mirrored direction components of the last flight segment are used, :1918)
         u1 = vx * t.kx + vy * t.ky + vz * t.kz;
@@ -1304,7 +1313,7 @@ __device__ inline bool scatter_pre(const KArgs &A, const Lds &l, Rng &g, Photon 
     p.nsg = p.nsg + p.wgt;
     if (A.jpa.calc_P && c.rhokap > 0.0) {                      // add_to_Pa: scattering_car.f90:830-859
         int ib = (VAR == 3) ? amr_JPa_bin(A.amr, p.ic, p.x, p.y, p.z) : A.jpa.ind_bin[cidx(A.g, p.ic, p.jc, p.kc)];   // add_to_Pa_amr: scattering_amr.f90:917-942
-        if (ib >= 1) atomicAdd(&A.jpa.P1[ib - 1], p.wgt / (c.rhokap * c.Dfreq / A.jpa.cross0));
+        if (ib >= 1) atomicAdd(&(l.jp_P ? l.jp_P : A.jpa.P1)[ib - 1], p.wgt / (c.rhokap * c.Dfreq / A.jpa.cross0));
     }
     sc.va = va; sc.cl_scale = cl_scale; sc.cl_Dfreq = cl_Dfreq; sc.xloc = (VAR == 4) ? p.xfreq * cl_scale : p.xfreq;
     return true;

@@ -35,6 +35,7 @@ struct lart_gpu {
     bool is_clump = false; DClumps cl{}; ClumpGeo *d_cl_geo = nullptr; ClumpPhys *d_cl_phys = nullptr; int *d_cl_int = nullptr;
     // fused tally buffer
     double *d_tally = nullptr; int64_t ntally = 0; DTally t{};
+    DRep rep{}; bool rep_dirty = false;                      // per-XCD copies of the contended tally sections
     // pool
     DPool pool{}; void *d_pool = nullptr; int64_t want_lanes = 0; int block = 256;
     DCtl *d_ctl = nullptr;
@@ -63,7 +64,10 @@ extern "C" int lart_gpu_create(lart_gpu **out, const lart_params *par, int devic
     return 0;
 }
 
-static void free_tally(lart_gpu *c) { if (c->d_tally) { (void)hipFree(c->d_tally); c->d_tally = nullptr; } }
+static void free_tally(lart_gpu *c) {
+    if (c->d_tally) { (void)hipFree(c->d_tally); c->d_tally = nullptr; }
+    if (c->rep.base) { (void)hipFree(c->rep.base); } c->rep = DRep{}; c->rep_dirty = false;
+}
 
 extern "C" int lart_gpu_destroy(lart_gpu *c) {
     if (!c) return 0;
@@ -87,11 +91,15 @@ static int build_tally(lart_gpu *c) {
     bool peel = p.save_peeloff && c->nobs > 0;
     int64_t off = 32;                                       // scalars 0..6; 8..31 are section clocks / trip counts of -DLART_PROFILE builds
     int64_t oJout = off; off += nxf; int64_t oJin = off; off += nxf; int64_t oJabs = off; off += nxf; int64_t oJmu = off; off += nxf * nmu;
+    const int64_t off_rep = off;                            // everything from here on is contended: gets per-XCD copies
     int64_t o3[6], o2[6];
     for (int k = 0; k < 6; k++) { bool on = peel && p.save_peeloff_3D && (k < 2 || p.use_stokes); o3[k] = on ? off : -1; if (on) off += n3; }
     for (int k = 0; k < 6; k++) { bool on = peel && p.save_peeloff_2D && (k < 2 || p.use_stokes); o2[k] = on ? off : -1; if (on) off += n2; }
     int64_t oJ1 = -1, oP1 = -1, oPn = -1;
+    c->jpa.lds_bins = 0;
     if (c->jpa.nbins > 0) {
+        // P1 / P1_new: per-block LDS copies while they fit
+        c->jpa.lds_bins = ((c->jpa.calc_P || c->jpa.calc_Pnew) && c->jpa.nbins <= 2048) ? c->jpa.nbins : 0;
         if (c->jpa.calc_J)    { oJ1 = off; off += nxf * c->jpa.nbins; }
         if (c->jpa.calc_P)    { oP1 = off; off += c->jpa.nbins; }
         if (c->jpa.calc_Pnew) { oPn = off; off += c->jpa.nbins; }
@@ -99,6 +107,12 @@ static int build_tally(lart_gpu *c) {
     c->ntally = off;
     HIPCHK(hipMalloc(&c->d_tally, off * sizeof(double)));
     HIPCHK(hipMemset(c->d_tally, 0, off * sizeof(double)));
+    const int64_t len_rep = off - off_rep;
+    if (len_rep > 0 && len_rep * 7 * 8 <= (int64_t)24 << 30) {       // 7 more copies, one per XCD, while they stay under 24 GiB
+        HIPCHK(hipMalloc(&c->rep.base, (size_t)len_rep * 7 * sizeof(double)));
+        HIPCHK(hipMemset(c->rep.base, 0, (size_t)len_rep * 7 * sizeof(double)));
+        c->rep.off = off_rep; c->rep.len = len_rep; c->rep.nrep = 8;
+    }
     c->t.scal = c->d_tally; c->t.Jout = c->d_tally + oJout; c->t.Jin = c->d_tally + oJin; c->t.Jabs = c->d_tally + oJabs; c->t.Jmu = c->d_tally + oJmu;
     for (int k = 0; k < 6; k++) { c->t.c3[k] = o3[k] >= 0 ? c->d_tally + o3[k] : nullptr; c->t.c2[k] = o2[k] >= 0 ? c->d_tally + o2[k] : nullptr; }
     c->jpa.J1 = oJ1 >= 0 ? c->d_tally + oJ1 : nullptr; c->jpa.P1 = oP1 >= 0 ? c->d_tally + oP1 : nullptr; c->jpa.P1_new = oPn >= 0 ? c->d_tally + oPn : nullptr;
@@ -411,14 +425,14 @@ extern "C" int lart_gpu_step(lart_gpu *c, int32_t nsteps, int32_t max_events) {
     HIPCHK(hipSetDevice(c->device));
     KArgs A{};
     A.par = c->par; A.g = c->g; A.t = c->t; A.pool = c->pool; A.mu = c->mu; A.obs = c->d_obs; A.nobs = c->par.save_peeloff ? c->nobs : 0;
-    A.nxim = c->nxim; A.nyim = c->nyim; A.dxim = c->dxim; A.dyim = c->dyim; A.ctl = c->d_ctl; A.heal_nside = c->heal_nside; A.jpa = c->jpa; A.amr = c->amr; A.cl = c->cl;
+    A.nxim = c->nxim; A.nyim = c->nyim; A.dxim = c->dxim; A.dyim = c->dyim; A.ctl = c->d_ctl; A.heal_nside = c->heal_nside; A.jpa = c->jpa; A.amr = c->amr; A.cl = c->cl; A.rep = c->rep;
     A.first_id = c->first_id; A.stride = c->stride; A.count = c->count; A.seed = c->seed; A.max_events = max_events;
     A.log_nscatt = c->d_log; A.log_xfreq = c->d_log ? c->d_log + c->nlog : nullptr;
     int var = c->is_clump ? 4 : c->is_amr ? 3 : (c->par.xyz_symmetry ? 1 : (c->par.xy_periodic ? 2 : 0));     // setup.f90:961-990
     int stokes = c->par.use_stokes ? 1 : 0, dust = c->par.DGR > 0.0 ? 1 : 0, peel = (c->par.save_peeloff && c->nobs > 0) ? 1 : 0;
     dim3 block(c->block), grid((unsigned)(c->pool.n / c->block));
-    // Voigt tables + faces | ring of random draws [LART_RNG_BUF][block]
-    size_t shmem = (size_t)(VT_END + c->g.nx + c->g.ny + c->g.nz + 3 + LART_RNG_BUF * c->block) * sizeof(double);
+    // Voigt tables + faces | ring of random draws [LART_RNG_BUF][block] | per-block P1, P1_new
+    size_t shmem = (size_t)(VT_END + c->g.nx + c->g.ny + c->g.nz + 3 + LART_RNG_BUF * c->block + 2 * c->jpa.lds_bins) * sizeof(double);
     if (shmem > 160 * 1024) return fail("step: grid faces do not fit the 160 KiB LDS");
     for (int s = 0; s < nsteps; s++) {
         hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
@@ -433,6 +447,7 @@ extern "C" int lart_gpu_step(lart_gpu *c, int32_t nsteps, int32_t max_events) {
         HIPCHK(hipEventRecord(e1, c->stream));
         c->ev.emplace_back(e0, e1);
     }
+    if (nsteps > 0 && c->rep.nrep > 1) c->rep_dirty = true;
     return 0;
 }
 
@@ -467,9 +482,31 @@ extern "C" int lart_gpu_run(lart_gpu *c, int64_t first_id, int64_t stride, int64
     return 0;
 }
 
+
+// add the per-XCD copies back into the fused buffer and clear them (DRep)
+__global__ void k_fold_copies(double *dst, double *copies, long long len, int ncopies) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= len) return;
+    double a = 0.0;
+    for (int r = 0; r < ncopies; r++) { double v = copies[(size_t)r * len + i]; if (v != 0.0) { a += v; copies[(size_t)r * len + i] = 0.0; } }
+    if (a != 0.0) dst[i] += a;
+}
+static int fold_copies(lart_gpu *c) {
+    if (c->rep.nrep > 1 && c->rep_dirty && c->d_tally) {
+        unsigned nb = (unsigned)((c->rep.len + 255) / 256);
+        hipLaunchKernelGGL(k_fold_copies, dim3(nb), dim3(256), 0, c->stream, c->d_tally + c->rep.off, c->rep.base, (long long)c->rep.len, c->rep.nrep - 1);
+        HIPCHK(hipGetLastError());
+        c->rep_dirty = false;
+    }
+    return 0;
+}
+
 extern "C" int lart_gpu_tally_buffer(lart_gpu *c, void **p, int64_t *n) {
     if (!c) return fail("tally_buffer: null context");
     if (!c->d_tally) { if (build_tally(c)) return 1; }
+    HIPCHK(hipSetDevice(c->device));
+    if (fold_copies(c)) return 1;                            // the buffer handed out (RCCL reduce) holds the totals
+    HIPCHK(hipStreamSynchronize(c->stream));
     if (p) *p = c->d_tally; if (n) *n = c->ntally;
     return 0;
 }
@@ -478,15 +515,18 @@ extern "C" int lart_gpu_zero_tallies(lart_gpu *c) {
     HIPCHK(hipSetDevice(c->device));
     if (!c->d_tally) { if (build_tally(c)) return 1; }
     HIPCHK(hipMemsetAsync(c->d_tally, 0, c->ntally * 8, c->stream));
+    if (c->rep.base) HIPCHK(hipMemsetAsync(c->rep.base, 0, (size_t)c->rep.len * (c->rep.nrep - 1) * 8, c->stream));
+    c->rep_dirty = false;
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
 }
 extern "C" int lart_gpu_get_tallies(lart_gpu *c, lart_tallies *o) {
     if (!c || !o) return fail("get_tallies: null argument");
     HIPCHK(hipSetDevice(c->device));
+    if (!c->d_tally) { if (build_tally(c)) return 1; }
+    if (fold_copies(c)) return 1;
     HIPCHK(hipStreamSynchronize(c->stream));
     if (collect_events(c)) return 1;
-    if (!c->d_tally) { if (build_tally(c)) return 1; }
     double s[16]; HIPCHK(hipMemcpy(s, c->d_tally, sizeof s, hipMemcpyDeviceToHost));
     o->nscatt_gas = s[0]; o->nscatt_dust = s[1]; o->n_events = s[2]; o->n_cellsteps = s[3]; o->n_cellsteps_peel = s[4]; o->nphotons_done = (int64_t)(s[5] + 0.5);
     DCtl h{}; HIPCHK(hipMemcpy(&h, c->d_ctl, sizeof h, hipMemcpyDeviceToHost)); o->nphotons_active = (int64_t)h.n_active;

@@ -55,7 +55,21 @@ __device__ inline void fly(const KArgs &A, const Lds &l, Rng &g, Photon &p, bool
 template <int VAR, bool STOKES, bool DUST, bool PEEL>
 __global__ __launch_bounds__(256, LART_WAVES(STOKES, PEEL)) void transport_kernel(KArgs A) {
     extern __shared__ double sh[];
+    if (A.rep.nrep > 1) {                                      // this block's copy of the contended tally sections (DRep)
+        const unsigned r = blockIdx.x % (unsigned)A.rep.nrep;
+        if (r) {
+            const ptrdiff_t shift = (A.rep.base + (size_t)(r - 1) * A.rep.len) - (A.t.scal + A.rep.off);
+            for (int q = 0; q < 6; q++) { if (A.t.c3[q]) A.t.c3[q] += shift; if (A.t.c2[q]) A.t.c2[q] += shift; }
+            if (A.jpa.J1) A.jpa.J1 += shift; if (A.jpa.P1) A.jpa.P1 += shift; if (A.jpa.P1_new) A.jpa.P1_new += shift;
+        }
+    }
     Lds l_ = lds_stage(sh, A.g); lds_set_dipole(l_, A.par.E1);
+    if (A.jpa.lds_bins > 0) {                                  // per-block copies of the P1 / P1_new profile tallies
+        double *jp = sh + VT_END + (A.g.nx + A.g.ny + A.g.nz + 3) + (size_t)LART_RNG_BUF * blockDim.x;
+        for (int i = threadIdx.x; i < 2 * A.jpa.lds_bins; i += blockDim.x) jp[i] = 0.0;
+        l_.jp_P = jp; l_.jp_Pn = jp + A.jpa.lds_bins;
+        __syncthreads();
+    }
     const Lds l = l_;
     double *rng_lds = sh + VT_END + (A.g.nx + A.g.ny + A.g.nz + 3) + threadIdx.x;      // [LART_RNG_BUF][blockDim.x] draws
     const lart_params &par = A.par;
@@ -118,6 +132,14 @@ __global__ __launch_bounds__(256, LART_WAVES(STOKES, PEEL)) void transport_kerne
         LART_PROF_MARK(p, 7);
     }
 
+    if (A.jpa.lds_bins > 0) {                                  // flush the block's profile tallies: one atomic per touched bin
+        __syncthreads();
+        for (int i = threadIdx.x; i < A.jpa.lds_bins; i += blockDim.x) {
+            double v = l.jp_P[i], w = l.jp_Pn[i];
+            if (A.jpa.P1 && v != 0.0) atomicAdd(&A.jpa.P1[i], v);
+            if (A.jpa.P1_new && w != 0.0) atomicAdd(&A.jpa.P1_new[i], w);
+        }
+    }
     A.pool.flags[lane] = (alive ? FLAG_ALIVE : 0) | (first ? FLAG_FIRST : 0);
     if (alive) {
         A.pool.k[lane] = k; A.pool.rng_n[lane] = g.n;
