@@ -347,7 +347,8 @@ contains
     else
        par%base_name = base_of(par%out_file)
     endif
-    par%out_file = trim(par%base_name)//'.fits'
+    par%file_format = strlowcase(par%file_format)
+    par%out_file = trim(par%base_name)
 
     write(*,'(a)')        ''
     write(*,'(3a)')       '+++++ ',trim(model_infile),' +++++'

@@ -1,5 +1,5 @@
 !------------------------------------------------------------------------------
-! LaRT_amd.x <input.in> [--dry-run]
+! LaRT_amd.x <input.in> [--dry-run | --dry-run-write]
 ! Same sequence as the reference's main.f90:19-69; run_simulation and output_reduce cross the
 ! C-ABI (include/lart_gpu.h) into the HIP kernels.  --dry-run stops after the grid/observer set-up
 ! (prints the same grid summary the reference prints) so the host logic can be checked without a GPU.
@@ -10,13 +10,14 @@ program LaRT_amd
   use lart_host
   use lart_gpu_c
   use lart_fits
+  use lart_out
   implicit none
   type(grid_type), target :: grid
   type(lart_params) :: cpar
   type(lart_tallies) :: t
   type(c_ptr) :: ctx
   character(len=256) :: infile, arg
-  logical :: dry_run
+  logical :: dry_run, dry_write
   integer :: i, ndev
   integer(int64) :: done, active, t0, t1, rate
   real(wp), allocatable, target :: xyz(:), rmat(:)
@@ -28,10 +29,13 @@ program LaRT_amd
      stop
   endif
   call get_command_argument(1, infile)
-  dry_run = .false.
+  dry_run = .false.; dry_write = .false.
   do i = 2, command_argument_count()
      call get_command_argument(i, arg)
      if (trim(arg) == '--dry-run') dry_run = .true.
+     if (trim(arg) == '--dry-run-write') then       ! set-up + the output files with empty tallies (container check without a GPU)
+        dry_run = .true.; dry_write = .true.
+     endif
   enddo
   call system_clock(t0, rate)
 
@@ -47,6 +51,7 @@ program LaRT_amd
   if (par%save_peeloff) write(*,'(a,i4,a,2i6,a,2es13.5)') 'observers: ', par%nobs, '  image ', par%nxim, par%nyim, '  pixel (deg) ', par%dxim, par%dyim
   write(*,'(a,2f10.3,i6)') 'xfreq_min, xfreq_max, nxfreq : ', grid%xfreq_min, grid%xfreq_max, grid%nxfreq
   if (dry_run) then
+     if (dry_write) call write_output(trim(par%out_file), grid)
      write(*,'(a)') '--dry-run: set-up only, no transport.'
      stop
   endif
@@ -175,15 +180,18 @@ contains
     p%xcrit = grid%xcrit; p%xcrit2 = grid%xcrit2
   end subroutine fill_params
 
-  !--- write_output_outside: `Spectrum` table + keywords (write_output_rect.f90:423-498), Jmu image (:524-539),
-  !--- peel-off HDUs Scattered/Direct/Stokes_* (:1113-1344) in <base>_obs.fits / <base>_stokes.fits
+  !--- write_output_outside: `Spectrum` table + keywords (write_output_rect.f90:423-498), Jmu image (:524-539), profile
+  !--- sections (:541-650), peel-off sections Scattered/Direct/Stokes_* (:1113-1344) in <base>_obs.* / <base>_stokes.*;
+  !--- container by par%file_format: HDF5 <base>.h5 (reference default) or gzip FITS <base>.fits.gz
   subroutine write_output(filename, g)
     character(len=*), intent(in) :: filename
     type(grid_type), intent(in) :: g
-    type(fits_file) :: f
+    type(out_file) :: o
+    type(key_list) :: kl, ki
     character(len=16) :: names(6)
     real(wp), allocatable :: cols(:,:)
-    integer :: ncol
+    integer :: ncol, fmt
+    fmt = out_format_of(trim(strlowcase(par%file_format)))
     ncol = 4; names(1:4) = [character(len=16) :: 'Xfreq', 'velocity', 'wavelength', 'Jout']
     if (par%save_Jabs) then
        ncol = ncol + 1; names(ncol) = 'Jabs'
@@ -200,90 +208,76 @@ contains
     if (par%save_Jin) then
        ncol = ncol + 1; cols(:,ncol) = g%Jin
     endif
-    call fits_open(f, filename)
-    call fits_begin_table(f, g%nxfreq, ncol, names(1:ncol))
-    call fits_key(f, 'ExeTime',  par%exetime,        'Excution Time (min)')
-    call fits_key(f, 'Nprocs',   1,                  'No. of Threads')
-    call fits_key(f, 'recoil',   par%recoil,         'recoil')
-    call fits_key(f, 'coreskip', par%core_skip,      'coreskip algorithm')
-    call fits_key(f, 'xyz_sym',  par%xyz_symmetry,   'xyz_symmetry')
-    call fits_key(f, 'xy_per',   par%xy_periodic,    'xy_periodic')
-    call fits_key(f, 'save_all', par%save_all,       'save all 3D output?')
-    call fits_key(f, 'save_Jin', par%save_Jin,       'save input J?')
-    call fits_key(f, 'save_Jab', par%save_Jabs,      'save absorbed J?')
-    call fits_key(f, 'nphotons', real(par%nphotons, wp), 'number of photons')
-    call fits_key(f, 'taumax',   par%taumax,         'tau_max')
-    call fits_key(f, 'tauhomo',  par%tauhomo,        'tau_homo')
-    call fits_key(f, 'Ngasmax',  par%N_gasmax,       'N(gas)_max cm^-2')
-    call fits_key(f, 'Ngashomo', par%N_gashomo,      'N(gas)_homo cm^-2')
-    call fits_key(f, 'temp',     par%temperature,    'temperature (K)')
-    call fits_key(f, 'Vexp',     par%Vexp,           'Velocity (km/s)')
-    call fits_key(f, 'DGR',      par%DGR,            'Dust-to-Gas Ratio')
-    call fits_key(f, 'atau3',    par%atau3,          '(a*tau_max)^(1/3)')
-    call fits_key(f, 'voigta',   g%voigt_amean,      'voigt_a')
-    call fits_key(f, 'Xfreq1',   g%xfreq_min,        'Xfreq_min')
-    call fits_key(f, 'Xfreq2',   g%xfreq_max,        'Xfreq_max')
-    call fits_key(f, 'Dxfreq',   g%dxfreq,           'Dxfreq')
-    call fits_key(f, 'Dwave',    g%dwave,            'Dwavelength (angstrom)')
-    call fits_key(f, 'I_unit',   par%intensity_unit, 'Intensity Unit (0:no dimension, 1:cm^-2 A^-1)')
-    call fits_key(f, 'Dfreq',    g%Dfreq_ref,        'Doppler Freq. (Hz)')
-    call fits_key(f, 'Nsc_dust', par%nscatt_dust,    'Nscatt_dust/photon')
-    call fits_key(f, 'Nsc_gas',  par%nscatt_gas,     'Nscatt_gas/photon')
-    call fits_key(f, 'Nsc_tot',  par%nscatt_tot,     'Nscatt_tot/photon')
-    call fits_key(f, 'nx',       g%nx,               'No. of x cells')
-    call fits_key(f, 'ny',       g%ny,               'No. of y cells')
-    call fits_key(f, 'nz',       g%nz,               'No. of z cells')
-    call fits_key(f, 'xmax',     par%xmax,           'xmax')
-    call fits_key(f, 'ymax',     par%ymax,           'ymax')
-    call fits_key(f, 'zmax',     par%zmax,           'zmax')
-    call fits_key(f, 'EXTNAME',  'Spectrum',         'Spectrum')
-    call fits_key(f, 'calc_P',   par%calc_P,         'calculated Pa within media?')
-    call fits_key(f, 'calc_Pnew', par%calc_Pnew,     'calculated Pa within media?')
-    call fits_key(f, 'calc_J',   par%calc_J,         'calculated J within media?')
-    call fits_end_header(f)
-    call fits_write_table_rows(f, cols)
-    if (par%save_Jmu) call put_image(f, 'Jmu', [g%nxfreq, par%nmu], g%Jmu)
+    call kadd(kl, 'ExeTime',  par%exetime,        'Excution Time (min)')
+    call kadd(kl, 'Nprocs',   1,                  'No. of Threads')
+    call kadd(kl, 'recoil',   par%recoil,         'recoil')
+    call kadd(kl, 'coreskip', par%core_skip,      'coreskip algorithm')
+    call kadd(kl, 'xyz_sym',  par%xyz_symmetry,   'xyz_symmetry')
+    call kadd(kl, 'xy_per',   par%xy_periodic,    'xy_periodic')
+    call kadd(kl, 'save_all', par%save_all,       'save all 3D output?')
+    call kadd(kl, 'save_Jin', par%save_Jin,       'save input J?')
+    call kadd(kl, 'save_Jab', par%save_Jabs,      'save absorbed J?')
+    call kadd(kl, 'nphotons', real(par%nphotons, wp), 'number of photons')
+    call kadd(kl, 'taumax',   par%taumax,         'tau_max')
+    call kadd(kl, 'tauhomo',  par%tauhomo,        'tau_homo')
+    call kadd(kl, 'Ngasmax',  par%N_gasmax,       'N(gas)_max cm^-2')
+    call kadd(kl, 'Ngashomo', par%N_gashomo,      'N(gas)_homo cm^-2')
+    call kadd(kl, 'temp',     par%temperature,    'temperature (K)')
+    call kadd(kl, 'Vexp',     par%Vexp,           'Velocity (km/s)')
+    call kadd(kl, 'DGR',      par%DGR,            'Dust-to-Gas Ratio')
+    call kadd(kl, 'atau3',    par%atau3,          '(a*tau_max)^(1/3)')
+    call kadd(kl, 'voigta',   g%voigt_amean,      'voigt_a')
+    call kadd(kl, 'Xfreq1',   g%xfreq_min,        'Xfreq_min')
+    call kadd(kl, 'Xfreq2',   g%xfreq_max,        'Xfreq_max')
+    call kadd(kl, 'Dxfreq',   g%dxfreq,           'Dxfreq')
+    call kadd(kl, 'Dwave',    g%dwave,            'Dwavelength (angstrom)')
+    call kadd(kl, 'I_unit',   par%intensity_unit, 'Intensity Unit (0:no dimension, 1:cm^-2 A^-1)')
+    call kadd(kl, 'Dfreq',    g%Dfreq_ref,        'Doppler Freq. (Hz)')
+    call kadd(kl, 'Nsc_dust', par%nscatt_dust,    'Nscatt_dust/photon')
+    call kadd(kl, 'Nsc_gas',  par%nscatt_gas,     'Nscatt_gas/photon')
+    call kadd(kl, 'Nsc_tot',  par%nscatt_tot,     'Nscatt_tot/photon')
+    call kadd(kl, 'nx',       g%nx,               'No. of x cells')
+    call kadd(kl, 'ny',       g%ny,               'No. of y cells')
+    call kadd(kl, 'nz',       g%nz,               'No. of z cells')
+    call kadd(kl, 'xmax',     par%xmax,           'xmax')
+    call kadd(kl, 'ymax',     par%ymax,           'ymax')
+    call kadd(kl, 'zmax',     par%zmax,           'zmax')
+    call kadd(kl, 'calc_P',   par%calc_P,         'calculated Pa within media?')
+    call kadd(kl, 'calc_Pnew', par%calc_Pnew,     'calculated Pa within media?')
+    call kadd(kl, 'calc_J',   par%calc_J,         'calculated J within media?')
+    call kadd(ki, 'nphotons', real(par%nphotons, wp), 'number of photons')
+    call kadd(ki, 'dxim', par%dxim, 'pixel size along x (deg)')
+    call kadd(ki, 'dyim', par%dyim, 'pixel size along y (deg)')
+    call kadd(ki, 'distance', par%distance, 'observer distance')
+
+    call out_open(o, trim(par%base_name), fmt)
+    call out_table(o, 'Spectrum', names(1:ncol), cols, kl)
+    if (par%save_Jmu) call out_image(o, 'Jmu', [g%nxfreq, par%nmu], g%Jmu, ki)
     !--- volume-normalised profiles on the octree (write_output_rect.f90:541-650, sections Jx_1D / Pa_1D / Pa_1D_new)
-    if (allocated(amr_J1))     call put_image(f, 'Jx_1D', shape(amr_J1), amr_J1)
-    if (allocated(amr_P1))     call put_image(f, 'Pa_1D', shape(amr_P1), amr_P1)
-    if (allocated(amr_P1_new)) call put_image(f, 'Pa_1D_new', shape(amr_P1_new), amr_P1_new)
-    call fits_close(f)
+    if (allocated(amr_J1))     call out_image(o, 'Jx_1D', shape(amr_J1), amr_J1, ki)
+    if (allocated(amr_P1))     call out_image(o, 'Pa_1D', shape(amr_P1), amr_P1, ki)
+    if (allocated(amr_P1_new)) call out_image(o, 'Pa_1D_new', shape(amr_P1_new), amr_P1_new, ki)
+    call out_close(o, .true.)
+    write(6,'(2a)') 'output written: ', trim(o%path)
     if (par%save_peeloff .and. par%nobs > 0) then
-       call fits_open(f, trim(par%base_name)//'_obs.fits')
+       call out_open(o, trim(par%base_name)//'_obs', fmt)
        if (allocated(obs_scatt)) then
-          call put_image(f, 'Scattered', shape(obs_scatt), obs_scatt)
-          call put_image(f, 'Direct', shape(obs_direc), obs_direc)
+          call out_image(o, 'Scattered', shape(obs_scatt), obs_scatt, ki)
+          call out_image(o, 'Direct', shape(obs_direc), obs_direc, ki)
        endif
        if (allocated(obs_scatt_2D)) then
-          call put_image(f, 'Scattered_2D', shape(obs_scatt_2D), obs_scatt_2D)
-          call put_image(f, 'Direct_2D', shape(obs_direc_2D), obs_direc_2D)
+          call out_image(o, 'Scattered_2D', shape(obs_scatt_2D), obs_scatt_2D, ki)
+          call out_image(o, 'Direct_2D', shape(obs_direc_2D), obs_direc_2D, ki)
        endif
-       call fits_close(f)
+       call out_close(o, .true.)
        if (par%use_stokes .and. allocated(obs_I)) then
-          call fits_open(f, trim(par%base_name)//'_stokes.fits')
-          call put_image(f, 'Stokes_I', shape(obs_I), obs_I)
-          call put_image(f, 'Stokes_Q', shape(obs_Q), obs_Q)
-          call put_image(f, 'Stokes_U', shape(obs_U), obs_U)
-          call put_image(f, 'Stokes_V', shape(obs_V), obs_V)
-          call fits_close(f)
+          call out_open(o, trim(par%base_name)//'_stokes', fmt)
+          call out_image(o, 'Stokes_I', shape(obs_I), obs_I, ki)
+          call out_image(o, 'Stokes_Q', shape(obs_Q), obs_Q, ki)
+          call out_image(o, 'Stokes_U', shape(obs_U), obs_U, ki)
+          call out_image(o, 'Stokes_V', shape(obs_V), obs_V, ki)
+          call out_close(o, .true.)
        endif
     endif
-    write(6,'(2a)') 'output written: ', filename
   end subroutine write_output
-
-  subroutine put_image(f, extname, naxes, a)
-    type(fits_file), intent(inout) :: f
-    character(len=*), intent(in) :: extname
-    integer, intent(in) :: naxes(:)
-    real(wp), intent(in) :: a(*)
-    call fits_begin_image(f, naxes)
-    call fits_key(f, 'EXTNAME', extname, extname)
-    call fits_key(f, 'nphotons', real(par%nphotons, wp), 'number of photons')
-    call fits_key(f, 'dxim', par%dxim, 'pixel size along x (deg)')
-    call fits_key(f, 'dyim', par%dyim, 'pixel size along y (deg)')
-    call fits_key(f, 'distance', par%distance, 'observer distance')
-    call fits_end_header(f)
-    f%nbytes = product(int(naxes, int64))
-    call fits_write_image(f, a)
-  end subroutine put_image
 end program LaRT_amd

@@ -65,7 +65,8 @@ def test_unknown_field_and_unsupported_mode_fail(exe, tmp_path):
 
 def read_fits(path):
     """tiny reader for the uncompressed FITS the host writes: returns {EXTNAME: (header dict, array or table dict)}"""
-    raw = open(path, "rb").read()
+    import gzip
+    raw = (gzip.open(path, "rb") if path.endswith(".gz") else open(path, "rb")).read()
     pos, hdus = 0, {}
     while pos < len(raw):
         hdr = {}
@@ -93,14 +94,78 @@ def read_fits(path):
     return hdus
 
 
+def read_h5(path):
+    """reader for the host's HDF5 files through the HDF5 C library (no h5py in the image): {group: (attrs, table dict | array)}
+    in creation order; arrays come back in Fortran index order (the file holds the reversed dimensions)"""
+    import ctypes as C
+    lib = None
+    for cand in ("/opt/conda/lib/libhdf5.so", "libhdf5.so"):
+        try:
+            lib = C.CDLL(cand); break
+        except OSError:
+            pass
+    if lib is None:
+        pytest.skip("no HDF5 C library in this image")
+    hid = C.c_int64
+    lib.H5open()
+    NATIVE_DOUBLE = hid.in_dll(lib, "H5T_NATIVE_DOUBLE_g").value; NATIVE_INT = hid.in_dll(lib, "H5T_NATIVE_INT_g").value
+    lib.H5Fopen.restype = hid; lib.H5Fopen.argtypes = [C.c_char_p, C.c_uint, hid]
+    lib.H5Gopen2.restype = hid; lib.H5Gopen2.argtypes = [hid, C.c_char_p, hid]
+    lib.H5Dopen2.restype = hid; lib.H5Dopen2.argtypes = [hid, C.c_char_p, hid]
+    lib.H5Dget_space.restype = hid; lib.H5Dget_space.argtypes = [hid]
+    lib.H5Sget_simple_extent_ndims.argtypes = [hid]; lib.H5Sget_simple_extent_dims.argtypes = [hid, C.c_void_p, C.c_void_p]
+    lib.H5Dread.argtypes = [hid, hid, hid, hid, hid, C.c_void_p]
+    lib.H5Aopen.restype = hid; lib.H5Aopen.argtypes = [hid, C.c_char_p, hid]
+    lib.H5Aget_type.restype = hid; lib.H5Aget_type.argtypes = [hid]; lib.H5Tget_class.argtypes = [hid]; lib.H5Tget_size.restype = C.c_size_t; lib.H5Tget_size.argtypes = [hid]
+    lib.H5Aread.argtypes = [hid, hid, C.c_void_p]
+    lib.H5Literate.argtypes = [hid, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.H5Aiterate2.argtypes = [hid, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    LCB = C.CFUNCTYPE(C.c_int, hid, C.c_char_p, C.c_void_p, C.c_void_p)
+
+    def names_of(loc, attrs=False):
+        out = []
+        cb = LCB(lambda g, name, info, data: out.append(name.decode()) or 0)
+        if attrs:
+            lib.H5Aiterate2(loc, 0, 0, None, cb, None)          # H5_INDEX_NAME, H5_ITER_INC
+        else:
+            lib.H5Literate(loc, 1, 0, None, cb, None)           # H5_INDEX_CRT_ORDER (tracked by the writer), H5_ITER_INC
+        return out
+    f = lib.H5Fopen(path.encode(), 0, 0)
+    assert f >= 0, path
+    res = {}
+    for gname in names_of(f):
+        g = lib.H5Gopen2(f, gname.encode(), 0)
+        attrs = {}
+        for an in names_of(g, attrs=True):
+            a = lib.H5Aopen(g, an.encode(), 0); t = lib.H5Aget_type(a); cls = lib.H5Tget_class(t)
+            if cls == 1:                                         # H5T_FLOAT
+                v = C.c_double(); lib.H5Aread(a, NATIVE_DOUBLE, C.byref(v)); attrs[an] = v.value
+            elif cls == 0:                                       # H5T_INTEGER
+                v = C.c_int(); lib.H5Aread(a, NATIVE_INT, C.byref(v)); attrs[an] = v.value
+            else:
+                buf = C.create_string_buffer(lib.H5Tget_size(t) + 1); lib.H5Aread(a, t, buf); attrs[an] = buf.value.decode().strip()
+            lib.H5Aclose(a)
+        cols = {}
+        for dn in names_of(g):
+            d = lib.H5Dopen2(g, dn.encode(), 0); sp = lib.H5Dget_space(d); nd = lib.H5Sget_simple_extent_ndims(sp)
+            dims = (C.c_uint64 * nd)(); lib.H5Sget_simple_extent_dims(sp, dims, None)
+            arr = np.zeros(tuple(dims), dtype=np.float64); lib.H5Dread(d, NATIVE_DOUBLE, 0, 0, 0, arr.ctypes.data_as(C.c_void_p))
+            cols[dn] = arr.T if nd > 1 else arr                  # back to Fortran index order
+            lib.H5Dclose(d)
+        res[gname] = (attrs, cols["data"] if list(cols) == ["data"] else cols)
+        lib.H5Gclose(g)
+    lib.H5Fclose(f)
+    return res
+
+
 @pytest.mark.gpu
 def test_end_to_end_matches_python_host(exe, tmp_path):
     text = ("&parameters\n par%no_photons = 30000\n par%iseed = 5\n par%temperature = 1e4\n par%taumax = 1e2\n par%nx = 31\n par%ny = 31\n"
-            " par%nz = 31\n par%rmax = 1.0\n par%nxfreq = 81\n par%nxim = 12\n par%nyim = 12\n par%use_stokes = .true.\n par%save_peeloff_2D = .true.\n/\n")
+            " par%nz = 31\n par%rmax = 1.0\n par%nxfreq = 81\n par%nxim = 12\n par%nyim = 12\n par%use_stokes = .true.\n par%save_peeloff_2D = .true.\n par%file_format = 'fits'\n/\n")
     r = run(exe, text, tmp_path, name="e2e.in")
     assert r.returncode == 0, r.stdout + r.stderr
     assert "Average Number of scattering" in r.stdout
-    spec = read_fits(str(tmp_path / "e2e.fits"))["Spectrum"]
+    spec = read_fits(str(tmp_path / "e2e.fits.gz"))["Spectrum"]
     assert list(spec[1].keys()) == ["Xfreq", "velocity", "wavelength", "Jout", "Jin"]
     from lart_amd import host
     sim = host.Simulation(dict(no_photons=30000, iseed=5, temperature=1e4, taumax=1e2, nx=31, ny=31, nz=31, rmax=1.0, nxfreq=81,
@@ -111,9 +176,9 @@ def test_end_to_end_matches_python_host(exe, tmp_path):
     assert np.allclose(spec[1]["Jout"], t["Jout"], rtol=1e-9, atol=1e-15)
     assert np.allclose(spec[1]["Jin"], t["Jin"], rtol=1e-9, atol=1e-15)
     assert np.isclose(float(spec[0]["Nsc_tot"]), t["nscatt_tot"], rtol=1e-9)
-    obs = read_fits(str(tmp_path / "e2e_obs.fits"))
+    obs = read_fits(str(tmp_path / "e2e_obs.fits.gz"))
     assert np.allclose(obs["Scattered"][1][..., 0], t["scatt"][..., 0], rtol=1e-6, atol=1e-12 * t["scatt"].max())
-    stk = read_fits(str(tmp_path / "e2e_stokes.fits"))
+    stk = read_fits(str(tmp_path / "e2e_stokes.fits.gz"))
     assert np.allclose(stk["Stokes_Q"][1][..., 0], t["Q"][..., 0], rtol=1e-6, atol=1e-9 * np.abs(t["I"]).max())
 
 
@@ -136,6 +201,7 @@ CLUMP_IN = """&parameters
  par%nxim = 16, par%nyim = 16
  par%save_peeloff_2D  = .true.
  par%iseed            = 7
+ par%file_format      = 'fits'
 /
 """
 
@@ -159,14 +225,14 @@ def test_clump_dry_run_equals_python_host(exe, tmp_path):
 def test_clump_end_to_end_matches_python_host(exe, tmp_path):
     r = run(exe, CLUMP_IN, tmp_path, name="clump.in")
     assert r.returncode == 0, r.stdout + r.stderr
-    spec = read_fits(str(tmp_path / "clump.fits"))["Spectrum"]
+    spec = read_fits(str(tmp_path / "clump.fits.gz"))["Spectrum"]
     from lart_amd import host
     sim = host.Simulation(str(tmp_path / "clump.in"))
     sim.run_simulation()
     t = sim.output_normalize()
     assert np.allclose(spec[1]["Jout"], t["Jout"], rtol=1e-9, atol=1e-15)           # same clumps, same seed, same photon ids
     assert np.isclose(float(spec[0]["Nsc_tot"]), t["nscatt_tot"], rtol=1e-9)
-    obs = read_fits(str(tmp_path / "clump_obs.fits"))
+    obs = read_fits(str(tmp_path / "clump_obs.fits.gz"))
     assert np.allclose(obs["Scattered"][1][..., 0], t["scatt"][..., 0], rtol=1e-6, atol=1e-12 * t["scatt"].max())
 
 
@@ -209,7 +275,8 @@ def test_amr_end_to_end_matches_python_host(exe, tmp_path):
     write_amr(tmp_path)
     r = run(exe, AMR_IN, tmp_path, name="amr.in")
     assert r.returncode == 0, r.stdout + r.stderr
-    hdus = read_fits(str(tmp_path / "amr.fits"))
+    hdus = read_h5(str(tmp_path / "amr.h5"))           # par%file_format defaults to 'hdf5' like the reference
+    assert list(hdus)[:2] == ["Spectrum", "Jx_1D"] and hdus["Spectrum"][0]["EXTNAME"] == "Spectrum"
     from lart_amd import host
     par = host.read_namelist(str(tmp_path / "amr.in")); par.amr_file = str(tmp_path / "sphere_small.dat")
     sim = host.Simulation(par)
@@ -218,3 +285,26 @@ def test_amr_end_to_end_matches_python_host(exe, tmp_path):
     assert np.allclose(hdus["Spectrum"][1]["Jout"], t["Jout"], rtol=1e-9, atol=1e-15)
     assert np.allclose(hdus["Jx_1D"][1], t["J1"], rtol=1e-8, atol=1e-12 * t["J1"].max())
     assert np.allclose(hdus["Pa_1D"][1].ravel(), t["P1"], rtol=1e-8) and np.allclose(hdus["Pa_1D_new"][1].ravel(), t["P1_new"], rtol=1e-8)
+
+
+def test_output_containers_hdf5_and_gzip_fits(exe, tmp_path):
+    """the same sections, columns and keywords in both containers (reference: hdf5io_mod.f90:8-13, write_output_rect.f90:427-498)"""
+    base = ("&parameters\n par%no_photons = 1000\n par%temperature = 1e4\n par%taumax = 1e2\n par%nx = 11\n par%ny = 11\n par%nz = 11\n"
+            " par%rmax = 1.0\n par%nxfreq = 41\n par%nxim = 8\n par%nyim = 8\n par%use_stokes = .true.\n par%save_Jmu = .true.\n par%nmu = 5\n")
+    r = run(exe, base + " par%file_format = 'fits'\n/\n", tmp_path, "--dry-run-write", name="cf.in")
+    assert r.returncode == 0, r.stdout + r.stderr
+    r = run(exe, base + "/\n", tmp_path, "--dry-run-write", name="ch.in")          # default container: HDF5
+    assert r.returncode == 0, r.stdout + r.stderr
+    F = read_fits(str(tmp_path / "cf.fits.gz")); H = read_h5(str(tmp_path / "ch.h5"))
+    assert list(F) == list(H) == ["Spectrum", "Jmu"]
+    assert list(F["Spectrum"][1]) == list(H["Spectrum"][1]) == ["Xfreq", "velocity", "wavelength", "Jout", "Jin"]
+    assert np.array_equal(F["Spectrum"][1]["Xfreq"], H["Spectrum"][1]["Xfreq"]) and len(H["Spectrum"][1]["Xfreq"]) == 41
+    fk = {k.lower(): v for k, v in F["Spectrum"][0].items()}
+    for k in ("taumax", "voigta", "dfreq", "xfreq1"):
+        assert np.isclose(float(fk[k]), float({kk.lower(): vv for kk, vv in H["Spectrum"][0].items()}[k]), rtol=1e-9), k
+    assert H["Spectrum"][0]["taumax"] == 100.0 and H["Spectrum"][0]["nx"] == 11 and H["Spectrum"][0]["xyz_sym"] == 0
+    assert H["Jmu"][1].shape == (41, 5) and F["Jmu"][1].shape == (41, 5)
+    S = read_h5(str(tmp_path / "ch_stokes.h5")); O = read_h5(str(tmp_path / "ch_obs.h5"))
+    assert list(S) == ["Stokes_I", "Stokes_Q", "Stokes_U", "Stokes_V"] and S["Stokes_Q"][1].shape == (41, 8, 8, 1)
+    assert list(O) == ["Scattered", "Direct"] and O["Direct"][1].shape == (41, 8, 8, 1)
+    assert list(read_fits(str(tmp_path / "cf_obs.fits.gz"))) == ["Scattered", "Direct"]
