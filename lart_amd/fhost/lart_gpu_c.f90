@@ -69,6 +69,14 @@ module lart_gpu_c
        import; type(c_ptr), value :: ctx; integer(c_int32_t), value :: nobs, nxim, nyim
        real(c_double), intent(in) :: xyz(*), rmatrix(*); real(c_double), value :: dxim, dyim; integer(c_int) :: rc
      end function
+     function lart_gpu_set_observers_heal(ctx, nobs, xyz, nside) bind(C, name='lart_gpu_set_observers_heal') result(rc)
+       import; type(c_ptr), value :: ctx; integer(c_int32_t), value :: nobs, nside
+       real(c_double), intent(in) :: xyz(*); integer(c_int) :: rc
+     end function
+     function lart_gpu_set_JPa(ctx, calc_J, calc_P, calc_Pnew, nbins, ind_bin, cross0) bind(C, name='lart_gpu_set_JPa') result(rc)
+       import; type(c_ptr), value :: ctx; integer(c_int32_t), value :: calc_J, calc_P, calc_Pnew, nbins
+       integer(c_int32_t), intent(in) :: ind_bin(*); real(c_double), value :: cross0; integer(c_int) :: rc
+     end function
      function lart_gpu_set_clumps(ctx, n, x, y, z, vx, vy, vz, radius, rhokap, rhokapD, voigt_a, Dfreq, sphere_R, Dfreq_ref, voigt_a_ref, &
                                   cgx, cg_min, cg_d, cg_start, cg_list) bind(C, name='lart_gpu_set_clumps') result(rc)
        import; type(c_ptr), value :: ctx; integer(c_int64_t), value :: n

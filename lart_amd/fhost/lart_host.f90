@@ -68,7 +68,7 @@ module lart_define
      real(wp) :: alpha(MAX_OBSERVERS) = nan64, beta(MAX_OBSERVERS) = nan64, gamma(MAX_OBSERVERS) = nan64
      real(wp) :: obsx(MAX_OBSERVERS) = nan64, obsy(MAX_OBSERVERS) = nan64, obsz(MAX_OBSERVERS) = nan64
      real(wp) :: dxim = nan64, dyim = nan64
-     integer  :: nside = 0
+     integer  :: nside = 0, npix = 0
      !--- outside this path (accepted at default only)
      logical  :: fine_structure = .false., include_deuterium = .false.
      !--- octree medium (generic text leaf table, read_generic_amr.f90:112-185) and the run-time form of CALCJ / CALCP / CALCPnew
@@ -131,7 +131,11 @@ module lart_define
   real(wp), allocatable, target :: amr_cx(:), amr_cy(:), amr_cz(:), amr_ch(:)
   integer(int32), allocatable, target :: amr_children(:,:), amr_neighbor(:,:), amr_ileaf(:), amr_icell_of_leaf(:)
   real(wp), allocatable, target :: amr_rhokap(:), amr_rhokapD(:), amr_Dfreq(:), amr_voigt_a(:), amr_vfx(:), amr_vfy(:), amr_vfz(:)
-  real(wp), allocatable, target :: amr_vol(:), amr_J1(:,:), amr_P1(:), amr_P1_new(:)
+  real(wp), allocatable, target :: amr_vol(:), prof_J1(:,:), prof_P1(:), prof_P1_new(:)
+  !--- Cartesian J(x)/P_alpha profile bins (create_JPa_mem, grid_mod_car.f90:1242-1434): bin of each cell, cells per bin
+  integer(int32) :: car_nbins = 0
+  integer(int32), allocatable, target :: car_ind_bin(:,:,:)
+  real(wp), allocatable :: car_ncount(:)
   !--- clump population (clump_mod.f90:27-118), filled by grid_create_clump
   integer(int64) :: N_clumps = 0_int64
   real(wp) :: sphere_R = 0.0_wp, r_min_clump = 0.0_wp, cl_radius_max = 0.0_wp
@@ -225,8 +229,8 @@ contains
        write(*,'(a)') 'ERROR: par%use_amr_grid = .true. needs par%amr_file'; stop 1
     endif
     if (par%use_amr_grid .and. par%use_clump_medium) call not_supported('use_amr_grid together with use_clump_medium')
-    if ((par%calc_J .or. par%calc_P .or. par%calc_Pnew) .and. .not. par%use_amr_grid) &
-       call not_supported('calc_J / calc_P / calc_Pnew on the Cartesian grid in the Fortran host (use lart_amd.host)')
+    if ((par%calc_J .or. par%calc_P .or. par%calc_Pnew) .and. par%use_clump_medium) &
+       call not_supported('calc_J / calc_P / calc_Pnew with par%use_clump_medium')
     if (par%use_clump_medium .and. len_trim(par%clump_input_file) > 0) call not_supported('par%clump_input_file')
     if (par%fine_structure)    call not_supported('par%fine_structure = .true.')
     if (par%include_deuterium) call not_supported('par%include_deuterium = .true.')
@@ -236,7 +240,6 @@ contains
     if (par%bturb > 0.0_wp) call not_supported('par%bturb')
     if (len_trim(par%dens_file) + len_trim(par%temp_file) + len_trim(par%velo_file) + len_trim(par%emiss_file) + &
         len_trim(par%cart_file) + len_trim(par%input_field) + len_trim(par%star_file) > 0) call not_supported('an input field file')
-    if (par%nside > 0) call not_supported('par%nside > 0 (HEALPix inside observer)')
     if (par%save_all_photons) call not_supported('par%save_all_photons')
 
     select case(trim(par%geometry))
@@ -264,6 +267,13 @@ contains
     endif
     if (par%nx == 1 .or. par%ny == 1 .or. par%nz == 1) par%xyz_symmetry = .false.            ! setup.f90:167
 
+    if (par%nside > 0) then                                                                      ! observer inside the medium: :169-186
+       if (par%use_clump_medium) then
+          write(*,'(a)') 'ERROR: nside>0 (HEALPIX inside observer) is not supported with clump mode'; stop 1
+       endif
+       par%use_stokes = .false.; par%save_peeloff = .true.; par%xyz_symmetry = .false.
+       par%nxim = 0; par%nyim = 0
+    endif
     if (.not.(par%save_peeloff_2D .or. par%save_peeloff_3D)) par%save_peeloff = .false.      ! :188-206
     if (par%nxim > 0 .and. par%nyim > 0)                     par%save_peeloff = .true.
     if (par%save_peeloff .and. par%xyz_symmetry) then
@@ -1121,18 +1131,93 @@ contains
        endif
     enddo
     if (par%calc_J) then
-       allocate(amr_J1(grid%nxfreq, amr_nbins)); amr_J1 = 0.0_wp
+       allocate(prof_J1(grid%nxfreq, amr_nbins)); prof_J1 = 0.0_wp
     endif
     if (par%calc_P) then
-       allocate(amr_P1(amr_nbins)); amr_P1 = 0.0_wp
+       allocate(prof_P1(amr_nbins)); prof_P1 = 0.0_wp
     endif
     if (par%calc_Pnew) then
-       allocate(amr_P1_new(amr_nbins)); amr_P1_new = 0.0_wp
+       allocate(prof_P1_new(amr_nbins)); prof_P1_new = 0.0_wp
     endif
     if (par%calc_J)    write(6,'(a,i0)') 'AMR CALCJ enabled, geometry_JPa = ', par%geometry_JPa
     if (par%calc_P)    write(6,'(a,i0)') 'AMR CALCP enabled, geometry_JPa = ', par%geometry_JPa
     if (par%calc_Pnew) write(6,'(a,i0)') 'AMR CALCPnew enabled, geometry_JPa = ', par%geometry_JPa
   end subroutine create_JPa_amr_mem
+
+  !--- create_JPa_mem: grid_mod_car.f90:1242-1434 (profile bin of every cell + the number of gas cells per bin)
+  subroutine create_JPa_mem(grid)
+    type(grid_type), intent(in) :: grid
+    integer :: nx, ny, nz, nr, i, j, k, ib
+    real(wp) :: rmax, dr, roff, xx, yy, zz, nadd
+    if (.not. (par%calc_J .or. par%calc_P .or. par%calc_Pnew)) return
+    nx = grid%nx; ny = grid%ny; nz = grid%nz
+    allocate(car_ind_bin(nx, ny, nz)); car_ind_bin = 0
+    select case (par%geometry_JPa)
+    case (1)                                              ! spherical shells
+       nr = maxval([nx, ny, nz])
+       if (.not. par%xyz_symmetry) then
+          if (mod(nr, 2) == 0) then
+             nr = nr/2
+          else
+             nr = (nr - 1)/2 + 1
+          endif
+       endif
+       rmax = minval([grid%xmax, grid%ymax, grid%zmax])
+       if (mod(nr, 2) == 0) then
+          dr = rmax/nr; roff = 0.0_wp
+       else
+          dr = rmax/(nr - 0.5_wp); roff = -dr/2.0_wp
+       endif
+       car_nbins = nr
+       allocate(car_ncount(nr)); car_ncount = 0.0_wp
+       do k = 1, nz; do j = 1, ny; do i = 1, nx
+          xx = (grid%xface(i) + grid%xface(i+1))/2.0_wp; yy = (grid%yface(j) + grid%yface(j+1))/2.0_wp; zz = (grid%zface(k) + grid%zface(k+1))/2.0_wp
+          ib = floor((sqrt(xx**2 + yy**2 + zz**2) - roff)/dr) + 1
+          if (ib >= 1 .and. ib <= nr) then
+             car_ind_bin(i,j,k) = ib
+             if (grid%rhokap(i,j,k) > 0.0_wp) car_ncount(ib) = car_ncount(ib) + cell_mult(i, j, k)
+          endif
+       enddo; enddo; enddo
+    case (-1)                                             ! plane-parallel layers
+       car_nbins = nz
+       allocate(car_ncount(nz)); car_ncount = 0.0_wp
+       do k = 1, nz
+          car_ind_bin(:,:,k) = k
+          car_ncount(k) = count(grid%rhokap(:,:,k) > 0.0_wp)
+       enddo
+    case default                                          ! 3: every cell its own bin
+       car_nbins = nx*ny*nz
+       allocate(car_ncount(car_nbins))
+       do k = 1, nz; do j = 1, ny; do i = 1, nx
+          ib = i + nx*((j - 1) + ny*(k - 1))
+          car_ind_bin(i,j,k) = ib
+          nadd = 1.0_wp
+          if (par%xyz_symmetry) nadd = cell_mult(i, j, k)
+          car_ncount(ib) = nadd
+       enddo; enddo; enddo
+    end select
+    if (par%calc_J) then
+       allocate(prof_J1(grid%nxfreq, car_nbins)); prof_J1 = 0.0_wp
+    endif
+    if (par%calc_P) then
+       allocate(prof_P1(car_nbins)); prof_P1 = 0.0_wp
+    endif
+    if (par%calc_Pnew) then
+       allocate(prof_P1_new(car_nbins)); prof_P1_new = 0.0_wp
+    endif
+  contains
+    !--- how many cells of the full box one cell of the +++ octant stands for (cells on a mirror plane are cut in half)
+    function cell_mult(ii, jj, kk) result(m)
+      integer, intent(in) :: ii, jj, kk
+      real(wp) :: m
+      m = 1.0_wp
+      if (.not. par%xyz_symmetry) return
+      m = 8.0_wp
+      if (mod(grid%nx, 2) == 1 .and. ii == 1) m = m/2.0_wp
+      if (mod(grid%ny, 2) == 1 .and. jj == 1) m = m/2.0_wp
+      if (mod(grid%nz, 2) == 1 .and. kk == 1) m = m/2.0_wp
+    end function cell_mult
+  end subroutine create_JPa_mem
 
   !--- car_setup_freq_grid: grid_mod_car.f90:1442-1548
   subroutine car_setup_freq_grid(grid)
@@ -1189,6 +1274,25 @@ contains
     integer :: i, iv, n
     if (.not. par%save_peeloff) then
        par%nobs = 0; return
+    endif
+    if (par%nside > 0) then                               ! observer_create_inside: observer_heal.f90:24-80
+       if (.not. (is_finite(par%obsx(1)) .and. is_finite(par%obsy(1)) .and. is_finite(par%obsz(1)))) then
+          par%obsx(1) = 0.0_wp; par%obsy(1) = 0.0_wp; par%obsz(1) = 0.0_wp
+       endif
+       n = count(is_finite(par%obsx) .and. is_finite(par%obsy) .and. is_finite(par%obsz))
+       par%nobs = n; par%npix = 12*par%nside**2
+       allocate(observer(n))
+       iv = 0
+       do i = 1, size(par%obsx)
+          if (.not. (is_finite(par%obsx(i)) .and. is_finite(par%obsy(i)) .and. is_finite(par%obsz(i)))) cycle
+          iv = iv + 1
+          observer(iv)%x = par%obsx(i); observer(iv)%y = par%obsy(i); observer(iv)%z = par%obsz(i)
+          observer(iv)%rmatrix = 0.0_wp; observer(iv)%dxim = 0.0_wp; observer(iv)%dyim = 0.0_wp
+          observer(iv)%nxim = par%npix; observer(iv)%nyim = 1
+          observer(iv)%steradian_pix = fourpi/par%npix
+       enddo
+       call alloc_peel(par%npix, 1)
+       return
     endif
     maxsz = maxval([par%xmax, par%ymax, par%zmax])
     where (is_finite(par%beta)  .and. .not. is_finite(par%alpha)) par%alpha = 0.0_wp
@@ -1284,21 +1388,25 @@ contains
        observer(i)%dxim = par%dxim; observer(i)%dyim = par%dyim; observer(i)%nxim = par%nxim; observer(i)%nyim = par%nyim
        observer(i)%steradian_pix = par%dxim*par%dyim*(deg2rad**2)
     enddo
-    n = par%nobs                                                                                ! :287-324
-    if (par%save_peeloff_2D) then
-       allocate(obs_scatt_2D(par%nxim,par%nyim,n), obs_direc_2D(par%nxim,par%nyim,n)); obs_scatt_2D = 0; obs_direc_2D = 0
-       if (par%use_stokes) then
-          allocate(obs_I_2D(par%nxim,par%nyim,n), obs_Q_2D(par%nxim,par%nyim,n), obs_U_2D(par%nxim,par%nyim,n), obs_V_2D(par%nxim,par%nyim,n))
-       endif
-    endif
-    if (par%save_peeloff_3D) then
-       allocate(obs_scatt(par%nxfreq,par%nxim,par%nyim,n), obs_direc(par%nxfreq,par%nxim,par%nyim,n)); obs_scatt = 0; obs_direc = 0
-       if (par%use_stokes) then
-          allocate(obs_I(par%nxfreq,par%nxim,par%nyim,n), obs_Q(par%nxfreq,par%nxim,par%nyim,n), &
-                   obs_U(par%nxfreq,par%nxim,par%nyim,n), obs_V(par%nxfreq,par%nxim,par%nyim,n))
-       endif
-    endif
+    call alloc_peel(par%nxim, par%nyim)                                                         ! :287-324
   contains
+    subroutine alloc_peel(nxi, nyi)
+      integer, intent(in) :: nxi, nyi
+      integer :: no
+      no = par%nobs
+      if (par%save_peeloff_2D) then
+         allocate(obs_scatt_2D(nxi,nyi,no), obs_direc_2D(nxi,nyi,no)); obs_scatt_2D = 0; obs_direc_2D = 0
+         if (par%use_stokes) then
+            allocate(obs_I_2D(nxi,nyi,no), obs_Q_2D(nxi,nyi,no), obs_U_2D(nxi,nyi,no), obs_V_2D(nxi,nyi,no))
+         endif
+      endif
+      if (par%save_peeloff_3D) then
+         allocate(obs_scatt(par%nxfreq,nxi,nyi,no), obs_direc(par%nxfreq,nxi,nyi,no)); obs_scatt = 0; obs_direc = 0
+         if (par%use_stokes) then
+            allocate(obs_I(par%nxfreq,nxi,nyi,no), obs_Q(par%nxfreq,nxi,nyi,no), obs_U(par%nxfreq,nxi,nyi,no), obs_V(par%nxfreq,nxi,nyi,no))
+         endif
+      endif
+    end subroutine alloc_peel
     subroutine default_gamma(k)
       integer, intent(in) :: k
       if (.not. is_finite(par%gamma(k))) then
@@ -1350,6 +1458,28 @@ contains
           obs_I = obs_I/scale_factor; obs_Q = obs_Q/scale_factor; obs_U = obs_U/scale_factor; obs_V = obs_V/scale_factor
        endif
     endif
+    !--- Cartesian profiles (output_sum_rect.f90:275-360): per gas cell of the bin, per unit volume
+    if (car_nbins > 0) then
+       block
+         integer :: ib
+         real(wp) :: dVol, f
+         dVol = grid%dx*grid%dy*grid%dz*par%distance2cm**2
+         f = 1.0_wp
+         if (par%xy_periodic .and. (par%geometry_JPa == 3 .or. par%geometry_JPa == -1)) &
+            f = (grid%xmax - grid%xmin)*(grid%ymax - grid%ymin)*par%distance2cm**2
+         do ib = 1, car_nbins
+            if (car_ncount(ib) > 0.0_wp) then
+               if (allocated(prof_J1))     prof_J1(:,ib)   = prof_J1(:,ib)/car_ncount(ib)*(f/(fourpi*dVol*par%nphotons*intensity_bin_unit))
+               if (allocated(prof_P1))     prof_P1(ib)     = prof_P1(ib)/car_ncount(ib)*(f/(dVol*par%nphotons))
+               if (allocated(prof_P1_new)) prof_P1_new(ib) = prof_P1_new(ib)/car_ncount(ib)*(f/(dVol*par%nphotons))
+            else
+               if (allocated(prof_J1))     prof_J1(:,ib)   = 0.0_wp
+               if (allocated(prof_P1))     prof_P1(ib)     = 0.0_wp
+               if (allocated(prof_P1_new)) prof_P1_new(ib) = 0.0_wp
+            endif
+         enddo
+       end block
+    endif
     !--- octree profiles: volume-weighted normalisation (output_sum_heal.f90:476-590)
     if (allocated(amr_vol)) then
        block
@@ -1358,9 +1488,9 @@ contains
          d2 = par%distance2cm**2
          do ib = 1, amr_nbins
             if (amr_vol(ib) > 0.0_wp) then
-               if (allocated(amr_J1))     amr_J1(:,ib)   = amr_J1(:,ib)/(fourpi*amr_vol(ib)*d2*par%nphotons*intensity_bin_unit)
-               if (allocated(amr_P1))     amr_P1(ib)     = amr_P1(ib)/(amr_vol(ib)*d2*par%nphotons)
-               if (allocated(amr_P1_new)) amr_P1_new(ib) = amr_P1_new(ib)/(amr_vol(ib)*d2*par%nphotons)
+               if (allocated(prof_J1))     prof_J1(:,ib)   = prof_J1(:,ib)/(fourpi*amr_vol(ib)*d2*par%nphotons*intensity_bin_unit)
+               if (allocated(prof_P1))     prof_P1(ib)     = prof_P1(ib)/(amr_vol(ib)*d2*par%nphotons)
+               if (allocated(prof_P1_new)) prof_P1_new(ib) = prof_P1_new(ib)/(amr_vol(ib)*d2*par%nphotons)
             endif
          enddo
        end block

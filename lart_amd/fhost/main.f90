@@ -46,8 +46,11 @@ program LaRT_amd
      call grid_create_amr(grid)
   else
      call grid_create(grid)
+     call create_JPa_mem(grid)
+     if (car_nbins > 0) write(*,'(a,i0,a,i0,a,es13.5)') 'profile bins: geometry_JPa = ', par%geometry_JPa, '  nbins = ', car_nbins, '  sum(ncount) = ', sum(car_ncount)
   endif
   call observer_create()
+  if (par%save_peeloff .and. par%nside > 0) write(*,'(a,i0,a,i0)') 'HEALPix inside observers: nside = ', par%nside, '  npix = ', par%npix
   if (par%save_peeloff) write(*,'(a,i4,a,2i6,a,2es13.5)') 'observers: ', par%nobs, '  image ', par%nxim, par%nyim, '  pixel (deg) ', par%dxim, par%dyim
   write(*,'(a,2f10.3,i6)') 'xfreq_min, xfreq_max, nxfreq : ', grid%xfreq_min, grid%xfreq_max, grid%nxfreq
   if (dry_run) then
@@ -90,6 +93,8 @@ program LaRT_amd
           grid%i0, grid%j0, grid%k0, grid%xface, grid%yface, grid%zface, grid%rhokap, grid%voigt_a, grid%Dfreq, &
           grid%vfx, grid%vfy, grid%vfz, c_null_ptr), 'lart_gpu_set_grid_car')
   endif
+  if (car_nbins > 0) call lart_check(lart_gpu_set_JPa(ctx, merge(1, 0, par%calc_J), merge(1, 0, par%calc_P), merge(1, 0, par%calc_Pnew), &
+       car_nbins, car_ind_bin, line%cross0), 'lart_gpu_set_JPa')
   if (scatt_mat%nPDF > 0) call lart_check(lart_gpu_set_mueller(ctx, scatt_mat%nPDF, scatt_mat%coss, scatt_mat%S11, scatt_mat%S12, &
        scatt_mat%S33, scatt_mat%S34, scatt_mat%phase_PDF, scatt_mat%alias), 'lart_gpu_set_mueller')
   if (par%nobs > 0 .and. par%save_peeloff) then
@@ -98,7 +103,11 @@ program LaRT_amd
         xyz(3*i-2:3*i) = [observer(i)%x, observer(i)%y, observer(i)%z]
         rmat(9*i-8:9*i) = [observer(i)%rmatrix(1,:), observer(i)%rmatrix(2,:), observer(i)%rmatrix(3,:)]
      enddo
-     call lart_check(lart_gpu_set_observers(ctx, par%nobs, xyz, rmat, par%dxim, par%dyim, par%nxim, par%nyim), 'lart_gpu_set_observers')
+     if (par%nside > 0) then
+        call lart_check(lart_gpu_set_observers_heal(ctx, par%nobs, xyz, par%nside), 'lart_gpu_set_observers_heal')
+     else
+        call lart_check(lart_gpu_set_observers(ctx, par%nobs, xyz, rmat, par%dxim, par%dyim, par%nxim, par%nyim), 'lart_gpu_set_observers')
+     endif
   endif
 
   !--- run_simulation (main.f90:42): bounded slices so progress can be printed like par%nprint does
@@ -131,9 +140,9 @@ program LaRT_amd
   if (allocated(obs_I_2D)) then
      t%I_2D = c_loc(obs_I_2D); t%Q_2D = c_loc(obs_Q_2D); t%U_2D = c_loc(obs_U_2D); t%V_2D = c_loc(obs_V_2D)
   endif
-  if (allocated(amr_J1))     t%J1     = c_loc(amr_J1)
-  if (allocated(amr_P1))     t%P1     = c_loc(amr_P1)
-  if (allocated(amr_P1_new)) t%P1_new = c_loc(amr_P1_new)
+  if (allocated(prof_J1))     t%J1     = c_loc(prof_J1)
+  if (allocated(prof_P1))     t%P1     = c_loc(prof_P1)
+  if (allocated(prof_P1_new)) t%P1_new = c_loc(prof_P1_new)
   call lart_check(lart_gpu_get_tallies(ctx, t), 'lart_gpu_get_tallies')
   par%nscatt_gas = t%nscatt_gas; par%nscatt_dust = t%nscatt_dust
 
@@ -254,9 +263,9 @@ contains
     call out_table(o, 'Spectrum', names(1:ncol), cols, kl)
     if (par%save_Jmu) call out_image(o, 'Jmu', [g%nxfreq, par%nmu], g%Jmu, ki)
     !--- volume-normalised profiles on the octree (write_output_rect.f90:541-650, sections Jx_1D / Pa_1D / Pa_1D_new)
-    if (allocated(amr_J1))     call out_image(o, 'Jx_1D', shape(amr_J1), amr_J1, ki)
-    if (allocated(amr_P1))     call out_image(o, 'Pa_1D', shape(amr_P1), amr_P1, ki)
-    if (allocated(amr_P1_new)) call out_image(o, 'Pa_1D_new', shape(amr_P1_new), amr_P1_new, ki)
+    if (allocated(prof_J1))     call out_image(o, 'Jx_1D', shape(prof_J1), prof_J1, ki)
+    if (allocated(prof_P1))     call out_image(o, 'Pa_1D', shape(prof_P1), prof_P1, ki)
+    if (allocated(prof_P1_new)) call out_image(o, 'Pa_1D_new', shape(prof_P1_new), prof_P1_new, ki)
     call out_close(o, .true.)
     write(6,'(2a)') 'output written: ', trim(o%path)
     if (par%save_peeloff .and. par%nobs > 0) then

@@ -308,3 +308,69 @@ def test_output_containers_hdf5_and_gzip_fits(exe, tmp_path):
     assert list(S) == ["Stokes_I", "Stokes_Q", "Stokes_U", "Stokes_V"] and S["Stokes_Q"][1].shape == (41, 8, 8, 1)
     assert list(O) == ["Scattered", "Direct"] and O["Direct"][1].shape == (41, 8, 8, 1)
     assert list(read_fits(str(tmp_path / "cf_obs.fits.gz"))) == ["Scattered", "Direct"]
+
+
+JPA_IN = ("&parameters\n par%no_photons = 20000\n par%temperature = 1e4\n par%taumax = 1e3\n par%nx = 21\n par%ny = 21\n par%nz = 21\n"
+          " par%rmax = 1.0\n par%nxfreq = 61\n par%calc_J = .true.\n par%calc_P = .true.\n par%calc_Pnew = .true.\n"
+          " par%geometry_JPa = {geo}\n par%xyz_symmetry = {sym}\n par%iseed = 7\n/\n")
+
+
+@pytest.mark.parametrize("geo,sym", [(1, ".false."), (1, ".true."), (3, ".true."), (-1, ".false.")])
+def test_cartesian_profile_bins_equal_python_host(exe, tmp_path, geo, sym):
+    """create_JPa_mem (grid_mod_car.f90:1242-1434): same bin count and the same number of gas cells behind the bins"""
+    r = run(exe, JPA_IN.format(geo=geo, sym=sym), tmp_path, "--dry-run", name="jpa.in")
+    assert r.returncode == 0, r.stdout + r.stderr
+    from lart_amd import host
+    par = host.read_namelist(str(tmp_path / "jpa.in"))
+    par, line, _ = host.read_input(par)
+    g = host.grid_create(par, line)
+    jp = host.create_JPa_mem(par, g)
+    m = re.search(r"profile bins: geometry_JPa = (-?\d+)\s+nbins = (\d+)\s+sum\(ncount\) =\s+(\S+)", r.stdout)
+    assert m, r.stdout
+    assert int(m.group(1)) == geo and int(m.group(2)) == jp.nbins and abs(float(m.group(3)) / jp.ncount.sum() - 1) < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("geo,sym", [(1, ".true."), (-1, ".false.")])
+def test_cartesian_profiles_end_to_end_match_python_host(exe, tmp_path, geo, sym):
+    r = run(exe, JPA_IN.format(geo=geo, sym=sym), tmp_path, name="jpa.in")
+    assert r.returncode == 0, r.stdout + r.stderr
+    H = read_h5(str(tmp_path / "jpa.h5"))
+    assert list(H) == ["Spectrum", "Jx_1D", "Pa_1D", "Pa_1D_new"]
+    from lart_amd import host
+    sim = host.Simulation(host.read_namelist(str(tmp_path / "jpa.in")))
+    sim.run_simulation()
+    t = sim.output_normalize()
+    assert t["J1"].max() > 0 and t["P1"].max() > 0
+    assert np.allclose(H["Spectrum"][1]["Jout"], t["Jout"], rtol=1e-9, atol=1e-15)
+    assert np.allclose(H["Jx_1D"][1], t["J1"], rtol=1e-8, atol=1e-12 * t["J1"].max())
+    assert np.allclose(H["Pa_1D"][1].ravel(), t["P1"], rtol=1e-8) and np.allclose(H["Pa_1D_new"][1].ravel(), t["P1_new"], rtol=1e-8)
+
+
+HEAL_IN = ("&parameters\n par%no_photons = 5000\n par%temperature = 1e4\n par%taumax = 1e2\n par%nx = 21\n par%ny = 21\n par%nz = 21\n"
+           " par%rmax = 1.0\n par%nxfreq = 41\n par%nside = 4\n par%obsx = 0.0, 0.3\n par%obsy = 0.0, 0.1\n par%obsz = 0.0, -0.2\n"
+           " par%use_stokes = .true.\n par%iseed = 11\n/\n")
+
+
+def test_healpix_inside_observers_dry_run(exe, tmp_path):
+    """observer_create_inside (observer_heal.f90:24-80): nobs from the finite obsx/obsy/obsz triples, npix = 12 nside^2"""
+    r = run(exe, HEAL_IN, tmp_path, "--dry-run-write", name="heal.in")
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert re.search(r"HEALPix inside observers: nside = 4\s+npix = 192", r.stdout) and re.search(r"observers:\s+2\b", r.stdout)
+    O = read_h5(str(tmp_path / "heal_obs.h5"))
+    assert O["Scattered"][1].shape == (41, 192, 1, 2) and O["Direct"][1].shape == (41, 192, 1, 2)
+    assert not os.path.exists(tmp_path / "heal_stokes.h5")               # setup.f90:183: no Stokes vectors for an inside observer
+
+
+@pytest.mark.gpu
+def test_healpix_end_to_end_matches_python_host(exe, tmp_path):
+    r = run(exe, HEAL_IN, tmp_path, name="heal.in")
+    assert r.returncode == 0, r.stdout + r.stderr
+    O = read_h5(str(tmp_path / "heal_obs.h5"))
+    from lart_amd import host
+    sim = host.Simulation(host.read_namelist(str(tmp_path / "heal.in")))
+    sim.run_simulation()
+    t = sim.output_normalize()
+    assert t["scatt"].max() > 0 and t["direc"].max() > 0
+    for sec, k in (("Scattered", "scatt"), ("Direct", "direc")):
+        assert np.allclose(O[sec][1], t[k].reshape(O[sec][1].shape, order="F") if t[k].shape != O[sec][1].shape else t[k], rtol=1e-8, atol=1e-12 * t[k].max()), sec
