@@ -2351,6 +2351,280 @@ void orc_raytrace_to_edge(const orc_sim *s, int variant, const double r[8], cons
 }
 void orc_raytrace_to_dist(const orc_sim *s, const double r[8], const int ic[4], double dist, double *tau) { photon_t p; unpack(r, ic, &p); *tau = raytrace_to_edge(s, &p, s->use_amr_grid ? 3 : 0, dist, 0); }
 
+/* =====================================================================================
+ * Sight-line maps (par%save_sightline_tau): sightline_tau_rect.f90, sightline_tau_heal.f90, sightline_tau_clump.f90
+ * tau_gas(nu) and N(HI) from the far side of the medium towards each observer pixel.  Gas only, and no tau_huge cut
+ * ("sightline tau output must be the full integrated value", raytrace_amr.f90:424-425).
+ * ===================================================================================== */
+/* raytrace_to_edge_car_tau_gas: raytrace_car.f90:1236-1327; dist >= 0: raytrace_to_dist_tau_gas_car :197-297 */
+static double tau_gas_car(const orc_sim *s, const photon_t *p, double dist) {
+    trav_t t; double tau = 0.0, d = 0.0;
+    t.kx = p->kx; t.ky = p->ky; t.kz = p->kz; t.icell = p->icell; t.jcell = p->jcell; t.kcell = p->kcell;
+    if (setup_traversal_car(s, p->x, p->y, p->z, &t)) return tau;
+    int iold = t.icell, jold = t.jcell, kold = t.kcell;
+    double u1 = udot(s, IDX(s,iold,jold,kold), t.kx, t.ky, t.kz), u2, xfreq = p->xfreq;
+    for (;;) {
+        size_t c = IDX(s,t.icell,t.jcell,t.kcell);
+        double rhokap = s->rhokap[c] * orc_voigt(xfreq, s->voigt_a[c]);
+        int idx = minloc3(t.tx, t.ty, t.tz);
+        double *tt = (idx == 1) ? &t.tx : (idx == 2) ? &t.ty : &t.tz;
+        if (dist >= 0.0 && *tt >= dist) { tau = tau + (dist - d) * rhokap; break; }
+        tau = tau + (*tt - d) * rhokap; d = *tt;
+        if (idx == 1)      { t.icell += t.istep; if (t.icell < 1 || t.icell > s->nx) break; t.tx += t.delx; }
+        else if (idx == 2) { t.jcell += t.jstep; if (t.jcell < 1 || t.jcell > s->ny) break; t.ty += t.dely; }
+        else               { t.kcell += t.kstep; if (t.kcell < 1 || t.kcell > s->nz) break; t.tz += t.delz; }
+        size_t cn = IDX(s,t.icell,t.jcell,t.kcell), co = IDX(s,iold,jold,kold);
+        u2 = udot(s, cn, t.kx, t.ky, t.kz);
+        xfreq = (xfreq + u1) * s->Dfreq[co] / s->Dfreq[cn] - u2;
+        iold = t.icell; jold = t.jcell; kold = t.kcell; u1 = u2;
+    }
+    return tau;
+}
+/* raytrace_to_edge_car_column: raytrace_car.f90:1329-1423; dist >= 0: raytrace_to_dist_column_car :299-408 */
+static void column_car(const orc_sim *s, const photon_t *p, double dist, double *N_gas, double *tau_dust) {
+    trav_t t; double d = 0.0; *N_gas = 0.0; *tau_dust = 0.0;
+    t.kx = p->kx; t.ky = p->ky; t.kz = p->kz; t.icell = p->icell; t.jcell = p->jcell; t.kcell = p->kcell;
+    if (setup_traversal_car(s, p->x, p->y, p->z, &t)) return;
+    for (;;) {
+        size_t c = IDX(s,t.icell,t.jcell,t.kcell);
+        double rho = s->rhokap[c] * s->Dfreq[c] / s->cross0, rhokapD = (s->DGR > 0.0) ? s->rhokapD[c] : 0.0, del;
+        int idx = minloc3(t.tx, t.ty, t.tz), last = 0;
+        double *tt = (idx == 1) ? &t.tx : (idx == 2) ? &t.ty : &t.tz;
+        if (dist >= 0.0 && *tt >= dist) { del = dist - d; last = 1; } else del = *tt - d;
+        *N_gas = *N_gas + del * rho;
+        if (s->DGR > 0.0) *tau_dust = *tau_dust + del * rhokapD;
+        if (last) break;
+        d = *tt;
+        if (idx == 1)      { t.icell += t.istep; if (t.icell < 1 || t.icell > s->nx) break; t.tx += t.delx; }
+        else if (idx == 2) { t.jcell += t.jstep; if (t.jcell < 1 || t.jcell > s->ny) break; t.ty += t.dely; }
+        else               { t.kcell += t.kstep; if (t.kcell < 1 || t.kcell > s->nz) break; t.tz += t.delz; }
+    }
+}
+/* raytrace_to_edge_tau_gas_amr: raytrace_amr.f90:395-472; dist >= 0: raytrace_to_dist_tau_gas_amr :650-732.
+ * want_column: raytrace_to_{edge,dist}_column_amr :477-554 / :737-823 on the same walk (the frequency plays no part in it) */
+static double sight_amr(const orc_sim *s, const photon_t *p, double dist, int want_column, double *N_gas, double *tau_dust) {
+    const amr_t *a = &s->amr;
+    double x = p->x, y = p->y, z = p->z, kx = p->kx, ky = p->ky, kz = p->kz, tau = 0.0, d = 0.0, xfreq = p->xfreq;
+    int il = p->icell;
+    if (want_column) { *N_gas = 0.0; *tau_dust = 0.0; }
+    if (il <= 0) { il = amr_find_leaf(a, x, y, z); if (il <= 0) return tau; }
+    double u1 = s->vfx[il-1] * kx + s->vfy[il-1] * ky + s->vfz[il-1] * kz, u2;
+    for (;;) {
+        int ic = a->icell_of_leaf[il-1], iface, last = 0; double t_exit, del;
+        amr_cell_exit(a, ic, x, y, z, kx, ky, kz, &t_exit, &iface);
+        if (dist >= 0.0 && d + t_exit >= dist) { del = dist - d; last = 1; } else del = t_exit;
+        if (want_column) {
+            *N_gas = *N_gas + del * s->rhokap[il-1] * s->Dfreq[il-1] / s->cross0;
+            if (s->DGR > 0.0) *tau_dust = *tau_dust + del * s->rhokapD[il-1];
+        } else tau = tau + del * (s->rhokap[il-1] * orc_voigt(xfreq, s->voigt_a[il-1]));
+        if (last) return tau;
+        d = d + t_exit; x = x + t_exit * kx; y = y + t_exit * ky; z = z + t_exit * kz;
+        int il_new = amr_next_leaf(a, ic, iface, x, y, z), reflected = 0;
+        if (il_new <= 0) il_new = amr_boundary(s, il, iface, &kx, &ky, &kz, &reflected);
+        if (il_new <= 0) return tau;
+        u2 = s->vfx[il_new-1] * kx + s->vfy[il_new-1] * ky + s->vfz[il_new-1] * kz;
+        if (reflected) xfreq = (xfreq + u1) - u2; else xfreq = (xfreq + u1) * s->Dfreq[il-1] / s->Dfreq[il_new-1] - u2;
+        u1 = u2; il = il_new;
+    }
+}
+/* raytrace_to_edge_tau_gas_clump (raytrace_clump.f90:274-285: raytrace_to_edge_clump with clump_gas_only) and
+ * raytrace_to_edge_column_clump (:289-334) on the same walk */
+static double sight_clump(const orc_sim *s, const photon_t *p0, int want_column, double *N_gas, double *tau_dust) {
+    const clumps_t *c = &s->cl;
+    double tau = 0.0, xp = p0->x, yp = p0->y, zp = p0->z, kx = p0->kx, ky = p0->ky, kz = p0->kz, xf = p0->xfreq;
+    int64_t icl_cur = p0->icell_clump, icl_found;
+    if (want_column) { *N_gas = 0.0; *tau_dust = 0.0; }
+    if (icl_cur > 0) {
+        double t_seg = clump_exit_dist(c, xp, yp, zp, kx, ky, kz, icl_cur);
+        if (want_column) {
+            *N_gas = *N_gas + (c->rhokap[icl_cur-1] / s->cross0) * c->Dfreq[icl_cur-1] * t_seg;
+            if (s->DGR > 0.0 && c->rhokapD) *tau_dust = *tau_dust + c->rhokapD[icl_cur-1] * t_seg;
+        } else tau = tau + c->rhokap[icl_cur-1] * voigt_clump(c, xf, icl_cur) * t_seg;
+        xp = xp + t_seg * kx; yp = yp + t_seg * ky; zp = zp + t_seg * kz;
+        xf = xf + ulos_clump(c, icl_cur, kx, ky, kz);
+        if (xp * xp + yp * yp + zp * zp >= c->sphere_R * c->sphere_R) return tau;
+    }
+    for (;;) {
+        double t_sp = sphere_exit_dist(c, xp, yp, zp, kx, ky, kz), te, tx2;
+        if (t_sp <= 0.0) break;
+        if (!find_next_clump(c, xp, yp, zp, kx, ky, kz, icl_cur, t_sp, &te, &tx2, &icl_found, 0)) break;
+        te = fmax(0.0, te);
+        xp = xp + te * kx; yp = yp + te * ky; zp = zp + te * kz;
+        double u_los = ulos_clump(c, icl_found, kx, ky, kz);
+        xf = xf - u_los;
+        double t_seg = clump_exit_dist(c, xp, yp, zp, kx, ky, kz, icl_found);
+        if (want_column) {
+            *N_gas = *N_gas + (c->rhokap[icl_found-1] / s->cross0) * c->Dfreq[icl_found-1] * t_seg;
+            if (s->DGR > 0.0 && c->rhokapD) *tau_dust = *tau_dust + c->rhokapD[icl_found-1] * t_seg;
+        } else tau = tau + c->rhokap[icl_found-1] * voigt_clump(c, xf, icl_found) * t_seg;
+        xp = xp + t_seg * kx; yp = yp + t_seg * ky; zp = zp + t_seg * kz;
+        xf = xf + u_los;
+        icl_cur = icl_found;
+        if (xp * xp + yp * yp + zp * zp >= c->sphere_R * c->sphere_R) break;
+    }
+    return tau;
+}
+/* pix2vec: healpix.f90:114-187 (RING scheme, ipix = 1..npix) */
+void orc_pix2vec(int nside, int ipix, double v[3]) {
+    int nl2 = 2 * nside, nl4 = 4 * nside, npix = 12 * nside * nside, ncap = 2 * nside * (nside - 1), iring, iphi, ip;
+    double fact1 = 1.5 * nside, fact2 = 3.0 * nside * nside, z, phi, hip, fihip, fodd;
+    if (ipix <= ncap) {
+        hip = ipix / 2.0; fihip = trunc(hip);
+        iring = (int)sqrt(fmax(0.0, hip - sqrt(fihip))) + 1;
+        iphi = ipix - 2 * iring * (iring - 1);
+        z = 1.0 - (double)(iring * iring) / fact2;
+        phi = ((double)iphi - 0.5) * PI / (2.0 * iring);
+    } else if (ipix <= nl2 * (5 * nside + 1)) {
+        ip = ipix - ncap - 1;
+        iring = ip / nl4 + nside;
+        iphi = ip % nl4 + 1;
+        fodd = 0.5 * (1 + (iring + nside) % 2);
+        z = (double)(nl2 - iring) / fact1;
+        phi = ((double)iphi - fodd) * PI / (2.0 * nside);
+    } else {
+        ip = npix - ipix + 1;
+        hip = ip / 2.0; fihip = trunc(hip);
+        iring = (int)sqrt(fmax(0.0, hip - sqrt(fihip))) + 1;
+        iphi = 4 * iring + 1 - (ip - 2 * iring * (iring - 1));
+        z = -1.0 + (double)(iring * iring) / fact2;
+        phi = ((double)iphi - 0.5) * PI / (2.0 * iring);
+    }
+    double sth = sqrt((1.0 - z) * (1.0 + z));
+    v[0] = sth * cos(phi); v[1] = sth * sin(phi); v[2] = z;
+}
+
+/* the start of one sight line: position on the far boundary, direction towards the observer, start cell.
+ * Returns 0 when the pixel sees no medium.  *dist = march length (inside observers), -1 = to the edge. */
+static int sight_start(const orc_sim *s, int io, int ix, int iy, photon_t *p, double *dist) {
+    const obs_t *o = &s->obs[io];
+    double delt[6], kx, ky, kz;
+    memset(p, 0, sizeof *p); *dist = -1.0;
+    if (s->nside > 0) { double v[3]; orc_pix2vec(s->nside, ix, v); p->kx = v[0]; p->ky = v[1]; p->kz = v[2]; }
+    else {                                                                                  /* sightline_tau_rect.f90:44-54 */
+        kx = tan((ix - (s->nxim + 1.0) / 2.0) * s->dxim / RAD2DEG); ky = tan((iy - (s->nyim + 1.0) / 2.0) * s->dyim / RAD2DEG); kz = -1.0;
+        double kr = sqrt(kx * kx + ky * ky + kz * kz); kx = kx / kr; ky = ky / kr; kz = kz / kr;
+        const double *m = o->rm;
+        p->kx = m[0] * kx + m[3] * ky + m[6] * kz; p->ky = m[1] * kx + m[4] * ky + m[7] * kz; p->kz = m[2] * kx + m[5] * ky + m[8] * kz;
+    }
+    if (s->use_clump_medium) {                                                              /* sightline_tau_clump.f90:78-116 */
+        if (s->nside > 0) return 0;
+        double R = s->cl.sphere_R, eps = 1.0e-9 * R;
+        double b = o->x * p->kx + o->y * p->ky + o->z * p->kz, c = o->x * o->x + o->y * o->y + o->z * o->z - R * R, disc = b * b - c;
+        if (disc < 0.0) return 0;
+        double t_far = -b + sqrt(disc);
+        if (t_far <= 0.0) return 0;
+        p->x = o->x + p->kx * t_far; p->y = o->y + p->ky * t_far; p->z = o->z + p->kz * t_far;
+        p->kx = -p->kx; p->ky = -p->ky; p->kz = -p->kz;
+        p->x = p->x + eps * p->kx; p->y = p->y + eps * p->ky; p->z = p->z + eps * p->kz;
+        p->icell_clump = 0; p->icell = p->jcell = p->kcell = 1;
+        return 1;
+    }
+    double lo[3], hi[3];
+    if (s->use_amr_grid) { lo[0] = s->amr.xmin; lo[1] = s->amr.ymin; lo[2] = s->amr.zmin; hi[0] = s->amr.xmax; hi[1] = s->amr.ymax; hi[2] = s->amr.zmax; }
+    else { lo[0] = s->xmin; lo[1] = s->ymin; lo[2] = s->zmin; hi[0] = s->xmax; hi[1] = s->ymax; hi[2] = s->zmax; }
+    const double none = (s->nside > 0) ? -999.0 : HUGEST, ob[3] = {o->x, o->y, o->z}, kk[3] = {p->kx, p->ky, p->kz};
+    for (int a = 0; a < 3; a++) {
+        if (kk[a] == 0.0) { delt[2*a] = none; delt[2*a+1] = none; }
+        else { delt[2*a] = (hi[a] - ob[a]) / kk[a]; delt[2*a+1] = (lo[a] - ob[a]) / kk[a]; }
+    }
+    int j0 = 0; double dd;
+    if (s->nside > 0) {                                                                     /* nearest positive face: sightline_tau_heal.f90:70-79 */
+        dd = HUGEST;
+        for (int jj = 1; jj <= 6; jj++) if (delt[jj-1] > 0.0 && delt[jj-1] < HUGEST && delt[jj-1] < dd) { dd = delt[jj-1]; j0 = jj; }
+        if (!(dd > 0.0 && dd < HUGEST)) return 0;
+    } else if (s->use_amr_grid) {                                                           /* farthest face point inside the box: sightline_tau_rect.f90:259-277 */
+        double eps = 1.0e-9 * s->amr.L_box; dd = -999.9;
+        for (int jj = 1; jj <= 6; jj++) if (delt[jj-1] > 0.0 && delt[jj-1] < HUGEST) {
+            double x = o->x + p->kx * delt[jj-1], y = o->y + p->ky * delt[jj-1], z = o->z + p->kz * delt[jj-1];
+            if (x >= lo[0] - eps && x <= hi[0] + eps && y >= lo[1] - eps && y <= hi[1] + eps && z >= lo[2] - eps && z <= hi[2] + eps)
+                if (delt[jj-1] > dd) { dd = delt[jj-1]; j0 = jj; }
+        }
+        if (dd <= 0.0 || dd >= HUGEST || j0 == 0) return 0;
+    } else {                                                                                /* :79-107 */
+        dd = -999.9;
+        for (int jj = 1; jj <= 6; jj++) if (delt[jj-1] > 0.0 && delt[jj-1] < HUGEST) {
+            double x = o->x + p->kx * delt[jj-1], y = o->y + p->ky * delt[jj-1], z = o->z + p->kz * delt[jj-1];
+            int ic = (int)floor((x - s->xmin) / s->dx) + 1, jc = (int)floor((y - s->ymin) / s->dy) + 1, kc = (int)floor((z - s->zmin) / s->dz) + 1;
+            if (jj == 1) ic = s->nx + 1; if (jj == 2) ic = 1; if (jj == 3) jc = s->ny + 1; if (jj == 4) jc = 1; if (jj == 5) kc = s->nz + 1; if (jj == 6) kc = 1;
+            if (ic >= 1 && ic <= s->nx + 1 && jc >= 1 && jc <= s->ny + 1 && kc >= 1 && kc <= s->nz + 1)
+                if (delt[jj-1] > dd) { dd = delt[jj-1]; j0 = jj; }
+        }
+        if (!(dd > 0.0 && dd < HUGEST)) return 0;
+    }
+    p->x = o->x + p->kx * dd; p->y = o->y + p->ky * dd; p->z = o->z + p->kz * dd;
+    if (s->nside > 0) *dist = dd;
+    if (s->use_amr_grid) {
+        if (s->nside > 0) {                                                                 /* sightline_tau_heal.f90:230-251 (the tiny() nudge is below one ulp) */
+            p->kx = -p->kx; p->ky = -p->ky; p->kz = -p->kz;
+            if (j0 == 1) p->x = hi[0]; else if (j0 == 2) p->x = lo[0]; else if (j0 == 3) p->y = hi[1]; else if (j0 == 4) p->y = lo[1]; else if (j0 == 5) p->z = hi[2]; else p->z = lo[2];
+        } else {                                                                            /* sightline_tau_rect.f90:281-297 */
+            double eps = 1.0e-9 * s->amr.L_box;
+            p->x = fmax(lo[0], fmin(hi[0], p->x)); p->y = fmax(lo[1], fmin(hi[1], p->y)); p->z = fmax(lo[2], fmin(hi[2], p->z));
+            p->kx = -p->kx; p->ky = -p->ky; p->kz = -p->kz;
+            p->x = p->x + eps * p->kx; p->y = p->y + eps * p->ky; p->z = p->z + eps * p->kz;
+        }
+        p->icell = amr_find_leaf(&s->amr, p->x, p->y, p->z); p->jcell = p->kcell = 1;
+        return p->icell > 0;
+    }
+    p->icell = (int)floor((p->x - s->xmin) / s->dx) + 1; p->jcell = (int)floor((p->y - s->ymin) / s->dy) + 1; p->kcell = (int)floor((p->z - s->zmin) / s->dz) + 1;
+    p->kx = -p->kx; p->ky = -p->ky; p->kz = -p->kz;                                         /* :117-142 */
+    if (j0 == 1) { p->icell = s->nx + 1; p->x = s->xface[s->nx]; } else if (j0 == 2) { p->icell = 1; p->x = s->xface[0]; }
+    else if (j0 == 3) { p->jcell = s->ny + 1; p->y = s->yface[s->ny]; } else if (j0 == 4) { p->jcell = 1; p->y = s->yface[0]; }
+    else if (j0 == 5) { p->kcell = s->nz + 1; p->z = s->zface[s->nz]; } else { p->kcell = 1; p->z = s->zface[0]; }
+    if (p->icell == s->nx + 1 && p->kx < 0.0) p->icell = s->nx;
+    if (p->jcell == s->ny + 1 && p->ky < 0.0) p->jcell = s->ny;
+    if (p->kcell == s->nz + 1 && p->kz < 0.0) p->kcell = s->nz;
+    /* the reference reads grid%vfx(icell,jcell,kcell) next (:149): a start index of n+1 (a ray through an edge of the box)
+     * would be out of bounds there, so such pixels are left empty here */
+    return p->icell >= 1 && p->icell <= s->nx && p->jcell >= 1 && p->jcell <= s->ny && p->kcell >= 1 && p->kcell <= s->nz;
+}
+
+/* make_sightline_tau_{outside,outside_amr,inside,inside_amr,clump}: tau_gas(nxfreq,nxim,nyim,nobs), N_gas(nxim,nyim,nobs),
+ * tau_dust(nxim,nyim,nobs) (filled when DGR > 0).  HEALPix observers: nxim = npix, nyim = 1. */
+int orc_sightline_tau(const orc_sim *s, double *tau_gas, double *N_gas, double *tau_dust) {
+    if (s->nobs <= 0) { snprintf(g_err, sizeof g_err, "orc_sightline_tau: no observers"); return 1; }
+    const int nxi = s->nside > 0 ? s->npix : s->nxim, nyi = s->nside > 0 ? 1 : s->nyim;
+    const size_t n2 = (size_t)nxi * nyi;
+    memset(tau_gas, 0, sizeof(double) * n2 * s->nxfreq * s->nobs); memset(N_gas, 0, sizeof(double) * n2 * s->nobs);
+    if (tau_dust) memset(tau_dust, 0, sizeof(double) * n2 * s->nobs);
+    for (int io = 0; io < s->nobs; io++) {
+        #pragma omp parallel for schedule(dynamic, 8)
+        for (long q = 0; q < (long)n2; q++) {
+            int ix = (int)(q % nxi) + 1, iy = (int)(q / nxi) + 1;
+            photon_t p; double dist, N, td;
+            if (!sight_start(s, io, ix, iy, &p, &dist)) continue;
+            double u1 = 0.0, Dloc = s->Dfreq_ref;
+            if (!s->use_clump_medium) {
+                size_t c = s->use_amr_grid ? (size_t)(p.icell - 1) : IDX(s, p.icell, p.jcell, p.kcell);
+                u1 = s->vfx[c] * p.kx + s->vfy[c] * p.ky + s->vfz[c] * p.kz; Dloc = s->Dfreq[c];
+            }
+            double *out = tau_gas + ((size_t)io * n2 + q) * s->nxfreq;
+            for (int kf = 1; kf <= s->nxfreq; kf++) {
+                double xf = (kf - 0.5) * s->dxfreq + s->xfreq_min;
+                if (s->use_clump_medium) { p.xfreq = xf; out[kf-1] = sight_clump(s, &p, 0, 0, 0); }
+                else {
+                    p.xfreq = xf * s->Dfreq_ref / Dloc - u1;                                  /* the local cell frame: :153 */
+                    out[kf-1] = s->use_amr_grid ? sight_amr(s, &p, dist, 0, 0, 0) : tau_gas_car(s, &p, dist);
+                }
+            }
+            if (s->use_clump_medium) sight_clump(s, &p, 1, &N, &td);
+            else if (s->use_amr_grid) sight_amr(s, &p, dist, 1, &N, &td);
+            else column_car(s, &p, dist, &N, &td);
+            N_gas[(size_t)io * n2 + q] = N;
+            if (tau_dust && s->DGR > 0.0) tau_dust[(size_t)io * n2 + q] = td;
+        }
+    }
+    return 0;
+}
+void orc_raytrace_tau_gas(const orc_sim *s, const double r[8], const int ic[4], double dist, double *tau) {
+    photon_t p; unpack_s(s, r, ic, &p);
+    *tau = s->use_clump_medium ? sight_clump(s, &p, 0, 0, 0) : s->use_amr_grid ? sight_amr(s, &p, dist, 0, 0, 0) : tau_gas_car(s, &p, dist);
+}
+void orc_raytrace_column(const orc_sim *s, const double r[8], const int ic[4], double dist, double *N_gas, double *tau_dust) {
+    photon_t p; unpack_s(s, r, ic, &p);
+    if (s->use_clump_medium) sight_clump(s, &p, 1, N_gas, tau_dust); else if (s->use_amr_grid) sight_amr(s, &p, dist, 1, N_gas, tau_dust); else column_car(s, &p, dist, N_gas, tau_dust);
+}
+
 int64_t orc_scatter_event(orc_sim *s, double st[18], int ic[4], uint64_t seed, uint64_t id, uint64_t n0) {
     photon_t p; unpack_s(s, st, ic, &p);
     p.mx = st[8]; p.my = st[9]; p.mz = st[10]; p.nx = st[11]; p.ny = st[12]; p.nz = st[13]; p.I = st[14]; p.Q = st[15]; p.U = st[16]; p.V = st[17];

@@ -71,6 +71,13 @@ void   orc_raytrace_to_tau(orc_sim *, int variant, double r[8], int ic[4], doubl
 int orc_amr_find_leaf(const orc_sim *s, double x, double y, double z);
 void   orc_raytrace_to_edge(const orc_sim *, int variant, const double r[8], const int ic[4], double *tau);
 void   orc_raytrace_to_dist(const orc_sim *, const double r[8], const int ic[4], double dist, double *tau);
+/* sight-line maps (make_sightline_tau, sightline_tau_{rect,heal,clump}.f90): tau_gas[nobs][nyim][nxim][nxfreq] in C order
+ * (= Fortran (nxfreq,nxim,nyim) per observer), N_gas[nobs][nyim][nxim], tau_dust likewise (may be NULL).  Needs observers. */
+int    orc_sightline_tau(const orc_sim *, double *tau_gas, double *N_gas, double *tau_dust);
+/* the marches behind it: raytrace_to_{edge,dist}_*_tau_gas / _column (gas only, no tau_huge cut); dist < 0 = to the edge */
+void   orc_raytrace_tau_gas(const orc_sim *, const double r[8], const int ic[4], double dist, double *tau);
+void   orc_raytrace_column(const orc_sim *, const double r[8], const int ic[4], double dist, double *N_gas, double *tau_dust);
+void   orc_pix2vec(int nside, int ipix, double v[3]);                    /* healpix.f90:114-187 */
 int    orc_vec2pix(int nside, double vx, double vy, double vz);          /* healpix.f90:29-112 */
 double orc_xcrit_local(const orc_sim *, int i, int j, int k, double x, double y, double z); /* grid_mod_car.f90:1598-1629 */
 /* one full scattering event from a given photon state (for GPU device-function parity):

@@ -57,6 +57,10 @@ class Oracle:
             L.orc_amr_find_leaf.argtypes = [_vp, _d, _d, _d]
             L.orc_xcrit_local.restype = _d; L.orc_xcrit_local.argtypes = [_vp, _i, _i, _i, _d, _d, _d]
             L.orc_scatter_event.restype = _i64; L.orc_scatter_event.argtypes = [_vp, _vp, _vp, _u64, _u64, _u64]
+            L.orc_sightline_tau.restype = _i; L.orc_sightline_tau.argtypes = [_vp, _vp, _vp, _vp]
+            L.orc_raytrace_tau_gas.argtypes = [_vp, _vp, _vp, _d, _vp]
+            L.orc_raytrace_column.argtypes = [_vp, _vp, _vp, _d, _vp, _vp]
+            L.orc_pix2vec.argtypes = [_i, _i, _vp]
             cls._lib = L
         return cls._lib
 
@@ -136,6 +140,27 @@ class Oracle:
         r = np.array(r, dtype=np.float64); ic = np.array(ic, dtype=np.int32); t = _d()
         self.lib().orc_raytrace_to_dist(self.h, _ptr(r), _ptr(ic), dist, C.byref(t)); return t.value
 
+    def raytrace_tau_gas(self, r, ic, dist=-1.0):
+        r = np.array(r, dtype=np.float64); ic = np.array(ic, dtype=np.int32); t = _d()
+        self.lib().orc_raytrace_tau_gas(self.h, _ptr(r), _ptr(ic), dist, C.byref(t)); return t.value
+
+    def raytrace_column(self, r, ic, dist=-1.0):
+        r = np.array(r, dtype=np.float64); ic = np.array(ic, dtype=np.int32); n = _d(); t = _d()
+        self.lib().orc_raytrace_column(self.h, _ptr(r), _ptr(ic), dist, C.byref(n), C.byref(t)); return n.value, t.value
+
+    def sightline_tau(self):
+        """tau_gas (nxfreq,nxim,nyim,nobs), N_gas (nxim,nyim,nobs), tau_dust (nxim,nyim,nobs) in Fortran order"""
+        ns = int(self.scalar("nside")); nob = int(self.scalar("nobs")); nxf = int(self.scalar("nxfreq"))
+        nxi, nyi = (int(self.scalar("npix")), 1) if ns > 0 else (int(self.scalar("nxim")), int(self.scalar("nyim")))
+        tg = np.zeros((nxf, nxi, nyi, nob), order="F"); ng = np.zeros((nxi, nyi, nob), order="F"); td = np.zeros((nxi, nyi, nob), order="F")
+        if self.lib().orc_sightline_tau(self.h, _ptr(tg), _ptr(ng), _ptr(td)):
+            raise RuntimeError(self.lib().orc_last_error().decode())
+        return tg, ng, td
+
+    @classmethod
+    def pix2vec(cls, nside, ipix):
+        v = np.zeros(3); cls.lib().orc_pix2vec(int(nside), int(ipix), _ptr(v)); return v
+
     def scatter_event(self, st, ic, seed, pid, n0=0):
         st = np.array(st, dtype=np.float64); ic = np.array(ic, dtype=np.int32)
         nd = self.lib().orc_scatter_event(self.h, _ptr(st), _ptr(ic), seed, pid, n0); return st, ic, nd
@@ -203,6 +228,10 @@ class Ref:
             L.ref_raytrace_to_edge.argtypes = [_i, _vp, _vp, _vp]
             L.ref_raytrace_to_dist.argtypes = [_vp, _vp, _d, _vp]
             L.ref_get_Jout.argtypes = [_vp]
+            if hasattr(L, "ref_raytrace_tau_gas"):
+                L.ref_raytrace_tau_gas.argtypes = [_vp, _vp, _d, _vp]
+                L.ref_raytrace_column.argtypes = [_vp, _vp, _d, _vp, _vp]
+                L.ref_pix2vec.argtypes = [_i, _i, _vp]
             L.ref_get_faces.argtypes = [_vp, _vp, _vp]
             v = [_d() for _ in range(5)]
             L.ref_init_line(*[C.byref(t) for t in v])
@@ -252,6 +281,21 @@ class Ref:
     def raytrace_to_dist(cls, r, ic, dist):
         r = np.array(r, dtype=np.float64); ic = np.array(ic, dtype=np.int32); t = _d()
         cls.lib().ref_raytrace_to_dist(_ptr(r), _ptr(ic), dist, C.byref(t)); return t.value
+
+
+    @classmethod
+    def raytrace_tau_gas(cls, r, ic, dist=-1.0):
+        r = np.array(r, dtype=np.float64); ic = np.array(ic, dtype=np.int32); t = _d()
+        cls.lib().ref_raytrace_tau_gas(_ptr(r), _ptr(ic), dist, C.byref(t)); return t.value
+
+    @classmethod
+    def raytrace_column(cls, r, ic, dist=-1.0):
+        r = np.array(r, dtype=np.float64); ic = np.array(ic, dtype=np.int32); n = _d(); t = _d()
+        cls.lib().ref_raytrace_column(_ptr(r), _ptr(ic), dist, C.byref(n), C.byref(t)); return n.value, t.value
+
+    @classmethod
+    def pix2vec(cls, nside, ipix):
+        v = np.zeros(3); cls.lib().ref_pix2vec(int(nside), int(ipix), _ptr(v)); return v
 
 
 class RefCalc(Ref):

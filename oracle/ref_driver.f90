@@ -326,6 +326,47 @@ contains
     call raytrace_to_dist_car(ph, g, dist, tau)
   end subroutine ref_raytrace_to_dist
 
+  !--- sight-line marches: raytrace_to_edge_car_tau_gas (:1236-1327), raytrace_to_dist_tau_gas_car (:197-297);
+  !    dist < 0 selects the to-edge routine
+  subroutine ref_raytrace_tau_gas(r, ic, dist, tau) bind(C, name='ref_raytrace_tau_gas')
+    real(c_double), intent(in) :: r(8)
+    integer(c_int), intent(in) :: ic(4)
+    real(c_double), value :: dist
+    real(c_double), intent(out) :: tau
+    type(photon_type) :: ph
+    call unpack(r, ic, ph)
+    if (dist < 0.0_wp) then
+       call raytrace_to_edge_car_tau_gas(ph, g, tau)
+    else
+       call raytrace_to_dist_tau_gas_car(ph, g, dist, tau)
+    endif
+  end subroutine ref_raytrace_tau_gas
+
+  !--- raytrace_to_edge_car_column (:1329-1423), raytrace_to_dist_column_car (:299-408)
+  subroutine ref_raytrace_column(r, ic, dist, N_gas, tau_dust) bind(C, name='ref_raytrace_column')
+    real(c_double), intent(in) :: r(8)
+    integer(c_int), intent(in) :: ic(4)
+    real(c_double), value :: dist
+    real(c_double), intent(out) :: N_gas, tau_dust
+    type(photon_type) :: ph
+    call unpack(r, ic, ph)
+    if (dist < 0.0_wp) then
+       call raytrace_to_edge_car_column(ph, g, N_gas, tau_dust)
+    else
+       call raytrace_to_dist_column_car(ph, g, dist, N_gas, tau_dust)
+    endif
+  end subroutine ref_raytrace_column
+
+  !--- healpix.f90:114-187 (RING pixel centre)
+  subroutine ref_pix2vec(nside, ipix, v) bind(C, name='ref_pix2vec')
+    use healpix, only: pix2vec
+    integer(c_int), value :: nside, ipix
+    real(c_double), intent(out) :: v(3)
+    real(wp) :: vx, vy, vz
+    call pix2vec(nside, ipix, vx, vy, vz)
+    v = [vx, vy, vz]
+  end subroutine ref_pix2vec
+
 #if defined(CALCJ) && defined(CALCPnew)
   !--- profile tallies compiled into raytrace_car.f90 by -DCALCJ -DCALCPnew (add_to_J :3979-4011, add_to_Pnew :4015-4045)
   subroutine ref_set_JPa(geometry_JPa, nbins, ind) bind(C, name='ref_set_JPa')
