@@ -172,6 +172,16 @@ int  lart_gpu_get_photon_log(lart_gpu *ctx, double *nscatt, double *xfreq_ref, i
 int  lart_gpu_set_pool(lart_gpu *ctx, int64_t nlanes, int32_t block);
 int  lart_gpu_pool_info(lart_gpu *ctx, int64_t *nlanes, int32_t *block);   /* valid after lart_gpu_begin */
 
+/* replaces `call make_sightline_tau(grid)` (main.f90:36; make_sightline_tau_outside / _outside_amr sightline_tau_rect.f90:11-345,
+ * make_sightline_tau_inside / _inside_amr sightline_tau_heal.f90:11-290, make_sightline_tau_clump sightline_tau_clump.f90:33-155):
+ * gas optical depth per frequency bin and HI column density along the sight line of every observer pixel, from the far
+ * side of the medium towards the observer (gas only, no tau_huge cut).  Needs the medium and the observers; independent of
+ * lart_gpu_begin.  Host arrays in Fortran order: tau_gas(nxfreq,nxim,nyim,nobs), N_gas(nxim,nyim,nobs),
+ * tau_dust(nxim,nyim,nobs) (NULL to skip; zeros unless DGR > 0); HEALPix observers: nxim = 12 nside^2, nyim = 1.
+ * cross0 = line%cross0 (N_gas = sum rhokap Dfreq / cross0 dl, raytrace_car.f90:1383).  Pixels that miss the medium stay 0. */
+int  lart_gpu_sightline_tau(lart_gpu *ctx, double cross0, double *tau_gas, double *N_gas, double *tau_dust);
+int  lart_gpu_sightline_time(lart_gpu *ctx, double *kernel_ms);   /* device time of the last map (HIP events) */
+
 /* replaces `call output_reduce(grid)` (main.f90:46): with one process per GPU the fused device tally
  * buffer is summed across ranks by the caller's RCCL collective (torch.distributed / ncclReduce) on the
  * pointer returned here, then copied out by lart_gpu_get_tallies. */

@@ -34,7 +34,7 @@ class LartTallies(C.Structure):
 SYMBOLS = ["lart_gpu_device_count", "lart_gpu_create", "lart_gpu_destroy", "lart_gpu_last_error",
            "lart_gpu_set_grid_car", "lart_gpu_set_mueller", "lart_gpu_set_observers", "lart_gpu_set_observers_heal",
            "lart_gpu_set_JPa", "lart_gpu_set_grid_amr", "lart_gpu_set_JPa_amr", "lart_gpu_set_clumps", "lart_host_last_error", "lart_host_clumps_generate", "lart_host_clumps_csr_dims", "lart_host_clumps_build_csr", "lart_host_amr_last_error", "lart_host_amr_count", "lart_host_amr_build", "lart_gpu_run",
-           "lart_gpu_begin", "lart_gpu_step", "lart_gpu_sync", "lart_gpu_kernel_time",
+           "lart_gpu_begin", "lart_gpu_step", "lart_gpu_sync", "lart_gpu_kernel_time", "lart_gpu_sightline_tau", "lart_gpu_sightline_time",
            "lart_gpu_enable_photon_log", "lart_gpu_get_photon_log", "lart_gpu_set_pool", "lart_gpu_pool_info",
            "lart_gpu_tally_buffer", "lart_gpu_zero_tallies", "lart_gpu_get_tallies",
            "lart_gpu_test_voigt", "lart_gpu_test_rand", "lart_gpu_test_raytrace", "lart_gpu_test_vec2pix", "lart_gpu_test_scatter"]
@@ -73,6 +73,8 @@ def lib():
         L.lart_gpu_step.argtypes = [_vp, _i32, _i32]
         L.lart_gpu_sync.argtypes = [_vp, C.POINTER(_i64), C.POINTER(_i64)]
         L.lart_gpu_kernel_time.argtypes = [_vp, C.POINTER(_d), C.POINTER(_i64)]
+        L.lart_gpu_sightline_tau.argtypes = [_vp, _d, _vp, _vp, _vp]
+        L.lart_gpu_sightline_time.argtypes = [_vp, C.POINTER(_d)]
         L.lart_gpu_enable_photon_log.argtypes = [_vp, _i32]
         L.lart_gpu_get_photon_log.argtypes = [_vp, _vp, _vp, _i64]
         L.lart_gpu_set_pool.argtypes = [_vp, _i64, _i32]
@@ -217,6 +219,19 @@ class Context:
         ms, n = _d(), _i64()
         _chk(lib().lart_gpu_kernel_time(self.h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def sightline_tau(self, cross0):
+        """make_sightline_tau: tau_gas (nxfreq,nxim,nyim,nobs), N_gas (nxim,nyim,nobs), tau_dust (nxim,nyim,nobs), Fortran order"""
+        nxf = int(self.par.nxfreq)
+        tg = np.zeros((nxf, self.nxim, self.nyim, self.nobs), order="F"); ng = np.zeros((self.nxim, self.nyim, self.nobs), order="F")
+        td = np.zeros((self.nxim, self.nyim, self.nobs), order="F")
+        _chk(lib().lart_gpu_sightline_tau(self.h, float(cross0), tg.ctypes.data_as(_vp), ng.ctypes.data_as(_vp), td.ctypes.data_as(_vp)))
+        return tg, ng, td
+
+    def sightline_time(self):
+        ms = _d()
+        _chk(lib().lart_gpu_sightline_time(self.h, C.byref(ms)))
+        return ms.value
 
     def photon_log(self, count):
         a, b = np.zeros(count), np.zeros(count)

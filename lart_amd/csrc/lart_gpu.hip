@@ -1,6 +1,7 @@
 // lart_gpu.hip -- C-ABI (include/lart_gpu.h) over the HIP transport kernels + device-function probes.
 // Host side is plain HIP runtime calls on one stream per context; no torch types, no CPU fallback.
 #include "transport_kernel.hpp"
+#include "sightline.hpp"
 #include <string>
 #include <vector>
 #include <cstring>
@@ -27,6 +28,7 @@ struct lart_gpu {
     DMueller mu{}; double *d_mu = nullptr; int *d_alias = nullptr;
     // observers
     DObs *d_obs = nullptr; int nobs = 0, nxim = 0, nyim = 0; double dxim = 0, dyim = 0; int heal_nside = 0;
+    std::vector<DObs> h_obs; std::vector<double> h_faces;    // host copies for the sight-line ray set-up
     // J/P profile tallies
     DJPa jpa{}; int *d_ind_bin = nullptr;
     // octree (VAR 3)
@@ -43,6 +45,7 @@ struct lart_gpu {
     long long first_id = 0, stride = 1, count = 0; unsigned long long seed = 0; bool begun = false;
     int log_on = 0; double *d_log = nullptr; int64_t nlog = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; double kernel_ms = 0.0; int64_t nlaunch = 0;
+    double sight_ms = 0.0;                                   // device time of the last sight-line map
 };
 
 extern "C" const char *lart_gpu_last_error(void) { return g_err.c_str(); }
@@ -145,6 +148,7 @@ extern "C" int lart_gpu_set_grid_car(lart_gpu *c, int32_t nx, int32_t ny, int32_
     std::memcpy(&f[0], xface, (nx + 1) * sizeof(double)); std::memcpy(&f[nx + 1], yface, (ny + 1) * sizeof(double)); std::memcpy(&f[nx + ny + 2], zface, (nz + 1) * sizeof(double));
     HIPCHK(hipMalloc(&c->d_faces, nf * sizeof(double)));
     HIPCHK(hipMemcpy(c->d_faces, f.data(), nf * sizeof(double), hipMemcpyHostToDevice));
+    c->h_faces = f;
     c->g.nx = nx; c->g.ny = ny; c->g.nz = nz; c->g.i0 = i0; c->g.j0 = j0; c->g.k0 = k0;
     c->g.xmin = xmin; c->g.ymin = ymin; c->g.zmin = zmin; c->g.dx = dx; c->g.dy = dy; c->g.dz = dz;
     c->g.cell = c->d_cell; c->g.faces = c->d_faces; c->ncell = nc; c->has_dust_table = rhokapD != nullptr;
@@ -181,7 +185,7 @@ extern "C" int lart_gpu_set_observers(lart_gpu *c, int32_t nobs, const double *x
     for (int i = 0; i < nobs; i++) { h[i].x = xyz[3 * i]; h[i].y = xyz[3 * i + 1]; h[i].z = xyz[3 * i + 2]; for (int q = 0; q < 9; q++) h[i].rm[q] = rmatrix[9 * i + q]; }
     HIPCHK(hipMalloc(&c->d_obs, h.size() * sizeof(DObs)));
     HIPCHK(hipMemcpy(c->d_obs, h.data(), h.size() * sizeof(DObs), hipMemcpyHostToDevice));
-    c->nobs = nobs; c->nxim = nxim; c->nyim = nyim; c->dxim = dxim; c->dyim = dyim; c->heal_nside = 0;
+    c->nobs = nobs; c->nxim = nxim; c->nyim = nyim; c->dxim = dxim; c->dyim = dyim; c->heal_nside = 0; h.resize(nobs > 0 ? nobs : 0); c->h_obs = h;
     free_tally(c);
     return 0;
 }
@@ -199,7 +203,7 @@ extern "C" int lart_gpu_set_observers_heal(lart_gpu *c, int32_t nobs, const doub
     for (int i = 0; i < nobs; i++) { h[i].x = xyz[3 * i]; h[i].y = xyz[3 * i + 1]; h[i].z = xyz[3 * i + 2]; for (int q = 0; q < 9; q++) h[i].rm[q] = 0.0; }
     HIPCHK(hipMalloc(&c->d_obs, h.size() * sizeof(DObs)));
     HIPCHK(hipMemcpy(c->d_obs, h.data(), h.size() * sizeof(DObs), hipMemcpyHostToDevice));
-    c->nobs = nobs; c->nxim = 12 * nside * nside; c->nyim = 1; c->dxim = 1.0; c->dyim = 1.0; c->heal_nside = nside;
+    c->nobs = nobs; c->nxim = 12 * nside * nside; c->nyim = 1; c->dxim = 1.0; c->dyim = 1.0; c->heal_nside = nside; c->h_obs = h;
     free_tally(c);
     return 0;
 }
@@ -716,3 +720,44 @@ extern "C" int lart_gpu_test_scatter(lart_gpu *c, int32_t n, double *st18, int32
     if (ds.back(st18) || di.back(ic4) || dn.back((long long *)ndraws)) return fail("test_scatter: copy back failed");
     return 0;
 }
+
+// make_sightline_tau: one ray per observer pixel from the far side of the medium, marched once per frequency bin
+extern "C" int lart_gpu_sightline_tau(lart_gpu *c, double cross0, double *tau_gas, double *N_gas, double *tau_dust) {
+    if (!c || !tau_gas || !N_gas) return fail("sightline_tau: null argument");
+    if (!c->d_cell && !c->is_clump) return fail("sightline_tau: set the medium first");
+    if (c->nobs < 1 || c->h_obs.size() != (size_t)c->nobs) return fail("sightline_tau: set the observers first (lart_gpu_set_observers / _heal)");
+    if (!(cross0 > 0.0)) return fail("sightline_tau: cross0 (line%cross0) must be > 0");
+    if (c->par.xyz_symmetry || c->par.xy_periodic) return fail("sightline_tau: needs the plain medium (no observers with xyz_symmetry / xy_periodic, setup.f90:198-206)");
+    if (c->is_clump && c->heal_nside > 0) return fail("sightline_tau: HEALPix inside observers are not supported with the clump medium (setup.f90:177)");
+    if (c->par.nxfreq < 1) return fail("sightline_tau: nxfreq must be >= 1");
+    HIPCHK(hipSetDevice(c->device));
+    SightGeom g{};
+    g.var = c->is_clump ? 4 : (c->is_amr ? 3 : 0);
+    g.nside = c->heal_nside; g.nobs = c->nobs; g.nxim = c->nxim; g.nyim = c->nyim; g.dxim = c->dxim; g.dyim = c->dyim; g.obs = c->h_obs.data();
+    if (g.var == 0) {
+        if (c->h_faces.size() != (size_t)c->g.nx + c->g.ny + c->g.nz + 3) return fail("sightline_tau: no host copy of the cell faces");
+        g.nx = c->g.nx; g.ny = c->g.ny; g.nz = c->g.nz; g.xmin = c->g.xmin; g.ymin = c->g.ymin; g.zmin = c->g.zmin; g.dx = c->g.dx; g.dy = c->g.dy; g.dz = c->g.dz;
+        g.xface = c->h_faces.data(); g.yface = g.xface + g.nx + 1; g.zface = g.yface + g.ny + 1;
+    }
+    g.lo = c->amr.lo; g.hi = c->amr.hi; g.sphere_R = c->cl.sphere_R;
+    std::vector<SightRay> rays;
+    lart_sight_build_rays(g, rays);
+    const size_t nray = rays.size(), nxf = (size_t)c->par.nxfreq;
+    const bool dust = c->par.DGR > 0.0 && c->has_dust_table;
+    DevBuf<SightRay> dr; DevBuf<double> dt, dn, dd;
+    if (dr.alloc(nray, rays.data()) || dt.alloc(nray * nxf, nullptr) || dn.alloc(nray, nullptr) || dd.alloc(nray, nullptr)) return fail("sightline_tau: hipMalloc failed");
+    HIPCHK(hipMemsetAsync(dt.p, 0, nray * nxf * sizeof(double), c->stream));
+    HIPCHK(hipMemsetAsync(dn.p, 0, nray * sizeof(double), c->stream));
+    HIPCHK(hipMemsetAsync(dd.p, 0, nray * sizeof(double), c->stream));
+    KArgs A = probe_args(c);
+    hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e0, c->stream));
+    HIPCHK(lart_sight_launch(A, g.var, dr.p, (int)nray, cross0, dust, dt.p, dn.p, dd.p, probe_shmem(c), c->stream));
+    HIPCHK(hipEventRecord(e1, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    float ms = 0.0f; (void)hipEventElapsedTime(&ms, e0, e1); c->sight_ms = ms; (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (dt.back(tau_gas) || dn.back(N_gas) || (tau_dust && dd.back(tau_dust))) return fail("sightline_tau: copy back failed");
+    return 0;
+}
+extern "C" int lart_gpu_sightline_time(lart_gpu *c, double *ms) { if (!c || !ms) return fail("sightline_time: null argument"); *ms = c->sight_ms; return 0; }
+

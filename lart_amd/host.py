@@ -843,6 +843,12 @@ class Simulation:
         self.nphotons_run = n
         return count
 
+    def make_sightline_tau(self):
+        """make_sightline_tau (main.f90:36, par%save_sightline_tau): tau_gas(nu), N(HI) and tau_dust maps of every observer"""
+        if not self.obs.nobs:
+            raise LartInputError("make_sightline_tau needs observers (par%save_peeloff)")
+        return self.ctx.sightline_tau(self.line.cross0)
+
     def output_reduce(self, dist=None, force=False):
         """sum of the fused tally buffer over ranks (reduce_mem, memory_mod_mpi.f90:366-394) by one RCCL collective"""
         if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not force):

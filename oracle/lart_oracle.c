@@ -765,7 +765,7 @@ static inline void add_to_Pa(const orc_sim *s, acc_t *A, const photon_t *p) {
 static int observer_create(orc_sim *s) {
     if (!s->save_peeloff) { s->nobs = 0; return 0; }
     if (s->nside > 0) {                                                             /* observer_create_inside: observer_heal.f90:24-80 */
-        if (s->raytrace_variant != 0) { snprintf(g_err, sizeof g_err, "HEALPix inside observers need the plain Cartesian grid"); return -1; }
+        if (s->raytrace_variant != 0 && s->raytrace_variant != 3) { snprintf(g_err, sizeof g_err, "HEALPix inside observers need the plain Cartesian grid or the full octree"); return -1; }
         if (!(isfinite(s->obsx[0]) && isfinite(s->obsy[0]) && isfinite(s->obsz[0]))) { s->obsx[0] = 0.0; s->obsy[0] = 0.0; s->obsz[0] = 0.0; }
         int n = 0; for (int i = 0; i < MAX_OBS; i++) if (isfinite(s->obsx[i]) && isfinite(s->obsy[i]) && isfinite(s->obsz[i])) n++;
         s->nobs = n; s->npix = 12 * s->nside * s->nside; s->nxim = s->npix; s->nyim = 1;

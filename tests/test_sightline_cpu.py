@@ -77,6 +77,9 @@ def test_octree_and_clump_maps(oracle_mod, tmp_path):
     a = o.array("voigt_a")[0]
     assert np.isclose(tg[10, 3, 3, 0], 2e2, rtol=1e-6) and np.isclose(ng[3, 3, 0], 2 * o.scalar("N_gasmax"), rtol=1e-6)
     assert ng[0, 0, 0] == 0.0
+    oi = oracle_mod.Oracle(use_amr_grid=True, amr_file=fn, temperature=1e4, taumax=1e2, rmax=1.0, nxfreq=21, nside=2, obsx=0.0, obsy=0.0, obsz=0.0)
+    ti, ni, _ = oi.sightline_tau()                                                           # make_sightline_tau_inside_amr
+    assert ti.shape == (21, 48, 1, 1) and np.all(np.abs(ti[10, :, 0, 0] / 1e2 - 1) < 0.05) and np.all(np.abs(ni[:, 0, 0] / oi.scalar("N_gasmax") - 1) < 0.05)
     # clumps: <N(HI)> over the disc = f_cov-weighted clump columns; here only: non-negative, zero outside the sphere, and
     # tau at line centre = N * cross0 / Dfreq * H(0) for static clumps (sigma_v = 0)
     oc = oracle_mod.Oracle(use_clump_medium=True, clump_radius=0.05, clump_f_cov=3.0, clump_tau0=10.0, clump_sigma_v=0.0, temperature=1e4,
