@@ -77,6 +77,10 @@ module lart_gpu_c
        import; type(c_ptr), value :: ctx; integer(c_int32_t), value :: calc_J, calc_P, calc_Pnew, nbins
        integer(c_int32_t), intent(in) :: ind_bin(*); real(c_double), value :: cross0; integer(c_int) :: rc
      end function
+     function lart_gpu_sightline_tau(ctx, cross0, tau_gas, N_gas, tau_dust) bind(C, name='lart_gpu_sightline_tau') result(rc)
+       import; type(c_ptr), value :: ctx; real(c_double), value :: cross0
+       real(c_double), intent(out) :: tau_gas(*), N_gas(*), tau_dust(*); integer(c_int) :: rc
+     end function
      function lart_gpu_set_clumps(ctx, n, x, y, z, vx, vy, vz, radius, rhokap, rhokapD, voigt_a, Dfreq, sphere_R, Dfreq_ref, voigt_a_ref, &
                                   cgx, cg_min, cg_d, cg_start, cg_list) bind(C, name='lart_gpu_set_clumps') result(rc)
        import; type(c_ptr), value :: ctx; integer(c_int64_t), value :: n

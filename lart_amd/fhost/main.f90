@@ -55,6 +55,7 @@ program LaRT_amd
   write(*,'(a,2f10.3,i6)') 'xfreq_min, xfreq_max, nxfreq : ', grid%xfreq_min, grid%xfreq_max, grid%nxfreq
   if (dry_run) then
      if (dry_write) call write_output(trim(par%out_file), grid)
+     if (dry_write .and. par%save_sightline_tau .and. par%save_peeloff .and. par%nobs > 0) call make_sightline_tau(.false.)
      write(*,'(a)') '--dry-run: set-up only, no transport.'
      stop
   endif
@@ -110,6 +111,8 @@ program LaRT_amd
      endif
   endif
 
+  if (par%save_sightline_tau .and. par%save_peeloff .and. par%nobs > 0) call make_sightline_tau(.true.)      ! main.f90:34-37
+
   !--- run_simulation (main.f90:42): bounded slices so progress can be printed like par%nprint does
   call time_stamp(dtime)
   write(6,'(a,f8.3,a)') '---> Now starting simulation...  @ ', dtime/60.0_wp, ' mins'
@@ -162,6 +165,64 @@ contains
     call system_clock(t1)
     dt = real(t1 - t0, wp)/real(rate, wp)
   end subroutine time_stamp
+
+  !--- make_sightline_tau (sightline_tau_rect.f90:11-190, sightline_tau_heal.f90:11-165, sightline_tau_clump.f90:33-155) + the
+  !    writers write_sightline_tau_outside (sightline_tau_rect.f90:347-407) / _inside (sightline_tau_heal.f90:292-345):
+  !    one file <base>_tau[_kkk] per observer with sections TAU_gas, N_gas[, TAU_dust]
+  subroutine make_sightline_tau(on_gpu)
+    logical, intent(in) :: on_gpu
+    real(wp), allocatable, target :: tau_gas(:,:,:,:), N_gas(:,:,:), tau_dust(:,:,:)
+    integer :: nxi, nyi, io, fmt
+    type(out_file) :: o
+    type(key_list) :: kw, k0
+    character(len=8) :: tail
+    nxi = par%nxim; nyi = par%nyim
+    if (par%nside > 0) then
+       nxi = par%npix; nyi = 1
+    endif
+    allocate(tau_gas(par%nxfreq, nxi, nyi, par%nobs), N_gas(nxi, nyi, par%nobs), tau_dust(nxi, nyi, par%nobs))
+    tau_gas = 0.0_wp; N_gas = 0.0_wp; tau_dust = 0.0_wp
+    if (on_gpu) call lart_check(lart_gpu_sightline_tau(ctx, line%cross0, tau_gas, N_gas, tau_dust), 'lart_gpu_sightline_tau')
+    fmt = out_format_of(par%file_format)
+    do io = 1, par%nobs
+       tail = ''
+       if (par%nobs > 1) write(tail,'(a,i3.3)') '_', io
+       kw%n = 0; k0%n = 0
+       call kadd(kw, 'EQUINOX', 2000, 'Equinox of Ref. Coord.')
+       if (par%nside > 0) then
+          call kadd(kw, 'NSIDE', par%nside, 'HEALPIX nside')
+          call kadd(kw, 'NPIX',  par%npix,  'HEALPIX npix')
+          call kadd(kw, 'OBSX',  observer(io)%x, 'observer x')
+          call kadd(kw, 'OBSY',  observer(io)%y, 'observer y')
+          call kadd(kw, 'OBSZ',  observer(io)%z, 'observer z')
+       else
+          call kadd(kw, 'CD1_1',  par%dxim, 'Degree / Pixel')
+          call kadd(kw, 'CD2_1',  0.0_wp,   'Degree / Pixel')
+          call kadd(kw, 'CD1_2',  0.0_wp,   'Degree / Pixel')
+          call kadd(kw, 'CD2_2',  par%dyim, 'Degree / Pixel')
+          call kadd(kw, 'CRPIX1', (par%nxim + 1)/2.0_wp, 'Reference Pixel in X')
+          call kadd(kw, 'CRPIX2', (par%nyim + 1)/2.0_wp, 'Reference Pixel in Y')
+          call kadd(kw, 'CRVAL1', 0.0_wp, 'R.A. (Degree)')
+          call kadd(kw, 'CRVAL2', 0.0_wp, 'Dec  (Degree)')
+          call kadd(kw, 'CTYPE1', 'RA--TAN', 'Coordinate Type')
+          call kadd(kw, 'CTYPE2', 'DEC-TAN', 'Coordinate Type')
+          call kadd(kw, 'DISTANCE', par%distance, 'Distance')
+       endif
+       call kadd(kw, 'DISTUNIT', trim(par%distance_unit), 'Distance Unit')
+       call out_open(o, trim(par%base_name)//'_tau'//trim(tail), fmt)
+       if (par%nside > 0) then
+          call out_image(o, 'TAU_gas', [par%nxfreq, nxi], tau_gas(:,:,1,io), kw)
+          call out_image(o, 'N_gas', [nxi], N_gas(:,1,io), k0)
+          if (par%DGR > 0.0_wp) call out_image(o, 'TAU_dust', [nxi], tau_dust(:,1,io), k0)
+       else
+          call out_image(o, 'TAU_gas', [par%nxfreq, nxi, nyi], tau_gas(:,:,:,io), kw)
+          call out_image(o, 'N_gas', [nxi, nyi], N_gas(:,:,io), k0)
+          if (par%DGR > 0.0_wp) call out_image(o, 'TAU_dust', [nxi, nyi], tau_dust(:,:,io), k0)
+       endif
+       call out_close(o, .true.)
+       write(6,'(2a)') 'sight-line maps written: ', trim(o%path)
+    enddo
+  end subroutine make_sightline_tau
 
   subroutine null_tallies(tt)
     type(lart_tallies), intent(out) :: tt

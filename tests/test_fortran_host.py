@@ -374,3 +374,39 @@ def test_healpix_end_to_end_matches_python_host(exe, tmp_path):
     assert t["scatt"].max() > 0 and t["direc"].max() > 0
     for sec, k in (("Scattered", "scatt"), ("Direct", "direc")):
         assert np.allclose(O[sec][1], t[k].reshape(O[sec][1].shape, order="F") if t[k].shape != O[sec][1].shape else t[k], rtol=1e-8, atol=1e-12 * t[k].max()), sec
+
+
+SIGHT_IN = ("&parameters\n par%no_photons = 2000\n par%temperature = 1e4\n par%taumax = 1e3\n par%nx = 21\n par%ny = 21\n par%nz = 21\n"
+            " par%rmax = 1.0\n par%nxfreq = 70\n par%nxim = 12\n par%nyim = 9\n par%alpha = 30.0, -100.0\n par%beta = 50.0, 120.0\n"
+            " par%velocity_type = 'hubble'\n par%Vexp = 40.0\n par%DGR = 1.0\n par%save_sightline_tau = .true.\n par%iseed = 3\n{extra}/\n")
+
+
+def test_sightline_files_dry_run(exe, tmp_path):
+    """write_sightline_tau_outside (sightline_tau_rect.f90:347-407): <base>_tau_kkk per observer, sections and WCS keywords"""
+    r = run(exe, SIGHT_IN.format(extra=""), tmp_path, "--dry-run-write", name="sl.in")
+    assert r.returncode == 0, r.stdout + r.stderr
+    for k in (1, 2):
+        H = read_h5(str(tmp_path / ("sl_tau_%03d.h5" % k)))
+        assert list(H) == ["TAU_gas", "N_gas", "TAU_dust"]
+        assert H["TAU_gas"][1].shape == (70, 12, 9) and H["N_gas"][1].shape == (12, 9) and H["TAU_dust"][1].shape == (12, 9)
+        kw = {a.upper(): b for a, b in H["TAU_gas"][0].items()}
+        assert kw["CTYPE1"] == "RA--TAN" and kw["CRPIX1"] == 6.5 and kw["CRPIX2"] == 5.0 and kw["EQUINOX"] == 2000
+    r = run(exe, SIGHT_IN.format(extra=" par%file_format = 'fits'\n"), tmp_path, "--dry-run-write", name="sf.in")
+    assert r.returncode == 0, r.stdout + r.stderr
+    F = read_fits(str(tmp_path / "sf_tau_002.fits.gz"))
+    assert list(F) == ["TAU_gas", "N_gas", "TAU_dust"] and F["TAU_gas"][1].shape == (70, 12, 9)
+
+
+@pytest.mark.gpu
+def test_sightline_end_to_end_matches_python_host(exe, tmp_path):
+    r = run(exe, SIGHT_IN.format(extra=""), tmp_path, name="sl.in")
+    assert r.returncode == 0, r.stdout + r.stderr
+    from lart_amd import host
+    sim = host.Simulation(host.read_namelist(str(tmp_path / "sl.in")))
+    tg, ng, td = sim.make_sightline_tau()
+    assert ng.max() > 0 and td.max() > 0
+    for k in (0, 1):
+        H = read_h5(str(tmp_path / ("sl_tau_%03d.h5" % (k + 1))))
+        assert np.allclose(H["TAU_gas"][1], tg[..., k], rtol=1e-12, atol=0) and np.allclose(H["N_gas"][1], ng[..., k], rtol=1e-13, atol=0)
+        assert np.allclose(H["TAU_dust"][1], td[..., k], rtol=1e-13, atol=0)
+    assert os.path.exists(tmp_path / "sl.h5")                           # the transport run still follows
