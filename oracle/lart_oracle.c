@@ -303,7 +303,7 @@ struct orc_sim {
     double temperature, taumax, tauhomo, N_gasmax, N_gashomo, Vexp;
     int velocity_type;               /* 0 none, 1 hubble, 2 constant_radial, 3 parallel_velocity */
     double Vx, Vy, Vz;
-    int comoving_source, recoil, core_skip, core_skip_global, xyz_symmetry, xy_periodic;
+    int comoving_source, recoil, core_skip, core_skip_global, xyz_symmetry, xy_periodic, xy_symmetry;
     int nx, ny, nz; double xmax, ymax, zmax, rmax, rmin;
     double xs_point, ys_point, zs_point, source_rmax; int source_geometry;   /* 0 point, 1 uniform_sphere */
     double xfreq0, par_xfreq_min, par_xfreq_max; int nxfreq;
@@ -378,7 +378,7 @@ static int set_param(orc_sim *s, const char *k, const char *v) {
 #define I(name) if (!strcmp(k, #name)) { s->name = atoi(v); return 0; }
 #define B(name) if (!strcmp(k, #name)) { s->name = parse_bool(v); return 0; }
     D(no_photons) I(iseed) D(temperature) D(taumax) D(tauhomo) D(Vexp) D(Vx) D(Vy) D(Vz)
-    B(comoving_source) B(recoil) B(core_skip) B(core_skip_global) B(xyz_symmetry) B(xy_periodic)
+    B(comoving_source) B(recoil) B(core_skip) B(core_skip_global) B(xyz_symmetry) B(xy_periodic) B(xy_symmetry)
     I(nx) I(ny) I(nz) D(xmax) D(ymax) D(zmax) D(rmax) D(rmin) D(xs_point) D(ys_point) D(zs_point) D(source_rmax)
     D(xfreq0) I(nxfreq) B(use_stokes) B(use_reduced_wgt) B(save_Jin) B(save_Jabs) B(save_Jmu) I(nmu)
     D(hgg) D(albedo) D(cext_dust) D(DGR) D(distance2cm) B(save_peeloff) B(save_peeloff_2D) B(save_peeloff_3D)
@@ -520,16 +520,16 @@ static int read_input_post(orc_sim *s) {
             double c[4] = {s->rmax, s->xmax, s->ymax, s->zmax}, r0 = -HUGEST;
             for (int i = 0; i < 4; i++) if (c[i] > 0.0 && c[i] > r0) r0 = c[i];
             if (r0 > 0.0) { s->rmax = s->xmax = s->ymax = s->zmax = r0; }
-            int n = s->nx; if (s->ny > n) n = s->ny; if (s->nz > n) n = s->nz;
-            s->nx = s->ny = s->nz = n;
+            if (!s->xy_symmetry) { int n = s->nx; if (s->ny > n) n = s->ny; if (s->nz > n) n = s->nz; s->nx = s->ny = s->nz = n; }
         }
     } else s->rmax = -1.0;
     if (s->source_rmax < 0.0) s->source_rmax = s->rmax;
     /* :438-459 geometry of the J/P profiles: 3 = per cell, 1 = spherical shells, -1 = plane-parallel layers */
     if (s->rmax <= 0.0) s->geometry_JPa = 3;                     /* evaluated on the INPUT rmax, also for the octree (grid_create_amr sets par%rmax later) */
     if (s->geometry_JPa < -1 || s->geometry_JPa > 3) { s->geometry_JPa = 1;
-        if (s->xy_periodic) s->geometry_JPa = -1; else if (s->xyz_symmetry) s->geometry_JPa = 1; }
-    if (s->geometry_JPa == 2 || s->geometry_JPa == 0) { snprintf(g_err, sizeof g_err, "geometry_JPa = %d (cylinder) not supported by the oracle", s->geometry_JPa); return -1; }
+        if (s->xy_periodic) s->geometry_JPa = -1; else if (s->xyz_symmetry) s->geometry_JPa = 1; else if (s->xy_symmetry) s->geometry_JPa = 2; }
+    if (s->xy_symmetry && (s->xyz_symmetry || s->xy_periodic)) { snprintf(g_err, sizeof g_err, "xy_symmetry excludes xyz_symmetry and xy_periodic (setup.f90:951-958 takes the first)"); return -1; }
+    if ((s->geometry_JPa == 2 || s->geometry_JPa == 0) && (s->calc_J || s->calc_P || s->calc_Pnew)) { snprintf(g_err, sizeof g_err, "geometry_JPa = %d (cylinder) not supported by the oracle", s->geometry_JPa); return -1; }
     /* :473-489 distance unit ('' -> 1) */
     if (s->distance2cm < 0.0) s->distance2cm = 1.0;
     /* :496-500 Mueller table / Stokes without table forces DGR = 0 */
@@ -552,6 +552,10 @@ static int grid_create(orc_sim *s) {
         sym_axis(nx, s->xmax, &s->dx, &s->xmin, &s->i0);
         sym_axis(ny, s->ymax, &s->dy, &s->ymin, &s->j0);
         sym_axis(nz, s->zmax, &s->dz, &s->zmin, &s->k0);
+    } else if (s->xy_symmetry) {                                                 /* :113-134: mirrors in x and y, the full z range */
+        sym_axis(nx, s->xmax, &s->dx, &s->xmin, &s->i0);
+        sym_axis(ny, s->ymax, &s->dy, &s->ymin, &s->j0);
+        s->dz = 2.0 * s->zmax / nz; s->zmin = -s->zmax; s->k0 = 0;
     } else {                                                                     /* :166-176 */
         s->dx = 2.0 * s->xmax / nx; s->dy = 2.0 * s->ymax / ny; s->dz = 2.0 * s->zmax / nz;
         s->xmin = -s->xmax; s->ymin = -s->ymax; s->zmin = -s->zmax; s->i0 = s->j0 = s->k0 = 0;
@@ -588,10 +592,11 @@ static int grid_create(orc_sim *s) {
     else if (s->zmax == -s->zmin) opac_length = s->zrange / 2.0;
     else opac_length = s->zrange;
     int nxcen, nycen;                                                               /* :505-515 */
-    if (s->xyz_symmetry) { nxcen = 1; nycen = 1; } else { nxcen = (nx + 1) / 2; nycen = (ny + 1) / 2; }
+    if (s->xyz_symmetry || s->xy_symmetry) { nxcen = 1; nycen = 1; } else { nxcen = (nx + 1) / 2; nycen = (ny + 1) / 2; }
 #define NADD(i,j,k,nadd) do { nadd = 1.0; if (s->xyz_symmetry) { \
         if ((i) == 1 && (nx/2)*2 != nx) nadd = nadd / 2.0; if ((j) == 1 && (ny/2)*2 != ny) nadd = nadd / 2.0; \
-        if ((k) == 1 && (nz/2)*2 != nz) nadd = nadd / 2.0; } } while (0)
+        if ((k) == 1 && (nz/2)*2 != nz) nadd = nadd / 2.0; } else if (s->xy_symmetry) { \
+        if ((i) == 1 && (nx/2)*2 != nx) nadd = nadd / 2.0; if ((j) == 1 && (ny/2)*2 != ny) nadd = nadd / 2.0; } } while (0)
     double opacity_sum, opacity1, opac_norm, nopac, nadd;
     if (s->taumax > 0.0) {                                                          /* :518-538 */
         opacity_sum = 0.0;
@@ -696,8 +701,9 @@ static int grid_create(orc_sim *s) {
            s->xcrit = 0.02 * exp(xi * pow(log(at), chi)); s->xcrit2 = s->xcrit * s->xcrit; }
     /* dispatch as setup_procedure, setup.f90:967-990 */
     if (s->xyz_symmetry) s->raytrace_variant = 1;
+    else if (s->xy_symmetry) s->raytrace_variant = 5;                               /* raytrace_to_{tau,edge}_car_xysym */
     else if (s->xy_periodic && s->nx == 1 && s->ny == 1) s->raytrace_variant = 2;
-    else if (s->xy_periodic) { snprintf(g_err, sizeof g_err, "xy_periodic with nx,ny>1 not supported by the oracle"); return -1; }
+    else if (s->xy_periodic) s->raytrace_variant = 6;                               /* raytrace_to_{tau,edge}_car_xyper */
     else s->raytrace_variant = 0;
     return 0;
 }
@@ -1574,6 +1580,31 @@ static int setup_axis_sym(int n, const double *face, double d, int i0, double xp
     } else { *step = 0; *t = HUGEST; *del = HUGEST; }
     return 0;
 }
+/* one plain (open) axis, as the z axis of _car_xysym / _car_xyper / _car_zonly: the tau routines leave only when the start
+ * sits exactly on the upper face (strict), the edge routines when it is on or beyond it */
+static int setup_axis_plain(int n, const double *face, double d, double xp, int strict_eq, int *cell, int *step, double k, double *t, double *del) {
+    if (k > 0.0) {
+        if (*cell > n && (strict_eq ? (face[*cell-1] == xp) : (face[*cell-1] <= xp))) return 1;
+        *step = 1; *t = (face[*cell] - xp) / k; *del = d / k;
+    } else if (k < 0.0) {
+        if (face[*cell-1] == xp) { if (*cell > 1) *cell -= 1; else return 1; }
+        *step = -1; *t = (face[*cell-1] - xp) / k; *del = -d / k;
+    } else { *step = 0; *t = HUGEST; *del = HUGEST; }
+    return 0;
+}
+/* one periodic axis: raytrace_to_tau_car_xyper :2287-2311 (a start on the upper face re-enters at the lower one),
+ * raytrace_to_edge_car_xyper :996-1017 (such a start leaves).  *xp is moved with the wrap. */
+static int setup_axis_per(int n, const double *face, double d, double *xp, int tau_mode, int *cell, int *step, double k, double *t, double *del) {
+    if (k > 0.0) {
+        if (tau_mode) { if (*cell > n && face[*cell-1] == *xp) { *cell = 1; *xp = face[0]; } }
+        else if (*cell > n && face[*cell-1] <= *xp) return 1;
+        *step = 1; *t = (face[*cell] - *xp) / k; *del = d / k;
+    } else if (k < 0.0) {
+        if (face[*cell-1] == *xp) { if (*cell > 1) *cell -= 1; else { *cell = n; *xp = face[n]; } }
+        *step = -1; *t = (face[*cell-1] - *xp) / k; *del = -d / k;
+    } else { *step = 0; *t = HUGEST; *del = HUGEST; }
+    return 0;
+}
 static inline int minloc3(double a, double b, double c) { int m = 1; double v = a; if (b < v) { m = 2; v = b; } if (c < v) m = 3; return m; }
 static inline double udot(const orc_sim *s, size_t c, double kx, double ky, double kz) { return s->vfx[c] * kx + s->vfy[c] * ky + s->vfz[c] * kz; }
 
@@ -1595,14 +1626,19 @@ static void raytrace_to_tau(const orc_sim *s, acc_t *A, photon_t *p, double tau_
         if (setup_axis_sym(s->nx, s->xface, s->dx, s->i0, xp, 1, &t.icell, &t.istep, &t.kx, &t.tx, &t.delx)) { p->inside = 0; return; }
         if (setup_axis_sym(s->ny, s->yface, s->dy, s->j0, yp, 1, &t.jcell, &t.jstep, &t.ky, &t.ty, &t.dely)) { p->inside = 0; return; }
         if (setup_axis_sym(s->nz, s->zface, s->dz, s->k0, zp, 1, &t.kcell, &t.kstep, &t.kz, &t.tz, &t.delz)) { p->inside = 0; return; }
+    } else if (variant == 5) {                                                       /* xysym :1985-2066 */
+        if (setup_axis_sym(s->nx, s->xface, s->dx, s->i0, xp, 1, &t.icell, &t.istep, &t.kx, &t.tx, &t.delx)) { p->inside = 0; return; }
+        if (setup_axis_sym(s->ny, s->yface, s->dy, s->j0, yp, 1, &t.jcell, &t.jstep, &t.ky, &t.ty, &t.dely)) { p->inside = 0; return; }
+        if (setup_axis_plain(s->nz, s->zface, s->dz, zp, 1, &t.kcell, &t.kstep, t.kz, &t.tz, &t.delz)) { p->inside = 0; return; }
+    } else if (variant == 6) {                                                       /* xyper :2287-2361 */
+        setup_axis_per(s->nx, s->xface, s->dx, &xp, 1, &t.icell, &t.istep, t.kx, &t.tx, &t.delx);
+        setup_axis_per(s->ny, s->yface, s->dy, &yp, 1, &t.jcell, &t.jstep, t.ky, &t.ty, &t.dely);
+        if (setup_axis_plain(s->nz, s->zface, s->dz, zp, 1, &t.kcell, &t.kstep, t.kz, &t.tz, &t.delz)) { p->inside = 0; return; }
     } else {                                                                         /* zonly :2558-2582 */
         t.istep = t.jstep = 0; t.tx = t.ty = HUGEST; t.delx = t.dely = HUGEST;
-        if (t.kz > 0.0) { if (t.kcell > s->nz && s->zface[t.kcell-1] == zp) { p->inside = 0; return; }
-            t.kstep = 1; t.tz = (s->zface[t.kcell] - zp) / t.kz; t.delz = s->dz / t.kz; }
-        else if (t.kz < 0.0) { if (s->zface[t.kcell-1] == zp) { if (t.kcell > 1) t.kcell -= 1; else { p->inside = 0; return; } }
-            t.kstep = -1; t.tz = (s->zface[t.kcell-1] - zp) / t.kz; t.delz = -s->dz / t.kz; }
-        else { t.kstep = 0; t.tz = HUGEST; t.delz = HUGEST; }
+        if (setup_axis_plain(s->nz, s->zface, s->dz, zp, 1, &t.kcell, &t.kstep, t.kz, &t.tz, &t.delz)) { p->inside = 0; return; }
     }
+    const int mirror_xy = (variant == 1 || variant == 5), mirror_z = (variant == 1), wrap_xy = (variant == 6);
     double tau = 0.0, d = 0.0, del = 0.0, rhokap, rhokapH = 0.0;
     int iold = t.icell, jold = t.jcell, kold = t.kcell;
     double u1 = udot(s, IDX(s,iold,jold,kold), t.kx, t.ky, t.kz), u2;
@@ -1616,19 +1652,21 @@ static void raytrace_to_tau(const orc_sim *s, acc_t *A, photon_t *p, double tau_
         del = *tt - d; tau = tau + del * rhokap; d = *tt;
         if (tau >= tau_in) {
             if (rhokap > 0.0) { double d_over = (tau - tau_in) / rhokap; d = d - d_over; del = del - d_over; }
-            if (variant != 1) { xp = xp + d * t.kx; yp = yp + d * t.ky; zp = zp + d * t.kz; }
+            if (!mirror_xy) { xp = xp + d * t.kx; yp = yp + d * t.ky; zp = zp + d * t.kz; }
             break;
         }
         if (idx == 1) { t.icell += t.istep;
-            if (variant == 1 && t.icell < 1) { t.icell = s->i0; t.istep = 1; t.kx = -t.kx; }
+            if (mirror_xy && t.icell < 1) { t.icell = s->i0; t.istep = 1; t.kx = -t.kx; }
+            else if (wrap_xy) { if (t.icell < 1) t.icell = s->nx; if (t.icell > s->nx) t.icell = 1; }
             else if (t.icell < 1 || t.icell > s->nx) { p->inside = 0; break; }
             t.tx += t.delx; }
         else if (idx == 2) { t.jcell += t.jstep;
-            if (variant == 1 && t.jcell < 1) { t.jcell = s->j0; t.jstep = 1; t.ky = -t.ky; }
+            if (mirror_xy && t.jcell < 1) { t.jcell = s->j0; t.jstep = 1; t.ky = -t.ky; }
+            else if (wrap_xy) { if (t.jcell < 1) t.jcell = s->ny; if (t.jcell > s->ny) t.jcell = 1; }
             else if (t.jcell < 1 || t.jcell > s->ny) { p->inside = 0; break; }
             t.ty += t.dely; }
         else { t.kcell += t.kstep;
-            if (variant == 1 && t.kcell < 1) { t.kcell = s->k0; t.kstep = 1; t.kz = -t.kz; }
+            if (mirror_z && t.kcell < 1) { t.kcell = s->k0; t.kstep = 1; t.kz = -t.kz; }
             else if (t.kcell < 1 || t.kcell > s->nz) { p->inside = 0; break; }
             t.tz += t.delz; }
         size_t cn = IDX(s,t.icell,t.jcell,t.kcell), co = IDX(s,iold,jold,kold);
@@ -1647,10 +1685,13 @@ static void raytrace_to_tau(const orc_sim *s, acc_t *A, photon_t *p, double tau_
         int ix = (int)floor((p->xfreq_ref - s->xfreq_min) / s->dxfreq) + 1;
         if (ix >= 1 && ix <= s->nxfreq) { A->Jout[ix-1] += p->wgt; if (s->save_Jmu) add_to_Jmu(s, A, p, ix); }
     }
-    if (variant == 1) {                                                              /* :1935-1946 */
+    if (mirror_xy) {                                                                 /* :1935-1946, xysym :2238-2248 (no fold in z) */
         p->x = p->x + d * p->kx; p->y = p->y + d * p->ky; p->z = p->z + d * p->kz;
-        if (p->x < s->xmin) p->x = -p->x; if (p->y < s->ymin) p->y = -p->y; if (p->z < s->zmin) p->z = -p->z;
+        if (p->x < s->xmin) p->x = -p->x; if (p->y < s->ymin) p->y = -p->y; if (mirror_z && p->z < s->zmin) p->z = -p->z;
         p->kx = t.kx; p->ky = t.ky; p->kz = t.kz;
+        p->icell = t.icell; p->jcell = t.jcell; p->kcell = t.kcell;
+    } else if (variant == 6) {                                                       /* :2509-2514: back into the base period */
+        p->x = xp - floor((xp - s->xmin) / s->xrange) * s->xrange; p->y = yp - floor((yp - s->ymin) / s->yrange) * s->yrange; p->z = zp;
         p->icell = t.icell; p->jcell = t.jcell; p->kcell = t.kcell;
     } else if (variant == 0) { p->x = xp; p->y = yp; p->z = zp; p->icell = t.icell; p->jcell = t.jcell; p->kcell = t.kcell; }
     else { p->x = xp; p->y = yp; p->z = zp; p->kcell = t.kcell; }                     /* zonly :2669-2673 */
@@ -1668,14 +1709,19 @@ static double raytrace_to_edge(const orc_sim *s, const photon_t *p, int variant,
         if (setup_axis_sym(s->nx, s->xface, s->dx, s->i0, xp, 0, &t.icell, &t.istep, &t.kx, &t.tx, &t.delx)) return tau;
         if (setup_axis_sym(s->ny, s->yface, s->dy, s->j0, yp, 0, &t.jcell, &t.jstep, &t.ky, &t.ty, &t.dely)) return tau;
         if (setup_axis_sym(s->nz, s->zface, s->dz, s->k0, zp, 0, &t.kcell, &t.kstep, &t.kz, &t.tz, &t.delz)) return tau;
+    } else if (variant == 5) {                                                       /* raytrace_to_edge_car_xysym :783-969 */
+        if (setup_axis_sym(s->nx, s->xface, s->dx, s->i0, xp, 0, &t.icell, &t.istep, &t.kx, &t.tx, &t.delx)) return tau;
+        if (setup_axis_sym(s->ny, s->yface, s->dy, s->j0, yp, 0, &t.jcell, &t.jstep, &t.ky, &t.ty, &t.dely)) return tau;
+        if (setup_axis_plain(s->nz, s->zface, s->dz, zp, 0, &t.kcell, &t.kstep, t.kz, &t.tz, &t.delz)) return tau;
+    } else if (variant == 6) {                                                       /* raytrace_to_edge_car_xyper :971-1136 */
+        if (setup_axis_per(s->nx, s->xface, s->dx, &xp, 0, &t.icell, &t.istep, t.kx, &t.tx, &t.delx)) return tau;
+        if (setup_axis_per(s->ny, s->yface, s->dy, &yp, 0, &t.jcell, &t.jstep, t.ky, &t.ty, &t.dely)) return tau;
+        if (setup_axis_plain(s->nz, s->zface, s->dz, zp, 0, &t.kcell, &t.kstep, t.kz, &t.tz, &t.delz)) return tau;
     } else {
         t.istep = t.jstep = 0; t.tx = t.ty = HUGEST; t.delx = t.dely = HUGEST;
-        if (t.kz > 0.0) { if (t.kcell > s->nz && s->zface[t.kcell-1] <= zp) return tau;
-            t.kstep = 1; t.tz = (s->zface[t.kcell] - zp) / t.kz; t.delz = s->dz / t.kz; }
-        else if (t.kz < 0.0) { if (s->zface[t.kcell-1] == zp) { if (t.kcell > 1) t.kcell -= 1; else return tau; }
-            t.kstep = -1; t.tz = (s->zface[t.kcell-1] - zp) / t.kz; t.delz = -s->dz / t.kz; }
-        else { t.kstep = 0; t.tz = HUGEST; t.delz = HUGEST; }
+        if (setup_axis_plain(s->nz, s->zface, s->dz, zp, 0, &t.kcell, &t.kstep, t.kz, &t.tz, &t.delz)) return tau;
     }
+    const int mirror_xy = (variant == 1 || variant == 5), mirror_z = (variant == 1), wrap_xy = (variant == 6);
     int iold = t.icell, jold = t.jcell, kold = t.kcell;
     double u1 = udot(s, IDX(s,iold,jold,kold), t.kx, t.ky, t.kz), u2, xfreq = p->xfreq, rhokap;
     for (;;) {
@@ -1688,15 +1734,17 @@ static double raytrace_to_edge(const orc_sim *s, const photon_t *p, int variant,
         if (dist >= 0.0) { if (*tt >= dist) { tau = tau + (dist - d) * rhokap; break; } }
         tau = tau + (*tt - d) * rhokap; d = *tt;
         if (idx == 1) { t.icell += t.istep;
-            if (variant == 1 && t.icell < 1) { t.icell = s->i0; t.istep = 1; t.kx = -t.kx; }
+            if (mirror_xy && t.icell < 1) { t.icell = s->i0; t.istep = 1; t.kx = -t.kx; }
+            else if (wrap_xy) { if (t.icell < 1) t.icell = s->nx; if (t.icell > s->nx) t.icell = 1; }
             else if (t.icell < 1 || t.icell > s->nx) break;
             t.tx += t.delx; }
         else if (idx == 2) { t.jcell += t.jstep;
-            if (variant == 1 && t.jcell < 1) { t.jcell = s->j0; t.jstep = 1; t.ky = -t.ky; }
+            if (mirror_xy && t.jcell < 1) { t.jcell = s->j0; t.jstep = 1; t.ky = -t.ky; }
+            else if (wrap_xy) { if (t.jcell < 1) t.jcell = s->ny; if (t.jcell > s->ny) t.jcell = 1; }
             else if (t.jcell < 1 || t.jcell > s->ny) break;
             t.ty += t.dely; }
         else { t.kcell += t.kstep;
-            if (variant == 1 && t.kcell < 1) { t.kcell = s->k0; t.kstep = 1; t.kz = -t.kz; }
+            if (mirror_z && t.kcell < 1) { t.kcell = s->k0; t.kstep = 1; t.kz = -t.kz; }
             else if (t.kcell < 1 || t.kcell > s->nz) break;
             t.tz += t.delz; }
         if (tau >= TAU_HUGE) break;

@@ -284,7 +284,7 @@ contains
     ic(4) = merge(1, 0, ph%inside)
   end subroutine pack
 
-  !--- variant: 0 = raytrace_to_tau_car (:1425), 1 = _car_xyzsym (:1650), 2 = _car_zonly (:2519)
+  !--- variant: 0 = raytrace_to_tau_car (:1425), 1 = _car_xyzsym (:1650), 2 = _car_zonly (:2519), 5 = _car_xysym (:1951), 6 = _car_xyper (:2252)
   subroutine ref_raytrace_to_tau(variant, r, ic, tau_in) bind(C, name='ref_raytrace_to_tau')
     integer(c_int), value :: variant
     real(c_double), intent(inout) :: r(8)
@@ -296,11 +296,13 @@ contains
     case (0); call raytrace_to_tau_car(ph, g, tau_in)
     case (1); call raytrace_to_tau_car_xyzsym(ph, g, tau_in)
     case (2); call raytrace_to_tau_car_zonly(ph, g, tau_in)
+    case (5); call raytrace_to_tau_car_xysym(ph, g, tau_in)
+    case (6); call raytrace_to_tau_car_xyper(ph, g, tau_in)
     end select
     call pack(ph, r, ic)
   end subroutine ref_raytrace_to_tau
 
-  !--- variant: 0 = raytrace_to_edge_car (:410), 1 = _car_xyzsym (:584), 2 = _car_zonly (:1138)
+  !--- variant: 0 = raytrace_to_edge_car (:410), 1 = _car_xyzsym (:584), 2 = _car_zonly (:1138), 5 = _car_xysym (:783), 6 = _car_xyper (:971)
   subroutine ref_raytrace_to_edge(variant, r, ic, tau) bind(C, name='ref_raytrace_to_edge')
     integer(c_int), value :: variant
     real(c_double), intent(in) :: r(8)
@@ -312,6 +314,8 @@ contains
     case (0); call raytrace_to_edge_car(ph, g, tau)
     case (1); call raytrace_to_edge_car_xyzsym(ph, g, tau)
     case (2); call raytrace_to_edge_car_zonly(ph, g, tau)
+    case (5); call raytrace_to_edge_car_xysym(ph, g, tau)
+    case (6); call raytrace_to_edge_car_xyper(ph, g, tau)
     end select
   end subroutine ref_raytrace_to_edge
 

@@ -359,6 +359,30 @@ def test_amr_profiles_peel_and_known_answer(capi, oracle_mod, amr_file):
     assert abs(ns.mean() - 2.8225e4) < 0.02 * 2.8225e4 + 4 * ns.std() / np.sqrt(n2), ns.mean()
 
 
+def test_amr_stokes_peel_and_inside_observer(capi, oracle_mod, amr_file, mueller_file):
+    """peeling_{dust,resonance}_stokes_amr (peelingoff_amr.f90:401-655) and peeling_*_inside_amr (:656-849): the octree peels
+    with Stokes vectors to a far observer, and with a HEALPix observer inside the box, against the oracle on the same streams"""
+    kw = dict(use_amr_grid=True, amr_file=amr_file, temperature=1e4, taumax=1e2, rmax=1.0, nxfreq=61, nxim=8, nyim=8, use_stokes=True,
+              DGR=1.0, scatt_mat_file=mueller_file, velocity_type="hubble", Vexp=20.0, alpha=30.0, beta=65.0, iseed=91)
+    n = 30000
+    sim = make(kw); sim.run_simulation(n); t = sim.ctx.tallies()
+    o = oracle_of(oracle_mod, kw); o.run(n, seed=91)
+    for k in ("scatt", "I", "Q", "U"):
+        g, r = t[k][..., 0], o.array(k + ":0").reshape((61, 8, 8), order="F")
+        assert np.allclose(g.sum(axis=0), r.sum(axis=0), rtol=0.05, atol=0.02 * np.abs(o.array("I:0")).reshape((61, 8, 8), order="F").sum(axis=0).max()), k
+    assert rms_diff(t["scatt"][..., 0].sum(axis=(1, 2)), o.array("scatt:0").reshape((61, 8, 8), order="F").sum(axis=(1, 2))) < 0.02
+    assert abs(t["direc"].sum() - o.array("direc:0").sum()) <= 0.01 * o.array("direc:0").sum() + 1e-12
+    assert np.isclose(t["nscatt_dust"], o.scalar("nscatt_dust"), rtol=0.05)
+    kw = dict(use_amr_grid=True, amr_file=amr_file, temperature=1e4, taumax=1e2, rmax=1.0, nxfreq=61, nside=4, obsx=0.3, obsy=-0.1, obsz=0.2,
+              save_peeloff_2D=True, velocity_type="hubble", Vexp=20.0, iseed=92)
+    sim = make(kw); sim.run_simulation(n); t = sim.ctx.tallies()
+    o = oracle_of(oracle_mod, kw); o.run(n, seed=92)
+    sc_g, sc_o = t["scatt"][:, :, 0, 0], o.array("scatt:0").reshape((61, 192), order="F")
+    assert sc_o.sum() > 0 and rms_diff(sc_g.sum(axis=1), sc_o.sum(axis=1)) < 0.01
+    assert np.allclose(sc_g.sum(axis=0), sc_o.sum(axis=0), rtol=0.05, atol=0.01 * sc_o.sum(axis=0).max())
+    assert abs(t["direc"].sum() - o.array("direc:0").sum()) <= 0.01 * o.array("direc:0").sum() + 1e-12
+
+
 def test_amr_boundary_errors(capi, amr_file):
     """the octree setter validates every index the kernels follow (a bad table must not reach the device)"""
     sim = make(dict(use_amr_grid=True, amr_file=amr_file, temperature=1e4, taumax=10.0, rmax=1.0))
