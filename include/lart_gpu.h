@@ -25,9 +25,9 @@ extern "C" {
 /* Run-time switches and scalars the kernels read.  Field names are the reference's par%/grid%/line%
  * names (define.f90:209-544, :117-206, :639-680). */
 typedef struct lart_params {
-    /* geometry / boundary variant: selects raytrace_to_{tau,edge}_car | _car_xyzsym | _car_zonly
-     * exactly as setup_procedure does (setup.f90:961-990) */
-    int32_t xyz_symmetry, xy_periodic;
+    /* geometry / boundary variant: selects raytrace_to_{tau,edge}_car | _car_xyzsym | _car_xysym | _car_zonly (xy_periodic
+     * with nx = ny = 1) | _car_xyper (xy_periodic otherwise) exactly as setup_procedure does (setup.f90:951-980) */
+    int32_t xyz_symmetry, xy_periodic, xy_symmetry;
     /* source: generate_photon.f90:33-132, :243-306 */
     int32_t source_geometry;       /* 0 'point', 1 'uniform_sphere' */
     int32_t spectral_type;         /* 0 'monochromatic', 1 'voigt' */

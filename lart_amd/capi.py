@@ -16,7 +16,7 @@ _d, _i32, _i64, _u64, _vp = C.c_double, C.c_int32, C.c_int64, C.c_uint64, C.c_vo
 class LartParams(C.Structure):
     """struct lart_params (include/lart_gpu.h) -- field names are the reference's par%/grid%/line% names."""
     _fields_ = [(n, _i32) for n in (
-        "xyz_symmetry", "xy_periodic", "source_geometry", "spectral_type", "comoving_source",
+        "xyz_symmetry", "xy_periodic", "xy_symmetry", "source_geometry", "spectral_type", "comoving_source",
         "recoil", "core_skip", "core_skip_global", "use_stokes", "use_reduced_wgt",
         "save_Jin", "save_Jabs", "save_Jmu", "nmu", "save_peeloff", "save_peeloff_2D", "save_peeloff_3D", "nxfreq")] + \
         [(n, _d) for n in (

@@ -525,6 +525,8 @@ __device__ inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > 
 //   VAR 0: plain grid            raytrace_to_tau_car :1425-1648, raytrace_to_edge_car :410-508
 //   VAR 1: +++ octant, mirrors   _car_xyzsym :1650-1949 / :584-781
 //   VAR 2: slab, z only          _car_zonly  :2519-2675 / :1138-1234
+//   VAR 5: mirrors in x and y    _car_xysym  :1951-2250 / :783-969
+//   VAR 6: periodic in x and y   _car_xyper  :2252-2517 / :971-1136
 // ---------------------------------------------------------------------------------------------
 struct Trav { int ic, jc, kc, is, js, ks; double kx, ky, kz, tx, ty, tz, delx, dely, delz; };
 
@@ -562,9 +564,30 @@ __device__ inline bool axis_setup_z(int n, const double *face, double d, double 
     } else { step = 0; t = LART_HUGEST; del = LART_HUGEST; }
     return false;
 }
+// one periodic axis of the xy-periodic box: the tau march re-enters a start on the upper face at the lower one (:2287-2311),
+// the edge march leaves there (:996-1017); a start on the lowest face moving down wraps to the top cell.  xp moves with the wrap.
+__device__ inline bool axis_setup_per(int n, const double *face, double d, double &xp, bool tau_mode, int &cell, int &step, double k, double &t, double &del) {
+    if (k > 0.0) {
+        if (tau_mode) { if (cell > n && face[cell - 1] == xp) { cell = 1; xp = face[0]; } }
+        else if (cell > n && face[cell - 1] <= xp) return true;
+        step = 1; t = (face[cell] - xp) / k; del = d / k;
+    } else if (k < 0.0) {
+        if (face[cell - 1] == xp) { if (cell > 1) cell -= 1; else { cell = n; xp = face[n]; } }
+        step = -1; t = (face[cell - 1] - xp) / k; del = -d / k;
+    } else { step = 0; t = LART_HUGEST; del = LART_HUGEST; }
+    return false;
+}
 template <int VAR>
-__device__ inline bool trav_setup(const DGrid &g, const Lds &l, double xp, double yp, double zp, bool strict, Trav &t) {
-    if (VAR == 0) {
+__device__ inline bool trav_setup(const DGrid &g, const Lds &l, double &xp, double &yp, double zp, bool strict, Trav &t) {
+    if (VAR == 5) {
+        if (axis_setup_sym(g.nx, l.xf, g.dx, g.i0, xp, strict, t.ic, t.is, t.kx, t.tx, t.delx)) return true;
+        if (axis_setup_sym(g.ny, l.yf, g.dy, g.j0, yp, strict, t.jc, t.js, t.ky, t.ty, t.dely)) return true;
+        if (axis_setup_z(g.nz, l.zf, g.dz, zp, strict, t.kc, t.ks, t.kz, t.tz, t.delz)) return true;
+    } else if (VAR == 6) {
+        if (axis_setup_per(g.nx, l.xf, g.dx, xp, strict, t.ic, t.is, t.kx, t.tx, t.delx)) return true;
+        if (axis_setup_per(g.ny, l.yf, g.dy, yp, strict, t.jc, t.js, t.ky, t.ty, t.dely)) return true;
+        if (axis_setup_z(g.nz, l.zf, g.dz, zp, strict, t.kc, t.ks, t.kz, t.tz, t.delz)) return true;
+    } else if (VAR == 0) {
         if (axis_setup_plain(g.nx, l.xf, g.dx, xp, t.ic, t.is, t.kx, t.tx, t.delx)) return true;
         if (axis_setup_plain(g.ny, l.yf, g.dy, yp, t.jc, t.js, t.ky, t.ty, t.dely)) return true;
         if (axis_setup_plain(g.nz, l.zf, g.dz, zp, t.kc, t.ks, t.kz, t.tz, t.delz)) return true;
@@ -591,11 +614,13 @@ __device__ inline bool trav_cross(const DGrid &g, Trav &t, int idx) {
     const double del = ax ? t.delx : (ay ? t.dely : t.delz);
     cell += step;
     bool ok = true;
-    if (VAR == 1 && cell < 1) { cell = m0; step = 1; k = -k; }
+    const bool mirror = VAR == 1 || (VAR == 5 && (ax || ay)), wrap = VAR == 6 && (ax || ay);
+    if (mirror && cell < 1) { cell = m0; step = 1; k = -k; }
+    else if (wrap) { cell = cell < 1 ? n : (cell > n ? 1 : cell); }
     else if (cell < 1 || cell > n) ok = false;
     if (ok) tt += del;
     t.ic = ax ? cell : t.ic; t.jc = ay ? cell : t.jc; t.kc = (!ax && !ay) ? cell : t.kc;
-    if (VAR == 1) {
+    if (VAR == 1 || VAR == 5) {
         t.is = ax ? step : t.is; t.js = ay ? step : t.js; t.ks = (!ax && !ay) ? step : t.ks;
         t.kx = ax ? k : t.kx; t.ky = ay ? k : t.ky; t.kz = (!ax && !ay) ? k : t.kz;
     }
@@ -853,8 +878,8 @@ __device__ inline double raytrace_to_edge(const KArgs &A, const Lds &l, bool dus
     if (VAR == 4) return raytrace_to_edge_clump(A, l, dust, p, xfreq, kx, ky, kz, nsteps);
     const DGrid &g = A.g;
     Trav t; t.kx = kx; t.ky = ky; t.kz = kz; t.ic = p.ic; t.jc = p.jc; t.kc = p.kc;
-    double tau = 0.0, d = 0.0;
-    if (trav_setup<VAR>(g, l, p.x, p.y, p.z, false, t)) return tau;
+    double tau = 0.0, d = 0.0, xp = p.x, yp = p.y;
+    if (trav_setup<VAR>(g, l, xp, yp, p.z, false, t)) return tau;
     const Cell *c = &g.cell[cidx(g, t.ic, t.jc, t.kc)];
     double Dold = c->Dfreq, u1 = c->vfx * t.kx + c->vfy * t.ky + c->vfz * t.kz;
     double rk = c->rhokap, va = c->voigt_a, rD = c->rhokapD;
@@ -987,12 +1012,17 @@ __device__ inline void raytrace_to_tau(const KArgs &A, const Lds &l, bool dust, 
         p.xfreq_ref = p.xfreq * (Dold / A.par.Dfreq_ref);
         tally_escape(A.par, A.t, p);
     }
-    if (VAR == 1) {                                           // :1935-1946 unfolded path, then fold back into the octant
+    if (VAR == 1 || VAR == 5) {                               // :1935-1946 unfolded path, then fold back into the octant (xysym :2238-2248: x and y only)
         p.x = p.x + d * p.kx; p.y = p.y + d * p.ky; p.z = p.z + d * p.kz;
         if (p.x < g.xmin) p.x = -p.x;
         if (p.y < g.ymin) p.y = -p.y;
-        if (p.z < g.zmin) p.z = -p.z;
+        if (VAR == 1 && p.z < g.zmin) p.z = -p.z;
         p.kx = t.kx; p.ky = t.ky; p.kz = t.kz;
+        p.ic = t.ic; p.jc = t.jc; p.kc = t.kc;
+    } else if (VAR == 6) {                                    // :2509-2514 back into the base period (xrange = nx dx)
+        if (p.inside) { xp = xp + d * t.kx; yp = yp + d * t.ky; zp = zp + d * t.kz; }
+        const double xr = -2.0 * g.xmin, yr = -2.0 * g.ymin;      // grid%xrange = xmax - xmin with xmin = -xmax (grid_mod_car.f90:166-181)
+        p.x = xp - floor((xp - g.xmin) / xr) * xr; p.y = yp - floor((yp - g.ymin) / yr) * yr; p.z = zp;
         p.ic = t.ic; p.jc = t.jc; p.kc = t.kc;
     } else {
         if (p.inside) { p.x = xp + d * t.kx; p.y = yp + d * t.ky; p.z = zp + d * t.kz; }

@@ -13,6 +13,8 @@ extern "C" void lart_launch_transport_var1(int, int, int, dim3, dim3, size_t, hi
 extern "C" void lart_launch_transport_var2(int, int, int, dim3, dim3, size_t, hipStream_t, const KArgs &);
 extern "C" void lart_launch_transport_var3(int, int, int, dim3, dim3, size_t, hipStream_t, const KArgs &);
 extern "C" void lart_launch_transport_var4(int, int, int, dim3, dim3, size_t, hipStream_t, const KArgs &);
+extern "C" void lart_launch_transport_var5(int, int, int, dim3, dim3, size_t, hipStream_t, const KArgs &);
+extern "C" void lart_launch_transport_var6(int, int, int, dim3, dim3, size_t, hipStream_t, const KArgs &);
 
 static thread_local std::string g_err;
 static int fail(const std::string &m) { g_err = m; return 1; }
@@ -388,6 +390,16 @@ static int ensure_pool(lart_gpu *c) {
     return 0;
 }
 
+// the ray-march variant, chosen as setup_procedure does (setup.f90:951-980)
+static int march_variant(const lart_gpu *c) {
+    if (c->is_clump) return 4;
+    if (c->is_amr) return 3;
+    if (c->par.xyz_symmetry) return 1;
+    if (c->par.xy_symmetry) return 5;
+    if (c->par.xy_periodic) return (c->g.nx == 1 && c->g.ny == 1) ? 2 : 6;
+    return 0;
+}
+
 extern "C" int lart_gpu_begin(lart_gpu *c, int64_t first_id, int64_t stride, int64_t count, uint64_t seed) {
     if (!c) return fail("begin: null context");
     if (!c->d_cell) return fail("begin: no medium (call lart_gpu_set_grid_car first)");
@@ -398,7 +410,9 @@ extern "C" int lart_gpu_begin(lart_gpu *c, int64_t first_id, int64_t stride, int
     if (c->par.DGR > 0.0 && !c->has_dust_table) return fail("begin: DGR > 0 but the grid has no rhokapD");
     if (c->is_clump && c->heal_nside > 0) return fail("begin: HEALPix inside observers are not supported with the clump medium (setup.f90:177)");
     if (c->is_amr && c->heal_nside > 0 && c->par.xyz_symmetry) return fail("begin: inside observers need the full octree");
-    if (c->par.xy_periodic && !(c->g.nx == 1 && c->g.ny == 1)) return fail("begin: xy_periodic is supported for nx = ny = 1 (raytrace_to_tau_car_zonly) only");
+    if (c->par.xy_symmetry && (c->par.xyz_symmetry || c->par.xy_periodic || c->is_amr || c->is_clump)) return fail("begin: xy_symmetry is a variant of the plain Cartesian grid only");
+    if (c->par.xy_symmetry && (c->g.i0 < 1 || c->g.j0 < 1 || c->g.i0 > c->g.nx || c->g.j0 > c->g.ny)) return fail("begin: xy_symmetry needs mirror indices i0, j0 inside the grid");
+    if (c->heal_nside > 0 && c->par.xy_symmetry) return fail("begin: HEALPix observers need the plain grid");
     HIPCHK(hipSetDevice(c->device));
     if (!c->d_tally) { if (build_tally(c)) return 1; }
     c->first_id = first_id; c->stride = stride; c->count = count; c->seed = seed;
@@ -432,7 +446,7 @@ extern "C" int lart_gpu_step(lart_gpu *c, int32_t nsteps, int32_t max_events) {
     A.nxim = c->nxim; A.nyim = c->nyim; A.dxim = c->dxim; A.dyim = c->dyim; A.ctl = c->d_ctl; A.heal_nside = c->heal_nside; A.jpa = c->jpa; A.amr = c->amr; A.cl = c->cl; A.rep = c->rep;
     A.first_id = c->first_id; A.stride = c->stride; A.count = c->count; A.seed = c->seed; A.max_events = max_events;
     A.log_nscatt = c->d_log; A.log_xfreq = c->d_log ? c->d_log + c->nlog : nullptr;
-    int var = c->is_clump ? 4 : c->is_amr ? 3 : (c->par.xyz_symmetry ? 1 : (c->par.xy_periodic ? 2 : 0));     // setup.f90:961-990
+    int var = march_variant(c);
     int stokes = c->par.use_stokes ? 1 : 0, dust = c->par.DGR > 0.0 ? 1 : 0, peel = (c->par.save_peeloff && c->nobs > 0) ? 1 : 0;
     dim3 block(c->block), grid((unsigned)(c->pool.n / c->block));
     // Voigt tables + faces | ring of random draws [LART_RNG_BUF][block] | per-block P1, P1_new
@@ -446,7 +460,9 @@ extern "C" int lart_gpu_step(lart_gpu *c, int32_t nsteps, int32_t max_events) {
         else if (var == 1) lart_launch_transport_var1(stokes, dust, peel, grid, block, shmem, c->stream, A);
         else if (var == 2) lart_launch_transport_var2(stokes, dust, peel, grid, block, shmem, c->stream, A);
         else if (var == 3) lart_launch_transport_var3(stokes, dust, peel, grid, block, shmem, c->stream, A);
-        else lart_launch_transport_var4(stokes, dust, peel, grid, block, shmem, c->stream, A);
+        else if (var == 4) lart_launch_transport_var4(stokes, dust, peel, grid, block, shmem, c->stream, A);
+        else if (var == 5) lart_launch_transport_var5(stokes, dust, peel, grid, block, shmem, c->stream, A);
+        else lart_launch_transport_var6(stokes, dust, peel, grid, block, shmem, c->stream, A);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(e1, c->stream));
         c->ev.emplace_back(e0, e1);
@@ -603,7 +619,9 @@ __global__ void k_test_raytrace(KArgs A, int mode, int n, double *r8, int *ic4, 
     else if (var == 1) test_ray_one<1>(A, l, kind, r8 + 8 * i, ic4 + 4 * i, tq ? tq[i] : 0.0, tau_out + i);
     else if (var == 2) test_ray_one<2>(A, l, kind, r8 + 8 * i, ic4 + 4 * i, tq ? tq[i] : 0.0, tau_out + i);
     else if (var == 3) test_ray_one<3>(A, l, kind, r8 + 8 * i, ic4 + 4 * i, tq ? tq[i] : 0.0, tau_out + i);
-    else test_ray_one<4>(A, l, kind, r8 + 8 * i, ic4 + 4 * i, tq ? tq[i] : 0.0, tau_out + i);
+    else if (var == 4) test_ray_one<4>(A, l, kind, r8 + 8 * i, ic4 + 4 * i, tq ? tq[i] : 0.0, tau_out + i);
+    else if (var == 5) test_ray_one<5>(A, l, kind, r8 + 8 * i, ic4 + 4 * i, tq ? tq[i] : 0.0, tau_out + i);
+    else test_ray_one<6>(A, l, kind, r8 + 8 * i, ic4 + 4 * i, tq ? tq[i] : 0.0, tau_out + i);
 }
 __global__ void k_test_vec2pix(int nside, int n, const double *v, int *ipix) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -674,8 +692,8 @@ extern "C" int lart_gpu_test_rand(lart_gpu *c, int32_t what, uint64_t seed, uint
 extern "C" int lart_gpu_test_raytrace(lart_gpu *c, int32_t mode, int32_t n, double *r8, int32_t *ic4, const double *tq, double *tau_out) {
     if (!c || n < 0 || !c->d_cell) return fail("test_raytrace: needs a context with a medium");
     int kind = mode / 10, var = mode % 10;
-    if (kind < 0 || kind > 2 || var < 0 || var > 4 || (kind == 2 && var != 0 && var != 3)) return fail("test_raytrace: bad mode");
-    if ((var == 3) != c->is_amr || (var == 4) != c->is_clump) return fail("test_raytrace: variant 3 needs the octree medium, 4 the clump medium, 0-2 the Cartesian one");
+    if (kind < 0 || kind > 2 || var < 0 || var > 6 || (kind == 2 && var != 0 && var != 3)) return fail("test_raytrace: bad mode");
+    if ((var == 3) != c->is_amr || (var == 4) != c->is_clump) return fail("test_raytrace: variant 3 needs the octree medium, 4 the clump medium, 0-2, 5, 6 the Cartesian one");
     HIPCHK(hipSetDevice(c->device));
     if (!c->d_tally) { if (build_tally(c)) return 1; }
     // host-side shape check before touching the kernel: every start cell must be a valid gather target
@@ -727,7 +745,7 @@ extern "C" int lart_gpu_sightline_tau(lart_gpu *c, double cross0, double *tau_ga
     if (!c->d_cell && !c->is_clump) return fail("sightline_tau: set the medium first");
     if (c->nobs < 1 || c->h_obs.size() != (size_t)c->nobs) return fail("sightline_tau: set the observers first (lart_gpu_set_observers / _heal)");
     if (!(cross0 > 0.0)) return fail("sightline_tau: cross0 (line%cross0) must be > 0");
-    if (c->par.xyz_symmetry || c->par.xy_periodic) return fail("sightline_tau: needs the plain medium (no observers with xyz_symmetry / xy_periodic, setup.f90:198-206)");
+    if (c->par.xyz_symmetry || c->par.xy_periodic || c->par.xy_symmetry) return fail("sightline_tau: needs the plain medium (no observers with xyz_symmetry / xy_periodic, setup.f90:198-206)");
     if (c->is_clump && c->heal_nside > 0) return fail("sightline_tau: HEALPix inside observers are not supported with the clump medium (setup.f90:177)");
     if (c->par.nxfreq < 1) return fail("sightline_tau: nxfreq must be >= 1");
     HIPCHK(hipSetDevice(c->device));

@@ -154,7 +154,8 @@ __device__ inline void sight_car(const KArgs &A, const Lds &l, const SightRay &r
     // the local frame of the start cell (sightline_tau_rect.f90:148-153)
     double xfreq = xf0 * A.par.Dfreq_ref / c->Dfreq - (c->vfx * r.kx + c->vfy * r.ky + c->vfz * r.kz);
     Trav t; t.kx = r.kx; t.ky = r.ky; t.kz = r.kz; t.ic = r.ic; t.jc = r.jc; t.kc = r.kc;
-    if (trav_setup<0>(g, l, r.x, r.y, r.z, false, t)) return;
+    double xs = r.x, ys = r.y;
+    if (trav_setup<0>(g, l, xs, ys, r.z, false, t)) return;
     c = &g.cell[cidx(g, t.ic, t.jc, t.kc)];
     double d = 0.0, Dold = c->Dfreq, u1 = c->vfx * t.kx + c->vfy * t.ky + c->vfz * t.kz;
     for (;;) {

@@ -13,7 +13,7 @@ module lart_gpu_c
 
   !--- struct lart_params (field names = par% / grid% / line% names of the reference)
   type, bind(C) :: lart_params
-     integer(c_int32_t) :: xyz_symmetry, xy_periodic
+     integer(c_int32_t) :: xyz_symmetry, xy_periodic, xy_symmetry
      integer(c_int32_t) :: source_geometry, spectral_type, comoving_source
      integer(c_int32_t) :: recoil, core_skip, core_skip_global, use_stokes, use_reduced_wgt
      integer(c_int32_t) :: save_Jin, save_Jabs, save_Jmu, nmu

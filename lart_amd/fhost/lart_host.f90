@@ -236,7 +236,14 @@ contains
     if (par%include_deuterium) call not_supported('par%include_deuterium = .true.')
     if (trim(par%line_id) /= 'ly_alpha') call not_supported('par%line_id /= ly_alpha')
     if (trim(strlowcase(par%h2_model)) /= 'none') call not_supported('par%h2_model')
-    if (par%xy_symmetry .or. par%z_symmetry) call not_supported('par%xy_symmetry / par%z_symmetry')
+    if (par%z_symmetry) call not_supported('par%z_symmetry')
+    if (par%xy_symmetry) then                       ! mirrors in x and y, the full z range (grid_mod_car.f90:113-134)
+       if (par%xyz_symmetry .or. par%xy_periodic .or. par%use_amr_grid .or. par%use_clump_medium) &
+          call not_supported('par%xy_symmetry together with xyz_symmetry / xy_periodic / octree / clumps')
+       if (trim(par%source_geometry) /= 'point' .or. par%xs_point /= 0.0_wp .or. par%ys_point /= 0.0_wp) &
+          call not_supported('par%xy_symmetry with a source off the z axis (sources are folded for xyz_symmetry only)')
+       if (par%calc_J .or. par%calc_P .or. par%calc_Pnew) call not_supported('par%geometry_JPa = 2 (cylindrical profiles, the xy_symmetry default)')
+    endif
     if (par%bturb > 0.0_wp) call not_supported('par%bturb')
     if (len_trim(par%dens_file) + len_trim(par%temp_file) + len_trim(par%velo_file) + len_trim(par%emiss_file) + &
         len_trim(par%cart_file) + len_trim(par%input_field) + len_trim(par%star_file) > 0) call not_supported('an input field file')
@@ -313,7 +320,9 @@ contains
           if (r0 > 0.0_wp) then
              par%rmax = r0; par%xmax = r0; par%ymax = r0; par%zmax = r0
           endif
-          par%nx = maxval([par%nx, par%ny, par%nz]); par%ny = par%nx; par%nz = par%nx
+          if (.not. par%xy_symmetry) then
+             par%nx = maxval([par%nx, par%ny, par%nz]); par%ny = par%nx; par%nz = par%nx
+          endif
        endif
     case ('rectangle')
        par%rmax = -1.0_wp
@@ -498,6 +507,10 @@ contains
        call sym_axis(nx, grid%xmax, grid%dx, grid%xmin, grid%i0)
        call sym_axis(ny, grid%ymax, grid%dy, grid%ymin, grid%j0)
        call sym_axis(nz, grid%zmax, grid%dz, grid%zmin, grid%k0)
+    else if (par%xy_symmetry) then                                                              ! :113-134
+       call sym_axis(nx, grid%xmax, grid%dx, grid%xmin, grid%i0)
+       call sym_axis(ny, grid%ymax, grid%dy, grid%ymin, grid%j0)
+       grid%dz = 2.0_wp*par%zmax/par%nz; grid%zmin = -grid%zmax; grid%k0 = 0
     else                                                                                        ! :166-176
        grid%dx = 2.0_wp*par%xmax/par%nx; grid%dy = 2.0_wp*par%ymax/par%ny; grid%dz = 2.0_wp*par%zmax/par%nz
        grid%xmin = -grid%xmax; grid%ymin = -grid%ymax; grid%zmin = -grid%zmax
@@ -542,7 +555,7 @@ contains
     else
        opac_length = grid%zrange
     endif
-    if (par%xyz_symmetry) then
+    if (par%xyz_symmetry .or. par%xy_symmetry) then
        nxcen = 1; nycen = 1
     else
        nxcen = (nx+1)/2; nycen = (ny+1)/2
@@ -695,6 +708,9 @@ contains
             if (ii == 1 .and. (nx/2)*2 /= nx) nadd = nadd/2.0_wp
             if (jj == 1 .and. (ny/2)*2 /= ny) nadd = nadd/2.0_wp
             if (kk == 1 .and. (nz/2)*2 /= nz) nadd = nadd/2.0_wp
+         else if (par%xy_symmetry) then
+            if (ii == 1 .and. (nx/2)*2 /= nx) nadd = nadd/2.0_wp
+            if (jj == 1 .and. (ny/2)*2 /= ny) nadd = nadd/2.0_wp
          endif
          if (grid%rhokap(ii,jj,kk) > 0.0_wp) then
             s_tau = s_tau + grid%rhokap(ii,jj,kk)*voigt0(grid%voigt_a(ii,jj,kk))*nadd

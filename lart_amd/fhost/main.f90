@@ -234,7 +234,7 @@ contains
 
   subroutine fill_params(p)
     type(lart_params), intent(out) :: p
-    p%xyz_symmetry = merge(1, 0, par%xyz_symmetry); p%xy_periodic = merge(1, 0, par%xy_periodic)
+    p%xyz_symmetry = merge(1, 0, par%xyz_symmetry); p%xy_periodic = merge(1, 0, par%xy_periodic); p%xy_symmetry = merge(1, 0, par%xy_symmetry)
     p%source_geometry = merge(1, 0, trim(par%source_geometry) == 'uniform_sphere')
     p%spectral_type = merge(1, 0, trim(par%spectral_type) == 'voigt')
     p%comoving_source = merge(1, 0, par%comoving_source)

@@ -59,6 +59,7 @@ class Params:
     core_skip: bool = False
     core_skip_global: bool = False
     xyz_symmetry: bool = False
+    xy_symmetry: bool = False
     xy_periodic: bool = False
     geometry: str = ""
     velocity_type: str = ""
@@ -161,7 +162,7 @@ class Params:
 # default, rejected ("not supported") when set to something that would change the path
 _UNSUPPORTED_DEFAULTS = {
     "fine_structure": False, "include_deuterium": False,
-    "line_id": "ly_alpha", "h2_model": "none", "xy_symmetry": False, "z_symmetry": False, "bturb": -999.0,
+    "line_id": "ly_alpha", "h2_model": "none", "z_symmetry": False, "bturb": -999.0,
     "dens_file": "", "temp_file": "", "velo_file": "", "emiss_file": "", "cart_file": "", "input_field": "",
     "star_file": "", "use_cie_condition": False, "density_rscale": -999.9, "density_zscale": -999.9,
     "density_alpha": 0.0, "cone_opening": 0.0, "Omega": 0.0, "save_all_photons": False, "temperature0": -999.0,
@@ -380,9 +381,17 @@ def read_input(par, line=None):
             c = [v for v in (par.rmax, par.xmax, par.ymax, par.zmax) if v > 0.0]
             if c:
                 par.rmax = par.xmax = par.ymax = par.zmax = max(c)
-            par.nx = par.ny = par.nz = max(par.nx, par.ny, par.nz)
+            if not par.xy_symmetry:
+                par.nx = par.ny = par.nz = max(par.nx, par.ny, par.nz)
     else:
         par.rmax = -1.0
+    if par.xy_symmetry:                                                   # mirrors in x and y, the full z range (grid_mod_car.f90:113-134)
+        if par.xyz_symmetry or par.xy_periodic or par.use_amr_grid or par.use_clump_medium:
+            raise LartInputError("par%xy_symmetry is a variant of the plain Cartesian grid (not with xyz_symmetry / xy_periodic / octree / clumps)")
+        if par.source_geometry != "point" or par.xs_point != 0.0 or par.ys_point != 0.0:
+            raise LartInputError("par%xy_symmetry needs a point source on the z axis (sources are folded for xyz_symmetry only, generate_photon.f90:352-356)")
+        if par.calc_J or par.calc_P or par.calc_Pnew:
+            raise LartInputError("par%geometry_JPa = 2 (cylindrical profiles, the xy_symmetry default) is not supported by this path")
     if par.source_rmax < 0.0:
         par.source_rmax = par.rmax
     if par.rmax <= 0.0:                                                   # geometry of the J/P profiles: setup.f90:438-459
@@ -469,6 +478,10 @@ def grid_create(par, line):
         g.dx, g.xmin, g.i0 = _sym_axis(nx, g.xmax)
         g.dy, g.ymin, g.j0 = _sym_axis(ny, g.ymax)
         g.dz, g.zmin, g.k0 = _sym_axis(nz, g.zmax)
+    elif par.xy_symmetry:                                                 # :113-134
+        g.dx, g.xmin, g.i0 = _sym_axis(nx, g.xmax)
+        g.dy, g.ymin, g.j0 = _sym_axis(ny, g.ymax)
+        g.dz, g.zmin, g.k0 = 2.0 * par.zmax / nz, -g.zmax, 0
     else:
         g.dx, g.dy, g.dz = 2.0 * par.xmax / nx, 2.0 * par.ymax / ny, 2.0 * par.zmax / nz
         g.xmin, g.ymin, g.zmin = -g.xmax, -g.ymax, -g.zmax
@@ -502,7 +515,7 @@ def grid_create(par, line):
         opac_length = (g.zmax - g.zmin) / 2.0
     else:
         opac_length = g.zmax - g.zmin
-    nxcen, nycen = (1, 1) if par.xyz_symmetry else ((nx + 1) // 2, (ny + 1) // 2)
+    nxcen, nycen = (1, 1) if (par.xyz_symmetry or par.xy_symmetry) else ((nx + 1) // 2, (ny + 1) // 2)
     H0 = voigt_center(g.voigt_a)
     pole_k = g.rhokap[nxcen - 1, nycen - 1, :] * H0[nxcen - 1, nycen - 1, :]
     pole_n = g.rhokap[nxcen - 1, nycen - 1, :] * g.Dfreq[nxcen - 1, nycen - 1, :]
@@ -514,6 +527,11 @@ def grid_create(par, line):
             nadd[:, 0, :] /= 2.0
         if nz % 2:
             nadd[:, :, 0] /= 2.0
+    elif par.xy_symmetry:
+        if nx % 2:
+            nadd[0, :, :] /= 2.0
+        if ny % 2:
+            nadd[:, 0, :] /= 2.0
     gas = g.rhokap > 0.0
 
     def pole(v):
@@ -758,7 +776,7 @@ def observer_create(par):
 
 def make_lart_params(par, line, g):
     p = capi.LartParams()
-    for n in ("xyz_symmetry", "xy_periodic", "comoving_source", "recoil", "core_skip", "core_skip_global", "use_stokes",
+    for n in ("xyz_symmetry", "xy_periodic", "xy_symmetry", "comoving_source", "recoil", "core_skip", "core_skip_global", "use_stokes",
               "use_reduced_wgt", "save_Jin", "save_Jabs", "save_Jmu", "nmu", "save_peeloff", "save_peeloff_2D", "save_peeloff_3D"):
         setattr(p, n, int(getattr(par, n)))
     p.source_geometry = {"point": 0, "uniform_sphere": 1}[par.source_geometry]

@@ -58,7 +58,10 @@ def test_product_does_not_touch_the_oracle():
 CASES = [dict(temperature=10.0, taumax=1e6, xyz_symmetry=True, nx=101, ny=101, nz=101, rmax=1.0, nxfreq=201),
          dict(temperature=10.0, taumax=1e4, use_stokes=True, xy_periodic=True, nx=1, ny=1, nz=201, hgg=0.6592, albedo=0.3899),
          dict(temperature=1e4, taumax=1e3, nx=30, ny=30, nz=30, rmax=1.0, nxim=16, nyim=16, use_stokes=True, Vexp=20.0, velocity_type="hubble"),
-         dict(temperature=1e4, N_HI=1e19, nx=21, ny=21, nz=21, geometry="rectangle", nxim=8, nyim=12)]
+         dict(temperature=1e4, N_HI=1e19, nx=21, ny=21, nz=21, geometry="rectangle", nxim=8, nyim=12),
+         dict(temperature=1e4, taumax=1e1, nx=21, ny=21, nz=31, xmax=1.0, ymax=1.0, zmax=1.5, geometry="rectangle", xy_symmetry=True, nxfreq=81),
+         dict(temperature=1e4, tauhomo=1e1, nx=20, ny=14, nz=31, rmax=1.0, xy_symmetry=True, velocity_type="hubble", Vexp=30.0, nxfreq=81),
+         dict(temperature=1e4, taumax=2e1, nx=6, ny=4, nz=21, xmax=0.5, ymax=0.3, zmax=1.0, geometry="rectangle", xy_periodic=True, nxfreq=81)]
 
 
 @pytest.mark.parametrize("kw", CASES)

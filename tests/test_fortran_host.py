@@ -410,3 +410,20 @@ def test_sightline_end_to_end_matches_python_host(exe, tmp_path):
         assert np.allclose(H["TAU_gas"][1], tg[..., k], rtol=1e-12, atol=0) and np.allclose(H["N_gas"][1], ng[..., k], rtol=1e-13, atol=0)
         assert np.allclose(H["TAU_dust"][1], td[..., k], rtol=1e-13, atol=0)
     assert os.path.exists(tmp_path / "sl.h5")                           # the transport run still follows
+
+
+def test_xy_symmetry_dry_run_equals_python_host(exe, tmp_path):
+    """grid_create with par%xy_symmetry (grid_mod_car.f90:113-134): mirror-plane cells count half in the homogeneous depth"""
+    text = ("&parameters\n par%no_photons = 1000\n par%temperature = 1e4\n par%taumax = 1e2\n par%nx = 21\n par%ny = 14\n par%nz = 31\n"
+            " par%rmax = 1.0\n par%nxfreq = 41\n par%xy_symmetry = .true.\n/\n")
+    r = run(exe, text, tmp_path, "--dry-run", name="xys.in")
+    assert r.returncode == 0, r.stdout + r.stderr
+    from lart_amd import host
+    par, line, _ = host.read_input(host.read_namelist(str(tmp_path / "xys.in")))
+    host.grid_create(par, line)
+    m = re.search(r"tau_homo  \(H  I\) :\s+(\S+)", r.stdout)
+    assert m and abs(float(m.group(1)) / par.tauhomo - 1) < 6e-4
+    m = re.search(r"N\(H  I\)_pole     :\s+(\S+)", r.stdout)
+    assert m and abs(float(m.group(1)) / par.N_gasmax - 1) < 6e-4
+    r = run(exe, text.replace("/\n", " par%xs_point = 0.2\n/\n"), tmp_path, "--dry-run", name="xys2.in")
+    assert r.returncode != 0 and "not supported" in r.stdout

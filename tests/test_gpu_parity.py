@@ -69,7 +69,7 @@ def test_other_samplers_device(capi, oracle_mod):
     assert np.allclose(g, o, rtol=1e-9, atol=1e-12)
 
 
-@pytest.mark.parametrize("name", ["car", "xyzsym_odd", "xyzsym_even", "zonly"])
+@pytest.mark.parametrize("name", ["car", "xyzsym_odd", "xyzsym_even", "zonly", "xysym_odd", "xysym_even", "xyper"])
 def test_ray_marches_device_vs_reference_vectors(capi, golden, name):
     """the committed vectors come from the reference's own compiled raytrace_car.f90"""
     from lart_amd import host
@@ -88,7 +88,8 @@ def test_ray_marches_device_vs_reference_vectors(capi, golden, name):
     assert np.array_equal(ic, z["ic_out"])
     assert np.allclose(r, z["r_out"], rtol=1e-10, atol=1e-12)
     _, _, te = sim.ctx.test_raytrace(1, v, z["r_in"], z["ic_in"])
-    assert np.allclose(te, z["tau_edge"], rtol=1e-10, atol=1e-300)
+    ok = np.isfinite(z["tau_edge"])                                      # (rays that never leave a periodic box have no reference value)
+    assert ok.sum() > 0.9 * len(ok) and np.allclose(te[ok], z["tau_edge"][ok], rtol=1e-10, atol=1e-300)
     if v == 0:
         _, _, td = sim.ctx.test_raytrace(2, v, z["r_in"], z["ic_in"], z["dist"])
         assert np.allclose(td, z["tau_dist"], rtol=1e-10, atol=1e-300)
@@ -143,6 +144,29 @@ def test_short_histories_photon_by_photon(capi, oracle_mod, kw, n):
     assert rms_diff(t["Jout"], o.array("Jout")) < 0.01
     if kw.get("save_Jmu"):
         assert rms_diff(t["Jmu"].ravel(order="F"), o.array("Jmu")) < 0.02
+
+
+@pytest.mark.parametrize("kw,n", [
+    (dict(temperature=1e4, taumax=1e1, nx=21, ny=21, nz=31, xmax=1.0, ymax=1.0, zmax=1.5, geometry="rectangle", xy_symmetry=True, nxfreq=81, iseed=41), 30000),
+    (dict(temperature=1e4, taumax=1e1, nx=20, ny=14, nz=31, rmax=1.0, xy_symmetry=True, velocity_type="hubble", Vexp=30.0, save_Jmu=True, nmu=6, nxfreq=81, iseed=42), 30000),
+    (dict(temperature=1e4, taumax=2e1, nx=6, ny=4, nz=21, xmax=0.5, ymax=0.3, zmax=1.0, geometry="rectangle", xy_periodic=True, recoil=True, nxfreq=81, iseed=43), 30000)])
+def test_xy_symmetric_and_periodic_histories_photon_by_photon(capi, oracle_mod, kw, n):
+    """raytrace_*_car_xysym / _car_xyper inside whole photon histories: same streams, same histories as the oracle; the
+    xy-periodic box with a uniform medium must also reproduce the 1-column slab (raytrace_*_car_zonly) statistically"""
+    sim = make(kw); sim.ctx.enable_photon_log(True); sim.run_simulation(n); t = sim.ctx.tallies()
+    o = oracle_of(oracle_mod, kw); o.run(n, seed=kw["iseed"])
+    assert int(o.scalar("raytrace_variant")) == (6 if kw.get("xy_periodic") else 5)
+    ng, xg = sim.ctx.photon_log(n); no, xo = o.photon_log()
+    same = np.isclose(ng, no, rtol=1e-12, atol=0) & np.isclose(xg, xo, rtol=1e-7, atol=1e-9)
+    assert same.mean() > 0.97, same.mean()
+    assert t["nphotons_done"] == n and rms_diff(t["Jout"], o.array("Jout")) < 0.01
+    assert np.isclose(t["n_cellsteps"], o.scalar("n_cellsteps"), rtol=0.02)
+    if kw.get("save_Jmu"):
+        assert rms_diff(t["Jmu"].ravel(order="F"), o.array("Jmu")) < 0.02
+    if kw.get("xy_periodic"):
+        slab = dict(kw, nx=1, ny=1); s1 = make(slab); s1.ctx.enable_photon_log(True); s1.run_simulation(n)
+        n1, _ = s1.ctx.photon_log(n)
+        assert abs(ng.mean() - n1.mean()) < 4 * np.hypot(ng.std(), n1.std()) / np.sqrt(n)
 
 
 def test_scheduling_independence(capi):
