@@ -1083,23 +1083,42 @@ __device__ inline int vec2pix(int nside, double vx, double vy, double vz) {
 // peel-off (next-event estimator): far observers peelingoff_rect.f90, inside observers peelingoff_heal.f90
 // ---------------------------------------------------------------------------------------------
 struct PeelDir { double kx, ky, kz, r2, dist; int ix, iy; bool in_image; };   // dist < 0: march to the grid edge
-__device__ inline PeelDir peel_dir(const KArgs &A, const DObs &o, const Photon &p) {
+// The peel routines of the reference compute the detector pixel first and the optical depth last.  Here the order is turned
+// round: direction -> (cheap, conservative) field-of-view test -> march -> weight; the pixel (two atan2 or vec2pix) and the
+// Stokes rotations are only evaluated for a non-zero weight.  Deep inside an optically thick medium e^-tau is exactly 0 for
+// almost every event, and a zero weight never reached the tallies before either, so the tallies are unchanged.
+__device__ inline PeelDir peel_dir0(const KArgs &A, const DObs &o, const Photon &p) {
     PeelDir q;
     q.kx = o.x - p.x; q.ky = o.y - p.y; q.kz = o.z - p.z;
     q.r2 = q.kx * q.kx + q.ky * q.ky + q.kz * q.kz;
     double r = sqrt(q.r2);
     q.kx = q.kx / r; q.ky = q.ky / r; q.kz = q.kz / r;
-    if (A.heal_nside > 0) {               // inside observer: pixel of -k_obs, tau to the observer (peelingoff_heal.f90:45,60)
-        q.ix = vec2pix(A.heal_nside, -q.kx, -q.ky, -q.kz); q.iy = 1; q.dist = r;
-        q.in_image = (q.ix >= 1 && q.ix <= A.nxim);
-        return q;
+    q.dist = A.heal_nside > 0 ? r : -1.0;      // inside observer: tau to the observer (peelingoff_heal.f90:60)
+    q.ix = 0; q.iy = 0; q.in_image = true;
+    if (A.heal_nside > 0) return q;             // every direction has a HEALPix pixel
+    // far observer: clearly outside the image -> no march (as the reference); anything near the border is decided exactly later
+    double kx = o.rm[0] * q.kx + o.rm[1] * q.ky + o.rm[2] * q.kz, ky = o.rm[3] * q.kx + o.rm[4] * q.ky + o.rm[5] * q.kz, kz = o.rm[6] * q.kx + o.rm[7] * q.ky + o.rm[8] * q.kz;
+    double hx = 0.5 * A.nxim * A.dxim * (1.0 / LART_RAD2DEG), hy = 0.5 * A.nyim * A.dyim * (1.0 / LART_RAD2DEG);
+    if (hx < 1.5 && hy < 1.5 && kz > 0.0) {      // (narrow fields only: tan is monotonic there)
+        double tx = fabs(kx) / kz, ty = fabs(ky) / kz, mx = hx + 1e-6, my = hy + 1e-6;
+        // tan(h) <= h + h^3/3 + 2h^5/15 + h^7 (h < 1.5): an upper bound, so the test never rejects a pixel of the image
+        double bx = mx * (1.0 + mx * mx * (1.0 / 3.0 + mx * mx * (2.0 / 15.0 + mx * mx))), by = my * (1.0 + my * my * (1.0 / 3.0 + my * my * (2.0 / 15.0 + my * my)));
+        if (mx > 0.7) bx = tan(mx); if (my > 0.7) by = tan(my);
+        if (tx > bx * (1.0 + 1e-9) || ty > by * (1.0 + 1e-9)) q.in_image = false;
     }
-    q.dist = -1.0;
+    return q;
+}
+// the pixel, exactly as the reference computes it (peelingoff_rect.f90:595-627 / peelingoff_heal.f90:35-45)
+__device__ inline void peel_pixel(const KArgs &A, const DObs &o, PeelDir &q) {
+    if (A.heal_nside > 0) {
+        q.ix = vec2pix(A.heal_nside, -q.kx, -q.ky, -q.kz); q.iy = 1;
+        q.in_image = (q.ix >= 1 && q.ix <= A.nxim);
+        return;
+    }
     double kx = o.rm[0] * q.kx + o.rm[1] * q.ky + o.rm[2] * q.kz, ky = o.rm[3] * q.kx + o.rm[4] * q.ky + o.rm[5] * q.kz, kz = o.rm[6] * q.kx + o.rm[7] * q.ky + o.rm[8] * q.kz;
     q.ix = (int)floor(atan2(-kx, kz) * LART_RAD2DEG / A.dxim + A.nxim / 2.0) + 1;
     q.iy = (int)floor(atan2(-ky, kz) * LART_RAD2DEG / A.dyim + A.nyim / 2.0) + 1;
     q.in_image = (q.ix >= 1 && q.ix <= A.nxim && q.iy >= 1 && q.iy <= A.nyim);
-    return q;
 }
 __device__ inline size_t pix2(const KArgs &A, int io, int ix, int iy) { return (size_t)io * A.nxim * A.nyim + (size_t)(ix - 1) + (size_t)A.nxim * (size_t)(iy - 1); }
 __device__ inline size_t pix3(const KArgs &A, int io, int ixf, int ix, int iy) {
@@ -1119,7 +1138,8 @@ template <int VAR>
 __device__ inline void peel_direct(const KArgs &A, const Lds &l, bool dust, const Photon &p, unsigned &nsteps) {
     const Cell &c = A.g.cell[cidx(A.g, p.ic, p.jc, p.kc)];
     for (int i = 0; i < A.nobs; i++) {
-        PeelDir q = peel_dir(A, A.obs[i], p);
+        PeelDir q = peel_dir0(A, A.obs[i], p);
+        if (!q.in_image) continue;
         double xfreq_ref, xf = p.xfreq;
         if (VAR == 4 && p.icl > 0) xfreq_ref = p.xfreq + peel_u1<VAR>(A, p, c, q);      // clump frame -> lab frame along the peel direction
         else if (!A.par.comoving_source) {
@@ -1128,9 +1148,11 @@ __device__ inline void peel_direct(const KArgs &A, const Lds &l, bool dust, cons
         } else { double u1 = c.vfx * q.kx + c.vfy * q.ky + c.vfz * q.kz; xfreq_ref = p.xfreq + u1; }
         xfreq_ref = xfreq_ref * (c.Dfreq / A.par.Dfreq_ref);
         int ixf = (int)floor((xfreq_ref - A.par.xfreq_min) / A.par.dxfreq) + 1;
-        if (!q.in_image) continue;
         double tau = raytrace_to_edge<VAR>(A, l, dust, p, xf, q.kx, q.ky, q.kz, q.dist, nsteps);
         double wgt = d_exp_neg(-tau) * (1.0 / (LART_FOURPI * q.r2) * p.wgt);
+        if (wgt == 0.0) continue;
+        peel_pixel(A, A.obs[i], q);
+        if (!q.in_image) continue;
         if (A.par.save_peeloff_2D) { add_if(A.t.c2[1], pix2(A, i, q.ix, q.iy), wgt); if (A.par.use_stokes) add_if(A.t.c2[2], pix2(A, i, q.ix, q.iy), wgt); }
         if (A.par.save_peeloff_3D && ixf >= 1 && ixf <= A.par.nxfreq) { add_if(A.t.c3[1], pix3(A, i, ixf, q.ix, q.iy), wgt); if (A.par.use_stokes) add_if(A.t.c3[2], pix3(A, i, ixf, q.ix, q.iy), wgt); }
     }
@@ -1140,19 +1162,22 @@ template <int VAR>
 __device__ inline void peel_resonance_nostokes(const KArgs &A, const Lds &l, bool dust, const Photon &p, double xfreq_atom, double ux, double uy, double uz, unsigned &nsteps) {
     const Cell &c = A.g.cell[cidx(A.g, p.ic, p.jc, p.kc)];
     for (int i = 0; i < A.nobs; i++) {
-        PeelDir q = peel_dir(A, A.obs[i], p);
+        PeelDir q = peel_dir0(A, A.obs[i], p);
         if (!q.in_image) continue;
         double cost = p.kx * q.kx + p.ky * q.ky + p.kz * q.kz, cost2 = cost * cost, sint = sqrt(1.0 - cost2);
         double rho1 = sqrt(1.0 - p.kz * p.kz) * sint, cosp = 1.0, sinp = 0.0;
         if (rho1 != 0.0) { double rho = 1.0 / rho1; cosp = rho * (cost * p.kz - q.kz); sinp = rho * (p.kx * q.ky - q.kx * p.ky); }
         double xfreq = xfreq_atom + (ux * cosp + uy * sinp) * sint + uz * cost;
         if (A.par.recoil) xfreq = xfreq - (A.par.g_recoil0 / c.Dfreq) * (1.0 - cost);
-        double u1 = peel_u1<VAR>(A, p, c, q);
-        double xfreq_ref = (xfreq + u1) * (c.Dfreq / A.par.Dfreq_ref);
-        int ixf = (int)floor((xfreq_ref - A.par.xfreq_min) / A.par.dxfreq) + 1;
         double tau = raytrace_to_edge<VAR>(A, l, dust, p, xfreq, q.kx, q.ky, q.kz, q.dist, nsteps);
         double peel = 0.75 * A.par.E1 * (cost2 + 1.0) + A.par.E2;
         double wgt = peel / (LART_FOURPI * q.r2) * d_exp_neg(-tau) * p.wgt;
+        if (wgt == 0.0) continue;
+        peel_pixel(A, A.obs[i], q);
+        if (!q.in_image) continue;
+        double u1 = peel_u1<VAR>(A, p, c, q);
+        double xfreq_ref = (xfreq + u1) * (c.Dfreq / A.par.Dfreq_ref);
+        int ixf = (int)floor((xfreq_ref - A.par.xfreq_min) / A.par.dxfreq) + 1;
         if (A.par.save_peeloff_2D) add_if(A.t.c2[0], pix2(A, i, q.ix, q.iy), wgt);
         if (A.par.save_peeloff_3D && ixf >= 1 && ixf <= A.par.nxfreq) add_if(A.t.c3[0], pix3(A, i, ixf, q.ix, q.iy), wgt);
     }
@@ -1181,13 +1206,18 @@ __device__ inline void peel_resonance_stokes(const KArgs &A, const Lds &l, bool 
     const Cell &c = A.g.cell[cidx(A.g, p.ic, p.jc, p.kc)];
     for (int i = 0; i < A.nobs; i++) {
         const DObs &o = A.obs[i];
-        PeelDir q = peel_dir(A, o, p);
+        PeelDir q = peel_dir0(A, o, p);
         if (!q.in_image) continue;
         StokesGeom s = stokes_geom(p, q);
-        double cost2 = s.cost * s.cost, E1 = A.par.E1, E2 = A.par.E2, E3 = A.par.E3;
-        double S22 = 0.75 * E1 * (cost2 + 1.0), S11 = S22 + E2, S12 = 0.75 * E1 * (cost2 - 1.0), S33 = 1.5 * E1 * s.cost, S44 = 1.5 * E3 * s.cost;
         double xfreq = xfreq_atom + (ux * s.cosp + uy * s.sinp) * s.sint + uz * s.cost;
         if (A.par.recoil) xfreq = xfreq - (A.par.g_recoil0 / c.Dfreq) * (1.0 - s.cost);
+        double tau = raytrace_to_edge<VAR>(A, l, dust, p, xfreq, q.kx, q.ky, q.kz, q.dist, nsteps);
+        double wgt = 1.0 / q.r2 * d_exp_neg(-tau) * p.wgt;
+        if (wgt == 0.0) continue;
+        peel_pixel(A, o, q);
+        if (!q.in_image) continue;
+        double cost2 = s.cost * s.cost, E1 = A.par.E1, E2 = A.par.E2, E3 = A.par.E3;
+        double S22 = 0.75 * E1 * (cost2 + 1.0), S11 = S22 + E2, S12 = 0.75 * E1 * (cost2 - 1.0), S33 = 1.5 * E1 * s.cost, S44 = 1.5 * E3 * s.cost;
         double u1 = peel_u1<VAR>(A, p, c, q);
         double xfreq_ref = (xfreq + u1) * (c.Dfreq / A.par.Dfreq_ref);
         int ixf = (int)floor((xfreq_ref - A.par.xfreq_min) / A.par.dxfreq) + 1;
@@ -1196,8 +1226,6 @@ __device__ inline void peel_resonance_stokes(const KArgs &A, const Lds &l, bool 
         double cosg = -(o.rm[0] * s.nx + o.rm[1] * s.ny + o.rm[2] * s.nz), sing = o.rm[3] * s.nx + o.rm[4] * s.ny + o.rm[5] * s.nz;
         double cos2g = 2.0 * cosg * cosg - 1.0, sin2g = 2.0 * cosg * sing;
         double Qdet = cos2g * Qobs + sin2g * Uobs, Udet = -sin2g * Qobs + cos2g * Uobs;
-        double tau = raytrace_to_edge<VAR>(A, l, dust, p, xfreq, q.kx, q.ky, q.kz, q.dist, nsteps);
-        double wgt = 1.0 / q.r2 * d_exp_neg(-tau) * p.wgt;
         stokes_deposit(A, i, q, ixf, wgt, Iobs, Qdet, Udet, Vobs);
     }
 }
@@ -1206,16 +1234,19 @@ template <int VAR>
 __device__ inline void peel_dust_nostokes(const KArgs &A, const Lds &l, const Photon &p, unsigned &nsteps) {
     const Cell &c = A.g.cell[cidx(A.g, p.ic, p.jc, p.kc)];
     for (int i = 0; i < A.nobs; i++) {
-        PeelDir q = peel_dir(A, A.obs[i], p);
+        PeelDir q = peel_dir0(A, A.obs[i], p);
         if (!q.in_image) continue;
-        double u1 = peel_u1<VAR>(A, p, c, q);
-        double xfreq_ref = (p.xfreq + u1) * (c.Dfreq / A.par.Dfreq_ref);
-        int ixf = (int)floor((xfreq_ref - A.par.xfreq_min) / A.par.dxfreq) + 1;
         double tau = raytrace_to_edge<VAR>(A, l, true, p, p.xfreq, q.kx, q.ky, q.kz, q.dist, nsteps);
         double cosa = p.kx * q.kx + p.ky * q.ky + p.kz * q.kz, hgg = A.par.hgg;
         double b = (1.0 + hgg * hgg) - 2.0 * hgg * cosa;
         double peel = (1.0 - hgg * hgg) / (b * sqrt(b)) / LART_FOURPI;
         double wgt = peel / q.r2 * d_exp_neg(-tau) * p.wgt;
+        if (wgt == 0.0) continue;
+        peel_pixel(A, A.obs[i], q);
+        if (!q.in_image) continue;
+        double u1 = peel_u1<VAR>(A, p, c, q);
+        double xfreq_ref = (p.xfreq + u1) * (c.Dfreq / A.par.Dfreq_ref);
+        int ixf = (int)floor((xfreq_ref - A.par.xfreq_min) / A.par.dxfreq) + 1;
         if (A.par.save_peeloff_2D) add_if(A.t.c2[0], pix2(A, i, q.ix, q.iy), wgt);
         if (A.par.save_peeloff_3D && ixf >= 1 && ixf <= A.par.nxfreq) add_if(A.t.c3[0], pix3(A, i, ixf, q.ix, q.iy), wgt);
     }
@@ -1226,11 +1257,16 @@ __device__ inline void peel_dust_stokes(const KArgs &A, const Lds &l, const Phot
     const Cell &c = A.g.cell[cidx(A.g, p.ic, p.jc, p.kc)];
     for (int i = 0; i < A.nobs; i++) {
         const DObs &o = A.obs[i];
-        PeelDir q = peel_dir(A, o, p);
+        PeelDir q = peel_dir0(A, o, p);
+        if (!q.in_image) continue;
+        double tau = raytrace_to_edge<VAR>(A, l, true, p, p.xfreq, q.kx, q.ky, q.kz, q.dist, nsteps);
+        double wgt = 1.0 / q.r2 * d_exp_neg(-tau) * p.wgt;
+        if (wgt == 0.0) continue;
+        peel_pixel(A, o, q);
+        if (!q.in_image) continue;
         double u1 = peel_u1<VAR>(A, p, c, q);
         double xfreq_ref = (p.xfreq + u1) * (c.Dfreq / A.par.Dfreq_ref);
         int ixf = (int)floor((xfreq_ref - A.par.xfreq_min) / A.par.dxfreq) + 1;
-        if (!q.in_image) continue;
         StokesGeom s = stokes_geom(p, q);
         const DMueller &m = A.mu;
         double S11 = interp_eq(m.nPDF, m.coss, m.S11, s.cost), S12 = interp_eq(m.nPDF, m.coss, m.S12, s.cost);
@@ -1241,8 +1277,6 @@ __device__ inline void peel_dust_stokes(const KArgs &A, const Lds &l, const Phot
         double cosg = -(o.rm[0] * s.nx + o.rm[1] * s.ny + o.rm[2] * s.nz), sing = o.rm[3] * s.nx + o.rm[4] * s.ny + o.rm[5] * s.nz;
         double cos2g = 2.0 * cosg * cosg - 1.0, sin2g = 2.0 * cosg * sing;
         double Qdet = cos2g * Qobs + sin2g * Uobs, Udet = -sin2g * Qobs + cos2g * Uobs;
-        double tau = raytrace_to_edge<VAR>(A, l, true, p, p.xfreq, q.kx, q.ky, q.kz, q.dist, nsteps);
-        double wgt = 1.0 / q.r2 * d_exp_neg(-tau) * p.wgt;
         stokes_deposit(A, i, q, ixf, wgt, Iobs, Qdet, Udet, Vobs);
     }
 }
