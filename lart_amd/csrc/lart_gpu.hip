@@ -450,7 +450,7 @@ extern "C" int lart_gpu_step(lart_gpu *c, int32_t nsteps, int32_t max_events) {
     int stokes = c->par.use_stokes ? 1 : 0, dust = c->par.DGR > 0.0 ? 1 : 0, peel = (c->par.save_peeloff && c->nobs > 0) ? 1 : 0;
     dim3 block(c->block), grid((unsigned)(c->pool.n / c->block));
     // Voigt tables + faces | ring of random draws [LART_RNG_BUF][block] | per-block P1, P1_new
-    size_t shmem = (size_t)(VT_END + c->g.nx + c->g.ny + c->g.nz + 3 + LART_RNG_BUF * c->block + 2 * c->jpa.lds_bins) * sizeof(double);
+    size_t shmem = (size_t)(VT_END + c->g.nx + c->g.ny + c->g.nz + 3 + LART_RNG_BUF * c->block + 2 * c->jpa.lds_bins) * sizeof(double) + (size_t)LART_COOP_BYTES * ((c->block + 63) / 64);   // ... + the wave-local scratch of vz_core_coop
     if (shmem > 160 * 1024) return fail("step: grid faces do not fit the 160 KiB LDS");
     for (int s = 0; s < nsteps; s++) {
         hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
@@ -634,7 +634,7 @@ __device__ void test_scatter_one(const KArgs &A, const Lds &l, double *st, int *
     p.ic = ic[0]; p.jc = ic[1]; p.kc = ic[2]; p.inside = true;
     if (VAR == 4) { p.icl = ic[0]; p.ic = 1; p.jc = 1; p.kc = 1; }
     Rng g; g.init(seed, id, 0); unsigned np = 0;
-    scatter_event<VAR, STOKES, DUST, false>(A, l, g, p, np);
+    scatter_event<VAR, STOKES, DUST, false>(A, l, g, p, np, true);
     st[0] = p.x; st[1] = p.y; st[2] = p.z; st[3] = p.kx; st[4] = p.ky; st[5] = p.kz; st[6] = p.xfreq; st[7] = p.wgt;
     st[8] = p.mx; st[9] = p.my; st[10] = p.mz; st[11] = p.nx; st[12] = p.ny; st[13] = p.nz; st[14] = 1.0; st[15] = p.Q; st[16] = p.U; st[17] = p.V;
     ic[3] = p.inside ? 1 : 0; *nd = (long long)g.n;

@@ -70,6 +70,8 @@ __global__ __launch_bounds__(256, LART_WAVES(STOKES, PEEL)) void transport_kerne
         l_.jp_P = jp; l_.jp_Pn = jp + A.jpa.lds_bins;
         __syncthreads();
     }
+    // wave-local scratch of the cooperative sampler, behind everything else: LART_COOP_BYTES per wave
+    l_.coop = (unsigned char *)(sh + VT_END + (A.g.nx + A.g.ny + A.g.nz + 3) + (size_t)LART_RNG_BUF * blockDim.x + 2 * (size_t)A.jpa.lds_bins) + LART_COOP_BYTES * (threadIdx.x >> 6);
     const Lds l = l_;
     double *rng_lds = sh + VT_END + (A.g.nx + A.g.ny + A.g.nz + 3) + threadIdx.x;      // [LART_RNG_BUF][blockDim.x] draws
     const lart_params &par = A.par;
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(256, LART_WAVES(STOKES, PEEL)) void transport_kerne
 #endif
         LART_PROF_TRIP(p, 2);
         fly<VAR, DUST>(A, l, g, p, first, nsteps);
-        if (p.inside) { scatter_event<VAR, STOKES, DUST, PEEL>(A, l, g, p, npeel); nev++; budget--; }
+        { const bool on = p.inside; scatter_event<VAR, STOKES, DUST, PEEL>(A, l, g, p, npeel, on); if (on) { nev++; budget--; } }
         LART_PROF_MARK(p, 6);
         if (!p.inside) {
             nsg_done += p.nsg; nsd_done += p.nsd; ndone++;
