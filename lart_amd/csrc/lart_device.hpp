@@ -181,6 +181,10 @@ __device__ inline void mulhilo32(uint32_t k, uint32_t v, uint32_t &hi, uint32_t 
 #ifndef LART_PHILOX_ROUNDS
 #define LART_PHILOX_ROUNDS 10      // Philox4x32-10 (the KAT-pinned default of Salmon et al. 2011); tuning builds only change this to measure
 #endif
+// orders LDS exchanges between the lanes of ONE wave (its LDS pipeline is in order: this only constrains the compiler)
+#define LART_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#define LART_COOP_BYTES 192          // wave-local LDS scratch of the cooperative samplers
+
 struct Rng {
     uint32_t k0, k1; uint64_t id, n; double spare;          // spare: second half of the last slow block, valid while n is odd
     // ring of LART_RNG_BUF (= 16) draws in LDS: draw i of the packet lives in slot i & 15 of this lane's column;
@@ -381,6 +385,126 @@ struct Photon {
 // ---------------------------------------------------------------------------------------------
 // samplers
 // ---------------------------------------------------------------------------------------------
+// The |x| > 1 sampler with its rejection loop run by the whole wave (see vz_core_coop).  Few lanes are in this branch at a
+// time (~16 % on the headline workload) and each needs ~1.15 tries, but the wave used to issue 2.4 passes until the last
+// of them was done.  Here the branch lanes compute their comparison function (stage A, as before), then every lane of the
+// wave evaluates one try of one of them: helper j of a target reads the target's draws n + d j .. (d = 2 or 3 draws per try)
+// from its LDS ring and evaluates exactly that try; the first accepted try wins (stage B); the winner's window (pb, delt)
+// goes back to the target, which draws the velocity inside it (stage C).  Same tries, same order, same draws.
+__device__ inline double vz_wing_coop(Rng &g, bool mine, double x0in, double a, unsigned char *wl) {
+    const double xc = 2.414213562373095048801688724209698, two_over_PI = 2.0 / LART_PI;
+    const unsigned lane = __lane_id();
+    const double x0 = fabs(x0in);
+    // --- stage A: the comparison function in beta-space (random_mt.f90:2588-2640), wing lanes only
+    double beta0 = 0.0, dbeta = 0.0, beta1 = 0.0, hA = 0.0, hB = 0.0, thr0 = 0.0, thr1 = 0.0;
+    int mode = 0;                                 // 0: single segment; 1: three segments; 2: two segments (dbeta = 0)
+    if (mine) {
+        const double x0sq = x0 * x0;
+        beta0 = d_exp_neg(-x0sq / 2.0);
+        const double h0_two = beta0 / a, h0 = h0_two / 2.0;
+        double S0 = beta0 * h0, S1 = 0.0, S2;
+        beta1 = beta0; hA = h0; mode = 1;
+        if (x0 < xc) {
+            dbeta = sqrt(two_over_PI * a * (1.0 - beta0) * beta0 * x0); beta1 = beta0 + dbeta;
+            double pb1 = sqrt(-2.0 * d_log(beta1));
+            hB = two_over_PI * beta1 * pb1 / (x0sq - pb1 * pb1);
+            S1 = dbeta * h0; S2 = (1.0 - beta1) * hB;
+        } else {
+            double h2 = 0.3861 / (x0sq - 1.373);
+            if (h0_two < h2) { mode = 0; hB = h2; S2 = 1.0; }
+            else if (h0 < h2) { mode = 2; hB = h2; S2 = (1.0 - beta0) * h2; }
+            else {
+                dbeta = sqrt(two_over_PI * a * (1.0 - beta0) * beta0 * x0); beta1 = beta0 + dbeta;
+                double pb1 = sqrt(-2.0 * d_log(beta1));
+                double h1 = two_over_PI * beta1 * pb1 / (x0sq - pb1 * pb1);
+                hB = h1 > h2 ? h1 : h2;
+                S1 = dbeta * h0; S2 = (1.0 - beta1) * hB;
+            }
+        }
+        const double Stot = S0 + S1 + S2;
+        thr0 = S0 / Stot; thr1 = 1.0 - S2 / Stot;
+    }
+    // --- stage B: the tries, by everybody
+    typedef __attribute__((address_space(3))) unsigned lds_u32;
+    typedef __attribute__((address_space(3))) unsigned char lds_u8;
+    lds_u32 *key = (lds_u32 *)wl; lds_u8 *tgt = (lds_u8 *)wl + 128;
+    bool pending = mine;
+    double pb = 0.0, delt = 0.0;
+    for (;;) {
+        const unsigned long long F = __ballot(pending);
+        if (F == 0ULL) break;
+        const unsigned dper = mode == 0 ? 2u : 3u;            // draws per try of this lane
+        const bool helpable = pending && g.have >= dper;
+        const unsigned long long H = __ballot(helpable), M = __ballot(1);
+        const int nH = __popcll(H), nM = __popcll(M);
+        const bool solo_pass = (nH == 0 || nH > 32);          // dry rings, or no room in the slot table: everybody for itself
+        if (pending && (solo_pass || !helpable)) {            // one classical try (same arithmetic as below)
+            double beta, Cb, rS = 2.0, u, acc;
+            if (mode == 0) g.next2(u, acc); else { g.next2(rS, u); acc = g.next(); }
+            if (mode == 0) { beta = u; Cb = hB; }
+            else if (rS < thr0)      { beta = beta0 * sqrt(u); Cb = beta / a; }
+            else if (mode == 2)      { beta = beta0 + (1.0 - beta0) * u; Cb = hB; }
+            else if (rS < thr1)      { beta = beta0 + dbeta * u; Cb = hA; }
+            else                     { beta = beta1 + (1.0 - beta1) * u; Cb = hB; }
+            pb = sqrt(-2.0 * d_log(beta));
+            const double den = fma(x0 - pb, x0 + pb, a * a);
+            delt = atan((2.0 * pb * a) / den); if (den < 0.0) delt = delt + LART_PI;
+            if (acc * Cb < (beta / (a * LART_PI)) * delt) pending = false;
+        }
+        if (solo_pass) continue;
+        const unsigned long long below = (1ULL << lane) - 1ULL;
+        const int rs = __popcll(H & below);
+        int K = nM / nH; if (K > LART_RNG_BUF / 2) K = LART_RNG_BUF / 2;
+        const int r = __popcll(M & below), j = r / nH, s = r - j * nH;
+        if (helpable) { tgt[rs] = (unsigned char)lane; key[rs] = 0xFFFFFFFFu; }
+        LART_WAVE_SYNC();
+        const int T = tgt[s];
+        // the target's state.  Cross-lane reads only at converged points (a shuffle from a lane that is masked off reads 0):
+        // what only segmented comparison functions need is fetched under wave-uniform conditions
+        const unsigned nT = __shfl((unsigned)g.n, T), haveT = __shfl(g.have, T); const int modeT = __shfl(mode, T);
+        const double x0T = __shfl(x0, T), aT = __shfl(a, T), hBT = __shfl(hB, T);
+        double beta0T = 0.0, thr0T = 0.0, thr1T = 0.0, beta1T = 0.0, dbetaT = 0.0, hAT = 0.0;
+        if (__ballot(helpable && mode != 0) != 0ULL) { beta0T = __shfl(beta0, T); thr0T = __shfl(thr0, T); }
+        if (__ballot(helpable && mode == 1) != 0ULL) { thr1T = __shfl(thr1, T); beta1T = __shfl(beta1, T); dbetaT = __shfl(dbeta, T); hAT = __shfl(hA, T); }
+        const unsigned dT = modeT == 0 ? 2u : 3u;
+        double pbh = 0.0, delth = 0.0;
+        if (j < min(K, (int)(haveT / dT))) {
+            const double *col = g.lbuf + (T - (int)lane);
+            const unsigned i0 = nT + dT * (unsigned)j;
+            const double d0 = col[(i0 & (LART_RNG_BUF - 1)) * g.stride], d1 = col[((i0 + 1u) & (LART_RNG_BUF - 1)) * g.stride];
+            double beta, Cb, acc;
+            if (modeT == 0) { beta = d0; Cb = hBT; acc = d1; }
+            else {
+                acc = col[((i0 + 2u) & (LART_RNG_BUF - 1)) * g.stride];
+                if (d0 < thr0T)       { beta = beta0T * sqrt(d1); Cb = beta / aT; }
+                else if (modeT == 2)  { beta = beta0T + (1.0 - beta0T) * d1; Cb = hBT; }
+                else if (d0 < thr1T)  { beta = beta0T + dbetaT * d1; Cb = hAT; }
+                else                  { beta = beta1T + (1.0 - beta1T) * d1; Cb = hBT; }
+            }
+            pbh = sqrt(-2.0 * d_log(beta));
+            const double den = fma(x0T - pbh, x0T + pbh, aT * aT);
+            delth = atan((2.0 * pbh * aT) / den); if (den < 0.0) delth = delth + LART_PI;
+            if (acc * Cb < (beta / (aT * LART_PI)) * delth) __hip_atomic_fetch_min(&key[s], ((unsigned)j << 8) | lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+        LART_WAVE_SYNC();
+        const unsigned kb = helpable ? key[rs] : 0xFFFFFFFFu;
+        const int src = kb != 0xFFFFFFFFu ? (int)(kb & 63u) : (int)lane;
+        const double pbw = __shfl(pbh, src), deltw = __shfl(delth, src);
+        if (helpable) {
+            const unsigned tried = (unsigned)min(K, (int)(g.have / dper));
+            const unsigned used = dper * (kb != 0xFFFFFFFFu ? (kb >> 8) + 1u : tried);
+            g.n += used; g.have -= used;
+            if (kb != 0xFFFFFFFFu) { pb = pbw; delt = deltw; pending = false; }
+        }
+    }
+    // --- stage C: the velocity inside the accepted window (:2683-2693)
+    double vz = 0.0;
+    if (mine) {
+        const double t1 = atan((-pb - x0) / a);
+        vz = x0 + a * d_tan(delt * g.next() + t1);
+    }
+    return x0in < 0.0 ? -vz : vz;
+}
 // atom velocity parallel to k: random_mt.f90:2562-2696 (rand_resonance_vz_seon)
 // |x| <= 1: Lorentzian proposal, Gaussian rejection (random_mt.f90:2579-2586)
 __device__ inline double vz_core(Rng &g, double x0in, double a LART_PROF_ARG(pp)) {
@@ -409,7 +533,6 @@ __device__ inline double vz_core(Rng &g, double x0in, double a LART_PROF_ARG(pp)
 // wl: 192 bytes of wave-local LDS (the headline configuration has < 1 KB of LDS to spare per workgroup at 4 workgroups per
 // CU): key[32] u32 = (first accepted try << 8) | lane that evaluated it, per slot; tgt[32] u8 = target lane of the slot.
 // With more than half of the lanes pending there is no helper to spare and everybody just takes its own next try.
-#define LART_COOP_BYTES 192
 __device__ inline double vz_core_coop(Rng &g, bool mine, double x0in, double a, unsigned char *wl) {
     const unsigned lane = __lane_id();
     const double x0 = fabs(x0in);
@@ -425,7 +548,6 @@ __device__ inline double vz_core_coop(Rng &g, bool mine, double x0in, double a, 
     typedef __attribute__((address_space(3))) unsigned lds_u32;
     typedef __attribute__((address_space(3))) unsigned char lds_u8;
     lds_u32 *key = (lds_u32 *)wl; lds_u8 *tgt = (lds_u8 *)wl + 128;
-#define LART_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
     for (;;) {
         const unsigned long long F = __ballot(pending);
         if (F == 0ULL) break;
@@ -1518,9 +1640,15 @@ __device__ inline void scatter_event(const KArgs &A, const Lds &l, Rng &g, Photo
     if (on) go = scatter_pre<VAR, STOKES, DUST, PEEL>(A, l, g, p, npeel, sc);
     const bool core = go && fabs(sc.xloc) <= 1.0;
     double uz_loc;
-    if (l.coop) uz_loc = vz_core_coop(g, core, sc.xloc, sc.va, l.coop);
-    else uz_loc = core ? vz_core(g, sc.xloc, sc.va) : 0.0;
-    if (go && !core) uz_loc = vz_wing(g, sc.xloc, sc.va);
+    if (l.coop) {
+        uz_loc = vz_core_coop(g, core, sc.xloc, sc.va, l.coop);
+#ifdef LART_NO_WING_COOP
+        if (go && !core) uz_loc = vz_wing(g, sc.xloc, sc.va);
+#else
+        const double uw = vz_wing_coop(g, go && !core, sc.xloc, sc.va, l.coop);
+        if (go && !core) uz_loc = uw;
+#endif
+    } else { uz_loc = core ? vz_core(g, sc.xloc, sc.va) : 0.0; if (go && !core) uz_loc = vz_wing(g, sc.xloc, sc.va); }
     if (go) scatter_post<VAR, STOKES, DUST, PEEL>(A, l, g, p, npeel, sc, uz_loc);
 #endif
 }
