@@ -58,7 +58,7 @@ module lart_define
      integer  :: nmu = 11
      real(wp) :: mu_min = -1.0_wp, dmu = 0.0_wp
      logical  :: save_peeloff = .false., save_peeloff_2D = .false., save_peeloff_3D = .true.
-     logical  :: save_sightline_tau = .false., save_direc0 = .false., save_all_photons = .false.
+     logical  :: save_sightline_tau = .false., save_direc0 = .false., save_all_photons = .false., save_radial_profile = .false.
      integer  :: intensity_unit = -999
      real(wp) :: hgg = 0.6761, albedo = 0.3253, cext_dust = 1.6059e-21, DGR = 0.0
      character(len=128) :: scatt_mat_file = ''

@@ -257,10 +257,12 @@ contains
     character(len=*), intent(in) :: filename
     type(grid_type), intent(in) :: g
     type(out_file) :: o
-    type(key_list) :: kl, ki
+    type(key_list) :: kl, ki, ko, k0
     character(len=16) :: names(6)
-    real(wp), allocatable :: cols(:,:)
-    integer :: ncol, fmt
+    character(len=8) :: tail
+    real(wp), allocatable :: cols(:,:), rad(:,:)
+    integer :: ncol, fmt, io, nxi, nyi
+    k0%n = 0
     fmt = out_format_of(trim(strlowcase(par%file_format)))
     ncol = 4; names(1:4) = [character(len=16) :: 'Xfreq', 'velocity', 'wavelength', 'Jout']
     if (par%save_Jabs) then
@@ -329,25 +331,184 @@ contains
     if (allocated(prof_P1_new)) call out_image(o, 'Pa_1D_new', shape(prof_P1_new), prof_P1_new, ki)
     call out_close(o, .true.)
     write(6,'(2a)') 'output written: ', trim(o%path)
+    !--- peel-off images: one set of files per observer (write_output_rect.f90:742-1350), <base>_obs[_kkk] / <base>_stokes[_kkk]
+    !    for the (nxfreq,nxim,nyim) cubes, <base>_obs2D[_kkk] / <base>_stokes_2D[_kkk] for the frequency-integrated images
     if (par%save_peeloff .and. par%nobs > 0) then
-       call out_open(o, trim(par%base_name)//'_obs', fmt)
-       if (allocated(obs_scatt)) then
-          call out_image(o, 'Scattered', shape(obs_scatt), obs_scatt, ki)
-          call out_image(o, 'Direct', shape(obs_direc), obs_direc, ki)
-       endif
-       if (allocated(obs_scatt_2D)) then
-          call out_image(o, 'Scattered_2D', shape(obs_scatt_2D), obs_scatt_2D, ki)
-          call out_image(o, 'Direct_2D', shape(obs_direc_2D), obs_direc_2D, ki)
-       endif
-       call out_close(o, .true.)
-       if (par%use_stokes .and. allocated(obs_I)) then
-          call out_open(o, trim(par%base_name)//'_stokes', fmt)
-          call out_image(o, 'Stokes_I', shape(obs_I), obs_I, ki)
-          call out_image(o, 'Stokes_Q', shape(obs_Q), obs_Q, ki)
-          call out_image(o, 'Stokes_U', shape(obs_U), obs_U, ki)
-          call out_image(o, 'Stokes_V', shape(obs_V), obs_V, ki)
-          call out_close(o, .true.)
-       endif
+       do io = 1, par%nobs
+          tail = ''
+          if (par%nobs > 1) write(tail,'(a,i3.3)') '_', io
+          call peel_keys(ko, io, g)
+          if (allocated(obs_scatt)) then
+             nxi = size(obs_scatt, 2); nyi = size(obs_scatt, 3)
+             call out_open(o, trim(par%base_name)//'_obs'//trim(tail), fmt)
+             if (par%nside > 0) then                     ! write_output_heal.f90: (nxfreq, npix) maps
+                call out_image(o, 'Scattered', [g%nxfreq, nxi], obs_scatt(:,:,1,io), ko)
+                call out_image(o, 'Direct',    [g%nxfreq, nxi], obs_direc(:,:,1,io), k0)
+             else
+                call out_image(o, 'Scattered', [g%nxfreq, nxi, nyi], obs_scatt(:,:,:,io), ko)
+                call out_image(o, 'Direct',    [g%nxfreq, nxi, nyi], obs_direc(:,:,:,io), k0)
+             endif
+             if (par%save_radial_profile .and. par%nside == 0) then
+                call radial_profiles(g, io, .false., rad)
+                call out_table(o, 'RadialI', [character(len=16) :: 'r', 'I'], rad(:,1:2), k0)
+             endif
+             call out_close(o, .true.)
+             if (par%use_stokes .and. allocated(obs_I)) then
+                call out_open(o, trim(par%base_name)//'_stokes'//trim(tail), fmt)
+                call out_image(o, 'Stokes_I', [g%nxfreq, nxi, nyi], obs_I(:,:,:,io), ko)
+                call out_image(o, 'Stokes_Q', [g%nxfreq, nxi, nyi], obs_Q(:,:,:,io), k0)
+                call out_image(o, 'Stokes_U', [g%nxfreq, nxi, nyi], obs_U(:,:,:,io), k0)
+                call out_image(o, 'Stokes_V', [g%nxfreq, nxi, nyi], obs_V(:,:,:,io), k0)
+                if (par%save_radial_profile .and. par%nside == 0) then
+                   call radial_profiles(g, io, .false., rad, stokes=.true.)
+                   call out_table(o, 'Stokes_radial', [character(len=16) :: 'r', 'I', 'Q', 'U', 'V', 'pol'], rad, k0)
+                endif
+                call out_close(o, .true.)
+             endif
+          endif
+          if (allocated(obs_scatt_2D)) then
+             nxi = size(obs_scatt_2D, 1); nyi = size(obs_scatt_2D, 2)
+             call out_open(o, trim(par%base_name)//'_obs2D'//trim(tail), fmt)
+             if (par%nside > 0) then
+                call out_image(o, 'Scattered', [nxi], obs_scatt_2D(:,1,io), ko)
+                call out_image(o, 'Direct',    [nxi], obs_direc_2D(:,1,io), k0)
+             else
+                call out_image(o, 'Scattered', [nxi, nyi], obs_scatt_2D(:,:,io), ko)
+                call out_image(o, 'Direct',    [nxi, nyi], obs_direc_2D(:,:,io), k0)
+             endif
+             if (par%save_radial_profile .and. par%nside == 0) then
+                call radial_profiles(g, io, .true., rad)
+                call out_table(o, 'RadialI', [character(len=16) :: 'r', 'I'], rad(:,1:2), k0)
+             endif
+             call out_close(o, .true.)
+             if (par%use_stokes .and. allocated(obs_I_2D)) then
+                call out_open(o, trim(par%base_name)//'_stokes_2D'//trim(tail), fmt)
+                call out_image(o, 'Stokes_I', [nxi, nyi], obs_I_2D(:,:,io), ko)
+                call out_image(o, 'Stokes_Q', [nxi, nyi], obs_Q_2D(:,:,io), k0)
+                call out_image(o, 'Stokes_U', [nxi, nyi], obs_U_2D(:,:,io), k0)
+                call out_image(o, 'Stokes_V', [nxi, nyi], obs_V_2D(:,:,io), k0)
+                if (par%save_radial_profile .and. par%nside == 0) then
+                   call radial_profiles(g, io, .true., rad, stokes=.true.)
+                   call out_table(o, 'Stokes_radial', [character(len=16) :: 'r', 'I', 'Q', 'U', 'V', 'pol'], rad, k0)
+                endif
+                call out_close(o, .true.)
+             endif
+          endif
+       enddo
     endif
   end subroutine write_output
+
+  !--- keywords of the first section of a peel-off file (write_output_rect.f90:1093-1160)
+  subroutine peel_keys(k, io, g)
+    type(key_list), intent(out) :: k
+    integer, intent(in) :: io
+    type(grid_type), intent(in) :: g
+    k%n = 0
+    call kadd(k, 'EQUINOX', 2000, 'Equinox of Ref. Coord.')
+    if (par%nside > 0) then
+       call kadd(k, 'NSIDE', par%nside, 'HEALPIX nside')
+       call kadd(k, 'NPIX',  par%npix,  'HEALPIX npix')
+    else
+       call kadd(k, 'CTYPE1', 'WAVE', 'vacuum wavelength (FITS WCS)')
+       call kadd(k, 'CUNIT1', 'Angstrom', 'wavelength unit')
+       call kadd(k, 'CRPIX1', 1.0_wp, 'reference pixel for spectral axis')
+       call kadd(k, 'CRVAL1', g%wavelength(1), 'wavelength at CRPIX1 (Angstrom)')
+       call kadd(k, 'CD1_1', -g%dwave, 'wavelength step (Angstrom/pixel)')
+       call kadd(k, 'CTYPE2', 'RA--TAN', 'Coordinate Type')
+       call kadd(k, 'CUNIT2', 'deg', 'RA unit')
+       call kadd(k, 'CRPIX2', (par%nxim + 1)/2.0_wp, 'Reference Pixel in X')
+       call kadd(k, 'CRVAL2', 0.0_wp, 'R.A. (Degree)')
+       call kadd(k, 'CD2_2', par%dxim, 'Degree / Pixel')
+       call kadd(k, 'CTYPE3', 'DEC-TAN', 'Coordinate Type')
+       call kadd(k, 'CUNIT3', 'deg', 'DEC unit')
+       call kadd(k, 'CRPIX3', (par%nyim + 1)/2.0_wp, 'Reference Pixel in Y')
+       call kadd(k, 'CRVAL3', 0.0_wp, 'Dec  (Degree)')
+       call kadd(k, 'CD3_3', par%dyim, 'Degree / Pixel')
+       call kadd(k, 'alpha', par%alpha(io), 'alpha (degree)')
+       call kadd(k, 'beta',  par%beta(io),  'beta (degree)')
+       call kadd(k, 'gamma', par%gamma(io), 'gamma (degree)')
+    endif
+    call kadd(k, 'DISTANCE', par%distance, 'Distance')
+    call kadd(k, 'DISTUNIT', trim(par%distance_unit), 'Distance Unit')
+    call kadd(k, 'DIST_CM', par%distance2cm, 'Distance Unit (cm)')
+    call kadd(k, 'Xfreq1', g%xfreq_min, 'Xfreq_min')
+    call kadd(k, 'Xfreq2', g%xfreq_max, 'Xfreq_max')
+    call kadd(k, 'Dxfreq', g%dxfreq, 'Dxfreq')
+    call kadd(k, 'Dwave', g%dwave, 'Dwavelength (angstrom)')
+    call kadd(k, 'I_unit', par%intensity_unit, 'Intensity Unit (0:no dimension, 1:cm^-2 A^-1)')
+    call kadd(k, 'Dfreq', g%Dfreq_ref, 'Doppler Freq.  (Hz)')
+    call kadd(k, 'nphotons', real(par%nphotons, wp), 'number of photons')
+    call kadd(k, 'obsx', observer(io)%x, 'Observer X coordinate')
+    call kadd(k, 'obsy', observer(io)%y, 'Observer Y coordinate')
+    call kadd(k, 'obsz', observer(io)%z, 'Observer Z coordinate')
+  end subroutine peel_keys
+
+  !--- make_radial_intensity / make_radial_stokes (output_sum_rect.f90:489-658): azimuthal means of the (normalised) peel-off
+  !    image about its centre; rad(:,1) = r, (:,2) = I, and with stokes (:,3:6) = Q, U, V, pol in the radial frame
+  subroutine radial_profiles(g, io, use_2D, rad, stokes)
+    type(grid_type), intent(in) :: g
+    integer, intent(in) :: io
+    logical, intent(in) :: use_2D
+    real(wp), allocatable, intent(out) :: rad(:,:)
+    logical, intent(in), optional :: stokes
+    integer :: nr, i, j, ir, nxi, nyi
+    integer, allocatable :: ncount(:)
+    real(wp) :: xcen, ycen, xx, yy, rr, cosp, sinp, cos2p, sin2p, unit, vi, vq, vu, vv
+    logical :: st
+    st = .false.
+    if (present(stokes)) st = stokes
+    unit = g%dxfreq
+    if (par%intensity_unit == 1) unit = g%dwave
+    nxi = par%nxim; nyi = par%nyim
+    nr = (max(nxi, nyi) + 1)/2
+    allocate(rad(nr, 6), ncount(nr)); rad = 0.0_wp; ncount = 0
+    if (mod(nr, 2) == 0) then
+       rad(:,1) = [((i - 0.5_wp)/nr, i = 1, nr)]
+    else
+       rad(:,1) = [((i - 1.0_wp)/(nr - 0.5_wp), i = 1, nr)]
+    endif
+    xcen = (nxi + 1.0_wp)/2.0_wp; ycen = (nxi + 1.0_wp)/2.0_wp          ! (the reference uses nxim for both)
+    do j = 1, nyi
+       yy = j - ycen
+       do i = 1, nxi
+          xx = i - xcen
+          rr = sqrt(xx**2 + yy**2)
+          if (mod(nr, 2) == 0) then
+             ir = floor(rr) + 1
+          else
+             ir = floor(rr + 0.5_wp) + 1
+          endif
+          if (ir < 1 .or. ir > nr) cycle
+          ncount(ir) = ncount(ir) + 1
+          if (.not. st) then
+             if (use_2D) then
+                rad(ir,2) = rad(ir,2) + obs_scatt_2D(i,j,io) + obs_direc_2D(i,j,io)
+             else
+                rad(ir,2) = rad(ir,2) + (sum(obs_scatt(:,i,j,io)) + sum(obs_direc(:,i,j,io)))*unit
+             endif
+             cycle
+          endif
+          if (rr == 0.0_wp) then
+             cosp = 1.0_wp; sinp = 0.0_wp
+          else
+             cosp = yy/rr; sinp = -xx/rr
+          endif
+          cos2p = 2.0_wp*cosp**2 - 1.0_wp; sin2p = 2.0_wp*cosp*sinp
+          if (use_2D) then
+             vi = obs_I_2D(i,j,io); vq = obs_Q_2D(i,j,io)*cos2p + obs_U_2D(i,j,io)*sin2p
+             vu = -obs_Q_2D(i,j,io)*sin2p + obs_U_2D(i,j,io)*cos2p; vv = obs_V_2D(i,j,io)
+          else
+             vi = sum(obs_I(:,i,j,io))*unit; vq = sum(obs_Q(:,i,j,io)*cos2p + obs_U(:,i,j,io)*sin2p)*unit
+             vu = sum(-obs_Q(:,i,j,io)*sin2p + obs_U(:,i,j,io)*cos2p)*unit; vv = sum(obs_V(:,i,j,io))*unit
+          endif
+          rad(ir,2) = rad(ir,2) + vi; rad(ir,3) = rad(ir,3) + vq; rad(ir,4) = rad(ir,4) + vu; rad(ir,5) = rad(ir,5) + vv
+       enddo
+    enddo
+    do ir = 1, nr
+       if (ncount(ir) > 0) then
+          rad(ir,2:5) = rad(ir,2:5)/ncount(ir)
+          if (st .and. rad(ir,2) > 0.0_wp) rad(ir,6) = sqrt(rad(ir,3)**2 + rad(ir,4)**2)/rad(ir,2)
+       endif
+    enddo
+  end subroutine radial_profiles
 end program LaRT_amd

@@ -161,7 +161,7 @@ def read_h5(path):
 @pytest.mark.gpu
 def test_end_to_end_matches_python_host(exe, tmp_path):
     text = ("&parameters\n par%no_photons = 30000\n par%iseed = 5\n par%temperature = 1e4\n par%taumax = 1e2\n par%nx = 31\n par%ny = 31\n"
-            " par%nz = 31\n par%rmax = 1.0\n par%nxfreq = 81\n par%nxim = 12\n par%nyim = 12\n par%use_stokes = .true.\n par%save_peeloff_2D = .true.\n par%file_format = 'fits'\n/\n")
+            " par%nz = 31\n par%rmax = 1.0\n par%nxfreq = 81\n par%nxim = 12\n par%nyim = 12\n par%use_stokes = .true.\n par%save_peeloff_2D = .true.\n par%save_radial_profile = .true.\n par%file_format = 'fits'\n/\n")
     r = run(exe, text, tmp_path, name="e2e.in")
     assert r.returncode == 0, r.stdout + r.stderr
     assert "Average Number of scattering" in r.stdout
@@ -176,10 +176,25 @@ def test_end_to_end_matches_python_host(exe, tmp_path):
     assert np.allclose(spec[1]["Jout"], t["Jout"], rtol=1e-9, atol=1e-15)
     assert np.allclose(spec[1]["Jin"], t["Jin"], rtol=1e-9, atol=1e-15)
     assert np.isclose(float(spec[0]["Nsc_tot"]), t["nscatt_tot"], rtol=1e-9)
+    # one set of files per observer, cubes in <base>_obs / <base>_stokes, images in <base>_obs2D / <base>_stokes_2D
     obs = read_fits(str(tmp_path / "e2e_obs.fits.gz"))
-    assert np.allclose(obs["Scattered"][1][..., 0], t["scatt"][..., 0], rtol=1e-6, atol=1e-12 * t["scatt"].max())
+    assert list(obs) == ["Scattered", "Direct", "RadialI"] and obs["Scattered"][1].shape == (81, 12, 12)
+    assert np.allclose(obs["Scattered"][1], t["scatt"][..., 0], rtol=1e-6, atol=1e-12 * t["scatt"].max())
+    assert obs["Scattered"][0]["CTYPE2"].strip() == "RA--TAN" and float(obs["Scattered"][0]["CRPIX2"]) == 6.5
     stk = read_fits(str(tmp_path / "e2e_stokes.fits.gz"))
-    assert np.allclose(stk["Stokes_Q"][1][..., 0], t["Q"][..., 0], rtol=1e-6, atol=1e-9 * np.abs(t["I"]).max())
+    assert list(stk) == ["Stokes_I", "Stokes_Q", "Stokes_U", "Stokes_V", "Stokes_radial"]
+    assert np.allclose(stk["Stokes_Q"][1], t["Q"][..., 0], rtol=1e-6, atol=1e-9 * np.abs(t["I"]).max())
+    o2 = read_fits(str(tmp_path / "e2e_obs2D.fits.gz")); s2 = read_fits(str(tmp_path / "e2e_stokes_2D.fits.gz"))
+    assert np.allclose(o2["Direct"][1], t["direc_2D"][..., 0], rtol=1e-6, atol=1e-12 * t["direc_2D"].max())
+    assert np.allclose(s2["Stokes_U"][1], t["U_2D"][..., 0], rtol=1e-6, atol=1e-9 * np.abs(t["I_2D"]).max())
+    # make_radial_intensity / make_radial_stokes (output_sum_rect.f90:489-658)
+    ri = host.radial_profiles(sim.par, sim.grid, t); rs = host.radial_profiles(sim.par, sim.grid, t, stokes=True)
+    r2 = host.radial_profiles(sim.par, sim.grid, t, use_2D=True, stokes=True)
+    assert np.allclose(obs["RadialI"][1]["r"], ri[:, 0]) and np.allclose(obs["RadialI"][1]["I"], ri[:, 1], rtol=1e-6, atol=1e-12 * ri[:, 1].max())
+    for c, k in enumerate(("r", "I", "Q", "U", "V", "pol")):
+        assert np.allclose(stk["Stokes_radial"][1][k], rs[:, c], rtol=1e-5, atol=1e-8 * np.abs(rs[:, 1]).max()), k
+        assert np.allclose(s2["Stokes_radial"][1][k], r2[:, c], rtol=1e-5, atol=1e-8 * np.abs(r2[:, 1]).max()), k
+    assert rs[:, 5].max() > 0.0                                         # a resolved sphere is radially polarised
 
 
 CLUMP_IN = """&parameters
@@ -233,7 +248,7 @@ def test_clump_end_to_end_matches_python_host(exe, tmp_path):
     assert np.allclose(spec[1]["Jout"], t["Jout"], rtol=1e-9, atol=1e-15)           # same clumps, same seed, same photon ids
     assert np.isclose(float(spec[0]["Nsc_tot"]), t["nscatt_tot"], rtol=1e-9)
     obs = read_fits(str(tmp_path / "clump_obs.fits.gz"))
-    assert np.allclose(obs["Scattered"][1][..., 0], t["scatt"][..., 0], rtol=1e-6, atol=1e-12 * t["scatt"].max())
+    assert np.allclose(obs["Scattered"][1], t["scatt"][..., 0], rtol=1e-6, atol=1e-12 * t["scatt"].max())
 
 
 AMR_IN = """&parameters
@@ -305,8 +320,8 @@ def test_output_containers_hdf5_and_gzip_fits(exe, tmp_path):
     assert H["Spectrum"][0]["taumax"] == 100.0 and H["Spectrum"][0]["nx"] == 11 and H["Spectrum"][0]["xyz_sym"] == 0
     assert H["Jmu"][1].shape == (41, 5) and F["Jmu"][1].shape == (41, 5)
     S = read_h5(str(tmp_path / "ch_stokes.h5")); O = read_h5(str(tmp_path / "ch_obs.h5"))
-    assert list(S) == ["Stokes_I", "Stokes_Q", "Stokes_U", "Stokes_V"] and S["Stokes_Q"][1].shape == (41, 8, 8, 1)
-    assert list(O) == ["Scattered", "Direct"] and O["Direct"][1].shape == (41, 8, 8, 1)
+    assert list(S) == ["Stokes_I", "Stokes_Q", "Stokes_U", "Stokes_V"] and S["Stokes_Q"][1].shape == (41, 8, 8)
+    assert list(O) == ["Scattered", "Direct"] and O["Direct"][1].shape == (41, 8, 8)
     assert list(read_fits(str(tmp_path / "cf_obs.fits.gz"))) == ["Scattered", "Direct"]
 
 
@@ -357,23 +372,25 @@ def test_healpix_inside_observers_dry_run(exe, tmp_path):
     r = run(exe, HEAL_IN, tmp_path, "--dry-run-write", name="heal.in")
     assert r.returncode == 0, r.stdout + r.stderr
     assert re.search(r"HEALPix inside observers: nside = 4\s+npix = 192", r.stdout) and re.search(r"observers:\s+2\b", r.stdout)
-    O = read_h5(str(tmp_path / "heal_obs.h5"))
-    assert O["Scattered"][1].shape == (41, 192, 1, 2) and O["Direct"][1].shape == (41, 192, 1, 2)
-    assert not os.path.exists(tmp_path / "heal_stokes.h5")               # setup.f90:183: no Stokes vectors for an inside observer
+    for k in (1, 2):                                                     # one file per observer, (nxfreq, npix) maps
+        O = read_h5(str(tmp_path / ("heal_obs_%03d.h5" % k)))
+        assert O["Scattered"][1].shape == (41, 192) and O["Direct"][1].shape == (41, 192) and O["Scattered"][0]["NSIDE"] == 4
+    assert not os.path.exists(tmp_path / "heal_stokes_001.h5")               # setup.f90:183: no Stokes vectors for an inside observer
 
 
 @pytest.mark.gpu
 def test_healpix_end_to_end_matches_python_host(exe, tmp_path):
     r = run(exe, HEAL_IN, tmp_path, name="heal.in")
     assert r.returncode == 0, r.stdout + r.stderr
-    O = read_h5(str(tmp_path / "heal_obs.h5"))
     from lart_amd import host
     sim = host.Simulation(host.read_namelist(str(tmp_path / "heal.in")))
     sim.run_simulation()
     t = sim.output_normalize()
     assert t["scatt"].max() > 0 and t["direc"].max() > 0
-    for sec, k in (("Scattered", "scatt"), ("Direct", "direc")):
-        assert np.allclose(O[sec][1], t[k].reshape(O[sec][1].shape, order="F") if t[k].shape != O[sec][1].shape else t[k], rtol=1e-8, atol=1e-12 * t[k].max()), sec
+    for io in (0, 1):
+        O = read_h5(str(tmp_path / ("heal_obs_%03d.h5" % (io + 1))))
+        for sec, k in (("Scattered", "scatt"), ("Direct", "direc")):
+            assert np.allclose(O[sec][1], t[k][:, :, 0, io], rtol=1e-8, atol=1e-12 * t[k].max()), sec
 
 
 SIGHT_IN = ("&parameters\n par%no_photons = 2000\n par%temperature = 1e4\n par%taumax = 1e3\n par%nx = 21\n par%ny = 21\n par%nz = 21\n"
