@@ -318,6 +318,7 @@ struct orc_sim {
     double atau3;
     /* --- line (line_mod.f90:1241-1270) --- */
     double cross0, vtherm1, damping, wavelength0, g_recoil0, E1, E2, E3;
+    int fine_structure, line_type; double DnuHK_Hz;     /* line_type 2: Ly-alpha doublet 2P1/2 (H) + 2P3/2 (K), line_mod.f90:1241-1270 */
     /* --- grid (define.f90:117-206) --- */
     int i0, j0, k0;
     double xmin, ymin, zmin, dx, dy, dz, xrange, yrange, zrange;
@@ -345,6 +346,12 @@ static int grid_create_amr(orc_sim *s);
 static int create_JPa_amr_mem(orc_sim *s);
 static int amr_JPa_bin(const orc_sim *s, int il, double x0, double y0, double z0);
 static void amr_xcrit_local(const orc_sim *s, int il, double x, double y, double z, double *xc, double *xc2);
+/* calc_voigt1 / calc_voigt2 (line_mod.f90:38-62): the line profile of a cell with Voigt parameter a and Doppler width Dfreq */
+static inline double calc_voigt(const orc_sim *s, double xfreq, double a, double Dfreq) {
+    if (s->line_type == 2) { double DnuHK = s->DnuHK_Hz / Dfreq;
+        return orc_voigt(xfreq + DnuHK, a) * (1.0 / 3.0) + orc_voigt(xfreq, a) * (2.0 / 3.0); }
+    return orc_voigt(xfreq, a);
+}
 #define IDX(s,i,j,k) ((size_t)((i)-1) + (size_t)(s)->nx * ((size_t)((j)-1) + (size_t)(s)->ny * (size_t)((k)-1)))
 
 /* per-thread accumulators, merged after the run */
@@ -378,7 +385,7 @@ static int set_param(orc_sim *s, const char *k, const char *v) {
 #define I(name) if (!strcmp(k, #name)) { s->name = atoi(v); return 0; }
 #define B(name) if (!strcmp(k, #name)) { s->name = parse_bool(v); return 0; }
     D(no_photons) I(iseed) D(temperature) D(taumax) D(tauhomo) D(Vexp) D(Vx) D(Vy) D(Vz)
-    B(comoving_source) B(recoil) B(core_skip) B(core_skip_global) B(xyz_symmetry) B(xy_periodic) B(xy_symmetry)
+    B(comoving_source) B(recoil) B(core_skip) B(core_skip_global) B(xyz_symmetry) B(xy_periodic) B(xy_symmetry) B(fine_structure)
     I(nx) I(ny) I(nz) D(xmax) D(ymax) D(zmax) D(rmax) D(rmin) D(xs_point) D(ys_point) D(zs_point) D(source_rmax)
     D(xfreq0) I(nxfreq) B(use_stokes) B(use_reduced_wgt) B(save_Jin) B(save_Jabs) B(save_Jmu) I(nmu)
     D(hgg) D(albedo) D(cext_dust) D(DGR) D(distance2cm) B(save_peeloff) B(save_peeloff_2D) B(save_peeloff_3D)
@@ -428,7 +435,12 @@ static int set_param(orc_sim *s, const char *k, const char *v) {
 /* line constants, Ly-alpha default branch: line_mod.f90:1241-1270 */
 static void setup_line(orc_sim *s) {
     const double sigma_0 = 0.026540083434, amu = 1.67262192e-24, vtherm1_amu = 0.12895319011972164, mass_amu = 1.00797;
-    s->E1 = 1.0; s->E2 = 0.0; s->E3 = 1.0;
+    s->E1 = 1.0; s->E2 = 0.0; s->E3 = 1.0; s->line_type = 1; s->DnuHK_Hz = 0.0;
+    if (s->fine_structure) {                                /* :1250-1253: delE_Hz(2) = (82259.2850014 - 82258.9191133) cm^-1 * c */
+        const double speedc_cm = 2.99792458e5 * 1.0e5;
+        double d1 = 82259.2850014 * speedc_cm, d2 = 82258.9191133 * speedc_cm;
+        s->line_type = 2; s->DnuHK_Hz = d1 - d2;
+    }
     s->wavelength0 = 0.1215668237310;
     s->damping = 6.2649e8;
     s->cross0 = sigma_0 / sqrt(PI) * (0.27760 + 0.13881 + 0.0);
@@ -685,9 +697,9 @@ static int grid_create(orc_sim *s) {
     if (!(isfinite(s->par_xfreq_max) && isfinite(s->par_xfreq_min))) {
         double xscale = (s->taumax <= 5e1) ? 25.0 : (s->taumax <= 5e2) ? 14.0 : (s->taumax <= 5e3) ? 10.0 : 5.0;
         double vt = vtherm_total(s, s->temperature);
-        if (s->Vexp == 0.0) { s->par_xfreq_max = floor(xscale * s->atau3) + 1; s->par_xfreq_min = -(floor(xscale * s->atau3 + 0.0) + 1); }
-        else if (s->Vexp > 0.0) { s->par_xfreq_max = floor(xscale * s->atau3) + 1; s->par_xfreq_min = -(floor(xscale * s->atau3 + fabs(s->Vexp) / vt + 0.0) + 1); }
-        else { s->par_xfreq_max = floor(xscale * s->atau3 + fabs(s->Vexp) / vt) + 1; s->par_xfreq_min = -(floor(xscale * s->atau3 + 0.0) + 1); }
+        if (s->Vexp == 0.0) { s->par_xfreq_max = floor(xscale * s->atau3) + 1; s->par_xfreq_min = -(floor(xscale * s->atau3 + s->DnuHK_Hz / s->Dfreq_ref) + 1); }
+        else if (s->Vexp > 0.0) { s->par_xfreq_max = floor(xscale * s->atau3) + 1; s->par_xfreq_min = -(floor(xscale * s->atau3 + fabs(s->Vexp) / vt + s->DnuHK_Hz / s->Dfreq_ref) + 1); }
+        else { s->par_xfreq_max = floor(xscale * s->atau3 + fabs(s->Vexp) / vt) + 1; s->par_xfreq_min = -(floor(xscale * s->atau3 + s->DnuHK_Hz / s->Dfreq_ref) + 1); }
     }
     s->dxfreq = (s->par_xfreq_max - s->par_xfreq_min) / s->nxfreq;
     s->xfreq_max = s->par_xfreq_max; s->xfreq_min = s->par_xfreq_min;
@@ -859,6 +871,7 @@ orc_sim *orc_create(const char *params) {
         if (set_param(s, k, eq + 1)) { free(buf); free(s); return NULL; }
     }
     free(buf);
+    setup_line(s);                                          /* again: par%fine_structure selects the line type */
     if (read_input_post(s) || (s->use_clump_medium ? grid_create_clump(s) : s->use_amr_grid ? (grid_create_amr(s) || create_JPa_amr_mem(s)) : (grid_create(s) || create_JPa_mem(s))) || observer_create(s)) { free(s); return NULL; }
     return s;
 }
@@ -1063,9 +1076,9 @@ static int grid_create_amr(orc_sim *s) {
     }
     if (!(isfinite(s->par_xfreq_max) && isfinite(s->par_xfreq_min))) {
         double xscale = (s->taumax <= 5e1) ? 25.0 : (s->taumax <= 5e2) ? 14.0 : (s->taumax <= 5e3) ? 10.0 : 5.0, vt = vtherm_total(s, s->temperature);
-        if (s->Vexp == 0.0) { s->par_xfreq_max = floor(xscale * s->atau3) + 1.0; s->par_xfreq_min = -(floor(xscale * s->atau3 + 0.0) + 1.0); }
-        else if (s->Vexp > 0.0) { s->par_xfreq_max = floor(xscale * s->atau3) + 1.0; s->par_xfreq_min = -(floor(xscale * s->atau3 + fabs(s->Vexp) / vt + 0.0) + 1.0); }
-        else { s->par_xfreq_max = floor(xscale * s->atau3 + fabs(s->Vexp) / vt) + 1.0; s->par_xfreq_min = -(floor(xscale * s->atau3 + 0.0) + 1.0); }
+        if (s->Vexp == 0.0) { s->par_xfreq_max = floor(xscale * s->atau3) + 1.0; s->par_xfreq_min = -(floor(xscale * s->atau3 + s->DnuHK_Hz / s->Dfreq_ref) + 1.0); }
+        else if (s->Vexp > 0.0) { s->par_xfreq_max = floor(xscale * s->atau3) + 1.0; s->par_xfreq_min = -(floor(xscale * s->atau3 + fabs(s->Vexp) / vt + s->DnuHK_Hz / s->Dfreq_ref) + 1.0); }
+        else { s->par_xfreq_max = floor(xscale * s->atau3 + fabs(s->Vexp) / vt) + 1.0; s->par_xfreq_min = -(floor(xscale * s->atau3 + s->DnuHK_Hz / s->Dfreq_ref) + 1.0); }
     }
     s->dxfreq = (s->par_xfreq_max - s->par_xfreq_min) / s->nxfreq; s->xfreq_max = s->par_xfreq_max; s->xfreq_min = s->par_xfreq_min;
     s->Jout = calloc(s->nxfreq, 8); s->Jin = calloc(s->nxfreq, 8); s->Jabs = calloc(s->nxfreq, 8); s->Jmu = calloc((size_t)s->nxfreq * (s->nmu > 0 ? s->nmu : 1), 8);
@@ -1151,7 +1164,7 @@ static void raytrace_to_tau_amr(const orc_sim *s, acc_t *A, photon_t *p, double 
     while (p->inside) {
         int ic = a->icell_of_leaf[il-1], iface; double t_exit;
         amr_cell_exit(a, ic, x, y, z, kx, ky, kz, &t_exit, &iface);
-        double rhokapH = s->rhokap[il-1] * orc_voigt(p->xfreq, s->voigt_a[il-1]), rhokap = rhokapH;
+        double rhokapH = s->rhokap[il-1] * calc_voigt(s, p->xfreq, s->voigt_a[il-1], s->Dfreq[il-1]), rhokap = rhokapH;
         if (s->DGR > 0.0) rhokap = rhokap + s->rhokapD[il-1];
         A->n_cellsteps += 1.0;
         if (tau + t_exit * rhokap >= tau_in) {
@@ -1188,7 +1201,7 @@ static double raytrace_to_edge_amr(const orc_sim *s, const photon_t *p, double d
     for (;;) {
         int ic = a->icell_of_leaf[il-1], iface; double t_exit;
         amr_cell_exit(a, ic, x, y, z, kx, ky, kz, &t_exit, &iface);
-        double rhokap = s->rhokap[il-1] * orc_voigt(xfreq, s->voigt_a[il-1]);
+        double rhokap = s->rhokap[il-1] * calc_voigt(s, xfreq, s->voigt_a[il-1], s->Dfreq[il-1]);
         if (s->DGR > 0.0) rhokap = rhokap + s->rhokapD[il-1];
         if (nsteps) *nsteps += 1.0;
         if (dist >= 0.0 && d + t_exit >= dist) { tau = tau + (dist - d) * rhokap; return tau; }
@@ -1212,9 +1225,14 @@ static double raytrace_to_edge_amr(const orc_sim *s, const photon_t *p, double d
  * photon%xfreq is in REF Doppler units (cl_Dfreq_ref) throughout; shifted by -/+ ulos_clump at clump entry/exit.
  * ===================================================================================== */
 /* voigt_clump (line type 1): clump_mod.f90:130-170; kappa_clump :176-182; ulos_clump :184-190 */
-static inline double voigt_clump(const clumps_t *c, double xfreq, int64_t icl) { return orc_voigt(xfreq * (c->Dfreq_ref / c->Dfreq[icl-1]), c->voigt_a[icl-1]); }
+static inline double voigt_clump(const orc_sim *s, double xfreq, int64_t icl) {
+    const clumps_t *c = &s->cl; double xloc = xfreq * (c->Dfreq_ref / c->Dfreq[icl-1]);
+    if (s->line_type == 2) { double Dnu = s->DnuHK_Hz / c->Dfreq[icl-1];
+        return orc_voigt(xloc + Dnu, c->voigt_a[icl-1]) * (1.0 / 3.0) + orc_voigt(xloc, c->voigt_a[icl-1]) * (2.0 / 3.0); }
+    return orc_voigt(xloc, c->voigt_a[icl-1]);
+}
 static inline double kappa_clump(const orc_sim *s, double xfreq, int64_t icl) {
-    const clumps_t *c = &s->cl; double kap = c->rhokap[icl-1] * voigt_clump(c, xfreq, icl);
+    const clumps_t *c = &s->cl; double kap = c->rhokap[icl-1] * voigt_clump(s, xfreq, icl);
     if (s->DGR > 0.0) kap = kap + c->rhokapD[icl-1];
     return kap;
 }
@@ -1644,7 +1662,7 @@ static void raytrace_to_tau(const orc_sim *s, acc_t *A, photon_t *p, double tau_
     double u1 = udot(s, IDX(s,iold,jold,kold), t.kx, t.ky, t.kz), u2;
     while (p->inside) {
         size_t c = IDX(s,t.icell,t.jcell,t.kcell);
-        rhokapH = s->rhokap[c] * orc_voigt(p->xfreq, s->voigt_a[c]);
+        rhokapH = s->rhokap[c] * calc_voigt(s, p->xfreq, s->voigt_a[c], s->Dfreq[c]);
         rhokap = (s->DGR > 0.0) ? rhokapH + s->rhokapD[c] : rhokapH;
         A->n_cellsteps += 1.0;
         int idx = (variant == 2) ? 3 : minloc3(t.tx, t.ty, t.tz);
@@ -1726,7 +1744,7 @@ static double raytrace_to_edge(const orc_sim *s, const photon_t *p, int variant,
     double u1 = udot(s, IDX(s,iold,jold,kold), t.kx, t.ky, t.kz), u2, xfreq = p->xfreq, rhokap;
     for (;;) {
         size_t c = IDX(s,t.icell,t.jcell,t.kcell);
-        rhokap = s->rhokap[c] * orc_voigt(xfreq, s->voigt_a[c]);
+        rhokap = s->rhokap[c] * calc_voigt(s, xfreq, s->voigt_a[c], s->Dfreq[c]);
         if (s->DGR > 0.0) rhokap = rhokap + s->rhokapD[c];
         if (nsteps) *nsteps += 1.0;
         int idx = (variant == 2) ? 3 : minloc3(t.tx, t.ty, t.tz);
@@ -1971,24 +1989,37 @@ static void peeling_dust_stokes(const orc_sim *s, acc_t *A, const photon_t *p) {
  * Scattering: scattering_car.f90
  * ===================================================================================== */
 /* do_resonance1: line_mod.f90:108-139 */
+/* do_resonance1 / do_resonance2 (line_mod.f90:108-192) and their clump forms (line_clump_mod.f90:30-110: local Doppler units and back) */
 static void do_resonance1(const orc_sim *s, rng_t *g, photon_t *p, double *uz, double *xfreq_atom, double *cost, double *sint,
                           double *S11, double *S22, double *S12, double *S33, double *S44) {
-    if (s->use_clump_medium) {                          /* do_resonance1_clump: line_clump_mod.f90:30-59 (local Doppler units and back) */
-        const clumps_t *c = &s->cl; int64_t icl = p->icell_clump;
-        double scale = c->Dfreq_ref / c->Dfreq[icl-1], scale_inv = 1.0 / scale, xfreq_loc = p->xfreq * scale;
-        double uz_loc = rand_resonance_vz(g, xfreq_loc, c->voigt_a[icl-1]);
-        *xfreq_atom = (xfreq_loc - uz_loc) * scale_inv; *uz = uz_loc * scale_inv;
+    double scale = 1.0, scale_inv = 1.0, va, Df;
+    if (s->use_clump_medium) { const clumps_t *c = &s->cl; int64_t icl = p->icell_clump;
+        scale = c->Dfreq_ref / c->Dfreq[icl-1]; scale_inv = 1.0 / scale; va = c->voigt_a[icl-1]; Df = c->Dfreq[icl-1]; }
+    else { size_t c = IDX(s,p->icell,p->jcell,p->kcell); va = s->voigt_a[c]; Df = s->Dfreq[c]; }
+    const double xfreq_loc = s->use_clump_medium ? p->xfreq * scale : p->xfreq;
+    double uz_loc, xatom_loc;
+    if (s->line_type == 2) {                                /* fine structure: pick the 2P1/2 (H) or 2P3/2 (K) level by its share of the profile */
+        double DnuHK = s->DnuHK_Hz / Df;
+        double pH = orc_voigt(xfreq_loc + DnuHK, va) * (1.0 / 3.0), pK = orc_voigt(xfreq_loc, va) * (2.0 / 3.0);
+        pH = pH / (pH + pK);
+        if (rnd(g) < pH) uz_loc = rand_resonance_vz(g, xfreq_loc + DnuHK, va); else uz_loc = rand_resonance_vz(g, xfreq_loc, va);
+        xatom_loc = xfreq_loc - uz_loc;
+        double qH = xatom_loc + DnuHK, qK = xatom_loc;
+        p->E1 = (2.0 * qK * qH + qH * qH) / (qK * qK + 2.0 * qH * qH);             /* E1 of the atom-frame frequency */
+        p->E2 = 1.0 - p->E1; p->E3 = (p->E1 + 2.0) / 3.0;
     } else {
-    *uz = rand_resonance_vz(g, p->xfreq, s->voigt_a[IDX(s,p->icell,p->jcell,p->kcell)]);
-    *xfreq_atom = p->xfreq - *uz;
+        uz_loc = rand_resonance_vz(g, xfreq_loc, va);
+        xatom_loc = xfreq_loc - uz_loc;
+        p->E1 = s->E1; p->E2 = s->E2; p->E3 = s->E3;
     }
-    p->E1 = s->E1; p->E2 = s->E2; p->E3 = s->E3;
+    if (s->use_clump_medium) { *xfreq_atom = xatom_loc * scale_inv; *uz = uz_loc * scale_inv; }
+    else { *uz = uz_loc; *xfreq_atom = xatom_loc; }
     *cost = rand_resonance(g, p->E1);
     double cost2 = (*cost) * (*cost);
     *sint = sqrt(1.0 - cost2);
-    if (S44) { *S22 = 0.75 * p->E1 * (cost2 + 1.0); *S11 = *S22 + p->E2; *S12 = 0.75 * p->E1 * (cost2 - 1.0); *S33 = 1.5 * p->E1 * (*cost); *S44 = 1.5 * p->E3 * (*cost); }
+    if (S44) { *S22 = 0.75 * p->E1 * (cost2 + 1.0); *S11 = *S22 + p->E2; *S12 = 0.75 * p->E1 * (cost2 - 1.0); *S33 = 1.5 * p->E1 * (*cost);
+               *S44 = (s->line_type == 2) ? (p->E1 + 2.0) / 2.0 * (*cost) : 1.5 * p->E3 * (*cost); }
 }
-/* direction update about the old k: scattering_car.f90:795-809 (also :568-582) */
 static inline void rotate_k(photon_t *p, double cost, double sint, double cosp, double sinp) {
     if (fabs(p->kz) >= 0.99999999999) { p->kx = sint * cosp; p->ky = sint * sinp; p->kz = cost; }
     else { double kx1 = p->kx, ky1 = p->ky, kz1 = p->kz, kr = sqrt(kx1 * kx1 + ky1 * ky1);
@@ -2108,7 +2139,7 @@ static void scattering(const orc_sim *s, acc_t *A, rng_t *g, photon_t *p) {
     if (s->use_clump_medium) {                                   /* scattering_car.f90:69-84 */
         if (s->DGR > 0.0) {
             int64_t icl = p->icell_clump; const clumps_t *c = &s->cl;
-            double p_dust = c->rhokapD[icl-1] / (c->rhokap[icl-1] * voigt_clump(c, p->xfreq, icl) + c->rhokapD[icl-1]);
+            double p_dust = c->rhokapD[icl-1] / (c->rhokap[icl-1] * voigt_clump(s, p->xfreq, icl) + c->rhokapD[icl-1]);
             if (rnd(g) <= p_dust) { if (s->use_stokes && s->nPDF > 0) scatter_dust_stokes(s, A, g, p); else scatter_dust_nostokes(s, A, g, p); return; }
         }
         if (s->use_stokes) scatter_resonance_stokes(s, A, g, p); else scatter_resonance_nostokes(s, A, g, p);
@@ -2116,7 +2147,7 @@ static void scattering(const orc_sim *s, acc_t *A, rng_t *g, photon_t *p) {
     }
     if (s->DGR > 0.0) {
         size_t c = IDX(s,p->icell,p->jcell,p->kcell);
-        double p_dust = s->rhokapD[c] / (s->rhokap[c] * orc_voigt(p->xfreq, s->voigt_a[c]) + s->rhokapD[c]);
+        double p_dust = s->rhokapD[c] / (s->rhokap[c] * calc_voigt(s, p->xfreq, s->voigt_a[c], s->Dfreq[c]) + s->rhokapD[c]);
         if (rnd(g) <= p_dust) { if (s->use_stokes && s->nPDF > 0) scatter_dust_stokes(s, A, g, p); else scatter_dust_nostokes(s, A, g, p); return; }
     }
     if (s->use_stokes) scatter_resonance_stokes(s, A, g, p); else scatter_resonance_nostokes(s, A, g, p);
@@ -2152,6 +2183,7 @@ static void generate_photon(const orc_sim *s, acc_t *A, rng_t *g, photon_t *p) {
     p->nscatt_gas = 0.0; p->nscatt_dust = 0.0; p->inside = 1; p->xfreq = s->xfreq0;
     p->E1 = 0.0; p->E2 = 1.0; p->E3 = 2.0 / 3.0;                                       /* photon_type defaults, define.f90:108-110 */
     size_t c = IDX(s,p->icell,p->jcell,p->kcell);
+    if (s->line_type == 2) { double DnuHK = s->DnuHK_Hz / s->Dfreq[c]; if (rnd(g) <= 1.0 / 3.0) p->xfreq = p->xfreq - DnuHK; }   /* :161-167: the source feeds both levels */
     if (s->spectral_type == 1) p->xfreq = p->xfreq + rand_voigt(g, s->voigt_a[c]);     /* :252-253 */
     double u1;
     if (!s->comoving_source) { u1 = udot(s, c, p->kx, p->ky, p->kz); p->xfreq = p->xfreq - u1; }   /* :303-306 */
@@ -2298,6 +2330,7 @@ double orc_get_scalar(const orc_sim *s, const char *k) {
         if (!strcmp(k, "cg_min")) return c->cg_min; if (!strcmp(k, "cg_d")) return c->cg_d; if (!strcmp(k, "cl_sphere_R")) return c->sphere_R; if (!strcmp(k, "cl_radius_max")) return c->radius_max; }
     if (!strcmp(k, "amr_ncells")) return s->amr.ncells; if (!strcmp(k, "amr_nleaf")) return s->amr.nleaf; if (!strcmp(k, "amr_levelmax")) return s->amr.levelmax;
     if (!strcmp(k, "amr_dr_JPa")) return s->amr.dr_JPa; if (!strcmp(k, "amr_dz_JPa")) return s->amr.dz_JPa; if (!strcmp(k, "amr_boxlen")) return s->amr.L_box;
+    G(line_type) G(DnuHK_Hz) G(fine_structure)
     G(use_clump_medium) G(tauhomo) G(N_gashomo) G(use_amr_grid) G(save_peeloff_2D) G(save_peeloff_3D) G(E1) G(E2) G(E3) G(nbins) G(geometry_JPa) G(calc_J) G(calc_P) G(calc_Pnew) G(nside) G(npix)
 #undef G
     return NAN;
@@ -2375,6 +2408,22 @@ void orc_rand_hg_v(int kind, uint64_t seed, uint64_t id, int n, double gg, doubl
 void orc_rand_voigt_v(int kind, uint64_t seed, uint64_t id, int n, double a, double *c) { rng_t t, *g = pick_rng(&t, kind, seed, id); for (int i = 0; i < n; i++) c[i] = rand_voigt(g, a); }
 void orc_rand_gauss_v(int kind, uint64_t seed, uint64_t id, int n, double *c) { rng_t t, *g = pick_rng(&t, kind, seed, id); for (int i = 0; i < n; i++) c[i] = rand_gauss(g); }
 
+/* do_resonance1 / do_resonance2 in cell (ic,jc,kc) (clump mode: ic = owner clump): n draws on one stream;
+ * out[12*i + ..] = uz, xfreq_atom, cost, sint, S11, S22, S12, S33, S44, E1, E2, E3 */
+void orc_do_resonance_v(const orc_sim *s, int kind, uint64_t seed, uint64_t id, int n, double xfreq, int ic, int jc, int kc, double *out) {
+    rng_t t, *g = pick_rng(&t, kind, seed, id);
+    for (int i = 0; i < n; i++) {
+        photon_t p; memset(&p, 0, sizeof p); p.xfreq = xfreq; p.icell = ic; p.jcell = jc; p.kcell = kc; p.icell_clump = ic;
+        if (s->use_clump_medium) { p.icell = p.jcell = p.kcell = 1; }
+        double *o = out + 12 * (size_t)i;
+        do_resonance1(s, g, &p, &o[0], &o[1], &o[2], &o[3], &o[4], &o[5], &o[6], &o[7], &o[8]);
+        o[9] = p.E1; o[10] = p.E2; o[11] = p.E3;
+    }
+}
+void orc_calc_voigt_v(const orc_sim *s, int n, const double *x, int ic, int jc, int kc, double *h) {
+    size_t c = s->use_amr_grid ? (size_t)(ic - 1) : IDX(s, ic, jc, kc);
+    for (int i = 0; i < n; i++) h[i] = calc_voigt(s, x[i], s->voigt_a[c], s->Dfreq[c]);
+}
 static void unpack(const double r[8], const int ic[4], photon_t *p) {
     memset(p, 0, sizeof *p); p->x = r[0]; p->y = r[1]; p->z = r[2]; p->kx = r[3]; p->ky = r[4]; p->kz = r[5]; p->xfreq = r[6]; p->wgt = r[7];
     p->icell = ic[0]; p->jcell = ic[1]; p->kcell = ic[2]; p->inside = ic[3];
@@ -2413,7 +2462,7 @@ static double tau_gas_car(const orc_sim *s, const photon_t *p, double dist) {
     double u1 = udot(s, IDX(s,iold,jold,kold), t.kx, t.ky, t.kz), u2, xfreq = p->xfreq;
     for (;;) {
         size_t c = IDX(s,t.icell,t.jcell,t.kcell);
-        double rhokap = s->rhokap[c] * orc_voigt(xfreq, s->voigt_a[c]);
+        double rhokap = s->rhokap[c] * calc_voigt(s, xfreq, s->voigt_a[c], s->Dfreq[c]);
         int idx = minloc3(t.tx, t.ty, t.tz);
         double *tt = (idx == 1) ? &t.tx : (idx == 2) ? &t.ty : &t.tz;
         if (dist >= 0.0 && *tt >= dist) { tau = tau + (dist - d) * rhokap; break; }
@@ -2464,7 +2513,7 @@ static double sight_amr(const orc_sim *s, const photon_t *p, double dist, int wa
         if (want_column) {
             *N_gas = *N_gas + del * s->rhokap[il-1] * s->Dfreq[il-1] / s->cross0;
             if (s->DGR > 0.0) *tau_dust = *tau_dust + del * s->rhokapD[il-1];
-        } else tau = tau + del * (s->rhokap[il-1] * orc_voigt(xfreq, s->voigt_a[il-1]));
+        } else tau = tau + del * (s->rhokap[il-1] * calc_voigt(s, xfreq, s->voigt_a[il-1], s->Dfreq[il-1]));
         if (last) return tau;
         d = d + t_exit; x = x + t_exit * kx; y = y + t_exit * ky; z = z + t_exit * kz;
         int il_new = amr_next_leaf(a, ic, iface, x, y, z), reflected = 0;
@@ -2487,7 +2536,7 @@ static double sight_clump(const orc_sim *s, const photon_t *p0, int want_column,
         if (want_column) {
             *N_gas = *N_gas + (c->rhokap[icl_cur-1] / s->cross0) * c->Dfreq[icl_cur-1] * t_seg;
             if (s->DGR > 0.0 && c->rhokapD) *tau_dust = *tau_dust + c->rhokapD[icl_cur-1] * t_seg;
-        } else tau = tau + c->rhokap[icl_cur-1] * voigt_clump(c, xf, icl_cur) * t_seg;
+        } else tau = tau + c->rhokap[icl_cur-1] * voigt_clump(s, xf, icl_cur) * t_seg;
         xp = xp + t_seg * kx; yp = yp + t_seg * ky; zp = zp + t_seg * kz;
         xf = xf + ulos_clump(c, icl_cur, kx, ky, kz);
         if (xp * xp + yp * yp + zp * zp >= c->sphere_R * c->sphere_R) return tau;
@@ -2504,7 +2553,7 @@ static double sight_clump(const orc_sim *s, const photon_t *p0, int want_column,
         if (want_column) {
             *N_gas = *N_gas + (c->rhokap[icl_found-1] / s->cross0) * c->Dfreq[icl_found-1] * t_seg;
             if (s->DGR > 0.0 && c->rhokapD) *tau_dust = *tau_dust + c->rhokapD[icl_found-1] * t_seg;
-        } else tau = tau + c->rhokap[icl_found-1] * voigt_clump(c, xf, icl_found) * t_seg;
+        } else tau = tau + c->rhokap[icl_found-1] * voigt_clump(s, xf, icl_found) * t_seg;
         xp = xp + t_seg * kx; yp = yp + t_seg * ky; zp = zp + t_seg * kz;
         xf = xf + u_los;
         icl_cur = icl_found;

@@ -78,6 +78,10 @@ int    orc_sightline_tau(const orc_sim *, double *tau_gas, double *N_gas, double
 void   orc_raytrace_tau_gas(const orc_sim *, const double r[8], const int ic[4], double dist, double *tau);
 void   orc_raytrace_column(const orc_sim *, const double r[8], const int ic[4], double dist, double *N_gas, double *tau_dust);
 void   orc_pix2vec(int nside, int ipix, double v[3]);                    /* healpix.f90:114-187 */
+/* do_resonance1 / do_resonance2 (line_mod.f90:108-192; par%fine_structure selects type 2) and calc_voigt1/2 (:38-62) in a cell:
+ * out[12*i + ..] = uz, xfreq_atom, cost, sint, S11, S22, S12, S33, S44, E1, E2, E3 */
+void   orc_do_resonance_v(const orc_sim *, int kind, uint64_t seed, uint64_t stream_id, int n, double xfreq, int ic, int jc, int kc, double *out);
+void   orc_calc_voigt_v(const orc_sim *, int n, const double *x, int ic, int jc, int kc, double *h);
 int    orc_vec2pix(int nside, double vx, double vy, double vz);          /* healpix.f90:29-112 */
 double orc_xcrit_local(const orc_sim *, int i, int j, int k, double x, double y, double z); /* grid_mod_car.f90:1598-1629 */
 /* one full scattering event from a given photon state (for GPU device-function parity):

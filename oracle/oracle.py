@@ -61,6 +61,8 @@ class Oracle:
             L.orc_raytrace_tau_gas.argtypes = [_vp, _vp, _vp, _d, _vp]
             L.orc_raytrace_column.argtypes = [_vp, _vp, _vp, _d, _vp, _vp]
             L.orc_pix2vec.argtypes = [_i, _i, _vp]
+            L.orc_do_resonance_v.argtypes = [_vp, _i, _u64, _u64, _i, _d, _i, _i, _i, _vp]
+            L.orc_calc_voigt_v.argtypes = [_vp, _i, _vp, _i, _i, _i, _vp]
             cls._lib = L
         return cls._lib
 
@@ -139,6 +141,13 @@ class Oracle:
     def raytrace_to_dist(self, r, ic, dist):
         r = np.array(r, dtype=np.float64); ic = np.array(ic, dtype=np.int32); t = _d()
         self.lib().orc_raytrace_to_dist(self.h, _ptr(r), _ptr(ic), dist, C.byref(t)); return t.value
+
+    def do_resonance(self, kind, seed, sid, n, xfreq, ic, jc, kc):
+        out = np.zeros((n, 12)); self.lib().orc_do_resonance_v(self.h, kind, seed, sid, n, float(xfreq), ic, jc, kc, _ptr(out)); return out
+
+    def calc_voigt(self, x, ic, jc, kc):
+        x = np.ascontiguousarray(x, dtype=np.float64); h = np.zeros_like(x)
+        self.lib().orc_calc_voigt_v(self.h, len(x), _ptr(x), ic, jc, kc, _ptr(h)); return h
 
     def raytrace_tau_gas(self, r, ic, dist=-1.0):
         r = np.array(r, dtype=np.float64); ic = np.array(ic, dtype=np.int32); t = _d()
@@ -228,6 +237,10 @@ class Ref:
             L.ref_raytrace_to_edge.argtypes = [_i, _vp, _vp, _vp]
             L.ref_raytrace_to_dist.argtypes = [_vp, _vp, _d, _vp]
             L.ref_get_Jout.argtypes = [_vp]
+            if hasattr(L, "ref_set_fine_structure"):
+                L.ref_set_fine_structure.argtypes = [_i, _vp]
+                L.ref_do_resonance2_v.argtypes = [_i, _d, _i, _i, _i, _vp]
+                L.ref_calc_voigt_v.argtypes = [_i, _vp, _i, _i, _i, _vp]
             if hasattr(L, "ref_raytrace_tau_gas"):
                 L.ref_raytrace_tau_gas.argtypes = [_vp, _vp, _d, _vp]
                 L.ref_raytrace_column.argtypes = [_vp, _vp, _d, _vp, _vp]
@@ -296,6 +309,20 @@ class Ref:
     @classmethod
     def pix2vec(cls, nside, ipix):
         v = np.zeros(3); cls.lib().ref_pix2vec(int(nside), int(ipix), _ptr(v)); return v
+
+
+    @classmethod
+    def set_fine_structure(cls, on):
+        v = _d(); cls.lib().ref_set_fine_structure(int(on), C.byref(v)); return v.value
+
+    @classmethod
+    def do_resonance2(cls, n, xfreq, ic, jc, kc):
+        out = np.zeros((n, 12)); cls.lib().ref_do_resonance2_v(n, float(xfreq), ic, jc, kc, _ptr(out)); return out
+
+    @classmethod
+    def calc_voigt(cls, x, ic, jc, kc):
+        x = np.ascontiguousarray(x, dtype=np.float64); h = np.zeros_like(x)
+        cls.lib().ref_calc_voigt_v(len(x), _ptr(x), ic, jc, kc, _ptr(h)); return h
 
 
 class RefCalc(Ref):

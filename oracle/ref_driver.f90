@@ -43,6 +43,47 @@ contains
     g_recoil0   = line%g_recoil0
   end subroutine ref_init_line
 
+  !--- par%fine_structure: line type 2 (Ly-alpha doublet) or back to type 1; sets the profile pointer as setup_procedure does
+  subroutine ref_set_fine_structure(on, DnuHK_Hz) bind(C, name='ref_set_fine_structure')
+    integer(c_int), value :: on
+    real(c_double), intent(out) :: DnuHK_Hz
+    par%line_id = 'ly_alpha'
+    par%fine_structure = (on /= 0)
+    call setup_resonance_line()
+    if (par%fine_structure) then
+       calc_voigt => calc_voigt2; do_resonance => do_resonance2
+    else
+       calc_voigt => calc_voigt1; do_resonance => do_resonance1
+    endif
+    DnuHK_Hz = line%DnuHK_Hz
+  end subroutine ref_set_fine_structure
+
+  !--- do_resonance2 (line_mod.f90:141-192) with the Stokes matrix elements and the per-photon E1..E3
+  subroutine ref_do_resonance2_v(n, xfreq, ic, jc, kc, out) bind(C, name='ref_do_resonance2_v')
+    integer(c_int), value :: n, ic, jc, kc
+    real(c_double), value :: xfreq
+    real(c_double), intent(out) :: out(12, n)      ! uz, xatom, cost, sint, S11, S22, S12, S33, S44, E1, E2, E3
+    type(photon_type) :: ph
+    integer :: i
+    do i = 1, n
+       ph%xfreq = xfreq
+       ph%icell = ic; ph%jcell = jc; ph%kcell = kc
+       call do_resonance2(ph, g, out(1,i), out(2,i), out(3,i), out(4,i), out(5,i), out(6,i), out(7,i), out(8,i), out(9,i))
+       out(10,i) = ph%E1; out(11,i) = ph%E2; out(12,i) = ph%E3
+    enddo
+  end subroutine ref_do_resonance2_v
+
+  !--- calc_voigt through the pointer (calc_voigt1 or calc_voigt2, line_mod.f90:38-62) in cell (ic,jc,kc)
+  subroutine ref_calc_voigt_v(n, x, ic, jc, kc, h) bind(C, name='ref_calc_voigt_v')
+    integer(c_int), value :: n, ic, jc, kc
+    real(c_double), intent(in) :: x(n)
+    real(c_double), intent(out) :: h(n)
+    integer :: i
+    do i = 1, n
+       h(i) = calc_voigt(g, x(i), ic, jc, kc)
+    enddo
+  end subroutine ref_calc_voigt_v
+
   function ref_voigt(x, a) bind(C, name='ref_voigt') result(h)
     real(c_double), value :: x, a
     real(c_double) :: h
