@@ -121,7 +121,7 @@ def main():
                        "cells_per_event": cells_all / max(ev_all, 1.0), "photons_finished_in_timed_region": done_all,
                        "tally_reduce_ms": reduce_ms, "tally_doubles": ntally, "parallelism": "photon-dp%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
-                         "kernel": "transport_kernel<1,false,false,false>", "avg_launch_ms": k_ms,
+                         "kernel": "transport_kernel<1,false,false,false,1>", "avg_launch_ms": k_ms,
                          "algorithmic_bytes_per_launch": bytes_launch,
                          "note": "fp64 ALU/latency-bound path; see DESIGN.md 'Roofline' for the VALU accounting"},
         }

@@ -18,10 +18,10 @@ class LartParams(C.Structure):
     _fields_ = [(n, _i32) for n in (
         "xyz_symmetry", "xy_periodic", "xy_symmetry", "source_geometry", "spectral_type", "comoving_source",
         "recoil", "core_skip", "core_skip_global", "use_stokes", "use_reduced_wgt",
-        "save_Jin", "save_Jabs", "save_Jmu", "nmu", "save_peeloff", "save_peeloff_2D", "save_peeloff_3D", "nxfreq")] + \
+        "save_Jin", "save_Jabs", "save_Jmu", "nmu", "save_peeloff", "save_peeloff_2D", "save_peeloff_3D", "nxfreq", "line_type")] + \
         [(n, _d) for n in (
             "xs_point", "ys_point", "zs_point", "source_rmax", "xfreq0", "xfreq_min", "dxfreq", "Dfreq_ref",
-            "DGR", "hgg", "albedo", "mu_min", "dmu", "g_recoil0", "E1", "E2", "E3", "xcrit", "xcrit2")]
+            "DGR", "hgg", "albedo", "mu_min", "dmu", "g_recoil0", "E1", "E2", "E3", "DnuHK_Hz", "xcrit", "xcrit2")]
 
 
 class LartTallies(C.Structure):

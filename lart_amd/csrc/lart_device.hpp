@@ -126,7 +126,10 @@ static __device__ const double c_voigt_tab[606] = {   // H0(101) | H1(202) | H2(
 struct Lds { const double *vt; const double *xf, *yf, *zf;
              double dip_p2, dip_qs;      // Cardano constants of the dipole phase function for par.E1 > 0 (rand_resonance): p, 1/(E1 p^3)
              double *jp_P, *jp_Pn;
-             unsigned char *coop; };    // LART_COOP_BYTES per wave: scratch of the cooperative |x|<=1 sampler (vz_core_coop), nullptr = off   // per-block LDS copies of P1 / P1_new (nullptr: deposits go to global memory)   // Cardano constants of the dipole phase function for par.E1 > 0 (rand_resonance): p, 1/(E1 p^3)
+             unsigned char *coop;
+             int lt; double dnu_hz; };  // line type (1 single line, 2 Ly-alpha doublet) and DnuHK_Hz: set from the kernel's template
+                                        // parameter, so that `l.lt == 2` folds away in the single-line kernels
+    // LART_COOP_BYTES per wave: scratch of the cooperative |x|<=1 sampler (vz_core_coop), nullptr = off   // per-block LDS copies of P1 / P1_new (nullptr: deposits go to global memory)   // Cardano constants of the dipole phase function for par.E1 > 0 (rand_resonance): p, 1/(E1 p^3)
 
 __device__ inline Lds lds_stage(double *sh, const DGrid &g) {
     for (int i = threadIdx.x; i < VT_END; i += blockDim.x) sh[i] = c_voigt_tab[i];
@@ -134,7 +137,7 @@ __device__ inline Lds lds_stage(double *sh, const DGrid &g) {
     for (int i = threadIdx.x; i < nf; i += blockDim.x) sh[VT_END + i] = g.faces[i];
     __syncthreads();
     Lds l; l.vt = sh; l.xf = sh + VT_END; l.yf = l.xf + (g.nx + 1); l.zf = l.yf + (g.ny + 1);
-    l.dip_p2 = 0.0; l.dip_qs = 0.0; l.jp_P = nullptr; l.jp_Pn = nullptr; l.coop = nullptr;
+    l.dip_p2 = 0.0; l.dip_qs = 0.0; l.jp_P = nullptr; l.jp_Pn = nullptr; l.coop = nullptr; l.lt = 1; l.dnu_hz = 0.0;
     return l;
 }
 
@@ -351,6 +354,12 @@ __device__ inline double voigt_H(const double *vt, double vin, double a) {
     }
     double v2 = 1.0 / (v * v);
     return 0.56418958354775628695 * a * v2 * (1.0 + ((1.5 - a * a) + 3.75 * v2) * v2);
+}
+// calc_voigt1 / calc_voigt2 (line_mod.f90:38-62): the profile of a cell with Voigt parameter a and Doppler width Dfreq.
+// Line type 2 = the Ly-alpha doublet: 1/3 of the strength at the 2P1/2 level, DnuHK below the 2P3/2 level.
+__device__ inline double calc_voigt(const Lds &l, double xfreq, double a, double Dfreq) {
+    if (l.lt == 2) { const double dnu = l.dnu_hz / Dfreq; return voigt_H(l.vt, xfreq + dnu, a) * (1.0 / 3.0) + voigt_H(l.vt, xfreq, a) * (2.0 / 3.0); }
+    return voigt_H(l.vt, xfreq, a);
 }
 
 // packet state of one lane (photon_type, define.f90)
@@ -908,7 +917,7 @@ __device__ inline double raytrace_to_edge_amr(const KArgs &A, const Lds &l, bool
     for (;;) {
         int ic = a.icell_of_leaf[il - 1], iface;
         double t_exit = amr_cell_exit(a.geom[ic - 1], x, y, z, kx, ky, kz, iface);
-        double rhokap = c->rhokap * voigt_H(l.vt, xfreq, c->voigt_a);
+        double rhokap = c->rhokap * calc_voigt(l, xfreq, c->voigt_a, c->Dfreq);
         if (dust) rhokap = rhokap + c->rhokapD;
         nsteps++;
         if (dist >= 0.0 && d + t_exit >= dist) return tau + (dist - d) * rhokap;
@@ -929,7 +938,7 @@ __device__ inline double raytrace_to_edge_amr(const KArgs &A, const Lds &l, bool
 // ---------------------------------------------------------------------------------------------
 // clump medium (VAR 4): clump_mod.f90 + raytrace_clump.f90.  xfreq stays in REF Doppler units; -/+ ulos at entry/exit.
 // ---------------------------------------------------------------------------------------------
-__device__ inline double voigt_clump(const KArgs &A, const Lds &l, double xfreq, const ClumpPhys &c) { return voigt_H(l.vt, xfreq * (A.cl.Dfreq_ref / c.Dfreq), c.voigt_a); }   // clump_mod.f90:130-170 (line type 1)
+__device__ inline double voigt_clump(const KArgs &A, const Lds &l, double xfreq, const ClumpPhys &c) { return calc_voigt(l, xfreq * (A.cl.Dfreq_ref / c.Dfreq), c.voigt_a, c.Dfreq); }   // clump_mod.f90:130-170 (line types 1, 2)
 __device__ inline double kappa_clump(const KArgs &A, const Lds &l, bool dust, double xfreq, const ClumpPhys &c) {                                                                 // :176-182
     double kap = c.rhokap * voigt_clump(A, l, xfreq, c);
     if (dust) kap = kap + c.rhokapD;
@@ -1081,7 +1090,7 @@ __device__ inline double raytrace_to_edge(const KArgs &A, const Lds &l, bool dus
     double Dold = c->Dfreq, u1 = c->vfx * t.kx + c->vfy * t.ky + c->vfz * t.kz;
     double rk = c->rhokap, va = c->voigt_a, rD = c->rhokapD;
     for (;;) {
-        double rhokap = rk * voigt_H(l.vt, xfreq, va);
+        double rhokap = rk * calc_voigt(l, xfreq, va, Dold);
         if (dust) rhokap = rhokap + rD;
         nsteps++;
         int idx = (VAR == 2) ? 3 : minloc3(t.tx, t.ty, t.tz);
@@ -1136,7 +1145,7 @@ __device__ inline void raytrace_to_tau_amr(const KArgs &A, const Lds &l, bool du
     for (;;) {
         int ic = a.icell_of_leaf[il - 1], iface;
         double t_exit = amr_cell_exit(a.geom[ic - 1], x, y, z, kx, ky, kz, iface);
-        double rhokapH = c->rhokap * voigt_H(l.vt, p.xfreq, c->voigt_a), rhokap = rhokapH;
+        double rhokapH = c->rhokap * calc_voigt(l, p.xfreq, c->voigt_a, c->Dfreq), rhokap = rhokapH;
         if (dust) rhokap = rhokap + c->rhokapD;
         nsteps++;
         if (tau + t_exit * rhokap >= tau_in) {
@@ -1180,7 +1189,7 @@ __device__ inline void raytrace_to_tau(const KArgs &A, const Lds &l, bool dust, 
     double vx = c->vfx, vy = c->vfy, vz = c->vfz;
     double del = 0.0, vH = 0.0;
     for (;;) {
-        vH = voigt_H(l.vt, p.xfreq, va);
+        vH = calc_voigt(l, p.xfreq, va, Dold);
         double rhokap = rk * vH;
         if (dust) rhokap = rhokap + rD;
         nsteps++;
@@ -1356,7 +1365,7 @@ __device__ inline void peel_direct(const KArgs &A, const Lds &l, bool dust, cons
 }
 // peeling_resonance_nostokes_outside: :576-690
 template <int VAR>
-__device__ inline void peel_resonance_nostokes(const KArgs &A, const Lds &l, bool dust, const Photon &p, double xfreq_atom, double ux, double uy, double uz, unsigned &nsteps) {
+__device__ inline void peel_resonance_nostokes(const KArgs &A, const Lds &l, bool dust, const Photon &p, double xfreq_atom, double ux, double uy, double uz, double E1, double E2, unsigned &nsteps) {
     const Cell &c = A.g.cell[cidx(A.g, p.ic, p.jc, p.kc)];
     for (int i = 0; i < A.nobs; i++) {
         PeelDir q = peel_dir0(A, A.obs[i], p);
@@ -1367,7 +1376,7 @@ __device__ inline void peel_resonance_nostokes(const KArgs &A, const Lds &l, boo
         double xfreq = xfreq_atom + (ux * cosp + uy * sinp) * sint + uz * cost;
         if (A.par.recoil) xfreq = xfreq - (A.par.g_recoil0 / c.Dfreq) * (1.0 - cost);
         double tau = raytrace_to_edge<VAR>(A, l, dust, p, xfreq, q.kx, q.ky, q.kz, q.dist, nsteps);
-        double peel = 0.75 * A.par.E1 * (cost2 + 1.0) + A.par.E2;
+        double peel = 0.75 * E1 * (cost2 + 1.0) + E2;
         double wgt = peel / (LART_FOURPI * q.r2) * d_exp_neg(-tau) * p.wgt;
         if (wgt == 0.0) continue;
         peel_pixel(A, A.obs[i], q);
@@ -1399,7 +1408,7 @@ __device__ inline StokesGeom stokes_geom(const Photon &p, const PeelDir &q) {
 }
 // peeling_resonance_stokes_outside: :303-482
 template <int VAR>
-__device__ inline void peel_resonance_stokes(const KArgs &A, const Lds &l, bool dust, const Photon &p, double xfreq_atom, double ux, double uy, double uz, unsigned &nsteps) {
+__device__ inline void peel_resonance_stokes(const KArgs &A, const Lds &l, bool dust, const Photon &p, double xfreq_atom, double ux, double uy, double uz, double E1, double E2, double E3, unsigned &nsteps) {
     const Cell &c = A.g.cell[cidx(A.g, p.ic, p.jc, p.kc)];
     for (int i = 0; i < A.nobs; i++) {
         const DObs &o = A.obs[i];
@@ -1413,7 +1422,7 @@ __device__ inline void peel_resonance_stokes(const KArgs &A, const Lds &l, bool 
         if (wgt == 0.0) continue;
         peel_pixel(A, o, q);
         if (!q.in_image) continue;
-        double cost2 = s.cost * s.cost, E1 = A.par.E1, E2 = A.par.E2, E3 = A.par.E3;
+        double cost2 = s.cost * s.cost;
         double S22 = 0.75 * E1 * (cost2 + 1.0), S11 = S22 + E2, S12 = 0.75 * E1 * (cost2 - 1.0), S33 = 1.5 * E1 * s.cost, S44 = 1.5 * E3 * s.cost;
         double u1 = peel_u1<VAR>(A, p, c, q);
         double xfreq_ref = (xfreq + u1) * (c.Dfreq / A.par.Dfreq_ref);
@@ -1534,7 +1543,7 @@ __device__ inline bool dust_absorb(const KArgs &A, Rng &g, Photon &p, const Cell
 //   scatter_pre  -> dust-or-gas decision; a dust event completes here; a resonance event returns true with the sampler's
 //                   arguments in ScatCtx (x in the local Doppler units of the cell / clump)
 //   scatter_post -> everything after do_resonance's `uz = rand_resonance_vz(x, a)`
-struct ScatCtx { double va, xloc, cl_scale, cl_Dfreq; };
+struct ScatCtx { double va, xloc, cl_scale, cl_Dfreq, xsamp, dnu; };   // xsamp: the sampler's frequency (xloc, or xloc + dnu for the 2P1/2 level)
 template <int VAR, bool STOKES, bool DUST, bool PEEL>
 __device__ inline bool scatter_pre(const KArgs &A, const Lds &l, Rng &g, Photon &p, unsigned &npeel, ScatCtx &sc) {
     const lart_params &par = A.par;
@@ -1546,7 +1555,7 @@ __device__ inline bool scatter_pre(const KArgs &A, const Lds &l, Rng &g, Photon 
     if (VAR == 4) { const ClumpPhys ph = A.cl.phys[p.icl - 1]; va = ph.voigt_a; cl_Dfreq = ph.Dfreq; cl_rhokap = ph.rhokap; cl_rhokapD = ph.rhokapD; cl_scale = A.cl.Dfreq_ref / ph.Dfreq; }
     if (DUST) {
         double rD = cl_rhokapD;
-        double p_dust = rD / (cl_rhokap * voigt_H(l.vt, p.xfreq * cl_scale, va) + rD);
+        double p_dust = rD / (cl_rhokap * calc_voigt(l, p.xfreq * cl_scale, va, cl_Dfreq) + rD);
         if (g.next() <= p_dust) {
             if (dust_absorb(A, g, p, c)) return false;
             if (STOKES && A.mu.nPDF > 0) {                     // scatter_dust_stokes :201-329
@@ -1577,6 +1586,13 @@ __device__ inline bool scatter_pre(const KArgs &A, const Lds &l, Rng &g, Photon 
         if (ib >= 1) atomicAdd(&(l.jp_P ? l.jp_P : A.jpa.P1)[ib - 1], p.wgt / (c.rhokap * c.Dfreq / A.jpa.cross0));
     }
     sc.va = va; sc.cl_scale = cl_scale; sc.cl_Dfreq = cl_Dfreq; sc.xloc = (VAR == 4) ? p.xfreq * cl_scale : p.xfreq;
+    sc.xsamp = sc.xloc; sc.dnu = 0.0;
+    if (l.lt == 2) {                                           // do_resonance2 (line_mod.f90:152-163): which level scatters
+        sc.dnu = l.dnu_hz / cl_Dfreq;
+        double pH = voigt_H(l.vt, sc.xloc + sc.dnu, va) * (1.0 / 3.0), pK = voigt_H(l.vt, sc.xloc, va) * (2.0 / 3.0);
+        pH = pH / (pH + pK);
+        if (g.next() < pH) sc.xsamp = sc.xloc + sc.dnu;
+    }
     return true;
 }
 template <int VAR, bool STOKES, bool DUST, bool PEEL>
@@ -1587,13 +1603,19 @@ __device__ inline void scatter_post(const KArgs &A, const Lds &l, Rng &g, Photon
     if (VAR == 4) { double scale_inv = 1.0 / sc.cl_scale; xfreq_atom = (sc.xloc - uz_loc) * scale_inv; uz = uz_loc * scale_inv; }
     else { uz = uz_loc; xfreq_atom = p.xfreq - uz; }
     double S11 = 0, S22 = 0, S12 = 0, S33 = 0, S44 = 0, sinp, cosp, cost, cost2, sint;
+    double E1 = par.E1, E2 = par.E2, E3 = par.E3;              // photon%E1..E3 of this event (the peel routines read them)
+    if (l.lt == 2) {                                           // do_resonance2 :166-171: E1 of the atom-frame frequency
+        const double qK = (VAR == 4) ? sc.xloc - uz_loc : xfreq_atom, qH = qK + sc.dnu;
+        E1 = (2.0 * qK * qH + qH * qH) / (qK * qK + 2.0 * qH * qH); E2 = 1.0 - E1; E3 = (E1 + 2.0) / 3.0;
+    }
     if (STOKES) {
-        cost = dipole_cost(l, g.next(), par.E1); cost2 = cost * cost; sint = sqrt(1.0 - cost2);
-        S22 = 0.75 * par.E1 * (cost2 + 1.0); S11 = S22 + par.E2; S12 = 0.75 * par.E1 * (cost2 - 1.0); S33 = 1.5 * par.E1 * cost; S44 = 1.5 * par.E3 * cost;
+        cost = (l.lt == 2) ? rand_resonance_u(g.next(), E1) : dipole_cost(l, g.next(), E1); cost2 = cost * cost; sint = sqrt(1.0 - cost2);
+        S22 = 0.75 * E1 * (cost2 + 1.0); S11 = S22 + E2; S12 = 0.75 * E1 * (cost2 - 1.0); S33 = 1.5 * E1 * cost;
+        S44 = (l.lt == 2) ? (E1 + 2.0) / 2.0 * cost : 1.5 * E3 * cost;
         phi_rejection(g, p, S12 / S11, sinp, cosp);
     } else {
         double ud, up; g.next2(ud, up);                       // polar angle, then azimuth: the reference's order of draws
-        cost = dipole_cost(l, ud, par.E1); cost2 = cost * cost; sint = sqrt(1.0 - cost2);
+        cost = (l.lt == 2) ? rand_resonance_u(ud, E1) : dipole_cost(l, ud, E1); cost2 = cost * cost; sint = sqrt(1.0 - cost2);
         d_sincos_2pi(up, &sinp, &cosp);
     }
     // perpendicular atom velocity; truncated tail when core-skipping (:726-752, :400-430)
@@ -1613,14 +1635,14 @@ __device__ inline void scatter_post(const KArgs &A, const Lds &l, Rng &g, Photon
     p.xfreq = xfreq_atom + uz * cost + (ux * cosp + uy * sinp) * sint;
     if (par.recoil) p.xfreq = p.xfreq - (par.g_recoil0 / sc.cl_Dfreq) * (1.0 - cost);
     if (STOKES) {
-        if (PEEL) peel_resonance_stokes<VAR>(A, l, DUST, p, xfreq_atom, ux, uy, uz, npeel);
+        if (PEEL) peel_resonance_stokes<VAR>(A, l, DUST, p, xfreq_atom, ux, uy, uz, E1, E2, E3, npeel);
         double cos2p = 2.0 * cosp * cosp - 1.0, sin2p = 2.0 * sinp * cosp;
         double Q0 = cos2p * p.Q + sin2p * p.U, U0 = -sin2p * p.Q + cos2p * p.U;
         double I1 = S11 + S12 * Q0, Q1 = S12 + S22 * Q0, U1 = S33 * U0, V1 = S44 * p.V;
         p.Q = Q1 / I1; p.U = U1 / I1; p.V = V1 / I1;
         rotate_triad(p, cost, sint, cosp, sinp);
     } else {
-        if (PEEL) peel_resonance_nostokes<VAR>(A, l, DUST, p, xfreq_atom, ux, uy, uz, npeel);
+        if (PEEL) peel_resonance_nostokes<VAR>(A, l, DUST, p, xfreq_atom, ux, uy, uz, E1, E2, npeel);
         rotate_k(p, cost, sint, cosp, sinp);
     }
 }
@@ -1628,27 +1650,27 @@ __device__ inline void scatter_post(const KArgs &A, const Lds &l, Rng &g, Photon
 // sampler is a wave-cooperative stage, vz_core_coop).
 template <int VAR, bool STOKES, bool DUST, bool PEEL>
 __device__ inline void scatter_event(const KArgs &A, const Lds &l, Rng &g, Photon &p, unsigned &npeel, bool on) {
-    ScatCtx sc; sc.xloc = 0.0; sc.va = 1.0;
+    ScatCtx sc; sc.xloc = 0.0; sc.xsamp = 0.0; sc.va = 1.0;
 #if defined(LART_PROFILE) || defined(LART_NO_COOP)
     if (!on || !scatter_pre<VAR, STOKES, DUST, PEEL>(A, l, g, p, npeel, sc)) return;
     LART_PROF_MARK(p, 4);
-    double uz_loc = rand_resonance_vz(g, sc.xloc, sc.va LART_PROF_PASS(p));
+    double uz_loc = rand_resonance_vz(g, sc.xsamp, sc.va LART_PROF_PASS(p));
     LART_PROF_MARK(p, 5);
     scatter_post<VAR, STOKES, DUST, PEEL>(A, l, g, p, npeel, sc, uz_loc);
 #else
     bool go = false;
     if (on) go = scatter_pre<VAR, STOKES, DUST, PEEL>(A, l, g, p, npeel, sc);
-    const bool core = go && fabs(sc.xloc) <= 1.0;
+    const bool core = go && fabs(sc.xsamp) <= 1.0;
     double uz_loc;
     if (l.coop) {
-        uz_loc = vz_core_coop(g, core, sc.xloc, sc.va, l.coop);
+        uz_loc = vz_core_coop(g, core, sc.xsamp, sc.va, l.coop);
 #ifdef LART_NO_WING_COOP
-        if (go && !core) uz_loc = vz_wing(g, sc.xloc, sc.va);
+        if (go && !core) uz_loc = vz_wing(g, sc.xsamp, sc.va);
 #else
-        const double uw = vz_wing_coop(g, go && !core, sc.xloc, sc.va, l.coop);
+        const double uw = vz_wing_coop(g, go && !core, sc.xsamp, sc.va, l.coop);
         if (go && !core) uz_loc = uw;
 #endif
-    } else { uz_loc = core ? vz_core(g, sc.xloc, sc.va) : 0.0; if (go && !core) uz_loc = vz_wing(g, sc.xloc, sc.va); }
+    } else { uz_loc = core ? vz_core(g, sc.xsamp, sc.va) : 0.0; if (go && !core) uz_loc = vz_wing(g, sc.xsamp, sc.va); }
     if (go) scatter_post<VAR, STOKES, DUST, PEEL>(A, l, g, p, npeel, sc, uz_loc);
 #endif
 }
@@ -1684,6 +1706,7 @@ __device__ inline void generate_photon(const KArgs &A, const Lds &l, Rng &g, Pho
     p.nsg = 0.0; p.nsd = 0.0; p.inside = true; p.xfreq = par.xfreq0;
     // a source outside the medium box never reaches a table in the reference's configs; clamp the gather
     const Cell &c = (VAR == 3 || VAR == 4) ? gr.cell[p.ic - 1] : gr.cell[cidx(gr, clampi(p.ic, 1, gr.nx), clampi(p.jc, 1, gr.ny), clampi(p.kc, 1, gr.nz))];
+    if (l.lt == 2) { const double dnu = l.dnu_hz / c.Dfreq; if (g.next() <= 1.0 / 3.0) p.xfreq = p.xfreq - dnu; }   // the source feeds both levels (generate_photon.f90:161-167)
     if (par.spectral_type == 1) p.xfreq = p.xfreq + rand_voigt(g, c.voigt_a);
     double u1 = c.vfx * p.kx + c.vfy * p.ky + c.vfz * p.kz;
     if (!par.comoving_source) p.xfreq = p.xfreq - u1;

@@ -60,6 +60,8 @@ extern "C" int lart_gpu_create(lart_gpu **out, const lart_params *par, int devic
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail("lart_gpu_create: no HIP device visible (this library has no CPU path)");
     if (device < 0 || device >= n) return fail("lart_gpu_create: device ordinal out of range");
     HIPCHK(hipSetDevice(device));
+    if (par->line_type != 1 && par->line_type != 2) return fail("lart_gpu_create: line_type must be 1 (single line) or 2 (Ly-alpha doublet, par%fine_structure)");
+    if (par->line_type == 2 && !(par->DnuHK_Hz > 0.0)) return fail("lart_gpu_create: line_type 2 needs DnuHK_Hz > 0 (line%DnuHK_Hz)");
     lart_gpu *c = new lart_gpu();
     c->device = device; c->par = *par;
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -611,7 +613,7 @@ __device__ void test_ray_one(const KArgs &A, const Lds &l, int kind, double *r, 
 }
 __global__ void k_test_raytrace(KArgs A, int mode, int n, double *r8, int *ic4, const double *tq, double *tau_out) {
     extern __shared__ double sh[];
-    Lds l = lds_stage(sh, A.g);
+    Lds l = lds_stage(sh, A.g); l.lt = A.par.line_type; l.dnu_hz = A.par.DnuHK_Hz;       // probes: the line type at run time
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int kind = mode / 10, var = mode % 10;
@@ -641,7 +643,7 @@ __device__ void test_scatter_one(const KArgs &A, const Lds &l, double *st, int *
 }
 __global__ void k_test_scatter(KArgs A, int n, double *st18, int *ic4, unsigned long long seed, const unsigned long long *ids, long long *nd) {
     extern __shared__ double sh[];
-    Lds l = lds_stage(sh, A.g);
+    Lds l = lds_stage(sh, A.g); l.lt = A.par.line_type; l.dnu_hz = A.par.DnuHK_Hz;       // probes: the line type at run time
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     bool stokes = A.par.use_stokes, dust = A.par.DGR > 0.0;

@@ -159,7 +159,7 @@ __device__ inline void sight_car(const KArgs &A, const Lds &l, const SightRay &r
     c = &g.cell[cidx(g, t.ic, t.jc, t.kc)];
     double d = 0.0, Dold = c->Dfreq, u1 = c->vfx * t.kx + c->vfy * t.ky + c->vfz * t.kz;
     for (;;) {
-        const double rhokap = c->rhokap * voigt_H(l.vt, xfreq, c->voigt_a);
+        const double rhokap = c->rhokap * calc_voigt(l, xfreq, c->voigt_a, c->Dfreq);
         const int idx = minloc3(t.tx, t.ty, t.tz);
         const double tt = idx == 1 ? t.tx : (idx == 2 ? t.ty : t.tz);
         const bool last = r.dist >= 0.0 && tt >= r.dist;
@@ -191,7 +191,7 @@ __device__ inline void sight_amr(const KArgs &A, const Lds &l, const SightRay &r
         const double t_exit = amr_cell_exit(a.geom[ic - 1], x, y, z, kx, ky, kz, iface);
         const bool last = r.dist >= 0.0 && d + t_exit >= r.dist;
         const double del = last ? r.dist - d : t_exit;
-        s.tau = s.tau + del * (c->rhokap * voigt_H(l.vt, xfreq, c->voigt_a));
+        s.tau = s.tau + del * (c->rhokap * calc_voigt(l, xfreq, c->voigt_a, c->Dfreq));
         s.N = s.N + del * c->rhokap * c->Dfreq / cross0;
         if (dust) s.td = s.td + del * c->rhokapD;
         if (last) return;
@@ -237,7 +237,8 @@ template <int VAR>
 __global__ __launch_bounds__(256) void k_sightline(const KArgs A, const SightRay *__restrict__ rays, int nray, int nchunk, double cross0, int dust,
                                                    double *__restrict__ tau_gas, double *__restrict__ N_gas, double *__restrict__ tau_dust) {
     extern __shared__ double sh[];
-    const Lds l = lds_stage(sh, A.g);
+    Lds l_ = lds_stage(sh, A.g); l_.lt = A.par.line_type; l_.dnu_hz = A.par.DnuHK_Hz;
+    const Lds l = l_;
     const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (wave >= (long long)nray * nchunk) return;
     const int ir = (int)(wave / nchunk), chunk = (int)(wave % nchunk), kf = chunk * 64 + (threadIdx.x & 63);

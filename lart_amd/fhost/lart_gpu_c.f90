@@ -19,11 +19,13 @@ module lart_gpu_c
      integer(c_int32_t) :: save_Jin, save_Jabs, save_Jmu, nmu
      integer(c_int32_t) :: save_peeloff, save_peeloff_2D, save_peeloff_3D
      integer(c_int32_t) :: nxfreq
+     integer(c_int32_t) :: line_type
      real(c_double) :: xs_point, ys_point, zs_point, source_rmax, xfreq0
      real(c_double) :: xfreq_min, dxfreq, Dfreq_ref
      real(c_double) :: DGR, hgg, albedo
      real(c_double) :: mu_min, dmu
      real(c_double) :: g_recoil0, E1, E2, E3
+     real(c_double) :: DnuHK_Hz
      real(c_double) :: xcrit, xcrit2
   end type lart_params
 

@@ -95,6 +95,8 @@ module lart_define
      real(wp) :: damping     = 6.2649e8_wp
      real(wp) :: cross0, vtherm1, g_recoil0
      real(wp) :: E1 = 1.0_wp, E2 = 0.0_wp, E3 = 1.0_wp
+     integer  :: line_type = 1
+     real(wp) :: DnuHK_Hz = 0.0_wp          ! 2P3/2 - 2P1/2 splitting, line type 2 (par%fine_structure)
   end type line_type
 
   type grid_type          ! define.f90:117-206 (tables are contiguous, Fortran order = what the C-ABI takes)
@@ -190,6 +192,11 @@ contains
     line%vtherm1     = vtherm1_amu/sqrt(mass_amu)
     line%g_recoil0   = (h_planck/amu/mass_amu)/(line%wavelength0*um2m)**2
     line%E1 = 1.0_wp; line%E2 = 0.0_wp; line%E3 = 1.0_wp
+    line%line_type = 1; line%DnuHK_Hz = 0.0_wp
+    if (par%fine_structure) then                                        ! line_mod.f90:1246-1253
+       line%line_type = 2
+       line%DnuHK_Hz  = 82259.2850014_wp*(2.99792458e5_wp*1.0e5_wp) - 82258.9191133_wp*(2.99792458e5_wp*1.0e5_wp)
+    endif
   end subroutine setup_resonance_line
 
   subroutine not_supported(what)
@@ -232,7 +239,6 @@ contains
     if ((par%calc_J .or. par%calc_P .or. par%calc_Pnew) .and. par%use_clump_medium) &
        call not_supported('calc_J / calc_P / calc_Pnew with par%use_clump_medium')
     if (par%use_clump_medium .and. len_trim(par%clump_input_file) > 0) call not_supported('par%clump_input_file')
-    if (par%fine_structure)    call not_supported('par%fine_structure = .true.')
     if (par%include_deuterium) call not_supported('par%include_deuterium = .true.')
     if (trim(par%line_id) /= 'ly_alpha') call not_supported('par%line_id /= ly_alpha')
     if (trim(strlowcase(par%h2_model)) /= 'none') call not_supported('par%h2_model')
@@ -1262,13 +1268,13 @@ contains
        endif
        if (par%Vexp == 0.0_wp) then
           par%xfreq_max = floor(xscale*atau3) + 1
-          par%xfreq_min = -(floor(xscale*atau3 + 0.0_wp) + 1)
+          par%xfreq_min = -(floor(xscale*atau3 + line%DnuHK_Hz/grid%Dfreq_ref) + 1)
        else if (par%Vexp > 0.0_wp) then
           par%xfreq_max = floor(xscale*atau3) + 1
-          par%xfreq_min = -(floor(xscale*atau3 + abs(par%Vexp)/vtherm + 0.0_wp) + 1)
+          par%xfreq_min = -(floor(xscale*atau3 + abs(par%Vexp)/vtherm + line%DnuHK_Hz/grid%Dfreq_ref) + 1)
        else
           par%xfreq_max = floor(xscale*atau3 + abs(par%Vexp)/vtherm) + 1
-          par%xfreq_min = -(floor(xscale*atau3 + 0.0_wp) + 1)
+          par%xfreq_min = -(floor(xscale*atau3 + line%DnuHK_Hz/grid%Dfreq_ref) + 1)
        endif
     endif
     allocate(grid%xfreq(grid%nxfreq), grid%velocity(grid%nxfreq), grid%wavelength(grid%nxfreq))

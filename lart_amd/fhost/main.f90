@@ -247,6 +247,7 @@ contains
     p%xfreq_min = grid%xfreq_min; p%dxfreq = grid%dxfreq; p%Dfreq_ref = grid%Dfreq_ref
     p%DGR = par%DGR; p%hgg = par%hgg; p%albedo = par%albedo; p%mu_min = par%mu_min; p%dmu = par%dmu
     p%g_recoil0 = line%g_recoil0; p%E1 = line%E1; p%E2 = line%E2; p%E3 = line%E3
+    p%line_type = line%line_type; p%DnuHK_Hz = line%DnuHK_Hz
     p%xcrit = grid%xcrit; p%xcrit2 = grid%xcrit2
   end subroutine fill_params
 

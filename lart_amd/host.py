@@ -60,6 +60,7 @@ class Params:
     core_skip_global: bool = False
     xyz_symmetry: bool = False
     xy_symmetry: bool = False
+    fine_structure: bool = False
     xy_periodic: bool = False
     geometry: str = ""
     velocity_type: str = ""
@@ -162,7 +163,7 @@ class Params:
 # fields of params_type that exist in the reference but select physics outside this path: accepted at their
 # default, rejected ("not supported") when set to something that would change the path
 _UNSUPPORTED_DEFAULTS = {
-    "fine_structure": False, "include_deuterium": False,
+    "include_deuterium": False,
     "line_id": "ly_alpha", "h2_model": "none", "z_symmetry": False, "bturb": -999.0,
     "dens_file": "", "temp_file": "", "velo_file": "", "emiss_file": "", "cart_file": "", "input_field": "",
     "star_file": "", "use_cie_condition": False, "density_rscale": -999.9, "density_zscale": -999.9,
@@ -248,6 +249,8 @@ class Line:
     E1: float = 1.0
     E2: float = 0.0
     E3: float = 1.0
+    line_type: int = 1
+    DnuHK_Hz: float = 0.0           # 2P3/2 - 2P1/2 splitting (par%fine_structure: line type 2, line_mod.f90:1250-1253)
 
 
 def vtherm_total(line, T):
@@ -305,6 +308,9 @@ def setup_scattering_matrix(par, path):
 def read_input(par, line=None):
     """post-processing part of read_input (setup.f90:42-562) for the fields this path uses. Returns (par, line, scatt_mat)."""
     line = line or Line()
+    if par.fine_structure:                                                # setup_resonance_line, line_mod.f90:1246-1253
+        speedc_cm = 2.99792458e5 * 1.0e5
+        line.line_type, line.DnuHK_Hz = 2, 82259.2850014 * speedc_cm - 82258.9191133 * speedc_cm
     if par.no_photons >= 1:
         par.nphotons = int(par.no_photons)
     for n in ("geometry", "source_geometry", "velocity_type", "spectral_type"):
@@ -655,13 +661,13 @@ def car_setup_freq_grid(par, line, g):
         xscale = 25.0 if par.taumax <= 5e1 else 14.0 if par.taumax <= 5e2 else 10.0 if par.taumax <= 5e3 else 5.0
         if par.Vexp == 0.0:
             par.xfreq_max = math.floor(xscale * par.atau3) + 1
-            par.xfreq_min = -(math.floor(xscale * par.atau3 + 0.0) + 1)
+            par.xfreq_min = -(math.floor(xscale * par.atau3 + line.DnuHK_Hz / g.Dfreq_ref) + 1)
         elif par.Vexp > 0.0:
             par.xfreq_max = math.floor(xscale * par.atau3) + 1
-            par.xfreq_min = -(math.floor(xscale * par.atau3 + abs(par.Vexp) / vth + 0.0) + 1)
+            par.xfreq_min = -(math.floor(xscale * par.atau3 + abs(par.Vexp) / vth + line.DnuHK_Hz / g.Dfreq_ref) + 1)
         else:
             par.xfreq_max = math.floor(xscale * par.atau3 + abs(par.Vexp) / vth) + 1
-            par.xfreq_min = -(math.floor(xscale * par.atau3 + 0.0) + 1)
+            par.xfreq_min = -(math.floor(xscale * par.atau3 + line.DnuHK_Hz / g.Dfreq_ref) + 1)
     g.dxfreq = (par.xfreq_max - par.xfreq_min) / par.nxfreq
     g.xfreq_max, g.xfreq_min = float(par.xfreq_max), float(par.xfreq_min)
     g.xfreq = (np.arange(1, g.nxfreq + 1) - 0.5) * g.dxfreq + g.xfreq_min
@@ -787,6 +793,7 @@ def make_lart_params(par, line, g):
         setattr(p, n, float(getattr(par, n)))
     p.xfreq_min, p.dxfreq, p.Dfreq_ref = g.xfreq_min, g.dxfreq, g.Dfreq_ref
     p.g_recoil0, p.E1, p.E2, p.E3 = line.g_recoil0, line.E1, line.E2, line.E3
+    p.line_type, p.DnuHK_Hz = line.line_type, line.DnuHK_Hz
     p.xcrit, p.xcrit2 = g.xcrit, g.xcrit2
     return p
 

@@ -98,9 +98,12 @@ def test_namelist_surface(built, tmp_path):
     with pytest.raises(host.LartInputError):
         host.read_namelist(str(bad))
     fs = tmp_path / "fs.in"
-    fs.write_text("&parameters\n par%fine_structure = .true.\n/\n")
+    fs.write_text("&parameters\n par%include_deuterium = .true.\n/\n")
     with pytest.raises(host.LartInputError, match="not supported"):
         host.read_namelist(str(fs))
+    fs.write_text("&parameters\n par%fine_structure = .true.\n par%temperature = 10.0\n par%taumax = 1e3\n/\n")
+    par, line, _ = host.read_input(host.read_namelist(str(fs)))
+    assert line.line_type == 2 and abs(line.DnuHK_Hz / 1.0969049e10 - 1) < 1e-6
     clump = tmp_path / "clump.in"
     clump.write_text("&parameters\n par%use_clump_medium = .true.\n par%clump_radius = 0.01\n par%clump_f_cov = 5.0\n par%clump_tau0 = 1.0e3\n/\n")
     par = host.read_namelist(str(clump))

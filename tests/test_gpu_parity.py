@@ -99,7 +99,9 @@ def test_ray_marches_device_vs_reference_vectors(capi, golden, name):
 @pytest.mark.parametrize("kw", [dict(temperature=1e4, taumax=1e3, nx=11, ny=11, nz=11, rmax=1.0),
                                 dict(temperature=1e4, taumax=1e3, nx=11, ny=11, nz=11, rmax=1.0, use_stokes=True, recoil=True),
                                 dict(temperature=10.0, taumax=1e5, nx=11, ny=11, nz=11, rmax=1.0, core_skip=True),
-                                dict(temperature=1e4, taumax=1e2, nx=11, ny=11, nz=11, rmax=1.0, DGR=1.0, cext_dust=1e-19, use_reduced_wgt=True)])
+                                dict(temperature=1e4, taumax=1e2, nx=11, ny=11, nz=11, rmax=1.0, DGR=1.0, cext_dust=1e-19, use_reduced_wgt=True),
+                                dict(temperature=20.0, taumax=1e3, nx=11, ny=11, nz=11, rmax=1.0, fine_structure=True),
+                                dict(temperature=20.0, taumax=1e3, nx=11, ny=11, nz=11, rmax=1.0, fine_structure=True, use_stokes=True, recoil=True)])
 def test_scatter_event_device(capi, oracle_mod, kw):
     sim = make(kw); o = oracle_of(oracle_mod, kw)
     rng = np.random.default_rng(3)
@@ -113,7 +115,8 @@ def test_scatter_event_device(capi, oracle_mod, kw):
         k = np.array([s * np.cos(ph), s * np.sin(ph), mu])
         m = np.array([mu * np.cos(ph), mu * np.sin(ph), -s]); nn = np.array([-np.sin(ph), np.cos(ph), 0.0])
         q, u = rng.uniform(-0.3, 0.3, 2)
-        st[i] = pos + list(k) + [rng.normal(0, 2.0) if i % 3 else rng.normal(0, 0.3), 1.0] + list(m) + list(nn) + [1.0, q, u, 0.05]
+        x0 = -1.2 if kw.get("fine_structure") else 0.0        # (the doublet: centre the frequencies between the two levels)
+        st[i] = pos + list(k) + [x0 + (rng.normal(0, 2.0) if i % 3 else rng.normal(0, 0.3)), 1.0] + list(m) + list(nn) + [1.0, q, u, 0.05]
         ic[i] = c + [1]
     ids = np.arange(1, n + 1, dtype=np.uint64)
     sg, icg, ndg = sim.ctx.test_scatter(st, ic, 4242, ids)
@@ -129,6 +132,9 @@ def test_scatter_event_device(capi, oracle_mod, kw):
     (dict(temperature=1e4, taumax=1e1, xyz_symmetry=True, nx=21, ny=21, nz=21, rmax=1.0, nxfreq=81, iseed=5), 20000),
     (dict(temperature=1e4, taumax=1e1, nx=21, ny=21, nz=21, rmax=1.0, nxfreq=81, iseed=6, source_geometry="uniform_sphere", save_Jmu=True, nmu=5), 20000),
     (dict(temperature=1e1, taumax=1e1, xy_periodic=True, nx=1, ny=1, nz=51, nxfreq=81, iseed=7, use_stokes=True), 20000),
+    (dict(temperature=1e1, taumax=3e1, nx=21, ny=21, nz=21, rmax=1.0, nxfreq=121, iseed=8, fine_structure=True), 20000),
+    (dict(temperature=3e1, taumax=3e1, xyz_symmetry=True, nx=21, ny=21, nz=21, rmax=1.0, nxfreq=121, iseed=9, fine_structure=True, use_stokes=True,
+          velocity_type="hubble", Vexp=5.0), 20000),
 ])
 def test_short_histories_photon_by_photon(capi, oracle_mod, kw, n):
     sim = make(kw); sim.ctx.enable_photon_log(True)
@@ -167,6 +173,46 @@ def test_xy_symmetric_and_periodic_histories_photon_by_photon(capi, oracle_mod, 
         slab = dict(kw, nx=1, ny=1); s1 = make(slab); s1.ctx.enable_photon_log(True); s1.run_simulation(n)
         n1, _ = s1.ctx.photon_log(n)
         assert abs(ng.mean() - n1.mean()) < 4 * np.hypot(ng.std(), n1.std()) / np.sqrt(n)
+
+
+def test_fine_structure_device_vs_reference_vectors(capi, golden):
+    """calc_voigt2 inside raytrace_to_{tau,edge}_car: vectors from the reference's compiled modules with par%fine_structure"""
+    from lart_amd import host
+    z = golden("fine_structure.npz")
+    kw = dict(tok.split("=") for tok in str(z["params"]).split())
+    par = host.Params()
+    for k, v in kw.items():
+        host.set_param(par, k, host._parse_value(v) if k != "geometry" else v)
+    sim = host.Simulation(par)
+    assert sim.line.line_type == 2 and sim.line.DnuHK_Hz == float(z["DnuHK_Hz"])
+    g = sim.grid
+    sim.ctx.set_grid_car(g.nx, g.ny, g.nz, g.xmin, g.ymin, g.zmin, g.dx, g.dy, g.dz, g.i0, g.j0, g.k0, g.xface, g.yface, g.zface,
+                         z["rhokap"], z["voigt_a"], z["Dfreq"], z["vfx"], z["vfy"], z["vfz"], z["rhokapD"])
+    r, ic, _ = sim.ctx.test_raytrace(0, 0, z["r_in"], z["ic_in"], z["tau_in"])
+    assert np.array_equal(ic, z["ic_out"]) and np.allclose(r, z["r_out"], rtol=1e-10, atol=1e-12)
+    _, _, te = sim.ctx.test_raytrace(1, 0, z["r_in"], z["ic_in"])
+    assert np.allclose(te, z["tau_edge"], rtol=1e-10, atol=1e-300)
+
+
+def test_fine_structure_peel_and_clumps_whole_path(capi, oracle_mod):
+    """the doublet through the peel-off (per-event E1..E3 of do_resonance2) and through the clump medium (voigt_clump type 2,
+    do_resonance2_clump), statistically against the oracle on the same streams"""
+    kw = dict(temperature=2e1, taumax=1e2, nx=21, ny=21, nz=21, rmax=1.0, nxfreq=121, nxim=8, nyim=8, use_stokes=True, fine_structure=True,
+              save_peeloff_2D=True, alpha=20.0, beta=55.0, iseed=93)
+    n = 30000
+    sim = make(kw); sim.run_simulation(n); t = sim.ctx.tallies()
+    o = oracle_of(oracle_mod, kw); o.run(n, seed=93)
+    assert rms_diff(t["Jout"], o.array("Jout")) < 0.01
+    for k in ("scatt", "I", "Q"):
+        g, r = t[k][..., 0], o.array(k + ":0").reshape((121, 8, 8), order="F")
+        assert np.allclose(g.sum(axis=0), r.sum(axis=0), rtol=0.05, atol=0.02 * np.abs(o.array("I:0")).reshape((121, 8, 8), order="F").sum(axis=0).max()), k
+    kw = dict(use_clump_medium=True, rmax=1.0, clump_radius=0.05, clump_f_cov=3.0, clump_tau0=30.0, temperature=2e1, nxfreq=121,
+              velocity_min=-15.0, velocity_max=15.0, fine_structure=True, iseed=94)
+    sim = make(kw); sim.ctx.enable_photon_log(True); sim.run_simulation(n); t = sim.ctx.tallies()
+    o = oracle_mod.Oracle(**kw); o.run(n, seed=94)
+    ng, xg = sim.ctx.photon_log(n); no, xo = o.photon_log()
+    same = np.isclose(ng, no, rtol=1e-12, atol=0) & np.isclose(xg, xo, rtol=1e-7, atol=1e-9)
+    assert same.mean() > 0.97 and rms_diff(t["Jout"], o.array("Jout")) < 0.01
 
 
 def test_scheduling_independence(capi):
