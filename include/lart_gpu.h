@@ -37,6 +37,7 @@ typedef struct lart_params {
     /* tallies */
     int32_t save_Jin, save_Jabs, save_Jmu, nmu;
     int32_t save_peeloff, save_peeloff_2D, save_peeloff_3D;
+    int32_t save_direc0, save_dust_scattered;  /* extra peel-off tallies: unattenuated source (direc0), dust-scattered light (scatt_dust) */
     int32_t nxfreq;
     int32_t line_type;             /* line%line_type: 1 single resonance line, 2 Ly-alpha doublet (par%fine_structure, line_mod.f90:1250-1253) */
     double  xs_point, ys_point, zs_point, source_rmax, xfreq0;
@@ -55,6 +56,7 @@ typedef struct lart_tallies {
     double *Jout, *Jin, *Jabs, *Jmu;                         /* nxfreq, nxfreq, nxfreq, nxfreq*nmu */
     double *scatt, *direc, *I, *Q, *U, *V;                   /* nobs*nxfreq*nxim*nyim each */
     double *scatt_2D, *direc_2D, *I_2D, *Q_2D, *U_2D, *V_2D; /* nobs*nxim*nyim each */
+    double *direc0, *direc0_2D, *scatt_dust;                 /* observer(:)%direc0, %direc0_2D (peelingoff_rect.f90:108-125), %scatt_dust (:284-287, :567-570) */
     double *J1, *P1, *P1_new;                                /* nxfreq*nbins, nbins, nbins (lart_gpu_set_JPa) */
     double nscatt_gas, nscatt_dust;                          /* weight sums over finished photons (par%nscatt_*) */
     double n_events;                                         /* scattering events executed */

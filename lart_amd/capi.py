@@ -18,7 +18,7 @@ class LartParams(C.Structure):
     _fields_ = [(n, _i32) for n in (
         "xyz_symmetry", "xy_periodic", "xy_symmetry", "source_geometry", "spectral_type", "comoving_source",
         "recoil", "core_skip", "core_skip_global", "use_stokes", "use_reduced_wgt",
-        "save_Jin", "save_Jabs", "save_Jmu", "nmu", "save_peeloff", "save_peeloff_2D", "save_peeloff_3D", "nxfreq", "line_type")] + \
+        "save_Jin", "save_Jabs", "save_Jmu", "nmu", "save_peeloff", "save_peeloff_2D", "save_peeloff_3D", "save_direc0", "save_dust_scattered", "nxfreq", "line_type")] + \
         [(n, _d) for n in (
             "xs_point", "ys_point", "zs_point", "source_rmax", "xfreq0", "xfreq_min", "dxfreq", "Dfreq_ref",
             "DGR", "hgg", "albedo", "mu_min", "dmu", "g_recoil0", "E1", "E2", "E3", "DnuHK_Hz", "xcrit", "xcrit2")]
@@ -26,7 +26,7 @@ class LartParams(C.Structure):
 
 class LartTallies(C.Structure):
     _fields_ = [(n, _vp) for n in ("Jout", "Jin", "Jabs", "Jmu", "scatt", "direc", "I", "Q", "U", "V",
-                                   "scatt_2D", "direc_2D", "I_2D", "Q_2D", "U_2D", "V_2D", "J1", "P1", "P1_new")] + \
+                                   "scatt_2D", "direc_2D", "I_2D", "Q_2D", "U_2D", "V_2D", "direc0", "direc0_2D", "scatt_dust", "J1", "P1", "P1_new")] + \
         [(n, _d) for n in ("nscatt_gas", "nscatt_dust", "n_events", "n_cellsteps", "n_cellsteps_peel")] + \
         [("nphotons_done", _i64), ("nphotons_active", _i64)]
 
@@ -262,6 +262,12 @@ class Context:
             if p.save_peeloff_2D:
                 for n in names3:
                     out[n + "_2D"] = np.zeros((self.nxim, self.nyim, self.nobs), order="F")
+            if p.save_direc0 and p.save_peeloff_3D:
+                out["direc0"] = np.zeros((nxf, self.nxim, self.nyim, self.nobs), order="F")
+            if p.save_direc0 and p.save_peeloff_2D:
+                out["direc0_2D"] = np.zeros((self.nxim, self.nyim, self.nobs), order="F")
+            if p.save_dust_scattered and p.save_peeloff_3D:
+                out["scatt_dust"] = np.zeros((nxf, self.nxim, self.nyim, self.nobs), order="F")
         if self.nbins:
             if self.jpa[0]:
                 out["J1"] = np.zeros((nxf, self.nbins), order="F")

@@ -64,8 +64,8 @@ struct DMueller { int nPDF; const double *coss, *S11, *S12, *S33, *S34, *phase_P
 struct DTally {
     double *scal;                 // [0] nscatt_gas [1] nscatt_dust [2] n_events [3] n_cellsteps [4] n_cellsteps_peel [5] nphotons_done
     double *Jout, *Jin, *Jabs, *Jmu;
-    double *c3[6];                // scatt, direc, I, Q, U, V       (nobs * nxfreq*nxim*nyim)
-    double *c2[6];                // *_2D                            (nobs * nxim*nyim)
+    double *c3[8];                // scatt, direc, I, Q, U, V, direc0 (par%save_direc0), scatt_dust (par%save_dust_scattered)   (nobs * nxfreq*nxim*nyim)
+    double *c2[8];                // *_2D (no scatt_dust image)      (nobs * nxim*nyim)
 };
 
 // resident photon pool (SoA, coalesced load/store at launch boundaries)
@@ -1355,12 +1355,14 @@ __device__ inline void peel_direct(const KArgs &A, const Lds &l, bool dust, cons
         xfreq_ref = xfreq_ref * (c.Dfreq / A.par.Dfreq_ref);
         int ixf = (int)floor((xfreq_ref - A.par.xfreq_min) / A.par.dxfreq) + 1;
         double tau = raytrace_to_edge<VAR>(A, l, dust, p, xf, q.kx, q.ky, q.kz, q.dist, nsteps);
-        double wgt = d_exp_neg(-tau) * (1.0 / (LART_FOURPI * q.r2) * p.wgt);
-        if (wgt == 0.0) continue;
+        const double wgt0 = 1.0 / (LART_FOURPI * q.r2) * p.wgt, wgt = d_exp_neg(-tau) * wgt0;      // wgt0: the unattenuated source (direc0)
+        if (wgt == 0.0 && !A.par.save_direc0) continue;
         peel_pixel(A, A.obs[i], q);
         if (!q.in_image) continue;
-        if (A.par.save_peeloff_2D) { add_if(A.t.c2[1], pix2(A, i, q.ix, q.iy), wgt); if (A.par.use_stokes) add_if(A.t.c2[2], pix2(A, i, q.ix, q.iy), wgt); }
-        if (A.par.save_peeloff_3D && ixf >= 1 && ixf <= A.par.nxfreq) { add_if(A.t.c3[1], pix3(A, i, ixf, q.ix, q.iy), wgt); if (A.par.use_stokes) add_if(A.t.c3[2], pix3(A, i, ixf, q.ix, q.iy), wgt); }
+        if (A.par.save_peeloff_2D) { add_if(A.t.c2[1], pix2(A, i, q.ix, q.iy), wgt); if (A.par.use_stokes) add_if(A.t.c2[2], pix2(A, i, q.ix, q.iy), wgt);
+                                     if (A.par.save_direc0) add_if(A.t.c2[6], pix2(A, i, q.ix, q.iy), wgt0); }
+        if (A.par.save_peeloff_3D && ixf >= 1 && ixf <= A.par.nxfreq) { add_if(A.t.c3[1], pix3(A, i, ixf, q.ix, q.iy), wgt); if (A.par.use_stokes) add_if(A.t.c3[2], pix3(A, i, ixf, q.ix, q.iy), wgt);
+                                     if (A.par.save_direc0) add_if(A.t.c3[6], pix3(A, i, ixf, q.ix, q.iy), wgt0); }
     }
 }
 // peeling_resonance_nostokes_outside: :576-690
@@ -1454,7 +1456,8 @@ __device__ inline void peel_dust_nostokes(const KArgs &A, const Lds &l, const Ph
         double xfreq_ref = (p.xfreq + u1) * (c.Dfreq / A.par.Dfreq_ref);
         int ixf = (int)floor((xfreq_ref - A.par.xfreq_min) / A.par.dxfreq) + 1;
         if (A.par.save_peeloff_2D) add_if(A.t.c2[0], pix2(A, i, q.ix, q.iy), wgt);
-        if (A.par.save_peeloff_3D && ixf >= 1 && ixf <= A.par.nxfreq) add_if(A.t.c3[0], pix3(A, i, ixf, q.ix, q.iy), wgt);
+        if (A.par.save_peeloff_3D && ixf >= 1 && ixf <= A.par.nxfreq) { add_if(A.t.c3[0], pix3(A, i, ixf, q.ix, q.iy), wgt);
+                                                                          if (A.par.save_dust_scattered) add_if(A.t.c3[7], pix3(A, i, ixf, q.ix, q.iy), wgt); }
     }
 }
 // peeling_dust_stokes_outside: :131-299
@@ -1484,6 +1487,7 @@ __device__ inline void peel_dust_stokes(const KArgs &A, const Lds &l, const Phot
         double cos2g = 2.0 * cosg * cosg - 1.0, sin2g = 2.0 * cosg * sing;
         double Qdet = cos2g * Qobs + sin2g * Uobs, Udet = -sin2g * Qobs + cos2g * Uobs;
         stokes_deposit(A, i, q, ixf, wgt, Iobs, Qdet, Udet, Vobs);
+        if (A.par.save_dust_scattered && A.par.save_peeloff_3D && ixf >= 1 && ixf <= A.par.nxfreq) add_if(A.t.c3[7], pix3(A, i, ixf, q.ix, q.iy), wgt * Iobs);   // :284-287
     }
 }
 

@@ -99,9 +99,10 @@ static int build_tally(lart_gpu *c) {
     int64_t off = 32;                                       // scalars 0..6; 8..31 are section clocks / trip counts of -DLART_PROFILE builds
     int64_t oJout = off; off += nxf; int64_t oJin = off; off += nxf; int64_t oJabs = off; off += nxf; int64_t oJmu = off; off += nxf * nmu;
     const int64_t off_rep = off;                            // everything from here on is contended: gets per-XCD copies
-    int64_t o3[6], o2[6];
-    for (int k = 0; k < 6; k++) { bool on = peel && p.save_peeloff_3D && (k < 2 || p.use_stokes); o3[k] = on ? off : -1; if (on) off += n3; }
-    for (int k = 0; k < 6; k++) { bool on = peel && p.save_peeloff_2D && (k < 2 || p.use_stokes); o2[k] = on ? off : -1; if (on) off += n2; }
+    int64_t o3[8], o2[8];
+    auto wanted = [&](int k) { return k < 2 || (k < 6 && p.use_stokes) || (k == 6 && p.save_direc0) || (k == 7 && p.save_dust_scattered); };
+    for (int k = 0; k < 8; k++) { bool on = peel && p.save_peeloff_3D && wanted(k); o3[k] = on ? off : -1; if (on) off += n3; }
+    for (int k = 0; k < 8; k++) { bool on = peel && p.save_peeloff_2D && wanted(k) && k != 7; o2[k] = on ? off : -1; if (on) off += n2; }
     int64_t oJ1 = -1, oP1 = -1, oPn = -1;
     c->jpa.lds_bins = 0;
     if (c->jpa.nbins > 0) {
@@ -121,7 +122,7 @@ static int build_tally(lart_gpu *c) {
         c->rep.off = off_rep; c->rep.len = len_rep; c->rep.nrep = 8;
     }
     c->t.scal = c->d_tally; c->t.Jout = c->d_tally + oJout; c->t.Jin = c->d_tally + oJin; c->t.Jabs = c->d_tally + oJabs; c->t.Jmu = c->d_tally + oJmu;
-    for (int k = 0; k < 6; k++) { c->t.c3[k] = o3[k] >= 0 ? c->d_tally + o3[k] : nullptr; c->t.c2[k] = o2[k] >= 0 ? c->d_tally + o2[k] : nullptr; }
+    for (int k = 0; k < 8; k++) { c->t.c3[k] = o3[k] >= 0 ? c->d_tally + o3[k] : nullptr; c->t.c2[k] = o2[k] >= 0 ? c->d_tally + o2[k] : nullptr; }
     c->jpa.J1 = oJ1 >= 0 ? c->d_tally + oJ1 : nullptr; c->jpa.P1 = oP1 >= 0 ? c->d_tally + oP1 : nullptr; c->jpa.P1_new = oPn >= 0 ? c->d_tally + oPn : nullptr;
     return 0;
 }
@@ -555,8 +556,8 @@ extern "C" int lart_gpu_get_tallies(lart_gpu *c, lart_tallies *o) {
     int64_t nxf = c->par.nxfreq, n2 = (int64_t)c->nobs * c->nxim * c->nyim, n3 = n2 * nxf;
 #define CP(dst, src, cnt) if ((dst) && (src) && (cnt) > 0) HIPCHK(hipMemcpy((dst), (src), (size_t)(cnt) * 8, hipMemcpyDeviceToHost))
     CP(o->Jout, c->t.Jout, nxf); CP(o->Jin, c->t.Jin, nxf); CP(o->Jabs, c->t.Jabs, nxf); CP(o->Jmu, c->t.Jmu, c->par.save_Jmu ? nxf * c->par.nmu : 0);
-    double *h3[6] = {o->scatt, o->direc, o->I, o->Q, o->U, o->V}, *h2[6] = {o->scatt_2D, o->direc_2D, o->I_2D, o->Q_2D, o->U_2D, o->V_2D};
-    for (int k = 0; k < 6; k++) { CP(h3[k], c->t.c3[k], n3); CP(h2[k], c->t.c2[k], n2); }
+    double *h3[8] = {o->scatt, o->direc, o->I, o->Q, o->U, o->V, o->direc0, o->scatt_dust}, *h2[8] = {o->scatt_2D, o->direc_2D, o->I_2D, o->Q_2D, o->U_2D, o->V_2D, o->direc0_2D, nullptr};
+    for (int k = 0; k < 8; k++) { CP(h3[k], c->t.c3[k], n3); CP(h2[k], c->t.c2[k], n2); }
     CP(o->J1, c->jpa.J1, nxf * c->jpa.nbins); CP(o->P1, c->jpa.P1, c->jpa.nbins); CP(o->P1_new, c->jpa.P1_new, c->jpa.nbins);
 #undef CP
     return 0;

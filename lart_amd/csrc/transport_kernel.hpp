@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256, LART_WAVES(STOKES, PEEL)) void transport_kerne
         const unsigned r = blockIdx.x % (unsigned)A.rep.nrep;
         if (r) {
             const ptrdiff_t shift = (A.rep.base + (size_t)(r - 1) * A.rep.len) - (A.t.scal + A.rep.off);
-            for (int q = 0; q < 6; q++) { if (A.t.c3[q]) A.t.c3[q] += shift; if (A.t.c2[q]) A.t.c2[q] += shift; }
+            for (int q = 0; q < 8; q++) { if (A.t.c3[q]) A.t.c3[q] += shift; if (A.t.c2[q]) A.t.c2[q] += shift; }
             if (A.jpa.J1) A.jpa.J1 += shift; if (A.jpa.P1) A.jpa.P1 += shift; if (A.jpa.P1_new) A.jpa.P1_new += shift;
         }
     }

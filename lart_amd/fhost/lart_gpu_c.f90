@@ -18,6 +18,7 @@ module lart_gpu_c
      integer(c_int32_t) :: recoil, core_skip, core_skip_global, use_stokes, use_reduced_wgt
      integer(c_int32_t) :: save_Jin, save_Jabs, save_Jmu, nmu
      integer(c_int32_t) :: save_peeloff, save_peeloff_2D, save_peeloff_3D
+     integer(c_int32_t) :: save_direc0, save_dust_scattered
      integer(c_int32_t) :: nxfreq
      integer(c_int32_t) :: line_type
      real(c_double) :: xs_point, ys_point, zs_point, source_rmax, xfreq0
@@ -34,6 +35,7 @@ module lart_gpu_c
      type(c_ptr) :: Jout, Jin, Jabs, Jmu
      type(c_ptr) :: scatt, direc, I, Q, U, V
      type(c_ptr) :: scatt_2D, direc_2D, I_2D, Q_2D, U_2D, V_2D
+     type(c_ptr) :: direc0, direc0_2D, scatt_dust
      type(c_ptr) :: J1, P1, P1_new
      real(c_double) :: nscatt_gas, nscatt_dust, n_events, n_cellsteps, n_cellsteps_peel
      integer(c_int64_t) :: nphotons_done, nphotons_active

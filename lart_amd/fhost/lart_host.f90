@@ -58,7 +58,7 @@ module lart_define
      integer  :: nmu = 11
      real(wp) :: mu_min = -1.0_wp, dmu = 0.0_wp
      logical  :: save_peeloff = .false., save_peeloff_2D = .false., save_peeloff_3D = .true.
-     logical  :: save_sightline_tau = .false., save_direc0 = .false., save_all_photons = .false., save_radial_profile = .false.
+     logical  :: save_sightline_tau = .false., save_direc0 = .false., save_all_photons = .false., save_radial_profile = .false., save_dust_scattered = .false.
      integer  :: intensity_unit = -999
      real(wp) :: hgg = 0.6761, albedo = 0.3253, cext_dust = 1.6059e-21, DGR = 0.0
      character(len=128) :: scatt_mat_file = ''
@@ -127,6 +127,7 @@ module lart_define
   !--- peel-off tallies of all observers: (nxfreq,nxim,nyim,nobs) and (nxim,nyim,nobs)
   real(wp), allocatable, target :: obs_scatt(:,:,:,:), obs_direc(:,:,:,:), obs_I(:,:,:,:), obs_Q(:,:,:,:), obs_U(:,:,:,:), obs_V(:,:,:,:)
   real(wp), allocatable, target :: obs_scatt_2D(:,:,:), obs_direc_2D(:,:,:), obs_I_2D(:,:,:), obs_Q_2D(:,:,:), obs_U_2D(:,:,:), obs_V_2D(:,:,:)
+  real(wp), allocatable, target :: obs_direc0(:,:,:,:), obs_direc0_2D(:,:,:), obs_scatt_dust(:,:,:,:)      ! par%save_direc0, par%save_dust_scattered
   !--- octree (amr_grid_type, octree_mod.f90:19-138), filled by grid_create_amr
   integer(int32) :: amr_ncells = 0, amr_nleaf = 0, amr_levelmax = 0, amr_nbins = 0
   real(wp) :: amr_lo = 0.0_wp, amr_hi = 0.0_wp, amr_dbin = 0.0_wp
@@ -1418,12 +1419,21 @@ contains
       no = par%nobs
       if (par%save_peeloff_2D) then
          allocate(obs_scatt_2D(nxi,nyi,no), obs_direc_2D(nxi,nyi,no)); obs_scatt_2D = 0; obs_direc_2D = 0
+         if (par%save_direc0) then
+            allocate(obs_direc0_2D(nxi,nyi,no)); obs_direc0_2D = 0
+         endif
          if (par%use_stokes) then
             allocate(obs_I_2D(nxi,nyi,no), obs_Q_2D(nxi,nyi,no), obs_U_2D(nxi,nyi,no), obs_V_2D(nxi,nyi,no))
          endif
       endif
       if (par%save_peeloff_3D) then
          allocate(obs_scatt(par%nxfreq,nxi,nyi,no), obs_direc(par%nxfreq,nxi,nyi,no)); obs_scatt = 0; obs_direc = 0
+         if (par%save_direc0) then
+            allocate(obs_direc0(par%nxfreq,nxi,nyi,no)); obs_direc0 = 0
+         endif
+         if (par%save_dust_scattered) then
+            allocate(obs_scatt_dust(par%nxfreq,nxi,nyi,no)); obs_scatt_dust = 0
+         endif
          if (par%use_stokes) then
             allocate(obs_I(par%nxfreq,nxi,nyi,no), obs_Q(par%nxfreq,nxi,nyi,no), obs_U(par%nxfreq,nxi,nyi,no), obs_V(par%nxfreq,nxi,nyi,no))
          endif
@@ -1469,6 +1479,7 @@ contains
     if (par%save_peeloff_2D .and. par%nobs > 0) then
        scale_factor = par%no_photons*observer(1)%steradian_pix*par%distance2cm**2
        obs_scatt_2D = obs_scatt_2D/scale_factor; obs_direc_2D = obs_direc_2D/scale_factor
+       if (allocated(obs_direc0_2D)) obs_direc0_2D = obs_direc0_2D/scale_factor
        if (par%use_stokes) then
           obs_I_2D = obs_I_2D/scale_factor; obs_Q_2D = obs_Q_2D/scale_factor; obs_U_2D = obs_U_2D/scale_factor; obs_V_2D = obs_V_2D/scale_factor
        endif
@@ -1476,6 +1487,8 @@ contains
     if (par%save_peeloff_3D .and. par%nobs > 0) then
        scale_factor = par%no_photons*observer(1)%steradian_pix*intensity_bin_unit*par%distance2cm**2
        obs_scatt = obs_scatt/scale_factor; obs_direc = obs_direc/scale_factor
+       if (allocated(obs_direc0)) obs_direc0 = obs_direc0/scale_factor
+       if (allocated(obs_scatt_dust)) obs_scatt_dust = obs_scatt_dust/scale_factor
        if (par%use_stokes) then
           obs_I = obs_I/scale_factor; obs_Q = obs_Q/scale_factor; obs_U = obs_U/scale_factor; obs_V = obs_V/scale_factor
        endif

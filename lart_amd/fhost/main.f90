@@ -143,6 +143,9 @@ program LaRT_amd
   if (allocated(obs_I_2D)) then
      t%I_2D = c_loc(obs_I_2D); t%Q_2D = c_loc(obs_Q_2D); t%U_2D = c_loc(obs_U_2D); t%V_2D = c_loc(obs_V_2D)
   endif
+  if (allocated(obs_direc0))     t%direc0     = c_loc(obs_direc0)
+  if (allocated(obs_direc0_2D))  t%direc0_2D  = c_loc(obs_direc0_2D)
+  if (allocated(obs_scatt_dust)) t%scatt_dust = c_loc(obs_scatt_dust)
   if (allocated(prof_J1))     t%J1     = c_loc(prof_J1)
   if (allocated(prof_P1))     t%P1     = c_loc(prof_P1)
   if (allocated(prof_P1_new)) t%P1_new = c_loc(prof_P1_new)
@@ -229,6 +232,7 @@ contains
     tt%Jout = c_null_ptr; tt%Jin = c_null_ptr; tt%Jabs = c_null_ptr; tt%Jmu = c_null_ptr
     tt%scatt = c_null_ptr; tt%direc = c_null_ptr; tt%I = c_null_ptr; tt%Q = c_null_ptr; tt%U = c_null_ptr; tt%V = c_null_ptr
     tt%scatt_2D = c_null_ptr; tt%direc_2D = c_null_ptr; tt%I_2D = c_null_ptr; tt%Q_2D = c_null_ptr; tt%U_2D = c_null_ptr; tt%V_2D = c_null_ptr
+    tt%direc0 = c_null_ptr; tt%direc0_2D = c_null_ptr; tt%scatt_dust = c_null_ptr
     tt%J1 = c_null_ptr; tt%P1 = c_null_ptr; tt%P1_new = c_null_ptr
   end subroutine null_tallies
 
@@ -242,6 +246,7 @@ contains
     p%use_stokes = merge(1, 0, par%use_stokes); p%use_reduced_wgt = merge(1, 0, par%use_reduced_wgt)
     p%save_Jin = merge(1, 0, par%save_Jin); p%save_Jabs = merge(1, 0, par%save_Jabs); p%save_Jmu = merge(1, 0, par%save_Jmu); p%nmu = par%nmu
     p%save_peeloff = merge(1, 0, par%save_peeloff); p%save_peeloff_2D = merge(1, 0, par%save_peeloff_2D); p%save_peeloff_3D = merge(1, 0, par%save_peeloff_3D)
+    p%save_direc0 = merge(1, 0, par%save_direc0); p%save_dust_scattered = merge(1, 0, par%save_dust_scattered)
     p%nxfreq = grid%nxfreq
     p%xs_point = par%xs_point; p%ys_point = par%ys_point; p%zs_point = par%zs_point; p%source_rmax = par%source_rmax; p%xfreq0 = par%xfreq0
     p%xfreq_min = grid%xfreq_min; p%dxfreq = grid%dxfreq; p%Dfreq_ref = grid%Dfreq_ref
@@ -348,6 +353,8 @@ contains
              else
                 call out_image(o, 'Scattered', [g%nxfreq, nxi, nyi], obs_scatt(:,:,:,io), ko)
                 call out_image(o, 'Direct',    [g%nxfreq, nxi, nyi], obs_direc(:,:,:,io), k0)
+                if (allocated(obs_direc0))     call out_image(o, 'Direct0',  [g%nxfreq, nxi, nyi], obs_direc0(:,:,:,io), k0)
+                if (allocated(obs_scatt_dust)) call out_image(o, 'ScatDust', [g%nxfreq, nxi, nyi], obs_scatt_dust(:,:,:,io), k0)
              endif
              if (par%save_radial_profile .and. par%nside == 0) then
                 call radial_profiles(g, io, .false., rad)
@@ -376,6 +383,7 @@ contains
              else
                 call out_image(o, 'Scattered', [nxi, nyi], obs_scatt_2D(:,:,io), ko)
                 call out_image(o, 'Direct',    [nxi, nyi], obs_direc_2D(:,:,io), k0)
+                if (allocated(obs_direc0_2D)) call out_image(o, 'Direct0', [nxi, nyi], obs_direc0_2D(:,:,io), k0)
              endif
              if (par%save_radial_profile .and. par%nside == 0) then
                 call radial_profiles(g, io, .true., rad)

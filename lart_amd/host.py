@@ -104,8 +104,9 @@ class Params:
     save_peeloff_2D: bool = False
     save_peeloff_3D: bool = True
     save_sightline_tau: bool = False
-    save_radial_profile: bool = False
     save_direc0: bool = False
+    save_dust_scattered: bool = False
+    save_radial_profile: bool = False
     hgg: float = _f32(0.6761)
     albedo: float = _f32(0.3253)
     cext_dust: float = _f32(1.6059e-21)
@@ -169,7 +170,7 @@ _UNSUPPORTED_DEFAULTS = {
     "star_file": "", "use_cie_condition": False, "density_rscale": -999.9, "density_zscale": -999.9,
     "density_alpha": 0.0, "cone_opening": 0.0, "Omega": 0.0, "save_all_photons": False, "temperature0": -999.0,
     "line_prof_file": "", "luminosity": 1.0, "save_backup": False, "save_input_grid": False,
-    "save_dust_scattered": False, "intensity_unit": -999, "out_bitpix": 0,
+    "intensity_unit": -999, "out_bitpix": 0,
 }
 
 
@@ -784,7 +785,8 @@ def observer_create(par):
 def make_lart_params(par, line, g):
     p = capi.LartParams()
     for n in ("xyz_symmetry", "xy_periodic", "xy_symmetry", "comoving_source", "recoil", "core_skip", "core_skip_global", "use_stokes",
-              "use_reduced_wgt", "save_Jin", "save_Jabs", "save_Jmu", "nmu", "save_peeloff", "save_peeloff_2D", "save_peeloff_3D"):
+              "use_reduced_wgt", "save_Jin", "save_Jabs", "save_Jmu", "nmu", "save_peeloff", "save_peeloff_2D", "save_peeloff_3D",
+              "save_direc0", "save_dust_scattered"):
         setattr(p, n, int(getattr(par, n)))
     p.source_geometry = {"point": 0, "uniform_sphere": 1}[par.source_geometry]
     p.spectral_type = {"monochromatic": 0, "voigt": 1}[par.spectral_type]
@@ -907,7 +909,7 @@ class Simulation:
         if self.obs.nobs:
             sc3 = nph * self.obs.steradian_pix * unit * par.distance2cm ** 2                    # :428-430
             sc2 = nph * self.obs.steradian_pix * par.distance2cm ** 2
-            for k in ("scatt", "direc", "I", "Q", "U", "V"):
+            for k in ("scatt", "direc", "I", "Q", "U", "V", "direc0", "scatt_dust"):
                 if k in t:
                     out[k] = t[k] / sc3
                 if k + "_2D" in t:

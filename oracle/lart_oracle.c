@@ -263,6 +263,7 @@ typedef struct {
     double x, y, z, rm[9];            /* rmatrix row-major rm[3*r+c] = rmatrix(r+1,c+1) */
     double *scatt, *direc, *I, *Q, *U, *V;
     double *scatt_2D, *direc_2D, *I_2D, *Q_2D, *U_2D, *V_2D;
+    double *direc0, *direc0_2D, *scatt_dust;      /* par%save_direc0, par%save_dust_scattered */
 } obs_t;
 
 typedef struct {
@@ -311,7 +312,7 @@ struct orc_sim {
     int use_stokes, use_reduced_wgt, save_Jin, save_Jabs, save_Jmu, nmu;
     double mu_min, dmu;
     double hgg, albedo, cext_dust, DGR, distance2cm;
-    int save_peeloff, save_peeloff_2D, save_peeloff_3D, nobs, nxim, nyim;
+    int save_peeloff, save_peeloff_2D, save_peeloff_3D, save_direc0, save_dust_scattered, nobs, nxim, nyim;
     double distance, alpha[MAX_OBS], beta[MAX_OBS], gamma[MAX_OBS], obsx[MAX_OBS], obsy[MAX_OBS], obsz[MAX_OBS], dxim, dyim;
     char scatt_mat_file[512];
     int geometry;                    /* 0 sphere, 1 rectangle */
@@ -388,7 +389,7 @@ static int set_param(orc_sim *s, const char *k, const char *v) {
     B(comoving_source) B(recoil) B(core_skip) B(core_skip_global) B(xyz_symmetry) B(xy_periodic) B(xy_symmetry) B(fine_structure)
     I(nx) I(ny) I(nz) D(xmax) D(ymax) D(zmax) D(rmax) D(rmin) D(xs_point) D(ys_point) D(zs_point) D(source_rmax)
     D(xfreq0) I(nxfreq) B(use_stokes) B(use_reduced_wgt) B(save_Jin) B(save_Jabs) B(save_Jmu) I(nmu)
-    D(hgg) D(albedo) D(cext_dust) D(DGR) D(distance2cm) B(save_peeloff) B(save_peeloff_2D) B(save_peeloff_3D)
+    D(hgg) D(albedo) D(cext_dust) D(DGR) D(distance2cm) B(save_peeloff) B(save_peeloff_2D) B(save_peeloff_3D) B(save_direc0) B(save_dust_scattered)
     I(nxim) I(nyim) D(distance) D(dxim) D(dyim) B(calc_J) B(calc_P) B(calc_Pnew) I(geometry_JPa) I(nside)
     if (!strcmp(k, "xfreq_min")) { s->par_xfreq_min = atof(v); return 0; }
     if (!strcmp(k, "xfreq_max")) { s->par_xfreq_max = atof(v); return 0; }
@@ -789,8 +790,8 @@ static int observer_create(orc_sim *s) {
         s->nobs = n; s->npix = 12 * s->nside * s->nside; s->nxim = s->npix; s->nyim = 1;
         size_t n2 = s->npix, n3 = n2 * s->nxfreq;
         for (int i = 0; i < n; i++) { obs_t *o = &s->obs[i]; o->x = s->obsx[i]; o->y = s->obsy[i]; o->z = s->obsz[i];
-            if (s->save_peeloff_2D) { o->scatt_2D = calloc(n2, 8); o->direc_2D = calloc(n2, 8); }
-            if (s->save_peeloff_3D) { o->scatt = calloc(n3, 8); o->direc = calloc(n3, 8); } }
+            if (s->save_peeloff_2D) { o->scatt_2D = calloc(n2, 8); o->direc_2D = calloc(n2, 8); if (s->save_direc0) o->direc0_2D = calloc(n2, 8); }
+            if (s->save_peeloff_3D) { o->scatt = calloc(n3, 8); o->direc = calloc(n3, 8); if (s->save_direc0) o->direc0 = calloc(n3, 8); if (s->save_dust_scattered) o->scatt_dust = calloc(n3, 8); } }
         return 0;
     }
     double cosa[MAX_OBS], sina[MAX_OBS], cosb[MAX_OBS], sinb[MAX_OBS], cosg[MAX_OBS], sing[MAX_OBS];
@@ -855,9 +856,9 @@ static int observer_create(orc_sim *s) {
     }
     size_t n2 = (size_t)s->nxim * s->nyim, n3 = n2 * s->nxfreq;                    /* :287-324 */
     for (int i = 0; i < s->nobs; i++) { obs_t *o = &s->obs[i];
-        if (s->save_peeloff_2D) { o->scatt_2D = calloc(n2, 8); o->direc_2D = calloc(n2, 8);
+        if (s->save_peeloff_2D) { o->scatt_2D = calloc(n2, 8); o->direc_2D = calloc(n2, 8); if (s->save_direc0) o->direc0_2D = calloc(n2, 8);
             if (s->use_stokes) { o->I_2D = calloc(n2, 8); o->Q_2D = calloc(n2, 8); o->U_2D = calloc(n2, 8); o->V_2D = calloc(n2, 8); } }
-        if (s->save_peeloff_3D) { o->scatt = calloc(n3, 8); o->direc = calloc(n3, 8);
+        if (s->save_peeloff_3D) { o->scatt = calloc(n3, 8); o->direc = calloc(n3, 8); if (s->save_direc0) o->direc0 = calloc(n3, 8); if (s->save_dust_scattered) o->scatt_dust = calloc(n3, 8);
             if (s->use_stokes) { o->I = calloc(n3, 8); o->Q = calloc(n3, 8); o->U = calloc(n3, 8); o->V = calloc(n3, 8); } } }
     return 0;
 }
@@ -876,7 +877,8 @@ orc_sim *orc_create(const char *params) {
     return s;
 }
 static void free_obs(obs_t *o) { free(o->scatt); free(o->direc); free(o->I); free(o->Q); free(o->U); free(o->V);
-    free(o->scatt_2D); free(o->direc_2D); free(o->I_2D); free(o->Q_2D); free(o->U_2D); free(o->V_2D); }
+    free(o->scatt_2D); free(o->direc_2D); free(o->I_2D); free(o->Q_2D); free(o->U_2D); free(o->V_2D);
+    free(o->direc0); free(o->direc0_2D); free(o->scatt_dust); }
 void orc_destroy(orc_sim *s) {
     if (!s) return;
     free(s->xface); free(s->yface); free(s->zface); free(s->rhokap); free(s->voigt_a); free(s->Dfreq); free(s->vfx); free(s->vfy); free(s->vfz); free(s->rhokapD);
@@ -1871,8 +1873,8 @@ static void peeling_direct(const orc_sim *s, acc_t *A, const photon_t *p) {
             double tau = peel_tau(s, A, &po, r2);
             double wgt0 = 1.0 / (FOURPI * r2) * p->wgt, wgt = exp(-tau) * wgt0;
             obs_t *o = &A->obs[i];
-            if (s->save_peeloff_2D) { o->direc_2D[PIX2(s,ix,iy)] += wgt; if (s->use_stokes) o->I_2D[PIX2(s,ix,iy)] += wgt; }
-            if (s->save_peeloff_3D && ixf >= 1 && ixf <= s->nxfreq) { o->direc[PIX3(s,ixf,ix,iy)] += wgt; if (s->use_stokes) o->I[PIX3(s,ixf,ix,iy)] += wgt; }
+            if (s->save_peeloff_2D) { o->direc_2D[PIX2(s,ix,iy)] += wgt; if (s->use_stokes) o->I_2D[PIX2(s,ix,iy)] += wgt; if (s->save_direc0) o->direc0_2D[PIX2(s,ix,iy)] += wgt0; }
+            if (s->save_peeloff_3D && ixf >= 1 && ixf <= s->nxfreq) { o->direc[PIX3(s,ixf,ix,iy)] += wgt; if (s->use_stokes) o->I[PIX3(s,ixf,ix,iy)] += wgt; if (s->save_direc0) o->direc0[PIX3(s,ixf,ix,iy)] += wgt0; }
         }
     }
 }
@@ -1956,7 +1958,7 @@ static void peeling_dust_nostokes(const orc_sim *s, acc_t *A, const photon_t *p)
         double wgt = peel / r2 * exp(-tau) * p->wgt;
         obs_t *o = &A->obs[i];
         if (s->save_peeloff_2D) o->scatt_2D[PIX2(s,ix,iy)] += wgt;
-        if (s->save_peeloff_3D && ixf >= 1 && ixf <= s->nxfreq) o->scatt[PIX3(s,ixf,ix,iy)] += wgt;
+        if (s->save_peeloff_3D && ixf >= 1 && ixf <= s->nxfreq) { o->scatt[PIX3(s,ixf,ix,iy)] += wgt; if (s->save_dust_scattered) o->scatt_dust[PIX3(s,ixf,ix,iy)] += wgt; }   /* :567-570 */
     }
 }
 /* peeling_dust_stokes_outside: :131-299 */
@@ -1982,6 +1984,7 @@ static void peeling_dust_stokes(const orc_sim *s, acc_t *A, const photon_t *p) {
         double tau = peel_tau(s, A, &po, r2);
         double wgt = 1.0 / r2 * exp(-tau) * p->wgt;
         stokes_deposit(s, &A->obs[i], ix, iy, ixf, wgt, Idet, Qdet, Udet, Vdet);
+        if (s->save_dust_scattered && s->save_peeloff_3D && ixf >= 1 && ixf <= s->nxfreq && ix >= 1 && ix <= s->nxim && iy >= 1 && iy <= s->nyim) A->obs[i].scatt_dust[PIX3(s,ixf,ix,iy)] += wgt * Idet;   /* :284-287 */
     }
 }
 
@@ -2239,6 +2242,7 @@ static void acc_alloc(acc_t *A, orc_sim *s) {
         if (q->scatt_2D) { o->scatt_2D = calloc(n2, 8); o->direc_2D = calloc(n2, 8); }
         if (q->I_2D) { o->I_2D = calloc(n2, 8); o->Q_2D = calloc(n2, 8); o->U_2D = calloc(n2, 8); o->V_2D = calloc(n2, 8); }
         if (q->scatt) { o->scatt = calloc(n3, 8); o->direc = calloc(n3, 8); }
+        if (q->direc0) o->direc0 = calloc(n3, 8); if (q->direc0_2D) o->direc0_2D = calloc(n2, 8); if (q->scatt_dust) o->scatt_dust = calloc(n3, 8);
         if (q->I) { o->I = calloc(n3, 8); o->Q = calloc(n3, 8); o->U = calloc(n3, 8); o->V = calloc(n3, 8); } }
 }
 static void addv(double *dst, const double *src, size_t n) { if (dst && src) for (size_t i = 0; i < n; i++) dst[i] += src[i]; }
@@ -2247,6 +2251,7 @@ static void acc_merge_free(acc_t *A, orc_sim *s) {
     size_t n2 = (size_t)s->nxim * s->nyim, n3 = n2 * s->nxfreq;
     for (int i = 0; i < s->nobs; i++) { obs_t *o = &A->obs[i], *q = &s->obs[i];
         addv(q->scatt_2D, o->scatt_2D, n2); addv(q->direc_2D, o->direc_2D, n2); addv(q->I_2D, o->I_2D, n2); addv(q->Q_2D, o->Q_2D, n2); addv(q->U_2D, o->U_2D, n2); addv(q->V_2D, o->V_2D, n2);
+        addv(q->direc0, o->direc0, n3); addv(q->direc0_2D, o->direc0_2D, n2); addv(q->scatt_dust, o->scatt_dust, n3);
         addv(q->scatt, o->scatt, n3); addv(q->direc, o->direc, n3); addv(q->I, o->I, n3); addv(q->Q, o->Q, n3); addv(q->U, o->U, n3); addv(q->V, o->V, n3);
         free_obs(o); }
     s->nscatt_gas += A->nscatt_gas; s->nscatt_dust += A->nscatt_dust;
@@ -2298,7 +2303,8 @@ void orc_zero_tallies(orc_sim *s) {
     size_t n2 = (size_t)s->nxim * s->nyim, n3 = n2 * s->nxfreq;
     for (int i = 0; i < s->nobs; i++) { obs_t *o = &s->obs[i];
         double *a2[6] = {o->scatt_2D, o->direc_2D, o->I_2D, o->Q_2D, o->U_2D, o->V_2D}, *a3[6] = {o->scatt, o->direc, o->I, o->Q, o->U, o->V};
-        for (int k = 0; k < 6; k++) { if (a2[k]) memset(a2[k], 0, n2 * 8); if (a3[k]) memset(a3[k], 0, n3 * 8); } }
+        for (int k = 0; k < 6; k++) { if (a2[k]) memset(a2[k], 0, n2 * 8); if (a3[k]) memset(a3[k], 0, n3 * 8); }
+        if (o->direc0) memset(o->direc0, 0, n3 * 8); if (o->direc0_2D) memset(o->direc0_2D, 0, n2 * 8); if (o->scatt_dust) memset(o->scatt_dust, 0, n3 * 8); }
     if (s->J1) memset(s->J1, 0, (size_t)s->nxfreq * s->nbins * 8); if (s->P1) memset(s->P1, 0, s->nbins * 8); if (s->P1_new) memset(s->P1_new, 0, s->nbins * 8);
     s->nscatt_gas = s->nscatt_dust = 0.0; s->nphotons_done = 0; s->n_cellsteps = s->n_cellsteps_peel = s->n_events = 0.0;
 }
@@ -2386,6 +2392,7 @@ int64_t orc_get_array(const orc_sim *s, const char *k, double *out, int64_t n) {
     if (col) { int io = atoi(col + 1); if (io < 0 || io >= s->nobs) return -1; const obs_t *o = &s->obs[io];
         int64_t n2 = (int64_t)s->nxim * s->nyim, n3 = n2 * s->nxfreq; size_t L = col - k;
 #define M(name, ptr, cnt) if (L == strlen(name) && !strncmp(k, name, L)) return copy_out(ptr, cnt, out, n);
+        M("direc0_2D", o->direc0_2D, n2) M("direc0", o->direc0, n3) M("scatt_dust", o->scatt_dust, n3)
         M("scatt", o->scatt, n3) M("direc", o->direc, n3) M("I", o->I, n3) M("Q", o->Q, n3) M("U", o->U, n3) M("V", o->V, n3)
         M("scatt_2D", o->scatt_2D, n2) M("direc_2D", o->direc_2D, n2) M("I_2D", o->I_2D, n2) M("Q_2D", o->Q_2D, n2) M("U_2D", o->U_2D, n2) M("V_2D", o->V_2D, n2)
 #undef M

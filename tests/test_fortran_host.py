@@ -323,6 +323,11 @@ def test_output_containers_hdf5_and_gzip_fits(exe, tmp_path):
     assert list(S) == ["Stokes_I", "Stokes_Q", "Stokes_U", "Stokes_V"] and S["Stokes_Q"][1].shape == (41, 8, 8)
     assert list(O) == ["Scattered", "Direct"] and O["Direct"][1].shape == (41, 8, 8)
     assert list(read_fits(str(tmp_path / "cf_obs.fits.gz"))) == ["Scattered", "Direct"]
+    r = run(exe, base + " par%DGR = 1.0\n par%use_stokes = .false.\n par%save_peeloff_2D = .true.\n par%save_direc0 = .true.\n par%save_dust_scattered = .true.\n/\n", tmp_path,
+            "--dry-run-write", name="cd.in")
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert list(read_h5(str(tmp_path / "cd_obs.h5"))) == ["Scattered", "Direct", "Direct0", "ScatDust"]
+    assert list(read_h5(str(tmp_path / "cd_obs2D.h5"))) == ["Scattered", "Direct", "Direct0"]
 
 
 JPA_IN = ("&parameters\n par%no_photons = 20000\n par%temperature = 1e4\n par%taumax = 1e3\n par%nx = 21\n par%ny = 21\n par%nz = 21\n"

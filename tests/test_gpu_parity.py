@@ -290,6 +290,29 @@ def test_dust_mueller_vs_oracle(capi, oracle_mod, mueller_file):
     assert abs(t["Jout"].sum() + t["Jabs"].sum() - n) < 0.01 * n
 
 
+@pytest.mark.parametrize("stokes", [False, True])
+def test_direct0_and_dust_scattered_tallies(capi, oracle_mod, mueller_file, stokes):
+    """par%save_direc0 (the source without extinction, peelingoff_rect.f90:108-125) and par%save_dust_scattered (the dust-scattered
+    part of the scattered light, :284-287 / :567-570) against the oracle on the same streams"""
+    kw = dict(temperature=1e4, taumax=3e1, nx=21, ny=21, nz=21, rmax=1.0, nxfreq=61, nxim=8, nyim=8, DGR=1.0, cext_dust=2e-15,
+              save_peeloff_2D=True, save_direc0=True, save_dust_scattered=True, alpha=15.0, beta=40.0, iseed=97)
+    if stokes:                                            # (the Mueller file brings its own cross-section per H: scale it with DGR)
+        kw.update(use_stokes=True, scatt_mat_file=mueller_file, DGR=1.2e6)
+    n = 30000
+    sim = make(kw); sim.run_simulation(n); t = sim.ctx.tallies()
+    o = oracle_of(oracle_mod, kw); o.run(n, seed=97)
+    d0 = o.array("direc0:0").reshape((61, 8, 8), order="F"); sd = o.array("scatt_dust:0").reshape((61, 8, 8), order="F")
+    # a point source: every photon peels its unattenuated 1/(4 pi r^2) into the pixel of the source
+    assert np.isclose(t["direc0"].sum(), d0.sum(), rtol=1e-9) and np.isclose(t["direc0_2D"].sum(), o.array("direc0_2D:0").sum(), rtol=1e-9)
+    assert np.isclose(t["direc0_2D"].sum(), n / (4 * np.pi * sim.par.distance ** 2), rtol=1e-6)
+    assert t["direc"].sum() < t["direc0"].sum() and np.isclose(t["direc"].sum(), o.array("direc:0").sum(), rtol=0.02)
+    assert sd.sum() > 0 and np.isclose(t["scatt_dust"].sum(), sd.sum(), rtol=0.06)
+    assert t["scatt_dust"].sum() < t["scatt"].sum()
+    assert rms_diff(t["scatt_dust"][..., 0].sum(axis=(1, 2)), sd.sum(axis=(1, 2))) < 0.05
+    out = sim.output_normalize(t)
+    assert out["direc0"].shape == t["direc0"].shape and np.all(np.isfinite(out["scatt_dust"]))
+
+
 def test_edge_cases(capi):
     # zero photons, one photon, optically thin medium (forced first scattering weight ~ tau0), source off-centre
     sim = make(dict(temperature=1e4, taumax=1e-3, nx=11, ny=11, nz=11, rmax=1.0, nxfreq=41, xfreq_min=-12.0, xfreq_max=12.0, xs_point=0.3, ys_point=-0.2, zs_point=0.1, iseed=3))
