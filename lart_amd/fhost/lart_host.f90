@@ -79,7 +79,7 @@ module lart_define
      logical  :: use_clump_medium = .false., clump_fully_inside = .true., save_clump_info = .false.
      real(wp) :: clump_radius = -1.0_wp, clump_N_clumps = -1.0_wp, clump_f_vol = -1.0_wp, clump_f_cov = -1.0_wp
      real(wp) :: clump_tau0 = -1.0_wp, clump_NHI = -1.0_wp, clump_nH = -1.0_wp, clump_temperature = -1.0_wp, clump_sigma_v = 0.0_wp
-     real(wp) :: Vrot = 0.0_wp, rinner = 0.0_wp
+     real(wp) :: Vrot = 0.0_wp, rinner = 0.0_wp, Vpeak = 0.0_wp, rpeak = 0.0_wp, DeltaV = 0.0_wp, velocity_alpha = 1.0_wp
      character(len=20)  :: line_id = 'ly_alpha'
      character(len=8)   :: h2_model = 'none'
      character(len=128) :: dens_file = '', temp_file = '', velo_file = '', emiss_file = '', cart_file = '', input_field = '', star_file = ''
@@ -268,8 +268,9 @@ contains
        call not_supported('par%spectral_type = '//trim(par%spectral_type))
     select case(trim(par%velocity_type))
     case ('', 'hubble', 'constant_radial', 'parallel_velocity')
-    case ('rotating_solid_body', 'rotating_galaxy_halo')       ! per-clump fields of assign_clump_velocities_from_type
-       if (.not. par%use_clump_medium) call not_supported('par%velocity_type = '//trim(par%velocity_type))
+    case ('rotating_solid_body', 'rotating_galaxy_halo')       ! Cartesian grid, or per-clump fields of assign_clump_velocities_from_type
+    case ('power_law', 'linear_decelerate', 'ssh')
+       if (par%use_clump_medium) call not_supported('par%velocity_type = '//trim(par%velocity_type)//' with the clump medium')
     case default; call not_supported('par%velocity_type = '//trim(par%velocity_type))
     end select
 
@@ -504,7 +505,7 @@ contains
     type(grid_type), intent(inout) :: grid
     integer  :: i, j, k, nx, ny, nz, nxcen, nycen
     real(wp) :: rr, vtherm, opac_length, opacity_sum, opacity1, opac_norm, nopac, nadd, os2
-    real(wp) :: tauhomo, taupole, N_gashomo, N_gaspole, atau0, atau0_cell, xi, chi, rpeak
+    real(wp) :: tauhomo, taupole, N_gashomo, N_gaspole, atau0, atau0_cell, xi, chi, rpeak, Vscale
     real(wp), allocatable :: xx(:), yy(:), zz(:)
 
     grid%nx = par%nx; grid%ny = par%ny; grid%nz = par%nz
@@ -658,6 +659,34 @@ contains
                 endif
              case ('parallel_velocity')
                 grid%vfx(i,j,k) = par%Vx/vtherm; grid%vfy(i,j,k) = par%Vy/vtherm; grid%vfz(i,j,k) = par%Vz/vtherm
+             case ('rotating_solid_body')                                                           ! :905-916
+                grid%vfx(i,j,k) = -par%Vrot/vtherm*yy(j)/par%rmax; grid%vfy(i,j,k) = par%Vrot/vtherm*xx(i)/par%rmax
+             case ('rotating_galaxy_halo')                                                          ! :917-934
+                rr = sqrt(xx(i)**2 + yy(j)**2)
+                if (rr < par%rinner) then
+                   grid%vfx(i,j,k) = -par%Vrot/vtherm*yy(j)/par%rinner; grid%vfy(i,j,k) = par%Vrot/vtherm*xx(i)/par%rinner
+                else
+                   grid%vfx(i,j,k) = -par%Vrot/vtherm*yy(j)/rr; grid%vfy(i,j,k) = par%Vrot/vtherm*xx(i)/rr
+                endif
+             case ('power_law', 'linear_decelerate')                                                ! :853-904
+                rr = sqrt(xx(i)**2 + yy(j)**2 + zz(k)**2)
+                if (rr > grid%dz/10.0_wp) then
+                   if (trim(par%velocity_type) == 'power_law') then
+                      Vscale = par%Vexp*(rr/rpeak)**par%velocity_alpha
+                   else
+                      Vscale = par%Vexp*max(0.0_wp, (rpeak - rr)/(rpeak - max(par%rmin, 0.0_wp)))
+                   endif
+                   grid%vfx(i,j,k) = Vscale/vtherm*xx(i)/rr; grid%vfy(i,j,k) = Vscale/vtherm*yy(j)/rr; grid%vfz(i,j,k) = Vscale/vtherm*zz(k)/rr
+                endif
+             case ('ssh')                                                                           ! :817-838 (par%rpeak is an input)
+                rr = sqrt(xx(i)**2 + yy(j)**2 + zz(k)**2)
+                if (rr < par%rpeak) then
+                   Vscale = par%Vpeak/par%rpeak
+                   grid%vfx(i,j,k) = Vscale/vtherm*xx(i); grid%vfy(i,j,k) = Vscale/vtherm*yy(j); grid%vfz(i,j,k) = Vscale/vtherm*zz(k)
+                else
+                   Vscale = par%Vpeak + par%DeltaV*(rr - par%rpeak)/(par%rmax - par%rpeak)
+                   grid%vfx(i,j,k) = Vscale/vtherm*xx(i)/rr; grid%vfy(i,j,k) = Vscale/vtherm*yy(j)/rr; grid%vfz(i,j,k) = Vscale/vtherm*zz(k)/rr
+                endif
              end select
           endif
        enddo; enddo; enddo

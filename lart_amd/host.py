@@ -148,6 +148,10 @@ class Params:
     save_clump_info: bool = False
     Vrot: float = 0.0
     rinner: float = 0.0
+    Vpeak: float = 0.0
+    rpeak: float = 0.0
+    DeltaV: float = 0.0
+    velocity_alpha: float = 1.0
     # octree medium (grid_mod_amr.f90); only the generic text format of read_generic_amr.f90:112-185 is read here
     use_amr_grid: bool = False
     amr_type: str = "generic"
@@ -328,8 +332,10 @@ def read_input(par, line=None):
         raise LartInputError("par%%source_geometry = '%s' is not supported by this path" % par.source_geometry)
     if par.spectral_type not in ("voigt", "monochromatic"):
         raise LartInputError("par%%spectral_type = '%s' is not supported by this path" % par.spectral_type)
-    if par.use_clump_medium and par.velocity_type in ("rotating_solid_body", "rotating_galaxy_halo"):
-        pass                                                              # per-clump fields of assign_clump_velocities_from_type
+    if par.velocity_type in ("rotating_solid_body", "rotating_galaxy_halo"):
+        pass                                                              # (clump medium: per-clump fields of assign_clump_velocities_from_type)
+    elif par.velocity_type in ("power_law", "linear_decelerate", "ssh") and not par.use_clump_medium:
+        pass
     elif par.velocity_type not in ("", "hubble", "constant_radial", "parallel_velocity"):
         raise LartInputError("par%%velocity_type = '%s' is not supported by this path" % par.velocity_type)
     if par.temperature <= 0.0:
@@ -584,8 +590,27 @@ def grid_create(par, line):
             m = gas & (rr > g.dz / 10.0)
             with np.errstate(invalid="ignore", divide="ignore"):
                 g.vfx[m] = (par.Vexp / vth * X / rr)[m]; g.vfy[m] = (par.Vexp / vth * Y / rr)[m]; g.vfz[m] = (par.Vexp / vth * Z / rr)[m]
-        else:
+        elif par.velocity_type == "parallel_velocity":
             g.vfx[gas] = par.Vx / vth; g.vfy[gas] = par.Vy / vth; g.vfz[gas] = par.Vz / vth
+        elif par.velocity_type == "rotating_solid_body":                  # :905-916
+            g.vfx[gas] = (-par.Vrot / vth * Y / par.rmax)[gas]; g.vfy[gas] = (par.Vrot / vth * X / par.rmax)[gas]
+        elif par.velocity_type == "rotating_galaxy_halo":                 # :917-934
+            rc = np.sqrt(X ** 2 + Y ** 2)
+            with np.errstate(invalid="ignore", divide="ignore"):
+                den = np.where(rc < par.rinner, par.rinner, rc)
+                g.vfx[gas] = (-par.Vrot / vth * Y / den)[gas]; g.vfy[gas] = (par.Vrot / vth * X / den)[gas]
+        else:                                                             # power_law :853-874, linear_decelerate :875-904, ssh :817-838
+            m = gas & (rr > g.dz / 10.0)
+            with np.errstate(invalid="ignore", divide="ignore"):
+                if par.velocity_type == "power_law":
+                    Vs = par.Vexp * (rr / rpeak) ** par.velocity_alpha
+                elif par.velocity_type == "linear_decelerate":
+                    Vs = par.Vexp * np.maximum(0.0, (rpeak - rr) / (rpeak - max(par.rmin, 0.0)))
+                else:
+                    rp = par.rpeak; m = gas
+                    Vs = np.where(rr < rp, par.Vpeak / rp * rr, par.Vpeak + par.DeltaV * (rr - rp) / (par.rmax - rp))
+                ur = np.where(rr > 0.0, 1.0 / np.where(rr > 0.0, rr, 1.0), 0.0)
+                g.vfx[m] = (Vs / vth * X * ur)[m]; g.vfy[m] = (Vs / vth * Y * ur)[m]; g.vfz[m] = (Vs / vth * Z * ur)[m]
     g.voigt_amean = (line.damping / FOURPI) / g.Dfreq_ref                 # :1150-1154
     atau0 = g.voigt_amean * par.tauhomo
     car_setup_freq_grid(par, line, g)

@@ -298,7 +298,7 @@ struct orc_sim {
     int use_amr_grid; char amr_file[512]; amr_t amr;
     int use_clump_medium, clump_fully_inside; clumps_t cl;
     double clump_radius, clump_N_clumps, clump_f_vol, clump_f_cov, clump_tau0, clump_NHI, clump_nH, clump_temperature, clump_sigma_v;
-    double Vrot, rinner, velocity_min, velocity_max;
+    double Vrot, rinner, velocity_min, velocity_max, Vpeak, rpeak, DeltaV, velocity_alpha;
     /* --- par% (define.f90:209-544) --- */
     double no_photons; int iseed;
     double temperature, taumax, tauhomo, N_gasmax, N_gashomo, Vexp;
@@ -378,7 +378,7 @@ static void set_defaults(orc_sim *s) {
     for (int i = 0; i < MAX_OBS; i++) s->alpha[i] = s->beta[i] = s->gamma[i] = s->obsx[i] = s->obsy[i] = s->obsz[i] = NAN;
     s->geometry = 0; s->geometry_JPa = 2147483647;
     s->clump_radius = s->clump_N_clumps = s->clump_f_vol = s->clump_f_cov = s->clump_tau0 = s->clump_NHI = s->clump_nH = s->clump_temperature = -1.0;
-    s->clump_fully_inside = 1; s->velocity_min = NAN; s->velocity_max = NAN;
+    s->clump_fully_inside = 1; s->velocity_min = NAN; s->velocity_max = NAN; s->velocity_alpha = 1.0;
 }
 
 static int set_param(orc_sim *s, const char *k, const char *v) {
@@ -397,7 +397,7 @@ static int set_param(orc_sim *s, const char *k, const char *v) {
     if (!strcmp(k, "N_HIhomo") || !strcmp(k, "N_gashomo")) { s->N_gashomo = atof(v); return 0; }
     if (!strcmp(k, "tau0")) { s->taumax = atof(v); return 0; }
     B(use_clump_medium) B(clump_fully_inside) D(clump_radius) D(clump_N_clumps) D(clump_f_vol) D(clump_f_cov) D(clump_tau0) D(clump_NHI) D(clump_nH)
-    D(clump_temperature) D(clump_sigma_v) D(Vrot) D(rinner) D(velocity_min) D(velocity_max)
+    D(clump_temperature) D(clump_sigma_v) D(Vrot) D(rinner) D(velocity_min) D(velocity_max) D(Vpeak) D(rpeak) D(DeltaV) D(velocity_alpha)
     if (!strcmp(k, "use_amr_grid")) { s->use_amr_grid = parse_bool(v); return 0; }
     if (!strcmp(k, "amr_file")) { snprintf(s->amr_file, sizeof s->amr_file, "%s", v); return 0; }
     if (!strcmp(k, "amr_type")) return 0;
@@ -413,7 +413,8 @@ static int set_param(orc_sim *s, const char *k, const char *v) {
     if (!strcmp(k, "velocity_type")) {
         if (!strcmp(v, "hubble")) s->velocity_type = 1; else if (!strcmp(v, "constant_radial")) s->velocity_type = 2;
         else if (!strcmp(v, "parallel_velocity")) s->velocity_type = 3; else if (!v[0]) s->velocity_type = 0;
-        else if (!strcmp(v, "rotating_solid_body")) s->velocity_type = 4; else if (!strcmp(v, "rotating_galaxy_halo")) s->velocity_type = 5;   /* clump medium only */
+        else if (!strcmp(v, "rotating_solid_body")) s->velocity_type = 4; else if (!strcmp(v, "rotating_galaxy_halo")) s->velocity_type = 5;
+        else if (!strcmp(v, "power_law")) s->velocity_type = 6; else if (!strcmp(v, "linear_decelerate")) s->velocity_type = 7; else if (!strcmp(v, "ssh")) s->velocity_type = 8;   /* Cartesian grid only */
         else { snprintf(g_err, sizeof g_err, "velocity_type '%s' not supported by the oracle", v); return -1; }
         return 0; }
     if (!strcmp(k, "geometry")) {
@@ -671,18 +672,35 @@ static int grid_create(orc_sim *s) {
     if (s->N_gasmax <= 0.0) s->N_gasmax = N_gaspole;
     if (s->N_gashomo <= 0.0) s->N_gashomo = N_gashomo;
     /* (3) velocity field :786-946 (velocities in units of the local thermal speed) */
-    if (s->velocity_type >= 4 && !s->use_clump_medium) { snprintf(g_err, sizeof g_err, "rotating velocity fields are supported for the clump medium only"); return -1; }
     if (s->velocity_type) {
         double rpeak = (s->rmax <= 0.0) ? fmax(s->xmax, fmax(s->ymax, s->zmax)) : s->rmax;
+        if (s->velocity_type == 8) rpeak = s->rpeak;                                /* 'ssh': par%rpeak is an input (Song, Seon & Hwang 2020) */
         for (int k = 1; k <= nz; k++) for (int j = 1; j <= ny; j++) for (int i = 1; i <= nx; i++) {
             size_t c = IDX(s,i,j,k); if (!(s->rhokap[c] > 0.0)) continue;
-            double vt = vtherm_total(s, s->temperature);
-            if (s->velocity_type == 1) {                                            /* hubble :786-803 */
-                s->vfx[c] = (s->Vexp / vt) * xx[i-1] / rpeak; s->vfy[c] = (s->Vexp / vt) * yy[j-1] / rpeak; s->vfz[c] = (s->Vexp / vt) * zz[k-1] / rpeak;
-            } else if (s->velocity_type == 2) {                                     /* constant_radial :839-865 */
-                double rr = sqrt(xx[i-1] * xx[i-1] + yy[j-1] * yy[j-1] + zz[k-1] * zz[k-1]);
-                if (rr > s->dz / 10.0) { s->vfx[c] = s->Vexp / vt * xx[i-1] / rr; s->vfy[c] = s->Vexp / vt * yy[j-1] / rr; s->vfz[c] = s->Vexp / vt * zz[k-1] / rr; }
-            } else { s->vfx[c] = s->Vx / vt; s->vfy[c] = s->Vy / vt; s->vfz[c] = s->Vz / vt; }   /* parallel :804-816 */
+            double vt = vtherm_total(s, s->temperature), x = xx[i-1], y = yy[j-1], z = zz[k-1], rr = sqrt(x * x + y * y + z * z), Vs;
+            switch (s->velocity_type) {
+            case 1:                                                                 /* hubble :786-803 */
+                s->vfx[c] = (s->Vexp / vt) * x / rpeak; s->vfy[c] = (s->Vexp / vt) * y / rpeak; s->vfz[c] = (s->Vexp / vt) * z / rpeak; break;
+            case 2:                                                                 /* constant_radial :839-852 */
+                if (rr > s->dz / 10.0) { s->vfx[c] = s->Vexp / vt * x / rr; s->vfy[c] = s->Vexp / vt * y / rr; s->vfz[c] = s->Vexp / vt * z / rr; } break;
+            case 3: s->vfx[c] = s->Vx / vt; s->vfy[c] = s->Vy / vt; s->vfz[c] = s->Vz / vt; break;   /* parallel_velocity :804-816 */
+            case 4:                                                                 /* rotating_solid_body :905-916 */
+                s->vfx[c] = -s->Vrot / vt * y / s->rmax; s->vfy[c] = s->Vrot / vt * x / s->rmax; break;
+            case 5: {                                                               /* rotating_galaxy_halo :917-934 */
+                double rc = sqrt(x * x + y * y);
+                if (rc < s->rinner) { s->vfx[c] = -s->Vrot / vt * y / s->rinner; s->vfy[c] = s->Vrot / vt * x / s->rinner; }
+                else { s->vfx[c] = -s->Vrot / vt * y / rc; s->vfy[c] = s->Vrot / vt * x / rc; } } break;
+            case 6:                                                                 /* power_law :853-874 */
+                if (rr > s->dz / 10.0) { Vs = s->Vexp * pow(rr / rpeak, s->velocity_alpha);
+                    s->vfx[c] = Vs / vt * x / rr; s->vfy[c] = Vs / vt * y / rr; s->vfz[c] = Vs / vt * z / rr; } break;
+            case 7:                                                                 /* linear_decelerate :875-904 */
+                if (rr > s->dz / 10.0) { Vs = s->Vexp * fmax(0.0, (rpeak - rr) / (rpeak - fmax(s->rmin, 0.0)));
+                    s->vfx[c] = Vs / vt * x / rr; s->vfy[c] = Vs / vt * y / rr; s->vfz[c] = Vs / vt * z / rr; } break;
+            case 8:                                                                 /* ssh :817-838 */
+                if (rr < rpeak) { Vs = s->Vpeak / rpeak; s->vfx[c] = Vs / vt * x; s->vfy[c] = Vs / vt * y; s->vfz[c] = Vs / vt * z; }
+                else { Vs = s->Vpeak + s->DeltaV * (rr - rpeak) / (s->rmax - rpeak);
+                       s->vfx[c] = Vs / vt * x / rr; s->vfy[c] = Vs / vt * y / rr; s->vfz[c] = Vs / vt * z / rr; } break;
+            }
         }
     }
     free(xx); free(yy); free(zz);

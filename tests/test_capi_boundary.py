@@ -61,7 +61,12 @@ CASES = [dict(temperature=10.0, taumax=1e6, xyz_symmetry=True, nx=101, ny=101, n
          dict(temperature=1e4, N_HI=1e19, nx=21, ny=21, nz=21, geometry="rectangle", nxim=8, nyim=12),
          dict(temperature=1e4, taumax=1e1, nx=21, ny=21, nz=31, xmax=1.0, ymax=1.0, zmax=1.5, geometry="rectangle", xy_symmetry=True, nxfreq=81),
          dict(temperature=1e4, tauhomo=1e1, nx=20, ny=14, nz=31, rmax=1.0, xy_symmetry=True, velocity_type="hubble", Vexp=30.0, nxfreq=81),
-         dict(temperature=1e4, taumax=2e1, nx=6, ny=4, nz=21, xmax=0.5, ymax=0.3, zmax=1.0, geometry="rectangle", xy_periodic=True, nxfreq=81)]
+         dict(temperature=1e4, taumax=2e1, nx=6, ny=4, nz=21, xmax=0.5, ymax=0.3, zmax=1.0, geometry="rectangle", xy_periodic=True, nxfreq=81),
+         dict(temperature=1e4, N_HImax=1e18, nx=21, ny=21, nz=21, rmax=1.0, velocity_type="rotating_solid_body", Vrot=100.0, velocity_min=-300.0, velocity_max=300.0, nxfreq=80),
+         dict(temperature=1e4, N_HImax=1e18, nx=21, ny=21, nz=21, rmax=1.0, velocity_type="rotating_galaxy_halo", Vrot=100.0, rinner=0.2, velocity_min=-300.0, velocity_max=300.0, nxfreq=80),
+         dict(temperature=1e4, taumax=1e3, nx=21, ny=21, nz=21, rmax=1.0, rmin=0.2, velocity_type="power_law", Vexp=80.0, velocity_alpha=0.5),
+         dict(temperature=1e4, taumax=1e3, nx=21, ny=21, nz=21, rmax=1.0, rmin=0.2, velocity_type="linear_decelerate", Vexp=80.0),
+         dict(temperature=1e4, taumax=1e3, nx=21, ny=21, nz=21, rmax=1.0, velocity_type="ssh", Vpeak=120.0, rpeak=0.3, DeltaV=-60.0, velocity_min=-400.0, velocity_max=400.0, nxfreq=80)]
 
 
 @pytest.mark.parametrize("kw", CASES)
