@@ -30,7 +30,7 @@ typedef struct lart_params {
     int32_t xyz_symmetry, xy_periodic, xy_symmetry;
     /* source: generate_photon.f90:33-132, :243-306 */
     int32_t source_geometry;       /* 0 'point', 1 'uniform_sphere' */
-    int32_t spectral_type;         /* 0 'monochromatic', 1 'voigt' */
+    int32_t spectral_type;         /* 0 'monochromatic', 1 'voigt', 2 'continuum', 3 'gaussian' (generate_photon.f90:243-266) */
     int32_t comoving_source;
     /* scattering physics: scattering_car.f90 */
     int32_t recoil, core_skip, core_skip_global, use_stokes, use_reduced_wgt;
@@ -42,6 +42,7 @@ typedef struct lart_params {
     int32_t line_type;             /* line%line_type: 1 single resonance line, 2 Ly-alpha doublet (par%fine_structure, line_mod.f90:1250-1253) */
     double  xs_point, ys_point, zs_point, source_rmax, xfreq0;
     double  xfreq_min, dxfreq, Dfreq_ref;          /* grid%xfreq_min, grid%dxfreq, grid%Dfreq_ref */
+    double  xfreq_max, source_sigma_x;             /* grid%xfreq_max (continuum source); Gaussian source sigma / vtherm_total(par%temperature) */
     double  DGR, hgg, albedo;
     double  mu_min, dmu;
     double  g_recoil0, E1, E2, E3;                 /* line%g_recoil0, line%E1..E3 (line_mod.f90:1255-1270) */

@@ -1712,6 +1712,13 @@ __device__ inline void generate_photon(const KArgs &A, const Lds &l, Rng &g, Pho
     const Cell &c = (VAR == 3 || VAR == 4) ? gr.cell[p.ic - 1] : gr.cell[cidx(gr, clampi(p.ic, 1, gr.nx), clampi(p.jc, 1, gr.ny), clampi(p.kc, 1, gr.nz))];
     if (l.lt == 2) { const double dnu = l.dnu_hz / c.Dfreq; if (g.next() <= 1.0 / 3.0) p.xfreq = p.xfreq - dnu; }   // the source feeds both levels (generate_photon.f90:161-167)
     if (par.spectral_type == 1) p.xfreq = p.xfreq + rand_voigt(g, c.voigt_a);
+    else if (par.spectral_type == 2) {                         // continuum: flat over the frequency axis, in units of the local cell (:244-247)
+        p.xfreq = g.next() * (par.xfreq_max - par.xfreq_min) + par.xfreq_min;
+        p.xfreq = p.xfreq / (c.Dfreq / par.Dfreq_ref);
+    } else if (par.spectral_type == 3) {                       // gaussian: sigma in reference Doppler units (:254-266); one deviate of the polar pair
+        double second; p.xfreq = p.xfreq + g.gauss_pair(second) * par.source_sigma_x;
+        p.xfreq = p.xfreq / (c.Dfreq / par.Dfreq_ref);
+    }
     double u1 = c.vfx * p.kx + c.vfy * p.ky + c.vfz * p.kz;
     if (!par.comoving_source) p.xfreq = p.xfreq - u1;
     if (par.save_Jin) {

@@ -80,6 +80,7 @@ module lart_define
      real(wp) :: clump_radius = -1.0_wp, clump_N_clumps = -1.0_wp, clump_f_vol = -1.0_wp, clump_f_cov = -1.0_wp
      real(wp) :: clump_tau0 = -1.0_wp, clump_NHI = -1.0_wp, clump_nH = -1.0_wp, clump_temperature = -1.0_wp, clump_sigma_v = 0.0_wp
      real(wp) :: Vrot = 0.0_wp, rinner = 0.0_wp, Vpeak = 0.0_wp, rpeak = 0.0_wp, DeltaV = 0.0_wp, velocity_alpha = 1.0_wp
+     real(wp) :: gaussian_sigma_vel = 12.843374_wp, gaussian_FWHM_vel = -999.0_wp
      character(len=20)  :: line_id = 'ly_alpha'
      character(len=8)   :: h2_model = 'none'
      character(len=128) :: dens_file = '', temp_file = '', velo_file = '', emiss_file = '', cart_file = '', input_field = '', star_file = ''
@@ -264,8 +265,11 @@ contains
     if (trim(par%source_geometry) == 'sphere') par%source_geometry = 'uniform_sphere'
     if (trim(par%source_geometry) /= 'point' .and. trim(par%source_geometry) /= 'uniform_sphere') &
        call not_supported('par%source_geometry = '//trim(par%source_geometry))
-    if (trim(par%spectral_type) /= 'voigt' .and. trim(par%spectral_type) /= 'monochromatic') &
-       call not_supported('par%spectral_type = '//trim(par%spectral_type))
+    select case (trim(par%spectral_type))
+    case ('voigt', 'monochromatic', 'gaussian')
+    case ('continuum'); par%comoving_source = .false.                                            ! setup.f90:115
+    case default; call not_supported('par%spectral_type = '//trim(par%spectral_type))
+    end select
     select case(trim(par%velocity_type))
     case ('', 'hubble', 'constant_radial', 'parallel_velocity')
     case ('rotating_solid_body', 'rotating_galaxy_halo')       ! Cartesian grid, or per-clump fields of assign_clump_velocities_from_type
@@ -1305,6 +1309,11 @@ contains
        else
           par%xfreq_max = floor(xscale*atau3 + abs(par%Vexp)/vtherm) + 1
           par%xfreq_min = -(floor(xscale*atau3 + line%DnuHK_Hz/grid%Dfreq_ref) + 1)
+       endif
+       if (trim(par%spectral_type) == 'continuum') then                                          ! :1490-1494
+          xscale = 4.0_wp*xscale
+          par%xfreq_max = floor(xscale*atau3 + abs(par%Vexp)/vtherm) + 1
+          par%xfreq_min = -(floor(xscale*atau3 + abs(par%Vexp)/vtherm + line%DnuHK_Hz/grid%Dfreq_ref) + 1)
        endif
     endif
     allocate(grid%xfreq(grid%nxfreq), grid%velocity(grid%nxfreq), grid%wavelength(grid%nxfreq))

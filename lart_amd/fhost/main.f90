@@ -240,7 +240,18 @@ contains
     type(lart_params), intent(out) :: p
     p%xyz_symmetry = merge(1, 0, par%xyz_symmetry); p%xy_periodic = merge(1, 0, par%xy_periodic); p%xy_symmetry = merge(1, 0, par%xy_symmetry)
     p%source_geometry = merge(1, 0, trim(par%source_geometry) == 'uniform_sphere')
-    p%spectral_type = merge(1, 0, trim(par%spectral_type) == 'voigt')
+    select case (trim(par%spectral_type))
+    case ('voigt');     p%spectral_type = 1
+    case ('continuum'); p%spectral_type = 2
+    case ('gaussian');  p%spectral_type = 3
+    case default;       p%spectral_type = 0
+    end select
+    p%xfreq_max = grid%xfreq_max
+    if (par%gaussian_FWHM_vel > 0.0_wp) then
+       p%source_sigma_x = par%gaussian_FWHM_vel/2.3548200450309493_wp/vtherm_total(par%temperature)
+    else
+       p%source_sigma_x = par%gaussian_sigma_vel/vtherm_total(par%temperature)
+    endif
     p%comoving_source = merge(1, 0, par%comoving_source)
     p%recoil = merge(1, 0, par%recoil); p%core_skip = merge(1, 0, par%core_skip); p%core_skip_global = merge(1, 0, par%core_skip_global)
     p%use_stokes = merge(1, 0, par%use_stokes); p%use_reduced_wgt = merge(1, 0, par%use_reduced_wgt)

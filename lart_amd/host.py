@@ -152,6 +152,8 @@ class Params:
     rpeak: float = 0.0
     DeltaV: float = 0.0
     velocity_alpha: float = 1.0
+    gaussian_sigma_vel: float = 12.843374
+    gaussian_FWHM_vel: float = -999.0
     # octree medium (grid_mod_amr.f90); only the generic text format of read_generic_amr.f90:112-185 is read here
     use_amr_grid: bool = False
     amr_type: str = "generic"
@@ -330,7 +332,7 @@ def read_input(par, line=None):
         par.source_geometry = "uniform_sphere"
     if par.source_geometry not in ("point", "uniform_sphere"):
         raise LartInputError("par%%source_geometry = '%s' is not supported by this path" % par.source_geometry)
-    if par.spectral_type not in ("voigt", "monochromatic"):
+    if par.spectral_type not in ("voigt", "monochromatic", "continuum", "gaussian"):
         raise LartInputError("par%%spectral_type = '%s' is not supported by this path" % par.spectral_type)
     if par.velocity_type in ("rotating_solid_body", "rotating_galaxy_halo"):
         pass                                                              # (clump medium: per-clump fields of assign_clump_velocities_from_type)
@@ -338,6 +340,8 @@ def read_input(par, line=None):
         pass
     elif par.velocity_type not in ("", "hubble", "constant_radial", "parallel_velocity"):
         raise LartInputError("par%%velocity_type = '%s' is not supported by this path" % par.velocity_type)
+    if par.spectral_type == "continuum":
+        par.comoving_source = False                                       # setup.f90:115
     if par.temperature <= 0.0:
         raise LartInputError("ERROR: par%temperature must be > 0 K (or set par%bturb > 0)")
     if par.nx == 1 or par.ny == 1 or par.nz == 1:
@@ -694,6 +698,10 @@ def car_setup_freq_grid(par, line, g):
         else:
             par.xfreq_max = math.floor(xscale * par.atau3 + abs(par.Vexp) / vth) + 1
             par.xfreq_min = -(math.floor(xscale * par.atau3 + line.DnuHK_Hz / g.Dfreq_ref) + 1)
+        if par.spectral_type == "continuum":                               # :1490-1494
+            xscale = 4.0 * xscale
+            par.xfreq_max = math.floor(xscale * par.atau3 + abs(par.Vexp) / vth) + 1
+            par.xfreq_min = -(math.floor(xscale * par.atau3 + abs(par.Vexp) / vth + line.DnuHK_Hz / g.Dfreq_ref) + 1)
     g.dxfreq = (par.xfreq_max - par.xfreq_min) / par.nxfreq
     g.xfreq_max, g.xfreq_min = float(par.xfreq_max), float(par.xfreq_min)
     g.xfreq = (np.arange(1, g.nxfreq + 1) - 0.5) * g.dxfreq + g.xfreq_min
@@ -814,7 +822,9 @@ def make_lart_params(par, line, g):
               "save_direc0", "save_dust_scattered"):
         setattr(p, n, int(getattr(par, n)))
     p.source_geometry = {"point": 0, "uniform_sphere": 1}[par.source_geometry]
-    p.spectral_type = {"monochromatic": 0, "voigt": 1}[par.spectral_type]
+    p.spectral_type = {"monochromatic": 0, "voigt": 1, "continuum": 2, "gaussian": 3}[par.spectral_type]
+    gsig = par.gaussian_FWHM_vel / 2.3548200450309493 if par.gaussian_FWHM_vel > 0.0 else par.gaussian_sigma_vel
+    p.xfreq_max, p.source_sigma_x = g.xfreq_max, gsig / vtherm_total(line, par.temperature)
     p.nxfreq = g.nxfreq
     for n in ("xs_point", "ys_point", "zs_point", "source_rmax", "xfreq0", "DGR", "hgg", "albedo", "mu_min", "dmu"):
         setattr(p, n, float(getattr(par, n)))

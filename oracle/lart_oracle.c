@@ -308,7 +308,8 @@ struct orc_sim {
     int nx, ny, nz; double xmax, ymax, zmax, rmax, rmin;
     double xs_point, ys_point, zs_point, source_rmax; int source_geometry;   /* 0 point, 1 uniform_sphere */
     double xfreq0, par_xfreq_min, par_xfreq_max; int nxfreq;
-    int spectral_type;               /* 0 monochromatic, 1 voigt */
+    int spectral_type;               /* 0 monochromatic, 1 voigt, 2 continuum, 3 gaussian */
+    double gaussian_sigma_vel, gaussian_FWHM_vel;
     int use_stokes, use_reduced_wgt, save_Jin, save_Jabs, save_Jmu, nmu;
     double mu_min, dmu;
     double hgg, albedo, cext_dust, DGR, distance2cm;
@@ -379,6 +380,7 @@ static void set_defaults(orc_sim *s) {
     s->geometry = 0; s->geometry_JPa = 2147483647;
     s->clump_radius = s->clump_N_clumps = s->clump_f_vol = s->clump_f_cov = s->clump_tau0 = s->clump_NHI = s->clump_nH = s->clump_temperature = -1.0;
     s->clump_fully_inside = 1; s->velocity_min = NAN; s->velocity_max = NAN; s->velocity_alpha = 1.0;
+    s->gaussian_sigma_vel = 12.843374; s->gaussian_FWHM_vel = -999.0;     /* define.f90:317-318 */
 }
 
 static int set_param(orc_sim *s, const char *k, const char *v) {
@@ -397,13 +399,14 @@ static int set_param(orc_sim *s, const char *k, const char *v) {
     if (!strcmp(k, "N_HIhomo") || !strcmp(k, "N_gashomo")) { s->N_gashomo = atof(v); return 0; }
     if (!strcmp(k, "tau0")) { s->taumax = atof(v); return 0; }
     B(use_clump_medium) B(clump_fully_inside) D(clump_radius) D(clump_N_clumps) D(clump_f_vol) D(clump_f_cov) D(clump_tau0) D(clump_NHI) D(clump_nH)
-    D(clump_temperature) D(clump_sigma_v) D(Vrot) D(rinner) D(velocity_min) D(velocity_max) D(Vpeak) D(rpeak) D(DeltaV) D(velocity_alpha)
+    D(clump_temperature) D(clump_sigma_v) D(Vrot) D(rinner) D(velocity_min) D(velocity_max) D(Vpeak) D(rpeak) D(DeltaV) D(velocity_alpha) D(gaussian_sigma_vel) D(gaussian_FWHM_vel)
     if (!strcmp(k, "use_amr_grid")) { s->use_amr_grid = parse_bool(v); return 0; }
     if (!strcmp(k, "amr_file")) { snprintf(s->amr_file, sizeof s->amr_file, "%s", v); return 0; }
     if (!strcmp(k, "amr_type")) return 0;
     if (!strcmp(k, "scatt_mat_file")) { snprintf(s->scatt_mat_file, sizeof s->scatt_mat_file, "%s", v); return 0; }
     if (!strcmp(k, "spectral_type")) {
         if (!strcmp(v, "voigt")) s->spectral_type = 1; else if (!strcmp(v, "monochromatic")) s->spectral_type = 0;
+        else if (!strcmp(v, "continuum")) s->spectral_type = 2; else if (!strcmp(v, "gaussian")) s->spectral_type = 3;
         else { snprintf(g_err, sizeof g_err, "spectral_type '%s' not supported by the oracle", v); return -1; }
         return 0; }
     if (!strcmp(k, "source_geometry")) {
@@ -512,6 +515,7 @@ static double rand_alias_linear(rng_t *g, int n, const double *prob_alias, const
 }
 
 static int read_input_post(orc_sim *s) {
+    if (s->spectral_type == 2) s->comoving_source = 0;          /* setup.f90:115: a continuum is flat in the lab frame */
     /* setup.f90:161-165: a 1-cell axis disables xyz_symmetry */
     if (s->nx == 1 || s->ny == 1 || s->nz == 1) s->xyz_symmetry = 0;
     /* :169-186 observer inside the medium (HEALPix): nostokes, no symmetry, no TAN image */
@@ -719,6 +723,8 @@ static int grid_create(orc_sim *s) {
         if (s->Vexp == 0.0) { s->par_xfreq_max = floor(xscale * s->atau3) + 1; s->par_xfreq_min = -(floor(xscale * s->atau3 + s->DnuHK_Hz / s->Dfreq_ref) + 1); }
         else if (s->Vexp > 0.0) { s->par_xfreq_max = floor(xscale * s->atau3) + 1; s->par_xfreq_min = -(floor(xscale * s->atau3 + fabs(s->Vexp) / vt + s->DnuHK_Hz / s->Dfreq_ref) + 1); }
         else { s->par_xfreq_max = floor(xscale * s->atau3 + fabs(s->Vexp) / vt) + 1; s->par_xfreq_min = -(floor(xscale * s->atau3 + s->DnuHK_Hz / s->Dfreq_ref) + 1); }
+        if (s->spectral_type == 2) { xscale = 4.0 * xscale;                         /* :1490-1494 */
+            s->par_xfreq_max = floor(xscale * s->atau3 + fabs(s->Vexp) / vt) + 1; s->par_xfreq_min = -(floor(xscale * s->atau3 + fabs(s->Vexp) / vt + s->DnuHK_Hz / s->Dfreq_ref) + 1); }
     }
     s->dxfreq = (s->par_xfreq_max - s->par_xfreq_min) / s->nxfreq;
     s->xfreq_max = s->par_xfreq_max; s->xfreq_min = s->par_xfreq_min;
@@ -1099,6 +1105,8 @@ static int grid_create_amr(orc_sim *s) {
         if (s->Vexp == 0.0) { s->par_xfreq_max = floor(xscale * s->atau3) + 1.0; s->par_xfreq_min = -(floor(xscale * s->atau3 + s->DnuHK_Hz / s->Dfreq_ref) + 1.0); }
         else if (s->Vexp > 0.0) { s->par_xfreq_max = floor(xscale * s->atau3) + 1.0; s->par_xfreq_min = -(floor(xscale * s->atau3 + fabs(s->Vexp) / vt + s->DnuHK_Hz / s->Dfreq_ref) + 1.0); }
         else { s->par_xfreq_max = floor(xscale * s->atau3 + fabs(s->Vexp) / vt) + 1.0; s->par_xfreq_min = -(floor(xscale * s->atau3 + s->DnuHK_Hz / s->Dfreq_ref) + 1.0); }
+        if (s->spectral_type == 2) { xscale = 4.0 * xscale;                         /* grid_mod_amr.f90:773-778 */
+            s->par_xfreq_max = floor(xscale * s->atau3 + fabs(s->Vexp) / vt) + 1.0; s->par_xfreq_min = -(floor(xscale * s->atau3 + fabs(s->Vexp) / vt + s->DnuHK_Hz / s->Dfreq_ref) + 1.0); }
     }
     s->dxfreq = (s->par_xfreq_max - s->par_xfreq_min) / s->nxfreq; s->xfreq_max = s->par_xfreq_max; s->xfreq_min = s->par_xfreq_min;
     s->Jout = calloc(s->nxfreq, 8); s->Jin = calloc(s->nxfreq, 8); s->Jabs = calloc(s->nxfreq, 8); s->Jmu = calloc((size_t)s->nxfreq * (s->nmu > 0 ? s->nmu : 1), 8);
@@ -2206,6 +2214,14 @@ static void generate_photon(const orc_sim *s, acc_t *A, rng_t *g, photon_t *p) {
     size_t c = IDX(s,p->icell,p->jcell,p->kcell);
     if (s->line_type == 2) { double DnuHK = s->DnuHK_Hz / s->Dfreq[c]; if (rnd(g) <= 1.0 / 3.0) p->xfreq = p->xfreq - DnuHK; }   /* :161-167: the source feeds both levels */
     if (s->spectral_type == 1) p->xfreq = p->xfreq + rand_voigt(g, s->voigt_a[c]);     /* :252-253 */
+    else if (s->spectral_type == 2) {                                                /* continuum :244-247, in units of the local cell */
+        p->xfreq = rnd(g) * (s->xfreq_max - s->xfreq_min) + s->xfreq_min;
+        p->xfreq = p->xfreq / (s->Dfreq[c] / s->Dfreq_ref);
+    } else if (s->spectral_type == 3) {                                              /* gaussian :254-266 */
+        double gsig = s->gaussian_FWHM_vel > 0.0 ? s->gaussian_FWHM_vel / 2.3548200450309493 : s->gaussian_sigma_vel;
+        p->xfreq = p->xfreq + rand_gauss(g) * (gsig / vtherm_total(s, s->temperature));
+        p->xfreq = p->xfreq / (s->Dfreq[c] / s->Dfreq_ref);
+    }
     double u1;
     if (!s->comoving_source) { u1 = udot(s, c, p->kx, p->ky, p->kz); p->xfreq = p->xfreq - u1; }   /* :303-306 */
     if (s->save_Jin) {                                                               /* :309-322 */

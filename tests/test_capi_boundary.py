@@ -66,6 +66,7 @@ CASES = [dict(temperature=10.0, taumax=1e6, xyz_symmetry=True, nx=101, ny=101, n
          dict(temperature=1e4, N_HImax=1e18, nx=21, ny=21, nz=21, rmax=1.0, velocity_type="rotating_galaxy_halo", Vrot=100.0, rinner=0.2, velocity_min=-300.0, velocity_max=300.0, nxfreq=80),
          dict(temperature=1e4, taumax=1e3, nx=21, ny=21, nz=21, rmax=1.0, rmin=0.2, velocity_type="power_law", Vexp=80.0, velocity_alpha=0.5),
          dict(temperature=1e4, taumax=1e3, nx=21, ny=21, nz=21, rmax=1.0, rmin=0.2, velocity_type="linear_decelerate", Vexp=80.0),
+         dict(temperature=1e4, taumax=1e3, nx=21, ny=21, nz=21, rmax=1.0, spectral_type="continuum", velocity_type="hubble", Vexp=-50.0),
          dict(temperature=1e4, taumax=1e3, nx=21, ny=21, nz=21, rmax=1.0, velocity_type="ssh", Vpeak=120.0, rpeak=0.3, DeltaV=-60.0, velocity_min=-400.0, velocity_max=400.0, nxfreq=80)]
 
 

@@ -133,6 +133,10 @@ def test_scatter_event_device(capi, oracle_mod, kw):
     (dict(temperature=1e4, taumax=1e1, nx=21, ny=21, nz=21, rmax=1.0, nxfreq=81, iseed=6, source_geometry="uniform_sphere", save_Jmu=True, nmu=5), 20000),
     (dict(temperature=1e1, taumax=1e1, xy_periodic=True, nx=1, ny=1, nz=51, nxfreq=81, iseed=7, use_stokes=True), 20000),
     (dict(temperature=1e1, taumax=3e1, nx=21, ny=21, nz=21, rmax=1.0, nxfreq=121, iseed=8, fine_structure=True), 20000),
+    (dict(temperature=1e4, taumax=1e1, nx=21, ny=21, nz=21, rmax=1.0, nxfreq=81, iseed=10, spectral_type="gaussian", gaussian_FWHM_vel=150.0,
+          velocity_type="hubble", Vexp=40.0, comoving_source=False), 20000),
+    (dict(temperature=1e4, taumax=1e1, nx=21, ny=21, nz=21, rmax=1.0, nxfreq=81, iseed=11, spectral_type="continuum", velocity_type="hubble", Vexp=-30.0,
+          save_Jin=True), 20000),
     (dict(temperature=3e1, taumax=3e1, xyz_symmetry=True, nx=21, ny=21, nz=21, rmax=1.0, nxfreq=121, iseed=9, fine_structure=True, use_stokes=True,
           velocity_type="hubble", Vexp=5.0), 20000),
 ])

@@ -171,3 +171,17 @@ def test_Pa_estimators_agree(oracle_mod):
     P, Pn = o.array("P1"), o.array("P1_new")
     assert abs(P.sum() / Pn.sum() - 1.0) < 0.01
     assert np.allclose(P[2:12], Pn[2:12], rtol=0.05)
+
+
+def test_source_spectra(oracle_mod):
+    """generate_photon.f90:243-266: a flat continuum over the frequency axis (in the lab frame: setup.f90:115) and a Gaussian line
+    of given FWHM; both tallied in Jin before any scattering"""
+    kw = dict(temperature=1e4, taumax=1e-3, nx=11, ny=11, nz=11, rmax=1.0, nxfreq=60)
+    o = oracle_mod.Oracle(spectral_type="continuum", **kw); o.run(60000, seed=2)
+    Jin = o.array("Jin")
+    assert int(o.scalar("comoving_source")) == 0 and abs(Jin.sum() / 60000 - 1) < 1e-12
+    assert np.all(np.abs(Jin - 1000.0) < 5 * np.sqrt(1000.0))                                     # flat within counting noise
+    o = oracle_mod.Oracle(spectral_type="gaussian", gaussian_FWHM_vel=100.0, velocity_min=-200.0, velocity_max=200.0, **kw); o.run(60000, seed=2)
+    x = o.xfreq_axis(); Jin = o.array("Jin"); vth = 0.12895319011972164 / np.sqrt(1.00797) * 100.0
+    sig = np.sqrt((Jin * x ** 2).sum() / Jin.sum())
+    assert abs(sig * vth / (100.0 / 2.3548200450309493) - 1) < 0.02 and abs((Jin * x).sum() / Jin.sum()) < 0.02
