@@ -89,6 +89,96 @@ module lart_define
      !--- GPU host additions (not in the reference): number of GPUs driven by this process, slice length
      integer  :: ngpu = 1
      integer  :: gpu_events_per_step = 4096
+       !--- the rest of the reference's namelist surface (define.f90:209-544): readable, rejected when set (check_unsupported_fields)
+     real(wp) :: luminosity = 1.0_wp
+     real(wp) :: temperature0 = -999.0_wp
+     real(wp) :: Dfreq0 = -999.0_wp
+     real(wp) :: voigt_a0 = -999.0_wp
+     logical :: HeI_coherent = .false.
+     real(wp) :: D_to_H_ratio = 1.5e-5_wp
+     real(wp) :: source_rscale = 0.0_wp
+     real(wp) :: sersic_m = 1.0_wp
+     real(wp) :: Reff = 0.0_wp
+     real(wp) :: xmin = nan64
+     real(wp) :: ymin = nan64
+     real(wp) :: zmin = nan64
+     real(wp) :: density_rscale = -999.9_wp
+     real(wp) :: density_zscale = -999.9_wp
+     real(wp) :: density_alpha = 0.0_wp
+     real(wp) :: cone_opening = 0.0_wp
+     real(wp) :: wavelength_min = nan64
+     real(wp) :: wavelength_max = nan64
+     integer :: nwavelength = 0
+     real(wp) :: q = 1.0_wp
+     real(wp) :: Omega = 0.0_wp
+     logical :: continuum_normalize = .true.
+     real(wp) :: source_zscale = 0.0_wp
+     real(wp) :: EW_line = 0.0_wp
+     real(wp) :: f_line = 0.0_wp
+     logical :: clump_allow_overlap = .false.
+     character(len=32) :: clump_radius_profile = 'constant'
+     character(len=32) :: clump_density_profile = 'constant'
+     character(len=32) :: clump_number_profile = 'constant'
+     real(wp) :: clump_radius_alpha = 0.0_wp
+     real(wp) :: clump_radius_r0 = 0.0_wp
+     real(wp) :: clump_density_alpha = 0.0_wp
+     real(wp) :: clump_density_r0 = 0.0_wp
+     real(wp) :: clump_number_alpha = 0.0_wp
+     real(wp) :: clump_number_r0 = 0.0_wp
+     real(wp) :: clump_radius_min = -1.0_wp
+     real(wp) :: clump_radius_max_in = -1.0_wp
+     character(len=256) :: clump_profile_file = ''
+     integer :: amr_snapnum = 0
+     character(len=32) :: ionization_model = 'cie_formula'
+     character(len=32) :: dust_model = 'global_dgr'
+     character(len=32) :: emissivity_model = 'none'
+     character(len=32) :: ion_model = 'none'
+     real(wp) :: metallicity_global = -1.0_wp
+     real(wp) :: Z_ref = 0.0134_wp
+     real(wp) :: f_ion_dust = 0.01_wp
+     integer :: out_bitpix = 0
+     integer :: sampling_method = 1
+     real(wp) :: f_composite = 0.5_wp
+     logical :: save_backup = .false.
+     logical :: save_input_grid = .false.
+     logical :: use_cie_condition = .false.
+     integer :: nxfreq_Ha = 0
+     real(wp) :: xfreq_max_Ha = 0.0_wp
+     integer :: ny_2gam = 101
+     real(wp) :: cext_dust_Ha = 3.801e-22_wp
+     real(wp) :: albedo_Ha = 0.6741_wp
+     real(wp) :: hgg_Ha = 0.4967_wp
+     logical :: transport_2gamma = .false.
+     real(wp) :: R_Ha = 0.0_wp
+     real(wp) :: W_conv = 0.0_wp
+     real(wp) :: W_esc1 = 0.0_wp
+     real(wp) :: W_abs1 = 0.0_wp
+     real(wp) :: W_esc2 = 0.0_wp
+     real(wp) :: W_abs2 = 0.0_wp
+     real(wp) :: f_H2 = 0.0_wp
+     real(wp) :: h2_temperature = 1000.0_wp
+     logical :: h2_pure_absorption = .false.
+     logical :: h2_hi_width = .false.
+     character(len=128) :: h2_data_dir = ''
+     real(wp) :: W_H2abs = 0.0_wp
+     real(wp) :: W_H2scat = 0.0_wp
+     character(len=128) :: line_prof_file = ''
+     integer :: line_prof_file_type = 0
+     integer :: reduce_factor = 1
+     integer :: centering = 0
+     real(wp) :: nrejected = 0.0_wp
+     real(wp) :: acceptance_rate = 1.0_wp
+     integer :: stellar_limb_darkening = 2
+     real(wp) :: distance_star_to_planet = 0.0_wp
+     real(wp) :: stellar_radius = 0.0_wp
+     real(wp) :: flux_factor = 0.0_wp
+     real(wp) :: inclination_angle(MAX_OBSERVERS) = nan64
+     real(wp) :: position_angle(MAX_OBSERVERS) = nan64
+     real(wp) :: phase_angle(MAX_OBSERVERS) = nan64
+     real(wp) :: rotation_center_x = nan64
+     real(wp) :: rotation_center_y = nan64
+     real(wp) :: rotation_center_z = nan64
+     logical :: observer_located_inside = .false.
   end type params_type
 
   type line_type          ! define.f90:639-680, Ly-alpha values of line_mod.f90:1241-1270
@@ -201,9 +291,90 @@ contains
     endif
   end subroutine setup_resonance_line
 
+  !--- fields of the reference's params_type that select physics or inputs outside this path: any non-default value stops the run
+  subroutine check_unsupported_fields()
+    if (par%temperature0 /= -999.0_wp) call not_supported('par%temperature0')
+    if (par%Dfreq0 /= -999.0_wp) call not_supported('par%Dfreq0')
+    if (par%voigt_a0 /= -999.0_wp) call not_supported('par%voigt_a0')
+    if (par%HeI_coherent) call not_supported('par%HeI_coherent')
+    if (par%D_to_H_ratio /= 1.5e-5_wp) call not_supported('par%D_to_H_ratio')
+    if (par%source_rscale /= 0.0_wp) call not_supported('par%source_rscale')
+    if (par%sersic_m /= 1.0_wp) call not_supported('par%sersic_m')
+    if (par%Reff /= 0.0_wp) call not_supported('par%Reff')
+    if (is_finite(par%xmin)) call not_supported('par%xmin')
+    if (is_finite(par%ymin)) call not_supported('par%ymin')
+    if (is_finite(par%zmin)) call not_supported('par%zmin')
+    if (par%density_rscale /= -999.9_wp) call not_supported('par%density_rscale')
+    if (par%density_zscale /= -999.9_wp) call not_supported('par%density_zscale')
+    if (par%density_alpha /= 0.0_wp) call not_supported('par%density_alpha')
+    if (par%cone_opening /= 0.0_wp) call not_supported('par%cone_opening')
+    if (is_finite(par%wavelength_min)) call not_supported('par%wavelength_min')
+    if (is_finite(par%wavelength_max)) call not_supported('par%wavelength_max')
+    if (par%nwavelength /= 0) call not_supported('par%nwavelength')
+    if (par%q /= 1.0_wp) call not_supported('par%q')
+    if (par%Omega /= 0.0_wp) call not_supported('par%Omega')
+    if (.not. par%continuum_normalize) call not_supported('par%continuum_normalize')
+    if (par%source_zscale /= 0.0_wp) call not_supported('par%source_zscale')
+    if (par%EW_line /= 0.0_wp) call not_supported('par%EW_line')
+    if (par%f_line /= 0.0_wp) call not_supported('par%f_line')
+    if (par%clump_allow_overlap) call not_supported('par%clump_allow_overlap')
+    if (trim(par%clump_radius_profile) /= 'constant') call not_supported('par%clump_radius_profile')
+    if (trim(par%clump_density_profile) /= 'constant') call not_supported('par%clump_density_profile')
+    if (trim(par%clump_number_profile) /= 'constant') call not_supported('par%clump_number_profile')
+    if (par%clump_radius_alpha /= 0.0_wp) call not_supported('par%clump_radius_alpha')
+    if (par%clump_radius_r0 /= 0.0_wp) call not_supported('par%clump_radius_r0')
+    if (par%clump_density_alpha /= 0.0_wp) call not_supported('par%clump_density_alpha')
+    if (par%clump_density_r0 /= 0.0_wp) call not_supported('par%clump_density_r0')
+    if (par%clump_number_alpha /= 0.0_wp) call not_supported('par%clump_number_alpha')
+    if (par%clump_number_r0 /= 0.0_wp) call not_supported('par%clump_number_r0')
+    if (par%clump_radius_min /= -1.0_wp) call not_supported('par%clump_radius_min')
+    if (par%clump_radius_max_in /= -1.0_wp) call not_supported('par%clump_radius_max_in')
+    if (trim(par%clump_profile_file) /= '') call not_supported('par%clump_profile_file')
+    if (par%amr_snapnum /= 0) call not_supported('par%amr_snapnum')
+    if (trim(par%ionization_model) /= 'cie_formula') call not_supported('par%ionization_model')
+    if (trim(par%dust_model) /= 'global_dgr') call not_supported('par%dust_model')
+    if (trim(par%emissivity_model) /= 'none') call not_supported('par%emissivity_model')
+    if (trim(par%ion_model) /= 'none') call not_supported('par%ion_model')
+    if (par%metallicity_global /= -1.0_wp) call not_supported('par%metallicity_global')
+    if (par%Z_ref /= 0.0134_wp) call not_supported('par%Z_ref')
+    if (par%f_ion_dust /= 0.01_wp) call not_supported('par%f_ion_dust')
+    if (par%out_bitpix /= 0) call not_supported('par%out_bitpix')
+    if (par%sampling_method /= 1) call not_supported('par%sampling_method')
+    if (par%f_composite /= 0.5_wp) call not_supported('par%f_composite')
+    if (par%save_backup) call not_supported('par%save_backup')
+    if (par%save_input_grid) call not_supported('par%save_input_grid')
+    if (par%use_cie_condition) call not_supported('par%use_cie_condition')
+    if (par%nxfreq_Ha /= 0) call not_supported('par%nxfreq_Ha')
+    if (par%xfreq_max_Ha /= 0.0_wp) call not_supported('par%xfreq_max_Ha')
+    if (par%ny_2gam /= 101) call not_supported('par%ny_2gam')
+    if (par%cext_dust_Ha /= 3.801e-22_wp) call not_supported('par%cext_dust_Ha')
+    if (par%albedo_Ha /= 0.6741_wp) call not_supported('par%albedo_Ha')
+    if (par%hgg_Ha /= 0.4967_wp) call not_supported('par%hgg_Ha')
+    if (par%transport_2gamma) call not_supported('par%transport_2gamma')
+    if (par%R_Ha /= 0.0_wp) call not_supported('par%R_Ha')
+    if (par%f_H2 /= 0.0_wp) call not_supported('par%f_H2')
+    if (par%h2_temperature /= 1000.0_wp) call not_supported('par%h2_temperature')
+    if (par%h2_pure_absorption) call not_supported('par%h2_pure_absorption')
+    if (par%h2_hi_width) call not_supported('par%h2_hi_width')
+    if (trim(par%h2_data_dir) /= '') call not_supported('par%h2_data_dir')
+    if (trim(par%line_prof_file) /= '') call not_supported('par%line_prof_file')
+    if (par%line_prof_file_type /= 0) call not_supported('par%line_prof_file_type')
+    if (par%reduce_factor /= 1) call not_supported('par%reduce_factor')
+    if (par%centering /= 0) call not_supported('par%centering')
+    if (par%stellar_limb_darkening /= 2) call not_supported('par%stellar_limb_darkening')
+    if (par%distance_star_to_planet /= 0.0_wp) call not_supported('par%distance_star_to_planet')
+    if (par%stellar_radius /= 0.0_wp) call not_supported('par%stellar_radius')
+    if (any(is_finite(par%inclination_angle))) call not_supported('par%inclination_angle')
+    if (any(is_finite(par%position_angle))) call not_supported('par%position_angle')
+    if (any(is_finite(par%phase_angle))) call not_supported('par%phase_angle')
+    if (is_finite(par%rotation_center_x)) call not_supported('par%rotation_center_x')
+    if (is_finite(par%rotation_center_y)) call not_supported('par%rotation_center_y')
+    if (is_finite(par%rotation_center_z)) call not_supported('par%rotation_center_z')
+  end subroutine check_unsupported_fields
+
   subroutine not_supported(what)
     character(len=*), intent(in) :: what
-    write(*,'(3a)') 'ERROR: ', what, ' is not supported by the MI355X photon path (Cartesian uniform media only).'
+    write(*,'(3a)') 'ERROR: ', what, ' is not supported by the MI355X photon path (see DESIGN.md, scope).'
     stop 1
   end subroutine not_supported
 
@@ -233,6 +404,7 @@ contains
     par%distance_unit   = strlowcase(par%distance_unit)
     par%spectral_type   = strlowcase(par%spectral_type)
 
+    call check_unsupported_fields()
     if (par%use_amr_grid .and. trim(strlowcase(par%amr_type)) /= 'generic') call not_supported('par%amr_type = '//trim(par%amr_type))
     if (par%use_amr_grid .and. len_trim(par%amr_file) == 0) then
        write(*,'(a)') 'ERROR: par%use_amr_grid = .true. needs par%amr_file'; stop 1

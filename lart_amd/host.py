@@ -177,6 +177,90 @@ _UNSUPPORTED_DEFAULTS = {
     "density_alpha": 0.0, "cone_opening": 0.0, "Omega": 0.0, "save_all_photons": False, "temperature0": -999.0,
     "line_prof_file": "", "luminosity": 1.0, "save_backup": False, "save_input_grid": False,
     "intensity_unit": -999, "out_bitpix": 0,
+    # the rest of the reference's namelist surface (define.f90:209-544): readable, rejected when set
+    "Dfreq0": -999.0,
+    "voigt_a0": -999.0,
+    "HeI_coherent": False,
+    "D_to_H_ratio": 1.5e-05,
+    "source_rscale": 0.0,
+    "sersic_m": 1.0,
+    "Reff": 0.0,
+    "xmin": float("nan"),
+    "ymin": float("nan"),
+    "zmin": float("nan"),
+    "wavelength_min": float("nan"),
+    "wavelength_max": float("nan"),
+    "nwavelength": 0,
+    "q": 1.0,
+    "continuum_normalize": True,
+    "source_zscale": 0.0,
+    "EW_line": 0.0,
+    "f_line": 0.0,
+    "clump_allow_overlap": False,
+    "clump_radius_profile": "constant",
+    "clump_density_profile": "constant",
+    "clump_number_profile": "constant",
+    "clump_radius_alpha": 0.0,
+    "clump_radius_r0": 0.0,
+    "clump_density_alpha": 0.0,
+    "clump_density_r0": 0.0,
+    "clump_number_alpha": 0.0,
+    "clump_number_r0": 0.0,
+    "clump_radius_min": -1.0,
+    "clump_radius_max_in": -1.0,
+    "clump_profile_file": "",
+    "clump_input_file": "",
+    "amr_snapnum": 0,
+    "ionization_model": "cie_formula",
+    "dust_model": "global_dgr",
+    "emissivity_model": "none",
+    "ion_model": "none",
+    "metallicity_global": -1.0,
+    "Z_ref": 0.0134,
+    "f_ion_dust": 0.01,
+    "base_name": "",
+    "sampling_method": 1,
+    "f_composite": 0.5,
+    "nxfreq_Ha": 0,
+    "xfreq_max_Ha": 0.0,
+    "ny_2gam": 101,
+    "cext_dust_Ha": 3.801e-22,
+    "albedo_Ha": 0.6741,
+    "hgg_Ha": 0.4967,
+    "transport_2gamma": False,
+    "R_Ha": 0.0,
+    "W_conv": 0.0,
+    "W_esc1": 0.0,
+    "W_abs1": 0.0,
+    "W_esc2": 0.0,
+    "W_abs2": 0.0,
+    "f_H2": 0.0,
+    "h2_temperature": 1000.0,
+    "h2_pure_absorption": False,
+    "h2_hi_width": False,
+    "h2_data_dir": "",
+    "W_H2abs": 0.0,
+    "W_H2scat": 0.0,
+    "line_prof_file_type": 0,
+    "reduce_factor": 1,
+    "centering": 0,
+    "nscatt_gas": 0.0,
+    "nscatt_dust": 0.0,
+    "nscatt_tot": 0.0,
+    "exetime": 0.0,
+    "nrejected": 0.0,
+    "acceptance_rate": 1.0,
+    "stellar_limb_darkening": 2,
+    "distance_star_to_planet": 0.0,
+    "stellar_radius": 0.0,
+    "flux_factor": 0.0,
+    "inclination_angle": float("nan"),
+    "position_angle": float("nan"),
+    "phase_angle": float("nan"),
+    "rotation_center_x": float("nan"),
+    "rotation_center_y": float("nan"),
+    "rotation_center_z": float("nan"),
+    "observer_located_inside": False,
 }
 
 

@@ -471,3 +471,24 @@ def test_velocity_fields_end_to_end_match_python_host(exe, tmp_path, vel):
     for k in (0, 1):
         O = read_h5(str(tmp_path / ("rot_obs_%03d.h5" % (k + 1))))
         assert np.allclose(O["Scattered"][1], t["scatt"][..., k], rtol=1e-6, atol=1e-12 * t["scatt"].max())
+
+
+def test_whole_namelist_surface_is_readable(exe, tmp_path):
+    """every field of the reference's params_type (define.f90:209-544) can be named in an input file: defaults pass, physics or
+    inputs outside the path stop with 'not supported' instead of a namelist error (and names the reference lacks still fail)"""
+    ok = ("&parameters\n par%temperature = 1e4\n par%taumax = 1e2\n par%f_H2 = 0.0\n par%cone_opening = 0.0\n par%clump_allow_overlap = .false.\n"
+          " par%amr_snapnum = 0\n par%stellar_radius = 0.0\n par%EW_line = 0.0\n par%Omega = 0.0\n par%q = 1.0\n par%D_to_H_ratio = 1.5e-5\n/\n")
+    r = run(exe, ok, tmp_path, "--dry-run", name="all.in")
+    assert r.returncode == 0, r.stdout + r.stderr
+    for bad in ("par%f_H2 = 1e-3", "par%cone_opening = 30.0", "par%clump_allow_overlap = .true.", "par%stellar_radius = 0.1", "par%Omega = 28.0",
+                "par%xmin = -1.0", "par%HeI_coherent = .true.", "par%ionization_model = 'file'", "par%phase_angle = 10.0, 20.0"):
+        r = run(exe, "&parameters\n par%temperature = 1e4\n par%taumax = 1e2\n " + bad + "\n/\n", tmp_path, "--dry-run", name="bad.in")
+        assert r.returncode != 0 and "not supported" in r.stdout and bad.split()[0][4:] in r.stdout, bad
+    r = run(exe, "&parameters\n par%metalz = 1.0\n/\n", tmp_path, "--dry-run", name="bad2.in")
+    assert r.returncode != 0 and "ERROR reading &parameters" in r.stdout
+    from lart_amd import host
+    (tmp_path / "all.in").write_text(ok)
+    host.read_namelist(str(tmp_path / "all.in"))
+    (tmp_path / "bad.in").write_text("&parameters\n par%cone_opening = 30.0\n/\n")
+    with pytest.raises(host.LartInputError, match="not supported"):
+        host.read_namelist(str(tmp_path / "bad.in"))
