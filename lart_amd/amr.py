@@ -61,7 +61,167 @@ def write_generic_amr(path, d):
                     (d["x"][i], d["y"][i], d["z"][i], d["level"][i], d["nH"][i], d["T"][i], d["vx"][i], d["vy"][i], d["vz"][i]))
 
 
+_COLS = ("x", "y", "z", "level", "dens", "T", "vx", "vy", "vz")
+
+
+def _fits_card(key, val, comment=""):
+    if isinstance(val, str):
+        v = "'%-8s'" % val
+        card = "%-8s= %-20s" % (key, v)
+    elif isinstance(val, (bool, np.bool_)):
+        card = "%-8s= %20s" % (key, "T" if val else "F")
+    elif isinstance(val, (int, np.integer)):
+        card = "%-8s= %20d" % (key, val)
+    else:
+        card = "%-8s= %20s" % (key, ("%.15E" % val))
+    if comment:
+        card += " / " + comment
+    return card[:80].ljust(80)
+
+
+def write_generic_amr_fits(path, d, origin=None, single=False):
+    """FITS binary table as python/AMR_grid/AMR_grid.py:_write_fits lays it out (primary HDU + BINTABLE 'AMR_GRID' with columns
+    x y z level dens T vx vy vz, keywords BOXLEN, ORIGINX/Y/Z, NLEAF); .gz paths are gzip-compressed"""
+    import gzip
+    n = len(d["x"]); bl = float(d["boxlen"]); org = [-0.5 * bl] * 3 if origin is None else list(origin)
+    ft = ">f4" if single else ">f8"; form = "1E" if single else "1D"
+    dt = np.dtype([(c, ">i4" if c == "level" else ft) for c in _COLS])
+    tab = np.zeros(n, dtype=dt)
+    for c, k in zip(_COLS, ("x", "y", "z", "level", "nH", "T", "vx", "vy", "vz")):
+        tab[c] = d[k]
+    def block(cards):
+        h = "".join(cards) + "END".ljust(80)
+        return (h + " " * (-len(h) % 2880)).encode("ascii")
+    prim = block([_fits_card("SIMPLE", True), _fits_card("BITPIX", 8), _fits_card("NAXIS", 0), _fits_card("EXTEND", True)])
+    cards = [_fits_card("XTENSION", "BINTABLE"), _fits_card("BITPIX", 8), _fits_card("NAXIS", 2), _fits_card("NAXIS1", dt.itemsize),
+             _fits_card("NAXIS2", n), _fits_card("PCOUNT", 0), _fits_card("GCOUNT", 1), _fits_card("TFIELDS", len(_COLS))]
+    for i, c in enumerate(_COLS):
+        cards += [_fits_card("TTYPE%d" % (i + 1), c), _fits_card("TFORM%d" % (i + 1), "1J" if c == "level" else form)]
+    cards += [_fits_card("EXTNAME", "AMR_GRID"), _fits_card("BOXLEN", bl, "Simulation box length"), _fits_card("ORIGINX", org[0]),
+              _fits_card("ORIGINY", org[1]), _fits_card("ORIGINZ", org[2]), _fits_card("NLEAF", n)]
+    body = tab.tobytes(); body += b"\0" * (-len(body) % 2880)
+    with (gzip.open(path, "wb") if path.endswith(".gz") else open(path, "wb")) as f:
+        f.write(prim + block(cards) + body)
+
+
+def _read_generic_amr_fits(path):
+    import gzip
+    with (gzip.open(path, "rb") if path.endswith(".gz") else open(path, "rb")) as f:
+        raw = f.read()
+    pos = 0
+    def header():
+        nonlocal pos
+        kw = {}
+        while True:
+            blk = raw[pos:pos + 2880].decode("ascii"); pos += 2880
+            for i in range(36):
+                card = blk[80 * i:80 * i + 80]; key = card[:8].strip()
+                if key == "END":
+                    return kw
+                if card[8:10] == "= ":
+                    v = card[10:].split("/")[0].strip() if "'" not in card[10:] else card[10:].split("'")[1].strip()
+                    kw[key] = v
+    h0 = header()
+    if int(h0.get("NAXIS", 0)) > 0:
+        nb = abs(int(h0["BITPIX"])) // 8
+        for i in range(int(h0["NAXIS"])):
+            nb *= int(h0["NAXIS%d" % (i + 1)])
+        pos += (nb + 2879) // 2880 * 2880
+    h = header()
+    if h.get("XTENSION", "") != "BINTABLE" or "BOXLEN" not in h:
+        raise LartInputError("generic_amr_read_binary: no BINTABLE with BOXLEN in " + path)
+    codes = {"D": ">f8", "E": ">f4", "J": ">i4", "K": ">i8", "I": ">i2"}
+    dt = np.dtype([("c%d" % i, codes[h["TFORM%d" % (i + 1)].lstrip("0123456789")[0]]) for i in range(int(h["TFIELDS"]))])
+    n = int(h["NAXIS2"]); tab = np.frombuffer(raw, dtype=dt, count=n, offset=pos)
+    bl = float(h["BOXLEN"]); org = [float(h.get(k, -0.5 * bl)) for k in ("ORIGINX", "ORIGINY", "ORIGINZ")]
+    a = [tab["c%d" % i].astype(np.float64) for i in range(9)]
+    return dict(x=a[0], y=a[1], z=a[2], level=a[3].astype(np.int32), nH=a[4], T=a[5], vx=a[6], vy=a[7], vz=a[8], boxlen=bl, origin=org)
+
+
+def _h5():
+    import ctypes as C
+    lib = None
+    for cand in ("/opt/conda/lib/libhdf5.so", "libhdf5.so"):
+        try:
+            lib = C.CDLL(cand); break
+        except OSError:
+            pass
+    if lib is None:
+        raise LartInputError("no HDF5 C library found (generic AMR .h5 files)")
+    hid = C.c_int64; lib.H5open()
+    for fn in ("H5Fcreate", "H5Fopen", "H5Gcreate2", "H5Gopen2", "H5Screate_simple", "H5Screate", "H5Dcreate2", "H5Dopen2", "H5Acreate2", "H5Aopen", "H5Dget_space"):
+        getattr(lib, fn).restype = hid
+    lib.H5Fcreate.argtypes = [C.c_char_p, C.c_uint, hid, hid]; lib.H5Fopen.argtypes = [C.c_char_p, C.c_uint, hid]
+    lib.H5Gcreate2.argtypes = [hid, C.c_char_p, hid, hid, hid]; lib.H5Gopen2.argtypes = [hid, C.c_char_p, hid]
+    lib.H5Screate_simple.argtypes = [C.c_int, C.c_void_p, C.c_void_p]; lib.H5Screate.argtypes = [C.c_int]
+    lib.H5Dcreate2.argtypes = [hid, C.c_char_p, hid, hid, hid, hid, hid]; lib.H5Dopen2.argtypes = [hid, C.c_char_p, hid]
+    lib.H5Dwrite.argtypes = [hid, hid, hid, hid, hid, C.c_void_p]; lib.H5Dread.argtypes = [hid, hid, hid, hid, hid, C.c_void_p]
+    lib.H5Acreate2.argtypes = [hid, C.c_char_p, hid, hid, hid, hid]; lib.H5Aopen.argtypes = [hid, C.c_char_p, hid]
+    lib.H5Awrite.argtypes = [hid, hid, C.c_void_p]; lib.H5Aread.argtypes = [hid, hid, C.c_void_p]
+    lib.H5Dget_space.argtypes = [hid]; lib.H5Sget_simple_extent_dims.argtypes = [hid, C.c_void_p, C.c_void_p]
+    lib.H5Aexists.argtypes = [hid, C.c_char_p]; lib.H5Lexists.argtypes = [hid, C.c_char_p, hid]
+    for fn in ("H5Fclose", "H5Gclose", "H5Sclose", "H5Dclose", "H5Aclose"):
+        getattr(lib, fn).argtypes = [hid]
+    T = {k: hid.in_dll(lib, "H5T_NATIVE_%s_g" % k).value for k in ("DOUBLE", "INT")}
+    return C, lib, T
+
+
+def write_generic_amr_h5(path, d, origin=None, group="AMR_GRID"):
+    """HDF5 form of python/AMR_grid/AMR_grid.py:_write_hdf5: one group of 1-D datasets + attributes BOXLEN, ORIGINX/Y/Z, NLEAF"""
+    C, lib, T = _h5()
+    n = len(d["x"]); bl = float(d["boxlen"]); org = [-0.5 * bl] * 3 if origin is None else list(origin)
+    f = lib.H5Fcreate(path.encode(), 2, 0, 0)                      # H5F_ACC_TRUNC
+    g = lib.H5Gcreate2(f, group.encode(), 0, 0, 0)
+    dims = (C.c_uint64 * 1)(n); sp = lib.H5Screate_simple(1, dims, None)
+    for c, k in zip(_COLS, ("x", "y", "z", "level", "nH", "T", "vx", "vy", "vz")):
+        if c == "level":
+            a = np.ascontiguousarray(d[k], dtype=np.int32); t = T["INT"]
+        else:
+            a = np.ascontiguousarray(d[k], dtype=np.float64); t = T["DOUBLE"]
+        ds = lib.H5Dcreate2(g, c.encode(), t, sp, 0, 0, 0); lib.H5Dwrite(ds, t, 0, 0, 0, a.ctypes.data_as(C.c_void_p)); lib.H5Dclose(ds)
+    lib.H5Sclose(sp)
+    sc = lib.H5Screate(0)                                          # H5S_SCALAR
+    for k, v in (("BOXLEN", bl), ("ORIGINX", org[0]), ("ORIGINY", org[1]), ("ORIGINZ", org[2])):
+        a = lib.H5Acreate2(g, k.encode(), T["DOUBLE"], sc, 0, 0); lib.H5Awrite(a, T["DOUBLE"], C.byref(C.c_double(v))); lib.H5Aclose(a)
+    for k in ("NLEAF", "NAXIS2"):
+        a = lib.H5Acreate2(g, k.encode(), T["INT"], sc, 0, 0); lib.H5Awrite(a, T["INT"], C.byref(C.c_int(n))); lib.H5Aclose(a)
+    lib.H5Sclose(sc); lib.H5Gclose(g); lib.H5Fclose(f)
+
+
+def _read_generic_amr_h5(path, group="AMR_GRID"):
+    C, lib, T = _h5()
+    f = lib.H5Fopen(path.encode(), 0, 0)
+    if f < 0:
+        raise LartInputError("generic_amr_read_binary: cannot open " + path)
+    g = lib.H5Gopen2(f, group.encode(), 0)
+    if g < 0:
+        raise LartInputError("generic_amr_read_binary: no group %s in %s" % (group, path))
+    def attr(k, default=None):
+        if lib.H5Aexists(g, k.encode()) <= 0:
+            return default
+        a = lib.H5Aopen(g, k.encode(), 0); v = C.c_double(); lib.H5Aread(a, T["DOUBLE"], C.byref(v)); lib.H5Aclose(a); return v.value
+    bl = attr("BOXLEN"); org = [attr(k, -0.5 * bl) for k in ("ORIGINX", "ORIGINY", "ORIGINZ")]
+    cols = []
+    for c in _COLS:
+        ds = lib.H5Dopen2(g, c.encode(), 0); sp = lib.H5Dget_space(ds); dims = (C.c_uint64 * 1)(); lib.H5Sget_simple_extent_dims(sp, dims, None)
+        a = np.zeros(dims[0]); lib.H5Dread(ds, T["DOUBLE"], 0, 0, 0, a.ctypes.data_as(C.c_void_p)); lib.H5Sclose(sp); lib.H5Dclose(ds)
+        cols.append(a)
+    lib.H5Gclose(g); lib.H5Fclose(f)
+    return dict(x=cols[0], y=cols[1], z=cols[2], level=cols[3].astype(np.int32), nH=cols[4], T=cols[5], vx=cols[6], vy=cols[7], vz=cols[8],
+                boxlen=bl, origin=org)
+
+
 def read_generic_amr(path):
+    """generic_amr_read (read_generic_amr.f90:52-279): text, FITS binary table (.fits, .fits.gz) or HDF5 (.h5, .hdf5)"""
+    low = path.lower()
+    if low.endswith((".fits", ".fits.gz")):
+        return _read_generic_amr_fits(path)
+    if low.endswith((".h5", ".hdf5")):
+        return _read_generic_amr_h5(path)
+    return _read_generic_amr_text(path)
+
+
+def _read_generic_amr_text(path):
     n, bl, rows = 0, -1.0, []
     with open(path) as f:
         lines = iter(f)
@@ -240,8 +400,10 @@ def grid_create_amr(par, line, path):
     Returns (AmrGrid, Grid-like namespace with the spectral axis)."""
     from . import host
     d = read_generic_amr(path)
-    bl = d["boxlen"]
-    g = amr_build_tree(d["x"], d["y"], d["z"], d["level"], -0.5 * bl, 0.5 * bl)
+    bl = d["boxlen"]; org = d.get("origin", [-0.5 * bl] * 3)
+    if not (org[0] == org[1] == org[2]):
+        raise LartInputError("an AMR box with different ORIGINX/Y/Z is not supported by this path (cubic box [lo,hi]^3)")
+    g = amr_build_tree(d["x"], d["y"], d["z"], d["level"], org[0], org[0] + bl)
     amr_build_neighbors(g)
     if par.geometry == "sphere":
         par.rmax = g.L_box * 0.5; par.xmax = par.ymax = par.zmax = par.rmax

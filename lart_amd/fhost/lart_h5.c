@@ -74,3 +74,132 @@ int lart_gzip_file(const char *path) {
     if (!rc) remove(path);
     return rc;
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Generic AMR leaf tables in the binary containers of the reference (read_generic_amr.f90:186-279; written by
+ * python/AMR_grid/AMR_grid.py:1544-1630): a FITS binary table (.fits / .fits.gz, second HDU) or an HDF5 group of 1-D
+ * datasets.  Columns 1-9 = x y z level dens T vx vy vz; keywords BOXLEN (mandatory) and ORIGINX/Y/Z (default -BOXLEN/2).
+ * data = 9 * nleaf doubles, column after column (malloc'd here, released with lart_free).
+ * ------------------------------------------------------------------------------------------------------------------ */
+void lart_free(void *p) { free(p); }
+
+static double be_f64(const unsigned char *b) { unsigned long long v = 0; for (int i = 0; i < 8; i++) v = (v << 8) | b[i]; double d; memcpy(&d, &v, 8); return d; }
+static double be_f32(const unsigned char *b) { unsigned v = 0; for (int i = 0; i < 4; i++) v = (v << 8) | b[i]; float f; memcpy(&f, &v, 4); return (double)f; }
+static double be_int(const unsigned char *b, int n) { long long v = (b[0] & 0x80) ? -1 : 0; for (int i = 0; i < n; i++) v = (v << 8) | b[i]; return (double)v; }
+
+/* one FITS header: calls back with every card until END; returns 0, or 1 at end of file */
+static int fits_header(gzFile f, void (*card)(const char *key, const char *val, void *u), void *u) {
+    char blk[2880]; int done = 0;
+    while (!done) {
+        if (gzread(f, blk, 2880) != 2880) return 1;
+        for (int c = 0; c < 36 && !done; c++) {
+            char key[9], val[72]; memcpy(key, blk + 80 * c, 8); key[8] = 0;
+            for (int i = 7; i >= 0 && key[i] == ' '; i--) key[i] = 0;
+            if (!strcmp(key, "END")) { done = 1; break; }
+            if (blk[80 * c + 8] != '=') continue;
+            const char *p = blk + 80 * c + 10; int n = 0;
+            while (*p == ' ' && p < blk + 80 * c + 80) p++;
+            if (*p == '\'') { p++; while (p < blk + 80 * c + 80 && *p != '\'' && n < 70) val[n++] = *p++; while (n > 0 && val[n-1] == ' ') n--; }
+            else { while (p < blk + 80 * c + 80 && *p != '/' && *p != ' ' && n < 70) val[n++] = *p++; }
+            val[n] = 0;
+            card(key, val, u);
+        }
+    }
+    return 0;
+}
+typedef struct { long naxis, naxes[8], bitpix, tfields, pcount; char tform[64][12]; double boxlen, origin[3]; int has_origin[3], bintable; } fits_hdr;
+static void fits_card(const char *k, const char *v, void *u) {
+    fits_hdr *h = (fits_hdr *)u;
+    if (!strcmp(k, "NAXIS")) h->naxis = atol(v);
+    else if (!strncmp(k, "NAXIS", 5) && k[5] >= '1' && k[5] <= '8' && !k[6]) h->naxes[k[5] - '1'] = atol(v);
+    else if (!strcmp(k, "BITPIX")) h->bitpix = atol(v);
+    else if (!strcmp(k, "PCOUNT")) h->pcount = atol(v);
+    else if (!strcmp(k, "TFIELDS")) h->tfields = atol(v);
+    else if (!strcmp(k, "XTENSION")) h->bintable = !strncmp(v, "BINTABLE", 8);
+    else if (!strncmp(k, "TFORM", 5)) { int i = atoi(k + 5); if (i >= 1 && i <= 64) { strncpy(h->tform[i-1], v, 11); h->tform[i-1][11] = 0; } }
+    else if (!strcmp(k, "BOXLEN")) h->boxlen = atof(v);
+    else if (!strcmp(k, "ORIGINX")) { h->origin[0] = atof(v); h->has_origin[0] = 1; }
+    else if (!strcmp(k, "ORIGINY")) { h->origin[1] = atof(v); h->has_origin[1] = 1; }
+    else if (!strcmp(k, "ORIGINZ")) { h->origin[2] = atof(v); h->has_origin[2] = 1; }
+}
+static int amr_read_fits(const char *path, int *nleaf, double *boxlen, double *origin, double **data) {
+    gzFile f = gzopen(path, "rb"); if (!f) return 1;                    /* (zlib reads plain files through the same calls) */
+    fits_hdr h; memset(&h, 0, sizeof h);
+    if (fits_header(f, fits_card, &h)) { gzclose(f); return 2; }
+    long long skip = 0;
+    if (h.naxis > 0) { skip = labs(h.bitpix) / 8; for (long i = 0; i < h.naxis; i++) skip *= h.naxes[i]; skip = (skip + 2879) / 2880 * 2880; }
+    char junk[2880]; for (long long s = 0; s < skip; s += 2880) if (gzread(f, junk, 2880) != 2880) { gzclose(f); return 2; }
+    memset(&h, 0, sizeof h);
+    if (fits_header(f, fits_card, &h) || !h.bintable || h.tfields < 9 || h.naxes[1] <= 0 || !(h.boxlen > 0.0)) { gzclose(f); return 3; }
+    int width[64], off[64], kind[64], row = 0;                          /* kind: 0 f64, 1 f32, 2 int */
+    for (long i = 0; i < h.tfields && i < 64; i++) {
+        const char *t = h.tform[i]; int rep = 1; while (*t >= '0' && *t <= '9') { rep = (t == h.tform[i]) ? (*t - '0') : rep * 10 + (*t - '0'); t++; }
+        int w = 0, k = 0;
+        switch (*t) { case 'D': w = 8; k = 0; break; case 'E': w = 4; k = 1; break; case 'J': w = 4; k = 2; break; case 'K': w = 8; k = 2; break;
+                      case 'I': w = 2; k = 2; break; case 'B': case 'L': case 'A': w = 1; k = 2; break; default: gzclose(f); return 4; }
+        if (i < 9 && rep != 1) { gzclose(f); return 4; }
+        off[i] = row; width[i] = w; kind[i] = k; row += w * rep;
+    }
+    if (row != h.naxes[0]) { gzclose(f); return 4; }
+    long n = h.naxes[1];
+    double *d = (double *)malloc(sizeof(double) * 9 * (size_t)n); unsigned char *buf = (unsigned char *)malloc((size_t)row);
+    if (!d || !buf) { free(d); free(buf); gzclose(f); return 5; }
+    for (long r = 0; r < n; r++) {
+        if (gzread(f, buf, (unsigned)row) != row) { free(d); free(buf); gzclose(f); return 2; }
+        for (int c = 0; c < 9; c++) { const unsigned char *b = buf + off[c];
+            d[(size_t)c * n + r] = kind[c] == 0 ? be_f64(b) : kind[c] == 1 ? be_f32(b) : be_int(b, width[c]); }
+    }
+    free(buf); gzclose(f);
+    *nleaf = (int)n; *boxlen = h.boxlen; for (int a = 0; a < 3; a++) origin[a] = h.has_origin[a] ? h.origin[a] : -0.5 * h.boxlen;
+    *data = d;
+    return 0;
+}
+
+#ifdef LART_HDF5
+static int h5_attr_f64(hid_t g, const char *name, double *v) {
+    if (H5Aexists(g, name) <= 0) return 1;
+    hid_t a = H5Aopen(g, name, H5P_DEFAULT); if (a < 0) return 1;
+    int rc = H5Aread(a, H5T_NATIVE_DOUBLE, v) < 0; H5Aclose(a); return rc;
+}
+static int amr_read_h5(const char *path, int *nleaf, double *boxlen, double *origin, double **data) {
+    hid_t f = H5Fopen(path, H5F_ACC_RDONLY, H5P_DEFAULT); if (f < 0) return 1;
+    char gname[256]; gname[0] = 0;
+    H5G_info_t gi; if (H5Gget_info(f, &gi) < 0 || gi.nlinks < 1) { H5Fclose(f); return 3; }
+    for (hsize_t i = 0; i < gi.nlinks && !gname[0]; i++) {              /* the first group of the file */
+        char nm[256]; if (H5Lget_name_by_idx(f, ".", H5_INDEX_NAME, H5_ITER_INC, i, nm, sizeof nm, H5P_DEFAULT) < 0) continue;
+        hid_t o = H5Oopen(f, nm, H5P_DEFAULT);                         /* (H5Oget_info changed its signature between 1.10 and 1.12) */
+        if (o >= 0) { if (H5Iget_type(o) == H5I_GROUP) strcpy(gname, nm); H5Oclose(o); }
+    }
+    if (!gname[0]) { H5Fclose(f); return 3; }
+    hid_t g = H5Gopen2(f, gname, H5P_DEFAULT);
+    if (h5_attr_f64(g, "BOXLEN", boxlen) || !(*boxlen > 0.0)) { H5Gclose(g); H5Fclose(f); return 3; }
+    const char *on[3] = {"ORIGINX", "ORIGINY", "ORIGINZ"};
+    for (int a = 0; a < 3; a++) if (h5_attr_f64(g, on[a], &origin[a])) origin[a] = -0.5 * (*boxlen);
+    const char *cols[9][3] = {{"x", 0, 0}, {"y", 0, 0}, {"z", 0, 0}, {"level", 0, 0}, {"dens", "nH", "density"}, {"T", "temperature", 0},
+                              {"vx", 0, 0}, {"vy", 0, 0}, {"vz", 0, 0}};
+    double *d = NULL; hsize_t n = 0;
+    for (int c = 0; c < 9; c++) {
+        hid_t ds = -1;
+        for (int k = 0; k < 3 && ds < 0; k++) if (cols[c][k] && H5Lexists(g, cols[c][k], H5P_DEFAULT) > 0) ds = H5Dopen2(g, cols[c][k], H5P_DEFAULT);
+        if (ds < 0) { free(d); H5Gclose(g); H5Fclose(f); return 4; }
+        hid_t sp = H5Dget_space(ds); hsize_t dims[4] = {0, 0, 0, 0}; int rk = H5Sget_simple_extent_dims(sp, dims, NULL); H5Sclose(sp);
+        if (rk != 1 || (c > 0 && dims[0] != n)) { H5Dclose(ds); free(d); H5Gclose(g); H5Fclose(f); return 4; }
+        if (c == 0) { n = dims[0]; d = (double *)malloc(sizeof(double) * 9 * (size_t)n); if (!d) { H5Dclose(ds); H5Gclose(g); H5Fclose(f); return 5; } }
+        int rc = H5Dread(ds, H5T_NATIVE_DOUBLE, H5S_ALL, H5S_ALL, H5P_DEFAULT, d + (size_t)c * n) < 0;       /* any stored type converts */
+        H5Dclose(ds);
+        if (rc) { free(d); H5Gclose(g); H5Fclose(f); return 2; }
+    }
+    H5Gclose(g); H5Fclose(f);
+    *nleaf = (int)n; *data = d;
+    return 0;
+}
+#else
+static int amr_read_h5(const char *path, int *nleaf, double *boxlen, double *origin, double **data) { (void)path; (void)nleaf; (void)boxlen; (void)origin; (void)data; return 6; }
+#endif
+
+/* 0 ok, 1 cannot open, 2 short read, 3 not a leaf table (no BINTABLE / group / BOXLEN), 4 unexpected columns, 5 memory, 6 no HDF5 in this build */
+int lart_amr_read_binary(const char *path, int *nleaf, double *boxlen, double *origin, double **data) {
+    size_t L = strlen(path);
+    if ((L > 3 && !strcmp(path + L - 3, ".h5")) || (L > 5 && !strcmp(path + L - 5, ".hdf5"))) return amr_read_h5(path, nleaf, boxlen, origin, data);
+    return amr_read_fits(path, nleaf, boxlen, origin, data);
+}

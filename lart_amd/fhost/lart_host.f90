@@ -1130,13 +1130,17 @@ contains
   subroutine grid_create_amr(grid)
     type(grid_type), intent(inout) :: grid
     integer :: unit, ios, n, i, il, ic, nread
-    real(wp) :: boxlen, row(9), vt, opac_length, nopac, tauhomo, tau_raw, NHI, taupole, opac_norm, xc, zc, t, atau0_cell, xi, chi, H0
+    real(wp) :: amr_origin, boxlen, row(9), vt, opac_length, nopac, tauhomo, tau_raw, NHI, taupole, opac_norm, xc, zc, t, atau0_cell, xi, chi, H0
     real(wp), allocatable, target :: lx(:), ly(:), lz(:), nH(:), Tl(:), lvx(:), lvy(:), lvz(:)
     integer(int32), allocatable, target :: lev(:)
     integer(c_int32_t) :: nc, lm
     character(len=512) :: line_txt
     character(len=512) :: q
 
+    !--- binary containers (read_generic_amr.f90:186-279): FITS binary table (.fits, .fits.gz) or HDF5 group (.h5, .hdf5)
+    if (amr_is_binary(trim(par%amr_file))) then
+       call amr_read_binary_file()
+    else
     !--- read_generic_amr.f90:112-185: "NLEAF n" / "BOXLEN L" or legacy "n L", rows x y z level nH T vx vy vz, '#' comments
     open(newunit=unit, file=trim(par%amr_file), status='old', action='read', iostat=ios)
     if (ios /= 0) then
@@ -1180,9 +1184,11 @@ contains
     if (nread /= n) then
        write(*,'(a,i0,a,i0)') 'generic_amr_read: expected ', n, ' rows, got ', nread; stop 1
     endif
+    amr_origin = -0.5_wp*boxlen                           ! text files carry no origin: centred box (:177-181)
+    endif
 
     !--- tree + neighbour tables (octree_mod.f90:460-569, 619-682) by the host helper; text files: box centred on the origin (:179-181)
-    amr_nleaf = n; amr_lo = -0.5_wp*boxlen; amr_hi = 0.5_wp*boxlen
+    amr_nleaf = n; amr_lo = amr_origin; amr_hi = amr_origin + boxlen
     call amr_check(lart_host_amr_count(amr_nleaf, lx, ly, lz, lev, amr_lo, amr_hi, nc), 'lart_host_amr_count')
     amr_ncells = nc
     allocate(amr_cx(nc), amr_cy(nc), amr_cz(nc), amr_ch(nc), amr_children(8,nc), amr_neighbor(6,nc), amr_ileaf(nc), amr_icell_of_leaf(n))
@@ -1276,6 +1282,45 @@ contains
        grid%xcrit = 0.02_wp*exp(xi*(log(atau0_cell))**chi); grid%xcrit2 = grid%xcrit**2
     endif
     call create_JPa_amr_mem(grid)
+  contains
+    logical function amr_is_binary(f)
+      character(len=*), intent(in) :: f
+      integer :: n
+      character(len=len(f)) :: g
+      g = strlowcase(f); n = len_trim(g); amr_is_binary = .false.
+      if (n > 3) amr_is_binary = g(n-2:n) == '.h5'
+      if (n > 5) amr_is_binary = amr_is_binary .or. g(n-4:n) == '.fits' .or. g(n-4:n) == '.hdf5'
+      if (n > 8) amr_is_binary = amr_is_binary .or. g(n-7:n) == '.fits.gz'
+    end function amr_is_binary
+    subroutine amr_read_binary_file()
+      interface
+         function lart_amr_read_binary(path, nleaf, boxlen, origin, data) bind(C, name='lart_amr_read_binary') result(rc)
+           import; character(kind=c_char), intent(in) :: path(*); integer(c_int), intent(out) :: nleaf
+           real(c_double), intent(out) :: boxlen, origin(3); type(c_ptr), intent(out) :: data; integer(c_int) :: rc
+         end function
+         subroutine lart_free(p) bind(C, name='lart_free')
+           import; type(c_ptr), value :: p
+         end subroutine
+      end interface
+      type(c_ptr) :: cdata
+      real(c_double), pointer :: tab(:,:)
+      real(c_double) :: org(3)
+      integer(c_int) :: nl, rc
+      rc = lart_amr_read_binary(trim(par%amr_file)//c_null_char, nl, boxlen, org, cdata)
+      if (rc /= 0) then
+         write(*,'(3a,i0,a)') 'generic_amr_read_binary: cannot read ', trim(par%amr_file), ' (code ', rc, &
+              ': 1 open, 2 short file, 3 no leaf table / BOXLEN, 4 columns, 6 no HDF5 in this build)'; stop 1
+      endif
+      if (org(1) /= org(2) .or. org(1) /= org(3)) then
+         write(*,'(a)') 'ERROR: an AMR box with different ORIGINX/Y/Z is not supported by the MI355X photon path (cubic box [lo,hi]^3).'; stop 1
+      endif
+      n = nl; amr_origin = org(1)
+      call c_f_pointer(cdata, tab, [n, 9])
+      allocate(lx(n), ly(n), lz(n), lev(n), nH(n), Tl(n), lvx(n), lvy(n), lvz(n))
+      lx = tab(:,1); ly = tab(:,2); lz = tab(:,3); lev = nint(tab(:,4)); nH = tab(:,5); Tl = tab(:,6)
+      lvx = tab(:,7); lvy = tab(:,8); lvz = tab(:,9)
+      call lart_free(cdata)
+    end subroutine amr_read_binary_file
   end subroutine grid_create_amr
 
   subroutine amr_check(rc, where)

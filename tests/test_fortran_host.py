@@ -492,3 +492,35 @@ def test_whole_namelist_surface_is_readable(exe, tmp_path):
     (tmp_path / "bad.in").write_text("&parameters\n par%cone_opening = 30.0\n/\n")
     with pytest.raises(host.LartInputError, match="not supported"):
         host.read_namelist(str(tmp_path / "bad.in"))
+
+
+@pytest.mark.parametrize("ext", ["fits.gz", "fits", "h5"])
+def test_amr_binary_containers_equal_text(exe, tmp_path, ext):
+    """generic_amr_read_binary (read_generic_amr.f90:186-279): the FITS binary table / HDF5 group written by the reference's
+    python/AMR_grid tools gives the same octree and normalisation as the text table; an off-centre origin moves the box"""
+    from lart_amd import amr, host
+    d = amr.make_amr_sphere(level_min=2, level_max=5)
+    amr.write_generic_amr(str(tmp_path / "sphere_small.dat"), d)
+    if ext == "h5":
+        amr.write_generic_amr_h5(str(tmp_path / "s.h5"), d)
+    else:
+        amr.write_generic_amr_fits(str(tmp_path / ("s." + ext)), d, single=(ext == "fits"))
+    a = run(exe, AMR_IN, tmp_path, "--dry-run", name="amr.in")
+    b = run(exe, AMR_IN.replace("sphere_small.dat", "s." + ext), tmp_path, "--dry-run", name="amrb.in")
+    assert a.returncode == 0 and b.returncode == 0, b.stdout + b.stderr
+    pick = lambda out: [ln for ln in out.splitlines() if ln.startswith(("AMR ", "xfreq_min"))]
+    assert pick(a.stdout) == pick(b.stdout) and len(pick(a.stdout)) >= 4
+    # the python mirror reads the same containers
+    par = host.read_namelist(str(tmp_path / "amrb.in")); par.amr_file = str(tmp_path / ("s." + ext))
+    par, line, _ = host.read_input(par)
+    g, _ = amr.grid_create_amr(par, line, par.amr_file)
+    assert g.nleaf == len(d["x"])
+    # corner-based origin: the same leaves shifted by +1 in a box [0, 2]^3
+    d2 = dict(d, x=d["x"] + 1.0, y=d["y"] + 1.0, z=d["z"] + 1.0)
+    if ext == "h5":
+        amr.write_generic_amr_h5(str(tmp_path / "o.h5"), d2, origin=[0.0, 0.0, 0.0])
+    else:
+        amr.write_generic_amr_fits(str(tmp_path / ("o." + ext)), d2, origin=[0.0, 0.0, 0.0])
+    c = run(exe, AMR_IN.replace("sphere_small.dat", "o." + ext), tmp_path, "--dry-run", name="amro.in")
+    assert c.returncode == 0, c.stdout + c.stderr
+    assert [ln for ln in pick(c.stdout) if "nleaf" in ln] == [ln for ln in pick(a.stdout) if "nleaf" in ln]
