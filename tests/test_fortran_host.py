@@ -524,3 +524,25 @@ def test_amr_binary_containers_equal_text(exe, tmp_path, ext):
     c = run(exe, AMR_IN.replace("sphere_small.dat", "o." + ext), tmp_path, "--dry-run", name="amro.in")
     assert c.returncode == 0, c.stdout + c.stderr
     assert [ln for ln in pick(c.stdout) if "nleaf" in ln] == [ln for ln in pick(a.stdout) if "nleaf" in ln]
+
+
+@pytest.mark.gpu
+def test_reference_example_amr_sphere_reproduces_the_shipped_log(exe, tmp_path):
+    """examples/amr_sphere_generic: the parameters of sphere_amr_inside_test1M.in (the run behind log_amr_1M.txt) on the leaf
+    table of the example's generator (levels 3..7 refined on the surface, written here as uniform_amr_sphere.fits.gz) through
+    LaRT_amd.x: the log's header lines, <N_scatt> = 2.8225E+04 within the Monte-Carlo error of 1e5 photons, and the HEALPix files"""
+    from lart_amd import amr
+    amr.write_generic_amr_fits(str(tmp_path / "uniform_amr_sphere.fits.gz"), amr.make_amr_sphere())
+    text = ("&parameters\n par%use_amr_grid = .true.\n par%amr_type = 'generic'\n par%amr_file = 'uniform_amr_sphere.fits.gz'\n par%no_photons = 1e5\n"
+            " par%taumax = 1.0e4\n par%DGR = 0.0\n par%source_geometry = 'point'\n par%spectral_type = 'voigt'\n par%rmax = 1.0\n par%nxfreq = 121\n"
+            " par%nside = 8\n par%obsx = 0.0\n par%obsy = 0.0\n par%obsz = 0.0\n par%save_peeloff_2D = .true.\n par%save_Jin = .true.\n par%nprint = 100000\n"
+            " par%out_merge = .false.\n par%iseed = 1\n/\n")
+    r = run(exe, text, tmp_path, name="sphere_amr_inside_test.in")
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = r.stdout
+    for line in ("AMR nleaf    : 178480", "AMR voigt_a      :   4.7186E-04", "AMR N(HI)_pole   :   1.6954E+17", "AMR tau_pole      :   1.0000E+04"):
+        assert line in out, line
+    m = re.search(r"Average Number of scattering :\s+(\S+)", out)
+    assert m and abs(float(m.group(1)) / 2.8225e4 - 1) < 0.02
+    O = read_h5(str(tmp_path / "sphere_amr_inside_test_obs.h5"))
+    assert O["Scattered"][1].shape == (121, 768) and O["Scattered"][1].sum() > 0
