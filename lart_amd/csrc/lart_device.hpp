@@ -123,13 +123,12 @@ static __device__ const double c_voigt_tab[606] = {   // H0(101) | H1(202) | H2(
 #define VT_H3 404
 #define VT_END 606
 
-struct Lds { const double *vt; const double *xf, *yf, *zf;
+struct Lds { const double *vt; const double *xf, *yf, *zf;   // Voigt tables and cell faces staged in LDS
              double dip_p2, dip_qs;      // Cardano constants of the dipole phase function for par.E1 > 0 (rand_resonance): p, 1/(E1 p^3)
-             double *jp_P, *jp_Pn;
-             unsigned char *coop;
-             int lt; double dnu_hz; };  // line type (1 single line, 2 Ly-alpha doublet) and DnuHK_Hz: set from the kernel's template
-                                        // parameter, so that `l.lt == 2` folds away in the single-line kernels
-    // LART_COOP_BYTES per wave: scratch of the cooperative |x|<=1 sampler (vz_core_coop), nullptr = off   // per-block LDS copies of P1 / P1_new (nullptr: deposits go to global memory)   // Cardano constants of the dipole phase function for par.E1 > 0 (rand_resonance): p, 1/(E1 p^3)
+             double *jp_P, *jp_Pn;       // per-block LDS copies of P1 / P1_new (nullptr: deposits go to global memory)
+             unsigned char *coop;        // LART_COOP_BYTES per wave: scratch of the cooperative samplers (vz_core_coop / vz_wing_coop), nullptr = off
+             int lt; double dnu_hz; };   // line type (1 single line, 2 Ly-alpha doublet) and DnuHK_Hz: set from the kernel's template
+                                         // parameter, so that `l.lt == 2` folds away in the single-line kernels
 
 __device__ inline Lds lds_stage(double *sh, const DGrid &g) {
     for (int i = threadIdx.x; i < VT_END; i += blockDim.x) sh[i] = c_voigt_tab[i];
