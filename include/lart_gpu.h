@@ -29,7 +29,7 @@ typedef struct lart_params {
      * with nx = ny = 1) | _car_xyper (xy_periodic otherwise) exactly as setup_procedure does (setup.f90:951-980) */
     int32_t xyz_symmetry, xy_periodic, xy_symmetry;
     /* source: generate_photon.f90:33-132, :243-306 */
-    int32_t source_geometry;       /* 0 'point', 1 'uniform_sphere' */
+    int32_t source_geometry;       /* 0 'point', 1 'uniform_sphere', 2 'uniform_cylinder', 3 'uniform', 4 'uniform_xy', 5 'gaussian' (generate_photon.f90:31-72) */
     int32_t spectral_type;         /* 0 'monochromatic', 1 'voigt', 2 'continuum', 3 'gaussian' (generate_photon.f90:243-266) */
     int32_t comoving_source;
     /* scattering physics: scattering_car.f90 */
@@ -43,6 +43,7 @@ typedef struct lart_params {
     double  xs_point, ys_point, zs_point, source_rmax, xfreq0;
     double  xfreq_min, dxfreq, Dfreq_ref;          /* grid%xfreq_min, grid%dxfreq, grid%Dfreq_ref */
     double  xfreq_max, source_sigma_x;             /* grid%xfreq_max (continuum source); Gaussian source sigma / vtherm_total(par%temperature) */
+    double  xrange, yrange, zrange, source_zscale; /* grid%xrange.. (extended sources), par%source_zscale */
     double  DGR, hgg, albedo;
     double  mu_min, dmu;
     double  g_recoil0, E1, E2, E3;                 /* line%g_recoil0, line%E1..E3 (line_mod.f90:1255-1270) */

@@ -20,7 +20,7 @@ class LartParams(C.Structure):
         "recoil", "core_skip", "core_skip_global", "use_stokes", "use_reduced_wgt",
         "save_Jin", "save_Jabs", "save_Jmu", "nmu", "save_peeloff", "save_peeloff_2D", "save_peeloff_3D", "save_direc0", "save_dust_scattered", "nxfreq", "line_type")] + \
         [(n, _d) for n in (
-            "xs_point", "ys_point", "zs_point", "source_rmax", "xfreq0", "xfreq_min", "dxfreq", "Dfreq_ref", "xfreq_max", "source_sigma_x",
+            "xs_point", "ys_point", "zs_point", "source_rmax", "xfreq0", "xfreq_min", "dxfreq", "Dfreq_ref", "xfreq_max", "source_sigma_x", "xrange", "yrange", "zrange", "source_zscale",
             "DGR", "hgg", "albedo", "mu_min", "dmu", "g_recoil0", "E1", "E2", "E3", "DnuHK_Hz", "xcrit", "xcrit2")]
 
 

@@ -1688,6 +1688,18 @@ __device__ inline void generate_photon(const KArgs &A, const Lds &l, Rng &g, Pho
         double rp = cbrt(g.next()) * par.source_rmax, cost = 2.0 * g.next() - 1.0, sint = sqrt(1.0 - cost * cost), sp, cp;
         d_sincos_2pi(g.next(), &sp, &cp);
         p.x = rp * sint * cp; p.y = rp * sint * sp; p.z = rp * cost;
+    } else if (par.source_geometry == 2) {                     // uniform_cylinder :43-49
+        double rp = sqrt(g.next()) * par.source_rmax, sp, cp; d_sincos_2pi(g.next(), &sp, &cp);
+        p.x = rp * cp; p.y = rp * sp; p.z = par.zrange * g.next() + gr.zmin;
+    } else if (par.source_geometry == 3) {                     // uniform over the box :50-54
+        p.x = par.xrange * g.next() + gr.xmin; p.y = par.yrange * g.next() + gr.ymin; p.z = par.zrange * g.next() + gr.zmin;
+    } else if (par.source_geometry == 4) {                     // uniform_xy: a sheet at z = 0 :55-67
+        if (par.source_rmax > 0.0) { double rp = sqrt(g.next()) * par.source_rmax, sp, cp; d_sincos_2pi(g.next(), &sp, &cp); p.x = rp * cp; p.y = rp * sp; }
+        else { p.x = par.xrange * g.next() + gr.xmin; p.y = par.yrange * g.next() + gr.ymin; }
+        p.z = 0.0;
+    } else if (par.source_geometry == 5) {                     // gaussian in z :68-72 (one deviate of the polar pair)
+        p.x = par.xrange * g.next() + gr.xmin; p.y = par.yrange * g.next() + gr.ymin;
+        double second; p.z = par.source_zscale / 1.4142135623730951 * g.gauss_pair(second);
     } else { p.x = par.xs_point; p.y = par.ys_point; p.z = par.zs_point; }
     p.wgt = 1.0;
     if (VAR == 1) { if (p.x < gr.xmin) p.x = -p.x; if (p.y < gr.ymin) p.y = -p.y; if (p.z < gr.zmin) p.z = -p.z; }

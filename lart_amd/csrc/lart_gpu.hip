@@ -60,6 +60,7 @@ extern "C" int lart_gpu_create(lart_gpu **out, const lart_params *par, int devic
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail("lart_gpu_create: no HIP device visible (this library has no CPU path)");
     if (device < 0 || device >= n) return fail("lart_gpu_create: device ordinal out of range");
     HIPCHK(hipSetDevice(device));
+    if (par->source_geometry < 0 || par->source_geometry > 5) return fail("lart_gpu_create: source_geometry must be 0..5 (point, uniform_sphere, uniform_cylinder, uniform, uniform_xy, gaussian)");
     if (par->spectral_type < 0 || par->spectral_type > 3) return fail("lart_gpu_create: spectral_type must be 0 monochromatic, 1 voigt, 2 continuum or 3 gaussian");
     if (par->line_type != 1 && par->line_type != 2) return fail("lart_gpu_create: line_type must be 1 (single line) or 2 (Ly-alpha doublet, par%fine_structure)");
     if (par->line_type == 2 && !(par->DnuHK_Hz > 0.0)) return fail("lart_gpu_create: line_type 2 needs DnuHK_Hz > 0 (line%DnuHK_Hz)");

@@ -24,6 +24,7 @@ module lart_gpu_c
      real(c_double) :: xs_point, ys_point, zs_point, source_rmax, xfreq0
      real(c_double) :: xfreq_min, dxfreq, Dfreq_ref
      real(c_double) :: xfreq_max, source_sigma_x
+     real(c_double) :: xrange, yrange, zrange, source_zscale
      real(c_double) :: DGR, hgg, albedo
      real(c_double) :: mu_min, dmu
      real(c_double) :: g_recoil0, E1, E2, E3

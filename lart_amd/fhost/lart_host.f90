@@ -80,7 +80,7 @@ module lart_define
      real(wp) :: clump_radius = -1.0_wp, clump_N_clumps = -1.0_wp, clump_f_vol = -1.0_wp, clump_f_cov = -1.0_wp
      real(wp) :: clump_tau0 = -1.0_wp, clump_NHI = -1.0_wp, clump_nH = -1.0_wp, clump_temperature = -1.0_wp, clump_sigma_v = 0.0_wp
      real(wp) :: Vrot = 0.0_wp, rinner = 0.0_wp, Vpeak = 0.0_wp, rpeak = 0.0_wp, DeltaV = 0.0_wp, velocity_alpha = 1.0_wp
-     real(wp) :: gaussian_sigma_vel = 12.843374_wp, gaussian_FWHM_vel = -999.0_wp
+     real(wp) :: gaussian_sigma_vel = 12.843374_wp, gaussian_FWHM_vel = -999.0_wp, source_zscale = 0.0_wp
      character(len=20)  :: line_id = 'ly_alpha'
      character(len=8)   :: h2_model = 'none'
      character(len=128) :: dens_file = '', temp_file = '', velo_file = '', emiss_file = '', cart_file = '', input_field = '', star_file = ''
@@ -112,7 +112,6 @@ module lart_define
      real(wp) :: q = 1.0_wp
      real(wp) :: Omega = 0.0_wp
      logical :: continuum_normalize = .true.
-     real(wp) :: source_zscale = 0.0_wp
      real(wp) :: EW_line = 0.0_wp
      real(wp) :: f_line = 0.0_wp
      logical :: clump_allow_overlap = .false.
@@ -314,7 +313,6 @@ contains
     if (par%q /= 1.0_wp) call not_supported('par%q')
     if (par%Omega /= 0.0_wp) call not_supported('par%Omega')
     if (.not. par%continuum_normalize) call not_supported('par%continuum_normalize')
-    if (par%source_zscale /= 0.0_wp) call not_supported('par%source_zscale')
     if (par%EW_line /= 0.0_wp) call not_supported('par%EW_line')
     if (par%f_line /= 0.0_wp) call not_supported('par%f_line')
     if (par%clump_allow_overlap) call not_supported('par%clump_allow_overlap')
@@ -434,9 +432,14 @@ contains
     case ('box'); par%geometry = 'rectangle'
     end select
     if (trim(par%geometry) /= 'sphere' .and. trim(par%geometry) /= 'rectangle') call not_supported('par%geometry = '//trim(par%geometry))
-    if (trim(par%source_geometry) == 'sphere') par%source_geometry = 'uniform_sphere'
-    if (trim(par%source_geometry) /= 'point' .and. trim(par%source_geometry) /= 'uniform_sphere') &
-       call not_supported('par%source_geometry = '//trim(par%source_geometry))
+    if (trim(par%source_geometry) == 'sphere')   par%source_geometry = 'uniform_sphere'
+    if (trim(par%source_geometry) == 'cylinder') par%source_geometry = 'uniform_cylinder'
+    select case (trim(par%source_geometry))
+    case ('point', 'uniform_sphere')
+    case ('uniform_cylinder', 'uniform', 'uniform_xy', 'gaussian')                             ! generate_photon.f90:43-72
+       if (par%use_amr_grid .or. par%use_clump_medium) call not_supported('par%source_geometry = '//trim(par%source_geometry)//' with the octree / clump medium')
+    case default; call not_supported('par%source_geometry = '//trim(par%source_geometry))
+    end select
     select case (trim(par%spectral_type))
     case ('voigt', 'monochromatic', 'gaussian')
     case ('continuum'); par%comoving_source = .false.                                            ! setup.f90:115

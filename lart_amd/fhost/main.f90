@@ -239,7 +239,15 @@ contains
   subroutine fill_params(p)
     type(lart_params), intent(out) :: p
     p%xyz_symmetry = merge(1, 0, par%xyz_symmetry); p%xy_periodic = merge(1, 0, par%xy_periodic); p%xy_symmetry = merge(1, 0, par%xy_symmetry)
-    p%source_geometry = merge(1, 0, trim(par%source_geometry) == 'uniform_sphere')
+    select case (trim(par%source_geometry))
+    case ('uniform_sphere');   p%source_geometry = 1
+    case ('uniform_cylinder'); p%source_geometry = 2
+    case ('uniform');          p%source_geometry = 3
+    case ('uniform_xy');       p%source_geometry = 4
+    case ('gaussian');         p%source_geometry = 5
+    case default;              p%source_geometry = 0
+    end select
+    p%xrange = grid%xrange; p%yrange = grid%yrange; p%zrange = grid%zrange; p%source_zscale = par%source_zscale
     select case (trim(par%spectral_type))
     case ('voigt');     p%spectral_type = 1
     case ('continuum'); p%spectral_type = 2

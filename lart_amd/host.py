@@ -154,6 +154,7 @@ class Params:
     velocity_alpha: float = 1.0
     gaussian_sigma_vel: float = 12.843374
     gaussian_FWHM_vel: float = -999.0
+    source_zscale: float = 0.0
     # octree medium (grid_mod_amr.f90); only the generic text format of read_generic_amr.f90:112-185 is read here
     use_amr_grid: bool = False
     amr_type: str = "generic"
@@ -193,7 +194,6 @@ _UNSUPPORTED_DEFAULTS = {
     "nwavelength": 0,
     "q": 1.0,
     "continuum_normalize": True,
-    "source_zscale": 0.0,
     "EW_line": 0.0,
     "f_line": 0.0,
     "clump_allow_overlap": False,
@@ -396,6 +396,9 @@ def setup_scattering_matrix(par, path):
     return sm
 
 
+_SOURCE_GEOMETRIES = {"point": 0, "uniform_sphere": 1, "uniform_cylinder": 2, "uniform": 3, "uniform_xy": 4, "gaussian": 5}
+
+
 def read_input(par, line=None):
     """post-processing part of read_input (setup.f90:42-562) for the fields this path uses. Returns (par, line, scatt_mat)."""
     line = line or Line()
@@ -412,9 +415,8 @@ def read_input(par, line=None):
         par.geometry = "rectangle"
     if par.geometry not in ("sphere", "rectangle"):
         raise LartInputError("par%%geometry = '%s' is not supported by this path" % par.geometry)
-    if par.source_geometry == "sphere":
-        par.source_geometry = "uniform_sphere"
-    if par.source_geometry not in ("point", "uniform_sphere"):
+    par.source_geometry = {"sphere": "uniform_sphere", "cylinder": "uniform_cylinder"}.get(par.source_geometry, par.source_geometry)
+    if par.source_geometry not in _SOURCE_GEOMETRIES or (par.source_geometry not in ("point", "uniform_sphere") and (par.use_amr_grid or par.use_clump_medium)):
         raise LartInputError("par%%source_geometry = '%s' is not supported by this path" % par.source_geometry)
     if par.spectral_type not in ("voigt", "monochromatic", "continuum", "gaussian"):
         raise LartInputError("par%%spectral_type = '%s' is not supported by this path" % par.spectral_type)
@@ -905,7 +907,8 @@ def make_lart_params(par, line, g):
               "use_reduced_wgt", "save_Jin", "save_Jabs", "save_Jmu", "nmu", "save_peeloff", "save_peeloff_2D", "save_peeloff_3D",
               "save_direc0", "save_dust_scattered"):
         setattr(p, n, int(getattr(par, n)))
-    p.source_geometry = {"point": 0, "uniform_sphere": 1}[par.source_geometry]
+    p.source_geometry = _SOURCE_GEOMETRIES[par.source_geometry]
+    p.xrange, p.yrange, p.zrange, p.source_zscale = g.xmax - g.xmin, g.ymax - g.ymin, g.zmax - g.zmin, par.source_zscale
     p.spectral_type = {"monochromatic": 0, "voigt": 1, "continuum": 2, "gaussian": 3}[par.spectral_type]
     gsig = par.gaussian_FWHM_vel / 2.3548200450309493 if par.gaussian_FWHM_vel > 0.0 else par.gaussian_sigma_vel
     p.xfreq_max, p.source_sigma_x = g.xfreq_max, gsig / vtherm_total(line, par.temperature)

@@ -306,7 +306,8 @@ struct orc_sim {
     double Vx, Vy, Vz;
     int comoving_source, recoil, core_skip, core_skip_global, xyz_symmetry, xy_periodic, xy_symmetry;
     int nx, ny, nz; double xmax, ymax, zmax, rmax, rmin;
-    double xs_point, ys_point, zs_point, source_rmax; int source_geometry;   /* 0 point, 1 uniform_sphere */
+    double xs_point, ys_point, zs_point, source_rmax; int source_geometry;   /* 0 point, 1 uniform_sphere, 2 uniform_cylinder, 3 uniform, 4 uniform_xy, 5 gaussian */
+    double source_zscale;
     double xfreq0, par_xfreq_min, par_xfreq_max; int nxfreq;
     int spectral_type;               /* 0 monochromatic, 1 voigt, 2 continuum, 3 gaussian */
     double gaussian_sigma_vel, gaussian_FWHM_vel;
@@ -399,7 +400,7 @@ static int set_param(orc_sim *s, const char *k, const char *v) {
     if (!strcmp(k, "N_HIhomo") || !strcmp(k, "N_gashomo")) { s->N_gashomo = atof(v); return 0; }
     if (!strcmp(k, "tau0")) { s->taumax = atof(v); return 0; }
     B(use_clump_medium) B(clump_fully_inside) D(clump_radius) D(clump_N_clumps) D(clump_f_vol) D(clump_f_cov) D(clump_tau0) D(clump_NHI) D(clump_nH)
-    D(clump_temperature) D(clump_sigma_v) D(Vrot) D(rinner) D(velocity_min) D(velocity_max) D(Vpeak) D(rpeak) D(DeltaV) D(velocity_alpha) D(gaussian_sigma_vel) D(gaussian_FWHM_vel)
+    D(clump_temperature) D(clump_sigma_v) D(Vrot) D(rinner) D(velocity_min) D(velocity_max) D(Vpeak) D(rpeak) D(DeltaV) D(velocity_alpha) D(gaussian_sigma_vel) D(gaussian_FWHM_vel) D(source_zscale)
     if (!strcmp(k, "use_amr_grid")) { s->use_amr_grid = parse_bool(v); return 0; }
     if (!strcmp(k, "amr_file")) { snprintf(s->amr_file, sizeof s->amr_file, "%s", v); return 0; }
     if (!strcmp(k, "amr_type")) return 0;
@@ -411,6 +412,8 @@ static int set_param(orc_sim *s, const char *k, const char *v) {
         return 0; }
     if (!strcmp(k, "source_geometry")) {
         if (!strcmp(v, "point")) s->source_geometry = 0; else if (!strcmp(v, "uniform_sphere") || !strcmp(v, "sphere")) s->source_geometry = 1;
+        else if (!strcmp(v, "uniform_cylinder") || !strcmp(v, "cylinder")) s->source_geometry = 2; else if (!strcmp(v, "uniform")) s->source_geometry = 3;
+        else if (!strcmp(v, "uniform_xy")) s->source_geometry = 4; else if (!strcmp(v, "gaussian")) s->source_geometry = 5;
         else { snprintf(g_err, sizeof g_err, "source_geometry '%s' not supported by the oracle", v); return -1; }
         return 0; }
     if (!strcmp(k, "velocity_type")) {
@@ -2207,6 +2210,17 @@ static void generate_photon(const orc_sim *s, acc_t *A, rng_t *g, photon_t *p) {
     if (s->source_geometry == 1) {                                                   /* :34-42 */
         double rp = pow(rnd(g), 1.0 / 3.0) * s->source_rmax, cost = 2.0 * rnd(g) - 1.0, sint = sqrt(1.0 - cost * cost), phi = TWOPI * rnd(g);
         p->x = rp * sint * cos(phi); p->y = rp * sint * sin(phi); p->z = rp * cost;
+    } else if (s->source_geometry == 2) {                                            /* uniform_cylinder :43-49 */
+        double rp = sqrt(rnd(g)) * s->source_rmax, phi = TWOPI * rnd(g);
+        p->x = rp * cos(phi); p->y = rp * sin(phi); p->z = s->zrange * rnd(g) + s->zmin;
+    } else if (s->source_geometry == 3) {                                            /* uniform :50-54 */
+        p->x = s->xrange * rnd(g) + s->xmin; p->y = s->yrange * rnd(g) + s->ymin; p->z = s->zrange * rnd(g) + s->zmin;
+    } else if (s->source_geometry == 4) {                                            /* uniform_xy :55-67 */
+        if (s->source_rmax > 0.0) { double rp = sqrt(rnd(g)) * s->source_rmax, phi = TWOPI * rnd(g); p->x = rp * cos(phi); p->y = rp * sin(phi); }
+        else { p->x = s->xrange * rnd(g) + s->xmin; p->y = s->yrange * rnd(g) + s->ymin; }
+        p->z = 0.0;
+    } else if (s->source_geometry == 5) {                                            /* gaussian (in z) :68-72 */
+        p->x = s->xrange * rnd(g) + s->xmin; p->y = s->yrange * rnd(g) + s->ymin; p->z = s->source_zscale / sqrt(2.0) * rand_gauss(g);
     } else { p->x = s->xs_point; p->y = s->ys_point; p->z = s->zs_point; }             /* :126-131 */
     setup_isotropic_injection(s, g, p);
     p->nscatt_gas = 0.0; p->nscatt_dust = 0.0; p->inside = 1; p->xfreq = s->xfreq0;
@@ -2361,7 +2375,7 @@ double orc_get_scalar(const orc_sim *s, const char *k) {
     G(taumax) G(tauhomo) G(N_gasmax) G(N_gashomo) G(voigt_amean) G(atau3) G(nobs) G(dxim) G(dyim) G(distance) G(nxim) G(nyim)
     G(rmax) G(xmax) G(ymax) G(zmax) G(DGR) G(albedo) G(hgg) G(cext_dust) G(cross0) G(g_recoil0) G(xcrit) G(raytrace_variant) G(save_peeloff)
     G(use_stokes) G(nPDF) G(save_Jabs) G(nmu) G(mu_min) G(dmu) G(distance2cm) G(source_rmax) G(comoving_source) G(recoil) G(core_skip) G(core_skip_global)
-    G(xyz_symmetry) G(xy_periodic) G(save_Jin) G(save_Jmu) G(use_reduced_wgt) G(xs_point) G(ys_point) G(zs_point) G(xfreq0) G(spectral_type) G(source_geometry)
+    G(xyz_symmetry) G(xy_periodic) G(save_Jin) G(save_Jmu) G(use_reduced_wgt) G(xs_point) G(ys_point) G(zs_point) G(xfreq0) G(spectral_type) G(source_geometry) G(xrange) G(yrange) G(zrange) G(source_zscale)
     if (s->use_clump_medium) { const clumps_t *c = &s->cl;
         if (!strcmp(k, "cl_N")) return (double)c->N; if (!strcmp(k, "cl_nreg")) return (double)c->nreg; if (!strcmp(k, "cl_cgx")) return c->cgx;
         if (!strcmp(k, "cl_rhokap_ref")) return c->rhokap_ref; if (!strcmp(k, "cl_voigt_a_ref")) return c->voigt_a_ref; if (!strcmp(k, "cl_Dfreq_ref")) return c->Dfreq_ref;

@@ -135,6 +135,13 @@ def test_scatter_event_device(capi, oracle_mod, kw):
     (dict(temperature=1e1, taumax=3e1, nx=21, ny=21, nz=21, rmax=1.0, nxfreq=121, iseed=8, fine_structure=True), 20000),
     (dict(temperature=1e4, taumax=1e1, nx=21, ny=21, nz=21, rmax=1.0, nxfreq=81, iseed=10, spectral_type="gaussian", gaussian_FWHM_vel=150.0,
           velocity_type="hubble", Vexp=40.0, comoving_source=False), 20000),
+    (dict(temperature=1e4, taumax=1e1, nx=21, ny=21, nz=21, xmax=1.0, ymax=1.0, zmax=1.0, geometry="rectangle", nxfreq=81, iseed=12, source_geometry="uniform"), 20000),
+    (dict(temperature=1e4, taumax=1e1, nx=21, ny=21, nz=31, xmax=1.0, ymax=1.0, zmax=1.5, geometry="rectangle", nxfreq=81, iseed=13, source_geometry="uniform_cylinder",
+          source_rmax=0.6), 20000),
+    (dict(temperature=1e4, taumax=1e1, nx=4, ny=4, nz=31, xmax=0.5, ymax=0.5, zmax=1.0, geometry="rectangle", xy_periodic=True, nxfreq=81, iseed=14,
+          source_geometry="uniform_xy"), 20000),
+    (dict(temperature=1e4, taumax=1e1, nx=4, ny=4, nz=31, xmax=0.5, ymax=0.5, zmax=1.0, geometry="rectangle", xy_periodic=True, nxfreq=81, iseed=15,
+          source_geometry="gaussian", source_zscale=0.3), 20000),
     (dict(temperature=1e4, taumax=1e1, nx=21, ny=21, nz=21, rmax=1.0, nxfreq=81, iseed=11, spectral_type="continuum", velocity_type="hubble", Vexp=-30.0,
           save_Jin=True), 20000),
     (dict(temperature=3e1, taumax=3e1, xyz_symmetry=True, nx=21, ny=21, nz=21, rmax=1.0, nxfreq=121, iseed=9, fine_structure=True, use_stokes=True,
