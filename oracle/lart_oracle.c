@@ -271,6 +271,7 @@ typedef struct {
     double x, y, z, kx, ky, kz, mx, my, mz, nx, ny, nz;
     int icell, jcell, kcell;
     int icell_clump;                  /* 0 = vacuum, > 0 = owner clump (define.f90:90) */
+    int species;                      /* line%selected_species_HD of the last resonance scattering: 1 H, 2 D */
     double xfreq, xfreq_ref, wgt;
     int inside;
     double I, Q, U, V, E1, E2, E3;
@@ -321,7 +322,8 @@ struct orc_sim {
     double atau3;
     /* --- line (line_mod.f90:1241-1270) --- */
     double cross0, vtherm1, damping, wavelength0, g_recoil0, E1, E2, E3;
-    int fine_structure, line_type; double DnuHK_Hz;     /* line_type 2: Ly-alpha doublet 2P1/2 (H) + 2P3/2 (K), line_mod.f90:1241-1270 */
+    int fine_structure, line_type; double DnuHK_Hz;
+    int include_deuterium; double D_to_H_ratio, nD_over_nH, delta_nu_HD_Hz, ratio_Dfreq_HD, ratio_voigta_HD, g_recoil0_D;   /* line_type 7: H + D (line_mod.f90:1155-1191) */     /* line_type 2: Ly-alpha doublet 2P1/2 (H) + 2P3/2 (K), line_mod.f90:1241-1270 */
     /* --- grid (define.f90:117-206) --- */
     int i0, j0, k0;
     double xmin, ymin, zmin, dx, dy, dz, xrange, yrange, zrange;
@@ -353,6 +355,9 @@ static void amr_xcrit_local(const orc_sim *s, int il, double x, double y, double
 static inline double calc_voigt(const orc_sim *s, double xfreq, double a, double Dfreq) {
     if (s->line_type == 2) { double DnuHK = s->DnuHK_Hz / Dfreq;
         return orc_voigt(xfreq + DnuHK, a) * (1.0 / 3.0) + orc_voigt(xfreq, a) * (2.0 / 3.0); }
+    if (s->line_type == 7) {                                /* calc_voigt_HD :82-106: H profile + the D line seen from the H frame */
+        double dx_HD = s->delta_nu_HD_Hz / Dfreq, xfreq_D = (xfreq - dx_HD) * s->ratio_Dfreq_HD;
+        return orc_voigt(xfreq, a) + s->nD_over_nH * s->ratio_Dfreq_HD * orc_voigt(xfreq_D, a * s->ratio_voigta_HD); }
     return orc_voigt(xfreq, a);
 }
 #define IDX(s,i,j,k) ((size_t)((i)-1) + (size_t)(s)->nx * ((size_t)((j)-1) + (size_t)(s)->ny * (size_t)((k)-1)))
@@ -381,6 +386,7 @@ static void set_defaults(orc_sim *s) {
     s->geometry = 0; s->geometry_JPa = 2147483647;
     s->clump_radius = s->clump_N_clumps = s->clump_f_vol = s->clump_f_cov = s->clump_tau0 = s->clump_NHI = s->clump_nH = s->clump_temperature = -1.0;
     s->clump_fully_inside = 1; s->velocity_min = NAN; s->velocity_max = NAN; s->velocity_alpha = 1.0;
+    s->D_to_H_ratio = 1.5e-5;
     s->gaussian_sigma_vel = 12.843374; s->gaussian_FWHM_vel = -999.0;     /* define.f90:317-318 */
 }
 
@@ -389,7 +395,7 @@ static int set_param(orc_sim *s, const char *k, const char *v) {
 #define I(name) if (!strcmp(k, #name)) { s->name = atoi(v); return 0; }
 #define B(name) if (!strcmp(k, #name)) { s->name = parse_bool(v); return 0; }
     D(no_photons) I(iseed) D(temperature) D(taumax) D(tauhomo) D(Vexp) D(Vx) D(Vy) D(Vz)
-    B(comoving_source) B(recoil) B(core_skip) B(core_skip_global) B(xyz_symmetry) B(xy_periodic) B(xy_symmetry) B(fine_structure)
+    B(comoving_source) B(recoil) B(core_skip) B(core_skip_global) B(xyz_symmetry) B(xy_periodic) B(xy_symmetry) B(fine_structure) B(include_deuterium)
     I(nx) I(ny) I(nz) D(xmax) D(ymax) D(zmax) D(rmax) D(rmin) D(xs_point) D(ys_point) D(zs_point) D(source_rmax)
     D(xfreq0) I(nxfreq) B(use_stokes) B(use_reduced_wgt) B(save_Jin) B(save_Jabs) B(save_Jmu) I(nmu)
     D(hgg) D(albedo) D(cext_dust) D(DGR) D(distance2cm) B(save_peeloff) B(save_peeloff_2D) B(save_peeloff_3D) B(save_direc0) B(save_dust_scattered)
@@ -400,11 +406,13 @@ static int set_param(orc_sim *s, const char *k, const char *v) {
     if (!strcmp(k, "N_HIhomo") || !strcmp(k, "N_gashomo")) { s->N_gashomo = atof(v); return 0; }
     if (!strcmp(k, "tau0")) { s->taumax = atof(v); return 0; }
     B(use_clump_medium) B(clump_fully_inside) D(clump_radius) D(clump_N_clumps) D(clump_f_vol) D(clump_f_cov) D(clump_tau0) D(clump_NHI) D(clump_nH)
-    D(clump_temperature) D(clump_sigma_v) D(Vrot) D(rinner) D(velocity_min) D(velocity_max) D(Vpeak) D(rpeak) D(DeltaV) D(velocity_alpha) D(gaussian_sigma_vel) D(gaussian_FWHM_vel) D(source_zscale)
+    D(clump_temperature) D(clump_sigma_v) D(Vrot) D(rinner) D(velocity_min) D(velocity_max) D(Vpeak) D(rpeak) D(DeltaV) D(velocity_alpha) D(gaussian_sigma_vel) D(gaussian_FWHM_vel) D(source_zscale) D(D_to_H_ratio)
     if (!strcmp(k, "use_amr_grid")) { s->use_amr_grid = parse_bool(v); return 0; }
     if (!strcmp(k, "amr_file")) { snprintf(s->amr_file, sizeof s->amr_file, "%s", v); return 0; }
     if (!strcmp(k, "amr_type")) return 0;
     if (!strcmp(k, "scatt_mat_file")) { snprintf(s->scatt_mat_file, sizeof s->scatt_mat_file, "%s", v); return 0; }
+    if (!strcmp(k, "line_id")) { if (!strcmp(v, "ly_alpha")) return 0; if (!strcmp(v, "ly_alpha_HD")) { s->include_deuterium = 1; return 0; }
+        snprintf(g_err, sizeof g_err, "line_id '%s' not supported by the oracle", v); return -1; }
     if (!strcmp(k, "spectral_type")) {
         if (!strcmp(v, "voigt")) s->spectral_type = 1; else if (!strcmp(v, "monochromatic")) s->spectral_type = 0;
         else if (!strcmp(v, "continuum")) s->spectral_type = 2; else if (!strcmp(v, "gaussian")) s->spectral_type = 3;
@@ -455,6 +463,16 @@ static void setup_line(orc_sim *s) {
     s->vtherm1 = vtherm1_amu / sqrt(mass_amu);
     double wl = s->wavelength0 * UM2M;
     s->g_recoil0 = (H_PLANCK / amu / mass_amu) / (wl * wl);
+    if (s->include_deuterium) {                             /* 'ly_alpha_HD' (:580-588 promotion, fine structure switched off; :1155-1191) */
+        const double speedc_cm = 2.99792458e5 * 1.0e5, um2m = UM2M;
+        const double wl_D = 0.1215337431, mass_D = 2.01410177812, damping_D = 6.2649e8;
+        s->fine_structure = 0; s->line_type = 7; s->DnuHK_Hz = 0.0;
+        s->nD_over_nH = s->D_to_H_ratio;
+        s->delta_nu_HD_Hz = speedc_cm * (1.0 / (wl_D * um2m * 1.0e2) - 1.0 / (s->wavelength0 * um2m * 1.0e2));
+        s->ratio_Dfreq_HD = (wl_D / s->wavelength0) * sqrt(mass_D / mass_amu);
+        s->ratio_voigta_HD = (damping_D / s->damping) * s->ratio_Dfreq_HD;
+        s->g_recoil0_D = (H_PLANCK / amu / mass_D) / ((wl_D * um2m) * (wl_D * um2m));
+    }
 }
 void orc_line_constants(double *cross0, double *vtherm1, double *damping, double *wavelength0, double *g_recoil0) {
     orc_sim t; setup_line(&t);
@@ -1260,6 +1278,8 @@ static inline double voigt_clump(const orc_sim *s, double xfreq, int64_t icl) {
     const clumps_t *c = &s->cl; double xloc = xfreq * (c->Dfreq_ref / c->Dfreq[icl-1]);
     if (s->line_type == 2) { double Dnu = s->DnuHK_Hz / c->Dfreq[icl-1];
         return orc_voigt(xloc + Dnu, c->voigt_a[icl-1]) * (1.0 / 3.0) + orc_voigt(xloc, c->voigt_a[icl-1]) * (2.0 / 3.0); }
+    if (s->line_type == 7) { double Dnu = s->delta_nu_HD_Hz / c->Dfreq[icl-1], xD = (xloc - Dnu) * s->ratio_Dfreq_HD;      /* clump_mod.f90:159-164 */
+        return orc_voigt(xloc, c->voigt_a[icl-1]) + s->nD_over_nH * s->ratio_Dfreq_HD * orc_voigt(xD, c->voigt_a[icl-1] * s->ratio_voigta_HD); }
     return orc_voigt(xloc, c->voigt_a[icl-1]);
 }
 static inline double kappa_clump(const orc_sim *s, double xfreq, int64_t icl) {
@@ -1919,7 +1939,7 @@ static void peeling_resonance_nostokes(const orc_sim *s, acc_t *A, const photon_
         else { double rho = 1.0 / rho1; cosp = rho * (cost * p->kz - po.kz); sinp = rho * (p->kx * po.ky - po.kx * p->ky); }
         xfreq = xfreq_atom + (va[0] * cosp + va[1] * sinp) * sint + va[2] * cost;
         size_t c = IDX(s,p->icell,p->jcell,p->kcell);
-        if (s->recoil) { double g_recoil = s->g_recoil0 / s->Dfreq[c]; xfreq = xfreq - g_recoil * (1.0 - cost); }
+        if (s->recoil) { double g_recoil = ((s->line_type == 7 && p->species == 2) ? s->g_recoil0_D : s->g_recoil0) / s->Dfreq[c]; xfreq = xfreq - g_recoil * (1.0 - cost); }
         double u1 = peel_u1(s, p, c, &po), xfreq_ref = xfreq + u1;
         xfreq_ref = xfreq_ref * (s->Dfreq[c] / s->Dfreq_ref);
         int ixf = (int)floor((xfreq_ref - s->xfreq_min) / s->dxfreq) + 1;
@@ -1957,7 +1977,7 @@ static void peeling_resonance_stokes(const orc_sim *s, acc_t *A, const photon_t 
         double cost2 = cost * cost, S22 = 0.75 * p->E1 * (cost2 + 1.0), S11 = S22 + p->E2, S12 = 0.75 * p->E1 * (cost2 - 1.0), S33 = 1.5 * p->E1 * cost, S44 = 1.5 * p->E3 * cost;
         double xfreq = xfreq_atom + (va[0] * cosp + va[1] * sinp) * sint + va[2] * cost;
         size_t c = IDX(s,p->icell,p->jcell,p->kcell);
-        if (s->recoil) { double g_recoil = s->g_recoil0 / s->Dfreq[c]; xfreq = xfreq - g_recoil * (1.0 - cost); }
+        if (s->recoil) { double g_recoil = ((s->line_type == 7 && p->species == 2) ? s->g_recoil0_D : s->g_recoil0) / s->Dfreq[c]; xfreq = xfreq - g_recoil * (1.0 - cost); }
         double u1 = peel_u1(s, p, c, &po), xfreq_ref = (xfreq + u1) * (s->Dfreq[c] / s->Dfreq_ref);
         int ixf = (int)floor((xfreq_ref - s->xfreq_min) / s->dxfreq) + 1;
         double Q0 = cos2p * p->Q + sin2p * p->U, U0 = -sin2p * p->Q + cos2p * p->U;
@@ -2039,6 +2059,13 @@ static void do_resonance1(const orc_sim *s, rng_t *g, photon_t *p, double *uz, d
         double qH = xatom_loc + DnuHK, qK = xatom_loc;
         p->E1 = (2.0 * qK * qH + qH * qH) / (qK * qK + 2.0 * qH * qH);             /* E1 of the atom-frame frequency */
         p->E2 = 1.0 - p->E1; p->E3 = (p->E1 + 2.0) / 3.0;
+    } else if (s->line_type == 7) {                         /* do_resonance_HD :476-549 (clump form line_clump_mod.f90:262-300): H or D atom */
+        double dx_HD = s->delta_nu_HD_Hz / Df, xfreq_D = (xfreq_loc - dx_HD) * s->ratio_Dfreq_HD;
+        double pH = orc_voigt(xfreq_loc, va), pD = s->nD_over_nH * s->ratio_Dfreq_HD * orc_voigt(xfreq_D, va * s->ratio_voigta_HD);
+        if (rnd(g) < pH / (pH + pD)) { p->species = 1; uz_loc = rand_resonance_vz(g, xfreq_loc, va); }
+        else { p->species = 2; uz_loc = rand_resonance_vz(g, xfreq_D, va * s->ratio_voigta_HD) / s->ratio_Dfreq_HD; }
+        xatom_loc = xfreq_loc - uz_loc;
+        p->E1 = s->E1; p->E2 = s->E2; p->E3 = s->E3;
     } else {
         uz_loc = rand_resonance_vz(g, xfreq_loc, va);
         xatom_loc = xfreq_loc - uz_loc;
@@ -2069,9 +2096,11 @@ static inline void rotate_triad(photon_t *p, double cost, double sint, double co
 /* clump thermal-width ratio (scattering_car.f90:384-388, 715-719) and recoil constant (:428-433, 769-774) of the owner clump */
 static inline double clump_vth_ratio(const orc_sim *s, const photon_t *p) { return (s->use_clump_medium && p->icell_clump > 0) ? s->cl.Dfreq[p->icell_clump-1] / s->cl.Dfreq_ref : 1.0; }
 static inline double recoil_const(const orc_sim *s, const photon_t *p) {
-    if (s->use_clump_medium && p->icell_clump > 0) return s->g_recoil0 / s->cl.Dfreq[p->icell_clump-1];
-    return s->g_recoil0 / s->Dfreq[IDX(s,p->icell,p->jcell,p->kcell)];
+    const double g0 = (s->line_type == 7 && p->species == 2) ? s->g_recoil0_D : s->g_recoil0;      /* a deuterium atom recoils less (scattering_car.f90:427-437) */
+    if (s->use_clump_medium && p->icell_clump > 0) return g0 / s->cl.Dfreq[p->icell_clump-1];
+    return g0 / s->Dfreq[IDX(s,p->icell,p->jcell,p->kcell)];
 }
+/* D scatter: the perpendicular velocity comes in D Doppler units -> the photon's H units (scattering_car.f90:402-409, :417-424) */
 /* perpendicular atom velocity: core-skip branch :733-737, plain :749-752 */
 static inline void perp_velocity_rayleigh(const orc_sim *s, rng_t *g, const photon_t *p, double *ux, double *uy) {
     double xc = 0.0, xc2 = 0.0, phi2, uxy;
@@ -2079,6 +2108,7 @@ static inline void perp_velocity_rayleigh(const orc_sim *s, rng_t *g, const phot
     if (s->core_skip && fabs(p->xfreq) < xc) { phi2 = TWOPI * rnd(g); uxy = sqrt(xc2 - log(rnd(g))); }
     else                                     { phi2 = TWOPI * rnd(g); uxy = sqrt(-log(rnd(g))); }
     *ux = uxy * cos(phi2); *uy = uxy * sin(phi2);
+    if (s->line_type == 7 && p->species == 2) { *ux = *ux / s->ratio_Dfreq_HD; *uy = *uy / s->ratio_Dfreq_HD; }
     double vr = clump_vth_ratio(s, p); *ux = *ux * vr; *uy = *uy * vr;
 }
 /* scatter_resonance_nostokes: :660-827 */
@@ -2117,6 +2147,7 @@ static void scatter_resonance_stokes(const orc_sim *s, acc_t *A, rng_t *g, photo
         if (g->kind == 0) { ux = rand_gauss(g) * (1.0 / sqrt(2.0)); uy = rand_gauss(g) * (1.0 / sqrt(2.0)); }
         else { double g2, g1 = gauss_pair(g, &g2); ux = g1 * (1.0 / sqrt(2.0)); uy = g2 * (1.0 / sqrt(2.0)); }
     }
+    if (s->line_type == 7 && p->species == 2) { ux = ux / s->ratio_Dfreq_HD; uy = uy / s->ratio_Dfreq_HD; }
     { double vr = clump_vth_ratio(s, p); ux = ux * vr; uy = uy * vr; }
     p->xfreq = xfreq_atom + uz * cost + (ux * cosp + uy * sinp) * sint;
     if (s->recoil) { double g_recoil = recoil_const(s, p); p->xfreq = p->xfreq - g_recoil * (1.0 - cost); }
@@ -2384,7 +2415,7 @@ double orc_get_scalar(const orc_sim *s, const char *k) {
         if (!strcmp(k, "cg_min")) return c->cg_min; if (!strcmp(k, "cg_d")) return c->cg_d; if (!strcmp(k, "cl_sphere_R")) return c->sphere_R; if (!strcmp(k, "cl_radius_max")) return c->radius_max; }
     if (!strcmp(k, "amr_ncells")) return s->amr.ncells; if (!strcmp(k, "amr_nleaf")) return s->amr.nleaf; if (!strcmp(k, "amr_levelmax")) return s->amr.levelmax;
     if (!strcmp(k, "amr_dr_JPa")) return s->amr.dr_JPa; if (!strcmp(k, "amr_dz_JPa")) return s->amr.dz_JPa; if (!strcmp(k, "amr_boxlen")) return s->amr.L_box;
-    G(line_type) G(DnuHK_Hz) G(fine_structure)
+    G(line_type) G(DnuHK_Hz) G(fine_structure) G(include_deuterium) G(delta_nu_HD_Hz) G(ratio_Dfreq_HD) G(ratio_voigta_HD) G(nD_over_nH) G(g_recoil0_D)
     G(use_clump_medium) G(tauhomo) G(N_gashomo) G(use_amr_grid) G(save_peeloff_2D) G(save_peeloff_3D) G(E1) G(E2) G(E3) G(nbins) G(geometry_JPa) G(calc_J) G(calc_P) G(calc_Pnew) G(nside) G(npix)
 #undef G
     return NAN;
@@ -2464,7 +2495,7 @@ void orc_rand_voigt_v(int kind, uint64_t seed, uint64_t id, int n, double a, dou
 void orc_rand_gauss_v(int kind, uint64_t seed, uint64_t id, int n, double *c) { rng_t t, *g = pick_rng(&t, kind, seed, id); for (int i = 0; i < n; i++) c[i] = rand_gauss(g); }
 
 /* do_resonance1 / do_resonance2 in cell (ic,jc,kc) (clump mode: ic = owner clump): n draws on one stream;
- * out[12*i + ..] = uz, xfreq_atom, cost, sint, S11, S22, S12, S33, S44, E1, E2, E3 */
+ * out[12*i + ..] = uz, xfreq_atom, cost, sint, S11, S22, S12, S33, S44, E1, E2, E3 (line type 7: E3 slot <- species 1 H / 2 D) */
 void orc_do_resonance_v(const orc_sim *s, int kind, uint64_t seed, uint64_t id, int n, double xfreq, int ic, int jc, int kc, double *out) {
     rng_t t, *g = pick_rng(&t, kind, seed, id);
     for (int i = 0; i < n; i++) {
@@ -2472,7 +2503,7 @@ void orc_do_resonance_v(const orc_sim *s, int kind, uint64_t seed, uint64_t id, 
         if (s->use_clump_medium) { p.icell = p.jcell = p.kcell = 1; }
         double *o = out + 12 * (size_t)i;
         do_resonance1(s, g, &p, &o[0], &o[1], &o[2], &o[3], &o[4], &o[5], &o[6], &o[7], &o[8]);
-        o[9] = p.E1; o[10] = p.E2; o[11] = p.E3;
+        o[9] = p.E1; o[10] = p.E2; o[11] = (s->line_type == 7) ? (double)p.species : p.E3;
     }
 }
 void orc_calc_voigt_v(const orc_sim *s, int n, const double *x, int ic, int jc, int kc, double *h) {

@@ -237,6 +237,9 @@ class Ref:
             L.ref_raytrace_to_edge.argtypes = [_i, _vp, _vp, _vp]
             L.ref_raytrace_to_dist.argtypes = [_vp, _vp, _d, _vp]
             L.ref_get_Jout.argtypes = [_vp]
+            if hasattr(L, "ref_set_deuterium"):
+                L.ref_set_deuterium.argtypes = [_i, _d, _vp]
+                L.ref_do_resonance_HD_v.argtypes = [_i, _d, _i, _i, _i, _vp]
             if hasattr(L, "ref_set_fine_structure"):
                 L.ref_set_fine_structure.argtypes = [_i, _vp]
                 L.ref_do_resonance2_v.argtypes = [_i, _d, _i, _i, _i, _vp]
@@ -323,6 +326,15 @@ class Ref:
     def calc_voigt(cls, x, ic, jc, kc):
         x = np.ascontiguousarray(x, dtype=np.float64); h = np.zeros_like(x)
         cls.lib().ref_calc_voigt_v(len(x), _ptr(x), ic, jc, kc, _ptr(h)); return h
+
+
+    @classmethod
+    def set_deuterium(cls, on, D_to_H=1.5e-5):
+        out = np.zeros(4); cls.lib().ref_set_deuterium(int(on), float(D_to_H), _ptr(out)); return out
+
+    @classmethod
+    def do_resonance_HD(cls, n, xfreq, ic, jc, kc):
+        out = np.zeros((n, 5)); cls.lib().ref_do_resonance_HD_v(n, float(xfreq), ic, jc, kc, _ptr(out)); return out
 
 
 class RefCalc(Ref):

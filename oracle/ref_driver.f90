@@ -73,6 +73,42 @@ contains
     enddo
   end subroutine ref_do_resonance2_v
 
+  !--- par%include_deuterium: 'ly_alpha_HD' (line type 7) or back to plain Ly-alpha; out = delta_nu_HD_Hz, ratio_Dfreq_HD, ratio_voigta_HD, g_recoil0_D
+  subroutine ref_set_deuterium(on, D_to_H, out) bind(C, name='ref_set_deuterium')
+    integer(c_int), value :: on
+    real(c_double), value :: D_to_H
+    real(c_double), intent(out) :: out(4)
+    par%fine_structure = .false.
+    par%D_to_H_ratio = D_to_H
+    if (on /= 0) then
+       par%line_id = 'ly_alpha_HD'
+    else
+       par%line_id = 'ly_alpha'
+    endif
+    call setup_resonance_line()
+    if (on /= 0) then
+       calc_voigt => calc_voigt_HD; do_resonance => do_resonance_HD
+    else
+       calc_voigt => calc_voigt1; do_resonance => do_resonance1
+    endif
+    out = [line%delta_nu_HD_Hz, line%ratio_Dfreq_HD, line%ratio_voigta_HD, line%g_recoil0_D]
+  end subroutine ref_set_deuterium
+
+  !--- do_resonance_HD (line_mod.f90:476-549): out(:,i) = uz, xatom, cost, sint, species (1 H, 2 D)
+  subroutine ref_do_resonance_HD_v(n, xfreq, ic, jc, kc, out) bind(C, name='ref_do_resonance_HD_v')
+    integer(c_int), value :: n, ic, jc, kc
+    real(c_double), value :: xfreq
+    real(c_double), intent(out) :: out(5, n)
+    type(photon_type) :: ph
+    integer :: i
+    do i = 1, n
+       ph%xfreq = xfreq
+       ph%icell = ic; ph%jcell = jc; ph%kcell = kc
+       call do_resonance_HD(ph, g, out(1,i), out(2,i), out(3,i), out(4,i))
+       out(5,i) = real(line%selected_species_HD, c_double)
+    enddo
+  end subroutine ref_do_resonance_HD_v
+
   !--- calc_voigt through the pointer (calc_voigt1 or calc_voigt2, line_mod.f90:38-62) in cell (ic,jc,kc)
   subroutine ref_calc_voigt_v(n, x, ic, jc, kc, h) bind(C, name='ref_calc_voigt_v')
     integer(c_int), value :: n, ic, jc, kc
