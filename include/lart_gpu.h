@@ -39,7 +39,8 @@ typedef struct lart_params {
     int32_t save_peeloff, save_peeloff_2D, save_peeloff_3D;
     int32_t save_direc0, save_dust_scattered;  /* extra peel-off tallies: unattenuated source (direc0), dust-scattered light (scatt_dust) */
     int32_t nxfreq;
-    int32_t line_type;             /* line%line_type: 1 single resonance line, 2 Ly-alpha doublet (par%fine_structure, line_mod.f90:1250-1253) */
+    int32_t line_type;             /* line%line_type: 1 single resonance line, 2 Ly-alpha doublet (par%fine_structure, line_mod.f90:1250-1253),
+                                    * 7 hydrogen + deuterium ('ly_alpha_HD' / par%include_deuterium, :1155-1191) */
     double  xs_point, ys_point, zs_point, source_rmax, xfreq0;
     double  xfreq_min, dxfreq, Dfreq_ref;          /* grid%xfreq_min, grid%dxfreq, grid%Dfreq_ref */
     double  xfreq_max, source_sigma_x;             /* grid%xfreq_max (continuum source); Gaussian source sigma / vtherm_total(par%temperature) */
@@ -48,6 +49,7 @@ typedef struct lart_params {
     double  mu_min, dmu;
     double  g_recoil0, E1, E2, E3;                 /* line%g_recoil0, line%E1..E3 (line_mod.f90:1255-1270) */
     double  DnuHK_Hz;                              /* line%DnuHK_Hz: 2P3/2 - 2P1/2 splitting in Hz (line type 2; 0 otherwise) */
+    double  delta_nu_HD_Hz, ratio_Dfreq_HD, ratio_voigta_HD, nD_over_nH, g_recoil0_D;   /* line type 7: the cross-species constants of line% */
     double  xcrit, xcrit2;                         /* grid%xcrit, grid%xcrit2 (core_skip_global) */
 } lart_params;
 

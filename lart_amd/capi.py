@@ -21,7 +21,7 @@ class LartParams(C.Structure):
         "save_Jin", "save_Jabs", "save_Jmu", "nmu", "save_peeloff", "save_peeloff_2D", "save_peeloff_3D", "save_direc0", "save_dust_scattered", "nxfreq", "line_type")] + \
         [(n, _d) for n in (
             "xs_point", "ys_point", "zs_point", "source_rmax", "xfreq0", "xfreq_min", "dxfreq", "Dfreq_ref", "xfreq_max", "source_sigma_x", "xrange", "yrange", "zrange", "source_zscale",
-            "DGR", "hgg", "albedo", "mu_min", "dmu", "g_recoil0", "E1", "E2", "E3", "DnuHK_Hz", "xcrit", "xcrit2")]
+            "DGR", "hgg", "albedo", "mu_min", "dmu", "g_recoil0", "E1", "E2", "E3", "DnuHK_Hz", "delta_nu_HD_Hz", "ratio_Dfreq_HD", "ratio_voigta_HD", "nD_over_nH", "g_recoil0_D", "xcrit", "xcrit2")]
 
 
 class LartTallies(C.Structure):

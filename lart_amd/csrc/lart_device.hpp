@@ -127,8 +127,9 @@ struct Lds { const double *vt; const double *xf, *yf, *zf;   // Voigt tables and
              double dip_p2, dip_qs;      // Cardano constants of the dipole phase function for par.E1 > 0 (rand_resonance): p, 1/(E1 p^3)
              double *jp_P, *jp_Pn;       // per-block LDS copies of P1 / P1_new (nullptr: deposits go to global memory)
              unsigned char *coop;        // LART_COOP_BYTES per wave: scratch of the cooperative samplers (vz_core_coop / vz_wing_coop), nullptr = off
-             int lt; double dnu_hz; };   // line type (1 single line, 2 Ly-alpha doublet) and DnuHK_Hz: set from the kernel's template
-                                         // parameter, so that `l.lt == 2` folds away in the single-line kernels
+             int lt; double dnu_hz;      // line type (1 single line, 2 Ly-alpha doublet, 7 H + D) and DnuHK_Hz / delta_nu_HD_Hz: set from the kernel's template
+             double hd_ratio, hd_ratio_a, hd_nD; };   // line type 7: ratio_Dfreq_HD, ratio_voigta_HD, nD_over_nH (line_mod.f90:1186-1191)
+                                         // (lt comes from a template parameter, so that `l.lt == 2` / `== 7` fold away in the single-line kernels)
 
 __device__ inline Lds lds_stage(double *sh, const DGrid &g) {
     for (int i = threadIdx.x; i < VT_END; i += blockDim.x) sh[i] = c_voigt_tab[i];
@@ -136,7 +137,7 @@ __device__ inline Lds lds_stage(double *sh, const DGrid &g) {
     for (int i = threadIdx.x; i < nf; i += blockDim.x) sh[VT_END + i] = g.faces[i];
     __syncthreads();
     Lds l; l.vt = sh; l.xf = sh + VT_END; l.yf = l.xf + (g.nx + 1); l.zf = l.yf + (g.ny + 1);
-    l.dip_p2 = 0.0; l.dip_qs = 0.0; l.jp_P = nullptr; l.jp_Pn = nullptr; l.coop = nullptr; l.lt = 1; l.dnu_hz = 0.0;
+    l.dip_p2 = 0.0; l.dip_qs = 0.0; l.jp_P = nullptr; l.jp_Pn = nullptr; l.coop = nullptr; l.lt = 1; l.dnu_hz = 0.0; l.hd_ratio = 1.0; l.hd_ratio_a = 1.0; l.hd_nD = 0.0;
     return l;
 }
 
@@ -358,6 +359,10 @@ __device__ inline double voigt_H(const double *vt, double vin, double a) {
 // Line type 2 = the Ly-alpha doublet: 1/3 of the strength at the 2P1/2 level, DnuHK below the 2P3/2 level.
 __device__ inline double calc_voigt(const Lds &l, double xfreq, double a, double Dfreq) {
     if (l.lt == 2) { const double dnu = l.dnu_hz / Dfreq; return voigt_H(l.vt, xfreq + dnu, a) * (1.0 / 3.0) + voigt_H(l.vt, xfreq, a) * (2.0 / 3.0); }
+    if (l.lt == 7) {                                           // calc_voigt_HD :82-106: H profile + the D line seen from the H frame
+        const double dx = l.dnu_hz / Dfreq, xD = (xfreq - dx) * l.hd_ratio;
+        return voigt_H(l.vt, xfreq, a) + l.hd_nD * l.hd_ratio * voigt_H(l.vt, xD, a * l.hd_ratio_a);
+    }
     return voigt_H(l.vt, xfreq, a);
 }
 
@@ -1366,7 +1371,7 @@ __device__ inline void peel_direct(const KArgs &A, const Lds &l, bool dust, cons
 }
 // peeling_resonance_nostokes_outside: :576-690
 template <int VAR>
-__device__ inline void peel_resonance_nostokes(const KArgs &A, const Lds &l, bool dust, const Photon &p, double xfreq_atom, double ux, double uy, double uz, double E1, double E2, unsigned &nsteps) {
+__device__ inline void peel_resonance_nostokes(const KArgs &A, const Lds &l, bool dust, const Photon &p, double xfreq_atom, double ux, double uy, double uz, double E1, double E2, double g_rec0, unsigned &nsteps) {
     const Cell &c = A.g.cell[cidx(A.g, p.ic, p.jc, p.kc)];
     for (int i = 0; i < A.nobs; i++) {
         PeelDir q = peel_dir0(A, A.obs[i], p);
@@ -1375,7 +1380,7 @@ __device__ inline void peel_resonance_nostokes(const KArgs &A, const Lds &l, boo
         double rho1 = sqrt(1.0 - p.kz * p.kz) * sint, cosp = 1.0, sinp = 0.0;
         if (rho1 != 0.0) { double rho = 1.0 / rho1; cosp = rho * (cost * p.kz - q.kz); sinp = rho * (p.kx * q.ky - q.kx * p.ky); }
         double xfreq = xfreq_atom + (ux * cosp + uy * sinp) * sint + uz * cost;
-        if (A.par.recoil) xfreq = xfreq - (A.par.g_recoil0 / c.Dfreq) * (1.0 - cost);
+        if (A.par.recoil) xfreq = xfreq - (g_rec0 / c.Dfreq) * (1.0 - cost);
         double tau = raytrace_to_edge<VAR>(A, l, dust, p, xfreq, q.kx, q.ky, q.kz, q.dist, nsteps);
         double peel = 0.75 * E1 * (cost2 + 1.0) + E2;
         double wgt = peel / (LART_FOURPI * q.r2) * d_exp_neg(-tau) * p.wgt;
@@ -1409,7 +1414,7 @@ __device__ inline StokesGeom stokes_geom(const Photon &p, const PeelDir &q) {
 }
 // peeling_resonance_stokes_outside: :303-482
 template <int VAR>
-__device__ inline void peel_resonance_stokes(const KArgs &A, const Lds &l, bool dust, const Photon &p, double xfreq_atom, double ux, double uy, double uz, double E1, double E2, double E3, unsigned &nsteps) {
+__device__ inline void peel_resonance_stokes(const KArgs &A, const Lds &l, bool dust, const Photon &p, double xfreq_atom, double ux, double uy, double uz, double E1, double E2, double E3, double g_rec0, unsigned &nsteps) {
     const Cell &c = A.g.cell[cidx(A.g, p.ic, p.jc, p.kc)];
     for (int i = 0; i < A.nobs; i++) {
         const DObs &o = A.obs[i];
@@ -1417,7 +1422,7 @@ __device__ inline void peel_resonance_stokes(const KArgs &A, const Lds &l, bool 
         if (!q.in_image) continue;
         StokesGeom s = stokes_geom(p, q);
         double xfreq = xfreq_atom + (ux * s.cosp + uy * s.sinp) * s.sint + uz * s.cost;
-        if (A.par.recoil) xfreq = xfreq - (A.par.g_recoil0 / c.Dfreq) * (1.0 - s.cost);
+        if (A.par.recoil) xfreq = xfreq - (g_rec0 / c.Dfreq) * (1.0 - s.cost);
         double tau = raytrace_to_edge<VAR>(A, l, dust, p, xfreq, q.kx, q.ky, q.kz, q.dist, nsteps);
         double wgt = 1.0 / q.r2 * d_exp_neg(-tau) * p.wgt;
         if (wgt == 0.0) continue;
@@ -1546,7 +1551,7 @@ __device__ inline bool dust_absorb(const KArgs &A, Rng &g, Photon &p, const Cell
 //   scatter_pre  -> dust-or-gas decision; a dust event completes here; a resonance event returns true with the sampler's
 //                   arguments in ScatCtx (x in the local Doppler units of the cell / clump)
 //   scatter_post -> everything after do_resonance's `uz = rand_resonance_vz(x, a)`
-struct ScatCtx { double va, xloc, cl_scale, cl_Dfreq, xsamp, dnu; };   // xsamp: the sampler's frequency (xloc, or xloc + dnu for the 2P1/2 level)
+struct ScatCtx { double va, xloc, cl_scale, cl_Dfreq, xsamp, dnu, vsamp; int species; };   // xsamp / vsamp: the sampler's frequency and Voigt parameter (2P1/2 level: xloc + dnu; deuterium, species 2: the D frame)
 template <int VAR, bool STOKES, bool DUST, bool PEEL>
 __device__ inline bool scatter_pre(const KArgs &A, const Lds &l, Rng &g, Photon &p, unsigned &npeel, ScatCtx &sc) {
     const lart_params &par = A.par;
@@ -1589,7 +1594,12 @@ __device__ inline bool scatter_pre(const KArgs &A, const Lds &l, Rng &g, Photon 
         if (ib >= 1) atomicAdd(&(l.jp_P ? l.jp_P : A.jpa.P1)[ib - 1], p.wgt / (c.rhokap * c.Dfreq / A.jpa.cross0));
     }
     sc.va = va; sc.cl_scale = cl_scale; sc.cl_Dfreq = cl_Dfreq; sc.xloc = (VAR == 4) ? p.xfreq * cl_scale : p.xfreq;
-    sc.xsamp = sc.xloc; sc.dnu = 0.0;
+    sc.xsamp = sc.xloc; sc.dnu = 0.0; sc.vsamp = va; sc.species = 1;
+    if (l.lt == 7) {                                           // do_resonance_HD (line_mod.f90:490-510): a hydrogen or a deuterium atom
+        const double dx = l.dnu_hz / cl_Dfreq, xD = (sc.xloc - dx) * l.hd_ratio;
+        const double pH = voigt_H(l.vt, sc.xloc, va), pD = l.hd_nD * l.hd_ratio * voigt_H(l.vt, xD, va * l.hd_ratio_a);
+        if (!(g.next() < pH / (pH + pD))) { sc.species = 2; sc.xsamp = xD; sc.vsamp = va * l.hd_ratio_a; }
+    }
     if (l.lt == 2) {                                           // do_resonance2 (line_mod.f90:152-163): which level scatters
         sc.dnu = l.dnu_hz / cl_Dfreq;
         double pH = voigt_H(l.vt, sc.xloc + sc.dnu, va) * (1.0 / 3.0), pK = voigt_H(l.vt, sc.xloc, va) * (2.0 / 3.0);
@@ -1599,10 +1609,13 @@ __device__ inline bool scatter_pre(const KArgs &A, const Lds &l, Rng &g, Photon 
     return true;
 }
 template <int VAR, bool STOKES, bool DUST, bool PEEL>
-__device__ inline void scatter_post(const KArgs &A, const Lds &l, Rng &g, Photon &p, unsigned &npeel, const ScatCtx &sc, double uz_loc) {
+__device__ inline void scatter_post(const KArgs &A, const Lds &l, Rng &g, Photon &p, unsigned &npeel, const ScatCtx &sc, double uz_loc_in) {
+    double uz_loc = uz_loc_in;
     const lart_params &par = A.par;
     // do_resonance1 (line_mod.f90:108-139; do_resonance1_clump: local Doppler units and back)
     double uz, xfreq_atom;
+    const bool deut = (l.lt == 7) && sc.species == 2;          // a deuterium atom scattered (line%selected_species_HD = 2)
+    if (deut) uz_loc = uz_loc / l.hd_ratio;                    // D Doppler units -> the photon's H units (line_mod.f90:507)
     if (VAR == 4) { double scale_inv = 1.0 / sc.cl_scale; xfreq_atom = (sc.xloc - uz_loc) * scale_inv; uz = uz_loc * scale_inv; }
     else { uz = uz_loc; xfreq_atom = p.xfreq - uz; }
     double S11 = 0, S22 = 0, S12 = 0, S33 = 0, S44 = 0, sinp, cosp, cost, cost2, sint;
@@ -1634,18 +1647,20 @@ __device__ inline void scatter_post(const KArgs &A, const Lds &l, Rng &g, Photon
         double u2, u3; g.next2(u2, u3); double uxy = sqrt(-d_log(u3)), s2, c2; d_sincos_2pi(u2, &s2, &c2);
         ux = uxy * c2; uy = uxy * s2;
     }
+    if (deut) { ux = ux / l.hd_ratio; uy = uy / l.hd_ratio; }  // scattering_car.f90:402-409, 417-424
     if (VAR == 4) { double vth_ratio = sc.cl_Dfreq / A.cl.Dfreq_ref; ux = ux * vth_ratio; uy = uy * vth_ratio; }   // scattering_car.f90:384-388, 715-719
     p.xfreq = xfreq_atom + uz * cost + (ux * cosp + uy * sinp) * sint;
-    if (par.recoil) p.xfreq = p.xfreq - (par.g_recoil0 / sc.cl_Dfreq) * (1.0 - cost);
+    const double g_rec0 = deut ? par.g_recoil0_D : par.g_recoil0;      // :427-437
+    if (par.recoil) p.xfreq = p.xfreq - (g_rec0 / sc.cl_Dfreq) * (1.0 - cost);
     if (STOKES) {
-        if (PEEL) peel_resonance_stokes<VAR>(A, l, DUST, p, xfreq_atom, ux, uy, uz, E1, E2, E3, npeel);
+        if (PEEL) peel_resonance_stokes<VAR>(A, l, DUST, p, xfreq_atom, ux, uy, uz, E1, E2, E3, g_rec0, npeel);
         double cos2p = 2.0 * cosp * cosp - 1.0, sin2p = 2.0 * sinp * cosp;
         double Q0 = cos2p * p.Q + sin2p * p.U, U0 = -sin2p * p.Q + cos2p * p.U;
         double I1 = S11 + S12 * Q0, Q1 = S12 + S22 * Q0, U1 = S33 * U0, V1 = S44 * p.V;
         p.Q = Q1 / I1; p.U = U1 / I1; p.V = V1 / I1;
         rotate_triad(p, cost, sint, cosp, sinp);
     } else {
-        if (PEEL) peel_resonance_nostokes<VAR>(A, l, DUST, p, xfreq_atom, ux, uy, uz, E1, E2, npeel);
+        if (PEEL) peel_resonance_nostokes<VAR>(A, l, DUST, p, xfreq_atom, ux, uy, uz, E1, E2, g_rec0, npeel);
         rotate_k(p, cost, sint, cosp, sinp);
     }
 }
@@ -1653,11 +1668,11 @@ __device__ inline void scatter_post(const KArgs &A, const Lds &l, Rng &g, Photon
 // sampler is a wave-cooperative stage, vz_core_coop).
 template <int VAR, bool STOKES, bool DUST, bool PEEL>
 __device__ inline void scatter_event(const KArgs &A, const Lds &l, Rng &g, Photon &p, unsigned &npeel, bool on) {
-    ScatCtx sc; sc.xloc = 0.0; sc.xsamp = 0.0; sc.va = 1.0;
+    ScatCtx sc; sc.xloc = 0.0; sc.xsamp = 0.0; sc.va = 1.0; sc.vsamp = 1.0; sc.species = 1;
 #if defined(LART_PROFILE) || defined(LART_NO_COOP)
     if (!on || !scatter_pre<VAR, STOKES, DUST, PEEL>(A, l, g, p, npeel, sc)) return;
     LART_PROF_MARK(p, 4);
-    double uz_loc = rand_resonance_vz(g, sc.xsamp, sc.va LART_PROF_PASS(p));
+    double uz_loc = rand_resonance_vz(g, sc.xsamp, sc.vsamp LART_PROF_PASS(p));
     LART_PROF_MARK(p, 5);
     scatter_post<VAR, STOKES, DUST, PEEL>(A, l, g, p, npeel, sc, uz_loc);
 #else
@@ -1666,14 +1681,14 @@ __device__ inline void scatter_event(const KArgs &A, const Lds &l, Rng &g, Photo
     const bool core = go && fabs(sc.xsamp) <= 1.0;
     double uz_loc;
     if (l.coop) {
-        uz_loc = vz_core_coop(g, core, sc.xsamp, sc.va, l.coop);
+        uz_loc = vz_core_coop(g, core, sc.xsamp, sc.vsamp, l.coop);
 #ifdef LART_NO_WING_COOP
-        if (go && !core) uz_loc = vz_wing(g, sc.xsamp, sc.va);
+        if (go && !core) uz_loc = vz_wing(g, sc.xsamp, sc.vsamp);
 #else
-        const double uw = vz_wing_coop(g, go && !core, sc.xsamp, sc.va, l.coop);
+        const double uw = vz_wing_coop(g, go && !core, sc.xsamp, sc.vsamp, l.coop);
         if (go && !core) uz_loc = uw;
 #endif
-    } else { uz_loc = core ? vz_core(g, sc.xsamp, sc.va) : 0.0; if (go && !core) uz_loc = vz_wing(g, sc.xsamp, sc.va); }
+    } else { uz_loc = core ? vz_core(g, sc.xsamp, sc.vsamp) : 0.0; if (go && !core) uz_loc = vz_wing(g, sc.xsamp, sc.vsamp); }
     if (go) scatter_post<VAR, STOKES, DUST, PEEL>(A, l, g, p, npeel, sc, uz_loc);
 #endif
 }

@@ -62,7 +62,8 @@ extern "C" int lart_gpu_create(lart_gpu **out, const lart_params *par, int devic
     HIPCHK(hipSetDevice(device));
     if (par->source_geometry < 0 || par->source_geometry > 5) return fail("lart_gpu_create: source_geometry must be 0..5 (point, uniform_sphere, uniform_cylinder, uniform, uniform_xy, gaussian)");
     if (par->spectral_type < 0 || par->spectral_type > 3) return fail("lart_gpu_create: spectral_type must be 0 monochromatic, 1 voigt, 2 continuum or 3 gaussian");
-    if (par->line_type != 1 && par->line_type != 2) return fail("lart_gpu_create: line_type must be 1 (single line) or 2 (Ly-alpha doublet, par%fine_structure)");
+    if (par->line_type != 1 && par->line_type != 2 && par->line_type != 7) return fail("lart_gpu_create: line_type must be 1 (single line), 2 (Ly-alpha doublet, par%fine_structure) or 7 (H + D, ly_alpha_HD)");
+    if (par->line_type == 7 && !(par->ratio_Dfreq_HD > 0.0 && par->ratio_voigta_HD > 0.0 && par->delta_nu_HD_Hz > 0.0 && par->nD_over_nH >= 0.0)) return fail("lart_gpu_create: line_type 7 needs the cross-species constants of line% (delta_nu_HD_Hz, ratio_Dfreq_HD, ratio_voigta_HD, nD_over_nH)");
     if (par->line_type == 2 && !(par->DnuHK_Hz > 0.0)) return fail("lart_gpu_create: line_type 2 needs DnuHK_Hz > 0 (line%DnuHK_Hz)");
     lart_gpu *c = new lart_gpu();
     c->device = device; c->par = *par;
@@ -616,7 +617,7 @@ __device__ void test_ray_one(const KArgs &A, const Lds &l, int kind, double *r, 
 }
 __global__ void k_test_raytrace(KArgs A, int mode, int n, double *r8, int *ic4, const double *tq, double *tau_out) {
     extern __shared__ double sh[];
-    Lds l = lds_stage(sh, A.g); l.lt = A.par.line_type; l.dnu_hz = A.par.DnuHK_Hz;       // probes: the line type at run time
+    Lds l = lds_stage(sh, A.g); l.lt = A.par.line_type; l.dnu_hz = A.par.line_type == 7 ? A.par.delta_nu_HD_Hz : A.par.DnuHK_Hz; l.hd_ratio = A.par.ratio_Dfreq_HD; l.hd_ratio_a = A.par.ratio_voigta_HD; l.hd_nD = A.par.nD_over_nH;       // probes: the line type at run time
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int kind = mode / 10, var = mode % 10;
@@ -646,7 +647,7 @@ __device__ void test_scatter_one(const KArgs &A, const Lds &l, double *st, int *
 }
 __global__ void k_test_scatter(KArgs A, int n, double *st18, int *ic4, unsigned long long seed, const unsigned long long *ids, long long *nd) {
     extern __shared__ double sh[];
-    Lds l = lds_stage(sh, A.g); l.lt = A.par.line_type; l.dnu_hz = A.par.DnuHK_Hz;       // probes: the line type at run time
+    Lds l = lds_stage(sh, A.g); l.lt = A.par.line_type; l.dnu_hz = A.par.line_type == 7 ? A.par.delta_nu_HD_Hz : A.par.DnuHK_Hz; l.hd_ratio = A.par.ratio_Dfreq_HD; l.hd_ratio_a = A.par.ratio_voigta_HD; l.hd_nD = A.par.nD_over_nH;       // probes: the line type at run time
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     bool stokes = A.par.use_stokes, dust = A.par.DGR > 0.0;

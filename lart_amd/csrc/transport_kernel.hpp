@@ -52,7 +52,7 @@ __device__ inline void fly(const KArgs &A, const Lds &l, Rng &g, Photon &p, bool
     LART_PROF_MARK(p, 3);
 }
 
-// LT: line%line_type as a compile-time constant (1 single line, 2 Ly-alpha doublet), handed to the device functions through Lds
+// LT: line%line_type as a compile-time constant (1 single line, 2 Ly-alpha doublet, 7 hydrogen + deuterium), handed to the device functions through Lds
 template <int VAR, bool STOKES, bool DUST, bool PEEL, int LT>
 __global__ __launch_bounds__(256, LART_WAVES(STOKES, PEEL)) void transport_kernel(KArgs A) {
     extern __shared__ double sh[];
@@ -64,7 +64,8 @@ __global__ __launch_bounds__(256, LART_WAVES(STOKES, PEEL)) void transport_kerne
             if (A.jpa.J1) A.jpa.J1 += shift; if (A.jpa.P1) A.jpa.P1 += shift; if (A.jpa.P1_new) A.jpa.P1_new += shift;
         }
     }
-    Lds l_ = lds_stage(sh, A.g); lds_set_dipole(l_, A.par.E1); l_.lt = LT; l_.dnu_hz = (LT == 2) ? A.par.DnuHK_Hz : 0.0;
+    Lds l_ = lds_stage(sh, A.g); lds_set_dipole(l_, A.par.E1); l_.lt = LT; l_.dnu_hz = (LT == 2) ? A.par.DnuHK_Hz : (LT == 7) ? A.par.delta_nu_HD_Hz : 0.0;
+    if (LT == 7) { l_.hd_ratio = A.par.ratio_Dfreq_HD; l_.hd_ratio_a = A.par.ratio_voigta_HD; l_.hd_nD = A.par.nD_over_nH; }
     if (A.jpa.lds_bins > 0) {                                  // per-block copies of the P1 / P1_new profile tallies
         double *jp = sh + VT_END + (A.g.nx + A.g.ny + A.g.nz + 3) + (size_t)LART_RNG_BUF * blockDim.x;
         for (int i = threadIdx.x; i < 2 * A.jpa.lds_bins; i += blockDim.x) jp[i] = 0.0;
@@ -182,4 +183,4 @@ typedef void (*transport_launch_fn)(int stokes, int dust, int peel, dim3 grid, d
     if (stokes == S && dust == D && peel == P && A.par.line_type == LT) { \
         if (shmem > 64 * 1024) (void)hipFuncSetAttribute((const void *)transport_kernel<VAR, (bool)S, (bool)D, (bool)P, LT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
         hipLaunchKernelGGL((transport_kernel<VAR, (bool)S, (bool)D, (bool)P, LT>), grid, block, shmem, st, A); return; }
-#define LART_LAUNCH_CASE(VAR, S, D, P) LART_LAUNCH_CASE1(VAR, S, D, P, 1) LART_LAUNCH_CASE1(VAR, S, D, P, 2)
+#define LART_LAUNCH_CASE(VAR, S, D, P) LART_LAUNCH_CASE1(VAR, S, D, P, 1) LART_LAUNCH_CASE1(VAR, S, D, P, 2) LART_LAUNCH_CASE1(VAR, S, D, P, 7)

@@ -29,6 +29,7 @@ module lart_gpu_c
      real(c_double) :: mu_min, dmu
      real(c_double) :: g_recoil0, E1, E2, E3
      real(c_double) :: DnuHK_Hz
+     real(c_double) :: delta_nu_HD_Hz, ratio_Dfreq_HD, ratio_voigta_HD, nD_over_nH, g_recoil0_D
      real(c_double) :: xcrit, xcrit2
   end type lart_params
 

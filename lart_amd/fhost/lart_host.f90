@@ -187,6 +187,7 @@ module lart_define
      real(wp) :: E1 = 1.0_wp, E2 = 0.0_wp, E3 = 1.0_wp
      integer  :: line_type = 1
      real(wp) :: DnuHK_Hz = 0.0_wp          ! 2P3/2 - 2P1/2 splitting, line type 2 (par%fine_structure)
+     real(wp) :: delta_nu_HD_Hz = 0.0_wp, ratio_Dfreq_HD = 1.0_wp, ratio_voigta_HD = 1.0_wp, nD_over_nH = 0.0_wp, g_recoil0_D = 0.0_wp   ! line type 7
   end type line_type
 
   type grid_type          ! define.f90:117-206 (tables are contiguous, Fortran order = what the C-ABI takes)
@@ -284,6 +285,15 @@ contains
     line%g_recoil0   = (h_planck/amu/mass_amu)/(line%wavelength0*um2m)**2
     line%E1 = 1.0_wp; line%E2 = 0.0_wp; line%E3 = 1.0_wp
     line%line_type = 1; line%DnuHK_Hz = 0.0_wp
+    if (par%include_deuterium .and. trim(par%line_id) == 'ly_alpha') par%line_id = 'ly_alpha_HD'       ! line_mod.f90:580-588
+    if (trim(par%line_id) == 'ly_alpha_HD') then                         ! :1155-1191: hydrogen + deuterium, no fine structure
+       par%fine_structure = .false.
+       line%line_type = 7; line%nD_over_nH = par%D_to_H_ratio
+       line%delta_nu_HD_Hz  = (2.99792458e5_wp*1.0e5_wp)*(1.0_wp/(0.1215337431_wp*um2m*1.0e2_wp) - 1.0_wp/(line%wavelength0*um2m*1.0e2_wp))
+       line%ratio_Dfreq_HD  = (0.1215337431_wp/line%wavelength0)*sqrt(2.01410177812_wp/mass_amu)
+       line%ratio_voigta_HD = (6.2649e8_wp/line%damping)*line%ratio_Dfreq_HD
+       line%g_recoil0_D     = (h_planck/amu/2.01410177812_wp)/(0.1215337431_wp*um2m)**2
+    endif
     if (par%fine_structure) then                                        ! line_mod.f90:1246-1253
        line%line_type = 2
        line%DnuHK_Hz  = 82259.2850014_wp*(2.99792458e5_wp*1.0e5_wp) - 82258.9191133_wp*(2.99792458e5_wp*1.0e5_wp)
@@ -296,7 +306,6 @@ contains
     if (par%Dfreq0 /= -999.0_wp) call not_supported('par%Dfreq0')
     if (par%voigt_a0 /= -999.0_wp) call not_supported('par%voigt_a0')
     if (par%HeI_coherent) call not_supported('par%HeI_coherent')
-    if (par%D_to_H_ratio /= 1.5e-5_wp) call not_supported('par%D_to_H_ratio')
     if (par%source_rscale /= 0.0_wp) call not_supported('par%source_rscale')
     if (par%sersic_m /= 1.0_wp) call not_supported('par%sersic_m')
     if (par%Reff /= 0.0_wp) call not_supported('par%Reff')
@@ -411,8 +420,7 @@ contains
     if ((par%calc_J .or. par%calc_P .or. par%calc_Pnew) .and. par%use_clump_medium) &
        call not_supported('calc_J / calc_P / calc_Pnew with par%use_clump_medium')
     if (par%use_clump_medium .and. len_trim(par%clump_input_file) > 0) call not_supported('par%clump_input_file')
-    if (par%include_deuterium) call not_supported('par%include_deuterium = .true.')
-    if (trim(par%line_id) /= 'ly_alpha') call not_supported('par%line_id /= ly_alpha')
+    if (trim(par%line_id) /= 'ly_alpha' .and. trim(par%line_id) /= 'ly_alpha_HD') call not_supported('par%line_id = '//trim(par%line_id))
     if (trim(strlowcase(par%h2_model)) /= 'none') call not_supported('par%h2_model')
     if (par%z_symmetry) call not_supported('par%z_symmetry')
     if (par%xy_symmetry) then                       ! mirrors in x and y, the full z range (grid_mod_car.f90:113-134)

@@ -272,6 +272,8 @@ contains
     p%DGR = par%DGR; p%hgg = par%hgg; p%albedo = par%albedo; p%mu_min = par%mu_min; p%dmu = par%dmu
     p%g_recoil0 = line%g_recoil0; p%E1 = line%E1; p%E2 = line%E2; p%E3 = line%E3
     p%line_type = line%line_type; p%DnuHK_Hz = line%DnuHK_Hz
+    p%delta_nu_HD_Hz = line%delta_nu_HD_Hz; p%ratio_Dfreq_HD = line%ratio_Dfreq_HD; p%ratio_voigta_HD = line%ratio_voigta_HD
+    p%nD_over_nH = line%nD_over_nH; p%g_recoil0_D = line%g_recoil0_D
     p%xcrit = grid%xcrit; p%xcrit2 = grid%xcrit2
   end subroutine fill_params
 

@@ -61,6 +61,9 @@ class Params:
     xyz_symmetry: bool = False
     xy_symmetry: bool = False
     fine_structure: bool = False
+    include_deuterium: bool = False
+    D_to_H_ratio: float = 1.5e-5
+    line_id: str = "ly_alpha"
     xy_periodic: bool = False
     geometry: str = ""
     velocity_type: str = ""
@@ -171,8 +174,7 @@ class Params:
 # fields of params_type that exist in the reference but select physics outside this path: accepted at their
 # default, rejected ("not supported") when set to something that would change the path
 _UNSUPPORTED_DEFAULTS = {
-    "include_deuterium": False,
-    "line_id": "ly_alpha", "h2_model": "none", "z_symmetry": False, "bturb": -999.0,
+    "h2_model": "none", "z_symmetry": False, "bturb": -999.0,
     "dens_file": "", "temp_file": "", "velo_file": "", "emiss_file": "", "cart_file": "", "input_field": "",
     "star_file": "", "use_cie_condition": False, "density_rscale": -999.9, "density_zscale": -999.9,
     "density_alpha": 0.0, "cone_opening": 0.0, "Omega": 0.0, "save_all_photons": False, "temperature0": -999.0,
@@ -182,7 +184,6 @@ _UNSUPPORTED_DEFAULTS = {
     "Dfreq0": -999.0,
     "voigt_a0": -999.0,
     "HeI_coherent": False,
-    "D_to_H_ratio": 1.5e-05,
     "source_rscale": 0.0,
     "sersic_m": 1.0,
     "Reff": 0.0,
@@ -341,6 +342,11 @@ class Line:
     E2: float = 0.0
     E3: float = 1.0
     line_type: int = 1
+    delta_nu_HD_Hz: float = 0.0     # line type 7 (H + D): the cross-species constants of line_mod.f90:1186-1191
+    ratio_Dfreq_HD: float = 1.0
+    ratio_voigta_HD: float = 1.0
+    nD_over_nH: float = 0.0
+    g_recoil0_D: float = 0.0
     DnuHK_Hz: float = 0.0           # 2P3/2 - 2P1/2 splitting (par%fine_structure: line type 2, line_mod.f90:1250-1253)
 
 
@@ -402,6 +408,19 @@ _SOURCE_GEOMETRIES = {"point": 0, "uniform_sphere": 1, "uniform_cylinder": 2, "u
 def read_input(par, line=None):
     """post-processing part of read_input (setup.f90:42-562) for the fields this path uses. Returns (par, line, scatt_mat)."""
     line = line or Line()
+    if par.line_id not in ("ly_alpha", "ly_alpha_HD"):
+        raise LartInputError("par%%line_id = '%s' is not supported by this path (ly_alpha, ly_alpha_HD)" % par.line_id)
+    if par.include_deuterium and par.line_id == "ly_alpha":               # line_mod.f90:580-588
+        par.line_id = "ly_alpha_HD"
+    if par.line_id == "ly_alpha_HD":                                      # :1155-1191
+        par.fine_structure = False
+        wl_D, mass_D, damping_D = 0.1215337431, 2.01410177812, 6.2649e8
+        speedc_cm = 2.99792458e5 * 1.0e5
+        line.line_type = 7; line.nD_over_nH = par.D_to_H_ratio
+        line.delta_nu_HD_Hz = speedc_cm * (1.0 / (wl_D * UM2M * 1.0e2) - 1.0 / (line.wavelength0 * UM2M * 1.0e2))
+        line.ratio_Dfreq_HD = (wl_D / line.wavelength0) * math.sqrt(mass_D / 1.00797)
+        line.ratio_voigta_HD = (damping_D / line.damping) * line.ratio_Dfreq_HD
+        line.g_recoil0_D = (H_PLANCK / 1.67262192e-24 / mass_D) / (wl_D * UM2M) ** 2
     if par.fine_structure:                                                # setup_resonance_line, line_mod.f90:1246-1253
         speedc_cm = 2.99792458e5 * 1.0e5
         line.line_type, line.DnuHK_Hz = 2, 82259.2850014 * speedc_cm - 82258.9191133 * speedc_cm
@@ -918,6 +937,8 @@ def make_lart_params(par, line, g):
     p.xfreq_min, p.dxfreq, p.Dfreq_ref = g.xfreq_min, g.dxfreq, g.Dfreq_ref
     p.g_recoil0, p.E1, p.E2, p.E3 = line.g_recoil0, line.E1, line.E2, line.E3
     p.line_type, p.DnuHK_Hz = line.line_type, line.DnuHK_Hz
+    p.delta_nu_HD_Hz, p.ratio_Dfreq_HD, p.ratio_voigta_HD, p.nD_over_nH, p.g_recoil0_D = (line.delta_nu_HD_Hz, line.ratio_Dfreq_HD, line.ratio_voigta_HD,
+                                                                                           line.nD_over_nH, line.g_recoil0_D)
     p.xcrit, p.xcrit2 = g.xcrit, g.xcrit2
     return p
 

