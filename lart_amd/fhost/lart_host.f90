@@ -186,6 +186,7 @@ module lart_define
      real(wp) :: cross0, vtherm1, g_recoil0
      real(wp) :: E1 = 1.0_wp, E2 = 0.0_wp, E3 = 1.0_wp
      integer  :: line_type = 1
+     character(len=8) :: ion_id = 'H  I'    ! label of the log lines (grid_mod_car.f90:1231-1234)
      real(wp) :: DnuHK_Hz = 0.0_wp          ! 2P3/2 - 2P1/2 splitting, line type 2 (par%fine_structure)
      real(wp) :: delta_nu_HD_Hz = 0.0_wp, ratio_Dfreq_HD = 1.0_wp, ratio_voigta_HD = 1.0_wp, nD_over_nH = 0.0_wp, g_recoil0_D = 0.0_wp   ! line type 7
   end type line_type
@@ -273,6 +274,19 @@ module lart_host
   implicit none
 contains
 
+  subroutine metal_line(typ, wl, f1, damping, mass, mass_recoil, k_hi, k_lo)
+    integer,  intent(in) :: typ
+    real(wp), intent(in) :: wl, f1, damping, mass, mass_recoil, k_hi, k_lo
+    real(wp), parameter :: sigma_0 = 0.026540083434_wp, amu = 1.67262192e-24_wp, vtherm1_amu = 0.12895319011972164_wp
+    line%line_type = typ; line%wavelength0 = wl; line%damping = damping
+    line%cross0    = sigma_0/sqrt(pi)*f1
+    line%vtherm1   = vtherm1_amu/sqrt(mass)
+    line%g_recoil0 = (h_planck/amu/mass_recoil)/(wl*um2m)**2
+    line%DnuHK_Hz  = 0.0_wp
+    if (typ == 2) line%DnuHK_Hz = (2.99792458e5_wp*1.0e5_wp)*(k_hi - k_lo)
+    par%fine_structure = .false.; par%include_deuterium = .false.
+  end subroutine metal_line
+
   !--- setup_resonance_line, Ly-alpha branch: line_mod.f90:1241-1270
   subroutine setup_resonance_line()
     real(wp), parameter :: sigma_0 = 0.026540083434_wp, amu = 1.67262192e-24_wp, vtherm1_amu = 0.12895319011972164_wp
@@ -285,10 +299,21 @@ contains
     line%g_recoil0   = (h_planck/amu/mass_amu)/(line%wavelength0*um2m)**2
     line%E1 = 1.0_wp; line%E2 = 0.0_wp; line%E3 = 1.0_wp
     line%line_type = 1; line%DnuHK_Hz = 0.0_wp
+    select case (trim(par%line_id))                                     ! single lines / S-P doublets: line_mod.f90:590-713
+    case ('CIV_1548');  line%ion_id = 'C IV'; call metal_line(2, 0.1548187_wp,    0.190_wp, 2.647e8_wp,    12.011_wp,   1.00797_wp,  64591.7_wp,     64484.0_wp)   ! (:605: recoil with line%mass_amu's default)
+    case ('NV_1239');   line%ion_id = 'N V'; call metal_line(2, 0.1238821_wp,    0.156_wp, 3.390e8_wp,    14.0067_wp,  14.0067_wp,  80721.9_wp,     80463.2_wp)
+    case ('OVI_1032');  line%ion_id = 'O VI'; call metal_line(2, 0.1031912_wp,    0.133_wp, 4.137e8_wp,    15.9994_wp,  15.9994_wp,  96907.5_wp,     96375.0_wp)
+    case ('NaI_D');     line%ion_id = 'Na I'; call metal_line(2, 0.5891583253_wp, 0.641_wp, 6.153e7_wp,    22.98977_wp, 22.98977_wp, 16973.36619_wp, 16956.17025_wp)
+    case ('CaII_HK');   line%ion_id = 'Ca II'; call metal_line(2, 0.3934777_wp,    0.682_wp, 1.446667e8_wp, 40.078_wp,   40.078_wp,   25414.40_wp,    25191.51_wp)
+    case ('MgII_2796'); line%ion_id = 'Mg II'; call metal_line(2, 0.2796352_wp,    0.608_wp, 2.590e8_wp,    24.305_wp,   24.305_wp,   35760.88_wp,    35669.31_wp)
+    case ('SiIV_1394'); line%ion_id = 'Si IV'; call metal_line(2, 0.1393755_wp,    0.513_wp, 8.743e8_wp,    28.0855_wp,  28.0855_wp,  71748.64_wp,    71287.54_wp)
+    case ('AlII_1671'); line%ion_id = 'Al II'; call metal_line(1, 0.16707874_wp,   1.77_wp,  1.41e9_wp, real(26.98154, wp), real(26.98154, wp), 0.0_wp, 0.0_wp)       ! (:706: a default-kind literal)
+    end select
+    if (line%line_type /= 1 .or. trim(par%line_id) == 'AlII_1671') return
     if (par%include_deuterium .and. trim(par%line_id) == 'ly_alpha') par%line_id = 'ly_alpha_HD'       ! line_mod.f90:580-588
     if (trim(par%line_id) == 'ly_alpha_HD') then                         ! :1155-1191: hydrogen + deuterium, no fine structure
        par%fine_structure = .false.
-       line%line_type = 7; line%nD_over_nH = par%D_to_H_ratio
+       line%line_type = 7; line%nD_over_nH = par%D_to_H_ratio; line%ion_id = 'H+D'
        line%delta_nu_HD_Hz  = (2.99792458e5_wp*1.0e5_wp)*(1.0_wp/(0.1215337431_wp*um2m*1.0e2_wp) - 1.0_wp/(line%wavelength0*um2m*1.0e2_wp))
        line%ratio_Dfreq_HD  = (0.1215337431_wp/line%wavelength0)*sqrt(2.01410177812_wp/mass_amu)
        line%ratio_voigta_HD = (6.2649e8_wp/line%damping)*line%ratio_Dfreq_HD
@@ -420,7 +445,11 @@ contains
     if ((par%calc_J .or. par%calc_P .or. par%calc_Pnew) .and. par%use_clump_medium) &
        call not_supported('calc_J / calc_P / calc_Pnew with par%use_clump_medium')
     if (par%use_clump_medium .and. len_trim(par%clump_input_file) > 0) call not_supported('par%clump_input_file')
-    if (trim(par%line_id) /= 'ly_alpha' .and. trim(par%line_id) /= 'ly_alpha_HD') call not_supported('par%line_id = '//trim(par%line_id))
+    select case (trim(par%line_id))
+    case ('ly_alpha', 'ly_alpha_HD', 'CIV_1548', 'NV_1239', 'OVI_1032', 'NaI_D', 'CaII_HK', 'MgII_2796', 'SiIV_1394', 'AlII_1671')
+    case default
+       call not_supported('par%line_id = '//trim(par%line_id))
+    end select
     if (trim(strlowcase(par%h2_model)) /= 'none') call not_supported('par%h2_model')
     if (par%z_symmetry) call not_supported('par%z_symmetry')
     if (par%xy_symmetry) then                       ! mirrors in x and y, the full z range (grid_mod_car.f90:113-134)
@@ -900,10 +929,10 @@ contains
 
     write(6,'(a,es16.3)') 'voigt_a          : ', grid%voigt_amean                                ! :1228-1237
     write(6,'(a,es16.3)') 'temperature (K)  : ', par%temperature
-    write(6,'(a,es16.3)') 'N(H  I)_pole     : ', N_gaspole
-    write(6,'(a,es16.3)') 'N(H  I)_homo     : ', N_gashomo
-    write(6,'(a,es16.3)') 'tau_pole  (H  I) : ', taupole
-    write(6,'(a,es16.3)') 'tau_homo  (H  I) : ', tauhomo
+    write(6,'(a,es16.3)') 'N('//trim(line%ion_id)//')_pole     : ', N_gaspole
+    write(6,'(a,es16.3)') 'N('//trim(line%ion_id)//')_homo     : ', N_gashomo
+    write(6,'(a,es16.3)') 'tau_pole  ('//trim(line%ion_id)//') : ', taupole
+    write(6,'(a,es16.3)') 'tau_homo  ('//trim(line%ion_id)//') : ', tauhomo
   contains
     subroutine sym_axis(n, vmax, d, vmin, i0)
       integer, intent(in) :: n

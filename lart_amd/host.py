@@ -402,14 +402,38 @@ def setup_scattering_matrix(par, path):
     return sm
 
 
+# par%line_id -> line type, wavelength0 [um], f12(1), damping, mass of vtherm1, mass of g_recoil0, the two level wavenumbers [1/cm] of
+# DnuHK_Hz (setup_resonance_line, line_mod.f90:590-713).  As in the reference, CIV_1548 recoils with line%mass_amu's default 1.00797
+# (define.f90:646, line_mod.f90:605) and AlII_1671's mass is a single precision literal (:706).
+_AL_MASS = float(np.float32(26.98154))
+_METAL_LINES = {
+    "CIV_1548":  (2, 0.1548187,    0.190, 2.647e8,    12.011,   1.00797,  64591.7,     64484.0),
+    "NV_1239":   (2, 0.1238821,    0.156, 3.390e8,    14.0067,  14.0067,  80721.9,     80463.2),
+    "OVI_1032":  (2, 0.1031912,    0.133, 4.137e8,    15.9994,  15.9994,  96907.5,     96375.0),
+    "NaI_D":     (2, 0.5891583253, 0.641, 6.153e7,    22.98977, 22.98977, 16973.36619, 16956.17025),
+    "CaII_HK":   (2, 0.3934777,    0.682, 1.446667e8, 40.078,   40.078,   25414.40,    25191.51),
+    "MgII_2796": (2, 0.2796352,    0.608, 2.590e8,    24.305,   24.305,   35760.88,    35669.31),
+    "SiIV_1394": (2, 0.1393755,    0.513, 8.743e8,    28.0855,  28.0855,  71748.64,    71287.54),
+    "AlII_1671": (1, 0.16707874,   1.77,  1.41e9,     _AL_MASS, _AL_MASS, 0.0,         0.0),
+}
+
 _SOURCE_GEOMETRIES = {"point": 0, "uniform_sphere": 1, "uniform_cylinder": 2, "uniform": 3, "uniform_xy": 4, "gaussian": 5}
 
 
 def read_input(par, line=None):
     """post-processing part of read_input (setup.f90:42-562) for the fields this path uses. Returns (par, line, scatt_mat)."""
     line = line or Line()
-    if par.line_id not in ("ly_alpha", "ly_alpha_HD"):
-        raise LartInputError("par%%line_id = '%s' is not supported by this path (ly_alpha, ly_alpha_HD)" % par.line_id)
+    if par.line_id in _METAL_LINES:                                       # single lines / S-P doublets: line_mod.f90:590-713
+        typ, wl, f1, damping, mass, mass_recoil, k_hi, k_lo = _METAL_LINES[par.line_id]
+        line.line_type, line.wavelength0, line.damping = typ, wl, damping
+        line.cross0 = 0.026540083434 / math.sqrt(PI) * f1
+        line.vtherm1 = 0.12895319011972164 / math.sqrt(mass)
+        line.g_recoil0 = (H_PLANCK / 1.67262192e-24 / mass_recoil) / (wl * UM2M) ** 2
+        line.DnuHK_Hz = (2.99792458e5 * 1.0e5) * (k_hi - k_lo) if typ == 2 else 0.0
+        line.E1, line.E2, line.E3 = 1.0, 0.0, 1.0
+        par.fine_structure = par.include_deuterium = False               # (both only act on the ly_alpha branches)
+    elif par.line_id not in ("ly_alpha", "ly_alpha_HD"):
+        raise LartInputError("par%%line_id = '%s' is not supported by this path (ly_alpha, ly_alpha_HD, %s)" % (par.line_id, ", ".join(_METAL_LINES)))
     if par.include_deuterium and par.line_id == "ly_alpha":               # line_mod.f90:580-588
         par.line_id = "ly_alpha_HD"
     if par.line_id == "ly_alpha_HD":                                      # :1155-1191

@@ -322,7 +322,7 @@ struct orc_sim {
     double atau3;
     /* --- line (line_mod.f90:1241-1270) --- */
     double cross0, vtherm1, damping, wavelength0, g_recoil0, E1, E2, E3;
-    int fine_structure, line_type; double DnuHK_Hz;
+    int fine_structure, line_type; double DnuHK_Hz; char line_id[24];      /* par%line_id: '' = ly_alpha */
     int include_deuterium; double D_to_H_ratio, nD_over_nH, delta_nu_HD_Hz, ratio_Dfreq_HD, ratio_voigta_HD, g_recoil0_D;   /* line_type 7: H + D (line_mod.f90:1155-1191) */     /* line_type 2: Ly-alpha doublet 2P1/2 (H) + 2P3/2 (K), line_mod.f90:1241-1270 */
     /* --- grid (define.f90:117-206) --- */
     int i0, j0, k0;
@@ -390,6 +390,25 @@ static void set_defaults(orc_sim *s) {
     s->gaussian_sigma_vel = 12.843374; s->gaussian_FWHM_vel = -999.0;     /* define.f90:317-318 */
 }
 
+/* the single resonance lines (type 1) and S1/2-P1/2,3/2 doublets (type 2) of setup_resonance_line, line_mod.f90:590-713:
+   wavelength0 [um], f12(1), damping, the mass of vtherm1, the mass of g_recoil0, and the two level wavenumbers [cm^-1] of DnuHK_Hz.
+   Two quirks of the reference are restated as they are: CIV_1548 takes g_recoil0 from line%mass_amu, which still holds its default
+   1.00797 (define.f90:646; line_mod.f90:605), and AlII_1671's mass is a default-kind (single precision) literal (:706). */
+typedef struct { const char *id; int type; double wl, f1, damping, mass, mass_recoil, k_hi, k_lo; } metal_line;
+static const metal_line METAL_LINES[] = {
+    {"CIV_1548",  2, 0.1548187,    0.190, 2.647e8,    12.011,   1.00797,  64591.7,     64484.0},
+    {"NV_1239",   2, 0.1238821,    0.156, 3.390e8,    14.0067,  14.0067,  80721.9,     80463.2},
+    {"OVI_1032",  2, 0.1031912,    0.133, 4.137e8,    15.9994,  15.9994,  96907.5,     96375.0},
+    {"NaI_D",     2, 0.5891583253, 0.641, 6.153e7,    22.98977, 22.98977, 16973.36619, 16956.17025},
+    {"CaII_HK",   2, 0.3934777,    0.682, 1.446667e8, 40.078,   40.078,   25414.40,    25191.51},
+    {"MgII_2796", 2, 0.2796352,    0.608, 2.590e8,    24.305,   24.305,   35760.88,    35669.31},
+    {"SiIV_1394", 2, 0.1393755,    0.513, 8.743e8,    28.0855,  28.0855,  71748.64,    71287.54},
+    {"AlII_1671", 1, 0.16707874,   1.77,  1.41e9,     (double)26.98154f, (double)26.98154f, 0.0, 0.0},
+};
+static const metal_line *find_metal_line(const char *id) {
+    for (size_t i = 0; i < sizeof METAL_LINES / sizeof METAL_LINES[0]; i++) if (!strcmp(id, METAL_LINES[i].id)) return &METAL_LINES[i];
+    return NULL; }
+
 static int set_param(orc_sim *s, const char *k, const char *v) {
 #define D(name) if (!strcmp(k, #name)) { s->name = atof(v); return 0; }
 #define I(name) if (!strcmp(k, #name)) { s->name = atoi(v); return 0; }
@@ -411,7 +430,8 @@ static int set_param(orc_sim *s, const char *k, const char *v) {
     if (!strcmp(k, "amr_file")) { snprintf(s->amr_file, sizeof s->amr_file, "%s", v); return 0; }
     if (!strcmp(k, "amr_type")) return 0;
     if (!strcmp(k, "scatt_mat_file")) { snprintf(s->scatt_mat_file, sizeof s->scatt_mat_file, "%s", v); return 0; }
-    if (!strcmp(k, "line_id")) { if (!strcmp(v, "ly_alpha")) return 0; if (!strcmp(v, "ly_alpha_HD")) { s->include_deuterium = 1; return 0; }
+    if (!strcmp(k, "line_id")) { if (!strcmp(v, "ly_alpha")) { s->line_id[0] = 0; return 0; } if (!strcmp(v, "ly_alpha_HD")) { s->include_deuterium = 1; return 0; }
+        if (find_metal_line(v)) { snprintf(s->line_id, sizeof s->line_id, "%s", v); return 0; }
         snprintf(g_err, sizeof g_err, "line_id '%s' not supported by the oracle", v); return -1; }
     if (!strcmp(k, "spectral_type")) {
         if (!strcmp(v, "voigt")) s->spectral_type = 1; else if (!strcmp(v, "monochromatic")) s->spectral_type = 0;
@@ -450,6 +470,16 @@ static int set_param(orc_sim *s, const char *k, const char *v) {
 
 /* line constants, Ly-alpha default branch: line_mod.f90:1241-1270 */
 static void setup_line(orc_sim *s) {
+    if (s->line_id[0]) {                                    /* :590-713; par%fine_structure plays no part for these ids */
+        const double sigma_0 = 0.026540083434, amu = 1.67262192e-24, vtherm1_amu = 0.12895319011972164, speedc_cm = 2.99792458e5 * 1.0e5;
+        const metal_line *m = find_metal_line(s->line_id);
+        double wl = m->wl * UM2M;
+        s->line_type = m->type; s->wavelength0 = m->wl; s->damping = m->damping; s->cross0 = sigma_0 / sqrt(PI) * m->f1;
+        s->vtherm1 = vtherm1_amu / sqrt(m->mass); s->g_recoil0 = (H_PLANCK / amu / m->mass_recoil) / (wl * wl);
+        s->DnuHK_Hz = m->type == 2 ? speedc_cm * (m->k_hi - m->k_lo) : 0.0;
+        s->E1 = 1.0; s->E2 = 0.0; s->E3 = 1.0; s->fine_structure = 0; s->include_deuterium = 0;
+        return;
+    }
     const double sigma_0 = 0.026540083434, amu = 1.67262192e-24, vtherm1_amu = 0.12895319011972164, mass_amu = 1.00797;
     s->E1 = 1.0; s->E2 = 0.0; s->E3 = 1.0; s->line_type = 1; s->DnuHK_Hz = 0.0;
     if (s->fine_structure) {                                /* :1250-1253: delE_Hz(2) = (82259.2850014 - 82258.9191133) cm^-1 * c */
@@ -475,7 +505,7 @@ static void setup_line(orc_sim *s) {
     }
 }
 void orc_line_constants(double *cross0, double *vtherm1, double *damping, double *wavelength0, double *g_recoil0) {
-    orc_sim t; setup_line(&t);
+    orc_sim t; t.line_id[0] = 0; t.fine_structure = 0; t.include_deuterium = 0; setup_line(&t);
     *cross0 = t.cross0; *vtherm1 = t.vtherm1; *damping = t.damping; *wavelength0 = t.wavelength0; *g_recoil0 = t.g_recoil0;
 }
 /* vtherm_total: define.f90:928-933 (bturb unset) */
@@ -2415,6 +2445,7 @@ double orc_get_scalar(const orc_sim *s, const char *k) {
         if (!strcmp(k, "cg_min")) return c->cg_min; if (!strcmp(k, "cg_d")) return c->cg_d; if (!strcmp(k, "cl_sphere_R")) return c->sphere_R; if (!strcmp(k, "cl_radius_max")) return c->radius_max; }
     if (!strcmp(k, "amr_ncells")) return s->amr.ncells; if (!strcmp(k, "amr_nleaf")) return s->amr.nleaf; if (!strcmp(k, "amr_levelmax")) return s->amr.levelmax;
     if (!strcmp(k, "amr_dr_JPa")) return s->amr.dr_JPa; if (!strcmp(k, "amr_dz_JPa")) return s->amr.dz_JPa; if (!strcmp(k, "amr_boxlen")) return s->amr.L_box;
+    G(wavelength0) G(damping) G(cross0) G(vtherm1) G(g_recoil0)
     G(line_type) G(DnuHK_Hz) G(fine_structure) G(include_deuterium) G(delta_nu_HD_Hz) G(ratio_Dfreq_HD) G(ratio_voigta_HD) G(nD_over_nH) G(g_recoil0_D)
     G(use_clump_medium) G(tauhomo) G(N_gashomo) G(use_amr_grid) G(save_peeloff_2D) G(save_peeloff_3D) G(E1) G(E2) G(E3) G(nbins) G(geometry_JPa) G(calc_J) G(calc_P) G(calc_Pnew) G(nside) G(npix)
 #undef G

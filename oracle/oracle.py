@@ -329,6 +329,10 @@ class Ref:
 
 
     @classmethod
+    def set_line_id(cls, name):
+        out = np.zeros(10); cls.lib().ref_set_line_id(name.encode() + b"\0", _ptr(out)); return out
+
+    @classmethod
     def set_deuterium(cls, on, D_to_H=1.5e-5):
         out = np.zeros(4); cls.lib().ref_set_deuterium(int(on), float(D_to_H), _ptr(out)); return out
 

@@ -73,6 +73,28 @@ contains
     enddo
   end subroutine ref_do_resonance2_v
 
+  !--- par%line_id = one of the single-line / doublet ids of setup_resonance_line (line_mod.f90:590-713), or 'ly_alpha' to go back;
+  !--- out = line_type, wavelength0, damping, cross0, vtherm1, g_recoil0, DnuHK_Hz, E1, E2, E3
+  subroutine ref_set_line_id(name, out) bind(C, name='ref_set_line_id')
+    character(kind=c_char), intent(in) :: name(*)
+    real(c_double), intent(out) :: out(10)
+    integer :: i
+    par%line_id = ''
+    do i = 1, len(par%line_id)
+       if (name(i) == c_null_char) exit
+       par%line_id(i:i) = name(i)
+    enddo
+    par%fine_structure = .false.
+    call setup_resonance_line()
+    if (line%line_type == 2) then
+       calc_voigt => calc_voigt2; do_resonance => do_resonance2
+    else
+       calc_voigt => calc_voigt1; do_resonance => do_resonance1
+    endif
+    out = [real(line%line_type, c_double), line%wavelength0, line%damping, line%cross0, line%vtherm1, line%g_recoil0, line%DnuHK_Hz, &
+           line%E1, line%E2, line%E3]
+  end subroutine ref_set_line_id
+
   !--- par%include_deuterium: 'ly_alpha_HD' (line type 7) or back to plain Ly-alpha; out = delta_nu_HD_Hz, ratio_Dfreq_HD, ratio_voigta_HD, g_recoil0_D
   subroutine ref_set_deuterium(on, D_to_H, out) bind(C, name='ref_set_deuterium')
     integer(c_int), value :: on

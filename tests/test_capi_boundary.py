@@ -122,3 +122,18 @@ def test_namelist_surface(built, tmp_path):
     amr.write_text("&parameters\n par%use_amr_grid = .true.\n par%amr_type = 'generic'\n par%amr_file = 'leaves.dat'\n/\n")
     par = host.read_namelist(str(amr))
     assert par.use_amr_grid and par.amr_file == "leaves.dat"
+
+
+def test_line_id_constants_of_the_python_host(golden):
+    """host.read_input's table of single lines and doublets (setup_resonance_line, line_mod.f90:590-713) against the constants the
+    reference's compiled module gives (tests/golden/line_ids.npz)"""
+    from lart_amd import host
+    z = golden("line_ids.npz")
+    for lid, ref in zip(z["ids"], z["constants"]):
+        par = host.Params(); par.line_id = str(lid); par.temperature = 1e4; par.taumax = 10.0; par.fine_structure = True
+        par, L, _ = host.read_input(par)
+        got = [L.line_type, L.wavelength0, L.damping, L.cross0, L.vtherm1, L.g_recoil0, L.DnuHK_Hz, L.E1, L.E2, L.E3]
+        assert np.allclose(got, ref, rtol=1e-14, atol=0) and not par.fine_structure, (lid, got, ref)
+    par = host.Params(); par.line_id = "SiII_1527"
+    with pytest.raises(host.LartInputError, match="not supported"):
+        host.read_input(par)

@@ -490,7 +490,7 @@ def test_whole_namelist_surface_is_readable(exe, tmp_path):
     r = run(exe, "&parameters\n par%temperature = 1e4\n par%taumax = 1e2\n par%include_deuterium = .true.\n par%fine_structure = .true.\n/\n", tmp_path,
             "--dry-run", name="hd.in")                                                    # promoted to ly_alpha_HD, the doublet switched off
     assert r.returncode == 0 and "ly_alpha_HD" in r.stdout, r.stdout
-    r = run(exe, "&parameters\n par%temperature = 1e4\n par%taumax = 1e2\n par%line_id = 'CaII_HK'\n/\n", tmp_path, "--dry-run", name="ca.in")
+    r = run(exe, "&parameters\n par%temperature = 1e4\n par%taumax = 1e2\n par%line_id = 'SiII_1527'\n/\n", tmp_path, "--dry-run", name="ca.in")
     assert r.returncode != 0 and "not supported" in r.stdout
     from lart_amd import host
     (tmp_path / "all.in").write_text(ok)
@@ -552,3 +552,21 @@ def test_reference_example_amr_sphere_reproduces_the_shipped_log(exe, tmp_path):
     assert m and abs(float(m.group(1)) / 2.8225e4 - 1) < 0.02
     O = read_h5(str(tmp_path / "sphere_amr_inside_test_obs.h5"))
     assert O["Scattered"][1].shape == (121, 768) and O["Scattered"][1].sum() > 0
+
+
+@pytest.mark.parametrize("lid", ["CIV_1548", "NV_1239", "OVI_1032", "NaI_D", "CaII_HK", "MgII_2796", "SiIV_1394", "AlII_1671"])
+def test_line_ids_set_up_like_the_python_host(exe, tmp_path, lid):
+    """par%line_id for the single lines and S-P doublets (line_mod.f90:590-713): the log of the set-up (Voigt parameter, optical depth
+    for a column density, frequency window of a continuum source: damping, cross0, vtherm1, wavelength0, DnuHK_Hz) equals the Python host's"""
+    text = ("&parameters\n par%%temperature = 2e4\n par%%N_HImax = 3e13\n par%%rmax = 1.0\n par%%nx = 11\n par%%ny = 11\n par%%nz = 11\n par%%line_id = '%s'\n"
+            " par%%spectral_type = 'continuum'\n par%%velocity_min = -1500.0\n par%%velocity_max = 500.0\n par%%nvelocity = 100\n/\n" % lid)
+    r = run(exe, text, tmp_path, "--dry-run", name="line.in")
+    assert r.returncode == 0, r.stdout + r.stderr
+    from lart_amd import host
+    par, line, _ = host.read_input(host.read_namelist(str(tmp_path / "line.in")))
+    g = host.grid_create(par, line)
+    val = lambda key: float([l for l in r.stdout.splitlines() if l.startswith(key)][0].split(":")[1].split()[0])
+    assert np.isclose(val("voigt_a"), g.voigt_amean, rtol=2e-3) and np.isclose(val("tau_pole"), par.taumax, rtol=2e-3)
+    xmin = float([l for l in r.stdout.splitlines() if l.startswith("xfreq_min")][0].split(":")[1].split()[0])
+    assert np.isclose(xmin, par.xfreq_min, rtol=1e-5)
+    assert "Line ID                   : " + lid in r.stdout

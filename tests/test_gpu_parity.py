@@ -104,7 +104,9 @@ def test_ray_marches_device_vs_reference_vectors(capi, golden, name):
                                 dict(temperature=20.0, taumax=1e3, nx=11, ny=11, nz=11, rmax=1.0, fine_structure=True, use_stokes=True, recoil=True),
                                 dict(temperature=1e4, taumax=1e3, nx=11, ny=11, nz=11, rmax=1.0, include_deuterium=True, D_to_H_ratio=1e-3),
                                 dict(temperature=1e2, taumax=1e3, nx=11, ny=11, nz=11, rmax=1.0, include_deuterium=True, D_to_H_ratio=3e-3, use_stokes=True,
-                                     recoil=True)])
+                                     recoil=True),
+                                dict(temperature=1e4, N_gasmax=1e14, nx=11, ny=11, nz=11, rmax=1.0, line_id="CIV_1548", use_stokes=True, recoil=True),
+                                dict(temperature=3e4, N_gasmax=1e14, nx=11, ny=11, nz=11, rmax=1.0, line_id="AlII_1671", recoil=True)])
 def test_scatter_event_device(capi, oracle_mod, kw):
     sim = make(kw); o = oracle_of(oracle_mod, kw)
     rng = np.random.default_rng(3)
@@ -119,6 +121,8 @@ def test_scatter_event_device(capi, oracle_mod, kw):
         m = np.array([mu * np.cos(ph), mu * np.sin(ph), -s]); nn = np.array([-np.sin(ph), np.cos(ph), 0.0])
         q, u = rng.uniform(-0.3, 0.3, 2)
         x0 = -1.2 if kw.get("fine_structure") else 0.0        # (the doublet: centre the frequencies between the two levels)
+        if kw.get("line_id") == "CIV_1548" and i % 2:           # (a wide doublet: half of the events around the H component)
+            x0 = -sim.line.DnuHK_Hz / float(g.Dfreq_ref)
         if kw.get("include_deuterium") and i % 2:             # (H + D: half of the events around the deuterium line centre)
             x0 = sim.line.delta_nu_HD_Hz / float(g.Dfreq_ref)
         st[i] = pos + list(k) + [x0 + (rng.normal(0, 2.0) if i % 3 else rng.normal(0, 0.3)), 1.0] + list(m) + list(nn) + [1.0, q, u, 0.05]
@@ -155,6 +159,9 @@ def test_scatter_event_device(capi, oracle_mod, kw):
           spectral_type="continuum", velocity_min=-200.0, velocity_max=200.0), 20000),
     (dict(temperature=1e2, taumax=1e2, xyz_symmetry=True, nx=21, ny=21, nz=21, rmax=1.0, nxfreq=121, iseed=17, line_id="ly_alpha_HD", D_to_H_ratio=0.01,
           use_stokes=True, velocity_type="hubble", Vexp=60.0), 20000),
+    (dict(temperature=1e4, N_gasmax=2e13, nx=21, ny=21, nz=21, rmax=1.0, nxfreq=160, iseed=18, line_id="MgII_2796", spectral_type="continuum",
+          velocity_min=-1200.0, velocity_max=400.0, velocity_type="hubble", Vexp=100.0, use_stokes=True), 20000),
+    (dict(temperature=5e4, N_gasmax=1e14, nx=21, ny=21, nz=21, rmax=1.0, nxfreq=121, iseed=19, line_id="SiIV_1394", recoil=True), 20000),
 ])
 def test_short_histories_photon_by_photon(capi, oracle_mod, kw, n):
     sim = make(kw); sim.ctx.enable_photon_log(True)
@@ -232,6 +239,28 @@ def test_deuterium_device_vs_reference_vectors(capi, golden):
     assert np.array_equal(ic, z["ic_out"]) and np.allclose(r, z["r_out"], rtol=1e-10, atol=1e-12)
     _, _, te = sim.ctx.test_raytrace(1, 0, z["r_in"], z["ic_in"])
     assert np.allclose(te, z["tau_edge"], rtol=1e-10, atol=1e-300)
+
+
+@pytest.mark.parametrize("tag", ["mg", "c4"])
+def test_metal_doublets_device_vs_reference_vectors(capi, golden, tag):
+    """par%line_id = MgII_2796 / CIV_1548 (type 2 with a splitting of 40-170 Doppler widths): calc_voigt2 inside the marches against
+    vectors from the reference's compiled modules; the host's line constants against setup_resonance_line's"""
+    from lart_amd import host
+    z = golden("line_ids.npz")
+    kw = dict(tok.split("=") for tok in str(z[tag + "_params"]).split())
+    par = host.Params()
+    for k, v in kw.items():
+        host.set_param(par, k, host._parse_value(v) if k not in ("geometry", "line_id") else v)
+    sim = host.Simulation(par); L = sim.line
+    ref = dict(zip(z["ids"], z["constants"]))[kw["line_id"]]
+    assert np.allclose([L.line_type, L.wavelength0, L.damping, L.cross0, L.vtherm1, L.g_recoil0, L.DnuHK_Hz], ref[:7], rtol=1e-14, atol=0)
+    g = sim.grid
+    sim.ctx.set_grid_car(g.nx, g.ny, g.nz, g.xmin, g.ymin, g.zmin, g.dx, g.dy, g.dz, g.i0, g.j0, g.k0, g.xface, g.yface, g.zface,
+                         z[tag + "_rhokap"], z[tag + "_voigt_a"], z[tag + "_Dfreq"], z[tag + "_vfx"], z[tag + "_vfy"], z[tag + "_vfz"], z[tag + "_rhokapD"])
+    r, ic, _ = sim.ctx.test_raytrace(0, 0, z[tag + "_r_in"], z[tag + "_ic_in"], z[tag + "_tau_in"])
+    assert np.array_equal(ic, z[tag + "_ic_out"]) and np.allclose(r, z[tag + "_r_out"], rtol=1e-10, atol=1e-12)
+    _, _, te = sim.ctx.test_raytrace(1, 0, z[tag + "_r_in"], z[tag + "_ic_in"])
+    assert np.allclose(te, z[tag + "_tau_edge"], rtol=1e-10, atol=1e-300)
 
 
 def test_deuterium_peel_and_clumps_whole_path(capi, oracle_mod):
