@@ -132,6 +132,32 @@ int  lart_gpu_set_clumps(lart_gpu *ctx, int64_t n, const double *x, const double
                          double sphere_R, double Dfreq_ref, double voigt_a_ref,
                          int32_t cgx, double cg_min, double cg_d, const int32_t *cg_start, const int32_t *cg_list);
 
+/* ---- resonance + fluorescence multiplets (line types 4, 5, 6 of setup_resonance_line, line_mod.f90:713-1153) ----
+ * nup <= 3 upward transitions from the ground level (f12, delE_Hz = frequency offset of the level from the first one, damping_up =
+ * sum of its A21), each with ndown <= 4 downward branches: P_down/A_down = the alias table of random_alias_setup (P_down scaled
+ * by ndown, A_down 1-based; random_mt.f90:2016-2067) for A21/damping_up, Elow_Hz = the lower level above the ground level (the
+ * fluorescence photon comes out that much redder), E1..E3 = the phase-function coefficients of that channel.  The per-line
+ * scalars (wavelength0, cross0, vtherm1, g_recoil0, damping) are what the hosts use for the grid set-up.
+ * lart_host_line_lookup fills the record for a par%line_id (0, or -1 if the id is not one of the multiplets; CPU, no device);
+ * lart_gpu_set_line_multiplet hands it to the kernels -- required before a run when lart_params.line_type is 4, 5 or 6
+ * (replaces line%b(:) read by calc_voigt3 / do_resonance4,5,6[_clump] / generate_photon, line_mod.f90:64-80, :249-474,
+ * generate_photon.f90:161-243). */
+#define LART_LINE_MAX_UP   3
+#define LART_LINE_MAX_DOWN 4
+typedef struct lart_line_multiplet {
+    int32_t line_type, nup;
+    int32_t ndown[LART_LINE_MAX_UP];
+    int32_t A_down[LART_LINE_MAX_UP][LART_LINE_MAX_DOWN];
+    char    ion_id[8];
+    double  wavelength0, cross0, vtherm1, g_recoil0, damping;
+    double  f12[LART_LINE_MAX_UP], delE_Hz[LART_LINE_MAX_UP], damping_up[LART_LINE_MAX_UP];
+    double  A21[LART_LINE_MAX_UP][LART_LINE_MAX_DOWN], Elow_Hz[LART_LINE_MAX_UP][LART_LINE_MAX_DOWN];
+    double  E1[LART_LINE_MAX_UP][LART_LINE_MAX_DOWN], E2[LART_LINE_MAX_UP][LART_LINE_MAX_DOWN], E3[LART_LINE_MAX_UP][LART_LINE_MAX_DOWN];
+    double  P_down[LART_LINE_MAX_UP][LART_LINE_MAX_DOWN];
+} lart_line_multiplet;
+int  lart_host_line_lookup(const char *line_id, lart_line_multiplet *out);
+int  lart_gpu_set_line_multiplet(lart_gpu *ctx, const lart_line_multiplet *m);
+
 /* ---- host-side set-up helpers for the clump medium (CPU, no device): the per-clump loops of init_clumps ----
  * lart_host_clumps_generate: generate_clumps, uniform path (clump_mod.f90:897-1151): n non-overlapping centres in the shell
  *   [r_min, sphere_R] by random sequential adsorption with the reference's grid and its MT19937-64 stream seeded with

@@ -414,7 +414,7 @@ def grid_create_amr(par, line, path):
     Dfreq_ref = vtherm_total(line, par.temperature) / (line.wavelength0 * UM2KM)
     voigt_amean = (line.damping / FOURPI) / Dfreq_ref
     T = np.maximum(d["T"], 10.0)
-    vt = line.vtherm1 * np.sqrt(T)
+    vt = vtherm_total(line, T)                                            # grid_mod_amr.f90:220-221
     g.Dfreq = vt / (line.wavelength0 * UM2KM)
     g.voigt_a = (line.damping / FOURPI) / g.Dfreq
     g.rhokap = d["nH"] * line.cross0 / g.Dfreq * par.distance2cm

@@ -31,7 +31,15 @@ class LartTallies(C.Structure):
         [("nphotons_done", _i64), ("nphotons_active", _i64)]
 
 
-SYMBOLS = ["lart_gpu_device_count", "lart_gpu_create", "lart_gpu_destroy", "lart_gpu_last_error",
+class LartLineMultiplet(C.Structure):
+    """lart_line_multiplet of include/lart_gpu.h (line types 4, 5, 6: line%b(:), line_mod.f90:713-1153)"""
+    _fields_ = [("line_type", _i32), ("nup", _i32), ("ndown", _i32 * 3), ("A_down", (_i32 * 4) * 3), ("ion_id", C.c_char * 8),
+                ("wavelength0", _d), ("cross0", _d), ("vtherm1", _d), ("g_recoil0", _d), ("damping", _d),
+                ("f12", _d * 3), ("delE_Hz", _d * 3), ("damping_up", _d * 3)] + \
+        [(n, (_d * 4) * 3) for n in ("A21", "Elow_Hz", "E1", "E2", "E3", "P_down")]
+
+
+SYMBOLS = ["lart_host_line_lookup", "lart_gpu_set_line_multiplet", "lart_gpu_device_count", "lart_gpu_create", "lart_gpu_destroy", "lart_gpu_last_error",
            "lart_gpu_set_grid_car", "lart_gpu_set_mueller", "lart_gpu_set_observers", "lart_gpu_set_observers_heal",
            "lart_gpu_set_JPa", "lart_gpu_set_grid_amr", "lart_gpu_set_JPa_amr", "lart_gpu_set_clumps", "lart_host_last_error", "lart_host_clumps_generate", "lart_host_clumps_csr_dims", "lart_host_clumps_build_csr", "lart_host_amr_last_error", "lart_host_amr_count", "lart_host_amr_build", "lart_gpu_run",
            "lart_gpu_begin", "lart_gpu_step", "lart_gpu_sync", "lart_gpu_kernel_time", "lart_gpu_sightline_tau", "lart_gpu_sightline_time",
@@ -90,6 +98,23 @@ def lib():
     return _lib
 
 
+def line_lookup(line_id):
+    """lart_host_line_lookup: the multiplet record of a par%line_id, or None when the id is not one of line types 4, 5, 6"""
+    m = LartLineMultiplet()
+    L = lib(); L.lart_host_line_lookup.argtypes = [C.c_char_p, _vp]
+    return m if L.lart_host_line_lookup(line_id.encode(), C.byref(m)) == 0 else None
+
+
+def pack_multiplet(m):
+    """the record as the 98 numbers tests/golden/multiplets.npz holds (oracle 'line_multiplet' / ref_get_multiplet order)"""
+    v = [m.line_type, m.nup] + list(m.ndown) + list(m.f12) + list(m.delE_Hz) + list(m.damping_up)
+    for i in range(3):
+        for d in range(4):
+            real = i < m.nup and d < m.ndown[i] and m.ndown[i] > 1
+            v += [m.A21[i][d], m.Elow_Hz[i][d], m.E1[i][d], m.E2[i][d], m.E3[i][d], m.P_down[i][d] if real else 0.0, m.A_down[i][d] if real else 0.0]
+    return np.array(v, dtype=np.float64)
+
+
 class LartError(RuntimeError):
     pass
 
@@ -131,6 +156,9 @@ class Context:
             if a is not None and a.size != n:
                 raise ValueError("table size %d != %d" % (a.size, n))
         _chk(lib().lart_gpu_set_grid_car(self.h, nx, ny, nz, xmin, ymin, zmin, dx, dy, dz, i0, j0, k0, *[_p(a) for a in arrs]))
+
+    def set_line_multiplet(self, m):
+        _chk(lib().lart_gpu_set_line_multiplet(self.h, C.byref(m)))
 
     def set_mueller(self, coss, S11, S12, S33, S34, phase_PDF, alias):
         n = len(coss)

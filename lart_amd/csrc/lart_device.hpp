@@ -92,6 +92,11 @@ struct DRep { double *base; long long off, len; int nrep; };
 
 struct DCtl { unsigned long long next_k; unsigned long long n_active; };
 
+// resonance + fluorescence multiplets (line types 4, 5, 6: lart_line_multiplet).  The per-level constants are wave-uniform and ride
+// in the kernel arguments; the per-branch tables are gathered with lane-varying (iup, idown) from global memory:
+// tab[k*12 + iup*4 + idown], k = 0 Elow_Hz, 1 E1, 2 E2, 3 E3, 4 P_down;  itab[0..2] = ndown, itab[3 + iup*4 + idown] = A_down
+struct DMulti { int nup; double delE_Hz[3], damping_up[3], f12[3]; const double *tab; const int *itab; };
+
 struct KArgs {
     lart_params par;
     DGrid g;
@@ -109,6 +114,7 @@ struct KArgs {
     unsigned long long seed;
     int max_events;
     double *log_nscatt, *log_xfreq;
+    DMulti ml;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -128,6 +134,7 @@ struct Lds { const double *vt; const double *xf, *yf, *zf;   // Voigt tables and
              double *jp_P, *jp_Pn;       // per-block LDS copies of P1 / P1_new (nullptr: deposits go to global memory)
              unsigned char *coop;        // LART_COOP_BYTES per wave: scratch of the cooperative samplers (vz_core_coop / vz_wing_coop), nullptr = off
              int lt; double dnu_hz;      // line type (1 single line, 2 Ly-alpha doublet, 7 H + D) and DnuHK_Hz / delta_nu_HD_Hz: set from the kernel's template
+             int ml_nup; double ml_dE[3], ml_damp[3], ml_f12[3]; const double *ml_tab; const int *ml_itab;   // lt 4 = the multiplets (line types 4, 5, 6): DMulti
              double hd_ratio, hd_ratio_a, hd_nD; };   // line type 7: ratio_Dfreq_HD, ratio_voigta_HD, nD_over_nH (line_mod.f90:1186-1191)
                                          // (lt comes from a template parameter, so that `l.lt == 2` / `== 7` fold away in the single-line kernels)
 
@@ -137,7 +144,8 @@ __device__ inline Lds lds_stage(double *sh, const DGrid &g) {
     for (int i = threadIdx.x; i < nf; i += blockDim.x) sh[VT_END + i] = g.faces[i];
     __syncthreads();
     Lds l; l.vt = sh; l.xf = sh + VT_END; l.yf = l.xf + (g.nx + 1); l.zf = l.yf + (g.ny + 1);
-    l.dip_p2 = 0.0; l.dip_qs = 0.0; l.jp_P = nullptr; l.jp_Pn = nullptr; l.coop = nullptr; l.lt = 1; l.dnu_hz = 0.0; l.hd_ratio = 1.0; l.hd_ratio_a = 1.0; l.hd_nD = 0.0;
+    l.dip_p2 = 0.0; l.dip_qs = 0.0; l.jp_P = nullptr; l.jp_Pn = nullptr; l.coop = nullptr; l.lt = 1; l.dnu_hz = 0.0; l.hd_ratio = 1.0; l.hd_ratio_a = 1.0; l.hd_nD = 0.0; l.ml_nup = 1; l.ml_tab = nullptr; l.ml_itab = nullptr;
+    for (int i = 0; i < 3; i++) { l.ml_dE[i] = 0.0; l.ml_damp[i] = 1.0; l.ml_f12[i] = 0.0; }
     return l;
 }
 
@@ -355,6 +363,10 @@ __device__ inline double voigt_H(const double *vt, double vin, double a) {
     double v2 = 1.0 / (v * v);
     return 0.56418958354775628695 * a * v2 * (1.0 + ((1.5 - a * a) + 3.75 * v2) * v2);
 }
+__device__ inline void lds_set_multiplet(Lds &l, const DMulti &m) {
+    l.ml_nup = m.nup; l.ml_tab = m.tab; l.ml_itab = m.itab;
+    for (int i = 0; i < 3; i++) { l.ml_dE[i] = m.delE_Hz[i]; l.ml_damp[i] = m.damping_up[i]; l.ml_f12[i] = m.f12[i]; }
+}
 // calc_voigt1 / calc_voigt2 (line_mod.f90:38-62): the profile of a cell with Voigt parameter a and Doppler width Dfreq.
 // Line type 2 = the Ly-alpha doublet: 1/3 of the strength at the 2P1/2 level, DnuHK below the 2P3/2 level.
 __device__ inline double calc_voigt(const Lds &l, double xfreq, double a, double Dfreq) {
@@ -362,6 +374,14 @@ __device__ inline double calc_voigt(const Lds &l, double xfreq, double a, double
     if (l.lt == 7) {                                           // calc_voigt_HD :82-106: H profile + the D line seen from the H frame
         const double dx = l.dnu_hz / Dfreq, xD = (xfreq - dx) * l.hd_ratio;
         return voigt_H(l.vt, xfreq, a) + l.hd_nD * l.hd_ratio * voigt_H(l.vt, xD, a * l.hd_ratio_a);
+    }
+    if (l.lt == 4) {                                           // calc_voigt3 :64-80 (types 5, 6; nup = 1 for type 4 = calc_voigt1)
+        double v = voigt_H(l.vt, xfreq, a);
+        for (int i = 1; i < l.ml_nup; i++) {
+            const double Dnu = l.ml_dE[i] / Dfreq, a_ratio = l.ml_damp[i] / l.ml_damp[0], f_ratio = l.ml_f12[i] / l.ml_f12[0];
+            v = v + voigt_H(l.vt, xfreq + Dnu, a * a_ratio) * f_ratio;
+        }
+        return v;
     }
     return voigt_H(l.vt, xfreq, a);
 }
@@ -1551,7 +1571,7 @@ __device__ inline bool dust_absorb(const KArgs &A, Rng &g, Photon &p, const Cell
 //   scatter_pre  -> dust-or-gas decision; a dust event completes here; a resonance event returns true with the sampler's
 //                   arguments in ScatCtx (x in the local Doppler units of the cell / clump)
 //   scatter_post -> everything after do_resonance's `uz = rand_resonance_vz(x, a)`
-struct ScatCtx { double va, xloc, cl_scale, cl_Dfreq, xsamp, dnu, vsamp; int species; };   // xsamp / vsamp: the sampler's frequency and Voigt parameter (2P1/2 level: xloc + dnu; deuterium, species 2: the D frame)
+struct ScatCtx { double va, xloc, cl_scale, cl_Dfreq, xsamp, dnu, vsamp; int species, iup; };   // xsamp / vsamp: the sampler's frequency and Voigt parameter (2P1/2 level: xloc + dnu; deuterium, species 2: the D frame)
 template <int VAR, bool STOKES, bool DUST, bool PEEL>
 __device__ inline bool scatter_pre(const KArgs &A, const Lds &l, Rng &g, Photon &p, unsigned &npeel, ScatCtx &sc) {
     const lart_params &par = A.par;
@@ -1594,7 +1614,21 @@ __device__ inline bool scatter_pre(const KArgs &A, const Lds &l, Rng &g, Photon 
         if (ib >= 1) atomicAdd(&(l.jp_P ? l.jp_P : A.jpa.P1)[ib - 1], p.wgt / (c.rhokap * c.Dfreq / A.jpa.cross0));
     }
     sc.va = va; sc.cl_scale = cl_scale; sc.cl_Dfreq = cl_Dfreq; sc.xloc = (VAR == 4) ? p.xfreq * cl_scale : p.xfreq;
-    sc.xsamp = sc.xloc; sc.dnu = 0.0; sc.vsamp = va; sc.species = 1;
+    sc.xsamp = sc.xloc; sc.dnu = 0.0; sc.vsamp = va; sc.species = 1; sc.iup = 0;
+    if (l.lt == 4 && l.ml_nup > 1) {                           // do_resonance5 / 6 (line_mod.f90:358-376, :421-449): which upward transition
+        const double Dx2 = l.ml_dE[1] / cl_Dfreq, va2 = va * l.ml_damp[1] / l.ml_damp[0];
+        const double p1 = voigt_H(l.vt, sc.xloc, va) * l.ml_f12[0], p2 = voigt_H(l.vt, sc.xloc + Dx2, va2) * l.ml_f12[1];
+        const double xi = g.next();
+        if (l.ml_nup == 2) {
+            if (!(xi < p1 / (p2 + p1))) { sc.iup = 1; sc.xsamp = sc.xloc + Dx2; sc.vsamp = va2; }
+        } else {
+            const double Dx3 = l.ml_dE[2] / cl_Dfreq, va3 = va * l.ml_damp[2] / l.ml_damp[0];
+            const double p3 = voigt_H(l.vt, sc.xloc + Dx3, va3) * l.ml_f12[2], ptot = p1 + p2 + p3;
+            if (xi < p1 / ptot) {}
+            else if (xi < (p1 + p2) / ptot) { sc.iup = 1; sc.xsamp = sc.xloc + Dx2; sc.vsamp = va2; }
+            else { sc.iup = 2; sc.xsamp = sc.xloc + Dx3; sc.vsamp = va3; }
+        }
+    }
     if (l.lt == 7) {                                           // do_resonance_HD (line_mod.f90:490-510): a hydrogen or a deuterium atom
         const double dx = l.dnu_hz / cl_Dfreq, xD = (sc.xloc - dx) * l.hd_ratio;
         const double pH = voigt_H(l.vt, sc.xloc, va), pD = l.hd_nD * l.hd_ratio * voigt_H(l.vt, xD, va * l.hd_ratio_a);
@@ -1620,18 +1654,30 @@ __device__ inline void scatter_post(const KArgs &A, const Lds &l, Rng &g, Photon
     else { uz = uz_loc; xfreq_atom = p.xfreq - uz; }
     double S11 = 0, S22 = 0, S12 = 0, S33 = 0, S44 = 0, sinp, cosp, cost, cost2, sint;
     double E1 = par.E1, E2 = par.E2, E3 = par.E3;              // photon%E1..E3 of this event (the peel routines read them)
+    if (l.lt == 4) {                                           // do_resonance4 / 5 / 6[_clump]: the downward channel (alias draw when the level has > 1)
+        int idown = 0; const int nd = l.ml_itab[sc.iup];
+        if (nd > 1) {
+            double u1, u2; g.next2(u1, u2);
+            const int k = (int)floor(nd * u1);                 // rand_alias_choise (random_mt.f90:2122-2135), 0-based here
+            idown = (u2 < l.ml_tab[48 + sc.iup * 4 + k]) ? k : l.ml_itab[3 + sc.iup * 4 + k] - 1;
+            const double del_xfreq = l.ml_tab[sc.iup * 4 + idown] / sc.cl_Dfreq;
+            if (VAR == 4) { const double scale_inv = 1.0 / sc.cl_scale; xfreq_atom = (sc.xloc - uz_loc - del_xfreq) * scale_inv; }
+            else xfreq_atom = xfreq_atom - del_xfreq;
+        }
+        E1 = l.ml_tab[12 + sc.iup * 4 + idown]; E2 = l.ml_tab[24 + sc.iup * 4 + idown]; E3 = l.ml_tab[36 + sc.iup * 4 + idown];
+    }
     if (l.lt == 2) {                                           // do_resonance2 :166-171: E1 of the atom-frame frequency
         const double qK = (VAR == 4) ? sc.xloc - uz_loc : xfreq_atom, qH = qK + sc.dnu;
         E1 = (2.0 * qK * qH + qH * qH) / (qK * qK + 2.0 * qH * qH); E2 = 1.0 - E1; E3 = (E1 + 2.0) / 3.0;
     }
     if (STOKES) {
-        cost = (l.lt == 2) ? rand_resonance_u(g.next(), E1) : dipole_cost(l, g.next(), E1); cost2 = cost * cost; sint = sqrt(1.0 - cost2);
+        cost = (l.lt == 2 || l.lt == 4) ? rand_resonance_u(g.next(), E1) : dipole_cost(l, g.next(), E1); cost2 = cost * cost; sint = sqrt(1.0 - cost2);
         S22 = 0.75 * E1 * (cost2 + 1.0); S11 = S22 + E2; S12 = 0.75 * E1 * (cost2 - 1.0); S33 = 1.5 * E1 * cost;
         S44 = (l.lt == 2) ? (E1 + 2.0) / 2.0 * cost : 1.5 * E3 * cost;
         phi_rejection(g, p, S12 / S11, sinp, cosp);
     } else {
         double ud, up; g.next2(ud, up);                       // polar angle, then azimuth: the reference's order of draws
-        cost = (l.lt == 2) ? rand_resonance_u(ud, E1) : dipole_cost(l, ud, E1); cost2 = cost * cost; sint = sqrt(1.0 - cost2);
+        cost = (l.lt == 2 || l.lt == 4) ? rand_resonance_u(ud, E1) : dipole_cost(l, ud, E1); cost2 = cost * cost; sint = sqrt(1.0 - cost2);
         d_sincos_2pi(up, &sinp, &cosp);
     }
     // perpendicular atom velocity; truncated tail when core-skipping (:726-752, :400-430)
@@ -1668,7 +1714,7 @@ __device__ inline void scatter_post(const KArgs &A, const Lds &l, Rng &g, Photon
 // sampler is a wave-cooperative stage, vz_core_coop).
 template <int VAR, bool STOKES, bool DUST, bool PEEL>
 __device__ inline void scatter_event(const KArgs &A, const Lds &l, Rng &g, Photon &p, unsigned &npeel, bool on) {
-    ScatCtx sc; sc.xloc = 0.0; sc.xsamp = 0.0; sc.va = 1.0; sc.vsamp = 1.0; sc.species = 1;
+    ScatCtx sc; sc.xloc = 0.0; sc.xsamp = 0.0; sc.va = 1.0; sc.vsamp = 1.0; sc.species = 1; sc.iup = 0;
 #if defined(LART_PROFILE) || defined(LART_NO_COOP)
     if (!on || !scatter_pre<VAR, STOKES, DUST, PEEL>(A, l, g, p, npeel, sc)) return;
     LART_PROF_MARK(p, 4);
@@ -1736,7 +1782,23 @@ __device__ inline void generate_photon(const KArgs &A, const Lds &l, Rng &g, Pho
     p.nsg = 0.0; p.nsd = 0.0; p.inside = true; p.xfreq = par.xfreq0;
     // a source outside the medium box never reaches a table in the reference's configs; clamp the gather
     const Cell &c = (VAR == 3 || VAR == 4) ? gr.cell[p.ic - 1] : gr.cell[cidx(gr, clampi(p.ic, 1, gr.nx), clampi(p.jc, 1, gr.ny), clampi(p.kc, 1, gr.nz))];
-    if (l.lt == 2) { const double dnu = l.dnu_hz / c.Dfreq; if (g.next() <= 1.0 / 3.0) p.xfreq = p.xfreq - dnu; }   // the source feeds both levels (generate_photon.f90:161-167)
+    if (l.lt == 2 && par.spectral_type != 2) { const double dnu = l.dnu_hz / c.Dfreq; if (g.next() <= 1.0 / 3.0) p.xfreq = p.xfreq - dnu; }   // the source feeds both levels (generate_photon.f90:160-167; not for a continuum)
+    if (l.lt == 4 && par.spectral_type != 2) {                 // :168-243: the source feeds the levels by f12 and every downward channel by its branching ratio
+        int iup = 0;
+        if (l.ml_nup > 1) {
+            const double p1 = l.ml_f12[0], p2 = l.ml_f12[1], xi = g.next();
+            if (l.ml_nup == 2) { if (!(xi < p1 / (p2 + p1))) iup = 1; }
+            else { const double ptot = p1 + p2 + l.ml_f12[2]; if (xi < p1 / ptot) {} else if (xi < (p1 + p2) / ptot) iup = 1; else iup = 2; }
+            if (iup > 0) p.xfreq = p.xfreq - l.ml_dE[iup] / c.Dfreq;
+        }
+        const int nd = l.ml_itab[iup];
+        if (nd > 1) {
+            double u1, u2; g.next2(u1, u2);
+            const int k = (int)floor(nd * u1);
+            const int idown = (u2 < l.ml_tab[48 + iup * 4 + k]) ? k : l.ml_itab[3 + iup * 4 + k] - 1;
+            p.xfreq = p.xfreq - l.ml_tab[iup * 4 + idown] / c.Dfreq;
+        }
+    }
     if (par.spectral_type == 1) p.xfreq = p.xfreq + rand_voigt(g, c.voigt_a);
     else if (par.spectral_type == 2) {                         // continuum: flat over the frequency axis, in units of the local cell (:244-247)
         p.xfreq = g.next() * (par.xfreq_max - par.xfreq_min) + par.xfreq_min;

@@ -28,6 +28,8 @@ struct lart_gpu {
     DGrid g{}; Cell *d_cell = nullptr; double *d_faces = nullptr; size_t ncell = 0; bool has_dust_table = false;
     // Mueller
     DMueller mu{}; double *d_mu = nullptr; int *d_alias = nullptr;
+    // resonance + fluorescence multiplet (line types 4, 5, 6)
+    DMulti ml{}; double *d_ml_tab = nullptr; int *d_ml_itab = nullptr; bool has_ml = false;
     // observers
     DObs *d_obs = nullptr; int nobs = 0, nxim = 0, nyim = 0; double dxim = 0, dyim = 0; int heal_nside = 0;
     std::vector<DObs> h_obs; std::vector<double> h_faces;    // host copies for the sight-line ray set-up
@@ -62,7 +64,8 @@ extern "C" int lart_gpu_create(lart_gpu **out, const lart_params *par, int devic
     HIPCHK(hipSetDevice(device));
     if (par->source_geometry < 0 || par->source_geometry > 5) return fail("lart_gpu_create: source_geometry must be 0..5 (point, uniform_sphere, uniform_cylinder, uniform, uniform_xy, gaussian)");
     if (par->spectral_type < 0 || par->spectral_type > 3) return fail("lart_gpu_create: spectral_type must be 0 monochromatic, 1 voigt, 2 continuum or 3 gaussian");
-    if (par->line_type != 1 && par->line_type != 2 && par->line_type != 7) return fail("lart_gpu_create: line_type must be 1 (single line), 2 (Ly-alpha doublet, par%fine_structure) or 7 (H + D, ly_alpha_HD)");
+    if (par->line_type != 1 && par->line_type != 2 && par->line_type != 7 && !(par->line_type >= 4 && par->line_type <= 6))
+        return fail("lart_gpu_create: line_type must be 1 (single line), 2 (S-P doublet, par%fine_structure), 4 / 5 / 6 (resonance + fluorescence multiplets, with lart_gpu_set_line_multiplet) or 7 (H + D, ly_alpha_HD)");
     if (par->line_type == 7 && !(par->ratio_Dfreq_HD > 0.0 && par->ratio_voigta_HD > 0.0 && par->delta_nu_HD_Hz > 0.0 && par->nD_over_nH >= 0.0)) return fail("lart_gpu_create: line_type 7 needs the cross-species constants of line% (delta_nu_HD_Hz, ratio_Dfreq_HD, ratio_voigta_HD, nD_over_nH)");
     if (par->line_type == 2 && !(par->DnuHK_Hz > 0.0)) return fail("lart_gpu_create: line_type 2 needs DnuHK_Hz > 0 (line%DnuHK_Hz)");
     lart_gpu *c = new lart_gpu();
@@ -84,7 +87,7 @@ extern "C" int lart_gpu_destroy(lart_gpu *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (auto &e : c->ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-    (void)hipFree(c->d_cell); (void)hipFree(c->d_faces); (void)hipFree(c->d_mu); (void)hipFree(c->d_alias); (void)hipFree(c->d_obs); (void)hipFree(c->d_ind_bin); (void)hipFree(c->d_amr_int); (void)hipFree(c->d_amr_geom); (void)hipFree(c->d_cl_geo); (void)hipFree(c->d_cl_phys); (void)hipFree(c->d_cl_int);
+    (void)hipFree(c->d_cell); (void)hipFree(c->d_faces); (void)hipFree(c->d_mu); (void)hipFree(c->d_alias); (void)hipFree(c->d_ml_tab); (void)hipFree(c->d_ml_itab); (void)hipFree(c->d_obs); (void)hipFree(c->d_ind_bin); (void)hipFree(c->d_amr_int); (void)hipFree(c->d_amr_geom); (void)hipFree(c->d_cl_geo); (void)hipFree(c->d_cl_phys); (void)hipFree(c->d_cl_int);
     free_tally(c); (void)hipFree(c->d_pool); (void)hipFree(c->d_ctl); (void)hipFree(c->d_log);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -161,6 +164,32 @@ extern "C" int lart_gpu_set_grid_car(lart_gpu *c, int32_t nx, int32_t ny, int32_
     c->g.xmin = xmin; c->g.ymin = ymin; c->g.zmin = zmin; c->g.dx = dx; c->g.dy = dy; c->g.dz = dz;
     c->g.cell = c->d_cell; c->g.faces = c->d_faces; c->ncell = nc; c->has_dust_table = rhokapD != nullptr;
     c->is_amr = false; c->is_clump = false; c->jpa.nbins = 0; free_tally(c);
+    return 0;
+}
+
+extern "C" int lart_gpu_set_line_multiplet(lart_gpu *c, const lart_line_multiplet *m) {
+    if (!c || !m) return fail("set_line_multiplet: null argument");
+    if (m->line_type != c->par.line_type || m->line_type < 4 || m->line_type > 6) return fail("set_line_multiplet: line_type must be 4, 5 or 6 and equal lart_params.line_type");
+    if (m->nup < 1 || m->nup > LART_LINE_MAX_UP || (m->line_type == 4 && m->nup != 1) || (m->line_type == 5 && m->nup != 2) || (m->line_type == 6 && m->nup != 3))
+        return fail("set_line_multiplet: nup must be 1 (type 4), 2 (type 5) or 3 (type 6)");
+    double tab[60] = {0}; int itab[15] = {0};
+    for (int i = 0; i < m->nup; i++) {
+        const int nd = m->ndown[i];
+        if (nd < 1 || nd > LART_LINE_MAX_DOWN || !(m->f12[i] > 0.0) || !(m->damping_up[i] > 0.0)) return fail("set_line_multiplet: bad level record (ndown 1..4, f12 > 0, damping_up > 0)");
+        itab[i] = nd;
+        for (int d = 0; d < nd; d++) {
+            if (nd > 1 && (m->A_down[i][d] < 0 || m->A_down[i][d] > nd || !(m->P_down[i][d] >= 0.0))) return fail("set_line_multiplet: bad alias table (A_down 0..ndown, 1-based; P_down >= 0)");
+            itab[3 + i * 4 + d] = m->A_down[i][d] > 0 ? m->A_down[i][d] : d + 1;
+            tab[i * 4 + d] = m->Elow_Hz[i][d]; tab[12 + i * 4 + d] = m->E1[i][d]; tab[24 + i * 4 + d] = m->E2[i][d]; tab[36 + i * 4 + d] = m->E3[i][d];
+            tab[48 + i * 4 + d] = m->P_down[i][d];
+        }
+    }
+    HIPCHK(hipSetDevice(c->device));
+    if (!c->d_ml_tab) { HIPCHK(hipMalloc(&c->d_ml_tab, sizeof tab)); HIPCHK(hipMalloc(&c->d_ml_itab, sizeof itab)); }
+    HIPCHK(hipMemcpy(c->d_ml_tab, tab, sizeof tab, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(c->d_ml_itab, itab, sizeof itab, hipMemcpyHostToDevice));
+    c->ml = DMulti{}; c->ml.nup = m->nup; c->ml.tab = c->d_ml_tab; c->ml.itab = c->d_ml_itab;
+    for (int i = 0; i < 3; i++) { c->ml.delE_Hz[i] = i < m->nup ? m->delE_Hz[i] : 0.0; c->ml.damping_up[i] = i < m->nup ? m->damping_up[i] : 1.0; c->ml.f12[i] = i < m->nup ? m->f12[i] : 0.0; }
+    c->has_ml = true;
     return 0;
 }
 
@@ -414,6 +443,7 @@ extern "C" int lart_gpu_begin(lart_gpu *c, int64_t first_id, int64_t stride, int
     if (c->heal_nside > 0 && (c->par.use_stokes || c->par.xyz_symmetry || c->par.xy_periodic)) return fail("begin: HEALPix observers need the plain grid without Stokes");
     if (c->par.save_peeloff && c->par.xyz_symmetry) return fail("begin: peel-off is not allowed with xyz_symmetry (setup.f90:198-206)");
     if (c->par.DGR > 0.0 && !c->has_dust_table) return fail("begin: DGR > 0 but the grid has no rhokapD");
+    if (c->par.line_type >= 4 && c->par.line_type <= 6 && !c->has_ml) return fail("begin: line_type 4/5/6 needs lart_gpu_set_line_multiplet first");
     if (c->is_clump && c->heal_nside > 0) return fail("begin: HEALPix inside observers are not supported with the clump medium (setup.f90:177)");
     if (c->is_amr && c->heal_nside > 0 && c->par.xyz_symmetry) return fail("begin: inside observers need the full octree");
     if (c->par.xy_symmetry && (c->par.xyz_symmetry || c->par.xy_periodic || c->is_amr || c->is_clump)) return fail("begin: xy_symmetry is a variant of the plain Cartesian grid only");
@@ -449,7 +479,7 @@ extern "C" int lart_gpu_step(lart_gpu *c, int32_t nsteps, int32_t max_events) {
     HIPCHK(hipSetDevice(c->device));
     KArgs A{};
     A.par = c->par; A.g = c->g; A.t = c->t; A.pool = c->pool; A.mu = c->mu; A.obs = c->d_obs; A.nobs = c->par.save_peeloff ? c->nobs : 0;
-    A.nxim = c->nxim; A.nyim = c->nyim; A.dxim = c->dxim; A.dyim = c->dyim; A.ctl = c->d_ctl; A.heal_nside = c->heal_nside; A.jpa = c->jpa; A.amr = c->amr; A.cl = c->cl; A.rep = c->rep;
+    A.nxim = c->nxim; A.nyim = c->nyim; A.dxim = c->dxim; A.dyim = c->dyim; A.ctl = c->d_ctl; A.heal_nside = c->heal_nside; A.jpa = c->jpa; A.amr = c->amr; A.cl = c->cl; A.rep = c->rep; A.ml = c->ml;
     A.first_id = c->first_id; A.stride = c->stride; A.count = c->count; A.seed = c->seed; A.max_events = max_events;
     A.log_nscatt = c->d_log; A.log_xfreq = c->d_log ? c->d_log + c->nlog : nullptr;
     int var = march_variant(c);
@@ -618,6 +648,7 @@ __device__ void test_ray_one(const KArgs &A, const Lds &l, int kind, double *r, 
 __global__ void k_test_raytrace(KArgs A, int mode, int n, double *r8, int *ic4, const double *tq, double *tau_out) {
     extern __shared__ double sh[];
     Lds l = lds_stage(sh, A.g); l.lt = A.par.line_type; l.dnu_hz = A.par.line_type == 7 ? A.par.delta_nu_HD_Hz : A.par.DnuHK_Hz; l.hd_ratio = A.par.ratio_Dfreq_HD; l.hd_ratio_a = A.par.ratio_voigta_HD; l.hd_nD = A.par.nD_over_nH;       // probes: the line type at run time
+    if (A.par.line_type >= 4 && A.par.line_type <= 6) { l.lt = 4; lds_set_multiplet(l, A.ml); }
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int kind = mode / 10, var = mode % 10;
@@ -648,6 +679,7 @@ __device__ void test_scatter_one(const KArgs &A, const Lds &l, double *st, int *
 __global__ void k_test_scatter(KArgs A, int n, double *st18, int *ic4, unsigned long long seed, const unsigned long long *ids, long long *nd) {
     extern __shared__ double sh[];
     Lds l = lds_stage(sh, A.g); l.lt = A.par.line_type; l.dnu_hz = A.par.line_type == 7 ? A.par.delta_nu_HD_Hz : A.par.DnuHK_Hz; l.hd_ratio = A.par.ratio_Dfreq_HD; l.hd_ratio_a = A.par.ratio_voigta_HD; l.hd_nD = A.par.nD_over_nH;       // probes: the line type at run time
+    if (A.par.line_type >= 4 && A.par.line_type <= 6) { l.lt = 4; lds_set_multiplet(l, A.ml); }
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     bool stokes = A.par.use_stokes, dust = A.par.DGR > 0.0;
@@ -671,7 +703,7 @@ template <typename T> struct DevBuf {
     ~DevBuf() { if (p) (void)hipFree(p); }
 };
 static KArgs probe_args(lart_gpu *c) {
-    KArgs A{}; A.par = c->par; A.g = c->g; A.t = c->t; A.mu = c->mu; A.obs = c->d_obs; A.nobs = 0; A.nxim = c->nxim; A.nyim = c->nyim; A.dxim = c->dxim; A.dyim = c->dyim; A.ctl = c->d_ctl; A.heal_nside = c->heal_nside; A.jpa = c->jpa; A.amr = c->amr; A.cl = c->cl;
+    KArgs A{}; A.par = c->par; A.g = c->g; A.t = c->t; A.mu = c->mu; A.obs = c->d_obs; A.nobs = 0; A.nxim = c->nxim; A.nyim = c->nyim; A.dxim = c->dxim; A.dyim = c->dyim; A.ctl = c->d_ctl; A.heal_nside = c->heal_nside; A.jpa = c->jpa; A.amr = c->amr; A.cl = c->cl; A.ml = c->ml;
     return A;
 }
 static size_t probe_shmem(lart_gpu *c) { return (size_t)(VT_END + c->g.nx + c->g.ny + c->g.nz + 3) * sizeof(double); }
@@ -712,6 +744,7 @@ extern "C" int lart_gpu_test_raytrace(lart_gpu *c, int32_t mode, int32_t n, doub
     }
     DevBuf<double> dr, dt, dq; DevBuf<int> di;
     if (dr.alloc((size_t)8 * n, r8) || di.alloc((size_t)4 * n, ic4) || dt.alloc(n, nullptr) || dq.alloc(n, tq)) return fail("test_raytrace: hipMalloc failed");
+    if (c->par.line_type >= 4 && c->par.line_type <= 6 && !c->has_ml) return fail("line_type 4/5/6 needs lart_gpu_set_line_multiplet first");
     KArgs A = probe_args(c);
     hipLaunchKernelGGL(k_test_raytrace, dim3((n + 63) / 64), dim3(64), probe_shmem(c), c->stream, A, mode, n, dr.p, di.p, tq ? dq.p : nullptr, dt.p);
     HIPCHK(hipGetLastError()); HIPCHK(hipStreamSynchronize(c->stream));
@@ -738,6 +771,7 @@ extern "C" int lart_gpu_test_scatter(lart_gpu *c, int32_t n, double *st18, int32
     if (c->par.use_stokes && c->par.DGR > 0.0 && c->mu.nPDF == 0) return fail("test_scatter: Stokes dust scattering needs a Mueller table");
     DevBuf<double> ds; DevBuf<int> di; DevBuf<unsigned long long> dd; DevBuf<long long> dn;
     if (ds.alloc((size_t)18 * n, st18) || di.alloc((size_t)4 * n, ic4) || dd.alloc(n, (const unsigned long long *)ids) || dn.alloc(n, nullptr)) return fail("test_scatter: hipMalloc failed");
+    if (c->par.line_type >= 4 && c->par.line_type <= 6 && !c->has_ml) return fail("line_type 4/5/6 needs lart_gpu_set_line_multiplet first");
     KArgs A = probe_args(c);
     hipLaunchKernelGGL(k_test_scatter, dim3((n + 63) / 64), dim3(64), probe_shmem(c), c->stream, A, n, ds.p, di.p, (unsigned long long)seed, dd.p, dn.p);
     HIPCHK(hipGetLastError()); HIPCHK(hipStreamSynchronize(c->stream));
@@ -773,6 +807,7 @@ extern "C" int lart_gpu_sightline_tau(lart_gpu *c, double cross0, double *tau_ga
     HIPCHK(hipMemsetAsync(dt.p, 0, nray * nxf * sizeof(double), c->stream));
     HIPCHK(hipMemsetAsync(dn.p, 0, nray * sizeof(double), c->stream));
     HIPCHK(hipMemsetAsync(dd.p, 0, nray * sizeof(double), c->stream));
+    if (c->par.line_type >= 4 && c->par.line_type <= 6 && !c->has_ml) return fail("line_type 4/5/6 needs lart_gpu_set_line_multiplet first");
     KArgs A = probe_args(c);
     hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipEventRecord(e0, c->stream));

@@ -238,6 +238,7 @@ __global__ __launch_bounds__(256) void k_sightline(const KArgs A, const SightRay
                                                    double *__restrict__ tau_gas, double *__restrict__ N_gas, double *__restrict__ tau_dust) {
     extern __shared__ double sh[];
     Lds l_ = lds_stage(sh, A.g); l_.lt = A.par.line_type; l_.dnu_hz = A.par.line_type == 7 ? A.par.delta_nu_HD_Hz : A.par.DnuHK_Hz; l_.hd_ratio = A.par.ratio_Dfreq_HD; l_.hd_ratio_a = A.par.ratio_voigta_HD; l_.hd_nD = A.par.nD_over_nH;
+    if (A.par.line_type >= 4 && A.par.line_type <= 6) { l_.lt = 4; lds_set_multiplet(l_, A.ml); }
     const Lds l = l_;
     const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (wave >= (long long)nray * nchunk) return;

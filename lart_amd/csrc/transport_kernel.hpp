@@ -65,6 +65,7 @@ __global__ __launch_bounds__(256, LART_WAVES(STOKES, PEEL)) void transport_kerne
         }
     }
     Lds l_ = lds_stage(sh, A.g); lds_set_dipole(l_, A.par.E1); l_.lt = LT; l_.dnu_hz = (LT == 2) ? A.par.DnuHK_Hz : (LT == 7) ? A.par.delta_nu_HD_Hz : 0.0;
+    if (LT == 4) lds_set_multiplet(l_, A.ml);
     if (LT == 7) { l_.hd_ratio = A.par.ratio_Dfreq_HD; l_.hd_ratio_a = A.par.ratio_voigta_HD; l_.hd_nD = A.par.nD_over_nH; }
     if (A.jpa.lds_bins > 0) {                                  // per-block copies of the P1 / P1_new profile tallies
         double *jp = sh + VT_END + (A.g.nx + A.g.ny + A.g.nz + 3) + (size_t)LART_RNG_BUF * blockDim.x;
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(256, LART_WAVES(STOKES, PEEL)) void transport_kerne
 typedef void (*transport_launch_fn)(int stokes, int dust, int peel, dim3 grid, dim3 block, size_t shmem, hipStream_t st, const KArgs &A);
 
 #define LART_LAUNCH_CASE1(VAR, S, D, P, LT) \
-    if (stokes == S && dust == D && peel == P && A.par.line_type == LT) { \
+    if (stokes == S && dust == D && peel == P && (A.par.line_type == LT || (LT == 4 && (A.par.line_type == 5 || A.par.line_type == 6)))) { \
         if (shmem > 64 * 1024) (void)hipFuncSetAttribute((const void *)transport_kernel<VAR, (bool)S, (bool)D, (bool)P, LT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
         hipLaunchKernelGGL((transport_kernel<VAR, (bool)S, (bool)D, (bool)P, LT>), grid, block, shmem, st, A); return; }
-#define LART_LAUNCH_CASE(VAR, S, D, P) LART_LAUNCH_CASE1(VAR, S, D, P, 1) LART_LAUNCH_CASE1(VAR, S, D, P, 2) LART_LAUNCH_CASE1(VAR, S, D, P, 7)
+#define LART_LAUNCH_CASE(VAR, S, D, P) LART_LAUNCH_CASE1(VAR, S, D, P, 1) LART_LAUNCH_CASE1(VAR, S, D, P, 2) LART_LAUNCH_CASE1(VAR, S, D, P, 4) LART_LAUNCH_CASE1(VAR, S, D, P, 7)

@@ -34,6 +34,17 @@ module lart_gpu_c
   end type lart_params
 
   !--- struct lart_tallies: host pointers (c_null_ptr = skip) + scalars
+  !--- lart_line_multiplet of include/lart_gpu.h (line types 4, 5, 6: line%b(:) of the reference); C [3][4] arrays = Fortran (4,3)
+  type, bind(C) :: lart_line_multiplet
+     integer(c_int32_t) :: line_type, nup
+     integer(c_int32_t) :: ndown(3)
+     integer(c_int32_t) :: A_down(4,3)
+     character(kind=c_char) :: ion_id(8)
+     real(c_double) :: wavelength0, cross0, vtherm1, g_recoil0, damping
+     real(c_double) :: f12(3), delE_Hz(3), damping_up(3)
+     real(c_double) :: A21(4,3), Elow_Hz(4,3), E1(4,3), E2(4,3), E3(4,3), P_down(4,3)
+  end type lart_line_multiplet
+
   type, bind(C) :: lart_tallies
      type(c_ptr) :: Jout, Jin, Jabs, Jmu
      type(c_ptr) :: scatt, direc, I, Q, U, V
@@ -66,6 +77,12 @@ module lart_gpu_c
        real(c_double), intent(in) :: xface(*), yface(*), zface(*), rhokap(*), voigt_a(*), Dfreq(*), vfx(*), vfy(*), vfz(*)
        type(c_ptr), value :: rhokapD          ! c_loc(array) or c_null_ptr when DGR = 0
        integer(c_int) :: rc
+     end function
+     function lart_host_line_lookup(line_id, m) bind(C, name='lart_host_line_lookup') result(rc)
+       import; character(kind=c_char), intent(in) :: line_id(*); type(lart_line_multiplet), intent(out) :: m; integer(c_int) :: rc
+     end function
+     function lart_gpu_set_line_multiplet(ctx, m) bind(C, name='lart_gpu_set_line_multiplet') result(rc)
+       import; type(c_ptr), value :: ctx; type(lart_line_multiplet), intent(in) :: m; integer(c_int) :: rc
      end function
      function lart_gpu_set_mueller(ctx, nPDF, coss, S11, S12, S33, S34, phase_PDF, alias) bind(C, name='lart_gpu_set_mueller') result(rc)
        import; type(c_ptr), value :: ctx; integer(c_int32_t), value :: nPDF

@@ -8,6 +8,7 @@
 !------------------------------------------------------------------------------
 module lart_define
   use, intrinsic :: iso_fortran_env, only: real64, int32, int64
+  use lart_gpu_c, only: lart_line_multiplet
   use, intrinsic :: ieee_arithmetic
   implicit none
   public
@@ -186,6 +187,7 @@ module lart_define
      real(wp) :: cross0, vtherm1, g_recoil0
      real(wp) :: E1 = 1.0_wp, E2 = 0.0_wp, E3 = 1.0_wp
      integer  :: line_type = 1
+     type(lart_line_multiplet) :: ml        ! line types 4, 5, 6: the record of lart_host_line_lookup (line%b(:) of the reference)
      character(len=8) :: ion_id = 'H  I'    ! label of the log lines (grid_mod_car.f90:1231-1234)
      real(wp) :: DnuHK_Hz = 0.0_wp          ! 2P3/2 - 2P1/2 splitting, line type 2 (par%fine_structure)
      real(wp) :: delta_nu_HD_Hz = 0.0_wp, ratio_Dfreq_HD = 1.0_wp, ratio_voigta_HD = 1.0_wp, nD_over_nH = 0.0_wp, g_recoil0_D = 0.0_wp   ! line type 7
@@ -248,10 +250,11 @@ contains
     r = ieee_is_finite(x)
   end function is_finite
 
-  elemental function vtherm_total(T) result(vt)       ! define.f90:928-933 (par%bturb unset)
+  elemental function vtherm_total(T) result(vt)       ! define.f90:928-933
     real(wp), intent(in) :: T
     real(wp) :: vt
     vt = line%vtherm1 * sqrt(T)
+    if (par%bturb > 0.0_wp) vt = sqrt(vt*vt + par%bturb*par%bturb)
   end function vtherm_total
 
   function strlowcase(s) result(t)
@@ -291,6 +294,7 @@ contains
   subroutine setup_resonance_line()
     real(wp), parameter :: sigma_0 = 0.026540083434_wp, amu = 1.67262192e-24_wp, vtherm1_amu = 0.12895319011972164_wp
     real(wp) :: mass_amu
+    integer :: i
     line%wavelength0 = 0.1215668237310_wp
     line%damping     = 6.2649e8_wp
     line%cross0      = sigma_0/sqrt(pi)*(0.27760_wp + 0.13881_wp + 0.0_wp)
@@ -299,6 +303,17 @@ contains
     line%g_recoil0   = (h_planck/amu/mass_amu)/(line%wavelength0*um2m)**2
     line%E1 = 1.0_wp; line%E2 = 0.0_wp; line%E3 = 1.0_wp
     line%line_type = 1; line%DnuHK_Hz = 0.0_wp
+    if (lart_host_line_lookup(trim(par%line_id)//c_null_char, line%ml) == 0) then     ! resonance + fluorescence multiplets: line_mod.f90:713-1153
+       line%line_type = line%ml%line_type; line%wavelength0 = line%ml%wavelength0; line%damping = line%ml%damping; line%cross0 = line%ml%cross0
+       line%vtherm1 = line%ml%vtherm1; line%g_recoil0 = line%ml%g_recoil0; line%DnuHK_Hz = 0.0_wp
+       line%ion_id = ''
+       do i = 1, 8
+          if (line%ml%ion_id(i) == c_null_char) exit
+          line%ion_id(i:i) = line%ml%ion_id(i)
+       enddo
+       par%fine_structure = .false.; par%include_deuterium = .false.
+       return
+    endif
     select case (trim(par%line_id))                                     ! single lines / S-P doublets: line_mod.f90:590-713
     case ('CIV_1548');  line%ion_id = 'C IV'; call metal_line(2, 0.1548187_wp,    0.190_wp, 2.647e8_wp,    12.011_wp,   1.00797_wp,  64591.7_wp,     64484.0_wp)   ! (:605: recoil with line%mass_amu's default)
     case ('NV_1239');   line%ion_id = 'N V'; call metal_line(2, 0.1238821_wp,    0.156_wp, 3.390e8_wp,    14.0067_wp,  14.0067_wp,  80721.9_wp,     80463.2_wp)
@@ -341,9 +356,6 @@ contains
     if (par%density_zscale /= -999.9_wp) call not_supported('par%density_zscale')
     if (par%density_alpha /= 0.0_wp) call not_supported('par%density_alpha')
     if (par%cone_opening /= 0.0_wp) call not_supported('par%cone_opening')
-    if (is_finite(par%wavelength_min)) call not_supported('par%wavelength_min')
-    if (is_finite(par%wavelength_max)) call not_supported('par%wavelength_max')
-    if (par%nwavelength /= 0) call not_supported('par%nwavelength')
     if (par%q /= 1.0_wp) call not_supported('par%q')
     if (par%Omega /= 0.0_wp) call not_supported('par%Omega')
     if (.not. par%continuum_normalize) call not_supported('par%continuum_normalize')
@@ -446,6 +458,8 @@ contains
        call not_supported('calc_J / calc_P / calc_Pnew with par%use_clump_medium')
     if (par%use_clump_medium .and. len_trim(par%clump_input_file) > 0) call not_supported('par%clump_input_file')
     select case (trim(par%line_id))
+    case ('CII_1334', 'SiII_1527', 'SiII_1260', 'SiII_1193', 'SiII_1190', 'SiII_1304', 'FeII_2250', 'FeII_2261', 'FeII_UV3', 'FeII_2344', 'FeII_UV1', 'FeII_2600', &
+          'FeII_UV2', 'FeII_2383', 'HeI_10833')
     case ('ly_alpha', 'ly_alpha_HD', 'CIV_1548', 'NV_1239', 'OVI_1032', 'NaI_D', 'CaII_HK', 'MgII_2796', 'SiIV_1394', 'AlII_1671')
     case default
        call not_supported('par%line_id = '//trim(par%line_id))
@@ -459,7 +473,6 @@ contains
           call not_supported('par%xy_symmetry with a source off the z axis (sources are folded for xyz_symmetry only)')
        if (par%calc_J .or. par%calc_P .or. par%calc_Pnew) call not_supported('par%geometry_JPa = 2 (cylindrical profiles, the xy_symmetry default)')
     endif
-    if (par%bturb > 0.0_wp) call not_supported('par%bturb')
     if (len_trim(par%dens_file) + len_trim(par%temp_file) + len_trim(par%velo_file) + len_trim(par%emiss_file) + &
         len_trim(par%cart_file) + len_trim(par%input_field) + len_trim(par%star_file) > 0) call not_supported('an input field file')
     if (par%save_all_photons) call not_supported('par%save_all_photons')
@@ -493,7 +506,7 @@ contains
     call setup_resonance_line()
     par%nscatt_dust = 0.0_wp; par%nscatt_gas = 0.0_wp; par%nscatt_tot = 0.0_wp
 
-    if (par%temperature <= 0.0_wp) then
+    if (par%temperature <= 0.0_wp .and. par%bturb <= 0.0_wp) then
        write(*,'(a)') 'ERROR: par%temperature must be > 0 K (or set par%bturb > 0)'; stop 1
     endif
     if (par%nx == 1 .or. par%ny == 1 .or. par%nz == 1) par%xyz_symmetry = .false.            ! setup.f90:167
@@ -1253,7 +1266,7 @@ contains
     if (par%DGR > 0.0_wp) allocate(amr_rhokapD(n))
     par%distance_unit = ''; par%distance2cm = merge(par%distance2cm, 1.0_wp, par%distance2cm > 0.0_wp)
     do il = 1, n
-       vt = line%vtherm1*sqrt(max(Tl(il), 10.0_wp))
+       vt = vtherm_total(max(Tl(il), 10.0_wp))
        amr_Dfreq(il)   = vt/(line%wavelength0*um2km)
        amr_voigt_a(il) = (line%damping/fourpi)/amr_Dfreq(il)
        amr_rhokap(il)  = nH(il)*line%cross0/amr_Dfreq(il)*par%distance2cm
@@ -1540,7 +1553,12 @@ contains
     atau3 = (grid%voigt_amean*par%tauhomo)**(1.0_wp/3.0_wp)
     par%atau3 = atau3
     vtherm = vtherm_total(par%temperature)
-    if (is_finite(par%velocity_min) .and. is_finite(par%velocity_max)) then
+    if (is_finite(par%wavelength_min) .and. is_finite(par%wavelength_max)) then                   ! grid_mod_car.f90:1457-1461
+       if (par%nwavelength == 0 .and. par%nxfreq > 0) par%nwavelength = par%nxfreq
+       if (par%nwavelength > 0) par%nxfreq = par%nwavelength
+       par%xfreq_min = -(par%wavelength_max - line%wavelength0*1e4)/(line%wavelength0*1e4)*(2.99792458e5_wp/vtherm)
+       par%xfreq_max = -(par%wavelength_min - line%wavelength0*1e4)/(line%wavelength0*1e4)*(2.99792458e5_wp/vtherm)
+    else if (is_finite(par%velocity_min) .and. is_finite(par%velocity_max)) then
        if (par%nvelocity == 0 .and. par%nxfreq > 0) par%nvelocity = par%nxfreq
        if (par%nvelocity > 0) par%nxfreq = par%nvelocity
        par%xfreq_min = -par%velocity_max/vtherm

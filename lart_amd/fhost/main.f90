@@ -96,6 +96,7 @@ program LaRT_amd
   endif
   if (car_nbins > 0) call lart_check(lart_gpu_set_JPa(ctx, merge(1, 0, par%calc_J), merge(1, 0, par%calc_P), merge(1, 0, par%calc_Pnew), &
        car_nbins, car_ind_bin, line%cross0), 'lart_gpu_set_JPa')
+  if (line%line_type >= 4 .and. line%line_type <= 6) call lart_check(lart_gpu_set_line_multiplet(ctx, line%ml), 'lart_gpu_set_line_multiplet')
   if (scatt_mat%nPDF > 0) call lart_check(lart_gpu_set_mueller(ctx, scatt_mat%nPDF, scatt_mat%coss, scatt_mat%S11, scatt_mat%S12, &
        scatt_mat%S33, scatt_mat%S34, scatt_mat%phase_PDF, scatt_mat%alias), 'lart_gpu_set_mueller')
   if (par%nobs > 0 .and. par%save_peeloff) then

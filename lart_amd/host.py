@@ -85,6 +85,10 @@ class Params:
     xfreq_max: float = NAN
     nxfreq: int = 121
     velocity_min: float = NAN
+    bturb: float = -999.0           # turbulent b parameter [km/s], in quadrature with the thermal width (define.f90:928-933)
+    wavelength_min: float = NAN     # angstrom; takes precedence over the velocity window (grid_mod_car.f90:1457-1461)
+    wavelength_max: float = NAN
+    nwavelength: int = 0
     velocity_max: float = NAN
     nvelocity: int = 0
     source_geometry: str = "point"
@@ -174,7 +178,7 @@ class Params:
 # fields of params_type that exist in the reference but select physics outside this path: accepted at their
 # default, rejected ("not supported") when set to something that would change the path
 _UNSUPPORTED_DEFAULTS = {
-    "h2_model": "none", "z_symmetry": False, "bturb": -999.0,
+    "h2_model": "none", "z_symmetry": False,
     "dens_file": "", "temp_file": "", "velo_file": "", "emiss_file": "", "cart_file": "", "input_field": "",
     "star_file": "", "use_cie_condition": False, "density_rscale": -999.9, "density_zscale": -999.9,
     "density_alpha": 0.0, "cone_opening": 0.0, "Omega": 0.0, "save_all_photons": False, "temperature0": -999.0,
@@ -190,9 +194,6 @@ _UNSUPPORTED_DEFAULTS = {
     "xmin": float("nan"),
     "ymin": float("nan"),
     "zmin": float("nan"),
-    "wavelength_min": float("nan"),
-    "wavelength_max": float("nan"),
-    "nwavelength": 0,
     "q": 1.0,
     "continuum_normalize": True,
     "EW_line": 0.0,
@@ -347,12 +348,17 @@ class Line:
     ratio_voigta_HD: float = 1.0
     nD_over_nH: float = 0.0
     g_recoil0_D: float = 0.0
+    bturb: float = -999.0           # par%bturb (km/s)
+    multiplet: object = None        # capi.LartLineMultiplet for line types 4, 5, 6 (line%b(:))
     DnuHK_Hz: float = 0.0           # 2P3/2 - 2P1/2 splitting (par%fine_structure: line type 2, line_mod.f90:1250-1253)
 
 
 def vtherm_total(line, T):
-    """define.f90:928-933 with par%bturb unset"""
-    return line.vtherm1 * math.sqrt(T)
+    """define.f90:928-933: thermal width and par%bturb (line.bturb, set by read_input) in quadrature; T may be an array"""
+    vt = line.vtherm1 * np.sqrt(T)
+    if line.bturb > 0.0:
+        vt = np.sqrt(vt * vt + line.bturb * line.bturb)
+    return vt if isinstance(vt, np.ndarray) else float(vt)
 
 
 @dataclass
@@ -423,7 +429,13 @@ _SOURCE_GEOMETRIES = {"point": 0, "uniform_sphere": 1, "uniform_cylinder": 2, "u
 def read_input(par, line=None):
     """post-processing part of read_input (setup.f90:42-562) for the fields this path uses. Returns (par, line, scatt_mat)."""
     line = line or Line()
-    if par.line_id in _METAL_LINES:                                       # single lines / S-P doublets: line_mod.f90:590-713
+    ml = capi.line_lookup(par.line_id) if par.line_id not in ("ly_alpha", "ly_alpha_HD") and par.line_id not in _METAL_LINES else None
+    if ml is not None:                                                    # resonance + fluorescence multiplets, types 4-6: line_mod.f90:713-1153
+        line.line_type, line.wavelength0, line.damping, line.cross0 = ml.line_type, ml.wavelength0, ml.damping, ml.cross0
+        line.vtherm1, line.g_recoil0, line.DnuHK_Hz, line.multiplet = ml.vtherm1, ml.g_recoil0, 0.0, ml
+        line.E1, line.E2, line.E3 = 1.0, 0.0, 1.0
+        par.fine_structure = par.include_deuterium = False
+    elif par.line_id in _METAL_LINES:                                     # single lines / S-P doublets: line_mod.f90:590-713
         typ, wl, f1, damping, mass, mass_recoil, k_hi, k_lo = _METAL_LINES[par.line_id]
         line.line_type, line.wavelength0, line.damping = typ, wl, damping
         line.cross0 = 0.026540083434 / math.sqrt(PI) * f1
@@ -433,7 +445,7 @@ def read_input(par, line=None):
         line.E1, line.E2, line.E3 = 1.0, 0.0, 1.0
         par.fine_structure = par.include_deuterium = False               # (both only act on the ly_alpha branches)
     elif par.line_id not in ("ly_alpha", "ly_alpha_HD"):
-        raise LartInputError("par%%line_id = '%s' is not supported by this path (ly_alpha, ly_alpha_HD, %s)" % (par.line_id, ", ".join(_METAL_LINES)))
+        raise LartInputError("par%%line_id = '%s' is not supported by this path (ly_alpha, ly_alpha_HD, %s)" % (par.line_id, ", ".join(_METAL_LINES) + " and the multiplets of lart_host_line_lookup"))
     if par.include_deuterium and par.line_id == "ly_alpha":               # line_mod.f90:580-588
         par.line_id = "ly_alpha_HD"
     if par.line_id == "ly_alpha_HD":                                      # :1155-1191
@@ -471,7 +483,8 @@ def read_input(par, line=None):
         raise LartInputError("par%%velocity_type = '%s' is not supported by this path" % par.velocity_type)
     if par.spectral_type == "continuum":
         par.comoving_source = False                                       # setup.f90:115
-    if par.temperature <= 0.0:
+    line.bturb = par.bturb
+    if par.temperature <= 0.0 and par.bturb <= 0.0:
         raise LartInputError("ERROR: par%temperature must be > 0 K (or set par%bturb > 0)")
     if par.nx == 1 or par.ny == 1 or par.nz == 1:
         par.xyz_symmetry = False                                          # setup.f90:167
@@ -809,7 +822,15 @@ def car_setup_freq_grid(par, line, g):
     """grid_mod_car.f90:1442-1548"""
     par.atau3 = (g.voigt_amean * par.tauhomo) ** (1.0 / 3.0)
     vth = vtherm_total(line, par.temperature)
-    if math.isfinite(par.velocity_min) and math.isfinite(par.velocity_max):
+    if math.isfinite(par.wavelength_min) and math.isfinite(par.wavelength_max):
+        if par.nwavelength == 0 and par.nxfreq > 0:
+            par.nwavelength = par.nxfreq
+        if par.nwavelength > 0:
+            par.nxfreq = par.nwavelength
+        speedc = 2.99792458e5
+        par.xfreq_min = -(par.wavelength_max - line.wavelength0 * 1e4) / (line.wavelength0 * 1e4) * (speedc / vth)
+        par.xfreq_max = -(par.wavelength_min - line.wavelength0 * 1e4) / (line.wavelength0 * 1e4) * (speedc / vth)
+    elif math.isfinite(par.velocity_min) and math.isfinite(par.velocity_max):
         if par.nvelocity == 0 and par.nxfreq > 0:
             par.nvelocity = par.nxfreq
         if par.nvelocity > 0:
@@ -991,6 +1012,8 @@ class Simulation:
         self.obs = observer_create(self.par)
         self.cpar = make_lart_params(self.par, self.line, self.grid)
         self.ctx = capi.Context(self.cpar, device)
+        if self.line.multiplet is not None:
+            self.ctx.set_line_multiplet(self.line.multiplet)
         g = self.grid
         if self.clumps is not None:
             c = self.clumps

@@ -299,6 +299,8 @@ struct orc_sim {
     int use_amr_grid; char amr_file[512]; amr_t amr;
     int use_clump_medium, clump_fully_inside; clumps_t cl;
     double clump_radius, clump_N_clumps, clump_f_vol, clump_f_cov, clump_tau0, clump_NHI, clump_nH, clump_temperature, clump_sigma_v;
+    double bturb;                            /* par%bturb [km/s], <= 0: none */
+    double wavelength_min, wavelength_max;   /* angstrom: the spectral window, takes precedence over velocity_min/max (grid_mod_car.f90:1457-1461) */
     double Vrot, rinner, velocity_min, velocity_max, Vpeak, rpeak, DeltaV, velocity_alpha;
     /* --- par% (define.f90:209-544) --- */
     double no_photons; int iseed;
@@ -322,6 +324,8 @@ struct orc_sim {
     double atau3;
     /* --- line (line_mod.f90:1241-1270) --- */
     double cross0, vtherm1, damping, wavelength0, g_recoil0, E1, E2, E3;
+    /* line types 4, 5, 6 (resonance + fluorescence multiplets, line%b(:) of define.f90:639-680; set by setup_resonance_line, line_mod.f90:713-1153) */
+    struct { int nup, ndown[3], A_down[3][4]; double f12[3], delE_Hz[3], damping_up[3], A21[3][4], Elow_Hz[3][4], E1[3][4], E2[3][4], E3[3][4], P_down[3][4]; } ml;
     int fine_structure, line_type; double DnuHK_Hz; char line_id[24];      /* par%line_id: '' = ly_alpha */
     int include_deuterium; double D_to_H_ratio, nD_over_nH, delta_nu_HD_Hz, ratio_Dfreq_HD, ratio_voigta_HD, g_recoil0_D;   /* line_type 7: H + D (line_mod.f90:1155-1191) */     /* line_type 2: Ly-alpha doublet 2P1/2 (H) + 2P3/2 (K), line_mod.f90:1241-1270 */
     /* --- grid (define.f90:117-206) --- */
@@ -358,7 +362,13 @@ static inline double calc_voigt(const orc_sim *s, double xfreq, double a, double
     if (s->line_type == 7) {                                /* calc_voigt_HD :82-106: H profile + the D line seen from the H frame */
         double dx_HD = s->delta_nu_HD_Hz / Dfreq, xfreq_D = (xfreq - dx_HD) * s->ratio_Dfreq_HD;
         return orc_voigt(xfreq, a) + s->nD_over_nH * s->ratio_Dfreq_HD * orc_voigt(xfreq_D, a * s->ratio_voigta_HD); }
-    return orc_voigt(xfreq, a);
+    if (s->line_type == 5 || s->line_type == 6) {           /* calc_voigt3 :64-80 (octree_mod.f90:329-347, clump_mod.f90:151-158 alike) */
+        double v = orc_voigt(xfreq, a);
+        for (int i = 2; i <= s->ml.nup; i++) {
+            double Dnu = s->ml.delE_Hz[i-1] / Dfreq, a_ratio = s->ml.damping_up[i-1] / s->ml.damping_up[0], f_ratio = s->ml.f12[i-1] / s->ml.f12[0];
+            v = v + orc_voigt(xfreq + Dnu, a * a_ratio) * f_ratio; }
+        return v; }
+    return orc_voigt(xfreq, a);                             /* types 1, 4: calc_voigt1 */
 }
 #define IDX(s,i,j,k) ((size_t)((i)-1) + (size_t)(s)->nx * ((size_t)((j)-1) + (size_t)(s)->ny * (size_t)((k)-1)))
 
@@ -385,7 +395,7 @@ static void set_defaults(orc_sim *s) {
     for (int i = 0; i < MAX_OBS; i++) s->alpha[i] = s->beta[i] = s->gamma[i] = s->obsx[i] = s->obsy[i] = s->obsz[i] = NAN;
     s->geometry = 0; s->geometry_JPa = 2147483647;
     s->clump_radius = s->clump_N_clumps = s->clump_f_vol = s->clump_f_cov = s->clump_tau0 = s->clump_NHI = s->clump_nH = s->clump_temperature = -1.0;
-    s->clump_fully_inside = 1; s->velocity_min = NAN; s->velocity_max = NAN; s->velocity_alpha = 1.0;
+    s->clump_fully_inside = 1; s->velocity_min = NAN; s->velocity_max = NAN; s->wavelength_min = NAN; s->wavelength_max = NAN; s->velocity_alpha = 1.0;
     s->D_to_H_ratio = 1.5e-5;
     s->gaussian_sigma_vel = 12.843374; s->gaussian_FWHM_vel = -999.0;     /* define.f90:317-318 */
 }
@@ -405,6 +415,15 @@ static const metal_line METAL_LINES[] = {
     {"SiIV_1394", 2, 0.1393755,    0.513, 8.743e8,    28.0855,  28.0855,  71748.64,    71287.54},
     {"AlII_1671", 1, 0.16707874,   1.77,  1.41e9,     (double)26.98154f, (double)26.98154f, 0.0, 0.0},
 };
+typedef struct { const char *id, *id2, *ion; int type; double wl, mass; int nup; double f12[3], level_cm[3]; int ndown[3];
+                 double A21[3][4], Elow_cm[3][4], E1[3][4], E2[3][4], E3[3][4]; } multiplet_row;
+static const multiplet_row MULTIPLETS[] = {
+#include "line_table.inc"
+};
+static const multiplet_row *find_multiplet(const char *id) {
+    for (size_t i = 0; i < sizeof MULTIPLETS / sizeof MULTIPLETS[0]; i++)
+        if (!strcmp(id, MULTIPLETS[i].id) || (MULTIPLETS[i].id2[0] && !strcmp(id, MULTIPLETS[i].id2))) return &MULTIPLETS[i];
+    return NULL; }
 static const metal_line *find_metal_line(const char *id) {
     for (size_t i = 0; i < sizeof METAL_LINES / sizeof METAL_LINES[0]; i++) if (!strcmp(id, METAL_LINES[i].id)) return &METAL_LINES[i];
     return NULL; }
@@ -425,13 +444,13 @@ static int set_param(orc_sim *s, const char *k, const char *v) {
     if (!strcmp(k, "N_HIhomo") || !strcmp(k, "N_gashomo")) { s->N_gashomo = atof(v); return 0; }
     if (!strcmp(k, "tau0")) { s->taumax = atof(v); return 0; }
     B(use_clump_medium) B(clump_fully_inside) D(clump_radius) D(clump_N_clumps) D(clump_f_vol) D(clump_f_cov) D(clump_tau0) D(clump_NHI) D(clump_nH)
-    D(clump_temperature) D(clump_sigma_v) D(Vrot) D(rinner) D(velocity_min) D(velocity_max) D(Vpeak) D(rpeak) D(DeltaV) D(velocity_alpha) D(gaussian_sigma_vel) D(gaussian_FWHM_vel) D(source_zscale) D(D_to_H_ratio)
+    D(clump_temperature) D(clump_sigma_v) D(Vrot) D(rinner) D(velocity_min) D(velocity_max) D(Vpeak) D(rpeak) D(DeltaV) D(velocity_alpha) D(gaussian_sigma_vel) D(gaussian_FWHM_vel) D(source_zscale) D(D_to_H_ratio) D(wavelength_min) D(wavelength_max) D(bturb)
     if (!strcmp(k, "use_amr_grid")) { s->use_amr_grid = parse_bool(v); return 0; }
     if (!strcmp(k, "amr_file")) { snprintf(s->amr_file, sizeof s->amr_file, "%s", v); return 0; }
     if (!strcmp(k, "amr_type")) return 0;
     if (!strcmp(k, "scatt_mat_file")) { snprintf(s->scatt_mat_file, sizeof s->scatt_mat_file, "%s", v); return 0; }
     if (!strcmp(k, "line_id")) { if (!strcmp(v, "ly_alpha")) { s->line_id[0] = 0; return 0; } if (!strcmp(v, "ly_alpha_HD")) { s->include_deuterium = 1; return 0; }
-        if (find_metal_line(v)) { snprintf(s->line_id, sizeof s->line_id, "%s", v); return 0; }
+        if (find_metal_line(v) || find_multiplet(v)) { snprintf(s->line_id, sizeof s->line_id, "%s", v); return 0; }
         snprintf(g_err, sizeof g_err, "line_id '%s' not supported by the oracle", v); return -1; }
     if (!strcmp(k, "spectral_type")) {
         if (!strcmp(v, "voigt")) s->spectral_type = 1; else if (!strcmp(v, "monochromatic")) s->spectral_type = 0;
@@ -469,7 +488,30 @@ static int set_param(orc_sim *s, const char *k, const char *v) {
 }
 
 /* line constants, Ly-alpha default branch: line_mod.f90:1241-1270 */
+static void alias_setup(int n, double *probs, int *alias);
 static void setup_line(orc_sim *s) {
+    const multiplet_row *mr = s->line_id[0] ? find_multiplet(s->line_id) : NULL;
+    if (mr) {                                               /* line types 4, 5, 6: line_mod.f90:713-1153 */
+        const double sigma_0 = 0.026540083434, amu = 1.67262192e-24, vtherm1_amu = 0.12895319011972164, speedc_cm = 2.99792458e5 * 1.0e5;
+        double wl = mr->wl * UM2M;
+        memset(&s->ml, 0, sizeof s->ml);
+        s->line_type = mr->type; s->wavelength0 = mr->wl; s->cross0 = sigma_0 / sqrt(PI) * mr->f12[0];
+        s->vtherm1 = vtherm1_amu / sqrt(mr->mass); s->g_recoil0 = (H_PLANCK / amu / mr->mass) / (wl * wl);
+        s->ml.nup = mr->nup;
+        for (int i = 0; i < mr->nup; i++) {
+            s->ml.f12[i] = mr->f12[i]; s->ml.ndown[i] = mr->ndown[i];
+            s->ml.delE_Hz[i] = mr->nup > 1 ? mr->level_cm[0] * speedc_cm - mr->level_cm[i] * speedc_cm : 0.0;       /* e.g. :833-834 */
+            double sum = 0.0;
+            for (int d = 0; d < mr->ndown[i]; d++) { s->ml.A21[i][d] = mr->A21[i][d]; sum += mr->A21[i][d]; s->ml.Elow_Hz[i][d] = mr->Elow_cm[i][d] * speedc_cm;
+                s->ml.E1[i][d] = mr->E1[i][d]; s->ml.E2[i][d] = mr->E2[i][d]; s->ml.E3[i][d] = mr->E3[i][d]; }
+            s->ml.damping_up[i] = sum;
+            if (mr->ndown[i] > 1) { for (int d = 0; d < mr->ndown[i]; d++) s->ml.P_down[i][d] = mr->A21[i][d] / sum;
+                                    alias_setup(mr->ndown[i], s->ml.P_down[i], s->ml.A_down[i]); }
+        }
+        s->damping = s->ml.damping_up[0]; s->DnuHK_Hz = 0.0;
+        s->E1 = 1.0; s->E2 = 0.0; s->E3 = 1.0; s->fine_structure = 0; s->include_deuterium = 0;
+        return;
+    }
     if (s->line_id[0]) {                                    /* :590-713; par%fine_structure plays no part for these ids */
         const double sigma_0 = 0.026540083434, amu = 1.67262192e-24, vtherm1_amu = 0.12895319011972164, speedc_cm = 2.99792458e5 * 1.0e5;
         const metal_line *m = find_metal_line(s->line_id);
@@ -508,8 +550,8 @@ void orc_line_constants(double *cross0, double *vtherm1, double *damping, double
     orc_sim t; t.line_id[0] = 0; t.fine_structure = 0; t.include_deuterium = 0; setup_line(&t);
     *cross0 = t.cross0; *vtherm1 = t.vtherm1; *damping = t.damping; *wavelength0 = t.wavelength0; *g_recoil0 = t.g_recoil0;
 }
-/* vtherm_total: define.f90:928-933 (bturb unset) */
-static double vtherm_total(const orc_sim *s, double T) { return s->vtherm1 * sqrt(T); }
+/* vtherm_total: define.f90:928-933: thermal width and the turbulent b parameter par%bturb in quadrature */
+static double vtherm_total(const orc_sim *s, double T) { double vt = s->vtherm1 * sqrt(T); if (s->bturb > 0.0) vt = sqrt(vt * vt + s->bturb * s->bturb); return vt; }
 
 /* random_alias_setup64: random_mt.f90:2016-2067 */
 static void alias_setup(int n, double *probs, int *alias) {
@@ -764,6 +806,11 @@ static int grid_create(orc_sim *s) {
     double atau0 = s->voigt_amean * s->tauhomo;
     /* car_setup_freq_grid :1442-1548 */
     s->atau3 = pow(s->voigt_amean * s->tauhomo, 1.0 / 3.0);
+    if (isfinite(s->wavelength_min) && isfinite(s->wavelength_max)) {               /* :1457-1461 */
+        double vt0 = vtherm_total(s, s->temperature), speedc = 2.99792458e5;
+        s->par_xfreq_min = -(s->wavelength_max - s->wavelength0 * 1e4) / (s->wavelength0 * 1e4) * (speedc / vt0);
+        s->par_xfreq_max = -(s->wavelength_min - s->wavelength0 * 1e4) / (s->wavelength0 * 1e4) * (speedc / vt0);
+    } else
     if (isfinite(s->velocity_min) && isfinite(s->velocity_max)) {                   /* :1462-1467 */
         double vt0 = vtherm_total(s, s->temperature);
         s->par_xfreq_min = -s->velocity_max / vt0; s->par_xfreq_max = -s->velocity_min / vt0;
@@ -1147,6 +1194,11 @@ static int grid_create_amr(orc_sim *s) {
     if (at <= 1.0) { s->xcrit = 0.0; s->xcrit2 = 0.0; } else { double xi = (at <= 60.0) ? 0.6 : 1.4, chi = (at <= 60.0) ? 1.2 : 0.6; s->xcrit = 0.02 * exp(xi * pow(log(at), chi)); s->xcrit2 = s->xcrit * s->xcrit; }
     /* amr_setup_freq_grid (:726-800): same rules as the Cartesian grid */
     s->atau3 = pow(s->voigt_amean * s->tauhomo, 1.0 / 3.0);
+    if (isfinite(s->wavelength_min) && isfinite(s->wavelength_max)) {               /* :1457-1461 */
+        double vt0 = vtherm_total(s, s->temperature), speedc = 2.99792458e5;
+        s->par_xfreq_min = -(s->wavelength_max - s->wavelength0 * 1e4) / (s->wavelength0 * 1e4) * (speedc / vt0);
+        s->par_xfreq_max = -(s->wavelength_min - s->wavelength0 * 1e4) / (s->wavelength0 * 1e4) * (speedc / vt0);
+    } else
     if (isfinite(s->velocity_min) && isfinite(s->velocity_max)) {                   /* :1462-1467 */
         double vt0 = vtherm_total(s, s->temperature);
         s->par_xfreq_min = -s->velocity_max / vt0; s->par_xfreq_max = -s->velocity_min / vt0;
@@ -1310,6 +1362,7 @@ static inline double voigt_clump(const orc_sim *s, double xfreq, int64_t icl) {
         return orc_voigt(xloc + Dnu, c->voigt_a[icl-1]) * (1.0 / 3.0) + orc_voigt(xloc, c->voigt_a[icl-1]) * (2.0 / 3.0); }
     if (s->line_type == 7) { double Dnu = s->delta_nu_HD_Hz / c->Dfreq[icl-1], xD = (xloc - Dnu) * s->ratio_Dfreq_HD;      /* clump_mod.f90:159-164 */
         return orc_voigt(xloc, c->voigt_a[icl-1]) + s->nD_over_nH * s->ratio_Dfreq_HD * orc_voigt(xD, c->voigt_a[icl-1] * s->ratio_voigta_HD); }
+    if (s->line_type == 5 || s->line_type == 6) return calc_voigt(s, xloc, c->voigt_a[icl-1], c->Dfreq[icl-1]);     /* clump_mod.f90:151-158 = calc_voigt3 */
     return orc_voigt(xloc, c->voigt_a[icl-1]);
 }
 static inline double kappa_clump(const orc_sim *s, double xfreq, int64_t icl) {
@@ -2089,6 +2142,30 @@ static void do_resonance1(const orc_sim *s, rng_t *g, photon_t *p, double *uz, d
         double qH = xatom_loc + DnuHK, qK = xatom_loc;
         p->E1 = (2.0 * qK * qH + qH * qH) / (qK * qK + 2.0 * qH * qH);             /* E1 of the atom-frame frequency */
         p->E2 = 1.0 - p->E1; p->E3 = (p->E1 + 2.0) / 3.0;
+    } else if (s->line_type >= 4 && s->line_type <= 6) {   /* do_resonance4 :249-291, 5 :347-406, 6 :408-474 and their clump forms (line_clump_mod.f90:105-260) */
+        int iup = 1, idown = 1;
+        if (s->line_type == 4) uz_loc = rand_resonance_vz(g, xfreq_loc, va);
+        else {
+            double Dx2 = s->ml.delE_Hz[1] / Df, va2 = va * s->ml.damping_up[1] / s->ml.damping_up[0];
+            double p1 = orc_voigt(xfreq_loc, va) * s->ml.f12[0], p2 = orc_voigt(xfreq_loc + Dx2, va2) * s->ml.f12[1];
+            if (s->line_type == 5) {
+                p1 = p1 / (p2 + p1);
+                if (rnd(g) < p1) { uz_loc = rand_resonance_vz(g, xfreq_loc, va); iup = 1; } else { uz_loc = rand_resonance_vz(g, xfreq_loc + Dx2, va2); iup = 2; }
+            } else {
+                double Dx3 = s->ml.delE_Hz[2] / Df, va3 = va * s->ml.damping_up[2] / s->ml.damping_up[0];
+                double p3 = orc_voigt(xfreq_loc + Dx3, va3) * s->ml.f12[2], ptot = p1 + p2 + p3, pcum1 = p1 / ptot, pcum2 = (p1 + p2) / ptot, xi = rnd(g);
+                if (xi < pcum1) { uz_loc = rand_resonance_vz(g, xfreq_loc, va); iup = 1; }
+                else if (xi < pcum2) { uz_loc = rand_resonance_vz(g, xfreq_loc + Dx2, va2); iup = 2; }
+                else { uz_loc = rand_resonance_vz(g, xfreq_loc + Dx3, va3); iup = 3; }
+            }
+        }
+        xatom_loc = xfreq_loc - uz_loc;
+        if (s->line_type == 4 || (s->line_type == 5 && s->ml.ndown[iup-1] > 1)) {           /* rand_alias_choise: random_mt.f90:2122-2135 */
+            int n = s->ml.ndown[iup-1], k = (int)floor(n * rnd(g)) + 1;
+            idown = (rnd(g) < s->ml.P_down[iup-1][k-1]) ? k : s->ml.A_down[iup-1][k-1];
+            if (s->line_type == 5 || idown != 1) xatom_loc = xatom_loc - s->ml.Elow_Hz[iup-1][idown-1] / Df;
+        }
+        p->E1 = s->ml.E1[iup-1][idown-1]; p->E2 = s->ml.E2[iup-1][idown-1]; p->E3 = s->ml.E3[iup-1][idown-1];
     } else if (s->line_type == 7) {                         /* do_resonance_HD :476-549 (clump form line_clump_mod.f90:262-300): H or D atom */
         double dx_HD = s->delta_nu_HD_Hz / Df, xfreq_D = (xfreq_loc - dx_HD) * s->ratio_Dfreq_HD;
         double pH = orc_voigt(xfreq_loc, va), pD = s->nD_over_nH * s->ratio_Dfreq_HD * orc_voigt(xfreq_D, va * s->ratio_voigta_HD);
@@ -2287,7 +2364,25 @@ static void generate_photon(const orc_sim *s, acc_t *A, rng_t *g, photon_t *p) {
     p->nscatt_gas = 0.0; p->nscatt_dust = 0.0; p->inside = 1; p->xfreq = s->xfreq0;
     p->E1 = 0.0; p->E2 = 1.0; p->E3 = 2.0 / 3.0;                                       /* photon_type defaults, define.f90:108-110 */
     size_t c = IDX(s,p->icell,p->jcell,p->kcell);
-    if (s->line_type == 2) { double DnuHK = s->DnuHK_Hz / s->Dfreq[c]; if (rnd(g) <= 1.0 / 3.0) p->xfreq = p->xfreq - DnuHK; }   /* :161-167: the source feeds both levels */
+    if (s->spectral_type != 2) {                            /* :160-243 (not for a continuum source) */
+        const double Dfreq_local = s->Dfreq[c];
+        if (s->line_type == 2) { double DnuHK = s->DnuHK_Hz / Dfreq_local; if (rnd(g) <= 1.0 / 3.0) p->xfreq = p->xfreq - DnuHK; }   /* :162-167: the source feeds both levels */
+        else if (s->line_type == 4) {                       /* :181-188 */
+            int n = s->ml.ndown[0], k = (int)floor(n * rnd(g)) + 1, idown = (rnd(g) < s->ml.P_down[0][k-1]) ? k : s->ml.A_down[0][k-1];
+            if (idown != 1) p->xfreq = p->xfreq - s->ml.Elow_Hz[0][idown-1] / Dfreq_local;
+        } else if (s->line_type == 5) {                     /* :189-215 */
+            double p1 = s->ml.f12[0], p2 = s->ml.f12[1]; int iup;
+            p1 = p1 / (p2 + p1);
+            if (rnd(g) < p1) iup = 1; else { iup = 2; p->xfreq = p->xfreq - s->ml.delE_Hz[1] / Dfreq_local; }
+            if (s->ml.ndown[iup-1] > 1) {
+                int n = s->ml.ndown[iup-1], k = (int)floor(n * rnd(g)) + 1, idown = (rnd(g) < s->ml.P_down[iup-1][k-1]) ? k : s->ml.A_down[iup-1][k-1];
+                p->xfreq = p->xfreq - s->ml.Elow_Hz[iup-1][idown-1] / Dfreq_local;
+            }
+        } else if (s->line_type == 6) {                     /* :216-242 */
+            double p1 = s->ml.f12[0], p2 = s->ml.f12[1], p3 = s->ml.f12[2], ptot = p1 + p2 + p3, pcum1 = p1 / ptot, pcum2 = (p1 + p2) / ptot, xi = rnd(g);
+            if (xi < pcum1) {} else if (xi < pcum2) p->xfreq = p->xfreq - s->ml.delE_Hz[1] / Dfreq_local; else p->xfreq = p->xfreq - s->ml.delE_Hz[2] / Dfreq_local;
+        }
+    }
     if (s->spectral_type == 1) p->xfreq = p->xfreq + rand_voigt(g, s->voigt_a[c]);     /* :252-253 */
     else if (s->spectral_type == 2) {                                                /* continuum :244-247, in units of the local cell */
         p->xfreq = rnd(g) * (s->xfreq_max - s->xfreq_min) + s->xfreq_min;
@@ -2454,6 +2549,16 @@ double orc_get_scalar(const orc_sim *s, const char *k) {
 static int64_t copy_out(const double *src, int64_t cnt, double *out, int64_t n) { if (!src) return -1; for (int64_t i = 0; i < cnt && i < n; i++) out[i] = src[i]; return cnt; }
 int64_t orc_get_array(const orc_sim *s, const char *k, double *out, int64_t n) {
     int64_t nc = (int64_t)s->nx * s->ny * s->nz;
+    if (!strcmp(k, "line_multiplet")) {                     /* type, nup, ndown[3], f12[3], delE_Hz[3], damping_up[3], then [iup][idown]: A21, Elow_Hz, E1, E2, E3, P_down, A_down */
+        double v[98]; int q = 0;
+        v[q++] = s->line_type; v[q++] = s->ml.nup;
+        for (int i = 0; i < 3; i++) v[q++] = s->ml.ndown[i];
+        for (int i = 0; i < 3; i++) v[q++] = s->ml.f12[i];
+        for (int i = 0; i < 3; i++) v[q++] = s->ml.delE_Hz[i];
+        for (int i = 0; i < 3; i++) v[q++] = s->ml.damping_up[i];
+        for (int i = 0; i < 3; i++) for (int d = 0; d < 4; d++) { v[q++] = s->ml.A21[i][d]; v[q++] = s->ml.Elow_Hz[i][d]; v[q++] = s->ml.E1[i][d]; v[q++] = s->ml.E2[i][d];
+            v[q++] = s->ml.E3[i][d]; v[q++] = s->ml.P_down[i][d]; v[q++] = s->ml.A_down[i][d]; }
+        return copy_out(v, 98, out, n); }
     if (!strcmp(k, "Jout")) return copy_out(s->Jout, s->nxfreq, out, n);
     if (!strcmp(k, "Jin")) return copy_out(s->Jin, s->nxfreq, out, n);
     if (!strcmp(k, "Jabs")) return copy_out(s->Jabs, s->nxfreq, out, n);

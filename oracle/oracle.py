@@ -243,6 +243,7 @@ class Ref:
             if hasattr(L, "ref_set_fine_structure"):
                 L.ref_set_fine_structure.argtypes = [_i, _vp]
                 L.ref_do_resonance2_v.argtypes = [_i, _d, _i, _i, _i, _vp]
+                L.ref_do_resonance_ptr_v.argtypes = [_i, _d, _i, _i, _i, _vp]
                 L.ref_calc_voigt_v.argtypes = [_i, _vp, _i, _i, _i, _vp]
             if hasattr(L, "ref_raytrace_tau_gas"):
                 L.ref_raytrace_tau_gas.argtypes = [_vp, _vp, _d, _vp]
@@ -331,6 +332,14 @@ class Ref:
     @classmethod
     def set_line_id(cls, name):
         out = np.zeros(10); cls.lib().ref_set_line_id(name.encode() + b"\0", _ptr(out)); return out
+
+    @classmethod
+    def get_multiplet(cls):
+        out = np.zeros(98); cls.lib().ref_get_multiplet(_ptr(out)); return out
+
+    @classmethod
+    def do_resonance_ptr(cls, n, xfreq, ic, jc, kc):
+        out = np.zeros((n, 12)); cls.lib().ref_do_resonance_ptr_v(n, float(xfreq), ic, jc, kc, _ptr(out)); return out
 
     @classmethod
     def set_deuterium(cls, on, D_to_H=1.5e-5):

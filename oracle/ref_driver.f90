@@ -85,15 +85,54 @@ contains
        par%line_id(i:i) = name(i)
     enddo
     par%fine_structure = .false.
+    if (allocated(line%b)) deallocate(line%b)
+    line%delE_Hz = 0.0_wp; line%f12 = 0.0_wp; line%nup = 1
     call setup_resonance_line()
-    if (line%line_type == 2) then
-       calc_voigt => calc_voigt2; do_resonance => do_resonance2
-    else
-       calc_voigt => calc_voigt1; do_resonance => do_resonance1
-    endif
+    select case (line%line_type)                     ! as setup_procedure does (setup.f90:778-803)
+    case (2); calc_voigt => calc_voigt2; do_resonance => do_resonance2
+    case (4); calc_voigt => calc_voigt1; do_resonance => do_resonance4
+    case (5); calc_voigt => calc_voigt3; do_resonance => do_resonance5
+    case (6); calc_voigt => calc_voigt3; do_resonance => do_resonance6
+    case default; calc_voigt => calc_voigt1; do_resonance => do_resonance1
+    end select
     out = [real(line%line_type, c_double), line%wavelength0, line%damping, line%cross0, line%vtherm1, line%g_recoil0, line%DnuHK_Hz, &
            line%E1, line%E2, line%E3]
   end subroutine ref_set_line_id
+
+  !--- line%b(:) of the current line (types 4, 5, 6): type, nup, ndown(3), f12(3), delE_Hz(3), damping(3), then for every (iup, idown) of a 3 x 4
+  !--- table: A21, Elow_Hz, E1, E2, E3, P_down, A_down (zeros where the reference has no entry)
+  subroutine ref_get_multiplet(out) bind(C, name='ref_get_multiplet')
+    real(c_double), intent(out) :: out(98)
+    integer :: i, d, q
+    out = 0.0_c_double
+    out(1) = line%line_type; out(2) = line%nup
+    do i = 1, line%nup
+       out(2+i) = line%b(i)%ndown; out(5+i) = line%f12(i); out(11+i) = line%b(i)%damping
+       if (line%nup > 1) out(8+i) = line%delE_Hz(i)
+       do d = 1, line%b(i)%ndown
+          q = 14 + ((i-1)*4 + (d-1))*7
+          out(q+1) = line%b(i)%A21(d); out(q+2) = line%b(i)%Elow_Hz(d); out(q+3) = line%b(i)%E1(d); out(q+4) = line%b(i)%E2(d); out(q+5) = line%b(i)%E3(d)
+          if (allocated(line%b(i)%P_down)) then
+             out(q+6) = line%b(i)%P_down(d); out(q+7) = line%b(i)%A_down(d)
+          endif
+       enddo
+    enddo
+  end subroutine ref_get_multiplet
+
+  !--- do_resonance through the pointer (do_resonance4 / 5 / 6 ...): out(:,i) = uz, xatom, cost, sint, S11, S22, S12, S33, S44, E1, E2, E3
+  subroutine ref_do_resonance_ptr_v(n, xfreq, ic, jc, kc, out) bind(C, name='ref_do_resonance_ptr_v')
+    integer(c_int), value :: n, ic, jc, kc
+    real(c_double), value :: xfreq
+    real(c_double), intent(out) :: out(12, n)
+    type(photon_type) :: ph
+    integer :: i
+    do i = 1, n
+       ph%xfreq = xfreq
+       ph%icell = ic; ph%jcell = jc; ph%kcell = kc
+       call do_resonance(ph, g, out(1,i), out(2,i), out(3,i), out(4,i), out(5,i), out(6,i), out(7,i), out(8,i), out(9,i))
+       out(10,i) = ph%E1; out(11,i) = ph%E2; out(12,i) = ph%E3
+    enddo
+  end subroutine ref_do_resonance_ptr_v
 
   !--- par%include_deuterium: 'ly_alpha_HD' (line type 7) or back to plain Ly-alpha; out = delta_nu_HD_Hz, ratio_Dfreq_HD, ratio_voigta_HD, g_recoil0_D
   subroutine ref_set_deuterium(on, D_to_H, out) bind(C, name='ref_set_deuterium')

@@ -134,6 +134,6 @@ def test_line_id_constants_of_the_python_host(golden):
         par, L, _ = host.read_input(par)
         got = [L.line_type, L.wavelength0, L.damping, L.cross0, L.vtherm1, L.g_recoil0, L.DnuHK_Hz, L.E1, L.E2, L.E3]
         assert np.allclose(got, ref, rtol=1e-14, atol=0) and not par.fine_structure, (lid, got, ref)
-    par = host.Params(); par.line_id = "SiII_1527"
+    par = host.Params(); par.line_id = "ly_beta"
     with pytest.raises(host.LartInputError, match="not supported"):
         host.read_input(par)

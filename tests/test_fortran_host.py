@@ -454,7 +454,8 @@ def test_xy_symmetry_dry_run_equals_python_host(exe, tmp_path):
 @pytest.mark.gpu
 @pytest.mark.parametrize("vel", [" par%velocity_type = 'rotating_galaxy_halo'\n par%Vrot = 100.0\n par%rinner = 0.2\n",
                                  " par%velocity_type = 'ssh'\n par%Vpeak = 120.0\n par%rpeak = 0.3\n par%DeltaV = -60.0\n",
-                                 " par%velocity_type = 'hubble'\n par%Vexp = 80.0\n par%include_deuterium = .true.\n par%D_to_H_ratio = 0.02\n par%recoil = .true.\n"])
+                                 " par%velocity_type = 'hubble'\n par%Vexp = 80.0\n par%include_deuterium = .true.\n par%D_to_H_ratio = 0.02\n par%recoil = .true.\n",
+                                 " par%velocity_type = 'hubble'\n par%Vexp = 40.0\n par%line_id = 'FeII_UV1'\n par%bturb = 4.0\n"])
 def test_velocity_fields_end_to_end_match_python_host(exe, tmp_path, vel):
     """the analytic velocity fields of grid_create (grid_mod_car.f90:786-946) as examples/rotating_galaxy_halo uses them"""
     text = ("&parameters\n par%no_photons = 20000\n par%temperature = 1e4\n par%N_HImax = 1e16\n par%rmax = 1.0\n par%nx = 31\n par%ny = 31\n par%nz = 31\n"
@@ -490,7 +491,7 @@ def test_whole_namelist_surface_is_readable(exe, tmp_path):
     r = run(exe, "&parameters\n par%temperature = 1e4\n par%taumax = 1e2\n par%include_deuterium = .true.\n par%fine_structure = .true.\n/\n", tmp_path,
             "--dry-run", name="hd.in")                                                    # promoted to ly_alpha_HD, the doublet switched off
     assert r.returncode == 0 and "ly_alpha_HD" in r.stdout, r.stdout
-    r = run(exe, "&parameters\n par%temperature = 1e4\n par%taumax = 1e2\n par%line_id = 'SiII_1527'\n/\n", tmp_path, "--dry-run", name="ca.in")
+    r = run(exe, "&parameters\n par%temperature = 1e4\n par%taumax = 1e2\n par%line_id = 'ly_beta'\n/\n", tmp_path, "--dry-run", name="ca.in")
     assert r.returncode != 0 and "not supported" in r.stdout
     from lart_amd import host
     (tmp_path / "all.in").write_text(ok)

@@ -106,7 +106,10 @@ def test_ray_marches_device_vs_reference_vectors(capi, golden, name):
                                 dict(temperature=1e2, taumax=1e3, nx=11, ny=11, nz=11, rmax=1.0, include_deuterium=True, D_to_H_ratio=3e-3, use_stokes=True,
                                      recoil=True),
                                 dict(temperature=1e4, N_gasmax=1e14, nx=11, ny=11, nz=11, rmax=1.0, line_id="CIV_1548", use_stokes=True, recoil=True),
-                                dict(temperature=3e4, N_gasmax=1e14, nx=11, ny=11, nz=11, rmax=1.0, line_id="AlII_1671", recoil=True)])
+                                dict(temperature=3e4, N_gasmax=1e14, nx=11, ny=11, nz=11, rmax=1.0, line_id="AlII_1671", recoil=True),
+                                dict(temperature=1e5, taumax=1e1, nx=11, ny=11, nz=11, rmax=1.0, line_id="SiII_1527", recoil=True),
+                                dict(temperature=3e4, taumax=1e2, nx=11, ny=11, nz=11, rmax=1.0, line_id="FeII_UV1", use_stokes=True, recoil=True),
+                                dict(temperature=1e4, taumax=1e2, nx=11, ny=11, nz=11, rmax=1.0, line_id="HeI_10833", use_stokes=True, bturb=3.0)])
 def test_scatter_event_device(capi, oracle_mod, kw):
     sim = make(kw); o = oracle_of(oracle_mod, kw)
     rng = np.random.default_rng(3)
@@ -123,6 +126,9 @@ def test_scatter_event_device(capi, oracle_mod, kw):
         x0 = -1.2 if kw.get("fine_structure") else 0.0        # (the doublet: centre the frequencies between the two levels)
         if kw.get("line_id") == "CIV_1548" and i % 2:           # (a wide doublet: half of the events around the H component)
             x0 = -sim.line.DnuHK_Hz / float(g.Dfreq_ref)
+        ml = sim.line.multiplet
+        if ml is not None and ml.nup > 1 and i % ml.nup:        # (multiplets: the events spread over the line centres x = -delE_Hz(i)/Dfreq)
+            x0 = -ml.delE_Hz[i % ml.nup] / float(g.Dfreq_ref)
         if kw.get("include_deuterium") and i % 2:             # (H + D: half of the events around the deuterium line centre)
             x0 = sim.line.delta_nu_HD_Hz / float(g.Dfreq_ref)
         st[i] = pos + list(k) + [x0 + (rng.normal(0, 2.0) if i % 3 else rng.normal(0, 0.3)), 1.0] + list(m) + list(nn) + [1.0, q, u, 0.05]
@@ -162,6 +168,13 @@ def test_scatter_event_device(capi, oracle_mod, kw):
     (dict(temperature=1e4, N_gasmax=2e13, nx=21, ny=21, nz=21, rmax=1.0, nxfreq=160, iseed=18, line_id="MgII_2796", spectral_type="continuum",
           velocity_min=-1200.0, velocity_max=400.0, velocity_type="hubble", Vexp=100.0, use_stokes=True), 20000),
     (dict(temperature=5e4, N_gasmax=1e14, nx=21, ny=21, nz=21, rmax=1.0, nxfreq=121, iseed=19, line_id="SiIV_1394", recoil=True), 20000),
+    (dict(temperature=1e5, taumax=1e1, nx=21, ny=21, nz=21, rmax=1.0, nxfreq=200, iseed=20, line_id="SiII_1527", wavelength_min=1526.0, wavelength_max=1536.0), 20000),
+    (dict(temperature=3e4, taumax=3e1, nx=21, ny=21, nz=21, rmax=1.0, nxfreq=300, iseed=21, line_id="FeII_UV1", wavelength_min=2580.0, wavelength_max=2640.0,
+          use_stokes=True, velocity_type="hubble", Vexp=50.0, recoil=True), 20000),
+    (dict(temperature=1e4, taumax=2e1, xyz_symmetry=True, nx=21, ny=21, nz=21, rmax=1.0, nxfreq=161, iseed=22, line_id="HeI_10833", velocity_min=-200.0,
+          velocity_max=200.0, bturb=5.0, spectral_type="gaussian", gaussian_FWHM_vel=60.0), 20000),
+    (dict(temperature=2e4, taumax=2e1, nx=21, ny=21, nz=21, rmax=1.0, nxfreq=300, iseed=23, line_id="FeII_UV2", wavelength_min=2360.0, wavelength_max=2400.0,
+          spectral_type="continuum"), 20000),
 ])
 def test_short_histories_photon_by_photon(capi, oracle_mod, kw, n):
     sim = make(kw); sim.ctx.enable_photon_log(True)
@@ -261,6 +274,52 @@ def test_metal_doublets_device_vs_reference_vectors(capi, golden, tag):
     assert np.array_equal(ic, z[tag + "_ic_out"]) and np.allclose(r, z[tag + "_r_out"], rtol=1e-10, atol=1e-12)
     _, _, te = sim.ctx.test_raytrace(1, 0, z[tag + "_r_in"], z[tag + "_ic_in"])
     assert np.allclose(te, z[tag + "_tau_edge"], rtol=1e-10, atol=1e-300)
+
+
+@pytest.mark.parametrize("tag,typ", [("si", 4), ("fe", 5), ("he", 6)])
+def test_multiplets_device_vs_reference_vectors(capi, golden, tag, typ):
+    """line types 4, 5, 6 (SiII_1527, FeII_UV1, HeI_10833): calc_voigt1/3 inside the marches against vectors from the reference's
+    compiled modules; the record the hosts hand to lart_gpu_set_line_multiplet against line%b(:) of the reference"""
+    from lart_amd import host
+    z = golden("multiplets.npz")
+    kw = dict(tok.split("=") for tok in str(z[tag + "_params"]).split())
+    par = host.Params()
+    for k, v in kw.items():
+        host.set_param(par, k, host._parse_value(v) if k not in ("geometry", "line_id") else v)
+    sim = host.Simulation(par); L = sim.line
+    i = list(z["ids"]).index(kw["line_id"])
+    assert L.line_type == typ and [L.line_type, L.wavelength0, L.damping, L.cross0, L.vtherm1, L.g_recoil0] == list(z["constants"][i][:6])
+    assert np.array_equal(capi.pack_multiplet(L.multiplet), z["tables"][i])
+    g = sim.grid
+    sim.ctx.set_grid_car(g.nx, g.ny, g.nz, g.xmin, g.ymin, g.zmin, g.dx, g.dy, g.dz, g.i0, g.j0, g.k0, g.xface, g.yface, g.zface,
+                         z[tag + "_rhokap"], z[tag + "_voigt_a"], z[tag + "_Dfreq"], z[tag + "_vfx"], z[tag + "_vfy"], z[tag + "_vfz"], z[tag + "_rhokapD"])
+    r, ic, _ = sim.ctx.test_raytrace(0, 0, z[tag + "_r_in"], z[tag + "_ic_in"], z[tag + "_tau_in"])
+    assert np.array_equal(ic, z[tag + "_ic_out"]) and np.allclose(r, z[tag + "_r_out"], rtol=1e-10, atol=1e-12)
+    _, _, te = sim.ctx.test_raytrace(1, 0, z[tag + "_r_in"], z[tag + "_ic_in"])
+    assert np.allclose(te, z[tag + "_tau_edge"], rtol=1e-10, atol=1e-300)
+
+
+def test_multiplets_peel_and_clumps_whole_path(capi, oracle_mod):
+    """fluorescence through the peel-off (the peeled photon carries the channel's frequency shift and E1..E3) and through the clump
+    medium (voigt_clump types 5/6, do_resonance4/5_clump), against the oracle on the same streams"""
+    kw = dict(temperature=3e4, taumax=3e1, nx=21, ny=21, nz=21, rmax=1.0, nxfreq=240, nxim=8, nyim=8, use_stokes=True, line_id="FeII_UV1",
+              wavelength_min=2580.0, wavelength_max=2640.0, save_peeloff_2D=True, alpha=20.0, beta=55.0, iseed=97)
+    n = 30000
+    sim = make(kw); sim.run_simulation(n); t = sim.ctx.tallies()
+    o = oracle_of(oracle_mod, kw); o.run(n, seed=97)
+    assert rms_diff(t["Jout"], o.array("Jout")) < 0.01
+    for k in ("scatt", "I", "Q"):
+        g, r = t[k][..., 0], o.array(k + ":0").reshape((240, 8, 8), order="F")
+        assert np.allclose(g.sum(axis=0), r.sum(axis=0), rtol=0.05, atol=0.02 * np.abs(o.array("I:0")).reshape((240, 8, 8), order="F").sum(axis=0).max()), k
+        assert np.allclose(g.sum(axis=(1, 2)), r.sum(axis=(1, 2)), rtol=0.05, atol=0.02 * np.abs(r.sum(axis=(1, 2))).max()), k
+    for lid, w0, w1, seed in (("SiII_1260", 1258.0, 1268.0, 98), ("FeII_UV2", 2360.0, 2400.0, 99)):
+        kw = dict(use_clump_medium=True, rmax=1.0, clump_radius=0.05, clump_f_cov=3.0, clump_tau0=30.0, temperature=2e4, nxfreq=200, line_id=lid,
+                  wavelength_min=w0, wavelength_max=w1, iseed=seed)
+        sim = make(kw); sim.ctx.enable_photon_log(True); sim.run_simulation(n); t = sim.ctx.tallies()
+        o = oracle_mod.Oracle(**kw); o.run(n, seed=seed)
+        ng, xg = sim.ctx.photon_log(n); no, xo = o.photon_log()
+        same = np.isclose(ng, no, rtol=1e-12, atol=0) & np.isclose(xg, xo, rtol=1e-7, atol=1e-9)
+        assert same.mean() > 0.97 and rms_diff(t["Jout"], o.array("Jout")) < 0.01, lid
 
 
 def test_deuterium_peel_and_clumps_whole_path(capi, oracle_mod):
