@@ -146,6 +146,7 @@ int  lart_gpu_set_clumps(lart_gpu *ctx, int64_t n, const double *x, const double
 #define LART_LINE_MAX_DOWN 4
 typedef struct lart_line_multiplet {
     int32_t line_type, nup;
+    int32_t HeI_coherent;        /* par%HeI_coherent (type 6 only): E1..E3 of the atom-frame frequency, compute_HeI_E_coherent line_mod.f90:8-34 */
     int32_t ndown[LART_LINE_MAX_UP];
     int32_t A_down[LART_LINE_MAX_UP][LART_LINE_MAX_DOWN];
     char    ion_id[8];

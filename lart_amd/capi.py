@@ -33,7 +33,7 @@ class LartTallies(C.Structure):
 
 class LartLineMultiplet(C.Structure):
     """lart_line_multiplet of include/lart_gpu.h (line types 4, 5, 6: line%b(:), line_mod.f90:713-1153)"""
-    _fields_ = [("line_type", _i32), ("nup", _i32), ("ndown", _i32 * 3), ("A_down", (_i32 * 4) * 3), ("ion_id", C.c_char * 8),
+    _fields_ = [("line_type", _i32), ("nup", _i32), ("HeI_coherent", _i32), ("ndown", _i32 * 3), ("A_down", (_i32 * 4) * 3), ("ion_id", C.c_char * 8),
                 ("wavelength0", _d), ("cross0", _d), ("vtherm1", _d), ("g_recoil0", _d), ("damping", _d),
                 ("f12", _d * 3), ("delE_Hz", _d * 3), ("damping_up", _d * 3)] + \
         [(n, (_d * 4) * 3) for n in ("A21", "Elow_Hz", "E1", "E2", "E3", "P_down")]

@@ -95,7 +95,7 @@ struct DCtl { unsigned long long next_k; unsigned long long n_active; };
 // resonance + fluorescence multiplets (line types 4, 5, 6: lart_line_multiplet).  The per-level constants are wave-uniform and ride
 // in the kernel arguments; the per-branch tables are gathered with lane-varying (iup, idown) from global memory:
 // tab[k*12 + iup*4 + idown], k = 0 Elow_Hz, 1 E1, 2 E2, 3 E3, 4 P_down;  itab[0..2] = ndown, itab[3 + iup*4 + idown] = A_down
-struct DMulti { int nup; double delE_Hz[3], damping_up[3], f12[3]; const double *tab; const int *itab; };
+struct DMulti { int nup, coherent; double delE_Hz[3], damping_up[3], f12[3]; const double *tab; const int *itab; };
 
 struct KArgs {
     lart_params par;
@@ -134,7 +134,7 @@ struct Lds { const double *vt; const double *xf, *yf, *zf;   // Voigt tables and
              double *jp_P, *jp_Pn;       // per-block LDS copies of P1 / P1_new (nullptr: deposits go to global memory)
              unsigned char *coop;        // LART_COOP_BYTES per wave: scratch of the cooperative samplers (vz_core_coop / vz_wing_coop), nullptr = off
              int lt; double dnu_hz;      // line type (1 single line, 2 Ly-alpha doublet, 7 H + D) and DnuHK_Hz / delta_nu_HD_Hz: set from the kernel's template
-             int ml_nup; double ml_dE[3], ml_damp[3], ml_f12[3]; const double *ml_tab; const int *ml_itab;   // lt 4 = the multiplets (line types 4, 5, 6): DMulti
+             int ml_nup, ml_coh; double ml_dE[3], ml_damp[3], ml_f12[3]; const double *ml_tab; const int *ml_itab;   // lt 4 = the multiplets (line types 4, 5, 6): DMulti
              double hd_ratio, hd_ratio_a, hd_nD; };   // line type 7: ratio_Dfreq_HD, ratio_voigta_HD, nD_over_nH (line_mod.f90:1186-1191)
                                          // (lt comes from a template parameter, so that `l.lt == 2` / `== 7` fold away in the single-line kernels)
 
@@ -144,7 +144,7 @@ __device__ inline Lds lds_stage(double *sh, const DGrid &g) {
     for (int i = threadIdx.x; i < nf; i += blockDim.x) sh[VT_END + i] = g.faces[i];
     __syncthreads();
     Lds l; l.vt = sh; l.xf = sh + VT_END; l.yf = l.xf + (g.nx + 1); l.zf = l.yf + (g.ny + 1);
-    l.dip_p2 = 0.0; l.dip_qs = 0.0; l.jp_P = nullptr; l.jp_Pn = nullptr; l.coop = nullptr; l.lt = 1; l.dnu_hz = 0.0; l.hd_ratio = 1.0; l.hd_ratio_a = 1.0; l.hd_nD = 0.0; l.ml_nup = 1; l.ml_tab = nullptr; l.ml_itab = nullptr;
+    l.dip_p2 = 0.0; l.dip_qs = 0.0; l.jp_P = nullptr; l.jp_Pn = nullptr; l.coop = nullptr; l.lt = 1; l.dnu_hz = 0.0; l.hd_ratio = 1.0; l.hd_ratio_a = 1.0; l.hd_nD = 0.0; l.ml_nup = 1; l.ml_coh = 0; l.ml_tab = nullptr; l.ml_itab = nullptr;
     for (int i = 0; i < 3; i++) { l.ml_dE[i] = 0.0; l.ml_damp[i] = 1.0; l.ml_f12[i] = 0.0; }
     return l;
 }
@@ -364,7 +364,7 @@ __device__ inline double voigt_H(const double *vt, double vin, double a) {
     return 0.56418958354775628695 * a * v2 * (1.0 + ((1.5 - a * a) + 3.75 * v2) * v2);
 }
 __device__ inline void lds_set_multiplet(Lds &l, const DMulti &m) {
-    l.ml_nup = m.nup; l.ml_tab = m.tab; l.ml_itab = m.itab;
+    l.ml_nup = m.nup; l.ml_coh = m.coherent; l.ml_tab = m.tab; l.ml_itab = m.itab;
     for (int i = 0; i < 3; i++) { l.ml_dE[i] = m.delE_Hz[i]; l.ml_damp[i] = m.damping_up[i]; l.ml_f12[i] = m.f12[i]; }
 }
 // calc_voigt1 / calc_voigt2 (line_mod.f90:38-62): the profile of a cell with Voigt parameter a and Doppler width Dfreq.
@@ -1665,6 +1665,14 @@ __device__ inline void scatter_post(const KArgs &A, const Lds &l, Rng &g, Photon
             else xfreq_atom = xfreq_atom - del_xfreq;
         }
         E1 = l.ml_tab[12 + sc.iup * 4 + idown]; E2 = l.ml_tab[24 + sc.iup * 4 + idown]; E3 = l.ml_tab[36 + sc.iup * 4 + idown];
+        if (l.ml_coh && l.ml_nup == 3) {                        // par%HeI_coherent: compute_HeI_E_coherent (line_mod.f90:8-34) of the atom-frame frequency
+            const double D2 = (VAR == 4) ? sc.xloc - uz_loc : xfreq_atom, D1 = D2 + l.ml_dE[1] / sc.cl_Dfreq, D0 = D2 + l.ml_dE[2] / sc.cl_Dfreq;
+            const double D2D0 = D2 * D0, D2D1 = D2 * D1, D0D1 = D0 * D1, pp = D2 * D0 * D1;
+            const double den = 4.0 * (D2D1 * D2D1 + 3.0 * D2D0 * D2D0 + 5.0 * D0D1 * D0D1);
+            E1 = (3.0 * D2D0 * D2D0 + 7.0 * D0D1 * D0D1 + 8.0 * pp * D1 + 18.0 * pp * D0) / den;
+            E3 = (3.0 * D2D0 * D2D0 + 15.0 * D0D1 * D0D1 + 8.0 * D2 * pp + 10.0 * pp * D0) / den;
+            E2 = 1.0 - E1;
+        }
     }
     if (l.lt == 2) {                                           // do_resonance2 :166-171: E1 of the atom-frame frequency
         const double qK = (VAR == 4) ? sc.xloc - uz_loc : xfreq_atom, qH = qK + sc.dnu;

@@ -187,7 +187,7 @@ extern "C" int lart_gpu_set_line_multiplet(lart_gpu *c, const lart_line_multiple
     HIPCHK(hipSetDevice(c->device));
     if (!c->d_ml_tab) { HIPCHK(hipMalloc(&c->d_ml_tab, sizeof tab)); HIPCHK(hipMalloc(&c->d_ml_itab, sizeof itab)); }
     HIPCHK(hipMemcpy(c->d_ml_tab, tab, sizeof tab, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(c->d_ml_itab, itab, sizeof itab, hipMemcpyHostToDevice));
-    c->ml = DMulti{}; c->ml.nup = m->nup; c->ml.tab = c->d_ml_tab; c->ml.itab = c->d_ml_itab;
+    c->ml = DMulti{}; c->ml.nup = m->nup; c->ml.coherent = (m->HeI_coherent != 0 && m->line_type == 6) ? 1 : 0; c->ml.tab = c->d_ml_tab; c->ml.itab = c->d_ml_itab;
     for (int i = 0; i < 3; i++) { c->ml.delE_Hz[i] = i < m->nup ? m->delE_Hz[i] : 0.0; c->ml.damping_up[i] = i < m->nup ? m->damping_up[i] : 1.0; c->ml.f12[i] = i < m->nup ? m->f12[i] : 0.0; }
     c->has_ml = true;
     return 0;

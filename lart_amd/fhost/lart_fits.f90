@@ -5,9 +5,10 @@
 ! 2880-byte blocks, 80-character cards, big-endian IEEE data.  No external library.
 !------------------------------------------------------------------------------
 module lart_fits
-  use, intrinsic :: iso_fortran_env, only: real64, int32, int64
+  use, intrinsic :: iso_fortran_env, only: real32, real64, int32, int64
   implicit none
   private
+  public :: fits_bitpix
   public :: fits_file, fits_open, fits_close, fits_begin_table, fits_begin_image, fits_key, fits_end_header, &
             fits_write_table_rows, fits_write_image
 
@@ -15,6 +16,8 @@ module lart_fits
      integer :: unit = -1
      integer(int64) :: nbytes = 0          ! bytes written in the current header / data unit
   end type fits_file
+
+  integer :: fits_bitpix = -64             ! par%out_bitpix: -32 writes float32 images and 1E table columns
 
   interface fits_key
      module procedure key_r8, key_i4, key_l, key_s
@@ -104,14 +107,19 @@ contains
     call put_card(f, "XTENSION= 'BINTABLE'           / binary table extension")
     call key_i4(f, 'BITPIX', 8, 'array data type')
     call key_i4(f, 'NAXIS', 2, 'number of array dimensions')
-    call key_i4(f, 'NAXIS1', 8*ncol, 'length of dimension 1')
+    call key_i4(f, 'NAXIS1', merge(4, 8, fits_bitpix == -32)*ncol, 'length of dimension 1')
     call key_i4(f, 'NAXIS2', nrow, 'length of dimension 2')
     call key_i4(f, 'PCOUNT', 0, 'number of group parameters')
     call key_i4(f, 'GCOUNT', 1, 'number of groups')
     call key_i4(f, 'TFIELDS', ncol, 'number of table fields')
     do i = 1, ncol
        write(kw, '("TTYPE",i0)') i; call key_s(f, kw, trim(names(i)), 'label for field')
-       write(kw, '("TFORM",i0)') i; call key_s(f, kw, '1D', 'data format of field: 8-byte DOUBLE')
+       write(kw, '("TFORM",i0)') i
+       if (fits_bitpix == -32) then
+          call key_s(f, kw, '1E', 'data format of field: 4-byte REAL')
+       else
+          call key_s(f, kw, '1D', 'data format of field: 8-byte DOUBLE')
+       endif
     enddo
   end subroutine fits_begin_table
 
@@ -122,7 +130,7 @@ contains
     integer :: i
     f%nbytes = 0
     call put_card(f, "XTENSION= 'IMAGE   '           / IMAGE extension")
-    call key_i4(f, 'BITPIX', -64, 'number of bits per data pixel')
+    call key_i4(f, 'BITPIX', fits_bitpix, 'number of bits per data pixel')
     call key_i4(f, 'NAXIS', size(naxes), 'number of data axes')
     do i = 1, size(naxes)
        write(kw, '("NAXIS",i0)') i; call key_i4(f, kw, naxes(i), 'length of data axis')
@@ -143,10 +151,14 @@ contains
     integer :: i, j
     do i = 1, size(cols, 1)
        do j = 1, size(cols, 2)
-          write(f%unit) cols(i, j)
+          if (fits_bitpix == -32) then
+             write(f%unit) real(cols(i, j), real32)
+          else
+             write(f%unit) cols(i, j)
+          endif
        enddo
     enddo
-    f%nbytes = 8_int64*size(cols)
+    f%nbytes = merge(4_int64, 8_int64, fits_bitpix == -32)*size(cols)
     call pad_block(f, achar(0))
   end subroutine fits_write_table_rows
 
@@ -155,8 +167,12 @@ contains
     real(real64), intent(in) :: a(*)
     integer(int64) :: n
     n = f%nbytes                                     ! caller passes the element count through nbytes
-    write(f%unit) a(1:n)
-    f%nbytes = 8_int64*n
+    if (fits_bitpix == -32) then
+       write(f%unit) real(a(1:n), real32)
+    else
+       write(f%unit) a(1:n)
+    endif
+    f%nbytes = merge(4_int64, 8_int64, fits_bitpix == -32)*n
     call pad_block(f, achar(0))
   end subroutine fits_write_image
 end module lart_fits

@@ -36,7 +36,7 @@ module lart_gpu_c
   !--- struct lart_tallies: host pointers (c_null_ptr = skip) + scalars
   !--- lart_line_multiplet of include/lart_gpu.h (line types 4, 5, 6: line%b(:) of the reference); C [3][4] arrays = Fortran (4,3)
   type, bind(C) :: lart_line_multiplet
-     integer(c_int32_t) :: line_type, nup
+     integer(c_int32_t) :: line_type, nup, HeI_coherent
      integer(c_int32_t) :: ndown(3)
      integer(c_int32_t) :: A_down(4,3)
      character(kind=c_char) :: ion_id(8)

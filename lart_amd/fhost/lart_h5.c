@@ -25,11 +25,15 @@ long long lh5_group(long long file, const char *name) {
     H5Pclose(gcpl);
     return (long long)g;
 }
+/* par%out_bitpix (define.f90:418): -32 stores the datasets as float32, -64 (and 0 here: this host keeps full precision where the
+   reference's auto mode may pick float32) as float64; the memory type stays double, the library converts */
+static int g_bitpix = -64;
+void lh5_set_bitpix(int bp) { g_bitpix = (bp == -32) ? -32 : -64; }
 /* fdims = Fortran extents (fastest first); the file gets them reversed, as the HDF5 Fortran API does */
 int lh5_put_f64(long long grp, const char *name, int rank, const long long *fdims, const double *a) {
     hsize_t d[8]; if (rank < 1 || rank > 8) return 1;
     for (int i = 0; i < rank; i++) d[i] = (hsize_t)fdims[rank - 1 - i];
-    hid_t sp = H5Screate_simple(rank, d, NULL), ds = H5Dcreate2((hid_t)grp, name, H5T_NATIVE_DOUBLE, sp, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
+    hid_t sp = H5Screate_simple(rank, d, NULL), ds = H5Dcreate2((hid_t)grp, name, g_bitpix == -32 ? H5T_IEEE_F32LE : H5T_NATIVE_DOUBLE, sp, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
     int rc = (ds < 0) || H5Dwrite(ds, H5T_NATIVE_DOUBLE, H5S_ALL, H5S_ALL, H5P_DEFAULT, a) < 0;
     if (ds >= 0) H5Dclose(ds);
     H5Sclose(sp);
@@ -53,6 +57,7 @@ int lh5_close_group(long long grp) { return H5Gclose((hid_t)grp) < 0; }
 int lh5_close(long long file) { return H5Fclose((hid_t)file) < 0; }
 #else
 int lh5_available(void) { return 0; }
+void lh5_set_bitpix(int bp) { (void)bp; }
 long long lh5_create(const char *path) { (void)path; return -1; }
 long long lh5_group(long long file, const char *name) { (void)file; (void)name; return -1; }
 int lh5_put_f64(long long grp, const char *name, int rank, const long long *fdims, const double *a) { (void)grp; (void)name; (void)rank; (void)fdims; (void)a; return 1; }

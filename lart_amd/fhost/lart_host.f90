@@ -311,6 +311,7 @@ contains
           if (line%ml%ion_id(i) == c_null_char) exit
           line%ion_id(i:i) = line%ml%ion_id(i)
        enddo
+       line%ml%HeI_coherent = merge(1, 0, par%HeI_coherent .and. line%line_type == 6)
        par%fine_structure = .false.; par%include_deuterium = .false.
        return
     endif
@@ -345,7 +346,6 @@ contains
     if (par%temperature0 /= -999.0_wp) call not_supported('par%temperature0')
     if (par%Dfreq0 /= -999.0_wp) call not_supported('par%Dfreq0')
     if (par%voigt_a0 /= -999.0_wp) call not_supported('par%voigt_a0')
-    if (par%HeI_coherent) call not_supported('par%HeI_coherent')
     if (par%source_rscale /= 0.0_wp) call not_supported('par%source_rscale')
     if (par%sersic_m /= 1.0_wp) call not_supported('par%sersic_m')
     if (par%Reff /= 0.0_wp) call not_supported('par%Reff')
@@ -382,7 +382,7 @@ contains
     if (par%metallicity_global /= -1.0_wp) call not_supported('par%metallicity_global')
     if (par%Z_ref /= 0.0134_wp) call not_supported('par%Z_ref')
     if (par%f_ion_dust /= 0.01_wp) call not_supported('par%f_ion_dust')
-    if (par%out_bitpix /= 0) call not_supported('par%out_bitpix')
+    if (par%out_bitpix /= 0 .and. par%out_bitpix /= -32 .and. par%out_bitpix /= -64) call not_supported('par%out_bitpix (0, -32 or -64)')
     if (par%sampling_method /= 1) call not_supported('par%sampling_method')
     if (par%f_composite /= 0.5_wp) call not_supported('par%f_composite')
     if (par%save_backup) call not_supported('par%save_backup')

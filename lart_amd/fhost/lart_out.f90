@@ -15,6 +15,7 @@ module lart_out
   private
   integer, parameter :: wp = real64
   integer, parameter, public :: OUT_FITS = 1, OUT_HDF5 = 2
+  integer, public :: out_bitpix = 0        ! par%out_bitpix, set by the caller before out_open (-32: float32 storage)
 
   type, public :: key_t
      character(len=16) :: name = ''
@@ -45,6 +46,9 @@ module lart_out
      function lh5_available() bind(C, name='lh5_available') result(a)
        import; integer(c_int) :: a
      end function
+     subroutine lh5_set_bitpix(bp) bind(C, name='lh5_set_bitpix')
+       import; integer(c_int), value :: bp
+     end subroutine
      function lh5_create(path) bind(C, name='lh5_create') result(id)
        import; character(kind=c_char), intent(in) :: path(*); integer(c_long_long) :: id
      end function
@@ -114,12 +118,14 @@ contains
     o%fmt = fmt
     if (fmt == OUT_HDF5) then
        o%path = trim(base)//'.h5'
+       call lh5_set_bitpix(int(out_bitpix, c_int))
        o%h5 = lh5_create(cstr(o%path))
        if (o%h5 < 0) then
           write(*,'(2a)') 'ERROR: cannot create ', trim(o%path); stop 1
        endif
     else
        o%path = trim(base)//'.fits'
+       fits_bitpix = merge(-32, -64, out_bitpix == -32)
        call fits_open(o%f, trim(o%path))
     endif
   end subroutine out_open

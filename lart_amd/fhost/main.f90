@@ -54,6 +54,7 @@ program LaRT_amd
   if (par%save_peeloff) write(*,'(a,i4,a,2i6,a,2es13.5)') 'observers: ', par%nobs, '  image ', par%nxim, par%nyim, '  pixel (deg) ', par%dxim, par%dyim
   write(*,'(a,2f10.3,i6)') 'xfreq_min, xfreq_max, nxfreq : ', grid%xfreq_min, grid%xfreq_max, grid%nxfreq
   if (dry_run) then
+     out_bitpix = par%out_bitpix
      if (dry_write) call write_output(trim(par%out_file), grid)
      if (dry_write .and. par%save_sightline_tau .and. par%save_peeloff .and. par%nobs > 0) call make_sightline_tau(.false.)
      write(*,'(a)') '--dry-run: set-up only, no transport.'
@@ -66,6 +67,7 @@ program LaRT_amd
      write(*,'(a)') 'ERROR: no MI355X/HIP device visible; this build has no CPU transport path.'; stop 1
   endif
   call fill_params(cpar)
+  out_bitpix = par%out_bitpix
   call lart_check(lart_gpu_create(ctx, cpar, 0_c_int), 'lart_gpu_create')
   if (par%use_amr_grid) then
      if (par%DGR > 0.0_wp) then

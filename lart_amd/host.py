@@ -85,6 +85,7 @@ class Params:
     xfreq_max: float = NAN
     nxfreq: int = 121
     velocity_min: float = NAN
+    HeI_coherent: bool = False      # line type 6: frequency-dependent E1..E3 (compute_HeI_E_coherent, line_mod.f90:8-34)
     bturb: float = -999.0           # turbulent b parameter [km/s], in quadrature with the thermal width (define.f90:928-933)
     wavelength_min: float = NAN     # angstrom; takes precedence over the velocity window (grid_mod_car.f90:1457-1461)
     wavelength_max: float = NAN
@@ -187,7 +188,6 @@ _UNSUPPORTED_DEFAULTS = {
     # the rest of the reference's namelist surface (define.f90:209-544): readable, rejected when set
     "Dfreq0": -999.0,
     "voigt_a0": -999.0,
-    "HeI_coherent": False,
     "source_rscale": 0.0,
     "sersic_m": 1.0,
     "Reff": 0.0,
@@ -434,6 +434,7 @@ def read_input(par, line=None):
         line.line_type, line.wavelength0, line.damping, line.cross0 = ml.line_type, ml.wavelength0, ml.damping, ml.cross0
         line.vtherm1, line.g_recoil0, line.DnuHK_Hz, line.multiplet = ml.vtherm1, ml.g_recoil0, 0.0, ml
         line.E1, line.E2, line.E3 = 1.0, 0.0, 1.0
+        ml.HeI_coherent = 1 if (par.HeI_coherent and ml.line_type == 6) else 0
         par.fine_structure = par.include_deuterium = False
     elif par.line_id in _METAL_LINES:                                     # single lines / S-P doublets: line_mod.f90:590-713
         typ, wl, f1, damping, mass, mass_recoil, k_hi, k_lo = _METAL_LINES[par.line_id]

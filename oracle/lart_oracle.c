@@ -299,6 +299,7 @@ struct orc_sim {
     int use_amr_grid; char amr_file[512]; amr_t amr;
     int use_clump_medium, clump_fully_inside; clumps_t cl;
     double clump_radius, clump_N_clumps, clump_f_vol, clump_f_cov, clump_tau0, clump_NHI, clump_nH, clump_temperature, clump_sigma_v;
+    int HeI_coherent;                        /* par%HeI_coherent (line type 6) */
     double bturb;                            /* par%bturb [km/s], <= 0: none */
     double wavelength_min, wavelength_max;   /* angstrom: the spectral window, takes precedence over velocity_min/max (grid_mod_car.f90:1457-1461) */
     double Vrot, rinner, velocity_min, velocity_max, Vpeak, rpeak, DeltaV, velocity_alpha;
@@ -433,7 +434,7 @@ static int set_param(orc_sim *s, const char *k, const char *v) {
 #define I(name) if (!strcmp(k, #name)) { s->name = atoi(v); return 0; }
 #define B(name) if (!strcmp(k, #name)) { s->name = parse_bool(v); return 0; }
     D(no_photons) I(iseed) D(temperature) D(taumax) D(tauhomo) D(Vexp) D(Vx) D(Vy) D(Vz)
-    B(comoving_source) B(recoil) B(core_skip) B(core_skip_global) B(xyz_symmetry) B(xy_periodic) B(xy_symmetry) B(fine_structure) B(include_deuterium)
+    B(comoving_source) B(recoil) B(core_skip) B(core_skip_global) B(xyz_symmetry) B(xy_periodic) B(xy_symmetry) B(fine_structure) B(include_deuterium) B(HeI_coherent)
     I(nx) I(ny) I(nz) D(xmax) D(ymax) D(zmax) D(rmax) D(rmin) D(xs_point) D(ys_point) D(zs_point) D(source_rmax)
     D(xfreq0) I(nxfreq) B(use_stokes) B(use_reduced_wgt) B(save_Jin) B(save_Jabs) B(save_Jmu) I(nmu)
     D(hgg) D(albedo) D(cext_dust) D(DGR) D(distance2cm) B(save_peeloff) B(save_peeloff_2D) B(save_peeloff_3D) B(save_direc0) B(save_dust_scattered)
@@ -2166,6 +2167,14 @@ static void do_resonance1(const orc_sim *s, rng_t *g, photon_t *p, double *uz, d
             if (s->line_type == 5 || idown != 1) xatom_loc = xatom_loc - s->ml.Elow_Hz[iup-1][idown-1] / Df;
         }
         p->E1 = s->ml.E1[iup-1][idown-1]; p->E2 = s->ml.E2[iup-1][idown-1]; p->E3 = s->ml.E3[iup-1][idown-1];
+        if (s->line_type == 6 && s->HeI_coherent) {         /* compute_HeI_E_coherent :8-34 (clump form line_clump_mod.f90:236-238): offsets from P2, P1, P0 */
+            double D2 = xatom_loc, D1 = xatom_loc + s->ml.delE_Hz[1] / Df, D0 = xatom_loc + s->ml.delE_Hz[2] / Df;
+            double D2D0 = D2 * D0, D2D1 = D2 * D1, D0D1 = D0 * D1, pp = D2 * D0 * D1;
+            double den = 4.0 * (D2D1 * D2D1 + 3.0 * D2D0 * D2D0 + 5.0 * D0D1 * D0D1);
+            p->E1 = (3.0 * D2D0 * D2D0 + 7.0 * D0D1 * D0D1 + 8.0 * pp * D1 + 18.0 * pp * D0) / den;
+            p->E3 = (3.0 * D2D0 * D2D0 + 15.0 * D0D1 * D0D1 + 8.0 * D2 * pp + 10.0 * pp * D0) / den;
+            p->E2 = 1.0 - p->E1;
+        }
     } else if (s->line_type == 7) {                         /* do_resonance_HD :476-549 (clump form line_clump_mod.f90:262-300): H or D atom */
         double dx_HD = s->delta_nu_HD_Hz / Df, xfreq_D = (xfreq_loc - dx_HD) * s->ratio_Dfreq_HD;
         double pH = orc_voigt(xfreq_loc, va), pD = s->nD_over_nH * s->ratio_Dfreq_HD * orc_voigt(xfreq_D, va * s->ratio_voigta_HD);

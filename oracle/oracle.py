@@ -334,6 +334,10 @@ class Ref:
         out = np.zeros(10); cls.lib().ref_set_line_id(name.encode() + b"\0", _ptr(out)); return out
 
     @classmethod
+    def set_HeI_coherent(cls, on):
+        cls.lib().ref_set_HeI_coherent(int(on))
+
+    @classmethod
     def get_multiplet(cls):
         out = np.zeros(98); cls.lib().ref_get_multiplet(_ptr(out)); return out
 

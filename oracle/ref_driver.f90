@@ -99,6 +99,11 @@ contains
            line%E1, line%E2, line%E3]
   end subroutine ref_set_line_id
 
+  subroutine ref_set_HeI_coherent(on) bind(C, name='ref_set_HeI_coherent')
+    integer(c_int), value :: on
+    par%HeI_coherent = (on /= 0)
+  end subroutine ref_set_HeI_coherent
+
   !--- line%b(:) of the current line (types 4, 5, 6): type, nup, ndown(3), f12(3), delE_Hz(3), damping(3), then for every (iup, idown) of a 3 x 4
   !--- table: A21, Elow_Hz, E1, E2, E3, P_down, A_down (zeros where the reference has no entry)
   subroutine ref_get_multiplet(out) bind(C, name='ref_get_multiplet')

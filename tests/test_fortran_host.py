@@ -59,7 +59,7 @@ def test_unknown_field_and_unsupported_mode_fail(exe, tmp_path):
     assert r.returncode != 0 and "ERROR" in r.stdout
     r = run(exe, "&parameters\n par%use_amr_grid = .true.\n/\n", tmp_path, "--dry-run", name="amr.in")
     assert r.returncode != 0 and "needs par%amr_file" in r.stdout
-    r = run(exe, "&parameters\n par%HeI_coherent = .true.\n/\n", tmp_path, "--dry-run", name="fs.in")
+    r = run(exe, "&parameters\n par%cone_opening = 30.0\n/\n", tmp_path, "--dry-run", name="fs.in")
     assert r.returncode != 0 and "not supported" in r.stdout
 
 
@@ -328,6 +328,17 @@ def test_output_containers_hdf5_and_gzip_fits(exe, tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     assert list(read_h5(str(tmp_path / "cd_obs.h5"))) == ["Scattered", "Direct", "Direct0", "ScatDust"]
     assert list(read_h5(str(tmp_path / "cd_obs2D.h5"))) == ["Scattered", "Direct", "Direct0"]
+    # par%out_bitpix = -32: float32 storage in both containers (define.f90:418); -64 / 0 keep float64
+    r = run(exe, base + " par%out_bitpix = -32\n/\n", tmp_path, "--dry-run-write", name="c32.in")
+    assert r.returncode == 0, r.stdout + r.stderr
+    import ctypes
+    raw = open(str(tmp_path / "c32.h5"), "rb").read()
+    H32 = read_h5(str(tmp_path / "c32.h5"))
+    assert np.allclose(H32["Spectrum"][1]["Xfreq"], H["Spectrum"][1]["Xfreq"], rtol=1e-6) and not np.array_equal(H32["Spectrum"][1]["Xfreq"], H["Spectrum"][1]["Xfreq"])
+    assert len(raw) < os.path.getsize(str(tmp_path / "ch.h5"))
+    r = run(exe, base + " par%out_bitpix = -32\n par%file_format = 'fits'\n/\n", tmp_path, "--dry-run-write", name="f32.in")
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert os.path.exists(str(tmp_path / "f32.fits.gz"))
 
 
 JPA_IN = ("&parameters\n par%no_photons = 20000\n par%temperature = 1e4\n par%taumax = 1e3\n par%nx = 21\n par%ny = 21\n par%nz = 21\n"
@@ -483,7 +494,7 @@ def test_whole_namelist_surface_is_readable(exe, tmp_path):
     r = run(exe, ok, tmp_path, "--dry-run", name="all.in")
     assert r.returncode == 0, r.stdout + r.stderr
     for bad in ("par%f_H2 = 1e-3", "par%cone_opening = 30.0", "par%clump_allow_overlap = .true.", "par%stellar_radius = 0.1", "par%Omega = 28.0",
-                "par%xmin = -1.0", "par%HeI_coherent = .true.", "par%ionization_model = 'file'", "par%phase_angle = 10.0, 20.0"):
+                "par%xmin = -1.0", "par%save_all_photons = .true.", "par%ionization_model = 'file'", "par%phase_angle = 10.0, 20.0"):
         r = run(exe, "&parameters\n par%temperature = 1e4\n par%taumax = 1e2\n " + bad + "\n/\n", tmp_path, "--dry-run", name="bad.in")
         assert r.returncode != 0 and "not supported" in r.stdout and bad.split()[0][4:] in r.stdout, bad
     r = run(exe, "&parameters\n par%metalz = 1.0\n/\n", tmp_path, "--dry-run", name="bad2.in")

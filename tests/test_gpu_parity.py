@@ -109,7 +109,8 @@ def test_ray_marches_device_vs_reference_vectors(capi, golden, name):
                                 dict(temperature=3e4, N_gasmax=1e14, nx=11, ny=11, nz=11, rmax=1.0, line_id="AlII_1671", recoil=True),
                                 dict(temperature=1e5, taumax=1e1, nx=11, ny=11, nz=11, rmax=1.0, line_id="SiII_1527", recoil=True),
                                 dict(temperature=3e4, taumax=1e2, nx=11, ny=11, nz=11, rmax=1.0, line_id="FeII_UV1", use_stokes=True, recoil=True),
-                                dict(temperature=1e4, taumax=1e2, nx=11, ny=11, nz=11, rmax=1.0, line_id="HeI_10833", use_stokes=True, bturb=3.0)])
+                                dict(temperature=1e4, taumax=1e2, nx=11, ny=11, nz=11, rmax=1.0, line_id="HeI_10833", use_stokes=True, bturb=3.0),
+                                dict(temperature=1e4, taumax=1e2, nx=11, ny=11, nz=11, rmax=1.0, line_id="HeI_10833", use_stokes=True, HeI_coherent=True)])
 def test_scatter_event_device(capi, oracle_mod, kw):
     sim = make(kw); o = oracle_of(oracle_mod, kw)
     rng = np.random.default_rng(3)
@@ -173,6 +174,8 @@ def test_scatter_event_device(capi, oracle_mod, kw):
           use_stokes=True, velocity_type="hubble", Vexp=50.0, recoil=True), 20000),
     (dict(temperature=1e4, taumax=2e1, xyz_symmetry=True, nx=21, ny=21, nz=21, rmax=1.0, nxfreq=161, iseed=22, line_id="HeI_10833", velocity_min=-200.0,
           velocity_max=200.0, bturb=5.0, spectral_type="gaussian", gaussian_FWHM_vel=60.0), 20000),
+    (dict(temperature=1e4, taumax=2e1, nx=21, ny=21, nz=21, rmax=1.0, nxfreq=161, iseed=24, line_id="HeI_10833", velocity_min=-200.0, velocity_max=200.0,
+          HeI_coherent=True, use_stokes=True, velocity_type="hubble", Vexp=20.0), 20000),
     (dict(temperature=2e4, taumax=2e1, nx=21, ny=21, nz=21, rmax=1.0, nxfreq=300, iseed=23, line_id="FeII_UV2", wavelength_min=2360.0, wavelength_max=2400.0,
           spectral_type="continuum"), 20000),
 ])

@@ -60,3 +60,16 @@ def test_whole_path_fluorescence(oracle_mod):
     assert abs(J.sum() - 20000.0) < 1.0
     red = J[lam > 1532.0].sum() / J.sum()
     assert 0.55 < red < 1.0
+
+
+def test_HeI_coherent_on_the_reference_stream(oracle_mod, golden):
+    """par%HeI_coherent: E1..E3 as the polynomial of the atom-frame offsets from the three 2^3P levels (compute_HeI_E_coherent)"""
+    z = golden("multiplets.npz")
+    o = oracle_mod.Oracle(str(z["he_params"]) + " HeI_coherent=1")
+    for k in ("rhokap", "voigt_a", "Dfreq", "vfx", "vfy", "vfz", "rhokapD"):
+        o.set_array(k, z["he_" + k])
+    ref_all = z["he_coherent_resonance"]
+    assert np.ptp(ref_all[..., 9]) > 0.3                                          # E1 now varies from event to event
+    for i, (x, ref) in enumerate(zip(z["he_xres"], ref_all)):
+        got = o.do_resonance(0, 800 + i, 0, 256, float(x), *map(int, z["he_cells"][i % 3]))
+        assert np.allclose(got, ref, rtol=1e-9, atol=1e-12), (i, x)

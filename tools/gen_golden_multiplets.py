@@ -55,6 +55,12 @@ for tag, lid, T in (("si", "SiII_1527", 1e5), ("fe", "FeII_UV1", 3e4), ("he", "H
                 tag + "_r_out": np.array(rout), tag + "_ic_out": np.array(icout), tag + "_tau_edge": np.array(tedge)})
     for k in ("rhokap", "voigt_a", "Dfreq", "vfx", "vfy", "vfz", "rhokapD"):
         out[tag + "_" + k] = o.array(k)
+    if tag == "he":                                                               # par%HeI_coherent: E1..E3 of the atom-frame frequency
+        R.set_HeI_coherent(1); coh = []
+        for i, x in enumerate(xres):
+            R.seed(800 + i); coh.append(R.do_resonance_ptr(256, x, *cells[i % 3]))
+        R.set_HeI_coherent(0)
+        out["he_coherent_resonance"] = np.array(coh)
     rr = np.array(res)
     print(lid, "offsets", offs, "E1 values", np.unique(np.round(rr[..., 9], 6)))
 R.set_line_id("ly_alpha")
