@@ -20,6 +20,15 @@ CONFIGS = {
                                                                     nx=11, ny=11, nz=11, no_photons=1e7, iseed=1),
     "C5 octree sphere levels 3-7 (178480 leaves) tau0=1e4 CALCJ+CALCP+CALCPnew": dict(use_amr_grid=True, amr_file=afile, temperature=1e4, taumax=1e4, rmax=1.0, nxfreq=241,
                                                                                    xfreq_min=-15.0, xfreq_max=15.0, calc_J=True, calc_P=True, calc_Pnew=True, no_photons=1e7, iseed=1),
+    # line types beyond plain Ly-alpha on the headline geometry (tau0 = 1e6 octant): the LT = 2 / 7 / 4 kernel families
+    "L2 headline sphere with par%fine_structure (LT=2)": dict(temperature=10.0, taumax=1e6, xyz_symmetry=True, nx=101, ny=101, nz=101, rmax=1.0, nxfreq=201, fine_structure=True,
+                                                              no_photons=1e7, iseed=1),
+    "L7 headline sphere T=1e4 with deuterium D/H=1.5e-5 (LT=7)": dict(temperature=1e4, taumax=1e6, xyz_symmetry=True, nx=101, ny=101, nz=101, rmax=1.0, nxfreq=201,
+                                                                     include_deuterium=True, no_photons=1e7, iseed=1),
+    "L4 examples/FeII_test-like: FeII_UV1 tau0=1e2 T=1e4 sphere 101^3 (LT=4, fluorescence)": dict(temperature=1e4, taumax=1e2, nx=101, ny=101, nz=101, rmax=1.0, nxfreq=600,
+                                                                                              line_id="FeII_UV1", wavelength_min=2575.0, wavelength_max=2640.0, no_photons=4e9, iseed=1)   # (few events per photon: enough photons to keep every lane busy),
+    "L6 HeI_10833 tau0=1e3 T=1e4 sphere 101^3 (LT=4, three blended levels)": dict(temperature=1e4, taumax=1e3, nx=101, ny=101, nz=101, rmax=1.0, nxfreq=201, line_id="HeI_10833",
+                                                                                velocity_min=-300.0, velocity_max=300.0, no_photons=1e7, iseed=1),
 }
 for name, kw in CONFIGS.items():
     sim = host.Simulation(dict(kw))
