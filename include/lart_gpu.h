@@ -203,6 +203,13 @@ int  lart_gpu_kernel_time(lart_gpu *ctx, double *total_ms, int64_t *nlaunches);
  * device keeps nscatt and exit xfreq_ref for photon k = 0..count-1 of the current begin() */
 int  lart_gpu_enable_photon_log(lart_gpu *ctx, int32_t on);
 int  lart_gpu_get_photon_log(lart_gpu *ctx, double *nscatt, double *xfreq_ref, int64_t n);
+/* par%save_all_photons: the per-photon table of make_all_initial_photons / make_all_photons (run_simulation_mod.f90:249-358) that
+ * write_output_allph (write_output_rect.f90:1353-1515) writes.  Enable before lart_gpu_begin; afterwards out[10][n] (n = the photon
+ * count of lart_gpu_begin, record k = the k-th photon id of this context) holds the columns r (impact parameter of the escaping
+ * ray), xfreq1 (at birth), xfreq2 (lab frame at escape or absorption), NSCATT_gas, NSCATT_dust, I, Q, U, V (Stokes runs; weight 0
+ * for a photon absorbed by dust) and r0 (impact parameter of the first ray; extended sources).  Costs 96 bytes of HBM per photon. */
+int  lart_gpu_enable_all_photons(lart_gpu *ctx, int32_t on);
+int  lart_gpu_get_all_photons(lart_gpu *ctx, double *out, int64_t n);
 /* pool geometry knobs (0 = default): resident photon lanes and threads per workgroup */
 int  lart_gpu_set_pool(lart_gpu *ctx, int64_t nlanes, int32_t block);
 int  lart_gpu_pool_info(lart_gpu *ctx, int64_t *nlanes, int32_t *block);   /* valid after lart_gpu_begin */

@@ -43,7 +43,7 @@ SYMBOLS = ["lart_host_line_lookup", "lart_gpu_set_line_multiplet", "lart_gpu_dev
            "lart_gpu_set_grid_car", "lart_gpu_set_mueller", "lart_gpu_set_observers", "lart_gpu_set_observers_heal",
            "lart_gpu_set_JPa", "lart_gpu_set_grid_amr", "lart_gpu_set_JPa_amr", "lart_gpu_set_clumps", "lart_host_last_error", "lart_host_clumps_generate", "lart_host_clumps_csr_dims", "lart_host_clumps_build_csr", "lart_host_amr_last_error", "lart_host_amr_count", "lart_host_amr_build", "lart_gpu_run",
            "lart_gpu_begin", "lart_gpu_step", "lart_gpu_sync", "lart_gpu_kernel_time", "lart_gpu_sightline_tau", "lart_gpu_sightline_time",
-           "lart_gpu_enable_photon_log", "lart_gpu_get_photon_log", "lart_gpu_set_pool", "lart_gpu_pool_info",
+           "lart_gpu_enable_photon_log", "lart_gpu_get_photon_log", "lart_gpu_enable_all_photons", "lart_gpu_get_all_photons", "lart_gpu_set_pool", "lart_gpu_pool_info",
            "lart_gpu_tally_buffer", "lart_gpu_zero_tallies", "lart_gpu_get_tallies",
            "lart_gpu_test_voigt", "lart_gpu_test_rand", "lart_gpu_test_raytrace", "lart_gpu_test_vec2pix", "lart_gpu_test_scatter"]
 
@@ -85,6 +85,8 @@ def lib():
         L.lart_gpu_sightline_time.argtypes = [_vp, C.POINTER(_d)]
         L.lart_gpu_enable_photon_log.argtypes = [_vp, _i32]
         L.lart_gpu_get_photon_log.argtypes = [_vp, _vp, _vp, _i64]
+        L.lart_gpu_enable_all_photons.argtypes = [_vp, _i32]
+        L.lart_gpu_get_all_photons.argtypes = [_vp, _vp, _i64]
         L.lart_gpu_set_pool.argtypes = [_vp, _i64, _i32]
         L.lart_gpu_pool_info.argtypes = [_vp, C.POINTER(_i64), C.POINTER(_i32)]
         L.lart_gpu_tally_buffer.argtypes = [_vp, C.POINTER(_vp), C.POINTER(_i64)]
@@ -228,6 +230,15 @@ class Context:
 
     def enable_photon_log(self, on=True):
         _chk(lib().lart_gpu_enable_photon_log(self.h, int(on)))
+
+    def enable_all_photons(self, on=True):
+        _chk(lib().lart_gpu_enable_all_photons(self.h, int(on)))
+
+    def all_photons(self, count):
+        """par%save_all_photons: dict of the ten columns write_output_allph writes (r, xfreq1, xfreq2, NSCATT_gas, NSCATT_dust, I, Q, U, V, r0)"""
+        a = np.zeros((10, count))
+        _chk(lib().lart_gpu_get_all_photons(self.h, _p(a), count))
+        return dict(zip(("r", "xfreq1", "xfreq2", "NSCATT_gas", "NSCATT_dust", "I", "Q", "U", "V", "r0"), a))
 
     def run(self, count, first_id=1, stride=1, seed=1234):
         _chk(lib().lart_gpu_run(self.h, first_id, stride, int(count), seed))

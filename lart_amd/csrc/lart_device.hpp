@@ -114,6 +114,7 @@ struct KArgs {
     unsigned long long seed;
     int max_events;
     double *log_nscatt, *log_xfreq;
+    double *allph; long long allph_n;   // par%save_all_photons: 10 columns of allph_n records (r, xfreq1, xfreq2, nscatt_gas, nscatt_dust, I, Q, U, V, r0), nullptr = off
     DMulti ml;
 };
 
@@ -1561,7 +1562,13 @@ __device__ inline bool dust_absorb(const KArgs &A, Rng &g, Photon &p, const Cell
         if (ix >= 1 && ix <= par.nxfreq) atomicAdd(&A.t.Jabs[ix - 1], dep);
         p.xfreq_ref = xr;
     }
-    if (killed) { p.inside = false; return true; }
+    if (killed) {
+        if (A.allph) {                                         // par%save_all_photons: the absorbed photon's lab-frame frequency, weight 0 (scattering_car.f90:236-246, 525-535)
+            if (!par.save_Jabs) { const double uu1 = c.vfx * p.kx + c.vfy * p.ky + c.vfz * p.kz; p.xfreq_ref = (p.xfreq + uu1) * (c.Dfreq / par.Dfreq_ref); }
+            p.wgt = 0.0;
+        }
+        p.inside = false; return true;
+    }
     if (par.use_reduced_wgt) p.wgt = p.wgt * par.albedo;
     return false;
 }
@@ -1716,6 +1723,30 @@ __device__ inline void scatter_post(const KArgs &A, const Lds &l, Rng &g, Photon
     } else {
         if (PEEL) peel_resonance_nostokes<VAR>(A, l, DUST, p, xfreq_atom, ux, uy, uz, E1, E2, g_rec0, npeel);
         rotate_k(p, cost, sint, cosp, sinp);
+    }
+}
+// par%save_all_photons (run_simulation_mod.f90:249-358): the record of photon k.  The impact parameter |r - (r.k)k| does not change along
+// the ray, so the reference's move to the sphere's surface (:302-324) drops out.
+__device__ inline double impact_parameter(const Photon &p, double &mx, double &my, double &mz) {
+    const double rk = p.x * p.kx + p.y * p.ky + p.z * p.kz;
+    mx = p.x - rk * p.kx; my = p.y - rk * p.ky; mz = p.z - rk * p.kz;
+    return sqrt(mx * mx + my * my + mz * mz);
+}
+__device__ inline void allph_initial(const KArgs &A, const Photon &p, long long k) {          // make_all_initial_photons :249-292
+    A.allph[1 * A.allph_n + k] = p.xfreq;
+    if (A.par.source_geometry != 0) { double mx, my, mz; A.allph[9 * A.allph_n + k] = impact_parameter(p, mx, my, mz); }
+}
+template <bool STOKES>
+__device__ inline void allph_final(const KArgs &A, const Photon &p, long long k) {            // make_all_photons :294-358
+    const long long n = A.allph_n; double mx, my, mz; const double mm = impact_parameter(p, mx, my, mz);
+    A.allph[k] = mm; A.allph[2 * n + k] = p.xfreq_ref; A.allph[3 * n + k] = p.nsg; A.allph[4 * n + k] = p.nsd;
+    if (STOKES) {
+        double cos2p = 1.0, sin2p = 0.0;
+        if (mm > 0.0) { mx = mx / mm; my = my / mm; mz = mz / mm;
+            const double cosp = mx * p.mx + my * p.my + mz * p.mz, sinp = mx * p.nx + my * p.ny + mz * p.nz;
+            cos2p = 2.0 * cosp * cosp - 1.0; sin2p = 2.0 * sinp * cosp; }
+        A.allph[5 * n + k] = p.wgt; A.allph[6 * n + k] = (cos2p * p.Q + sin2p * p.U) * p.wgt;
+        A.allph[7 * n + k] = (-sin2p * p.Q + cos2p * p.U) * p.wgt; A.allph[8 * n + k] = p.V * p.wgt;
     }
 }
 // `on`: this lane has a packet to scatter.  Every lane of the wave that is inside the event loop calls this (the |x| <= 1

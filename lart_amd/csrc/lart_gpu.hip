@@ -401,7 +401,8 @@ extern "C" int lart_gpu_pool_info(lart_gpu *c, int64_t *nlanes, int32_t *block) 
     return 0;
 }
 
-extern "C" int lart_gpu_enable_photon_log(lart_gpu *c, int32_t on) { if (!c) return fail("null context"); c->log_on = on; return 0; }
+extern "C" int lart_gpu_enable_photon_log(lart_gpu *c, int32_t on) { if (!c) return fail("null context"); c->log_on = on ? (c->log_on == 2 ? 2 : 1) : 0; return 0; }
+extern "C" int lart_gpu_enable_all_photons(lart_gpu *c, int32_t on) { if (!c) return fail("null context"); c->log_on = on ? 2 : 0; return 0; }
 
 static int ensure_pool(lart_gpu *c) {
     int64_t n = c->want_lanes;
@@ -456,7 +457,8 @@ extern "C" int lart_gpu_begin(lart_gpu *c, int64_t first_id, int64_t stride, int
     HIPCHK(hipMemsetAsync(c->pool.flags, 0, (size_t)c->pool.n * 4, c->stream));
     HIPCHK(hipMemsetAsync(c->d_ctl, 0, sizeof(DCtl), c->stream));
     (void)hipFree(c->d_log); c->d_log = nullptr; c->nlog = 0;
-    if (c->log_on && count > 0) { HIPCHK(hipMalloc(&c->d_log, (size_t)count * 16)); HIPCHK(hipMemsetAsync(c->d_log, 0, (size_t)count * 16, c->stream)); c->nlog = count; }
+    if (c->log_on && count > 0) { const size_t bytes = (size_t)count * 8 * (c->log_on == 2 ? 12 : 2);
+        HIPCHK(hipMalloc(&c->d_log, bytes)); HIPCHK(hipMemsetAsync(c->d_log, 0, bytes, c->stream)); c->nlog = count; }
     for (auto &e : c->ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     c->ev.clear(); c->kernel_ms = 0.0; c->nlaunch = 0;
     c->begun = true;
@@ -482,6 +484,7 @@ extern "C" int lart_gpu_step(lart_gpu *c, int32_t nsteps, int32_t max_events) {
     A.nxim = c->nxim; A.nyim = c->nyim; A.dxim = c->dxim; A.dyim = c->dyim; A.ctl = c->d_ctl; A.heal_nside = c->heal_nside; A.jpa = c->jpa; A.amr = c->amr; A.cl = c->cl; A.rep = c->rep; A.ml = c->ml;
     A.first_id = c->first_id; A.stride = c->stride; A.count = c->count; A.seed = c->seed; A.max_events = max_events;
     A.log_nscatt = c->d_log; A.log_xfreq = c->d_log ? c->d_log + c->nlog : nullptr;
+    A.allph = (c->d_log && c->log_on == 2) ? c->d_log + 2 * c->nlog : nullptr; A.allph_n = c->nlog;
     int var = march_variant(c);
     int stokes = c->par.use_stokes ? 1 : 0, dust = c->par.DGR > 0.0 ? 1 : 0, peel = (c->par.save_peeloff && c->nobs > 0) ? 1 : 0;
     dim3 block(c->block), grid((unsigned)(c->pool.n / c->block));
@@ -603,6 +606,16 @@ extern "C" int lart_gpu_get_photon_log(lart_gpu *c, double *nscatt, double *xfre
     int64_t m = n < c->nlog ? n : c->nlog;
     if (nscatt) HIPCHK(hipMemcpy(nscatt, c->d_log, (size_t)m * 8, hipMemcpyDeviceToHost));
     if (xfreq_ref) HIPCHK(hipMemcpy(xfreq_ref, c->d_log + c->nlog, (size_t)m * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int lart_gpu_get_all_photons(lart_gpu *c, double *out, int64_t n) {
+    if (!c || !out) return fail("all_photons: null argument");
+    if (!c->d_log || c->log_on != 2) return fail("all_photons: not enabled (lart_gpu_enable_all_photons before lart_gpu_begin)");
+    if (n != c->nlog) return fail("all_photons: n must equal the photon count of lart_gpu_begin");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out, c->d_log + 2 * c->nlog, (size_t)n * 80, hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -117,6 +117,7 @@ __global__ __launch_bounds__(256, LART_WAVES(STOKES, PEEL)) void transport_kerne
             k = (long long)kk;
             g.init(A.seed, (uint64_t)(A.first_id + k * A.stride), 0);
             generate_photon<VAR, STOKES, DUST, PEEL>(A, l, g, p, npeel);
+            if (A.allph) allph_initial(A, p, k);
             alive = true; first = true;
             LART_PROF_MARK(p, 1);
         }
@@ -132,6 +133,7 @@ __global__ __launch_bounds__(256, LART_WAVES(STOKES, PEEL)) void transport_kerne
         if (!p.inside) {
             nsg_done += p.nsg; nsd_done += p.nsd; ndone++;
             if (A.log_nscatt) { A.log_nscatt[k] = p.nsg + p.nsd; A.log_xfreq[k] = p.xfreq_ref; }
+            if (A.allph) allph_final<STOKES>(A, p, k);
             alive = false;
         }
         LART_PROF_MARK(p, 7);

@@ -167,6 +167,12 @@ module lart_gpu_c
        type(c_ptr), value :: cell_level
        integer(c_int) :: rc
      end function
+     function lart_gpu_enable_all_photons(ctx, on) bind(C, name='lart_gpu_enable_all_photons') result(rc)
+       import; type(c_ptr), value :: ctx; integer(c_int32_t), value :: on; integer(c_int) :: rc
+     end function
+     function lart_gpu_get_all_photons(ctx, out, n) bind(C, name='lart_gpu_get_all_photons') result(rc)
+       import; type(c_ptr), value :: ctx; real(c_double), intent(out) :: out(*); integer(c_int64_t), value :: n; integer(c_int) :: rc
+     end function
      function lart_gpu_run(ctx, first_id, stride, count, seed) bind(C, name='lart_gpu_run') result(rc)
        import; type(c_ptr), value :: ctx; integer(c_int64_t), value :: first_id, stride, count, seed; integer(c_int) :: rc
      end function

@@ -475,7 +475,6 @@ contains
     endif
     if (len_trim(par%dens_file) + len_trim(par%temp_file) + len_trim(par%velo_file) + len_trim(par%emiss_file) + &
         len_trim(par%cart_file) + len_trim(par%input_field) + len_trim(par%star_file) > 0) call not_supported('an input field file')
-    if (par%save_all_photons) call not_supported('par%save_all_photons')
 
     select case(trim(par%geometry))
     case ('');    par%geometry = 'sphere'

@@ -119,6 +119,7 @@ program LaRT_amd
   !--- run_simulation (main.f90:42): bounded slices so progress can be printed like par%nprint does
   call time_stamp(dtime)
   write(6,'(a,f8.3,a)') '---> Now starting simulation...  @ ', dtime/60.0_wp, ' mins'
+  if (par%save_all_photons) call lart_check(lart_gpu_enable_all_photons(ctx, 1_c_int32_t), 'lart_gpu_enable_all_photons')
   call lart_check(lart_gpu_begin(ctx, 1_c_int64_t, 1_c_int64_t, par%nphotons, int(par%iseed, c_int64_t)), 'lart_gpu_begin')
   do
      call lart_check(lart_gpu_step(ctx, 1_c_int32_t, int(par%gpu_events_per_step, c_int32_t)), 'lart_gpu_step')
@@ -158,6 +159,7 @@ program LaRT_amd
   call output_normalize(grid)
   call time_stamp(dtime); par%exetime = dtime/60.0_wp
   call write_output(trim(par%out_file), grid)
+  if (par%save_all_photons) call write_output_allph()
 
   write(6,'(a,es12.4)')   'Average Number of scattering : ', par%nscatt_tot
   write(6,'(a,2es12.4)')  'Nscatt_dust, Nscatt_gas      : ', par%nscatt_dust, par%nscatt_gas
@@ -283,6 +285,29 @@ contains
   !--- write_output_outside: `Spectrum` table + keywords (write_output_rect.f90:423-498), Jmu image (:524-539), profile
   !--- sections (:541-650), peel-off sections Scattered/Direct/Stokes_* (:1113-1344) in <base>_obs.* / <base>_stokes.*;
   !--- container by par%file_format: HDF5 <base>.h5 (reference default) or gzip FITS <base>.fits.gz
+  !--- write_output_allph (write_output_rect.f90:1353-1515): <base>_allph, one row per photon
+  subroutine write_output_allph()
+    real(wp), allocatable :: rec(:,:)
+    character(len=16) :: names(10)
+    integer :: cols(10), ncol, fmt, j
+    type(out_file) :: o
+    type(key_list) :: k0
+    allocate(rec(par%nphotons, 10))
+    call lart_check(lart_gpu_get_all_photons(ctx, rec, int(par%nphotons, c_int64_t)), 'lart_gpu_get_all_photons')
+    names(1:5) = [character(len=16) :: 'r', 'xfreq1', 'xfreq2', 'NSCATT_gas', 'NSCATT_dust']; cols(1:5) = [1, 2, 3, 4, 5]; ncol = 5
+    if (par%use_stokes) then
+       names(ncol+1:ncol+4) = [character(len=16) :: 'I', 'Q', 'U', 'V']; cols(ncol+1:ncol+4) = [6, 7, 8, 9]; ncol = ncol + 4
+    endif
+    if (trim(par%source_geometry) /= 'point') then
+       ncol = ncol + 1; names(ncol) = 'r0'; cols(ncol) = 10
+    endif
+    fmt = out_format_of(par%file_format)
+    call out_open(o, trim(par%base_name)//'_allph', fmt)
+    call out_table(o, 'AllPhotons', names(1:ncol), rec(:, cols(1:ncol)), k0)
+    call out_close(o, .true.)
+    write(*,'(2a)') 'all photons  -> ', trim(o%path)
+  end subroutine write_output_allph
+
   subroutine write_output(filename, g)
     character(len=*), intent(in) :: filename
     type(grid_type), intent(in) :: g

@@ -85,6 +85,7 @@ class Params:
     xfreq_max: float = NAN
     nxfreq: int = 121
     velocity_min: float = NAN
+    save_all_photons: bool = False  # the per-photon table of write_output_allph (Context.all_photons)
     HeI_coherent: bool = False      # line type 6: frequency-dependent E1..E3 (compute_HeI_E_coherent, line_mod.f90:8-34)
     bturb: float = -999.0           # turbulent b parameter [km/s], in quadrature with the thermal width (define.f90:928-933)
     wavelength_min: float = NAN     # angstrom; takes precedence over the velocity window (grid_mod_car.f90:1457-1461)
@@ -182,7 +183,7 @@ _UNSUPPORTED_DEFAULTS = {
     "h2_model": "none", "z_symmetry": False,
     "dens_file": "", "temp_file": "", "velo_file": "", "emiss_file": "", "cart_file": "", "input_field": "",
     "star_file": "", "use_cie_condition": False, "density_rscale": -999.9, "density_zscale": -999.9,
-    "density_alpha": 0.0, "cone_opening": 0.0, "Omega": 0.0, "save_all_photons": False, "temperature0": -999.0,
+    "density_alpha": 0.0, "cone_opening": 0.0, "Omega": 0.0, "temperature0": -999.0,
     "line_prof_file": "", "luminosity": 1.0, "save_backup": False, "save_input_grid": False,
     "intensity_unit": -999, "out_bitpix": 0,
     # the rest of the reference's namelist surface (define.f90:209-544): readable, rejected when set
@@ -1058,6 +1059,8 @@ class Simulation:
         """photon ids rank+1, rank+1+nproc, ... <= nphotons (run_equal_number, run_simulation_mod.f90:150-151)"""
         n = self.par.nphotons if nphotons is None else int(nphotons)
         count = photons_of_rank(n, rank, nproc)
+        if self.par.save_all_photons:
+            self.ctx.enable_all_photons(True)
         self.ctx.run(count, first_id=rank + 1, stride=nproc, seed=self.par.iseed if seed is None else seed)
         self.nphotons_run = n
         return count

@@ -349,6 +349,7 @@ struct orc_sim {
     /* --- HEALPix inside observers (observer_heal.f90) --- */
     int nside, npix;
     int64_t log_n; double *log_nscatt, *log_xfreq;
+    int save_all_photons; double *allph;     /* par%save_all_photons: 10 columns x log_n (r, xfreq1, xfreq2, nscatt_gas, nscatt_dust, I, Q, U, V, r0) */
 };
 
 static int grid_create_clump(orc_sim *s);
@@ -434,7 +435,7 @@ static int set_param(orc_sim *s, const char *k, const char *v) {
 #define I(name) if (!strcmp(k, #name)) { s->name = atoi(v); return 0; }
 #define B(name) if (!strcmp(k, #name)) { s->name = parse_bool(v); return 0; }
     D(no_photons) I(iseed) D(temperature) D(taumax) D(tauhomo) D(Vexp) D(Vx) D(Vy) D(Vz)
-    B(comoving_source) B(recoil) B(core_skip) B(core_skip_global) B(xyz_symmetry) B(xy_periodic) B(xy_symmetry) B(fine_structure) B(include_deuterium) B(HeI_coherent)
+    B(comoving_source) B(recoil) B(core_skip) B(core_skip_global) B(xyz_symmetry) B(xy_periodic) B(xy_symmetry) B(fine_structure) B(include_deuterium) B(HeI_coherent) B(save_all_photons)
     I(nx) I(ny) I(nz) D(xmax) D(ymax) D(zmax) D(rmax) D(rmin) D(xs_point) D(ys_point) D(zs_point) D(source_rmax)
     D(xfreq0) I(nxfreq) B(use_stokes) B(use_reduced_wgt) B(save_Jin) B(save_Jabs) B(save_Jmu) I(nmu)
     D(hgg) D(albedo) D(cext_dust) D(DGR) D(distance2cm) B(save_peeloff) B(save_peeloff_2D) B(save_peeloff_3D) B(save_direc0) B(save_dust_scattered)
@@ -2282,6 +2283,8 @@ static int dust_absorb(const orc_sim *s, acc_t *A, rng_t *g, photon_t *p) {
         if (rnd(g) > s->albedo) {
             if (s->save_Jabs) { double uu1 = udot(s, c, p->kx, p->ky, p->kz), xr = (p->xfreq + uu1) * (s->Dfreq[c] / s->Dfreq_ref);
                 int ix = (int)floor((xr - s->xfreq_min) / s->dxfreq) + 1; if (ix >= 1 && ix <= s->nxfreq) A->Jabs[ix-1] += p->wgt; }
+            if (s->save_all_photons) {                      /* scattering_car.f90:236-246, :525-535: lab-frame frequency at absorption, weight 0 */
+                double uu1 = udot(s, c, p->kx, p->ky, p->kz); p->xfreq_ref = (p->xfreq + uu1) * (s->Dfreq[c] / s->Dfreq_ref); p->wgt = 0.0; }
             p->inside = 0; return 1; }
     } else {
         if (s->save_Jabs) { double uu1 = udot(s, c, p->kx, p->ky, p->kz), xr = (p->xfreq + uu1) * (s->Dfreq[c] / s->Dfreq_ref);
@@ -2428,8 +2431,23 @@ static void add_escaped_fraction_to_Jout(const orc_sim *s, acc_t *A, const photo
             A->Jmu[(size_t)(ix - 1) + (size_t)s->nxfreq * (imu - 1)] += wgt_esc; } }
 }
 /* one photon: run_equal_number body, run_simulation_mod.f90:155-192 */
-static void run_photon(const orc_sim *s, acc_t *A, rng_t *g, photon_t *p) {
+/* make_all_initial_photons / make_all_photons: run_simulation_mod.f90:249-358 */
+static double allph_impact(const orc_sim *s, const photon_t *p, double *mx, double *my, double *mz) {
+    double xp = p->x, yp = p->y, zp = p->z;
+    if (s->rmax > 0.0) {
+        double rr = p->x * p->x + p->y * p->y + p->z * p->z, dist = 0.0;
+        if (rr > s->rmax * s->rmax) { double rk = p->x * p->kx + p->y * p->ky + p->z * p->kz, det = rk * rk - (rr - s->rmax * s->rmax);
+            dist = det < 0.0 ? 0.0 : -rk + sqrt(fmax(0.0, det)); }
+        xp = p->x + dist * p->kx; yp = p->y + dist * p->ky; zp = p->z + dist * p->kz;
+    }
+    double rk = xp * p->kx + yp * p->ky + zp * p->kz;
+    *mx = xp - rk * p->kx; *my = yp - rk * p->ky; *mz = zp - rk * p->kz;
+    return sqrt((*mx) * (*mx) + (*my) * (*my) + (*mz) * (*mz));
+}
+static void run_photon(const orc_sim *s, acc_t *A, rng_t *g, photon_t *p, int64_t k) {
     generate_photon(s, A, g, p);
+    const int64_t n = s->log_n; double *R = s->save_all_photons ? s->allph : NULL;
+    if (R) { R[1 * n + k] = p->xfreq; if (s->source_geometry != 0) { double mx, my, mz; R[9 * n + k] = allph_impact(s, p, &mx, &my, &mz); } }
     int first = 1; double tau, tau0, wgt1;
     while (p->inside) {
         if (first) {
@@ -2444,6 +2462,13 @@ static void run_photon(const orc_sim *s, acc_t *A, rng_t *g, photon_t *p) {
         if (p->inside) scattering(s, A, g, p);
     }
     A->nscatt_gas += p->nscatt_gas; A->nscatt_dust += p->nscatt_dust;
+    if (R) { double mx, my, mz, mm = allph_impact(s, p, &mx, &my, &mz), cos2p = 1.0, sin2p = 0.0;
+        R[k] = mm; R[2 * n + k] = p->xfreq_ref; R[3 * n + k] = p->nscatt_gas; R[4 * n + k] = p->nscatt_dust;
+        if (s->use_stokes) {
+            if (mm > 0.0) { mx = mx / mm; my = my / mm; mz = mz / mm;
+                double cosp = mx * p->mx + my * p->my + mz * p->mz, sinp = mx * p->nx + my * p->ny + mz * p->nz;
+                cos2p = 2.0 * cosp * cosp - 1.0; sin2p = 2.0 * sinp * cosp; }
+            R[5 * n + k] = p->wgt; R[6 * n + k] = (cos2p * p->Q + sin2p * p->U) * p->wgt; R[7 * n + k] = (-sin2p * p->Q + cos2p * p->U) * p->wgt; R[8 * n + k] = p->V * p->wgt; } }
 }
 
 static void acc_alloc(acc_t *A, orc_sim *s) {
@@ -2476,6 +2501,7 @@ static void acc_merge_free(acc_t *A, orc_sim *s) {
 int orc_run(orc_sim *s, int64_t first_id, int64_t stride, int64_t count, int rng_kind, uint64_t seed, int nthreads) {
     if (nthreads < 1) nthreads = 1;
     free(s->log_nscatt); free(s->log_xfreq);
+    free(s->allph); s->allph = s->save_all_photons ? calloc((size_t)(count > 0 ? count : 1) * 10, 8) : NULL;
     s->log_n = count; s->log_nscatt = calloc(count > 0 ? count : 1, 8); s->log_xfreq = calloc(count > 0 ? count : 1, 8);
     acc_t *accs = malloc(nthreads * sizeof(acc_t));
     for (int t = 0; t < nthreads; t++) acc_alloc(&accs[t], s);
@@ -2491,13 +2517,13 @@ int orc_run(orc_sim *s, int64_t first_id, int64_t stride, int64_t count, int rng
         if (rng_kind == 0) {   /* static interleave over workers, seed + 9999*worker: run_simulation_mod.f90:150-151, random_mt.f90:940-953 */
             memset(&g, 0, sizeof g); g.kind = 0; g.mt = &mt; mt_init(&mt, (int64_t)(int32_t)((int32_t)seed + 9999 * tid));
             for (int64_t k = tid; k < count; k += nthreads) { memset(&p, 0, sizeof p); p.id = (double)(first_id + k * stride);
-                run_photon(s, A, &g, &p); s->log_nscatt[k] = p.nscatt_gas + p.nscatt_dust; s->log_xfreq[k] = p.xfreq_ref; }
+                run_photon(s, A, &g, &p, k); s->log_nscatt[k] = p.nscatt_gas + p.nscatt_dust; s->log_xfreq[k] = p.xfreq_ref; }
         } else {
 #ifdef _OPENMP
 #pragma omp for schedule(dynamic, 1)
 #endif
             for (int64_t k = 0; k < count; k++) { memset(&p, 0, sizeof p); uint64_t id = (uint64_t)(first_id + k * stride); p.id = (double)id;
-                rng_philox(&g, seed, id, 0); run_photon(s, A, &g, &p); s->log_nscatt[k] = p.nscatt_gas + p.nscatt_dust; s->log_xfreq[k] = p.xfreq_ref; }
+                rng_philox(&g, seed, id, 0); run_photon(s, A, &g, &p, k); s->log_nscatt[k] = p.nscatt_gas + p.nscatt_dust; s->log_xfreq[k] = p.xfreq_ref; }
         }
     }
     for (int t = 0; t < nthreads; t++) acc_merge_free(&accs[t], s);
@@ -2558,6 +2584,7 @@ double orc_get_scalar(const orc_sim *s, const char *k) {
 static int64_t copy_out(const double *src, int64_t cnt, double *out, int64_t n) { if (!src) return -1; for (int64_t i = 0; i < cnt && i < n; i++) out[i] = src[i]; return cnt; }
 int64_t orc_get_array(const orc_sim *s, const char *k, double *out, int64_t n) {
     int64_t nc = (int64_t)s->nx * s->ny * s->nz;
+    if (!strcmp(k, "allph")) return s->allph ? copy_out(s->allph, s->log_n * 10, out, n) : 0;
     if (!strcmp(k, "line_multiplet")) {                     /* type, nup, ndown[3], f12[3], delE_Hz[3], damping_up[3], then [iup][idown]: A21, Elow_Hz, E1, E2, E3, P_down, A_down */
         double v[98]; int q = 0;
         v[q++] = s->line_type; v[q++] = s->ml.nup;

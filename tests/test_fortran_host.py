@@ -466,7 +466,8 @@ def test_xy_symmetry_dry_run_equals_python_host(exe, tmp_path):
 @pytest.mark.parametrize("vel", [" par%velocity_type = 'rotating_galaxy_halo'\n par%Vrot = 100.0\n par%rinner = 0.2\n",
                                  " par%velocity_type = 'ssh'\n par%Vpeak = 120.0\n par%rpeak = 0.3\n par%DeltaV = -60.0\n",
                                  " par%velocity_type = 'hubble'\n par%Vexp = 80.0\n par%include_deuterium = .true.\n par%D_to_H_ratio = 0.02\n par%recoil = .true.\n",
-                                 " par%velocity_type = 'hubble'\n par%Vexp = 40.0\n par%line_id = 'FeII_UV1'\n par%bturb = 4.0\n"])
+                                 " par%velocity_type = 'hubble'\n par%Vexp = 40.0\n par%line_id = 'FeII_UV1'\n par%bturb = 4.0\n",
+                                 " par%velocity_type = 'hubble'\n par%Vexp = 20.0\n par%save_all_photons = .true.\n"])
 def test_velocity_fields_end_to_end_match_python_host(exe, tmp_path, vel):
     """the analytic velocity fields of grid_create (grid_mod_car.f90:786-946) as examples/rotating_galaxy_halo uses them"""
     text = ("&parameters\n par%no_photons = 20000\n par%temperature = 1e4\n par%N_HImax = 1e16\n par%rmax = 1.0\n par%nx = 31\n par%ny = 31\n par%nz = 31\n"
@@ -481,6 +482,9 @@ def test_velocity_fields_end_to_end_match_python_host(exe, tmp_path, vel):
     t = sim.output_normalize()
     H = read_h5(str(tmp_path / "rot.h5"))
     assert np.allclose(H["Spectrum"][1]["Jout"], t["Jout"], rtol=1e-9, atol=1e-15)
+    if "save_all_photons" in vel:                              # <base>_allph (write_output_allph): one row per photon, the columns of a non-Stokes point source
+        P = read_h5(str(tmp_path / "rot_allph.h5"))["AllPhotons"][1]; a = sim.ctx.all_photons(20000)
+        assert list(P) == ["r", "xfreq1", "xfreq2", "NSCATT_gas", "NSCATT_dust"] and all(np.array_equal(P[k], a[k]) for k in P)
     for k in (0, 1):
         O = read_h5(str(tmp_path / ("rot_obs_%03d.h5" % (k + 1))))
         assert np.allclose(O["Scattered"][1], t["scatt"][..., k], rtol=1e-6, atol=1e-12 * t["scatt"].max())
@@ -494,7 +498,7 @@ def test_whole_namelist_surface_is_readable(exe, tmp_path):
     r = run(exe, ok, tmp_path, "--dry-run", name="all.in")
     assert r.returncode == 0, r.stdout + r.stderr
     for bad in ("par%f_H2 = 1e-3", "par%cone_opening = 30.0", "par%clump_allow_overlap = .true.", "par%stellar_radius = 0.1", "par%Omega = 28.0",
-                "par%xmin = -1.0", "par%save_all_photons = .true.", "par%ionization_model = 'file'", "par%phase_angle = 10.0, 20.0"):
+                "par%xmin = -1.0", "par%h2_model = 'simple'", "par%ionization_model = 'file'", "par%phase_angle = 10.0, 20.0"):
         r = run(exe, "&parameters\n par%temperature = 1e4\n par%taumax = 1e2\n " + bad + "\n/\n", tmp_path, "--dry-run", name="bad.in")
         assert r.returncode != 0 and "not supported" in r.stdout and bad.split()[0][4:] in r.stdout, bad
     r = run(exe, "&parameters\n par%metalz = 1.0\n/\n", tmp_path, "--dry-run", name="bad2.in")

@@ -771,3 +771,31 @@ def test_clump_known_answer_and_boundary(capi):
         sim.ctx.set_clumps(*args[:17], bad, c.cg_list)
     with pytest.raises(RuntimeError, match="profile tallies"):
         sim.ctx.set_JPa(True, False, False, 1, np.ones(1, dtype=np.int32), 1e-13)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(temperature=1e4, taumax=3e1, nx=21, ny=21, nz=21, rmax=1.0, nxfreq=81, iseed=31, save_all_photons=True, source_geometry="uniform_sphere"),
+    dict(temperature=1e4, taumax=1e1, nx=21, ny=21, nz=21, rmax=1.0, nxfreq=81, iseed=32, save_all_photons=True, use_stokes=True, DGR=3e5, velocity_type="hubble",
+         Vexp=30.0),
+    dict(temperature=1e4, taumax=1e1, nx=15, ny=15, nz=21, xmax=1.0, ymax=1.0, zmax=1.5, geometry="rectangle", nxfreq=81, iseed=33, save_all_photons=True,
+         save_Jabs=False, DGR=3e5)])
+def test_save_all_photons_table(capi, oracle_mod, mueller_file, kw):
+    """par%save_all_photons: the per-photon record of make_all_initial_photons / make_all_photons (impact parameters, birth and exit
+    frequencies, scattering counts, Stokes vector in the frame of the impact vector, weight 0 for dust-absorbed photons)"""
+    kw = dict(kw)
+    if kw.get("use_stokes"):
+        kw["scatt_mat_file"] = mueller_file
+    n = 20000
+    sim = make(kw); sim.run_simulation(n); g = sim.ctx.all_photons(n)
+    o = oracle_of(oracle_mod, kw); o.run(n, seed=kw["iseed"])
+    r = o.array("allph").reshape(10, n)
+    cols = ["r", "xfreq1", "xfreq2", "NSCATT_gas", "NSCATT_dust"] + (["I", "Q", "U", "V"] if kw.get("use_stokes") else []) + (["r0"] if kw.get("source_geometry") else [])
+    idx = dict(r=0, xfreq1=1, xfreq2=2, NSCATT_gas=3, NSCATT_dust=4, I=5, Q=6, U=7, V=8, r0=9)
+    same = np.isclose(g["NSCATT_gas"], r[3], rtol=1e-12, atol=0) & np.isclose(g["xfreq2"], r[2], rtol=1e-7, atol=1e-9)
+    assert same.mean() > 0.97, same.mean()                     # the same histories (a last-bit libm difference may flip a rejection)
+    for c in cols:
+        assert np.allclose(g[c][same], r[idx[c]][same], rtol=1e-7, atol=1e-9), c
+    assert np.isclose(g["xfreq1"], r[1], rtol=1e-9, atol=1e-12).mean() > 0.999      # the same births (tan() near its poles amplifies a last-bit libm difference)
+    if kw.get("DGR"):
+        if kw.get("use_stokes"):
+            assert (g["I"][same] == 0.0).sum() == (r[5][same] == 0.0).sum() > 0      # dust-absorbed photons carry weight 0
