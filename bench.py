@@ -17,6 +17,16 @@ events on the launch stream.  The kernel is fp64-ALU/latency bound, not HBM boun
 is expected to be tiny and is reported as such.
 cpu_baseline = the CPU oracle (a port, oracle/lart_oracle.c) on a bounded sample of the same workload on the
 host cores of this box (rank 0, N = 1 only).
+
+After the timed region (not part of `value`): --completion-photons photons per GPU of the same workload are run to the last
+photon.  That gives (a) the other half of BASELINE.json's metric, "spectrum_rms_vs_ref" = rms difference of the normalised
+emergent spectrum Jout against the committed tau0 = 1e6 reference spectrum tests/golden/c2_tau6.npz (CPU oracle on the
+reference's MT19937-64 stream, tools/gen_golden_bigtau.py), quoted next to the Poisson-expected rms of the two runs, and
+(b) "run_to_completion" = total events / wall time including the drain tail (lane compaction).
+
+--gpus N > 1 without a torchrun environment: this process starts `python -m torch.distributed.run --nproc-per-node N` on
+itself as a child BEFORE touching the GPU and returns its exit code; the printed n_gpus is the rank count RCCL reported for
+the library's own communicator (lart_gpu_comm_info), and the run fails if that differs from --gpus.
 """
 import argparse
 import json
@@ -42,9 +52,23 @@ def main():
     ap.add_argument("--cpu-photons", type=int, default=0, help="oracle sample size (0 = auto, ~20 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the tally reduction even with one rank (rehearsal of the N>1 path)")
+    ap.add_argument("--completion-photons", type=int, default=1000000, help="photons per GPU run to the last photon after the timed region "
+                    "(spectrum_rms_vs_ref + run_to_completion); 0 = skip")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: start one rank per GPU as a child job (nothing in this process has touched the GPU yet) and hand its code back
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started %d rank(s)" % (a.gpus, world))
     import torch
     import torch.distributed as dist
     use_dist = world > 1 or a.force_dist
@@ -95,12 +119,18 @@ def main():
         dt = float(mx[3])
     ev_all, cells_all, done_all = float(tot[0]), float(tot[1]), float(tot[2])
 
-    # the path's only exchange step: one RCCL sum of the fused tally buffer (output_reduce)
+    # the path's only exchange step: one RCCL reduce(sum, f64) of the fused tally buffer onto rank 0 (output_reduce), done by the
+    # library's own communicator; the first call also creates it, so time a second one
+    sim.output_reduce(dist if use_dist else None, force=a.force_dist)
+    n_rccl = sim.ctx.comm_info()[0] if use_dist else 1
+    if n_rccl != world:
+        sys.exit("bench.py: RCCL reports %d rank(s), expected %d" % (n_rccl, world))
     t_r0 = time.perf_counter()
     sim.output_reduce(dist if use_dist else None, force=a.force_dist)
-    torch.cuda.synchronize()
     reduce_ms = (time.perf_counter() - t_r0) * 1e3
     _, ntally = sim.ctx.tally_buffer()
+
+    completion = run_to_completion(sim, a, rank, world, dist if use_dist else None, barrier) if a.completion_photons > 0 else None
 
     if rank == 0:
         launches = max(nl_b - nl_a, 1)
@@ -112,7 +142,7 @@ def main():
         traffic = pmc_traffic(a.events_per_step)
         out = {
             "metric": "scattering events/sec (whole node), tau0=1e6 sphere",
-            "value": ev_all / dt, "unit": "events/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "value": ev_all / dt, "unit": "events/s", "n_gpus": n_rccl, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "examples/sphere/t1tau6.in: static uniform sphere tau0=1e6, T=10K, 101^3 xyz_symmetry octant, "
@@ -125,12 +155,60 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_launch,
                          "note": "fp64 ALU/latency-bound path; see DESIGN.md 'Roofline' for the VALU accounting"},
         }
+        if completion is not None:
+            out["spectrum_rms_vs_ref"] = completion.pop("spectrum_rms_vs_ref")
+            out["spectrum"] = completion.pop("spectrum")
+            out["run_to_completion"] = completion
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_photons)
+            out["cpu_baseline"]["reference_events_per_s_per_core"] = 2.8e6   # the reference's own Fortran, 1 core, this workload
         print(json.dumps(out))
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def run_to_completion(sim, a, rank, world, dist, barrier):
+    """--completion-photons photons per GPU of the same workload, to the last photon: throughput with the drain tail, and the
+    emergent spectrum against the committed tau0 = 1e6 reference spectrum (outside the timed region of `value`)."""
+    import numpy as np
+    import torch
+    nph = a.completion_photons * world
+    sim.ctx.zero_tallies()
+    count = (nph - rank - 1) // world + 1 if nph > rank else 0
+    barrier()
+    t0 = time.perf_counter()
+    sim.ctx.begin(count, first_id=rank + 1, stride=world, seed=WORKLOAD["iseed"] + 1)
+    launches = 0
+    while True:
+        sim.ctx.step(1, a.events_per_step); launches += 1
+        if sim.ctx.sync()[1] == 0:
+            break
+    barrier()
+    dt = time.perf_counter() - t0
+    live, ncompact = sim.ctx.live_lanes()
+    if dist is not None:
+        mx = torch.tensor([dt], dtype=torch.float64, device="cuda"); dist.all_reduce(mx, op=dist.ReduceOp.MAX); dt = float(mx[0])
+    sim.output_reduce(dist, force=a.force_dist)
+    if rank != 0:
+        return None
+    t = sim.ctx.tallies()
+    out = {"photons": int(t["nphotons_done"]), "events": t["n_events"], "seconds": dt, "value": t["n_events"] / dt, "unit": "events/s",
+           "launches": launches, "lane_compactions": ncompact, "mean_scatterings": t["nscatt_gas"] / max(t["nphotons_done"], 1)}
+    fx = os.path.join(ROOT, "tests", "golden", "c2_tau6.npz")
+    out["spectrum_rms_vs_ref"] = None; out["spectrum"] = {"fixture": None}
+    if os.path.exists(fx):
+        d = np.load(fx)
+        scale = float(d["Jout_scale_per_photon"]) * t["nphotons_done"]
+        jg, sg = t["Jout"] / scale, np.sqrt(t["Jout"]) / scale          # weights are 1 - exp(-tau0) = 1 here: Poisson error of a bin = sqrt(sum)
+        jr, sr = d["Jout"], d["Jout_err"]
+        pk = jr.max()
+        out["spectrum_rms_vs_ref"] = float(np.sqrt(np.mean((jg - jr) ** 2)) / pk)
+        out["spectrum"] = {"fixture": "tests/golden/c2_tau6.npz", "definition": "sqrt(mean_i (J_gpu,i - J_ref,i)^2) / max_i J_ref,i over the nxfreq bins of normalised Jout",
+                           "rms_expected_poisson": float(np.sqrt(np.mean(sg ** 2 + sr ** 2)) / pk), "ref_photons": int(d["nphotons"]), "gpu_photons": int(t["nphotons_done"]),
+                           "chi2_per_bin": float(np.mean((jg - jr) ** 2 / np.maximum(sg ** 2 + sr ** 2, 1e-300))),
+                           "mean_scatterings_gpu": out["mean_scatterings"], "mean_scatterings_ref": float(d["nscatt_mean"]), "mean_scatterings_ref_err": float(d["nscatt_err"])}
+    return out
 
 
 def pmc_traffic(events_per_step):

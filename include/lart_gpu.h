@@ -213,6 +213,15 @@ int  lart_gpu_get_all_photons(lart_gpu *ctx, double *out, int64_t n);
 /* pool geometry knobs (0 = default): resident photon lanes and threads per workgroup */
 int  lart_gpu_set_pool(lart_gpu *ctx, int64_t nlanes, int32_t block);
 int  lart_gpu_pool_info(lart_gpu *ctx, int64_t *nlanes, int32_t *block);   /* valid after lart_gpu_begin */
+/* Lane compaction = the role of the reference's dynamic master/worker scheduler (run_simulation_mod.f90:31-64: no worker
+ * idles while photons are left).  A lane refills itself from the photon counter; once the counter is exhausted the pool
+ * drains, and lart_gpu_step packs the live lanes to the front of the pool and launches a smaller grid whenever fewer than
+ * 3/4 of the launched lanes are still alive (after a lart_gpu_sync told it so).  lart_gpu_compact forces one pass;
+ * lart_gpu_set_auto_compact(ctx, 0) switches the automatic pass off; lart_gpu_live_lanes reports the lanes the next launch
+ * covers and the number of passes since lart_gpu_begin.  Results do not depend on it: a history is a function of (seed, id). */
+int  lart_gpu_compact(lart_gpu *ctx);
+int  lart_gpu_set_auto_compact(lart_gpu *ctx, int32_t on);
+int  lart_gpu_live_lanes(lart_gpu *ctx, int64_t *live_lanes, int64_t *ncompactions);
 
 /* replaces `call make_sightline_tau(grid)` (main.f90:36; make_sightline_tau_outside / _outside_amr sightline_tau_rect.f90:11-345,
  * make_sightline_tau_inside / _inside_amr sightline_tau_heal.f90:11-290, make_sightline_tau_clump sightline_tau_clump.f90:33-155):
@@ -224,12 +233,30 @@ int  lart_gpu_pool_info(lart_gpu *ctx, int64_t *nlanes, int32_t *block);   /* va
 int  lart_gpu_sightline_tau(lart_gpu *ctx, double cross0, double *tau_gas, double *N_gas, double *tau_dust);
 int  lart_gpu_sightline_time(lart_gpu *ctx, double *kernel_ms);   /* device time of the last map (HIP events) */
 
-/* replaces `call output_reduce(grid)` (main.f90:46): with one process per GPU the fused device tally
- * buffer is summed across ranks by the caller's RCCL collective (torch.distributed / ncclReduce) on the
- * pointer returned here, then copied out by lart_gpu_get_tallies. */
+/* replaces `call output_reduce(grid)` (main.f90:46; output_reduce_outside output_sum_rect.f90:7-149 -> reduce_mem =
+ * MPI_REDUCE(SUM) to rank 0, memory_mod_mpi.f90:366-394): ONE ncclReduce(sum, f64) over xGMI of the fused device tally buffer
+ * [scalars | Jout | Jin | Jabs | Jmu | peel cubes and images | J1 | P1 | P1_new] to the root context, then lart_gpu_get_tallies
+ * on the root copies the totals out.
+ *   one process per GPU (mpirun / torchrun ranks): rank 0 calls lart_gpu_comm_unique_id, the host shares the 128 bytes
+ *     (MPI_BCAST in a Fortran host), every rank calls lart_gpu_comm_init(ctx, id, nranks, rank), then lart_gpu_reduce_tallies(ctx, root);
+ *   one process, all GPUs of the node: lart_gpu_run_multi(ctx[], n, nphotons, seed, max_events) transports the photons
+ *     r+1, r+1+n, ... on context r (run_simulation_mod.f90:150-151) and lart_gpu_reduce_tallies_multi(ctx[], n, root) sums them
+ *     (communicator from ncclCommInitAll on first use).
+ * lart_gpu_comm_info reports the rank count RCCL itself saw (ncclCommCount).  The device pointer is still available for a
+ * caller-owned collective (lart_gpu_tally_buffer). */
+int  lart_gpu_comm_unique_id(uint8_t *id128);
+int  lart_gpu_comm_init(lart_gpu *ctx, const uint8_t *id128, int32_t nranks, int32_t rank);
+int  lart_gpu_comm_info(lart_gpu *ctx, int32_t *nranks, int32_t *rank);
+int  lart_gpu_comm_destroy(lart_gpu *ctx);
+int  lart_gpu_reduce_tallies(lart_gpu *ctx, int32_t root);
+int  lart_gpu_reduce_tallies_multi(lart_gpu **ctx, int32_t n, int32_t root);
+int  lart_gpu_run_multi(lart_gpu **ctx, int32_t n, int64_t nphotons, uint64_t seed, int32_t max_events);
 int  lart_gpu_tally_buffer(lart_gpu *ctx, void **device_ptr, int64_t *n_doubles);
 int  lart_gpu_zero_tallies(lart_gpu *ctx);
 int  lart_gpu_get_tallies(lart_gpu *ctx, lart_tallies *out);
+/* par%iseed = 0 means "seed from the operating system" in the reference (init_random_mt_seed: /dev/urandom, else clock xor pid,
+ * random_mt.f90:889-947).  The hosts call this once, print the value and use it as the Philox key on every rank. CPU, no device. */
+int  lart_host_entropy_seed(uint64_t *seed);
 
 /* device-function probes used by the parity tests (each runs a tiny kernel, one lane per element) */
 int  lart_gpu_test_voigt(lart_gpu *ctx, int32_t n, const double *x, const double *a, double *h);

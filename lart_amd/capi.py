@@ -45,6 +45,9 @@ SYMBOLS = ["lart_host_line_lookup", "lart_gpu_set_line_multiplet", "lart_gpu_dev
            "lart_gpu_begin", "lart_gpu_step", "lart_gpu_sync", "lart_gpu_kernel_time", "lart_gpu_sightline_tau", "lart_gpu_sightline_time",
            "lart_gpu_enable_photon_log", "lart_gpu_get_photon_log", "lart_gpu_enable_all_photons", "lart_gpu_get_all_photons", "lart_gpu_set_pool", "lart_gpu_pool_info",
            "lart_gpu_tally_buffer", "lart_gpu_zero_tallies", "lart_gpu_get_tallies",
+           "lart_gpu_compact", "lart_gpu_set_auto_compact", "lart_gpu_live_lanes",
+           "lart_gpu_comm_unique_id", "lart_gpu_comm_init", "lart_gpu_comm_info", "lart_gpu_comm_destroy", "lart_gpu_reduce_tallies",
+           "lart_gpu_reduce_tallies_multi", "lart_gpu_run_multi", "lart_host_entropy_seed",
            "lart_gpu_test_voigt", "lart_gpu_test_rand", "lart_gpu_test_raytrace", "lart_gpu_test_vec2pix", "lart_gpu_test_scatter"]
 
 _lib = None
@@ -92,6 +95,17 @@ def lib():
         L.lart_gpu_tally_buffer.argtypes = [_vp, C.POINTER(_vp), C.POINTER(_i64)]
         L.lart_gpu_zero_tallies.argtypes = [_vp]
         L.lart_gpu_get_tallies.argtypes = [_vp, C.POINTER(LartTallies)]
+        L.lart_gpu_compact.argtypes = [_vp]
+        L.lart_gpu_set_auto_compact.argtypes = [_vp, _i32]
+        L.lart_gpu_live_lanes.argtypes = [_vp, C.POINTER(_i64), C.POINTER(_i64)]
+        L.lart_gpu_comm_unique_id.argtypes = [_vp]
+        L.lart_gpu_comm_init.argtypes = [_vp, _vp, _i32, _i32]
+        L.lart_gpu_comm_info.argtypes = [_vp, C.POINTER(_i32), C.POINTER(_i32)]
+        L.lart_gpu_comm_destroy.argtypes = [_vp]
+        L.lart_gpu_reduce_tallies.argtypes = [_vp, _i32]
+        L.lart_gpu_reduce_tallies_multi.argtypes = [_vp, _i32, _i32]
+        L.lart_gpu_run_multi.argtypes = [_vp, _i32, _i64, _u64, _i32]
+        L.lart_host_entropy_seed.argtypes = [C.POINTER(_u64)]
         L.lart_gpu_test_voigt.argtypes = [_vp, _i32, _vp, _vp, _vp]
         L.lart_gpu_test_rand.argtypes = [_vp, _i32, _u64, _u64, _i32, _d, _d, _vp]
         L.lart_gpu_test_raytrace.argtypes = [_vp, _i32, _i32, _vp, _vp, _vp, _vp]
@@ -119,6 +133,33 @@ def pack_multiplet(m):
 
 class LartError(RuntimeError):
     pass
+
+
+def entropy_seed():
+    """lart_host_entropy_seed: the Philox key for par%iseed = 0 (the reference seeds from /dev/urandom then, random_mt.f90:889-947)"""
+    v = _u64()
+    if lib().lart_host_entropy_seed(C.byref(v)) != 0:
+        raise LartError("lart_host_entropy_seed failed")
+    return int(v.value)
+
+
+def comm_unique_id():
+    """lart_gpu_comm_unique_id: the 128 bytes rank 0 shares with the other ranks before lart_gpu_comm_init"""
+    b = (C.c_uint8 * 128)()
+    _chk(lib().lart_gpu_comm_unique_id(b))
+    return bytes(b)
+
+
+def run_multi(contexts, nphotons, seed, max_events=4096):
+    """lart_gpu_run_multi: one host thread, context r transports the photons r+1, r+1+n, ..."""
+    arr = (_vp * len(contexts))(*[c.h for c in contexts])
+    _chk(lib().lart_gpu_run_multi(arr, len(contexts), int(nphotons), int(seed), int(max_events)))
+
+
+def reduce_tallies_multi(contexts, root=0):
+    """lart_gpu_reduce_tallies_multi: ncclReduce(sum, f64) of the fused tally buffers of the contexts of this process"""
+    arr = (_vp * len(contexts))(*[c.h for c in contexts])
+    _chk(lib().lart_gpu_reduce_tallies_multi(arr, len(contexts), int(root)))
 
 
 def _chk(rc):
@@ -227,6 +268,32 @@ class Context:
         n, b = _i64(), _i32()
         _chk(lib().lart_gpu_pool_info(self.h, C.byref(n), C.byref(b)))
         return n.value, b.value
+
+    def compact(self):
+        _chk(lib().lart_gpu_compact(self.h))
+
+    def set_auto_compact(self, on=True):
+        _chk(lib().lart_gpu_set_auto_compact(self.h, int(on)))
+
+    def live_lanes(self):
+        n, k = _i64(), _i64()
+        _chk(lib().lart_gpu_live_lanes(self.h, C.byref(n), C.byref(k)))
+        return n.value, k.value
+
+    def comm_init(self, unique_id, nranks, rank):
+        b = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        _chk(lib().lart_gpu_comm_init(self.h, b, int(nranks), int(rank)))
+
+    def comm_info(self):
+        n, r = _i32(), _i32()
+        _chk(lib().lart_gpu_comm_info(self.h, C.byref(n), C.byref(r)))
+        return n.value, r.value
+
+    def comm_destroy(self):
+        _chk(lib().lart_gpu_comm_destroy(self.h))
+
+    def reduce_tallies(self, root=0):
+        _chk(lib().lart_gpu_reduce_tallies(self.h, int(root)))
 
     def enable_photon_log(self, on=True):
         _chk(lib().lart_gpu_enable_photon_log(self.h, int(on)))

@@ -2,11 +2,14 @@
 // Host side is plain HIP runtime calls on one stream per context; no torch types, no CPU fallback.
 #include "transport_kernel.hpp"
 #include "sightline.hpp"
+#include <rccl/rccl.h>
+#include <unistd.h>
 #include <string>
 #include <vector>
 #include <cstring>
 #include <cstdio>
 #include <cmath>
+#include <ctime>
 
 extern "C" void lart_launch_transport_var0(int, int, int, dim3, dim3, size_t, hipStream_t, const KArgs &);
 extern "C" void lart_launch_transport_var1(int, int, int, dim3, dim3, size_t, hipStream_t, const KArgs &);
@@ -50,6 +53,11 @@ struct lart_gpu {
     int log_on = 0; double *d_log = nullptr; int64_t nlog = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; double kernel_ms = 0.0; int64_t nlaunch = 0;
     double sight_ms = 0.0;                                   // device time of the last sight-line map
+    // lane compaction: the launch covers lanes [0, live_lanes); state of the last lart_gpu_sync
+    int64_t live_lanes = 0; bool state_valid = false; int64_t last_alive = 0, last_next_k = 0; int auto_compact = 1;
+    int *d_compact = nullptr; int64_t n_compactions = 0;
+    // output_reduce across GPUs: RCCL communicator of this context (one rank per context)
+    ncclComm_t comm = nullptr; int comm_n = 0, comm_rank = -1;
 };
 
 extern "C" const char *lart_gpu_last_error(void) { return g_err.c_str(); }
@@ -82,13 +90,23 @@ static void free_tally(lart_gpu *c) {
     if (c->rep.base) { (void)hipFree(c->rep.base); } c->rep = DRep{}; c->rep_dirty = false;
 }
 
+// a setter replaces device tables a resident photon pool refers to: wait for the stream, drop the tally layout and end the current
+// run, so that lart_gpu_step cannot launch with stale pointers (the caller has to lart_gpu_begin again)
+static void invalidate_run(lart_gpu *c) {
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    free_tally(c);
+    c->begun = false; c->state_valid = false;
+}
+
 extern "C" int lart_gpu_destroy(lart_gpu *c) {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (auto &e : c->ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     (void)hipFree(c->d_cell); (void)hipFree(c->d_faces); (void)hipFree(c->d_mu); (void)hipFree(c->d_alias); (void)hipFree(c->d_ml_tab); (void)hipFree(c->d_ml_itab); (void)hipFree(c->d_obs); (void)hipFree(c->d_ind_bin); (void)hipFree(c->d_amr_int); (void)hipFree(c->d_amr_geom); (void)hipFree(c->d_cl_geo); (void)hipFree(c->d_cl_phys); (void)hipFree(c->d_cl_int);
-    free_tally(c); (void)hipFree(c->d_pool); (void)hipFree(c->d_ctl); (void)hipFree(c->d_log);
+    free_tally(c); (void)hipFree(c->d_pool); (void)hipFree(c->d_ctl); (void)hipFree(c->d_log); (void)hipFree(c->d_compact);
+    if (c->comm) { (void)ncclCommDestroy(c->comm); c->comm = nullptr; }
     (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -163,7 +181,7 @@ extern "C" int lart_gpu_set_grid_car(lart_gpu *c, int32_t nx, int32_t ny, int32_
     c->g.nx = nx; c->g.ny = ny; c->g.nz = nz; c->g.i0 = i0; c->g.j0 = j0; c->g.k0 = k0;
     c->g.xmin = xmin; c->g.ymin = ymin; c->g.zmin = zmin; c->g.dx = dx; c->g.dy = dy; c->g.dz = dz;
     c->g.cell = c->d_cell; c->g.faces = c->d_faces; c->ncell = nc; c->has_dust_table = rhokapD != nullptr;
-    c->is_amr = false; c->is_clump = false; c->jpa.nbins = 0; free_tally(c);
+    c->is_amr = false; c->is_clump = false; c->jpa.nbins = 0; invalidate_run(c);
     return 0;
 }
 
@@ -223,7 +241,7 @@ extern "C" int lart_gpu_set_observers(lart_gpu *c, int32_t nobs, const double *x
     HIPCHK(hipMalloc(&c->d_obs, h.size() * sizeof(DObs)));
     HIPCHK(hipMemcpy(c->d_obs, h.data(), h.size() * sizeof(DObs), hipMemcpyHostToDevice));
     c->nobs = nobs; c->nxim = nxim; c->nyim = nyim; c->dxim = dxim; c->dyim = dyim; c->heal_nside = 0; h.resize(nobs > 0 ? nobs : 0); c->h_obs = h;
-    free_tally(c);
+    invalidate_run(c);
     return 0;
 }
 
@@ -241,7 +259,7 @@ extern "C" int lart_gpu_set_observers_heal(lart_gpu *c, int32_t nobs, const doub
     HIPCHK(hipMalloc(&c->d_obs, h.size() * sizeof(DObs)));
     HIPCHK(hipMemcpy(c->d_obs, h.data(), h.size() * sizeof(DObs), hipMemcpyHostToDevice));
     c->nobs = nobs; c->nxim = 12 * nside * nside; c->nyim = 1; c->dxim = 1.0; c->dyim = 1.0; c->heal_nside = nside; c->h_obs = h;
-    free_tally(c);
+    invalidate_run(c);
     return 0;
 }
 
@@ -257,7 +275,7 @@ extern "C" int lart_gpu_set_JPa(lart_gpu *c, int32_t calc_J, int32_t calc_P, int
     HIPCHK(hipMemcpy(c->d_ind_bin, ind_bin, c->ncell * sizeof(int), hipMemcpyHostToDevice));
     c->jpa.calc_J = calc_J ? 1 : 0; c->jpa.calc_P = calc_P ? 1 : 0; c->jpa.calc_Pnew = calc_Pnew ? 1 : 0;
     c->jpa.nbins = (calc_J || calc_P || calc_Pnew) ? nbins : 0; c->jpa.ind_bin = c->d_ind_bin; c->jpa.cross0 = cross0;
-    free_tally(c);
+    invalidate_run(c);
     return 0;
 }
 
@@ -317,7 +335,7 @@ extern "C" int lart_gpu_set_grid_amr(lart_gpu *c, int32_t ncells, int32_t nleaf,
     c->g = DGrid{}; c->g.nx = 1; c->g.ny = 1; c->g.nz = 1; c->g.i0 = 1; c->g.j0 = 1; c->g.k0 = 1;
     c->g.xmin = lo; c->g.ymin = lo; c->g.zmin = lo; c->g.dx = hi - lo; c->g.dy = hi - lo; c->g.dz = hi - lo;
     c->g.cell = c->d_cell; c->g.faces = c->d_faces; c->ncell = nleaf; c->has_dust_table = rhokapD != nullptr;
-    c->is_amr = true; c->is_clump = false; c->jpa.nbins = 0; free_tally(c);
+    c->is_amr = true; c->is_clump = false; c->jpa.nbins = 0; invalidate_run(c);
     return 0;
 }
 
@@ -331,7 +349,7 @@ extern "C" int lart_gpu_set_JPa_amr(lart_gpu *c, int32_t calc_J, int32_t calc_P,
     c->amr.jpa_geometry = geometry_JPa; c->amr.dr_JPa = dbin; c->amr.dz_JPa = dbin; c->amr.nr_JPa = nbins; c->amr.nz_JPa = nbins;
     c->jpa.calc_J = calc_J ? 1 : 0; c->jpa.calc_P = calc_P ? 1 : 0; c->jpa.calc_Pnew = calc_Pnew ? 1 : 0;
     c->jpa.nbins = (calc_J || calc_P || calc_Pnew) ? nbins : 0; c->jpa.ind_bin = nullptr; c->jpa.cross0 = cross0;
-    free_tally(c);
+    invalidate_run(c);
     return 0;
 }
 
@@ -383,7 +401,7 @@ extern "C" int lart_gpu_set_clumps(lart_gpu *c, int64_t n, const double *x, cons
     c->g = DGrid{}; c->g.nx = 1; c->g.ny = 1; c->g.nz = 1; c->g.i0 = 1; c->g.j0 = 1; c->g.k0 = 1;
     c->g.xmin = -sphere_R; c->g.ymin = -sphere_R; c->g.zmin = -sphere_R; c->g.dx = 2 * sphere_R; c->g.dy = 2 * sphere_R; c->g.dz = 2 * sphere_R;
     c->g.cell = c->d_cell; c->g.faces = c->d_faces; c->ncell = 1; c->has_dust_table = rhokapD != nullptr;
-    c->is_clump = true; c->is_amr = false; c->jpa.nbins = 0; free_tally(c);
+    c->is_clump = true; c->is_amr = false; c->jpa.nbins = 0; invalidate_run(c);
     return 0;
 }
 
@@ -461,10 +479,13 @@ extern "C" int lart_gpu_begin(lart_gpu *c, int64_t first_id, int64_t stride, int
         HIPCHK(hipMalloc(&c->d_log, bytes)); HIPCHK(hipMemsetAsync(c->d_log, 0, bytes, c->stream)); c->nlog = count; }
     for (auto &e : c->ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     c->ev.clear(); c->kernel_ms = 0.0; c->nlaunch = 0;
+    c->live_lanes = c->pool.n; c->state_valid = false; c->n_compactions = 0;
     c->begun = true;
     return 0;
 }
 
+extern "C" int lart_gpu_sync(lart_gpu *c, int64_t *done, int64_t *active);
+extern "C" int lart_gpu_compact(lart_gpu *c);
 static int collect_events(lart_gpu *c) {
     for (auto &e : c->ev) {
         float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, e.first, e.second));
@@ -475,10 +496,76 @@ static int collect_events(lart_gpu *c) {
     return 0;
 }
 
-extern "C" int lart_gpu_step(lart_gpu *c, int32_t nsteps, int32_t max_events) {
-    if (!c || !c->begun) return fail("step: call lart_gpu_begin first");
-    if (max_events < 1) return fail("step: max_events must be >= 1");
+// ---------------------------------------------------------------------------------------------
+// Lane compaction.  The reference keeps every worker busy with a dynamic master/worker scheduler (run_simulation_mod.f90:31-64);
+// here a lane refills itself from the photon counter, and once the counter is exhausted the pool drains: packets end at very
+// different times (<N_scatt> ~ 1e6 at tau0 = 1e6 with a spread of the same size), so waves would run on with a few live lanes.
+// Between launches the live lanes beyond the first `m` (= number alive) move into the dead slots below m and the grid shrinks to m.
+// A packet's history depends only on (seed, id), so the move changes nothing but the lane a packet sits in.
+// ---------------------------------------------------------------------------------------------
+__device__ inline int wave_slot(bool pred, unsigned *counter) {           // one atomic per wave: this lane's slot among the lanes with pred
+    const unsigned long long b = __ballot(pred);
+    const int lane = threadIdx.x & 63;
+    unsigned base = 0;
+    if (lane == 0 && b) base = atomicAdd(counter, (unsigned)__popcll(b));
+    base = __shfl(base, 0, 64);
+    return (int)(base + (unsigned)__popcll(b & ((1ull << lane) - 1ull)));
+}
+__global__ void k_compact_scan(DPool pool, long long live, long long m, int *holes, int *movers, unsigned *cnt) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in = i < live, alive = in && (pool.flags[i] & FLAG_ALIVE);
+    const bool hole = in && i < m && !alive, mover = in && i >= m && alive;
+    const int sh = wave_slot(hole, &cnt[0]), sm = wave_slot(mover, &cnt[1]);
+    if (hole) holes[sh] = (int)i;
+    if (mover) movers[sm] = (int)i;
+}
+__global__ void k_compact_move(DPool pool, const int *holes, const int *movers, const unsigned *cnt, int nplanes) {
+    const unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= cnt[1] || j >= cnt[0]) return;
+    const long long src = movers[j], dst = holes[j], P = pool.n;
+    for (int q = 0; q < nplanes; q++) pool.f[(size_t)q * P + dst] = pool.f[(size_t)q * P + src];
+    pool.rng_n[dst] = pool.rng_n[src]; pool.k[dst] = pool.k[src];
+    pool.ic[dst] = pool.ic[src]; pool.jc[dst] = pool.jc[src]; pool.kc[dst] = pool.kc[src];
+    pool.flags[dst] = pool.flags[src]; pool.flags[src] = 0;
+}
+
+extern "C" int lart_gpu_compact(lart_gpu *c) {
+    if (!c || !c->begun) return fail("compact: call lart_gpu_begin first");
     HIPCHK(hipSetDevice(c->device));
+    if (!c->state_valid) { if (lart_gpu_sync(c, nullptr, nullptr)) return 1; }
+    if (!c->state_valid) return 0;                                  // nothing launched yet
+    const int64_t m = c->last_alive, live = c->live_lanes;
+    int64_t new_live = ((m + c->block - 1) / c->block) * c->block; if (new_live < c->block) new_live = c->block;
+    if (new_live >= live) return 0;
+    if (!c->d_compact) HIPCHK(hipMalloc(&c->d_compact, ((size_t)2 * c->pool.n + 2) * sizeof(int)));
+    int *holes = c->d_compact + 2, *movers = holes + c->pool.n; unsigned *cnt = (unsigned *)c->d_compact;
+    HIPCHK(hipMemsetAsync(cnt, 0, 2 * sizeof(unsigned), c->stream));
+    hipLaunchKernelGGL(k_compact_scan, dim3((unsigned)((live + 255) / 256)), dim3(256), 0, c->stream, c->pool, (long long)live, (long long)m, holes, movers, cnt);
+    HIPCHK(hipGetLastError());
+    const int64_t nmove_max = m < live - m ? m : live - m;           // movers sit beyond m, holes below it
+    if (nmove_max > 0) {
+        hipLaunchKernelGGL(k_compact_move, dim3((unsigned)((nmove_max + 255) / 256)), dim3(256), 0, c->stream, c->pool, holes, movers, cnt, c->par.use_stokes ? (int)F_COUNT : (int)F_MX);
+        HIPCHK(hipGetLastError());
+    }
+    unsigned h[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(h, cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (h[0] != h[1]) return fail("compact: live-lane bookkeeping is inconsistent (holes != movers)");
+    c->live_lanes = new_live; c->n_compactions++;
+    return 0;
+}
+extern "C" int lart_gpu_set_auto_compact(lart_gpu *c, int32_t on) { if (!c) return fail("null context"); c->auto_compact = on ? 1 : 0; return 0; }
+extern "C" int lart_gpu_live_lanes(lart_gpu *c, int64_t *live, int64_t *ncompactions) { if (!c) return fail("null context"); if (live) *live = c->live_lanes; if (ncompactions) *ncompactions = c->n_compactions; return 0; }
+
+extern "C" int lart_gpu_step(lart_gpu *c, int32_t nsteps, int32_t max_events) {
+    if (!c || !c->begun) return fail("step: call lart_gpu_begin first (a set_* call ends the current run)");
+    if (max_events < 1) return fail("step: max_events must be >= 1");
+    if (!c->d_tally || (!c->d_cell && !c->is_clump) || !c->d_pool) return fail("step: no medium / tally buffer / photon pool on the device");
+    HIPCHK(hipSetDevice(c->device));
+    // drain phase (no photon left to refill a lane with): pack the live lanes to the front of the pool and shrink the grid
+    if (c->auto_compact && c->state_valid && c->last_next_k >= (int64_t)c->count && c->last_alive * 4 < c->live_lanes * 3 && c->live_lanes > c->block) {
+        if (lart_gpu_compact(c)) return 1;
+    }
     KArgs A{};
     A.par = c->par; A.g = c->g; A.t = c->t; A.pool = c->pool; A.mu = c->mu; A.obs = c->d_obs; A.nobs = c->par.save_peeloff ? c->nobs : 0;
     A.nxim = c->nxim; A.nyim = c->nyim; A.dxim = c->dxim; A.dyim = c->dyim; A.ctl = c->d_ctl; A.heal_nside = c->heal_nside; A.jpa = c->jpa; A.amr = c->amr; A.cl = c->cl; A.rep = c->rep; A.ml = c->ml;
@@ -487,7 +574,7 @@ extern "C" int lart_gpu_step(lart_gpu *c, int32_t nsteps, int32_t max_events) {
     A.allph = (c->d_log && c->log_on == 2) ? c->d_log + 2 * c->nlog : nullptr; A.allph_n = c->nlog;
     int var = march_variant(c);
     int stokes = c->par.use_stokes ? 1 : 0, dust = c->par.DGR > 0.0 ? 1 : 0, peel = (c->par.save_peeloff && c->nobs > 0) ? 1 : 0;
-    dim3 block(c->block), grid((unsigned)(c->pool.n / c->block));
+    dim3 block(c->block), grid((unsigned)(c->live_lanes / c->block));
     // Voigt tables + faces | ring of random draws [LART_RNG_BUF][block] | per-block P1, P1_new
     size_t shmem = (size_t)(VT_END + c->g.nx + c->g.ny + c->g.nz + 3 + LART_RNG_BUF * c->block + 2 * c->jpa.lds_bins) * sizeof(double) + (size_t)LART_COOP_BYTES * ((c->block + 63) / 64);   // ... + the wave-local scratch of vz_core_coop
     if (shmem > 160 * 1024) return fail("step: grid faces do not fit the 160 KiB LDS");
@@ -507,6 +594,7 @@ extern "C" int lart_gpu_step(lart_gpu *c, int32_t nsteps, int32_t max_events) {
         c->ev.emplace_back(e0, e1);
     }
     if (nsteps > 0 && c->rep.nrep > 1) c->rep_dirty = true;
+    if (nsteps > 0) c->state_valid = false;
     return 0;
 }
 
@@ -520,6 +608,7 @@ extern "C" int lart_gpu_sync(lart_gpu *c, int64_t *done, int64_t *active) {
     if (c->d_tally) HIPCHK(hipMemcpy(&nd, c->d_tally + 5, 8, hipMemcpyDeviceToHost));
     if (done) *done = (int64_t)(nd + 0.5);
     if (active) *active = (int64_t)h.n_active + ((int64_t)h.next_k < c->count ? (c->count - (int64_t)h.next_k) : 0);
+    if (c->begun && c->nlaunch > 0) { c->last_alive = (int64_t)h.n_active; c->last_next_k = (int64_t)h.next_k; c->state_valid = true; }
     return 0;
 }
 
@@ -598,6 +687,115 @@ extern "C" int lart_gpu_get_tallies(lart_gpu *c, lart_tallies *o) {
 #undef CP
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// output_reduce across GPUs (reference: reduce_mem = MPI_REDUCE(SUM) to rank 0, memory_mod_mpi.f90:366-394, called for every
+// tally in output_reduce_outside, output_sum_rect.f90:7-149).  Here: ONE ncclReduce(sum, f64) of the fused tally buffer to
+// the root over xGMI.  Two ways to form the communicator: one context per process (ranks started by mpirun / torchrun; the
+// host broadcasts the 128-byte unique id) or all contexts in this process (ncclCommInitAll).
+// ---------------------------------------------------------------------------------------------
+#define NCCLCHK(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) return fail(std::string(#x) + ": " + ncclGetErrorString(r_)); } while (0)
+
+extern "C" int lart_gpu_comm_unique_id(uint8_t *id128) {
+    if (!id128) return fail("comm_unique_id: null argument");
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    ncclUniqueId u; NCCLCHK(ncclGetUniqueId(&u));
+    std::memcpy(id128, &u, sizeof u);
+    return 0;
+}
+extern "C" int lart_gpu_comm_init(lart_gpu *c, const uint8_t *id128, int32_t nranks, int32_t rank) {
+    if (!c || !id128) return fail("comm_init: null argument");
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail("comm_init: need 0 <= rank < nranks");
+    HIPCHK(hipSetDevice(c->device));
+    if (c->comm) { NCCLCHK(ncclCommDestroy(c->comm)); c->comm = nullptr; }
+    ncclUniqueId u; std::memcpy(&u, id128, sizeof u);
+    NCCLCHK(ncclCommInitRank(&c->comm, nranks, u, rank));
+    int n = 0, r = -1; NCCLCHK(ncclCommCount(c->comm, &n)); NCCLCHK(ncclCommUserRank(c->comm, &r));
+    c->comm_n = n; c->comm_rank = r;
+    return 0;
+}
+extern "C" int lart_gpu_comm_info(lart_gpu *c, int32_t *nranks, int32_t *rank) {
+    if (!c) return fail("comm_info: null context");
+    if (nranks) *nranks = c->comm ? c->comm_n : 0; if (rank) *rank = c->comm ? c->comm_rank : -1;
+    return 0;
+}
+extern "C" int lart_gpu_comm_destroy(lart_gpu *c) {
+    if (!c) return fail("comm_destroy: null context");
+    if (c->comm) { (void)hipSetDevice(c->device); NCCLCHK(ncclCommDestroy(c->comm)); c->comm = nullptr; c->comm_n = 0; c->comm_rank = -1; }
+    return 0;
+}
+static int reduce_prepare(lart_gpu *c) {
+    HIPCHK(hipSetDevice(c->device));
+    if (!c->d_tally) { if (build_tally(c)) return 1; }
+    return fold_copies(c);                                    // the buffer that travels holds this GPU's totals
+}
+extern "C" int lart_gpu_reduce_tallies(lart_gpu *c, int32_t root) {
+    if (!c) return fail("reduce_tallies: null context");
+    if (!c->comm) return fail("reduce_tallies: no communicator (lart_gpu_comm_init first)");
+    if (root < 0 || root >= c->comm_n) return fail("reduce_tallies: root out of range");
+    if (reduce_prepare(c)) return 1;
+    NCCLCHK(ncclReduce(c->d_tally, c->d_tally, (size_t)c->ntally, ncclDouble, ncclSum, root, c->comm, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+// all contexts live in this process (one host thread drives the GPUs of the node)
+extern "C" int lart_gpu_reduce_tallies_multi(lart_gpu **ctx, int32_t n, int32_t root) {
+    if (!ctx || n < 1 || root < 0 || root >= n) return fail("reduce_tallies_multi: bad arguments");
+    for (int i = 0; i < n; i++) { if (!ctx[i]) return fail("reduce_tallies_multi: null context"); if (reduce_prepare(ctx[i])) return 1; }
+    for (int i = 1; i < n; i++) if (ctx[i]->ntally != ctx[0]->ntally) return fail("reduce_tallies_multi: contexts have different tally layouts");
+    for (int i = 0; i < n; i++) for (int j = 0; j < i; j++) if (ctx[i]->device == ctx[j]->device) return fail("reduce_tallies_multi: two contexts share a device");
+    if (n == 1) { HIPCHK(hipStreamSynchronize(ctx[0]->stream)); return 0; }
+    bool have = true;
+    for (int i = 0; i < n; i++) have = have && ctx[i]->comm && ctx[i]->comm_n == n && ctx[i]->comm_rank == i;
+    if (!have) {
+        std::vector<ncclComm_t> comms(n); std::vector<int> devs(n);
+        for (int i = 0; i < n; i++) { devs[i] = ctx[i]->device; if (ctx[i]->comm) { (void)hipSetDevice(ctx[i]->device); (void)ncclCommDestroy(ctx[i]->comm); ctx[i]->comm = nullptr; } }
+        NCCLCHK(ncclCommInitAll(comms.data(), n, devs.data()));
+        for (int i = 0; i < n; i++) { ctx[i]->comm = comms[i]; ctx[i]->comm_n = n; ctx[i]->comm_rank = i; }
+    }
+    NCCLCHK(ncclGroupStart());
+    for (int i = 0; i < n; i++) {
+        (void)hipSetDevice(ctx[i]->device);
+        ncclResult_t r = ncclReduce(ctx[i]->d_tally, ctx[i]->d_tally, (size_t)ctx[i]->ntally, ncclDouble, ncclSum, root, ctx[i]->comm, ctx[i]->stream);
+        if (r != ncclSuccess) { (void)ncclGroupEnd(); return fail(std::string("ncclReduce: ") + ncclGetErrorString(r)); }
+    }
+    NCCLCHK(ncclGroupEnd());
+    for (int i = 0; i < n; i++) { HIPCHK(hipSetDevice(ctx[i]->device)); HIPCHK(hipStreamSynchronize(ctx[i]->stream)); }
+    return 0;
+}
+// run_simulation over the GPUs of the node from one host thread: context r transports the photons r+1, r+1+n, ... <= nphotons
+// (the reference's static decomposition `do ip = rank+1, nphotons, nproc`, run_simulation_mod.f90:150-151); launches are
+// asynchronous per device, so the loop enqueues one slice on every GPU and then waits for all of them.
+extern "C" int lart_gpu_run_multi(lart_gpu **ctx, int32_t n, int64_t nphotons, uint64_t seed, int32_t max_events) {
+    if (!ctx || n < 1 || nphotons < 0) return fail("run_multi: bad arguments");
+    if (max_events < 1) max_events = 4096;
+    for (int r = 0; r < n; r++) {
+        if (!ctx[r]) return fail("run_multi: null context");
+        const int64_t cnt = nphotons > r ? (nphotons - 1 - r) / n + 1 : 0;
+        if (lart_gpu_begin(ctx[r], r + 1, n, cnt, seed)) return 1;
+    }
+    for (;;) {
+        for (int r = 0; r < n; r++) if (lart_gpu_step(ctx[r], 1, max_events)) return 1;
+        int64_t left = 0;
+        for (int r = 0; r < n; r++) { int64_t done = 0, active = 0; if (lart_gpu_sync(ctx[r], &done, &active)) return 1; left += active; }
+        if (left == 0) break;
+    }
+    return 0;
+}
+
+// par%iseed = 0: "seed from the operating system" (init_random_mt_seed reads /dev/urandom, falls back to clock xor pid,
+// random_mt.f90:889-947).  The host calls this once (rank 0) and shares the value, so that all ranks use one Philox key.
+extern "C" int lart_host_entropy_seed(uint64_t *seed) {
+    if (!seed) return 1;
+    uint64_t t = 0;
+    FILE *f = std::fopen("/dev/urandom", "rb");
+    if (f) { if (std::fread(&t, sizeof t, 1, f) != 1) t = 0; std::fclose(f); }
+    if (t == 0) { t = (uint64_t)std::time(nullptr) * 1000003ull ^ (uint64_t)getpid(); }
+    t &= 0x7fffffffffffffffull; if (t == 0) t = 1;            // positive and non-zero: fits the hosts' integer(int64) / a Python int
+    *seed = t;
+    return 0;
+}
+
 extern "C" int lart_gpu_get_photon_log(lart_gpu *c, double *nscatt, double *xfreq_ref, int64_t n) {
     if (!c) return fail("photon_log: null context");
     if (!c->d_log) return fail("photon_log: not enabled (lart_gpu_enable_photon_log before lart_gpu_begin)");

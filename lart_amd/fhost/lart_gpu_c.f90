@@ -185,6 +185,28 @@ module lart_gpu_c
      function lart_gpu_sync(ctx, nphotons_done, nphotons_active) bind(C, name='lart_gpu_sync') result(rc)
        import; type(c_ptr), value :: ctx; integer(c_int64_t), intent(out) :: nphotons_done, nphotons_active; integer(c_int) :: rc
      end function
+     !--- output_reduce over the GPUs of this process / over ranks (include/lart_gpu.h; reduce_mem, memory_mod_mpi.f90:366-394)
+     function lart_gpu_reduce_tallies_multi(ctxs, n, root) bind(C, name='lart_gpu_reduce_tallies_multi') result(rc)
+       import; type(c_ptr), intent(in) :: ctxs(*); integer(c_int32_t), value :: n, root; integer(c_int) :: rc
+     end function
+     function lart_gpu_run_multi(ctxs, n, nphotons, seed, max_events) bind(C, name='lart_gpu_run_multi') result(rc)
+       import; type(c_ptr), intent(in) :: ctxs(*); integer(c_int32_t), value :: n, max_events; integer(c_int64_t), value :: nphotons, seed; integer(c_int) :: rc
+     end function
+     function lart_gpu_comm_unique_id(id128) bind(C, name='lart_gpu_comm_unique_id') result(rc)
+       import; integer(c_int8_t), intent(out) :: id128(128); integer(c_int) :: rc
+     end function
+     function lart_gpu_comm_init(ctx, id128, nranks, rank) bind(C, name='lart_gpu_comm_init') result(rc)
+       import; type(c_ptr), value :: ctx; integer(c_int8_t), intent(in) :: id128(128); integer(c_int32_t), value :: nranks, rank; integer(c_int) :: rc
+     end function
+     function lart_gpu_reduce_tallies(ctx, root) bind(C, name='lart_gpu_reduce_tallies') result(rc)
+       import; type(c_ptr), value :: ctx; integer(c_int32_t), value :: root; integer(c_int) :: rc
+     end function
+     function lart_gpu_compact(ctx) bind(C, name='lart_gpu_compact') result(rc)
+       import; type(c_ptr), value :: ctx; integer(c_int) :: rc
+     end function
+     function lart_host_entropy_seed(seed) bind(C, name='lart_host_entropy_seed') result(rc)
+       import; integer(c_int64_t), intent(out) :: seed; integer(c_int) :: rc
+     end function
      function lart_gpu_zero_tallies(ctx) bind(C, name='lart_gpu_zero_tallies') result(rc)
        import; type(c_ptr), value :: ctx; integer(c_int) :: rc
      end function

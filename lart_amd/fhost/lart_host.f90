@@ -88,7 +88,8 @@ module lart_define
      character(len=256) :: amr_file = '', clump_input_file = ''
      real(wp) :: bturb = -999.0
      !--- GPU host additions (not in the reference): number of GPUs driven by this process, slice length
-     integer  :: ngpu = 1
+     integer  :: ngpu = 0                        ! GPUs of this node to use: 0 = all visible HIP devices (the role of mpirun -np N)
+     integer(int64) :: run_seed = 0              ! the Philox key of the run (= iseed, or the operating-system seed when iseed = 0)
      integer  :: gpu_events_per_step = 4096
        !--- the rest of the reference's namelist surface (define.f90:209-544): readable, rejected when set (check_unsupported_fields)
      real(wp) :: luminosity = 1.0_wp

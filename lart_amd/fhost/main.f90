@@ -16,10 +16,11 @@ program LaRT_amd
   type(lart_params) :: cpar
   type(lart_tallies) :: t
   type(c_ptr) :: ctx
+  type(c_ptr), allocatable :: ctxs(:)
   character(len=256) :: infile, arg
   logical :: dry_run, dry_write
-  integer :: i, ndev
-  integer(int64) :: done, active, t0, t1, rate
+  integer :: i, ndev, ngpu, r
+  integer(int64) :: done, active, left, t0, t1, rate, run_seed, cnt_r
   real(wp), allocatable, target :: xyz(:), rmat(:)
   real(wp) :: dtime
 
@@ -40,6 +41,16 @@ program LaRT_amd
   call system_clock(t0, rate)
 
   call read_input(trim(infile))
+  !--- par%iseed = 0: seed from the operating system, as init_random_mt_seed does (random_mt.f90:889-947); printed and written
+  !    to the output header (keyword ISEED) so that the run can be repeated.  A non-zero iseed is used as it is.
+  run_seed = int(par%iseed, int64)
+  if (par%iseed == 0) then
+     if (lart_host_entropy_seed(run_seed) /= 0) run_seed = 1_int64
+     par%iseed = int(mod(run_seed, 2147483647_int64))      ! the host-side MT stream (clump placement) takes a default integer
+     if (par%iseed == 0) par%iseed = 1
+     write(*,'(a,i0)') 'par%iseed = 0: seeded from the operating system, seed = ', run_seed
+  endif
+  par%run_seed = run_seed
   if (par%use_clump_medium) then            ! main.f90:25-27
      call grid_create_clump(grid)
   else if (par%use_amr_grid) then           ! main.f90:28-30
@@ -68,51 +79,25 @@ program LaRT_amd
   endif
   call fill_params(cpar)
   out_bitpix = par%out_bitpix
-  call lart_check(lart_gpu_create(ctx, cpar, 0_c_int), 'lart_gpu_create')
-  if (par%use_amr_grid) then
-     if (par%DGR > 0.0_wp) then
-        call lart_check(lart_gpu_set_grid_amr(ctx, amr_ncells, amr_nleaf, amr_lo, amr_hi, amr_cx, amr_cy, amr_cz, amr_ch, amr_children, amr_neighbor, &
-             amr_ileaf, amr_icell_of_leaf, amr_rhokap, amr_voigt_a, amr_Dfreq, amr_vfx, amr_vfy, amr_vfz, c_loc(amr_rhokapD)), 'lart_gpu_set_grid_amr')
-     else
-        call lart_check(lart_gpu_set_grid_amr(ctx, amr_ncells, amr_nleaf, amr_lo, amr_hi, amr_cx, amr_cy, amr_cz, amr_ch, amr_children, amr_neighbor, &
-             amr_ileaf, amr_icell_of_leaf, amr_rhokap, amr_voigt_a, amr_Dfreq, amr_vfx, amr_vfy, amr_vfz, c_null_ptr), 'lart_gpu_set_grid_amr')
-     endif
-     if (amr_nbins > 0) call lart_check(lart_gpu_set_JPa_amr(ctx, merge(1, 0, par%calc_J), merge(1, 0, par%calc_P), merge(1, 0, par%calc_Pnew), &
-          par%geometry_JPa, amr_nbins, amr_dbin, line%cross0), 'lart_gpu_set_JPa_amr')
-  else if (par%use_clump_medium) then
-     if (par%DGR > 0.0_wp) then
-        call lart_check(lart_gpu_set_clumps(ctx, N_clumps, cl_x, cl_y, cl_z, cl_vx, cl_vy, cl_vz, cl_radius, cl_rhokap, c_loc(cl_rhokapD), &
-             cl_voigt_a, cl_Dfreq, sphere_R, cl_Dfreq_ref, cl_voigt_a_ref, cgx, cg_xmin, cg_dx, cg_start, cg_list), 'lart_gpu_set_clumps')
-     else
-        call lart_check(lart_gpu_set_clumps(ctx, N_clumps, cl_x, cl_y, cl_z, cl_vx, cl_vy, cl_vz, cl_radius, cl_rhokap, c_null_ptr, &
-             cl_voigt_a, cl_Dfreq, sphere_R, cl_Dfreq_ref, cl_voigt_a_ref, cgx, cg_xmin, cg_dx, cg_start, cg_list), 'lart_gpu_set_clumps')
-     endif
-  else if (par%DGR > 0.0_wp) then
-     call lart_check(lart_gpu_set_grid_car(ctx, grid%nx, grid%ny, grid%nz, grid%xmin, grid%ymin, grid%zmin, grid%dx, grid%dy, grid%dz, &
-          grid%i0, grid%j0, grid%k0, grid%xface, grid%yface, grid%zface, grid%rhokap, grid%voigt_a, grid%Dfreq, &
-          grid%vfx, grid%vfy, grid%vfz, c_loc(grid%rhokapD)), 'lart_gpu_set_grid_car')
-  else
-     call lart_check(lart_gpu_set_grid_car(ctx, grid%nx, grid%ny, grid%nz, grid%xmin, grid%ymin, grid%zmin, grid%dx, grid%dy, grid%dz, &
-          grid%i0, grid%j0, grid%k0, grid%xface, grid%yface, grid%zface, grid%rhokap, grid%voigt_a, grid%Dfreq, &
-          grid%vfx, grid%vfy, grid%vfz, c_null_ptr), 'lart_gpu_set_grid_car')
+  !--- one context per GPU, all driven by this host thread (par%ngpu: 0 = every visible device; HIP_VISIBLE_DEVICES narrows it).
+  !    Replaces `mpirun -np N`: context r transports the photons r, r+N, ... (run_simulation_mod.f90:150-151).
+  ngpu = par%ngpu
+  if (ngpu <= 0) ngpu = ndev
+  if (ngpu > ndev) then
+     write(*,'(a,i0,a,i0,a)') 'ERROR: par%ngpu = ', ngpu, ' but only ', ndev, ' HIP device(s) are visible.'; stop 1
   endif
-  if (car_nbins > 0) call lart_check(lart_gpu_set_JPa(ctx, merge(1, 0, par%calc_J), merge(1, 0, par%calc_P), merge(1, 0, par%calc_Pnew), &
-       car_nbins, car_ind_bin, line%cross0), 'lart_gpu_set_JPa')
-  if (line%line_type >= 4 .and. line%line_type <= 6) call lart_check(lart_gpu_set_line_multiplet(ctx, line%ml), 'lart_gpu_set_line_multiplet')
-  if (scatt_mat%nPDF > 0) call lart_check(lart_gpu_set_mueller(ctx, scatt_mat%nPDF, scatt_mat%coss, scatt_mat%S11, scatt_mat%S12, &
-       scatt_mat%S33, scatt_mat%S34, scatt_mat%phase_PDF, scatt_mat%alias), 'lart_gpu_set_mueller')
-  if (par%nobs > 0 .and. par%save_peeloff) then
-     allocate(xyz(3*par%nobs), rmat(9*par%nobs))
-     do i = 1, par%nobs
-        xyz(3*i-2:3*i) = [observer(i)%x, observer(i)%y, observer(i)%z]
-        rmat(9*i-8:9*i) = [observer(i)%rmatrix(1,:), observer(i)%rmatrix(2,:), observer(i)%rmatrix(3,:)]
-     enddo
-     if (par%nside > 0) then
-        call lart_check(lart_gpu_set_observers_heal(ctx, par%nobs, xyz, par%nside), 'lart_gpu_set_observers_heal')
-     else
-        call lart_check(lart_gpu_set_observers(ctx, par%nobs, xyz, rmat, par%dxim, par%dyim, par%nxim, par%nyim), 'lart_gpu_set_observers')
-     endif
+  if (par%save_all_photons .and. ngpu > 1) then
+     write(*,'(a)') 'par%save_all_photons: the per-photon table is kept by one context; using one GPU.'
+     ngpu = 1
   endif
+  if (int(ngpu, int64) > max(par%nphotons, 1_int64)) ngpu = int(max(par%nphotons, 1_int64))
+  allocate(ctxs(ngpu))
+  do r = 1, ngpu
+     call lart_check(lart_gpu_create(ctxs(r), cpar, int(r - 1, c_int)), 'lart_gpu_create')
+     call setup_device(ctxs(r))
+  enddo
+  ctx = ctxs(1)
+  write(*,'(a,i0)') 'GPUs used                    : ', ngpu
 
   if (par%save_sightline_tau .and. par%save_peeloff .and. par%nobs > 0) call make_sightline_tau(.true.)      ! main.f90:34-37
 
@@ -120,17 +105,29 @@ program LaRT_amd
   call time_stamp(dtime)
   write(6,'(a,f8.3,a)') '---> Now starting simulation...  @ ', dtime/60.0_wp, ' mins'
   if (par%save_all_photons) call lart_check(lart_gpu_enable_all_photons(ctx, 1_c_int32_t), 'lart_gpu_enable_all_photons')
-  call lart_check(lart_gpu_begin(ctx, 1_c_int64_t, 1_c_int64_t, par%nphotons, int(par%iseed, c_int64_t)), 'lart_gpu_begin')
+  do r = 1, ngpu
+     cnt_r = 0
+     if (par%nphotons >= r) cnt_r = (par%nphotons - r)/ngpu + 1
+     call lart_check(lart_gpu_begin(ctxs(r), int(r, c_int64_t), int(ngpu, c_int64_t), cnt_r, run_seed), 'lart_gpu_begin')
+  enddo
   do
-     call lart_check(lart_gpu_step(ctx, 1_c_int32_t, int(par%gpu_events_per_step, c_int32_t)), 'lart_gpu_step')
-     call lart_check(lart_gpu_sync(ctx, done, active), 'lart_gpu_sync')
-     if (active == 0) exit
+     do r = 1, ngpu        ! launches are asynchronous: one slice is enqueued on every GPU before the first wait
+        call lart_check(lart_gpu_step(ctxs(r), 1_c_int32_t, int(par%gpu_events_per_step, c_int32_t)), 'lart_gpu_step')
+     enddo
+     left = 0
+     do r = 1, ngpu
+        call lart_check(lart_gpu_sync(ctxs(r), done, active), 'lart_gpu_sync')
+        left = left + active
+     enddo
+     if (left == 0) exit
   enddo
   call time_stamp(dtime)
   write(6,'(es14.5,a,f8.3,a)') dble(par%nphotons), ' photons calculated: ', dtime/60.0_wp, ' mins'
 
-  !--- output_reduce (main.f90:46): one GPU per process here, so the "reduce" is the device->host copy
+  !--- output_reduce (main.f90:46): one RCCL reduce(sum, f64) of the fused tally buffers onto GPU 0 (reduce_mem,
+  !    memory_mod_mpi.f90:366-394), then the device->host copy
   write(6,'(a)') '---> Now Gathering Results...'
+  if (ngpu > 1) call lart_check(lart_gpu_reduce_tallies_multi(ctxs, int(ngpu, c_int32_t), 0_c_int32_t), 'lart_gpu_reduce_tallies_multi')
   call null_tallies(t)
   t%Jout = c_loc(grid%Jout); t%Jin = c_loc(grid%Jin)
   if (par%save_Jabs) t%Jabs = c_loc(grid%Jabs)
@@ -165,9 +162,61 @@ program LaRT_amd
   write(6,'(a,2es12.4)')  'Nscatt_dust, Nscatt_gas      : ', par%nscatt_dust, par%nscatt_gas
   write(6,'(a,es12.4)')   'Scattering events per second : ', t%n_events/max(dtime, 1e-9_wp)
   write(6,'(a,f8.3,a)')   'Total Excution Time          : ', par%exetime, ' mins'
-  call lart_check(lart_gpu_destroy(ctx), 'lart_gpu_destroy')
+  do r = 1, ngpu
+     call lart_check(lart_gpu_destroy(ctxs(r)), 'lart_gpu_destroy')
+  enddo
 
 contains
+  !--- hand the read-only tables to one device
+  subroutine setup_device(ctx)
+    type(c_ptr), intent(in) :: ctx
+    integer :: i
+  if (par%use_amr_grid) then
+       if (par%DGR > 0.0_wp) then
+          call lart_check(lart_gpu_set_grid_amr(ctx, amr_ncells, amr_nleaf, amr_lo, amr_hi, amr_cx, amr_cy, amr_cz, amr_ch, amr_children, amr_neighbor, &
+               amr_ileaf, amr_icell_of_leaf, amr_rhokap, amr_voigt_a, amr_Dfreq, amr_vfx, amr_vfy, amr_vfz, c_loc(amr_rhokapD)), 'lart_gpu_set_grid_amr')
+       else
+          call lart_check(lart_gpu_set_grid_amr(ctx, amr_ncells, amr_nleaf, amr_lo, amr_hi, amr_cx, amr_cy, amr_cz, amr_ch, amr_children, amr_neighbor, &
+               amr_ileaf, amr_icell_of_leaf, amr_rhokap, amr_voigt_a, amr_Dfreq, amr_vfx, amr_vfy, amr_vfz, c_null_ptr), 'lart_gpu_set_grid_amr')
+       endif
+       if (amr_nbins > 0) call lart_check(lart_gpu_set_JPa_amr(ctx, merge(1, 0, par%calc_J), merge(1, 0, par%calc_P), merge(1, 0, par%calc_Pnew), &
+            par%geometry_JPa, amr_nbins, amr_dbin, line%cross0), 'lart_gpu_set_JPa_amr')
+    else if (par%use_clump_medium) then
+       if (par%DGR > 0.0_wp) then
+          call lart_check(lart_gpu_set_clumps(ctx, N_clumps, cl_x, cl_y, cl_z, cl_vx, cl_vy, cl_vz, cl_radius, cl_rhokap, c_loc(cl_rhokapD), &
+               cl_voigt_a, cl_Dfreq, sphere_R, cl_Dfreq_ref, cl_voigt_a_ref, cgx, cg_xmin, cg_dx, cg_start, cg_list), 'lart_gpu_set_clumps')
+       else
+          call lart_check(lart_gpu_set_clumps(ctx, N_clumps, cl_x, cl_y, cl_z, cl_vx, cl_vy, cl_vz, cl_radius, cl_rhokap, c_null_ptr, &
+               cl_voigt_a, cl_Dfreq, sphere_R, cl_Dfreq_ref, cl_voigt_a_ref, cgx, cg_xmin, cg_dx, cg_start, cg_list), 'lart_gpu_set_clumps')
+       endif
+    else if (par%DGR > 0.0_wp) then
+       call lart_check(lart_gpu_set_grid_car(ctx, grid%nx, grid%ny, grid%nz, grid%xmin, grid%ymin, grid%zmin, grid%dx, grid%dy, grid%dz, &
+            grid%i0, grid%j0, grid%k0, grid%xface, grid%yface, grid%zface, grid%rhokap, grid%voigt_a, grid%Dfreq, &
+            grid%vfx, grid%vfy, grid%vfz, c_loc(grid%rhokapD)), 'lart_gpu_set_grid_car')
+    else
+       call lart_check(lart_gpu_set_grid_car(ctx, grid%nx, grid%ny, grid%nz, grid%xmin, grid%ymin, grid%zmin, grid%dx, grid%dy, grid%dz, &
+            grid%i0, grid%j0, grid%k0, grid%xface, grid%yface, grid%zface, grid%rhokap, grid%voigt_a, grid%Dfreq, &
+            grid%vfx, grid%vfy, grid%vfz, c_null_ptr), 'lart_gpu_set_grid_car')
+    endif
+    if (car_nbins > 0) call lart_check(lart_gpu_set_JPa(ctx, merge(1, 0, par%calc_J), merge(1, 0, par%calc_P), merge(1, 0, par%calc_Pnew), &
+         car_nbins, car_ind_bin, line%cross0), 'lart_gpu_set_JPa')
+    if (line%line_type >= 4 .and. line%line_type <= 6) call lart_check(lart_gpu_set_line_multiplet(ctx, line%ml), 'lart_gpu_set_line_multiplet')
+    if (scatt_mat%nPDF > 0) call lart_check(lart_gpu_set_mueller(ctx, scatt_mat%nPDF, scatt_mat%coss, scatt_mat%S11, scatt_mat%S12, &
+         scatt_mat%S33, scatt_mat%S34, scatt_mat%phase_PDF, scatt_mat%alias), 'lart_gpu_set_mueller')
+    if (par%nobs > 0 .and. par%save_peeloff) then
+       if (.not. allocated(xyz)) allocate(xyz(3*par%nobs), rmat(9*par%nobs))
+       do i = 1, par%nobs
+          xyz(3*i-2:3*i) = [observer(i)%x, observer(i)%y, observer(i)%z]
+          rmat(9*i-8:9*i) = [observer(i)%rmatrix(1,:), observer(i)%rmatrix(2,:), observer(i)%rmatrix(3,:)]
+       enddo
+       if (par%nside > 0) then
+          call lart_check(lart_gpu_set_observers_heal(ctx, par%nobs, xyz, par%nside), 'lart_gpu_set_observers_heal')
+       else
+          call lart_check(lart_gpu_set_observers(ctx, par%nobs, xyz, rmat, par%dxim, par%dyim, par%nxim, par%nyim), 'lart_gpu_set_observers')
+       endif
+    endif
+  end subroutine setup_device
+
   subroutine time_stamp(dt)
     real(wp), intent(out) :: dt
     call system_clock(t1)

@@ -1055,13 +1055,26 @@ class Simulation:
             self.ctx.set_JPa(self.par.calc_J, self.par.calc_P, self.par.calc_Pnew, self.jpa.nbins, self.jpa.ind_bin, self.line.cross0)
         self.nphotons_run = 0
 
+    def seed(self):
+        """the Philox key of this run: par%iseed, or -- for par%iseed = 0, where the reference seeds from the operating system
+        (init_random_mt_seed, random_mt.f90:889-947) -- one value drawn once per Simulation (lart_host_entropy_seed); with several
+        ranks the caller shares rank 0's value (bench.py / output_reduce broadcast it) so that the photon ids stay disjoint"""
+        if self.par.iseed != 0:
+            return int(self.par.iseed)
+        if not getattr(self, "seed_used", 0):
+            self.seed_used = capi.entropy_seed()
+            print("par%%iseed = 0: seeded from the operating system, seed = %d" % self.seed_used)
+        return self.seed_used
+
     def run_simulation(self, nphotons=None, rank=0, nproc=1, seed=None):
-        """photon ids rank+1, rank+1+nproc, ... <= nphotons (run_equal_number, run_simulation_mod.f90:150-151)"""
+        """photon ids rank+1, rank+1+nproc, ... <= nphotons (run_equal_number, run_simulation_mod.f90:150-151).
+        The device tallies are cumulative over calls (lart_gpu_zero_tallies resets them); output_normalize divides by the
+        photons the device has finished, so a second call adds statistics instead of skewing the normalisation."""
         n = self.par.nphotons if nphotons is None else int(nphotons)
         count = photons_of_rank(n, rank, nproc)
         if self.par.save_all_photons:
             self.ctx.enable_all_photons(True)
-        self.ctx.run(count, first_id=rank + 1, stride=nproc, seed=self.par.iseed if seed is None else seed)
+        self.ctx.run(count, first_id=rank + 1, stride=nproc, seed=self.seed() if seed is None else seed)
         self.nphotons_run = n
         return count
 
@@ -1071,22 +1084,24 @@ class Simulation:
             raise LartInputError("make_sightline_tau needs observers (par%save_peeloff)")
         return self.ctx.sightline_tau(self.line.cross0)
 
-    def output_reduce(self, dist=None, force=False):
-        """sum of the fused tally buffer over ranks (reduce_mem, memory_mod_mpi.f90:366-394) by one RCCL collective"""
+    def output_reduce(self, dist=None, force=False, root=0):
+        """output_reduce (main.f90:46): the fused tally buffer summed onto the root rank (reduce_mem = MPI_REDUCE to rank 0,
+        memory_mod_mpi.f90:366-394) by the library's own RCCL reduce (lart_gpu_comm_init + lart_gpu_reduce_tallies, one
+        ncclReduce(sum, f64) over xGMI).  torch.distributed only carries the 128-byte communicator id from rank 0 to the others."""
         if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
             return
-        import torch
-        ptr, n = self.ctx.tally_buffer()
-        t = _as_cuda_tensor(ptr, n, self.ctx)
-        torch.cuda.synchronize()
-        reduce_tally_buffer(t, dist)
-        torch.cuda.synchronize()
+        world, rank = dist.get_world_size(), dist.get_rank()
+        if self.ctx.comm_info()[0] != world:
+            box = [capi.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            self.ctx.comm_init(box[0], world, rank)
+        self.ctx.reduce_tallies(root)
 
     def output_normalize(self, t=None, nphotons=None):
         """output_normalize_outside (output_sum_rect.f90:151-487): physical units for Jout/Jin/Jabs/Jmu and peel cubes"""
         t = t or self.ctx.tallies()
         par, g = self.par, self.grid
-        nph = float(nphotons or self.nphotons_run or t["nphotons_done"])
+        nph = float(nphotons or t["nphotons_done"] or self.nphotons_run)     # photons the device(s) finished (cumulative, summed by output_reduce)
         out = dict(t)
         unit = g.dwave if par.distance2cm != 1.0 else g.dxfreq            # par%intensity_unit default, setup.f90:491-497
         if par.xy_periodic:                                               # slab, two faces: :174-190
@@ -1171,10 +1186,10 @@ def photons_of_rank(nphotons, rank, nproc):
     return (nphotons - rank - 1) // nproc + 1 if nphotons > rank else 0
 
 
-def reduce_tally_buffer(t, dist):
-    """the path's only exchange step: element-wise SUM of the fused tally buffer over all ranks
-    (backend nccl = RCCL over xGMI on GPUs, gloo on CPU tensors in the tests)"""
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+def reduce_tally_buffer(t, dist, root=0):
+    """caller-owned variant of the exchange step on a torch tensor (lart_gpu_tally_buffer wrapped by _as_cuda_tensor, or a CPU
+    copy in the gloo tests): element-wise SUM onto the root rank, as reduce_mem does (MPI_REDUCE, memory_mod_mpi.f90:377-393)"""
+    dist.reduce(t, dst=root, op=dist.ReduceOp.SUM)
     return t
 
 
