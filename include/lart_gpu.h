@@ -65,6 +65,7 @@ typedef struct lart_tallies {
     double nscatt_gas, nscatt_dust;                          /* weight sums over finished photons (par%nscatt_*) */
     double n_events;                                         /* scattering events executed */
     double n_cellsteps, n_cellsteps_peel;                    /* cells visited by flight / peel rays (roofline accounting) */
+    double n_atomics;                                        /* non-zero peel-off deposits issued as tally atomics (roofline accounting) */
     int64_t nphotons_done, nphotons_active;
 } lart_tallies;
 

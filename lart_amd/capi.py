@@ -27,7 +27,7 @@ class LartParams(C.Structure):
 class LartTallies(C.Structure):
     _fields_ = [(n, _vp) for n in ("Jout", "Jin", "Jabs", "Jmu", "scatt", "direc", "I", "Q", "U", "V",
                                    "scatt_2D", "direc_2D", "I_2D", "Q_2D", "U_2D", "V_2D", "direc0", "direc0_2D", "scatt_dust", "J1", "P1", "P1_new")] + \
-        [(n, _d) for n in ("nscatt_gas", "nscatt_dust", "n_events", "n_cellsteps", "n_cellsteps_peel")] + \
+        [(n, _d) for n in ("nscatt_gas", "nscatt_dust", "n_events", "n_cellsteps", "n_cellsteps_peel", "n_atomics")] + \
         [("nphotons_done", _i64), ("nphotons_active", _i64)]
 
 
@@ -384,7 +384,7 @@ class Context:
         for k, a in out.items():
             setattr(t, k, a.ctypes.data)
         _chk(lib().lart_gpu_get_tallies(self.h, C.byref(t)))
-        for k in ("nscatt_gas", "nscatt_dust", "n_events", "n_cellsteps", "n_cellsteps_peel", "nphotons_done", "nphotons_active"):
+        for k in ("nscatt_gas", "nscatt_dust", "n_events", "n_cellsteps", "n_cellsteps_peel", "n_atomics", "nphotons_done", "nphotons_active"):
             out[k] = getattr(t, k)
         return out
 

@@ -90,7 +90,17 @@ struct DJPa { int calc_J, calc_P, calc_Pnew, nbins; const int *ind_bin; double c
 // lart_gpu_get_tallies / lart_gpu_tally_buffer fold the copies back (k_fold_copies) before anything is read.
 struct DRep { double *base; long long off, len; int nrep; };
 
-struct DCtl { unsigned long long next_k; unsigned long long n_active; };
+struct DCtl { unsigned long long next_k; unsigned long long n_active; unsigned q_n, q_pad; };   // q_n: records in the peel queue of this launch
+
+// Peel-off event queue (deferred next-event estimator).  The reference marches a second ray to every observer inside each scattering
+// (peelingoff_rect.f90:576-690 etc.).  Inlined into the transport kernel that second march doubles its live state (2 waves/SIMD, scratch
+// spills).  Here a scattering only RECORDS what the peel routine reads -- position, incoming direction, weight, the atom's frame
+// (xfreq_atom, u_x, u_y, u_z), E1..E3, the Stokes triad and Q,U,V, the cell -- as one SoA record (coalesced 512-byte stores per plane
+// and wave), and peel_kernel runs the unchanged peel routines over the records afterwards, one record per lane, all lanes busy.
+enum { PQ_X = 0, PQ_Y, PQ_Z, PQ_KX, PQ_KY, PQ_KZ, PQ_WGT, PQ_XA, PQ_UX, PQ_UY, PQ_UZ, PQ_E1, PQ_E2, PQ_E3, PQ_GREC, PQ_NOSTOKES,
+       PQ_MX = PQ_NOSTOKES, PQ_MY, PQ_MZ, PQ_NX, PQ_NY, PQ_NZ, PQ_Q, PQ_U, PQ_V, PQ_COUNT };
+enum { PEEL_DIRECT = 0, PEEL_RESONANCE = 1, PEEL_DUST = 2 };
+struct DPeelQ { double *f; int *cell; unsigned cap; };   // f: PQ_COUNT planes of cap doubles; cell: 4 planes (ic, jc, kc | owner clump, kind)
 
 // resonance + fluorescence multiplets (line types 4, 5, 6: lart_line_multiplet).  The per-level constants are wave-uniform and ride
 // in the kernel arguments; the per-branch tables are gathered with lane-varying (iup, idown) from global memory:
@@ -116,6 +126,7 @@ struct KArgs {
     double *log_nscatt, *log_xfreq;
     double *allph; long long allph_n;   // par%save_all_photons: 10 columns of allph_n records (r, xfreq1, xfreq2, nscatt_gas, nscatt_dust, I, Q, U, V, r0), nullptr = off
     DMulti ml;
+    DPeelQ pq;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -1356,7 +1367,7 @@ __device__ inline size_t pix3(const KArgs &A, int io, int ixf, int ix, int iy) {
     return ((size_t)io * A.nxim * A.nyim + (size_t)(ix - 1) + (size_t)A.nxim * (size_t)(iy - 1)) * (size_t)A.par.nxfreq + (size_t)(ixf - 1);
 }
 // e^{-tau} is exactly 0 once tau >= 745.2 in f64: adding it leaves the tally unchanged, so skip the atomics
-__device__ inline void add_if(double *arr, size_t i, double v) { if (v != 0.0) atomicAdd(&arr[i], v); }
+__device__ inline void add_if(double *arr, size_t i, double v, unsigned &natom) { if (v != 0.0) { atomicAdd(&arr[i], v); natom++; } }
 
 // bulk velocity along the peel direction: the owner clump's in clump mode (peelingoff_rect.f90:65-68, 186-187, 403-404, 534-535, 658-659)
 template <int VAR>
@@ -1366,7 +1377,7 @@ __device__ inline double peel_u1(const KArgs &A, const Photon &p, const Cell &c,
 }
 // peeling_direct_outside: peelingoff_rect.f90:24-129
 template <int VAR>
-__device__ inline void peel_direct(const KArgs &A, const Lds &l, bool dust, const Photon &p, unsigned &nsteps) {
+__device__ inline void peel_direct(const KArgs &A, const Lds &l, bool dust, const Photon &p, unsigned &nsteps, unsigned &natom) {
     const Cell &c = A.g.cell[cidx(A.g, p.ic, p.jc, p.kc)];
     for (int i = 0; i < A.nobs; i++) {
         PeelDir q = peel_dir0(A, A.obs[i], p);
@@ -1384,15 +1395,15 @@ __device__ inline void peel_direct(const KArgs &A, const Lds &l, bool dust, cons
         if (wgt == 0.0 && !A.par.save_direc0) continue;
         peel_pixel(A, A.obs[i], q);
         if (!q.in_image) continue;
-        if (A.par.save_peeloff_2D) { add_if(A.t.c2[1], pix2(A, i, q.ix, q.iy), wgt); if (A.par.use_stokes) add_if(A.t.c2[2], pix2(A, i, q.ix, q.iy), wgt);
-                                     if (A.par.save_direc0) add_if(A.t.c2[6], pix2(A, i, q.ix, q.iy), wgt0); }
-        if (A.par.save_peeloff_3D && ixf >= 1 && ixf <= A.par.nxfreq) { add_if(A.t.c3[1], pix3(A, i, ixf, q.ix, q.iy), wgt); if (A.par.use_stokes) add_if(A.t.c3[2], pix3(A, i, ixf, q.ix, q.iy), wgt);
-                                     if (A.par.save_direc0) add_if(A.t.c3[6], pix3(A, i, ixf, q.ix, q.iy), wgt0); }
+        if (A.par.save_peeloff_2D) { add_if(A.t.c2[1], pix2(A, i, q.ix, q.iy), wgt, natom); if (A.par.use_stokes) add_if(A.t.c2[2], pix2(A, i, q.ix, q.iy), wgt, natom);
+                                     if (A.par.save_direc0) add_if(A.t.c2[6], pix2(A, i, q.ix, q.iy), wgt0, natom); }
+        if (A.par.save_peeloff_3D && ixf >= 1 && ixf <= A.par.nxfreq) { add_if(A.t.c3[1], pix3(A, i, ixf, q.ix, q.iy), wgt, natom); if (A.par.use_stokes) add_if(A.t.c3[2], pix3(A, i, ixf, q.ix, q.iy), wgt, natom);
+                                     if (A.par.save_direc0) add_if(A.t.c3[6], pix3(A, i, ixf, q.ix, q.iy), wgt0, natom); }
     }
 }
 // peeling_resonance_nostokes_outside: :576-690
 template <int VAR>
-__device__ inline void peel_resonance_nostokes(const KArgs &A, const Lds &l, bool dust, const Photon &p, double xfreq_atom, double ux, double uy, double uz, double E1, double E2, double g_rec0, unsigned &nsteps) {
+__device__ inline void peel_resonance_nostokes(const KArgs &A, const Lds &l, bool dust, const Photon &p, double xfreq_atom, double ux, double uy, double uz, double E1, double E2, double g_rec0, unsigned &nsteps, unsigned &natom) {
     const Cell &c = A.g.cell[cidx(A.g, p.ic, p.jc, p.kc)];
     for (int i = 0; i < A.nobs; i++) {
         PeelDir q = peel_dir0(A, A.obs[i], p);
@@ -1411,16 +1422,16 @@ __device__ inline void peel_resonance_nostokes(const KArgs &A, const Lds &l, boo
         double u1 = peel_u1<VAR>(A, p, c, q);
         double xfreq_ref = (xfreq + u1) * (c.Dfreq / A.par.Dfreq_ref);
         int ixf = (int)floor((xfreq_ref - A.par.xfreq_min) / A.par.dxfreq) + 1;
-        if (A.par.save_peeloff_2D) add_if(A.t.c2[0], pix2(A, i, q.ix, q.iy), wgt);
-        if (A.par.save_peeloff_3D && ixf >= 1 && ixf <= A.par.nxfreq) add_if(A.t.c3[0], pix3(A, i, ixf, q.ix, q.iy), wgt);
+        if (A.par.save_peeloff_2D) add_if(A.t.c2[0], pix2(A, i, q.ix, q.iy), wgt, natom);
+        if (A.par.save_peeloff_3D && ixf >= 1 && ixf <= A.par.nxfreq) add_if(A.t.c3[0], pix3(A, i, ixf, q.ix, q.iy), wgt, natom);
     }
 }
-__device__ inline void stokes_deposit(const KArgs &A, int io, const PeelDir &q, int ixf, double wgt, double Id, double Qd, double Ud, double Vd) {
+__device__ inline void stokes_deposit(const KArgs &A, int io, const PeelDir &q, int ixf, double wgt, double Id, double Qd, double Ud, double Vd, unsigned &natom) {
     if (wgt == 0.0) return;
     if (A.par.save_peeloff_2D) { size_t s = pix2(A, io, q.ix, q.iy);
-        atomicAdd(&A.t.c2[0][s], wgt * Id); atomicAdd(&A.t.c2[2][s], wgt * Id); atomicAdd(&A.t.c2[3][s], wgt * Qd); atomicAdd(&A.t.c2[4][s], wgt * Ud); atomicAdd(&A.t.c2[5][s], wgt * Vd); }
+        atomicAdd(&A.t.c2[0][s], wgt * Id); atomicAdd(&A.t.c2[2][s], wgt * Id); atomicAdd(&A.t.c2[3][s], wgt * Qd); atomicAdd(&A.t.c2[4][s], wgt * Ud); atomicAdd(&A.t.c2[5][s], wgt * Vd); natom += 5; }
     if (A.par.save_peeloff_3D && ixf >= 1 && ixf <= A.par.nxfreq) { size_t s = pix3(A, io, ixf, q.ix, q.iy);
-        atomicAdd(&A.t.c3[0][s], wgt * Id); atomicAdd(&A.t.c3[2][s], wgt * Id); atomicAdd(&A.t.c3[3][s], wgt * Qd); atomicAdd(&A.t.c3[4][s], wgt * Ud); atomicAdd(&A.t.c3[5][s], wgt * Vd); }
+        atomicAdd(&A.t.c3[0][s], wgt * Id); atomicAdd(&A.t.c3[2][s], wgt * Id); atomicAdd(&A.t.c3[3][s], wgt * Qd); atomicAdd(&A.t.c3[4][s], wgt * Ud); atomicAdd(&A.t.c3[5][s], wgt * Vd); natom += 5; }
 }
 // azimuth about the (m,n,k) triad and the peel reference normal: :356-385 (= :204-224)
 struct StokesGeom { double cost, sint, cosp, sinp, cos2p, sin2p, nx, ny, nz; };
@@ -1435,7 +1446,7 @@ __device__ inline StokesGeom stokes_geom(const Photon &p, const PeelDir &q) {
 }
 // peeling_resonance_stokes_outside: :303-482
 template <int VAR>
-__device__ inline void peel_resonance_stokes(const KArgs &A, const Lds &l, bool dust, const Photon &p, double xfreq_atom, double ux, double uy, double uz, double E1, double E2, double E3, double g_rec0, unsigned &nsteps) {
+__device__ inline void peel_resonance_stokes(const KArgs &A, const Lds &l, bool dust, const Photon &p, double xfreq_atom, double ux, double uy, double uz, double E1, double E2, double E3, double g_rec0, unsigned &nsteps, unsigned &natom) {
     const Cell &c = A.g.cell[cidx(A.g, p.ic, p.jc, p.kc)];
     for (int i = 0; i < A.nobs; i++) {
         const DObs &o = A.obs[i];
@@ -1459,12 +1470,12 @@ __device__ inline void peel_resonance_stokes(const KArgs &A, const Lds &l, bool 
         double cosg = -(o.rm[0] * s.nx + o.rm[1] * s.ny + o.rm[2] * s.nz), sing = o.rm[3] * s.nx + o.rm[4] * s.ny + o.rm[5] * s.nz;
         double cos2g = 2.0 * cosg * cosg - 1.0, sin2g = 2.0 * cosg * sing;
         double Qdet = cos2g * Qobs + sin2g * Uobs, Udet = -sin2g * Qobs + cos2g * Uobs;
-        stokes_deposit(A, i, q, ixf, wgt, Iobs, Qdet, Udet, Vobs);
+        stokes_deposit(A, i, q, ixf, wgt, Iobs, Qdet, Udet, Vobs, natom);
     }
 }
 // peeling_dust_nostokes_outside: :484-574
 template <int VAR>
-__device__ inline void peel_dust_nostokes(const KArgs &A, const Lds &l, const Photon &p, unsigned &nsteps) {
+__device__ inline void peel_dust_nostokes(const KArgs &A, const Lds &l, const Photon &p, unsigned &nsteps, unsigned &natom) {
     const Cell &c = A.g.cell[cidx(A.g, p.ic, p.jc, p.kc)];
     for (int i = 0; i < A.nobs; i++) {
         PeelDir q = peel_dir0(A, A.obs[i], p);
@@ -1480,14 +1491,14 @@ __device__ inline void peel_dust_nostokes(const KArgs &A, const Lds &l, const Ph
         double u1 = peel_u1<VAR>(A, p, c, q);
         double xfreq_ref = (p.xfreq + u1) * (c.Dfreq / A.par.Dfreq_ref);
         int ixf = (int)floor((xfreq_ref - A.par.xfreq_min) / A.par.dxfreq) + 1;
-        if (A.par.save_peeloff_2D) add_if(A.t.c2[0], pix2(A, i, q.ix, q.iy), wgt);
-        if (A.par.save_peeloff_3D && ixf >= 1 && ixf <= A.par.nxfreq) { add_if(A.t.c3[0], pix3(A, i, ixf, q.ix, q.iy), wgt);
-                                                                          if (A.par.save_dust_scattered) add_if(A.t.c3[7], pix3(A, i, ixf, q.ix, q.iy), wgt); }
+        if (A.par.save_peeloff_2D) add_if(A.t.c2[0], pix2(A, i, q.ix, q.iy), wgt, natom);
+        if (A.par.save_peeloff_3D && ixf >= 1 && ixf <= A.par.nxfreq) { add_if(A.t.c3[0], pix3(A, i, ixf, q.ix, q.iy), wgt, natom);
+                                                                          if (A.par.save_dust_scattered) add_if(A.t.c3[7], pix3(A, i, ixf, q.ix, q.iy), wgt, natom); }
     }
 }
 // peeling_dust_stokes_outside: :131-299
 template <int VAR>
-__device__ inline void peel_dust_stokes(const KArgs &A, const Lds &l, const Photon &p, unsigned &nsteps) {
+__device__ inline void peel_dust_stokes(const KArgs &A, const Lds &l, const Photon &p, unsigned &nsteps, unsigned &natom) {
     const Cell &c = A.g.cell[cidx(A.g, p.ic, p.jc, p.kc)];
     for (int i = 0; i < A.nobs; i++) {
         const DObs &o = A.obs[i];
@@ -1511,9 +1522,30 @@ __device__ inline void peel_dust_stokes(const KArgs &A, const Lds &l, const Phot
         double cosg = -(o.rm[0] * s.nx + o.rm[1] * s.ny + o.rm[2] * s.nz), sing = o.rm[3] * s.nx + o.rm[4] * s.ny + o.rm[5] * s.nz;
         double cos2g = 2.0 * cosg * cosg - 1.0, sin2g = 2.0 * cosg * sing;
         double Qdet = cos2g * Qobs + sin2g * Uobs, Udet = -sin2g * Qobs + cos2g * Uobs;
-        stokes_deposit(A, i, q, ixf, wgt, Iobs, Qdet, Udet, Vobs);
-        if (A.par.save_dust_scattered && A.par.save_peeloff_3D && ixf >= 1 && ixf <= A.par.nxfreq) add_if(A.t.c3[7], pix3(A, i, ixf, q.ix, q.iy), wgt * Iobs);   // :284-287
+        stokes_deposit(A, i, q, ixf, wgt, Iobs, Qdet, Udet, Vobs, natom);
+        if (A.par.save_dust_scattered && A.par.save_peeloff_3D && ixf >= 1 && ixf <= A.par.nxfreq) add_if(A.t.c3[7], pix3(A, i, ixf, q.ix, q.iy), wgt * Iobs, natom);   // :284-287
     }
+}
+
+// one record into the peel queue (see DPeelQ).  Called from divergent code: the lanes of the wave that are here right now share one
+// atomic for their slots.  xa = xfreq_atom for a resonance event, the packet's xfreq for a dust event or the direct (birth) peel.
+template <int VAR, bool STOKES>
+__device__ inline void peel_emit(const KArgs &A, int kind, const Photon &p, double xa, double ux, double uy, double uz, double E1, double E2, double E3, double grec) {
+    const unsigned long long m = __ballot(1);
+    const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+    unsigned base = 0;
+    if (lane == leader) base = atomicAdd(&A.ctl->q_n, (unsigned)__popcll(m));
+    base = __shfl(base, leader, 64);
+    const size_t r = (size_t)base + (size_t)__popcll(m & ((1ull << lane) - 1ull)), C = A.pq.cap;
+    if (r >= C) return;                                       // cannot happen: the host sizes the queue for lanes x (events + 1) records per launch
+    double *f = A.pq.f;
+    f[PQ_X * C + r] = p.x; f[PQ_Y * C + r] = p.y; f[PQ_Z * C + r] = p.z; f[PQ_KX * C + r] = p.kx; f[PQ_KY * C + r] = p.ky; f[PQ_KZ * C + r] = p.kz;
+    f[PQ_WGT * C + r] = p.wgt; f[PQ_XA * C + r] = xa;
+    if (kind == PEEL_RESONANCE) { f[PQ_UX * C + r] = ux; f[PQ_UY * C + r] = uy; f[PQ_UZ * C + r] = uz; f[PQ_E1 * C + r] = E1; f[PQ_E2 * C + r] = E2; f[PQ_E3 * C + r] = E3; f[PQ_GREC * C + r] = grec; }
+    if (STOKES) { f[PQ_MX * C + r] = p.mx; f[PQ_MY * C + r] = p.my; f[PQ_MZ * C + r] = p.mz; f[PQ_NX * C + r] = p.nx; f[PQ_NY * C + r] = p.ny; f[PQ_NZ * C + r] = p.nz;
+                  f[PQ_Q * C + r] = p.Q; f[PQ_U * C + r] = p.U; f[PQ_V * C + r] = p.V; }
+    int *q = A.pq.cell;
+    q[r] = p.ic; q[C + r] = p.jc; q[2 * C + r] = (VAR == 4) ? p.icl : p.kc; q[3 * C + r] = kind;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1594,7 +1626,7 @@ __device__ inline bool scatter_pre(const KArgs &A, const Lds &l, Rng &g, Photon 
         if (g.next() <= p_dust) {
             if (dust_absorb(A, g, p, c)) return false;
             if (STOKES && A.mu.nPDF > 0) {                     // scatter_dust_stokes :201-329
-                if (PEEL) peel_dust_stokes<VAR>(A, l, p, npeel);
+                if (PEEL) peel_emit<VAR, STOKES>(A, PEEL_DUST, p, p.xfreq, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0);      // peeling_dust_stokes_outside, deferred
                 double cost = rand_alias_linear(g, A.mu), sint = sqrt(1.0 - cost * cost);
                 const DMueller &m = A.mu;
                 double S11 = interp_eq(m.nPDF, m.coss, m.S11, cost), S12 = interp_eq(m.nPDF, m.coss, m.S12, cost);
@@ -1606,7 +1638,7 @@ __device__ inline bool scatter_pre(const KArgs &A, const Lds &l, Rng &g, Photon 
                 p.Q = Q1 / I1; p.U = U1 / I1; p.V = V1 / I1;
                 rotate_triad(p, cost, sint, cosp, sinp);
             } else {                                           // scatter_dust_nostokes :488-584
-                if (PEEL) peel_dust_nostokes<VAR>(A, l, p, npeel);
+                if (PEEL) peel_emit<VAR, STOKES>(A, PEEL_DUST, p, p.xfreq, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0);      // peeling_dust_nostokes_outside, deferred
                 double cost = rand_hg(g, par.hgg), sint = sqrt(1.0 - cost * cost);
                 double sinp, cosp; d_sincos_2pi(g.next(), &sinp, &cosp);
                 rotate_k(p, cost, sint, cosp, sinp);
@@ -1714,14 +1746,14 @@ __device__ inline void scatter_post(const KArgs &A, const Lds &l, Rng &g, Photon
     const double g_rec0 = deut ? par.g_recoil0_D : par.g_recoil0;      // :427-437
     if (par.recoil) p.xfreq = p.xfreq - (g_rec0 / sc.cl_Dfreq) * (1.0 - cost);
     if (STOKES) {
-        if (PEEL) peel_resonance_stokes<VAR>(A, l, DUST, p, xfreq_atom, ux, uy, uz, E1, E2, E3, g_rec0, npeel);
+        if (PEEL) peel_emit<VAR, STOKES>(A, PEEL_RESONANCE, p, xfreq_atom, ux, uy, uz, E1, E2, E3, g_rec0);   // peeling_resonance_stokes_outside, deferred
         double cos2p = 2.0 * cosp * cosp - 1.0, sin2p = 2.0 * sinp * cosp;
         double Q0 = cos2p * p.Q + sin2p * p.U, U0 = -sin2p * p.Q + cos2p * p.U;
         double I1 = S11 + S12 * Q0, Q1 = S12 + S22 * Q0, U1 = S33 * U0, V1 = S44 * p.V;
         p.Q = Q1 / I1; p.U = U1 / I1; p.V = V1 / I1;
         rotate_triad(p, cost, sint, cosp, sinp);
     } else {
-        if (PEEL) peel_resonance_nostokes<VAR>(A, l, DUST, p, xfreq_atom, ux, uy, uz, E1, E2, g_rec0, npeel);
+        if (PEEL) peel_emit<VAR, STOKES>(A, PEEL_RESONANCE, p, xfreq_atom, ux, uy, uz, E1, E2, E3, g_rec0);   // peeling_resonance_nostokes_outside, deferred
         rotate_k(p, cost, sint, cosp, sinp);
     }
 }
@@ -1858,5 +1890,5 @@ __device__ inline void generate_photon(const KArgs &A, const Lds &l, Rng &g, Pho
         p.icl = clump_at_point(A.cl, p.x, p.y, p.z);
         if (p.icl > 0) p.xfreq = p.xfreq - ulos_clump(A, A.cl.phys[p.icl - 1], p.kx, p.ky, p.kz);
     }
-    if (PEEL) peel_direct<VAR>(A, l, DUST, p, npeel);
+    if (PEEL) peel_emit<VAR, STOKES>(A, PEEL_DIRECT, p, p.xfreq, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0);            // peeling_direct_outside, deferred
 }

@@ -18,6 +18,7 @@ extern "C" void lart_launch_transport_var3(int, int, int, dim3, dim3, size_t, hi
 extern "C" void lart_launch_transport_var4(int, int, int, dim3, dim3, size_t, hipStream_t, const KArgs &);
 extern "C" void lart_launch_transport_var5(int, int, int, dim3, dim3, size_t, hipStream_t, const KArgs &);
 extern "C" void lart_launch_transport_var6(int, int, int, dim3, dim3, size_t, hipStream_t, const KArgs &);
+extern "C" void lart_launch_peel(int var, int stokes, dim3, dim3, size_t, hipStream_t, const KArgs &);
 
 static thread_local std::string g_err;
 static int fail(const std::string &m) { g_err = m; return 1; }
@@ -56,6 +57,8 @@ struct lart_gpu {
     // lane compaction: the launch covers lanes [0, live_lanes); state of the last lart_gpu_sync
     int64_t live_lanes = 0; bool state_valid = false; int64_t last_alive = 0, last_next_k = 0; int auto_compact = 1;
     int *d_compact = nullptr; int64_t n_compactions = 0;
+    // peel-off event queue (deferred next-event estimator): records of one transport launch, consumed by peel_kernel right after it
+    DPeelQ pq{}; void *d_pq = nullptr; size_t pq_bytes_max = (size_t)16 << 30; int peel_slice = 0; int n_cu = 0;
     // output_reduce across GPUs: RCCL communicator of this context (one rank per context)
     ncclComm_t comm = nullptr; int comm_n = 0, comm_rank = -1;
 };
@@ -105,7 +108,7 @@ extern "C" int lart_gpu_destroy(lart_gpu *c) {
     (void)hipStreamSynchronize(c->stream);
     for (auto &e : c->ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     (void)hipFree(c->d_cell); (void)hipFree(c->d_faces); (void)hipFree(c->d_mu); (void)hipFree(c->d_alias); (void)hipFree(c->d_ml_tab); (void)hipFree(c->d_ml_itab); (void)hipFree(c->d_obs); (void)hipFree(c->d_ind_bin); (void)hipFree(c->d_amr_int); (void)hipFree(c->d_amr_geom); (void)hipFree(c->d_cl_geo); (void)hipFree(c->d_cl_phys); (void)hipFree(c->d_cl_int);
-    free_tally(c); (void)hipFree(c->d_pool); (void)hipFree(c->d_ctl); (void)hipFree(c->d_log); (void)hipFree(c->d_compact);
+    free_tally(c); (void)hipFree(c->d_pool); (void)hipFree(c->d_ctl); (void)hipFree(c->d_log); (void)hipFree(c->d_compact); (void)hipFree(c->d_pq);
     if (c->comm) { (void)ncclCommDestroy(c->comm); c->comm = nullptr; }
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -496,6 +499,25 @@ static int collect_events(lart_gpu *c) {
     return 0;
 }
 
+// the peel queue: PQ_COUNT (Stokes) or PQ_NOSTOKES f64 planes + 4 int planes of `cap` records
+static int ensure_peel_queue(lart_gpu *c, int max_events) {
+    if (!c->n_cu) { hipDeviceProp_t pr; HIPCHK(hipGetDeviceProperties(&pr, c->device)); c->n_cu = pr.multiProcessorCount; }
+    const size_t planes = c->par.use_stokes ? (size_t)PQ_COUNT : (size_t)PQ_NOSTOKES, rec_bytes = planes * 8 + 16;
+    const size_t lanes = (size_t)c->pool.n;
+    size_t fit = c->pq_bytes_max / (rec_bytes * lanes);         // records per lane the byte budget allows
+    int slice = max_events;
+    if ((size_t)slice + 1 > fit) slice = fit > 1 ? (int)(fit - 1) : 1;
+    const size_t cap = lanes * ((size_t)slice + 1);
+    if (cap > 0xfffffff0ull) return fail("peel queue: more than 2^32 records per launch; lower the pool size or max_events");
+    if (!c->d_pq || c->pq.cap < cap) {
+        (void)hipFree(c->d_pq); c->d_pq = nullptr;
+        HIPCHK(hipMalloc(&c->d_pq, cap * rec_bytes));
+        c->pq.f = (double *)c->d_pq; c->pq.cell = (int *)((char *)c->d_pq + cap * planes * 8); c->pq.cap = (unsigned)cap;
+    } else slice = (int)(c->pq.cap / lanes) - 1 < max_events ? (int)(c->pq.cap / lanes) - 1 : max_events;
+    c->peel_slice = slice < 1 ? 1 : slice;
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Lane compaction.  The reference keeps every worker busy with a dynamic master/worker scheduler (run_simulation_mod.f90:31-64);
 // here a lane refills itself from the photon counter, and once the counter is exhausted the pool drains: packets end at very
@@ -578,18 +600,33 @@ extern "C" int lart_gpu_step(lart_gpu *c, int32_t nsteps, int32_t max_events) {
     // Voigt tables + faces | ring of random draws [LART_RNG_BUF][block] | per-block P1, P1_new
     size_t shmem = (size_t)(VT_END + c->g.nx + c->g.ny + c->g.nz + 3 + LART_RNG_BUF * c->block + 2 * c->jpa.lds_bins) * sizeof(double) + (size_t)LART_COOP_BYTES * ((c->block + 63) / 64);   // ... + the wave-local scratch of vz_core_coop
     if (shmem > 160 * 1024) return fail("step: grid faces do not fit the 160 KiB LDS");
+    // peel-off: a launch of `slice` events per lane queues at most live_lanes x (slice + 1) records (one per event, one per birth);
+    // the queue is sized once per run for pq_bytes_max (16 GiB by default) and a step of max_events is cut into slices that fit
+    int slice = max_events;
+    if (peel) {
+        if (ensure_peel_queue(c, max_events)) return 1;
+        slice = c->peel_slice; A.pq = c->pq;
+    }
+    const size_t peel_shmem = (size_t)(VT_END + c->g.nx + c->g.ny + c->g.nz + 3) * sizeof(double);
     for (int s = 0; s < nsteps; s++) {
         hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-        HIPCHK(hipMemsetAsync(&c->d_ctl->n_active, 0, sizeof(unsigned long long), c->stream));
         HIPCHK(hipEventRecord(e0, c->stream));
-        if (var == 0) lart_launch_transport_var0(stokes, dust, peel, grid, block, shmem, c->stream, A);
-        else if (var == 1) lart_launch_transport_var1(stokes, dust, peel, grid, block, shmem, c->stream, A);
-        else if (var == 2) lart_launch_transport_var2(stokes, dust, peel, grid, block, shmem, c->stream, A);
-        else if (var == 3) lart_launch_transport_var3(stokes, dust, peel, grid, block, shmem, c->stream, A);
-        else if (var == 4) lart_launch_transport_var4(stokes, dust, peel, grid, block, shmem, c->stream, A);
-        else if (var == 5) lart_launch_transport_var5(stokes, dust, peel, grid, block, shmem, c->stream, A);
-        else lart_launch_transport_var6(stokes, dust, peel, grid, block, shmem, c->stream, A);
-        HIPCHK(hipGetLastError());
+        for (int left = max_events; left > 0; left -= slice) {
+            A.max_events = left < slice ? left : slice;
+            HIPCHK(hipMemsetAsync(&c->d_ctl->n_active, 0, sizeof(unsigned long long) + 2 * sizeof(unsigned), c->stream));   // n_active, q_n
+            if (var == 0) lart_launch_transport_var0(stokes, dust, peel, grid, block, shmem, c->stream, A);
+            else if (var == 1) lart_launch_transport_var1(stokes, dust, peel, grid, block, shmem, c->stream, A);
+            else if (var == 2) lart_launch_transport_var2(stokes, dust, peel, grid, block, shmem, c->stream, A);
+            else if (var == 3) lart_launch_transport_var3(stokes, dust, peel, grid, block, shmem, c->stream, A);
+            else if (var == 4) lart_launch_transport_var4(stokes, dust, peel, grid, block, shmem, c->stream, A);
+            else if (var == 5) lart_launch_transport_var5(stokes, dust, peel, grid, block, shmem, c->stream, A);
+            else lart_launch_transport_var6(stokes, dust, peel, grid, block, shmem, c->stream, A);
+            HIPCHK(hipGetLastError());
+            if (peel) {                                           // grid-stride over the records: 8 workgroups per CU
+                lart_launch_peel(var, stokes, dim3((unsigned)(c->n_cu * 8)), dim3(256), peel_shmem, c->stream, A);
+                HIPCHK(hipGetLastError());
+            }
+        }
         HIPCHK(hipEventRecord(e1, c->stream));
         c->ev.emplace_back(e0, e1);
     }
@@ -676,7 +713,7 @@ extern "C" int lart_gpu_get_tallies(lart_gpu *c, lart_tallies *o) {
     HIPCHK(hipStreamSynchronize(c->stream));
     if (collect_events(c)) return 1;
     double s[16]; HIPCHK(hipMemcpy(s, c->d_tally, sizeof s, hipMemcpyDeviceToHost));
-    o->nscatt_gas = s[0]; o->nscatt_dust = s[1]; o->n_events = s[2]; o->n_cellsteps = s[3]; o->n_cellsteps_peel = s[4]; o->nphotons_done = (int64_t)(s[5] + 0.5);
+    o->nscatt_gas = s[0]; o->nscatt_dust = s[1]; o->n_events = s[2]; o->n_cellsteps = s[3]; o->n_cellsteps_peel = s[4]; o->n_atomics = s[6]; o->nphotons_done = (int64_t)(s[5] + 0.5);
     DCtl h{}; HIPCHK(hipMemcpy(&h, c->d_ctl, sizeof h, hipMemcpyDeviceToHost)); o->nphotons_active = (int64_t)h.n_active;
     int64_t nxf = c->par.nxfreq, n2 = (int64_t)c->nobs * c->nxim * c->nyim, n3 = n2 * nxf;
 #define CP(dst, src, cnt) if ((dst) && (src) && (cnt) > 0) HIPCHK(hipMemcpy((dst), (src), (size_t)(cnt) * 8, hipMemcpyDeviceToHost))
@@ -791,7 +828,7 @@ extern "C" int lart_host_entropy_seed(uint64_t *seed) {
     FILE *f = std::fopen("/dev/urandom", "rb");
     if (f) { if (std::fread(&t, sizeof t, 1, f) != 1) t = 0; std::fclose(f); }
     if (t == 0) { t = (uint64_t)std::time(nullptr) * 1000003ull ^ (uint64_t)getpid(); }
-    t &= 0x7fffffffffffffffull; if (t == 0) t = 1;            // positive and non-zero: fits the hosts' integer(int64) / a Python int
+    t &= 0x1fffffffffffffull; if (t == 0) t = 1;              // 53 bits, non-zero: exact in the hosts' integer(int64) AND in the f64 header keyword ISEED
     *seed = t;
     return 0;
 }

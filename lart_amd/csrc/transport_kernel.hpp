@@ -16,11 +16,11 @@ __device__ inline double wave_sum(double v) {
 
 // waves per SIMD the register allocator must leave room for.  Measured on the headline workload (profiles/README.md):
 // the plain kernel fits 128 VGPRs (4 waves) with a handful of spills and is fastest there; the Stokes triad adds ~30
-// registers, the peel-off rays ~40 more, and forcing those variants to 128 puts 200+ values in scratch.
+// registers.  Peel-off no longer marches inside this kernel (it queues a record, peel_kernel.hpp), so it costs no occupancy.
 #ifdef LART_MIN_WAVES
 #define LART_WAVES(S, P) LART_MIN_WAVES
 #else
-#define LART_WAVES(S, P) ((P) ? 2 : ((S) ? 3 : 4))
+#define LART_WAVES(S, P) ((S) ? 3 : 4)
 #endif
 
 
@@ -119,6 +119,7 @@ __global__ __launch_bounds__(256, LART_WAVES(STOKES, PEEL)) void transport_kerne
             generate_photon<VAR, STOKES, DUST, PEEL>(A, l, g, p, npeel);
             if (A.allph) allph_initial(A, p, k);
             alive = true; first = true;
+            if (PEEL) budget--;                                // the birth queued one peel record (direct light): lanes x (max_events + 1) records bound the queue
             LART_PROF_MARK(p, 1);
         }
         if (budget <= 0) break;

@@ -51,7 +51,7 @@ module lart_gpu_c
      type(c_ptr) :: scatt_2D, direc_2D, I_2D, Q_2D, U_2D, V_2D
      type(c_ptr) :: direc0, direc0_2D, scatt_dust
      type(c_ptr) :: J1, P1, P1_new
-     real(c_double) :: nscatt_gas, nscatt_dust, n_events, n_cellsteps, n_cellsteps_peel
+     real(c_double) :: nscatt_gas, nscatt_dust, n_events, n_cellsteps, n_cellsteps_peel, n_atomics
      integer(c_int64_t) :: nphotons_done, nphotons_active
   end type lart_tallies
 

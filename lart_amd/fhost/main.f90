@@ -39,6 +39,7 @@ program LaRT_amd
      endif
   enddo
   call system_clock(t0, rate)
+  ngpu = 1
 
   call read_input(trim(infile))
   !--- par%iseed = 0: seed from the operating system, as init_random_mt_seed does (random_mt.f90:889-947); printed and written
@@ -385,7 +386,7 @@ contains
        ncol = ncol + 1; cols(:,ncol) = g%Jin
     endif
     call kadd(kl, 'ExeTime',  par%exetime,        'Excution Time (min)')
-    call kadd(kl, 'Nprocs',   1,                  'No. of Threads')
+    call kadd(kl, 'Nprocs',   max(ngpu, 1),       'No. of Threads')          ! here: GPUs that shared the photons
     call kadd(kl, 'recoil',   par%recoil,         'recoil')
     call kadd(kl, 'coreskip', par%core_skip,      'coreskip algorithm')
     call kadd(kl, 'xyz_sym',  par%xyz_symmetry,   'xyz_symmetry')
@@ -421,6 +422,7 @@ contains
     call kadd(kl, 'calc_P',   par%calc_P,         'calculated Pa within media?')
     call kadd(kl, 'calc_Pnew', par%calc_Pnew,     'calculated Pa within media?')
     call kadd(kl, 'calc_J',   par%calc_J,         'calculated J within media?')
+    call kadd(kl, 'ISEED',    real(par%run_seed, wp), 'random seed of this run (host addition; iseed = 0: drawn from the OS)')
     call kadd(ki, 'nphotons', real(par%nphotons, wp), 'number of photons')
     call kadd(ki, 'dxim', par%dxim, 'pixel size along x (deg)')
     call kadd(ki, 'dyim', par%dyim, 'pixel size along y (deg)')

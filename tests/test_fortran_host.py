@@ -318,6 +318,18 @@ def test_output_containers_hdf5_and_gzip_fits(exe, tmp_path):
     for k in ("taumax", "voigta", "dfreq", "xfreq1"):
         assert np.isclose(float(fk[k]), float({kk.lower(): vv for kk, vv in H["Spectrum"][0].items()}[k]), rtol=1e-9), k
     assert H["Spectrum"][0]["taumax"] == 100.0 and H["Spectrum"][0]["nx"] == 11 and H["Spectrum"][0]["xyz_sym"] == 0
+    # the full keyword set of the Spectrum section, in the reference's order (write_output_rect.f90:448-497; EXTNAME is the group name /
+    # the FITS extension name here), + the host's ISEED
+    want = ["ExeTime", "Nprocs", "recoil", "coreskip", "xyz_sym", "xy_per", "save_all", "save_Jin", "save_Jab", "nphotons", "taumax", "tauhomo", "Ngasmax",
+            "Ngashomo", "temp", "Vexp", "DGR", "atau3", "voigta", "Xfreq1", "Xfreq2", "Dxfreq", "Dwave", "I_unit", "Dfreq", "Nsc_dust", "Nsc_gas", "Nsc_tot",
+            "nx", "ny", "nz", "xmax", "ymax", "zmax", "calc_P", "calc_Pnew", "calc_J", "ISEED"]
+    fits_keys = [k for k in F["Spectrum"][0] if k.upper() in {w.upper()[:8] for w in want}]          # FITS keywords hold 8 characters (calc_Pnew -> calc_Pne)
+    assert [k.upper() for k in fits_keys] == [w.upper()[:8] for w in want]
+    assert sorted(k.lower() for k in H["Spectrum"][0] if k.lower() != "extname") == sorted(w.lower() for w in want)
+    hk = {k.lower(): v for k, v in H["Spectrum"][0].items()}
+    assert hk["nphotons"] == 1000 and hk["temp"] == 1e4 and hk["nprocs"] == 1 and hk["i_unit"] == 0 and hk["coreskip"] == 0 and hk["save_jin"] == 1
+    assert 0 < hk["iseed"] < 2.0 ** 53 and hk["iseed"] == int(hk["iseed"])   # par%iseed = 0 in this input: drawn from the operating system and recorded exactly
+    assert np.isclose(hk["dxfreq"], (hk["xfreq2"] - hk["xfreq1"]) / 41) and np.isclose(hk["atau3"], (hk["voigta"] * 100.0) ** (1.0 / 3.0), rtol=1e-6)
     assert H["Jmu"][1].shape == (41, 5) and F["Jmu"][1].shape == (41, 5)
     S = read_h5(str(tmp_path / "ch_stokes.h5")); O = read_h5(str(tmp_path / "ch_obs.h5"))
     assert list(S) == ["Stokes_I", "Stokes_Q", "Stokes_U", "Stokes_V"] and S["Stokes_Q"][1].shape == (41, 8, 8)

@@ -345,9 +345,8 @@ def test_deuterium_peel_and_clumps_whole_path(capi, oracle_mod):
     ng, xg = sim.ctx.photon_log(n); no, xo = o.photon_log()
     same = np.isclose(ng, no, rtol=1e-12, atol=0) & np.isclose(xg, xo, rtol=1e-7, atol=1e-9)
     assert same.mean() > 0.97 and rms_diff(t["Jout"], o.array("Jout")) < 0.01
-    # the deuterium notch: with D/H = 0.02 the blue side (82 km/s) has fewer escaping photons than the red side
-    v = np.linspace(-300, 300, 161); J = t["Jout"]
-    assert J[(v < -60) & (v > -110)].sum() < J[(v > 60) & (v < 110)].sum() or True
+    # (no dust: every photon escapes, so the angle-integrated spectrum has no deuterium notch to test for -- photon conservation instead)
+    assert 0.95 * n < t["Jout"].sum() <= n * (1 + 1e-9)       # (a few leave through the ends of the frequency axis of the continuum source)
 
 
 def test_fine_structure_peel_and_clumps_whole_path(capi, oracle_mod):
@@ -444,6 +443,72 @@ def test_dust_mueller_vs_oracle(capi, oracle_mod, mueller_file):
     assert abs(t["Jabs"].sum() - o.array("Jabs").sum()) < 0.05 * o.array("Jabs").sum() + 50
     # energy bookkeeping: escaped + absorbed = emitted
     assert abs(t["Jout"].sum() + t["Jabs"].sum() - n) < 0.01 * n
+
+
+def _cubes_batchwise(sim, o, names, shapes, nbatch, per, seed):
+    """run `nbatch` batches of `per` photons (ids 1 + b*per ...) on the device and in the oracle with the same streams; return per batch
+    whether every photon of it had the same history on both sides, and the (device, oracle) deposits of the batch for every tally in `names`"""
+    sim.ctx.enable_photon_log(True)
+    prev = None; out = []
+    for b in range(nbatch):
+        first = 1 + b * per
+        sim.ctx.run(per, first_id=first, stride=1, seed=seed)
+        t = sim.ctx.tallies()
+        ng, xg = sim.ctx.photon_log(per)
+        o.zero(); o.run(per, first_id=first, stride=1, seed=seed)
+        no, xo = o.photon_log()
+        clean = bool(np.all(np.isclose(ng, no, rtol=1e-12, atol=0) & np.isclose(xg, xo, rtol=1e-9, atol=1e-12)))
+        cur = {k: t[k].copy() for k in names}                               # device tallies are cumulative over runs: take the increment
+        dev = {k: (cur[k] - prev[k] if prev is not None else cur[k]) for k in names}
+        prev = cur
+        ora = {k: o.array(k + ":0").reshape(shapes[k], order="F") for k in names}
+        out.append((clean, dev, ora))
+    return out
+
+
+@pytest.mark.parametrize("case", ["resonance_stokes", "dust_mueller_stokes", "dust_hg_direc0", "amr_stokes", "clump_dust_stokes"])
+def test_peel_cubes_equal_the_oracle_on_identical_histories(capi, oracle_mod, mueller_file, amr_file, case):
+    """The peel-off tallies on the SAME photon histories.  Device and oracle run the same (seed, id) streams; ~97 % of the histories are
+    identical, the rest flip at a rejection test on a last-bit difference and then diverge.  Batches of 16 photons in which every
+    history is identical must give the same Stokes cubes and images to 1e-9 of the cube's largest entry -- a wrong sign of a Stokes
+    rotation or a wrong pixel on any branch shows up at order one here, where the statistical comparisons allow percents."""
+    if case == "resonance_stokes":
+        kw = dict(temperature=1e4, taumax=50.0, nx=41, ny=41, nz=41, rmax=1.0, nxfreq=61, nxim=16, nyim=16, use_stokes=True,
+                  save_peeloff_2D=True, alpha=25.0, beta=60.0, recoil=True)
+    elif case == "dust_mueller_stokes":
+        kw = dict(temperature=1e4, taumax=3e1, nx=21, ny=21, nz=21, rmax=1.0, nxfreq=61, nxim=16, nyim=16, use_stokes=True, DGR=1.2e6, scatt_mat_file=mueller_file,
+                  save_peeloff_2D=True, save_direc0=True, save_dust_scattered=True, alpha=15.0, beta=40.0, velocity_type="hubble", Vexp=30.0)
+    elif case == "dust_hg_direc0":
+        kw = dict(temperature=1e4, taumax=3e1, nx=21, ny=21, nz=21, rmax=1.0, nxfreq=61, nxim=16, nyim=16, DGR=1.0, cext_dust=2e-15,
+                  save_peeloff_2D=True, save_direc0=True, save_dust_scattered=True, alpha=15.0, beta=40.0, source_geometry="uniform_sphere", source_rmax=0.7)
+    elif case == "amr_stokes":
+        kw = dict(use_amr_grid=True, amr_file=amr_file, temperature=1e4, taumax=1e2, rmax=1.0, nxfreq=61, nxim=16, nyim=16, use_stokes=True,
+                  DGR=1.0, scatt_mat_file=mueller_file, velocity_type="hubble", Vexp=20.0, alpha=30.0, beta=65.0, save_peeloff_2D=True)
+    else:
+        kw = dict(CLUMP, clump_tau0=1e2, use_stokes=True, DGR=1.0, scatt_mat_file=mueller_file, cext_dust=1.6e-21, nxim=16, nyim=16,
+                  save_peeloff_2D=True, alpha=20.0, beta=50.0)
+    kw["iseed"] = 1
+    sim = make(kw)
+    o = oracle_mod.Oracle(**{k: v for k, v in kw.items() if k != "iseed"})
+    nxf = sim.cpar.nxfreq
+    names = ["scatt", "direc"] + (["I", "Q", "U", "V"] if kw.get("use_stokes") else []) + (["direc0", "scatt_dust"] if kw.get("save_direc0") else [])
+    names2 = [k + "_2D" for k in ("scatt", "direc") + (("I", "Q", "U", "V") if kw.get("use_stokes") else ())]
+    shapes = {k: (nxf, 16, 16) for k in names}; shapes.update({k: (16, 16) for k in names2})
+    res = _cubes_batchwise(sim, o, names + names2, shapes, nbatch=60, per=16, seed=2024)
+    nclean = sum(1 for c, _, _ in res if c)
+    assert nclean >= 12, nclean                                             # enough batches without a flipped history
+    tot = {k: 0.0 for k in names + names2}
+    for clean, dev, ora in res:
+        if not clean:
+            continue
+        for k in names + names2:
+            d = dev[k][..., 0] if dev[k].ndim > len(shapes[k]) else dev[k]
+            scale = max(np.abs(ora["I" if "I" in ora else "scatt"]).max(), 1e-300) if not k.endswith("_2D") else max(np.abs(ora["I_2D" if "I_2D" in ora else "scatt_2D"]).max(), 1e-300)
+            assert np.allclose(d, ora[k], rtol=1e-9, atol=1e-9 * scale), (case, k, float(np.abs(d - ora[k]).max() / scale))
+            tot[k] += np.abs(ora[k]).sum()
+    assert tot["scatt"] > 0 and tot["direc"] >= 0
+    if kw.get("use_stokes"):
+        assert tot["Q"] > 0 and tot["U"] > 0                                 # the polarised deposits were really exercised
 
 
 @pytest.mark.parametrize("stokes", [False, True])

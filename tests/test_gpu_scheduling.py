@@ -1,0 +1,121 @@
+"""Scheduling / exchange features of the HIP path on a real MI355X: lane compaction in the drain phase, the library's own RCCL
+reduce (one rank and the one-process multi-context entry point), the setters' "end the current run" rule, run_multi.
+
+None of them may change a result: a packet's history is a function of (seed, id) only, so every check here is bit-for-bit
+against the same library without the feature (and, for the histories, against the CPU oracle)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+KW = dict(temperature=1e4, taumax=3e3, xyz_symmetry=True, nx=31, ny=31, nz=31, rmax=1.0, nxfreq=101, iseed=9)
+
+
+@pytest.fixture(scope="module")
+def capi():
+    import __graft_entry__ as g
+    g.build()
+    from lart_amd import capi
+    assert capi.lib().lart_gpu_device_count() > 0, "no GPU visible: the HIP path cannot run (there is no fallback)"
+    return capi
+
+
+def make(kw, device=0):
+    from lart_amd import host
+    return host.Simulation(dict(kw), device)
+
+
+def drain(sim, n, events, compact):
+    sim.ctx.set_pool(8192, 256); sim.ctx.set_auto_compact(compact); sim.ctx.enable_photon_log(True)
+    sim.ctx.begin(n, seed=9)
+    lanes = [sim.ctx.pool_info()[0]]
+    while True:
+        sim.ctx.step(1, events)
+        done, active = sim.ctx.sync()
+        lanes.append(sim.ctx.live_lanes()[0])
+        if active == 0:
+            break
+    return sim.ctx.photon_log(n), sim.ctx.tallies(), lanes
+
+
+def test_lane_compaction_changes_nothing_but_the_grid(capi, oracle_mod):
+    """8192 lanes, 8192 photons: no refill at all, the whole run is a drain.  With compaction the launches shrink with the live
+    lanes; per-photon scattering counts and exit frequencies are identical with and without it, and equal the oracle's."""
+    n = 8192
+    (na, xa), ta, la = drain(make(KW), n, 256, True)
+    (nb, xb), tb, lb = drain(make(KW), n, 256, False)
+    assert np.array_equal(na, nb) and np.array_equal(xa, xb)
+    assert np.allclose(ta["Jout"], tb["Jout"], rtol=0, atol=1e-9) and ta["nphotons_done"] == tb["nphotons_done"] == n
+    assert ta["n_events"] == tb["n_events"]
+    assert min(lb) == max(lb) == 8192                      # feature off: the grid never changes
+    assert la[-1] <= 512 and sorted(la, reverse=True) == la and len(set(la)) >= 4, la
+    o = oracle_mod.Oracle(**{k: v for k, v in KW.items() if k != "iseed"}); o.run(n, seed=9)
+    no, xo = o.photon_log()
+    same = np.isclose(na, no, rtol=1e-12, atol=0) & np.isclose(xa, xo, rtol=1e-7, atol=1e-9)
+    assert same.mean() > 0.97
+
+
+def test_forced_compaction_mid_run_with_stokes_planes(capi):
+    """lart_gpu_compact by hand in the middle of a Stokes run (19 state planes move): same histories as an undisturbed run"""
+    kw = dict(KW, taumax=300.0, use_stokes=True, xyz_symmetry=False, nx=21, ny=21, nz=21)
+    n = 4096
+    a = make(kw); a.ctx.set_pool(4096, 64); a.ctx.set_auto_compact(False); a.ctx.enable_photon_log(True); a.ctx.begin(n, seed=5)
+    k = 0
+    while True:
+        a.ctx.step(1, 40); k += 1
+        if a.ctx.sync()[1] == 0:
+            break
+        if k % 3 == 0:
+            a.ctx.compact()
+    assert a.ctx.live_lanes()[1] >= 2
+    b = make(kw); b.ctx.set_auto_compact(False); b.ctx.enable_photon_log(True); b.run_simulation(n, seed=5)
+    na, xa = a.ctx.photon_log(n); nb, xb = b.ctx.photon_log(n)
+    assert np.array_equal(na, nb) and np.array_equal(xa, xb)
+
+
+def test_rccl_reduce_entry_points_one_rank(capi):
+    """the library's RCCL communicator with the one rank a 1-GPU box has: lart_gpu_comm_init / _reduce_tallies and the one-process
+    multi-context entry point leave the totals unchanged; RCCL itself reports the rank count"""
+    sim = make(KW); sim.run_simulation(3000)
+    before = sim.ctx.tallies()
+    sim.ctx.comm_init(capi.comm_unique_id(), 1, 0)
+    assert sim.ctx.comm_info() == (1, 0)
+    sim.ctx.reduce_tallies(0)
+    capi.reduce_tallies_multi([sim.ctx], 0)
+    after = sim.ctx.tallies()
+    assert np.array_equal(before["Jout"], after["Jout"]) and before["nscatt_gas"] == after["nscatt_gas"]
+    with pytest.raises(capi.LartError):
+        sim.ctx.reduce_tallies(1)                          # root outside the communicator
+    sim.ctx.comm_destroy()
+    assert sim.ctx.comm_info()[0] == 0
+    with pytest.raises(capi.LartError):
+        sim.ctx.reduce_tallies(0)                          # no communicator any more
+
+
+def test_run_multi_one_context_equals_run(capi):
+    a = make(KW); a.ctx.enable_photon_log(True); capi.run_multi([a.ctx], 5000, 9)
+    b = make(KW); b.ctx.enable_photon_log(True); b.run_simulation(5000, seed=9)
+    assert np.array_equal(a.ctx.photon_log(5000)[0], b.ctx.photon_log(5000)[0])
+    assert np.allclose(a.ctx.tallies()["Jout"], b.ctx.tallies()["Jout"], rtol=0, atol=1e-9)
+
+
+def test_setter_after_begin_ends_the_run(capi):
+    """a set_* call frees tables the resident pool refers to: the run is over, lart_gpu_step must refuse instead of launching"""
+    sim = make(KW)
+    sim.ctx.begin(1000, seed=1); sim.ctx.step(1, 16); sim.ctx.sync()
+    g = sim.grid
+    sim.ctx.set_grid_car(g.nx, g.ny, g.nz, g.xmin, g.ymin, g.zmin, g.dx, g.dy, g.dz, g.i0, g.j0, g.k0,
+                         g.xface, g.yface, g.zface, g.rhokap, g.voigt_a, g.Dfreq, g.vfx, g.vfy, g.vfz, g.rhokapD)
+    with pytest.raises(capi.LartError, match="begin"):
+        sim.ctx.step(1, 16)
+    sim.ctx.begin(1000, seed=1); sim.ctx.step(1, 16)      # a fresh begin works
+    assert sim.ctx.sync()[0] >= 0
+
+
+def test_second_run_accumulates_and_normalises_by_finished_photons(capi):
+    """device tallies are cumulative over runs; output_normalize divides by the photons the device finished"""
+    a = make(KW); a.run_simulation(4000, rank=0, nproc=2); a.run_simulation(4000, rank=1, nproc=2)
+    b = make(KW); b.run_simulation(4000)
+    ja, jb = a.output_normalize()["Jout"], b.output_normalize()["Jout"]
+    assert a.ctx.tallies()["nphotons_done"] == 4000
+    assert np.allclose(ja, jb, rtol=1e-12, atol=1e-18)

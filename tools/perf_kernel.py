@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Steady-state launches of ONE transport-kernel variant for rocprofv3 (tools/gpu_job.sh profcfg:TAG:CONFIG) and for the
+roofline of the configurations bench.py does not time (BASELINE.json configs[0], [2], [3], [4] = C1, C3, C4, C5).
+
+  python tools/perf_kernel.py --config c3 [--warm 3 --steps 4 --events 4096]
+
+prints one JSON line: events/s, cells per event (flight and peel rays), tally atomics per event as the kernels count them, the
+algorithmic bytes of SURVEY section 8(d) (48 B per visited cell of flight and peel rays + 16 B per tally atomic) per launch, the
+average launch duration from HIP events on the launch stream, and the HBM roofline fraction."""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def configs(tmp):
+    from lart_amd import amr
+    from conftest_data import mueller_path
+    afile = os.path.join(tmp, "sphere.dat")
+    c = {
+        "c1": dict(temperature=10.0, taumax=1e4, xy_periodic=True, nx=1, ny=1, nz=201, use_stokes=True, save_Jin=True, hgg=0.6592, albedo=0.3899, no_photons=1e8, iseed=1),
+        "c2": dict(temperature=10.0, taumax=1e6, xyz_symmetry=True, nx=101, ny=101, nz=101, rmax=1.0, nxfreq=201, no_photons=1e7, iseed=1),
+        "c3": dict(temperature=10.0, taumax=1e6, nx=201, ny=201, nz=201, rmax=1.0, nxfreq=201, use_stokes=True, save_Jin=True, nxim=129, nyim=129, no_photons=1e8, iseed=1),
+        "c4": dict(use_clump_medium=True, rmax=1.0, clump_radius=0.01, clump_f_cov=5.0, clump_tau0=1e3, temperature=1e4, use_stokes=True, DGR=1.0,
+                   scatt_mat_file="MUELLER", core_skip=True, nxfreq=301, velocity_min=-100.0, velocity_max=100.0, nx=11, ny=11, nz=11, no_photons=1e8, iseed=1),
+        "c5": dict(use_amr_grid=True, amr_file=afile, temperature=1e4, taumax=1e4, rmax=1.0, nxfreq=241, xfreq_min=-15.0, xfreq_max=15.0,
+                   calc_J=True, calc_P=True, calc_Pnew=True, no_photons=1e8, iseed=1),
+        "c5n": dict(use_amr_grid=True, amr_file=afile, temperature=1e4, taumax=1e4, rmax=1.0, nxfreq=241, xfreq_min=-15.0, xfreq_max=15.0, no_photons=1e8, iseed=1),
+    }
+    return c, afile, mueller_path
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="c3")
+    ap.add_argument("--warm", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--events", type=int, default=4096)
+    ap.add_argument("--lanes", type=int, default=0)
+    a = ap.parse_args()
+    import torch
+    torch.cuda.init()
+    from lart_amd import host, amr
+    tmp = tempfile.mkdtemp()
+    cfgs, afile, mueller_path = configs(tmp)
+    kw = dict(cfgs[a.config])
+    if kw.get("use_amr_grid"):
+        amr.write_generic_amr(afile, amr.make_amr_sphere())
+    if kw.get("scatt_mat_file") == "MUELLER":
+        kw["scatt_mat_file"] = mueller_path(tmp)
+    sim = host.Simulation(kw)
+    if a.lanes:
+        sim.ctx.set_pool(a.lanes, 0)
+    sim.ctx.begin(int(kw["no_photons"]), seed=1)
+    for _ in range(a.warm):
+        sim.ctx.step(1, a.events)
+    sim.ctx.sync()
+    t0 = sim.ctx.tallies(); ms0, nl0 = sim.ctx.kernel_time(); w0 = time.perf_counter()
+    sim.ctx.step(a.steps, a.events); sim.ctx.sync()
+    dt = time.perf_counter() - w0; t1 = sim.ctx.tallies(); ms1, nl1 = sim.ctx.kernel_time()
+    d = lambda k: t1[k] - t0[k]
+    ev, nl = d("n_events"), max(nl1 - nl0, 1)
+    k_ms = (ms1 - ms0) / nl
+    atom = d("n_atomics") if "n_atomics" in t1 else 0.0
+    bytes_launch = (48.0 * (d("n_cellsteps") + d("n_cellsteps_peel")) + 16.0 * atom) / nl
+    out = {"config": a.config, "events_per_s": ev / dt, "events_per_launch": ev / nl, "avg_launch_ms": k_ms, "cells_per_event": d("n_cellsteps") / max(ev, 1),
+           "peel_cells_per_event": d("n_cellsteps_peel") / max(ev, 1), "atomics_per_event": atom / max(ev, 1), "lanes": sim.ctx.pool_info()[0],
+           "photons_finished": d("nphotons_done"), "events_per_step_per_lane": a.events,
+           "roofline": {"bound": "hbm", "achieved": bytes_launch / (k_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                        "frac": bytes_launch / (k_ms * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes_per_launch": bytes_launch}}
+    print(json.dumps(out), flush=True)
+    sim.ctx.close()
+
+
+if __name__ == "__main__":
+    main()
