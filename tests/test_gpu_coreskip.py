@@ -33,7 +33,7 @@ def make(kw):
 
 def histories(capi, oracle_mod, kw, n, seed):
     sim = make(dict(kw, iseed=seed)); sim.ctx.enable_photon_log(True); sim.run_simulation(n)
-    o = oracle_mod.Oracle(**kw); o.run(n, seed=seed)
+    o = oracle_mod.Oracle(**(dict(kw, iseed=seed) if kw.get("use_clump_medium") else kw)); o.run(n, seed=seed)      # (clumps: the same placement stream)
     ng, xg = sim.ctx.photon_log(n); no, xo = o.photon_log()
     same = np.isclose(ng, no, rtol=1e-12, atol=0) & np.isclose(xg, xo, rtol=1e-7, atol=1e-9)
     return sim, o, ng, no, same
@@ -102,7 +102,7 @@ def test_clump_core_skip_stress(capi, oracle_mod):
     assert np.array_equal(a.ctx.photon_log(n)[0], b.ctx.photon_log(n)[0])
     kw = dict(base, core_skip_global=True)
     sim, o, ng, no, same = histories(capi, oracle_mod, kw, n, 5)
-    assert sim.cpar.xcrit > 0.0
+    assert sim.cpar.xcrit > 0.0 and np.isclose(sim.cpar.xcrit, o.scalar("xcrit"), rtol=1e-12)
     assert same.mean() > 0.95, same.mean()
-    assert ng.mean() < 0.8 * b.ctx.photon_log(n)[0].mean()
+    assert np.mean(ng != b.ctx.photon_log(n)[0]) > 0.3       # grid%xcrit of the clump set-up is small (a tau_homo / ... < 1 per cell): few events skip, many histories change
     assert rms_diff(sim.ctx.tallies()["Jout"], o.array("Jout")) < flipped_rms(same, n)

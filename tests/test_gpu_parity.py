@@ -489,7 +489,7 @@ def test_peel_cubes_equal_the_oracle_on_identical_histories(capi, oracle_mod, mu
                   save_peeloff_2D=True, alpha=20.0, beta=50.0)
     kw["iseed"] = 1
     sim = make(kw)
-    o = oracle_mod.Oracle(**{k: v for k, v in kw.items() if k != "iseed"})
+    o = oracle_mod.Oracle(**{k: v for k, v in kw.items() if k != "iseed" or kw.get("use_clump_medium")})      # (clumps: iseed places them)
     nxf = sim.cpar.nxfreq
     names = ["scatt", "direc"] + (["I", "Q", "U", "V"] if kw.get("use_stokes") else []) + (["direc0", "scatt_dust"] if kw.get("save_direc0") else [])
     names2 = [k + "_2D" for k in ("scatt", "direc") + (("I", "Q", "U", "V") if kw.get("use_stokes") else ())]

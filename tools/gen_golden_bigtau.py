@@ -18,6 +18,7 @@ from the scatter between chunks, <N_scatt> and its error, and for c3 the peel-in
 """
 import argparse
 import glob
+import json
 import os
 import sys
 import time
@@ -128,7 +129,7 @@ def merge(a):
     scale = nph * dxf * 2.0 * np.pi * area
     out = {"nphotons": nph, "nchunk": nchunk, "chunk": chunk, "xfreq": o.xfreq_axis(), "dxfreq": dxf, "Jout_scale_per_photon": dxf * 2.0 * np.pi * area,
            "nscatt_mean": logn.mean(), "nscatt_err": logn.std() / np.sqrt(len(logn)),
-           "params": " ".join("%s=%s" % kv for kv in sorted(kw.items())), "rng": "MT19937-64, seed0 + 100003*worker + chunk"}
+           "params": json.dumps(kw, sort_keys=True), "rng": "MT19937-64, seed0 + 100003*worker + chunk"}
     for k, v in acc.items():
         mean_chunk = v / nchunk
         var_chunk = np.maximum(acc2[k] / nchunk - mean_chunk ** 2, 0.0) * nchunk / max(nchunk - 1, 1)

@@ -42,7 +42,7 @@ for spec in "$@"; do
   case $what in
     smoke)   step smoke 400 python __graft_entry__.py smoke ;;
     avail)   step avail 120 rocprofv3 --list-avail ;;
-    tests)   if [ -n "$a1" ]; then step tests 1100 python -m pytest tests -m gpu -q -x --timeout=900 -k "$a1"; else step tests 1100 python -m pytest tests -m gpu -q -x --timeout=900; fi ;;
+    tests)   if [ -n "$a1" ]; then step tests 1100 python -m pytest tests -m gpu -q --timeout=900 --durations=40 -k "$a1"; else step tests 1100 python -m pytest tests -m gpu -q --timeout=900 --durations=40; fi ;;
     bench)   step bench 900 python bench.py ${a1//,/ } ;;
     configs) step configs 900 python tools/perf_configs.py ;;
     prof)    profile "$a1" transport_kernel 4096 python3 bench.py --no-cpu-baseline --completion-photons 0 ${a2//,/ } ;;
