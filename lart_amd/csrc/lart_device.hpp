@@ -90,7 +90,7 @@ struct DJPa { int calc_J, calc_P, calc_Pnew, nbins; const int *ind_bin; double c
 // lart_gpu_get_tallies / lart_gpu_tally_buffer fold the copies back (k_fold_copies) before anything is read.
 struct DRep { double *base; long long off, len; int nrep; };
 
-struct DCtl { unsigned long long next_k; unsigned long long n_active; unsigned q_n, q_pad; };   // q_n: records in the peel queue of this launch
+struct DCtl { unsigned long long next_k; unsigned long long n_active; unsigned q_n, q_pad; unsigned long long q_head; };   // q_n: records in the peel queue of this launch; q_head: (record, observer) items peel_kernel has handed out
 
 // Peel-off event queue (deferred next-event estimator).  The reference marches a second ray to every observer inside each scattering
 // (peelingoff_rect.f90:576-690 etc.).  Inlined into the transport kernel that second march doubles its live state (2 waves/SIMD, scratch
@@ -100,7 +100,10 @@ struct DCtl { unsigned long long next_k; unsigned long long n_active; unsigned q
 enum { PQ_X = 0, PQ_Y, PQ_Z, PQ_KX, PQ_KY, PQ_KZ, PQ_WGT, PQ_XA, PQ_UX, PQ_UY, PQ_UZ, PQ_E1, PQ_E2, PQ_E3, PQ_GREC, PQ_NOSTOKES,
        PQ_MX = PQ_NOSTOKES, PQ_MY, PQ_MZ, PQ_NX, PQ_NY, PQ_NZ, PQ_Q, PQ_U, PQ_V, PQ_COUNT };
 enum { PEEL_DIRECT = 0, PEEL_RESONANCE = 1, PEEL_DUST = 2 };
-struct DPeelQ { double *f; int *cell; unsigned cap; };   // f: PQ_COUNT planes of cap doubles; cell: 4 planes (ic, jc, kc | owner clump, kind)
+// Every producer wave owns one region of `region` consecutive record slots (64 lanes x (events of the launch + 1)) and fills it from the
+// front: the slot counter is a per-wave word in LDS, so queueing costs no global atomic (one counter for the whole grid serialises in
+// L2: measured +6 ms on a 9 ms launch); count[w] = records wave w wrote.  peel_kernel takes whole regions from the queue head.
+struct DPeelQ { double *f; int *cell; unsigned cap; unsigned region, nregions; unsigned *count; };   // f: PQ_COUNT planes of cap doubles; cell: 4 planes (ic, jc, kc | owner clump, kind)
 
 // resonance + fluorescence multiplets (line types 4, 5, 6: lart_line_multiplet).  The per-level constants are wave-uniform and ride
 // in the kernel arguments; the per-branch tables are gathered with lane-varying (iup, idown) from global memory:
@@ -144,6 +147,7 @@ static __device__ const double c_voigt_tab[606] = {   // H0(101) | H1(202) | H2(
 struct Lds { const double *vt; const double *xf, *yf, *zf;   // Voigt tables and cell faces staged in LDS
              double dip_p2, dip_qs;      // Cardano constants of the dipole phase function for par.E1 > 0 (rand_resonance): p, 1/(E1 p^3)
              double *jp_P, *jp_Pn;       // per-block LDS copies of P1 / P1_new (nullptr: deposits go to global memory)
+             unsigned *pq_cnt;           // this wave's record counter of the peel queue (LDS word), nullptr = no peel-off
              unsigned char *coop;        // LART_COOP_BYTES per wave: scratch of the cooperative samplers (vz_core_coop / vz_wing_coop), nullptr = off
              int lt; double dnu_hz;      // line type (1 single line, 2 Ly-alpha doublet, 7 H + D) and DnuHK_Hz / delta_nu_HD_Hz: set from the kernel's template
              int ml_nup, ml_coh; double ml_dE[3], ml_damp[3], ml_f12[3]; const double *ml_tab; const int *ml_itab;   // lt 4 = the multiplets (line types 4, 5, 6): DMulti
@@ -156,7 +160,7 @@ __device__ inline Lds lds_stage(double *sh, const DGrid &g) {
     for (int i = threadIdx.x; i < nf; i += blockDim.x) sh[VT_END + i] = g.faces[i];
     __syncthreads();
     Lds l; l.vt = sh; l.xf = sh + VT_END; l.yf = l.xf + (g.nx + 1); l.zf = l.yf + (g.ny + 1);
-    l.dip_p2 = 0.0; l.dip_qs = 0.0; l.jp_P = nullptr; l.jp_Pn = nullptr; l.coop = nullptr; l.lt = 1; l.dnu_hz = 0.0; l.hd_ratio = 1.0; l.hd_ratio_a = 1.0; l.hd_nD = 0.0; l.ml_nup = 1; l.ml_coh = 0; l.ml_tab = nullptr; l.ml_itab = nullptr;
+    l.dip_p2 = 0.0; l.dip_qs = 0.0; l.jp_P = nullptr; l.jp_Pn = nullptr; l.coop = nullptr; l.pq_cnt = nullptr; l.lt = 1; l.dnu_hz = 0.0; l.hd_ratio = 1.0; l.hd_ratio_a = 1.0; l.hd_nD = 0.0; l.ml_nup = 1; l.ml_coh = 0; l.ml_tab = nullptr; l.ml_itab = nullptr;
     for (int i = 0; i < 3; i++) { l.ml_dE[i] = 0.0; l.ml_damp[i] = 1.0; l.ml_f12[i] = 0.0; }
     return l;
 }
@@ -942,32 +946,42 @@ __device__ inline void jpa_segment_amr(const KArgs &A, const Lds &l, const Photo
     }
     if (A.jpa.calc_Pnew) atomicAdd(&(l.jp_Pn ? l.jp_Pn : A.jpa.P1_new)[ib - 1], dtauH * p.wgt / (c.rhokap * c.Dfreq / A.jpa.cross0));
 }
+// State of a tau-to-the-edge march between two cell steps.  raytrace_to_edge runs begin + step until done; the peel kernel keeps one
+// march per lane and lets every lane advance by one cell per iteration, so that a lane whose ray is over takes the next record while its
+// neighbours are still marching (peel_kernel.hpp).  Same statements in the same order as the one-piece loops they replace.
+struct EdgeMarch {
+    bool live;
+    double tau, d, xfreq, dist, kx, ky, kz;
+    Trav t; double Dold, u1, rk, va, rD;          // Cartesian variants
+    double x, y, z; int il; long long icl;        // octree leaf / owner clump and the running position
+};
 // raytrace_to_edge_amr (:265-344) / raytrace_to_dist_amr (:559-640)
-__device__ inline double raytrace_to_edge_amr(const KArgs &A, const Lds &l, bool dust, const Photon &p, double xfreq, double kx, double ky, double kz, double dist, unsigned &nsteps) {
+__device__ inline void edge_begin_amr(const KArgs &A, const Photon &p, EdgeMarch &m) {
     const DAmr &a = A.amr;
-    double x = p.x, y = p.y, z = p.z, tau = 0.0, d = 0.0;
-    int il = p.ic;
-    if (il <= 0) { il = amr_find_leaf(a, x, y, z); if (il <= 0) return tau; }
-    const Cell *c = &A.g.cell[il - 1];
-    double u1 = c->vfx * kx + c->vfy * ky + c->vfz * kz;
-    for (;;) {
-        int ic = a.icell_of_leaf[il - 1], iface;
-        double t_exit = amr_cell_exit(a.geom[ic - 1], x, y, z, kx, ky, kz, iface);
-        double rhokap = c->rhokap * calc_voigt(l, xfreq, c->voigt_a, c->Dfreq);
-        if (dust) rhokap = rhokap + c->rhokapD;
-        nsteps++;
-        if (dist >= 0.0 && d + t_exit >= dist) return tau + (dist - d) * rhokap;
-        tau = tau + t_exit * rhokap;
-        if (tau >= LART_TAU_HUGE) return tau;
-        d = d + t_exit; x = x + t_exit * kx; y = y + t_exit * ky; z = z + t_exit * kz;
-        int il_new = amr_next_leaf(a, ic, iface, x, y, z); bool reflected = false;
-        if (il_new <= 0) il_new = amr_boundary(A.par, il, iface, kx, ky, kz, reflected);
-        if (il_new <= 0) return tau;
-        const Cell *cn = &A.g.cell[il_new - 1];
-        double u2 = cn->vfx * kx + cn->vfy * ky + cn->vfz * kz;
-        xfreq = reflected ? (xfreq + u1) - u2 : (xfreq + u1) * c->Dfreq / cn->Dfreq - u2;
-        u1 = u2; il = il_new; c = cn;
-    }
+    m.x = p.x; m.y = p.y; m.z = p.z; m.il = p.ic;
+    if (m.il <= 0) { m.il = amr_find_leaf(a, m.x, m.y, m.z); if (m.il <= 0) { m.live = false; return; } }
+    const Cell *c = &A.g.cell[m.il - 1];
+    m.u1 = c->vfx * m.kx + c->vfy * m.ky + c->vfz * m.kz;
+}
+__device__ inline void edge_step_amr(const KArgs &A, const Lds &l, bool dust, EdgeMarch &m, unsigned &nsteps) {
+    const DAmr &a = A.amr;
+    const Cell *c = &A.g.cell[m.il - 1];
+    int ic = a.icell_of_leaf[m.il - 1], iface;
+    double t_exit = amr_cell_exit(a.geom[ic - 1], m.x, m.y, m.z, m.kx, m.ky, m.kz, iface);
+    double rhokap = c->rhokap * calc_voigt(l, m.xfreq, c->voigt_a, c->Dfreq);
+    if (dust) rhokap = rhokap + c->rhokapD;
+    nsteps++;
+    if (m.dist >= 0.0 && m.d + t_exit >= m.dist) { m.tau = m.tau + (m.dist - m.d) * rhokap; m.live = false; return; }
+    m.tau = m.tau + t_exit * rhokap;
+    if (m.tau >= LART_TAU_HUGE) { m.live = false; return; }
+    m.d = m.d + t_exit; m.x = m.x + t_exit * m.kx; m.y = m.y + t_exit * m.ky; m.z = m.z + t_exit * m.kz;
+    int il_new = amr_next_leaf(a, ic, iface, m.x, m.y, m.z); bool reflected = false;
+    if (il_new <= 0) il_new = amr_boundary(A.par, m.il, iface, m.kx, m.ky, m.kz, reflected);
+    if (il_new <= 0) { m.live = false; return; }
+    const Cell *cn = &A.g.cell[il_new - 1];
+    double u2 = cn->vfx * m.kx + cn->vfy * m.ky + cn->vfz * m.kz;
+    m.xfreq = reflected ? (m.xfreq + m.u1) - u2 : (m.xfreq + m.u1) * c->Dfreq / cn->Dfreq - u2;
+    m.u1 = u2; m.il = il_new;
 }
 
 
@@ -1079,68 +1093,80 @@ __device__ inline void raytrace_to_tau_clump(const KArgs &A, const Lds &l, bool 
 }
 // raytrace_to_edge_clump_capped: :494-541.  The uncapped form (:204-267) is what the reference calls for the forced first
 // flight; its only consumers are exp(-tau0) and 1 - exp(-tau0), which are exactly 0 and 1 beyond the cap, so one routine serves both.
-__device__ inline double raytrace_to_edge_clump(const KArgs &A, const Lds &l, bool dust, const Photon &p0, double xf, double kx, double ky, double kz, unsigned &nsteps) {
+__device__ inline void edge_begin_clump(const KArgs &A, const Lds &l, bool dust, const Photon &p0, EdgeMarch &m, unsigned &nsteps) {
     const DClumps &c = A.cl;
-    double tau = 0.0, xp = p0.x, yp = p0.y, zp = p0.z; long long icl_cur = p0.icl, icl_found;
-    if (icl_cur > 0) {
-        const ClumpPhys ph = c.phys[icl_cur - 1];
-        double t_seg = clump_exit_dist(c.geo[icl_cur - 1], xp, yp, zp, kx, ky, kz);
+    m.x = p0.x; m.y = p0.y; m.z = p0.z; m.icl = p0.icl;
+    if (m.icl > 0) {
+        const ClumpPhys ph = c.phys[m.icl - 1];
+        double t_seg = clump_exit_dist(c.geo[m.icl - 1], m.x, m.y, m.z, m.kx, m.ky, m.kz);
         nsteps++;
-        tau = tau + kappa_clump(A, l, dust, xf, ph) * t_seg;
-        if (tau >= LART_TAU_HUGE) return tau;
-        xp = xp + t_seg * kx; yp = yp + t_seg * ky; zp = zp + t_seg * kz;
-        xf = xf + ulos_clump(A, ph, kx, ky, kz);
-        if (xp * xp + yp * yp + zp * zp >= c.sphere_R * c.sphere_R) return tau;
+        m.tau = m.tau + kappa_clump(A, l, dust, m.xfreq, ph) * t_seg;
+        if (m.tau >= LART_TAU_HUGE) { m.live = false; return; }
+        m.x = m.x + t_seg * m.kx; m.y = m.y + t_seg * m.ky; m.z = m.z + t_seg * m.kz;
+        m.xfreq = m.xfreq + ulos_clump(A, ph, m.kx, m.ky, m.kz);
+        if (m.x * m.x + m.y * m.y + m.z * m.z >= c.sphere_R * c.sphere_R) { m.live = false; return; }
     }
-    for (;;) {
-        double t_sp = sphere_exit_dist(c, xp, yp, zp, kx, ky, kz), te, tx2;
-        if (t_sp <= 0.0) break;
-        if (!find_next_clump(c, xp, yp, zp, kx, ky, kz, icl_cur, t_sp, te, tx2, icl_found, nsteps)) break;
-        te = fmax(0.0, te);
-        xp = xp + te * kx; yp = yp + te * ky; zp = zp + te * kz;
-        const ClumpPhys ph = c.phys[icl_found - 1];
-        double u_los = ulos_clump(A, ph, kx, ky, kz);
-        xf = xf - u_los;
-        double t_seg = clump_exit_dist(c.geo[icl_found - 1], xp, yp, zp, kx, ky, kz);
-        nsteps++;
-        tau = tau + kappa_clump(A, l, dust, xf, ph) * t_seg;
-        if (tau >= LART_TAU_HUGE) return tau;
-        xp = xp + t_seg * kx; yp = yp + t_seg * ky; zp = zp + t_seg * kz;
-        xf = xf + u_los;
-        icl_cur = icl_found;
-        if (xp * xp + yp * yp + zp * zp >= c.sphere_R * c.sphere_R) break;
-    }
-    return tau;
+}
+// one clump of the vacuum walk: the next entry (find_next_clump over the CSR cells) and the chord through it
+__device__ inline void edge_step_clump(const KArgs &A, const Lds &l, bool dust, EdgeMarch &m, unsigned &nsteps) {
+    const DClumps &c = A.cl;
+    double t_sp = sphere_exit_dist(c, m.x, m.y, m.z, m.kx, m.ky, m.kz), te, tx2; long long icl_found;
+    if (t_sp <= 0.0) { m.live = false; return; }
+    if (!find_next_clump(c, m.x, m.y, m.z, m.kx, m.ky, m.kz, m.icl, t_sp, te, tx2, icl_found, nsteps)) { m.live = false; return; }
+    te = fmax(0.0, te);
+    m.x = m.x + te * m.kx; m.y = m.y + te * m.ky; m.z = m.z + te * m.kz;
+    const ClumpPhys ph = c.phys[icl_found - 1];
+    double u_los = ulos_clump(A, ph, m.kx, m.ky, m.kz);
+    m.xfreq = m.xfreq - u_los;
+    double t_seg = clump_exit_dist(c.geo[icl_found - 1], m.x, m.y, m.z, m.kx, m.ky, m.kz);
+    nsteps++;
+    m.tau = m.tau + kappa_clump(A, l, dust, m.xfreq, ph) * t_seg;
+    if (m.tau >= LART_TAU_HUGE) { m.live = false; return; }
+    m.x = m.x + t_seg * m.kx; m.y = m.y + t_seg * m.ky; m.z = m.z + t_seg * m.kz;
+    m.xfreq = m.xfreq + u_los;
+    m.icl = icl_found;
+    if (m.x * m.x + m.y * m.y + m.z * m.z >= c.sphere_R * c.sphere_R) m.live = false;
 }
 
 // tau to the grid edge (dist < 0) or to a finite distance (raytrace_to_dist_car :89-195, VAR 0 only)
 template <int VAR>
-__device__ inline double raytrace_to_edge(const KArgs &A, const Lds &l, bool dust, const Photon &p, double xfreq, double kx, double ky, double kz, double dist, unsigned &nsteps) {
-    if (VAR == 3) return raytrace_to_edge_amr(A, l, dust, p, xfreq, kx, ky, kz, dist, nsteps);
-    if (VAR == 4) return raytrace_to_edge_clump(A, l, dust, p, xfreq, kx, ky, kz, nsteps);
+__device__ inline void edge_begin(const KArgs &A, const Lds &l, bool dust, const Photon &p, double xfreq, double kx, double ky, double kz, double dist, EdgeMarch &m, unsigned &nsteps) {
+    m.live = true; m.tau = 0.0; m.d = 0.0; m.xfreq = xfreq; m.dist = dist; m.kx = kx; m.ky = ky; m.kz = kz;
+    if (VAR == 3) { edge_begin_amr(A, p, m); return; }
+    if (VAR == 4) { edge_begin_clump(A, l, dust, p, m, nsteps); return; }
     const DGrid &g = A.g;
-    Trav t; t.kx = kx; t.ky = ky; t.kz = kz; t.ic = p.ic; t.jc = p.jc; t.kc = p.kc;
-    double tau = 0.0, d = 0.0, xp = p.x, yp = p.y;
-    if (trav_setup<VAR>(g, l, xp, yp, p.z, false, t)) return tau;
+    m.t.kx = kx; m.t.ky = ky; m.t.kz = kz; m.t.ic = p.ic; m.t.jc = p.jc; m.t.kc = p.kc;
+    double xp = p.x, yp = p.y;
+    if (trav_setup<VAR>(g, l, xp, yp, p.z, false, m.t)) { m.live = false; return; }
+    const Cell *c = &g.cell[cidx(g, m.t.ic, m.t.jc, m.t.kc)];
+    m.Dold = c->Dfreq; m.u1 = c->vfx * m.t.kx + c->vfy * m.t.ky + c->vfz * m.t.kz;
+    m.rk = c->rhokap; m.va = c->voigt_a; m.rD = c->rhokapD;
+}
+template <int VAR>
+__device__ inline void edge_step(const KArgs &A, const Lds &l, bool dust, EdgeMarch &m, unsigned &nsteps) {
+    if (VAR == 3) { edge_step_amr(A, l, dust, m, nsteps); return; }
+    if (VAR == 4) { edge_step_clump(A, l, dust, m, nsteps); return; }
+    const DGrid &g = A.g; Trav &t = m.t;
+    double rhokap = m.rk * calc_voigt(l, m.xfreq, m.va, m.Dold);
+    if (dust) rhokap = rhokap + m.rD;
+    nsteps++;
+    int idx = (VAR == 2) ? 3 : minloc3(t.tx, t.ty, t.tz);
+    double tt = idx == 1 ? t.tx : (idx == 2 ? t.ty : t.tz);
+    if (m.dist >= 0.0 && tt >= m.dist) { m.tau = m.tau + (m.dist - m.d) * rhokap; m.live = false; return; }
+    m.tau = m.tau + (tt - m.d) * rhokap; m.d = tt;
+    if (!trav_cross<VAR>(g, t, idx)) { m.live = false; return; }
+    if (m.tau >= LART_TAU_HUGE) { m.live = false; return; }
     const Cell *c = &g.cell[cidx(g, t.ic, t.jc, t.kc)];
-    double Dold = c->Dfreq, u1 = c->vfx * t.kx + c->vfy * t.ky + c->vfz * t.kz;
-    double rk = c->rhokap, va = c->voigt_a, rD = c->rhokapD;
-    for (;;) {
-        double rhokap = rk * calc_voigt(l, xfreq, va, Dold);
-        if (dust) rhokap = rhokap + rD;
-        nsteps++;
-        int idx = (VAR == 2) ? 3 : minloc3(t.tx, t.ty, t.tz);
-        double tt = idx == 1 ? t.tx : (idx == 2 ? t.ty : t.tz);
-        if (dist >= 0.0 && tt >= dist) { tau = tau + (dist - d) * rhokap; break; }
-        tau = tau + (tt - d) * rhokap; d = tt;
-        if (!trav_cross<VAR>(g, t, idx)) break;
-        if (tau >= LART_TAU_HUGE) break;
-        c = &g.cell[cidx(g, t.ic, t.jc, t.kc)];
-        double Dn = c->Dfreq, u2 = c->vfx * t.kx + c->vfy * t.ky + c->vfz * t.kz;
-        xfreq = (xfreq + u1) * Dold / Dn - u2;
-        Dold = Dn; u1 = u2; rk = c->rhokap; va = c->voigt_a; rD = c->rhokapD;
-    }
-    return tau;
+    double Dn = c->Dfreq, u2 = c->vfx * t.kx + c->vfy * t.ky + c->vfz * t.kz;
+    m.xfreq = (m.xfreq + m.u1) * m.Dold / Dn - u2;
+    m.Dold = Dn; m.u1 = u2; m.rk = c->rhokap; m.va = c->voigt_a; m.rD = c->rhokapD;
+}
+template <int VAR>
+__device__ inline double raytrace_to_edge(const KArgs &A, const Lds &l, bool dust, const Photon &p, double xfreq, double kx, double ky, double kz, double dist, unsigned &nsteps) {
+    EdgeMarch m;
+    edge_begin<VAR>(A, l, dust, p, xfreq, kx, ky, kz, dist, m, nsteps);
+    while (m.live) edge_step<VAR>(A, l, dust, m, nsteps);
+    return m.tau;
 }
 
 __device__ inline void tally_escape(const lart_params &par, const DTally &T, const Photon &p) {
@@ -1416,22 +1442,64 @@ __device__ inline double peel_u1(const KArgs &A, const Photon &p, const Cell &c,
     if (VAR == 4 && p.icl > 0) return ulos_clump(A, A.cl.phys[p.icl - 1], q.kx, q.ky, q.kz);
     return c.vfx * q.kx + c.vfy * q.ky + c.vfz * q.kz;
 }
+// azimuth about the (m,n,k) triad and the peel reference normal: :356-385 (= :204-224)
+struct StokesGeom { double cost, sint, cosp, sinp, cos2p, sin2p, nx, ny, nz; };
+__device__ inline StokesGeom stokes_geom(const Photon &p, const PeelDir &q) {
+    StokesGeom s;
+    s.cost = p.kx * q.kx + p.ky * q.ky + p.kz * q.kz; s.sint = sqrt(1.0 - s.cost * s.cost);
+    if (s.sint == 0.0) { s.cosp = 1.0; s.sinp = 0.0; s.cos2p = 1.0; s.sin2p = 0.0; }
+    else { s.cosp = (q.kx * p.mx + q.ky * p.my + q.kz * p.mz) / s.sint; s.sinp = (q.kx * p.nx + q.ky * p.ny + q.kz * p.nz) / s.sint;
+           s.cos2p = 2.0 * s.cosp * s.cosp - 1.0; s.sin2p = 2.0 * s.cosp * s.sinp; }
+    s.nx = -s.sinp * p.mx + s.cosp * p.nx; s.ny = -s.sinp * p.my + s.cosp * p.ny; s.nz = -s.sinp * p.mz + s.cosp * p.nz;
+    return s;
+}
+// Every peel routine is: head (direction to the observer, field-of-view test, frequency along that direction) -> optical depth to
+// the observer -> weight, pixel, deposit.  The heads are separate functions because the peel kernel marches the rays of many records
+// interleaved: it calls the head to start a march (peel_ray_begin) and, when the march of (record, observer `only`) is over, the
+// routine itself with `only` and the optical depth it found (`tau_given`); the default arguments give the one-piece routine.
+template <int VAR>
+__device__ inline bool peel_head_direct(const KArgs &A, const DObs &o, const Photon &p, const Cell &c, PeelDir &q, double &xf, double &xfreq_ref) {
+    q = peel_dir0(A, o, p);
+    if (!q.in_image) return false;
+    xf = p.xfreq;
+    if (VAR == 4 && p.icl > 0) xfreq_ref = p.xfreq + peel_u1<VAR>(A, p, c, q);      // clump frame -> lab frame along the peel direction
+    else if (!A.par.comoving_source) {
+        double u1 = c.vfx * p.kx + c.vfy * p.ky + c.vfz * p.kz; xfreq_ref = p.xfreq + u1;
+        double u2 = c.vfx * q.kx + c.vfy * q.ky + c.vfz * q.kz; xf = xfreq_ref - u2;
+    } else { double u1 = c.vfx * q.kx + c.vfy * q.ky + c.vfz * q.kz; xfreq_ref = p.xfreq + u1; }
+    xfreq_ref = xfreq_ref * (c.Dfreq / A.par.Dfreq_ref);
+    return true;
+}
+__device__ inline bool peel_head_res_nostokes(const KArgs &A, const DObs &o, const Photon &p, const Cell &c, double xfreq_atom, double ux, double uy, double uz, double g_rec0,
+                                              PeelDir &q, double &cost2, double &xfreq) {
+    q = peel_dir0(A, o, p);
+    if (!q.in_image) return false;
+    double cost = p.kx * q.kx + p.ky * q.ky + p.kz * q.kz, sint; cost2 = cost * cost; sint = sqrt(1.0 - cost2);
+    double rho1 = sqrt(1.0 - p.kz * p.kz) * sint, cosp = 1.0, sinp = 0.0;
+    if (rho1 != 0.0) { double rho = 1.0 / rho1; cosp = rho * (cost * p.kz - q.kz); sinp = rho * (p.kx * q.ky - q.kx * p.ky); }
+    xfreq = xfreq_atom + (ux * cosp + uy * sinp) * sint + uz * cost;
+    if (A.par.recoil) xfreq = xfreq - (g_rec0 / c.Dfreq) * (1.0 - cost);
+    return true;
+}
+__device__ inline bool peel_head_res_stokes(const KArgs &A, const DObs &o, const Photon &p, const Cell &c, double xfreq_atom, double ux, double uy, double uz, double g_rec0,
+                                            PeelDir &q, StokesGeom &s, double &xfreq) {
+    q = peel_dir0(A, o, p);
+    if (!q.in_image) return false;
+    s = stokes_geom(p, q);
+    xfreq = xfreq_atom + (ux * s.cosp + uy * s.sinp) * s.sint + uz * s.cost;
+    if (A.par.recoil) xfreq = xfreq - (g_rec0 / c.Dfreq) * (1.0 - s.cost);
+    return true;
+}
 // peeling_direct_outside: peelingoff_rect.f90:24-129
 template <int VAR>
-__device__ inline void peel_direct(const KArgs &A, const Lds &l, bool dust, const Photon &p, unsigned &nsteps, unsigned &natom) {
+__device__ inline void peel_direct(const KArgs &A, const Lds &l, bool dust, const Photon &p, unsigned &nsteps, unsigned &natom, int only = -1, double tau_given = 0.0) {
     const Cell &c = A.g.cell[cidx(A.g, p.ic, p.jc, p.kc)];
     for (int i = 0; i < A.nobs; i++) {
-        PeelDir q = peel_dir0(A, A.obs[i], p);
-        if (!q.in_image) continue;
-        double xfreq_ref, xf = p.xfreq;
-        if (VAR == 4 && p.icl > 0) xfreq_ref = p.xfreq + peel_u1<VAR>(A, p, c, q);      // clump frame -> lab frame along the peel direction
-        else if (!A.par.comoving_source) {
-            double u1 = c.vfx * p.kx + c.vfy * p.ky + c.vfz * p.kz; xfreq_ref = p.xfreq + u1;
-            double u2 = c.vfx * q.kx + c.vfy * q.ky + c.vfz * q.kz; xf = xfreq_ref - u2;
-        } else { double u1 = c.vfx * q.kx + c.vfy * q.ky + c.vfz * q.kz; xfreq_ref = p.xfreq + u1; }
-        xfreq_ref = xfreq_ref * (c.Dfreq / A.par.Dfreq_ref);
+        if (only >= 0 && i != only) continue;
+        PeelDir q; double xf, xfreq_ref;
+        if (!peel_head_direct<VAR>(A, A.obs[i], p, c, q, xf, xfreq_ref)) continue;
         int ixf = (int)floor((xfreq_ref - A.par.xfreq_min) / A.par.dxfreq) + 1;
-        double tau = raytrace_to_edge<VAR>(A, l, dust, p, xf, q.kx, q.ky, q.kz, q.dist, nsteps);
+        double tau = only >= 0 ? tau_given : raytrace_to_edge<VAR>(A, l, dust, p, xf, q.kx, q.ky, q.kz, q.dist, nsteps);
         const double wgt0 = 1.0 / (LART_FOURPI * q.r2) * p.wgt, wgt = d_exp_neg(-tau) * wgt0;      // wgt0: the unattenuated source (direc0)
         if (wgt == 0.0 && !A.par.save_direc0) continue;
         peel_pixel(A, A.obs[i], q);
@@ -1444,17 +1512,14 @@ __device__ inline void peel_direct(const KArgs &A, const Lds &l, bool dust, cons
 }
 // peeling_resonance_nostokes_outside: :576-690
 template <int VAR>
-__device__ inline void peel_resonance_nostokes(const KArgs &A, const Lds &l, bool dust, const Photon &p, double xfreq_atom, double ux, double uy, double uz, double E1, double E2, double g_rec0, unsigned &nsteps, unsigned &natom) {
+__device__ inline void peel_resonance_nostokes(const KArgs &A, const Lds &l, bool dust, const Photon &p, double xfreq_atom, double ux, double uy, double uz, double E1, double E2, double g_rec0, unsigned &nsteps, unsigned &natom,
+                                               int only = -1, double tau_given = 0.0) {
     const Cell &c = A.g.cell[cidx(A.g, p.ic, p.jc, p.kc)];
     for (int i = 0; i < A.nobs; i++) {
-        PeelDir q = peel_dir0(A, A.obs[i], p);
-        if (!q.in_image) continue;
-        double cost = p.kx * q.kx + p.ky * q.ky + p.kz * q.kz, cost2 = cost * cost, sint = sqrt(1.0 - cost2);
-        double rho1 = sqrt(1.0 - p.kz * p.kz) * sint, cosp = 1.0, sinp = 0.0;
-        if (rho1 != 0.0) { double rho = 1.0 / rho1; cosp = rho * (cost * p.kz - q.kz); sinp = rho * (p.kx * q.ky - q.kx * p.ky); }
-        double xfreq = xfreq_atom + (ux * cosp + uy * sinp) * sint + uz * cost;
-        if (A.par.recoil) xfreq = xfreq - (g_rec0 / c.Dfreq) * (1.0 - cost);
-        double tau = raytrace_to_edge<VAR>(A, l, dust, p, xfreq, q.kx, q.ky, q.kz, q.dist, nsteps);
+        if (only >= 0 && i != only) continue;
+        PeelDir q; double cost2, xfreq;
+        if (!peel_head_res_nostokes(A, A.obs[i], p, c, xfreq_atom, ux, uy, uz, g_rec0, q, cost2, xfreq)) continue;
+        double tau = only >= 0 ? tau_given : raytrace_to_edge<VAR>(A, l, dust, p, xfreq, q.kx, q.ky, q.kz, q.dist, nsteps);
         double peel = 0.75 * E1 * (cost2 + 1.0) + E2;
         double wgt = peel / (LART_FOURPI * q.r2) * d_exp_neg(-tau) * p.wgt;
         if (wgt == 0.0) continue;
@@ -1474,29 +1539,17 @@ __device__ inline void stokes_deposit(const KArgs &A, int io, const PeelDir &q, 
     if (A.par.save_peeloff_3D && ixf >= 1 && ixf <= A.par.nxfreq) { size_t s = pix3(A, io, ixf, q.ix, q.iy);
         atomicAdd(&A.t.c3[0][s], wgt * Id); atomicAdd(&A.t.c3[2][s], wgt * Id); atomicAdd(&A.t.c3[3][s], wgt * Qd); atomicAdd(&A.t.c3[4][s], wgt * Ud); atomicAdd(&A.t.c3[5][s], wgt * Vd); natom += 5; }
 }
-// azimuth about the (m,n,k) triad and the peel reference normal: :356-385 (= :204-224)
-struct StokesGeom { double cost, sint, cosp, sinp, cos2p, sin2p, nx, ny, nz; };
-__device__ inline StokesGeom stokes_geom(const Photon &p, const PeelDir &q) {
-    StokesGeom s;
-    s.cost = p.kx * q.kx + p.ky * q.ky + p.kz * q.kz; s.sint = sqrt(1.0 - s.cost * s.cost);
-    if (s.sint == 0.0) { s.cosp = 1.0; s.sinp = 0.0; s.cos2p = 1.0; s.sin2p = 0.0; }
-    else { s.cosp = (q.kx * p.mx + q.ky * p.my + q.kz * p.mz) / s.sint; s.sinp = (q.kx * p.nx + q.ky * p.ny + q.kz * p.nz) / s.sint;
-           s.cos2p = 2.0 * s.cosp * s.cosp - 1.0; s.sin2p = 2.0 * s.cosp * s.sinp; }
-    s.nx = -s.sinp * p.mx + s.cosp * p.nx; s.ny = -s.sinp * p.my + s.cosp * p.ny; s.nz = -s.sinp * p.mz + s.cosp * p.nz;
-    return s;
-}
 // peeling_resonance_stokes_outside: :303-482
 template <int VAR>
-__device__ inline void peel_resonance_stokes(const KArgs &A, const Lds &l, bool dust, const Photon &p, double xfreq_atom, double ux, double uy, double uz, double E1, double E2, double E3, double g_rec0, unsigned &nsteps, unsigned &natom) {
+__device__ inline void peel_resonance_stokes(const KArgs &A, const Lds &l, bool dust, const Photon &p, double xfreq_atom, double ux, double uy, double uz, double E1, double E2, double E3, double g_rec0, unsigned &nsteps, unsigned &natom,
+                                             int only = -1, double tau_given = 0.0) {
     const Cell &c = A.g.cell[cidx(A.g, p.ic, p.jc, p.kc)];
     for (int i = 0; i < A.nobs; i++) {
+        if (only >= 0 && i != only) continue;
         const DObs &o = A.obs[i];
-        PeelDir q = peel_dir0(A, o, p);
-        if (!q.in_image) continue;
-        StokesGeom s = stokes_geom(p, q);
-        double xfreq = xfreq_atom + (ux * s.cosp + uy * s.sinp) * s.sint + uz * s.cost;
-        if (A.par.recoil) xfreq = xfreq - (g_rec0 / c.Dfreq) * (1.0 - s.cost);
-        double tau = raytrace_to_edge<VAR>(A, l, dust, p, xfreq, q.kx, q.ky, q.kz, q.dist, nsteps);
+        PeelDir q; StokesGeom s; double xfreq;
+        if (!peel_head_res_stokes(A, o, p, c, xfreq_atom, ux, uy, uz, g_rec0, q, s, xfreq)) continue;
+        double tau = only >= 0 ? tau_given : raytrace_to_edge<VAR>(A, l, dust, p, xfreq, q.kx, q.ky, q.kz, q.dist, nsteps);
         double wgt = 1.0 / q.r2 * d_exp_neg(-tau) * p.wgt;
         if (wgt == 0.0) continue;
         peel_pixel(A, o, q);
@@ -1516,12 +1569,13 @@ __device__ inline void peel_resonance_stokes(const KArgs &A, const Lds &l, bool 
 }
 // peeling_dust_nostokes_outside: :484-574
 template <int VAR>
-__device__ inline void peel_dust_nostokes(const KArgs &A, const Lds &l, const Photon &p, unsigned &nsteps, unsigned &natom) {
+__device__ inline void peel_dust_nostokes(const KArgs &A, const Lds &l, const Photon &p, unsigned &nsteps, unsigned &natom, int only = -1, double tau_given = 0.0) {
     const Cell &c = A.g.cell[cidx(A.g, p.ic, p.jc, p.kc)];
     for (int i = 0; i < A.nobs; i++) {
+        if (only >= 0 && i != only) continue;
         PeelDir q = peel_dir0(A, A.obs[i], p);
         if (!q.in_image) continue;
-        double tau = raytrace_to_edge<VAR>(A, l, true, p, p.xfreq, q.kx, q.ky, q.kz, q.dist, nsteps);
+        double tau = only >= 0 ? tau_given : raytrace_to_edge<VAR>(A, l, true, p, p.xfreq, q.kx, q.ky, q.kz, q.dist, nsteps);
         double cosa = p.kx * q.kx + p.ky * q.ky + p.kz * q.kz, hgg = A.par.hgg;
         double b = (1.0 + hgg * hgg) - 2.0 * hgg * cosa;
         double peel = (1.0 - hgg * hgg) / (b * sqrt(b)) / LART_FOURPI;
@@ -1539,13 +1593,14 @@ __device__ inline void peel_dust_nostokes(const KArgs &A, const Lds &l, const Ph
 }
 // peeling_dust_stokes_outside: :131-299
 template <int VAR>
-__device__ inline void peel_dust_stokes(const KArgs &A, const Lds &l, const Photon &p, unsigned &nsteps, unsigned &natom) {
+__device__ inline void peel_dust_stokes(const KArgs &A, const Lds &l, const Photon &p, unsigned &nsteps, unsigned &natom, int only = -1, double tau_given = 0.0) {
     const Cell &c = A.g.cell[cidx(A.g, p.ic, p.jc, p.kc)];
     for (int i = 0; i < A.nobs; i++) {
+        if (only >= 0 && i != only) continue;
         const DObs &o = A.obs[i];
         PeelDir q = peel_dir0(A, o, p);
         if (!q.in_image) continue;
-        double tau = raytrace_to_edge<VAR>(A, l, true, p, p.xfreq, q.kx, q.ky, q.kz, q.dist, nsteps);
+        double tau = only >= 0 ? tau_given : raytrace_to_edge<VAR>(A, l, true, p, p.xfreq, q.kx, q.ky, q.kz, q.dist, nsteps);
         double wgt = 1.0 / q.r2 * d_exp_neg(-tau) * p.wgt;
         if (wgt == 0.0) continue;
         peel_pixel(A, o, q);
@@ -1567,18 +1622,71 @@ __device__ inline void peel_dust_stokes(const KArgs &A, const Lds &l, const Phot
         if (A.par.save_dust_scattered && A.par.save_peeloff_3D && ixf >= 1 && ixf <= A.par.nxfreq) add_if(A.t.c3[7], pix3(A, i, ixf, q.ix, q.iy), wgt * Iobs, natom);   // :284-287
     }
 }
+// the head of the routine for `kind`, for one observer: false = nothing to march (outside the image); else the ray (q, frequency xf in the
+// frame of the packet's cell, whether dust opacity counts along it)
+template <int VAR, bool STOKES>
+__device__ inline bool peel_ray_begin(const KArgs &A, int kind, const Photon &p, double ux, double uy, double uz, double grec, const DObs &o, bool dust, PeelDir &q, double &xf, bool &ray_dust) {
+    const Cell &c = A.g.cell[cidx(A.g, p.ic, p.jc, p.kc)];
+    if (kind == PEEL_DIRECT) { double xfreq_ref; ray_dust = dust; return peel_head_direct<VAR>(A, o, p, c, q, xf, xfreq_ref); }
+    if (kind == PEEL_DUST) { ray_dust = true; q = peel_dir0(A, o, p); xf = p.xfreq; return q.in_image; }
+    ray_dust = dust;
+    if (STOKES) { StokesGeom s; return peel_head_res_stokes(A, o, p, c, p.xfreq, ux, uy, uz, grec, q, s, xf); }
+    double cost2; return peel_head_res_nostokes(A, o, p, c, p.xfreq, ux, uy, uz, grec, q, cost2, xf);
+}
+
+// Is every peel ray of this event extinguished inside the cell (leaf, clump) it starts in?  Deep inside an optically thick medium the
+// line-centre depth of one cell is ~1e4, and exp(-tau) is exactly 0 in f64 from tau = 745.2 on (the reference's tau_huge cut): such an
+// event can deposit nothing, so it is not queued at all.  The test is the first step of the march without its divisions:
+// tau_1 = kappa * min_i(d_i / |k_i|) >= 745.2  <=>  kappa * d_i >= 745.2 |k_i| on the three axes (d_i = distance to the face the ray
+// moves towards).  Any other case -- an observer inside the medium, a start in the vacuum between clumps, the direct light of a
+// birth -- is queued and decided by the march itself.
+template <int VAR, bool STOKES>
+__device__ inline bool peel_all_opaque(const KArgs &A, const Lds &l, int kind, const Photon &p, double xa, double ux, double uy, double uz, double grec, bool dust) {
+    if (kind == PEEL_DIRECT || A.heal_nside > 0 || VAR == 1) return false;
+    if (VAR == 4 && p.icl <= 0) return false;
+    if (VAR != 3 && VAR != 4 && (p.ic < 1 || p.ic > A.g.nx || p.jc < 1 || p.jc > A.g.ny || p.kc < 1 || p.kc > A.g.nz)) return false;
+    Photon pp = p; pp.xfreq = xa;
+    for (int i = 0; i < A.nobs; i++) {
+        PeelDir q; double xf; bool rd;
+        if (!peel_ray_begin<VAR, STOKES>(A, kind, pp, ux, uy, uz, grec, A.obs[i], dust, q, xf, rd)) continue;      // outside the image: no deposit either
+        const double T = LART_TAU_HUGE;
+        if (VAR == 4) {
+            const ClumpPhys ph = A.cl.phys[p.icl - 1];
+            if (!(kappa_clump(A, l, rd, xf, ph) * clump_exit_dist(A.cl.geo[p.icl - 1], p.x, p.y, p.z, q.kx, q.ky, q.kz) >= T)) return false;
+            continue;
+        }
+        const Cell &c = A.g.cell[(VAR == 3) ? (size_t)(p.ic - 1) : cidx(A.g, p.ic, p.jc, p.kc)];
+        double kap = c.rhokap * calc_voigt(l, xf, c.voigt_a, c.Dfreq);
+        if (rd) kap = kap + c.rhokapD;
+        double dx, dy, dz;
+        if (VAR == 3) {
+            const AmrGeom g = A.amr.geom[A.amr.icell_of_leaf[p.ic - 1] - 1];
+            dx = q.kx > 0.0 ? (g.cx + g.ch) - p.x : p.x - (g.cx - g.ch); dy = q.ky > 0.0 ? (g.cy + g.ch) - p.y : p.y - (g.cy - g.ch); dz = q.kz > 0.0 ? (g.cz + g.ch) - p.z : p.z - (g.cz - g.ch);
+        } else {
+            dx = q.kx > 0.0 ? l.xf[p.ic] - p.x : p.x - l.xf[p.ic - 1]; dy = q.ky > 0.0 ? l.yf[p.jc] - p.y : p.y - l.yf[p.jc - 1]; dz = q.kz > 0.0 ? l.zf[p.kc] - p.z : p.z - l.zf[p.kc - 1];
+        }
+        bool opaque = kap * dz >= T * fabs(q.kz);
+        if (VAR != 2) opaque = opaque && kap * dx >= T * fabs(q.kx) && kap * dy >= T * fabs(q.ky);
+        if (!opaque) return false;
+    }
+    return true;
+}
 
 // one record into the peel queue (see DPeelQ).  Called from divergent code: the lanes of the wave that are here right now share one
 // atomic for their slots.  xa = xfreq_atom for a resonance event, the packet's xfreq for a dust event or the direct (birth) peel.
 template <int VAR, bool STOKES>
-__device__ inline void peel_emit(const KArgs &A, int kind, const Photon &p, double xa, double ux, double uy, double uz, double E1, double E2, double E3, double grec) {
+__device__ inline void peel_emit(const KArgs &A, const Lds &l, bool dust, int kind, const Photon &p, double xa, double ux, double uy, double uz, double E1, double E2, double E3, double grec, unsigned &npeel) {
+#ifndef LART_NO_PEEL_PREFILTER
+    if (peel_all_opaque<VAR, STOKES>(A, l, kind, p, xa, ux, uy, uz, grec, dust)) { npeel += (unsigned)A.nobs; return; }   // (the one cell each ray was tested in)
+#endif
     const unsigned long long m = __ballot(1);
     const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
     unsigned base = 0;
-    if (lane == leader) base = atomicAdd(&A.ctl->q_n, (unsigned)__popcll(m));
+    if (lane == leader) { base = *l.pq_cnt; *l.pq_cnt = base + (unsigned)__popcll(m); }      // the wave's own counter: no atomic needed, the wave runs in lockstep
     base = __shfl(base, leader, 64);
-    const size_t r = (size_t)base + (size_t)__popcll(m & ((1ull << lane) - 1ull)), C = A.pq.cap;
-    if (r >= C) return;                                       // cannot happen: the host sizes the queue for lanes x (events + 1) records per launch
+    const unsigned k = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+    if (k >= A.pq.region) return;                             // cannot happen: the host sizes a region for 64 lanes x (events + 1) records
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, r = wave * A.pq.region + k, C = A.pq.cap;
     double *f = A.pq.f;
     f[PQ_X * C + r] = p.x; f[PQ_Y * C + r] = p.y; f[PQ_Z * C + r] = p.z; f[PQ_KX * C + r] = p.kx; f[PQ_KY * C + r] = p.ky; f[PQ_KZ * C + r] = p.kz;
     f[PQ_WGT * C + r] = p.wgt; f[PQ_XA * C + r] = xa;
@@ -1667,7 +1775,7 @@ __device__ inline bool scatter_pre(const KArgs &A, const Lds &l, Rng &g, Photon 
         if (g.next() <= p_dust) {
             if (dust_absorb(A, g, p, c)) return false;
             if (STOKES && A.mu.nPDF > 0) {                     // scatter_dust_stokes :201-329
-                if (PEEL) peel_emit<VAR, STOKES>(A, PEEL_DUST, p, p.xfreq, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0);      // peeling_dust_stokes_outside, deferred
+                if (PEEL) peel_emit<VAR, STOKES>(A, l, DUST, PEEL_DUST, p, p.xfreq, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, npeel);      // peeling_dust_stokes_outside, deferred
                 double cost = rand_alias_linear(g, A.mu), sint = sqrt(1.0 - cost * cost);
                 const DMueller &m = A.mu;
                 double S11 = interp_eq(m.nPDF, m.coss, m.S11, cost), S12 = interp_eq(m.nPDF, m.coss, m.S12, cost);
@@ -1679,7 +1787,7 @@ __device__ inline bool scatter_pre(const KArgs &A, const Lds &l, Rng &g, Photon 
                 p.Q = Q1 / I1; p.U = U1 / I1; p.V = V1 / I1;
                 rotate_triad(p, cost, sint, cosp, sinp);
             } else {                                           // scatter_dust_nostokes :488-584
-                if (PEEL) peel_emit<VAR, STOKES>(A, PEEL_DUST, p, p.xfreq, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0);      // peeling_dust_nostokes_outside, deferred
+                if (PEEL) peel_emit<VAR, STOKES>(A, l, DUST, PEEL_DUST, p, p.xfreq, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, npeel);      // peeling_dust_nostokes_outside, deferred
                 double cost = rand_hg(g, par.hgg), sint = sqrt(1.0 - cost * cost);
                 double sinp, cosp; d_sincos_2pi(g.next(), &sinp, &cosp);
                 rotate_k(p, cost, sint, cosp, sinp);
@@ -1787,14 +1895,14 @@ __device__ inline void scatter_post(const KArgs &A, const Lds &l, Rng &g, Photon
     const double g_rec0 = deut ? par.g_recoil0_D : par.g_recoil0;      // :427-437
     if (par.recoil) p.xfreq = p.xfreq - (g_rec0 / sc.cl_Dfreq) * (1.0 - cost);
     if (STOKES) {
-        if (PEEL) peel_emit<VAR, STOKES>(A, PEEL_RESONANCE, p, xfreq_atom, ux, uy, uz, E1, E2, E3, g_rec0);   // peeling_resonance_stokes_outside, deferred
+        if (PEEL) peel_emit<VAR, STOKES>(A, l, DUST, PEEL_RESONANCE, p, xfreq_atom, ux, uy, uz, E1, E2, E3, g_rec0, npeel);   // peeling_resonance_stokes_outside, deferred
         double cos2p = 2.0 * cosp * cosp - 1.0, sin2p = 2.0 * sinp * cosp;
         double Q0 = cos2p * p.Q + sin2p * p.U, U0 = -sin2p * p.Q + cos2p * p.U;
         double I1 = S11 + S12 * Q0, Q1 = S12 + S22 * Q0, U1 = S33 * U0, V1 = S44 * p.V;
         p.Q = Q1 / I1; p.U = U1 / I1; p.V = V1 / I1;
         rotate_triad(p, cost, sint, cosp, sinp);
     } else {
-        if (PEEL) peel_emit<VAR, STOKES>(A, PEEL_RESONANCE, p, xfreq_atom, ux, uy, uz, E1, E2, E3, g_rec0);   // peeling_resonance_nostokes_outside, deferred
+        if (PEEL) peel_emit<VAR, STOKES>(A, l, DUST, PEEL_RESONANCE, p, xfreq_atom, ux, uy, uz, E1, E2, E3, g_rec0, npeel);   // peeling_resonance_nostokes_outside, deferred
         rotate_k(p, cost, sint, cosp, sinp);
     }
 }
@@ -1931,5 +2039,5 @@ __device__ inline void generate_photon(const KArgs &A, const Lds &l, Rng &g, Pho
         p.icl = clump_at_point(A.cl, p.x, p.y, p.z);
         if (p.icl > 0) p.xfreq = p.xfreq - ulos_clump(A, A.cl.phys[p.icl - 1], p.kx, p.ky, p.kz);
     }
-    if (PEEL) peel_emit<VAR, STOKES>(A, PEEL_DIRECT, p, p.xfreq, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0);            // peeling_direct_outside, deferred
+    if (PEEL) peel_emit<VAR, STOKES>(A, l, DUST, PEEL_DIRECT, p, p.xfreq, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, npeel);            // peeling_direct_outside, deferred
 }

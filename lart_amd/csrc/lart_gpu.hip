@@ -9,6 +9,8 @@
 #include <cstring>
 #include <cstdio>
 #include <cmath>
+#include <cstddef>
+#include <cstdlib>
 #include <ctime>
 
 extern "C" void lart_launch_transport_var0(int, int, int, dim3, dim3, size_t, hipStream_t, const KArgs &);
@@ -504,6 +506,7 @@ static int ensure_peel_queue(lart_gpu *c, int max_events) {
     if (!c->n_cu) { hipDeviceProp_t pr; HIPCHK(hipGetDeviceProperties(&pr, c->device)); c->n_cu = pr.multiProcessorCount; }
     const size_t planes = c->par.use_stokes ? (size_t)PQ_COUNT : (size_t)PQ_NOSTOKES, rec_bytes = planes * 8 + 16;
     const size_t lanes = (size_t)c->pool.n;
+    if (const char *e = std::getenv("LART_PEEL_QUEUE_GB")) { const double gb = std::atof(e); if (gb >= 0.25 && gb <= 200.0) c->pq_bytes_max = (size_t)(gb * 1073741824.0); }   // tuning knob: HBM set aside for the queue
     size_t fit = c->pq_bytes_max / (rec_bytes * lanes);         // records per lane the byte budget allows
     int slice = max_events;
     if ((size_t)slice + 1 > fit) slice = fit > 1 ? (int)(fit - 1) : 1;
@@ -511,10 +514,12 @@ static int ensure_peel_queue(lart_gpu *c, int max_events) {
     if (cap > 0xfffffff0ull) return fail("peel queue: more than 2^32 records per launch; lower the pool size or max_events");
     if (!c->d_pq || c->pq.cap < cap) {
         (void)hipFree(c->d_pq); c->d_pq = nullptr;
-        HIPCHK(hipMalloc(&c->d_pq, cap * rec_bytes));
+        HIPCHK(hipMalloc(&c->d_pq, cap * rec_bytes + (lanes / 64 + 1) * sizeof(unsigned)));
         c->pq.f = (double *)c->d_pq; c->pq.cell = (int *)((char *)c->d_pq + cap * planes * 8); c->pq.cap = (unsigned)cap;
+        c->pq.count = (unsigned *)((char *)c->d_pq + cap * rec_bytes);
     } else slice = (int)(c->pq.cap / lanes) - 1 < max_events ? (int)(c->pq.cap / lanes) - 1 : max_events;
     c->peel_slice = slice < 1 ? 1 : slice;
+    c->pq.region = 64u * ((unsigned)c->peel_slice + 1u);      // one producer wave's slots: every lane queues at most one record per event and one per birth
     return 0;
 }
 
@@ -598,14 +603,14 @@ extern "C" int lart_gpu_step(lart_gpu *c, int32_t nsteps, int32_t max_events) {
     int stokes = c->par.use_stokes ? 1 : 0, dust = c->par.DGR > 0.0 ? 1 : 0, peel = (c->par.save_peeloff && c->nobs > 0) ? 1 : 0;
     dim3 block(c->block), grid((unsigned)(c->live_lanes / c->block));
     // Voigt tables + faces | ring of random draws [LART_RNG_BUF][block] | per-block P1, P1_new
-    size_t shmem = (size_t)(VT_END + c->g.nx + c->g.ny + c->g.nz + 3 + LART_RNG_BUF * c->block + 2 * c->jpa.lds_bins) * sizeof(double) + (size_t)LART_COOP_BYTES * ((c->block + 63) / 64);   // ... + the wave-local scratch of vz_core_coop
+    size_t shmem = (size_t)(VT_END + c->g.nx + c->g.ny + c->g.nz + 3 + LART_RNG_BUF * c->block + 2 * c->jpa.lds_bins) * sizeof(double) + (size_t)(LART_COOP_BYTES + 4) * ((c->block + 63) / 64);   // ... + the wave-local scratch of vz_core_coop + the waves' peel-queue counters
     if (shmem > 160 * 1024) return fail("step: grid faces do not fit the 160 KiB LDS");
     // peel-off: a launch of `slice` events per lane queues at most live_lanes x (slice + 1) records (one per event, one per birth);
     // the queue is sized once per run for pq_bytes_max (16 GiB by default) and a step of max_events is cut into slices that fit
     int slice = max_events;
     if (peel) {
         if (ensure_peel_queue(c, max_events)) return 1;
-        slice = c->peel_slice; A.pq = c->pq;
+        slice = c->peel_slice; A.pq = c->pq; A.pq.nregions = (unsigned)(c->live_lanes / 64);
     }
     const size_t peel_shmem = (size_t)(VT_END + c->g.nx + c->g.ny + c->g.nz + 3) * sizeof(double);
     for (int s = 0; s < nsteps; s++) {
@@ -613,7 +618,7 @@ extern "C" int lart_gpu_step(lart_gpu *c, int32_t nsteps, int32_t max_events) {
         HIPCHK(hipEventRecord(e0, c->stream));
         for (int left = max_events; left > 0; left -= slice) {
             A.max_events = left < slice ? left : slice;
-            HIPCHK(hipMemsetAsync(&c->d_ctl->n_active, 0, sizeof(unsigned long long) + 2 * sizeof(unsigned), c->stream));   // n_active, q_n
+            HIPCHK(hipMemsetAsync(&c->d_ctl->n_active, 0, sizeof(DCtl) - offsetof(DCtl, n_active), c->stream));   // n_active, q_n, q_head
             if (var == 0) lart_launch_transport_var0(stokes, dust, peel, grid, block, shmem, c->stream, A);
             else if (var == 1) lart_launch_transport_var1(stokes, dust, peel, grid, block, shmem, c->stream, A);
             else if (var == 2) lart_launch_transport_var2(stokes, dust, peel, grid, block, shmem, c->stream, A);
@@ -622,8 +627,8 @@ extern "C" int lart_gpu_step(lart_gpu *c, int32_t nsteps, int32_t max_events) {
             else if (var == 5) lart_launch_transport_var5(stokes, dust, peel, grid, block, shmem, c->stream, A);
             else lart_launch_transport_var6(stokes, dust, peel, grid, block, shmem, c->stream, A);
             HIPCHK(hipGetLastError());
-            if (peel) {                                           // grid-stride over the records: 8 workgroups per CU
-                lart_launch_peel(var, stokes, dim3((unsigned)(c->n_cu * 8)), dim3(256), peel_shmem, c->stream, A);
+            if (peel) {                                           // persistent waves that pull (record, observer) items from the queue head
+                lart_launch_peel(var, stokes, dim3((unsigned)(c->n_cu * 4)), dim3(256), peel_shmem, c->stream, A);
                 HIPCHK(hipGetLastError());
             }
         }

@@ -1,10 +1,35 @@
 // peel_kernel.hpp -- the deferred next-event estimator: the reference's peeling_*_outside / _inside routines
 // (peelingoff_rect.f90:24-690, peelingoff_heal.f90:12-250, peelingoff_amr.f90) run over the event records the transport kernel
-// queued (DPeelQ, lart_device.hpp), one record per lane with a grid-stride loop: every lane marches one ray per observer
-// (raytrace_to_edge / _dist with the tau >= 745.2 cut) and deposits with atomics when the attenuated weight is non-zero.
-// The arithmetic of a deposit is the peel routine's, unchanged; only the place where it runs moved out of the scattering.
+// queued (DPeelQ, lart_device.hpp).
+//
+// Work item = (record, observer).  A peel ray crosses 1.5 cells on average at tau0 = 1e6 (e^-tau is exactly 0 beyond tau = 745.2, and
+// one cell has a line-centre depth of ~1e4), but a ray at a wing frequency crosses a hundred: with one item per lane and a plain
+// loop a wave would march at the pace of its longest ray (measured: 13.9 ms per 8e7 records, 10x the arithmetic).  So every lane
+// keeps ONE march in flight (EdgeMarch), every iteration advances all marches of the wave by one cell, and a lane whose march is
+// over -- or never started, outside the image -- takes the next item from the queue head (one atomic per wave).  The deposit
+// (exp, pixel, Stokes rotations, atomics) runs only for a non-zero weight, 0.2 % of the items at tau0 = 1e6: the routine of the
+// record's kind is called with the observer and the optical depth just found (its `only` / `tau_given` arguments), so the
+// arithmetic of a deposit is the one-piece routine's, statement for statement.
 #pragma once
 #include "transport_kernel.hpp"
+
+template <int VAR, bool STOKES>
+__device__ inline void peel_load(const KArgs &A, size_t r, bool full, Photon &p, int &kind, double &ux, double &uy, double &uz, double &E1, double &E2, double &E3, double &grec) {
+    const size_t C = A.pq.cap; const double *f = A.pq.f; const int *qc = A.pq.cell;
+    p.x = f[PQ_X * C + r]; p.y = f[PQ_Y * C + r]; p.z = f[PQ_Z * C + r]; p.kx = f[PQ_KX * C + r]; p.ky = f[PQ_KY * C + r]; p.kz = f[PQ_KZ * C + r];
+    p.xfreq = f[PQ_XA * C + r]; p.nsg = 0.0; p.nsd = 0.0; p.xfreq_ref = 0.0; p.inside = true; p.wgt = 0.0; p.Q = 0.0; p.U = 0.0; p.V = 0.0;
+    p.ic = qc[r]; p.jc = qc[C + r]; p.kc = qc[2 * C + r]; p.icl = 0;
+    if (VAR == 4) { p.icl = p.kc; p.kc = 1; }
+    kind = qc[3 * C + r];
+    ux = 0.0; uy = 0.0; uz = 0.0; E1 = 0.0; E2 = 0.0; E3 = 0.0; grec = 0.0;
+    if (kind == PEEL_RESONANCE) { ux = f[PQ_UX * C + r]; uy = f[PQ_UY * C + r]; uz = f[PQ_UZ * C + r]; grec = f[PQ_GREC * C + r]; }
+    if (STOKES) { p.mx = f[PQ_MX * C + r]; p.my = f[PQ_MY * C + r]; p.mz = f[PQ_MZ * C + r]; p.nx = f[PQ_NX * C + r]; p.ny = f[PQ_NY * C + r]; p.nz = f[PQ_NZ * C + r]; }
+    if (full) {                                                // what only the deposit reads
+        p.wgt = f[PQ_WGT * C + r];
+        if (kind == PEEL_RESONANCE) { E1 = f[PQ_E1 * C + r]; E2 = f[PQ_E2 * C + r]; E3 = f[PQ_E3 * C + r]; }
+        if (STOKES) { p.Q = f[PQ_Q * C + r]; p.U = f[PQ_U * C + r]; p.V = f[PQ_V * C + r]; }
+    }
+}
 
 template <int VAR, bool STOKES>
 __global__ __launch_bounds__(256, 3) void peel_kernel(KArgs A) {
@@ -21,27 +46,57 @@ __global__ __launch_bounds__(256, 3) void peel_kernel(KArgs A) {
     l.lt = A.par.line_type; l.dnu_hz = A.par.line_type == 7 ? A.par.delta_nu_HD_Hz : A.par.DnuHK_Hz;
     l.hd_ratio = A.par.ratio_Dfreq_HD; l.hd_ratio_a = A.par.ratio_voigta_HD; l.hd_nD = A.par.nD_over_nH;
     if (A.par.line_type >= 4 && A.par.line_type <= 6) { l.lt = 4; lds_set_multiplet(l, A.ml); }
-    const size_t n = A.ctl->q_n < A.pq.cap ? A.ctl->q_n : A.pq.cap, C = A.pq.cap;
-    const double *f = A.pq.f; const int *qc = A.pq.cell;
+    const unsigned long long nregions = A.pq.nregions;        // producer waves of the transport launch this kernel follows
     const bool dust = A.par.DGR > 0.0;
+    const int lane = threadIdx.x & 63;
     unsigned nsteps = 0, natom = 0;
-    for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (size_t)gridDim.x * blockDim.x) {
-        Photon p;
-        p.x = f[PQ_X * C + r]; p.y = f[PQ_Y * C + r]; p.z = f[PQ_Z * C + r]; p.kx = f[PQ_KX * C + r]; p.ky = f[PQ_KY * C + r]; p.kz = f[PQ_KZ * C + r];
-        p.wgt = f[PQ_WGT * C + r]; p.xfreq = f[PQ_XA * C + r]; p.nsg = 0.0; p.nsd = 0.0; p.xfreq_ref = 0.0; p.inside = true;
-        if (STOKES) { p.mx = f[PQ_MX * C + r]; p.my = f[PQ_MY * C + r]; p.mz = f[PQ_MZ * C + r]; p.nx = f[PQ_NX * C + r]; p.ny = f[PQ_NY * C + r]; p.nz = f[PQ_NZ * C + r];
-                      p.Q = f[PQ_Q * C + r]; p.U = f[PQ_U * C + r]; p.V = f[PQ_V * C + r]; }
-        p.ic = qc[r]; p.jc = qc[C + r]; p.kc = qc[2 * C + r]; p.icl = 0;
-        if (VAR == 4) { p.icl = p.kc; p.kc = 1; }
-        const int kind = qc[3 * C + r];
-        if (kind == PEEL_DIRECT) peel_direct<VAR>(A, l, dust, p, nsteps, natom);
-        else if (kind == PEEL_DUST) {
-            if (STOKES && A.mu.nPDF > 0) peel_dust_stokes<VAR>(A, l, p, nsteps, natom);
-            else peel_dust_nostokes<VAR>(A, l, p, nsteps, natom);
-        } else {
-            const double ux = f[PQ_UX * C + r], uy = f[PQ_UY * C + r], uz = f[PQ_UZ * C + r], E1 = f[PQ_E1 * C + r], E2 = f[PQ_E2 * C + r], E3 = f[PQ_E3 * C + r], grec = f[PQ_GREC * C + r];
-            if (STOKES) peel_resonance_stokes<VAR>(A, l, dust, p, p.xfreq, ux, uy, uz, E1, E2, E3, grec, nsteps, natom);
-            else peel_resonance_nostokes<VAR>(A, l, dust, p, p.xfreq, ux, uy, uz, E1, E2, grec, nsteps, natom);
+    EdgeMarch m; m.live = false; m.tau = 0.0;
+    int st = 0;                                                // 0 no item, 1 marching, 2 march over (weight and deposit pending)
+    unsigned long long w_base = 0, w_next = 0, w_end = 0; size_t rec = 0; int io = 0; bool exhausted = false, ray_dust = false;
+    for (;;) {
+        // (1) lanes without a march take the next items.  The wave takes one producer region at a time from the queue head (one atomic per
+        // region, ~1e3 records) and hands its records to its idle lanes in order: the record reads of an iteration are consecutive addresses.
+        const bool idle = st == 0 && !exhausted;
+        const unsigned long long mk = __ballot(idle);
+        if (mk) {
+            if (w_next >= w_end) {                             // wave-uniform: region used up
+                unsigned long long w = 0; const int leader = __ffsll((long long)mk) - 1;
+                if (lane == leader) w = atomicAdd(&A.ctl->q_head, 1ull);
+                w = __shfl(w, leader, 64);
+                if (w >= nregions) { if (idle) exhausted = true; }
+                else { w_base = w * A.pq.region; w_next = 0; w_end = (unsigned long long)A.pq.count[w] * (unsigned)A.nobs; }
+            }
+            const unsigned long long avail = w_end - w_next, want = (unsigned long long)__popcll(mk);
+            const unsigned long long mine = w_next + (unsigned long long)__popcll(mk & ((1ull << lane) - 1ull));
+            w_next += want < avail ? want : avail;
+            if (idle && !exhausted && mine < w_end) {          // (idle lanes beyond the region's end wait for the next region, one iteration later)
+                rec = (size_t)(w_base + mine / (unsigned)A.nobs); io = (int)(mine % (unsigned)A.nobs);
+                Photon p; int kind; double ux, uy, uz, E1, E2, E3, grec;
+                peel_load<VAR, STOKES>(A, rec, false, p, kind, ux, uy, uz, E1, E2, E3, grec);
+                PeelDir q; double xf;
+                if (peel_ray_begin<VAR, STOKES>(A, kind, p, ux, uy, uz, grec, A.obs[io], dust, q, xf, ray_dust)) {
+                    edge_begin<VAR>(A, l, ray_dust, p, xf, q.kx, q.ky, q.kz, q.dist, m, nsteps);
+                    st = m.live ? 1 : 2;                       // (a ray that leaves the medium at once: tau = 0, deposit at full weight)
+                }                                              // else outside the image: nothing to deposit, st stays 0
+            }
+        }
+        if (!__ballot(st != 0)) { if (!__ballot(!exhausted)) break; continue; }
+        // (2) one cell for every march of the wave; a finished march with a non-zero transmission deposits
+        if (st == 1) { edge_step<VAR>(A, l, ray_dust, m, nsteps); if (!m.live) st = 2; }
+        if (st == 2) {
+            const size_t r = rec;
+            const int kind = A.pq.cell[3 * (size_t)A.pq.cap + r];
+            if (d_exp_neg(-m.tau) != 0.0 || (kind == PEEL_DIRECT && A.par.save_direc0)) {
+                Photon p; int k2; double ux, uy, uz, E1, E2, E3, grec;
+                peel_load<VAR, STOKES>(A, r, true, p, k2, ux, uy, uz, E1, E2, E3, grec);
+                if (kind == PEEL_DIRECT) peel_direct<VAR>(A, l, dust, p, nsteps, natom, io, m.tau);
+                else if (kind == PEEL_DUST) {
+                    if (STOKES && A.mu.nPDF > 0) peel_dust_stokes<VAR>(A, l, p, nsteps, natom, io, m.tau);
+                    else peel_dust_nostokes<VAR>(A, l, p, nsteps, natom, io, m.tau);
+                } else if (STOKES) peel_resonance_stokes<VAR>(A, l, dust, p, p.xfreq, ux, uy, uz, E1, E2, E3, grec, nsteps, natom, io, m.tau);
+                else peel_resonance_nostokes<VAR>(A, l, dust, p, p.xfreq, ux, uy, uz, E1, E2, grec, nsteps, natom, io, m.tau);
+            }
+            st = 0;
         }
     }
     const double s4 = wave_sum((double)nsteps), s6 = wave_sum((double)natom);

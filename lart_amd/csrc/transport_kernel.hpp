@@ -75,6 +75,10 @@ __global__ __launch_bounds__(256, LART_WAVES(STOKES, PEEL)) void transport_kerne
     }
     // wave-local scratch of the cooperative sampler, behind everything else: LART_COOP_BYTES per wave
     l_.coop = (unsigned char *)(sh + VT_END + (A.g.nx + A.g.ny + A.g.nz + 3) + (size_t)LART_RNG_BUF * blockDim.x + 2 * (size_t)A.jpa.lds_bins) + LART_COOP_BYTES * (threadIdx.x >> 6);
+    if (PEEL) {                                                // this wave's record counter of the peel queue
+        l_.pq_cnt = (unsigned *)(l_.coop - LART_COOP_BYTES * (threadIdx.x >> 6) + LART_COOP_BYTES * (blockDim.x >> 6)) + (threadIdx.x >> 6);
+        if ((threadIdx.x & 63) == 0) *l_.pq_cnt = 0u;
+    }
     const Lds l = l_;
     double *rng_lds = sh + VT_END + (A.g.nx + A.g.ny + A.g.nz + 3) + threadIdx.x;      // [LART_RNG_BUF][blockDim.x] draws
     const lart_params &par = A.par;
@@ -148,6 +152,7 @@ __global__ __launch_bounds__(256, LART_WAVES(STOKES, PEEL)) void transport_kerne
             if (A.jpa.P1_new && w != 0.0) atomicAdd(&A.jpa.P1_new[i], w);
         }
     }
+    if (PEEL && (threadIdx.x & 63) == 0) A.pq.count[lane >> 6] = *l.pq_cnt;
     A.pool.flags[lane] = (alive ? FLAG_ALIVE : 0) | (first ? FLAG_FIRST : 0);
     if (alive) {
         A.pool.k[lane] = k; A.pool.rng_n[lane] = g.n;

@@ -8,9 +8,12 @@
 #   tests[:EXPR]               pytest -m gpu (optionally -k EXPR)
 #   bench[:ARGS]               python bench.py ARGS            (ARGS with commas for spaces: bench:--steps,2,--no-cpu-baseline)
 #   configs                    tools/perf_configs.py (events/s of the other BASELINE configs)
+#   perf:C1,C2[:ARGS]          tools/perf_kernel.py --config C (steady-state launches of one kernel variant + its section-8(d) roofline)
 #   prof:TAG[:ARGS]            rocprofv3 of `python3 bench.py --no-cpu-baseline --completion-photons 0 ARGS`: kernel-trace --stats,
 #                              then SEPARATE --pmc passes (SQ set, lane set, FETCH_SIZE, WRITE_SIZE) -> gpurun_out/TAG_* summaries
 #   profcfg:TAG:CONFIG         the same passes on tools/perf_kernel.py --config CONFIG (c3, c5, c1, c4: the other transport kernels)
+#   stats:TAG:CONFIG           only the kernel-trace --stats pass on tools/perf_kernel.py --config CONFIG
+#   py:SCRIPT[:ARGS]           python SCRIPT ARGS (debug helpers under tools/dbg)
 #   explore[:ARGS]             tools/perf_explore.py ARGS (throughput vs photon age, drain tail)
 #   ab:VARIANTS:LANES          tuning builds x pool sizes through tools/perf_explore.py (VARIANTS like default,_w3 ; LANES like 0,786432)
 set -o pipefail
@@ -45,8 +48,12 @@ for spec in "$@"; do
     tests)   if [ -n "$a1" ]; then step tests 1100 python -m pytest tests -m gpu -q --timeout=900 --durations=40 -k "$a1"; else step tests 1100 python -m pytest tests -m gpu -q --timeout=900 --durations=40; fi ;;
     bench)   step bench 900 python bench.py ${a1//,/ } ;;
     configs) step configs 900 python tools/perf_configs.py ;;
+    perf)    for c in ${a1//,/ }; do step perf_$c 400 python tools/perf_kernel.py --config $c ${a2//,/ }; done ;;
     prof)    profile "$a1" transport_kernel 4096 python3 bench.py --no-cpu-baseline --completion-photons 0 ${a2//,/ } ;;
     profcfg) profile "$a1" transport_kernel 4096 python3 tools/perf_kernel.py --config "$a2" ;;
+    stats)   step ${a1}_stats 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${a1}_stats -- python3 tools/perf_kernel.py --config "$a2"
+             f=$(find gpurun_out/${a1}_stats -name "*kernel_stats.csv" | head -n 1); [ -n "$f" ] && cp "$f" gpurun_out/${a1}_kernel_stats.csv && head -n 8 gpurun_out/${a1}_kernel_stats.csv | cut -c1-300; rm -rf gpurun_out/${a1}_stats ;;
+    py)      step py_$(basename ${a1%.py}) 600 python ${a1} ${a2//,/ } ;;
     explore) step explore 1100 python tools/perf_explore.py ${a1//,/ } ;;
     ab)      for v in ${a1//,/ }; do [ "$v" = default ] && v=""; for l in ${a2//,/ }; do
                LART_GPU_LIB=$PWD/lart_amd/csrc/liblart_gpu$v.so step "ab${v}_l$l" 300 python tools/perf_explore.py --steps 3 --events 4096 --lanes $l; done; done ;;

@@ -26,6 +26,7 @@ def configs(tmp):
         "c1": dict(temperature=10.0, taumax=1e4, xy_periodic=True, nx=1, ny=1, nz=201, use_stokes=True, save_Jin=True, hgg=0.6592, albedo=0.3899, no_photons=1e8, iseed=1),
         "c2": dict(temperature=10.0, taumax=1e6, xyz_symmetry=True, nx=101, ny=101, nz=101, rmax=1.0, nxfreq=201, no_photons=1e7, iseed=1),
         "c3": dict(temperature=10.0, taumax=1e6, nx=201, ny=201, nz=201, rmax=1.0, nxfreq=201, use_stokes=True, save_Jin=True, nxim=129, nyim=129, no_photons=1e8, iseed=1),
+        "c3n": dict(temperature=10.0, taumax=1e6, nx=201, ny=201, nz=201, rmax=1.0, nxfreq=201, use_stokes=True, save_Jin=True, no_photons=1e8, iseed=1),   # C3 without its observer
         "c4": dict(use_clump_medium=True, rmax=1.0, clump_radius=0.01, clump_f_cov=5.0, clump_tau0=1e3, temperature=1e4, use_stokes=True, DGR=1.0,
                    scatt_mat_file="MUELLER", core_skip=True, nxfreq=301, velocity_min=-100.0, velocity_max=100.0, nx=11, ny=11, nz=11, no_photons=1e8, iseed=1),
         "c5": dict(use_amr_grid=True, amr_file=afile, temperature=1e4, taumax=1e4, rmax=1.0, nxfreq=241, xfreq_min=-15.0, xfreq_max=15.0,
