@@ -90,7 +90,9 @@ struct DJPa { int calc_J, calc_P, calc_Pnew, nbins; const int *ind_bin; double c
 // lart_gpu_get_tallies / lart_gpu_tally_buffer fold the copies back (k_fold_copies) before anything is read.
 struct DRep { double *base; long long off, len; int nrep; };
 
-struct DCtl { unsigned long long next_k; unsigned long long n_active; unsigned q_n, q_pad; unsigned long long q_head; };   // q_n: records in the peel queue of this launch; q_head: (record, observer) items peel_kernel has handed out
+struct DCtl { unsigned long long next_k; unsigned long long n_active; };
+struct DPeelCtl { unsigned long long q_head, d_n; };   // per queue buffer: producer regions peel_kernel has taken; entries of the deposit list
+//   // q_n: records in the peel queue of this launch; q_head: (record, observer) items peel_kernel has handed out
 
 // Peel-off event queue (deferred next-event estimator).  The reference marches a second ray to every observer inside each scattering
 // (peelingoff_rect.f90:576-690 etc.).  Inlined into the transport kernel that second march doubles its live state (2 waves/SIMD, scratch
@@ -103,7 +105,8 @@ enum { PEEL_DIRECT = 0, PEEL_RESONANCE = 1, PEEL_DUST = 2 };
 // Every producer wave owns one region of `region` consecutive record slots (64 lanes x (events of the launch + 1)) and fills it from the
 // front: the slot counter is a per-wave word in LDS, so queueing costs no global atomic (one counter for the whole grid serialises in
 // L2: measured +6 ms on a 9 ms launch); count[w] = records wave w wrote.  peel_kernel takes whole regions from the queue head.
-struct DPeelQ { double *f; int *cell; unsigned cap; unsigned region, nregions; unsigned *count; };   // f: PQ_COUNT planes of cap doubles; cell: 4 planes (ic, jc, kc | owner clump, kind)
+struct DPeelQ { double *f; int *cell; unsigned cap; unsigned region, nregions; unsigned *count;
+                unsigned *dep_idx; double *dep_tau; unsigned long long dep_cap; DPeelCtl *pctl; };   // deposit list: (record, observer) and the optical depth of the rays that came through (peel_kernel.hpp)   // f: PQ_COUNT planes of cap doubles; cell: 4 planes (ic, jc, kc | owner clump, kind)
 
 // resonance + fluorescence multiplets (line types 4, 5, 6: lart_line_multiplet).  The per-level constants are wave-uniform and ride
 // in the kernel arguments; the per-branch tables are gathered with lane-varying (iup, idown) from global memory:

@@ -20,7 +20,7 @@ extern "C" void lart_launch_transport_var3(int, int, int, dim3, dim3, size_t, hi
 extern "C" void lart_launch_transport_var4(int, int, int, dim3, dim3, size_t, hipStream_t, const KArgs &);
 extern "C" void lart_launch_transport_var5(int, int, int, dim3, dim3, size_t, hipStream_t, const KArgs &);
 extern "C" void lart_launch_transport_var6(int, int, int, dim3, dim3, size_t, hipStream_t, const KArgs &);
-extern "C" void lart_launch_peel(int var, int stokes, dim3, dim3, size_t, hipStream_t, const KArgs &);
+extern "C" void lart_launch_peel(int var, int stokes, dim3, dim3, dim3, size_t, hipStream_t, const KArgs &);
 
 static thread_local std::string g_err;
 static int fail(const std::string &m) { g_err = m; return 1; }
@@ -60,7 +60,9 @@ struct lart_gpu {
     int64_t live_lanes = 0; bool state_valid = false; int64_t last_alive = 0, last_next_k = 0; int auto_compact = 1;
     int *d_compact = nullptr; int64_t n_compactions = 0;
     // peel-off event queue (deferred next-event estimator): records of one transport launch, consumed by peel_kernel right after it
-    DPeelQ pq{}; void *d_pq = nullptr; size_t pq_bytes_max = (size_t)16 << 30; int peel_slice = 0; int n_cu = 0;
+    // two buffers: while peel_kernel works through the records of slice k on stream2, the transport kernel of slice k + 1 fills the other one
+    DPeelQ pq[2]{}; void *d_pq = nullptr; size_t pq_bytes_max = 0; int peel_slice = 0; int n_cu = 0;
+    hipStream_t stream2 = nullptr; hipEvent_t ev_filled[2] = {nullptr, nullptr}, ev_drained[2] = {nullptr, nullptr}; bool drained_pending[2] = {false, false};
     // output_reduce across GPUs: RCCL communicator of this context (one rank per context)
     ncclComm_t comm = nullptr; int comm_n = 0, comm_rank = -1;
 };
@@ -112,6 +114,8 @@ extern "C" int lart_gpu_destroy(lart_gpu *c) {
     (void)hipFree(c->d_cell); (void)hipFree(c->d_faces); (void)hipFree(c->d_mu); (void)hipFree(c->d_alias); (void)hipFree(c->d_ml_tab); (void)hipFree(c->d_ml_itab); (void)hipFree(c->d_obs); (void)hipFree(c->d_ind_bin); (void)hipFree(c->d_amr_int); (void)hipFree(c->d_amr_geom); (void)hipFree(c->d_cl_geo); (void)hipFree(c->d_cl_phys); (void)hipFree(c->d_cl_int);
     free_tally(c); (void)hipFree(c->d_pool); (void)hipFree(c->d_ctl); (void)hipFree(c->d_log); (void)hipFree(c->d_compact); (void)hipFree(c->d_pq);
     if (c->comm) { (void)ncclCommDestroy(c->comm); c->comm = nullptr; }
+    for (int b = 0; b < 2; b++) { if (c->ev_filled[b]) (void)hipEventDestroy(c->ev_filled[b]); if (c->ev_drained[b]) (void)hipEventDestroy(c->ev_drained[b]); }
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -501,25 +505,46 @@ static int collect_events(lart_gpu *c) {
     return 0;
 }
 
-// the peel queue: PQ_COUNT (Stokes) or PQ_NOSTOKES f64 planes + 4 int planes of `cap` records
+// the peel queue: two buffers of PQ_COUNT (Stokes) or PQ_NOSTOKES f64 planes + 4 int planes of `cap` records, the producer waves' counts and
+// the deposit list; sized once per run for pq_bytes_max of HBM (default: a quarter of the free memory, at most 64 GiB; LART_PEEL_QUEUE_GB)
 static int ensure_peel_queue(lart_gpu *c, int max_events) {
     if (!c->n_cu) { hipDeviceProp_t pr; HIPCHK(hipGetDeviceProperties(&pr, c->device)); c->n_cu = pr.multiProcessorCount; }
+    if (!c->stream2) {
+        HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+        for (int b = 0; b < 2; b++) { HIPCHK(hipEventCreateWithFlags(&c->ev_filled[b], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_drained[b], hipEventDisableTiming)); }
+    }
+    const size_t nobs = (size_t)(c->nobs > 0 ? c->nobs : 1);
     const size_t planes = c->par.use_stokes ? (size_t)PQ_COUNT : (size_t)PQ_NOSTOKES, rec_bytes = planes * 8 + 16;
     const size_t lanes = (size_t)c->pool.n;
-    if (const char *e = std::getenv("LART_PEEL_QUEUE_GB")) { const double gb = std::atof(e); if (gb >= 0.25 && gb <= 200.0) c->pq_bytes_max = (size_t)(gb * 1073741824.0); }   // tuning knob: HBM set aside for the queue
-    size_t fit = c->pq_bytes_max / (rec_bytes * lanes);         // records per lane the byte budget allows
+    if (!c->pq_bytes_max) {
+        size_t fr = 0, tot = 0; HIPCHK(hipMemGetInfo(&fr, &tot));
+        c->pq_bytes_max = fr / 4 < ((size_t)64 << 30) ? fr / 4 : ((size_t)64 << 30);
+        if (const char *e = std::getenv("LART_PEEL_QUEUE_GB")) { const double gb = std::atof(e); if (gb >= 0.25 && gb <= 200.0) c->pq_bytes_max = (size_t)(gb * 1073741824.0); }   // tuning knob
+    }
+    size_t fit = c->pq_bytes_max / (2 * (rec_bytes + 16 * nobs) * lanes);      // records per lane and buffer the byte budget allows (+ one deposit-list entry per observer)
     int slice = max_events;
     if ((size_t)slice + 1 > fit) slice = fit > 1 ? (int)(fit - 1) : 1;
     const size_t cap = lanes * ((size_t)slice + 1);
     if (cap > 0xfffffff0ull) return fail("peel queue: more than 2^32 records per launch; lower the pool size or max_events");
-    if (!c->d_pq || c->pq.cap < cap) {
+    if (!c->d_pq || c->pq[0].cap < cap) {
+        HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipStreamSynchronize(c->stream2));
         (void)hipFree(c->d_pq); c->d_pq = nullptr;
-        HIPCHK(hipMalloc(&c->d_pq, cap * rec_bytes + (lanes / 64 + 1) * sizeof(unsigned)));
-        c->pq.f = (double *)c->d_pq; c->pq.cell = (int *)((char *)c->d_pq + cap * planes * 8); c->pq.cap = (unsigned)cap;
-        c->pq.count = (unsigned *)((char *)c->d_pq + cap * rec_bytes);
-    } else slice = (int)(c->pq.cap / lanes) - 1 < max_events ? (int)(c->pq.cap / lanes) - 1 : max_events;
+        // the deposit list: (record, observer, tau) of every (record, observer) pair, plus one chunk per marching wave of slack
+        const size_t dep_cap = cap * nobs + (size_t)c->n_cu * 16 * 256;
+        const size_t cnt_bytes = ((lanes / 64 + 1) * sizeof(unsigned) + 15) / 16 * 16;
+        const size_t one = (cap * rec_bytes + cnt_bytes + dep_cap * 16 + sizeof(DPeelCtl) + 255) / 256 * 256;
+        HIPCHK(hipMalloc(&c->d_pq, 2 * one));
+        for (int b = 0; b < 2; b++) {
+            char *base = (char *)c->d_pq + (size_t)b * one; DPeelQ &q = c->pq[b];
+            q.f = (double *)base; q.cell = (int *)(base + cap * planes * 8); q.cap = (unsigned)cap;
+            q.count = (unsigned *)(base + cap * rec_bytes);
+            q.dep_tau = (double *)(base + cap * rec_bytes + cnt_bytes); q.dep_idx = (unsigned *)(q.dep_tau + dep_cap); q.dep_cap = dep_cap;
+            q.pctl = (DPeelCtl *)(base + cap * rec_bytes + cnt_bytes + dep_cap * 16);
+        }
+        c->drained_pending[0] = c->drained_pending[1] = false;
+    } else slice = (int)(c->pq[0].cap / lanes) - 1 < max_events ? (int)(c->pq[0].cap / lanes) - 1 : max_events;
     c->peel_slice = slice < 1 ? 1 : slice;
-    c->pq.region = 64u * ((unsigned)c->peel_slice + 1u);      // one producer wave's slots: every lane queues at most one record per event and one per birth
+    for (int b = 0; b < 2; b++) c->pq[b].region = 64u * ((unsigned)c->peel_slice + 1u);      // one producer wave's slots: every lane queues at most one record per event and one per birth
     return 0;
 }
 
@@ -610,15 +635,21 @@ extern "C" int lart_gpu_step(lart_gpu *c, int32_t nsteps, int32_t max_events) {
     int slice = max_events;
     if (peel) {
         if (ensure_peel_queue(c, max_events)) return 1;
-        slice = c->peel_slice; A.pq = c->pq; A.pq.nregions = (unsigned)(c->live_lanes / 64);
+        slice = c->peel_slice;
     }
     const size_t peel_shmem = (size_t)(VT_END + c->g.nx + c->g.ny + c->g.nz + 3) * sizeof(double);
+    int nslice = 0;
     for (int s = 0; s < nsteps; s++) {
         hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
         HIPCHK(hipEventRecord(e0, c->stream));
-        for (int left = max_events; left > 0; left -= slice) {
+        for (int left = max_events; left > 0; left -= slice, nslice++) {
+            const int b = nslice & 1;
             A.max_events = left < slice ? left : slice;
-            HIPCHK(hipMemsetAsync(&c->d_ctl->n_active, 0, sizeof(DCtl) - offsetof(DCtl, n_active), c->stream));   // n_active, q_n, q_head
+            if (peel) {                                           // this buffer's previous records must have been worked through
+                A.pq = c->pq[b]; A.pq.nregions = (unsigned)(c->live_lanes / 64);
+                if (c->drained_pending[b]) { HIPCHK(hipStreamWaitEvent(c->stream, c->ev_drained[b], 0)); c->drained_pending[b] = false; }
+            }
+            HIPCHK(hipMemsetAsync(&c->d_ctl->n_active, 0, sizeof(unsigned long long), c->stream));
             if (var == 0) lart_launch_transport_var0(stokes, dust, peel, grid, block, shmem, c->stream, A);
             else if (var == 1) lart_launch_transport_var1(stokes, dust, peel, grid, block, shmem, c->stream, A);
             else if (var == 2) lart_launch_transport_var2(stokes, dust, peel, grid, block, shmem, c->stream, A);
@@ -627,11 +658,19 @@ extern "C" int lart_gpu_step(lart_gpu *c, int32_t nsteps, int32_t max_events) {
             else if (var == 5) lart_launch_transport_var5(stokes, dust, peel, grid, block, shmem, c->stream, A);
             else lart_launch_transport_var6(stokes, dust, peel, grid, block, shmem, c->stream, A);
             HIPCHK(hipGetLastError());
-            if (peel) {                                           // persistent waves that pull (record, observer) items from the queue head
-                lart_launch_peel(var, stokes, dim3((unsigned)(c->n_cu * 4)), dim3(256), peel_shmem, c->stream, A);
+            if (peel) {
+                // the peel kernels of this slice run on the second stream, next to the transport kernel of the next slice: the march is bound
+                // by gather latency (VALU a quarter busy), the transport kernel by VALU issue
+                HIPCHK(hipEventRecord(c->ev_filled[b], c->stream));
+                HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_filled[b], 0));
+                HIPCHK(hipMemsetAsync(A.pq.pctl, 0, sizeof(DPeelCtl), c->stream2));
+                lart_launch_peel(var, stokes, dim3((unsigned)(c->n_cu * 4)), dim3((unsigned)(c->n_cu * 2)), dim3(256), peel_shmem, c->stream2, A);
                 HIPCHK(hipGetLastError());
+                HIPCHK(hipEventRecord(c->ev_drained[b], c->stream2)); c->drained_pending[b] = true;
             }
         }
+        if (peel) for (int b = 0; b < 2; b++)                     // the step is over when its deposits are in: everything after it on `stream` sees the tallies
+            if (c->drained_pending[b]) { HIPCHK(hipStreamWaitEvent(c->stream, c->ev_drained[b], 0)); c->drained_pending[b] = false; }
         HIPCHK(hipEventRecord(e1, c->stream));
         c->ev.emplace_back(e0, e1);
     }

@@ -6,12 +6,19 @@
 // one cell has a line-centre depth of ~1e4), but a ray at a wing frequency crosses a hundred: with one item per lane and a plain
 // loop a wave would march at the pace of its longest ray (measured: 13.9 ms per 8e7 records, 10x the arithmetic).  So every lane
 // keeps ONE march in flight (EdgeMarch), every iteration advances all marches of the wave by one cell, and a lane whose march is
-// over -- or never started, outside the image -- takes the next item from the queue head (one atomic per wave).  The deposit
-// (exp, pixel, Stokes rotations, atomics) runs only for a non-zero weight, 0.2 % of the items at tau0 = 1e6: the routine of the
-// record's kind is called with the observer and the optical depth just found (its `only` / `tau_given` arguments), so the
-// arithmetic of a deposit is the one-piece routine's, statement for statement.
+// over -- or never started, outside the image -- takes the next item from the queue.  The march kernel is bound by the latency of its
+// dependent gathers (record -> cell -> next cell), so it carries nothing but the march: a ray that came through with a non-zero
+// transmission (0.2 % of the items at tau0 = 1e6) is appended to a deposit list (record, observer, tau), and peel_deposit_kernel
+// afterwards calls the routine of the record's kind with that observer and optical depth (its `only` / `tau_given` arguments): the
+// arithmetic of a deposit (exp, pixel, Stokes rotations, atomics) is the one-piece routine's, statement for statement.
 #pragma once
 #include "transport_kernel.hpp"
+#ifndef LART_PEEL_WAVES
+#define LART_PEEL_WAVES 4
+#endif
+#ifndef LART_DEP_CHUNK
+#define LART_DEP_CHUNK 256ull
+#endif
 
 template <int VAR, bool STOKES>
 __device__ inline void peel_load(const KArgs &A, size_t r, bool full, Photon &p, int &kind, double &ux, double &uy, double &uz, double &E1, double &E2, double &E3, double &grec) {
@@ -32,7 +39,7 @@ __device__ inline void peel_load(const KArgs &A, size_t r, bool full, Photon &p,
 }
 
 template <int VAR, bool STOKES>
-__global__ __launch_bounds__(256, 3) void peel_kernel(KArgs A) {
+__global__ __launch_bounds__(256, LART_PEEL_WAVES) void peel_kernel(KArgs A) {
     extern __shared__ double sh[];
     if (A.rep.nrep > 1) {                                      // this block's copy of the contended tally sections (DRep)
         const unsigned r = blockIdx.x % (unsigned)A.rep.nrep;
@@ -52,7 +59,7 @@ __global__ __launch_bounds__(256, 3) void peel_kernel(KArgs A) {
     unsigned nsteps = 0, natom = 0;
     EdgeMarch m; m.live = false; m.tau = 0.0;
     int st = 0;                                                // 0 no item, 1 marching, 2 march over (weight and deposit pending)
-    unsigned long long w_base = 0, w_next = 0, w_end = 0; size_t rec = 0; int io = 0; bool exhausted = false, ray_dust = false;
+    unsigned long long w_base = 0, w_next = 0, w_end = 0, d_next = 0, d_end = 0; size_t rec = 0; int io = 0, kind = 0; bool exhausted = false, ray_dust = false;
     for (;;) {
         // (1) lanes without a march take the next items.  The wave takes one producer region at a time from the queue head (one atomic per
         // region, ~1e3 records) and hands its records to its idle lanes in order: the record reads of an iteration are consecutive addresses.
@@ -61,7 +68,7 @@ __global__ __launch_bounds__(256, 3) void peel_kernel(KArgs A) {
         if (mk) {
             if (w_next >= w_end) {                             // wave-uniform: region used up
                 unsigned long long w = 0; const int leader = __ffsll((long long)mk) - 1;
-                if (lane == leader) w = atomicAdd(&A.ctl->q_head, 1ull);
+                if (lane == leader) w = atomicAdd(&A.pq.pctl->q_head, 1ull);
                 w = __shfl(w, leader, 64);
                 if (w >= nregions) { if (idle) exhausted = true; }
                 else { w_base = w * A.pq.region; w_next = 0; w_end = (unsigned long long)A.pq.count[w] * (unsigned)A.nobs; }
@@ -71,7 +78,7 @@ __global__ __launch_bounds__(256, 3) void peel_kernel(KArgs A) {
             w_next += want < avail ? want : avail;
             if (idle && !exhausted && mine < w_end) {          // (idle lanes beyond the region's end wait for the next region, one iteration later)
                 rec = (size_t)(w_base + mine / (unsigned)A.nobs); io = (int)(mine % (unsigned)A.nobs);
-                Photon p; int kind; double ux, uy, uz, E1, E2, E3, grec;
+                Photon p; double ux, uy, uz, E1, E2, E3, grec;
                 peel_load<VAR, STOKES>(A, rec, false, p, kind, ux, uy, uz, E1, E2, E3, grec);
                 PeelDir q; double xf;
                 if (peel_ray_begin<VAR, STOKES>(A, kind, p, ux, uy, uz, grec, A.obs[io], dust, q, xf, ray_dust)) {
@@ -83,27 +90,70 @@ __global__ __launch_bounds__(256, 3) void peel_kernel(KArgs A) {
         if (!__ballot(st != 0)) { if (!__ballot(!exhausted)) break; continue; }
         // (2) one cell for every march of the wave; a finished march with a non-zero transmission deposits
         if (st == 1) { edge_step<VAR>(A, l, ray_dust, m, nsteps); if (!m.live) st = 2; }
-        if (st == 2) {
-            const size_t r = rec;
-            const int kind = A.pq.cell[3 * (size_t)A.pq.cap + r];
-            if (d_exp_neg(-m.tau) != 0.0 || (kind == PEEL_DIRECT && A.par.save_direc0)) {
-                Photon p; int k2; double ux, uy, uz, E1, E2, E3, grec;
-                peel_load<VAR, STOKES>(A, r, true, p, k2, ux, uy, uz, E1, E2, E3, grec);
-                if (kind == PEEL_DIRECT) peel_direct<VAR>(A, l, dust, p, nsteps, natom, io, m.tau);
-                else if (kind == PEEL_DUST) {
-                    if (STOKES && A.mu.nPDF > 0) peel_dust_stokes<VAR>(A, l, p, nsteps, natom, io, m.tau);
-                    else peel_dust_nostokes<VAR>(A, l, p, nsteps, natom, io, m.tau);
-                } else if (STOKES) peel_resonance_stokes<VAR>(A, l, dust, p, p.xfreq, ux, uy, uz, E1, E2, E3, grec, nsteps, natom, io, m.tau);
-                else peel_resonance_nostokes<VAR>(A, l, dust, p, p.xfreq, ux, uy, uz, E1, E2, grec, nsteps, natom, io, m.tau);
+        // a finished march whose transmission is not exactly zero goes to the deposit list: the wave reserves LART_DEP_CHUNK entries at a
+        // time (wave-uniform d_next / d_end) and marks what it leaves unused at the end
+        const bool dep = st == 2 && (d_exp_neg(-m.tau) != 0.0 || (kind == PEEL_DIRECT && A.par.save_direc0));
+        const unsigned long long dm = __ballot(dep);
+        if (dm) {
+            const unsigned long long want = (unsigned long long)__popcll(dm);
+            if (d_next + want > d_end) {                       // wave-uniform: not enough left in the chunk
+                for (unsigned long long e = d_next + (unsigned)lane; e < d_end && e < A.pq.dep_cap; e += 64) A.pq.dep_idx[2 * e] = 0xffffffffu;   // void entries
+                unsigned long long b = 0; const int leader = __ffsll((long long)dm) - 1;
+                if (lane == leader) b = atomicAdd(&A.pq.pctl->d_n, (unsigned long long)LART_DEP_CHUNK);
+                b = __shfl(b, leader, 64);
+                d_next = b; d_end = b + LART_DEP_CHUNK;
             }
-            st = 0;
+            if (dep) {
+                const unsigned long long e = d_next + (unsigned long long)__popcll(dm & ((1ull << lane) - 1ull));
+                if (e < A.pq.dep_cap) { A.pq.dep_idx[2 * e] = (unsigned)rec; A.pq.dep_idx[2 * e + 1] = (unsigned)io; A.pq.dep_tau[e] = m.tau; }
+            }
+            d_next += want;
+        }
+        if (st == 2) st = 0;
+    }
+    for (unsigned long long e = d_next + (unsigned)lane; e < d_end && e < A.pq.dep_cap; e += 64) A.pq.dep_idx[2 * e] = 0xffffffffu;
+    const double s4 = wave_sum((double)nsteps);
+    if ((threadIdx.x & 63) == 0) { if (s4 != 0.0) atomicAdd(&A.t.scal[4], s4); }
+}
+
+// the deposits of the rays on the list: one entry per lane, grid-stride
+template <int VAR, bool STOKES>
+__global__ __launch_bounds__(256, 2) void peel_deposit_kernel(KArgs A) {
+    extern __shared__ double sh[];
+    if (A.rep.nrep > 1) {                                      // this block's copy of the contended tally sections (DRep)
+        const unsigned r = blockIdx.x % (unsigned)A.rep.nrep;
+        if (r) {
+            const ptrdiff_t shift = (A.rep.base + (size_t)(r - 1) * A.rep.len) - (A.t.scal + A.rep.off);
+            for (int q = 0; q < 8; q++) { if (A.t.c3[q]) A.t.c3[q] += shift; if (A.t.c2[q]) A.t.c2[q] += shift; }
         }
     }
-    const double s4 = wave_sum((double)nsteps), s6 = wave_sum((double)natom);
-    if ((threadIdx.x & 63) == 0) { if (s4 != 0.0) atomicAdd(&A.t.scal[4], s4); if (s6 != 0.0) atomicAdd(&A.t.scal[6], s6); }
+    Lds l = lds_stage(sh, A.g);
+    l.lt = A.par.line_type; l.dnu_hz = A.par.line_type == 7 ? A.par.delta_nu_HD_Hz : A.par.DnuHK_Hz;
+    l.hd_ratio = A.par.ratio_Dfreq_HD; l.hd_ratio_a = A.par.ratio_voigta_HD; l.hd_nD = A.par.nD_over_nH;
+    if (A.par.line_type >= 4 && A.par.line_type <= 6) { l.lt = 4; lds_set_multiplet(l, A.ml); }
+    const unsigned long long n = A.pq.pctl->d_n < A.pq.dep_cap ? A.pq.pctl->d_n : A.pq.dep_cap;
+    const bool dust = A.par.DGR > 0.0;
+    unsigned nsteps = 0, natom = 0;
+    for (unsigned long long e = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (unsigned long long)gridDim.x * blockDim.x) {
+        const unsigned r = A.pq.dep_idx[2 * e];
+        if (r == 0xffffffffu) continue;
+        const int io = (int)A.pq.dep_idx[2 * e + 1]; const double tau = A.pq.dep_tau[e];
+        Photon p; int kind; double ux, uy, uz, E1, E2, E3, grec;
+        peel_load<VAR, STOKES>(A, r, true, p, kind, ux, uy, uz, E1, E2, E3, grec);
+        if (kind == PEEL_DIRECT) peel_direct<VAR>(A, l, dust, p, nsteps, natom, io, tau);
+        else if (kind == PEEL_DUST) {
+            if (STOKES && A.mu.nPDF > 0) peel_dust_stokes<VAR>(A, l, p, nsteps, natom, io, tau);
+            else peel_dust_nostokes<VAR>(A, l, p, nsteps, natom, io, tau);
+        } else if (STOKES) peel_resonance_stokes<VAR>(A, l, dust, p, p.xfreq, ux, uy, uz, E1, E2, E3, grec, nsteps, natom, io, tau);
+        else peel_resonance_nostokes<VAR>(A, l, dust, p, p.xfreq, ux, uy, uz, E1, E2, grec, nsteps, natom, io, tau);
+    }
+    const double s6 = wave_sum((double)natom);
+    if ((threadIdx.x & 63) == 0 && s6 != 0.0) atomicAdd(&A.t.scal[6], s6);
 }
 
 #define LART_PEEL_CASE(VAR, S) \
     if (var == VAR && stokes == S) { \
-        if (shmem > 64 * 1024) (void)hipFuncSetAttribute((const void *)peel_kernel<VAR, (bool)S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
-        hipLaunchKernelGGL((peel_kernel<VAR, (bool)S>), grid, block, shmem, st, A); return; }
+        if (shmem > 64 * 1024) { (void)hipFuncSetAttribute((const void *)peel_kernel<VAR, (bool)S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
+                                 (void)hipFuncSetAttribute((const void *)peel_deposit_kernel<VAR, (bool)S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); } \
+        hipLaunchKernelGGL((peel_kernel<VAR, (bool)S>), grid, block, shmem, st, A); \
+        hipLaunchKernelGGL((peel_deposit_kernel<VAR, (bool)S>), grid_dep, block, shmem, st, A); return; }
