@@ -1693,8 +1693,11 @@ __device__ inline void peel_emit(const KArgs &A, const Lds &l, bool dust, int ki
     double *f = A.pq.f;
     f[PQ_X * C + r] = p.x; f[PQ_Y * C + r] = p.y; f[PQ_Z * C + r] = p.z; f[PQ_KX * C + r] = p.kx; f[PQ_KY * C + r] = p.ky; f[PQ_KZ * C + r] = p.kz;
     f[PQ_WGT * C + r] = p.wgt; f[PQ_XA * C + r] = xa;
-    if (kind == PEEL_RESONANCE) { f[PQ_UX * C + r] = ux; f[PQ_UY * C + r] = uy; f[PQ_UZ * C + r] = uz; f[PQ_E1 * C + r] = E1; f[PQ_E2 * C + r] = E2; f[PQ_E3 * C + r] = E3; f[PQ_GREC * C + r] = grec; }
-    if (STOKES) { f[PQ_MX * C + r] = p.mx; f[PQ_MY * C + r] = p.my; f[PQ_MZ * C + r] = p.mz; f[PQ_NX * C + r] = p.nx; f[PQ_NY * C + r] = p.ny; f[PQ_NZ * C + r] = p.nz;
+    // what a single line (line type 1) would only repeat is left out: E1..E3 are line%E1..E3 and the recoil constant line%g_recoil0 there
+    // (lart_params), and the third vector of the right-handed triad is n = k x m (peel_load)
+    if (kind == PEEL_RESONANCE) { f[PQ_UX * C + r] = ux; f[PQ_UY * C + r] = uy; f[PQ_UZ * C + r] = uz;
+        if (l.lt != 1) { f[PQ_E1 * C + r] = E1; f[PQ_E2 * C + r] = E2; f[PQ_E3 * C + r] = E3; f[PQ_GREC * C + r] = grec; } }
+    if (STOKES) { f[PQ_MX * C + r] = p.mx; f[PQ_MY * C + r] = p.my; f[PQ_MZ * C + r] = p.mz;
                   f[PQ_Q * C + r] = p.Q; f[PQ_U * C + r] = p.U; f[PQ_V * C + r] = p.V; }
     int *q = A.pq.cell;
     q[r] = p.ic; q[C + r] = p.jc; q[2 * C + r] = (VAR == 4) ? p.icl : p.kc; q[3 * C + r] = kind;

@@ -21,7 +21,7 @@
 #endif
 
 template <int VAR, bool STOKES>
-__device__ inline void peel_load(const KArgs &A, size_t r, bool full, Photon &p, int &kind, double &ux, double &uy, double &uz, double &E1, double &E2, double &E3, double &grec) {
+__device__ inline void peel_load(const KArgs &A, const Lds &l, size_t r, bool full, Photon &p, int &kind, double &ux, double &uy, double &uz, double &E1, double &E2, double &E3, double &grec) {
     const size_t C = A.pq.cap; const double *f = A.pq.f; const int *qc = A.pq.cell;
     p.x = f[PQ_X * C + r]; p.y = f[PQ_Y * C + r]; p.z = f[PQ_Z * C + r]; p.kx = f[PQ_KX * C + r]; p.ky = f[PQ_KY * C + r]; p.kz = f[PQ_KZ * C + r];
     p.xfreq = f[PQ_XA * C + r]; p.nsg = 0.0; p.nsd = 0.0; p.xfreq_ref = 0.0; p.inside = true; p.wgt = 0.0; p.Q = 0.0; p.U = 0.0; p.V = 0.0;
@@ -29,11 +29,12 @@ __device__ inline void peel_load(const KArgs &A, size_t r, bool full, Photon &p,
     if (VAR == 4) { p.icl = p.kc; p.kc = 1; }
     kind = qc[3 * C + r];
     ux = 0.0; uy = 0.0; uz = 0.0; E1 = 0.0; E2 = 0.0; E3 = 0.0; grec = 0.0;
-    if (kind == PEEL_RESONANCE) { ux = f[PQ_UX * C + r]; uy = f[PQ_UY * C + r]; uz = f[PQ_UZ * C + r]; grec = f[PQ_GREC * C + r]; }
-    if (STOKES) { p.mx = f[PQ_MX * C + r]; p.my = f[PQ_MY * C + r]; p.mz = f[PQ_MZ * C + r]; p.nx = f[PQ_NX * C + r]; p.ny = f[PQ_NY * C + r]; p.nz = f[PQ_NZ * C + r]; }
+    if (kind == PEEL_RESONANCE) { ux = f[PQ_UX * C + r]; uy = f[PQ_UY * C + r]; uz = f[PQ_UZ * C + r]; grec = (l.lt != 1) ? f[PQ_GREC * C + r] : A.par.g_recoil0; }
+    if (STOKES) { p.mx = f[PQ_MX * C + r]; p.my = f[PQ_MY * C + r]; p.mz = f[PQ_MZ * C + r];
+                  p.nx = p.ky * p.mz - p.kz * p.my; p.ny = p.kz * p.mx - p.kx * p.mz; p.nz = p.kx * p.my - p.ky * p.mx; }   // n = k x m: (m, n, k) is a right-handed triad
     if (full) {                                                // what only the deposit reads
         p.wgt = f[PQ_WGT * C + r];
-        if (kind == PEEL_RESONANCE) { E1 = f[PQ_E1 * C + r]; E2 = f[PQ_E2 * C + r]; E3 = f[PQ_E3 * C + r]; }
+        if (kind == PEEL_RESONANCE) { if (l.lt != 1) { E1 = f[PQ_E1 * C + r]; E2 = f[PQ_E2 * C + r]; E3 = f[PQ_E3 * C + r]; } else { E1 = A.par.E1; E2 = A.par.E2; E3 = A.par.E3; } }
         if (STOKES) { p.Q = f[PQ_Q * C + r]; p.U = f[PQ_U * C + r]; p.V = f[PQ_V * C + r]; }
     }
 }
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(256, LART_PEEL_WAVES) void peel_kernel(KArgs A) {
             if (idle && !exhausted && mine < w_end) {          // (idle lanes beyond the region's end wait for the next region, one iteration later)
                 rec = (size_t)(w_base + mine / (unsigned)A.nobs); io = (int)(mine % (unsigned)A.nobs);
                 Photon p; double ux, uy, uz, E1, E2, E3, grec;
-                peel_load<VAR, STOKES>(A, rec, false, p, kind, ux, uy, uz, E1, E2, E3, grec);
+                peel_load<VAR, STOKES>(A, l, rec, false, p, kind, ux, uy, uz, E1, E2, E3, grec);
                 PeelDir q; double xf;
                 if (peel_ray_begin<VAR, STOKES>(A, kind, p, ux, uy, uz, grec, A.obs[io], dust, q, xf, ray_dust)) {
                     edge_begin<VAR>(A, l, ray_dust, p, xf, q.kx, q.ky, q.kz, q.dist, m, nsteps);
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void peel_deposit_kernel(KArgs A) {
         if (r == 0xffffffffu) continue;
         const int io = (int)A.pq.dep_idx[2 * e + 1]; const double tau = A.pq.dep_tau[e];
         Photon p; int kind; double ux, uy, uz, E1, E2, E3, grec;
-        peel_load<VAR, STOKES>(A, r, true, p, kind, ux, uy, uz, E1, E2, E3, grec);
+        peel_load<VAR, STOKES>(A, l, r, true, p, kind, ux, uy, uz, E1, E2, E3, grec);
         if (kind == PEEL_DIRECT) peel_direct<VAR>(A, l, dust, p, nsteps, natom, io, tau);
         else if (kind == PEEL_DUST) {
             if (STOKES && A.mu.nPDF > 0) peel_dust_stokes<VAR>(A, l, p, nsteps, natom, io, tau);
