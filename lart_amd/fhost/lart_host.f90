@@ -599,9 +599,9 @@ contains
     if (par%DGR == 0.0_wp) par%save_Jabs = .false.
 
     if (len_trim(par%out_file) == 0) then
-       par%base_name = base_of(model_infile)
+       par%base_name = base_of(model_infile, .true.)
     else
-       par%base_name = base_of(par%out_file)
+       par%base_name = base_of(par%out_file, .false.)
     endif
     par%file_format = strlowcase(par%file_format)
     par%out_file = trim(par%base_name)
@@ -648,14 +648,32 @@ contains
       close(uin)
       rewind(uout)
     end subroutine open_sanitized
-    function base_of(f) result(b)
+    !--- get_base_input_name (utility.f90:250-258: everything before the first '.in') for the input file, get_base_name (:220-248: only a
+    !    recognised output extension is stripped) for par%out_file; the directory part goes in both
+    function base_of(f, is_input) result(b)
       character(len=*), intent(in) :: f
+      logical, intent(in) :: is_input
       character(len=128) :: b
-      integer :: i1, i2
+      integer :: i1, i2, n
       i1 = index(f, '/', back=.true.) + 1
       b = f(i1:)
-      i2 = index(b, '.')
-      if (i2 > 1) b = b(1:i2-1)
+      n = len_trim(b)
+      if (is_input) then
+         i2 = index(b, '.in')
+         if (i2 > 1) b = b(1:i2-1)
+         return
+      endif
+      i2 = n
+      if (n >= 8) then
+         if (b(n-7:n) == '.fits.gz') i2 = n - 8
+      endif
+      if (i2 == n .and. n >= 5) then
+         if (b(n-4:n) == '.hdf5' .or. b(n-4:n) == '.fits') i2 = n - 5
+      endif
+      if (i2 == n .and. n >= 3) then
+         if (b(n-2:n) == '.h5') i2 = n - 3
+      endif
+      if (i2 >= 1) b = b(1:i2)
     end function base_of
   end subroutine read_input
 

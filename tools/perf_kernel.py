@@ -31,6 +31,9 @@ def configs(tmp):
                    scatt_mat_file="MUELLER", core_skip=True, nxfreq=301, velocity_min=-100.0, velocity_max=100.0, nx=11, ny=11, nz=11, no_photons=1e8, iseed=1),
         "c5": dict(use_amr_grid=True, amr_file=afile, temperature=1e4, taumax=1e4, rmax=1.0, nxfreq=241, xfreq_min=-15.0, xfreq_max=15.0,
                    calc_J=True, calc_P=True, calc_Pnew=True, no_photons=1e8, iseed=1),
+        "c5j": dict(use_amr_grid=True, amr_file=afile, temperature=1e4, taumax=1e4, rmax=1.0, nxfreq=241, xfreq_min=-15.0, xfreq_max=15.0, calc_J=True, no_photons=1e8, iseed=1),
+        "c5p": dict(use_amr_grid=True, amr_file=afile, temperature=1e4, taumax=1e4, rmax=1.0, nxfreq=241, xfreq_min=-15.0, xfreq_max=15.0, calc_P=True, no_photons=1e8, iseed=1),
+        "c5q": dict(use_amr_grid=True, amr_file=afile, temperature=1e4, taumax=1e4, rmax=1.0, nxfreq=241, xfreq_min=-15.0, xfreq_max=15.0, calc_Pnew=True, no_photons=1e8, iseed=1),
         "c5n": dict(use_amr_grid=True, amr_file=afile, temperature=1e4, taumax=1e4, rmax=1.0, nxfreq=241, xfreq_min=-15.0, xfreq_max=15.0, no_photons=1e8, iseed=1),
     }
     return c, afile, mueller_path
