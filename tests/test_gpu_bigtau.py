@@ -84,7 +84,7 @@ def test_c3_sphere_peel_tau6_full_size(capi, golden):
     """201^3 cells, Stokes, one far observer with a 129 x 129 x 201 cube, tau0 = 1e6: emergent spectrum, peel-integrated spectra of the
     scattered light and of Stokes I, the radial surface-brightness profile, and Q, U consistent with zero when integrated over a sphere's image"""
     fx = golden("c3_peel_tau6.npz")
-    n = 200000
+    n = 100000
     nr = float(fx["nphotons"])
     sim, t, ns = run(capi, fx, n, 20261006)
     rms, exp, chi2 = compare(t["Jout"], n, fx["Jout_raw"], nr, "C3 Jout")
