@@ -59,7 +59,6 @@ struct lart_gpu {
     // lane compaction: the launch covers lanes [0, live_lanes); state of the last lart_gpu_sync
     int64_t live_lanes = 0; bool state_valid = false; int64_t last_alive = 0, last_next_k = 0; int auto_compact = 1;
     int *d_compact = nullptr; int64_t n_compactions = 0;
-    void *d_spread = nullptr; int64_t spread_cap = 0, spread_alive = 0; int spread_q = 0;      // drain tail: few packets per wave (lart_gpu_compact)
     // peel-off event queue (deferred next-event estimator): records of one transport launch, consumed by peel_kernel right after it
     // two buffers: while peel_kernel works through the records of slice k on stream2, the transport kernel of slice k + 1 fills the other one
     DPeelQ pq[2]{}; void *d_pq = nullptr; size_t pq_bytes_max = 0; int peel_slice = 0; int n_cu = 0;
@@ -113,7 +112,7 @@ extern "C" int lart_gpu_destroy(lart_gpu *c) {
     (void)hipStreamSynchronize(c->stream);
     for (auto &e : c->ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     (void)hipFree(c->d_cell); (void)hipFree(c->d_faces); (void)hipFree(c->d_mu); (void)hipFree(c->d_alias); (void)hipFree(c->d_ml_tab); (void)hipFree(c->d_ml_itab); (void)hipFree(c->d_obs); (void)hipFree(c->d_ind_bin); (void)hipFree(c->d_amr_int); (void)hipFree(c->d_amr_geom); (void)hipFree(c->d_cl_geo); (void)hipFree(c->d_cl_phys); (void)hipFree(c->d_cl_int);
-    free_tally(c); (void)hipFree(c->d_pool); (void)hipFree(c->d_ctl); (void)hipFree(c->d_log); (void)hipFree(c->d_compact); (void)hipFree(c->d_spread); (void)hipFree(c->d_pq);
+    free_tally(c); (void)hipFree(c->d_pool); (void)hipFree(c->d_ctl); (void)hipFree(c->d_log); (void)hipFree(c->d_compact); (void)hipFree(c->d_pq);
     if (c->comm) { (void)ncclCommDestroy(c->comm); c->comm = nullptr; }
     for (int b = 0; b < 2; b++) { if (c->ev_filled[b]) (void)hipEventDestroy(c->ev_filled[b]); if (c->ev_drained[b]) (void)hipEventDestroy(c->ev_drained[b]); }
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
@@ -489,7 +488,7 @@ extern "C" int lart_gpu_begin(lart_gpu *c, int64_t first_id, int64_t stride, int
         HIPCHK(hipMalloc(&c->d_log, bytes)); HIPCHK(hipMemsetAsync(c->d_log, 0, bytes, c->stream)); c->nlog = count; }
     for (auto &e : c->ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     c->ev.clear(); c->kernel_ms = 0.0; c->nlaunch = 0;
-    c->live_lanes = c->pool.n; c->state_valid = false; c->n_compactions = 0; c->spread_q = 0; c->spread_alive = 0;
+    c->live_lanes = c->pool.n; c->state_valid = false; c->n_compactions = 0;
     c->begun = true;
     return 0;
 }
@@ -582,72 +581,12 @@ __global__ void k_compact_move(DPool pool, const int *holes, const int *movers, 
     pool.flags[dst] = pool.flags[src]; pool.flags[src] = 0;
 }
 
-// Drain tail: when fewer packets are left than the chip has wave slots, the run time is the longest remaining history times the time
-// of ONE event in its wave -- and a wave pays for every branch any of its lanes takes (2.4e3 VALU instructions per wave-event with 64
-// live lanes against ~1.6e3 along one lane's own path, profiles/README.md).  So the last packets are not packed but spread: q packets
-// per wave with q = ceil(alive / wave slots), through a small staging buffer.
-__global__ void k_spread_gather(DPool pool, long long live, int nplanes, double *tf, unsigned long long *trng, long long *tk, int *ti, long long T, unsigned *cnt) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool alive = i < live && (pool.flags[i] & FLAG_ALIVE);
-    const int j = wave_slot(alive, cnt);
-    if (!alive || j >= T) return;
-    const long long P = pool.n;
-    for (int q = 0; q < nplanes; q++) tf[(size_t)q * T + j] = pool.f[(size_t)q * P + i];
-    trng[j] = pool.rng_n[i]; tk[j] = pool.k[i];
-    ti[j] = pool.ic[i]; ti[T + j] = pool.jc[i]; ti[2 * T + j] = pool.kc[i]; ti[3 * T + j] = pool.flags[i];
-}
-__global__ void k_spread_scatter(DPool pool, long long m, int q, int nplanes, const double *tf, const unsigned long long *trng, const long long *tk, const int *ti, long long T) {
-    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= m) return;
-    const long long dst = (j / q) * 64 + (j % q), P = pool.n;
-    for (int p = 0; p < nplanes; p++) pool.f[(size_t)p * P + dst] = tf[(size_t)p * T + j];
-    pool.rng_n[dst] = trng[j]; pool.k[dst] = tk[j];
-    pool.ic[dst] = ti[j]; pool.jc[dst] = ti[T + j]; pool.kc[dst] = ti[2 * T + j]; pool.flags[dst] = ti[3 * T + j];
-}
-static int spread_lanes(lart_gpu *c, int64_t m, int q) {
-    const int nplanes = c->par.use_stokes ? (int)F_COUNT : (int)F_MX;
-    const int64_t T = c->spread_cap;
-    if (!c->d_spread) return fail("compact: no staging buffer");
-    char *b = (char *)c->d_spread;
-    double *tf = (double *)b; b += (size_t)T * F_COUNT * 8;
-    unsigned long long *trng = (unsigned long long *)b; b += (size_t)T * 8;
-    long long *tk = (long long *)b; b += (size_t)T * 8;
-    int *ti = (int *)b; b += (size_t)T * 16;
-    unsigned *cnt = (unsigned *)b;
-    const int64_t live = c->live_lanes;
-    int64_t new_live = ((m + q - 1) / q) * 64; new_live = ((new_live + c->block - 1) / c->block) * c->block;
-    if (new_live > c->pool.n) return 0;
-    HIPCHK(hipMemsetAsync(cnt, 0, 2 * sizeof(unsigned), c->stream));
-    hipLaunchKernelGGL(k_spread_gather, dim3((unsigned)((live + 255) / 256)), dim3(256), 0, c->stream, c->pool, (long long)live, nplanes, tf, trng, tk, ti, (long long)T, cnt);
-    HIPCHK(hipGetLastError());
-    const int64_t span = live > new_live ? live : new_live;
-    HIPCHK(hipMemsetAsync(c->pool.flags, 0, (size_t)span * sizeof(int), c->stream));
-    hipLaunchKernelGGL(k_spread_scatter, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, c->pool, (long long)m, q, nplanes, tf, trng, tk, ti, (long long)T);
-    HIPCHK(hipGetLastError());
-    unsigned h = 0; HIPCHK(hipMemcpyAsync(&h, cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    if ((int64_t)h != m) return fail("compact: live-lane bookkeeping is inconsistent (gathered != alive)");
-    c->live_lanes = new_live; c->n_compactions++; c->spread_q = q; c->spread_alive = m;
-    return 0;
-}
-
 extern "C" int lart_gpu_compact(lart_gpu *c) {
     if (!c || !c->begun) return fail("compact: call lart_gpu_begin first");
     HIPCHK(hipSetDevice(c->device));
     if (!c->state_valid) { if (lart_gpu_sync(c, nullptr, nullptr)) return 1; }
     if (!c->state_valid) return 0;                                  // nothing launched yet
     const int64_t m = c->last_alive, live = c->live_lanes;
-    if (!c->n_cu) { hipDeviceProp_t pr; HIPCHK(hipGetDeviceProperties(&pr, c->device)); c->n_cu = pr.multiProcessorCount; }
-    const int64_t W = (int64_t)c->n_cu * 16;                     // wave slots of the chip at 4 waves per SIMD
-    if (m > 0 && m <= W * 8 && c->last_next_k >= (int64_t)c->count) {   // the tail: q packets per wave instead of 64
-        const int q = (int)((m + W - 1) / W);
-        int64_t want = ((m + q - 1) / q) * 64; want = ((want + c->block - 1) / c->block) * c->block;
-        if (want <= c->pool.n) {                                 // (a pool smaller than the chip's wave slots stays packed)
-            if (!c->d_spread) { c->spread_cap = W * 8; HIPCHK(hipMalloc(&c->d_spread, (size_t)c->spread_cap * (F_COUNT * 8 + 8 + 8 + 16) + 16)); }
-            return spread_lanes(c, m, q);
-        }
-        c->spread_alive = m; c->spread_q = -1;
-    }
     int64_t new_live = ((m + c->block - 1) / c->block) * c->block; if (new_live < c->block) new_live = c->block;
     if (new_live >= live) return 0;
     if (!c->d_compact) HIPCHK(hipMalloc(&c->d_compact, ((size_t)2 * c->pool.n + 2) * sizeof(int)));
@@ -676,12 +615,8 @@ extern "C" int lart_gpu_step(lart_gpu *c, int32_t nsteps, int32_t max_events) {
     if (!c->d_tally || (!c->d_cell && !c->is_clump) || !c->d_pool) return fail("step: no medium / tally buffer / photon pool on the device");
     HIPCHK(hipSetDevice(c->device));
     // drain phase (no photon left to refill a lane with): pack the live lanes to the front of the pool and shrink the grid
-    if (c->auto_compact && c->state_valid && c->last_next_k >= (int64_t)c->count && c->live_lanes > c->block) {
-        const int64_t W = (int64_t)(c->n_cu ? c->n_cu : 256) * 16;
-        const bool tail = c->last_alive > 0 && c->last_alive <= W * 8;
-        // dense phase: pack when a quarter of the launched lanes have died; tail: re-spread when a quarter of the packets of the last spread are gone
-        const bool due = tail ? (c->spread_q == 0 || c->last_alive * 4 < c->spread_alive * 3) : (c->last_alive * 4 < c->live_lanes * 3);
-        if (due && lart_gpu_compact(c)) return 1;
+    if (c->auto_compact && c->state_valid && c->last_next_k >= (int64_t)c->count && c->last_alive * 4 < c->live_lanes * 3 && c->live_lanes > c->block) {
+        if (lart_gpu_compact(c)) return 1;
     }
     KArgs A{};
     A.par = c->par; A.g = c->g; A.t = c->t; A.pool = c->pool; A.mu = c->mu; A.obs = c->d_obs; A.nobs = c->par.save_peeloff ? c->nobs : 0;

@@ -48,8 +48,7 @@ def test_lane_compaction_changes_nothing_but_the_grid(capi, oracle_mod):
     assert np.allclose(ta["Jout"], tb["Jout"], rtol=0, atol=1e-9) and ta["nphotons_done"] == tb["nphotons_done"] == n
     assert ta["n_events"] == tb["n_events"]
     assert min(lb) == max(lb) == 8192                      # feature off: the grid never changes
-    # feature on: the launches shrink while the pool drains (packed), and the last packets are spread again, one per wave (64 lanes each)
-    assert min(la) <= 2048 and len(set(la)) >= 4, la
+    assert la[-1] <= 512 and sorted(la, reverse=True) == la and len(set(la)) >= 4, la
     o = oracle_mod.Oracle(**{k: v for k, v in KW.items() if k != "iseed"}); o.run(n, seed=9)
     no, xo = o.photon_log()
     same = np.isclose(na, no, rtol=1e-12, atol=0) & np.isclose(xa, xo, rtol=1e-7, atol=1e-9)
