@@ -47,12 +47,16 @@ def test_rng_stream_device(capi, oracle_mod):
                                  (8.0, 1.492e-2), (30.0, 1.492e-2), (-2.0, 1.492e-2), (2.45, 1e-3), (2.6, 5e-2)])
 def test_vz_sampler_device(capi, oracle_mod, x, a):
     sim = make(dict(temperature=1e4, taumax=10.0, nx=5, ny=5, nz=5, rmax=1.0))
-    # same stream, same rejection decisions: streams stay aligned unless a last-bit libm difference flips a comparison
-    n = 400
-    g = sim.ctx.test_rand(1, 99, 5, n, x, a)
-    o = oracle_mod.rand_resonance_vz(1, 99, 5, n, x, a)
-    first_bad = np.argmax(~np.isclose(g, o, rtol=1e-9, atol=1e-12)) if not np.allclose(g, o, rtol=1e-9, atol=1e-12) else n
-    assert first_bad >= n // 2, (x, a, first_bad)
+    # same stream, same rejection decisions: 64 independent streams (photon ids) of 8 velocities each.  A stream only goes out of step when a
+    # last-bit difference flips one accept/reject comparison, so the first velocity of every stream and (all but at most one of) the
+    # streams as a whole must agree to 1e-9
+    nbad = 0
+    for sid in range(64):
+        g = sim.ctx.test_rand(1, 99, 1000 + sid, 8, x, a)
+        o = oracle_mod.rand_resonance_vz(1, 99, 1000 + sid, 8, x, a)
+        assert np.isclose(g[0], o[0], rtol=1e-9, atol=1e-12), (x, a, sid, g[0], o[0])
+        nbad += not np.allclose(g, o, rtol=1e-9, atol=1e-12)
+    assert nbad <= 1, (x, a, nbad)
     # and as distributions (long run): mean / variance agree
     g2 = sim.ctx.test_rand(1, 7, 11, 20000, x, a); o2 = oracle_mod.rand_resonance_vz(1, 8, 12, 20000, x, a)
     assert abs(g2.mean() - o2.mean()) < 5 * np.hypot(g2.std(), o2.std()) / np.sqrt(20000)
