@@ -82,7 +82,9 @@ struct DPool {
 
 // J(x) / P_alpha profile tallies (compile-time CALCJ/CALCP/CALCPnew in the reference; run-time switches here)
 // profile tallies; P1 / P1_new are accumulated per block in LDS when `lds_bins` > 0 and flushed once at kernel end
-struct DJPa { int calc_J, calc_P, calc_Pnew, nbins; const int *ind_bin; double cross0; double *J1, *P1, *P1_new; int lds_bins; };
+// J1: the frequency bins [lds_j_lo, lds_j_lo + lds_j_w) around the line centre of every profile bin are accumulated per block in LDS too when they fit
+// (lds_j_w > 0): scattered f64 atomics run at the memory side at ~1e10 per second for the whole chip, which is what one deposit per event asks for
+struct DJPa { int calc_J, calc_P, calc_Pnew, nbins; const int *ind_bin; double cross0; double *J1, *P1, *P1_new; int lds_bins, lds_j_lo, lds_j_w; };
 // Copies of the contended tally sections (peel cubes and images, J1, P1, P1_new = the tail [off, off+len) of the fused buffer).
 // Workgroups are dispatched round-robin over the 8 XCDs, each with its own L2: same-address atomics from different XCDs meet
 // at the memory side and serialise there (measured: 70x slow-down of a 64-bin P_alpha profile).  Block b therefore adds into
@@ -150,6 +152,7 @@ static __device__ const double c_voigt_tab[606] = {   // H0(101) | H1(202) | H2(
 struct Lds { const double *vt; const double *xf, *yf, *zf;   // Voigt tables and cell faces staged in LDS
              double dip_p2, dip_qs;      // Cardano constants of the dipole phase function for par.E1 > 0 (rand_resonance): p, 1/(E1 p^3)
              double *jp_P, *jp_Pn;       // per-block LDS copies of P1 / P1_new (nullptr: deposits go to global memory)
+             double *jp_J; int j_lo, j_w; // per-block LDS copy of the line-centre window of J1: [j_w][nbins] (nullptr: off)
              unsigned *pq_cnt;           // this wave's record counter of the peel queue (LDS word), nullptr = no peel-off
              unsigned char *coop;        // LART_COOP_BYTES per wave: scratch of the cooperative samplers (vz_core_coop / vz_wing_coop), nullptr = off
              int lt; double dnu_hz;      // line type (1 single line, 2 Ly-alpha doublet, 7 H + D) and DnuHK_Hz / delta_nu_HD_Hz: set from the kernel's template
@@ -163,7 +166,7 @@ __device__ inline Lds lds_stage(double *sh, const DGrid &g) {
     for (int i = threadIdx.x; i < nf; i += blockDim.x) sh[VT_END + i] = g.faces[i];
     __syncthreads();
     Lds l; l.vt = sh; l.xf = sh + VT_END; l.yf = l.xf + (g.nx + 1); l.zf = l.yf + (g.ny + 1);
-    l.dip_p2 = 0.0; l.dip_qs = 0.0; l.jp_P = nullptr; l.jp_Pn = nullptr; l.coop = nullptr; l.pq_cnt = nullptr; l.lt = 1; l.dnu_hz = 0.0; l.hd_ratio = 1.0; l.hd_ratio_a = 1.0; l.hd_nD = 0.0; l.ml_nup = 1; l.ml_coh = 0; l.ml_tab = nullptr; l.ml_itab = nullptr;
+    l.dip_p2 = 0.0; l.dip_qs = 0.0; l.jp_P = nullptr; l.jp_Pn = nullptr; l.jp_J = nullptr; l.j_lo = 0; l.j_w = 0; l.coop = nullptr; l.pq_cnt = nullptr; l.lt = 1; l.dnu_hz = 0.0; l.hd_ratio = 1.0; l.hd_ratio_a = 1.0; l.hd_nD = 0.0; l.ml_nup = 1; l.ml_coh = 0; l.ml_tab = nullptr; l.ml_itab = nullptr;
     for (int i = 0; i < 3; i++) { l.ml_dE[i] = 0.0; l.ml_damp[i] = 1.0; l.ml_f12[i] = 0.0; }
     return l;
 }
@@ -930,6 +933,12 @@ __device__ inline int amr_boundary(const lart_params &par, int il, int iface, do
     }
     return 0;
 }
+// one deposit into J1(ix, ib): the block's LDS window around the line centre, or global memory
+__device__ inline void jpa_add_J(const KArgs &A, const Lds &l, int ix, int ib, double v) {
+    const int w = ix - 1 - l.j_lo;
+    if (l.jp_J && w >= 0 && w < l.j_w) atomicAdd(&l.jp_J[w + l.j_w * (ib - 1)], v);
+    else atomicAdd(&A.jpa.J1[(size_t)(ix - 1) + (size_t)A.par.nxfreq * (ib - 1)], v);
+}
 // amr_JPa_bin: octree_mod.f90:286-311 (3 = the leaf itself)
 __device__ inline int amr_JPa_bin(const DAmr &a, int il, double x0, double y0, double z0) {
     if (a.jpa_geometry == 3) return il;
@@ -945,7 +954,7 @@ __device__ inline void jpa_segment_amr(const KArgs &A, const Lds &l, const Photo
     if (A.jpa.calc_J) {
         double xr = p.xfreq * (c.Dfreq / A.par.Dfreq_ref);
         int ix = (int)floor((xr - A.par.xfreq_min) / A.par.dxfreq) + 1;
-        if (ix >= 1 && ix <= A.par.nxfreq) atomicAdd(&A.jpa.J1[(size_t)(ix - 1) + (size_t)A.par.nxfreq * (ib - 1)], del * p.wgt);
+        if (ix >= 1 && ix <= A.par.nxfreq) jpa_add_J(A, l, ix, ib, del * p.wgt);
     }
     if (A.jpa.calc_Pnew) atomicAdd(&(l.jp_Pn ? l.jp_Pn : A.jpa.P1_new)[ib - 1], dtauH * p.wgt / (c.rhokap * c.Dfreq / A.jpa.cross0));
 }
@@ -1193,7 +1202,7 @@ __device__ inline void jpa_segment(const KArgs &A, const Lds &l, const Photon &p
     if (A.jpa.calc_J) {
         double xr = p.xfreq * (Dfreq_cell / A.par.Dfreq_ref);
         int ix = (int)floor((xr - A.par.xfreq_min) / A.par.dxfreq) + 1;
-        if (ix > 0 && ix <= A.par.nxfreq) atomicAdd(&A.jpa.J1[(size_t)(ix - 1) + (size_t)A.par.nxfreq * (ib - 1)], del * p.wgt);
+        if (ix > 0 && ix <= A.par.nxfreq) jpa_add_J(A, l, ix, ib, del * p.wgt);
     }
     if (A.jpa.calc_Pnew) atomicAdd(&(l.jp_Pn ? l.jp_Pn : A.jpa.P1_new)[ib - 1], dtauH * p.wgt / (rhokap_cell * Dfreq_cell / A.jpa.cross0));
 }

@@ -141,6 +141,18 @@ static int build_tally(lart_gpu *c) {
     if (c->jpa.nbins > 0) {
         // P1 / P1_new: per-block LDS copies while they fit
         c->jpa.lds_bins = ((c->jpa.calc_P || c->jpa.calc_Pnew) && c->jpa.nbins <= 2048) ? c->jpa.nbins : 0;
+        // J1: a window of frequency bins around the line centre per block in LDS, as wide as three workgroups per CU leave room for (160 KiB / 3)
+        c->jpa.lds_j_w = 0; c->jpa.lds_j_lo = 0;
+        if (c->jpa.calc_J && !std::getenv("LART_NO_LDS_J")) {
+            const long long base = (long long)(VT_END + c->g.nx + c->g.ny + c->g.nz + 3 + LART_RNG_BUF * c->block + 2 * c->jpa.lds_bins) * 8 + (LART_COOP_BYTES + 4) * ((c->block + 63) / 64);
+            long long w = ((long long)160 * 1024 / 3 - 256 - base) / (8LL * c->jpa.nbins);
+            if (w > 48) w = 48; if (w > nxf) w = nxf;
+            if (w >= 8) {
+                const int ixc = (int)std::floor((0.0 - p.xfreq_min) / p.dxfreq);       // 0-based bin of the line centre in reference units
+                int lo = ixc - (int)w / 2; if (lo < 0) lo = 0; if (lo + w > nxf) lo = (int)(nxf - w);
+                c->jpa.lds_j_w = (int)w; c->jpa.lds_j_lo = lo;
+            }
+        }
         if (c->jpa.calc_J)    { oJ1 = off; off += nxf * c->jpa.nbins; }
         if (c->jpa.calc_P)    { oP1 = off; off += c->jpa.nbins; }
         if (c->jpa.calc_Pnew) { oPn = off; off += c->jpa.nbins; }
@@ -628,7 +640,7 @@ extern "C" int lart_gpu_step(lart_gpu *c, int32_t nsteps, int32_t max_events) {
     int stokes = c->par.use_stokes ? 1 : 0, dust = c->par.DGR > 0.0 ? 1 : 0, peel = (c->par.save_peeloff && c->nobs > 0) ? 1 : 0;
     dim3 block(c->block), grid((unsigned)(c->live_lanes / c->block));
     // Voigt tables + faces | ring of random draws [LART_RNG_BUF][block] | per-block P1, P1_new
-    size_t shmem = (size_t)(VT_END + c->g.nx + c->g.ny + c->g.nz + 3 + LART_RNG_BUF * c->block + 2 * c->jpa.lds_bins) * sizeof(double) + (size_t)(LART_COOP_BYTES + 4) * ((c->block + 63) / 64);   // ... + the wave-local scratch of vz_core_coop + the waves' peel-queue counters
+    size_t shmem = (size_t)(VT_END + c->g.nx + c->g.ny + c->g.nz + 3 + LART_RNG_BUF * c->block + 2 * c->jpa.lds_bins + c->jpa.lds_j_w * c->jpa.nbins) * sizeof(double) + (size_t)(LART_COOP_BYTES + 4) * ((c->block + 63) / 64);   // ... + the wave-local scratch of vz_core_coop + the waves' peel-queue counters
     if (shmem > 160 * 1024) return fail("step: grid faces do not fit the 160 KiB LDS");
     // peel-off: a launch of `slice` events per lane queues at most live_lanes x (slice + 1) records (one per event, one per birth);
     // the queue is sized once per run for pq_bytes_max (16 GiB by default) and a step of max_events is cut into slices that fit

@@ -73,8 +73,15 @@ __global__ __launch_bounds__(256, LART_WAVES(STOKES, PEEL)) void transport_kerne
         l_.jp_P = jp; l_.jp_Pn = jp + A.jpa.lds_bins;
         __syncthreads();
     }
+    const int nJ = A.jpa.lds_j_w * A.jpa.nbins;                 // line-centre window of J1 per block
+    if (nJ > 0) {
+        double *jj = sh + VT_END + (A.g.nx + A.g.ny + A.g.nz + 3) + (size_t)LART_RNG_BUF * blockDim.x + 2 * (size_t)A.jpa.lds_bins;
+        for (int i = threadIdx.x; i < nJ; i += blockDim.x) jj[i] = 0.0;
+        l_.jp_J = jj; l_.j_lo = A.jpa.lds_j_lo; l_.j_w = A.jpa.lds_j_w;
+        __syncthreads();
+    }
     // wave-local scratch of the cooperative sampler, behind everything else: LART_COOP_BYTES per wave
-    l_.coop = (unsigned char *)(sh + VT_END + (A.g.nx + A.g.ny + A.g.nz + 3) + (size_t)LART_RNG_BUF * blockDim.x + 2 * (size_t)A.jpa.lds_bins) + LART_COOP_BYTES * (threadIdx.x >> 6);
+    l_.coop = (unsigned char *)(sh + VT_END + (A.g.nx + A.g.ny + A.g.nz + 3) + (size_t)LART_RNG_BUF * blockDim.x + 2 * (size_t)A.jpa.lds_bins + (size_t)nJ) + LART_COOP_BYTES * (threadIdx.x >> 6);
     if (PEEL) {                                                // this wave's record counter of the peel queue
         l_.pq_cnt = (unsigned *)(l_.coop - LART_COOP_BYTES * (threadIdx.x >> 6) + LART_COOP_BYTES * (blockDim.x >> 6)) + (threadIdx.x >> 6);
         if ((threadIdx.x & 63) == 0) *l_.pq_cnt = 0u;
@@ -144,6 +151,13 @@ __global__ __launch_bounds__(256, LART_WAVES(STOKES, PEEL)) void transport_kerne
         LART_PROF_MARK(p, 7);
     }
 
+    if (nJ > 0) {                                              // flush the block's J1 window
+        __syncthreads();
+        for (int i = threadIdx.x; i < nJ; i += blockDim.x) {
+            const double v = l.jp_J[i];
+            if (v != 0.0) atomicAdd(&A.jpa.J1[(size_t)(A.jpa.lds_j_lo + i % A.jpa.lds_j_w) + (size_t)A.par.nxfreq * (i / A.jpa.lds_j_w)], v);
+        }
+    }
     if (A.jpa.lds_bins > 0) {                                  // flush the block's profile tallies: one atomic per touched bin
         __syncthreads();
         for (int i = threadIdx.x; i < A.jpa.lds_bins; i += blockDim.x) {

@@ -17,6 +17,19 @@ def build(ref=True):
     subprocess.check_call(["make", "-s", "-C", HERE] + tgt)
 
 
+def usable_cores():
+    """cores this process may really use: the cgroup CPU quota when there is one (a 1-GPU box gets a 16-core share of a 256-thread
+    host; 256 spinning OpenMP threads on 16 cores crawl), else the affinity mask"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per) + 0.5)))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
+
+
 def _ptr(a):
     return a.ctypes.data_as(_vp)
 
@@ -109,7 +122,7 @@ class Oracle:
 
     def run(self, count, first_id=1, stride=1, rng_kind=1, seed=1234, nthreads=None):
         if nthreads is None:
-            nthreads = os.cpu_count() or 1
+            nthreads = usable_cores()
         return self.lib().orc_run(self.h, first_id, stride, int(count), rng_kind, seed, nthreads)
 
     def zero(self):

@@ -119,3 +119,18 @@ def test_second_run_accumulates_and_normalises_by_finished_photons(capi):
     ja, jb = a.output_normalize()["Jout"], b.output_normalize()["Jout"]
     assert a.ctx.tallies()["nphotons_done"] == 4000
     assert np.allclose(ja, jb, rtol=1e-12, atol=1e-18)
+
+
+def test_J_window_in_lds_changes_nothing(capi, monkeypatch):
+    """CALCJ: the frequency bins around the line centre are accumulated per workgroup in LDS and flushed once per launch (scattered f64
+    atomics run at the memory side at ~1e10/s for the whole chip); the same run with every deposit as a global atomic gives the same J(x, r)
+    up to the order of the additions, in a window that does not start at bin 0 and with deposits on both sides of it"""
+    kw = dict(temperature=1e4, taumax=3e2, nx=21, ny=21, nz=21, rmax=1.0, nxfreq=161, xfreq_min=-12.0, xfreq_max=20.0, calc_J=True, calc_P=True, calc_Pnew=True, iseed=3)
+    a = make(kw); a.run_simulation(20000); ta = a.ctx.tallies()
+    monkeypatch.setenv("LART_NO_LDS_J", "1")
+    b = make(kw); b.run_simulation(20000); tb = b.ctx.tallies()
+    assert ta["J1"].sum() > 0 and np.allclose(ta["J1"], tb["J1"], rtol=1e-11, atol=1e-12 * ta["J1"].max())
+    assert np.allclose(ta["P1"], tb["P1"], rtol=1e-11) and np.allclose(ta["P1_new"], tb["P1_new"], rtol=1e-11)
+    # the window really is narrower than the axis: mass on both sides of it
+    j = ta["J1"].sum(axis=1)
+    assert j[:40].sum() > 0 and j[-60:].sum() > 0
