@@ -143,7 +143,8 @@ static int build_tally(lart_gpu *c) {
         c->jpa.lds_bins = ((c->jpa.calc_P || c->jpa.calc_Pnew) && c->jpa.nbins <= 2048) ? c->jpa.nbins : 0;
         // J1: a window of frequency bins around the line centre per block in LDS, as wide as three workgroups per CU leave room for (160 KiB / 3)
         c->jpa.lds_j_w = 0; c->jpa.lds_j_lo = 0;
-        if (c->jpa.calc_J && !std::getenv("LART_NO_LDS_J")) {
+        // (with J alone the occupancy it costs outweighs the atomics it saves: 14.5e9 -> 11.4e9 events/s on the octree; with P / P_new too 9.3 -> 10.6e9)
+        if (c->jpa.calc_J && (c->jpa.calc_P || c->jpa.calc_Pnew) && !std::getenv("LART_NO_LDS_J")) {
             const long long base = (long long)(VT_END + c->g.nx + c->g.ny + c->g.nz + 3 + LART_RNG_BUF * c->block + 2 * c->jpa.lds_bins) * 8 + (LART_COOP_BYTES + 4) * ((c->block + 63) / 64);
             long long w = ((long long)160 * 1024 / 3 - 256 - base) / (8LL * c->jpa.nbins);
             if (w > 48) w = 48; if (w > nxf) w = nxf;

@@ -46,7 +46,8 @@ def flipped_rms(same, n, nbins_eff=40):
     return 2.0 * np.sqrt(2.0 * f * nbins_eff / n)
 
 
-CAR = dict(temperature=10.0, taumax=1e6, nx=5, ny=5, nz=5, rmax=1.0, nxfreq=121)      # coarse cells: a tau_cell dl/dx ~ 3e3, xcrit up to ~3
+CAR = dict(temperature=10.0, taumax=2e5, nx=5, ny=5, nz=5, rmax=1.0, nxfreq=121)      # coarse cells: a tau_cell dl/dx ~ 6e2, xcrit up to ~1.7
+# (a device run of a few hundred photons lasts as long as its longest history: ~9 us per scattering, hence the moderate optical depth)
 
 
 @pytest.mark.parametrize("extra,n", [(dict(xyz_symmetry=True, core_skip=True), 500),
@@ -56,7 +57,7 @@ CAR = dict(temperature=10.0, taumax=1e6, nx=5, ny=5, nz=5, rmax=1.0, nxfreq=121)
                                      (dict(core_skip_global=True, use_stokes=True), 1000)],
                          ids=["cell", "cell_stokes", "cell_recoil_outflow", "global", "global_stokes"])
 def test_cartesian_core_skip_histories(capi, oracle_mod, extra, n):
-    """tau0 = 1e6, T = 10 K on a coarse grid (xcrit > 1 away from the cell faces): photon by photon against the oracle, and the
+    """tau0 = 2e5, T = 10 K on a coarse grid (xcrit > 1 away from the cell faces): photon by photon against the oracle, and the
     skipping really happens: the same photon ids without it have different histories and scatter several times more often"""
     kw = dict(CAR, **extra)
     sim, o, ng, no, same = histories(capi, oracle_mod, kw, n, 31)
@@ -71,14 +72,14 @@ def test_cartesian_core_skip_histories(capi, oracle_mod, extra, n):
     plain = make(dict({k: v for k, v in kw.items() if not k.startswith("core_skip")}, iseed=31)); plain.ctx.enable_photon_log(True); plain.run_simulation(m)
     npl = plain.ctx.photon_log(m)[0]
     assert np.mean(npl != ng[:m]) > 0.9                     # same ids, same streams: the truncated-tail branch changed the histories
-    assert npl.mean() > 2.0 * ng.mean()
+    assert npl.mean() > (2.0 if extra.get("core_skip_global") else 1.3) * ng.mean()
 
 
 @pytest.mark.parametrize("extra,n", [(dict(core_skip=True), 300), (dict(core_skip=True, use_stokes=True), 250), (dict(core_skip_global=True), 2000)],
                          ids=["cell", "cell_stokes", "global"])
 def test_octree_core_skip_histories(capi, oracle_mod, amr_file, extra, n):
     """amr_xcrit_local: the distance to the nearest face of the LEAF sets xcrit (octree_mod.f90:248-278)"""
-    kw = dict(use_amr_grid=True, amr_file=amr_file, temperature=10.0, taumax=3e5, rmax=1.0, nxfreq=121, **extra)
+    kw = dict(use_amr_grid=True, amr_file=amr_file, temperature=10.0, taumax=1e5, rmax=1.0, nxfreq=121, **extra)
     sim, o, ng, no, same = histories(capi, oracle_mod, kw, n, 33)
     assert same.mean() > 0.95, same.mean()
     assert rms_diff(sim.ctx.tallies()["Jout"], o.array("Jout")) < flipped_rms(same, n)
