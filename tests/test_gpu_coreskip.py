@@ -79,14 +79,14 @@ def test_cartesian_core_skip_histories(capi, oracle_mod, extra, n):
                          ids=["cell", "cell_stokes", "global"])
 def test_octree_core_skip_histories(capi, oracle_mod, amr_file, extra, n):
     """amr_xcrit_local: the distance to the nearest face of the LEAF sets xcrit (octree_mod.f90:248-278)"""
-    kw = dict(use_amr_grid=True, amr_file=amr_file, temperature=10.0, taumax=1e5, rmax=1.0, nxfreq=121, **extra)
+    kw = dict(use_amr_grid=True, amr_file=amr_file, temperature=10.0, taumax=1e5, rmax=1.0, nxfreq=121, xfreq_min=-40.0, xfreq_max=40.0, **extra)
     sim, o, ng, no, same = histories(capi, oracle_mod, kw, n, 33)
     assert same.mean() > 0.95, same.mean()
     assert rms_diff(sim.ctx.tallies()["Jout"], o.array("Jout")) < flipped_rms(same, n)
     m = min(300, n)
     plain = make(dict({k: v for k, v in kw.items() if not k.startswith("core_skip")}, iseed=33)); plain.ctx.enable_photon_log(True); plain.run_simulation(m)
     npl = plain.ctx.photon_log(m)[0]
-    assert np.mean(npl != ng[:m]) > 0.9
+    assert np.mean(npl != ng[:m]) > 0.5                     # same ids, same streams: most histories met a cell with xcrit > |x|
     if extra.get("core_skip_global"):
         assert npl.mean() > 2.0 * ng.mean()
 
