@@ -180,11 +180,15 @@ def run_to_completion(sim, a, rank, world, dist, barrier):
     barrier()
     t0 = time.perf_counter()
     sim.ctx.begin(count, first_id=rank + 1, stride=world, seed=WORKLOAD["iseed"] + 1)
-    launches = 0
+    launches = 0; t_msg = t0
     while True:
         sim.ctx.step(1, a.events_per_step); launches += 1
-        if sim.ctx.sync()[1] == 0:
+        done, left = sim.ctx.sync()
+        if left == 0:
             break
+        if rank == 0 and time.perf_counter() - t_msg > 30.0:          # a long leg stays visibly alive (stderr: stdout carries the one JSON line)
+            t_msg = time.perf_counter()
+            print("bench.py: run to completion, %.0f s, %d photons of this rank still in flight or waiting" % (t_msg - t0, left), file=sys.stderr, flush=True)
     barrier()
     dt = time.perf_counter() - t0
     live, ncompact = sim.ctx.live_lanes()
