@@ -228,7 +228,7 @@ def pmc_traffic(events_per_step):
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary*.json")), reverse=True):
         try:
             d = json.load(open(f))
-            if int(d.get("events_per_step", -1)) == int(events_per_step) and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+            if "bench.py" in d.get("command", "") and int(d.get("events_per_step", -1)) == int(events_per_step) and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
                 return (2.0 * d["FETCH_SIZE"]["mean_per_launch"] + d["WRITE_SIZE"]["mean_per_launch"]) * 1024.0
         except Exception:
             pass
