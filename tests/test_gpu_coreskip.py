@@ -22,7 +22,7 @@ def capi():
 def amr_file(tmp_path_factory):
     from lart_amd import amr
     p = tmp_path_factory.mktemp("amr") / "sphere_small.dat"
-    amr.write_generic_amr(str(p), amr.make_amr_sphere(level_min=2, level_max=3))
+    amr.write_generic_amr(str(p), amr.make_amr_sphere(level_min=2, level_max=3, T=10.0))      # leaves at par%temperature: the frequency axis is in their Doppler units
     return str(p)
 
 
@@ -79,7 +79,7 @@ def test_cartesian_core_skip_histories(capi, oracle_mod, extra, n):
                          ids=["cell", "cell_stokes", "global"])
 def test_octree_core_skip_histories(capi, oracle_mod, amr_file, extra, n):
     """amr_xcrit_local: the distance to the nearest face of the LEAF sets xcrit (octree_mod.f90:248-278)"""
-    kw = dict(use_amr_grid=True, amr_file=amr_file, temperature=10.0, taumax=1e5, rmax=1.0, nxfreq=121, xfreq_min=-40.0, xfreq_max=40.0, **extra)
+    kw = dict(use_amr_grid=True, amr_file=amr_file, temperature=10.0, taumax=1e5, rmax=1.0, nxfreq=121, **extra)
     sim, o, ng, no, same = histories(capi, oracle_mod, kw, n, 33)
     assert same.mean() > 0.95, same.mean()
     assert rms_diff(sim.ctx.tallies()["Jout"], o.array("Jout")) < flipped_rms(same, n)
