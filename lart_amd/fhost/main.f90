@@ -443,7 +443,7 @@ contains
        do io = 1, par%nobs
           tail = ''
           if (par%nobs > 1) write(tail,'(a,i3.3)') '_', io
-          call peel_keys(ko, io, g)
+          call peel_keys(ko, io, g, merge(3, 1, par%nside > 0))
           if (allocated(obs_scatt)) then
              nxi = size(obs_scatt, 2); nyi = size(obs_scatt, 3)
              call out_open(o, trim(par%base_name)//'_obs'//trim(tail), fmt)
@@ -475,6 +475,7 @@ contains
              endif
           endif
           if (allocated(obs_scatt_2D)) then
+             call peel_keys(ko, io, g, merge(4, 2, par%nside > 0))
              nxi = size(obs_scatt_2D, 1); nyi = size(obs_scatt_2D, 2)
              call out_open(o, trim(par%base_name)//'_obs2D'//trim(tail), fmt)
              if (par%nside > 0) then
@@ -507,17 +508,16 @@ contains
     endif
   end subroutine write_output
 
-  !--- keywords of the first section of a peel-off file (write_output_rect.f90:1093-1160)
-  subroutine peel_keys(k, io, g)
+  !--- keywords of the first section of a peel-off file, in the reference's order:
+  !    mode 1 = (nxfreq,nxim,nyim) cube  write_output_rect.f90:1093-1150     mode 2 = (nxim,nyim) image  write_output_rect.f90:829-853
+  !    mode 3 = (nxfreq,npix) HEALPix    write_output_heal.f90:757-771       mode 4 = (npix) HEALPix     write_output_heal.f90:592-602
+  subroutine peel_keys(k, io, g, mode)
     type(key_list), intent(out) :: k
-    integer, intent(in) :: io
+    integer, intent(in) :: io, mode
     type(grid_type), intent(in) :: g
     k%n = 0
     call kadd(k, 'EQUINOX', 2000, 'Equinox of Ref. Coord.')
-    if (par%nside > 0) then
-       call kadd(k, 'NSIDE', par%nside, 'HEALPIX nside')
-       call kadd(k, 'NPIX',  par%npix,  'HEALPIX npix')
-    else
+    if (mode == 1) then
        call kadd(k, 'CTYPE1', 'WAVE', 'vacuum wavelength (FITS WCS)')
        call kadd(k, 'CUNIT1', 'Angstrom', 'wavelength unit')
        call kadd(k, 'CRPIX1', 1.0_wp, 'reference pixel for spectral axis')
@@ -533,23 +533,50 @@ contains
        call kadd(k, 'CRPIX3', (par%nyim + 1)/2.0_wp, 'Reference Pixel in Y')
        call kadd(k, 'CRVAL3', 0.0_wp, 'Dec  (Degree)')
        call kadd(k, 'CD3_3', par%dyim, 'Degree / Pixel')
+    else if (mode == 2) then
+       call kadd(k, 'CD1_1',  par%dxim, 'Degree / Pixel')
+       call kadd(k, 'CD2_1',  0.0_wp,   'Degree / Pixel')
+       call kadd(k, 'CD1_2',  0.0_wp,   'Degree / Pixel')
+       call kadd(k, 'CD2_2',  par%dyim, 'Degree / Pixel')
+       call kadd(k, 'CRPIX1', (par%nxim + 1)/2.0_wp, 'Reference Pixel in X')
+       call kadd(k, 'CRPIX2', (par%nyim + 1)/2.0_wp, 'Reference Pixel in Y')
+       call kadd(k, 'CRVAL1', 0.0_wp, 'R.A. (Degree)')
+       call kadd(k, 'CRVAL2', 0.0_wp, 'Dec  (Degree)')
+       call kadd(k, 'CTYPE1', 'RA--TAN', 'Coordinate Type')
+       call kadd(k, 'CTYPE2', 'DEC-TAN', 'Coordinate Type')
+    else if (mode == 4) then
+       call kadd(k, 'NSIDE', par%nside, 'HEALPIX NSIDE')
+       call kadd(k, 'NPIX',  par%npix,  'HEALPIX NPIX')
+    endif
+    if (mode <= 2) call kadd(k, 'DISTANCE', par%distance, 'Distance')
+    call kadd(k, 'DISTUNIT', trim(par%distance_unit), 'Distance Unit')
+    call kadd(k, 'DIST_CM', par%distance2cm, 'Distance Unit (cm)')
+    if (mode == 1 .or. mode == 3) then
+       call kadd(k, 'Xfreq1', g%xfreq_min, 'Xfreq_min')
+       call kadd(k, 'Xfreq2', g%xfreq_max, 'Xfreq_max')
+       call kadd(k, 'Dxfreq', g%dxfreq, 'Dxfreq')
+       call kadd(k, 'Dwave', g%dwave, 'Dwavelength (angstrom)')
+       call kadd(k, 'I_unit', par%intensity_unit, 'Intensity Unit (0:no dimension, 1:cm^-2 A^-1)')
+       call kadd(k, 'Dfreq', g%Dfreq_ref, 'Doppler Freq.  (Hz)')
+    endif
+    call kadd(k, 'nphotons', real(par%nphotons, wp), 'number of photons')
+    if (mode <= 2) then
        call kadd(k, 'alpha', par%alpha(io), 'alpha (degree)')
        call kadd(k, 'beta',  par%beta(io),  'beta (degree)')
        call kadd(k, 'gamma', par%gamma(io), 'gamma (degree)')
     endif
-    call kadd(k, 'DISTANCE', par%distance, 'Distance')
-    call kadd(k, 'DISTUNIT', trim(par%distance_unit), 'Distance Unit')
-    call kadd(k, 'DIST_CM', par%distance2cm, 'Distance Unit (cm)')
-    call kadd(k, 'Xfreq1', g%xfreq_min, 'Xfreq_min')
-    call kadd(k, 'Xfreq2', g%xfreq_max, 'Xfreq_max')
-    call kadd(k, 'Dxfreq', g%dxfreq, 'Dxfreq')
-    call kadd(k, 'Dwave', g%dwave, 'Dwavelength (angstrom)')
-    call kadd(k, 'I_unit', par%intensity_unit, 'Intensity Unit (0:no dimension, 1:cm^-2 A^-1)')
-    call kadd(k, 'Dfreq', g%Dfreq_ref, 'Doppler Freq.  (Hz)')
-    call kadd(k, 'nphotons', real(par%nphotons, wp), 'number of photons')
     call kadd(k, 'obsx', observer(io)%x, 'Observer X coordinate')
     call kadd(k, 'obsy', observer(io)%y, 'Observer Y coordinate')
     call kadd(k, 'obsz', observer(io)%z, 'Observer Z coordinate')
+    if (mode <= 2) then                                  ! observer_rect.f90:36-38: the rotation centre defaults to the origin
+       call kadd(k, 'rot_cenx', 0.0_wp, 'Rotation Center X coordinate')
+       call kadd(k, 'rot_ceny', 0.0_wp, 'Rotation Center Y coordinate')
+       call kadd(k, 'rot_cenz', 0.0_wp, 'Rotation Center Z coordinate')
+    endif
+    if (mode == 3) then                                  ! (the all-sky maps also say how they are pixelised; the reference's 3-D file leaves it to the 2-D one)
+       call kadd(k, 'NSIDE', par%nside, 'HEALPIX NSIDE')
+       call kadd(k, 'NPIX',  par%npix,  'HEALPIX NPIX')
+    endif
   end subroutine peel_keys
 
   !--- make_radial_intensity / make_radial_stokes (output_sum_rect.f90:489-658): azimuthal means of the (normalised) peel-off

@@ -334,12 +334,28 @@ def test_output_containers_hdf5_and_gzip_fits(exe, tmp_path):
     S = read_h5(str(tmp_path / "ch_stokes.h5")); O = read_h5(str(tmp_path / "ch_obs.h5"))
     assert list(S) == ["Stokes_I", "Stokes_Q", "Stokes_U", "Stokes_V"] and S["Stokes_Q"][1].shape == (41, 8, 8)
     assert list(O) == ["Scattered", "Direct"] and O["Direct"][1].shape == (41, 8, 8)
-    assert list(read_fits(str(tmp_path / "cf_obs.fits.gz"))) == ["Scattered", "Direct"]
+    FO = read_fits(str(tmp_path / "cf_obs.fits.gz"))
+    assert list(FO) == ["Scattered", "Direct"]
+    # keywords of the first section of a peel-off cube, in the reference's order (write_output_rect.f90:1093-1150)
+    want3 = ["EQUINOX", "CTYPE1", "CUNIT1", "CRPIX1", "CRVAL1", "CD1_1", "CTYPE2", "CUNIT2", "CRPIX2", "CRVAL2", "CD2_2", "CTYPE3", "CUNIT3", "CRPIX3", "CRVAL3", "CD3_3",
+             "DISTANCE", "DISTUNIT", "DIST_CM", "Xfreq1", "Xfreq2", "Dxfreq", "Dwave", "I_unit", "Dfreq", "nphotons", "alpha", "beta", "gamma", "obsx", "obsy", "obsz",
+             "rot_cenx", "rot_ceny", "rot_cenz"]
+    assert [k.upper() for k in FO["Scattered"][0] if k.upper() in {w.upper() for w in want3}] == [w.upper() for w in want3]
+    assert sorted(k.lower() for k in O["Scattered"][0] if k.lower() != "extname") == sorted(w.lower() for w in want3)
+    ok = {k.lower(): v for k, v in O["Scattered"][0].items()}
+    assert ok["ctype1"] == "WAVE" and ok["crpix2"] == 4.5 and ok["rot_cenx"] == 0.0 and ok["nphotons"] == 1000 and ok["dist_cm"] > 0
     r = run(exe, base + " par%DGR = 1.0\n par%use_stokes = .false.\n par%save_peeloff_2D = .true.\n par%save_direc0 = .true.\n par%save_dust_scattered = .true.\n/\n", tmp_path,
             "--dry-run-write", name="cd.in")
     assert r.returncode == 0, r.stdout + r.stderr
     assert list(read_h5(str(tmp_path / "cd_obs.h5"))) == ["Scattered", "Direct", "Direct0", "ScatDust"]
-    assert list(read_h5(str(tmp_path / "cd_obs2D.h5"))) == ["Scattered", "Direct", "Direct0"]
+    O2 = read_h5(str(tmp_path / "cd_obs2D.h5"))
+    assert list(O2) == ["Scattered", "Direct", "Direct0"]
+    # the (nxim, nyim) images carry a two-axis WCS of their own (write_output_rect.f90:829-853)
+    want2 = ["EQUINOX", "CD1_1", "CD2_1", "CD1_2", "CD2_2", "CRPIX1", "CRPIX2", "CRVAL1", "CRVAL2", "CTYPE1", "CTYPE2", "DISTANCE", "DISTUNIT", "DIST_CM", "nphotons",
+             "alpha", "beta", "gamma", "obsx", "obsy", "obsz", "rot_cenx", "rot_ceny", "rot_cenz"]
+    assert sorted(k.lower() for k in O2["Scattered"][0] if k.lower() != "extname") == sorted(w.lower() for w in want2)
+    k2 = {k.lower(): v for k, v in O2["Scattered"][0].items()}
+    assert k2["ctype1"] == "RA--TAN" and k2["ctype2"] == "DEC-TAN" and k2["cd2_1"] == 0.0 and k2["crpix1"] == 4.5
     # par%out_bitpix = -32: float32 storage in both containers (define.f90:418); -64 / 0 keep float64
     r = run(exe, base + " par%out_bitpix = -32\n/\n", tmp_path, "--dry-run-write", name="c32.in")
     assert r.returncode == 0, r.stdout + r.stderr
@@ -403,6 +419,8 @@ def test_healpix_inside_observers_dry_run(exe, tmp_path):
     for k in (1, 2):                                                     # one file per observer, (nxfreq, npix) maps
         O = read_h5(str(tmp_path / ("heal_obs_%03d.h5" % k)))
         assert O["Scattered"][1].shape == (41, 192) and O["Direct"][1].shape == (41, 192) and O["Scattered"][0]["NSIDE"] == 4
+        hk = {a.lower() for a in O["Scattered"][0]} - {"extname"}            # write_output_heal.f90:757-771 (+ NSIDE/NPIX): no WCS, no alpha/beta/gamma
+        assert hk == {"equinox", "distunit", "dist_cm", "xfreq1", "xfreq2", "dxfreq", "dwave", "i_unit", "dfreq", "nphotons", "obsx", "obsy", "obsz", "nside", "npix"}
     assert not os.path.exists(tmp_path / "heal_stokes_001.h5")               # setup.f90:183: no Stokes vectors for an inside observer
 
 
