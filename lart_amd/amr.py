@@ -52,6 +52,29 @@ def make_amr_sphere(level_min=3, level_max=7, boxlen=2.0, radius=None, nH=1.0, T
                 vx=np.zeros(n), vy=np.zeros(n), vz=np.zeros(n), boxlen=boxlen)
 
 
+def make_amr_slab(level_min=2, level_max=3, boxlen=2.0, zgas=None, nH=1.0, T=1.0e4):
+    """plane-parallel medium in a cubic box for par%xy_periodic runs: uniform gas for |z| <= zgas (the whole box when None), leaves at
+    level_min, the x > 0, y > 0 quadrant split down to level_max -- so a packet that wraps in x or y lands on leaves of another size
+    than the ones it left, while the physics is that of the uniform slab.  Columns as make_amr_sphere."""
+    out = []
+
+    def rec(cx, cy, cz, h, lev):
+        if lev < level_min or (lev < level_max and cx > 0.0 and cy > 0.0):
+            q = h / 2.0
+            for iz in (-1, 1):
+                for iy in (-1, 1):
+                    for ix in (-1, 1):
+                        rec(cx + ix * q, cy + iy * q, cz + iz * q, q, lev + 1)
+        else:
+            out.append((cx, cy, cz, lev, nH if (zgas is None or abs(cz) <= zgas) else 0.0))
+
+    rec(0.0, 0.0, 0.0, boxlen / 2.0, 0)
+    a = np.array(out)
+    n = len(a)
+    return dict(x=a[:, 0], y=a[:, 1], z=a[:, 2], level=a[:, 3].astype(np.int32), nH=a[:, 4], T=np.full(n, T),
+                vx=np.zeros(n), vy=np.zeros(n), vz=np.zeros(n), boxlen=boxlen)
+
+
 def write_generic_amr(path, d):
     with open(path, "w") as f:
         f.write("# generic AMR leaf table: x y z level nH T vx vy vz (box centred on the origin)\n")
@@ -465,7 +488,7 @@ def create_JPa_amr_mem(par, g):
     rmax = par.rmax if par.rmax > 0 else g.L_box * 0.5
     nr = min(512, max(1, 2 ** max(0, g.levelmax - 1))); nz = min(512, max(1, 2 ** max(0, g.levelmax)))
     g.nr_JPa, g.nz_JPa, g.dr_JPa, g.dz_JPa = nr, nz, rmax / nr, g.L_box / nz
-    nadd = 8 if par.xyz_symmetry else 1
+    nadd = 8 if par.xyz_symmetry else (4 if par.xy_symmetry else 1)      # :577-588: the periodic slab does not fold
     ic = g.icell_of_leaf - 1
     hc = g.ch[ic]; vleaf = (2.0 * hc) ** 3 * nadd
     if par.geometry_JPa == 3:

@@ -18,6 +18,9 @@
 #define LART_HALFPI  (LART_PI / 2.0)
 #define LART_RAD2DEG (180.0 / LART_PI)
 #define LART_HUGEST  1.7976931348623157e308
+// a march in the periodic octree box that keeps wrapping without absorbing anything (|kz| < 1e-7 through vacuum) is ended here: the
+// reference would not return from it, and a wave that never finishes takes the GPU with it
+#define LART_AMR_MAX_WRAPS 10000000
 #define LART_TAU_HUGE 745.2                 // raytrace_car.f90:432 -- exp(-tau_huge) underflows
 
 // ---------------------------------------------------------------------------------------------
@@ -924,12 +927,21 @@ __device__ inline int amr_next_leaf(const DAmr &a, int ic, int iface, double x, 
     }
     return a.ileaf[ng - 1];
 }
-// mirror planes of the +++ octant (raytrace_amr.f90:176-201); returns the leaf to continue in, 0 = escape
-__device__ inline int amr_boundary(const lart_params &par, int il, int iface, double &kx, double &ky, double &kz, bool &reflected) {
-    if (par.xyz_symmetry) {
+// a face of the root box (raytrace_amr.f90:176-201): periodic in x and y (wrap by the box size, look the leaf up from the root), mirror
+// planes of the +++ octant / of the ++ quadrant (reflect, stay in the leaf); returns the leaf to continue in, 0 = escape
+__device__ inline int amr_boundary(const KArgs &A, int il, int iface, double &x, double &y, double z, double &kx, double &ky, double &kz, bool &reflected) {
+    const lart_params &par = A.par;
+    if (par.xy_periodic) {
+        if (iface == 1) x = x - (A.amr.hi - A.amr.lo); else if (iface == 2) x = x + (A.amr.hi - A.amr.lo);
+        else if (iface == 3) y = y - (A.amr.hi - A.amr.lo); else if (iface == 4) y = y + (A.amr.hi - A.amr.lo);
+        return iface <= 4 ? amr_find_leaf(A.amr, x, y, z) : 0;
+    } else if (par.xyz_symmetry) {
         if (iface == 2) { kx = -kx; reflected = true; return il; }
         if (iface == 4) { ky = -ky; reflected = true; return il; }
         if (iface == 6) { kz = -kz; reflected = true; return il; }
+    } else if (par.xy_symmetry) {
+        if (iface == 2) { kx = -kx; reflected = true; return il; }
+        if (iface == 4) { ky = -ky; reflected = true; return il; }
     }
     return 0;
 }
@@ -988,7 +1000,7 @@ __device__ inline void edge_step_amr(const KArgs &A, const Lds &l, bool dust, Ed
     if (m.tau >= LART_TAU_HUGE) { m.live = false; return; }
     m.d = m.d + t_exit; m.x = m.x + t_exit * m.kx; m.y = m.y + t_exit * m.ky; m.z = m.z + t_exit * m.kz;
     int il_new = amr_next_leaf(a, ic, iface, m.x, m.y, m.z); bool reflected = false;
-    if (il_new <= 0) il_new = amr_boundary(A.par, m.il, iface, m.kx, m.ky, m.kz, reflected);
+    if (il_new <= 0) { il_new = amr_boundary(A, m.il, iface, m.x, m.y, m.z, m.kx, m.ky, m.kz, reflected); if (m.d > LART_AMR_MAX_WRAPS * (a.hi - a.lo)) il_new = 0; }
     if (il_new <= 0) { m.live = false; return; }
     const Cell *cn = &A.g.cell[il_new - 1];
     double u2 = cn->vfx * m.kx + cn->vfy * m.ky + cn->vfz * m.kz;
@@ -1231,6 +1243,7 @@ __device__ inline void raytrace_to_tau_amr(const KArgs &A, const Lds &l, bool du
     }
 #endif
     double u1 = c->vfx * kx + c->vfy * ky + c->vfz * kz;
+    int nbound = 0;
     for (;;) {
         int ic = a.icell_of_leaf[il - 1], iface;
         double t_exit = amr_cell_exit(a.geom[ic - 1], x, y, z, kx, ky, kz, iface);
@@ -1246,7 +1259,7 @@ __device__ inline void raytrace_to_tau_amr(const KArgs &A, const Lds &l, bool du
         tau = tau + t_exit * rhokap; x = x + t_exit * kx; y = y + t_exit * ky; z = z + t_exit * kz;
         if (A.jpa.nbins) jpa_segment_amr(A, l, p, il, *c, x - 0.5 * t_exit * kx, y - 0.5 * t_exit * ky, z - 0.5 * t_exit * kz, t_exit, t_exit * rhokapH);
         int il_new = amr_next_leaf(a, ic, iface, x, y, z); bool reflected = false;
-        if (il_new <= 0) il_new = amr_boundary(A.par, il, iface, kx, ky, kz, reflected);
+        if (il_new <= 0) { il_new = amr_boundary(A, il, iface, x, y, z, kx, ky, kz, reflected); if (++nbound > LART_AMR_MAX_WRAPS) il_new = 0; }
         if (il_new <= 0) { p.inside = false; break; }
         const Cell *cn = &A.g.cell[il_new - 1];
         double u2 = cn->vfx * kx + cn->vfy * ky + cn->vfz * kz;

@@ -311,7 +311,6 @@ extern "C" int lart_gpu_set_grid_amr(lart_gpu *c, int32_t ncells, int32_t nleaf,
     if (!cx || !cy || !cz || !ch || !children || !neighbor || !ileaf || !icell_of_leaf) return fail("set_grid_amr: null tree table");
     if (!rhokap || !voigt_a || !Dfreq || !vfx || !vfy || !vfz) return fail("set_grid_amr: null medium table");
     if (c->par.DGR > 0.0 && !rhokapD) return fail("set_grid_amr: DGR > 0 needs rhokapD");
-    if (c->par.xy_periodic) return fail("set_grid_amr: xy_periodic is not defined for the octree path");
     // every index the kernels follow is checked here, so a bad table cannot send a wave out of bounds
     for (size_t i = 0; i < (size_t)8 * ncells; i++) if (children[i] < 0 || children[i] > ncells) return fail("set_grid_amr: children entries must be 0..ncells");
     for (size_t i = 0; i < (size_t)6 * ncells; i++) if (neighbor[i] < 0 || neighbor[i] > ncells) return fail("set_grid_amr: neighbor entries must be 0..ncells");
@@ -487,8 +486,8 @@ extern "C" int lart_gpu_begin(lart_gpu *c, int64_t first_id, int64_t stride, int
     if (c->par.line_type >= 4 && c->par.line_type <= 6 && !c->has_ml) return fail("begin: line_type 4/5/6 needs lart_gpu_set_line_multiplet first");
     if (c->is_clump && c->heal_nside > 0) return fail("begin: HEALPix inside observers are not supported with the clump medium (setup.f90:177)");
     if (c->is_amr && c->heal_nside > 0 && c->par.xyz_symmetry) return fail("begin: inside observers need the full octree");
-    if (c->par.xy_symmetry && (c->par.xyz_symmetry || c->par.xy_periodic || c->is_amr || c->is_clump)) return fail("begin: xy_symmetry is a variant of the plain Cartesian grid only");
-    if (c->par.xy_symmetry && (c->g.i0 < 1 || c->g.j0 < 1 || c->g.i0 > c->g.nx || c->g.j0 > c->g.ny)) return fail("begin: xy_symmetry needs mirror indices i0, j0 inside the grid");
+    if (c->par.xy_symmetry && (c->par.xyz_symmetry || c->par.xy_periodic || c->is_clump)) return fail("begin: xy_symmetry excludes xyz_symmetry, xy_periodic and the clump medium");
+    if (c->par.xy_symmetry && !c->is_amr && (c->g.i0 < 1 || c->g.j0 < 1 || c->g.i0 > c->g.nx || c->g.j0 > c->g.ny)) return fail("begin: xy_symmetry needs mirror indices i0, j0 inside the grid");
     if (c->heal_nside > 0 && c->par.xy_symmetry) return fail("begin: HEALPix observers need the plain grid");
     HIPCHK(hipSetDevice(c->device));
     if (!c->d_tally) { if (build_tally(c)) return 1; }

@@ -197,7 +197,7 @@ __device__ inline void sight_amr(const KArgs &A, const Lds &l, const SightRay &r
         if (last) return;
         d = d + t_exit; x = x + t_exit * kx; y = y + t_exit * ky; z = z + t_exit * kz;
         int il_new = amr_next_leaf(a, ic, iface, x, y, z); bool reflected = false;
-        if (il_new <= 0) il_new = amr_boundary(A.par, il, iface, kx, ky, kz, reflected);
+        if (il_new <= 0) { il_new = amr_boundary(A, il, iface, x, y, z, kx, ky, kz, reflected); if (d > LART_AMR_MAX_WRAPS * (a.hi - a.lo)) il_new = 0; }
         if (il_new <= 0) return;
         const Cell *cn = &A.g.cell[il_new - 1];
         const double u2 = cn->vfx * kx + cn->vfy * ky + cn->vfz * kz;

@@ -468,8 +468,8 @@ contains
     if (trim(strlowcase(par%h2_model)) /= 'none') call not_supported('par%h2_model')
     if (par%z_symmetry) call not_supported('par%z_symmetry')
     if (par%xy_symmetry) then                       ! mirrors in x and y, the full z range (grid_mod_car.f90:113-134)
-       if (par%xyz_symmetry .or. par%xy_periodic .or. par%use_amr_grid .or. par%use_clump_medium) &
-          call not_supported('par%xy_symmetry together with xyz_symmetry / xy_periodic / octree / clumps')
+       if (par%xyz_symmetry .or. par%xy_periodic .or. par%use_clump_medium) &
+          call not_supported('par%xy_symmetry together with xyz_symmetry / xy_periodic / clumps')
        if (trim(par%source_geometry) /= 'point' .or. par%xs_point /= 0.0_wp .or. par%ys_point /= 0.0_wp) &
           call not_supported('par%xy_symmetry with a source off the z axis (sources are folded for xyz_symmetry only)')
        if (par%calc_J .or. par%calc_P .or. par%calc_Pnew) call not_supported('par%geometry_JPa = 2 (cylindrical profiles, the xy_symmetry default)')
@@ -1444,8 +1444,12 @@ contains
     if (rmax <= 0.0_wp) rmax = (amr_hi - amr_lo)*0.5_wp
     nr = min(512, max(1, 2**max(0, amr_levelmax - 1))); nz = min(512, max(1, 2**max(0, amr_levelmax)))
     dr = rmax/nr; dz = (amr_hi - amr_lo)/nz
-    nadd = 1.0_wp
-    if (par%xyz_symmetry) nadd = 8.0_wp
+    nadd = 1.0_wp                                   ! grid_mod_amr.f90:577-588: only the mirror symmetries fold, the periodic slab is stored whole
+    if (par%xyz_symmetry) then
+       nadd = 8.0_wp
+    else if (par%xy_symmetry) then
+       nadd = 4.0_wp
+    endif
     select case (par%geometry_JPa)
     case (3);     amr_nbins = amr_nleaf; amr_dbin = 0.0_wp
     case (-1);    amr_nbins = nz;        amr_dbin = dz
@@ -1802,6 +1806,7 @@ contains
        area = fourpi*grid%rmax**2*(par%distance2cm)**2
     else
        area = (grid%xmax*grid%ymax + grid%ymax*grid%zmax + grid%zmax*grid%xmax)*8.0_wp*(par%distance2cm)**2
+       if (par%use_amr_grid) area = 6.0_wp*(amr_hi - amr_lo)**2*(par%distance2cm)**2      ! the six faces of the octree box (output_sum_rect.f90:808-813)
     endif
     grid%Jout(:) = grid%Jout(:)/(par%nphotons*intensity_bin_unit*twopi*area)
     if (par%save_Jin) grid%Jin(:) = grid%Jin(:)/(par%nphotons*intensity_bin_unit*twopi*area)
@@ -1852,6 +1857,8 @@ contains
          integer :: ib
          real(wp) :: d2
          d2 = par%distance2cm**2
+         !--- periodic slab (one photon per cm^2): the slab area replaces 1/d2 for the leaf and plane bins (output_sum_rect.f90:874-1000)
+         if (par%xy_periodic .and. (par%geometry_JPa == 3 .or. par%geometry_JPa == -1)) d2 = 1.0_wp/(amr_hi - amr_lo)**2
          do ib = 1, amr_nbins
             if (amr_vol(ib) > 0.0_wp) then
                if (allocated(prof_J1))     prof_J1(:,ib)   = prof_J1(:,ib)/(fourpi*amr_vol(ib)*d2*par%nphotons*intensity_bin_unit)

@@ -536,8 +536,6 @@ def read_input(par, line=None):
             raise LartInputError("par%%amr_type = '%s' is not supported by this path (generic text files only)" % par.amr_type)
         if not par.amr_file:
             raise LartInputError("par%use_amr_grid = .true. needs par%amr_file")
-        if par.xy_periodic:
-            raise LartInputError("par%xy_periodic is not defined for the octree path")
     if par.geometry == "sphere":                                          # :398-428
         if not par.xy_periodic and not par.use_amr_grid:
             c = [v for v in (par.rmax, par.xmax, par.ymax, par.zmax) if v > 0.0]
@@ -548,8 +546,8 @@ def read_input(par, line=None):
     else:
         par.rmax = -1.0
     if par.xy_symmetry:                                                   # mirrors in x and y, the full z range (grid_mod_car.f90:113-134)
-        if par.xyz_symmetry or par.xy_periodic or par.use_amr_grid or par.use_clump_medium:
-            raise LartInputError("par%xy_symmetry is a variant of the plain Cartesian grid (not with xyz_symmetry / xy_periodic / octree / clumps)")
+        if par.xyz_symmetry or par.xy_periodic or par.use_clump_medium:
+            raise LartInputError("par%xy_symmetry excludes xyz_symmetry / xy_periodic / clumps")
         if par.source_geometry != "point" or par.xs_point != 0.0 or par.ys_point != 0.0:
             raise LartInputError("par%xy_symmetry needs a point source on the z axis (sources are folded for xyz_symmetry only, generate_photon.f90:352-356)")
         if par.calc_J or par.calc_P or par.calc_Pnew:
@@ -1110,6 +1108,8 @@ class Simulation:
             area = FOURPI * g.rmax ** 2 * par.distance2cm ** 2
         else:
             area = (g.xmax * g.ymax + g.ymax * g.zmax + g.zmax * g.xmax) * 8.0 * par.distance2cm ** 2
+            if self.amr is not None:                                      # the six faces of the octree box (output_sum_rect.f90:808-813)
+                area = 6.0 * self.amr.L_box ** 2 * par.distance2cm ** 2
         scale = nph * unit * TWOPI * area
         for k in ("Jout", "Jin", "Jabs"):
             out[k] = t[k] / scale
@@ -1125,6 +1125,8 @@ class Simulation:
                     out[k + "_2D"] = t[k + "_2D"] / sc2
         if self.jpa.nbins and self.amr is not None:                       # octree: volume-weighted, output_sum_heal.f90:476-590
             vol = np.where(self.amr.vol > 0, self.amr.vol, np.inf) * par.distance2cm ** 2
+            if par.xy_periodic and par.geometry_JPa in (3, -1):           # slab, one photon per cm^2: the slab area replaces 1/d^2 (:874-1000)
+                vol = np.where(self.amr.vol > 0, self.amr.vol, np.inf) / self.amr.L_box ** 2
             if "J1" in t:
                 out["J1"] = t["J1"] / (FOURPI * vol[None, :] * nph * unit)
             for k in ("P1", "P1_new"):

@@ -1216,7 +1216,6 @@ static int grid_create_amr(orc_sim *s) {
     s->dxfreq = (s->par_xfreq_max - s->par_xfreq_min) / s->nxfreq; s->xfreq_max = s->par_xfreq_max; s->xfreq_min = s->par_xfreq_min;
     s->Jout = calloc(s->nxfreq, 8); s->Jin = calloc(s->nxfreq, 8); s->Jabs = calloc(s->nxfreq, 8); s->Jmu = calloc((size_t)s->nxfreq * (s->nmu > 0 ? s->nmu : 1), 8);
     s->raytrace_variant = 3;
-    if (s->xy_periodic) { snprintf(g_err, sizeof g_err, "xy_periodic AMR boxes are not supported by the oracle"); return -1; }
     return 0;
 }
 /* create_JPa_amr_mem: grid_mod_amr.f90:543-724 (position-binned deposits, gas volume per bin by ns^3 sub-sampling) */
@@ -1227,7 +1226,7 @@ static int create_JPa_amr_mem(orc_sim *s) {
     int nr = 1; { int e = a->levelmax - 1; if (e < 0) e = 0; nr = 1 << e; if (nr > 512) nr = 512; if (nr < 1) nr = 1; }
     int nz = 1; { int e = a->levelmax; if (e < 0) e = 0; nz = 1 << e; if (nz > 512) nz = 512; }
     a->nr_JPa = nr; a->nz_JPa = nz; a->rmax_JPa = rmax; a->dr_JPa = rmax / nr; a->dz_JPa = (a->zmax - a->zmin) / nz;
-    int nadd = s->xyz_symmetry ? 8 : 1;
+    int nadd = s->xyz_symmetry ? 8 : (s->xy_symmetry ? 4 : 1);              /* :577-588: the periodic slab does not fold */
     if (s->geometry_JPa == 1) s->nbins = nr; else if (s->geometry_JPa == -1) s->nbins = nz; else s->nbins = a->nleaf;
     s->ncount = calloc(s->nbins, 8);                             /* here: gas volume per bin (vol_sph / vol_plane / vol_leaf) */
     for (int il = 1; il <= a->nleaf; il++) {
@@ -1277,12 +1276,25 @@ static void amr_xcrit_local(const orc_sim *s, int il, double x, double y, double
     double atau = s->voigt_a[il-1] * s->rhokap[il-1] * dl;
     if (atau > 1.0) { *xc = pow(atau, 1.0 / 3.0) / 5.0; *xc2 = (*xc) * (*xc); }
 }
-/* boundary handling shared by the three AMR marches (raytrace_amr.f90:176-201): mirror planes of the +++ octant */
-static inline int amr_boundary(const orc_sim *s, int il, int iface, double *kx, double *ky, double *kz, int *reflected) {
-    if (s->xyz_symmetry) {
+/* boundary handling shared by the three AMR marches (raytrace_amr.f90:176-201): periodic in x and y (wrap by the box size and look the leaf up
+ * from the root), mirror planes of the +++ octant (xyz_symmetry) or the ++ quadrant (xy_symmetry); the leaf to go on in, 0 = the packet leaves */
+static inline int amr_boundary(const orc_sim *s, int il, int iface, double *x, double *y, double z, double *kx, double *ky, double *kz, int *reflected) {
+    const amr_t *a = &s->amr;
+    if (s->xy_periodic) {
+        switch (iface) {
+        case 1: *x = *x - (a->xmax - a->xmin); break;
+        case 2: *x = *x + (a->xmax - a->xmin); break;
+        case 3: *y = *y - (a->ymax - a->ymin); break;
+        case 4: *y = *y + (a->ymax - a->ymin); break;
+        }
+        return iface <= 4 ? amr_find_leaf(a, *x, *y, z) : 0;
+    } else if (s->xyz_symmetry) {
         if (iface == 2) { *kx = -*kx; *reflected = 1; return il; }
         if (iface == 4) { *ky = -*ky; *reflected = 1; return il; }
         if (iface == 6) { *kz = -*kz; *reflected = 1; return il; }
+    } else if (s->xy_symmetry) {
+        if (iface == 2) { *kx = -*kx; *reflected = 1; return il; }
+        if (iface == 4) { *ky = -*ky; *reflected = 1; return il; }
     }
     return 0;
 }
@@ -1309,7 +1321,7 @@ static void raytrace_to_tau_amr(const orc_sim *s, acc_t *A, photon_t *p, double 
         tau = tau + t_exit * rhokap; x = x + t_exit * kx; y = y + t_exit * ky; z = z + t_exit * kz;
         if (s->nbins) add_to_JPnew_amr(s, A, p, il, x - 0.5 * t_exit * kx, y - 0.5 * t_exit * ky, z - 0.5 * t_exit * kz, t_exit, t_exit * rhokapH);
         int il_new = amr_next_leaf(a, ic, iface, x, y, z), reflected = 0;
-        if (il_new <= 0) il_new = amr_boundary(s, il, iface, &kx, &ky, &kz, &reflected);
+        if (il_new <= 0) il_new = amr_boundary(s, il, iface, &x, &y, z, &kx, &ky, &kz, &reflected);
         if (il_new <= 0) { p->inside = 0; break; }
         u2 = s->vfx[il_new-1] * kx + s->vfy[il_new-1] * ky + s->vfz[il_new-1] * kz;
         if (reflected) p->xfreq = (p->xfreq + u1) - u2; else p->xfreq = (p->xfreq + u1) * s->Dfreq[il-1] / s->Dfreq[il_new-1] - u2;
@@ -1342,7 +1354,7 @@ static double raytrace_to_edge_amr(const orc_sim *s, const photon_t *p, double d
         if (tau >= TAU_HUGE) return tau;
         d = d + t_exit; x = x + t_exit * kx; y = y + t_exit * ky; z = z + t_exit * kz;
         int il_new = amr_next_leaf(a, ic, iface, x, y, z), reflected = 0;
-        if (il_new <= 0) il_new = amr_boundary(s, il, iface, &kx, &ky, &kz, &reflected);
+        if (il_new <= 0) il_new = amr_boundary(s, il, iface, &x, &y, z, &kx, &ky, &kz, &reflected);
         if (il_new <= 0) return tau;
         u2 = s->vfx[il_new-1] * kx + s->vfy[il_new-1] * ky + s->vfz[il_new-1] * kz;
         if (reflected) xfreq = (xfreq + u1) - u2; else xfreq = (xfreq + u1) * s->Dfreq[il-1] / s->Dfreq[il_new-1] - u2;
@@ -2553,6 +2565,7 @@ int orc_normalized_Jout(const orc_sim *s, double *out, int n) {
     double nph = (double)s->nphotons_done, area, scale;
     if (s->xy_periodic) area = 2.0;
     else if (s->geometry == 0) area = FOURPI * s->rmax * s->rmax * s->distance2cm * s->distance2cm;
+    else if (s->use_amr_grid) area = 6.0 * s->amr.L_box * s->amr.L_box * s->distance2cm * s->distance2cm;   /* output_normalize_amr :808-813: the six faces of the box */
     else area = (s->xmax * s->ymax + s->ymax * s->zmax + s->zmax * s->xmax) * 8.0 * s->distance2cm * s->distance2cm;
     scale = nph * s->dxfreq * TWOPI * area;
     for (int i = 0; i < n && i < s->nxfreq; i++) out[i] = s->Jout[i] / scale;
@@ -2775,7 +2788,7 @@ static double sight_amr(const orc_sim *s, const photon_t *p, double dist, int wa
         if (last) return tau;
         d = d + t_exit; x = x + t_exit * kx; y = y + t_exit * ky; z = z + t_exit * kz;
         int il_new = amr_next_leaf(a, ic, iface, x, y, z), reflected = 0;
-        if (il_new <= 0) il_new = amr_boundary(s, il, iface, &kx, &ky, &kz, &reflected);
+        if (il_new <= 0) il_new = amr_boundary(s, il, iface, &x, &y, z, &kx, &ky, &kz, &reflected);
         if (il_new <= 0) return tau;
         u2 = s->vfx[il_new-1] * kx + s->vfy[il_new-1] * ky + s->vfz[il_new-1] * kz;
         if (reflected) xfreq = (xfreq + u1) - u2; else xfreq = (xfreq + u1) * s->Dfreq[il-1] / s->Dfreq[il_new-1] - u2;

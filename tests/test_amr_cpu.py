@@ -52,8 +52,7 @@ def test_input_rules(small_amr):
     # setup.f90:438: the profile geometry is decided on the INPUT rmax, before grid_create_amr sets par%rmax
     par, _, g, _ = host_grid(dict(use_amr_grid=True, amr_file=fn, temperature=1e4, taumax=1e2, calc_P=True))
     assert par.geometry_JPa == 3 and g.nbins == g.nleaf and par.rmax == 1.0
-    for bad in (dict(use_amr_grid=True), dict(use_amr_grid=True, amr_file=fn, amr_type="ramses"),
-                dict(use_amr_grid=True, amr_file=fn, xy_periodic=True, nx=1, ny=1)):
+    for bad in (dict(use_amr_grid=True), dict(use_amr_grid=True, amr_file=fn, amr_type="ramses")):
         p = host.Params()
         for k, v in dict(temperature=1e4, taumax=10.0, **bad).items():
             host.set_param(p, k, v)
@@ -111,3 +110,49 @@ def test_whole_path_known_answer(oracle_mod, small_amr):
     o.run(n, seed=5)
     ns, _ = o.photon_log()
     assert abs(ns.mean() - 2.8225e4) < 0.02 * 2.8225e4 + 4 * ns.std() / np.sqrt(n)
+
+
+def test_periodic_octree_slab(oracle_mod, tmp_path):
+    """par%xy_periodic on the octree (raytrace_amr.f90:176-187, :309-319): a side face of the root box wraps to the opposite one and the
+    leaf is looked up from the root.  Uniform gas on leaves of two sizes (the wrap lands on another refinement level): the physics is the
+    plane-parallel slab, so <N_scatt> and the emergent spectrum equal those of the Cartesian nx = ny = 1 slab of the same tau0; without
+    the wrap the same box leaks through its sides and scatters less."""
+    from lart_amd import amr
+    fn = str(tmp_path / "slab.dat")
+    amr.write_generic_amr(fn, amr.make_amr_slab(level_min=2, level_max=3))
+    n = 20000
+    kw = dict(use_amr_grid=True, amr_file=fn, temperature=1e4, taumax=3e2, nxfreq=61, xfreq_min=-12.0, xfreq_max=12.0)
+    a = oracle_mod.Oracle(xy_periodic=True, **kw); a.run(n, seed=5)
+    assert int(a.scalar("amr_nleaf")) == 48 + 16 * 8 and a.scalar("taumax") == 3e2
+    c = oracle_mod.Oracle(temperature=1e4, taumax=3e2, xy_periodic=True, nx=1, ny=1, nz=64, nxfreq=61, xfreq_min=-12.0, xfreq_max=12.0); c.run(n, seed=6)
+    b = oracle_mod.Oracle(**kw); b.run(n, seed=5)
+    na, nc, nb = a.photon_log()[0], c.photon_log()[0], b.photon_log()[0]
+    assert abs(na.mean() - nc.mean()) < 4.0 * np.hypot(na.std(), nc.std()) / np.sqrt(n), (na.mean(), nc.mean())
+    assert nb.mean() < 0.85 * na.mean()
+    ja, jc = a.array("Jout"), c.array("Jout")
+    assert ja.sum() == n and jc.sum() == n                          # nothing is lost through the sides (every packet leaves through z)
+    chi2 = np.sum((ja - jc) ** 2 / np.maximum(ja + jc, 1.0)) / np.count_nonzero(ja + jc)
+    assert chi2 < 1.6, chi2
+    assert np.allclose(a.normalized_Jout(), ja / (n * a.scalar("dxfreq") * 2.0 * np.pi * 2.0))      # two faces, no area (output_sum_rect.f90:802-804)
+    # the plane profile of the scattering rate (geometry_JPa = -1 by default for a periodic box): symmetric in z, same on both refinement levels
+    p = oracle_mod.Oracle(xy_periodic=True, calc_P=True, rmax=1.0, **kw); p.run(n, seed=5)
+    assert int(p.scalar("geometry_JPa")) == -1 and int(p.scalar("nbins")) == 8
+    P = p.array("P1") / p.array("ncount")
+    assert np.allclose(P, P[::-1], rtol=0.08) and P[3] > P[0]
+
+
+def test_mirrored_octree_quadrant(oracle_mod, tmp_path):
+    """par%xy_symmetry on the octree (raytrace_amr.f90:193-197): the -x and -y faces of the root box reflect, +x, +y and both z faces let
+    the packet out.  The box [0, L]^2 x [-L/2.., ..] cannot be written as a generic file centred on the origin, so the check is on the
+    boundary rule itself: a uniform box with mirrors on two sides scatters more than the open box and less than the periodic slab."""
+    from lart_amd import amr
+    fn = str(tmp_path / "box.dat")
+    amr.write_generic_amr(fn, amr.make_amr_slab(level_min=2, level_max=3))
+    n = 10000
+    kw = dict(use_amr_grid=True, amr_file=fn, temperature=1e4, taumax=3e2, nxfreq=61, xfreq_min=-12.0, xfreq_max=12.0)
+    means = []
+    for extra in (dict(), dict(xy_symmetry=True), dict(xy_periodic=True)):
+        o = oracle_mod.Oracle(**kw, **extra); o.run(n, seed=5)
+        assert o.array("Jout").sum() == n
+        means.append(o.photon_log()[0].mean())
+    assert means[0] < 0.95 * means[1] and means[1] < 0.95 * means[2], means

@@ -302,6 +302,36 @@ def test_amr_end_to_end_matches_python_host(exe, tmp_path):
     assert np.allclose(hdus["Pa_1D"][1].ravel(), t["P1"], rtol=1e-8) and np.allclose(hdus["Pa_1D_new"][1].ravel(), t["P1_new"], rtol=1e-8)
 
 
+PERIODIC_AMR_IN = ("&parameters\n par%use_amr_grid = .true.\n par%amr_file = 'slab.dat'\n par%no_photons = 20000\n par%taumax = 1e2\n par%temperature = 1e4\n"
+                   " par%xy_periodic = .true.\n par%nxfreq = 61\n par%xfreq_min = -12.0\n par%xfreq_max = 12.0\n par%calc_P = .true.\n par%calc_J = .true.\n"
+                   " par%rmax = 1.0\n par%iseed = 23\n/\n")
+
+
+def test_periodic_octree_dry_run(exe, tmp_path):
+    """par%xy_periodic with an octree (raytrace_amr.f90:176-187): accepted, plane profiles by default (setup.f90:446-447)"""
+    from lart_amd import amr
+    amr.write_generic_amr(str(tmp_path / "slab.dat"), amr.make_amr_slab(level_min=2, level_max=3))
+    r = run(exe, PERIODIC_AMR_IN, tmp_path, "--dry-run-write", name="pamr.in")
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert re.search(r"AMR nleaf\s+:\s+176\b", r.stdout) and "geometry_JPa = -1" in r.stdout
+    H = read_h5(str(tmp_path / "pamr.h5"))
+    assert H["Spectrum"][0]["xy_per"] == 1 and H["Pa_1D"][1].size == 8 and H["Jx_1D"][1].shape == (61, 8)
+
+
+@pytest.mark.gpu
+def test_periodic_octree_end_to_end_matches_python_host(exe, tmp_path):
+    from lart_amd import amr, host
+    amr.write_generic_amr(str(tmp_path / "slab.dat"), amr.make_amr_slab(level_min=2, level_max=3))
+    r = run(exe, PERIODIC_AMR_IN, tmp_path, name="pamr.in")
+    assert r.returncode == 0, r.stdout + r.stderr
+    H = read_h5(str(tmp_path / "pamr.h5"))
+    par = host.read_namelist(str(tmp_path / "pamr.in")); par.amr_file = str(tmp_path / "slab.dat")
+    sim = host.Simulation(par); sim.run_simulation(); t = sim.output_normalize()
+    assert np.allclose(H["Spectrum"][1]["Jout"], t["Jout"], rtol=1e-9, atol=1e-15)
+    assert np.allclose(H["Pa_1D"][1].ravel(), t["P1"], rtol=1e-8) and np.allclose(H["Jx_1D"][1], t["J1"], rtol=1e-8, atol=1e-12 * t["J1"].max())
+    assert np.isclose(H["Spectrum"][1]["Jout"].sum() * (24.0 / 61) * 2.0 * np.pi * 2.0, 1.0, rtol=1e-9)     # every packet leaves through z: two faces, no area
+
+
 def test_output_containers_hdf5_and_gzip_fits(exe, tmp_path):
     """the same sections, columns and keywords in both containers (reference: hdf5io_mod.f90:8-13, write_output_rect.f90:427-498)"""
     base = ("&parameters\n par%no_photons = 1000\n par%temperature = 1e4\n par%taumax = 1e2\n par%nx = 11\n par%ny = 11\n par%nz = 11\n"

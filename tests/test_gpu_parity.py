@@ -658,6 +658,44 @@ def test_amr_short_histories_photon_by_photon(capi, oracle_mod, amr_file, extra)
     assert np.isclose(t["n_cellsteps"], o.scalar("n_cellsteps"), rtol=0.02)     # the same leaves are visited
 
 
+@pytest.fixture(scope="module")
+def amr_slab_file(tmp_path_factory):
+    from lart_amd import amr
+    fn = str(tmp_path_factory.mktemp("amr") / "slab.dat")
+    amr.write_generic_amr(fn, amr.make_amr_slab(level_min=2, level_max=3))
+    return fn
+
+
+@pytest.mark.parametrize("extra", [dict(xy_periodic=True), dict(xy_symmetry=True), dict(xy_periodic=True, velocity_type="hubble", Vexp=20.0, DGR=1.0),
+                                   dict(xy_periodic=True, use_stokes=True, nxim=9, nyim=9, alpha=0.0, beta=40.0, calc_P=True, calc_J=True, rmax=1.0)])
+def test_amr_box_boundaries_photon_by_photon(capi, oracle_mod, amr_slab_file, extra):
+    """the faces of the octree's root box (raytrace_amr.f90:176-201): periodic in x and y (wrap + leaf lookup from the root, on leaves of two
+    sizes), mirrors at -x / -y.  Whole histories against the oracle on the same streams; with an observer the peel rays wrap too
+    (raytrace_to_edge_amr :309-319) and the plane profiles (geometry_JPa = -1) are filled."""
+    kw = dict(use_amr_grid=True, amr_file=amr_slab_file, temperature=1e4, taumax=1e2, nxfreq=61, xfreq_min=-12.0, xfreq_max=12.0, iseed=23, **extra)
+    n = 20000
+    sim = make(kw); sim.ctx.enable_photon_log(True); sim.run_simulation(n); t = sim.ctx.tallies()
+    o = oracle_of(oracle_mod, kw); o.run(n, seed=23)
+    ng, xg = sim.ctx.photon_log(n); no, xo = o.photon_log()
+    same = np.isclose(ng, no, rtol=1e-12, atol=0) & (np.isclose(xg, xo, rtol=1e-7, atol=1e-9) | (xo == 0))
+    assert same.mean() > 0.97, same.mean()
+    assert t["nphotons_done"] == n and rms_diff(t["Jout"], o.array("Jout")) < 0.01
+    assert np.isclose(t["n_cellsteps"], o.scalar("n_cellsteps"), rtol=0.02)
+    if "xy_periodic" in extra and "DGR" not in extra:
+        assert abs(t["Jout"].sum() - n) < 1e-6                                # no packet is lost through a side face
+    if "nxim" in extra:
+        assert sim.jpa.nbins == int(o.scalar("nbins")) == 8 and int(o.scalar("geometry_JPa")) == -1
+        assert np.allclose(t["P1"], o.array("P1"), rtol=0.03, atol=2e-3 * o.array("P1").max())
+        assert rms_diff(t["J1"].ravel(order="F"), o.array("J1")) < 0.01
+        for k in ("scatt", "I", "Q"):
+            g3, o3 = t[k][..., 0], o.array(k + ":0").reshape((61, 9, 9), order="F")
+            assert rms_diff(g3.sum(axis=0), o3.sum(axis=0)) < 0.02, k         # image
+            assert rms_diff(g3.sum(axis=(1, 2)), o3.sum(axis=(1, 2))) < 0.02 if k != "Q" else True, k
+        assert abs(t["direc"].sum() - o.array("direc:0").sum()) <= 0.01 * o.array("direc:0").sum() + 1e-12
+        out = sim.output_normalize(t)
+        assert np.all(np.isfinite(out["P1"])) and np.allclose(out["P1"], t["P1"] * 4.0 / (sim.amr.vol * n))     # slab area 2 x 2 instead of 1/d^2
+
+
 def test_amr_profiles_peel_and_known_answer(capi, oracle_mod, amr_file):
     """octree + radial J/P profiles + a far observer, against the oracle on the same streams; then the reference's
     logged <N_scatt> = 2.8225E+04 (examples/amr_sphere_generic/log_amr_1M.txt) at tau0 = 1e4"""
