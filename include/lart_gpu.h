@@ -125,13 +125,18 @@ int  lart_gpu_set_JPa_amr(lart_gpu *ctx, int32_t calc_J, int32_t calc_P, int32_t
  * par.DGR = 0), voigt_a, Dfreq [Hz].  Dfreq_ref / voigt_a_ref = cl_Dfreq_ref / cl_voigt_a_ref (the units of xfreq and the
  * uniform background record of grid_create_clump, grid_mod_clump.f90:101-113).  CSR acceleration grid: cgx^3 cells of edge
  * cg_d from cg_min on every axis, cg_start[cgx^3+1] (1-based offsets, cg_start[0] = 1), cg_list[cg_start[cgx^3]-1] (1-based
- * clump numbers).  Non-overlapping clumps only (has_overlap = .false.).  Replaces raytrace_to_{tau,edge}_clump[_capped],
- * do_resonance1_clump and the clump branches of scattering / generate_photon / peeling_*_outside for the kernels. */
+ * clump numbers).  Replaces raytrace_to_{tau,edge}_clump[_capped], do_resonance1_clump and the clump branches of scattering /
+ * generate_photon / peeling_*_outside for the kernels.
+ * lart_gpu_set_clump_overlap(ctx, 1) after it = setup_clump_overlap (setup.f90:1053-1082) when check_has_overlap found a pair of
+ * overlapping clumps: the kernels then run raytrace_to_{tau,edge}_clump_overlap[_capped] (raytrace_clump.f90:606-918; the frequency of the
+ * flight stays in the global frame, the opacity inside k clumps is the sum of their k profiles) and scatter_resonance_clump_{no,}stokes
+ * (scattering_car.f90:898-937; the scattering clump drawn opacity-weighted).  Single-line profiles (line type 1), no sight-line maps. */
 int  lart_gpu_set_clumps(lart_gpu *ctx, int64_t n, const double *x, const double *y, const double *z,
                          const double *vx, const double *vy, const double *vz, const double *radius,
                          const double *rhokap, const double *rhokapD, const double *voigt_a, const double *Dfreq,
                          double sphere_R, double Dfreq_ref, double voigt_a_ref,
                          int32_t cgx, double cg_min, double cg_d, const int32_t *cg_start, const int32_t *cg_list);
+int  lart_gpu_set_clump_overlap(lart_gpu *ctx, int32_t has_overlap);
 
 /* ---- resonance + fluorescence multiplets (line types 4, 5, 6 of setup_resonance_line, line_mod.f90:713-1153) ----
  * nup <= 3 upward transitions from the ground level (f12, delE_Hz = frequency offset of the level from the first one, damping_up =
@@ -164,15 +169,18 @@ int  lart_gpu_set_line_multiplet(lart_gpu *ctx, const lart_line_multiplet *m);
  * lart_host_clumps_generate: generate_clumps, uniform path (clump_mod.f90:897-1151): n non-overlapping centres in the shell
  *   [r_min, sphere_R] by random sequential adsorption with the reference's grid and its MT19937-64 stream seeded with
  *   par%iseed (rank 0); sigma_v_over_vtherm = par%clump_sigma_v / cl_vtherm adds Gaussian bulk velocities (rand_gauss).
+ *   flags: bit 0 = par%clump_fully_inside, bit 1 = par%clump_allow_overlap (a trial that overlaps an earlier clump is kept, :1090).
  * lart_host_clumps_csr_dims / _build_csr: build_clump_csr (:1267-1360); call _build_csr with cg_list = NULL first to
- *   learn the registration count.  Errors: non-zero + lart_host_last_error(). */
+ *   learn the registration count.  lart_host_clumps_has_overlap: check_has_overlap (:1544-1591).  Errors: non-zero + lart_host_last_error(). */
 const char *lart_host_last_error(void);
-int  lart_host_clumps_generate(int64_t n, double sphere_R, double r_min, double clump_radius, int32_t fully_inside,
+int  lart_host_clumps_generate(int64_t n, double sphere_R, double r_min, double clump_radius, int32_t flags,
                                double sigma_v_over_vtherm, int64_t iseed, double *x, double *y, double *z,
                                double *vx, double *vy, double *vz, double *acceptance);
 int  lart_host_clumps_csr_dims(int64_t n, double sphere_R, double radius_max, int32_t *cgx, double *cg_min, double *cg_d);
 int  lart_host_clumps_build_csr(int64_t n, const double *x, const double *y, const double *z, const double *radius,
                                 int32_t cgx, double cg_min, double cg_d, int32_t *cg_start, int32_t *cg_list, int64_t *nreg);
+int  lart_host_clumps_has_overlap(int64_t n, const double *x, const double *y, const double *z, const double *radius,
+                                  int32_t cgx, double cg_min, double cg_d, const int32_t *cg_start, const int32_t *cg_list, int32_t *has_overlap);
 
 /* ---- host-side set-up helpers for the octree (CPU): amr_build_tree + amr_build_neighbors (octree_mod.f90:460-569, 619-682)
  * from a list of leaf cells (centre, refinement level) in the cube [lo,hi]^3, numbered like the reference (root = 1, cells in

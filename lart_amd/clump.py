@@ -42,6 +42,7 @@ class Clumps:
     cg_d: float = 0.0
     cg_start: np.ndarray = None
     cg_list: np.ndarray = None
+    has_overlap: bool = False                              # clump_mod.f90:88, check_has_overlap
 
 
 def _hchk(rc):
@@ -138,12 +139,19 @@ def init_clumps(par, line, R_sphere):
     cl.rhokapD = np.full(n, cl.rhokap_ref * par.cext_dust * par.DGR * cl.Dfreq_ref / line.cross0) if par.DGR > 0.0 else None
     acc = C.c_double()
     sig = par.clump_sigma_v / cl.vtherm_ref if par.clump_sigma_v > 0.0 else 0.0
-    _hchk(capi.lib().lart_host_clumps_generate(n, cl.sphere_R, cl.r_min, rc, int(par.clump_fully_inside), sig, int(par.iseed),
+    _hchk(capi.lib().lart_host_clumps_generate(n, cl.sphere_R, cl.r_min, rc, int(par.clump_fully_inside) | (2 if par.clump_allow_overlap else 0), sig, int(par.iseed),
                                                capi._p(cl.x), capi._p(cl.y), capi._p(cl.z), capi._p(cl.vx), capi._p(cl.vy), capi._p(cl.vz), C.byref(acc)))
     cl.rsa_acceptance = acc.value
     if par.velocity_type:
         assign_clump_velocities(par, cl)
-    return build_csr(cl)
+    build_csr(cl)
+    if par.clump_allow_overlap:                            # clump_mod.f90:889-891: only then is the population searched for overlapping pairs
+        has = C.c_int32()
+        _hchk(capi.lib().lart_host_clumps_has_overlap(cl.N, capi._p(cl.x), capi._p(cl.y), capi._p(cl.z), capi._p(cl.radius), cl.cgx, cl.cg_min, cl.cg_d,
+                                                      capi._p(cl.cg_start), capi._p(cl.cg_list), C.byref(has)))
+        cl.has_overlap = bool(has.value)
+        print(" Overlap check: overlapping clumps detected — using overlap-aware raytrace." if cl.has_overlap else " Overlap check: no overlaps found — using standard raytrace.")
+    return cl
 
 
 def compute_clump_scalars(par, line, cl):

@@ -52,6 +52,8 @@ struct DAmr {
 // clump medium (VAR 4): clump_mod.f90:27-118.  Geometry and physics in separate records: the CSR search only touches geometry.
 struct ClumpGeo  { double x, y, z, r2; };                                           // centre, radius^2
 struct ClumpPhys { double rhokap, rhokapD, voigt_a, Dfreq, vx, vy, vz, pad; };     // v in units of the clump's thermal speed
+// VAR 4 (disjoint clumps) and VAR 7 (overlapping clumps) share the owner-clump bookkeeping of the scattering and peel-off routines
+__host__ __device__ constexpr bool is_clump(int var) { return var == 4 || var == 7; }
 struct DClumps {
     long long N;
     const ClumpGeo *geo; const ClumpPhys *phys;
@@ -1152,12 +1154,140 @@ __device__ inline void edge_step_clump(const KArgs &A, const Lds &l, bool dust, 
     if (m.x * m.x + m.y * m.y + m.z * m.z >= c.sphere_R * c.sphere_R) m.live = false;
 }
 
+// ---------------------------------------------------------------------------------------------
+// overlapping clumps (VAR 7): raytrace_clump.f90:606-918.  The frequency of the flight stays in the GLOBAL frame; inside k overlapping
+// clumps the opacity is the sum of the k line profiles, each at its own frame frequency, and the scattering clump is drawn opacity-weighted.
+//
+// The reference collects every ENTER/EXIT of the ray up to the sphere's surface into arrays of 2048 events, sorts them and walks the
+// intervals.  Here the same event sequence is produced on the fly: the CSR cells are visited in ray order, the clumps of a cell put their
+// events into a short sorted list, and the list is drained up to the cell's far face before the next cell is read (a clump is registered in
+// every cell its sphere touches, so an event inside a cell is known by the time the cell is left).  Same intervals, same order of the active
+// list (append on ENTER, swap with the last on EXIT), so the same sums, bit for bit, while the lists fit: LART_OVL_ACT clumps around one point,
+// LART_OVL_PEND events ahead of the ray inside one CSR cell row.  An overflow is counted in scal[7] and lart_gpu_get_tallies refuses the run.
+// ---------------------------------------------------------------------------------------------
+#define LART_OVL_ACT 32
+#define LART_OVL_PEND 64
+// sum_kap_active: :621-636
+__device__ inline double ovl_sum_kap(const KArgs &A, const Lds &l, bool dust, const int *act, int na, double xfreq_g, double kx, double ky, double kz) {
+    double sum = 0.0;
+    for (int m = 0; m < na; m++) { const ClumpPhys ph = A.cl.phys[act[m] - 1]; sum = sum + kappa_clump(A, l, dust, xfreq_g - ulos_clump(A, ph, kx, ky, kz), ph); }
+    return sum;
+}
+// TO_TAU: raytrace_to_tau_clump_overlap (:668-788): lim = the optical depth to go; returns with owner > 0 and t_end = the path length to the
+//         scattering point, or owner = 0 and t_end = the path to the sphere's surface (escape).  u_own = the draw of sample_owner_clump (:644-664).
+// else:   raytrace_to_edge_clump_overlap_capped (:858-918): lim = the cap; returns the optical depth.
+template <bool TO_TAU>
+__device__ inline double ovl_march(const KArgs &A, const Lds &l, bool dust, double xp, double yp, double zp, double kx, double ky, double kz,
+                                   double xfreq_g, double lim, double u_own, unsigned &nsteps, double &t_end, int &owner) {
+    const DClumps &c = A.cl; const int cg = c.cgx;
+    owner = 0; t_end = 0.0;
+    const double t_sp = sphere_exit_dist(c, xp, yp, zp, kx, ky, kz);
+    if (t_sp <= 0.0) return 0.0;
+    int act[LART_OVL_ACT], pid[LART_OVL_PEND], na = 0, np = 0; double pt[LART_OVL_PEND];        // pid: +icl = ENTER, -icl = EXIT; pt descending, the next event last
+    bool over = false;
+    int ci = cg_clamp(c, xp), cj = cg_clamp(c, yp), ck = cg_clamp(c, zp);
+    // active_set_at_point: clump_mod.f90:1594-1634
+    for (int k = (ck > 0 ? ck - 1 : 0); k <= (ck < cg - 1 ? ck + 1 : cg - 1); k++)
+        for (int j = (cj > 0 ? cj - 1 : 0); j <= (cj < cg - 1 ? cj + 1 : cg - 1); j++)
+            for (int i = (ci > 0 ? ci - 1 : 0); i <= (ci < cg - 1 ? ci + 1 : cg - 1); i++) {
+                const size_t q = (size_t)i + (size_t)j * cg + (size_t)k * cg * cg;
+                const int ip1 = c.cg_start[q + 1];
+                for (int ip = c.cg_start[q]; ip < ip1; ip++) {
+                    const int icl = c.cg_list[ip - 1]; const ClumpGeo g = c.geo[icl - 1];
+                    const double rx = xp - g.x, ry = yp - g.y, rz = zp - g.z;
+                    if (rx * rx + ry * ry + rz * rz <= g.r2) {
+                        bool dup = false; for (int m = 0; m < na; m++) dup = dup || act[m] == icl;
+                        if (!dup) { if (na < LART_OVL_ACT) act[na++] = icl; else over = true; }
+                    }
+                }
+            }
+    int si, sj, sk; double tx, ty, tz, delx, dely, delz;                                      // collect_ray_events_overlap: clump_mod.f90:1664-1693
+    if (kx > 0.0) { si = 1; delx = c.cg_d / kx; tx = ((c.cg_min + (double)(ci + 1) * c.cg_d) - xp) / kx; }
+    else if (kx < 0.0) { si = -1; delx = -c.cg_d / kx; tx = ((c.cg_min + (double)ci * c.cg_d) - xp) / kx; } else { si = 0; delx = LART_HUGEST; tx = LART_HUGEST; }
+    if (ky > 0.0) { sj = 1; dely = c.cg_d / ky; ty = ((c.cg_min + (double)(cj + 1) * c.cg_d) - yp) / ky; }
+    else if (ky < 0.0) { sj = -1; dely = -c.cg_d / ky; ty = ((c.cg_min + (double)cj * c.cg_d) - yp) / ky; } else { sj = 0; dely = LART_HUGEST; ty = LART_HUGEST; }
+    if (kz > 0.0) { sk = 1; delz = c.cg_d / kz; tz = ((c.cg_min + (double)(ck + 1) * c.cg_d) - zp) / kz; }
+    else if (kz < 0.0) { sk = -1; delz = -c.cg_d / kz; tz = ((c.cg_min + (double)ck * c.cg_d) - zp) / kz; } else { sk = 0; delz = LART_HUGEST; tz = LART_HUGEST; }
+    double d = 0.0, t_cur = 0.0, acc = TO_TAU ? lim : 0.0;                                    // acc: optical depth still to go / gone so far
+    bool cells = true, done = false;
+    while (!done) {
+        double t_lim = LART_HUGEST;
+        if (cells && !(d > t_sp) && ci >= 0 && ci < cg && cj >= 0 && cj < cg && ck >= 0 && ck < cg) {
+            const size_t q = (size_t)ci + (size_t)cj * cg + (size_t)ck * cg * cg;
+            const int ip1 = c.cg_start[q + 1];
+            for (int ip = c.cg_start[q]; ip < ip1; ip++) {
+                const int icl = c.cg_list[ip - 1]; const ClumpGeo g = c.geo[icl - 1];
+                const double rx = xp - g.x, ry = yp - g.y, rz = zp - g.z, b = rx * kx + ry * ky + rz * kz;     // ray_sphere_isect :1362-1386
+                double disc = b * b - (rx * rx + ry * ry + rz * rz) + g.r2;
+                if (disc < 0.0) continue;
+                disc = sqrt(disc);
+                const double te = -b - disc, tx2 = -b + disc;
+                if (!(tx2 > 0.0) || te > t_sp) continue;
+                const double tex = fmin(tx2, t_sp);
+                if (tex <= t_cur) continue;                                    // its EXIT lies behind the ray: seen and done in an earlier cell
+                bool seen = false; for (int m = 0; m < np; m++) seen = seen || pid[m] == icl || pid[m] == -icl;
+                if (seen) continue;
+                if (np + 2 > LART_OVL_PEND) { over = true; continue; }
+                for (int e = (te > 0.0 ? 0 : 1); e < 2; e++) {                                // ENTER (only when the origin is outside), then EXIT
+                    const double tn = e == 0 ? te : tex; const int idn = e == 0 ? icl : -icl;
+                    int pos = 0; while (pos < np && pt[pos] > tn) pos++;                      // after the later ones, before the equal ones (stable: first seen, first out)
+                    for (int m = np; m > pos; m--) { pt[m] = pt[m - 1]; pid[m] = pid[m - 1]; }
+                    pt[pos] = tn; pid[pos] = idn; np++;
+                }
+            }
+            if (tx <= ty && tx <= tz) { d = tx; tx = tx + delx; ci += si; }
+            else if (ty <= tz)        { d = ty; ty = ty + dely; cj += sj; }
+            else                      { d = tz; tz = tz + delz; ck += sk; }
+            t_lim = d;
+        } else cells = false;
+        for (;;) {                                                                            // the intervals up to t_lim (:713-743 / :884-897)
+            const bool ev = np > 0 && pt[np - 1] <= t_lim;
+            if (!ev && cells) break;
+            const double t_next = fmin(ev ? pt[np - 1] : t_sp, t_sp), dt = t_next - t_cur;
+            if (dt > 0.0) {
+                const double kap = ovl_sum_kap(A, l, dust, act, na, xfreq_g, kx, ky, kz);
+                nsteps++;
+                if (TO_TAU) {
+                    if (kap > 0.0 && acc <= kap * dt) {
+                        t_end = t_cur + acc / kap;
+                        double cumul = 0.0;                                                   // sample_owner_clump :644-664
+                        for (int m = 0; m < na; m++) {
+                            const ClumpPhys ph = c.phys[act[m] - 1];
+                            cumul = cumul + kappa_clump(A, l, dust, xfreq_g - ulos_clump(A, ph, kx, ky, kz), ph); owner = act[m];
+                            if (u_own * kap <= cumul) break;
+                        }
+                        done = true; break;
+                    }
+                    acc = acc - kap * dt;
+                } else { acc = acc + kap * dt; if (acc >= lim) { done = true; break; } }
+                t_cur = t_next;
+            }
+            if (!ev) { done = true; break; }                                                  // that was the last interval, up to the surface
+            const int id = pid[--np];                                                         // apply_event :769-786
+            if (id > 0) { if (na < LART_OVL_ACT) act[na++] = id; else over = true; }
+            else for (int m = 0; m < na; m++) if (act[m] == -id) { act[m] = act[na - 1]; na--; break; }
+        }
+    }
+    if (over) atomicAdd(&A.t.scal[7], 1.0);
+    if (TO_TAU) { if (owner == 0) t_end = t_sp; return 0.0; }
+    return acc;
+}
+// raytrace_to_tau_clump_overlap: :668-788
+__device__ inline void raytrace_to_tau_clump_ovl(const KArgs &A, const Lds &l, bool dust, Photon &p, double tau_in, double u_own, unsigned &nsteps) {
+    double t_end; int owner;
+    ovl_march<true>(A, l, dust, p.x, p.y, p.z, p.kx, p.ky, p.kz, p.xfreq, tau_in, u_own, nsteps, t_end, owner);
+    p.x = p.x + t_end * p.kx; p.y = p.y + t_end * p.ky; p.z = p.z + t_end * p.kz;
+    p.icl = owner;
+    if (owner == 0) { p.inside = false; p.xfreq_ref = p.xfreq; tally_escape(A.par, A.t, p); }
+}
+
 // tau to the grid edge (dist < 0) or to a finite distance (raytrace_to_dist_car :89-195, VAR 0 only)
 template <int VAR>
 __device__ inline void edge_begin(const KArgs &A, const Lds &l, bool dust, const Photon &p, double xfreq, double kx, double ky, double kz, double dist, EdgeMarch &m, unsigned &nsteps) {
     m.live = true; m.tau = 0.0; m.d = 0.0; m.xfreq = xfreq; m.dist = dist; m.kx = kx; m.ky = ky; m.kz = kz;
     if (VAR == 3) { edge_begin_amr(A, p, m); return; }
     if (VAR == 4) { edge_begin_clump(A, l, dust, p, m, nsteps); return; }
+    if (VAR == 7) { double te_; int ow_; m.tau = ovl_march<false>(A, l, dust, p.x, p.y, p.z, kx, ky, kz, xfreq, LART_TAU_HUGE, 0.0, nsteps, te_, ow_); m.live = false; return; }   // one piece: the event lists do not survive between steps
     const DGrid &g = A.g;
     m.t.kx = kx; m.t.ky = ky; m.t.kz = kz; m.t.ic = p.ic; m.t.jc = p.jc; m.t.kc = p.kc;
     double xp = p.x, yp = p.y;
@@ -1277,9 +1407,10 @@ __device__ inline void raytrace_to_tau_amr(const KArgs &A, const Lds &l, bool du
 
 // march to optical depth tau_in; moves the packet, re-expresses xfreq at every crossing, tallies escape
 template <int VAR>
-__device__ inline void raytrace_to_tau(const KArgs &A, const Lds &l, bool dust, Photon &p, double tau_in, unsigned &nsteps) {
+__device__ inline void raytrace_to_tau(const KArgs &A, const Lds &l, bool dust, Photon &p, double tau_in, unsigned &nsteps, double u_own = 0.0) {
     if (VAR == 3) { raytrace_to_tau_amr(A, l, dust, p, tau_in, nsteps); return; }
     if (VAR == 4) { raytrace_to_tau_clump(A, l, dust, p, tau_in, nsteps); return; }
+    if (VAR == 7) { raytrace_to_tau_clump_ovl(A, l, dust, p, tau_in, u_own, nsteps); return; }
     const DGrid &g = A.g;
 #ifndef LART_NO_FAST_FLIGHT
     // Fast path: the flight ends inside the cell it starts in (99.6 % of the flights at tau0 = 1e6: the line-centre depth of one cell is
@@ -1464,7 +1595,7 @@ __device__ inline void add_if(double *arr, size_t i, double v, unsigned &natom) 
 // bulk velocity along the peel direction: the owner clump's in clump mode (peelingoff_rect.f90:65-68, 186-187, 403-404, 534-535, 658-659)
 template <int VAR>
 __device__ inline double peel_u1(const KArgs &A, const Photon &p, const Cell &c, const PeelDir &q) {
-    if (VAR == 4 && p.icl > 0) return ulos_clump(A, A.cl.phys[p.icl - 1], q.kx, q.ky, q.kz);
+    if (is_clump(VAR) && p.icl > 0) return ulos_clump(A, A.cl.phys[p.icl - 1], q.kx, q.ky, q.kz);
     return c.vfx * q.kx + c.vfy * q.ky + c.vfz * q.kz;
 }
 // azimuth about the (m,n,k) triad and the peel reference normal: :356-385 (= :204-224)
@@ -1487,7 +1618,7 @@ __device__ inline bool peel_head_direct(const KArgs &A, const DObs &o, const Pho
     q = peel_dir0(A, o, p);
     if (!q.in_image) return false;
     xf = p.xfreq;
-    if (VAR == 4 && p.icl > 0) xfreq_ref = p.xfreq + peel_u1<VAR>(A, p, c, q);      // clump frame -> lab frame along the peel direction
+    if (is_clump(VAR) && p.icl > 0) xfreq_ref = p.xfreq + peel_u1<VAR>(A, p, c, q);      // clump frame -> lab frame along the peel direction
     else if (!A.par.comoving_source) {
         double u1 = c.vfx * p.kx + c.vfy * p.ky + c.vfz * p.kz; xfreq_ref = p.xfreq + u1;
         double u2 = c.vfx * q.kx + c.vfy * q.ky + c.vfz * q.kz; xf = xfreq_ref - u2;
@@ -1668,6 +1799,7 @@ __device__ inline bool peel_ray_begin(const KArgs &A, int kind, const Photon &p,
 template <int VAR, bool STOKES>
 __device__ inline bool peel_all_opaque(const KArgs &A, const Lds &l, int kind, const Photon &p, double xa, double ux, double uy, double uz, double grec, bool dust) {
     if (kind == PEEL_DIRECT || A.heal_nside > 0 || VAR == 1) return false;
+    if (VAR == 7) return false;                              // the ray may cross any number of clumps from its first metre on
     if (VAR == 4 && p.icl <= 0) return false;
     if (VAR != 3 && VAR != 4 && (p.ic < 1 || p.ic > A.g.nx || p.jc < 1 || p.jc > A.g.ny || p.kc < 1 || p.kc > A.g.nz)) return false;
     Photon pp = p; pp.xfreq = xa;
@@ -1722,7 +1854,7 @@ __device__ inline void peel_emit(const KArgs &A, const Lds &l, bool dust, int ki
     if (STOKES) { f[PQ_MX * C + r] = p.mx; f[PQ_MY * C + r] = p.my; f[PQ_MZ * C + r] = p.mz;
                   f[PQ_Q * C + r] = p.Q; f[PQ_U * C + r] = p.U; f[PQ_V * C + r] = p.V; }
     int *q = A.pq.cell;
-    q[r] = p.ic; q[C + r] = p.jc; q[2 * C + r] = (VAR == 4) ? p.icl : p.kc; q[3 * C + r] = kind;
+    q[r] = p.ic; q[C + r] = p.jc; q[2 * C + r] = is_clump(VAR) ? p.icl : p.kc; q[3 * C + r] = kind;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1796,7 +1928,7 @@ __device__ inline bool scatter_pre(const KArgs &A, const Lds &l, Rng &g, Photon 
     // clump mode (scattering_car.f90:69-84, line_clump_mod.f90:30-59): opacities, Voigt parameter and Doppler width of the owner clump;
     // scale = Dfreq_ref / Dfreq_clump moves x into the clump's local Doppler units for the sampler and back
     double cl_scale = 1.0, cl_Dfreq = c.Dfreq, cl_rhokap = c.rhokap, cl_rhokapD = c.rhokapD;
-    if (VAR == 4) { const ClumpPhys ph = A.cl.phys[p.icl - 1]; va = ph.voigt_a; cl_Dfreq = ph.Dfreq; cl_rhokap = ph.rhokap; cl_rhokapD = ph.rhokapD; cl_scale = A.cl.Dfreq_ref / ph.Dfreq; }
+    if (is_clump(VAR)) { const ClumpPhys ph = A.cl.phys[p.icl - 1]; va = ph.voigt_a; cl_Dfreq = ph.Dfreq; cl_rhokap = ph.rhokap; cl_rhokapD = ph.rhokapD; cl_scale = A.cl.Dfreq_ref / ph.Dfreq; }
     if (DUST) {
         double rD = cl_rhokapD;
         double p_dust = rD / (cl_rhokap * calc_voigt(l, p.xfreq * cl_scale, va, cl_Dfreq) + rD);
@@ -1824,12 +1956,13 @@ __device__ inline bool scatter_pre(const KArgs &A, const Lds &l, Rng &g, Photon 
         }
     }
     // resonance scattering: scatter_resonance_nostokes :660-827 / _stokes :331-486
+    if (VAR == 7) p.xfreq = p.xfreq - ulos_clump(A, A.cl.phys[p.icl - 1], p.kx, p.ky, p.kz);   // scatter_resonance_clump_*: global -> owner frame (:898-937)
     p.nsg = p.nsg + p.wgt;
     if (A.jpa.calc_P && c.rhokap > 0.0) {                      // add_to_Pa: scattering_car.f90:830-859
         int ib = (VAR == 3) ? amr_JPa_bin(A.amr, p.ic, p.x, p.y, p.z) : A.jpa.ind_bin[cidx(A.g, p.ic, p.jc, p.kc)];   // add_to_Pa_amr: scattering_amr.f90:917-942
         if (ib >= 1) atomicAdd(&(l.jp_P ? l.jp_P : A.jpa.P1)[ib - 1], p.wgt / (c.rhokap * c.Dfreq / A.jpa.cross0));
     }
-    sc.va = va; sc.cl_scale = cl_scale; sc.cl_Dfreq = cl_Dfreq; sc.xloc = (VAR == 4) ? p.xfreq * cl_scale : p.xfreq;
+    sc.va = va; sc.cl_scale = cl_scale; sc.cl_Dfreq = cl_Dfreq; sc.xloc = is_clump(VAR) ? p.xfreq * cl_scale : p.xfreq;
     sc.xsamp = sc.xloc; sc.dnu = 0.0; sc.vsamp = va; sc.species = 1; sc.iup = 0;
     if (l.lt == 4 && l.ml_nup > 1) {                           // do_resonance5 / 6 (line_mod.f90:358-376, :421-449): which upward transition
         const double Dx2 = l.ml_dE[1] / cl_Dfreq, va2 = va * l.ml_damp[1] / l.ml_damp[0];
@@ -1866,7 +1999,7 @@ __device__ inline void scatter_post(const KArgs &A, const Lds &l, Rng &g, Photon
     double uz, xfreq_atom;
     const bool deut = (l.lt == 7) && sc.species == 2;          // a deuterium atom scattered (line%selected_species_HD = 2)
     if (deut) uz_loc = uz_loc / l.hd_ratio;                    // D Doppler units -> the photon's H units (line_mod.f90:507)
-    if (VAR == 4) { double scale_inv = 1.0 / sc.cl_scale; xfreq_atom = (sc.xloc - uz_loc) * scale_inv; uz = uz_loc * scale_inv; }
+    if (is_clump(VAR)) { double scale_inv = 1.0 / sc.cl_scale; xfreq_atom = (sc.xloc - uz_loc) * scale_inv; uz = uz_loc * scale_inv; }
     else { uz = uz_loc; xfreq_atom = p.xfreq - uz; }
     double S11 = 0, S22 = 0, S12 = 0, S33 = 0, S44 = 0, sinp, cosp, cost, cost2, sint;
     double E1 = par.E1, E2 = par.E2, E3 = par.E3;              // photon%E1..E3 of this event (the peel routines read them)
@@ -1877,12 +2010,12 @@ __device__ inline void scatter_post(const KArgs &A, const Lds &l, Rng &g, Photon
             const int k = (int)floor(nd * u1);                 // rand_alias_choise (random_mt.f90:2122-2135), 0-based here
             idown = (u2 < l.ml_tab[48 + sc.iup * 4 + k]) ? k : l.ml_itab[3 + sc.iup * 4 + k] - 1;
             const double del_xfreq = l.ml_tab[sc.iup * 4 + idown] / sc.cl_Dfreq;
-            if (VAR == 4) { const double scale_inv = 1.0 / sc.cl_scale; xfreq_atom = (sc.xloc - uz_loc - del_xfreq) * scale_inv; }
+            if (is_clump(VAR)) { const double scale_inv = 1.0 / sc.cl_scale; xfreq_atom = (sc.xloc - uz_loc - del_xfreq) * scale_inv; }
             else xfreq_atom = xfreq_atom - del_xfreq;
         }
         E1 = l.ml_tab[12 + sc.iup * 4 + idown]; E2 = l.ml_tab[24 + sc.iup * 4 + idown]; E3 = l.ml_tab[36 + sc.iup * 4 + idown];
         if (l.ml_coh && l.ml_nup == 3) {                        // par%HeI_coherent: compute_HeI_E_coherent (line_mod.f90:8-34) of the atom-frame frequency
-            const double D2 = (VAR == 4) ? sc.xloc - uz_loc : xfreq_atom, D1 = D2 + l.ml_dE[1] / sc.cl_Dfreq, D0 = D2 + l.ml_dE[2] / sc.cl_Dfreq;
+            const double D2 = is_clump(VAR) ? sc.xloc - uz_loc : xfreq_atom, D1 = D2 + l.ml_dE[1] / sc.cl_Dfreq, D0 = D2 + l.ml_dE[2] / sc.cl_Dfreq;
             const double D2D0 = D2 * D0, D2D1 = D2 * D1, D0D1 = D0 * D1, pp = D2 * D0 * D1;
             const double den = 4.0 * (D2D1 * D2D1 + 3.0 * D2D0 * D2D0 + 5.0 * D0D1 * D0D1);
             E1 = (3.0 * D2D0 * D2D0 + 7.0 * D0D1 * D0D1 + 8.0 * pp * D1 + 18.0 * pp * D0) / den;
@@ -1891,7 +2024,7 @@ __device__ inline void scatter_post(const KArgs &A, const Lds &l, Rng &g, Photon
         }
     }
     if (l.lt == 2) {                                           // do_resonance2 :166-171: E1 of the atom-frame frequency
-        const double qK = (VAR == 4) ? sc.xloc - uz_loc : xfreq_atom, qH = qK + sc.dnu;
+        const double qK = is_clump(VAR) ? sc.xloc - uz_loc : xfreq_atom, qH = qK + sc.dnu;
         E1 = (2.0 * qK * qH + qH * qH) / (qK * qK + 2.0 * qH * qH); E2 = 1.0 - E1; E3 = (E1 + 2.0) / 3.0;
     }
     if (STOKES) {
@@ -1918,7 +2051,7 @@ __device__ inline void scatter_post(const KArgs &A, const Lds &l, Rng &g, Photon
         ux = uxy * c2; uy = uxy * s2;
     }
     if (deut) { ux = ux / l.hd_ratio; uy = uy / l.hd_ratio; }  // scattering_car.f90:402-409, 417-424
-    if (VAR == 4) { double vth_ratio = sc.cl_Dfreq / A.cl.Dfreq_ref; ux = ux * vth_ratio; uy = uy * vth_ratio; }   // scattering_car.f90:384-388, 715-719
+    if (is_clump(VAR)) { double vth_ratio = sc.cl_Dfreq / A.cl.Dfreq_ref; ux = ux * vth_ratio; uy = uy * vth_ratio; }   // scattering_car.f90:384-388, 715-719
     p.xfreq = xfreq_atom + uz * cost + (ux * cosp + uy * sinp) * sint;
     const double g_rec0 = deut ? par.g_recoil0_D : par.g_recoil0;      // :427-437
     if (par.recoil) p.xfreq = p.xfreq - (g_rec0 / sc.cl_Dfreq) * (1.0 - cost);
@@ -1933,6 +2066,7 @@ __device__ inline void scatter_post(const KArgs &A, const Lds &l, Rng &g, Photon
         if (PEEL) peel_emit<VAR, STOKES>(A, l, DUST, PEEL_RESONANCE, p, xfreq_atom, ux, uy, uz, E1, E2, E3, g_rec0, npeel);   // peeling_resonance_nostokes_outside, deferred
         rotate_k(p, cost, sint, cosp, sinp);
     }
+    if (VAR == 7) p.xfreq = p.xfreq + ulos_clump(A, A.cl.phys[p.icl - 1], p.kx, p.ky, p.kz);   // ... and back to the global frame along the new direction
 }
 // par%save_all_photons (run_simulation_mod.f90:249-358): the record of photon k.  The impact parameter |r - (r.k)k| does not change along
 // the ray, so the reference's move to the sphere's surface (:302-324) drops out.
@@ -2016,7 +2150,7 @@ __device__ inline void generate_photon(const KArgs &A, const Lds &l, Rng &g, Pho
     d_sincos_2pi(g.next(), &sinp, &cosp);
     p.kx = sint * cosp; p.ky = sint * sinp; p.kz = cost;
     if (VAR == 3) { p.ic = amr_find_leaf(A.amr, p.x, p.y, p.z); p.jc = 1; p.kc = 1; if (p.ic <= 0) p.ic = 1; }   // generate_photon.f90:375-379 (source inside the box)
-    else if (VAR == 4) { p.ic = 1; p.jc = 1; p.kc = 1; }                       // the background grid is uniform (grid_mod_clump.f90:101-108): one record
+    else if (is_clump(VAR)) { p.ic = 1; p.jc = 1; p.kc = 1; }                       // the background grid is uniform (grid_mod_clump.f90:101-108): one record
     else {
     p.ic = (int)floor((p.x - gr.xmin) / gr.dx) + 1; p.jc = (int)floor((p.y - gr.ymin) / gr.dy) + 1; p.kc = (int)floor((p.z - gr.zmin) / gr.dz) + 1;
     if (p.kx < 0.0 && p.ic == gr.nx + 1) p.ic = gr.nx;
@@ -2029,7 +2163,7 @@ __device__ inline void generate_photon(const KArgs &A, const Lds &l, Rng &g, Pho
     if (STOKES) { p.mx = cost * cosp; p.my = cost * sinp; p.mz = -sint; p.nx = -sinp; p.ny = cosp; p.nz = 0.0; p.Q = 0.0; p.U = 0.0; p.V = 0.0; }
     p.nsg = 0.0; p.nsd = 0.0; p.inside = true; p.xfreq = par.xfreq0; p.xfreq_ref = 0.0;
     // a source outside the medium box never reaches a table in the reference's configs; clamp the gather
-    const Cell &c = (VAR == 3 || VAR == 4) ? gr.cell[p.ic - 1] : gr.cell[cidx(gr, clampi(p.ic, 1, gr.nx), clampi(p.jc, 1, gr.ny), clampi(p.kc, 1, gr.nz))];
+    const Cell &c = (VAR == 3 || is_clump(VAR)) ? gr.cell[p.ic - 1] : gr.cell[cidx(gr, clampi(p.ic, 1, gr.nx), clampi(p.jc, 1, gr.ny), clampi(p.kc, 1, gr.nz))];
     if (l.lt == 2 && par.spectral_type != 2) { const double dnu = l.dnu_hz / c.Dfreq; if (g.next() <= 1.0 / 3.0) p.xfreq = p.xfreq - dnu; }   // the source feeds both levels (generate_photon.f90:160-167; not for a continuum)
     if (l.lt == 4 && par.spectral_type != 2) {                 // :168-243: the source feeds the levels by f12 and every downward channel by its branching ratio
         int iup = 0;

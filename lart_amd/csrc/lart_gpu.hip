@@ -20,6 +20,7 @@ extern "C" void lart_launch_transport_var3(int, int, int, dim3, dim3, size_t, hi
 extern "C" void lart_launch_transport_var4(int, int, int, dim3, dim3, size_t, hipStream_t, const KArgs &);
 extern "C" void lart_launch_transport_var5(int, int, int, dim3, dim3, size_t, hipStream_t, const KArgs &);
 extern "C" void lart_launch_transport_var6(int, int, int, dim3, dim3, size_t, hipStream_t, const KArgs &);
+extern "C" void lart_launch_transport_var7(int, int, int, dim3, dim3, size_t, hipStream_t, const KArgs &);
 extern "C" void lart_launch_peel(int var, int stokes, dim3, dim3, dim3, size_t, hipStream_t, const KArgs &);
 
 static thread_local std::string g_err;
@@ -44,7 +45,7 @@ struct lart_gpu {
     // octree (VAR 3)
     bool is_amr = false; DAmr amr{}; int *d_amr_int = nullptr; AmrGeom *d_amr_geom = nullptr;
     // clump medium (VAR 4)
-    bool is_clump = false; DClumps cl{}; ClumpGeo *d_cl_geo = nullptr; ClumpPhys *d_cl_phys = nullptr; int *d_cl_int = nullptr;
+    bool is_clump = false, clump_overlap = false; DClumps cl{}; ClumpGeo *d_cl_geo = nullptr; ClumpPhys *d_cl_phys = nullptr; int *d_cl_int = nullptr;
     // fused tally buffer
     double *d_tally = nullptr; int64_t ntally = 0; DTally t{};
     DRep rep{}; bool rep_dirty = false;                      // per-XCD copies of the contended tally sections
@@ -422,7 +423,15 @@ extern "C" int lart_gpu_set_clumps(lart_gpu *c, int64_t n, const double *x, cons
     c->g = DGrid{}; c->g.nx = 1; c->g.ny = 1; c->g.nz = 1; c->g.i0 = 1; c->g.j0 = 1; c->g.k0 = 1;
     c->g.xmin = -sphere_R; c->g.ymin = -sphere_R; c->g.zmin = -sphere_R; c->g.dx = 2 * sphere_R; c->g.dy = 2 * sphere_R; c->g.dz = 2 * sphere_R;
     c->g.cell = c->d_cell; c->g.faces = c->d_faces; c->ncell = 1; c->has_dust_table = rhokapD != nullptr;
-    c->is_clump = true; c->is_amr = false; c->jpa.nbins = 0; invalidate_run(c);
+    c->is_clump = true; c->clump_overlap = false; c->is_amr = false; c->jpa.nbins = 0; invalidate_run(c);
+    return 0;
+}
+// setup_clump_overlap (setup.f90:1053-1082): the overlap-aware marches and scattering wrappers for a population with has_overlap = .true.
+extern "C" int lart_gpu_set_clump_overlap(lart_gpu *c, int32_t has_overlap) {
+    if (!c) return fail("set_clump_overlap: null context");
+    if (!c->is_clump) return fail("set_clump_overlap: call lart_gpu_set_clumps first");
+    if (has_overlap && c->par.line_type != 1) return fail("set_clump_overlap: overlapping clumps are built for single-line profiles (line_type 1) only");
+    c->clump_overlap = has_overlap != 0; invalidate_run(c);
     return 0;
 }
 
@@ -467,7 +476,7 @@ static int ensure_pool(lart_gpu *c) {
 
 // the ray-march variant, chosen as setup_procedure does (setup.f90:951-980)
 static int march_variant(const lart_gpu *c) {
-    if (c->is_clump) return 4;
+    if (c->is_clump) return c->clump_overlap ? 7 : 4;
     if (c->is_amr) return 3;
     if (c->par.xyz_symmetry) return 1;
     if (c->par.xy_symmetry) return 5;
@@ -668,7 +677,8 @@ extern "C" int lart_gpu_step(lart_gpu *c, int32_t nsteps, int32_t max_events) {
             else if (var == 3) lart_launch_transport_var3(stokes, dust, peel, grid, block, shmem, c->stream, A);
             else if (var == 4) lart_launch_transport_var4(stokes, dust, peel, grid, block, shmem, c->stream, A);
             else if (var == 5) lart_launch_transport_var5(stokes, dust, peel, grid, block, shmem, c->stream, A);
-            else lart_launch_transport_var6(stokes, dust, peel, grid, block, shmem, c->stream, A);
+            else if (var == 6) lart_launch_transport_var6(stokes, dust, peel, grid, block, shmem, c->stream, A);
+            else lart_launch_transport_var7(stokes, dust, peel, grid, block, shmem, c->stream, A);
             HIPCHK(hipGetLastError());
             if (peel) {
                 // the peel kernels of this slice run on the second stream, next to the transport kernel of the next slice: the march is bound
@@ -769,6 +779,7 @@ extern "C" int lart_gpu_get_tallies(lart_gpu *c, lart_tallies *o) {
     HIPCHK(hipStreamSynchronize(c->stream));
     if (collect_events(c)) return 1;
     double s[16]; HIPCHK(hipMemcpy(s, c->d_tally, sizeof s, hipMemcpyDeviceToHost));
+    if (s[7] > 0.0) return fail("get_tallies: a ray met more overlapping clumps than the march lists hold (LART_OVL_ACT clumps around a point, LART_OVL_PEND events ahead): the result is not the reference's");
     o->nscatt_gas = s[0]; o->nscatt_dust = s[1]; o->n_events = s[2]; o->n_cellsteps = s[3]; o->n_cellsteps_peel = s[4]; o->n_atomics = s[6]; o->nphotons_done = (int64_t)(s[5] + 0.5);
     DCtl h{}; HIPCHK(hipMemcpy(&h, c->d_ctl, sizeof h, hipMemcpyDeviceToHost)); o->nphotons_active = (int64_t)h.n_active;
     int64_t nxf = c->par.nxfreq, n2 = (int64_t)c->nobs * c->nxim * c->nyim, n3 = n2 * nxf;
@@ -941,12 +952,12 @@ template <int VAR>
 __device__ void test_ray_one(const KArgs &A, const Lds &l, int kind, double *r, int *ic, double tq, double *tau_out) {
     Photon p{}; p.x = r[0]; p.y = r[1]; p.z = r[2]; p.kx = r[3]; p.ky = r[4]; p.kz = r[5]; p.xfreq = r[6]; p.wgt = r[7];
     p.ic = ic[0]; p.jc = ic[1]; p.kc = ic[2]; p.inside = ic[3] != 0;
-    if (VAR == 4) { p.icl = ic[0]; p.ic = 1; p.jc = 1; p.kc = 1; }          // clump mode: ic[0] carries the owner clump (0 = vacuum)
+    if (is_clump(VAR)) { p.icl = ic[0]; p.ic = 1; p.jc = 1; p.kc = 1; }          // clump mode: ic[0] carries the owner clump (0 = vacuum)
     unsigned ns = 0; bool dust = A.par.DGR > 0.0;
     if (kind == 0) {
         raytrace_to_tau<VAR>(A, l, dust, p, tq, ns);
         r[0] = p.x; r[1] = p.y; r[2] = p.z; r[3] = p.kx; r[4] = p.ky; r[5] = p.kz; r[6] = p.xfreq; r[7] = p.wgt;
-        ic[0] = (VAR == 4) ? p.icl : p.ic; ic[1] = p.jc; ic[2] = p.kc; ic[3] = p.inside ? 1 : 0;
+        ic[0] = is_clump(VAR) ? p.icl : p.ic; ic[1] = p.jc; ic[2] = p.kc; ic[3] = p.inside ? 1 : 0;
     } else *tau_out = raytrace_to_edge<VAR>(A, l, dust, p, p.xfreq, p.kx, p.ky, p.kz, kind == 2 ? tq : -1.0, ns);
 }
 __global__ void k_test_raytrace(KArgs A, int mode, int n, double *r8, int *ic4, const double *tq, double *tau_out) {
@@ -973,7 +984,7 @@ __device__ void test_scatter_one(const KArgs &A, const Lds &l, double *st, int *
     Photon p{}; p.x = st[0]; p.y = st[1]; p.z = st[2]; p.kx = st[3]; p.ky = st[4]; p.kz = st[5]; p.xfreq = st[6]; p.wgt = st[7];
     p.mx = st[8]; p.my = st[9]; p.mz = st[10]; p.nx = st[11]; p.ny = st[12]; p.nz = st[13]; p.Q = st[15]; p.U = st[16]; p.V = st[17];
     p.ic = ic[0]; p.jc = ic[1]; p.kc = ic[2]; p.inside = true;
-    if (VAR == 4) { p.icl = ic[0]; p.ic = 1; p.jc = 1; p.kc = 1; }
+    if (is_clump(VAR)) { p.icl = ic[0]; p.ic = 1; p.jc = 1; p.kc = 1; }
     Rng g; g.init(seed, id, 0); unsigned np = 0;
     scatter_event<VAR, STOKES, DUST, false>(A, l, g, p, np, true);
     st[0] = p.x; st[1] = p.y; st[2] = p.z; st[3] = p.kx; st[4] = p.ky; st[5] = p.kz; st[6] = p.xfreq; st[7] = p.wgt;
@@ -1089,6 +1100,7 @@ extern "C" int lart_gpu_sightline_tau(lart_gpu *c, double cross0, double *tau_ga
     if (!c->d_cell && !c->is_clump) return fail("sightline_tau: set the medium first");
     if (c->nobs < 1 || c->h_obs.size() != (size_t)c->nobs) return fail("sightline_tau: set the observers first (lart_gpu_set_observers / _heal)");
     if (!(cross0 > 0.0)) return fail("sightline_tau: cross0 (line%cross0) must be > 0");
+    if (c->is_clump && c->clump_overlap) return fail("sightline_tau: the overlap forms of the sight-line marches (raytrace_clump.f90:922-1001) are not built");
     if (c->par.xyz_symmetry || c->par.xy_periodic || c->par.xy_symmetry) return fail("sightline_tau: needs the plain medium (no observers with xyz_symmetry / xy_periodic, setup.f90:198-206)");
     if (c->is_clump && c->heal_nside > 0) return fail("sightline_tau: HEALPix inside observers are not supported with the clump medium (setup.f90:177)");
     if (c->par.nxfreq < 1) return fail("sightline_tau: nxfreq must be >= 1");

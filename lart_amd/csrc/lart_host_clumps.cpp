@@ -32,11 +32,12 @@ struct Mt {
 extern "C" const char *lart_host_last_error(void) { return h_err.c_str(); }
 
 // generate_clumps, uniform path: clump_mod.f90:897-1151
-extern "C" int lart_host_clumps_generate(int64_t n, double sphere_R, double r_min, double clump_radius, int32_t fully_inside,
+extern "C" int lart_host_clumps_generate(int64_t n, double sphere_R, double r_min, double clump_radius, int32_t flags,
                                          double sigma_v_over_vtherm, int64_t iseed, double *x, double *y, double *z,
                                          double *vx, double *vy, double *vz, double *acceptance) {
     if (n < 1 || !(sphere_R > 0.0) || !(clump_radius > 0.0) || r_min < 0.0 || r_min >= sphere_R || !x || !y || !z || !vx || !vy || !vz)
         return hfail("clumps_generate: bad argument");
+    const bool fully_inside = flags & 1, allow_overlap = flags & 2;      // par%clump_fully_inside, par%clump_allow_overlap (:1090: the overlap test runs, the trial is kept)
     if (fully_inside && (clump_radius >= sphere_R || r_min + 2.0 * clump_radius > sphere_R))
         return hfail("clumps_generate: clump_fully_inside but no clump fits inside the shell (clump_mod.f90:937-951)");
     int rg = (int)std::pow((double)n, 1.0 / 3.0) + 1; if (rg < 32) rg = 32; if (rg > 512) rg = 512;
@@ -69,7 +70,7 @@ extern "C" int lart_host_clumps_generate(int64_t n, double sphere_R, double r_mi
                         double dx = xc - x[jnb - 1], dy = yc - y[jnb - 1], dz = zc - z[jnb - 1];
                         if (dx * dx + dy * dy + dz * dz < min_sep2) { overlap = true; break; }
                     }
-        if (overlap) continue;
+        if (overlap && !allow_overlap) continue;
         icl++;
         x[icl - 1] = xc; y[icl - 1] = yc; z[icl - 1] = zc;
         vx[icl - 1] = 0.0; vy[icl - 1] = 0.0; vz[icl - 1] = 0.0;
@@ -112,5 +113,28 @@ extern "C" int lart_host_clumps_build_csr(int64_t n, const double *x, const doub
     for (int64_t i = 0; i < n; i++) { range(i, r);
         for (int k = r[4]; k <= r[5]; k++) for (int j = r[2]; j <= r[3]; j++) for (int ii = r[0]; ii <= r[1]; ii++) {
             size_t q = (size_t)ii + (size_t)j * cgx + (size_t)k * cgx * cgx; cg_list[cg_start[q] - 1 + cnt[q]] = (int32_t)(i + 1); cnt[q]++; } }
+    return 0;
+}
+
+// check_has_overlap: clump_mod.f90:1544-1591 (any pair of clumps closer than the sum of its radii, searched through the CSR cells)
+extern "C" int lart_host_clumps_has_overlap(int64_t n, const double *x, const double *y, const double *z, const double *radius,
+                                            int32_t cgx, double cg_min, double cg_d, const int32_t *cg_start, const int32_t *cg_list, int32_t *has_overlap) {
+    if (n < 1 || !x || !y || !z || !radius || cgx < 1 || !(cg_d > 0.0) || !cg_start || !cg_list || !has_overlap) return hfail("clumps_has_overlap: bad argument");
+    const double inv = 1.0 / cg_d; const int m = cgx - 1;
+    *has_overlap = 0;
+    for (int64_t i = 0; i < n; i++) {
+        const double rc = radius[i];
+        const int i0 = std::max(0, (int)((x[i] - cg_min - rc) * inv)), i1 = std::min(m, (int)((x[i] - cg_min + rc) * inv));
+        const int j0 = std::max(0, (int)((y[i] - cg_min - rc) * inv)), j1 = std::min(m, (int)((y[i] - cg_min + rc) * inv));
+        const int k0 = std::max(0, (int)((z[i] - cg_min - rc) * inv)), k1 = std::min(m, (int)((z[i] - cg_min + rc) * inv));
+        for (int k = k0; k <= k1; k++) for (int j = j0; j <= j1; j++) for (int ii = i0; ii <= i1; ii++) {
+            const size_t q = (size_t)ii + (size_t)j * cgx + (size_t)k * cgx * cgx;
+            for (int32_t ip = cg_start[q]; ip < cg_start[q + 1]; ip++) {
+                const int64_t jc = cg_list[ip - 1] - 1; if (jc <= i) continue;
+                const double dx = x[jc] - x[i], dy = y[jc] - y[i], dz = z[jc] - z[i], rs = radius[i] + radius[jc];
+                if (dx * dx + dy * dy + dz * dz < rs * rs) { *has_overlap = 1; return 0; }
+            }
+        }
+    }
     return 0;
 }

@@ -26,7 +26,7 @@ __device__ inline void peel_load(const KArgs &A, const Lds &l, size_t r, bool fu
     p.x = f[PQ_X * C + r]; p.y = f[PQ_Y * C + r]; p.z = f[PQ_Z * C + r]; p.kx = f[PQ_KX * C + r]; p.ky = f[PQ_KY * C + r]; p.kz = f[PQ_KZ * C + r];
     p.xfreq = f[PQ_XA * C + r]; p.nsg = 0.0; p.nsd = 0.0; p.xfreq_ref = 0.0; p.inside = true; p.wgt = 0.0; p.Q = 0.0; p.U = 0.0; p.V = 0.0;
     p.ic = qc[r]; p.jc = qc[C + r]; p.kc = qc[2 * C + r]; p.icl = 0;
-    if (VAR == 4) { p.icl = p.kc; p.kc = 1; }
+    if (is_clump(VAR)) { p.icl = p.kc; p.kc = 1; }
     kind = qc[3 * C + r];
     ux = 0.0; uy = 0.0; uz = 0.0; E1 = 0.0; E2 = 0.0; E3 = 0.0; grec = 0.0;
     if (kind == PEEL_RESONANCE) { ux = f[PQ_UX * C + r]; uy = f[PQ_UY * C + r]; uz = f[PQ_UZ * C + r]; grec = (l.lt != 1) ? f[PQ_GREC * C + r] : A.par.g_recoil0; }

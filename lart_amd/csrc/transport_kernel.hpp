@@ -44,11 +44,13 @@ __device__ inline void fly(const KArgs &A, const Lds &l, Rng &g, Photon &p, bool
         tau = (tau0 > 0.0) ? -d_log(1.0 - g.next() * wgt1) : LART_HUGEST;
         first = false;
     } else tau = -d_log(g.next());
+    double u_own = 0.0;
+    if (VAR == 7) u_own = g.next();                        // the draw of sample_owner_clump (raytrace_clump.f90:648), taken here: a packet that escapes instead has no later draw to shift
     LART_PROF_MARK(p, 2);
 #ifdef LART_EXPERIMENT_RAY2                            // timing experiment: cost of one flight (the copy's escapes are tallied twice: timing only)
     { Photon p2 = p; unsigned ns2 = 0; raytrace_to_tau<VAR>(A, l, DUST, p2, tau, ns2); if (p2.x == 1e300) p.x = p2.y; }
 #endif
-    raytrace_to_tau<VAR>(A, l, DUST, p, tau, nsteps);
+    raytrace_to_tau<VAR>(A, l, DUST, p, tau, nsteps, u_own);
     LART_PROF_MARK(p, 3);
 }
 
@@ -112,7 +114,7 @@ __global__ __launch_bounds__(256, LART_WAVES(STOKES, PEEL)) void transport_kerne
             p.Q = F[F_Q * P + lane]; p.U = F[F_U * P + lane]; p.V = F[F_V * P + lane];
         }
         p.ic = A.pool.ic[lane]; p.jc = A.pool.jc[lane]; p.kc = A.pool.kc[lane]; p.inside = true; p.xfreq_ref = 0.0; p.icl = 0;
-        if (VAR == 4) { p.icl = p.ic; p.ic = 1; }               // clump mode keeps the owner clump in the cell-index plane
+        if (is_clump(VAR)) { p.icl = p.ic; p.ic = 1; }               // clump mode keeps the owner clump in the cell-index plane
         g.init(A.seed, (uint64_t)(A.first_id + k * A.stride), A.pool.rng_n[lane]);
     }
 
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(256, LART_WAVES(STOKES, PEEL)) void transport_kerne
             F[F_NX * P + lane] = p.nx; F[F_NY * P + lane] = p.ny; F[F_NZ * P + lane] = p.nz;
             F[F_Q * P + lane] = p.Q; F[F_U * P + lane] = p.U; F[F_V * P + lane] = p.V;
         }
-        A.pool.ic[lane] = (VAR == 4) ? p.icl : p.ic; A.pool.jc[lane] = p.jc; A.pool.kc[lane] = p.kc;
+        A.pool.ic[lane] = is_clump(VAR) ? p.icl : p.ic; A.pool.jc[lane] = p.jc; A.pool.kc[lane] = p.kc;
     }
 #ifdef LART_PROFILE
     LART_PROF_MARK(p, 0);

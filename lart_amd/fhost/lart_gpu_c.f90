@@ -139,6 +139,16 @@ module lart_gpu_c
        integer(c_int64_t), intent(out) :: nreg
        integer(c_int) :: rc
      end function
+     function lart_host_clumps_has_overlap(n, x, y, z, radius, cgx, cg_min, cg_d, cg_start, cg_list, has_overlap) bind(C, name='lart_host_clumps_has_overlap') result(rc)
+       import; integer(c_int64_t), value :: n; real(c_double), intent(in) :: x(*), y(*), z(*), radius(*)
+       integer(c_int32_t), value :: cgx; real(c_double), value :: cg_min, cg_d
+       integer(c_int32_t), intent(in) :: cg_start(*), cg_list(*)
+       integer(c_int32_t), intent(out) :: has_overlap
+       integer(c_int) :: rc
+     end function
+     function lart_gpu_set_clump_overlap(ctx, has_overlap) bind(C, name='lart_gpu_set_clump_overlap') result(rc)
+       import; type(c_ptr), value :: ctx; integer(c_int32_t), value :: has_overlap; integer(c_int) :: rc
+     end function
      function lart_gpu_set_grid_amr(ctx, ncells, nleaf, lo, hi, cx, cy, cz, ch, children, neighbor, ileaf, icell_of_leaf, &
                                     rhokap, voigt_a, Dfreq, vfx, vfy, vfz, rhokapD) bind(C, name='lart_gpu_set_grid_amr') result(rc)
        import; type(c_ptr), value :: ctx; integer(c_int32_t), value :: ncells, nleaf; real(c_double), value :: lo, hi

@@ -243,6 +243,7 @@ module lart_define
   integer(int32) :: cgx = 0
   real(wp) :: cg_xmin = 0.0_wp, cg_dx = 0.0_wp
   integer(int32), allocatable, target :: cg_start(:), cg_list(:)
+  logical :: has_overlap = .false.                ! clump_mod.f90:88
 
 contains
   elemental function is_finite(x) result(r)
@@ -362,7 +363,6 @@ contains
     if (.not. par%continuum_normalize) call not_supported('par%continuum_normalize')
     if (par%EW_line /= 0.0_wp) call not_supported('par%EW_line')
     if (par%f_line /= 0.0_wp) call not_supported('par%f_line')
-    if (par%clump_allow_overlap) call not_supported('par%clump_allow_overlap')
     if (trim(par%clump_radius_profile) /= 'constant') call not_supported('par%clump_radius_profile')
     if (trim(par%clump_density_profile) /= 'constant') call not_supported('par%clump_density_profile')
     if (trim(par%clump_number_profile) /= 'constant') call not_supported('par%clump_number_profile')
@@ -1031,7 +1031,7 @@ contains
     real(wp), intent(in) :: R_sphere
     real(wp) :: temp_cl, vtherm, rc, shell2, GF_los, fvol_realized, fcov_realized, sig, acc
     real(c_double) :: cmin, cd
-    integer(c_int32_t) :: cg
+    integer(c_int32_t) :: cg, ovl
     integer(c_int64_t) :: nreg
     integer :: n
     sphere_R = R_sphere
@@ -1096,9 +1096,14 @@ contains
     endif
     sig = 0.0_wp
     if (par%clump_sigma_v > 0.0_wp) sig = par%clump_sigma_v/cl_vtherm_ref
-    call host_check(lart_host_clumps_generate(N_clumps, sphere_R, r_min_clump, rc, merge(1_c_int32_t, 0_c_int32_t, par%clump_fully_inside), &
+    call host_check(lart_host_clumps_generate(N_clumps, sphere_R, r_min_clump, rc, &
+         merge(1_c_int32_t, 0_c_int32_t, par%clump_fully_inside) + merge(2_c_int32_t, 0_c_int32_t, par%clump_allow_overlap), &
          sig, int(par%iseed, c_int64_t), cl_x, cl_y, cl_z, cl_vx, cl_vy, cl_vz, acc), 'lart_host_clumps_generate')
-    write(*,'(a,f6.1,a)') ' RSA done, acceptance rate = ', acc*100.0_wp, '%'
+    if (par%clump_allow_overlap) then
+       write(*,'(a)') ' Random placement done (overlap allowed).'
+    else
+       write(*,'(a,f6.1,a)') ' RSA done, acceptance rate = ', acc*100.0_wp, '%'
+    endif
     if (len_trim(par%velocity_type) > 0) call assign_clump_velocities_from_type()
     call host_check(lart_host_clumps_csr_dims(N_clumps, sphere_R, cl_radius_max, cg, cmin, cd), 'lart_host_clumps_csr_dims')
     cgx = cg; cg_xmin = cmin; cg_dx = cd
@@ -1107,6 +1112,16 @@ contains
     allocate(cg_list(max(1_int64, nreg)))
     call host_check(lart_host_clumps_build_csr(N_clumps, cl_x, cl_y, cl_z, cl_radius, cgx, cg_xmin, cg_dx, cg_start, c_loc(cg_list), nreg), 'lart_host_clumps_build_csr')
     write(*,'(a,i12,a,i5,a)') ' CSR grid: ', nreg, ' registrations in ', cgx, '^3 cells.'
+    has_overlap = .false.
+    if (par%clump_allow_overlap) then               ! clump_mod.f90:889-891, check_has_overlap :1544-1591
+       call host_check(lart_host_clumps_has_overlap(N_clumps, cl_x, cl_y, cl_z, cl_radius, cgx, cg_xmin, cg_dx, cg_start, cg_list, ovl), 'lart_host_clumps_has_overlap')
+       has_overlap = ovl /= 0
+       if (has_overlap) then
+          write(*,'(a)') ' Overlap check: overlapping clumps detected — using overlap-aware raytrace.'
+       else
+          write(*,'(a)') ' Overlap check: no overlaps found — using standard raytrace.'
+       endif
+    endif
   end subroutine init_clumps
 
   !--- assign_clump_velocities_from_type: clump_mod.f90:1153-1264 (the fields this path supports)

@@ -190,6 +190,7 @@ contains
           call lart_check(lart_gpu_set_clumps(ctx, N_clumps, cl_x, cl_y, cl_z, cl_vx, cl_vy, cl_vz, cl_radius, cl_rhokap, c_null_ptr, &
                cl_voigt_a, cl_Dfreq, sphere_R, cl_Dfreq_ref, cl_voigt_a_ref, cgx, cg_xmin, cg_dx, cg_start, cg_list), 'lart_gpu_set_clumps')
        endif
+       if (has_overlap) call lart_check(lart_gpu_set_clump_overlap(ctx, 1), 'lart_gpu_set_clump_overlap')      ! setup_clump_overlap: setup.f90:1053-1082
     else if (par%DGR > 0.0_wp) then
        call lart_check(lart_gpu_set_grid_car(ctx, grid%nx, grid%ny, grid%nz, grid%xmin, grid%ymin, grid%zmin, grid%dx, grid%dy, grid%dz, &
             grid%i0, grid%j0, grid%k0, grid%xface, grid%yface, grid%zface, grid%rhokap, grid%voigt_a, grid%Dfreq, &

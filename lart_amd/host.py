@@ -154,6 +154,7 @@ class Params:
     clump_temperature: float = -1.0
     clump_sigma_v: float = 0.0
     clump_fully_inside: bool = True
+    clump_allow_overlap: bool = False
     save_clump_info: bool = False
     Vrot: float = 0.0
     rinner: float = 0.0
@@ -199,7 +200,6 @@ _UNSUPPORTED_DEFAULTS = {
     "continuum_normalize": True,
     "EW_line": 0.0,
     "f_line": 0.0,
-    "clump_allow_overlap": False,
     "clump_radius_profile": "constant",
     "clump_density_profile": "constant",
     "clump_number_profile": "constant",
@@ -1019,6 +1019,8 @@ class Simulation:
             c = self.clumps
             self.ctx.set_clumps(c.x, c.y, c.z, c.vx, c.vy, c.vz, c.radius, c.rhokap, c.rhokapD, c.voigt_a, c.Dfreq,
                                 c.sphere_R, c.Dfreq_ref, c.voigt_a_ref, c.cgx, c.cg_min, c.cg_d, c.cg_start, c.cg_list)
+            if c.has_overlap:                                             # setup_clump_overlap: setup.f90:1053-1082
+                self.ctx.set_clump_overlap(True)
         elif self.amr is not None:
             a = self.amr
             self.ctx.set_grid_amr(a.xmin, a.xmax, a.cx, a.cy, a.cz, a.ch, a.children, a.neighbor, a.ileaf, a.icell_of_leaf,

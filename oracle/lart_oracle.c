@@ -293,11 +293,12 @@ typedef struct {
     double *x, *y, *z, *vx, *vy, *vz, *radius, *radius2, *rhokap, *rhokapD, *voigt_a, *Dfreq, *vtherm;
     int cgx; double cg_min, cg_d, cg_inv; int32_t *cg_start, *cg_list; int64_t nreg;
     double fvol, fcov; int rsa_grid; double rsa_acceptance;
+    int has_overlap;                                         /* clump_mod.f90:88, set by check_has_overlap */
 } clumps_t;
 
 struct orc_sim {
     int use_amr_grid; char amr_file[512]; amr_t amr;
-    int use_clump_medium, clump_fully_inside; clumps_t cl;
+    int use_clump_medium, clump_fully_inside, clump_allow_overlap; clumps_t cl;
     double clump_radius, clump_N_clumps, clump_f_vol, clump_f_cov, clump_tau0, clump_NHI, clump_nH, clump_temperature, clump_sigma_v;
     int HeI_coherent;                        /* par%HeI_coherent (line type 6) */
     double bturb;                            /* par%bturb [km/s], <= 0: none */
@@ -376,7 +377,8 @@ static inline double calc_voigt(const orc_sim *s, double xfreq, double a, double
 
 /* per-thread accumulators, merged after the run */
 typedef struct { orc_sim *s; double *Jout, *Jin, *Jabs, *Jmu, *J1, *P1, *P1_new; obs_t obs[MAX_OBS];
-                 double nscatt_gas, nscatt_dust, n_cellsteps, n_cellsteps_peel, n_events; } acc_t;
+                 double nscatt_gas, nscatt_dust, n_cellsteps, n_cellsteps_peel, n_events;
+                 rng_t *g; } acc_t;                          /* the packet's stream, for the one draw inside the overlap march (sample_owner_clump) */
 
 /* =====================================================================================
  * Parameter parsing + read_input post-processing (setup.f90:42-562)
@@ -445,7 +447,7 @@ static int set_param(orc_sim *s, const char *k, const char *v) {
     if (!strcmp(k, "N_HImax") || !strcmp(k, "N_gasmax") || !strcmp(k, "N_HI")) { s->N_gasmax = atof(v); return 0; }
     if (!strcmp(k, "N_HIhomo") || !strcmp(k, "N_gashomo")) { s->N_gashomo = atof(v); return 0; }
     if (!strcmp(k, "tau0")) { s->taumax = atof(v); return 0; }
-    B(use_clump_medium) B(clump_fully_inside) D(clump_radius) D(clump_N_clumps) D(clump_f_vol) D(clump_f_cov) D(clump_tau0) D(clump_NHI) D(clump_nH)
+    B(use_clump_medium) B(clump_fully_inside) B(clump_allow_overlap) D(clump_radius) D(clump_N_clumps) D(clump_f_vol) D(clump_f_cov) D(clump_tau0) D(clump_NHI) D(clump_nH)
     D(clump_temperature) D(clump_sigma_v) D(Vrot) D(rinner) D(velocity_min) D(velocity_max) D(Vpeak) D(rpeak) D(DeltaV) D(velocity_alpha) D(gaussian_sigma_vel) D(gaussian_FWHM_vel) D(source_zscale) D(D_to_H_ratio) D(wavelength_min) D(wavelength_max) D(bturb)
     if (!strcmp(k, "use_amr_grid")) { s->use_amr_grid = parse_bool(v); return 0; }
     if (!strcmp(k, "amr_file")) { snprintf(s->amr_file, sizeof s->amr_file, "%s", v); return 0; }
@@ -1431,7 +1433,7 @@ static int generate_clumps(orc_sim *s, rng_t *g) {
                         jnb = nxt[jnb-1];
                     }
                 }
-        if (overlap) continue;
+        if (overlap && !s->clump_allow_overlap) continue;            /* :1090 */
         icl++;
         c->x[icl-1] = xc; c->y[icl-1] = yc; c->z[icl-1] = zc;
         if (s->clump_sigma_v > 0.0) {                                /* :1126-1131 */
@@ -1492,6 +1494,21 @@ static void build_clump_csr(clumps_t *c) {
             size_t q = CGIDX(c,ii,j,k); c->cg_list[c->cg_start[q] - 1 + cnt[q]] = (int32_t)(i + 1); cnt[q]++; } }
     free(cnt);
 }
+/* check_has_overlap: clump_mod.f90:1544-1591 (any pair closer than the sum of its radii) */
+static void check_has_overlap(clumps_t *c) {
+    c->has_overlap = 0;
+    for (int64_t i = 1; i <= c->N; i++) {
+        int r[6]; clump_cell_range(c, i, r);
+        for (int k = r[4]; k <= r[5]; k++) for (int j = r[2]; j <= r[3]; j++) for (int ii = r[0]; ii <= r[1]; ii++) {
+            size_t q = CGIDX(c,ii,j,k);
+            for (int32_t ip = c->cg_start[q]; ip <= c->cg_start[q+1] - 1; ip++) {
+                int64_t jc = c->cg_list[ip-1]; if (jc <= i) continue;
+                double dx = c->x[jc-1] - c->x[i-1], dy = c->y[jc-1] - c->y[i-1], dz = c->z[jc-1] - c->z[i-1], rs = c->radius[i-1] + c->radius[jc-1];
+                if (dx * dx + dy * dy + dz * dz < rs * rs) { c->has_overlap = 1; return; }
+            }
+        }
+    }
+}
 /* init_clumps, uniform path: clump_mod.f90:646-891 */
 static int init_clumps(orc_sim *s, double R_sphere) {
     clumps_t *c = &s->cl; memset(c, 0, sizeof *c);
@@ -1534,6 +1551,7 @@ static int init_clumps(orc_sim *s, double R_sphere) {
     if (rc_) return -1;
     if (s->velocity_type) assign_clump_velocities(s);
     build_clump_csr(c);
+    if (s->clump_allow_overlap) check_has_overlap(c);           /* :889-891 */
     return 0;
 }
 /* compute_clump_scalars: :2316-2378 */
@@ -1561,7 +1579,7 @@ static int grid_create_clump(orc_sim *s) {
     size_t nc = (size_t)s->nx * s->ny * s->nz;
     for (size_t i = 0; i < nc; i++) { s->rhokap[i] = 0.0; s->Dfreq[i] = s->cl.Dfreq_ref; s->voigt_a[i] = s->cl.voigt_a_ref; s->vfx[i] = s->vfy[i] = s->vfz[i] = 0.0; }
     s->Dfreq_ref = s->cl.Dfreq_ref; s->voigt_amean = s->cl.voigt_a_ref;
-    s->raytrace_variant = 4;
+    s->raytrace_variant = s->cl.has_overlap ? 7 : 4;               /* setup_clump_overlap: setup.f90:1053-1082 */
     return 0;
 }
 /* find_next_clump: clump_mod.f90:1390-1507 (DDA over the CSR grid, nearest entry first) */
@@ -1702,6 +1720,148 @@ static double raytrace_to_edge_clump(const orc_sim *s, const photon_t *p0, doubl
     return tau;
 }
 
+/* ---- overlapping clumps (raytrace_clump.f90:606-1208).  photon%xfreq stays in the GLOBAL frame during the flight; the Doppler shift
+ * into the owner clump's frame is applied by the scattering wrappers (scattering_car.f90:898-937). ---- */
+#define OVL_MAX_EVT 2048
+/* active_set_at_point: clump_mod.f90:1594-1634 (all clumps containing the point, 27 CSR cells, first-seen order) */
+static int active_set_at_point(const clumps_t *c, double xp, double yp, double zp, int64_t *active) {
+    int cg = c->cgx, n = 0;
+    int ci = (int)((xp - c->cg_min) * c->cg_inv), cj = (int)((yp - c->cg_min) * c->cg_inv), ck = (int)((zp - c->cg_min) * c->cg_inv);
+    if (ci > cg - 1) ci = cg - 1; if (ci < 0) ci = 0; if (cj > cg - 1) cj = cg - 1; if (cj < 0) cj = 0; if (ck > cg - 1) ck = cg - 1; if (ck < 0) ck = 0;
+    for (int k = (ck > 0 ? ck - 1 : 0); k <= (ck < cg - 1 ? ck + 1 : cg - 1); k++)
+        for (int j = (cj > 0 ? cj - 1 : 0); j <= (cj < cg - 1 ? cj + 1 : cg - 1); j++)
+            for (int i = (ci > 0 ? ci - 1 : 0); i <= (ci < cg - 1 ? ci + 1 : cg - 1); i++) {
+                size_t q = CGIDX(c,i,j,k);
+                for (int32_t ip = c->cg_start[q]; ip <= c->cg_start[q+1] - 1; ip++) {
+                    int64_t icl = c->cg_list[ip-1];
+                    double rx = xp - c->x[icl-1], ry = yp - c->y[icl-1], rz = zp - c->z[icl-1];
+                    if (rx * rx + ry * ry + rz * rz <= c->radius2[icl-1]) {
+                        int dup = 0; for (int m = 0; m < n; m++) if (active[m] == icl) { dup = 1; break; }
+                        if (!dup && n < OVL_MAX_EVT) active[n++] = icl;
+                    }
+                }
+            }
+    return n;
+}
+/* collect_ray_events_overlap: clump_mod.f90:1637-1759 (every ENTER/EXIT along the ray up to t_max, sorted by t; stable insertion sort) */
+static int collect_ray_events_overlap(const clumps_t *c, double xp, double yp, double zp, double kx, double ky, double kz, double t_max,
+                                      double *ev_t, int64_t *ev_icl, int *ev_type, double *ncell) {
+    int n_ev = 0, cg = c->cgx; double d = 0.0;
+    int ci = (int)((xp - c->cg_min) * c->cg_inv), cj = (int)((yp - c->cg_min) * c->cg_inv), ck = (int)((zp - c->cg_min) * c->cg_inv);
+    if (ci > cg - 1) ci = cg - 1; if (ci < 0) ci = 0; if (cj > cg - 1) cj = cg - 1; if (cj < 0) cj = 0; if (ck > cg - 1) ck = cg - 1; if (ck < 0) ck = 0;
+    int si, sj, sk; double tx, ty, tz, delx, dely, delz;
+    if (kx > 0.0) { si = 1; delx = c->cg_d / kx; tx = ((c->cg_min + (double)(ci + 1) * c->cg_d) - xp) / kx; }
+    else if (kx < 0.0) { si = -1; delx = -c->cg_d / kx; tx = ((c->cg_min + (double)ci * c->cg_d) - xp) / kx; } else { si = 0; delx = HUGEST; tx = HUGEST; }
+    if (ky > 0.0) { sj = 1; dely = c->cg_d / ky; ty = ((c->cg_min + (double)(cj + 1) * c->cg_d) - yp) / ky; }
+    else if (ky < 0.0) { sj = -1; dely = -c->cg_d / ky; ty = ((c->cg_min + (double)cj * c->cg_d) - yp) / ky; } else { sj = 0; dely = HUGEST; ty = HUGEST; }
+    if (kz > 0.0) { sk = 1; delz = c->cg_d / kz; tz = ((c->cg_min + (double)(ck + 1) * c->cg_d) - zp) / kz; }
+    else if (kz < 0.0) { sk = -1; delz = -c->cg_d / kz; tz = ((c->cg_min + (double)ck * c->cg_d) - zp) / kz; } else { sk = 0; delz = HUGEST; tz = HUGEST; }
+    for (;;) {
+        if (d > t_max) break;
+        if (ci < 0 || ci >= cg || cj < 0 || cj >= cg || ck < 0 || ck >= cg) break;
+        if (ncell) *ncell += 1.0;
+        size_t q = CGIDX(c,ci,cj,ck);
+        for (int32_t ip = c->cg_start[q]; ip <= c->cg_start[q+1] - 1; ip++) {
+            int64_t icl = c->cg_list[ip-1];
+            double rx = xp - c->x[icl-1], ry = yp - c->y[icl-1], rz = zp - c->z[icl-1];       /* ray_sphere_isect :1362-1386 */
+            double b = rx * kx + ry * ky + rz * kz, disc = b * b - (rx * rx + ry * ry + rz * rz) + c->radius2[icl-1];
+            if (disc < 0.0) continue;
+            disc = sqrt(disc);
+            double te = -b - disc, tx2 = -b + disc;
+            if (!(tx2 > 0.0)) continue;                                             /* hit = (t_exit > 0); then t_exit <= 0 is skipped again */
+            if (te > t_max) continue;
+            int dup = 0; for (int ie = 0; ie < n_ev; ie++) if (ev_icl[ie] == icl) { dup = 1; break; }
+            if (dup || n_ev + 2 > OVL_MAX_EVT) continue;
+            if (te > 0.0) { ev_t[n_ev] = te; ev_icl[n_ev] = icl; ev_type[n_ev] = +1; n_ev++; }
+            ev_t[n_ev] = fmin(tx2, t_max); ev_icl[n_ev] = icl; ev_type[n_ev] = -1; n_ev++;
+        }
+        if (tx <= ty && tx <= tz) { d = tx; tx = tx + delx; ci += si; }
+        else if (ty <= tz)        { d = ty; ty = ty + dely; cj += sj; }
+        else                      { d = tz; tz = tz + delz; ck += sk; }
+    }
+    for (int ie = 1; ie < n_ev; ie++) {
+        double t = ev_t[ie]; int64_t ic = ev_icl[ie]; int ty_ = ev_type[ie]; int ii = ie - 1;
+        while (ii >= 0 && ev_t[ii] > t) { ev_t[ii+1] = ev_t[ii]; ev_icl[ii+1] = ev_icl[ii]; ev_type[ii+1] = ev_type[ii]; ii--; }
+        ev_t[ii+1] = t; ev_icl[ii+1] = ic; ev_type[ii+1] = ty_;
+    }
+    return n_ev;
+}
+/* sum_kap_active: raytrace_clump.f90:621-636 (each clump at its own frame frequency, summed in the order of the active list) */
+static double sum_kap_active(const orc_sim *s, const int64_t *active, int n, double xfreq_g, double kx, double ky, double kz) {
+    double sum = 0.0;
+    for (int m = 0; m < n; m++) { int64_t icl = active[m]; double x_cl = xfreq_g - ulos_clump(&s->cl, icl, kx, ky, kz); sum = sum + kappa_clump(s, x_cl, icl); }
+    return sum;
+}
+/* sample_owner_clump: :644-664 (one draw; the total is re-summed for every candidate exactly as written there) */
+static int64_t sample_owner_clump(const orc_sim *s, rng_t *g, const int64_t *active, int n, double xfreq_g, double kx, double ky, double kz) {
+    double cumul = 0.0, r = rnd(g); int64_t owner = 0;
+    for (int m = 0; m < n; m++) {
+        int64_t icl = active[m]; double x_cl = xfreq_g - ulos_clump(&s->cl, icl, kx, ky, kz);
+        cumul = cumul + kappa_clump(s, x_cl, icl); owner = icl;
+        if (r * sum_kap_active(s, active, n, xfreq_g, kx, ky, kz) <= cumul) return owner;
+    }
+    return owner;
+}
+static inline void ovl_apply_event(int64_t icl, int type, int64_t *aset, int *na) {           /* apply_event :769-786 */
+    if (type == +1) { if (*na < OVL_MAX_EVT) { aset[*na] = icl; (*na)++; } }
+    else for (int m = 0; m < *na; m++) if (aset[m] == icl) { aset[m] = aset[*na - 1]; (*na)--; return; }
+}
+/* raytrace_to_tau_clump_overlap: :668-788 */
+static void raytrace_to_tau_clump_overlap(const orc_sim *s, acc_t *A, rng_t *g, photon_t *p, double tau_in) {
+    const clumps_t *c = &s->cl;
+    static __thread double ev_t[OVL_MAX_EVT]; static __thread int64_t ev_icl[OVL_MAX_EVT], active[OVL_MAX_EVT]; static __thread int ev_type[OVL_MAX_EVT];
+    double kx = p->kx, ky = p->ky, kz = p->kz, xfreq_g = p->xfreq, tau_rem = tau_in;
+    while (p->inside) {
+        double t_sp = sphere_exit_dist(c, p->x, p->y, p->z, kx, ky, kz);
+        if (t_sp <= 0.0) { p->inside = 0; update_cell_idx(s, p); p->xfreq_ref = xfreq_g; p->xfreq = xfreq_g; clump_escape(s, A, p); return; }
+        int n_ev = collect_ray_events_overlap(c, p->x, p->y, p->z, kx, ky, kz, t_sp, ev_t, ev_icl, ev_type, NULL);
+        int n_active = active_set_at_point(c, p->x, p->y, p->z, active);
+        double t_cur = 0.0;
+        for (int ie = 1; ie <= n_ev + 1; ie++) {
+            double t_next = ie <= n_ev ? ev_t[ie-1] : t_sp; t_next = fmin(t_next, t_sp);
+            double dt = t_next - t_cur;
+            if (dt <= 0.0) { if (ie <= n_ev) ovl_apply_event(ev_icl[ie-1], ev_type[ie-1], active, &n_active); continue; }
+            double kap_tot = sum_kap_active(s, active, n_active, xfreq_g, kx, ky, kz);
+            A->n_cellsteps += 1.0;
+            if (kap_tot > 0.0 && tau_rem <= kap_tot * dt) {
+                double ds = tau_rem / kap_tot;
+                p->x = p->x + (t_cur + ds) * kx; p->y = p->y + (t_cur + ds) * ky; p->z = p->z + (t_cur + ds) * kz;
+                p->xfreq = xfreq_g;
+                p->icell_clump = (int)sample_owner_clump(s, g, active, n_active, xfreq_g, kx, ky, kz);
+                update_cell_idx(s, p); return;
+            }
+            tau_rem = tau_rem - kap_tot * dt; t_cur = t_next;
+            if (ie <= n_ev) ovl_apply_event(ev_icl[ie-1], ev_type[ie-1], active, &n_active);
+        }
+        p->x = p->x + t_sp * kx; p->y = p->y + t_sp * ky; p->z = p->z + t_sp * kz;
+        p->xfreq = xfreq_g; p->icell_clump = 0; p->inside = 0; update_cell_idx(s, p); p->xfreq_ref = xfreq_g; clump_escape(s, A, p); return;
+    }
+}
+/* raytrace_to_edge_clump_overlap (:792-854, tau_max < 0) and _capped (:858-918, the peel-off march) */
+static double raytrace_to_edge_clump_overlap(const orc_sim *s, const photon_t *p0, double tau_max, double *nsteps) {
+    const clumps_t *c = &s->cl;
+    static __thread double ev_t[OVL_MAX_EVT]; static __thread int64_t ev_icl[OVL_MAX_EVT], active[OVL_MAX_EVT]; static __thread int ev_type[OVL_MAX_EVT];
+    double tau = 0.0, kx = p0->kx, ky = p0->ky, kz = p0->kz, xfreq_g = p0->xfreq; int capped = tau_max >= 0.0;
+    double t_sp = sphere_exit_dist(c, p0->x, p0->y, p0->z, kx, ky, kz);
+    if (t_sp <= 0.0) return tau;
+    int n_ev = collect_ray_events_overlap(c, p0->x, p0->y, p0->z, kx, ky, kz, t_sp, ev_t, ev_icl, ev_type, NULL);
+    int n_active = active_set_at_point(c, p0->x, p0->y, p0->z, active);
+    double t_cur = 0.0;
+    for (int ie = 1; ie <= n_ev + 1; ie++) {
+        double t_next = ie <= n_ev ? ev_t[ie-1] : t_sp; t_next = fmin(t_next, t_sp);
+        double dt = t_next - t_cur;
+        if (dt > 0.0) {
+            double kap_tot = sum_kap_active(s, active, n_active, xfreq_g, kx, ky, kz);
+            if (nsteps) *nsteps += 1.0;
+            tau = tau + kap_tot * dt;
+            if (capped && tau >= tau_max) return tau;
+        }
+        t_cur = t_next;
+        if (ie <= n_ev) ovl_apply_event(ev_icl[ie-1], ev_type[ie-1], active, &n_active);
+    }
+    return tau;
+}
+
 /* =====================================================================================
  * Ray marches: raytrace_car.f90
  * ===================================================================================== */
@@ -1783,6 +1943,7 @@ static void add_to_Jmu(const orc_sim *s, acc_t *A, const photon_t *p, int ix) { 
 
 /* raytrace_to_tau_car (:1425-1648), _car_xyzsym (:1650-1949), _car_zonly (:2519-2675) */
 static void raytrace_to_tau(const orc_sim *s, acc_t *A, photon_t *p, double tau_in, int variant) {
+    if (variant == 7) { raytrace_to_tau_clump_overlap(s, A, A->g, p, tau_in); return; }
     if (variant == 3) { raytrace_to_tau_amr(s, A, p, tau_in); return; }
     if (variant == 4) { raytrace_to_tau_clump(s, A, p, tau_in); return; }
     trav_t t; double xp = p->x, yp = p->y, zp = p->z;
@@ -1868,6 +2029,7 @@ static void raytrace_to_tau(const orc_sim *s, acc_t *A, photon_t *p, double tau_
 static double raytrace_to_edge(const orc_sim *s, const photon_t *p, int variant, double dist, double *nsteps) {
     if (variant == 3) return raytrace_to_edge_amr(s, p, dist, nsteps);
     if (variant == 4) return raytrace_to_edge_clump(s, p, -1.0, nsteps);                 /* uncapped: first flight (run_simulation_mod.f90:165) */
+    if (variant == 7) return raytrace_to_edge_clump_overlap(s, p, -1.0, nsteps);
     trav_t t; double xp = p->x, yp = p->y, zp = p->z, tau = 0.0, d = 0.0;
     t.kx = p->kx; t.ky = p->ky; t.kz = p->kz; t.icell = p->icell; t.jcell = p->jcell; t.kcell = p->kcell;
     if (variant == 0) { if (setup_traversal_car(s, xp, yp, zp, &t)) return tau; }
@@ -1981,6 +2143,7 @@ static inline void obs_dir_s(const orc_sim *s, int i, const photon_t *p, photon_
 }
 /* tau along the peel ray: to the grid edge (far observers) or to the observer (inside: raytrace_to_dist, peelingoff_heal.f90:60) */
 static inline double peel_tau(const orc_sim *s, acc_t *A, const photon_t *po, double r2) {
+    if (s->use_clump_medium && s->cl.has_overlap) return raytrace_to_edge_clump_overlap(s, po, TAU_HUGE, &A->n_cellsteps_peel);      /* :895-896 */
     if (s->use_clump_medium) return raytrace_to_edge_clump(s, po, TAU_HUGE, &A->n_cellsteps_peel);      /* peel_raytrace_to_edge: peelingoff_rect.f90:872-906 */
     return raytrace_to_edge(s, po, s->raytrace_variant, s->nside > 0 ? sqrt(r2) : -1.0, &A->n_cellsteps_peel);
 }
@@ -2336,6 +2499,13 @@ static void scattering(const orc_sim *s, acc_t *A, rng_t *g, photon_t *p) {
             double p_dust = c->rhokapD[icl-1] / (c->rhokap[icl-1] * voigt_clump(s, p->xfreq, icl) + c->rhokapD[icl-1]);
             if (rnd(g) <= p_dust) { if (s->use_stokes && s->nPDF > 0) scatter_dust_stokes(s, A, g, p); else scatter_dust_nostokes(s, A, g, p); return; }
         }
+        if (s->cl.has_overlap) {                                  /* scatter_resonance_clump_{no,}stokes: scattering_car.f90:898-937 */
+            const int64_t icl = p->icell_clump;
+            p->xfreq = p->xfreq - ulos_clump(&s->cl, icl, p->kx, p->ky, p->kz);
+            if (s->use_stokes) scatter_resonance_stokes(s, A, g, p); else scatter_resonance_nostokes(s, A, g, p);
+            p->xfreq = p->xfreq + ulos_clump(&s->cl, icl, p->kx, p->ky, p->kz);
+            return;
+        }
         if (s->use_stokes) scatter_resonance_stokes(s, A, g, p); else scatter_resonance_nostokes(s, A, g, p);
         return;
     }
@@ -2425,7 +2595,7 @@ static void generate_photon(const orc_sim *s, acc_t *A, rng_t *g, photon_t *p) {
         if (ix >= 1 && ix <= s->nxfreq) A->Jin[ix-1] += p->wgt;
     }
     p->icell_clump = 0;
-    if (s->use_clump_medium) {                                                       /* :325-332 */
+    if (s->use_clump_medium && !s->cl.has_overlap) {                                 /* :325-332 */
         int64_t icl = clump_at_point(&s->cl, p->x, p->y, p->z);
         if (icl > 0) { p->icell_clump = (int)icl; p->xfreq = p->xfreq - ulos_clump(&s->cl, icl, p->kx, p->ky, p->kz); }
     }
@@ -2457,6 +2627,7 @@ static double allph_impact(const orc_sim *s, const photon_t *p, double *mx, doub
     return sqrt((*mx) * (*mx) + (*my) * (*my) + (*mz) * (*mz));
 }
 static void run_photon(const orc_sim *s, acc_t *A, rng_t *g, photon_t *p, int64_t k) {
+    A->g = g;
     generate_photon(s, A, g, p);
     const int64_t n = s->log_n; double *R = s->save_all_photons ? s->allph : NULL;
     if (R) { R[1 * n + k] = p->xfreq; if (s->source_geometry != 0) { double mx, my, mz; R[9 * n + k] = allph_impact(s, p, &mx, &my, &mz); } }
@@ -2583,7 +2754,7 @@ double orc_get_scalar(const orc_sim *s, const char *k) {
     if (s->use_clump_medium) { const clumps_t *c = &s->cl;
         if (!strcmp(k, "cl_N")) return (double)c->N; if (!strcmp(k, "cl_nreg")) return (double)c->nreg; if (!strcmp(k, "cl_cgx")) return c->cgx;
         if (!strcmp(k, "cl_rhokap_ref")) return c->rhokap_ref; if (!strcmp(k, "cl_voigt_a_ref")) return c->voigt_a_ref; if (!strcmp(k, "cl_Dfreq_ref")) return c->Dfreq_ref;
-        if (!strcmp(k, "cl_vtherm_ref")) return c->vtherm_ref; if (!strcmp(k, "cl_fvol")) return c->fvol; if (!strcmp(k, "cl_fcov")) return c->fcov;
+        if (!strcmp(k, "cl_vtherm_ref")) return c->vtherm_ref; if (!strcmp(k, "cl_fvol")) return c->fvol; if (!strcmp(k, "cl_fcov")) return c->fcov; if (!strcmp(k, "cl_has_overlap")) return c->has_overlap;
         if (!strcmp(k, "cl_rsa_grid")) return c->rsa_grid; if (!strcmp(k, "cl_rsa_acceptance")) return c->rsa_acceptance;
         if (!strcmp(k, "cg_min")) return c->cg_min; if (!strcmp(k, "cg_d")) return c->cg_d; if (!strcmp(k, "cl_sphere_R")) return c->sphere_R; if (!strcmp(k, "cl_radius_max")) return c->radius_max; }
     if (!strcmp(k, "amr_ncells")) return s->amr.ncells; if (!strcmp(k, "amr_nleaf")) return s->amr.nleaf; if (!strcmp(k, "amr_levelmax")) return s->amr.levelmax;
@@ -2706,6 +2877,7 @@ static void unpack_s(const orc_sim *s, const double r[8], const int ic[4], photo
 }
 void orc_raytrace_to_tau(orc_sim *s, int variant, double r[8], int ic[4], double tau_in) {
     photon_t p; unpack_s(s, r, ic, &p); acc_t A; acc_alloc(&A, s);
+    rng_t g; memset(&g, 0, sizeof g); rng_philox(&g, (uint64_t)s->iseed, (uint64_t)(r[7] > 0.0 && variant == 7 ? (int64_t)r[7] : 1), 0); A.g = &g;   /* variant 7 draws the owner clump: stream (iseed, id = wgt slot) */
     raytrace_to_tau(s, &A, &p, tau_in, variant);
     acc_merge_free(&A, s);
     r[0] = p.x; r[1] = p.y; r[2] = p.z; r[3] = p.kx; r[4] = p.ky; r[5] = p.kz; r[6] = p.xfreq; r[7] = p.wgt;
@@ -2715,6 +2887,7 @@ int orc_amr_find_leaf(const orc_sim *s, double x, double y, double z) { return s
 void orc_raytrace_to_edge(const orc_sim *s, int variant, const double r[8], const int ic[4], double *tau) {
     photon_t p; unpack_s(s, r, ic, &p);
     if (variant == 14) *tau = raytrace_to_edge_clump(s, &p, TAU_HUGE, 0);         /* the capped peel-off form */
+    else if (variant == 17) *tau = raytrace_to_edge_clump_overlap(s, &p, TAU_HUGE, 0);
     else *tau = raytrace_to_edge(s, &p, variant, -1.0, 0);
 }
 void orc_raytrace_to_dist(const orc_sim *s, const double r[8], const int ic[4], double dist, double *tau) { photon_t p; unpack(r, ic, &p); *tau = raytrace_to_edge(s, &p, s->use_amr_grid ? 3 : 0, dist, 0); }
@@ -2951,6 +3124,7 @@ static int sight_start(const orc_sim *s, int io, int ix, int iy, photon_t *p, do
  * tau_dust(nxim,nyim,nobs) (filled when DGR > 0).  HEALPix observers: nxim = npix, nyim = 1. */
 int orc_sightline_tau(const orc_sim *s, double *tau_gas, double *N_gas, double *tau_dust) {
     if (s->nobs <= 0) { snprintf(g_err, sizeof g_err, "orc_sightline_tau: no observers"); return 1; }
+    if (s->use_clump_medium && s->cl.has_overlap) { snprintf(g_err, sizeof g_err, "orc_sightline_tau: the overlap forms (raytrace_clump.f90:922-1001) are not restated"); return 1; }
     const int nxi = s->nside > 0 ? s->npix : s->nxim, nyi = s->nside > 0 ? 1 : s->nyim;
     const size_t n2 = (size_t)nxi * nyi;
     memset(tau_gas, 0, sizeof(double) * n2 * s->nxfreq * s->nobs); memset(N_gas, 0, sizeof(double) * n2 * s->nobs);
@@ -3009,6 +3183,8 @@ int64_t orc_set_array(orc_sim *s, const char *k, const double *in, int64_t n) {
     int64_t nc = (int64_t)s->nx * s->ny * s->nz; double *dst = NULL;
     if (s->use_clump_medium && !strncmp(k, "cl_", 3)) {            /* per-clump properties (tests: clumps of different temperature / opacity) */
         clumps_t *c = &s->cl; double *d = NULL;
+        if (!strcmp(k, "cl_has_overlap") && n == 1) {                 /* tests: run a non-overlapping population through the overlap forms */
+            c->has_overlap = in[0] != 0.0; s->raytrace_variant = c->has_overlap ? 7 : 4; return 1; }
         if (!strcmp(k, "cl_rhokap")) d = c->rhokap; else if (!strcmp(k, "cl_rhokapD")) d = c->rhokapD; else if (!strcmp(k, "cl_voigt_a")) d = c->voigt_a;
         else if (!strcmp(k, "cl_Dfreq")) d = c->Dfreq; else if (!strcmp(k, "cl_vx")) d = c->vx; else if (!strcmp(k, "cl_vy")) d = c->vy; else if (!strcmp(k, "cl_vz")) d = c->vz;
         if (!d || n != c->N) return -1;

@@ -105,3 +105,77 @@ def test_whole_path_known_answer(oracle_mod):
     o.run(n, seed=4)
     ns, _ = o.photon_log()
     assert abs(ns.mean() - 4345.4) < 0.03 * 4345.4 + 4 * ns.std() / np.sqrt(n), (ns.mean(), ns.std() / np.sqrt(n))
+
+
+# examples/clump_sphere/clump_overlap_mono.in (static) and clump_overlap_peel.in (sigma_v = 100 km/s): 30 clumps of radius 0.3 in the unit sphere
+OVERLAP = dict(use_clump_medium=True, rmax=1.0, clump_radius=0.3, clump_f_cov=2.0, clump_tau0=1e3, temperature=1e4, clump_allow_overlap=True,
+               nxfreq=101, velocity_min=-100.0, velocity_max=100.0, nx=11, ny=11, nz=11, iseed=7)
+
+
+def test_overlapping_population_host_equals_oracle(oracle_mod):
+    """par%clump_allow_overlap (clump_mod.f90:1090): the trial that overlaps is kept, check_has_overlap (:1544-1591) finds the pairs"""
+    for extra, want in ((dict(), True), (dict(clump_sigma_v=100.0), True), (dict(clump_radius=0.01, clump_f_cov=0.02), False)):
+        kw = dict(OVERLAP, **extra)
+        o = oracle_mod.Oracle(**kw)
+        par, line, cl, g = host_clumps(kw)
+        assert cl.N == int(o.scalar("cl_N")) and (cl.N == 30 or not want)
+        for k in ("x", "y", "z", "vx", "vy", "vz"):
+            assert np.array_equal(o.array("cl_" + k), getattr(cl, k)), k
+        assert cl.has_overlap == bool(o.scalar("cl_has_overlap")) == want
+        assert int(o.scalar("raytrace_variant")) == (7 if want else 4)
+    # the same placement draws with and without the switch while no trial is rejected; a dense population differs after the first rejection
+    a = oracle_mod.Oracle(**dict(OVERLAP, clump_allow_overlap=False, clump_radius=0.05, clump_f_cov=1.0))
+    b = oracle_mod.Oracle(**dict(OVERLAP, clump_radius=0.05, clump_f_cov=1.0))
+    xa, xb = a.array("cl_x"), b.array("cl_x")
+    assert xa[0] == xb[0] and not np.array_equal(xa, xb) and bool(b.scalar("cl_has_overlap")) and not bool(a.scalar("cl_has_overlap"))
+
+
+def test_overlap_forms_on_a_disjoint_population_equal_the_standard_forms(oracle_mod):
+    """raytrace_to_{tau,edge}_clump_overlap + scatter_resonance_clump_* (raytrace_clump.f90:606-918, scattering_car.f90:898-937) against
+    raytrace_to_{tau,edge}_clump on clumps that do not overlap: the same physics through two different bookkeepings (global-frame frequency
+    and event lists against clump-frame frequency and nearest-entry search), so the results agree statistically -- with moving clumps, dust
+    and a far observer"""
+    kw = dict(use_clump_medium=True, rmax=1.0, clump_radius=0.08, clump_f_cov=3.0, clump_tau0=1e2, temperature=1e4, clump_sigma_v=30.0, nxfreq=101,
+              velocity_min=-150.0, velocity_max=150.0, nx=11, ny=11, nz=11, iseed=7)
+    n = 20000
+
+    def pair(kw, n, seeds=(3, 4)):
+        a = oracle_mod.Oracle(**kw); a.run(n, seed=seeds[0])
+        b = oracle_mod.Oracle(**kw); b.set_array("cl_has_overlap", np.array([1.0])); assert int(b.scalar("raytrace_variant")) == 7
+        b.run(n, seed=seeds[1])
+        return a, b
+    a, b = pair(kw, n)
+    na, nb = a.photon_log()[0], b.photon_log()[0]
+    assert abs(na.mean() - nb.mean()) < 4.0 * np.hypot(na.std(), nb.std()) / np.sqrt(n), (na.mean(), nb.mean())
+    ja, jb = a.array("Jout"), b.array("Jout")
+    assert np.sum((ja - jb) ** 2 / np.maximum(ja + jb, 1.0)) / np.count_nonzero(ja + jb) < 1.6
+    # dust and a far observer on static clumps.  (With moving clumps the two forms differ BY CONSTRUCTION in the reference: the dust
+    # probability of scattering_car.f90:75-76 and the capped peel march see photon%xfreq, which is the clump-frame frequency in the
+    # standard forms and the global-frame one in the overlap forms.  Restated as written; visible as Jabs 1e-3 against 6e2 at sigma_v = 30.)
+    kw0 = dict(kw, clump_sigma_v=0.0, DGR=1.0, cext_dust=3e-18, nxim=8, nyim=8)
+    a0, b0 = pair(kw0, n)
+    Ja, Jb = a0.array("Jabs").sum(), b0.array("Jabs").sum()
+    assert Ja > 0.02 * n and abs(Ja - Jb) < 0.03 * Ja + 4 * np.sqrt(Ja), (Ja, Jb)
+    sa, sb = a0.array("scatt:0").sum(), b0.array("scatt:0").sum()
+    assert abs(sa - sb) < 0.05 * sa, (sa, sb)
+    a1, b1 = pair(kw0, 2000, seeds=(3, 3))                        # direct light: no draw of the scattering involved, only the edge march
+    assert np.isclose(a1.array("direc:0").sum(), b1.array("direc:0").sum(), rtol=1e-9)
+
+
+def test_overlapping_clumps_whole_path(oracle_mod):
+    """30 clumps of radius 0.3: inside k clumps the opacity is the sum of k profiles; merged clumps trap more than the same clumps would
+    one after the other (fewer free surfaces), every packet still leaves, and the covering factor keeps its meaning: a direct ray from the centre
+    sees exp(-sum of chord optical depths)"""
+    n = 3000
+    o = oracle_mod.Oracle(**dict(OVERLAP, clump_tau0=30.0)); o.run(n, seed=5)
+    assert o.array("Jout").sum() == n and o.photon_log()[0].mean() > 5.0
+    # optical depth of a ray through the overlap forms = sum over clumps of kappa * chord (static clumps, line centre): additive by construction
+    x, y, z, r = o.array("cl_x"), o.array("cl_y"), o.array("cl_z"), 0.3
+    k = np.array([0.3, -0.5, 0.81]); k /= np.linalg.norm(k)
+    b = -(x * k[0] + y * k[1] + z * k[2]); disc = b * b - (x * x + y * y + z * z) + r * r
+    hit = disc > 0
+    t1 = np.clip(-b[hit] - np.sqrt(disc[hit]), 0.0, 1.0); t2 = np.clip(-b[hit] + np.sqrt(disc[hit]), 0.0, 1.0)
+    from oracle import oracle as om
+    kap = o.array("cl_rhokap")[0] * om.voigt(np.array([0.0]), o.scalar("cl_voigt_a_ref"))[0]
+    tau = o.raytrace_to_edge(7, np.array([0, 0, 0, k[0], k[1], k[2], 0.0, 1.0]), np.array([0, 1, 1, 1], dtype=np.int32))
+    assert np.isclose(tau, kap * np.sum(t2 - t1), rtol=1e-10)
