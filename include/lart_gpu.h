@@ -130,7 +130,8 @@ int  lart_gpu_set_JPa_amr(lart_gpu *ctx, int32_t calc_J, int32_t calc_P, int32_t
  * lart_gpu_set_clump_overlap(ctx, 1) after it = setup_clump_overlap (setup.f90:1053-1082) when check_has_overlap found a pair of
  * overlapping clumps: the kernels then run raytrace_to_{tau,edge}_clump_overlap[_capped] (raytrace_clump.f90:606-918; the frequency of the
  * flight stays in the global frame, the opacity inside k clumps is the sum of their k profiles) and scatter_resonance_clump_{no,}stokes
- * (scattering_car.f90:898-937; the scattering clump drawn opacity-weighted).  Single-line profiles (line type 1), no sight-line maps. */
+ * (scattering_car.f90:898-937; the scattering clump drawn opacity-weighted), and lart_gpu_sightline_tau the overlap forms of its two
+ * marches (:922-1001).  Single-line profiles (line type 1). */
 int  lart_gpu_set_clumps(lart_gpu *ctx, int64_t n, const double *x, const double *y, const double *z,
                          const double *vx, const double *vy, const double *vz, const double *radius,
                          const double *rhokap, const double *rhokapD, const double *voigt_a, const double *Dfreq,

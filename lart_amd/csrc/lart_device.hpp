@@ -1176,9 +1176,10 @@ __device__ inline double ovl_sum_kap(const KArgs &A, const Lds &l, bool dust, co
 // TO_TAU: raytrace_to_tau_clump_overlap (:668-788): lim = the optical depth to go; returns with owner > 0 and t_end = the path length to the
 //         scattering point, or owner = 0 and t_end = the path to the sphere's surface (escape).  u_own = the draw of sample_owner_clump (:644-664).
 // else:   raytrace_to_edge_clump_overlap_capped (:858-918): lim = the cap; returns the optical depth.
+//         col != nullptr: also raytrace_to_edge_column_clump_overlap (:935-1001): col[0] += N_gas, col[1] += tau_dust of every interval (cross0 = col[2])
 template <bool TO_TAU>
 __device__ inline double ovl_march(const KArgs &A, const Lds &l, bool dust, double xp, double yp, double zp, double kx, double ky, double kz,
-                                   double xfreq_g, double lim, double u_own, unsigned &nsteps, double &t_end, int &owner) {
+                                   double xfreq_g, double lim, double u_own, unsigned &nsteps, double &t_end, int &owner, double *col = nullptr) {
     const DClumps &c = A.cl; const int cg = c.cgx;
     owner = 0; t_end = 0.0;
     const double t_sp = sphere_exit_dist(c, xp, yp, zp, kx, ky, kz);
@@ -1259,7 +1260,10 @@ __device__ inline double ovl_march(const KArgs &A, const Lds &l, bool dust, doub
                         done = true; break;
                     }
                     acc = acc - kap * dt;
-                } else { acc = acc + kap * dt; if (acc >= lim) { done = true; break; } }
+                } else {
+                    acc = acc + kap * dt; if (acc >= lim) { done = true; break; }
+                    if (col) for (int m = 0; m < na; m++) { const ClumpPhys ph = c.phys[act[m] - 1]; col[0] = col[0] + (ph.rhokap / col[2]) * ph.Dfreq * dt; col[1] = col[1] + ph.rhokapD * dt; }
+                }
                 t_cur = t_next;
             }
             if (!ev) { done = true; break; }                                                  // that was the last interval, up to the surface
@@ -1268,7 +1272,7 @@ __device__ inline double ovl_march(const KArgs &A, const Lds &l, bool dust, doub
             else for (int m = 0; m < na; m++) if (act[m] == -id) { act[m] = act[na - 1]; na--; break; }
         }
     }
-    if (over) atomicAdd(&A.t.scal[7], 1.0);
+    if (over && A.t.scal) atomicAdd(&A.t.scal[7], 1.0);
     if (TO_TAU) { if (owner == 0) t_end = t_sp; return 0.0; }
     return acc;
 }

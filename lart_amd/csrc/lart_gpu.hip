@@ -1100,7 +1100,6 @@ extern "C" int lart_gpu_sightline_tau(lart_gpu *c, double cross0, double *tau_ga
     if (!c->d_cell && !c->is_clump) return fail("sightline_tau: set the medium first");
     if (c->nobs < 1 || c->h_obs.size() != (size_t)c->nobs) return fail("sightline_tau: set the observers first (lart_gpu_set_observers / _heal)");
     if (!(cross0 > 0.0)) return fail("sightline_tau: cross0 (line%cross0) must be > 0");
-    if (c->is_clump && c->clump_overlap) return fail("sightline_tau: the overlap forms of the sight-line marches (raytrace_clump.f90:922-1001) are not built");
     if (c->par.xyz_symmetry || c->par.xy_periodic || c->par.xy_symmetry) return fail("sightline_tau: needs the plain medium (no observers with xyz_symmetry / xy_periodic, setup.f90:198-206)");
     if (c->is_clump && c->heal_nside > 0) return fail("sightline_tau: HEALPix inside observers are not supported with the clump medium (setup.f90:177)");
     if (c->par.nxfreq < 1) return fail("sightline_tau: nxfreq must be >= 1");
@@ -1124,14 +1123,18 @@ extern "C" int lart_gpu_sightline_tau(lart_gpu *c, double cross0, double *tau_ga
     HIPCHK(hipMemsetAsync(dn.p, 0, nray * sizeof(double), c->stream));
     HIPCHK(hipMemsetAsync(dd.p, 0, nray * sizeof(double), c->stream));
     if (c->par.line_type >= 4 && c->par.line_type <= 6 && !c->has_ml) return fail("line_type 4/5/6 needs lart_gpu_set_line_multiplet first");
+    const bool ovl = c->is_clump && c->clump_overlap;                    // setup_clump_overlap: the overlap forms of the two marches (raytrace_clump.f90:922-1001)
+    if (ovl && !c->d_tally) { if (build_tally(c)) return 1; }            // the list-overflow counter lives with the scalar tallies
     KArgs A = probe_args(c);
     hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipEventRecord(e0, c->stream));
-    HIPCHK(lart_sight_launch(A, g.var, dr.p, (int)nray, cross0, dust, dt.p, dn.p, dd.p, probe_shmem(c), c->stream));
+    HIPCHK(lart_sight_launch(A, ovl ? 7 : g.var, dr.p, (int)nray, cross0, dust, dt.p, dn.p, dd.p, probe_shmem(c), c->stream));
     HIPCHK(hipEventRecord(e1, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     float ms = 0.0f; (void)hipEventElapsedTime(&ms, e0, e1); c->sight_ms = ms; (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (dt.back(tau_gas) || dn.back(N_gas) || (tau_dust && dd.back(tau_dust))) return fail("sightline_tau: copy back failed");
+    if (ovl) { double over = 0.0; HIPCHK(hipMemcpy(&over, c->d_tally + 7, sizeof over, hipMemcpyDeviceToHost));
+        if (over > 0.0) return fail("sightline_tau: a ray met more overlapping clumps than the march lists hold"); }
     return 0;
 }
 extern "C" int lart_gpu_sightline_time(lart_gpu *c, double *ms) { if (!c || !ms) return fail("sightline_time: null argument"); *ms = c->sight_ms; return 0; }

@@ -249,6 +249,11 @@ __global__ __launch_bounds__(256) void k_sightline(const KArgs A, const SightRay
     SightAcc s{0.0, 0.0, 0.0};
     if (VAR == 0) sight_car(A, l, r, xf0, cross0, dust != 0, s);
     else if (VAR == 3) sight_amr(A, l, r, xf0, cross0, dust != 0, s);
+    else if (VAR == 7) {                                                  // raytrace_to_edge_tau_gas_clump_overlap + _column_clump_overlap (raytrace_clump.f90:922-1001): gas only, no cap
+        double col[3] = {0.0, 0.0, cross0}, te_; int ow_; unsigned ns_ = 0;
+        s.tau = ovl_march<false>(A, l, false, r.x, r.y, r.z, r.kx, r.ky, r.kz, xf0, LART_HUGEST, 0.0, ns_, te_, ow_, col);
+        s.N = col[0]; if (dust) s.td = col[1];
+    }
     else sight_clump(A, l, r, xf0, cross0, dust != 0, s);
     if (kf < A.par.nxfreq) tau_gas[(size_t)ir * A.par.nxfreq + kf] = s.tau;
     if (kf == 0) { N_gas[ir] = s.N; if (tau_dust) tau_dust[ir] = s.td; }
@@ -262,6 +267,7 @@ hipError_t lart_sight_launch(const KArgs &A, int var, const SightRay *d_rays, in
     const dim3 block(256), grid((unsigned)((nwave + 3) / 4));
     if (var == 0) hipLaunchKernelGGL(k_sightline<0>, grid, block, shmem, stream, A, d_rays, nray, nchunk, cross0, dust ? 1 : 0, d_tau_gas, d_N_gas, d_tau_dust);
     else if (var == 3) hipLaunchKernelGGL(k_sightline<3>, grid, block, shmem, stream, A, d_rays, nray, nchunk, cross0, dust ? 1 : 0, d_tau_gas, d_N_gas, d_tau_dust);
+    else if (var == 7) hipLaunchKernelGGL(k_sightline<7>, grid, block, shmem, stream, A, d_rays, nray, nchunk, cross0, dust ? 1 : 0, d_tau_gas, d_N_gas, d_tau_dust);
     else hipLaunchKernelGGL(k_sightline<4>, grid, block, shmem, stream, A, d_rays, nray, nchunk, cross0, dust ? 1 : 0, d_tau_gas, d_N_gas, d_tau_dust);
     return hipGetLastError();
 }

@@ -2970,8 +2970,36 @@ static double sight_amr(const orc_sim *s, const photon_t *p, double dist, int wa
 }
 /* raytrace_to_edge_tau_gas_clump (raytrace_clump.f90:274-285: raytrace_to_edge_clump with clump_gas_only) and
  * raytrace_to_edge_column_clump (:289-334) on the same walk */
+/* raytrace_to_edge_tau_gas_clump_overlap (:922-931: the uncapped overlap march with clump_gas_only) and raytrace_to_edge_column_clump_overlap (:935-1001) */
+static double sight_clump_overlap(const orc_sim *s, const photon_t *p0, int want_column, double *N_gas, double *tau_dust) {
+    const clumps_t *c = &s->cl;
+    static __thread double ev_t[OVL_MAX_EVT]; static __thread int64_t ev_icl[OVL_MAX_EVT], active[OVL_MAX_EVT]; static __thread int ev_type[OVL_MAX_EVT];
+    double tau = 0.0, kx = p0->kx, ky = p0->ky, kz = p0->kz, xfreq_g = p0->xfreq;
+    if (want_column) { *N_gas = 0.0; *tau_dust = 0.0; }
+    double t_sp = sphere_exit_dist(c, p0->x, p0->y, p0->z, kx, ky, kz);
+    if (t_sp <= 0.0) return tau;
+    int n_ev = collect_ray_events_overlap(c, p0->x, p0->y, p0->z, kx, ky, kz, t_sp, ev_t, ev_icl, ev_type, NULL);
+    int n_active = active_set_at_point(c, p0->x, p0->y, p0->z, active);
+    double t_cur = 0.0;
+    for (int ie = 1; ie <= n_ev + 1; ie++) {
+        double t_next = ie <= n_ev ? ev_t[ie-1] : t_sp; t_next = fmin(t_next, t_sp);
+        double dt = t_next - t_cur;
+        if (dt > 0.0) {
+            if (want_column) for (int m = 0; m < n_active; m++) { int64_t icl = active[m];
+                *N_gas = *N_gas + (c->rhokap[icl-1] / s->cross0) * c->Dfreq[icl-1] * dt;
+                if (s->DGR > 0.0 && c->rhokapD) *tau_dust = *tau_dust + c->rhokapD[icl-1] * dt; }
+            else { double kap = 0.0;
+                for (int m = 0; m < n_active; m++) { int64_t icl = active[m]; kap = kap + c->rhokap[icl-1] * voigt_clump(s, xfreq_g - ulos_clump(c, icl, kx, ky, kz), icl); }
+                tau = tau + kap * dt; }
+        }
+        t_cur = t_next;
+        if (ie <= n_ev) ovl_apply_event(ev_icl[ie-1], ev_type[ie-1], active, &n_active);
+    }
+    return tau;
+}
 static double sight_clump(const orc_sim *s, const photon_t *p0, int want_column, double *N_gas, double *tau_dust) {
     const clumps_t *c = &s->cl;
+    if (c->has_overlap) return sight_clump_overlap(s, p0, want_column, N_gas, tau_dust);
     double tau = 0.0, xp = p0->x, yp = p0->y, zp = p0->z, kx = p0->kx, ky = p0->ky, kz = p0->kz, xf = p0->xfreq;
     int64_t icl_cur = p0->icell_clump, icl_found;
     if (want_column) { *N_gas = 0.0; *tau_dust = 0.0; }
@@ -3124,7 +3152,6 @@ static int sight_start(const orc_sim *s, int io, int ix, int iy, photon_t *p, do
  * tau_dust(nxim,nyim,nobs) (filled when DGR > 0).  HEALPix observers: nxim = npix, nyim = 1. */
 int orc_sightline_tau(const orc_sim *s, double *tau_gas, double *N_gas, double *tau_dust) {
     if (s->nobs <= 0) { snprintf(g_err, sizeof g_err, "orc_sightline_tau: no observers"); return 1; }
-    if (s->use_clump_medium && s->cl.has_overlap) { snprintf(g_err, sizeof g_err, "orc_sightline_tau: the overlap forms (raytrace_clump.f90:922-1001) are not restated"); return 1; }
     const int nxi = s->nside > 0 ? s->npix : s->nxim, nyi = s->nside > 0 ? 1 : s->nyim;
     const size_t n2 = (size_t)nxi * nyi;
     memset(tau_gas, 0, sizeof(double) * n2 * s->nxfreq * s->nobs); memset(N_gas, 0, sizeof(double) * n2 * s->nobs);

@@ -251,6 +251,55 @@ def test_clump_end_to_end_matches_python_host(exe, tmp_path):
     assert np.allclose(obs["Scattered"][1], t["scatt"][..., 0], rtol=1e-6, atol=1e-12 * t["scatt"].max())
 
 
+# the parameters of examples/clump_sphere/clump_overlap_peel.in (fewer photons, a fixed seed, a smaller image)
+OVERLAP_IN = """&parameters
+ par%use_clump_medium    = .true.
+ par%rmax                = 1.0
+ par%clump_radius        = 0.3
+ par%clump_f_cov         = 2.0
+ par%clump_tau0          = 1.0e3
+ par%temperature         = 1.0e4
+ par%clump_sigma_v       = 100.0
+ par%clump_allow_overlap = .true.
+ par%no_photons          = 2e4
+ par%spectral_type       = 'voigt'
+ par%nxfreq              = 101
+ par%velocity_min        = -200.0
+ par%velocity_max        =  200.0
+ par%nx = 11, par%ny = 11, par%nz = 11
+ par%save_peeloff        = .true.
+ par%nxim                = 17
+ par%nyim                = 17
+ par%iseed               = 5
+/
+"""
+
+
+def test_overlapping_clumps_dry_run(exe, tmp_path):
+    """par%clump_allow_overlap: placement without rejection and the overlap check of init_clumps (clump_mod.f90:889-891, :1544-1591)"""
+    r = run(exe, OVERLAP_IN, tmp_path, "--dry-run", name="ovl.in")
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Random placement done (overlap allowed)." in r.stdout and "overlapping clumps detected" in r.stdout
+    assert re.search(r"Clumps: N_clumps\s+=\s+30\b", r.stdout)
+    from lart_amd import host, clump
+    par = host.read_namelist(str(tmp_path / "ovl.in")); par, line, _ = host.read_input(par)
+    cl, g = clump.grid_create_clump(par, line)
+    assert cl.N == 30 and cl.has_overlap
+    m = re.search(r"Clump derived: taumax\s+=\s+(\S+)", r.stdout); assert abs(float(m.group(1)) / par.taumax - 1) < 1e-5
+
+
+@pytest.mark.gpu
+def test_overlapping_clumps_end_to_end_matches_python_host(exe, tmp_path):
+    r = run(exe, OVERLAP_IN, tmp_path, name="ovl.in")
+    assert r.returncode == 0, r.stdout + r.stderr
+    H = read_h5(str(tmp_path / "ovl.h5"))
+    from lart_amd import host
+    sim = host.Simulation(str(tmp_path / "ovl.in")); sim.run_simulation(); t = sim.output_normalize()
+    assert np.allclose(H["Spectrum"][1]["Jout"], t["Jout"], rtol=1e-9, atol=1e-15)
+    O = read_h5(str(tmp_path / "ovl_obs.h5"))
+    assert np.allclose(O["Scattered"][1], t["scatt"][..., 0], rtol=1e-6, atol=1e-12 * t["scatt"].max())
+
+
 AMR_IN = """&parameters
  par%use_amr_grid  = .true.
  par%amr_type      = 'generic'
@@ -557,7 +606,7 @@ def test_whole_namelist_surface_is_readable(exe, tmp_path):
           " par%amr_snapnum = 0\n par%stellar_radius = 0.0\n par%EW_line = 0.0\n par%Omega = 0.0\n par%q = 1.0\n par%D_to_H_ratio = 1.5e-5\n/\n")
     r = run(exe, ok, tmp_path, "--dry-run", name="all.in")
     assert r.returncode == 0, r.stdout + r.stderr
-    for bad in ("par%f_H2 = 1e-3", "par%cone_opening = 30.0", "par%clump_allow_overlap = .true.", "par%stellar_radius = 0.1", "par%Omega = 28.0",
+    for bad in ("par%f_H2 = 1e-3", "par%cone_opening = 30.0", "par%clump_radius_alpha = 1.0", "par%stellar_radius = 0.1", "par%Omega = 28.0",
                 "par%xmin = -1.0", "par%h2_model = 'simple'", "par%ionization_model = 'file'", "par%phase_angle = 10.0, 20.0"):
         r = run(exe, "&parameters\n par%temperature = 1e4\n par%taumax = 1e2\n " + bad + "\n/\n", tmp_path, "--dry-run", name="bad.in")
         assert r.returncode != 0 and "not supported" in r.stdout and bad.split()[0][4:] in r.stdout, bad

@@ -88,3 +88,23 @@ def test_octree_and_clump_maps(oracle_mod, tmp_path):
     assert nc.min() >= 0.0 and nc[0, 0, 0] == 0.0 and nc[4, 4, 0] > 0.0
     H0 = oracle_mod.voigt(0.0, oc.scalar("cl_voigt_a_ref"))
     assert np.allclose(tc[10, :, :, 0], nc[:, :, 0] * oc.scalar("cross0") / oc.scalar("cl_Dfreq_ref") * H0, rtol=1e-9)
+
+
+def test_overlap_forms_of_the_clump_maps(oracle_mod):
+    """raytrace_to_edge_tau_gas_clump_overlap / _column_clump_overlap (raytrace_clump.f90:922-1001).  Both forms are deterministic, so on a
+    population WITHOUT overlaps the overlap forms must give the maps of the standard forms to rounding (moving clumps, dust column); on
+    overlapping clumps at rest the column is additive: tau(line centre) = N cross0 / Dfreq H(0), pixel by pixel"""
+    kw = dict(use_clump_medium=True, clump_radius=0.05, clump_f_cov=3.0, clump_tau0=10.0, clump_sigma_v=40.0, temperature=1e4, rmax=1.0, nxfreq=41,
+              velocity_min=-150.0, velocity_max=150.0, nxim=9, nyim=9, save_peeloff=1, iseed=3, DGR=1.0, cext_dust=3e-18, alpha=20.0, beta=50.0)
+    a = oracle_mod.Oracle(**kw); ta, na, da = a.sightline_tau()
+    b = oracle_mod.Oracle(**kw); b.set_array("cl_has_overlap", np.array([1.0])); tb, nb, db = b.sightline_tau()
+    assert na.max() > 0 and np.allclose(na, nb, rtol=1e-11, atol=1e-12 * na.max()) and np.allclose(da, db, rtol=1e-11, atol=1e-12 * da.max())
+    assert np.allclose(ta, tb, rtol=1e-9, atol=1e-12 * ta.max())
+    ov = oracle_mod.Oracle(use_clump_medium=True, clump_radius=0.3, clump_f_cov=2.0, clump_tau0=10.0, clump_allow_overlap=True, temperature=1e4, rmax=1.0,
+                           nxfreq=21, nxim=9, nyim=9, save_peeloff=1, iseed=7)
+    assert bool(ov.scalar("cl_has_overlap"))
+    tc, nc, _ = ov.sightline_tau()
+    H0 = oracle_mod.voigt(0.0, ov.scalar("cl_voigt_a_ref"))
+    assert np.allclose(tc[10, :, :, 0], nc[:, :, 0] * ov.scalar("cross0") / ov.scalar("cl_Dfreq_ref") * H0, rtol=1e-9)
+    # the central pixel looks through the whole sphere: its column exceeds that of any single clump chord (2 r = 0.6 of tau0 / r per unit length)
+    assert tc[10, 4, 4, 0] > 2 * 10.0

@@ -115,6 +115,18 @@ def test_clump_medium(capi, oracle_mod):
     assert ng.max() > 0
 
 
+def test_overlapping_clumps(capi, oracle_mod):
+    """the overlap forms of the two marches (raytrace_clump.f90:922-1001) through the device's streaming event walk: examples/clump_sphere/
+    clump_overlap_peel.in has par%save_sightline_tau"""
+    kw = dict(use_clump_medium=True, rmax=1.0, clump_radius=0.3, clump_f_cov=2.0, clump_tau0=1e3, temperature=1e4, clump_sigma_v=100.0, clump_allow_overlap=True,
+              nxfreq=101, velocity_min=-200.0, velocity_max=200.0, nx=11, ny=11, nz=11, nxim=33, nyim=33, alpha=[0.0, 25.0], beta=[0.0, 60.0], save_peeloff=True,
+              DGR=1.0, cext_dust=3e-18, iseed=5)
+    sim, o = pair(oracle_mod, kw)
+    assert sim.clumps.has_overlap and int(o.scalar("raytrace_variant")) == 7
+    tg, ng, td = compare(sim, o, dust=True)
+    assert ng.max() > 0 and td.max() > 0
+
+
 def test_boundary_errors(capi):
     from lart_amd import host, capi as cp
     sim = host.Simulation(dict(temperature=1e4, taumax=10.0, nx=9, ny=9, nz=9, rmax=1.0))          # no observers

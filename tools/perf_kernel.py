@@ -29,6 +29,8 @@ def configs(tmp):
         "c3n": dict(temperature=10.0, taumax=1e6, nx=201, ny=201, nz=201, rmax=1.0, nxfreq=201, use_stokes=True, save_Jin=True, no_photons=1e8, iseed=1),   # C3 without its observer
         "c4": dict(use_clump_medium=True, rmax=1.0, clump_radius=0.01, clump_f_cov=5.0, clump_tau0=1e3, temperature=1e4, use_stokes=True, DGR=1.0,
                    scatt_mat_file="MUELLER", core_skip=True, nxfreq=301, velocity_min=-100.0, velocity_max=100.0, nx=11, ny=11, nz=11, no_photons=1e8, iseed=1),
+        "c4o": dict(use_clump_medium=True, rmax=1.0, clump_radius=0.3, clump_f_cov=2.0, clump_tau0=1e3, temperature=1e4, clump_sigma_v=100.0, clump_allow_overlap=True,
+                    nxfreq=101, velocity_min=-200.0, velocity_max=200.0, nx=11, ny=11, nz=11, no_photons=1e8, iseed=1),        # examples/clump_sphere/clump_overlap_sigv.in
         "c5": dict(use_amr_grid=True, amr_file=afile, temperature=1e4, taumax=1e4, rmax=1.0, nxfreq=241, xfreq_min=-15.0, xfreq_max=15.0,
                    calc_J=True, calc_P=True, calc_Pnew=True, no_photons=1e8, iseed=1),
         "c5j": dict(use_amr_grid=True, amr_file=afile, temperature=1e4, taumax=1e4, rmax=1.0, nxfreq=241, xfreq_min=-15.0, xfreq_max=15.0, calc_J=True, no_photons=1e8, iseed=1),
