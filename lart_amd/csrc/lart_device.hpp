@@ -58,7 +58,7 @@ struct DClumps {
     long long N;
     const ClumpGeo *geo; const ClumpPhys *phys;
     const int *cg_start, *cg_list;                             // CSR over cgx^3 cells, 1-based entries as the reference builds them
-    int cgx; double cg_min, cg_d, cg_inv, sphere_R, Dfreq_ref;
+    int cgx; double cg_min, cg_d, cg_inv, sphere_R, Dfreq_ref, radius_max;
 };
 
 struct DObs { double x, y, z, rm[9]; };
@@ -1187,21 +1187,58 @@ __device__ inline double ovl_march(const KArgs &A, const Lds &l, bool dust, doub
     int act[LART_OVL_ACT], pid[LART_OVL_PEND], na = 0, np = 0; double pt[LART_OVL_PEND];        // pid: +icl = ENTER, -icl = EXIT; pt descending, the next event last
     bool over = false;
     int ci = cg_clamp(c, xp), cj = cg_clamp(c, yp), ck = cg_clamp(c, zp);
-    // active_set_at_point: clump_mod.f90:1594-1634
-    for (int k = (ck > 0 ? ck - 1 : 0); k <= (ck < cg - 1 ? ck + 1 : cg - 1); k++)
-        for (int j = (cj > 0 ? cj - 1 : 0); j <= (cj < cg - 1 ? cj + 1 : cg - 1); j++)
-            for (int i = (ci > 0 ? ci - 1 : 0); i <= (ci < cg - 1 ? ci + 1 : cg - 1); i++) {
-                const size_t q = (size_t)i + (size_t)j * cg + (size_t)k * cg * cg;
-                const int ip1 = c.cg_start[q + 1];
-                for (int ip = c.cg_start[q]; ip < ip1; ip++) {
-                    const int icl = c.cg_list[ip - 1]; const ClumpGeo g = c.geo[icl - 1];
-                    const double rx = xp - g.x, ry = yp - g.y, rz = zp - g.z;
-                    if (rx * rx + ry * ry + rz * rz <= g.r2) {
-                        bool dup = false; for (int m = 0; m < na; m++) dup = dup || act[m] == icl;
-                        if (!dup) { if (na < LART_OVL_ACT) act[na++] = icl; else over = true; }
-                    }
-                }
+    // active_set_at_point (clump_mod.f90:1594-1634) reads the 27 CSR cells around the point and keeps the clumps that hold it in first-seen
+    // order.  A clump that holds the point is registered in the point's OWN cell (registration is by bounding box), so one cell gives the set;
+    // the order of the 27-cell scan (k outer, i inner; first cell of the scan that registers the clump, then clump number: the CSR lists ascend)
+    // is restored by a sort on that key, so the sums over the list and the owner draw are the reference's, bit for bit (tested against the
+    // oracle's 27-cell restatement).  The same cell also bounds the distance to every surface from below -- a clump whose surface comes closer
+    // than the point's distance to the faces of its cell is registered in it -- which the in-clump fast path below needs.
+    double free_in = LART_HUGEST, free_out = LART_HUGEST;                                     // min of R^2 - |r|^2 over the holders, of |r|^2 - R^2 over the others
+    {
+        const size_t q = (size_t)ci + (size_t)cj * cg + (size_t)ck * cg * cg;
+        const int ip1 = c.cg_start[q + 1];
+        for (int ip = c.cg_start[q]; ip < ip1; ip++) {
+            const int icl = c.cg_list[ip - 1]; const ClumpGeo g = c.geo[icl - 1];
+            const double rx = xp - g.x, ry = yp - g.y, rz = zp - g.z, rr = rx * rx + ry * ry + rz * rz;
+            if (rr <= g.r2) { if (na < LART_OVL_ACT) act[na++] = icl; else over = true; free_in = fmin(free_in, g.r2 - rr); }
+            else free_out = fmin(free_out, rr - g.r2);
+        }
+        if (na > 1) {
+            long long key[LART_OVL_ACT];
+            for (int m = 0; m < na; m++) {
+                const ClumpGeo g = c.geo[act[m] - 1]; const double rc = sqrt(g.r2);
+                const int i0 = max(max(0, (int)((g.x - c.cg_min - rc) * c.cg_inv)), ci - 1), j0 = max(max(0, (int)((g.y - c.cg_min - rc) * c.cg_inv)), cj - 1),
+                          k0 = max(max(0, (int)((g.z - c.cg_min - rc) * c.cg_inv)), ck - 1);
+                key[m] = ((((long long)k0 * cg + j0) * cg + i0) << 31) | (long long)act[m];
             }
+            for (int m = 1; m < na; m++) { const long long km = key[m]; const int am = act[m]; int n = m - 1;
+                while (n >= 0 && key[n] > km) { key[n + 1] = key[n]; act[n + 1] = act[n]; n--; }
+                key[n + 1] = km; act[n + 1] = am; }
+        }
+    }
+    if (TO_TAU && na > 0 && !over) {
+        // In-clump fast path (the counterpart of the in-cell one of raytrace_to_tau): deep inside a clump the flight ends long before the next
+        // ENTER or EXIT; the march would find one interval [0, t_first) with this list and stop at acc / kap in it.  Lower bounds of the
+        // distances to the surfaces: (|r|^2 - R^2) / (|r| + R) outside, (R^2 - |r|^2) / (R + |r|) inside, denominators bounded from above.
+        // Taken only when acc / kap lies clearly below all of them; everything else goes through the march.
+        const double kap = ovl_sum_kap(A, l, dust, act, na, xfreq_g, kx, ky, kz);
+        if (kap > 0.0) {
+            const double x0 = c.cg_min + (double)ci * c.cg_d, y0 = c.cg_min + (double)cj * c.cg_d, z0 = c.cg_min + (double)ck * c.cg_d;
+            const double dface = fmin(fmin(fmin(xp - x0, x0 + c.cg_d - xp), fmin(yp - y0, y0 + c.cg_d - yp)), fmin(zp - z0, z0 + c.cg_d - zp));
+            const double s_ = lim / kap, reach = fmin(fmin(dface, t_sp), fmin(free_out / (3.4641016151377544 * c.cg_d + 2.0 * c.radius_max), free_in / (2.0 * c.radius_max)));
+            if (s_ < reach * (1.0 - 1e-9)) {
+                nsteps++;
+                t_end = s_;
+                double cumul = 0.0;                                                           // sample_owner_clump :644-664
+                for (int m = 0; m < na; m++) {
+                    const ClumpPhys ph = c.phys[act[m] - 1];
+                    cumul = cumul + kappa_clump(A, l, dust, xfreq_g - ulos_clump(A, ph, kx, ky, kz), ph); owner = act[m];
+                    if (u_own * kap <= cumul) break;
+                }
+                return 0.0;
+            }
+        }
+    }
     int si, sj, sk; double tx, ty, tz, delx, dely, delz;                                      // collect_ray_events_overlap: clump_mod.f90:1664-1693
     if (kx > 0.0) { si = 1; delx = c.cg_d / kx; tx = ((c.cg_min + (double)(ci + 1) * c.cg_d) - xp) / kx; }
     else if (kx < 0.0) { si = -1; delx = -c.cg_d / kx; tx = ((c.cg_min + (double)ci * c.cg_d) - xp) / kx; } else { si = 0; delx = LART_HUGEST; tx = LART_HUGEST; }

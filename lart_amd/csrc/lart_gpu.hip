@@ -415,6 +415,7 @@ extern "C" int lart_gpu_set_clumps(lart_gpu *c, int64_t n, const double *x, cons
     c->cl = DClumps{};
     c->cl.N = n; c->cl.geo = c->d_cl_geo; c->cl.phys = c->d_cl_phys; c->cl.cg_start = c->d_cl_int; c->cl.cg_list = c->d_cl_int + ncells + 1;
     c->cl.cgx = cgx; c->cl.cg_min = cg_min; c->cl.cg_d = cg_d; c->cl.cg_inv = 1.0 / cg_d; c->cl.sphere_R = sphere_R; c->cl.Dfreq_ref = Dfreq_ref;
+    c->cl.radius_max = 0.0; for (int64_t i = 0; i < n; i++) c->cl.radius_max = std::fmax(c->cl.radius_max, radius[i]);
     // the background medium of grid_create_clump is uniform (rhokap = 0, Dfreq = Dfreq_ref, voigt_a = voigt_a_ref, v = 0): one record
     Cell bg{}; bg.rhokap = 0.0; bg.voigt_a = voigt_a_ref; bg.Dfreq = Dfreq_ref; bg.vfx = bg.vfy = bg.vfz = 0.0; bg.rhokapD = 0.0; bg.pad = 0.0;
     HIPCHK(hipMalloc(&c->d_cell, sizeof(Cell))); HIPCHK(hipMemcpy(c->d_cell, &bg, sizeof(Cell), hipMemcpyHostToDevice));
