@@ -67,7 +67,9 @@ contains
     character(len=*), intent(in) :: name, comment
     real(real64), intent(in) :: v
     character(len=80) :: c
-    write(c, '(a8,"= ",es20.12e3," / ",a)') name, v, comment
+    character(len=8) :: k8
+    k8 = name                              ! keyword names are left-justified in their 8 columns
+    write(c, '(a8,"= ",es20.12e3," / ",a)') k8, v, comment(1:min(len(comment), 47))        ! a card holds 80 characters
     call put_card(f, c)
   end subroutine key_r8
   subroutine key_i4(f, name, v, comment)
@@ -75,7 +77,9 @@ contains
     character(len=*), intent(in) :: name, comment
     integer, intent(in) :: v
     character(len=80) :: c
-    write(c, '(a8,"= ",i20," / ",a)') name, v, comment
+    character(len=8) :: k8
+    k8 = name                              ! keyword names are left-justified in their 8 columns
+    write(c, '(a8,"= ",i20," / ",a)') k8, v, comment(1:min(len(comment), 47))
     call put_card(f, c)
   end subroutine key_i4
   subroutine key_l(f, name, v, comment)
@@ -83,16 +87,20 @@ contains
     character(len=*), intent(in) :: name, comment
     logical, intent(in) :: v
     character(len=80) :: c
-    write(c, '(a8,"= ",a20," / ",a)') name, merge('                   T', '                   F', v), comment
+    character(len=8) :: k8
+    k8 = name                              ! keyword names are left-justified in their 8 columns
+    write(c, '(a8,"= ",a20," / ",a)') k8, merge('                   T', '                   F', v), comment(1:min(len(comment), 47))
     call put_card(f, c)
   end subroutine key_l
   subroutine key_s(f, name, v, comment)
     type(fits_file), intent(inout) :: f
     character(len=*), intent(in) :: name, v, comment
     character(len=80) :: c
+    character(len=8) :: k8
     character(len=18) :: q
+    k8 = name                              ! keyword names are left-justified in their 8 columns
     q = v
-    write(c, '(a8,"= ''",a,"'' / ",a)') name, q(1:max(8, len_trim(v))), comment
+    write(c, '(a8,"= ''",a,"'' / ",a)') k8, q(1:max(8, len_trim(v))), comment(1:min(len(comment), 47))
     call put_card(f, c)
   end subroutine key_s
 

@@ -3,6 +3,7 @@
  * keywords are attributes of the group; Fortran array order = reversed HDF5 dimensions) through the HDF5 C API, and gzip
  * for the FITS form (<base>.fits.gz).  Built with -DLART_HDF5 when <hdf5.h> is in the image; otherwise the HDF5 entry
  * points report "unavailable" and the host writes FITS. */
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -207,4 +208,94 @@ int lart_amr_read_binary(const char *path, int *nleaf, double *boxlen, double *o
     size_t L = strlen(path);
     if ((L > 3 && !strcmp(path + L - 3, ".h5")) || (L > 5 && !strcmp(path + L - 5, ".hdf5"))) return amr_read_h5(path, nleaf, boxlen, origin, data);
     return amr_read_fits(path, nleaf, boxlen, origin, data);
+}
+
+
+/* ---- clump population files (write_clumps_info / read_clumps_info, clump_mod.f90:1779-1961, 2040-2312): the first table section of a
+ * FITS[.gz] file (BINTABLE after the primary HDU) or of an HDF5 file (the first group with a dataset X).  data = 9 * n doubles, column after
+ * column: X Y Z VX VY VZ R_CLUMP RHOKAP TEMP; present[c] = 0 when the file has no such column (RHOKAP: 1 = RHOKAP, 2 = DENSITY, 3 = DENS,
+ * read_perclump_or_keyword :1965-2036).  keys = N_CLUMPS CL_RAD RHOKAP TEMP_CL DIST_CM (NaN when absent), distunit = DISTUNIT ('' when absent).
+ * 0 ok, 1 cannot open, 2 short read, 3 no table section, 4 unexpected layout, 5 memory, 6 no HDF5 in this build */
+static const char *cl_col[9][3] = {{"X", 0, 0}, {"Y", 0, 0}, {"Z", 0, 0}, {"VX", 0, 0}, {"VY", 0, 0}, {"VZ", 0, 0}, {"R_CLUMP", 0, 0}, {"RHOKAP", "DENSITY", "DENS"}, {"TEMP", 0, 0}};
+static const char *cl_key[5] = {"N_CLUMPS", "CL_RAD", "RHOKAP", "TEMP_CL", "DIST_CM"};
+typedef struct { fits_hdr h; char ttype[64][24]; double keys[5]; int has[5]; char distunit[64]; } cl_hdr;
+static void cl_card(const char *k, const char *v, void *u) {
+    cl_hdr *c = (cl_hdr *)u; fits_card(k, v, &c->h);
+    if (!strncmp(k, "TTYPE", 5)) { int i = atoi(k + 5); if (i >= 1 && i <= 64) { strncpy(c->ttype[i-1], v, 23); c->ttype[i-1][23] = 0; } }
+    for (int q = 0; q < 5; q++) if (!strcmp(k, cl_key[q])) { c->keys[q] = atof(v); c->has[q] = 1; }
+    if (!strcmp(k, "DISTUNIT")) { strncpy(c->distunit, v, 63); c->distunit[63] = 0; }
+}
+static int clumps_read_fits(const char *path, long long *n_out, double **data, int *present, double *keys, char *distunit) {
+    gzFile f = gzopen(path, "rb"); if (!f) return 1;
+    cl_hdr c; memset(&c, 0, sizeof c);
+    if (fits_header(f, cl_card, &c)) { gzclose(f); return 2; }
+    long long skip = 0;
+    if (c.h.naxis > 0) { skip = labs(c.h.bitpix) / 8; for (long i = 0; i < c.h.naxis; i++) skip *= c.h.naxes[i]; skip = (skip + 2879) / 2880 * 2880; }
+    char junk[2880]; for (long long s = 0; s < skip; s += 2880) if (gzread(f, junk, 2880) != 2880) { gzclose(f); return 2; }
+    memset(&c, 0, sizeof c);
+    if (fits_header(f, cl_card, &c) || !c.h.bintable || c.h.tfields < 1 || c.h.naxes[1] <= 0) { gzclose(f); return 3; }
+    int width[64], off[64], kind[64], row = 0;
+    for (long i = 0; i < c.h.tfields && i < 64; i++) {
+        const char *t = c.h.tform[i]; int rep = 0; while (*t >= '0' && *t <= '9') { rep = rep * 10 + (*t - '0'); t++; } if (rep == 0) rep = 1;
+        int w = 0, k = 0;
+        switch (*t) { case 'D': w = 8; k = 0; break; case 'E': w = 4; k = 1; break; case 'J': w = 4; k = 2; break; case 'K': w = 8; k = 2; break;
+                      case 'I': w = 2; k = 2; break; case 'B': case 'L': case 'A': w = 1; k = 2; break; default: gzclose(f); return 4; }
+        off[i] = row; width[i] = w; kind[i] = k; row += w * rep;
+    }
+    if (row != c.h.naxes[0]) { gzclose(f); return 4; }
+    int src[9];
+    for (int q = 0; q < 9; q++) { src[q] = -1; present[q] = 0;
+        for (int a = 0; a < 3 && src[q] < 0; a++) if (cl_col[q][a]) for (long i = 0; i < c.h.tfields && i < 64; i++) if (!strcmp(c.ttype[i], cl_col[q][a])) { src[q] = (int)i; present[q] = a + 1; break; } }
+    long n = c.h.naxes[1];
+    double *d = (double *)calloc((size_t)9 * (size_t)n, sizeof(double)); unsigned char *buf = (unsigned char *)malloc((size_t)row);
+    if (!d || !buf) { free(d); free(buf); gzclose(f); return 5; }
+    for (long r = 0; r < n; r++) {
+        if (gzread(f, buf, (unsigned)row) != row) { free(d); free(buf); gzclose(f); return 2; }
+        for (int q = 0; q < 9; q++) if (src[q] >= 0) { const unsigned char *b = buf + off[src[q]]; int kk = kind[src[q]];
+            d[(size_t)q * n + r] = kk == 0 ? be_f64(b) : kk == 1 ? be_f32(b) : be_int(b, width[src[q]]); }
+    }
+    free(buf); gzclose(f);
+    for (int q = 0; q < 5; q++) keys[q] = c.has[q] ? c.keys[q] : NAN;
+    strcpy(distunit, c.distunit);
+    *n_out = n; *data = d;
+    return 0;
+}
+#ifdef LART_HDF5
+static int clumps_read_h5(const char *path, long long *n_out, double **data, int *present, double *keys, char *distunit) {
+    hid_t f = H5Fopen(path, H5F_ACC_RDONLY, H5P_DEFAULT); if (f < 0) return 1;
+    H5G_info_t gi; if (H5Gget_info(f, &gi) < 0 || gi.nlinks < 1) { H5Fclose(f); return 3; }
+    hid_t g = -1;
+    for (hsize_t i = 0; i < gi.nlinks && g < 0; i++) {
+        char nm[256]; if (H5Lget_name_by_idx(f, ".", H5_INDEX_NAME, H5_ITER_INC, i, nm, sizeof nm, H5P_DEFAULT) < 0) continue;
+        hid_t o = H5Oopen(f, nm, H5P_DEFAULT);
+        if (o >= 0) { if (H5Iget_type(o) == H5I_GROUP && H5Lexists(o, "X", H5P_DEFAULT) > 0) g = H5Gopen2(f, nm, H5P_DEFAULT); H5Oclose(o); }
+    }
+    if (g < 0) { H5Fclose(f); return 3; }
+    double *d = NULL; hsize_t n = 0;
+    for (int q = 0; q < 9; q++) {
+        hid_t ds = -1; present[q] = 0;
+        for (int a = 0; a < 3 && ds < 0; a++) if (cl_col[q][a] && H5Lexists(g, cl_col[q][a], H5P_DEFAULT) > 0) { ds = H5Dopen2(g, cl_col[q][a], H5P_DEFAULT); present[q] = a + 1; }
+        if (ds < 0) { if (q < 6) { free(d); H5Gclose(g); H5Fclose(f); return 4; } continue; }
+        hid_t sp = H5Dget_space(ds); hsize_t dims[4] = {0, 0, 0, 0}; int rk = H5Sget_simple_extent_dims(sp, dims, NULL); H5Sclose(sp);
+        if (rk != 1 || (q > 0 && dims[0] != n)) { H5Dclose(ds); free(d); H5Gclose(g); H5Fclose(f); return 4; }
+        if (q == 0) { n = dims[0]; d = (double *)calloc((size_t)9 * (size_t)n, sizeof(double)); if (!d) { H5Dclose(ds); H5Gclose(g); H5Fclose(f); return 5; } }
+        int rc = H5Dread(ds, H5T_NATIVE_DOUBLE, H5S_ALL, H5S_ALL, H5P_DEFAULT, d + (size_t)q * n) < 0; H5Dclose(ds);
+        if (rc) { free(d); H5Gclose(g); H5Fclose(f); return 2; }
+    }
+    for (int q = 0; q < 5; q++) if (h5_attr_f64(g, cl_key[q], &keys[q])) keys[q] = NAN;
+    distunit[0] = 0;
+    if (H5Aexists(g, "DISTUNIT") > 0) { hid_t a = H5Aopen(g, "DISTUNIT", H5P_DEFAULT); hid_t t = H5Aget_type(a);
+        if (H5Tget_class(t) == H5T_STRING && !H5Tis_variable_str(t) && H5Tget_size(t) < 63) { char b[64]; memset(b, 0, sizeof b); if (H5Aread(a, t, b) >= 0) { strcpy(distunit, b); for (int i = (int)strlen(distunit) - 1; i >= 0 && distunit[i] == ' '; i--) distunit[i] = 0; } }
+        H5Tclose(t); H5Aclose(a); }
+    H5Gclose(g); H5Fclose(f);
+    *n_out = (long long)n; *data = d;
+    return 0;
+}
+#else
+static int clumps_read_h5(const char *path, long long *n_out, double **data, int *present, double *keys, char *distunit) { (void)path; (void)n_out; (void)data; (void)present; (void)keys; (void)distunit; return 6; }
+#endif
+int lart_clumps_file_read(const char *path, long long *n, double **data, int *present, double *keys, char *distunit) {
+    size_t L = strlen(path);
+    if ((L > 3 && !strcmp(path + L - 3, ".h5")) || (L > 5 && !strcmp(path + L - 5, ".hdf5"))) return clumps_read_h5(path, n, data, present, keys, distunit);
+    return clumps_read_fits(path, n, data, present, keys, distunit);
 }

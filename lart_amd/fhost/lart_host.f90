@@ -239,7 +239,9 @@ module lart_define
   real(wp) :: sphere_R = 0.0_wp, r_min_clump = 0.0_wp, cl_radius_max = 0.0_wp
   real(wp) :: cl_rhokap_ref = 0.0_wp, cl_voigt_a_ref = 0.0_wp, cl_Dfreq_ref = 0.0_wp, cl_vtherm_ref = 0.0_wp
   real(wp), allocatable, target :: cl_x(:), cl_y(:), cl_z(:), cl_vx(:), cl_vy(:), cl_vz(:)
-  real(wp), allocatable, target :: cl_radius(:), cl_rhokap(:), cl_rhokapD(:), cl_voigt_a(:), cl_Dfreq(:), cl_vtherm(:)
+  real(wp), allocatable, target :: cl_radius(:), cl_rhokap(:), cl_rhokapD(:), cl_voigt_a(:), cl_Dfreq(:), cl_vtherm(:), cl_temperature(:)
+  real(wp) :: cl_temperature_ref = 0.0_wp
+  logical :: clumps_from_file = .false.          ! clump_mod.f90:86-87
   integer(int32) :: cgx = 0
   real(wp) :: cg_xmin = 0.0_wp, cg_dx = 0.0_wp
   integer(int32), allocatable, target :: cg_start(:), cg_list(:)
@@ -457,7 +459,6 @@ contains
     if (par%use_amr_grid .and. par%use_clump_medium) call not_supported('use_amr_grid together with use_clump_medium')
     if ((par%calc_J .or. par%calc_P .or. par%calc_Pnew) .and. par%use_clump_medium) &
        call not_supported('calc_J / calc_P / calc_Pnew with par%use_clump_medium')
-    if (par%use_clump_medium .and. len_trim(par%clump_input_file) > 0) call not_supported('par%clump_input_file')
     select case (trim(par%line_id))
     case ('CII_1334', 'SiII_1527', 'SiII_1260', 'SiII_1193', 'SiII_1190', 'SiII_1304', 'FeII_2250', 'FeII_2261', 'FeII_UV3', 'FeII_2344', 'FeII_UV1', 'FeII_2600', &
           'FeII_UV2', 'FeII_2383', 'HeI_10833')
@@ -788,7 +789,9 @@ contains
     vtherm = vtherm_total(par%temperature)                                                      ! :273-284
     grid%Dfreq   = vtherm/(line%wavelength0*um2km)
     grid%voigt_a = (line%damping/fourpi)/grid%Dfreq
-    par%distance_unit = ''; par%distance2cm = 1.0_wp                                            ! :352-365
+    if (.not. par%use_clump_medium) then                                                        ! :352-363: the clump population carries the length unit
+       par%distance_unit = ''; par%distance2cm = 1.0_wp
+    endif
     grid%rhokap = 1.0_wp
     if (par%DGR > 0.0_wp) grid%rhokapD = par%cext_dust * par%DGR
     if (par%rmax > 0.0_wp) then                                                                 ! :367-395
@@ -1042,12 +1045,16 @@ contains
     if (r_min_clump >= R_sphere) then
        write(*,'(a,2es12.4)') 'ERROR: par%rmin must be < par%rmax for clump placement; rmin, rmax = ', r_min_clump, R_sphere; stop 1
     endif
+    if (len_trim(par%clump_input_file) > 0) then      ! clump_mod.f90:674-680: a pre-built population replaces the generator
+       call read_clumps_info(trim(par%clump_input_file), R_sphere)
+       return
+    endif
     cl_radius_max = par%clump_radius; rc = cl_radius_max
     temp_cl = par%clump_temperature
     if (temp_cl < 0.0_wp) temp_cl = par%temperature
     vtherm         = vtherm_total(temp_cl)
     cl_Dfreq_ref   = vtherm/(line%wavelength0*um2km)
-    cl_vtherm_ref  = vtherm
+    cl_vtherm_ref  = vtherm; cl_temperature_ref = temp_cl
     cl_voigt_a_ref = (line%damping/fourpi)/cl_Dfreq_ref
     shell2 = R_sphere**2 + R_sphere*r_min_clump + r_min_clump**2
     if (par%clump_N_clumps > 0.0_wp) then
@@ -1091,6 +1098,7 @@ contains
     n = int(N_clumps)
     allocate(cl_x(n), cl_y(n), cl_z(n), cl_vx(n), cl_vy(n), cl_vz(n), cl_radius(n), cl_rhokap(n), cl_voigt_a(n), cl_Dfreq(n), cl_vtherm(n))
     cl_radius = rc; cl_rhokap = cl_rhokap_ref; cl_voigt_a = cl_voigt_a_ref; cl_Dfreq = cl_Dfreq_ref; cl_vtherm = cl_vtherm_ref
+    allocate(cl_temperature(n)); cl_temperature = cl_temperature_ref
     if (par%DGR > 0.0_wp) then
        allocate(cl_rhokapD(n)); cl_rhokapD = cl_rhokap_ref*par%cext_dust*par%DGR*cl_Dfreq_ref/line%cross0
     endif
@@ -1105,15 +1113,27 @@ contains
        write(*,'(a,f6.1,a)') ' RSA done, acceptance rate = ', acc*100.0_wp, '%'
     endif
     if (len_trim(par%velocity_type) > 0) call assign_clump_velocities_from_type()
+    call build_clump_csr(par%clump_allow_overlap)
+  end subroutine init_clumps
+
+
+  !--- build_clump_csr (clump_mod.f90:1267-1360) + check_has_overlap (:1544-1591; init_clumps runs it for par%clump_allow_overlap and for every loaded file)
+  subroutine build_clump_csr(check_overlap)
+    logical, intent(in) :: check_overlap
+    real(c_double) :: cmin, cd
+    integer(c_int32_t) :: cg, ovl
+    integer(c_int64_t) :: nreg
     call host_check(lart_host_clumps_csr_dims(N_clumps, sphere_R, cl_radius_max, cg, cmin, cd), 'lart_host_clumps_csr_dims')
     cgx = cg; cg_xmin = cmin; cg_dx = cd
+    if (allocated(cg_start)) deallocate(cg_start)
+    if (allocated(cg_list)) deallocate(cg_list)
     allocate(cg_start(cgx**3 + 1))
     call host_check(lart_host_clumps_build_csr(N_clumps, cl_x, cl_y, cl_z, cl_radius, cgx, cg_xmin, cg_dx, cg_start, c_null_ptr, nreg), 'lart_host_clumps_build_csr')
     allocate(cg_list(max(1_int64, nreg)))
     call host_check(lart_host_clumps_build_csr(N_clumps, cl_x, cl_y, cl_z, cl_radius, cgx, cg_xmin, cg_dx, cg_start, c_loc(cg_list), nreg), 'lart_host_clumps_build_csr')
     write(*,'(a,i12,a,i5,a)') ' CSR grid: ', nreg, ' registrations in ', cgx, '^3 cells.'
     has_overlap = .false.
-    if (par%clump_allow_overlap) then               ! clump_mod.f90:889-891, check_has_overlap :1544-1591
+    if (check_overlap) then
        call host_check(lart_host_clumps_has_overlap(N_clumps, cl_x, cl_y, cl_z, cl_radius, cgx, cg_xmin, cg_dx, cg_start, cg_list, ovl), 'lart_host_clumps_has_overlap')
        has_overlap = ovl /= 0
        if (has_overlap) then
@@ -1122,7 +1142,169 @@ contains
           write(*,'(a)') ' Overlap check: no overlaps found — using standard raytrace.'
        endif
     endif
-  end subroutine init_clumps
+  end subroutine build_clump_csr
+
+  !--- io_resolve_filename: iofile_mod.f90:143-177
+  function resolve_filename(fname) result(res)
+    character(len=*), intent(in) :: fname
+    character(len=512) :: res
+    character(len=8), parameter :: exts(4) = [character(len=8) :: '.h5', '.fits.gz', '.fits', '.dat']
+    integer :: i, k
+    logical :: ex
+    res = fname
+    do k = len_trim(fname), 1, -1
+       if (fname(k:k) == '/' .or. fname(k:k) == char(92)) exit
+       if (fname(k:k) == '.') return
+    enddo
+    do i = 1, size(exts)
+       res = trim(fname)//trim(exts(i))
+       inquire(file=trim(res), exist=ex)
+       if (ex) return
+    enddo
+    write(*,'(3a)') 'io_resolve_filename: no file found for "', trim(fname), '"'; stop 1
+  end function resolve_filename
+
+  !--- the four sums of compute_clump_scalars (clump_mod.f90:2316-2378): tauhomo, taumax, N_gashomo, N_gasmax
+  subroutine clump_scalars(vals)
+    real(wp), intent(out) :: vals(4)
+    integer(int64) :: i
+    real(wp) :: voigt0_i, di2, shell2, w_homo, w_max
+    shell2 = sphere_R**2 + sphere_R*r_min_clump + r_min_clump**2
+    if (shell2 <= 0.0_wp) shell2 = sphere_R**2
+    vals = 0.0_wp
+    do i = 1_int64, N_clumps
+       voigt0_i = voigt0(cl_voigt_a(i))
+       di2    = max(cl_x(i)**2 + cl_y(i)**2 + cl_z(i)**2, cl_radius(i)**2)
+       w_homo = cl_radius(i)**3/shell2
+       w_max  = cl_radius(i)**3/(3.0_wp*di2)
+       vals(1) = vals(1) + cl_rhokap(i)*voigt0_i*w_homo
+       vals(2) = vals(2) + cl_rhokap(i)*voigt0_i*w_max
+       vals(3) = vals(3) + cl_rhokap(i)*cl_Dfreq(i)*w_homo/line%cross0
+       vals(4) = vals(4) + cl_rhokap(i)*cl_Dfreq(i)*w_max/line%cross0
+    enddo
+  end subroutine clump_scalars
+
+  !--- read_clumps_info + rescale_loaded_clumps_to_target: clump_mod.f90:2040-2312, 2385-2449
+  subroutine read_clumps_info(fname, R_sphere)
+    character(len=*), intent(in) :: fname
+    real(wp), intent(in) :: R_sphere
+    interface
+       function lart_clumps_file_read(path, n, data, present, keys, distunit) bind(C, name='lart_clumps_file_read') result(rc)
+         import; character(kind=c_char), intent(in) :: path(*); integer(c_long_long), intent(out) :: n; type(c_ptr), intent(out) :: data
+         integer(c_int), intent(out) :: present(9); real(c_double), intent(out) :: keys(5); character(kind=c_char), intent(out) :: distunit(64)
+         integer(c_int) :: rc
+       end function
+       subroutine lart_free(p) bind(C, name='lart_free')
+         import; type(c_ptr), value :: p
+       end subroutine
+    end interface
+    character(len=512) :: path
+    type(c_ptr) :: cdata
+    real(c_double), pointer :: tab(:,:)
+    real(c_double) :: keys(5)
+    integer(c_int) :: present(9), rc
+    integer(c_long_long) :: nn
+    character(kind=c_char) :: cunit(64)
+    character(len=64) :: distunit_file
+    integer :: n, i
+    real(wp) :: vals(4), realized, target_val, alpha
+    character(len=12) :: which
+    logical :: user_set
+    sphere_R = R_sphere; clumps_from_file = .true.
+    r_min_clump = max(0.0_wp, par%rmin)
+    path = resolve_filename(fname)
+    write(*,'(2a)') ' Clumps: reading from ', trim(path)
+    rc = lart_clumps_file_read(trim(path)//c_null_char, nn, cdata, present, keys, cunit)
+    if (rc /= 0) then
+       write(*,'(3a,i0,a)') 'ERROR: cannot read clump_input_file: ', trim(path), ' (code ', rc, ': 1 open, 2 short file, 3 no table section, 4 columns, 6 no HDF5 in this build)'; stop 1
+    endif
+    if (keys(1) /= keys(1) .or. keys(1) <= 0.0_wp) then
+       write(*,'(a)') 'ERROR: clump_input_file: N_CLUMPS keyword missing or <= 0'; stop 1
+    endif
+    N_clumps = int(keys(1), int64); n = int(N_clumps)
+    if (n > nn .or. any(present(1:6) == 0)) then
+       write(*,'(a)') 'ERROR: clump_input_file: the table needs the columns X, Y, Z, VX, VY, VZ with N_CLUMPS rows'; stop 1
+    endif
+    call c_f_pointer(cdata, tab, [int(nn), 9])
+    allocate(cl_x(n), cl_y(n), cl_z(n), cl_vx(n), cl_vy(n), cl_vz(n), cl_radius(n), cl_rhokap(n), cl_voigt_a(n), cl_Dfreq(n), cl_vtherm(n), cl_temperature(n))
+    cl_x = tab(1:n,1); cl_y = tab(1:n,2); cl_z = tab(1:n,3); cl_vx = tab(1:n,4); cl_vy = tab(1:n,5); cl_vz = tab(1:n,6)
+    !--- read_perclump_or_keyword (:1965-2036): the column when the file has it, else the keyword for every clump
+    call col_or_key(7, 2, 'R_CLUMP', 'CL_RAD', cl_radius)
+    call col_or_key(8, 3, 'RHOKAP', 'RHOKAP', cl_rhokap)
+    call col_or_key(9, 4, 'TEMP', 'TEMP_CL', cl_temperature)
+    call lart_free(cdata)
+    distunit_file = ''
+    do i = 1, 64
+       if (cunit(i) == c_null_char) exit
+       distunit_file(i:i) = cunit(i)
+    enddo
+    user_set = len_trim(par%distance_unit) > 0 .and. par%distance2cm > 1.0_wp                  ! :2164-2176
+    if (.not. user_set) then
+       if (len_trim(distunit_file) > 0) then
+          par%distance_unit = trim(distunit_file)
+          write(*,'(3a)') " Clumps: adopting DISTUNIT = '", trim(par%distance_unit), "' from clump_input_file"
+       endif
+       if (keys(5) == keys(5) .and. keys(5) > 0.0_wp) then
+          par%distance2cm = keys(5)
+          write(*,'(a,es12.5,a)') ' Clumps: adopting DIST_CM = ', par%distance2cm, ' cm/code-unit from clump_input_file'
+       endif
+    endif
+    do i = 1, n
+       cl_vtherm(i) = vtherm_total(cl_temperature(i)); cl_Dfreq(i) = cl_vtherm(i)/(line%wavelength0*um2km); cl_voigt_a(i) = (line%damping/fourpi)/cl_Dfreq(i)
+       cl_vx(i) = cl_vx(i)/cl_vtherm(i); cl_vy(i) = cl_vy(i)/cl_vtherm(i); cl_vz(i) = cl_vz(i)/cl_vtherm(i)
+    enddo
+    if (present(8) >= 2) then                                                                     ! DENSITY / DENS: :2190-2207
+       if (len_trim(par%distance_unit) > 0 .or. par%distance2cm > 1.0_wp) then
+          cl_rhokap = cl_rhokap*line%cross0/cl_Dfreq*par%distance2cm
+          write(*,'(a,es12.4,a)') ' Clumps: density column converted to opacity using par%distance2cm = ', par%distance2cm, ' cm/code-unit'
+       else
+          write(*,'(a)') ' Clumps: WARNING -- a density column found but par%distance_unit/distance2cm is not set; treating the values as RHOKAP'
+       endif
+    endif
+    cl_radius_max = maxval(cl_radius); cl_temperature_ref = cl_temperature(1); cl_vtherm_ref = cl_vtherm(1)
+    cl_Dfreq_ref = cl_Dfreq(1); cl_voigt_a_ref = cl_voigt_a(1); cl_rhokap_ref = cl_rhokap(1)
+    if (par%taumax > 0.0_wp .or. par%tauhomo > 0.0_wp .or. par%N_gasmax > 0.0_wp .or. par%N_gashomo > 0.0_wp) then
+       call clump_scalars(vals)
+       if (par%taumax > 0.0_wp) then
+          realized = vals(2); target_val = par%taumax; which = 'taumax'
+       else if (par%tauhomo > 0.0_wp) then
+          realized = vals(1); target_val = par%tauhomo; which = 'tauhomo'
+       else if (par%N_gasmax > 0.0_wp) then
+          realized = vals(4); target_val = par%N_gasmax; which = 'N_gasmax'
+       else
+          realized = vals(3); target_val = par%N_gashomo; which = 'N_gashomo'
+       endif
+       if (realized <= 0.0_wp) then
+          write(*,'(a)') ' Clumps: WARNING -- realized tau/NHI from loaded clumps is zero; cannot rescale. Leaving cl_rhokap unchanged.'
+       else
+          alpha = target_val/realized
+          cl_rhokap = cl_rhokap*alpha; cl_rhokap_ref = cl_rhokap_ref*alpha
+          write(*,'(3a,es12.4,a,es12.4)') ' Clumps: rescaled to par%', trim(which), ' = ', target_val, ', alpha = ', alpha
+       endif
+    endif
+    if (par%DGR > 0.0_wp) then
+       allocate(cl_rhokapD(n)); cl_rhokapD = cl_rhokap*par%cext_dust*par%DGR*cl_Dfreq/line%cross0
+    endif
+    write(*,'(a,i14)')    ' Clumps: N_clumps  = ', N_clumps
+    write(*,'(a,es12.4)') ' Clumps: cl_rhokap = ', cl_rhokap_ref
+    write(*,'(a,f12.5)')  ' Clumps: voigt_a   = ', cl_voigt_a_ref
+    write(*,'(a,es12.4)') ' Clumps: cl_Dfreq  = ', cl_Dfreq_ref
+    write(*,'(a,2es12.4)')' Clumps: r_cl min/max  = ', minval(cl_radius), cl_radius_max
+    call build_clump_csr(.true.)
+  contains
+    subroutine col_or_key(icol, ikey, cname, kname, dst)
+      integer, intent(in) :: icol, ikey
+      character(len=*), intent(in) :: cname, kname
+      real(wp), intent(out) :: dst(:)
+      if (present(icol) /= 0) then
+         dst = tab(1:n, icol)
+      else if (keys(ikey) == keys(ikey)) then
+         dst = keys(ikey)
+      else
+         write(*,'(5a)') 'ERROR: clump_input_file: neither a column ', cname, ' nor the keyword ', kname, ' in the file'; stop 1
+      endif
+    end subroutine col_or_key
+  end subroutine read_clumps_info
 
   !--- assign_clump_velocities_from_type: clump_mod.f90:1153-1264 (the fields this path supports)
   subroutine assign_clump_velocities_from_type()
@@ -1162,21 +1344,8 @@ contains
 
   !--- compute_clump_scalars: clump_mod.f90:2316-2378
   subroutine compute_clump_scalars()
-    integer(int64) :: i
-    real(wp) :: voigt0_i, di2, shell2, w_homo, w_max, vals(4)
-    shell2 = sphere_R**2 + sphere_R*r_min_clump + r_min_clump**2
-    if (shell2 <= 0.0_wp) shell2 = sphere_R**2
-    vals = 0.0_wp
-    do i = 1_int64, N_clumps
-       voigt0_i = voigt0(cl_voigt_a(i))
-       di2    = max(cl_x(i)**2 + cl_y(i)**2 + cl_z(i)**2, cl_radius(i)**2)
-       w_homo = cl_radius(i)**3/shell2
-       w_max  = cl_radius(i)**3/(3.0_wp*di2)
-       vals(1) = vals(1) + cl_rhokap(i)*voigt0_i*w_homo
-       vals(2) = vals(2) + cl_rhokap(i)*voigt0_i*w_max
-       vals(3) = vals(3) + cl_rhokap(i)*cl_Dfreq(i)*w_homo/line%cross0
-       vals(4) = vals(4) + cl_rhokap(i)*cl_Dfreq(i)*w_max/line%cross0
-    enddo
+    real(wp) :: vals(4)
+    call clump_scalars(vals)
     par%tauhomo = vals(1); par%taumax = vals(2); par%N_gashomo = vals(3); par%N_gasmax = vals(4)
   end subroutine compute_clump_scalars
 

@@ -54,6 +54,7 @@ program LaRT_amd
   par%run_seed = run_seed
   if (par%use_clump_medium) then            ! main.f90:25-27
      call grid_create_clump(grid)
+     if (par%save_clump_info) call write_clumps_info()       ! grid_mod_clump.f90:123-129
   else if (par%use_amr_grid) then           ! main.f90:28-30
      call grid_create_amr(grid)
   else
@@ -337,6 +338,73 @@ contains
   !--- sections (:541-650), peel-off sections Scattered/Direct/Stokes_* (:1113-1344) in <base>_obs.* / <base>_stokes.*;
   !--- container by par%file_format: HDF5 <base>.h5 (reference default) or gzip FITS <base>.fits.gz
   !--- write_output_allph (write_output_rect.f90:1353-1515): <base>_allph, one row per photon
+  !--- write_clumps_info (clump_mod.f90:1779-1961): <base>_clumps.{h5,fits.gz}; one table section of float32 columns X Y Z [code units],
+  !--- VX VY VZ [km/s] and, only where they vary by more than 1e-3 of their mean, R_CLUMP RHOKAP TEMP; the scalars as keywords of the section
+  subroutine write_clumps_info()
+    type(out_file) :: o
+    type(key_list) :: kl
+    character(len=16) :: names(9)
+    real(wp), allocatable :: cols(:,:)
+    real(wp) :: f_vol, f_cov, shell2, vshell
+    integer :: n, ncol, keep_bitpix
+    n = int(N_clumps); allocate(cols(n, 9))
+    names(1:6) = [character(len=16) :: 'X', 'Y', 'Z', 'VX', 'VY', 'VZ']; ncol = 6
+    cols(:,1) = cl_x; cols(:,2) = cl_y; cols(:,3) = cl_z
+    cols(:,4) = cl_vx*cl_vtherm; cols(:,5) = cl_vy*cl_vtherm; cols(:,6) = cl_vz*cl_vtherm
+    if (varies(cl_radius)) then
+       ncol = ncol + 1; names(ncol) = 'R_CLUMP'; cols(:,ncol) = cl_radius
+    endif
+    if (varies(cl_rhokap)) then
+       ncol = ncol + 1; names(ncol) = 'RHOKAP'; cols(:,ncol) = cl_rhokap
+    endif
+    if (varies(cl_temperature)) then
+       ncol = ncol + 1; names(ncol) = 'TEMP'; cols(:,ncol) = cl_temperature
+    endif
+    vshell = max(sphere_R**3 - r_min_clump**3, tiny(1.0_wp)); shell2 = max(sphere_R**2 + sphere_R*r_min_clump + r_min_clump**2, tiny(1.0_wp))
+    if (clumps_from_file) then
+       f_vol = sum(cl_radius**3)/vshell; f_cov = 0.75_wp*sum(cl_radius**2)/shell2
+    else
+       f_vol = real(N_clumps, wp)*cl_radius_max**3/vshell; f_cov = 0.75_wp*real(N_clumps, wp)*cl_radius_max**2/shell2
+    endif
+    write(*,'(a,es12.4)') ' Clumps: realized f_vol      = ', f_vol
+    write(*,'(a,es12.4)') ' Clumps: realized f_cov      = ', f_cov
+    write(*,'(a,3l2)') ' Clumps: clump columns saved (R_CLUMP/RHOKAP/TEMP) = ', varies(cl_radius), varies(cl_rhokap), varies(cl_temperature)
+    kl%n = 0
+    call kadd(kl, 'N_CLUMPS', n,                    'number of clumps (realized)')
+    call kadd(kl, 'SPHERE_R', sphere_R,             'outer sphere radius [code units]')
+    call kadd(kl, 'RMIN',     r_min_clump,          'inner placement radius [code units]')
+    call kadd(kl, 'CL_RAD',   cl_radius_max,        'clump radius (max) [code units]')
+    call kadd(kl, 'F_VOL',    f_vol,                'volume filling factor (realized)')
+    call kadd(kl, 'F_COV',    f_cov,                'covering factor (realized)')
+    call kadd(kl, 'TAU0',     par%clump_tau0,       'line-center tau (center to surface)')
+    call kadd(kl, 'SIGMA_V',  par%clump_sigma_v,    'bulk velocity sigma [km/s]')
+    call kadd(kl, 'TEMP_CL',  cl_temperature_ref,   'clump temperature [K] (reference)')
+    call kadd(kl, 'RHOKAP',   cl_rhokap_ref,        'opacity/code-unit inside clumps (ref)')
+    call kadd(kl, 'CL_DFREQ', cl_Dfreq_ref,         'Doppler frequency [Hz] (reference)')
+    call kadd(kl, 'VTHERM',   cl_vtherm_ref,        'thermal velocity [km/s] (reference)')
+    call kadd(kl, 'VOIGT_A',  cl_voigt_a_ref,       'Voigt damping parameter (reference)')
+    call kadd(kl, 'RMAX',     par%rmax,             'outer sphere radius input (par%rmax)')
+    call kadd(kl, 'IN_FCOV',  par%clump_f_cov,      'covering factor (input)')
+    call kadd(kl, 'IN_FVOL',  par%clump_f_vol,      'volume filling factor (input)')
+    call kadd(kl, 'IN_NCL',   par%clump_N_clumps,   'N_clumps (input)')
+    call kadd(kl, 'IN_NHI',   par%clump_NHI,        'clump NHI input [cm^-2] (clump center to surface)')
+    call kadd(kl, 'IN_NH',    par%clump_nH,         'clump nH density input [cm^-3]')
+    call kadd(kl, 'IN_TEMP',  par%clump_temperature,'clump temperature input [K]')
+    call kadd(kl, 'DISTUNIT', trim(par%distance_unit), 'Distance Unit')
+    call kadd(kl, 'DIST_CM',  par%distance2cm,      'Distance Unit (cm)')
+    keep_bitpix = out_bitpix; out_bitpix = -32              ! float32 columns (:1805)
+    call out_open(o, trim(par%base_name)//'_clumps', out_format_of(trim(strlowcase(par%file_format))))
+    call out_table(o, 'section_001', names(1:ncol), cols(:, 1:ncol), kl)
+    call out_close(o, .true.)
+    out_bitpix = keep_bitpix
+    write(*,'(2a)') ' Clumps saved to ', trim(o%path)
+  contains
+    logical function varies(a)
+      real(wp), intent(in) :: a(:)
+      varies = (maxval(a) - minval(a)) > 1.0e-3_wp*max(abs(sum(a)/max(real(size(a), wp), 1.0_wp)), tiny(1.0_wp))
+    end function varies
+  end subroutine write_clumps_info
+
   subroutine write_output_allph()
     real(wp), allocatable :: rec(:,:)
     character(len=16) :: names(10)

@@ -155,6 +155,7 @@ class Params:
     clump_sigma_v: float = 0.0
     clump_fully_inside: bool = True
     clump_allow_overlap: bool = False
+    clump_input_file: str = ""
     save_clump_info: bool = False
     Vrot: float = 0.0
     rinner: float = 0.0
@@ -212,7 +213,6 @@ _UNSUPPORTED_DEFAULTS = {
     "clump_radius_min": -1.0,
     "clump_radius_max_in": -1.0,
     "clump_profile_file": "",
-    "clump_input_file": "",
     "amr_snapnum": 0,
     "ionization_model": "cie_formula",
     "dust_model": "global_dgr",
@@ -656,7 +656,8 @@ def grid_create(par, line):
     g.Dfreq_ref = vth / (line.wavelength0 * UM2KM)
     g.Dfreq = np.full(shape, vth / (line.wavelength0 * UM2KM), order="F")
     g.voigt_a = (line.damping / FOURPI) / g.Dfreq
-    par.distance_unit, par.distance2cm = "", 1.0                          # :352-365
+    if not par.use_clump_medium:                                          # :352-363: the clump population carries the physical length unit
+        par.distance_unit, par.distance2cm = "", 1.0
     g.rhokap = np.ones(shape, order="F")
     g.rhokapD = np.full(shape, par.cext_dust * par.DGR, order="F") if par.DGR > 0.0 else None
     X, Y, Z = np.meshgrid(xx, yy, zz, indexing="ij")

@@ -692,7 +692,7 @@ static int grid_create(orc_sim *s) {
     double vth = vtherm_total(s, s->temperature);
     for (size_t c = 0; c < nc; c++) { s->Dfreq[c] = vth / (s->wavelength0 * UM2KM); s->voigt_a[c] = (s->damping / FOURPI) / s->Dfreq[c]; }
     /* (2) density: :352-365 synthetic medium, distance2cm reset to 1 */
-    s->distance2cm = 1.0;
+    if (!s->use_clump_medium) s->distance2cm = 1.0;              /* grid_mod_car.f90:352-363: the clump population carries the length unit */
     for (size_t c = 0; c < nc; c++) { s->rhokap[c] = 1.0; if (s->DGR > 0.0) s->rhokapD[c] = s->cext_dust * s->DGR; }
     if (s->rmax > 0.0) {                                                            /* :367-395 sphere carved by cell centre */
         for (int k = 1; k <= nz; k++) for (int j = 1; j <= ny; j++) for (int i = 1; i <= nx; i++) {
@@ -1498,7 +1498,7 @@ static void build_clump_csr(clumps_t *c) {
 static void check_has_overlap(clumps_t *c) {
     c->has_overlap = 0;
     for (int64_t i = 1; i <= c->N; i++) {
-        int r[6]; clump_cell_range(c, i, r);
+        int r[6]; clump_cell_range(c, i - 1, r);
         for (int k = r[4]; k <= r[5]; k++) for (int j = r[2]; j <= r[3]; j++) for (int ii = r[0]; ii <= r[1]; ii++) {
             size_t q = CGIDX(c,ii,j,k);
             for (int32_t ip = c->cg_start[q]; ip <= c->cg_start[q+1] - 1; ip++) {
@@ -3212,6 +3212,16 @@ int64_t orc_set_array(orc_sim *s, const char *k, const double *in, int64_t n) {
         clumps_t *c = &s->cl; double *d = NULL;
         if (!strcmp(k, "cl_has_overlap") && n == 1) {                 /* tests: run a non-overlapping population through the overlap forms */
             c->has_overlap = in[0] != 0.0; s->raytrace_variant = c->has_overlap ? 7 : 4; return 1; }
+        if (!strcmp(k, "cl_rebuild") && n == 1) {                     /* tests: a population loaded from a clump file (read_clumps_info :2040-2312): new positions / radii ->
+                                                                        * build_clump_csr again, check_has_overlap as init_clumps :678-679 does for a loaded file, the scalars of grid_create_clump */
+            c->radius_max = 0.0; for (int64_t i = 0; i < c->N; i++) { c->radius2[i] = c->radius[i] * c->radius[i]; if (c->radius[i] > c->radius_max) c->radius_max = c->radius[i]; }
+            c->Dfreq_ref = c->Dfreq[0]; c->voigt_a_ref = c->voigt_a[0]; c->rhokap_ref = c->rhokap[0]; c->vtherm_ref = c->vtherm[0];
+            build_clump_csr(c); check_has_overlap(c); s->raytrace_variant = c->has_overlap ? 7 : 4; compute_clump_scalars(s);
+            size_t nc = (size_t)s->nx * s->ny * s->nz;
+            for (size_t i = 0; i < nc; i++) { s->Dfreq[i] = c->Dfreq_ref; s->voigt_a[i] = c->voigt_a_ref; }
+            s->Dfreq_ref = c->Dfreq_ref; s->voigt_amean = c->voigt_a_ref;
+            return 1; }
+        if (!strcmp(k, "cl_x")) d = c->x; else if (!strcmp(k, "cl_y")) d = c->y; else if (!strcmp(k, "cl_z")) d = c->z; else if (!strcmp(k, "cl_radius")) d = c->radius; else if (!strcmp(k, "cl_vtherm")) d = c->vtherm; else
         if (!strcmp(k, "cl_rhokap")) d = c->rhokap; else if (!strcmp(k, "cl_rhokapD")) d = c->rhokapD; else if (!strcmp(k, "cl_voigt_a")) d = c->voigt_a;
         else if (!strcmp(k, "cl_Dfreq")) d = c->Dfreq; else if (!strcmp(k, "cl_vx")) d = c->vx; else if (!strcmp(k, "cl_vy")) d = c->vy; else if (!strcmp(k, "cl_vz")) d = c->vz;
         if (!d || n != c->N) return -1;

@@ -300,6 +300,39 @@ def test_overlapping_clumps_end_to_end_matches_python_host(exe, tmp_path):
     assert np.allclose(O["Scattered"][1], t["scatt"][..., 0], rtol=1e-6, atol=1e-12 * t["scatt"].max())
 
 
+@pytest.mark.parametrize("fmt", ["hdf5", "fits"])
+def test_clump_file_written_and_read_back(exe, tmp_path, fmt):
+    """par%save_clump_info -> <base>_clumps.{h5,fits.gz} (write_clumps_info, clump_mod.f90:1779-1961); par%clump_input_file (read_clumps_info
+    :2040-2312) loads it again, also without its extension, and rescales to par%taumax (:2385-2449).  Both hosts read both hosts' files."""
+    from lart_amd import host, clump
+    base = OVERLAP_IN.replace(" par%no_photons          = 2e4\n", " par%no_photons = 100\n par%save_clump_info = .true.\n par%file_format = '" + fmt + "'\n")
+    r = run(exe, base, tmp_path, "--dry-run", name="w.in")
+    assert r.returncode == 0, r.stdout + r.stderr
+    fn = str(tmp_path / ("w_clumps" + (".h5" if fmt == "hdf5" else ".fits.gz")))
+    assert "Clumps saved to" in r.stdout and os.path.exists(fn) and "(R_CLUMP/RHOKAP/TEMP) =  F F F" in r.stdout
+    cols, keys = clump.read_table_file(fn)
+    assert sorted(cols) == ["VX", "VY", "VZ", "X", "Y", "Z"] and int(keys["N_CLUMPS"]) == 30 and keys["CL_RAD"] == 0.3 and keys["SIGMA_V"] == 100.0
+    par = host.read_namelist(str(tmp_path / "w.in")); par, line, _ = host.read_input(par)
+    cl, g = clump.grid_create_clump(par, line)                                        # the population the file was written from
+    assert np.array_equal(cols["X"], cl.x.astype(np.float32).astype(np.float64)) and np.allclose(cols["VZ"], cl.vz * cl.vtherm, rtol=1e-6, atol=1e-4)
+    assert np.isclose(keys["RHOKAP"], cl.rhokap_ref, rtol=1e-12) and np.isclose(keys["F_COV"], cl.fcov, rtol=1e-12)
+    # read back by the Fortran host (extension left to io_resolve_filename) and by the Python host: the same population, the same scalars
+    rd = base.replace(" par%save_clump_info = .true.\n", " par%clump_input_file = 'w_clumps'\n par%taumax = 2.0e3\n")
+    r2 = run(exe, rd, tmp_path, "--dry-run", name="r.in")
+    assert r2.returncode == 0, r2.stdout + r2.stderr
+    assert "Clumps: reading from w_clumps" in r2.stdout and "rescaled to par%taumax" in r2.stdout and "overlapping clumps detected" in r2.stdout
+    par2 = host.read_namelist(str(tmp_path / "r.in")); par2.clump_input_file = fn; par2, line2, _ = host.read_input(par2)
+    cl2, g2 = clump.grid_create_clump(par2, line2)
+    assert cl2.N == 30 and cl2.has_overlap and np.isclose(par2.taumax, 2.0e3, rtol=1e-12)
+    m = re.search(r"Clump derived: taumax\s+=\s+(\S+)", r2.stdout); assert abs(float(m.group(1)) / 2.0e3 - 1) < 1e-5
+    m = re.search(r"Clumps: cl_rhokap =\s+(\S+)", r2.stdout); assert abs(float(m.group(1)) / cl2.rhokap_ref - 1) < 1e-4
+    m = re.search(r"CSR grid:\s+(\d+) registrations", r2.stdout); assert int(m.group(1)) == len(cl2.cg_list)
+    # a file written by the Python host is read by the Fortran host
+    clump.write_clumps_info(str(tmp_path / ("py_clumps" + (".h5" if fmt == "hdf5" else ".fits"))), par, line, cl)
+    r3 = run(exe, rd.replace("'w_clumps'", "'py_clumps'"), tmp_path, "--dry-run", name="r3.in")
+    assert r3.returncode == 0 and re.search(r"CSR grid:\s+%d registrations" % len(cl2.cg_list), r3.stdout), r3.stdout + r3.stderr
+
+
 AMR_IN = """&parameters
  par%use_amr_grid  = .true.
  par%amr_type      = 'generic'
@@ -413,6 +446,11 @@ def test_output_containers_hdf5_and_gzip_fits(exe, tmp_path):
     S = read_h5(str(tmp_path / "ch_stokes.h5")); O = read_h5(str(tmp_path / "ch_obs.h5"))
     assert list(S) == ["Stokes_I", "Stokes_Q", "Stokes_U", "Stokes_V"] and S["Stokes_Q"][1].shape == (41, 8, 8)
     assert list(O) == ["Scattered", "Direct"] and O["Direct"][1].shape == (41, 8, 8)
+    import gzip
+    raw = gzip.open(str(tmp_path / "cf.fits.gz")).read()
+    cards = [raw[i:i + 80].decode("ascii") for i in range(0, 2880 * 3, 80)]
+    assert any(c.startswith("BITPIX  =") for c in cards) and any(c.startswith("NAXIS1  =") for c in cards) and any(c.startswith("taumax  =") for c in cards)
+    assert not any(c[0] == " " and c[8:10] == "= " for c in cards)                # keyword names left-justified in columns 1-8 (FITS standard 4.1.2)
     FO = read_fits(str(tmp_path / "cf_obs.fits.gz"))
     assert list(FO) == ["Scattered", "Direct"]
     # keywords of the first section of a peel-off cube, in the reference's order (write_output_rect.f90:1093-1150)
