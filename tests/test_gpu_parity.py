@@ -888,6 +888,37 @@ def test_overlapping_clumps_peel_off(capi, oracle_mod):
     assert rms_diff(t["scatt"][..., 0].sum(axis=(1, 2)), o.array("scatt:0").reshape(sh3, order="F").sum(axis=(1, 2))) < 0.02
 
 
+def test_file_loaded_overlapping_population(capi, oracle_mod, tmp_path):
+    """par%clump_input_file (read_clumps_info, clump_mod.f90:2040-2312): clumps of different radii and opacities, some overlapping, loaded from a
+    table file -- the case the reference's overlap forms were written for.  The oracle gets the same arrays; whole histories and peel cubes agree."""
+    from lart_amd import clump
+    rng = np.random.default_rng(11); n = 60
+    pos = rng.normal(0, 0.4, (4 * n, 3)); pos = pos[np.linalg.norm(pos, axis=1) < 0.8][:n]
+    cols = [("X", pos[:, 0]), ("Y", pos[:, 1]), ("Z", pos[:, 2]), ("VX", rng.normal(0, 40, n)), ("VY", rng.normal(0, 40, n)), ("VZ", rng.normal(0, 40, n)),
+            ("R_CLUMP", rng.uniform(0.05, 0.2, n)), ("RHOKAP", rng.uniform(50.0, 500.0, n))]
+    fn = str(tmp_path / "made_clumps.h5")
+    clump.write_table_file(fn, cols, dict(N_CLUMPS=n, TEMP_CL=1.0e4))
+    kw = dict(use_clump_medium=True, rmax=1.0, clump_radius=0.1, clump_input_file=fn, temperature=1e4, nxfreq=101, velocity_min=-200.0, velocity_max=200.0,
+              nx=11, ny=11, nz=11, nxim=11, nyim=11, alpha=15.0, beta=40.0, iseed=19)
+    sim = make(kw); cl = sim.clumps
+    assert cl.N == n and cl.has_overlap and cl.from_file and cl.radius.min() < 0.5 * cl.radius.max()
+    okw = {k: v for k, v in kw.items() if k != "clump_input_file"}
+    o = oracle_mod.Oracle(clump_N_clumps=n, clump_tau0=1.0, **okw)
+    for k in ("x", "y", "z", "vx", "vy", "vz", "radius", "rhokap"):
+        o.set_array("cl_" + k, getattr(cl, k))
+    o.set_array("cl_rebuild", np.array([1.0]))
+    assert int(o.scalar("raytrace_variant")) == 7 and np.array_equal(o.array("cg_list"), cl.cg_list) and np.isclose(o.scalar("taumax"), sim.par.taumax, rtol=1e-12)
+    m = 20000
+    sim.ctx.enable_photon_log(True); sim.run_simulation(m); t = sim.ctx.tallies()
+    o.run(m, seed=19)
+    ng, xg = sim.ctx.photon_log(m); no, xo = o.photon_log()
+    same = np.isclose(ng, no, rtol=1e-12, atol=0) & np.isclose(xg, xo, rtol=1e-7, atol=1e-9)
+    assert same.mean() > 0.95, same.mean()
+    assert rms_diff(t["Jout"], o.array("Jout")) < 0.01
+    g3 = t["scatt"][..., 0]; o3 = o.array("scatt:0").reshape((101, 11, 11), order="F")
+    assert np.abs(g3 - o3).max() < 0.02 * o3.max() and abs(g3.sum() - o3.sum()) < 0.02 * o3.sum()
+
+
 def test_overlap_list_overflow_is_refused(capi):
     """more clumps around one point than the march lists hold: lart_gpu_get_tallies fails instead of handing out a result that is not the reference's"""
     kw = dict(OVERLAP, clump_radius=0.9, clump_N_clumps=80, clump_f_cov=-1.0, clump_fully_inside=False, clump_tau0=1.0)
