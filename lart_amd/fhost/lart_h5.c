@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <strings.h>
 #include <zlib.h>
 
 #ifdef LART_HDF5
@@ -298,4 +299,100 @@ int lart_clumps_file_read(const char *path, long long *n, double **data, int *pr
     size_t L = strlen(path);
     if ((L > 3 && !strcmp(path + L - 3, ".h5")) || (L > 5 && !strcmp(path + L - 5, ".hdf5"))) return clumps_read_h5(path, n, data, present, keys, distunit);
     return clumps_read_fits(path, n, data, present, keys, distunit);
+}
+
+
+/* ---- reading back one array or keyword of an output file of this host (par%out_merge: write_output_rect.f90:112-420, 780-1000, 1041-1340: the
+ * previous file is read, combined photon-weighted with the new run and written again).  section = EXTNAME / group name; name = a table column,
+ * or "data" for an image section.  FITS[.gz] or HDF5 by the extension.  0 ok, 1 cannot open, 2 short read, 3 no such section / column /
+ * keyword, 4 size mismatch, 6 no HDF5 in this build. */
+typedef struct { fits_hdr h; char ttype[64][24]; char extname[72]; const char *want; double keyval; int has_key; } rd_hdr;
+static void rd_card(const char *k, const char *v, void *u) {
+    rd_hdr *c = (rd_hdr *)u; fits_card(k, v, &c->h);
+    if (!strncmp(k, "TTYPE", 5)) { int i = atoi(k + 5); if (i >= 1 && i <= 64) { strncpy(c->ttype[i-1], v, 23); c->ttype[i-1][23] = 0; } }
+    else if (!strcmp(k, "EXTNAME")) { strncpy(c->extname, v, 71); c->extname[71] = 0; }
+    if (c->want && !strcasecmp(k, c->want)) { c->keyval = atof(v); c->has_key = 1; }       /* FITS keeps 8 characters: the caller passes the truncated name */
+}
+static int fits_find(gzFile f, const char *section, rd_hdr *c, const char *key) {
+    for (int hdu = 0; hdu < 64; hdu++) {
+        memset(c, 0, sizeof *c); c->want = key;
+        if (fits_header(f, rd_card, c)) return 3;
+        if (!strcmp(c->extname, section)) return 0;
+        long long skip = 0;
+        if (c->h.naxis > 0) { skip = labs(c->h.bitpix) / 8; for (long i = 0; i < c->h.naxis; i++) skip *= c->h.naxes[i]; skip += c->h.pcount; skip = (skip + 2879) / 2880 * 2880; }
+        char junk[2880]; for (long long s = 0; s < skip; s += 2880) if (gzread(f, junk, 2880) != 2880) return 3;
+    }
+    return 3;
+}
+static int is_h5(const char *path) { size_t L = strlen(path); return (L > 3 && !strcmp(path + L - 3, ".h5")) || (L > 5 && !strcmp(path + L - 5, ".hdf5")); }
+int lart_out_read(const char *path, const char *section, const char *name, double *dst, long long n) {
+    if (is_h5(path)) {
+#ifdef LART_HDF5
+        H5E_auto2_t ef; void *ed; H5Eget_auto2(H5E_DEFAULT, &ef, &ed); H5Eset_auto2(H5E_DEFAULT, NULL, NULL);
+        hid_t f = H5Fopen(path, H5F_ACC_RDONLY, H5P_DEFAULT); int rc = 1;
+        if (f >= 0) { rc = 3;
+            if (H5Lexists(f, section, H5P_DEFAULT) > 0) { hid_t g = H5Gopen2(f, section, H5P_DEFAULT);
+                if (g >= 0) { if (H5Lexists(g, name, H5P_DEFAULT) > 0) { hid_t ds = H5Dopen2(g, name, H5P_DEFAULT);
+                        if (ds >= 0) { hid_t sp = H5Dget_space(ds); hssize_t np = H5Sget_simple_extent_npoints(sp); H5Sclose(sp);
+                            rc = (np != (hssize_t)n) ? 4 : (H5Dread(ds, H5T_NATIVE_DOUBLE, H5S_ALL, H5S_ALL, H5P_DEFAULT, dst) < 0 ? 2 : 0); H5Dclose(ds); } }
+                    H5Gclose(g); } }
+            H5Fclose(f); }
+        H5Eset_auto2(H5E_DEFAULT, ef, ed);
+        return rc;
+#else
+        return 6;
+#endif
+    }
+    gzFile f = gzopen(path, "rb"); if (!f) return 1;
+    rd_hdr c; int rc = fits_find(f, section, &c, NULL);
+    if (rc) { gzclose(f); return rc; }
+    if (!c.h.bintable) {                                                   /* image */
+        long long np = 1; for (long i = 0; i < c.h.naxis; i++) np *= c.h.naxes[i];
+        int w = (int)(labs(c.h.bitpix) / 8);
+        if (c.h.naxis < 1 || np != n || (c.h.bitpix != -64 && c.h.bitpix != -32)) { gzclose(f); return 4; }
+        unsigned char buf[8 * 512];
+        for (long long i = 0; i < n; ) { long long m = n - i < 512 ? n - i : 512;
+            if (gzread(f, buf, (unsigned)(m * w)) != m * w) { gzclose(f); return 2; }
+            for (long long j = 0; j < m; j++) dst[i + j] = w == 8 ? be_f64(buf + 8 * j) : be_f32(buf + 4 * j);
+            i += m; }
+        gzclose(f); return 0;
+    }
+    int off[64], width[64], kind[64], row = 0, col = -1;
+    for (long i = 0; i < c.h.tfields && i < 64; i++) {
+        const char *t = c.h.tform[i]; int rep = 0; while (*t >= '0' && *t <= '9') { rep = rep * 10 + (*t - '0'); t++; } if (rep == 0) rep = 1;
+        int w = 0, k = 0;
+        switch (*t) { case 'D': w = 8; k = 0; break; case 'E': w = 4; k = 1; break; case 'J': w = 4; k = 2; break; case 'K': w = 8; k = 2; break; case 'I': w = 2; k = 2; break; default: gzclose(f); return 4; }
+        off[i] = row; width[i] = w; kind[i] = k; row += w * rep;
+        if (!strcmp(c.ttype[i], name)) col = (int)i;
+    }
+    if (col < 0) { gzclose(f); return 3; }
+    if (row != c.h.naxes[0] || c.h.naxes[1] != n) { gzclose(f); return 4; }
+    unsigned char *buf = (unsigned char *)malloc((size_t)row);
+    for (long long r = 0; r < n; r++) {
+        if (gzread(f, buf, (unsigned)row) != row) { free(buf); gzclose(f); return 2; }
+        const unsigned char *b = buf + off[col]; dst[r] = kind[col] == 0 ? be_f64(b) : kind[col] == 1 ? be_f32(b) : be_int(b, width[col]);
+    }
+    free(buf); gzclose(f); return 0;
+}
+int lart_out_read_key(const char *path, const char *section, const char *key, double *v) {
+    if (is_h5(path)) {
+#ifdef LART_HDF5
+        H5E_auto2_t ef; void *ed; H5Eget_auto2(H5E_DEFAULT, &ef, &ed); H5Eset_auto2(H5E_DEFAULT, NULL, NULL);
+        hid_t f = H5Fopen(path, H5F_ACC_RDONLY, H5P_DEFAULT); int rc = 1;
+        if (f >= 0) { rc = 3;
+            if (H5Lexists(f, section, H5P_DEFAULT) > 0) { hid_t g = H5Gopen2(f, section, H5P_DEFAULT); if (g >= 0) { rc = h5_attr_f64(g, key, v) ? 3 : 0; H5Gclose(g); } }
+            H5Fclose(f); }
+        H5Eset_auto2(H5E_DEFAULT, ef, ed);
+        return rc;
+#else
+        return 6;
+#endif
+    }
+    gzFile f = gzopen(path, "rb"); if (!f) return 1;
+    char k8[9]; strncpy(k8, key, 8); k8[8] = 0;
+    rd_hdr c; int rc = fits_find(f, section, &c, k8);
+    gzclose(f);
+    if (rc) return rc;
+    if (!c.has_key) return 3;
+    *v = c.keyval; return 0;
 }

@@ -19,6 +19,15 @@ program LaRT_amd
   type(c_ptr), allocatable :: ctxs(:)
   character(len=256) :: infile, arg
   logical :: dry_run, dry_write
+  real(wp) :: nph_key = 0.0_wp                   ! the photon count a peel-off file's keyword reports (this run, or this run + the merged file)
+  interface
+     function lart_out_read(path, section, name, dst, n) bind(C, name='lart_out_read') result(rc)
+       import; character(kind=c_char), intent(in) :: path(*), section(*), name(*); real(c_double), intent(out) :: dst(*); integer(c_long_long), value :: n; integer(c_int) :: rc
+     end function
+     function lart_out_read_key(path, section, key, v) bind(C, name='lart_out_read_key') result(rc)
+       import; character(kind=c_char), intent(in) :: path(*), section(*), key(*); real(c_double), intent(out) :: v; integer(c_int) :: rc
+     end function
+  end interface
   integer :: i, ndev, ngpu, r
   integer(int64) :: done, active, left, t0, t1, rate, run_seed, cnt_r
   real(wp), allocatable, target :: xyz(:), rmat(:)
@@ -429,8 +438,9 @@ contains
 
   subroutine write_output(filename, g)
     character(len=*), intent(in) :: filename
-    type(grid_type), intent(in) :: g
+    type(grid_type), intent(inout) :: g
     type(out_file) :: o
+    real(wp) :: nph_main, exetime_tot
     type(key_list) :: kl, ki, ko, k0
     character(len=16) :: names(6)
     character(len=8) :: tail
@@ -438,6 +448,8 @@ contains
     integer :: ncol, fmt, io, nxi, nyi
     k0%n = 0
     fmt = out_format_of(trim(strlowcase(par%file_format)))
+    nph_main = real(par%nphotons, wp); exetime_tot = par%exetime; nph_key = nph_main
+    if (par%out_merge) call merge_main_file()          ! write_output_rect.f90:75-78, 112-420
     ncol = 4; names(1:4) = [character(len=16) :: 'Xfreq', 'velocity', 'wavelength', 'Jout']
     if (par%save_Jabs) then
        ncol = ncol + 1; names(ncol) = 'Jabs'
@@ -454,7 +466,7 @@ contains
     if (par%save_Jin) then
        ncol = ncol + 1; cols(:,ncol) = g%Jin
     endif
-    call kadd(kl, 'ExeTime',  par%exetime,        'Excution Time (min)')
+    call kadd(kl, 'ExeTime',  exetime_tot,        'Excution Time (min)')
     call kadd(kl, 'Nprocs',   max(ngpu, 1),       'No. of Threads')          ! here: GPUs that shared the photons
     call kadd(kl, 'recoil',   par%recoil,         'recoil')
     call kadd(kl, 'coreskip', par%core_skip,      'coreskip algorithm')
@@ -463,7 +475,7 @@ contains
     call kadd(kl, 'save_all', par%save_all,       'save all 3D output?')
     call kadd(kl, 'save_Jin', par%save_Jin,       'save input J?')
     call kadd(kl, 'save_Jab', par%save_Jabs,      'save absorbed J?')
-    call kadd(kl, 'nphotons', real(par%nphotons, wp), 'number of photons')
+    call kadd(kl, 'nphotons', nph_main, 'number of photons')
     call kadd(kl, 'taumax',   par%taumax,         'tau_max')
     call kadd(kl, 'tauhomo',  par%tauhomo,        'tau_homo')
     call kadd(kl, 'Ngasmax',  par%N_gasmax,       'N(gas)_max cm^-2')
@@ -492,7 +504,7 @@ contains
     call kadd(kl, 'calc_Pnew', par%calc_Pnew,     'calculated Pa within media?')
     call kadd(kl, 'calc_J',   par%calc_J,         'calculated J within media?')
     call kadd(kl, 'ISEED',    real(par%run_seed, wp), 'random seed of this run (host addition; iseed = 0: drawn from the OS)')
-    call kadd(ki, 'nphotons', real(par%nphotons, wp), 'number of photons')
+    call kadd(ki, 'nphotons', nph_main, 'number of photons')
     call kadd(ki, 'dxim', par%dxim, 'pixel size along x (deg)')
     call kadd(ki, 'dyim', par%dyim, 'pixel size along y (deg)')
     call kadd(ki, 'distance', par%distance, 'observer distance')
@@ -512,6 +524,8 @@ contains
        do io = 1, par%nobs
           tail = ''
           if (par%nobs > 1) write(tail,'(a,i3.3)') '_', io
+          nph_key = real(par%nphotons, wp)
+          if (par%out_merge .and. allocated(obs_scatt)) call merge_peel_files(io, trim(tail), .false.)     ! write_output_rect.f90:1031-1340
           call peel_keys(ko, io, g, merge(3, 1, par%nside > 0))
           if (allocated(obs_scatt)) then
              nxi = size(obs_scatt, 2); nyi = size(obs_scatt, 3)
@@ -544,6 +558,8 @@ contains
              endif
           endif
           if (allocated(obs_scatt_2D)) then
+             nph_key = real(par%nphotons, wp)
+             if (par%out_merge) call merge_peel_files(io, trim(tail), .true.)                                 ! write_output_rect.f90:770-1000
              call peel_keys(ko, io, g, merge(4, 2, par%nside > 0))
              nxi = size(obs_scatt_2D, 1); nyi = size(obs_scatt_2D, 2)
              call out_open(o, trim(par%base_name)//'_obs2D'//trim(tail), fmt)
@@ -575,6 +591,105 @@ contains
           endif
        enddo
     endif
+  contains
+    !--- par%out_merge: a previous output of the same name is read and combined, photon-weighted, with this run before the file is written
+    !--- again: a = (a_old nph_old + a_new nph_new) / (nph_old + nph_new) for every array, the same for the scattering counts, the execution
+    !--- times added (write_output_rect.f90:112-420).  Here for both containers (the reference's HDF5 backend cannot read-and-rewrite).
+    function cstr(x) result(c)
+      character(len=*), intent(in) :: x
+      character(kind=c_char, len=:), allocatable :: c
+      c = trim(x)//c_null_char
+    end function cstr
+    function out_path(base) result(path)
+      character(len=*), intent(in) :: base
+      character(len=512) :: path
+      path = trim(base)//'.fits.gz'
+      if (fmt == OUT_HDF5) path = trim(base)//'.h5'
+    end function out_path
+    logical function old_nph(path, section, nph1)
+      character(len=*), intent(in) :: path, section
+      real(wp), intent(out) :: nph1
+      logical :: ex
+      old_nph = .false.; nph1 = 0.0_wp
+      inquire(file=trim(path), exist=ex)
+      if (.not. ex) return
+      if (lart_out_read_key(cstr(path), cstr(section), cstr('nphotons'), nph1) /= 0 .or. nph1 <= 0.0_wp) then
+         write(*,'(4a)') 'out_merge: no nphotons keyword in section ', section, ' of ', trim(path); return
+      endif
+      old_nph = .true.
+    end function old_nph
+    subroutine merge_arr(path, section, name, a, n, nph1)
+      character(len=*), intent(in) :: path, section, name
+      integer, intent(in) :: n
+      real(wp), intent(inout) :: a(n)
+      real(wp), intent(in) :: nph1
+      real(wp), allocatable :: old(:)
+      real(wp) :: nph2
+      integer :: rc
+      allocate(old(n)); nph2 = real(par%nphotons, wp)
+      rc = lart_out_read(cstr(path), cstr(section), cstr(name), old, int(n, c_long_long))
+      if (rc /= 0) then
+         write(*,'(6a,i0,a)') 'out_merge: cannot read ', name, ' of section ', section, ' in ', trim(path), rc, ': kept this run only'; return
+      endif
+      a = (old*nph1 + a*nph2)/(nph1 + nph2)
+    end subroutine merge_arr
+    subroutine merge_main_file()
+      character(len=512) :: path
+      real(wp) :: nph1, nph2, v
+      path = out_path(trim(par%base_name))
+      if (.not. old_nph(path, 'Spectrum', nph1)) return
+      nph2 = real(par%nphotons, wp); nph_main = nph1 + nph2
+      if (lart_out_read_key(cstr(path), cstr('Spectrum'), cstr('ExeTime'), v) == 0) exetime_tot = par%exetime + v
+      if (lart_out_read_key(cstr(path), cstr('Spectrum'), cstr('Nsc_gas'), v) == 0)  par%nscatt_gas  = (v*nph1 + par%nscatt_gas*nph2)/nph_main
+      if (lart_out_read_key(cstr(path), cstr('Spectrum'), cstr('Nsc_dust'), v) == 0) par%nscatt_dust = (v*nph1 + par%nscatt_dust*nph2)/nph_main
+      if (lart_out_read_key(cstr(path), cstr('Spectrum'), cstr('Nsc_tot'), v) == 0)  par%nscatt_tot  = (v*nph1 + par%nscatt_tot*nph2)/nph_main
+      call merge_arr(path, 'Spectrum', 'Jout', g%Jout, g%nxfreq, nph1)
+      if (par%save_Jabs) call merge_arr(path, 'Spectrum', 'Jabs', g%Jabs, g%nxfreq, nph1)
+      if (par%save_Jin)  call merge_arr(path, 'Spectrum', 'Jin',  g%Jin,  g%nxfreq, nph1)
+      if (par%save_Jmu)  call merge_arr(path, 'Jmu', 'data', g%Jmu, size(g%Jmu), nph1)
+      if (allocated(prof_J1))     call merge_arr(path, 'Jx_1D', 'data', prof_J1, size(prof_J1), nph1)
+      if (allocated(prof_P1))     call merge_arr(path, 'Pa_1D', 'data', prof_P1, size(prof_P1), nph1)
+      if (allocated(prof_P1_new)) call merge_arr(path, 'Pa_1D_new', 'data', prof_P1_new, size(prof_P1_new), nph1)
+      write(*,'(3a,es12.4,a,es12.4)') 'out_merge: combined with ', trim(path), ': photons ', nph1, ' + ', nph2
+    end subroutine merge_main_file
+    subroutine merge_peel_files(io, tail, two_d)
+      integer, intent(in) :: io
+      character(len=*), intent(in) :: tail
+      logical, intent(in) :: two_d
+      character(len=512) :: path
+      real(wp) :: nph1
+      integer :: n
+      if (two_d) then
+         path = out_path(trim(par%base_name)//'_obs2D'//tail); n = size(obs_scatt_2D, 1)*size(obs_scatt_2D, 2)
+         if (old_nph(path, 'Scattered', nph1)) then
+            call merge_arr(path, 'Scattered', 'data', obs_scatt_2D(:,:,io), n, nph1); call merge_arr(path, 'Direct', 'data', obs_direc_2D(:,:,io), n, nph1)
+            if (allocated(obs_direc0_2D)) call merge_arr(path, 'Direct0', 'data', obs_direc0_2D(:,:,io), n, nph1)
+            nph_key = nph1 + real(par%nphotons, wp)
+         endif
+         if (par%use_stokes .and. allocated(obs_I_2D)) then
+            path = out_path(trim(par%base_name)//'_stokes_2D'//tail)
+            if (old_nph(path, 'Stokes_I', nph1)) then
+               call merge_arr(path, 'Stokes_I', 'data', obs_I_2D(:,:,io), n, nph1); call merge_arr(path, 'Stokes_Q', 'data', obs_Q_2D(:,:,io), n, nph1)
+               call merge_arr(path, 'Stokes_U', 'data', obs_U_2D(:,:,io), n, nph1); call merge_arr(path, 'Stokes_V', 'data', obs_V_2D(:,:,io), n, nph1)
+            endif
+         endif
+      else
+         path = out_path(trim(par%base_name)//'_obs'//tail); n = size(obs_scatt, 1)*size(obs_scatt, 2)*size(obs_scatt, 3)
+         if (old_nph(path, 'Scattered', nph1)) then
+            call merge_arr(path, 'Scattered', 'data', obs_scatt(:,:,:,io), n, nph1); call merge_arr(path, 'Direct', 'data', obs_direc(:,:,:,io), n, nph1)
+            if (allocated(obs_direc0))     call merge_arr(path, 'Direct0',  'data', obs_direc0(:,:,:,io), n, nph1)
+            if (allocated(obs_scatt_dust)) call merge_arr(path, 'ScatDust', 'data', obs_scatt_dust(:,:,:,io), n, nph1)
+            nph_key = nph1 + real(par%nphotons, wp)
+         endif
+         if (par%use_stokes .and. allocated(obs_I)) then
+            path = out_path(trim(par%base_name)//'_stokes'//tail)
+            if (old_nph(path, 'Stokes_I', nph1)) then
+               call merge_arr(path, 'Stokes_I', 'data', obs_I(:,:,:,io), n, nph1); call merge_arr(path, 'Stokes_Q', 'data', obs_Q(:,:,:,io), n, nph1)
+               call merge_arr(path, 'Stokes_U', 'data', obs_U(:,:,:,io), n, nph1); call merge_arr(path, 'Stokes_V', 'data', obs_V(:,:,:,io), n, nph1)
+            endif
+         endif
+      endif
+    end subroutine merge_peel_files
   end subroutine write_output
 
   !--- keywords of the first section of a peel-off file, in the reference's order:
@@ -628,7 +743,7 @@ contains
        call kadd(k, 'I_unit', par%intensity_unit, 'Intensity Unit (0:no dimension, 1:cm^-2 A^-1)')
        call kadd(k, 'Dfreq', g%Dfreq_ref, 'Doppler Freq.  (Hz)')
     endif
-    call kadd(k, 'nphotons', real(par%nphotons, wp), 'number of photons')
+    call kadd(k, 'nphotons', nph_key, 'number of photons')
     if (mode <= 2) then
        call kadd(k, 'alpha', par%alpha(io), 'alpha (degree)')
        call kadd(k, 'beta',  par%beta(io),  'beta (degree)')

@@ -118,6 +118,8 @@ def read_h5(path):
     lib.H5Aopen.restype = hid; lib.H5Aopen.argtypes = [hid, C.c_char_p, hid]
     lib.H5Aget_type.restype = hid; lib.H5Aget_type.argtypes = [hid]; lib.H5Tget_class.argtypes = [hid]; lib.H5Tget_size.restype = C.c_size_t; lib.H5Tget_size.argtypes = [hid]
     lib.H5Aread.argtypes = [hid, hid, C.c_void_p]
+    for fn in ("H5Fclose", "H5Gclose", "H5Dclose", "H5Aclose", "H5Sclose", "H5Tclose"):
+        getattr(lib, fn).argtypes = [hid]                     # 64-bit identifiers: without this every close fails and the file stays locked
     lib.H5Literate.argtypes = [hid, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.H5Aiterate2.argtypes = [hid, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     LCB = C.CFUNCTYPE(C.c_int, hid, C.c_char_p, C.c_void_p, C.c_void_p)
@@ -144,14 +146,14 @@ def read_h5(path):
                 v = C.c_int(); lib.H5Aread(a, NATIVE_INT, C.byref(v)); attrs[an] = v.value
             else:
                 buf = C.create_string_buffer(lib.H5Tget_size(t) + 1); lib.H5Aread(a, t, buf); attrs[an] = buf.value.decode().strip()
-            lib.H5Aclose(a)
+            lib.H5Tclose(t); lib.H5Aclose(a)
         cols = {}
         for dn in names_of(g):
             d = lib.H5Dopen2(g, dn.encode(), 0); sp = lib.H5Dget_space(d); nd = lib.H5Sget_simple_extent_ndims(sp)
             dims = (C.c_uint64 * nd)(); lib.H5Sget_simple_extent_dims(sp, dims, None)
             arr = np.zeros(tuple(dims), dtype=np.float64); lib.H5Dread(d, NATIVE_DOUBLE, 0, 0, 0, arr.ctypes.data_as(C.c_void_p))
             cols[dn] = arr.T if nd > 1 else arr                  # back to Fortran index order
-            lib.H5Dclose(d)
+            lib.H5Sclose(sp); lib.H5Dclose(d)
         res[gname] = (attrs, cols["data"] if list(cols) == ["data"] else cols)
         lib.H5Gclose(g)
     lib.H5Fclose(f)
@@ -331,6 +333,61 @@ def test_clump_file_written_and_read_back(exe, tmp_path, fmt):
     clump.write_clumps_info(str(tmp_path / ("py_clumps" + (".h5" if fmt == "hdf5" else ".fits"))), par, line, cl)
     r3 = run(exe, rd.replace("'w_clumps'", "'py_clumps'"), tmp_path, "--dry-run", name="r3.in")
     assert r3.returncode == 0 and re.search(r"CSR grid:\s+%d registrations" % len(cl2.cg_list), r3.stdout), r3.stdout + r3.stderr
+
+
+MERGE_IN = ("&parameters\n par%no_photons = {n}\n par%temperature = 1e4\n par%taumax = 1e2\n par%nx = 21\n par%ny = 21\n par%nz = 21\n par%rmax = 1.0\n par%nxfreq = 51\n"
+            " par%nxim = 8\n par%nyim = 8\n par%use_stokes = .true.\n par%save_peeloff_2D = .true.\n par%save_Jin = .true.\n par%save_Jmu = .true.\n par%nmu = 4\n"
+            " par%iseed = {seed}\n par%out_merge = {merge}\n par%file_format = '{fmt}'\n/\n")
+
+
+@pytest.mark.parametrize("fmt", ["hdf5", "fits"])
+def test_out_merge_dry_run(exe, tmp_path, fmt):
+    """par%out_merge (write_output_rect.f90:75-78, 112-143): no previous file -> a plain write; with one -> the photon counts add up in every file"""
+    rd = read_h5 if fmt == "hdf5" else read_fits; ext = ".h5" if fmt == "hdf5" else ".fits.gz"
+    r = run(exe, MERGE_IN.format(n=1000, seed=3, merge=".true.", fmt=fmt), tmp_path, "--dry-run-write", name="m.in")
+    assert r.returncode == 0 and "out_merge: combined" not in r.stdout, r.stdout + r.stderr
+    k = {a.lower(): b for a, b in rd(str(tmp_path / ("m" + ext)))["Spectrum"][0].items()}
+    assert float(k["nphotons"]) == 1000
+    r = run(exe, MERGE_IN.format(n=3000, seed=4, merge=".true.", fmt=fmt), tmp_path, "--dry-run-write", name="m.in")
+    assert r.returncode == 0 and "out_merge: combined with m" + ext in r.stdout, r.stdout + r.stderr
+    k = {a.lower(): b for a, b in rd(str(tmp_path / ("m" + ext)))["Spectrum"][0].items()}
+    assert float(k["nphotons"]) == 4000
+    for f, sec in (("m_obs", "Scattered"), ("m_stokes", "Stokes_I"), ("m_obs2D", "Scattered"), ("m_stokes_2D", "Stokes_I")):
+        kk = {a.lower(): b for a, b in rd(str(tmp_path / (f + ext)))[sec][0].items()}
+        assert float(kk["nphotons"]) == 4000, f
+    r = run(exe, MERGE_IN.format(n=500, seed=5, merge=".false.", fmt=fmt), tmp_path, "--dry-run-write", name="m.in")      # switched off: overwritten
+    k = {a.lower(): b for a, b in rd(str(tmp_path / ("m" + ext)))["Spectrum"][0].items()}
+    assert r.returncode == 0 and float(k["nphotons"]) == 500
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt", ["hdf5", "fits"])
+def test_out_merge_end_to_end(exe, tmp_path, fmt):
+    """two runs with different seeds merged by the host = the photon-weighted mean of the two runs made separately (every array of every file)"""
+    rd = read_h5 if fmt == "hdf5" else read_fits; ext = ".h5" if fmt == "hdf5" else ".fits.gz"
+    out = {}
+    for name, n, seed in (("a", 20000, 3), ("b", 60000, 4)):
+        r = run(exe, MERGE_IN.format(n=n, seed=seed, merge=".false.", fmt=fmt), tmp_path, name=name + ".in")
+        assert r.returncode == 0, r.stdout + r.stderr
+        out[name] = {f: rd(str(tmp_path / (name + f + ext))) for f in ("", "_obs", "_stokes", "_obs2D", "_stokes_2D")}
+    for n, seed in ((20000, 3), (60000, 4)):
+        r = run(exe, MERGE_IN.format(n=n, seed=seed, merge=".true.", fmt=fmt), tmp_path, name="m.in")
+        assert r.returncode == 0, r.stdout + r.stderr
+    M = {f: rd(str(tmp_path / ("m" + f + ext))) for f in ("", "_obs", "_stokes", "_obs2D", "_stokes_2D")}
+    w = lambda x, y: (np.asarray(x) * 20000 + np.asarray(y) * 60000) / 80000
+    for col in ("Jout", "Jin"):
+        assert np.allclose(M[""]["Spectrum"][1][col], w(out["a"][""]["Spectrum"][1][col], out["b"][""]["Spectrum"][1][col]), rtol=1e-6, atol=1e-12), col
+    assert np.allclose(M[""]["Jmu"][1], w(out["a"][""]["Jmu"][1], out["b"][""]["Jmu"][1]), rtol=1e-6, atol=1e-12)
+    for f, secs in (("_obs", ("Scattered", "Direct")), ("_stokes", ("Stokes_I", "Stokes_Q", "Stokes_U")), ("_obs2D", ("Scattered", "Direct")), ("_stokes_2D", ("Stokes_I", "Stokes_Q"))):
+        for sec in secs:
+            A, B, C_ = out["a"][f][sec][1], out["b"][f][sec][1], M[f][sec][1]
+            assert np.allclose(C_, w(A, B), rtol=1e-5, atol=1e-9 * np.abs(C_).max()), (f, sec)
+    k = {a.lower(): b for a, b in M[""]["Spectrum"][0].items()}
+    ka = {a.lower(): b for a, b in out["a"][""]["Spectrum"][0].items()}; kb = {a.lower(): b for a, b in out["b"][""]["Spectrum"][0].items()}
+    assert float(k["nphotons"]) == 80000 and np.isclose(float(k["nsc_tot"]), (float(ka["nsc_tot"]) * 20000 + float(kb["nsc_tot"]) * 60000) / 80000, rtol=1e-6)
+    # the radial profiles are recomputed from the merged images
+    ra, rb, rm = out["a"]["_obs"]["RadialI"][1]["I"], out["b"]["_obs"]["RadialI"][1]["I"], M["_obs"]["RadialI"][1]["I"]
+    assert np.allclose(rm, w(ra, rb), rtol=1e-5, atol=1e-9 * np.abs(rm).max())
 
 
 AMR_IN = """&parameters
