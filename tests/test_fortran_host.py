@@ -337,7 +337,7 @@ def test_clump_file_written_and_read_back(exe, tmp_path, fmt):
 
 MERGE_IN = ("&parameters\n par%no_photons = {n}\n par%temperature = 1e4\n par%taumax = 1e2\n par%nx = 21\n par%ny = 21\n par%nz = 21\n par%rmax = 1.0\n par%nxfreq = 51\n"
             " par%nxim = 8\n par%nyim = 8\n par%use_stokes = .true.\n par%save_peeloff_2D = .true.\n par%save_Jin = .true.\n par%save_Jmu = .true.\n par%nmu = 4\n"
-            " par%iseed = {seed}\n par%out_merge = {merge}\n par%file_format = '{fmt}'\n/\n")
+            " par%save_radial_profile = .true.\n par%iseed = {seed}\n par%out_merge = {merge}\n par%file_format = '{fmt}'\n/\n")
 
 
 @pytest.mark.parametrize("fmt", ["hdf5", "fits"])
