@@ -177,6 +177,9 @@ const char *lart_host_last_error(void);
 int  lart_host_clumps_generate(int64_t n, double sphere_R, double r_min, double clump_radius, int32_t flags,
                                double sigma_v_over_vtherm, int64_t iseed, double *x, double *y, double *z,
                                double *vx, double *vy, double *vz, double *acceptance);
+int  lart_host_clumps_generate_cone(int64_t n, double sphere_R, double r_min, double clump_radius, int32_t flags, double cone_opening_deg,
+                                    double sigma_v_over_vtherm, int64_t iseed, double *x, double *y, double *z,
+                                    double *vx, double *vy, double *vz, double *acceptance);   /* ... inside the bicone of par%cone_opening about the z axis (:1029-1048) */
 int  lart_host_clumps_csr_dims(int64_t n, double sphere_R, double radius_max, int32_t *cgx, double *cg_min, double *cg_d);
 int  lart_host_clumps_build_csr(int64_t n, const double *x, const double *y, const double *z, const double *radius,
                                 int32_t cgx, double cg_min, double cg_d, int32_t *cg_start, int32_t *cg_list, int64_t *nreg);

@@ -443,6 +443,14 @@ def grid_create_amr(par, line, path):
     g.rhokap = d["nH"] * line.cross0 / g.Dfreq * par.distance2cm
     g.rhokapD = d["nH"] * par.cext_dust * par.DGR * par.distance2cm if par.DGR > 0.0 else None
     g.vfx, g.vfy, g.vfz = d["vx"] / vt, d["vy"] / vt, d["vz"] / vt
+    if 0.0 < par.cone_opening < 90.0:                    # Step 4b (:336-350): biconical mask by leaf centre
+        ic = g.icell_of_leaf - 1
+        rr = np.sqrt(g.cx[ic] ** 2 + g.cy[ic] ** 2 + g.cz[ic] ** 2)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            out = (rr > 0.0) & (np.abs(g.cz[ic]) / rr < math.cos(par.cone_opening * math.pi / 180.0))
+        g.rhokap[out] = 0.0
+        if g.rhokapD is not None:
+            g.rhokapD[out] = 0.0
     H0 = voigt_center(g.voigt_a)
     nopac = float((g.rhokap > 0).sum())
     opac_length = bl / 2.0

@@ -41,7 +41,7 @@ class LartLineMultiplet(C.Structure):
 
 SYMBOLS = ["lart_host_line_lookup", "lart_gpu_set_line_multiplet", "lart_gpu_device_count", "lart_gpu_create", "lart_gpu_destroy", "lart_gpu_last_error",
            "lart_gpu_set_grid_car", "lart_gpu_set_mueller", "lart_gpu_set_observers", "lart_gpu_set_observers_heal",
-           "lart_gpu_set_JPa", "lart_gpu_set_grid_amr", "lart_gpu_set_JPa_amr", "lart_gpu_set_clumps", "lart_gpu_set_clump_overlap", "lart_host_last_error", "lart_host_clumps_generate", "lart_host_clumps_csr_dims", "lart_host_clumps_build_csr", "lart_host_clumps_has_overlap", "lart_host_amr_last_error", "lart_host_amr_count", "lart_host_amr_build", "lart_gpu_run",
+           "lart_gpu_set_JPa", "lart_gpu_set_grid_amr", "lart_gpu_set_JPa_amr", "lart_gpu_set_clumps", "lart_gpu_set_clump_overlap", "lart_host_last_error", "lart_host_clumps_generate", "lart_host_clumps_generate_cone", "lart_host_clumps_csr_dims", "lart_host_clumps_build_csr", "lart_host_clumps_has_overlap", "lart_host_amr_last_error", "lart_host_amr_count", "lart_host_amr_build", "lart_gpu_run",
            "lart_gpu_begin", "lart_gpu_step", "lart_gpu_sync", "lart_gpu_kernel_time", "lart_gpu_sightline_tau", "lart_gpu_sightline_time",
            "lart_gpu_enable_photon_log", "lart_gpu_get_photon_log", "lart_gpu_enable_all_photons", "lart_gpu_get_all_photons", "lart_gpu_set_pool", "lart_gpu_pool_info",
            "lart_gpu_tally_buffer", "lart_gpu_zero_tallies", "lart_gpu_get_tallies",
@@ -72,6 +72,7 @@ def lib():
         L.lart_gpu_set_JPa_amr.argtypes = [_vp, _i32, _i32, _i32, _i32, _i32, _d, _d]
         L.lart_host_last_error.restype = C.c_char_p
         L.lart_host_clumps_generate.argtypes = [_i64, _d, _d, _d, _i32, _d, _i64] + [_vp] * 7
+        L.lart_host_clumps_generate_cone.argtypes = [_i64, _d, _d, _d, _i32, _d, _d, _i64] + [_vp] * 7
         L.lart_host_clumps_csr_dims.argtypes = [_i64, _d, _d, _vp, _vp, _vp]
         L.lart_host_clumps_build_csr.argtypes = [_i64, _vp, _vp, _vp, _vp, _i32, _d, _d, _vp, _vp, _vp]
         L.lart_host_clumps_has_overlap.argtypes = [_i64, _vp, _vp, _vp, _vp, _i32, _d, _d, _vp, _vp, _vp]

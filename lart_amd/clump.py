@@ -139,7 +139,7 @@ def init_clumps(par, line, R_sphere):
     cl.rhokapD = np.full(n, cl.rhokap_ref * par.cext_dust * par.DGR * cl.Dfreq_ref / line.cross0) if par.DGR > 0.0 else None
     acc = C.c_double()
     sig = par.clump_sigma_v / cl.vtherm_ref if par.clump_sigma_v > 0.0 else 0.0
-    _hchk(capi.lib().lart_host_clumps_generate(n, cl.sphere_R, cl.r_min, rc, int(par.clump_fully_inside) | (2 if par.clump_allow_overlap else 0), sig, int(par.iseed),
+    _hchk(capi.lib().lart_host_clumps_generate_cone(n, cl.sphere_R, cl.r_min, rc, int(par.clump_fully_inside) | (2 if par.clump_allow_overlap else 0), float(par.cone_opening), sig, int(par.iseed),
                                                capi._p(cl.x), capi._p(cl.y), capi._p(cl.z), capi._p(cl.vx), capi._p(cl.vy), capi._p(cl.vz), C.byref(acc)))
     cl.rsa_acceptance = acc.value
     if par.velocity_type:

@@ -35,9 +35,16 @@ extern "C" const char *lart_host_last_error(void) { return h_err.c_str(); }
 extern "C" int lart_host_clumps_generate(int64_t n, double sphere_R, double r_min, double clump_radius, int32_t flags,
                                          double sigma_v_over_vtherm, int64_t iseed, double *x, double *y, double *z,
                                          double *vx, double *vy, double *vz, double *acceptance) {
+    return lart_host_clumps_generate_cone(n, sphere_R, r_min, clump_radius, flags, 0.0, sigma_v_over_vtherm, iseed, x, y, z, vx, vy, vz, acceptance);
+}
+// ... with par%cone_opening [deg]: centres drawn directly inside the bicone about the z axis (:1029-1048), 0 or >= 90 = the whole shell
+extern "C" int lart_host_clumps_generate_cone(int64_t n, double sphere_R, double r_min, double clump_radius, int32_t flags, double cone_opening_deg,
+                                              double sigma_v_over_vtherm, int64_t iseed, double *x, double *y, double *z,
+                                              double *vx, double *vy, double *vz, double *acceptance) {
     if (n < 1 || !(sphere_R > 0.0) || !(clump_radius > 0.0) || r_min < 0.0 || r_min >= sphere_R || !x || !y || !z || !vx || !vy || !vz)
         return hfail("clumps_generate: bad argument");
-    const bool fully_inside = flags & 1, allow_overlap = flags & 2;      // par%clump_fully_inside, par%clump_allow_overlap (:1090: the overlap test runs, the trial is kept)
+    const bool fully_inside = flags & 1, allow_overlap = flags & 2;
+    const double cos_cone = (cone_opening_deg > 0.0 && cone_opening_deg < 90.0) ? std::cos(cone_opening_deg * (3.14159265358979323846264338327950288 / 180.0)) : -1.0;      // par%clump_fully_inside, par%clump_allow_overlap (:1090: the overlap test runs, the trial is kept)
     if (fully_inside && (clump_radius >= sphere_R || r_min + 2.0 * clump_radius > sphere_R))
         return hfail("clumps_generate: clump_fully_inside but no clump fits inside the shell (clump_mod.f90:937-951)");
     int rg = (int)std::pow((double)n, 1.0 / 3.0) + 1; if (rg < 32) rg = 32; if (rg > 512) rg = 512;
@@ -55,6 +62,22 @@ extern "C" int lart_host_clumps_generate(int64_t n, double sphere_R, double r_mi
     while (icl < n) {
         if (++attempts > max_attempts) return hfail("clumps_generate: random sequential adsorption did not converge (volume filling too high)");
         double xc, yc, zc, d2;
+        if (cos_cone > 0.0) {                                      // direct sampling inside the bicone: clump_mod.f90:1029-1048
+            double r_trial, cos_theta, sin_theta;
+            for (;;) {
+                r_trial = std::pow(r_min_c * r_min_c * r_min_c + (r_max_c * r_max_c * r_max_c - r_min_c * r_min_c * r_min_c) * mt.rnd(), 1.0 / 3.0);
+                cos_theta = cos_cone + (1.0 - cos_cone) * mt.rnd();
+                if (mt.rnd() < 0.5) cos_theta = -cos_theta;
+                sin_theta = std::sqrt(std::fmax(0.0, 1.0 - cos_theta * cos_theta));
+                if (fully_inside && r_trial > clump_radius) {
+                    const double q = clump_radius / r_trial, cos_theta_min = std::fabs(cos_theta) * std::sqrt(1.0 - q * q) - sin_theta * q;
+                    if (cos_theta_min < cos_cone) continue;
+                }
+                break;
+            }
+            const double phi = 6.283185307179586476925286766559 * mt.rnd();
+            xc = r_trial * sin_theta * std::cos(phi); yc = r_trial * sin_theta * std::sin(phi); zc = r_trial * cos_theta;
+        } else
         for (;;) {
             xc = (2.0 * mt.rnd() - 1.0) * r_max_c; yc = (2.0 * mt.rnd() - 1.0) * r_max_c; zc = (2.0 * mt.rnd() - 1.0) * r_max_c;
             d2 = xc * xc + yc * yc + zc * zc;

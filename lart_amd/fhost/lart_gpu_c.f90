@@ -126,6 +126,13 @@ module lart_gpu_c
        real(c_double), intent(out) :: x(*), y(*), z(*), vx(*), vy(*), vz(*), acceptance
        integer(c_int) :: rc
      end function
+     function lart_host_clumps_generate_cone(n, sphere_R, r_min, clump_radius, flags, cone_opening_deg, sigma_v_over_vtherm, iseed, &
+                                             x, y, z, vx, vy, vz, acceptance) bind(C, name='lart_host_clumps_generate_cone') result(rc)
+       import; integer(c_int64_t), value :: n, iseed; real(c_double), value :: sphere_R, r_min, clump_radius, cone_opening_deg, sigma_v_over_vtherm
+       integer(c_int32_t), value :: flags
+       real(c_double), intent(out) :: x(*), y(*), z(*), vx(*), vy(*), vz(*), acceptance
+       integer(c_int) :: rc
+     end function
      function lart_host_clumps_csr_dims(n, sphere_R, radius_max, cgx, cg_min, cg_d) bind(C, name='lart_host_clumps_csr_dims') result(rc)
        import; integer(c_int64_t), value :: n; real(c_double), value :: sphere_R, radius_max
        integer(c_int32_t), intent(out) :: cgx; real(c_double), intent(out) :: cg_min, cg_d

@@ -359,7 +359,6 @@ contains
     if (par%density_rscale /= -999.9_wp) call not_supported('par%density_rscale')
     if (par%density_zscale /= -999.9_wp) call not_supported('par%density_zscale')
     if (par%density_alpha /= 0.0_wp) call not_supported('par%density_alpha')
-    if (par%cone_opening /= 0.0_wp) call not_supported('par%cone_opening')
     if (par%q /= 1.0_wp) call not_supported('par%q')
     if (par%Omega /= 0.0_wp) call not_supported('par%Omega')
     if (.not. par%continuum_normalize) call not_supported('par%continuum_normalize')
@@ -803,6 +802,17 @@ contains
           endif
        enddo; enddo; enddo
     endif
+    if (par%cone_opening > 0.0_wp .and. par%cone_opening < 90.0_wp) then                        ! :397-412 biconical mask about the z axis
+       do k = 1, nz; do j = 1, ny; do i = 1, nx
+          rr = sqrt(xx(i)**2 + yy(j)**2 + zz(k)**2)
+          if (rr > 0.0_wp) then
+             if (abs(zz(k))/rr < cos(par%cone_opening*deg2rad)) then
+                grid%rhokap(i,j,k) = 0.0_wp
+                if (par%DGR > 0.0_wp) grid%rhokapD(i,j,k) = 0.0_wp
+             endif
+          endif
+       enddo; enddo; enddo
+    endif
     grid%rhokap = grid%rhokap/grid%Dfreq*line%cross0                                            ! :487-493
     if (par%rmax > 0.0_wp .and. par%rmin > 0.0_wp) then                                         ! :495-503
        opac_length = par%rmax - par%rmin
@@ -1104,8 +1114,8 @@ contains
     endif
     sig = 0.0_wp
     if (par%clump_sigma_v > 0.0_wp) sig = par%clump_sigma_v/cl_vtherm_ref
-    call host_check(lart_host_clumps_generate(N_clumps, sphere_R, r_min_clump, rc, &
-         merge(1_c_int32_t, 0_c_int32_t, par%clump_fully_inside) + merge(2_c_int32_t, 0_c_int32_t, par%clump_allow_overlap), &
+    call host_check(lart_host_clumps_generate_cone(N_clumps, sphere_R, r_min_clump, rc, &
+         merge(1_c_int32_t, 0_c_int32_t, par%clump_fully_inside) + merge(2_c_int32_t, 0_c_int32_t, par%clump_allow_overlap), par%cone_opening, &
          sig, int(par%iseed, c_int64_t), cl_x, cl_y, cl_z, cl_vx, cl_vy, cl_vz, acc), 'lart_host_clumps_generate')
     if (par%clump_allow_overlap) then
        write(*,'(a)') ' Random placement done (overlap allowed).'
@@ -1476,6 +1486,17 @@ contains
        amr_vfx(il) = lvx(il)/vt; amr_vfy(il) = lvy(il)/vt; amr_vfz(il) = lvz(il)/vt
     enddo
 
+    if (par%cone_opening > 0.0_wp .and. par%cone_opening < 90.0_wp) then     ! Step 4b (:336-350): biconical mask by leaf centre
+       do il = 1, n
+          xc = sqrt(amr_cx(amr_icell_of_leaf(il))**2 + amr_cy(amr_icell_of_leaf(il))**2 + amr_cz(amr_icell_of_leaf(il))**2)
+          if (xc > 0.0_wp) then
+             if (abs(amr_cz(amr_icell_of_leaf(il)))/xc < cos(par%cone_opening*deg2rad)) then
+                amr_rhokap(il) = 0.0_wp
+                if (allocated(amr_rhokapD)) amr_rhokapD(il) = 0.0_wp
+             endif
+          endif
+       enddo
+    endif
     !--- homogeneous and +z pole optical depths, normalisation (:352-470)
     opac_length = boxlen/2.0_wp
     nopac = real(count(amr_rhokap > 0.0_wp), wp)

@@ -155,6 +155,7 @@ class Params:
     clump_sigma_v: float = 0.0
     clump_fully_inside: bool = True
     clump_allow_overlap: bool = False
+    cone_opening: float = 0.0       # bicone half-opening angle about the z axis [deg], 0 = everything
     clump_input_file: str = ""
     save_clump_info: bool = False
     Vrot: float = 0.0
@@ -185,7 +186,7 @@ _UNSUPPORTED_DEFAULTS = {
     "h2_model": "none", "z_symmetry": False,
     "dens_file": "", "temp_file": "", "velo_file": "", "emiss_file": "", "cart_file": "", "input_field": "",
     "star_file": "", "use_cie_condition": False, "density_rscale": -999.9, "density_zscale": -999.9,
-    "density_alpha": 0.0, "cone_opening": 0.0, "Omega": 0.0, "temperature0": -999.0,
+    "density_alpha": 0.0, "Omega": 0.0, "temperature0": -999.0,
     "line_prof_file": "", "luminosity": 1.0, "save_backup": False, "save_input_grid": False,
     "intensity_unit": -999, "out_bitpix": 0,
     # the rest of the reference's namelist surface (define.f90:209-544): readable, rejected when set
@@ -664,6 +665,12 @@ def grid_create(par, line):
     rr = np.sqrt(X ** 2 + Y ** 2 + Z ** 2)
     if par.rmax > 0.0:                                                    # :367-395
         out = (rr < par.rmin) | (rr > par.rmax)
+        g.rhokap[out] = 0.0
+        if g.rhokapD is not None:
+            g.rhokapD[out] = 0.0
+    if 0.0 < par.cone_opening < 90.0:                                     # :397-412 biconical mask about the z axis
+        with np.errstate(invalid="ignore", divide="ignore"):
+            out = (rr > 0.0) & (np.abs(Z) / rr < math.cos(par.cone_opening * math.pi / 180.0))
         g.rhokap[out] = 0.0
         if g.rhokapD is not None:
             g.rhokapD[out] = 0.0

@@ -299,6 +299,7 @@ typedef struct {
 struct orc_sim {
     int use_amr_grid; char amr_file[512]; amr_t amr;
     int use_clump_medium, clump_fully_inside, clump_allow_overlap; clumps_t cl;
+    double cone_opening;                                    /* par%cone_opening [deg]: bicone about the z axis, 0 = everything */
     double clump_radius, clump_N_clumps, clump_f_vol, clump_f_cov, clump_tau0, clump_NHI, clump_nH, clump_temperature, clump_sigma_v;
     int HeI_coherent;                        /* par%HeI_coherent (line type 6) */
     double bturb;                            /* par%bturb [km/s], <= 0: none */
@@ -447,7 +448,7 @@ static int set_param(orc_sim *s, const char *k, const char *v) {
     if (!strcmp(k, "N_HImax") || !strcmp(k, "N_gasmax") || !strcmp(k, "N_HI")) { s->N_gasmax = atof(v); return 0; }
     if (!strcmp(k, "N_HIhomo") || !strcmp(k, "N_gashomo")) { s->N_gashomo = atof(v); return 0; }
     if (!strcmp(k, "tau0")) { s->taumax = atof(v); return 0; }
-    B(use_clump_medium) B(clump_fully_inside) B(clump_allow_overlap) D(clump_radius) D(clump_N_clumps) D(clump_f_vol) D(clump_f_cov) D(clump_tau0) D(clump_NHI) D(clump_nH)
+    B(use_clump_medium) B(clump_fully_inside) B(clump_allow_overlap) D(cone_opening) D(clump_radius) D(clump_N_clumps) D(clump_f_vol) D(clump_f_cov) D(clump_tau0) D(clump_NHI) D(clump_nH)
     D(clump_temperature) D(clump_sigma_v) D(Vrot) D(rinner) D(velocity_min) D(velocity_max) D(Vpeak) D(rpeak) D(DeltaV) D(velocity_alpha) D(gaussian_sigma_vel) D(gaussian_FWHM_vel) D(source_zscale) D(D_to_H_ratio) D(wavelength_min) D(wavelength_max) D(bturb)
     if (!strcmp(k, "use_amr_grid")) { s->use_amr_grid = parse_bool(v); return 0; }
     if (!strcmp(k, "amr_file")) { snprintf(s->amr_file, sizeof s->amr_file, "%s", v); return 0; }
@@ -698,6 +699,13 @@ static int grid_create(orc_sim *s) {
         for (int k = 1; k <= nz; k++) for (int j = 1; j <= ny; j++) for (int i = 1; i <= nx; i++) {
             double rr = sqrt(xx[i-1] * xx[i-1] + yy[j-1] * yy[j-1] + zz[k-1] * zz[k-1]);
             if (rr < s->rmin || rr > s->rmax) { s->rhokap[IDX(s,i,j,k)] = 0.0; if (s->DGR > 0.0) s->rhokapD[IDX(s,i,j,k)] = 0.0; }
+        }
+    }
+    if (s->cone_opening > 0.0 && s->cone_opening < 90.0) {                          /* :397-412 biconical mask about the z axis */
+        const double cos_cone = cos(s->cone_opening * (PI / 180.0));
+        for (int k = 1; k <= nz; k++) for (int j = 1; j <= ny; j++) for (int i = 1; i <= nx; i++) {
+            double rr = sqrt(xx[i-1] * xx[i-1] + yy[j-1] * yy[j-1] + zz[k-1] * zz[k-1]);
+            if (rr > 0.0 && fabs(zz[k-1]) / rr < cos_cone) { s->rhokap[IDX(s,i,j,k)] = 0.0; if (s->DGR > 0.0) s->rhokapD[IDX(s,i,j,k)] = 0.0; }
         }
     }
     for (size_t c = 0; c < nc; c++) s->rhokap[c] = s->rhokap[c] / s->Dfreq[c] * s->cross0;    /* :487-493 */
@@ -1173,6 +1181,11 @@ static int grid_create_amr(orc_sim *s) {
         s->vfx[il] = col[6][il] / vt; s->vfy[il] = col[7][il] / vt; s->vfz[il] = col[8][il] / vt;
     }
     for (int c = 0; c < 9; c++) free(col[c]); free(lev);
+    if (s->cone_opening > 0.0 && s->cone_opening < 90.0) {                                  /* Step 4b :336-350: biconical mask by leaf centre */
+        const double cos_cone = cos(s->cone_opening * (PI / 180.0));
+        for (int il = 0; il < nleaf; il++) { int ic = a->icell_of_leaf[il]; double rr = sqrt(a->cx[ic-1] * a->cx[ic-1] + a->cy[ic-1] * a->cy[ic-1] + a->cz[ic-1] * a->cz[ic-1]);
+            if (rr > 0.0 && fabs(a->cz[ic-1]) / rr < cos_cone) { s->rhokap[il] = 0.0; if (s->DGR > 0.0) s->rhokapD[il] = 0.0; } }
+    }
     /* Step 5 (:355-446): tau_homo and the +z pole traversal from the box centre */
     double opacity_sum = 0.0, nopac = 0.0, opac_length = boxlen / 2.0, tauhomo = 0.0, taupole, NHI_pole_raw = 0.0, tau_raw = 0.0, opac_norm = 1.0;
     for (int il = 0; il < nleaf; il++) { opacity_sum += s->rhokap[il] * orc_voigt(0.0, s->voigt_a[il]); if (s->rhokap[il] > 0.0) nopac += 1.0; }
@@ -1412,10 +1425,27 @@ static int generate_clumps(orc_sim *s, rng_t *g) {
     double r_max_center = s->clump_fully_inside ? c->sphere_R - s->clump_radius : c->sphere_R;
     double r_min_center = s->clump_fully_inside ? c->r_min + s->clump_radius : c->r_min;
     double r_max_center2 = r_max_center * r_max_center, r_min_center2 = r_min_center * r_min_center;
+    const double cos_cone = (s->cone_opening > 0.0 && s->cone_opening < 90.0) ? cos(s->cone_opening * (PI / 180.0)) : -1.0;      /* :970-975 */
     while (icl < N) {
         n_attempts++;
         double xc, yc, zc, d2;
-        for (;;) {                                                  /* box rejection :1044-1051 */
+        if (cos_cone > 0.0) {                                       /* direct sampling inside the bicone :1029-1048 */
+            double r_trial, cos_theta, sin_theta;
+            for (;;) {
+                r_trial = pow(r_min_center * r_min_center * r_min_center + (r_max_center * r_max_center * r_max_center - r_min_center * r_min_center * r_min_center) * rnd(g), 1.0 / 3.0);
+                cos_theta = cos_cone + (1.0 - cos_cone) * rnd(g);
+                if (rnd(g) < 0.5) cos_theta = -cos_theta;
+                sin_theta = sqrt(fmax(0.0, 1.0 - cos_theta * cos_theta));
+                if (s->clump_fully_inside && r_trial > s->clump_radius) {
+                    double q = s->clump_radius / r_trial, cmin = fabs(cos_theta) * sqrt(1.0 - q * q) - sin_theta * q;
+                    if (cmin < cos_cone) continue;
+                }
+                break;
+            }
+            double phi = TWOPI * rnd(g);
+            xc = r_trial * sin_theta * cos(phi); yc = r_trial * sin_theta * sin(phi); zc = r_trial * cos_theta;
+        } else
+        for (;;) {                                                  /* box rejection :1049-1056 */
             xc = (2.0 * rnd(g) - 1.0) * r_max_center; yc = (2.0 * rnd(g) - 1.0) * r_max_center; zc = (2.0 * rnd(g) - 1.0) * r_max_center;
             d2 = xc * xc + yc * yc + zc * zc;
             if (d2 <= r_max_center2 && d2 >= r_min_center2) break;

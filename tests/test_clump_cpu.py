@@ -226,3 +226,29 @@ def test_clump_file_with_clump_columns_and_overlaps(tmp_path):
     assert np.allclose(cl.vx * cl.vtherm, cols[3][1].astype(np.float32), rtol=1e-12)
     with pytest.raises(host.LartInputError):
         host_clumps(dict(use_clump_medium=True, rmax=1.0, clump_radius=0.2, clump_input_file=str(tmp_path / "nothing_here"), temperature=1e4))
+
+
+def test_bicone(oracle_mod, tmp_path):
+    """par%cone_opening (examples/bicone): clump centres drawn directly inside the bicone about the z axis (clump_mod.f90:1029-1048), cells and
+    leaves outside it emptied (grid_mod_car.f90:397-412, grid_mod_amr.f90:336-350); hosts equal the oracle"""
+    from lart_amd import host, amr
+    kw = dict(use_clump_medium=True, rmax=1.0, clump_radius=0.02, clump_f_cov=2.0, clump_tau0=1e3, temperature=1e4, cone_opening=45.0, rmin=0.025, nxfreq=121, iseed=3)
+    o = oracle_mod.Oracle(**kw); par, line, cl, g = host_clumps(kw)
+    assert cl.N == int(o.scalar("cl_N")) and np.array_equal(o.array("cl_x"), cl.x) and np.array_equal(o.array("cl_z"), cl.z)
+    r = np.sqrt(cl.x ** 2 + cl.y ** 2 + cl.z ** 2)
+    mu = np.abs(cl.z) / r                                                       # fully inside: the whole clump, not only its centre
+    assert np.all(mu * np.sqrt(1 - (0.02 / r) ** 2) - np.sqrt(1 - mu ** 2) * 0.02 / r >= np.cos(np.pi / 4) - 1e-12) and (cl.z > 0).any() and (cl.z < 0).any()
+    kc = dict(temperature=1e4, taumax=1e2, nx=21, ny=21, nz=21, rmax=1.0, cone_opening=40.0, nxfreq=61, DGR=1.0)
+    oc = oracle_mod.Oracle(**kc); p = host.Params()
+    for k, v in kc.items():
+        host.set_param(p, k, v)
+    p, ln, _ = host.read_input(p); gc = host.grid_create(p, ln)
+    assert np.allclose(oc.array("rhokap"), gc.rhokap.ravel(order="F"), rtol=1e-14) and np.allclose(oc.array("rhokapD"), gc.rhokapD.ravel(order="F"), rtol=1e-14)
+    assert 0.1 < (gc.rhokap > 0).mean() < 0.2 and gc.rhokap[10, 10, 15] > 0 and gc.rhokap[15, 10, 10] == 0
+    fn = str(tmp_path / "s.dat"); amr.write_generic_amr(fn, amr.make_amr_sphere(level_min=2, level_max=4))
+    ka = dict(use_amr_grid=True, amr_file=fn, temperature=1e4, taumax=1e2, rmax=1.0, cone_opening=40.0, nxfreq=61)
+    oa = oracle_mod.Oracle(**ka); pa = host.Params()
+    for k, v in ka.items():
+        host.set_param(pa, k, v)
+    pa, la, _ = host.read_input(pa); ga, sg = amr.grid_create_amr(pa, la, fn)
+    assert np.allclose(oa.array("rhokap"), ga.rhokap, rtol=1e-14) and 0 < (ga.rhokap > 0).mean() < 0.3 and oa.scalar("taumax") == 1e2

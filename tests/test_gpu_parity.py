@@ -919,6 +919,21 @@ def test_file_loaded_overlapping_population(capi, oracle_mod, tmp_path):
     assert np.abs(g3 - o3).max() < 0.02 * o3.max() and abs(g3.sum() - o3.sum()) < 0.02 * o3.sum()
 
 
+@pytest.mark.parametrize("kw", [dict(temperature=1e4, taumax=1e2, nx=31, ny=31, nz=31, rmax=1.0, cone_opening=40.0, nxfreq=61, velocity_type="hubble", Vexp=100.0, iseed=4),
+                                dict(use_clump_medium=True, rmax=1.0, clump_radius=0.03, clump_f_cov=3.0, clump_tau0=50.0, temperature=1e4, cone_opening=45.0, rmin=0.04,
+                                     velocity_type="hubble", Vexp=200.0, nxfreq=121, velocity_min=-400.0, velocity_max=400.0, nx=11, ny=11, nz=11, iseed=3)])
+def test_bicone_histories(capi, oracle_mod, kw):
+    """par%cone_opening (examples/bicone): the biconical outflow through the Cartesian mask and through clumps placed inside the cone"""
+    n = 20000
+    sim = make(kw); sim.ctx.enable_photon_log(True); sim.run_simulation(n); t = sim.ctx.tallies()
+    o = oracle_of(oracle_mod, kw) if not kw.get("use_clump_medium") else oracle_mod.Oracle(**kw)
+    o.run(n, seed=kw["iseed"])
+    ng, xg = sim.ctx.photon_log(n); no, xo = o.photon_log()
+    same = np.isclose(ng, no, rtol=1e-12, atol=0) & np.isclose(xg, xo, rtol=1e-7, atol=1e-9)
+    assert same.mean() > 0.95, same.mean()
+    assert rms_diff(t["Jout"], o.array("Jout")) < 0.01 and t["Jout"].sum() == n
+
+
 def test_overlap_list_overflow_is_refused(capi):
     """more clumps around one point than the march lists hold: lart_gpu_get_tallies fails instead of handing out a result that is not the reference's"""
     kw = dict(OVERLAP, clump_radius=0.9, clump_N_clumps=80, clump_f_cov=-1.0, clump_fully_inside=False, clump_tau0=1.0)
