@@ -920,7 +920,7 @@ def test_file_loaded_overlapping_population(capi, oracle_mod, tmp_path):
 
 
 @pytest.mark.parametrize("kw", [dict(temperature=1e4, taumax=1e2, nx=31, ny=31, nz=31, rmax=1.0, cone_opening=40.0, nxfreq=61, velocity_type="hubble", Vexp=100.0, iseed=4),
-                                dict(use_clump_medium=True, rmax=1.0, clump_radius=0.03, clump_f_cov=3.0, clump_tau0=50.0, temperature=1e4, cone_opening=45.0, rmin=0.04,
+                                dict(use_clump_medium=True, rmax=1.0, clump_radius=0.03, clump_f_cov=1.0, clump_tau0=50.0, temperature=1e4, cone_opening=45.0, rmin=0.04,
                                      velocity_type="hubble", Vexp=200.0, nxfreq=121, velocity_min=-400.0, velocity_max=400.0, nx=11, ny=11, nz=11, iseed=3)])
 def test_bicone_histories(capi, oracle_mod, kw):
     """par%cone_opening (examples/bicone): the biconical outflow through the Cartesian mask and through clumps placed inside the cone"""
@@ -931,7 +931,7 @@ def test_bicone_histories(capi, oracle_mod, kw):
     ng, xg = sim.ctx.photon_log(n); no, xo = o.photon_log()
     same = np.isclose(ng, no, rtol=1e-12, atol=0) & np.isclose(xg, xo, rtol=1e-7, atol=1e-9)
     assert same.mean() > 0.95, same.mean()
-    assert rms_diff(t["Jout"], o.array("Jout")) < 0.01 and t["Jout"].sum() == n
+    assert rms_diff(t["Jout"], o.array("Jout")) < 0.01 and abs(t["Jout"].sum() - o.array("Jout").sum()) < 1e-6 * n and t["Jout"].sum() > 0.99 * n
 
 
 def test_overlap_list_overflow_is_refused(capi):
