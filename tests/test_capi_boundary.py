@@ -104,7 +104,7 @@ def test_namelist_surface(built, tmp_path):
     with pytest.raises(host.LartInputError):
         host.read_namelist(str(bad))
     fs = tmp_path / "fs.in"
-    fs.write_text("&parameters\n par%cone_opening = 30.0\n/\n")
+    fs.write_text("&parameters\n par%density_rscale = 0.5\n/\n")
     with pytest.raises(host.LartInputError, match="not supported"):
         host.read_namelist(str(fs))
     fs.write_text("&parameters\n par%include_deuterium = .true.\n par%fine_structure = .true.\n par%temperature = 1e4\n par%taumax = 1e3\n/\n")

@@ -59,7 +59,7 @@ def test_unknown_field_and_unsupported_mode_fail(exe, tmp_path):
     assert r.returncode != 0 and "ERROR" in r.stdout
     r = run(exe, "&parameters\n par%use_amr_grid = .true.\n/\n", tmp_path, "--dry-run", name="amr.in")
     assert r.returncode != 0 and "needs par%amr_file" in r.stdout
-    r = run(exe, "&parameters\n par%cone_opening = 30.0\n/\n", tmp_path, "--dry-run", name="fs.in")
+    r = run(exe, "&parameters\n par%density_rscale = 0.5\n/\n", tmp_path, "--dry-run", name="fs.in")
     assert r.returncode != 0 and "not supported" in r.stdout
 
 
