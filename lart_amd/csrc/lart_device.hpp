@@ -1221,7 +1221,8 @@ __device__ inline double ovl_march(const KArgs &A, const Lds &l, bool dust, doub
         // ENTER or EXIT; the march would find one interval [0, t_first) with this list and stop at acc / kap in it.  Lower bounds of the
         // distances to the surfaces: (|r|^2 - R^2) / (|r| + R) outside, (R^2 - |r|^2) / (R + |r|) inside, denominators bounded from above.
         // Taken only when acc / kap lies clearly below all of them; everything else goes through the march.
-        const double kap = ovl_sum_kap(A, l, dust, act, na, xfreq_g, kx, ky, kz);
+        double kv[LART_OVL_ACT], kap = 0.0;                                                   // every clump's opacity once: the sum (:621-636) and the owner draw (:644-664) add the same numbers in the same order
+        for (int m = 0; m < na; m++) { const ClumpPhys ph = c.phys[act[m] - 1]; kv[m] = kappa_clump(A, l, dust, xfreq_g - ulos_clump(A, ph, kx, ky, kz), ph); kap = kap + kv[m]; }
         if (kap > 0.0) {
             const double x0 = c.cg_min + (double)ci * c.cg_d, y0 = c.cg_min + (double)cj * c.cg_d, z0 = c.cg_min + (double)ck * c.cg_d;
             const double dface = fmin(fmin(fmin(xp - x0, x0 + c.cg_d - xp), fmin(yp - y0, y0 + c.cg_d - yp)), fmin(zp - z0, z0 + c.cg_d - zp));
@@ -1230,11 +1231,7 @@ __device__ inline double ovl_march(const KArgs &A, const Lds &l, bool dust, doub
                 nsteps++;
                 t_end = s_;
                 double cumul = 0.0;                                                           // sample_owner_clump :644-664
-                for (int m = 0; m < na; m++) {
-                    const ClumpPhys ph = c.phys[act[m] - 1];
-                    cumul = cumul + kappa_clump(A, l, dust, xfreq_g - ulos_clump(A, ph, kx, ky, kz), ph); owner = act[m];
-                    if (u_own * kap <= cumul) break;
-                }
+                for (int m = 0; m < na; m++) { cumul = cumul + kv[m]; owner = act[m]; if (u_own * kap <= cumul) break; }
                 return 0.0;
             }
         }

@@ -31,6 +31,8 @@ def configs(tmp):
                    scatt_mat_file="MUELLER", core_skip=True, nxfreq=301, velocity_min=-100.0, velocity_max=100.0, nx=11, ny=11, nz=11, no_photons=1e8, iseed=1),
         "c4o": dict(use_clump_medium=True, rmax=1.0, clump_radius=0.3, clump_f_cov=2.0, clump_tau0=1e3, temperature=1e4, clump_sigma_v=100.0, clump_allow_overlap=True,
                     nxfreq=101, velocity_min=-200.0, velocity_max=200.0, nx=11, ny=11, nz=11, no_photons=1e8, iseed=1),        # examples/clump_sphere/clump_overlap_sigv.in
+        "c4os": dict(use_clump_medium=True, rmax=1.0, clump_radius=0.3, clump_f_cov=2.0, clump_tau0=1e3, temperature=1e4, clump_allow_overlap=True,
+                     nxfreq=101, velocity_min=-100.0, velocity_max=100.0, nx=11, ny=11, nz=11, no_photons=1e8, iseed=1),       # examples/clump_sphere/clump_overlap_mono.in with a Voigt source: static clumps
         "c5": dict(use_amr_grid=True, amr_file=afile, temperature=1e4, taumax=1e4, rmax=1.0, nxfreq=241, xfreq_min=-15.0, xfreq_max=15.0,
                    calc_J=True, calc_P=True, calc_Pnew=True, no_photons=1e8, iseed=1),
         "c5j": dict(use_amr_grid=True, amr_file=afile, temperature=1e4, taumax=1e4, rmax=1.0, nxfreq=241, xfreq_min=-15.0, xfreq_max=15.0, calc_J=True, no_photons=1e8, iseed=1),
