@@ -266,7 +266,8 @@ int  lart_gpu_reduce_tallies_multi(lart_gpu **ctx, int32_t n, int32_t root);
 int  lart_gpu_run_multi(lart_gpu **ctx, int32_t n, int64_t nphotons, uint64_t seed, int32_t max_events);
 int  lart_gpu_tally_buffer(lart_gpu *ctx, void **device_ptr, int64_t *n_doubles);
 int  lart_gpu_zero_tallies(lart_gpu *ctx);
-int  lart_gpu_get_tallies(lart_gpu *ctx, lart_tallies *out);
+int  lart_gpu_get_tallies(lart_gpu *ctx, lart_tallies *out);   /* fails (instead of handing out numbers) when a ray of the overlap forms met more
+                                                                  * clumps than its event lists hold: lart_gpu_zero_tallies clears the condition */
 /* par%iseed = 0 means "seed from the operating system" in the reference (init_random_mt_seed: /dev/urandom, else clock xor pid,
  * random_mt.f90:889-947).  The hosts call this once, print the value and use it as the Philox key on every rank. CPU, no device. */
 int  lart_host_entropy_seed(uint64_t *seed);
