@@ -39,7 +39,9 @@ typedef struct lart_params {
     int32_t save_peeloff, save_peeloff_2D, save_peeloff_3D;
     int32_t save_direc0, save_dust_scattered;  /* extra peel-off tallies: unattenuated source (direc0), dust-scattered light (scatt_dust) */
     int32_t nxfreq;
-    int32_t line_type;             /* line%line_type: 1 single resonance line, 2 Ly-alpha doublet (par%fine_structure, line_mod.f90:1250-1253),
+    int32_t line_type;             /* line%line_type: 1 single resonance line, 2 S-P doublet sharing one lower level (par%fine_structure and the
+                                    * doublet line ids, line_mod.f90:590-713, 1250-1253), 4 / 5 / 6 resonance + fluorescence multiplets with 1 / 2 / 3
+                                    * upper levels (tables through lart_gpu_set_line_multiplet; 6 = He I 10833 with par%HeI_coherent),
                                     * 7 hydrogen + deuterium ('ly_alpha_HD' / par%include_deuterium, :1155-1191) */
     double  xs_point, ys_point, zs_point, source_rmax, xfreq0;
     double  xfreq_min, dxfreq, Dfreq_ref;          /* grid%xfreq_min, grid%dxfreq, grid%Dfreq_ref */
@@ -51,6 +53,19 @@ typedef struct lart_params {
     double  DnuHK_Hz;                              /* line%DnuHK_Hz: 2P3/2 - 2P1/2 splitting in Hz (line type 2; 0 otherwise) */
     double  delta_nu_HD_Hz, ratio_Dfreq_HD, ratio_voigta_HD, nD_over_nH, g_recoil0_D;   /* line type 7: the cross-species constants of line% */
     double  xcrit, xcrit2;                         /* grid%xcrit, grid%xcrit2 (core_skip_global) */
+    /* shearing box (TIGRESS-type boxes): par%Omega as grid_create leaves it (grid_mod_car.f90:346-351), i.e. the change of the y velocity, in
+     * units of the thermal speed like grid%vfy, of a packet that crosses the periodic x boundary.  Non-zero with xy_periodic and nx, ny > 1
+     * selects raytrace_to_tau_car_xyper_shear (setup.f90:967-969, raytrace_car.f90:2677-2954); raytrace_to_edge then stays the plain march */
+    double  Omega;
+    /* line type 8, 'ly_beta' (do_resonance8 line_mod.f90:293-345): a scattering converts the packet to H-alpha (band 2) with probability
+     * P_conv = line%b(1)%P_down(2); E1..E3 of the two channels; the band-2 spectral axis grid%xfreq_min_Ha / dxfreq_Ha / nxfreq_Ha
+     * (grid_mod_car.f90:1518-1529) and dust constants par%R_Ha = cext_dust_Ha / cext_dust, par%albedo_Ha, par%hgg_Ha (define.f90:461-468) */
+    int32_t nxfreq_Ha, h2_nlines;                  /* h2_nlines > 0: the H2 lines next to Ly-alpha are on (h2_mod.f90: h2_on), at most 4 */
+    double  xfreq_min_Ha, dxfreq_Ha, R_Ha, albedo_Ha, hgg_Ha, P_conv, E_conv[3];
+    /* H2 pumping by Ly-alpha (par%h2_model = 'neufeld', h2_mod.f90:139-222): per line h2l(:)%dnu_Hz, %strength, %a_damp, %p_scat, the
+     * H2 Doppler width h2_Dfreq_Hz, and par%h2_hi_width (1: the lines take the H I Doppler width of the cell) */
+    int32_t h2_hi_width, pad_;
+    double  h2_Dfreq_Hz, h2_dnu_Hz[4], h2_strength[4], h2_a_damp[4], h2_p_scat[4];
 } lart_params;
 
 /* Host views of the tallies the path adds into (reference: grid%Jout/Jin/Jabs/Jmu, par%nscatt_*,
@@ -67,6 +82,11 @@ typedef struct lart_tallies {
     double n_cellsteps, n_cellsteps_peel;                    /* cells visited by flight / peel rays (roofline accounting) */
     double n_atomics;                                        /* non-zero peel-off deposits issued as tally atomics (roofline accounting) */
     int64_t nphotons_done, nphotons_active;
+    /* line type 8: grid%Jout_Ha, grid%Jabs_Ha (nxfreq_Ha each), observer(:)%peel_Ha (nobs*nxfreq_Ha*nxim*nyim), the conversion-rate profile
+     * of add_to_Pconv (nbins), and the weight budget W_conv, W_esc1, W_abs1, W_esc2, W_abs2 (define.f90:471-475) in aux[0..4];
+     * H2: W_H2abs, W_H2scat (define.f90:490-491) in aux[0..1], W_H2pump(1..h2_nlines) (h2_mod.f90:49) in aux[2..] */
+    double *Jout_Ha, *Jabs_Ha, *peel_Ha, *Pconv;
+    double aux[8];
 } lart_tallies;
 
 typedef struct lart_gpu lart_gpu;   /* one context = one GPU */
@@ -95,7 +115,8 @@ int  lart_gpu_set_observers(lart_gpu *ctx, int32_t nobs, const double *xyz, cons
                             double dxim, double dyim, int32_t nxim, int32_t nyim);
 
 /* observers inside the medium, HEALPix all-sky maps (observer_create_inside, observer_heal.f90:24-80): xyz[3*nobs], nside.
- * Tallies use the scatt/direc (+_2D) members of lart_tallies with nxim = 12*nside^2, nyim = 1.  Plain grid, no Stokes. */
+ * Tallies use the scatt/direc (+_2D) members of lart_tallies with nxim = 12*nside^2, nyim = 1.  Plain Cartesian grid or octree
+ * (peeling_*_inside_amr, peelingoff_amr.f90:656-849); no Stokes vectors (setup.f90:181), no symmetry / periodic variant, no clumps. */
 int  lart_gpu_set_observers_heal(lart_gpu *ctx, int32_t nobs, const double *xyz, int32_t nside);
 /* J(x) / P_alpha profile tallies, the reference's compile-time switches CALCJ / CALCP / CALCPnew as run-time flags
  * (add_to_J raytrace_car.f90:3979-4011, add_to_Pnew :4015-4045, add_to_Pa scattering_car.f90:830-859).
@@ -255,8 +276,10 @@ int  lart_gpu_sightline_time(lart_gpu *ctx, double *kernel_ms);   /* device time
  *   one process, all GPUs of the node: lart_gpu_run_multi(ctx[], n, nphotons, seed, max_events) transports the photons
  *     r+1, r+1+n, ... on context r (run_simulation_mod.f90:150-151) and lart_gpu_reduce_tallies_multi(ctx[], n, root) sums them
  *     (communicator from ncclCommInitAll on first use).
+ * The root receives into a buffer of its own (as MPI_REDUCE does): every rank's sums stay as they are, so a second reduce gives the
+ * same totals, and lart_gpu_get_tallies on the root hands out the totals until that context adds events or zeroes its tallies.
  * lart_gpu_comm_info reports the rank count RCCL itself saw (ncclCommCount).  The device pointer is still available for a
- * caller-owned collective (lart_gpu_tally_buffer). */
+ * caller-owned collective (lart_gpu_tally_buffer: this rank's own sums). */
 int  lart_gpu_comm_unique_id(uint8_t *id128);
 int  lart_gpu_comm_init(lart_gpu *ctx, const uint8_t *id128, int32_t nranks, int32_t rank);
 int  lart_gpu_comm_info(lart_gpu *ctx, int32_t *nranks, int32_t *rank);
@@ -267,7 +290,8 @@ int  lart_gpu_run_multi(lart_gpu **ctx, int32_t n, int64_t nphotons, uint64_t se
 int  lart_gpu_tally_buffer(lart_gpu *ctx, void **device_ptr, int64_t *n_doubles);
 int  lart_gpu_zero_tallies(lart_gpu *ctx);
 int  lart_gpu_get_tallies(lart_gpu *ctx, lart_tallies *out);   /* fails (instead of handing out numbers) when a ray of the overlap forms met more
-                                                                  * clumps than its event lists hold: lart_gpu_zero_tallies clears the condition */
+                                                                  * clumps than its event lists hold, or when the peel-off deposit list dropped
+                                                                  * an entry: lart_gpu_zero_tallies clears the condition */
 /* par%iseed = 0 means "seed from the operating system" in the reference (init_random_mt_seed: /dev/urandom, else clock xor pid,
  * random_mt.f90:889-947).  The hosts call this once, print the value and use it as the Philox key on every rank. CPU, no device. */
 int  lart_host_entropy_seed(uint64_t *seed);
@@ -278,6 +302,12 @@ int  lart_gpu_test_rand(lart_gpu *ctx, int32_t what, uint64_t seed, uint64_t id,
 int  lart_gpu_test_raytrace(lart_gpu *ctx, int32_t mode, int32_t n, double *r8, int32_t *ic4, const double *tau_or_dist, double *tau_out);
 int  lart_gpu_test_vec2pix(lart_gpu *ctx, int32_t nside, int32_t n, const double *v3, int32_t *ipix);
 int  lart_gpu_test_scatter(lart_gpu *ctx, int32_t n, double *st18, int32_t *ic4, uint64_t seed, const uint64_t *ids, int64_t *ndraws);
+/* per-event history probe (tests/test_gpu_divergence.py): runs the photons first_id + k*stride, k < count, like lart_gpu_run and records, for
+ * every k with slot[k] >= 0, 8 doubles after the birth and after every event into trace[(slot*cap + i)*8 ..]: draws consumed, xfreq
+ * (xfreq_ref once outside), x, y, z, cell code (icell + 2^21 jcell + 2^42 kcell; the owner clump in clump media), kz, kind (0 birth,
+ * 1 scattered, 2 left or absorbed); n_out[slot] = records produced (those beyond cap are counted, not stored) */
+int  lart_gpu_test_trace(lart_gpu *ctx, int64_t first_id, int64_t stride, int64_t count, uint64_t seed, const int32_t *slot, int32_t nslots,
+                         int32_t cap, double *trace, int32_t *n_out);
 
 #ifdef __cplusplus
 }

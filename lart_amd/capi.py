@@ -21,14 +21,17 @@ class LartParams(C.Structure):
         "save_Jin", "save_Jabs", "save_Jmu", "nmu", "save_peeloff", "save_peeloff_2D", "save_peeloff_3D", "save_direc0", "save_dust_scattered", "nxfreq", "line_type")] + \
         [(n, _d) for n in (
             "xs_point", "ys_point", "zs_point", "source_rmax", "xfreq0", "xfreq_min", "dxfreq", "Dfreq_ref", "xfreq_max", "source_sigma_x", "xrange", "yrange", "zrange", "source_zscale",
-            "DGR", "hgg", "albedo", "mu_min", "dmu", "g_recoil0", "E1", "E2", "E3", "DnuHK_Hz", "delta_nu_HD_Hz", "ratio_Dfreq_HD", "ratio_voigta_HD", "nD_over_nH", "g_recoil0_D", "xcrit", "xcrit2")]
+            "DGR", "hgg", "albedo", "mu_min", "dmu", "g_recoil0", "E1", "E2", "E3", "DnuHK_Hz", "delta_nu_HD_Hz", "ratio_Dfreq_HD", "ratio_voigta_HD", "nD_over_nH", "g_recoil0_D", "xcrit", "xcrit2",
+            "Omega")] + [("nxfreq_Ha", _i32), ("h2_nlines", _i32)] + \
+        [(n, _d) for n in ("xfreq_min_Ha", "dxfreq_Ha", "R_Ha", "albedo_Ha", "hgg_Ha", "P_conv")] + [("E_conv", _d * 3), ("h2_hi_width", _i32), ("pad_", _i32), ("h2_Dfreq_Hz", _d)] + \
+        [(n, _d * 4) for n in ("h2_dnu_Hz", "h2_strength", "h2_a_damp", "h2_p_scat")]
 
 
 class LartTallies(C.Structure):
     _fields_ = [(n, _vp) for n in ("Jout", "Jin", "Jabs", "Jmu", "scatt", "direc", "I", "Q", "U", "V",
                                    "scatt_2D", "direc_2D", "I_2D", "Q_2D", "U_2D", "V_2D", "direc0", "direc0_2D", "scatt_dust", "J1", "P1", "P1_new")] + \
         [(n, _d) for n in ("nscatt_gas", "nscatt_dust", "n_events", "n_cellsteps", "n_cellsteps_peel", "n_atomics")] + \
-        [("nphotons_done", _i64), ("nphotons_active", _i64)]
+        [("nphotons_done", _i64), ("nphotons_active", _i64)] + [(n, _vp) for n in ("Jout_Ha", "Jabs_Ha", "peel_Ha", "Pconv")] + [("aux", _d * 8)]
 
 
 class LartLineMultiplet(C.Structure):
@@ -48,7 +51,7 @@ SYMBOLS = ["lart_host_line_lookup", "lart_gpu_set_line_multiplet", "lart_gpu_dev
            "lart_gpu_compact", "lart_gpu_set_auto_compact", "lart_gpu_live_lanes",
            "lart_gpu_comm_unique_id", "lart_gpu_comm_init", "lart_gpu_comm_info", "lart_gpu_comm_destroy", "lart_gpu_reduce_tallies",
            "lart_gpu_reduce_tallies_multi", "lart_gpu_run_multi", "lart_host_entropy_seed",
-           "lart_gpu_test_voigt", "lart_gpu_test_rand", "lart_gpu_test_raytrace", "lart_gpu_test_vec2pix", "lart_gpu_test_scatter"]
+           "lart_gpu_test_voigt", "lart_gpu_test_rand", "lart_gpu_test_raytrace", "lart_gpu_test_vec2pix", "lart_gpu_test_scatter", "lart_gpu_test_trace"]
 
 _lib = None
 
@@ -113,6 +116,7 @@ def lib():
         L.lart_gpu_test_rand.argtypes = [_vp, _i32, _u64, _u64, _i32, _d, _d, _vp]
         L.lart_gpu_test_raytrace.argtypes = [_vp, _i32, _i32, _vp, _vp, _vp, _vp]
         L.lart_gpu_test_scatter.argtypes = [_vp, _i32, _vp, _vp, _u64, _vp, _vp]
+        L.lart_gpu_test_trace.argtypes = [_vp, _i64, _i64, _i64, _u64, _vp, _i32, _i32, _vp, _vp]
         _lib = L
     return _lib
 
@@ -403,9 +407,11 @@ class Context:
         out = np.zeros(n)
         _chk(lib().lart_gpu_test_rand(self.h, what, seed, pid, n, p1, p2, _p(out))); return out
 
-    def test_raytrace(self, kind, variant, r8, ic4, tq=None):
+    def test_raytrace(self, kind, variant, r8, ic4, tq=None, shear=None):
+        """kind 0 raytrace_to_tau, 1 raytrace_to_edge, 2 raytrace_to_dist; variant 8 (shearing box): photon%vfy_shear goes in through
+        `shear` and comes back in the third return value"""
         r = np.ascontiguousarray(r8, dtype=np.float64).copy(); ic = np.ascontiguousarray(ic4, dtype=np.int32).copy()
-        n = r.shape[0]; tau = np.zeros(n)
+        n = r.shape[0]; tau = np.zeros(n) if shear is None else np.ascontiguousarray(shear, dtype=np.float64).copy()
         q = None if tq is None else np.ascontiguousarray(tq, dtype=np.float64)
         _chk(lib().lart_gpu_test_raytrace(self.h, 10 * kind + variant, n, _p(r), _p(ic), _p(q), _p(tau)))
         return r, ic, tau
@@ -413,6 +419,15 @@ class Context:
     def test_vec2pix(self, nside, v3):
         v = np.ascontiguousarray(v3, dtype=np.float64); out = np.zeros(v.shape[0], dtype=np.int32)
         _chk(lib().lart_gpu_test_vec2pix(self.h, nside, v.shape[0], _p(v), _p(out))); return out
+
+    def test_trace(self, count, select, cap, seed, first_id=1, stride=1):
+        """history probe: runs photons first_id + k*stride (k < count) to the last one; for the ordinals in `select` returns
+        (records[len(select), cap, 8], n_records[len(select)]): draws consumed, xfreq, x, y, z, cell code, kz, kind per event"""
+        select = np.asarray(select, dtype=np.int64)
+        slot = np.full(int(count), -1, dtype=np.int32); slot[select] = np.arange(len(select), dtype=np.int32)
+        tr = np.zeros((len(select), int(cap), 8)); n = np.zeros(len(select), dtype=np.int32)
+        _chk(lib().lart_gpu_test_trace(self.h, int(first_id), int(stride), int(count), int(seed), _p(slot), len(select), int(cap), _p(tr), _p(n)))
+        return tr, n
 
     def test_scatter(self, st18, ic4, seed, ids):
         st = np.ascontiguousarray(st18, dtype=np.float64).copy(); ic = np.ascontiguousarray(ic4, dtype=np.int32).copy()

@@ -54,6 +54,11 @@ struct ClumpGeo  { double x, y, z, r2; };                                       
 struct ClumpPhys { double rhokap, rhokapD, voigt_a, Dfreq, vx, vy, vz, pad; };     // v in units of the clump's thermal speed
 // VAR 4 (disjoint clumps) and VAR 7 (overlapping clumps) share the owner-clump bookkeeping of the scattering and peel-off routines
 __host__ __device__ constexpr bool is_clump(int var) { return var == 4 || var == 7; }
+// VAR 8 = the xy-periodic box with a shearing x boundary (raytrace_to_tau_car_xyper_shear, raytrace_car.f90:2677-2954, chosen at setup.f90:967-969
+// when par%Omega /= 0): the tau march of VAR 6 with photon%vfy_shear; setup_procedure leaves raytrace_to_edge at its default there, the
+// PLAIN Cartesian march (setup.f90:941, :967-969 assign raytrace_to_tau only), so every edge / peel march of VAR 8 is VAR 0's
+__host__ __device__ constexpr bool is_per(int var) { return var == 6 || var == 8; }
+__host__ __device__ constexpr int edge_var(int var) { return var == 8 ? 0 : var; }
 struct DClumps {
     long long N;
     const ClumpGeo *geo; const ClumpPhys *phys;
@@ -75,7 +80,7 @@ struct DTally {
 
 // resident photon pool (SoA, coalesced load/store at launch boundaries)
 enum { F_X = 0, F_Y, F_Z, F_KX, F_KY, F_KZ, F_XFREQ, F_WGT, F_NSG, F_NSD,
-       F_MX, F_MY, F_MZ, F_NX, F_NY, F_NZ, F_Q, F_U, F_V, F_COUNT };
+       F_MX, F_MY, F_MZ, F_NX, F_NY, F_NZ, F_Q, F_U, F_V, F_SHEAR /* photon%vfy_shear, VAR 8 only */, F_COUNT };
 enum { FLAG_ALIVE = 1, FLAG_FIRST = 2 };
 struct DPool {
     int64_t n;                    // lanes
@@ -112,6 +117,8 @@ enum { PEEL_DIRECT = 0, PEEL_RESONANCE = 1, PEEL_DUST = 2 };
 // Every producer wave owns one region of `region` consecutive record slots (64 lanes x (events of the launch + 1)) and fills it from the
 // front: the slot counter is a per-wave word in LDS, so queueing costs no global atomic (one counter for the whole grid serialises in
 // L2: measured +6 ms on a 9 ms launch); count[w] = records wave w wrote.  peel_kernel takes whole regions from the queue head.
+// scalar 24 of the fused tally buffer: deposit-list entries that did not fit (lart_gpu_get_tallies refuses the run; scal[7] likewise for the overlap lists)
+#define LART_SCAL_PEEL_DROPPED 24
 struct DPeelQ { double *f; int *cell; unsigned cap; unsigned region, nregions; unsigned *count;
                 unsigned *dep_idx; double *dep_tau; unsigned long long dep_cap; DPeelCtl *pctl; };   // deposit list: (record, observer) and the optical depth of the rays that came through (peel_kernel.hpp)   // f: PQ_COUNT planes of cap doubles; cell: 4 planes (ic, jc, kc | owner clump, kind)
 
@@ -140,7 +147,11 @@ struct KArgs {
     double *allph; long long allph_n;   // par%save_all_photons: 10 columns of allph_n records (r, xfreq1, xfreq2, nscatt_gas, nscatt_dust, I, Q, U, V, r0), nullptr = off
     DMulti ml;
     DPeelQ pq;
+    // per-event history probe of the parity tests (lart_gpu_test_trace): trace_slot[k] >= 0 selects photon ordinal k; record i of slot s
+    // is trace[(s * trace_cap + i) * LART_TRACE_W ..]; trace_n[s] counts the records (also those beyond trace_cap, which are not stored)
+    const int *trace_slot; double *trace; int *trace_n; int trace_cap;
 };
+#define LART_TRACE_W 8
 
 // ---------------------------------------------------------------------------------------------
 // LDS image: Voigt tables (606 f64) followed by the three face arrays
@@ -419,6 +430,7 @@ struct Photon {
     double mx, my, mz, nx, ny, nz, Q, U, V;
     int ic, jc, kc; bool inside;
     int icl;                       // owner clump (VAR 4): 0 = vacuum (photon%icell_clump, define.f90:90)
+    double shear;                  // photon%vfy_shear (define.f90:100): y velocity picked up at the shearing x boundary, in thermal units (VAR 8)
     double xfreq_ref;
 #ifdef LART_PROFILE
     long long pt[12], plast;       // tuning builds only: wave clocks per code section (prof_mark)
@@ -840,7 +852,7 @@ __device__ inline bool trav_setup(const DGrid &g, const Lds &l, double &xp, doub
         if (axis_setup_sym(g.nx, l.xf, g.dx, g.i0, xp, strict, t.ic, t.is, t.kx, t.tx, t.delx)) return true;
         if (axis_setup_sym(g.ny, l.yf, g.dy, g.j0, yp, strict, t.jc, t.js, t.ky, t.ty, t.dely)) return true;
         if (axis_setup_z(g.nz, l.zf, g.dz, zp, strict, t.kc, t.ks, t.kz, t.tz, t.delz)) return true;
-    } else if (VAR == 6) {
+    } else if (is_per(VAR)) {
         if (axis_setup_per(g.nx, l.xf, g.dx, xp, strict, t.ic, t.is, t.kx, t.tx, t.delx)) return true;
         if (axis_setup_per(g.ny, l.yf, g.dy, yp, strict, t.jc, t.js, t.ky, t.ty, t.dely)) return true;
         if (axis_setup_z(g.nz, l.zf, g.dz, zp, strict, t.kc, t.ks, t.kz, t.tz, t.delz)) return true;
@@ -871,7 +883,7 @@ __device__ inline bool trav_cross(const DGrid &g, Trav &t, int idx) {
     const double del = ax ? t.delx : (ay ? t.dely : t.delz);
     cell += step;
     bool ok = true;
-    const bool mirror = VAR == 1 || (VAR == 5 && (ax || ay)), wrap = VAR == 6 && (ax || ay);
+    const bool mirror = VAR == 1 || (VAR == 5 && (ax || ay)), wrap = is_per(VAR) && (ax || ay);
     if (mirror && cell < 1) { cell = m0; step = 1; k = -k; }
     else if (wrap) { cell = cell < 1 ? n : (cell > n ? 1 : cell); }
     else if (cell < 1 || cell > n) ok = false;
@@ -1322,6 +1334,7 @@ __device__ inline void raytrace_to_tau_clump_ovl(const KArgs &A, const Lds &l, b
 // tau to the grid edge (dist < 0) or to a finite distance (raytrace_to_dist_car :89-195, VAR 0 only)
 template <int VAR>
 __device__ inline void edge_begin(const KArgs &A, const Lds &l, bool dust, const Photon &p, double xfreq, double kx, double ky, double kz, double dist, EdgeMarch &m, unsigned &nsteps) {
+    if (VAR == 8) { edge_begin<0>(A, l, dust, p, xfreq, kx, ky, kz, dist, m, nsteps); return; }
     m.live = true; m.tau = 0.0; m.d = 0.0; m.xfreq = xfreq; m.dist = dist; m.kx = kx; m.ky = ky; m.kz = kz;
     if (VAR == 3) { edge_begin_amr(A, p, m); return; }
     if (VAR == 4) { edge_begin_clump(A, l, dust, p, m, nsteps); return; }
@@ -1336,6 +1349,7 @@ __device__ inline void edge_begin(const KArgs &A, const Lds &l, bool dust, const
 }
 template <int VAR>
 __device__ inline void edge_step(const KArgs &A, const Lds &l, bool dust, EdgeMarch &m, unsigned &nsteps) {
+    if (VAR == 8) { edge_step<0>(A, l, dust, m, nsteps); return; }
     if (VAR == 3) { edge_step_amr(A, l, dust, m, nsteps); return; }
     if (VAR == 4) { edge_step_clump(A, l, dust, m, nsteps); return; }
     const DGrid &g = A.g; Trav &t = m.t;
@@ -1481,9 +1495,10 @@ __device__ inline void raytrace_to_tau(const KArgs &A, const Lds &l, bool dust, 
     if (trav_setup<VAR>(g, l, xp, yp, zp, true, t)) { p.inside = false; return; }
     double tau = 0.0, d = 0.0;
     const Cell *c = &g.cell[cidx(g, t.ic, t.jc, t.kc)];
-    double Dold = c->Dfreq, u1 = c->vfx * t.kx + c->vfy * t.ky + c->vfz * t.kz;
     double rk = c->rhokap, va = c->voigt_a, rD = c->rhokapD;
     double vx = c->vfx, vy = c->vfy, vz = c->vfz;
+    if (VAR == 8) vy = vy + p.shear;                          // :2808-2809 the cell's y velocity + what the packet picked up at the shearing boundary
+    double Dold = c->Dfreq, u1 = vx * t.kx + vy * t.ky + vz * t.kz;
     double del = 0.0, vH = 0.0;
     for (;;) {
         vH = calc_voigt(l, p.xfreq, va, Dold);
@@ -1500,9 +1515,14 @@ __device__ inline void raytrace_to_tau(const KArgs &A, const Lds &l, bool dust, 
         }
         int io = t.ic, jo = t.jc, ko = t.kc;
         if (!trav_cross<VAR>(g, t, idx)) { p.inside = false; t.ic = io; t.jc = jo; t.kc = ko; break; }
+        if (VAR == 8 && idx == 1) {                           // :2843-2852 a packet that wraps in x changes its y velocity by -+ par%Omega (q Omega Lx)
+            if (t.is < 0 && io == 1) p.shear = p.shear - A.par.Omega;
+            if (t.is > 0 && io == g.nx) p.shear = p.shear + A.par.Omega;
+        }
         if (A.jpa.nbins) jpa_segment(A, l, p, cidx(g, io, jo, ko), rk, Dold, del, del * (rk * vH));      // add_to_J / add_to_Pnew :1579-1584
         c = &g.cell[cidx(g, t.ic, t.jc, t.kc)];
         vx = c->vfx; vy = c->vfy; vz = c->vfz;
+        if (VAR == 8) vy = vy + p.shear;
         double Dn = c->Dfreq, u2 = vx * t.kx + vy * t.ky + vz * t.kz;
         p.xfreq = (p.xfreq + u1) * Dold / Dn - u2;
         Dold = Dn; u1 = u2; rk = c->rhokap; va = c->voigt_a; rD = c->rhokapD;
@@ -1522,7 +1542,7 @@ __device__ inline void raytrace_to_tau(const KArgs &A, const Lds &l, bool dust, 
         if (VAR == 1 && p.z < g.zmin) p.z = -p.z;
         p.kx = t.kx; p.ky = t.ky; p.kz = t.kz;
         p.ic = t.ic; p.jc = t.jc; p.kc = t.kc;
-    } else if (VAR == 6) {                                    // :2509-2514 back into the base period (xrange = nx dx)
+    } else if (is_per(VAR)) {                                 // :2509-2514 (shear :2943-2949) back into the base period (xrange = nx dx)
         if (p.inside) { xp = xp + d * t.kx; yp = yp + d * t.ky; zp = zp + d * t.kz; }
         const double xr = -2.0 * g.xmin, yr = -2.0 * g.ymin;      // grid%xrange = xmax - xmin with xmin = -xmax (grid_mod_car.f90:166-181)
         p.x = xp - floor((xp - g.xmin) / xr) * xr; p.y = yp - floor((yp - g.ymin) / yr) * yr; p.z = zp;
@@ -2112,6 +2132,19 @@ __device__ inline double impact_parameter(const Photon &p, double &mx, double &m
     const double rk = p.x * p.kx + p.y * p.ky + p.z * p.kz;
     mx = p.x - rk * p.kx; my = p.y - rk * p.ky; mz = p.z - rk * p.kz;
     return sqrt(mx * mx + my * my + mz * mz);
+}
+// one record of the history probe: the state a packet is in after its birth (kind 0), after a scattering (1) or when it has left / was absorbed (2).
+// [0] draws consumed, [1] xfreq, [2..4] position, [5] cell code (ic + 2^21 jc + 2^42 kc; the owner clump in clump media), [6] kz, [7] kind
+template <int VAR>
+__device__ inline void trace_rec(const KArgs &A, long long k, unsigned long long rng_n, const Photon &p, int kind) {
+    const int sl = A.trace_slot[k];
+    if (sl < 0) return;
+    const int i = A.trace_n[sl]; A.trace_n[sl] = i + 1;            // one lane owns a packet: no atomic
+    if (i >= A.trace_cap) return;
+    double *r = A.trace + ((size_t)sl * A.trace_cap + i) * LART_TRACE_W;
+    r[0] = (double)rng_n; r[1] = p.inside ? p.xfreq : p.xfreq_ref; r[2] = p.x; r[3] = p.y; r[4] = p.z;
+    r[5] = is_clump(VAR) ? (double)p.icl : (double)p.ic + 2097152.0 * (double)p.jc + 4398046511104.0 * (double)p.kc;
+    r[6] = p.kz; r[7] = (double)kind;
 }
 __device__ inline void allph_initial(const KArgs &A, const Photon &p, long long k) {          // make_all_initial_photons :249-292
     A.allph[1 * A.allph_n + k] = p.xfreq;

@@ -21,6 +21,7 @@ extern "C" void lart_launch_transport_var4(int, int, int, dim3, dim3, size_t, hi
 extern "C" void lart_launch_transport_var5(int, int, int, dim3, dim3, size_t, hipStream_t, const KArgs &);
 extern "C" void lart_launch_transport_var6(int, int, int, dim3, dim3, size_t, hipStream_t, const KArgs &);
 extern "C" void lart_launch_transport_var7(int, int, int, dim3, dim3, size_t, hipStream_t, const KArgs &);
+extern "C" void lart_launch_transport_var8(int, int, int, dim3, dim3, size_t, hipStream_t, const KArgs &);
 extern "C" void lart_launch_peel(int var, int stokes, dim3, dim3, dim3, size_t, hipStream_t, const KArgs &);
 
 static thread_local std::string g_err;
@@ -59,13 +60,18 @@ struct lart_gpu {
     double sight_ms = 0.0;                                   // device time of the last sight-line map
     // lane compaction: the launch covers lanes [0, live_lanes); state of the last lart_gpu_sync
     int64_t live_lanes = 0; bool state_valid = false; int64_t last_alive = 0, last_next_k = 0; int auto_compact = 1;
-    int *d_compact = nullptr; int64_t n_compactions = 0;
+    int *d_compact = nullptr; int64_t compact_lanes = 0; int64_t n_compactions = 0;      // d_compact holds the slot lists of a pool of compact_lanes lanes
     // peel-off event queue (deferred next-event estimator): records of one transport launch, consumed by peel_kernel right after it
     // two buffers: while peel_kernel works through the records of slice k on stream2, the transport kernel of slice k + 1 fills the other one
-    DPeelQ pq[2]{}; void *d_pq = nullptr; size_t pq_bytes_max = 0; int peel_slice = 0; int n_cu = 0;
+    DPeelQ pq[2]{}; void *d_pq = nullptr; size_t pq_bytes_max = 0; int peel_slice = 0; int n_cu = 0; size_t pq_nobs = 0, pq_lanes = 0;   // (the queue was laid out for pq_nobs observers and pq_lanes lanes)
     hipStream_t stream2 = nullptr; hipEvent_t ev_filled[2] = {nullptr, nullptr}, ev_drained[2] = {nullptr, nullptr}; bool drained_pending[2] = {false, false};
     // output_reduce across GPUs: RCCL communicator of this context (one rank per context)
     ncclComm_t comm = nullptr; int comm_n = 0, comm_rank = -1;
+    // the root's receive buffer of output_reduce (MPI_REDUCE has separate send / receive buffers, memory_mod_mpi.f90:377-393: reducing twice gives
+    // the same totals).  Valid until this context adds events or zeroes its tallies; lart_gpu_get_tallies hands out the totals while it is.
+    double *d_reduced = nullptr; bool reduced_valid = false;
+    // history probe (lart_gpu_test_trace)
+    int *d_trace_slot = nullptr, *d_trace_n = nullptr; double *d_trace = nullptr; int trace_cap = 0;
 };
 
 extern "C" const char *lart_gpu_last_error(void) { return g_err.c_str(); }
@@ -95,6 +101,7 @@ extern "C" int lart_gpu_create(lart_gpu **out, const lart_params *par, int devic
 
 static void free_tally(lart_gpu *c) {
     if (c->d_tally) { (void)hipFree(c->d_tally); c->d_tally = nullptr; }
+    if (c->d_reduced) { (void)hipFree(c->d_reduced); c->d_reduced = nullptr; } c->reduced_valid = false;
     if (c->rep.base) { (void)hipFree(c->rep.base); } c->rep = DRep{}; c->rep_dirty = false;
 }
 
@@ -464,6 +471,7 @@ static int ensure_pool(lart_gpu *c) {
     n = ((n + c->block - 1) / c->block) * c->block;
     if (c->d_pool && c->pool.n == n) return 0;
     (void)hipFree(c->d_pool); c->d_pool = nullptr;
+    (void)hipFree(c->d_compact); c->d_compact = nullptr; c->compact_lanes = 0;     // the slot lists are sized with the pool
     size_t bytes = (size_t)n * (F_COUNT * 8 + 8 + 8 + 4 * 4);
     HIPCHK(hipMalloc(&c->d_pool, bytes));
     char *b = (char *)c->d_pool;
@@ -481,7 +489,7 @@ static int march_variant(const lart_gpu *c) {
     if (c->is_amr) return 3;
     if (c->par.xyz_symmetry) return 1;
     if (c->par.xy_symmetry) return 5;
-    if (c->par.xy_periodic) return (c->g.nx == 1 && c->g.ny == 1) ? 2 : 6;
+    if (c->par.xy_periodic) return (c->g.nx == 1 && c->g.ny == 1) ? 2 : (c->par.Omega != 0.0 ? 8 : 6);     // setup.f90:959-973
     return 0;
 }
 
@@ -548,10 +556,11 @@ static int ensure_peel_queue(lart_gpu *c, int max_events) {
     if ((size_t)slice + 1 > fit) slice = fit > 1 ? (int)(fit - 1) : 1;
     const size_t cap = lanes * ((size_t)slice + 1);
     if (cap > 0xfffffff0ull) return fail("peel queue: more than 2^32 records per launch; lower the pool size or max_events");
-    if (!c->d_pq || c->pq[0].cap < cap) {
+    if (!c->d_pq || c->pq[0].cap < cap || c->pq_nobs != nobs || c->pq_lanes != lanes) {     // the deposit list scales with nobs, the waves' counters with the lanes
         HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipStreamSynchronize(c->stream2));
         (void)hipFree(c->d_pq); c->d_pq = nullptr;
-        // the deposit list: (record, observer, tau) of every (record, observer) pair, plus one chunk per marching wave of slack
+        // the deposit list: (record, observer, tau) of every (record, observer) pair, plus the unused tail of every marching wave's last chunk
+        // (peel_kernel: n_cu x 4 workgroups of 4 waves, LART_DEP_CHUNK = 256 entries; a wave fills its chunks to the last entry)
         const size_t dep_cap = cap * nobs + (size_t)c->n_cu * 16 * 256;
         const size_t cnt_bytes = ((lanes / 64 + 1) * sizeof(unsigned) + 15) / 16 * 16;
         const size_t one = (cap * rec_bytes + cnt_bytes + dep_cap * 16 + sizeof(DPeelCtl) + 255) / 256 * 256;
@@ -563,7 +572,7 @@ static int ensure_peel_queue(lart_gpu *c, int max_events) {
             q.dep_tau = (double *)(base + cap * rec_bytes + cnt_bytes); q.dep_idx = (unsigned *)(q.dep_tau + dep_cap); q.dep_cap = dep_cap;
             q.pctl = (DPeelCtl *)(base + cap * rec_bytes + cnt_bytes + dep_cap * 16);
         }
-        c->drained_pending[0] = c->drained_pending[1] = false;
+        c->drained_pending[0] = c->drained_pending[1] = false; c->pq_nobs = nobs; c->pq_lanes = lanes;
     } else slice = (int)(c->pq[0].cap / lanes) - 1 < max_events ? (int)(c->pq[0].cap / lanes) - 1 : max_events;
     c->peel_slice = slice < 1 ? 1 : slice;
     for (int b = 0; b < 2; b++) c->pq[b].region = 64u * ((unsigned)c->peel_slice + 1u);      // one producer wave's slots: every lane queues at most one record per event and one per birth
@@ -593,11 +602,12 @@ __global__ void k_compact_scan(DPool pool, long long live, long long m, int *hol
     if (hole) holes[sh] = (int)i;
     if (mover) movers[sm] = (int)i;
 }
-__global__ void k_compact_move(DPool pool, const int *holes, const int *movers, const unsigned *cnt, int nplanes) {
+__global__ void k_compact_move(DPool pool, const int *holes, const int *movers, const unsigned *cnt, int nplanes, int extra_plane) {
     const unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= cnt[1] || j >= cnt[0]) return;
     const long long src = movers[j], dst = holes[j], P = pool.n;
     for (int q = 0; q < nplanes; q++) pool.f[(size_t)q * P + dst] = pool.f[(size_t)q * P + src];
+    if (extra_plane >= 0) pool.f[(size_t)extra_plane * P + dst] = pool.f[(size_t)extra_plane * P + src];
     pool.rng_n[dst] = pool.rng_n[src]; pool.k[dst] = pool.k[src];
     pool.ic[dst] = pool.ic[src]; pool.jc[dst] = pool.jc[src]; pool.kc[dst] = pool.kc[src];
     pool.flags[dst] = pool.flags[src]; pool.flags[src] = 0;
@@ -611,14 +621,17 @@ extern "C" int lart_gpu_compact(lart_gpu *c) {
     const int64_t m = c->last_alive, live = c->live_lanes;
     int64_t new_live = ((m + c->block - 1) / c->block) * c->block; if (new_live < c->block) new_live = c->block;
     if (new_live >= live) return 0;
-    if (!c->d_compact) HIPCHK(hipMalloc(&c->d_compact, ((size_t)2 * c->pool.n + 2) * sizeof(int)));
+    if (!c->d_compact || c->compact_lanes < c->pool.n) {             // the pool may have been re-created larger by a later lart_gpu_begin
+        (void)hipFree(c->d_compact); c->d_compact = nullptr; c->compact_lanes = 0;
+        HIPCHK(hipMalloc(&c->d_compact, ((size_t)2 * c->pool.n + 2) * sizeof(int))); c->compact_lanes = c->pool.n;
+    }
     int *holes = c->d_compact + 2, *movers = holes + c->pool.n; unsigned *cnt = (unsigned *)c->d_compact;
     HIPCHK(hipMemsetAsync(cnt, 0, 2 * sizeof(unsigned), c->stream));
     hipLaunchKernelGGL(k_compact_scan, dim3((unsigned)((live + 255) / 256)), dim3(256), 0, c->stream, c->pool, (long long)live, (long long)m, holes, movers, cnt);
     HIPCHK(hipGetLastError());
     const int64_t nmove_max = m < live - m ? m : live - m;           // movers sit beyond m, holes below it
     if (nmove_max > 0) {
-        hipLaunchKernelGGL(k_compact_move, dim3((unsigned)((nmove_max + 255) / 256)), dim3(256), 0, c->stream, c->pool, holes, movers, cnt, c->par.use_stokes ? (int)F_COUNT : (int)F_MX);
+        hipLaunchKernelGGL(k_compact_move, dim3((unsigned)((nmove_max + 255) / 256)), dim3(256), 0, c->stream, c->pool, holes, movers, cnt, c->par.use_stokes ? (int)F_SHEAR : (int)F_MX, march_variant(c) == 8 ? (int)F_SHEAR : -1);
         HIPCHK(hipGetLastError());
     }
     unsigned h[2] = {0, 0};
@@ -646,6 +659,7 @@ extern "C" int lart_gpu_step(lart_gpu *c, int32_t nsteps, int32_t max_events) {
     A.first_id = c->first_id; A.stride = c->stride; A.count = c->count; A.seed = c->seed; A.max_events = max_events;
     A.log_nscatt = c->d_log; A.log_xfreq = c->d_log ? c->d_log + c->nlog : nullptr;
     A.allph = (c->d_log && c->log_on == 2) ? c->d_log + 2 * c->nlog : nullptr; A.allph_n = c->nlog;
+    A.trace_slot = c->d_trace_slot; A.trace = c->d_trace; A.trace_n = c->d_trace_n; A.trace_cap = c->trace_cap;
     int var = march_variant(c);
     int stokes = c->par.use_stokes ? 1 : 0, dust = c->par.DGR > 0.0 ? 1 : 0, peel = (c->par.save_peeloff && c->nobs > 0) ? 1 : 0;
     dim3 block(c->block), grid((unsigned)(c->live_lanes / c->block));
@@ -679,7 +693,8 @@ extern "C" int lart_gpu_step(lart_gpu *c, int32_t nsteps, int32_t max_events) {
             else if (var == 4) lart_launch_transport_var4(stokes, dust, peel, grid, block, shmem, c->stream, A);
             else if (var == 5) lart_launch_transport_var5(stokes, dust, peel, grid, block, shmem, c->stream, A);
             else if (var == 6) lart_launch_transport_var6(stokes, dust, peel, grid, block, shmem, c->stream, A);
-            else lart_launch_transport_var7(stokes, dust, peel, grid, block, shmem, c->stream, A);
+            else if (var == 7) lart_launch_transport_var7(stokes, dust, peel, grid, block, shmem, c->stream, A);
+            else lart_launch_transport_var8(stokes, dust, peel, grid, block, shmem, c->stream, A);
             HIPCHK(hipGetLastError());
             if (peel) {
                 // the peel kernels of this slice run on the second stream, next to the transport kernel of the next slice: the march is bound
@@ -687,7 +702,7 @@ extern "C" int lart_gpu_step(lart_gpu *c, int32_t nsteps, int32_t max_events) {
                 HIPCHK(hipEventRecord(c->ev_filled[b], c->stream));
                 HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_filled[b], 0));
                 HIPCHK(hipMemsetAsync(A.pq.pctl, 0, sizeof(DPeelCtl), c->stream2));
-                lart_launch_peel(var, stokes, dim3((unsigned)(c->n_cu * 4)), dim3((unsigned)(c->n_cu * 2)), dim3(256), peel_shmem, c->stream2, A);
+                lart_launch_peel(edge_var(var), stokes, dim3((unsigned)(c->n_cu * 4)), dim3((unsigned)(c->n_cu * 2)), dim3(256), peel_shmem, c->stream2, A);
                 HIPCHK(hipGetLastError());
                 HIPCHK(hipEventRecord(c->ev_drained[b], c->stream2)); c->drained_pending[b] = true;
             }
@@ -698,7 +713,7 @@ extern "C" int lart_gpu_step(lart_gpu *c, int32_t nsteps, int32_t max_events) {
         c->ev.emplace_back(e0, e1);
     }
     if (nsteps > 0 && c->rep.nrep > 1) c->rep_dirty = true;
-    if (nsteps > 0) c->state_valid = false;
+    if (nsteps > 0) { c->state_valid = false; c->reduced_valid = false; }
     return 0;
 }
 
@@ -768,7 +783,7 @@ extern "C" int lart_gpu_zero_tallies(lart_gpu *c) {
     if (!c->d_tally) { if (build_tally(c)) return 1; }
     HIPCHK(hipMemsetAsync(c->d_tally, 0, c->ntally * 8, c->stream));
     if (c->rep.base) HIPCHK(hipMemsetAsync(c->rep.base, 0, (size_t)c->rep.len * (c->rep.nrep - 1) * 8, c->stream));
-    c->rep_dirty = false;
+    c->rep_dirty = false; c->reduced_valid = false;
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -779,12 +794,16 @@ extern "C" int lart_gpu_get_tallies(lart_gpu *c, lart_tallies *o) {
     if (fold_copies(c)) return 1;
     HIPCHK(hipStreamSynchronize(c->stream));
     if (collect_events(c)) return 1;
-    double s[16]; HIPCHK(hipMemcpy(s, c->d_tally, sizeof s, hipMemcpyDeviceToHost));
+    // after output_reduce the root hands out the totals over all ranks (its receive buffer), until it adds events of its own again
+    const ptrdiff_t rs = (c->reduced_valid && c->d_reduced) ? c->d_reduced - c->d_tally : 0;
+    double s[16]; HIPCHK(hipMemcpy(s, c->d_tally + rs, sizeof s, hipMemcpyDeviceToHost));
+    { double dr = 0.0; HIPCHK(hipMemcpy(&dr, c->d_tally + rs + LART_SCAL_PEEL_DROPPED, 8, hipMemcpyDeviceToHost));
+      if (dr > 0.0) return fail("get_tallies: the peel-off deposit list overflowed (" + std::to_string((long long)dr) + " rays dropped): the images have lost flux; this is a sizing bug of the peel queue, not a property of the input"); }
     if (s[7] > 0.0) return fail("get_tallies: a ray met more overlapping clumps than the march lists hold (LART_OVL_ACT clumps around a point, LART_OVL_PEND events ahead): the result is not the reference's");
     o->nscatt_gas = s[0]; o->nscatt_dust = s[1]; o->n_events = s[2]; o->n_cellsteps = s[3]; o->n_cellsteps_peel = s[4]; o->n_atomics = s[6]; o->nphotons_done = (int64_t)(s[5] + 0.5);
     DCtl h{}; HIPCHK(hipMemcpy(&h, c->d_ctl, sizeof h, hipMemcpyDeviceToHost)); o->nphotons_active = (int64_t)h.n_active;
     int64_t nxf = c->par.nxfreq, n2 = (int64_t)c->nobs * c->nxim * c->nyim, n3 = n2 * nxf;
-#define CP(dst, src, cnt) if ((dst) && (src) && (cnt) > 0) HIPCHK(hipMemcpy((dst), (src), (size_t)(cnt) * 8, hipMemcpyDeviceToHost))
+#define CP(dst, src, cnt) if ((dst) && (src) && (cnt) > 0) HIPCHK(hipMemcpy((dst), (src) + rs, (size_t)(cnt) * 8, hipMemcpyDeviceToHost))
     CP(o->Jout, c->t.Jout, nxf); CP(o->Jin, c->t.Jin, nxf); CP(o->Jabs, c->t.Jabs, nxf); CP(o->Jmu, c->t.Jmu, c->par.save_Jmu ? nxf * c->par.nmu : 0);
     double *h3[8] = {o->scatt, o->direc, o->I, o->Q, o->U, o->V, o->direc0, o->scatt_dust}, *h2[8] = {o->scatt_2D, o->direc_2D, o->I_2D, o->Q_2D, o->U_2D, o->V_2D, o->direc0_2D, nullptr};
     for (int k = 0; k < 8; k++) { CP(h3[k], c->t.c3[k], n3); CP(h2[k], c->t.c2[k], n2); }
@@ -839,8 +858,12 @@ extern "C" int lart_gpu_reduce_tallies(lart_gpu *c, int32_t root) {
     if (!c->comm) return fail("reduce_tallies: no communicator (lart_gpu_comm_init first)");
     if (root < 0 || root >= c->comm_n) return fail("reduce_tallies: root out of range");
     if (reduce_prepare(c)) return 1;
-    NCCLCHK(ncclReduce(c->d_tally, c->d_tally, (size_t)c->ntally, ncclDouble, ncclSum, root, c->comm, c->stream));
+    const bool is_root = c->comm_rank == root;
+    if (is_root && !c->d_reduced) HIPCHK(hipMalloc(&c->d_reduced, (size_t)c->ntally * sizeof(double)));
+    c->reduced_valid = false;
+    NCCLCHK(ncclReduce(c->d_tally, is_root ? c->d_reduced : c->d_tally, (size_t)c->ntally, ncclDouble, ncclSum, root, c->comm, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    c->reduced_valid = is_root;                               // (RCCL writes the receive buffer on the root only) every rank's own sums stay untouched: a second reduce gives the same totals
     return 0;
 }
 // all contexts live in this process (one host thread drives the GPUs of the node)
@@ -850,6 +873,8 @@ extern "C" int lart_gpu_reduce_tallies_multi(lart_gpu **ctx, int32_t n, int32_t 
     for (int i = 1; i < n; i++) if (ctx[i]->ntally != ctx[0]->ntally) return fail("reduce_tallies_multi: contexts have different tally layouts");
     for (int i = 0; i < n; i++) for (int j = 0; j < i; j++) if (ctx[i]->device == ctx[j]->device) return fail("reduce_tallies_multi: two contexts share a device");
     if (n == 1) { HIPCHK(hipStreamSynchronize(ctx[0]->stream)); return 0; }
+    { lart_gpu *r = ctx[root]; HIPCHK(hipSetDevice(r->device)); if (!r->d_reduced) HIPCHK(hipMalloc(&r->d_reduced, (size_t)r->ntally * sizeof(double))); }
+    for (int i = 0; i < n; i++) ctx[i]->reduced_valid = false;
     bool have = true;
     for (int i = 0; i < n; i++) have = have && ctx[i]->comm && ctx[i]->comm_n == n && ctx[i]->comm_rank == i;
     if (!have) {
@@ -861,11 +886,12 @@ extern "C" int lart_gpu_reduce_tallies_multi(lart_gpu **ctx, int32_t n, int32_t 
     NCCLCHK(ncclGroupStart());
     for (int i = 0; i < n; i++) {
         (void)hipSetDevice(ctx[i]->device);
-        ncclResult_t r = ncclReduce(ctx[i]->d_tally, ctx[i]->d_tally, (size_t)ctx[i]->ntally, ncclDouble, ncclSum, root, ctx[i]->comm, ctx[i]->stream);
+        ncclResult_t r = ncclReduce(ctx[i]->d_tally, i == root ? ctx[i]->d_reduced : ctx[i]->d_tally, (size_t)ctx[i]->ntally, ncclDouble, ncclSum, root, ctx[i]->comm, ctx[i]->stream);
         if (r != ncclSuccess) { (void)ncclGroupEnd(); return fail(std::string("ncclReduce: ") + ncclGetErrorString(r)); }
     }
     NCCLCHK(ncclGroupEnd());
     for (int i = 0; i < n; i++) { HIPCHK(hipSetDevice(ctx[i]->device)); HIPCHK(hipStreamSynchronize(ctx[i]->stream)); }
+    ctx[root]->reduced_valid = true;
     return 0;
 }
 // run_simulation over the GPUs of the node from one host thread: context r transports the photons r+1, r+1+n, ... <= nphotons
@@ -912,6 +938,26 @@ extern "C" int lart_gpu_get_photon_log(lart_gpu *c, double *nscatt, double *xfre
     return 0;
 }
 
+// the per-event history probe of the parity tests: the photons first_id + k * stride, k < count, run to the last one (as lart_gpu_run
+// does, tallies included), and for every k with slot[k] >= 0 the state after the birth and after every event is recorded
+// (LART_TRACE_W = 8 doubles per record, at most cap records per slot; n_out = records the packet produced)
+extern "C" int lart_gpu_test_trace(lart_gpu *c, int64_t first_id, int64_t stride, int64_t count, uint64_t seed, const int32_t *slot, int32_t nslots, int32_t cap,
+                                   double *trace_out, int32_t *n_out) {
+    if (!c || !slot || !trace_out || !n_out || count < 1 || nslots < 1 || cap < 1) return fail("test_trace: bad arguments");
+    for (int64_t k = 0; k < count; k++) if (slot[k] >= nslots) return fail("test_trace: slot entries must be < nslots");
+    HIPCHK(hipSetDevice(c->device));
+    const size_t nt = (size_t)nslots * cap * LART_TRACE_W;
+    HIPCHK(hipMalloc(&c->d_trace_slot, (size_t)count * 4)); HIPCHK(hipMalloc(&c->d_trace_n, (size_t)nslots * 4)); HIPCHK(hipMalloc(&c->d_trace, nt * 8));
+    HIPCHK(hipMemcpy(c->d_trace_slot, slot, (size_t)count * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(c->d_trace_n, 0, (size_t)nslots * 4)); HIPCHK(hipMemset(c->d_trace, 0, nt * 8));
+    c->trace_cap = cap;
+    int rc = lart_gpu_run(c, first_id, stride, count, seed);
+    if (!rc) { if (hipMemcpy(trace_out, c->d_trace, nt * 8, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(n_out, c->d_trace_n, (size_t)nslots * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = fail("test_trace: copy back failed"); }
+    (void)hipFree(c->d_trace_slot); (void)hipFree(c->d_trace_n); (void)hipFree(c->d_trace);
+    c->d_trace_slot = nullptr; c->d_trace_n = nullptr; c->d_trace = nullptr; c->trace_cap = 0;
+    return rc;
+}
+
 extern "C" int lart_gpu_get_all_photons(lart_gpu *c, double *out, int64_t n) {
     if (!c || !out) return fail("all_photons: null argument");
     if (!c->d_log || c->log_on != 2) return fail("all_photons: not enabled (lart_gpu_enable_all_photons before lart_gpu_begin)");
@@ -954,11 +1000,13 @@ __device__ void test_ray_one(const KArgs &A, const Lds &l, int kind, double *r, 
     Photon p{}; p.x = r[0]; p.y = r[1]; p.z = r[2]; p.kx = r[3]; p.ky = r[4]; p.kz = r[5]; p.xfreq = r[6]; p.wgt = r[7];
     p.ic = ic[0]; p.jc = ic[1]; p.kc = ic[2]; p.inside = ic[3] != 0;
     if (is_clump(VAR)) { p.icl = ic[0]; p.ic = 1; p.jc = 1; p.kc = 1; }          // clump mode: ic[0] carries the owner clump (0 = vacuum)
+    if (VAR == 8 && kind == 0) p.shear = *tau_out;                               // photon%vfy_shear comes in through tau_out and leaves through it
     unsigned ns = 0; bool dust = A.par.DGR > 0.0;
     if (kind == 0) {
         raytrace_to_tau<VAR>(A, l, dust, p, tq, ns);
         r[0] = p.x; r[1] = p.y; r[2] = p.z; r[3] = p.kx; r[4] = p.ky; r[5] = p.kz; r[6] = p.xfreq; r[7] = p.wgt;
         ic[0] = is_clump(VAR) ? p.icl : p.ic; ic[1] = p.jc; ic[2] = p.kc; ic[3] = p.inside ? 1 : 0;
+        if (VAR == 8) *tau_out = p.shear;
     } else *tau_out = raytrace_to_edge<VAR>(A, l, dust, p, p.xfreq, p.kx, p.ky, p.kz, kind == 2 ? tq : -1.0, ns);
 }
 __global__ void k_test_raytrace(KArgs A, int mode, int n, double *r8, int *ic4, const double *tq, double *tau_out) {
@@ -974,6 +1022,7 @@ __global__ void k_test_raytrace(KArgs A, int mode, int n, double *r8, int *ic4, 
     else if (var == 3) test_ray_one<3>(A, l, kind, r8 + 8 * i, ic4 + 4 * i, tq ? tq[i] : 0.0, tau_out + i);
     else if (var == 4) test_ray_one<4>(A, l, kind, r8 + 8 * i, ic4 + 4 * i, tq ? tq[i] : 0.0, tau_out + i);
     else if (var == 5) test_ray_one<5>(A, l, kind, r8 + 8 * i, ic4 + 4 * i, tq ? tq[i] : 0.0, tau_out + i);
+    else if (var == 8) test_ray_one<8>(A, l, kind, r8 + 8 * i, ic4 + 4 * i, tq ? tq[i] : 0.0, tau_out + i);
     else test_ray_one<6>(A, l, kind, r8 + 8 * i, ic4 + 4 * i, tq ? tq[i] : 0.0, tau_out + i);
 }
 __global__ void k_test_vec2pix(int nside, int n, const double *v, int *ipix) {
@@ -1046,7 +1095,7 @@ extern "C" int lart_gpu_test_rand(lart_gpu *c, int32_t what, uint64_t seed, uint
 extern "C" int lart_gpu_test_raytrace(lart_gpu *c, int32_t mode, int32_t n, double *r8, int32_t *ic4, const double *tq, double *tau_out) {
     if (!c || n < 0 || !c->d_cell) return fail("test_raytrace: needs a context with a medium");
     int kind = mode / 10, var = mode % 10;
-    if (kind < 0 || kind > 2 || var < 0 || var > 6 || (kind == 2 && var != 0 && var != 3)) return fail("test_raytrace: bad mode");
+    if (kind < 0 || kind > 2 || var < 0 || (var > 6 && var != 8) || (kind == 2 && var != 0 && var != 3)) return fail("test_raytrace: bad mode");
     if ((var == 3) != c->is_amr || (var == 4) != c->is_clump) return fail("test_raytrace: variant 3 needs the octree medium, 4 the clump medium, 0-2, 5, 6 the Cartesian one");
     HIPCHK(hipSetDevice(c->device));
     if (!c->d_tally) { if (build_tally(c)) return 1; }
@@ -1059,7 +1108,7 @@ extern "C" int lart_gpu_test_raytrace(lart_gpu *c, int32_t mode, int32_t n, doub
         if (q[0] > c->g.nx || q[1] > c->g.ny || q[2] > c->g.nz) return fail("test_raytrace: probe start cells must be interior (1..n)");
     }
     DevBuf<double> dr, dt, dq; DevBuf<int> di;
-    if (dr.alloc((size_t)8 * n, r8) || di.alloc((size_t)4 * n, ic4) || dt.alloc(n, nullptr) || dq.alloc(n, tq)) return fail("test_raytrace: hipMalloc failed");
+    if (dr.alloc((size_t)8 * n, r8) || di.alloc((size_t)4 * n, ic4) || dt.alloc(n, (var == 8 && tau_out) ? tau_out : nullptr) || dq.alloc(n, tq)) return fail("test_raytrace: hipMalloc failed");
     if (c->par.line_type >= 4 && c->par.line_type <= 6 && !c->has_ml) return fail("line_type 4/5/6 needs lart_gpu_set_line_multiplet first");
     KArgs A = probe_args(c);
     hipLaunchKernelGGL(k_test_raytrace, dim3((n + 63) / 64), dim3(64), probe_shmem(c), c->stream, A, mode, n, dr.p, di.p, tq ? dq.p : nullptr, dt.p);

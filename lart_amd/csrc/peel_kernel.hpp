@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256, LART_PEEL_WAVES) void peel_kernel(KArgs A) {
     const unsigned long long nregions = A.pq.nregions;        // producer waves of the transport launch this kernel follows
     const bool dust = A.par.DGR > 0.0;
     const int lane = threadIdx.x & 63;
-    unsigned nsteps = 0, natom = 0;
+    unsigned nsteps = 0, natom = 0, ndrop = 0;
     EdgeMarch m; m.live = false; m.tau = 0.0;
     int st = 0;                                                // 0 no item, 1 marching, 2 march over (weight and deposit pending)
     unsigned long long w_base = 0, w_next = 0, w_end = 0, d_next = 0, d_end = 0; size_t rec = 0; int io = 0, kind = 0; bool exhausted = false, ray_dust = false;
@@ -92,29 +92,31 @@ __global__ __launch_bounds__(256, LART_PEEL_WAVES) void peel_kernel(KArgs A) {
         // (2) one cell for every march of the wave; a finished march with a non-zero transmission deposits
         if (st == 1) { edge_step<VAR>(A, l, ray_dust, m, nsteps); if (!m.live) st = 2; }
         // a finished march whose transmission is not exactly zero goes to the deposit list: the wave reserves LART_DEP_CHUNK entries at a
-        // time (wave-uniform d_next / d_end) and marks what it leaves unused at the end
+        // time (wave-uniform d_next / d_end) and marks the unused tail of its last chunk when it ends
         const bool dep = st == 2 && (d_exp_neg(-m.tau) != 0.0 || (kind == PEEL_DIRECT && A.par.save_direc0));
         const unsigned long long dm = __ballot(dep);
         if (dm) {
-            const unsigned long long want = (unsigned long long)__popcll(dm);
-            if (d_next + want > d_end) {                       // wave-uniform: not enough left in the chunk
-                for (unsigned long long e = d_next + (unsigned)lane; e < d_end && e < A.pq.dep_cap; e += 64) A.pq.dep_idx[2 * e] = 0xffffffffu;   // void entries
-                unsigned long long b = 0; const int leader = __ffsll((long long)dm) - 1;
-                if (lane == leader) b = atomicAdd(&A.pq.pctl->d_n, (unsigned long long)LART_DEP_CHUNK);
-                b = __shfl(b, leader, 64);
-                d_next = b; d_end = b + LART_DEP_CHUNK;
+            // the wave fills its chunk to the last entry and continues in a new one: nothing is left unused but the tail of a wave's last chunk
+            const unsigned long long want = (unsigned long long)__popcll(dm), left = d_end - d_next;
+            unsigned long long nb = 0;
+            if (want > left) {                                 // wave-uniform
+                const int leader = __ffsll((long long)dm) - 1;
+                if (lane == leader) nb = atomicAdd(&A.pq.pctl->d_n, (unsigned long long)LART_DEP_CHUNK);
+                nb = __shfl(nb, leader, 64);
             }
             if (dep) {
-                const unsigned long long e = d_next + (unsigned long long)__popcll(dm & ((1ull << lane) - 1ull));
+                const unsigned long long rk = (unsigned long long)__popcll(dm & ((1ull << lane) - 1ull));
+                const unsigned long long e = rk < left ? d_next + rk : nb + (rk - left);
                 if (e < A.pq.dep_cap) { A.pq.dep_idx[2 * e] = (unsigned)rec; A.pq.dep_idx[2 * e + 1] = (unsigned)io; A.pq.dep_tau[e] = m.tau; }
+                else ndrop++;                                  // never silently: lart_gpu_get_tallies refuses the run (scal[LART_SCAL_PEEL_DROPPED])
             }
-            d_next += want;
+            if (want > left) { d_next = nb + (want - left); d_end = nb + LART_DEP_CHUNK; } else d_next += want;
         }
         if (st == 2) st = 0;
     }
     for (unsigned long long e = d_next + (unsigned)lane; e < d_end && e < A.pq.dep_cap; e += 64) A.pq.dep_idx[2 * e] = 0xffffffffu;
-    const double s4 = wave_sum((double)nsteps);
-    if ((threadIdx.x & 63) == 0) { if (s4 != 0.0) atomicAdd(&A.t.scal[4], s4); }
+    const double s4 = wave_sum((double)nsteps), sd = wave_sum((double)ndrop);
+    if ((threadIdx.x & 63) == 0) { if (s4 != 0.0) atomicAdd(&A.t.scal[4], s4); if (sd != 0.0) atomicAdd(&A.t.scal[LART_SCAL_PEEL_DROPPED], sd); }
 }
 
 // the deposits of the rays on the list: one entry per lane, grid-stride

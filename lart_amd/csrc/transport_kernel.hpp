@@ -115,6 +115,7 @@ __global__ __launch_bounds__(256, LART_WAVES(STOKES, PEEL)) void transport_kerne
         }
         p.ic = A.pool.ic[lane]; p.jc = A.pool.jc[lane]; p.kc = A.pool.kc[lane]; p.inside = true; p.xfreq_ref = 0.0; p.icl = 0;
         if (is_clump(VAR)) { p.icl = p.ic; p.ic = 1; }               // clump mode keeps the owner clump in the cell-index plane
+        if (VAR == 8) p.shear = F[F_SHEAR * P + lane];
         g.init(A.seed, (uint64_t)(A.first_id + k * A.stride), A.pool.rng_n[lane]);
     }
 
@@ -129,8 +130,10 @@ __global__ __launch_bounds__(256, LART_WAVES(STOKES, PEEL)) void transport_kerne
             if (kk >= (unsigned long long)A.count) break;
             k = (long long)kk;
             g.init(A.seed, (uint64_t)(A.first_id + k * A.stride), 0);
+            if (VAR == 8) p.shear = 0.0;                       // generate_photon.f90:141
             generate_photon<VAR, STOKES, DUST, PEEL>(A, l, g, p, npeel);
             if (A.allph) allph_initial(A, p, k);
+            if (A.trace_slot) trace_rec<VAR>(A, k, g.n, p, 0);
             alive = true; first = true;
             if (PEEL) budget--;                                // the birth queued one peel record (direct light): lanes x (max_events + 1) records bound the queue
             LART_PROF_MARK(p, 1);
@@ -144,6 +147,7 @@ __global__ __launch_bounds__(256, LART_WAVES(STOKES, PEEL)) void transport_kerne
         fly<VAR, DUST>(A, l, g, p, first, nsteps);
         { const bool on = p.inside; scatter_event<VAR, STOKES, DUST, PEEL>(A, l, g, p, npeel, on); if (on) { nev++; budget--; } }
         LART_PROF_MARK(p, 6);
+        if (A.trace_slot) trace_rec<VAR>(A, k, g.n, p, p.inside ? 1 : 2);
         if (!p.inside) {
             nsg_done += p.nsg; nsd_done += p.nsd; ndone++;
             if (A.log_nscatt) { A.log_nscatt[k] = p.nsg + p.nsd; A.log_xfreq[k] = p.xfreq_ref; }
@@ -180,6 +184,7 @@ __global__ __launch_bounds__(256, LART_WAVES(STOKES, PEEL)) void transport_kerne
             F[F_NX * P + lane] = p.nx; F[F_NY * P + lane] = p.ny; F[F_NZ * P + lane] = p.nz;
             F[F_Q * P + lane] = p.Q; F[F_U * P + lane] = p.U; F[F_V * P + lane] = p.V;
         }
+        if (VAR == 8) F[F_SHEAR * P + lane] = p.shear;
         A.pool.ic[lane] = is_clump(VAR) ? p.icl : p.ic; A.pool.jc[lane] = p.jc; A.pool.kc[lane] = p.kc;
     }
 #ifdef LART_PROFILE

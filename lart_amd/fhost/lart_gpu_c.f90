@@ -31,6 +31,11 @@ module lart_gpu_c
      real(c_double) :: DnuHK_Hz
      real(c_double) :: delta_nu_HD_Hz, ratio_Dfreq_HD, ratio_voigta_HD, nD_over_nH, g_recoil0_D
      real(c_double) :: xcrit, xcrit2
+     real(c_double) :: Omega
+     integer(c_int32_t) :: nxfreq_Ha = 0, h2_nlines = 0
+     real(c_double) :: xfreq_min_Ha = 0, dxfreq_Ha = 0, R_Ha = 0, albedo_Ha = 0, hgg_Ha = 0, P_conv = 0, E_conv(3) = 0
+     integer(c_int32_t) :: h2_hi_width = 0, pad_ = 0
+     real(c_double) :: h2_Dfreq_Hz = 0, h2_dnu_Hz(4) = 0, h2_strength(4) = 0, h2_a_damp(4) = 0, h2_p_scat(4) = 0
   end type lart_params
 
   !--- struct lart_tallies: host pointers (c_null_ptr = skip) + scalars
@@ -53,6 +58,8 @@ module lart_gpu_c
      type(c_ptr) :: J1, P1, P1_new
      real(c_double) :: nscatt_gas, nscatt_dust, n_events, n_cellsteps, n_cellsteps_peel, n_atomics
      integer(c_int64_t) :: nphotons_done, nphotons_active
+     type(c_ptr) :: Jout_Ha = c_null_ptr, Jabs_Ha = c_null_ptr, peel_Ha = c_null_ptr, Pconv = c_null_ptr
+     real(c_double) :: aux(8)
   end type lart_tallies
 
   interface

@@ -359,8 +359,8 @@ contains
     if (par%density_rscale /= -999.9_wp) call not_supported('par%density_rscale')
     if (par%density_zscale /= -999.9_wp) call not_supported('par%density_zscale')
     if (par%density_alpha /= 0.0_wp) call not_supported('par%density_alpha')
-    if (par%q /= 1.0_wp) call not_supported('par%q')
-    if (par%Omega /= 0.0_wp) call not_supported('par%Omega')
+    !--- par%q only enters through par%Omega = q Omega xrange in the dens_file branch of grid_create (grid_mod_car.f90:346-351): without a
+    !--- dens_file par%Omega is used as it stands (the shear of grid%vfy per x wrap, setup.f90:967-969)
     if (.not. par%continuum_normalize) call not_supported('par%continuum_normalize')
     if (par%EW_line /= 0.0_wp) call not_supported('par%EW_line')
     if (par%f_line /= 0.0_wp) call not_supported('par%f_line')

@@ -341,6 +341,7 @@ contains
     p%delta_nu_HD_Hz = line%delta_nu_HD_Hz; p%ratio_Dfreq_HD = line%ratio_Dfreq_HD; p%ratio_voigta_HD = line%ratio_voigta_HD
     p%nD_over_nH = line%nD_over_nH; p%g_recoil0_D = line%g_recoil0_D
     p%xcrit = grid%xcrit; p%xcrit2 = grid%xcrit2
+    p%Omega = par%Omega
   end subroutine fill_params
 
   !--- write_output_outside: `Spectrum` table + keywords (write_output_rect.f90:423-498), Jmu image (:524-539), profile

@@ -178,6 +178,10 @@ class Params:
     atau3: float = 0.0
     N_gasmax: float = -999.0
     N_gashomo: float = -999.0
+    # shearing box (define.f90:308-312): background y velocity -q Omega x.  Without a dens_file grid_create leaves par%Omega as it is
+    # (grid_mod_car.f90:346-351 rescales it only there), i.e. the change of grid%vfy, in thermal-speed units, per wrap around the x boundary
+    q: float = 1.0
+    Omega: float = 0.0
 
 
 # fields of params_type that exist in the reference but select physics outside this path: accepted at their
@@ -186,7 +190,7 @@ _UNSUPPORTED_DEFAULTS = {
     "h2_model": "none", "z_symmetry": False,
     "dens_file": "", "temp_file": "", "velo_file": "", "emiss_file": "", "cart_file": "", "input_field": "",
     "star_file": "", "use_cie_condition": False, "density_rscale": -999.9, "density_zscale": -999.9,
-    "density_alpha": 0.0, "Omega": 0.0, "temperature0": -999.0,
+    "density_alpha": 0.0, "temperature0": -999.0,
     "line_prof_file": "", "luminosity": 1.0, "save_backup": False, "save_input_grid": False,
     "intensity_unit": -999, "out_bitpix": 0,
     # the rest of the reference's namelist surface (define.f90:209-544): readable, rejected when set
@@ -198,7 +202,6 @@ _UNSUPPORTED_DEFAULTS = {
     "xmin": float("nan"),
     "ymin": float("nan"),
     "zmin": float("nan"),
-    "q": 1.0,
     "continuum_normalize": True,
     "EW_line": 0.0,
     "f_line": 0.0,
@@ -993,6 +996,7 @@ def make_lart_params(par, line, g):
     p.delta_nu_HD_Hz, p.ratio_Dfreq_HD, p.ratio_voigta_HD, p.nD_over_nH, p.g_recoil0_D = (line.delta_nu_HD_Hz, line.ratio_Dfreq_HD, line.ratio_voigta_HD,
                                                                                            line.nD_over_nH, line.g_recoil0_D)
     p.xcrit, p.xcrit2 = g.xcrit, g.xcrit2
+    p.Omega = float(par.Omega)                 # raytrace_to_tau_car_xyper_shear when xy_periodic and nx, ny > 1 (setup.f90:967-969)
     return p
 
 

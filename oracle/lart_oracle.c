@@ -92,6 +92,23 @@ typedef struct {
 } rng_t;
 
 /* uniform deviate on the OPEN interval (0,1): (x>>12 + 0.5)/2^52   (random_mt.f90:627-629) */
+/* -------------------------------------------------------------------------------------
+ * Decision margins (divergence audit of the photon-by-photon parity tests, tests/test_gpu_divergence.py).  While a history is
+ * traced (orc_trace) every data-dependent comparison on the path notes how close it was: the relative distance of the two
+ * compared numbers, divided by the condition number of the ill-conditioned side where there is one (the acceptance window of the
+ * wing sampler is a difference of two arctangents).  The trace keeps, per event, the smallest margin and which comparison had it:
+ * a device history may only part from the oracle's at an event whose smallest margin is at rounding level.
+ * ids: 10-19 rand_resonance_vz, 20 gauss pair, 21-22 Voigt regime / table node, 30 alias table, 40-42 Cartesian march,
+ * 43-45 octree, 46-55 clumps, 60-66 scattering, 70-72 birth / first flight
+ * ------------------------------------------------------------------------------------- */
+static __thread int g_mrg_on = 0, g_mrg_id = 0; static __thread double g_mrg = 1e300;
+static inline void mrg_note(double l, double r, int id, double cond) {
+    if (!g_mrg_on) return;
+    double sc = fmax(fabs(l), fabs(r)); if (!(sc > 0.0)) sc = 1e-300;
+    double m = fabs(l - r) / (sc * (cond > 1.0 ? cond : 1.0));
+    if (m < g_mrg) { g_mrg = m; g_mrg_id = id; }
+}
+#define MRG(l, r, id) mrg_note((l), (r), (id), 1.0)
 static inline double u64_to_open01(uint64_t x) { return ((double)(x >> 12) + 0.5) * (1.0 / 4503599627370496.0); }
 
 static double rnd(rng_t *g) {
@@ -118,6 +135,7 @@ static double gauss_pair(rng_t *g, double *second) {
         v1 = 2.0 * rnd(g) - 1.0;
         v2 = 2.0 * rnd(g) - 1.0;
         rsq = v1 * v1 + v2 * v2;
+        MRG(rsq, 1.0, 20);
     } while (!(rsq > 0.0 && rsq < 1.0));
     rsq = sqrt(-2.0 * log(rsq) / rsq);
     *second = v1 * rsq;
@@ -140,6 +158,7 @@ static double rand_gauss(rng_t *g) {
 double orc_voigt(double vin, double a) {
     double v = (vin < 0.0) ? -vin : vin, vv, y1, y2, y3;
     int k1, k2, k3;
+    if (g_mrg_on) { MRG(v, 1.0, 21); MRG(v, 5.0, 21); MRG(v, 10.0, 21); if (v >= 1.0 && v < 5.0) { double vq = v * 20.0; MRG(vq, rint(vq), 22); } }
     if (v < 1.0) {
         vv = v * 20.0; k1 = (int)vv + 1; k2 = k1 + 1;
         y1 = VOIGT_H0[k1-1] + a * (VOIGT_H1[k1-1] + a * VOIGT_H2[k1-1]);
@@ -171,44 +190,49 @@ void orc_voigt_v(int n, const double *x, const double *a, double *h) { for (int 
 static double rand_resonance_vz(rng_t *g, double x0in, double a) {
     const double xc = 1.0 + sqrt(2.0), two_over_PI = 2.0 / PI;
     double x0 = fabs(x0in), vz, beta = 0, Cb = 0, pb, t1 = 0, t2, delt = 0;
+    MRG(x0, 1.0, 10);
     if (x0 <= 1.0) {
         for (;;) {
             vz = x0 + a * tan(PI * (rnd(g) - 0.5));
-            if (rnd(g) <= exp(-(vz * vz))) break;
+            const double r_ = rnd(g), e_ = exp(-(vz * vz)); MRG(r_, e_, 11);
+            if (r_ <= e_) break;
         }
         return (x0in < 0.0) ? -vz : vz;
     }
     double x0sq = x0 * x0, api = a * PI, beta0 = exp(-x0sq / 2.0), h0_two = beta0 / a, h0 = h0_two / 2.0;
+    MRG(x0, xc, 12);
     if (x0 < xc) {
         double dbeta = sqrt(two_over_PI * a * (1.0 - beta0) * beta0 * x0), beta1 = beta0 + dbeta, one_b1 = 1.0 - beta1;
         double pb1 = sqrt(-2.0 * log(beta1)), h1 = two_over_PI * beta1 * pb1 / (x0sq - pb1 * pb1);
         double S0 = beta0 * h0, S1 = dbeta * h0, S2 = one_b1 * h1, Stot = S0 + S1 + S2;
         for (;;) {
-            double rS = rnd(g);
+            double rS = rnd(g); MRG(rS, S0 / Stot, 13); MRG(rS, 1.0 - S2 / Stot, 14);
             if (rS < S0 / Stot)              { beta = beta0 * sqrt(rnd(g)); Cb = beta / a; }
             else if (rS < 1.0 - S2 / Stot)   { beta = beta0 + dbeta * rnd(g); Cb = h0; }
             else                             { beta = beta1 + one_b1 * rnd(g); Cb = h1; }
             pb = sqrt(-2.0 * log(beta));
             t2 = atan((pb - x0) / a); t1 = atan((-pb - x0) / a); delt = t2 - t1;
-            if (rnd(g) * Cb < (beta / api) * delt) break;
+            { const double l_ = rnd(g) * Cb, r_ = (beta / api) * delt; mrg_note(l_, r_, 15, (fabs(t1) + fabs(t2)) / fabs(delt)); if (l_ < r_) break; }
         }
     } else {
         double h2 = 0.3861 / (x0sq - 1.373);
+        MRG(h0_two, h2, 16); MRG(h0, h2, 17);
         if (h0_two < h2) {
             for (;;) {
                 beta = rnd(g); Cb = h2;
                 pb = sqrt(-2.0 * log(beta));
                 t2 = atan((pb - x0) / a); t1 = atan((-pb - x0) / a); delt = t2 - t1;
-                if (rnd(g) * Cb < (beta / api) * delt) break;
+                { const double l_ = rnd(g) * Cb, r_ = (beta / api) * delt; mrg_note(l_, r_, 15, (fabs(t1) + fabs(t2)) / fabs(delt)); if (l_ < r_) break; }
             }
         } else if (h0 < h2) {
             double S0 = beta0 * h0, one_b0 = 1.0 - beta0, S1 = one_b0 * h2, Stot = S0 + S1;
             for (;;) {
-                if (rnd(g) < S0 / Stot) { beta = beta0 * sqrt(rnd(g)); Cb = beta / a; }
+                const double rS = rnd(g); MRG(rS, S0 / Stot, 18);
+                if (rS < S0 / Stot) { beta = beta0 * sqrt(rnd(g)); Cb = beta / a; }
                 else                    { beta = beta0 + one_b0 * rnd(g); Cb = h2; }
                 pb = sqrt(-2.0 * log(beta));
                 t2 = atan((pb - x0) / a); t1 = atan((-pb - x0) / a); delt = t2 - t1;
-                if (rnd(g) * Cb < (beta / api) * delt) break;
+                { const double l_ = rnd(g) * Cb, r_ = (beta / api) * delt; mrg_note(l_, r_, 15, (fabs(t1) + fabs(t2)) / fabs(delt)); if (l_ < r_) break; }
             }
         } else {
             double dbeta = sqrt(two_over_PI * a * (1.0 - beta0) * beta0 * x0), beta1 = beta0 + dbeta, one_b1 = 1.0 - beta1;
@@ -216,13 +240,13 @@ static double rand_resonance_vz(rng_t *g, double x0in, double a) {
             double hmax = (h1 > h2) ? h1 : h2;
             double S0 = beta0 * h0, S1 = dbeta * h0, S2 = one_b1 * hmax, Stot = S0 + S1 + S2;
             for (;;) {
-                double rS = rnd(g);
+                double rS = rnd(g); MRG(rS, S0 / Stot, 13); MRG(rS, 1.0 - S2 / Stot, 14);
                 if (rS < S0 / Stot)              { beta = beta0 * sqrt(rnd(g)); Cb = beta / a; }
                 else if (rS < 1.0 - S2 / Stot)   { beta = beta0 + dbeta * rnd(g); Cb = h0; }
                 else                             { beta = beta1 + one_b1 * rnd(g); Cb = hmax; }
                 pb = sqrt(-2.0 * log(beta));
                 t2 = atan((pb - x0) / a); t1 = atan((-pb - x0) / a); delt = t2 - t1;
-                if (rnd(g) * Cb < (beta / api) * delt) break;
+                { const double l_ = rnd(g) * Cb, r_ = (beta / api) * delt; mrg_note(l_, r_, 15, (fabs(t1) + fabs(t2)) / fabs(delt)); if (l_ < r_) break; }
             }
         }
     }
@@ -271,6 +295,7 @@ typedef struct {
     double x, y, z, kx, ky, kz, mx, my, mz, nx, ny, nz;
     int icell, jcell, kcell;
     int icell_clump;                  /* 0 = vacuum, > 0 = owner clump (define.f90:90) */
+    double vfy_shear;                 /* y velocity picked up at the shearing x boundary (define.f90:100) */
     int species;                      /* line%selected_species_HD of the last resonance scattering: 1 H, 2 D */
     double xfreq, xfreq_ref, wgt;
     int inside;
@@ -320,6 +345,7 @@ struct orc_sim {
     int use_stokes, use_reduced_wgt, save_Jin, save_Jabs, save_Jmu, nmu;
     double mu_min, dmu;
     double hgg, albedo, cext_dust, DGR, distance2cm;
+    double Omega;                    /* par%Omega (define.f90:308-312) as grid_create leaves it without a dens_file: added to vfy per x wrap (raytrace_car.f90:2843-2852) */
     int save_peeloff, save_peeloff_2D, save_peeloff_3D, save_direc0, save_dust_scattered, nobs, nxim, nyim;
     double distance, alpha[MAX_OBS], beta[MAX_OBS], gamma[MAX_OBS], obsx[MAX_OBS], obsy[MAX_OBS], obsz[MAX_OBS], dxim, dyim;
     char scatt_mat_file[512];
@@ -441,7 +467,7 @@ static int set_param(orc_sim *s, const char *k, const char *v) {
     B(comoving_source) B(recoil) B(core_skip) B(core_skip_global) B(xyz_symmetry) B(xy_periodic) B(xy_symmetry) B(fine_structure) B(include_deuterium) B(HeI_coherent) B(save_all_photons)
     I(nx) I(ny) I(nz) D(xmax) D(ymax) D(zmax) D(rmax) D(rmin) D(xs_point) D(ys_point) D(zs_point) D(source_rmax)
     D(xfreq0) I(nxfreq) B(use_stokes) B(use_reduced_wgt) B(save_Jin) B(save_Jabs) B(save_Jmu) I(nmu)
-    D(hgg) D(albedo) D(cext_dust) D(DGR) D(distance2cm) B(save_peeloff) B(save_peeloff_2D) B(save_peeloff_3D) B(save_direc0) B(save_dust_scattered)
+    D(hgg) D(albedo) D(cext_dust) D(DGR) D(distance2cm) D(Omega) B(save_peeloff) B(save_peeloff_2D) B(save_peeloff_3D) B(save_direc0) B(save_dust_scattered)
     I(nxim) I(nyim) D(distance) D(dxim) D(dyim) B(calc_J) B(calc_P) B(calc_Pnew) I(geometry_JPa) I(nside)
     if (!strcmp(k, "xfreq_min")) { s->par_xfreq_min = atof(v); return 0; }
     if (!strcmp(k, "xfreq_max")) { s->par_xfreq_max = atof(v); return 0; }
@@ -607,7 +633,7 @@ static double interp_eq(int n, const double *x, const double *y, double xnew) {
 /* rand_alias_linear64: random_mt.f90:2196-2216 */
 static double rand_alias_linear(rng_t *g, int n, const double *prob_alias, const int *alias, const double *xaxis, const double *prob) {
     int k = (int)floor(n * rnd(g)) + 1, idx;
-    if (rnd(g) < prob_alias[k-1]) idx = k; else idx = alias[k-1];
+    { const double r_ = rnd(g); MRG(r_, prob_alias[k-1], 30); if (r_ < prob_alias[k-1]) idx = k; else idx = alias[k-1]; }
     double p0 = prob[idx-1], p1 = prob[idx];
     return (sqrt(p0 * p0 + (p1 * p1 - p0 * p0) * rnd(g)) - p0) * (xaxis[idx] - xaxis[idx-1]) / (p1 - p0) + xaxis[idx-1];
 }
@@ -850,7 +876,7 @@ static int grid_create(orc_sim *s) {
     if (s->xyz_symmetry) s->raytrace_variant = 1;
     else if (s->xy_symmetry) s->raytrace_variant = 5;                               /* raytrace_to_{tau,edge}_car_xysym */
     else if (s->xy_periodic && s->nx == 1 && s->ny == 1) s->raytrace_variant = 2;
-    else if (s->xy_periodic) s->raytrace_variant = 6;                               /* raytrace_to_{tau,edge}_car_xyper */
+    else if (s->xy_periodic) s->raytrace_variant = (s->Omega != 0.0) ? 8 : 6;       /* raytrace_to_{tau,edge}_car_xyper; 8 = raytrace_to_tau_car_xyper_shear (setup.f90:959-973) */
     else s->raytrace_variant = 0;
     return 0;
 }
@@ -1289,6 +1315,7 @@ static void amr_xcrit_local(const orc_sim *s, int il, double x, double y, double
     double dl = fmin(h - fabs(x - a->cx[ic-1]), fmin(h - fabs(y - a->cy[ic-1]), h - fabs(z - a->cz[ic-1])));
     if (dl <= 0.0) return;
     double atau = s->voigt_a[il-1] * s->rhokap[il-1] * dl;
+    MRG(atau, 1.0, 65);
     if (atau > 1.0) { *xc = pow(atau, 1.0 / 3.0) / 5.0; *xc2 = (*xc) * (*xc); }
 }
 /* boundary handling shared by the three AMR marches (raytrace_amr.f90:176-201): periodic in x and y (wrap by the box size and look the leaf up
@@ -1327,6 +1354,7 @@ static void raytrace_to_tau_amr(const orc_sim *s, acc_t *A, photon_t *p, double 
         double rhokapH = s->rhokap[il-1] * calc_voigt(s, p->xfreq, s->voigt_a[il-1], s->Dfreq[il-1]), rhokap = rhokapH;
         if (s->DGR > 0.0) rhokap = rhokap + s->rhokapD[il-1];
         A->n_cellsteps += 1.0;
+        MRG(tau + t_exit * rhokap, tau_in, 43);
         if (tau + t_exit * rhokap >= tau_in) {
             double d_step = (rhokap > 0.0) ? (tau_in - tau) / rhokap : t_exit;
             if (s->nbins) add_to_JPnew_amr(s, A, p, il, x + 0.5 * d_step * kx, y + 0.5 * d_step * ky, z + 0.5 * d_step * kz, d_step, d_step * rhokapH);
@@ -1634,15 +1662,18 @@ static int find_next_clump(const clumps_t *c, double xp, double yp, double zp, d
             if (icl == skip_icl) continue;
             double rx = xp - c->x[icl-1], ry = yp - c->y[icl-1], rz = zp - c->z[icl-1];       /* ray_sphere_isect :1363-1387 */
             double b = rx * kx + ry * ky + rz * kz, disc = b * b - (rx * rx + ry * ry + rz * rz) + c->radius2[icl-1];
+            if (g_mrg_on) mrg_note(b * b + c->radius2[icl-1], rx * rx + ry * ry + rz * rz, 47, 1.0);      /* a grazing ray: disc = 0 */
             if (disc < 0.0) continue;
             disc = sqrt(disc);
             double te = -b - disc, tx2 = -b + disc;
+            if (g_mrg_on && tx2 > 0.0 && best_icl > 0) MRG(te, best_te, 48);
             if (tx2 > 0.0 && te < best_te) { best_te = te; best_tx2 = tx2; best_icl = icl; }       /* (te > 0 .or. icl /= skip) holds: skip was excluded above */
         }
         if (tx <= ty && tx <= tz) { d = tx; ci += si; if (ci < 0 || ci >= cg) break; tx += delx; }
         else if (ty <= tz)        { d = ty; cj += sj; if (cj < 0 || cj >= cg) break; ty += dely; }
         else                      { d = tz; ck += sk; if (ck < 0 || ck >= cg) break; tz += delz; }
     }
+    if (best_icl > 0) MRG(best_te, t_max, 51);
     if (best_icl > 0 && best_te <= t_max) { *t_entry = best_te; *t_exit = fmin(best_tx2, t_max); *icl_found = best_icl; return 1; }
     return 0;
 }
@@ -1691,6 +1722,7 @@ static void raytrace_to_tau_clump(const orc_sim *s, acc_t *A, photon_t *p, doubl
             int64_t icl = p->icell_clump;
             double t_seg = clump_exit_dist(c, p->x, p->y, p->z, kx, ky, kz, icl), kap = kappa_clump(s, p->xfreq, icl);
             A->n_cellsteps += 1.0;
+            MRG(tau_rem, kap * t_seg, 46);
             if (tau_rem <= kap * t_seg) {
                 double ds = tau_rem / fmax(kap, 2.2250738585072014e-308);
                 p->x = p->x + ds * kx; p->y = p->y + ds * ky; p->z = p->z + ds * kz;
@@ -1700,6 +1732,7 @@ static void raytrace_to_tau_clump(const orc_sim *s, acc_t *A, photon_t *p, doubl
             p->x = p->x + t_seg * kx; p->y = p->y + t_seg * ky; p->z = p->z + t_seg * kz;
             p->xfreq = p->xfreq + ulos_clump(c, icl, kx, ky, kz);
             last_icl = icl; p->icell_clump = 0;
+            MRG(p->x * p->x + p->y * p->y + p->z * p->z, c->sphere_R * c->sphere_R, 50);
             if (p->x * p->x + p->y * p->y + p->z * p->z >= c->sphere_R * c->sphere_R) { p->inside = 0; update_cell_idx(s, p); p->xfreq_ref = p->xfreq; clump_escape(s, A, p); return; }
         } else {
             double t_sp = sphere_exit_dist(c, p->x, p->y, p->z, kx, ky, kz), te, tx2; int64_t icl_found;
@@ -1987,7 +2020,7 @@ static void raytrace_to_tau(const orc_sim *s, acc_t *A, photon_t *p, double tau_
         if (setup_axis_sym(s->nx, s->xface, s->dx, s->i0, xp, 1, &t.icell, &t.istep, &t.kx, &t.tx, &t.delx)) { p->inside = 0; return; }
         if (setup_axis_sym(s->ny, s->yface, s->dy, s->j0, yp, 1, &t.jcell, &t.jstep, &t.ky, &t.ty, &t.dely)) { p->inside = 0; return; }
         if (setup_axis_plain(s->nz, s->zface, s->dz, zp, 1, &t.kcell, &t.kstep, t.kz, &t.tz, &t.delz)) { p->inside = 0; return; }
-    } else if (variant == 6) {                                                       /* xyper :2287-2361 */
+    } else if (variant == 6 || variant == 8) {                                       /* xyper :2287-2361, shear :2718-2770 */
         setup_axis_per(s->nx, s->xface, s->dx, &xp, 1, &t.icell, &t.istep, t.kx, &t.tx, &t.delx);
         setup_axis_per(s->ny, s->yface, s->dy, &yp, 1, &t.jcell, &t.jstep, t.ky, &t.ty, &t.dely);
         if (setup_axis_plain(s->nz, s->zface, s->dz, zp, 1, &t.kcell, &t.kstep, t.kz, &t.tz, &t.delz)) { p->inside = 0; return; }
@@ -1995,10 +2028,11 @@ static void raytrace_to_tau(const orc_sim *s, acc_t *A, photon_t *p, double tau_
         t.istep = t.jstep = 0; t.tx = t.ty = HUGEST; t.delx = t.dely = HUGEST;
         if (setup_axis_plain(s->nz, s->zface, s->dz, zp, 1, &t.kcell, &t.kstep, t.kz, &t.tz, &t.delz)) { p->inside = 0; return; }
     }
-    const int mirror_xy = (variant == 1 || variant == 5), mirror_z = (variant == 1), wrap_xy = (variant == 6);
+    const int mirror_xy = (variant == 1 || variant == 5), mirror_z = (variant == 1), wrap_xy = (variant == 6 || variant == 8), shear = (variant == 8);
     double tau = 0.0, d = 0.0, del = 0.0, rhokap, rhokapH = 0.0;
     int iold = t.icell, jold = t.jcell, kold = t.kcell;
     double u1 = udot(s, IDX(s,iold,jold,kold), t.kx, t.ky, t.kz), u2;
+    if (shear) u1 = s->vfx[IDX(s,iold,jold,kold)] * t.kx + (s->vfy[IDX(s,iold,jold,kold)] + p->vfy_shear) * t.ky + s->vfz[IDX(s,iold,jold,kold)] * t.kz;   /* :2808-2809 */
     while (p->inside) {
         size_t c = IDX(s,t.icell,t.jcell,t.kcell);
         rhokapH = s->rhokap[c] * calc_voigt(s, p->xfreq, s->voigt_a[c], s->Dfreq[c]);
@@ -2007,6 +2041,7 @@ static void raytrace_to_tau(const orc_sim *s, acc_t *A, photon_t *p, double tau_
         int idx = (variant == 2) ? 3 : minloc3(t.tx, t.ty, t.tz);
         double *tt = (idx == 1) ? &t.tx : (idx == 2) ? &t.ty : &t.tz;
         del = *tt - d; tau = tau + del * rhokap; d = *tt;
+        MRG(tau, tau_in, 40);
         if (tau >= tau_in) {
             if (rhokap > 0.0) { double d_over = (tau - tau_in) / rhokap; d = d - d_over; del = del - d_over; }
             if (!mirror_xy) { xp = xp + d * t.kx; yp = yp + d * t.ky; zp = zp + d * t.kz; }
@@ -2014,7 +2049,8 @@ static void raytrace_to_tau(const orc_sim *s, acc_t *A, photon_t *p, double tau_
         }
         if (idx == 1) { t.icell += t.istep;
             if (mirror_xy && t.icell < 1) { t.icell = s->i0; t.istep = 1; t.kx = -t.kx; }
-            else if (wrap_xy) { if (t.icell < 1) t.icell = s->nx; if (t.icell > s->nx) t.icell = 1; }
+            else if (wrap_xy) { if (t.icell < 1) { t.icell = s->nx; if (shear) p->vfy_shear = p->vfy_shear - s->Omega; }            /* :2843-2852 */
+                                if (t.icell > s->nx) { t.icell = 1; if (shear) p->vfy_shear = p->vfy_shear + s->Omega; } }
             else if (t.icell < 1 || t.icell > s->nx) { p->inside = 0; break; }
             t.tx += t.delx; }
         else if (idx == 2) { t.jcell += t.jstep;
@@ -2028,7 +2064,7 @@ static void raytrace_to_tau(const orc_sim *s, acc_t *A, photon_t *p, double tau_
             t.tz += t.delz; }
         size_t cn = IDX(s,t.icell,t.jcell,t.kcell), co = IDX(s,iold,jold,kold);
         if (s->nbins) add_to_JPnew(s, A, p, co, del, del * rhokapH);                   /* :1579-1584 */
-        u2 = udot(s, cn, t.kx, t.ky, t.kz);
+        u2 = shear ? s->vfx[cn] * t.kx + (s->vfy[cn] + p->vfy_shear) * t.ky + s->vfz[cn] * t.kz : udot(s, cn, t.kx, t.ky, t.kz);
         p->xfreq = (p->xfreq + u1) * s->Dfreq[co] / s->Dfreq[cn] - u2;
         iold = t.icell; jold = t.jcell; kold = t.kcell; u1 = u2;
     }
@@ -2036,7 +2072,7 @@ static void raytrace_to_tau(const orc_sim *s, acc_t *A, photon_t *p, double tau_
     if (s->nbins) add_to_JPnew(s, A, p, IDX(s,t.icell,t.jcell,t.kcell), del, del * rhokapH);   /* :1604-1609 last segment */
     if (!p->inside) {                                                                /* escape tally :1613-1623 */
         size_t c = IDX(s,t.icell,t.jcell,t.kcell);
-        u1 = udot(s, c, t.kx, t.ky, t.kz);
+        u1 = shear ? s->vfx[c] * t.kx + (s->vfy[c] + p->vfy_shear) * t.ky + s->vfz[c] * t.kz : udot(s, c, t.kx, t.ky, t.kz);
         p->xfreq = p->xfreq + u1;
         p->xfreq_ref = p->xfreq * (s->Dfreq[c] / s->Dfreq_ref);
         int ix = (int)floor((p->xfreq_ref - s->xfreq_min) / s->dxfreq) + 1;
@@ -2047,7 +2083,7 @@ static void raytrace_to_tau(const orc_sim *s, acc_t *A, photon_t *p, double tau_
         if (p->x < s->xmin) p->x = -p->x; if (p->y < s->ymin) p->y = -p->y; if (mirror_z && p->z < s->zmin) p->z = -p->z;
         p->kx = t.kx; p->ky = t.ky; p->kz = t.kz;
         p->icell = t.icell; p->jcell = t.jcell; p->kcell = t.kcell;
-    } else if (variant == 6) {                                                       /* :2509-2514: back into the base period */
+    } else if (variant == 6 || variant == 8) {                                       /* :2509-2514, :2943-2949: back into the base period */
         p->x = xp - floor((xp - s->xmin) / s->xrange) * s->xrange; p->y = yp - floor((yp - s->ymin) / s->yrange) * s->yrange; p->z = zp;
         p->icell = t.icell; p->jcell = t.jcell; p->kcell = t.kcell;
     } else if (variant == 0) { p->x = xp; p->y = yp; p->z = zp; p->icell = t.icell; p->jcell = t.jcell; p->kcell = t.kcell; }
@@ -2060,6 +2096,7 @@ static double raytrace_to_edge(const orc_sim *s, const photon_t *p, int variant,
     if (variant == 3) return raytrace_to_edge_amr(s, p, dist, nsteps);
     if (variant == 4) return raytrace_to_edge_clump(s, p, -1.0, nsteps);                 /* uncapped: first flight (run_simulation_mod.f90:165) */
     if (variant == 7) return raytrace_to_edge_clump_overlap(s, p, -1.0, nsteps);
+    if (variant == 8) variant = 0;            /* setup_procedure assigns raytrace_to_tau only for the shearing box (setup.f90:967-969): raytrace_to_edge stays raytrace_to_edge_car (:941) */
     trav_t t; double xp = p->x, yp = p->y, zp = p->z, tau = 0.0, d = 0.0;
     t.kx = p->kx; t.ky = p->ky; t.kz = p->kz; t.icell = p->icell; t.jcell = p->jcell; t.kcell = p->kcell;
     if (variant == 0) { if (setup_traversal_car(s, xp, yp, zp, &t)) return tau; }
@@ -2124,6 +2161,7 @@ static void car_xcrit_local(const orc_sim *s, int i, int j, int k, double x, dou
     double dl = fmin(dlx, fmin(dly, dlz));
     if (dl <= 0.0) return;
     double atau = s->voigt_a[IDX(s,i,j,k)] * s->rhokap[IDX(s,i,j,k)] * dl;
+    MRG(atau, 1.0, 65);
     if (atau > 1.0) { *xc = pow(atau, 1.0 / 3.0) / 5.0; *xc2 = (*xc) * (*xc); }
 }
 double orc_xcrit_local(const orc_sim *s, int i, int j, int k, double x, double y, double z) { double a, b; car_xcrit_local(s, i, j, k, x, y, z, &a, &b); return a; }
@@ -2344,7 +2382,8 @@ static void do_resonance1(const orc_sim *s, rng_t *g, photon_t *p, double *uz, d
         double DnuHK = s->DnuHK_Hz / Df;
         double pH = orc_voigt(xfreq_loc + DnuHK, va) * (1.0 / 3.0), pK = orc_voigt(xfreq_loc, va) * (2.0 / 3.0);
         pH = pH / (pH + pK);
-        if (rnd(g) < pH) uz_loc = rand_resonance_vz(g, xfreq_loc + DnuHK, va); else uz_loc = rand_resonance_vz(g, xfreq_loc, va);
+        const double rl_ = rnd(g); MRG(rl_, pH, 63);
+        if (rl_ < pH) uz_loc = rand_resonance_vz(g, xfreq_loc + DnuHK, va); else uz_loc = rand_resonance_vz(g, xfreq_loc, va);
         xatom_loc = xfreq_loc - uz_loc;
         double qH = xatom_loc + DnuHK, qK = xatom_loc;
         p->E1 = (2.0 * qK * qH + qH * qH) / (qK * qK + 2.0 * qH * qH);             /* E1 of the atom-frame frequency */
@@ -2357,10 +2396,11 @@ static void do_resonance1(const orc_sim *s, rng_t *g, photon_t *p, double *uz, d
             double p1 = orc_voigt(xfreq_loc, va) * s->ml.f12[0], p2 = orc_voigt(xfreq_loc + Dx2, va2) * s->ml.f12[1];
             if (s->line_type == 5) {
                 p1 = p1 / (p2 + p1);
-                if (rnd(g) < p1) { uz_loc = rand_resonance_vz(g, xfreq_loc, va); iup = 1; } else { uz_loc = rand_resonance_vz(g, xfreq_loc + Dx2, va2); iup = 2; }
+                const double rl_ = rnd(g); MRG(rl_, p1, 63);
+                if (rl_ < p1) { uz_loc = rand_resonance_vz(g, xfreq_loc, va); iup = 1; } else { uz_loc = rand_resonance_vz(g, xfreq_loc + Dx2, va2); iup = 2; }
             } else {
                 double Dx3 = s->ml.delE_Hz[2] / Df, va3 = va * s->ml.damping_up[2] / s->ml.damping_up[0];
-                double p3 = orc_voigt(xfreq_loc + Dx3, va3) * s->ml.f12[2], ptot = p1 + p2 + p3, pcum1 = p1 / ptot, pcum2 = (p1 + p2) / ptot, xi = rnd(g);
+                double p3 = orc_voigt(xfreq_loc + Dx3, va3) * s->ml.f12[2], ptot = p1 + p2 + p3, pcum1 = p1 / ptot, pcum2 = (p1 + p2) / ptot, xi = rnd(g); MRG(xi, pcum1, 63); MRG(xi, pcum2, 63);
                 if (xi < pcum1) { uz_loc = rand_resonance_vz(g, xfreq_loc, va); iup = 1; }
                 else if (xi < pcum2) { uz_loc = rand_resonance_vz(g, xfreq_loc + Dx2, va2); iup = 2; }
                 else { uz_loc = rand_resonance_vz(g, xfreq_loc + Dx3, va3); iup = 3; }
@@ -2369,7 +2409,7 @@ static void do_resonance1(const orc_sim *s, rng_t *g, photon_t *p, double *uz, d
         xatom_loc = xfreq_loc - uz_loc;
         if (s->line_type == 4 || (s->line_type == 5 && s->ml.ndown[iup-1] > 1)) {           /* rand_alias_choise: random_mt.f90:2122-2135 */
             int n = s->ml.ndown[iup-1], k = (int)floor(n * rnd(g)) + 1;
-            idown = (rnd(g) < s->ml.P_down[iup-1][k-1]) ? k : s->ml.A_down[iup-1][k-1];
+            { const double rl_ = rnd(g); MRG(rl_, s->ml.P_down[iup-1][k-1], 63); idown = (rl_ < s->ml.P_down[iup-1][k-1]) ? k : s->ml.A_down[iup-1][k-1]; }
             if (s->line_type == 5 || idown != 1) xatom_loc = xatom_loc - s->ml.Elow_Hz[iup-1][idown-1] / Df;
         }
         p->E1 = s->ml.E1[iup-1][idown-1]; p->E2 = s->ml.E2[iup-1][idown-1]; p->E3 = s->ml.E3[iup-1][idown-1];
@@ -2384,7 +2424,8 @@ static void do_resonance1(const orc_sim *s, rng_t *g, photon_t *p, double *uz, d
     } else if (s->line_type == 7) {                         /* do_resonance_HD :476-549 (clump form line_clump_mod.f90:262-300): H or D atom */
         double dx_HD = s->delta_nu_HD_Hz / Df, xfreq_D = (xfreq_loc - dx_HD) * s->ratio_Dfreq_HD;
         double pH = orc_voigt(xfreq_loc, va), pD = s->nD_over_nH * s->ratio_Dfreq_HD * orc_voigt(xfreq_D, va * s->ratio_voigta_HD);
-        if (rnd(g) < pH / (pH + pD)) { p->species = 1; uz_loc = rand_resonance_vz(g, xfreq_loc, va); }
+        const double rl_ = rnd(g); MRG(rl_, pH / (pH + pD), 63);
+        if (rl_ < pH / (pH + pD)) { p->species = 1; uz_loc = rand_resonance_vz(g, xfreq_loc, va); }
         else { p->species = 2; uz_loc = rand_resonance_vz(g, xfreq_D, va * s->ratio_voigta_HD) / s->ratio_Dfreq_HD; }
         xatom_loc = xfreq_loc - uz_loc;
         p->E1 = s->E1; p->E2 = s->E2; p->E3 = s->E3;
@@ -2427,6 +2468,7 @@ static inline double recoil_const(const orc_sim *s, const photon_t *p) {
 static inline void perp_velocity_rayleigh(const orc_sim *s, rng_t *g, const photon_t *p, double *ux, double *uy) {
     double xc = 0.0, xc2 = 0.0, phi2, uxy;
     if (s->core_skip) car_xcrit_local(s, p->icell, p->jcell, p->kcell, p->x, p->y, p->z, &xc, &xc2);
+    if (s->core_skip) MRG(fabs(p->xfreq), xc, 64);
     if (s->core_skip && fabs(p->xfreq) < xc) { phi2 = TWOPI * rnd(g); uxy = sqrt(xc2 - log(rnd(g))); }
     else                                     { phi2 = TWOPI * rnd(g); uxy = sqrt(-log(rnd(g))); }
     *ux = uxy * cos(phi2); *uy = uxy * sin(phi2);
@@ -2452,6 +2494,7 @@ static inline double phi_rejection(rng_t *g, const photon_t *p, double S12overS1
         double phi = TWOPI * rnd(g), phi1 = 2.0 * phi;
         double Prand = (1.0 + fabs(S12overS11) * sqrt(p->Q * p->Q + p->U * p->U)) * rnd(g);
         double Pcomp = 1.0 + S12overS11 * (p->Q * cos(phi1) + p->U * sin(phi1));
+        MRG(Prand, Pcomp, 62);
         if (Prand <= Pcomp) return phi;
     }
 }
@@ -2464,6 +2507,7 @@ static void scatter_resonance_stokes(const orc_sim *s, acc_t *A, rng_t *g, photo
     double phi = phi_rejection(g, p, S12 / S11), cosp = cos(phi), sinp = sin(phi);
     double xc = 0.0, xc2 = 0.0;
     if (s->core_skip) car_xcrit_local(s, p->icell, p->jcell, p->kcell, p->x, p->y, p->z, &xc, &xc2);
+    if (s->core_skip) MRG(fabs(p->xfreq), xc, 64);
     if (s->core_skip && fabs(p->xfreq) < xc) { double phi2 = TWOPI * rnd(g), uxy = sqrt(xc2 - log(rnd(g))); ux = uxy * cos(phi2); uy = uxy * sin(phi2); }
     else {                                                                            /* :413-414 two gaussians / sqrt2 */
         if (g->kind == 0) { ux = rand_gauss(g) * (1.0 / sqrt(2.0)); uy = rand_gauss(g) * (1.0 / sqrt(2.0)); }
@@ -2485,7 +2529,8 @@ static int dust_absorb(const orc_sim *s, acc_t *A, rng_t *g, photon_t *p) {
     p->nscatt_dust = p->nscatt_dust + p->wgt;
     size_t c = IDX(s,p->icell,p->jcell,p->kcell);
     if (!s->use_reduced_wgt) {
-        if (rnd(g) > s->albedo) {
+        const double ra_ = rnd(g); MRG(ra_, s->albedo, 61);
+        if (ra_ > s->albedo) {
             if (s->save_Jabs) { double uu1 = udot(s, c, p->kx, p->ky, p->kz), xr = (p->xfreq + uu1) * (s->Dfreq[c] / s->Dfreq_ref);
                 int ix = (int)floor((xr - s->xfreq_min) / s->dxfreq) + 1; if (ix >= 1 && ix <= s->nxfreq) A->Jabs[ix-1] += p->wgt; }
             if (s->save_all_photons) {                      /* scattering_car.f90:236-246, :525-535: lab-frame frequency at absorption, weight 0 */
@@ -2527,7 +2572,8 @@ static void scattering(const orc_sim *s, acc_t *A, rng_t *g, photon_t *p) {
         if (s->DGR > 0.0) {
             int64_t icl = p->icell_clump; const clumps_t *c = &s->cl;
             double p_dust = c->rhokapD[icl-1] / (c->rhokap[icl-1] * voigt_clump(s, p->xfreq, icl) + c->rhokapD[icl-1]);
-            if (rnd(g) <= p_dust) { if (s->use_stokes && s->nPDF > 0) scatter_dust_stokes(s, A, g, p); else scatter_dust_nostokes(s, A, g, p); return; }
+            const double rd_ = rnd(g); MRG(rd_, p_dust, 60);
+            if (rd_ <= p_dust) { if (s->use_stokes && s->nPDF > 0) scatter_dust_stokes(s, A, g, p); else scatter_dust_nostokes(s, A, g, p); return; }
         }
         if (s->cl.has_overlap) {                                  /* scatter_resonance_clump_{no,}stokes: scattering_car.f90:898-937 */
             const int64_t icl = p->icell_clump;
@@ -2542,7 +2588,8 @@ static void scattering(const orc_sim *s, acc_t *A, rng_t *g, photon_t *p) {
     if (s->DGR > 0.0) {
         size_t c = IDX(s,p->icell,p->jcell,p->kcell);
         double p_dust = s->rhokapD[c] / (s->rhokap[c] * calc_voigt(s, p->xfreq, s->voigt_a[c], s->Dfreq[c]) + s->rhokapD[c]);
-        if (rnd(g) <= p_dust) { if (s->use_stokes && s->nPDF > 0) scatter_dust_stokes(s, A, g, p); else scatter_dust_nostokes(s, A, g, p); return; }
+        const double rd_ = rnd(g); MRG(rd_, p_dust, 60);
+            if (rd_ <= p_dust) { if (s->use_stokes && s->nPDF > 0) scatter_dust_stokes(s, A, g, p); else scatter_dust_nostokes(s, A, g, p); return; }
     }
     if (s->use_stokes) scatter_resonance_stokes(s, A, g, p); else scatter_resonance_nostokes(s, A, g, p);
 }
@@ -2603,7 +2650,7 @@ static void generate_photon(const orc_sim *s, acc_t *A, rng_t *g, photon_t *p) {
                 p->xfreq = p->xfreq - s->ml.Elow_Hz[iup-1][idown-1] / Dfreq_local;
             }
         } else if (s->line_type == 6) {                     /* :216-242 */
-            double p1 = s->ml.f12[0], p2 = s->ml.f12[1], p3 = s->ml.f12[2], ptot = p1 + p2 + p3, pcum1 = p1 / ptot, pcum2 = (p1 + p2) / ptot, xi = rnd(g);
+            double p1 = s->ml.f12[0], p2 = s->ml.f12[1], p3 = s->ml.f12[2], ptot = p1 + p2 + p3, pcum1 = p1 / ptot, pcum2 = (p1 + p2) / ptot, xi = rnd(g); MRG(xi, pcum1, 63); MRG(xi, pcum2, 63);
             if (xi < pcum1) {} else if (xi < pcum2) p->xfreq = p->xfreq - s->ml.delE_Hz[1] / Dfreq_local; else p->xfreq = p->xfreq - s->ml.delE_Hz[2] / Dfreq_local;
         }
     }
@@ -2656,9 +2703,23 @@ static double allph_impact(const orc_sim *s, const photon_t *p, double *mx, doub
     *mx = xp - rk * p->kx; *my = yp - rk * p->ky; *mz = zp - rk * p->kz;
     return sqrt((*mx) * (*mx) + (*my) * (*my) + (*mz) * (*mz));
 }
+/* history probe (orc_trace): one record after the birth (kind 0), after every scattering (1) and when the packet has left or was absorbed (2):
+ * draws consumed, xfreq (xfreq_ref once outside), x, y, z, cell code (icell + 2^21 jcell + 2^42 kcell; the owner clump in clump media), kz,
+ * kind, and the smallest decision margin of the event with the id of that comparison (mrg_note) */
+#define ORC_TRACE_W 10
+static __thread double *g_tr = NULL; static __thread int g_tr_n = 0, g_tr_cap = 0;
+static inline void trace_rec(const orc_sim *s, const rng_t *g, const photon_t *p, int kind) {
+    if (!g_tr) return;
+    if (g_tr_n < g_tr_cap) { double *r = g_tr + (size_t)g_tr_n * ORC_TRACE_W;
+        r[0] = (double)g->n; r[1] = p->inside ? p->xfreq : p->xfreq_ref; r[2] = p->x; r[3] = p->y; r[4] = p->z;
+        r[5] = s->use_clump_medium ? (double)p->icell_clump : (double)p->icell + 2097152.0 * (double)p->jcell + 4398046511104.0 * (double)p->kcell;
+        r[6] = p->kz; r[7] = (double)kind; r[8] = g_mrg; r[9] = (double)g_mrg_id; }
+    g_tr_n++; g_mrg = 1e300; g_mrg_id = 0;
+}
 static void run_photon(const orc_sim *s, acc_t *A, rng_t *g, photon_t *p, int64_t k) {
     A->g = g;
     generate_photon(s, A, g, p);
+    trace_rec(s, g, p, 0);
     const int64_t n = s->log_n; double *R = s->save_all_photons ? s->allph : NULL;
     if (R) { R[1 * n + k] = p->xfreq; if (s->source_geometry != 0) { double mx, my, mz; R[9 * n + k] = allph_impact(s, p, &mx, &my, &mz); } }
     int first = 1; double tau, tau0, wgt1;
@@ -2673,6 +2734,7 @@ static void run_photon(const orc_sim *s, acc_t *A, rng_t *g, photon_t *p, int64_
         } else tau = -log(rnd(g));
         raytrace_to_tau(s, A, p, tau, s->raytrace_variant);
         if (p->inside) scattering(s, A, g, p);
+        trace_rec(s, g, p, p->inside ? 1 : 2);
     }
     A->nscatt_gas += p->nscatt_gas; A->nscatt_dust += p->nscatt_dust;
     if (R) { double mx, my, mz, mm = allph_impact(s, p, &mx, &my, &mz), cos2p = 1.0, sin2p = 0.0;
@@ -2743,6 +2805,25 @@ int orc_run(orc_sim *s, int64_t first_id, int64_t stride, int64_t count, int rng
     free(accs);
     s->nphotons_done += count;
     return 0;
+}
+/* the history of ONE photon on the counter-based stream (seed, id), with the tallies going into a scratch accumulator that is
+ * thrown away: out[ORC_TRACE_W * cap]; returns the number of records the history has (those beyond cap are not stored) */
+int64_t orc_trace(orc_sim *s, uint64_t seed, uint64_t id, int64_t cap, double *out) {
+    acc_t A; rng_t g; photon_t p;
+    double *ln = s->log_nscatt, *lx = s->log_xfreq, *al = s->allph; int64_t lnn = s->log_n;
+    double one[2] = {0.0, 0.0}; s->log_nscatt = one; s->log_xfreq = one + 1; s->log_n = 1; s->allph = NULL;
+    const int sap = s->save_all_photons; s->save_all_photons = 0;
+    acc_alloc(&A, s);
+    memset(&p, 0, sizeof p); p.id = (double)id; rng_philox(&g, seed, id, 0);
+    g_tr = out; g_tr_n = 0; g_tr_cap = (int)cap; g_mrg_on = 1; g_mrg = 1e300; g_mrg_id = 0;
+    run_photon(s, &A, &g, &p, 0);
+    const int64_t n = g_tr_n;
+    g_tr = NULL; g_tr_n = 0; g_tr_cap = 0; g_mrg_on = 0;
+    /* discard the scratch tallies (acc_merge_free would add them): free what acc_alloc allocated */
+    for (int i = 0; i < s->nobs; i++) free_obs(&A.obs[i]);
+    free(A.Jout); free(A.Jin); free(A.Jabs); free(A.Jmu); free(A.J1); free(A.P1); free(A.P1_new);
+    s->log_nscatt = ln; s->log_xfreq = lx; s->log_n = lnn; s->allph = al; s->save_all_photons = sap;
+    return n;
 }
 int64_t orc_get_photon_log(const orc_sim *s, double *nscatt, double *xfreq_out, int64_t n) {
     int64_t m = s->log_n < n ? s->log_n : n;
@@ -2904,6 +2985,16 @@ static void unpack(const double r[8], const int ic[4], photon_t *p) {
 static void unpack_s(const orc_sim *s, const double r[8], const int ic[4], photon_t *p) {
     unpack(r, ic, p);
     if (s->use_clump_medium) { p->icell_clump = ic[0]; p->icell = p->jcell = p->kcell = 1; }
+}
+/* the shearing-box march (variant 8) with photon%vfy_shear in / out */
+void orc_raytrace_to_tau_shear(orc_sim *s, double r[8], int ic[4], double tau_in, double *shear) {
+    photon_t p; unpack_s(s, r, ic, &p); acc_t A; acc_alloc(&A, s);
+    p.vfy_shear = *shear;
+    raytrace_to_tau(s, &A, &p, tau_in, 8);
+    acc_merge_free(&A, s);
+    *shear = p.vfy_shear;
+    r[0] = p.x; r[1] = p.y; r[2] = p.z; r[3] = p.kx; r[4] = p.ky; r[5] = p.kz; r[6] = p.xfreq; r[7] = p.wgt;
+    ic[0] = p.icell; ic[1] = p.jcell; ic[2] = p.kcell; ic[3] = p.inside;
 }
 void orc_raytrace_to_tau(orc_sim *s, int variant, double r[8], int ic[4], double tau_in) {
     photon_t p; unpack_s(s, r, ic, &p); acc_t A; acc_alloc(&A, s);

@@ -51,6 +51,9 @@ int     orc_normalized_Jout(const orc_sim *, double *out, int n);
 
 /* per-photon record of the last orc_run (count entries, indexed k): nscatt, xfreq_ref at exit, flag */
 int64_t orc_get_photon_log(const orc_sim *, double *nscatt, double *xfreq_out, int64_t n);
+/* history probe of the divergence audit: 10 doubles per record (birth, every event): draws consumed, xfreq, x, y, z, cell code, kz, kind,
+ * smallest decision margin of the event, id of that comparison; counter-based stream (seed, id); tallies are not touched */
+int64_t orc_trace(orc_sim *, uint64_t seed, uint64_t id, int64_t cap, double *out);
 
 /* ---- function-level entry points (pinned against oracle/_ref, and used to check device functions) ---- */
 double orc_voigt(double x, double a);                                   /* voigt_mod.f90:541-733 */
@@ -87,6 +90,7 @@ double orc_xcrit_local(const orc_sim *, int i, int j, int k, double x, double y,
 /* one full scattering event from a given photon state (for GPU device-function parity):
  * st = [x,y,z,kx,ky,kz,xfreq,wgt, mx,my,mz,nx,ny,nz, I,Q,U,V], ic as above; Philox stream (seed,id) from draw n0;
  * returns draws consumed */
+void orc_raytrace_to_tau_shear(orc_sim *, double r[8], int ic[4], double tau_in, double *shear);   /* raytrace_to_tau_car_xyper_shear, vfy_shear in / out */
 int64_t orc_scatter_event(orc_sim *, double st[18], int ic[4], uint64_t seed, uint64_t id, uint64_t n0);
 #ifdef __cplusplus
 }

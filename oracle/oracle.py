@@ -54,6 +54,7 @@ class Oracle:
             L.orc_set_array.restype = _i64; L.orc_set_array.argtypes = [_vp, C.c_char_p, _vp, _i64]
             L.orc_normalized_Jout.argtypes = [_vp, _vp, _i]
             L.orc_get_photon_log.restype = _i64; L.orc_get_photon_log.argtypes = [_vp, _vp, _vp, _i64]
+            L.orc_trace.restype = _i64; L.orc_trace.argtypes = [_vp, _u64, _u64, _i64, _vp]
             L.orc_voigt.restype = _d; L.orc_voigt.argtypes = [_d, _d]
             L.orc_voigt_v.argtypes = [_i, _vp, _vp, _vp]
             L.orc_line_constants.argtypes = [_vp] * 5
@@ -66,6 +67,7 @@ class Oracle:
             L.orc_philox4x32_10.argtypes = [_vp, _vp, _vp]
             L.orc_raytrace_to_tau.argtypes = [_vp, _i, _vp, _vp, _d]
             L.orc_raytrace_to_edge.argtypes = [_vp, _i, _vp, _vp, _vp]
+            L.orc_raytrace_to_tau_shear.argtypes = [_vp, _vp, _vp, _d, _vp]
             L.orc_raytrace_to_dist.argtypes = [_vp, _vp, _vp, _d, _vp]
             L.orc_amr_find_leaf.argtypes = [_vp, _d, _d, _d]
             L.orc_xcrit_local.restype = _d; L.orc_xcrit_local.argtypes = [_vp, _i, _i, _i, _d, _d, _d]
@@ -136,6 +138,12 @@ class Oracle:
         L = self.lib(); n = L.orc_get_photon_log(self.h, None, None, 0)
         a, b = np.zeros(n), np.zeros(n); L.orc_get_photon_log(self.h, _ptr(a), _ptr(b), n); return a, b
 
+    def trace(self, seed, pid, cap):
+        """history of one photon on the Philox stream (seed, pid): (records[n, 10], n_total) -- draws consumed, xfreq, x, y, z, cell code, kz,
+        kind (0 birth, 1 scattered, 2 left / absorbed), smallest decision margin of the event, id of that comparison"""
+        out = np.zeros((int(cap), 10)); n = self.lib().orc_trace(self.h, int(seed), int(pid), int(cap), _ptr(out))
+        return out[:min(n, cap)], int(n)
+
     def xfreq_axis(self):
         n = int(self.scalar("nxfreq"))
         return (np.arange(n) + 0.5) * self.scalar("dxfreq") + self.scalar("xfreq_min")
@@ -143,6 +151,10 @@ class Oracle:
     def raytrace_to_tau(self, variant, r, ic, tau):
         r = np.array(r, dtype=np.float64); ic = np.array(ic, dtype=np.int32)
         self.lib().orc_raytrace_to_tau(self.h, variant, _ptr(r), _ptr(ic), tau); return r, ic
+
+    def raytrace_to_tau_shear(self, r, ic, tau, shear=0.0):
+        r = np.array(r, dtype=np.float64); ic = np.array(ic, dtype=np.int32); sh = _d(shear)
+        self.lib().orc_raytrace_to_tau_shear(self.h, _ptr(r), _ptr(ic), tau, C.byref(sh)); return r, ic, sh.value
 
     def raytrace_to_edge(self, variant, r, ic):
         r = np.array(r, dtype=np.float64); ic = np.array(ic, dtype=np.int32); t = _d()
@@ -250,6 +262,16 @@ class Ref:
             L.ref_raytrace_to_edge.argtypes = [_i, _vp, _vp, _vp]
             L.ref_raytrace_to_dist.argtypes = [_vp, _vp, _d, _vp]
             L.ref_get_Jout.argtypes = [_vp]
+            if hasattr(L, "ref_raytrace_to_tau_shear"):
+                L.ref_raytrace_to_tau_shear.argtypes = [_vp, _vp, _d, _d, _vp]
+                L.ref_do_resonance8_v.argtypes = [_i, _d, _i, _i, _i, _vp]
+                L.ref_set_band2.argtypes = [_d, _d, _i, _d]
+                L.ref_raytrace_to_tau_band.argtypes = [_i, _vp, _vp, _d]
+                L.ref_raytrace_to_edge_dust_Ha.argtypes = [_vp, _vp, _vp]
+                L.ref_get_band2.argtypes = [_vp, _vp]
+                L.ref_h2_init.argtypes = [C.c_char_p, _d, _d, _i, _i, _d, _vp]
+                L.ref_h2_kappa_v.argtypes = [_i, _vp, _d, _vp]
+                L.ref_h2_select_v.argtypes = [_i, _vp, _d, _vp]
             if hasattr(L, "ref_set_deuterium"):
                 L.ref_set_deuterium.argtypes = [_i, _d, _vp]
                 L.ref_do_resonance_HD_v.argtypes = [_i, _d, _i, _i, _i, _vp]
@@ -306,6 +328,11 @@ class Ref:
     def raytrace_to_edge(cls, variant, r, ic):
         r = np.array(r, dtype=np.float64); ic = np.array(ic, dtype=np.int32); t = _d()
         cls.lib().ref_raytrace_to_edge(variant, _ptr(r), _ptr(ic), C.byref(t)); return t.value
+
+    @classmethod
+    def raytrace_to_tau_shear(cls, r, ic, tau, Omega, shear=0.0):
+        r = np.array(r, dtype=np.float64); ic = np.array(ic, dtype=np.int32); sh = _d(shear)
+        cls.lib().ref_raytrace_to_tau_shear(_ptr(r), _ptr(ic), tau, Omega, C.byref(sh)); return r, ic, sh.value
 
     @classmethod
     def raytrace_to_dist(cls, r, ic, dist):

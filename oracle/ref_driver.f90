@@ -445,6 +445,133 @@ contains
     call pack(ph, r, ic)
   end subroutine ref_raytrace_to_tau
 
+  !--- raytrace_to_tau_car_xyper_shear (:2677-2954): the xy-periodic march with the shearing x boundary; Omega = par%Omega as grid_create
+  !--- leaves it (the change of vfy per x wrap, thermal units); shear = photon%vfy_shear in / out
+  subroutine ref_raytrace_to_tau_shear(r, ic, tau_in, Omega, shear) bind(C, name='ref_raytrace_to_tau_shear')
+    real(c_double), intent(inout) :: r(8)
+    integer(c_int), intent(inout) :: ic(4)
+    real(c_double), value :: tau_in, Omega
+    real(c_double), intent(inout) :: shear
+    type(photon_type) :: ph
+    call unpack(r, ic, ph)
+    par%Omega = Omega
+    ph%vfy_shear = shear
+    call raytrace_to_tau_car_xyper_shear(ph, g, tau_in)
+    shear = ph%vfy_shear
+    call pack(ph, r, ic)
+  end subroutine ref_raytrace_to_tau_shear
+
+  !--- line type 8 ('ly_beta', line_mod.f90:1192-1240): do_resonance8 (:293-345); out(:,i) = uz, xatom, cost, sint, E1, E2, E3, iband
+  subroutine ref_do_resonance8_v(n, xfreq, ic, jc, kc, out) bind(C, name='ref_do_resonance8_v')
+    integer(c_int), value :: n, ic, jc, kc
+    real(c_double), value :: xfreq
+    real(c_double), intent(out) :: out(8, n)
+    type(photon_type) :: ph
+    integer :: i
+    do i = 1, n
+       ph%xfreq = xfreq; ph%iband = 1
+       ph%icell = ic; ph%jcell = jc; ph%kcell = kc
+       call do_resonance8(ph, g, out(1,i), out(2,i), out(3,i), out(4,i))
+       out(5,i) = ph%E1; out(6,i) = ph%E2; out(7,i) = ph%E3; out(8,i) = ph%iband
+    enddo
+  end subroutine ref_do_resonance8_v
+
+  !--- band 2 of line type 8: the H-alpha spectral axis and dust ratio the marches read (grid%xfreq_min_Ha, dxfreq_Ha, nxfreq_Ha, par%R_Ha)
+  subroutine ref_set_band2(xfreq_min_Ha, dxfreq_Ha, nxfreq_Ha, R_Ha) bind(C, name='ref_set_band2')
+    real(c_double), value :: xfreq_min_Ha, dxfreq_Ha, R_Ha
+    integer(c_int), value :: nxfreq_Ha
+    g%xfreq_min_Ha = xfreq_min_Ha; g%dxfreq_Ha = dxfreq_Ha; g%nxfreq_Ha = nxfreq_Ha
+    g%xfreq_max_Ha = xfreq_min_Ha + nxfreq_Ha*dxfreq_Ha
+    par%R_Ha = R_Ha
+    if (associated(g%Jout_Ha)) deallocate(g%Jout_Ha)
+    allocate(g%Jout_Ha(nxfreq_Ha)); g%Jout_Ha = 0.0_wp
+    par%W_esc1 = 0.0_wp; par%W_esc2 = 0.0_wp
+  end subroutine ref_set_band2
+
+  !--- raytrace_to_tau_car (:1425-1648) with photon%iband given (2: dust-only opacity rhokapD R_Ha, lab-frame frequency, Jout_Ha / W_esc2)
+  subroutine ref_raytrace_to_tau_band(iband, r, ic, tau_in) bind(C, name='ref_raytrace_to_tau_band')
+    integer(c_int), value :: iband
+    real(c_double), intent(inout) :: r(8)
+    integer(c_int), intent(inout) :: ic(4)
+    real(c_double), value :: tau_in
+    type(photon_type) :: ph
+    call unpack(r, ic, ph)
+    ph%iband = iband
+    call raytrace_to_tau_car(ph, g, tau_in)
+    call pack(ph, r, ic)
+    if (.not. ph%inside) r(7) = ph%xfreq_ref
+  end subroutine ref_raytrace_to_tau_band
+
+  !--- raytrace_to_edge_car_dust_Ha (:510-582)
+  subroutine ref_raytrace_to_edge_dust_Ha(r, ic, tau) bind(C, name='ref_raytrace_to_edge_dust_Ha')
+    real(c_double), intent(in) :: r(8)
+    integer(c_int), intent(in) :: ic(4)
+    real(c_double), intent(out) :: tau
+    type(photon_type) :: ph
+    call unpack(r, ic, ph)
+    ph%iband = 2
+    call raytrace_to_edge_car_dust_Ha(ph, g, tau)
+  end subroutine ref_raytrace_to_edge_dust_Ha
+
+  subroutine ref_get_band2(Jout_Ha, W) bind(C, name='ref_get_band2')
+    real(c_double), intent(out) :: Jout_Ha(g%nxfreq_Ha), W(2)
+    Jout_Ha = g%Jout_Ha; W = [par%W_esc1, par%W_esc2]
+  end subroutine ref_get_band2
+
+  !--- H2 lines next to Ly-alpha (h2_mod.f90): h2_init with par%h2_model = 'neufeld' reads <data_dir>/energy_X.dat; T_h2 < 0 switches the lines off.
+  !--- out = n_h2_lines, h2_Dfreq_Hz, then per line dnu_Hz, strength, a_damp, p_scat, pop, f_osc
+  subroutine ref_h2_init(data_dir, T_h2, f_H2, hi_width, pure_absorption, bturb, out) bind(C, name='ref_h2_init')
+    use h2_mod
+    character(kind=c_char), intent(in) :: data_dir(*)
+    real(c_double), value :: T_h2, f_H2, bturb
+    integer(c_int), value :: hi_width, pure_absorption
+    real(c_double), intent(out) :: out(26)
+    character(len=256) :: dir
+    integer :: i
+    dir = ''
+    do i = 1, len(dir)
+       if (data_dir(i) == c_null_char) exit
+       dir(i:i) = data_dir(i)
+    enddo
+    out = 0.0_c_double
+    if (T_h2 < 0.0_wp) then
+       par%h2_model = 'none'; call h2_init(trim(dir)); return
+    endif
+    par%h2_model = 'neufeld'; par%h2_temperature = T_h2; par%f_H2 = f_H2
+    par%h2_hi_width = (hi_width /= 0); par%h2_pure_absorption = (pure_absorption /= 0); par%bturb = bturb
+    call h2_init(trim(dir))
+    out(1) = n_h2_lines; out(2) = h2_Dfreq_Hz
+    do i = 1, n_h2_lines
+       out(2+(i-1)*6+1) = h2l(i)%dnu_Hz; out(2+(i-1)*6+2) = h2l(i)%strength; out(2+(i-1)*6+3) = h2l(i)%a_damp
+       out(2+(i-1)*6+4) = h2l(i)%p_scat; out(2+(i-1)*6+5) = h2l(i)%pop; out(2+(i-1)*6+6) = h2l(i)%f_osc
+    enddo
+  end subroutine ref_h2_init
+
+  !--- h2_kappa_D (:58-78) and h2_select_line_D (:81-115; consumes one random number per call)
+  subroutine ref_h2_kappa_v(n, x, Dfreq, kap) bind(C, name='ref_h2_kappa_v')
+    use h2_mod
+    integer(c_int), value :: n
+    real(c_double), value :: Dfreq
+    real(c_double), intent(in) :: x(n)
+    real(c_double), intent(out) :: kap(n)
+    integer :: i
+    do i = 1, n
+       kap(i) = h2_kappa_D(x(i), Dfreq)
+    enddo
+  end subroutine ref_h2_kappa_v
+
+  subroutine ref_h2_select_v(n, x, Dfreq, il) bind(C, name='ref_h2_select_v')
+    use h2_mod
+    integer(c_int), value :: n
+    real(c_double), value :: Dfreq
+    real(c_double), intent(in) :: x(n)
+    integer(c_int), intent(out) :: il(n)
+    integer :: i
+    do i = 1, n
+       il(i) = h2_select_line_D(x(i), Dfreq)
+    enddo
+  end subroutine ref_h2_select_v
+
   !--- variant: 0 = raytrace_to_edge_car (:410), 1 = _car_xyzsym (:584), 2 = _car_zonly (:1138), 5 = _car_xysym (:783), 6 = _car_xyper (:971)
   subroutine ref_raytrace_to_edge(variant, r, ic, tau) bind(C, name='ref_raytrace_to_edge')
     integer(c_int), value :: variant

@@ -14,6 +14,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "slow: longer oracle statistics run")
 
 
+def pytest_collection_modifyitems(config, items):
+    """device tests that are marked `slow` as well (the property-only sweep over all shipped parameter sets) only run when asked for:
+    pytest -m "gpu and slow", or LART_RUN_SLOW=1 -- the default device suite has to stay within the driver's time limit"""
+    if "slow" in (config.getoption("-m") or "") or os.environ.get("LART_RUN_SLOW"):
+        return
+    skip = pytest.mark.skip(reason="slow device sweep: run with -m 'gpu and slow' or LART_RUN_SLOW=1")
+    for it in items:
+        if "slow" in it.keywords and "gpu" in it.keywords:
+            it.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def oracle_mod():
     from oracle import oracle as O
@@ -47,3 +58,30 @@ def rms_diff(a, b):
     """spectrum rms-diff as BASELINE.json's metric defines it: sqrt(mean((a-b)^2)) / max(b)"""
     a, b = np.asarray(a, float), np.asarray(b, float)
     return float(np.sqrt(np.mean((a - b) ** 2)) / np.max(b))
+
+
+def run_together(jobs, events=4096):
+    """several simulations on one GPU at once: jobs = [(sim, nphotons, seed), ...]; every context has its own HIP stream and is driven by
+    its own host thread (the C-ABI calls release the GIL; the library keeps no state outside its contexts), so the drain tails (the longest
+    history of each job runs alone on a wave) overlap instead of adding up.  Same photon ids, same streams, same results as
+    sim.run_simulation(n, seed=seed) one after the other."""
+    import threading
+    errors = []
+
+    def drive(sim, n, seed):
+        try:
+            sim.ctx.begin(int(n), first_id=1, stride=1, seed=int(seed)); sim.nphotons_run = int(n)
+            while True:
+                sim.ctx.step(1, events)
+                if sim.ctx.sync()[1] == 0:
+                    break
+        except Exception as e:                               # noqa: BLE001 -- re-raised in the caller's thread
+            errors.append(e)
+
+    threads = [threading.Thread(target=drive, args=j) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]

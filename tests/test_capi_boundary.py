@@ -31,12 +31,14 @@ def test_library_exports_every_declared_symbol(built):
 def test_struct_layout_matches_header(built, tmp_path):
     src = tmp_path / "sz.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "lart_gpu.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(lart_params), '
-                   'offsetof(lart_params, xs_point), offsetof(lart_params, xcrit2), sizeof(lart_tallies), offsetof(lart_tallies, nphotons_done));return 0;}')
+                   'offsetof(lart_params, xs_point), offsetof(lart_params, xcrit2), sizeof(lart_tallies), offsetof(lart_tallies, nphotons_done));'
+                   'printf("%zu %zu %zu %zu\\n", offsetof(lart_params, Omega), offsetof(lart_params, E_conv), offsetof(lart_params, h2_p_scat), offsetof(lart_tallies, aux));return 0;}')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     sz = [int(t) for t in subprocess.check_output([str(exe)]).split()]
     P, T = built.LartParams, built.LartTallies
-    assert sz == [ctypes.sizeof(P), P.xs_point.offset, P.xcrit2.offset, ctypes.sizeof(T), T.nphotons_done.offset]
+    assert sz == [ctypes.sizeof(P), P.xs_point.offset, P.xcrit2.offset, ctypes.sizeof(T), T.nphotons_done.offset,
+                  P.Omega.offset, P.E_conv.offset, P.h2_p_scat.offset, T.aux.offset]
 
 
 def test_no_device_fails_loudly(built):

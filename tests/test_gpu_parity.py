@@ -100,6 +100,52 @@ def test_ray_marches_device_vs_reference_vectors(capi, golden, name):
     assert np.allclose(sim.ctx.tallies()["Jout"], z["Jout"], rtol=0, atol=1e-12)
 
 
+def test_shearing_box_march_device_vs_reference_vectors(capi, golden):
+    """raytrace_to_tau_car_xyper_shear (raytrace_car.f90:2677-2954, chosen at setup.f90:967-969 for par%Omega /= 0 in an xy-periodic box):
+    vectors from the reference's own compiled routine; photon%vfy_shear in and out (exact: it counts the x wraps), cells exact; the edge
+    march of this configuration is the plain raytrace_to_edge_car"""
+    from lart_amd import host
+    z = golden("raytrace_shear.npz")
+    kw = dict(tok.split("=") for tok in str(z["params"]).split())
+    par = host.Params()
+    for k, v in kw.items():
+        host.set_param(par, k, host._parse_value(v) if k != "geometry" else v)
+    sim = host.Simulation(par)
+    assert sim.cpar.Omega == float(z["Omega"])
+    g = sim.grid
+    sim.ctx.set_grid_car(g.nx, g.ny, g.nz, g.xmin, g.ymin, g.zmin, g.dx, g.dy, g.dz, g.i0, g.j0, g.k0, g.xface, g.yface, g.zface,
+                         z["rhokap"], z["voigt_a"], z["Dfreq"], z["vfx"], z["vfy"], z["vfz"], z["rhokapD"])
+    sim.ctx.zero_tallies()
+    r, ic, sh = sim.ctx.test_raytrace(0, 8, z["r_in"], z["ic_in"], z["tau_in"], shear=z["shear_in"])
+    assert np.array_equal(ic, z["ic_out"]) and np.array_equal(sh, z["shear_out"])
+    assert np.allclose(r, z["r_out"], rtol=1e-10, atol=1e-12)
+    _, _, te = sim.ctx.test_raytrace(1, 8, z["r_in"], z["ic_in"])
+    assert np.allclose(te, z["tau_edge"], rtol=1e-10, atol=1e-300)
+    assert np.allclose(sim.ctx.tallies()["Jout"], z["Jout"], rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("extra,n", [(dict(Omega=2.5), 30000), (dict(Omega=-1.3, use_stokes=True, recoil=True, velocity_type="parallel_velocity", Vy=40.0), 30000),
+                                     (dict(Omega=0.8, DGR=1.0, cext_dust=3e-19, nxim=8, nyim=8, save_peeloff_2D=True), 20000)])
+def test_shearing_box_histories_photon_by_photon(capi, oracle_mod, extra, n):
+    """the shearing box inside whole histories (flights wrap around x several times at tau0 = 5 across the box), against the oracle on the same
+    streams; with an observer the peel rays and the first-flight escape use the plain edge march, as the reference's pointers stand"""
+    kw = dict(dict(temperature=1e4, taumax=5.0, nx=6, ny=4, nz=21, xmax=0.5, ymax=0.3, zmax=1.0, geometry="rectangle", xy_periodic=True, nxfreq=101,
+                   xfreq_min=-40.0, xfreq_max=40.0, iseed=47), **extra)
+    sim = make(kw); sim.ctx.enable_photon_log(True); sim.run_simulation(n); t = sim.ctx.tallies()
+    o = oracle_of(oracle_mod, kw); o.run(n, seed=kw["iseed"])
+    assert int(o.scalar("raytrace_variant")) == 8
+    ng, xg = sim.ctx.photon_log(n); no, xo = o.photon_log()
+    same = np.isclose(ng, no, rtol=1e-12, atol=0) & np.isclose(xg, xo, rtol=1e-7, atol=1e-9)
+    assert same.mean() > 0.97, same.mean()
+    assert t["nphotons_done"] == n and rms_diff(t["Jout"], o.array("Jout")) < 0.01
+    plain = make(dict(kw, Omega=0.0)); plain.ctx.enable_photon_log(True); plain.run_simulation(n)       # the shear matters: without it the spectrum is narrower
+    xp = plain.ctx.photon_log(n)[1]
+    assert np.std(xg) > 1.05 * np.std(xp)
+    if "nxim" in extra:
+        g2, o2 = t["scatt_2D"][..., 0], o.array("scatt_2D:0").reshape((8, 8), order="F")
+        assert abs(g2.sum() - o2.sum()) < 0.02 * o2.sum()
+
+
 @pytest.mark.parametrize("kw", [dict(temperature=1e4, taumax=1e3, nx=11, ny=11, nz=11, rmax=1.0),
                                 dict(temperature=1e4, taumax=1e3, nx=11, ny=11, nz=11, rmax=1.0, use_stokes=True, recoil=True),
                                 dict(temperature=10.0, taumax=1e5, nx=11, ny=11, nz=11, rmax=1.0, core_skip=True),

@@ -92,6 +92,52 @@ def test_rccl_reduce_entry_points_one_rank(capi):
         sim.ctx.reduce_tallies(0)                          # no communicator any more
 
 
+def test_reduce_twice_gives_the_same_totals(capi):
+    """output_reduce is idempotent (MPI_REDUCE has separate send and receive buffers, memory_mod_mpi.f90:377-393): the root receives into a buffer of
+    its own, this rank's sums stay as they are, and new events invalidate the received totals"""
+    sim = make(KW); sim.run_simulation(3000)
+    before = sim.ctx.tallies()
+    sim.ctx.comm_init(capi.comm_unique_id(), 1, 0)
+    for _ in range(3):
+        sim.ctx.reduce_tallies(0)
+        after = sim.ctx.tallies()
+        assert np.array_equal(before["Jout"], after["Jout"]) and before["nscatt_gas"] == after["nscatt_gas"] and after["nphotons_done"] == 3000
+    sim.run_simulation(2000, seed=99)                      # the context adds events: what get_tallies hands out is its own sums again
+    more = sim.ctx.tallies()
+    assert more["nphotons_done"] == 5000 and more["Jout"].sum() > before["Jout"].sum()
+    sim.ctx.reduce_tallies(0)
+    assert np.array_equal(sim.ctx.tallies()["Jout"], more["Jout"])
+    sim.ctx.comm_destroy()
+
+
+def test_a_larger_run_after_a_small_one_on_the_same_context(capi):
+    """the pool (and with it the slot lists of the lane compaction) is re-created when a later lart_gpu_begin asks for more lanes; every run
+    ends in a drain, so the compaction runs in both: the second run equals the same run on a fresh context"""
+    kw = dict(KW, taumax=300.0)
+    a = make(kw); a.ctx.enable_photon_log(True)
+    a.run_simulation(500, seed=3)
+    lanes_small = a.ctx.pool_info()[0]
+    a.ctx.zero_tallies(); a.run_simulation(50000, seed=4)
+    assert a.ctx.pool_info()[0] > lanes_small and a.ctx.live_lanes()[1] >= 1
+    b = make(kw); b.ctx.enable_photon_log(True); b.run_simulation(50000, seed=4)
+    assert np.array_equal(a.ctx.photon_log(50000)[0], b.ctx.photon_log(50000)[0])
+    assert np.allclose(a.ctx.tallies()["Jout"], b.ctx.tallies()["Jout"], rtol=0, atol=1e-9)
+
+
+def test_peel_deposit_list_holds_every_ray_of_a_thin_medium(capi):
+    """an optically thin medium with several observers and save_direc0: nearly every (record, observer) pair deposits, the case in which the
+    deposit list of the peel pass is fullest; lart_gpu_get_tallies would refuse the run if an entry had been dropped.  The image sums equal
+    those of a run with a small pool (many short slices), which fills the list in a different pattern"""
+    kw = dict(temperature=1e4, taumax=0.5, nx=11, ny=11, nz=11, rmax=1.0, nxfreq=41, nxim=8, nyim=8, save_peeloff_2D=True, save_direc0=True,
+              obsx=[1.0, 0.0, 0.0, -1.0], obsy=[0.0, 1.0, 0.0, 1.0], obsz=[0.0, 0.0, 1.0, 1.0], iseed=12)
+    a = make(kw); a.run_simulation(400000); ta = a.ctx.tallies()
+    b = make(kw); b.ctx.set_pool(16384, 256); b.run_simulation(400000); tb = b.ctx.tallies()
+    assert ta["nphotons_done"] == tb["nphotons_done"] == 400000
+    for k in ("scatt", "direc", "direc0"):
+        assert np.isclose(ta[k].sum(), tb[k].sum(), rtol=1e-9), k
+        assert ta[k].sum() > 0.0
+
+
 def test_run_multi_one_context_equals_run(capi):
     a = make(KW); a.ctx.enable_photon_log(True); capi.run_multi([a.ctx], 5000, 9)
     b = make(KW); b.ctx.enable_photon_log(True); b.run_simulation(5000, seed=9)

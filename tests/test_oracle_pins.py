@@ -74,6 +74,23 @@ def test_ray_marches_vs_reference(oracle_mod, golden, name):
     assert np.array_equal(o.array("Jout"), z["Jout"])            # escape tallies: same bins, same weights
 
 
+def test_shearing_box_march_vs_reference(oracle_mod, golden):
+    """raytrace_to_tau_car_xyper_shear (raytrace_car.f90:2677-2954): vectors from the reference's own compiled routine (tools/gen_golden_shear.py);
+    photon%vfy_shear goes in and comes out; the edge march of this configuration is the plain raytrace_to_edge_car (setup.f90:941, :967-969)"""
+    z = golden("raytrace_shear.npz")
+    o = oracle_mod.Oracle(str(z["params"]))
+    assert int(o.scalar("raytrace_variant")) == 8
+    for k in ("rhokap", "voigt_a", "Dfreq", "vfx", "vfy", "vfz", "rhokapD"):
+        o.set_array(k, z[k])
+    for r, ic, tau, sh0, r_ref, ic_ref, sh1, te in zip(z["r_in"], z["ic_in"], z["tau_in"], z["shear_in"], z["r_out"], z["ic_out"], z["shear_out"], z["tau_edge"]):
+        ro, ico, sho = o.raytrace_to_tau_shear(r, ic, float(tau), float(sh0))
+        assert np.array_equal(ico, ic_ref) and sho == sh1            # cells, inside flag and the number of x wraps: exact
+        assert np.allclose(ro, r_ref, rtol=1e-10, atol=1e-13)
+        assert np.isclose(o.raytrace_to_edge(8, r, ic), te, rtol=1e-10, atol=1e-300)
+    assert np.array_equal(o.array("Jout"), z["Jout"])
+    assert np.sum(z["shear_out"] != z["shear_in"]) > 300
+
+
 def test_alias_and_interp(oracle_mod, golden, mueller_file):
     z = golden("alias_mueller.npz")
     o = oracle_mod.Oracle("temperature=1e4 taumax=10 nx=5 ny=5 nz=5 rmax=1 DGR=1 use_stokes=1 scatt_mat_file=%s" % mueller_file)
