@@ -391,11 +391,22 @@ class Context:
                 out["P1"] = np.zeros(self.nbins)
             if self.jpa[2]:
                 out["P1_new"] = np.zeros(self.nbins)
+        if p.line_type == 8:                                               # band 2 (H-alpha): grid%Jout_Ha, grid%Jabs_Ha, observer%peel_Ha, the conversion-rate profile
+            out["Jout_Ha"] = np.zeros(p.nxfreq_Ha); out["Jabs_Ha"] = np.zeros(p.nxfreq_Ha)
+            if p.save_peeloff and self.nobs and p.save_peeloff_3D:
+                out["peel_Ha"] = np.zeros((p.nxfreq_Ha, self.nxim, self.nyim, self.nobs), order="F")
+            if self.nbins and self.jpa[1]:
+                out["Pconv"] = np.zeros(self.nbins)
         for k, a in out.items():
             setattr(t, k, a.ctypes.data)
         _chk(lib().lart_gpu_get_tallies(self.h, C.byref(t)))
         for k in ("nscatt_gas", "nscatt_dust", "n_events", "n_cellsteps", "n_cellsteps_peel", "n_atomics", "nphotons_done", "nphotons_active"):
             out[k] = getattr(t, k)
+        aux = [t.aux[i] for i in range(8)]
+        if p.line_type == 8:                                               # the weight budget of output_sum_rect.f90:452-467
+            out.update(W_conv=aux[0], W_esc1=aux[1], W_abs1=aux[2], W_esc2=aux[3], W_abs2=aux[4])
+        if p.h2_nlines > 0:                                                # :470-485
+            out.update(W_H2abs=aux[0], W_H2scat=aux[1], W_H2pump=np.array(aux[2:2 + p.h2_nlines]))
         return out
 
     # ---- device-function probes -------------------------------------------------------------

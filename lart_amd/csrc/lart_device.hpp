@@ -76,12 +76,16 @@ struct DTally {
     double *Jout, *Jin, *Jabs, *Jmu;
     double *c3[8];                // scatt, direc, I, Q, U, V, direc0 (par%save_direc0), scatt_dust (par%save_dust_scattered)   (nobs * nxfreq*nxim*nyim)
     double *c2[8];                // *_2D (no scatt_dust image)      (nobs * nxim*nyim)
+    double *Jout_Ha, *Jabs_Ha;    // line type 8: the band-2 (H-alpha) spectra grid%Jout_Ha, grid%Jabs_Ha (nxfreq_Ha)
+    double *peel_Ha;              // line type 8: observer(:)%peel_Ha (nobs * nxfreq_Ha*nxim*nyim)
 };
+// scalars 25..31 of the fused tally buffer: line type 8: W_conv, W_esc1, W_abs1, W_esc2, W_abs2 (define.f90:471-475); H2: W_H2abs, W_H2scat, W_H2pump(1..4)
+#define LART_SCAL_AUX 25
 
 // resident photon pool (SoA, coalesced load/store at launch boundaries)
 enum { F_X = 0, F_Y, F_Z, F_KX, F_KY, F_KZ, F_XFREQ, F_WGT, F_NSG, F_NSD,
        F_MX, F_MY, F_MZ, F_NX, F_NY, F_NZ, F_Q, F_U, F_V, F_SHEAR /* photon%vfy_shear, VAR 8 only */, F_COUNT };
-enum { FLAG_ALIVE = 1, FLAG_FIRST = 2 };
+enum { FLAG_ALIVE = 1, FLAG_FIRST = 2, FLAG_BAND2 = 4 };
 struct DPool {
     int64_t n;                    // lanes
     double *f;                    // F_COUNT planes of n doubles
@@ -94,7 +98,7 @@ struct DPool {
 // profile tallies; P1 / P1_new are accumulated per block in LDS when `lds_bins` > 0 and flushed once at kernel end
 // J1: the frequency bins [lds_j_lo, lds_j_lo + lds_j_w) around the line centre of every profile bin are accumulated per block in LDS too when they fit
 // (lds_j_w > 0): scattered f64 atomics run at the memory side at ~1e10 per second for the whole chip, which is what one deposit per event asks for
-struct DJPa { int calc_J, calc_P, calc_Pnew, nbins; const int *ind_bin; double cross0; double *J1, *P1, *P1_new; int lds_bins, lds_j_lo, lds_j_w; };
+struct DJPa { int calc_J, calc_P, calc_Pnew, nbins; const int *ind_bin; double cross0; double *J1, *P1, *P1_new; int lds_bins, lds_j_lo, lds_j_w; double *Pconv; };   // Pconv: add_to_Pconv (line type 8)
 // Copies of the contended tally sections (peel cubes and images, J1, P1, P1_new = the tail [off, off+len) of the fused buffer).
 // Workgroups are dispatched round-robin over the 8 XCDs, each with its own L2: same-address atomics from different XCDs meet
 // at the memory side and serialise there (measured: 70x slow-down of a 64-bin P_alpha profile).  Block b therefore adds into
@@ -430,6 +434,7 @@ struct Photon {
     double mx, my, mz, nx, ny, nz, Q, U, V;
     int ic, jc, kc; bool inside;
     int icl;                       // owner clump (VAR 4): 0 = vacuum (photon%icell_clump, define.f90:90)
+    int iband;                     // photon%iband (define.f90:96): 1 the line's band, 2 H-alpha after a Ly-beta conversion (line type 8); kept in FLAG_BAND2 between launches
     double shear;                  // photon%vfy_shear (define.f90:100): y velocity picked up at the shearing x boundary, in thermal units (VAR 8)
     double xfreq_ref;
 #ifdef LART_PROFILE
@@ -896,6 +901,14 @@ __device__ inline bool trav_cross(const DGrid &g, Trav &t, int idx) {
     t.tx = ax ? tt : t.tx; t.ty = ay ? tt : t.ty; t.tz = (!ax && !ay) ? tt : t.tz;
     return ok;
 }
+// h2_kappa_D (h2_mod.f90:58-78): the opacity of the H2 lines next to Ly-alpha as a multiplier of the H I opacity of a cell of Doppler width Dfreq.
+// The kernels of this case carry the pseudo line type 9 = line type 1 + H2 (lart_gpu.hip sets it when lart_params.h2_nlines > 0)
+__device__ inline double h2_kappa_D(const lart_params &par, const Lds &l, double xfreq, double Dfreq) {
+    double kap = 0.0;
+    const double ratio = par.h2_hi_width ? 1.0 : Dfreq / par.h2_Dfreq_Hz;
+    for (int il = 0; il < par.h2_nlines; il++) { const double dx = par.h2_dnu_Hz[il] / Dfreq, x_h2 = (xfreq - dx) * ratio; kap = kap + par.h2_strength[il] * ratio * voigt_H(l.vt, x_h2, par.h2_a_damp[il]); }
+    return kap;
+}
 __device__ inline int minloc3(double a, double b, double c) { int m = 1; double v = a; if (b < v) { m = 2; v = b; } if (c < v) m = 3; return m; }
 
 
@@ -1007,6 +1020,7 @@ __device__ inline void edge_step_amr(const KArgs &A, const Lds &l, bool dust, Ed
     int ic = a.icell_of_leaf[m.il - 1], iface;
     double t_exit = amr_cell_exit(a.geom[ic - 1], m.x, m.y, m.z, m.kx, m.ky, m.kz, iface);
     double rhokap = c->rhokap * calc_voigt(l, m.xfreq, c->voigt_a, c->Dfreq);
+    if (l.lt == 9 && m.dist < 0.0) rhokap = rhokap + c->rhokap * h2_kappa_D(A.par, l, m.xfreq, c->Dfreq);
     if (dust) rhokap = rhokap + c->rhokapD;
     nsteps++;
     if (m.dist >= 0.0 && m.d + t_exit >= m.dist) { m.tau = m.tau + (m.dist - m.d) * rhokap; m.live = false; return; }
@@ -1354,6 +1368,7 @@ __device__ inline void edge_step(const KArgs &A, const Lds &l, bool dust, EdgeMa
     if (VAR == 4) { edge_step_clump(A, l, dust, m, nsteps); return; }
     const DGrid &g = A.g; Trav &t = m.t;
     double rhokap = m.rk * calc_voigt(l, m.xfreq, m.va, m.Dold);
+    if (l.lt == 9 && m.dist < 0.0) rhokap = rhokap + m.rk * h2_kappa_D(A.par, l, m.xfreq, m.Dold);
     if (dust) rhokap = rhokap + m.rD;
     nsteps++;
     int idx = (VAR == 2) ? 3 : minloc3(t.tx, t.ty, t.tz);
@@ -1388,6 +1403,13 @@ __device__ inline void tally_escape(const lart_params &par, const DTally &T, con
     }
 }
 
+// a band-2 (H-alpha) packet leaves: its frequency is the lab-frame one in reference units already (raytrace_car.f90:1625-1636, raytrace_amr.f90:244-256)
+__device__ inline void tally_escape_Ha(const KArgs &A, Photon &p) {
+    p.xfreq_ref = p.xfreq;
+    const int ix = (int)floor((p.xfreq_ref - A.par.xfreq_min_Ha) / A.par.dxfreq_Ha) + 1;
+    if (ix >= 1 && ix <= A.par.nxfreq_Ha) atomicAdd(&A.t.Jout_Ha[ix - 1], p.wgt);
+    atomicAdd(&A.t.scal[LART_SCAL_AUX + 3], p.wgt);           // W_esc2
+}
 // add_to_J (raytrace_car.f90:3979-4011) + add_to_Pnew (:4015-4045): one path segment of length del in cell `ci`
 __device__ inline void jpa_segment(const KArgs &A, const Lds &l, const Photon &p, size_t ci, double rhokap_cell, double Dfreq_cell, double del, double dtauH) {
     if (!(rhokap_cell > 0.0)) return;
@@ -1412,12 +1434,17 @@ __device__ inline void raytrace_to_tau_amr(const KArgs &A, const Lds &l, bool du
 #ifndef LART_NO_FAST_FLIGHT
     {   // fast path: the flight ends clearly inside the leaf it starts in (see raytrace_to_tau): no exit-face solve (three divisions)
         const AmrGeom q = a.geom[a.icell_of_leaf[il - 1] - 1];
-        const double kapH0 = c->rhokap * calc_voigt(l, p.xfreq, c->voigt_a, c->Dfreq), kap0 = dust ? kapH0 + c->rhokapD : kapH0;
+        const bool b2 = l.lt == 8 && p.iband == 2;           // band 2 (H-alpha): dust only, scaled to 6563 A (raytrace_amr.f90:111-127)
+        const double kapH0 = b2 ? 0.0 : c->rhokap * calc_voigt(l, p.xfreq, c->voigt_a, c->Dfreq);
+        double kap0 = kapH0;
+        if (l.lt == 9) kap0 = kap0 + c->rhokap * h2_kappa_D(A.par, l, p.xfreq, c->Dfreq);
+        if (dust) kap0 = kap0 + c->rhokapD;
+        if (b2) kap0 = dust ? c->rhokapD * A.par.R_Ha : 0.0;
         if (kap0 > 0.0) {
             const double s = tau_in / kap0, xn = x + s * kx, yn = y + s * ky, zn = z + s * kz, h = q.ch * (1.0 - 1e-9);
             if (fabs(xn - q.cx) < h && fabs(yn - q.cy) < h && fabs(zn - q.cz) < h) {
                 nsteps++;
-                if (A.jpa.nbins) jpa_segment_amr(A, l, p, il, *c, x + 0.5 * s * kx, y + 0.5 * s * ky, z + 0.5 * s * kz, s, s * kapH0);
+                if (A.jpa.nbins && !b2) jpa_segment_amr(A, l, p, il, *c, x + 0.5 * s * kx, y + 0.5 * s * ky, z + 0.5 * s * kz, s, s * kapH0);
                 p.x = xn; p.y = yn; p.z = zn; p.ic = il; p.jc = 1; p.kc = 1;
                 return;
             }
@@ -1429,31 +1456,36 @@ __device__ inline void raytrace_to_tau_amr(const KArgs &A, const Lds &l, bool du
     for (;;) {
         int ic = a.icell_of_leaf[il - 1], iface;
         double t_exit = amr_cell_exit(a.geom[ic - 1], x, y, z, kx, ky, kz, iface);
-        double rhokapH = c->rhokap * calc_voigt(l, p.xfreq, c->voigt_a, c->Dfreq), rhokap = rhokapH;
+        const bool b2 = l.lt == 8 && p.iband == 2;
+        double rhokapH = b2 ? 0.0 : c->rhokap * calc_voigt(l, p.xfreq, c->voigt_a, c->Dfreq), rhokap = rhokapH;
+        if (l.lt == 9) rhokap = rhokap + c->rhokap * h2_kappa_D(A.par, l, p.xfreq, c->Dfreq);
         if (dust) rhokap = rhokap + c->rhokapD;
+        if (b2) rhokap = dust ? c->rhokapD * A.par.R_Ha : 0.0;
         nsteps++;
         if (tau + t_exit * rhokap >= tau_in) {
             double d_step = (rhokap > 0.0) ? (tau_in - tau) / rhokap : t_exit;
-            if (A.jpa.nbins) jpa_segment_amr(A, l, p, il, *c, x + 0.5 * d_step * kx, y + 0.5 * d_step * ky, z + 0.5 * d_step * kz, d_step, d_step * rhokapH);
+            if (A.jpa.nbins && !b2) jpa_segment_amr(A, l, p, il, *c, x + 0.5 * d_step * kx, y + 0.5 * d_step * ky, z + 0.5 * d_step * kz, d_step, d_step * rhokapH);
             x = x + d_step * kx; y = y + d_step * ky; z = z + d_step * kz;
             break;
         }
         tau = tau + t_exit * rhokap; x = x + t_exit * kx; y = y + t_exit * ky; z = z + t_exit * kz;
-        if (A.jpa.nbins) jpa_segment_amr(A, l, p, il, *c, x - 0.5 * t_exit * kx, y - 0.5 * t_exit * ky, z - 0.5 * t_exit * kz, t_exit, t_exit * rhokapH);
+        if (A.jpa.nbins && !b2) jpa_segment_amr(A, l, p, il, *c, x - 0.5 * t_exit * kx, y - 0.5 * t_exit * ky, z - 0.5 * t_exit * kz, t_exit, t_exit * rhokapH);
         int il_new = amr_next_leaf(a, ic, iface, x, y, z); bool reflected = false;
         if (il_new <= 0) { il_new = amr_boundary(A, il, iface, x, y, z, kx, ky, kz, reflected); if (++nbound > LART_AMR_MAX_WRAPS) il_new = 0; }
         if (il_new <= 0) { p.inside = false; break; }
         const Cell *cn = &A.g.cell[il_new - 1];
         double u2 = cn->vfx * kx + cn->vfy * ky + cn->vfz * kz;
-        p.xfreq = reflected ? (p.xfreq + u1) - u2 : (p.xfreq + u1) * c->Dfreq / cn->Dfreq - u2;
+        if (!b2) p.xfreq = reflected ? (p.xfreq + u1) - u2 : (p.xfreq + u1) * c->Dfreq / cn->Dfreq - u2;      // band 2 carries a lab-frame frequency
         u1 = u2; il = il_new; c = cn;
     }
     p.x = x; p.y = y; p.z = z; p.kx = kx; p.ky = ky; p.kz = kz; p.ic = il; p.jc = 1; p.kc = 1;
-    if (!p.inside) {
+    if (!p.inside && l.lt == 8 && p.iband == 2) tally_escape_Ha(A, p);
+    else if (!p.inside) {
         u1 = c->vfx * kx + c->vfy * ky + c->vfz * kz;
         p.xfreq = p.xfreq + u1;
         p.xfreq_ref = p.xfreq * (c->Dfreq / A.par.Dfreq_ref);
         tally_escape(A.par, A.t, p);
+        if (l.lt == 8) atomicAdd(&A.t.scal[LART_SCAL_AUX + 1], p.wgt);      // W_esc1
     }
 }
 
@@ -1474,8 +1506,11 @@ __device__ inline void raytrace_to_tau(const KArgs &A, const Lds &l, bool dust, 
         const size_t ci = cidx(g, p.ic, p.jc, p.kc);
         const Cell &c0 = g.cell[ci];
         const double rk0 = c0.rhokap, D0 = c0.Dfreq, vH0 = calc_voigt(l, p.xfreq, c0.voigt_a, D0);
+        const bool b2 = l.lt == 8 && p.iband == 2;           // band 2 (H-alpha): dust only, scaled to 6563 A (raytrace_car.f90:1495-1503)
         double kap0 = rk0 * vH0;
+        if (l.lt == 9) kap0 = kap0 + rk0 * h2_kappa_D(A.par, l, p.xfreq, D0);        // :1490-1493
         if (dust) kap0 = kap0 + c0.rhokapD;
+        if (b2) kap0 = dust ? c0.rhokapD * A.par.R_Ha : 0.0;
         if (kap0 > 0.0) {
             const double s = tau_in / kap0, xn = p.x + s * p.kx, yn = p.y + s * p.ky, zn = p.z + s * p.kz;
             const double ex = 1e-9 * g.dx, ey = 1e-9 * g.dy, ez = 1e-9 * g.dz;
@@ -1483,7 +1518,7 @@ __device__ inline void raytrace_to_tau(const KArgs &A, const Lds &l, bool dust, 
             if (VAR != 2) in = in && xn > l.xf[p.ic - 1] + ex && xn < l.xf[p.ic] - ex && yn > l.yf[p.jc - 1] + ey && yn < l.yf[p.jc] - ey;
             if (in) {
                 nsteps++;
-                if (A.jpa.nbins) jpa_segment(A, l, p, ci, rk0, D0, s, s * (rk0 * vH0));
+                if (A.jpa.nbins && !b2) jpa_segment(A, l, p, ci, rk0, D0, s, s * (rk0 * vH0));
                 p.x = xn; p.y = yn; p.z = zn;
                 return;
             }
@@ -1500,10 +1535,13 @@ __device__ inline void raytrace_to_tau(const KArgs &A, const Lds &l, bool dust, 
     if (VAR == 8) vy = vy + p.shear;                          // :2808-2809 the cell's y velocity + what the packet picked up at the shearing boundary
     double Dold = c->Dfreq, u1 = vx * t.kx + vy * t.ky + vz * t.kz;
     double del = 0.0, vH = 0.0;
+    const bool band2 = l.lt == 8 && p.iband == 2;
     for (;;) {
         vH = calc_voigt(l, p.xfreq, va, Dold);
         double rhokap = rk * vH;
+        if (l.lt == 9) rhokap = rhokap + rk * h2_kappa_D(A.par, l, p.xfreq, Dold);
         if (dust) rhokap = rhokap + rD;
+        if (band2) { vH = 0.0; rhokap = dust ? rD * A.par.R_Ha : 0.0; }
         nsteps++;
         int idx = (VAR == 2) ? 3 : minloc3(t.tx, t.ty, t.tz);
         double tt = idx == 1 ? t.tx : (idx == 2 ? t.ty : t.tz);
@@ -1519,21 +1557,24 @@ __device__ inline void raytrace_to_tau(const KArgs &A, const Lds &l, bool dust, 
             if (t.is < 0 && io == 1) p.shear = p.shear - A.par.Omega;
             if (t.is > 0 && io == g.nx) p.shear = p.shear + A.par.Omega;
         }
-        if (A.jpa.nbins) jpa_segment(A, l, p, cidx(g, io, jo, ko), rk, Dold, del, del * (rk * vH));      // add_to_J / add_to_Pnew :1579-1584
+        if (A.jpa.nbins && !band2) jpa_segment(A, l, p, cidx(g, io, jo, ko), rk, Dold, del, del * (rk * vH));      // add_to_J / add_to_Pnew :1579-1584
         c = &g.cell[cidx(g, t.ic, t.jc, t.kc)];
         vx = c->vfx; vy = c->vfy; vz = c->vfz;
         if (VAR == 8) vy = vy + p.shear;
         double Dn = c->Dfreq, u2 = vx * t.kx + vy * t.ky + vz * t.kz;
-        p.xfreq = (p.xfreq + u1) * Dold / Dn - u2;
+        if (!band2) p.xfreq = (p.xfreq + u1) * Dold / Dn - u2;
         Dold = Dn; u1 = u2; rk = c->rhokap; va = c->voigt_a; rD = c->rhokapD;
     }
-    if (A.jpa.nbins) jpa_segment(A, l, p, cidx(g, t.ic, t.jc, t.kc), rk, Dold, del, del * (rk * vH));          // last segment :1604-1609
+    if (A.jpa.nbins && !band2) jpa_segment(A, l, p, cidx(g, t.ic, t.jc, t.kc), rk, Dold, del, del * (rk * vH));          // last segment :1604-1609
+    if (!p.inside && band2) tally_escape_Ha(A, p);
+    else
     if (!p.inside) {                                          // :1613-1623 fluid frame -> lab frame, escape tally
         // (for VAR 1 the mirrored direction components of the last flight segment are used, :1918)
         u1 = vx * t.kx + vy * t.ky + vz * t.kz;
         p.xfreq = p.xfreq + u1;
         p.xfreq_ref = p.xfreq * (Dold / A.par.Dfreq_ref);
         tally_escape(A.par, A.t, p);
+        if (l.lt == 8) atomicAdd(&A.t.scal[LART_SCAL_AUX + 1], p.wgt);      // W_esc1 :1624
     }
     if (VAR == 1 || VAR == 5) {                               // :1935-1946 unfolded path, then fold back into the octant (xysym :2238-2248: x and y only)
         p.x = p.x + d * p.kx; p.y = p.y + d * p.ky; p.z = p.z + d * p.kz;
@@ -1916,6 +1957,85 @@ __device__ inline void peel_emit(const KArgs &A, const Lds &l, bool dust, int ki
 }
 
 // ---------------------------------------------------------------------------------------------
+// line type 8 ('ly_beta'), band 2 = H-alpha: the sight line is dust only and a band-2 packet only meets dust.  A history has one conversion
+// at most and a handful of band-2 dust events, so these peels march inside the transport kernel instead of going through the peel queue.
+// ---------------------------------------------------------------------------------------------
+// raytrace_to_edge_car_dust_Ha (raytrace_car.f90:510-582) / raytrace_to_edge_amr_dust_Ha (raytrace_amr.f90:353-390)
+template <int VAR>
+__device__ inline double edge_dust_Ha(const KArgs &A, const Lds &l, bool dust, const Photon &p, double kx, double ky, double kz, unsigned &nsteps) {
+    double tau = 0.0;
+    if (!dust) return tau;
+    if (VAR == 3) {
+        const DAmr &a = A.amr; double x = p.x, y = p.y, z = p.z; int il = p.ic;
+        if (il <= 0) { il = amr_find_leaf(a, x, y, z); if (il <= 0) return tau; }
+        for (;;) {
+            const int ic = a.icell_of_leaf[il - 1]; int iface;
+            const double t_exit = amr_cell_exit(a.geom[ic - 1], x, y, z, kx, ky, kz, iface);
+            nsteps++;
+            tau = tau + t_exit * (A.g.cell[il - 1].rhokapD * A.par.R_Ha);
+            if (tau >= LART_TAU_HUGE) return tau;
+            x = x + t_exit * kx; y = y + t_exit * ky; z = z + t_exit * kz;
+            const int il_new = amr_next_leaf(a, ic, iface, x, y, z);
+            if (il_new <= 0) return tau;
+            il = il_new;
+        }
+    }
+    const DGrid &g = A.g;
+    Trav t; t.kx = kx; t.ky = ky; t.kz = kz; t.ic = p.ic; t.jc = p.jc; t.kc = p.kc;
+    double xp = p.x, yp = p.y, d = 0.0;
+    if (trav_setup<0>(g, l, xp, yp, p.z, false, t)) return tau;
+    for (;;) {
+        const double rhokap = g.cell[cidx(g, t.ic, t.jc, t.kc)].rhokapD * A.par.R_Ha;
+        nsteps++;
+        const int idx = minloc3(t.tx, t.ty, t.tz);
+        const double tt = idx == 1 ? t.tx : (idx == 2 ? t.ty : t.tz);
+        tau = tau + (tt - d) * rhokap; d = tt;
+        if (!trav_cross<0>(g, t, idx)) break;
+        if (tau >= LART_TAU_HUGE) break;
+    }
+    return tau;
+}
+__device__ inline size_t pix3_Ha(const KArgs &A, int io, int ixf, int ix, int iy) {
+    return ((size_t)io * A.nxim * A.nyim + (size_t)(ix - 1) + (size_t)A.nxim * (size_t)(iy - 1)) * (size_t)A.par.nxfreq_Ha + (size_t)(ixf - 1);
+}
+// peeling_conversion_Ha_outside: peelingoff_rect.f90:692-792 (peelingoff_amr.f90 twin): the newborn H-alpha packet, emitted at line centre in the
+// atom frame; dipole phase function of the conversion channel (E1, E2); dust-only sight line; no recoil; into observer%peel_Ha
+template <int VAR>
+__device__ inline void peel_conversion_Ha(const KArgs &A, const Lds &l, bool dust, const Photon &p, const Cell &c, double ux, double uy, double uz, double E1, double E2, unsigned &nsteps, unsigned &natom) {
+    if (!A.t.peel_Ha) return;
+    for (int i = 0; i < A.nobs; i++) {
+        PeelDir q = peel_dir0(A, A.obs[i], p);
+        if (!q.in_image) continue;
+        peel_pixel(A, A.obs[i], q);
+        if (!q.in_image) continue;
+        const double cost = p.kx * q.kx + p.ky * q.ky + p.kz * q.kz, cost2 = cost * cost, sint = sqrt(1.0 - cost2), rho1 = sqrt(1.0 - p.kz * p.kz) * sint;
+        double cosp = 1.0, sinp = 0.0;
+        if (rho1 != 0.0) { const double rho = 1.0 / rho1; cosp = rho * (cost * p.kz - q.kz); sinp = rho * (p.kx * q.ky - q.kx * p.ky); }
+        const double xfreq = (ux * cosp + uy * sinp) * sint + uz * cost;
+        const double u1 = c.vfx * q.kx + c.vfy * q.ky + c.vfz * q.kz, xfreq_ref = (xfreq + u1) * (c.Dfreq / A.par.Dfreq_ref);
+        const int ixf = (int)floor((xfreq_ref - A.par.xfreq_min_Ha) / A.par.dxfreq_Ha) + 1;
+        const double tau = edge_dust_Ha<VAR>(A, l, dust, p, q.kx, q.ky, q.kz, nsteps);
+        const double peel = 0.75 * E1 * (cost2 + 1.0) + E2, wgt = peel / (LART_FOURPI * q.r2) * d_exp_neg(-tau) * p.wgt;
+        if (ixf >= 1 && ixf <= A.par.nxfreq_Ha) add_if(A.t.peel_Ha, pix3_Ha(A, i, ixf, q.ix, q.iy), wgt, natom);
+    }
+}
+// peeling_dust_Ha_outside: :794-870 (HG phase function of par%hgg_Ha; the packet's lab-frame frequency as it is)
+template <int VAR>
+__device__ inline void peel_dust_Ha(const KArgs &A, const Lds &l, bool dust, const Photon &p, unsigned &nsteps, unsigned &natom) {
+    if (!A.t.peel_Ha) return;
+    for (int i = 0; i < A.nobs; i++) {
+        PeelDir q = peel_dir0(A, A.obs[i], p);
+        if (!q.in_image) continue;
+        peel_pixel(A, A.obs[i], q);
+        if (!q.in_image) continue;
+        const int ixf = (int)floor((p.xfreq - A.par.xfreq_min_Ha) / A.par.dxfreq_Ha) + 1;
+        const double tau = edge_dust_Ha<VAR>(A, l, dust, p, q.kx, q.ky, q.kz, nsteps);
+        const double cosa = p.kx * q.kx + p.ky * q.ky + p.kz * q.kz, gg = A.par.hgg_Ha;
+        const double peel = (1.0 - gg * gg) / pow((1.0 + gg * gg) - 2.0 * gg * cosa, 1.5) / LART_FOURPI, wgt = peel / q.r2 * d_exp_neg(-tau) * p.wgt;
+        if (ixf >= 1 && ixf <= A.par.nxfreq_Ha) add_if(A.t.peel_Ha, pix3_Ha(A, i, ixf, q.ix, q.iy), wgt, natom);
+    }
+}
+// ---------------------------------------------------------------------------------------------
 // scattering: scattering_car.f90
 // ---------------------------------------------------------------------------------------------
 // closed-form rotation of k by (theta, phi) about the old k: :795-809
@@ -1954,6 +2074,7 @@ __device__ inline bool dust_absorb(const KArgs &A, Rng &g, Photon &p, const Cell
     double dep = 0.0; bool killed = false;
     if (!par.use_reduced_wgt) { if (g.next() > par.albedo) { dep = p.wgt; killed = true; } }
     else { dep = p.wgt * (1.0 - par.albedo); }
+    if (par.line_type == 8 && dep != 0.0) atomicAdd(&A.t.scal[LART_SCAL_AUX + 2], dep);      // W_abs1 (scattering_car.f90:524, :553)
     if (dep != 0.0 && par.save_Jabs) {
         double uu1 = c.vfx * p.kx + c.vfy * p.ky + c.vfz * p.kz;
         double xr = (p.xfreq + uu1) * (c.Dfreq / par.Dfreq_ref);
@@ -1977,7 +2098,7 @@ __device__ inline bool dust_absorb(const KArgs &A, Rng &g, Photon &p, const Cell
 //   scatter_pre  -> dust-or-gas decision; a dust event completes here; a resonance event returns true with the sampler's
 //                   arguments in ScatCtx (x in the local Doppler units of the cell / clump)
 //   scatter_post -> everything after do_resonance's `uz = rand_resonance_vz(x, a)`
-struct ScatCtx { double va, xloc, cl_scale, cl_Dfreq, xsamp, dnu, vsamp; int species, iup; };   // xsamp / vsamp: the sampler's frequency and Voigt parameter (2P1/2 level: xloc + dnu; deuterium, species 2: the D frame)
+struct ScatCtx { double va, xloc, cl_scale, cl_Dfreq, xsamp, dnu, vsamp; int species, iup, h2; };   // h2: 1-based H2 line of an H2 scattering (pseudo line type 9), 0 = an H I event;   // xsamp / vsamp: the sampler's frequency and Voigt parameter (2P1/2 level: xloc + dnu; deuterium, species 2: the D frame)
 template <int VAR, bool STOKES, bool DUST, bool PEEL>
 __device__ inline bool scatter_pre(const KArgs &A, const Lds &l, Rng &g, Photon &p, unsigned &npeel, ScatCtx &sc) {
     const lart_params &par = A.par;
@@ -1987,6 +2108,45 @@ __device__ inline bool scatter_pre(const KArgs &A, const Lds &l, Rng &g, Photon 
     // scale = Dfreq_ref / Dfreq_clump moves x into the clump's local Doppler units for the sampler and back
     double cl_scale = 1.0, cl_Dfreq = c.Dfreq, cl_rhokap = c.rhokap, cl_rhokapD = c.rhokapD;
     if (is_clump(VAR)) { const ClumpPhys ph = A.cl.phys[p.icl - 1]; va = ph.voigt_a; cl_Dfreq = ph.Dfreq; cl_rhokap = ph.rhokap; cl_rhokapD = ph.rhokapD; cl_scale = A.cl.Dfreq_ref / ph.Dfreq; }
+    sc.h2 = 0;
+    if (l.lt == 8 && p.iband == 2) {                          // scatter_dust_Ha_nostokes (scattering_car.f90:586-658; _amr scattering_amr.f90:147-209): every event of a band-2 packet is a dust event
+        p.nsd = p.nsd + p.wgt;
+        if (!par.use_reduced_wgt) {
+            if (g.next() > par.albedo_Ha) {
+                if (par.save_Jabs) { const int ix = (int)floor((p.xfreq - par.xfreq_min_Ha) / par.dxfreq_Ha) + 1; if (ix >= 1 && ix <= par.nxfreq_Ha) atomicAdd(&A.t.Jabs_Ha[ix - 1], p.wgt); }
+                p.inside = false; atomicAdd(&A.t.scal[LART_SCAL_AUX + 4], p.wgt);       // W_abs2
+                if (A.allph) { p.xfreq_ref = p.xfreq; p.wgt = 0.0; }
+                return false;
+            }
+        } else {
+            if (par.save_Jabs) { const int ix = (int)floor((p.xfreq - par.xfreq_min_Ha) / par.dxfreq_Ha) + 1; if (ix >= 1 && ix <= par.nxfreq_Ha) atomicAdd(&A.t.Jabs_Ha[ix - 1], p.wgt * (1.0 - par.albedo_Ha)); }
+            atomicAdd(&A.t.scal[LART_SCAL_AUX + 4], p.wgt * (1.0 - par.albedo_Ha));
+            p.wgt = p.wgt * par.albedo_Ha;
+        }
+        if (PEEL) { unsigned natom = 0; peel_dust_Ha<VAR>(A, l, DUST, p, npeel, natom); }
+        const double cost = rand_hg(g, par.hgg_Ha), sint = sqrt(1.0 - cost * cost);
+        double sinp, cosp; d_sincos_2pi(g.next(), &sinp, &cosp);
+        rotate_k(p, cost, sint, cosp, sinp);
+        return false;
+    }
+    if (l.lt == 9) {                                           // the H2 channel (scattering_car.f90:92-104, octree :44-57): three-way split H I / H2 / dust
+        const double kap_HI = c.rhokap * calc_voigt(l, p.xfreq, va, c.Dfreq), kap_H2 = c.rhokap * h2_kappa_D(par, l, p.xfreq, c.Dfreq), kap_D = DUST ? c.rhokapD : 0.0;
+        if (g.next() * (kap_HI + kap_H2 + kap_D) <= kap_H2) {  // scatter_h2 :122-199
+            const double ratio = par.h2_hi_width ? 1.0 : c.Dfreq / par.h2_Dfreq_Hz;       // h2_select_line_D (h2_mod.f90:81-115)
+            double w[4], wtot = 0.0; int il = 1;
+            for (int q = 0; q < par.h2_nlines; q++) { const double dx = par.h2_dnu_Hz[q] / c.Dfreq, x_h2 = (p.xfreq - dx) * ratio; w[q] = par.h2_strength[q] * ratio * voigt_H(l.vt, x_h2, par.h2_a_damp[q]); wtot = wtot + w[q]; }
+            if (wtot > 0.0) { const double r = g.next() * wtot; double acc = 0.0; il = par.h2_nlines; for (int q = 0; q < par.h2_nlines; q++) { acc = acc + w[q]; if (r <= acc) { il = q + 1; break; } } }
+            atomicAdd(&A.t.scal[LART_SCAL_AUX + 2 + il - 1], p.wgt);                      // W_H2pump(il)
+            if (g.next() > par.h2_p_scat[il - 1]) {            // fluorescence to another wavelength: the packet leaves Ly-alpha
+                atomicAdd(&A.t.scal[LART_SCAL_AUX + 0], p.wgt); p.inside = false; if (A.allph) p.wgt = 0.0;
+                return false;
+            }
+            atomicAdd(&A.t.scal[LART_SCAL_AUX + 1], p.wgt); p.nsg = p.nsg + p.wgt;
+            const double rt = c.Dfreq / par.h2_Dfreq_Hz, dx = par.h2_dnu_Hz[il - 1] / c.Dfreq;       // (scatter_h2 always uses the H2 Doppler width: :163-166)
+            sc.h2 = il; sc.cl_Dfreq = c.Dfreq; sc.xsamp = (p.xfreq - dx) * rt; sc.vsamp = par.h2_a_damp[il - 1]; sc.xloc = sc.xsamp;
+            return true;
+        }
+    }
     if (DUST) {
         double rD = cl_rhokapD;
         double p_dust = rD / (cl_rhokap * calc_voigt(l, p.xfreq * cl_scale, va, cl_Dfreq) + rD);
@@ -2053,6 +2213,17 @@ template <int VAR, bool STOKES, bool DUST, bool PEEL>
 __device__ inline void scatter_post(const KArgs &A, const Lds &l, Rng &g, Photon &p, unsigned &npeel, const ScatCtx &sc, double uz_loc_in) {
     double uz_loc = uz_loc_in;
     const lart_params &par = A.par;
+    if (l.lt == 9 && sc.h2 > 0) {                              // scatter_h2 (scattering_car.f90:160-199): coherent in the molecule's frame, isotropic re-emission, H2 Doppler units and back
+        const double ratio = sc.cl_Dfreq / par.h2_Dfreq_Hz, dx = par.h2_dnu_Hz[sc.h2 - 1] / sc.cl_Dfreq, xatom = sc.xsamp - uz_loc;
+        double u0, u1, u2, u3; g.next2(u0, u1); g.next2(u2, u3);
+        const double cost = 2.0 * u0 - 1.0, sint = sqrt(1.0 - cost * cost);
+        double sinp, cosp, s2, c2; d_sincos_2pi(u1, &sinp, &cosp); d_sincos_2pi(u2, &s2, &c2);
+        const double uxy = sqrt(-d_log(u3)), ux = uxy * c2, uy = uxy * s2;
+        const double x_h2_new = xatom + uz_loc * cost + (ux * cosp + uy * sinp) * sint;
+        p.xfreq = x_h2_new / ratio + dx;
+        rotate_k(p, cost, sint, cosp, sinp);
+        return;
+    }
     // do_resonance1 (line_mod.f90:108-139; do_resonance1_clump: local Doppler units and back)
     double uz, xfreq_atom;
     const bool deut = (l.lt == 7) && sc.species == 2;          // a deuterium atom scattered (line%selected_species_HD = 2)
@@ -2085,6 +2256,18 @@ __device__ inline void scatter_post(const KArgs &A, const Lds &l, Rng &g, Photon
         const double qK = is_clump(VAR) ? sc.xloc - uz_loc : xfreq_atom, qH = qK + sc.dnu;
         E1 = (2.0 * qK * qH + qH * qH) / (qK * qK + 2.0 * qH * qH); E2 = 1.0 - E1; E3 = (E1 + 2.0) / 3.0;
     }
+    bool converted = false;
+    if (l.lt == 8) {                                           // do_resonance8 (line_mod.f90:318-329): 3p -> 2s with probability P_down(2): the packet turns into H-alpha
+        if (g.next() < par.P_conv) { converted = true; p.iband = 2; E1 = par.E_conv[0]; E2 = par.E_conv[1]; E3 = par.E_conv[2]; }
+        if (converted) {                                       // scattering_car.f90:697-705: W_conv and the conversion-rate profile (add_to_Pconv :861-894)
+            atomicAdd(&A.t.scal[LART_SCAL_AUX + 0], p.wgt);
+            const Cell &cc = A.g.cell[cidx(A.g, p.ic, p.jc, p.kc)];
+            if (A.jpa.Pconv && cc.rhokap > 0.0) {
+                const int ib = (VAR == 3) ? amr_JPa_bin(A.amr, p.ic, p.x, p.y, p.z) : A.jpa.ind_bin[cidx(A.g, p.ic, p.jc, p.kc)];
+                if (ib >= 1) atomicAdd(&A.jpa.Pconv[ib - 1], p.wgt / (cc.rhokap * cc.Dfreq / A.jpa.cross0));
+            }
+        }
+    }
     if (STOKES) {
         cost = (l.lt == 2 || l.lt == 4) ? rand_resonance_u(g.next(), E1) : dipole_cost(l, g.next(), E1); cost2 = cost * cost; sint = sqrt(1.0 - cost2);
         S22 = 0.75 * E1 * (cost2 + 1.0); S11 = S22 + E2; S12 = 0.75 * E1 * (cost2 - 1.0); S33 = 1.5 * E1 * cost;
@@ -2112,7 +2295,7 @@ __device__ inline void scatter_post(const KArgs &A, const Lds &l, Rng &g, Photon
     if (is_clump(VAR)) { double vth_ratio = sc.cl_Dfreq / A.cl.Dfreq_ref; ux = ux * vth_ratio; uy = uy * vth_ratio; }   // scattering_car.f90:384-388, 715-719
     p.xfreq = xfreq_atom + uz * cost + (ux * cosp + uy * sinp) * sint;
     const double g_rec0 = deut ? par.g_recoil0_D : par.g_recoil0;      // :427-437
-    if (par.recoil) p.xfreq = p.xfreq - (g_rec0 / sc.cl_Dfreq) * (1.0 - cost);
+    if (par.recoil && !converted) p.xfreq = p.xfreq - (g_rec0 / sc.cl_Dfreq) * (1.0 - cost);      // (no recoil on the conversion channel: :768-770)
     if (STOKES) {
         if (PEEL) peel_emit<VAR, STOKES>(A, l, DUST, PEEL_RESONANCE, p, xfreq_atom, ux, uy, uz, E1, E2, E3, g_rec0, npeel);   // peeling_resonance_stokes_outside, deferred
         double cos2p = 2.0 * cosp * cosp - 1.0, sin2p = 2.0 * sinp * cosp;
@@ -2121,8 +2304,14 @@ __device__ inline void scatter_post(const KArgs &A, const Lds &l, Rng &g, Photon
         p.Q = Q1 / I1; p.U = U1 / I1; p.V = V1 / I1;
         rotate_triad(p, cost, sint, cosp, sinp);
     } else {
-        if (PEEL) peel_emit<VAR, STOKES>(A, l, DUST, PEEL_RESONANCE, p, xfreq_atom, ux, uy, uz, E1, E2, E3, g_rec0, npeel);   // peeling_resonance_nostokes_outside, deferred
+        if (PEEL && converted) { unsigned natom = 0; peel_conversion_Ha<VAR>(A, l, DUST, p, A.g.cell[cidx(A.g, p.ic, p.jc, p.kc)], ux, uy, uz, E1, E2, npeel, natom); }      // peeling_conversion_Ha (:784-788)
+        else if (PEEL) peel_emit<VAR, STOKES>(A, l, DUST, PEEL_RESONANCE, p, xfreq_atom, ux, uy, uz, E1, E2, E3, g_rec0, npeel);   // peeling_resonance_nostokes_outside, deferred
         rotate_k(p, cost, sint, cosp, sinp);
+        if (converted) {                                       // :811-827: emitted at line centre in the atom frame -> the lab frame along the new direction, reference Doppler units
+            const Cell &cc = A.g.cell[cidx(A.g, p.ic, p.jc, p.kc)];
+            const double u1_fluid = cc.vfx * p.kx + cc.vfy * p.ky + cc.vfz * p.kz;
+            p.xfreq = (p.xfreq - xfreq_atom + u1_fluid) * (cc.Dfreq / par.Dfreq_ref);
+        }
     }
     if (VAR == 7) p.xfreq = p.xfreq + ulos_clump(A, A.cl.phys[p.icl - 1], p.kx, p.ky, p.kz);   // ... and back to the global frame along the new direction
 }
@@ -2167,7 +2356,7 @@ __device__ inline void allph_final(const KArgs &A, const Photon &p, long long k)
 // sampler is a wave-cooperative stage, vz_core_coop).
 template <int VAR, bool STOKES, bool DUST, bool PEEL>
 __device__ inline void scatter_event(const KArgs &A, const Lds &l, Rng &g, Photon &p, unsigned &npeel, bool on) {
-    ScatCtx sc; sc.xloc = 0.0; sc.xsamp = 0.0; sc.va = 1.0; sc.vsamp = 1.0; sc.species = 1; sc.iup = 0;
+    ScatCtx sc; sc.xloc = 0.0; sc.xsamp = 0.0; sc.va = 1.0; sc.vsamp = 1.0; sc.species = 1; sc.iup = 0; sc.h2 = 0;
 #if defined(LART_PROFILE) || defined(LART_NO_COOP)
     if (!on || !scatter_pre<VAR, STOKES, DUST, PEEL>(A, l, g, p, npeel, sc)) return;
     LART_PROF_MARK(p, 4);

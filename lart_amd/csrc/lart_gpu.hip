@@ -22,6 +22,7 @@ extern "C" void lart_launch_transport_var5(int, int, int, dim3, dim3, size_t, hi
 extern "C" void lart_launch_transport_var6(int, int, int, dim3, dim3, size_t, hipStream_t, const KArgs &);
 extern "C" void lart_launch_transport_var7(int, int, int, dim3, dim3, size_t, hipStream_t, const KArgs &);
 extern "C" void lart_launch_transport_var8(int, int, int, dim3, dim3, size_t, hipStream_t, const KArgs &);
+extern "C" int lart_launch_transport_lt89(int var, int dust, int peel, dim3, dim3, size_t, hipStream_t, const KArgs &);
 extern "C" void lart_launch_peel(int var, int stokes, dim3, dim3, dim3, size_t, hipStream_t, const KArgs &);
 
 static thread_local std::string g_err;
@@ -86,8 +87,23 @@ extern "C" int lart_gpu_create(lart_gpu **out, const lart_params *par, int devic
     HIPCHK(hipSetDevice(device));
     if (par->source_geometry < 0 || par->source_geometry > 5) return fail("lart_gpu_create: source_geometry must be 0..5 (point, uniform_sphere, uniform_cylinder, uniform, uniform_xy, gaussian)");
     if (par->spectral_type < 0 || par->spectral_type > 3) return fail("lart_gpu_create: spectral_type must be 0 monochromatic, 1 voigt, 2 continuum or 3 gaussian");
-    if (par->line_type != 1 && par->line_type != 2 && par->line_type != 7 && !(par->line_type >= 4 && par->line_type <= 6))
-        return fail("lart_gpu_create: line_type must be 1 (single line), 2 (S-P doublet, par%fine_structure), 4 / 5 / 6 (resonance + fluorescence multiplets, with lart_gpu_set_line_multiplet) or 7 (H + D, ly_alpha_HD)");
+    if (par->line_type != 1 && par->line_type != 2 && par->line_type != 7 && par->line_type != 8 && !(par->line_type >= 4 && par->line_type <= 6))
+        return fail("lart_gpu_create: line_type must be 1 (single line), 2 (S-P doublet, par%fine_structure), 4 / 5 / 6 (resonance + fluorescence multiplets, with lart_gpu_set_line_multiplet), 7 (H + D, ly_alpha_HD) or 8 (ly_beta)");
+    if (par->line_type == 8) {                                  // the reference's vetoes for ly_beta (setup.f90:239-280) and what the band-2 path needs
+        if (par->use_stokes) return fail("lart_gpu_create: ly_beta: Stokes polarization not yet supported (setup.f90:254-258)");
+        if (par->xyz_symmetry || par->xy_symmetry || par->xy_periodic || par->Omega != 0.0) return fail("lart_gpu_create: ly_beta: xyz/xy symmetry, xy_periodic and shear not yet supported (setup.f90:270-275)");
+        if (par->core_skip || par->core_skip_global) return fail("lart_gpu_create: ly_beta forces core_skip = .false. (setup.f90:281-290): the host has to clear it");
+        if (!(par->P_conv >= 0.0 && par->P_conv <= 1.0) || par->nxfreq_Ha < 1 || !(par->dxfreq_Ha > 0.0) || !(par->R_Ha >= 0.0) || !(par->albedo_Ha >= 0.0 && par->albedo_Ha <= 1.0) || !(fabs(par->hgg_Ha) < 1.0))
+            return fail("lart_gpu_create: line_type 8 needs P_conv in [0,1], the H-alpha axis (nxfreq_Ha, xfreq_min_Ha, dxfreq_Ha) and the band-2 dust constants (R_Ha, albedo_Ha, hgg_Ha)");
+    }
+    if (par->h2_nlines != 0) {                                  // H2 lines next to Ly-alpha (setup.f90:302-348)
+        if (par->h2_nlines < 0 || par->h2_nlines > 4) return fail("lart_gpu_create: h2_nlines must be 0..4");
+        if (par->line_type != 1) return fail("lart_gpu_create: H2: only supported for line_id = 'ly_alpha' (line_type 1)");
+        if (par->use_stokes) return fail("lart_gpu_create: H2: Stokes polarization not yet supported");
+        if (par->xyz_symmetry || par->xy_symmetry || par->Omega != 0.0) return fail("lart_gpu_create: H2: xyz/xy symmetry and shear not yet supported");
+        if (!(par->h2_Dfreq_Hz > 0.0)) return fail("lart_gpu_create: H2: h2_Dfreq_Hz must be > 0");
+        for (int i = 0; i < par->h2_nlines; i++) if (!(par->h2_strength[i] >= 0.0) || !(par->h2_a_damp[i] > 0.0) || !(par->h2_p_scat[i] >= 0.0 && par->h2_p_scat[i] <= 1.0)) return fail("lart_gpu_create: H2: bad line record (strength >= 0, a_damp > 0, p_scat in [0,1])");
+    }
     if (par->line_type == 7 && !(par->ratio_Dfreq_HD > 0.0 && par->ratio_voigta_HD > 0.0 && par->delta_nu_HD_Hz > 0.0 && par->nD_over_nH >= 0.0)) return fail("lart_gpu_create: line_type 7 needs the cross-species constants of line% (delta_nu_HD_Hz, ratio_Dfreq_HD, ratio_voigta_HD, nD_over_nH)");
     if (par->line_type == 2 && !(par->DnuHK_Hz > 0.0)) return fail("lart_gpu_create: line_type 2 needs DnuHK_Hz > 0 (line%DnuHK_Hz)");
     lart_gpu *c = new lart_gpu();
@@ -139,12 +155,15 @@ static int build_tally(lart_gpu *c) {
     bool peel = p.save_peeloff && c->nobs > 0;
     int64_t off = 32;                                       // scalars 0..6; 8..31 are section clocks / trip counts of -DLART_PROFILE builds
     int64_t oJout = off; off += nxf; int64_t oJin = off; off += nxf; int64_t oJabs = off; off += nxf; int64_t oJmu = off; off += nxf * nmu;
+    const bool lyb = p.line_type == 8; const int64_t nxh = lyb ? p.nxfreq_Ha : 0;
+    int64_t oJoutHa = off; off += nxh; int64_t oJabsHa = off; off += nxh;
     const int64_t off_rep = off;                            // everything from here on is contended: gets per-XCD copies
     int64_t o3[8], o2[8];
     auto wanted = [&](int k) { return k < 2 || (k < 6 && p.use_stokes) || (k == 6 && p.save_direc0) || (k == 7 && p.save_dust_scattered); };
     for (int k = 0; k < 8; k++) { bool on = peel && p.save_peeloff_3D && wanted(k); o3[k] = on ? off : -1; if (on) off += n3; }
     for (int k = 0; k < 8; k++) { bool on = peel && p.save_peeloff_2D && wanted(k) && k != 7; o2[k] = on ? off : -1; if (on) off += n2; }
-    int64_t oJ1 = -1, oP1 = -1, oPn = -1;
+    int64_t oPeelHa = -1; if (lyb && peel && p.save_peeloff_3D) { oPeelHa = off; off += n2 * nxh; }       // observer(:)%peel_Ha (observer_rect.f90:306-311)
+    int64_t oJ1 = -1, oP1 = -1, oPn = -1, oPc = -1;
     c->jpa.lds_bins = 0;
     if (c->jpa.nbins > 0) {
         // P1 / P1_new: per-block LDS copies while they fit
@@ -165,6 +184,7 @@ static int build_tally(lart_gpu *c) {
         if (c->jpa.calc_J)    { oJ1 = off; off += nxf * c->jpa.nbins; }
         if (c->jpa.calc_P)    { oP1 = off; off += c->jpa.nbins; }
         if (c->jpa.calc_Pnew) { oPn = off; off += c->jpa.nbins; }
+        if (c->jpa.calc_P && lyb) { oPc = off; off += c->jpa.nbins; }
     }
     c->ntally = off;
     HIPCHK(hipMalloc(&c->d_tally, off * sizeof(double)));
@@ -178,6 +198,8 @@ static int build_tally(lart_gpu *c) {
     c->t.scal = c->d_tally; c->t.Jout = c->d_tally + oJout; c->t.Jin = c->d_tally + oJin; c->t.Jabs = c->d_tally + oJabs; c->t.Jmu = c->d_tally + oJmu;
     for (int k = 0; k < 8; k++) { c->t.c3[k] = o3[k] >= 0 ? c->d_tally + o3[k] : nullptr; c->t.c2[k] = o2[k] >= 0 ? c->d_tally + o2[k] : nullptr; }
     c->jpa.J1 = oJ1 >= 0 ? c->d_tally + oJ1 : nullptr; c->jpa.P1 = oP1 >= 0 ? c->d_tally + oP1 : nullptr; c->jpa.P1_new = oPn >= 0 ? c->d_tally + oPn : nullptr;
+    c->jpa.Pconv = oPc >= 0 ? c->d_tally + oPc : nullptr;
+    c->t.Jout_Ha = lyb ? c->d_tally + oJoutHa : nullptr; c->t.Jabs_Ha = lyb ? c->d_tally + oJabsHa : nullptr; c->t.peel_Ha = oPeelHa >= 0 ? c->d_tally + oPeelHa : nullptr;
     return 0;
 }
 
@@ -661,6 +683,11 @@ extern "C" int lart_gpu_step(lart_gpu *c, int32_t nsteps, int32_t max_events) {
     A.allph = (c->d_log && c->log_on == 2) ? c->d_log + 2 * c->nlog : nullptr; A.allph_n = c->nlog;
     A.trace_slot = c->d_trace_slot; A.trace = c->d_trace; A.trace_n = c->d_trace_n; A.trace_cap = c->trace_cap;
     int var = march_variant(c);
+    const bool h2 = c->par.h2_nlines > 0;
+    if (h2) A.par.line_type = 9;                               // pseudo line type of the kernels: Ly-alpha + the H2 lines (lart_device.hpp, h2_kappa_D)
+    if ((c->par.line_type == 8 && var != 0 && var != 3) || (h2 && var != 0 && var != 2 && var != 3)) return fail("step: ly_beta runs on the plain Cartesian grid and the octree, the H2 lines also on the 1-column slab (setup.f90:239-280, 302-348)");
+    if (c->par.line_type == 8 && (c->heal_nside > 0)) return fail("step: ly_beta: inside-observer (HEALPix) not yet supported (setup.f90:249-253)");
+    if (h2 && c->heal_nside > 0) return fail("step: H2: inside-observer (HEALPix) not yet supported");
     int stokes = c->par.use_stokes ? 1 : 0, dust = c->par.DGR > 0.0 ? 1 : 0, peel = (c->par.save_peeloff && c->nobs > 0) ? 1 : 0;
     dim3 block(c->block), grid((unsigned)(c->live_lanes / c->block));
     // Voigt tables + faces | ring of random draws [LART_RNG_BUF][block] | per-block P1, P1_new
@@ -686,7 +713,8 @@ extern "C" int lart_gpu_step(lart_gpu *c, int32_t nsteps, int32_t max_events) {
                 if (c->drained_pending[b]) { HIPCHK(hipStreamWaitEvent(c->stream, c->ev_drained[b], 0)); c->drained_pending[b] = false; }
             }
             HIPCHK(hipMemsetAsync(&c->d_ctl->n_active, 0, sizeof(unsigned long long), c->stream));
-            if (var == 0) lart_launch_transport_var0(stokes, dust, peel, grid, block, shmem, c->stream, A);
+            if (c->par.line_type == 8 || h2) { if (lart_launch_transport_lt89(var, dust, peel, grid, block, shmem, c->stream, A)) return fail("step: no kernel for this combination of line type and medium"); }
+            else if (var == 0) lart_launch_transport_var0(stokes, dust, peel, grid, block, shmem, c->stream, A);
             else if (var == 1) lart_launch_transport_var1(stokes, dust, peel, grid, block, shmem, c->stream, A);
             else if (var == 2) lart_launch_transport_var2(stokes, dust, peel, grid, block, shmem, c->stream, A);
             else if (var == 3) lart_launch_transport_var3(stokes, dust, peel, grid, block, shmem, c->stream, A);
@@ -808,6 +836,8 @@ extern "C" int lart_gpu_get_tallies(lart_gpu *c, lart_tallies *o) {
     double *h3[8] = {o->scatt, o->direc, o->I, o->Q, o->U, o->V, o->direc0, o->scatt_dust}, *h2[8] = {o->scatt_2D, o->direc_2D, o->I_2D, o->Q_2D, o->U_2D, o->V_2D, o->direc0_2D, nullptr};
     for (int k = 0; k < 8; k++) { CP(h3[k], c->t.c3[k], n3); CP(h2[k], c->t.c2[k], n2); }
     CP(o->J1, c->jpa.J1, nxf * c->jpa.nbins); CP(o->P1, c->jpa.P1, c->jpa.nbins); CP(o->P1_new, c->jpa.P1_new, c->jpa.nbins);
+    CP(o->Jout_Ha, c->t.Jout_Ha, c->par.nxfreq_Ha); CP(o->Jabs_Ha, c->t.Jabs_Ha, c->par.nxfreq_Ha); CP(o->peel_Ha, c->t.peel_Ha, n2 * c->par.nxfreq_Ha); CP(o->Pconv, c->jpa.Pconv, c->jpa.nbins);
+    { double w[8] = {0}; HIPCHK(hipMemcpy(w, c->d_tally + rs + LART_SCAL_AUX, 7 * 8, hipMemcpyDeviceToHost)); for (int i = 0; i < 8; i++) o->aux[i] = w[i]; }
 #undef CP
     return 0;
 }
@@ -1002,9 +1032,11 @@ __device__ void test_ray_one(const KArgs &A, const Lds &l, int kind, double *r, 
     if (is_clump(VAR)) { p.icl = ic[0]; p.ic = 1; p.jc = 1; p.kc = 1; }          // clump mode: ic[0] carries the owner clump (0 = vacuum)
     if (VAR == 8 && kind == 0) p.shear = *tau_out;                               // photon%vfy_shear comes in through tau_out and leaves through it
     unsigned ns = 0; bool dust = A.par.DGR > 0.0;
+    if (kind == 3) { p.iband = 2; kind = 0; }                                    // the tau march of a band-2 (H-alpha) packet of line type 8
+    if (kind == 4) { *tau_out = edge_dust_Ha<VAR>(A, l, dust, p, p.kx, p.ky, p.kz, ns); return; }      // raytrace_to_edge_*_dust_Ha
     if (kind == 0) {
         raytrace_to_tau<VAR>(A, l, dust, p, tq, ns);
-        r[0] = p.x; r[1] = p.y; r[2] = p.z; r[3] = p.kx; r[4] = p.ky; r[5] = p.kz; r[6] = p.xfreq; r[7] = p.wgt;
+        r[0] = p.x; r[1] = p.y; r[2] = p.z; r[3] = p.kx; r[4] = p.ky; r[5] = p.kz; r[6] = (p.iband == 2 && !p.inside) ? p.xfreq_ref : p.xfreq; r[7] = p.wgt;
         ic[0] = is_clump(VAR) ? p.icl : p.ic; ic[1] = p.jc; ic[2] = p.kc; ic[3] = p.inside ? 1 : 0;
         if (VAR == 8) *tau_out = p.shear;
     } else *tau_out = raytrace_to_edge<VAR>(A, l, dust, p, p.xfreq, p.kx, p.ky, p.kz, kind == 2 ? tq : -1.0, ns);
@@ -1033,13 +1065,13 @@ template <int VAR, bool STOKES, bool DUST>
 __device__ void test_scatter_one(const KArgs &A, const Lds &l, double *st, int *ic, unsigned long long seed, unsigned long long id, long long *nd) {
     Photon p{}; p.x = st[0]; p.y = st[1]; p.z = st[2]; p.kx = st[3]; p.ky = st[4]; p.kz = st[5]; p.xfreq = st[6]; p.wgt = st[7];
     p.mx = st[8]; p.my = st[9]; p.mz = st[10]; p.nx = st[11]; p.ny = st[12]; p.nz = st[13]; p.Q = st[15]; p.U = st[16]; p.V = st[17];
-    p.ic = ic[0]; p.jc = ic[1]; p.kc = ic[2]; p.inside = true;
+    p.ic = ic[0]; p.jc = ic[1]; p.kc = ic[2]; p.inside = true; p.iband = (ic[3] == 2) ? 2 : 1;
     if (is_clump(VAR)) { p.icl = ic[0]; p.ic = 1; p.jc = 1; p.kc = 1; }
     Rng g; g.init(seed, id, 0); unsigned np = 0;
     scatter_event<VAR, STOKES, DUST, false>(A, l, g, p, np, true);
     st[0] = p.x; st[1] = p.y; st[2] = p.z; st[3] = p.kx; st[4] = p.ky; st[5] = p.kz; st[6] = p.xfreq; st[7] = p.wgt;
     st[8] = p.mx; st[9] = p.my; st[10] = p.mz; st[11] = p.nx; st[12] = p.ny; st[13] = p.nz; st[14] = 1.0; st[15] = p.Q; st[16] = p.U; st[17] = p.V;
-    ic[3] = p.inside ? 1 : 0; *nd = (long long)g.n;
+    ic[3] = p.inside ? (p.iband == 2 ? 2 : 1) : 0; *nd = (long long)g.n;
 }
 __global__ void k_test_scatter(KArgs A, int n, double *st18, int *ic4, unsigned long long seed, const unsigned long long *ids, long long *nd) {
     extern __shared__ double sh[];
@@ -1068,7 +1100,7 @@ template <typename T> struct DevBuf {
     ~DevBuf() { if (p) (void)hipFree(p); }
 };
 static KArgs probe_args(lart_gpu *c) {
-    KArgs A{}; A.par = c->par; A.g = c->g; A.t = c->t; A.mu = c->mu; A.obs = c->d_obs; A.nobs = 0; A.nxim = c->nxim; A.nyim = c->nyim; A.dxim = c->dxim; A.dyim = c->dyim; A.ctl = c->d_ctl; A.heal_nside = c->heal_nside; A.jpa = c->jpa; A.amr = c->amr; A.cl = c->cl; A.ml = c->ml;
+    KArgs A{}; A.par = c->par; if (c->par.h2_nlines > 0) A.par.line_type = 9; A.g = c->g; A.t = c->t; A.mu = c->mu; A.obs = c->d_obs; A.nobs = 0; A.nxim = c->nxim; A.nyim = c->nyim; A.dxim = c->dxim; A.dyim = c->dyim; A.ctl = c->d_ctl; A.heal_nside = c->heal_nside; A.jpa = c->jpa; A.amr = c->amr; A.cl = c->cl; A.ml = c->ml;
     return A;
 }
 static size_t probe_shmem(lart_gpu *c) { return (size_t)(VT_END + c->g.nx + c->g.ny + c->g.nz + 3) * sizeof(double); }
@@ -1095,7 +1127,7 @@ extern "C" int lart_gpu_test_rand(lart_gpu *c, int32_t what, uint64_t seed, uint
 extern "C" int lart_gpu_test_raytrace(lart_gpu *c, int32_t mode, int32_t n, double *r8, int32_t *ic4, const double *tq, double *tau_out) {
     if (!c || n < 0 || !c->d_cell) return fail("test_raytrace: needs a context with a medium");
     int kind = mode / 10, var = mode % 10;
-    if (kind < 0 || kind > 2 || var < 0 || (var > 6 && var != 8) || (kind == 2 && var != 0 && var != 3)) return fail("test_raytrace: bad mode");
+    if (kind < 0 || kind > 4 || var < 0 || (var > 6 && var != 8) || (kind == 2 && var != 0 && var != 3) || (kind >= 3 && (c->par.line_type != 8 || (var != 0 && var != 3)))) return fail("test_raytrace: bad mode");
     if ((var == 3) != c->is_amr || (var == 4) != c->is_clump) return fail("test_raytrace: variant 3 needs the octree medium, 4 the clump medium, 0-2, 5, 6 the Cartesian one");
     HIPCHK(hipSetDevice(c->device));
     if (!c->d_tally) { if (build_tally(c)) return 1; }

@@ -38,6 +38,7 @@ __device__ inline void fly(const KArgs &A, const Lds &l, Rng &g, Photon &p, bool
             double u1 = c.vfx * p.kx + c.vfy * p.ky + c.vfz * p.kz;
             Photon e = p; e.wgt = p.wgt * esc; e.xfreq_ref = (p.xfreq + u1) * (c.Dfreq / par.Dfreq_ref);
             if (e.wgt != 0.0) tally_escape(par, A.t, e);
+            if (l.lt == 8 && e.wgt != 0.0) atomicAdd(&A.t.scal[LART_SCAL_AUX + 1], e.wgt);      // W_esc1: run_simulation_mod.f90:168
         }
         double wgt1 = 1.0 - esc;
         p.wgt = p.wgt * wgt1;
@@ -64,6 +65,7 @@ __global__ __launch_bounds__(256, LART_WAVES(STOKES, PEEL)) void transport_kerne
             const ptrdiff_t shift = (A.rep.base + (size_t)(r - 1) * A.rep.len) - (A.t.scal + A.rep.off);
             for (int q = 0; q < 8; q++) { if (A.t.c3[q]) A.t.c3[q] += shift; if (A.t.c2[q]) A.t.c2[q] += shift; }
             if (A.jpa.J1) A.jpa.J1 += shift; if (A.jpa.P1) A.jpa.P1 += shift; if (A.jpa.P1_new) A.jpa.P1_new += shift;
+            if (A.jpa.Pconv) A.jpa.Pconv += shift; if (A.t.peel_Ha) A.t.peel_Ha += shift;
         }
     }
     Lds l_ = lds_stage(sh, A.g); lds_set_dipole(l_, A.par.E1); l_.lt = LT; l_.dnu_hz = (LT == 2) ? A.par.DnuHK_Hz : (LT == 7) ? A.par.delta_nu_HD_Hz : 0.0;
@@ -103,6 +105,7 @@ __global__ __launch_bounds__(256, LART_WAVES(STOKES, PEEL)) void transport_kerne
 #endif
     int flags = A.pool.flags[lane];
     bool alive = flags & FLAG_ALIVE, first = flags & FLAG_FIRST;
+    p.iband = (flags & FLAG_BAND2) ? 2 : 1;
     long long k = A.pool.k[lane];
     if (alive) {
         p.x = F[F_X * P + lane]; p.y = F[F_Y * P + lane]; p.z = F[F_Z * P + lane];
@@ -131,6 +134,7 @@ __global__ __launch_bounds__(256, LART_WAVES(STOKES, PEEL)) void transport_kerne
             k = (long long)kk;
             g.init(A.seed, (uint64_t)(A.first_id + k * A.stride), 0);
             if (VAR == 8) p.shear = 0.0;                       // generate_photon.f90:141
+            p.iband = 1;                                       // :139
             generate_photon<VAR, STOKES, DUST, PEEL>(A, l, g, p, npeel);
             if (A.allph) allph_initial(A, p, k);
             if (A.trace_slot) trace_rec<VAR>(A, k, g.n, p, 0);
@@ -173,7 +177,7 @@ __global__ __launch_bounds__(256, LART_WAVES(STOKES, PEEL)) void transport_kerne
         }
     }
     if (PEEL && (threadIdx.x & 63) == 0) A.pq.count[lane >> 6] = *l.pq_cnt;
-    A.pool.flags[lane] = (alive ? FLAG_ALIVE : 0) | (first ? FLAG_FIRST : 0);
+    A.pool.flags[lane] = (alive ? FLAG_ALIVE : 0) | (first ? FLAG_FIRST : 0) | ((LT == 8 && p.iband == 2) ? FLAG_BAND2 : 0);
     if (alive) {
         A.pool.k[lane] = k; A.pool.rng_n[lane] = g.n;
         F[F_X * P + lane] = p.x; F[F_Y * P + lane] = p.y; F[F_Z * P + lane] = p.z;

@@ -182,12 +182,26 @@ class Params:
     # (grid_mod_car.f90:346-351 rescales it only there), i.e. the change of grid%vfy, in thermal-speed units, per wrap around the x boundary
     q: float = 1.0
     Omega: float = 0.0
+    # line_id = 'ly_beta' (line type 8): band-2 (H-alpha) spectral axis and dust constants (define.f90:461-468; Draine 2003, R_V = 3.1 at 6562 A)
+    nxfreq_Ha: int = 0
+    xfreq_max_Ha: float = 0.0
+    cext_dust_Ha: float = 3.801e-22
+    albedo_Ha: float = 0.6741
+    hgg_Ha: float = 0.4967
+    R_Ha: float = 0.0
+    # H2 lines next to Ly-alpha (define.f90:478-491; h2_mod.f90): 'none' | 'neufeld'
+    h2_model: str = "none"
+    f_H2: float = 0.0
+    h2_temperature: float = 1000.0
+    h2_pure_absorption: bool = False
+    h2_hi_width: bool = False
+    h2_data_dir: str = ""
 
 
 # fields of params_type that exist in the reference but select physics outside this path: accepted at their
 # default, rejected ("not supported") when set to something that would change the path
 _UNSUPPORTED_DEFAULTS = {
-    "h2_model": "none", "z_symmetry": False,
+    "z_symmetry": False,
     "dens_file": "", "temp_file": "", "velo_file": "", "emiss_file": "", "cart_file": "", "input_field": "",
     "star_file": "", "use_cie_condition": False, "density_rscale": -999.9, "density_zscale": -999.9,
     "density_alpha": 0.0, "temperature0": -999.0,
@@ -228,24 +242,13 @@ _UNSUPPORTED_DEFAULTS = {
     "base_name": "",
     "sampling_method": 1,
     "f_composite": 0.5,
-    "nxfreq_Ha": 0,
-    "xfreq_max_Ha": 0.0,
     "ny_2gam": 101,
-    "cext_dust_Ha": 3.801e-22,
-    "albedo_Ha": 0.6741,
-    "hgg_Ha": 0.4967,
     "transport_2gamma": False,
-    "R_Ha": 0.0,
     "W_conv": 0.0,
     "W_esc1": 0.0,
     "W_abs1": 0.0,
     "W_esc2": 0.0,
     "W_abs2": 0.0,
-    "f_H2": 0.0,
-    "h2_temperature": 1000.0,
-    "h2_pure_absorption": False,
-    "h2_hi_width": False,
-    "h2_data_dir": "",
     "W_H2abs": 0.0,
     "W_H2scat": 0.0,
     "line_prof_file_type": 0,
@@ -356,6 +359,11 @@ class Line:
     bturb: float = -999.0           # par%bturb (km/s)
     multiplet: object = None        # capi.LartLineMultiplet for line types 4, 5, 6 (line%b(:))
     DnuHK_Hz: float = 0.0           # 2P3/2 - 2P1/2 splitting (par%fine_structure: line type 2, line_mod.f90:1250-1253)
+    P_conv: float = 0.0             # line type 8: line%b(1)%P_down(2), the 3p -> 2s branch (line_mod.f90:1230-1238)
+    E_conv: tuple = (1.0, 0.0, 1.0)
+    wavelength0_Ha: float = 0.6564553
+    mass_amu: float = 1.00797
+    h2: object = None               # H2Lines (h2_init) when par%h2_model /= 'none'
 
 
 def vtherm_total(line, T):
@@ -431,10 +439,72 @@ _METAL_LINES = {
 _SOURCE_GEOMETRIES = {"point": 0, "uniform_sphere": 1, "uniform_cylinder": 2, "uniform": 3, "uniform_xy": 4, "gaussian": 5}
 
 
+@dataclass
+class H2Lines:
+    """h2_mod.f90:30-49: the H2 lines next to Ly-alpha as h2_init leaves them"""
+    n: int = 0
+    Dfreq_Hz: float = 0.0
+    dv_kms: tuple = ()
+    dnu_Hz: tuple = ()
+    strength: tuple = ()
+    a_damp: tuple = ()
+    p_scat: tuple = ()
+    pop: tuple = ()
+    f_osc: tuple = ()
+
+
+def read_energy_X(fname):
+    """read_energy_X (h2_mod.f90:250-296): rows 'V J E[cm^-1]' after a magic-number line and '#' comments"""
+    if not os.path.exists(fname):
+        raise LartInputError("h2_mod: cannot find " + fname)
+    rows = []
+    for ln in open(fname):
+        q = ln.strip()
+        if not q or q.startswith("#") or "//" in q:
+            continue
+        t = q.split()
+        try:
+            rows.append((float(t[0]), float(t[1]), float(t[2])))
+        except (ValueError, IndexError):
+            continue
+    return np.array(rows)
+
+
+def h2_init(par, line):
+    """h2_init (h2_mod.f90:120-222): the two B-X lines closest to Ly-alpha, R(6) and P(5) of v = 1 <- 2 (Neufeld 1990), LTE populations of the lower
+    levels at par%h2_temperature from the X-state level table <par%h2_data_dir>/energy_X.dat, strengths relative to the H I line-centre opacity"""
+    speedc, f_osc_Lya, hc_over_k, f_osc_const = SPEEDC, 0.4162, 1.4387769, 1.4992e-16
+    nu_Lya = (speedc * 1.0e5) / (line.wavelength0 * UM2M * 1.0e2)
+    vth1 = line.vtherm1 * math.sqrt(line.mass_amu / (2.0 * line.mass_amu)); T = par.h2_temperature
+    bt2 = par.bturb ** 2 if par.bturb > 0.0 else 0.0
+    vth = math.sqrt((vth1 * math.sqrt(T)) ** 2 + bt2)
+    Dfreq = nu_Lya * vth / speedc
+    dv, lam, A_ul, A_tot = (14.140, 99.229), (1215.72534, 1216.07038), (1.36e8, 1.59e8), (1.6825e9, 1.7199e9)
+    vl, Jl, Ju = (2, 2), (6, 5), (7, 4)
+    lev = read_energy_X(os.path.join(par.h2_data_dir or "data/h2", "energy_X.dat"))
+    Z = 0.0
+    for vv, jj, ee in lev:                                                # the reference's summation order
+        gns = 3.0 if int(round(jj)) % 2 != 0 else 1.0
+        Z = Z + gns * (2.0 * jj + 1.0) * math.exp(-hc_over_k * ee / T)
+    out = dict(dnu=[], s=[], a=[], p=[], pop=[], f=[])
+    for i in range(2):
+        sel = [ee for vv, jj, ee in lev if int(round(vv)) == vl[i] and int(round(jj)) == Jl[i]]
+        if not sel:
+            raise LartInputError("h2_mod: X-level (v=%d, J=%d) not found in energy_X.dat" % (vl[i], Jl[i]))
+        f_osc = f_osc_const * (2.0 * Ju[i] + 1.0) / (2.0 * Jl[i] + 1.0) * lam[i] ** 2 * A_ul[i]
+        gns = 3.0 if Jl[i] % 2 != 0 else 1.0
+        pop = gns * (2.0 * Jl[i] + 1.0) * math.exp(-hc_over_k * sel[0] / T) / Z
+        out["dnu"].append(-(dv[i] / speedc) * nu_Lya); out["f"].append(f_osc); out["pop"].append(pop)
+        out["s"].append(par.f_H2 * pop * (f_osc / f_osc_Lya)); out["a"].append(A_tot[i] / (4.0 * PI * Dfreq))
+        out["p"].append(0.0 if par.h2_pure_absorption else A_ul[i] / A_tot[i])
+    return H2Lines(n=2, Dfreq_Hz=Dfreq, dv_kms=dv, dnu_Hz=tuple(out["dnu"]), strength=tuple(out["s"]), a_damp=tuple(out["a"]), p_scat=tuple(out["p"]),
+                   pop=tuple(out["pop"]), f_osc=tuple(out["f"]))
+
+
 def read_input(par, line=None):
     """post-processing part of read_input (setup.f90:42-562) for the fields this path uses. Returns (par, line, scatt_mat)."""
     line = line or Line()
-    ml = capi.line_lookup(par.line_id) if par.line_id not in ("ly_alpha", "ly_alpha_HD") and par.line_id not in _METAL_LINES else None
+    ml = capi.line_lookup(par.line_id) if par.line_id not in ("ly_alpha", "ly_alpha_HD", "ly_beta") and par.line_id not in _METAL_LINES else None
     if ml is not None:                                                    # resonance + fluorescence multiplets, types 4-6: line_mod.f90:713-1153
         line.line_type, line.wavelength0, line.damping, line.cross0 = ml.line_type, ml.wavelength0, ml.damping, ml.cross0
         line.vtherm1, line.g_recoil0, line.DnuHK_Hz, line.multiplet = ml.vtherm1, ml.g_recoil0, 0.0, ml
@@ -450,6 +520,15 @@ def read_input(par, line=None):
         line.DnuHK_Hz = (2.99792458e5 * 1.0e5) * (k_hi - k_lo) if typ == 2 else 0.0
         line.E1, line.E2, line.E3 = 1.0, 0.0, 1.0
         par.fine_structure = par.include_deuterium = False               # (both only act on the ly_alpha branches)
+    elif par.line_id == "ly_beta":                                        # line_mod.f90:1192-1240: H I Lyman beta with the 3p -> 2s conversion to H-alpha
+        line.line_type, line.wavelength0, line.damping = 8, 0.10257222, 1.8970e8
+        line.cross0 = 0.026540083434 / math.sqrt(PI) * 0.07910
+        line.vtherm1 = 0.12895319011972164 / math.sqrt(1.00797)
+        line.g_recoil0 = (H_PLANCK / 1.67262192e-24 / 1.00797) / (line.wavelength0 * UM2M) ** 2
+        line.DnuHK_Hz, line.E1, line.E2, line.E3 = 0.0, 1.0, 0.0, 1.0
+        A21 = (1.6725e8, 2.2448e7)
+        line.P_conv = A21[1] / (A21[0] + A21[1])
+        par.include_deuterium = False
     elif par.line_id not in ("ly_alpha", "ly_alpha_HD"):
         raise LartInputError("par%%line_id = '%s' is not supported by this path (ly_alpha, ly_alpha_HD, %s)" % (par.line_id, ", ".join(_METAL_LINES) + " and the multiplets of lart_host_line_lookup"))
     if par.include_deuterium and par.line_id == "ly_alpha":               # line_mod.f90:580-588
@@ -526,6 +605,30 @@ def read_input(par, line=None):
         par.save_Jabs = False
     if par.core_skip_global:
         par.core_skip = True
+    if line.line_type == 8:                                               # setup.f90:239-300: vetoes, no core-skip, band-1 dust re-defaults, R_Ha
+        why = ("clump medium" if par.use_clump_medium else "inside-observer (HEALPix)" if par.nside > 0 else "Stokes polarization" if par.use_stokes else
+               "fine structure" if par.fine_structure else "xyz/xy symmetry, xy_periodic and shear" if (par.xyz_symmetry or par.xy_symmetry or par.xy_periodic or par.Omega != 0.0) else None)
+        if why:
+            raise LartInputError("ly_beta: %s not yet supported" % why)
+        if par.core_skip or par.core_skip_global:
+            print("NOTE: ly_beta forces core_skip = .false. (core-skip would bias the conversion rate).")
+        par.core_skip = par.core_skip_global = False
+        # (:282-291 compares with the double-precision literals 0.3253_wp, 0.6761_wp, 1.6059e-21_wp while the defaults are single-precision literals
+        #  widened to double, define.f90:454-456: the re-default only happens when the input sets those double values itself)
+        if par.albedo == 0.3253 and par.hgg == 0.6761 and par.cext_dust == 1.6059e-21:
+            par.albedo, par.hgg, par.cext_dust = 0.2804, 0.6483, 2.047e-21
+            print("NOTE: ly_beta re-defaults band-1 dust constants to Draine 1026A values (cext=2.047e-21, albedo=0.2804, hgg=0.6483).")
+        par.R_Ha = 0.0 if (par.cext_dust_Ha <= 0.0 or par.cext_dust <= 0.0) else par.cext_dust_Ha / par.cext_dust
+    par.h2_model = par.h2_model.lower()
+    if par.h2_model != "none":                                            # setup.f90:302-365
+        why = ("only supported for line_id = 'ly_alpha' (line_type 1)" if line.line_type != 1 else "Phase 1 supports only h2_model='neufeld'; got " + par.h2_model if par.h2_model != "neufeld" else
+               "clump medium not yet supported" if par.use_clump_medium else "inside-observer (HEALPix) not yet supported" if par.nside > 0 else
+               "Stokes polarization not yet supported" if par.use_stokes else "xyz/xy symmetry and shear not yet supported" if (par.xyz_symmetry or par.xy_symmetry or par.Omega != 0.0) else
+               "xy_periodic supported only for the nx=ny=1 slab" if (par.xy_periodic and (par.nx > 1 or par.ny > 1)) else "par%f_H2 must be > 0 when h2_model /= 'none'" if not par.f_H2 > 0.0 else None)
+        if why:
+            raise LartInputError("H2: " + why)
+        line.bturb = par.bturb
+        line.h2 = h2_init(par, line)
     if par.save_Jmu:                                                      # :367-381
         if par.nmu < 1:
             raise LartInputError("ERROR: par%nmu must be >= 1 when par%save_Jmu = .true.")
@@ -865,6 +968,15 @@ def car_setup_freq_grid(par, line, g):
             par.xfreq_min = -(math.floor(xscale * par.atau3 + abs(par.Vexp) / vth + line.DnuHK_Hz / g.Dfreq_ref) + 1)
     g.dxfreq = (par.xfreq_max - par.xfreq_min) / par.nxfreq
     g.xfreq_max, g.xfreq_min = float(par.xfreq_max), float(par.xfreq_min)
+    if line.line_type == 8:                                                # :1518-1529 the band-2 (H-alpha) axis
+        g.nxfreq_Ha = par.nxfreq_Ha if par.nxfreq_Ha > 0 else g.nxfreq
+        par.nxfreq_Ha = g.nxfreq_Ha
+        if par.xfreq_max_Ha > 0.0:
+            g.xfreq_max_Ha, g.xfreq_min_Ha = float(par.xfreq_max_Ha), -float(par.xfreq_max_Ha)
+        else:
+            g.xfreq_min_Ha, g.xfreq_max_Ha = g.xfreq_min, g.xfreq_max
+        g.dxfreq_Ha = (g.xfreq_max_Ha - g.xfreq_min_Ha) / g.nxfreq_Ha
+        g.dwave_Ha = vth / SPEEDC * (line.wavelength0_Ha * 1e4) * g.dxfreq_Ha
     g.xfreq = (np.arange(1, g.nxfreq + 1) - 0.5) * g.dxfreq + g.xfreq_min
     g.velocity = -vth * g.xfreq
     g.dwave = vth / SPEEDC * (line.wavelength0 * 1e4) * g.dxfreq
@@ -997,6 +1109,16 @@ def make_lart_params(par, line, g):
                                                                                            line.nD_over_nH, line.g_recoil0_D)
     p.xcrit, p.xcrit2 = g.xcrit, g.xcrit2
     p.Omega = float(par.Omega)                 # raytrace_to_tau_car_xyper_shear when xy_periodic and nx, ny > 1 (setup.f90:967-969)
+    if line.line_type == 8:
+        p.nxfreq_Ha, p.xfreq_min_Ha, p.dxfreq_Ha = int(g.nxfreq_Ha), float(g.xfreq_min_Ha), float(g.dxfreq_Ha)
+        p.R_Ha, p.albedo_Ha, p.hgg_Ha, p.P_conv = float(par.R_Ha), float(par.albedo_Ha), float(par.hgg_Ha), float(line.P_conv)
+        for i in range(3):
+            p.E_conv[i] = float(line.E_conv[i])
+    if line.h2 is not None:
+        h = line.h2
+        p.h2_nlines, p.h2_hi_width, p.h2_Dfreq_Hz = h.n, int(par.h2_hi_width), h.Dfreq_Hz
+        for i in range(h.n):
+            p.h2_dnu_Hz[i], p.h2_strength[i], p.h2_a_damp[i], p.h2_p_scat[i] = h.dnu_Hz[i], h.strength[i], h.a_damp[i], h.p_scat[i]
     return p
 
 

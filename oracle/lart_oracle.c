@@ -288,6 +288,7 @@ typedef struct {
     double *scatt, *direc, *I, *Q, *U, *V;
     double *scatt_2D, *direc_2D, *I_2D, *Q_2D, *U_2D, *V_2D;
     double *direc0, *direc0_2D, *scatt_dust;      /* par%save_direc0, par%save_dust_scattered */
+    double *peel_Ha;                              /* line type 8: observer%peel_Ha(nxfreq_Ha, nxim, nyim) (define.f90:567-568) */
 } obs_t;
 
 typedef struct {
@@ -296,6 +297,7 @@ typedef struct {
     int icell, jcell, kcell;
     int icell_clump;                  /* 0 = vacuum, > 0 = owner clump (define.f90:90) */
     double vfy_shear;                 /* y velocity picked up at the shearing x boundary (define.f90:100) */
+    int iband;                        /* 1 = the line's own band, 2 = H-alpha after a Ly-beta conversion (define.f90:96); 0 in a zeroed packet counts as 1 */
     int species;                      /* line%selected_species_HD of the last resonance scattering: 1 H, 2 D */
     double xfreq, xfreq_ref, wgt;
     int inside;
@@ -378,6 +380,14 @@ struct orc_sim {
     int nside, npix;
     int64_t log_n; double *log_nscatt, *log_xfreq;
     int save_all_photons; double *allph;     /* par%save_all_photons: 10 columns x log_n (r, xfreq1, xfreq2, nscatt_gas, nscatt_dust, I, Q, U, V, r0) */
+    /* --- line type 8, 'ly_beta' (line_mod.f90:1192-1240, define.f90:461-475): band-2 (H-alpha) dust constants and spectral axis, the conversion
+     *     branch of the 3p level, the weight budget W_conv, W_esc1, W_abs1, W_esc2, W_abs2 --- */
+    double cext_dust_Ha, albedo_Ha, hgg_Ha, R_Ha, par_xfreq_max_Ha; int par_nxfreq_Ha;
+    int nxfreq_Ha; double xfreq_min_Ha, xfreq_max_Ha, dxfreq_Ha, P_conv, E_conv[3];
+    double *Jout_Ha, *Jabs_Ha, *Pconv, W[5];
+    /* --- H2 lines next to Ly-alpha (h2_mod.f90; par%h2_model = 'neufeld'): per line dnu_Hz, strength, a_damp, p_scat; W_H2abs, W_H2scat, W_H2pump(:) --- */
+    char h2_model[16], h2_data_dir[512]; double f_H2, h2_temperature; int h2_pure_absorption, h2_hi_width;
+    int h2_on, h2_nlines; double h2_Dfreq_Hz, h2_dnu_Hz[4], h2_strength[4], h2_a_damp[4], h2_p_scat[4], h2_pop[4], h2_f_osc[4], W_H2[6];
 };
 
 static int grid_create_clump(orc_sim *s);
@@ -404,6 +414,7 @@ static inline double calc_voigt(const orc_sim *s, double xfreq, double a, double
 
 /* per-thread accumulators, merged after the run */
 typedef struct { orc_sim *s; double *Jout, *Jin, *Jabs, *Jmu, *J1, *P1, *P1_new; obs_t obs[MAX_OBS];
+                 double *Jout_Ha, *Jabs_Ha, *Pconv, W[5], W_H2[6];
                  double nscatt_gas, nscatt_dust, n_cellsteps, n_cellsteps_peel, n_events;
                  rng_t *g; } acc_t;                          /* the packet's stream, for the one draw inside the overlap march (sample_owner_clump) */
 
@@ -429,6 +440,8 @@ static void set_defaults(orc_sim *s) {
     s->clump_fully_inside = 1; s->velocity_min = NAN; s->velocity_max = NAN; s->wavelength_min = NAN; s->wavelength_max = NAN; s->velocity_alpha = 1.0;
     s->D_to_H_ratio = 1.5e-5;
     s->gaussian_sigma_vel = 12.843374; s->gaussian_FWHM_vel = -999.0;     /* define.f90:317-318 */
+    s->cext_dust_Ha = 3.801e-22; s->albedo_Ha = 0.6741; s->hgg_Ha = 0.4967;    /* define.f90:464-466 (double precision literals) */
+    strcpy(s->h2_model, "none"); s->h2_temperature = 1000.0;               /* define.f90:480-485 */
 }
 
 /* the single resonance lines (type 1) and S1/2-P1/2,3/2 doublets (type 2) of setup_resonance_line, line_mod.f90:590-713:
@@ -480,7 +493,13 @@ static int set_param(orc_sim *s, const char *k, const char *v) {
     if (!strcmp(k, "amr_file")) { snprintf(s->amr_file, sizeof s->amr_file, "%s", v); return 0; }
     if (!strcmp(k, "amr_type")) return 0;
     if (!strcmp(k, "scatt_mat_file")) { snprintf(s->scatt_mat_file, sizeof s->scatt_mat_file, "%s", v); return 0; }
-    if (!strcmp(k, "line_id")) { if (!strcmp(v, "ly_alpha")) { s->line_id[0] = 0; return 0; } if (!strcmp(v, "ly_alpha_HD")) { s->include_deuterium = 1; return 0; }
+    if (!strcmp(k, "nxfreq_Ha")) { s->par_nxfreq_Ha = atoi(v); return 0; }
+    if (!strcmp(k, "xfreq_max_Ha")) { s->par_xfreq_max_Ha = atof(v); return 0; }
+    D(cext_dust_Ha) D(albedo_Ha) D(hgg_Ha) D(f_H2) D(h2_temperature) B(h2_pure_absorption) B(h2_hi_width)
+    if (!strcmp(k, "h2_model")) { snprintf(s->h2_model, sizeof s->h2_model, "%s", v); for (char *q = s->h2_model; *q; q++) if (*q >= 'A' && *q <= 'Z') *q += 32; return 0; }
+    if (!strcmp(k, "h2_data_dir")) { snprintf(s->h2_data_dir, sizeof s->h2_data_dir, "%s", v); return 0; }
+    if (!strcmp(k, "line_id")) { if (!strcmp(v, "ly_alpha")) { s->line_id[0] = 0; return 0; }
+        if (!strcmp(v, "ly_beta")) { snprintf(s->line_id, sizeof s->line_id, "%s", v); return 0; } if (!strcmp(v, "ly_alpha_HD")) { s->include_deuterium = 1; return 0; }
         if (find_metal_line(v) || find_multiplet(v)) { snprintf(s->line_id, sizeof s->line_id, "%s", v); return 0; }
         snprintf(g_err, sizeof g_err, "line_id '%s' not supported by the oracle", v); return -1; }
     if (!strcmp(k, "spectral_type")) {
@@ -541,6 +560,16 @@ static void setup_line(orc_sim *s) {
         }
         s->damping = s->ml.damping_up[0]; s->DnuHK_Hz = 0.0;
         s->E1 = 1.0; s->E2 = 0.0; s->E3 = 1.0; s->fine_structure = 0; s->include_deuterium = 0;
+        return;
+    }
+    if (!strcmp(s->line_id, "ly_beta")) {                   /* :1192-1240: H I Lyman beta, 3p -> 1s re-emission or 3p -> 2s conversion to H-alpha (+ two photons) */
+        const double sigma_0 = 0.026540083434, amu = 1.67262192e-24, vtherm1_amu = 0.12895319011972164, mass_amu = 1.00797;
+        s->line_type = 8; s->wavelength0 = 0.10257222; s->damping = 1.8970e8; s->cross0 = sigma_0 / sqrt(PI) * 0.07910;
+        s->vtherm1 = vtherm1_amu / sqrt(mass_amu);
+        { double wl = s->wavelength0 * UM2M; s->g_recoil0 = (H_PLANCK / amu / mass_amu) / (wl * wl); }
+        s->DnuHK_Hz = 0.0; s->E1 = 1.0; s->E2 = 0.0; s->E3 = 1.0; s->fine_structure = 0; s->include_deuterium = 0;
+        { const double A21[2] = {1.6725e8, 2.2448e7}; s->P_conv = A21[1] / (A21[0] + A21[1]); }      /* P_down = A21 / sum(A21), :1233-1236 */
+        s->E_conv[0] = 1.0; s->E_conv[1] = 0.0; s->E_conv[2] = 1.0;                                  /* both channels are s -> p -> s ladders */
         return;
     }
     if (s->line_id[0]) {                                    /* :590-713; par%fine_structure plays no part for these ids */
@@ -638,6 +667,59 @@ static double rand_alias_linear(rng_t *g, int n, const double *prob_alias, const
     return (sqrt(p0 * p0 + (p1 * p1 - p0 * p0) * rnd(g)) - p0) * (xaxis[idx] - xaxis[idx-1]) / (p1 - p0) + xaxis[idx-1];
 }
 
+/* h2_init: h2_mod.f90:120-222 (the two B-X lines closest to Ly-alpha, R(6) and P(5) of v = 1 <- 2; LTE populations from the X-state level table
+ * <h2_data_dir>/energy_X.dat: a magic-number first line, '#' comments, rows "V J E[cm^-1]") */
+static int h2_init(orc_sim *s) {
+    const double speedc = 2.99792458e5, f_osc_Lya = 0.4162, hc_over_k = 1.4387769, f_osc_const = 1.4992e-16;
+    const double nu_Lya_Hz = (speedc * 1.0e5) / (s->wavelength0 * UM2M * 1.0e2);
+    const double mass_amu = 1.00797, vth1_H2 = s->vtherm1 * sqrt(mass_amu / (2.0 * mass_amu)), T = s->h2_temperature;
+    const double bturb2 = s->bturb > 0.0 ? s->bturb * s->bturb : 0.0, vth_H2 = sqrt((vth1_H2 * sqrt(T)) * (vth1_H2 * sqrt(T)) + bturb2);
+    s->h2_Dfreq_Hz = nu_Lya_Hz * vth_H2 / speedc;
+    const double dv[2] = {14.140, 99.229}, lam[2] = {1215.72534, 1216.07038}, A_ul[2] = {1.36e8, 1.59e8}, A_tot[2] = {1.6825e9, 1.7199e9};
+    const int vl[2] = {2, 2}, Jl[2] = {6, 5}, Ju[2] = {7, 4};
+    char fn[600]; snprintf(fn, sizeof fn, "%s/energy_X.dat", s->h2_data_dir[0] ? s->h2_data_dir : "data/h2");
+    FILE *f = fopen(fn, "r"); if (!f) { snprintf(g_err, sizeof g_err, "h2_init: cannot find %s", fn); return -1; }
+    char line[300]; double Z = 0.0, El[2] = {-1.0, -1.0};
+    while (fgets(line, sizeof line, f)) {
+        char *q = line; while (*q == ' ' || *q == '\t') q++;
+        if (!*q || *q == '\n' || *q == '#' || strstr(q, "//")) continue;
+        double vv, jj, ee; if (sscanf(q, "%lf %lf %lf", &vv, &jj, &ee) != 3) continue;
+        const double gns = (((long)lrint(jj)) % 2 != 0) ? 3.0 : 1.0;
+        Z = Z + gns * (2.0 * jj + 1.0) * exp(-hc_over_k * ee / T);
+        for (int i = 0; i < 2; i++) if ((long)lrint(vv) == vl[i] && (long)lrint(jj) == Jl[i] && El[i] < 0.0) El[i] = ee;
+    }
+    fclose(f);
+    s->h2_nlines = 2;
+    for (int i = 0; i < 2; i++) {
+        if (El[i] < 0.0) { snprintf(g_err, sizeof g_err, "h2_init: X-level (v=%d, J=%d) not found in %s", vl[i], Jl[i], fn); return -1; }
+        s->h2_dnu_Hz[i] = -(dv[i] / speedc) * nu_Lya_Hz;
+        s->h2_f_osc[i] = f_osc_const * (2.0 * Ju[i] + 1.0) / (2.0 * Jl[i] + 1.0) * (lam[i] * lam[i]) * A_ul[i];
+        const double gns = (Jl[i] % 2 != 0) ? 3.0 : 1.0;
+        s->h2_pop[i] = gns * (2.0 * Jl[i] + 1.0) * exp(-hc_over_k * El[i] / T) / Z;
+        s->h2_strength[i] = s->f_H2 * s->h2_pop[i] * (s->h2_f_osc[i] / f_osc_Lya);
+        s->h2_a_damp[i] = A_tot[i] / (4.0 * PI * s->h2_Dfreq_Hz);
+        s->h2_p_scat[i] = s->h2_pure_absorption ? 0.0 : A_ul[i] / A_tot[i];
+    }
+    s->h2_on = 1;
+    return 0;
+}
+/* h2_kappa_D: h2_mod.f90:58-78 (multiplier of the H I opacity of a cell of Doppler width Dfreq) */
+static inline double h2_kappa_D(const orc_sim *s, double xfreq, double Dfreq) {
+    double kap = 0.0; if (!s->h2_on) return kap;
+    const double ratio = s->h2_hi_width ? 1.0 : Dfreq / s->h2_Dfreq_Hz;
+    for (int il = 0; il < s->h2_nlines; il++) { double dx = s->h2_dnu_Hz[il] / Dfreq, x_h2 = (xfreq - dx) * ratio; kap = kap + s->h2_strength[il] * ratio * orc_voigt(x_h2, s->h2_a_damp[il]); }
+    return kap;
+}
+static double rnd(rng_t *g);
+/* h2_select_line_D: h2_mod.f90:81-115 (1-based line number) */
+static int h2_select_line_D(const orc_sim *s, rng_t *g, double xfreq, double Dfreq) {
+    const double ratio = s->h2_hi_width ? 1.0 : Dfreq / s->h2_Dfreq_Hz; double w[4], wtot = 0.0;
+    for (int il = 0; il < s->h2_nlines; il++) { double dx = s->h2_dnu_Hz[il] / Dfreq, x_h2 = (xfreq - dx) * ratio; w[il] = s->h2_strength[il] * ratio * orc_voigt(x_h2, s->h2_a_damp[il]); wtot = wtot + w[il]; }
+    if (wtot <= 0.0) return 1;
+    const double r = rnd(g) * wtot; double acc = 0.0;
+    for (int il = 0; il < s->h2_nlines; il++) { acc = acc + w[il]; MRG(r, acc, 67); if (r <= acc) return il + 1; }
+    return s->h2_nlines;
+}
 static int read_input_post(orc_sim *s) {
     if (s->spectral_type == 2) s->comoving_source = 0;          /* setup.f90:115: a continuum is flat in the lab frame */
     /* setup.f90:161-165: a 1-cell axis disables xyz_symmetry */
@@ -654,6 +736,24 @@ static int read_input_post(orc_sim *s) {
     if (s->cext_dust <= 0.0) s->DGR = 0.0;
     if (s->DGR == 0.0) s->save_Jabs = 0;
     if (s->core_skip_global) s->core_skip = 1;
+    if (s->line_type == 8) {                                     /* setup.f90:239-300 */
+        const char *why = s->use_clump_medium ? "clump medium" : (s->nside > 0) ? "inside-observer (HEALPix)" : s->use_stokes ? "Stokes polarization" :
+            s->fine_structure ? "fine structure" : (s->xyz_symmetry || s->xy_symmetry || s->xy_periodic || s->Omega != 0.0) ? "xyz/xy symmetry, xy_periodic and shear" : NULL;
+        if (why) { snprintf(g_err, sizeof g_err, "ly_beta: %s not yet supported", why); return -1; }
+        s->core_skip = 0; s->core_skip_global = 0;               /* every skipped core scattering would carry the conversion chance */
+        if (s->albedo == 0.3253 && s->hgg == 0.6761 && s->cext_dust == 1.6059e-21) {      /* :282-291; NB these are double-precision literals while the defaults are float32
+            literals widened to double (define.f90:454-456): the comparison only holds when the input sets the double values itself */
+            s->albedo = 0.2804; s->hgg = 0.6483; s->cext_dust = 2.047e-21; }
+        s->R_Ha = (s->cext_dust_Ha <= 0.0 || s->cext_dust <= 0.0) ? 0.0 : s->cext_dust_Ha / s->cext_dust;
+    }
+    if (strcmp(s->h2_model, "none")) {                            /* setup.f90:302-365 */
+        const char *why = (s->line_type != 1) ? "only supported for line_id = 'ly_alpha' (line_type 1)" : strcmp(s->h2_model, "neufeld") ? "Phase 1 supports only h2_model='neufeld'" :
+            s->use_clump_medium ? "clump medium not yet supported" : (s->nside > 0) ? "inside-observer (HEALPix) not yet supported" : s->use_stokes ? "Stokes polarization not yet supported" :
+            (s->xyz_symmetry || s->xy_symmetry || s->Omega != 0.0) ? "xyz/xy symmetry and shear not yet supported" :
+            (s->xy_periodic && (s->nx > 1 || s->ny > 1)) ? "xy_periodic supported only for the nx=ny=1 slab" : !(s->f_H2 > 0.0) ? "par%f_H2 must be > 0 when h2_model /= 'none'" : NULL;
+        if (why) { snprintf(g_err, sizeof g_err, "H2: %s", why); return -1; }
+        if (h2_init(s)) return -1;
+    }
     /* :367-381 Jmu */
     if (s->save_Jmu) { if (s->xyz_symmetry) { s->mu_min = 0.0; s->dmu = 1.0 / s->nmu; } else { s->mu_min = -1.0; s->dmu = 2.0 / s->nmu; } }
     /* :398-428 geometry normalisation */
@@ -864,6 +964,12 @@ static int grid_create(orc_sim *s) {
     }
     s->dxfreq = (s->par_xfreq_max - s->par_xfreq_min) / s->nxfreq;
     s->xfreq_max = s->par_xfreq_max; s->xfreq_min = s->par_xfreq_min;
+    if (s->line_type == 8) {                                    /* car_setup_freq_grid :1518-1529 / amr_setup_freq_grid: the band-2 (H-alpha) axis */
+        s->nxfreq_Ha = s->par_nxfreq_Ha > 0 ? s->par_nxfreq_Ha : s->nxfreq;
+        if (s->par_xfreq_max_Ha > 0.0) { s->xfreq_max_Ha = s->par_xfreq_max_Ha; s->xfreq_min_Ha = -s->par_xfreq_max_Ha; } else { s->xfreq_min_Ha = s->xfreq_min; s->xfreq_max_Ha = s->xfreq_max; }
+        s->dxfreq_Ha = (s->xfreq_max_Ha - s->xfreq_min_Ha) / s->nxfreq_Ha;
+        s->Jout_Ha = calloc(s->nxfreq_Ha, 8); s->Jabs_Ha = calloc(s->nxfreq_Ha, 8);
+    }
     /* tallies :1161-1183 */
     s->Jout = calloc(s->nxfreq, sizeof(double)); s->Jin = calloc(s->nxfreq, sizeof(double)); s->Jabs = calloc(s->nxfreq, sizeof(double));
     s->Jmu = calloc((size_t)s->nxfreq * (s->nmu > 0 ? s->nmu : 1), sizeof(double));
@@ -916,6 +1022,7 @@ static int create_JPa_mem(orc_sim *s) {
     }
     if (s->calc_J) s->J1 = calloc((size_t)s->nxfreq * s->nbins, sizeof(double));
     if (s->calc_P) s->P1 = calloc(s->nbins, sizeof(double));
+    if (s->calc_P && s->line_type == 8) s->Pconv = calloc(s->nbins, sizeof(double));
     if (s->calc_Pnew) s->P1_new = calloc(s->nbins, sizeof(double));
     return 0;
 }
@@ -938,6 +1045,16 @@ static inline void add_to_Pa(const orc_sim *s, acc_t *A, const photon_t *p) {
     int ib = s->use_amr_grid ? amr_JPa_bin(s, p->icell, p->x, p->y, p->z) : s->ind_bin[c];   /* add_to_Pa_amr: scattering_amr.f90:917-942 */
     if (ib < 1) return;
     A->P1[ib-1] += p->wgt / (s->rhokap[c] * s->Dfreq[c] / s->cross0);
+}
+
+/* add_to_Pconv (scattering_car.f90:861-894) / add_to_Pconv_amr: the conversion-rate profile of line type 8, binned and normalised like add_to_Pa */
+static inline void add_to_Pconv(const orc_sim *s, acc_t *A, const photon_t *p) {
+    if (!s->calc_P || !A->Pconv) return;
+    size_t c = IDX(s,p->icell,p->jcell,p->kcell);
+    if (!(s->rhokap[c] > 0.0)) return;
+    int ib = s->use_amr_grid ? amr_JPa_bin(s, p->icell, p->x, p->y, p->z) : s->ind_bin[c];
+    if (ib < 1) return;
+    A->Pconv[ib-1] += p->wgt / (s->rhokap[c] * s->Dfreq[c] / s->cross0);
 }
 
 /* observer_create_outside: observer_rect.f90:24-326 */
@@ -1018,6 +1135,7 @@ static int observer_create(orc_sim *s) {
     for (int i = 0; i < s->nobs; i++) { obs_t *o = &s->obs[i];
         if (s->save_peeloff_2D) { o->scatt_2D = calloc(n2, 8); o->direc_2D = calloc(n2, 8); if (s->save_direc0) o->direc0_2D = calloc(n2, 8);
             if (s->use_stokes) { o->I_2D = calloc(n2, 8); o->Q_2D = calloc(n2, 8); o->U_2D = calloc(n2, 8); o->V_2D = calloc(n2, 8); } }
+        if (s->save_peeloff_3D && s->line_type == 8) o->peel_Ha = calloc(n2 * s->nxfreq_Ha, 8);      /* observer_rect.f90:306-311 */
         if (s->save_peeloff_3D) { o->scatt = calloc(n3, 8); o->direc = calloc(n3, 8); if (s->save_direc0) o->direc0 = calloc(n3, 8); if (s->save_dust_scattered) o->scatt_dust = calloc(n3, 8);
             if (s->use_stokes) { o->I = calloc(n3, 8); o->Q = calloc(n3, 8); o->U = calloc(n3, 8); o->V = calloc(n3, 8); } } }
     return 0;
@@ -1036,7 +1154,7 @@ orc_sim *orc_create(const char *params) {
     if (read_input_post(s) || (s->use_clump_medium ? grid_create_clump(s) : s->use_amr_grid ? (grid_create_amr(s) || create_JPa_amr_mem(s)) : (grid_create(s) || create_JPa_mem(s))) || observer_create(s)) { free(s); return NULL; }
     return s;
 }
-static void free_obs(obs_t *o) { free(o->scatt); free(o->direc); free(o->I); free(o->Q); free(o->U); free(o->V);
+static void free_obs(obs_t *o) { free(o->peel_Ha); o->peel_Ha = NULL; free(o->scatt); free(o->direc); free(o->I); free(o->Q); free(o->U); free(o->V);
     free(o->scatt_2D); free(o->direc_2D); free(o->I_2D); free(o->Q_2D); free(o->U_2D); free(o->V_2D);
     free(o->direc0); free(o->direc0_2D); free(o->scatt_dust); }
 void orc_destroy(orc_sim *s) {
@@ -1255,6 +1373,12 @@ static int grid_create_amr(orc_sim *s) {
             s->par_xfreq_max = floor(xscale * s->atau3 + fabs(s->Vexp) / vt) + 1.0; s->par_xfreq_min = -(floor(xscale * s->atau3 + fabs(s->Vexp) / vt + s->DnuHK_Hz / s->Dfreq_ref) + 1.0); }
     }
     s->dxfreq = (s->par_xfreq_max - s->par_xfreq_min) / s->nxfreq; s->xfreq_max = s->par_xfreq_max; s->xfreq_min = s->par_xfreq_min;
+    if (s->line_type == 8) {                                    /* car_setup_freq_grid :1518-1529 / amr_setup_freq_grid: the band-2 (H-alpha) axis */
+        s->nxfreq_Ha = s->par_nxfreq_Ha > 0 ? s->par_nxfreq_Ha : s->nxfreq;
+        if (s->par_xfreq_max_Ha > 0.0) { s->xfreq_max_Ha = s->par_xfreq_max_Ha; s->xfreq_min_Ha = -s->par_xfreq_max_Ha; } else { s->xfreq_min_Ha = s->xfreq_min; s->xfreq_max_Ha = s->xfreq_max; }
+        s->dxfreq_Ha = (s->xfreq_max_Ha - s->xfreq_min_Ha) / s->nxfreq_Ha;
+        s->Jout_Ha = calloc(s->nxfreq_Ha, 8); s->Jabs_Ha = calloc(s->nxfreq_Ha, 8);
+    }
     s->Jout = calloc(s->nxfreq, 8); s->Jin = calloc(s->nxfreq, 8); s->Jabs = calloc(s->nxfreq, 8); s->Jmu = calloc((size_t)s->nxfreq * (s->nmu > 0 ? s->nmu : 1), 8);
     s->raytrace_variant = 3;
     return 0;
@@ -1289,6 +1413,7 @@ static int create_JPa_amr_mem(orc_sim *s) {
     }
     if (s->calc_J) s->J1 = calloc((size_t)s->nxfreq * s->nbins, 8);
     if (s->calc_P) s->P1 = calloc(s->nbins, 8);
+    if (s->calc_P && s->line_type == 8) s->Pconv = calloc(s->nbins, 8);
     if (s->calc_Pnew) s->P1_new = calloc(s->nbins, 8);
     return 0;
 }
@@ -1351,32 +1476,42 @@ static void raytrace_to_tau_amr(const orc_sim *s, acc_t *A, photon_t *p, double 
     while (p->inside) {
         int ic = a->icell_of_leaf[il-1], iface; double t_exit;
         amr_cell_exit(a, ic, x, y, z, kx, ky, kz, &t_exit, &iface);
-        double rhokapH = s->rhokap[il-1] * calc_voigt(s, p->xfreq, s->voigt_a[il-1], s->Dfreq[il-1]), rhokap = rhokapH;
-        if (s->DGR > 0.0) rhokap = rhokap + s->rhokapD[il-1];
+        double rhokapH, rhokap;
+        if (p->iband != 2) {
+            rhokapH = s->rhokap[il-1] * calc_voigt(s, p->xfreq, s->voigt_a[il-1], s->Dfreq[il-1]); rhokap = rhokapH;
+            if (s->h2_on) rhokap = rhokap + s->rhokap[il-1] * h2_kappa_D(s, p->xfreq, s->Dfreq[il-1]);
+            if (s->DGR > 0.0) rhokap = rhokap + s->rhokapD[il-1];
+        } else { rhokapH = 0.0; rhokap = (s->DGR > 0.0) ? s->rhokapD[il-1] * s->R_Ha : 0.0; }
         A->n_cellsteps += 1.0;
         MRG(tau + t_exit * rhokap, tau_in, 43);
         if (tau + t_exit * rhokap >= tau_in) {
             double d_step = (rhokap > 0.0) ? (tau_in - tau) / rhokap : t_exit;
-            if (s->nbins) add_to_JPnew_amr(s, A, p, il, x + 0.5 * d_step * kx, y + 0.5 * d_step * ky, z + 0.5 * d_step * kz, d_step, d_step * rhokapH);
+            if (s->nbins && p->iband != 2) add_to_JPnew_amr(s, A, p, il, x + 0.5 * d_step * kx, y + 0.5 * d_step * ky, z + 0.5 * d_step * kz, d_step, d_step * rhokapH);
             x = x + d_step * kx; y = y + d_step * ky; z = z + d_step * kz; tau = tau_in;
             break;
         }
         tau = tau + t_exit * rhokap; x = x + t_exit * kx; y = y + t_exit * ky; z = z + t_exit * kz;
-        if (s->nbins) add_to_JPnew_amr(s, A, p, il, x - 0.5 * t_exit * kx, y - 0.5 * t_exit * ky, z - 0.5 * t_exit * kz, t_exit, t_exit * rhokapH);
+        if (s->nbins && p->iband != 2) add_to_JPnew_amr(s, A, p, il, x - 0.5 * t_exit * kx, y - 0.5 * t_exit * ky, z - 0.5 * t_exit * kz, t_exit, t_exit * rhokapH);
         int il_new = amr_next_leaf(a, ic, iface, x, y, z), reflected = 0;
         if (il_new <= 0) il_new = amr_boundary(s, il, iface, &x, &y, z, &kx, &ky, &kz, &reflected);
         if (il_new <= 0) { p->inside = 0; break; }
         u2 = s->vfx[il_new-1] * kx + s->vfy[il_new-1] * ky + s->vfz[il_new-1] * kz;
-        if (reflected) p->xfreq = (p->xfreq + u1) - u2; else p->xfreq = (p->xfreq + u1) * s->Dfreq[il-1] / s->Dfreq[il_new-1] - u2;
+        if (p->iband != 2) { if (reflected) p->xfreq = (p->xfreq + u1) - u2; else p->xfreq = (p->xfreq + u1) * s->Dfreq[il-1] / s->Dfreq[il_new-1] - u2; }
         u1 = u2; il = il_new;
     }
     p->x = x; p->y = y; p->z = z; p->kx = kx; p->ky = ky; p->kz = kz; p->icell = il; p->jcell = 1; p->kcell = 1;
-    if (!p->inside) {
+    if (!p->inside && p->iband == 2) {                       /* :244-256 */
+        p->xfreq_ref = p->xfreq;
+        int ix = (int)floor((p->xfreq - s->xfreq_min_Ha) / s->dxfreq_Ha) + 1;
+        if (ix >= 1 && ix <= s->nxfreq_Ha) A->Jout_Ha[ix-1] += p->wgt;
+        A->W[3] += p->wgt;
+    } else if (!p->inside) {
         u1 = s->vfx[il-1] * kx + s->vfy[il-1] * ky + s->vfz[il-1] * kz;
         p->xfreq = p->xfreq + u1;
         p->xfreq_ref = p->xfreq * (s->Dfreq[il-1] / s->Dfreq_ref);
         int ix = (int)floor((p->xfreq_ref - s->xfreq_min) / s->dxfreq) + 1;
         if (ix >= 1 && ix <= s->nxfreq) { A->Jout[ix-1] += p->wgt; if (s->save_Jmu) add_to_Jmu(s, A, p, ix); }
+        if (s->line_type == 8) A->W[1] += p->wgt;
     }
 }
 /* raytrace_to_edge_amr (:265-344) and raytrace_to_dist_amr (:559-640, dist >= 0) */
@@ -1390,6 +1525,7 @@ static double raytrace_to_edge_amr(const orc_sim *s, const photon_t *p, double d
         int ic = a->icell_of_leaf[il-1], iface; double t_exit;
         amr_cell_exit(a, ic, x, y, z, kx, ky, kz, &t_exit, &iface);
         double rhokap = s->rhokap[il-1] * calc_voigt(s, xfreq, s->voigt_a[il-1], s->Dfreq[il-1]);
+        if (s->h2_on && dist < 0.0) rhokap = rhokap + s->rhokap[il-1] * h2_kappa_D(s, xfreq, s->Dfreq[il-1]);
         if (s->DGR > 0.0) rhokap = rhokap + s->rhokapD[il-1];
         if (nsteps) *nsteps += 1.0;
         if (dist >= 0.0 && d + t_exit >= dist) { tau = tau + (dist - d) * rhokap; return tau; }
@@ -1798,6 +1934,7 @@ static int active_set_at_point(const clumps_t *c, double xp, double yp, double z
                 for (int32_t ip = c->cg_start[q]; ip <= c->cg_start[q+1] - 1; ip++) {
                     int64_t icl = c->cg_list[ip-1];
                     double rx = xp - c->x[icl-1], ry = yp - c->y[icl-1], rz = zp - c->z[icl-1];
+                    MRG(rx * rx + ry * ry + rz * rz, c->radius2[icl-1], 52);
                     if (rx * rx + ry * ry + rz * rz <= c->radius2[icl-1]) {
                         int dup = 0; for (int m = 0; m < n; m++) if (active[m] == icl) { dup = 1; break; }
                         if (!dup && n < OVL_MAX_EVT) active[n++] = icl;
@@ -1828,9 +1965,11 @@ static int collect_ray_events_overlap(const clumps_t *c, double xp, double yp, d
             int64_t icl = c->cg_list[ip-1];
             double rx = xp - c->x[icl-1], ry = yp - c->y[icl-1], rz = zp - c->z[icl-1];       /* ray_sphere_isect :1362-1386 */
             double b = rx * kx + ry * ky + rz * kz, disc = b * b - (rx * rx + ry * ry + rz * rz) + c->radius2[icl-1];
+            if (g_mrg_on) mrg_note(b * b + c->radius2[icl-1], rx * rx + ry * ry + rz * rz, 47, 1.0);
             if (disc < 0.0) continue;
             disc = sqrt(disc);
             double te = -b - disc, tx2 = -b + disc;
+            if (g_mrg_on) { mrg_note(b, -disc, 53, 1.0); mrg_note(b, disc, 53, 1.0); MRG(te, t_max, 51); }      /* t_exit > 0, t_entry > 0: -b against -+ sqrt(disc) */
             if (!(tx2 > 0.0)) continue;                                             /* hit = (t_exit > 0); then t_exit <= 0 is skipped again */
             if (te > t_max) continue;
             int dup = 0; for (int ie = 0; ie < n_ev; ie++) if (ev_icl[ie] == icl) { dup = 1; break; }
@@ -1844,6 +1983,7 @@ static int collect_ray_events_overlap(const clumps_t *c, double xp, double yp, d
     }
     for (int ie = 1; ie < n_ev; ie++) {
         double t = ev_t[ie]; int64_t ic = ev_icl[ie]; int ty_ = ev_type[ie]; int ii = ie - 1;
+        if (g_mrg_on) for (int iq = 0; iq < ie; iq++) MRG(ev_t[iq], t, 54);                /* the order of two events along the ray */
         while (ii >= 0 && ev_t[ii] > t) { ev_t[ii+1] = ev_t[ii]; ev_icl[ii+1] = ev_icl[ii]; ev_type[ii+1] = ev_type[ii]; ii--; }
         ev_t[ii+1] = t; ev_icl[ii+1] = ic; ev_type[ii+1] = ty_;
     }
@@ -1861,6 +2001,7 @@ static int64_t sample_owner_clump(const orc_sim *s, rng_t *g, const int64_t *act
     for (int m = 0; m < n; m++) {
         int64_t icl = active[m]; double x_cl = xfreq_g - ulos_clump(&s->cl, icl, kx, ky, kz);
         cumul = cumul + kappa_clump(s, x_cl, icl); owner = icl;
+        MRG(r * sum_kap_active(s, active, n, xfreq_g, kx, ky, kz), cumul, 55);
         if (r * sum_kap_active(s, active, n, xfreq_g, kx, ky, kz) <= cumul) return owner;
     }
     return owner;
@@ -1883,9 +2024,11 @@ static void raytrace_to_tau_clump_overlap(const orc_sim *s, acc_t *A, rng_t *g, 
         for (int ie = 1; ie <= n_ev + 1; ie++) {
             double t_next = ie <= n_ev ? ev_t[ie-1] : t_sp; t_next = fmin(t_next, t_sp);
             double dt = t_next - t_cur;
+            MRG(t_next, t_cur, 56);
             if (dt <= 0.0) { if (ie <= n_ev) ovl_apply_event(ev_icl[ie-1], ev_type[ie-1], active, &n_active); continue; }
             double kap_tot = sum_kap_active(s, active, n_active, xfreq_g, kx, ky, kz);
             A->n_cellsteps += 1.0;
+            MRG(tau_rem, kap_tot * dt, 46);
             if (kap_tot > 0.0 && tau_rem <= kap_tot * dt) {
                 double ds = tau_rem / kap_tot;
                 p->x = p->x + (t_cur + ds) * kx; p->y = p->y + (t_cur + ds) * ky; p->z = p->z + (t_cur + ds) * kz;
@@ -2035,8 +2178,12 @@ static void raytrace_to_tau(const orc_sim *s, acc_t *A, photon_t *p, double tau_
     if (shear) u1 = s->vfx[IDX(s,iold,jold,kold)] * t.kx + (s->vfy[IDX(s,iold,jold,kold)] + p->vfy_shear) * t.ky + s->vfz[IDX(s,iold,jold,kold)] * t.kz;   /* :2808-2809 */
     while (p->inside) {
         size_t c = IDX(s,t.icell,t.jcell,t.kcell);
-        rhokapH = s->rhokap[c] * calc_voigt(s, p->xfreq, s->voigt_a[c], s->Dfreq[c]);
-        rhokap = (s->DGR > 0.0) ? rhokapH + s->rhokapD[c] : rhokapH;
+        if (p->iband != 2) {
+            rhokapH = s->rhokap[c] * calc_voigt(s, p->xfreq, s->voigt_a[c], s->Dfreq[c]);
+            rhokap = rhokapH;
+            if (s->h2_on) rhokap = rhokap + s->rhokap[c] * h2_kappa_D(s, p->xfreq, s->Dfreq[c]);       /* :1490-1493 (kept out of rhokapH) */
+            if (s->DGR > 0.0) rhokap = rhokap + s->rhokapD[c];
+        } else { rhokapH = 0.0; rhokap = (s->DGR > 0.0) ? s->rhokapD[c] * s->R_Ha : 0.0; }            /* :1495-1503 band 2: dust only, scaled to 6563 A */
         A->n_cellsteps += 1.0;
         int idx = (variant == 2) ? 3 : minloc3(t.tx, t.ty, t.tz);
         double *tt = (idx == 1) ? &t.tx : (idx == 2) ? &t.ty : &t.tz;
@@ -2063,13 +2210,19 @@ static void raytrace_to_tau(const orc_sim *s, acc_t *A, photon_t *p, double tau_
             else if (t.kcell < 1 || t.kcell > s->nz) { p->inside = 0; break; }
             t.tz += t.delz; }
         size_t cn = IDX(s,t.icell,t.jcell,t.kcell), co = IDX(s,iold,jold,kold);
-        if (s->nbins) add_to_JPnew(s, A, p, co, del, del * rhokapH);                   /* :1579-1584 */
+        if (s->nbins && p->iband != 2) add_to_JPnew(s, A, p, co, del, del * rhokapH);                   /* :1579-1584 */
         u2 = shear ? s->vfx[cn] * t.kx + (s->vfy[cn] + p->vfy_shear) * t.ky + s->vfz[cn] * t.kz : udot(s, cn, t.kx, t.ky, t.kz);
-        p->xfreq = (p->xfreq + u1) * s->Dfreq[co] / s->Dfreq[cn] - u2;
+        if (p->iband != 2) p->xfreq = (p->xfreq + u1) * s->Dfreq[co] / s->Dfreq[cn] - u2;            /* band 2 carries a lab-frame frequency: :1587-1589 */
         iold = t.icell; jold = t.jcell; kold = t.kcell; u1 = u2;
     }
     if (!p->inside) { t.icell = iold; t.jcell = jold; t.kcell = kold; }
-    if (s->nbins) add_to_JPnew(s, A, p, IDX(s,t.icell,t.jcell,t.kcell), del, del * rhokapH);   /* :1604-1609 last segment */
+    if (s->nbins && p->iband != 2) add_to_JPnew(s, A, p, IDX(s,t.icell,t.jcell,t.kcell), del, del * rhokapH);   /* :1604-1609 last segment */
+    if (!p->inside && p->iband == 2) {                                               /* :1625-1636 band-2 escape: no fluid shift, the H-alpha axis */
+        p->xfreq_ref = p->xfreq;
+        int ix = (int)floor((p->xfreq_ref - s->xfreq_min_Ha) / s->dxfreq_Ha) + 1;
+        if (ix >= 1 && ix <= s->nxfreq_Ha) A->Jout_Ha[ix-1] += p->wgt;
+        A->W[3] += p->wgt;
+    } else
     if (!p->inside) {                                                                /* escape tally :1613-1623 */
         size_t c = IDX(s,t.icell,t.jcell,t.kcell);
         u1 = shear ? s->vfx[c] * t.kx + (s->vfy[c] + p->vfy_shear) * t.ky + s->vfz[c] * t.kz : udot(s, c, t.kx, t.ky, t.kz);
@@ -2077,6 +2230,7 @@ static void raytrace_to_tau(const orc_sim *s, acc_t *A, photon_t *p, double tau_
         p->xfreq_ref = p->xfreq * (s->Dfreq[c] / s->Dfreq_ref);
         int ix = (int)floor((p->xfreq_ref - s->xfreq_min) / s->dxfreq) + 1;
         if (ix >= 1 && ix <= s->nxfreq) { A->Jout[ix-1] += p->wgt; if (s->save_Jmu) add_to_Jmu(s, A, p, ix); }
+        if (s->line_type == 8) A->W[1] += p->wgt;                                    /* W_esc1 :1624 */
     }
     if (mirror_xy) {                                                                 /* :1935-1946, xysym :2238-2248 (no fold in z) */
         p->x = p->x + d * p->kx; p->y = p->y + d * p->ky; p->z = p->z + d * p->kz;
@@ -2122,6 +2276,7 @@ static double raytrace_to_edge(const orc_sim *s, const photon_t *p, int variant,
     for (;;) {
         size_t c = IDX(s,t.icell,t.jcell,t.kcell);
         rhokap = s->rhokap[c] * calc_voigt(s, xfreq, s->voigt_a[c], s->Dfreq[c]);
+        if (s->h2_on && dist < 0.0) rhokap = rhokap + s->rhokap[c] * h2_kappa_D(s, xfreq, s->Dfreq[c]);      /* H2 peel attenuation: _edge_car :473, _zonly :1216 (not in raytrace_to_dist) */
         if (s->DGR > 0.0) rhokap = rhokap + s->rhokapD[c];
         if (nsteps) *nsteps += 1.0;
         int idx = (variant == 2) ? 3 : minloc3(t.tx, t.ty, t.tz);
@@ -2210,7 +2365,41 @@ static inline void obs_dir_s(const orc_sim *s, int i, const photon_t *p, photon_
     } else obs_dir(&s->obs[i], p, pobs, r2, s->nxim, s->nyim, s->dxim, s->dyim, ix, iy);
 }
 /* tau along the peel ray: to the grid edge (far observers) or to the observer (inside: raytrace_to_dist, peelingoff_heal.f90:60) */
+/* raytrace_to_edge_car_dust_Ha (raytrace_car.f90:510-582) and raytrace_to_edge_amr_dust_Ha (raytrace_amr.f90:353-390): the band-2 sight line, dust only */
+static double raytrace_to_edge_dust_Ha(const orc_sim *s, const photon_t *p, double *nsteps) {
+    double tau = 0.0;
+    if (s->DGR <= 0.0) return tau;
+    if (s->use_amr_grid) {
+        const amr_t *a = &s->amr; double x = p->x, y = p->y, z = p->z; int il = p->icell;
+        if (il <= 0) { il = amr_find_leaf(a, x, y, z); if (il <= 0) return tau; }
+        for (;;) {
+            int ic = a->icell_of_leaf[il-1], iface; double t_exit;
+            amr_cell_exit(a, ic, x, y, z, p->kx, p->ky, p->kz, &t_exit, &iface);
+            if (nsteps) *nsteps += 1.0;
+            tau = tau + t_exit * (s->rhokapD[il-1] * s->R_Ha);
+            if (tau >= TAU_HUGE) return tau;
+            x = x + t_exit * p->kx; y = y + t_exit * p->ky; z = z + t_exit * p->kz;
+            int il_new = amr_next_leaf(a, ic, iface, x, y, z);
+            if (il_new <= 0) return tau;
+            il = il_new;
+        }
+    }
+    trav_t t; double d = 0.0;
+    t.kx = p->kx; t.ky = p->ky; t.kz = p->kz; t.icell = p->icell; t.jcell = p->jcell; t.kcell = p->kcell;
+    if (setup_traversal_car(s, p->x, p->y, p->z, &t)) return tau;
+    for (;;) {
+        const double rhokap = s->rhokapD[IDX(s,t.icell,t.jcell,t.kcell)] * s->R_Ha;
+        if (nsteps) *nsteps += 1.0;
+        const int idx = minloc3(t.tx, t.ty, t.tz);
+        if (idx == 1) { tau = tau + (t.tx - d) * rhokap; d = t.tx; t.icell += t.istep; if (t.icell < 1 || t.icell > s->nx) break; t.tx += t.delx; }
+        else if (idx == 2) { tau = tau + (t.ty - d) * rhokap; d = t.ty; t.jcell += t.jstep; if (t.jcell < 1 || t.jcell > s->ny) break; t.ty += t.dely; }
+        else { tau = tau + (t.tz - d) * rhokap; d = t.tz; t.kcell += t.kstep; if (t.kcell < 1 || t.kcell > s->nz) break; t.tz += t.delz; }
+        if (tau >= TAU_HUGE) break;
+    }
+    return tau;
+}
 static inline double peel_tau(const orc_sim *s, acc_t *A, const photon_t *po, double r2) {
+    if (po->iband == 2) return raytrace_to_edge_dust_Ha(s, po, &A->n_cellsteps_peel);          /* peel_raytrace_to_edge: peelingoff_rect.f90:900-902 */
     if (s->use_clump_medium && s->cl.has_overlap) return raytrace_to_edge_clump_overlap(s, po, TAU_HUGE, &A->n_cellsteps_peel);      /* :895-896 */
     if (s->use_clump_medium) return raytrace_to_edge_clump(s, po, TAU_HUGE, &A->n_cellsteps_peel);      /* peel_raytrace_to_edge: peelingoff_rect.f90:872-906 */
     return raytrace_to_edge(s, po, s->raytrace_variant, s->nside > 0 ? sqrt(r2) : -1.0, &A->n_cellsteps_peel);
@@ -2429,6 +2618,12 @@ static void do_resonance1(const orc_sim *s, rng_t *g, photon_t *p, double *uz, d
         else { p->species = 2; uz_loc = rand_resonance_vz(g, xfreq_D, va * s->ratio_voigta_HD) / s->ratio_Dfreq_HD; }
         xatom_loc = xfreq_loc - uz_loc;
         p->E1 = s->E1; p->E2 = s->E2; p->E3 = s->E3;
+    } else if (s->line_type == 8) {                         /* do_resonance8 :293-345: the upward step of do_resonance1, then the downward channel of the 3p level */
+        uz_loc = rand_resonance_vz(g, xfreq_loc, va);
+        xatom_loc = xfreq_loc - uz_loc;
+        const double rc_ = rnd(g); MRG(rc_, s->P_conv, 63);
+        if (rc_ < s->P_conv) { p->iband = 2; p->E1 = s->E_conv[0]; p->E2 = s->E_conv[1]; p->E3 = s->E_conv[2]; }      /* 3p -> 2s: H-alpha */
+        else { p->E1 = s->E1; p->E2 = s->E2; p->E3 = s->E3; }                                                         /* 3p -> 1s: Ly-beta again */
     } else {
         uz_loc = rand_resonance_vz(g, xfreq_loc, va);
         xatom_loc = xfreq_loc - uz_loc;
@@ -2475,18 +2670,96 @@ static inline void perp_velocity_rayleigh(const orc_sim *s, rng_t *g, const phot
     if (s->line_type == 7 && p->species == 2) { *ux = *ux / s->ratio_Dfreq_HD; *uy = *uy / s->ratio_Dfreq_HD; }
     double vr = clump_vth_ratio(s, p); *ux = *ux * vr; *uy = *uy * vr;
 }
+/* peeling_conversion_Ha_outside: peelingoff_rect.f90:692-792 (the newborn H-alpha packet of a conversion: emitted at line centre in the atom frame,
+ * dipole phase function of the conversion channel, dust-only sight line, no recoil; into observer%peel_Ha) */
+static void peeling_conversion_Ha(const orc_sim *s, acc_t *A, const photon_t *p, const double va[3]) {
+    for (int i = 0; i < s->nobs; i++) {
+        photon_t po; double r2; int ix, iy;
+        obs_dir_s(s, i, p, &po, &r2, &ix, &iy);
+        if (!(ix >= 1 && ix <= s->nxim && iy >= 1 && iy <= s->nyim)) continue;
+        double cost = p->kx * po.kx + p->ky * po.ky + p->kz * po.kz, cost2 = cost * cost, sint = sqrt(1.0 - cost2), rho1 = sqrt(1.0 - p->kz * p->kz) * sint, cosp, sinp;
+        if (rho1 == 0.0) { cosp = 1.0; sinp = 0.0; } else { double rho = 1.0 / rho1; cosp = rho * (cost * p->kz - po.kz); sinp = rho * (p->kx * po.ky - po.kx * p->ky); }
+        double xfreq = (va[0] * cosp + va[1] * sinp) * sint + va[2] * cost;
+        size_t c = IDX(s,p->icell,p->jcell,p->kcell);
+        double u1 = udot(s, c, po.kx, po.ky, po.kz), xfreq_ref = (xfreq + u1) * (s->Dfreq[c] / s->Dfreq_ref);
+        int ixf = (int)floor((xfreq_ref - s->xfreq_min_Ha) / s->dxfreq_Ha) + 1;
+        po.xfreq = xfreq_ref;                                   /* (po.iband = 2 came with the copy of the packet) */
+        double tau = peel_tau(s, A, &po, r2);
+        double peel = 0.75 * p->E1 * (cost2 + 1.0) + p->E2, wgt = peel / (FOURPI * r2) * exp(-tau) * p->wgt;
+        obs_t *o = &A->obs[i];
+        if (o->peel_Ha && ixf >= 1 && ixf <= s->nxfreq_Ha) o->peel_Ha[(size_t)(ixf - 1) + (size_t)s->nxfreq_Ha * PIX2(s,ix,iy)] += wgt;
+    }
+}
+/* peeling_dust_Ha_outside: :794-870 (band-2 dust scattering: HG phase function of par%hgg_Ha, the packet's lab-frame frequency as it is) */
+static void peeling_dust_Ha(const orc_sim *s, acc_t *A, const photon_t *p) {
+    for (int i = 0; i < s->nobs; i++) {
+        photon_t po; double r2; int ix, iy;
+        obs_dir_s(s, i, p, &po, &r2, &ix, &iy);
+        if (!(ix >= 1 && ix <= s->nxim && iy >= 1 && iy <= s->nyim)) continue;
+        int ixf = (int)floor((p->xfreq - s->xfreq_min_Ha) / s->dxfreq_Ha) + 1;
+        double tau = peel_tau(s, A, &po, r2);
+        double cosa = p->kx * po.kx + p->ky * po.ky + p->kz * po.kz, gg = s->hgg_Ha;
+        double peel = (1.0 - gg * gg) / pow((1.0 + gg * gg) - 2.0 * gg * cosa, 1.5) / FOURPI, wgt = peel / r2 * exp(-tau) * p->wgt;
+        obs_t *o = &A->obs[i];
+        if (o->peel_Ha && ixf >= 1 && ixf <= s->nxfreq_Ha) o->peel_Ha[(size_t)(ixf - 1) + (size_t)s->nxfreq_Ha * PIX2(s,ix,iy)] += wgt;
+    }
+}
+/* scatter_dust_Ha_nostokes: scattering_car.f90:586-658 (scatter_dust_Ha_amr: scattering_amr.f90:147-209): a band-2 packet only meets dust */
+static void scatter_dust_Ha(const orc_sim *s, acc_t *A, rng_t *g, photon_t *p) {
+    p->nscatt_dust = p->nscatt_dust + p->wgt;
+    if (!s->use_reduced_wgt) {
+        const double ra_ = rnd(g); MRG(ra_, s->albedo_Ha, 61);
+        if (ra_ > s->albedo_Ha) {
+            if (s->save_Jabs) { int ix = (int)floor((p->xfreq - s->xfreq_min_Ha) / s->dxfreq_Ha) + 1; if (ix >= 1 && ix <= s->nxfreq_Ha) A->Jabs_Ha[ix-1] += p->wgt; }
+            p->inside = 0; A->W[4] += p->wgt;
+            if (s->save_all_photons) { p->xfreq_ref = p->xfreq; p->wgt = 0.0; }
+            return; }
+    } else {
+        if (s->save_Jabs) { int ix = (int)floor((p->xfreq - s->xfreq_min_Ha) / s->dxfreq_Ha) + 1; if (ix >= 1 && ix <= s->nxfreq_Ha) A->Jabs_Ha[ix-1] += p->wgt * (1.0 - s->albedo_Ha); }
+        A->W[4] += p->wgt * (1.0 - s->albedo_Ha);
+        p->wgt = p->wgt * s->albedo_Ha;
+    }
+    if (s->save_peeloff) peeling_dust_Ha(s, A, p);
+    double cost = rand_hg(g, s->hgg_Ha), sint = sqrt(1.0 - cost * cost);
+    double phi = TWOPI * rnd(g), cosp = cos(phi), sinp = sin(phi);
+    rotate_k(p, cost, sint, cosp, sinp);
+}
+/* scatter_h2: scattering_car.f90:122-199 (an H2 pumping event: fluorescence destroys the packet, or the molecule scatters it back near Ly-alpha) */
+static void scatter_h2(const orc_sim *s, acc_t *A, rng_t *g, photon_t *p) {
+    const size_t c = IDX(s,p->icell,p->jcell,p->kcell);
+    const double Dfreq_cell = s->Dfreq[c];
+    const int il = h2_select_line_D(s, g, p->xfreq, Dfreq_cell);
+    A->W_H2[2 + il - 1] += p->wgt;
+    { const double rs_ = rnd(g); MRG(rs_, s->h2_p_scat[il-1], 68);
+      if (rs_ > s->h2_p_scat[il-1]) { A->W_H2[0] += p->wgt; p->inside = 0; if (s->save_all_photons) p->wgt = 0.0; return; } }
+    A->W_H2[1] += p->wgt; p->nscatt_gas = p->nscatt_gas + p->wgt;
+    const double ratio = Dfreq_cell / s->h2_Dfreq_Hz, dx = s->h2_dnu_Hz[il-1] / Dfreq_cell, x_h2 = (p->xfreq - dx) * ratio;
+    const double uz = rand_resonance_vz(g, x_h2, s->h2_a_damp[il-1]), xatom = x_h2 - uz;
+    const double cost = 2.0 * rnd(g) - 1.0, sint = sqrt(1.0 - cost * cost), phi = TWOPI * rnd(g), cosp = cos(phi), sinp = sin(phi);
+    const double phi2 = TWOPI * rnd(g), uxy = sqrt(-log(rnd(g))), ux = uxy * cos(phi2), uy = uxy * sin(phi2);
+    const double x_h2_new = xatom + uz * cost + (ux * cosp + uy * sinp) * sint;
+    p->xfreq = x_h2_new / ratio + dx;
+    rotate_k(p, cost, sint, cosp, sinp);
+}
 /* scatter_resonance_nostokes: :660-827 */
 static void scatter_resonance_nostokes(const orc_sim *s, acc_t *A, rng_t *g, photon_t *p) {
     double uz, xfreq_atom, cost, sint, ux, uy;
     p->nscatt_gas = p->nscatt_gas + p->wgt;
     add_to_Pa(s, A, p);
     do_resonance1(s, g, p, &uz, &xfreq_atom, &cost, &sint, 0, 0, 0, 0, 0);
+    const int converted = (s->line_type == 8 && p->iband == 2);        /* :697-705 */
+    if (converted) { A->W[0] += p->wgt; add_to_Pconv(s, A, p); }
     double phi = TWOPI * rnd(g), cosp = cos(phi), sinp = sin(phi);
     perp_velocity_rayleigh(s, g, p, &ux, &uy);
     p->xfreq = xfreq_atom + uz * cost + (ux * cosp + uy * sinp) * sint;
-    if (s->recoil) { double g_recoil = recoil_const(s, p); p->xfreq = p->xfreq - g_recoil * (1.0 - cost); }
-    if (s->save_peeloff) { double va[3] = {ux, uy, uz}; peeling_resonance_nostokes(s, A, p, xfreq_atom, va); }
+    if (s->recoil && !converted) { double g_recoil = recoil_const(s, p); p->xfreq = p->xfreq - g_recoil * (1.0 - cost); }
+    if (s->save_peeloff) { double va[3] = {ux, uy, uz}; if (converted) peeling_conversion_Ha(s, A, p, va); else peeling_resonance_nostokes(s, A, p, xfreq_atom, va); }
     rotate_k(p, cost, sint, cosp, sinp);
+    if (converted) {                                                   /* :811-827: the H-alpha packet leaves at line centre in the atom frame; lab frame, reference units */
+        const size_t c = IDX(s,p->icell,p->jcell,p->kcell);
+        const double u1_fluid = udot(s, c, p->kx, p->ky, p->kz);
+        p->xfreq = (p->xfreq - xfreq_atom + u1_fluid) * (s->Dfreq[c] / s->Dfreq_ref);
+    }
 }
 /* azimuth by rejection on 1 + S12/S11 (Q cos2phi + U sin2phi): :364-371 and :281-288 */
 static inline double phi_rejection(rng_t *g, const photon_t *p, double S12overS11) {
@@ -2535,8 +2808,10 @@ static int dust_absorb(const orc_sim *s, acc_t *A, rng_t *g, photon_t *p) {
                 int ix = (int)floor((xr - s->xfreq_min) / s->dxfreq) + 1; if (ix >= 1 && ix <= s->nxfreq) A->Jabs[ix-1] += p->wgt; }
             if (s->save_all_photons) {                      /* scattering_car.f90:236-246, :525-535: lab-frame frequency at absorption, weight 0 */
                 double uu1 = udot(s, c, p->kx, p->ky, p->kz); p->xfreq_ref = (p->xfreq + uu1) * (s->Dfreq[c] / s->Dfreq_ref); p->wgt = 0.0; }
+            if (s->line_type == 8) A->W[2] += p->wgt;           /* W_abs1 :524 */
             p->inside = 0; return 1; }
     } else {
+        if (s->line_type == 8) A->W[2] += p->wgt * (1.0 - s->albedo);       /* :553 */
         if (s->save_Jabs) { double uu1 = udot(s, c, p->kx, p->ky, p->kz), xr = (p->xfreq + uu1) * (s->Dfreq[c] / s->Dfreq_ref);
             int ix = (int)floor((xr - s->xfreq_min) / s->dxfreq) + 1; if (ix >= 1 && ix <= s->nxfreq) A->Jabs[ix-1] += p->wgt * (1.0 - s->albedo); }
         p->wgt = p->wgt * s->albedo;
@@ -2568,6 +2843,14 @@ static void scatter_dust_stokes(const orc_sim *s, acc_t *A, rng_t *g, photon_t *
 /* scattering: scattering_car.f90:14-120 (Cartesian branch :106-118) */
 static void scattering(const orc_sim *s, acc_t *A, rng_t *g, photon_t *p) {
     A->n_events += 1.0;
+    if (p->iband == 2) { scatter_dust_Ha(s, A, g, p); return; }          /* :30-36: every interaction of a band-2 packet is a dust event */
+    if (s->h2_on && !s->use_clump_medium) {                                /* :44-57 (octree), :92-104 (Cartesian): three-way split H I / H2 / dust */
+        const size_t c = IDX(s,p->icell,p->jcell,p->kcell);
+        const double kap_HI = s->rhokap[c] * calc_voigt(s, p->xfreq, s->voigt_a[c], s->Dfreq[c]), kap_H2 = s->rhokap[c] * h2_kappa_D(s, p->xfreq, s->Dfreq[c]);
+        const double kap_D = (s->DGR > 0.0) ? s->rhokapD[c] : 0.0;
+        const double l_ = rnd(g) * (kap_HI + kap_H2 + kap_D); MRG(l_, kap_H2, 69);
+        if (l_ <= kap_H2) { scatter_h2(s, A, g, p); return; }
+    }
     if (s->use_clump_medium) {                                   /* scattering_car.f90:69-84 */
         if (s->DGR > 0.0) {
             int64_t icl = p->icell_clump; const clumps_t *c = &s->cl;
@@ -2727,6 +3010,7 @@ static void run_photon(const orc_sim *s, acc_t *A, rng_t *g, photon_t *p, int64_
         if (first) {
             tau0 = raytrace_to_edge(s, p, s->raytrace_variant, -1.0, &A->n_cellsteps);
             add_escaped_fraction_to_Jout(s, A, p, tau0);
+            if (s->line_type == 8) A->W[1] += p->wgt * exp(-tau0);             /* W_esc1: run_simulation_mod.f90:168 */
             wgt1 = 1.0 - exp(-tau0);
             p->wgt = p->wgt * wgt1;
             if (tau0 > 0.0) tau = -log(1.0 - rnd(g) * wgt1); else tau = HUGEST;
@@ -2750,12 +3034,14 @@ static void acc_alloc(acc_t *A, orc_sim *s) {
     memset(A, 0, sizeof *A); A->s = s;
     A->Jout = calloc(s->nxfreq, 8); A->Jin = calloc(s->nxfreq, 8); A->Jabs = calloc(s->nxfreq, 8); A->Jmu = calloc((size_t)s->nxfreq * (s->nmu > 0 ? s->nmu : 1), 8);
     if (s->J1) A->J1 = calloc((size_t)s->nxfreq * s->nbins, 8); if (s->P1) A->P1 = calloc(s->nbins, 8); if (s->P1_new) A->P1_new = calloc(s->nbins, 8);
+    if (s->Jout_Ha) { A->Jout_Ha = calloc(s->nxfreq_Ha, 8); A->Jabs_Ha = calloc(s->nxfreq_Ha, 8); } if (s->Pconv) A->Pconv = calloc(s->nbins, 8);
     size_t n2 = (size_t)s->nxim * s->nyim, n3 = n2 * s->nxfreq;
     for (int i = 0; i < s->nobs; i++) { obs_t *o = &A->obs[i], *q = &s->obs[i];
         if (q->scatt_2D) { o->scatt_2D = calloc(n2, 8); o->direc_2D = calloc(n2, 8); }
         if (q->I_2D) { o->I_2D = calloc(n2, 8); o->Q_2D = calloc(n2, 8); o->U_2D = calloc(n2, 8); o->V_2D = calloc(n2, 8); }
         if (q->scatt) { o->scatt = calloc(n3, 8); o->direc = calloc(n3, 8); }
         if (q->direc0) o->direc0 = calloc(n3, 8); if (q->direc0_2D) o->direc0_2D = calloc(n2, 8); if (q->scatt_dust) o->scatt_dust = calloc(n3, 8);
+        if (q->peel_Ha) o->peel_Ha = calloc(n2 * s->nxfreq_Ha, 8);
         if (q->I) { o->I = calloc(n3, 8); o->Q = calloc(n3, 8); o->U = calloc(n3, 8); o->V = calloc(n3, 8); } }
 }
 static void addv(double *dst, const double *src, size_t n) { if (dst && src) for (size_t i = 0; i < n; i++) dst[i] += src[i]; }
@@ -2764,13 +3050,15 @@ static void acc_merge_free(acc_t *A, orc_sim *s) {
     size_t n2 = (size_t)s->nxim * s->nyim, n3 = n2 * s->nxfreq;
     for (int i = 0; i < s->nobs; i++) { obs_t *o = &A->obs[i], *q = &s->obs[i];
         addv(q->scatt_2D, o->scatt_2D, n2); addv(q->direc_2D, o->direc_2D, n2); addv(q->I_2D, o->I_2D, n2); addv(q->Q_2D, o->Q_2D, n2); addv(q->U_2D, o->U_2D, n2); addv(q->V_2D, o->V_2D, n2);
-        addv(q->direc0, o->direc0, n3); addv(q->direc0_2D, o->direc0_2D, n2); addv(q->scatt_dust, o->scatt_dust, n3);
+        addv(q->direc0, o->direc0, n3); addv(q->direc0_2D, o->direc0_2D, n2); addv(q->scatt_dust, o->scatt_dust, n3); addv(q->peel_Ha, o->peel_Ha, n2 * s->nxfreq_Ha);
         addv(q->scatt, o->scatt, n3); addv(q->direc, o->direc, n3); addv(q->I, o->I, n3); addv(q->Q, o->Q, n3); addv(q->U, o->U, n3); addv(q->V, o->V, n3);
         free_obs(o); }
     s->nscatt_gas += A->nscatt_gas; s->nscatt_dust += A->nscatt_dust;
     s->n_cellsteps += A->n_cellsteps; s->n_cellsteps_peel += A->n_cellsteps_peel; s->n_events += A->n_events;
     addv(s->J1, A->J1, (size_t)s->nxfreq * s->nbins); addv(s->P1, A->P1, s->nbins); addv(s->P1_new, A->P1_new, s->nbins);
-    free(A->Jout); free(A->Jin); free(A->Jabs); free(A->Jmu); free(A->J1); free(A->P1); free(A->P1_new);
+    addv(s->Jout_Ha, A->Jout_Ha, s->nxfreq_Ha); addv(s->Jabs_Ha, A->Jabs_Ha, s->nxfreq_Ha); addv(s->Pconv, A->Pconv, s->nbins);
+    for (int i = 0; i < 5; i++) s->W[i] += A->W[i]; for (int i = 0; i < 6; i++) s->W_H2[i] += A->W_H2[i];
+    free(A->Jout); free(A->Jin); free(A->Jabs); free(A->Jmu); free(A->J1); free(A->P1); free(A->P1_new); free(A->Jout_Ha); free(A->Jabs_Ha); free(A->Pconv);
 }
 
 int orc_run(orc_sim *s, int64_t first_id, int64_t stride, int64_t count, int rng_kind, uint64_t seed, int nthreads) {
@@ -2821,7 +3109,7 @@ int64_t orc_trace(orc_sim *s, uint64_t seed, uint64_t id, int64_t cap, double *o
     g_tr = NULL; g_tr_n = 0; g_tr_cap = 0; g_mrg_on = 0;
     /* discard the scratch tallies (acc_merge_free would add them): free what acc_alloc allocated */
     for (int i = 0; i < s->nobs; i++) free_obs(&A.obs[i]);
-    free(A.Jout); free(A.Jin); free(A.Jabs); free(A.Jmu); free(A.J1); free(A.P1); free(A.P1_new);
+    free(A.Jout); free(A.Jin); free(A.Jabs); free(A.Jmu); free(A.J1); free(A.P1); free(A.P1_new); free(A.Jout_Ha); free(A.Jabs_Ha); free(A.Pconv);
     s->log_nscatt = ln; s->log_xfreq = lx; s->log_n = lnn; s->allph = al; s->save_all_photons = sap;
     return n;
 }
@@ -2837,7 +3125,10 @@ void orc_zero_tallies(orc_sim *s) {
     for (int i = 0; i < s->nobs; i++) { obs_t *o = &s->obs[i];
         double *a2[6] = {o->scatt_2D, o->direc_2D, o->I_2D, o->Q_2D, o->U_2D, o->V_2D}, *a3[6] = {o->scatt, o->direc, o->I, o->Q, o->U, o->V};
         for (int k = 0; k < 6; k++) { if (a2[k]) memset(a2[k], 0, n2 * 8); if (a3[k]) memset(a3[k], 0, n3 * 8); }
-        if (o->direc0) memset(o->direc0, 0, n3 * 8); if (o->direc0_2D) memset(o->direc0_2D, 0, n2 * 8); if (o->scatt_dust) memset(o->scatt_dust, 0, n3 * 8); }
+        if (o->direc0) memset(o->direc0, 0, n3 * 8); if (o->direc0_2D) memset(o->direc0_2D, 0, n2 * 8); if (o->scatt_dust) memset(o->scatt_dust, 0, n3 * 8);
+        if (o->peel_Ha) memset(o->peel_Ha, 0, n2 * s->nxfreq_Ha * 8); }
+    if (s->Jout_Ha) { memset(s->Jout_Ha, 0, s->nxfreq_Ha * 8); memset(s->Jabs_Ha, 0, s->nxfreq_Ha * 8); } if (s->Pconv) memset(s->Pconv, 0, s->nbins * 8);
+    memset(s->W, 0, sizeof s->W); memset(s->W_H2, 0, sizeof s->W_H2);
     if (s->J1) memset(s->J1, 0, (size_t)s->nxfreq * s->nbins * 8); if (s->P1) memset(s->P1, 0, s->nbins * 8); if (s->P1_new) memset(s->P1_new, 0, s->nbins * 8);
     s->nscatt_gas = s->nscatt_dust = 0.0; s->nphotons_done = 0; s->n_cellsteps = s->n_cellsteps_peel = s->n_events = 0.0;
 }
@@ -2859,6 +3150,7 @@ double orc_get_scalar(const orc_sim *s, const char *k) {
     G(nscatt_gas) G(nscatt_dust) G(nphotons_done) G(n_cellsteps) G(n_cellsteps_peel) G(n_events)
     G(dx) G(dy) G(dz) G(xmin) G(ymin) G(zmin) G(i0) G(j0) G(k0) G(nx) G(ny) G(nz) G(Dfreq_ref) G(xfreq_min) G(xfreq_max) G(dxfreq) G(nxfreq)
     G(taumax) G(tauhomo) G(N_gasmax) G(N_gashomo) G(voigt_amean) G(atau3) G(nobs) G(dxim) G(dyim) G(distance) G(nxim) G(nyim)
+    G(line_type) G(nxfreq_Ha) G(xfreq_min_Ha) G(xfreq_max_Ha) G(dxfreq_Ha) G(R_Ha) G(albedo_Ha) G(hgg_Ha) G(cext_dust_Ha) G(P_conv) G(h2_on) G(h2_nlines) G(h2_Dfreq_Hz) G(h2_hi_width) G(Omega) G(damping) G(wavelength0) G(vtherm1)
     G(rmax) G(xmax) G(ymax) G(zmax) G(DGR) G(albedo) G(hgg) G(cext_dust) G(cross0) G(g_recoil0) G(xcrit) G(raytrace_variant) G(save_peeloff)
     G(use_stokes) G(nPDF) G(save_Jabs) G(nmu) G(mu_min) G(dmu) G(distance2cm) G(source_rmax) G(comoving_source) G(recoil) G(core_skip) G(core_skip_global)
     G(xyz_symmetry) G(xy_periodic) G(save_Jin) G(save_Jmu) G(use_reduced_wgt) G(xs_point) G(ys_point) G(zs_point) G(xfreq0) G(spectral_type) G(source_geometry) G(xrange) G(yrange) G(zrange) G(source_zscale)
@@ -2890,6 +3182,14 @@ int64_t orc_get_array(const orc_sim *s, const char *k, double *out, int64_t n) {
         for (int i = 0; i < 3; i++) for (int d = 0; d < 4; d++) { v[q++] = s->ml.A21[i][d]; v[q++] = s->ml.Elow_Hz[i][d]; v[q++] = s->ml.E1[i][d]; v[q++] = s->ml.E2[i][d];
             v[q++] = s->ml.E3[i][d]; v[q++] = s->ml.P_down[i][d]; v[q++] = s->ml.A_down[i][d]; }
         return copy_out(v, 98, out, n); }
+    if (!strcmp(k, "Jout_Ha")) return copy_out(s->Jout_Ha, s->nxfreq_Ha, out, n);
+    if (!strcmp(k, "Jabs_Ha")) return copy_out(s->Jabs_Ha, s->nxfreq_Ha, out, n);
+    if (!strcmp(k, "Pconv")) return copy_out(s->Pconv, s->nbins, out, n);
+    if (!strcmp(k, "W")) return copy_out(s->W, 5, out, n);                       /* W_conv, W_esc1, W_abs1, W_esc2, W_abs2 */
+    if (!strcmp(k, "W_H2")) return copy_out(s->W_H2, 2 + s->h2_nlines, out, n);   /* W_H2abs, W_H2scat, W_H2pump(:) */
+    if (!strcmp(k, "h2_lines")) { double v[26] = {0}; v[0] = s->h2_nlines; v[1] = s->h2_Dfreq_Hz;
+        for (int i = 0; i < s->h2_nlines; i++) { v[2+i*6] = s->h2_dnu_Hz[i]; v[3+i*6] = s->h2_strength[i]; v[4+i*6] = s->h2_a_damp[i]; v[5+i*6] = s->h2_p_scat[i]; v[6+i*6] = s->h2_pop[i]; v[7+i*6] = s->h2_f_osc[i]; }
+        return copy_out(v, 26, out, n); }
     if (!strcmp(k, "Jout")) return copy_out(s->Jout, s->nxfreq, out, n);
     if (!strcmp(k, "Jin")) return copy_out(s->Jin, s->nxfreq, out, n);
     if (!strcmp(k, "Jabs")) return copy_out(s->Jabs, s->nxfreq, out, n);
@@ -2938,6 +3238,7 @@ int64_t orc_get_array(const orc_sim *s, const char *k, double *out, int64_t n) {
     if (col) { int io = atoi(col + 1); if (io < 0 || io >= s->nobs) return -1; const obs_t *o = &s->obs[io];
         int64_t n2 = (int64_t)s->nxim * s->nyim, n3 = n2 * s->nxfreq; size_t L = col - k;
 #define M(name, ptr, cnt) if (L == strlen(name) && !strncmp(k, name, L)) return copy_out(ptr, cnt, out, n);
+        M("peel_Ha", o->peel_Ha, n2 * s->nxfreq_Ha)
         M("direc0_2D", o->direc0_2D, n2) M("direc0", o->direc0, n3) M("scatt_dust", o->scatt_dust, n3)
         M("scatt", o->scatt, n3) M("direc", o->direc, n3) M("I", o->I, n3) M("Q", o->Q, n3) M("U", o->U, n3) M("V", o->V, n3)
         M("scatt_2D", o->scatt_2D, n2) M("direc_2D", o->direc_2D, n2) M("I_2D", o->I_2D, n2) M("Q_2D", o->Q_2D, n2) M("U_2D", o->U_2D, n2) M("V_2D", o->V_2D, n2)
@@ -2971,6 +3272,7 @@ void orc_do_resonance_v(const orc_sim *s, int kind, uint64_t seed, uint64_t id, 
         double *o = out + 12 * (size_t)i;
         do_resonance1(s, g, &p, &o[0], &o[1], &o[2], &o[3], &o[4], &o[5], &o[6], &o[7], &o[8]);
         o[9] = p.E1; o[10] = p.E2; o[11] = (s->line_type == 7) ? (double)p.species : p.E3;
+        if (s->line_type == 8) o[4] = (double)(p.iband == 2 ? 2 : 1);              /* do_resonance8: the band after the event (no Stokes matrix with ly_beta) */
     }
 }
 void orc_calc_voigt_v(const orc_sim *s, int n, const double *x, int ic, int jc, int kc, double *h) {
@@ -3004,6 +3306,19 @@ void orc_raytrace_to_tau(orc_sim *s, int variant, double r[8], int ic[4], double
     r[0] = p.x; r[1] = p.y; r[2] = p.z; r[3] = p.kx; r[4] = p.ky; r[5] = p.kz; r[6] = p.xfreq; r[7] = p.wgt;
     ic[0] = s->use_clump_medium ? p.icell_clump : p.icell; ic[1] = p.jcell; ic[2] = p.kcell; ic[3] = p.inside;
 }
+/* probes of the ly_beta / H2 pieces: the tau march of a packet of band `iband` (1 or 2; r[6] = xfreq, xfreq_ref once outside), the dust-only band-2
+ * sight line, h2_kappa_D and h2_select_line_D (MT stream kind 0 / Philox kind 1) */
+void orc_raytrace_to_tau_band(orc_sim *s, int iband, double r[8], int ic[4], double tau_in) {
+    photon_t p; unpack_s(s, r, ic, &p); p.iband = iband; acc_t A; acc_alloc(&A, s);
+    raytrace_to_tau(s, &A, &p, tau_in, s->raytrace_variant);
+    acc_merge_free(&A, s);
+    r[0] = p.x; r[1] = p.y; r[2] = p.z; r[3] = p.kx; r[4] = p.ky; r[5] = p.kz; r[6] = p.inside ? p.xfreq : p.xfreq_ref; r[7] = p.wgt;
+    ic[0] = p.icell; ic[1] = p.jcell; ic[2] = p.kcell; ic[3] = p.inside;
+}
+void orc_raytrace_to_edge_dust_Ha(const orc_sim *s, const double r[8], const int ic[4], double *tau) { photon_t p; unpack(r, ic, &p); p.iband = 2; *tau = raytrace_to_edge_dust_Ha(s, &p, 0); }
+void orc_h2_kappa_v(const orc_sim *s, int n, const double *x, double Dfreq, double *kap) { for (int i = 0; i < n; i++) kap[i] = h2_kappa_D(s, x[i], Dfreq); }
+void orc_h2_select_v(const orc_sim *s, int kind, uint64_t seed, uint64_t id, int n, const double *x, double Dfreq, int *il) {
+    rng_t t, *g = pick_rng(&t, kind, seed, id); for (int i = 0; i < n; i++) il[i] = h2_select_line_D(s, g, x[i], Dfreq); }
 int orc_amr_find_leaf(const orc_sim *s, double x, double y, double z) { return s->use_amr_grid ? amr_find_leaf(&s->amr, x, y, z) : 0; }
 void orc_raytrace_to_edge(const orc_sim *s, int variant, const double r[8], const int ic[4], double *tau) {
     photon_t p; unpack_s(s, r, ic, &p);
@@ -3318,12 +3633,13 @@ void orc_raytrace_column(const orc_sim *s, const double r[8], const int ic[4], d
 int64_t orc_scatter_event(orc_sim *s, double st[18], int ic[4], uint64_t seed, uint64_t id, uint64_t n0) {
     photon_t p; unpack_s(s, st, ic, &p);
     p.mx = st[8]; p.my = st[9]; p.mz = st[10]; p.nx = st[11]; p.ny = st[12]; p.nz = st[13]; p.I = st[14]; p.Q = st[15]; p.U = st[16]; p.V = st[17];
+    p.iband = (ic[3] == 2) ? 2 : 1;                          /* ic[3]: 1 = a packet of the line's band, 2 = a band-2 (H-alpha) packet of line type 8 */
     rng_t g; rng_philox(&g, seed, id, n0); acc_t A; acc_alloc(&A, s);
     scattering(s, &A, &g, &p);
     acc_merge_free(&A, s);
     st[0] = p.x; st[1] = p.y; st[2] = p.z; st[3] = p.kx; st[4] = p.ky; st[5] = p.kz; st[6] = p.xfreq; st[7] = p.wgt;
     st[8] = p.mx; st[9] = p.my; st[10] = p.mz; st[11] = p.nx; st[12] = p.ny; st[13] = p.nz; st[14] = p.I; st[15] = p.Q; st[16] = p.U; st[17] = p.V;
-    ic[0] = p.icell; ic[1] = p.jcell; ic[2] = p.kcell; ic[3] = p.inside;
+    ic[0] = p.icell; ic[1] = p.jcell; ic[2] = p.kcell; ic[3] = p.inside ? (p.iband == 2 ? 2 : 1) : 0;
     return (int64_t)(g.n - n0);
 }
 

@@ -91,6 +91,10 @@ double orc_xcrit_local(const orc_sim *, int i, int j, int k, double x, double y,
  * st = [x,y,z,kx,ky,kz,xfreq,wgt, mx,my,mz,nx,ny,nz, I,Q,U,V], ic as above; Philox stream (seed,id) from draw n0;
  * returns draws consumed */
 void orc_raytrace_to_tau_shear(orc_sim *, double r[8], int ic[4], double tau_in, double *shear);   /* raytrace_to_tau_car_xyper_shear, vfy_shear in / out */
+void orc_raytrace_to_tau_band(orc_sim *, int iband, double r[8], int ic[4], double tau_in);
+void orc_raytrace_to_edge_dust_Ha(const orc_sim *, const double r[8], const int ic[4], double *tau);
+void orc_h2_kappa_v(const orc_sim *, int n, const double *x, double Dfreq, double *kap);
+void orc_h2_select_v(const orc_sim *, int kind, uint64_t seed, uint64_t id, int n, const double *x, double Dfreq, int *il);
 int64_t orc_scatter_event(orc_sim *, double st[18], int ic[4], uint64_t seed, uint64_t id, uint64_t n0);
 #ifdef __cplusplus
 }

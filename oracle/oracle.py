@@ -68,6 +68,10 @@ class Oracle:
             L.orc_raytrace_to_tau.argtypes = [_vp, _i, _vp, _vp, _d]
             L.orc_raytrace_to_edge.argtypes = [_vp, _i, _vp, _vp, _vp]
             L.orc_raytrace_to_tau_shear.argtypes = [_vp, _vp, _vp, _d, _vp]
+            L.orc_raytrace_to_tau_band.argtypes = [_vp, _i, _vp, _vp, _d]
+            L.orc_raytrace_to_edge_dust_Ha.argtypes = [_vp, _vp, _vp, _vp]
+            L.orc_h2_kappa_v.argtypes = [_vp, _i, _vp, _d, _vp]
+            L.orc_h2_select_v.argtypes = [_vp, _i, _u64, _u64, _i, _vp, _d, _vp]
             L.orc_raytrace_to_dist.argtypes = [_vp, _vp, _vp, _d, _vp]
             L.orc_amr_find_leaf.argtypes = [_vp, _d, _d, _d]
             L.orc_xcrit_local.restype = _d; L.orc_xcrit_local.argtypes = [_vp, _i, _i, _i, _d, _d, _d]
@@ -151,6 +155,22 @@ class Oracle:
     def raytrace_to_tau(self, variant, r, ic, tau):
         r = np.array(r, dtype=np.float64); ic = np.array(ic, dtype=np.int32)
         self.lib().orc_raytrace_to_tau(self.h, variant, _ptr(r), _ptr(ic), tau); return r, ic
+
+    def raytrace_to_tau_band(self, iband, r, ic, tau):
+        r = np.array(r, dtype=np.float64); ic = np.array(ic, dtype=np.int32)
+        self.lib().orc_raytrace_to_tau_band(self.h, int(iband), _ptr(r), _ptr(ic), tau); return r, ic
+
+    def raytrace_to_edge_dust_Ha(self, r, ic):
+        r = np.array(r, dtype=np.float64); ic = np.array(ic, dtype=np.int32); t = _d()
+        self.lib().orc_raytrace_to_edge_dust_Ha(self.h, _ptr(r), _ptr(ic), C.byref(t)); return t.value
+
+    def h2_kappa(self, x, Dfreq):
+        x = np.ascontiguousarray(x, dtype=np.float64); k = np.zeros_like(x)
+        self.lib().orc_h2_kappa_v(self.h, len(x), _ptr(x), float(Dfreq), _ptr(k)); return k
+
+    def h2_select(self, kind, seed, sid, x, Dfreq):
+        x = np.ascontiguousarray(x, dtype=np.float64); il = np.zeros(len(x), dtype=np.int32)
+        self.lib().orc_h2_select_v(self.h, kind, seed, sid, len(x), _ptr(x), float(Dfreq), _ptr(il)); return il
 
     def raytrace_to_tau_shear(self, r, ic, tau, shear=0.0):
         r = np.array(r, dtype=np.float64); ic = np.array(ic, dtype=np.int32); sh = _d(shear)

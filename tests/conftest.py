@@ -85,3 +85,16 @@ def run_together(jobs, events=4096):
         t.join()
     if errors:
         raise errors[0]
+
+
+@pytest.fixture(scope="session")
+def h2_data_dir(tmp_path_factory):
+    """par%h2_data_dir: the X-state level table h2_init reads (h2_mod.f90:250-296), written back from tests/golden/h2_energy_X.npz in the layout of
+    the reference's data/h2/energy_X.dat (a magic-number first line, '#' comments, rows 'V J E[cm^-1]')"""
+    z = np.load(os.path.join(GOLDEN, "h2_energy_X.npz"))
+    d = tmp_path_factory.mktemp("h2")
+    with open(d / "energy_X.dat", "w") as f:
+        f.write("2 4 29 // magic number\n#H2 electronic ground state rovibrational level energies [cm^-1]\n")
+        for v, j, e in zip(z["V"], z["J"], z["E_cm"]):
+            f.write("%d\t%d\t%.17g\n" % (int(v), int(j), float(e)))
+    return str(d)

@@ -1,19 +1,25 @@
 """Divergence audit of the photon-by-photon parity tests.
 
-Device and oracle run the same counter-based streams (seed, photon id), so whole histories are identical -- except where a
-last-bit difference (FMA contraction, libm) flips one data-dependent comparison, after which the two histories consume different
-draws and have nothing in common any more.  The photon-by-photon tests used to forgive 3-5 % of mismatching photons without
-looking at them; a real bug that hits a rare branch would hide in that allowance.  Here every mismatching photon is examined:
+Device and oracle run the same counter-based streams (seed, photon id), so whole histories are identical -- except where a last-bit difference
+(FMA contraction, libm) flips one data-dependent comparison, after which the two histories consume different draws and have nothing in common
+any more.  The photon-by-photon tests used to forgive 3-5 % of mismatching photons without looking at them; a real bug that hits a rare branch
+would hide in that allowance.  Here every photon whose logged scattering count or exit frequency differs is examined:
 
-  * both sides record the state after the birth and after every event (lart_gpu_test_trace / orc_trace: draws consumed, frequency,
-    position, cell, direction, kind of event);
-  * the first record in which the two histories differ is located (an integer comparison of the draw counters and cells, 1e-7
-    on the floating-point state);
-  * the oracle's record of THAT event carries the smallest margin of all comparisons the event made (oracle/lart_oracle.c,
-    mrg_note: relative distance of the two compared numbers, divided by the condition number of the acceptance window of the
-    wing sampler, which is a difference of two arctangents).  The divergence is explained when that margin is at rounding level.
+  * both sides record the state after the birth and after every event (lart_gpu_test_trace / orc_trace: draws consumed, frequency, position,
+    cell or owner clump, direction, kind of event);
+  * the first record in which the two histories differ DISCRETELY (draw counter, cell, kind) is located;
+  * the oracle's record of THAT event carries the smallest margin of all comparisons the event made (oracle/lart_oracle.c, mrg_note: relative
+    distance of the two compared numbers, divided by the condition number of the acceptance window of the wing sampler, a difference of two
+    arctangents).  The divergence is explained when that margin is at rounding level (MARGIN) -- see audit() for the allowance in chaotic media.
 
-Any mismatching photon whose first divergent event has no comparison within MARGIN of its threshold fails the test.
+What the audit found (MI355X, 1e5 photons per case, profiles/r03_divergence_audit.txt): in every Cartesian and octree case (12 + 3 configurations:
+plain, octant, slab, quadrant, periodic box, dust HG / Mueller, Stokes, recoil, outflows, doublet, H + D, He I triplet, core-skip) there is NOT ONE
+discrete divergence; the 1-17 photons per 1e5 whose logs differ have identical histories and differ in the last digits of the weight
+1 - exp(-tau0) of the forced first scattering (a packet born in the far wing has a tiny tau0; the subtraction cancels on both sides).  In the
+clump media 0.1-0.7 % of the histories do part: flights between spheres are a Sinai billiard, the positions of two arithmetically equivalent
+marches drift apart geometrically from rounding level and finally flip a hit / miss (comparisons 46-48, 53, 54); the drift never jumps.
+
+Any mismatching photon that is not explained in this way fails the test.
 References: run_simulation_mod.f90:150-202 (loop), random_mt.f90:2562-2696 (rejection sampler), raytrace_car.f90:1485-1596,
 raytrace_amr.f90:77-259, raytrace_clump.f90:83-201, 668-788, scattering_car.f90:14-120."""
 import numpy as np
@@ -33,31 +39,66 @@ def capi():
     return capi
 
 
-def first_difference(dev, nd, orc, no):
-    """index of the first record in which the two histories differ (None: one is a prefix of the other and both end there)"""
+def state_distance(dev, orc, length):
+    """relative distance of the floating-point state of two records (position in units of `length`: the clump radius or 1, frequency, direction);
+    the frequency of a packet that was absorbed is not defined (the oracle logs 0) and is left out"""
+    d, o = dev, orc[:, :W]
+    dpos = np.abs(d[:, 2:5] - o[:, 2:5]).max(axis=1) / length
+    skipx = (d[:, 7] == 2) & ((o[:, 1] == 0.0) | (d[:, 1] == 0.0))
+    dx = np.where(skipx, 0.0, np.abs(d[:, 1] - o[:, 1]) / np.maximum(1.0, np.abs(o[:, 1])))
+    return np.maximum(np.maximum(dpos, dx), np.abs(d[:, 6] - o[:, 6]))
+
+
+def first_difference(dev, nd, orc, no, length=1.0):
+    """(i, drift): index of the first record in which the two histories differ DISCRETELY -- draws consumed, cell / owner clump, kind of event --
+    or, failing that, by more than 1e-7 in the floating-point state of a medium whose marches are not chaotic; drift = the state distance of the
+    record before it (the allowance a flipped comparison gets, see audit).  i = None: one history is a prefix of the other and both end there"""
     m = min(nd, no, len(dev), len(orc))
-    d, o = dev[:m], orc[:m, :W]
-    bad = (d[:, 0] != o[:, 0]) | (d[:, 5] != o[:, 5]) | (d[:, 7] != o[:, 7])
-    bad |= ~np.isclose(d[:, 1], o[:, 1], rtol=1e-7, atol=1e-9) | ~np.isclose(d[:, 6], o[:, 6], rtol=1e-7, atol=1e-9)
-    bad |= ~np.all(np.isclose(d[:, 2:5], o[:, 2:5], rtol=1e-7, atol=1e-9), axis=1)
+    d, o = dev[:m], orc[:m]
+    delta = state_distance(d, o, length)
+    # (the draw counter of a packet that has left is not compared: the overlap forms take the owner-clump draw of sample_owner_clump before the
+    #  march -- transport_kernel.hpp, fly() -- so a packet that escapes instead has consumed one draw it never uses)
+    bad = ((d[:, 0] != o[:, 0]) & ~((d[:, 7] == 2) & (o[:, 7] == 2))) | (d[:, 5] != o[:, 5]) | (d[:, 7] != o[:, 7])
+    if length == 1.0:
+        bad |= delta > 1e-7
     i = np.nonzero(bad)[0]
     if len(i):
-        return int(i[0])
-    return None if nd == no else m
+        i = int(i[0]); return i, (float(delta[i - 1]) if i > 0 else 0.0), float(delta[:i].max()) if i > 0 else 0.0
+    return (None, 0.0, float(delta.max()) if m else 0.0) if nd == no else (m, float(delta[m - 1]) if m else 0.0, float(delta.max()) if m else 0.0)
 
 
-def audit(sim, o, n, seed, label, budget_bytes=1 << 30):
-    """run n photons on both sides, then explain every mismatching photon; returns (fraction of identical histories, report)"""
+def drift_jumps(dev, orc, upto, length, floor=1e-11, growth=1e3, cond=1e-3):
+    """events before record `upto` in which the distance of the two states grows by more than `growth` x (from above `floor`) although every
+    comparison of the event was farther than `cond` from its threshold: a drift may only grow geometrically through ill-conditioned encounters
+    (a ray grazing a sphere: comparison 47), it must not jump -- a jump is two different formulas, not rounding"""
+    m = min(upto, len(dev), len(orc))
+    if m < 2:
+        return []
+    delta = state_distance(dev[:m], orc[:m], length)
+    prev = np.maximum(delta[:-1], floor)
+    j = np.nonzero((delta[1:] > growth * prev) & (orc[1:m, 8] > cond))[0] + 1
+    return [(int(q), float(delta[q - 1]), float(delta[q]), float(orc[q, 8]), int(orc[q, 9])) for q in j]
+
+
+def audit(sim, o, n, seed, label, budget_bytes=1 << 30, length=1.0):
+    """run n photons on both sides, then explain every mismatching photon; returns (fraction of identical histories, unexplained, report).
+
+    A mismatching photon is explained when
+      (a) its two histories are discretely identical to the end (same draws, same cells, same events): the logs differ by the rounding of the
+          weight 1 - exp(-tau0) of the forced first scattering or by the drift below; or
+      (b) the first discrete difference happens in an event whose smallest comparison margin (oracle, mrg_note) is below MARGIN, or below 1e3 x the
+          distance of the two states just before that event.  The second clause matters in the clump medium only: flights between spheres are a
+          Sinai billiard, every ray-sphere encounter multiplies a position difference, so two arithmetically equivalent marches drift apart
+          geometrically from rounding level (measured: 1e-15 -> 1e-8 of the box in 3000 events) until the drift flips a hit / miss decision;
+          `length` = the clump radius puts that drift on the scale the decisions see."""
     sim.ctx.enable_photon_log(True)
     sim.run_simulation(n, seed=seed)
     ng, xg = sim.ctx.photon_log(n)
     o.run(n, seed=seed); no, xo = o.photon_log()
-    same = np.isclose(ng, no, rtol=1e-12, atol=0) & (np.isclose(xg, xo, rtol=1e-7, atol=1e-9) | ((xo == 0) & (xg == 0)))
+    same = np.isclose(ng, no, rtol=1e-12, atol=0) & (np.isclose(xg, xo, rtol=1e-7, atol=1e-9) | (xo == 0))      # (an absorbed packet has no exit frequency: the oracle logs 0)
     bad = np.nonzero(~same)[0]
-    unexplained, ids, margins = [], [], []
+    unexplained, ids, margins, drifts, n_same_history = [], [], [], [], 0
     if len(bad):
-        # records needed per photon: up to the first difference, which lies within the shorter history; weights are <= 1 per event,
-        # so ceil(nscatt) + 3 bounds the record count of a history from below only for unit weights -- take a generous cap and batches
         est = (np.minimum(ng[bad], no[bad]) * 1.05 + 64).astype(np.int64)
         order = np.argsort(est)
         bad, est = bad[order], est[order]
@@ -72,17 +113,27 @@ def audit(sim, o, n, seed, label, budget_bytes=1 << 30):
             tr, nrec = sim.ctx.test_trace(n, sel, cap, seed)
             for j, k in enumerate(sel):
                 otr, on = o.trace(seed, int(k) + 1, cap)
-                i = first_difference(tr[j], int(nrec[j]), otr, on)
-                if i is None or i >= len(otr):
-                    unexplained.append((int(k), -1, 0.0, 0)); continue       # histories agree as far as recorded, yet the logs differ
+                i, drift, drift_max = first_difference(tr[j], int(nrec[j]), otr, on, length)
+                if i is None:                                   # (a): the same history; the logged weight sum / exit frequency differ by rounding or drift only
+                    n_same_history += 1
+                    # (the weight of the forced first scattering is 1 - exp(-tau0), run_simulation_mod.f90:169: for a packet born in the far wing tau0 is
+                    #  tiny and the subtraction loses log10(1 / tau0) digits on both sides alike; every later nscatt increment carries that weight)
+                    if not (np.isclose(ng[k], no[k], rtol=1e-6, atol=0) and (xo[k] == 0 or np.isclose(xg[k], xo[k], rtol=1e-6 + 10 * drift_max, atol=1e-9))):
+                        unexplained.append((int(k), -1, drift_max, 0))
+                    continue
+                if i >= len(otr) or i >= cap:
+                    unexplained.append((int(k), -2, 0.0, 0)); continue       # the difference lies beyond what was recorded
                 mg, mid = float(otr[i, 8]), int(otr[i, 9])
-                ids.append(mid); margins.append(mg)
-                if not mg < MARGIN:
-                    unexplained.append((int(k), i, mg, mid))
+                ids.append(mid); margins.append(mg); drifts.append(drift)
+                if not mg < max(MARGIN, 1e3 * drift):
+                    unexplained.append((int(k), i, mg, mid, drift))
+                jumps = drift_jumps(tr[j], otr, i, length)
+                if jumps:
+                    unexplained.append((int(k), "drift jump", jumps[:3]))
             i0 = i1
-    rep = "%s: %d photons, %.3f %% identical histories, %d divergent; comparison ids %s; margins max %.2e median %.2e" % (
-        label, n, 100.0 * same.mean(), len(bad), dict(zip(*[a.tolist() for a in np.unique(ids, return_counts=True)])) if ids else {},
-        max(margins) if margins else 0.0, float(np.median(margins)) if margins else 0.0)
+    rep = "%s: %d photons, %.3f %% identical logs, %d mismatching of which %d with identical histories (weight rounding); flipped comparisons by id %s; margins max %.2e median %.2e; drift before the flip max %.2e" % (
+        label, n, 100.0 * same.mean(), len(bad), n_same_history, dict(zip(*[a.tolist() for a in np.unique(ids, return_counts=True)])) if ids else {},
+        max(margins) if margins else 0.0, float(np.median(margins)) if margins else 0.0, max(drifts) if drifts else 0.0)
     print(rep)
     return same.mean(), unexplained, rep
 
@@ -163,7 +214,7 @@ OVERLAP = dict(use_clump_medium=True, rmax=1.0, clump_radius=0.3, clump_f_cov=2.
 def test_clump_divergences_are_rounding_flips(capi, oracle_mod, base, extra, n):
     kw = dict(base, **extra)                               # (the oracle gets par%iseed too: it seeds the clump placement)
     sim = make(kw); o = oracle_mod.Oracle(**kw)
-    frac, unexplained, rep = audit(sim, o, n, 11, "clump " + str(extra))
+    frac, unexplained, rep = audit(sim, o, n, 11, "clump " + str(extra), length=float(kw["clump_radius"]))
     assert not unexplained, (rep, unexplained[:10])
 
 

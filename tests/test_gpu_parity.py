@@ -136,7 +136,7 @@ def test_shearing_box_histories_photon_by_photon(capi, oracle_mod, extra, n):
     assert int(o.scalar("raytrace_variant")) == 8
     ng, xg = sim.ctx.photon_log(n); no, xo = o.photon_log()
     same = np.isclose(ng, no, rtol=1e-12, atol=0) & np.isclose(xg, xo, rtol=1e-7, atol=1e-9)
-    assert same.mean() > 0.97, same.mean()
+    assert same.mean() > 0.999, same.mean()
     assert t["nphotons_done"] == n and rms_diff(t["Jout"], o.array("Jout")) < 0.01
     plain = make(dict(kw, Omega=0.0)); plain.ctx.enable_photon_log(True); plain.run_simulation(n)       # the shear matters: without it the spectrum is narrower
     xp = plain.ctx.photon_log(n)[1]
@@ -237,7 +237,7 @@ def test_short_histories_photon_by_photon(capi, oracle_mod, kw, n):
     ng, xg = sim.ctx.photon_log(n); no, xo = o.photon_log()
     # nscatt is a WEIGHT sum (forced first scattering: wgt = 1 - exp(-tau0)), so equal up to the libm exp() last bit
     same = np.isclose(ng, no, rtol=1e-12, atol=0) & np.isclose(xg, xo, rtol=1e-7, atol=1e-9)
-    assert same.mean() > 0.97, same.mean()
+    assert same.mean() > 0.999, same.mean()
     assert t["nphotons_done"] == n
     assert np.abs(t["Jin"] - o.array("Jin")).sum() <= 4          # same births, same bins (a bin edge may flip on the last bit)
     assert rms_diff(t["Jout"], o.array("Jout")) < 0.01
@@ -257,7 +257,7 @@ def test_xy_symmetric_and_periodic_histories_photon_by_photon(capi, oracle_mod, 
     assert int(o.scalar("raytrace_variant")) == (6 if kw.get("xy_periodic") else 5)
     ng, xg = sim.ctx.photon_log(n); no, xo = o.photon_log()
     same = np.isclose(ng, no, rtol=1e-12, atol=0) & np.isclose(xg, xo, rtol=1e-7, atol=1e-9)
-    assert same.mean() > 0.97, same.mean()
+    assert same.mean() > 0.999, same.mean()
     assert t["nphotons_done"] == n and rms_diff(t["Jout"], o.array("Jout")) < 0.01
     assert np.isclose(t["n_cellsteps"], o.scalar("n_cellsteps"), rtol=0.02)
     if kw.get("save_Jmu"):
@@ -372,7 +372,7 @@ def test_multiplets_peel_and_clumps_whole_path(capi, oracle_mod):
         o = oracle_mod.Oracle(**kw); o.run(n, seed=seed)
         ng, xg = sim.ctx.photon_log(n); no, xo = o.photon_log()
         same = np.isclose(ng, no, rtol=1e-12, atol=0) & np.isclose(xg, xo, rtol=1e-7, atol=1e-9)
-        assert same.mean() > 0.97 and rms_diff(t["Jout"], o.array("Jout")) < 0.01, lid
+        assert same.mean() > 0.999 and rms_diff(t["Jout"], o.array("Jout")) < 0.01, lid
 
 
 def test_deuterium_peel_and_clumps_whole_path(capi, oracle_mod):
@@ -394,7 +394,7 @@ def test_deuterium_peel_and_clumps_whole_path(capi, oracle_mod):
     o = oracle_mod.Oracle(**kw); o.run(n, seed=96)
     ng, xg = sim.ctx.photon_log(n); no, xo = o.photon_log()
     same = np.isclose(ng, no, rtol=1e-12, atol=0) & np.isclose(xg, xo, rtol=1e-7, atol=1e-9)
-    assert same.mean() > 0.97 and rms_diff(t["Jout"], o.array("Jout")) < 0.01
+    assert same.mean() > 0.999 and rms_diff(t["Jout"], o.array("Jout")) < 0.01
     # (no dust: every photon escapes, so the angle-integrated spectrum has no deuterium notch to test for -- photon conservation instead)
     assert 0.95 * n < t["Jout"].sum() <= n * (1 + 1e-9)       # (a few leave through the ends of the frequency axis of the continuum source)
 
@@ -417,7 +417,7 @@ def test_fine_structure_peel_and_clumps_whole_path(capi, oracle_mod):
     o = oracle_mod.Oracle(**kw); o.run(n, seed=94)
     ng, xg = sim.ctx.photon_log(n); no, xo = o.photon_log()
     same = np.isclose(ng, no, rtol=1e-12, atol=0) & np.isclose(xg, xo, rtol=1e-7, atol=1e-9)
-    assert same.mean() > 0.97 and rms_diff(t["Jout"], o.array("Jout")) < 0.01
+    assert same.mean() > 0.999 and rms_diff(t["Jout"], o.array("Jout")) < 0.01
 
 
 def test_scheduling_independence(capi):
@@ -698,7 +698,7 @@ def test_amr_short_histories_photon_by_photon(capi, oracle_mod, amr_file, extra)
     o = oracle_of(oracle_mod, kw); o.run(n, seed=61)
     ng, xg = sim.ctx.photon_log(n); no, xo = o.photon_log()
     same = np.isclose(ng, no, rtol=1e-12, atol=0) & np.isclose(xg, xo, rtol=1e-7, atol=1e-9)
-    assert same.mean() > 0.97, same.mean()
+    assert same.mean() > 0.999, same.mean()
     assert t["nphotons_done"] == n
     assert rms_diff(t["Jout"], o.array("Jout")) < 0.01
     assert np.isclose(t["n_cellsteps"], o.scalar("n_cellsteps"), rtol=0.02)     # the same leaves are visited
@@ -724,7 +724,7 @@ def test_amr_box_boundaries_photon_by_photon(capi, oracle_mod, amr_slab_file, ex
     o = oracle_of(oracle_mod, kw); o.run(n, seed=23)
     ng, xg = sim.ctx.photon_log(n); no, xo = o.photon_log()
     same = np.isclose(ng, no, rtol=1e-12, atol=0) & (np.isclose(xg, xo, rtol=1e-7, atol=1e-9) | (xo == 0))
-    assert same.mean() > 0.97, same.mean()
+    assert same.mean() > 0.999, same.mean()
     assert t["nphotons_done"] == n and rms_diff(t["Jout"], o.array("Jout")) < 0.01
     assert np.isclose(t["n_cellsteps"], o.scalar("n_cellsteps"), rtol=0.02)
     if "xy_periodic" in extra and "DGR" not in extra:
@@ -885,7 +885,7 @@ def test_clump_histories_photon_by_photon(capi, oracle_mod, extra, n):
     o = oracle_mod.Oracle(**kw); o.run(n, seed=kw["iseed"])
     ng, xg = sim.ctx.photon_log(n); no, xo = o.photon_log()
     same = np.isclose(ng, no, rtol=1e-12, atol=0) & np.isclose(xg, xo, rtol=1e-7, atol=1e-9)
-    assert same.mean() > 0.95, same.mean()
+    assert same.mean() > 0.99, same.mean()
     assert t["nphotons_done"] == n
     assert rms_diff(t["Jout"], o.array("Jout")) < 0.01
     assert abs(ng.mean() - no.mean()) < 4 * np.hypot(ng.std(), no.std()) / np.sqrt(n) + 1e-9
@@ -910,7 +910,7 @@ def test_overlapping_clumps_histories_photon_by_photon(capi, oracle_mod, extra, 
     assert int(o.scalar("raytrace_variant")) == 7
     ng, xg = sim.ctx.photon_log(n); no, xo = o.photon_log()
     same = np.isclose(ng, no, rtol=1e-12, atol=0) & (np.isclose(xg, xo, rtol=1e-7, atol=1e-9) | (xo == 0))
-    assert same.mean() > 0.95, same.mean()
+    assert same.mean() > 0.99, same.mean()
     assert t["nphotons_done"] == n and rms_diff(t["Jout"], o.array("Jout")) < 0.01
     assert abs(ng.mean() - no.mean()) < 4 * np.hypot(ng.std(), no.std()) / np.sqrt(n) + 1e-9
     assert np.isclose(t["n_cellsteps"], o.scalar("n_cellsteps"), rtol=0.03)        # one per interval of constant active set
@@ -959,7 +959,7 @@ def test_file_loaded_overlapping_population(capi, oracle_mod, tmp_path):
     o.run(m, seed=19)
     ng, xg = sim.ctx.photon_log(m); no, xo = o.photon_log()
     same = np.isclose(ng, no, rtol=1e-12, atol=0) & np.isclose(xg, xo, rtol=1e-7, atol=1e-9)
-    assert same.mean() > 0.95, same.mean()
+    assert same.mean() > 0.99, same.mean()
     assert rms_diff(t["Jout"], o.array("Jout")) < 0.01
     g3 = t["scatt"][..., 0]; o3 = o.array("scatt:0").reshape((101, 11, 11), order="F")
     assert np.abs(g3 - o3).max() < 0.02 * o3.max() and abs(g3.sum() - o3.sum()) < 0.02 * o3.sum()
@@ -976,7 +976,7 @@ def test_bicone_histories(capi, oracle_mod, kw):
     o.run(n, seed=kw["iseed"])
     ng, xg = sim.ctx.photon_log(n); no, xo = o.photon_log()
     same = np.isclose(ng, no, rtol=1e-12, atol=0) & np.isclose(xg, xo, rtol=1e-7, atol=1e-9)
-    assert same.mean() > 0.95, same.mean()
+    assert same.mean() > 0.99, same.mean()
     assert rms_diff(t["Jout"], o.array("Jout")) < 0.01 and abs(t["Jout"].sum() - o.array("Jout").sum()) < 1e-6 * n and t["Jout"].sum() > 0.99 * n
 
 
@@ -1049,7 +1049,7 @@ def test_save_all_photons_table(capi, oracle_mod, mueller_file, kw):
     cols = ["r", "xfreq1", "xfreq2", "NSCATT_gas", "NSCATT_dust"] + (["I", "Q", "U", "V"] if kw.get("use_stokes") else []) + (["r0"] if kw.get("source_geometry") else [])
     idx = dict(r=0, xfreq1=1, xfreq2=2, NSCATT_gas=3, NSCATT_dust=4, I=5, Q=6, U=7, V=8, r0=9)
     same = np.isclose(g["NSCATT_gas"], r[3], rtol=1e-12, atol=0) & np.isclose(g["xfreq2"], r[2], rtol=1e-7, atol=1e-9)
-    assert same.mean() > 0.97, same.mean()                     # the same histories (a last-bit libm difference may flip a rejection)
+    assert same.mean() > 0.999, same.mean()                     # the same histories (a last-bit libm difference may flip a rejection)
     for c in cols:
         assert np.allclose(g[c][same], r[idx[c]][same], rtol=1e-7, atol=1e-9), c
     assert np.isclose(g["xfreq1"], r[1], rtol=1e-9, atol=1e-12).mean() > 0.999      # the same births (tan() near its poles amplifies a last-bit libm difference)

@@ -52,7 +52,7 @@ def test_lane_compaction_changes_nothing_but_the_grid(capi, oracle_mod):
     o = oracle_mod.Oracle(**{k: v for k, v in KW.items() if k != "iseed"}); o.run(n, seed=9)
     no, xo = o.photon_log()
     same = np.isclose(na, no, rtol=1e-12, atol=0) & np.isclose(xa, xo, rtol=1e-7, atol=1e-9)
-    assert same.mean() > 0.97
+    assert same.mean() > 0.999
 
 
 def test_forced_compaction_mid_run_with_stokes_planes(capi):
