@@ -52,8 +52,9 @@ def main():
     ap.add_argument("--cpu-photons", type=int, default=0, help="oracle sample size (0 = auto, ~20 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the tally reduction even with one rank (rehearsal of the N>1 path)")
-    ap.add_argument("--completion-photons", type=int, default=1000000, help="photons per GPU run to the last photon after the timed region "
-                    "(spectrum_rms_vs_ref + run_to_completion); 0 = skip")
+    ap.add_argument("--completion-photons", type=int, default=3000000, help="photons per GPU run to the last photon after the timed region "
+                    "(spectrum_rms_vs_ref + run_to_completion); 0 = skip.  3e6 keeps the whole command within ~6 minutes; BASELINE.json's 1e7 takes ~12")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short steady-state legs of BASELINE.json configs[2] (C3) and configs[4] (C5)")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -131,6 +132,7 @@ def main():
     reduce_ms = (time.perf_counter() - t_r0) * 1e3
     _, ntally = sim.ctx.tally_buffer()
 
+    others = other_configs(local, a.events_per_step) if (rank == 0 and world == 1 and not a.no_other_configs) else None
     completion = run_to_completion(sim, a, rank, world, dist if use_dist else None, barrier) if a.completion_photons > 0 else None
 
     if rank == 0:
@@ -140,7 +142,7 @@ def main():
         # (Jout escape + forced-first-scatter fraction: 2 per finished photon; scalar counters are per wave)
         bytes_launch = (48.0 * cells + 16.0 * 2.0 * done) / launches
         achieved = bytes_launch / (k_ms * 1e-3) / 1e9
-        traffic = pmc_traffic(a.events_per_step)
+        traffic, traffic_src = pmc_traffic(a.events_per_step)
         out = {
             "metric": "scattering events/sec (whole node), tau0=1e6 sphere",
             "value": ev_all / dt, "unit": "events/s", "n_gpus": n_rccl, "steps": a.steps, "warmup": a.warmup,
@@ -151,11 +153,13 @@ def main():
                        "events_per_step_per_lane": a.events_per_step, "lanes_per_gpu": lanes_timed, "block": block_timed,
                        "cells_per_event": cells_all / max(ev_all, 1.0), "photons_finished_in_timed_region": done_all,
                        "tally_reduce_ms": reduce_ms, "tally_doubles": ntally, "parallelism": "photon-dp%d" % world},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "transport_kernel<1,false,false,false,1>", "avg_launch_ms": k_ms,
                          "algorithmic_bytes_per_launch": bytes_launch,
                          "note": "fp64 ALU/latency-bound path; see DESIGN.md 'Roofline' for the VALU accounting"},
         }
+        if others is not None:
+            out["other_configs"] = others
         if completion is not None:
             out["spectrum_rms_vs_ref"] = completion.pop("spectrum_rms_vs_ref")
             out["spectrum"] = completion.pop("spectrum")
@@ -229,10 +233,49 @@ def pmc_traffic(events_per_step):
         try:
             d = json.load(open(f))
             if "bench.py" in d.get("command", "") and int(d.get("events_per_step", -1)) == int(events_per_step) and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
-                return (2.0 * d["FETCH_SIZE"]["mean_per_launch"] + d["WRITE_SIZE"]["mean_per_launch"]) * 1024.0
+                return (2.0 * d["FETCH_SIZE"]["mean_per_launch"] + d["WRITE_SIZE"]["mean_per_launch"]) * 1024.0, "profiles/" + os.path.basename(f) + " (committed rocprofv3 --pmc passes of this command, not measured in this run)"
         except Exception:
             pass
-    return None
+    return None, None
+
+
+def other_configs(device, events):
+    """short steady-state legs of the two other GPU configurations of BASELINE.json that fit one device: configs[2] (C3: sphere_peel/t1tau6.in, 201^3, Stokes,
+    129 x 129 x 201 peel cube) and configs[4] (C5: the 178 480-leaf octree with calc_J + calc_P + calc_Pnew).  3 warm-up steps (the pool has to reach its
+    steady mix of packet ages), 3 timed steps of `events` scattering events per lane; each with the roofline of SURVEY section 8(d): 48 B per cell visited by a
+    flight or a peel ray + 16 B per tally atomic, over the average launch time from HIP events on the launch stream.  Not part of `value`."""
+    import tempfile
+    from lart_amd import host, amr
+    out = {}
+    tmp = tempfile.mkdtemp()
+    afile = os.path.join(tmp, "sphere.dat")
+    cfgs = {
+        "c3_sphere_peel_tau6": dict(temperature=10.0, taumax=1e6, nx=201, ny=201, nz=201, rmax=1.0, nxfreq=201, use_stokes=True, save_Jin=True, nxim=129, nyim=129, no_photons=1e8, iseed=1),
+        "c5_octree_JP": dict(use_amr_grid=True, amr_file=afile, temperature=1e4, taumax=1e4, rmax=1.0, nxfreq=121, nxim=100, nyim=100, calc_J=True, calc_P=True, calc_Pnew=True,
+                             no_photons=1e8, iseed=1),
+    }
+    for name, kw in cfgs.items():
+        if kw.get("use_amr_grid"):
+            amr.write_generic_amr(afile, amr.make_amr_sphere())
+        sim = host.Simulation(dict(kw), device=device)
+        sim.ctx.begin(int(kw["no_photons"]), seed=1)
+        for _ in range(3):
+            sim.ctx.step(1, events)
+        sim.ctx.sync()
+        t0 = sim.ctx.tallies(); ms0, nl0 = sim.ctx.kernel_time(); w0 = time.perf_counter()
+        sim.ctx.step(3, events); sim.ctx.sync()
+        dt = time.perf_counter() - w0; t1 = sim.ctx.tallies(); ms1, nl1 = sim.ctx.kernel_time()
+        d = lambda k: t1[k] - t0[k]
+        nl = max(nl1 - nl0, 1); k_ms = (ms1 - ms0) / nl
+        by = (48.0 * (d("n_cellsteps") + d("n_cellsteps_peel")) + 16.0 * d("n_atomics")) / nl
+        ach = by / (k_ms * 1e-3) / 1e9
+        out[name] = {"value": d("n_events") / dt, "unit": "events/s", "steps": 3, "events_per_step_per_lane": events, "lanes": sim.ctx.pool_info()[0],
+                     "cells_per_event": d("n_cellsteps") / max(d("n_events"), 1), "peel_cells_per_event": d("n_cellsteps_peel") / max(d("n_events"), 1),
+                     "atomics_per_event": d("n_atomics") / max(d("n_events"), 1),
+                     "roofline": {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None, "avg_launch_ms": k_ms,
+                                  "algorithmic_bytes_per_launch": by}}
+        sim.ctx.close()
+    return out
 
 
 def host_cores():

@@ -350,6 +350,40 @@ struct Rng {
         uint32_t stored = freeb < LART_RNG_TOPUP ? freeb : LART_RNG_TOPUP;
         have = (uint32_t)(e + 2 * stored - n);
     }
+    // The same top-up for a wave that holds few packets (the drain phase: DESIGN.md 3.4).  With at most 64 / LART_RNG_TOPUP packet lanes in the wave,
+    // lane j evaluates block (j mod TOPUP) of the (j div TOPUP)-th packet lane and stores it into that lane's ring: one block per lane instead of
+    // TOPUP blocks per packet lane, i.e. a fifth of the latency on a wave that has its SIMD to itself (the generator is 39 % of a lone packet's event:
+    // profiles/r03_lone_wave_sections.txt).  Same counters, same slots, same draws as prefill().  Call with the whole wave; `act` = this lane holds a packet.
+    __device__ inline void prefill_sparse(bool act, unsigned long long mask) {
+        const int lane = threadIdx.x & 63;
+        unsigned long long e = 0; uint32_t freeb = 0;
+        if (act) { e = have ? n + have : (n & ~1ULL); const uint32_t used = (uint32_t)(e - (n & ~1ULL)); freeb = (LART_RNG_BUF - used) >> 1; }
+        const int t = lane / LART_RNG_TOPUP, b = lane - t * LART_RNG_TOPUP;
+        unsigned long long mk = mask;
+#pragma unroll
+        for (int q = 0; q < 64 / LART_RNG_TOPUP; q++) if (q < t) mk &= mk - 1;       // drop the t lowest packet lanes: the lowest one left is this helper's target
+        const bool work = mk != 0 && t < 64 / LART_RNG_TOPUP;
+        const int src = work ? __ffsll((long long)mk) - 1 : lane;
+        const unsigned long long sid = __shfl((unsigned long long)id, src, 64), se = __shfl(e, src, 64);
+        const uint32_t sfree = __shfl(freeb, src, 64);
+        if (work && (uint32_t)b < sfree) {
+            const unsigned long long blk = (se >> 1) + (unsigned long long)b;
+            uint32_t c0 = (uint32_t)blk, c1 = (uint32_t)(blk >> 32), c2 = (uint32_t)sid, c3 = (uint32_t)(sid >> 32), ka = k0, kb = k1;
+#pragma unroll 1
+            for (int r = 0; r < LART_PHILOX_ROUNDS; r++) {
+                uint32_t h0, l0, h1, l1;
+                mulhilo32(0xD2511F53u, c0, h0, l0); mulhilo32(0xCD9E8D57u, c2, h1, l1);
+                const uint32_t n0 = h1 ^ c1 ^ ka, n2 = h0 ^ c3 ^ kb;
+                c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+                ka += 0x9E3779B9u; kb += 0xBB67AE85u;
+            }
+            double *col = lbuf + (src - lane);                 // the target lane's column of the ring
+            const uint32_t slot = (uint32_t)se + 2u * (uint32_t)b;
+            col[(slot & (LART_RNG_BUF - 1)) * stride] = open01(c0, c1); col[((slot + 1) & (LART_RNG_BUF - 1)) * stride] = open01(c2, c3);
+        }
+        LART_WAVE_SYNC();
+        if (act) { const uint32_t stored = freeb < LART_RNG_TOPUP ? freeb : LART_RNG_TOPUP; have = (uint32_t)(e + 2 * stored - n); }
+    }
     __device__ inline double next() {
         if (have) { double v = lbuf[((uint32_t)n & (LART_RNG_BUF - 1)) * stride]; n++; have--; return v; }
         uint64_t m = n++;

@@ -61,7 +61,8 @@ struct lart_gpu {
     double sight_ms = 0.0;                                   // device time of the last sight-line map
     // lane compaction: the launch covers lanes [0, live_lanes); state of the last lart_gpu_sync
     int64_t live_lanes = 0; bool state_valid = false; int64_t last_alive = 0, last_next_k = 0; int auto_compact = 1;
-    int *d_compact = nullptr; int64_t compact_lanes = 0; int64_t n_compactions = 0;      // d_compact holds the slot lists of a pool of compact_lanes lanes
+    int *d_compact = nullptr; int64_t compact_lanes = 0; int64_t n_compactions = 0; int64_t compact_alive = 0, compact_waves = 0; int spread_drain = 1;
+         // d_compact holds the slot lists of a pool of compact_lanes lanes
     // peel-off event queue (deferred next-event estimator): records of one transport launch, consumed by peel_kernel right after it
     // two buffers: while peel_kernel works through the records of slice k on stream2, the transport kernel of slice k + 1 fills the other one
     DPeelQ pq[2]{}; void *d_pq = nullptr; size_t pq_bytes_max = 0; int peel_slice = 0; int n_cu = 0; size_t pq_nobs = 0, pq_lanes = 0;   // (the queue was laid out for pq_nobs observers and pq_lanes lanes)
@@ -540,7 +541,8 @@ extern "C" int lart_gpu_begin(lart_gpu *c, int64_t first_id, int64_t stride, int
         HIPCHK(hipMalloc(&c->d_log, bytes)); HIPCHK(hipMemsetAsync(c->d_log, 0, bytes, c->stream)); c->nlog = count; }
     for (auto &e : c->ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     c->ev.clear(); c->kernel_ms = 0.0; c->nlaunch = 0;
-    c->live_lanes = c->pool.n; c->state_valid = false; c->n_compactions = 0;
+    c->live_lanes = c->pool.n; c->state_valid = false; c->n_compactions = 0; c->compact_alive = c->pool.n; c->compact_waves = 0;
+    if (const char *e = std::getenv("LART_DENSE_DRAIN")) c->spread_drain = std::atoi(e) ? 0 : 1;      // tuning knob: pack the last packets densely (round 2 behaviour)
     c->begun = true;
     return 0;
 }
@@ -616,10 +618,17 @@ __device__ inline int wave_slot(bool pred, unsigned *counter) {           // one
     base = __shfl(base, 0, 64);
     return (int)(base + (unsigned)__popcll(b & ((1ull << lane) - 1ull)));
 }
-__global__ void k_compact_scan(DPool pool, long long live, long long m, int *holes, int *movers, unsigned *cnt) {
+// the lanes the m live packets are to sit in: dealt round-robin over `waves` waves -- packet j goes to wave j mod waves, row j div waves -- so that the
+// last packets of a run have a wave (and, below one wave per SIMD, a SIMD) each instead of sharing the divergence of a full wave: one event of a lone
+// packet takes 5.2 us, one round of a full wave 10.1 us (profiles/r03_lone_wave_sections.txt).  waves = ceil(m / 64): the dense layout.
+__device__ inline bool compact_wanted(long long i, long long m, long long waves) {
+    const long long w = i >> 6, r = i & 63, q = m / waves, rem = m - q * waves;
+    return w < waves && (r < q || (r == q && w < rem));
+}
+__global__ void k_compact_scan(DPool pool, long long live, long long m, long long waves, int *holes, int *movers, unsigned *cnt) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool in = i < live, alive = in && (pool.flags[i] & FLAG_ALIVE);
-    const bool hole = in && i < m && !alive, mover = in && i >= m && alive;
+    const bool in = i < live, alive = in && (pool.flags[i] & FLAG_ALIVE), want = compact_wanted(i, m, waves);
+    const bool hole = in && want && !alive, mover = in && !want && alive;
     const int sh = wave_slot(hole, &cnt[0]), sm = wave_slot(mover, &cnt[1]);
     if (hole) holes[sh] = (int)i;
     if (mover) movers[sm] = (int)i;
@@ -641,17 +650,30 @@ extern "C" int lart_gpu_compact(lart_gpu *c) {
     if (!c->state_valid) { if (lart_gpu_sync(c, nullptr, nullptr)) return 1; }
     if (!c->state_valid) return 0;                                  // nothing launched yet
     const int64_t m = c->last_alive, live = c->live_lanes;
-    int64_t new_live = ((m + c->block - 1) / c->block) * c->block; if (new_live < c->block) new_live = c->block;
-    if (new_live >= live) return 0;
+    // wave slots that run side by side: 4 per SIMD (the occupancy the transport kernel is built for); fewer packets than that -> one packet per wave
+    if (!c->n_cu) { hipDeviceProp_t pr; HIPCHK(hipGetDeviceProperties(&pr, c->device)); c->n_cu = pr.multiProcessorCount; }
+    // Measured on the headline workload (profiles/r03_drain_timeline.txt): one round of a wave costs 4.7 us with one packet in it and 10.1 us with 64
+    // when the wave has its SIMD to itself (latency-bound), and 4 us of issue time per full wave otherwise.  So: full waves while there are at least
+    // two of them per SIMD; below that the packets are dealt out over two waves per SIMD (half the divergence, the issue slots still suffice: 7.5 us
+    // against 10.1 us at 32 against 64 packets per wave), and from one packet per SIMD on every packet has a wave and a SIMD of its own.
+    const int64_t wpb = c->block / 64, simds = (int64_t)c->n_cu * 4, slots = 2 * simds;
+    int64_t waves = (m + 63) / 64;                                   // dense
+    if (c->spread_drain && waves < slots) waves = m < slots ? m : slots;
+    if (waves < 1) waves = 1;
+    waves = ((waves + wpb - 1) / wpb) * wpb;                         // whole workgroups
+    int64_t new_live = waves * 64;
+    if (new_live > live) { waves = live / 64; new_live = waves * 64; }       // (the layout never grows the launch)
+    if (m > new_live) return 0;
+    if (new_live == live && c->compact_waves == waves) { c->compact_alive = m; return 0; }
     if (!c->d_compact || c->compact_lanes < c->pool.n) {             // the pool may have been re-created larger by a later lart_gpu_begin
         (void)hipFree(c->d_compact); c->d_compact = nullptr; c->compact_lanes = 0;
         HIPCHK(hipMalloc(&c->d_compact, ((size_t)2 * c->pool.n + 2) * sizeof(int))); c->compact_lanes = c->pool.n;
     }
     int *holes = c->d_compact + 2, *movers = holes + c->pool.n; unsigned *cnt = (unsigned *)c->d_compact;
     HIPCHK(hipMemsetAsync(cnt, 0, 2 * sizeof(unsigned), c->stream));
-    hipLaunchKernelGGL(k_compact_scan, dim3((unsigned)((live + 255) / 256)), dim3(256), 0, c->stream, c->pool, (long long)live, (long long)m, holes, movers, cnt);
+    hipLaunchKernelGGL(k_compact_scan, dim3((unsigned)((live + 255) / 256)), dim3(256), 0, c->stream, c->pool, (long long)live, (long long)m, (long long)waves, holes, movers, cnt);
     HIPCHK(hipGetLastError());
-    const int64_t nmove_max = m < live - m ? m : live - m;           // movers sit beyond m, holes below it
+    const int64_t nmove_max = m;                                     // at most every live packet moves
     if (nmove_max > 0) {
         hipLaunchKernelGGL(k_compact_move, dim3((unsigned)((nmove_max + 255) / 256)), dim3(256), 0, c->stream, c->pool, holes, movers, cnt, c->par.use_stokes ? (int)F_SHEAR : (int)F_MX, march_variant(c) == 8 ? (int)F_SHEAR : -1);
         HIPCHK(hipGetLastError());
@@ -660,7 +682,7 @@ extern "C" int lart_gpu_compact(lart_gpu *c) {
     HIPCHK(hipMemcpyAsync(h, cnt, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (h[0] != h[1]) return fail("compact: live-lane bookkeeping is inconsistent (holes != movers)");
-    c->live_lanes = new_live; c->n_compactions++;
+    c->live_lanes = new_live; c->n_compactions++; c->compact_alive = m; c->compact_waves = waves;
     return 0;
 }
 extern "C" int lart_gpu_set_auto_compact(lart_gpu *c, int32_t on) { if (!c) return fail("null context"); c->auto_compact = on ? 1 : 0; return 0; }
@@ -672,7 +694,8 @@ extern "C" int lart_gpu_step(lart_gpu *c, int32_t nsteps, int32_t max_events) {
     if (!c->d_tally || (!c->d_cell && !c->is_clump) || !c->d_pool) return fail("step: no medium / tally buffer / photon pool on the device");
     HIPCHK(hipSetDevice(c->device));
     // drain phase (no photon left to refill a lane with): pack the live lanes to the front of the pool and shrink the grid
-    if (c->auto_compact && c->state_valid && c->last_next_k >= (int64_t)c->count && c->last_alive * 4 < c->live_lanes * 3 && c->live_lanes > c->block) {
+    // (again whenever a quarter of the packets of the last layout have finished)
+    if (c->auto_compact && c->state_valid && c->last_next_k >= (int64_t)c->count && c->last_alive * 4 < c->compact_alive * 3 && c->live_lanes > c->block) {
         if (lart_gpu_compact(c)) return 1;
     }
     KArgs A{};
@@ -1036,7 +1059,7 @@ __device__ void test_ray_one(const KArgs &A, const Lds &l, int kind, double *r, 
     if (kind == 4) { *tau_out = edge_dust_Ha<VAR>(A, l, dust, p, p.kx, p.ky, p.kz, ns); return; }      // raytrace_to_edge_*_dust_Ha
     if (kind == 0) {
         raytrace_to_tau<VAR>(A, l, dust, p, tq, ns);
-        r[0] = p.x; r[1] = p.y; r[2] = p.z; r[3] = p.kx; r[4] = p.ky; r[5] = p.kz; r[6] = (p.iband == 2 && !p.inside) ? p.xfreq_ref : p.xfreq; r[7] = p.wgt;
+        r[0] = p.x; r[1] = p.y; r[2] = p.z; r[3] = p.kx; r[4] = p.ky; r[5] = p.kz; r[6] = (A.par.line_type == 8 && !p.inside) ? p.xfreq_ref : p.xfreq; r[7] = p.wgt;      // (line type 8 probes: the exit frequency in reference units, 0 for a ray that starts outside)
         ic[0] = is_clump(VAR) ? p.icl : p.ic; ic[1] = p.jc; ic[2] = p.kc; ic[3] = p.inside ? 1 : 0;
         if (VAR == 8) *tau_out = p.shear;
     } else *tau_out = raytrace_to_edge<VAR>(A, l, dust, p, p.xfreq, p.kx, p.ky, p.kz, kind == 2 ? tq : -1.0, ns);

@@ -98,6 +98,7 @@ __global__ __launch_bounds__(256, LART_WAVES(STOKES, PEEL)) void transport_kerne
     double *F = A.pool.f;
 
     Photon p; Rng g; g.attach(rng_lds, blockDim.x);
+    g.k0 = (uint32_t)A.seed; g.k1 = (uint32_t)(A.seed >> 32);                  // (a lane that never holds a packet still lends its ALU to Rng::prefill_sparse: the key is the run's)
 #ifdef LART_PROFILE
     for (int i = 0; i < 12; i++) p.pt[i] = 0;
     for (int i = 0; i < 4; i++) p.pc[i] = 0;
@@ -127,36 +128,48 @@ __global__ __launch_bounds__(256, LART_WAVES(STOKES, PEEL)) void transport_kerne
     double nsg_done = 0.0, nsd_done = 0.0;
     int budget = A.max_events;
 
+    // The event loop is left by the WAVE, not by the lane: a lane without a packet (none left to draw, or its launch budget used up) stays in and
+    // lends its ALU to the packets of the wave -- the random-draw top-up (Rng::prefill_sparse) and the rejection loops of the vz sampler
+    // (vz_core_coop / vz_wing_coop) spread over all 64 lanes.  In the drain phase a wave holds a few packets or one (lart_gpu_compact deals the
+    // last packets out over the wave slots), and an event of a lone packet is what the tail of a run is made of.
+    bool exhausted = false;
     for (;;) {
-        if (!alive) {
+        if (!alive && !exhausted && budget > 0) {
             unsigned long long kk = atomicAdd(&A.ctl->next_k, 1ULL);
-            if (kk >= (unsigned long long)A.count) break;
-            k = (long long)kk;
-            g.init(A.seed, (uint64_t)(A.first_id + k * A.stride), 0);
-            if (VAR == 8) p.shear = 0.0;                       // generate_photon.f90:141
-            p.iband = 1;                                       // :139
-            generate_photon<VAR, STOKES, DUST, PEEL>(A, l, g, p, npeel);
-            if (A.allph) allph_initial(A, p, k);
-            if (A.trace_slot) trace_rec<VAR>(A, k, g.n, p, 0);
-            alive = true; first = true;
-            if (PEEL) budget--;                                // the birth queued one peel record (direct light): lanes x (max_events + 1) records bound the queue
-            LART_PROF_MARK(p, 1);
+            if (kk >= (unsigned long long)A.count) exhausted = true;
+            else {
+                k = (long long)kk;
+                g.init(A.seed, (uint64_t)(A.first_id + k * A.stride), 0);
+                if (VAR == 8) p.shear = 0.0;                   // generate_photon.f90:141
+                p.iband = 1;                                   // :139
+                generate_photon<VAR, STOKES, DUST, PEEL>(A, l, g, p, npeel);
+                if (A.allph) allph_initial(A, p, k);
+                if (A.trace_slot) trace_rec<VAR>(A, k, g.n, p, 0);
+                alive = true; first = true;
+                if (PEEL) budget--;                            // the birth queued one peel record (direct light): lanes x max_events records bound the queue
+                LART_PROF_MARK(p, 1);
+            }
         }
-        if (budget <= 0) break;
-        g.prefill();
+        const bool act = alive && budget > 0;
+        const unsigned long long am = __ballot(act);
+        if (!am) break;
+        if (__popcll(am) * LART_RNG_TOPUP <= 64) g.prefill_sparse(act, am);
+        else if (act) g.prefill();
 #ifdef LART_EXPERIMENT_PREFILL2                        // timing experiment: cost of one buffer fill
-        g.prefill();
+        if (act) g.prefill();
 #endif
         LART_PROF_TRIP(p, 2);
-        fly<VAR, DUST>(A, l, g, p, first, nsteps);
-        { const bool on = p.inside; scatter_event<VAR, STOKES, DUST, PEEL>(A, l, g, p, npeel, on); if (on) { nev++; budget--; } }
+        if (act) fly<VAR, DUST>(A, l, g, p, first, nsteps);
+        { const bool on = act && p.inside; scatter_event<VAR, STOKES, DUST, PEEL>(A, l, g, p, npeel, on); if (on) { nev++; budget--; } }
         LART_PROF_MARK(p, 6);
-        if (A.trace_slot) trace_rec<VAR>(A, k, g.n, p, p.inside ? 1 : 2);
-        if (!p.inside) {
-            nsg_done += p.nsg; nsd_done += p.nsd; ndone++;
-            if (A.log_nscatt) { A.log_nscatt[k] = p.nsg + p.nsd; A.log_xfreq[k] = p.xfreq_ref; }
-            if (A.allph) allph_final<STOKES>(A, p, k);
-            alive = false;
+        if (act) {
+            if (A.trace_slot) trace_rec<VAR>(A, k, g.n, p, p.inside ? 1 : 2);
+            if (!p.inside) {
+                nsg_done += p.nsg; nsd_done += p.nsd; ndone++;
+                if (A.log_nscatt) { A.log_nscatt[k] = p.nsg + p.nsd; A.log_xfreq[k] = p.xfreq_ref; }
+                if (A.allph) allph_final<STOKES>(A, p, k);
+                alive = false;
+            }
         }
         LART_PROF_MARK(p, 7);
     }

@@ -528,6 +528,8 @@ def read_input(par, line=None):
         line.DnuHK_Hz, line.E1, line.E2, line.E3 = 0.0, 1.0, 0.0, 1.0
         A21 = (1.6725e8, 2.2448e7)
         line.P_conv = A21[1] / (A21[0] + A21[1])
+        if par.fine_structure:                                            # setup.f90:259-263
+            raise LartInputError("ly_beta: fine structure not yet supported")
         par.include_deuterium = False
     elif par.line_id not in ("ly_alpha", "ly_alpha_HD"):
         raise LartInputError("par%%line_id = '%s' is not supported by this path (ly_alpha, ly_alpha_HD, %s)" % (par.line_id, ", ".join(_METAL_LINES) + " and the multiplets of lart_host_line_lookup"))

@@ -8,7 +8,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
-SMALL = ["--steps", "2", "--warmup", "1", "--events-per-step", "256", "--lanes", "131072", "--completion-photons", "400"]
+SMALL = ["--steps", "2", "--warmup", "1", "--events-per-step", "256", "--lanes", "131072", "--completion-photons", "400", "--no-other-configs"]
 
 
 def last_json(out):

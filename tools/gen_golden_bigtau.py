@@ -158,15 +158,15 @@ def merge(a):
     o = O.Oracle(**kw)
     nxf = int(o.scalar("nxfreq")); dxf = o.scalar("dxfreq")
     # output_normalize_outside: output_sum_rect.f90:185 (slab: area 2), :194-202 (sphere: 4 pi rmax^2 distance2cm^2)
-    if name == "c4":
-        out["cl_N"] = int(o.scalar("cl_N"))
-    if name == "c5":
-        out["nbins"] = int(o.scalar("nbins")); out["nleaf"] = int(o.scalar("amr_nleaf")); out["dr_JPa"] = o.scalar("amr_dr_JPa")
     area = 2.0 if kw.get("xy_periodic") else 4.0 * np.pi * o.scalar("rmax") ** 2 * o.scalar("distance2cm") ** 2
     scale = nph * dxf * 2.0 * np.pi * area
     out = {"nphotons": nph, "nchunk": nchunk, "chunk": chunk, "xfreq": o.xfreq_axis(), "dxfreq": dxf, "Jout_scale_per_photon": dxf * 2.0 * np.pi * area,
            "nscatt_mean": logn.mean(), "nscatt_err": logn.std() / np.sqrt(len(logn)),
            "params": json.dumps(CONFIGS[name], sort_keys=True), "rng": "MT19937-64, seed0 + 100003*worker + chunk"}
+    if name == "c4":
+        out["cl_N"] = int(o.scalar("cl_N"))
+    if name == "c5":
+        out["nbins"] = int(o.scalar("nbins")); out["nleaf"] = int(o.scalar("amr_nleaf")); out["dr_JPa"] = o.scalar("amr_dr_JPa")
     for k, v in acc.items():
         mean_chunk = v / nchunk
         var_chunk = np.maximum(acc2[k] / nchunk - mean_chunk ** 2, 0.0) * nchunk / max(nchunk - 1, 1)
