@@ -154,6 +154,7 @@ struct KArgs {
     // per-event history probe of the parity tests (lart_gpu_test_trace): trace_slot[k] >= 0 selects photon ordinal k; record i of slot s
     // is trace[(s * trace_cap + i) * LART_TRACE_W ..]; trace_n[s] counts the records (also those beyond trace_cap, which are not stored)
     const int *trace_slot; double *trace; int *trace_n; int trace_cap;
+    const double *h2tab;          // the H2 line table (see h2_kappa_D), nullptr without H2
 };
 #define LART_TRACE_W 8
 
@@ -416,7 +417,7 @@ struct Rng {
 // ---------------------------------------------------------------------------------------------
 // Voigt H(x,a): voigt_mod.f90:541-733 (four regimes on a 0.05 grid)
 // ---------------------------------------------------------------------------------------------
-__device__ inline double voigt_H(const double *vt, double vin, double a) {
+__device__ __forceinline__ double voigt_H(const double *vt, double vin, double a) {
     double v = vin < 0.0 ? -vin : vin;
     if (v < 1.0) {
         double vv = v * 20.0; int k = (int)vv;                // k = k1-1
@@ -445,7 +446,7 @@ __device__ inline void lds_set_multiplet(Lds &l, const DMulti &m) {
 }
 // calc_voigt1 / calc_voigt2 (line_mod.f90:38-62): the profile of a cell with Voigt parameter a and Doppler width Dfreq.
 // Line type 2 = the Ly-alpha doublet: 1/3 of the strength at the 2P1/2 level, DnuHK below the 2P3/2 level.
-__device__ inline double calc_voigt(const Lds &l, double xfreq, double a, double Dfreq) {
+__device__ __forceinline__ double calc_voigt(const Lds &l, double xfreq, double a, double Dfreq) {
     if (l.lt == 2) { const double dnu = l.dnu_hz / Dfreq; return voigt_H(l.vt, xfreq + dnu, a) * (1.0 / 3.0) + voigt_H(l.vt, xfreq, a) * (2.0 / 3.0); }
     if (l.lt == 7) {                                           // calc_voigt_HD :82-106: H profile + the D line seen from the H frame
         const double dx = l.dnu_hz / Dfreq, xD = (xfreq - dx) * l.hd_ratio;
@@ -936,11 +937,13 @@ __device__ inline bool trav_cross(const DGrid &g, Trav &t, int idx) {
     return ok;
 }
 // h2_kappa_D (h2_mod.f90:58-78): the opacity of the H2 lines next to Ly-alpha as a multiplier of the H I opacity of a cell of Doppler width Dfreq.
-// The kernels of this case carry the pseudo line type 9 = line type 1 + H2 (lart_gpu.hip sets it when lart_params.h2_nlines > 0)
-__device__ inline double h2_kappa_D(const lart_params &par, const Lds &l, double xfreq, double Dfreq) {
+// The kernels of this case carry the pseudo line type 9 = line type 1 + H2 (lart_gpu.hip sets it when lart_params.h2_nlines > 0).  The line table is read
+// from a small device array (h2[0..3] dnu_Hz, [4..7] strength, [8..11] a_damp, [12..15] p_scat): indexing the kernel arguments with a run-time line number
+// would copy the whole parameter block into scratch memory (measured on the peel kernel, which takes the line type at run time: 2.5x slower)
+__device__ __forceinline__ double h2_kappa_D(const lart_params &par, const double *h2, const Lds &l, double xfreq, double Dfreq) {
     double kap = 0.0;
     const double ratio = par.h2_hi_width ? 1.0 : Dfreq / par.h2_Dfreq_Hz;
-    for (int il = 0; il < par.h2_nlines; il++) { const double dx = par.h2_dnu_Hz[il] / Dfreq, x_h2 = (xfreq - dx) * ratio; kap = kap + par.h2_strength[il] * ratio * voigt_H(l.vt, x_h2, par.h2_a_damp[il]); }
+    for (int il = 0; il < par.h2_nlines; il++) { const double dx = h2[il] / Dfreq, x_h2 = (xfreq - dx) * ratio; kap = kap + h2[4 + il] * ratio * voigt_H(l.vt, x_h2, h2[8 + il]); }
     return kap;
 }
 __device__ inline int minloc3(double a, double b, double c) { int m = 1; double v = a; if (b < v) { m = 2; v = b; } if (c < v) m = 3; return m; }
@@ -1041,20 +1044,20 @@ struct EdgeMarch {
     double x, y, z; int il; long long icl;        // octree leaf / owner clump and the running position
 };
 // raytrace_to_edge_amr (:265-344) / raytrace_to_dist_amr (:559-640)
-__device__ inline void edge_begin_amr(const KArgs &A, const Photon &p, EdgeMarch &m) {
+__device__ __forceinline__ void edge_begin_amr(const KArgs &A, const Photon &p, EdgeMarch &m) {
     const DAmr &a = A.amr;
     m.x = p.x; m.y = p.y; m.z = p.z; m.il = p.ic;
     if (m.il <= 0) { m.il = amr_find_leaf(a, m.x, m.y, m.z); if (m.il <= 0) { m.live = false; return; } }
     const Cell *c = &A.g.cell[m.il - 1];
     m.u1 = c->vfx * m.kx + c->vfy * m.ky + c->vfz * m.kz;
 }
-__device__ inline void edge_step_amr(const KArgs &A, const Lds &l, bool dust, EdgeMarch &m, unsigned &nsteps) {
+__device__ __forceinline__ void edge_step_amr(const KArgs &A, const Lds &l, bool dust, EdgeMarch &m, unsigned &nsteps) {
     const DAmr &a = A.amr;
     const Cell *c = &A.g.cell[m.il - 1];
     int ic = a.icell_of_leaf[m.il - 1], iface;
     double t_exit = amr_cell_exit(a.geom[ic - 1], m.x, m.y, m.z, m.kx, m.ky, m.kz, iface);
     double rhokap = c->rhokap * calc_voigt(l, m.xfreq, c->voigt_a, c->Dfreq);
-    if (l.lt == 9 && m.dist < 0.0) rhokap = rhokap + c->rhokap * h2_kappa_D(A.par, l, m.xfreq, c->Dfreq);
+    if (l.lt == 9 && m.dist < 0.0) rhokap = rhokap + c->rhokap * h2_kappa_D(A.par, A.h2tab, l, m.xfreq, c->Dfreq);
     if (dust) rhokap = rhokap + c->rhokapD;
     nsteps++;
     if (m.dist >= 0.0 && m.d + t_exit >= m.dist) { m.tau = m.tau + (m.dist - m.d) * rhokap; m.live = false; return; }
@@ -1074,8 +1077,8 @@ __device__ inline void edge_step_amr(const KArgs &A, const Lds &l, bool dust, Ed
 // ---------------------------------------------------------------------------------------------
 // clump medium (VAR 4): clump_mod.f90 + raytrace_clump.f90.  xfreq stays in REF Doppler units; -/+ ulos at entry/exit.
 // ---------------------------------------------------------------------------------------------
-__device__ inline double voigt_clump(const KArgs &A, const Lds &l, double xfreq, const ClumpPhys &c) { return calc_voigt(l, xfreq * (A.cl.Dfreq_ref / c.Dfreq), c.voigt_a, c.Dfreq); }   // clump_mod.f90:130-170 (line types 1, 2)
-__device__ inline double kappa_clump(const KArgs &A, const Lds &l, bool dust, double xfreq, const ClumpPhys &c) {                                                                 // :176-182
+__device__ __forceinline__ double voigt_clump(const KArgs &A, const Lds &l, double xfreq, const ClumpPhys &c) { return calc_voigt(l, xfreq * (A.cl.Dfreq_ref / c.Dfreq), c.voigt_a, c.Dfreq); }   // clump_mod.f90:130-170 (line types 1, 2)
+__device__ __forceinline__ double kappa_clump(const KArgs &A, const Lds &l, bool dust, double xfreq, const ClumpPhys &c) {                                                                 // :176-182
     double kap = c.rhokap * voigt_clump(A, l, xfreq, c);
     if (dust) kap = kap + c.rhokapD;
     return kap;
@@ -1144,7 +1147,7 @@ __device__ inline int clump_at_point(const DClumps &c, double xp, double yp, dou
 }
 __device__ inline void tally_escape(const lart_params &par, const DTally &T, const Photon &p);
 // raytrace_to_tau_clump: raytrace_clump.f90:83-201
-__device__ inline void raytrace_to_tau_clump(const KArgs &A, const Lds &l, bool dust, Photon &p, double tau_in, unsigned &nsteps) {
+__device__ __forceinline__ void raytrace_to_tau_clump(const KArgs &A, const Lds &l, bool dust, Photon &p, double tau_in, unsigned &nsteps) {
     const DClumps &c = A.cl;
     const double kx = p.kx, ky = p.ky, kz = p.kz; double tau_rem = tau_in; long long last_icl = 0;
     while (p.inside) {
@@ -1179,7 +1182,7 @@ __device__ inline void raytrace_to_tau_clump(const KArgs &A, const Lds &l, bool 
 }
 // raytrace_to_edge_clump_capped: :494-541.  The uncapped form (:204-267) is what the reference calls for the forced first
 // flight; its only consumers are exp(-tau0) and 1 - exp(-tau0), which are exactly 0 and 1 beyond the cap, so one routine serves both.
-__device__ inline void edge_begin_clump(const KArgs &A, const Lds &l, bool dust, const Photon &p0, EdgeMarch &m, unsigned &nsteps) {
+__device__ __forceinline__ void edge_begin_clump(const KArgs &A, const Lds &l, bool dust, const Photon &p0, EdgeMarch &m, unsigned &nsteps) {
     const DClumps &c = A.cl;
     m.x = p0.x; m.y = p0.y; m.z = p0.z; m.icl = p0.icl;
     if (m.icl > 0) {
@@ -1194,7 +1197,7 @@ __device__ inline void edge_begin_clump(const KArgs &A, const Lds &l, bool dust,
     }
 }
 // one clump of the vacuum walk: the next entry (find_next_clump over the CSR cells) and the chord through it
-__device__ inline void edge_step_clump(const KArgs &A, const Lds &l, bool dust, EdgeMarch &m, unsigned &nsteps) {
+__device__ __forceinline__ void edge_step_clump(const KArgs &A, const Lds &l, bool dust, EdgeMarch &m, unsigned &nsteps) {
     const DClumps &c = A.cl;
     double t_sp = sphere_exit_dist(c, m.x, m.y, m.z, m.kx, m.ky, m.kz), te, tx2; long long icl_found;
     if (t_sp <= 0.0) { m.live = false; return; }
@@ -1381,7 +1384,7 @@ __device__ inline void raytrace_to_tau_clump_ovl(const KArgs &A, const Lds &l, b
 
 // tau to the grid edge (dist < 0) or to a finite distance (raytrace_to_dist_car :89-195, VAR 0 only)
 template <int VAR>
-__device__ inline void edge_begin(const KArgs &A, const Lds &l, bool dust, const Photon &p, double xfreq, double kx, double ky, double kz, double dist, EdgeMarch &m, unsigned &nsteps) {
+__device__ __forceinline__ void edge_begin(const KArgs &A, const Lds &l, bool dust, const Photon &p, double xfreq, double kx, double ky, double kz, double dist, EdgeMarch &m, unsigned &nsteps) {
     if (VAR == 8) { edge_begin<0>(A, l, dust, p, xfreq, kx, ky, kz, dist, m, nsteps); return; }
     m.live = true; m.tau = 0.0; m.d = 0.0; m.xfreq = xfreq; m.dist = dist; m.kx = kx; m.ky = ky; m.kz = kz;
     if (VAR == 3) { edge_begin_amr(A, p, m); return; }
@@ -1396,13 +1399,13 @@ __device__ inline void edge_begin(const KArgs &A, const Lds &l, bool dust, const
     m.rk = c->rhokap; m.va = c->voigt_a; m.rD = c->rhokapD;
 }
 template <int VAR>
-__device__ inline void edge_step(const KArgs &A, const Lds &l, bool dust, EdgeMarch &m, unsigned &nsteps) {
+__device__ __forceinline__ void edge_step(const KArgs &A, const Lds &l, bool dust, EdgeMarch &m, unsigned &nsteps) {
     if (VAR == 8) { edge_step<0>(A, l, dust, m, nsteps); return; }
     if (VAR == 3) { edge_step_amr(A, l, dust, m, nsteps); return; }
     if (VAR == 4) { edge_step_clump(A, l, dust, m, nsteps); return; }
     const DGrid &g = A.g; Trav &t = m.t;
     double rhokap = m.rk * calc_voigt(l, m.xfreq, m.va, m.Dold);
-    if (l.lt == 9 && m.dist < 0.0) rhokap = rhokap + m.rk * h2_kappa_D(A.par, l, m.xfreq, m.Dold);
+    if (l.lt == 9 && m.dist < 0.0) rhokap = rhokap + m.rk * h2_kappa_D(A.par, A.h2tab, l, m.xfreq, m.Dold);
     if (dust) rhokap = rhokap + m.rD;
     nsteps++;
     int idx = (VAR == 2) ? 3 : minloc3(t.tx, t.ty, t.tz);
@@ -1417,7 +1420,7 @@ __device__ inline void edge_step(const KArgs &A, const Lds &l, bool dust, EdgeMa
     m.Dold = Dn; m.u1 = u2; m.rk = c->rhokap; m.va = c->voigt_a; m.rD = c->rhokapD;
 }
 template <int VAR>
-__device__ inline double raytrace_to_edge(const KArgs &A, const Lds &l, bool dust, const Photon &p, double xfreq, double kx, double ky, double kz, double dist, unsigned &nsteps) {
+__device__ __forceinline__ double raytrace_to_edge(const KArgs &A, const Lds &l, bool dust, const Photon &p, double xfreq, double kx, double ky, double kz, double dist, unsigned &nsteps) {
     EdgeMarch m;
     edge_begin<VAR>(A, l, dust, p, xfreq, kx, ky, kz, dist, m, nsteps);
     while (m.live) edge_step<VAR>(A, l, dust, m, nsteps);
@@ -1459,7 +1462,7 @@ __device__ inline void jpa_segment(const KArgs &A, const Lds &l, const Photon &p
 
 
 // raytrace_to_tau_amr: raytrace_amr.f90:77-259
-__device__ inline void raytrace_to_tau_amr(const KArgs &A, const Lds &l, bool dust, Photon &p, double tau_in, unsigned &nsteps) {
+__device__ __forceinline__ void raytrace_to_tau_amr(const KArgs &A, const Lds &l, bool dust, Photon &p, double tau_in, unsigned &nsteps) {
     const DAmr &a = A.amr;
     double x = p.x, y = p.y, z = p.z, kx = p.kx, ky = p.ky, kz = p.kz, tau = 0.0;
     int il = p.ic;
@@ -1471,7 +1474,7 @@ __device__ inline void raytrace_to_tau_amr(const KArgs &A, const Lds &l, bool du
         const bool b2 = l.lt == 8 && p.iband == 2;           // band 2 (H-alpha): dust only, scaled to 6563 A (raytrace_amr.f90:111-127)
         const double kapH0 = b2 ? 0.0 : c->rhokap * calc_voigt(l, p.xfreq, c->voigt_a, c->Dfreq);
         double kap0 = kapH0;
-        if (l.lt == 9) kap0 = kap0 + c->rhokap * h2_kappa_D(A.par, l, p.xfreq, c->Dfreq);
+        if (l.lt == 9) kap0 = kap0 + c->rhokap * h2_kappa_D(A.par, A.h2tab, l, p.xfreq, c->Dfreq);
         if (dust) kap0 = kap0 + c->rhokapD;
         if (b2) kap0 = dust ? c->rhokapD * A.par.R_Ha : 0.0;
         if (kap0 > 0.0) {
@@ -1492,7 +1495,7 @@ __device__ inline void raytrace_to_tau_amr(const KArgs &A, const Lds &l, bool du
         double t_exit = amr_cell_exit(a.geom[ic - 1], x, y, z, kx, ky, kz, iface);
         const bool b2 = l.lt == 8 && p.iband == 2;
         double rhokapH = b2 ? 0.0 : c->rhokap * calc_voigt(l, p.xfreq, c->voigt_a, c->Dfreq), rhokap = rhokapH;
-        if (l.lt == 9) rhokap = rhokap + c->rhokap * h2_kappa_D(A.par, l, p.xfreq, c->Dfreq);
+        if (l.lt == 9) rhokap = rhokap + c->rhokap * h2_kappa_D(A.par, A.h2tab, l, p.xfreq, c->Dfreq);
         if (dust) rhokap = rhokap + c->rhokapD;
         if (b2) rhokap = dust ? c->rhokapD * A.par.R_Ha : 0.0;
         nsteps++;
@@ -1525,7 +1528,7 @@ __device__ inline void raytrace_to_tau_amr(const KArgs &A, const Lds &l, bool du
 
 // march to optical depth tau_in; moves the packet, re-expresses xfreq at every crossing, tallies escape
 template <int VAR>
-__device__ inline void raytrace_to_tau(const KArgs &A, const Lds &l, bool dust, Photon &p, double tau_in, unsigned &nsteps, double u_own = 0.0) {
+__device__ __forceinline__ void raytrace_to_tau(const KArgs &A, const Lds &l, bool dust, Photon &p, double tau_in, unsigned &nsteps, double u_own = 0.0) {
     if (VAR == 3) { raytrace_to_tau_amr(A, l, dust, p, tau_in, nsteps); return; }
     if (VAR == 4) { raytrace_to_tau_clump(A, l, dust, p, tau_in, nsteps); return; }
     if (VAR == 7) { raytrace_to_tau_clump_ovl(A, l, dust, p, tau_in, u_own, nsteps); return; }
@@ -1542,7 +1545,7 @@ __device__ inline void raytrace_to_tau(const KArgs &A, const Lds &l, bool dust, 
         const double rk0 = c0.rhokap, D0 = c0.Dfreq, vH0 = calc_voigt(l, p.xfreq, c0.voigt_a, D0);
         const bool b2 = l.lt == 8 && p.iband == 2;           // band 2 (H-alpha): dust only, scaled to 6563 A (raytrace_car.f90:1495-1503)
         double kap0 = rk0 * vH0;
-        if (l.lt == 9) kap0 = kap0 + rk0 * h2_kappa_D(A.par, l, p.xfreq, D0);        // :1490-1493
+        if (l.lt == 9) kap0 = kap0 + rk0 * h2_kappa_D(A.par, A.h2tab, l, p.xfreq, D0);        // :1490-1493
         if (dust) kap0 = kap0 + c0.rhokapD;
         if (b2) kap0 = dust ? c0.rhokapD * A.par.R_Ha : 0.0;
         if (kap0 > 0.0) {
@@ -1573,7 +1576,7 @@ __device__ inline void raytrace_to_tau(const KArgs &A, const Lds &l, bool dust, 
     for (;;) {
         vH = calc_voigt(l, p.xfreq, va, Dold);
         double rhokap = rk * vH;
-        if (l.lt == 9) rhokap = rhokap + rk * h2_kappa_D(A.par, l, p.xfreq, Dold);
+        if (l.lt == 9) rhokap = rhokap + rk * h2_kappa_D(A.par, A.h2tab, l, p.xfreq, Dold);
         if (dust) rhokap = rhokap + rD;
         if (band2) { vH = 0.0; rhokap = dust ? rD * A.par.R_Ha : 0.0; }
         nsteps++;
@@ -1914,7 +1917,7 @@ __device__ inline void peel_dust_stokes(const KArgs &A, const Lds &l, const Phot
 // the head of the routine for `kind`, for one observer: false = nothing to march (outside the image); else the ray (q, frequency xf in the
 // frame of the packet's cell, whether dust opacity counts along it)
 template <int VAR, bool STOKES>
-__device__ inline bool peel_ray_begin(const KArgs &A, int kind, const Photon &p, double ux, double uy, double uz, double grec, const DObs &o, bool dust, PeelDir &q, double &xf, bool &ray_dust) {
+__device__ __forceinline__ bool peel_ray_begin(const KArgs &A, int kind, const Photon &p, double ux, double uy, double uz, double grec, const DObs &o, bool dust, PeelDir &q, double &xf, bool &ray_dust) {
     const Cell &c = A.g.cell[cidx(A.g, p.ic, p.jc, p.kc)];
     if (kind == PEEL_DIRECT) { double xfreq_ref; ray_dust = dust; return peel_head_direct<VAR>(A, o, p, c, q, xf, xfreq_ref); }
     if (kind == PEEL_DUST) { ray_dust = true; q = peel_dir0(A, o, p); xf = p.xfreq; return q.in_image; }
@@ -1930,7 +1933,7 @@ __device__ inline bool peel_ray_begin(const KArgs &A, int kind, const Photon &p,
 // moves towards).  Any other case -- an observer inside the medium, a start in the vacuum between clumps, the direct light of a
 // birth -- is queued and decided by the march itself.
 template <int VAR, bool STOKES>
-__device__ inline bool peel_all_opaque(const KArgs &A, const Lds &l, int kind, const Photon &p, double xa, double ux, double uy, double uz, double grec, bool dust) {
+__device__ __forceinline__ bool peel_all_opaque(const KArgs &A, const Lds &l, int kind, const Photon &p, double xa, double ux, double uy, double uz, double grec, bool dust) {
     if (kind == PEEL_DIRECT || A.heal_nside > 0 || VAR == 1) return false;
     if (VAR == 7) return false;                              // the ray may cross any number of clumps from its first metre on
     if (VAR == 4 && p.icl <= 0) return false;
@@ -1965,7 +1968,7 @@ __device__ inline bool peel_all_opaque(const KArgs &A, const Lds &l, int kind, c
 // one record into the peel queue (see DPeelQ).  Called from divergent code: the lanes of the wave that are here right now share one
 // atomic for their slots.  xa = xfreq_atom for a resonance event, the packet's xfreq for a dust event or the direct (birth) peel.
 template <int VAR, bool STOKES>
-__device__ inline void peel_emit(const KArgs &A, const Lds &l, bool dust, int kind, const Photon &p, double xa, double ux, double uy, double uz, double E1, double E2, double E3, double grec, unsigned &npeel) {
+__device__ __forceinline__ void peel_emit(const KArgs &A, const Lds &l, bool dust, int kind, const Photon &p, double xa, double ux, double uy, double uz, double E1, double E2, double E3, double grec, unsigned &npeel) {
 #ifndef LART_NO_PEEL_PREFILTER
     if (peel_all_opaque<VAR, STOKES>(A, l, kind, p, xa, ux, uy, uz, grec, dust)) { npeel += (unsigned)A.nobs; return; }   // (the one cell each ray was tested in)
 #endif
@@ -2102,7 +2105,7 @@ __device__ inline void phi_rejection(Rng &g, const Photon &p, double r, double &
     }
 }
 // dust absorption / reduced weight: :504-555 (= :217-264). true when the packet is destroyed
-__device__ inline bool dust_absorb(const KArgs &A, Rng &g, Photon &p, const Cell &c) {
+__device__ __forceinline__ bool dust_absorb(const KArgs &A, Rng &g, Photon &p, const Cell &c) {
     p.nsd = p.nsd + p.wgt;
     const lart_params &par = A.par;
     double dep = 0.0; bool killed = false;
@@ -2134,7 +2137,7 @@ __device__ inline bool dust_absorb(const KArgs &A, Rng &g, Photon &p, const Cell
 //   scatter_post -> everything after do_resonance's `uz = rand_resonance_vz(x, a)`
 struct ScatCtx { double va, xloc, cl_scale, cl_Dfreq, xsamp, dnu, vsamp; int species, iup, h2; };   // h2: 1-based H2 line of an H2 scattering (pseudo line type 9), 0 = an H I event;   // xsamp / vsamp: the sampler's frequency and Voigt parameter (2P1/2 level: xloc + dnu; deuterium, species 2: the D frame)
 template <int VAR, bool STOKES, bool DUST, bool PEEL>
-__device__ inline bool scatter_pre(const KArgs &A, const Lds &l, Rng &g, Photon &p, unsigned &npeel, ScatCtx &sc) {
+__device__ __forceinline__ bool scatter_pre(const KArgs &A, const Lds &l, Rng &g, Photon &p, unsigned &npeel, ScatCtx &sc) {
     const lart_params &par = A.par;
     const Cell &c = A.g.cell[cidx(A.g, p.ic, p.jc, p.kc)];
     double va = c.voigt_a;
@@ -2164,20 +2167,20 @@ __device__ inline bool scatter_pre(const KArgs &A, const Lds &l, Rng &g, Photon 
         return false;
     }
     if (l.lt == 9) {                                           // the H2 channel (scattering_car.f90:92-104, octree :44-57): three-way split H I / H2 / dust
-        const double kap_HI = c.rhokap * calc_voigt(l, p.xfreq, va, c.Dfreq), kap_H2 = c.rhokap * h2_kappa_D(par, l, p.xfreq, c.Dfreq), kap_D = DUST ? c.rhokapD : 0.0;
+        const double kap_HI = c.rhokap * calc_voigt(l, p.xfreq, va, c.Dfreq), kap_H2 = c.rhokap * h2_kappa_D(par, A.h2tab, l, p.xfreq, c.Dfreq), kap_D = DUST ? c.rhokapD : 0.0;
         if (g.next() * (kap_HI + kap_H2 + kap_D) <= kap_H2) {  // scatter_h2 :122-199
             const double ratio = par.h2_hi_width ? 1.0 : c.Dfreq / par.h2_Dfreq_Hz;       // h2_select_line_D (h2_mod.f90:81-115)
             double w[4], wtot = 0.0; int il = 1;
-            for (int q = 0; q < par.h2_nlines; q++) { const double dx = par.h2_dnu_Hz[q] / c.Dfreq, x_h2 = (p.xfreq - dx) * ratio; w[q] = par.h2_strength[q] * ratio * voigt_H(l.vt, x_h2, par.h2_a_damp[q]); wtot = wtot + w[q]; }
+            for (int q = 0; q < par.h2_nlines; q++) { const double dx = A.h2tab[q] / c.Dfreq, x_h2 = (p.xfreq - dx) * ratio; w[q] = A.h2tab[4 + q] * ratio * voigt_H(l.vt, x_h2, A.h2tab[8 + q]); wtot = wtot + w[q]; }
             if (wtot > 0.0) { const double r = g.next() * wtot; double acc = 0.0; il = par.h2_nlines; for (int q = 0; q < par.h2_nlines; q++) { acc = acc + w[q]; if (r <= acc) { il = q + 1; break; } } }
             atomicAdd(&A.t.scal[LART_SCAL_AUX + 2 + il - 1], p.wgt);                      // W_H2pump(il)
-            if (g.next() > par.h2_p_scat[il - 1]) {            // fluorescence to another wavelength: the packet leaves Ly-alpha
+            if (g.next() > A.h2tab[12 + il - 1]) {            // fluorescence to another wavelength: the packet leaves Ly-alpha
                 atomicAdd(&A.t.scal[LART_SCAL_AUX + 0], p.wgt); p.inside = false; if (A.allph) p.wgt = 0.0;
                 return false;
             }
             atomicAdd(&A.t.scal[LART_SCAL_AUX + 1], p.wgt); p.nsg = p.nsg + p.wgt;
-            const double rt = c.Dfreq / par.h2_Dfreq_Hz, dx = par.h2_dnu_Hz[il - 1] / c.Dfreq;       // (scatter_h2 always uses the H2 Doppler width: :163-166)
-            sc.h2 = il; sc.cl_Dfreq = c.Dfreq; sc.xsamp = (p.xfreq - dx) * rt; sc.vsamp = par.h2_a_damp[il - 1]; sc.xloc = sc.xsamp;
+            const double rt = c.Dfreq / par.h2_Dfreq_Hz, dx = A.h2tab[il - 1] / c.Dfreq;       // (scatter_h2 always uses the H2 Doppler width: :163-166)
+            sc.h2 = il; sc.cl_Dfreq = c.Dfreq; sc.xsamp = (p.xfreq - dx) * rt; sc.vsamp = A.h2tab[8 + il - 1]; sc.xloc = sc.xsamp;
             return true;
         }
     }
@@ -2244,11 +2247,11 @@ __device__ inline bool scatter_pre(const KArgs &A, const Lds &l, Rng &g, Photon 
     return true;
 }
 template <int VAR, bool STOKES, bool DUST, bool PEEL>
-__device__ inline void scatter_post(const KArgs &A, const Lds &l, Rng &g, Photon &p, unsigned &npeel, const ScatCtx &sc, double uz_loc_in) {
+__device__ __forceinline__ void scatter_post(const KArgs &A, const Lds &l, Rng &g, Photon &p, unsigned &npeel, const ScatCtx &sc, double uz_loc_in) {
     double uz_loc = uz_loc_in;
     const lart_params &par = A.par;
     if (l.lt == 9 && sc.h2 > 0) {                              // scatter_h2 (scattering_car.f90:160-199): coherent in the molecule's frame, isotropic re-emission, H2 Doppler units and back
-        const double ratio = sc.cl_Dfreq / par.h2_Dfreq_Hz, dx = par.h2_dnu_Hz[sc.h2 - 1] / sc.cl_Dfreq, xatom = sc.xsamp - uz_loc;
+        const double ratio = sc.cl_Dfreq / par.h2_Dfreq_Hz, dx = A.h2tab[sc.h2 - 1] / sc.cl_Dfreq, xatom = sc.xsamp - uz_loc;
         double u0, u1, u2, u3; g.next2(u0, u1); g.next2(u2, u3);
         const double cost = 2.0 * u0 - 1.0, sint = sqrt(1.0 - cost * cost);
         double sinp, cosp, s2, c2; d_sincos_2pi(u1, &sinp, &cosp); d_sincos_2pi(u2, &s2, &c2);
@@ -2389,7 +2392,7 @@ __device__ inline void allph_final(const KArgs &A, const Photon &p, long long k)
 // `on`: this lane has a packet to scatter.  Every lane of the wave that is inside the event loop calls this (the |x| <= 1
 // sampler is a wave-cooperative stage, vz_core_coop).
 template <int VAR, bool STOKES, bool DUST, bool PEEL>
-__device__ inline void scatter_event(const KArgs &A, const Lds &l, Rng &g, Photon &p, unsigned &npeel, bool on) {
+__device__ __forceinline__ void scatter_event(const KArgs &A, const Lds &l, Rng &g, Photon &p, unsigned &npeel, bool on) {
     ScatCtx sc; sc.xloc = 0.0; sc.xsamp = 0.0; sc.va = 1.0; sc.vsamp = 1.0; sc.species = 1; sc.iup = 0; sc.h2 = 0;
 #if defined(LART_PROFILE) || defined(LART_NO_COOP)
     if (!on || !scatter_pre<VAR, STOKES, DUST, PEEL>(A, l, g, p, npeel, sc)) return;
@@ -2419,7 +2422,7 @@ __device__ inline void scatter_event(const KArgs &A, const Lds &l, Rng &g, Photo
 // photon birth: generate_photon.f90:3-339, setup_isotropic_injection :342-408
 // ---------------------------------------------------------------------------------------------
 template <int VAR, bool STOKES, bool DUST, bool PEEL>
-__device__ inline void generate_photon(const KArgs &A, const Lds &l, Rng &g, Photon &p, unsigned &npeel) {
+__device__ __forceinline__ void generate_photon(const KArgs &A, const Lds &l, Rng &g, Photon &p, unsigned &npeel) {
     const lart_params &par = A.par; const DGrid &gr = A.g;
     if (par.source_geometry == 1) {
         double rp = cbrt(g.next()) * par.source_rmax, cost = 2.0 * g.next() - 1.0, sint = sqrt(1.0 - cost * cost), sp, cp;

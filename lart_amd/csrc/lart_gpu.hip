@@ -74,6 +74,7 @@ struct lart_gpu {
     double *d_reduced = nullptr; bool reduced_valid = false;
     // history probe (lart_gpu_test_trace)
     int *d_trace_slot = nullptr, *d_trace_n = nullptr; double *d_trace = nullptr; int trace_cap = 0;
+    double *d_h2tab = nullptr;                               // the H2 line table of h2_kappa_D (16 doubles)
 };
 
 extern "C" const char *lart_gpu_last_error(void) { return g_err.c_str(); }
@@ -112,6 +113,10 @@ extern "C" int lart_gpu_create(lart_gpu **out, const lart_params *par, int devic
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIPCHK(hipMalloc(&c->d_ctl, sizeof(DCtl)));
     HIPCHK(hipMemset(c->d_ctl, 0, sizeof(DCtl)));
+    if (par->h2_nlines > 0) {
+        double h[16] = {0}; for (int i = 0; i < par->h2_nlines; i++) { h[i] = par->h2_dnu_Hz[i]; h[4 + i] = par->h2_strength[i]; h[8 + i] = par->h2_a_damp[i]; h[12 + i] = par->h2_p_scat[i]; }
+        HIPCHK(hipMalloc(&c->d_h2tab, sizeof h)); HIPCHK(hipMemcpy(c->d_h2tab, h, sizeof h, hipMemcpyHostToDevice));
+    }
     *out = c;
     return 0;
 }
@@ -137,7 +142,7 @@ extern "C" int lart_gpu_destroy(lart_gpu *c) {
     (void)hipStreamSynchronize(c->stream);
     for (auto &e : c->ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     (void)hipFree(c->d_cell); (void)hipFree(c->d_faces); (void)hipFree(c->d_mu); (void)hipFree(c->d_alias); (void)hipFree(c->d_ml_tab); (void)hipFree(c->d_ml_itab); (void)hipFree(c->d_obs); (void)hipFree(c->d_ind_bin); (void)hipFree(c->d_amr_int); (void)hipFree(c->d_amr_geom); (void)hipFree(c->d_cl_geo); (void)hipFree(c->d_cl_phys); (void)hipFree(c->d_cl_int);
-    free_tally(c); (void)hipFree(c->d_pool); (void)hipFree(c->d_ctl); (void)hipFree(c->d_log); (void)hipFree(c->d_compact); (void)hipFree(c->d_pq);
+    free_tally(c); (void)hipFree(c->d_h2tab); (void)hipFree(c->d_pool); (void)hipFree(c->d_ctl); (void)hipFree(c->d_log); (void)hipFree(c->d_compact); (void)hipFree(c->d_pq);
     if (c->comm) { (void)ncclCommDestroy(c->comm); c->comm = nullptr; }
     for (int b = 0; b < 2; b++) { if (c->ev_filled[b]) (void)hipEventDestroy(c->ev_filled[b]); if (c->ev_drained[b]) (void)hipEventDestroy(c->ev_drained[b]); }
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
@@ -704,7 +709,7 @@ extern "C" int lart_gpu_step(lart_gpu *c, int32_t nsteps, int32_t max_events) {
     A.first_id = c->first_id; A.stride = c->stride; A.count = c->count; A.seed = c->seed; A.max_events = max_events;
     A.log_nscatt = c->d_log; A.log_xfreq = c->d_log ? c->d_log + c->nlog : nullptr;
     A.allph = (c->d_log && c->log_on == 2) ? c->d_log + 2 * c->nlog : nullptr; A.allph_n = c->nlog;
-    A.trace_slot = c->d_trace_slot; A.trace = c->d_trace; A.trace_n = c->d_trace_n; A.trace_cap = c->trace_cap;
+    A.trace_slot = c->d_trace_slot; A.trace = c->d_trace; A.trace_n = c->d_trace_n; A.trace_cap = c->trace_cap; A.h2tab = c->d_h2tab;
     int var = march_variant(c);
     const bool h2 = c->par.h2_nlines > 0;
     if (h2) A.par.line_type = 9;                               // pseudo line type of the kernels: Ly-alpha + the H2 lines (lart_device.hpp, h2_kappa_D)
@@ -1123,7 +1128,7 @@ template <typename T> struct DevBuf {
     ~DevBuf() { if (p) (void)hipFree(p); }
 };
 static KArgs probe_args(lart_gpu *c) {
-    KArgs A{}; A.par = c->par; if (c->par.h2_nlines > 0) A.par.line_type = 9; A.g = c->g; A.t = c->t; A.mu = c->mu; A.obs = c->d_obs; A.nobs = 0; A.nxim = c->nxim; A.nyim = c->nyim; A.dxim = c->dxim; A.dyim = c->dyim; A.ctl = c->d_ctl; A.heal_nside = c->heal_nside; A.jpa = c->jpa; A.amr = c->amr; A.cl = c->cl; A.ml = c->ml;
+    KArgs A{}; A.par = c->par; if (c->par.h2_nlines > 0) A.par.line_type = 9; A.h2tab = c->d_h2tab; A.g = c->g; A.t = c->t; A.mu = c->mu; A.obs = c->d_obs; A.nobs = 0; A.nxim = c->nxim; A.nyim = c->nyim; A.dxim = c->dxim; A.dyim = c->dyim; A.ctl = c->d_ctl; A.heal_nside = c->heal_nside; A.jpa = c->jpa; A.amr = c->amr; A.cl = c->cl; A.ml = c->ml;
     return A;
 }
 static size_t probe_shmem(lart_gpu *c) { return (size_t)(VT_END + c->g.nx + c->g.ny + c->g.nz + 3) * sizeof(double); }
