@@ -50,7 +50,7 @@ def compare(jg_raw, ng, jr_raw, nr, label):
     return rms, exp, chi2
 
 
-N_DEVICE = {"c1": 1000000, "c2": 1000000, "c3": 100000, "c4": 1000000, "c5": 300000}
+N_DEVICE = {"c1": 1000000, "c2": 1000000, "c3": 100000, "c4": 1000000, "c5": 300000}       # (the run time is the longest history of c2 / c3, not the photon count)
 SEED = {"c1": 20261005, "c2": 20261004, "c3": 20261006, "c4": 20261007, "c5": 20261008}
 FIXTURE = {"c1": "c1_slab_tau4.npz", "c2": "c2_tau6.npz", "c3": "c3_peel_tau6.npz", "c4": "c4_clump_dust.npz", "c5": "c5_amr_JP.npz"}
 
@@ -168,7 +168,8 @@ def test_c4_clumps_dust_stokes_full_size(runs):
     assert abs(ns.mean() - float(fx["nscatt_mean"])) < 4 * err, (ns.mean(), float(fx["nscatt_mean"]), err)
     # dust: tau_dust of a clump is 2.7e-5, so absorption is rare; absorbed + escaped = emitted, and the absorbed share agrees within its counting error
     ja, jr = t["Jabs"].sum(), float(fx["Jabs_raw"].sum())
-    assert abs(t["Jout"].sum() + ja - n) < 1e-6 * n
+    lost_g, lost_r = 1.0 - (t["Jout"].sum() + ja) / n, 1.0 - (float(fx["Jout_raw"].sum()) + jr) / nr      # packets that leave through the ends of the +-100 km/s axis
+    assert 0.0 <= lost_g < 1e-3 and abs(lost_g - lost_r) < 4.0 * np.sqrt(max(lost_r, 1e-6) * (1.0 / n + 1.0 / nr)) + 1e-6, (lost_g, lost_r)
     assert abs(ja / n - jr / nr) < 4.0 * np.sqrt(jr / nr * (1.0 / n + 1.0 / nr)) + 1e-7, (ja / n, jr / nr)
     peel_checks(t, n, fx, nr, ("scatt", "I"), "C4", 129)
     rms, exp, chi2, g, r, sig = weighted(t["direc"][..., 0].sum(axis=(1, 2)), n, fx, "direc_spec", nr, "C4 peel direct spectrum")

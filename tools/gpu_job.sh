@@ -49,7 +49,7 @@ for spec in "$@"; do
     bench)   step bench 900 python bench.py ${a1//,/ } ;;
     configs) step configs 900 python tools/perf_configs.py ;;
     perf)    for c in ${a1//,/ }; do step perf_$c 400 python tools/perf_kernel.py --config $c ${a2//,/ }; done ;;
-    prof)    profile "$a1" transport_kernel 4096 python3 bench.py --no-cpu-baseline --completion-photons 0 ${a2//,/ } ;;
+    prof)    profile "$a1" transport_kernel 4096 python3 bench.py --no-cpu-baseline --completion-photons 0 --no-other-configs ${a2//,/ } ;;
     profcfg) profile "$a1" transport_kernel 4096 python3 tools/perf_kernel.py --config "$a2" ;;
     stats)   step ${a1}_stats 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${a1}_stats -- python3 tools/perf_kernel.py --config "$a2"
              f=$(find gpurun_out/${a1}_stats -name "*kernel_stats.csv" | head -n 1); [ -n "$f" ] && cp "$f" gpurun_out/${a1}_kernel_stats.csv && head -n 8 gpurun_out/${a1}_kernel_stats.csv | cut -c1-300; rm -rf gpurun_out/${a1}_stats ;;
