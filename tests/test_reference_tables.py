@@ -138,3 +138,85 @@ def test_hei_sphere_nscatt_table_thin_rows(exe, tmp_path, row):
     want = row["Nscatt"] * 7.0 / 9.0
     # the weight of the forced first scattering is 1 - exp(-tau) ~ tau with a spread of its own size: 4 sigma of 4e6 photons + the second-order term in tau
     assert abs(nsc / want - 1.0) < 4.0 / np.sqrt(n) * 1.5 + 0.6 * tau + 2e-3, (nsc, want)
+
+
+# ---- reference-held numbers outside the example directories' own tables ----------------------------------------------------------------------
+# docs/LaRT_AMR_description.pdf, section 11 "Validation" (text recovered from the PDF streams): uniform H I sphere, central point
+# source, T = 1e4 K, no dust, 101^3 Cartesian grid against the octree of the same resolution:
+#     tau0   J_out,max AMR   J_out,max CAR   ratio   peak velocity
+#     1e2    6.630e-3        6.836e-3        0.970   +-26.75 km/s
+#     1e4    7.144e-3        7.402e-3        0.965   +-38.21 km/s
+# and the "smoke test" of section 10 (Cartesian 64^3, tau0 = 1e4, 1e6 photons): sum Jout = 8.5136e-2 (AMR: 8.5134e-2).
+AMR_DOC = {1e2: dict(car=6.836e-3, amr=6.630e-3, vpeak=26.75), 1e4: dict(car=7.402e-3, amr=7.144e-3, vpeak=38.21)}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tau0,n", [(1e2, 4000000), (1e4, 1000000)])
+def test_amr_description_validation_table(tau0, n):
+    """J_out,max and the peak velocities of the 101^3 Cartesian run and of the octree (levels 3..7, 178 480 leaves: the example's generator) as the
+    reference's AMR description tabulates them: pins output_normalize_outside / _amr and the frequency axis for both media"""
+    import __graft_entry__ as g
+    g.build()
+    from lart_amd import host, amr
+    import tempfile
+    want = AMR_DOC[tau0]
+    car = host.Simulation(dict(temperature=1e4, taumax=tau0, nx=101, ny=101, nz=101, rmax=1.0, DGR=0.0, spectral_type="voigt", nxfreq=121, iseed=3))
+    car.run_simulation(n); oc = car.output_normalize(car.ctx.tallies())
+    jc = oc["Jout"]; vc = car.grid.velocity
+    fn = os.path.join(tempfile.mkdtemp(), "sphere.dat"); amr.write_generic_amr(fn, amr.make_amr_sphere())
+    oct_ = host.Simulation(dict(use_amr_grid=True, amr_file=fn, temperature=1e4, taumax=tau0, rmax=1.0, DGR=0.0, spectral_type="voigt", nxfreq=121, iseed=4))
+    oct_.run_simulation(n); oa = oct_.output_normalize(oct_.ctx.tallies())
+    ja = oa["Jout"]
+    def peak(j, v):
+        i = int(np.argmax(j)); return j[i], abs(v[i])
+    pc, v1 = peak(jc, vc); pa, w1 = peak(ja, oct_.grid.velocity)
+    dv = abs(vc[1] - vc[0])
+    print("tau0 %g: J_max CAR %.4e (doc %.3e)  AMR %.4e (doc %.3e)  ratio %.4f (doc %.3f)  peak CAR %.2f AMR %.2f km/s (doc %.2f, bin %.2f)" % (tau0, pc, want["car"], pa, want["amr"], pa / pc, want["amr"] / want["car"], v1, w1, want["vpeak"], dv))
+    assert abs(pc / want["car"] - 1.0) < 0.02 and abs(pa / want["amr"] - 1.0) < 0.02
+    assert abs(pa / pc - want["amr"] / want["car"]) < 0.015                       # the 3-5 % amplitude loss of the voxelised boundary
+    assert abs(want["vpeak"] / dv - round(want["vpeak"] / dv)) < 0.01             # the tabulated peak is a bin centre of this axis (setup_freq_grid's default range)
+    assert abs(v1 - want["vpeak"]) < 3.5 * dv and abs(w1 - want["vpeak"]) < 3.5 * dv     # the flat top moves the arg max by a few bins between noise realisations
+
+
+@pytest.mark.gpu
+def test_amr_description_inside_observer_smoke_table():
+    """section 10 of the same document (sphere_car_inside_test1M.in / sphere_amr_inside_test1M.in: tau0 = 1e4, HEALPix observer nside = 8 at x = 0.3, 1e6
+    photons):  sum Jout = sum Jin = 8.5136e-2 (Cartesian 64^3), 8.5134e-2 / 8.5135e-2 (octree); sum of the scattered HEALPix cube 2322 / 2592"""
+    import __graft_entry__ as g
+    g.build()
+    from lart_amd import host, amr
+    import tempfile
+    base = dict(temperature=1e4, taumax=1e4, DGR=0.0, spectral_type="voigt", source_geometry="point", rmax=1.0, nside=8, obsx=0.3, obsy=0.0, obsz=0.0, nxfreq=121,
+                save_peeloff=True, save_peeloff_2D=True, save_Jin=True)
+    fn = os.path.join(tempfile.mkdtemp(), "sphere.dat"); amr.write_generic_amr(fn, amr.make_amr_sphere())
+    res = {}
+    for name, kw in (("car", dict(nx=64, ny=64, nz=64, iseed=5)), ("amr", dict(use_amr_grid=True, amr_file=fn, iseed=6))):
+        sim = host.Simulation(dict(base, **kw)); sim.run_simulation(1000000); o = sim.output_normalize(sim.ctx.tallies())
+        res[name] = o
+        print(name, "sum Jout %.5e  sum Jin %.5e" % (o["Jout"].sum(), o["Jin"].sum()), {k: float(np.sum(v)) for k, v in o.items() if k.startswith(("scatt", "direc"))})
+    assert abs(res["car"]["Jout"].sum() / 8.5136e-2 - 1.0) < 2e-4 and abs(res["car"]["Jin"].sum() / 8.5136e-2 - 1.0) < 2e-4
+    assert abs(res["amr"]["Jout"].sum() / 8.5134e-2 - 1.0) < 2e-4 and abs(res["amr"]["Jin"].sum() / 8.5135e-2 - 1.0) < 2e-4
+    for name, want in (("car", 2322.0), ("amr", 2592.0)):
+        assert abs(np.sum(res[name]["scatt"]) / want - 1.0) < 0.2, (name, np.sum(res[name]["scatt"]))
+
+
+@pytest.mark.gpu
+def test_clump_sphere_log_back_fcov5():
+    """examples/clump_sphere/log_back:114-178 (clump_NHI18_fcov5.in: 6 666 667 clumps of radius 0.001, f_cov = 5, N_HI = 1e18 per sight line, flat rotation
+    curve, monochromatic source): the set-up lines of the log and 'Average Number of scattering : 4.2399E+04' with 1e5 photons"""
+    import __graft_entry__ as g
+    g.build()
+    from lart_amd import host
+    kw = dict(use_clump_medium=True, rmax=1.0, rmin=0.1, clump_fully_inside=False, clump_radius=0.001, clump_f_cov=5.0, N_HImax=1e18, temperature=1e4, clump_sigma_v=0.0,
+              spectral_type="monochromatic", geometry="sphere", velocity_type="rotating_galaxy_halo", Vrot=300.0, rinner=0.1, nxfreq=500, velocity_min=-1000.0,
+              velocity_max=1000.0, nx=11, ny=11, nz=11, iseed=1)
+    n = 100000
+    sim = host.Simulation(kw); sim.ctx.enable_photon_log(True)
+    c = sim.clumps
+    assert c.N == 6666667 and abs(c.fvol - 0.006667) < 1e-6                       # log_back:123-124
+    assert np.isclose(c.rhokap_ref, 4.4261e7, rtol=2e-5) and np.isclose(c.Dfreq_ref, 1.0566e11, rtol=1e-4)       # :127, :129
+    sim.run_simulation(n)
+    ns, _ = sim.ctx.photon_log(n)
+    err = ns.std() / np.sqrt(n)
+    print("clump_NHI18_fcov5: <N_scatt> = %.4e +- %.2e (log_back: 4.2399E+04)" % (ns.mean(), err))
+    assert abs(ns.mean() - 4.2399e4) < 0.01 * 4.2399e4 + 4 * err, (ns.mean(), err)
