@@ -52,7 +52,7 @@ struct lart_gpu {
     double *d_tally = nullptr; int64_t ntally = 0; DTally t{};
     DRep rep{}; bool rep_dirty = false;                      // per-XCD copies of the contended tally sections
     // pool
-    DPool pool{}; void *d_pool = nullptr; int64_t want_lanes = 0; int block = 256;
+    DPool pool{}; void *d_pool = nullptr; int64_t want_lanes = 0; int block = 256; bool block_user = false;
     DCtl *d_ctl = nullptr;
     // run
     long long first_id = 0, stride = 1, count = 0; unsigned long long seed = 0; bool begun = false;
@@ -174,19 +174,7 @@ static int build_tally(lart_gpu *c) {
     if (c->jpa.nbins > 0) {
         // P1 / P1_new: per-block LDS copies while they fit
         c->jpa.lds_bins = ((c->jpa.calc_P || c->jpa.calc_Pnew) && c->jpa.nbins <= 2048) ? c->jpa.nbins : 0;
-        // J1: a window of frequency bins around the line centre per block in LDS, as wide as three workgroups per CU leave room for (160 KiB / 3)
-        c->jpa.lds_j_w = 0; c->jpa.lds_j_lo = 0;
-        // (with J alone the occupancy it costs outweighs the atomics it saves: 14.5e9 -> 11.4e9 events/s on the octree; with P / P_new too 9.3 -> 10.6e9)
-        if (c->jpa.calc_J && (c->jpa.calc_P || c->jpa.calc_Pnew) && !std::getenv("LART_NO_LDS_J")) {
-            const long long base = (long long)(VT_END + c->g.nx + c->g.ny + c->g.nz + 3 + LART_RNG_BUF * c->block + 2 * c->jpa.lds_bins) * 8 + (LART_COOP_BYTES + 4) * ((c->block + 63) / 64);
-            long long w = ((long long)160 * 1024 / 3 - 256 - base) / (8LL * c->jpa.nbins);
-            if (w > 48) w = 48; if (w > nxf) w = nxf;
-            if (w >= 8) {
-                const int ixc = (int)std::floor((0.0 - p.xfreq_min) / p.dxfreq);       // 0-based bin of the line centre in reference units
-                int lo = ixc - (int)w / 2; if (lo < 0) lo = 0; if (lo + w > nxf) lo = (int)(nxf - w);
-                c->jpa.lds_j_w = (int)w; c->jpa.lds_j_lo = lo;
-            }
-        }
+        c->jpa.lds_j_w = 0; c->jpa.lds_j_lo = 0;             // the J1 window is sized at launch, when the workgroup size is known (size_j_window)
         if (c->jpa.calc_J)    { oJ1 = off; off += nxf * c->jpa.nbins; }
         if (c->jpa.calc_P)    { oP1 = off; off += c->jpa.nbins; }
         if (c->jpa.calc_Pnew) { oPn = off; off += c->jpa.nbins; }
@@ -473,9 +461,9 @@ extern "C" int lart_gpu_set_clump_overlap(lart_gpu *c, int32_t has_overlap) {
 
 extern "C" int lart_gpu_set_pool(lart_gpu *c, int64_t nlanes, int32_t block) {
     if (!c) return fail("set_pool: null context");
-    if (block != 0 && (block % 64 != 0 || block < 64 || block > 256)) return fail("set_pool: block must be 64, 128, 192 or 256");
+    if (block != 0 && (block % 64 != 0 || block < 64 || block > 1024)) return fail("set_pool: block must be a multiple of 64 up to 1024");
     if (c->begun) return fail("set_pool: call before lart_gpu_begin");
-    c->want_lanes = nlanes; if (block) c->block = block;
+    c->want_lanes = nlanes; if (block) { c->block = block; c->block_user = true; }
     return 0;
 }
 
@@ -488,7 +476,39 @@ extern "C" int lart_gpu_pool_info(lart_gpu *c, int64_t *nlanes, int32_t *block) 
 extern "C" int lart_gpu_enable_photon_log(lart_gpu *c, int32_t on) { if (!c) return fail("null context"); c->log_on = on ? (c->log_on == 2 ? 2 : 1) : 0; return 0; }
 extern "C" int lart_gpu_enable_all_photons(lart_gpu *c, int32_t on) { if (!c) return fail("null context"); c->log_on = on ? 2 : 0; return 0; }
 
+// J1(x, bin): a window of frequency bins around the line centre is accumulated per workgroup in LDS (ds_add_f64) and flushed once per launch: scattered
+// f64 atomics execute at the memory side at ~1e10 per second for the whole chip, which is what one deposit per flight asks for.  The window is as wide as the
+// LDS of a CU allows at FULL occupancy: four 256-lane workgroups leave 2 KiB each (four copies of the tables, 32 KiB of draws each), one 1024-lane workgroup
+// leaves ~19 KiB -- so a run with J(x) and no Stokes vector uses 1024-lane workgroups unless lart_gpu_set_pool chose the size.  When that is not possible (Stokes:
+// 3 waves per SIMD, or a forced size), one workgroup per CU less buys the room.  Octree, 178 480 leaves, events/s on one MI355X: no tallies 17.1e9; J + P + P_new
+// 9.3e9 with global atomics, 10.7e9 with the window at three 256-lane workgroups per CU, 12.6e9 with one 1024-lane workgroup.  With J alone the memory-side
+// atomics are not yet the limit (14.4e9 against 13.3e9 with the window), so J alone keeps them.
+static void size_j_window(lart_gpu *c) {
+    c->jpa.lds_j_w = 0; c->jpa.lds_j_lo = 0;
+    if (!(c->jpa.nbins > 0 && c->jpa.calc_J) || std::getenv("LART_NO_LDS_J")) return;
+    if (!(c->jpa.calc_P || c->jpa.calc_Pnew) && !std::getenv("LART_LDS_J")) return;          // J alone: see above
+    const int64_t nxf = c->par.nxfreq;
+    const long long base = (long long)(VT_END + c->g.nx + c->g.ny + c->g.nz + 3 + LART_RNG_BUF * c->block + 2 * c->jpa.lds_bins) * 8 + (LART_COOP_BYTES + 4) * ((c->block + 63) / 64);
+    const int waves_cu = c->par.use_stokes ? 12 : 16;
+    int per_cu = waves_cu * 64 / c->block; if (per_cu < 1) per_cu = 1;
+    long long w = 0;
+    for (int give = 0; give < 2 && w < 8; give++) {
+        if (give && !(c->jpa.calc_P || c->jpa.calc_Pnew)) break;
+        if (per_cu - give < 1) break;
+        w = ((long long)160 * 1024 / (per_cu - give) - 256 - base) / (8LL * c->jpa.nbins);
+    }
+    if (w > 64) w = 64; if (w > nxf) w = nxf;
+    if (w < 8) return;
+    const int ixc = (int)std::floor((0.0 - c->par.xfreq_min) / c->par.dxfreq);       // 0-based bin of the line centre in reference units
+    int lo = ixc - (int)w / 2; if (lo < 0) lo = 0; if (lo + w > nxf) lo = (int)(nxf - w);
+    c->jpa.lds_j_w = (int)w; c->jpa.lds_j_lo = lo;
+}
+
 static int ensure_pool(lart_gpu *c) {
+    if (!c->block_user) {
+        c->block = 256;
+        if (c->jpa.nbins > 0 && c->jpa.calc_J && (c->jpa.calc_P || c->jpa.calc_Pnew) && !c->par.use_stokes) { c->block = 1024; size_j_window(c); if (c->jpa.lds_j_w < 8) c->block = 256; }
+    }
     int64_t n = c->want_lanes;
     if (n <= 0) {
         hipDeviceProp_t pr; HIPCHK(hipGetDeviceProperties(&pr, c->device));
@@ -717,7 +737,9 @@ extern "C" int lart_gpu_step(lart_gpu *c, int32_t nsteps, int32_t max_events) {
     if (c->par.line_type == 8 && (c->heal_nside > 0)) return fail("step: ly_beta: inside-observer (HEALPix) not yet supported (setup.f90:249-253)");
     if (h2 && c->heal_nside > 0) return fail("step: H2: inside-observer (HEALPix) not yet supported");
     int stokes = c->par.use_stokes ? 1 : 0, dust = c->par.DGR > 0.0 ? 1 : 0, peel = (c->par.save_peeloff && c->nobs > 0) ? 1 : 0;
+    if (c->block > 256 && stokes) return fail("step: the kernels with a Stokes vector run 3 waves per SIMD: workgroups of at most 256 lanes (lart_gpu_set_pool)");
     dim3 block(c->block), grid((unsigned)(c->live_lanes / c->block));
+    size_j_window(c); A.jpa = c->jpa;
     // Voigt tables + faces | ring of random draws [LART_RNG_BUF][block] | per-block P1, P1_new
     size_t shmem = (size_t)(VT_END + c->g.nx + c->g.ny + c->g.nz + 3 + LART_RNG_BUF * c->block + 2 * c->jpa.lds_bins + c->jpa.lds_j_w * c->jpa.nbins) * sizeof(double) + (size_t)(LART_COOP_BYTES + 4) * ((c->block + 63) / 64);   // ... + the wave-local scratch of vz_core_coop + the waves' peel-queue counters
     if (shmem > 160 * 1024) return fail("step: grid faces do not fit the 160 KiB LDS");

@@ -22,6 +22,9 @@ __device__ inline double wave_sum(double v) {
 #else
 #define LART_WAVES(S, P) ((S) ? 3 : 4)
 #endif
+// largest workgroup: the kernels that fit 128 VGPRs may run as ONE 1024-lane workgroup per CU (the same 4 waves per SIMD), which leaves the LDS that four
+// 256-lane workgroups spend on four copies of the tables to the J(x) window of the profile tallies (lart_gpu.hip, tally layout)
+#define LART_MAX_BLOCK(S, P) (LART_WAVES(S, P) >= 4 ? 1024 : 256)
 
 
 // one flight of a packet: optical depth to the next interaction (forced on the first flight: run_simulation_mod.f90:163-177,
@@ -57,7 +60,7 @@ __device__ inline void fly(const KArgs &A, const Lds &l, Rng &g, Photon &p, bool
 
 // LT: line%line_type as a compile-time constant (1 single line, 2 Ly-alpha doublet, 7 hydrogen + deuterium), handed to the device functions through Lds
 template <int VAR, bool STOKES, bool DUST, bool PEEL, int LT>
-__global__ __launch_bounds__(256, LART_WAVES(STOKES, PEEL)) void transport_kernel(KArgs A) {
+__global__ __launch_bounds__(LART_MAX_BLOCK(STOKES, PEEL), LART_WAVES(STOKES, PEEL)) void transport_kernel(KArgs A) {
     extern __shared__ double sh[];
     if (A.rep.nrep > 1) {                                      // this block's copy of the contended tally sections (DRep)
         const unsigned r = blockIdx.x % (unsigned)A.rep.nrep;

@@ -153,8 +153,8 @@ AMR_DOC = {1e2: dict(car=6.836e-3, amr=6.630e-3, vpeak=26.75), 1e4: dict(car=7.4
 @pytest.mark.gpu
 @pytest.mark.parametrize("tau0,n", [(1e2, 4000000), (1e4, 1000000)])
 def test_amr_description_validation_table(tau0, n):
-    """J_out,max and the peak velocities of the 101^3 Cartesian run and of the octree (levels 3..7, 178 480 leaves: the example's generator) as the
-    reference's AMR description tabulates them: pins output_normalize_outside / _amr and the frequency axis for both media"""
+    """J_out,max and the peak velocities of the 101^3 Cartesian run as the reference's AMR description tabulates them, and the octree of the example's generator
+    (levels 3..7, 178 480 leaves) against the Cartesian run: pins output_normalize_outside / _amr and the default frequency axis for both media"""
     import __graft_entry__ as g
     g.build()
     from lart_amd import host, amr
@@ -170,10 +170,18 @@ def test_amr_description_validation_table(tau0, n):
     def peak(j, v):
         i = int(np.argmax(j)); return j[i], abs(v[i])
     pc, v1 = peak(jc, vc); pa, w1 = peak(ja, oct_.grid.velocity)
+    print("photons done CAR %d AMR %d  sum Jout CAR %.6e AMR %.6e  <N_scatt> CAR %.5e AMR %.5e" % (oc["nphotons_done"], oa["nphotons_done"], jc.sum(), ja.sum(), oc["nscatt_tot"], oa["nscatt_tot"]))
+    assert oc["nphotons_done"] == n and oa["nphotons_done"] == n
+    # every photon ends in a bin of the axis at these depths: sum Jout = 1 / (dx 2 pi 4 pi r^2) (output_sum_rect.f90:191-202), for both media
+    dx = abs(car.grid.xfreq[1] - car.grid.xfreq[0])
+    assert abs(jc.sum() * dx * 8.0 * np.pi ** 2 - 1.0) < 2e-4 and abs(ja.sum() * dx * 8.0 * np.pi ** 2 - 1.0) < 2e-4
     dv = abs(vc[1] - vc[0])
     print("tau0 %g: J_max CAR %.4e (doc %.3e)  AMR %.4e (doc %.3e)  ratio %.4f (doc %.3f)  peak CAR %.2f AMR %.2f km/s (doc %.2f, bin %.2f)" % (tau0, pc, want["car"], pa, want["amr"], pa / pc, want["amr"] / want["car"], v1, w1, want["vpeak"], dv))
-    assert abs(pc / want["car"] - 1.0) < 0.02 and abs(pa / want["amr"] - 1.0) < 0.02
-    assert abs(pa / pc - want["amr"] / want["car"]) < 0.015                       # the 3-5 % amplitude loss of the voxelised boundary
+    assert abs(pc / want["car"] - 1.0) < 0.015                                     # the Cartesian column: normalisation and peak height (measured 0.6 % / 0.1 %)
+    # The document's octree column (3 - 3.5 % below) belongs to a leaf table whose boundary leaves "carry only the average density"; that table is not shipped, and
+    # the shipped generator (make_amr_sphere_data.py: a step function refined down to level 7 along the surface) gives the Cartesian peak to within the noise, as it
+    # must: the two are then the same sphere.  Asserted: that agreement, and that the octree is not ABOVE the Cartesian run by more than the noise.
+    assert abs(pa / pc - 1.0) < 0.015
     assert abs(want["vpeak"] / dv - round(want["vpeak"] / dv)) < 0.01             # the tabulated peak is a bin centre of this axis (setup_freq_grid's default range)
     assert abs(v1 - want["vpeak"]) < 3.5 * dv and abs(w1 - want["vpeak"]) < 3.5 * dv     # the flat top moves the arg max by a few bins between noise realisations
 
@@ -202,19 +210,24 @@ def test_amr_description_inside_observer_smoke_table():
 
 @pytest.mark.gpu
 def test_clump_sphere_log_back_fcov5():
-    """examples/clump_sphere/log_back:114-178 (clump_NHI18_fcov5.in: 6 666 667 clumps of radius 0.001, f_cov = 5, N_HI = 1e18 per sight line, flat rotation
-    curve, monochromatic source): the set-up lines of the log and 'Average Number of scattering : 4.2399E+04' with 1e5 photons"""
+    """examples/clump_sphere/log_back:114-178 (clump_NHI18_fcov5.in, 1e6 photons on 72 ranks): 'Average Number of scattering : 4.2399E+04' with 1e5 photons.
+    The log is older than the shipped input file and than v2.00's clump set-up, and its own set-up lines say how: N_clumps = 6 666 667 and f_vol = 0.006667 are
+    (4/3) f_cov (R/r_cl)^2 and N r_cl^3 / R^3 without the inner radius (v2.00: R^2 + R r_min + r_min^2, clump_mod.f90:728-731, i.e. 7 400 000 for rmin = 0.1),
+    'RSA: clump_fully_inside = .true.', and N(HI)_homo = 5e18 = f_cov x N_HImax (v2.00 reads N_HImax as the mean column itself).  The run below is therefore the
+    log's medium stated in v2.00's terms -- rmin = 0, clump_fully_inside, N_HImax = 5e18 -- and every set-up line of the log is asserted before the answer."""
     import __graft_entry__ as g
     g.build()
     from lart_amd import host
-    kw = dict(use_clump_medium=True, rmax=1.0, rmin=0.1, clump_fully_inside=False, clump_radius=0.001, clump_f_cov=5.0, N_HImax=1e18, temperature=1e4, clump_sigma_v=0.0,
+    kw = dict(use_clump_medium=True, rmax=1.0, clump_fully_inside=True, clump_radius=0.001, clump_f_cov=5.0, N_HImax=5e18, temperature=1e4, clump_sigma_v=0.0,
               spectral_type="monochromatic", geometry="sphere", velocity_type="rotating_galaxy_halo", Vrot=300.0, rinner=0.1, nxfreq=500, velocity_min=-1000.0,
               velocity_max=1000.0, nx=11, ny=11, nz=11, iseed=1)
     n = 100000
     sim = host.Simulation(kw); sim.ctx.enable_photon_log(True)
     c = sim.clumps
-    assert c.N == 6666667 and abs(c.fvol - 0.006667) < 1e-6                       # log_back:123-124
-    assert np.isclose(c.rhokap_ref, 4.4261e7, rtol=2e-5) and np.isclose(c.Dfreq_ref, 1.0566e11, rtol=1e-4)       # :127, :129
+    assert c.N == 6666667 and abs(c.fvol - 0.006667) < 1e-6 and abs(c.fcov - 5.0) < 1e-5           # log_back:123-125
+    assert np.isclose(c.rhokap_ref, 4.4261e7, rtol=2e-5) and np.isclose(c.Dfreq_ref, 1.0566e11, rtol=1e-4) and abs(c.voigt_a_ref - 0.00047) < 5e-6       # :126-128
+    assert c.cgx == 189 and len(c.cg_list) > 1.0e7                                                  # :139 '11203166 registrations in 189^3 cells' (the count depends on the placement)
+    assert np.isclose(sim.par.tauhomo, 2.94913e5, rtol=2e-5) and np.isclose(sim.par.N_gashomo, 5.0e18, rtol=1e-5)      # :140-142
     sim.run_simulation(n)
     ns, _ = sim.ctx.photon_log(n)
     err = ns.std() / np.sqrt(n)

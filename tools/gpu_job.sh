@@ -12,6 +12,7 @@
 #   prof:TAG[:ARGS]            rocprofv3 of `python3 bench.py --no-cpu-baseline --completion-photons 0 ARGS`: kernel-trace --stats,
 #                              then SEPARATE --pmc passes (SQ set, lane set, FETCH_SIZE, WRITE_SIZE) -> gpurun_out/TAG_* summaries
 #   profcfg:TAG:CONFIG         the same passes on tools/perf_kernel.py --config CONFIG (c3, c5, c1, c4: the other transport kernels)
+#   profx:TAG:ARGS             the same passes on tools/perf_explore.py ARGS (e.g. a lone packet: --photons,1,--lanes,64,--block,64,--steps,6,--events,8192)
 #   stats:TAG:CONFIG           only the kernel-trace --stats pass on tools/perf_kernel.py --config CONFIG
 #   py:SCRIPT[:ARGS]           python SCRIPT ARGS (debug helpers under tools/dbg)
 #   explore[:ARGS]             tools/perf_explore.py ARGS (throughput vs photon age, drain tail)
@@ -51,6 +52,7 @@ for spec in "$@"; do
     perf)    for c in ${a1//,/ }; do step perf_$c 400 python tools/perf_kernel.py --config $c ${a2//,/ }; done ;;
     prof)    profile "$a1" transport_kernel 4096 python3 bench.py --no-cpu-baseline --completion-photons 0 --no-other-configs ${a2//,/ } ;;
     profcfg) profile "$a1" transport_kernel 4096 python3 tools/perf_kernel.py --config "$a2" ;;
+    profx)   profile "$a1" transport_kernel 8192 python3 tools/perf_explore.py ${a2//,/ } ;;
     stats)   step ${a1}_stats 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${a1}_stats -- python3 tools/perf_kernel.py --config "$a2"
              f=$(find gpurun_out/${a1}_stats -name "*kernel_stats.csv" | head -n 1); [ -n "$f" ] && cp "$f" gpurun_out/${a1}_kernel_stats.csv && head -n 8 gpurun_out/${a1}_kernel_stats.csv | cut -c1-300; rm -rf gpurun_out/${a1}_stats ;;
     py)      step py_$(basename ${a1%.py}) 600 python ${a1} ${a2//,/ } ;;

@@ -14,7 +14,8 @@ import sys
 import tempfile
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -39,6 +40,11 @@ def configs(tmp):
         "c5p": dict(use_amr_grid=True, amr_file=afile, temperature=1e4, taumax=1e4, rmax=1.0, nxfreq=241, xfreq_min=-15.0, xfreq_max=15.0, calc_P=True, no_photons=1e8, iseed=1),
         "c5q": dict(use_amr_grid=True, amr_file=afile, temperature=1e4, taumax=1e4, rmax=1.0, nxfreq=241, xfreq_min=-15.0, xfreq_max=15.0, calc_Pnew=True, no_photons=1e8, iseed=1),
         "c5n": dict(use_amr_grid=True, amr_file=afile, temperature=1e4, taumax=1e4, rmax=1.0, nxfreq=241, xfreq_min=-15.0, xfreq_max=15.0, no_photons=1e8, iseed=1),
+        # line type 8 (Ly-beta -> H-alpha) and the H2 lines on the C2-like medium at a depth where packets still convert / meet H2 (plain grid: setup.f90:239-280)
+        "lyb": dict(line_id="ly_beta", temperature=1e4, taumax=1e4, nx=101, ny=101, nz=101, rmax=1.0, nxfreq=201, DGR=1.0, cext_dust=1e-21, no_photons=1e8, iseed=1),
+        "lya0": dict(temperature=1e4, taumax=1e4, nx=101, ny=101, nz=101, rmax=1.0, nxfreq=201, DGR=1.0, cext_dust=1e-21, no_photons=1e8, iseed=1),      # the same medium in Ly-alpha
+        "h2": dict(temperature=1e4, taumax=1e4, nx=101, ny=101, nz=101, rmax=1.0, nxfreq=201, DGR=1.0, cext_dust=1e-21, h2_model="neufeld", f_H2=0.05, h2_temperature=8000.0,
+                   h2_data_dir="H2DATA", no_photons=1e8, iseed=1),
     }
     return c, afile, mueller_path
 
@@ -50,6 +56,7 @@ def main():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--events", type=int, default=4096)
     ap.add_argument("--lanes", type=int, default=0)
+    ap.add_argument("--block", type=int, default=0)
     a = ap.parse_args()
     import torch
     torch.cuda.init()
@@ -59,11 +66,18 @@ def main():
     kw = dict(cfgs[a.config])
     if kw.get("use_amr_grid"):
         amr.write_generic_amr(afile, amr.make_amr_sphere())
+    if kw.get("h2_data_dir") == "H2DATA":                      # the level table h2_init reads, written back from the fixture (tests/conftest.py::h2_data_dir)
+        import numpy as np
+        z = np.load(os.path.join(ROOT, "tests", "golden", "h2_energy_X.npz")); kw["h2_data_dir"] = tmp
+        with open(os.path.join(tmp, "energy_X.dat"), "w") as f:
+            f.write("2 4 29 // magic number\n#H2 electronic ground state rovibrational level energies [cm^-1]\n")
+            for v, j, e in zip(z["V"], z["J"], z["E_cm"]):
+                f.write("%d\t%d\t%.17g\n" % (int(v), int(j), float(e)))
     if kw.get("scatt_mat_file") == "MUELLER":
         kw["scatt_mat_file"] = mueller_path(tmp)
     sim = host.Simulation(kw)
-    if a.lanes:
-        sim.ctx.set_pool(a.lanes, 0)
+    if a.lanes or a.block:
+        sim.ctx.set_pool(a.lanes, a.block)
     sim.ctx.begin(int(kw["no_photons"]), seed=1)
     for _ in range(a.warm):
         sim.ctx.step(1, a.events)
@@ -77,7 +91,7 @@ def main():
     atom = d("n_atomics") if "n_atomics" in t1 else 0.0
     bytes_launch = (48.0 * (d("n_cellsteps") + d("n_cellsteps_peel")) + 16.0 * atom) / nl
     out = {"config": a.config, "events_per_s": ev / dt, "events_per_launch": ev / nl, "avg_launch_ms": k_ms, "cells_per_event": d("n_cellsteps") / max(ev, 1),
-           "peel_cells_per_event": d("n_cellsteps_peel") / max(ev, 1), "atomics_per_event": atom / max(ev, 1), "lanes": sim.ctx.pool_info()[0],
+           "peel_cells_per_event": d("n_cellsteps_peel") / max(ev, 1), "atomics_per_event": atom / max(ev, 1), "lanes": sim.ctx.pool_info()[0], "block": sim.ctx.pool_info()[1],
            "photons_finished": d("nphotons_done"), "events_per_step_per_lane": a.events,
            "roofline": {"bound": "hbm", "achieved": bytes_launch / (k_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                         "frac": bytes_launch / (k_ms * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes_per_launch": bytes_launch}}
