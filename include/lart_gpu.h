@@ -244,7 +244,9 @@ int  lart_gpu_get_photon_log(lart_gpu *ctx, double *nscatt, double *xfreq_ref, i
  * for a photon absorbed by dust) and r0 (impact parameter of the first ray; extended sources).  Costs 96 bytes of HBM per photon. */
 int  lart_gpu_enable_all_photons(lart_gpu *ctx, int32_t on);
 int  lart_gpu_get_all_photons(lart_gpu *ctx, double *out, int64_t n);
-/* pool geometry knobs (0 = default): resident photon lanes and threads per workgroup */
+/* pool geometry knobs (0 = default): resident photon lanes and threads per workgroup (a multiple of 64; at most 256 for runs with a Stokes vector,
+ * at most 1024 otherwise).  With block = 0 the library chooses: 256, or 1024 when J(x) profiles are tallied together with P / P_new (one workgroup per
+ * CU leaves the LDS for the line-centre window of J; results do not depend on the choice). */
 int  lart_gpu_set_pool(lart_gpu *ctx, int64_t nlanes, int32_t block);
 int  lart_gpu_pool_info(lart_gpu *ctx, int64_t *nlanes, int32_t *block);   /* valid after lart_gpu_begin */
 /* Lane compaction = the role of the reference's dynamic master/worker scheduler (run_simulation_mod.f90:31-64: no worker

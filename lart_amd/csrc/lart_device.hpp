@@ -64,6 +64,7 @@ struct DClumps {
     const ClumpGeo *geo; const ClumpPhys *phys;
     const int *cg_start, *cg_list;                             // CSR over cgx^3 cells, 1-based entries as the reference builds them
     int cgx; double cg_min, cg_d, cg_inv, sphere_R, Dfreq_ref, radius_max;
+    const unsigned long long *cg_mask;                          // populations of at most 128 clumps: [2] words per CSR cell, bit icl-1 set when clump icl is registered in it (nullptr otherwise)
 };
 
 struct DObs { double x, y, z, rm[9]; };
@@ -1240,11 +1241,33 @@ __device__ inline double ovl_sum_kap(const KArgs &A, const Lds &l, bool dust, co
 //         scattering point, or owner = 0 and t_end = the path to the sphere's surface (escape).  u_own = the draw of sample_owner_clump (:644-664).
 // else:   raytrace_to_edge_clump_overlap_capped (:858-918): lim = the cap; returns the optical depth.
 //         col != nullptr: also raytrace_to_edge_column_clump_overlap (:935-1001): col[0] += N_gas, col[1] += tau_dust of every interval (cross0 = col[2])
+// The holders of a point that took the in-clump fast path, carried to the next flight of the same packet (which starts where that one ended: a scattering does not
+// move the packet).  reach = what is left of the lower bound on the distance to anything that could change the list -- the faces of the CSR cell the list was read
+// from (which also fix the list's order), the sphere's surface, every clump surface -- after the flights taken since; all bounds hold for every direction.
+// While the next flight stays below it, the list the 27-cell scan would rebuild is this one, in this order: no cell read, no containment tests, no sort.
+#define LART_OVL_HOLD 4
+struct OvlHold { int na; double reach; int act[LART_OVL_HOLD]; };
 template <bool TO_TAU>
 __device__ inline double ovl_march(const KArgs &A, const Lds &l, bool dust, double xp, double yp, double zp, double kx, double ky, double kz,
-                                   double xfreq_g, double lim, double u_own, unsigned &nsteps, double &t_end, int &owner, double *col = nullptr) {
+                                   double xfreq_g, double lim, double u_own, unsigned &nsteps, double &t_end, int &owner, double *col = nullptr, OvlHold *oh = nullptr) {
     const DClumps &c = A.cl; const int cg = c.cgx;
     owner = 0; t_end = 0.0;
+    if (TO_TAU && oh && oh->na > 0) {
+        double kv[LART_OVL_HOLD], kap = 0.0;
+        for (int m = 0; m < oh->na; m++) { const ClumpPhys ph = c.phys[oh->act[m] - 1]; kv[m] = kappa_clump(A, l, dust, xfreq_g - ulos_clump(A, ph, kx, ky, kz), ph); kap = kap + kv[m]; }
+        if (kap > 0.0) {
+            const double s_ = lim / kap;
+            if (s_ < oh->reach * (1.0 - 1e-9) - 1e-12 * c.cg_d) {
+                nsteps++;
+                t_end = s_;
+                double cumul = 0.0;                                                           // sample_owner_clump :644-664
+                for (int m = 0; m < oh->na; m++) { cumul = cumul + kv[m]; owner = oh->act[m]; if (u_own * kap <= cumul) break; }
+                oh->reach = oh->reach - s_;
+                return 0.0;
+            }
+        }
+        oh->na = 0;
+    }
     const double t_sp = sphere_exit_dist(c, xp, yp, zp, kx, ky, kz);
     if (t_sp <= 0.0) return 0.0;
     int act[LART_OVL_ACT], pid[LART_OVL_PEND], na = 0, np = 0; double pt[LART_OVL_PEND];        // pid: +icl = ENTER, -icl = EXIT; pt descending, the next event last
@@ -1295,6 +1318,10 @@ __device__ inline double ovl_march(const KArgs &A, const Lds &l, bool dust, doub
                 t_end = s_;
                 double cumul = 0.0;                                                           // sample_owner_clump :644-664
                 for (int m = 0; m < na; m++) { cumul = cumul + kv[m]; owner = act[m]; if (u_own * kap <= cumul) break; }
+                if (oh && na <= LART_OVL_HOLD) {                                              // the same bounds without the direction: R - |r| instead of t_sp
+                    const double left = fmin(reach, c.sphere_R - sqrt(xp * xp + yp * yp + zp * zp)) - s_;
+                    if (left > 0.0) { oh->na = na; oh->reach = left; for (int m = 0; m < LART_OVL_HOLD; m++) oh->act[m] = m < na ? act[m] : 0; }
+                }
                 return 0.0;
             }
         }
@@ -1308,30 +1335,47 @@ __device__ inline double ovl_march(const KArgs &A, const Lds &l, bool dust, doub
     else if (kz < 0.0) { sk = -1; delz = -c.cg_d / kz; tz = ((c.cg_min + (double)ck * c.cg_d) - zp) / kz; } else { sk = 0; delz = LART_HUGEST; tz = LART_HUGEST; }
     double d = 0.0, t_cur = 0.0, acc = TO_TAU ? lim : 0.0;                                    // acc: optical depth still to go / gone so far
     bool cells = true, done = false;
+    // A clump of a population of large spheres is registered in many cells of the row: once the ray has dealt with it (events queued, or never to be met: missed,
+    // behind the origin, beyond the sphere's surface, EXIT already behind the ray), every later cell would come to the same `continue`.  While the population
+    // fits a 128-bit mask (the shipped overlap examples have 30 clumps) the clumps dealt with are remembered exactly, and the cells carry their list as such a
+    // mask too (cg_mask; the lists ascend, so the set bits in ascending order ARE the list): a cell costs one 16-byte load and an and-not, a clump one sphere
+    // intersection per ray instead of one per cell it is registered in.
+    unsigned long long vis0 = 0ull, vis1 = 0ull;
+    auto visit = [&](int icl) {
+        const unsigned long long bit = 1ull << ((icl - 1) & 63); const bool hi = ((icl - 1) & 64) != 0;
+        const ClumpGeo g = c.geo[icl - 1];
+        const double rx = xp - g.x, ry = yp - g.y, rz = zp - g.z, b = rx * kx + ry * ky + rz * kz;     // ray_sphere_isect :1362-1386
+        double disc = b * b - (rx * rx + ry * ry + rz * rz) + g.r2;
+        bool dealt = disc < 0.0;
+        double te = 0.0, tex = 0.0;
+        if (!dealt) {
+            disc = sqrt(disc);
+            te = -b - disc; const double tx2 = -b + disc;
+            dealt = !(tx2 > 0.0) || te > t_sp;
+            if (!dealt) { tex = fmin(tx2, t_sp); dealt = tex <= t_cur; }                       // its EXIT lies behind the ray: seen and done in an earlier cell
+            if (!dealt) for (int m = 0; m < np; m++) dealt = dealt || pid[m] == icl || pid[m] == -icl;
+        }
+        if (!dealt && np + 2 > LART_OVL_PEND) { over = true; return; }                       // (not marked: a later cell tries again, as the list walk did)
+        if (hi) vis1 |= bit; else vis0 |= bit;
+        if (dealt) return;
+        for (int e = (te > 0.0 ? 0 : 1); e < 2; e++) {                                // ENTER (only when the origin is outside), then EXIT
+            const double tn = e == 0 ? te : tex; const int idn = e == 0 ? icl : -icl;
+            int pos = 0; while (pos < np && pt[pos] > tn) pos++;                      // after the later ones, before the equal ones (stable: first seen, first out)
+            for (int m = np; m > pos; m--) { pt[m] = pt[m - 1]; pid[m] = pid[m - 1]; }
+            pt[pos] = tn; pid[pos] = idn; np++;
+        }
+    };
     while (!done) {
         double t_lim = LART_HUGEST;
         if (cells && !(d > t_sp) && ci >= 0 && ci < cg && cj >= 0 && cj < cg && ck >= 0 && ck < cg) {
             const size_t q = (size_t)ci + (size_t)cj * cg + (size_t)ck * cg * cg;
-            const int ip1 = c.cg_start[q + 1];
-            for (int ip = c.cg_start[q]; ip < ip1; ip++) {
-                const int icl = c.cg_list[ip - 1]; const ClumpGeo g = c.geo[icl - 1];
-                const double rx = xp - g.x, ry = yp - g.y, rz = zp - g.z, b = rx * kx + ry * ky + rz * kz;     // ray_sphere_isect :1362-1386
-                double disc = b * b - (rx * rx + ry * ry + rz * rz) + g.r2;
-                if (disc < 0.0) continue;
-                disc = sqrt(disc);
-                const double te = -b - disc, tx2 = -b + disc;
-                if (!(tx2 > 0.0) || te > t_sp) continue;
-                const double tex = fmin(tx2, t_sp);
-                if (tex <= t_cur) continue;                                    // its EXIT lies behind the ray: seen and done in an earlier cell
-                bool seen = false; for (int m = 0; m < np; m++) seen = seen || pid[m] == icl || pid[m] == -icl;
-                if (seen) continue;
-                if (np + 2 > LART_OVL_PEND) { over = true; continue; }
-                for (int e = (te > 0.0 ? 0 : 1); e < 2; e++) {                                // ENTER (only when the origin is outside), then EXIT
-                    const double tn = e == 0 ? te : tex; const int idn = e == 0 ? icl : -icl;
-                    int pos = 0; while (pos < np && pt[pos] > tn) pos++;                      // after the later ones, before the equal ones (stable: first seen, first out)
-                    for (int m = np; m > pos; m--) { pt[m] = pt[m - 1]; pid[m] = pid[m - 1]; }
-                    pt[pos] = tn; pid[pos] = idn; np++;
-                }
+            if (c.cg_mask) {
+                unsigned long long m0 = c.cg_mask[2 * q] & ~vis0, m1 = c.cg_mask[2 * q + 1] & ~vis1;
+                while (m0) { const int bpos = __ffsll((long long)m0) - 1; m0 &= m0 - 1; visit(bpos + 1); }
+                while (m1) { const int bpos = __ffsll((long long)m1) - 1; m1 &= m1 - 1; visit(bpos + 65); }
+            } else {
+                const int ip1 = c.cg_start[q + 1];
+                for (int ip = c.cg_start[q]; ip < ip1; ip++) visit(c.cg_list[ip - 1]);
             }
             if (tx <= ty && tx <= tz) { d = tx; tx = tx + delx; ci += si; }
             else if (ty <= tz)        { d = ty; ty = ty + dely; cj += sj; }
@@ -1374,9 +1418,9 @@ __device__ inline double ovl_march(const KArgs &A, const Lds &l, bool dust, doub
     return acc;
 }
 // raytrace_to_tau_clump_overlap: :668-788
-__device__ inline void raytrace_to_tau_clump_ovl(const KArgs &A, const Lds &l, bool dust, Photon &p, double tau_in, double u_own, unsigned &nsteps) {
+__device__ inline void raytrace_to_tau_clump_ovl(const KArgs &A, const Lds &l, bool dust, Photon &p, double tau_in, double u_own, unsigned &nsteps, OvlHold *oh = nullptr) {
     double t_end; int owner;
-    ovl_march<true>(A, l, dust, p.x, p.y, p.z, p.kx, p.ky, p.kz, p.xfreq, tau_in, u_own, nsteps, t_end, owner);
+    ovl_march<true>(A, l, dust, p.x, p.y, p.z, p.kx, p.ky, p.kz, p.xfreq, tau_in, u_own, nsteps, t_end, owner, nullptr, oh);
     p.x = p.x + t_end * p.kx; p.y = p.y + t_end * p.ky; p.z = p.z + t_end * p.kz;
     p.icl = owner;
     if (owner == 0) { p.inside = false; p.xfreq_ref = p.xfreq; tally_escape(A.par, A.t, p); }
@@ -1528,10 +1572,10 @@ __device__ __forceinline__ void raytrace_to_tau_amr(const KArgs &A, const Lds &l
 
 // march to optical depth tau_in; moves the packet, re-expresses xfreq at every crossing, tallies escape
 template <int VAR>
-__device__ __forceinline__ void raytrace_to_tau(const KArgs &A, const Lds &l, bool dust, Photon &p, double tau_in, unsigned &nsteps, double u_own = 0.0) {
+__device__ __forceinline__ void raytrace_to_tau(const KArgs &A, const Lds &l, bool dust, Photon &p, double tau_in, unsigned &nsteps, double u_own = 0.0, OvlHold *oh = nullptr) {
     if (VAR == 3) { raytrace_to_tau_amr(A, l, dust, p, tau_in, nsteps); return; }
     if (VAR == 4) { raytrace_to_tau_clump(A, l, dust, p, tau_in, nsteps); return; }
-    if (VAR == 7) { raytrace_to_tau_clump_ovl(A, l, dust, p, tau_in, u_own, nsteps); return; }
+    if (VAR == 7) { raytrace_to_tau_clump_ovl(A, l, dust, p, tau_in, u_own, nsteps, oh); return; }
     const DGrid &g = A.g;
 #ifndef LART_NO_FAST_FLIGHT
     // Fast path: the flight ends inside the cell it starts in (99.6 % of the flights at tau0 = 1e6: the line-centre depth of one cell is

@@ -47,7 +47,7 @@ struct lart_gpu {
     // octree (VAR 3)
     bool is_amr = false; DAmr amr{}; int *d_amr_int = nullptr; AmrGeom *d_amr_geom = nullptr;
     // clump medium (VAR 4)
-    bool is_clump = false, clump_overlap = false; DClumps cl{}; ClumpGeo *d_cl_geo = nullptr; ClumpPhys *d_cl_phys = nullptr; int *d_cl_int = nullptr;
+    bool is_clump = false, clump_overlap = false; DClumps cl{}; ClumpGeo *d_cl_geo = nullptr; ClumpPhys *d_cl_phys = nullptr; int *d_cl_int = nullptr; unsigned long long *d_cl_mask = nullptr;
     // fused tally buffer
     double *d_tally = nullptr; int64_t ntally = 0; DTally t{};
     DRep rep{}; bool rep_dirty = false;                      // per-XCD copies of the contended tally sections
@@ -141,7 +141,7 @@ extern "C" int lart_gpu_destroy(lart_gpu *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (auto &e : c->ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-    (void)hipFree(c->d_cell); (void)hipFree(c->d_faces); (void)hipFree(c->d_mu); (void)hipFree(c->d_alias); (void)hipFree(c->d_ml_tab); (void)hipFree(c->d_ml_itab); (void)hipFree(c->d_obs); (void)hipFree(c->d_ind_bin); (void)hipFree(c->d_amr_int); (void)hipFree(c->d_amr_geom); (void)hipFree(c->d_cl_geo); (void)hipFree(c->d_cl_phys); (void)hipFree(c->d_cl_int);
+    (void)hipFree(c->d_cell); (void)hipFree(c->d_faces); (void)hipFree(c->d_mu); (void)hipFree(c->d_alias); (void)hipFree(c->d_ml_tab); (void)hipFree(c->d_ml_itab); (void)hipFree(c->d_obs); (void)hipFree(c->d_ind_bin); (void)hipFree(c->d_amr_int); (void)hipFree(c->d_amr_geom); (void)hipFree(c->d_cl_geo); (void)hipFree(c->d_cl_phys); (void)hipFree(c->d_cl_int); (void)hipFree(c->d_cl_mask);
     free_tally(c); (void)hipFree(c->d_h2tab); (void)hipFree(c->d_pool); (void)hipFree(c->d_ctl); (void)hipFree(c->d_log); (void)hipFree(c->d_compact); (void)hipFree(c->d_pq);
     if (c->comm) { (void)ncclCommDestroy(c->comm); c->comm = nullptr; }
     for (int b = 0; b < 2; b++) { if (c->ev_filled[b]) (void)hipEventDestroy(c->ev_filled[b]); if (c->ev_drained[b]) (void)hipEventDestroy(c->ev_drained[b]); }
@@ -439,6 +439,17 @@ extern "C" int lart_gpu_set_clumps(lart_gpu *c, int64_t n, const double *x, cons
     c->cl.N = n; c->cl.geo = c->d_cl_geo; c->cl.phys = c->d_cl_phys; c->cl.cg_start = c->d_cl_int; c->cl.cg_list = c->d_cl_int + ncells + 1;
     c->cl.cgx = cgx; c->cl.cg_min = cg_min; c->cl.cg_d = cg_d; c->cl.cg_inv = 1.0 / cg_d; c->cl.sphere_R = sphere_R; c->cl.Dfreq_ref = Dfreq_ref;
     c->cl.radius_max = 0.0; for (int64_t i = 0; i < n; i++) c->cl.radius_max = std::fmax(c->cl.radius_max, radius[i]);
+    (void)hipFree(c->d_cl_mask); c->d_cl_mask = nullptr;
+    if (n <= 128) {                                            // membership masks of the CSR cells for the overlap march (lart_device.hpp, ovl_march)
+        std::vector<unsigned long long> mk(2 * ncells, 0ull); bool ascending = true;
+        for (size_t q = 0; q < ncells && ascending; q++)
+            for (int ip = cg_start[q]; ip < cg_start[q + 1]; ip++) {
+                const int icl = cg_list[ip - 1];
+                if (ip > cg_start[q] && cg_list[ip - 2] >= icl) { ascending = false; break; }      // the walk's order is the list's: only an ascending list is its own mask
+                mk[2 * q + ((icl - 1) >> 6)] |= 1ull << ((icl - 1) & 63);
+            }
+        if (ascending) { HIPCHK(hipMalloc(&c->d_cl_mask, mk.size() * 8)); HIPCHK(hipMemcpy(c->d_cl_mask, mk.data(), mk.size() * 8, hipMemcpyHostToDevice)); c->cl.cg_mask = c->d_cl_mask; }
+    }
     // the background medium of grid_create_clump is uniform (rhokap = 0, Dfreq = Dfreq_ref, voigt_a = voigt_a_ref, v = 0): one record
     Cell bg{}; bg.rhokap = 0.0; bg.voigt_a = voigt_a_ref; bg.Dfreq = Dfreq_ref; bg.vfx = bg.vfy = bg.vfz = 0.0; bg.rhokapD = 0.0; bg.pad = 0.0;
     HIPCHK(hipMalloc(&c->d_cell, sizeof(Cell))); HIPCHK(hipMemcpy(c->d_cell, &bg, sizeof(Cell), hipMemcpyHostToDevice));

@@ -30,7 +30,7 @@ __device__ inline double wave_sum(double v) {
 // one flight of a packet: optical depth to the next interaction (forced on the first flight: run_simulation_mod.f90:163-177,
 // add_escaped_fraction_to_Jout :208-247), then the march
 template <int VAR, bool DUST>
-__device__ inline void fly(const KArgs &A, const Lds &l, Rng &g, Photon &p, bool &first, unsigned &nsteps) {
+__device__ inline void fly(const KArgs &A, const Lds &l, Rng &g, Photon &p, bool &first, unsigned &nsteps, OvlHold *oh = nullptr) {
     const lart_params &par = A.par;
     double tau;
     if (first) {
@@ -54,7 +54,7 @@ __device__ inline void fly(const KArgs &A, const Lds &l, Rng &g, Photon &p, bool
 #ifdef LART_EXPERIMENT_RAY2                            // timing experiment: cost of one flight (the copy's escapes are tallied twice: timing only)
     { Photon p2 = p; unsigned ns2 = 0; raytrace_to_tau<VAR>(A, l, DUST, p2, tau, ns2); if (p2.x == 1e300) p.x = p2.y; }
 #endif
-    raytrace_to_tau<VAR>(A, l, DUST, p, tau, nsteps, u_own);
+    raytrace_to_tau<VAR>(A, l, DUST, p, tau, nsteps, u_own, oh);
     LART_PROF_MARK(p, 3);
 }
 
@@ -101,6 +101,7 @@ __global__ __launch_bounds__(LART_MAX_BLOCK(STOKES, PEEL), LART_WAVES(STOKES, PE
     double *F = A.pool.f;
 
     Photon p; Rng g; g.attach(rng_lds, blockDim.x);
+    OvlHold oh; oh.na = 0; oh.reach = 0.0;                                        // VAR 7: holders carried from one flight to the next (not kept between launches)
     g.k0 = (uint32_t)A.seed; g.k1 = (uint32_t)(A.seed >> 32);                  // (a lane that never holds a packet still lends its ALU to Rng::prefill_sparse: the key is the run's)
 #ifdef LART_PROFILE
     for (int i = 0; i < 12; i++) p.pt[i] = 0;
@@ -145,6 +146,7 @@ __global__ __launch_bounds__(LART_MAX_BLOCK(STOKES, PEEL), LART_WAVES(STOKES, PE
                 g.init(A.seed, (uint64_t)(A.first_id + k * A.stride), 0);
                 if (VAR == 8) p.shear = 0.0;                   // generate_photon.f90:141
                 p.iband = 1;                                   // :139
+                oh.na = 0;
                 generate_photon<VAR, STOKES, DUST, PEEL>(A, l, g, p, npeel);
                 if (A.allph) allph_initial(A, p, k);
                 if (A.trace_slot) trace_rec<VAR>(A, k, g.n, p, 0);
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(LART_MAX_BLOCK(STOKES, PEEL), LART_WAVES(STOKES, PE
         if (act) g.prefill();
 #endif
         LART_PROF_TRIP(p, 2);
-        if (act) fly<VAR, DUST>(A, l, g, p, first, nsteps);
+        if (act) fly<VAR, DUST>(A, l, g, p, first, nsteps, VAR == 7 ? &oh : nullptr);
         { const bool on = act && p.inside; scatter_event<VAR, STOKES, DUST, PEEL>(A, l, g, p, npeel, on); if (on) { nev++; budget--; } }
         LART_PROF_MARK(p, 6);
         if (act) {

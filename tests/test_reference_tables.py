@@ -87,15 +87,32 @@ def nscat_of(stdout):
     return float(re.search(r"Average Number of scattering :\s+(\S+)", stdout).group(1))
 
 
+HEI_N = 2.0e6
+
+
+@pytest.fixture(scope="module")
+def hei_runs(exe, tmp_path_factory):
+    """the 20 runs of the summary table through LaRT_amd.x, four processes at a time on the one GPU (each run ends on its longest history: side by side the
+    tails overlap; the box allows six GPU processes)"""
+    from concurrent.futures import ThreadPoolExecutor
+    rows = TAB["HeI_coherent_test"]["rows"]
+    dirs = {r["case"]: tmp_path_factory.mktemp(r["case"]) for r in rows}
+    def one(row):
+        return run(exe, namelist(row["namelist"], no_photons="%.1e" % HEI_N, iseed=1234), dirs[row["case"]], name=row["case"] + ".in")
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        res = list(ex.map(one, rows))
+    return {row["case"]: (r, dirs[row["case"]]) for row, r in zip(rows, res)}
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("row", TAB["HeI_coherent_test"]["rows"], ids=lambda r: r["case"])
-def test_hei_coherent_summary(exe, tmp_path, row):
+def test_hei_coherent_summary(hei_runs, row):
     """results_summary.txt:7-37, one row.  2e6 photons here against 5e6 there; tolerances = the Monte-Carlo error of the two runs:
     <N_scat> is a mean over photons (relative error ~ 1.2 / sqrt(N)), sum Jout is exact photon conservation (4 digits, as printed),
     peak Jout is one of 201 bins (counting error of the bin), img.sum a peel-off estimator summed over the cube."""
-    n = 2.0e6
+    n = HEI_N
     name = row["case"]
-    r = run(exe, namelist(row["namelist"], no_photons="%.1e" % n, iseed=1234), tmp_path, name=name + ".in")
+    r, tmp_path = hei_runs[name]
     assert r.returncode == 0, r.stdout + r.stderr
     S = read_h5(str(tmp_path / (name + ".h5")))["Spectrum"]
     jout = S[1]["Jout"]
