@@ -130,7 +130,7 @@ def test_periodic_octree_slab(oracle_mod, tmp_path):
     assert abs(na.mean() - nc.mean()) < 4.0 * np.hypot(na.std(), nc.std()) / np.sqrt(n), (na.mean(), nc.mean())
     assert nb.mean() < 0.85 * na.mean()
     ja, jc = a.array("Jout"), c.array("Jout")
-    assert ja.sum() == n and jc.sum() == n                          # nothing is lost through the sides (every packet leaves through z)
+    assert abs(ja.sum() - n) < 1e-9 * n and abs(jc.sum() - n) < 1e-9 * n   # nothing is lost through the sides (every packet leaves through z; esc + (1 - esc) is 1 up to rounding)
     chi2 = np.sum((ja - jc) ** 2 / np.maximum(ja + jc, 1.0)) / np.count_nonzero(ja + jc)
     assert chi2 < 1.6, chi2
     assert np.allclose(a.normalized_Jout(), ja / (n * a.scalar("dxfreq") * 2.0 * np.pi * 2.0))      # two faces, no area (output_sum_rect.f90:802-804)

@@ -136,6 +136,9 @@ def test_line_id_constants_of_the_python_host(golden):
         par, L, _ = host.read_input(par)
         got = [L.line_type, L.wavelength0, L.damping, L.cross0, L.vtherm1, L.g_recoil0, L.DnuHK_Hz, L.E1, L.E2, L.E3]
         assert np.allclose(got, ref, rtol=1e-14, atol=0) and not par.fine_structure, (lid, got, ref)
-    par = host.Params(); par.line_id = "ly_beta"
-    with pytest.raises(host.LartInputError, match="not supported"):
+    par = host.Params(); par.line_id = "ly_beta"; par.taumax = 10.0             # line type 8 since round 3 (line_mod.f90:330-372): 3p -> 2s conversion to H-alpha
+    par, L, _ = host.read_input(par)
+    assert L.line_type == 8 and abs(L.P_conv - 0.11833545951986842) < 1e-15 and abs(L.wavelength0_Ha - 0.6563) < 1e-3
+    par = host.Params(); par.line_id = "ly_gamma"; par.taumax = 10.0
+    with pytest.raises(host.LartInputError):
         host.read_input(par)

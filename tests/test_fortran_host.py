@@ -701,10 +701,13 @@ def test_whole_namelist_surface_is_readable(exe, tmp_path):
           " par%amr_snapnum = 0\n par%stellar_radius = 0.0\n par%EW_line = 0.0\n par%Omega = 0.0\n par%q = 1.0\n par%D_to_H_ratio = 1.5e-5\n/\n")
     r = run(exe, ok, tmp_path, "--dry-run", name="all.in")
     assert r.returncode == 0, r.stdout + r.stderr
-    for bad in ("par%f_H2 = 1e-3", "par%density_rscale = 0.5", "par%clump_radius_alpha = 1.0", "par%stellar_radius = 0.1", "par%Omega = 28.0",
+    for bad in ("par%f_H2 = 1e-3", "par%density_rscale = 0.5", "par%clump_radius_alpha = 1.0", "par%stellar_radius = 0.1",
                 "par%xmin = -1.0", "par%h2_model = 'simple'", "par%ionization_model = 'file'", "par%phase_angle = 10.0, 20.0"):
         r = run(exe, "&parameters\n par%temperature = 1e4\n par%taumax = 1e2\n " + bad + "\n/\n", tmp_path, "--dry-run", name="bad.in")
         assert r.returncode != 0 and "not supported" in r.stdout and bad.split()[0][4:] in r.stdout, bad
+    r = run(exe, "&parameters\n par%temperature = 1e4\n par%taumax = 1e2\n par%xy_periodic = .true.\n par%nx = 4\n par%ny = 4\n par%nz = 11\n par%Omega = 28.0\n/\n", tmp_path,
+            "--dry-run", name="shear.in")                                                  # the shearing box is a parameter of the march since round 3 (VAR 8)
+    assert r.returncode == 0, r.stdout + r.stderr
     r = run(exe, "&parameters\n par%metalz = 1.0\n/\n", tmp_path, "--dry-run", name="bad2.in")
     assert r.returncode != 0 and "ERROR reading &parameters" in r.stdout
     r = run(exe, "&parameters\n par%temperature = 1e4\n par%taumax = 1e2\n par%include_deuterium = .true.\n par%fine_structure = .true.\n/\n", tmp_path,
