@@ -50,7 +50,7 @@ def compare(jg_raw, ng, jr_raw, nr, label):
     return rms, exp, chi2
 
 
-N_DEVICE = {"c1": 1000000, "c2": 600000, "c3": 100000, "c4": 1000000, "c5": 300000}       # (the run time is the longest history of c2 / c3, not the photon count)
+N_DEVICE = {"c1": 1000000, "c2": 500000, "c3": 80000, "c4": 1000000, "c5": 300000}       # (the run time is the longest history of c2 / c3, not the photon count)
 SEED = {"c1": 20261005, "c2": 20261004, "c3": 20261006, "c4": 20261007, "c5": 20261008}
 FIXTURE = {"c1": "c1_slab_tau4.npz", "c2": "c2_tau6.npz", "c3": "c3_peel_tau6.npz", "c4": "c4_clump_dust.npz", "c5": "c5_amr_JP.npz"}
 
