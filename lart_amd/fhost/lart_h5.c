@@ -105,7 +105,7 @@ static int fits_header(gzFile f, void (*card)(const char *key, const char *val, 
             if (!strcmp(key, "END")) { done = 1; break; }
             if (blk[80 * c + 8] != '=') continue;
             const char *p = blk + 80 * c + 10; int n = 0;
-            while (*p == ' ' && p < blk + 80 * c + 80) p++;
+            while (p < blk + 80 * c + 80 && *p == ' ') p++;
             if (*p == '\'') { p++; while (p < blk + 80 * c + 80 && *p != '\'' && n < 70) val[n++] = *p++; while (n > 0 && val[n-1] == ' ') n--; }
             else { while (p < blk + 80 * c + 80 && *p != '/' && *p != ' ' && n < 70) val[n++] = *p++; }
             val[n] = 0;
@@ -247,6 +247,7 @@ static int clumps_read_fits(const char *path, long long *n_out, double **data, i
     int src[9];
     for (int q = 0; q < 9; q++) { src[q] = -1; present[q] = 0;
         for (int a = 0; a < 3 && src[q] < 0; a++) if (cl_col[q][a]) for (long i = 0; i < c.h.tfields && i < 64; i++) if (!strcmp(c.ttype[i], cl_col[q][a])) { src[q] = (int)i; present[q] = a + 1; break; } }
+    for (int q = 0; q < 6; q++) if (src[q] < 0) { gzclose(f); return 4; }        /* positions and velocities are columns of every population file (the HDF5 reader fails the same way) */
     long n = c.h.naxes[1];
     double *d = (double *)calloc((size_t)9 * (size_t)n, sizeof(double)); unsigned char *buf = (unsigned char *)malloc((size_t)row);
     if (!d || !buf) { free(d); free(buf); gzclose(f); return 5; }
@@ -368,6 +369,7 @@ int lart_out_read(const char *path, const char *section, const char *name, doubl
     if (col < 0) { gzclose(f); return 3; }
     if (row != c.h.naxes[0] || c.h.naxes[1] != n) { gzclose(f); return 4; }
     unsigned char *buf = (unsigned char *)malloc((size_t)row);
+    if (!buf) { gzclose(f); return 5; }
     for (long long r = 0; r < n; r++) {
         if (gzread(f, buf, (unsigned)row) != row) { free(buf); gzclose(f); return 2; }
         const unsigned char *b = buf + off[col]; dst[r] = kind[col] == 0 ? be_f64(b) : kind[col] == 1 ? be_f32(b) : be_int(b, width[col]);

@@ -1124,11 +1124,26 @@ def make_lart_params(par, line, g):
     return p
 
 
+def job_seed(iseed, dist=None):
+    """(Philox key of the job, seed of the host-side MT stream).  A non-zero par%iseed is both.  par%iseed = 0: one value from the operating system
+    (lart_host_entropy_seed), drawn by rank 0 and received by the others when `dist` is an initialised torch.distributed; the MT seed is its residue
+    mod 2^31 - 1, never 0 (main.f90 of the Fortran host does the same)"""
+    if iseed != 0:
+        return int(iseed), int(iseed)
+    multi = dist is not None and dist.is_initialized() and dist.get_world_size() > 1
+    box = [capi.entropy_seed() if (not multi or dist.get_rank() == 0) else None]
+    if multi:
+        dist.broadcast_object_list(box, src=0)
+    run_seed = int(box[0])
+    print("par%%iseed = 0: seeded from the operating system, seed = %d" % run_seed)
+    return run_seed, (run_seed % 2147483647 or 1)
+
+
 class Simulation:
     """main.f90:19-69 sequence: read_input -> setup -> grid_create -> observer_create -> run_simulation ->
     output_reduce -> output_normalize, with run_simulation/output_reduce crossing the C-ABI."""
 
-    def __init__(self, par, device=0):
+    def __init__(self, par, device=0, dist=None):
         if isinstance(par, str):
             par = read_namelist(par)
         elif isinstance(par, dict):
@@ -1137,6 +1152,11 @@ class Simulation:
                 set_param(par, k, v)
         self.par, self.line, self.scatt_mat = read_input(par)
         self.amr = None; self.clumps = None
+        # par%iseed = 0: seed from the operating system (init_random_mt_seed, random_mt.f90:889-947), ONE value for the whole job: with several ranks (dist = an
+        # initialised torch.distributed) rank 0 draws it and the others receive it before anything random is generated -- the clump population has to be the same
+        # on every rank and the photon ids of the ranks interleave on one Philox key.  As main.f90 of the Fortran host: the 53-bit value is the Philox key, its
+        # residue mod 2^31 - 1 (never 0) the seed of the host-side MT stream that places the clumps.
+        self.run_seed, self.par.iseed = job_seed(self.par.iseed, dist)
         if self.par.use_clump_medium:                                     # grid_create_clump (main.f90:25-27)
             from . import clump as clump_mod
             self.clumps, self.grid = clump_mod.grid_create_clump(self.par, self.line)
@@ -1192,15 +1212,8 @@ class Simulation:
         self.nphotons_run = 0
 
     def seed(self):
-        """the Philox key of this run: par%iseed, or -- for par%iseed = 0, where the reference seeds from the operating system
-        (init_random_mt_seed, random_mt.f90:889-947) -- one value drawn once per Simulation (lart_host_entropy_seed); with several
-        ranks the caller shares rank 0's value (bench.py / output_reduce broadcast it) so that the photon ids stay disjoint"""
-        if self.par.iseed != 0:
-            return int(self.par.iseed)
-        if not getattr(self, "seed_used", 0):
-            self.seed_used = capi.entropy_seed()
-            print("par%%iseed = 0: seeded from the operating system, seed = %d" % self.seed_used)
-        return self.seed_used
+        """the Philox key of this run: par%iseed as given, or the value __init__ drew (and shared between the ranks) for par%iseed = 0"""
+        return self.run_seed
 
     def run_simulation(self, nphotons=None, rank=0, nproc=1, seed=None):
         """photon ids rank+1, rank+1+nproc, ... <= nphotons (run_equal_number, run_simulation_mod.f90:150-151).

@@ -25,8 +25,13 @@ def _worker(rank, world, port, out):
     o.run(count, first_id=rank + 1, stride=world, rng_kind=1, seed=SEED, nthreads=2)
     buf = torch.from_numpy(np.concatenate([[o.scalar("nscatt_gas"), float(count)], o.array("Jout"), o.array("Jin")]))
     host.reduce_tally_buffer(buf, dist)
+    # par%iseed = 0: one seed for the job, drawn on rank 0 (clump placement and photon streams must agree between the ranks); a given seed is left alone
+    s0 = host.job_seed(0, dist); own = host.job_seed(0)
+    both = [None, None]; dist.all_gather_object(both, (s0, own, host.job_seed(12345, dist)))
     if rank == 0:
         np.save(out, buf.numpy())
+        assert both[0][0] == both[1][0] and 0 < s0[0] < 2 ** 53 and 0 < s0[1] < 2 ** 31 and s0[1] == (s0[0] % 2147483647 or 1)
+        assert both[0][1] != both[1][1] and both[0][2] == both[1][2] == (12345, 12345)
     dist.barrier()
     dist.destroy_process_group()
 
