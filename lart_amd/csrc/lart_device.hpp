@@ -1245,13 +1245,29 @@ __device__ inline double ovl_sum_kap(const KArgs &A, const Lds &l, bool dust, co
 // move the packet).  reach = what is left of the lower bound on the distance to anything that could change the list -- the faces of the CSR cell the list was read
 // from (which also fix the list's order), the sphere's surface, every clump surface -- after the flights taken since; all bounds hold for every direction.
 // While the next flight stays below it, the list the 27-cell scan would rebuild is this one, in this order: no cell read, no containment tests, no sort.
-#define LART_OVL_HOLD 4
+#define LART_OVL_HOLD 8
 struct OvlHold { int na; double reach; int act[LART_OVL_HOLD]; };
+// The march as a state that survives between calls: ovl_start does everything up to the first cell (holder list, fast paths, the traversal set-up), ovl_advance
+// walks at most `max_cells` CSR cells -- each with the intervals up to its far face -- and says whether the march is over, ovl_finish hands out the result.
+// ovl_march = start + advance to the end + finish is the one-piece form (peel rays, sight lines, probes); the transport kernel lets a lane that is in a march
+// advance by a few cells per round of its wave while the other lanes go on scattering (transport_kernel.hpp): the same statements in the same order either way.
+#ifdef LART_OVL_STATS                                   // diagnostic build (make SUFFIX=_st EXTRA=-DLART_OVL_STATS): how the flights of VAR 7 divide, in scal[8..15]
+#define OVL_STAT(A, i, v) atomicAdd(&(A).t.scal[8 + (i)], (double)(v))
+#else
+#define OVL_STAT(A, i, v) do { } while (0)
+#endif
+struct OvlState {
+    bool live, over, cells; int na, np, ci, cj, ck, si, sj, sk;
+    double tx, ty, tz, delx, dely, delz, d, t_cur, acc, t_sp, u_own;
+    unsigned long long vis0, vis1;
+    int act[LART_OVL_ACT], pid[LART_OVL_PEND]; double pt[LART_OVL_PEND];        // pid: +icl = ENTER, -icl = EXIT; pt descending, the next event last
+};
+// returns true when the answer is known without a march (t_end, owner set); otherwise S holds the march at its first cell
 template <bool TO_TAU>
-__device__ inline double ovl_march(const KArgs &A, const Lds &l, bool dust, double xp, double yp, double zp, double kx, double ky, double kz,
-                                   double xfreq_g, double lim, double u_own, unsigned &nsteps, double &t_end, int &owner, double *col = nullptr, OvlHold *oh = nullptr) {
+__device__ inline bool ovl_start(const KArgs &A, const Lds &l, bool dust, double xp, double yp, double zp, double kx, double ky, double kz,
+                                 double xfreq_g, double lim, double u_own, unsigned &nsteps, double &t_end, int &owner, OvlHold *oh, OvlState &S) {
     const DClumps &c = A.cl; const int cg = c.cgx;
-    owner = 0; t_end = 0.0;
+    owner = 0; t_end = 0.0; S.live = false; S.over = false; S.acc = TO_TAU ? lim : 0.0; S.t_sp = 0.0; S.u_own = u_own;
     if (TO_TAU && oh && oh->na > 0) {
         double kv[LART_OVL_HOLD], kap = 0.0;
         for (int m = 0; m < oh->na; m++) { const ClumpPhys ph = c.phys[oh->act[m] - 1]; kv[m] = kappa_clump(A, l, dust, xfreq_g - ulos_clump(A, ph, kx, ky, kz), ph); kap = kap + kv[m]; }
@@ -1263,14 +1279,17 @@ __device__ inline double ovl_march(const KArgs &A, const Lds &l, bool dust, doub
                 double cumul = 0.0;                                                           // sample_owner_clump :644-664
                 for (int m = 0; m < oh->na; m++) { cumul = cumul + kv[m]; owner = oh->act[m]; if (u_own * kap <= cumul) break; }
                 oh->reach = oh->reach - s_;
-                return 0.0;
+                OVL_STAT(A, 0, 1);                                                            // flights on the carried list
+                return true;
             }
         }
         oh->na = 0;
     }
     const double t_sp = sphere_exit_dist(c, xp, yp, zp, kx, ky, kz);
-    if (t_sp <= 0.0) return 0.0;
-    int act[LART_OVL_ACT], pid[LART_OVL_PEND], na = 0, np = 0; double pt[LART_OVL_PEND];        // pid: +icl = ENTER, -icl = EXIT; pt descending, the next event last
+    S.t_sp = t_sp;
+    if (t_sp <= 0.0) return true;
+    if (TO_TAU) OVL_STAT(A, 1, 1);                                                            // holder lists rebuilt
+    int *act = S.act; int na = 0;
     bool over = false;
     int ci = cg_clamp(c, xp), cj = cg_clamp(c, yp), ck = cg_clamp(c, zp);
     // active_set_at_point (clump_mod.f90:1594-1634) reads the 27 CSR cells around the point and keeps the clumps that hold it in first-seen
@@ -1280,7 +1299,22 @@ __device__ inline double ovl_march(const KArgs &A, const Lds &l, bool dust, doub
     // oracle's 27-cell restatement).  The same cell also bounds the distance to every surface from below -- a clump whose surface comes closer
     // than the point's distance to the faces of its cell is registered in it -- which the in-clump fast path below needs.
     double free_in = LART_HUGEST, free_out = LART_HUGEST;                                     // min of R^2 - |r|^2 over the holders, of |r|^2 - R^2 over the others
-    {
+    // populations of at most 128 clumps (cg_mask): EVERY clump is tested against the point, not only the ones of its cell -- the same holders (a holder is registered
+    // in the point's own cell), and lower bounds on the distances to ALL surfaces that do not depend on the size of the CSR cells (with 30 clumps of radius 0.3 the
+    // grid has 32^3 cells of 0.06: the distance to the faces of the cell would end the carried list after three flights).  d_srf: min over all clumps of a lower bound
+    // of | |r| - R | (single precision, rounded towards zero by a relative 4e-6: a bound, not a result).
+    const bool all_clumps = TO_TAU && c.cg_mask != nullptr;
+    double d_srf = LART_HUGEST;
+    if (all_clumps) {
+        for (int icl = 1; icl <= (int)c.N; icl++) {
+            const ClumpGeo g = c.geo[icl - 1];
+            const double rx = xp - g.x, ry = yp - g.y, rz = zp - g.z, rr = rx * rx + ry * ry + rz * rz;
+            const bool in = rr <= g.r2;
+            if (in) { if (na < LART_OVL_ACT) act[na++] = icl; else over = true; }
+            const float num = (float)fabs(rr - g.r2) * 0.999998f, den = (sqrtf((float)rr) + sqrtf((float)g.r2)) * 1.000002f;
+            d_srf = fmin(d_srf, (double)(num / den));
+        }
+    } else {
         const size_t q = (size_t)ci + (size_t)cj * cg + (size_t)ck * cg * cg;
         const int ip1 = c.cg_start[q + 1];
         for (int ip = c.cg_start[q]; ip < ip1; ip++) {
@@ -1289,18 +1323,27 @@ __device__ inline double ovl_march(const KArgs &A, const Lds &l, bool dust, doub
             if (rr <= g.r2) { if (na < LART_OVL_ACT) act[na++] = icl; else over = true; free_in = fmin(free_in, g.r2 - rr); }
             else free_out = fmin(free_out, rr - g.r2);
         }
-        if (na > 1) {
-            long long key[LART_OVL_ACT];
-            for (int m = 0; m < na; m++) {
-                const ClumpGeo g = c.geo[act[m] - 1]; const double rc = sqrt(g.r2);
-                const int i0 = max(max(0, (int)((g.x - c.cg_min - rc) * c.cg_inv)), ci - 1), j0 = max(max(0, (int)((g.y - c.cg_min - rc) * c.cg_inv)), cj - 1),
-                          k0 = max(max(0, (int)((g.z - c.cg_min - rc) * c.cg_inv)), ck - 1);
-                key[m] = ((((long long)k0 * cg + j0) * cg + i0) << 31) | (long long)act[m];
-            }
-            for (int m = 1; m < na; m++) { const long long km = key[m]; const int am = act[m]; int n = m - 1;
-                while (n >= 0 && key[n] > km) { key[n + 1] = key[n]; act[n + 1] = act[n]; n--; }
-                key[n + 1] = km; act[n + 1] = am; }
+    }
+    // the order of the list: first cell of the 27-cell scan that registers the clump, then the clump number.  order_reach: how far the point may move before that
+    // order could change -- when the bounding box of every holder starts below the scan (i0 <= ci - 1 on every axis) all keys share the scan's first cell and the
+    // order is the clump number, which stays so while the point does not move below those cells; otherwise the order is tied to this cell.
+    double order_reach = LART_HUGEST;
+    if (na > 1) {
+        long long key[LART_OVL_ACT];
+        const double x0 = c.cg_min + (double)ci * c.cg_d, y0 = c.cg_min + (double)cj * c.cg_d, z0 = c.cg_min + (double)ck * c.cg_d;
+        int wx = 1 << 20, wy = 1 << 20, wz = 1 << 20;                                         // cells between the holders' bounding boxes and the scan, per axis (< 0: a box starts inside the scan)
+        for (int m = 0; m < na; m++) {
+            const ClumpGeo g = c.geo[act[m] - 1]; const double rc = sqrt(g.r2);
+            const int b0 = max(0, (int)((g.x - c.cg_min - rc) * c.cg_inv)), b1 = max(0, (int)((g.y - c.cg_min - rc) * c.cg_inv)), b2 = max(0, (int)((g.z - c.cg_min - rc) * c.cg_inv));
+            const int i0 = max(b0, ci - 1), j0 = max(b1, cj - 1), k0 = max(b2, ck - 1);
+            wx = min(wx, ci - 1 - b0); wy = min(wy, cj - 1 - b1); wz = min(wz, ck - 1 - b2);
+            key[m] = ((((long long)k0 * cg + j0) * cg + i0) << 31) | (long long)act[m];
         }
+        for (int m = 1; m < na; m++) { const long long km = key[m]; const int am = act[m]; int n = m - 1;
+            while (n >= 0 && key[n] > km) { key[n + 1] = key[n]; act[n + 1] = act[n]; n--; }
+            key[n + 1] = km; act[n + 1] = am; }
+        if (wx >= 0 && wy >= 0 && wz >= 0 && ci >= 1 && cj >= 1 && ck >= 1) order_reach = fmin(fmin((xp - x0) + (double)wx * c.cg_d, (yp - y0) + (double)wy * c.cg_d), (zp - z0) + (double)wz * c.cg_d);
+        else order_reach = fmin(fmin(fmin(xp - x0, x0 + c.cg_d - xp), fmin(yp - y0, y0 + c.cg_d - yp)), fmin(zp - z0, z0 + c.cg_d - zp));
     }
     if (TO_TAU && na > 0 && !over) {
         // In-clump fast path (the counterpart of the in-cell one of raytrace_to_tau): deep inside a clump the flight ends long before the next
@@ -1312,7 +1355,13 @@ __device__ inline double ovl_march(const KArgs &A, const Lds &l, bool dust, doub
         if (kap > 0.0) {
             const double x0 = c.cg_min + (double)ci * c.cg_d, y0 = c.cg_min + (double)cj * c.cg_d, z0 = c.cg_min + (double)ck * c.cg_d;
             const double dface = fmin(fmin(fmin(xp - x0, x0 + c.cg_d - xp), fmin(yp - y0, y0 + c.cg_d - yp)), fmin(zp - z0, z0 + c.cg_d - zp));
-            const double s_ = lim / kap, reach = fmin(fmin(dface, t_sp), fmin(free_out / (3.4641016151377544 * c.cg_d + 2.0 * c.radius_max), free_in / (2.0 * c.radius_max)));
+            const double s_ = lim / kap;
+            const double reach = all_clumps ? fmin(fmin(order_reach, t_sp), d_srf)
+                                            : fmin(fmin(dface, t_sp), fmin(free_out / (3.4641016151377544 * c.cg_d + 2.0 * c.radius_max), free_in / (2.0 * c.radius_max)));
+#ifdef LART_OVL_STATS
+            { const int which = reach == (all_clumps ? order_reach : dface) ? 0 : reach == t_sp ? 1 : 2;
+              OVL_STAT(A, 8 + which, 1); OVL_STAT(A, 12, reach); OVL_STAT(A, 13, fmin(s_, 10.0)); OVL_STAT(A, 14, na > LART_OVL_HOLD ? 1 : 0); OVL_STAT(A, 15, dface); }
+#endif
             if (s_ < reach * (1.0 - 1e-9)) {
                 nsteps++;
                 t_end = s_;
@@ -1320,27 +1369,42 @@ __device__ inline double ovl_march(const KArgs &A, const Lds &l, bool dust, doub
                 for (int m = 0; m < na; m++) { cumul = cumul + kv[m]; owner = act[m]; if (u_own * kap <= cumul) break; }
                 if (oh && na <= LART_OVL_HOLD) {                                              // the same bounds without the direction: R - |r| instead of t_sp
                     const double left = fmin(reach, c.sphere_R - sqrt(xp * xp + yp * yp + zp * zp)) - s_;
-                    if (left > 0.0) { oh->na = na; oh->reach = left; for (int m = 0; m < LART_OVL_HOLD; m++) oh->act[m] = m < na ? act[m] : 0; }
+                    if (left > 0.0) { oh->na = na; oh->reach = left; for (int m = 0; m < LART_OVL_HOLD; m++) oh->act[m] = m < na ? act[m] : 0; OVL_STAT(A, 3, 1); }
                 }
-                return 0.0;
+                OVL_STAT(A, 2, 1);                                                            // ... of which the fast path took the flight (3: and left a list behind)
+                return true;
             }
         }
     }
-    int si, sj, sk; double tx, ty, tz, delx, dely, delz;                                      // collect_ray_events_overlap: clump_mod.f90:1664-1693
-    if (kx > 0.0) { si = 1; delx = c.cg_d / kx; tx = ((c.cg_min + (double)(ci + 1) * c.cg_d) - xp) / kx; }
-    else if (kx < 0.0) { si = -1; delx = -c.cg_d / kx; tx = ((c.cg_min + (double)ci * c.cg_d) - xp) / kx; } else { si = 0; delx = LART_HUGEST; tx = LART_HUGEST; }
-    if (ky > 0.0) { sj = 1; dely = c.cg_d / ky; ty = ((c.cg_min + (double)(cj + 1) * c.cg_d) - yp) / ky; }
-    else if (ky < 0.0) { sj = -1; dely = -c.cg_d / ky; ty = ((c.cg_min + (double)cj * c.cg_d) - yp) / ky; } else { sj = 0; dely = LART_HUGEST; ty = LART_HUGEST; }
-    if (kz > 0.0) { sk = 1; delz = c.cg_d / kz; tz = ((c.cg_min + (double)(ck + 1) * c.cg_d) - zp) / kz; }
-    else if (kz < 0.0) { sk = -1; delz = -c.cg_d / kz; tz = ((c.cg_min + (double)ck * c.cg_d) - zp) / kz; } else { sk = 0; delz = LART_HUGEST; tz = LART_HUGEST; }
-    double d = 0.0, t_cur = 0.0, acc = TO_TAU ? lim : 0.0;                                    // acc: optical depth still to go / gone so far
-    bool cells = true, done = false;
+    // collect_ray_events_overlap: clump_mod.f90:1664-1693
+    if (kx > 0.0) { S.si = 1; S.delx = c.cg_d / kx; S.tx = ((c.cg_min + (double)(ci + 1) * c.cg_d) - xp) / kx; }
+    else if (kx < 0.0) { S.si = -1; S.delx = -c.cg_d / kx; S.tx = ((c.cg_min + (double)ci * c.cg_d) - xp) / kx; } else { S.si = 0; S.delx = LART_HUGEST; S.tx = LART_HUGEST; }
+    if (ky > 0.0) { S.sj = 1; S.dely = c.cg_d / ky; S.ty = ((c.cg_min + (double)(cj + 1) * c.cg_d) - yp) / ky; }
+    else if (ky < 0.0) { S.sj = -1; S.dely = -c.cg_d / ky; S.ty = ((c.cg_min + (double)cj * c.cg_d) - yp) / ky; } else { S.sj = 0; S.dely = LART_HUGEST; S.ty = LART_HUGEST; }
+    if (kz > 0.0) { S.sk = 1; S.delz = c.cg_d / kz; S.tz = ((c.cg_min + (double)(ck + 1) * c.cg_d) - zp) / kz; }
+    else if (kz < 0.0) { S.sk = -1; S.delz = -c.cg_d / kz; S.tz = ((c.cg_min + (double)ck * c.cg_d) - zp) / kz; } else { S.sk = 0; S.delz = LART_HUGEST; S.tz = LART_HUGEST; }
+    S.ci = ci; S.cj = cj; S.ck = ck; S.na = na; S.np = 0; S.over = over;
+    S.d = 0.0; S.t_cur = 0.0;                                                                 // acc: optical depth still to go / gone so far
+    S.cells = true; S.vis0 = 0ull; S.vis1 = 0ull; S.live = true;
+    if (TO_TAU) { OVL_STAT(A, 4, 1); OVL_STAT(A, 7, na); }                                    // marches begun (7: holders at their start)
+    return false;
+}
+// at most max_cells rounds of (one CSR cell, then the intervals up to its far face); true when the march is over
+template <bool TO_TAU>
+__device__ inline bool ovl_advance(const KArgs &A, const Lds &l, bool dust, double xp, double yp, double zp, double kx, double ky, double kz,
+                                   double xfreq_g, double lim, unsigned &nsteps, double &t_end, int &owner, double *col, OvlState &S, int max_cells) {
+    const DClumps &c = A.cl; const int cg = c.cgx;
+    int *act = S.act, *pid = S.pid; double *pt = S.pt;
+    int na = S.na, np = S.np, ci = S.ci, cj = S.cj, ck = S.ck;
+    double tx = S.tx, ty = S.ty, tz = S.tz, d = S.d, t_cur = S.t_cur, acc = S.acc;
+    const double t_sp = S.t_sp;
+    bool over = S.over, cells = S.cells, done = false;
     // A clump of a population of large spheres is registered in many cells of the row: once the ray has dealt with it (events queued, or never to be met: missed,
     // behind the origin, beyond the sphere's surface, EXIT already behind the ray), every later cell would come to the same `continue`.  While the population
     // fits a 128-bit mask (the shipped overlap examples have 30 clumps) the clumps dealt with are remembered exactly, and the cells carry their list as such a
     // mask too (cg_mask; the lists ascend, so the set bits in ascending order ARE the list): a cell costs one 16-byte load and an and-not, a clump one sphere
     // intersection per ray instead of one per cell it is registered in.
-    unsigned long long vis0 = 0ull, vis1 = 0ull;
+    unsigned long long vis0 = S.vis0, vis1 = S.vis1;
     auto visit = [&](int icl) {
         const unsigned long long bit = 1ull << ((icl - 1) & 63); const bool hi = ((icl - 1) & 64) != 0;
         const ClumpGeo g = c.geo[icl - 1];
@@ -1365,8 +1429,9 @@ __device__ inline double ovl_march(const KArgs &A, const Lds &l, bool dust, doub
             pt[pos] = tn; pid[pos] = idn; np++;
         }
     };
-    while (!done) {
+    for (int round = 0; round < max_cells && !done; round++) {
         double t_lim = LART_HUGEST;
+        if (TO_TAU) OVL_STAT(A, 5, 1);                                                        // cells walked
         if (cells && !(d > t_sp) && ci >= 0 && ci < cg && cj >= 0 && cj < cg && ck >= 0 && ck < cg) {
             const size_t q = (size_t)ci + (size_t)cj * cg + (size_t)ck * cg * cg;
             if (c.cg_mask) {
@@ -1377,9 +1442,9 @@ __device__ inline double ovl_march(const KArgs &A, const Lds &l, bool dust, doub
                 const int ip1 = c.cg_start[q + 1];
                 for (int ip = c.cg_start[q]; ip < ip1; ip++) visit(c.cg_list[ip - 1]);
             }
-            if (tx <= ty && tx <= tz) { d = tx; tx = tx + delx; ci += si; }
-            else if (ty <= tz)        { d = ty; ty = ty + dely; cj += sj; }
-            else                      { d = tz; tz = tz + delz; ck += sk; }
+            if (tx <= ty && tx <= tz) { d = tx; tx = tx + S.delx; ci += S.si; }
+            else if (ty <= tz)        { d = ty; ty = ty + S.dely; cj += S.sj; }
+            else                      { d = tz; tz = tz + S.delz; ck += S.sk; }
             t_lim = d;
         } else cells = false;
         for (;;) {                                                                            // the intervals up to t_lim (:713-743 / :884-897)
@@ -1389,6 +1454,7 @@ __device__ inline double ovl_march(const KArgs &A, const Lds &l, bool dust, doub
             if (dt > 0.0) {
                 const double kap = ovl_sum_kap(A, l, dust, act, na, xfreq_g, kx, ky, kz);
                 nsteps++;
+                if (TO_TAU) OVL_STAT(A, 6, 1);                                                // intervals evaluated
                 if (TO_TAU) {
                     if (kap > 0.0 && acc <= kap * dt) {
                         t_end = t_cur + acc / kap;
@@ -1396,7 +1462,7 @@ __device__ inline double ovl_march(const KArgs &A, const Lds &l, bool dust, doub
                         for (int m = 0; m < na; m++) {
                             const ClumpPhys ph = c.phys[act[m] - 1];
                             cumul = cumul + kappa_clump(A, l, dust, xfreq_g - ulos_clump(A, ph, kx, ky, kz), ph); owner = act[m];
-                            if (u_own * kap <= cumul) break;
+                            if (S.u_own * kap <= cumul) break;
                         }
                         done = true; break;
                     }
@@ -1413,17 +1479,37 @@ __device__ inline double ovl_march(const KArgs &A, const Lds &l, bool dust, doub
             else for (int m = 0; m < na; m++) if (act[m] == -id) { act[m] = act[na - 1]; na--; break; }
         }
     }
-    if (over && A.t.scal) atomicAdd(&A.t.scal[7], 1.0);
-    if (TO_TAU) { if (owner == 0) t_end = t_sp; return 0.0; }
-    return acc;
+    S.na = na; S.np = np; S.ci = ci; S.cj = cj; S.ck = ck; S.tx = tx; S.ty = ty; S.tz = tz; S.d = d; S.t_cur = t_cur; S.acc = acc;
+    S.over = over; S.cells = cells; S.vis0 = vis0; S.vis1 = vis1;
+    if (done) S.live = false;
+    return done;
+}
+template <bool TO_TAU>
+__device__ inline double ovl_finish(const KArgs &A, const OvlState &S, double &t_end, int owner) {
+    if (S.over && A.t.scal) atomicAdd(&A.t.scal[7], 1.0);
+    if (TO_TAU) { if (owner == 0) t_end = S.t_sp; return 0.0; }
+    return S.acc;
+}
+template <bool TO_TAU>
+__device__ inline double ovl_march(const KArgs &A, const Lds &l, bool dust, double xp, double yp, double zp, double kx, double ky, double kz,
+                                   double xfreq_g, double lim, double u_own, unsigned &nsteps, double &t_end, int &owner, double *col = nullptr, OvlHold *oh = nullptr,
+                                   OvlState *room = nullptr) {
+    OvlState own; OvlState &S = room ? *room : own;          // (the transport kernel lends its own state: one set of lists in scratch instead of two)
+    if (ovl_start<TO_TAU>(A, l, dust, xp, yp, zp, kx, ky, kz, xfreq_g, lim, u_own, nsteps, t_end, owner, oh, S)) return 0.0;
+    while (!ovl_advance<TO_TAU>(A, l, dust, xp, yp, zp, kx, ky, kz, xfreq_g, lim, nsteps, t_end, owner, col, S, 1 << 30)) { }
+    return ovl_finish<TO_TAU>(A, S, t_end, owner);
+}
+// the end of raytrace_to_tau_clump_overlap (:668-788): move to the scattering point or out of the sphere
+__device__ inline void ovl_apply(const KArgs &A, Photon &p, double t_end, int owner) {
+    p.x = p.x + t_end * p.kx; p.y = p.y + t_end * p.ky; p.z = p.z + t_end * p.kz;
+    p.icl = owner;
+    if (owner == 0) { p.inside = false; p.xfreq_ref = p.xfreq; tally_escape(A.par, A.t, p); }
 }
 // raytrace_to_tau_clump_overlap: :668-788
 __device__ inline void raytrace_to_tau_clump_ovl(const KArgs &A, const Lds &l, bool dust, Photon &p, double tau_in, double u_own, unsigned &nsteps, OvlHold *oh = nullptr) {
     double t_end; int owner;
     ovl_march<true>(A, l, dust, p.x, p.y, p.z, p.kx, p.ky, p.kz, p.xfreq, tau_in, u_own, nsteps, t_end, owner, nullptr, oh);
-    p.x = p.x + t_end * p.kx; p.y = p.y + t_end * p.ky; p.z = p.z + t_end * p.kz;
-    p.icl = owner;
-    if (owner == 0) { p.inside = false; p.xfreq_ref = p.xfreq; tally_escape(A.par, A.t, p); }
+    ovl_apply(A, p, t_end, owner);
 }
 
 // tau to the grid edge (dist < 0) or to a finite distance (raytrace_to_dist_car :89-195, VAR 0 only)

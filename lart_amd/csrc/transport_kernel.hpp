@@ -25,16 +25,21 @@ __device__ inline double wave_sum(double v) {
 // largest workgroup: the kernels that fit 128 VGPRs may run as ONE 1024-lane workgroup per CU (the same 4 waves per SIMD), which leaves the LDS that four
 // 256-lane workgroups spend on four copies of the tables to the J(x) window of the profile tallies (lart_gpu.hip, tally layout)
 #define LART_MAX_BLOCK(S, P) (LART_WAVES(S, P) >= 4 ? 1024 : 256)
+#ifndef LART_OVL_CELLS_PER_ROUND
+#define LART_OVL_CELLS_PER_ROUND 4           // CSR cells a lane in an overlap march walks per round of its wave
+#endif
 
 
 // one flight of a packet: optical depth to the next interaction (forced on the first flight: run_simulation_mod.f90:163-177,
 // add_escaped_fraction_to_Jout :208-247), then the march
 template <int VAR, bool DUST>
-__device__ inline void fly(const KArgs &A, const Lds &l, Rng &g, Photon &p, bool &first, unsigned &nsteps, OvlHold *oh = nullptr) {
+__device__ inline void fly(const KArgs &A, const Lds &l, Rng &g, Photon &p, bool &first, unsigned &nsteps, OvlHold *oh = nullptr, OvlState *os = nullptr) {
     const lart_params &par = A.par;
     double tau;
     if (first) {
-        double tau0 = raytrace_to_edge<VAR>(A, l, DUST, p, p.xfreq, p.kx, p.ky, p.kz, -1.0, nsteps);
+        double tau0;
+        if (VAR == 7) { double te_; int ow_; tau0 = ovl_march<false>(A, l, DUST, p.x, p.y, p.z, p.kx, p.ky, p.kz, p.xfreq, LART_TAU_HUGE, 0.0, nsteps, te_, ow_, nullptr, nullptr, os); }   // = raytrace_to_edge<7> (edge_begin), in the kernel's own march state
+        else tau0 = raytrace_to_edge<VAR>(A, l, DUST, p, p.xfreq, p.kx, p.ky, p.kz, -1.0, nsteps);
         double esc = d_exp_neg(-tau0);
         {
             const Cell &c = A.g.cell[cidx(A.g, p.ic, p.jc, p.kc)];
@@ -54,7 +59,10 @@ __device__ inline void fly(const KArgs &A, const Lds &l, Rng &g, Photon &p, bool
 #ifdef LART_EXPERIMENT_RAY2                            // timing experiment: cost of one flight (the copy's escapes are tallied twice: timing only)
     { Photon p2 = p; unsigned ns2 = 0; raytrace_to_tau<VAR>(A, l, DUST, p2, tau, ns2); if (p2.x == 1e300) p.x = p2.y; }
 #endif
-    raytrace_to_tau<VAR>(A, l, DUST, p, tau, nsteps, u_own, oh);
+    if (VAR == 7) {                                        // overlapping clumps: the march may be left in flight in *os (the kernel's loop advances it)
+        double t_end; int owner;
+        if (ovl_start<true>(A, l, DUST, p.x, p.y, p.z, p.kx, p.ky, p.kz, p.xfreq, tau, u_own, nsteps, t_end, owner, oh, *os)) ovl_apply(A, p, t_end, owner);
+    } else raytrace_to_tau<VAR>(A, l, DUST, p, tau, nsteps, u_own, oh);
     LART_PROF_MARK(p, 3);
 }
 
@@ -102,6 +110,7 @@ __global__ __launch_bounds__(LART_MAX_BLOCK(STOKES, PEEL), LART_WAVES(STOKES, PE
 
     Photon p; Rng g; g.attach(rng_lds, blockDim.x);
     OvlHold oh; oh.na = 0; oh.reach = 0.0;                                        // VAR 7: holders carried from one flight to the next (not kept between launches)
+    OvlState os; os.live = false;                                                 // VAR 7: the march of a flight that left its clump, between two rounds of the wave
     g.k0 = (uint32_t)A.seed; g.k1 = (uint32_t)(A.seed >> 32);                  // (a lane that never holds a packet still lends its ALU to Rng::prefill_sparse: the key is the run's)
 #ifdef LART_PROFILE
     for (int i = 0; i < 12; i++) p.pt[i] = 0;
@@ -164,10 +173,17 @@ __global__ __launch_bounds__(LART_MAX_BLOCK(STOKES, PEEL), LART_WAVES(STOKES, PE
         if (act) g.prefill();
 #endif
         LART_PROF_TRIP(p, 2);
-        if (act) fly<VAR, DUST>(A, l, g, p, first, nsteps, VAR == 7 ? &oh : nullptr);
-        { const bool on = act && p.inside; scatter_event<VAR, STOKES, DUST, PEEL>(A, l, g, p, npeel, on); if (on) { nev++; budget--; } }
+        if (act && !(VAR == 7 && os.live)) fly<VAR, DUST>(A, l, g, p, first, nsteps, VAR == 7 ? &oh : nullptr, VAR == 7 ? &os : nullptr);
+        if (VAR == 7 && act && os.live) {                  // a flight that left its clump: a few cells of the march per round, the other lanes of the wave go on scattering
+            double t_end = 0.0; int owner = 0;
+            if (ovl_advance<true>(A, l, DUST, p.x, p.y, p.z, p.kx, p.ky, p.kz, p.xfreq, 0.0, nsteps, t_end, owner, nullptr, os, LART_OVL_CELLS_PER_ROUND)) {
+                ovl_finish<true>(A, os, t_end, owner); ovl_apply(A, p, t_end, owner);
+            }
+        }
+        const bool marching = VAR == 7 && os.live;
+        { const bool on = act && p.inside && !marching; scatter_event<VAR, STOKES, DUST, PEEL>(A, l, g, p, npeel, on); if (on) { nev++; budget--; } }
         LART_PROF_MARK(p, 6);
-        if (act) {
+        if (act && !marching) {
             if (A.trace_slot) trace_rec<VAR>(A, k, g.n, p, p.inside ? 1 : 2);
             if (!p.inside) {
                 nsg_done += p.nsg; nsd_done += p.nsd; ndone++;

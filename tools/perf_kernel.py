@@ -96,6 +96,15 @@ def main():
            "roofline": {"bound": "hbm", "achieved": bytes_launch / (k_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                         "frac": bytes_launch / (k_ms * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes_per_launch": bytes_launch}}
     print(json.dumps(out), flush=True)
+    if os.environ.get("LART_GPU_LIB", "").endswith("_st.so"):              # -DLART_OVL_STATS build: how the flights of the overlap march divide
+        ptr, nt = sim.ctx.tally_buffer()
+        b = host._as_cuda_tensor(ptr, 32, sim.ctx).cpu().numpy(); ev_all = t1["n_events"]
+        names = ["carried_list", "rebuilds", "rebuild_fast", "rebuild_fast_cached", "marches", "cells", "intervals", "holders_at_march_start"]
+        print(json.dumps({"per_event": {k: float(b[8 + i] / ev_all) for i, k in enumerate(names)}, "cells_per_march": float(b[13] / max(b[12], 1)), "intervals_per_march": float(b[14] / max(b[12], 1)),
+                          "binding_bound_share": {k: float(b[16 + i] / max(b[16:20].sum(), 1)) for i, k in enumerate(["cell_face", "sphere", "other_clump", "own_clump"])},
+                          "mean_reach": float(b[20] / max(b[16:20].sum(), 1)), "mean_flight_capped10": float(b[21] / max(b[16:20].sum(), 1)), "more_than_4_holders": float(b[22] / max(b[16:20].sum(), 1)),
+                          "mean_dface": float(b[23] / max(b[16:20].sum(), 1)),
+                          "cgx": int(sim.clumps.cgx), "cg_d": float(sim.clumps.cg_d) if hasattr(sim.clumps, "cg_d") else None}))
     sim.ctx.close()
 
 
