@@ -919,7 +919,7 @@ __device__ inline bool trav_cross(const DGrid &g, Trav &t, int idx) {
     // of `t`, which moves the whole traversal state into scratch memory
     const bool ax = idx == 1, ay = idx == 2;
     int cell = ax ? t.ic : (ay ? t.jc : t.kc), step = ax ? t.is : (ay ? t.js : t.ks);
-    const int n = ax ? g.nx : (ay ? g.ny : g.nz), m0 = ax ? g.i0 : (ay ? g.j0 : g.k0);
+    const int n = ax ? g.nx : (ay ? g.ny : g.nz), m0 = VAR == 5 ? (ax ? g.i0 : g.j0) : (ax ? g.i0 : (ay ? g.j0 : g.k0));
     double k = ax ? t.kx : (ay ? t.ky : t.kz), tt = ax ? t.tx : (ay ? t.ty : t.tz);
     const double del = ax ? t.delx : (ay ? t.dely : t.delz);
     cell += step;

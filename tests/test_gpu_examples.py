@@ -1,6 +1,6 @@
 """The parameter combinations of the reference's shipped inputs (tests/golden/reference_example_params.json, written by
 tools/gen_example_params.py from examples/*/*.in) on the device, at reduced optical depth, grid and photon number: every accepted input
-must set up, run to its last photon and conserve photons.  Property checks, not parity: every seventh set (31 of the 214, spread over the example
+must set up, run to its last photon and conserve photons.  Property checks, not parity: every third set (72 of the 214, spread over the example
 directories) runs in the default device suite, the rest carry the `slow` marker (pytest -m "gpu and slow")."""
 import json
 import os
@@ -44,7 +44,7 @@ def capi():
     return capi
 
 
-@pytest.mark.parametrize("name", [pytest.param(n, marks=() if i % 7 == 0 else pytest.mark.slow) for i, n in enumerate(NAMES)])
+@pytest.mark.parametrize("name", [pytest.param(n, marks=() if i % 3 == 0 else pytest.mark.slow) for i, n in enumerate(NAMES)])
 def test_shipped_parameter_set_runs(capi, tmp_path, name):
     from lart_amd import host
     kw = reduced(SETS[name], str(tmp_path))
