@@ -116,6 +116,10 @@ struct DPeelCtl { unsigned long long q_head, d_n; };   // per queue buffer: prod
 // spills).  Here a scattering only RECORDS what the peel routine reads -- position, incoming direction, weight, the atom's frame
 // (xfreq_atom, u_x, u_y, u_z), E1..E3, the Stokes triad and Q,U,V, the cell -- as one SoA record (coalesced 512-byte stores per plane
 // and wave), and peel_kernel runs the unchanged peel routines over the records afterwards, one record per lane, all lanes busy.
+// A mirror plane flips the direction of a packet and leaves the vectors m and n of its Stokes frame as they are (the mirrored quadrant, raytrace_car.f90:2235-2244;
+// the octree with mirrored root-box faces, raytrace_amr.f90:176-201): after that (m, n, k) is no right-handed triad any more, and a peel record has to carry n
+// instead of leaving it to n = k x m (peel_load)
+template <int VAR> __device__ __forceinline__ bool peel_record_has_n(const lart_params &par) { return VAR == 5 || (VAR == 3 && (par.xy_symmetry || par.xyz_symmetry)); }
 enum { PQ_X = 0, PQ_Y, PQ_Z, PQ_KX, PQ_KY, PQ_KZ, PQ_WGT, PQ_XA, PQ_UX, PQ_UY, PQ_UZ, PQ_E1, PQ_E2, PQ_E3, PQ_GREC, PQ_NOSTOKES,
        PQ_MX = PQ_NOSTOKES, PQ_MY, PQ_MZ, PQ_NX, PQ_NY, PQ_NZ, PQ_Q, PQ_U, PQ_V, PQ_COUNT };
 enum { PEEL_DIRECT = 0, PEEL_RESONANCE = 1, PEEL_DUST = 2 };
@@ -2118,6 +2122,7 @@ __device__ __forceinline__ void peel_emit(const KArgs &A, const Lds &l, bool dus
     if (kind == PEEL_RESONANCE) { f[PQ_UX * C + r] = ux; f[PQ_UY * C + r] = uy; f[PQ_UZ * C + r] = uz;
         if (l.lt != 1) { f[PQ_E1 * C + r] = E1; f[PQ_E2 * C + r] = E2; f[PQ_E3 * C + r] = E3; f[PQ_GREC * C + r] = grec; } }
     if (STOKES) { f[PQ_MX * C + r] = p.mx; f[PQ_MY * C + r] = p.my; f[PQ_MZ * C + r] = p.mz;
+                  if (peel_record_has_n<VAR>(A.par)) { f[PQ_NX * C + r] = p.nx; f[PQ_NY * C + r] = p.ny; f[PQ_NZ * C + r] = p.nz; }
                   f[PQ_Q * C + r] = p.Q; f[PQ_U * C + r] = p.U; f[PQ_V * C + r] = p.V; }
     int *q = A.pq.cell;
     q[r] = p.ic; q[C + r] = p.jc; q[2 * C + r] = is_clump(VAR) ? p.icl : p.kc; q[3 * C + r] = kind;

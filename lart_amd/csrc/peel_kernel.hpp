@@ -31,7 +31,8 @@ __device__ inline void peel_load(const KArgs &A, const Lds &l, size_t r, bool fu
     ux = 0.0; uy = 0.0; uz = 0.0; E1 = 0.0; E2 = 0.0; E3 = 0.0; grec = 0.0;
     if (kind == PEEL_RESONANCE) { ux = f[PQ_UX * C + r]; uy = f[PQ_UY * C + r]; uz = f[PQ_UZ * C + r]; grec = (l.lt != 1) ? f[PQ_GREC * C + r] : A.par.g_recoil0; }
     if (STOKES) { p.mx = f[PQ_MX * C + r]; p.my = f[PQ_MY * C + r]; p.mz = f[PQ_MZ * C + r];
-                  p.nx = p.ky * p.mz - p.kz * p.my; p.ny = p.kz * p.mx - p.kx * p.mz; p.nz = p.kx * p.my - p.ky * p.mx; }   // n = k x m: (m, n, k) is a right-handed triad
+                  if (peel_record_has_n<VAR>(A.par)) { p.nx = f[PQ_NX * C + r]; p.ny = f[PQ_NY * C + r]; p.nz = f[PQ_NZ * C + r]; }   // (stored: a mirror flips k only)
+                  else { p.nx = p.ky * p.mz - p.kz * p.my; p.ny = p.kz * p.mx - p.kx * p.mz; p.nz = p.kx * p.my - p.ky * p.mx; } }   // n = k x m: (m, n, k) is a right-handed triad
     if (full) {                                                // what only the deposit reads
         p.wgt = f[PQ_WGT * C + r];
         if (kind == PEEL_RESONANCE) { if (l.lt != 1) { E1 = f[PQ_E1 * C + r]; E2 = f[PQ_E2 * C + r]; E3 = f[PQ_E3 * C + r]; } else { E1 = A.par.E1; E2 = A.par.E2; E3 = A.par.E3; } }

@@ -517,8 +517,8 @@ def _cubes_batchwise(sim, o, names, shapes, nbatch, per, seed):
     return out
 
 
-@pytest.mark.parametrize("case", ["resonance_stokes", "dust_mueller_stokes", "dust_hg_direc0", "amr_stokes", "clump_dust_stokes"])
-def test_peel_cubes_equal_the_oracle_on_identical_histories(capi, oracle_mod, mueller_file, amr_file, case):
+@pytest.mark.parametrize("case", ["resonance_stokes", "dust_mueller_stokes", "dust_hg_direc0", "amr_stokes", "clump_dust_stokes", "xysym_stokes", "xyper_dust", "amr_mirror_stokes"])
+def test_peel_cubes_equal_the_oracle_on_identical_histories(capi, oracle_mod, mueller_file, amr_file, amr_slab_file, case):
     """The peel-off tallies on the SAME photon histories.  Device and oracle run the same (seed, id) streams; ~97 % of the histories are
     identical, the rest flip at a rejection test on a last-bit difference and then diverge.  Batches of 16 photons in which every
     history is identical must give the same Stokes cubes and images to 1e-9 of the cube's largest entry -- a wrong sign of a Stokes
@@ -534,6 +534,15 @@ def test_peel_cubes_equal_the_oracle_on_identical_histories(capi, oracle_mod, mu
     elif case == "dust_hg_direc0":
         kw = dict(temperature=1e4, taumax=3e1, nx=21, ny=21, nz=21, rmax=1.0, nxfreq=61, nxim=15, nyim=15, DGR=1.0, cext_dust=2e-15,
                   save_peeloff_2D=True, save_direc0=True, save_dust_scattered=True, alpha=15.0, beta=40.0, source_geometry="uniform_sphere", source_rmax=0.7)
+    elif case == "xysym_stokes":                               # peel rays through the mirrored quadrant (raytrace_to_edge_car_xysym): peel_kernel<5, true>
+        kw = dict(temperature=1e4, taumax=3e1, nx=20, ny=14, nz=31, rmax=1.0, xy_symmetry=True, nxfreq=61, nxim=15, nyim=15, use_stokes=True,
+                  save_peeloff_2D=True, alpha=25.0, beta=60.0, velocity_type="hubble", Vexp=30.0)
+    elif case == "amr_mirror_stokes":                          # the octree's root box with mirrors at -x / -y (raytrace_amr.f90:176-201): k flips, the Stokes frame does not
+        kw = dict(use_amr_grid=True, amr_file=amr_slab_file, temperature=1e4, taumax=3e1, nxfreq=61, xfreq_min=-12.0, xfreq_max=12.0, xy_symmetry=True, use_stokes=True,
+                  nxim=15, nyim=15, alpha=25.0, beta=60.0, save_peeloff_2D=True)
+    elif case == "xyper_dust":                                 # ... and through the periodic box (raytrace_to_edge_car_xyper): peel_kernel<6, false>
+        kw = dict(temperature=1e4, taumax=2e1, nx=6, ny=5, nz=31, xmax=0.6, ymax=0.5, zmax=1.0, geometry="rectangle", xy_periodic=True, nxfreq=61, nxim=15, nyim=15, DGR=1.0,
+                  cext_dust=2e-15, save_peeloff_2D=True, alpha=15.0, beta=40.0)
     elif case == "amr_stokes":
         kw = dict(use_amr_grid=True, amr_file=amr_file, temperature=1e4, taumax=1e2, rmax=1.0, nxfreq=61, nxim=15, nyim=15, use_stokes=True,
                   DGR=1.0, scatt_mat_file=mueller_file, velocity_type="hubble", Vexp=20.0, alpha=30.0, beta=65.0, save_peeloff_2D=True)
@@ -556,12 +565,20 @@ def test_peel_cubes_equal_the_oracle_on_identical_histories(capi, oracle_mod, mu
             continue
         for k in names + names2:
             d = dev[k][..., 0] if dev[k].ndim > len(shapes[k]) else dev[k]
-            scale = max(np.abs(ora["I" if "I" in ora else "scatt"]).max(), 1e-300) if not k.endswith("_2D") else max(np.abs(ora["I_2D" if "I_2D" in ora else "scatt_2D"]).max(), 1e-300)
+            scale = max(np.abs(ora["I" if "I" in ora else "scatt"]).max(), 1e-300) if not k.endswith("_2D") else max(np.nanmax(np.abs(ora["I_2D" if "I_2D" in ora else "scatt_2D"])), 1e-300)
             # (clumps: a peel ray crosses ~50 spheres, each chord b^2 - |r|^2 + R^2 a cancellation, and a ray that grazes one amplifies the last bit;
             #  single photons' deposits differ by 1e-6 .. 1e-4 of the cube maximum between device and oracle there)
             tol = 3e-4 if case == "clump_dust_stokes" else 1e-9
-            assert np.allclose(d, ora[k], rtol=tol, atol=tol * scale), (case, k, float(np.abs(d - ora[k]).max() / scale))
-            tot[k] += np.abs(ora[k]).sum()
+            ref = ora[k]
+            if case in ("xysym_stokes", "amr_mirror_stokes") and k.endswith("_2D"):
+                # A mirror flips k and leaves the Stokes frame as it is (raytrace_car.f90:2235-2244, raytrace_amr.f90:176-201), so (m, n, k) is no triad after a
+                # reflection and the azimuth of a Stokes peel (peelingoff_rect.f90:356-385) can leave its domain: the frequency of such a deposit is NaN.  The cube
+                # skips it (no frequency bin); the reference's 2-D image adds it and keeps a NaN pixel, which the oracle restates.  The device drops the deposit
+                # (a ray whose optical depth is NaN does not come through the march kernel): compared where the oracle's image is finite, and finite everywhere.
+                assert np.all(np.isfinite(d)) and np.isnan(ref).sum() <= 0.2 * ref.size
+                ok = np.isfinite(ref); d, ref = d[ok], ref[ok]
+            assert np.allclose(d, ref, rtol=tol, atol=tol * scale), (case, k, float(np.abs(d - ref).max() / scale))
+            tot[k] += np.abs(ref).sum()
     assert tot["scatt"] > 0 and tot["direc"] >= 0
     if kw.get("use_stokes"):
         assert tot["Q"] > 0 and tot["U"] > 0                                 # the polarised deposits were really exercised
