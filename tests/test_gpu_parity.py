@@ -517,7 +517,9 @@ def _cubes_batchwise(sim, o, names, shapes, nbatch, per, seed):
     return out
 
 
-@pytest.mark.parametrize("case", ["resonance_stokes", "dust_mueller_stokes", "dust_hg_direc0", "amr_stokes", "clump_dust_stokes", "xysym_stokes", "xyper_dust", "amr_mirror_stokes"])
+@pytest.mark.parametrize("case", ["resonance_stokes", "dust_mueller_stokes", "dust_hg_direc0", "amr_stokes", "clump_dust_stokes", "xysym_stokes", "xyper_dust", "amr_mirror_stokes",
+                                  "slab_stokes", "xyper_mueller_stokes", "xysym_dust_hg", "shear_box", "fine_structure_stokes", "deuterium_recoil", "hei_triplet_stokes",
+                                  "amr_periodic_dust_stokes", "clump_moving", "core_skip_stokes", "extended_source_stokes"])
 def test_peel_cubes_equal_the_oracle_on_identical_histories(capi, oracle_mod, mueller_file, amr_file, amr_slab_file, case):
     """The peel-off tallies on the SAME photon histories.  Device and oracle run the same (seed, id) streams; ~97 % of the histories are
     identical, the rest flip at a rejection test on a last-bit difference and then diverge.  Batches of 16 photons in which every
@@ -537,6 +539,38 @@ def test_peel_cubes_equal_the_oracle_on_identical_histories(capi, oracle_mod, mu
     elif case == "xysym_stokes":                               # peel rays through the mirrored quadrant (raytrace_to_edge_car_xysym): peel_kernel<5, true>
         kw = dict(temperature=1e4, taumax=3e1, nx=20, ny=14, nz=31, rmax=1.0, xy_symmetry=True, nxfreq=61, nxim=15, nyim=15, use_stokes=True,
                   save_peeloff_2D=True, alpha=25.0, beta=60.0, velocity_type="hubble", Vexp=30.0)
+    # --- combinations that no other exact comparison reaches (round 3: one of them, the mirrored quadrant with a Stokes vector, was wrong) ---
+    elif case == "slab_stokes":                                # 1-column slab (raytrace_to_edge_car_zonly): peel_kernel<2, true>
+        kw = dict(temperature=1e4, taumax=2e1, nx=1, ny=1, nz=41, xmax=1.0, ymax=1.0, zmax=1.0, geometry="rectangle", xy_periodic=True, nxfreq=61, nxim=15, nyim=15, use_stokes=True,
+                  save_peeloff_2D=True, alpha=15.0, beta=40.0, recoil=True)
+    elif case == "xyper_mueller_stokes":
+        kw = dict(temperature=1e4, taumax=2e1, nx=6, ny=5, nz=31, xmax=0.6, ymax=0.5, zmax=1.0, geometry="rectangle", xy_periodic=True, nxfreq=61, nxim=15, nyim=15, use_stokes=True,
+                  DGR=1.2e6, scatt_mat_file=mueller_file, save_peeloff_2D=True, save_direc0=True, save_dust_scattered=True, alpha=15.0, beta=40.0)
+    elif case == "xysym_dust_hg":
+        kw = dict(temperature=1e4, taumax=3e1, nx=20, ny=14, nz=31, rmax=1.0, xy_symmetry=True, nxfreq=61, nxim=15, nyim=15, DGR=1.0, cext_dust=2e-15,
+                  save_peeloff_2D=True, save_direc0=True, save_dust_scattered=True, alpha=25.0, beta=60.0)
+    elif case == "shear_box":                                  # VAR 8: the flights shear, the peel rays use the plain open-box march (setup.f90:941, 967-969)
+        kw = dict(temperature=1e4, taumax=2e1, nx=6, ny=5, nz=31, xmax=0.6, ymax=0.5, zmax=1.0, geometry="rectangle", xy_periodic=True, Omega=1.7, nxfreq=61, nxim=15, nyim=15,
+                  save_peeloff_2D=True, alpha=15.0, beta=40.0)
+    elif case == "fine_structure_stokes":
+        kw = dict(temperature=20.0, taumax=50.0, nx=21, ny=21, nz=21, rmax=1.0, nxfreq=61, fine_structure=True, use_stokes=True, recoil=True, nxim=15, nyim=15,
+                  save_peeloff_2D=True, alpha=25.0, beta=60.0)
+    elif case == "deuterium_recoil":
+        kw = dict(temperature=1e2, taumax=50.0, nx=21, ny=21, nz=21, rmax=1.0, nxfreq=61, include_deuterium=True, D_to_H_ratio=3e-3, recoil=True, use_stokes=True, nxim=15, nyim=15,
+                  save_peeloff_2D=True, alpha=25.0, beta=60.0)
+    elif case == "hei_triplet_stokes":
+        kw = dict(temperature=1e4, taumax=30.0, nx=21, ny=21, nz=21, rmax=1.0, nxfreq=61, line_id="HeI_10833", use_stokes=True, bturb=3.0, nxim=15, nyim=15,
+                  save_peeloff_2D=True, alpha=25.0, beta=60.0)
+    elif case == "amr_periodic_dust_stokes":
+        kw = dict(use_amr_grid=True, amr_file=amr_slab_file, temperature=1e4, taumax=3e1, nxfreq=61, xfreq_min=-12.0, xfreq_max=12.0, xy_periodic=True, use_stokes=True,
+                  DGR=1.0, scatt_mat_file=mueller_file, nxim=15, nyim=15, alpha=25.0, beta=60.0, save_peeloff_2D=True)
+    elif case == "clump_moving":
+        kw = dict(CLUMP, clump_tau0=1e2, clump_sigma_v=30.0, velocity_type="hubble", Vexp=80.0, nxim=15, nyim=15, save_peeloff_2D=True, alpha=20.0, beta=50.0)
+    elif case == "core_skip_stokes":
+        kw = dict(temperature=10.0, taumax=3e3, nx=11, ny=11, nz=11, rmax=1.0, nxfreq=61, core_skip=True, use_stokes=True, nxim=15, nyim=15, save_peeloff_2D=True, alpha=25.0, beta=60.0)
+    elif case == "extended_source_stokes":
+        kw = dict(temperature=1e4, taumax=3e1, nx=21, ny=21, nz=21, rmax=1.0, nxfreq=61, nxim=15, nyim=15, use_stokes=True, save_peeloff_2D=True, alpha=15.0, beta=40.0,
+                  source_geometry="uniform_sphere", source_rmax=0.7, velocity_type="hubble", Vexp=30.0)
     elif case == "amr_mirror_stokes":                          # the octree's root box with mirrors at -x / -y (raytrace_amr.f90:176-201): k flips, the Stokes frame does not
         kw = dict(use_amr_grid=True, amr_file=amr_slab_file, temperature=1e4, taumax=3e1, nxfreq=61, xfreq_min=-12.0, xfreq_max=12.0, xy_symmetry=True, use_stokes=True,
                   nxim=15, nyim=15, alpha=25.0, beta=60.0, save_peeloff_2D=True)
@@ -568,7 +602,7 @@ def test_peel_cubes_equal_the_oracle_on_identical_histories(capi, oracle_mod, mu
             scale = max(np.abs(ora["I" if "I" in ora else "scatt"]).max(), 1e-300) if not k.endswith("_2D") else max(np.nanmax(np.abs(ora["I_2D" if "I_2D" in ora else "scatt_2D"])), 1e-300)
             # (clumps: a peel ray crosses ~50 spheres, each chord b^2 - |r|^2 + R^2 a cancellation, and a ray that grazes one amplifies the last bit;
             #  single photons' deposits differ by 1e-6 .. 1e-4 of the cube maximum between device and oracle there)
-            tol = 3e-4 if case == "clump_dust_stokes" else 1e-9
+            tol = 3e-4 if case in ("clump_dust_stokes", "clump_moving") else 1e-9
             ref = ora[k]
             if case in ("xysym_stokes", "amr_mirror_stokes") and k.endswith("_2D"):
                 # A mirror flips k and leaves the Stokes frame as it is (raytrace_car.f90:2235-2244, raytrace_amr.f90:176-201), so (m, n, k) is no triad after a
