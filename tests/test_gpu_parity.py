@@ -618,6 +618,41 @@ def test_peel_cubes_equal_the_oracle_on_identical_histories(capi, oracle_mod, mu
         assert tot["Q"] > 0 and tot["U"] > 0                                 # the polarised deposits were really exercised
 
 
+@pytest.mark.parametrize("case", ["car", "car_dust_stokes", "amr_stokes"])
+def test_healpix_maps_equal_the_oracle_on_identical_histories(capi, oracle_mod, mueller_file, amr_file, case):
+    """the same comparison for an observer INSIDE the medium (HEALPix maps, peeling_*_inside: peelingoff_heal.f90 / peelingoff_amr.f90:656-849): the peel ray ends at
+    the observer (raytrace_to_dist), the pixel is that of the arrival direction"""
+    if case == "car":
+        kw = dict(temperature=1e4, taumax=50.0, nx=31, ny=31, nz=31, rmax=1.0, nxfreq=61, nside=4, obsx=0.3, obsy=-0.2, obsz=0.1, save_peeloff_2D=True, recoil=True)
+    elif case == "car_dust_stokes":
+        kw = dict(temperature=1e4, taumax=3e1, nx=21, ny=21, nz=21, rmax=1.0, nxfreq=61, nside=4, obsx=0.3, obsy=0.0, obsz=0.0, use_stokes=True, DGR=1.2e6, scatt_mat_file=mueller_file,
+                  save_peeloff_2D=True, velocity_type="hubble", Vexp=30.0)
+    else:                                                                 # (clump media and the periodic / mirrored boxes have no inside observer: refused at set-up)
+        kw = dict(use_amr_grid=True, amr_file=amr_file, temperature=1e4, taumax=1e2, rmax=1.0, nxfreq=61, nside=4, obsx=0.3, obsy=-0.1, obsz=0.2, use_stokes=True,
+                  save_peeloff_2D=True, velocity_type="hubble", Vexp=20.0)
+    kw["iseed"] = 1
+    sim = make(kw)
+    o = oracle_mod.Oracle(**{k: v for k, v in kw.items() if k != "iseed"})
+    nxf, npix = sim.cpar.nxfreq, 12 * 4 * 4
+    names = ["scatt", "direc"]                                             # (the inside peels have no Stokes form: peelingoff_heal.f90:101-250 are the _nostokes_ routines, also in Stokes runs)
+    shapes = {k: (nxf, npix) for k in names}
+    res = _cubes_batchwise(sim, o, names, shapes, nbatch=50, per=16, seed=2025)
+    nclean = sum(1 for c, _, _ in res if c)
+    assert nclean >= 10, nclean
+    tot = {k: 0.0 for k in names}
+    for clean, dev, ora in res:
+        if not clean:
+            continue
+        scale = max(np.abs(ora["scatt"]).max(), 1e-300)
+        for k in names:
+            d = np.asarray(dev[k]).reshape(shapes[k], order="F") if np.asarray(dev[k]).size == nxf * npix else None
+            assert d is not None, (k, np.asarray(dev[k]).shape)
+            tol = 3e-4 if case == "clump" else 1e-9
+            assert np.allclose(d, ora[k], rtol=tol, atol=tol * scale), (case, k, float(np.abs(d - ora[k]).max() / scale))
+            tot[k] += np.abs(ora[k]).sum()
+    assert tot["scatt"] > 0
+
+
 @pytest.mark.parametrize("stokes", [False, True])
 def test_direct0_and_dust_scattered_tallies(capi, oracle_mod, mueller_file, stokes):
     """par%save_direc0 (the source without extinction, peelingoff_rect.f90:108-125) and par%save_dust_scattered (the dust-scattered
