@@ -8,7 +8,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
-SMALL = ["--steps", "2", "--warmup", "1", "--events-per-step", "256", "--lanes", "131072", "--completion-photons", "128", "--no-other-configs"]
+SMALL = ["--steps", "2", "--warmup", "1", "--events-per-step", "256", "--lanes", "131072", "--completion-photons", "32", "--no-other-configs"]
 
 
 def last_json(out):
@@ -29,11 +29,11 @@ def test_bench_line_contract():
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["reference_events_per_s_per_core"] == 2.8e6
-    # the other half of BASELINE.json's metric and the run-to-completion leg (128 photons here: the numbers only have to be there and consistent)
-    assert d["spectrum"]["fixture"] == "tests/golden/c2_tau6.npz" and d["spectrum"]["gpu_photons"] == 128 and d["spectrum_rms_vs_ref"] > 0
-    assert abs(d["spectrum"]["mean_scatterings_gpu"] / d["spectrum"]["mean_scatterings_ref"] - 1.0) < 0.3
+    # the other half of BASELINE.json's metric and the run-to-completion leg (32 photons here: the numbers only have to be there and consistent)
+    assert d["spectrum"]["fixture"] == "tests/golden/c2_tau6.npz" and d["spectrum"]["gpu_photons"] == 32 and d["spectrum_rms_vs_ref"] > 0
+    assert abs(d["spectrum"]["mean_scatterings_gpu"] / d["spectrum"]["mean_scatterings_ref"] - 1.0) < 0.6      # (32 histories: 15 % per sigma)
     rc = d["run_to_completion"]
-    assert rc["photons"] == 128 and rc["events"] > 1e8 and rc["lane_compactions"] >= 0 and abs(rc["value"] - rc["events"] / rc["seconds"]) < 1e-6 * rc["value"]
+    assert rc["photons"] == 32 and rc["events"] > 1e7 and rc["lane_compactions"] >= 0 and abs(rc["value"] - rc["events"] / rc["seconds"]) < 1e-6 * rc["value"]
 
 
 def test_bench_distributed_path_single_rank():
@@ -44,7 +44,7 @@ def test_bench_distributed_path_single_rank():
     assert r.returncode == 0, r.stdout + r.stderr
     d = last_json(r.stdout)
     assert d["n_gpus"] == 1 and d["value"] > 1e8 and d["config"]["tally_reduce_ms"] > 0
-    assert d["run_to_completion"]["photons"] == 128       # the reduce of the completion leg went through the library's RCCL communicator
+    assert d["run_to_completion"]["photons"] == 32       # the reduce of the completion leg went through the library's RCCL communicator
 
 
 def test_bench_refuses_a_rank_count_that_differs_from_gpus():
