@@ -50,11 +50,11 @@ CAR = dict(temperature=10.0, taumax=2e5, nx=5, ny=5, nz=5, rmax=1.0, nxfreq=121)
 # (a device run of a few hundred photons lasts as long as its longest history: ~9 us per scattering, hence the moderate optical depth)
 
 
-@pytest.mark.parametrize("extra,n", [(dict(xyz_symmetry=True, core_skip=True), 350),
-                                     (dict(core_skip=True, use_stokes=True), 200),
+@pytest.mark.parametrize("extra,n", [(dict(xyz_symmetry=True, core_skip=True), 250),
+                                     (dict(core_skip=True, use_stokes=True), 140),
                                      (dict(core_skip=True, recoil=True, velocity_type="hubble", Vexp=20.0), 600),
                                      (dict(xyz_symmetry=True, core_skip_global=True), 1000),
-                                     (dict(core_skip_global=True, use_stokes=True), 700)],
+                                     (dict(core_skip_global=True, use_stokes=True), 500)],
                          ids=["cell", "cell_stokes", "cell_recoil_outflow", "global", "global_stokes"])
 def test_cartesian_core_skip_histories(capi, oracle_mod, extra, n):
     """tau0 = 2e5, T = 10 K on a coarse grid (xcrit > 1 away from the cell faces): photon by photon against the oracle, and the
