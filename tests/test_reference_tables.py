@@ -216,7 +216,7 @@ def test_amr_description_inside_observer_smoke_table():
     fn = os.path.join(tempfile.mkdtemp(), "sphere.dat"); amr.write_generic_amr(fn, amr.make_amr_sphere())
     res = {}
     for name, kw in (("car", dict(nx=64, ny=64, nz=64, iseed=5)), ("amr", dict(use_amr_grid=True, amr_file=fn, iseed=6))):
-        sim = host.Simulation(dict(base, **kw)); sim.run_simulation(300000); o = sim.output_normalize(sim.ctx.tallies())       # (the document ran 1e6: the sums do not depend on it)
+        sim = host.Simulation(dict(base, **kw)); sim.run_simulation(500000); o = sim.output_normalize(sim.ctx.tallies())       # (the document ran 1e6: the sums do not depend on it)
         res[name] = o
         print(name, "sum Jout %.5e  sum Jin %.5e" % (o["Jout"].sum(), o["Jin"].sum()), {k: float(np.sum(v)) for k, v in o.items() if k.startswith(("scatt", "direc"))})
     assert abs(res["car"]["Jout"].sum() / 8.5136e-2 - 1.0) < 2e-4 and abs(res["car"]["Jin"].sum() / 8.5136e-2 - 1.0) < 2e-4
