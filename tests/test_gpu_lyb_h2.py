@@ -212,6 +212,57 @@ def test_h2_histories_photon_by_photon(capi, oracle_mod, h2_data_dir, extra, n):
     assert noh2.ctx.tallies()["Jout"].sum() > t["Jout"].sum() / n * 5000 + 50         # the lines matter
 
 
+@pytest.mark.parametrize("case", ["lyb_peel_profiles", "lyb_outflow_reduced_weight", "lyb_octree_peel", "h2_sphere_peel_dust", "h2_slab", "h2_octree"])
+def test_tallies_equal_the_oracle_on_identical_histories(capi, oracle_mod, h2_data_dir, amr_file, case):
+    """every tally of the two line types bin for bin on batches of photons whose histories are the oracle's: both spectra of either band, the H-alpha peel cube, the
+    conversion profile, the scattered-light cube, the weight budgets -- the comparisons above allow 1-3 %"""
+    H2 = dict(temperature=1e3, taumax=1e3, nxfreq=121, h2_model="neufeld", f_H2=0.3, h2_temperature=3000.0, h2_data_dir=h2_data_dir)
+    if case == "lyb_peel_profiles":
+        kw = dict(LYB, nxim=12, nyim=12, calc_P=True)
+    elif case == "lyb_outflow_reduced_weight":
+        kw = dict(LYB, taumax=1e2, velocity_type="hubble", Vexp=40.0, recoil=True, use_reduced_wgt=True, nxim=12, nyim=12)
+    elif case == "lyb_octree_peel":
+        kw = dict(line_id="ly_beta", use_amr_grid=True, amr_file=amr_file, temperature=1e4, taumax=3e1, rmax=1.0, nxfreq=81, DGR=1.0, cext_dust=1e-15, cext_dust_Ha=5e-16, nxim=12, nyim=12)
+    elif case == "h2_sphere_peel_dust":
+        kw = dict(H2, nx=21, ny=21, nz=21, rmax=1.0, nxim=12, nyim=12, DGR=1.0, cext_dust=1e-19)
+    elif case == "h2_slab":
+        kw = dict(H2, nx=1, ny=1, nz=51, xmax=1.0, ymax=1.0, zmax=1.0, xy_periodic=True)
+    else:
+        kw = dict(H2, use_amr_grid=True, amr_file=amr_file, rmax=1.0, nxim=12, nyim=12)
+    kw["iseed"] = 1
+    sim = make(kw); sim.ctx.enable_photon_log(True)
+    o = oracle_of(oracle_mod, kw)
+    lyb = kw.get("line_id") == "ly_beta"
+    names = ["Jout", "Jin", "Jabs"] + (["Jout_Ha", "Jabs_Ha"] if lyb else []) + (["Pconv", "P1"] if kw.get("calc_P") else [])
+    cubes = (["scatt", "direc"] + (["peel_Ha"] if lyb else [])) if "nxim" in kw else []
+    scal = ["W_conv", "W_esc1", "W_abs1", "W_esc2", "W_abs2"] if lyb else ["W_H2abs", "W_H2scat"]
+    per, nclean, prev, tot = 16, 0, None, 0.0
+    for b in range(40):
+        first = 1 + b * per
+        sim.ctx.run(per, first_id=first, stride=1, seed=99); t = sim.ctx.tallies()
+        ng, xg = sim.ctx.photon_log(per)
+        o.zero(); o.run(per, first_id=first, stride=1, seed=99); no, xo = o.photon_log()
+        cur = {k: np.array(t[k], dtype=float).copy() for k in names + cubes + scal + (["W_H2pump"] if not lyb else [])}
+        dev = {k: (cur[k] - prev[k] if prev is not None else cur[k]) for k in cur}; prev = cur
+        if not (np.all(np.isclose(ng, no, rtol=1e-12, atol=0)) and np.all(np.isclose(xg, xo, rtol=1e-9, atol=1e-12) | (xo == 0.0))):
+            continue
+        nclean += 1
+        for k in names:
+            r = o.array(k).reshape(dev[k].shape, order="F")
+            assert np.allclose(dev[k], r, rtol=1e-9, atol=1e-12 * per), (case, k, b, float(np.abs(dev[k] - r).max()))
+        scale = max(np.abs(o.array("scatt:0")).max(), 1e-300) if cubes else 1.0     # (one scale for all cubes: the direct light of an opaque medium is e^-700, denormal numbers)
+        for k in cubes:
+            r = o.array(k + ":0"); d = dev[k][..., 0].ravel(order="F")
+            assert np.allclose(d, r, rtol=1e-9, atol=1e-9 * scale), (case, k, b, float(np.abs(d - r).max() / scale))
+            tot += np.abs(r).sum() if k != "direc" else 0.0
+        W = o.array("W") if lyb else o.array("W_H2")
+        for i, k in enumerate(scal):
+            assert abs(dev[k] - W[i]) < 1e-9 * per, (case, k, b, float(dev[k]), float(W[i]))
+        if not lyb:
+            assert np.allclose(dev["W_H2pump"], W[2:2 + len(np.atleast_1d(dev["W_H2pump"]))], rtol=1e-9, atol=1e-9 * per)
+    assert nclean >= 8 and (tot > 0 or not cubes), (nclean, tot)
+
+
 def test_ly_beta_and_h2_divergence_audit(capi, oracle_mod, h2_data_dir):
     from test_gpu_divergence import audit
     kw = dict(LYB, taumax=1e2)
