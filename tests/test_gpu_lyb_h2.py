@@ -189,8 +189,8 @@ def test_ly_beta_on_the_octree(capi, oracle_mod, amr_file):
     assert abs(gH.sum() / oH.sum() - 1.0) < 0.01
 
 
-@pytest.mark.parametrize("extra,n", [(dict(nx=1, ny=1, nz=51, xmax=1.0, ymax=1.0, zmax=1.0, xy_periodic=True), 12000),
-                                     (dict(nx=21, ny=21, nz=21, rmax=1.0, nxim=10, nyim=10, DGR=1.0, cext_dust=1e-19), 12000)], ids=["slab", "sphere_peel_dust"])
+@pytest.mark.parametrize("extra,n", [(dict(nx=1, ny=1, nz=51, xmax=1.0, ymax=1.0, zmax=1.0, xy_periodic=True), 7000),
+                                     (dict(nx=21, ny=21, nz=21, rmax=1.0, nxim=10, nyim=10, DGR=1.0, cext_dust=1e-19), 7000)], ids=["slab", "sphere_peel_dust"])
 def test_h2_histories_photon_by_photon(capi, oracle_mod, h2_data_dir, extra, n):
     """Ly-alpha with the H2 lines (Neufeld 1990 slab set-up and a dusty sphere with an observer): histories, the H2 budget of output_sum_rect.f90:470-485"""
     kw = dict(dict(temperature=1e3, taumax=1e4, nxfreq=121, h2_model="neufeld", f_H2=0.3, h2_temperature=3000.0, h2_data_dir=h2_data_dir, iseed=63), **extra)
