@@ -19,12 +19,18 @@ __device__ inline double wave_sum(double v) {
 // registers.  Peel-off no longer marches inside this kernel (it queues a record, peel_kernel.hpp), so it costs no occupancy.
 #ifdef LART_MIN_WAVES
 #define LART_WAVES(S, P) LART_MIN_WAVES
+#define LART_WAVES_V4(V, S, D, P) LART_MIN_WAVES
 #else
 #define LART_WAVES(S, P) ((S) ? 3 : 4)
+// Stokes kernels, per instantiation where it was measured AND run through the device suite (round 3, events/s at 3 -> 4 waves per SIMD): the 1-column slab without
+// dust (C1) 8.63 -> 9.31e9 and the clump medium with dust + peel-off (C4) 7.08 -> 7.37e9 gain from the fourth wave; the plain grid with peel-off (C3) loses
+// (5.93 -> 5.43e9), and the slab kernel with dust squeezed into 128 VGPRs (115 spills) aborted on the device -- every other instantiation stays at 3.
+#define LART_WAVES_V4(V, S, D, P) (!(S) || ((V) == 2 && !(D) && !(P)) || ((V) == 4 && (D) && (P)) ? 4 : 3)
 #endif
 // largest workgroup: the kernels that fit 128 VGPRs may run as ONE 1024-lane workgroup per CU (the same 4 waves per SIMD), which leaves the LDS that four
 // 256-lane workgroups spend on four copies of the tables to the J(x) window of the profile tallies (lart_gpu.hip, tally layout)
 #define LART_MAX_BLOCK(S, P) (LART_WAVES(S, P) >= 4 ? 1024 : 256)
+#define LART_MAX_BLOCK_V(S) (!(S) ? 1024 : 256)
 #ifndef LART_OVL_CELLS_PER_ROUND
 #define LART_OVL_CELLS_PER_ROUND 4           // CSR cells a lane in an overlap march walks per round of its wave
 #endif
@@ -68,7 +74,7 @@ __device__ inline void fly(const KArgs &A, const Lds &l, Rng &g, Photon &p, bool
 
 // LT: line%line_type as a compile-time constant (1 single line, 2 Ly-alpha doublet, 7 hydrogen + deuterium), handed to the device functions through Lds
 template <int VAR, bool STOKES, bool DUST, bool PEEL, int LT>
-__global__ __launch_bounds__(LART_MAX_BLOCK(STOKES, PEEL), LART_WAVES(STOKES, PEEL)) void transport_kernel(KArgs A) {
+__global__ __launch_bounds__(LART_MAX_BLOCK_V(STOKES), LART_WAVES_V4(VAR, STOKES, DUST, PEEL)) void transport_kernel(KArgs A) {
     extern __shared__ double sh[];
     if (A.rep.nrep > 1) {                                      // this block's copy of the contended tally sections (DRep)
         const unsigned r = blockIdx.x % (unsigned)A.rep.nrep;
