@@ -22,10 +22,10 @@ __device__ inline double wave_sum(double v) {
 #define LART_WAVES_V4(V, S, D, P) LART_MIN_WAVES
 #else
 #define LART_WAVES(S, P) ((S) ? 3 : 4)
-// Stokes kernels, per instantiation where it was measured AND run through the device suite (round 3, events/s at 3 -> 4 waves per SIMD): the 1-column slab without
-// dust (C1) 8.63 -> 9.31e9 and the clump medium with dust + peel-off (C4) 7.08 -> 7.37e9 gain from the fourth wave; the plain grid with peel-off (C3) loses
-// (5.93 -> 5.43e9), and the slab kernel with dust squeezed into 128 VGPRs (115 spills) aborted on the device -- every other instantiation stays at 3.
-#define LART_WAVES_V4(V, S, D, P) (!(S) || ((V) == 2 && !(D) && !(P)) || ((V) == 4 && (D) && (P)) ? 4 : 3)
+// Stokes kernels, per instantiation where it was measured AND run through the device suite at full size (round 3, events/s at 3 -> 4 waves per SIMD): the 1-column
+// slab without dust (C1) gains, 8.63 -> 9.31e9; the plain grid with peel-off (C3) loses (5.93 -> 5.43e9); the clump kernel with dust gains 4 % without an observer
+// but was not measured with one (C4 has one); and the slab kernel with dust, squeezed into 128 VGPRs (115 spills), died with a memory fault -- so only C1's.
+#define LART_WAVES_V4(V, S, D, P) (!(S) || ((V) == 2 && !(D) && !(P)) ? 4 : 3)
 #endif
 // largest workgroup: the kernels that fit 128 VGPRs may run as ONE 1024-lane workgroup per CU (the same 4 waves per SIMD), which leaves the LDS that four
 // 256-lane workgroups spend on four copies of the tables to the J(x) window of the profile tallies (lart_gpu.hip, tally layout)
