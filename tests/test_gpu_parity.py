@@ -480,6 +480,7 @@ def test_peel_stokes_vs_oracle(capi, oracle_mod):
     assert np.allclose(t["scatt_2D"][..., 0].sum(), t["scatt"][..., 0].sum(), rtol=0.02)   # out-of-band bins only
 
 
+@pytest.mark.slow      # (statistical; the exact comparisons on identical histories carry the Mueller dust path in the default suite)
 def test_dust_mueller_vs_oracle(capi, oracle_mod, mueller_file):
     kw = dict(temperature=1e4, taumax=1e3, nx=31, ny=31, nz=31, rmax=1.0, nxfreq=81, nxim=8, nyim=8, use_stokes=True, DGR=1.0,
               scatt_mat_file=mueller_file, cext_dust=1.6e-21, iseed=41)
