@@ -158,6 +158,7 @@ CAR = [
     ("quadrant_outflow", dict(temperature=1e4, taumax=3e1, nx=20, ny=14, nz=31, rmax=1.0, xy_symmetry=True, velocity_type="hubble", Vexp=30.0, nxfreq=81), 100000),
     ("periodic_box_recoil", dict(temperature=1e4, taumax=2e1, nx=6, ny=4, nz=21, xmax=0.5, ymax=0.3, zmax=1.0, geometry="rectangle", xy_periodic=True,
                                  recoil=True, nxfreq=81), 100000),
+    ("shearing_box", dict(temperature=1e4, taumax=2e1, nx=6, ny=4, nz=21, xmax=0.5, ymax=0.3, zmax=1.0, geometry="rectangle", xy_periodic=True, Omega=2.5, nxfreq=81), 100000),
     ("dust_hg_reduced_weight", dict(temperature=1e4, taumax=1e2, nx=21, ny=21, nz=21, rmax=1.0, nxfreq=81, DGR=1.0, cext_dust=2e-19, use_reduced_wgt=True), 100000),
     ("fine_structure_stokes", dict(temperature=3e1, taumax=3e1, xyz_symmetry=True, nx=21, ny=21, nz=21, rmax=1.0, nxfreq=121, fine_structure=True, use_stokes=True,
                                    velocity_type="hubble", Vexp=5.0), 100000),
