@@ -132,7 +132,9 @@ def main():
     reduce_ms = (time.perf_counter() - t_r0) * 1e3
     _, ntally = sim.ctx.tally_buffer()
 
-    others = other_configs(local, a.events_per_step) if (rank == 0 and world == 1 and not a.no_other_configs) else None
+    # BASELINE.json configs[2] (sphere_peel, the designated 1 -> 8 GPU workload) runs on every rank of an N-GPU job too: rank r takes the ids r+1, r+1+N, ...
+    # of the 1e8-photon job; configs[4] (octree) only at N = 1
+    others = other_configs(local, a.events_per_step, rank, world, dist if use_dist else None, barrier) if not a.no_other_configs else None
     completion = run_to_completion(sim, a, rank, world, dist if use_dist else None, barrier) if a.completion_photons > 0 else None
 
     if rank == 0:
@@ -166,7 +168,10 @@ def main():
             out["run_to_completion"] = completion
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_photons)
-            out["cpu_baseline"]["reference_events_per_s_per_core"] = 2.8e6   # the reference's own Fortran, 1 core, this workload
+            ref_core = 2.8e6                                                  # the reference's own Fortran, 1 core, this workload (measured where /root/reference is mounted)
+            out["cpu_baseline"]["reference_events_per_s_per_core"] = ref_core
+            out["cpu_baseline"]["port_vs_reference_per_core"] = out["cpu_baseline"]["value"] / out["cpu_baseline"]["cores"] / ref_core
+            out["cpu_baseline"]["note"] = "kind 'port': the builder's C restatement, faster per core than the reference's Fortran by the factor port_vs_reference_per_core; a GPU / cpu_baseline ratio is not GPU vs reference"
         print(json.dumps(out))
     if use_dist:
         dist.barrier()
@@ -239,12 +244,31 @@ def pmc_traffic(events_per_step):
     return None, None
 
 
-def other_configs(device, events):
+def config_traffic(tag):
+    """HBM bytes per launch of the transport kernel of one of the other configurations, from the committed rocprofv3 PMC passes of `tools/perf_kernel.py --config TAG`
+    (newest profiles/r*_TAG_pmc_summary.json; 2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes, as pmc_traffic)"""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_pmc_summary.json" % tag)), reverse=True):
+        try:
+            d = json.load(open(f))
+            if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+                return (2.0 * d["FETCH_SIZE"]["mean_per_launch"] + d["WRITE_SIZE"]["mean_per_launch"]) * 1024.0, "profiles/" + os.path.basename(f)
+        except Exception:
+            pass
+    return None, None
+
+
+def other_configs(device, events, rank=0, world=1, dist=None, barrier=None):
     """short steady-state legs of the two other GPU configurations of BASELINE.json that fit one device: configs[2] (C3: sphere_peel/t1tau6.in, 201^3, Stokes,
     129 x 129 x 201 peel cube) and configs[4] (C5: the 178 480-leaf octree with calc_J + calc_P + calc_Pnew).  3 warm-up steps (the pool has to reach its
     steady mix of packet ages), 3 timed steps of `events` scattering events per lane; each with the roofline of SURVEY section 8(d): 48 B per cell visited by a
-    flight or a peel ray + 16 B per tally atomic, over the average launch time from HIP events on the launch stream.  Not part of `value`."""
+    flight or a peel ray + 16 B per tally atomic, over the average launch time from HIP events on the launch stream.  Not part of `value`.
+
+    With N > 1 ranks the C3 leg is BASELINE.json configs[2] as written -- ONE 1e8-photon job split over the GPUs (rank r: ids r+1, r+1+N, ...; run_simulation_mod.f90:150-151),
+    timed between barriers, max over ranks, followed by the job's one exchange step: the library's ncclReduce of the fused buffer with the 129 x 129 x 201 cubes
+    (output_sum_rect.f90:107-127), timed on its second call."""
     import tempfile
+    import torch
     from lart_amd import host, amr
     out = {}
     tmp = tempfile.mkdtemp()
@@ -254,28 +278,47 @@ def other_configs(device, events):
         "c5_octree_JP": dict(use_amr_grid=True, amr_file=afile, temperature=1e4, taumax=1e4, rmax=1.0, nxfreq=121, nxim=100, nyim=100, calc_J=True, calc_P=True, calc_Pnew=True,
                              no_photons=1e8, iseed=1),
     }
+    tags = {"c3_sphere_peel_tau6": "c3", "c5_octree_JP": "c5obs"}
     for name, kw in cfgs.items():
+        if world > 1 and name != "c3_sphere_peel_tau6":
+            continue
         if kw.get("use_amr_grid"):
             amr.write_generic_amr(afile, amr.make_amr_sphere())
         sim = host.Simulation(dict(kw), device=device)
-        sim.ctx.begin(int(kw["no_photons"]), seed=1)
+        nph = int(kw["no_photons"])
+        sim.ctx.begin((nph - rank - 1) // world + 1, first_id=rank + 1, stride=world, seed=1)
         for _ in range(3):
             sim.ctx.step(1, events)
         sim.ctx.sync()
-        t0 = sim.ctx.tallies(); ms0, nl0 = sim.ctx.kernel_time(); w0 = time.perf_counter()
+        t0 = sim.ctx.tallies(); ms0, nl0 = sim.ctx.kernel_time()
+        if barrier:
+            barrier()
+        w0 = time.perf_counter()
         sim.ctx.step(3, events); sim.ctx.sync()
+        if barrier:
+            barrier()
         dt = time.perf_counter() - w0; t1 = sim.ctx.tallies(); ms1, nl1 = sim.ctx.kernel_time()
         d = lambda k: t1[k] - t0[k]
+        ev_all = d("n_events"); reduce_ms = None; ntally = sim.ctx.tally_buffer()[1]
+        if dist is not None:
+            tot = torch.tensor([ev_all, dt], dtype=torch.float64, device="cuda")
+            mx = tot.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX); dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+            ev_all, dt = float(tot[0]), float(mx[1])
+            sim.output_reduce(dist)                              # creates the communicator of this context; the second call is the exchange step alone
+            barrier(); r0 = time.perf_counter(); sim.output_reduce(dist); barrier()
+            reduce_ms = (time.perf_counter() - r0) * 1e3
         nl = max(nl1 - nl0, 1); k_ms = (ms1 - ms0) / nl
         by = (48.0 * (d("n_cellsteps") + d("n_cellsteps_peel")) + 16.0 * d("n_atomics")) / nl
         ach = by / (k_ms * 1e-3) / 1e9
-        out[name] = {"value": d("n_events") / dt, "unit": "events/s", "steps": 3, "events_per_step_per_lane": events, "lanes": sim.ctx.pool_info()[0],
+        traffic, traffic_src = config_traffic(tags[name])
+        out[name] = {"value": ev_all / dt, "unit": "events/s", "n_gpus": world, "scaling": "strong" if world > 1 else None, "steps": 3, "events_per_step_per_lane": events,
+                     "lanes": sim.ctx.pool_info()[0],
                      "cells_per_event": d("n_cellsteps") / max(d("n_events"), 1), "peel_cells_per_event": d("n_cellsteps_peel") / max(d("n_events"), 1),
-                     "atomics_per_event": d("n_atomics") / max(d("n_events"), 1),
-                     "roofline": {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None, "avg_launch_ms": k_ms,
-                                  "algorithmic_bytes_per_launch": by}}
+                     "atomics_per_event": d("n_atomics") / max(d("n_events"), 1), "tally_doubles": ntally, "tally_reduce_ms": reduce_ms,
+                     "roofline": {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
+                                  "avg_launch_ms": k_ms, "algorithmic_bytes_per_launch": by}}
         sim.ctx.close()
-    return out
+    return out if rank == 0 else None
 
 
 def host_cores():

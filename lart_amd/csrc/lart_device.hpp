@@ -180,6 +180,7 @@ struct Lds { const double *vt; const double *xf, *yf, *zf;   // Voigt tables and
              double *jp_P, *jp_Pn;       // per-block LDS copies of P1 / P1_new (nullptr: deposits go to global memory)
              double *jp_J; int j_lo, j_w; // per-block LDS copy of the line-centre window of J1: [j_w][nbins] (nullptr: off)
              unsigned *pq_cnt;           // this wave's record counter of the peel queue (LDS word), nullptr = no peel-off
+             double fov_bx, fov_by;      // peel prefilter: tan of the half field of view (+ margin) in x and y, < 0 = no field-of-view test (lds_set_fov)
              unsigned char *coop;        // LART_COOP_BYTES per wave: scratch of the cooperative samplers (vz_core_coop / vz_wing_coop), nullptr = off
              int lt; double dnu_hz;      // line type (1 single line, 2 Ly-alpha doublet, 7 H + D) and DnuHK_Hz / delta_nu_HD_Hz: set from the kernel's template
              int ml_nup, ml_coh; double ml_dE[3], ml_damp[3], ml_f12[3]; const double *ml_tab; const int *ml_itab;   // lt 4 = the multiplets (line types 4, 5, 6): DMulti
@@ -192,7 +193,7 @@ __device__ inline Lds lds_stage(double *sh, const DGrid &g) {
     for (int i = threadIdx.x; i < nf; i += blockDim.x) sh[VT_END + i] = g.faces[i];
     __syncthreads();
     Lds l; l.vt = sh; l.xf = sh + VT_END; l.yf = l.xf + (g.nx + 1); l.zf = l.yf + (g.ny + 1);
-    l.dip_p2 = 0.0; l.dip_qs = 0.0; l.jp_P = nullptr; l.jp_Pn = nullptr; l.jp_J = nullptr; l.j_lo = 0; l.j_w = 0; l.coop = nullptr; l.pq_cnt = nullptr; l.lt = 1; l.dnu_hz = 0.0; l.hd_ratio = 1.0; l.hd_ratio_a = 1.0; l.hd_nD = 0.0; l.ml_nup = 1; l.ml_coh = 0; l.ml_tab = nullptr; l.ml_itab = nullptr;
+    l.dip_p2 = 0.0; l.dip_qs = 0.0; l.jp_P = nullptr; l.jp_Pn = nullptr; l.jp_J = nullptr; l.j_lo = 0; l.j_w = 0; l.coop = nullptr; l.pq_cnt = nullptr; l.fov_bx = -1.0; l.fov_by = -1.0; l.lt = 1; l.dnu_hz = 0.0; l.hd_ratio = 1.0; l.hd_ratio_a = 1.0; l.hd_nD = 0.0; l.ml_nup = 1; l.ml_coh = 0; l.ml_tab = nullptr; l.ml_itab = nullptr;
     for (int i = 0; i < 3; i++) { l.ml_dE[i] = 0.0; l.ml_damp[i] = 1.0; l.ml_f12[i] = 0.0; }
     return l;
 }
@@ -234,8 +235,26 @@ __device__ inline void mulhilo32(uint32_t k, uint32_t v, uint32_t &hi, uint32_t 
 #ifndef LART_RNG_BUF
 #define LART_RNG_BUF 16
 #endif
-#ifndef LART_RNG_TOPUP
-#define LART_RNG_TOPUP 5         // blocks evaluated per event round (tools/gpu_ab*.sh sweeps)
+// blocks per fill point of the event loop (Rng::fill): before the flight / between the vz sampler and scatter_post; by kernel family (tools/gpu_job.sh perflib sweeps,
+// profiles/r04_rng_fill.md).  LART_RNG_TOPUP is the round-1 name of the single fill and still sets the top fill of a build that defines it.
+#ifdef LART_RNG_TOPUP
+#define LART_FILL_TOP(S) LART_RNG_TOPUP
+#define LART_FILL_MID(S) 0
+#else
+#ifndef LART_FILL_TOP_S
+#define LART_FILL_TOP_S 4
+#endif
+#ifndef LART_FILL_MID_S
+#define LART_FILL_MID_S 4
+#endif
+#ifndef LART_FILL_TOP_N
+#define LART_FILL_TOP_N 2
+#endif
+#ifndef LART_FILL_MID_N
+#define LART_FILL_MID_N 3
+#endif
+#define LART_FILL_TOP(S) ((S) ? LART_FILL_TOP_S : LART_FILL_TOP_N)
+#define LART_FILL_MID(S) ((S) ? LART_FILL_MID_S : LART_FILL_MID_N)
 #endif
 #ifndef LART_PHILOX_ROUNDS
 #define LART_PHILOX_ROUNDS 10      // Philox4x32-10 (the KAT-pinned default of Salmon et al. 2011); tuning builds only change this to measure
@@ -249,6 +268,12 @@ struct Rng {
     // ring of LART_RNG_BUF (= 16) draws in LDS: draw i of the packet lives in slot i & 15 of this lane's column;
     // `have` draws are buffered ahead of n (n + have is even while have > 0); have == 0: slow path until the next prefill()
     double *lbuf = nullptr; uint32_t stride = 0, have = 0;
+#ifdef LART_RNG_STATS                                       // tuning builds: single-block evaluations off the ring (per lane) and how often the WAVE takes that detour
+    uint32_t nslow = 0, nslow_w = 0;
+#define LART_RNG_SLOW() do { nslow++; if ((int)__lane_id() == __ffsll((long long)__ballot(1)) - 1) nslow_w++; } while (0)
+#else
+#define LART_RNG_SLOW() do { } while (0)
+#endif
     __device__ inline void init(uint64_t seed, uint64_t pid, uint64_t n0) {
         k0 = (uint32_t)seed; k1 = (uint32_t)(seed >> 32); id = pid; n = n0 & ~1ULL; spare = 0.0;
         have = 0;
@@ -290,85 +315,59 @@ struct Rng {
     __device__ inline void store2(uint32_t slot, bool on, const Ctr &c) {
         if (on) { lbuf[(slot & (LART_RNG_BUF - 1)) * stride] = open01(c.c0, c.c1); lbuf[((slot + 1) & (LART_RNG_BUF - 1)) * stride] = open01(c.c2, c.c3); }
     }
-    // Top the ring up with LART_RNG_TOPUP blocks (2 draws each) behind the draws still buffered; call with the whole wave
-    // converged.  Every lane evaluates the same number of blocks; a lane whose ring is nearly full stores only what fits
-    // (those counters are simply produced again later).  An event consumes ~8 draws on average, so 5 blocks per round keep
-    // the ring filling while a lane that needs many tries draws the reserve down before it falls back to single blocks.
+    // Top the ring up with K blocks (2 draws each) behind the draws still buffered.  Every lane evaluates the same number of blocks; a lane whose
+    // ring is nearly full stores only what fits (those counters are simply produced again later).  The event loop fills twice per round (round 4):
+    // LART_FILL_TOP blocks before the flight (tau draw, vz sampler) and LART_FILL_MID blocks between the vz sampler and scatter_post (polar angle,
+    // azimuth, perpendicular velocity).  One fill of 5 blocks per round, the round-1 scheme, leaves a lane whose packet sits in the line wing with
+    // a Stokes vector (11-12 draws per event) with a dry ring on EVERY round of the excursion: it then evaluates single blocks inside the divergent
+    // code, ~100 instructions at a handful of lanes each time -- counted with -DLART_RNG_STATS: 10.4 such detours per wave-round in the Stokes
+    // kernels, 1.5 in the headline kernel (profiles/r04_rng_fill.md).
+    template <int K>
     __device__ inline void prefill() {
         static_assert(LART_RNG_BUF == 16, "the ring indexes draws by i & 15");
-        static_assert(LART_RNG_TOPUP >= 3 && LART_RNG_TOPUP <= 8, "LART_RNG_TOPUP must be 3..8 blocks");
+        static_assert(K >= 1 && K <= 8, "1..8 blocks per fill");
         uint64_t e = have ? n + have : (n & ~1ULL);          // first draw not buffered (even); nothing buffered: restart on draw n's block
         uint32_t used = (uint32_t)(e - (n & ~1ULL)), freeb = (LART_RNG_BUF - used) >> 1, slot = (uint32_t)e;
         uint64_t b0 = e >> 1;
-        Ctr q0 = ctr_of(b0), q1 = ctr_of(b0 + 1), q2 = ctr_of(b0 + 2);
-#if LART_RNG_TOPUP >= 4
-        Ctr q3 = ctr_of(b0 + 3);
-#endif
-#if LART_RNG_TOPUP >= 5
-        Ctr q4 = ctr_of(b0 + 4);
-#endif
-#if LART_RNG_TOPUP >= 6
-        Ctr q5 = ctr_of(b0 + 5);
-#endif
-#if LART_RNG_TOPUP >= 7
-        Ctr q6 = ctr_of(b0 + 6);
-#endif
-#if LART_RNG_TOPUP >= 8
-        Ctr q7 = ctr_of(b0 + 7);
-#endif
+        Ctr q0 = ctr_of(b0), q1 = ctr_of(b0 + 1), q2 = ctr_of(b0 + 2), q3 = ctr_of(b0 + 3), q4 = ctr_of(b0 + 4), q5 = ctr_of(b0 + 5), q6 = ctr_of(b0 + 6), q7 = ctr_of(b0 + 7);
         uint32_t a = k0, b = k1;
 #pragma unroll 1
         for (int r = 0; r < LART_PHILOX_ROUNDS; r++) {
-            round1(q0, a, b); round1(q1, a, b); round1(q2, a, b);
-#if LART_RNG_TOPUP >= 4
-            round1(q3, a, b);
-#endif
-#if LART_RNG_TOPUP >= 5
-            round1(q4, a, b);
-#endif
-#if LART_RNG_TOPUP >= 6
-            round1(q5, a, b);
-#endif
-#if LART_RNG_TOPUP >= 7
-            round1(q6, a, b);
-#endif
-#if LART_RNG_TOPUP >= 8
-            round1(q7, a, b);
-#endif
+            round1(q0, a, b);
+            if (K >= 2) round1(q1, a, b);
+            if (K >= 3) round1(q2, a, b);
+            if (K >= 4) round1(q3, a, b);
+            if (K >= 5) round1(q4, a, b);
+            if (K >= 6) round1(q5, a, b);
+            if (K >= 7) round1(q6, a, b);
+            if (K >= 8) round1(q7, a, b);
             a += 0x9E3779B9u; b += 0xBB67AE85u;
         }
-        store2(slot, freeb > 0, q0); store2(slot + 2, freeb > 1, q1); store2(slot + 4, freeb > 2, q2);
-#if LART_RNG_TOPUP >= 4
-        store2(slot + 6, freeb > 3, q3);
-#endif
-#if LART_RNG_TOPUP >= 5
-        store2(slot + 8, freeb > 4, q4);
-#endif
-#if LART_RNG_TOPUP >= 6
-        store2(slot + 10, freeb > 5, q5);
-#endif
-#if LART_RNG_TOPUP >= 7
-        store2(slot + 12, freeb > 6, q6);
-#endif
-#if LART_RNG_TOPUP >= 8
-        store2(slot + 14, freeb > 7, q7);
-#endif
-        uint32_t stored = freeb < LART_RNG_TOPUP ? freeb : LART_RNG_TOPUP;
+        store2(slot, freeb > 0, q0);
+        if (K >= 2) store2(slot + 2, freeb > 1, q1);
+        if (K >= 3) store2(slot + 4, freeb > 2, q2);
+        if (K >= 4) store2(slot + 6, freeb > 3, q3);
+        if (K >= 5) store2(slot + 8, freeb > 4, q4);
+        if (K >= 6) store2(slot + 10, freeb > 5, q5);
+        if (K >= 7) store2(slot + 12, freeb > 6, q6);
+        if (K >= 8) store2(slot + 14, freeb > 7, q7);
+        uint32_t stored = freeb < (uint32_t)K ? freeb : (uint32_t)K;
         have = (uint32_t)(e + 2 * stored - n);
     }
-    // The same top-up for a wave that holds few packets (the drain phase: DESIGN.md 3.4).  With at most 64 / LART_RNG_TOPUP packet lanes in the wave,
-    // lane j evaluates block (j mod TOPUP) of the (j div TOPUP)-th packet lane and stores it into that lane's ring: one block per lane instead of
-    // TOPUP blocks per packet lane, i.e. a fifth of the latency on a wave that has its SIMD to itself (the generator is 39 % of a lone packet's event:
-    // profiles/r03_lone_wave_sections.txt).  Same counters, same slots, same draws as prefill().  Call with the whole wave; `act` = this lane holds a packet.
+    // The same top-up for a wave that holds few packets (the drain phase: DESIGN.md 3.4).  With at most 64 / K packet lanes in the wave,
+    // lane j evaluates block (j mod K) of the (j div K)-th packet lane and stores it into that lane's ring: one block per lane instead of
+    // K blocks per packet lane, i.e. a fraction of the latency on a wave that has its SIMD to itself (the generator is 39 % of a lone packet's event:
+    // profiles/r03_lone_wave_sections.txt).  Same counters, same slots, same draws as prefill<K>().  Call with the whole wave; `act` = this lane holds a packet.
+    template <int K>
     __device__ inline void prefill_sparse(bool act, unsigned long long mask) {
         const int lane = threadIdx.x & 63;
         unsigned long long e = 0; uint32_t freeb = 0;
         if (act) { e = have ? n + have : (n & ~1ULL); const uint32_t used = (uint32_t)(e - (n & ~1ULL)); freeb = (LART_RNG_BUF - used) >> 1; }
-        const int t = lane / LART_RNG_TOPUP, b = lane - t * LART_RNG_TOPUP;
+        const int t = lane / K, b = lane - t * K;
         unsigned long long mk = mask;
 #pragma unroll
-        for (int q = 0; q < 64 / LART_RNG_TOPUP; q++) if (q < t) mk &= mk - 1;       // drop the t lowest packet lanes: the lowest one left is this helper's target
-        const bool work = mk != 0 && t < 64 / LART_RNG_TOPUP;
+        for (int q = 0; q < 64 / K; q++) if (q < t) mk &= mk - 1;       // drop the t lowest packet lanes: the lowest one left is this helper's target
+        const bool work = mk != 0 && t < 64 / K;
         const int src = work ? __ffsll((long long)mk) - 1 : lane;
         const unsigned long long sid = __shfl((unsigned long long)id, src, 64), se = __shfl(e, src, 64);
         const uint32_t sfree = __shfl(freeb, src, 64);
@@ -388,12 +387,22 @@ struct Rng {
             col[(slot & (LART_RNG_BUF - 1)) * stride] = open01(c0, c1); col[((slot + 1) & (LART_RNG_BUF - 1)) * stride] = open01(c2, c3);
         }
         LART_WAVE_SYNC();
-        if (act) { const uint32_t stored = freeb < LART_RNG_TOPUP ? freeb : LART_RNG_TOPUP; have = (uint32_t)(e + 2 * stored - n); }
+        if (act) { const uint32_t stored = freeb < (uint32_t)K ? freeb : (uint32_t)K; have = (uint32_t)(e + 2 * stored - n); }
+    }
+    // one fill point of the event loop, called by the whole wave: `act` = this lane holds a packet that draws from its ring in the stage that follows
+    template <int K>
+    __device__ inline void fill(bool act) {
+        if (K <= 0 || lbuf == nullptr) return;                // (the single-event probes of the parity tests run without a ring: every draw is a single block there)
+        const unsigned long long am = __ballot(act);
+        if (!am) return;
+        if (__popcll(am) * (K > 0 ? K : 1) <= 64) prefill_sparse<(K > 0 ? K : 1)>(act, am);
+        else if (act) prefill<(K > 0 ? K : 1)>();
     }
     __device__ inline double next() {
         if (have) { double v = lbuf[((uint32_t)n & (LART_RNG_BUF - 1)) * stride]; n++; have--; return v; }
         uint64_t m = n++;
         if (m & 1ULL) return spare;
+        LART_RNG_SLOW();
         double first; block(m >> 1, first, spare);
         return first;
     }
@@ -405,6 +414,7 @@ struct Rng {
         }
         bool odd = n & 1ULL;                                  // one buffered draw left <=> n odd (n + have is even)
         double prev = have ? lbuf[((uint32_t)n & (LART_RNG_BUF - 1)) * stride] : spare, first, second;
+        LART_RNG_SLOW();
         block((n + 1) >> 1, first, second);
         if (odd) { u1 = prev; u2 = first; spare = second; } else { u1 = first; u2 = second; }
         have = 0; n += 2;
@@ -478,7 +488,7 @@ struct Photon {
     double shear;                  // photon%vfy_shear (define.f90:100): y velocity picked up at the shearing x boundary, in thermal units (VAR 8)
     double xfreq_ref;
 #ifdef LART_PROFILE
-    long long pt[12], plast;       // tuning builds only: wave clocks per code section (prof_mark)
+    long long pt[16], plast;       // tuning builds only: wave clocks per code section (prof_mark)
     unsigned pc[4];                // wave-level trip counts
 #endif
 };
@@ -2066,34 +2076,75 @@ __device__ __forceinline__ bool peel_ray_begin(const KArgs &A, int kind, const P
 // tau_1 = kappa * min_i(d_i / |k_i|) >= 745.2  <=>  kappa * d_i >= 745.2 |k_i| on the three axes (d_i = distance to the face the ray
 // moves towards).  Any other case -- an observer inside the medium, a start in the vacuum between clumps, the direct light of a
 // birth -- is queued and decided by the march itself.
+// the field-of-view bounds of peel_dir0 (tan of the half image size + 1e-6, its polynomial upper bound below 0.7 rad), once per kernel
+__device__ inline void lds_set_fov(Lds &l, const KArgs &A) {
+    if (A.heal_nside > 0) return;
+    const double hx = 0.5 * A.nxim * A.dxim * (1.0 / LART_RAD2DEG), hy = 0.5 * A.nyim * A.dyim * (1.0 / LART_RAD2DEG);
+    if (!(hx < 1.5 && hy < 1.5)) return;
+    const double mx = hx + 1e-6, my = hy + 1e-6;
+    double bx = mx * (1.0 + mx * mx * (1.0 / 3.0 + mx * mx * (2.0 / 15.0 + mx * mx))), by = my * (1.0 + my * my * (1.0 / 3.0 + my * my * (2.0 / 15.0 + my * my)));
+    if (mx > 0.7) bx = tan(mx); if (my > 0.7) by = tan(my);
+    l.fov_bx = uniform_f64(bx); l.fov_by = uniform_f64(by);
+}
+// 1 / sqrt(x) to rounding level without the division sequence: the hardware estimate and two Newton steps (the prefilter below only)
+__device__ inline double rsqrt_nr(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * fma(-0.5 * x * y, y, 1.5);
+    return y * fma(-0.5 * x * y, y, 1.5);
+}
 template <int VAR, bool STOKES>
 __device__ __forceinline__ bool peel_all_opaque(const KArgs &A, const Lds &l, int kind, const Photon &p, double xa, double ux, double uy, double uz, double grec, bool dust) {
     if (kind == PEEL_DIRECT || A.heal_nside > 0 || VAR == 1) return false;
     if (VAR == 7) return false;                              // the ray may cross any number of clumps from its first metre on
     if (VAR == 4 && p.icl <= 0) return false;
     if (VAR != 3 && VAR != 4 && (p.ic < 1 || p.ic > A.g.nx || p.jc < 1 || p.jc > A.g.ny || p.kc < 1 || p.kc > A.g.nz)) return false;
-    Photon pp = p; pp.xfreq = xa;
+    // Round 4: the test no longer runs the head of the peel routine (peel_ray_begin: two square roots, seven divisions, the polynomial of the field-of-view
+    // bound -- 20 % of the C3 transport kernel's time, profiles/r04_sections.md) but a division-free form of the same quantities.  It only has to be
+    // CONSERVATIVE -- a record that is queued needlessly is marched and found opaque by the peel kernel, which computes everything as the reference does --
+    // so the threshold carries a margin of 1e-9 (the forms differ from the head's by a few ulp; a ray this close to 745.2 would deposit exp(-745.2) ~ 5e-324
+    // of its weight): nothing that the exact test would queue is dropped here.
+    //   direction q = (o - r) / |o - r| by a Newton-refined reciprocal square root;
+    //   frequency along q: x_atom + u_x cos(phi) sin(theta) + u_y sin(phi) sin(theta) + u_z cos(theta) with cos(phi) sin(theta) = q.m, sin(phi) sin(theta) = q.n,
+    //   cos(theta) = q.k in the Stokes frame (stokes_geom), and the corresponding projections on the frame of peel_head_res_nostokes otherwise.
+    const double T = LART_TAU_HUGE * (1.0 + 1e-9);
+    const Cell &c = A.g.cell[(VAR == 3 || is_clump(VAR)) ? (size_t)(p.ic - 1) : cidx(A.g, p.ic, p.jc, p.kc)];
     for (int i = 0; i < A.nobs; i++) {
-        PeelDir q; double xf; bool rd;
-        if (!peel_ray_begin<VAR, STOKES>(A, kind, pp, ux, uy, uz, grec, A.obs[i], dust, q, xf, rd)) continue;      // outside the image: no deposit either
-        const double T = LART_TAU_HUGE;
+        const DObs &o = A.obs[i];
+        double qx = o.x - p.x, qy = o.y - p.y, qz = o.z - p.z;
+        const double rinv = rsqrt_nr(qx * qx + qy * qy + qz * qz);
+        qx = qx * rinv; qy = qy * rinv; qz = qz * rinv;
+        if (l.fov_bx > 0.0) {                                // clearly outside the image: no march, no deposit (as peel_dir0, with the margin on the other side)
+            const double kx = o.rm[0] * qx + o.rm[1] * qy + o.rm[2] * qz, ky = o.rm[3] * qx + o.rm[4] * qy + o.rm[5] * qz, kz = o.rm[6] * qx + o.rm[7] * qy + o.rm[8] * qz;
+            if (kz > 0.0 && (fabs(kx) > l.fov_bx * kz * (1.0 + 3e-9) || fabs(ky) > l.fov_by * kz * (1.0 + 3e-9))) continue;
+        }
+        double xf = xa; bool rd = dust;
+        if (kind == PEEL_DUST) rd = true;
+        else {
+            const double cost = p.kx * qx + p.ky * qy + p.kz * qz;
+            if (STOKES) xf = xa + ux * (qx * p.mx + qy * p.my + qz * p.mz) + uy * (qx * p.nx + qy * p.ny + qz * p.nz) + uz * cost;
+            else {
+                const double s2 = 1.0 - p.kz * p.kz;
+                if (!(s2 > 1e-12)) return false;             // (k along z: the head's special case decides)
+                xf = xa + (ux * (cost * p.kz - qz) + uy * (p.kx * qy - qx * p.ky)) * rsqrt_nr(s2) + uz * cost;
+            }
+            if (A.par.recoil) xf = xf - (grec / c.Dfreq) * (1.0 - cost);
+        }
         if (VAR == 4) {
             const ClumpPhys ph = A.cl.phys[p.icl - 1];
-            if (!(kappa_clump(A, l, rd, xf, ph) * clump_exit_dist(A.cl.geo[p.icl - 1], p.x, p.y, p.z, q.kx, q.ky, q.kz) >= T)) return false;
+            if (!(kappa_clump(A, l, rd, xf, ph) * clump_exit_dist(A.cl.geo[p.icl - 1], p.x, p.y, p.z, qx, qy, qz) >= T)) return false;
             continue;
         }
-        const Cell &c = A.g.cell[(VAR == 3) ? (size_t)(p.ic - 1) : cidx(A.g, p.ic, p.jc, p.kc)];
         double kap = c.rhokap * calc_voigt(l, xf, c.voigt_a, c.Dfreq);
         if (rd) kap = kap + c.rhokapD;
         double dx, dy, dz;
         if (VAR == 3) {
             const AmrGeom g = A.amr.geom[A.amr.icell_of_leaf[p.ic - 1] - 1];
-            dx = q.kx > 0.0 ? (g.cx + g.ch) - p.x : p.x - (g.cx - g.ch); dy = q.ky > 0.0 ? (g.cy + g.ch) - p.y : p.y - (g.cy - g.ch); dz = q.kz > 0.0 ? (g.cz + g.ch) - p.z : p.z - (g.cz - g.ch);
+            dx = qx > 0.0 ? (g.cx + g.ch) - p.x : p.x - (g.cx - g.ch); dy = qy > 0.0 ? (g.cy + g.ch) - p.y : p.y - (g.cy - g.ch); dz = qz > 0.0 ? (g.cz + g.ch) - p.z : p.z - (g.cz - g.ch);
         } else {
-            dx = q.kx > 0.0 ? l.xf[p.ic] - p.x : p.x - l.xf[p.ic - 1]; dy = q.ky > 0.0 ? l.yf[p.jc] - p.y : p.y - l.yf[p.jc - 1]; dz = q.kz > 0.0 ? l.zf[p.kc] - p.z : p.z - l.zf[p.kc - 1];
+            dx = qx > 0.0 ? l.xf[p.ic] - p.x : p.x - l.xf[p.ic - 1]; dy = qy > 0.0 ? l.yf[p.jc] - p.y : p.y - l.yf[p.jc - 1]; dz = qz > 0.0 ? l.zf[p.kc] - p.z : p.z - l.zf[p.kc - 1];
         }
-        bool opaque = kap * dz >= T * fabs(q.kz);
-        if (VAR != 2) opaque = opaque && kap * dx >= T * fabs(q.kx) && kap * dy >= T * fabs(q.ky);
+        bool opaque = kap * dz >= T * fabs(qz);
+        if (VAR != 2) opaque = opaque && kap * dx >= T * fabs(qx) && kap * dy >= T * fabs(qy);
         if (!opaque) return false;
     }
     return true;
@@ -2444,7 +2495,9 @@ __device__ __forceinline__ void scatter_post(const KArgs &A, const Lds &l, Rng &
         cost = (l.lt == 2 || l.lt == 4) ? rand_resonance_u(g.next(), E1) : dipole_cost(l, g.next(), E1); cost2 = cost * cost; sint = sqrt(1.0 - cost2);
         S22 = 0.75 * E1 * (cost2 + 1.0); S11 = S22 + E2; S12 = 0.75 * E1 * (cost2 - 1.0); S33 = 1.5 * E1 * cost;
         S44 = (l.lt == 2) ? (E1 + 2.0) / 2.0 * cost : 1.5 * E3 * cost;
+        LART_PROF_MARK(p, 12);
         phi_rejection(g, p, S12 / S11, sinp, cosp);
+        LART_PROF_MARK(p, 13);
     } else {
         double ud, up; g.next2(ud, up);                       // polar angle, then azimuth: the reference's order of draws
         cost = (l.lt == 2 || l.lt == 4) ? rand_resonance_u(ud, E1) : dipole_cost(l, ud, E1); cost2 = cost * cost; sint = sqrt(1.0 - cost2);
@@ -2463,13 +2516,16 @@ __device__ __forceinline__ void scatter_post(const KArgs &A, const Lds &l, Rng &
         double u2, u3; g.next2(u2, u3); double uxy = sqrt(-d_log(u3)), s2, c2; d_sincos_2pi(u2, &s2, &c2);
         ux = uxy * c2; uy = uxy * s2;
     }
+    LART_PROF_MARK(p, 14);
     if (deut) { ux = ux / l.hd_ratio; uy = uy / l.hd_ratio; }  // scattering_car.f90:402-409, 417-424
     if (is_clump(VAR)) { double vth_ratio = sc.cl_Dfreq / A.cl.Dfreq_ref; ux = ux * vth_ratio; uy = uy * vth_ratio; }   // scattering_car.f90:384-388, 715-719
     p.xfreq = xfreq_atom + uz * cost + (ux * cosp + uy * sinp) * sint;
     const double g_rec0 = deut ? par.g_recoil0_D : par.g_recoil0;      // :427-437
     if (par.recoil && !converted) p.xfreq = p.xfreq - (g_rec0 / sc.cl_Dfreq) * (1.0 - cost);      // (no recoil on the conversion channel: :768-770)
     if (STOKES) {
+        LART_PROF_MARK(p, 6);
         if (PEEL) peel_emit<VAR, STOKES>(A, l, DUST, PEEL_RESONANCE, p, xfreq_atom, ux, uy, uz, E1, E2, E3, g_rec0, npeel);   // peeling_resonance_stokes_outside, deferred
+        LART_PROF_MARK(p, 15);
         double cos2p = 2.0 * cosp * cosp - 1.0, sin2p = 2.0 * sinp * cosp;
         double Q0 = cos2p * p.Q + sin2p * p.U, U0 = -sin2p * p.Q + cos2p * p.U;
         double I1 = S11 + S12 * Q0, Q1 = S12 + S22 * Q0, U1 = S33 * U0, V1 = S44 * p.V;
@@ -2529,26 +2585,29 @@ __device__ inline void allph_final(const KArgs &A, const Photon &p, long long k)
 template <int VAR, bool STOKES, bool DUST, bool PEEL>
 __device__ __forceinline__ void scatter_event(const KArgs &A, const Lds &l, Rng &g, Photon &p, unsigned &npeel, bool on) {
     ScatCtx sc; sc.xloc = 0.0; sc.xsamp = 0.0; sc.va = 1.0; sc.vsamp = 1.0; sc.species = 1; sc.iup = 0; sc.h2 = 0;
-#if defined(LART_PROFILE) || defined(LART_NO_COOP)
+#if defined(LART_NO_COOP)
     if (!on || !scatter_pre<VAR, STOKES, DUST, PEEL>(A, l, g, p, npeel, sc)) return;
-    LART_PROF_MARK(p, 4);
     double uz_loc = rand_resonance_vz(g, sc.xsamp, sc.vsamp LART_PROF_PASS(p));
-    LART_PROF_MARK(p, 5);
     scatter_post<VAR, STOKES, DUST, PEEL>(A, l, g, p, npeel, sc, uz_loc);
 #else
     bool go = false;
     if (on) go = scatter_pre<VAR, STOKES, DUST, PEEL>(A, l, g, p, npeel, sc);
+    LART_PROF_MARK(p, 4);
     const bool core = go && fabs(sc.xsamp) <= 1.0;
     double uz_loc;
     if (l.coop) {
         uz_loc = vz_core_coop(g, core, sc.xsamp, sc.vsamp, l.coop);
+        LART_PROF_MARK(p, 5);
 #ifdef LART_NO_WING_COOP
-        if (go && !core) uz_loc = vz_wing(g, sc.xsamp, sc.vsamp);
+        if (go && !core) uz_loc = vz_wing(g, sc.xsamp, sc.vsamp LART_PROF_PASS(p));
 #else
         const double uw = vz_wing_coop(g, go && !core, sc.xsamp, sc.vsamp, l.coop);
         if (go && !core) uz_loc = uw;
+        LART_PROF_MARK(p, 9);
 #endif
-    } else { uz_loc = core ? vz_core(g, sc.xsamp, sc.vsamp) : 0.0; if (go && !core) uz_loc = vz_wing(g, sc.xsamp, sc.vsamp); }
+    } else { uz_loc = core ? vz_core(g, sc.xsamp, sc.vsamp LART_PROF_PASS(p)) : 0.0; if (go && !core) uz_loc = vz_wing(g, sc.xsamp, sc.vsamp LART_PROF_PASS(p)); }
+    g.template fill<LART_FILL_MID(STOKES)>(go);                // the draws of scatter_post: polar angle, azimuth (tries), perpendicular velocity (tries)
+    LART_PROF_MARK(p, 11);
     if (go) scatter_post<VAR, STOKES, DUST, PEEL>(A, l, g, p, npeel, sc, uz_loc);
 #endif
 }

@@ -87,6 +87,7 @@ __global__ __launch_bounds__(LART_MAX_BLOCK_V(STOKES), LART_WAVES_V4(VAR, STOKES
     }
     Lds l_ = lds_stage(sh, A.g); lds_set_dipole(l_, A.par.E1); l_.lt = LT; l_.dnu_hz = (LT == 2) ? A.par.DnuHK_Hz : (LT == 7) ? A.par.delta_nu_HD_Hz : 0.0;
     if (LT == 4) lds_set_multiplet(l_, A.ml);
+    if (PEEL) lds_set_fov(l_, A);
     if (LT == 7) { l_.hd_ratio = A.par.ratio_Dfreq_HD; l_.hd_ratio_a = A.par.ratio_voigta_HD; l_.hd_nD = A.par.nD_over_nH; }
     if (A.jpa.lds_bins > 0) {                                  // per-block copies of the P1 / P1_new profile tallies
         double *jp = sh + VT_END + (A.g.nx + A.g.ny + A.g.nz + 3) + (size_t)LART_RNG_BUF * blockDim.x;
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(LART_MAX_BLOCK_V(STOKES), LART_WAVES_V4(VAR, STOKES
     OvlState os; os.live = false;                                                 // VAR 7: the march of a flight that left its clump, between two rounds of the wave
     g.k0 = (uint32_t)A.seed; g.k1 = (uint32_t)(A.seed >> 32);                  // (a lane that never holds a packet still lends its ALU to Rng::prefill_sparse: the key is the run's)
 #ifdef LART_PROFILE
-    for (int i = 0; i < 12; i++) p.pt[i] = 0;
+    for (int i = 0; i < 16; i++) p.pt[i] = 0;
     for (int i = 0; i < 4; i++) p.pc[i] = 0;
     p.plast = clock64();
 #endif
@@ -173,10 +174,9 @@ __global__ __launch_bounds__(LART_MAX_BLOCK_V(STOKES), LART_WAVES_V4(VAR, STOKES
         const bool act = alive && budget > 0;
         const unsigned long long am = __ballot(act);
         if (!am) break;
-        if (__popcll(am) * LART_RNG_TOPUP <= 64) g.prefill_sparse(act, am);
-        else if (act) g.prefill();
+        g.template fill<LART_FILL_TOP(STOKES)>(act);          // draws of the flight and the vz sampler; scatter_event fills again before scatter_post
 #ifdef LART_EXPERIMENT_PREFILL2                        // timing experiment: cost of one buffer fill
-        if (act) g.prefill();
+        if (act) g.template prefill<LART_FILL_TOP(STOKES)>();
 #endif
         LART_PROF_TRIP(p, 2);
         if (act && !(VAR == 7 && os.live)) fly<VAR, DUST>(A, l, g, p, first, nsteps, VAR == 7 ? &oh : nullptr, VAR == 7 ? &os : nullptr);
@@ -234,7 +234,11 @@ __global__ __launch_bounds__(LART_MAX_BLOCK_V(STOKES), LART_WAVES_V4(VAR, STOKES
 #ifdef LART_PROFILE
     LART_PROF_MARK(p, 0);
     if ((threadIdx.x & 63) == 0) for (int i = 0; i < 12; i++) atomicAdd(&A.t.scal[8 + i], (double)p.pt[i]);
+    if ((threadIdx.x & 63) == 0) for (int i = 12; i < 16; i++) atomicAdd(&A.t.scal[LART_SCAL_AUX + i - 12], (double)p.pt[i]);      // (line type 1 leaves the aux scalars free)
     for (int i = 0; i < 4; i++) { double v = wave_sum((double)p.pc[i]); if ((threadIdx.x & 63) == 0) atomicAdd(&A.t.scal[20 + i], v); }
+#endif
+#ifdef LART_RNG_STATS
+    { double v0 = wave_sum((double)g.nslow), v1 = wave_sum((double)g.nslow_w); if ((threadIdx.x & 63) == 0) { atomicAdd(&A.t.scal[8], v0); atomicAdd(&A.t.scal[9], v1); } }
 #endif
     // per-wave pre-reduction, one atomic per wave per scalar
     double s0 = wave_sum(nsg_done), s1 = wave_sum(nsd_done), s2 = wave_sum((double)nev), s3 = wave_sum((double)nsteps),

@@ -145,6 +145,35 @@ def test_run_multi_one_context_equals_run(capi):
     assert np.allclose(a.ctx.tallies()["Jout"], b.ctx.tallies()["Jout"], rtol=0, atol=1e-9)
 
 
+def test_run_multi_two_contexts_on_one_device_sum_to_the_one_context_run(capi):
+    """the N > 1 decomposition executed on the one GPU a test box has (run_simulation_mod.f90:150-151: rank r of 2 transports the ids r+1, r+3, ...;
+    output_sum_rect.f90:107-127: the element-wise sum of the ranks' buffers): lart_gpu_run_multi drives two contexts -- two pools, two HIP streams, two
+    fused tally buffers with their per-XCD copies, peel queues included -- on device 0; the two lart_gpu_tally_buffer images summed on the host equal the
+    buffer of ONE context that ran all ids (up to the order of the atomic additions), and photon k of context r is photon 2k + r of that run."""
+    from lart_amd import host
+    kw = dict(temperature=1e4, taumax=3e2, nx=21, ny=21, nz=21, rmax=1.0, nxfreq=61, use_stokes=True, save_Jin=True, nxim=16, nyim=16, iseed=9)
+    n = 6001                                                   # odd: the ranks get 3001 and 3000 photons
+    a, b = make(kw), make(kw)
+    for s in (a, b):
+        s.ctx.enable_photon_log(True)
+    capi.run_multi([a.ctx, b.ctx], n, 9)
+    one = make(kw); one.ctx.enable_photon_log(True); one.run_simulation(n, seed=9)
+
+    def image(s):
+        ptr, cnt = s.ctx.tally_buffer()
+        return host._as_cuda_tensor(ptr, cnt, s.ctx).cpu().numpy().copy()
+    ia, ib, io = image(a), image(b), image(one)
+    assert ia.shape == ib.shape == io.shape and ia[32:].sum() > 0 and ib[32:].sum() > 0
+    assert ia[5] == 3001 and ib[5] == 3000 and io[5] == n      # nphotons_done per "rank"
+    tot = ia + ib
+    assert np.allclose(tot[:7], io[:7], rtol=1e-12, atol=0)    # nscatt_gas, nscatt_dust, events, cell steps, peel cell steps, photons
+    assert np.allclose(tot[32:], io[32:], rtol=0, atol=1e-12 * np.abs(io[32:]).max())
+    ta, to = a.ctx.tallies(), one.ctx.tallies()
+    assert to["scatt"].sum() > 0 and to["Q"].any()
+    (na, xa), (nb, xb), (no, xo) = a.ctx.photon_log(3001), b.ctx.photon_log(3000), one.ctx.photon_log(n)
+    assert np.array_equal(na, no[0::2]) and np.array_equal(nb, no[1::2]) and np.array_equal(xa, xo[0::2]) and np.array_equal(xb, xo[1::2])
+
+
 def test_setter_after_begin_ends_the_run(capi):
     """a set_* call frees tables the resident pool refers to: the run is over, lart_gpu_step must refuse instead of launching"""
     sim = make(KW)

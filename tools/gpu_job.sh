@@ -16,6 +16,7 @@
 #   stats:TAG:CONFIG           only the kernel-trace --stats pass on tools/perf_kernel.py --config CONFIG
 #   py:SCRIPT[:ARGS]           python SCRIPT ARGS (debug helpers under tools/dbg)
 #   explore[:ARGS]             tools/perf_explore.py ARGS (throughput vs photon age, drain tail)
+#   perflib:SUFFIXES:CONFIGS   tools/perf_kernel.py --config C with LART_GPU_LIB = liblart_gpu<SUFFIX>.so for every pair (SUFFIXES like default,_t6,_prof)
 #   ab:VARIANTS:LANES          tuning builds x pool sizes through tools/perf_explore.py (VARIANTS like default,_w3 ; LANES like 0,786432)
 set -o pipefail
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
@@ -57,6 +58,8 @@ for spec in "$@"; do
              f=$(find gpurun_out/${a1}_stats -name "*kernel_stats.csv" | head -n 1); [ -n "$f" ] && cp "$f" gpurun_out/${a1}_kernel_stats.csv && head -n 8 gpurun_out/${a1}_kernel_stats.csv | cut -c1-300; rm -rf gpurun_out/${a1}_stats ;;
     py)      step py_$(basename ${a1%.py}) 600 python ${a1} ${a2//,/ } ;;
     explore) step explore 1100 python tools/perf_explore.py ${a1//,/ } ;;
+    perflib) for v in ${a1//,/ }; do [ "$v" = default ] && v=""; for c in ${a2//,/ }; do
+               LART_GPU_LIB=$PWD/lart_amd/csrc/liblart_gpu$v.so step "perf${v}_$c" 400 python tools/perf_kernel.py --config $c; done; done ;;
     ab)      for v in ${a1//,/ }; do [ "$v" = default ] && v=""; for l in ${a2//,/ }; do
                LART_GPU_LIB=$PWD/lart_amd/csrc/liblart_gpu$v.so step "ab${v}_l$l" 300 python tools/perf_explore.py --steps 3 --events 4096 --lanes $l; done; done ;;
     *) echo "unknown step $spec"; exit 2 ;;

@@ -36,6 +36,8 @@ def configs(tmp):
                      nxfreq=101, velocity_min=-100.0, velocity_max=100.0, nx=11, ny=11, nz=11, no_photons=1e8, iseed=1),       # examples/clump_sphere/clump_overlap_mono.in with a Voigt source: static clumps
         "c5": dict(use_amr_grid=True, amr_file=afile, temperature=1e4, taumax=1e4, rmax=1.0, nxfreq=241, xfreq_min=-15.0, xfreq_max=15.0,
                    calc_J=True, calc_P=True, calc_Pnew=True, no_photons=1e8, iseed=1),
+        "c5obs": dict(use_amr_grid=True, amr_file=afile, temperature=1e4, taumax=1e4, rmax=1.0, nxfreq=121, nxim=100, nyim=100, calc_J=True, calc_P=True, calc_Pnew=True,
+                      no_photons=1e8, iseed=1),                # the C5 leg of bench.py (other_configs: c5_octree_JP, with its 100 x 100 observer)
         "c5j": dict(use_amr_grid=True, amr_file=afile, temperature=1e4, taumax=1e4, rmax=1.0, nxfreq=241, xfreq_min=-15.0, xfreq_max=15.0, calc_J=True, no_photons=1e8, iseed=1),
         "c5p": dict(use_amr_grid=True, amr_file=afile, temperature=1e4, taumax=1e4, rmax=1.0, nxfreq=241, xfreq_min=-15.0, xfreq_max=15.0, calc_P=True, no_photons=1e8, iseed=1),
         "c5q": dict(use_amr_grid=True, amr_file=afile, temperature=1e4, taumax=1e4, rmax=1.0, nxfreq=241, xfreq_min=-15.0, xfreq_max=15.0, calc_Pnew=True, no_photons=1e8, iseed=1),
@@ -96,7 +98,20 @@ def main():
            "roofline": {"bound": "hbm", "achieved": bytes_launch / (k_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                         "frac": bytes_launch / (k_ms * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes_per_launch": bytes_launch}}
     print(json.dumps(out), flush=True)
-    if os.environ.get("LART_GPU_LIB", "").endswith("_st.so"):              # -DLART_OVL_STATS build: how the flights of the overlap march divide
+    lib = os.environ.get("LART_GPU_LIB", "")
+    if lib.endswith("_prof.so"):                                           # -DLART_PROFILE build: wave clocks per code section (lart_device.hpp, LART_PROF_MARK)
+        ptr, nt = sim.ctx.tally_buffer()
+        b = host._as_cuda_tensor(ptr, 32, sim.ctx).cpu().numpy()
+        sc = list(b[8:20]) + list(b[25:29]); tr = b[20:24]; tot = sum(sc)
+        names = ["pool", "birth", "tau+first", "raytrace_to_tau", "scatter_pre", "vz_core_loop", "post_rest(ux..emit)", "finish+rotate", "vz_wing_setup", "vz_wing_loop", "vz_wing_tan", "mid_fill",
+                 "post_head(E,cost,S)", "phi_rejection", "perp_velocity", "peel_emit"]
+        print(json.dumps({"section_clock_share": {k: round(float(v / tot), 4) for k, v in zip(names, sc)},
+                          "wave_trips_per_round": {"core_tries": tr[0] / tr[2], "wing_tries": tr[1] / tr[2], "wing_entered": tr[3] / tr[2]}, "clocks_per_round": float(tot / tr[2])}), flush=True)
+    if lib.endswith("_rs.so"):                                             # -DLART_RNG_STATS build: single-block evaluations off the draw ring
+        ptr, nt = sim.ctx.tally_buffer()
+        b = host._as_cuda_tensor(ptr, 32, sim.ctx).cpu().numpy(); ev_all = t1["n_events"]
+        print(json.dumps({"slow_blocks_per_event": float(b[8] / ev_all), "wave_detours_per_wave_event": float(b[9] / (ev_all / 64.0))}), flush=True)
+    if os.environ.get("LART_GPU_LIB", "").endswith("_st.so"):             # -DLART_OVL_STATS build: how the flights of the overlap march divide
         ptr, nt = sim.ctx.tally_buffer()
         b = host._as_cuda_tensor(ptr, 32, sim.ctx).cpu().numpy(); ev_all = t1["n_events"]
         names = ["carried_list", "rebuilds", "rebuild_fast", "rebuild_fast_cached", "marches", "cells", "intervals", "holders_at_march_start"]
