@@ -298,12 +298,106 @@ int  lart_gpu_get_tallies(lart_gpu *ctx, lart_tallies *out);   /* fails (instead
  * random_mt.f90:889-947).  The hosts call this once, print the value and use it as the Philox key on every rank. CPU, no device. */
 int  lart_host_entropy_seed(uint64_t *seed);
 
+/* ---------------------------------------------------------------------------------------------------------------------------------
+ * Host set-up helpers (CPU, lart_amd/csrc/lart_host_setup.cpp): the arithmetic the reference does around the photon loop for the media this
+ * path supports, ONCE for both hosts (lart_amd/host.py via ctypes, lart_amd/fhost/lart_host.f90 via ISO_C_BINDING).  In/out structs: the
+ * members above the "out" comment are inputs.  Errors: non-zero return + lart_host_setup_last_error().
+ * --------------------------------------------------------------------------------------------------------------------------------- */
+#define LART_MAX_OBSERVERS 16
+enum { LART_VEL_NONE = 0, LART_VEL_HUBBLE, LART_VEL_CONSTANT_RADIAL, LART_VEL_PARALLEL, LART_VEL_ROT_SOLID, LART_VEL_ROT_HALO,
+       LART_VEL_POWER_LAW, LART_VEL_LINEAR_DECEL, LART_VEL_SSH };          /* par%velocity_type (grid_mod_car.f90:786-946) */
+/* line%... of setup_resonance_line (line_mod.f90:551-1272) for 'ly_alpha' (+ par%fine_structure / par%include_deuterium), 'ly_alpha_HD', 'ly_beta' and the
+ * single lines / S-P doublets; lart_host_line_setup returns 2 for the ids of lart_host_line_lookup (the multiplets) */
+typedef struct lart_host_line {
+    int32_t line_type, fine_structure, include_deuterium, pad_;
+    double  wavelength0, damping, cross0, vtherm1, mass_amu, g_recoil0, DnuHK_Hz, E1, E2, E3;
+    double  delta_nu_HD_Hz, ratio_Dfreq_HD, ratio_voigta_HD, nD_over_nH, g_recoil0_D;
+    double  P_conv, E_conv[3], wavelength0_Ha;
+    char    line_id[32];                                                    /* 'ly_alpha' + par%include_deuterium becomes 'ly_alpha_HD' */
+    char    ion_id[8];                                                      /* label of the log lines: 'H  I', 'C IV', ... (grid_mod_car.f90:1231-1234) */
+} lart_host_line;
+typedef struct lart_host_h2 { int32_t n, pad_; double Dfreq_Hz, dv_kms[4], dnu_Hz[4], strength[4], a_damp[4], p_scat[4], pop[4], f_osc[4]; } lart_host_h2;      /* h2l(:) of h2_mod.f90:30-49 */
+typedef struct lart_host_medium {
+    int32_t nx, ny, nz, xyz_symmetry, xy_symmetry, velocity_type, pad0_, pad1_;
+    double  xmax, ymax, zmax, rmin, rmax, cone_opening;
+    double  vtherm, wavelength0, damping, cross0;                           /* vtherm_total(par%temperature) [km/s]; line%wavelength0 [um], %damping, %cross0 */
+    double  dust_opacity;                                                   /* par%cext_dust * par%DGR */
+    double  taumax, tauhomo, N_gasmax, N_gashomo;                           /* the first one that is > 0 normalises the opacity; all four hold the medium's values on return */
+    double  Vexp, Vx, Vy, Vz, Vrot, rinner, velocity_alpha, rpeak, Vpeak, DeltaV;
+    /* out */
+    double  dx, dy, dz, xmin, ymin, zmin, Dfreq_ref, voigt_amean, taupole_out, tauhomo_out, N_gaspole_out, N_gashomo_out;
+    int32_t i0, j0, k0, pad2_;
+} lart_host_medium;
+typedef struct lart_host_freq {
+    int32_t nxfreq, nwavelength, nvelocity, continuum, line_type, nxfreq_Ha, core_skip_global, pad_;      /* nxfreq, nwavelength, nvelocity, nxfreq_Ha: in and out */
+    double  wavelength_min, wavelength_max, velocity_min, velocity_max, xfreq_min, xfreq_max;             /* NaN = not given; xfreq_min / _max: in and out */
+    double  vtherm, wavelength0, wavelength0_Ha, Dfreq_ref, DnuHK_Hz, voigt_amean, tauhomo, taumax, Vexp, xfreq_max_Ha, cells_per_radius;   /* cells_per_radius = grid%xmax / grid%dx */
+    /* out */
+    double  dxfreq, dwave, atau3, xfreq_min_Ha, dxfreq_Ha, dwave_Ha, xcrit, xcrit2;
+} lart_host_freq;
+typedef struct lart_host_obs {
+    int32_t nside, sphere, nxim, nyim, nobs, npix;                          /* nobs, npix (and nxim, nyim for nside > 0): out */
+    double  xmax, ymax, zmax, rmax, distance, dxim, dyim;                   /* distance, dxim, dyim: NaN = not given, set on return */
+    double  steradian_pix;                                                  /* out */
+} lart_host_obs;
+typedef struct lart_host_clumps_in {
+    double  sphere_R, rmin, clump_radius, N_clumps_in, f_vol_in, f_cov_in, clump_tau0, clump_NHI, clump_nH, taumax, N_gasmax, distance2cm;
+    double  vtherm, wavelength0, damping, cross0;                           /* vtherm_total(clump temperature) */
+    /* out */
+    int64_t N; double r_min, fvol, fcov, Dfreq_ref, voigt_a_ref, rhokap_ref;
+} lart_host_clumps_in;
+typedef struct lart_host_norm {
+    int32_t xy_periodic, sphere;
+    double  nphotons, bin_unit, bin_unit_Ha, distance2cm, rmax, xmax, ymax, zmax, amr_L_box, steradian_pix;
+    /* out */
+    double  area, scale_J, scale_J_Ha, scale_cube, scale_image, scale_cube_Ha;
+} lart_host_norm;
+/* read_input (setup.f90:160-500): the fields the rules between namelist entries read and change; notes = LART_NOTE_* bits of the messages to print */
+enum { LART_UNIT_NONE = 0, LART_UNIT_KPC, LART_UNIT_PC, LART_UNIT_AU, LART_UNIT_OTHER, LART_UNIT_USER };      /* par%distance_unit */
+#define LART_NOTE_NO_PEEL_WITH_XYZSYM 1
+typedef struct lart_host_rules {
+    int32_t nx, ny, nz, nr, nside, nxim, nyim, nmu, geometry_JPa, distance_unit, intensity_unit, notes;
+    int32_t xyz_symmetry, xy_symmetry, xy_periodic, use_clump_medium, use_amr_grid, use_stokes, sphere, save_all;
+    int32_t save_peeloff, save_peeloff_2D, save_peeloff_3D, save_Jabs, save_Jmu, core_skip, core_skip_global, pad_;
+    double  tau0, taumax, N_HI, N_HImax, N_HIhomo, N_gasmax, N_gashomo, cext_dust, DGR, mu_min, dmu;
+    double  rmax, xmax, ymax, zmax, source_rmax, distance2cm;
+} lart_host_rules;
+int    lart_host_input_rules(lart_host_rules *r);
+const char *lart_host_setup_last_error(void);
+int    lart_host_line_setup(const char *line_id, int32_t fine_structure, int32_t include_deuterium, double D_to_H_ratio, lart_host_line *out);
+double lart_host_vtherm_total(double vtherm1, double bturb, double T);      /* define.f90:928-933 */
+int    lart_host_h2_init(const char *energy_X_path, double wavelength0_um, double vtherm1, double mass_amu, double bturb, double T_H2, double f_H2,
+                         int32_t pure_absorption, lart_host_h2 *out);       /* h2_mod.f90:120-296 */
+/* grid_create, analytic media (grid_mod_car.f90:73-946): arrays in Fortran (i,j,k) order, xface(nx+1) ...; rhokapD may be NULL */
+int    lart_host_car_medium(lart_host_medium *m, double *xface, double *yface, double *zface, double *rhokap, double *voigt_a, double *Dfreq,
+                            double *vfx, double *vfy, double *vfz, double *rhokapD);
+int    lart_host_freq_grid(lart_host_freq *f);                              /* car_setup_freq_grid + the core-skip scale (grid_mod_car.f90:1150-1548) */
+int    lart_host_freq_axis(int32_t n, double xfreq_min, double dxfreq, double vtherm, double wavelength0_um, double *xfreq, double *velocity, double *wavelength);
+int    lart_host_jpa_car(int32_t geometry_JPa, int32_t xyz_symmetry, int32_t nx, int32_t ny, int32_t nz, const double *xface, const double *yface, const double *zface,
+                         double xmax, double ymax, double zmax, const double *rhokap, int32_t *nbins, int32_t *ind_bin, double *ncount);      /* create_JPa_mem :1242-1434 */
+/* observer_create (observer_rect.f90:24-326, observer_heal.f90:24-80): arrays of LART_MAX_OBSERVERS entries, NaN = not given, completed on return;
+ * xyz[3 nobs], rmatrix[9 nobs] row-major */
+int    lart_host_observers(lart_host_obs *o, double *alpha, double *beta, double *gamma, double *obsx, double *obsy, double *obsz, double *xyz, double *rmatrix);
+int    lart_host_clump_population(lart_host_clumps_in *c);                  /* init_clumps: population size and clump opacity (clump_mod.f90:646-760) */
+int    lart_host_clump_scalars(int64_t n, double sphere_R, double r_min, double cross0, const double *x, const double *y, const double *z, const double *radius,
+                               const double *rhokap, const double *voigt_a, const double *Dfreq, double *out4);      /* compute_clump_scalars :2316-2378 */
+int    lart_host_clump_velocities(int64_t n, int32_t velocity_type, double sphere_R, double Vexp, double Vx, double Vy, double Vz, double Vrot, double rinner,
+                                  const double *x, const double *y, const double *z, const double *vtherm, double *vx, double *vy, double *vz);      /* :1153-1264 */
+int    lart_host_alias_setup(int32_t n, double *probs, int32_t *alias);     /* random_alias_setup (random_mt.f90:2016-2067) */
+int    lart_host_mueller_setup(int32_t n, const double *coss, double *S11, double *S12, double *S33, double *S34, double *phase_PDF, int32_t *alias);   /* setup.f90:615-649 */
+int    lart_host_norm_scales(lart_host_norm *s);                            /* the divisors of output_normalize_outside (output_sum_rect.f90:151-487) */
+
 /* device-function probes used by the parity tests (each runs a tiny kernel, one lane per element) */
 int  lart_gpu_test_voigt(lart_gpu *ctx, int32_t n, const double *x, const double *a, double *h);
 int  lart_gpu_test_rand(lart_gpu *ctx, int32_t what, uint64_t seed, uint64_t id, int32_t n, double p1, double p2, double *out);
 int  lart_gpu_test_raytrace(lart_gpu *ctx, int32_t mode, int32_t n, double *r8, int32_t *ic4, const double *tau_or_dist, double *tau_out);
 int  lart_gpu_test_vec2pix(lart_gpu *ctx, int32_t nside, int32_t n, const double *v3, int32_t *ipix);
 int  lart_gpu_test_scatter(lart_gpu *ctx, int32_t n, double *st18, int32_t *ic4, uint64_t seed, const uint64_t *ids, int64_t *ndraws);
+/* ONE event round of the photon loop (run_simulation_mod.f90:160-200: optical depth draw [forced on the first flight], raytrace_to_tau, scattering) from a
+ * given packet state and draw counter; st27 per packet, in and out: x y z kx ky kz xfreq wgt m(3) n(3) Q U V nscatt_gas nscatt_dust draws icell jcell kcell
+ * owner_clump vfy_shear iband kind (out: 1 scattered, 2 left or absorbed).  The one-step re-synchronised check of tests/test_gpu_divergence.py feeds the
+ * oracle's state of the event before a divergence in here.  Plain grid and clump media, line type 1. */
+int  lart_gpu_test_event(lart_gpu *ctx, int32_t n, double *st27, uint64_t seed, const uint64_t *ids, const int32_t *first);
 /* per-event history probe (tests/test_gpu_divergence.py): runs the photons first_id + k*stride, k < count, like lart_gpu_run and records, for
  * every k with slot[k] >= 0, 8 doubles after the birth and after every event into trace[(slot*cap + i)*8 ..]: draws consumed, xfreq
  * (xfreq_ref once outside), x, y, z, cell code (icell + 2^21 jcell + 2^42 kcell; the owner clump in clump media), kz, kind (0 birth,

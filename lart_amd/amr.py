@@ -16,6 +16,13 @@ import numpy as np
 from .host import (LartInputError, FOURPI, UM2KM, vtherm_total, voigt_center)
 
 
+def _seqsum(v):
+    s = 0.0
+    for t in v:
+        s = s + float(t)
+    return s
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # input generation
 # ---------------------------------------------------------------------------------------------------------------
@@ -454,7 +461,7 @@ def grid_create_amr(par, line, path):
     H0 = voigt_center(g.voigt_a)
     nopac = float((g.rhokap > 0).sum())
     opac_length = bl / 2.0
-    tauhomo = host._seqsum(g.rhokap * H0) / nopac * opac_length if nopac > 0 else 0.0
+    tauhomo = _seqsum(g.rhokap * H0) / nopac * opac_length if nopac > 0 else 0.0
     # pole traversal +z from the box centre
     xc = yc = zc = float(g.cx[0]); tau_raw = NHI = 0.0
     while zc < g.xmax:
@@ -476,7 +483,7 @@ def grid_create_amr(par, line, path):
     g.rhokap = g.rhokap * opac_norm
     if g.rhokapD is not None:
         g.rhokapD = g.rhokapD * opac_norm
-    tauhomo = host._seqsum(g.rhokap * H0) / nopac * opac_length if nopac > 0 else 0.0
+    tauhomo = _seqsum(g.rhokap * H0) / nopac * opac_length if nopac > 0 else 0.0
     taupole = par.taumax if par.taumax > 0 else tauhomo
     par.N_gasmax = NHI * opac_norm; par.N_gashomo = par.N_gasmax; par.tauhomo = tauhomo; par.taumax = taupole
     sg = host.Grid(nx=g.nleaf, ny=1, nz=1, Dfreq_ref=Dfreq_ref, voigt_amean=voigt_amean, xmax=par.xmax, ymax=par.ymax, zmax=par.zmax,

@@ -51,7 +51,7 @@ SYMBOLS = ["lart_host_line_lookup", "lart_gpu_set_line_multiplet", "lart_gpu_dev
            "lart_gpu_compact", "lart_gpu_set_auto_compact", "lart_gpu_live_lanes",
            "lart_gpu_comm_unique_id", "lart_gpu_comm_init", "lart_gpu_comm_info", "lart_gpu_comm_destroy", "lart_gpu_reduce_tallies",
            "lart_gpu_reduce_tallies_multi", "lart_gpu_run_multi", "lart_host_entropy_seed",
-           "lart_gpu_test_voigt", "lart_gpu_test_rand", "lart_gpu_test_raytrace", "lart_gpu_test_vec2pix", "lart_gpu_test_scatter", "lart_gpu_test_trace"]
+           "lart_gpu_test_voigt", "lart_gpu_test_rand", "lart_gpu_test_raytrace", "lart_gpu_test_vec2pix", "lart_gpu_test_scatter", "lart_gpu_test_trace", "lart_gpu_test_event"]
 
 _lib = None
 
@@ -117,6 +117,7 @@ def lib():
         L.lart_gpu_test_raytrace.argtypes = [_vp, _i32, _i32, _vp, _vp, _vp, _vp]
         L.lart_gpu_test_scatter.argtypes = [_vp, _i32, _vp, _vp, _u64, _vp, _vp]
         L.lart_gpu_test_trace.argtypes = [_vp, _i64, _i64, _i64, _u64, _vp, _i32, _i32, _vp, _vp]
+        L.lart_gpu_test_event.argtypes = [_vp, _i32, _vp, _u64, _vp, _vp]
         _lib = L
     return _lib
 
@@ -439,6 +440,13 @@ class Context:
         tr = np.zeros((len(select), int(cap), 8)); n = np.zeros(len(select), dtype=np.int32)
         _chk(lib().lart_gpu_test_trace(self.h, int(first_id), int(stride), int(count), int(seed), _p(slot), len(select), int(cap), _p(tr), _p(n)))
         return tr, n
+
+    def test_event(self, st27, seed, ids, first):
+        """lart_gpu_test_event: one event round (flight + scattering) per row of st27 (the oracle's state-record layout); returns the records after the event"""
+        st = np.ascontiguousarray(st27, dtype=np.float64).copy().reshape(-1, 27)
+        ids = np.ascontiguousarray(ids, dtype=np.uint64); first = np.ascontiguousarray(first, dtype=np.int32)
+        _chk(lib().lart_gpu_test_event(self.h, st.shape[0], _p(st), int(seed), _p(ids), _p(first)))
+        return st
 
     def test_scatter(self, st18, ic4, seed, ids):
         st = np.ascontiguousarray(st18, dtype=np.float64).copy(); ic = np.ascontiguousarray(ic4, dtype=np.int32).copy()

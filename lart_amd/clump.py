@@ -67,70 +67,25 @@ def build_csr(cl):
 
 
 def assign_clump_velocities(par, cl):
-    """assign_clump_velocities_from_type: clump_mod.f90:1153-1264 (the fields this path supports)"""
-    x, y, z = cl.x, cl.y, cl.z
-    rr = np.sqrt(x * x + y * y + z * z)
-    vx = np.zeros_like(x); vy = np.zeros_like(x); vz = np.zeros_like(x)
-    vt = par.velocity_type
-    if vt == "hubble":
-        vx, vy, vz = par.Vexp * x / cl.sphere_R, par.Vexp * y / cl.sphere_R, par.Vexp * z / cl.sphere_R
-    elif vt == "constant_radial":
-        ok = rr > 0
-        vx[ok], vy[ok], vz[ok] = par.Vexp * x[ok] / rr[ok], par.Vexp * y[ok] / rr[ok], par.Vexp * z[ok] / rr[ok]
-    elif vt == "parallel_velocity":
-        vx[:], vy[:], vz[:] = par.Vx, par.Vy, par.Vz
-    elif vt == "rotating_solid_body":
-        vx, vy = -par.Vrot * y / cl.sphere_R, par.Vrot * x / cl.sphere_R
-    elif vt == "rotating_galaxy_halo":
-        rc = np.sqrt(x * x + y * y)
-        inner = (rc > 0) & (rc < par.rinner); outer = rc >= par.rinner
-        vx[inner], vy[inner] = -par.Vrot * y[inner] / par.rinner, par.Vrot * x[inner] / par.rinner
-        vx[outer], vy[outer] = -par.Vrot * y[outer] / rc[outer], par.Vrot * x[outer] / rc[outer]
-    cl.vx = cl.vx + vx / cl.vtherm; cl.vy = cl.vy + vy / cl.vtherm; cl.vz = cl.vz + vz / cl.vtherm
+    """assign_clump_velocities_from_type (clump_mod.f90:1153-1264, the fields this path supports) through lart_host_clump_velocities"""
+    from . import hostlib
+    vt = hostlib.VELOCITY_TYPES.get(par.velocity_type, 0)
+    hostlib.check(hostlib.lib().lart_host_clump_velocities(cl.N, vt, cl.sphere_R, par.Vexp, par.Vx, par.Vy, par.Vz, par.Vrot, par.rinner,
+                                                             *[hostlib.p(a) for a in (cl.x, cl.y, cl.z, cl.vtherm, cl.vx, cl.vy, cl.vz)]), LartInputError)
 
 
 def init_clumps(par, line, R_sphere):
     """init_clumps, uniform path: clump_mod.f90:646-891"""
+    from . import hostlib
     cl = Clumps(sphere_R=float(R_sphere))
-    if par.clump_radius <= 0.0:
-        raise LartInputError("ERROR: clump_radius must be > 0")
-    cl.r_min = max(0.0, par.rmin)
-    if cl.r_min >= R_sphere:
-        raise LartInputError("ERROR: par%rmin must be < par%rmax for clump placement")
-    cl.radius_max = rc = par.clump_radius
     temp_cl = par.temperature if par.clump_temperature < 0.0 else par.clump_temperature
-    vth = vtherm_total(line, temp_cl)
-    cl.Dfreq_ref = vth / (line.wavelength0 * UM2KM); cl.vtherm_ref = vth; cl.temperature_ref = temp_cl
-    cl.voigt_a_ref = (line.damping / FOURPI) / cl.Dfreq_ref
-    R, r0 = R_sphere, cl.r_min
-    shell2 = R * R + R * r0 + r0 * r0
-    nint = lambda v: int(math.floor(v + 0.5)) if v >= 0 else -int(math.floor(-v + 0.5))
-    if par.clump_N_clumps > 0.0:
-        cl.N = int(par.clump_N_clumps)
-    elif par.clump_f_vol > 0.0:
-        cl.N = nint(par.clump_f_vol * (R ** 3 - r0 ** 3) / rc ** 3)
-    elif par.clump_f_cov > 0.0:
-        cl.N = nint((4.0 / 3.0) * par.clump_f_cov * shell2 / (rc * rc))
-    else:
-        raise LartInputError("ERROR: specify clump_N_clumps, clump_f_vol, or clump_f_cov")
-    cl.N = max(cl.N, 1)
-    tiny = 2.2250738585072014e-308
-    cl.fvol = cl.N * rc ** 3 / max(R ** 3 - r0 ** 3, tiny)
-    cl.fcov = 0.75 * cl.N * rc * rc / max(shell2, tiny)
-    H0 = float(voigt_center(np.float64(cl.voigt_a_ref)))
-    if par.clump_tau0 > 0.0:
-        cl.rhokap_ref = par.clump_tau0 / (H0 * par.clump_radius)
-    elif par.clump_NHI > 0.0:
-        cl.rhokap_ref = par.clump_NHI * line.cross0 / (cl.Dfreq_ref * par.clump_radius)
-    elif par.clump_nH > 0.0:
-        if par.distance2cm <= 0.0:
-            raise LartInputError("ERROR: clump_nH requires distance_unit")
-        cl.rhokap_ref = par.clump_nH * line.cross0 * par.distance2cm / cl.Dfreq_ref
-    elif par.taumax > 0.0 or par.N_gasmax > 0.0:
-        GF = cl.N * rc ** 3 / max(shell2, tiny)
-        cl.rhokap_ref = par.taumax / (GF * H0) if par.taumax > 0.0 else par.N_gasmax * line.cross0 / (GF * cl.Dfreq_ref)
-    else:
-        raise LartInputError("ERROR: specify clump_tau0, clump_NHI, clump_nH, taumax, or N_HImax")
+    c = hostlib.HostClumpsIn(sphere_R=float(R_sphere), rmin=par.rmin, clump_radius=par.clump_radius, N_clumps_in=par.clump_N_clumps, f_vol_in=par.clump_f_vol,
+                             f_cov_in=par.clump_f_cov, clump_tau0=par.clump_tau0, clump_NHI=par.clump_NHI, clump_nH=par.clump_nH, taumax=par.taumax, N_gasmax=par.N_gasmax,
+                             distance2cm=par.distance2cm, vtherm=vtherm_total(line, temp_cl), wavelength0=line.wavelength0, damping=line.damping, cross0=line.cross0)
+    hostlib.check(hostlib.lib().lart_host_clump_population(C.byref(c)), LartInputError)      # population size, f_vol / f_cov, the opacity of one clump (:646-760)
+    cl.r_min, cl.radius_max, rc = c.r_min, par.clump_radius, par.clump_radius
+    cl.Dfreq_ref, cl.vtherm_ref, cl.temperature_ref, cl.voigt_a_ref = c.Dfreq_ref, c.vtherm, temp_cl, c.voigt_a_ref
+    cl.N, cl.fvol, cl.fcov, cl.rhokap_ref = int(c.N), c.fvol, c.fcov, c.rhokap_ref
     n = cl.N
     cl.x, cl.y, cl.z = np.zeros(n), np.zeros(n), np.zeros(n)
     cl.vx, cl.vy, cl.vz = np.zeros(n), np.zeros(n), np.zeros(n)
@@ -405,15 +360,12 @@ def read_clumps_info(par, line, fname, R_sphere):
 
 
 def clump_scalars(line, cl):
-    """compute_clump_scalars: clump_mod.f90:2316-2378 (sequential sums in clump order, as the reference loops)"""
-    shell2 = cl.sphere_R ** 2 + cl.sphere_R * cl.r_min + cl.r_min ** 2
-    H0 = voigt_center(cl.voigt_a)
-    r3 = cl.radius ** 3
-    di2 = np.maximum(cl.x ** 2 + cl.y ** 2 + cl.z ** 2, cl.radius ** 2)
-    wh, wm = r3 / shell2, r3 / (3.0 * di2)
-    seq = lambda v: float(np.cumsum(v)[-1])               # left-to-right double sum
-    return dict(tauhomo=seq(cl.rhokap * H0 * wh), taumax=seq(cl.rhokap * H0 * wm),
-                N_gashomo=seq(cl.rhokap * cl.Dfreq * wh / line.cross0), N_gasmax=seq(cl.rhokap * cl.Dfreq * wm / line.cross0))
+    """compute_clump_scalars: clump_mod.f90:2316-2378 (sequential sums in clump order) through lart_host_clump_scalars"""
+    from . import hostlib
+    out = np.zeros(4)
+    hostlib.check(hostlib.lib().lart_host_clump_scalars(cl.N, cl.sphere_R, cl.r_min, line.cross0, *[hostlib.p(np.ascontiguousarray(a, dtype=np.float64)) for a in
+                                                          (cl.x, cl.y, cl.z, cl.radius, cl.rhokap, cl.voigt_a, cl.Dfreq)], hostlib.p(out)), LartInputError)
+    return dict(tauhomo=float(out[0]), taumax=float(out[1]), N_gashomo=float(out[2]), N_gasmax=float(out[3]))
 
 
 def compute_clump_scalars(par, line, cl):

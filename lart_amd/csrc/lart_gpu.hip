@@ -1154,6 +1154,48 @@ __global__ void k_test_scatter(KArgs A, int n, double *st18, int *ic4, unsigned 
     else test_scatter_one<0, false, false>(A, l, st18 + 18 * i, ic4 + 4 * i, seed, ids[i], nd + i);
 }
 
+// ONE event round of the photon loop (flight to the next interaction, then the scattering) from a given packet state and draw counter: what one pass of
+// transport_kernel's loop does to a packet, with the generator off the ring.  st27 in the layout of the oracle's state record (oracle/lart_oracle.c,
+// ORC_STATE_W): x y z kx ky kz xfreq wgt m(3) n(3) Q U V nscatt_gas nscatt_dust draws icell jcell kcell owner_clump vfy_shear iband kind; `first` = the
+// packet has not flown yet (forced first scattering).  On return the same record after the event (kind 1 scattered, 2 left or absorbed).
+template <int VAR, bool STOKES, bool DUST>
+__device__ void test_event_one(const KArgs &A, const Lds &l, double *st, unsigned long long seed, unsigned long long id, int first_in) {
+    Photon p{}; p.x = st[0]; p.y = st[1]; p.z = st[2]; p.kx = st[3]; p.ky = st[4]; p.kz = st[5]; p.xfreq = st[6]; p.wgt = st[7];
+    p.mx = st[8]; p.my = st[9]; p.mz = st[10]; p.nx = st[11]; p.ny = st[12]; p.nz = st[13]; p.Q = st[14]; p.U = st[15]; p.V = st[16]; p.nsg = st[17]; p.nsd = st[18];
+    p.ic = (int)st[20]; p.jc = (int)st[21]; p.kc = (int)st[22]; p.icl = (int)st[23]; p.shear = st[24]; p.iband = st[25] == 2.0 ? 2 : 1; p.inside = true; p.xfreq_ref = 0.0;
+    if (is_clump(VAR)) { p.ic = 1; p.jc = 1; p.kc = 1; }
+    Rng g; g.init(seed, id, (unsigned long long)st[19]);
+    bool first = first_in != 0; unsigned ns = 0, np = 0;
+    OvlHold oh; oh.na = 0; oh.reach = 0.0; OvlState os; os.live = false;
+    fly<VAR, DUST>(A, l, g, p, first, ns, VAR == 7 ? &oh : nullptr, VAR == 7 ? &os : nullptr);
+    if (VAR == 7) while (os.live) {                            // the march of a flight that left its clump, to its end (the kernel advances it a few cells per round)
+        double t_end = 0.0; int owner = 0;
+        if (ovl_advance<true>(A, l, DUST, p.x, p.y, p.z, p.kx, p.ky, p.kz, p.xfreq, 0.0, ns, t_end, owner, nullptr, os, 1 << 20)) { ovl_finish<true>(A, os, t_end, owner); ovl_apply(A, p, t_end, owner); }
+    }
+    scatter_event<VAR, STOKES, DUST, false>(A, l, g, p, np, p.inside);
+    st[0] = p.x; st[1] = p.y; st[2] = p.z; st[3] = p.kx; st[4] = p.ky; st[5] = p.kz; st[6] = p.inside ? p.xfreq : p.xfreq_ref; st[7] = p.wgt;
+    st[8] = p.mx; st[9] = p.my; st[10] = p.mz; st[11] = p.nx; st[12] = p.ny; st[13] = p.nz; st[14] = p.Q; st[15] = p.U; st[16] = p.V; st[17] = p.nsg; st[18] = p.nsd;
+    st[19] = (double)g.n; st[20] = is_clump(VAR) ? 1.0 : (double)p.ic; st[21] = (double)p.jc; st[22] = (double)p.kc; st[23] = (double)p.icl; st[24] = p.shear; st[25] = (double)p.iband;
+    st[26] = p.inside ? 1.0 : 2.0;
+}
+template <int VAR>
+__device__ void test_event_var(const KArgs &A, const Lds &l, double *st, unsigned long long seed, unsigned long long id, int first) {
+    const bool stokes = A.par.use_stokes, dust = A.par.DGR > 0.0;
+    if (stokes && dust) test_event_one<VAR, true, true>(A, l, st, seed, id, first);
+    else if (stokes) test_event_one<VAR, true, false>(A, l, st, seed, id, first);
+    else if (dust) test_event_one<VAR, false, true>(A, l, st, seed, id, first);
+    else test_event_one<VAR, false, false>(A, l, st, seed, id, first);
+}
+__global__ void k_test_event(KArgs A, int var, int n, double *st27, unsigned long long seed, const unsigned long long *ids, const int *first) {
+    extern __shared__ double sh[];
+    Lds l = lds_stage(sh, A.g); l.lt = 1; lds_set_dipole(l, A.par.E1);
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (var == 7) test_event_var<7>(A, l, st27 + 27 * i, seed, ids[i], first[i]);
+    else if (var == 4) test_event_var<4>(A, l, st27 + 27 * i, seed, ids[i], first[i]);
+    else test_event_var<0>(A, l, st27 + 27 * i, seed, ids[i], first[i]);
+}
+
 template <typename T> struct DevBuf {
     T *p = nullptr; size_t n = 0;
     int alloc(size_t cnt, const T *src) { n = cnt; if (hipMalloc(&p, cnt * sizeof(T) + 8) != hipSuccess) return 1; if (src && hipMemcpy(p, src, cnt * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return 1; return 0; }
@@ -1234,6 +1276,26 @@ extern "C" int lart_gpu_test_scatter(lart_gpu *c, int32_t n, double *st18, int32
     hipLaunchKernelGGL(k_test_scatter, dim3((n + 63) / 64), dim3(64), probe_shmem(c), c->stream, A, n, ds.p, di.p, (unsigned long long)seed, dd.p, dn.p);
     HIPCHK(hipGetLastError()); HIPCHK(hipStreamSynchronize(c->stream));
     if (ds.back(st18) || di.back(ic4) || dn.back((long long *)ndraws)) return fail("test_scatter: copy back failed");
+    return 0;
+}
+
+extern "C" int lart_gpu_test_event(lart_gpu *c, int32_t n, double *st27, uint64_t seed, const uint64_t *ids, const int32_t *first) {
+    if (!c || n < 0 || !st27 || !ids || !first || !c->d_cell) return fail("test_event: needs a context with a medium and the state, id and first-flight arrays");
+    const int var = march_variant(c);
+    if (var != 0 && var != 4 && var != 7) return fail("test_event: built for the plain grid and the clump media (march variants 0, 4, 7)");
+    if (c->par.line_type != 1 || c->par.h2_nlines > 0) return fail("test_event: single-line profiles (line_type 1) only");
+    if (c->par.use_stokes && c->par.DGR > 0.0 && c->mu.nPDF == 0) return fail("test_event: Stokes dust scattering needs a Mueller table");
+    HIPCHK(hipSetDevice(c->device));
+    if (!c->d_tally) { if (build_tally(c)) return 1; }
+    for (int i = 0; i < n; i++) { const double *q = st27 + 27 * (size_t)i;
+        if (c->is_clump) { if (q[23] < 0 || q[23] > (double)c->cl.N) return fail("test_event: owner clump out of range"); continue; }
+        if (q[20] < 1 || q[20] > c->g.nx || q[21] < 1 || q[21] > c->g.ny || q[22] < 1 || q[22] > c->g.nz) return fail("test_event: cell outside the grid"); }
+    DevBuf<double> ds; DevBuf<unsigned long long> dd; DevBuf<int> df;
+    if (ds.alloc((size_t)27 * n, st27) || dd.alloc(n, (const unsigned long long *)ids) || df.alloc(n, first)) return fail("test_event: hipMalloc failed");
+    KArgs A = probe_args(c);
+    hipLaunchKernelGGL(k_test_event, dim3((n + 63) / 64), dim3(64), probe_shmem(c), c->stream, A, var, n, ds.p, (unsigned long long)seed, dd.p, df.p);
+    HIPCHK(hipGetLastError()); HIPCHK(hipStreamSynchronize(c->stream));
+    if (ds.back(st27)) return fail("test_event: copy back failed");
     return 0;
 }
 

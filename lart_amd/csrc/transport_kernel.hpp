@@ -22,10 +22,13 @@ __device__ inline double wave_sum(double v) {
 #define LART_WAVES_V4(V, S, D, P) LART_MIN_WAVES
 #else
 #define LART_WAVES(S, P) ((S) ? 3 : 4)
-// Stokes kernels, per instantiation where it was measured AND run through the device suite at full size (round 3, events/s at 3 -> 4 waves per SIMD): the 1-column
-// slab without dust (C1) gains, 8.63 -> 9.31e9; the plain grid with peel-off (C3) loses (5.93 -> 5.43e9); the clump kernel with dust gains 4 % without an observer
-// but was not measured with one (C4 has one); and the slab kernel with dust, squeezed into 128 VGPRs (115 spills), died with a memory fault -- so only C1's.
-#define LART_WAVES_V4(V, S, D, P) (!(S) || ((V) == 2 && !(D) && !(P)) ? 4 : 3)
+// Round 3 built ONE Stokes instantiation, the 1-column slab without dust (C1), at 4 waves per SIMD because it measured 8 % faster there.  Round 4 found what
+// the squeeze to 128 VGPRs can cost (profiles/r04_exec_restore_miscompile.md): with dozens of spills the register allocator splits live ranges across the
+// divergent `if (pending)` of vz_core_coop and puts the split copy and a spill store at the TOP of the join block, in front of the `s_or_b64 exec` that brings
+// back the lanes which skipped the branch -- those lanes later read a stale register / scratch slot (C1: garbage event counters; the round-3 memory fault of
+// the slab kernel with dust was the same pattern hitting an index).  Every Stokes kernel is back at 3 waves (168 VGPRs, no live-range splits of that kind), and
+// tools/isa_lint.py -- run by tests/test_isa_lint.py on the BASELINE instantiations -- fails the build check if the pattern ever shows up again.
+#define LART_WAVES_V4(V, S, D, P) ((S) ? 3 : 4)
 #endif
 // largest workgroup: the kernels that fit 128 VGPRs may run as ONE 1024-lane workgroup per CU (the same 4 waves per SIMD), which leaves the LDS that four
 // 256-lane workgroups spend on four copies of the tables to the J(x) window of the profile tallies (lart_gpu.hip, tally layout)

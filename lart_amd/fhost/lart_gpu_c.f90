@@ -62,6 +62,51 @@ module lart_gpu_c
      real(c_double) :: aux(8)
   end type lart_tallies
 
+  !--- host set-up helpers of the library (include/lart_gpu.h, "Host set-up helpers"; csrc/lart_host_setup.cpp): in/out records, member for member
+  integer(c_int32_t), parameter :: LART_VEL_NONE = 0, LART_VEL_HUBBLE = 1, LART_VEL_CONSTANT_RADIAL = 2, LART_VEL_PARALLEL = 3, LART_VEL_ROT_SOLID = 4, &
+                                   LART_VEL_ROT_HALO = 5, LART_VEL_POWER_LAW = 6, LART_VEL_LINEAR_DECEL = 7, LART_VEL_SSH = 8
+  type, bind(C) :: lart_host_line
+     integer(c_int32_t) :: line_type, fine_structure, include_deuterium, pad_
+     real(c_double) :: wavelength0, damping, cross0, vtherm1, mass_amu, g_recoil0, DnuHK_Hz, E1, E2, E3
+     real(c_double) :: delta_nu_HD_Hz, ratio_Dfreq_HD, ratio_voigta_HD, nD_over_nH, g_recoil0_D
+     real(c_double) :: P_conv, E_conv(3), wavelength0_Ha
+     character(kind=c_char) :: line_id(32), ion_id(8)
+  end type lart_host_line
+  type, bind(C) :: lart_host_h2
+     integer(c_int32_t) :: n, pad_
+     real(c_double) :: Dfreq_Hz, dv_kms(4), dnu_Hz(4), strength(4), a_damp(4), p_scat(4), pop(4), f_osc(4)
+  end type lart_host_h2
+  type, bind(C) :: lart_host_medium
+     integer(c_int32_t) :: nx, ny, nz, xyz_symmetry, xy_symmetry, velocity_type, pad0_ = 0, pad1_ = 0
+     real(c_double) :: xmax, ymax, zmax, rmin, rmax, cone_opening
+     real(c_double) :: vtherm, wavelength0, damping, cross0, dust_opacity
+     real(c_double) :: taumax, tauhomo, N_gasmax, N_gashomo
+     real(c_double) :: Vexp, Vx, Vy, Vz, Vrot, rinner, velocity_alpha, rpeak, Vpeak, DeltaV
+     real(c_double) :: dx, dy, dz, xmin, ymin, zmin, Dfreq_ref, voigt_amean, taupole_out, tauhomo_out, N_gaspole_out, N_gashomo_out
+     integer(c_int32_t) :: i0, j0, k0, pad2_ = 0
+  end type lart_host_medium
+  type, bind(C) :: lart_host_freq
+     integer(c_int32_t) :: nxfreq, nwavelength, nvelocity, continuum, line_type, nxfreq_Ha, core_skip_global, pad_ = 0
+     real(c_double) :: wavelength_min, wavelength_max, velocity_min, velocity_max, xfreq_min, xfreq_max
+     real(c_double) :: vtherm, wavelength0, wavelength0_Ha, Dfreq_ref, DnuHK_Hz, voigt_amean, tauhomo, taumax, Vexp, xfreq_max_Ha, cells_per_radius
+     real(c_double) :: dxfreq, dwave, atau3, xfreq_min_Ha, dxfreq_Ha, dwave_Ha, xcrit, xcrit2
+  end type lart_host_freq
+  type, bind(C) :: lart_host_obs
+     integer(c_int32_t) :: nside, sphere, nxim, nyim, nobs, npix
+     real(c_double) :: xmax, ymax, zmax, rmax, distance, dxim, dyim, steradian_pix
+  end type lart_host_obs
+  type, bind(C) :: lart_host_clumps_in
+     real(c_double) :: sphere_R, rmin, clump_radius, N_clumps_in, f_vol_in, f_cov_in, clump_tau0, clump_NHI, clump_nH, taumax, N_gasmax, distance2cm
+     real(c_double) :: vtherm, wavelength0, damping, cross0
+     integer(c_int64_t) :: N
+     real(c_double) :: r_min, fvol, fcov, Dfreq_ref, voigt_a_ref, rhokap_ref
+  end type lart_host_clumps_in
+  type, bind(C) :: lart_host_norm
+     integer(c_int32_t) :: xy_periodic, sphere
+     real(c_double) :: nphotons, bin_unit, bin_unit_Ha, distance2cm, rmax, xmax, ymax, zmax, amr_L_box, steradian_pix
+     real(c_double) :: area, scale_J, scale_J_Ha, scale_cube, scale_image, scale_cube_Ha
+  end type lart_host_norm
+
   interface
      function lart_gpu_device_count() bind(C, name='lart_gpu_device_count') result(n)
        import; integer(c_int) :: n
@@ -227,6 +272,56 @@ module lart_gpu_c
      end function
      function lart_gpu_compact(ctx) bind(C, name='lart_gpu_compact') result(rc)
        import; type(c_ptr), value :: ctx; integer(c_int) :: rc
+     end function
+     function lart_host_setup_last_error() bind(C, name='lart_host_setup_last_error') result(p)
+       import; type(c_ptr) :: p
+     end function
+     function lart_host_line_setup(line_id, fine_structure, include_deuterium, D_to_H_ratio, L) bind(C, name='lart_host_line_setup') result(rc)
+       import; character(kind=c_char), intent(in) :: line_id(*); integer(c_int32_t), value :: fine_structure, include_deuterium
+       real(c_double), value :: D_to_H_ratio; type(lart_host_line), intent(out) :: L; integer(c_int) :: rc
+     end function
+     function lart_host_h2_init(path, wavelength0, vtherm1, mass_amu, bturb, T_H2, f_H2, pure_absorption, H) bind(C, name='lart_host_h2_init') result(rc)
+       import; character(kind=c_char), intent(in) :: path(*); real(c_double), value :: wavelength0, vtherm1, mass_amu, bturb, T_H2, f_H2
+       integer(c_int32_t), value :: pure_absorption; type(lart_host_h2), intent(out) :: H; integer(c_int) :: rc
+     end function
+     function lart_host_car_medium(m, xface, yface, zface, rhokap, voigt_a, Dfreq, vfx, vfy, vfz, rhokapD) bind(C, name='lart_host_car_medium') result(rc)
+       import; type(lart_host_medium), intent(inout) :: m; real(c_double), intent(out) :: xface(*), yface(*), zface(*), rhokap(*), voigt_a(*), Dfreq(*), vfx(*), vfy(*), vfz(*)
+       type(c_ptr), value :: rhokapD; integer(c_int) :: rc
+     end function
+     function lart_host_freq_grid(f) bind(C, name='lart_host_freq_grid') result(rc)
+       import; type(lart_host_freq), intent(inout) :: f; integer(c_int) :: rc
+     end function
+     function lart_host_freq_axis(n, xfreq_min, dxfreq, vtherm, wavelength0, xfreq, velocity, wavelength) bind(C, name='lart_host_freq_axis') result(rc)
+       import; integer(c_int32_t), value :: n; real(c_double), value :: xfreq_min, dxfreq, vtherm, wavelength0
+       real(c_double), intent(out) :: xfreq(*), velocity(*), wavelength(*); integer(c_int) :: rc
+     end function
+     function lart_host_jpa_car(geometry_JPa, xyz_symmetry, nx, ny, nz, xface, yface, zface, xmax, ymax, zmax, rhokap, nbins, ind_bin, ncount) &
+                                bind(C, name='lart_host_jpa_car') result(rc)
+       import; integer(c_int32_t), value :: geometry_JPa, xyz_symmetry, nx, ny, nz; real(c_double), intent(in) :: xface(*), yface(*), zface(*), rhokap(*)
+       real(c_double), value :: xmax, ymax, zmax; integer(c_int32_t), intent(out) :: nbins, ind_bin(*); real(c_double), intent(out) :: ncount(*); integer(c_int) :: rc
+     end function
+     function lart_host_observers(o, alpha, beta, gamma, obsx, obsy, obsz, xyz, rmatrix) bind(C, name='lart_host_observers') result(rc)
+       import; type(lart_host_obs), intent(inout) :: o; real(c_double), intent(inout) :: alpha(*), beta(*), gamma(*), obsx(*), obsy(*), obsz(*)
+       real(c_double), intent(out) :: xyz(*), rmatrix(*); integer(c_int) :: rc
+     end function
+     function lart_host_clump_population(c) bind(C, name='lart_host_clump_population') result(rc)
+       import; type(lart_host_clumps_in), intent(inout) :: c; integer(c_int) :: rc
+     end function
+     function lart_host_clump_scalars(n, sphere_R, r_min, cross0, x, y, z, radius, rhokap, voigt_a, Dfreq, out4) bind(C, name='lart_host_clump_scalars') result(rc)
+       import; integer(c_int64_t), value :: n; real(c_double), value :: sphere_R, r_min, cross0
+       real(c_double), intent(in) :: x(*), y(*), z(*), radius(*), rhokap(*), voigt_a(*), Dfreq(*); real(c_double), intent(out) :: out4(4); integer(c_int) :: rc
+     end function
+     function lart_host_clump_velocities(n, velocity_type, sphere_R, Vexp, Vx, Vy, Vz, Vrot, rinner, x, y, z, vtherm, vx_, vy_, vz_) &
+                                         bind(C, name='lart_host_clump_velocities') result(rc)
+       import; integer(c_int64_t), value :: n; integer(c_int32_t), value :: velocity_type; real(c_double), value :: sphere_R, Vexp, Vx, Vy, Vz, Vrot, rinner
+       real(c_double), intent(in) :: x(*), y(*), z(*), vtherm(*); real(c_double), intent(inout) :: vx_(*), vy_(*), vz_(*); integer(c_int) :: rc
+     end function
+     function lart_host_mueller_setup(n, coss, S11, S12, S33, S34, phase_PDF, alias) bind(C, name='lart_host_mueller_setup') result(rc)
+       import; integer(c_int32_t), value :: n; real(c_double), intent(in) :: coss(*); real(c_double), intent(inout) :: S11(*), S12(*), S33(*), S34(*)
+       real(c_double), intent(out) :: phase_PDF(*); integer(c_int32_t), intent(out) :: alias(*); integer(c_int) :: rc
+     end function
+     function lart_host_norm_scales(s) bind(C, name='lart_host_norm_scales') result(rc)
+       import; type(lart_host_norm), intent(inout) :: s; integer(c_int) :: rc
      end function
      function lart_host_entropy_seed(seed) bind(C, name='lart_host_entropy_seed') result(rc)
        import; integer(c_int64_t), intent(out) :: seed; integer(c_int) :: rc

@@ -8,7 +8,7 @@
 !------------------------------------------------------------------------------
 module lart_define
   use, intrinsic :: iso_fortran_env, only: real64, int32, int64
-  use lart_gpu_c, only: lart_line_multiplet
+  use lart_gpu_c, only: lart_line_multiplet, lart_host_h2
   use, intrinsic :: ieee_arithmetic
   implicit none
   public
@@ -192,6 +192,8 @@ module lart_define
      character(len=8) :: ion_id = 'H  I'    ! label of the log lines (grid_mod_car.f90:1231-1234)
      real(wp) :: DnuHK_Hz = 0.0_wp          ! 2P3/2 - 2P1/2 splitting, line type 2 (par%fine_structure)
      real(wp) :: delta_nu_HD_Hz = 0.0_wp, ratio_Dfreq_HD = 1.0_wp, ratio_voigta_HD = 1.0_wp, nD_over_nH = 0.0_wp, g_recoil0_D = 0.0_wp   ! line type 7
+     real(wp) :: mass_amu = 1.00797_wp, P_conv = 0.0_wp, E_conv(3) = [1.0_wp, 0.0_wp, 1.0_wp], wavelength0_Ha = 0.6564553_wp                 ! line type 8 (ly_beta)
+     type(lart_host_h2) :: h2                ! the H2 lines next to Ly-alpha (h2_init), h2%n = 0: off
   end type line_type
 
   type grid_type          ! define.f90:117-206 (tables are contiguous, Fortran order = what the C-ABI takes)
@@ -202,6 +204,9 @@ module lart_define
      real(wp), allocatable :: vfx(:,:,:), vfy(:,:,:), vfz(:,:,:), Dfreq(:,:,:), voigt_a(:,:,:), rhokap(:,:,:)
      real(wp), allocatable :: rhokapD(:,:,:)
      real(wp), allocatable :: Jin(:), Jout(:), Jabs(:), Jmu(:,:)
+     integer  :: nxfreq_Ha = 0                                              ! band 2 (H-alpha) of ly_beta: grid_mod_car.f90:1518-1529
+     real(wp) :: xfreq_min_Ha = 0.0_wp, xfreq_max_Ha = 0.0_wp, dxfreq_Ha = 0.0_wp, dwave_Ha = 0.0_wp
+     real(wp), allocatable :: Jout_Ha(:), Jabs_Ha(:)
   end type grid_type
 
   type observer_type      ! define.f90:547-600
@@ -223,6 +228,7 @@ module lart_define
   real(wp), allocatable, target :: obs_scatt(:,:,:,:), obs_direc(:,:,:,:), obs_I(:,:,:,:), obs_Q(:,:,:,:), obs_U(:,:,:,:), obs_V(:,:,:,:)
   real(wp), allocatable, target :: obs_scatt_2D(:,:,:), obs_direc_2D(:,:,:), obs_I_2D(:,:,:), obs_Q_2D(:,:,:), obs_U_2D(:,:,:), obs_V_2D(:,:,:)
   real(wp), allocatable, target :: obs_direc0(:,:,:,:), obs_direc0_2D(:,:,:), obs_scatt_dust(:,:,:,:)      ! par%save_direc0, par%save_dust_scattered
+  real(wp), allocatable, target :: obs_peel_Ha(:,:,:,:), prof_Pconv(:)                                      ! ly_beta: observer(:)%peel_Ha, the conversion-rate profile
   !--- octree (amr_grid_type, octree_mod.f90:19-138), filled by grid_create_amr
   integer(int32) :: amr_ncells = 0, amr_nleaf = 0, amr_levelmax = 0, amr_nbins = 0
   real(wp) :: amr_lo = 0.0_wp, amr_hi = 0.0_wp, amr_dbin = 0.0_wp
@@ -281,68 +287,60 @@ module lart_host
   implicit none
 contains
 
-  subroutine metal_line(typ, wl, f1, damping, mass, mass_recoil, k_hi, k_lo)
-    integer,  intent(in) :: typ
-    real(wp), intent(in) :: wl, f1, damping, mass, mass_recoil, k_hi, k_lo
-    real(wp), parameter :: sigma_0 = 0.026540083434_wp, amu = 1.67262192e-24_wp, vtherm1_amu = 0.12895319011972164_wp
-    line%line_type = typ; line%wavelength0 = wl; line%damping = damping
-    line%cross0    = sigma_0/sqrt(pi)*f1
-    line%vtherm1   = vtherm1_amu/sqrt(mass)
-    line%g_recoil0 = (h_planck/amu/mass_recoil)/(wl*um2m)**2
-    line%DnuHK_Hz  = 0.0_wp
-    if (typ == 2) line%DnuHK_Hz = (2.99792458e5_wp*1.0e5_wp)*(k_hi - k_lo)
-    par%fine_structure = .false.; par%include_deuterium = .false.
-  end subroutine metal_line
+  !--- message of the host helpers of the library, then stop (reference convention: print and abort)
+  subroutine setup_check(rc, where)
+    integer(c_int), intent(in) :: rc
+    character(len=*), intent(in) :: where
+    character(kind=c_char), pointer :: msg(:)
+    type(c_ptr) :: p
+    integer :: n
+    if (rc == 0) return
+    p = lart_host_setup_last_error()
+    call c_f_pointer(p, msg, [1024])
+    n = 0
+    do while (n < 1024)
+       if (msg(n+1) == c_null_char) exit
+       n = n + 1
+    enddo
+    write(*,'(64a)') msg(1:min(n,1024))
+    write(*,'(2a)') '   in ', where
+    stop 1
+  end subroutine setup_check
 
-  !--- setup_resonance_line, Ly-alpha branch: line_mod.f90:1241-1270
-  subroutine setup_resonance_line()
-    real(wp), parameter :: sigma_0 = 0.026540083434_wp, amu = 1.67262192e-24_wp, vtherm1_amu = 0.12895319011972164_wp
-    real(wp) :: mass_amu
+  pure function cstring(c) result(t)
+    character(kind=c_char), intent(in) :: c(:)
+    character(len=size(c)) :: t
     integer :: i
-    line%wavelength0 = 0.1215668237310_wp
-    line%damping     = 6.2649e8_wp
-    line%cross0      = sigma_0/sqrt(pi)*(0.27760_wp + 0.13881_wp + 0.0_wp)
-    mass_amu         = 1.00797_wp
-    line%vtherm1     = vtherm1_amu/sqrt(mass_amu)
-    line%g_recoil0   = (h_planck/amu/mass_amu)/(line%wavelength0*um2m)**2
-    line%E1 = 1.0_wp; line%E2 = 0.0_wp; line%E3 = 1.0_wp
-    line%line_type = 1; line%DnuHK_Hz = 0.0_wp
-    if (lart_host_line_lookup(trim(par%line_id)//c_null_char, line%ml) == 0) then     ! resonance + fluorescence multiplets: line_mod.f90:713-1153
+    t = ''
+    do i = 1, size(c)
+       if (c(i) == c_null_char) exit
+       t(i:i) = c(i)
+    enddo
+  end function cstring
+
+  !--- setup_resonance_line (line_mod.f90:551-1272): the constants of par%line_id from the library -- lart_host_line_setup for 'ly_alpha' (with
+  !--- par%fine_structure / par%include_deuterium), 'ly_alpha_HD', 'ly_beta' and the single lines / doublets, lart_host_line_lookup for the multiplets
+  subroutine setup_resonance_line()
+    type(lart_host_line) :: h
+    integer(c_int) :: rc
+    rc = lart_host_line_setup(trim(par%line_id)//c_null_char, merge(1, 0, par%fine_structure), merge(1, 0, par%include_deuterium), par%D_to_H_ratio, h)
+    if (rc == 2) then                                                   ! resonance + fluorescence multiplets, line types 4, 5, 6
+       rc = lart_host_line_lookup(trim(par%line_id)//c_null_char, line%ml)
        line%line_type = line%ml%line_type; line%wavelength0 = line%ml%wavelength0; line%damping = line%ml%damping; line%cross0 = line%ml%cross0
        line%vtherm1 = line%ml%vtherm1; line%g_recoil0 = line%ml%g_recoil0; line%DnuHK_Hz = 0.0_wp
-       line%ion_id = ''
-       do i = 1, 8
-          if (line%ml%ion_id(i) == c_null_char) exit
-          line%ion_id(i:i) = line%ml%ion_id(i)
-       enddo
+       line%E1 = 1.0_wp; line%E2 = 0.0_wp; line%E3 = 1.0_wp
+       line%ion_id = cstring(line%ml%ion_id)
        line%ml%HeI_coherent = merge(1, 0, par%HeI_coherent .and. line%line_type == 6)
        par%fine_structure = .false.; par%include_deuterium = .false.
        return
     endif
-    select case (trim(par%line_id))                                     ! single lines / S-P doublets: line_mod.f90:590-713
-    case ('CIV_1548');  line%ion_id = 'C IV'; call metal_line(2, 0.1548187_wp,    0.190_wp, 2.647e8_wp,    12.011_wp,   1.00797_wp,  64591.7_wp,     64484.0_wp)   ! (:605: recoil with line%mass_amu's default)
-    case ('NV_1239');   line%ion_id = 'N V'; call metal_line(2, 0.1238821_wp,    0.156_wp, 3.390e8_wp,    14.0067_wp,  14.0067_wp,  80721.9_wp,     80463.2_wp)
-    case ('OVI_1032');  line%ion_id = 'O VI'; call metal_line(2, 0.1031912_wp,    0.133_wp, 4.137e8_wp,    15.9994_wp,  15.9994_wp,  96907.5_wp,     96375.0_wp)
-    case ('NaI_D');     line%ion_id = 'Na I'; call metal_line(2, 0.5891583253_wp, 0.641_wp, 6.153e7_wp,    22.98977_wp, 22.98977_wp, 16973.36619_wp, 16956.17025_wp)
-    case ('CaII_HK');   line%ion_id = 'Ca II'; call metal_line(2, 0.3934777_wp,    0.682_wp, 1.446667e8_wp, 40.078_wp,   40.078_wp,   25414.40_wp,    25191.51_wp)
-    case ('MgII_2796'); line%ion_id = 'Mg II'; call metal_line(2, 0.2796352_wp,    0.608_wp, 2.590e8_wp,    24.305_wp,   24.305_wp,   35760.88_wp,    35669.31_wp)
-    case ('SiIV_1394'); line%ion_id = 'Si IV'; call metal_line(2, 0.1393755_wp,    0.513_wp, 8.743e8_wp,    28.0855_wp,  28.0855_wp,  71748.64_wp,    71287.54_wp)
-    case ('AlII_1671'); line%ion_id = 'Al II'; call metal_line(1, 0.16707874_wp,   1.77_wp,  1.41e9_wp, real(26.98154, wp), real(26.98154, wp), 0.0_wp, 0.0_wp)       ! (:706: a default-kind literal)
-    end select
-    if (line%line_type /= 1 .or. trim(par%line_id) == 'AlII_1671') return
-    if (par%include_deuterium .and. trim(par%line_id) == 'ly_alpha') par%line_id = 'ly_alpha_HD'       ! line_mod.f90:580-588
-    if (trim(par%line_id) == 'ly_alpha_HD') then                         ! :1155-1191: hydrogen + deuterium, no fine structure
-       par%fine_structure = .false.
-       line%line_type = 7; line%nD_over_nH = par%D_to_H_ratio; line%ion_id = 'H+D'
-       line%delta_nu_HD_Hz  = (2.99792458e5_wp*1.0e5_wp)*(1.0_wp/(0.1215337431_wp*um2m*1.0e2_wp) - 1.0_wp/(line%wavelength0*um2m*1.0e2_wp))
-       line%ratio_Dfreq_HD  = (0.1215337431_wp/line%wavelength0)*sqrt(2.01410177812_wp/mass_amu)
-       line%ratio_voigta_HD = (6.2649e8_wp/line%damping)*line%ratio_Dfreq_HD
-       line%g_recoil0_D     = (h_planck/amu/2.01410177812_wp)/(0.1215337431_wp*um2m)**2
-    endif
-    if (par%fine_structure) then                                        ! line_mod.f90:1246-1253
-       line%line_type = 2
-       line%DnuHK_Hz  = 82259.2850014_wp*(2.99792458e5_wp*1.0e5_wp) - 82258.9191133_wp*(2.99792458e5_wp*1.0e5_wp)
-    endif
+    call setup_check(rc, 'setup_resonance_line')
+    line%line_type = h%line_type; line%wavelength0 = h%wavelength0; line%damping = h%damping; line%cross0 = h%cross0; line%vtherm1 = h%vtherm1
+    line%g_recoil0 = h%g_recoil0; line%DnuHK_Hz = h%DnuHK_Hz; line%E1 = h%E1; line%E2 = h%E2; line%E3 = h%E3; line%mass_amu = h%mass_amu
+    line%delta_nu_HD_Hz = h%delta_nu_HD_Hz; line%ratio_Dfreq_HD = h%ratio_Dfreq_HD; line%ratio_voigta_HD = h%ratio_voigta_HD
+    line%nD_over_nH = h%nD_over_nH; line%g_recoil0_D = h%g_recoil0_D; line%P_conv = h%P_conv; line%E_conv = h%E_conv; line%wavelength0_Ha = h%wavelength0_Ha
+    line%ion_id = cstring(h%ion_id); par%line_id = cstring(h%line_id)
+    par%fine_structure = h%fine_structure /= 0; par%include_deuterium = h%include_deuterium /= 0
   end subroutine setup_resonance_line
 
   !--- fields of the reference's params_type that select physics or inputs outside this path: any non-default value stops the run
@@ -390,19 +388,8 @@ contains
     if (par%save_backup) call not_supported('par%save_backup')
     if (par%save_input_grid) call not_supported('par%save_input_grid')
     if (par%use_cie_condition) call not_supported('par%use_cie_condition')
-    if (par%nxfreq_Ha /= 0) call not_supported('par%nxfreq_Ha')
-    if (par%xfreq_max_Ha /= 0.0_wp) call not_supported('par%xfreq_max_Ha')
     if (par%ny_2gam /= 101) call not_supported('par%ny_2gam')
-    if (par%cext_dust_Ha /= 3.801e-22_wp) call not_supported('par%cext_dust_Ha')
-    if (par%albedo_Ha /= 0.6741_wp) call not_supported('par%albedo_Ha')
-    if (par%hgg_Ha /= 0.4967_wp) call not_supported('par%hgg_Ha')
     if (par%transport_2gamma) call not_supported('par%transport_2gamma')
-    if (par%R_Ha /= 0.0_wp) call not_supported('par%R_Ha')
-    if (par%f_H2 /= 0.0_wp) call not_supported('par%f_H2')
-    if (par%h2_temperature /= 1000.0_wp) call not_supported('par%h2_temperature')
-    if (par%h2_pure_absorption) call not_supported('par%h2_pure_absorption')
-    if (par%h2_hi_width) call not_supported('par%h2_hi_width')
-    if (trim(par%h2_data_dir) /= '') call not_supported('par%h2_data_dir')
     if (trim(par%line_prof_file) /= '') call not_supported('par%line_prof_file')
     if (par%line_prof_file_type /= 0) call not_supported('par%line_prof_file_type')
     if (par%reduce_factor /= 1) call not_supported('par%reduce_factor')
@@ -461,11 +448,10 @@ contains
     select case (trim(par%line_id))
     case ('CII_1334', 'SiII_1527', 'SiII_1260', 'SiII_1193', 'SiII_1190', 'SiII_1304', 'FeII_2250', 'FeII_2261', 'FeII_UV3', 'FeII_2344', 'FeII_UV1', 'FeII_2600', &
           'FeII_UV2', 'FeII_2383', 'HeI_10833')
-    case ('ly_alpha', 'ly_alpha_HD', 'CIV_1548', 'NV_1239', 'OVI_1032', 'NaI_D', 'CaII_HK', 'MgII_2796', 'SiIV_1394', 'AlII_1671')
+    case ('ly_alpha', 'ly_alpha_HD', 'ly_beta', 'CIV_1548', 'NV_1239', 'OVI_1032', 'NaI_D', 'CaII_HK', 'MgII_2796', 'SiIV_1394', 'AlII_1671')
     case default
        call not_supported('par%line_id = '//trim(par%line_id))
     end select
-    if (trim(strlowcase(par%h2_model)) /= 'none') call not_supported('par%h2_model')
     if (par%z_symmetry) call not_supported('par%z_symmetry')
     if (par%xy_symmetry) then                       ! mirrors in x and y, the full z range (grid_mod_car.f90:113-134)
        if (par%xyz_symmetry .or. par%xy_periodic .or. par%use_clump_medium) &
@@ -536,6 +522,10 @@ contains
     if (par%cext_dust <= 0.0_wp) par%DGR       = 0.0_wp
     if (par%DGR == 0.0_wp)       par%save_Jabs = .false.
     if (par%core_skip_global)    par%core_skip = .true.
+
+    if (line%line_type == 8) call ly_beta_rules()                                               ! setup.f90:239-300
+    par%h2_model = strlowcase(par%h2_model)
+    if (trim(par%h2_model) /= 'none') call h2_rules()                                           ! setup.f90:302-365
 
     if (par%save_Jmu) then                                                                      ! :367-381
        if (par%nmu < 1) then
@@ -614,6 +604,64 @@ contains
     if (par%DGR > 0.0) write(*,'(a,es12.3)') 'Dust Extinction per H     : ', par%cext_dust
     write(*,'(a,es12.3)') 'Total number of photons   : ', par%no_photons
   contains
+    !--- 'ly_beta' (line type 8): what the band-2 path cannot do is refused, core-skipping would bias the conversion rate, the dust of band 1 takes the
+    !--- Draine values at 1026 A when the input left the three defaults alone, and R_Ha is the ratio of the two extinction cross-sections
+    subroutine ly_beta_rules()
+      character(len=64) :: why
+      why = ''
+      if (par%use_clump_medium) then
+         why = 'clump medium'
+      else if (par%nside > 0) then
+         why = 'inside-observer (HEALPix)'
+      else if (par%use_stokes) then
+         why = 'Stokes polarization'
+      else if (par%xyz_symmetry .or. par%xy_symmetry .or. par%xy_periodic .or. par%Omega /= 0.0_wp) then
+         why = 'xyz/xy symmetry, xy_periodic and shear'
+      endif
+      if (len_trim(why) > 0) then
+         write(*,'(3a)') 'ly_beta: ', trim(why), ' not yet supported'; stop 1
+      endif
+      if (par%core_skip .or. par%core_skip_global) write(*,'(a)') 'NOTE: ly_beta forces core_skip = .false. (core-skip would bias the conversion rate).'
+      par%core_skip = .false.; par%core_skip_global = .false.
+      !--- (the reference compares with double-precision literals while the defaults are single-precision ones widened to double, define.f90:454-456:
+      !---  the re-default only happens when the input sets those double values itself)
+      if (par%albedo == 0.3253_wp .and. par%hgg == 0.6761_wp .and. par%cext_dust == 1.6059e-21_wp) then
+         par%albedo = 0.2804_wp; par%hgg = 0.6483_wp; par%cext_dust = 2.047e-21_wp
+         write(*,'(a)') 'NOTE: ly_beta re-defaults band-1 dust constants to Draine 1026A values (cext=2.047e-21, albedo=0.2804, hgg=0.6483).'
+      endif
+      par%R_Ha = 0.0_wp
+      if (par%cext_dust_Ha > 0.0_wp .and. par%cext_dust > 0.0_wp) par%R_Ha = par%cext_dust_Ha/par%cext_dust
+    end subroutine ly_beta_rules
+    !--- the H2 Lyman-band lines next to Ly-alpha (par%h2_model = 'neufeld'): refusals as the reference's, then h2_init through the library
+    subroutine h2_rules()
+      character(len=96) :: why
+      character(len=256) :: dir
+      why = ''
+      if (line%line_type /= 1) then
+         why = "only supported for line_id = 'ly_alpha' (line_type 1)"
+      else if (trim(par%h2_model) /= 'neufeld') then
+         why = "Phase 1 supports only h2_model='neufeld'; got "//trim(par%h2_model)
+      else if (par%use_clump_medium) then
+         why = 'clump medium not yet supported'
+      else if (par%nside > 0) then
+         why = 'inside-observer (HEALPix) not yet supported'
+      else if (par%use_stokes) then
+         why = 'Stokes polarization not yet supported'
+      else if (par%xyz_symmetry .or. par%xy_symmetry .or. par%Omega /= 0.0_wp) then
+         why = 'xyz/xy symmetry and shear not yet supported'
+      else if (par%xy_periodic .and. (par%nx > 1 .or. par%ny > 1)) then
+         why = 'xy_periodic supported only for the nx=ny=1 slab'
+      else if (.not. par%f_H2 > 0.0_wp) then
+         why = "par%f_H2 must be > 0 when h2_model /= 'none'"
+      endif
+      if (len_trim(why) > 0) then
+         write(*,'(2a)') 'H2: ', trim(why); stop 1
+      endif
+      dir = par%h2_data_dir
+      if (len_trim(dir) == 0) dir = 'data/h2'
+      call setup_check(lart_host_h2_init(trim(dir)//'/energy_X.dat'//c_null_char, line%wavelength0, line%vtherm1, line%mass_amu, par%bturb, par%h2_temperature, &
+                                         par%f_H2, merge(1, 0, par%h2_pure_absorption), line%h2), 'h2_init')
+    end subroutine h2_rules
     !--- the shipped example inputs assign real literals to integer fields (par%nprint = 1e5), which ifort and
     !--- gfortran accept and flang rejects: copy the file to a scratch unit with those literals made integer.
     subroutine open_sanitized(fname, uout)
@@ -677,67 +725,26 @@ contains
     end function base_of
   end subroutine read_input
 
-  !--- random_alias_setup64: random_mt.f90:2016-2067
-  subroutine random_alias_setup(probs, alias)
-    real(wp), intent(inout) :: probs(:)
-    integer(int32), intent(out) :: alias(:)
-    integer, allocatable :: small(:), large(:)
-    integer :: n, i, ns, nl, ks, kl
-    n = size(probs)
-    allocate(small(n), large(n)); small = 0; large = 0; alias = 0
-    ns = 0; nl = 0
-    do i = 1, n
-       probs(i) = n * probs(i)
-       if (probs(i) < 1.0_wp) then
-          ns = ns + 1; small(ns) = i
-       else
-          nl = nl + 1; large(nl) = i
-       endif
-    enddo
-    do while (ns > 0 .and. nl > 0)
-       ks = small(ns); kl = large(nl); ns = ns - 1; nl = nl - 1
-       alias(ks) = kl
-       probs(kl) = probs(kl) + probs(ks) - 1.0_wp
-       if (probs(kl) < 1.0_wp) then
-          ns = ns + 1; small(ns) = kl
-       else
-          nl = nl + 1; large(nl) = kl
-       endif
-    enddo
-  end subroutine random_alias_setup
-
-  !--- setup_scattering_matrix: setup.f90:581-649
+  !--- setup_scattering_matrix (setup.f90:581-649): the header of the table overrides albedo / hgg / cext_dust; lart_host_mueller_setup normalises the
+  !--- columns by the integral of S11 and builds the alias table of the scattering-angle bins
   subroutine setup_scattering_matrix(fname)
     character(len=*), intent(in) :: fname
-    character(len=128) :: string_tmp
-    real(wp) :: wavelength, cext, albedo, hgg, S11_norm
-    integer :: i, unit, n, ios
-    open(newunit=unit, file=fname, status='old', iostat=ios)
+    character(len=128) :: skip
+    real(wp) :: wl
+    integer :: i, u, n, ios
+    open(newunit=u, file=fname, status='old', iostat=ios)
     if (ios /= 0) then
        write(*,'(2a)') 'ERROR: cannot open par%scatt_mat_file ', fname; stop 1
     endif
-    read(unit,*) string_tmp
-    read(unit,*) wavelength, cext, albedo, hgg, n
-    par%albedo = albedo; par%hgg = hgg; par%cext_dust = cext
-    read(unit,*) string_tmp
+    read(u,*) skip
+    read(u,*) wl, par%cext_dust, par%albedo, par%hgg, n
+    read(u,*) skip
     scatt_mat%nPDF = n
-    allocate(scatt_mat%coss(n), scatt_mat%S11(n), scatt_mat%S12(n), scatt_mat%S33(n), scatt_mat%S34(n))
-    allocate(scatt_mat%phase_PDF(n-1), scatt_mat%alias(n-1))
-    do i = 1, n
-       read(unit,*) scatt_mat%coss(i), scatt_mat%S11(i), scatt_mat%S12(i), scatt_mat%S33(i), scatt_mat%S34(i)
-    enddo
-    close(unit)
-    S11_norm = 0.0_wp                                  ! calc_Integral, mathlib.f90:218-240
-    do i = 2, n
-       S11_norm = S11_norm + 0.5_wp*(scatt_mat%S11(i) + scatt_mat%S11(i-1))*abs(scatt_mat%coss(i) - scatt_mat%coss(i-1))
-    enddo
-    scatt_mat%S11 = scatt_mat%S11/S11_norm; scatt_mat%S12 = scatt_mat%S12/S11_norm
-    scatt_mat%S33 = scatt_mat%S33/S11_norm; scatt_mat%S34 = scatt_mat%S34/S11_norm
-    do i = 1, n-1
-       scatt_mat%phase_PDF(i) = (scatt_mat%S11(i) + scatt_mat%S11(i+1))/2.0_wp
-    enddo
-    scatt_mat%phase_PDF = scatt_mat%phase_PDF / sum(scatt_mat%phase_PDF)
-    call random_alias_setup(scatt_mat%phase_PDF, scatt_mat%alias)
+    allocate(scatt_mat%coss(n), scatt_mat%S11(n), scatt_mat%S12(n), scatt_mat%S33(n), scatt_mat%S34(n), scatt_mat%phase_PDF(n-1), scatt_mat%alias(n-1))
+    read(u,*) (scatt_mat%coss(i), scatt_mat%S11(i), scatt_mat%S12(i), scatt_mat%S33(i), scatt_mat%S34(i), i = 1, n)
+    close(u)
+    call setup_check(lart_host_mueller_setup(int(n, c_int32_t), scatt_mat%coss, scatt_mat%S11, scatt_mat%S12, scatt_mat%S33, scatt_mat%S34, &
+                                             scatt_mat%phase_PDF, scatt_mat%alias), 'setup_scattering_matrix')
   end subroutine setup_scattering_matrix
 
   !--- H(0,a) on the x = 0 node of the Voigt table (voigt_mod.f90:691-700 with v = 0)
@@ -747,274 +754,67 @@ contains
     h = 1.0_wp + a*(-1.1283791671_wp + a*1.0_wp)
   end function voigt0
 
-  !--- grid_create: grid_mod_car.f90:73-1238, analytic-medium subset
+  function velocity_code(name) result(c)
+    character(len=*), intent(in) :: name
+    integer(c_int32_t) :: c
+    select case (trim(name))
+    case ('');                     c = LART_VEL_NONE
+    case ('hubble');               c = LART_VEL_HUBBLE
+    case ('constant_radial');      c = LART_VEL_CONSTANT_RADIAL
+    case ('parallel_velocity');    c = LART_VEL_PARALLEL
+    case ('rotating_solid_body');  c = LART_VEL_ROT_SOLID
+    case ('rotating_galaxy_halo'); c = LART_VEL_ROT_HALO
+    case ('power_law');            c = LART_VEL_POWER_LAW
+    case ('linear_decelerate');    c = LART_VEL_LINEAR_DECEL
+    case ('ssh');                  c = LART_VEL_SSH
+    case default;                  c = -1
+    end select
+  end function velocity_code
+
+  !--- grid_create (grid_mod_car.f90:73-1238), analytic-medium subset: the library builds the axes, the density mask of the shell / bicone, the opacity
+  !--- normalisation and the velocity field (lart_host_car_medium), then the spectral axis and the core-skip scale (car_setup_freq_grid)
   subroutine grid_create(grid)
-    type(grid_type), intent(inout) :: grid
-    integer  :: i, j, k, nx, ny, nz, nxcen, nycen
-    real(wp) :: rr, vtherm, opac_length, opacity_sum, opacity1, opac_norm, nopac, nadd, os2
-    real(wp) :: tauhomo, taupole, N_gashomo, N_gaspole, atau0, atau0_cell, xi, chi, rpeak, Vscale
-    real(wp), allocatable :: xx(:), yy(:), zz(:)
-
-    grid%nx = par%nx; grid%ny = par%ny; grid%nz = par%nz
+    type(grid_type), intent(inout), target :: grid
+    type(lart_host_medium) :: m
+    type(c_ptr) :: pD
+    integer :: nx, ny, nz
+    nx = par%nx; ny = par%ny; nz = par%nz
+    grid%nx = nx; grid%ny = ny; grid%nz = nz
     grid%xmax = par%xmax; grid%ymax = par%ymax; grid%zmax = par%zmax; grid%rmin = par%rmin; grid%rmax = par%rmax
-    nx = grid%nx; ny = grid%ny; nz = grid%nz
-    if (par%xyz_symmetry) then                                                                  ! :85-112
-       call sym_axis(nx, grid%xmax, grid%dx, grid%xmin, grid%i0)
-       call sym_axis(ny, grid%ymax, grid%dy, grid%ymin, grid%j0)
-       call sym_axis(nz, grid%zmax, grid%dz, grid%zmin, grid%k0)
-    else if (par%xy_symmetry) then                                                              ! :113-134
-       call sym_axis(nx, grid%xmax, grid%dx, grid%xmin, grid%i0)
-       call sym_axis(ny, grid%ymax, grid%dy, grid%ymin, grid%j0)
-       grid%dz = 2.0_wp*par%zmax/par%nz; grid%zmin = -grid%zmax; grid%k0 = 0
-    else                                                                                        ! :166-176
-       grid%dx = 2.0_wp*par%xmax/par%nx; grid%dy = 2.0_wp*par%ymax/par%ny; grid%dz = 2.0_wp*par%zmax/par%nz
-       grid%xmin = -grid%xmax; grid%ymin = -grid%ymax; grid%zmin = -grid%zmax
-       grid%i0 = 0; grid%j0 = 0; grid%k0 = 0
-    endif
-    grid%xrange = grid%xmax - grid%xmin; grid%yrange = grid%ymax - grid%ymin; grid%zrange = grid%zmax - grid%zmin
-    allocate(grid%xface(nx+1), grid%yface(ny+1), grid%zface(nz+1))
-    grid%xface(:) = [ ((i-1)*grid%dx + grid%xmin, i=1,nx+1) ]
-    grid%yface(:) = [ ((j-1)*grid%dy + grid%ymin, j=1,ny+1) ]
-    grid%zface(:) = [ ((k-1)*grid%dz + grid%zmin, k=1,nz+1) ]
-    allocate(grid%vfx(nx,ny,nz), grid%vfy(nx,ny,nz), grid%vfz(nx,ny,nz), grid%Dfreq(nx,ny,nz), grid%voigt_a(nx,ny,nz), grid%rhokap(nx,ny,nz))
-    if (par%DGR > 0.0_wp) allocate(grid%rhokapD(nx,ny,nz))
-    grid%vfx = 0.0_wp; grid%vfy = 0.0_wp; grid%vfz = 0.0_wp
-    allocate(xx(nx), yy(ny), zz(nz))
-    do i = 1, nx; xx(i) = (grid%xface(i) + grid%xface(i+1))/2.0_wp; enddo
-    do j = 1, ny; yy(j) = (grid%yface(j) + grid%yface(j+1))/2.0_wp; enddo
-    do k = 1, nz; zz(k) = (grid%zface(k) + grid%zface(k+1))/2.0_wp; enddo
-
-    grid%Dfreq_ref = vtherm_total(par%temperature)/(line%wavelength0*um2km)                      ! :238
-    vtherm = vtherm_total(par%temperature)                                                      ! :273-284
-    grid%Dfreq   = vtherm/(line%wavelength0*um2km)
-    grid%voigt_a = (line%damping/fourpi)/grid%Dfreq
-    if (.not. par%use_clump_medium) then                                                        ! :352-363: the clump population carries the length unit
+    m%nx = nx; m%ny = ny; m%nz = nz; m%xyz_symmetry = merge(1, 0, par%xyz_symmetry); m%xy_symmetry = merge(1, 0, par%xy_symmetry)
+    m%velocity_type = velocity_code(par%velocity_type)
+    m%xmax = par%xmax; m%ymax = par%ymax; m%zmax = par%zmax; m%rmin = par%rmin; m%rmax = par%rmax; m%cone_opening = par%cone_opening
+    m%vtherm = vtherm_total(par%temperature); m%wavelength0 = line%wavelength0; m%damping = line%damping; m%cross0 = line%cross0
+    m%dust_opacity = par%cext_dust*par%DGR
+    m%taumax = par%taumax; m%tauhomo = par%tauhomo; m%N_gasmax = par%N_gasmax; m%N_gashomo = par%N_gashomo
+    m%Vexp = par%Vexp; m%Vx = par%Vx; m%Vy = par%Vy; m%Vz = par%Vz; m%Vrot = par%Vrot; m%rinner = par%rinner
+    m%velocity_alpha = par%velocity_alpha; m%rpeak = par%rpeak; m%Vpeak = par%Vpeak; m%DeltaV = par%DeltaV
+    if (.not. par%use_clump_medium) then                                 ! the clump population carries the physical length unit
        par%distance_unit = ''; par%distance2cm = 1.0_wp
     endif
-    grid%rhokap = 1.0_wp
-    if (par%DGR > 0.0_wp) grid%rhokapD = par%cext_dust * par%DGR
-    if (par%rmax > 0.0_wp) then                                                                 ! :367-395
-       do k = 1, nz; do j = 1, ny; do i = 1, nx
-          rr = sqrt(xx(i)**2 + yy(j)**2 + zz(k)**2)
-          if (rr < par%rmin .or. rr > par%rmax) then
-             grid%rhokap(i,j,k) = 0.0_wp
-             if (par%DGR > 0.0_wp) grid%rhokapD(i,j,k) = 0.0_wp
-          endif
-       enddo; enddo; enddo
+    allocate(grid%xface(nx+1), grid%yface(ny+1), grid%zface(nz+1))
+    allocate(grid%vfx(nx,ny,nz), grid%vfy(nx,ny,nz), grid%vfz(nx,ny,nz), grid%Dfreq(nx,ny,nz), grid%voigt_a(nx,ny,nz), grid%rhokap(nx,ny,nz))
+    pD = c_null_ptr
+    if (par%DGR > 0.0_wp) then
+       allocate(grid%rhokapD(nx,ny,nz)); pD = c_loc(grid%rhokapD)
     endif
-    if (par%cone_opening > 0.0_wp .and. par%cone_opening < 90.0_wp) then                        ! :397-412 biconical mask about the z axis
-       do k = 1, nz; do j = 1, ny; do i = 1, nx
-          rr = sqrt(xx(i)**2 + yy(j)**2 + zz(k)**2)
-          if (rr > 0.0_wp) then
-             if (abs(zz(k))/rr < cos(par%cone_opening*deg2rad)) then
-                grid%rhokap(i,j,k) = 0.0_wp
-                if (par%DGR > 0.0_wp) grid%rhokapD(i,j,k) = 0.0_wp
-             endif
-          endif
-       enddo; enddo; enddo
-    endif
-    grid%rhokap = grid%rhokap/grid%Dfreq*line%cross0                                            ! :487-493
-    if (par%rmax > 0.0_wp .and. par%rmin > 0.0_wp) then                                         ! :495-503
-       opac_length = par%rmax - par%rmin
-    else if (par%rmax > 0.0_wp) then
-       opac_length = par%rmax
-    else if (grid%zmax == -grid%zmin) then
-       opac_length = grid%zrange/2.0_wp
-    else
-       opac_length = grid%zrange
-    endif
-    if (par%xyz_symmetry .or. par%xy_symmetry) then
-       nxcen = 1; nycen = 1
-    else
-       nxcen = (nx+1)/2; nycen = (ny+1)/2
-    endif
-
-    if (par%taumax > 0.0_wp) then                                                               ! :518-538
-       opacity_sum = 0.0_wp
-       do k = 1, nz
-          opacity_sum = opacity_sum + grid%rhokap(nxcen,nycen,k)*voigt0(grid%voigt_a(nxcen,nycen,k))
-       enddo
-       if (par%xyz_symmetry) then
-          if ((nz/2)*2 == nz) then
-             opac_norm = par%taumax/(opacity_sum*grid%dz)
-          else
-             opacity1  = grid%rhokap(nxcen,nycen,1)*voigt0(grid%voigt_a(nxcen,nycen,1))
-             opac_norm = par%taumax/((opacity_sum - opacity1/2.0_wp)*grid%dz)
-          endif
-       else if (grid%zmax == -grid%zmin) then
-          opac_norm = (2.0_wp*par%taumax)/(opacity_sum*grid%dz)
-       else
-          opac_norm = par%taumax/(opacity_sum*grid%dz)
-       endif
-       call scale_opacity(opac_norm)
-    else if (par%tauhomo > 0.0_wp) then                                                         ! :539-566
-       call homo_sums(opacity_sum, os2, nopac)
-       call scale_opacity(par%tauhomo/(opacity_sum/nopac*opac_length))
-    else if (par%N_gasmax > 0.0_wp) then                                                        ! :567-586
-       opacity_sum = 0.0_wp
-       do k = 1, nz
-          opacity_sum = opacity_sum + grid%rhokap(nxcen,nycen,k)*grid%Dfreq(nxcen,nycen,k)
-       enddo
-       if (par%xyz_symmetry) then
-          if ((nz/2)*2 == nz) then
-             opac_norm = par%N_gasmax/(opacity_sum*grid%dz/line%cross0)
-          else
-             opacity1  = grid%rhokap(nxcen,nycen,1)*grid%Dfreq(nxcen,nycen,1)
-             opac_norm = par%N_gasmax/((opacity_sum - opacity1/2.0_wp)*grid%dz/line%cross0)
-          endif
-       else if (grid%zmax == -grid%zmin) then
-          opac_norm = (2.0_wp*par%N_gasmax)/(opacity_sum*grid%dz/line%cross0)
-       else
-          opac_norm = par%N_gasmax/(opacity_sum*grid%dz/line%cross0)
-       endif
-       call scale_opacity(opac_norm)
-    else if (par%N_gashomo > 0.0_wp) then                                                       ! :587-615
-       call homo_sums(opacity_sum, os2, nopac)
-       call scale_opacity(par%N_gashomo/((os2/nopac/line%cross0)*opac_length))
-    endif
-
-    call homo_sums(opacity_sum, os2, nopac)                                                     ! :617-737
-    tauhomo   = opacity_sum/nopac*opac_length
-    N_gashomo = os2/nopac/line%cross0*opac_length
-    opacity_sum = 0.0_wp; os2 = 0.0_wp
-    do k = 1, nz
-       opacity_sum = opacity_sum + grid%rhokap(nxcen,nycen,k)*voigt0(grid%voigt_a(nxcen,nycen,k))
-       os2         = os2 + grid%rhokap(nxcen,nycen,k)*grid%Dfreq(nxcen,nycen,k)
-    enddo
-    if (par%xyz_symmetry) then
-       taupole = opacity_sum*grid%dz; N_gaspole = os2*grid%dz/line%cross0
-       if ((nz/2)*2 /= nz) then
-          taupole   = taupole - grid%rhokap(nxcen,nycen,1)*voigt0(grid%voigt_a(nxcen,nycen,1))*grid%dz/2.0_wp
-          N_gaspole = N_gaspole - grid%rhokap(nxcen,nycen,1)*grid%Dfreq(nxcen,nycen,1)*grid%dz/2.0_wp/line%cross0
-       endif
-    else if (grid%zmax == -grid%zmin) then
-       taupole = opacity_sum*grid%dz/2.0_wp; N_gaspole = os2*grid%dz/2.0_wp/line%cross0
-    else
-       taupole = opacity_sum*grid%dz; N_gaspole = os2*grid%dz/line%cross0
-    endif
-    if (par%taumax    <= 0.0_wp) par%taumax    = taupole
-    if (par%tauhomo   <= 0.0_wp) par%tauhomo   = tauhomo
-    if (par%N_gasmax  <= 0.0_wp) par%N_gasmax  = N_gaspole
-    if (par%N_gashomo <= 0.0_wp) par%N_gashomo = N_gashomo
-
-    if (len_trim(par%velocity_type) > 0) then                                                   ! :786-946
-       if (par%rmax <= 0.0_wp) then
-          rpeak = maxval([grid%xmax, grid%ymax, grid%zmax])
-       else
-          rpeak = par%rmax
-       endif
-       do k = 1, nz; do j = 1, ny; do i = 1, nx
-          if (grid%rhokap(i,j,k) > 0.0_wp) then
-             select case(trim(par%velocity_type))
-             case ('hubble')
-                grid%vfx(i,j,k) = (par%Vexp/vtherm)*xx(i)/rpeak
-                grid%vfy(i,j,k) = (par%Vexp/vtherm)*yy(j)/rpeak
-                grid%vfz(i,j,k) = (par%Vexp/vtherm)*zz(k)/rpeak
-             case ('constant_radial')
-                rr = sqrt(xx(i)**2 + yy(j)**2 + zz(k)**2)
-                if (rr > grid%dz/10.0_wp) then
-                   grid%vfx(i,j,k) = par%Vexp/vtherm*xx(i)/rr
-                   grid%vfy(i,j,k) = par%Vexp/vtherm*yy(j)/rr
-                   grid%vfz(i,j,k) = par%Vexp/vtherm*zz(k)/rr
-                endif
-             case ('parallel_velocity')
-                grid%vfx(i,j,k) = par%Vx/vtherm; grid%vfy(i,j,k) = par%Vy/vtherm; grid%vfz(i,j,k) = par%Vz/vtherm
-             case ('rotating_solid_body')                                                           ! :905-916
-                grid%vfx(i,j,k) = -par%Vrot/vtherm*yy(j)/par%rmax; grid%vfy(i,j,k) = par%Vrot/vtherm*xx(i)/par%rmax
-             case ('rotating_galaxy_halo')                                                          ! :917-934
-                rr = sqrt(xx(i)**2 + yy(j)**2)
-                if (rr < par%rinner) then
-                   grid%vfx(i,j,k) = -par%Vrot/vtherm*yy(j)/par%rinner; grid%vfy(i,j,k) = par%Vrot/vtherm*xx(i)/par%rinner
-                else
-                   grid%vfx(i,j,k) = -par%Vrot/vtherm*yy(j)/rr; grid%vfy(i,j,k) = par%Vrot/vtherm*xx(i)/rr
-                endif
-             case ('power_law', 'linear_decelerate')                                                ! :853-904
-                rr = sqrt(xx(i)**2 + yy(j)**2 + zz(k)**2)
-                if (rr > grid%dz/10.0_wp) then
-                   if (trim(par%velocity_type) == 'power_law') then
-                      Vscale = par%Vexp*(rr/rpeak)**par%velocity_alpha
-                   else
-                      Vscale = par%Vexp*max(0.0_wp, (rpeak - rr)/(rpeak - max(par%rmin, 0.0_wp)))
-                   endif
-                   grid%vfx(i,j,k) = Vscale/vtherm*xx(i)/rr; grid%vfy(i,j,k) = Vscale/vtherm*yy(j)/rr; grid%vfz(i,j,k) = Vscale/vtherm*zz(k)/rr
-                endif
-             case ('ssh')                                                                           ! :817-838 (par%rpeak is an input)
-                rr = sqrt(xx(i)**2 + yy(j)**2 + zz(k)**2)
-                if (rr < par%rpeak) then
-                   Vscale = par%Vpeak/par%rpeak
-                   grid%vfx(i,j,k) = Vscale/vtherm*xx(i); grid%vfy(i,j,k) = Vscale/vtherm*yy(j); grid%vfz(i,j,k) = Vscale/vtherm*zz(k)
-                else
-                   Vscale = par%Vpeak + par%DeltaV*(rr - par%rpeak)/(par%rmax - par%rpeak)
-                   grid%vfx(i,j,k) = Vscale/vtherm*xx(i)/rr; grid%vfy(i,j,k) = Vscale/vtherm*yy(j)/rr; grid%vfz(i,j,k) = Vscale/vtherm*zz(k)/rr
-                endif
-             end select
-          endif
-       enddo; enddo; enddo
-    endif
-
-    grid%voigt_amean = (line%damping/fourpi)/grid%Dfreq_ref                                     ! :1150-1154
-    atau0 = grid%voigt_amean*par%tauhomo
-    call car_setup_freq_grid(grid)
+    call setup_check(lart_host_car_medium(m, grid%xface, grid%yface, grid%zface, grid%rhokap, grid%voigt_a, grid%Dfreq, grid%vfx, grid%vfy, grid%vfz, pD), 'grid_create')
+    grid%dx = m%dx; grid%dy = m%dy; grid%dz = m%dz; grid%xmin = m%xmin; grid%ymin = m%ymin; grid%zmin = m%zmin; grid%i0 = m%i0; grid%j0 = m%j0; grid%k0 = m%k0
+    grid%xrange = grid%xmax - grid%xmin; grid%yrange = grid%ymax - grid%ymin; grid%zrange = grid%zmax - grid%zmin
+    grid%Dfreq_ref = m%Dfreq_ref; grid%voigt_amean = m%voigt_amean
+    par%taumax = m%taumax; par%tauhomo = m%tauhomo; par%N_gasmax = m%N_gasmax; par%N_gashomo = m%N_gashomo       ! what was not given is the medium's own
+    call car_setup_freq_grid(grid, .true.)
     allocate(grid%Jout(grid%nxfreq), grid%Jin(grid%nxfreq), grid%Jabs(grid%nxfreq), grid%Jmu(grid%nxfreq, max(par%nmu,1)))
     grid%Jout = 0.0_wp; grid%Jin = 0.0_wp; grid%Jabs = 0.0_wp; grid%Jmu = 0.0_wp
-    if (par%core_skip_global) then                                                              ! :1186-1219
-       atau0_cell = atau0
-    else
-       atau0_cell = atau0/(grid%xmax/grid%dx)
+    if (line%line_type == 8) then                                        ! grid%Jout_Ha, grid%Jabs_Ha: the band-2 spectra
+       allocate(grid%Jout_Ha(grid%nxfreq_Ha), grid%Jabs_Ha(grid%nxfreq_Ha)); grid%Jout_Ha = 0.0_wp; grid%Jabs_Ha = 0.0_wp
     endif
-    if (atau0_cell > 1.0_wp) then
-       if (atau0_cell <= 60.0_wp) then
-          xi = 0.6_wp; chi = 1.2_wp
-       else
-          xi = 1.4_wp; chi = 0.6_wp
-       endif
-       grid%xcrit = 0.02_wp*exp(xi*(log(atau0_cell))**chi); grid%xcrit2 = grid%xcrit**2
-    endif
-
-    write(6,'(a,es16.3)') 'voigt_a          : ', grid%voigt_amean                                ! :1228-1237
+    write(6,'(a,es16.3)') 'voigt_a          : ', grid%voigt_amean
     write(6,'(a,es16.3)') 'temperature (K)  : ', par%temperature
-    write(6,'(a,es16.3)') 'N('//trim(line%ion_id)//')_pole     : ', N_gaspole
-    write(6,'(a,es16.3)') 'N('//trim(line%ion_id)//')_homo     : ', N_gashomo
-    write(6,'(a,es16.3)') 'tau_pole  ('//trim(line%ion_id)//') : ', taupole
-    write(6,'(a,es16.3)') 'tau_homo  ('//trim(line%ion_id)//') : ', tauhomo
-  contains
-    subroutine sym_axis(n, vmax, d, vmin, i0)
-      integer, intent(in) :: n
-      real(wp), intent(in) :: vmax
-      real(wp), intent(out) :: d, vmin
-      integer, intent(out) :: i0
-      if ((n/2)*2 == n) then
-         d = vmax/n; vmin = 0.0_wp; i0 = 1
-      else
-         d = vmax/(n - 0.5_wp); vmin = -d/2.0_wp; i0 = 2
-      endif
-    end subroutine sym_axis
-    subroutine scale_opacity(f)
-      real(wp), intent(in) :: f
-      grid%rhokap = grid%rhokap*f
-      if (par%DGR > 0.0_wp) grid%rhokapD = grid%rhokapD*f
-    end subroutine scale_opacity
-    subroutine homo_sums(s_tau, s_n, cnt)
-      real(wp), intent(out) :: s_tau, s_n, cnt
-      integer :: ii, jj, kk
-      s_tau = 0.0_wp; s_n = 0.0_wp; cnt = 0.0_wp
-      do kk = 1, nz; do jj = 1, ny; do ii = 1, nx
-         nadd = 1.0_wp
-         if (par%xyz_symmetry) then
-            if (ii == 1 .and. (nx/2)*2 /= nx) nadd = nadd/2.0_wp
-            if (jj == 1 .and. (ny/2)*2 /= ny) nadd = nadd/2.0_wp
-            if (kk == 1 .and. (nz/2)*2 /= nz) nadd = nadd/2.0_wp
-         else if (par%xy_symmetry) then
-            if (ii == 1 .and. (nx/2)*2 /= nx) nadd = nadd/2.0_wp
-            if (jj == 1 .and. (ny/2)*2 /= ny) nadd = nadd/2.0_wp
-         endif
-         if (grid%rhokap(ii,jj,kk) > 0.0_wp) then
-            s_tau = s_tau + grid%rhokap(ii,jj,kk)*voigt0(grid%voigt_a(ii,jj,kk))*nadd
-            s_n   = s_n   + grid%rhokap(ii,jj,kk)*grid%Dfreq(ii,jj,kk)*nadd
-            cnt   = cnt + nadd
-         endif
-      enddo; enddo; enddo
-    end subroutine homo_sums
+    write(6,'(a,es16.3)') 'N('//trim(line%ion_id)//')_pole     : ', m%N_gaspole_out
+    write(6,'(a,es16.3)') 'N('//trim(line%ion_id)//')_homo     : ', m%N_gashomo_out
+    write(6,'(a,es16.3)') 'tau_pole  ('//trim(line%ion_id)//') : ', m%taupole_out
+    write(6,'(a,es16.3)') 'tau_homo  ('//trim(line%ion_id)//') : ', m%tauhomo_out
   end subroutine grid_create
 
   !--- host-side error of the lart_host_* helpers: print and stop (reference convention)
@@ -1042,65 +842,33 @@ contains
   !--- build_clump_csr :1267-1342) run in liblart_gpu's host helpers on the reference's MT19937-64 stream
   subroutine init_clumps(R_sphere)
     real(wp), intent(in) :: R_sphere
-    real(wp) :: temp_cl, vtherm, rc, shell2, GF_los, fvol_realized, fcov_realized, sig, acc
-    real(c_double) :: cmin, cd
-    integer(c_int32_t) :: cg, ovl
-    integer(c_int64_t) :: nreg
+    real(wp) :: temp_cl, rc, sig, acc
+    type(lart_host_clumps_in) :: c
     integer :: n
     sphere_R = R_sphere
-    if (par%clump_radius <= 0.0_wp) then
-       write(*,*) 'ERROR: clump_radius must be > 0'; stop 1
-    endif
-    r_min_clump = max(0.0_wp, par%rmin)
-    if (r_min_clump >= R_sphere) then
-       write(*,'(a,2es12.4)') 'ERROR: par%rmin must be < par%rmax for clump placement; rmin, rmax = ', r_min_clump, R_sphere; stop 1
-    endif
-    if (len_trim(par%clump_input_file) > 0) then      ! clump_mod.f90:674-680: a pre-built population replaces the generator
+    if (len_trim(par%clump_input_file) > 0) then      ! a pre-built population replaces the generator (clump_mod.f90:674-680)
+       if (par%clump_radius <= 0.0_wp) then
+          write(*,*) 'ERROR: clump_radius must be > 0'; stop 1
+       endif
+       r_min_clump = max(0.0_wp, par%rmin)
+       if (r_min_clump >= R_sphere) then
+          write(*,'(a,2es12.4)') 'ERROR: par%rmin must be < par%rmax for clump placement; rmin, rmax = ', r_min_clump, R_sphere; stop 1
+       endif
        call read_clumps_info(trim(par%clump_input_file), R_sphere)
        return
     endif
-    cl_radius_max = par%clump_radius; rc = cl_radius_max
-    temp_cl = par%clump_temperature
-    if (temp_cl < 0.0_wp) temp_cl = par%temperature
-    vtherm         = vtherm_total(temp_cl)
-    cl_Dfreq_ref   = vtherm/(line%wavelength0*um2km)
-    cl_vtherm_ref  = vtherm; cl_temperature_ref = temp_cl
-    cl_voigt_a_ref = (line%damping/fourpi)/cl_Dfreq_ref
-    shell2 = R_sphere**2 + R_sphere*r_min_clump + r_min_clump**2
-    if (par%clump_N_clumps > 0.0_wp) then
-       N_clumps = int(par%clump_N_clumps, int64)
-    else if (par%clump_f_vol > 0.0_wp) then
-       N_clumps = nint(par%clump_f_vol*(R_sphere**3 - r_min_clump**3)/rc**3, int64)
-    else if (par%clump_f_cov > 0.0_wp) then
-       N_clumps = nint((4.0_wp/3.0_wp)*par%clump_f_cov*shell2/rc**2, int64)
-    else
-       write(*,*) 'ERROR: specify clump_N_clumps, clump_f_vol, or clump_f_cov'; stop 1
-    endif
-    if (N_clumps <= 0_int64) N_clumps = 1_int64
-    fvol_realized = real(N_clumps, wp)*rc**3/max(R_sphere**3 - r_min_clump**3, tiny(1.0_wp))
-    fcov_realized = 0.75_wp*real(N_clumps, wp)*rc**2/max(shell2, tiny(1.0_wp))
-    if (par%clump_tau0 > 0.0_wp) then
-       cl_rhokap_ref = par%clump_tau0/(voigt0(cl_voigt_a_ref)*par%clump_radius)
-    else if (par%clump_NHI > 0.0_wp) then
-       cl_rhokap_ref = par%clump_NHI*line%cross0/(cl_Dfreq_ref*par%clump_radius)
-    else if (par%clump_nH > 0.0_wp) then
-       if (par%distance2cm <= 0.0_wp) then
-          write(*,*) 'ERROR: clump_nH requires distance_unit'; stop 1
-       endif
-       cl_rhokap_ref = par%clump_nH*line%cross0*par%distance2cm/cl_Dfreq_ref
-    else if (par%taumax > 0.0_wp .or. par%N_gasmax > 0.0_wp) then
-       GF_los = real(N_clumps, wp)*rc**3/max(shell2, tiny(1.0_wp))
-       if (par%taumax > 0.0_wp) then
-          cl_rhokap_ref = par%taumax/(GF_los*voigt0(cl_voigt_a_ref))
-       else
-          cl_rhokap_ref = par%N_gasmax*line%cross0/(GF_los*cl_Dfreq_ref)
-       endif
-    else
-       write(*,*) 'ERROR: specify clump_tau0, clump_NHI, clump_nH, taumax, or N_HImax'; stop 1
-    endif
+    temp_cl = merge(par%temperature, par%clump_temperature, par%clump_temperature < 0.0_wp)
+    c%sphere_R = R_sphere; c%rmin = par%rmin; c%clump_radius = par%clump_radius; c%N_clumps_in = par%clump_N_clumps; c%f_vol_in = par%clump_f_vol
+    c%f_cov_in = par%clump_f_cov; c%clump_tau0 = par%clump_tau0; c%clump_NHI = par%clump_NHI; c%clump_nH = par%clump_nH; c%taumax = par%taumax
+    c%N_gasmax = par%N_gasmax; c%distance2cm = par%distance2cm
+    c%vtherm = vtherm_total(temp_cl); c%wavelength0 = line%wavelength0; c%damping = line%damping; c%cross0 = line%cross0
+    call setup_check(lart_host_clump_population(c), 'init_clumps')      ! population size, f_vol / f_cov, the opacity of one clump
+    r_min_clump = c%r_min; cl_radius_max = par%clump_radius; rc = cl_radius_max
+    cl_Dfreq_ref = c%Dfreq_ref; cl_vtherm_ref = c%vtherm; cl_temperature_ref = temp_cl; cl_voigt_a_ref = c%voigt_a_ref
+    N_clumps = c%N; cl_rhokap_ref = c%rhokap_ref
     write(*,'(a,i14)')    ' Clumps: N_clumps  = ', N_clumps
-    write(*,'(a,f12.6)')  ' Clumps: f_vol     = ', fvol_realized
-    write(*,'(a,f12.5)')  ' Clumps: f_cov     = ', fcov_realized
+    write(*,'(a,f12.6)')  ' Clumps: f_vol     = ', c%fvol
+    write(*,'(a,f12.5)')  ' Clumps: f_cov     = ', c%fcov
     write(*,'(a,2f12.5)') ' Clumps: rmin/rmax = ', r_min_clump, R_sphere
     write(*,'(a,es12.4)') ' Clumps: cl_rhokap = ', cl_rhokap_ref
     write(*,'(a,f12.5)')  ' Clumps: voigt_a   = ', cl_voigt_a_ref
@@ -1177,21 +945,7 @@ contains
   !--- the four sums of compute_clump_scalars (clump_mod.f90:2316-2378): tauhomo, taumax, N_gashomo, N_gasmax
   subroutine clump_scalars(vals)
     real(wp), intent(out) :: vals(4)
-    integer(int64) :: i
-    real(wp) :: voigt0_i, di2, shell2, w_homo, w_max
-    shell2 = sphere_R**2 + sphere_R*r_min_clump + r_min_clump**2
-    if (shell2 <= 0.0_wp) shell2 = sphere_R**2
-    vals = 0.0_wp
-    do i = 1_int64, N_clumps
-       voigt0_i = voigt0(cl_voigt_a(i))
-       di2    = max(cl_x(i)**2 + cl_y(i)**2 + cl_z(i)**2, cl_radius(i)**2)
-       w_homo = cl_radius(i)**3/shell2
-       w_max  = cl_radius(i)**3/(3.0_wp*di2)
-       vals(1) = vals(1) + cl_rhokap(i)*voigt0_i*w_homo
-       vals(2) = vals(2) + cl_rhokap(i)*voigt0_i*w_max
-       vals(3) = vals(3) + cl_rhokap(i)*cl_Dfreq(i)*w_homo/line%cross0
-       vals(4) = vals(4) + cl_rhokap(i)*cl_Dfreq(i)*w_max/line%cross0
-    enddo
+    call setup_check(lart_host_clump_scalars(N_clumps, sphere_R, r_min_clump, line%cross0, cl_x, cl_y, cl_z, cl_radius, cl_rhokap, cl_voigt_a, cl_Dfreq, vals), 'clump_scalars')
   end subroutine clump_scalars
 
   !--- read_clumps_info + rescale_loaded_clumps_to_target: clump_mod.f90:2040-2312, 2385-2449
@@ -1316,39 +1070,10 @@ contains
     end subroutine col_or_key
   end subroutine read_clumps_info
 
-  !--- assign_clump_velocities_from_type: clump_mod.f90:1153-1264 (the fields this path supports)
+  !--- assign_clump_velocities_from_type (clump_mod.f90:1153-1264, the fields this path supports): the systematic field added to the clumps' velocities
   subroutine assign_clump_velocities_from_type()
-    integer(int64) :: icl
-    real(wp) :: xc, yc, zc, rr, rr_cyl, vx, vy, vz
-    do icl = 1_int64, N_clumps
-       xc = cl_x(icl); yc = cl_y(icl); zc = cl_z(icl)
-       rr = sqrt(xc**2 + yc**2 + zc**2)
-       vx = 0.0_wp; vy = 0.0_wp; vz = 0.0_wp
-       select case (trim(par%velocity_type))
-       case ('hubble')
-          vx = par%Vexp*xc/sphere_R; vy = par%Vexp*yc/sphere_R; vz = par%Vexp*zc/sphere_R
-       case ('constant_radial')
-          if (rr > 0.0_wp) then
-             vx = par%Vexp*xc/rr; vy = par%Vexp*yc/rr; vz = par%Vexp*zc/rr
-          endif
-       case ('parallel_velocity')
-          vx = par%Vx; vy = par%Vy; vz = par%Vz
-       case ('rotating_solid_body')
-          vx = -par%Vrot*yc/sphere_R; vy = par%Vrot*xc/sphere_R
-       case ('rotating_galaxy_halo')
-          rr_cyl = sqrt(xc**2 + yc**2)
-          if (rr_cyl > 0.0_wp) then
-             if (rr_cyl < par%rinner) then
-                vx = -par%Vrot*yc/par%rinner; vy = par%Vrot*xc/par%rinner
-             else
-                vx = -par%Vrot*yc/rr_cyl; vy = par%Vrot*xc/rr_cyl
-             endif
-          endif
-       end select
-       cl_vx(icl) = cl_vx(icl) + vx/cl_vtherm(icl)
-       cl_vy(icl) = cl_vy(icl) + vy/cl_vtherm(icl)
-       cl_vz(icl) = cl_vz(icl) + vz/cl_vtherm(icl)
-    enddo
+    call setup_check(lart_host_clump_velocities(N_clumps, velocity_code(par%velocity_type), sphere_R, par%Vexp, par%Vx, par%Vy, par%Vz, par%Vrot, par%rinner, &
+                                                cl_x, cl_y, cl_z, cl_vtherm, cl_vx, cl_vy, cl_vz), 'assign_clump_velocities_from_type')
     write(*,'(2a)') ' Clumps: velocity_type   = ', trim(par%velocity_type)
   end subroutine assign_clump_velocities_from_type
 
@@ -1700,55 +1425,14 @@ contains
   !--- create_JPa_mem: grid_mod_car.f90:1242-1434 (profile bin of every cell + the number of gas cells per bin)
   subroutine create_JPa_mem(grid)
     type(grid_type), intent(in) :: grid
-    integer :: nx, ny, nz, nr, i, j, k, ib
-    real(wp) :: rmax, dr, roff, xx, yy, zz, nadd
+    integer :: nx, ny, nz
+    real(wp), allocatable :: cnt(:)
     if (.not. (par%calc_J .or. par%calc_P .or. par%calc_Pnew)) return
     nx = grid%nx; ny = grid%ny; nz = grid%nz
-    allocate(car_ind_bin(nx, ny, nz)); car_ind_bin = 0
-    select case (par%geometry_JPa)
-    case (1)                                              ! spherical shells
-       nr = maxval([nx, ny, nz])
-       if (.not. par%xyz_symmetry) then
-          if (mod(nr, 2) == 0) then
-             nr = nr/2
-          else
-             nr = (nr - 1)/2 + 1
-          endif
-       endif
-       rmax = minval([grid%xmax, grid%ymax, grid%zmax])
-       if (mod(nr, 2) == 0) then
-          dr = rmax/nr; roff = 0.0_wp
-       else
-          dr = rmax/(nr - 0.5_wp); roff = -dr/2.0_wp
-       endif
-       car_nbins = nr
-       allocate(car_ncount(nr)); car_ncount = 0.0_wp
-       do k = 1, nz; do j = 1, ny; do i = 1, nx
-          xx = (grid%xface(i) + grid%xface(i+1))/2.0_wp; yy = (grid%yface(j) + grid%yface(j+1))/2.0_wp; zz = (grid%zface(k) + grid%zface(k+1))/2.0_wp
-          ib = floor((sqrt(xx**2 + yy**2 + zz**2) - roff)/dr) + 1
-          if (ib >= 1 .and. ib <= nr) then
-             car_ind_bin(i,j,k) = ib
-             if (grid%rhokap(i,j,k) > 0.0_wp) car_ncount(ib) = car_ncount(ib) + cell_mult(i, j, k)
-          endif
-       enddo; enddo; enddo
-    case (-1)                                             ! plane-parallel layers
-       car_nbins = nz
-       allocate(car_ncount(nz)); car_ncount = 0.0_wp
-       do k = 1, nz
-          car_ind_bin(:,:,k) = k
-          car_ncount(k) = count(grid%rhokap(:,:,k) > 0.0_wp)
-       enddo
-    case default                                          ! 3: every cell its own bin
-       car_nbins = nx*ny*nz
-       allocate(car_ncount(car_nbins))
-       do k = 1, nz; do j = 1, ny; do i = 1, nx
-          ib = i + nx*((j - 1) + ny*(k - 1))
-          car_ind_bin(i,j,k) = ib
-          nadd = 1.0_wp
-          if (par%xyz_symmetry) nadd = cell_mult(i, j, k)
-          car_ncount(ib) = nadd
-       enddo; enddo; enddo
-    end select
+    allocate(car_ind_bin(nx, ny, nz), cnt(nx*ny*nz))
+    call setup_check(lart_host_jpa_car(int(par%geometry_JPa, c_int32_t), merge(1, 0, par%xyz_symmetry), nx, ny, nz, grid%xface, grid%yface, grid%zface, &
+                                       grid%xmax, grid%ymax, grid%zmax, grid%rhokap, car_nbins, car_ind_bin, cnt), 'create_JPa_mem')
+    allocate(car_ncount(car_nbins)); car_ncount = cnt(1:car_nbins)
     if (par%calc_J) then
        allocate(prof_J1(grid%nxfreq, car_nbins)); prof_J1 = 0.0_wp
     endif
@@ -1758,198 +1442,72 @@ contains
     if (par%calc_Pnew) then
        allocate(prof_P1_new(car_nbins)); prof_P1_new = 0.0_wp
     endif
-  contains
-    !--- how many cells of the full box one cell of the +++ octant stands for (cells on a mirror plane are cut in half)
-    function cell_mult(ii, jj, kk) result(m)
-      integer, intent(in) :: ii, jj, kk
-      real(wp) :: m
-      m = 1.0_wp
-      if (.not. par%xyz_symmetry) return
-      m = 8.0_wp
-      if (mod(grid%nx, 2) == 1 .and. ii == 1) m = m/2.0_wp
-      if (mod(grid%ny, 2) == 1 .and. jj == 1) m = m/2.0_wp
-      if (mod(grid%nz, 2) == 1 .and. kk == 1) m = m/2.0_wp
-    end function cell_mult
+    if (line%line_type == 8 .and. par%calc_P) then                      ! the conversion-rate profile of ly_beta (add_to_Pconv)
+       allocate(prof_Pconv(car_nbins)); prof_Pconv = 0.0_wp
+    endif
   end subroutine create_JPa_mem
 
-  !--- car_setup_freq_grid: grid_mod_car.f90:1442-1548
-  subroutine car_setup_freq_grid(grid)
+  !--- car_setup_freq_grid (grid_mod_car.f90:1442-1548) through lart_host_freq_grid: the spectral axis from the wavelength / velocity window or from
+  !--- (a tau)^(1/3), the band-2 axis of ly_beta; core_skip_scale: also grid%xcrit of the Cartesian grid (:1186-1219; the octree sets its own)
+  subroutine car_setup_freq_grid(grid, core_skip_scale)
     type(grid_type), intent(inout) :: grid
-    real(wp) :: vtherm, xscale, atau3
-    integer :: i
-    atau3 = (grid%voigt_amean*par%tauhomo)**(1.0_wp/3.0_wp)
-    par%atau3 = atau3
-    vtherm = vtherm_total(par%temperature)
-    if (is_finite(par%wavelength_min) .and. is_finite(par%wavelength_max)) then                   ! grid_mod_car.f90:1457-1461
-       if (par%nwavelength == 0 .and. par%nxfreq > 0) par%nwavelength = par%nxfreq
-       if (par%nwavelength > 0) par%nxfreq = par%nwavelength
-       par%xfreq_min = -(par%wavelength_max - line%wavelength0*1e4)/(line%wavelength0*1e4)*(2.99792458e5_wp/vtherm)
-       par%xfreq_max = -(par%wavelength_min - line%wavelength0*1e4)/(line%wavelength0*1e4)*(2.99792458e5_wp/vtherm)
-    else if (is_finite(par%velocity_min) .and. is_finite(par%velocity_max)) then
-       if (par%nvelocity == 0 .and. par%nxfreq > 0) par%nvelocity = par%nxfreq
-       if (par%nvelocity > 0) par%nxfreq = par%nvelocity
-       par%xfreq_min = -par%velocity_max/vtherm
-       par%xfreq_max = -par%velocity_min/vtherm
+    logical, intent(in), optional :: core_skip_scale
+    type(lart_host_freq) :: f
+    logical :: cs
+    cs = .false.
+    if (present(core_skip_scale)) cs = core_skip_scale
+    f%nxfreq = par%nxfreq; f%nwavelength = par%nwavelength; f%nvelocity = par%nvelocity; f%continuum = merge(1, 0, trim(par%spectral_type) == 'continuum')
+    f%line_type = line%line_type; f%nxfreq_Ha = par%nxfreq_Ha; f%core_skip_global = merge(1, 0, par%core_skip_global)
+    f%wavelength_min = par%wavelength_min; f%wavelength_max = par%wavelength_max; f%velocity_min = par%velocity_min; f%velocity_max = par%velocity_max
+    f%xfreq_min = par%xfreq_min; f%xfreq_max = par%xfreq_max; f%vtherm = vtherm_total(par%temperature); f%wavelength0 = line%wavelength0
+    f%wavelength0_Ha = line%wavelength0_Ha; f%Dfreq_ref = grid%Dfreq_ref; f%DnuHK_Hz = line%DnuHK_Hz; f%voigt_amean = grid%voigt_amean
+    f%tauhomo = par%tauhomo; f%taumax = par%taumax; f%Vexp = par%Vexp; f%xfreq_max_Ha = par%xfreq_max_Ha
+    f%cells_per_radius = 1.0_wp
+    if (cs .and. grid%dx > 0.0_wp) f%cells_per_radius = grid%xmax/grid%dx
+    call setup_check(lart_host_freq_grid(f), 'car_setup_freq_grid')
+    par%atau3 = f%atau3; par%nxfreq = f%nxfreq; par%nwavelength = f%nwavelength; par%nvelocity = f%nvelocity; par%xfreq_min = f%xfreq_min; par%xfreq_max = f%xfreq_max
+    grid%nxfreq = f%nxfreq; grid%dxfreq = f%dxfreq; grid%xfreq_min = f%xfreq_min; grid%xfreq_max = f%xfreq_max; grid%dwave = f%dwave
+    if (line%line_type == 8) then
+       par%nxfreq_Ha = f%nxfreq_Ha; grid%nxfreq_Ha = f%nxfreq_Ha
+       grid%xfreq_min_Ha = f%xfreq_min_Ha; grid%xfreq_max_Ha = f%xfreq_max_Ha; grid%dxfreq_Ha = f%dxfreq_Ha; grid%dwave_Ha = f%dwave_Ha
     endif
-    grid%nxfreq = par%nxfreq
-    if (.not.(is_finite(par%xfreq_max) .and. is_finite(par%xfreq_min))) then
-       if (par%taumax <= 5e1_wp) then
-          xscale = 25.0_wp
-       else if (par%taumax <= 5e2_wp) then
-          xscale = 14.0_wp
-       else if (par%taumax <= 5e3_wp) then
-          xscale = 10.0_wp
-       else
-          xscale = 5.0_wp
-       endif
-       if (par%Vexp == 0.0_wp) then
-          par%xfreq_max = floor(xscale*atau3) + 1
-          par%xfreq_min = -(floor(xscale*atau3 + line%DnuHK_Hz/grid%Dfreq_ref) + 1)
-       else if (par%Vexp > 0.0_wp) then
-          par%xfreq_max = floor(xscale*atau3) + 1
-          par%xfreq_min = -(floor(xscale*atau3 + abs(par%Vexp)/vtherm + line%DnuHK_Hz/grid%Dfreq_ref) + 1)
-       else
-          par%xfreq_max = floor(xscale*atau3 + abs(par%Vexp)/vtherm) + 1
-          par%xfreq_min = -(floor(xscale*atau3 + line%DnuHK_Hz/grid%Dfreq_ref) + 1)
-       endif
-       if (trim(par%spectral_type) == 'continuum') then                                          ! :1490-1494
-          xscale = 4.0_wp*xscale
-          par%xfreq_max = floor(xscale*atau3 + abs(par%Vexp)/vtherm) + 1
-          par%xfreq_min = -(floor(xscale*atau3 + abs(par%Vexp)/vtherm + line%DnuHK_Hz/grid%Dfreq_ref) + 1)
-       endif
+    if (cs) then
+       grid%xcrit = f%xcrit; grid%xcrit2 = f%xcrit2
     endif
     allocate(grid%xfreq(grid%nxfreq), grid%velocity(grid%nxfreq), grid%wavelength(grid%nxfreq))
-    grid%dxfreq    = (par%xfreq_max - par%xfreq_min)/par%nxfreq
-    grid%xfreq_max = par%xfreq_max; grid%xfreq_min = par%xfreq_min
-    grid%xfreq(:)      = [ ((i-0.5_wp)*grid%dxfreq + grid%xfreq_min, i=1, grid%nxfreq) ]
-    grid%velocity(:)   = -vtherm_total(par%temperature)*grid%xfreq(:)
-    grid%dwave         =  vtherm_total(par%temperature)/speedc*(line%wavelength0*1e4_wp)*grid%dxfreq
-    grid%wavelength(:) = (grid%velocity(:)/speedc + 1.0_wp)*(line%wavelength0*1e4_wp)
+    call setup_check(lart_host_freq_axis(grid%nxfreq, grid%xfreq_min, grid%dxfreq, f%vtherm, line%wavelength0, grid%xfreq, grid%velocity, grid%wavelength), 'freq axis')
   end subroutine car_setup_freq_grid
 
-  !--- observer_create_outside: observer_rect.f90:24-326 (rotation centre at the origin)
+  !--- observer_create_outside (observer_rect.f90:24-326, rotation centre at the origin) / observer_create_inside (observer_heal.f90:24-80) through
+  !--- lart_host_observers; par%alpha/beta/gamma, par%obsx/y/z, par%distance, par%dxim/dyim come back completed, as the reference leaves them
   subroutine observer_create()
-    real(wp), allocatable :: cosa(:), sina(:), cosb(:), sinb(:), cosg(:), sing(:)
-    real(wp) :: dist_scale, maxsz, px, py, pz, kx, ky, kz, ang_x, ang_y, max_ang_x, max_ang_y
-    real(wp), parameter :: vertex_x(8) = [1.0, 1.0, 1.0, -1.0, -1.0, -1.0,  1.0, -1.0]
-    real(wp), parameter :: vertex_y(8) = [1.0, 1.0, -1.0, 1.0, -1.0,  1.0, -1.0, -1.0]
-    real(wp), parameter :: vertex_z(8) = [1.0, -1.0, 1.0, 1.0,  1.0, -1.0, -1.0, -1.0]
-    integer :: i, iv, n
+    type(lart_host_obs) :: o
+    real(c_double) :: xyz(3*MAX_OBSERVERS), rm(9*MAX_OBSERVERS)
+    integer :: i
     if (.not. par%save_peeloff) then
        par%nobs = 0; return
     endif
-    if (par%nside > 0) then                               ! observer_create_inside: observer_heal.f90:24-80
-       if (.not. (is_finite(par%obsx(1)) .and. is_finite(par%obsy(1)) .and. is_finite(par%obsz(1)))) then
-          par%obsx(1) = 0.0_wp; par%obsy(1) = 0.0_wp; par%obsz(1) = 0.0_wp
-       endif
-       n = count(is_finite(par%obsx) .and. is_finite(par%obsy) .and. is_finite(par%obsz))
-       par%nobs = n; par%npix = 12*par%nside**2
-       allocate(observer(n))
-       iv = 0
-       do i = 1, size(par%obsx)
-          if (.not. (is_finite(par%obsx(i)) .and. is_finite(par%obsy(i)) .and. is_finite(par%obsz(i)))) cycle
-          iv = iv + 1
-          observer(iv)%x = par%obsx(i); observer(iv)%y = par%obsy(i); observer(iv)%z = par%obsz(i)
-          observer(iv)%rmatrix = 0.0_wp; observer(iv)%dxim = 0.0_wp; observer(iv)%dyim = 0.0_wp
-          observer(iv)%nxim = par%npix; observer(iv)%nyim = 1
-          observer(iv)%steradian_pix = fourpi/par%npix
+    o%nside = par%nside; o%sphere = merge(1, 0, trim(par%geometry) == 'sphere'); o%nxim = par%nxim; o%nyim = par%nyim
+    o%xmax = par%xmax; o%ymax = par%ymax; o%zmax = par%zmax; o%rmax = par%rmax; o%distance = par%distance; o%dxim = par%dxim; o%dyim = par%dyim
+    call setup_check(lart_host_observers(o, par%alpha, par%beta, par%gamma, par%obsx, par%obsy, par%obsz, xyz, rm), 'observer_create')
+    par%nobs = o%nobs
+    allocate(observer(par%nobs))
+    do i = 1, par%nobs
+       observer(i)%x = xyz(3*i-2); observer(i)%y = xyz(3*i-1); observer(i)%z = xyz(3*i)
+       observer(i)%rmatrix = transpose(reshape(rm(9*i-8:9*i), [3, 3]))   ! the library's rows are Fortran's first index
+       observer(i)%steradian_pix = o%steradian_pix
+    enddo
+    if (par%nside > 0) then
+       par%npix = o%npix
+       do i = 1, par%nobs
+          observer(i)%rmatrix = 0.0_wp; observer(i)%dxim = 0.0_wp; observer(i)%dyim = 0.0_wp; observer(i)%nxim = par%npix; observer(i)%nyim = 1
        enddo
        call alloc_peel(par%npix, 1)
        return
     endif
-    maxsz = maxval([par%xmax, par%ymax, par%zmax])
-    where (is_finite(par%beta)  .and. .not. is_finite(par%alpha)) par%alpha = 0.0_wp
-    where (is_finite(par%alpha) .and. .not. is_finite(par%beta))  par%beta  = 0.0_wp
-    if (.not. (is_finite(par%alpha(1)) .and. is_finite(par%beta(1))) .and. &
-        .not. (is_finite(par%obsx(1)) .and. is_finite(par%obsy(1)) .and. is_finite(par%obsz(1)))) then
-       if (.not. is_finite(par%distance)) par%distance = maxsz*100.0_wp
-       par%obsx(1) = 0.0_wp; par%obsy(1) = 0.0_wp; par%obsz(1) = 1.0_wp
-       par%alpha(1) = 0.0_wp; par%beta(1) = 0.0_wp
-    endif
-    if (is_finite(par%alpha(1)) .and. is_finite(par%beta(1))) then
-       n = count(is_finite(par%alpha) .and. is_finite(par%beta))
-       par%nobs = n
-       allocate(cosa(n), sina(n), cosb(n), sinb(n), cosg(n), sing(n), observer(n))
-       if (.not. is_finite(par%distance)) par%distance = maxsz*100.0_wp
-       do i = 1, n
-          call default_gamma(i)
-          cosa(i) = cos(par%alpha(i)*deg2rad); sina(i) = sin(par%alpha(i)*deg2rad)
-          cosb(i) = cos(par%beta(i) *deg2rad); sinb(i) = sin(par%beta(i) *deg2rad)
-          cosg(i) = cos(par%gamma(i)*deg2rad); sing(i) = sin(par%gamma(i)*deg2rad)
-          observer(i)%x = par%distance*cosa(i)*sinb(i)
-          observer(i)%y = par%distance*sina(i)*sinb(i)
-          observer(i)%z = par%distance*cosb(i)
-       enddo
-    else
-       n = count(is_finite(par%obsx) .and. is_finite(par%obsy) .and. is_finite(par%obsz))
-       par%nobs = n
-       allocate(cosa(n), sina(n), cosb(n), sinb(n), cosg(n), sing(n), observer(n))
-       if (.not. is_finite(par%distance)) then
-          par%distance = sqrt(par%obsx(1)**2 + par%obsy(1)**2 + par%obsz(1)**2)
-          if (par%distance < 10.0_wp*maxsz) par%distance = maxsz*100.0_wp
-       endif
-       do i = 1, n
-          call default_gamma(i)
-          dist_scale = par%distance/sqrt(par%obsx(i)**2 + par%obsy(i)**2 + par%obsz(i)**2)
-          if (dist_scale > 1.001_wp) then
-             observer(i)%x = par%obsx(i)*dist_scale; observer(i)%y = par%obsy(i)*dist_scale; observer(i)%z = par%obsz(i)*dist_scale
-          else
-             observer(i)%x = par%obsx(i); observer(i)%y = par%obsy(i); observer(i)%z = par%obsz(i)
-          endif
-          cosb(i) = observer(i)%z/par%distance
-          if (abs(cosb(i) - 1.0_wp) < epsilon(0.0_wp)) cosb(i) =  1.0_wp
-          if (abs(cosb(i) + 1.0_wp) < epsilon(0.0_wp)) cosb(i) = -1.0_wp
-          sinb(i) = sqrt(1.0_wp - cosb(i)**2)
-          par%beta(i) = atan2(sinb(i), cosb(i))*rad2deg
-          cosg(i) = cos(par%gamma(i)*deg2rad); sing(i) = sin(par%gamma(i)*deg2rad)
-          if (sinb(i) == 0.0_wp) then
-             cosa(i) = 1.0_wp; sina(i) = 0.0_wp; par%alpha(i) = 0.0_wp
-          else
-             par%alpha(i) = atan2(observer(i)%y, observer(i)%x)
-             cosa(i) = cos(par%alpha(i)); sina(i) = sin(par%alpha(i)); par%alpha(i) = par%alpha(i)*rad2deg
-          endif
-       enddo
-    endif
-    do i = 1, par%nobs                                                                          ! :207-217
-       observer(i)%rmatrix(1,1) =  cosa(i)*cosb(i)*cosg(i) - sina(i)*sing(i)
-       observer(i)%rmatrix(1,2) =  sina(i)*cosb(i)*cosg(i) + cosa(i)*sing(i)
-       observer(i)%rmatrix(1,3) = -sinb(i)*cosg(i)
-       observer(i)%rmatrix(2,1) = -cosa(i)*cosb(i)*sing(i) - sina(i)*cosg(i)
-       observer(i)%rmatrix(2,2) = -sina(i)*cosb(i)*sing(i) + cosa(i)*cosg(i)
-       observer(i)%rmatrix(2,3) =  sinb(i)*sing(i)
-       observer(i)%rmatrix(3,1) =  cosa(i)*sinb(i)
-       observer(i)%rmatrix(3,2) =  sina(i)*sinb(i)
-       observer(i)%rmatrix(3,3) =  cosb(i)
-    enddo
-    if (.not. (is_finite(par%dxim) .and. is_finite(par%dyim))) then                             ! :244-276
-       if (trim(par%geometry) == 'sphere') then
-          par%dxim = asin(par%rmax/par%distance)/(par%nxim/2.0_wp)*rad2deg
-          par%dyim = asin(par%rmax/par%distance)/(par%nyim/2.0_wp)*rad2deg
-       else
-          max_ang_x = -999.0; max_ang_y = -999.0
-          do i = 1, par%nobs
-             do iv = 1, 8
-                px = observer(i)%x - vertex_x(iv)*par%xmax; py = observer(i)%y - vertex_y(iv)*par%ymax; pz = observer(i)%z - vertex_z(iv)*par%zmax
-                kx = observer(i)%rmatrix(1,1)*px + observer(i)%rmatrix(1,2)*py + observer(i)%rmatrix(1,3)*pz
-                ky = observer(i)%rmatrix(2,1)*px + observer(i)%rmatrix(2,2)*py + observer(i)%rmatrix(2,3)*pz
-                kz = observer(i)%rmatrix(3,1)*px + observer(i)%rmatrix(3,2)*py + observer(i)%rmatrix(3,3)*pz
-                ang_x = abs(atan2(-kx, kz)); ang_y = abs(atan2(-ky, kz))
-                if (max_ang_x < ang_x) max_ang_x = ang_x
-                if (max_ang_y < ang_y) max_ang_y = ang_y
-             enddo
-          enddo
-          if (par%nxim == par%nyim) then
-             par%dxim = maxval([max_ang_x, max_ang_y])/(par%nxim/2.0_wp)*rad2deg
-             par%dyim = maxval([max_ang_x, max_ang_y])/(par%nyim/2.0_wp)*rad2deg
-          else
-             if (.not. is_finite(par%dxim)) par%dxim = max_ang_x/(par%nxim/2.0_wp)*rad2deg
-             if (.not. is_finite(par%dyim)) par%dyim = max_ang_y/(par%nyim/2.0_wp)*rad2deg
-          endif
-       endif
-    endif
+    par%distance = o%distance; par%dxim = o%dxim; par%dyim = o%dyim
     do i = 1, par%nobs
        observer(i)%dxim = par%dxim; observer(i)%dyim = par%dyim; observer(i)%nxim = par%nxim; observer(i)%nyim = par%nyim
-       observer(i)%steradian_pix = par%dxim*par%dyim*(deg2rad**2)
     enddo
     call alloc_peel(par%nxim, par%nyim)                                                         ! :287-324
   contains
@@ -1974,64 +1532,53 @@ contains
          if (par%save_dust_scattered) then
             allocate(obs_scatt_dust(par%nxfreq,nxi,nyi,no)); obs_scatt_dust = 0
          endif
+         if (line%line_type == 8) then                                   ! observer(:)%peel_Ha: the band-2 cube of ly_beta (define.f90:567-568)
+            allocate(obs_peel_Ha(par%nxfreq_Ha,nxi,nyi,no)); obs_peel_Ha = 0
+         endif
          if (par%use_stokes) then
             allocate(obs_I(par%nxfreq,nxi,nyi,no), obs_Q(par%nxfreq,nxi,nyi,no), obs_U(par%nxfreq,nxi,nyi,no), obs_V(par%nxfreq,nxi,nyi,no))
          endif
       endif
     end subroutine alloc_peel
-    subroutine default_gamma(k)
-      integer, intent(in) :: k
-      if (.not. is_finite(par%gamma(k))) then
-         if (par%beta(k) > 0.0_wp .and. par%beta(k) <= 90.0_wp) then
-            par%gamma(k) = 90.0_wp
-         else if (par%beta(k) > 90.0_wp) then
-            par%gamma(k) = -90.0_wp
-         else
-            par%gamma(k) = 0.0_wp
-         endif
-      endif
-    end subroutine default_gamma
   end subroutine observer_create
 
-  !--- output_normalize_outside: output_sum_rect.f90:151-487 (Jout/Jin/Jabs/Jmu and the peel tallies)
+  !--- output_normalize_outside (output_sum_rect.f90:151-487): the divisors come from lart_host_norm_scales (Jout/Jin/Jabs/Jmu, the peel cubes and
+  !--- images, and for ly_beta the band-2 sections with the H-alpha bin unit :210-236, :433-435)
   subroutine output_normalize(grid)
     type(grid_type), intent(inout) :: grid
-    real(wp) :: area, intensity_bin_unit, scale_factor
+    type(lart_host_norm) :: q
+    real(wp) :: intensity_bin_unit
     par%nscatt_dust = par%nscatt_dust/par%nphotons
     par%nscatt_gas  = par%nscatt_gas /par%nphotons
     par%nscatt_tot  = par%nscatt_gas + par%nscatt_dust
-    if (par%intensity_unit == 1) then
-       intensity_bin_unit = grid%dwave
-    else
-       intensity_bin_unit = grid%dxfreq
-    endif
-    if (par%xy_periodic) then
-       area = 2.0_wp
-    else if (trim(par%geometry) == 'sphere') then
-       area = fourpi*grid%rmax**2*(par%distance2cm)**2
-    else
-       area = (grid%xmax*grid%ymax + grid%ymax*grid%zmax + grid%zmax*grid%xmax)*8.0_wp*(par%distance2cm)**2
-       if (par%use_amr_grid) area = 6.0_wp*(amr_hi - amr_lo)**2*(par%distance2cm)**2      ! the six faces of the octree box (output_sum_rect.f90:808-813)
-    endif
-    grid%Jout(:) = grid%Jout(:)/(par%nphotons*intensity_bin_unit*twopi*area)
-    if (par%save_Jin) grid%Jin(:) = grid%Jin(:)/(par%nphotons*intensity_bin_unit*twopi*area)
-    if (par%save_Jmu) grid%Jmu(:,:) = grid%Jmu(:,:)*par%nmu/(par%nphotons*intensity_bin_unit*twopi*area)
-    if (par%DGR > 0.0_wp .and. par%save_Jabs) grid%Jabs(:) = grid%Jabs(:)/(par%nphotons*intensity_bin_unit*twopi*area)
+    intensity_bin_unit = merge(grid%dwave, grid%dxfreq, par%intensity_unit == 1)
+    q%xy_periodic = merge(1, 0, par%xy_periodic); q%sphere = merge(1, 0, trim(par%geometry) == 'sphere'); q%nphotons = real(par%nphotons, wp)
+    q%bin_unit = intensity_bin_unit; q%bin_unit_Ha = intensity_bin_unit
+    if (line%line_type == 8) q%bin_unit_Ha = merge(grid%dwave_Ha, grid%dxfreq_Ha, par%intensity_unit == 1)
+    q%distance2cm = par%distance2cm; q%rmax = grid%rmax; q%xmax = grid%xmax; q%ymax = grid%ymax; q%zmax = grid%zmax
+    q%amr_L_box = merge(amr_hi - amr_lo, 0.0_wp, par%use_amr_grid); q%steradian_pix = 0.0_wp
+    if (par%nobs > 0 .and. allocated(observer)) q%steradian_pix = observer(1)%steradian_pix
+    call setup_check(lart_host_norm_scales(q), 'output_normalize')
+    grid%Jout = grid%Jout/q%scale_J
+    if (par%save_Jin) grid%Jin = grid%Jin/q%scale_J
+    if (par%save_Jmu) grid%Jmu = grid%Jmu*par%nmu/q%scale_J
+    if (par%DGR > 0.0_wp .and. par%save_Jabs) grid%Jabs = grid%Jabs/q%scale_J
+    if (allocated(grid%Jout_Ha)) grid%Jout_Ha = grid%Jout_Ha/q%scale_J_Ha
+    if (allocated(grid%Jabs_Ha)) grid%Jabs_Ha = grid%Jabs_Ha/q%scale_J_Ha
     if (par%save_peeloff_2D .and. par%nobs > 0) then
-       scale_factor = par%no_photons*observer(1)%steradian_pix*par%distance2cm**2
-       obs_scatt_2D = obs_scatt_2D/scale_factor; obs_direc_2D = obs_direc_2D/scale_factor
-       if (allocated(obs_direc0_2D)) obs_direc0_2D = obs_direc0_2D/scale_factor
+       obs_scatt_2D = obs_scatt_2D/q%scale_image; obs_direc_2D = obs_direc_2D/q%scale_image
+       if (allocated(obs_direc0_2D)) obs_direc0_2D = obs_direc0_2D/q%scale_image
        if (par%use_stokes) then
-          obs_I_2D = obs_I_2D/scale_factor; obs_Q_2D = obs_Q_2D/scale_factor; obs_U_2D = obs_U_2D/scale_factor; obs_V_2D = obs_V_2D/scale_factor
+          obs_I_2D = obs_I_2D/q%scale_image; obs_Q_2D = obs_Q_2D/q%scale_image; obs_U_2D = obs_U_2D/q%scale_image; obs_V_2D = obs_V_2D/q%scale_image
        endif
     endif
     if (par%save_peeloff_3D .and. par%nobs > 0) then
-       scale_factor = par%no_photons*observer(1)%steradian_pix*intensity_bin_unit*par%distance2cm**2
-       obs_scatt = obs_scatt/scale_factor; obs_direc = obs_direc/scale_factor
-       if (allocated(obs_direc0)) obs_direc0 = obs_direc0/scale_factor
-       if (allocated(obs_scatt_dust)) obs_scatt_dust = obs_scatt_dust/scale_factor
+       obs_scatt = obs_scatt/q%scale_cube; obs_direc = obs_direc/q%scale_cube
+       if (allocated(obs_direc0)) obs_direc0 = obs_direc0/q%scale_cube
+       if (allocated(obs_scatt_dust)) obs_scatt_dust = obs_scatt_dust/q%scale_cube
+       if (allocated(obs_peel_Ha)) obs_peel_Ha = obs_peel_Ha/q%scale_cube_Ha
        if (par%use_stokes) then
-          obs_I = obs_I/scale_factor; obs_Q = obs_Q/scale_factor; obs_U = obs_U/scale_factor; obs_V = obs_V/scale_factor
+          obs_I = obs_I/q%scale_cube; obs_Q = obs_Q/q%scale_cube; obs_U = obs_U/q%scale_cube; obs_V = obs_V/q%scale_cube
        endif
     endif
     !--- Cartesian profiles (output_sum_rect.f90:275-360): per gas cell of the bin, per unit volume
@@ -2048,10 +1595,12 @@ contains
                if (allocated(prof_J1))     prof_J1(:,ib)   = prof_J1(:,ib)/car_ncount(ib)*(f/(fourpi*dVol*par%nphotons*intensity_bin_unit))
                if (allocated(prof_P1))     prof_P1(ib)     = prof_P1(ib)/car_ncount(ib)*(f/(dVol*par%nphotons))
                if (allocated(prof_P1_new)) prof_P1_new(ib) = prof_P1_new(ib)/car_ncount(ib)*(f/(dVol*par%nphotons))
+               if (allocated(prof_Pconv))  prof_Pconv(ib)  = prof_Pconv(ib)/car_ncount(ib)*(f/(dVol*par%nphotons))
             else
                if (allocated(prof_J1))     prof_J1(:,ib)   = 0.0_wp
                if (allocated(prof_P1))     prof_P1(ib)     = 0.0_wp
                if (allocated(prof_P1_new)) prof_P1_new(ib) = 0.0_wp
+               if (allocated(prof_Pconv))  prof_Pconv(ib)  = 0.0_wp
             endif
          enddo
        end block
@@ -2069,6 +1618,7 @@ contains
                if (allocated(prof_J1))     prof_J1(:,ib)   = prof_J1(:,ib)/(fourpi*amr_vol(ib)*d2*par%nphotons*intensity_bin_unit)
                if (allocated(prof_P1))     prof_P1(ib)     = prof_P1(ib)/(amr_vol(ib)*d2*par%nphotons)
                if (allocated(prof_P1_new)) prof_P1_new(ib) = prof_P1_new(ib)/(amr_vol(ib)*d2*par%nphotons)
+               if (allocated(prof_Pconv))  prof_Pconv(ib)  = prof_Pconv(ib)/(amr_vol(ib)*d2*par%nphotons)
             endif
          enddo
        end block

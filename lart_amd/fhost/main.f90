@@ -161,8 +161,18 @@ program LaRT_amd
   if (allocated(prof_J1))     t%J1     = c_loc(prof_J1)
   if (allocated(prof_P1))     t%P1     = c_loc(prof_P1)
   if (allocated(prof_P1_new)) t%P1_new = c_loc(prof_P1_new)
+  if (allocated(grid%Jout_Ha)) then
+     t%Jout_Ha = c_loc(grid%Jout_Ha); t%Jabs_Ha = c_loc(grid%Jabs_Ha)
+  endif
+  if (allocated(obs_peel_Ha)) t%peel_Ha = c_loc(obs_peel_Ha)
+  if (allocated(prof_Pconv))  t%Pconv   = c_loc(prof_Pconv)
   call lart_check(lart_gpu_get_tallies(ctx, t), 'lart_gpu_get_tallies')
   par%nscatt_gas = t%nscatt_gas; par%nscatt_dust = t%nscatt_dust
+  if (line%line_type == 8) then                                         ! the weight budget of the two bands (define.f90:471-475)
+     par%W_conv = t%aux(1); par%W_esc1 = t%aux(2); par%W_abs1 = t%aux(3); par%W_esc2 = t%aux(4); par%W_abs2 = t%aux(5)
+  else if (line%h2%n > 0) then                                          ! H2: destroyed / re-emitted Ly-alpha weight (define.f90:490-491)
+     par%W_H2abs = t%aux(1); par%W_H2scat = t%aux(2)
+  endif
 
   call output_normalize(grid)
   call time_stamp(dtime); par%exetime = dtime/60.0_wp
@@ -172,6 +182,20 @@ program LaRT_amd
   write(6,'(a,es12.4)')   'Average Number of scattering : ', par%nscatt_tot
   write(6,'(a,2es12.4)')  'Nscatt_dust, Nscatt_gas      : ', par%nscatt_dust, par%nscatt_gas
   write(6,'(a,es12.4)')   'Scattering events per second : ', t%n_events/max(dtime, 1e-9_wp)
+  write(6,'(a,es12.4)')   'Scattering events per photon : ', t%n_events/real(max(par%nphotons, 1_int64), wp)      ! unweighted count (the <N_scatt> of the reference's logs before v2.00)
+  if (line%line_type == 8) then                                         ! output_sum_rect.f90:446-466: band1_esc + band1_abs + conv = 1, band2_esc + band2_abs = conv
+     write(*,'(a)')        '--- ly_beta bookkeeping (weights per source photon) ---'
+     write(*,'(a,es14.6)') '  band-1 (Ly-beta) escaped        : ', par%W_esc1/par%nphotons
+     write(*,'(a,es14.6)') '  band-1 (Ly-beta) dust-absorbed  : ', par%W_abs1/par%nphotons
+     write(*,'(a,es14.6)') '  conversions (3p->2s)            : ', par%W_conv/par%nphotons
+     write(*,'(a,es14.6)') '  band-2 (H-alpha) escaped        : ', par%W_esc2/par%nphotons
+     write(*,'(a,es14.6)') '  band-2 (H-alpha) dust-absorbed  : ', par%W_abs2/par%nphotons
+     write(*,'(a,es14.6)') '  band1_esc + band1_abs + conv (=1)     : ', (par%W_esc1 + par%W_abs1 + par%W_conv)/par%nphotons
+     write(*,'(a,es14.6)') '  band2_esc + band2_abs (= conv)        : ', (par%W_esc2 + par%W_abs2)/par%nphotons
+  else if (line%h2%n > 0) then
+     write(*,'(a,es14.6)') 'H2: Ly-alpha weight destroyed by H2 per photon : ', par%W_H2abs/par%nphotons
+     write(*,'(a,es14.6)') 'H2: Ly-alpha weight re-emitted by H2 per photon: ', par%W_H2scat/par%nphotons
+  endif
   write(6,'(a,f8.3,a)')   'Total Excution Time          : ', par%exetime, ' mins'
   do r = 1, ngpu
      call lart_check(lart_gpu_destroy(ctxs(r)), 'lart_gpu_destroy')
@@ -342,6 +366,14 @@ contains
     p%nD_over_nH = line%nD_over_nH; p%g_recoil0_D = line%g_recoil0_D
     p%xcrit = grid%xcrit; p%xcrit2 = grid%xcrit2
     p%Omega = par%Omega
+    if (line%line_type == 8) then                                       ! ly_beta: the band-2 (H-alpha) axis, the dust of band 2, the conversion channel
+       p%nxfreq_Ha = grid%nxfreq_Ha; p%xfreq_min_Ha = grid%xfreq_min_Ha; p%dxfreq_Ha = grid%dxfreq_Ha
+       p%R_Ha = par%R_Ha; p%albedo_Ha = par%albedo_Ha; p%hgg_Ha = par%hgg_Ha; p%P_conv = line%P_conv; p%E_conv = line%E_conv
+    endif
+    if (line%h2%n > 0) then                                             ! the H2 lines next to Ly-alpha (h2l(:) of h2_mod.f90)
+       p%h2_nlines = line%h2%n; p%h2_hi_width = merge(1, 0, par%h2_hi_width); p%h2_Dfreq_Hz = line%h2%Dfreq_Hz
+       p%h2_dnu_Hz = line%h2%dnu_Hz; p%h2_strength = line%h2%strength; p%h2_a_damp = line%h2%a_damp; p%h2_p_scat = line%h2%p_scat
+    endif
   end subroutine fill_params
 
   !--- write_output_outside: `Spectrum` table + keywords (write_output_rect.f90:423-498), Jmu image (:524-539), profile
@@ -442,7 +474,7 @@ contains
     type(grid_type), intent(inout) :: g
     type(out_file) :: o
     real(wp) :: nph_main, exetime_tot
-    type(key_list) :: kl, ki, ko, k0
+    type(key_list) :: kl, ki, ko, k0, kh
     character(len=16) :: names(6)
     character(len=8) :: tail
     real(wp), allocatable :: cols(:,:), rad(:,:)
@@ -517,6 +549,23 @@ contains
     if (allocated(prof_J1))     call out_image(o, 'Jx_1D', shape(prof_J1), prof_J1, ki)
     if (allocated(prof_P1))     call out_image(o, 'Pa_1D', shape(prof_P1), prof_P1, ki)
     if (allocated(prof_P1_new)) call out_image(o, 'Pa_1D_new', shape(prof_P1_new), prof_P1_new, ki)
+    if (line%line_type == 8) then                                       ! write_output_rect.f90:652-733: the band-2 sections, behind every older one
+       kh%n = 0
+       call kadd(kh, 'nxfreq_Ha', g%nxfreq_Ha,    'No. of band-2 frequency bins')
+       call kadd(kh, 'Xfreq1_Ha', g%xfreq_min_Ha, 'band-2 Xfreq_min')
+       call kadd(kh, 'Xfreq2_Ha', g%xfreq_max_Ha, 'band-2 Xfreq_max')
+       call kadd(kh, 'Dxfreq_Ha', g%dxfreq_Ha,    'band-2 Dxfreq')
+       call kadd(kh, 'Dwave_Ha',  g%dwave_Ha,     'band-2 Dwavelength (angstrom)')
+       call kadd(kh, 'lambda0_Ha', line%wavelength0_Ha*1e4_wp, 'H-alpha rest wavelength (angstrom)')
+       call kadd(kh, 'W_esc1', par%W_esc1/nph_main, 'band-1 escaped weight/photon (this run)')
+       call kadd(kh, 'W_abs1', par%W_abs1/nph_main, 'band-1 dust-absorbed weight/photon (this run)')
+       call kadd(kh, 'W_conv', par%W_conv/nph_main, 'conversion weight/photon (this run)')
+       call kadd(kh, 'W_esc2', par%W_esc2/nph_main, 'band-2 escaped weight/photon (this run)')
+       call kadd(kh, 'W_abs2', par%W_abs2/nph_main, 'band-2 dust-absorbed weight/photon (this run)')
+       if (allocated(g%Jout_Ha)) call out_image(o, 'Jout_Ha', [g%nxfreq_Ha], g%Jout_Ha, kh)
+       if (allocated(g%Jabs_Ha)) call out_image(o, 'Jabs_Ha', [g%nxfreq_Ha], g%Jabs_Ha, kh)
+       if (allocated(prof_Pconv)) call out_image(o, 'Pconv_1D', shape(prof_Pconv), prof_Pconv, ki)
+    endif
     call out_close(o, .true.)
     write(6,'(2a)') 'output written: ', trim(o%path)
     !--- peel-off images: one set of files per observer (write_output_rect.f90:742-1350), <base>_obs[_kkk] / <base>_stokes[_kkk]
@@ -539,6 +588,7 @@ contains
                 call out_image(o, 'Direct',    [g%nxfreq, nxi, nyi], obs_direc(:,:,:,io), k0)
                 if (allocated(obs_direc0))     call out_image(o, 'Direct0',  [g%nxfreq, nxi, nyi], obs_direc0(:,:,:,io), k0)
                 if (allocated(obs_scatt_dust)) call out_image(o, 'ScatDust', [g%nxfreq, nxi, nyi], obs_scatt_dust(:,:,:,io), k0)
+                if (allocated(obs_peel_Ha))    call out_image(o, 'Peel_Ha',  [g%nxfreq_Ha, nxi, nyi], obs_peel_Ha(:,:,:,io), k0)      ! observer(:)%peel_Ha (ly_beta)
              endif
              if (par%save_radial_profile .and. par%nside == 0) then
                 call radial_profiles(g, io, .false., rad)

@@ -1,352 +1,46 @@
 """Python mirror of the reference's host-side interface around the photon path.
 
 Same names, argument meaning and error behaviour as the Fortran host of the reference:
-    read_input        setup.f90:4-579            namelist &parameters par%... / + post-processing
-    setup_resonance_line  line_mod.f90:551-1272  (Ly-alpha branch)
-    grid_create       grid_mod_car.f90:11-1238   (analytic uniform sphere / slab / box subset)
-    observer_create   observer_rect.f90:24-326
+    read_input        setup.f90:4-579            namelist &parameters par%... (lart_amd/params.py) + post-processing
+    setup_resonance_line  line_mod.f90:551-1272  -> lart_host_line_setup / lart_host_line_lookup
+    grid_create       grid_mod_car.f90:11-1238   -> lart_host_car_medium + lart_host_freq_grid (analytic sphere / slab / box subset)
+    observer_create   observer_rect.f90:24-326   -> lart_host_observers
     run_simulation    main.f90:42                -> lart_gpu_run through the C-ABI (lart_amd.capi)
     output_reduce     main.f90:46                -> RCCL sum of the fused device tally buffer
-    output_normalize  output_sum_rect.f90:151-487 (Jout/Jin/Jabs/Jmu + peel cubes)
-This module is host plumbing (numpy); all transport arithmetic runs in liblart_gpu.so.  The Fortran host
-with the same sequence lives in lart_amd/fhost/*.f90.
+    output_normalize  output_sum_rect.f90:151-487 -> lart_host_norm_scales (Jout/Jin/Jabs/Jmu, peel cubes, the band-2 sections of ly_beta)
+This module is plumbing: the set-up arithmetic lives once, in the library (lart_amd/csrc/lart_host_setup.cpp, bound by lart_amd/hostlib.py and by the
+Fortran host lart_amd/fhost/*.f90 alike); all transport arithmetic runs in liblart_gpu.so.
 """
+import ctypes as C
 import math
 import os
-import re
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 import numpy as np
 
-from . import capi
+from . import capi, hostlib
+from .params import LartInputError, Params, MAX_OBSERVERS, NAN, read_namelist, set_param, _f32     # noqa: F401  (re-exported: the namelist surface)
+from .postproc import radial_profiles                                                               # noqa: F401  (re-exported)
 
 PI = 3.141592653589793238462643383279502884197
 TWOPI, FOURPI = 2 * PI, 4 * PI
 UM2KM, UM2M = 1.0e-9, 1.0e-6
-H_PLANCK = 6.62607004e-34
 SPEEDC = 2.99792458e5
 DEG2RAD, RAD2DEG = PI / 180.0, 180.0 / PI
-NAN = float("nan")
-MAX_OBSERVERS = capi_max = 16
+_HL = hostlib.lib
 
 
-class LartInputError(ValueError):
-    """raised where the reference prints a message and aborts (setup.f90:132-139, :244-280)"""
-
-
-def _f32(x):
-    return float(np.float32(x))
-
-
-@dataclass
-class Params:
-    """subset of params_type (define.f90:209-544) that the Cartesian hot path reads; defaults as there.
-    hgg / albedo / cext_dust defaults are float32 literals widened to f64 (define.f90:454-456)."""
-    no_photons: float = 1e5
-    iseed: int = 0
-    temperature: float = 1e4
-    taumax: float = -999.0
-    tauhomo: float = -999.0
-    tau0: float = -999.0
-    N_HImax: float = -999.0
-    N_HIhomo: float = -999.0
-    N_HI: float = -999.0
-    Vexp: float = 0.0
-    Vx: float = 0.0
-    Vy: float = 0.0
-    Vz: float = 0.0
-    comoving_source: bool = True
-    recoil: bool = False
-    core_skip: bool = False
-    core_skip_global: bool = False
-    xyz_symmetry: bool = False
-    xy_symmetry: bool = False
-    fine_structure: bool = False
-    include_deuterium: bool = False
-    D_to_H_ratio: float = 1.5e-5
-    line_id: str = "ly_alpha"
-    xy_periodic: bool = False
-    geometry: str = ""
-    velocity_type: str = ""
-    nx: int = 1
-    ny: int = 1
-    nz: int = 11
-    nr: int = -999
-    xmax: float = 1.0
-    ymax: float = 1.0
-    zmax: float = 1.0
-    rmin: float = -999.0
-    rmax: float = -999.0
-    source_rmax: float = -999.0
-    xs_point: float = 0.0
-    ys_point: float = 0.0
-    zs_point: float = 0.0
-    xfreq0: float = 0.0
-    xfreq_min: float = NAN
-    xfreq_max: float = NAN
-    nxfreq: int = 121
-    velocity_min: float = NAN
-    save_all_photons: bool = False  # the per-photon table of write_output_allph (Context.all_photons)
-    HeI_coherent: bool = False      # line type 6: frequency-dependent E1..E3 (compute_HeI_E_coherent, line_mod.f90:8-34)
-    bturb: float = -999.0           # turbulent b parameter [km/s], in quadrature with the thermal width (define.f90:928-933)
-    wavelength_min: float = NAN     # angstrom; takes precedence over the velocity window (grid_mod_car.f90:1457-1461)
-    wavelength_max: float = NAN
-    nwavelength: int = 0
-    velocity_max: float = NAN
-    nvelocity: int = 0
-    source_geometry: str = "point"
-    spectral_type: str = "voigt"
-    distance2cm: float = -999.9
-    distance_unit: str = ""
-    out_file: str = ""
-    out_merge: bool = False
-    file_format: str = "hdf5"
-    use_master_slave: bool = True
-    num_send_at_once: int = 100
-    use_reduced_wgt: bool = False
-    use_stokes: bool = False
-    save_all: bool = False
-    save_Jin: bool = True
-    save_Jabs: bool = True
-    save_Jmu: bool = False
-    nmu: int = 11
-    save_peeloff: bool = False
-    save_peeloff_2D: bool = False
-    save_peeloff_3D: bool = True
-    save_sightline_tau: bool = False
-    save_direc0: bool = False
-    save_dust_scattered: bool = False
-    save_radial_profile: bool = False
-    hgg: float = _f32(0.6761)
-    albedo: float = _f32(0.3253)
-    cext_dust: float = _f32(1.6059e-21)
-    DGR: float = 0.0
-    scatt_mat_file: str = ""
-    nprint: int = 10000000
-    no_print: float = 0.0
-    nobs: int = 1
-    nxim: int = 0
-    nyim: int = 0
-    distance: float = NAN
-    alpha: list = field(default_factory=lambda: [NAN] * MAX_OBSERVERS)
-    beta: list = field(default_factory=lambda: [NAN] * MAX_OBSERVERS)
-    gamma: list = field(default_factory=lambda: [NAN] * MAX_OBSERVERS)
-    obsx: list = field(default_factory=lambda: [NAN] * MAX_OBSERVERS)
-    obsy: list = field(default_factory=lambda: [NAN] * MAX_OBSERVERS)
-    obsz: list = field(default_factory=lambda: [NAN] * MAX_OBSERVERS)
-    dxim: float = NAN
-    dyim: float = NAN
-    nside: int = 0
-    npix: int = 0
-    # the reference's compile-time tally switches (Makefile:33-61), run-time here
-    calc_J: bool = False
-    calc_P: bool = False
-    calc_Pnew: bool = False
-    geometry_JPa: int = 2147483647
-    # clump medium (define.f90:325-352; uniform clump properties, no overlap, no radial profiles / file input)
-    use_clump_medium: bool = False
-    clump_radius: float = -1.0
-    clump_N_clumps: float = -1.0
-    clump_f_vol: float = -1.0
-    clump_f_cov: float = -1.0
-    clump_tau0: float = -1.0
-    clump_NHI: float = -1.0
-    clump_nH: float = -1.0
-    clump_temperature: float = -1.0
-    clump_sigma_v: float = 0.0
-    clump_fully_inside: bool = True
-    clump_allow_overlap: bool = False
-    cone_opening: float = 0.0       # bicone half-opening angle about the z axis [deg], 0 = everything
-    clump_input_file: str = ""
-    save_clump_info: bool = False
-    Vrot: float = 0.0
-    rinner: float = 0.0
-    Vpeak: float = 0.0
-    rpeak: float = 0.0
-    DeltaV: float = 0.0
-    velocity_alpha: float = 1.0
-    gaussian_sigma_vel: float = 12.843374
-    gaussian_FWHM_vel: float = -999.0
-    source_zscale: float = 0.0
-    # octree medium (grid_mod_amr.f90); only the generic text format of read_generic_amr.f90:112-185 is read here
-    use_amr_grid: bool = False
-    amr_type: str = "generic"
-    amr_file: str = ""
-    # derived (not inputs)
-    nphotons: int = 100000
-    mu_min: float = -1.0
-    dmu: float = 0.0
-    atau3: float = 0.0
-    N_gasmax: float = -999.0
-    N_gashomo: float = -999.0
-    # shearing box (define.f90:308-312): background y velocity -q Omega x.  Without a dens_file grid_create leaves par%Omega as it is
-    # (grid_mod_car.f90:346-351 rescales it only there), i.e. the change of grid%vfy, in thermal-speed units, per wrap around the x boundary
-    q: float = 1.0
-    Omega: float = 0.0
-    # line_id = 'ly_beta' (line type 8): band-2 (H-alpha) spectral axis and dust constants (define.f90:461-468; Draine 2003, R_V = 3.1 at 6562 A)
-    nxfreq_Ha: int = 0
-    xfreq_max_Ha: float = 0.0
-    cext_dust_Ha: float = 3.801e-22
-    albedo_Ha: float = 0.6741
-    hgg_Ha: float = 0.4967
-    R_Ha: float = 0.0
-    # H2 lines next to Ly-alpha (define.f90:478-491; h2_mod.f90): 'none' | 'neufeld'
-    h2_model: str = "none"
-    f_H2: float = 0.0
-    h2_temperature: float = 1000.0
-    h2_pure_absorption: bool = False
-    h2_hi_width: bool = False
-    h2_data_dir: str = ""
-
-
-# fields of params_type that exist in the reference but select physics outside this path: accepted at their
-# default, rejected ("not supported") when set to something that would change the path
-_UNSUPPORTED_DEFAULTS = {
-    "z_symmetry": False,
-    "dens_file": "", "temp_file": "", "velo_file": "", "emiss_file": "", "cart_file": "", "input_field": "",
-    "star_file": "", "use_cie_condition": False, "density_rscale": -999.9, "density_zscale": -999.9,
-    "density_alpha": 0.0, "temperature0": -999.0,
-    "line_prof_file": "", "luminosity": 1.0, "save_backup": False, "save_input_grid": False,
-    "intensity_unit": -999, "out_bitpix": 0,
-    # the rest of the reference's namelist surface (define.f90:209-544): readable, rejected when set
-    "Dfreq0": -999.0,
-    "voigt_a0": -999.0,
-    "source_rscale": 0.0,
-    "sersic_m": 1.0,
-    "Reff": 0.0,
-    "xmin": float("nan"),
-    "ymin": float("nan"),
-    "zmin": float("nan"),
-    "continuum_normalize": True,
-    "EW_line": 0.0,
-    "f_line": 0.0,
-    "clump_radius_profile": "constant",
-    "clump_density_profile": "constant",
-    "clump_number_profile": "constant",
-    "clump_radius_alpha": 0.0,
-    "clump_radius_r0": 0.0,
-    "clump_density_alpha": 0.0,
-    "clump_density_r0": 0.0,
-    "clump_number_alpha": 0.0,
-    "clump_number_r0": 0.0,
-    "clump_radius_min": -1.0,
-    "clump_radius_max_in": -1.0,
-    "clump_profile_file": "",
-    "amr_snapnum": 0,
-    "ionization_model": "cie_formula",
-    "dust_model": "global_dgr",
-    "emissivity_model": "none",
-    "ion_model": "none",
-    "metallicity_global": -1.0,
-    "Z_ref": 0.0134,
-    "f_ion_dust": 0.01,
-    "base_name": "",
-    "sampling_method": 1,
-    "f_composite": 0.5,
-    "ny_2gam": 101,
-    "transport_2gamma": False,
-    "W_conv": 0.0,
-    "W_esc1": 0.0,
-    "W_abs1": 0.0,
-    "W_esc2": 0.0,
-    "W_abs2": 0.0,
-    "W_H2abs": 0.0,
-    "W_H2scat": 0.0,
-    "line_prof_file_type": 0,
-    "reduce_factor": 1,
-    "centering": 0,
-    "nscatt_gas": 0.0,
-    "nscatt_dust": 0.0,
-    "nscatt_tot": 0.0,
-    "exetime": 0.0,
-    "nrejected": 0.0,
-    "acceptance_rate": 1.0,
-    "stellar_limb_darkening": 2,
-    "distance_star_to_planet": 0.0,
-    "stellar_radius": 0.0,
-    "flux_factor": 0.0,
-    "inclination_angle": float("nan"),
-    "position_angle": float("nan"),
-    "phase_angle": float("nan"),
-    "rotation_center_x": float("nan"),
-    "rotation_center_y": float("nan"),
-    "rotation_center_z": float("nan"),
-    "observer_located_inside": False,
-}
-
-
-def _parse_value(s):
-    s = s.strip().rstrip(",")
-    if s.lower() in (".true.", "t", ".t."):
-        return True
-    if s.lower() in (".false.", "f", ".f."):
-        return False
-    if s[:1] in "'\"":
-        return s.strip("'\"")
-    t = re.sub(r"[dD]", "e", s)
-    try:
-        return int(t)
-    except ValueError:
-        return float(t)
-
-
-def read_namelist(path):
-    """&parameters par%name = value ... /  (setup.f90:27-40).  Unknown names fail like a Fortran namelist read."""
-    par = Params()
-    txt = open(path).read()
-    m = re.search(r"&parameters(.*?)^\s*/", txt, re.S | re.M | re.I)
-    if not m:
-        raise LartInputError("no &parameters namelist group in " + path)
-    # strip comments, then split the group body at every `par%name[(i)] =`: several assignments may share a line
-    # (par%nx = 11, par%ny = 11) and a value list may follow one name (par%alpha = -90.0, -90.0)
-    body = "\n".join(ln.split("!")[0] for ln in m.group(1).splitlines())
-    parts = re.split(r"(par%\w+\s*(?:\(\s*\d+\s*\))?\s*=)", body, flags=re.I)
-    if parts[0].strip().strip(","):
-        raise LartInputError("cannot parse namelist text: " + parts[0].strip())
-    for key, val in zip(parts[1::2], parts[2::2]):
-        mm = re.match(r"par%(\w+)\s*(?:\(\s*(\d+)\s*\))?\s*=", key, re.I)
-        val = val.strip().rstrip(",").strip()
-        if not val:
-            raise LartInputError("no value for par%" + mm.group(1))
-        if val[:1] in "'\"":
-            v = _parse_value(val)
-        else:
-            items = [t for t in re.split(r"[,\s]+", val) if t]
-            v = _parse_value(items[0]) if len(items) == 1 else [_parse_value(t) for t in items]
-        set_param(par, mm.group(1), v, mm.group(2))
-    return par
-
-
-def set_param(par, name, val, idx=None):
-    if name in _UNSUPPORTED_DEFAULTS:
-        if val != _UNSUPPORTED_DEFAULTS[name]:
-            raise LartInputError("par%%%s = %r is not supported by this path (only the default %r)" % (name, val, _UNSUPPORTED_DEFAULTS[name]))
-        return
-    if not hasattr(par, name):
-        raise LartInputError("unknown namelist variable par%" + name)
-    cur = getattr(par, name)
-    if isinstance(cur, list):
-        vals = val if isinstance(val, (list, tuple)) else [val]
-        i0 = int(idx) - 1 if idx else 0
-        for k, v in enumerate(vals):
-            cur[i0 + k] = float(v)
-    elif isinstance(cur, bool):
-        setattr(par, name, bool(val))
-    elif isinstance(cur, int):
-        setattr(par, name, int(val))
-    elif isinstance(cur, float):
-        setattr(par, name, float(val))
-    else:
-        setattr(par, name, str(val))
+def _chk(rc):
+    hostlib.check(rc, LartInputError)
 
 
 @dataclass
 class Line:
-    """line_type (define.f90:639-680) for Ly-alpha: line_mod.f90:1241-1270"""
-    wavelength0: float = 0.1215668237310
-    damping: float = 6.2649e8
-    cross0: float = 0.026540083434 / math.sqrt(PI) * (0.27760 + 0.13881 + 0.0)
-    vtherm1: float = 0.12895319011972164 / math.sqrt(1.00797)
-    g_recoil0: float = (H_PLANCK / 1.67262192e-24 / 1.00797) / (0.1215668237310 * UM2M) ** 2
+    """line_type (define.f90:639-680) as lart_host_line_setup / lart_host_line_lookup fill it (Ly-alpha by default)"""
+    wavelength0: float = 0.0
+    damping: float = 0.0
+    cross0: float = 0.0
+    vtherm1: float = 0.0
+    g_recoil0: float = 0.0
     E1: float = 1.0
     E2: float = 0.0
     E3: float = 1.0
@@ -364,6 +58,22 @@ class Line:
     wavelength0_Ha: float = 0.6564553
     mass_amu: float = 1.00797
     h2: object = None               # H2Lines (h2_init) when par%h2_model /= 'none'
+
+    def __post_init__(self):
+        if self.wavelength0 == 0.0:
+            _fill_line(self, "ly_alpha", False, False, 0.0)
+
+
+def _fill_line(line, line_id, fine_structure, include_deuterium, D_to_H):
+    """setup_resonance_line through the library; returns (rc, record): rc = 2 for the ids of the multiplet table"""
+    h = hostlib.HostLine()
+    rc = _HL().lart_host_line_setup(line_id.encode(), int(fine_structure), int(include_deuterium), float(D_to_H), C.byref(h))
+    if rc == 0:
+        for n in ("line_type", "wavelength0", "damping", "cross0", "vtherm1", "g_recoil0", "DnuHK_Hz", "E1", "E2", "E3", "delta_nu_HD_Hz", "ratio_Dfreq_HD",
+                  "ratio_voigta_HD", "nD_over_nH", "g_recoil0_D", "P_conv", "wavelength0_Ha", "mass_amu"):
+            setattr(line, n, getattr(h, n))
+        line.E_conv = tuple(h.E_conv)
+    return rc, h
 
 
 def vtherm_total(line, T):
@@ -388,21 +98,13 @@ class ScattMat:
 
 def random_alias_setup(probs):
     """random_mt.f90:2016-2067; returns (scaled probs, 1-based alias)"""
-    n = len(probs)
-    probs = np.array(probs, dtype=np.float64) * n
-    alias = np.zeros(n, dtype=np.int32)
-    small = [i + 1 for i in range(n) if probs[i] < 1.0]
-    large = [i + 1 for i in range(n) if not probs[i] < 1.0]
-    while small and large:
-        ks, kl = small.pop(), large.pop()
-        alias[ks - 1] = kl
-        probs[kl - 1] = probs[kl - 1] + probs[ks - 1] - 1.0
-        (small if probs[kl - 1] < 1.0 else large).append(kl)
-    return probs, alias
+    p = np.array(probs, dtype=np.float64); alias = np.zeros(len(p), dtype=np.int32)
+    _chk(_HL().lart_host_alias_setup(len(p), hostlib.p(p), hostlib.p(alias)))
+    return p, alias
 
 
 def setup_scattering_matrix(par, path):
-    """setup.f90:581-649: header overrides albedo/hgg/cext_dust; S11..S34 normalised by the trapezoid integral of S11"""
+    """setup.f90:581-649: the header overrides albedo / hgg / cext_dust; the table is normalised and given its alias table by lart_host_mueller_setup"""
     with open(path) as f:
         f.readline()
         h = f.readline().split()
@@ -410,31 +112,21 @@ def setup_scattering_matrix(par, path):
         par.cext_dust, par.albedo, par.hgg, n = float(h[1]), float(h[2]), float(h[3]), int(h[4])
         tab = np.array([[float(t) for t in f.readline().split()[:5]] for _ in range(n)])
     sm = ScattMat(nPDF=n, coss=tab[:, 0].copy(), S11=tab[:, 1].copy(), S12=tab[:, 2].copy(), S33=tab[:, 3].copy(), S34=tab[:, 4].copy())
-    norm = 0.0
-    for i in range(1, n):
-        norm = norm + 0.5 * (sm.S11[i] + sm.S11[i - 1]) * abs(sm.coss[i] - sm.coss[i - 1])
-    for a in (sm.S11, sm.S12, sm.S33, sm.S34):
-        a /= norm
-    pdf = (sm.S11[:-1] + sm.S11[1:]) / 2.0
-    pdf = pdf / pdf.sum()
-    sm.phase_PDF, sm.alias = random_alias_setup(pdf)
+    sm.phase_PDF, sm.alias = np.zeros(n - 1), np.zeros(n - 1, dtype=np.int32)
+    _chk(_HL().lart_host_mueller_setup(n, *[hostlib.p(a) for a in (sm.coss, sm.S11, sm.S12, sm.S33, sm.S34, sm.phase_PDF, sm.alias)]))
     return sm
 
 
-# par%line_id -> line type, wavelength0 [um], f12(1), damping, mass of vtherm1, mass of g_recoil0, the two level wavenumbers [1/cm] of
+
+
+
 # DnuHK_Hz (setup_resonance_line, line_mod.f90:590-713).  As in the reference, CIV_1548 recoils with line%mass_amu's default 1.00797
 # (define.f90:646, line_mod.f90:605) and AlII_1671's mass is a single precision literal (:706).
-_AL_MASS = float(np.float32(26.98154))
-_METAL_LINES = {
-    "CIV_1548":  (2, 0.1548187,    0.190, 2.647e8,    12.011,   1.00797,  64591.7,     64484.0),
-    "NV_1239":   (2, 0.1238821,    0.156, 3.390e8,    14.0067,  14.0067,  80721.9,     80463.2),
-    "OVI_1032":  (2, 0.1031912,    0.133, 4.137e8,    15.9994,  15.9994,  96907.5,     96375.0),
-    "NaI_D":     (2, 0.5891583253, 0.641, 6.153e7,    22.98977, 22.98977, 16973.36619, 16956.17025),
-    "CaII_HK":   (2, 0.3934777,    0.682, 1.446667e8, 40.078,   40.078,   25414.40,    25191.51),
-    "MgII_2796": (2, 0.2796352,    0.608, 2.590e8,    24.305,   24.305,   35760.88,    35669.31),
-    "SiIV_1394": (2, 0.1393755,    0.513, 8.743e8,    28.0855,  28.0855,  71748.64,    71287.54),
-    "AlII_1671": (1, 0.16707874,   1.77,  1.41e9,     _AL_MASS, _AL_MASS, 0.0,         0.0),
-}
+
+
+
+
+
 
 _SOURCE_GEOMETRIES = {"point": 0, "uniform_sphere": 1, "uniform_cylinder": 2, "uniform": 3, "uniform_xy": 4, "gaussian": 5}
 
@@ -453,100 +145,34 @@ class H2Lines:
     f_osc: tuple = ()
 
 
-def read_energy_X(fname):
-    """read_energy_X (h2_mod.f90:250-296): rows 'V J E[cm^-1]' after a magic-number line and '#' comments"""
-    if not os.path.exists(fname):
-        raise LartInputError("h2_mod: cannot find " + fname)
-    rows = []
-    for ln in open(fname):
-        q = ln.strip()
-        if not q or q.startswith("#") or "//" in q:
-            continue
-        t = q.split()
-        try:
-            rows.append((float(t[0]), float(t[1]), float(t[2])))
-        except (ValueError, IndexError):
-            continue
-    return np.array(rows)
+
 
 
 def h2_init(par, line):
-    """h2_init (h2_mod.f90:120-222): the two B-X lines closest to Ly-alpha, R(6) and P(5) of v = 1 <- 2 (Neufeld 1990), LTE populations of the lower
-    levels at par%h2_temperature from the X-state level table <par%h2_data_dir>/energy_X.dat, strengths relative to the H I line-centre opacity"""
-    speedc, f_osc_Lya, hc_over_k, f_osc_const = SPEEDC, 0.4162, 1.4387769, 1.4992e-16
-    nu_Lya = (speedc * 1.0e5) / (line.wavelength0 * UM2M * 1.0e2)
-    vth1 = line.vtherm1 * math.sqrt(line.mass_amu / (2.0 * line.mass_amu)); T = par.h2_temperature
-    bt2 = par.bturb ** 2 if par.bturb > 0.0 else 0.0
-    vth = math.sqrt((vth1 * math.sqrt(T)) ** 2 + bt2)
-    Dfreq = nu_Lya * vth / speedc
-    dv, lam, A_ul, A_tot = (14.140, 99.229), (1215.72534, 1216.07038), (1.36e8, 1.59e8), (1.6825e9, 1.7199e9)
-    vl, Jl, Ju = (2, 2), (6, 5), (7, 4)
-    lev = read_energy_X(os.path.join(par.h2_data_dir or "data/h2", "energy_X.dat"))
-    Z = 0.0
-    for vv, jj, ee in lev:                                                # the reference's summation order
-        gns = 3.0 if int(round(jj)) % 2 != 0 else 1.0
-        Z = Z + gns * (2.0 * jj + 1.0) * math.exp(-hc_over_k * ee / T)
-    out = dict(dnu=[], s=[], a=[], p=[], pop=[], f=[])
-    for i in range(2):
-        sel = [ee for vv, jj, ee in lev if int(round(vv)) == vl[i] and int(round(jj)) == Jl[i]]
-        if not sel:
-            raise LartInputError("h2_mod: X-level (v=%d, J=%d) not found in energy_X.dat" % (vl[i], Jl[i]))
-        f_osc = f_osc_const * (2.0 * Ju[i] + 1.0) / (2.0 * Jl[i] + 1.0) * lam[i] ** 2 * A_ul[i]
-        gns = 3.0 if Jl[i] % 2 != 0 else 1.0
-        pop = gns * (2.0 * Jl[i] + 1.0) * math.exp(-hc_over_k * sel[0] / T) / Z
-        out["dnu"].append(-(dv[i] / speedc) * nu_Lya); out["f"].append(f_osc); out["pop"].append(pop)
-        out["s"].append(par.f_H2 * pop * (f_osc / f_osc_Lya)); out["a"].append(A_tot[i] / (4.0 * PI * Dfreq))
-        out["p"].append(0.0 if par.h2_pure_absorption else A_ul[i] / A_tot[i])
-    return H2Lines(n=2, Dfreq_Hz=Dfreq, dv_kms=dv, dnu_Hz=tuple(out["dnu"]), strength=tuple(out["s"]), a_damp=tuple(out["a"]), p_scat=tuple(out["p"]),
-                   pop=tuple(out["pop"]), f_osc=tuple(out["f"]))
+    """h2_init (h2_mod.f90:120-296) through lart_host_h2_init: the two B-X lines next to Ly-alpha with LTE populations at par%h2_temperature from
+    <par%h2_data_dir>/energy_X.dat, strengths relative to the H I line-centre opacity"""
+    h = hostlib.HostH2()
+    _chk(_HL().lart_host_h2_init(os.path.join(par.h2_data_dir or "data/h2", "energy_X.dat").encode(), line.wavelength0, line.vtherm1, line.mass_amu, float(par.bturb),
+                                 float(par.h2_temperature), float(par.f_H2), int(par.h2_pure_absorption), C.byref(h)))
+    v = lambda a: tuple(a[i] for i in range(h.n))
+    return H2Lines(n=h.n, Dfreq_Hz=h.Dfreq_Hz, dv_kms=v(h.dv_kms), dnu_Hz=v(h.dnu_Hz), strength=v(h.strength), a_damp=v(h.a_damp), p_scat=v(h.p_scat), pop=v(h.pop), f_osc=v(h.f_osc))
 
 
 def read_input(par, line=None):
     """post-processing part of read_input (setup.f90:42-562) for the fields this path uses. Returns (par, line, scatt_mat)."""
     line = line or Line()
-    ml = capi.line_lookup(par.line_id) if par.line_id not in ("ly_alpha", "ly_alpha_HD", "ly_beta") and par.line_id not in _METAL_LINES else None
-    if ml is not None:                                                    # resonance + fluorescence multiplets, types 4-6: line_mod.f90:713-1153
+    rc, h = _fill_line(line, par.line_id, par.fine_structure, par.include_deuterium, par.D_to_H_ratio)       # setup_resonance_line, line_mod.f90:551-1272
+    if rc == 2:                                                           # resonance + fluorescence multiplets, types 4-6 (:713-1153): the table of lart_host_line_lookup
+        ml = capi.line_lookup(par.line_id)
         line.line_type, line.wavelength0, line.damping, line.cross0 = ml.line_type, ml.wavelength0, ml.damping, ml.cross0
         line.vtherm1, line.g_recoil0, line.DnuHK_Hz, line.multiplet = ml.vtherm1, ml.g_recoil0, 0.0, ml
         line.E1, line.E2, line.E3 = 1.0, 0.0, 1.0
         ml.HeI_coherent = 1 if (par.HeI_coherent and ml.line_type == 6) else 0
         par.fine_structure = par.include_deuterium = False
-    elif par.line_id in _METAL_LINES:                                     # single lines / S-P doublets: line_mod.f90:590-713
-        typ, wl, f1, damping, mass, mass_recoil, k_hi, k_lo = _METAL_LINES[par.line_id]
-        line.line_type, line.wavelength0, line.damping = typ, wl, damping
-        line.cross0 = 0.026540083434 / math.sqrt(PI) * f1
-        line.vtherm1 = 0.12895319011972164 / math.sqrt(mass)
-        line.g_recoil0 = (H_PLANCK / 1.67262192e-24 / mass_recoil) / (wl * UM2M) ** 2
-        line.DnuHK_Hz = (2.99792458e5 * 1.0e5) * (k_hi - k_lo) if typ == 2 else 0.0
-        line.E1, line.E2, line.E3 = 1.0, 0.0, 1.0
-        par.fine_structure = par.include_deuterium = False               # (both only act on the ly_alpha branches)
-    elif par.line_id == "ly_beta":                                        # line_mod.f90:1192-1240: H I Lyman beta with the 3p -> 2s conversion to H-alpha
-        line.line_type, line.wavelength0, line.damping = 8, 0.10257222, 1.8970e8
-        line.cross0 = 0.026540083434 / math.sqrt(PI) * 0.07910
-        line.vtherm1 = 0.12895319011972164 / math.sqrt(1.00797)
-        line.g_recoil0 = (H_PLANCK / 1.67262192e-24 / 1.00797) / (line.wavelength0 * UM2M) ** 2
-        line.DnuHK_Hz, line.E1, line.E2, line.E3 = 0.0, 1.0, 0.0, 1.0
-        A21 = (1.6725e8, 2.2448e7)
-        line.P_conv = A21[1] / (A21[0] + A21[1])
-        if par.fine_structure:                                            # setup.f90:259-263
-            raise LartInputError("ly_beta: fine structure not yet supported")
-        par.include_deuterium = False
-    elif par.line_id not in ("ly_alpha", "ly_alpha_HD"):
-        raise LartInputError("par%%line_id = '%s' is not supported by this path (ly_alpha, ly_alpha_HD, %s)" % (par.line_id, ", ".join(_METAL_LINES) + " and the multiplets of lart_host_line_lookup"))
-    if par.include_deuterium and par.line_id == "ly_alpha":               # line_mod.f90:580-588
-        par.line_id = "ly_alpha_HD"
-    if par.line_id == "ly_alpha_HD":                                      # :1155-1191
-        par.fine_structure = False
-        wl_D, mass_D, damping_D = 0.1215337431, 2.01410177812, 6.2649e8
-        speedc_cm = 2.99792458e5 * 1.0e5
-        line.line_type = 7; line.nD_over_nH = par.D_to_H_ratio
-        line.delta_nu_HD_Hz = speedc_cm * (1.0 / (wl_D * UM2M * 1.0e2) - 1.0 / (line.wavelength0 * UM2M * 1.0e2))
-        line.ratio_Dfreq_HD = (wl_D / line.wavelength0) * math.sqrt(mass_D / 1.00797)
-        line.ratio_voigta_HD = (damping_D / line.damping) * line.ratio_Dfreq_HD
-        line.g_recoil0_D = (H_PLANCK / 1.67262192e-24 / mass_D) / (wl_D * UM2M) ** 2
-    if par.fine_structure:                                                # setup_resonance_line, line_mod.f90:1246-1253
-        speedc_cm = 2.99792458e5 * 1.0e5
-        line.line_type, line.DnuHK_Hz = 2, 82259.2850014 * speedc_cm - 82258.9191133 * speedc_cm
+    elif rc != 0:
+        raise LartInputError(_HL().lart_host_setup_last_error().decode())
+    else:
+        par.fine_structure, par.include_deuterium, par.line_id = bool(h.fine_structure), bool(h.include_deuterium), h.line_id.decode()
     if par.no_photons >= 1:
         par.nphotons = int(par.no_photons)
     for n in ("geometry", "source_geometry", "velocity_type", "spectral_type"):
@@ -573,40 +199,17 @@ def read_input(par, line=None):
     line.bturb = par.bturb
     if par.temperature <= 0.0 and par.bturb <= 0.0:
         raise LartInputError("ERROR: par%temperature must be > 0 K (or set par%bturb > 0)")
-    if par.nx == 1 or par.ny == 1 or par.nz == 1:
-        par.xyz_symmetry = False                                          # setup.f90:167
-    if par.nside > 0 and par.use_clump_medium:                           # setup.f90:177-181
-        raise LartInputError("ERROR: nside>0 (HEALPIX inside observer) is not supported with clump mode")
-    if par.use_clump_medium and par.use_amr_grid:
-        raise LartInputError("par%use_clump_medium and par%use_amr_grid are mutually exclusive")
-    if par.nside > 0:                                                    # observer inside the medium: setup.f90:169-186
-        par.use_stokes = False
-        par.save_peeloff = True
-        par.xyz_symmetry = False
-        par.nxim = par.nyim = 0
-    if not (par.save_peeloff_2D or par.save_peeloff_3D):                  # :188-206
-        par.save_peeloff = False
-    if par.nxim > 0 and par.nyim > 0:
-        par.save_peeloff = True
-    if par.save_peeloff and par.xyz_symmetry:
-        par.save_peeloff = False
+    r = hostlib.HostRules(sphere=int(par.geometry == "sphere"), distance_unit=hostlib.DISTANCE_UNITS.get(par.distance_unit, 4), intensity_unit=0)
+    rule_fields = ("nx", "ny", "nz", "nr", "nside", "nxim", "nyim", "nmu", "geometry_JPa", "xyz_symmetry", "xy_symmetry", "xy_periodic", "use_clump_medium", "use_amr_grid",
+                   "use_stokes", "save_all", "save_peeloff", "save_peeloff_2D", "save_peeloff_3D", "save_Jabs", "save_Jmu", "core_skip", "core_skip_global", "tau0", "taumax",
+                   "N_HI", "N_HImax", "N_HIhomo", "N_gasmax", "N_gashomo", "cext_dust", "DGR", "mu_min", "dmu", "rmax", "xmax", "ymax", "zmax", "source_rmax", "distance2cm")
+    for n in rule_fields:
+        setattr(r, n, getattr(par, n))
+    _chk(_HL().lart_host_input_rules(C.byref(r)))                        # the rules between the namelist fields (setup.f90:160-500), once for both hosts
+    for n in rule_fields:
+        setattr(par, n, type(getattr(par, n))(getattr(r, n)))
+    if r.notes & 1:
         print("---> peelingoff is not allowed for a geometry with the xyz_symmetry.\n---> setting par%save_peeloff = .false.")
-    if not par.save_peeloff:
-        par.save_peeloff_2D = par.save_peeloff_3D = False
-    if par.tau0 > 0.0 and par.taumax < 0.0:                               # :228-233
-        par.taumax = par.tau0
-    if par.N_HI > 0.0 and par.N_HImax < 0.0:
-        par.N_HImax = par.N_HI
-    if par.N_HImax > 0.0 and par.N_gasmax < 0.0:
-        par.N_gasmax = par.N_HImax
-    if par.N_HIhomo > 0.0 and par.N_gashomo < 0.0:
-        par.N_gashomo = par.N_HIhomo
-    if par.cext_dust <= 0.0:
-        par.DGR = 0.0
-    if par.DGR == 0.0:
-        par.save_Jabs = False
-    if par.core_skip_global:
-        par.core_skip = True
     if line.line_type == 8:                                               # setup.f90:239-300: vetoes, no core-skip, band-1 dust re-defaults, R_Ha
         why = ("clump medium" if par.use_clump_medium else "inside-observer (HEALPix)" if par.nside > 0 else "Stokes polarization" if par.use_stokes else
                "fine structure" if par.fine_structure else "xyz/xy symmetry, xy_periodic and shear" if (par.xyz_symmetry or par.xy_symmetry or par.xy_periodic or par.Omega != 0.0) else None)
@@ -631,29 +234,11 @@ def read_input(par, line=None):
             raise LartInputError("H2: " + why)
         line.bturb = par.bturb
         line.h2 = h2_init(par, line)
-    if par.save_Jmu:                                                      # :367-381
-        if par.nmu < 1:
-            raise LartInputError("ERROR: par%nmu must be >= 1 when par%save_Jmu = .true.")
-        if par.xyz_symmetry:
-            par.mu_min, par.dmu = 0.0, 1.0 / par.nmu
-        else:
-            par.mu_min, par.dmu = -1.0, 2.0 / par.nmu
-    if par.nr > 1:
-        par.nx = par.ny = par.nz = par.nr
     if par.use_amr_grid:
         if par.amr_type.lower() != "generic":
             raise LartInputError("par%%amr_type = '%s' is not supported by this path (generic text files only)" % par.amr_type)
         if not par.amr_file:
             raise LartInputError("par%use_amr_grid = .true. needs par%amr_file")
-    if par.geometry == "sphere":                                          # :398-428
-        if not par.xy_periodic and not par.use_amr_grid:
-            c = [v for v in (par.rmax, par.xmax, par.ymax, par.zmax) if v > 0.0]
-            if c:
-                par.rmax = par.xmax = par.ymax = par.zmax = max(c)
-            if not par.xy_symmetry:
-                par.nx = par.ny = par.nz = max(par.nx, par.ny, par.nz)
-    else:
-        par.rmax = -1.0
     if par.xy_symmetry:                                                   # mirrors in x and y, the full z range (grid_mod_car.f90:113-134)
         if par.xyz_symmetry or par.xy_periodic or par.use_clump_medium:
             raise LartInputError("par%xy_symmetry excludes xyz_symmetry / xy_periodic / clumps")
@@ -661,16 +246,8 @@ def read_input(par, line=None):
             raise LartInputError("par%xy_symmetry needs a point source on the z axis (sources are folded for xyz_symmetry only, generate_photon.f90:352-356)")
         if par.calc_J or par.calc_P or par.calc_Pnew:
             raise LartInputError("par%geometry_JPa = 2 (cylindrical profiles, the xy_symmetry default) is not supported by this path")
-    if par.source_rmax < 0.0:
-        par.source_rmax = par.rmax
-    if par.rmax <= 0.0:                                                   # geometry of the J/P profiles: setup.f90:438-459
-        par.geometry_JPa = 3
-    if par.geometry_JPa < -1 or par.geometry_JPa > 3:
-        par.geometry_JPa = 3 if par.save_all else (-1 if par.xy_periodic else 1)
     if par.geometry_JPa in (0, 2) and (par.calc_J or par.calc_P or par.calc_Pnew):
         raise LartInputError("par%geometry_JPa = 2 (cylindrical profiles) is not supported by this path")
-    if par.distance2cm < 0.0:                                             # :473-489
-        par.distance2cm = {"kpc": 3.0856776e21, "pc": 3.0856776e18, "au": 1.4960e13, "": 1.0}.get(par.distance_unit, 3.0856776e21)
     scatt_mat = ScattMat()
     if par.scatt_mat_file and par.DGR > 0.0:                              # :496-500
         scatt_mat = setup_scattering_matrix(par, par.scatt_mat_file)
@@ -727,11 +304,7 @@ class Grid:
     tauhomo: float = 0.0
 
 
-def _sym_axis(n, vmax):
-    if (n // 2) * 2 == n:
-        return vmax / n, 0.0, 1
-    d = vmax / (n - 0.5)
-    return d, -d / 2.0, 2
+
 
 
 def voigt_center(a):
@@ -740,147 +313,30 @@ def voigt_center(a):
 
 
 def grid_create(par, line):
-    """grid_mod_car.f90:73-1238, analytic-medium subset (no input files)."""
+    """grid_mod_car.f90:73-1238, analytic-medium subset (no input files): lart_host_car_medium builds the axes, the density mask of the shell / bicone, the
+    opacity normalisation (taumax | tauhomo | N_gasmax | N_gashomo) and the velocity field, car_setup_freq_grid the spectral axis and the core-skip scale"""
     g = Grid(nx=par.nx, ny=par.ny, nz=par.nz, xmax=par.xmax, ymax=par.ymax, zmax=par.zmax, rmin=par.rmin, rmax=par.rmax)
-    nx, ny, nz = g.nx, g.ny, g.nz
-    if par.xyz_symmetry:
-        g.dx, g.xmin, g.i0 = _sym_axis(nx, g.xmax)
-        g.dy, g.ymin, g.j0 = _sym_axis(ny, g.ymax)
-        g.dz, g.zmin, g.k0 = _sym_axis(nz, g.zmax)
-    elif par.xy_symmetry:                                                 # :113-134
-        g.dx, g.xmin, g.i0 = _sym_axis(nx, g.xmax)
-        g.dy, g.ymin, g.j0 = _sym_axis(ny, g.ymax)
-        g.dz, g.zmin, g.k0 = 2.0 * par.zmax / nz, -g.zmax, 0
-    else:
-        g.dx, g.dy, g.dz = 2.0 * par.xmax / nx, 2.0 * par.ymax / ny, 2.0 * par.zmax / nz
-        g.xmin, g.ymin, g.zmin = -g.xmax, -g.ymax, -g.zmax
-    g.xface = np.arange(nx + 1) * g.dx + g.xmin
-    g.yface = np.arange(ny + 1) * g.dy + g.ymin
-    g.zface = np.arange(nz + 1) * g.dz + g.zmin
-    xx = (g.xface[:-1] + g.xface[1:]) / 2.0
-    yy = (g.yface[:-1] + g.yface[1:]) / 2.0
-    zz = (g.zface[:-1] + g.zface[1:]) / 2.0
-    shape = (nx, ny, nz)
-    vth = vtherm_total(line, par.temperature)
-    g.Dfreq_ref = vth / (line.wavelength0 * UM2KM)
-    g.Dfreq = np.full(shape, vth / (line.wavelength0 * UM2KM), order="F")
-    g.voigt_a = (line.damping / FOURPI) / g.Dfreq
+    if par.velocity_type not in hostlib.VELOCITY_TYPES:
+        raise LartInputError("par%%velocity_type = '%s' is not supported by this path" % par.velocity_type)
+    m = hostlib.HostMedium(nx=g.nx, ny=g.ny, nz=g.nz, xyz_symmetry=int(par.xyz_symmetry), xy_symmetry=int(par.xy_symmetry), velocity_type=hostlib.VELOCITY_TYPES[par.velocity_type])
+    for n in ("xmax", "ymax", "zmax", "rmin", "rmax", "cone_opening", "taumax", "tauhomo", "N_gasmax", "N_gashomo", "Vexp", "Vx", "Vy", "Vz", "Vrot", "rinner", "velocity_alpha",
+              "rpeak", "Vpeak", "DeltaV"):
+        setattr(m, n, float(getattr(par, n)))
+    m.vtherm, m.wavelength0, m.damping, m.cross0 = vtherm_total(line, par.temperature), line.wavelength0, line.damping, line.cross0
+    m.dust_opacity = par.cext_dust * par.DGR
     if not par.use_clump_medium:                                          # :352-363: the clump population carries the physical length unit
         par.distance_unit, par.distance2cm = "", 1.0
-    g.rhokap = np.ones(shape, order="F")
-    g.rhokapD = np.full(shape, par.cext_dust * par.DGR, order="F") if par.DGR > 0.0 else None
-    X, Y, Z = np.meshgrid(xx, yy, zz, indexing="ij")
-    rr = np.sqrt(X ** 2 + Y ** 2 + Z ** 2)
-    if par.rmax > 0.0:                                                    # :367-395
-        out = (rr < par.rmin) | (rr > par.rmax)
-        g.rhokap[out] = 0.0
-        if g.rhokapD is not None:
-            g.rhokapD[out] = 0.0
-    if 0.0 < par.cone_opening < 90.0:                                     # :397-412 biconical mask about the z axis
-        with np.errstate(invalid="ignore", divide="ignore"):
-            out = (rr > 0.0) & (np.abs(Z) / rr < math.cos(par.cone_opening * math.pi / 180.0))
-        g.rhokap[out] = 0.0
-        if g.rhokapD is not None:
-            g.rhokapD[out] = 0.0
-    g.rhokap = g.rhokap / g.Dfreq * line.cross0                           # :487-493
-    if par.rmax > 0.0 and par.rmin > 0.0:
-        opac_length = par.rmax - par.rmin
-    elif par.rmax > 0.0:
-        opac_length = par.rmax
-    elif g.zmax == -g.zmin:
-        opac_length = (g.zmax - g.zmin) / 2.0
-    else:
-        opac_length = g.zmax - g.zmin
-    nxcen, nycen = (1, 1) if (par.xyz_symmetry or par.xy_symmetry) else ((nx + 1) // 2, (ny + 1) // 2)
-    H0 = voigt_center(g.voigt_a)
-    pole_k = g.rhokap[nxcen - 1, nycen - 1, :] * H0[nxcen - 1, nycen - 1, :]
-    pole_n = g.rhokap[nxcen - 1, nycen - 1, :] * g.Dfreq[nxcen - 1, nycen - 1, :]
-    nadd = np.ones(shape)
-    if par.xyz_symmetry:
-        if nx % 2:
-            nadd[0, :, :] /= 2.0
-        if ny % 2:
-            nadd[:, 0, :] /= 2.0
-        if nz % 2:
-            nadd[:, :, 0] /= 2.0
-    elif par.xy_symmetry:
-        if nx % 2:
-            nadd[0, :, :] /= 2.0
-        if ny % 2:
-            nadd[:, 0, :] /= 2.0
-    gas = g.rhokap > 0.0
-
-    def pole(v):
-        s = _seqsum(v)
-        if par.xyz_symmetry:
-            return (s - v[0] / 2.0) * g.dz if nz % 2 else s * g.dz
-        return s * g.dz / 2.0 if g.zmax == -g.zmin else s * g.dz
-
-    opac_norm = None
-    if par.taumax > 0.0:                                                  # :518-538
-        opac_norm = par.taumax / pole(pole_k)
-    elif par.tauhomo > 0.0:                                               # :539-566
-        opac_norm = par.tauhomo / ((g.rhokap * H0 * nadd)[gas].sum() / nadd[gas].sum() * opac_length)
-    elif par.N_gasmax > 0.0:                                              # :567-586
-        opac_norm = par.N_gasmax / (pole(pole_n) / line.cross0)
-    elif par.N_gashomo > 0.0:                                             # :587-615
-        opac_norm = par.N_gashomo / ((g.rhokap * g.Dfreq * nadd)[gas].sum() / nadd[gas].sum() / line.cross0 * opac_length)
-    if opac_norm is not None:
-        g.rhokap *= opac_norm
-        if g.rhokapD is not None:
-            g.rhokapD *= opac_norm
-        pole_k = pole_k * opac_norm
-        pole_n = pole_n * opac_norm
-    g.tauhomo = (g.rhokap * H0 * nadd)[gas].sum() / nadd[gas].sum() * opac_length      # :617-640
-    g.taupole = pole(pole_k)
-    N_gashomo = (g.rhokap * g.Dfreq * nadd)[gas].sum() / nadd[gas].sum() / line.cross0 * opac_length
-    N_gaspole = pole(pole_n) / line.cross0
-    if par.taumax <= 0.0:
-        par.taumax = g.taupole
-    if par.tauhomo <= 0.0:
-        par.tauhomo = g.tauhomo
-    if par.N_gasmax <= 0.0:
-        par.N_gasmax = N_gaspole
-    if par.N_gashomo <= 0.0:
-        par.N_gashomo = N_gashomo
-    g.vfx = np.zeros(shape, order="F"); g.vfy = np.zeros(shape, order="F"); g.vfz = np.zeros(shape, order="F")
-    if par.velocity_type:                                                 # :786-946
-        rpeak = max(g.xmax, g.ymax, g.zmax) if par.rmax <= 0.0 else par.rmax
-        if par.velocity_type == "hubble":
-            g.vfx[gas] = ((par.Vexp / vth) * X / rpeak)[gas]; g.vfy[gas] = ((par.Vexp / vth) * Y / rpeak)[gas]; g.vfz[gas] = ((par.Vexp / vth) * Z / rpeak)[gas]
-        elif par.velocity_type == "constant_radial":
-            m = gas & (rr > g.dz / 10.0)
-            with np.errstate(invalid="ignore", divide="ignore"):
-                g.vfx[m] = (par.Vexp / vth * X / rr)[m]; g.vfy[m] = (par.Vexp / vth * Y / rr)[m]; g.vfz[m] = (par.Vexp / vth * Z / rr)[m]
-        elif par.velocity_type == "parallel_velocity":
-            g.vfx[gas] = par.Vx / vth; g.vfy[gas] = par.Vy / vth; g.vfz[gas] = par.Vz / vth
-        elif par.velocity_type == "rotating_solid_body":                  # :905-916
-            g.vfx[gas] = (-par.Vrot / vth * Y / par.rmax)[gas]; g.vfy[gas] = (par.Vrot / vth * X / par.rmax)[gas]
-        elif par.velocity_type == "rotating_galaxy_halo":                 # :917-934
-            rc = np.sqrt(X ** 2 + Y ** 2)
-            with np.errstate(invalid="ignore", divide="ignore"):
-                den = np.where(rc < par.rinner, par.rinner, rc)
-                g.vfx[gas] = (-par.Vrot / vth * Y / den)[gas]; g.vfy[gas] = (par.Vrot / vth * X / den)[gas]
-        else:                                                             # power_law :853-874, linear_decelerate :875-904, ssh :817-838
-            m = gas & (rr > g.dz / 10.0)
-            with np.errstate(invalid="ignore", divide="ignore"):
-                if par.velocity_type == "power_law":
-                    Vs = par.Vexp * (rr / rpeak) ** par.velocity_alpha
-                elif par.velocity_type == "linear_decelerate":
-                    Vs = par.Vexp * np.maximum(0.0, (rpeak - rr) / (rpeak - max(par.rmin, 0.0)))
-                else:
-                    rp = par.rpeak; m = gas
-                    Vs = np.where(rr < rp, par.Vpeak / rp * rr, par.Vpeak + par.DeltaV * (rr - rp) / (par.rmax - rp))
-                ur = np.where(rr > 0.0, 1.0 / np.where(rr > 0.0, rr, 1.0), 0.0)
-                g.vfx[m] = (Vs / vth * X * ur)[m]; g.vfy[m] = (Vs / vth * Y * ur)[m]; g.vfz[m] = (Vs / vth * Z * ur)[m]
-    g.voigt_amean = (line.damping / FOURPI) / g.Dfreq_ref                 # :1150-1154
-    atau0 = g.voigt_amean * par.tauhomo
-    car_setup_freq_grid(par, line, g)
-    at = atau0 if par.core_skip_global else atau0 / (g.xmax / g.dx)       # :1186-1219
-    if at > 1.0:
-        xi, chi = (0.6, 1.2) if at <= 60.0 else (1.4, 0.6)
-        g.xcrit = 0.02 * math.exp(xi * math.log(at) ** chi)
-        g.xcrit2 = g.xcrit ** 2
+    shape = (g.nx, g.ny, g.nz)
+    g.xface, g.yface, g.zface = np.zeros(g.nx + 1), np.zeros(g.ny + 1), np.zeros(g.nz + 1)
+    for n in ("rhokap", "voigt_a", "Dfreq", "vfx", "vfy", "vfz"):
+        setattr(g, n, np.zeros(shape, order="F"))
+    g.rhokapD = np.zeros(shape, order="F") if par.DGR > 0.0 else None
+    _chk(_HL().lart_host_car_medium(C.byref(m), *[hostlib.p(a) for a in (g.xface, g.yface, g.zface, g.rhokap, g.voigt_a, g.Dfreq, g.vfx, g.vfy, g.vfz, g.rhokapD)]))
+    for n in ("dx", "dy", "dz", "xmin", "ymin", "zmin", "i0", "j0", "k0", "Dfreq_ref", "voigt_amean"):
+        setattr(g, n, getattr(m, n))
+    g.taupole, g.tauhomo = m.taupole_out, m.tauhomo_out
+    par.taumax, par.tauhomo, par.N_gasmax, par.N_gashomo = m.taumax, m.tauhomo, m.N_gasmax, m.N_gashomo      # what was not given is the medium's own (:617-737)
+    car_setup_freq_grid(par, line, g, core_skip_scale=True)
     return g
 
 
@@ -895,94 +351,32 @@ class JPa:
 def create_JPa_mem(par, g):
     if not (par.calc_J or par.calc_P or par.calc_Pnew):
         return JPa()
-    nx, ny, nz = g.nx, g.ny, g.nz
-    nadd = np.ones((nx, ny, nz))
-    if par.xyz_symmetry:
-        nadd[:] = 8.0
-        if nx % 2:
-            nadd[0, :, :] /= 2.0
-        if ny % 2:
-            nadd[:, 0, :] /= 2.0
-        if nz % 2:
-            nadd[:, :, 0] /= 2.0
-    gas = g.rhokap > 0.0
-    if par.geometry_JPa == 1:
-        nr = max(nx, ny, nz)
-        if not par.xyz_symmetry:
-            nr = nr // 2 if nr % 2 == 0 else (nr - 1) // 2 + 1
-        rmax = min(g.xmax, g.ymax, g.zmax)
-        dr, roff = (rmax / nr, 0.0) if nr % 2 == 0 else (rmax / (nr - 0.5), -(rmax / (nr - 0.5)) / 2.0)
-        xx = (g.xface[:-1] + g.xface[1:]) / 2.0; yy = (g.yface[:-1] + g.yface[1:]) / 2.0; zz = (g.zface[:-1] + g.zface[1:]) / 2.0
-        X, Y, Z = np.meshgrid(xx, yy, zz, indexing="ij")
-        ib = np.floor((np.sqrt(X ** 2 + Y ** 2 + Z ** 2) - roff) / dr).astype(np.int64) + 1
-        ok = (ib >= 1) & (ib <= nr)
-        ind = np.where(ok, ib, 0).astype(np.int32)
-        ncount = np.zeros(nr)
-        np.add.at(ncount, ib[ok & gas] - 1, nadd[ok & gas])
-        return JPa(nr, np.asfortranarray(ind), ncount)
-    if par.geometry_JPa == -1:
-        ind = np.broadcast_to(np.arange(1, nz + 1, dtype=np.int32)[None, None, :], (nx, ny, nz))
-        return JPa(nz, np.asfortranarray(ind), gas.sum(axis=(0, 1)).astype(float))
-    ind = (np.arange(nx * ny * nz, dtype=np.int32) + 1).reshape((nx, ny, nz), order="F")
-    return JPa(nx * ny * nz, np.asfortranarray(ind), (nadd if par.xyz_symmetry else np.ones((nx, ny, nz))).ravel(order="F"))
+    ind = np.zeros((g.nx, g.ny, g.nz), dtype=np.int32, order="F"); ncount = np.zeros(g.nx * g.ny * g.nz); nb = C.c_int32()
+    _chk(_HL().lart_host_jpa_car(int(par.geometry_JPa), int(par.xyz_symmetry), g.nx, g.ny, g.nz, hostlib.p(g.xface), hostlib.p(g.yface), hostlib.p(g.zface),
+                                 g.xmax, g.ymax, g.zmax, hostlib.p(g.rhokap), C.byref(nb), hostlib.p(ind), hostlib.p(ncount)))
+    return JPa(nb.value, ind, ncount[:nb.value].copy())
 
 
-def _seqsum(v):
-    s = 0.0
-    for t in v:
-        s = s + float(t)
-    return s
-
-
-def car_setup_freq_grid(par, line, g):
-    """grid_mod_car.f90:1442-1548"""
-    par.atau3 = (g.voigt_amean * par.tauhomo) ** (1.0 / 3.0)
+def car_setup_freq_grid(par, line, g, core_skip_scale=False):
+    """grid_mod_car.f90:1442-1548 through lart_host_freq_grid: the spectral axis from the wavelength / velocity window or from (a tau)^(1/3), the band-2 axis of
+    ly_beta; core_skip_scale: also grid%xcrit of the Cartesian grid (:1186-1219; the octree sets its own)"""
     vth = vtherm_total(line, par.temperature)
-    if math.isfinite(par.wavelength_min) and math.isfinite(par.wavelength_max):
-        if par.nwavelength == 0 and par.nxfreq > 0:
-            par.nwavelength = par.nxfreq
-        if par.nwavelength > 0:
-            par.nxfreq = par.nwavelength
-        speedc = 2.99792458e5
-        par.xfreq_min = -(par.wavelength_max - line.wavelength0 * 1e4) / (line.wavelength0 * 1e4) * (speedc / vth)
-        par.xfreq_max = -(par.wavelength_min - line.wavelength0 * 1e4) / (line.wavelength0 * 1e4) * (speedc / vth)
-    elif math.isfinite(par.velocity_min) and math.isfinite(par.velocity_max):
-        if par.nvelocity == 0 and par.nxfreq > 0:
-            par.nvelocity = par.nxfreq
-        if par.nvelocity > 0:
-            par.nxfreq = par.nvelocity
-        par.xfreq_min, par.xfreq_max = -par.velocity_max / vth, -par.velocity_min / vth
-    g.nxfreq = par.nxfreq
-    if not (math.isfinite(par.xfreq_max) and math.isfinite(par.xfreq_min)):
-        xscale = 25.0 if par.taumax <= 5e1 else 14.0 if par.taumax <= 5e2 else 10.0 if par.taumax <= 5e3 else 5.0
-        if par.Vexp == 0.0:
-            par.xfreq_max = math.floor(xscale * par.atau3) + 1
-            par.xfreq_min = -(math.floor(xscale * par.atau3 + line.DnuHK_Hz / g.Dfreq_ref) + 1)
-        elif par.Vexp > 0.0:
-            par.xfreq_max = math.floor(xscale * par.atau3) + 1
-            par.xfreq_min = -(math.floor(xscale * par.atau3 + abs(par.Vexp) / vth + line.DnuHK_Hz / g.Dfreq_ref) + 1)
-        else:
-            par.xfreq_max = math.floor(xscale * par.atau3 + abs(par.Vexp) / vth) + 1
-            par.xfreq_min = -(math.floor(xscale * par.atau3 + line.DnuHK_Hz / g.Dfreq_ref) + 1)
-        if par.spectral_type == "continuum":                               # :1490-1494
-            xscale = 4.0 * xscale
-            par.xfreq_max = math.floor(xscale * par.atau3 + abs(par.Vexp) / vth) + 1
-            par.xfreq_min = -(math.floor(xscale * par.atau3 + abs(par.Vexp) / vth + line.DnuHK_Hz / g.Dfreq_ref) + 1)
-    g.dxfreq = (par.xfreq_max - par.xfreq_min) / par.nxfreq
-    g.xfreq_max, g.xfreq_min = float(par.xfreq_max), float(par.xfreq_min)
-    if line.line_type == 8:                                                # :1518-1529 the band-2 (H-alpha) axis
-        g.nxfreq_Ha = par.nxfreq_Ha if par.nxfreq_Ha > 0 else g.nxfreq
-        par.nxfreq_Ha = g.nxfreq_Ha
-        if par.xfreq_max_Ha > 0.0:
-            g.xfreq_max_Ha, g.xfreq_min_Ha = float(par.xfreq_max_Ha), -float(par.xfreq_max_Ha)
-        else:
-            g.xfreq_min_Ha, g.xfreq_max_Ha = g.xfreq_min, g.xfreq_max
-        g.dxfreq_Ha = (g.xfreq_max_Ha - g.xfreq_min_Ha) / g.nxfreq_Ha
-        g.dwave_Ha = vth / SPEEDC * (line.wavelength0_Ha * 1e4) * g.dxfreq_Ha
-    g.xfreq = (np.arange(1, g.nxfreq + 1) - 0.5) * g.dxfreq + g.xfreq_min
-    g.velocity = -vth * g.xfreq
-    g.dwave = vth / SPEEDC * (line.wavelength0 * 1e4) * g.dxfreq
-    g.wavelength = (g.velocity / SPEEDC + 1.0) * (line.wavelength0 * 1e4)
+    f = hostlib.HostFreq(nxfreq=par.nxfreq, nwavelength=par.nwavelength, nvelocity=par.nvelocity, continuum=int(par.spectral_type == "continuum"), line_type=line.line_type,
+                         nxfreq_Ha=par.nxfreq_Ha, core_skip_global=int(par.core_skip_global))
+    for n in ("wavelength_min", "wavelength_max", "velocity_min", "velocity_max", "xfreq_min", "xfreq_max", "tauhomo", "taumax", "Vexp", "xfreq_max_Ha"):
+        setattr(f, n, float(getattr(par, n)))
+    f.vtherm, f.wavelength0, f.wavelength0_Ha, f.Dfreq_ref, f.DnuHK_Hz, f.voigt_amean = vth, line.wavelength0, line.wavelength0_Ha, g.Dfreq_ref, line.DnuHK_Hz, g.voigt_amean
+    f.cells_per_radius = g.xmax / g.dx if (core_skip_scale and g.dx > 0.0) else 1.0
+    _chk(_HL().lart_host_freq_grid(C.byref(f)))
+    par.atau3, par.nxfreq, par.nwavelength, par.nvelocity, par.xfreq_min, par.xfreq_max = f.atau3, f.nxfreq, f.nwavelength, f.nvelocity, f.xfreq_min, f.xfreq_max
+    g.nxfreq, g.dxfreq, g.xfreq_max, g.xfreq_min, g.dwave = f.nxfreq, f.dxfreq, f.xfreq_max, f.xfreq_min, f.dwave
+    if line.line_type == 8:
+        g.nxfreq_Ha = par.nxfreq_Ha = f.nxfreq_Ha
+        g.xfreq_min_Ha, g.xfreq_max_Ha, g.dxfreq_Ha, g.dwave_Ha = f.xfreq_min_Ha, f.xfreq_max_Ha, f.dxfreq_Ha, f.dwave_Ha
+    if core_skip_scale:
+        g.xcrit, g.xcrit2 = f.xcrit, f.xcrit2
+    g.xfreq, g.velocity, g.wavelength = np.zeros(g.nxfreq), np.zeros(g.nxfreq), np.zeros(g.nxfreq)
+    _chk(_HL().lart_host_freq_axis(g.nxfreq, g.xfreq_min, g.dxfreq, vth, line.wavelength0, hostlib.p(g.xfreq), hostlib.p(g.velocity), hostlib.p(g.wavelength)))
 
 
 @dataclass
@@ -998,96 +392,25 @@ class Observers:
 
 
 def observer_create(par):
-    """observer_create_outside: observer_rect.f90:24-326 (rotation centre at the origin)"""
+    """observer_create_outside (observer_rect.f90:24-326, rotation centre at the origin) / observer_create_inside (observer_heal.f90:24-80) through
+    lart_host_observers; par%alpha/beta/gamma, par%obsx/y/z, par%distance, par%dxim/dyim come back completed, as the reference leaves them"""
     if not par.save_peeloff:
         return Observers()
-    fin = math.isfinite
-    if par.nside > 0:                                                     # observer_create_inside: observer_heal.f90:24-80
-        if not (fin(par.obsx[0]) and fin(par.obsy[0]) and fin(par.obsz[0])):
-            par.obsx[0] = par.obsy[0] = par.obsz[0] = 0.0
-        n = sum(1 for i in range(MAX_OBSERVERS) if fin(par.obsx[i]) and fin(par.obsy[i]) and fin(par.obsz[i]))
-        par.nobs, par.npix = n, 12 * par.nside ** 2
-        return Observers(nobs=n, xyz=np.array([[par.obsx[i], par.obsy[i], par.obsz[i]] for i in range(n)]), nxim=par.npix, nyim=1,
-                         steradian_pix=4.0 * PI / par.npix)
-    maxsz = max(par.xmax, par.ymax, par.zmax)
-    for i in range(MAX_OBSERVERS):
-        if fin(par.beta[i]) and not fin(par.alpha[i]):
-            par.alpha[i] = 0.0
-        if fin(par.alpha[i]) and not fin(par.beta[i]):
-            par.beta[i] = 0.0
-    if not (fin(par.alpha[0]) and fin(par.beta[0])) and not (fin(par.obsx[0]) and fin(par.obsy[0]) and fin(par.obsz[0])):
-        if not fin(par.distance):
-            par.distance = maxsz * 100.0
-        par.obsx[0], par.obsy[0], par.obsz[0] = 0.0, 0.0, 1.0
-        par.alpha[0], par.beta[0] = 0.0, 0.0
-
-    def default_gamma(i):
-        if not fin(par.gamma[i]):
-            par.gamma[i] = 90.0 if 0.0 < par.beta[i] <= 90.0 else (-90.0 if par.beta[i] > 90.0 else 0.0)
-
-    xyz, trig = [], []
-    if fin(par.alpha[0]) and fin(par.beta[0]):
-        n = sum(1 for i in range(MAX_OBSERVERS) if fin(par.alpha[i]) and fin(par.beta[i]))
-        if not fin(par.distance):
-            par.distance = maxsz * 100.0
-        for i in range(n):
-            default_gamma(i)
-            ca, sa = math.cos(par.alpha[i] * DEG2RAD), math.sin(par.alpha[i] * DEG2RAD)
-            cb, sb = math.cos(par.beta[i] * DEG2RAD), math.sin(par.beta[i] * DEG2RAD)
-            cg, sg = math.cos(par.gamma[i] * DEG2RAD), math.sin(par.gamma[i] * DEG2RAD)
-            xyz.append((par.distance * ca * sb, par.distance * sa * sb, par.distance * cb))
-            trig.append((ca, sa, cb, sb, cg, sg))
-    else:
-        n = sum(1 for i in range(MAX_OBSERVERS) if fin(par.obsx[i]) and fin(par.obsy[i]) and fin(par.obsz[i]))
-        if not fin(par.distance):
-            par.distance = math.sqrt(par.obsx[0] ** 2 + par.obsy[0] ** 2 + par.obsz[0] ** 2)
-            if par.distance < 10.0 * maxsz:
-                par.distance = maxsz * 100.0
-        eps = np.finfo(np.float64).eps
-        for i in range(n):
-            default_gamma(i)
-            ds = par.distance / math.sqrt(par.obsx[i] ** 2 + par.obsy[i] ** 2 + par.obsz[i] ** 2)
-            p = (par.obsx[i] * ds, par.obsy[i] * ds, par.obsz[i] * ds) if ds > 1.001 else (par.obsx[i], par.obsy[i], par.obsz[i])
-            cb = p[2] / par.distance
-            if abs(cb - 1.0) < eps:
-                cb = 1.0
-            if abs(cb + 1.0) < eps:
-                cb = -1.0
-            sb = math.sqrt(1.0 - cb * cb)
-            par.beta[i] = math.atan2(sb, cb) * RAD2DEG
-            cg, sg = math.cos(par.gamma[i] * DEG2RAD), math.sin(par.gamma[i] * DEG2RAD)
-            if sb == 0.0:
-                ca, sa, par.alpha[i] = 1.0, 0.0, 0.0
-            else:
-                al = math.atan2(p[1], p[0]); ca, sa = math.cos(al), math.sin(al); par.alpha[i] = al * RAD2DEG
-            xyz.append(p); trig.append((ca, sa, cb, sb, cg, sg))
-    par.nobs = n
-    rm = np.zeros((n, 3, 3))
-    for i, (ca, sa, cb, sb, cg, sg) in enumerate(trig):                   # :207-217
-        rm[i] = [[ca * cb * cg - sa * sg, sa * cb * cg + ca * sg, -sb * cg],
-                 [-ca * cb * sg - sa * cg, -sa * cb * sg + ca * cg, sb * sg],
-                 [ca * sb, sa * sb, cb]]
-    if not (fin(par.dxim) and fin(par.dyim)):                             # :244-276
-        if par.geometry == "sphere":
-            par.dxim = math.asin(par.rmax / par.distance) / (par.nxim / 2.0) * RAD2DEG
-            par.dyim = math.asin(par.rmax / par.distance) / (par.nyim / 2.0) * RAD2DEG
-        else:
-            vx = [1, 1, 1, -1, -1, -1, 1, -1]; vy = [1, 1, -1, 1, -1, 1, -1, -1]; vz = [1, -1, 1, 1, 1, -1, -1, -1]
-            mx = my = -999.0
-            for i in range(n):
-                for iv in range(8):
-                    pv = np.array(xyz[i]) - np.array([vx[iv] * par.xmax, vy[iv] * par.ymax, vz[iv] * par.zmax])
-                    k = rm[i] @ pv
-                    mx = max(mx, abs(math.atan2(-k[0], k[2]))); my = max(my, abs(math.atan2(-k[1], k[2])))
-            if par.nxim == par.nyim:
-                par.dxim = max(mx, my) / (par.nxim / 2.0) * RAD2DEG; par.dyim = max(mx, my) / (par.nyim / 2.0) * RAD2DEG
-            else:
-                if not fin(par.dxim):
-                    par.dxim = mx / (par.nxim / 2.0) * RAD2DEG
-                if not fin(par.dyim):
-                    par.dyim = my / (par.nyim / 2.0) * RAD2DEG
-    return Observers(nobs=n, xyz=np.array(xyz), rmatrix=rm, dxim=par.dxim, dyim=par.dyim, nxim=par.nxim, nyim=par.nyim,
-                     steradian_pix=par.dxim * par.dyim * DEG2RAD ** 2)
+    o = hostlib.HostObs(nside=par.nside, sphere=int(par.geometry == "sphere"), nxim=par.nxim, nyim=par.nyim)
+    for n in ("xmax", "ymax", "zmax", "rmax", "distance", "dxim", "dyim"):
+        setattr(o, n, float(getattr(par, n)))
+    arr = {n: hostlib.nan_array(getattr(par, n)) for n in ("alpha", "beta", "gamma", "obsx", "obsy", "obsz")}
+    xyz, rm = np.zeros(3 * MAX_OBSERVERS), np.zeros(9 * MAX_OBSERVERS)
+    _chk(_HL().lart_host_observers(C.byref(o), *[hostlib.p(arr[n]) for n in ("alpha", "beta", "gamma", "obsx", "obsy", "obsz")], hostlib.p(xyz), hostlib.p(rm)))
+    for n, a in arr.items():
+        getattr(par, n)[:] = [float(v) for v in a]
+    par.nobs, n = o.nobs, o.nobs
+    if par.nside > 0:
+        par.npix = o.npix
+        return Observers(nobs=n, xyz=xyz[:3 * n].reshape(n, 3).copy(), nxim=o.nxim, nyim=1, steradian_pix=o.steradian_pix)
+    par.distance, par.dxim, par.dyim = o.distance, o.dxim, o.dyim
+    return Observers(nobs=n, xyz=xyz[:3 * n].reshape(n, 3).copy(), rmatrix=rm[:9 * n].reshape(n, 3, 3).copy(), dxim=o.dxim, dyim=o.dyim, nxim=par.nxim, nyim=par.nyim,
+                     steradian_pix=o.steradian_pix)
 
 
 def make_lart_params(par, line, g):
@@ -1247,91 +570,58 @@ class Simulation:
         self.ctx.reduce_tallies(root)
 
     def output_normalize(self, t=None, nphotons=None):
-        """output_normalize_outside (output_sum_rect.f90:151-487): physical units for Jout/Jin/Jabs/Jmu and peel cubes"""
+        """output_normalize_outside (output_sum_rect.f90:151-487): physical units for Jout/Jin/Jabs/Jmu, the peel cubes and images, the J / P profiles, and for
+        ly_beta the band-2 sections (Jout_Ha, Jabs_Ha by the H-alpha bin unit :210-236, peel_Ha :433-435, Pconv like P1 :345-372) and the weight budget per photon"""
         t = t or self.ctx.tallies()
         par, g = self.par, self.grid
         nph = float(nphotons or t["nphotons_done"] or self.nphotons_run)     # photons the device(s) finished (cumulative, summed by output_reduce)
         out = dict(t)
-        unit = g.dwave if par.distance2cm != 1.0 else g.dxfreq            # par%intensity_unit default, setup.f90:491-497
-        if par.xy_periodic:                                               # slab, two faces: :174-190
-            area = 2.0
-        elif par.geometry == "sphere":                                    # :191-196
-            area = FOURPI * g.rmax ** 2 * par.distance2cm ** 2
-        else:
-            area = (g.xmax * g.ymax + g.ymax * g.zmax + g.zmax * g.xmax) * 8.0 * par.distance2cm ** 2
-            if self.amr is not None:                                      # the six faces of the octree box (output_sum_rect.f90:808-813)
-                area = 6.0 * self.amr.L_box ** 2 * par.distance2cm ** 2
-        scale = nph * unit * TWOPI * area
+        phys = par.distance2cm != 1.0                                     # par%intensity_unit default, setup.f90:491-497: per Angstrom when a length unit is set
+        s = hostlib.HostNorm(xy_periodic=int(par.xy_periodic), sphere=int(par.geometry == "sphere"), nphotons=nph, bin_unit=g.dwave if phys else g.dxfreq,
+                             distance2cm=par.distance2cm, rmax=g.rmax, xmax=g.xmax, ymax=g.ymax, zmax=g.zmax, amr_L_box=self.amr.L_box if self.amr is not None else 0.0,
+                             steradian_pix=self.obs.steradian_pix if self.obs.nobs else 0.0)
+        s.bin_unit_Ha = (g.dwave_Ha if phys else g.dxfreq_Ha) if self.line.line_type == 8 else s.bin_unit
+        _chk(_HL().lart_host_norm_scales(C.byref(s)))
+        unit = s.bin_unit
         for k in ("Jout", "Jin", "Jabs"):
-            out[k] = t[k] / scale
+            out[k] = t[k] / s.scale_J
         if "Jmu" in t:
-            out["Jmu"] = t["Jmu"] * par.nmu / scale                       # :188-190, :206-208
+            out["Jmu"] = t["Jmu"] * par.nmu / s.scale_J                  # :188-190, :206-208
+        for k in ("Jout_Ha", "Jabs_Ha"):
+            if k in t:
+                out[k] = t[k] / s.scale_J_Ha
         if self.obs.nobs:
-            sc3 = nph * self.obs.steradian_pix * unit * par.distance2cm ** 2                    # :428-430
-            sc2 = nph * self.obs.steradian_pix * par.distance2cm ** 2
             for k in ("scatt", "direc", "I", "Q", "U", "V", "direc0", "scatt_dust"):
                 if k in t:
-                    out[k] = t[k] / sc3
+                    out[k] = t[k] / s.scale_cube                          # :428-430
                 if k + "_2D" in t:
-                    out[k + "_2D"] = t[k + "_2D"] / sc2
+                    out[k + "_2D"] = t[k + "_2D"] / s.scale_image
+            if "peel_Ha" in t:
+                out["peel_Ha"] = t["peel_Ha"] / s.scale_cube_Ha
+        for k in ("W_conv", "W_esc1", "W_abs1", "W_esc2", "W_abs2", "W_H2abs", "W_H2scat"):     # :455-465: the budget is printed per photon
+            if k in t:
+                out[k] = t[k] / nph
         if self.jpa.nbins and self.amr is not None:                       # octree: volume-weighted, output_sum_heal.f90:476-590
             vol = np.where(self.amr.vol > 0, self.amr.vol, np.inf) * par.distance2cm ** 2
             if par.xy_periodic and par.geometry_JPa in (3, -1):           # slab, one photon per cm^2: the slab area replaces 1/d^2 (:874-1000)
                 vol = np.where(self.amr.vol > 0, self.amr.vol, np.inf) / self.amr.L_box ** 2
             if "J1" in t:
                 out["J1"] = t["J1"] / (FOURPI * vol[None, :] * nph * unit)
-            for k in ("P1", "P1_new"):
+            for k in ("P1", "P1_new", "Pconv"):
                 if k in t:
                     out[k] = t[k] / (vol * nph)
-        elif self.jpa.nbins:                                              # :275-360 J(x) and P_alpha profiles
+        elif self.jpa.nbins:                                              # :275-372 J(x), P_alpha and conversion-rate profiles
             dVol = g.dx * g.dy * g.dz * par.distance2cm ** 2
             cnt = np.where(self.jpa.ncount > 0, self.jpa.ncount, np.inf)
             geo_area = (g.xmax - g.xmin) * (g.ymax - g.ymin) * par.distance2cm ** 2 if par.xy_periodic else 1.0
             f = geo_area if (par.xy_periodic and par.geometry_JPa in (3, -1)) else 1.0
             if "J1" in t:
                 out["J1"] = t["J1"] / cnt[None, :] * (f / (FOURPI * dVol * nph * unit))
-            if "P1" in t:
-                out["P1"] = t["P1"] / cnt * (f / (dVol * nph))
-            if "P1_new" in t:
-                out["P1_new"] = t["P1_new"] / cnt * (f / (dVol * nph))
+            for k in ("P1", "P1_new", "Pconv"):
+                if k in t:
+                    out[k] = t[k] / cnt * (f / (dVol * nph))
         out["nscatt_tot"] = (t["nscatt_gas"] + t["nscatt_dust"]) / nph
         return out
-
-
-def radial_profiles(par, g, out, io=0, use_2D=False, stokes=False):
-    """make_radial_intensity / make_radial_stokes (output_sum_rect.f90:489-658) on the normalised tallies `out` of
-    Simulation.output_normalize: columns r, I[, Q, U, V, pol] of the azimuthal means about the image centre"""
-    unit = g.dwave if par.distance2cm != 1.0 else g.dxfreq
-    nxi, nyi = par.nxim, par.nyim
-    nr = (max(nxi, nyi) + 1) // 2
-    r = (np.arange(1, nr + 1) - 0.5) / nr if nr % 2 == 0 else (np.arange(1, nr + 1) - 1.0) / (nr - 0.5)
-    xx, yy = np.meshgrid(np.arange(1, nxi + 1) - (nxi + 1.0) / 2.0, np.arange(1, nyi + 1) - (nxi + 1.0) / 2.0, indexing="ij")
-    rr = np.sqrt(xx ** 2 + yy ** 2)
-    ir = (np.floor(rr) if nr % 2 == 0 else np.floor(rr + 0.5)).astype(int)          # 0-based bin
-    ok = ir < nr
-    cnt = np.bincount(ir[ok], minlength=nr).astype(float)
-
-    def img(k):
-        return out[k + "_2D"][:, :, io] if use_2D else out[k][:, :, :, io].sum(axis=0) * unit
-
-    def mean(a):
-        return np.where(cnt > 0, np.bincount(ir[ok], weights=a[ok], minlength=nr) / np.maximum(cnt, 1.0), 0.0)
-
-    if not stokes:
-        return np.column_stack([r, mean(img("scatt") + img("direc"))])
-    with np.errstate(invalid="ignore", divide="ignore"):
-        cosp = np.where(rr == 0.0, 1.0, yy / rr); sinp = np.where(rr == 0.0, 0.0, -xx / rr)
-    c2, s2 = 2.0 * cosp ** 2 - 1.0, 2.0 * cosp * sinp
-    if use_2D:
-        I, Q, U, V = img("I"), img("Q") * c2 + img("U") * s2, -img("Q") * s2 + img("U") * c2, img("V")
-    else:
-        q3, u3 = out["Q"][:, :, :, io], out["U"][:, :, :, io]
-        I, V = img("I"), img("V")
-        Q = (q3 * c2[None] + u3 * s2[None]).sum(axis=0) * unit; U = (-q3 * s2[None] + u3 * c2[None]).sum(axis=0) * unit
-    mI, mQ, mU, mV = mean(I), mean(Q), mean(U), mean(V)
-    with np.errstate(invalid="ignore", divide="ignore"):
-        pol = np.where(mI > 0.0, np.sqrt(mQ ** 2 + mU ** 2) / mI, 0.0)
-    return np.column_stack([r, mI, mQ, mU, mV, pol])
 
 
 def photons_of_rank(nphotons, rank, nproc):

@@ -2991,7 +2991,17 @@ static double allph_impact(const orc_sim *s, const photon_t *p, double *mx, doub
  * kind, and the smallest decision margin of the event with the id of that comparison (mrg_note) */
 #define ORC_TRACE_W 10
 static __thread double *g_tr = NULL; static __thread int g_tr_n = 0, g_tr_cap = 0;
+/* orc_trace_state: the FULL packet state at record g_st_at (what a single event needs to start from: the one-step re-synchronised check of the
+ * divergence audit, tests/test_gpu_divergence.py) -- [0..5] x y z kx ky kz, [6] xfreq, [7] wgt, [8..13] m n, [14..16] Q U V, [17..18] nscatt_gas / _dust,
+ * [19] draws consumed, [20..22] icell jcell kcell, [23] owner clump, [24] vfy_shear, [25] iband, [26] kind of the record */
+#define ORC_STATE_W 27
+static __thread double *g_st_out = NULL; static __thread int g_st_at = -1;
 static inline void trace_rec(const orc_sim *s, const rng_t *g, const photon_t *p, int kind) {
+    if (g_st_out && g_tr_n == g_st_at) { double *q = g_st_out;
+        q[0] = p->x; q[1] = p->y; q[2] = p->z; q[3] = p->kx; q[4] = p->ky; q[5] = p->kz; q[6] = p->xfreq; q[7] = p->wgt;
+        q[8] = p->mx; q[9] = p->my; q[10] = p->mz; q[11] = p->nx; q[12] = p->ny; q[13] = p->nz; q[14] = p->Q; q[15] = p->U; q[16] = p->V;
+        q[17] = p->nscatt_gas; q[18] = p->nscatt_dust; q[19] = (double)g->n; q[20] = p->icell; q[21] = p->jcell; q[22] = p->kcell; q[23] = p->icell_clump;
+        q[24] = p->vfy_shear; q[25] = p->iband == 2 ? 2.0 : 1.0; q[26] = (double)kind; }
     if (!g_tr) return;
     if (g_tr_n < g_tr_cap) { double *r = g_tr + (size_t)g_tr_n * ORC_TRACE_W;
         r[0] = (double)g->n; r[1] = p->inside ? p->xfreq : p->xfreq_ref; r[2] = p->x; r[3] = p->y; r[4] = p->z;
@@ -3111,6 +3121,14 @@ int64_t orc_trace(orc_sim *s, uint64_t seed, uint64_t id, int64_t cap, double *o
     for (int i = 0; i < s->nobs; i++) free_obs(&A.obs[i]);
     free(A.Jout); free(A.Jin); free(A.Jabs); free(A.Jmu); free(A.J1); free(A.P1); free(A.P1_new); free(A.Jout_Ha); free(A.Jabs_Ha); free(A.Pconv);
     s->log_nscatt = ln; s->log_xfreq = lx; s->log_n = lnn; s->allph = al; s->save_all_photons = sap;
+    return n;
+}
+/* the full state of photon (seed, id) at record `at` of its history (0 = after the birth): out[ORC_STATE_W]; returns the number of records of the history */
+int64_t orc_trace_state(orc_sim *s, uint64_t seed, uint64_t id, int64_t at, double *out) {
+    double scratch[ORC_TRACE_W];
+    g_st_out = out; g_st_at = (int)at;
+    const int64_t n = orc_trace(s, seed, id, 1, scratch);
+    g_st_out = NULL; g_st_at = -1;
     return n;
 }
 int64_t orc_get_photon_log(const orc_sim *s, double *nscatt, double *xfreq_out, int64_t n) {

@@ -54,6 +54,7 @@ int64_t orc_get_photon_log(const orc_sim *, double *nscatt, double *xfreq_out, i
 /* history probe of the divergence audit: 10 doubles per record (birth, every event): draws consumed, xfreq, x, y, z, cell code, kz, kind,
  * smallest decision margin of the event, id of that comparison; counter-based stream (seed, id); tallies are not touched */
 int64_t orc_trace(orc_sim *, uint64_t seed, uint64_t id, int64_t cap, double *out);
+int64_t orc_trace_state(orc_sim *, uint64_t seed, uint64_t id, int64_t at, double *out27);
 
 /* ---- function-level entry points (pinned against oracle/_ref, and used to check device functions) ---- */
 double orc_voigt(double x, double a);                                   /* voigt_mod.f90:541-733 */

@@ -55,6 +55,7 @@ class Oracle:
             L.orc_normalized_Jout.argtypes = [_vp, _vp, _i]
             L.orc_get_photon_log.restype = _i64; L.orc_get_photon_log.argtypes = [_vp, _vp, _vp, _i64]
             L.orc_trace.restype = _i64; L.orc_trace.argtypes = [_vp, _u64, _u64, _i64, _vp]
+            L.orc_trace_state.restype = _i64; L.orc_trace_state.argtypes = [_vp, _u64, _u64, _i64, _vp]
             L.orc_voigt.restype = _d; L.orc_voigt.argtypes = [_d, _d]
             L.orc_voigt_v.argtypes = [_i, _vp, _vp, _vp]
             L.orc_line_constants.argtypes = [_vp] * 5
@@ -147,6 +148,12 @@ class Oracle:
         kind (0 birth, 1 scattered, 2 left / absorbed), smallest decision margin of the event, id of that comparison"""
         out = np.zeros((int(cap), 10)); n = self.lib().orc_trace(self.h, int(seed), int(pid), int(cap), _ptr(out))
         return out[:min(n, cap)], int(n)
+
+    def trace_state(self, seed, pid, at):
+        """full packet state at record `at` of the history of photon (seed, pid) -- x y z kx ky kz xfreq wgt m(3) n(3) Q U V nscatt_gas nscatt_dust draws icell jcell kcell
+        owner_clump vfy_shear iband kind (lart_oracle.c, ORC_STATE_W = 27) -- and the number of records of the history"""
+        out = np.zeros(27); n = self.lib().orc_trace_state(self.h, int(seed), int(pid), int(at), _ptr(out))
+        return out, int(n)
 
     def xfreq_axis(self):
         n = int(self.scalar("nxfreq"))

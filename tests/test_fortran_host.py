@@ -701,8 +701,8 @@ def test_whole_namelist_surface_is_readable(exe, tmp_path):
           " par%amr_snapnum = 0\n par%stellar_radius = 0.0\n par%EW_line = 0.0\n par%Omega = 0.0\n par%q = 1.0\n par%D_to_H_ratio = 1.5e-5\n/\n")
     r = run(exe, ok, tmp_path, "--dry-run", name="all.in")
     assert r.returncode == 0, r.stdout + r.stderr
-    for bad in ("par%f_H2 = 1e-3", "par%density_rscale = 0.5", "par%clump_radius_alpha = 1.0", "par%stellar_radius = 0.1",
-                "par%xmin = -1.0", "par%h2_model = 'simple'", "par%ionization_model = 'file'", "par%phase_angle = 10.0, 20.0"):
+    for bad in ("par%density_rscale = 0.5", "par%clump_radius_alpha = 1.0", "par%stellar_radius = 0.1",
+                "par%xmin = -1.0", "par%ionization_model = 'file'", "par%phase_angle = 10.0, 20.0"):
         r = run(exe, "&parameters\n par%temperature = 1e4\n par%taumax = 1e2\n " + bad + "\n/\n", tmp_path, "--dry-run", name="bad.in")
         assert r.returncode != 0 and "not supported" in r.stdout and bad.split()[0][4:] in r.stdout, bad
     r = run(exe, "&parameters\n par%temperature = 1e4\n par%taumax = 1e2\n par%xy_periodic = .true.\n par%nx = 4\n par%ny = 4\n par%nz = 11\n par%Omega = 28.0\n/\n", tmp_path,
@@ -713,8 +713,16 @@ def test_whole_namelist_surface_is_readable(exe, tmp_path):
     r = run(exe, "&parameters\n par%temperature = 1e4\n par%taumax = 1e2\n par%include_deuterium = .true.\n par%fine_structure = .true.\n/\n", tmp_path,
             "--dry-run", name="hd.in")                                                    # promoted to ly_alpha_HD, the doublet switched off
     assert r.returncode == 0 and "ly_alpha_HD" in r.stdout, r.stdout
-    r = run(exe, "&parameters\n par%temperature = 1e4\n par%taumax = 1e2\n par%line_id = 'ly_beta'\n/\n", tmp_path, "--dry-run", name="ca.in")
-    assert r.returncode != 0 and "not supported" in r.stdout
+    # round 4: the Fortran host drives ly_beta (line type 8) and the H2 lines as the Python host does; what the reference refuses is refused with its message
+    r = run(exe, "&parameters\n par%temperature = 1e4\n par%taumax = 1e2\n par%line_id = 'ly_beta'\n par%nx = 11\n par%ny = 11\n par%nz = 11\n par%rmax = 1.0\n/\n", tmp_path,
+            "--dry-run", name="lyb.in")
+    assert r.returncode == 0 and "Line ID                   : ly_beta" in r.stdout, r.stdout + r.stderr
+    r = run(exe, "&parameters\n par%temperature = 1e4\n par%taumax = 1e2\n par%line_id = 'ly_beta'\n par%use_stokes = .true.\n/\n", tmp_path, "--dry-run", name="lyb2.in")
+    assert r.returncode != 0 and "ly_beta: Stokes polarization not yet supported" in r.stdout
+    r = run(exe, "&parameters\n par%temperature = 1e4\n par%taumax = 1e2\n par%h2_model = 'simple'\n par%f_H2 = 1e-3\n/\n", tmp_path, "--dry-run", name="h2bad.in")
+    assert r.returncode != 0 and "H2: Phase 1 supports only h2_model='neufeld'" in r.stdout
+    r = run(exe, "&parameters\n par%temperature = 1e4\n par%taumax = 1e2\n par%h2_model = 'neufeld'\n/\n", tmp_path, "--dry-run", name="h2bad2.in")
+    assert r.returncode != 0 and "par%f_H2 must be > 0" in r.stdout
     from lart_amd import host
     (tmp_path / "all.in").write_text(ok)
     host.read_namelist(str(tmp_path / "all.in"))
