@@ -180,6 +180,7 @@ struct Lds { const double *vt; const double *xf, *yf, *zf;   // Voigt tables and
              double *jp_P, *jp_Pn;       // per-block LDS copies of P1 / P1_new (nullptr: deposits go to global memory)
              double *jp_J; int j_lo, j_w; // per-block LDS copy of the line-centre window of J1: [j_w][nbins] (nullptr: off)
              unsigned *pq_cnt;           // this wave's record counter of the peel queue (LDS word), nullptr = no peel-off
+             const ClumpGeo *ct_geo; const ClumpPhys *ct_phys;   // VAR 7, populations of at most 128 clumps: the clump records staged in LDS (nullptr: read from global memory)
              double fov_bx, fov_by;      // peel prefilter: tan of the half field of view (+ margin) in x and y, < 0 = no field-of-view test (lds_set_fov)
              unsigned char *coop;        // LART_COOP_BYTES per wave: scratch of the cooperative samplers (vz_core_coop / vz_wing_coop), nullptr = off
              int lt; double dnu_hz;      // line type (1 single line, 2 Ly-alpha doublet, 7 H + D) and DnuHK_Hz / delta_nu_HD_Hz: set from the kernel's template
@@ -193,7 +194,7 @@ __device__ inline Lds lds_stage(double *sh, const DGrid &g) {
     for (int i = threadIdx.x; i < nf; i += blockDim.x) sh[VT_END + i] = g.faces[i];
     __syncthreads();
     Lds l; l.vt = sh; l.xf = sh + VT_END; l.yf = l.xf + (g.nx + 1); l.zf = l.yf + (g.ny + 1);
-    l.dip_p2 = 0.0; l.dip_qs = 0.0; l.jp_P = nullptr; l.jp_Pn = nullptr; l.jp_J = nullptr; l.j_lo = 0; l.j_w = 0; l.coop = nullptr; l.pq_cnt = nullptr; l.fov_bx = -1.0; l.fov_by = -1.0; l.lt = 1; l.dnu_hz = 0.0; l.hd_ratio = 1.0; l.hd_ratio_a = 1.0; l.hd_nD = 0.0; l.ml_nup = 1; l.ml_coh = 0; l.ml_tab = nullptr; l.ml_itab = nullptr;
+    l.dip_p2 = 0.0; l.dip_qs = 0.0; l.jp_P = nullptr; l.jp_Pn = nullptr; l.jp_J = nullptr; l.j_lo = 0; l.j_w = 0; l.coop = nullptr; l.pq_cnt = nullptr; l.fov_bx = -1.0; l.fov_by = -1.0; l.ct_geo = nullptr; l.ct_phys = nullptr; l.lt = 1; l.dnu_hz = 0.0; l.hd_ratio = 1.0; l.hd_ratio_a = 1.0; l.hd_nD = 0.0; l.ml_nup = 1; l.ml_coh = 0; l.ml_tab = nullptr; l.ml_itab = nullptr;
     for (int i = 0; i < 3; i++) { l.ml_dE[i] = 0.0; l.ml_damp[i] = 1.0; l.ml_f12[i] = 0.0; }
     return l;
 }
@@ -1092,6 +1093,20 @@ __device__ __forceinline__ void edge_step_amr(const KArgs &A, const Lds &l, bool
 // ---------------------------------------------------------------------------------------------
 // clump medium (VAR 4): clump_mod.f90 + raytrace_clump.f90.  xfreq stays in REF Doppler units; -/+ ulos at entry/exit.
 // ---------------------------------------------------------------------------------------------
+// the records of clump icl: from the workgroup's LDS copy when the population was staged there (lds_stage_clumps), else from global memory
+__device__ __forceinline__ ClumpGeo cl_geo(const KArgs &A, const Lds &l, int icl) { return l.ct_geo ? l.ct_geo[icl - 1] : A.cl.geo[icl - 1]; }
+__device__ __forceinline__ ClumpPhys cl_phys(const KArgs &A, const Lds &l, int icl) { return l.ct_phys ? l.ct_phys[icl - 1] : A.cl.phys[icl - 1]; }
+#define LART_OVL_LDS_CLUMPS 128                          // largest population that is staged (= the populations that carry cg_mask)
+__device__ inline size_t lds_clump_bytes(const DClumps &c) { return (c.cg_mask && c.N <= LART_OVL_LDS_CLUMPS) ? (size_t)c.N * (sizeof(ClumpGeo) + sizeof(ClumpPhys)) : 0; }
+__device__ inline void lds_stage_clumps(Lds &l, const DClumps &c, unsigned char *at) {
+    if (!lds_clump_bytes(c)) return;
+    ClumpPhys *ph = (ClumpPhys *)at; ClumpGeo *ge = (ClumpGeo *)(at + (size_t)c.N * sizeof(ClumpPhys));
+    const double *sp = (const double *)c.phys, *sg = (const double *)c.geo; double *dp = (double *)ph, *dg = (double *)ge;
+    for (int i = threadIdx.x; i < (int)c.N * 8; i += blockDim.x) dp[i] = sp[i];
+    for (int i = threadIdx.x; i < (int)c.N * 4; i += blockDim.x) dg[i] = sg[i];
+    __syncthreads();
+    l.ct_phys = ph; l.ct_geo = ge;
+}
 __device__ __forceinline__ double voigt_clump(const KArgs &A, const Lds &l, double xfreq, const ClumpPhys &c) { return calc_voigt(l, xfreq * (A.cl.Dfreq_ref / c.Dfreq), c.voigt_a, c.Dfreq); }   // clump_mod.f90:130-170 (line types 1, 2)
 __device__ __forceinline__ double kappa_clump(const KArgs &A, const Lds &l, bool dust, double xfreq, const ClumpPhys &c) {                                                                 // :176-182
     double kap = c.rhokap * voigt_clump(A, l, xfreq, c);
@@ -1248,7 +1263,7 @@ __device__ __forceinline__ void edge_step_clump(const KArgs &A, const Lds &l, bo
 // sum_kap_active: :621-636
 __device__ inline double ovl_sum_kap(const KArgs &A, const Lds &l, bool dust, const int *act, int na, double xfreq_g, double kx, double ky, double kz) {
     double sum = 0.0;
-    for (int m = 0; m < na; m++) { const ClumpPhys ph = A.cl.phys[act[m] - 1]; sum = sum + kappa_clump(A, l, dust, xfreq_g - ulos_clump(A, ph, kx, ky, kz), ph); }
+    for (int m = 0; m < na; m++) { const ClumpPhys ph = cl_phys(A, l, act[m]); sum = sum + kappa_clump(A, l, dust, xfreq_g - ulos_clump(A, ph, kx, ky, kz), ph); }
     return sum;
 }
 // TO_TAU: raytrace_to_tau_clump_overlap (:668-788): lim = the optical depth to go; returns with owner > 0 and t_end = the path length to the
@@ -1260,7 +1275,18 @@ __device__ inline double ovl_sum_kap(const KArgs &A, const Lds &l, bool dust, co
 // from (which also fix the list's order), the sphere's surface, every clump surface -- after the flights taken since; all bounds hold for every direction.
 // While the next flight stays below it, the list the 27-cell scan would rebuild is this one, in this order: no cell read, no containment tests, no sort.
 #define LART_OVL_HOLD 8
-struct OvlHold { int na; double reach; int act[LART_OVL_HOLD]; };
+// (round 4: the eight clump numbers live in four 64-bit registers, two per word, picked by selects -- an int[8] indexed at run time is a scratch array, and this list is
+//  read on 88 % of the flights)
+struct OvlHold {
+    int na; double reach; unsigned long long w0, w1, w2, w3;
+    __device__ __forceinline__ int get(int m) const { const unsigned long long w = m < 2 ? w0 : (m < 4 ? w1 : (m < 6 ? w2 : w3)); return (int)((m & 1) ? (w >> 32) : (w & 0xffffffffull)); }
+    __device__ __forceinline__ void set(int m, int id) {
+        const unsigned long long v = (unsigned long long)(unsigned)id;
+        unsigned long long w = m < 2 ? w0 : (m < 4 ? w1 : (m < 6 ? w2 : w3));
+        w = (m & 1) ? ((w & 0xffffffffull) | (v << 32)) : ((w & 0xffffffff00000000ull) | v);
+        w0 = m < 2 ? w : w0; w1 = (m >= 2 && m < 4) ? w : w1; w2 = (m >= 4 && m < 6) ? w : w2; w3 = m >= 6 ? w : w3;
+    }
+};
 // The march as a state that survives between calls: ovl_start does everything up to the first cell (holder list, fast paths, the traversal set-up), ovl_advance
 // walks at most `max_cells` CSR cells -- each with the intervals up to its far face -- and says whether the march is over, ovl_finish hands out the result.
 // ovl_march = start + advance to the end + finish is the one-piece form (peel rays, sight lines, probes); the transport kernel lets a lane that is in a march
@@ -1283,15 +1309,15 @@ __device__ inline bool ovl_start(const KArgs &A, const Lds &l, bool dust, double
     const DClumps &c = A.cl; const int cg = c.cgx;
     owner = 0; t_end = 0.0; S.live = false; S.over = false; S.acc = TO_TAU ? lim : 0.0; S.t_sp = 0.0; S.u_own = u_own;
     if (TO_TAU && oh && oh->na > 0) {
-        double kv[LART_OVL_HOLD], kap = 0.0;
-        for (int m = 0; m < oh->na; m++) { const ClumpPhys ph = c.phys[oh->act[m] - 1]; kv[m] = kappa_clump(A, l, dust, xfreq_g - ulos_clump(A, ph, kx, ky, kz), ph); kap = kap + kv[m]; }
+        double kap = 0.0;                                                                     // (no array of the terms: the owner draw below evaluates them again, the same numbers in the same order)
+        for (int m = 0; m < oh->na; m++) { const ClumpPhys ph = cl_phys(A, l, oh->get(m)); kap = kap + kappa_clump(A, l, dust, xfreq_g - ulos_clump(A, ph, kx, ky, kz), ph); }
         if (kap > 0.0) {
             const double s_ = lim / kap;
             if (s_ < oh->reach * (1.0 - 1e-9) - 1e-12 * c.cg_d) {
                 nsteps++;
                 t_end = s_;
                 double cumul = 0.0;                                                           // sample_owner_clump :644-664
-                for (int m = 0; m < oh->na; m++) { cumul = cumul + kv[m]; owner = oh->act[m]; if (u_own * kap <= cumul) break; }
+                for (int m = 0; m < oh->na; m++) { const ClumpPhys ph = cl_phys(A, l, oh->get(m)); cumul = cumul + kappa_clump(A, l, dust, xfreq_g - ulos_clump(A, ph, kx, ky, kz), ph); owner = oh->get(m); if (u_own * kap <= cumul) break; }
                 oh->reach = oh->reach - s_;
                 OVL_STAT(A, 0, 1);                                                            // flights on the carried list
                 return true;
@@ -1321,7 +1347,7 @@ __device__ inline bool ovl_start(const KArgs &A, const Lds &l, bool dust, double
     double d_srf = LART_HUGEST;
     if (all_clumps) {
         for (int icl = 1; icl <= (int)c.N; icl++) {
-            const ClumpGeo g = c.geo[icl - 1];
+            const ClumpGeo g = cl_geo(A, l, icl);
             const double rx = xp - g.x, ry = yp - g.y, rz = zp - g.z, rr = rx * rx + ry * ry + rz * rz;
             const bool in = rr <= g.r2;
             if (in) { if (na < LART_OVL_ACT) act[na++] = icl; else over = true; }
@@ -1332,7 +1358,7 @@ __device__ inline bool ovl_start(const KArgs &A, const Lds &l, bool dust, double
         const size_t q = (size_t)ci + (size_t)cj * cg + (size_t)ck * cg * cg;
         const int ip1 = c.cg_start[q + 1];
         for (int ip = c.cg_start[q]; ip < ip1; ip++) {
-            const int icl = c.cg_list[ip - 1]; const ClumpGeo g = c.geo[icl - 1];
+            const int icl = c.cg_list[ip - 1]; const ClumpGeo g = cl_geo(A, l, icl);
             const double rx = xp - g.x, ry = yp - g.y, rz = zp - g.z, rr = rx * rx + ry * ry + rz * rz;
             if (rr <= g.r2) { if (na < LART_OVL_ACT) act[na++] = icl; else over = true; free_in = fmin(free_in, g.r2 - rr); }
             else free_out = fmin(free_out, rr - g.r2);
@@ -1347,7 +1373,7 @@ __device__ inline bool ovl_start(const KArgs &A, const Lds &l, bool dust, double
         const double x0 = c.cg_min + (double)ci * c.cg_d, y0 = c.cg_min + (double)cj * c.cg_d, z0 = c.cg_min + (double)ck * c.cg_d;
         int wx = 1 << 20, wy = 1 << 20, wz = 1 << 20;                                         // cells between the holders' bounding boxes and the scan, per axis (< 0: a box starts inside the scan)
         for (int m = 0; m < na; m++) {
-            const ClumpGeo g = c.geo[act[m] - 1]; const double rc = sqrt(g.r2);
+            const ClumpGeo g = cl_geo(A, l, act[m]); const double rc = sqrt(g.r2);
             const int b0 = max(0, (int)((g.x - c.cg_min - rc) * c.cg_inv)), b1 = max(0, (int)((g.y - c.cg_min - rc) * c.cg_inv)), b2 = max(0, (int)((g.z - c.cg_min - rc) * c.cg_inv));
             const int i0 = max(b0, ci - 1), j0 = max(b1, cj - 1), k0 = max(b2, ck - 1);
             wx = min(wx, ci - 1 - b0); wy = min(wy, cj - 1 - b1); wz = min(wz, ck - 1 - b2);
@@ -1365,7 +1391,7 @@ __device__ inline bool ovl_start(const KArgs &A, const Lds &l, bool dust, double
         // distances to the surfaces: (|r|^2 - R^2) / (|r| + R) outside, (R^2 - |r|^2) / (R + |r|) inside, denominators bounded from above.
         // Taken only when acc / kap lies clearly below all of them; everything else goes through the march.
         double kv[LART_OVL_ACT], kap = 0.0;                                                   // every clump's opacity once: the sum (:621-636) and the owner draw (:644-664) add the same numbers in the same order
-        for (int m = 0; m < na; m++) { const ClumpPhys ph = c.phys[act[m] - 1]; kv[m] = kappa_clump(A, l, dust, xfreq_g - ulos_clump(A, ph, kx, ky, kz), ph); kap = kap + kv[m]; }
+        for (int m = 0; m < na; m++) { const ClumpPhys ph = cl_phys(A, l, act[m]); kv[m] = kappa_clump(A, l, dust, xfreq_g - ulos_clump(A, ph, kx, ky, kz), ph); kap = kap + kv[m]; }
         if (kap > 0.0) {
             const double x0 = c.cg_min + (double)ci * c.cg_d, y0 = c.cg_min + (double)cj * c.cg_d, z0 = c.cg_min + (double)ck * c.cg_d;
             const double dface = fmin(fmin(fmin(xp - x0, x0 + c.cg_d - xp), fmin(yp - y0, y0 + c.cg_d - yp)), fmin(zp - z0, z0 + c.cg_d - zp));
@@ -1383,7 +1409,7 @@ __device__ inline bool ovl_start(const KArgs &A, const Lds &l, bool dust, double
                 for (int m = 0; m < na; m++) { cumul = cumul + kv[m]; owner = act[m]; if (u_own * kap <= cumul) break; }
                 if (oh && na <= LART_OVL_HOLD) {                                              // the same bounds without the direction: R - |r| instead of t_sp
                     const double left = fmin(reach, c.sphere_R - sqrt(xp * xp + yp * yp + zp * zp)) - s_;
-                    if (left > 0.0) { oh->na = na; oh->reach = left; for (int m = 0; m < LART_OVL_HOLD; m++) oh->act[m] = m < na ? act[m] : 0; OVL_STAT(A, 3, 1); }
+                    if (left > 0.0) { oh->na = na; oh->reach = left; for (int m = 0; m < na; m++) oh->set(m, act[m]); OVL_STAT(A, 3, 1); }
                 }
                 OVL_STAT(A, 2, 1);                                                            // ... of which the fast path took the flight (3: and left a list behind)
                 return true;
@@ -1421,7 +1447,7 @@ __device__ inline bool ovl_advance(const KArgs &A, const Lds &l, bool dust, doub
     unsigned long long vis0 = S.vis0, vis1 = S.vis1;
     auto visit = [&](int icl) {
         const unsigned long long bit = 1ull << ((icl - 1) & 63); const bool hi = ((icl - 1) & 64) != 0;
-        const ClumpGeo g = c.geo[icl - 1];
+        const ClumpGeo g = cl_geo(A, l, icl);
         const double rx = xp - g.x, ry = yp - g.y, rz = zp - g.z, b = rx * kx + ry * ky + rz * kz;     // ray_sphere_isect :1362-1386
         double disc = b * b - (rx * rx + ry * ry + rz * rz) + g.r2;
         bool dealt = disc < 0.0;
@@ -1474,7 +1500,7 @@ __device__ inline bool ovl_advance(const KArgs &A, const Lds &l, bool dust, doub
                         t_end = t_cur + acc / kap;
                         double cumul = 0.0;                                                   // sample_owner_clump :644-664
                         for (int m = 0; m < na; m++) {
-                            const ClumpPhys ph = c.phys[act[m] - 1];
+                            const ClumpPhys ph = cl_phys(A, l, act[m]);
                             cumul = cumul + kappa_clump(A, l, dust, xfreq_g - ulos_clump(A, ph, kx, ky, kz), ph); owner = act[m];
                             if (S.u_own * kap <= cumul) break;
                         }
@@ -1483,7 +1509,7 @@ __device__ inline bool ovl_advance(const KArgs &A, const Lds &l, bool dust, doub
                     acc = acc - kap * dt;
                 } else {
                     acc = acc + kap * dt; if (acc >= lim) { done = true; break; }
-                    if (col) for (int m = 0; m < na; m++) { const ClumpPhys ph = c.phys[act[m] - 1]; col[0] = col[0] + (ph.rhokap / col[2]) * ph.Dfreq * dt; col[1] = col[1] + ph.rhokapD * dt; }
+                    if (col) for (int m = 0; m < na; m++) { const ClumpPhys ph = cl_phys(A, l, act[m]); col[0] = col[0] + (ph.rhokap / col[2]) * ph.Dfreq * dt; col[1] = col[1] + ph.rhokapD * dt; }
                 }
                 t_cur = t_next;
             }
@@ -2092,8 +2118,11 @@ __device__ inline double rsqrt_nr(double x) {
     y = y * fma(-0.5 * x * y, y, 1.5);
     return y * fma(-0.5 * x * y, y, 1.5);
 }
+// opacity constants of the cell (leaf, owner clump) an event happens in, as scatter_pre read them: handed to the peel prefilter so that it does not gather the record again
+// (the gather sat exposed in front of the record stores: 3 waves per SIMD do not hide it)
+struct PeelCell { double rhokap, rhokapD, voigt_a, Dfreq; };
 template <int VAR, bool STOKES>
-__device__ __forceinline__ bool peel_all_opaque(const KArgs &A, const Lds &l, int kind, const Photon &p, double xa, double ux, double uy, double uz, double grec, bool dust) {
+__device__ __forceinline__ bool peel_all_opaque(const KArgs &A, const Lds &l, int kind, const Photon &p, double xa, double ux, double uy, double uz, double grec, bool dust, const PeelCell *pc = nullptr) {
     if (kind == PEEL_DIRECT || A.heal_nside > 0 || VAR == 1) return false;
     if (VAR == 7) return false;                              // the ray may cross any number of clumps from its first metre on
     if (VAR == 4 && p.icl <= 0) return false;
@@ -2107,7 +2136,11 @@ __device__ __forceinline__ bool peel_all_opaque(const KArgs &A, const Lds &l, in
     //   frequency along q: x_atom + u_x cos(phi) sin(theta) + u_y sin(phi) sin(theta) + u_z cos(theta) with cos(phi) sin(theta) = q.m, sin(phi) sin(theta) = q.n,
     //   cos(theta) = q.k in the Stokes frame (stokes_geom), and the corresponding projections on the frame of peel_head_res_nostokes otherwise.
     const double T = LART_TAU_HUGE * (1.0 + 1e-9);
-    const Cell &c = A.g.cell[(VAR == 3 || is_clump(VAR)) ? (size_t)(p.ic - 1) : cidx(A.g, p.ic, p.jc, p.kc)];
+    PeelCell cc;
+    if (pc) cc = *pc;
+    else if (VAR == 4) { const ClumpPhys ph = A.cl.phys[p.icl - 1]; cc.rhokap = ph.rhokap; cc.rhokapD = ph.rhokapD; cc.voigt_a = ph.voigt_a; cc.Dfreq = ph.Dfreq; }
+    else { const Cell &c = A.g.cell[(VAR == 3 || is_clump(VAR)) ? (size_t)(p.ic - 1) : cidx(A.g, p.ic, p.jc, p.kc)]; cc.rhokap = c.rhokap; cc.rhokapD = c.rhokapD; cc.voigt_a = c.voigt_a; cc.Dfreq = c.Dfreq; }
+    const double Dfreq_bg = (VAR == 4) ? A.g.cell[0].Dfreq : cc.Dfreq;      // (the recoil term of the peel head uses the background record of a clump medium, as peel_head_res_* do)
     for (int i = 0; i < A.nobs; i++) {
         const DObs &o = A.obs[i];
         double qx = o.x - p.x, qy = o.y - p.y, qz = o.z - p.z;
@@ -2127,15 +2160,15 @@ __device__ __forceinline__ bool peel_all_opaque(const KArgs &A, const Lds &l, in
                 if (!(s2 > 1e-12)) return false;             // (k along z: the head's special case decides)
                 xf = xa + (ux * (cost * p.kz - qz) + uy * (p.kx * qy - qx * p.ky)) * rsqrt_nr(s2) + uz * cost;
             }
-            if (A.par.recoil) xf = xf - (grec / c.Dfreq) * (1.0 - cost);
+            if (A.par.recoil) xf = xf - (grec / Dfreq_bg) * (1.0 - cost);
         }
         if (VAR == 4) {
-            const ClumpPhys ph = A.cl.phys[p.icl - 1];
+            ClumpPhys ph; ph.rhokap = cc.rhokap; ph.rhokapD = cc.rhokapD; ph.voigt_a = cc.voigt_a; ph.Dfreq = cc.Dfreq;      // (kappa_clump reads these four)
             if (!(kappa_clump(A, l, rd, xf, ph) * clump_exit_dist(A.cl.geo[p.icl - 1], p.x, p.y, p.z, qx, qy, qz) >= T)) return false;
             continue;
         }
-        double kap = c.rhokap * calc_voigt(l, xf, c.voigt_a, c.Dfreq);
-        if (rd) kap = kap + c.rhokapD;
+        double kap = cc.rhokap * calc_voigt(l, xf, cc.voigt_a, cc.Dfreq);
+        if (rd) kap = kap + cc.rhokapD;
         double dx, dy, dz;
         if (VAR == 3) {
             const AmrGeom g = A.amr.geom[A.amr.icell_of_leaf[p.ic - 1] - 1];
@@ -2153,9 +2186,9 @@ __device__ __forceinline__ bool peel_all_opaque(const KArgs &A, const Lds &l, in
 // one record into the peel queue (see DPeelQ).  Called from divergent code: the lanes of the wave that are here right now share one
 // atomic for their slots.  xa = xfreq_atom for a resonance event, the packet's xfreq for a dust event or the direct (birth) peel.
 template <int VAR, bool STOKES>
-__device__ __forceinline__ void peel_emit(const KArgs &A, const Lds &l, bool dust, int kind, const Photon &p, double xa, double ux, double uy, double uz, double E1, double E2, double E3, double grec, unsigned &npeel) {
+__device__ __forceinline__ void peel_emit(const KArgs &A, const Lds &l, bool dust, int kind, const Photon &p, double xa, double ux, double uy, double uz, double E1, double E2, double E3, double grec, unsigned &npeel, const PeelCell *pc = nullptr) {
 #ifndef LART_NO_PEEL_PREFILTER
-    if (peel_all_opaque<VAR, STOKES>(A, l, kind, p, xa, ux, uy, uz, grec, dust)) { npeel += (unsigned)A.nobs; return; }   // (the one cell each ray was tested in)
+    if (peel_all_opaque<VAR, STOKES>(A, l, kind, p, xa, ux, uy, uz, grec, dust, pc)) { npeel += (unsigned)A.nobs; return; }   // (the one cell each ray was tested in)
 #endif
     const unsigned long long m = __ballot(1);
     const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
@@ -2321,7 +2354,7 @@ __device__ __forceinline__ bool dust_absorb(const KArgs &A, Rng &g, Photon &p, c
 //   scatter_pre  -> dust-or-gas decision; a dust event completes here; a resonance event returns true with the sampler's
 //                   arguments in ScatCtx (x in the local Doppler units of the cell / clump)
 //   scatter_post -> everything after do_resonance's `uz = rand_resonance_vz(x, a)`
-struct ScatCtx { double va, xloc, cl_scale, cl_Dfreq, xsamp, dnu, vsamp; int species, iup, h2; };   // h2: 1-based H2 line of an H2 scattering (pseudo line type 9), 0 = an H I event;   // xsamp / vsamp: the sampler's frequency and Voigt parameter (2P1/2 level: xloc + dnu; deuterium, species 2: the D frame)
+struct ScatCtx { double va, xloc, cl_scale, cl_Dfreq, xsamp, dnu, vsamp, rhokap, rhokapD; int species, iup, h2; };   // h2: 1-based H2 line of an H2 scattering (pseudo line type 9), 0 = an H I event;   // xsamp / vsamp: the sampler's frequency and Voigt parameter (2P1/2 level: xloc + dnu; deuterium, species 2: the D frame)
 template <int VAR, bool STOKES, bool DUST, bool PEEL>
 __device__ __forceinline__ bool scatter_pre(const KArgs &A, const Lds &l, Rng &g, Photon &p, unsigned &npeel, ScatCtx &sc) {
     const lart_params &par = A.par;
@@ -2330,7 +2363,7 @@ __device__ __forceinline__ bool scatter_pre(const KArgs &A, const Lds &l, Rng &g
     // clump mode (scattering_car.f90:69-84, line_clump_mod.f90:30-59): opacities, Voigt parameter and Doppler width of the owner clump;
     // scale = Dfreq_ref / Dfreq_clump moves x into the clump's local Doppler units for the sampler and back
     double cl_scale = 1.0, cl_Dfreq = c.Dfreq, cl_rhokap = c.rhokap, cl_rhokapD = c.rhokapD;
-    if (is_clump(VAR)) { const ClumpPhys ph = A.cl.phys[p.icl - 1]; va = ph.voigt_a; cl_Dfreq = ph.Dfreq; cl_rhokap = ph.rhokap; cl_rhokapD = ph.rhokapD; cl_scale = A.cl.Dfreq_ref / ph.Dfreq; }
+    if (is_clump(VAR)) { const ClumpPhys ph = cl_phys(A, l, p.icl); va = ph.voigt_a; cl_Dfreq = ph.Dfreq; cl_rhokap = ph.rhokap; cl_rhokapD = ph.rhokapD; cl_scale = A.cl.Dfreq_ref / ph.Dfreq; }
     sc.h2 = 0;
     if (l.lt == 8 && p.iband == 2) {                          // scatter_dust_Ha_nostokes (scattering_car.f90:586-658; _amr scattering_amr.f90:147-209): every event of a band-2 packet is a dust event
         p.nsd = p.nsd + p.wgt;
@@ -2397,13 +2430,14 @@ __device__ __forceinline__ bool scatter_pre(const KArgs &A, const Lds &l, Rng &g
         }
     }
     // resonance scattering: scatter_resonance_nostokes :660-827 / _stokes :331-486
-    if (VAR == 7) p.xfreq = p.xfreq - ulos_clump(A, A.cl.phys[p.icl - 1], p.kx, p.ky, p.kz);   // scatter_resonance_clump_*: global -> owner frame (:898-937)
+    if (VAR == 7) p.xfreq = p.xfreq - ulos_clump(A, cl_phys(A, l, p.icl), p.kx, p.ky, p.kz);   // scatter_resonance_clump_*: global -> owner frame (:898-937)
     p.nsg = p.nsg + p.wgt;
     if (A.jpa.calc_P && c.rhokap > 0.0) {                      // add_to_Pa: scattering_car.f90:830-859
         int ib = (VAR == 3) ? amr_JPa_bin(A.amr, p.ic, p.x, p.y, p.z) : A.jpa.ind_bin[cidx(A.g, p.ic, p.jc, p.kc)];   // add_to_Pa_amr: scattering_amr.f90:917-942
         if (ib >= 1) atomicAdd(&(l.jp_P ? l.jp_P : A.jpa.P1)[ib - 1], p.wgt / (c.rhokap * c.Dfreq / A.jpa.cross0));
     }
     sc.va = va; sc.cl_scale = cl_scale; sc.cl_Dfreq = cl_Dfreq; sc.xloc = is_clump(VAR) ? p.xfreq * cl_scale : p.xfreq;
+    sc.rhokap = cl_rhokap; sc.rhokapD = DUST ? cl_rhokapD : 0.0;   // (the peel prefilter of scatter_post reads them: no second gather of the cell / clump record)
     sc.xsamp = sc.xloc; sc.dnu = 0.0; sc.vsamp = va; sc.species = 1; sc.iup = 0;
     if (l.lt == 4 && l.ml_nup > 1) {                           // do_resonance5 / 6 (line_mod.f90:358-376, :421-449): which upward transition
         const double Dx2 = l.ml_dE[1] / cl_Dfreq, va2 = va * l.ml_damp[1] / l.ml_damp[0];
@@ -2524,7 +2558,7 @@ __device__ __forceinline__ void scatter_post(const KArgs &A, const Lds &l, Rng &
     if (par.recoil && !converted) p.xfreq = p.xfreq - (g_rec0 / sc.cl_Dfreq) * (1.0 - cost);      // (no recoil on the conversion channel: :768-770)
     if (STOKES) {
         LART_PROF_MARK(p, 6);
-        if (PEEL) peel_emit<VAR, STOKES>(A, l, DUST, PEEL_RESONANCE, p, xfreq_atom, ux, uy, uz, E1, E2, E3, g_rec0, npeel);   // peeling_resonance_stokes_outside, deferred
+        if (PEEL) { const PeelCell pc = {sc.rhokap, sc.rhokapD, sc.va, sc.cl_Dfreq}; peel_emit<VAR, STOKES>(A, l, DUST, PEEL_RESONANCE, p, xfreq_atom, ux, uy, uz, E1, E2, E3, g_rec0, npeel, &pc); }   // peeling_resonance_stokes_outside, deferred
         LART_PROF_MARK(p, 15);
         double cos2p = 2.0 * cosp * cosp - 1.0, sin2p = 2.0 * sinp * cosp;
         double Q0 = cos2p * p.Q + sin2p * p.U, U0 = -sin2p * p.Q + cos2p * p.U;
@@ -2533,7 +2567,7 @@ __device__ __forceinline__ void scatter_post(const KArgs &A, const Lds &l, Rng &
         rotate_triad(p, cost, sint, cosp, sinp);
     } else {
         if (PEEL && converted) { unsigned natom = 0; peel_conversion_Ha<VAR>(A, l, DUST, p, A.g.cell[cidx(A.g, p.ic, p.jc, p.kc)], ux, uy, uz, E1, E2, npeel, natom); }      // peeling_conversion_Ha (:784-788)
-        else if (PEEL) peel_emit<VAR, STOKES>(A, l, DUST, PEEL_RESONANCE, p, xfreq_atom, ux, uy, uz, E1, E2, E3, g_rec0, npeel);   // peeling_resonance_nostokes_outside, deferred
+        else if (PEEL) { const PeelCell pc = {sc.rhokap, sc.rhokapD, sc.va, sc.cl_Dfreq}; peel_emit<VAR, STOKES>(A, l, DUST, PEEL_RESONANCE, p, xfreq_atom, ux, uy, uz, E1, E2, E3, g_rec0, npeel, &pc); }   // peeling_resonance_nostokes_outside, deferred
         rotate_k(p, cost, sint, cosp, sinp);
         if (converted) {                                       // :811-827: emitted at line centre in the atom frame -> the lab frame along the new direction, reference Doppler units
             const Cell &cc = A.g.cell[cidx(A.g, p.ic, p.jc, p.kc)];
@@ -2541,7 +2575,7 @@ __device__ __forceinline__ void scatter_post(const KArgs &A, const Lds &l, Rng &
             p.xfreq = (p.xfreq - xfreq_atom + u1_fluid) * (cc.Dfreq / par.Dfreq_ref);
         }
     }
-    if (VAR == 7) p.xfreq = p.xfreq + ulos_clump(A, A.cl.phys[p.icl - 1], p.kx, p.ky, p.kz);   // ... and back to the global frame along the new direction
+    if (VAR == 7) p.xfreq = p.xfreq + ulos_clump(A, cl_phys(A, l, p.icl), p.kx, p.ky, p.kz);   // ... and back to the global frame along the new direction
 }
 // par%save_all_photons (run_simulation_mod.f90:249-358): the record of photon k.  The impact parameter |r - (r.k)k| does not change along
 // the ray, so the reference's move to the sphere's surface (:302-324) drops out.

@@ -519,6 +519,9 @@ static int ensure_pool(lart_gpu *c) {
     if (!c->block_user) {
         c->block = 256;
         if (c->jpa.nbins > 0 && c->jpa.calc_J && (c->jpa.calc_P || c->jpa.calc_Pnew) && !c->par.use_stokes) { c->block = 1024; size_j_window(c); if (c->jpa.lds_j_w < 8) c->block = 256; }
+        // overlapping clumps, a population small enough for its records to live in LDS (lds_stage_clumps: 96 B per clump): four 256-lane workgroups per CU have no room
+        // for four copies, one 1024-lane workgroup has
+        if (c->is_clump && c->clump_overlap && c->cl.cg_mask && c->cl.N <= LART_OVL_LDS_CLUMPS && !c->par.use_stokes) c->block = 1024;
     }
     int64_t n = c->want_lanes;
     if (n <= 0) {
@@ -753,6 +756,7 @@ extern "C" int lart_gpu_step(lart_gpu *c, int32_t nsteps, int32_t max_events) {
     size_j_window(c); A.jpa = c->jpa;
     // Voigt tables + faces | ring of random draws [LART_RNG_BUF][block] | per-block P1, P1_new
     size_t shmem = (size_t)(VT_END + c->g.nx + c->g.ny + c->g.nz + 3 + LART_RNG_BUF * c->block + 2 * c->jpa.lds_bins + c->jpa.lds_j_w * c->jpa.nbins) * sizeof(double) + (size_t)(LART_COOP_BYTES + 4) * ((c->block + 63) / 64);   // ... + the wave-local scratch of vz_core_coop + the waves' peel-queue counters
+    if (var == 7 && c->cl.cg_mask && c->cl.N <= LART_OVL_LDS_CLUMPS) shmem = ((shmem + 15) & ~(size_t)15) + (size_t)c->cl.N * (sizeof(ClumpGeo) + sizeof(ClumpPhys));      // ... + the clump records (lds_stage_clumps)
     if (shmem > 160 * 1024) return fail("step: grid faces do not fit the 160 KiB LDS");
     // peel-off: a launch of `slice` events per lane queues at most live_lanes x (slice + 1) records (one per event, one per birth);
     // the queue is sized once per run for pq_bytes_max (16 GiB by default) and a step of max_events is cut into slices that fit
@@ -1166,7 +1170,7 @@ __device__ void test_event_one(const KArgs &A, const Lds &l, double *st, unsigne
     if (is_clump(VAR)) { p.ic = 1; p.jc = 1; p.kc = 1; }
     Rng g; g.init(seed, id, (unsigned long long)st[19]);
     bool first = first_in != 0; unsigned ns = 0, np = 0;
-    OvlHold oh; oh.na = 0; oh.reach = 0.0; OvlState os; os.live = false;
+    OvlHold oh; oh.na = 0; oh.reach = 0.0; oh.w0 = 0; oh.w1 = 0; oh.w2 = 0; oh.w3 = 0; OvlState os; os.live = false;
     fly<VAR, DUST>(A, l, g, p, first, ns, VAR == 7 ? &oh : nullptr, VAR == 7 ? &os : nullptr);
     if (VAR == 7) while (os.live) {                            // the march of a flight that left its clump, to its end (the kernel advances it a few cells per round)
         double t_end = 0.0; int owner = 0;

@@ -111,6 +111,11 @@ __global__ __launch_bounds__(LART_MAX_BLOCK_V(STOKES), LART_WAVES_V4(VAR, STOKES
         l_.pq_cnt = (unsigned *)(l_.coop - LART_COOP_BYTES * (threadIdx.x >> 6) + LART_COOP_BYTES * (blockDim.x >> 6)) + (threadIdx.x >> 6);
         if ((threadIdx.x & 63) == 0) *l_.pq_cnt = 0u;
     }
+    if (VAR == 7) {                                            // the clump records of a small population, behind everything else (the offset lart_gpu_step sizes the launch for)
+        const size_t off = (((size_t)(VT_END + (A.g.nx + A.g.ny + A.g.nz + 3) + (size_t)LART_RNG_BUF * blockDim.x + 2 * (size_t)A.jpa.lds_bins + (size_t)nJ) * sizeof(double)
+                             + (size_t)(LART_COOP_BYTES + 4) * (blockDim.x >> 6)) + 15) & ~(size_t)15;
+        lds_stage_clumps(l_, A.cl, (unsigned char *)sh + off);
+    }
     const Lds l = l_;
     double *rng_lds = sh + VT_END + (A.g.nx + A.g.ny + A.g.nz + 3) + threadIdx.x;      // [LART_RNG_BUF][blockDim.x] draws
     const lart_params &par = A.par;
@@ -119,7 +124,7 @@ __global__ __launch_bounds__(LART_MAX_BLOCK_V(STOKES), LART_WAVES_V4(VAR, STOKES
     double *F = A.pool.f;
 
     Photon p; Rng g; g.attach(rng_lds, blockDim.x);
-    OvlHold oh; oh.na = 0; oh.reach = 0.0;                                        // VAR 7: holders carried from one flight to the next (not kept between launches)
+    OvlHold oh; oh.na = 0; oh.reach = 0.0; oh.w0 = 0; oh.w1 = 0; oh.w2 = 0; oh.w3 = 0;                                        // VAR 7: holders carried from one flight to the next (not kept between launches)
     OvlState os; os.live = false;                                                 // VAR 7: the march of a flight that left its clump, between two rounds of the wave
     g.k0 = (uint32_t)A.seed; g.k1 = (uint32_t)(A.seed >> 32);                  // (a lane that never holds a packet still lends its ALU to Rng::prefill_sparse: the key is the run's)
 #ifdef LART_PROFILE

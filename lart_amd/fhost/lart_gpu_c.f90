@@ -65,6 +65,15 @@ module lart_gpu_c
   !--- host set-up helpers of the library (include/lart_gpu.h, "Host set-up helpers"; csrc/lart_host_setup.cpp): in/out records, member for member
   integer(c_int32_t), parameter :: LART_VEL_NONE = 0, LART_VEL_HUBBLE = 1, LART_VEL_CONSTANT_RADIAL = 2, LART_VEL_PARALLEL = 3, LART_VEL_ROT_SOLID = 4, &
                                    LART_VEL_ROT_HALO = 5, LART_VEL_POWER_LAW = 6, LART_VEL_LINEAR_DECEL = 7, LART_VEL_SSH = 8
+  integer(c_int32_t), parameter :: LART_UNIT_NONE = 0, LART_UNIT_KPC = 1, LART_UNIT_PC = 2, LART_UNIT_AU = 3, LART_UNIT_OTHER = 4, LART_UNIT_USER = 5, &
+                                   LART_NOTE_NO_PEEL_WITH_XYZSYM = 1
+  type, bind(C) :: lart_host_rules
+     integer(c_int32_t) :: nx, ny, nz, nr, nside, nxim, nyim, nmu, geometry_JPa, distance_unit, intensity_unit, notes
+     integer(c_int32_t) :: xyz_symmetry, xy_symmetry, xy_periodic, use_clump_medium, use_amr_grid, use_stokes, sphere, save_all
+     integer(c_int32_t) :: save_peeloff, save_peeloff_2D, save_peeloff_3D, save_Jabs, save_Jmu, core_skip, core_skip_global, pad_ = 0
+     real(c_double) :: tau0, taumax, N_HI, N_HImax, N_HIhomo, N_gasmax, N_gashomo, cext_dust, DGR, mu_min, dmu
+     real(c_double) :: rmax, xmax, ymax, zmax, source_rmax, distance2cm
+  end type lart_host_rules
   type, bind(C) :: lart_host_line
      integer(c_int32_t) :: line_type, fine_structure, include_deuterium, pad_
      real(c_double) :: wavelength0, damping, cross0, vtherm1, mass_amu, g_recoil0, DnuHK_Hz, E1, E2, E3
@@ -275,6 +284,9 @@ module lart_gpu_c
      end function
      function lart_host_setup_last_error() bind(C, name='lart_host_setup_last_error') result(p)
        import; type(c_ptr) :: p
+     end function
+     function lart_host_input_rules(r) bind(C, name='lart_host_input_rules') result(rc)
+       import; type(lart_host_rules), intent(inout) :: r; integer(c_int) :: rc
      end function
      function lart_host_line_setup(line_id, fine_structure, include_deuterium, D_to_H_ratio, L) bind(C, name='lart_host_line_setup') result(rc)
        import; character(kind=c_char), intent(in) :: line_id(*); integer(c_int32_t), value :: fine_structure, include_deuterium

@@ -51,18 +51,13 @@ module lart_define
      real(wp) :: distance2cm = -999.9_wp
      character(len=128) :: distance_unit = '', source_geometry = 'point', spectral_type = 'voigt'
      character(len=128) :: base_name = '', out_file = ''
-     logical  :: out_merge = .false.
-     character(len=8) :: file_format = 'hdf5'
-     integer(int64) :: num_send_at_once = 100
      logical  :: use_master_slave = .true., use_reduced_wgt = .false., use_stokes = .false.
      logical  :: save_all = .false., save_Jin = .true., save_Jabs = .true., save_Jmu = .false.
      integer  :: nmu = 11
      real(wp) :: mu_min = -1.0_wp, dmu = 0.0_wp
      logical  :: save_peeloff = .false., save_peeloff_2D = .false., save_peeloff_3D = .true.
      logical  :: save_sightline_tau = .false., save_direc0 = .false., save_all_photons = .false., save_radial_profile = .false., save_dust_scattered = .false.
-     integer  :: intensity_unit = -999
      real(wp) :: hgg = 0.6761, albedo = 0.3253, cext_dust = 1.6059e-21, DGR = 0.0
-     character(len=128) :: scatt_mat_file = ''
      real(wp) :: nscatt_gas = 0.0_wp, nscatt_dust = 0.0_wp, nscatt_tot = 0.0_wp, exetime = 0.0_wp
      integer  :: nobs = 1, nxim = 0, nyim = 0
      real(wp) :: distance = nan64
@@ -75,14 +70,12 @@ module lart_define
      !--- octree medium (generic text leaf table, read_generic_amr.f90:112-185) and the run-time form of CALCJ / CALCP / CALCPnew
      logical  :: use_amr_grid = .false., calc_J = .false., calc_P = .false., calc_Pnew = .false.
      character(len=16) :: amr_type = 'generic'
-     integer  :: geometry_JPa = huge(1)
      !--- clump medium (define.f90:325-352): uniform clump properties, non-overlapping clumps
      logical  :: use_clump_medium = .false., clump_fully_inside = .true., save_clump_info = .false.
      real(wp) :: clump_radius = -1.0_wp, clump_N_clumps = -1.0_wp, clump_f_vol = -1.0_wp, clump_f_cov = -1.0_wp
      real(wp) :: clump_tau0 = -1.0_wp, clump_NHI = -1.0_wp, clump_nH = -1.0_wp, clump_temperature = -1.0_wp, clump_sigma_v = 0.0_wp
      real(wp) :: Vrot = 0.0_wp, rinner = 0.0_wp, Vpeak = 0.0_wp, rpeak = 0.0_wp, DeltaV = 0.0_wp, velocity_alpha = 1.0_wp
      real(wp) :: gaussian_sigma_vel = 12.843374_wp, gaussian_FWHM_vel = -999.0_wp, source_zscale = 0.0_wp
-     character(len=20)  :: line_id = 'ly_alpha'
      character(len=8)   :: h2_model = 'none'
      character(len=128) :: dens_file = '', temp_file = '', velo_file = '', emiss_file = '', cart_file = '', input_field = '', star_file = ''
      character(len=256) :: amr_file = '', clump_input_file = ''
@@ -96,7 +89,6 @@ module lart_define
      real(wp) :: temperature0 = -999.0_wp
      real(wp) :: Dfreq0 = -999.0_wp
      real(wp) :: voigt_a0 = -999.0_wp
-     logical :: HeI_coherent = .false.
      real(wp) :: D_to_H_ratio = 1.5e-5_wp
      real(wp) :: source_rscale = 0.0_wp
      real(wp) :: sersic_m = 1.0_wp
@@ -106,43 +98,24 @@ module lart_define
      real(wp) :: zmin = nan64
      real(wp) :: density_rscale = -999.9_wp
      real(wp) :: density_zscale = -999.9_wp
-     real(wp) :: density_alpha = 0.0_wp
-     real(wp) :: cone_opening = 0.0_wp
-     real(wp) :: wavelength_min = nan64
-     real(wp) :: wavelength_max = nan64
+     real(wp) :: density_alpha = 0.0_wp, cone_opening = 0.0_wp, wavelength_min = nan64, wavelength_max = nan64
      integer :: nwavelength = 0
      real(wp) :: q = 1.0_wp
      real(wp) :: Omega = 0.0_wp
-     logical :: continuum_normalize = .true.
      real(wp) :: EW_line = 0.0_wp
      real(wp) :: f_line = 0.0_wp
-     logical :: clump_allow_overlap = .false.
-     character(len=32) :: clump_radius_profile = 'constant'
-     character(len=32) :: clump_density_profile = 'constant'
-     character(len=32) :: clump_number_profile = 'constant'
-     real(wp) :: clump_radius_alpha = 0.0_wp
-     real(wp) :: clump_radius_r0 = 0.0_wp
-     real(wp) :: clump_density_alpha = 0.0_wp
-     real(wp) :: clump_density_r0 = 0.0_wp
-     real(wp) :: clump_number_alpha = 0.0_wp
-     real(wp) :: clump_number_r0 = 0.0_wp
-     real(wp) :: clump_radius_min = -1.0_wp
-     real(wp) :: clump_radius_max_in = -1.0_wp
+     character(len=32) :: clump_radius_profile = 'constant', clump_density_profile = 'constant', clump_number_profile = 'constant'
+     real(wp) :: clump_radius_alpha = 0.0_wp, clump_radius_r0 = 0.0_wp, clump_density_alpha = 0.0_wp, clump_density_r0 = 0.0_wp, clump_number_alpha = 0.0_wp
+     real(wp) :: clump_number_r0 = 0.0_wp, clump_radius_min = -1.0_wp, clump_radius_max_in = -1.0_wp
      character(len=256) :: clump_profile_file = ''
      integer :: amr_snapnum = 0
-     character(len=32) :: ionization_model = 'cie_formula'
-     character(len=32) :: dust_model = 'global_dgr'
-     character(len=32) :: emissivity_model = 'none'
-     character(len=32) :: ion_model = 'none'
+     character(len=32) :: ionization_model = 'cie_formula', dust_model = 'global_dgr', emissivity_model = 'none', ion_model = 'none'
      real(wp) :: metallicity_global = -1.0_wp
      real(wp) :: Z_ref = 0.0134_wp
      real(wp) :: f_ion_dust = 0.01_wp
-     integer :: out_bitpix = 0
-     integer :: sampling_method = 1
+     integer :: out_bitpix = 0, sampling_method = 1
      real(wp) :: f_composite = 0.5_wp
-     logical :: save_backup = .false.
-     logical :: save_input_grid = .false.
-     logical :: use_cie_condition = .false.
+     logical  :: save_backup = .false., save_input_grid = .false., use_cie_condition = .false.
      integer :: nxfreq_Ha = 0
      real(wp) :: xfreq_max_Ha = 0.0_wp
      integer :: ny_2gam = 101
@@ -163,13 +136,9 @@ module lart_define
      character(len=128) :: h2_data_dir = ''
      real(wp) :: W_H2abs = 0.0_wp
      real(wp) :: W_H2scat = 0.0_wp
-     character(len=128) :: line_prof_file = ''
-     integer :: line_prof_file_type = 0
-     integer :: reduce_factor = 1
-     integer :: centering = 0
+     integer  :: line_prof_file_type = 0, reduce_factor = 1, centering = 0
      real(wp) :: nrejected = 0.0_wp
      real(wp) :: acceptance_rate = 1.0_wp
-     integer :: stellar_limb_darkening = 2
      real(wp) :: distance_star_to_planet = 0.0_wp
      real(wp) :: stellar_radius = 0.0_wp
      real(wp) :: flux_factor = 0.0_wp
@@ -179,7 +148,12 @@ module lart_define
      real(wp) :: rotation_center_x = nan64
      real(wp) :: rotation_center_y = nan64
      real(wp) :: rotation_center_z = nan64
-     logical :: observer_located_inside = .false.
+     !--- (fields declared one per line in the reference, gathered by type)
+     logical :: out_merge = .false., HeI_coherent = .false., continuum_normalize = .true., clump_allow_overlap = .false., observer_located_inside = .false.
+     character(len=8) :: file_format = 'hdf5';  integer(int64) :: num_send_at_once = 100
+     integer :: intensity_unit = -999, geometry_JPa = huge(1), stellar_limb_darkening = 2
+     character(len=128) :: scatt_mat_file = '', line_prof_file = ''
+     character(len=20) :: line_id = 'ly_alpha'
   end type params_type
 
   type line_type          ! define.f90:639-680, Ly-alpha values of line_mod.f90:1241-1270
@@ -253,7 +227,27 @@ module lart_define
   integer(int32), allocatable, target :: cg_start(:), cg_list(:)
   logical :: has_overlap = .false.                ! clump_mod.f90:88
 
+  interface say                       ! one labelled value per log line, in the reference's formats (the labels are what tools parse)
+     module procedure say_r, say_i8, say_i
+  end interface say
+
 contains
+  subroutine say_r(label, v, fmt)
+    character(len=*), intent(in) :: label, fmt
+    real(wp), intent(in) :: v
+    write(*,'(a,'//fmt//')') label, v
+  end subroutine say_r
+  subroutine say_i8(label, v, fmt)
+    character(len=*), intent(in) :: label, fmt
+    integer(int64), intent(in) :: v
+    write(*,'(a,'//fmt//')') label, v
+  end subroutine say_i8
+  subroutine say_i(label, v, fmt)
+    character(len=*), intent(in) :: label, fmt
+    integer, intent(in) :: v
+    write(*,'(a,'//fmt//')') label, v
+  end subroutine say_i
+
   elemental function is_finite(x) result(r)
     real(wp), intent(in) :: x
     logical :: r
@@ -415,7 +409,6 @@ contains
   subroutine read_input(model_infile)
     character(len=*), intent(in) :: model_infile
     integer :: unit, ios
-    real(wp) :: r0
     character(len=256) :: msg
     namelist /parameters/ par
 
@@ -431,11 +424,8 @@ contains
     if (par%nprint >= par%nphotons) par%nprint = int(par%nphotons/10)
     if (par%no_photons <= 10) par%nprint = 1
 
-    par%geometry        = strlowcase(par%geometry)
-    par%source_geometry = strlowcase(par%source_geometry)
-    par%velocity_type   = strlowcase(par%velocity_type)
-    par%distance_unit   = strlowcase(par%distance_unit)
-    par%spectral_type   = strlowcase(par%spectral_type)
+    par%geometry = strlowcase(par%geometry); par%source_geometry = strlowcase(par%source_geometry); par%velocity_type = strlowcase(par%velocity_type)
+    par%distance_unit = strlowcase(par%distance_unit); par%spectral_type = strlowcase(par%spectral_type); par%h2_model = strlowcase(par%h2_model)
 
     call check_unsupported_fields()
     if (par%use_amr_grid .and. trim(strlowcase(par%amr_type)) /= 'generic') call not_supported('par%amr_type = '//trim(par%amr_type))
@@ -495,92 +485,12 @@ contains
     if (par%temperature <= 0.0_wp .and. par%bturb <= 0.0_wp) then
        write(*,'(a)') 'ERROR: par%temperature must be > 0 K (or set par%bturb > 0)'; stop 1
     endif
-    if (par%nx == 1 .or. par%ny == 1 .or. par%nz == 1) par%xyz_symmetry = .false.            ! setup.f90:167
-
-    if (par%nside > 0) then                                                                      ! observer inside the medium: :169-186
-       if (par%use_clump_medium) then
-          write(*,'(a)') 'ERROR: nside>0 (HEALPIX inside observer) is not supported with clump mode'; stop 1
-       endif
-       par%use_stokes = .false.; par%save_peeloff = .true.; par%xyz_symmetry = .false.
-       par%nxim = 0; par%nyim = 0
-    endif
-    if (.not.(par%save_peeloff_2D .or. par%save_peeloff_3D)) par%save_peeloff = .false.      ! :188-206
-    if (par%nxim > 0 .and. par%nyim > 0)                     par%save_peeloff = .true.
-    if (par%save_peeloff .and. par%xyz_symmetry) then
-       par%save_peeloff = .false.
-       write(*,'(a)') '---> peelingoff is not allowed for a geometry with the xyz_symmetry.'
-       write(*,'(a)') '---> setting par%save_peeloff = .false.'
-    endif
-    if (.not. par%save_peeloff) then
-       par%save_peeloff_2D = .false.; par%save_peeloff_3D = .false.
-    endif
-
-    if (par%tau0 > 0.0_wp .and. par%taumax  < 0.0_wp) par%taumax  = par%tau0                   ! :228-233
-    if (par%N_HI > 0.0_wp .and. par%N_HImax < 0.0_wp) par%N_HImax = par%N_HI
-    if (par%N_HImax  > 0.0_wp .and. par%N_gasmax  < 0.0_wp) par%N_gasmax  = par%N_HImax
-    if (par%N_HIhomo > 0.0_wp .and. par%N_gashomo < 0.0_wp) par%N_gashomo = par%N_HIhomo
-    if (par%cext_dust <= 0.0_wp) par%DGR       = 0.0_wp
-    if (par%DGR == 0.0_wp)       par%save_Jabs = .false.
-    if (par%core_skip_global)    par%core_skip = .true.
+    call input_rules()                                                   ! the rules between the namelist fields (setup.f90:160-500): lart_host_input_rules, once for both hosts
 
     if (line%line_type == 8) call ly_beta_rules()                                               ! setup.f90:239-300
-    par%h2_model = strlowcase(par%h2_model)
     if (trim(par%h2_model) /= 'none') call h2_rules()                                           ! setup.f90:302-365
-
-    if (par%save_Jmu) then                                                                      ! :367-381
-       if (par%nmu < 1) then
-          write(*,'(a)') 'ERROR: par%nmu must be >= 1 when par%save_Jmu = .true.'; stop 1
-       endif
-       if (par%xyz_symmetry) then
-          par%mu_min = 0.0_wp;  par%dmu = 1.0_wp/par%nmu
-       else
-          par%mu_min = -1.0_wp; par%dmu = 2.0_wp/par%nmu
-       endif
-    endif
-    if (par%nr > 1) then
-       par%nx = par%nr; par%ny = par%nr; par%nz = par%nr
-    endif
-    select case(trim(par%geometry))                                                             ! :398-428
-    case ('sphere')
-       if (.not. par%xy_periodic .and. .not. par%use_amr_grid) then
-          r0 = maxval([par%rmax, par%xmax, par%ymax, par%zmax], mask=[par%rmax, par%xmax, par%ymax, par%zmax] > 0.0_wp)
-          if (r0 > 0.0_wp) then
-             par%rmax = r0; par%xmax = r0; par%ymax = r0; par%zmax = r0
-          endif
-          if (.not. par%xy_symmetry) then
-             par%nx = maxval([par%nx, par%ny, par%nz]); par%ny = par%nx; par%nz = par%nx
-          endif
-       endif
-    case ('rectangle')
-       par%rmax = -1.0_wp
-    end select
-    if (par%source_rmax < 0.0_wp) par%source_rmax = par%rmax
-    if (par%rmax <= 0.0_wp) par%geometry_JPa = 3                                                 ! :438-459
-    if (par%geometry_JPa < -1 .or. par%geometry_JPa > 3) then
-       par%geometry_JPa = 1
-       if (par%save_all) par%geometry_JPa = 3
-       if (par%geometry_JPa /= 3 .and. par%xy_periodic) par%geometry_JPa = -1
-    endif
     if ((par%geometry_JPa == 0 .or. par%geometry_JPa == 2) .and. (par%calc_J .or. par%calc_P .or. par%calc_Pnew)) &
        call not_supported('par%geometry_JPa = 2 (cylindrical profiles)')
-    if (par%distance2cm < 0.0_wp) then                                                          ! :473-489
-       select case(trim(par%distance_unit))
-       case ('kpc'); par%distance2cm = 3.0856776e18_wp*1e3_wp
-       case ('pc');  par%distance2cm = 3.0856776e18_wp
-       case ('au');  par%distance2cm = 1.4960e13_wp
-       case ('');    par%distance2cm = 1.0_wp
-       case default; par%distance2cm = 3.0856776e18_wp*1e3_wp
-       end select
-    else
-       par%distance_unit = 'user'
-    endif
-    if (par%intensity_unit < 0) then
-       if (par%distance2cm /= 1.0_wp) then
-          par%intensity_unit = 1
-       else
-          par%intensity_unit = 0
-       endif
-    endif
     if (len_trim(par%scatt_mat_file) > 0 .and. par%DGR > 0.0_wp) then                          ! :496-500
        call setup_scattering_matrix(trim(par%scatt_mat_file))
     else
@@ -600,10 +510,47 @@ contains
     write(*,'(3a)')       '+++++ ',trim(model_infile),' +++++'
     write(*,'(2a)')       'Line ID                   : ', trim(par%line_id)
     write(*,'(a,2f7.4)')  'Dust Parameters(a, g)     : ', par%albedo, par%hgg
-    write(*,'(a,es12.3)') 'Dust-to-Gas Ratio         : ', par%DGR
+    call say('Dust-to-Gas Ratio         : ', par%DGR, 'es12.3')
     if (par%DGR > 0.0) write(*,'(a,es12.3)') 'Dust Extinction per H     : ', par%cext_dust
-    write(*,'(a,es12.3)') 'Total number of photons   : ', par%no_photons
+    call say('Total number of photons   : ', par%no_photons, 'es12.3')
   contains
+    !--- the namelist fields the rules read and change go through the library's record and come back
+    subroutine input_rules()
+      type(lart_host_rules) :: r
+      r%nx = par%nx; r%ny = par%ny; r%nz = par%nz; r%nr = par%nr; r%nside = par%nside; r%nxim = par%nxim; r%nyim = par%nyim; r%nmu = par%nmu
+      r%geometry_JPa = par%geometry_JPa; r%intensity_unit = par%intensity_unit
+      select case (trim(par%distance_unit))
+      case ('');    r%distance_unit = LART_UNIT_NONE
+      case ('kpc'); r%distance_unit = LART_UNIT_KPC
+      case ('pc');  r%distance_unit = LART_UNIT_PC
+      case ('au');  r%distance_unit = LART_UNIT_AU
+      case default; r%distance_unit = LART_UNIT_OTHER
+      end select
+      r%xyz_symmetry = b2i(par%xyz_symmetry); r%xy_symmetry = b2i(par%xy_symmetry); r%xy_periodic = b2i(par%xy_periodic)
+      r%use_clump_medium = b2i(par%use_clump_medium); r%use_amr_grid = b2i(par%use_amr_grid); r%use_stokes = b2i(par%use_stokes)
+      r%sphere = b2i(trim(par%geometry) == 'sphere'); r%save_all = b2i(par%save_all)
+      r%save_peeloff = b2i(par%save_peeloff); r%save_peeloff_2D = b2i(par%save_peeloff_2D); r%save_peeloff_3D = b2i(par%save_peeloff_3D)
+      r%save_Jabs = b2i(par%save_Jabs); r%save_Jmu = b2i(par%save_Jmu); r%core_skip = b2i(par%core_skip); r%core_skip_global = b2i(par%core_skip_global)
+      r%tau0 = par%tau0; r%taumax = par%taumax; r%N_HI = par%N_HI; r%N_HImax = par%N_HImax; r%N_HIhomo = par%N_HIhomo; r%N_gasmax = par%N_gasmax
+      r%N_gashomo = par%N_gashomo; r%cext_dust = par%cext_dust; r%DGR = par%DGR; r%mu_min = par%mu_min; r%dmu = par%dmu
+      r%rmax = par%rmax; r%xmax = par%xmax; r%ymax = par%ymax; r%zmax = par%zmax; r%source_rmax = par%source_rmax; r%distance2cm = par%distance2cm
+      call setup_check(lart_host_input_rules(r), 'read_input')
+      par%nx = r%nx; par%ny = r%ny; par%nz = r%nz; par%nxim = r%nxim; par%nyim = r%nyim; par%geometry_JPa = r%geometry_JPa; par%intensity_unit = r%intensity_unit
+      if (r%distance_unit == LART_UNIT_USER) par%distance_unit = 'user'
+      par%xyz_symmetry = r%xyz_symmetry /= 0; par%use_stokes = r%use_stokes /= 0
+      par%save_peeloff = r%save_peeloff /= 0; par%save_peeloff_2D = r%save_peeloff_2D /= 0; par%save_peeloff_3D = r%save_peeloff_3D /= 0
+      par%save_Jabs = r%save_Jabs /= 0; par%core_skip = r%core_skip /= 0
+      par%taumax = r%taumax; par%N_HImax = r%N_HImax; par%N_gasmax = r%N_gasmax; par%N_gashomo = r%N_gashomo; par%DGR = r%DGR; par%mu_min = r%mu_min; par%dmu = r%dmu
+      par%rmax = r%rmax; par%xmax = r%xmax; par%ymax = r%ymax; par%zmax = r%zmax; par%source_rmax = r%source_rmax; par%distance2cm = r%distance2cm
+      if (iand(r%notes, LART_NOTE_NO_PEEL_WITH_XYZSYM) /= 0) then
+         write(*,'(a)') '---> peelingoff is not allowed for a geometry with the xyz_symmetry.'; write(*,'(a)') '---> setting par%save_peeloff = .false.'
+      endif
+    end subroutine input_rules
+    pure function b2i(l) result(i)
+      logical, intent(in) :: l
+      integer(c_int32_t) :: i
+      i = merge(1, 0, l)
+    end function b2i
     !--- 'ly_beta' (line type 8): what the band-2 path cannot do is refused, core-skipping would bias the conversion rate, the dust of band 1 takes the
     !--- Draine values at 1026 A when the input left the three defaults alone, and R_Ha is the ratio of the two extinction cross-sections
     subroutine ly_beta_rules()
@@ -809,8 +756,8 @@ contains
     if (line%line_type == 8) then                                        ! grid%Jout_Ha, grid%Jabs_Ha: the band-2 spectra
        allocate(grid%Jout_Ha(grid%nxfreq_Ha), grid%Jabs_Ha(grid%nxfreq_Ha)); grid%Jout_Ha = 0.0_wp; grid%Jabs_Ha = 0.0_wp
     endif
-    write(6,'(a,es16.3)') 'voigt_a          : ', grid%voigt_amean
-    write(6,'(a,es16.3)') 'temperature (K)  : ', par%temperature
+    call say('voigt_a          : ', grid%voigt_amean, 'es16.3')
+    call say('temperature (K)  : ', par%temperature, 'es16.3')
     write(6,'(a,es16.3)') 'N('//trim(line%ion_id)//')_pole     : ', m%N_gaspole_out
     write(6,'(a,es16.3)') 'N('//trim(line%ion_id)//')_homo     : ', m%N_gashomo_out
     write(6,'(a,es16.3)') 'tau_pole  ('//trim(line%ion_id)//') : ', m%taupole_out
@@ -866,13 +813,13 @@ contains
     r_min_clump = c%r_min; cl_radius_max = par%clump_radius; rc = cl_radius_max
     cl_Dfreq_ref = c%Dfreq_ref; cl_vtherm_ref = c%vtherm; cl_temperature_ref = temp_cl; cl_voigt_a_ref = c%voigt_a_ref
     N_clumps = c%N; cl_rhokap_ref = c%rhokap_ref
-    write(*,'(a,i14)')    ' Clumps: N_clumps  = ', N_clumps
+    call say(' Clumps: N_clumps  = ', N_clumps, 'i14')
     write(*,'(a,f12.6)')  ' Clumps: f_vol     = ', c%fvol
     write(*,'(a,f12.5)')  ' Clumps: f_cov     = ', c%fcov
     write(*,'(a,2f12.5)') ' Clumps: rmin/rmax = ', r_min_clump, R_sphere
-    write(*,'(a,es12.4)') ' Clumps: cl_rhokap = ', cl_rhokap_ref
-    write(*,'(a,f12.5)')  ' Clumps: voigt_a   = ', cl_voigt_a_ref
-    write(*,'(a,es12.4)') ' Clumps: cl_Dfreq  = ', cl_Dfreq_ref
+    call say(' Clumps: cl_rhokap = ', cl_rhokap_ref, 'es12.4')
+    call say(' Clumps: voigt_a   = ', cl_voigt_a_ref, 'f12.5')
+    call say(' Clumps: cl_Dfreq  = ', cl_Dfreq_ref, 'es12.4')
     n = int(N_clumps)
     allocate(cl_x(n), cl_y(n), cl_z(n), cl_vx(n), cl_vy(n), cl_vz(n), cl_radius(n), cl_rhokap(n), cl_voigt_a(n), cl_Dfreq(n), cl_vtherm(n))
     cl_radius = rc; cl_rhokap = cl_rhokap_ref; cl_voigt_a = cl_voigt_a_ref; cl_Dfreq = cl_Dfreq_ref; cl_vtherm = cl_vtherm_ref
@@ -1029,15 +976,17 @@ contains
     cl_Dfreq_ref = cl_Dfreq(1); cl_voigt_a_ref = cl_voigt_a(1); cl_rhokap_ref = cl_rhokap(1)
     if (par%taumax > 0.0_wp .or. par%tauhomo > 0.0_wp .or. par%N_gasmax > 0.0_wp .or. par%N_gashomo > 0.0_wp) then
        call clump_scalars(vals)
-       if (par%taumax > 0.0_wp) then
-          realized = vals(2); target_val = par%taumax; which = 'taumax'
-       else if (par%tauhomo > 0.0_wp) then
-          realized = vals(1); target_val = par%tauhomo; which = 'tauhomo'
-       else if (par%N_gasmax > 0.0_wp) then
-          realized = vals(4); target_val = par%N_gasmax; which = 'N_gasmax'
-       else
-          realized = vals(3); target_val = par%N_gashomo; which = 'N_gashomo'
-       endif
+       block                                                            ! the first given target in the order taumax, tauhomo, N_gasmax, N_gashomo
+         integer, parameter :: slot(4) = [2, 1, 4, 3]
+         character(len=9), parameter :: names(4) = [character(len=9) :: 'taumax', 'tauhomo', 'N_gasmax', 'N_gashomo']
+         real(wp) :: given(4)
+         integer :: k
+         given = [par%taumax, par%tauhomo, par%N_gasmax, par%N_gashomo]
+         do k = 1, 4
+            if (given(k) > 0.0_wp) exit
+         enddo
+         realized = vals(slot(k)); target_val = given(k); which = names(k)
+       end block
        if (realized <= 0.0_wp) then
           write(*,'(a)') ' Clumps: WARNING -- realized tau/NHI from loaded clumps is zero; cannot rescale. Leaving cl_rhokap unchanged.'
        else
@@ -1049,10 +998,10 @@ contains
     if (par%DGR > 0.0_wp) then
        allocate(cl_rhokapD(n)); cl_rhokapD = cl_rhokap*par%cext_dust*par%DGR*cl_Dfreq/line%cross0
     endif
-    write(*,'(a,i14)')    ' Clumps: N_clumps  = ', N_clumps
-    write(*,'(a,es12.4)') ' Clumps: cl_rhokap = ', cl_rhokap_ref
-    write(*,'(a,f12.5)')  ' Clumps: voigt_a   = ', cl_voigt_a_ref
-    write(*,'(a,es12.4)') ' Clumps: cl_Dfreq  = ', cl_Dfreq_ref
+    call say(' Clumps: N_clumps  = ', N_clumps, 'i14')
+    call say(' Clumps: cl_rhokap = ', cl_rhokap_ref, 'es12.4')
+    call say(' Clumps: voigt_a   = ', cl_voigt_a_ref, 'f12.5')
+    call say(' Clumps: cl_Dfreq  = ', cl_Dfreq_ref, 'es12.4')
     write(*,'(a,2es12.4)')' Clumps: r_cl min/max  = ', minval(cl_radius), cl_radius_max
     call build_clump_csr(.true.)
   contains
@@ -1098,10 +1047,10 @@ contains
     par%xyz_symmetry = .false.; par%xy_symmetry = .false.; par%xy_periodic = .false.; par%z_symmetry = .false.
     call init_clumps(par%rmax)
     call compute_clump_scalars()
-    write(*,'(a,es14.5)') ' Clump derived: tauhomo   = ', par%tauhomo
-    write(*,'(a,es14.5)') ' Clump derived: taumax    = ', par%taumax
-    write(*,'(a,es14.5)') ' Clump derived: N_gashomo = ', par%N_gashomo
-    write(*,'(a,es14.5)') ' Clump derived: N_gasmax  = ', par%N_gasmax
+    call say(' Clump derived: tauhomo   = ', par%tauhomo, 'es14.5')
+    call say(' Clump derived: taumax    = ', par%taumax, 'es14.5')
+    call say(' Clump derived: N_gashomo = ', par%N_gashomo, 'es14.5')
+    call say(' Clump derived: N_gasmax  = ', par%N_gasmax, 'es14.5')
     vtype = par%velocity_type; par%velocity_type = ''       ! the background grid is static; velocities live on the clumps
     call grid_create(grid)
     par%velocity_type = vtype
@@ -1109,11 +1058,11 @@ contains
     grid%vfx = 0.0_wp; grid%vfy = 0.0_wp; grid%vfz = 0.0_wp
     if (allocated(grid%rhokapD)) grid%rhokapD = 0.0_wp
     grid%Dfreq_ref = cl_Dfreq_ref; grid%voigt_amean = cl_voigt_a_ref
-    write(*,'(a,f12.5)')  ' Clump grid: rmax      = ', par%rmax
+    call say(' Clump grid: rmax      = ', par%rmax, 'f12.5')
     write(*,'(a,3i5)')    ' Clump grid: nx,ny,nz  = ', grid%nx, grid%ny, grid%nz
-    write(*,'(a,es12.4)') ' Clump grid: cl_Dfreq_ref  = ', cl_Dfreq_ref
+    call say(' Clump grid: cl_Dfreq_ref  = ', cl_Dfreq_ref, 'es12.4')
     write(*,'(a,f12.5,a)')' Clump grid: cl_vtherm_ref = ', cl_vtherm_ref, ' km/s'
-    write(*,'(a,f12.5)')  ' Clump grid: voigt_a   = ', cl_voigt_a_ref
+    call say(' Clump grid: voigt_a   = ', cl_voigt_a_ref, 'f12.5')
   end subroutine grid_create_clump
 
   !--- grid_create_amr: grid_mod_amr.f90:34-526 for the generic text leaf table (all hydrogen neutral, no dust model file)
@@ -1197,8 +1146,7 @@ contains
     if (par%source_rmax < 0.0_wp) par%source_rmax = par%rmax
 
     !--- leaf physics (:230-330): T floor 10 K, all H neutral
-    grid%Dfreq_ref   = vtherm_total(par%temperature)/(line%wavelength0*um2km)
-    grid%voigt_amean = (line%damping/fourpi)/grid%Dfreq_ref
+    grid%Dfreq_ref = vtherm_total(par%temperature)/(line%wavelength0*um2km); grid%voigt_amean = (line%damping/fourpi)/grid%Dfreq_ref
     allocate(amr_Dfreq(n), amr_voigt_a(n), amr_rhokap(n), amr_vfx(n), amr_vfy(n), amr_vfz(n))
     if (par%DGR > 0.0_wp) allocate(amr_rhokapD(n))
     par%distance_unit = ''; par%distance2cm = merge(par%distance2cm, 1.0_wp, par%distance2cm > 0.0_wp)
@@ -1548,9 +1496,7 @@ contains
     type(grid_type), intent(inout) :: grid
     type(lart_host_norm) :: q
     real(wp) :: intensity_bin_unit
-    par%nscatt_dust = par%nscatt_dust/par%nphotons
-    par%nscatt_gas  = par%nscatt_gas /par%nphotons
-    par%nscatt_tot  = par%nscatt_gas + par%nscatt_dust
+    par%nscatt_dust = par%nscatt_dust/par%nphotons; par%nscatt_gas = par%nscatt_gas/par%nphotons; par%nscatt_tot = par%nscatt_gas + par%nscatt_dust
     intensity_bin_unit = merge(grid%dwave, grid%dxfreq, par%intensity_unit == 1)
     q%xy_periodic = merge(1, 0, par%xy_periodic); q%sphere = merge(1, 0, trim(par%geometry) == 'sphere'); q%nphotons = real(par%nphotons, wp)
     q%bin_unit = intensity_bin_unit; q%bin_unit_Ha = intensity_bin_unit

@@ -18,7 +18,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import capi, hostlib
-from .params import LartInputError, Params, MAX_OBSERVERS, NAN, read_namelist, set_param, _f32     # noqa: F401  (re-exported: the namelist surface)
+from .params import LartInputError, Params, MAX_OBSERVERS, NAN, read_namelist, set_param, _f32, _parse_value     # noqa: F401  (re-exported: the namelist surface)
 from .postproc import radial_profiles                                                               # noqa: F401  (re-exported)
 
 PI = 3.141592653589793238462643383279502884197

@@ -63,6 +63,21 @@ def main():
             rows.append({"case": name, "Nscat": float(m.group(1)), "namelist": parse_namelist(os.path.join(REF, "FeII_test", name + ".in"))}); name = None
     assert len(rows) == 9
     tab["FeII_test"] = {"cite": "examples/FeII_test/out.txt ('Average Number of scattering', 1e8 photons per case)", "rows": rows}
+    # ---- SiII_1527 (log of 2023/07/25) and SiII_1193 (2022/06/06): 'Average Number of scattering' of every run of the two logs.  Both logs are older than v2.00 and count
+    # every scattering as 1 (v2.00 adds the packet weight, scattering_car.f90:690): the comparable quantity of a v2.00 run is the UNWEIGHTED number of scattering events per photon
+    for ex in ("SiII_1527", "SiII_1193"):
+        rows, name, setup = [], None, {}
+        for line in open(os.path.join(REF, ex, "out.txt")):
+            m = re.match(r"\+\+\+\+\+ (\S+)\.in \+\+\+\+\+", line)
+            if m:
+                name = m.group(1); setup = {}
+            m = re.match(r"(voigt_a|temperature \(K\)|N\(Si II\)_pole|tau_pole  \(Si II\))\s*:\s+([0-9.eE+-]+)", line)
+            if m:
+                setup[m.group(1)] = float(m.group(2))
+            m = re.match(r"Average Number of scattering :\s+([0-9.eE+-]+)", line)
+            if m and name:
+                rows.append({"case": name, "Nscat_unweighted": float(m.group(1)), "setup": setup, "namelist": parse_namelist(os.path.join(REF, ex, name + ".in"))}); name = None
+        tab[ex] = {"cite": "examples/%s/out.txt ('Average Number of scattering' of every run; logs older than v2.00: one count per scattering, not the packet weight)" % ex, "rows": rows}
     dst = os.path.join(ROOT, "tests", "golden", "reference_tables.json")
     json.dump(tab, open(dst, "w"), indent=1)
     print("wrote", dst, {k: len(v["rows"]) for k, v in tab.items() if isinstance(v, dict)})
