@@ -180,6 +180,7 @@ struct Lds { const double *vt; const double *xf, *yf, *zf;   // Voigt tables and
              double *jp_P, *jp_Pn;       // per-block LDS copies of P1 / P1_new (nullptr: deposits go to global memory)
              double *jp_J; int j_lo, j_w; // per-block LDS copy of the line-centre window of J1: [j_w][nbins] (nullptr: off)
              unsigned *pq_cnt;           // this wave's record counter of the peel queue (LDS word), nullptr = no peel-off
+             double *aux;                // line type 8 / H2: the weight budget of the block (8 doubles in LDS, flushed once per launch), nullptr: add to the global scalars
              const ClumpGeo *ct_geo; const ClumpPhys *ct_phys;   // VAR 7, populations of at most 128 clumps: the clump records staged in LDS (nullptr: read from global memory)
              double fov_bx, fov_by;      // peel prefilter: tan of the half field of view (+ margin) in x and y, < 0 = no field-of-view test (lds_set_fov)
              unsigned char *coop;        // LART_COOP_BYTES per wave: scratch of the cooperative samplers (vz_core_coop / vz_wing_coop), nullptr = off
@@ -188,13 +189,17 @@ struct Lds { const double *vt; const double *xf, *yf, *zf;   // Voigt tables and
              double hd_ratio, hd_ratio_a, hd_nD; };   // line type 7: ratio_Dfreq_HD, ratio_voigta_HD, nD_over_nH (line_mod.f90:1186-1191)
                                          // (lt comes from a template parameter, so that `l.lt == 2` / `== 7` fold away in the single-line kernels)
 
+// one term of the weight budget (W_conv, W_esc1, ...; W_H2abs, W_H2scat, W_H2pump): into the block's LDS accumulators when the kernel set them up -- every lane of a
+// launch adding to ONE global address serialises at the memory side --, else (probes) into the global scalars
+struct KArgs;
+__device__ __forceinline__ void aux_add(double *scal, const Lds &l, int k, double w) { if (l.aux) atomicAdd(&l.aux[k], w); else atomicAdd(&scal[25 + k], w); }
 __device__ inline Lds lds_stage(double *sh, const DGrid &g) {
     for (int i = threadIdx.x; i < VT_END; i += blockDim.x) sh[i] = c_voigt_tab[i];
     int nf = g.nx + g.ny + g.nz + 3;
     for (int i = threadIdx.x; i < nf; i += blockDim.x) sh[VT_END + i] = g.faces[i];
     __syncthreads();
     Lds l; l.vt = sh; l.xf = sh + VT_END; l.yf = l.xf + (g.nx + 1); l.zf = l.yf + (g.ny + 1);
-    l.dip_p2 = 0.0; l.dip_qs = 0.0; l.jp_P = nullptr; l.jp_Pn = nullptr; l.jp_J = nullptr; l.j_lo = 0; l.j_w = 0; l.coop = nullptr; l.pq_cnt = nullptr; l.fov_bx = -1.0; l.fov_by = -1.0; l.ct_geo = nullptr; l.ct_phys = nullptr; l.lt = 1; l.dnu_hz = 0.0; l.hd_ratio = 1.0; l.hd_ratio_a = 1.0; l.hd_nD = 0.0; l.ml_nup = 1; l.ml_coh = 0; l.ml_tab = nullptr; l.ml_itab = nullptr;
+    l.dip_p2 = 0.0; l.dip_qs = 0.0; l.jp_P = nullptr; l.jp_Pn = nullptr; l.jp_J = nullptr; l.j_lo = 0; l.j_w = 0; l.coop = nullptr; l.pq_cnt = nullptr; l.fov_bx = -1.0; l.fov_by = -1.0; l.ct_geo = nullptr; l.ct_phys = nullptr; l.aux = nullptr; l.lt = 1; l.dnu_hz = 0.0; l.hd_ratio = 1.0; l.hd_ratio_a = 1.0; l.hd_nD = 0.0; l.ml_nup = 1; l.ml_coh = 0; l.ml_tab = nullptr; l.ml_itab = nullptr;
     for (int i = 0; i < 3; i++) { l.ml_dE[i] = 0.0; l.ml_damp[i] = 1.0; l.ml_f12[i] = 0.0; }
     return l;
 }
@@ -1611,11 +1616,11 @@ __device__ inline void tally_escape(const lart_params &par, const DTally &T, con
 }
 
 // a band-2 (H-alpha) packet leaves: its frequency is the lab-frame one in reference units already (raytrace_car.f90:1625-1636, raytrace_amr.f90:244-256)
-__device__ inline void tally_escape_Ha(const KArgs &A, Photon &p) {
+__device__ inline void tally_escape_Ha(const KArgs &A, const Lds &l, Photon &p) {
     p.xfreq_ref = p.xfreq;
     const int ix = (int)floor((p.xfreq_ref - A.par.xfreq_min_Ha) / A.par.dxfreq_Ha) + 1;
     if (ix >= 1 && ix <= A.par.nxfreq_Ha) atomicAdd(&A.t.Jout_Ha[ix - 1], p.wgt);
-    atomicAdd(&A.t.scal[LART_SCAL_AUX + 3], p.wgt);           // W_esc2
+    aux_add(A.t.scal, l, 3, p.wgt);                            // W_esc2
 }
 // add_to_J (raytrace_car.f90:3979-4011) + add_to_Pnew (:4015-4045): one path segment of length del in cell `ci`
 __device__ inline void jpa_segment(const KArgs &A, const Lds &l, const Photon &p, size_t ci, double rhokap_cell, double Dfreq_cell, double del, double dtauH) {
@@ -1686,13 +1691,13 @@ __device__ __forceinline__ void raytrace_to_tau_amr(const KArgs &A, const Lds &l
         u1 = u2; il = il_new; c = cn;
     }
     p.x = x; p.y = y; p.z = z; p.kx = kx; p.ky = ky; p.kz = kz; p.ic = il; p.jc = 1; p.kc = 1;
-    if (!p.inside && l.lt == 8 && p.iband == 2) tally_escape_Ha(A, p);
+    if (!p.inside && l.lt == 8 && p.iband == 2) tally_escape_Ha(A, l, p);
     else if (!p.inside) {
         u1 = c->vfx * kx + c->vfy * ky + c->vfz * kz;
         p.xfreq = p.xfreq + u1;
         p.xfreq_ref = p.xfreq * (c->Dfreq / A.par.Dfreq_ref);
         tally_escape(A.par, A.t, p);
-        if (l.lt == 8) atomicAdd(&A.t.scal[LART_SCAL_AUX + 1], p.wgt);      // W_esc1
+        if (l.lt == 8) aux_add(A.t.scal, l, 1, p.wgt);      // W_esc1
     }
 }
 
@@ -1773,7 +1778,7 @@ __device__ __forceinline__ void raytrace_to_tau(const KArgs &A, const Lds &l, bo
         Dold = Dn; u1 = u2; rk = c->rhokap; va = c->voigt_a; rD = c->rhokapD;
     }
     if (A.jpa.nbins && !band2) jpa_segment(A, l, p, cidx(g, t.ic, t.jc, t.kc), rk, Dold, del, del * (rk * vH));          // last segment :1604-1609
-    if (!p.inside && band2) tally_escape_Ha(A, p);
+    if (!p.inside && band2) tally_escape_Ha(A, l, p);
     else
     if (!p.inside) {                                          // :1613-1623 fluid frame -> lab frame, escape tally
         // (for VAR 1 the mirrored direction components of the last flight segment are used, :1918)
@@ -1781,7 +1786,7 @@ __device__ __forceinline__ void raytrace_to_tau(const KArgs &A, const Lds &l, bo
         p.xfreq = p.xfreq + u1;
         p.xfreq_ref = p.xfreq * (Dold / A.par.Dfreq_ref);
         tally_escape(A.par, A.t, p);
-        if (l.lt == 8) atomicAdd(&A.t.scal[LART_SCAL_AUX + 1], p.wgt);      // W_esc1 :1624
+        if (l.lt == 8) aux_add(A.t.scal, l, 1, p.wgt);      // W_esc1 :1624
     }
     if (VAR == 1 || VAR == 5) {                               // :1935-1946 unfolded path, then fold back into the octant (xysym :2238-2248: x and y only)
         p.x = p.x + d * p.kx; p.y = p.y + d * p.ky; p.z = p.z + d * p.kz;
@@ -2324,13 +2329,13 @@ __device__ inline void phi_rejection(Rng &g, const Photon &p, double r, double &
     }
 }
 // dust absorption / reduced weight: :504-555 (= :217-264). true when the packet is destroyed
-__device__ __forceinline__ bool dust_absorb(const KArgs &A, Rng &g, Photon &p, const Cell &c) {
+__device__ __forceinline__ bool dust_absorb(const KArgs &A, const Lds &l, Rng &g, Photon &p, const Cell &c) {
     p.nsd = p.nsd + p.wgt;
     const lart_params &par = A.par;
     double dep = 0.0; bool killed = false;
     if (!par.use_reduced_wgt) { if (g.next() > par.albedo) { dep = p.wgt; killed = true; } }
     else { dep = p.wgt * (1.0 - par.albedo); }
-    if (par.line_type == 8 && dep != 0.0) atomicAdd(&A.t.scal[LART_SCAL_AUX + 2], dep);      // W_abs1 (scattering_car.f90:524, :553)
+    if (par.line_type == 8 && dep != 0.0) aux_add(A.t.scal, l, 2, dep);      // W_abs1 (scattering_car.f90:524, :553)
     if (dep != 0.0 && par.save_Jabs) {
         double uu1 = c.vfx * p.kx + c.vfy * p.ky + c.vfz * p.kz;
         double xr = (p.xfreq + uu1) * (c.Dfreq / par.Dfreq_ref);
@@ -2370,13 +2375,13 @@ __device__ __forceinline__ bool scatter_pre(const KArgs &A, const Lds &l, Rng &g
         if (!par.use_reduced_wgt) {
             if (g.next() > par.albedo_Ha) {
                 if (par.save_Jabs) { const int ix = (int)floor((p.xfreq - par.xfreq_min_Ha) / par.dxfreq_Ha) + 1; if (ix >= 1 && ix <= par.nxfreq_Ha) atomicAdd(&A.t.Jabs_Ha[ix - 1], p.wgt); }
-                p.inside = false; atomicAdd(&A.t.scal[LART_SCAL_AUX + 4], p.wgt);       // W_abs2
+                p.inside = false; aux_add(A.t.scal, l, 4, p.wgt);       // W_abs2
                 if (A.allph) { p.xfreq_ref = p.xfreq; p.wgt = 0.0; }
                 return false;
             }
         } else {
             if (par.save_Jabs) { const int ix = (int)floor((p.xfreq - par.xfreq_min_Ha) / par.dxfreq_Ha) + 1; if (ix >= 1 && ix <= par.nxfreq_Ha) atomicAdd(&A.t.Jabs_Ha[ix - 1], p.wgt * (1.0 - par.albedo_Ha)); }
-            atomicAdd(&A.t.scal[LART_SCAL_AUX + 4], p.wgt * (1.0 - par.albedo_Ha));
+            aux_add(A.t.scal, l, 4, p.wgt * (1.0 - par.albedo_Ha));
             p.wgt = p.wgt * par.albedo_Ha;
         }
         if (PEEL) { unsigned natom = 0; peel_dust_Ha<VAR>(A, l, DUST, p, npeel, natom); }
@@ -2392,12 +2397,12 @@ __device__ __forceinline__ bool scatter_pre(const KArgs &A, const Lds &l, Rng &g
             double w[4], wtot = 0.0; int il = 1;
             for (int q = 0; q < par.h2_nlines; q++) { const double dx = A.h2tab[q] / c.Dfreq, x_h2 = (p.xfreq - dx) * ratio; w[q] = A.h2tab[4 + q] * ratio * voigt_H(l.vt, x_h2, A.h2tab[8 + q]); wtot = wtot + w[q]; }
             if (wtot > 0.0) { const double r = g.next() * wtot; double acc = 0.0; il = par.h2_nlines; for (int q = 0; q < par.h2_nlines; q++) { acc = acc + w[q]; if (r <= acc) { il = q + 1; break; } } }
-            atomicAdd(&A.t.scal[LART_SCAL_AUX + 2 + il - 1], p.wgt);                      // W_H2pump(il)
+            aux_add(A.t.scal, l, 2 + il - 1, p.wgt);                      // W_H2pump(il)
             if (g.next() > A.h2tab[12 + il - 1]) {            // fluorescence to another wavelength: the packet leaves Ly-alpha
-                atomicAdd(&A.t.scal[LART_SCAL_AUX + 0], p.wgt); p.inside = false; if (A.allph) p.wgt = 0.0;
+                aux_add(A.t.scal, l, 0, p.wgt); p.inside = false; if (A.allph) p.wgt = 0.0;
                 return false;
             }
-            atomicAdd(&A.t.scal[LART_SCAL_AUX + 1], p.wgt); p.nsg = p.nsg + p.wgt;
+            aux_add(A.t.scal, l, 1, p.wgt); p.nsg = p.nsg + p.wgt;
             const double rt = c.Dfreq / par.h2_Dfreq_Hz, dx = A.h2tab[il - 1] / c.Dfreq;       // (scatter_h2 always uses the H2 Doppler width: :163-166)
             sc.h2 = il; sc.cl_Dfreq = c.Dfreq; sc.xsamp = (p.xfreq - dx) * rt; sc.vsamp = A.h2tab[8 + il - 1]; sc.xloc = sc.xsamp;
             return true;
@@ -2407,7 +2412,7 @@ __device__ __forceinline__ bool scatter_pre(const KArgs &A, const Lds &l, Rng &g
         double rD = cl_rhokapD;
         double p_dust = rD / (cl_rhokap * calc_voigt(l, p.xfreq * cl_scale, va, cl_Dfreq) + rD);
         if (g.next() <= p_dust) {
-            if (dust_absorb(A, g, p, c)) return false;
+            if (dust_absorb(A, l, g, p, c)) return false;
             if (STOKES && A.mu.nPDF > 0) {                     // scatter_dust_stokes :201-329
                 if (PEEL) peel_emit<VAR, STOKES>(A, l, DUST, PEEL_DUST, p, p.xfreq, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, npeel);      // peeling_dust_stokes_outside, deferred
                 double cost = rand_alias_linear(g, A.mu), sint = sqrt(1.0 - cost * cost);
@@ -2517,7 +2522,7 @@ __device__ __forceinline__ void scatter_post(const KArgs &A, const Lds &l, Rng &
     if (l.lt == 8) {                                           // do_resonance8 (line_mod.f90:318-329): 3p -> 2s with probability P_down(2): the packet turns into H-alpha
         if (g.next() < par.P_conv) { converted = true; p.iband = 2; E1 = par.E_conv[0]; E2 = par.E_conv[1]; E3 = par.E_conv[2]; }
         if (converted) {                                       // scattering_car.f90:697-705: W_conv and the conversion-rate profile (add_to_Pconv :861-894)
-            atomicAdd(&A.t.scal[LART_SCAL_AUX + 0], p.wgt);
+            aux_add(A.t.scal, l, 0, p.wgt);
             const Cell &cc = A.g.cell[cidx(A.g, p.ic, p.jc, p.kc)];
             if (A.jpa.Pconv && cc.rhokap > 0.0) {
                 const int ib = (VAR == 3) ? amr_JPa_bin(A.amr, p.ic, p.x, p.y, p.z) : A.jpa.ind_bin[cidx(A.g, p.ic, p.jc, p.kc)];

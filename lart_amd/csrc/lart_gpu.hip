@@ -756,6 +756,7 @@ extern "C" int lart_gpu_step(lart_gpu *c, int32_t nsteps, int32_t max_events) {
     size_j_window(c); A.jpa = c->jpa;
     // Voigt tables + faces | ring of random draws [LART_RNG_BUF][block] | per-block P1, P1_new
     size_t shmem = (size_t)(VT_END + c->g.nx + c->g.ny + c->g.nz + 3 + LART_RNG_BUF * c->block + 2 * c->jpa.lds_bins + c->jpa.lds_j_w * c->jpa.nbins) * sizeof(double) + (size_t)(LART_COOP_BYTES + 4) * ((c->block + 63) / 64);   // ... + the wave-local scratch of vz_core_coop + the waves' peel-queue counters
+    if (c->par.line_type == 8 || h2) shmem = ((shmem + 15) & ~(size_t)15) + 8 * sizeof(double);      // ... + the block's accumulators of the ly_beta / H2 weight budget
     if (var == 7 && c->cl.cg_mask && c->cl.N <= LART_OVL_LDS_CLUMPS) shmem = ((shmem + 15) & ~(size_t)15) + (size_t)c->cl.N * (sizeof(ClumpGeo) + sizeof(ClumpPhys));      // ... + the clump records (lds_stage_clumps)
     if (shmem > 160 * 1024) return fail("step: grid faces do not fit the 160 KiB LDS");
     // peel-off: a launch of `slice` events per lane queues at most live_lanes x (slice + 1) records (one per event, one per birth);
@@ -888,21 +889,22 @@ extern "C" int lart_gpu_get_tallies(lart_gpu *c, lart_tallies *o) {
     HIPCHK(hipStreamSynchronize(c->stream));
     if (collect_events(c)) return 1;
     // after output_reduce the root hands out the totals over all ranks (its receive buffer), until it adds events of its own again
-    const ptrdiff_t rs = (c->reduced_valid && c->d_reduced) ? c->d_reduced - c->d_tally : 0;
-    double s[16]; HIPCHK(hipMemcpy(s, c->d_tally + rs, sizeof s, hipMemcpyDeviceToHost));
-    { double dr = 0.0; HIPCHK(hipMemcpy(&dr, c->d_tally + rs + LART_SCAL_PEEL_DROPPED, 8, hipMemcpyDeviceToHost));
+    // (the section pointers of c->t point into d_tally; a section of the receive buffer is addressed as base + its OFFSET in d_tally -- no arithmetic between the two allocations)
+    const double *base = (c->reduced_valid && c->d_reduced) ? c->d_reduced : c->d_tally;
+    double s[16]; HIPCHK(hipMemcpy(s, base, sizeof s, hipMemcpyDeviceToHost));
+    { double dr = 0.0; HIPCHK(hipMemcpy(&dr, base + LART_SCAL_PEEL_DROPPED, 8, hipMemcpyDeviceToHost));
       if (dr > 0.0) return fail("get_tallies: the peel-off deposit list overflowed (" + std::to_string((long long)dr) + " rays dropped): the images have lost flux; this is a sizing bug of the peel queue, not a property of the input"); }
     if (s[7] > 0.0) return fail("get_tallies: a ray met more overlapping clumps than the march lists hold (LART_OVL_ACT clumps around a point, LART_OVL_PEND events ahead): the result is not the reference's");
     o->nscatt_gas = s[0]; o->nscatt_dust = s[1]; o->n_events = s[2]; o->n_cellsteps = s[3]; o->n_cellsteps_peel = s[4]; o->n_atomics = s[6]; o->nphotons_done = (int64_t)(s[5] + 0.5);
     DCtl h{}; HIPCHK(hipMemcpy(&h, c->d_ctl, sizeof h, hipMemcpyDeviceToHost)); o->nphotons_active = (int64_t)h.n_active;
     int64_t nxf = c->par.nxfreq, n2 = (int64_t)c->nobs * c->nxim * c->nyim, n3 = n2 * nxf;
-#define CP(dst, src, cnt) if ((dst) && (src) && (cnt) > 0) HIPCHK(hipMemcpy((dst), (src) + rs, (size_t)(cnt) * 8, hipMemcpyDeviceToHost))
+#define CP(dst, src, cnt) if ((dst) && (src) && (cnt) > 0) HIPCHK(hipMemcpy((dst), base + ((src) - c->d_tally), (size_t)(cnt) * 8, hipMemcpyDeviceToHost))
     CP(o->Jout, c->t.Jout, nxf); CP(o->Jin, c->t.Jin, nxf); CP(o->Jabs, c->t.Jabs, nxf); CP(o->Jmu, c->t.Jmu, c->par.save_Jmu ? nxf * c->par.nmu : 0);
     double *h3[8] = {o->scatt, o->direc, o->I, o->Q, o->U, o->V, o->direc0, o->scatt_dust}, *h2[8] = {o->scatt_2D, o->direc_2D, o->I_2D, o->Q_2D, o->U_2D, o->V_2D, o->direc0_2D, nullptr};
     for (int k = 0; k < 8; k++) { CP(h3[k], c->t.c3[k], n3); CP(h2[k], c->t.c2[k], n2); }
     CP(o->J1, c->jpa.J1, nxf * c->jpa.nbins); CP(o->P1, c->jpa.P1, c->jpa.nbins); CP(o->P1_new, c->jpa.P1_new, c->jpa.nbins);
     CP(o->Jout_Ha, c->t.Jout_Ha, c->par.nxfreq_Ha); CP(o->Jabs_Ha, c->t.Jabs_Ha, c->par.nxfreq_Ha); CP(o->peel_Ha, c->t.peel_Ha, n2 * c->par.nxfreq_Ha); CP(o->Pconv, c->jpa.Pconv, c->jpa.nbins);
-    { double w[8] = {0}; HIPCHK(hipMemcpy(w, c->d_tally + rs + LART_SCAL_AUX, 7 * 8, hipMemcpyDeviceToHost)); for (int i = 0; i < 8; i++) o->aux[i] = w[i]; }
+    { double w[8] = {0}; HIPCHK(hipMemcpy(w, base + LART_SCAL_AUX, 7 * 8, hipMemcpyDeviceToHost)); for (int i = 0; i < 8; i++) o->aux[i] = w[i]; }
 #undef CP
     return 0;
 }

@@ -55,7 +55,7 @@ __device__ inline void fly(const KArgs &A, const Lds &l, Rng &g, Photon &p, bool
             double u1 = c.vfx * p.kx + c.vfy * p.ky + c.vfz * p.kz;
             Photon e = p; e.wgt = p.wgt * esc; e.xfreq_ref = (p.xfreq + u1) * (c.Dfreq / par.Dfreq_ref);
             if (e.wgt != 0.0) tally_escape(par, A.t, e);
-            if (l.lt == 8 && e.wgt != 0.0) atomicAdd(&A.t.scal[LART_SCAL_AUX + 1], e.wgt);      // W_esc1: run_simulation_mod.f90:168
+            if (l.lt == 8 && e.wgt != 0.0) aux_add(A.t.scal, l, 1, e.wgt);      // W_esc1: run_simulation_mod.f90:168
         }
         double wgt1 = 1.0 - esc;
         p.wgt = p.wgt * wgt1;
@@ -110,6 +110,13 @@ __global__ __launch_bounds__(LART_MAX_BLOCK_V(STOKES), LART_WAVES_V4(VAR, STOKES
     if (PEEL) {                                                // this wave's record counter of the peel queue
         l_.pq_cnt = (unsigned *)(l_.coop - LART_COOP_BYTES * (threadIdx.x >> 6) + LART_COOP_BYTES * (blockDim.x >> 6)) + (threadIdx.x >> 6);
         if ((threadIdx.x & 63) == 0) *l_.pq_cnt = 0u;
+    }
+    if (LT == 8 || LT == 9) {                                  // the block's accumulators of the weight budget, in the spare words behind the peel counters (8 doubles)
+        double *ax = (double *)(((size_t)((unsigned char *)sh + ((size_t)(VT_END + (A.g.nx + A.g.ny + A.g.nz + 3) + (size_t)LART_RNG_BUF * blockDim.x + 2 * (size_t)A.jpa.lds_bins + (size_t)nJ) * sizeof(double)
+                                          + (size_t)(LART_COOP_BYTES + 4) * (blockDim.x >> 6))) + 15) & ~(size_t)15);
+        if (threadIdx.x < 8) ax[threadIdx.x] = 0.0;
+        __syncthreads();
+        l_.aux = ax;
     }
     if (VAR == 7) {                                            // the clump records of a small population, behind everything else (the offset lart_gpu_step sizes the launch for)
         const size_t off = (((size_t)(VT_END + (A.g.nx + A.g.ny + A.g.nz + 3) + (size_t)LART_RNG_BUF * blockDim.x + 2 * (size_t)A.jpa.lds_bins + (size_t)nJ) * sizeof(double)
@@ -223,6 +230,10 @@ __global__ __launch_bounds__(LART_MAX_BLOCK_V(STOKES), LART_WAVES_V4(VAR, STOKES
             if (A.jpa.P1 && v != 0.0) atomicAdd(&A.jpa.P1[i], v);
             if (A.jpa.P1_new && w != 0.0) atomicAdd(&A.jpa.P1_new[i], w);
         }
+    }
+    if (l.aux) {                                               // flush the block's weight budget: one atomic per term
+        __syncthreads();
+        if (threadIdx.x < 8 && l.aux[threadIdx.x] != 0.0) atomicAdd(&A.t.scal[LART_SCAL_AUX + threadIdx.x], l.aux[threadIdx.x]);
     }
     if (PEEL && (threadIdx.x & 63) == 0) A.pq.count[lane >> 6] = *l.pq_cnt;
     A.pool.flags[lane] = (alive ? FLAG_ALIVE : 0) | (first ? FLAG_FIRST : 0) | ((LT == 8 && p.iband == 2) ? FLAG_BAND2 : 0);

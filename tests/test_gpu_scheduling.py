@@ -55,6 +55,23 @@ def test_lane_compaction_changes_nothing_but_the_grid(capi, oracle_mod):
     assert same.mean() > 0.999
 
 
+def test_drain_compaction_layouts_with_the_shear_plane(capi, monkeypatch):
+    """the drain-phase re-layout (lart_gpu_compact: round-robin spread over the wave slots below 64 x W packets, dense above; holes / movers lists) on a pool that carries
+    the extra state plane of the shearing box (F_SHEAR, VAR 8) and a Stokes vector: the run with automatic compaction, the same with LART_DENSE_DRAIN=1 (dense layout only)
+    and the run without compaction give identical per-photon histories, and the first two did compact (the bench contract test no longer pins this)"""
+    kw = dict(temperature=1e4, taumax=3e2, nx=6, ny=4, nz=21, xmax=0.5, ymax=0.3, zmax=1.0, geometry="rectangle", xy_periodic=True, Omega=2.5, nxfreq=81, use_stokes=True, iseed=9)
+    n = 8192
+    (na, xa), ta, la = drain(make(kw), n, 64, True)
+    monkeypatch.setenv("LART_DENSE_DRAIN", "1")
+    (nd, xd), td, ld = drain(make(kw), n, 64, True)
+    monkeypatch.delenv("LART_DENSE_DRAIN")
+    (nb, xb), tb, lb = drain(make(kw), n, 64, False)
+    assert np.array_equal(na, nb) and np.array_equal(xa, xb) and np.array_equal(nd, nb) and np.array_equal(xd, xb)
+    assert ta["nphotons_done"] == td["nphotons_done"] == tb["nphotons_done"] == n and ta["n_events"] == tb["n_events"] == td["n_events"]
+    assert np.allclose(ta["Jout"], tb["Jout"], rtol=0, atol=1e-9) and np.allclose(td["Jout"], tb["Jout"], rtol=0, atol=1e-9)
+    assert min(lb) == max(lb) == 8192 and la[-1] < 8192 and ld[-1] < 8192 and len(set(la)) >= 3 and len(set(ld)) >= 3, (la[-5:], ld[-5:])
+
+
 def test_forced_compaction_mid_run_with_stokes_planes(capi):
     """lart_gpu_compact by hand in the middle of a Stokes run (19 state planes move): same histories as an undisturbed run"""
     kw = dict(KW, taumax=300.0, use_stokes=True, xyz_symmetry=False, nx=21, ny=21, nz=21)
