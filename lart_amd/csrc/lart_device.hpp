@@ -53,7 +53,8 @@ struct DAmr {
 struct ClumpGeo  { double x, y, z, r2; };                                           // centre, radius^2
 struct ClumpPhys { double rhokap, rhokapD, voigt_a, Dfreq, vx, vy, vz, pad; };     // v in units of the clump's thermal speed
 // VAR 4 (disjoint clumps) and VAR 7 (overlapping clumps) share the owner-clump bookkeeping of the scattering and peel-off routines
-__host__ __device__ constexpr bool is_clump(int var) { return var == 4 || var == 7; }
+__host__ __device__ constexpr bool is_clump(int var) { return var == 4 || var == 7 || var == 9; }
+__host__ __device__ constexpr bool is_ovl(int var) { return var == 7 || var == 9; }      // overlapping clumps; 9 = at most 64 of them, flights by the wave (ovl_coop)
 // VAR 8 = the xy-periodic box with a shearing x boundary (raytrace_to_tau_car_xyper_shear, raytrace_car.f90:2677-2954, chosen at setup.f90:967-969
 // when par%Omega /= 0): the tau march of VAR 6 with photon%vfy_shear; setup_procedure leaves raytrace_to_edge at its default there, the
 // PLAIN Cartesian march (setup.f90:941, :967-969 assign raytrace_to_tau only), so every edge / peel march of VAR 8 is VAR 0's
@@ -1275,15 +1276,18 @@ __device__ inline double ovl_sum_kap(const KArgs &A, const Lds &l, bool dust, co
 //         scattering point, or owner = 0 and t_end = the path to the sphere's surface (escape).  u_own = the draw of sample_owner_clump (:644-664).
 // else:   raytrace_to_edge_clump_overlap_capped (:858-918): lim = the cap; returns the optical depth.
 //         col != nullptr: also raytrace_to_edge_column_clump_overlap (:935-1001): col[0] += N_gas, col[1] += tau_dust of every interval (cross0 = col[2])
-// The holders of a point that took the in-clump fast path, carried to the next flight of the same packet (which starts where that one ended: a scattering does not
-// move the packet).  reach = what is left of the lower bound on the distance to anything that could change the list -- the faces of the CSR cell the list was read
-// from (which also fix the list's order), the sphere's surface, every clump surface -- after the flights taken since; all bounds hold for every direction.
-// While the next flight stays below it, the list the 27-cell scan would rebuild is this one, in this order: no cell read, no containment tests, no sort.
+// The holders of a point that took the in-clump fast path, carried to the later flights of the same packet.  reach = a lower bound on the distance from that point
+// to anything that could change the list -- the faces of the CSR cell the list was read from (which also fix the list's order), the sphere's surface, every clump
+// surface; all bounds hold for every direction, so the list is the one the 27-cell scan would rebuild, in this order, at every point of the BALL of that radius
+// around the point.  Round 4: a flight is taken on the list when its end point stays in the ball, |P - P0| + s < reach (rounds 2-3 subtracted the flights' lengths
+// from the reach -- the triangle inequality's bound on the same distance: a packet that scatters back and forth inside its clump used the reach up seven flights
+// after a rebuild, its displacement grows like the square root of their number): no cell read, no containment tests, no sort.
 #define LART_OVL_HOLD 8
 // (round 4: the eight clump numbers live in four 64-bit registers, two per word, picked by selects -- an int[8] indexed at run time is a scratch array, and this list is
 //  read on 88 % of the flights)
 struct OvlHold {
-    int na; double reach; unsigned long long w0, w1, w2, w3;
+    int na; double reach, x0, y0, z0; unsigned long long w0, w1, w2, w3;       // reach: radius of the ball around (x0, y0, z0), the point the list was built at, inside which it holds
+    __device__ __forceinline__ void clear() { na = 0; reach = 0.0; x0 = 0.0; y0 = 0.0; z0 = 0.0; w0 = 0; w1 = 0; w2 = 0; w3 = 0; }
     __device__ __forceinline__ int get(int m) const { const unsigned long long w = m < 2 ? w0 : (m < 4 ? w1 : (m < 6 ? w2 : w3)); return (int)((m & 1) ? (w >> 32) : (w & 0xffffffffull)); }
     __device__ __forceinline__ void set(int m, int id) {
         const unsigned long long v = (unsigned long long)(unsigned)id;
@@ -1301,6 +1305,37 @@ struct OvlHold {
 #else
 #define OVL_STAT(A, i, v) do { } while (0)
 #endif
+// a flight on the carried holder list: true when it ends inside what is left of the list's reach (t_end, owner set); otherwise the list is dropped
+__device__ inline bool ovl_carried(const KArgs &A, const Lds &l, bool dust, double xp, double yp, double zp, double kx, double ky, double kz, double xfreq_g, double lim, double u_own,
+                                   unsigned &nsteps, double &t_end, int &owner, OvlHold &oh) {
+    if (oh.na <= 0) return false;
+    // every holder's opacity once: the eight terms live in registers picked by selects (an array indexed at run time would be a scratch array), the owner draw below adds
+    // the same numbers in the same order as the sum
+    double k0 = 0.0, k1 = 0.0, k2 = 0.0, k3 = 0.0, k4 = 0.0, k5 = 0.0, k6 = 0.0, k7 = 0.0, kap = 0.0;
+    for (int m = 0; m < oh.na; m++) {
+        const ClumpPhys ph = cl_phys(A, l, oh.get(m)); const double kv = kappa_clump(A, l, dust, xfreq_g - ulos_clump(A, ph, kx, ky, kz), ph);
+        kap = kap + kv;
+        k0 = m == 0 ? kv : k0; k1 = m == 1 ? kv : k1; k2 = m == 2 ? kv : k2; k3 = m == 3 ? kv : k3; k4 = m == 4 ? kv : k4; k5 = m == 5 ? kv : k5; k6 = m == 6 ? kv : k6; k7 = m == 7 ? kv : k7;
+    }
+    if (kap > 0.0) {
+        const double s_ = lim / kap;
+        const double dx = xp - oh.x0, dy = yp - oh.y0, dz = zp - oh.z0, d2 = dx * dx + dy * dy + dz * dz;
+        const double room = (oh.reach * (1.0 - 1e-9) - 1e-12 * A.cl.cg_d) - s_;             // |P - P0| + s < reach, without the square root
+        if (room > 0.0 && d2 < room * room) {
+            nsteps++;
+            t_end = s_;
+            double cumul = 0.0;                                                               // sample_owner_clump :644-664
+            for (int m = 0; m < oh.na; m++) {
+                const double kv = m < 4 ? (m < 2 ? (m == 0 ? k0 : k1) : (m == 2 ? k2 : k3)) : (m < 6 ? (m == 4 ? k4 : k5) : (m == 6 ? k6 : k7));
+                cumul = cumul + kv; owner = oh.get(m); if (u_own * kap <= cumul) break;
+            }
+            OVL_STAT(A, 0, 1);                                                                // flights on the carried list
+            return true;
+        }
+    }
+    oh.na = 0;
+    return false;
+}
 struct OvlState {
     bool live, over, cells; int na, np, ci, cj, ck, si, sj, sk;
     double tx, ty, tz, delx, dely, delz, d, t_cur, acc, t_sp, u_own;
@@ -1313,23 +1348,7 @@ __device__ inline bool ovl_start(const KArgs &A, const Lds &l, bool dust, double
                                  double xfreq_g, double lim, double u_own, unsigned &nsteps, double &t_end, int &owner, OvlHold *oh, OvlState &S) {
     const DClumps &c = A.cl; const int cg = c.cgx;
     owner = 0; t_end = 0.0; S.live = false; S.over = false; S.acc = TO_TAU ? lim : 0.0; S.t_sp = 0.0; S.u_own = u_own;
-    if (TO_TAU && oh && oh->na > 0) {
-        double kap = 0.0;                                                                     // (no array of the terms: the owner draw below evaluates them again, the same numbers in the same order)
-        for (int m = 0; m < oh->na; m++) { const ClumpPhys ph = cl_phys(A, l, oh->get(m)); kap = kap + kappa_clump(A, l, dust, xfreq_g - ulos_clump(A, ph, kx, ky, kz), ph); }
-        if (kap > 0.0) {
-            const double s_ = lim / kap;
-            if (s_ < oh->reach * (1.0 - 1e-9) - 1e-12 * c.cg_d) {
-                nsteps++;
-                t_end = s_;
-                double cumul = 0.0;                                                           // sample_owner_clump :644-664
-                for (int m = 0; m < oh->na; m++) { const ClumpPhys ph = cl_phys(A, l, oh->get(m)); cumul = cumul + kappa_clump(A, l, dust, xfreq_g - ulos_clump(A, ph, kx, ky, kz), ph); owner = oh->get(m); if (u_own * kap <= cumul) break; }
-                oh->reach = oh->reach - s_;
-                OVL_STAT(A, 0, 1);                                                            // flights on the carried list
-                return true;
-            }
-        }
-        oh->na = 0;
-    }
+    if (TO_TAU && oh && ovl_carried(A, l, dust, xp, yp, zp, kx, ky, kz, xfreq_g, lim, u_own, nsteps, t_end, owner, *oh)) return true;
     const double t_sp = sphere_exit_dist(c, xp, yp, zp, kx, ky, kz);
     S.t_sp = t_sp;
     if (t_sp <= 0.0) return true;
@@ -1413,8 +1432,8 @@ __device__ inline bool ovl_start(const KArgs &A, const Lds &l, bool dust, double
                 double cumul = 0.0;                                                           // sample_owner_clump :644-664
                 for (int m = 0; m < na; m++) { cumul = cumul + kv[m]; owner = act[m]; if (u_own * kap <= cumul) break; }
                 if (oh && na <= LART_OVL_HOLD) {                                              // the same bounds without the direction: R - |r| instead of t_sp
-                    const double left = fmin(reach, c.sphere_R - sqrt(xp * xp + yp * yp + zp * zp)) - s_;
-                    if (left > 0.0) { oh->na = na; oh->reach = left; for (int m = 0; m < na; m++) oh->set(m, act[m]); OVL_STAT(A, 3, 1); }
+                    const double ball = fmin(reach, c.sphere_R - sqrt(xp * xp + yp * yp + zp * zp));
+                    if (ball - s_ > 0.0) { oh->na = na; oh->reach = ball; oh->x0 = xp; oh->y0 = yp; oh->z0 = zp; for (int m = 0; m < na; m++) oh->set(m, act[m]); OVL_STAT(A, 3, 1); }
                 }
                 OVL_STAT(A, 2, 1);                                                            // ... of which the fast path took the flight (3: and left a list behind)
                 return true;
@@ -1557,6 +1576,152 @@ __device__ inline void raytrace_to_tau_clump_ovl(const KArgs &A, const Lds &l, b
     ovl_apply(A, p, t_end, owner);
 }
 
+// ---------------------------------------------------------------------------------------------
+// VAR 9 = VAR 7 for a population of at most 64 clumps whose records are staged in LDS (the shipped overlap inputs have 30).  Round 4: counters of the
+// -DLART_PROFILE build put 45 % of the wave clocks of VAR 7 into the marches (3.6 % of the flights) and most of another 35 % into the holder-list rebuilds
+// (12 %): one or two lanes of a wave walking scratch-backed lists (sorted event queue, holder list, sort keys: 1.9 KB per lane, every access a memory
+// round trip) while the other lanes wait.  Here a flight that cannot stay on its carried list is executed by the WAVE, one flight at a time, ONE LANE PER
+// CLUMP: containment test, distance bound, sort key, opacity at the ray's frequency (one line profile per lane instead of one per holder in sequence) and
+// the ray's ENTER / EXIT times are computed side by side; the holder list lives in one VGPR (lane m = the m-th holder); the event queue is not stored at
+// all -- the next event is the wave minimum of the lanes' next times.  Same event sequence (ENTER before EXIT of one clump; two clumps at exactly equal
+// times: the lower number first, where the list walk had first seen, first out), same order of the holder list (first cell of the 27-cell scan that
+// registers the clump, then the clump number; append on ENTER, swap with the last on EXIT), the sums over it added in that order: the same numbers as
+// ovl_start / ovl_advance, with no list that could overflow and nothing in scratch.
+// ---------------------------------------------------------------------------------------------
+#define LART_OVL_COOP_CLUMPS 64
+__device__ __forceinline__ int rl_i32(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ double rl_f64(double v, int lane) { return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane)); }
+__device__ __forceinline__ long long rl_i64(long long v, int lane) {
+    return (long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)((unsigned long long)v >> 32), lane) << 32) | (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, lane));
+}
+template <int CTRL> __device__ __forceinline__ double dpp_f64(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    return __hiloint2double(__builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false), __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false));
+}
+// minimum over the 64 lanes, in every lane: two quad permutes and two row rotations (DPP) leave each row of 16 with its minimum, the four rows meet through v_readlane
+__device__ __forceinline__ double wave_min_f64(double v) {
+    v = fmin(v, dpp_f64<0xB1>(v));                            // quad_perm:[1,0,3,2]
+    v = fmin(v, dpp_f64<0x4E>(v));                            // quad_perm:[2,3,0,1]
+    v = fmin(v, dpp_f64<0x124>(v));                           // row_ror:4
+    v = fmin(v, dpp_f64<0x128>(v));                           // row_ror:8
+    return fmin(fmin(rl_f64(v, 0), rl_f64(v, 16)), fmin(rl_f64(v, 32), rl_f64(v, 48)));
+}
+// the flights of the lanes with `need`, one after the other, by the whole wave (every lane of the wave calls this, converged).  TO_TAU: res = t_end, owner as
+// ovl_start / ovl_advance / ovl_finish leave them (lim = the optical depth to go), *oh = the list carried to the next flight; else res = the optical depth to the
+// sphere's surface (raytrace_to_edge_clump_overlap_capped with lim = the cap).
+template <bool TO_TAU>
+__device__ inline void ovl_coop(const KArgs &A, const Lds &l, bool dust, bool need, const Photon &p, double lim, double u_own, unsigned &nsteps, double &res, int &owner, OvlHold *oh) {
+    const DClumps &c = A.cl; const int cg = c.cgx; const int N = (int)c.N;
+    const int j = (int)(threadIdx.x & 63u);                   // this lane's clump: number j + 1
+    const bool has = j < N;
+    const double INF = LART_HUGEST;
+    unsigned long long todo = __ballot(need);
+    while (todo) {
+        const int L = __ffsll((long long)todo) - 1; todo &= todo - 1;
+        const double xp = rl_f64(p.x, L), yp = rl_f64(p.y, L), zp = rl_f64(p.z, L), kx = rl_f64(p.kx, L), ky = rl_f64(p.ky, L), kz = rl_f64(p.kz, L);
+        const double xfreq_g = rl_f64(p.xfreq, L), limL = rl_f64(lim, L), u_ownL = rl_f64(u_own, L);
+        double out = 0.0; int own = 0; unsigned cnt = 0;      // the flight's result (the same in every lane)
+        int hna = 0; double hreach = 0.0; unsigned long long hw0 = 0, hw1 = 0, hw2 = 0, hw3 = 0;      // the list it leaves behind
+        const double t_sp = sphere_exit_dist(c, xp, yp, zp, kx, ky, kz);
+        if (t_sp > 0.0) {
+            if (TO_TAU) if (j == 0) OVL_STAT(A, 1, 1);             // holder lists rebuilt
+            const ClumpGeo g = has ? l.ct_geo[j] : ClumpGeo{0.0, 0.0, 0.0, -1.0};
+            const double rx = xp - g.x, ry = yp - g.y, rz = zp - g.z, rr = rx * rx + ry * ry + rz * rz;
+            const bool in = has && rr <= g.r2;                // active_set_at_point (clump_mod.f90:1594-1634): a holder is registered in the point's own cell, so "every clump" finds the same set
+            const unsigned long long hm = __ballot(in);
+            int na = __popcll(hm);
+            // the order of the list: first cell of the 27-cell scan that registers the clump, then the clump number (see ovl_start); rank = this holder's place
+            const int ci = cg_clamp(c, xp), cj = cg_clamp(c, yp), ck = cg_clamp(c, zp);
+            int rank = 0; double order_reach = INF;
+            if (na > 1) {
+                const double rc = sqrt(g.r2);
+                const int b0 = max(0, (int)((g.x - c.cg_min - rc) * c.cg_inv)), b1 = max(0, (int)((g.y - c.cg_min - rc) * c.cg_inv)), b2 = max(0, (int)((g.z - c.cg_min - rc) * c.cg_inv));
+                const int i0 = max(b0, ci - 1), j0 = max(b1, cj - 1), k0 = max(b2, ck - 1);
+                const long long key = ((((long long)k0 * cg + j0) * cg + i0) << 31) | (long long)(j + 1);
+                const int wxj = ci - 1 - b0, wyj = cj - 1 - b1, wzj = ck - 1 - b2;
+                int wx = 1 << 20, wy = 1 << 20, wz = 1 << 20;
+                for (unsigned long long m = hm; m; m &= m - 1) {
+                    const int h = __ffsll((long long)m) - 1;
+                    rank += (rl_i64(key, h) < key) ? 1 : 0;
+                    wx = min(wx, rl_i32(wxj, h)); wy = min(wy, rl_i32(wyj, h)); wz = min(wz, rl_i32(wzj, h));
+                }
+                const double x0 = c.cg_min + (double)ci * c.cg_d, y0 = c.cg_min + (double)cj * c.cg_d, z0 = c.cg_min + (double)ck * c.cg_d;
+                if (wx >= 0 && wy >= 0 && wz >= 0 && ci >= 1 && cj >= 1 && ck >= 1) order_reach = fmin(fmin((xp - x0) + (double)wx * c.cg_d, (yp - y0) + (double)wy * c.cg_d), (zp - z0) + (double)wz * c.cg_d);
+                else order_reach = fmin(fmin(fmin(xp - x0, x0 + c.cg_d - xp), fmin(yp - y0, y0 + c.cg_d - yp)), fmin(zp - z0, z0 + c.cg_d - zp));
+            }
+            int v_act = __builtin_amdgcn_ds_permute((in ? rank : 63) << 2, j + 1);       // lane m = the m-th holder (lanes >= na: unused)
+            // every clump's opacity at the ray's frequency: constant along the ray (sum_kap_active :621-636 evaluates it per interval)
+            double kapj = 0.0;
+            if (has) { const ClumpPhys ph = l.ct_phys[j]; kapj = kappa_clump(A, l, dust, xfreq_g - ulos_clump(A, ph, kx, ky, kz), ph); }
+            auto sum_act = [&]() { double s = 0.0; for (int m = 0; m < na; m++) s = s + rl_f64(kapj, rl_i32(v_act, m) - 1); return s; };
+            auto draw_owner = [&](double kap) { double cumul = 0.0; int o = 0;                // sample_owner_clump :644-664
+                for (int m = 0; m < na; m++) { o = rl_i32(v_act, m); cumul = cumul + rl_f64(kapj, o - 1); if (u_ownL * kap <= cumul) break; } return o; };
+            bool finished = false;
+            if (TO_TAU && na > 0) {                           // the in-clump fast path of ovl_start
+                const double kap = sum_act();
+                if (kap > 0.0) {
+                    const float num = (float)fabs(rr - g.r2) * 0.999998f, den = (sqrtf((float)rr) + sqrtf((float)g.r2)) * 1.000002f;
+                    const double d_srf = wave_min_f64(has ? (double)(num / den) : INF);
+                    const double s_ = limL / kap, reach = fmin(fmin(order_reach, t_sp), d_srf);
+                    if (s_ < reach * (1.0 - 1e-9)) {
+                        cnt++; out = s_; own = draw_owner(kap);
+                        if (oh && na <= LART_OVL_HOLD) {
+                            const double ball = fmin(reach, c.sphere_R - sqrt(xp * xp + yp * yp + zp * zp));
+                            if (ball - s_ > 0.0) {
+                                hna = na; hreach = ball;
+                                for (int m = 0; m < na; m++) { const unsigned long long v = (unsigned long long)(unsigned)rl_i32(v_act, m) << ((m & 1) * 32);
+                                    if (m < 2) hw0 |= v; else if (m < 4) hw1 |= v; else if (m < 6) hw2 |= v; else hw3 |= v; }
+                                if (j == 0) OVL_STAT(A, 3, 1);
+                            }
+                        }
+                        if (j == 0) OVL_STAT(A, 2, 1);
+                        finished = true;
+                    }
+                }
+            }
+            if (!finished) {                                  // the march: collect_ray_events_overlap (clump_mod.f90:1664-1693) + the interval walk (:713-743 / :884-897)
+                if (TO_TAU) { if (j == 0) { OVL_STAT(A, 4, 1); OVL_STAT(A, 7, na); } }
+                const double b = rx * kx + ry * ky + rz * kz;                                 // ray_sphere_isect :1362-1386
+                double disc = b * b - rr + g.r2;
+                bool hit = has && !(disc < 0.0);
+                disc = sqrt(fmax(disc, 0.0));
+                const double te = -b - disc, tx2 = -b + disc;
+                hit = hit && tx2 > 0.0 && !(te > t_sp);
+                double t_in = (hit && te > 0.0) ? te : INF, t_out = hit ? fmin(tx2, t_sp) : INF;     // ENTER only when the origin is outside
+                double t_cur = 0.0, acc = TO_TAU ? limL : 0.0;
+                for (;;) {
+                    const double cand = fmin(t_in, t_out), tmin = wave_min_f64(cand);
+                    const bool ev = tmin < INF;
+                    const double t_next = fmin(ev ? tmin : t_sp, t_sp), dt = t_next - t_cur;
+                    if (dt > 0.0) {
+                        const double kap = sum_act();
+                        cnt++;
+                        if (TO_TAU) { if (j == 0) OVL_STAT(A, 6, 1);
+                            if (kap > 0.0 && acc <= kap * dt) { out = t_cur + acc / kap; own = draw_owner(kap); break; }
+                            acc = acc - kap * dt;
+                        } else { acc = acc + kap * dt; if (acc >= limL) break; }
+                        t_cur = t_next;
+                    }
+                    if (!ev) break;                                                           // that was the last interval, up to the surface
+                    const int W = __ffsll((long long)__ballot(cand == tmin)) - 1;             // apply_event :769-786
+                    const bool enter = rl_i32((t_in <= t_out) ? 1 : 0, W) != 0;
+                    if (enter) { if (j == na) v_act = W + 1; na++; if (j == W) t_in = INF; }
+                    else {
+                        const unsigned long long at = __ballot(j < na && v_act == W + 1);
+                        if (at) { const int pos = __ffsll((long long)at) - 1, last = rl_i32(v_act, na - 1); if (j == pos) v_act = last; na--; }
+                        if (j == W) t_out = INF;
+                    }
+                }
+                if (TO_TAU) { if (own == 0) out = t_sp; } else out = acc;
+            }
+        }
+        if (j == L) {
+            res = out; owner = own; nsteps += cnt;
+            if (TO_TAU && oh) { oh->na = hna; oh->reach = hreach; oh->x0 = xp; oh->y0 = yp; oh->z0 = zp; oh->w0 = hw0; oh->w1 = hw1; oh->w2 = hw2; oh->w3 = hw3; }
+        }
+    }
+}
+
 // tau to the grid edge (dist < 0) or to a finite distance (raytrace_to_dist_car :89-195, VAR 0 only)
 template <int VAR>
 __device__ __forceinline__ void edge_begin(const KArgs &A, const Lds &l, bool dust, const Photon &p, double xfreq, double kx, double ky, double kz, double dist, EdgeMarch &m, unsigned &nsteps) {
@@ -1564,7 +1729,7 @@ __device__ __forceinline__ void edge_begin(const KArgs &A, const Lds &l, bool du
     m.live = true; m.tau = 0.0; m.d = 0.0; m.xfreq = xfreq; m.dist = dist; m.kx = kx; m.ky = ky; m.kz = kz;
     if (VAR == 3) { edge_begin_amr(A, p, m); return; }
     if (VAR == 4) { edge_begin_clump(A, l, dust, p, m, nsteps); return; }
-    if (VAR == 7) { double te_; int ow_; m.tau = ovl_march<false>(A, l, dust, p.x, p.y, p.z, kx, ky, kz, xfreq, LART_TAU_HUGE, 0.0, nsteps, te_, ow_); m.live = false; return; }   // one piece: the event lists do not survive between steps
+    if (is_ovl(VAR)) { double te_; int ow_; m.tau = ovl_march<false>(A, l, dust, p.x, p.y, p.z, kx, ky, kz, xfreq, LART_TAU_HUGE, 0.0, nsteps, te_, ow_); m.live = false; return; }   // one piece: the event lists do not survive between steps
     const DGrid &g = A.g;
     m.t.kx = kx; m.t.ky = ky; m.t.kz = kz; m.t.ic = p.ic; m.t.jc = p.jc; m.t.kc = p.kc;
     double xp = p.x, yp = p.y;
@@ -1706,7 +1871,7 @@ template <int VAR>
 __device__ __forceinline__ void raytrace_to_tau(const KArgs &A, const Lds &l, bool dust, Photon &p, double tau_in, unsigned &nsteps, double u_own = 0.0, OvlHold *oh = nullptr) {
     if (VAR == 3) { raytrace_to_tau_amr(A, l, dust, p, tau_in, nsteps); return; }
     if (VAR == 4) { raytrace_to_tau_clump(A, l, dust, p, tau_in, nsteps); return; }
-    if (VAR == 7) { raytrace_to_tau_clump_ovl(A, l, dust, p, tau_in, u_own, nsteps, oh); return; }
+    if (is_ovl(VAR)) { raytrace_to_tau_clump_ovl(A, l, dust, p, tau_in, u_own, nsteps, oh); return; }
     const DGrid &g = A.g;
 #ifndef LART_NO_FAST_FLIGHT
     // Fast path: the flight ends inside the cell it starts in (99.6 % of the flights at tau0 = 1e6: the line-centre depth of one cell is
@@ -2129,7 +2294,7 @@ struct PeelCell { double rhokap, rhokapD, voigt_a, Dfreq; };
 template <int VAR, bool STOKES>
 __device__ __forceinline__ bool peel_all_opaque(const KArgs &A, const Lds &l, int kind, const Photon &p, double xa, double ux, double uy, double uz, double grec, bool dust, const PeelCell *pc = nullptr) {
     if (kind == PEEL_DIRECT || A.heal_nside > 0 || VAR == 1) return false;
-    if (VAR == 7) return false;                              // the ray may cross any number of clumps from its first metre on
+    if (is_ovl(VAR)) return false;                           // the ray may cross any number of clumps from its first metre on
     if (VAR == 4 && p.icl <= 0) return false;
     if (VAR != 3 && VAR != 4 && (p.ic < 1 || p.ic > A.g.nx || p.jc < 1 || p.jc > A.g.ny || p.kc < 1 || p.kc > A.g.nz)) return false;
     // Round 4: the test no longer runs the head of the peel routine (peel_ray_begin: two square roots, seven divisions, the polynomial of the field-of-view
@@ -2435,7 +2600,7 @@ __device__ __forceinline__ bool scatter_pre(const KArgs &A, const Lds &l, Rng &g
         }
     }
     // resonance scattering: scatter_resonance_nostokes :660-827 / _stokes :331-486
-    if (VAR == 7) p.xfreq = p.xfreq - ulos_clump(A, cl_phys(A, l, p.icl), p.kx, p.ky, p.kz);   // scatter_resonance_clump_*: global -> owner frame (:898-937)
+    if (is_ovl(VAR)) p.xfreq = p.xfreq - ulos_clump(A, cl_phys(A, l, p.icl), p.kx, p.ky, p.kz);   // scatter_resonance_clump_*: global -> owner frame (:898-937)
     p.nsg = p.nsg + p.wgt;
     if (A.jpa.calc_P && c.rhokap > 0.0) {                      // add_to_Pa: scattering_car.f90:830-859
         int ib = (VAR == 3) ? amr_JPa_bin(A.amr, p.ic, p.x, p.y, p.z) : A.jpa.ind_bin[cidx(A.g, p.ic, p.jc, p.kc)];   // add_to_Pa_amr: scattering_amr.f90:917-942
@@ -2580,7 +2745,7 @@ __device__ __forceinline__ void scatter_post(const KArgs &A, const Lds &l, Rng &
             p.xfreq = (p.xfreq - xfreq_atom + u1_fluid) * (cc.Dfreq / par.Dfreq_ref);
         }
     }
-    if (VAR == 7) p.xfreq = p.xfreq + ulos_clump(A, cl_phys(A, l, p.icl), p.kx, p.ky, p.kz);   // ... and back to the global frame along the new direction
+    if (is_ovl(VAR)) p.xfreq = p.xfreq + ulos_clump(A, cl_phys(A, l, p.icl), p.kx, p.ky, p.kz);   // ... and back to the global frame along the new direction
 }
 // par%save_all_photons (run_simulation_mod.f90:249-358): the record of photon k.  The impact parameter |r - (r.k)k| does not change along
 // the ray, so the reference's move to the sphere's surface (:302-324) drops out.

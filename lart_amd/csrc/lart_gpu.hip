@@ -22,6 +22,7 @@ extern "C" void lart_launch_transport_var5(int, int, int, dim3, dim3, size_t, hi
 extern "C" void lart_launch_transport_var6(int, int, int, dim3, dim3, size_t, hipStream_t, const KArgs &);
 extern "C" void lart_launch_transport_var7(int, int, int, dim3, dim3, size_t, hipStream_t, const KArgs &);
 extern "C" void lart_launch_transport_var8(int, int, int, dim3, dim3, size_t, hipStream_t, const KArgs &);
+extern "C" void lart_launch_transport_var9(int, int, int, dim3, dim3, size_t, hipStream_t, const KArgs &);
 extern "C" int lart_launch_transport_lt89(int var, int dust, int peel, dim3, dim3, size_t, hipStream_t, const KArgs &);
 extern "C" void lart_launch_peel(int var, int stokes, dim3, dim3, dim3, size_t, hipStream_t, const KArgs &);
 
@@ -515,13 +516,20 @@ static void size_j_window(lart_gpu *c) {
     c->jpa.lds_j_w = (int)w; c->jpa.lds_j_lo = lo;
 }
 
+// overlapping clumps, at most 64 of them (with their records staged in LDS): the transport kernel whose marches are executed by the wave, one lane per clump (variant 9, ovl_coop).
+// LART_OVL_NO_COOP=1 keeps the per-lane lists of variant 7 -- the same histories, for the tests that say so
+static bool ovl_coop9(const lart_gpu *c) {
+    return c->is_clump && c->clump_overlap && c->cl.cg_mask && c->cl.N <= LART_OVL_COOP_CLUMPS && !std::getenv("LART_OVL_NO_COOP");
+}
+
 static int ensure_pool(lart_gpu *c) {
     if (!c->block_user) {
         c->block = 256;
         if (c->jpa.nbins > 0 && c->jpa.calc_J && (c->jpa.calc_P || c->jpa.calc_Pnew) && !c->par.use_stokes) { c->block = 1024; size_j_window(c); if (c->jpa.lds_j_w < 8) c->block = 256; }
         // overlapping clumps, a population small enough for its records to live in LDS (lds_stage_clumps: 96 B per clump): four 256-lane workgroups per CU have no room
         // for four copies, one 1024-lane workgroup has
-        if (c->is_clump && c->clump_overlap && c->cl.cg_mask && c->cl.N <= LART_OVL_LDS_CLUMPS && !c->par.use_stokes) c->block = 1024;
+        // (the wave-cooperative kernel of the smallest populations runs 3 waves per SIMD: three 256-lane workgroups, which do have the room)
+        if (c->is_clump && c->clump_overlap && c->cl.cg_mask && c->cl.N <= LART_OVL_LDS_CLUMPS && !c->par.use_stokes && !ovl_coop9(c)) c->block = 1024;
     }
     int64_t n = c->want_lanes;
     if (n <= 0) {
@@ -759,6 +767,8 @@ extern "C" int lart_gpu_step(lart_gpu *c, int32_t nsteps, int32_t max_events) {
     if (c->par.line_type == 8 || h2) shmem = ((shmem + 15) & ~(size_t)15) + 8 * sizeof(double);      // ... + the block's accumulators of the ly_beta / H2 weight budget
     if (var == 7 && c->cl.cg_mask && c->cl.N <= LART_OVL_LDS_CLUMPS) shmem = ((shmem + 15) & ~(size_t)15) + (size_t)c->cl.N * (sizeof(ClumpGeo) + sizeof(ClumpPhys));      // ... + the clump records (lds_stage_clumps)
     if (shmem > 160 * 1024) return fail("step: grid faces do not fit the 160 KiB LDS");
+    const bool coop9 = var == 7 && ovl_coop9(c);
+    if (coop9 && c->block > 256) return fail("step: the wave-cooperative overlap kernel runs 3 waves per SIMD: workgroups of at most 256 lanes (lart_gpu_set_pool)");
     // peel-off: a launch of `slice` events per lane queues at most live_lanes x (slice + 1) records (one per event, one per birth);
     // the queue is sized once per run for pq_bytes_max (16 GiB by default) and a step of max_events is cut into slices that fit
     int slice = max_events;
@@ -787,6 +797,7 @@ extern "C" int lart_gpu_step(lart_gpu *c, int32_t nsteps, int32_t max_events) {
             else if (var == 4) lart_launch_transport_var4(stokes, dust, peel, grid, block, shmem, c->stream, A);
             else if (var == 5) lart_launch_transport_var5(stokes, dust, peel, grid, block, shmem, c->stream, A);
             else if (var == 6) lart_launch_transport_var6(stokes, dust, peel, grid, block, shmem, c->stream, A);
+            else if (var == 7 && coop9) lart_launch_transport_var9(stokes, dust, peel, grid, block, shmem, c->stream, A);
             else if (var == 7) lart_launch_transport_var7(stokes, dust, peel, grid, block, shmem, c->stream, A);
             else lart_launch_transport_var8(stokes, dust, peel, grid, block, shmem, c->stream, A);
             HIPCHK(hipGetLastError());
@@ -1172,7 +1183,7 @@ __device__ void test_event_one(const KArgs &A, const Lds &l, double *st, unsigne
     if (is_clump(VAR)) { p.ic = 1; p.jc = 1; p.kc = 1; }
     Rng g; g.init(seed, id, (unsigned long long)st[19]);
     bool first = first_in != 0; unsigned ns = 0, np = 0;
-    OvlHold oh; oh.na = 0; oh.reach = 0.0; oh.w0 = 0; oh.w1 = 0; oh.w2 = 0; oh.w3 = 0; OvlState os; os.live = false;
+    OvlHold oh; oh.clear(); OvlState os; os.live = false;
     fly<VAR, DUST>(A, l, g, p, first, ns, VAR == 7 ? &oh : nullptr, VAR == 7 ? &os : nullptr);
     if (VAR == 7) while (os.live) {                            // the march of a flight that left its clump, to its end (the kernel advances it a few cells per round)
         double t_end = 0.0; int owner = 0;

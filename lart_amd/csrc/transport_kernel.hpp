@@ -28,12 +28,13 @@ __device__ inline double wave_sum(double v) {
 // back the lanes which skipped the branch -- those lanes later read a stale register / scratch slot (C1: garbage event counters; the round-3 memory fault of
 // the slab kernel with dust was the same pattern hitting an index).  Every Stokes kernel is back at 3 waves (168 VGPRs, no live-range splits of that kind), and
 // tools/isa_lint.py -- run by tests/test_isa_lint.py on the BASELINE instantiations -- fails the build check if the pattern ever shows up again.
-#define LART_WAVES_V4(V, S, D, P) ((S) ? 3 : 4)
+// (VAR 9, the wave-cooperative overlap kernel: 3 waves as well -- at 128 VGPRs it spills 60-75 registers and the lint above has a hit in it)
+#define LART_WAVES_V4(V, S, D, P) (((S) || (V) == 9) ? 3 : 4)
 #endif
 // largest workgroup: the kernels that fit 128 VGPRs may run as ONE 1024-lane workgroup per CU (the same 4 waves per SIMD), which leaves the LDS that four
 // 256-lane workgroups spend on four copies of the tables to the J(x) window of the profile tallies (lart_gpu.hip, tally layout)
 #define LART_MAX_BLOCK(S, P) (LART_WAVES(S, P) >= 4 ? 1024 : 256)
-#define LART_MAX_BLOCK_V(S) (!(S) ? 1024 : 256)
+#define LART_MAX_BLOCK_V(V, S) ((!(S) && (V) != 9) ? 1024 : 256)
 #ifndef LART_OVL_CELLS_PER_ROUND
 #define LART_OVL_CELLS_PER_ROUND 4           // CSR cells a lane in an overlap march walks per round of its wave
 #endif
@@ -75,9 +76,39 @@ __device__ inline void fly(const KArgs &A, const Lds &l, Rng &g, Photon &p, bool
     LART_PROF_MARK(p, 3);
 }
 
+// the same for VAR 9 (overlapping clumps, at most 64 of them), called by the whole wave: the flights that need the clump table -- the optical depth to the surface of a
+// first flight, a flight that does not end on its carried holder list -- are executed by the wave together (ovl_coop), the rest is each lane's own
+template <bool DUST>
+__device__ inline void fly_coop(const KArgs &A, const Lds &l, Rng &g, Photon &p, bool act, bool &first, unsigned &nsteps, OvlHold &oh) {
+    const lart_params &par = A.par;
+    double tau0 = 0.0; int none = 0;
+    const bool born = act && first;
+    if (__ballot(born)) ovl_coop<false>(A, l, DUST, born, p, LART_TAU_HUGE, 0.0, nsteps, tau0, none, nullptr);        // = raytrace_to_edge (edge_begin) of the first flight
+    double tau = 0.0, u_own = 0.0, t_end = 0.0; int owner = 0; bool need = false;
+    if (act) {
+        if (first) {
+            const double esc = d_exp_neg(-tau0);
+            const Cell &c = A.g.cell[cidx(A.g, p.ic, p.jc, p.kc)];
+            const double u1 = c.vfx * p.kx + c.vfy * p.ky + c.vfz * p.kz;
+            Photon e = p; e.wgt = p.wgt * esc; e.xfreq_ref = (p.xfreq + u1) * (c.Dfreq / par.Dfreq_ref);
+            if (e.wgt != 0.0) tally_escape(par, A.t, e);
+            const double wgt1 = 1.0 - esc;
+            p.wgt = p.wgt * wgt1;
+            tau = (tau0 > 0.0) ? -d_log(1.0 - g.next() * wgt1) : LART_HUGEST;
+            first = false;
+        } else tau = -d_log(g.next());
+        u_own = g.next();                                      // the draw of sample_owner_clump (raytrace_clump.f90:648)
+        need = !ovl_carried(A, l, DUST, p.x, p.y, p.z, p.kx, p.ky, p.kz, p.xfreq, tau, u_own, nsteps, t_end, owner, oh);
+    }
+    LART_PROF_MARK(p, 2);
+    if (__ballot(need)) ovl_coop<true>(A, l, DUST, need, p, tau, u_own, nsteps, t_end, owner, &oh);
+    if (act) ovl_apply(A, p, t_end, owner);
+    LART_PROF_MARK(p, 3);
+}
+
 // LT: line%line_type as a compile-time constant (1 single line, 2 Ly-alpha doublet, 7 hydrogen + deuterium), handed to the device functions through Lds
 template <int VAR, bool STOKES, bool DUST, bool PEEL, int LT>
-__global__ __launch_bounds__(LART_MAX_BLOCK_V(STOKES), LART_WAVES_V4(VAR, STOKES, DUST, PEEL)) void transport_kernel(KArgs A) {
+__global__ __launch_bounds__(LART_MAX_BLOCK_V(VAR, STOKES), LART_WAVES_V4(VAR, STOKES, DUST, PEEL)) void transport_kernel(KArgs A) {
     extern __shared__ double sh[];
     if (A.rep.nrep > 1) {                                      // this block's copy of the contended tally sections (DRep)
         const unsigned r = blockIdx.x % (unsigned)A.rep.nrep;
@@ -118,7 +149,7 @@ __global__ __launch_bounds__(LART_MAX_BLOCK_V(STOKES), LART_WAVES_V4(VAR, STOKES
         __syncthreads();
         l_.aux = ax;
     }
-    if (VAR == 7) {                                            // the clump records of a small population, behind everything else (the offset lart_gpu_step sizes the launch for)
+    if (is_ovl(VAR)) {                                         // the clump records of a small population, behind everything else (the offset lart_gpu_step sizes the launch for)
         const size_t off = (((size_t)(VT_END + (A.g.nx + A.g.ny + A.g.nz + 3) + (size_t)LART_RNG_BUF * blockDim.x + 2 * (size_t)A.jpa.lds_bins + (size_t)nJ) * sizeof(double)
                              + (size_t)(LART_COOP_BYTES + 4) * (blockDim.x >> 6)) + 15) & ~(size_t)15;
         lds_stage_clumps(l_, A.cl, (unsigned char *)sh + off);
@@ -131,7 +162,7 @@ __global__ __launch_bounds__(LART_MAX_BLOCK_V(STOKES), LART_WAVES_V4(VAR, STOKES
     double *F = A.pool.f;
 
     Photon p; Rng g; g.attach(rng_lds, blockDim.x);
-    OvlHold oh; oh.na = 0; oh.reach = 0.0; oh.w0 = 0; oh.w1 = 0; oh.w2 = 0; oh.w3 = 0;                                        // VAR 7: holders carried from one flight to the next (not kept between launches)
+    OvlHold oh; oh.clear();                                        // VAR 7: holders carried from one flight to the next (not kept between launches)
     OvlState os; os.live = false;                                                 // VAR 7: the march of a flight that left its clump, between two rounds of the wave
     g.k0 = (uint32_t)A.seed; g.k1 = (uint32_t)(A.seed >> 32);                  // (a lane that never holds a packet still lends its ALU to Rng::prefill_sparse: the key is the run's)
 #ifdef LART_PROFILE
@@ -194,7 +225,8 @@ __global__ __launch_bounds__(LART_MAX_BLOCK_V(STOKES), LART_WAVES_V4(VAR, STOKES
         if (act) g.template prefill<LART_FILL_TOP(STOKES)>();
 #endif
         LART_PROF_TRIP(p, 2);
-        if (act && !(VAR == 7 && os.live)) fly<VAR, DUST>(A, l, g, p, first, nsteps, VAR == 7 ? &oh : nullptr, VAR == 7 ? &os : nullptr);
+        if (VAR == 9) fly_coop<DUST>(A, l, g, p, act, first, nsteps, oh);
+        else if (act && !(VAR == 7 && os.live)) fly<VAR, DUST>(A, l, g, p, first, nsteps, VAR == 7 ? &oh : nullptr, VAR == 7 ? &os : nullptr);
         if (VAR == 7 && act && os.live) {                  // a flight that left its clump: a few cells of the march per round, the other lanes of the wave go on scattering
             double t_end = 0.0; int owner = 0;
             if (ovl_advance<true>(A, l, DUST, p.x, p.y, p.z, p.kx, p.ky, p.kz, p.xfreq, 0.0, nsteps, t_end, owner, nullptr, os, LART_OVL_CELLS_PER_ROUND)) {

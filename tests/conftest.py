@@ -25,6 +25,48 @@ def pytest_collection_modifyitems(config, items):
             it.add_marker(skip)
 
 
+class Background:
+    """a job started when the collection ends and joined by the fixture that needs it: the full-size BASELINE configurations of test_gpu_bigtau.py last as long as their
+    longest photon history on a lone wave (~2 min of a mostly idle GPU), so they run on contexts and host threads of their own WHILE the other device tests
+    run (the library keeps no state outside its contexts; its error strings are thread-local) and those tests come last in the order"""
+    def __init__(self, fn):
+        import threading
+        self.result, self.error = None, None
+
+        def work():
+            try:
+                self.result = fn()
+            except BaseException as e:                       # noqa: BLE001 -- re-raised in join()
+                self.error = e
+        self.thread = threading.Thread(target=work, daemon=True); self.thread.start()
+
+    def join(self):
+        self.thread.join()
+        if self.error is not None:
+            raise self.error
+        return self.result
+
+
+BACKGROUND = {}
+import threading
+STOP = threading.Event()                                     # set when the session ends: a background job still running (a test failed under -x) leaves its loop before the process exits
+
+
+def pytest_sessionfinish(session, exitstatus):
+    STOP.set()
+    for job in BACKGROUND.values():
+        job.thread.join(timeout=120)
+
+
+def pytest_collection_finish(session):
+    items = [it for it in session.items if "test_gpu_bigtau.py" in it.nodeid and not any(m.name == "skip" for m in it.iter_markers())]
+    if not items or session.config.option.collectonly:
+        return
+    session.items[:] = [it for it in session.items if "test_gpu_bigtau.py" not in it.nodeid] + [it for it in session.items if "test_gpu_bigtau.py" in it.nodeid]
+    import test_gpu_bigtau
+    BACKGROUND["bigtau"] = Background(test_gpu_bigtau.run_all)
+
+
 @pytest.fixture(scope="session")
 def oracle_mod():
     from oracle import oracle as O
@@ -73,7 +115,7 @@ def run_together(jobs, events=4096):
             sim.ctx.begin(int(n), first_id=1, stride=1, seed=int(seed)); sim.nphotons_run = int(n)
             while True:
                 sim.ctx.step(1, events)
-                if sim.ctx.sync()[1] == 0:
+                if sim.ctx.sync()[1] == 0 or STOP.is_set():
                     break
         except Exception as e:                               # noqa: BLE001 -- re-raised in the caller's thread
             errors.append(e)

@@ -297,7 +297,7 @@ def test_overlapping_clumps_end_to_end_matches_python_host(exe, tmp_path):
     H = read_h5(str(tmp_path / "ovl.h5"))
     from lart_amd import host
     sim = host.Simulation(str(tmp_path / "ovl.in")); sim.run_simulation(); t = sim.output_normalize()
-    assert np.allclose(H["Spectrum"][1]["Jout"], t["Jout"], rtol=1e-9, atol=1e-15)
+    np.testing.assert_allclose(H["Spectrum"][1]["Jout"], t["Jout"], rtol=1e-9, atol=1e-15)
     O = read_h5(str(tmp_path / "ovl_obs.h5"))
     assert np.allclose(O["Scattered"][1], t["scatt"][..., 0], rtol=1e-6, atol=1e-12 * t["scatt"].max())
 
@@ -436,7 +436,7 @@ def test_amr_end_to_end_matches_python_host(exe, tmp_path):
     sim = host.Simulation(par)
     sim.run_simulation()
     t = sim.output_normalize()
-    assert np.allclose(hdus["Spectrum"][1]["Jout"], t["Jout"], rtol=1e-9, atol=1e-15)
+    np.testing.assert_allclose(hdus["Spectrum"][1]["Jout"], t["Jout"], rtol=1e-9, atol=1e-15)
     assert np.allclose(hdus["Jx_1D"][1], t["J1"], rtol=1e-8, atol=1e-12 * t["J1"].max())
     assert np.allclose(hdus["Pa_1D"][1].ravel(), t["P1"], rtol=1e-8) and np.allclose(hdus["Pa_1D_new"][1].ravel(), t["P1_new"], rtol=1e-8)
 
@@ -466,7 +466,7 @@ def test_periodic_octree_end_to_end_matches_python_host(exe, tmp_path):
     H = read_h5(str(tmp_path / "pamr.h5"))
     par = host.read_namelist(str(tmp_path / "pamr.in")); par.amr_file = str(tmp_path / "slab.dat")
     sim = host.Simulation(par); sim.run_simulation(); t = sim.output_normalize()
-    assert np.allclose(H["Spectrum"][1]["Jout"], t["Jout"], rtol=1e-9, atol=1e-15)
+    np.testing.assert_allclose(H["Spectrum"][1]["Jout"], t["Jout"], rtol=1e-9, atol=1e-15)
     assert np.allclose(H["Pa_1D"][1].ravel(), t["P1"], rtol=1e-8) and np.allclose(H["Jx_1D"][1], t["J1"], rtol=1e-8, atol=1e-12 * t["J1"].max())
     assert np.isclose(H["Spectrum"][1]["Jout"].sum() * (24.0 / 61) * 2.0 * np.pi * 2.0, 1.0, rtol=1e-9)     # every packet leaves through z: two faces, no area
 
@@ -575,7 +575,7 @@ def test_cartesian_profiles_end_to_end_match_python_host(exe, tmp_path, geo, sym
     sim.run_simulation()
     t = sim.output_normalize()
     assert t["J1"].max() > 0 and t["P1"].max() > 0
-    assert np.allclose(H["Spectrum"][1]["Jout"], t["Jout"], rtol=1e-9, atol=1e-15)
+    np.testing.assert_allclose(H["Spectrum"][1]["Jout"], t["Jout"], rtol=1e-9, atol=1e-15)
     assert np.allclose(H["Jx_1D"][1], t["J1"], rtol=1e-8, atol=1e-12 * t["J1"].max())
     assert np.allclose(H["Pa_1D"][1].ravel(), t["P1"], rtol=1e-8) and np.allclose(H["Pa_1D_new"][1].ravel(), t["P1_new"], rtol=1e-8)
 
@@ -685,7 +685,7 @@ def test_velocity_fields_end_to_end_match_python_host(exe, tmp_path, vel):
     sim.run_simulation()
     t = sim.output_normalize()
     H = read_h5(str(tmp_path / "rot.h5"))
-    assert np.allclose(H["Spectrum"][1]["Jout"], t["Jout"], rtol=1e-9, atol=1e-15)
+    np.testing.assert_allclose(H["Spectrum"][1]["Jout"], t["Jout"], rtol=1e-9, atol=1e-15)
     if "save_all_photons" in vel:                              # <base>_allph (write_output_allph): one row per photon, the columns of a non-Stokes point source
         P = read_h5(str(tmp_path / "rot_allph.h5"))["AllPhotons"][1]; a = sim.ctx.all_photons(20000)
         assert list(P) == ["r", "xfreq1", "xfreq2", "NSCATT_gas", "NSCATT_dust"] and all(np.array_equal(P[k], a[k]) for k in P)

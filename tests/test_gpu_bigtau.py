@@ -55,20 +55,24 @@ SEED = {"c1": 20261005, "c2": 20261004, "c3": 20261006, "c4": 20261007, "c5": 20
 FIXTURE = {"c1": "c1_slab_tau4.npz", "c2": "c2_tau6.npz", "c3": "c3_peel_tau6.npz", "c4": "c4_clump_dust.npz", "c5": "c5_amr_JP.npz"}
 
 
-@pytest.fixture(scope="module")
-def runs(capi, golden, tmp_path_factory):
-    """the five BASELINE configurations, run together; {name: (fixture, simulation, tallies, per-photon scattering counts)}"""
+def run_all():
+    """the five BASELINE configurations, run together; {name: (fixture, simulation, tallies, per-photon scattering counts)}.  Called by conftest.Background when the
+    collection ends (host threads and contexts of its own, next to the other device tests), or by the fixture below when this file is imported some other way"""
     import sys
-    from conftest import run_together
-    from lart_amd import host
+    import tempfile
+    import __graft_entry__ as g
+    g.build()
+    from conftest import run_together, GOLDEN
+    from lart_amd import host, capi
+    assert capi.lib().lart_gpu_device_count() > 0, "no GPU visible: the HIP path cannot run (there is no fallback)"
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from gen_golden_bigtau import materialize
-    tmp = str(tmp_path_factory.mktemp("bigtau"))
+    tmp = tempfile.mkdtemp(prefix="bigtau")
     sims, fxs = {}, {}
     for name, f in FIXTURE.items():
-        if not os.path.exists(os.path.join(ROOT, "tests", "golden", f)):
+        if not os.path.exists(os.path.join(GOLDEN, f)):
             continue
-        fxs[name] = golden(f)
+        fxs[name] = np.load(os.path.join(GOLDEN, f), allow_pickle=False)
         kw = materialize(params_of(fxs[name]), tmp)            # iseed of c4 = the clump-placement stream of the fixture; the photon stream is SEED[name]
         sims[name] = host.Simulation(dict(kw, iseed=kw.get("iseed", SEED[name])))
         sims[name].ctx.enable_photon_log(True)
@@ -77,6 +81,13 @@ def runs(capi, golden, tmp_path_factory):
     for k, sim in sims.items():
         out[k] = (fxs[k], sim, sim.ctx.tallies(), sim.ctx.photon_log(N_DEVICE[k])[0])
     return out
+
+
+@pytest.fixture(scope="module")
+def runs(capi):
+    import conftest
+    job = conftest.BACKGROUND.get("bigtau")
+    return job.join() if job is not None else run_all()
 
 
 def test_c2_sphere_tau6_spectrum_within_one_percent(runs):

@@ -1167,6 +1167,28 @@ def test_bicone_histories(capi, oracle_mod, kw):
     assert rms_diff(t["Jout"], o.array("Jout")) < 0.01 and abs(t["Jout"].sum() - o.array("Jout").sum()) < 1e-6 * n and t["Jout"].sum() > 0.99 * n
 
 
+@pytest.mark.parametrize("extra", [dict(clump_sigma_v=100.0), dict(clump_sigma_v=30.0, DGR=1.0, cext_dust=3e-18, use_stokes=True)])
+def test_overlap_flights_by_the_wave_equal_the_per_lane_lists(capi, oracle_mod, monkeypatch, extra):
+    """populations of at most 64 clumps run the transport kernel whose overlap flights are executed by the wave, one lane per clump (variant 9, ovl_coop: no event
+    queue, holder list in a register, nothing in scratch); LART_OVL_NO_COOP=1 keeps the per-lane lists of variant 7.  Same event sequence, same order of the sums.
+    The two compile the same expressions in different surroundings (fused multiply-adds fall differently), so a history can differ where a comparison sits at rounding
+    distance: each is held against the oracle like the other overlap tests, the two against each other, and the tallies have to agree within the noise of the flips"""
+    kw = dict(OVERLAP, **extra); n = 40000
+    a = make(kw); a.ctx.enable_photon_log(True); a.run_simulation(n); ta = a.ctx.tallies()
+    assert a.ctx.pool_info()[1] == 256
+    monkeypatch.setenv("LART_OVL_NO_COOP", "1")
+    b = make(kw); b.ctx.enable_photon_log(True); b.run_simulation(n); tb = b.ctx.tallies()
+    o = oracle_mod.Oracle(**kw); o.run(n, seed=kw["iseed"])
+    na, xa = a.ctx.photon_log(n); nb, xb = b.ctx.photon_log(n); no, xo = o.photon_log()
+    eq = lambda n1, x1, n2, x2: float((np.isclose(n1, n2, rtol=1e-12, atol=0) & (np.isclose(x1, x2, rtol=1e-7, atol=1e-9) | ((x1 == 0) & (x2 == 0)))).mean())
+    ab, ao, bo = eq(na, xa, nb, xb), eq(na, xa, no, xo), eq(nb, xb, no, xo)
+    print("identical histories: wave / lists %.5f, wave / oracle %.5f, lists / oracle %.5f" % (ab, ao, bo))
+    assert ao > 0.99 and bo > 0.99 and ab > 0.99 and ao > bo - 0.003
+    assert ta["nphotons_done"] == tb["nphotons_done"] == n
+    assert abs(ta["n_cellsteps"] / tb["n_cellsteps"] - 1.0) < 5e-3 and abs(ta["nscatt_gas"] / tb["nscatt_gas"] - 1.0) < 5e-3
+    assert rms_diff(ta["Jout"], tb["Jout"]) < 5e-3
+
+
 def test_overlap_list_overflow_is_refused(capi):
     """more clumps around one point than the march lists hold: lart_gpu_get_tallies fails instead of handing out a result that is not the reference's"""
     kw = dict(OVERLAP, clump_radius=0.9, clump_N_clumps=80, clump_f_cov=-1.0, clump_fully_inside=False, clump_tau0=1.0)

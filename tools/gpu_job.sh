@@ -6,6 +6,7 @@
 #   smoke                      __graft_entry__.smoke()
 #   avail                      rocprofv3 --list-avail (counter names of this GPU) -> gpurun_out/avail.log
 #   tests[:EXPR]               pytest -m gpu (optionally -k EXPR)
+#   pytest:FILES               pytest -m gpu on the given files (commas for spaces)
 #   bench[:ARGS]               python bench.py ARGS            (ARGS with commas for spaces: bench:--steps,2,--no-cpu-baseline)
 #   configs                    tools/perf_configs.py (events/s of the other BASELINE configs)
 #   perf:C1,C2[:ARGS]          tools/perf_kernel.py --config C (steady-state launches of one kernel variant + its section-8(d) roofline)
@@ -48,6 +49,7 @@ for spec in "$@"; do
     smoke)   step smoke 400 python __graft_entry__.py smoke ;;
     avail)   step avail 120 rocprofv3 --list-avail ;;
     tests)   if [ -n "$a1" ]; then step tests 1100 python -m pytest tests -m gpu -q --timeout=900 --durations=40 -k "$a1"; else step tests 1100 python -m pytest tests -m gpu -q --timeout=900 --durations=40; fi ;;
+    pytest)  step pytest_$(echo "$a1" | tr -c 'A-Za-z0-9\n' '_' | cut -c1-40) 1100 python -m pytest ${a1//,/ } -m gpu -q --timeout=900 --durations=15 ;;
     bench)   step bench 900 python bench.py ${a1//,/ } ;;
     configs) step configs 900 python tools/perf_configs.py ;;
     perf)    for c in ${a1//,/ }; do step perf_$c 400 python tools/perf_kernel.py --config $c ${a2//,/ }; done ;;
