@@ -27,6 +27,14 @@ extern "C" int lart_launch_transport_lt89(int var, int dust, int peel, dim3, dim
 extern "C" void lart_launch_peel(int var, int stokes, dim3, dim3, dim3, size_t, hipStream_t, const KArgs &);
 
 static thread_local std::string g_err;
+// Every fill and copy goes through the context's OWN stream.  The streams are created non-blocking, so the null stream is not ordered with them: a hipMemset on it is a
+// fill KERNEL that may run long after the host call has returned -- with other contexts keeping the GPU busy, after the first transport kernel of the run, zeroing
+// tallies in mid-run (round 4: three "equals the other host" tests failed next to the full-size runs of the device suite; tools/dbg/bg_race.py).  A fill is stream-ordered
+// in front of the kernels that use the memory; a copy is followed by a synchronisation of that stream (the host buffers are pageable and often temporaries).
+static hipError_t lart_put(hipStream_t st, void *dst, const void *src, size_t bytes) {
+    const hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st); return e != hipSuccess ? e : hipStreamSynchronize(st); }
+static hipError_t lart_get(hipStream_t st, void *dst, const void *src, size_t bytes) {
+    const hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st); return e != hipSuccess ? e : hipStreamSynchronize(st); }
 static int fail(const std::string &m) { g_err = m; return 1; }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
 
@@ -113,10 +121,10 @@ extern "C" int lart_gpu_create(lart_gpu **out, const lart_params *par, int devic
     c->device = device; c->par = *par;
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIPCHK(hipMalloc(&c->d_ctl, sizeof(DCtl)));
-    HIPCHK(hipMemset(c->d_ctl, 0, sizeof(DCtl)));
+    HIPCHK(hipMemsetAsync(c->d_ctl, 0, sizeof(DCtl), c->stream));
     if (par->h2_nlines > 0) {
         double h[16] = {0}; for (int i = 0; i < par->h2_nlines; i++) { h[i] = par->h2_dnu_Hz[i]; h[4 + i] = par->h2_strength[i]; h[8 + i] = par->h2_a_damp[i]; h[12 + i] = par->h2_p_scat[i]; }
-        HIPCHK(hipMalloc(&c->d_h2tab, sizeof h)); HIPCHK(hipMemcpy(c->d_h2tab, h, sizeof h, hipMemcpyHostToDevice));
+        HIPCHK(hipMalloc(&c->d_h2tab, sizeof h)); HIPCHK(lart_put(c->stream, c->d_h2tab, h, sizeof h));
     }
     *out = c;
     return 0;
@@ -183,11 +191,11 @@ static int build_tally(lart_gpu *c) {
     }
     c->ntally = off;
     HIPCHK(hipMalloc(&c->d_tally, off * sizeof(double)));
-    HIPCHK(hipMemset(c->d_tally, 0, off * sizeof(double)));
+    HIPCHK(hipMemsetAsync(c->d_tally, 0, off * sizeof(double), c->stream));
     const int64_t len_rep = off - off_rep;
     if (len_rep > 0 && len_rep * 7 * 8 <= (int64_t)24 << 30) {       // 7 more copies, one per XCD, while they stay under 24 GiB
         HIPCHK(hipMalloc(&c->rep.base, (size_t)len_rep * 7 * sizeof(double)));
-        HIPCHK(hipMemset(c->rep.base, 0, (size_t)len_rep * 7 * sizeof(double)));
+        HIPCHK(hipMemsetAsync(c->rep.base, 0, (size_t)len_rep * 7 * sizeof(double), c->stream));
         c->rep.off = off_rep; c->rep.len = len_rep; c->rep.nrep = 8;
     }
     c->t.scal = c->d_tally; c->t.Jout = c->d_tally + oJout; c->t.Jin = c->d_tally + oJin; c->t.Jabs = c->d_tally + oJabs; c->t.Jmu = c->d_tally + oJmu;
@@ -218,12 +226,12 @@ extern "C" int lart_gpu_set_grid_car(lart_gpu *c, int32_t nx, int32_t ny, int32_
     }
     (void)hipFree(c->d_cell); (void)hipFree(c->d_faces); c->d_cell = nullptr; c->d_faces = nullptr;
     HIPCHK(hipMalloc(&c->d_cell, nc * sizeof(Cell)));
-    HIPCHK(hipMemcpy(c->d_cell, h.data(), nc * sizeof(Cell), hipMemcpyHostToDevice));
+    HIPCHK(lart_put(c->stream, c->d_cell, h.data(), nc * sizeof(Cell)));
     size_t nf = (size_t)nx + ny + nz + 3;
     std::vector<double> f(nf);
     std::memcpy(&f[0], xface, (nx + 1) * sizeof(double)); std::memcpy(&f[nx + 1], yface, (ny + 1) * sizeof(double)); std::memcpy(&f[nx + ny + 2], zface, (nz + 1) * sizeof(double));
     HIPCHK(hipMalloc(&c->d_faces, nf * sizeof(double)));
-    HIPCHK(hipMemcpy(c->d_faces, f.data(), nf * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(lart_put(c->stream, c->d_faces, f.data(), nf * sizeof(double)));
     c->h_faces = f;
     c->g.nx = nx; c->g.ny = ny; c->g.nz = nz; c->g.i0 = i0; c->g.j0 = j0; c->g.k0 = k0;
     c->g.xmin = xmin; c->g.ymin = ymin; c->g.zmin = zmin; c->g.dx = dx; c->g.dy = dy; c->g.dz = dz;
@@ -251,7 +259,7 @@ extern "C" int lart_gpu_set_line_multiplet(lart_gpu *c, const lart_line_multiple
     }
     HIPCHK(hipSetDevice(c->device));
     if (!c->d_ml_tab) { HIPCHK(hipMalloc(&c->d_ml_tab, sizeof tab)); HIPCHK(hipMalloc(&c->d_ml_itab, sizeof itab)); }
-    HIPCHK(hipMemcpy(c->d_ml_tab, tab, sizeof tab, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(c->d_ml_itab, itab, sizeof itab, hipMemcpyHostToDevice));
+    HIPCHK(lart_put(c->stream, c->d_ml_tab, tab, sizeof tab)); HIPCHK(lart_put(c->stream, c->d_ml_itab, itab, sizeof itab));
     c->ml = DMulti{}; c->ml.nup = m->nup; c->ml.coherent = (m->HeI_coherent != 0 && m->line_type == 6) ? 1 : 0; c->ml.tab = c->d_ml_tab; c->ml.itab = c->d_ml_itab;
     for (int i = 0; i < 3; i++) { c->ml.delE_Hz[i] = i < m->nup ? m->delE_Hz[i] : 0.0; c->ml.damping_up[i] = i < m->nup ? m->damping_up[i] : 1.0; c->ml.f12[i] = i < m->nup ? m->f12[i] : 0.0; }
     c->has_ml = true;
@@ -269,9 +277,9 @@ extern "C" int lart_gpu_set_mueller(lart_gpu *c, int32_t nPDF, const double *cos
     std::vector<double> h(6 * n, 0.0);
     std::memcpy(&h[0], coss, n * 8); std::memcpy(&h[n], S11, n * 8); std::memcpy(&h[2 * n], S12, n * 8);
     std::memcpy(&h[3 * n], S33, n * 8); std::memcpy(&h[4 * n], S34, n * 8); std::memcpy(&h[5 * n], phase_PDF, (n - 1) * 8);
-    HIPCHK(hipMalloc(&c->d_mu, 6 * n * 8)); HIPCHK(hipMemcpy(c->d_mu, h.data(), 6 * n * 8, hipMemcpyHostToDevice));
-    HIPCHK(hipMalloc(&c->d_alias, n * 4)); HIPCHK(hipMemset(c->d_alias, 0, n * 4));
-    HIPCHK(hipMemcpy(c->d_alias, alias, (n - 1) * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&c->d_mu, 6 * n * 8)); HIPCHK(lart_put(c->stream, c->d_mu, h.data(), 6 * n * 8));
+    HIPCHK(hipMalloc(&c->d_alias, n * 4)); HIPCHK(hipMemsetAsync(c->d_alias, 0, n * 4, c->stream));
+    HIPCHK(lart_put(c->stream, c->d_alias, alias, (n - 1) * 4));
     c->mu.nPDF = nPDF; c->mu.coss = c->d_mu; c->mu.S11 = c->d_mu + n; c->mu.S12 = c->d_mu + 2 * n; c->mu.S33 = c->d_mu + 3 * n; c->mu.S34 = c->d_mu + 4 * n;
     c->mu.phase_PDF = c->d_mu + 5 * n; c->mu.alias = c->d_alias;
     return 0;
@@ -286,7 +294,7 @@ extern "C" int lart_gpu_set_observers(lart_gpu *c, int32_t nobs, const double *x
     std::vector<DObs> h(nobs > 0 ? nobs : 1);
     for (int i = 0; i < nobs; i++) { h[i].x = xyz[3 * i]; h[i].y = xyz[3 * i + 1]; h[i].z = xyz[3 * i + 2]; for (int q = 0; q < 9; q++) h[i].rm[q] = rmatrix[9 * i + q]; }
     HIPCHK(hipMalloc(&c->d_obs, h.size() * sizeof(DObs)));
-    HIPCHK(hipMemcpy(c->d_obs, h.data(), h.size() * sizeof(DObs), hipMemcpyHostToDevice));
+    HIPCHK(lart_put(c->stream, c->d_obs, h.data(), h.size() * sizeof(DObs)));
     c->nobs = nobs; c->nxim = nxim; c->nyim = nyim; c->dxim = dxim; c->dyim = dyim; c->heal_nside = 0; h.resize(nobs > 0 ? nobs : 0); c->h_obs = h;
     invalidate_run(c);
     return 0;
@@ -304,7 +312,7 @@ extern "C" int lart_gpu_set_observers_heal(lart_gpu *c, int32_t nobs, const doub
     std::vector<DObs> h(nobs);
     for (int i = 0; i < nobs; i++) { h[i].x = xyz[3 * i]; h[i].y = xyz[3 * i + 1]; h[i].z = xyz[3 * i + 2]; for (int q = 0; q < 9; q++) h[i].rm[q] = 0.0; }
     HIPCHK(hipMalloc(&c->d_obs, h.size() * sizeof(DObs)));
-    HIPCHK(hipMemcpy(c->d_obs, h.data(), h.size() * sizeof(DObs), hipMemcpyHostToDevice));
+    HIPCHK(lart_put(c->stream, c->d_obs, h.data(), h.size() * sizeof(DObs)));
     c->nobs = nobs; c->nxim = 12 * nside * nside; c->nyim = 1; c->dxim = 1.0; c->dyim = 1.0; c->heal_nside = nside; c->h_obs = h;
     invalidate_run(c);
     return 0;
@@ -319,7 +327,7 @@ extern "C" int lart_gpu_set_JPa(lart_gpu *c, int32_t calc_J, int32_t calc_P, int
     HIPCHK(hipSetDevice(c->device));
     (void)hipFree(c->d_ind_bin); c->d_ind_bin = nullptr;
     HIPCHK(hipMalloc(&c->d_ind_bin, c->ncell * sizeof(int)));
-    HIPCHK(hipMemcpy(c->d_ind_bin, ind_bin, c->ncell * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(lart_put(c->stream, c->d_ind_bin, ind_bin, c->ncell * sizeof(int)));
     c->jpa.calc_J = calc_J ? 1 : 0; c->jpa.calc_P = calc_P ? 1 : 0; c->jpa.calc_Pnew = calc_Pnew ? 1 : 0;
     c->jpa.nbins = (calc_J || calc_P || calc_Pnew) ? nbins : 0; c->jpa.ind_bin = c->d_ind_bin; c->jpa.cross0 = cross0;
     invalidate_run(c);
@@ -359,20 +367,20 @@ extern "C" int lart_gpu_set_grid_amr(lart_gpu *c, int32_t ncells, int32_t nleaf,
     (void)hipFree(c->d_cell); (void)hipFree(c->d_faces); (void)hipFree(c->d_amr_int); (void)hipFree(c->d_amr_geom);
     c->d_cell = nullptr; c->d_faces = nullptr; c->d_amr_int = nullptr; c->d_amr_geom = nullptr;
     HIPCHK(hipMalloc(&c->d_cell, (size_t)nleaf * sizeof(Cell)));
-    HIPCHK(hipMemcpy(c->d_cell, h.data(), (size_t)nleaf * sizeof(Cell), hipMemcpyHostToDevice));
+    HIPCHK(lart_put(c->stream, c->d_cell, h.data(), (size_t)nleaf * sizeof(Cell)));
     double f[6] = {lo, hi, lo, hi, lo, hi};
-    HIPCHK(hipMalloc(&c->d_faces, sizeof f)); HIPCHK(hipMemcpy(c->d_faces, f, sizeof f, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&c->d_faces, sizeof f)); HIPCHK(lart_put(c->stream, c->d_faces, f, sizeof f));
     std::vector<AmrGeom> gq(ncells);
     for (int i = 0; i < ncells; i++) { gq[i].cx = cx[i]; gq[i].cy = cy[i]; gq[i].cz = cz[i]; gq[i].ch = ch[i]; }
     HIPCHK(hipMalloc(&c->d_amr_geom, (size_t)ncells * sizeof(AmrGeom)));
-    HIPCHK(hipMemcpy(c->d_amr_geom, gq.data(), (size_t)ncells * sizeof(AmrGeom), hipMemcpyHostToDevice));
+    HIPCHK(lart_put(c->stream, c->d_amr_geom, gq.data(), (size_t)ncells * sizeof(AmrGeom)));
     size_t ni = (size_t)15 * ncells + nleaf;
     HIPCHK(hipMalloc(&c->d_amr_int, ni * sizeof(int)));
     int *d = c->d_amr_int;
-    HIPCHK(hipMemcpy(d, children, (size_t)8 * ncells * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d + (size_t)8 * ncells, neighbor, (size_t)6 * ncells * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d + (size_t)14 * ncells, ileaf, (size_t)ncells * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d + (size_t)15 * ncells, icell_of_leaf, (size_t)nleaf * 4, hipMemcpyHostToDevice));
+    HIPCHK(lart_put(c->stream, d, children, (size_t)8 * ncells * 4));
+    HIPCHK(lart_put(c->stream, d + (size_t)8 * ncells, neighbor, (size_t)6 * ncells * 4));
+    HIPCHK(lart_put(c->stream, d + (size_t)14 * ncells, ileaf, (size_t)ncells * 4));
+    HIPCHK(lart_put(c->stream, d + (size_t)15 * ncells, icell_of_leaf, (size_t)nleaf * 4));
     c->amr = DAmr{};
     c->amr.ncells = ncells; c->amr.nleaf = nleaf; c->amr.children = d; c->amr.neighbor = d + (size_t)8 * ncells;
     c->amr.ileaf = d + (size_t)14 * ncells; c->amr.icell_of_leaf = d + (size_t)15 * ncells; c->amr.geom = c->d_amr_geom;
@@ -430,12 +438,12 @@ extern "C" int lart_gpu_set_clumps(lart_gpu *c, int64_t n, const double *x, cons
     }
     (void)hipFree(c->d_cl_geo); (void)hipFree(c->d_cl_phys); (void)hipFree(c->d_cl_int); c->d_cl_geo = nullptr; c->d_cl_phys = nullptr; c->d_cl_int = nullptr;
     (void)hipFree(c->d_cell); (void)hipFree(c->d_faces); c->d_cell = nullptr; c->d_faces = nullptr;
-    HIPCHK(hipMalloc(&c->d_cl_geo, (size_t)n * sizeof(ClumpGeo))); HIPCHK(hipMemcpy(c->d_cl_geo, hg.data(), (size_t)n * sizeof(ClumpGeo), hipMemcpyHostToDevice));
-    HIPCHK(hipMalloc(&c->d_cl_phys, (size_t)n * sizeof(ClumpPhys))); HIPCHK(hipMemcpy(c->d_cl_phys, hp.data(), (size_t)n * sizeof(ClumpPhys), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&c->d_cl_geo, (size_t)n * sizeof(ClumpGeo))); HIPCHK(lart_put(c->stream, c->d_cl_geo, hg.data(), (size_t)n * sizeof(ClumpGeo)));
+    HIPCHK(hipMalloc(&c->d_cl_phys, (size_t)n * sizeof(ClumpPhys))); HIPCHK(lart_put(c->stream, c->d_cl_phys, hp.data(), (size_t)n * sizeof(ClumpPhys)));
     size_t ni = ncells + 1 + (size_t)(nreg > 0 ? nreg : 1);
     HIPCHK(hipMalloc(&c->d_cl_int, ni * sizeof(int)));
-    HIPCHK(hipMemcpy(c->d_cl_int, cg_start, (ncells + 1) * sizeof(int), hipMemcpyHostToDevice));
-    if (nreg > 0) HIPCHK(hipMemcpy(c->d_cl_int + ncells + 1, cg_list, (size_t)nreg * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(lart_put(c->stream, c->d_cl_int, cg_start, (ncells + 1) * sizeof(int)));
+    if (nreg > 0) HIPCHK(lart_put(c->stream, c->d_cl_int + ncells + 1, cg_list, (size_t)nreg * sizeof(int)));
     c->cl = DClumps{};
     c->cl.N = n; c->cl.geo = c->d_cl_geo; c->cl.phys = c->d_cl_phys; c->cl.cg_start = c->d_cl_int; c->cl.cg_list = c->d_cl_int + ncells + 1;
     c->cl.cgx = cgx; c->cl.cg_min = cg_min; c->cl.cg_d = cg_d; c->cl.cg_inv = 1.0 / cg_d; c->cl.sphere_R = sphere_R; c->cl.Dfreq_ref = Dfreq_ref;
@@ -449,13 +457,13 @@ extern "C" int lart_gpu_set_clumps(lart_gpu *c, int64_t n, const double *x, cons
                 if (ip > cg_start[q] && cg_list[ip - 2] >= icl) { ascending = false; break; }      // the walk's order is the list's: only an ascending list is its own mask
                 mk[2 * q + ((icl - 1) >> 6)] |= 1ull << ((icl - 1) & 63);
             }
-        if (ascending) { HIPCHK(hipMalloc(&c->d_cl_mask, mk.size() * 8)); HIPCHK(hipMemcpy(c->d_cl_mask, mk.data(), mk.size() * 8, hipMemcpyHostToDevice)); c->cl.cg_mask = c->d_cl_mask; }
+        if (ascending) { HIPCHK(hipMalloc(&c->d_cl_mask, mk.size() * 8)); HIPCHK(lart_put(c->stream, c->d_cl_mask, mk.data(), mk.size() * 8)); c->cl.cg_mask = c->d_cl_mask; }
     }
     // the background medium of grid_create_clump is uniform (rhokap = 0, Dfreq = Dfreq_ref, voigt_a = voigt_a_ref, v = 0): one record
     Cell bg{}; bg.rhokap = 0.0; bg.voigt_a = voigt_a_ref; bg.Dfreq = Dfreq_ref; bg.vfx = bg.vfy = bg.vfz = 0.0; bg.rhokapD = 0.0; bg.pad = 0.0;
-    HIPCHK(hipMalloc(&c->d_cell, sizeof(Cell))); HIPCHK(hipMemcpy(c->d_cell, &bg, sizeof(Cell), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&c->d_cell, sizeof(Cell))); HIPCHK(lart_put(c->stream, c->d_cell, &bg, sizeof(Cell)));
     double f[6] = {-sphere_R, sphere_R, -sphere_R, sphere_R, -sphere_R, sphere_R};
-    HIPCHK(hipMalloc(&c->d_faces, sizeof f)); HIPCHK(hipMemcpy(c->d_faces, f, sizeof f, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&c->d_faces, sizeof f)); HIPCHK(lart_put(c->stream, c->d_faces, f, sizeof f));
     c->g = DGrid{}; c->g.nx = 1; c->g.ny = 1; c->g.nz = 1; c->g.i0 = 1; c->g.j0 = 1; c->g.k0 = 1;
     c->g.xmin = -sphere_R; c->g.ymin = -sphere_R; c->g.zmin = -sphere_R; c->g.dx = 2 * sphere_R; c->g.dy = 2 * sphere_R; c->g.dz = 2 * sphere_R;
     c->g.cell = c->d_cell; c->g.faces = c->d_faces; c->ncell = 1; c->has_dust_table = rhokapD != nullptr;
@@ -828,8 +836,8 @@ extern "C" int lart_gpu_sync(lart_gpu *c, int64_t *done, int64_t *active) {
     HIPCHK(hipStreamSynchronize(c->stream));
     if (collect_events(c)) return 1;
     DCtl h{}; double nd = 0.0;
-    HIPCHK(hipMemcpy(&h, c->d_ctl, sizeof h, hipMemcpyDeviceToHost));
-    if (c->d_tally) HIPCHK(hipMemcpy(&nd, c->d_tally + 5, 8, hipMemcpyDeviceToHost));
+    HIPCHK(lart_get(c->stream, &h, c->d_ctl, sizeof h));
+    if (c->d_tally) HIPCHK(lart_get(c->stream, &nd, c->d_tally + 5, 8));
     if (done) *done = (int64_t)(nd + 0.5);
     if (active) *active = (int64_t)h.n_active + ((int64_t)h.next_k < c->count ? (c->count - (int64_t)h.next_k) : 0);
     if (c->begun && c->nlaunch > 0) { c->last_alive = (int64_t)h.n_active; c->last_next_k = (int64_t)h.next_k; c->state_valid = true; }
@@ -902,20 +910,20 @@ extern "C" int lart_gpu_get_tallies(lart_gpu *c, lart_tallies *o) {
     // after output_reduce the root hands out the totals over all ranks (its receive buffer), until it adds events of its own again
     // (the section pointers of c->t point into d_tally; a section of the receive buffer is addressed as base + its OFFSET in d_tally -- no arithmetic between the two allocations)
     const double *base = (c->reduced_valid && c->d_reduced) ? c->d_reduced : c->d_tally;
-    double s[16]; HIPCHK(hipMemcpy(s, base, sizeof s, hipMemcpyDeviceToHost));
-    { double dr = 0.0; HIPCHK(hipMemcpy(&dr, base + LART_SCAL_PEEL_DROPPED, 8, hipMemcpyDeviceToHost));
+    double s[16]; HIPCHK(lart_get(c->stream, s, base, sizeof s));
+    { double dr = 0.0; HIPCHK(lart_get(c->stream, &dr, base + LART_SCAL_PEEL_DROPPED, 8));
       if (dr > 0.0) return fail("get_tallies: the peel-off deposit list overflowed (" + std::to_string((long long)dr) + " rays dropped): the images have lost flux; this is a sizing bug of the peel queue, not a property of the input"); }
     if (s[7] > 0.0) return fail("get_tallies: a ray met more overlapping clumps than the march lists hold (LART_OVL_ACT clumps around a point, LART_OVL_PEND events ahead): the result is not the reference's");
     o->nscatt_gas = s[0]; o->nscatt_dust = s[1]; o->n_events = s[2]; o->n_cellsteps = s[3]; o->n_cellsteps_peel = s[4]; o->n_atomics = s[6]; o->nphotons_done = (int64_t)(s[5] + 0.5);
-    DCtl h{}; HIPCHK(hipMemcpy(&h, c->d_ctl, sizeof h, hipMemcpyDeviceToHost)); o->nphotons_active = (int64_t)h.n_active;
+    DCtl h{}; HIPCHK(lart_get(c->stream, &h, c->d_ctl, sizeof h)); o->nphotons_active = (int64_t)h.n_active;
     int64_t nxf = c->par.nxfreq, n2 = (int64_t)c->nobs * c->nxim * c->nyim, n3 = n2 * nxf;
-#define CP(dst, src, cnt) if ((dst) && (src) && (cnt) > 0) HIPCHK(hipMemcpy((dst), base + ((src) - c->d_tally), (size_t)(cnt) * 8, hipMemcpyDeviceToHost))
+#define CP(dst, src, cnt) if ((dst) && (src) && (cnt) > 0) HIPCHK(lart_get(c->stream, (dst), base + ((src) - c->d_tally), (size_t)(cnt) * 8))
     CP(o->Jout, c->t.Jout, nxf); CP(o->Jin, c->t.Jin, nxf); CP(o->Jabs, c->t.Jabs, nxf); CP(o->Jmu, c->t.Jmu, c->par.save_Jmu ? nxf * c->par.nmu : 0);
     double *h3[8] = {o->scatt, o->direc, o->I, o->Q, o->U, o->V, o->direc0, o->scatt_dust}, *h2[8] = {o->scatt_2D, o->direc_2D, o->I_2D, o->Q_2D, o->U_2D, o->V_2D, o->direc0_2D, nullptr};
     for (int k = 0; k < 8; k++) { CP(h3[k], c->t.c3[k], n3); CP(h2[k], c->t.c2[k], n2); }
     CP(o->J1, c->jpa.J1, nxf * c->jpa.nbins); CP(o->P1, c->jpa.P1, c->jpa.nbins); CP(o->P1_new, c->jpa.P1_new, c->jpa.nbins);
     CP(o->Jout_Ha, c->t.Jout_Ha, c->par.nxfreq_Ha); CP(o->Jabs_Ha, c->t.Jabs_Ha, c->par.nxfreq_Ha); CP(o->peel_Ha, c->t.peel_Ha, n2 * c->par.nxfreq_Ha); CP(o->Pconv, c->jpa.Pconv, c->jpa.nbins);
-    { double w[8] = {0}; HIPCHK(hipMemcpy(w, base + LART_SCAL_AUX, 7 * 8, hipMemcpyDeviceToHost)); for (int i = 0; i < 8; i++) o->aux[i] = w[i]; }
+    { double w[8] = {0}; HIPCHK(lart_get(c->stream, w, base + LART_SCAL_AUX, 7 * 8)); for (int i = 0; i < 8; i++) o->aux[i] = w[i]; }
 #undef CP
     return 0;
 }
@@ -1041,8 +1049,8 @@ extern "C" int lart_gpu_get_photon_log(lart_gpu *c, double *nscatt, double *xfre
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
     int64_t m = n < c->nlog ? n : c->nlog;
-    if (nscatt) HIPCHK(hipMemcpy(nscatt, c->d_log, (size_t)m * 8, hipMemcpyDeviceToHost));
-    if (xfreq_ref) HIPCHK(hipMemcpy(xfreq_ref, c->d_log + c->nlog, (size_t)m * 8, hipMemcpyDeviceToHost));
+    if (nscatt) HIPCHK(lart_get(c->stream, nscatt, c->d_log, (size_t)m * 8));
+    if (xfreq_ref) HIPCHK(lart_get(c->stream, xfreq_ref, c->d_log + c->nlog, (size_t)m * 8));
     return 0;
 }
 
@@ -1056,11 +1064,11 @@ extern "C" int lart_gpu_test_trace(lart_gpu *c, int64_t first_id, int64_t stride
     HIPCHK(hipSetDevice(c->device));
     const size_t nt = (size_t)nslots * cap * LART_TRACE_W;
     HIPCHK(hipMalloc(&c->d_trace_slot, (size_t)count * 4)); HIPCHK(hipMalloc(&c->d_trace_n, (size_t)nslots * 4)); HIPCHK(hipMalloc(&c->d_trace, nt * 8));
-    HIPCHK(hipMemcpy(c->d_trace_slot, slot, (size_t)count * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemset(c->d_trace_n, 0, (size_t)nslots * 4)); HIPCHK(hipMemset(c->d_trace, 0, nt * 8));
+    HIPCHK(lart_put(c->stream, c->d_trace_slot, slot, (size_t)count * 4));
+    HIPCHK(hipMemsetAsync(c->d_trace_n, 0, (size_t)nslots * 4, c->stream)); HIPCHK(hipMemsetAsync(c->d_trace, 0, nt * 8, c->stream));
     c->trace_cap = cap;
     int rc = lart_gpu_run(c, first_id, stride, count, seed);
-    if (!rc) { if (hipMemcpy(trace_out, c->d_trace, nt * 8, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(n_out, c->d_trace_n, (size_t)nslots * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = fail("test_trace: copy back failed"); }
+    if (!rc) { if (lart_get(c->stream, trace_out, c->d_trace, nt * 8) != hipSuccess || lart_get(c->stream, n_out, c->d_trace_n, (size_t)nslots * 4) != hipSuccess) rc = fail("test_trace: copy back failed"); }
     (void)hipFree(c->d_trace_slot); (void)hipFree(c->d_trace_n); (void)hipFree(c->d_trace);
     c->d_trace_slot = nullptr; c->d_trace_n = nullptr; c->d_trace = nullptr; c->trace_cap = 0;
     return rc;
@@ -1072,7 +1080,7 @@ extern "C" int lart_gpu_get_all_photons(lart_gpu *c, double *out, int64_t n) {
     if (n != c->nlog) return fail("all_photons: n must equal the photon count of lart_gpu_begin");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipMemcpy(out, c->d_log + 2 * c->nlog, (size_t)n * 80, hipMemcpyDeviceToHost));
+    HIPCHK(lart_get(c->stream, out, c->d_log + 2 * c->nlog, (size_t)n * 80));
     return 0;
 }
 
@@ -1213,10 +1221,10 @@ __global__ void k_test_event(KArgs A, int var, int n, double *st27, unsigned lon
     else test_event_var<0>(A, l, st27 + 27 * i, seed, ids[i], first[i]);
 }
 
-template <typename T> struct DevBuf {
-    T *p = nullptr; size_t n = 0;
-    int alloc(size_t cnt, const T *src) { n = cnt; if (hipMalloc(&p, cnt * sizeof(T) + 8) != hipSuccess) return 1; if (src && hipMemcpy(p, src, cnt * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return 1; return 0; }
-    int back(T *dst) { return hipMemcpy(dst, p, n * sizeof(T), hipMemcpyDeviceToHost) != hipSuccess; }
+template <typename T> struct DevBuf {                      // a probe's scratch buffer; copies on the stream the probe's kernel runs on (given to alloc)
+    T *p = nullptr; size_t n = 0; hipStream_t st = nullptr;
+    int alloc(hipStream_t stream, size_t cnt, const T *src) { st = stream; n = cnt; if (hipMalloc(&p, cnt * sizeof(T) + 8) != hipSuccess) return 1; if (src && lart_put(st, p, src, cnt * sizeof(T)) != hipSuccess) return 1; return 0; }
+    int back(T *dst) { return lart_get(st, dst, p, n * sizeof(T)) != hipSuccess; }
     ~DevBuf() { if (p) (void)hipFree(p); }
 };
 static KArgs probe_args(lart_gpu *c) {
@@ -1228,8 +1236,8 @@ static size_t probe_shmem(lart_gpu *c) { return (size_t)(VT_END + c->g.nx + c->g
 extern "C" int lart_gpu_test_voigt(lart_gpu *c, int32_t n, const double *x, const double *a, double *h) {
     if (!c || n < 0) return fail("test_voigt: bad argument");
     HIPCHK(hipSetDevice(c->device));
-    DevBuf<double> dx, da, dh; if (dx.alloc(n, x) || da.alloc(n, a) || dh.alloc(n, nullptr)) return fail("test_voigt: hipMalloc failed");
-    DGrid g{}; g.nx = g.ny = g.nz = 0; double zero[3] = {0, 0, 0}; DevBuf<double> df; if (df.alloc(3, zero)) return fail("test_voigt: hipMalloc failed"); g.faces = df.p;
+    DevBuf<double> dx, da, dh; if (dx.alloc(c->stream, n, x) || da.alloc(c->stream, n, a) || dh.alloc(c->stream, n, nullptr)) return fail("test_voigt: hipMalloc failed");
+    DGrid g{}; g.nx = g.ny = g.nz = 0; double zero[3] = {0, 0, 0}; DevBuf<double> df; if (df.alloc(c->stream, 3, zero)) return fail("test_voigt: hipMalloc failed"); g.faces = df.p;
     hipLaunchKernelGGL(k_test_voigt, dim3((n + 255) / 256), dim3(256), (VT_END + 3) * sizeof(double), c->stream, g, n, dx.p, da.p, dh.p);
     HIPCHK(hipGetLastError()); HIPCHK(hipStreamSynchronize(c->stream));
     if (dh.back(h)) return fail("test_voigt: copy back failed");
@@ -1238,7 +1246,7 @@ extern "C" int lart_gpu_test_voigt(lart_gpu *c, int32_t n, const double *x, cons
 extern "C" int lart_gpu_test_rand(lart_gpu *c, int32_t what, uint64_t seed, uint64_t id, int32_t n, double p1, double p2, double *out) {
     if (!c || n < 0) return fail("test_rand: bad argument");
     HIPCHK(hipSetDevice(c->device));
-    DevBuf<double> d; if (d.alloc(n, nullptr)) return fail("test_rand: hipMalloc failed");
+    DevBuf<double> d; if (d.alloc(c->stream, n, nullptr)) return fail("test_rand: hipMalloc failed");
     hipLaunchKernelGGL(k_test_rand, dim3(1), dim3(64), 0, c->stream, what, (unsigned long long)seed, (unsigned long long)id, n, p1, p2, d.p);
     HIPCHK(hipGetLastError()); HIPCHK(hipStreamSynchronize(c->stream));
     if (d.back(out)) return fail("test_rand: copy back failed");
@@ -1260,7 +1268,7 @@ extern "C" int lart_gpu_test_raytrace(lart_gpu *c, int32_t mode, int32_t n, doub
         if (q[0] > c->g.nx || q[1] > c->g.ny || q[2] > c->g.nz) return fail("test_raytrace: probe start cells must be interior (1..n)");
     }
     DevBuf<double> dr, dt, dq; DevBuf<int> di;
-    if (dr.alloc((size_t)8 * n, r8) || di.alloc((size_t)4 * n, ic4) || dt.alloc(n, (var == 8 && tau_out) ? tau_out : nullptr) || dq.alloc(n, tq)) return fail("test_raytrace: hipMalloc failed");
+    if (dr.alloc(c->stream, (size_t)8 * n, r8) || di.alloc(c->stream, (size_t)4 * n, ic4) || dt.alloc(c->stream, n, (var == 8 && tau_out) ? tau_out : nullptr) || dq.alloc(c->stream, n, tq)) return fail("test_raytrace: hipMalloc failed");
     if (c->par.line_type >= 4 && c->par.line_type <= 6 && !c->has_ml) return fail("line_type 4/5/6 needs lart_gpu_set_line_multiplet first");
     KArgs A = probe_args(c);
     hipLaunchKernelGGL(k_test_raytrace, dim3((n + 63) / 64), dim3(64), probe_shmem(c), c->stream, A, mode, n, dr.p, di.p, tq ? dq.p : nullptr, dt.p);
@@ -1272,7 +1280,7 @@ extern "C" int lart_gpu_test_vec2pix(lart_gpu *c, int32_t nside, int32_t n, cons
     if (!c || n < 0 || nside < 1) return fail("test_vec2pix: bad argument");
     HIPCHK(hipSetDevice(c->device));
     DevBuf<double> dv; DevBuf<int> di;
-    if (dv.alloc((size_t)3 * n, v3) || di.alloc(n, nullptr)) return fail("test_vec2pix: hipMalloc failed");
+    if (dv.alloc(c->stream, (size_t)3 * n, v3) || di.alloc(c->stream, n, nullptr)) return fail("test_vec2pix: hipMalloc failed");
     hipLaunchKernelGGL(k_test_vec2pix, dim3((n + 255) / 256), dim3(256), 0, c->stream, nside, n, dv.p, di.p);
     HIPCHK(hipGetLastError()); HIPCHK(hipStreamSynchronize(c->stream));
     if (di.back(ipix)) return fail("test_vec2pix: copy back failed");
@@ -1287,7 +1295,7 @@ extern "C" int lart_gpu_test_scatter(lart_gpu *c, int32_t n, double *st18, int32
         if (q[0] < 1 || q[0] > c->g.nx || q[1] < 1 || q[1] > c->g.ny || q[2] < 1 || q[2] > c->g.nz) return fail("test_scatter: cell outside the grid"); }
     if (c->par.use_stokes && c->par.DGR > 0.0 && c->mu.nPDF == 0) return fail("test_scatter: Stokes dust scattering needs a Mueller table");
     DevBuf<double> ds; DevBuf<int> di; DevBuf<unsigned long long> dd; DevBuf<long long> dn;
-    if (ds.alloc((size_t)18 * n, st18) || di.alloc((size_t)4 * n, ic4) || dd.alloc(n, (const unsigned long long *)ids) || dn.alloc(n, nullptr)) return fail("test_scatter: hipMalloc failed");
+    if (ds.alloc(c->stream, (size_t)18 * n, st18) || di.alloc(c->stream, (size_t)4 * n, ic4) || dd.alloc(c->stream, n, (const unsigned long long *)ids) || dn.alloc(c->stream, n, nullptr)) return fail("test_scatter: hipMalloc failed");
     if (c->par.line_type >= 4 && c->par.line_type <= 6 && !c->has_ml) return fail("line_type 4/5/6 needs lart_gpu_set_line_multiplet first");
     KArgs A = probe_args(c);
     hipLaunchKernelGGL(k_test_scatter, dim3((n + 63) / 64), dim3(64), probe_shmem(c), c->stream, A, n, ds.p, di.p, (unsigned long long)seed, dd.p, dn.p);
@@ -1308,7 +1316,7 @@ extern "C" int lart_gpu_test_event(lart_gpu *c, int32_t n, double *st27, uint64_
         if (c->is_clump) { if (q[23] < 0 || q[23] > (double)c->cl.N) return fail("test_event: owner clump out of range"); continue; }
         if (q[20] < 1 || q[20] > c->g.nx || q[21] < 1 || q[21] > c->g.ny || q[22] < 1 || q[22] > c->g.nz) return fail("test_event: cell outside the grid"); }
     DevBuf<double> ds; DevBuf<unsigned long long> dd; DevBuf<int> df;
-    if (ds.alloc((size_t)27 * n, st27) || dd.alloc(n, (const unsigned long long *)ids) || df.alloc(n, first)) return fail("test_event: hipMalloc failed");
+    if (ds.alloc(c->stream, (size_t)27 * n, st27) || dd.alloc(c->stream, n, (const unsigned long long *)ids) || df.alloc(c->stream, n, first)) return fail("test_event: hipMalloc failed");
     KArgs A = probe_args(c);
     hipLaunchKernelGGL(k_test_event, dim3((n + 63) / 64), dim3(64), probe_shmem(c), c->stream, A, var, n, ds.p, (unsigned long long)seed, dd.p, df.p);
     HIPCHK(hipGetLastError()); HIPCHK(hipStreamSynchronize(c->stream));
@@ -1340,7 +1348,7 @@ extern "C" int lart_gpu_sightline_tau(lart_gpu *c, double cross0, double *tau_ga
     const size_t nray = rays.size(), nxf = (size_t)c->par.nxfreq;
     const bool dust = c->par.DGR > 0.0 && c->has_dust_table;
     DevBuf<SightRay> dr; DevBuf<double> dt, dn, dd;
-    if (dr.alloc(nray, rays.data()) || dt.alloc(nray * nxf, nullptr) || dn.alloc(nray, nullptr) || dd.alloc(nray, nullptr)) return fail("sightline_tau: hipMalloc failed");
+    if (dr.alloc(c->stream, nray, rays.data()) || dt.alloc(c->stream, nray * nxf, nullptr) || dn.alloc(c->stream, nray, nullptr) || dd.alloc(c->stream, nray, nullptr)) return fail("sightline_tau: hipMalloc failed");
     HIPCHK(hipMemsetAsync(dt.p, 0, nray * nxf * sizeof(double), c->stream));
     HIPCHK(hipMemsetAsync(dn.p, 0, nray * sizeof(double), c->stream));
     HIPCHK(hipMemsetAsync(dd.p, 0, nray * sizeof(double), c->stream));
@@ -1355,7 +1363,7 @@ extern "C" int lart_gpu_sightline_tau(lart_gpu *c, double cross0, double *tau_ga
     HIPCHK(hipStreamSynchronize(c->stream));
     float ms = 0.0f; (void)hipEventElapsedTime(&ms, e0, e1); c->sight_ms = ms; (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (dt.back(tau_gas) || dn.back(N_gas) || (tau_dust && dd.back(tau_dust))) return fail("sightline_tau: copy back failed");
-    if (ovl) { double over = 0.0; HIPCHK(hipMemcpy(&over, c->d_tally + 7, sizeof over, hipMemcpyDeviceToHost));
+    if (ovl) { double over = 0.0; HIPCHK(lart_get(c->stream, &over, c->d_tally + 7, sizeof over));
         if (over > 0.0) return fail("sightline_tau: a ray met more overlapping clumps than the march lists hold"); }
     return 0;
 }

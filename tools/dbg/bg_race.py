@@ -24,25 +24,38 @@ def run_case(name, tmp):
     fn = os.path.join(tmp, name + ".in"); open(fn, "w").write(CASES[name])
     sim = host.Simulation(host.read_namelist(fn)); sim.ctx.enable_photon_log(True)
     sim.run_simulation()
-    t = sim.ctx.tallies(); n = int(t["nphotons_done"])
-    return t, sim.ctx.photon_log(n)
+    t = sim.ctx.tallies()
+    return t, sim.ctx.photon_log(20000)
 
 
 def main():
     tmp = tempfile.mkdtemp(prefix="bgrace")
     alone = {k: run_case(k, tmp) for k in CASES}
     stop = threading.Event()
-    big = host.Simulation(dict(temperature=10.0, taumax=1e6, xyz_symmetry=True, nx=101, ny=101, nz=101, rmax=1.0, nxfreq=201, iseed=5))
+    import time
+    t_start = time.time()
+    if len(sys.argv) > 1 and sys.argv[1] == "bigtau":          # the background of the device suite: the five full-size configurations of tests/test_gpu_bigtau.py
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import conftest, test_gpu_bigtau
+        def drive():
+            test_gpu_bigtau.run_all()
+            print("background finished at %.1f s" % (time.time() - t_start), flush=True)
+        stop = conftest.STOP
+    else:
+        big = host.Simulation(dict(temperature=10.0, taumax=1e6, xyz_symmetry=True, nx=101, ny=101, nz=101, rmax=1.0, nxfreq=201, iseed=5))
 
-    def drive():
-        big.ctx.begin(200000, first_id=1, stride=1, seed=5)
-        while not stop.is_set():
-            big.ctx.step(1, 4096)
-            if big.ctx.sync()[1] == 0:
-                break
+        def drive():
+            big.ctx.begin(200000, first_id=1, stride=1, seed=5)
+            while not stop.is_set():
+                big.ctx.step(1, 4096)
+                if big.ctx.sync()[1] == 0:
+                    break
     th = threading.Thread(target=drive); th.start()
     try:
-        for rep in range(2):
+        for rep in range(40 if len(sys.argv) > 1 else 2):
+            if not th.is_alive() and rep > 2:
+                break
+            print("--- pass %d at %.1f s" % (rep, time.time() - t_start), flush=True)
             for k in CASES:
                 t, (ns, xs) = run_case(k, tmp); t0, (ns0, xs0) = alone[k]
                 line = ["%s rep %d:" % (k, rep), "done %d/%d" % (t["nphotons_done"], t0["nphotons_done"]), "histories identical %.6f" % np.mean((ns == ns0) & (xs == xs0))]
