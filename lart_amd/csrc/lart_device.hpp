@@ -54,6 +54,15 @@ struct ClumpGeo  { double x, y, z, r2; };                                       
 struct ClumpPhys { double rhokap, rhokapD, voigt_a, Dfreq, vx, vy, vz, pad; };     // v in units of the clump's thermal speed
 // VAR 4 (disjoint clumps) and VAR 7 (overlapping clumps) share the owner-clump bookkeeping of the scattering and peel-off routines
 __host__ __device__ constexpr bool is_clump(int var) { return var == 4 || var == 7 || var == 9; }
+// Waves per SIMD a transport kernel is built for (its __launch_bounds__, transport_kernel.hpp) -- 4 = 128 VGPRs, workgroups up to 1024 lanes; 3 = 168 VGPRs, up to 256 lanes.
+// One list for the kernel and the host (lart_gpu_step refuses a workgroup the kernel was not built for).  3 waves: every kernel with a Stokes vector and the
+// wave-cooperative overlap kernel (profiles/r04_exec_restore_miscompile.md), and every other instantiation in which tools/isa_lint.py --build finds allocator copies
+// in front of an exec restore at 128 VGPRs: a hit means "this build of this kernel must not ship", whatever the copies turn out to be.
+__host__ __device__ constexpr int lart_kernel_waves(int var, bool stokes, bool dust, bool peel, int lt) {
+    return (stokes || var == 9) ? 3
+         : (var == 4 && !dust && peel && lt == 7) ? 3             // round 4: .LBB19_547 of transport_kernel<4,false,false,true,7>
+         : 4;
+}
 __host__ __device__ constexpr bool is_ovl(int var) { return var == 7 || var == 9; }      // overlapping clumps; 9 = at most 64 of them, flights by the wave (ovl_coop)
 // VAR 8 = the xy-periodic box with a shearing x boundary (raytrace_to_tau_car_xyper_shear, raytrace_car.f90:2677-2954, chosen at setup.f90:967-969
 // when par%Omega /= 0): the tau march of VAR 6 with photon%vfy_shear; setup_procedure leaves raytrace_to_edge at its default there, the
@@ -1615,6 +1624,13 @@ __device__ inline void ovl_coop(const KArgs &A, const Lds &l, bool dust, bool ne
     const int j = (int)(threadIdx.x & 63u);                   // this lane's clump: number j + 1
     const bool has = j < N;
     const double INF = LART_HUGEST;
+    // what depends on the flight alone, computed by the flights' own lanes side by side (two fp64 square roots and three conversions less in every turn of the loop below)
+    double my_tsp = 0.0, my_rp = 0.0; int my_ci = 0, my_cj = 0, my_ck = 0;
+    if (need) {
+        my_tsp = sphere_exit_dist(c, p.x, p.y, p.z, p.kx, p.ky, p.kz);
+        if (TO_TAU) my_rp = sqrt(p.x * p.x + p.y * p.y + p.z * p.z);
+        my_ci = cg_clamp(c, p.x); my_cj = cg_clamp(c, p.y); my_ck = cg_clamp(c, p.z);
+    }
     unsigned long long todo = __ballot(need);
     while (todo) {
         const int L = __ffsll((long long)todo) - 1; todo &= todo - 1;
@@ -1622,7 +1638,7 @@ __device__ inline void ovl_coop(const KArgs &A, const Lds &l, bool dust, bool ne
         const double xfreq_g = rl_f64(p.xfreq, L), limL = rl_f64(lim, L), u_ownL = rl_f64(u_own, L);
         double out = 0.0; int own = 0; unsigned cnt = 0;      // the flight's result (the same in every lane)
         int hna = 0; double hreach = 0.0; unsigned long long hw0 = 0, hw1 = 0, hw2 = 0, hw3 = 0;      // the list it leaves behind
-        const double t_sp = sphere_exit_dist(c, xp, yp, zp, kx, ky, kz);
+        const double t_sp = rl_f64(my_tsp, L);
         if (t_sp > 0.0) {
             if (TO_TAU) if (j == 0) OVL_STAT(A, 1, 1);             // holder lists rebuilt
             const ClumpGeo g = has ? l.ct_geo[j] : ClumpGeo{0.0, 0.0, 0.0, -1.0};
@@ -1631,7 +1647,7 @@ __device__ inline void ovl_coop(const KArgs &A, const Lds &l, bool dust, bool ne
             const unsigned long long hm = __ballot(in);
             int na = __popcll(hm);
             // the order of the list: first cell of the 27-cell scan that registers the clump, then the clump number (see ovl_start); rank = this holder's place
-            const int ci = cg_clamp(c, xp), cj = cg_clamp(c, yp), ck = cg_clamp(c, zp);
+            const int ci = rl_i32(my_ci, L), cj = rl_i32(my_cj, L), ck = rl_i32(my_ck, L);
             int rank = 0; double order_reach = INF;
             if (na > 1) {
                 const double rc = sqrt(g.r2);
@@ -1666,7 +1682,7 @@ __device__ inline void ovl_coop(const KArgs &A, const Lds &l, bool dust, bool ne
                     if (s_ < reach * (1.0 - 1e-9)) {
                         cnt++; out = s_; own = draw_owner(kap);
                         if (oh && na <= LART_OVL_HOLD) {
-                            const double ball = fmin(reach, c.sphere_R - sqrt(xp * xp + yp * yp + zp * zp));
+                            const double ball = fmin(reach, c.sphere_R - rl_f64(my_rp, L));
                             if (ball - s_ > 0.0) {
                                 hna = na; hreach = ball;
                                 for (int m = 0; m < na; m++) { const unsigned long long v = (unsigned long long)(unsigned)rl_i32(v_act, m) << ((m & 1) * 32);

@@ -530,6 +530,13 @@ static bool ovl_coop9(const lart_gpu *c) {
     return c->is_clump && c->clump_overlap && c->cl.cg_mask && c->cl.N <= LART_OVL_COOP_CLUMPS && !std::getenv("LART_OVL_NO_COOP");
 }
 
+static int march_variant(const lart_gpu *c);
+// waves per SIMD of the transport kernel this context's runs launch (lart_kernel_waves)
+static int kernel_waves_of(const lart_gpu *c) {
+    const int var = march_variant(c); const bool h2 = c->par.h2_nlines > 0;
+    return lart_kernel_waves((var == 7 && ovl_coop9(c)) ? 9 : var, c->par.use_stokes != 0, c->par.DGR > 0.0, c->par.save_peeloff && c->nobs > 0, h2 ? 9 : (int)c->par.line_type);
+}
+
 static int ensure_pool(lart_gpu *c) {
     if (!c->block_user) {
         c->block = 256;
@@ -538,6 +545,7 @@ static int ensure_pool(lart_gpu *c) {
         // for four copies, one 1024-lane workgroup has
         // (the wave-cooperative kernel of the smallest populations runs 3 waves per SIMD: three 256-lane workgroups, which do have the room)
         if (c->is_clump && c->clump_overlap && c->cl.cg_mask && c->cl.N <= LART_OVL_LDS_CLUMPS && !c->par.use_stokes && !ovl_coop9(c)) c->block = 1024;
+        if (c->block > 256 && kernel_waves_of(c) < 4) { c->block = 256; size_j_window(c); }      // a kernel built for 3 waves per SIMD takes 256-lane workgroups
     }
     int64_t n = c->want_lanes;
     if (n <= 0) {
@@ -767,7 +775,6 @@ extern "C" int lart_gpu_step(lart_gpu *c, int32_t nsteps, int32_t max_events) {
     if (c->par.line_type == 8 && (c->heal_nside > 0)) return fail("step: ly_beta: inside-observer (HEALPix) not yet supported (setup.f90:249-253)");
     if (h2 && c->heal_nside > 0) return fail("step: H2: inside-observer (HEALPix) not yet supported");
     int stokes = c->par.use_stokes ? 1 : 0, dust = c->par.DGR > 0.0 ? 1 : 0, peel = (c->par.save_peeloff && c->nobs > 0) ? 1 : 0;
-    if (c->block > 256 && stokes) return fail("step: the kernels with a Stokes vector run 3 waves per SIMD: workgroups of at most 256 lanes (lart_gpu_set_pool)");
     dim3 block(c->block), grid((unsigned)(c->live_lanes / c->block));
     size_j_window(c); A.jpa = c->jpa;
     // Voigt tables + faces | ring of random draws [LART_RNG_BUF][block] | per-block P1, P1_new
@@ -776,7 +783,8 @@ extern "C" int lart_gpu_step(lart_gpu *c, int32_t nsteps, int32_t max_events) {
     if (var == 7 && c->cl.cg_mask && c->cl.N <= LART_OVL_LDS_CLUMPS) shmem = ((shmem + 15) & ~(size_t)15) + (size_t)c->cl.N * (sizeof(ClumpGeo) + sizeof(ClumpPhys));      // ... + the clump records (lds_stage_clumps)
     if (shmem > 160 * 1024) return fail("step: grid faces do not fit the 160 KiB LDS");
     const bool coop9 = var == 7 && ovl_coop9(c);
-    if (coop9 && c->block > 256) return fail("step: the wave-cooperative overlap kernel runs 3 waves per SIMD: workgroups of at most 256 lanes (lart_gpu_set_pool)");
+    if (c->block > 256 && kernel_waves_of(c) < 4)
+        return fail("step: this transport kernel is built for 3 waves per SIMD (Stokes vector, wave-cooperative overlap kernel, see lart_kernel_waves): workgroups of at most 256 lanes (lart_gpu_set_pool)");
     // peel-off: a launch of `slice` events per lane queues at most live_lanes x (slice + 1) records (one per event, one per birth);
     // the queue is sized once per run for pq_bytes_max (16 GiB by default) and a step of max_events is cut into slices that fit
     int slice = max_events;

@@ -17,24 +17,21 @@ __device__ inline double wave_sum(double v) {
 // waves per SIMD the register allocator must leave room for.  Measured on the headline workload (profiles/README.md):
 // the plain kernel fits 128 VGPRs (4 waves) with a handful of spills and is fastest there; the Stokes triad adds ~30
 // registers.  Peel-off no longer marches inside this kernel (it queues a record, peel_kernel.hpp), so it costs no occupancy.
-#ifdef LART_MIN_WAVES
-#define LART_WAVES(S, P) LART_MIN_WAVES
-#define LART_WAVES_V4(V, S, D, P) LART_MIN_WAVES
-#else
-#define LART_WAVES(S, P) ((S) ? 3 : 4)
+// Waves per SIMD: lart_kernel_waves (lart_device.hpp) -- 4 without a Stokes vector (128 VGPRs), 3 with one (168), plus the instantiations the ISA lint demotes.
 // Round 3 built ONE Stokes instantiation, the 1-column slab without dust (C1), at 4 waves per SIMD because it measured 8 % faster there.  Round 4 found what
 // the squeeze to 128 VGPRs can cost (profiles/r04_exec_restore_miscompile.md): with dozens of spills the register allocator splits live ranges across the
 // divergent `if (pending)` of vz_core_coop and puts the split copy and a spill store at the TOP of the join block, in front of the `s_or_b64 exec` that brings
 // back the lanes which skipped the branch -- those lanes later read a stale register / scratch slot (C1: garbage event counters; the round-3 memory fault of
 // the slab kernel with dust was the same pattern hitting an index).  Every Stokes kernel is back at 3 waves (168 VGPRs, no live-range splits of that kind), and
-// tools/isa_lint.py -- run by tests/test_isa_lint.py on the BASELINE instantiations -- fails the build check if the pattern ever shows up again.
-// (VAR 9, the wave-cooperative overlap kernel: 3 waves as well -- at 128 VGPRs it spills 60-75 registers and the lint above has a hit in it)
-#define LART_WAVES_V4(V, S, D, P) (((S) || (V) == 9) ? 3 : 4)
+// tools/isa_lint.py -- run by tests/test_isa_lint.py on the BASELINE instantiations, with --build on every translation unit -- fails the build check if the pattern shows up.
+#ifdef LART_MIN_WAVES
+#define LART_WAVES_V5(V, S, D, P, LT) LART_MIN_WAVES
+#else
+#define LART_WAVES_V5(V, S, D, P, LT) lart_kernel_waves(V, S, D, P, LT)
 #endif
 // largest workgroup: the kernels that fit 128 VGPRs may run as ONE 1024-lane workgroup per CU (the same 4 waves per SIMD), which leaves the LDS that four
 // 256-lane workgroups spend on four copies of the tables to the J(x) window of the profile tallies (lart_gpu.hip, tally layout)
-#define LART_MAX_BLOCK(S, P) (LART_WAVES(S, P) >= 4 ? 1024 : 256)
-#define LART_MAX_BLOCK_V(V, S) ((!(S) && (V) != 9) ? 1024 : 256)
+#define LART_MAX_BLOCK_V5(V, S, D, P, LT) (LART_WAVES_V5(V, S, D, P, LT) >= 4 ? 1024 : 256)
 #ifndef LART_OVL_CELLS_PER_ROUND
 #define LART_OVL_CELLS_PER_ROUND 4           // CSR cells a lane in an overlap march walks per round of its wave
 #endif
@@ -108,7 +105,7 @@ __device__ inline void fly_coop(const KArgs &A, const Lds &l, Rng &g, Photon &p,
 
 // LT: line%line_type as a compile-time constant (1 single line, 2 Ly-alpha doublet, 7 hydrogen + deuterium), handed to the device functions through Lds
 template <int VAR, bool STOKES, bool DUST, bool PEEL, int LT>
-__global__ __launch_bounds__(LART_MAX_BLOCK_V(VAR, STOKES), LART_WAVES_V4(VAR, STOKES, DUST, PEEL)) void transport_kernel(KArgs A) {
+__global__ __launch_bounds__(LART_MAX_BLOCK_V5(VAR, STOKES, DUST, PEEL, LT), LART_WAVES_V5(VAR, STOKES, DUST, PEEL, LT)) void transport_kernel(KArgs A) {
     extern __shared__ double sh[];
     if (A.rep.nrep > 1) {                                      // this block's copy of the contended tally sections (DRep)
         const unsigned r = blockIdx.x % (unsigned)A.rep.nrep;

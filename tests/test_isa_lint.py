@@ -48,3 +48,11 @@ def test_the_lint_sees_the_pattern(tmp_path):
     ok.write_text("_Z1kv:\n.LBB0_301:\n\tv_readlane_b32 s52, v127, 19\n\tv_readlane_b32 s53, v127, 20\n\ts_or_b64 exec, exec, s[52:53]\n\tv_mov_b32_e32 v36, v68\n")
     assert len(isa_lint.lint(str(bad))) == 1 and isa_lint.lint(str(bad))[0][2] == ".LBB0_352"
     assert isa_lint.lint(str(ok)) == []
+
+
+@pytest.mark.skipif(not os.environ.get("LART_RUN_SLOW"), reason="compiles every translation unit to assembly (minutes of eight cores): LART_RUN_SLOW=1, or tools/isa_lint.py --build by hand")
+def test_every_translation_unit_is_lint_clean():
+    """tools/isa_lint.py --build: all instantiations the library ships, not only the BASELINE ones (round 4: a hit in transport_kernel<4,false,false,true,7>
+    at 128 VGPRs -> that instantiation is built for 3 waves per SIMD, lart_kernel_waves in csrc/lart_device.hpp)"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_lint.py"), "--build"], capture_output=True, text=True)
+    assert r.returncode == 0 and "0 hit(s)" in r.stdout, r.stdout[-3000:]
