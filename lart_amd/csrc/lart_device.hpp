@@ -130,16 +130,21 @@ struct DPeelCtl { unsigned long long q_head, d_n; };   // per queue buffer: prod
 // the octree with mirrored root-box faces, raytrace_amr.f90:176-201): after that (m, n, k) is no right-handed triad any more, and a peel record has to carry n
 // instead of leaving it to n = k x m (peel_load)
 template <int VAR> __device__ __forceinline__ bool peel_record_has_n(const lart_params &par) { return VAR == 5 || (VAR == 3 && (par.xy_symmetry || par.xyz_symmetry)); }
-enum { PQ_X = 0, PQ_Y, PQ_Z, PQ_KX, PQ_KY, PQ_KZ, PQ_WGT, PQ_XA, PQ_UX, PQ_UY, PQ_UZ, PQ_E1, PQ_E2, PQ_E3, PQ_GREC, PQ_NOSTOKES,
-       PQ_MX = PQ_NOSTOKES, PQ_MY, PQ_MZ, PQ_NX, PQ_NY, PQ_NZ, PQ_Q, PQ_U, PQ_V, PQ_COUNT };
+// one record = 18 doubles (144 B) without a Stokes vector, 28 (224 B) with one, 16-byte aligned, fields paired so that a record is written and read with
+// 16-byte accesses at constant offsets from ONE address (round 4; rounds 1-3 kept one plane per field: 21 plane bases in scalar registers, 21 address
+// computations and 21 narrow stores per record).  12-13: the cell / leaf / clump indices and the kind as four ints.
+enum { PQ_X = 0, PQ_Y, PQ_Z, PQ_KX, PQ_KY, PQ_KZ, PQ_WGT, PQ_XA, PQ_UX, PQ_UY, PQ_UZ, PQ_GREC, PQ_INTS, PQ_INTS2, PQ_E1, PQ_E2, PQ_E3, PQ_PAD, PQ_NOSTOKES,
+       PQ_MX = PQ_NOSTOKES, PQ_MY, PQ_MZ, PQ_Q, PQ_U, PQ_V, PQ_NX, PQ_NY, PQ_NZ, PQ_PAD2, PQ_COUNT };
+static_assert(PQ_NOSTOKES % 2 == 0 && PQ_COUNT % 2 == 0 && PQ_INTS % 2 == 0, "peel records are read and written in 16-byte pieces");
+__host__ __device__ constexpr unsigned pq_recd(bool stokes) { return stokes ? (unsigned)PQ_COUNT : (unsigned)PQ_NOSTOKES; }      // doubles per record
 enum { PEEL_DIRECT = 0, PEEL_RESONANCE = 1, PEEL_DUST = 2 };
 // Every producer wave owns one region of `region` consecutive record slots (64 lanes x (events of the launch + 1)) and fills it from the
 // front: the slot counter is a per-wave word in LDS, so queueing costs no global atomic (one counter for the whole grid serialises in
 // L2: measured +6 ms on a 9 ms launch); count[w] = records wave w wrote.  peel_kernel takes whole regions from the queue head.
 // scalar 24 of the fused tally buffer: deposit-list entries that did not fit (lart_gpu_get_tallies refuses the run; scal[7] likewise for the overlap lists)
 #define LART_SCAL_PEEL_DROPPED 24
-struct DPeelQ { double *f; int *cell; unsigned cap; unsigned region, nregions; unsigned *count;
-                unsigned *dep_idx; double *dep_tau; unsigned long long dep_cap; DPeelCtl *pctl; };   // deposit list: (record, observer) and the optical depth of the rays that came through (peel_kernel.hpp)   // f: PQ_COUNT planes of cap doubles; cell: 4 planes (ic, jc, kc | owner clump, kind)
+struct DPeelQ { double *f; unsigned cap; unsigned region, nregions; unsigned *count;
+                unsigned *dep_idx; double *dep_tau; unsigned long long dep_cap; DPeelCtl *pctl; };   // deposit list: (record, observer) and the optical depth of the rays that came through (peel_kernel.hpp)   // f: cap records of pq_recd(stokes) doubless (ic, jc, kc | owner clump, kind)
 
 // resonance + fluorescence multiplets (line types 4, 5, 6: lart_line_multiplet).  The per-level constants are wave-uniform and ride
 // in the kernel arguments; the per-branch tables are gathered with lane-varying (iup, idown) from global memory:
@@ -2383,19 +2388,17 @@ __device__ __forceinline__ void peel_emit(const KArgs &A, const Lds &l, bool dus
     base = __shfl(base, leader, 64);
     const unsigned k = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
     if (k >= A.pq.region) return;                             // cannot happen: the host sizes a region for 64 lanes x (events + 1) records
-    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, r = wave * A.pq.region + k, C = A.pq.cap;
-    double *f = A.pq.f;
-    f[PQ_X * C + r] = p.x; f[PQ_Y * C + r] = p.y; f[PQ_Z * C + r] = p.z; f[PQ_KX * C + r] = p.kx; f[PQ_KY * C + r] = p.ky; f[PQ_KZ * C + r] = p.kz;
-    f[PQ_WGT * C + r] = p.wgt; f[PQ_XA * C + r] = xa;
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, r = wave * A.pq.region + k;
+    double *rec = A.pq.f + r * pq_recd(STOKES);                // 16-byte aligned: hipMalloc base, record sizes of 144 / 224 B
+    double2 *r2 = reinterpret_cast<double2 *>(rec);
+    r2[PQ_X / 2] = make_double2(p.x, p.y); r2[PQ_Z / 2] = make_double2(p.z, p.kx); r2[PQ_KY / 2] = make_double2(p.ky, p.kz); r2[PQ_WGT / 2] = make_double2(p.wgt, xa);
     // what a single line (line type 1) would only repeat is left out: E1..E3 are line%E1..E3 and the recoil constant line%g_recoil0 there
     // (lart_params), and the third vector of the right-handed triad is n = k x m (peel_load)
-    if (kind == PEEL_RESONANCE) { f[PQ_UX * C + r] = ux; f[PQ_UY * C + r] = uy; f[PQ_UZ * C + r] = uz;
-        if (l.lt != 1) { f[PQ_E1 * C + r] = E1; f[PQ_E2 * C + r] = E2; f[PQ_E3 * C + r] = E3; f[PQ_GREC * C + r] = grec; } }
-    if (STOKES) { f[PQ_MX * C + r] = p.mx; f[PQ_MY * C + r] = p.my; f[PQ_MZ * C + r] = p.mz;
-                  if (peel_record_has_n<VAR>(A.par)) { f[PQ_NX * C + r] = p.nx; f[PQ_NY * C + r] = p.ny; f[PQ_NZ * C + r] = p.nz; }
-                  f[PQ_Q * C + r] = p.Q; f[PQ_U * C + r] = p.U; f[PQ_V * C + r] = p.V; }
-    int *q = A.pq.cell;
-    q[r] = p.ic; q[C + r] = p.jc; q[2 * C + r] = is_clump(VAR) ? p.icl : p.kc; q[3 * C + r] = kind;
+    if (kind == PEEL_RESONANCE) { r2[PQ_UX / 2] = make_double2(ux, uy); r2[PQ_UZ / 2] = make_double2(uz, grec);
+        if (l.lt != 1) { r2[PQ_E1 / 2] = make_double2(E1, E2); rec[PQ_E3] = E3; } }
+    *reinterpret_cast<int4 *>(rec + PQ_INTS) = make_int4(p.ic, p.jc, is_clump(VAR) ? p.icl : p.kc, kind);
+    if (STOKES) { r2[PQ_MX / 2] = make_double2(p.mx, p.my); r2[PQ_MZ / 2] = make_double2(p.mz, p.Q); r2[PQ_U / 2] = make_double2(p.U, p.V);
+                  if (peel_record_has_n<VAR>(A.par)) { r2[PQ_NX / 2] = make_double2(p.nx, p.ny); rec[PQ_NZ] = p.nz; } }
 }
 
 // ---------------------------------------------------------------------------------------------

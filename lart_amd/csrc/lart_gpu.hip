@@ -622,7 +622,7 @@ static int collect_events(lart_gpu *c) {
     return 0;
 }
 
-// the peel queue: two buffers of PQ_COUNT (Stokes) or PQ_NOSTOKES f64 planes + 4 int planes of `cap` records, the producer waves' counts and
+// the peel queue: two buffers of `cap` records of pq_recd(stokes) doubles (224 / 144 B: lart_device.hpp, PQ_*), the producer waves' counts and
 // the deposit list; sized once per run for pq_bytes_max of HBM (default: a quarter of the free memory, at most 64 GiB; LART_PEEL_QUEUE_GB)
 static int ensure_peel_queue(lart_gpu *c, int max_events) {
     if (!c->n_cu) { hipDeviceProp_t pr; HIPCHK(hipGetDeviceProperties(&pr, c->device)); c->n_cu = pr.multiProcessorCount; }
@@ -631,7 +631,7 @@ static int ensure_peel_queue(lart_gpu *c, int max_events) {
         for (int b = 0; b < 2; b++) { HIPCHK(hipEventCreateWithFlags(&c->ev_filled[b], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_drained[b], hipEventDisableTiming)); }
     }
     const size_t nobs = (size_t)(c->nobs > 0 ? c->nobs : 1);
-    const size_t planes = c->par.use_stokes ? (size_t)PQ_COUNT : (size_t)PQ_NOSTOKES, rec_bytes = planes * 8 + 16;
+    const size_t rec_bytes = (size_t)pq_recd(c->par.use_stokes != 0) * 8;
     const size_t lanes = (size_t)c->pool.n;
     if (!c->pq_bytes_max) {
         size_t fr = 0, tot = 0; HIPCHK(hipMemGetInfo(&fr, &tot));
@@ -654,7 +654,7 @@ static int ensure_peel_queue(lart_gpu *c, int max_events) {
         HIPCHK(hipMalloc(&c->d_pq, 2 * one));
         for (int b = 0; b < 2; b++) {
             char *base = (char *)c->d_pq + (size_t)b * one; DPeelQ &q = c->pq[b];
-            q.f = (double *)base; q.cell = (int *)(base + cap * planes * 8); q.cap = (unsigned)cap;
+            q.f = (double *)base; q.cap = (unsigned)cap;
             q.count = (unsigned *)(base + cap * rec_bytes);
             q.dep_tau = (double *)(base + cap * rec_bytes + cnt_bytes); q.dep_idx = (unsigned *)(q.dep_tau + dep_cap); q.dep_cap = dep_cap;
             q.pctl = (DPeelCtl *)(base + cap * rec_bytes + cnt_bytes + dep_cap * 16);

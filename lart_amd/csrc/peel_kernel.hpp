@@ -22,21 +22,24 @@
 
 template <int VAR, bool STOKES>
 __device__ inline void peel_load(const KArgs &A, const Lds &l, size_t r, bool full, Photon &p, int &kind, double &ux, double &uy, double &uz, double &E1, double &E2, double &E3, double &grec) {
-    const size_t C = A.pq.cap; const double *f = A.pq.f; const int *qc = A.pq.cell;
-    p.x = f[PQ_X * C + r]; p.y = f[PQ_Y * C + r]; p.z = f[PQ_Z * C + r]; p.kx = f[PQ_KX * C + r]; p.ky = f[PQ_KY * C + r]; p.kz = f[PQ_KZ * C + r];
-    p.xfreq = f[PQ_XA * C + r]; p.nsg = 0.0; p.nsd = 0.0; p.xfreq_ref = 0.0; p.inside = true; p.wgt = 0.0; p.Q = 0.0; p.U = 0.0; p.V = 0.0;
-    p.ic = qc[r]; p.jc = qc[C + r]; p.kc = qc[2 * C + r]; p.icl = 0;
+    const double *rec = A.pq.f + r * pq_recd(STOKES);          // one record, 16-byte pieces at constant offsets (lart_device.hpp, PQ_*)
+    const double2 *r2 = reinterpret_cast<const double2 *>(rec);
+    const double2 a0 = r2[PQ_X / 2], a1 = r2[PQ_Z / 2], a2 = r2[PQ_KY / 2], a3 = r2[PQ_WGT / 2];
+    const int4 qi = *reinterpret_cast<const int4 *>(rec + PQ_INTS);
+    p.x = a0.x; p.y = a0.y; p.z = a1.x; p.kx = a1.y; p.ky = a2.x; p.kz = a2.y;
+    p.xfreq = a3.y; p.nsg = 0.0; p.nsd = 0.0; p.xfreq_ref = 0.0; p.inside = true; p.wgt = 0.0; p.Q = 0.0; p.U = 0.0; p.V = 0.0;
+    p.ic = qi.x; p.jc = qi.y; p.kc = qi.z; p.icl = 0;
     if (is_clump(VAR)) { p.icl = p.kc; p.kc = 1; }
-    kind = qc[3 * C + r];
+    kind = qi.w;
     ux = 0.0; uy = 0.0; uz = 0.0; E1 = 0.0; E2 = 0.0; E3 = 0.0; grec = 0.0;
-    if (kind == PEEL_RESONANCE) { ux = f[PQ_UX * C + r]; uy = f[PQ_UY * C + r]; uz = f[PQ_UZ * C + r]; grec = (l.lt != 1) ? f[PQ_GREC * C + r] : A.par.g_recoil0; }
-    if (STOKES) { p.mx = f[PQ_MX * C + r]; p.my = f[PQ_MY * C + r]; p.mz = f[PQ_MZ * C + r];
-                  if (peel_record_has_n<VAR>(A.par)) { p.nx = f[PQ_NX * C + r]; p.ny = f[PQ_NY * C + r]; p.nz = f[PQ_NZ * C + r]; }   // (stored: a mirror flips k only)
-                  else { p.nx = p.ky * p.mz - p.kz * p.my; p.ny = p.kz * p.mx - p.kx * p.mz; p.nz = p.kx * p.my - p.ky * p.mx; } }   // n = k x m: (m, n, k) is a right-handed triad
+    if (kind == PEEL_RESONANCE) { const double2 u0 = r2[PQ_UX / 2], u1 = r2[PQ_UZ / 2]; ux = u0.x; uy = u0.y; uz = u1.x; grec = (l.lt != 1) ? u1.y : A.par.g_recoil0; }
+    if (STOKES) { const double2 m0 = r2[PQ_MX / 2], m1 = r2[PQ_MZ / 2]; p.mx = m0.x; p.my = m0.y; p.mz = m1.x;
+                  if (peel_record_has_n<VAR>(A.par)) { const double2 n0 = r2[PQ_NX / 2]; p.nx = n0.x; p.ny = n0.y; p.nz = rec[PQ_NZ]; }   // (stored: a mirror flips k only)
+                  else { p.nx = p.ky * p.mz - p.kz * p.my; p.ny = p.kz * p.mx - p.kx * p.mz; p.nz = p.kx * p.my - p.ky * p.mx; }   // n = k x m: (m, n, k) is a right-handed triad
+                  if (full) { const double2 s1 = r2[PQ_U / 2]; p.Q = m1.y; p.U = s1.x; p.V = s1.y; } }
     if (full) {                                                // what only the deposit reads
-        p.wgt = f[PQ_WGT * C + r];
-        if (kind == PEEL_RESONANCE) { if (l.lt != 1) { E1 = f[PQ_E1 * C + r]; E2 = f[PQ_E2 * C + r]; E3 = f[PQ_E3 * C + r]; } else { E1 = A.par.E1; E2 = A.par.E2; E3 = A.par.E3; } }
-        if (STOKES) { p.Q = f[PQ_Q * C + r]; p.U = f[PQ_U * C + r]; p.V = f[PQ_V * C + r]; }
+        p.wgt = a3.x;
+        if (kind == PEEL_RESONANCE) { if (l.lt != 1) { const double2 e0 = r2[PQ_E1 / 2]; E1 = e0.x; E2 = e0.y; E3 = rec[PQ_E3]; } else { E1 = A.par.E1; E2 = A.par.E2; E3 = A.par.E3; } }
     }
 }
 

@@ -49,7 +49,7 @@ for spec in "$@"; do
     smoke)   step smoke 400 python __graft_entry__.py smoke ;;
     avail)   step avail 120 rocprofv3 --list-avail ;;
     tests)   if [ -n "$a1" ]; then step tests 1100 python -m pytest tests -m gpu -q --timeout=900 --durations=40 -k "$a1"; else step tests 1100 python -m pytest tests -m gpu -q --timeout=900 --durations=40; fi ;;
-    pytest)  step pytest_$(echo "$a1" | tr -c 'A-Za-z0-9\n' '_' | cut -c1-40) 1100 python -m pytest ${a1//,/ } -m gpu -q --timeout=900 --durations=15 ;;
+    pytest)  step pytest_$(echo "$a1" | tr -c 'A-Za-z0-9\n' '_' | cut -c1-40) 1100 python -m pytest ${a1//,/ } -m gpu -q -rP --timeout=900 --durations=15 ;;
     bench)   step bench 900 python bench.py ${a1//,/ } ;;
     configs) step configs 900 python tools/perf_configs.py ;;
     perf)    for c in ${a1//,/ }; do step perf_$c 400 python tools/perf_kernel.py --config $c ${a2//,/ }; done ;;
