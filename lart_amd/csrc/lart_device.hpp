@@ -197,6 +197,7 @@ struct Lds { const double *vt; const double *xf, *yf, *zf;   // Voigt tables and
              unsigned *pq_cnt;           // this wave's record counter of the peel queue (LDS word), nullptr = no peel-off
              double *aux;                // line type 8 / H2: the weight budget of the block (8 doubles in LDS, flushed once per launch), nullptr: add to the global scalars
              const ClumpGeo *ct_geo; const ClumpPhys *ct_phys;   // VAR 7, populations of at most 128 clumps: the clump records staged in LDS (nullptr: read from global memory)
+             const DObs *obs;            // peel prefilter: the observers' records staged in LDS (nullptr: read from global memory)
              double fov_bx, fov_by;      // peel prefilter: tan of the half field of view (+ margin) in x and y, < 0 = no field-of-view test (lds_set_fov)
              unsigned char *coop;        // LART_COOP_BYTES per wave: scratch of the cooperative samplers (vz_core_coop / vz_wing_coop), nullptr = off
              int lt; double dnu_hz;      // line type (1 single line, 2 Ly-alpha doublet, 7 H + D) and DnuHK_Hz / delta_nu_HD_Hz: set from the kernel's template
@@ -214,7 +215,7 @@ __device__ inline Lds lds_stage(double *sh, const DGrid &g) {
     for (int i = threadIdx.x; i < nf; i += blockDim.x) sh[VT_END + i] = g.faces[i];
     __syncthreads();
     Lds l; l.vt = sh; l.xf = sh + VT_END; l.yf = l.xf + (g.nx + 1); l.zf = l.yf + (g.ny + 1);
-    l.dip_p2 = 0.0; l.dip_qs = 0.0; l.jp_P = nullptr; l.jp_Pn = nullptr; l.jp_J = nullptr; l.j_lo = 0; l.j_w = 0; l.coop = nullptr; l.pq_cnt = nullptr; l.fov_bx = -1.0; l.fov_by = -1.0; l.ct_geo = nullptr; l.ct_phys = nullptr; l.aux = nullptr; l.lt = 1; l.dnu_hz = 0.0; l.hd_ratio = 1.0; l.hd_ratio_a = 1.0; l.hd_nD = 0.0; l.ml_nup = 1; l.ml_coh = 0; l.ml_tab = nullptr; l.ml_itab = nullptr;
+    l.dip_p2 = 0.0; l.dip_qs = 0.0; l.jp_P = nullptr; l.jp_Pn = nullptr; l.jp_J = nullptr; l.j_lo = 0; l.j_w = 0; l.coop = nullptr; l.pq_cnt = nullptr; l.fov_bx = -1.0; l.fov_by = -1.0; l.obs = nullptr; l.ct_geo = nullptr; l.ct_phys = nullptr; l.aux = nullptr; l.lt = 1; l.dnu_hz = 0.0; l.hd_ratio = 1.0; l.hd_ratio_a = 1.0; l.hd_nD = 0.0; l.ml_nup = 1; l.ml_coh = 0; l.ml_tab = nullptr; l.ml_itab = nullptr;
     for (int i = 0; i < 3; i++) { l.ml_dE[i] = 0.0; l.ml_damp[i] = 1.0; l.ml_f12[i] = 0.0; }
     return l;
 }
@@ -1116,6 +1117,7 @@ __device__ __forceinline__ void edge_step_amr(const KArgs &A, const Lds &l, bool
 // the records of clump icl: from the workgroup's LDS copy when the population was staged there (lds_stage_clumps), else from global memory
 __device__ __forceinline__ ClumpGeo cl_geo(const KArgs &A, const Lds &l, int icl) { return l.ct_geo ? l.ct_geo[icl - 1] : A.cl.geo[icl - 1]; }
 __device__ __forceinline__ ClumpPhys cl_phys(const KArgs &A, const Lds &l, int icl) { return l.ct_phys ? l.ct_phys[icl - 1] : A.cl.phys[icl - 1]; }
+#define LART_LDS_OBSERVERS 16                           // observers whose records (96 B each) are staged in LDS for the peel prefilter
 #define LART_OVL_LDS_CLUMPS 128                          // largest population that is staged (= the populations that carry cg_mask)
 __device__ inline size_t lds_clump_bytes(const DClumps &c) { return (c.cg_mask && c.N <= LART_OVL_LDS_CLUMPS) ? (size_t)c.N * (sizeof(ClumpGeo) + sizeof(ClumpPhys)) : 0; }
 __device__ inline void lds_stage_clumps(Lds &l, const DClumps &c, unsigned char *at) {
@@ -2333,7 +2335,7 @@ __device__ __forceinline__ bool peel_all_opaque(const KArgs &A, const Lds &l, in
     else { const Cell &c = A.g.cell[(VAR == 3 || is_clump(VAR)) ? (size_t)(p.ic - 1) : cidx(A.g, p.ic, p.jc, p.kc)]; cc.rhokap = c.rhokap; cc.rhokapD = c.rhokapD; cc.voigt_a = c.voigt_a; cc.Dfreq = c.Dfreq; }
     const double Dfreq_bg = (VAR == 4) ? A.g.cell[0].Dfreq : cc.Dfreq;      // (the recoil term of the peel head uses the background record of a clump medium, as peel_head_res_* do)
     for (int i = 0; i < A.nobs; i++) {
-        const DObs &o = A.obs[i];
+        const DObs o = l.obs ? l.obs[i] : A.obs[i];          // (LDS copy: this test runs on every event and must not wait for memory)
         double qx = o.x - p.x, qy = o.y - p.y, qz = o.z - p.z;
         const double rinv = rsqrt_nr(qx * qx + qy * qy + qz * qz);
         qx = qx * rinv; qy = qy * rinv; qz = qz * rinv;

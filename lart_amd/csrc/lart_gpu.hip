@@ -509,13 +509,14 @@ static void size_j_window(lart_gpu *c) {
     if (!(c->jpa.calc_P || c->jpa.calc_Pnew) && !std::getenv("LART_LDS_J")) return;          // J alone: see above
     const int64_t nxf = c->par.nxfreq;
     const long long base = (long long)(VT_END + c->g.nx + c->g.ny + c->g.nz + 3 + LART_RNG_BUF * c->block + 2 * c->jpa.lds_bins) * 8 + (LART_COOP_BYTES + 4) * ((c->block + 63) / 64);
+    const long long tail = (c->par.save_peeloff && c->nobs > 0 && c->nobs <= LART_LDS_OBSERVERS) ? (long long)c->nobs * (long long)sizeof(DObs) + 16 : 0;      // the observers' records behind the window (lart_gpu_step)
     const int waves_cu = c->par.use_stokes ? 12 : 16;
     int per_cu = waves_cu * 64 / c->block; if (per_cu < 1) per_cu = 1;
     long long w = 0;
     for (int give = 0; give < 2 && w < 8; give++) {
         if (give && !(c->jpa.calc_P || c->jpa.calc_Pnew)) break;
         if (per_cu - give < 1) break;
-        w = ((long long)160 * 1024 / (per_cu - give) - 256 - base) / (8LL * c->jpa.nbins);
+        w = ((long long)160 * 1024 / (per_cu - give) - 256 - tail - base) / (8LL * c->jpa.nbins);
     }
     if (w > 64) w = 64; if (w > nxf) w = nxf;
     if (w < 8) return;
@@ -779,8 +780,10 @@ extern "C" int lart_gpu_step(lart_gpu *c, int32_t nsteps, int32_t max_events) {
     size_j_window(c); A.jpa = c->jpa;
     // Voigt tables + faces | ring of random draws [LART_RNG_BUF][block] | per-block P1, P1_new
     size_t shmem = (size_t)(VT_END + c->g.nx + c->g.ny + c->g.nz + 3 + LART_RNG_BUF * c->block + 2 * c->jpa.lds_bins + c->jpa.lds_j_w * c->jpa.nbins) * sizeof(double) + (size_t)(LART_COOP_BYTES + 4) * ((c->block + 63) / 64);   // ... + the wave-local scratch of vz_core_coop + the waves' peel-queue counters
-    if (c->par.line_type == 8 || h2) shmem = ((shmem + 15) & ~(size_t)15) + 8 * sizeof(double);      // ... + the block's accumulators of the ly_beta / H2 weight budget
-    if (var == 7 && c->cl.cg_mask && c->cl.N <= LART_OVL_LDS_CLUMPS) shmem = ((shmem + 15) & ~(size_t)15) + (size_t)c->cl.N * (sizeof(ClumpGeo) + sizeof(ClumpPhys));      // ... + the clump records (lds_stage_clumps)
+    shmem = (shmem + 15) & ~(size_t)15;                        // the tail of the kernel's LDS layout (transport_kernel.hpp), in its order:
+    if (c->par.line_type == 8 || h2) shmem += 8 * sizeof(double);                                                           // the block's accumulators of the ly_beta / H2 weight budget
+    if (var == 7 && c->cl.cg_mask && c->cl.N <= LART_OVL_LDS_CLUMPS) shmem += (((size_t)c->cl.N * (sizeof(ClumpGeo) + sizeof(ClumpPhys))) + 15) & ~(size_t)15;   // the clump records (lds_stage_clumps)
+    if (peel && c->nobs <= LART_LDS_OBSERVERS) shmem += (size_t)c->nobs * sizeof(DObs);                                     // the observers' records of the peel prefilter
     if (shmem > 160 * 1024) return fail("step: grid faces do not fit the 160 KiB LDS");
     const bool coop9 = var == 7 && ovl_coop9(c);
     if (c->block > 256 && kernel_waves_of(c) < 4)

@@ -139,17 +139,22 @@ __global__ __launch_bounds__(LART_MAX_BLOCK_V5(VAR, STOKES, DUST, PEEL, LT), LAR
         l_.pq_cnt = (unsigned *)(l_.coop - LART_COOP_BYTES * (threadIdx.x >> 6) + LART_COOP_BYTES * (blockDim.x >> 6)) + (threadIdx.x >> 6);
         if ((threadIdx.x & 63) == 0) *l_.pq_cnt = 0u;
     }
-    if (LT == 8 || LT == 9) {                                  // the block's accumulators of the weight budget, in the spare words behind the peel counters (8 doubles)
-        double *ax = (double *)(((size_t)((unsigned char *)sh + ((size_t)(VT_END + (A.g.nx + A.g.ny + A.g.nz + 3) + (size_t)LART_RNG_BUF * blockDim.x + 2 * (size_t)A.jpa.lds_bins + (size_t)nJ) * sizeof(double)
-                                          + (size_t)(LART_COOP_BYTES + 4) * (blockDim.x >> 6))) + 15) & ~(size_t)15);
+    // behind everything else, in this order (the launch is sized for them by lart_gpu_step, the same sums): the block's accumulators of the ly_beta / H2 weight budget
+    // (8 doubles), the clump records of a small overlapping population, the observers' records of the peel prefilter
+    size_t tail = (((size_t)(VT_END + (A.g.nx + A.g.ny + A.g.nz + 3) + (size_t)LART_RNG_BUF * blockDim.x + 2 * (size_t)A.jpa.lds_bins + (size_t)nJ) * sizeof(double)
+                     + (size_t)(LART_COOP_BYTES + 4) * (blockDim.x >> 6)) + 15) & ~(size_t)15;
+    if (LT == 8 || LT == 9) {
+        double *ax = (double *)((unsigned char *)sh + tail); tail += 8 * sizeof(double);
         if (threadIdx.x < 8) ax[threadIdx.x] = 0.0;
         __syncthreads();
         l_.aux = ax;
     }
-    if (is_ovl(VAR)) {                                         // the clump records of a small population, behind everything else (the offset lart_gpu_step sizes the launch for)
-        const size_t off = (((size_t)(VT_END + (A.g.nx + A.g.ny + A.g.nz + 3) + (size_t)LART_RNG_BUF * blockDim.x + 2 * (size_t)A.jpa.lds_bins + (size_t)nJ) * sizeof(double)
-                             + (size_t)(LART_COOP_BYTES + 4) * (blockDim.x >> 6)) + 15) & ~(size_t)15;
-        lds_stage_clumps(l_, A.cl, (unsigned char *)sh + off);
+    if (is_ovl(VAR)) { lds_stage_clumps(l_, A.cl, (unsigned char *)sh + tail); tail += (lds_clump_bytes(A.cl) + 15) & ~(size_t)15; }
+    if (PEEL && A.nobs > 0 && A.nobs <= LART_LDS_OBSERVERS) {
+        double *ob = (double *)((unsigned char *)sh + tail); const double *src = (const double *)A.obs;
+        for (int i = threadIdx.x; i < A.nobs * (int)(sizeof(DObs) / sizeof(double)); i += blockDim.x) ob[i] = src[i];
+        __syncthreads();
+        l_.obs = (const DObs *)ob;
     }
     const Lds l = l_;
     double *rng_lds = sh + VT_END + (A.g.nx + A.g.ny + A.g.nz + 3) + threadIdx.x;      // [LART_RNG_BUF][blockDim.x] draws
