@@ -6,6 +6,7 @@
 #   smoke                      __graft_entry__.smoke()
 #   avail                      rocprofv3 --list-avail (counter names of this GPU) -> gpurun_out/avail.log
 #   tests[:EXPR]               pytest -m gpu (optionally -k EXPR)
+#   slow:EXPR                  pytest -m "gpu and slow" -k EXPR with a heartbeat line per minute (long silent set-ups: the 74e6-clump placement)
 #   pytest:FILES               pytest -m gpu on the given files (commas for spaces)
 #   bench[:ARGS]               python bench.py ARGS            (ARGS with commas for spaces: bench:--steps,2,--no-cpu-baseline)
 #   configs                    tools/perf_configs.py (events/s of the other BASELINE configs)
@@ -49,6 +50,8 @@ for spec in "$@"; do
     smoke)   step smoke 400 python __graft_entry__.py smoke ;;
     avail)   step avail 120 rocprofv3 --list-avail ;;
     tests)   if [ -n "$a1" ]; then step tests 1100 python -m pytest tests -m gpu -q --timeout=900 --durations=40 -k "$a1"; else step tests 1100 python -m pytest tests -m gpu -q --timeout=900 --durations=40; fi ;;
+    slow)    ( while true; do sleep 60; echo "heartbeat $(date +%T)"; done ) & hb=$!
+             LART_RUN_SLOW=1 step slow 1150 python -m pytest tests -m "gpu and slow" -q -rP --timeout=1100 -k "$a1"; kill $hb 2>/dev/null ;;
     pytest)  step pytest_$(echo "$a1" | tr -c 'A-Za-z0-9\n' '_' | cut -c1-40) 1100 python -m pytest ${a1//,/ } -m gpu -q -rP --timeout=900 --durations=15 ;;
     bench)   step bench 900 python bench.py ${a1//,/ } ;;
     configs) step configs 900 python tools/perf_configs.py ;;
