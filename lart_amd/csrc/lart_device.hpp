@@ -1622,16 +1622,31 @@ __device__ __forceinline__ double wave_min_f64(double v) {
     v = fmin(v, dpp_f64<0x128>(v));                           // row_ror:8
     return fmin(fmin(rl_f64(v, 0), rl_f64(v, 16)), fmin(rl_f64(v, 32), rl_f64(v, 48)));
 }
-// the flights of the lanes with `need`, one after the other, by the whole wave (every lane of the wave calls this, converged).  TO_TAU: res = t_end, owner as
-// ovl_start / ovl_advance / ovl_finish leave them (lim = the optical depth to go), *oh = the list carried to the next flight; else res = the optical depth to the
-// sphere's surface (raytrace_to_edge_clump_overlap_capped with lim = the cap).
-template <bool TO_TAU>
-__device__ inline void ovl_coop(const KArgs &A, const Lds &l, bool dust, bool need, const Photon &p, double lim, double u_own, unsigned &nsteps, double &res, int &owner, OvlHold *oh) {
+// minimum over the lanes [B, B + W) of a value whose rows of 16 lanes already hold their minima in every lane (the four DPP steps of wave_min_f64)
+template <int W> __device__ __forceinline__ double group_min_rows(double v, int B) {
+    if (W == 16) return rl_f64(v, B);
+    if (W == 32) return fmin(rl_f64(v, B), rl_f64(v, B + 16));
+    return fmin(fmin(rl_f64(v, 0), rl_f64(v, 16)), fmin(rl_f64(v, 32), rl_f64(v, 48)));
+}
+__device__ __forceinline__ double row_min_f64(double v) {
+    v = fmin(v, dpp_f64<0xB1>(v)); v = fmin(v, dpp_f64<0x4E>(v)); v = fmin(v, dpp_f64<0x124>(v)); v = fmin(v, dpp_f64<0x128>(v));
+    return v;
+}
+// the flights of the lanes with `need` by the whole wave (every lane of the wave calls this, converged): W lanes per flight, one lane per clump, 64 / W flights side by
+// side -- what depends on (flight, clump) is computed for all of them at once (containment, distance bound, sort key, opacity at the ray's frequency, ENTER / EXIT
+// times), what depends on the flight alone (the order of the holders, the sums over them, the walk over the events) one flight after the other on the lanes
+// [B, B + W) of its group.  TO_TAU: res = t_end, owner as ovl_start / ovl_advance / ovl_finish leave them (lim = the optical depth to go), *oh = the list carried to the
+// next flights; else res = the optical depth to the sphere's surface (raytrace_to_edge_clump_overlap_capped with lim = the cap).
+template <bool TO_TAU, int W>
+__device__ inline void ovl_coop_w(const KArgs &A, const Lds &l, bool dust, bool need, const Photon &p, double lim, double u_own, unsigned &nsteps, double &res, int &owner, OvlHold *oh) {
+    static_assert(W == 32 || W == 64, "one or two flights per turn");
+    constexpr int G = 64 / W;
     const DClumps &c = A.cl; const int cg = c.cgx; const int N = (int)c.N;
-    const int j = (int)(threadIdx.x & 63u);                   // this lane's clump: number j + 1
+    const int lane = (int)(threadIdx.x & 63u), j = lane & (W - 1), grp = lane / W;      // this lane's clump: number j + 1; its group of lanes
     const bool has = j < N;
     const double INF = LART_HUGEST;
-    // what depends on the flight alone, computed by the flights' own lanes side by side (two fp64 square roots and three conversions less in every turn of the loop below)
+    const unsigned long long GM = W == 64 ? ~0ull : ((1ull << (W & 63)) - 1ull);
+    // what depends on the flight alone, computed by the flights' own lanes side by side
     double my_tsp = 0.0, my_rp = 0.0; int my_ci = 0, my_cj = 0, my_ck = 0;
     if (need) {
         my_tsp = sphere_exit_dist(c, p.x, p.y, p.z, p.kx, p.ky, p.kz);
@@ -1640,109 +1655,128 @@ __device__ inline void ovl_coop(const KArgs &A, const Lds &l, bool dust, bool ne
     }
     unsigned long long todo = __ballot(need);
     while (todo) {
-        const int L = __ffsll((long long)todo) - 1; todo &= todo - 1;
-        const double xp = rl_f64(p.x, L), yp = rl_f64(p.y, L), zp = rl_f64(p.z, L), kx = rl_f64(p.kx, L), ky = rl_f64(p.ky, L), kz = rl_f64(p.kz, L);
-        const double xfreq_g = rl_f64(p.xfreq, L), limL = rl_f64(lim, L), u_ownL = rl_f64(u_own, L);
-        double out = 0.0; int own = 0; unsigned cnt = 0;      // the flight's result (the same in every lane)
-        int hna = 0; double hreach = 0.0; unsigned long long hw0 = 0, hw1 = 0, hw2 = 0, hw3 = 0;      // the list it leaves behind
-        const double t_sp = rl_f64(my_tsp, L);
-        if (t_sp > 0.0) {
-            if (TO_TAU) if (j == 0) OVL_STAT(A, 1, 1);             // holder lists rebuilt
-            const ClumpGeo g = has ? l.ct_geo[j] : ClumpGeo{0.0, 0.0, 0.0, -1.0};
-            const double rx = xp - g.x, ry = yp - g.y, rz = zp - g.z, rr = rx * rx + ry * ry + rz * rz;
-            const bool in = has && rr <= g.r2;                // active_set_at_point (clump_mod.f90:1594-1634): a holder is registered in the point's own cell, so "every clump" finds the same set
-            const unsigned long long hm = __ballot(in);
-            int na = __popcll(hm);
-            // the order of the list: first cell of the 27-cell scan that registers the clump, then the clump number (see ovl_start); rank = this holder's place
-            const int ci = rl_i32(my_ci, L), cj = rl_i32(my_cj, L), ck = rl_i32(my_ck, L);
-            int rank = 0; double order_reach = INF;
-            if (na > 1) {
-                const double rc = sqrt(g.r2);
-                const int b0 = max(0, (int)((g.x - c.cg_min - rc) * c.cg_inv)), b1 = max(0, (int)((g.y - c.cg_min - rc) * c.cg_inv)), b2 = max(0, (int)((g.z - c.cg_min - rc) * c.cg_inv));
-                const int i0 = max(b0, ci - 1), j0 = max(b1, cj - 1), k0 = max(b2, ck - 1);
-                const long long key = ((((long long)k0 * cg + j0) * cg + i0) << 31) | (long long)(j + 1);
-                const int wxj = ci - 1 - b0, wyj = cj - 1 - b1, wzj = ck - 1 - b2;
-                int wx = 1 << 20, wy = 1 << 20, wz = 1 << 20;
-                for (unsigned long long m = hm; m; m &= m - 1) {
-                    const int h = __ffsll((long long)m) - 1;
-                    rank += (rl_i64(key, h) < key) ? 1 : 0;
-                    wx = min(wx, rl_i32(wxj, h)); wy = min(wy, rl_i32(wyj, h)); wz = min(wz, rl_i32(wzj, h));
+        // the flights of this turn: group q takes the q-th of the waiting lanes
+        const int L0 = __ffsll((long long)todo) - 1; todo &= todo - 1;
+        int L1 = -1; if (G > 1 && todo) { L1 = __ffsll((long long)todo) - 1; todo &= todo - 1; }
+        const int mine = grp == 0 ? L0 : L1;
+        const bool live = mine >= 0;
+        const int src = live ? mine : lane;
+        // ---- per (flight, clump): every lane for its group's flight
+        const double xq = __shfl(p.x, src, 64), yq = __shfl(p.y, src, 64), zq = __shfl(p.z, src, 64), kxq = __shfl(p.kx, src, 64), kyq = __shfl(p.ky, src, 64), kzq = __shfl(p.kz, src, 64);
+        const double xfq = __shfl(p.xfreq, src, 64), tspq = __shfl(my_tsp, src, 64);
+        const int ciq = __shfl(my_ci, src, 64), cjq = __shfl(my_cj, src, 64), ckq = __shfl(my_ck, src, 64);
+        const ClumpGeo g = has ? l.ct_geo[j] : ClumpGeo{0.0, 0.0, 0.0, -1.0};      // this lane's clump (read again in every turn: LDS is cheaper than eight registers held across the loop)
+        const double rx = xq - g.x, ry = yq - g.y, rz = zq - g.z, rr = rx * rx + ry * ry + rz * rz;
+        const bool in = live && has && rr <= g.r2;            // active_set_at_point (clump_mod.f90:1594-1634): a holder is registered in the point's own cell, so "every clump" finds the same set
+        const unsigned long long hm_all = __ballot(in);
+        const double rc = sqrt(fmax(g.r2, 0.0));
+        const int b0 = max(0, (int)((g.x - c.cg_min - rc) * c.cg_inv)), b1 = max(0, (int)((g.y - c.cg_min - rc) * c.cg_inv)), b2 = max(0, (int)((g.z - c.cg_min - rc) * c.cg_inv));
+        const int i0 = max(b0, ciq - 1), j0 = max(b1, cjq - 1), k0 = max(b2, ckq - 1);
+        const long long key = ((((long long)k0 * cg + j0) * cg + i0) << 31) | (long long)(j + 1);      // the order of the list: first cell of the 27-cell scan that registers the clump, then the clump number (ovl_start)
+        const int wxj = ciq - 1 - b0, wyj = cjq - 1 - b1, wzj = ckq - 1 - b2;
+        double kapj = 0.0;                                    // every clump's opacity at the ray's frequency: constant along the ray (sum_kap_active :621-636 evaluates it per interval)
+        if (live && has) { const ClumpPhys ph = l.ct_phys[j]; kapj = kappa_clump(A, l, dust, xfq - ulos_clump(A, ph, kxq, kyq, kzq), ph); }
+        double dsrf = INF;                                    // lower bound of | |r| - R | (single precision, rounded towards zero: a bound, not a result)
+        if (TO_TAU && has) { const float num = (float)fabs(rr - g.r2) * 0.999998f, den = (sqrtf((float)rr) + sqrtf((float)g.r2)) * 1.000002f; dsrf = (double)(num / den); }
+        if (TO_TAU) dsrf = row_min_f64(dsrf);
+        const double bq = rx * kxq + ry * kyq + rz * kzq;       // ray_sphere_isect :1362-1386
+        double disc = bq * bq - rr + g.r2;
+        bool hit = live && has && !(disc < 0.0);
+        disc = sqrt(fmax(disc, 0.0));
+        const double te = -bq - disc, tx2 = -bq + disc;
+        hit = hit && tx2 > 0.0 && !(te > tspq);
+        double t_in = (hit && te > 0.0) ? te : INF, t_out = hit ? fmin(tx2, tspq) : INF;     // ENTER only when the origin is outside
+        int v_act = 0;                                        // the holder lists: lane B + m = the m-th holder of the group's flight
+        // ---- per flight
+        for (int q = 0; q < G; q++) {
+            const int L = q == 0 ? L0 : L1; if (L < 0) break;
+            const int B = q * W; const bool ing = grp == q;
+            const double xp = rl_f64(p.x, L), yp = rl_f64(p.y, L), zp = rl_f64(p.z, L), limL = rl_f64(lim, L), u_ownL = rl_f64(u_own, L), t_sp = rl_f64(my_tsp, L);
+            double out = 0.0; int own = 0; unsigned cnt = 0;  // the flight's result (the same in every lane)
+            int hna = 0; double hreach = 0.0; unsigned long long hw0 = 0, hw1 = 0, hw2 = 0, hw3 = 0;      // the list it leaves behind
+            if (t_sp > 0.0) {
+                if (TO_TAU) if (lane == 0) OVL_STAT(A, 1, 1);      // holder lists rebuilt
+                const unsigned long long hm = (hm_all >> B) & GM;
+                int na = __popcll(hm);
+                int rank = 0; double order_reach = INF;
+                if (na > 1) {
+                    const int ci = rl_i32(my_ci, L), cj = rl_i32(my_cj, L), ck = rl_i32(my_ck, L);
+                    int wx = 1 << 20, wy = 1 << 20, wz = 1 << 20;
+                    for (unsigned long long m = hm; m; m &= m - 1) {
+                        const int h = B + __ffsll((long long)m) - 1;
+                        rank += (rl_i64(key, h) < key) ? 1 : 0;
+                        wx = min(wx, rl_i32(wxj, h)); wy = min(wy, rl_i32(wyj, h)); wz = min(wz, rl_i32(wzj, h));
+                    }
+                    const double x0 = c.cg_min + (double)ci * c.cg_d, y0 = c.cg_min + (double)cj * c.cg_d, z0 = c.cg_min + (double)ck * c.cg_d;
+                    if (wx >= 0 && wy >= 0 && wz >= 0 && ci >= 1 && cj >= 1 && ck >= 1) order_reach = fmin(fmin((xp - x0) + (double)wx * c.cg_d, (yp - y0) + (double)wy * c.cg_d), (zp - z0) + (double)wz * c.cg_d);
+                    else order_reach = fmin(fmin(fmin(xp - x0, x0 + c.cg_d - xp), fmin(yp - y0, y0 + c.cg_d - yp)), fmin(zp - z0, z0 + c.cg_d - zp));
                 }
-                const double x0 = c.cg_min + (double)ci * c.cg_d, y0 = c.cg_min + (double)cj * c.cg_d, z0 = c.cg_min + (double)ck * c.cg_d;
-                if (wx >= 0 && wy >= 0 && wz >= 0 && ci >= 1 && cj >= 1 && ck >= 1) order_reach = fmin(fmin((xp - x0) + (double)wx * c.cg_d, (yp - y0) + (double)wy * c.cg_d), (zp - z0) + (double)wz * c.cg_d);
-                else order_reach = fmin(fmin(fmin(xp - x0, x0 + c.cg_d - xp), fmin(yp - y0, y0 + c.cg_d - yp)), fmin(zp - z0, z0 + c.cg_d - zp));
-            }
-            int v_act = __builtin_amdgcn_ds_permute((in ? rank : 63) << 2, j + 1);       // lane m = the m-th holder (lanes >= na: unused)
-            // every clump's opacity at the ray's frequency: constant along the ray (sum_kap_active :621-636 evaluates it per interval)
-            double kapj = 0.0;
-            if (has) { const ClumpPhys ph = l.ct_phys[j]; kapj = kappa_clump(A, l, dust, xfreq_g - ulos_clump(A, ph, kx, ky, kz), ph); }
-            auto sum_act = [&]() { double s = 0.0; for (int m = 0; m < na; m++) s = s + rl_f64(kapj, rl_i32(v_act, m) - 1); return s; };
-            auto draw_owner = [&](double kap) { double cumul = 0.0; int o = 0;                // sample_owner_clump :644-664
-                for (int m = 0; m < na; m++) { o = rl_i32(v_act, m); cumul = cumul + rl_f64(kapj, o - 1); if (u_ownL * kap <= cumul) break; } return o; };
-            bool finished = false;
-            if (TO_TAU && na > 0) {                           // the in-clump fast path of ovl_start
-                const double kap = sum_act();
-                if (kap > 0.0) {
-                    const float num = (float)fabs(rr - g.r2) * 0.999998f, den = (sqrtf((float)rr) + sqrtf((float)g.r2)) * 1.000002f;
-                    const double d_srf = wave_min_f64(has ? (double)(num / den) : INF);
-                    const double s_ = limL / kap, reach = fmin(fmin(order_reach, t_sp), d_srf);
-                    if (s_ < reach * (1.0 - 1e-9)) {
-                        cnt++; out = s_; own = draw_owner(kap);
-                        if (oh && na <= LART_OVL_HOLD) {
-                            const double ball = fmin(reach, c.sphere_R - rl_f64(my_rp, L));
-                            if (ball - s_ > 0.0) {
-                                hna = na; hreach = ball;
-                                for (int m = 0; m < na; m++) { const unsigned long long v = (unsigned long long)(unsigned)rl_i32(v_act, m) << ((m & 1) * 32);
-                                    if (m < 2) hw0 |= v; else if (m < 4) hw1 |= v; else if (m < 6) hw2 |= v; else hw3 |= v; }
-                                if (j == 0) OVL_STAT(A, 3, 1);
+                { const int got = __builtin_amdgcn_ds_permute(((ing && in) ? B + rank : (G > 1 ? ((B + W) & 63) : 63)) << 2, j + 1); if (ing) v_act = got; }      // lane B + m = the m-th holder (everybody else aims at a lane whose value is dropped)
+                auto sum_act = [&]() { double s = 0.0; for (int m = 0; m < na; m++) s = s + rl_f64(kapj, B + rl_i32(v_act, B + m) - 1); return s; };
+                auto draw_owner = [&](double kap) { double cumul = 0.0; int o = 0;                // sample_owner_clump :644-664
+                    for (int m = 0; m < na; m++) { o = rl_i32(v_act, B + m); cumul = cumul + rl_f64(kapj, B + o - 1); if (u_ownL * kap <= cumul) break; } return o; };
+                bool finished = false;
+                if (TO_TAU && na > 0) {                           // the in-clump fast path of ovl_start
+                    const double kap = sum_act();
+                    if (kap > 0.0) {
+                        const double d_srf = group_min_rows<W>(dsrf, B);
+                        const double s_ = limL / kap, reach = fmin(fmin(order_reach, t_sp), d_srf);
+                        if (s_ < reach * (1.0 - 1e-9)) {
+                            cnt++; out = s_; own = draw_owner(kap);
+                            if (oh && na <= LART_OVL_HOLD) {
+                                const double ball = fmin(reach, c.sphere_R - rl_f64(my_rp, L));
+                                if (ball - s_ > 0.0) {
+                                    hna = na; hreach = ball;
+                                    for (int m = 0; m < na; m++) { const unsigned long long v = (unsigned long long)(unsigned)rl_i32(v_act, B + m) << ((m & 1) * 32);
+                                        if (m < 2) hw0 |= v; else if (m < 4) hw1 |= v; else if (m < 6) hw2 |= v; else hw3 |= v; }
+                                    if (lane == 0) OVL_STAT(A, 3, 1);
+                                }
                             }
+                            if (lane == 0) OVL_STAT(A, 2, 1);
+                            finished = true;
                         }
-                        if (j == 0) OVL_STAT(A, 2, 1);
-                        finished = true;
                     }
                 }
-            }
-            if (!finished) {                                  // the march: collect_ray_events_overlap (clump_mod.f90:1664-1693) + the interval walk (:713-743 / :884-897)
-                if (TO_TAU) { if (j == 0) { OVL_STAT(A, 4, 1); OVL_STAT(A, 7, na); } }
-                const double b = rx * kx + ry * ky + rz * kz;                                 // ray_sphere_isect :1362-1386
-                double disc = b * b - rr + g.r2;
-                bool hit = has && !(disc < 0.0);
-                disc = sqrt(fmax(disc, 0.0));
-                const double te = -b - disc, tx2 = -b + disc;
-                hit = hit && tx2 > 0.0 && !(te > t_sp);
-                double t_in = (hit && te > 0.0) ? te : INF, t_out = hit ? fmin(tx2, t_sp) : INF;     // ENTER only when the origin is outside
-                double t_cur = 0.0, acc = TO_TAU ? limL : 0.0;
-                for (;;) {
-                    const double cand = fmin(t_in, t_out), tmin = wave_min_f64(cand);
-                    const bool ev = tmin < INF;
-                    const double t_next = fmin(ev ? tmin : t_sp, t_sp), dt = t_next - t_cur;
-                    if (dt > 0.0) {
-                        const double kap = sum_act();
-                        cnt++;
-                        if (TO_TAU) { if (j == 0) OVL_STAT(A, 6, 1);
-                            if (kap > 0.0 && acc <= kap * dt) { out = t_cur + acc / kap; own = draw_owner(kap); break; }
-                            acc = acc - kap * dt;
-                        } else { acc = acc + kap * dt; if (acc >= limL) break; }
-                        t_cur = t_next;
+                if (!finished) {                                  // the march: collect_ray_events_overlap (clump_mod.f90:1664-1693) + the interval walk (:713-743 / :884-897)
+                    if (TO_TAU) { if (lane == 0) { OVL_STAT(A, 4, 1); OVL_STAT(A, 7, na); } }
+                    double t_cur = 0.0, acc = TO_TAU ? limL : 0.0;
+                    for (;;) {
+                        const double cand = fmin(t_in, t_out), tmin = group_min_rows<W>(row_min_f64(cand), B);
+                        const bool ev = tmin < INF;
+                        const double t_next = fmin(ev ? tmin : t_sp, t_sp), dt = t_next - t_cur;
+                        if (dt > 0.0) {
+                            const double kap = sum_act();
+                            cnt++;
+                            if (TO_TAU) { if (lane == 0) OVL_STAT(A, 6, 1);
+                                if (kap > 0.0 && acc <= kap * dt) { out = t_cur + acc / kap; own = draw_owner(kap); break; }
+                                acc = acc - kap * dt;
+                            } else { acc = acc + kap * dt; if (acc >= limL) break; }
+                            t_cur = t_next;
+                        }
+                        if (!ev) break;                                                           // that was the last interval, up to the surface
+                        const int Wn = __ffsll((long long)((__ballot(cand == tmin) >> B) & GM)) - 1;      // apply_event :769-786 (the lowest clump number of the group at that time)
+                        const bool enter = rl_i32((t_in <= t_out) ? 1 : 0, B + Wn) != 0;
+                        if (enter) { if (lane == B + na) v_act = Wn + 1; na++; if (lane == B + Wn) t_in = INF; }
+                        else {
+                            const unsigned long long at = (__ballot(ing && j < na && v_act == Wn + 1) >> B) & GM;
+                            if (at) { const int pos = __ffsll((long long)at) - 1, last = rl_i32(v_act, B + na - 1); if (lane == B + pos) v_act = last; na--; }
+                            if (lane == B + Wn) t_out = INF;
+                        }
                     }
-                    if (!ev) break;                                                           // that was the last interval, up to the surface
-                    const int W = __ffsll((long long)__ballot(cand == tmin)) - 1;             // apply_event :769-786
-                    const bool enter = rl_i32((t_in <= t_out) ? 1 : 0, W) != 0;
-                    if (enter) { if (j == na) v_act = W + 1; na++; if (j == W) t_in = INF; }
-                    else {
-                        const unsigned long long at = __ballot(j < na && v_act == W + 1);
-                        if (at) { const int pos = __ffsll((long long)at) - 1, last = rl_i32(v_act, na - 1); if (j == pos) v_act = last; na--; }
-                        if (j == W) t_out = INF;
-                    }
+                    if (TO_TAU) { if (own == 0) out = t_sp; } else out = acc;
                 }
-                if (TO_TAU) { if (own == 0) out = t_sp; } else out = acc;
             }
-        }
-        if (j == L) {
-            res = out; owner = own; nsteps += cnt;
-            if (TO_TAU && oh) { oh->na = hna; oh->reach = hreach; oh->x0 = xp; oh->y0 = yp; oh->z0 = zp; oh->w0 = hw0; oh->w1 = hw1; oh->w2 = hw2; oh->w3 = hw3; }
+            if (lane == L) {
+                res = out; owner = own; nsteps += cnt;
+                if (TO_TAU && oh) { oh->na = hna; oh->reach = hreach; oh->x0 = xp; oh->y0 = yp; oh->z0 = zp; oh->w0 = hw0; oh->w1 = hw1; oh->w2 = hw2; oh->w3 = hw3; }
+            }
         }
     }
+}
+template <bool TO_TAU>
+__device__ inline void ovl_coop(const KArgs &A, const Lds &l, bool dust, bool need, const Photon &p, double lim, double u_own, unsigned &nsteps, double &res, int &owner, OvlHold *oh) {
+    if (A.cl.N <= 32) ovl_coop_w<TO_TAU, 32>(A, l, dust, need, p, lim, u_own, nsteps, res, owner, oh);       // two flights side by side (the shipped overlap inputs have 30 clumps)
+    else ovl_coop_w<TO_TAU, 64>(A, l, dust, need, p, lim, u_own, nsteps, res, owner, oh);
 }
 
 // tau to the grid edge (dist < 0) or to a finite distance (raytrace_to_dist_car :89-195, VAR 0 only)
