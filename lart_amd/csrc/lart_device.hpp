@@ -2347,7 +2347,7 @@ __device__ inline double rsqrt_nr(double x) {
 }
 // opacity constants of the cell (leaf, owner clump) an event happens in, as scatter_pre read them: handed to the peel prefilter so that it does not gather the record again
 // (the gather sat exposed in front of the record stores: 3 waves per SIMD do not hide it)
-struct PeelCell { double rhokap, rhokapD, voigt_a, Dfreq; };
+struct PeelCell { double rhokap, rhokapD, voigt_a, Dfreq; int uni; };      // uni: Cell::pad of a Cartesian medium = cells of the uniform cube around the cell (lart_gpu.hip, uniform_cubes)
 template <int VAR, bool STOKES>
 __device__ __forceinline__ bool peel_all_opaque(const KArgs &A, const Lds &l, int kind, const Photon &p, double xa, double ux, double uy, double uz, double grec, bool dust, const PeelCell *pc = nullptr) {
     if (kind == PEEL_DIRECT || A.heal_nside > 0 || VAR == 1) return false;
@@ -2365,8 +2365,8 @@ __device__ __forceinline__ bool peel_all_opaque(const KArgs &A, const Lds &l, in
     const double T = LART_TAU_HUGE * (1.0 + 1e-9);
     PeelCell cc;
     if (pc) cc = *pc;
-    else if (VAR == 4) { const ClumpPhys ph = A.cl.phys[p.icl - 1]; cc.rhokap = ph.rhokap; cc.rhokapD = ph.rhokapD; cc.voigt_a = ph.voigt_a; cc.Dfreq = ph.Dfreq; }
-    else { const Cell &c = A.g.cell[(VAR == 3 || is_clump(VAR)) ? (size_t)(p.ic - 1) : cidx(A.g, p.ic, p.jc, p.kc)]; cc.rhokap = c.rhokap; cc.rhokapD = c.rhokapD; cc.voigt_a = c.voigt_a; cc.Dfreq = c.Dfreq; }
+    else if (VAR == 4) { const ClumpPhys ph = A.cl.phys[p.icl - 1]; cc.rhokap = ph.rhokap; cc.rhokapD = ph.rhokapD; cc.voigt_a = ph.voigt_a; cc.Dfreq = ph.Dfreq; cc.uni = 0; }
+    else { const Cell &c = A.g.cell[(VAR == 3 || is_clump(VAR)) ? (size_t)(p.ic - 1) : cidx(A.g, p.ic, p.jc, p.kc)]; cc.rhokap = c.rhokap; cc.rhokapD = c.rhokapD; cc.voigt_a = c.voigt_a; cc.Dfreq = c.Dfreq; cc.uni = (VAR == 3 || is_clump(VAR)) ? 0 : (int)c.pad; }
     const double Dfreq_bg = (VAR == 4) ? A.g.cell[0].Dfreq : cc.Dfreq;      // (the recoil term of the peel head uses the background record of a clump medium, as peel_head_res_* do)
     for (int i = 0; i < A.nobs; i++) {
         const DObs o = l.obs ? l.obs[i] : A.obs[i];          // (LDS copy: this test runs on every event and must not wait for memory)
@@ -2401,7 +2401,10 @@ __device__ __forceinline__ bool peel_all_opaque(const KArgs &A, const Lds &l, in
             const AmrGeom g = A.amr.geom[A.amr.icell_of_leaf[p.ic - 1] - 1];
             dx = qx > 0.0 ? (g.cx + g.ch) - p.x : p.x - (g.cx - g.ch); dy = qy > 0.0 ? (g.cy + g.ch) - p.y : p.y - (g.cy - g.ch); dz = qz > 0.0 ? (g.cz + g.ch) - p.z : p.z - (g.cz - g.ch);
         } else {
-            dx = qx > 0.0 ? l.xf[p.ic] - p.x : p.x - l.xf[p.ic - 1]; dy = qy > 0.0 ? l.yf[p.jc] - p.y : p.y - l.yf[p.jc - 1]; dz = qz > 0.0 ? l.zf[p.kc] - p.z : p.z - l.zf[p.kc - 1];
+            // Round 4: not the rest of the first cell but the way out of the largest cube of copies of this cell around it (Cell::pad, computed by lart_gpu_set_grid_car): the
+            // ray keeps its frequency and its opacity until it has crossed R more cells on one axis, so kappa x (that path) is what the march would add up, cell by cell
+            const int R = cc.uni;
+            dx = qx > 0.0 ? l.xf[p.ic + R] - p.x : p.x - l.xf[p.ic - 1 - R]; dy = qy > 0.0 ? l.yf[p.jc + R] - p.y : p.y - l.yf[p.jc - 1 - R]; dz = qz > 0.0 ? l.zf[p.kc + R] - p.z : p.z - l.zf[p.kc - 1 - R];
         }
         bool opaque = kap * dz >= T * fabs(qz);
         if (VAR != 2) opaque = opaque && kap * dx >= T * fabs(qx) && kap * dy >= T * fabs(qy);
@@ -2579,7 +2582,7 @@ __device__ __forceinline__ bool dust_absorb(const KArgs &A, const Lds &l, Rng &g
 //   scatter_pre  -> dust-or-gas decision; a dust event completes here; a resonance event returns true with the sampler's
 //                   arguments in ScatCtx (x in the local Doppler units of the cell / clump)
 //   scatter_post -> everything after do_resonance's `uz = rand_resonance_vz(x, a)`
-struct ScatCtx { double va, xloc, cl_scale, cl_Dfreq, xsamp, dnu, vsamp, rhokap, rhokapD; int species, iup, h2; };   // h2: 1-based H2 line of an H2 scattering (pseudo line type 9), 0 = an H I event;   // xsamp / vsamp: the sampler's frequency and Voigt parameter (2P1/2 level: xloc + dnu; deuterium, species 2: the D frame)
+struct ScatCtx { double va, xloc, cl_scale, cl_Dfreq, xsamp, dnu, vsamp, rhokap, rhokapD; int species, iup, h2, uni; };   // h2: 1-based H2 line of an H2 scattering (pseudo line type 9), 0 = an H I event;   // xsamp / vsamp: the sampler's frequency and Voigt parameter (2P1/2 level: xloc + dnu; deuterium, species 2: the D frame)
 template <int VAR, bool STOKES, bool DUST, bool PEEL>
 __device__ __forceinline__ bool scatter_pre(const KArgs &A, const Lds &l, Rng &g, Photon &p, unsigned &npeel, ScatCtx &sc) {
     const lart_params &par = A.par;
@@ -2662,6 +2665,7 @@ __device__ __forceinline__ bool scatter_pre(const KArgs &A, const Lds &l, Rng &g
         if (ib >= 1) atomicAdd(&(l.jp_P ? l.jp_P : A.jpa.P1)[ib - 1], p.wgt / (c.rhokap * c.Dfreq / A.jpa.cross0));
     }
     sc.va = va; sc.cl_scale = cl_scale; sc.cl_Dfreq = cl_Dfreq; sc.xloc = is_clump(VAR) ? p.xfreq * cl_scale : p.xfreq;
+    sc.uni = (VAR == 3 || is_clump(VAR)) ? 0 : (int)c.pad;
     sc.rhokap = cl_rhokap; sc.rhokapD = DUST ? cl_rhokapD : 0.0;   // (the peel prefilter of scatter_post reads them: no second gather of the cell / clump record)
     sc.xsamp = sc.xloc; sc.dnu = 0.0; sc.vsamp = va; sc.species = 1; sc.iup = 0;
     if (l.lt == 4 && l.ml_nup > 1) {                           // do_resonance5 / 6 (line_mod.f90:358-376, :421-449): which upward transition
@@ -2783,7 +2787,7 @@ __device__ __forceinline__ void scatter_post(const KArgs &A, const Lds &l, Rng &
     if (par.recoil && !converted) p.xfreq = p.xfreq - (g_rec0 / sc.cl_Dfreq) * (1.0 - cost);      // (no recoil on the conversion channel: :768-770)
     if (STOKES) {
         LART_PROF_MARK(p, 6);
-        if (PEEL) { const PeelCell pc = {sc.rhokap, sc.rhokapD, sc.va, sc.cl_Dfreq}; peel_emit<VAR, STOKES>(A, l, DUST, PEEL_RESONANCE, p, xfreq_atom, ux, uy, uz, E1, E2, E3, g_rec0, npeel, &pc); }   // peeling_resonance_stokes_outside, deferred
+        if (PEEL) { const PeelCell pc = {sc.rhokap, sc.rhokapD, sc.va, sc.cl_Dfreq, sc.uni}; peel_emit<VAR, STOKES>(A, l, DUST, PEEL_RESONANCE, p, xfreq_atom, ux, uy, uz, E1, E2, E3, g_rec0, npeel, &pc); }   // peeling_resonance_stokes_outside, deferred
         LART_PROF_MARK(p, 15);
         double cos2p = 2.0 * cosp * cosp - 1.0, sin2p = 2.0 * sinp * cosp;
         double Q0 = cos2p * p.Q + sin2p * p.U, U0 = -sin2p * p.Q + cos2p * p.U;
@@ -2792,7 +2796,7 @@ __device__ __forceinline__ void scatter_post(const KArgs &A, const Lds &l, Rng &
         rotate_triad(p, cost, sint, cosp, sinp);
     } else {
         if (PEEL && converted) { unsigned natom = 0; peel_conversion_Ha<VAR>(A, l, DUST, p, A.g.cell[cidx(A.g, p.ic, p.jc, p.kc)], ux, uy, uz, E1, E2, npeel, natom); }      // peeling_conversion_Ha (:784-788)
-        else if (PEEL) { const PeelCell pc = {sc.rhokap, sc.rhokapD, sc.va, sc.cl_Dfreq}; peel_emit<VAR, STOKES>(A, l, DUST, PEEL_RESONANCE, p, xfreq_atom, ux, uy, uz, E1, E2, E3, g_rec0, npeel, &pc); }   // peeling_resonance_nostokes_outside, deferred
+        else if (PEEL) { const PeelCell pc = {sc.rhokap, sc.rhokapD, sc.va, sc.cl_Dfreq, sc.uni}; peel_emit<VAR, STOKES>(A, l, DUST, PEEL_RESONANCE, p, xfreq_atom, ux, uy, uz, E1, E2, E3, g_rec0, npeel, &pc); }   // peeling_resonance_nostokes_outside, deferred
         rotate_k(p, cost, sint, cosp, sinp);
         if (converted) {                                       // :811-827: emitted at line centre in the atom frame -> the lab frame along the new direction, reference Doppler units
             const Cell &cc = A.g.cell[cidx(A.g, p.ic, p.jc, p.kc)];

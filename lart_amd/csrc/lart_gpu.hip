@@ -206,6 +206,37 @@ static int build_tally(lart_gpu *c) {
     return 0;
 }
 
+// Cell::pad of a Cartesian medium = R, the half width in cells of the largest cube around the cell that lies inside the grid and holds nothing but copies of this
+// cell (opacities, Voigt parameter, Doppler width, velocity: compared bit for bit).  A peel ray that starts anywhere in the cell keeps its frequency and its opacity
+// for the whole way out of that cube, at least R more cells on the axis it leaves through: the prefilter of peel_emit (peel_all_opaque) tests that path instead of
+// the rest of the first cell.  Chebyshev distance to the nearest cell that differs from one of its six neighbours or touches the grid boundary, minus one, by the
+// two-pass chamfer transform over the 26-neighbourhood (exact for that metric); capped at 1000.
+static void uniform_cubes(std::vector<Cell> &h, int nx, int ny, int nz) {
+    const size_t nc = h.size(), sx = 1, sy = (size_t)nx, sz = (size_t)nx * ny;
+    auto same = [&](size_t a, size_t b) { return std::memcmp(&h[a], &h[b], 7 * sizeof(double)) == 0; };      // the seven fields in front of pad
+    std::vector<unsigned short> d(nc, 1001);
+    for (int k = 0; k < nz; k++) for (int j = 0; j < ny; j++) for (int i = 0; i < nx; i++) {
+        const size_t q = (size_t)i + sy * j + sz * k;
+        bool bad = i == 0 || j == 0 || k == 0 || i == nx - 1 || j == ny - 1 || k == nz - 1;
+        if (!bad) bad = !same(q, q - sx) || !same(q, q + sx) || !same(q, q - sy) || !same(q, q + sy) || !same(q, q - sz) || !same(q, q + sz);
+        if (bad) d[q] = 0;
+    }
+    for (int pass = 0; pass < 2; pass++)
+        for (int kk = 0; kk < nz; kk++) for (int jj = 0; jj < ny; jj++) for (int ii = 0; ii < nx; ii++) {
+            const int k = pass ? nz - 1 - kk : kk, j = pass ? ny - 1 - jj : jj, i = pass ? nx - 1 - ii : ii, f = pass ? -1 : 1;      // backward pass: the mirrored offsets
+            const size_t q = (size_t)i + sy * j + sz * k;
+            unsigned m = d[q]; if (m == 0) continue;
+            for (int dk = -1; dk <= 0; dk++) for (int dj = -1; dj <= 1; dj++) for (int di = -1; di <= 1; di++) {      // the 13 neighbours in front of this one in scan order
+                if (dk == 0 && (dj > 0 || (dj == 0 && di >= 0))) continue;
+                const int k2 = k + f * dk, j2 = j + f * dj, i2 = i + f * di;
+                if (k2 < 0 || k2 >= nz || j2 < 0 || j2 >= ny || i2 < 0 || i2 >= nx) continue;
+                const unsigned v = d[(size_t)i2 + sy * j2 + sz * k2] + 1u; if (v < m) m = v;
+            }
+            d[q] = (unsigned short)m;
+        }
+    for (size_t q = 0; q < nc; q++) h[q].pad = d[q] > 0 ? (double)(d[q] > 1001 ? 1000 : d[q] - 1) : 0.0;
+}
+
 extern "C" int lart_gpu_set_grid_car(lart_gpu *c, int32_t nx, int32_t ny, int32_t nz, double xmin, double ymin, double zmin,
                                      double dx, double dy, double dz, int32_t i0, int32_t j0, int32_t k0,
                                      const double *xface, const double *yface, const double *zface,
@@ -224,6 +255,7 @@ extern "C" int lart_gpu_set_grid_car(lart_gpu *c, int32_t nx, int32_t ny, int32_
         h[i].vfx = vfx[i]; h[i].vfy = vfy[i]; h[i].vfz = vfz[i]; h[i].rhokapD = rhokapD ? rhokapD[i] : 0.0; h[i].pad = 0.0;
         if (!(Dfreq[i] > 0.0)) return fail("set_grid_car: Dfreq must be > 0 in every cell (grid_mod_car.f90:276-277)");
     }
+    uniform_cubes(h, nx, ny, nz);
     (void)hipFree(c->d_cell); (void)hipFree(c->d_faces); c->d_cell = nullptr; c->d_faces = nullptr;
     HIPCHK(hipMalloc(&c->d_cell, nc * sizeof(Cell)));
     HIPCHK(lart_put(c->stream, c->d_cell, h.data(), nc * sizeof(Cell)));
@@ -628,7 +660,9 @@ static int collect_events(lart_gpu *c) {
 static int ensure_peel_queue(lart_gpu *c, int max_events) {
     if (!c->n_cu) { hipDeviceProp_t pr; HIPCHK(hipGetDeviceProperties(&pr, c->device)); c->n_cu = pr.multiProcessorCount; }
     if (!c->stream2) {
-        HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+        // the peel kernels' stream gets the highest priority the device offers: their workgroups are short and few, and the queue buffer they drain is needed again two slices later
+        int prio_lo = 0, prio_hi = 0; HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        HIPCHK(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_hi));
         for (int b = 0; b < 2; b++) { HIPCHK(hipEventCreateWithFlags(&c->ev_filled[b], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_drained[b], hipEventDisableTiming)); }
     }
     const size_t nobs = (size_t)(c->nobs > 0 ? c->nobs : 1);
@@ -796,6 +830,7 @@ extern "C" int lart_gpu_step(lart_gpu *c, int32_t nsteps, int32_t max_events) {
         slice = c->peel_slice;
     }
     const size_t peel_shmem = (size_t)(VT_END + c->g.nx + c->g.ny + c->g.nz + 3) * sizeof(double);
+    const bool no_march = std::getenv("LART_TIMING_NO_MARCH") != nullptr;      // TIMING EXPERIMENTS ONLY (tools/perf_kernel.py): the queued records are dropped, the peel tallies stay empty
     int nslice = 0;
     for (int s = 0; s < nsteps; s++) {
         hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
@@ -826,7 +861,7 @@ extern "C" int lart_gpu_step(lart_gpu *c, int32_t nsteps, int32_t max_events) {
                 HIPCHK(hipEventRecord(c->ev_filled[b], c->stream));
                 HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_filled[b], 0));
                 HIPCHK(hipMemsetAsync(A.pq.pctl, 0, sizeof(DPeelCtl), c->stream2));
-                lart_launch_peel(edge_var(var), stokes, dim3((unsigned)(c->n_cu * 4)), dim3((unsigned)(c->n_cu * 2)), dim3(256), peel_shmem, c->stream2, A);
+                if (!no_march) lart_launch_peel(edge_var(var), stokes, dim3((unsigned)(c->n_cu * 4)), dim3((unsigned)(c->n_cu * 2)), dim3(256), peel_shmem, c->stream2, A);
                 HIPCHK(hipGetLastError());
                 HIPCHK(hipEventRecord(c->ev_drained[b], c->stream2)); c->drained_pending[b] = true;
             }

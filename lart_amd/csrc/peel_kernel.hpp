@@ -124,8 +124,14 @@ __global__ __launch_bounds__(256, LART_PEEL_WAVES) void peel_kernel(KArgs A) {
 }
 
 // the deposits of the rays on the list: one entry per lane, grid-stride
+#ifndef LART_DEPOSIT_WAVES
+#define LART_DEPOSIT_WAVES(S) ((S) ? 3 : 4)
+#endif
+// (round 4: the register budget of a transport wave of the same run -- 128 VGPRs without a Stokes vector, 168 with one.  The kernel has two thousandths of the march's items and no use for its 170-200 registers, but a wave of
+//  that size does not fit the slot a finishing transport wave of 128 / 168 registers leaves behind: next to the transport kernel of the following slice the deposit
+//  kernel starved -- 12.7 ms per slice in profiles/r04_c3_kernel_stats.csv for 1.8e6 deposits -- and held back the queue buffer it has to release)
 template <int VAR, bool STOKES>
-__global__ __launch_bounds__(256, 2) void peel_deposit_kernel(KArgs A) {
+__global__ __launch_bounds__(256, LART_DEPOSIT_WAVES(STOKES)) void peel_deposit_kernel(KArgs A) {
     extern __shared__ double sh[];
     if (A.rep.nrep > 1) {                                      // this block's copy of the contended tally sections (DRep)
         const unsigned r = blockIdx.x % (unsigned)A.rep.nrep;

@@ -19,6 +19,7 @@
 #   py:SCRIPT[:ARGS]           python SCRIPT ARGS (debug helpers under tools/dbg)
 #   explore[:ARGS]             tools/perf_explore.py ARGS (throughput vs photon age, drain tail)
 #   perflib:SUFFIXES:CONFIGS   tools/perf_kernel.py --config C with LART_GPU_LIB = liblart_gpu<SUFFIX>.so for every pair (SUFFIXES like default,_t6,_prof)
+#   envperf:VAR=VALUE:CONFIGS  tools/perf_kernel.py --config C with one environment variable set (timing knobs of the library)
 #   ab:VARIANTS:LANES          tuning builds x pool sizes through tools/perf_explore.py (VARIANTS like default,_w3 ; LANES like 0,786432)
 set -o pipefail
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
@@ -65,6 +66,7 @@ for spec in "$@"; do
     explore) step explore 1100 python tools/perf_explore.py ${a1//,/ } ;;
     perflib) for v in ${a1//,/ }; do [ "$v" = default ] && v=""; for c in ${a2//,/ }; do
                LART_GPU_LIB=$PWD/lart_amd/csrc/liblart_gpu$v.so step "perf${v}_$c" 400 python tools/perf_kernel.py --config $c; done; done ;;
+    envperf) for c in ${a2//,/ }; do export "$a1"; step "perf_${a1%%=*}_$c" 400 python tools/perf_kernel.py --config $c; unset "${a1%%=*}"; done ;;
     ab)      for v in ${a1//,/ }; do [ "$v" = default ] && v=""; for l in ${a2//,/ }; do
                LART_GPU_LIB=$PWD/lart_amd/csrc/liblart_gpu$v.so step "ab${v}_l$l" 300 python tools/perf_explore.py --steps 3 --events 4096 --lanes $l; done; done ;;
     *) echo "unknown step $spec"; exit 2 ;;
