@@ -2347,7 +2347,7 @@ __device__ inline double rsqrt_nr(double x) {
 }
 // opacity constants of the cell (leaf, owner clump) an event happens in, as scatter_pre read them: handed to the peel prefilter so that it does not gather the record again
 // (the gather sat exposed in front of the record stores: 3 waves per SIMD do not hide it)
-struct PeelCell { double rhokap, rhokapD, voigt_a, Dfreq; int uni; };      // uni: Cell::pad of a Cartesian medium = cells of the uniform cube around the cell (lart_gpu.hip, uniform_cubes)
+struct PeelCell { double rhokap, rhokapD, voigt_a, Dfreq, uni; };      // uni: Cell::pad -- Cartesian medium: cells of the uniform cube around the cell; octree: the length a leaf's box can grow by (lart_gpu.hip, uniform_cubes / uniform_margins_amr)
 template <int VAR, bool STOKES>
 __device__ __forceinline__ bool peel_all_opaque(const KArgs &A, const Lds &l, int kind, const Photon &p, double xa, double ux, double uy, double uz, double grec, bool dust, const PeelCell *pc = nullptr) {
     if (kind == PEEL_DIRECT || A.heal_nside > 0 || VAR == 1) return false;
@@ -2365,8 +2365,8 @@ __device__ __forceinline__ bool peel_all_opaque(const KArgs &A, const Lds &l, in
     const double T = LART_TAU_HUGE * (1.0 + 1e-9);
     PeelCell cc;
     if (pc) cc = *pc;
-    else if (VAR == 4) { const ClumpPhys ph = A.cl.phys[p.icl - 1]; cc.rhokap = ph.rhokap; cc.rhokapD = ph.rhokapD; cc.voigt_a = ph.voigt_a; cc.Dfreq = ph.Dfreq; cc.uni = 0; }
-    else { const Cell &c = A.g.cell[(VAR == 3 || is_clump(VAR)) ? (size_t)(p.ic - 1) : cidx(A.g, p.ic, p.jc, p.kc)]; cc.rhokap = c.rhokap; cc.rhokapD = c.rhokapD; cc.voigt_a = c.voigt_a; cc.Dfreq = c.Dfreq; cc.uni = (VAR == 3 || is_clump(VAR)) ? 0 : (int)c.pad; }
+    else if (VAR == 4) { const ClumpPhys ph = A.cl.phys[p.icl - 1]; cc.rhokap = ph.rhokap; cc.rhokapD = ph.rhokapD; cc.voigt_a = ph.voigt_a; cc.Dfreq = ph.Dfreq; cc.uni = 0.0; }
+    else { const Cell &c = A.g.cell[(VAR == 3 || is_clump(VAR)) ? (size_t)(p.ic - 1) : cidx(A.g, p.ic, p.jc, p.kc)]; cc.rhokap = c.rhokap; cc.rhokapD = c.rhokapD; cc.voigt_a = c.voigt_a; cc.Dfreq = c.Dfreq; cc.uni = is_clump(VAR) ? 0.0 : c.pad; }
     const double Dfreq_bg = (VAR == 4) ? A.g.cell[0].Dfreq : cc.Dfreq;      // (the recoil term of the peel head uses the background record of a clump medium, as peel_head_res_* do)
     for (int i = 0; i < A.nobs; i++) {
         const DObs o = l.obs ? l.obs[i] : A.obs[i];          // (LDS copy: this test runs on every event and must not wait for memory)
@@ -2399,11 +2399,12 @@ __device__ __forceinline__ bool peel_all_opaque(const KArgs &A, const Lds &l, in
         double dx, dy, dz;
         if (VAR == 3) {
             const AmrGeom g = A.amr.geom[A.amr.icell_of_leaf[p.ic - 1] - 1];
-            dx = qx > 0.0 ? (g.cx + g.ch) - p.x : p.x - (g.cx - g.ch); dy = qy > 0.0 ? (g.cy + g.ch) - p.y : p.y - (g.cy - g.ch); dz = qz > 0.0 ? (g.cz + g.ch) - p.z : p.z - (g.cz - g.ch);
+            const double gh = g.ch + cc.uni;                     // the leaf's box grown by the margin in which the medium is this leaf's (Cell::pad, uniform_margins_amr)
+            dx = qx > 0.0 ? (g.cx + gh) - p.x : p.x - (g.cx - gh); dy = qy > 0.0 ? (g.cy + gh) - p.y : p.y - (g.cy - gh); dz = qz > 0.0 ? (g.cz + gh) - p.z : p.z - (g.cz - gh);
         } else {
             // Round 4: not the rest of the first cell but the way out of the largest cube of copies of this cell around it (Cell::pad, computed by lart_gpu_set_grid_car): the
             // ray keeps its frequency and its opacity until it has crossed R more cells on one axis, so kappa x (that path) is what the march would add up, cell by cell
-            const int R = cc.uni;
+            const int R = (int)cc.uni;
             dx = qx > 0.0 ? l.xf[p.ic + R] - p.x : p.x - l.xf[p.ic - 1 - R]; dy = qy > 0.0 ? l.yf[p.jc + R] - p.y : p.y - l.yf[p.jc - 1 - R]; dz = qz > 0.0 ? l.zf[p.kc + R] - p.z : p.z - l.zf[p.kc - 1 - R];
         }
         bool opaque = kap * dz >= T * fabs(qz);
@@ -2582,7 +2583,7 @@ __device__ __forceinline__ bool dust_absorb(const KArgs &A, const Lds &l, Rng &g
 //   scatter_pre  -> dust-or-gas decision; a dust event completes here; a resonance event returns true with the sampler's
 //                   arguments in ScatCtx (x in the local Doppler units of the cell / clump)
 //   scatter_post -> everything after do_resonance's `uz = rand_resonance_vz(x, a)`
-struct ScatCtx { double va, xloc, cl_scale, cl_Dfreq, xsamp, dnu, vsamp, rhokap, rhokapD; int species, iup, h2, uni; };   // h2: 1-based H2 line of an H2 scattering (pseudo line type 9), 0 = an H I event;   // xsamp / vsamp: the sampler's frequency and Voigt parameter (2P1/2 level: xloc + dnu; deuterium, species 2: the D frame)
+struct ScatCtx { double va, xloc, cl_scale, cl_Dfreq, xsamp, dnu, vsamp, rhokap, rhokapD; int species, iup, h2; double uni; };   // h2: 1-based H2 line of an H2 scattering (pseudo line type 9), 0 = an H I event;   // xsamp / vsamp: the sampler's frequency and Voigt parameter (2P1/2 level: xloc + dnu; deuterium, species 2: the D frame)
 template <int VAR, bool STOKES, bool DUST, bool PEEL>
 __device__ __forceinline__ bool scatter_pre(const KArgs &A, const Lds &l, Rng &g, Photon &p, unsigned &npeel, ScatCtx &sc) {
     const lart_params &par = A.par;
@@ -2665,7 +2666,7 @@ __device__ __forceinline__ bool scatter_pre(const KArgs &A, const Lds &l, Rng &g
         if (ib >= 1) atomicAdd(&(l.jp_P ? l.jp_P : A.jpa.P1)[ib - 1], p.wgt / (c.rhokap * c.Dfreq / A.jpa.cross0));
     }
     sc.va = va; sc.cl_scale = cl_scale; sc.cl_Dfreq = cl_Dfreq; sc.xloc = is_clump(VAR) ? p.xfreq * cl_scale : p.xfreq;
-    sc.uni = (VAR == 3 || is_clump(VAR)) ? 0 : (int)c.pad;
+    sc.uni = is_clump(VAR) ? 0.0 : c.pad;
     sc.rhokap = cl_rhokap; sc.rhokapD = DUST ? cl_rhokapD : 0.0;   // (the peel prefilter of scatter_post reads them: no second gather of the cell / clump record)
     sc.xsamp = sc.xloc; sc.dnu = 0.0; sc.vsamp = va; sc.species = 1; sc.iup = 0;
     if (l.lt == 4 && l.ml_nup > 1) {                           // do_resonance5 / 6 (line_mod.f90:358-376, :421-449): which upward transition

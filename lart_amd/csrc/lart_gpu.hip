@@ -211,16 +211,9 @@ static int build_tally(lart_gpu *c) {
 // for the whole way out of that cube, at least R more cells on the axis it leaves through: the prefilter of peel_emit (peel_all_opaque) tests that path instead of
 // the rest of the first cell.  Chebyshev distance to the nearest cell that differs from one of its six neighbours or touches the grid boundary, minus one, by the
 // two-pass chamfer transform over the 26-neighbourhood (exact for that metric); capped at 1000.
-static void uniform_cubes(std::vector<Cell> &h, int nx, int ny, int nz) {
-    const size_t nc = h.size(), sx = 1, sy = (size_t)nx, sz = (size_t)nx * ny;
-    auto same = [&](size_t a, size_t b) { return std::memcmp(&h[a], &h[b], 7 * sizeof(double)) == 0; };      // the seven fields in front of pad
-    std::vector<unsigned short> d(nc, 1001);
-    for (int k = 0; k < nz; k++) for (int j = 0; j < ny; j++) for (int i = 0; i < nx; i++) {
-        const size_t q = (size_t)i + sy * j + sz * k;
-        bool bad = i == 0 || j == 0 || k == 0 || i == nx - 1 || j == ny - 1 || k == nz - 1;
-        if (!bad) bad = !same(q, q - sx) || !same(q, q + sx) || !same(q, q - sy) || !same(q, q + sy) || !same(q, q - sz) || !same(q, q + sz);
-        if (bad) d[q] = 0;
-    }
+// Chebyshev distance of every cell of an nx x ny x nz array to the nearest cell with d = 0: the two-pass chamfer transform over the 26-neighbourhood (exact for that metric)
+static void chamfer_chebyshev(std::vector<unsigned short> &d, int nx, int ny, int nz) {
+    const size_t sy = (size_t)nx, sz = (size_t)nx * ny;
     for (int pass = 0; pass < 2; pass++)
         for (int kk = 0; kk < nz; kk++) for (int jj = 0; jj < ny; jj++) for (int ii = 0; ii < nx; ii++) {
             const int k = pass ? nz - 1 - kk : kk, j = pass ? ny - 1 - jj : jj, i = pass ? nx - 1 - ii : ii, f = pass ? -1 : 1;      // backward pass: the mirrored offsets
@@ -234,7 +227,55 @@ static void uniform_cubes(std::vector<Cell> &h, int nx, int ny, int nz) {
             }
             d[q] = (unsigned short)m;
         }
-    for (size_t q = 0; q < nc; q++) h[q].pad = d[q] > 0 ? (double)(d[q] > 1001 ? 1000 : d[q] - 1) : 0.0;
+}
+static bool same_medium(const Cell &a, const Cell &b) { return std::memcmp(&a, &b, 7 * sizeof(double)) == 0; }      // the seven fields in front of pad, bit for bit
+static void uniform_cubes(std::vector<Cell> &h, int nx, int ny, int nz) {
+    const size_t nc = h.size(), sx = 1, sy = (size_t)nx, sz = (size_t)nx * ny;
+    std::vector<unsigned short> d(nc, 1001);
+    for (int k = 0; k < nz; k++) for (int j = 0; j < ny; j++) for (int i = 0; i < nx; i++) {
+        const size_t q = (size_t)i + sy * j + sz * k;
+        bool bad = i == 0 || j == 0 || k == 0 || i == nx - 1 || j == ny - 1 || k == nz - 1;
+        if (!bad) bad = !same_medium(h[q], h[q - sx]) || !same_medium(h[q], h[q + sx]) || !same_medium(h[q], h[q - sy]) || !same_medium(h[q], h[q + sy]) || !same_medium(h[q], h[q - sz]) || !same_medium(h[q], h[q + sz]);
+        if (bad) d[q] = 0;
+    }
+    chamfer_chebyshev(d, nx, ny, nz);
+    for (size_t q = 0; q < nc; q++) h[q].pad = d[q] > 0 ? (double)(d[q] - 1) : 0.0;
+}
+// The same for the leaves of an octree: Cell::pad = a length M such that the leaf's box grown by M on every side lies inside the root box and holds nothing but leaves
+// with this leaf's medium.  The leaves are painted onto the uniform grid of the finest level (at most 256^3 cells, else no margins), the cube radius R of every fine
+// cell comes from the same transform, and M = (the smallest R on the leaf's surface layer) x the fine cell width: every point within M of the leaf is within M of one
+// of its surface cells, i.e. inside that cell's cube.
+static void uniform_margins_amr(std::vector<Cell> &h, int nleaf, double lo, double hi, const double *cx, const double *cy, const double *cz, const double *ch, const int32_t *icell_of_leaf) {
+    double hmin = 1e300; for (int i = 0; i < nleaf; i++) hmin = std::min(hmin, ch[icell_of_leaf[i] - 1]);
+    const double w = 2.0 * hmin, fn = (hi - lo) / w; const int n = (int)std::llround(fn);
+    if (n < 3 || n > 256 || std::fabs(fn - n) > 1e-6 * n) return;
+    const size_t sy = (size_t)n, sz = (size_t)n * n;
+    std::vector<int> id((size_t)n * n * n, -1);
+    struct Box { int i0, j0, k0, s; }; std::vector<Box> box(nleaf);
+    for (int L = 0; L < nleaf; L++) {
+        const int ic = icell_of_leaf[L] - 1; const double hw = ch[ic];
+        const int s = (int)std::llround(hw / hmin), i0 = (int)std::llround((cx[ic] - hw - lo) / w), j0 = (int)std::llround((cy[ic] - hw - lo) / w), k0 = (int)std::llround((cz[ic] - hw - lo) / w);
+        if (s < 1 || i0 < 0 || j0 < 0 || k0 < 0 || i0 + s > n || j0 + s > n || k0 + s > n) return;      // not the regular refinement this needs: no margins
+        box[L] = {i0, j0, k0, s};
+        for (int k = k0; k < k0 + s; k++) for (int j = j0; j < j0 + s; j++) for (int i = i0; i < i0 + s; i++) id[(size_t)i + sy * j + sz * k] = L;
+    }
+    std::vector<unsigned short> d(id.size(), 1001);
+    for (int k = 0; k < n; k++) for (int j = 0; j < n; j++) for (int i = 0; i < n; i++) {
+        const size_t q = (size_t)i + sy * j + sz * k; const int a = id[q];
+        bool bad = a < 0 || i == 0 || j == 0 || k == 0 || i == n - 1 || j == n - 1 || k == n - 1;
+        if (!bad) { const size_t nb[6] = {q - 1, q + 1, q - sy, q + sy, q - sz, q + sz};
+            for (int t = 0; t < 6 && !bad; t++) { const int b = id[nb[t]]; bad = b < 0 || (b != a && !same_medium(h[a], h[b])); } }
+        if (bad) d[q] = 0;
+    }
+    chamfer_chebyshev(d, n, n, n);
+    for (int L = 0; L < nleaf; L++) {
+        const Box &b = box[L]; unsigned m = 1001;
+        for (int k = b.k0; k < b.k0 + b.s; k++) for (int j = b.j0; j < b.j0 + b.s; j++) for (int i = b.i0; i < b.i0 + b.s; i++) {
+            if (k != b.k0 && k != b.k0 + b.s - 1 && j != b.j0 && j != b.j0 + b.s - 1 && i != b.i0 && i != b.i0 + b.s - 1) continue;      // the surface layer only
+            m = std::min(m, (unsigned)d[(size_t)i + sy * j + sz * k]);
+        }
+        h[L].pad = m > 1 ? (double)(m - 1) * w * (1.0 - 1e-12) : 0.0;
+    }
 }
 
 extern "C" int lart_gpu_set_grid_car(lart_gpu *c, int32_t nx, int32_t ny, int32_t nz, double xmin, double ymin, double zmin,
@@ -396,6 +437,7 @@ extern "C" int lart_gpu_set_grid_amr(lart_gpu *c, int32_t ncells, int32_t nleaf,
         h[i].rhokap = rhokap[i]; h[i].voigt_a = voigt_a[i]; h[i].Dfreq = Dfreq[i];
         h[i].vfx = vfx[i]; h[i].vfy = vfy[i]; h[i].vfz = vfz[i]; h[i].rhokapD = rhokapD ? rhokapD[i] : 0.0; h[i].pad = 0.0;
     }
+    uniform_margins_amr(h, nleaf, lo, hi, cx, cy, cz, ch, icell_of_leaf);
     (void)hipFree(c->d_cell); (void)hipFree(c->d_faces); (void)hipFree(c->d_amr_int); (void)hipFree(c->d_amr_geom);
     c->d_cell = nullptr; c->d_faces = nullptr; c->d_amr_int = nullptr; c->d_amr_geom = nullptr;
     HIPCHK(hipMalloc(&c->d_cell, (size_t)nleaf * sizeof(Cell)));
