@@ -249,6 +249,9 @@ int  lart_gpu_get_all_photons(lart_gpu *ctx, double *out, int64_t n);
  * CU leaves the LDS for the line-centre window of J; results do not depend on the choice). */
 int  lart_gpu_set_pool(lart_gpu *ctx, int64_t nlanes, int32_t block);
 int  lart_gpu_pool_info(lart_gpu *ctx, int64_t *nlanes, int32_t *block);   /* valid after lart_gpu_begin */
+/* test probe: the spare word of every cell record (Cartesian medium: cells, Fortran order; octree: leaves) = the size of the region around the cell in which the
+   medium is a copy of it, as the peel prefilter uses it (csrc/lart_gpu.hip: uniform_cubes / uniform_margins_amr).  n = number of cells / leaves given to set_grid_* */
+int  lart_gpu_test_cell_margin(lart_gpu *ctx, double *out, int64_t n);
 /* Lane compaction = the role of the reference's dynamic master/worker scheduler (run_simulation_mod.f90:31-64: no worker
  * idles while photons are left).  A lane refills itself from the photon counter; once the counter is exhausted the pool
  * drains, and lart_gpu_step packs the live lanes to the front of the pool and launches a smaller grid whenever fewer than

@@ -46,7 +46,7 @@ SYMBOLS = ["lart_host_line_lookup", "lart_gpu_set_line_multiplet", "lart_gpu_dev
            "lart_gpu_set_grid_car", "lart_gpu_set_mueller", "lart_gpu_set_observers", "lart_gpu_set_observers_heal",
            "lart_gpu_set_JPa", "lart_gpu_set_grid_amr", "lart_gpu_set_JPa_amr", "lart_gpu_set_clumps", "lart_gpu_set_clump_overlap", "lart_host_last_error", "lart_host_clumps_generate", "lart_host_clumps_generate_cone", "lart_host_clumps_csr_dims", "lart_host_clumps_build_csr", "lart_host_clumps_has_overlap", "lart_host_amr_last_error", "lart_host_amr_count", "lart_host_amr_build", "lart_gpu_run",
            "lart_gpu_begin", "lart_gpu_step", "lart_gpu_sync", "lart_gpu_kernel_time", "lart_gpu_sightline_tau", "lart_gpu_sightline_time",
-           "lart_gpu_enable_photon_log", "lart_gpu_get_photon_log", "lart_gpu_enable_all_photons", "lart_gpu_get_all_photons", "lart_gpu_set_pool", "lart_gpu_pool_info",
+           "lart_gpu_enable_photon_log", "lart_gpu_get_photon_log", "lart_gpu_enable_all_photons", "lart_gpu_get_all_photons", "lart_gpu_set_pool", "lart_gpu_pool_info", "lart_gpu_test_cell_margin",
            "lart_gpu_tally_buffer", "lart_gpu_zero_tallies", "lart_gpu_get_tallies",
            "lart_gpu_compact", "lart_gpu_set_auto_compact", "lart_gpu_live_lanes",
            "lart_gpu_comm_unique_id", "lart_gpu_comm_init", "lart_gpu_comm_info", "lart_gpu_comm_destroy", "lart_gpu_reduce_tallies",
@@ -98,6 +98,7 @@ def lib():
         L.lart_gpu_get_all_photons.argtypes = [_vp, _vp, _i64]
         L.lart_gpu_set_pool.argtypes = [_vp, _i64, _i32]
         L.lart_gpu_pool_info.argtypes = [_vp, C.POINTER(_i64), C.POINTER(_i32)]
+        L.lart_gpu_test_cell_margin.argtypes = [_vp, C.POINTER(C.c_double), _i64]
         L.lart_gpu_tally_buffer.argtypes = [_vp, C.POINTER(_vp), C.POINTER(_i64)]
         L.lart_gpu_zero_tallies.argtypes = [_vp]
         L.lart_gpu_get_tallies.argtypes = [_vp, C.POINTER(LartTallies)]
@@ -279,6 +280,12 @@ class Context:
         n, b = _i64(), _i32()
         _chk(lib().lart_gpu_pool_info(self.h, C.byref(n), C.byref(b)))
         return n.value, b.value
+
+    def cell_margin(self, n):
+        """Cell::pad of the n cells / leaves: the uniform cube (cells) or margin (length) the peel prefilter uses"""
+        out = np.zeros(int(n))
+        _chk(lib().lart_gpu_test_cell_margin(self.h, out.ctypes.data_as(C.POINTER(C.c_double)), int(n)))
+        return out
 
     def compact(self):
         _chk(lib().lart_gpu_compact(self.h))

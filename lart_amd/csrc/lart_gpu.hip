@@ -561,6 +561,16 @@ extern "C" int lart_gpu_set_pool(lart_gpu *c, int64_t nlanes, int32_t block) {
     return 0;
 }
 
+extern "C" int lart_gpu_test_cell_margin(lart_gpu *c, double *out, int64_t n) {
+    if (!c || !out) return fail("test_cell_margin: null argument");
+    if (!c->d_cell || n != (int64_t)c->ncell) return fail("test_cell_margin: n must be the number of cells / leaves of the medium");
+    HIPCHK(hipSetDevice(c->device));
+    std::vector<Cell> h((size_t)n);
+    HIPCHK(lart_get(c->stream, h.data(), c->d_cell, (size_t)n * sizeof(Cell)));
+    for (int64_t i = 0; i < n; i++) out[i] = h[(size_t)i].pad;
+    return 0;
+}
+
 extern "C" int lart_gpu_pool_info(lart_gpu *c, int64_t *nlanes, int32_t *block) {
     if (!c) return fail("pool_info: null context");
     if (nlanes) *nlanes = c->pool.n; if (block) *block = c->block;

@@ -1265,3 +1265,56 @@ def test_save_all_photons_table(capi, oracle_mod, mueller_file, kw):
     if kw.get("DGR"):
         if kw.get("use_stokes"):
             assert (g["I"][same] == 0.0).sum() == (r[5][same] == 0.0).sum() > 0      # dust-absorbed photons carry weight 0
+
+
+def test_uniform_cube_of_every_cell_against_brute_force(capi):
+    """Cell::pad (lart_gpu_set_grid_car: uniform_cubes, a two-pass chamfer transform): R = the half width in cells of the largest cube around a cell that lies inside the grid
+    and holds bit-identical cells only.  The peel prefilter calls a ray opaque when it is opaque on its way out of that cube, so R must never be too large: checked
+    against the definition, cell by cell, on a blocky medium with a velocity step and a dusty slab in it"""
+    n = 24
+    sim = make(dict(temperature=1e4, taumax=50.0, nx=n, ny=n, nz=n, rmax=1.0, nxfreq=41, nxim=5, nyim=5, DGR=1.0, cext_dust=2e-21, iseed=1))
+    g = sim.grid
+    rk = np.array(g.rhokap, order="F").reshape((n, n, n), order="F").copy(); vx = np.zeros_like(rk); rD = np.array(g.rhokapD, order="F").reshape((n, n, n), order="F").copy()
+    rk[14:, :, :] *= 2.0; vx[:, :9, :] = 0.3; rD[:, :, 17:] *= 3.0
+    same_T = np.full((n, n, n), float(np.ravel(g.Dfreq)[0]))
+    F = lambda a: np.asfortranarray(a, dtype=np.float64)
+    sim.ctx.set_grid_car(n, n, n, g.xmin, g.ymin, g.zmin, g.dx, g.dy, g.dz, g.i0, g.j0, g.k0, g.xface, g.yface, g.zface, F(rk), F(np.full((n, n, n), float(np.ravel(g.voigt_a)[0]))), F(same_T),
+                         F(vx), F(np.zeros((n, n, n))), F(np.zeros((n, n, n))), F(rD))
+    R = sim.ctx.cell_margin(n ** 3).reshape((n, n, n), order="F")
+    key = rk * 1.0 + 1e3 * vx + 1e6 * rD                      # distinct media -> distinct keys (a few values each)
+    want = np.zeros((n, n, n))
+    for i in range(n):
+        for j in range(n):
+            for k in range(n):
+                r = 0
+                while True:
+                    r1 = r + 1
+                    if min(i, j, k) - r1 < 1 or max(i, j, k) + r1 > n - 2:      # cells 0 and n-1 of every axis are sites: a cube may not hold one
+                        break
+                    blk = key[i - r1:i + r1 + 1, j - r1:j + r1 + 1, k - r1:k + r1 + 1]
+                    if not np.all(blk == key[i, j, k]):
+                        break
+                    r = r1
+                want[i, j, k] = r
+    assert R.max() >= 3 and (R == np.floor(R)).all()
+    assert (R <= want).all(), "a cube larger than the medium allows"      # exactness of the prefilter rests on this
+    assert (R >= np.maximum(want - 1, 0)).all()               # (sites are cells that differ from a 6-neighbour: at most one cell short of the definition)
+
+
+def test_leaf_margins_of_the_octree_hold_one_medium(capi, tmp_path):
+    """Cell::pad of the leaves (uniform_margins_amr): the leaf's box grown by the margin lies inside the root box and meets only leaves with the leaf's medium"""
+    from lart_amd import amr
+    fn = str(tmp_path / "sphere.dat"); amr.write_generic_amr(fn, amr.make_amr_sphere())
+    sim = make(dict(use_amr_grid=True, amr_file=fn, temperature=1e4, taumax=1e3, rmax=1.0, nxfreq=41, nxim=5, nyim=5, iseed=1))
+    a = sim.amr
+    M = sim.ctx.cell_margin(a.nleaf)
+    ic = np.asarray(a.icell_of_leaf) - 1
+    cx, cy, cz, ch = (np.asarray(v)[ic] for v in (a.cx, a.cy, a.cz, a.ch))
+    rk = np.asarray(a.rhokap).ravel()
+    assert M.max() > 0 and (M >= 0).all()
+    rng = np.random.default_rng(3)
+    for L in rng.choice(np.nonzero(M > 0)[0], size=min(300, int((M > 0).sum())), replace=False):
+        gh = ch[L] + M[L]
+        assert cx[L] - gh >= a.xmin - 1e-12 and cx[L] + gh <= a.xmax + 1e-12 and cy[L] - gh >= a.xmin - 1e-12 and cy[L] + gh <= a.xmax + 1e-12 and cz[L] - gh >= a.xmin - 1e-12 and cz[L] + gh <= a.xmax + 1e-12
+        hit = (np.abs(cx - cx[L]) < ch + gh - 1e-12) & (np.abs(cy - cy[L]) < ch + gh - 1e-12) & (np.abs(cz - cz[L]) < ch + gh - 1e-12)      # leaves whose boxes overlap the grown box
+        assert np.all(rk[hit] == rk[L]), (L, M[L])
