@@ -13,8 +13,10 @@
 // arithmetic of a deposit (exp, pixel, Stokes rotations, atomics) is the one-piece routine's, statement for statement.
 #pragma once
 #include "transport_kernel.hpp"
+// waves per SIMD of the march: the register budget of a transport wave of the same run (168 VGPRs with a Stokes vector: the march then fits without spills and into the
+// slot a finishing transport wave leaves behind; 128 without).  Measured: 6 and 8 waves (84 / 64 VGPRs, spills) lose 3-30 %, 3 waves for the Stokes marches gains 1.4 % on C3.
 #ifndef LART_PEEL_WAVES
-#define LART_PEEL_WAVES 4
+#define LART_PEEL_WAVES(S) ((S) ? 3 : 4)
 #endif
 #ifndef LART_DEP_CHUNK
 #define LART_DEP_CHUNK 256ull
@@ -44,7 +46,7 @@ __device__ inline void peel_load(const KArgs &A, const Lds &l, size_t r, bool fu
 }
 
 template <int VAR, bool STOKES>
-__global__ __launch_bounds__(256, LART_PEEL_WAVES) void peel_kernel(KArgs A) {
+__global__ __launch_bounds__(256, LART_PEEL_WAVES(STOKES)) void peel_kernel(KArgs A) {
     extern __shared__ double sh[];
     if (A.rep.nrep > 1) {                                      // this block's copy of the contended tally sections (DRep)
         const unsigned r = blockIdx.x % (unsigned)A.rep.nrep;
