@@ -26,7 +26,7 @@ CONFIGS = {
     "L7 headline sphere T=1e4 with deuterium D/H=1.5e-5 (LT=7)": dict(temperature=1e4, taumax=1e6, xyz_symmetry=True, nx=101, ny=101, nz=101, rmax=1.0, nxfreq=201,
                                                                      include_deuterium=True, no_photons=1e7, iseed=1),
     "L4 examples/FeII_test-like: FeII_UV1 tau0=1e2 T=1e4 sphere 101^3 (LT=4, fluorescence)": dict(temperature=1e4, taumax=1e2, nx=101, ny=101, nz=101, rmax=1.0, nxfreq=600,
-                                                                                              line_id="FeII_UV1", wavelength_min=2575.0, wavelength_max=2640.0, no_photons=4e9, iseed=1)   # (few events per photon: enough photons to keep every lane busy),
+                                                                                              line_id="FeII_UV1", wavelength_min=2575.0, wavelength_max=2640.0, no_photons=4e9, iseed=1),   # (few events per photon: enough photons to keep every lane busy)
     "L6 HeI_10833 tau0=1e3 T=1e4 sphere 101^3 (LT=4, three blended levels)": dict(temperature=1e4, taumax=1e3, nx=101, ny=101, nz=101, rmax=1.0, nxfreq=201, line_id="HeI_10833",
                                                                                 velocity_min=-300.0, velocity_max=300.0, no_photons=1e7, iseed=1),
 }
