@@ -625,7 +625,11 @@ static int kernel_waves_of(const lart_gpu *c) {
 static int ensure_pool(lart_gpu *c) {
     if (!c->block_user) {
         c->block = 256;
-        if (c->jpa.nbins > 0 && c->jpa.calc_J && (c->jpa.calc_P || c->jpa.calc_Pnew) && !c->par.use_stokes) { c->block = 1024; size_j_window(c); if (c->jpa.lds_j_w < 8) c->block = 256; }
+        if (c->jpa.nbins > 0 && c->jpa.calc_J && (c->jpa.calc_P || c->jpa.calc_Pnew) && !c->par.use_stokes) {
+            // two 512-lane workgroups per CU (round 4; round 3 chose one of 1024): the J(x) window is half as wide, but a finishing workgroup frees half a CU instead of all
+            // or nothing -- for the next workgroup and for the peel kernels of the previous slice.  The octree with CALCJ + CALCP + CALCPnew: 12.9e9 events/s at 1024 lanes,
+            // 13.9e9 at 512; with a 100 x 100 observer 6.8e9 at 256, 8.2e9 at 512, 7.9e9 at 1024
+            c->block = 512; size_j_window(c); if (c->jpa.lds_j_w < 8) c->block = 256; }
         // overlapping clumps, a population small enough for its records to live in LDS (lds_stage_clumps: 96 B per clump): four 256-lane workgroups per CU have no room
         // for four copies, one 1024-lane workgroup has
         // (the wave-cooperative kernel of the smallest populations runs 3 waves per SIMD: three 256-lane workgroups, which do have the room)
