@@ -238,3 +238,41 @@ def test_J_window_in_lds_changes_nothing(capi, monkeypatch):
     d = make(dict(kw, use_stokes=True)); d.ctx.set_pool(0, 1024)
     with pytest.raises(RuntimeError, match="256 lanes"):
         d.run_simulation(1000)
+
+
+def test_runs_next_to_busy_contexts_of_the_same_process(capi):
+    """every fill and copy of a context goes through that context's own stream (round 4: set-up fills on the NULL stream landed after the first kernels of a run
+    when other contexts kept the GPU busy and zeroed tallies in mid-run; tools/dbg/bg_race.py).  Four contexts driven by their own threads keep the device busy
+    while fresh contexts are created, run and read out on the main thread: every one of those runs has to equal the run made alone, tally for tally"""
+    import threading
+    kw = dict(temperature=1e4, taumax=3e2, nx=21, ny=21, nz=21, rmax=1.0, nxfreq=81, nxim=9, nyim=9, alpha=10.0, beta=30.0, iseed=21)
+    n = 20000
+    alone = make(kw); alone.ctx.enable_photon_log(True); alone.run_simulation(n); t0 = alone.ctx.tallies(); ns0, xs0 = alone.ctx.photon_log(n)
+    stop = threading.Event(); errors = []
+    busy = [make(dict(temperature=10.0, taumax=1e5, xyz_symmetry=True, nx=41, ny=41, nz=41, rmax=1.0, nxfreq=101, iseed=5 + i)) for i in range(4)]
+    for b in busy:
+        b.ctx.set_pool(262144, 256)                          # (busy, not saturating: the test has to stay short)
+
+    def drive(sim, seed):
+        try:
+            sim.ctx.begin(10 ** 9, first_id=1, stride=1, seed=seed)
+            while not stop.is_set():
+                sim.ctx.step(1, 512); sim.ctx.sync()
+        except Exception as e:                               # noqa: BLE001 -- reported below
+            errors.append(e)
+    threads = [threading.Thread(target=drive, args=(s, 40 + i)) for i, s in enumerate(busy)]
+    for th in threads:
+        th.start()
+    try:
+        for rep in range(3):
+            sim = make(kw); sim.ctx.enable_photon_log(True); sim.run_simulation(n); t = sim.ctx.tallies(); ns, xs = sim.ctx.photon_log(n)
+            assert t["nphotons_done"] == n, (rep, t["nphotons_done"])
+            assert np.array_equal(ns, ns0) and np.array_equal(xs, xs0), rep
+            for key in ("Jout", "scatt", "direc"):
+                assert np.allclose(t[key], t0[key], rtol=1e-9, atol=1e-12 * max(1.0, float(np.abs(t0[key]).max()))), (rep, key)
+            sim.ctx.close()
+    finally:
+        stop.set()
+        for th in threads:
+            th.join()
+    assert not errors, errors
